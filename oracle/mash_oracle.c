@@ -1,0 +1,378 @@
+/*
+ * mash_oracle.c — CPU ORACLE (test infrastructure, never shipped; see mash_oracle.h).
+ *
+ * Plain-C restatement of the Mash 2.3 hot path.  Citations are into
+ * /root/reference/src/mash/.
+ */
+#include "mash_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------- */
+/* MurmurHash3_x64_128 — MurmurHash3.cpp:255-335 (Austin Appleby, public domain
+ * algorithm).  Little-endian block loads (MurmurHash3.cpp:60-63).           */
+
+static inline uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+
+/* fmix64 — MurmurHash3.cpp:81-90 */
+static inline uint64_t fmix64(uint64_t k)
+{
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdULL;
+    k ^= k >> 33;
+    k *= 0xc4ceb9fe1a85ec53ULL;
+    k ^= k >> 33;
+    return k;
+}
+
+void oracle_murmur3_x64_128(const void *key, int len, uint32_t seed, uint64_t out[2])
+{
+    const uint8_t *data = (const uint8_t *)key;
+    const int nblocks = len / 16;
+    uint64_t h1 = seed, h2 = seed;
+    const uint64_t c1 = 0x87c37b91114253d5ULL;
+    const uint64_t c2 = 0x4cf5ad432745937fULL;
+
+    for (int i = 0; i < nblocks; i++) {            /* body, :272-284 */
+        uint64_t k1, k2;
+        memcpy(&k1, data + 16 * i, 8);
+        memcpy(&k2, data + 16 * i + 8, 8);
+        k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+        h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+        k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+        h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+    }
+
+    const uint8_t *tail = data + nblocks * 16;     /* tail, :289-315 */
+    const int rem = len & 15;
+    uint64_t k1 = 0, k2 = 0;
+    for (int b = rem - 1; b >= 8; b--) k2 ^= (uint64_t)tail[b] << (8 * (b - 8));
+    if (rem > 8) { k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2; }
+    for (int b = (rem > 8 ? 8 : rem) - 1; b >= 0; b--) k1 ^= (uint64_t)tail[b] << (8 * b);
+    if (rem > 0) { k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1; }
+
+    h1 ^= (uint64_t)len; h2 ^= (uint64_t)len;     /* finalization, :319-331 */
+    h1 += h2; h2 += h1;
+    h1 = fmix64(h1); h2 = fmix64(h2);
+    h1 += h2; h2 += h1;
+    out[0] = h1; out[1] = h2;
+}
+
+/* getHash — hash.cpp:10-38 (non-ARCH_32 branch): first 8 (use64) or 4 bytes. */
+uint64_t oracle_get_hash(const char *kmer, int k, uint32_t seed, int use64)
+{
+    uint64_t out[2];
+    oracle_murmur3_x64_128(kmer, k, seed, out);
+    return use64 ? out[0] : (uint64_t)(uint32_t)out[0];
+}
+
+/* setAlphabetFromString — Sketch.cpp:1108-1137 */
+void oracle_set_alphabet(oracle_params *p, const char *characters)
+{
+    memset(p->alphabet, 0, 256);
+    for (const char *c = characters; *c; c++) {
+        char u = *c;
+        if (!p->preserve_case && u > 96 && u < 123) u -= 32;
+        p->alphabet[(unsigned char)u] = 1;
+    }
+    unsigned n = 0;
+    for (int i = 0; i < 256; i++) n += p->alphabet[i] ? 1 : 0;
+    p->use64 = pow((double)n, (double)p->kmer_size) > pow(2.0, 32.0);   /* :1136 */
+}
+
+/* ------------------------------------------------------------------------- */
+/* MinHashHeap — MinHashHeap.cpp:68-145 for multiplicityMinimum==1 and no
+ * bloom filter.  The reference keeps an unordered map {hash->count} plus a
+ * max-heap; the observable state is "set of kept hashes, their counts, the
+ * maximum kept hash".  A sorted array gives the same observable state.      */
+
+struct oracle_heap {
+    uint64_t  cap;      /* cardinalityMaximum */
+    uint64_t  n;
+    uint64_t  msum;     /* multiplicitySum */
+    int       use64;
+    uint64_t *v;        /* ascending, distinct, n <= cap+1 */
+    uint32_t *c;
+};
+
+oracle_heap *oracle_heap_new(uint64_t cardinality_max, int use64)
+{
+    oracle_heap *h = (oracle_heap *)calloc(1, sizeof *h);
+    h->cap = cardinality_max;
+    h->use64 = use64;
+    h->v = (uint64_t *)malloc((cardinality_max + 2) * sizeof(uint64_t));
+    h->c = (uint32_t *)malloc((cardinality_max + 2) * sizeof(uint32_t));
+    return h;
+}
+
+void oracle_heap_free(oracle_heap *h)
+{
+    if (!h) return;
+    free(h->v); free(h->c); free(h);
+}
+
+uint64_t oracle_heap_size(const oracle_heap *h) { return h->n; }
+
+void oracle_heap_try_insert(oracle_heap *h, uint64_t hash)
+{
+    /* :70-74  size < max || hash < top */
+    if (!(h->n < h->cap || hash < h->v[h->n - 1])) return;
+    /* lower bound */
+    uint64_t lo = 0, hi = h->n;
+    while (lo < hi) {
+        uint64_t mid = (lo + hi) >> 1;
+        if (h->v[mid] < hash) lo = mid + 1; else hi = mid;
+    }
+    if (lo < h->n && h->v[lo] == hash) {          /* :120-124 already kept: count++ */
+        h->c[lo]++;
+        h->msum++;
+    } else {                                       /* :96-100 insert with count 1 */
+        memmove(h->v + lo + 1, h->v + lo, (h->n - lo) * sizeof(uint64_t));
+        memmove(h->c + lo + 1, h->c + lo, (h->n - lo) * sizeof(uint32_t));
+        h->v[lo] = hash; h->c[lo] = 1;
+        h->n++; h->msum++;
+    }
+    if (h->n > h->cap) {                           /* :126-144 evict current max */
+        h->msum -= h->c[h->n - 1];
+        h->n--;
+    }
+}
+
+/* MinHashHeap.h:44-45 */
+double oracle_heap_estimate_multiplicity(const oracle_heap *h)
+{
+    return h->n ? (double)h->msum / (double)h->n : 0.0;
+}
+
+double oracle_heap_estimate_set_size(const oracle_heap *h)
+{
+    if (!h->n) return 0.0;
+    return pow(2.0, h->use64 ? 64.0 : 32.0) * (double)h->n / (double)h->v[h->n - 1];
+}
+
+uint64_t oracle_heap_to_list(const oracle_heap *h, uint64_t *hashes, uint32_t *counts)
+{
+    if (hashes) memcpy(hashes, h->v, h->n * sizeof(uint64_t));
+    if (counts) memcpy(counts, h->c, h->n * sizeof(uint32_t));
+    return h->n;
+}
+
+/* ------------------------------------------------------------------------- */
+/* reverseComplement — Sketch.cpp:1071-1106 (26-entry IUPAC table).          */
+static const char complement_tab[26] = {
+    'T','V','G','H','N','N','C','D','N','N','M','N','K',
+    'N','N','N','N','Y','S','A','A','B','W','N','R','N'
+};
+
+/* addMinHashes — Sketch.cpp:512-583 */
+void oracle_add_min_hashes(oracle_heap *h, char *seq, uint64_t length, const oracle_params *p)
+{
+    const int k = p->kmer_size;
+    if (!p->preserve_case)                          /* :524-530 */
+        for (uint64_t i = 0; i < length; i++)
+            if (seq[i] > 96 && seq[i] < 123) seq[i] -= 32;
+
+    char *rev = NULL;
+    if (!p->noncanonical) {                         /* :534-538 */
+        rev = (char *)malloc(length ? length : 1);
+        for (uint64_t i = 0; i < length; i++) {
+            int idx = (int)seq[length - i - 1] - 'A';
+            /* the reference indexes its table unchecked (UB for non-letters);
+             * such bytes are never inside a hashed k-mer, any value will do */
+            rev[i] = (idx >= 0 && idx < 26) ? complement_tab[idx] : 'N';
+        }
+    }
+
+    if (length >= (uint64_t)k) {
+        uint64_t j = 0;
+        for (uint64_t i = 0; i + k <= length; i++) { /* :542-581 */
+            int bad = 0;
+            for (; j < i + k; j++) {
+                if (!p->alphabet[(unsigned char)seq[j]]) {
+                    i = j++;                        /* skip past the bad character */
+                    bad = 1;
+                    break;
+                }
+            }
+            if (bad) continue;
+            const char *fwd = seq + i;
+            const char *kmer = fwd;
+            if (!p->noncanonical) {
+                const char *rv = rev + length - i - k;
+                if (memcmp(fwd, rv, (size_t)k) > 0) kmer = rv;   /* :569-571 */
+            }
+            oracle_heap_try_insert(h, oracle_get_hash(kmer, k, p->seed, p->use64));
+        }
+    }
+    free(rev);
+}
+
+/* sketchFile (concatenated) — Sketch.cpp:1147-1336; sketchSequence — :1338-1365 */
+int oracle_sketch_records(const char *bases, const uint64_t *rec_off, uint64_t nrec,
+                          const oracle_params *p,
+                          uint64_t *hashes_out, uint32_t *counts_out, uint64_t *n_out,
+                          uint64_t *length_out, double *set_size_out)
+{
+    oracle_heap *h = oracle_heap_new(p->sketch_size, p->use64);
+    uint64_t length = 0;
+    int any = 0;
+    for (uint64_t r = 0; r < nrec; r++) {
+        uint64_t l = rec_off[r + 1] - rec_off[r];
+        if (l < (uint64_t)p->kmer_size) continue;   /* :1222-1226 skipped, not counted */
+        any = 1;
+        length += l;                                /* :1253 */
+        char *copy = (char *)malloc(l + 1);
+        memcpy(copy, bases + rec_off[r], l);
+        copy[l] = 0;
+        oracle_add_min_hashes(h, copy, l, p);
+        free(copy);
+    }
+    uint64_t n = oracle_heap_to_list(h, hashes_out, counts_out);
+    if (n_out) *n_out = n;
+    if (length_out) *length_out = length;
+    if (set_size_out) *set_size_out = oracle_heap_estimate_set_size(h);
+    oracle_heap_free(h);
+    return any ? 0 : -1;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Binomial upper tail.  Reference: gsl_cdf_binomial_Q(x-1, r, n) or Boost
+ * cdf(complement(binomial(n,r), x-1)) — CommandDistance.cpp:443-447; both are
+ * P[X > k] = I_p(k+1, n-k) (regularized incomplete beta).                    */
+
+static double beta_cont_frac(double a, double b, double x)
+{
+    /* modified Lentz evaluation of the standard continued fraction for
+     * I_x(a,b) (Abramowitz & Stegun 26.5.8) */
+    const double tiny = 1e-300, eps = 1e-16;
+    double qab = a + b, qap = a + 1.0, qam = a - 1.0;
+    double c = 1.0, d = 1.0 - qab * x / qap;
+    if (fabs(d) < tiny) d = tiny;
+    d = 1.0 / d;
+    double h = d;
+    for (int m = 1; m <= 100000; m++) {
+        double m2 = 2.0 * m;
+        double aa = m * (b - m) * x / ((qam + m2) * (a + m2));
+        d = 1.0 + aa * d; if (fabs(d) < tiny) d = tiny;
+        c = 1.0 + aa / c; if (fabs(c) < tiny) c = tiny;
+        d = 1.0 / d;
+        h *= d * c;
+        aa = -(a + m) * (qab + m) * x / ((a + m2) * (qap + m2));
+        d = 1.0 + aa * d; if (fabs(d) < tiny) d = tiny;
+        c = 1.0 + aa / c; if (fabs(c) < tiny) c = tiny;
+        d = 1.0 / d;
+        double del = d * c;
+        h *= del;
+        if (fabs(del - 1.0) < eps) break;
+    }
+    return h;
+}
+
+static double reg_inc_beta(double a, double b, double x)
+{
+    if (x <= 0.0) return 0.0;
+    if (x >= 1.0) return 1.0;
+    double ln_pre = lgamma(a + b) - lgamma(a) - lgamma(b) + a * log(x) + b * log1p(-x);
+    if (x < (a + 1.0) / (a + b + 2.0))
+        return exp(ln_pre) * beta_cont_frac(a, b, x) / a;
+    return 1.0 - exp(ln_pre) * beta_cont_frac(b, a, 1.0 - x) / b;
+}
+
+double oracle_binomial_q(unsigned int k, double p, unsigned int n)
+{
+    if (k >= n) return 0.0;
+    return reg_inc_beta((double)k + 1.0, (double)n - (double)k, p);
+}
+
+/* pValue — CommandDistance.cpp:427-448 */
+double oracle_p_value(uint64_t x, uint64_t len_ref, uint64_t len_qry,
+                      double kmer_space, uint64_t sketch_size)
+{
+    if (x == 0) return 1.0;
+    double pX = 1.0 / (1.0 + kmer_space / (double)len_ref);
+    double pY = 1.0 / (1.0 + kmer_space / (double)len_qry);
+    double r = pX * pY / (pX + pY - pX * pY);
+    return oracle_binomial_q((unsigned int)(x - 1), r, (unsigned int)sketch_size);
+}
+
+/* compareSketches — CommandDistance.cpp:336-425 */
+void oracle_compare_sketches(oracle_pair *out,
+                             const uint64_t *ref, uint64_t nref, uint64_t len_ref,
+                             const uint64_t *qry, uint64_t nqry, uint64_t len_qry,
+                             uint64_t sketch_size, int kmer_size, double kmer_space,
+                             double max_distance, double max_p_value)
+{
+    uint64_t i = 0, j = 0, common = 0, denom = 0;
+    out->pass = 0;
+    while (denom < sketch_size && i < nref && j < nqry) {   /* :347-365 */
+        if (ref[i] < qry[j]) i++;
+        else if (qry[j] < ref[i]) j++;
+        else { i++; j++; common++; }
+        denom++;
+    }
+    if (denom < sketch_size) {                              /* :367-385 */
+        if (i < nref) denom += nref - i;
+        if (j < nqry) denom += nqry - j;
+        if (denom > sketch_size) denom = sketch_size;
+    }
+    double distance;
+    double jaccard = (double)common / (double)denom;        /* :388 */
+    if (common == denom) distance = 0;                      /* :390-407 */
+    else if (common == 0) distance = 1.;
+    else {
+        distance = -log(2 * jaccard / (1. + jaccard)) / kmer_size;
+        if (distance > 1) distance = 1;
+    }
+    if (max_distance >= 0 && distance > max_distance) return;   /* :409-412 */
+    out->numer = common;
+    out->denom = denom;
+    out->distance = distance;
+    out->p_value = oracle_p_value(common, len_ref, len_qry, kmer_space, denom);
+    if (max_p_value >= 0 && out->p_value > max_p_value) return; /* :419-422 */
+    out->pass = 1;
+}
+
+/* compare (triangle) — CommandTriangle.cpp:200-214, rows [row_begin,row_end) */
+uint64_t oracle_triangle(const uint64_t *table, const uint32_t *nhash, const uint64_t *lengths,
+                         uint64_t n, uint64_t s, uint64_t row_begin, uint64_t row_end,
+                         int kmer_size, double kmer_space, int want_stats,
+                         uint32_t *numer_out, uint32_t *denom_out,
+                         double *dist_out, double *pval_out)
+{
+    uint64_t idx = 0;
+    if (row_end > n) row_end = n;
+    for (uint64_t i = row_begin; i < row_end; i++) {
+        for (uint64_t j = 0; j < i; j++, idx++) {
+            oracle_pair po;
+            po.numer = po.denom = 0; po.distance = 0; po.p_value = 0;
+            if (want_stats) {
+                oracle_compare_sketches(&po, table + i * s, nhash[i], lengths ? lengths[i] : 1,
+                                        table + j * s, nhash[j], lengths ? lengths[j] : 1,
+                                        s, kmer_size, kmer_space, -1.0, -1.0);
+            } else {
+                /* merge only (what the device compare kernel produces) */
+                const uint64_t *a = table + i * s, *b = table + j * s;
+                uint64_t na = nhash[i], nb = nhash[j], ia = 0, ib = 0, common = 0, denom = 0;
+                while (denom < s && ia < na && ib < nb) {
+                    if (a[ia] < b[ib]) ia++;
+                    else if (b[ib] < a[ia]) ib++;
+                    else { ia++; ib++; common++; }
+                    denom++;
+                }
+                if (denom < s) {
+                    if (ia < na) denom += na - ia;
+                    if (ib < nb) denom += nb - ib;
+                    if (denom > s) denom = s;
+                }
+                po.numer = common; po.denom = denom;
+            }
+            if (numer_out) numer_out[idx] = (uint32_t)po.numer;
+            if (denom_out) denom_out[idx] = (uint32_t)po.denom;
+            if (dist_out) dist_out[idx] = po.distance;
+            if (pval_out) pval_out[idx] = po.p_value;
+        }
+    }
+    return idx;
+}

@@ -1,0 +1,175 @@
+"""ctypes loader for the CPU oracle (TEST INFRASTRUCTURE — see mash_oracle.h).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  The product package (mash_amd) never does.
+
+`Oracle()` wraps oracle/libmash_oracle.so (the plain-C restatement);
+`Oracle(ref=True)` wraps oracle/_ref/libmash_ref.so (the reference's own
+objects, built from /root/reference by `make -C oracle ref`) and exposes the
+same calls under the same names.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class OracleParams(C.Structure):
+    _fields_ = [
+        ("kmer_size", C.c_int),
+        ("sketch_size", C.c_uint64),
+        ("seed", C.c_uint32),
+        ("use64", C.c_int),
+        ("noncanonical", C.c_int),
+        ("preserve_case", C.c_int),
+        ("alphabet", C.c_uint8 * 256),
+    ]
+
+
+class OraclePair(C.Structure):
+    _fields_ = [
+        ("numer", C.c_uint64),
+        ("denom", C.c_uint64),
+        ("distance", C.c_double),
+        ("p_value", C.c_double),
+        ("pass_", C.c_int),
+    ]
+
+
+def build(ref=False):
+    """Compile the oracle (and, where /root/reference exists, oracle/_ref)."""
+    subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+    if ref and os.path.isdir("/root/reference/src/mash"):
+        subprocess.run(["make", "-C", _HERE, "-s", "ref"], check=True)
+
+
+def ref_available():
+    return os.path.exists(os.path.join(_HERE, "_ref", "libmash_ref.so"))
+
+
+def _u64p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint64))
+
+
+def _u32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def _f64p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Oracle:
+    def __init__(self, ref=False):
+        self.is_ref = ref
+        if ref:
+            path = os.path.join(_HERE, "_ref", "libmash_ref.so")
+            self.prefix = "ref_"
+        else:
+            path = os.path.join(_HERE, "libmash_oracle.so")
+            if not os.path.exists(path):
+                build()
+            self.prefix = "oracle_"
+        self.lib = C.CDLL(path)
+        L = self.lib
+        L.oracle_set_alphabet.argtypes = [C.POINTER(OracleParams), C.c_char_p]
+        L.oracle_binomial_q.restype = C.c_double
+        L.oracle_binomial_q.argtypes = [C.c_uint, C.c_double, C.c_uint]
+        L.oracle_p_value.restype = C.c_double
+        L.oracle_p_value.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_double, C.c_uint64]
+        L.oracle_triangle.restype = C.c_uint64
+        gh = getattr(L, self.prefix + "get_hash")
+        gh.restype = C.c_uint64
+        gh.argtypes = [C.c_char_p, C.c_int, C.c_uint32, C.c_int]
+        self._get_hash = gh
+        sk = getattr(L, self.prefix + "sketch_records")
+        sk.restype = C.c_int
+        self._sketch = sk
+        self._compare = getattr(L, self.prefix + "compare_sketches")
+        self._compare.restype = None
+        if ref:
+            L.ref_table_new.restype = C.c_void_p
+            L.ref_table_free.argtypes = [C.c_void_p]
+            L.ref_triangle.restype = C.c_uint64
+
+    # -- parameters --------------------------------------------------------
+    def params(self, k=21, s=1000, seed=42, alphabet="ACGT", noncanonical=False,
+               preserve_case=False):
+        p = OracleParams()
+        p.kmer_size = k
+        p.sketch_size = s
+        p.seed = seed
+        p.noncanonical = int(noncanonical)
+        p.preserve_case = int(preserve_case)
+        self.lib.oracle_set_alphabet(C.byref(p), alphabet.encode())
+        return p
+
+    # -- hashing -----------------------------------------------------------
+    def get_hash(self, kmer: bytes, seed=42, use64=True):
+        return int(self._get_hash(kmer, len(kmer), seed, int(use64)))
+
+    # -- sketching ---------------------------------------------------------
+    def sketch_records(self, records, p):
+        """records: list of bytes. Returns (hashes u64[n], counts u32[n], length, set_size)."""
+        bases = b"".join(records)
+        off = np.zeros(len(records) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(r) for r in records], dtype=np.uint64)
+        s = int(p.sketch_size)
+        hashes = np.zeros(s, dtype=np.uint64)
+        counts = np.zeros(s, dtype=np.uint32)
+        n = C.c_uint64(0)
+        length = C.c_uint64(0)
+        setsz = C.c_double(0)
+        rc = self._sketch(C.c_char_p(bases), _u64p(off), C.c_uint64(len(records)), C.byref(p),
+                          _u64p(hashes), _u32p(counts), C.byref(n), C.byref(length), C.byref(setsz))
+        return hashes[: n.value].copy(), counts[: n.value].copy(), int(length.value), float(setsz.value), rc
+
+    # -- comparing ---------------------------------------------------------
+    def compare(self, a, b, len_a, len_b, s, k, kmer_space, max_d=-1.0, max_p=-1.0, use64=True):
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        b = np.ascontiguousarray(b, dtype=np.uint64)
+        out = OraclePair()
+        args = [C.byref(out), _u64p(a), C.c_uint64(len(a)), C.c_uint64(len_a),
+                _u64p(b), C.c_uint64(len(b)), C.c_uint64(len_b),
+                C.c_uint64(s), C.c_int(k), C.c_double(kmer_space), C.c_double(max_d), C.c_double(max_p)]
+        if self.is_ref:
+            args.append(C.c_int(int(use64)))
+        self._compare(*args)
+        return out
+
+    def p_value(self, x, len_ref, len_qry, kmer_space, s):
+        return float(self.lib.oracle_p_value(x, len_ref, len_qry, kmer_space, s))
+
+    def binomial_q(self, k, p, n):
+        return float(self.lib.oracle_binomial_q(k, p, n))
+
+    def triangle(self, table, nhash, lengths, row_begin, row_end, k, kmer_space, stats=False):
+        """Rows [row_begin,row_end) of the lower triangle, reference order.
+        Returns (numer u32[], denom u32[], dist f64[]|None, pval f64[]|None)."""
+        table = np.ascontiguousarray(table, dtype=np.uint64)
+        nhash = np.ascontiguousarray(nhash, dtype=np.uint32)
+        lengths = np.ascontiguousarray(lengths, dtype=np.uint64)
+        n, s = table.shape
+        row_end = min(row_end, n)
+        npairs = sum(range(row_begin, row_end))
+        numer = np.zeros(npairs, dtype=np.uint32)
+        denom = np.zeros(npairs, dtype=np.uint32)
+        dist = np.zeros(npairs, dtype=np.float64) if stats else None
+        pval = np.zeros(npairs, dtype=np.float64) if stats else None
+        if self.is_ref:
+            t = self.lib.ref_table_new(_u64p(table), _u32p(nhash), _u64p(lengths), C.c_uint64(n), C.c_uint64(s))
+            try:
+                self.lib.ref_triangle(C.c_void_p(t), C.c_uint64(row_begin), C.c_uint64(row_end), C.c_int(k),
+                                      C.c_double(kmer_space), _u32p(numer), _u32p(denom),
+                                      _f64p(dist) if stats else None, _f64p(pval) if stats else None)
+            finally:
+                self.lib.ref_table_free(C.c_void_p(t))
+        else:
+            self.lib.oracle_triangle(_u64p(table), _u32p(nhash), _u64p(lengths), C.c_uint64(n), C.c_uint64(s),
+                                     C.c_uint64(row_begin), C.c_uint64(row_end), C.c_int(k),
+                                     C.c_double(kmer_space), C.c_int(int(stats)), _u32p(numer), _u32p(denom),
+                                     _f64p(dist) if stats else None, _f64p(pval) if stats else None)
+        return numer, denom, dist, pval

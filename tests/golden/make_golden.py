@@ -1,0 +1,135 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/ fixtures.  Run HERE (the container with /root/reference
+mounted); the GPU box only ever sees the committed outputs.
+
+Sources (all reference TEST DATA / golden outputs, no reference code):
+  /root/reference/test/ref/genomes.json   -> genomes_sketches.npz (3 x 1000 u64 + lengths + names)
+  /root/reference/test/ref/reads.json     -> reads_sketch.npz     (1000 u64 + length + comment)
+  /root/reference/test/ref/genomes.dist   -> genomes.dist  (verbatim golden text)
+  /root/reference/test/ref/screen         -> screen        (verbatim golden text)
+  /root/reference/test/reads{1,2}.fastq   -> reads{1,2}.fastq.gz (sketch input of reads.json)
+  doc/sphinx/tutorials.rst:24,56-57       -> tutorial known-answers (hard-coded below)
+Independent numeric cross-check:
+  scipy.stats.binom.sf (Boost-backed)     -> binom_sf.json (p-value fixtures)
+Reference-run vectors (oracle/_ref = the reference's own objects, run here):
+  random/adversarial sequences            -> ref_sketch_vectors.npz
+  random sketch pairs                     -> ref_compare_vectors.npz
+"""
+import gzip
+import json
+import os
+import shutil
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+
+def load_info_json(path):
+    with open(path) as f:
+        return json.load(f)
+
+
+def main():
+    g = load_info_json(f"{REF}/test/ref/genomes.json")
+    hashes = np.array([s["hashes"] for s in g["sketches"]], dtype=np.uint64)
+    np.savez_compressed(
+        f"{HERE}/genomes_sketches.npz",
+        hashes=hashes,
+        lengths=np.array([s["length"] for s in g["sketches"]], dtype=np.uint64),
+        names=np.array([s["name"] for s in g["sketches"]]),
+        comments=np.array([s["comment"] for s in g["sketches"]]),
+        kmer=g["kmer"], sketchSize=g["sketchSize"], hashSeed=g["hashSeed"], hashBits=g["hashBits"],
+    )
+    r = load_info_json(f"{REF}/test/ref/reads.json")
+    s0 = r["sketches"][0]
+    np.savez_compressed(
+        f"{HERE}/reads_sketch.npz",
+        hashes=np.array(s0["hashes"], dtype=np.uint64),
+        length=np.uint64(s0["length"]), name=s0["name"], comment=s0["comment"],
+        kmer=r["kmer"], sketchSize=r["sketchSize"], hashSeed=r["hashSeed"],
+    )
+    shutil.copy(f"{REF}/test/ref/genomes.dist", f"{HERE}/genomes.dist")
+    shutil.copy(f"{REF}/test/ref/screen", f"{HERE}/screen")
+    shutil.copy(f"{REF}/test/ref/genomes.json", f"{HERE}/genomes.json")
+    shutil.copy(f"{REF}/test/ref/reads.json", f"{HERE}/reads.json")
+    for n in ("reads1.fastq", "reads2.fastq"):
+        with open(f"{REF}/test/{n}", "rb") as fi, gzip.GzipFile(f"{HERE}/{n}.gz", "wb", mtime=0) as fo:
+            shutil.copyfileobj(fi, fo)
+
+    # ---- scipy binomial tail fixtures -----------------------------------
+    from scipy.stats import binom
+    rng = np.random.default_rng(12345)
+    cases = []
+    for n in (1000, 999, 400, 10000, 37):
+        for r_ in (1e-9, 1.0535e-7, 3.3e-6, 1e-4, 2.5e-3, 0.04, 0.3, 0.77):
+            for x in sorted(set([1, 2, 3, 5, 17, 41, 100, n // 2, n - 1, n] + list(rng.integers(1, n + 1, 3)))):
+                if x > n:
+                    continue
+                v = float(binom.sf(x - 1, n, r_))
+                cases.append({"x": int(x), "n": int(n), "r": r_, "sf": v})
+    with open(f"{HERE}/binom_sf.json", "w") as f:
+        json.dump(cases, f)
+
+    # ---- reference-run vectors (needs oracle/_ref) ------------------------
+    from oracle import pyoracle
+    pyoracle.build(ref=True)
+    ref = pyoracle.Oracle(ref=True)
+    from mash_amd import synth
+
+    seqs, outs = [], {}
+    cfgs = []
+    rng = np.random.default_rng(777)
+    idx = 0
+    for (k, s, alphabet, nonc, pc) in [
+        (21, 1000, "ACGT", False, False),
+        (21, 50, "ACGT", False, False),
+        (31, 400, "ACGT", False, False),
+        (32, 128, "ACGT", False, False),
+        (16, 300, "ACGT", False, False),      # 32-bit hashes
+        (11, 64, "ACGT", False, False),
+        (5, 1000, "ACGT", False, False),      # kmer space (512 canonical) < s
+        (21, 200, "ACGT", True, False),       # -n
+        (21, 200, "ACGT", False, True),       # -Z
+        (9, 300, "ACDEFGHIKLMNPQRSTVWY", True, False),   # protein
+        (3, 100, "ACDEFGHIKLMNPQRSTVWY", True, False),   # protein, 32-bit
+    ]:
+        p = ref.params(k=k, s=s, alphabet=alphabet, noncanonical=nonc, preserve_case=pc)
+        for variant in range(4):
+            if alphabet == "ACGT":
+                recs = synth.adversarial_dna_records(rng, variant)
+            else:
+                recs = synth.random_protein_records(rng, variant)
+            h, c, length, setsz, rc = ref.sketch_records(recs, p)
+            cfgs.append(dict(k=k, s=s, alphabet=alphabet, noncanonical=nonc, preserve_case=pc,
+                             nrec=len(recs), length=length, rc=rc, set_size=setsz, idx=idx))
+            outs[f"bases_{idx}"] = np.frombuffer(b"".join(recs), dtype=np.uint8)
+            outs[f"reclen_{idx}"] = np.array([len(x) for x in recs], dtype=np.uint64)
+            outs[f"hashes_{idx}"] = h
+            outs[f"counts_{idx}"] = c
+            idx += 1
+    outs["cfgs"] = np.array(json.dumps(cfgs))
+    np.savez_compressed(f"{HERE}/ref_sketch_vectors.npz", **outs)
+
+    # compare vectors
+    table, nhash, lengths = synth.clustered_sketches(64, 1000, clusters=4, seed=5)
+    # make some rows short / degenerate
+    nhash[3] = 0
+    nhash[7] = 1
+    nhash[11] = 999
+    nhash[13] = 500
+    table[21] = table[20]
+    nhash[21] = nhash[20]
+    kspace = 4.0 ** 21
+    numer, denom, dist, pval = ref.triangle(table, nhash, lengths, 0, 64, 21, kspace, stats=True)
+    np.savez_compressed(f"{HERE}/ref_compare_vectors.npz", table=table, nhash=nhash, lengths=lengths,
+                        numer=numer, denom=denom, dist=dist, pval=pval, k=21, kmer_space=kspace)
+    print("golden fixtures written to", HERE)
+
+
+if __name__ == "__main__":
+    main()

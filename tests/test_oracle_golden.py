@@ -1,0 +1,144 @@
+"""Pin the CPU oracle against every golden vector the reference holds for the
+hot path, and against outputs of the reference's own objects
+(oracle/_ref) generated in the build container (tests/golden/make_golden.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests import helpers
+
+K, S = 21, 1000
+KSPACE = 4.0 ** 21
+
+
+def test_murmur_known_vectors(oracle):
+    # getHash over ASCII k-mer text, seed 42 (hash.cpp:10-38); values cross-checked
+    # against the reference objects when available (test below) — here: stability
+    # of 64- vs 32-bit views
+    h64 = oracle.get_hash(b"ACGTACGTACGTACGTACGTA", 42, True)
+    h32 = oracle.get_hash(b"ACGTACGTACGTACGTACGTA", 42, False)
+    assert h32 == (h64 & 0xFFFFFFFF)
+
+
+def test_reads_json_golden(oracle, golden_dir):
+    """mash sketch -r -I reads reads1.fastq reads2.fastq == test/ref/reads.json."""
+    r1 = helpers.read_fastx(os.path.join(golden_dir, "reads1.fastq.gz"))
+    r2 = helpers.read_fastx(os.path.join(golden_dir, "reads2.fastq.gz"))
+    recs = helpers.round_robin([r1, r2])
+    assert len(recs) == 2000
+    p = oracle.params(k=K, s=S, seed=42)
+    h, c, length, setsz, rc = oracle.sketch_records([r[2] for r in recs], p)
+    gh, glen, gcomment = helpers.load_golden_reads()
+    assert rc == 0
+    assert np.array_equal(h, gh)
+    assert int(setsz) == glen == 502359          # reads: length = estimateSetSize (Sketch.cpp:1272-1282)
+    first = recs[0]
+    comment = "[%d seqs] %s %s [...]" % (len(recs), first[0].decode(), first[1].decode())
+    assert comment == gcomment
+
+
+def _dist_lines(golden_dir):
+    out = []
+    for ln in open(os.path.join(golden_dir, "genomes.dist")):
+        f = ln.rstrip("\n").split("\t")
+        out.append((f[0], f[1], f[2], f[3], f[4]))
+    return out
+
+
+def test_genomes_dist_golden(oracle, golden_dir):
+    """mash dist genomes.msh reads.msh == test/ref/genomes.dist (3 lines)."""
+    gh, glens, names = helpers.load_golden_genomes()
+    rh, rlen, _ = helpers.load_golden_reads()
+    lines = _dist_lines(golden_dir)
+    for i in range(3):
+        out = oracle.compare(gh[i], rh, int(glens[i]), rlen, S, K, KSPACE)
+        assert out.pass_ == 1
+        assert "%d/%d" % (out.numer, out.denom) == lines[i][4]
+        assert helpers.fmt_g(out.distance) == lines[i][2]
+        assert helpers.fmt_g(out.p_value) == lines[i][3]
+        assert names[i] == lines[i][0]
+
+
+def test_tutorial_known_answers(oracle):
+    """doc/sphinx/tutorials.rst:24,56-57: 456/1000 -> 0.0222766 ; 1000/1000 -> 0."""
+    a = np.arange(0, 2000, 2, dtype=np.uint64)          # 1000 values
+    b = a.copy()
+    out = oracle.compare(a, b, 4639675, 4631469, S, K, KSPACE)
+    assert (out.numer, out.denom) == (1000, 1000)
+    assert out.distance == 0.0 and helpers.fmt_g(out.p_value) == "0"
+    # construct a pair whose bottom-1000 of the union holds exactly 456 shared
+    shared = np.arange(0, 456, dtype=np.uint64) * 4
+    only_a = np.arange(0, 272, dtype=np.uint64) * 4 + 1
+    only_b = np.arange(0, 272, dtype=np.uint64) * 4 + 2
+    tail_a = np.arange(10**6, 10**6 + 272, dtype=np.uint64) * 4 + 1
+    tail_b = np.arange(10**6, 10**6 + 272, dtype=np.uint64) * 4 + 2
+    A = np.sort(np.concatenate([shared, only_a, tail_a]))
+    B = np.sort(np.concatenate([shared, only_b, tail_b]))
+    assert len(A) == 1000 and len(B) == 1000
+    out = oracle.compare(A, B, 4639675, 5498450, S, K, KSPACE)
+    assert (out.numer, out.denom) == (456, 1000)
+    assert helpers.fmt_g(out.distance) == "0.0222766"
+    assert helpers.fmt_g(out.p_value) == "0"
+
+
+def test_binomial_tail_vs_scipy_fixtures(oracle, golden_dir):
+    cases = json.load(open(os.path.join(golden_dir, "binom_sf.json")))
+    worst = 0.0
+    for c in cases:
+        got = oracle.binomial_q(c["x"] - 1, c["r"], c["n"])
+        want = c["sf"]
+        if want < 1e-290:
+            assert got < 1e-280
+            continue
+        rel = abs(got - want) / want
+        worst = max(worst, rel)
+        assert rel < 1e-9, (c, got)
+    assert worst < 1e-9
+
+
+def test_oracle_equals_reference_sketch_vectors(oracle):
+    """The restatement reproduces hash lists AND counts the reference's own objects
+    produced (tests/golden/ref_sketch_vectors.npz)."""
+    for cfg, recs, gh, gc in helpers.load_ref_sketch_vectors():
+        p = oracle.params(k=cfg["k"], s=cfg["s"], alphabet=cfg["alphabet"],
+                          noncanonical=cfg["noncanonical"], preserve_case=cfg["preserve_case"])
+        h, c, length, setsz, rc = oracle.sketch_records(recs, p)
+        assert rc == cfg["rc"]
+        assert length == cfg["length"]
+        assert np.array_equal(h, gh), cfg
+        assert np.array_equal(c, gc), cfg
+        assert setsz == cfg["set_size"]
+
+
+def test_oracle_equals_reference_compare_vectors(oracle, golden_dir):
+    z = np.load(os.path.join(golden_dir, "ref_compare_vectors.npz"))
+    numer, denom, dist, pval = oracle.triangle(z["table"], z["nhash"], z["lengths"], 0, 64,
+                                               int(z["k"]), float(z["kmer_space"]), stats=True)
+    assert np.array_equal(numer, z["numer"])
+    assert np.array_equal(denom, z["denom"])
+    assert np.array_equal(dist, z["dist"])            # same libm, bit-exact
+    assert np.array_equal(pval, z["pval"])
+    n2, d2, _, _ = oracle.triangle(z["table"], z["nhash"], z["lengths"], 0, 64,
+                                   int(z["k"]), float(z["kmer_space"]), stats=False)
+    assert np.array_equal(n2, z["numer"]) and np.array_equal(d2, z["denom"])
+
+
+def test_oracle_vs_reference_live(oracle, ref_oracle):
+    """Where oracle/_ref exists: random k-mers hash identically; random sketches too."""
+    rng = np.random.default_rng(99)
+    for k in (1, 7, 8, 9, 15, 16, 17, 21, 24, 31, 32):
+        for _ in range(50):
+            kmer = bytes(rng.integers(33, 127, k, dtype=np.uint8))
+            for use64 in (True, False):
+                assert oracle.get_hash(kmer, 42, use64) == ref_oracle.get_hash(kmer, 42, use64)
+            assert oracle.get_hash(kmer, 7, True) == ref_oracle.get_hash(kmer, 7, True)
+    from mash_amd import synth
+    for variant in range(4):
+        recs = synth.adversarial_dna_records(rng, variant)
+        for (k, s) in ((21, 1000), (15, 100), (32, 77)):
+            p = oracle.params(k=k, s=s)
+            a = oracle.sketch_records(recs, p)
+            b = ref_oracle.sketch_records(recs, p)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2:] == b[2:]
