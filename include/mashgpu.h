@@ -1,0 +1,173 @@
+/*
+ * mashgpu.h — C ABI of the MI355X-native Mash hot path (libmashgpu.so).
+ *
+ * This is the drop-in boundary for the ONE data-parallel path of marbl/Mash:
+ * k-mer hashing + bottom-s selection (sketching) and the early-terminating
+ * sorted-merge Jaccard / Mash distance (comparing).  The reference has no
+ * FFI/plugin API; its seams are the worker function pointers it hands to
+ * ThreadPool<In,Out>.  Each entry point below names the
+ * reference interface it replaces (file:line under /root/reference/src/mash).
+ * Per-record / per-pair callbacks are far too fine for a GPU, so the ABI works
+ * at batch granularity: plain pointers and sizes, caller-owned buffers, opaque
+ * handles for device-resident state, `int` status returns (0 = ok, <0 = error;
+ * text via mg_last_error).  No torch types, no exit(), no global state.
+ *
+ * Pointer conventions: `*_host` entry points take host pointers and stage
+ * through HBM themselves; `*_dev` entry points take DEVICE pointers (e.g.
+ * torch tensors' data_ptr()) and run on the context's stream without copies.
+ */
+#ifndef MASHGPU_H
+#define MASHGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MG_OK                 0
+#define MG_ERR_INVALID       -1   /* bad argument */
+#define MG_ERR_UNSUPPORTED   -2   /* parameter combination outside the device path */
+#define MG_ERR_HIP           -3   /* HIP runtime error (see mg_last_error) */
+#define MG_ERR_NOMEM         -4
+
+/* Byte that separates records inside one sketch's byte range: k-mers never
+ * span records (Sketch.cpp:1200-1270 calls addMinHashes once per record).
+ * Any byte outside the alphabet works; this one is the convention. */
+#define MG_RECORD_SEP  0x0A
+/* Padding value of unused hash slots in dense sketch tables. */
+#define MG_HASH_PAD    0xFFFFFFFFFFFFFFFFull
+
+typedef struct mg_ctx   mg_ctx;     /* one per process+GPU: device, stream, scratch */
+typedef struct mg_table mg_table;   /* device-resident dense sketch table */
+
+/* Mirrors the fields of Sketch::Parameters (Sketch.h:86-105) that change results. */
+typedef struct mg_params {
+    int32_t  kmer_size;        /* kmerSize, 1..32                     (Command.cpp:168) */
+    uint32_t seed;             /* seed, default 42                    (Command.cpp:178) */
+    uint64_t sketch_size;      /* minHashesPerWindow, default 1000               */
+    uint32_t alphabet_size;    /* alphabetSize                                   */
+    uint8_t  alphabet[256];    /* alphabet[] (1 = member)                        */
+    uint8_t  preserve_case;    /* preserveCase (-Z)                              */
+    uint8_t  use64;            /* use64 = alphabetSize^k > 2^32  (Sketch.cpp:1136) */
+    uint8_t  noncanonical;     /* noncanonical (-n, forced by -a / -z)           */
+    uint8_t  counts;           /* counts (multiplicities requested)              */
+} mg_params;
+
+/* {numer, denom} of one pair: what the merge loop of compareSketches produces
+ * (CommandDistance.cpp:347-385).  8 bytes per pair. */
+typedef struct mg_counts { uint32_t numer, denom; } mg_counts;
+
+/* Full PairOutput (CommandDistance.h:63-70). `pass` semantics as the reference:
+ * when the distance filter rejects, only `pass` (=0) is meaningful. */
+typedef struct mg_pair {
+    uint32_t numer, denom;
+    double   distance;
+    double   p_value;
+    uint8_t  pass;
+    uint8_t  _pad[7];
+} mg_pair;
+
+/* ---- context -------------------------------------------------------------- */
+int         mg_ctx_create(int device, mg_ctx **out);
+void        mg_ctx_destroy(mg_ctx *ctx);
+const char *mg_last_error(mg_ctx *ctx);      /* ctx may be NULL: last create error */
+/* Run on an existing hipStream_t (e.g. torch's current stream). NULL = own stream. */
+int         mg_ctx_set_stream(mg_ctx *ctx, void *hip_stream);
+int         mg_ctx_synchronize(mg_ctx *ctx);
+/* Number of CUs of the device (for callers sizing work). */
+int         mg_ctx_cu_count(mg_ctx *ctx);
+
+/* setAlphabetFromString + sketchParameterSetup core (Sketch.cpp:1108-1137,
+ * sketchParameterSetup.cpp:15-105): fills alphabet[], alphabet_size, use64. */
+int mg_params_init(mg_params *p, int kmer_size, uint64_t sketch_size, uint32_t seed,
+                   const char *alphabet, int noncanonical, int preserve_case);
+
+/* ---- sketching ------------------------------------------------------------
+ * Replaces sketchFile / sketchSequence / addMinHashes / MinHashHeap::tryInsert /
+ * setMinHashesForReference (Sketch.cpp:1147-1365, :512-583, :1139-1145;
+ * MinHashHeap.cpp:68-145; HashSet.cpp:78-118) for minCov==1, no Bloom filter.
+ *
+ * bases[nbases]: all input bytes. Sketch i covers bytes
+ * [sketch_off[i], sketch_off[i+1]); inside it records are separated by
+ * MG_RECORD_SEP (concatenated mode = many records in one range; `-i` = one
+ * record per range).  Bytes are exactly what kseq hands to addMinHashes (any
+ * case; uppercasing happens on device unless preserve_case).  Bytes >= 0x80
+ * are invalid bases (the reference's behaviour there is undefined).
+ *
+ * Outputs (row i = sketch i): hashes_out[nsketch * sketch_size] ascending,
+ * distinct, padded with MG_HASH_PAD (32-bit hashes are zero-extended);
+ * nhash_out[nsketch] = valid entries; counts_out (nullable) multiplicities.
+ */
+int mg_sketch_host(mg_ctx *ctx, const mg_params *p,
+                   const uint8_t *bases, uint64_t nbases,
+                   const uint64_t *sketch_off, uint64_t nsketch,
+                   uint64_t *hashes_out, uint32_t *nhash_out, uint32_t *counts_out);
+int mg_sketch_dev(mg_ctx *ctx, const mg_params *p,
+                  const uint8_t *bases_dev, uint64_t nbases,
+                  const uint64_t *sketch_off_host, uint64_t nsketch,
+                  uint64_t *hashes_out_dev, uint32_t *nhash_out_dev, uint32_t *counts_out_dev);
+
+/* ---- sketch tables ----------------------------------------------------------
+ * Dense replacement for vector<Sketch::Reference> (Sketch.h:131-139):
+ * hashes[n * s] row-major ascending + nhash[n] + lengths[n] (Reference::length). */
+int  mg_table_upload(mg_ctx *ctx, const uint64_t *hashes, const uint32_t *nhash,
+                     const uint64_t *lengths, uint64_t n, uint64_t s, mg_table **out);
+/* Adopt device buffers without copying (they must outlive the table). */
+int  mg_table_wrap_dev(mg_ctx *ctx, const uint64_t *hashes_dev, const uint32_t *nhash_dev,
+                       const uint64_t *lengths_dev, uint64_t n, uint64_t s, mg_table **out);
+void mg_table_free(mg_table *t);
+uint64_t mg_table_rows(const mg_table *t);
+uint64_t mg_table_sketch_size(const mg_table *t);
+
+/* ---- comparing --------------------------------------------------------------
+ * Merge counts of compareSketches (CommandDistance.cpp:336-385).
+ *
+ * Triangle (replaces compare(TriangleInput*), CommandTriangle.cpp:200-214):
+ * rows [row_begin,row_end) of the lower triangle, output in reference order:
+ * for i in rows, for j in [0,i): out[i*(i-1)/2 + j - row_begin*(row_begin-1)/2].
+ *
+ * Rect (replaces compare(CompareInput*), CommandDistance.cpp:306-334):
+ * queries [q_begin,q_end) x all refs, query-major: out[(q-q_begin)*nref + r].
+ * sketch_size = min of the two tables' sizes (CommandDistance.cpp:313-315).
+ */
+int mg_compare_tri_dev(mg_ctx *ctx, const mg_table *t, uint64_t row_begin, uint64_t row_end,
+                       mg_counts *out_dev);
+int mg_compare_tri_host(mg_ctx *ctx, const mg_table *t, uint64_t row_begin, uint64_t row_end,
+                        mg_counts *out_host);
+int mg_compare_rect_dev(mg_ctx *ctx, const mg_table *ref, const mg_table *qry,
+                        uint64_t q_begin, uint64_t q_end, mg_counts *out_dev);
+int mg_compare_rect_host(mg_ctx *ctx, const mg_table *ref, const mg_table *qry,
+                         uint64_t q_begin, uint64_t q_end, mg_counts *out_host);
+
+/* Distance + p-value + filters for pairs already counted (the tail of
+ * compareSketches, CommandDistance.cpp:387-424, and pValue, :427-448).
+ * Host arithmetic (glibc log, the same libm the reference links), so distances
+ * are bit-identical to the reference build on this box.
+ * len_ref/len_qry: Reference::length of the two sketches of each pair are taken
+ * from the tables by index: triangle pairs use (i,j) in reference order.
+ * max_distance / max_p_value < 0 disable the filters (the CLI passes 1 / 1). */
+int mg_finish_tri_host(const mg_counts *counts, const uint64_t *lengths, uint64_t row_begin,
+                       uint64_t row_end, int kmer_size, double kmer_space,
+                       double max_distance, double max_p_value, mg_pair *out);
+int mg_finish_rect_host(const mg_counts *counts, const uint64_t *len_ref, uint64_t nref,
+                        const uint64_t *len_qry, uint64_t nqry, int kmer_size, double kmer_space,
+                        double max_distance, double max_p_value, mg_pair *out);
+/* Scalar helpers (same arithmetic as the bulk calls). */
+double mg_distance(uint32_t numer, uint32_t denom, int kmer_size);
+double mg_p_value(uint64_t x, uint64_t len_ref, uint64_t len_qry, double kmer_space,
+                  uint64_t sketch_size);
+
+/* ---- timing hook for bench.py ----------------------------------------------
+ * Average duration (ms) of the last `name` kernel launches recorded with HIP
+ * events on the context's stream since mg_prof_reset; name = "compare" or
+ * "sketch".  launches_out receives the number of launches averaged. */
+int    mg_prof_enable(mg_ctx *ctx, int on);
+void   mg_prof_reset(mg_ctx *ctx);
+double mg_prof_avg_ms(mg_ctx *ctx, const char *name, uint64_t *launches_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MASHGPU_H */

@@ -1,0 +1,270 @@
+"""ctypes binding of libmashgpu.so (include/mashgpu.h) — plumbing for tests and bench.py.
+
+The product is the C ABI; this module only loads it.  There is no CPU fallback:
+if the HIP library is missing or no GPU is visible, calls fail loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmashgpu.so")
+
+MG_OK = 0
+HASH_PAD = 0xFFFFFFFFFFFFFFFF
+RECORD_SEP = 0x0A
+
+EXPORTS = [
+    "mg_ctx_create", "mg_ctx_destroy", "mg_last_error", "mg_ctx_set_stream", "mg_ctx_synchronize",
+    "mg_ctx_cu_count", "mg_params_init", "mg_sketch_host", "mg_sketch_dev", "mg_table_upload",
+    "mg_table_wrap_dev", "mg_table_free", "mg_table_rows", "mg_table_sketch_size",
+    "mg_compare_tri_dev", "mg_compare_tri_host", "mg_compare_rect_dev", "mg_compare_rect_host",
+    "mg_finish_tri_host", "mg_finish_rect_host", "mg_distance", "mg_p_value",
+    "mg_prof_enable", "mg_prof_reset", "mg_prof_avg_ms",
+]
+
+
+class MgParams(C.Structure):
+    _fields_ = [
+        ("kmer_size", C.c_int32),
+        ("seed", C.c_uint32),
+        ("sketch_size", C.c_uint64),
+        ("alphabet_size", C.c_uint32),
+        ("alphabet", C.c_uint8 * 256),
+        ("preserve_case", C.c_uint8),
+        ("use64", C.c_uint8),
+        ("noncanonical", C.c_uint8),
+        ("counts", C.c_uint8),
+    ]
+
+
+class MgPair(C.Structure):
+    _fields_ = [
+        ("numer", C.c_uint32),
+        ("denom", C.c_uint32),
+        ("distance", C.c_double),
+        ("p_value", C.c_double),
+        ("pass_", C.c_uint8),
+        ("_pad", C.c_uint8 * 7),
+    ]
+
+
+PAIR_DTYPE = np.dtype([("numer", "<u4"), ("denom", "<u4"), ("distance", "<f8"), ("p_value", "<f8"),
+                       ("pass", "u1"), ("_pad", "u1", 7)])
+COUNTS_DTYPE = np.dtype([("numer", "<u4"), ("denom", "<u4")])
+
+
+class MashGpuError(RuntimeError):
+    pass
+
+
+def load_library():
+    if not os.path.exists(LIB_PATH):
+        raise MashGpuError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    vp, u64, u32, i32, dbl = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_double
+    lib.mg_ctx_create.argtypes = [i32, C.POINTER(vp)]
+    lib.mg_ctx_destroy.argtypes = [vp]
+    lib.mg_ctx_destroy.restype = None
+    lib.mg_last_error.argtypes = [vp]
+    lib.mg_last_error.restype = C.c_char_p
+    lib.mg_ctx_set_stream.argtypes = [vp, vp]
+    lib.mg_ctx_synchronize.argtypes = [vp]
+    lib.mg_ctx_cu_count.argtypes = [vp]
+    lib.mg_params_init.argtypes = [C.POINTER(MgParams), i32, u64, u32, C.c_char_p, i32, i32]
+    lib.mg_sketch_host.argtypes = [vp, C.POINTER(MgParams), vp, u64, vp, u64, vp, vp, vp]
+    lib.mg_sketch_dev.argtypes = [vp, C.POINTER(MgParams), vp, u64, vp, u64, vp, vp, vp]
+    lib.mg_table_upload.argtypes = [vp, vp, vp, vp, u64, u64, C.POINTER(vp)]
+    lib.mg_table_wrap_dev.argtypes = [vp, vp, vp, vp, u64, u64, C.POINTER(vp)]
+    lib.mg_table_free.argtypes = [vp]
+    lib.mg_table_free.restype = None
+    lib.mg_table_rows.argtypes = [vp]
+    lib.mg_table_rows.restype = u64
+    lib.mg_table_sketch_size.argtypes = [vp]
+    lib.mg_table_sketch_size.restype = u64
+    lib.mg_compare_tri_dev.argtypes = [vp, vp, u64, u64, vp]
+    lib.mg_compare_tri_host.argtypes = [vp, vp, u64, u64, vp]
+    lib.mg_compare_rect_dev.argtypes = [vp, vp, vp, u64, u64, vp]
+    lib.mg_compare_rect_host.argtypes = [vp, vp, vp, u64, u64, vp]
+    lib.mg_finish_tri_host.argtypes = [vp, vp, u64, u64, i32, dbl, dbl, dbl, vp]
+    lib.mg_finish_rect_host.argtypes = [vp, vp, u64, vp, u64, i32, dbl, dbl, dbl, vp]
+    lib.mg_distance.argtypes = [u32, u32, i32]
+    lib.mg_distance.restype = dbl
+    lib.mg_p_value.argtypes = [u64, u64, u64, dbl, u64]
+    lib.mg_p_value.restype = dbl
+    lib.mg_prof_enable.argtypes = [vp, i32]
+    lib.mg_prof_reset.argtypes = [vp]
+    lib.mg_prof_reset.restype = None
+    lib.mg_prof_avg_ms.argtypes = [vp, C.c_char_p, C.POINTER(u64)]
+    lib.mg_prof_avg_ms.restype = dbl
+    return lib
+
+
+def tri_pairs(row_begin, row_end):
+    t = lambda x: x * (x - 1) // 2 if x else 0
+    return t(row_end) - t(row_begin)
+
+
+def make_params(lib, k=21, s=1000, seed=42, alphabet="ACGT", noncanonical=False, preserve_case=False):
+    p = MgParams()
+    rc = lib.mg_params_init(C.byref(p), k, s, seed, alphabet.encode(), int(noncanonical), int(preserve_case))
+    if rc != MG_OK:
+        raise MashGpuError(f"mg_params_init failed ({rc})")
+    return p
+
+
+def join_records(records):
+    """Records of ONE sketch -> byte string with MG_RECORD_SEP between records."""
+    return bytes([RECORD_SEP]).join(records)
+
+
+class Table:
+    def __init__(self, eng, handle, keep=()):
+        self.eng, self.handle, self._keep = eng, handle, keep
+
+    @property
+    def rows(self):
+        return int(self.eng.lib.mg_table_rows(self.handle))
+
+    @property
+    def sketch_size(self):
+        return int(self.eng.lib.mg_table_sketch_size(self.handle))
+
+    def free(self):
+        if self.handle:
+            self.eng.lib.mg_table_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class MashGpu:
+    """One context = one process + one GPU (mg_ctx)."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.mg_ctx_create(device, C.byref(h))
+        if rc != MG_OK:
+            raise MashGpuError("mg_ctx_create: " + self.lib.mg_last_error(None).decode())
+        self.ctx = h
+        if stream is not None:
+            self._check(self.lib.mg_ctx_set_stream(self.ctx, C.c_void_p(stream)))
+
+    def close(self):
+        if self.ctx:
+            self.lib.mg_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def _check(self, rc):
+        if rc != MG_OK:
+            raise MashGpuError(f"libmashgpu error {rc}: " + self.lib.mg_last_error(self.ctx).decode())
+
+    def params(self, **kw):
+        return make_params(self.lib, **kw)
+
+    def synchronize(self):
+        self._check(self.lib.mg_ctx_synchronize(self.ctx))
+
+    # ---- sketching ---------------------------------------------------------
+    def sketch_host(self, sketches, p):
+        """sketches: list (one per sketch) of lists of record bytes.
+        Returns (hashes u64[n, s], nhash u32[n])."""
+        blobs = [join_records(r) for r in sketches]
+        bases = np.frombuffer(b"".join(blobs), dtype=np.uint8)
+        off = np.zeros(len(blobs) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(b) for b in blobs], dtype=np.uint64)
+        return self.sketch_host_raw(bases, off, p)
+
+    def sketch_host_raw(self, bases, off, p):
+        n = len(off) - 1
+        s = int(p.sketch_size)
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        hashes = np.zeros((n, s), dtype=np.uint64)
+        nhash = np.zeros(n, dtype=np.uint32)
+        self._check(self.lib.mg_sketch_host(self.ctx, C.byref(p), bases.ctypes.data, len(bases),
+                                            off.ctypes.data, n, hashes.ctypes.data, nhash.ctypes.data, None))
+        return hashes, nhash
+
+    def sketch_dev(self, bases_ptr, nbases, off, p, hashes_ptr, nhash_ptr):
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        self._check(self.lib.mg_sketch_dev(self.ctx, C.byref(p), bases_ptr, nbases, off.ctypes.data,
+                                           len(off) - 1, hashes_ptr, nhash_ptr, None))
+
+    # ---- tables --------------------------------------------------------------
+    def table_upload(self, hashes, nhash, lengths=None):
+        hashes = np.ascontiguousarray(hashes, dtype=np.uint64)
+        nhash = np.ascontiguousarray(nhash, dtype=np.uint32)
+        n, s = hashes.shape
+        lp = None
+        if lengths is not None:
+            lengths = np.ascontiguousarray(lengths, dtype=np.uint64)
+            lp = lengths.ctypes.data
+        h = C.c_void_p()
+        self._check(self.lib.mg_table_upload(self.ctx, hashes.ctypes.data, nhash.ctypes.data, lp, n, s, C.byref(h)))
+        return Table(self, h)
+
+    def table_wrap(self, hashes_ptr, nhash_ptr, lengths_ptr, n, s, keep=()):
+        h = C.c_void_p()
+        self._check(self.lib.mg_table_wrap_dev(self.ctx, hashes_ptr, nhash_ptr, lengths_ptr, n, s, C.byref(h)))
+        return Table(self, h, keep)
+
+    # ---- comparing -------------------------------------------------------------
+    def compare_tri_host(self, table, row_begin=0, row_end=None):
+        row_end = table.rows if row_end is None else min(row_end, table.rows)
+        out = np.zeros(tri_pairs(row_begin, row_end), dtype=COUNTS_DTYPE)
+        self._check(self.lib.mg_compare_tri_host(self.ctx, table.handle, row_begin, row_end, out.ctypes.data))
+        return out
+
+    def compare_tri_dev(self, table, row_begin, row_end, out_ptr):
+        self._check(self.lib.mg_compare_tri_dev(self.ctx, table.handle, row_begin, row_end, out_ptr))
+
+    def compare_rect_host(self, ref, qry, q_begin=0, q_end=None):
+        q_end = qry.rows if q_end is None else min(q_end, qry.rows)
+        out = np.zeros((q_end - q_begin, ref.rows), dtype=COUNTS_DTYPE)
+        self._check(self.lib.mg_compare_rect_host(self.ctx, ref.handle, qry.handle, q_begin, q_end, out.ctypes.data))
+        return out
+
+    def compare_rect_dev(self, ref, qry, q_begin, q_end, out_ptr):
+        self._check(self.lib.mg_compare_rect_dev(self.ctx, ref.handle, qry.handle, q_begin, q_end, out_ptr))
+
+    # ---- finishing (host arithmetic) --------------------------------------------
+    def finish_tri(self, counts, lengths, row_begin, row_end, k, kmer_space, max_d=-1.0, max_p=-1.0):
+        counts = np.ascontiguousarray(counts)
+        lengths = np.ascontiguousarray(lengths, dtype=np.uint64)
+        out = np.zeros(len(counts), dtype=PAIR_DTYPE)
+        rc = self.lib.mg_finish_tri_host(counts.ctypes.data, lengths.ctypes.data, row_begin, row_end, k,
+                                         kmer_space, max_d, max_p, out.ctypes.data)
+        self._check(rc)
+        return out
+
+    def finish_rect(self, counts, len_ref, len_qry, k, kmer_space, max_d=-1.0, max_p=-1.0):
+        counts = np.ascontiguousarray(counts)
+        len_ref = np.ascontiguousarray(len_ref, dtype=np.uint64)
+        len_qry = np.ascontiguousarray(len_qry, dtype=np.uint64)
+        out = np.zeros(counts.shape, dtype=PAIR_DTYPE)
+        rc = self.lib.mg_finish_rect_host(counts.ctypes.data, len_ref.ctypes.data, len(len_ref),
+                                          len_qry.ctypes.data, len(len_qry), k, kmer_space, max_d, max_p,
+                                          out.ctypes.data)
+        self._check(rc)
+        return out
+
+    # ---- profiling hook -----------------------------------------------------------
+    def prof_enable(self, on=True):
+        self._check(self.lib.mg_prof_enable(self.ctx, int(on)))
+
+    def prof_reset(self):
+        self.lib.mg_prof_reset(self.ctx)
+
+    def prof_avg_ms(self, name):
+        n = C.c_uint64(0)
+        ms = self.lib.mg_prof_avg_ms(self.ctx, name.encode(), C.byref(n))
+        return float(ms), int(n.value)

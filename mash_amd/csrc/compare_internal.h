@@ -1,0 +1,36 @@
+// compare_internal.h — launch interface between mashgpu.cpp and compare.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mg {
+
+struct CompareTile {
+    uint32_t row0;          // first row of the tile (rows [row0, row0+R) clipped to row_end)
+    uint32_t col0, col1;    // columns [col0, col1)
+};
+
+struct CompareArgs {
+    const uint64_t *row_hashes;   // table whose rows sit in LDS (triangle: the table; rect: queries)
+    const uint32_t *row_nhash;
+    const uint64_t *col_hashes;   // table streamed through registers (triangle: same; rect: refs)
+    const uint32_t *col_nhash;
+    const CompareTile *tiles;
+    uint2 *out;                   // {numer, denom}
+    uint64_t row_stride, col_stride;
+    uint64_t row_begin, row_end;  // rows handled by this launch
+    uint64_t ncols;               // rect: number of refs
+    uint64_t out_base;            // triangle: row_begin*(row_begin-1)/2
+    uint32_t s;                   // sketch size used for the comparison
+    uint32_t rows_per_tile;       // R
+    uint32_t triangle;            // 1: only j < i, triangular output; 0: rect
+};
+
+// LDS-tiled kernel usable when s <= 1024; rows_per_tile chosen by compare_rows_per_tile.
+bool compare_tiled_supported(uint32_t s);
+uint32_t compare_rows_per_tile(uint32_t s);
+hipError_t launch_compare_tiled(const CompareArgs &a, uint32_t ntiles, hipStream_t stream);
+// Generic kernel (any s): one wave per pair, binary search in global memory.
+hipError_t launch_compare_generic(const CompareArgs &a, hipStream_t stream);
+
+}  // namespace mg

@@ -1,0 +1,628 @@
+// mashgpu.cpp — the C ABI (include/mashgpu.h) over the gfx950 kernels.
+// Host-side orchestration only: work lists, device buffers, launches, error strings.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mashgpu.h"
+#include "compare_internal.h"
+#include "pvalue.h"
+#include "sketch_internal.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct ProfRec { hipEvent_t a, b; };
+
+}  // namespace
+
+struct mg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int cu_count = 0;
+    std::string err;
+    bool prof = false;
+    std::vector<ProfRec> prof_compare, prof_sketch;
+};
+
+struct mg_table {
+    mg_ctx *ctx = nullptr;
+    const uint64_t *hashes = nullptr;
+    const uint32_t *nhash = nullptr;
+    const uint64_t *lengths = nullptr;
+    uint64_t n = 0, s = 0;
+    bool owns = false;
+};
+
+#define HIP_TRY(ctx, call)                                                           \
+    do {                                                                             \
+        hipError_t e__ = (call);                                                     \
+        if (e__ != hipSuccess) {                                                     \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);        \
+            return MG_ERR_HIP;                                                       \
+        }                                                                            \
+    } while (0)
+
+static int fail(mg_ctx *ctx, int code, const std::string &msg)
+{
+    if (ctx) ctx->err = msg; else g_create_error = msg;
+    return code;
+}
+
+static void prof_begin(mg_ctx *ctx, std::vector<ProfRec> &v)
+{
+    if (!ctx->prof) return;
+    ProfRec r;
+    hipEventCreate(&r.a);
+    hipEventCreate(&r.b);
+    hipEventRecord(r.a, ctx->stream);
+    v.push_back(r);
+}
+
+static void prof_end(mg_ctx *ctx, std::vector<ProfRec> &v)
+{
+    if (!ctx->prof || v.empty()) return;
+    hipEventRecord(v.back().b, ctx->stream);
+}
+
+extern "C" {
+
+int mg_ctx_create(int device, mg_ctx **out)
+{
+    if (!out) return fail(nullptr, MG_ERR_INVALID, "mg_ctx_create: out is NULL");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return fail(nullptr, MG_ERR_HIP, std::string("no HIP device: ") + hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail(nullptr, MG_ERR_INVALID, "mg_ctx_create: bad device index");
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return fail(nullptr, MG_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    mg_ctx *c = new mg_ctx;
+    c->device = device;
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return fail(nullptr, MG_ERR_HIP, "hipStreamCreate failed"); }
+    c->own_stream = true;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->cu_count = prop.multiProcessorCount;
+    *out = c;
+    return MG_OK;
+}
+
+void mg_ctx_destroy(mg_ctx *ctx)
+{
+    if (!ctx) return;
+    mg_prof_reset(ctx);
+    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *mg_last_error(mg_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int mg_ctx_set_stream(mg_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return MG_ERR_INVALID;
+    if (ctx->own_stream && ctx->stream) { hipStreamDestroy(ctx->stream); ctx->own_stream = false; }
+    if (hip_stream == nullptr) {
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+    } else {
+        ctx->stream = (hipStream_t)hip_stream;
+    }
+    return MG_OK;
+}
+
+int mg_ctx_synchronize(mg_ctx *ctx)
+{
+    if (!ctx) return MG_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MG_OK;
+}
+
+int mg_ctx_cu_count(mg_ctx *ctx) { return ctx ? ctx->cu_count : 0; }
+
+int mg_params_init(mg_params *p, int kmer_size, uint64_t sketch_size, uint32_t seed,
+                   const char *alphabet, int noncanonical, int preserve_case)
+{
+    if (!p || !alphabet || kmer_size < 1 || kmer_size > 32 || sketch_size < 1) return MG_ERR_INVALID;
+    memset(p, 0, sizeof *p);
+    p->kmer_size = kmer_size;
+    p->sketch_size = sketch_size;
+    p->seed = seed;
+    p->noncanonical = noncanonical ? 1 : 0;
+    p->preserve_case = preserve_case ? 1 : 0;
+    for (const char *c = alphabet; *c; c++) {            // Sketch.cpp:1113-1125
+        char u = *c;
+        if (!preserve_case && u > 96 && u < 123) u -= 32;
+        p->alphabet[(unsigned char)u] = 1;
+    }
+    for (int i = 0; i < 256; i++) p->alphabet_size += p->alphabet[i] ? 1 : 0;
+    p->use64 = pow((double)p->alphabet_size, (double)kmer_size) > pow(2.0, 32.0);   // :1136
+    return MG_OK;
+}
+
+/* ------------------------------------------------------------------ sketching */
+
+static bool alphabet_is_dna(const mg_params *p)
+{
+    if (p->alphabet_size != 4) return false;
+    return p->alphabet['A'] && p->alphabet['C'] && p->alphabet['G'] && p->alphabet['T'];
+}
+
+int mg_sketch_dev(mg_ctx *ctx, const mg_params *p, const uint8_t *bases_dev, uint64_t nbases,
+                  const uint64_t *sketch_off, uint64_t nsketch, uint64_t *hashes_out_dev,
+                  uint32_t *nhash_out_dev, uint32_t *counts_out_dev)
+{
+    if (!ctx) return MG_ERR_INVALID;
+    if (!p || !sketch_off || !hashes_out_dev || !nhash_out_dev || (!bases_dev && nbases))
+        return fail(ctx, MG_ERR_INVALID, "mg_sketch: NULL argument");
+    if (p->kmer_size < 1 || p->kmer_size > 32) return fail(ctx, MG_ERR_INVALID, "mg_sketch: k must be 1..32");
+    if (counts_out_dev || p->counts)
+        return fail(ctx, MG_ERR_UNSUPPORTED, "mg_sketch: multiplicities (counts) are not computed on device yet");
+    if (nsketch == 0) return MG_OK;
+    if (nsketch > 0xFFFFFFFFull) return fail(ctx, MG_ERR_INVALID, "mg_sketch: too many sketches");
+    if (((uintptr_t)bases_dev & 15) != 0) return fail(ctx, MG_ERR_INVALID, "mg_sketch: bases must be 16-byte aligned");
+    const bool dna = alphabet_is_dna(p);
+    if (!p->noncanonical && !dna)
+        return fail(ctx, MG_ERR_UNSUPPORTED, "mg_sketch: canonical k-mers need the ACGT alphabet");
+    int nt = 0;
+    uint32_t cap = 0;
+    if (!mg::sketch_geometry(p->sketch_size, &nt, &cap))
+        return fail(ctx, MG_ERR_UNSUPPORTED, "mg_sketch: sketch size too large for the LDS selector (max 12288)");
+    const int mode = dna ? (p->noncanonical ? 1 : 0) : 2;
+    const uint64_t s = p->sketch_size;
+    const uint64_t k = (uint64_t)p->kmer_size;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+    // ---- work list: chunks of k-mer start positions ----
+    const uint64_t tile = mg::sketch_tile(nt);
+    uint64_t total_pos = 0;
+    for (uint64_t i = 0; i < nsketch; i++) {
+        if (sketch_off[i + 1] < sketch_off[i] || sketch_off[i + 1] > nbases)
+            return fail(ctx, MG_ERR_INVALID, "mg_sketch: sketch_off not monotone / out of range");
+        const uint64_t len = sketch_off[i + 1] - sketch_off[i];
+        if (len >= k) total_pos += len - k + 1;
+    }
+    uint64_t target_items = 2048;
+    if (const char *e = getenv("MASHGPU_SKETCH_ITEMS")) target_items = strtoull(e, nullptr, 10);
+    if (target_items < 1) target_items = 1;
+    uint64_t chunk = (total_pos + target_items - 1) / target_items;
+    uint64_t min_chunk = 4 * tile;
+    if (const char *e = getenv("MASHGPU_SKETCH_MIN_CHUNK")) min_chunk = strtoull(e, nullptr, 10);
+    if (chunk < min_chunk) chunk = min_chunk;
+    chunk = (chunk + tile - 1) / tile * tile;
+
+    std::vector<mg::SketchWork> work;
+    std::vector<mg::MergeWork> merges;
+    uint64_t nslots = 0;
+    for (uint64_t i = 0; i < nsketch; i++) {
+        const uint64_t b = sketch_off[i], e = sketch_off[i + 1];
+        const uint64_t len = e - b;
+        if (len < k) continue;
+        const uint64_t npos = len - k + 1;
+        const uint64_t nch = (npos + chunk - 1) / chunk;
+        if (nch > 0xFFFFFFFFull || nslots + nch > 0xFFFFFFFFull) return fail(ctx, MG_ERR_INVALID, "mg_sketch: too many chunks");
+        if (nch > 1) {
+            mg::MergeWork m{(uint32_t)i, (uint32_t)nslots, (uint32_t)nch, 0};
+            merges.push_back(m);
+        }
+        for (uint64_t c = 0; c < nch; c++) {
+            mg::SketchWork w;
+            w.begin = b + c * chunk;
+            w.end = b + std::min(npos, (c + 1) * chunk);
+            w.limit = e;
+            w.sketch = (uint32_t)i;
+            w.slot = nch > 1 ? (uint32_t)(nslots + c) : 0u;
+            w.nchunks = (uint32_t)nch;
+            w._pad = 0;
+            work.push_back(w);
+        }
+        if (nch > 1) nslots += nch;
+    }
+
+    // outputs default to "empty sketch"
+    HIP_TRY(ctx, hipMemsetAsync(hashes_out_dev, 0xFF, nsketch * s * 8, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(nhash_out_dev, 0, nsketch * 4, ctx->stream));
+    if (work.empty()) return MG_OK;
+
+    mg::SketchWork *d_work = nullptr;
+    mg::MergeWork *d_merge = nullptr;
+    uint8_t *d_alpha = nullptr;
+    uint64_t *d_pool = nullptr, *d_gT = nullptr;
+    uint32_t *d_pool_n = nullptr;
+    int rc = MG_OK;
+    auto cleanup = [&]() {
+        hipStreamSynchronize(ctx->stream);
+        if (d_work) hipFree(d_work);
+        if (d_merge) hipFree(d_merge);
+        if (d_alpha) hipFree(d_alpha);
+        if (d_pool) hipFree(d_pool);
+        if (d_gT) hipFree(d_gT);
+        if (d_pool_n) hipFree(d_pool_n);
+    };
+#define TRY_C(call)                                                                   \
+    do {                                                                              \
+        hipError_t e__ = (call);                                                      \
+        if (e__ != hipSuccess) {                                                      \
+            ctx->err = std::string(#call) + ": " + hipGetErrorString(e__);           \
+            rc = MG_ERR_HIP;                                                          \
+            cleanup();                                                                \
+            return rc;                                                                \
+        }                                                                             \
+    } while (0)
+    TRY_C(hipMalloc(&d_work, work.size() * sizeof(mg::SketchWork)));
+    TRY_C(hipMemcpyAsync(d_work, work.data(), work.size() * sizeof(mg::SketchWork), hipMemcpyHostToDevice, ctx->stream));
+    TRY_C(hipMalloc(&d_alpha, 256));
+    TRY_C(hipMemcpyAsync(d_alpha, p->alphabet, 256, hipMemcpyHostToDevice, ctx->stream));
+    if (nslots) {
+        TRY_C(hipMalloc(&d_pool, nslots * s * 8));
+        TRY_C(hipMalloc(&d_pool_n, nslots * 4));
+        TRY_C(hipMemsetAsync(d_pool_n, 0, nslots * 4, ctx->stream));
+        TRY_C(hipMalloc(&d_gT, nsketch * 8));
+        TRY_C(hipMemsetAsync(d_gT, 0xFF, nsketch * 8, ctx->stream));
+        TRY_C(hipMalloc(&d_merge, merges.size() * sizeof(mg::MergeWork)));
+        TRY_C(hipMemcpyAsync(d_merge, merges.data(), merges.size() * sizeof(mg::MergeWork), hipMemcpyHostToDevice, ctx->stream));
+    }
+    mg::SketchArgs a;
+    a.bases = bases_dev;
+    a.work = d_work;
+    a.alphabet = d_alpha;
+    a.hashes_out = hashes_out_dev;
+    a.nhash_out = nhash_out_dev;
+    a.pool = d_pool;
+    a.pool_n = d_pool_n;
+    a.g_T = d_gT;
+    a.sketch_size = (uint32_t)s;
+    a.cap = cap;
+    a.seed = p->seed;
+    a.use64 = p->use64;
+    a.fold_case = p->preserve_case ? 0 : 1;
+    prof_begin(ctx, ctx->prof_sketch);
+    TRY_C(mg::launch_sketch_chunks(p->kmer_size, mode, nt, a, (uint32_t)work.size(), ctx->stream));
+    prof_end(ctx, ctx->prof_sketch);
+    if (!merges.empty()) {
+        mg::MergeArgs m;
+        m.work = d_merge;
+        m.pool = d_pool;
+        m.pool_n = d_pool_n;
+        m.hashes_out = hashes_out_dev;
+        m.nhash_out = nhash_out_dev;
+        m.sketch_size = (uint32_t)s;
+        m.cap = cap;
+        TRY_C(mg::launch_merge_chunks(nt, m, (uint32_t)merges.size(), ctx->stream));
+    }
+#undef TRY_C
+    // work lists are freed after the stream drains (keeps the call self-contained)
+    cleanup();
+    return rc;
+}
+
+int mg_sketch_host(mg_ctx *ctx, const mg_params *p, const uint8_t *bases, uint64_t nbases,
+                   const uint64_t *sketch_off, uint64_t nsketch, uint64_t *hashes_out,
+                   uint32_t *nhash_out, uint32_t *counts_out)
+{
+    if (!ctx) return MG_ERR_INVALID;
+    if (!p || !hashes_out || !nhash_out) return fail(ctx, MG_ERR_INVALID, "mg_sketch_host: NULL argument");
+    if (counts_out) return fail(ctx, MG_ERR_UNSUPPORTED, "mg_sketch: multiplicities (counts) are not computed on device yet");
+    if (nsketch == 0) return MG_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint64_t s = p->sketch_size;
+    uint8_t *d_bases = nullptr;
+    uint64_t *d_hashes = nullptr;
+    uint32_t *d_nhash = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d_bases, nbases + 64));
+    int rc = MG_OK;
+    if (hipMalloc(&d_hashes, nsketch * s * 8) != hipSuccess || hipMalloc(&d_nhash, nsketch * 4) != hipSuccess) {
+        rc = fail(ctx, MG_ERR_NOMEM, "mg_sketch_host: device allocation failed");
+    } else if (hipMemcpyAsync(d_bases, bases, nbases, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+        rc = fail(ctx, MG_ERR_HIP, "mg_sketch_host: H2D copy failed");
+    } else {
+        rc = mg_sketch_dev(ctx, p, d_bases, nbases, sketch_off, nsketch, d_hashes, d_nhash, nullptr);
+        if (rc == MG_OK) {
+            if (hipMemcpyAsync(hashes_out, d_hashes, nsketch * s * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                hipMemcpyAsync(nhash_out, d_nhash, nsketch * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess)
+                rc = fail(ctx, MG_ERR_HIP, "mg_sketch_host: D2H copy failed");
+        }
+    }
+    hipStreamSynchronize(ctx->stream);
+    if (d_bases) hipFree(d_bases);
+    if (d_hashes) hipFree(d_hashes);
+    if (d_nhash) hipFree(d_nhash);
+    return rc;
+}
+
+/* ------------------------------------------------------------------ tables */
+
+int mg_table_upload(mg_ctx *ctx, const uint64_t *hashes, const uint32_t *nhash, const uint64_t *lengths,
+                    uint64_t n, uint64_t s, mg_table **out)
+{
+    if (!ctx) return MG_ERR_INVALID;
+    if (!hashes || !nhash || !out || s == 0) return fail(ctx, MG_ERR_INVALID, "mg_table_upload: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    uint64_t *dh = nullptr, *dl = nullptr;
+    uint32_t *dn = nullptr;
+    HIP_TRY(ctx, hipMalloc(&dh, std::max<uint64_t>(n * s * 8, 8)));
+    HIP_TRY(ctx, hipMalloc(&dn, std::max<uint64_t>(n * 4, 4)));
+    HIP_TRY(ctx, hipMalloc(&dl, std::max<uint64_t>(n * 8, 8)));
+    HIP_TRY(ctx, hipMemcpyAsync(dh, hashes, n * s * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(dn, nhash, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (lengths) HIP_TRY(ctx, hipMemcpyAsync(dl, lengths, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    else HIP_TRY(ctx, hipMemsetAsync(dl, 0, n * 8, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    mg_table *t = new mg_table;
+    t->ctx = ctx; t->hashes = dh; t->nhash = dn; t->lengths = dl; t->n = n; t->s = s; t->owns = true;
+    *out = t;
+    return MG_OK;
+}
+
+int mg_table_wrap_dev(mg_ctx *ctx, const uint64_t *hashes_dev, const uint32_t *nhash_dev,
+                      const uint64_t *lengths_dev, uint64_t n, uint64_t s, mg_table **out)
+{
+    if (!ctx) return MG_ERR_INVALID;
+    if (!hashes_dev || !nhash_dev || !out || s == 0) return fail(ctx, MG_ERR_INVALID, "mg_table_wrap_dev: bad argument");
+    mg_table *t = new mg_table;
+    t->ctx = ctx; t->hashes = hashes_dev; t->nhash = nhash_dev; t->lengths = lengths_dev;
+    t->n = n; t->s = s; t->owns = false;
+    *out = t;
+    return MG_OK;
+}
+
+void mg_table_free(mg_table *t)
+{
+    if (!t) return;
+    if (t->owns) {
+        hipSetDevice(t->ctx->device);
+        hipFree((void *)t->hashes);
+        hipFree((void *)t->nhash);
+        hipFree((void *)t->lengths);
+    }
+    delete t;
+}
+
+uint64_t mg_table_rows(const mg_table *t) { return t ? t->n : 0; }
+uint64_t mg_table_sketch_size(const mg_table *t) { return t ? t->s : 0; }
+
+/* ------------------------------------------------------------------ comparing */
+
+static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, uint64_t row_begin,
+                       uint64_t row_end, bool triangle, mg_counts *out_dev)
+{
+    if (row_end > rows->n) row_end = rows->n;
+    if (row_begin >= row_end) return MG_OK;
+    if (rows->n > 0xFFFFFFFFull || cols->n > 0xFFFFFFFFull) return fail(ctx, MG_ERR_INVALID, "compare: table too large");
+    const uint64_t s64 = std::min(rows->s, cols->s);       // CommandDistance.cpp:313-315
+    if (s64 > 0xFFFFFFFFull) return fail(ctx, MG_ERR_INVALID, "compare: sketch size too large");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    mg::CompareArgs a;
+    a.row_hashes = rows->hashes; a.row_nhash = rows->nhash; a.row_stride = rows->s;
+    a.col_hashes = cols->hashes; a.col_nhash = cols->nhash; a.col_stride = cols->s;
+    a.tiles = nullptr;
+    a.out = reinterpret_cast<uint2 *>(out_dev);
+    a.row_begin = row_begin; a.row_end = row_end;
+    a.ncols = cols->n;
+    a.out_base = triangle ? row_begin * (row_begin - (row_begin ? 1 : 0)) / 2 : 0;
+    a.s = (uint32_t)s64;
+    a.triangle = triangle ? 1 : 0;
+    a.rows_per_tile = 0;
+    const char *force = getenv("MASHGPU_COMPARE_KERNEL");
+    const bool want_generic = force && strcmp(force, "generic") == 0;
+    if (!mg::compare_tiled_supported(a.s) || want_generic) {
+        prof_begin(ctx, ctx->prof_compare);
+        HIP_TRY(ctx, mg::launch_compare_generic(a, ctx->stream));
+        prof_end(ctx, ctx->prof_compare);
+        return MG_OK;
+    }
+    uint32_t R = mg::compare_rows_per_tile(a.s);
+    if (const char *e = getenv("MASHGPU_COMPARE_ROWS")) { uint32_t v = (uint32_t)atoi(e); if (v >= 1 && v < R) R = v; }
+    uint64_t CC = 1024;
+    if (const char *e = getenv("MASHGPU_COMPARE_COLS")) { uint64_t v = strtoull(e, nullptr, 10); if (v >= 16) CC = v; }
+    a.rows_per_tile = R;
+    // tiles: column chunk outer, row tile inner (concurrent workgroups share a column chunk in L2)
+    const uint64_t nrt = (row_end - row_begin + R - 1) / R;
+    const uint64_t maxcols = triangle ? (row_end - 1) : cols->n;       // columns [0, maxcols)
+    std::vector<mg::CompareTile> tiles;
+    for (uint64_t c0 = 0; c0 < maxcols; c0 += CC) {
+        for (uint64_t t = 0; t < nrt; t++) {
+            const uint64_t r0 = row_begin + t * R;
+            const uint64_t rlast = std::min(r0 + R, row_end) - 1;      // largest row index of the tile
+            const uint64_t cend = triangle ? rlast : cols->n;         // columns needed: [0, cend)
+            if (c0 >= cend) continue;
+            mg::CompareTile tl;
+            tl.row0 = (uint32_t)r0;
+            tl.col0 = (uint32_t)c0;
+            tl.col1 = (uint32_t)std::min(c0 + CC, cend);
+            tiles.push_back(tl);
+        }
+    }
+    if (tiles.empty()) return MG_OK;
+    mg::CompareTile *d_tiles = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d_tiles, tiles.size() * sizeof(mg::CompareTile)));
+    hipError_t e = hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(mg::CompareTile),
+                                  hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        a.tiles = d_tiles;
+        prof_begin(ctx, ctx->prof_compare);
+        e = mg::launch_compare_tiled(a, (uint32_t)tiles.size(), ctx->stream);
+        prof_end(ctx, ctx->prof_compare);
+    }
+    // the tile list must outlive the launch
+    hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    hipFree(d_tiles);
+    if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare launch: ") + hipGetErrorString(e));
+    if (e2 != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare kernel: ") + hipGetErrorString(e2));
+    return MG_OK;
+}
+
+static uint64_t tri_pairs(uint64_t row_begin, uint64_t row_end)
+{
+    // sum_{i=row_begin}^{row_end-1} i
+    auto tri = [](uint64_t x) { return x ? x * (x - 1) / 2 : 0; };
+    return tri(row_end) - tri(row_begin);
+}
+
+int mg_compare_tri_dev(mg_ctx *ctx, const mg_table *t, uint64_t row_begin, uint64_t row_end, mg_counts *out_dev)
+{
+    if (!ctx) return MG_ERR_INVALID;
+    if (!t || !out_dev) return fail(ctx, MG_ERR_INVALID, "mg_compare_tri_dev: NULL argument");
+    return run_compare(ctx, t, t, row_begin, row_end, true, out_dev);
+}
+
+int mg_compare_rect_dev(mg_ctx *ctx, const mg_table *ref, const mg_table *qry, uint64_t q_begin,
+                        uint64_t q_end, mg_counts *out_dev)
+{
+    if (!ctx) return MG_ERR_INVALID;
+    if (!ref || !qry || !out_dev) return fail(ctx, MG_ERR_INVALID, "mg_compare_rect_dev: NULL argument");
+    return run_compare(ctx, qry, ref, q_begin, q_end, false, out_dev);
+}
+
+// host-output variants: bounded device staging, processed in row blocks
+static int compare_host(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, uint64_t rb, uint64_t re,
+                        bool triangle, mg_counts *out_host)
+{
+    if (re > rows->n) re = rows->n;
+    if (rb >= re) return MG_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint64_t max_pairs = 1ull << 27;                 // 1 GiB of {numer,denom}
+    mg_counts *d_out = nullptr;
+    uint64_t done = 0, r = rb;
+    uint64_t cap_pairs = 0;
+    int rc = MG_OK;
+    while (r < re && rc == MG_OK) {
+        uint64_t r2 = r, pairs = 0;
+        while (r2 < re) {
+            const uint64_t add = triangle ? r2 : cols->n;
+            if (pairs && pairs + add > max_pairs) break;
+            pairs += add;
+            r2++;
+        }
+        if (pairs > cap_pairs) {
+            if (d_out) hipFree(d_out);
+            d_out = nullptr;
+            if (hipMalloc(&d_out, std::max<uint64_t>(pairs, 1) * sizeof(mg_counts)) != hipSuccess) {
+                rc = fail(ctx, MG_ERR_NOMEM, "compare: device allocation failed");
+                break;
+            }
+            cap_pairs = pairs;
+        }
+        rc = run_compare(ctx, rows, cols, r, r2, triangle, d_out);
+        if (rc == MG_OK && pairs) {
+            if (hipMemcpyAsync(out_host + done, d_out, pairs * sizeof(mg_counts), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess)
+                rc = fail(ctx, MG_ERR_HIP, "compare: D2H copy failed");
+        }
+        done += pairs;
+        r = r2;
+    }
+    if (d_out) hipFree(d_out);
+    (void)tri_pairs;
+    return rc;
+}
+
+int mg_compare_tri_host(mg_ctx *ctx, const mg_table *t, uint64_t row_begin, uint64_t row_end, mg_counts *out_host)
+{
+    if (!ctx) return MG_ERR_INVALID;
+    if (!t || !out_host) return fail(ctx, MG_ERR_INVALID, "mg_compare_tri_host: NULL argument");
+    return compare_host(ctx, t, t, row_begin, row_end, true, out_host);
+}
+
+int mg_compare_rect_host(mg_ctx *ctx, const mg_table *ref, const mg_table *qry, uint64_t q_begin,
+                         uint64_t q_end, mg_counts *out_host)
+{
+    if (!ctx) return MG_ERR_INVALID;
+    if (!ref || !qry || !out_host) return fail(ctx, MG_ERR_INVALID, "mg_compare_rect_host: NULL argument");
+    return compare_host(ctx, qry, ref, q_begin, q_end, false, out_host);
+}
+
+/* ------------------------------------------------------------------ finishing */
+
+double mg_distance(uint32_t numer, uint32_t denom, int kmer_size) { return mg::mash_distance(numer, denom, kmer_size); }
+
+double mg_p_value(uint64_t x, uint64_t len_ref, uint64_t len_qry, double kmer_space, uint64_t sketch_size)
+{
+    return mg::p_value(x, len_ref, len_qry, kmer_space, sketch_size);
+}
+
+static inline void finish_one(const mg_counts &c, uint64_t len_ref, uint64_t len_qry, int k, double kmer_space,
+                              double max_d, double max_p, mg_pair *o)
+{
+    memset(o, 0, sizeof *o);
+    o->numer = c.numer;
+    o->denom = c.denom;
+    o->distance = mg::mash_distance(c.numer, c.denom, k);
+    if (max_d >= 0 && o->distance > max_d) return;                      // CommandDistance.cpp:409-412
+    o->p_value = mg::p_value(c.numer, len_ref, len_qry, kmer_space, c.denom);
+    if (max_p >= 0 && o->p_value > max_p) return;                       // :419-422
+    o->pass = 1;
+}
+
+int mg_finish_tri_host(const mg_counts *counts, const uint64_t *lengths, uint64_t row_begin, uint64_t row_end,
+                       int kmer_size, double kmer_space, double max_distance, double max_p_value, mg_pair *out)
+{
+    if (!counts || !lengths || !out) return MG_ERR_INVALID;
+    uint64_t idx = 0;
+    for (uint64_t i = row_begin; i < row_end; i++)
+        for (uint64_t j = 0; j < i; j++, idx++)
+            finish_one(counts[idx], lengths[i], lengths[j], kmer_size, kmer_space, max_distance, max_p_value, out + idx);
+    return MG_OK;
+}
+
+int mg_finish_rect_host(const mg_counts *counts, const uint64_t *len_ref, uint64_t nref, const uint64_t *len_qry,
+                        uint64_t nqry, int kmer_size, double kmer_space, double max_distance, double max_p_value,
+                        mg_pair *out)
+{
+    if (!counts || !len_ref || !len_qry || !out) return MG_ERR_INVALID;
+    for (uint64_t q = 0; q < nqry; q++)
+        for (uint64_t r = 0; r < nref; r++) {
+            const uint64_t idx = q * nref + r;
+            finish_one(counts[idx], len_ref[r], len_qry[q], kmer_size, kmer_space, max_distance, max_p_value, out + idx);
+        }
+    return MG_OK;
+}
+
+/* ------------------------------------------------------------------ profiling */
+
+int mg_prof_enable(mg_ctx *ctx, int on)
+{
+    if (!ctx) return MG_ERR_INVALID;
+    ctx->prof = on != 0;
+    return MG_OK;
+}
+
+void mg_prof_reset(mg_ctx *ctx)
+{
+    if (!ctx) return;
+    for (auto *v : {&ctx->prof_compare, &ctx->prof_sketch}) {
+        for (auto &r : *v) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+        v->clear();
+    }
+}
+
+double mg_prof_avg_ms(mg_ctx *ctx, const char *name, uint64_t *launches_out)
+{
+    if (launches_out) *launches_out = 0;
+    if (!ctx || !name) return 0.0;
+    std::vector<ProfRec> *v = nullptr;
+    if (strcmp(name, "compare") == 0) v = &ctx->prof_compare;
+    else if (strcmp(name, "sketch") == 0) v = &ctx->prof_sketch;
+    if (!v || v->empty()) return 0.0;
+    hipStreamSynchronize(ctx->stream);
+    double tot = 0.0;
+    uint64_t n = 0;
+    for (auto &r : *v) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { tot += ms; n++; }
+    }
+    if (launches_out) *launches_out = n;
+    return n ? tot / (double)n : 0.0;
+}
+
+}  /* extern "C" */

@@ -1,0 +1,413 @@
+// sketch.hip — gfx950 sketching kernels: canonical k-mer streaming, MurmurHash3 in
+// registers, bottom-s distinct selection in LDS.
+//
+// Replaces addMinHashes + getHash + MinHashHeap::tryInsert + HashSet::toHashList
+// (Sketch.cpp:512-583, hash.cpp:10-38, MinHashHeap.cpp:68-145, HashSet.cpp:78-118).
+// The reference's result is order independent: the sketch is the s
+// smallest DISTINCT hashes over all valid k-mers — so any parallel selection that
+// yields that set is bit-exact.
+//
+// Work decomposition: a work item is a CHUNK of one sketch's byte range (a whole
+// sequence when there are enough sequences to fill the chip).  One workgroup per
+// chunk streams it in tiles of NT*60 k-mer start positions:
+//   global --16B coalesced--> LDS tile --odd-stride ds_read_b32--> per-lane run
+// Each lane rolls its ASCII/2-bit windows over 60 (28) consecutive k-mers (kmer_hash.h),
+// hashes, and appends hashes below the current threshold T to an LDS candidate
+// buffer (wave ballot + one LDS atomic per wave).  Every 8 k-mers the workgroup
+// checks capacity; when the buffer could overflow it is compacted: bitonic sort in
+// LDS, adjacent-unique, keep s, T := s-th smallest distinct.  Chunks of one sketch
+// share T through a global atomicMin (any subset's s-th smallest is an upper bound
+// of the final one, so a stale value is only less selective, never wrong).
+// Multi-chunk sketches are finished by merge_chunks_kernel.
+//
+// Roofline: integer-ALU bound (10 64-bit multiplies per 21-mer), ~1 B/base of HBM.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kmer_hash.h"
+#include "sketch_internal.h"
+
+namespace mg {
+
+// Geometry per workgroup size.  NT=256 (s <= 2048): 60 k-mer starts per lane per tile
+// (15-dword lane stride, odd -> conflict-free ds_read_b32), capacity check every 8 k-mers.
+// NT=1024 (s <= 12288, e.g. the s=10000 configuration): the candidate buffer takes
+// 128 KB of LDS, so the tile shrinks to 28 starts per lane (7-dword stride) and the
+// capacity check runs every 4 k-mers.
+__host__ __device__ constexpr int sk_L(int nt) { return nt == 256 ? 60 : 28; }
+__host__ __device__ constexpr int sk_seg_dw(int nt) { return nt == 256 ? 2 : 1; }
+constexpr int SK_E = 16;          // buffer elements per thread during unique-compaction
+constexpr uint64_t HPAD = 0xFFFFFFFFFFFFFFFFULL;
+
+// ---------------------------------------------------------------------------
+// block-wide exclusive scan of one uint per thread (NT threads); returns the
+// exclusive prefix, *total = sum.  s_wsum: LDS scratch of NT/64 + 1 uints.
+template <int NT>
+__device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t *s_wsum, uint32_t *total)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(inc, d);
+        if (lane >= d) inc += t;
+    }
+    if (lane == 63) s_wsum[wid] = inc;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; w++) {
+        uint32_t x = s_wsum[w];
+        if (w < wid) woff += x;
+        tot += x;
+    }
+    __syncthreads();
+    *total = tot;
+    return woff + inc - v;
+}
+
+struct SelState {            // LDS-resident selection state of one workgroup
+    uint64_t T;              // s-th smallest distinct so far (valid when full)
+    uint32_t count;          // entries in buf
+    uint32_t full;           // >= s distinct values known (or a shared threshold adopted)
+    uint32_t arrive;         // monotone wave-arrival ticket (segment boundaries)
+    uint32_t snap;           // `count` as seen by the last wave to finish a segment
+};
+
+// Sort + unique + truncate the candidate buffer.  All NT threads call.
+// On return: buf[0..count) ascending distinct, count <= s, T/full updated, and the
+// shared global threshold (if any) exchanged.
+template <int NT>
+__device__ void compact_buffer(uint64_t *buf, SelState *st, uint32_t *s_wsum, uint32_t s,
+                               unsigned long long *g_T)
+{
+    __syncthreads();
+    const uint32_t n = st->count;
+    const int tid = threadIdx.x;
+    uint32_t P = 2;
+    while (P < n) P <<= 1;
+    for (uint32_t i = n + tid; i < P; i += NT) buf[i] = HPAD;
+    __syncthreads();
+    // bitonic sort, ascending
+    for (uint32_t k = 2; k <= P; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < (P >> 1); t += NT) {
+                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const uint32_t l = i + j;
+                const uint64_t a = buf[i], b = buf[l];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) { buf[i] = b; buf[l] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    // adjacent-unique through registers (reads complete before any write)
+    uint64_t v[SK_E];
+    uint32_t keep = 0, cnt = 0;
+    const uint32_t base = tid * SK_E;
+    uint64_t prev = (base > 0 && base <= n) ? buf[base - 1] : 0;
+#pragma unroll
+    for (int e = 0; e < SK_E; e++) {
+        const uint32_t i = base + e;
+        v[e] = (i < n) ? buf[i] : HPAD;
+        const bool f = (i < n) && (i == 0 || v[e] != prev);
+        prev = v[e];
+        keep |= (f ? 1u : 0u) << e;
+        cnt += f ? 1u : 0u;
+    }
+    uint32_t total;
+    uint32_t off = block_exscan<NT>(cnt, s_wsum, &total);   // contains the barriers
+#pragma unroll
+    for (int e = 0; e < SK_E; e++) {
+        if ((keep >> e) & 1u) {
+            if (off < s) buf[off] = v[e];
+            off++;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t kept = total < s ? total : s;
+        st->count = kept;
+        uint64_t T = HPAD;
+        uint32_t full = 0;
+        if (total >= s) { full = 1; T = buf[s - 1]; }
+        if (g_T) {
+            // exchange with the other chunks of this sketch
+            if (full) atomicMin(g_T, (unsigned long long)T);
+            const uint64_t gt = __hip_atomic_load(g_T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (gt < T || (!full && gt != HPAD)) { T = gt; full = 1; }
+        }
+        st->T = T;
+        st->full = full;
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------
+// MODE 0: DNA canonical, 1: DNA forward-only (-n), 2: table alphabet forward-only
+template <int K, int MODE, int NT>
+__global__ __launch_bounds__(NT) void sketch_chunks_kernel(SketchArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int SK_L = sk_L(NT);
+    constexpr int SK_SEG_DW = sk_seg_dw(NT);
+    constexpr int TILE = NT * SK_L;
+    constexpr int TILE_DW = TILE / 4 + 32;                 // + slack for k-1 overlap & alignment
+    uint64_t *buf = reinterpret_cast<uint64_t *>(smem);                          // [cap]
+    uint32_t *tile = reinterpret_cast<uint32_t *>(smem + (size_t)a.cap * 8);     // [TILE_DW]
+    uint8_t *alpha = reinterpret_cast<uint8_t *>(tile + TILE_DW);                // [256] (MODE 2)
+    uint32_t *s_wsum = reinterpret_cast<uint32_t *>(alpha + 256);                // [NT/64 + 1]
+    SelState *st = reinterpret_cast<SelState *>(s_wsum + NT / 64 + 2);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const SketchWork w = a.work[blockIdx.x];
+    unsigned long long *g_T = w.nchunks > 1 ? (unsigned long long *)&a.g_T[w.sketch] : nullptr;
+
+    if (tid == 0) {
+        st->count = 0; st->full = 0; st->T = HPAD; st->arrive = 0; st->snap = 0;
+        if (g_T) {
+            const uint64_t gt = __hip_atomic_load(g_T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (gt != HPAD) { st->T = gt; st->full = 1; }
+        }
+    }
+    if (MODE == 2) for (int i = tid; i < 256; i += NT) alpha[i] = a.alphabet[i];
+    __syncthreads();
+
+    const uint32_t s = a.sketch_size;
+    const uint32_t cap = a.cap;
+    const uint32_t seed = a.seed;
+    const bool use64 = a.use64 != 0;
+    const bool fold = a.fold_case != 0;
+    constexpr int NBYTES = SK_L + K - 1;                   // bytes one lane consumes per tile
+    constexpr int ND = (NBYTES + 3) / 4;
+    constexpr uint32_t NW = NT / 64;
+    uint32_t seg_no = 0;                                   // segments finished (uniform)
+
+    for (uint64_t t0 = w.begin; t0 < w.end; t0 += TILE) {
+        // ---- stage the tile: bytes [a0, a0 + TILE_DW*4), a0 = t0 rounded down to 16 ----
+        const uint64_t a0 = t0 & ~15ULL;
+        const uint32_t shift = (uint32_t)(t0 - a0);
+        for (int q = tid; q < TILE_DW / 4; q += NT) {
+            const uint64_t o = a0 + (uint64_t)q * 16;
+            uint4 x = make_uint4(0, 0, 0, 0);
+            if (o + 16 <= w.limit) {
+                x = *reinterpret_cast<const uint4 *>(a.bases + o);
+            } else if (o < w.limit) {
+                uint32_t d[4] = {0, 0, 0, 0};
+                for (int b = 0; b < 16 && o + b < w.limit; b++)
+                    d[b >> 2] |= (uint32_t)a.bases[o + b] << (8 * (b & 3));
+                x = make_uint4(d[0], d[1], d[2], d[3]);
+            }
+            reinterpret_cast<uint4 *>(tile)[q] = x;
+        }
+        __syncthreads();
+
+        // ---- per-lane run ----
+        const uint32_t lane_byte0 = shift + (uint32_t)tid * SK_L;
+        const uint32_t *lw = tile + (lane_byte0 >> 2);
+        const uint32_t bsh = lane_byte0 & 3;               // == shift & 3 (uniform)
+        // k-mer starts this lane may emit: start < remaining (chunk end)
+        const uint64_t rem64 = w.end - t0;
+        const uint32_t remaining = rem64 > (uint64_t)TILE ? (uint32_t)TILE : (uint32_t)rem64;
+        const uint32_t lane_first = (uint32_t)tid * SK_L;
+
+        KmerRoller<K, MODE == 0> r;
+        r.reset();
+        uint64_t T = st->T;
+        bool full = st->full != 0;
+        uint32_t cur = lw[0];
+#pragma unroll 1
+        for (int d = 0; d < ND; d++) {
+            const uint32_t nxt = lw[d + 1];
+            const uint32_t word = __builtin_amdgcn_alignbyte(nxt, cur, bsh);
+            cur = nxt;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int pos = 4 * d + b;
+                uint32_t c = (word >> (8 * b)) & 0xFFu;
+                bool valid;
+                if (MODE == 2) {
+                    if (fold) c = fold_upper(c);
+                    valid = alpha[c] != 0;
+                    r.push(c, valid);
+                } else {
+                    if (fold) c &= 0xDFu;                  // DNA: only membership of ACGT matters
+                    uint32_t code, comp;
+                    valid = dna_classify(c, code, comp);
+                    r.push(c, valid, code, comp);
+                }
+                if (pos >= K - 1 && pos < NBYTES) {        // uniform
+                    const uint32_t start = (uint32_t)(pos - (K - 1));
+                    const uint64_t h = r.hash(seed, use64);
+                    const bool pass = r.kmer_valid() && (lane_first + start < remaining) &&
+                                      (!full || h < T);
+                    const uint64_t m = __ballot(pass);
+                    if (m != 0) {
+                        const uint32_t off = __builtin_amdgcn_mbcnt_hi(
+                            (uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+                        uint32_t bpos = 0;
+                        if (pass && off == 0) bpos = atomicAdd(&st->count, (uint32_t)__popcll(m));
+                        bpos = __shfl(bpos, __ffsll((unsigned long long)m) - 1);
+                        if (pass) buf[bpos + off] = h;
+                    }
+                }
+            }
+            if ((d % SK_SEG_DW) == SK_SEG_DW - 1 || d == ND - 1) {
+                // Segment boundary.  The capacity decision must be identical in every
+                // thread, but `count` keeps moving as fast waves enter the next segment:
+                // the LAST wave to arrive (monotone ticket) snapshots it — by then every
+                // wave has issued its appends — and everybody reads the snapshot after
+                // the barrier (it cannot be overwritten before all waves pass the next one).
+                seg_no++;
+                if (lane == 0) {
+                    const uint32_t t = atomicAdd(&st->arrive, 1u);
+                    if (t == NW * seg_no - 1) st->snap = st->count;
+                }
+                __syncthreads();
+                if (st->snap + (uint32_t)NT * 4 * SK_SEG_DW > cap) {    // uniform
+                    compact_buffer<NT>(buf, st, s_wsum, s, g_T);
+                    T = st->T;
+                    full = st->full != 0;
+                }
+            }
+        }
+        __syncthreads();      // tile may be overwritten
+    }
+
+    compact_buffer<NT>(buf, st, s_wsum, s, g_T);
+    const uint32_t n = st->count;
+    if (w.nchunks == 1) {
+        uint64_t *out = a.hashes_out + (uint64_t)w.sketch * s;
+        for (uint32_t i = tid; i < s; i += NT) out[i] = i < n ? buf[i] : HPAD;
+        if (tid == 0) a.nhash_out[w.sketch] = n;
+    } else {
+        uint64_t *out = a.pool + (uint64_t)w.slot * s;
+        for (uint32_t i = tid; i < n; i += NT) out[i] = buf[i];
+        if (tid == 0) a.pool_n[w.slot] = n;
+    }
+}
+
+// One workgroup per multi-chunk sketch: bottom-s distinct of the union of its chunk lists.
+template <int NT>
+__global__ __launch_bounds__(NT) void merge_chunks_kernel(MergeArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint64_t *buf = reinterpret_cast<uint64_t *>(smem);
+    uint32_t *s_wsum = reinterpret_cast<uint32_t *>(smem + (size_t)a.cap * 8);
+    SelState *st = reinterpret_cast<SelState *>(s_wsum + NT / 64 + 2);
+    const int tid = threadIdx.x;
+    const MergeWork w = a.work[blockIdx.x];
+    const uint32_t s = a.sketch_size, cap = a.cap;
+    if (tid == 0) { st->count = 0; st->full = 0; st->T = HPAD; st->arrive = 0; st->snap = 0; }
+    __syncthreads();
+    const uint32_t batch = cap - s;                        // room guaranteed after a compaction
+    for (uint32_t c = 0; c < w.nchunks; c++) {
+        const uint32_t slot = w.first_slot + c;
+        const uint32_t n = a.pool_n[slot];
+        const uint64_t *src = a.pool + (uint64_t)slot * s;
+        for (uint32_t b0 = 0; b0 < n; b0 += batch) {
+            const uint32_t nb = (n - b0) < batch ? (n - b0) : batch;
+            __syncthreads();
+            if (st->count + nb > cap) compact_buffer<NT>(buf, st, s_wsum, s, nullptr);
+            const uint64_t T = st->T;
+            const bool full = st->full != 0;
+            __syncthreads();
+            for (uint32_t i = tid; i < nb; i += NT) {
+                const uint64_t h = src[b0 + i];
+                if (!full || h < T) buf[atomicAdd(&st->count, 1u)] = h;
+            }
+        }
+    }
+    compact_buffer<NT>(buf, st, s_wsum, s, nullptr);
+    const uint32_t n = st->count;
+    uint64_t *out = a.hashes_out + (uint64_t)w.sketch * s;
+    for (uint32_t i = tid; i < s; i += NT) out[i] = i < n ? buf[i] : HPAD;
+    if (tid == 0) a.nhash_out[w.sketch] = n;
+}
+
+// ---------------------------------------------------------------------------
+// dispatch tables
+
+template <int K, int MODE, int NT>
+static hipError_t launch_one(const SketchArgs &a, uint32_t nwork, size_t smem, hipStream_t stream)
+{
+    auto kern = sketch_chunks_kernel<K, MODE, NT>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(nwork), dim3(NT), smem, stream, a);
+    return hipGetLastError();
+}
+
+template <int MODE, int NT>
+static hipError_t launch_k(int k, const SketchArgs &a, uint32_t nwork, size_t smem, hipStream_t st)
+{
+    switch (k) {
+#define MG_CASE(KK) case KK: return launch_one<KK, MODE, NT>(a, nwork, smem, st);
+        MG_CASE(1) MG_CASE(2) MG_CASE(3) MG_CASE(4) MG_CASE(5) MG_CASE(6) MG_CASE(7) MG_CASE(8)
+        MG_CASE(9) MG_CASE(10) MG_CASE(11) MG_CASE(12) MG_CASE(13) MG_CASE(14) MG_CASE(15) MG_CASE(16)
+        MG_CASE(17) MG_CASE(18) MG_CASE(19) MG_CASE(20) MG_CASE(21) MG_CASE(22) MG_CASE(23) MG_CASE(24)
+        MG_CASE(25) MG_CASE(26) MG_CASE(27) MG_CASE(28) MG_CASE(29) MG_CASE(30) MG_CASE(31) MG_CASE(32)
+#undef MG_CASE
+    }
+    return hipErrorInvalidValue;
+}
+
+size_t sketch_smem_bytes(uint32_t cap, int nt)
+{
+    const size_t tile_dw = (size_t)nt * sk_L(nt) / 4 + 32;
+    return (size_t)cap * 8 + tile_dw * 4 + 256 + ((size_t)nt / 64 + 2) * 4 + sizeof(SelState) + 16;
+}
+
+uint32_t sketch_tile(int nt) { return (uint32_t)nt * sk_L(nt); }
+
+// cap: power of two >= s + nt*8 (one segment of candidates always fits after a compaction)
+bool sketch_geometry(uint64_t s, int *nt_out, uint32_t *cap_out)
+{
+    for (int nt : {256, 1024}) {
+        uint64_t need = s + (uint64_t)nt * 4 * sk_seg_dw(nt);
+        uint64_t cap = 2;
+        while (cap < need) cap <<= 1;
+        if (cap / nt > SK_E) continue;                     // unique-compaction holds cap/nt per thread
+        if (sketch_smem_bytes((uint32_t)cap, nt) > 160 * 1024) continue;
+        *nt_out = nt; *cap_out = (uint32_t)cap;
+        return true;
+    }
+    return false;
+}
+
+hipError_t launch_sketch_chunks(int k, int mode, int nt, const SketchArgs &a, uint32_t nwork,
+                                hipStream_t stream)
+{
+    const size_t smem = sketch_smem_bytes(a.cap, nt);
+    if (nt == 256) {
+        if (mode == 0) return launch_k<0, 256>(k, a, nwork, smem, stream);
+        if (mode == 1) return launch_k<1, 256>(k, a, nwork, smem, stream);
+        return launch_k<2, 256>(k, a, nwork, smem, stream);
+    }
+    if (mode == 0) return launch_k<0, 1024>(k, a, nwork, smem, stream);
+    if (mode == 1) return launch_k<1, 1024>(k, a, nwork, smem, stream);
+    return launch_k<2, 1024>(k, a, nwork, smem, stream);
+}
+
+hipError_t launch_merge_chunks(int nt, const MergeArgs &a, uint32_t nwork, hipStream_t stream)
+{
+    const size_t smem = (size_t)a.cap * 8 + ((size_t)nt / 64 + 2) * 4 + sizeof(SelState) + 16;
+    if (nt == 256) {
+        auto kern = merge_chunks_kernel<256>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(nwork), dim3(256), smem, stream, a);
+    } else {
+        auto kern = merge_chunks_kernel<1024>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(nwork), dim3(1024), smem, stream, a);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace mg

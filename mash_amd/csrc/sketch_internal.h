@@ -1,0 +1,60 @@
+// sketch_internal.h — launch interface between the C-ABI layer (mashgpu.cpp) and
+// the sketch kernels (sketch.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mg {
+
+// One chunk of one sketch's byte range.  k-mer START positions [begin,end) belong
+// to this chunk; bytes are readable up to `limit` (end of the sketch's range).
+struct SketchWork {
+    uint64_t begin, end, limit;
+    uint32_t sketch;      // output row
+    uint32_t slot;        // pool slot (multi-chunk sketches)
+    uint32_t nchunks;     // chunks of this sketch (1 -> write the row directly)
+    uint32_t _pad;
+};
+
+struct SketchArgs {
+    const uint8_t *bases;
+    const SketchWork *work;
+    const uint8_t *alphabet;      // [256] device (MODE 2)
+    uint64_t *hashes_out;         // [nsketch * s]
+    uint32_t *nhash_out;          // [nsketch]
+    uint64_t *pool;               // [nslots * s]
+    uint32_t *pool_n;             // [nslots]
+    uint64_t *g_T;                // [nsketch] shared thresholds, initialised to ~0
+    uint32_t sketch_size;
+    uint32_t cap;                 // LDS candidate buffer entries (power of two)
+    uint32_t seed;
+    uint32_t use64;
+    uint32_t fold_case;
+};
+
+struct MergeWork {
+    uint32_t sketch, first_slot, nchunks, _pad;
+};
+
+struct MergeArgs {
+    const MergeWork *work;
+    const uint64_t *pool;
+    const uint32_t *pool_n;
+    uint64_t *hashes_out;
+    uint32_t *nhash_out;
+    uint32_t sketch_size;
+    uint32_t cap;
+};
+
+// geometry: threads per workgroup and LDS candidate capacity for sketch size s;
+// false if s is too large for the LDS-resident selector.
+bool sketch_geometry(uint64_t s, int *nt_out, uint32_t *cap_out);
+uint32_t sketch_tile(int nt);                       // k-mer starts per tile
+size_t sketch_smem_bytes(uint32_t cap, int nt);
+
+// mode 0: DNA canonical, 1: DNA forward only, 2: table alphabet forward only
+hipError_t launch_sketch_chunks(int k, int mode, int nt, const SketchArgs &a, uint32_t nwork,
+                                hipStream_t stream);
+hipError_t launch_merge_chunks(int nt, const MergeArgs &a, uint32_t nwork, hipStream_t stream);
+
+}  // namespace mg

@@ -1,0 +1,38 @@
+"""Row-block sharding of the all-vs-all triangle across the GPUs of one node
+(SURVEY.md §8e): every rank holds the whole sketch table (one RCCL broadcast over
+xGMI), owns a contiguous block of rows of equal AREA (row i has i pairs, so the
+boundaries follow a square-root law), and writes its own slice of the
+reference-ordered output.  No collective sits in the data path."""
+import math
+
+
+def equal_area_row_blocks(n, world):
+    """Boundaries b[0..world] with b[0]=0, b[world]=n: rank g owns rows [b[g], b[g+1]).
+    Pairs in a block = T(b[g+1]) - T(b[g]) with T(x) = x(x-1)/2, balanced to within one row."""
+    total = n * (n - 1) // 2
+    b = [0]
+    for g in range(1, world):
+        target = total * g / world
+        # smallest r with r(r-1)/2 >= target
+        r = int(math.ceil((1.0 + math.sqrt(1.0 + 8.0 * target)) / 2.0))
+        while r > 0 and (r - 1) * (r - 2) // 2 >= target:
+            r -= 1
+        while r * (r - 1) // 2 < target:
+            r += 1
+        b.append(min(max(r, b[-1]), n))
+    b.append(n)
+    return b
+
+
+def tri_pairs(row_begin, row_end):
+    t = lambda x: x * (x - 1) // 2 if x else 0
+    return t(row_end) - t(row_begin)
+
+
+def even_blocks(n, world):
+    """Contiguous near-equal split of n independent units (sketch inputs, query rows)."""
+    base, extra = divmod(n, world)
+    b = [0]
+    for g in range(world):
+        b.append(b[-1] + base + (1 if g < extra else 0))
+    return b

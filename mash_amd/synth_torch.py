@@ -1,0 +1,69 @@
+"""GPU-side generators for bench.py's synthetic workloads, built with
+torch so the BASELINE-sized inputs (100k sketches, 10^10 bases) are produced directly
+in HBM.  int64 tensors carry uint64 bit patterns (two's-complement wraparound)."""
+import torch
+
+_GOLDEN = -7046029254386353131            # 0x9E3779B97F4A7C15 as int64
+_M1 = -4658895280553007687                # 0xBF58476D1CE4E5B9
+_M2 = -7723592293110705685                # 0x94D049BB133111EB
+_PAD_SORT = (1 << 63) - 1
+
+
+def _lsr(z, k):
+    return (z >> k) & ((1 << (64 - k)) - 1)
+
+
+def splitmix64(state0, n):
+    """state0: int64 tensor [...]; returns outputs 1..n as int64 [..., n]."""
+    idx = torch.arange(1, n + 1, device=state0.device, dtype=torch.int64)
+    z = state0.unsqueeze(-1) + _GOLDEN * idx
+    z = (z ^ _lsr(z, 30)) * _M1
+    z = (z ^ _lsr(z, 27)) * _M2
+    return z ^ _lsr(z, 31)
+
+
+def clustered_sketch_table(n, s=1000, clusters=1000, seed=0, pool=1500, private=400, keep_p=0.8,
+                           length=1_000_000, device="cuda", block=20000):
+    """C3 table on `device`: (hashes int64[n, s] = uint64 bits, padded with -1 (=2^64-1);
+    nhash int32[n]; lengths int64[n])."""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    hashes = torch.empty((n, s), dtype=torch.int64, device=device)
+    nhash = torch.empty(n, dtype=torch.int32, device=device)
+    cid = torch.arange(clusters, device=device, dtype=torch.int64)
+    pools = _lsr(splitmix64(-3335678366873096957 * (cid + 1), pool), 10)      # 0xD1B54A32D192ED03
+    for b0 in range(0, n, block):
+        b1 = min(n, b0 + block)
+        m = torch.arange(b0, b1, device=device, dtype=torch.int64)
+        ph = pools[m % clusters]                                              # [B, pool]
+        take = torch.rand((b1 - b0, pool), device=device, generator=gen) < keep_p
+        ph = torch.where(take, ph, torch.full_like(ph, _PAD_SORT))
+        priv = _lsr(splitmix64(-6882143410218379217 * (m + 1) + seed, private), 10)   # 0xA0761D6478BD642F
+        x, _ = torch.sort(torch.cat([ph, priv], dim=1), dim=1)
+        dup = torch.zeros_like(x, dtype=torch.bool)
+        dup[:, 1:] = x[:, 1:] == x[:, :-1]
+        x = torch.where(dup, torch.full_like(x, _PAD_SORT), x)
+        x, _ = torch.sort(x, dim=1)
+        x = x[:, :s]
+        valid = x != _PAD_SORT
+        nhash[b0:b1] = valid.sum(dim=1).to(torch.int32)
+        hashes[b0:b1] = torch.where(valid, x, torch.full_like(x, -1))
+    lengths = torch.full((n,), length, dtype=torch.int64, device=device)
+    return hashes, nhash, lengths
+
+
+def synthetic_genomes(g_begin, g_end, length, device="cuda", block=256):
+    """ASCII bases uint8[(g_end-g_begin), length] of synthetic genomes g_begin..g_end-1
+    (same definition as mash_amd.synth.synthetic_genome)."""
+    n = g_end - g_begin
+    out = torch.empty((n, length), dtype=torch.uint8, device=device)
+    lut = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=device)
+    nw = (length + 31) // 32
+    shifts = torch.arange(32, device=device, dtype=torch.int64) * 2
+    for b0 in range(0, n, block):
+        b1 = min(n, b0 + block)
+        g = torch.arange(g_begin + b0, g_begin + b1, device=device, dtype=torch.int64)
+        w = splitmix64(_GOLDEN * (g + 1), nw)                                 # [B, nw]
+        codes = ((w.unsqueeze(-1) >> shifts) & 3).reshape(b1 - b0, nw * 32)[:, :length]
+        out[b0:b1] = lut[codes]
+    return out

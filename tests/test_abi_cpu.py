@@ -1,0 +1,102 @@
+"""CPU-only checks of the C-ABI library: it loads and exports every symbol that
+include/mashgpu.h declares; host-side helpers behave like the reference."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from mash_amd import abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    if not os.path.exists(abi.LIB_PATH):
+        g.build()
+    return abi.load_library()
+
+
+def test_header_symbols_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "mashgpu.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(mg_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(abi.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_params_init_matches_reference_rules(lib):
+    p = abi.make_params(lib, k=21, s=1000)
+    assert p.use64 == 1 and p.alphabet_size == 4 and p.noncanonical == 0
+    assert abi.make_params(lib, k=16).use64 == 0          # 4^16 == 2^32 is not > 2^32 (Sketch.cpp:1136)
+    assert abi.make_params(lib, k=17).use64 == 1
+    pp = abi.make_params(lib, k=9, alphabet="ACDEFGHIKLMNPQRSTVWY", noncanonical=True)
+    assert pp.alphabet_size == 20 and pp.use64 == 1
+    assert abi.make_params(lib, k=7, alphabet="ACDEFGHIKLMNPQRSTVWY", noncanonical=True).use64 == 0
+    low = abi.make_params(lib, k=21, alphabet="acgt")
+    assert low.alphabet[ord("A")] == 1 and low.alphabet[ord("a")] == 0
+    keep = abi.make_params(lib, k=21, alphabet="acgt", preserve_case=True)
+    assert keep.alphabet[ord("a")] == 1 and keep.alphabet[ord("A")] == 0
+    bad = abi.MgParams()
+    assert lib.mg_params_init(C.byref(bad), 33, 1000, 42, b"ACGT", 0, 0) != 0
+    assert lib.mg_params_init(C.byref(bad), 0, 1000, 42, b"ACGT", 0, 0) != 0
+
+
+def test_distance_and_pvalue_helpers(lib, oracle, golden_dir):
+    import json
+    assert lib.mg_distance(1000, 1000, 21) == 0.0
+    assert lib.mg_distance(0, 1000, 21) == 1.0
+    assert "%g" % lib.mg_distance(456, 1000, 21) == "0.0222766"      # tutorials.rst:24
+    for c in json.load(open(os.path.join(golden_dir, "binom_sf.json")))[::7]:
+        # mg_p_value(x, lenRef, lenQry, kmerSpace, n): pick lengths that reproduce r
+        want = c["sf"]
+        got = oracle.binomial_q(c["x"] - 1, c["r"], c["n"])
+        if want > 1e-290:
+            assert abs(got - want) / want < 1e-9
+    # golden p-values of test/ref/genomes.dist through the product arithmetic
+    from tests import helpers
+    gh, glens, _ = helpers.load_golden_genomes()
+    _, rlen, _ = helpers.load_golden_reads()
+    want = ["4.48626e-214", "2.61074e-180", "4.45454e-214"]
+    for i, x in enumerate((41, 35, 41)):
+        assert "%g" % lib.mg_p_value(x, int(glens[i]), rlen, 4.0 ** 21, 1000) == want[i]
+
+
+def test_finish_host_matches_oracle(lib, oracle, golden_dir):
+    z = np.load(os.path.join(golden_dir, "ref_compare_vectors.npz"))
+    counts = np.zeros(len(z["numer"]), dtype=abi.COUNTS_DTYPE)
+    counts["numer"] = z["numer"]
+    counts["denom"] = z["denom"]
+    lengths = np.ascontiguousarray(z["lengths"], dtype=np.uint64)
+    out = np.zeros(len(counts), dtype=abi.PAIR_DTYPE)
+    rc = lib.mg_finish_tri_host(counts.ctypes.data, lengths.ctypes.data, 0, 64, int(z["k"]),
+                                float(z["kmer_space"]), -1.0, -1.0, out.ctypes.data)
+    assert rc == 0
+    assert np.array_equal(out["distance"], z["dist"])          # same libm => bit-exact
+    ref_p = z["pval"]
+    nz = ref_p > 1e-290
+    assert np.all(np.abs(out["p_value"][nz] - ref_p[nz]) <= 1e-9 * ref_p[nz])
+    assert np.all(out["pass"] == 1)
+    # filters (CommandDistance.cpp:409-424)
+    out2 = np.zeros(len(counts), dtype=abi.PAIR_DTYPE)
+    lib.mg_finish_tri_host(counts.ctypes.data, lengths.ctypes.data, 0, 64, int(z["k"]),
+                           float(z["kmer_space"]), 0.1, 1e-10, out2.ctypes.data)
+    exp_pass = (z["dist"] <= 0.1) & (z["pval"] <= 1e-10)
+    assert np.array_equal(out2["pass"].astype(bool), exp_pass)
+
+
+def test_no_gpu_fails_loudly(lib):
+    """On a box without a GPU the context cannot be created — no silent fallback."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    h = C.c_void_p()
+    assert lib.mg_ctx_create(0, C.byref(h)) != 0
+    assert lib.mg_last_error(None)
+    with pytest.raises(abi.MashGpuError):
+        abi.MashGpu(0)

@@ -1,0 +1,80 @@
+"""N>1 path on CPU: world_size-2 gloo processes run the same sharding + table
+broadcast + per-rank slice logic bench.py uses on RCCL; the per-rank compute is the
+oracle here (no GPU), so this checks decomposition, ordering and reassembly."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from mash_amd import shard
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_equal_area_blocks_partition_and_balance():
+    for n in (2, 3, 17, 1000, 100000):
+        for w in (1, 2, 3, 4, 8):
+            b = shard.equal_area_row_blocks(n, w)
+            assert b[0] == 0 and b[-1] == n and len(b) == w + 1
+            assert all(b[i] <= b[i + 1] for i in range(w))
+            pairs = [shard.tri_pairs(b[i], b[i + 1]) for i in range(w)]
+            assert sum(pairs) == n * (n - 1) // 2
+            if n >= 1000:
+                assert max(pairs) - min(pairs) <= 2 * n        # within ~two rows of each other
+    assert shard.even_blocks(10, 4) == [0, 3, 6, 8, 10]
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from mash_amd import synth
+    from oracle import pyoracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, s = 120, 200
+    if rank == 0:
+        table, nhash, lengths = synth.clustered_sketches(n, s, clusters=4, seed=2, pool=300, private=80)
+        tt = torch.from_numpy(table.view(np.int64))
+        tn = torch.from_numpy(nhash.astype(np.int32))
+    else:
+        tt = torch.empty((n, s), dtype=torch.int64)
+        tn = torch.empty(n, dtype=torch.int32)
+    dist.broadcast(tt, 0)          # the one exchange step (RCCL broadcast over xGMI on the GPU box)
+    dist.broadcast(tn, 0)
+    table = tt.numpy().view(np.uint64)
+    nhash = tn.numpy().astype(np.uint32)
+    b = shard.equal_area_row_blocks(n, world)
+    orc = pyoracle.Oracle()
+    numer, denom, _, _ = orc.triangle(table, nhash, np.ones(n, np.uint64), b[rank], b[rank + 1], 21, 4.0 ** 21)
+    dist.barrier()
+    q.put((rank, b[rank], b[rank + 1], numer, denom))
+    dist.destroy_process_group()
+
+
+def test_two_rank_triangle_reassembles(oracle):
+    import torch.multiprocessing as mp
+    from mash_amd import synth
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n, sk = 120, 200
+    table, nhash, lengths = synth.clustered_sketches(n, sk, clusters=4, seed=2, pool=300, private=80)
+    numer, denom, _, _ = oracle.triangle(table, nhash, np.ones(n, np.uint64), 0, n, 21, 4.0 ** 21)
+    got_n = np.concatenate([r[3] for r in res])
+    got_d = np.concatenate([r[4] for r in res])
+    assert res[0][1] == 0 and res[0][2] == res[1][1] and res[1][2] == n
+    assert np.array_equal(got_n, numer) and np.array_equal(got_d, denom)
