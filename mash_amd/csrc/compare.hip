@@ -25,135 +25,276 @@
 
 namespace mg {
 
-constexpr int CMP_NT = 1024;
-constexpr int CMP_NW = CMP_NT / 64;
 constexpr int CMP_NB = 1024;                 // directory buckets per row
 constexpr int CMP_DIR = CMP_NB + 4;          // entries incl. dir[NB] = n, padded to 8 B
+constexpr int CMP_W = 4;                     // probe window: elements read per probe
 constexpr uint64_t HMAX = 0xFFFFFFFFFFFFFFFFULL;
 
-struct RowMeta { uint32_t n; uint32_t shift; };
+// Row image in LDS.  Every value v of the tile's rows is split at a tile-wide bit
+// position `shr` (chosen so the largest row value has a 32-bit prefix):
+//     hi[p] = v >> shr   (32-bit prefix, non-decreasing in p)   lo[p] = (uint32) v
+// Probes compare 32-bit prefixes only (full-rate VALU, 4-byte LDS reads); a probe whose
+// prefix TIES with a stored prefix — every true match, and ~1e-7 of the others — is
+// resolved exactly in a slow path on the reassembled 64-bit values.
+// dir[bucket] = lower bound of the bucket, bucket = mulhi(prefix, scale_row) spreads
+// the row's own values evenly over the NB buckets (~1 element per bucket at s = 1000).
+struct RowMeta {
+    uint32_t n;          // valid entries
+    uint32_t xmax;       // prefix of the row's largest value; larger prefixes -> bucket NB
+    uint32_t scale;      // floor(NB * 2^32 / (xmax + 1)), clamped to 2^32 - 1
+    uint32_t _pad;
+};
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63; }
 
-// LDS bytes per row: (s + 1) values (one sentinel) + directory
+__device__ __forceinline__ uint32_t prefix_of(uint64_t v, uint32_t shr)
+{
+    const uint64_t t = v >> shr;
+    return (t >> 32) != 0 ? 0xFFFFFFFFu : (uint32_t)t;      // saturate (only for v beyond the tile's range)
+}
+
+__device__ __forceinline__ uint32_t row_bucket(uint32_t x, const RowMeta &m)
+{
+    const uint32_t bk = __umulhi(x, m.scale);
+    return x > m.xmax ? (uint32_t)CMP_NB : bk;
+}
+
+// LDS bytes per row: (s + 1 + W) x {hi, lo}, then the directory
 __host__ __device__ inline size_t row_lds_bytes(uint32_t s)
 {
-    return (size_t)(s + 1) * 8 + (size_t)CMP_DIR * 2;
+    return (size_t)(s + 1 + CMP_W) * 8 + (size_t)CMP_DIR * 2;
 }
+
+constexpr size_t CMP_HDR = 64 * sizeof(RowMeta) + 64 * 8 + 16;     // meta, row maxima, shr
 
 bool compare_tiled_supported(uint32_t s) { return s >= 1 && s <= 1024; }
 
 uint32_t compare_rows_per_tile(uint32_t s)
 {
-    const size_t budget = 160 * 1024 - 64 * sizeof(RowMeta) - 64;
+    const size_t budget = 160 * 1024 - CMP_HDR;
     size_t r = budget / row_lds_bytes(s);
-    if (r > 64) r = 64;
     if (r > 16) r = 16;                      // more rows than waves buys nothing at s ~ 1000
     return (uint32_t)r;
 }
 
-template <int KITER>
-__global__ __launch_bounds__(CMP_NT) void compare_tiled_kernel(CompareArgs a)
+template <int NT, int KU>
+__global__ __launch_bounds__(NT) void compare_tiled_kernel(CompareArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t s = a.s;
     const uint32_t R = a.rows_per_tile;
     const size_t rbytes = row_lds_bytes(s);
+    const uint32_t cnt_ent = s + 1 + CMP_W;                              // entries per hi/lo array
     RowMeta *meta = reinterpret_cast<RowMeta *>(smem);                    // [64]
-    unsigned char *rows = smem + 64 * sizeof(RowMeta);
+    uint64_t *rowmax = reinterpret_cast<uint64_t *>(smem + 64 * sizeof(RowMeta));   // [64]
+    unsigned char *rows = smem + CMP_HDR;
 
     const CompareTile tile = a.tiles[blockIdx.x];
     const int tid = threadIdx.x;
     const uint32_t lane = lane_id();
     const uint32_t wid = tid >> 6;
+    constexpr uint32_t NW = NT / 64;
 
-    // ---- stage R rows into LDS: values (+sentinels), then the bucket directory ----
-    for (uint32_t r = 0; r < R; r++) {
-        const uint64_t i = (uint64_t)tile.row0 + r;
-        uint64_t *vals = reinterpret_cast<uint64_t *>(rows + r * rbytes);
+    // ---- stage R rows into LDS ----
+    if (tid < (int)R) {
+        const uint64_t i = (uint64_t)tile.row0 + tid;
         uint32_t n = 0;
         if (i < a.row_end) {
             n = a.row_nhash[i];
             if (n > s) n = s;
         }
+        meta[tid].n = n;
+        rowmax[tid] = n > 0 ? a.row_hashes[i * a.row_stride + n - 1] : 0;
+    }
+    __syncthreads();
+    uint64_t tmax = 1;
+    for (uint32_t r = 0; r < R; r++) tmax |= rowmax[r];
+    const int tbl = 64 - __clzll((unsigned long long)tmax);               // bit length of the tile's values
+    const uint32_t shr = tbl > 32 ? (uint32_t)(tbl - 32) : 0u;
+    const uint64_t lomask = (1ULL << shr) - 1ULL;                         // shr <= 32
+    for (uint32_t r = 0; r < R; r++) {
+        const uint64_t i = (uint64_t)tile.row0 + r;
+        uint32_t *hi = reinterpret_cast<uint32_t *>(rows + r * rbytes);
+        uint32_t *lo = hi + cnt_ent;
+        const uint32_t n = meta[r].n;
         const uint64_t *src = a.row_hashes + i * a.row_stride;
-        for (uint32_t p = tid; p <= s; p += CMP_NT) vals[p] = (p < n) ? src[p] : HMAX;
+        for (uint32_t p = tid; p < cnt_ent; p += NT) {
+            const uint64_t v = (p < n) ? src[p] : HMAX;
+            hi[p] = (p < n) ? (uint32_t)(v >> shr) : 0xFFFFFFFFu;
+            lo[p] = (uint32_t)v;
+        }
         if (tid == 0) {
-            uint32_t sh = 0;
-            if (n > 0) {
-                const uint64_t mx = src[n - 1];
-                const int bits = 64 - __clzll((unsigned long long)(mx | 1ULL));
-                sh = bits > 10 ? (uint32_t)(bits - 10) : 0u;
-            }
-            meta[r].n = n;
-            meta[r].shift = sh;
+            const uint32_t xmax = (uint32_t)(rowmax[r] >> shr);
+            const uint64_t sc = ((uint64_t)CMP_NB << 32) / ((uint64_t)xmax + 1ULL);
+            meta[r].xmax = xmax;
+            meta[r].scale = sc > 0xFFFFFFFFULL ? 0xFFFFFFFFu : (uint32_t)sc;
         }
     }
     __syncthreads();
     for (uint32_t r = 0; r < R; r++) {
-        const uint64_t *vals = reinterpret_cast<const uint64_t *>(rows + r * rbytes);
-        uint16_t *dir = reinterpret_cast<uint16_t *>(rows + r * rbytes + (size_t)(s + 1) * 8);
-        const uint32_t n = meta[r].n, sh = meta[r].shift;
-        for (uint32_t p = tid; p <= n; p += CMP_NT) {
+        const uint32_t *hi = reinterpret_cast<const uint32_t *>(rows + r * rbytes);
+        uint16_t *dir = reinterpret_cast<uint16_t *>(rows + r * rbytes + (size_t)cnt_ent * 8);
+        const RowMeta m = meta[r];
+        const uint32_t n = m.n;
+        for (uint32_t p = tid; p <= n; p += NT) {
             // element p opens buckets (bucket(p-1), bucket(p)]; p == n closes the tail
-            const uint32_t lo = (p == 0) ? 0u : (uint32_t)(vals[p - 1] >> sh) + 1u;
-            const uint32_t hi = (p == n) ? (uint32_t)CMP_NB : (uint32_t)(vals[p] >> sh);
-            for (uint32_t b = lo; b <= hi && b <= (uint32_t)CMP_NB; b++) dir[b] = (uint16_t)p;
+            const uint32_t lob = (p == 0) ? 0u : row_bucket(hi[p - 1], m) + 1u;
+            const uint32_t hib = (p == n) ? (uint32_t)CMP_NB : row_bucket(hi[p], m);
+            for (uint32_t b = lob; b <= hib && b <= (uint32_t)CMP_NB; b++) dir[b] = (uint16_t)p;
         }
     }
     __syncthreads();
 
-    // ---- stream columns: wave w takes columns col0 + w, col0 + w + 16, ... ----
-    for (uint32_t j = tile.col0 + wid; j < tile.col1; j += CMP_NW) {
+    // ---- stream columns: wave w takes columns col0 + w, col0 + w + NW, ... ----
+    // A column is consumed in groups of KU*64 elements (KU probes in flight per lane);
+    // per-row running state lives in lane r of two VGPRs so only one group of the
+    // column is register-resident, and rows that hit rank >= s drop out of later
+    // groups (unrelated pairs never touch the upper half of the column).
+    for (uint32_t j = tile.col0 + wid; j < tile.col1; j += NW) {
         uint32_t nB = a.col_nhash[j];
         if (nB > s) nB = s;
         const uint64_t *bsrc = a.col_hashes + (uint64_t)j * a.col_stride;
-        uint64_t bv[KITER];
-#pragma unroll
-        for (int k = 0; k < KITER; k++) {
-            const uint32_t q = k * 64 + lane;
-            bv[k] = (q < nB) ? bsrc[q] : HMAX;
-        }
+        uint32_t valid = 0;                                              // rows to compute (bitmask, uniform)
         for (uint32_t r = 0; r < R; r++) {
             const uint64_t i = (uint64_t)tile.row0 + r;
-            if (i >= a.row_end) break;
-            if (a.triangle && (uint64_t)j >= i) continue;
-            const uint64_t *vals = reinterpret_cast<const uint64_t *>(rows + r * rbytes);
-            const uint16_t *dir = reinterpret_cast<const uint16_t *>(rows + r * rbytes + (size_t)(s + 1) * 8);
-            const uint32_t nA = meta[r].n, sh = meta[r].shift;
-            uint32_t c_all = 0, common = 0;
-            bool broke = false;
+            if (i < a.row_end && (!a.triangle || (uint64_t)j < i)) valid |= 1u << r;
+        }
+        if (valid == 0) continue;
+        uint32_t active = valid, brokem = 0;
+        uint32_t st_call = 0, st_common = 0;                             // lane r <-> row r
+        const uint32_t ngroups = (nB + 64 * KU - 1) / (64 * KU);
+        uint64_t cur[KU], nxt[KU];
 #pragma unroll
-            for (int k = 0; k < KITER; k++) {
-                if ((uint32_t)(k * 64) >= nB) break;                      // uniform
-                const uint32_t q = k * 64 + lane;
-                const uint64_t b = bv[k];
-                const uint64_t bk64 = b >> sh;
-                const uint32_t bk = bk64 > (uint64_t)CMP_NB ? (uint32_t)CMP_NB : (uint32_t)bk64;
-                uint32_t p = dir[bk];
-                uint64_t av = vals[p];
-                while (av < b) { p++; av = vals[p]; }                     // sentinel-terminated
-                const bool match = (av == b) && (q < nB) && (p < nA);
-                const uint64_t m = __ballot(match);
-                const uint32_t before = c_all + __builtin_amdgcn_mbcnt_hi(
-                    (uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-                const uint32_t rank = q + p - before;
-                if ((uint32_t)__builtin_amdgcn_readfirstlane((int)rank) >= s) { broke = true; break; }
-                const uint64_t mi = __ballot(match && rank < s);
-                common += (uint32_t)__popcll(mi);
-                c_all += (uint32_t)__popcll(m);
+        for (int u = 0; u < KU; u++) {
+            const uint32_t q = u * 64 + lane;
+            cur[u] = (q < nB) ? bsrc[q] : HMAX;
+        }
+        for (uint32_t g = 0; g < ngroups && active != 0; g++) {
+            const uint32_t q0 = g * 64 * KU;
+            if (g + 1 < ngroups) {
+#pragma unroll
+                for (int u = 0; u < KU; u++) {
+                    const uint32_t q = q0 + (KU + u) * 64 + lane;
+                    nxt[u] = (q < nB) ? bsrc[q] : HMAX;
+                }
             }
+            uint32_t x[KU];
+            bool inb[KU];
+#pragma unroll
+            for (int u = 0; u < KU; u++) {
+                x[u] = prefix_of(cur[u], shr);
+                inb[u] = q0 + u * 64 + lane < nB;
+            }
+            uint32_t todo = active;
+            while (todo != 0) {
+                const uint32_t r = (uint32_t)__builtin_ctz(todo);
+                todo &= todo - 1;
+                const uint32_t *hi = reinterpret_cast<const uint32_t *>(rows + r * rbytes);
+                const uint32_t *lo = hi + cnt_ent;
+                const uint16_t *dir = reinterpret_cast<const uint16_t *>(rows + r * rbytes + (size_t)cnt_ent * 8);
+                const RowMeta m = meta[r];
+                const uint32_t nA = m.n;
+                // KU independent probes in flight: bucket -> dir -> window of W prefixes
+                uint32_t p[KU];
+#pragma unroll
+                for (int u = 0; u < KU; u++) p[u] = dir[row_bucket(x[u], m)];
+                uint32_t h[KU][CMP_W];
+#pragma unroll
+                for (int u = 0; u < KU; u++)
+#pragma unroll
+                    for (int w = 0; w < CMP_W; w++) h[u][w] = hi[p[u] + w];
+                bool slow = false, longwalk = false;
+                bool tie[KU];
+#pragma unroll
+                for (int u = 0; u < KU; u++) {
+                    uint32_t cnt = 0;
+                    bool t = false;
+#pragma unroll
+                    for (int w = 0; w < CMP_W; w++) {
+                        cnt += h[u][w] < x[u] ? 1u : 0u;
+                        t |= h[u][w] == x[u];
+                    }
+                    p[u] += cnt;
+                    tie[u] = t;
+                    longwalk |= (cnt == (uint32_t)CMP_W) && inb[u];
+                }
+                if (__ballot(longwalk) != 0) {
+                    // some bucket holds more than W smaller prefixes: keep walking (prefix
+                    // compares only, sentinel 0xFFFFFFFF / array end terminate the walk)
+#pragma unroll
+                    for (int u = 0; u < KU; u++) {
+                        uint32_t pp = p[u];
+                        uint32_t hv = hi[pp];
+                        while (hv < x[u] && pp < cnt_ent - 1) { pp++; hv = hi[pp]; }
+                        tie[u] |= hv == x[u];
+                        p[u] = pp;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < KU; u++) slow |= tie[u] && inb[u];
+                bool broke = false;
+                if (__ballot(slow) == 0) {
+                    // fast path: no element of this group occurs in the row and every lower
+                    // bound is exact, so match counts stay put; only the exit tests remain
+                    const uint32_t c_all = (uint32_t)__builtin_amdgcn_readlane((int)st_call, (int)r);
+#pragma unroll
+                    for (int u = 0; u < KU; u++) {
+                        const uint32_t qb = q0 + u * 64;
+                        if (qb >= nB || broke) break;
+                        const uint32_t rank0 = qb + (uint32_t)__builtin_amdgcn_readfirstlane((int)p[u]) - c_all;
+                        if (rank0 >= s) { broke = true; break; }
+                        if (qb + 63 < nB) {
+                            const uint32_t rank63 = qb + 63 + (uint32_t)__builtin_amdgcn_readlane((int)p[u], 63) - c_all;
+                            if (rank63 + 1u >= s) broke = true;
+                        }
+                    }
+                } else {
+                    // exact path on reassembled 64-bit values
+                    uint32_t c_all = (uint32_t)__builtin_amdgcn_readlane((int)st_call, (int)r);
+                    uint32_t common = (uint32_t)__builtin_amdgcn_readlane((int)st_common, (int)r);
+#pragma unroll
+                    for (int u = 0; u < KU; u++) {
+                        const uint32_t qb = q0 + u * 64;
+                        if (qb >= nB || broke) break;                     // uniform
+                        const uint64_t b = cur[u];
+                        // restart from the bucket's lower bound (p[u] may have skipped ties)
+                        uint32_t pp = dir[row_bucket(x[u], m)];
+                        uint64_t av = 0;
+                        while (pp < nA) {
+                            av = ((uint64_t)hi[pp] << shr) | ((uint64_t)lo[pp] & lomask);
+                            if (av >= b) break;
+                            pp++;
+                        }
+                        const uint32_t q = qb + lane;
+                        const bool mt = inb[u] && (pp < nA) && (av == b);
+                        const uint64_t mm = __ballot(mt);
+                        const uint32_t before = c_all + __builtin_amdgcn_mbcnt_hi(
+                            (uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0));
+                        const uint32_t rank = q + pp - before;
+                        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)rank) >= s) { broke = true; break; }
+                        common += (uint32_t)__popcll(__ballot(mt && rank < s));
+                        c_all += (uint32_t)__popcll(mm);
+                        if (qb + 63 < nB && (uint32_t)__builtin_amdgcn_readlane((int)rank, 63) + 1u >= s) broke = true;
+                    }
+                    st_call = (lane == r) ? c_all : st_call;
+                    st_common = (lane == r) ? common : st_common;
+                }
+                if (broke) { active &= ~(1u << r); brokem |= 1u << r; }
+            }
+#pragma unroll
+            for (int u = 0; u < KU; u++) cur[u] = nxt[u];
+        }
+        if (lane < R && ((valid >> lane) & 1u)) {
+            const uint64_t i = (uint64_t)tile.row0 + lane;
             uint32_t denom = s;
-            if (!broke) {
-                const uint32_t uni = nA + nB - c_all;
+            if (!((brokem >> lane) & 1u)) {
+                const uint32_t uni = meta[lane].n + nB - st_call;
                 denom = uni < s ? uni : s;
             }
-            if (lane == 0) {
-                uint64_t oidx;
-                if (a.triangle) oidx = i * (i - 1) / 2 + j - a.out_base;
-                else oidx = (i - a.row_begin) * a.ncols + j;
-                a.out[oidx] = make_uint2(common, denom);
-            }
+            uint64_t oidx;
+            if (a.triangle) oidx = i * (i - 1) / 2 + j - a.out_base;
+            else oidx = (i - a.row_begin) * a.ncols + j;
+            a.out[oidx] = make_uint2(st_common, denom);
         }
     }
 }
@@ -209,27 +350,31 @@ __global__ __launch_bounds__(256) void compare_generic_kernel(CompareArgs a)
     }
 }
 
-template <int KITER>
+template <int NT, int KU>
 static hipError_t launch_tiled_k(const CompareArgs &a, uint32_t ntiles, hipStream_t stream)
 {
-    const size_t smem = 64 * sizeof(RowMeta) + (size_t)a.rows_per_tile * row_lds_bytes(a.s);
-    auto kern = compare_tiled_kernel<KITER>;
+    const size_t smem = CMP_HDR + (size_t)a.rows_per_tile * row_lds_bytes(a.s);
+    auto kern = compare_tiled_kernel<NT, KU>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(ntiles), dim3(CMP_NT), smem, stream, a);
+    hipLaunchKernelGGL(kern, dim3(ntiles), dim3(NT), smem, stream, a);
     return hipGetLastError();
 }
 
+// variant = NT*10 + KU (tuning knob MASHGPU_COMPARE_VARIANT); 0 = default
 hipError_t launch_compare_tiled(const CompareArgs &a, uint32_t ntiles, hipStream_t stream)
 {
     if (ntiles == 0) return hipSuccess;
-    const uint32_t kiter = (a.s + 63) / 64;
-    if (kiter <= 1) return launch_tiled_k<1>(a, ntiles, stream);
-    if (kiter <= 2) return launch_tiled_k<2>(a, ntiles, stream);
-    if (kiter <= 4) return launch_tiled_k<4>(a, ntiles, stream);
-    if (kiter <= 8) return launch_tiled_k<8>(a, ntiles, stream);
-    return launch_tiled_k<16>(a, ntiles, stream);
+    switch (a.unroll) {
+        case 10242: return launch_tiled_k<1024, 2>(a, ntiles, stream);
+        case 10244: return launch_tiled_k<1024, 4>(a, ntiles, stream);
+        case 5122: return launch_tiled_k<512, 2>(a, ntiles, stream);
+        case 5124: return launch_tiled_k<512, 4>(a, ntiles, stream);
+        case 5128: return launch_tiled_k<512, 8>(a, ntiles, stream);
+        default: break;
+    }
+    return launch_tiled_k<1024, 4>(a, ntiles, stream);
 }
 
 hipError_t launch_compare_generic(const CompareArgs &a, hipStream_t stream)

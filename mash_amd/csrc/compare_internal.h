@@ -24,6 +24,7 @@ struct CompareArgs {
     uint32_t s;                   // sketch size used for the comparison
     uint32_t rows_per_tile;       // R
     uint32_t triangle;            // 1: only j < i, triangular output; 0: rect
+    uint32_t unroll;              // probes in flight per wave (tuning knob; 0 = default)
 };
 
 // LDS-tiled kernel usable when s <= 1024; rows_per_tile chosen by compare_rows_per_tile.

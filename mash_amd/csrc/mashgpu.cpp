@@ -413,6 +413,8 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
     a.s = (uint32_t)s64;
     a.triangle = triangle ? 1 : 0;
     a.rows_per_tile = 0;
+    a.unroll = 0;
+    if (const char *e = getenv("MASHGPU_COMPARE_VARIANT")) a.unroll = (uint32_t)atoi(e);
     const char *force = getenv("MASHGPU_COMPARE_KERNEL");
     const bool want_generic = force && strcmp(force, "generic") == 0;
     if (!mg::compare_tiled_supported(a.s) || want_generic) {

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""A/B sweep of compare-kernel variants in ONE process (interleaved rounds).
+usage: tools/sweep_compare.py [--n 30000] [--rounds 3] variant[:ROWS[:COLS]] ..."""
+import argparse, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=30000)
+    ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--mode", default="clustered")
+    ap.add_argument("variants", nargs="*", default=["0"])
+    a = ap.parse_args()
+    import torch
+    from mash_amd import abi, synth_torch
+    dev = torch.device("cuda", 0)
+    eng = abi.MashGpu(0)
+    n = a.n
+    hashes, nhash, lengths = synth_torch.clustered_sketch_table(n, 1000, clusters=max(1, n // 100), device=dev)
+    if a.mode == "identical":
+        hashes[:] = hashes[0]
+    table = eng.table_wrap(hashes.data_ptr(), nhash.data_ptr(), lengths.data_ptr(), n, 1000)
+    pairs = n * (n - 1) // 2
+    out = torch.empty((pairs, 2), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ref_sum = None
+    res = {v: [] for v in a.variants}
+    for rd in range(a.rounds + 1):
+        for v in a.variants:
+            parts = v.split(":")
+            os.environ["MASHGPU_COMPARE_VARIANT"] = parts[0]
+            for key, idx in (("MASHGPU_COMPARE_ROWS", 1), ("MASHGPU_COMPARE_COLS", 2)):
+                if len(parts) > idx and parts[idx]:
+                    os.environ[key] = parts[idx]
+                else:
+                    os.environ.pop(key, None)
+            out.zero_()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            eng.compare_tri_dev(table, 0, n, out.data_ptr())
+            eng.synchronize()
+            dt = time.perf_counter() - t0
+            chk = (int(out[:, 0].to(torch.int64).sum().item()), int(out[:, 1].to(torch.int64).sum().item()))
+            if ref_sum is None:
+                ref_sum = chk
+            assert chk == ref_sum, (v, chk, ref_sum)
+            if rd > 0:
+                res[v].append(pairs / dt)
+    for v in a.variants:
+        r = res[v]
+        print(f"variant {v:16s} median {np.median(r)/1e6:9.1f} Mpairs/s  min {min(r)/1e6:9.1f}  max {max(r)/1e6:9.1f}")
+    print("checksum", ref_sum)
+
+if __name__ == "__main__":
+    main()
