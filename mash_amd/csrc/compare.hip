@@ -10,14 +10,17 @@
 // is < s.  Ranks grow with q, so the scan over B stops at the first rank >= s (the
 // reference's `denom < sketchSize` exit) — unrelated sketches cost about half a scan.
 //
-// Tiled kernel (s <= 1024): one 1024-thread workgroup owns R rows.  The rows live in
-// LDS as sorted arrays + a 1024-bucket directory (bucket = value >> shift_row, the
-// sorted array doubles as its own hash table: dir[bucket] is the lower bound of the
-// bucket, a probe walks ~1-2 elements).  Each of the 16 waves streams whole columns
-// from HBM/L2 straight into registers (lane l holds B[64k + l], fully coalesced 512-B
-// loads) and probes every row: 64 lanes = 64 consecutive ranks per step, matches are
-// ranked with one ballot + mbcnt.  All integer work: no MFMA; the limiters are LDS
-// reads and VALU issue.  Algorithmic traffic: 2*s*8 + 8 B per pair.
+// Tiled kernel (s <= 1024): one 1024-thread workgroup owns R (=16 at s=1000) rows.  The
+// rows live in LDS as sorted arrays split into a 32-bit prefix and the low 32 bits, plus
+// a 1024-bucket directory (the sorted array doubles as its own hash table: dir[bucket]
+// is the lower bound of the bucket; a probe reads a window of 4 prefixes).  Each of the
+// 16 waves streams whole columns from HBM/L2 straight into registers (lane l holds
+// B[64k + l], fully coalesced 512-B loads), two 64-element blocks at a time, and probes
+// every row: 64 lanes = 64 consecutive ranks per step.  Unrelated sketches never tie on
+// a prefix, so their whole cost is the fast path: bucket, directory read, window read,
+// 4+4 compares, two scalar exit tests.  Ties (true matches) take an exact 64-bit path
+// that ranks matches with one ballot + mbcnt.  All integer work: no MFMA; the limiter
+// is VALU issue.  Algorithmic traffic: 2*s*8 + 8 B/pair.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -92,7 +95,9 @@ __global__ __launch_bounds__(NT) void compare_tiled_kernel(CompareArgs a)
     const CompareTile tile = a.tiles[blockIdx.x];
     const int tid = threadIdx.x;
     const uint32_t lane = lane_id();
-    const uint32_t wid = tid >> 6;
+    // wave index: uniform, but the compiler cannot know — tell it, so everything derived
+    // from the column index (row masks, loop control, row base addresses) stays scalar
+    const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr uint32_t NW = NT / 64;
 
     // ---- stage R rows into LDS ----
@@ -145,6 +150,9 @@ __global__ __launch_bounds__(NT) void compare_tiled_kernel(CompareArgs a)
     }
     __syncthreads();
 
+    // row meta of row `lane` stays in this lane's registers: the probe loop fetches it
+    // with v_readlane (scalar operands, no LDS round trip in the dependent chain)
+    const RowMeta my_meta = meta[lane];
     // ---- stream columns: wave w takes columns col0 + w, col0 + w + NW, ... ----
     // A column is consumed in groups of KU*64 elements (KU probes in flight per lane);
     // per-row running state lives in lane r of two VGPRs so only one group of the
@@ -179,11 +187,12 @@ __global__ __launch_bounds__(NT) void compare_tiled_kernel(CompareArgs a)
                 }
             }
             uint32_t x[KU];
-            bool inb[KU];
+            uint64_t inbm[KU];                                           // lanes whose element exists (scalar masks)
 #pragma unroll
             for (int u = 0; u < KU; u++) {
                 x[u] = prefix_of(cur[u], shr);
-                inb[u] = q0 + u * 64 + lane < nB;
+                const uint32_t qb = q0 + u * 64;
+                inbm[u] = qb + 64 <= nB ? ~0ULL : (qb >= nB ? 0ULL : ((1ULL << (nB - qb)) - 1ULL));
             }
             uint32_t todo = active;
             while (todo != 0) {
@@ -192,7 +201,10 @@ __global__ __launch_bounds__(NT) void compare_tiled_kernel(CompareArgs a)
                 const uint32_t *hi = reinterpret_cast<const uint32_t *>(rows + r * rbytes);
                 const uint32_t *lo = hi + cnt_ent;
                 const uint16_t *dir = reinterpret_cast<const uint16_t *>(rows + r * rbytes + (size_t)cnt_ent * 8);
-                const RowMeta m = meta[r];
+                RowMeta m;
+                m.n = (uint32_t)__builtin_amdgcn_readlane((int)my_meta.n, (int)r);
+                m.xmax = (uint32_t)__builtin_amdgcn_readlane((int)my_meta.xmax, (int)r);
+                m.scale = (uint32_t)__builtin_amdgcn_readlane((int)my_meta.scale, (int)r);
                 const uint32_t nA = m.n;
                 // KU independent probes in flight: bucket -> dir -> window of W prefixes
                 uint32_t p[KU];
@@ -203,22 +215,23 @@ __global__ __launch_bounds__(NT) void compare_tiled_kernel(CompareArgs a)
                 for (int u = 0; u < KU; u++)
 #pragma unroll
                     for (int w = 0; w < CMP_W; w++) h[u][w] = hi[p[u] + w];
-                bool slow = false, longwalk = false;
-                bool tie[KU];
+                // tie / long-walk flags live in scalar lane masks (the compare results themselves)
+                uint64_t tiem = 0, longm = 0;
 #pragma unroll
                 for (int u = 0; u < KU; u++) {
+                    const uint32_t xu = x[u];
                     uint32_t cnt = 0;
-                    bool t = false;
+                    uint64_t t = 0;
 #pragma unroll
                     for (int w = 0; w < CMP_W; w++) {
-                        cnt += h[u][w] < x[u] ? 1u : 0u;
-                        t |= h[u][w] == x[u];
+                        cnt += h[u][w] < xu ? 1u : 0u;
+                        t |= __ballot(h[u][w] == xu);
                     }
                     p[u] += cnt;
-                    tie[u] = t;
-                    longwalk |= (cnt == (uint32_t)CMP_W) && inb[u];
+                    tiem |= t & inbm[u];
+                    longm |= __ballot(cnt == (uint32_t)CMP_W) & inbm[u];
                 }
-                if (__ballot(longwalk) != 0) {
+                if (longm != 0) {
                     // some bucket holds more than W smaller prefixes: keep walking (prefix
                     // compares only, sentinel 0xFFFFFFFF / array end terminate the walk)
 #pragma unroll
@@ -226,14 +239,12 @@ __global__ __launch_bounds__(NT) void compare_tiled_kernel(CompareArgs a)
                         uint32_t pp = p[u];
                         uint32_t hv = hi[pp];
                         while (hv < x[u] && pp < cnt_ent - 1) { pp++; hv = hi[pp]; }
-                        tie[u] |= hv == x[u];
+                        tiem |= __ballot(hv == x[u]) & inbm[u];
                         p[u] = pp;
                     }
                 }
-#pragma unroll
-                for (int u = 0; u < KU; u++) slow |= tie[u] && inb[u];
                 bool broke = false;
-                if (__ballot(slow) == 0) {
+                if (tiem == 0) {
                     // fast path: no element of this group occurs in the row and every lower
                     // bound is exact, so match counts stay put; only the exit tests remain
                     const uint32_t c_all = (uint32_t)__builtin_amdgcn_readlane((int)st_call, (int)r);
@@ -266,7 +277,7 @@ __global__ __launch_bounds__(NT) void compare_tiled_kernel(CompareArgs a)
                             pp++;
                         }
                         const uint32_t q = qb + lane;
-                        const bool mt = inb[u] && (pp < nA) && (av == b);
+                        const bool mt = ((inbm[u] >> lane) & 1ULL) && (pp < nA) && (av == b);
                         const uint64_t mm = __ballot(mt);
                         const uint32_t before = c_all + __builtin_amdgcn_mbcnt_hi(
                             (uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0));
@@ -288,7 +299,7 @@ __global__ __launch_bounds__(NT) void compare_tiled_kernel(CompareArgs a)
             const uint64_t i = (uint64_t)tile.row0 + lane;
             uint32_t denom = s;
             if (!((brokem >> lane) & 1u)) {
-                const uint32_t uni = meta[lane].n + nB - st_call;
+                const uint32_t uni = my_meta.n + nB - st_call;
                 denom = uni < s ? uni : s;
             }
             uint64_t oidx;
@@ -374,7 +385,7 @@ hipError_t launch_compare_tiled(const CompareArgs &a, uint32_t ntiles, hipStream
         case 5128: return launch_tiled_k<512, 8>(a, ntiles, stream);
         default: break;
     }
-    return launch_tiled_k<1024, 4>(a, ntiles, stream);
+    return launch_tiled_k<1024, 2>(a, ntiles, stream);      // best measured (profiles/r01_compare_sweep.txt)
 }
 
 hipError_t launch_compare_generic(const CompareArgs &a, hipStream_t stream)
