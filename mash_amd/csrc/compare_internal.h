@@ -31,6 +31,10 @@ struct CompareArgs {
 bool compare_tiled_supported(uint32_t s);
 uint32_t compare_rows_per_tile(uint32_t s);
 hipError_t launch_compare_tiled(const CompareArgs &a, uint32_t ntiles, hipStream_t stream);
+// Merged-rows kernel (s <= 1024): one bucketed table for all rows of a tile.
+bool compare_merged_supported(uint32_t s);
+uint32_t compare_merged_rows(uint32_t s);
+hipError_t launch_compare_merged(const CompareArgs &a, uint32_t ntiles, hipStream_t stream);
 // Generic kernel (any s): one wave per pair, binary search in global memory.
 hipError_t launch_compare_generic(const CompareArgs &a, hipStream_t stream);
 

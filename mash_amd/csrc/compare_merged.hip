@@ -1,0 +1,381 @@
+// compare_merged.hip — gfx950 pairwise comparison, "merged rows" tile kernel.
+//
+// Same contract as compare.hip (the merge loop of compareSketches,
+// CommandDistance.cpp:347-385, rank formulation described there), different tile engine:
+// ALL R rows of a tile share ONE bucketed table in LDS, so a column element is probed once
+// for the whole tile instead of once per row.
+//
+//   table : R*s entries {32-bit prefix, 16-bit tag = row<<10 | index-in-row}, grouped by
+//           bucket = mulhi(prefix, scale_tile) (CSR layout, ~1 entry per bucket);
+//   dir   : u16 per bucket = first entry of the bucket, bit 15 set when the bucket holds
+//           more than W entries.
+//
+// Every value occurring in any row of the tile sits in the bucket its prefix maps to, so
+// "b occurs in some row" <=> one of the bucket's prefixes equals b's prefix (then verified
+// on the 64-bit value in HBM/L2).  Unrelated sketches never tie, so for them a column
+// costs one probe per element for all R rows plus one rank test per row per 128
+// elements:  rank(B[q] in row r) >= s-1  <=>  A_r[s-1-q+c_r - 1] < B[q]  — a single
+// 64-bit load per row.  Matches (ties) are ranked exactly with ballot + mbcnt using the
+// index stored in the tag (it IS the lower bound of the matched value in its row).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "compare_internal.h"
+
+namespace mg {
+
+constexpr int MR_NT = 1024;
+constexpr int MR_NW = MR_NT / 64;
+constexpr int MR_W = 4;                      // window: entries read per probe
+constexpr int MR_KU = 2;                     // 64-element blocks of a column in flight
+constexpr uint32_t MR_OVF = 0x8000u;         // dir flag: bucket has more than MR_W entries
+constexpr uint64_t HMAX64 = 0xFFFFFFFFFFFFFFFFULL;
+
+struct MergedHdr {
+    uint32_t shr;        // prefix = value >> shr (tile-wide)
+    uint32_t scale;      // bucket = mulhi(prefix, scale)
+    uint32_t xmax;       // largest prefix present in the tile
+    uint32_t nent;       // total entries E
+    uint32_t row_n[32];
+    uint32_t row_base[32];   // first entry id of row r in (row, index) enumeration order
+};
+
+__host__ __device__ inline uint32_t merged_buckets(uint32_t R, uint32_t s)
+{
+    uint32_t nb = 1024;
+    while (nb < R * s) nb <<= 1;
+    return nb;
+}
+
+__host__ __device__ inline size_t merged_lds_bytes(uint32_t R, uint32_t s)
+{
+    const size_t ecap = (size_t)R * s + MR_W;
+    const size_t nb = merged_buckets(R, s);
+    return 512 + (nb + 8) * 2 + ((ecap * 4 + 15) & ~(size_t)15) + ((ecap * 2 + 15) & ~(size_t)15);
+}
+
+bool compare_merged_supported(uint32_t s) { return s >= 1 && s <= 1024; }
+
+uint32_t compare_merged_rows(uint32_t s)
+{
+    uint32_t r = 16;
+    while (r > 1 && merged_lds_bytes(r, s) > 160 * 1024) r--;
+    return r;
+}
+
+__device__ __forceinline__ uint32_t mr_prefix(uint64_t v, uint32_t shr)
+{
+    const uint64_t t = v >> shr;
+    return (t >> 32) != 0 ? 0xFFFFFFFFu : (uint32_t)t;
+}
+
+__global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t s = a.s;
+    const uint32_t R = a.rows_per_tile;
+    const uint32_t NB = merged_buckets(R, s);
+    const uint32_t ecap = R * s + MR_W;
+    MergedHdr *hdr = reinterpret_cast<MergedHdr *>(smem);
+    uint16_t *dir = reinterpret_cast<uint16_t *>(smem + 512);                       // [NB + 8]
+    uint32_t *cnt32 = reinterpret_cast<uint32_t *>(dir);                            // build-time view
+    uint32_t *pfx = reinterpret_cast<uint32_t *>(smem + 512 + (size_t)(NB + 8) * 2);   // [ecap]
+    uint16_t *tag = reinterpret_cast<uint16_t *>(reinterpret_cast<unsigned char *>(pfx) + (((size_t)ecap * 4 + 15) & ~(size_t)15));
+    __shared__ uint32_t s_wsum[MR_NW + 2];
+    __shared__ uint64_t s_rowmax[32];
+
+    const CompareTile tile = a.tiles[blockIdx.x];
+    const int tid = threadIdx.x;
+    const uint32_t lane = tid & 63;
+    const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ------------------------------------------------------------------ build the tile table
+    if (tid < 32) {
+        uint32_t n = 0;
+        uint64_t mx = 0;
+        if ((uint32_t)tid < R) {
+            const uint64_t i = (uint64_t)tile.row0 + tid;
+            if (i < a.row_end) {
+                n = a.row_nhash[i];
+                if (n > s) n = s;
+                if (n > 0) mx = a.row_hashes[i * a.row_stride + n - 1];
+            }
+        }
+        hdr->row_n[tid] = n;
+        s_rowmax[tid] = mx;
+    }
+    for (uint32_t b = tid; b < (NB + 8) / 2; b += MR_NT) cnt32[b] = 0;
+    __syncthreads();
+    if (tid == 0) {
+        uint64_t tmax = 1;
+        uint32_t e = 0;
+        for (uint32_t r = 0; r < 32; r++) {
+            tmax |= s_rowmax[r];
+            hdr->row_base[r] = e;
+            e += hdr->row_n[r];
+        }
+        uint64_t mxall = 0;
+        for (uint32_t r = 0; r < 32; r++) mxall = s_rowmax[r] > mxall ? s_rowmax[r] : mxall;
+        const int tbl = 64 - __clzll((unsigned long long)tmax);
+        const uint32_t shr = tbl > 32 ? (uint32_t)(tbl - 32) : 0u;
+        const uint32_t xmax = (uint32_t)(mxall >> shr);
+        const uint64_t sc = ((uint64_t)NB << 32) / ((uint64_t)xmax + 1ULL);
+        hdr->shr = shr;
+        hdr->xmax = xmax;
+        hdr->scale = sc > 0xFFFFFFFFULL ? 0xFFFFFFFFu : (uint32_t)sc;
+        hdr->nent = e;
+    }
+    __syncthreads();
+    const uint32_t shr = hdr->shr, scale = hdr->scale, xmax = hdr->xmax, E = hdr->nent;
+
+    // pass 1: bucket histogram; thread `tid` owns element index tid of every row (s <= 1024 = NT)
+    constexpr int EPT = 16;                  // rows per tile <= 16
+    uint32_t e_pfx[EPT], e_bs[EPT];          // prefix; bucket | slot << 16, kept in registers
+#pragma unroll
+    for (int t = 0; t < EPT; t++) {
+        e_bs[t] = 0xFFFFFFFFu;
+        e_pfx[t] = 0;
+        if ((uint32_t)t < R && (uint32_t)tid < hdr->row_n[t]) {
+            const uint64_t v = a.row_hashes[((uint64_t)tile.row0 + t) * a.row_stride + tid];
+            const uint32_t x = (uint32_t)(v >> shr);
+            const uint32_t bk = __umulhi(x, scale);
+            const uint32_t old = atomicAdd(&cnt32[bk >> 1], (bk & 1u) ? 0x10000u : 1u);
+            const uint32_t slot = (bk & 1u) ? (old >> 16) : (old & 0xFFFFu);
+            e_pfx[t] = x;
+            e_bs[t] = bk | (slot << 16);             // bk < 16384
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the u16 counters -> dir (bit 15: bucket larger than the probe window)
+    {
+        const uint32_t per = (NB + MR_NT - 1) / MR_NT;                 // buckets per thread (16)
+        const uint32_t b0 = tid * per;
+        uint32_t sum = 0;
+        for (uint32_t b = b0; b < b0 + per && b < NB; b++) sum += dir[b];
+        // block exclusive scan of `sum`
+        uint32_t inc = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(inc, d);
+            if (lane >= (uint32_t)d) inc += t;
+        }
+        if (lane == 63) s_wsum[wid] = inc;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (uint32_t w = 0; w < wid; w++) woff += s_wsum[w];
+        uint32_t run = woff + inc - sum;
+        for (uint32_t b = b0; b < b0 + per && b < NB; b++) {
+            const uint32_t c = dir[b];
+            dir[b] = (uint16_t)(run | (c > (uint32_t)MR_W ? MR_OVF : 0u));
+            run += c;
+        }
+        if (tid == MR_NT - 1) {
+            for (uint32_t b = NB; b < NB + 8; b++) dir[b] = (uint16_t)E;
+        }
+    }
+    __syncthreads();
+    // pass 2: scatter
+#pragma unroll
+    for (int t = 0; t < EPT; t++) {
+        if (e_bs[t] != 0xFFFFFFFFu) {
+            const uint32_t bk = e_bs[t] & 0xFFFFu, slot = e_bs[t] >> 16;
+            const uint32_t pos = (dir[bk] & 0x7FFFu) + slot;
+            pfx[pos] = e_pfx[t];
+            tag[pos] = (uint16_t)(((uint32_t)t << 10) | (uint32_t)tid);
+        }
+    }
+    if (tid < MR_W) { pfx[E + tid] = 0xFFFFFFFFu; tag[E + tid] = 0xFFFFu; }
+    __syncthreads();
+
+    // ------------------------------------------------------------------ stream columns
+    const uint32_t my_n = lane < 32 ? hdr->row_n[lane] : 0;                // row `lane`
+    const uint64_t *my_row = a.row_hashes + ((uint64_t)tile.row0 + (lane < R ? lane : 0)) * a.row_stride;
+
+    for (uint32_t j = tile.col0 + wid; j < tile.col1; j += MR_NW) {
+        uint32_t nB = a.col_nhash[j];
+        if (nB > s) nB = s;
+        const uint64_t *bsrc = a.col_hashes + (uint64_t)j * a.col_stride;
+        uint32_t valid = 0;
+        for (uint32_t r = 0; r < R; r++) {
+            const uint64_t i = (uint64_t)tile.row0 + r;
+            if (i < a.row_end && (!a.triangle || (uint64_t)j < i)) valid |= 1u << r;
+        }
+        if (valid == 0) continue;
+        uint32_t active = valid, brokem = 0;
+        uint32_t st_call = 0, st_common = 0;                             // lane r <-> row r
+        const uint32_t ngroups = (nB + 64 * MR_KU - 1) / (64 * MR_KU);
+        uint64_t cur[MR_KU], nxt[MR_KU];
+#pragma unroll
+        for (int u = 0; u < MR_KU; u++) {
+            const uint32_t q = u * 64 + lane;
+            cur[u] = (q < nB) ? bsrc[q] : HMAX64;
+        }
+        for (uint32_t g = 0; g < ngroups && active != 0; g++) {
+            const uint32_t q0 = g * 64 * MR_KU;
+            const bool col_end = q0 + 64 * MR_KU >= nB;
+            if (!col_end) {
+#pragma unroll
+                for (int u = 0; u < MR_KU; u++) {
+                    const uint32_t q = q0 + (MR_KU + u) * 64 + lane;
+                    nxt[u] = (q < nB) ? bsrc[q] : HMAX64;
+                }
+            }
+            // rank test operand of row `lane`, prefetched: A_r[t-1] with t = s-1-qlast+c_r
+            const uint32_t qlast = q0 + 64 * MR_KU - 1;
+            int32_t t_chk = (int32_t)s - 1 - (int32_t)qlast + (int32_t)st_call;
+            uint64_t a_chk = 0;
+            const bool chk_rd = !col_end && lane < R && t_chk >= 1 && (uint32_t)t_chk <= my_n;
+            if (chk_rd) a_chk = my_row[t_chk - 1];
+
+            // ---- one probe per element for ALL rows of the tile ----
+            uint32_t x[MR_KU], s0[MR_KU], h[MR_KU][MR_W];
+            uint64_t inbm[MR_KU], tiem[MR_KU];
+            uint64_t anytie = 0;
+#pragma unroll
+            for (int u = 0; u < MR_KU; u++) {
+                const uint32_t qb = q0 + u * 64;
+                inbm[u] = qb + 64 <= nB ? ~0ULL : (qb >= nB ? 0ULL : ((1ULL << (nB - qb)) - 1ULL));
+                x[u] = mr_prefix(cur[u], shr);
+                const uint32_t bk = __umulhi(x[u], scale);
+                s0[u] = dir[x[u] > xmax ? NB : bk];
+            }
+#pragma unroll
+            for (int u = 0; u < MR_KU; u++)
+#pragma unroll
+                for (int w = 0; w < MR_W; w++) h[u][w] = pfx[(s0[u] & 0x7FFFu) + w];
+#pragma unroll
+            for (int u = 0; u < MR_KU; u++) {
+                uint64_t t = __ballot((s0[u] & MR_OVF) != 0);            // oversize bucket: inspect it fully
+#pragma unroll
+                for (int w = 0; w < MR_W; w++) t |= __ballot(h[u][w] == x[u]);
+                tiem[u] = t & inbm[u] & __ballot(x[u] <= xmax);
+                anytie |= tiem[u];
+            }
+
+            bool c_changed = false;
+            if (anytie != 0) {
+                // ---- exact path: which rows contain which elements, ranked in column order ----
+#pragma unroll
+                for (int u = 0; u < MR_KU; u++) {
+                    if (tiem[u] == 0) continue;                          // uniform
+                    const uint32_t qb = q0 + u * 64;
+                    const uint64_t b = cur[u];
+                    const bool mine = (tiem[u] >> lane) & 1ULL;
+                    // scan my bucket: rows whose value equals b (verified on 64 bits), remember
+                    // the index (= lower bound of b in that row) of up to the first 4 hits in regs
+                    uint32_t rowmask = 0;
+                    uint32_t hit_tag[MR_W];
+#pragma unroll
+                    for (int w = 0; w < MR_W; w++) hit_tag[w] = 0xFFFFFFFFu;
+                    uint32_t extra_lo = 0, extra_hi = 0;                 // entries beyond the window (oversize bucket)
+                    if (mine) {
+                        const uint32_t st = s0[u] & 0x7FFFu;
+#pragma unroll
+                        for (int w = 0; w < MR_W; w++) {
+                            if (h[u][w] == x[u] && st + w < E) {
+                                const uint32_t tg = tag[st + w];
+                                const uint32_t r = tg >> 10, idx = tg & 1023u;
+                                const uint64_t v = a.row_hashes[((uint64_t)tile.row0 + r) * a.row_stride + idx];
+                                if (v == b) { rowmask |= 1u << r; hit_tag[w] = tg; }
+                            }
+                        }
+                        if (s0[u] & MR_OVF) {
+                            const uint32_t bk = __umulhi(x[u], scale);
+                            extra_lo = st + MR_W;
+                            extra_hi = dir[bk + 1] & 0x7FFFu;
+                            for (uint32_t e = extra_lo; e < extra_hi; e++) {
+                                if (pfx[e] == x[u]) {
+                                    const uint32_t tg = tag[e];
+                                    const uint32_t r = tg >> 10, idx = tg & 1023u;
+                                    const uint64_t v = a.row_hashes[((uint64_t)tile.row0 + r) * a.row_stride + idx];
+                                    if (v == b) rowmask |= 1u << r;
+                                }
+                            }
+                        }
+                    }
+                    // rows involved anywhere in this block
+                    uint32_t rows_any = 0;
+                    for (uint32_t r = 0; r < R; r++)
+                        if (__ballot((rowmask >> r) & 1u) != 0) rows_any |= 1u << r;
+                    rows_any &= active;
+                    while (rows_any != 0) {
+                        const uint32_t r = (uint32_t)__builtin_ctz(rows_any);
+                        rows_any &= rows_any - 1;
+                        const bool mt = (rowmask >> r) & 1u;
+                        // index of b in row r
+                        uint32_t idx = 0;
+                        bool have = false;
+#pragma unroll
+                        for (int w = 0; w < MR_W; w++) {
+                            if (hit_tag[w] != 0xFFFFFFFFu && (hit_tag[w] >> 10) == r) { idx = hit_tag[w] & 1023u; have = true; }
+                        }
+                        if (mt && !have) {
+                            // hit came from beyond the window of an oversize bucket (rare): rescan
+                            for (uint32_t e = extra_lo; e < extra_hi; e++) {
+                                const uint32_t tg = tag[e];
+                                if (pfx[e] == x[u] && (tg >> 10) == r) {
+                                    const uint64_t v = a.row_hashes[((uint64_t)tile.row0 + r) * a.row_stride + (tg & 1023u)];
+                                    if (v == b) idx = tg & 1023u;
+                                }
+                            }
+                        }
+                        uint32_t c_all = (uint32_t)__builtin_amdgcn_readlane((int)st_call, (int)r);
+                        uint32_t common = (uint32_t)__builtin_amdgcn_readlane((int)st_common, (int)r);
+                        const uint64_t mm = __ballot(mt);
+                        const uint32_t before = c_all + __builtin_amdgcn_mbcnt_hi(
+                            (uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0));
+                        const uint32_t rank = qb + lane + idx - before;
+                        common += (uint32_t)__popcll(__ballot(mt && rank < s));
+                        c_all += (uint32_t)__popcll(mm);
+                        st_call = (lane == r) ? c_all : st_call;
+                        st_common = (lane == r) ? common : st_common;
+                        c_changed = true;
+                    }
+                }
+            }
+
+            // ---- rank test per row: has the union reached s elements at the group's last element?
+            if (!col_end) {
+                if (c_changed) {                                         // uniform; counts moved: re-read operand
+                    t_chk = (int32_t)s - 1 - (int32_t)qlast + (int32_t)st_call;
+                    a_chk = 0;
+                    if (lane < R && t_chk >= 1 && (uint32_t)t_chk <= my_n) a_chk = my_row[t_chk - 1];
+                }
+                const uint64_t blast = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cur[MR_KU - 1] >> 32), 63) << 32) |
+                                       (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cur[MR_KU - 1], 63);
+                const bool done = lane < R && (t_chk <= 0 || ((uint32_t)t_chk <= my_n && a_chk < blast));
+                const uint32_t dm = (uint32_t)__ballot(done) & active;
+                active &= ~dm;
+                brokem |= dm;
+#pragma unroll
+                for (int u = 0; u < MR_KU; u++) cur[u] = nxt[u];
+            }
+        }
+        if (lane < R && ((valid >> lane) & 1u)) {
+            const uint64_t i = (uint64_t)tile.row0 + lane;
+            uint32_t denom = s;
+            if (!((brokem >> lane) & 1u)) {
+                const uint32_t uni = my_n + nB - st_call;
+                denom = uni < s ? uni : s;
+            }
+            uint64_t oidx;
+            if (a.triangle) oidx = i * (i - 1) / 2 + j - a.out_base;
+            else oidx = (i - a.row_begin) * a.ncols + j;
+            a.out[oidx] = make_uint2(st_common, denom);
+        }
+    }
+}
+
+hipError_t launch_compare_merged(const CompareArgs &a, uint32_t ntiles, hipStream_t stream)
+{
+    if (ntiles == 0) return hipSuccess;
+    const size_t smem = merged_lds_bytes(a.rows_per_tile, a.s);
+    auto kern = compare_merged_kernel;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(ntiles), dim3(MR_NT), smem, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace mg

@@ -417,15 +417,17 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
     if (const char *e = getenv("MASHGPU_COMPARE_VARIANT")) a.unroll = (uint32_t)atoi(e);
     const char *force = getenv("MASHGPU_COMPARE_KERNEL");
     const bool want_generic = force && strcmp(force, "generic") == 0;
+    const bool want_tiled = force && strcmp(force, "tiled") == 0;
+    const bool use_merged = !want_tiled && mg::compare_merged_supported(a.s) && a.s * 16u <= 16384u;
     if (!mg::compare_tiled_supported(a.s) || want_generic) {
         prof_begin(ctx, ctx->prof_compare);
         HIP_TRY(ctx, mg::launch_compare_generic(a, ctx->stream));
         prof_end(ctx, ctx->prof_compare);
         return MG_OK;
     }
-    uint32_t R = mg::compare_rows_per_tile(a.s);
+    uint32_t R = use_merged ? mg::compare_merged_rows(a.s) : mg::compare_rows_per_tile(a.s);
     if (const char *e = getenv("MASHGPU_COMPARE_ROWS")) { uint32_t v = (uint32_t)atoi(e); if (v >= 1 && v < R) R = v; }
-    uint64_t CC = 1024;
+    uint64_t CC = use_merged ? 4096 : 1024;
     if (const char *e = getenv("MASHGPU_COMPARE_COLS")) { uint64_t v = strtoull(e, nullptr, 10); if (v >= 16) CC = v; }
     a.rows_per_tile = R;
     // tiles: column chunk outer, row tile inner (concurrent workgroups share a column chunk in L2)
@@ -453,7 +455,8 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
     if (e == hipSuccess) {
         a.tiles = d_tiles;
         prof_begin(ctx, ctx->prof_compare);
-        e = mg::launch_compare_tiled(a, (uint32_t)tiles.size(), ctx->stream);
+        e = use_merged ? mg::launch_compare_merged(a, (uint32_t)tiles.size(), ctx->stream)
+                       : mg::launch_compare_tiled(a, (uint32_t)tiles.size(), ctx->stream);
         prof_end(ctx, ctx->prof_compare);
     }
     // the tile list must outlive the launch

@@ -30,7 +30,12 @@ def main():
     for rd in range(a.rounds + 1):
         for v in a.variants:
             parts = v.split(":")
-            os.environ["MASHGPU_COMPARE_VARIANT"] = parts[0]
+            if parts[0] in ("merged", "tiled", "generic"):
+                os.environ["MASHGPU_COMPARE_KERNEL"] = parts[0]
+                os.environ.pop("MASHGPU_COMPARE_VARIANT", None)
+            else:
+                os.environ.pop("MASHGPU_COMPARE_KERNEL", None)
+                os.environ["MASHGPU_COMPARE_VARIANT"] = parts[0]
             for key, idx in (("MASHGPU_COMPARE_ROWS", 1), ("MASHGPU_COMPARE_COLS", 2)):
                 if len(parts) > idx and parts[idx]:
                     os.environ[key] = parts[idx]
