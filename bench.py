@@ -190,7 +190,7 @@ def main():
             traffic = None
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": "compare_tiled_kernel<1024,2>", "kernel_ms": round(kern_ms, 3), "launches": launches,
+                "kernel": "compare_merged_kernel", "kernel_ms": round(kern_ms, 3), "launches": launches,
                 "algorithmic_bytes_per_pair": bytes_per_pair,
                 "note": "no-reuse streaming model (SURVEY.md §8d): sketches are re-used from LDS/L2, so frac may exceed 1"}
 
