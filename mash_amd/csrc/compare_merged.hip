@@ -189,43 +189,59 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
 
     // ------------------------------------------------------------------ stream columns
     const uint32_t my_n = lane < 32 ? hdr->row_n[lane] : 0;                // row `lane`
-    const uint64_t *my_row = a.row_hashes + ((uint64_t)tile.row0 + (lane < R ? lane : 0)) * a.row_stride;
+    const uint64_t *my_row = a.row_hashes + ((uint64_t)tile.row0 + (((uint64_t)tile.row0 + lane < a.row_end && lane < R) ? lane : 0)) * a.row_stride;
 
-    for (uint32_t j = tile.col0 + wid; j < tile.col1; j += MR_NW) {
-        uint32_t nB = a.col_nhash[j];
-        if (nB > s) nB = s;
-        const uint64_t *bsrc = a.col_hashes + (uint64_t)j * a.col_stride;
-        uint32_t valid = 0;
-        for (uint32_t r = 0; r < R; r++) {
-            const uint64_t i = (uint64_t)tile.row0 + r;
-            if (i < a.row_end && (!a.triangle || (uint64_t)j < i)) valid |= 1u << r;
-        }
-        if (valid == 0) continue;
-        uint32_t active = valid, brokem = 0;
-        uint32_t st_call = 0, st_common = 0;                             // lane r <-> row r
-        const uint32_t ngroups = (nB + 64 * MR_KU - 1) / (64 * MR_KU);
-        uint64_t cur[MR_KU], nxt[MR_KU];
+    // Column streaming is software-pipelined with UNCONDITIONAL loads (indices clamped into
+    // the row, which is padded to s entries) so the compiler can count vmcnt exactly:
+    //   in flight while group g is probed:  rank-test operand of g, data of group g+1,
+    //   and (issued during group 0) the first group + length of the wave's next column.
+    // VMEM returns in order, so the small L2-resident rank-test operand is always issued
+    // BEFORE the streaming loads that follow it.
+    const uint32_t qclamp = s - 1;
+    auto load_group = [&](const uint64_t *src, uint32_t qbase, uint64_t (&dst)[MR_KU]) {
 #pragma unroll
         for (int u = 0; u < MR_KU; u++) {
-            const uint32_t q = u * 64 + lane;
-            cur[u] = (q < nB) ? bsrc[q] : HMAX64;
+            const uint32_t q = qbase + u * 64 + lane;
+            dst[u] = src[q < qclamp ? q : qclamp];
+        }
+    };
+    const uint32_t rmax = (a.row_end - tile.row0) < (uint64_t)R ? (uint32_t)(a.row_end - tile.row0) : R;
+    const uint32_t rows_all = rmax >= 32 ? 0xFFFFFFFFu : ((1u << rmax) - 1u);
+    uint64_t ncol[MR_KU];
+    uint32_t nB_next = 0;
+    uint32_t j = tile.col0 + wid;
+    if (j < tile.col1) {
+        load_group(a.col_hashes + (uint64_t)j * a.col_stride, 0, ncol);
+        nB_next = a.col_nhash[j];
+    }
+    for (; j < tile.col1; j += MR_NW) {
+        uint32_t nB = nB_next < s ? nB_next : s;
+        const uint64_t *bsrc = a.col_hashes + (uint64_t)j * a.col_stride;
+        uint64_t cur[MR_KU], nxt[MR_KU];
+#pragma unroll
+        for (int u = 0; u < MR_KU; u++) cur[u] = ncol[u];
+        // rows of the tile this column is compared with (triangle: only rows i > j)
+        uint32_t valid = rows_all;
+        if (a.triangle && j >= tile.row0) {
+            const uint32_t lo = j - tile.row0 + 1;
+            valid = lo >= 32 ? 0u : (valid & ~((1u << lo) - 1u));
+        }
+        uint32_t active = valid, brokem = 0;
+        uint32_t st_call = 0, st_common = 0;                             // lane r <-> row r
+        const uint32_t ngroups = valid == 0 ? 0 : (nB + 64 * MR_KU - 1) / (64 * MR_KU);
+        // prologue: rank-test operand of group 0, data of group 1, then the next column
+        int32_t t_chk = (int32_t)s - (int32_t)(64 * MR_KU) + (int32_t)st_call;      // s-1-qlast+c, qlast = 64*KU-1
+        uint64_t a_chk = my_row[t_chk >= 1 ? ((uint32_t)t_chk - 1 < qclamp ? (uint32_t)t_chk - 1 : qclamp) : 0];
+        load_group(bsrc, 64 * MR_KU, nxt);
+        {
+            const uint32_t jn = j + MR_NW < tile.col1 ? j + MR_NW : j;
+            load_group(a.col_hashes + (uint64_t)jn * a.col_stride, 0, ncol);
+            nB_next = a.col_nhash[jn];
         }
         for (uint32_t g = 0; g < ngroups && active != 0; g++) {
             const uint32_t q0 = g * 64 * MR_KU;
             const bool col_end = q0 + 64 * MR_KU >= nB;
-            if (!col_end) {
-#pragma unroll
-                for (int u = 0; u < MR_KU; u++) {
-                    const uint32_t q = q0 + (MR_KU + u) * 64 + lane;
-                    nxt[u] = (q < nB) ? bsrc[q] : HMAX64;
-                }
-            }
-            // rank test operand of row `lane`, prefetched: A_r[t-1] with t = s-1-qlast+c_r
             const uint32_t qlast = q0 + 64 * MR_KU - 1;
-            int32_t t_chk = (int32_t)s - 1 - (int32_t)qlast + (int32_t)st_call;
-            uint64_t a_chk = 0;
-            const bool chk_rd = !col_end && lane < R && t_chk >= 1 && (uint32_t)t_chk <= my_n;
-            if (chk_rd) a_chk = my_row[t_chk - 1];
 
             // ---- one probe per element for ALL rows of the tile ----
             uint32_t x[MR_KU], s0[MR_KU], h[MR_KU][MR_W];
@@ -338,8 +354,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
             if (!col_end) {
                 if (c_changed) {                                         // uniform; counts moved: re-read operand
                     t_chk = (int32_t)s - 1 - (int32_t)qlast + (int32_t)st_call;
-                    a_chk = 0;
-                    if (lane < R && t_chk >= 1 && (uint32_t)t_chk <= my_n) a_chk = my_row[t_chk - 1];
+                    a_chk = my_row[t_chk >= 1 ? ((uint32_t)t_chk - 1 < qclamp ? (uint32_t)t_chk - 1 : qclamp) : 0];
                 }
                 const uint64_t blast = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cur[MR_KU - 1] >> 32), 63) << 32) |
                                        (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cur[MR_KU - 1], 63);
@@ -347,8 +362,12 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
                 const uint32_t dm = (uint32_t)__ballot(done) & active;
                 active &= ~dm;
                 brokem |= dm;
+                // advance the pipeline: data of group g+1 becomes current; issue operand of g+1, data of g+2
 #pragma unroll
                 for (int u = 0; u < MR_KU; u++) cur[u] = nxt[u];
+                t_chk = (int32_t)s - 1 - (int32_t)(qlast + 64 * MR_KU) + (int32_t)st_call;
+                a_chk = my_row[t_chk >= 1 ? ((uint32_t)t_chk - 1 < qclamp ? (uint32_t)t_chk - 1 : qclamp) : 0];
+                load_group(bsrc, q0 + 2 * 64 * MR_KU, nxt);
             }
         }
         if (lane < R && ((valid >> lane) & 1u)) {
