@@ -27,6 +27,7 @@ namespace mg {
 constexpr int MR_NT = 1024;
 constexpr int MR_NW = MR_NT / 64;
 constexpr int MR_W = 4;                      // window: entries read per probe
+constexpr int MR_CB = 8;                     // consecutive columns per wave batch (64 B of output per row)
 constexpr int MR_KU = 2;                     // 64-element blocks of a column in flight
 constexpr uint32_t MR_OVF = 0x8000u;         // dir flag: bucket has more than MR_W entries
 constexpr uint64_t HMAX64 = 0xFFFFFFFFFFFFFFFFULL;
@@ -51,7 +52,8 @@ __host__ __device__ inline size_t merged_lds_bytes(uint32_t R, uint32_t s)
 {
     const size_t ecap = (size_t)R * s + MR_W;
     const size_t nb = merged_buckets(R, s);
-    return 512 + (nb + 8) * 2 + ((ecap * 4 + 15) & ~(size_t)15) + ((ecap * 2 + 15) & ~(size_t)15);
+    return 512 + (nb + 8) * 2 + ((ecap * 4 + 15) & ~(size_t)15) + ((ecap * 2 + 15) & ~(size_t)15) +
+           (size_t)MR_NW * 16 * MR_CB * 8;                            // + per-wave output staging
 }
 
 bool compare_merged_supported(uint32_t s) { return s >= 1 && s <= 1024; }
@@ -81,6 +83,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
     uint32_t *cnt32 = reinterpret_cast<uint32_t *>(dir);                            // build-time view
     uint32_t *pfx = reinterpret_cast<uint32_t *>(smem + 512 + (size_t)(NB + 8) * 2);   // [ecap]
     uint16_t *tag = reinterpret_cast<uint16_t *>(reinterpret_cast<unsigned char *>(pfx) + (((size_t)ecap * 4 + 15) & ~(size_t)15));
+    uint2 *stage_all = reinterpret_cast<uint2 *>(reinterpret_cast<unsigned char *>(tag) + (((size_t)ecap * 2 + 15) & ~(size_t)15));
     __shared__ uint32_t s_wsum[MR_NW + 2];
     __shared__ uint64_t s_rowmax[32];
 
@@ -207,14 +210,51 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
     };
     const uint32_t rmax = (a.row_end - tile.row0) < (uint64_t)R ? (uint32_t)(a.row_end - tile.row0) : R;
     const uint32_t rows_all = rmax >= 32 ? 0xFFFFFFFFu : ((1u << rmax) - 1u);
+    // Wave w owns batches of MR_CB consecutive columns: batch k -> columns
+    // col0 + (k*NW + w)*CB ... +CB-1.  Results of a batch are staged in LDS and written
+    // as 64-B row segments (nontemporal), instead of 8-B scattered stores that thrash L2.
+    uint2 *stage = stage_all + (size_t)wid * 16 * MR_CB;                  // [16 rows][CB]
+    auto col_of = [&](uint32_t t) -> uint32_t {
+        return tile.col0 + ((t / MR_CB) * MR_NW + wid) * MR_CB + (t % MR_CB);
+    };
+    auto flush_batch = [&](uint32_t jb, uint32_t ncols_done) {
+        // lane -> (row = lane/4, two columns 2*(lane%4), +1) : 16 B per lane, 64 B per row
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t r = lane >> 2, c0 = (lane & 3u) * 2;
+        const uint64_t i = (uint64_t)tile.row0 + r;
+        if (r < R && i < a.row_end) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(&stage[r * MR_CB + c0]);
+            const uint64_t j0 = (uint64_t)jb + c0;
+            const bool ok0 = c0 < ncols_done && (!a.triangle || j0 < i);
+            const bool ok1 = c0 + 1 < ncols_done && (!a.triangle || j0 + 1 < i);
+            uint64_t oidx;
+            if (a.triangle) oidx = i * (i - 1) / 2 + j0 - a.out_base;
+            else oidx = (i - a.row_begin) * a.ncols + j0;
+            uint2 *dst = a.out + oidx;
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            if (ok0 && ok1 && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+                u32x4 w = {v.x, v.y, v.z, v.w};
+                __builtin_nontemporal_store(w, reinterpret_cast<u32x4 *>(dst));
+            } else {
+                u32x2 w0 = {v.x, v.y}, w1 = {v.z, v.w};
+                if (ok0) __builtin_nontemporal_store(w0, reinterpret_cast<u32x2 *>(dst));
+                if (ok1) __builtin_nontemporal_store(w1, reinterpret_cast<u32x2 *>(dst + 1));
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
     uint64_t ncol[MR_KU];
     uint32_t nB_next = 0;
-    uint32_t j = tile.col0 + wid;
+    uint32_t tcol = 0;
+    uint32_t j = col_of(0);
     if (j < tile.col1) {
         load_group(a.col_hashes + (uint64_t)j * a.col_stride, 0, ncol);
         nB_next = a.col_nhash[j];
     }
-    for (; j < tile.col1; j += MR_NW) {
+    for (; j < tile.col1; tcol++, j = col_of(tcol)) {
         uint32_t nB = nB_next < s ? nB_next : s;
         const uint64_t *bsrc = a.col_hashes + (uint64_t)j * a.col_stride;
         uint64_t cur[MR_KU], nxt[MR_KU];
@@ -234,7 +274,8 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
         uint64_t a_chk = my_row[t_chk >= 1 ? ((uint32_t)t_chk - 1 < qclamp ? (uint32_t)t_chk - 1 : qclamp) : 0];
         load_group(bsrc, 64 * MR_KU, nxt);
         {
-            const uint32_t jn = j + MR_NW < tile.col1 ? j + MR_NW : j;
+            const uint32_t jnx = col_of(tcol + 1);
+            const uint32_t jn = jnx < tile.col1 ? jnx : j;
             load_group(a.col_hashes + (uint64_t)jn * a.col_stride, 0, ncol);
             nB_next = a.col_nhash[jn];
         }
@@ -370,18 +411,16 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
                 load_group(bsrc, q0 + 2 * 64 * MR_KU, nxt);
             }
         }
-        if (lane < R && ((valid >> lane) & 1u)) {
-            const uint64_t i = (uint64_t)tile.row0 + lane;
+        if (lane < 16) {
             uint32_t denom = s;
             if (!((brokem >> lane) & 1u)) {
                 const uint32_t uni = my_n + nB - st_call;
                 denom = uni < s ? uni : s;
             }
-            uint64_t oidx;
-            if (a.triangle) oidx = i * (i - 1) / 2 + j - a.out_base;
-            else oidx = (i - a.row_begin) * a.ncols + j;
-            a.out[oidx] = make_uint2(st_common, denom);
+            stage[lane * MR_CB + (tcol % MR_CB)] = make_uint2(st_common, denom);
         }
+        if ((tcol % MR_CB) == MR_CB - 1 || col_of(tcol + 1) >= tile.col1)
+            flush_batch(j - (tcol % MR_CB), (tcol % MR_CB) + 1);
     }
 }
 
