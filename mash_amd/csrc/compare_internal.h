@@ -15,6 +15,8 @@ struct CompareArgs {
     const uint32_t *row_nhash;
     const uint64_t *col_hashes;   // table streamed through registers (triangle: same; rect: refs)
     const uint32_t *col_nhash;
+    const uint32_t *row_pfx;      // u32 prefix images (value >> pfx_shr, saturated), same strides
+    const uint32_t *col_pfx;
     const CompareTile *tiles;
     uint2 *out;                   // {numer, denom}
     uint64_t row_stride, col_stride;
@@ -25,6 +27,7 @@ struct CompareArgs {
     uint32_t rows_per_tile;       // R
     uint32_t triangle;            // 1: only j < i, triangular output; 0: rect
     uint32_t unroll;              // probes in flight per wave (tuning knob; 0 = default)
+    uint32_t pfx_shr;             // prefix shift shared by both tables
 };
 
 // LDS-tiled kernel usable when s <= 1024; rows_per_tile chosen by compare_rows_per_tile.
@@ -35,6 +38,11 @@ hipError_t launch_compare_tiled(const CompareArgs &a, uint32_t ntiles, hipStream
 bool compare_merged_supported(uint32_t s);
 uint32_t compare_merged_rows(uint32_t s);
 hipError_t launch_compare_merged(const CompareArgs &a, uint32_t ntiles, hipStream_t stream);
+// table max (u64 atomicMax over the last valid entry of every row) and prefix image
+hipError_t launch_table_max(const uint64_t *hashes, const uint32_t *nhash, uint64_t n, uint64_t stride,
+                            unsigned long long *out_max, hipStream_t stream);
+hipError_t launch_make_prefix(const uint64_t *hashes, uint64_t count, uint32_t shr, uint32_t *out,
+                              hipStream_t stream);
 // Generic kernel (any s): one wave per pair, binary search in global memory.
 hipError_t launch_compare_generic(const CompareArgs &a, hipStream_t stream);
 

@@ -15,7 +15,9 @@
 // on the 64-bit value in HBM/L2).  Unrelated sketches never tie, so for them a column
 // costs one probe per element for all R rows plus one rank test per row per 128
 // elements:  rank(B[q] in row r) >= s-1  <=>  A_r[s-1-q+c_r - 1] < B[q]  — a single
-// 64-bit load per row.  Matches (ties) are ranked exactly with ballot + mbcnt using the
+// load per row (tested conservatively on prefixes).  Columns are streamed as 32-bit
+// prefixes (mg_table keeps a u32 image of the table with a table-wide shift), halving
+// the kernel's dominant HBM traffic; 64-bit values are fetched only for tied lanes.  Matches (ties) are ranked exactly with ballot + mbcnt using the
 // index stored in the tag (it IS the lower bound of the matched value in its row).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -33,7 +35,7 @@ constexpr uint32_t MR_OVF = 0x8000u;         // dir flag: bucket has more than M
 constexpr uint64_t HMAX64 = 0xFFFFFFFFFFFFFFFFULL;
 
 struct MergedHdr {
-    uint32_t shr;        // prefix = value >> shr (tile-wide)
+    uint32_t shr;        // (unused: the prefix shift is launch-wide, CompareArgs::pfx_shr)
     uint32_t scale;      // bucket = mulhi(prefix, scale)
     uint32_t xmax;       // largest prefix present in the tile
     uint32_t nent;       // total entries E
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
             if (i < a.row_end) {
                 n = a.row_nhash[i];
                 if (n > s) n = s;
-                if (n > 0) mx = a.row_hashes[i * a.row_stride + n - 1];
+                if (n > 0) mx = a.row_pfx[i * a.row_stride + n - 1];
             }
         }
         hdr->row_n[tid] = n;
@@ -110,26 +112,22 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
     for (uint32_t b = tid; b < (NB + 8) / 2; b += MR_NT) cnt32[b] = 0;
     __syncthreads();
     if (tid == 0) {
-        uint64_t tmax = 1;
         uint32_t e = 0;
         for (uint32_t r = 0; r < 32; r++) {
-            tmax |= s_rowmax[r];
             hdr->row_base[r] = e;
             e += hdr->row_n[r];
         }
         uint64_t mxall = 0;
         for (uint32_t r = 0; r < 32; r++) mxall = s_rowmax[r] > mxall ? s_rowmax[r] : mxall;
-        const int tbl = 64 - __clzll((unsigned long long)tmax);
-        const uint32_t shr = tbl > 32 ? (uint32_t)(tbl - 32) : 0u;
-        const uint32_t xmax = (uint32_t)(mxall >> shr);
+        const uint32_t xmax = (uint32_t)mxall;                    // largest prefix of the tile's rows
         const uint64_t sc = ((uint64_t)NB << 32) / ((uint64_t)xmax + 1ULL);
-        hdr->shr = shr;
+        hdr->shr = a.pfx_shr;
         hdr->xmax = xmax;
         hdr->scale = sc > 0xFFFFFFFFULL ? 0xFFFFFFFFu : (uint32_t)sc;
         hdr->nent = e;
     }
     __syncthreads();
-    const uint32_t shr = hdr->shr, scale = hdr->scale, xmax = hdr->xmax, E = hdr->nent;
+    const uint32_t scale = hdr->scale, xmax = hdr->xmax, E = hdr->nent;
 
     // pass 1: bucket histogram; thread `tid` owns element index tid of every row (s <= 1024 = NT)
     constexpr int EPT = 16;                  // rows per tile <= 16
@@ -139,8 +137,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
         e_bs[t] = 0xFFFFFFFFu;
         e_pfx[t] = 0;
         if ((uint32_t)t < R && (uint32_t)tid < hdr->row_n[t]) {
-            const uint64_t v = a.row_hashes[((uint64_t)tile.row0 + t) * a.row_stride + tid];
-            const uint32_t x = (uint32_t)(v >> shr);
+            const uint32_t x = a.row_pfx[((uint64_t)tile.row0 + t) * a.row_stride + tid];
             const uint32_t bk = __umulhi(x, scale);
             const uint32_t old = atomicAdd(&cnt32[bk >> 1], (bk & 1u) ? 0x10000u : 1u);
             const uint32_t slot = (bk & 1u) ? (old >> 16) : (old & 0xFFFFu);
@@ -192,7 +189,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
 
     // ------------------------------------------------------------------ stream columns
     const uint32_t my_n = lane < 32 ? hdr->row_n[lane] : 0;                // row `lane`
-    const uint64_t *my_row = a.row_hashes + ((uint64_t)tile.row0 + (((uint64_t)tile.row0 + lane < a.row_end && lane < R) ? lane : 0)) * a.row_stride;
+    const uint32_t *my_row = a.row_pfx + ((uint64_t)tile.row0 + (((uint64_t)tile.row0 + lane < a.row_end && lane < R) ? lane : 0)) * a.row_stride;
 
     // Column streaming is software-pipelined with UNCONDITIONAL loads (indices clamped into
     // the row, which is padded to s entries) so the compiler can count vmcnt exactly:
@@ -201,7 +198,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
     // VMEM returns in order, so the small L2-resident rank-test operand is always issued
     // BEFORE the streaming loads that follow it.
     const uint32_t qclamp = s - 1;
-    auto load_group = [&](const uint64_t *src, uint32_t qbase, uint64_t (&dst)[MR_KU]) {
+    auto load_group = [&](const uint32_t *src, uint32_t qbase, uint32_t (&dst)[MR_KU]) {
 #pragma unroll
         for (int u = 0; u < MR_KU; u++) {
             const uint32_t q = qbase + u * 64 + lane;
@@ -246,18 +243,19 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
-    uint64_t ncol[MR_KU];
+    uint32_t ncol[MR_KU];
     uint32_t nB_next = 0;
     uint32_t tcol = 0;
     uint32_t j = col_of(0);
     if (j < tile.col1) {
-        load_group(a.col_hashes + (uint64_t)j * a.col_stride, 0, ncol);
+        load_group(a.col_pfx + (uint64_t)j * a.col_stride, 0, ncol);
         nB_next = a.col_nhash[j];
     }
     for (; j < tile.col1; tcol++, j = col_of(tcol)) {
         uint32_t nB = nB_next < s ? nB_next : s;
-        const uint64_t *bsrc = a.col_hashes + (uint64_t)j * a.col_stride;
-        uint64_t cur[MR_KU], nxt[MR_KU];
+        const uint32_t *bsrc = a.col_pfx + (uint64_t)j * a.col_stride;
+        const uint64_t *bsrc64 = a.col_hashes + (uint64_t)j * a.col_stride;
+        uint32_t cur[MR_KU], nxt[MR_KU];
 #pragma unroll
         for (int u = 0; u < MR_KU; u++) cur[u] = ncol[u];
         // rows of the tile this column is compared with (triangle: only rows i > j)
@@ -271,12 +269,12 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
         const uint32_t ngroups = valid == 0 ? 0 : (nB + 64 * MR_KU - 1) / (64 * MR_KU);
         // prologue: rank-test operand of group 0, data of group 1, then the next column
         int32_t t_chk = (int32_t)s - (int32_t)(64 * MR_KU) + (int32_t)st_call;      // s-1-qlast+c, qlast = 64*KU-1
-        uint64_t a_chk = my_row[t_chk >= 1 ? ((uint32_t)t_chk - 1 < qclamp ? (uint32_t)t_chk - 1 : qclamp) : 0];
+        uint32_t a_chk = my_row[t_chk >= 1 ? ((uint32_t)t_chk - 1 < qclamp ? (uint32_t)t_chk - 1 : qclamp) : 0];
         load_group(bsrc, 64 * MR_KU, nxt);
         {
             const uint32_t jnx = col_of(tcol + 1);
             const uint32_t jn = jnx < tile.col1 ? jnx : j;
-            load_group(a.col_hashes + (uint64_t)jn * a.col_stride, 0, ncol);
+            load_group(a.col_pfx + (uint64_t)jn * a.col_stride, 0, ncol);
             nB_next = a.col_nhash[jn];
         }
         for (uint32_t g = 0; g < ngroups && active != 0; g++) {
@@ -292,7 +290,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
             for (int u = 0; u < MR_KU; u++) {
                 const uint32_t qb = q0 + u * 64;
                 inbm[u] = qb + 64 <= nB ? ~0ULL : (qb >= nB ? 0ULL : ((1ULL << (nB - qb)) - 1ULL));
-                x[u] = mr_prefix(cur[u], shr);
+                x[u] = cur[u];
                 const uint32_t bk = __umulhi(x[u], scale);
                 s0[u] = dir[x[u] > xmax ? NB : bk];
             }
@@ -316,8 +314,8 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
                 for (int u = 0; u < MR_KU; u++) {
                     if (tiem[u] == 0) continue;                          // uniform
                     const uint32_t qb = q0 + u * 64;
-                    const uint64_t b = cur[u];
                     const bool mine = (tiem[u] >> lane) & 1ULL;
+                    const uint64_t b = mine ? bsrc64[qb + lane] : 0;   // 64-bit value only for tied lanes
                     // scan my bucket: rows whose value equals b (verified on 64 bits), remember
                     // the index (= lower bound of b in that row) of up to the first 4 hits in regs
                     uint32_t rowmask = 0;
@@ -397,9 +395,9 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
                     t_chk = (int32_t)s - 1 - (int32_t)qlast + (int32_t)st_call;
                     a_chk = my_row[t_chk >= 1 ? ((uint32_t)t_chk - 1 < qclamp ? (uint32_t)t_chk - 1 : qclamp) : 0];
                 }
-                const uint64_t blast = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cur[MR_KU - 1] >> 32), 63) << 32) |
-                                       (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cur[MR_KU - 1], 63);
-                const bool done = lane < R && (t_chk <= 0 || ((uint32_t)t_chk <= my_n && a_chk < blast));
+                // prefix compare is conservative: prefix(A) < prefix(B) => A < B (a later exit is harmless)
+                const uint32_t xlast = (uint32_t)__builtin_amdgcn_readlane((int)cur[MR_KU - 1], 63);
+                const bool done = lane < R && (t_chk <= 0 || ((uint32_t)t_chk <= my_n && a_chk < xlast));
                 const uint32_t dm = (uint32_t)__ballot(done) & active;
                 active &= ~dm;
                 brokem |= dm;
@@ -422,6 +420,49 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
         if ((tcol % MR_CB) == MR_CB - 1 || col_of(tcol + 1) >= tile.col1)
             flush_batch(j - (tcol % MR_CB), (tcol % MR_CB) + 1);
     }
+}
+
+__global__ void table_max_kernel(const uint64_t *hashes, const uint32_t *nhash, uint64_t n, uint64_t stride,
+                                 unsigned long long *out_max)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long v = 0;
+    if (i < n) {
+        uint64_t k = nhash[i];
+        if (k > stride) k = stride;
+        if (k > 0) v = hashes[i * stride + k - 1];
+    }
+    for (int d = 32; d > 0; d >>= 1) {
+        const unsigned long long o = __shfl_xor(v, d);
+        v = o > v ? o : v;
+    }
+    if ((threadIdx.x & 63) == 0 && v) atomicMax(out_max, v);
+}
+
+__global__ void make_prefix_kernel(const uint64_t *hashes, uint64_t count, uint32_t shr, uint32_t *out)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride)
+        out[i] = mr_prefix(hashes[i], shr);
+}
+
+hipError_t launch_table_max(const uint64_t *hashes, const uint32_t *nhash, uint64_t n, uint64_t stride,
+                            unsigned long long *out_max, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(table_max_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, hashes, nhash, n,
+                       stride, out_max);
+    return hipGetLastError();
+}
+
+hipError_t launch_make_prefix(const uint64_t *hashes, uint64_t count, uint32_t shr, uint32_t *out,
+                              hipStream_t stream)
+{
+    if (count == 0) return hipSuccess;
+    uint64_t blocks = (count + 1023) / 1024;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(make_prefix_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, hashes, count, shr, out);
+    return hipGetLastError();
 }
 
 hipError_t launch_compare_merged(const CompareArgs &a, uint32_t ntiles, hipStream_t stream)

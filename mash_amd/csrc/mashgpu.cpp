@@ -40,6 +40,11 @@ struct mg_table {
     const uint64_t *lengths = nullptr;
     uint64_t n = 0, s = 0;
     bool owns = false;
+    // lazily built by the compare path (cached across calls; the table is immutable)
+    mutable bool have_max = false;
+    mutable uint64_t maxval = 0;
+    mutable uint32_t *pfx = nullptr;      // u32 prefix image [n * s]
+    mutable int pfx_shr = -1;
 };
 
 #define HIP_TRY(ctx, call)                                                           \
@@ -379,6 +384,7 @@ int mg_table_wrap_dev(mg_ctx *ctx, const uint64_t *hashes_dev, const uint32_t *n
 void mg_table_free(mg_table *t)
 {
     if (!t) return;
+    if (t->pfx) { hipSetDevice(t->ctx->device); hipFree(t->pfx); }
     if (t->owns) {
         hipSetDevice(t->ctx->device);
         hipFree((void *)t->hashes);
@@ -392,6 +398,36 @@ uint64_t mg_table_rows(const mg_table *t) { return t ? t->n : 0; }
 uint64_t mg_table_sketch_size(const mg_table *t) { return t ? t->s : 0; }
 
 /* ------------------------------------------------------------------ comparing */
+
+// largest hash of a table (device reduction, cached)
+static int table_max(mg_ctx *ctx, const mg_table *t, uint64_t *out)
+{
+    if (!t->have_max) {
+        unsigned long long *d = nullptr;
+        HIP_TRY(ctx, hipMalloc(&d, 8));
+        hipError_t e = hipMemsetAsync(d, 0, 8, ctx->stream);
+        if (e == hipSuccess) e = mg::launch_table_max(t->hashes, t->nhash, t->n, t->s, d, ctx->stream);
+        unsigned long long h = 0;
+        if (e == hipSuccess) e = hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        hipFree(d);
+        if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("table max: ") + hipGetErrorString(e));
+        t->maxval = h;
+        t->have_max = true;
+    }
+    *out = t->maxval;
+    return MG_OK;
+}
+
+// u32 prefix image of a table for shift `shr` (cached)
+static int table_prefix(mg_ctx *ctx, const mg_table *t, int shr)
+{
+    if (t->pfx && t->pfx_shr == shr) return MG_OK;
+    if (!t->pfx) HIP_TRY(ctx, hipMalloc(&t->pfx, std::max<uint64_t>(t->n * t->s * 4, 4)));
+    HIP_TRY(ctx, mg::launch_make_prefix(t->hashes, t->n * t->s, (uint32_t)shr, t->pfx, ctx->stream));
+    t->pfx_shr = shr;
+    return MG_OK;
+}
 
 static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, uint64_t row_begin,
                        uint64_t row_end, bool triangle, mg_counts *out_dev)
@@ -424,6 +460,24 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
         HIP_TRY(ctx, mg::launch_compare_generic(a, ctx->stream));
         prof_end(ctx, ctx->prof_compare);
         return MG_OK;
+    }
+    a.row_pfx = a.col_pfx = nullptr;
+    a.pfx_shr = 0;
+    if (use_merged) {
+        // both tables are viewed through one 32-bit prefix: value >> shr, shr from the larger maximum
+        uint64_t m1 = 0, m2 = 0;
+        int rc = table_max(ctx, rows, &m1);
+        if (rc == MG_OK) rc = table_max(ctx, cols, &m2);
+        if (rc != MG_OK) return rc;
+        const uint64_t mx = std::max(m1, m2) | 1ull;
+        const int bl = 64 - __builtin_clzll(mx);
+        const int shr = bl > 32 ? bl - 32 : 0;
+        rc = table_prefix(ctx, rows, shr);
+        if (rc == MG_OK && cols != rows) rc = table_prefix(ctx, cols, shr);
+        if (rc != MG_OK) return rc;
+        a.row_pfx = rows->pfx;
+        a.col_pfx = cols->pfx;
+        a.pfx_shr = (uint32_t)shr;
     }
     uint32_t R = use_merged ? mg::compare_merged_rows(a.s) : mg::compare_rows_per_tile(a.s);
     if (const char *e = getenv("MASHGPU_COMPARE_ROWS")) { uint32_t v = (uint32_t)atoi(e); if (v >= 1 && v < R) R = v; }
