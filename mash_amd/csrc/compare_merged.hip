@@ -30,7 +30,7 @@ constexpr int MR_NT = 1024;
 constexpr int MR_NW = MR_NT / 64;
 constexpr int MR_W = 4;                      // window: entries read per probe
 constexpr int MR_CB = 8;                     // consecutive columns per wave batch (64 B of output per row)
-constexpr int MR_KU = 2;                     // 64-element blocks of a column in flight
+constexpr int MR_KU = 4;                     // 64-element blocks of a column in flight
 constexpr uint32_t MR_OVF = 0x8000u;         // dir flag: bucket has more than MR_W entries
 constexpr uint64_t HMAX64 = 0xFFFFFFFFFFFFFFFFULL;
 

@@ -481,7 +481,7 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
     }
     uint32_t R = use_merged ? mg::compare_merged_rows(a.s) : mg::compare_rows_per_tile(a.s);
     if (const char *e = getenv("MASHGPU_COMPARE_ROWS")) { uint32_t v = (uint32_t)atoi(e); if (v >= 1 && v < R) R = v; }
-    uint64_t CC = use_merged ? 4096 : 1024;
+    uint64_t CC = use_merged ? 8192 : 1024;
     if (const char *e = getenv("MASHGPU_COMPARE_COLS")) { uint64_t v = strtoull(e, nullptr, 10); if (v >= 16) CC = v; }
     a.rows_per_tile = R;
     // tiles: column chunk outer, row tile inner (concurrent workgroups share a column chunk in L2)
