@@ -192,7 +192,12 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "kernel": "compare_merged_kernel", "kernel_ms": round(kern_ms, 3), "launches": launches,
                 "algorithmic_bytes_per_pair": bytes_per_pair,
-                "note": "no-reuse streaming model (SURVEY.md §8d): sketches are re-used from LDS/L2, so frac may exceed 1"}
+                "measured_hbm_frac": (round(traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                      if traffic and kern_ms > 0 and n == 100_000 and world == 1 else None),
+                "note": "achieved/frac use the mandated no-reuse model of SURVEY.md §8d (2*s*8+8 B per pair); every "
+                        "sketch is re-used ~1000x from LDS/L2, so frac exceeds 1. traffic = PMC-measured HBM bytes per "
+                        "launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/compare_pmc_latest.json); measured_hbm_frac = "
+                        "traffic / kernel time / peak"}
 
     result = {
         "metric": "pairwise Mash distances/sec (s=1000)",
