@@ -29,6 +29,7 @@ namespace mg {
 constexpr int MR_NT = 1024;
 constexpr int MR_NW = MR_NT / 64;
 constexpr int MR_W = 4;                      // window: entries read per probe
+constexpr int MR_EPT = 20;                   // table entries built per thread (R*s <= 20480)
 constexpr int MR_CB = 8;                     // consecutive columns per wave batch (64 B of output per row)
 constexpr int MR_KU = 4;                     // 64-element blocks of a column in flight
 constexpr uint32_t MR_OVF = 0x8000u;         // dir flag: bucket has more than MR_W entries
@@ -43,10 +44,19 @@ struct MergedHdr {
     uint32_t row_base[32];   // first entry id of row r in (row, index) enumeration order
 };
 
+// tag = row << idx_bits | index-in-row ; idx_bits = bits needed for an index < s (>= 10)
+__host__ __device__ inline uint32_t merged_idx_bits(uint32_t s)
+{
+    uint32_t b = 10;
+    while ((1u << b) < s) b++;
+    return b;
+}
+
+// power-of-two bucket count with about one entry per bucket (load factor <= 1.25)
 __host__ __device__ inline uint32_t merged_buckets(uint32_t R, uint32_t s)
 {
     uint32_t nb = 1024;
-    while (nb < R * s) nb <<= 1;
+    while (nb * 5 < R * s * 4) nb <<= 1;
     return nb;
 }
 
@@ -55,15 +65,20 @@ __host__ __device__ inline size_t merged_lds_bytes(uint32_t R, uint32_t s)
     const size_t ecap = (size_t)R * s + MR_W;
     const size_t nb = merged_buckets(R, s);
     return 512 + (nb + 8) * 2 + ((ecap * 4 + 15) & ~(size_t)15) + ((ecap * 2 + 15) & ~(size_t)15) +
-           (size_t)MR_NW * 16 * MR_CB * 8;                            // + per-wave output staging
+           (size_t)MR_NW * R * MR_CB * 8;                             // + per-wave output staging
 }
 
-bool compare_merged_supported(uint32_t s) { return s >= 1 && s <= 1024; }
+constexpr size_t MR_LDS_LIMIT = 160 * 1024 - 512;       // dynamic part; 512 B left for the static arrays
+
+bool compare_merged_supported(uint32_t s) { return s >= 1 && s <= 16384 && merged_lds_bytes(1, s) <= MR_LDS_LIMIT; }
 
 uint32_t compare_merged_rows(uint32_t s)
 {
     uint32_t r = 16;
-    while (r > 1 && merged_lds_bytes(r, s) > 160 * 1024) r--;
+    const uint32_t rcap = 1u << (16 - merged_idx_bits(s));
+    if (r > rcap) r = rcap;
+    while (r > 1 && (merged_lds_bytes(r, s) > MR_LDS_LIMIT || (uint64_t)r * s > 32767u ||
+                     (uint64_t)r * s > (uint64_t)MR_NT * MR_EPT)) r--;
     return r;
 }
 
@@ -129,20 +144,27 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
     __syncthreads();
     const uint32_t scale = hdr->scale, xmax = hdr->xmax, E = hdr->nent;
 
-    // pass 1: bucket histogram; thread `tid` owns element index tid of every row (s <= 1024 = NT)
-    constexpr int EPT = 16;                  // rows per tile <= 16
-    uint32_t e_pfx[EPT], e_bs[EPT];          // prefix; bucket | slot << 16, kept in registers
+    // pass 1: bucket histogram; entries are enumerated row-major, thread tid owns
+    // e = tid, tid + NT, ... (coalesced loads of the rows' prefix images)
+    const uint32_t idx_bits = merged_idx_bits(s);
+    const uint32_t idx_mask = (1u << idx_bits) - 1u;
+    uint32_t e_pfx[MR_EPT], e_bs[MR_EPT];    // prefix; bucket | slot << 16, kept in registers
+    uint16_t e_tag[MR_EPT];
 #pragma unroll
-    for (int t = 0; t < EPT; t++) {
+    for (int t = 0; t < MR_EPT; t++) {
+        const uint32_t e = (uint32_t)tid + (uint32_t)t * MR_NT;
+        const uint32_t r = e / s, idx = e - r * s;
         e_bs[t] = 0xFFFFFFFFu;
         e_pfx[t] = 0;
-        if ((uint32_t)t < R && (uint32_t)tid < hdr->row_n[t]) {
-            const uint32_t x = a.row_pfx[((uint64_t)tile.row0 + t) * a.row_stride + tid];
+        e_tag[t] = 0;
+        if (r < R && idx < hdr->row_n[r]) {
+            const uint32_t x = a.row_pfx[((uint64_t)tile.row0 + r) * a.row_stride + idx];
             const uint32_t bk = __umulhi(x, scale);
             const uint32_t old = atomicAdd(&cnt32[bk >> 1], (bk & 1u) ? 0x10000u : 1u);
             const uint32_t slot = (bk & 1u) ? (old >> 16) : (old & 0xFFFFu);
             e_pfx[t] = x;
-            e_bs[t] = bk | (slot << 16);             // bk < 16384
+            e_tag[t] = (uint16_t)((r << idx_bits) | idx);
+            e_bs[t] = bk | (slot << 16);             // bk < 32768
         }
     }
     __syncthreads();
@@ -176,12 +198,12 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
     __syncthreads();
     // pass 2: scatter
 #pragma unroll
-    for (int t = 0; t < EPT; t++) {
+    for (int t = 0; t < MR_EPT; t++) {
         if (e_bs[t] != 0xFFFFFFFFu) {
             const uint32_t bk = e_bs[t] & 0xFFFFu, slot = e_bs[t] >> 16;
             const uint32_t pos = (dir[bk] & 0x7FFFu) + slot;
             pfx[pos] = e_pfx[t];
-            tag[pos] = (uint16_t)(((uint32_t)t << 10) | (uint32_t)tid);
+            tag[pos] = e_tag[t];
         }
     }
     if (tid < MR_W) { pfx[E + tid] = 0xFFFFFFFFu; tag[E + tid] = 0xFFFFu; }
@@ -210,7 +232,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
     // Wave w owns batches of MR_CB consecutive columns: batch k -> columns
     // col0 + (k*NW + w)*CB ... +CB-1.  Results of a batch are staged in LDS and written
     // as 64-B row segments (nontemporal), instead of 8-B scattered stores that thrash L2.
-    uint2 *stage = stage_all + (size_t)wid * 16 * MR_CB;                  // [16 rows][CB]
+    uint2 *stage = stage_all + (size_t)wid * R * MR_CB;                   // [R rows][CB]
     auto col_of = [&](uint32_t t) -> uint32_t {
         return tile.col0 + ((t / MR_CB) * MR_NW + wid) * MR_CB + (t % MR_CB);
     };
@@ -329,7 +351,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
                         for (int w = 0; w < MR_W; w++) {
                             if (h[u][w] == x[u] && st + w < E) {
                                 const uint32_t tg = tag[st + w];
-                                const uint32_t r = tg >> 10, idx = tg & 1023u;
+                                const uint32_t r = tg >> idx_bits, idx = tg & idx_mask;
                                 const uint64_t v = a.row_hashes[((uint64_t)tile.row0 + r) * a.row_stride + idx];
                                 if (v == b) { rowmask |= 1u << r; hit_tag[w] = tg; }
                             }
@@ -341,7 +363,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
                             for (uint32_t e = extra_lo; e < extra_hi; e++) {
                                 if (pfx[e] == x[u]) {
                                     const uint32_t tg = tag[e];
-                                    const uint32_t r = tg >> 10, idx = tg & 1023u;
+                                    const uint32_t r = tg >> idx_bits, idx = tg & idx_mask;
                                     const uint64_t v = a.row_hashes[((uint64_t)tile.row0 + r) * a.row_stride + idx];
                                     if (v == b) rowmask |= 1u << r;
                                 }
@@ -362,15 +384,15 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
                         bool have = false;
 #pragma unroll
                         for (int w = 0; w < MR_W; w++) {
-                            if (hit_tag[w] != 0xFFFFFFFFu && (hit_tag[w] >> 10) == r) { idx = hit_tag[w] & 1023u; have = true; }
+                            if (hit_tag[w] != 0xFFFFFFFFu && (hit_tag[w] >> idx_bits) == r) { idx = hit_tag[w] & idx_mask; have = true; }
                         }
                         if (mt && !have) {
                             // hit came from beyond the window of an oversize bucket (rare): rescan
                             for (uint32_t e = extra_lo; e < extra_hi; e++) {
                                 const uint32_t tg = tag[e];
-                                if (pfx[e] == x[u] && (tg >> 10) == r) {
-                                    const uint64_t v = a.row_hashes[((uint64_t)tile.row0 + r) * a.row_stride + (tg & 1023u)];
-                                    if (v == b) idx = tg & 1023u;
+                                if (pfx[e] == x[u] && (tg >> idx_bits) == r) {
+                                    const uint64_t v = a.row_hashes[((uint64_t)tile.row0 + r) * a.row_stride + (tg & idx_mask)];
+                                    if (v == b) idx = tg & idx_mask;
                                 }
                             }
                         }
@@ -409,7 +431,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
                 load_group(bsrc, q0 + 2 * 64 * MR_KU, nxt);
             }
         }
-        if (lane < 16) {
+        if (lane < R) {
             uint32_t denom = s;
             if (!((brokem >> lane) & 1u)) {
                 const uint32_t uni = my_n + nB - st_call;

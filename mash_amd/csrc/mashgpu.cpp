@@ -454,8 +454,8 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
     const char *force = getenv("MASHGPU_COMPARE_KERNEL");
     const bool want_generic = force && strcmp(force, "generic") == 0;
     const bool want_tiled = force && strcmp(force, "tiled") == 0;
-    const bool use_merged = !want_tiled && mg::compare_merged_supported(a.s) && a.s * 16u <= 16384u;
-    if (!mg::compare_tiled_supported(a.s) || want_generic) {
+    const bool use_merged = !want_tiled && !want_generic && mg::compare_merged_supported(a.s);
+    if ((!use_merged && !mg::compare_tiled_supported(a.s)) || want_generic) {
         prof_begin(ctx, ctx->prof_compare);
         HIP_TRY(ctx, mg::launch_compare_generic(a, ctx->stream));
         prof_end(ctx, ctx->prof_compare);

@@ -125,10 +125,9 @@ def _oracle_tri(oracle, table, nhash, lengths, rb, re, k=21, kspace=KSPACE21):
     return numer, denom
 
 
-@pytest.mark.parametrize("kernel", ["tiled", "generic"])
+@pytest.mark.parametrize("kernel", ["merged", "tiled", "generic"])
 def test_compare_reference_run_vectors(eng, golden_dir, kernel, monkeypatch):
-    if kernel == "generic":
-        monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", "generic")
+    monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", kernel)
     z = np.load(os.path.join(golden_dir, "ref_compare_vectors.npz"))
     t = eng.table_upload(z["table"], z["nhash"], z["lengths"])
     got = eng.compare_tri_host(t)
@@ -141,8 +140,10 @@ def test_compare_reference_run_vectors(eng, golden_dir, kernel, monkeypatch):
     t.free()
 
 
+@pytest.mark.parametrize("kernel", ["merged", "tiled"])
 @pytest.mark.parametrize("s", [1, 7, 64, 65, 100, 400, 1000, 1024])
-def test_compare_tiled_vs_oracle_sizes(eng, oracle, s):
+def test_compare_tiled_vs_oracle_sizes(eng, oracle, s, kernel, monkeypatch):
+    monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", kernel)
     n = 150
     table, nhash, lengths = synth.clustered_sketches(n, s, clusters=5, seed=s, pool=int(1.5 * s) + 2,
                                                      private=max(1, int(0.4 * s)))
@@ -164,8 +165,12 @@ def test_compare_tiled_vs_oracle_sizes(eng, oracle, s):
     t.free()
 
 
-@pytest.mark.parametrize("s", [1500, 10000])
-def test_compare_large_sketch_generic(eng, oracle, s):
+@pytest.mark.parametrize("kernel", ["merged", "generic"])
+@pytest.mark.parametrize("s", [1500, 4096, 10000])
+def test_compare_large_sketch(eng, oracle, s, kernel, monkeypatch):
+    """Config-5 sized sketches (s = 10000): merged-rows kernel with few rows per tile, and the
+    generic binary-search kernel as an independent cross-check."""
+    monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", kernel)
     n = 24
     table, nhash, lengths = synth.clustered_sketches(n, s, clusters=3, seed=3, pool=int(1.5 * s),
                                                      private=int(0.4 * s))
@@ -237,13 +242,14 @@ def test_compare_c3_scale_properties(eng, oracle):
         numer, denom = _oracle_tri(oracle, table, nhash, lengths, i, i + 1)
         row = got[i * (i - 1) // 2: i * (i - 1) // 2 + i]
         assert np.array_equal(row["numer"], numer) and np.array_equal(row["denom"], denom), i
-    os.environ["MASHGPU_COMPARE_KERNEL"] = "generic"
-    try:
-        got_g = eng.compare_tri_host(t, 5000, 5400)
-    finally:
-        del os.environ["MASHGPU_COMPARE_KERNEL"]
     lo = 5000 * 4999 // 2
-    assert np.array_equal(got_g, got[lo: lo + len(got_g)])
+    for other in ("generic", "tiled"):
+        os.environ["MASHGPU_COMPARE_KERNEL"] = other
+        try:
+            got_g = eng.compare_tri_host(t, 5000, 5400)
+        finally:
+            del os.environ["MASHGPU_COMPARE_KERNEL"]
+        assert np.array_equal(got_g, got[lo: lo + len(got_g)]), other
     # cluster structure: same cluster <=> i % 60 == j % 60
     i = 4321
     row = got[i * (i - 1) // 2: i * (i - 1) // 2 + i]
