@@ -1,0 +1,79 @@
+// fastx.cpp — see fastx.h (semantics of kseq.h:67-208, re-implemented over zlib).
+#include "fastx.h"
+
+#include <cctype>
+#include <cstdio>
+
+namespace fastx {
+
+bool Reader::open(const std::string &path)
+{
+    close();
+    f_ = path == "-" ? gzdopen(fileno(stdin), "r") : gzopen(path.c_str(), "r");
+    begin_ = end_ = 0;
+    eof_ = false;
+    last_char_ = 0;
+    if (f_) gzbuffer(f_, 1 << 18);
+    return f_ != nullptr;
+}
+
+void Reader::close()
+{
+    if (f_) gzclose(f_);
+    f_ = nullptr;
+}
+
+int Reader::getc_()
+{
+    if (begin_ >= end_) {
+        if (eof_) return -1;
+        begin_ = 0;
+        end_ = gzread(f_, buf_, sizeof buf_);
+        if (end_ < (int)sizeof buf_) eof_ = true;
+        if (end_ <= 0) { end_ = 0; return -1; }
+    }
+    return buf_[begin_++];
+}
+
+int Reader::until_(int mode, std::string &out)
+{
+    out.clear();
+    for (;;) {
+        const int c = getc_();
+        if (c < 0) return -1;
+        if (mode == 0 ? isspace(c) : c == '\n') return c;
+        out.push_back((char)c);
+    }
+}
+
+long Reader::next(Record &rec)
+{
+    int c;
+    if (last_char_ == 0) {                         // jump to the next header line
+        while ((c = getc_()) != -1 && c != '>' && c != '@') {}
+        if (c == -1) return -1;
+        last_char_ = c;
+    }
+    rec.comment.clear();
+    rec.seq.clear();
+    c = until_(0, rec.name);
+    if (c == -1 && rec.name.empty() && begin_ >= end_ && eof_) return -1;
+    if (c != '\n' && c != -1) until_(1, rec.comment);
+    while ((c = getc_()) != -1 && c != '>' && c != '+' && c != '@')
+        if (isgraph(c)) rec.seq.push_back((char)c);
+    if (c == '>' || c == '@') last_char_ = c;
+    if (c != '+') {
+        if (c == -1) last_char_ = 0;
+        return (long)rec.seq.size();               // FASTA
+    }
+    while ((c = getc_()) != -1 && c != '\n') {}    // rest of the '+' line
+    if (c == -1) return -2;
+    size_t q = 0;
+    while (q < rec.seq.size() && (c = getc_()) != -1)
+        if (c >= 33 && c <= 127) q++;
+    last_char_ = 0;
+    if (q != rec.seq.size()) return -2;
+    return (long)rec.seq.size();
+}
+
+}  // namespace fastx

@@ -1,0 +1,1029 @@
+// mash_main.cpp — `mash sketch | dist | triangle | info | paste` on the MI355X hot path.
+//
+// Host C++ above the C ABI (include/mashgpu.h).  Option letters, defaults, file naming,
+// stdout/stderr text and output order follow the reference commands
+// (CommandSketch.cpp:36-169, CommandDistance.cpp:44-304, CommandTriangle.cpp:45-198,
+// CommandInfo.cpp:40-299, CommandPaste.cpp:30-89, Command.cpp:165-200,311-347,
+// sketchParameterSetup.cpp:15-125, Sketch.cpp:105-253).  All hashing / selection /
+// comparison runs on the GPU through libmashgpu; there is no CPU fallback.
+// Not built (the reference's reads-mode noise filters are order dependent):
+// -m >= 2, -b, -c.  Multiplicities (-M, implied by -r) are not stored yet.
+#include <unistd.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/mashgpu.h"
+#include "fastx.h"
+#include "msh_file.h"
+
+using std::cerr;
+using std::cout;
+using std::endl;
+using std::string;
+using std::vector;
+
+namespace {
+
+const char *kSuffix = ".msh";
+const char *kAlphabetNucleotide = "ACGT";
+const char *kAlphabetProtein = "ACDEFGHIKLMNPQRSTVWY";
+
+bool has_suffix(const string &s, const string &suf)
+{
+    return s.size() >= suf.size() && s.compare(s.size() - suf.size(), suf.size(), suf) == 0;
+}
+
+// ------------------------------------------------------------------------------- options
+// Command::Option (Command.h:27-66): numbers are parsed with stof and kept as float.
+struct Opt {
+    enum Type { Boolean, Number, Integer, Size, File, String } type = Boolean;
+    string id, def;
+    float lo = 0, hi = 0;
+    bool active = false;
+    string arg;
+    float num = 0;
+};
+
+struct Cmd {
+    string name;
+    std::map<string, Opt> opts;              // by long name
+    std::map<string, string> by_id;
+    vector<string> args;
+
+    void add(const string &name_, Opt::Type t, const string &id, const string &def = "", float lo = 0, float hi = 0)
+    {
+        Opt o;
+        o.type = t; o.id = id; o.def = def; o.lo = lo; o.hi = hi;
+        opts[name_] = o;
+        by_id[id] = name_;
+        set_arg(opts[name_], def);
+    }
+    static void set_arg(Opt &o, string a)
+    {
+        o.arg = a;
+        if (o.type == Opt::Number || o.type == Opt::Integer) {
+            if (a.empty()) { o.num = 0; return; }
+            bool failed = false;
+            try {
+                o.num = std::stof(a);
+                if (o.lo != o.hi && (o.num < o.lo || o.num > o.hi)) failed = true;
+                else if (o.type == Opt::Integer && (float)(uint64_t)o.num != o.num) failed = true;
+            } catch (const std::exception &) { failed = true; }
+            if (failed) {
+                cerr << "ERROR: Argument to -" << o.id << " must be a" << (o.type == Opt::Integer ? "n integer" : " number");
+                if (o.lo != o.hi) cerr << " between " << o.lo << " and " << o.hi;
+                cerr << " (" << a << " given)" << endl;
+                exit(1);
+            }
+        } else if (o.type == Opt::Size) {
+            if (a.empty()) { o.num = 0; return; }
+            char suffix = a[a.size() - 1];
+            double factor = 1;
+            if (suffix < '0' || suffix > '9') {
+                switch (suffix) {
+                    case 'k': case 'K': factor = 1e3; break;
+                    case 'm': case 'M': factor = 1e6; break;
+                    case 'g': case 'G': factor = 1e9; break;
+                    case 't': case 'T': factor = 1e12; break;
+                    default:
+                        cerr << "ERROR: Unrecognized unit (\"" << suffix << "\") in argument to -" << o.id
+                             << ". If specified, unit must be one of [kKmMgGtT]." << endl;
+                        exit(1);
+                }
+                a.resize(a.size() - 1);
+            }
+            bool fail = false;
+            try { o.num = std::stof(a); } catch (const std::exception &) { fail = true; }
+            if (o.num <= 0 || (float)(uint64_t)o.num != o.num) fail = true;
+            if (fail) {
+                cerr << "ERROR: Argument to -" << o.id << " must be a whole number, optionally followed by one of [kKmMgGtT]." << endl;
+                exit(1);
+            }
+            o.num = (float)(o.num * factor);
+        }
+    }
+    // Command::run(argc, argv), Command.cpp:311-347
+    int parse(int argc, const char **argv)
+    {
+        for (int i = 0; i < argc; i++) {
+            if (argv[i][0] == '-' && argv[i][1] != 0) {
+                if (!by_id.count(argv[i] + 1)) { cerr << "ERROR: Unrecognized option: " << argv[i] << endl; return 1; }
+                Opt &o = opts.at(by_id.at(argv[i] + 1));
+                o.active = true;
+                if (o.type != Opt::Boolean) {
+                    i++;
+                    if (i == argc) { cerr << "ERROR: -" << o.id << " requires an argument" << endl; return 1; }
+                    set_arg(o, argv[i]);
+                }
+            } else {
+                args.push_back(argv[i]);
+            }
+        }
+        return 0;
+    }
+    const Opt &o(const string &n) const { return opts.at(n); }
+    bool has(const string &n) const { return opts.count(n) != 0; }
+    void use_sketch_options()                  // Command::useSketchOptions, Command.cpp:354-379
+    {
+        add("threads", Opt::Integer, "p", "1");
+        add("kmer", Opt::Integer, "k", "21", 1, 32);
+        add("noncanonical", Opt::Boolean, "n");
+        add("protein", Opt::Boolean, "a");
+        add("alphabet", Opt::String, "z");
+        add("case", Opt::Boolean, "Z");
+        add("sketchSize", Opt::Integer, "s", "1000");
+        add("individual", Opt::Boolean, "i");
+        add("seed", Opt::Integer, "S", "42", 0, (float)0xFFFFFFFF);
+        add("warning", Opt::Number, "w", "0.01", 0, 1);
+        add("reads", Opt::Boolean, "r");
+        add("memory", Opt::Size, "b");
+        add("minCov", Opt::Integer, "m", "1");
+        add("targetCov", Opt::Number, "c");
+        add("genome", Opt::Size, "g");
+    }
+};
+
+// ------------------------------------------------------------------------------- parameters
+struct Params {                               // Sketch::Parameters (Sketch.h:34-106), fields used here
+    int kmer = 0;
+    uint64_t sketch_size = 0;
+    uint32_t seed = 0;
+    bool concatenated = false, noncanonical = false, preserve_case = false, reads = false, counts = false;
+    float warning = 0;
+    uint64_t genome_size = 0;
+    string alphabet;                          // normalised (uppercased unless preserve_case), sorted
+    uint32_t alphabet_size = 0;
+    bool use64 = false;
+};
+
+string normalise_alphabet(const string &chars, bool preserve_case)
+{
+    bool m[256] = {false};
+    for (char c : chars) {
+        char u = c;
+        if (!preserve_case && u > 96 && u < 123) u -= 32;
+        m[(unsigned char)u] = true;
+    }
+    string out;                               // Sketch::getAlphabetAsString: ascending byte order
+    for (int i = 0; i < 256; i++) if (m[i]) out.push_back((char)i);
+    return out;
+}
+
+void set_alphabet(Params &p, const string &chars)
+{
+    p.alphabet = normalise_alphabet(chars, p.preserve_case);
+    p.use64 = mshio::use64_for(p.alphabet, p.preserve_case, (uint32_t)p.kmer, &p.alphabet_size);
+}
+
+// sketchParameterSetup, sketchParameterSetup.cpp:15-105
+int sketch_parameter_setup(Params &p, const Cmd &c)
+{
+    p.kmer = (int)c.o("kmer").num;
+    p.sketch_size = (uint64_t)c.o("sketchSize").num;
+    p.concatenated = !c.o("individual").active;
+    p.noncanonical = c.o("noncanonical").active;
+    p.seed = (uint32_t)c.o("seed").num;
+    p.reads = c.o("reads").active;
+    p.preserve_case = c.o("case").active;
+    if (c.has("warning")) p.warning = c.o("warning").num;
+    if (c.o("memory").active || c.o("minCov").active || c.o("targetCov").active) {
+        if ((c.o("minCov").active && c.o("minCov").num > 1) || c.o("memory").active || c.o("targetCov").active) {
+            cerr << "ERROR: The options -m (>1), -b and -c depend on the order k-mers are seen and are not "
+                    "supported by the GPU sketching path." << endl;
+            return 1;
+        }
+        p.reads = true;
+    }
+    if (c.o("genome").active) { p.reads = true; p.genome_size = (uint64_t)c.o("genome").num; }
+    if (p.reads) p.counts = true;
+    if (p.reads && c.o("threads").active)
+        cerr << "WARNING: The option " << c.o("threads").id << " will be ignored with " << c.o("reads").id << "." << endl;
+    if (p.reads && !p.concatenated) {
+        cerr << "ERROR: The option " << c.o("individual").id << " cannot be used with " << c.o("reads").id << "." << endl;
+        return 1;
+    }
+    if (c.o("protein").active) {
+        p.noncanonical = true;
+        if (!c.o("kmer").active) p.kmer = 9;
+        set_alphabet(p, kAlphabetProtein);
+    } else if (c.o("alphabet").active) {
+        p.noncanonical = true;
+        set_alphabet(p, c.o("alphabet").arg);
+    } else {
+        set_alphabet(p, kAlphabetNucleotide);
+    }
+    return 0;
+}
+
+void split_file(const string &file, vector<string> &lines)      // Command.cpp:398-414
+{
+    std::ifstream in(file);
+    if (in.fail()) { cerr << "ERROR: Could not open " << file << ".\n"; exit(1); }
+    string line;
+    while (getline(in, line)) lines.push_back(line);
+}
+
+// ------------------------------------------------------------------------------- sketch set
+struct Ref {
+    string name, comment;
+    uint64_t length = 0;
+    vector<uint64_t> hashes;
+    vector<uint32_t> counts;
+};
+
+struct SketchSet {                            // the part of class Sketch the commands use
+    Params p;
+    vector<Ref> refs;
+    double kmer_space() const { return std::pow((double)p.alphabet_size, (double)p.kmer); }   // Sketch.cpp:509
+};
+
+struct Gpu {
+    mg_ctx *ctx = nullptr;
+    Gpu()
+    {
+        int dev = 0;
+        if (const char *e = getenv("MASH_GPU_DEVICE")) dev = atoi(e);
+        if (mg_ctx_create(dev, &ctx) != MG_OK) {
+            cerr << "ERROR: no usable GPU: " << mg_last_error(nullptr) << endl;
+            exit(1);
+        }
+    }
+    ~Gpu() { mg_ctx_destroy(ctx); }
+};
+
+void params_from_header(Params &p, const mshio::Header &h)     // initParametersFromCapnp, Sketch.cpp:255-324
+{
+    p.kmer = (int)h.kmer_size;
+    p.sketch_size = h.sketch_size;
+    p.concatenated = h.concatenated;
+    p.noncanonical = h.noncanonical;
+    p.preserve_case = h.preserve_case;
+    p.counts = h.has_counts;
+    p.seed = h.seed;
+    set_alphabet(p, h.has_alphabet ? h.alphabet : string(kAlphabetNucleotide));
+}
+
+// One batch of inputs -> GPU -> hash lists appended to `set`.
+struct PendingBatch {
+    vector<uint8_t> bases;
+    vector<uint64_t> off{0};
+    vector<Ref> refs;
+    void add_record(const string &seq)
+    {
+        bases.insert(bases.end(), seq.begin(), seq.end());
+        bases.push_back((uint8_t)MG_RECORD_SEP);
+    }
+    void end_sketch(Ref &&r)
+    {
+        off.push_back(bases.size());
+        refs.push_back(std::move(r));
+    }
+};
+
+void flush_batch(Gpu &gpu, SketchSet &set, PendingBatch &b)
+{
+    if (b.refs.empty()) return;
+    mg_params mp;
+    mg_params_init(&mp, set.p.kmer, set.p.sketch_size, set.p.seed, set.p.alphabet.c_str(), set.p.noncanonical,
+                   set.p.preserve_case);
+    const uint64_t n = b.refs.size(), s = set.p.sketch_size;
+    vector<uint64_t> hashes(n * s);
+    vector<uint32_t> nhash(n);
+    if (b.bases.empty()) b.bases.push_back((uint8_t)MG_RECORD_SEP);
+    if (mg_sketch_host(gpu.ctx, &mp, b.bases.data(), b.bases.size(), b.off.data(), n, hashes.data(), nhash.data(),
+                       nullptr) != MG_OK) {
+        cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl;
+        exit(1);
+    }
+    for (uint64_t i = 0; i < n; i++) {
+        b.refs[i].hashes.assign(hashes.begin() + i * s, hashes.begin() + i * s + nhash[i]);
+        set.refs.push_back(std::move(b.refs[i]));
+    }
+    b = PendingBatch();
+}
+
+const uint64_t kBatchBytes = 2ull << 30;
+
+// sketchFile in concatenated mode for ONE file (Sketch.cpp:1147-1336), non-reads
+void queue_file_concatenated(Gpu &gpu, SketchSet &set, PendingBatch &b, const string &file)
+{
+    fastx::Reader rd;
+    if (!rd.open(file)) { cerr << "ERROR: could not open " << file << endl; exit(1); }
+    Ref ref;
+    if (file != "-") ref.name = file;
+    fastx::Record rec;
+    long l;
+    int count = 0;
+    bool skipped = false;
+    while ((l = rd.next(rec)) >= 0) {
+        if (l < set.p.kmer) { skipped = true; continue; }
+        if (count == 0) {
+            if (file == "-") { ref.name = rec.name; ref.comment = rec.comment; }
+            else ref.comment = rec.name + " " + rec.comment;
+        }
+        count++;
+        ref.length += (uint64_t)l;
+        b.add_record(rec.seq);
+    }
+    if (count > 1) ref.comment = "[" + std::to_string(count) + " seqs] " + ref.comment + " [...]";
+    if (l != -1) { cerr << "\nERROR: reading input files." << endl; exit(1); }
+    if (ref.length == 0) {
+        if (skipped) cerr << "\nWARNING: All fasta records in input files were shorter than the k-mer size (" << set.p.kmer << ")." << endl;
+        else cerr << "\nERROR: Did not find fasta records in \"input files\"." << endl;
+        exit(1);
+    }
+    b.end_sketch(std::move(ref));
+    if (b.bases.size() > kBatchBytes) flush_batch(gpu, set, b);
+}
+
+// sketchFileBySequence (Sketch.cpp:326-370): one sketch per record
+void queue_file_by_sequence(Gpu &gpu, SketchSet &set, PendingBatch &b, const string &file)
+{
+    fastx::Reader rd;
+    if (!rd.open(file)) { cerr << "ERROR: could not open " << file << " for reading." << endl; exit(1); }
+    fastx::Record rec;
+    long l;
+    while ((l = rd.next(rec)) >= 0) {
+        if (l < set.p.kmer) continue;
+        Ref ref;
+        ref.name = rec.name;
+        ref.comment = rec.comment;
+        ref.length = (uint64_t)l;
+        b.add_record(rec.seq);
+        b.end_sketch(std::move(ref));
+        if (b.bases.size() > kBatchBytes) flush_batch(gpu, set, b);
+    }
+    if (l != -1) { cerr << "\nERROR: reading " << file << "." << endl; exit(1); }
+}
+
+// Sketch::initFromReads -> sketchFile over all files, round robin (Sketch.cpp:96-103, :1147-1336)
+void sketch_reads(Gpu &gpu, SketchSet &set, const vector<string> &files)
+{
+    vector<fastx::Reader *> readers;
+    Ref ref;
+    for (size_t f = 0; f < files.size(); f++) {
+        if (files[f] == "-" && f > 1) { cerr << "ERROR: '-' for stdin must be first input" << endl; exit(1); }
+        if (ref.name.empty() && files[f] != "-") ref.name = files[f];
+        fastx::Reader *r = new fastx::Reader;
+        if (!r->open(files[f])) { cerr << "ERROR: could not open " << files[f] << endl; exit(1); }
+        readers.push_back(r);
+    }
+    PendingBatch b;
+    fastx::Record rec;
+    size_t it = 0;
+    long l = -1;
+    int count = 0;
+    while (!readers.empty()) {
+        l = readers[it]->next(rec);
+        if (l < -1) break;
+        if (l == -1) {
+            delete readers[it];
+            readers.erase(readers.begin() + it);
+            if (it == readers.size()) it = 0;
+            continue;
+        }
+        if (l >= set.p.kmer) {
+            if (count == 0) {
+                if (files[0] == "-") { ref.name = rec.name; ref.comment = rec.comment; }
+                else ref.comment = rec.name + " " + rec.comment;
+            }
+            count++;
+            b.add_record(rec.seq);
+            it++;
+            if (it == readers.size()) it = 0;
+        }
+        // records shorter than k are skipped without advancing to the next file (Sketch.cpp:1222-1226)
+    }
+    for (auto *r : readers) delete r;
+    if (count > 1) ref.comment = "[" + std::to_string(count) + " seqs] " + ref.comment + " [...]";
+    if (l != -1) { cerr << "\nERROR: reading input files." << endl; exit(1); }
+    if (count == 0) { cerr << "\nERROR: Did not find fasta records in \"input files\"." << endl; exit(1); }
+    b.end_sketch(std::move(ref));
+    flush_batch(gpu, set, b);
+    Ref &r = set.refs.back();
+    // estimateSetSize (MinHashHeap.h:45): 2^bits * n / max kept hash
+    double est = 0;
+    if (!r.hashes.empty())
+        est = std::pow(2.0, set.p.use64 ? 64.0 : 32.0) * (double)r.hashes.size() / (double)r.hashes.back();
+    r.length = set.p.genome_size ? set.p.genome_size : (uint64_t)est;
+    cerr << "Estimated genome size: " << est << endl;
+    cerr << "Estimated coverage:    " << "n/a (multiplicities are not computed on the GPU path)" << endl;
+}
+
+// the .msh branch of Sketch::initFromFiles (Sketch.cpp:120-172) + loadCapnp
+bool load_msh_into(SketchSet &set, const string &file, bool first_sets_params, bool contain = false)
+{
+    mshio::File hdr;
+    string e = mshio::read_msh(file, hdr, true);
+    if (!e.empty()) { cerr << "ERROR: " << e << endl; exit(1); }
+    if (first_sets_params) params_from_header(set.p, hdr.header);
+    Params t;
+    params_from_header(t, hdr.header);
+    if (set.p.alphabet != t.alphabet) {
+        cerr << "\nWARNING: The sketch file " << file << " has different alphabet (" << t.alphabet << ") than the current alphabet (" << set.p.alphabet << "). This file will be skipped." << endl << endl;
+        return false;
+    }
+    if (t.seed != set.p.seed) {
+        cerr << "\nWARNING: The sketch " << file << " has a seed size (" << t.seed << ") that does not match the current seed (" << set.p.seed << "). This file will be skipped." << endl << endl;
+        return false;
+    }
+    if (t.kmer != set.p.kmer) {
+        cerr << "\nWARNING: The sketch " << file << " has a kmer size (" << t.kmer << ") that does not match the current kmer size (" << set.p.kmer << "). This file will be skipped." << endl << endl;
+        return false;
+    }
+    if (!contain && t.sketch_size < set.p.sketch_size) {
+        cerr << "\nWARNING: The sketch file " << file << " has a target sketch size (" << t.sketch_size << ") that is smaller than the current sketch size (" << set.p.sketch_size << "). This file will be skipped." << endl << endl;
+        return false;
+    }
+    if (t.noncanonical != set.p.noncanonical) {
+        cerr << "\nWARNING: The sketch file " << file << " is " << (t.noncanonical ? "noncanonical" : "canonical") << ", which is incompatible with the current setting. This file will be skipped." << endl << endl;
+        return false;
+    }
+    if (t.sketch_size > set.p.sketch_size)
+        cerr << "\nWARNING: The sketch file " << file << " has a target sketch size (" << t.sketch_size << ") that is larger than the current sketch size (" << set.p.sketch_size << "). Its sketches will be reduced." << endl << endl;
+    mshio::File f;
+    e = mshio::read_msh(file, f, false, set.p.sketch_size);
+    if (!e.empty()) { cerr << "ERROR: " << e << endl; exit(1); }
+    for (auto &r : f.references) {
+        Ref x;
+        x.name = std::move(r.name);
+        x.comment = std::move(r.comment);
+        x.length = r.length;
+        x.hashes = std::move(r.hashes);
+        x.counts = std::move(r.counts);
+        set.refs.push_back(std::move(x));
+    }
+    return true;
+}
+
+// Sketch::initFromFiles (Sketch.cpp:105-253)
+void init_from_files(Gpu &gpu, SketchSet &set, const vector<string> &files, const Params &p, int verbosity = 1,
+                     bool enforce_parameters = false)
+{
+    set.p = p;
+    PendingBatch b;
+    for (size_t i = 0; i < files.size(); i++) {
+        if (has_suffix(files[i], kSuffix)) {
+            flush_batch(gpu, set, b);                      // keep input order
+            load_msh_into(set, files[i], i == 0 && !enforce_parameters);
+        } else {
+            if (verbosity > 0) {
+                if (files[i] == "-") cerr << "Sketching from stdin..." << endl;
+                else cerr << "Sketching " << files[i] << "..." << endl;
+            }
+            if (files[i] != "-") {
+                FILE *t = fopen(files[i].c_str(), "r");
+                if (!t) { cerr << "ERROR: could not open " << files[i] << " for reading." << endl; exit(1); }
+                fclose(t);
+            }
+            if (set.p.concatenated) queue_file_concatenated(gpu, set, b, files[i]);
+            else queue_file_by_sequence(gpu, set, b, files[i]);
+        }
+    }
+    flush_batch(gpu, set, b);
+}
+
+string write_set(const SketchSet &set, const string &path)
+{
+    mshio::File f;
+    f.header.kmer_size = (uint32_t)set.p.kmer;
+    f.header.sketch_size = (uint32_t)set.p.sketch_size;
+    f.header.seed = set.p.seed;
+    f.header.concatenated = set.p.concatenated;
+    f.header.noncanonical = set.p.noncanonical;
+    f.header.preserve_case = set.p.preserve_case;
+    f.header.has_alphabet = true;
+    f.header.alphabet = set.p.alphabet;
+    f.header.has_counts = set.p.counts;
+    for (const Ref &r : set.refs) {
+        mshio::Reference x;
+        x.name = r.name; x.comment = r.comment; x.length = r.length; x.hashes = r.hashes; x.counts = r.counts;
+        f.references.push_back(std::move(x));
+    }
+    return mshio::write_msh(path, f);
+}
+
+// warnKmerSize machinery (CommandSketch.cpp:110-131, sketchParameterSetup.cpp:107-125, Sketch.cpp:53-61)
+struct KmerWarning {
+    uint64_t length_max = 0;
+    string name;
+    double random_chance = 0;
+    int k_min = 0;
+    int count = 0;
+};
+
+KmerWarning scan_kmer_warning(const SketchSet &set)
+{
+    KmerWarning w;
+    const double warning = set.p.warning;
+    const double threshold = (warning * set.kmer_space()) / (1. - warning);
+    for (const Ref &r : set.refs) {
+        if ((double)r.length > threshold) {
+            if (w.count == 0 || r.length > w.length_max) {
+                w.length_max = r.length;
+                w.name = r.name;
+                w.random_chance = 1. / (set.kmer_space() / r.length + 1.);
+                w.k_min = (int)std::ceil(std::log(r.length * (1 - warning) / warning) / std::log((double)set.p.alphabet_size));
+            }
+            w.count++;
+        }
+    }
+    return w;
+}
+
+void warn_kmer_size(const SketchSet &set, const KmerWarning &w)
+{
+    cerr << "\nWARNING: For the k-mer size used (" << set.p.kmer << "), the random match probability (" << w.random_chance
+         << ") is above the specified warning threshold (" << set.p.warning << ") for the sequence \"" << w.name
+         << "\" of size " << w.length_max;
+    if (w.count > 1) cerr << " (and " << (w.count - 1) << " others)";
+    cerr << ". Distances to " << (w.count == 1 ? "this sequence" : "these sequences")
+         << " may be underestimated as a result. To meet the threshold of " << set.p.warning << ", a k-mer size of at least "
+         << w.k_min << " is required. See: -k, -w." << endl << endl;
+}
+
+// dense table upload
+mg_table *upload(Gpu &gpu, const SketchSet &set, uint64_t s, vector<uint64_t> *lengths_out = nullptr)
+{
+    const uint64_t n = set.refs.size();
+    vector<uint64_t> h(std::max<uint64_t>(n * s, 1), MG_HASH_PAD), len(std::max<uint64_t>(n, 1));
+    vector<uint32_t> nh(std::max<uint64_t>(n, 1));
+    for (uint64_t i = 0; i < n; i++) {
+        const Ref &r = set.refs[i];
+        const uint64_t k = std::min<uint64_t>(r.hashes.size(), s);
+        nh[i] = (uint32_t)k;
+        len[i] = r.length;
+        std::copy(r.hashes.begin(), r.hashes.begin() + k, h.begin() + i * s);
+    }
+    mg_table *t = nullptr;
+    if (mg_table_upload(gpu.ctx, h.data(), nh.data(), len.data(), n, s, &t) != MG_OK) {
+        cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl;
+        exit(1);
+    }
+    if (lengths_out) *lengths_out = len;
+    return t;
+}
+
+// ------------------------------------------------------------------------------- commands
+int cmd_sketch(int argc, const char **argv)
+{
+    Cmd c;
+    c.name = "sketch";
+    c.add("help", Opt::Boolean, "h");
+    c.add("list", Opt::Boolean, "l");
+    c.add("prefix", Opt::File, "o");
+    c.add("id", Opt::File, "I");
+    c.add("comment", Opt::File, "C");
+    c.add("counts", Opt::Boolean, "M");
+    c.use_sketch_options();
+    if (c.parse(argc, argv)) return 1;
+    if (c.args.empty() || c.o("help").active) {
+        cout << "\nUsage:\n\n  mash sketch [options] <input> [<input>] ...\n\n"
+                "Create a sketch file (.msh) from fasta/fastq inputs (gzipped or not) on the GPU.\n"
+                "Options: -l -o <prefix> -I <id> -C <comment> -k <1-32> -s <size> -S <seed> -i -n -a -z <alphabet> -Z -r -g <size> -w <p>\n\n";
+        return 0;
+    }
+    Params p;
+    p.counts = c.o("counts").active;
+    if (sketch_parameter_setup(p, c)) return 1;
+    if (p.counts) cerr << "WARNING: k-mer multiplicities (-M / -r) are not stored by the GPU sketching path yet." << endl;
+    p.counts = false;
+    vector<string> files;
+    for (const string &a : c.args) { if (c.o("list").active) split_file(a, files); else files.push_back(a); }
+    if ((c.o("id").active || c.o("comment").active) && files.size() > 1 && !p.reads)
+        cerr << "WARNING: -I and -C will only apply to first sketch" << endl;
+    Gpu gpu;
+    SketchSet set;
+    if (p.reads) { set.p = p; sketch_reads(gpu, set, files); }
+    else init_from_files(gpu, set, files, p, 1);
+    if (c.o("id").active && !set.refs.empty()) set.refs[0].name = c.o("id").arg;
+    if (c.o("comment").active && !set.refs.empty()) set.refs[0].comment = c.o("comment").arg;
+    const KmerWarning w = scan_kmer_warning(set);
+    string prefix = !c.o("prefix").arg.empty() ? c.o("prefix").arg : (c.args[0] == "-" ? string("stdin") : c.args[0]);
+    if (!has_suffix(prefix, kSuffix)) prefix += kSuffix;
+    cerr << "Writing to " << prefix << "..." << endl;
+    const string e = write_set(set, prefix);
+    if (!e.empty()) { cerr << "ERROR: " << e << endl; return 1; }
+    if (w.count > 0 && !p.reads) warn_kmer_size(set, w);
+    return 0;
+}
+
+void print_pair_line(const Ref &ref, const Ref &qry, bool comment, const mg_pair &pr)
+{
+    cout << ref.name;
+    if (comment) cout << ':' << ref.comment;
+    cout << '\t' << qry.name;
+    if (comment) cout << ':' << qry.comment;
+    cout << '\t' << pr.distance << '\t' << pr.p_value << '\t' << pr.numer << '/' << pr.denom << endl;
+}
+
+int cmd_dist(int argc, const char **argv)
+{
+    Cmd c;
+    c.name = "dist";
+    c.add("help", Opt::Boolean, "h");
+    c.add("list", Opt::Boolean, "l");
+    c.add("table", Opt::Boolean, "t");
+    c.add("pvalue", Opt::Number, "v", "1.0", 0., 1.);
+    c.add("distance", Opt::Number, "d", "1.0", 0., 1.);
+    c.add("comment", Opt::Boolean, "C");
+    c.use_sketch_options();
+    if (c.parse(argc, argv)) return 1;
+    if (c.args.size() < 2 || c.o("help").active) {
+        cout << "\nUsage:\n\n  mash dist [options] <reference> <query> [<query>] ...\n\n"
+                "Output fields: [reference-ID, query-ID, distance, p-value, shared-hashes].\n"
+                "Options: -l -t -v <max p> -d <max dist> -C and the sketch options of `mash sketch`.\n\n";
+        return 0;
+    }
+    const bool table = c.o("table").active, comment = c.o("comment").active;
+    const double p_max = c.o("pvalue").num, d_max = c.o("distance").num;
+    Params p;
+    if (sketch_parameter_setup(p, c)) return 1;
+    const string &file_ref = c.args[0];
+    const bool is_sketch = has_suffix(file_ref, kSuffix);
+    if (is_sketch) {
+        for (const char *o : {"kmer", "noncanonical", "protein", "alphabet"})
+            if (c.o(o).active) {
+                cerr << "ERROR: The option -" << c.o(o).id << " cannot be used when a sketch is provided; it is inherited from the sketch." << endl;
+                return 1;
+            }
+    } else {
+        cerr << "Sketching " << file_ref << " (provide sketch file made with \"mash sketch\" to skip)...";
+    }
+    Gpu gpu;
+    SketchSet ref;
+    init_from_files(gpu, ref, {file_ref}, p, is_sketch ? 1 : 0);
+    KmerWarning w;
+    if (is_sketch) {
+        p.sketch_size = ref.p.sketch_size;
+        p.kmer = ref.p.kmer;
+        p.noncanonical = ref.p.noncanonical;
+        p.preserve_case = ref.p.preserve_case;
+        p.seed = ref.p.seed;
+        set_alphabet(p, ref.p.alphabet);
+    } else {
+        w = scan_kmer_warning(ref);
+        cerr << "done.\n";
+    }
+    if (table) {
+        cout << "#query";
+        for (const Ref &r : ref.refs) cout << '\t' << r.name;
+        cout << endl;
+    }
+    vector<string> qfiles;
+    for (size_t i = 1; i < c.args.size(); i++) { if (c.o("list").active) split_file(c.args[i], qfiles); else qfiles.push_back(c.args[i]); }
+    SketchSet qry;
+    init_from_files(gpu, qry, qfiles, p, 0, true);
+    const uint64_t nref = ref.refs.size(), nq = qry.refs.size();
+    if (nref == 0 || nq == 0) return 0;
+    vector<uint64_t> len_ref, len_qry;
+    mg_table *tr = upload(gpu, ref, ref.p.sketch_size, &len_ref);
+    mg_table *tq = upload(gpu, qry, qry.p.sketch_size, &len_qry);
+    const double kspace = ref.kmer_space();
+    const uint64_t qblock = std::max<uint64_t>(1, (1ull << 24) / nref);
+    vector<mg_counts> counts;
+    vector<mg_pair> pairs;
+    for (uint64_t q0 = 0; q0 < nq; q0 += qblock) {
+        const uint64_t q1 = std::min(nq, q0 + qblock);
+        counts.resize((q1 - q0) * nref);
+        pairs.resize(counts.size());
+        if (mg_compare_rect_host(gpu.ctx, tr, tq, q0, q1, counts.data()) != MG_OK) { cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl; return 1; }
+        mg_finish_rect_host(counts.data(), len_ref.data(), nref, len_qry.data() + q0, q1 - q0, ref.p.kmer, kspace, d_max, p_max, pairs.data());
+        for (uint64_t q = q0; q < q1; q++) {                 // writeOutput, CommandDistance.cpp:247-304
+            if (table) cout << qry.refs[q].name;
+            for (uint64_t r = 0; r < nref; r++) {
+                const mg_pair &pr = pairs[(q - q0) * nref + r];
+                if (table) { cout << '\t'; if (pr.pass) cout << pr.distance; }
+                else if (pr.pass) print_pair_line(ref.refs[r], qry.refs[q], comment, pr);
+            }
+            if (table) cout << endl;
+        }
+    }
+    mg_table_free(tr);
+    mg_table_free(tq);
+    if (w.count > 0 && !p.reads) warn_kmer_size(ref, w);
+    return 0;
+}
+
+int cmd_triangle(int argc, const char **argv)
+{
+    Cmd c;
+    c.name = "triangle";
+    c.add("help", Opt::Boolean, "h");
+    c.add("list", Opt::Boolean, "l");
+    c.add("comment", Opt::Boolean, "C");
+    c.add("edge", Opt::Boolean, "E");
+    c.add("pvalue", Opt::Number, "v", "1.0", 0., 1.);
+    c.add("distance", Opt::Number, "d", "1.0", 0., 1.);
+    c.use_sketch_options();
+    if (c.parse(argc, argv)) return 1;
+    if (c.args.empty() || c.o("help").active) {
+        cout << "\nUsage:\n\n  mash triangle [options] <seq1> [<seq2>] ...\n\n"
+                "Lower-triangular distance matrix in relaxed Phylip format (or -E edge list).\n"
+                "Options: -l -C -E -v <max p> -d <max dist> and the sketch options of `mash sketch`.\n\n";
+        return 0;
+    }
+    const bool comment = c.o("comment").active;
+    bool edge = c.o("edge").active;
+    const double p_max = c.o("pvalue").num, d_max = c.o("distance").num;
+    if (c.o("pvalue").active || c.o("distance").active) edge = true;
+    Params p;
+    if (sketch_parameter_setup(p, c)) return 1;
+    if (c.args.size() == 1 && !c.o("list").active) p.concatenated = false;   // CommandTriangle.cpp:74-77
+    vector<string> files;
+    for (const string &a : c.args) { if (c.o("list").active) split_file(a, files); else files.push_back(a); }
+    Gpu gpu;
+    SketchSet set;
+    init_from_files(gpu, set, files, p, 1);
+    const KmerWarning w = scan_kmer_warning(set);
+    const uint64_t n = set.refs.size();
+    if (n == 0) return 0;
+    auto label = [&](const Ref &r) -> const string & { return comment ? r.comment : r.name; };
+    if (!edge) {
+        cout << '\t' << n << endl;
+        cout << label(set.refs[0]) << endl;
+    }
+    vector<uint64_t> lengths;
+    mg_table *t = upload(gpu, set, set.p.sketch_size, &lengths);
+    const double kspace = set.kmer_space();
+    double p_peak = 0;
+    vector<mg_counts> counts;
+    vector<mg_pair> pairs;
+    uint64_t r0 = 1;
+    while (r0 < n) {
+        uint64_t r1 = r0, npairs = 0;
+        while (r1 < n && (npairs == 0 || npairs + r1 <= (1ull << 24))) { npairs += r1; r1++; }
+        counts.resize(npairs);
+        pairs.resize(npairs);
+        if (mg_compare_tri_host(gpu.ctx, t, r0, r1, counts.data()) != MG_OK) { cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl; return 1; }
+        mg_finish_tri_host(counts.data(), lengths.data(), r0, r1, set.p.kmer, kspace, d_max, p_max, pairs.data());
+        uint64_t idx = 0;
+        for (uint64_t i = r0; i < r1; i++) {                 // writeOutput, CommandTriangle.cpp:159-198
+            const Ref &ref = set.refs[i];
+            if (!edge) cout << label(ref);
+            for (uint64_t j = 0; j < i; j++, idx++) {
+                const mg_pair &pr = pairs[idx];
+                if (edge) {
+                    if (pr.pass)
+                        cout << label(ref) << '\t' << label(set.refs[j]) << '\t' << pr.distance << '\t' << pr.p_value << '\t'
+                             << pr.numer << '/' << pr.denom << endl;
+                } else {
+                    cout << '\t' << pr.distance;
+                }
+                if (pr.p_value > p_peak) p_peak = pr.p_value;
+            }
+            if (!edge) cout << endl;
+        }
+        r0 = r1;
+    }
+    mg_table_free(t);
+    if (!edge) cerr << "Max p-value: " << p_peak << endl;
+    if (w.count > 0 && !p.reads) warn_kmer_size(set, w);
+    return 0;
+}
+
+void print_columns(const vector<vector<string>> &cols, int indent, int spacing, const char *missing)
+{
+    vector<size_t> width(cols.size(), 0);
+    for (size_t i = 0; i < cols.size(); i++)
+        for (const string &s : cols[i]) width[i] = std::max(width[i], std::max<size_t>(s.size(), 1));
+    for (size_t r = 0; r < cols[0].size(); r++) {
+        size_t offset = 0, target = indent;
+        for (size_t j = 0; j < cols.size(); j++) {
+            for (size_t k = offset; k < target; k++) cout << ' ';
+            const string text = cols[j][r].empty() ? string(missing) : cols[j][r];
+            cout << text;
+            offset = target + text.size();
+            target += width[j] + spacing;
+        }
+        cout << endl;
+    }
+}
+
+int cmd_info(int argc, const char **argv)
+{
+    Cmd c;
+    c.name = "info";
+    c.add("help", Opt::Boolean, "h");
+    c.add("header", Opt::Boolean, "H");
+    c.add("tabular", Opt::Boolean, "t");
+    c.add("counts", Opt::Boolean, "c");
+    c.add("dump", Opt::Boolean, "d");
+    if (c.parse(argc, argv)) return 1;
+    if (c.args.size() != 1 || c.o("help").active) {
+        cout << "\nUsage:\n\n  mash info [options] <sketch>\n\nOptions: -H (header only) -t (tabular) -c (count histograms) -d (JSON dump)\n\n";
+        return 0;
+    }
+    const bool header = c.o("header").active, tabular = c.o("tabular").active, counts = c.o("counts").active, dump = c.o("dump").active;
+    auto incompatible = [](const char *a, const char *b) { cerr << "ERROR: The options " << a << " and " << b << " are incompatible." << endl; return 1; };
+    if (header && tabular) return incompatible("-H", "-t");
+    if (header && counts) return incompatible("-H", "-c");
+    if (tabular && counts) return incompatible("-t", "-c");
+    if (dump && tabular) return incompatible("-d", "-t");
+    if (dump && header) return incompatible("-d", "-H");
+    if (dump && counts) return incompatible("-d", "-c");
+    const string &file = c.args[0];
+    if (!has_suffix(file, kSuffix)) { cerr << "ERROR: The file \"" << file << "\" does not look like a sketch." << endl; return 1; }
+    mshio::File f;
+    const string e = mshio::read_msh(file, f, header);
+    if (!e.empty()) { cerr << "ERROR: " << e << endl; return 1; }
+    Params p;
+    params_from_header(p, f.header);
+    const uint64_t nref = header ? f.header.reference_count : f.references.size();
+    if (counts) {
+        if (f.references.empty()) { cerr << "ERROR: Sketch file contains no sketches" << endl; return 1; }
+        if (!f.header.has_counts) { cerr << "ERROR: Sketch file does not have hash counts. Re-sketch with -M to use this feature." << endl; return 1; }
+        cout << "#Sketch\tBin\tFrequency" << endl;
+        for (const auto &r : f.references) {
+            std::map<uint32_t, uint64_t> hist;
+            for (uint32_t v : r.counts) hist[v]++;
+            for (const auto &kv : hist) cout << r.name << '\t' << kv.first << '\t' << kv.second << endl;
+        }
+        return 0;
+    }
+    if (dump) {                                              // writeJson, CommandInfo.cpp:222-299 (byte for byte)
+        cout << "{" << endl;
+        cout << "	\"kmer\" : " << p.kmer << ',' << endl;
+        cout << "	\"alphabet\" : \"" << p.alphabet << "\"," << endl;
+        cout << "	\"preserveCase\" : " << (p.preserve_case ? "true" : "false") << ',' << endl;
+        cout << "	\"canonical\" : " << (p.noncanonical ? "false" : "true") << ',' << endl;
+        cout << "	\"sketchSize\" : " << p.sketch_size << ',' << endl;
+        cout << "	\"hashType\" : \"MurmurHash3_x64_128\"," << endl;
+        cout << "	\"hashBits\" : " << (p.use64 ? 64 : 32) << ',' << endl;
+        cout << "	\"hashSeed\" : " << p.seed << ',' << endl;
+        cout << " 	\"sketches\" :" << endl;
+        cout << "	[" << endl;
+        for (size_t i = 0; i < f.references.size(); i++) {
+            const auto &r = f.references[i];
+            cout << "		{" << endl;
+            cout << "			\"name\" : \"" << r.name << "\"," << endl;
+            cout << "			\"length\" : " << r.length << ',' << endl;
+            cout << "			\"comment\" : \"" << r.comment << "\"," << endl;
+            cout << "			\"hashes\" :" << endl;
+            cout << "			[" << endl;
+            for (size_t j = 0; j < r.hashes.size(); j++) {
+                cout << "				" << r.hashes[j];
+                if (j + 1 < r.hashes.size()) cout << ',';
+                cout << endl;
+            }
+            cout << "			]" << endl;
+            if (r.counts_sorted) {
+                cout << "			\"counts\" :" << endl;
+                cout << "			[" << endl;
+                for (size_t j = 0; j < r.counts.size(); j++) {
+                    cout << "				" << r.counts[j];
+                    if (j + 1 < r.hashes.size()) cout << ',';
+                    cout << endl;
+                }
+                cout << "			]" << endl;
+            }
+            cout << (i + 1 < f.references.size() ? "		}," : "		}") << endl;
+        }
+        cout << "	]" << endl;
+        cout << "}" << endl;
+        return 0;
+    }
+    if (tabular) {
+        cout << "#Hashes\tLength\tID\tComment" << endl;
+    } else {
+        cout << "Header:" << endl;
+        cout << "  Hash function (seed):          MurmurHash3_x64_128 (" << p.seed << ")" << endl;
+        cout << "  K-mer size:                    " << p.kmer << " (" << (p.use64 ? "64" : "32") << "-bit hashes)" << endl;
+        cout << "  Alphabet:                      " << p.alphabet << (p.noncanonical ? "" : " (canonical)") << (p.preserve_case ? " (case-sensitive)" : "") << endl;
+        cout << "  Target min-hashes per sketch:  " << p.sketch_size << endl;
+        cout << "  Sketches:                      " << nref << endl;
+    }
+    if (!header) {
+        vector<vector<string>> cols(4);
+        if (!tabular) {
+            cout << endl << "Sketches:" << endl;
+            cols[0].push_back("[Hashes]"); cols[1].push_back("[Length]"); cols[2].push_back("[ID]"); cols[3].push_back("[Comment]");
+        }
+        for (const auto &r : f.references) {
+            if (tabular) cout << r.hashes.size() << '\t' << r.length << '\t' << r.name << '\t' << r.comment << endl;
+            else {
+                cols[0].push_back(std::to_string(r.hashes.size()));
+                cols[1].push_back(std::to_string(r.length));
+                cols[2].push_back(r.name);
+                cols[3].push_back(r.comment);
+            }
+        }
+        if (!tabular) print_columns(cols, 2, 2, "-");
+    }
+    return 0;
+}
+
+int cmd_paste(int argc, const char **argv)
+{
+    Cmd c;
+    c.name = "paste";
+    c.add("help", Opt::Boolean, "h");
+    c.add("list", Opt::Boolean, "l");
+    if (c.parse(argc, argv)) return 1;
+    if (c.args.size() < 2 || c.o("help").active) {
+        cout << "\nUsage:\n\n  mash paste [options] <out_prefix> <sketch> [<sketch>] ...\n\nOptions: -l (inputs are lists of file names)\n\n";
+        return 0;
+    }
+    vector<string> files;
+    for (size_t i = 1; i < c.args.size(); i++) { if (c.o("list").active) split_file(c.args[i], files); else files.push_back(c.args[i]); }
+    for (const string &f : files)
+        if (!has_suffix(f, kSuffix)) { cerr << "ERROR: The file \"" << f << "\" does not look like a sketch." << endl; return 1; }
+    SketchSet set;
+    for (size_t i = 0; i < files.size(); i++) load_msh_into(set, files[i], i == 0);
+    string out = c.args[0];
+    if (!has_suffix(out, kSuffix)) out += kSuffix;
+    if (access(out.c_str(), F_OK) != -1) { cerr << "ERROR: \"" << out << "\" exists; remove to write." << endl; exit(1); }
+    cerr << "Writing " << out << "..." << endl;
+    const string e = write_set(set, out);
+    if (!e.empty()) { cerr << "ERROR: " << e << endl; return 1; }
+    return 0;
+}
+
+// test/interchange helper: rebuild a .msh from the JSON `mash info -d` prints (no GPU)
+int cmd_json2msh(int argc, const char **argv)
+{
+    if (argc != 2) { cerr << "usage: mash json2msh <info-dump.json> <out.msh>" << endl; return 1; }
+    std::ifstream in(argv[0]);
+    if (in.fail()) { cerr << "ERROR: Could not open " << argv[0] << endl; return 1; }
+    string text((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    auto find_value = [&](size_t from, const string &key, size_t *at) -> string {
+        const string pat = "\"" + key + "\" :";
+        size_t p = text.find(pat, from);
+        if (p == string::npos) { *at = string::npos; return ""; }
+        p += pat.size();
+        while (p < text.size() && (text[p] == ' ' || text[p] == '\n' || text[p] == '\t')) p++;
+        size_t e;
+        string v;
+        if (text[p] == '"') { e = text.find("\",\n", p + 1); if (e == string::npos) e = text.find("\"\n", p + 1); v = text.substr(p + 1, e - p - 1); }
+        else { e = text.find_first_of(",\n", p); v = text.substr(p, e - p); }
+        *at = e;
+        return v;
+    };
+    size_t at;
+    mshio::File f;
+    f.header.kmer_size = (uint32_t)std::stoul(find_value(0, "kmer", &at));
+    f.header.alphabet = find_value(0, "alphabet", &at);
+    f.header.has_alphabet = true;
+    f.header.preserve_case = find_value(0, "preserveCase", &at) == "true";
+    f.header.noncanonical = find_value(0, "canonical", &at) != "true";
+    f.header.sketch_size = (uint32_t)std::stoul(find_value(0, "sketchSize", &at));
+    f.header.seed = (uint32_t)std::stoul(find_value(0, "hashSeed", &at));
+    f.header.concatenated = true;
+    size_t pos = text.find("\"sketches\"");
+    while (true) {
+        size_t a1;
+        const string name = find_value(pos, "name", &a1);
+        if (a1 == string::npos) break;
+        mshio::Reference r;
+        r.name = name;
+        r.length = std::stoull(find_value(a1, "length", &a1));
+        r.comment = find_value(a1, "comment", &a1);
+        size_t hb = text.find('[', text.find("\"hashes\"", a1)), he = text.find(']', hb);
+        const char *q = text.c_str() + hb + 1, *qe = text.c_str() + he;
+        while (q < qe) {
+            while (q < qe && (*q < '0' || *q > '9')) q++;
+            if (q >= qe) break;
+            char *end;
+            r.hashes.push_back(strtoull(q, &end, 10));
+            q = end;
+        }
+        f.references.push_back(std::move(r));
+        pos = he;
+    }
+    const string e = mshio::write_msh(argv[1], f);
+    if (!e.empty()) { cerr << "ERROR: " << e << endl; return 1; }
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, const char **argv)
+{
+    const string usage =
+        "\nMash (MI355X hot path), commands:\n\n  sketch    Create sketches (reduced representations for fast operations).\n"
+        "  dist      Estimate the distance of query sequences to references.\n"
+        "  triangle  Estimate a lower-triangular distance matrix.\n  info      Display information about sketch files.\n"
+        "  paste     Create a single sketch file from multiple sketch files.\n\n";
+    if (argc < 2) { cout << usage; return 0; }
+    const string cmd = argv[1];
+    if (cmd == "sketch") return cmd_sketch(argc - 2, argv + 2);
+    if (cmd == "dist") return cmd_dist(argc - 2, argv + 2);
+    if (cmd == "triangle") return cmd_triangle(argc - 2, argv + 2);
+    if (cmd == "info") return cmd_info(argc - 2, argv + 2);
+    if (cmd == "paste") return cmd_paste(argc - 2, argv + 2);
+    if (cmd == "json2msh") return cmd_json2msh(argc - 2, argv + 2);
+    if (cmd == "--version") { cout << "2.3-mi355x" << endl; return 0; }
+    cerr << "ERROR: Unknown command: " << cmd << endl;
+    cout << usage;
+    return 1;
+}

@@ -1,0 +1,71 @@
+// mshio_c.cpp — tiny C surface over the .msh codec and the fastx reader, for the CPU tests
+// (ctypes).  Host-only; no GPU dependency.
+#include <cstring>
+#include <string>
+
+#include "fastx.h"
+#include "msh_file.h"
+
+extern "C" {
+
+// parse -> re-serialize -> parse again; returns 0 when both parses agree field by field
+int mshio_roundtrip_check(const char *path)
+{
+    mshio::File a, b;
+    if (!mshio::read_msh(path, a).empty()) return -1;
+    std::vector<uint64_t> words;
+    if (!mshio::serialize_msh(a, words).empty()) return -2;
+    if (!mshio::parse_msh(reinterpret_cast<const uint8_t *>(words.data()), words.size() * 8, b, false, 0).empty()) return -3;
+    if (a.references.size() != b.references.size()) return 1;
+    if (a.header.kmer_size != b.header.kmer_size || a.header.sketch_size != b.header.sketch_size ||
+        a.header.seed != b.header.seed || a.header.alphabet != b.header.alphabet ||
+        a.header.noncanonical != b.header.noncanonical || a.header.preserve_case != b.header.preserve_case)
+        return 2;
+    for (size_t i = 0; i < a.references.size(); i++) {
+        const auto &x = a.references[i], &y = b.references[i];
+        if (x.name != y.name || x.comment != y.comment || x.length != y.length || x.hashes != y.hashes || x.counts != y.counts)
+            return 3;
+    }
+    return 0;
+}
+
+// parse a raw message image (used with hand-built multi-segment / far-pointer messages)
+int mshio_parse_summary(const uint8_t *data, uint64_t size, uint32_t *kmer, uint32_t *sketch_size, uint32_t *seed,
+                        uint64_t *nref, uint64_t *first_hash, uint64_t *last_hash, char *name0, uint64_t name_cap)
+{
+    mshio::File f;
+    const std::string e = mshio::parse_msh(data, size, f, false, 0);
+    if (!e.empty()) return -1;
+    *kmer = f.header.kmer_size;
+    *sketch_size = f.header.sketch_size;
+    *seed = f.header.seed;
+    *nref = f.references.size();
+    *first_hash = *last_hash = 0;
+    if (!f.references.empty()) {
+        const auto &r = f.references.back();
+        if (!r.hashes.empty()) { *first_hash = r.hashes.front(); *last_hash = r.hashes.back(); }
+        strncpy(name0, f.references[0].name.c_str(), name_cap - 1);
+        name0[name_cap - 1] = 0;
+    }
+    return 0;
+}
+
+// count records / total sequence bytes of a fasta/fastq file the way kseq would
+long fastx_count(const char *path, long min_len, unsigned long long *total_bases, unsigned long long *name_bytes)
+{
+    fastx::Reader rd;
+    if (!rd.open(path)) return -10;
+    fastx::Record rec;
+    long l, n = 0;
+    *total_bases = 0;
+    *name_bytes = 0;
+    while ((l = rd.next(rec)) >= 0) {
+        if (l < min_len) continue;
+        n++;
+        *total_bases += (unsigned long long)l;
+        *name_bytes += rec.name.size() + rec.comment.size();
+    }
+    return l == -1 ? n : l;
+}
+
+}

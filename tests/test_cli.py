@@ -1,0 +1,211 @@
+"""Host layer: .msh codec (no libcapnp), kseq-compatible reader, `mash` CLI.
+CPU tests cover the codec and the GPU-free commands (info, paste); `-m gpu` tests run the
+reference's own `make test` recipe (Makefile.in:94-111) through the GPU CLI."""
+import ctypes as C
+import gzip
+import os
+import shutil
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from mash_amd import synth
+from tests import helpers
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MASH = os.path.join(ROOT, "mash_amd", "bin", "mash")
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as g
+    if not os.path.exists(MASH) or not os.path.exists(os.path.join(ROOT, "mash_amd", "libmshio.so")):
+        g.build()
+    return True
+
+
+def run(*args, check=True, cwd=None):
+    r = subprocess.run([MASH, *args], capture_output=True, text=True, cwd=cwd)
+    if check:
+        assert r.returncode == 0, r.stderr
+    return r
+
+
+def test_info_dump_reproduces_golden_json(built, tmp_path):
+    """json -> .msh (our writer) -> `mash info -d` (our reader) is byte-identical to the
+    reference's goldens test/ref/genomes.json and test/ref/reads.json."""
+    for name in ("genomes", "reads"):
+        msh = str(tmp_path / f"{name}.msh")
+        run("json2msh", os.path.join(GOLD, f"{name}.json"), msh)
+        out = run("info", "-d", msh).stdout
+        assert out == open(os.path.join(GOLD, f"{name}.json")).read()
+
+
+def test_info_header_tabular_and_paste(built, tmp_path):
+    g, r = str(tmp_path / "genomes.msh"), str(tmp_path / "reads.msh")
+    run("json2msh", os.path.join(GOLD, "genomes.json"), g)
+    run("json2msh", os.path.join(GOLD, "reads.json"), r)
+    hdr = run("info", "-H", g).stdout
+    assert "K-mer size:                    21 (64-bit hashes)" in hdr
+    assert "Alphabet:                      ACGT (canonical)" in hdr
+    assert "Sketches:                      3" in hdr
+    tab = run("info", "-t", g).stdout.splitlines()
+    assert tab[0] == "#Hashes\tLength\tID\tComment"
+    assert tab[1].startswith("1000\t4639675\tgenome1.fna\tgi|49175990|")
+    run("paste", str(tmp_path / "all"), g, r)
+    tab = run("info", "-t", str(tmp_path / "all.msh")).stdout.splitlines()
+    assert len(tab) == 5 and tab[4].startswith("1000\t502359\treads\t[2000 seqs] SRR7885321.1 1 length=302 [...]")
+    again = run("paste", str(tmp_path / "all"), g, r, check=False)       # refuses to overwrite (CommandPaste.cpp:79-83)
+    assert again.returncode == 1 and "exists; remove to write." in again.stderr
+    bad = run("info", str(tmp_path / "nosuffix"), check=False)
+    assert bad.returncode == 1 and "does not look like a sketch" in bad.stderr
+    inc = run("info", "-H", "-t", g, check=False)
+    assert inc.returncode == 1 and "incompatible" in inc.stderr
+
+
+def test_msh_wire_layout_and_foreign_encodings(built, tmp_path):
+    """Wire-level checks of the hand-written codec: slot layout, seed
+    default XOR, and reading what libcapnp may emit (multi-segment, far / double-far pointers)."""
+    lib = C.CDLL(os.path.join(ROOT, "mash_amd", "libmshio.so"))
+    g = str(tmp_path / "genomes.msh")
+    run("json2msh", os.path.join(GOLD, "genomes.json"), g)
+    assert lib.mshio_roundtrip_check(g.encode()) == 0
+    raw = open(g, "rb").read()
+    words = np.frombuffer(raw, dtype="<u8").copy()
+    assert words[0] == (len(words) - 1) << 32                  # 1 segment, its size in words
+    seg = words[1:]
+    rootp = int(seg[0])
+    assert rootp & 3 == 0 and (rootp >> 32) & 0xFFFF == 3 and rootp >> 48 == 4      # MinHash: 3 data, 4 pointers
+    assert int(seg[1]) & 0xFFFFFFFF == 21 and int(seg[2]) & 0xFFFFFFFF == 1000       # kmerSize, minHashesPerWindow
+    assert int(seg[3]) >> 32 == 0                               # hashSeed 42 is stored XOR 42
+    assert int(seg[4]) != 0 and int(seg[7]) == 0                # seed 42 -> referenceListOld (p0), referenceList null
+
+    def summary(buf):
+        kmer, ssz, seed = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        nref, h0, h1 = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        name = C.create_string_buffer(256)
+        rc = lib.mshio_parse_summary(buf, C.c_uint64(len(buf)), C.byref(kmer), C.byref(ssz), C.byref(seed),
+                                     C.byref(nref), C.byref(h0), C.byref(h1), name, C.c_uint64(256))
+        return rc, kmer.value, ssz.value, seed.value, nref.value, h0.value, h1.value, name.value.decode()
+
+    want = summary(raw)
+    assert want[:5] == (0, 21, 1000, 42, 3) and want[7] == "genome1.fna"
+    gh, _, _ = helpers.load_golden_genomes()
+    assert want[5] == int(gh[2][0]) and want[6] == int(gh[2][-1])
+    # two segments: root is a FAR pointer to a landing pad at word 0 of segment 1
+    far = struct.pack("<Q", 2 | (0 << 3) | (1 << 32))
+    seg1 = seg.tobytes()                                        # word 0 (the old root pointer) is the landing pad
+    hdr = struct.pack("<IIII", 1, 1, len(seg), 0)
+    assert summary(hdr + far + seg1) == want
+    # three segments: DOUBLE-far: pad in segment 2 = {far -> seg 1 word 1, tag struct(3,4)}
+    dfar = struct.pack("<Q", 2 | (1 << 2) | (0 << 3) | (2 << 32))
+    pad = struct.pack("<QQ", 2 | (1 << 3) | (1 << 32), 0 | (3 << 32) | (4 << 48))
+    hdr3 = struct.pack("<IIII", 2, 1, len(seg), 2)
+    assert summary(hdr3 + dfar + seg1 + pad) == want
+    # non-default seed moves the list to referenceList (p3) and stores seed ^ 42
+    js = open(os.path.join(GOLD, "reads.json")).read().replace('"hashSeed" : 42', '"hashSeed" : 7')
+    p = tmp_path / "seed7.json"
+    p.write_text(js)
+    m7 = str(tmp_path / "seed7.msh")
+    run("json2msh", str(p), m7)
+    w7 = np.frombuffer(open(m7, "rb").read(), dtype="<u8")[1:]
+    assert int(w7[3]) >> 32 == (7 ^ 42) and int(w7[4]) == 0 and int(w7[7]) != 0
+    assert '"hashSeed" : 7' in run("info", "-d", m7).stdout
+    # truncated / corrupt files are errors, not crashes
+    assert summary(raw[: len(raw) // 2 // 8 * 8])[0] == -1
+    assert summary(b"\x00" * 16)[0] in (0, -1)
+
+
+def test_fastx_reader_has_kseq_semantics(built, tmp_path):
+    lib = C.CDLL(os.path.join(ROOT, "mash_amd", "libmshio.so"))
+    lib.fastx_count.restype = C.c_long
+    tb, nb = C.c_ulonglong(), C.c_ulonglong()
+    n = lib.fastx_count(os.path.join(GOLD, "reads1.fastq.gz").encode(), C.c_long(0), C.byref(tb), C.byref(nb))
+    recs = helpers.read_fastx(os.path.join(GOLD, "reads1.fastq.gz"))
+    assert n == len(recs) == 1000 and tb.value == sum(len(r[2]) for r in recs)
+    fa = tmp_path / "x.fa"
+    fa.write_bytes(b"junk before\n>s1 first comment\r\nACGT\nAC GT\n\n>s2\nAAAA>s3 c\nTT\n>s4 tail")
+    n = lib.fastx_count(str(fa).encode(), C.c_long(0), C.byref(tb), C.byref(nb))
+    assert n == 4 and tb.value == 8 + 4 + 2 + 0                  # '>' mid-line starts a record, as in kseq
+    fq = tmp_path / "bad.fq"
+    fq.write_bytes(b"@r1\nACGT\n+\nII\n")
+    assert lib.fastx_count(str(fq).encode(), C.c_long(0), C.byref(tb), C.byref(nb)) == -2
+
+
+# ---------------------------------------------------------------------------------- GPU
+
+@pytest.mark.gpu
+def test_make_test_recipe_on_gpu(built, tmp_path, oracle):
+    """The reference's `make test` (Makefile.in:94-111) with what the mount provides:
+    sketch reads -> info -d == reads.json (hashes/name/length/comment); dist == genomes.dist."""
+    for f in ("reads1.fastq", "reads2.fastq"):
+        with gzip.open(os.path.join(GOLD, f + ".gz"), "rb") as fi, open(tmp_path / f, "wb") as fo:
+            shutil.copyfileobj(fi, fo)
+    r = run("sketch", "-r", "-I", "reads", "reads1.fastq", "reads2.fastq", "-o", "reads.msh", cwd=tmp_path)
+    assert "Writing to reads.msh..." in r.stderr
+    dump = run("info", "-d", "reads.msh", cwd=tmp_path).stdout
+    assert dump == open(os.path.join(GOLD, "reads.json")).read()
+    run("json2msh", os.path.join(GOLD, "genomes.json"), "genomes.msh", cwd=tmp_path)
+    out = run("dist", "genomes.msh", "reads.msh", cwd=tmp_path).stdout
+    assert out == open(os.path.join(GOLD, "genomes.dist")).read()
+    # gz input, table output, filters
+    out_t = run("dist", "-t", "genomes.msh", "reads.msh", cwd=tmp_path).stdout.splitlines()
+    assert out_t[0] == "#query\tgenome1.fna\tgenome2.fna\tgenome3.fna" and out_t[1] == "reads\t0.12101\t0.12827\t0.12101"
+    out_d = run("dist", "-d", "0.125", "genomes.msh", "reads.msh", cwd=tmp_path).stdout.splitlines()
+    assert len(out_d) == 2 and all("0.12101" in l for l in out_d)
+
+
+@pytest.mark.gpu
+def test_sketch_and_triangle_cli_vs_oracle(built, tmp_path, oracle):
+    rng = np.random.default_rng(3)
+    genomes = [synth._rand_dna(rng, 40000) for _ in range(5)]
+    genomes[1] = genomes[0][:20000] + genomes[1][20000:]              # related pair
+    genomes[4] = genomes[0]                                           # identical pair
+    fa = tmp_path / "multi.fa"
+    with open(fa, "wb") as f:
+        for i, g in enumerate(genomes):
+            f.write(b">seq%d comment %d\n" % (i, i))
+            for o in range(0, len(g), 70):
+                f.write(g[o:o + 70] + b"\n")
+        f.write(b">tiny\nACGT\n")
+    # -i : one sketch per record (records < k skipped)
+    run("sketch", "-i", "-s", "400", "-o", "ind", "multi.fa", cwd=tmp_path)
+    tab = run("info", "-t", "ind.msh", cwd=tmp_path).stdout.splitlines()[1:]
+    assert [l.split("\t")[2] for l in tab] == ["seq%d" % i for i in range(5)]
+    assert [l.split("\t")[1] for l in tab] == ["40000"] * 5
+    p = oracle.params(k=21, s=400)
+    import json
+    dump = json.loads(run("info", "-d", "ind.msh", cwd=tmp_path).stdout)
+    for i, g in enumerate(genomes):
+        h, _, _, _, _ = oracle.sketch_records([g], p)
+        assert dump["sketches"][i]["hashes"] == [int(x) for x in h]
+        assert dump["sketches"][i]["comment"] == "comment %d" % i
+    # concatenated default: one sketch, comment "[5 seqs] seq0 comment 0 [...]", length = sum of records >= k
+    run("sketch", "-s", "400", "-o", "cat", "multi.fa", cwd=tmp_path)
+    t = run("info", "-t", "cat.msh", cwd=tmp_path).stdout.splitlines()[1].split("\t")
+    assert t[1] == "200000" and t[2] == "multi.fa" and t[3] == "[5 seqs] seq0 comment 0 [...]"
+    # triangle on the single multi-fasta (=> per-sequence sketches, CommandTriangle.cpp:74-77)
+    r = run("triangle", "-s", "400", "multi.fa", cwd=tmp_path)
+    lines = r.stdout.splitlines()
+    assert lines[0] == "\t5" and lines[1] == "seq0"
+    kspace = 4.0 ** 21
+    sk = [oracle.sketch_records([g], p)[0] for g in genomes]
+    for i in range(1, 5):
+        f = lines[1 + i].split("\t")
+        assert f[0] == "seq%d" % i and len(f) == i + 1
+        for j in range(i):
+            o = oracle.compare(sk[i], sk[j], 40000, 40000, 400, 21, kspace)
+            assert f[1 + j] == "%g" % o.distance
+    assert "Max p-value:" in r.stderr
+    assert lines[5].split("\t")[1] == "0"                            # identical pair
+    # edge list agrees with dist on the same sketches
+    e = run("triangle", "-E", "ind.msh", cwd=tmp_path).stdout.splitlines()
+    d = run("dist", "ind.msh", "ind.msh", cwd=tmp_path).stdout.splitlines()
+    dd = {(l.split("\t")[0], l.split("\t")[1]): l.split("\t")[2:] for l in d}
+    assert len(e) == 10
+    for l in e:
+        a, b, *rest = l.split("\t")
+        assert dd[(b, a)] == rest
