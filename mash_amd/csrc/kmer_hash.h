@@ -1,7 +1,7 @@
 // kmer_hash.h — per-lane k-mer state for the sketch kernel (host+device).
 //
 // One lane walks a run of consecutive bases.  It keeps, in registers:
-//   * the ASCII text of the current forward k-mer as little-endian 64-bit words
+//   * the ASCII text of the current forward k-mer as little-endian 32-bit words
 //     (byte i of the k-mer = byte i of the 32-byte window) — this is exactly the
 //     buffer MurmurHash3_x64_128 reads in the reference (hash.cpp:10-38 hashes the
 //     k ASCII bytes, MurmurHash3.cpp:60-63 loads blocks little-endian);
@@ -13,7 +13,11 @@
 //   * the count of consecutive in-alphabet bytes ending at the current byte: a
 //     k-mer is valid iff all its k bytes are in the alphabet (Sketch.cpp:544-567).
 // Everything is templated on K so the window words, shifts and the murmur
-// block/tail structure are static.
+// block/tail structure are static.  The arithmetic is written on 32-bit halves with
+// explicit byte/bit aligns because gfx950 integer VALU issue is the kernel's limiter
+// (~4.3 cycles per wave64 instruction, tools/ubench_valu.hip): a 64-bit rotate is two
+// v_alignbit, a window roll one v_alignbyte per dword, a 64x64 multiply one
+// v_mad_u64_u32 + two v_mul_lo_u32 + one v_add3.
 #pragma once
 #include <stdint.h>
 
@@ -25,46 +29,93 @@
 
 namespace mg {
 
-MG_HD uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
-
-MG_HD uint64_t fmix64(uint64_t k)
+// ({hi,lo} >> (8*n)) & 0xFFFFFFFF, n in 0..3
+MG_HD uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t n)
 {
-    k ^= k >> 33; k *= 0xff51afd7ed558ccdULL;
-    k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL;
-    k ^= k >> 33;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbyte(hi, lo, n);
+#else
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * n));
+#endif
+}
+
+// ({hi,lo} >> n) & 0xFFFFFFFF, n in 0..31
+MG_HD uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t n)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, n);
+#else
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> n);
+#endif
+}
+
+struct u64x2 {               // a 64-bit value as two 32-bit halves
+    uint32_t lo, hi;
+};
+
+MG_HD u64x2 make64(uint64_t v) { return {(uint32_t)v, (uint32_t)(v >> 32)}; }
+MG_HD uint64_t to64(u64x2 v) { return ((uint64_t)v.hi << 32) | v.lo; }
+
+template <int R>
+MG_HD u64x2 rotl64h(u64x2 x)
+{
+    static_assert(R > 0 && R < 64 && R != 32, "rotation");
+    if (R < 32) return {alignbit(x.lo, x.hi, 32 - R), alignbit(x.hi, x.lo, 32 - R)};
+    return {alignbit(x.hi, x.lo, 64 - R), alignbit(x.lo, x.hi, 64 - R)};
+}
+
+MG_HD u64x2 mul64c(u64x2 x, uint64_t c)
+{
+    const uint32_t cl = (uint32_t)c, ch = (uint32_t)(c >> 32);
+    const uint64_t p = (uint64_t)x.lo * cl;                       // v_mad_u64_u32
+    return {(uint32_t)p, (uint32_t)(p >> 32) + x.lo * ch + x.hi * cl};
+}
+
+MG_HD u64x2 add64(u64x2 a, u64x2 b) { return make64(to64(a) + to64(b)); }
+MG_HD u64x2 xor64(u64x2 a, u64x2 b) { return {a.lo ^ b.lo, a.hi ^ b.hi}; }
+
+MG_HD u64x2 fmix64h(u64x2 k)
+{
+    k.lo ^= k.hi >> 1;                                            // k ^= k >> 33
+    k = mul64c(k, 0xff51afd7ed558ccdULL);
+    k.lo ^= k.hi >> 1;
+    k = mul64c(k, 0xc4ceb9fe1a85ec53ULL);
+    k.lo ^= k.hi >> 1;
     return k;
 }
 
-// MurmurHash3_x64_128 (MurmurHash3.cpp:255-335) of the K bytes held in w[0..3]
-// (little-endian words, bytes >= K are zero).  Returns h1 (the only half getHash
+// MurmurHash3_x64_128 (MurmurHash3.cpp:255-335) of the K bytes held in w[0..7]
+// (little-endian dwords, bytes >= K are zero).  Returns h1 (the only half getHash
 // consumes, hash.cpp:28-35); h2 still has to be carried (h1 += h2 at the end).
 template <int K>
-MG_HD uint64_t murmur3_h1(const uint64_t w[4], uint32_t seed)
+MG_HD uint64_t murmur3_h1(const uint32_t w[8], uint32_t seed)
 {
     const uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
-    uint64_t h1 = seed, h2 = seed;
+    u64x2 h1 = {seed, 0}, h2 = {seed, 0};
     constexpr int NB = K / 16, REM = K & 15;
 #pragma unroll
     for (int i = 0; i < NB; i++) {
-        uint64_t k1 = w[2 * i], k2 = w[2 * i + 1];
-        k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
-        h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
-        k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
-        h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+        u64x2 k1 = {w[4 * i], w[4 * i + 1]}, k2 = {w[4 * i + 2], w[4 * i + 3]};
+        k1 = mul64c(k1, c1); k1 = rotl64h<31>(k1); k1 = mul64c(k1, c2); h1 = xor64(h1, k1);
+        h1 = rotl64h<27>(h1); h1 = add64(h1, h2);
+        h1 = make64(to64(h1) * 5 + 0x52dce729);
+        k2 = mul64c(k2, c2); k2 = rotl64h<33>(k2); k2 = mul64c(k2, c1); h2 = xor64(h2, k2);
+        h2 = rotl64h<31>(h2); h2 = add64(h2, h1);
+        h2 = make64(to64(h2) * 5 + 0x38495ab5);
     }
     if (REM > 8) {
-        uint64_t k2 = w[(2 * NB + 1) & 3];
-        k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+        u64x2 k2 = {w[(4 * NB + 2) & 7], w[(4 * NB + 3) & 7]};
+        k2 = mul64c(k2, c2); k2 = rotl64h<33>(k2); k2 = mul64c(k2, c1); h2 = xor64(h2, k2);
     }
     if (REM > 0) {
-        uint64_t k1 = w[(2 * NB) & 3];
-        k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+        u64x2 k1 = {w[(4 * NB) & 7], w[(4 * NB + 1) & 7]};
+        k1 = mul64c(k1, c1); k1 = rotl64h<31>(k1); k1 = mul64c(k1, c2); h1 = xor64(h1, k1);
     }
-    h1 ^= (uint64_t)K; h2 ^= (uint64_t)K;
-    h1 += h2; h2 += h1;
-    h1 = fmix64(h1); h2 = fmix64(h2);
-    h1 += h2;
-    return h1;
+    h1.lo ^= (uint32_t)K; h2.lo ^= (uint32_t)K;
+    h1 = add64(h1, h2); h2 = add64(h2, h1);
+    h1 = fmix64h(h1); h2 = fmix64h(h2);
+    h1 = add64(h1, h2);
+    return to64(h1);
 }
 
 // Case folding exactly as Sketch.cpp:524-530: only a..z are changed.
@@ -72,18 +123,18 @@ MG_HD uint32_t fold_upper(uint32_t c) { return c - (((c - 97u) < 26u) ? 32u : 0u
 
 template <int K, bool CANON>
 struct KmerRoller {
-    static constexpr int NW = (K + 7) / 8;                  // window words in use
-    static constexpr int TOPB = (K - 1) & 7;                // byte lane of k-mer byte K-1 in its word
-    uint64_t fw[4];      // forward ASCII window
-    uint64_t rw[4];      // reverse-complement ASCII window (CANON only)
-    uint64_t f2, r2;     // 2-bit packed strands (CANON only), first base most significant
-    uint32_t run;        // consecutive valid bytes ending here (saturates at K)
+    static constexpr int NW = (K + 3) / 4;                  // window dwords in use
+    static constexpr int TOPB = (K - 1) & 3;                // byte lane of k-mer byte K-1 in its dword
+    uint32_t fw[8];      // forward ASCII window
+    uint32_t rw[8];      // reverse-complement ASCII window (CANON only)
+    u64x2 f2, r2;        // 2-bit packed strands (CANON only), first base most significant
+    uint32_t run;        // consecutive valid bytes ending here
 
     MG_HD void reset()
     {
 #pragma unroll
-        for (int i = 0; i < 4; i++) { fw[i] = 0; rw[i] = 0; }
-        f2 = r2 = 0; run = 0;
+        for (int i = 0; i < 8; i++) { fw[i] = 0; rw[i] = 0; }
+        f2 = {0, 0}; r2 = {0, 0}; run = 0;
     }
 
     // Push one byte: `c` is the byte to hash (already case-folded), `valid` whether it
@@ -93,19 +144,27 @@ struct KmerRoller {
     {
         // forward: drop byte 0, append c as byte K-1
 #pragma unroll
-        for (int i = 0; i < NW - 1; i++) fw[i] = (fw[i] >> 8) | (fw[i + 1] << 56);
-        fw[NW - 1] = (fw[NW - 1] >> 8) | ((uint64_t)c << (8 * TOPB));
+        for (int i = 0; i < NW - 1; i++) fw[i] = alignbyte(fw[i + 1], fw[i], 1);
+        if (TOPB == 0) fw[NW - 1] = c;
+        else fw[NW - 1] = (fw[NW - 1] >> 8) | (c << (8 * TOPB));
         if (CANON) {
             // reverse complement: prepend comp as byte 0, drop byte K
 #pragma unroll
-            for (int i = NW - 1; i > 0; i--) rw[i] = (rw[i] << 8) | (rw[i - 1] >> 56);
-            rw[0] = (rw[0] << 8) | (uint64_t)comp;
-            if (TOPB != 7) rw[NW - 1] &= (~0ULL) >> (8 * (7 - TOPB));
+            for (int i = NW - 1; i > 0; i--) rw[i] = alignbyte(rw[i], rw[i - 1], 3);
+            rw[0] = (rw[0] << 8) | comp;
+            if (TOPB != 3) rw[NW - 1] &= 0xFFFFFFFFu >> (8 * (3 - TOPB));
+            // f2 = ((f2 << 2) | code) & mask(2K bits) ; r2 = (r2 >> 2) | ((3-code) << 2(K-1))
             constexpr uint64_t M2 = (K == 32) ? ~0ULL : ((1ULL << (2 * (K & 31))) - 1ULL);
-            f2 = ((f2 << 2) | (uint64_t)code) & M2;
-            r2 = (r2 >> 2) | ((uint64_t)(3u - code) << (2 * (K - 1)));
+            f2.hi = alignbit(f2.hi, f2.lo, 30) & (uint32_t)(M2 >> 32);
+            f2.lo = ((f2.lo << 2) | code) & (uint32_t)M2;
+            const uint32_t ccode = 3u - code;
+            r2.lo = alignbit(r2.hi, r2.lo, 2);
+            r2.hi >>= 2;
+            constexpr int TOPSH = 2 * (K - 1);
+            if (TOPSH >= 32) r2.hi |= ccode << (TOPSH - 32);
+            else r2.lo |= ccode << TOPSH;
         }
-        run = valid ? (run < (uint32_t)K ? run + 1 : (uint32_t)K) : 0u;
+        run = valid ? run + 1u : 0u;                         // < 2^32 steps between resets
     }
 
     MG_HD bool kmer_valid() const { return run >= (uint32_t)K; }
@@ -115,10 +174,10 @@ struct KmerRoller {
     {
         uint64_t h;
         if (CANON) {
-            const bool use_f = f2 <= r2;                    // memcmp(fwd, rev, k) <= 0
-            uint64_t w[4];
+            const bool use_f = to64(f2) <= to64(r2);        // memcmp(fwd, rev, k) <= 0
+            uint32_t w[8];
 #pragma unroll
-            for (int i = 0; i < 4; i++) w[i] = use_f ? fw[i] : rw[i];
+            for (int i = 0; i < 8; i++) w[i] = use_f ? fw[i] : rw[i];
             h = murmur3_h1<K>(w, seed);
         } else {
             h = murmur3_h1<K>(fw, seed);

@@ -24,6 +24,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "kmer_hash.h"
 #include "sketch_internal.h"
 
@@ -212,65 +214,88 @@ __global__ __launch_bounds__(NT) void sketch_chunks_kernel(SketchArgs a)
         const uint32_t remaining = rem64 > (uint64_t)TILE ? (uint32_t)TILE : (uint32_t)rem64;
         const uint32_t lane_first = (uint32_t)tid * SK_L;
 
-        KmerRoller<K, MODE == 0> r;
-        r.reset();
-        uint64_t T = st->T;
-        bool full = st->full != 0;
-        uint32_t cur = lw[0];
+        // One pass of every lane over its run.  SEG = true: capacity is checked every
+        // SK_SEG_DW dwords (needed while the threshold is still loose).  SEG = false: the
+        // steady state — the threshold is set, candidates are rare, so the tile runs without
+        // a single barrier; appends are bounds-checked and an overflow (pathological repeats)
+        // discards the tile's candidates and re-runs it with SEG = true.
+        auto run_tile = [&](auto seg_tag) {
+            constexpr bool SEG = decltype(seg_tag)::value;
+            KmerRoller<K, MODE == 0> r;
+            r.reset();
+            uint64_t T = st->T;
+            bool full = st->full != 0;
+            uint32_t cur = lw[0];
 #pragma unroll 1
-        for (int d = 0; d < ND; d++) {
-            const uint32_t nxt = lw[d + 1];
-            const uint32_t word = __builtin_amdgcn_alignbyte(nxt, cur, bsh);
-            cur = nxt;
+            for (int d = 0; d < ND; d++) {
+                const uint32_t nxt = lw[d + 1];
+                const uint32_t word = __builtin_amdgcn_alignbyte(nxt, cur, bsh);
+                cur = nxt;
 #pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const int pos = 4 * d + b;
-                uint32_t c = (word >> (8 * b)) & 0xFFu;
-                bool valid;
-                if (MODE == 2) {
-                    if (fold) c = fold_upper(c);
-                    valid = alpha[c] != 0;
-                    r.push(c, valid);
-                } else {
-                    if (fold) c &= 0xDFu;                  // DNA: only membership of ACGT matters
-                    uint32_t code, comp;
-                    valid = dna_classify(c, code, comp);
-                    r.push(c, valid, code, comp);
+                for (int b = 0; b < 4; b++) {
+                    const int pos = 4 * d + b;
+                    uint32_t c = (word >> (8 * b)) & 0xFFu;
+                    bool valid;
+                    if (MODE == 2) {
+                        if (fold) c = fold_upper(c);
+                        valid = alpha[c] != 0;
+                        r.push(c, valid);
+                    } else {
+                        if (fold) c &= 0xDFu;              // DNA: only membership of ACGT matters
+                        uint32_t code, comp;
+                        valid = dna_classify(c, code, comp);
+                        r.push(c, valid, code, comp);
+                    }
+                    if (pos >= K - 1 && pos < NBYTES) {    // uniform
+                        const uint32_t start = (uint32_t)(pos - (K - 1));
+                        const uint64_t h = r.hash(seed, use64);
+                        const bool pass = r.kmer_valid() && (lane_first + start < remaining) &&
+                                          (!full || h < T);
+                        const uint64_t m = __ballot(pass);
+                        if (m != 0) {
+                            const uint32_t off = __builtin_amdgcn_mbcnt_hi(
+                                (uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+                            uint32_t bpos = 0;
+                            if (pass && off == 0) bpos = atomicAdd(&st->count, (uint32_t)__popcll(m));
+                            bpos = __shfl(bpos, __ffsll((unsigned long long)m) - 1);
+                            if (pass && (SEG || bpos + off < cap)) buf[bpos + off] = h;
+                        }
+                    }
                 }
-                if (pos >= K - 1 && pos < NBYTES) {        // uniform
-                    const uint32_t start = (uint32_t)(pos - (K - 1));
-                    const uint64_t h = r.hash(seed, use64);
-                    const bool pass = r.kmer_valid() && (lane_first + start < remaining) &&
-                                      (!full || h < T);
-                    const uint64_t m = __ballot(pass);
-                    if (m != 0) {
-                        const uint32_t off = __builtin_amdgcn_mbcnt_hi(
-                            (uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-                        uint32_t bpos = 0;
-                        if (pass && off == 0) bpos = atomicAdd(&st->count, (uint32_t)__popcll(m));
-                        bpos = __shfl(bpos, __ffsll((unsigned long long)m) - 1);
-                        if (pass) buf[bpos + off] = h;
+                if (SEG && ((d % SK_SEG_DW) == SK_SEG_DW - 1 || d == ND - 1)) {
+                    // Segment boundary.  The capacity decision must be identical in every
+                    // thread, but `count` keeps moving as fast waves enter the next segment:
+                    // the LAST wave to arrive (monotone ticket) snapshots it — by then every
+                    // wave has issued its appends — and everybody reads the snapshot after
+                    // the barrier (it cannot be overwritten before all waves pass the next one).
+                    seg_no++;
+                    if (lane == 0) {
+                        const uint32_t t = atomicAdd(&st->arrive, 1u);
+                        if (t == NW * seg_no - 1) st->snap = st->count;
+                    }
+                    __syncthreads();
+                    if (st->snap + (uint32_t)NT * 4 * SK_SEG_DW > cap) {    // uniform
+                        compact_buffer<NT>(buf, st, s_wsum, s, g_T);
+                        T = st->T;
+                        full = st->full != 0;
                     }
                 }
             }
-            if ((d % SK_SEG_DW) == SK_SEG_DW - 1 || d == ND - 1) {
-                // Segment boundary.  The capacity decision must be identical in every
-                // thread, but `count` keeps moving as fast waves enter the next segment:
-                // the LAST wave to arrive (monotone ticket) snapshots it — by then every
-                // wave has issued its appends — and everybody reads the snapshot after
-                // the barrier (it cannot be overwritten before all waves pass the next one).
-                seg_no++;
-                if (lane == 0) {
-                    const uint32_t t = atomicAdd(&st->arrive, 1u);
-                    if (t == NW * seg_no - 1) st->snap = st->count;
-                }
+        };
+        const uint32_t count0 = st->count;
+        const bool steady = st->full != 0 && count0 + (uint32_t)NT <= cap;
+        __syncthreads();                                   // everybody has read count0 / full
+        if (steady) {
+            run_tile(std::false_type{});
+            __syncthreads();
+            if (st->count > cap) {                         // uniform: overflow, redo the tile carefully
                 __syncthreads();
-                if (st->snap + (uint32_t)NT * 4 * SK_SEG_DW > cap) {    // uniform
-                    compact_buffer<NT>(buf, st, s_wsum, s, g_T);
-                    T = st->T;
-                    full = st->full != 0;
-                }
+                if (tid == 0) st->count = count0;
+                compact_buffer<NT>(buf, st, s_wsum, s, g_T);
+                run_tile(std::true_type{});
             }
+        } else {
+            run_tile(std::true_type{});
         }
         __syncthreads();      // tile may be overwritten
     }
