@@ -78,3 +78,26 @@ def test_two_rank_triangle_reassembles(oracle):
     got_d = np.concatenate([r[4] for r in res])
     assert res[0][1] == 0 and res[0][2] == res[1][1] and res[1][2] == n
     assert np.array_equal(got_n, numer) and np.array_equal(got_d, denom)
+
+
+def test_bench_multirank_plumbing_dry(tmp_path):
+    """bench.py's N>1 control flow (env parsing, process group, table broadcast, equal-area
+    sharding, barrier + MAX-reduce timing, single JSON line from rank 0) under torchrun with
+    gloo and 2 ranks; kernels are stubbed (--dry-cpu), the line is marked dry."""
+    import json
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-cpu", "--n-sketches", "300", "--no-cpu"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                # only rank 0 prints
+    d = json.loads(lines[0])
+    assert d["dry"] is True and d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong"
+    assert d["rank_blocks"][0] == 0 and d["rank_blocks"][-1] == 300 and len(d["rank_blocks"]) == 3
+    assert d["config"]["parallelism"] == "rowblock2" and d["config"]["table_broadcast_ms"] > 0
