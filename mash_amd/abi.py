@@ -174,25 +174,27 @@ class MashGpu:
         self._check(self.lib.mg_ctx_synchronize(self.ctx))
 
     # ---- sketching ---------------------------------------------------------
-    def sketch_host(self, sketches, p):
+    def sketch_host(self, sketches, p, counts=False):
         """sketches: list (one per sketch) of lists of record bytes.
-        Returns (hashes u64[n, s], nhash u32[n])."""
+        Returns (hashes u64[n, s], nhash u32[n]) and, with counts=True, multiplicities u32[n, s]."""
         blobs = [join_records(r) for r in sketches]
         bases = np.frombuffer(b"".join(blobs), dtype=np.uint8)
         off = np.zeros(len(blobs) + 1, dtype=np.uint64)
         off[1:] = np.cumsum([len(b) for b in blobs], dtype=np.uint64)
-        return self.sketch_host_raw(bases, off, p)
+        return self.sketch_host_raw(bases, off, p, counts)
 
-    def sketch_host_raw(self, bases, off, p):
+    def sketch_host_raw(self, bases, off, p, counts=False):
         n = len(off) - 1
         s = int(p.sketch_size)
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
         off = np.ascontiguousarray(off, dtype=np.uint64)
         hashes = np.zeros((n, s), dtype=np.uint64)
         nhash = np.zeros(n, dtype=np.uint32)
+        cnt = np.zeros((n, s), dtype=np.uint32) if counts else None
         self._check(self.lib.mg_sketch_host(self.ctx, C.byref(p), bases.ctypes.data, len(bases),
-                                            off.ctypes.data, n, hashes.ctypes.data, nhash.ctypes.data, None))
-        return hashes, nhash
+                                            off.ctypes.data, n, hashes.ctypes.data, nhash.ctypes.data,
+                                            cnt.ctypes.data if counts else None))
+        return (hashes, nhash, cnt) if counts else (hashes, nhash)
 
     def sketch_dev(self, bases_ptr, nbases, off, p, hashes_ptr, nhash_ptr):
         off = np.ascontiguousarray(off, dtype=np.uint64)

@@ -170,8 +170,8 @@ int mg_sketch_dev(mg_ctx *ctx, const mg_params *p, const uint8_t *bases_dev, uin
     if (!p || !sketch_off || !hashes_out_dev || !nhash_out_dev || (!bases_dev && nbases))
         return fail(ctx, MG_ERR_INVALID, "mg_sketch: NULL argument");
     if (p->kmer_size < 1 || p->kmer_size > 32) return fail(ctx, MG_ERR_INVALID, "mg_sketch: k must be 1..32");
-    if (counts_out_dev || p->counts)
-        return fail(ctx, MG_ERR_UNSUPPORTED, "mg_sketch: multiplicities (counts) are not computed on device yet");
+    if (counts_out_dev && !mg::count_supported(p->sketch_size))
+        return fail(ctx, MG_ERR_UNSUPPORTED, "mg_sketch: sketch size too large for the multiplicity pass");
     if (nsketch == 0) return MG_OK;
     if (nsketch > 0xFFFFFFFFull) return fail(ctx, MG_ERR_INVALID, "mg_sketch: too many sketches");
     if (((uintptr_t)bases_dev & 15) != 0) return fail(ctx, MG_ERR_INVALID, "mg_sketch: bases must be 16-byte aligned");
@@ -238,14 +238,20 @@ int mg_sketch_dev(mg_ctx *ctx, const mg_params *p, const uint8_t *bases_dev, uin
     HIP_TRY(ctx, hipMemsetAsync(nhash_out_dev, 0, nsketch * 4, ctx->stream));
     if (work.empty()) return MG_OK;
 
-    mg::SketchWork *d_work = nullptr;
+    if (counts_out_dev) HIP_TRY(ctx, hipMemsetAsync(counts_out_dev, 0, nsketch * s * 4, ctx->stream));
+    mg::SketchWork *d_work = nullptr, *d_work2 = nullptr;
     mg::MergeWork *d_merge = nullptr;
     uint8_t *d_alpha = nullptr;
     uint64_t *d_pool = nullptr, *d_gT = nullptr;
-    uint32_t *d_pool_n = nullptr;
+    uint32_t *d_pool_n = nullptr, *d_fix = nullptr;
+    unsigned long long *d_firstpos = nullptr, *d_tstar = nullptr;
     int rc = MG_OK;
     auto cleanup = [&]() {
         hipStreamSynchronize(ctx->stream);
+        if (d_work2) hipFree(d_work2);
+        if (d_fix) hipFree(d_fix);
+        if (d_firstpos) hipFree(d_firstpos);
+        if (d_tstar) hipFree(d_tstar);
         if (d_work) hipFree(d_work);
         if (d_merge) hipFree(d_merge);
         if (d_alpha) hipFree(d_alpha);
@@ -304,6 +310,43 @@ int mg_sketch_dev(mg_ctx *ctx, const mg_params *p, const uint8_t *bases_dev, uin
         m.cap = cap;
         TRY_C(mg::launch_merge_chunks(nt, m, (uint32_t)merges.size(), ctx->stream));
     }
+    if (counts_out_dev) {
+        // multiplicities: re-stream every chunk against the finished sketches (count_chunks_kernel)
+        TRY_C(hipMalloc(&d_firstpos, nsketch * s * 8));
+        TRY_C(hipMemsetAsync(d_firstpos, 0xFF, nsketch * s * 8, ctx->stream));
+        TRY_C(hipMalloc(&d_tstar, nsketch * 8));
+        TRY_C(hipMalloc(&d_fix, nsketch * 4));
+        mg::CountArgs ca;
+        ca.bases = bases_dev;
+        ca.work = d_work;
+        ca.alphabet = d_alpha;
+        ca.hashes = hashes_out_dev;
+        ca.nhash = nhash_out_dev;
+        ca.counts = counts_out_dev;
+        ca.firstpos = d_firstpos;
+        ca.tstar = d_tstar;
+        ca.sketch_size = (uint32_t)s;
+        ca.seed = p->seed;
+        ca.use64 = p->use64;
+        ca.fold_case = p->preserve_case ? 0 : 1;
+        ca.phase = 0;
+        TRY_C(mg::launch_count_chunks(p->kmer_size, mode, ca, (uint32_t)work.size(), ctx->stream));
+        TRY_C(mg::launch_count_tstar(nhash_out_dev, counts_out_dev, d_firstpos, d_tstar, d_fix, (uint32_t)nsketch,
+                                     (uint32_t)s, ctx->stream));
+        std::vector<uint32_t> fix(nsketch);
+        TRY_C(hipMemcpyAsync(fix.data(), d_fix, nsketch * 4, hipMemcpyDeviceToHost, ctx->stream));
+        TRY_C(hipStreamSynchronize(ctx->stream));
+        std::vector<mg::SketchWork> work2;
+        for (const mg::SketchWork &w : work) if (fix[w.sketch]) work2.push_back(w);
+        if (!work2.empty()) {
+            // the reference stops counting its largest kept hash once the heap is full with it on top
+            TRY_C(hipMalloc(&d_work2, work2.size() * sizeof(mg::SketchWork)));
+            TRY_C(hipMemcpyAsync(d_work2, work2.data(), work2.size() * sizeof(mg::SketchWork), hipMemcpyHostToDevice, ctx->stream));
+            ca.work = d_work2;
+            ca.phase = 1;
+            TRY_C(mg::launch_count_chunks(p->kmer_size, mode, ca, (uint32_t)work2.size(), ctx->stream));
+        }
+    }
 #undef TRY_C
     // work lists are freed after the stream drains (keeps the call self-contained)
     cleanup();
@@ -316,13 +359,13 @@ int mg_sketch_host(mg_ctx *ctx, const mg_params *p, const uint8_t *bases, uint64
 {
     if (!ctx) return MG_ERR_INVALID;
     if (!p || !hashes_out || !nhash_out) return fail(ctx, MG_ERR_INVALID, "mg_sketch_host: NULL argument");
-    if (counts_out) return fail(ctx, MG_ERR_UNSUPPORTED, "mg_sketch: multiplicities (counts) are not computed on device yet");
     if (nsketch == 0) return MG_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint64_t s = p->sketch_size;
     uint8_t *d_bases = nullptr;
     uint64_t *d_hashes = nullptr;
-    uint32_t *d_nhash = nullptr;
+    uint32_t *d_nhash = nullptr, *d_counts = nullptr;
+    if (counts_out) HIP_TRY(ctx, hipMalloc(&d_counts, nsketch * s * 4));
     HIP_TRY(ctx, hipMalloc(&d_bases, nbases + 64));
     int rc = MG_OK;
     if (hipMalloc(&d_hashes, nsketch * s * 8) != hipSuccess || hipMalloc(&d_nhash, nsketch * 4) != hipSuccess) {
@@ -330,9 +373,10 @@ int mg_sketch_host(mg_ctx *ctx, const mg_params *p, const uint8_t *bases, uint64
     } else if (hipMemcpyAsync(d_bases, bases, nbases, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
         rc = fail(ctx, MG_ERR_HIP, "mg_sketch_host: H2D copy failed");
     } else {
-        rc = mg_sketch_dev(ctx, p, d_bases, nbases, sketch_off, nsketch, d_hashes, d_nhash, nullptr);
+        rc = mg_sketch_dev(ctx, p, d_bases, nbases, sketch_off, nsketch, d_hashes, d_nhash, d_counts);
         if (rc == MG_OK) {
-            if (hipMemcpyAsync(hashes_out, d_hashes, nsketch * s * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            if ((counts_out && hipMemcpyAsync(counts_out, d_counts, nsketch * s * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) ||
+                hipMemcpyAsync(hashes_out, d_hashes, nsketch * s * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
                 hipMemcpyAsync(nhash_out, d_nhash, nsketch * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
                 hipStreamSynchronize(ctx->stream) != hipSuccess)
                 rc = fail(ctx, MG_ERR_HIP, "mg_sketch_host: D2H copy failed");
@@ -342,6 +386,7 @@ int mg_sketch_host(mg_ctx *ctx, const mg_params *p, const uint8_t *bases, uint64
     if (d_bases) hipFree(d_bases);
     if (d_hashes) hipFree(d_hashes);
     if (d_nhash) hipFree(d_nhash);
+    if (d_counts) hipFree(d_counts);
     return rc;
 }
 

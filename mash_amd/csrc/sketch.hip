@@ -352,6 +352,137 @@ __global__ __launch_bounds__(NT) void merge_chunks_kernel(MergeArgs a)
 }
 
 // ---------------------------------------------------------------------------
+// Multiplicities (Sketch::Reference::counts, HashSet.cpp:78-118 / MinHashHeap.cpp:96-124).
+// Every kept hash except the largest is counted on each occurrence in the reference, so its
+// count is its exact multiplicity.  The largest kept hash h_max is only counted while the
+// heap is not yet "full with h_max on top": occurrences after t* = max over kept hashes of
+// their FIRST occurrence are dropped (MinHashHeap.cpp:70-74 tests `hash < top`).
+// Phase 0 re-streams the chunk, looks every hash <= h_max up in the final sketch (LDS, binary
+// search) and accumulates multiplicity + first position; launch_count_tstar derives t*; phase 1
+// (only sketches whose h_max repeats) recounts h_max over positions <= t*.
+template <int K, int MODE>
+__global__ __launch_bounds__(256) void count_chunks_kernel(CountArgs a)
+{
+    constexpr int NT = 256;
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int SK_L = sk_L(NT);
+    constexpr int TILE = NT * SK_L;
+    constexpr int TILE_DW = TILE / 4 + 32;
+    uint64_t *hl = reinterpret_cast<uint64_t *>(smem);                              // [s]
+    uint32_t *tile = reinterpret_cast<uint32_t *>(smem + (size_t)a.sketch_size * 8);
+    uint8_t *alpha = reinterpret_cast<uint8_t *>(tile + TILE_DW);
+
+    const int tid = threadIdx.x;
+    const SketchWork w = a.work[blockIdx.x];
+    const uint32_t s = a.sketch_size;
+    const uint32_t n = a.nhash[w.sketch];
+    if (n == 0) return;
+    const uint64_t *row = a.hashes + (uint64_t)w.sketch * s;
+    for (uint32_t i = tid; i < n; i += NT) hl[i] = row[i];
+    if (MODE == 2) for (int i = tid; i < 256; i += NT) alpha[i] = a.alphabet[i];
+    __syncthreads();
+    const uint64_t T = hl[n - 1];
+    const uint64_t tstar = a.phase ? a.tstar[w.sketch] : 0;
+    uint32_t *cnt = a.counts + (uint64_t)w.sketch * s;
+    unsigned long long *fp = a.firstpos + (uint64_t)w.sketch * s;
+    const uint32_t seed = a.seed;
+    const bool use64 = a.use64 != 0, fold = a.fold_case != 0;
+    constexpr int NBYTES = SK_L + K - 1;
+    constexpr int ND = (NBYTES + 3) / 4;
+
+    for (uint64_t t0 = w.begin; t0 < w.end; t0 += TILE) {
+        const uint64_t a0 = t0 & ~15ULL;
+        const uint32_t shift = (uint32_t)(t0 - a0);
+        for (int q = tid; q < TILE_DW / 4; q += NT) {
+            const uint64_t o = a0 + (uint64_t)q * 16;
+            uint4 x = make_uint4(0, 0, 0, 0);
+            if (o + 16 <= w.limit) {
+                x = *reinterpret_cast<const uint4 *>(a.bases + o);
+            } else if (o < w.limit) {
+                uint32_t d[4] = {0, 0, 0, 0};
+                for (int b = 0; b < 16 && o + b < w.limit; b++)
+                    d[b >> 2] |= (uint32_t)a.bases[o + b] << (8 * (b & 3));
+                x = make_uint4(d[0], d[1], d[2], d[3]);
+            }
+            reinterpret_cast<uint4 *>(tile)[q] = x;
+        }
+        __syncthreads();
+        const uint32_t lane_byte0 = shift + (uint32_t)tid * SK_L;
+        const uint32_t *lw = tile + (lane_byte0 >> 2);
+        const uint32_t bsh = lane_byte0 & 3;
+        const uint64_t rem64 = w.end - t0;
+        const uint32_t remaining = rem64 > (uint64_t)TILE ? (uint32_t)TILE : (uint32_t)rem64;
+        const uint32_t lane_first = (uint32_t)tid * SK_L;
+        KmerRoller<K, MODE == 0> r;
+        r.reset();
+        uint32_t cur = lw[0];
+#pragma unroll 1
+        for (int d = 0; d < ND; d++) {
+            const uint32_t nxt = lw[d + 1];
+            const uint32_t word = __builtin_amdgcn_alignbyte(nxt, cur, bsh);
+            cur = nxt;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int pos = 4 * d + b;
+                uint32_t c = (word >> (8 * b)) & 0xFFu;
+                if (MODE == 2) {
+                    if (fold) c = fold_upper(c);
+                    r.push(c, alpha[c] != 0);
+                } else {
+                    if (fold) c &= 0xDFu;
+                    uint32_t code, comp;
+                    const bool valid = dna_classify(c, code, comp);
+                    r.push(c, valid, code, comp);
+                }
+                if (pos >= K - 1 && pos < NBYTES) {
+                    const uint32_t start = (uint32_t)(pos - (K - 1));
+                    const uint64_t h = r.hash(seed, use64);
+                    if (r.kmer_valid() && (lane_first + start < remaining) && h <= T) {
+                        const uint64_t kpos = t0 + lane_first + start;
+                        if (a.phase == 0) {
+                            uint32_t lo = 0, hi = n;
+                            while (lo < hi) {
+                                const uint32_t mid = (lo + hi) >> 1;
+                                if (hl[mid] < h) lo = mid + 1; else hi = mid;
+                            }
+                            if (lo < n && hl[lo] == h) {          // always true: every value <= h_max is kept
+                                atomicAdd(&cnt[lo], 1u);
+                                atomicMin(&fp[lo], (unsigned long long)kpos);
+                            }
+                        } else if (h == T && kpos <= tstar) {
+                            atomicAdd(&cnt[n - 1], 1u);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// one thread per sketch: t* = latest first occurrence among the kept hashes of a FULL sketch;
+// the largest hash needs the positional recount only if it repeats
+__global__ void count_tstar_kernel(const uint32_t *nhash, uint32_t *counts, const unsigned long long *firstpos,
+                                   unsigned long long *tstar, uint32_t *need_fix, uint32_t nsketch, uint32_t s)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nsketch) return;
+    const uint32_t n = nhash[i];
+    uint32_t fix = 0;
+    unsigned long long t = 0;
+    if (n == s && counts[(uint64_t)i * s + n - 1] > 1) {
+        for (uint32_t k = 0; k < n; k++) {
+            const unsigned long long f = firstpos[(uint64_t)i * s + k];
+            t = f > t ? f : t;
+        }
+        fix = 1;
+        counts[(uint64_t)i * s + n - 1] = 0;
+    }
+    tstar[i] = t;
+    need_fix[i] = fix;
+}
+
+// ---------------------------------------------------------------------------
 // dispatch tables
 
 template <int K, int MODE, int NT>
@@ -414,6 +545,55 @@ hipError_t launch_sketch_chunks(int k, int mode, int nt, const SketchArgs &a, ui
     if (mode == 0) return launch_k<0, 1024>(k, a, nwork, smem, stream);
     if (mode == 1) return launch_k<1, 1024>(k, a, nwork, smem, stream);
     return launch_k<2, 1024>(k, a, nwork, smem, stream);
+}
+
+bool count_supported(uint64_t s)
+{
+    return s * 8 + ((size_t)256 * sk_L(256) / 4 + 32) * 4 + 256 + 64 <= 160 * 1024;
+}
+
+template <int K, int MODE>
+static hipError_t launch_count_one(const CountArgs &a, uint32_t nwork, hipStream_t stream)
+{
+    const size_t smem = (size_t)a.sketch_size * 8 + ((size_t)256 * sk_L(256) / 4 + 32) * 4 + 256 + 64;
+    auto kern = count_chunks_kernel<K, MODE>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(nwork), dim3(256), smem, stream, a);
+    return hipGetLastError();
+}
+
+template <int MODE>
+static hipError_t launch_count_k(int k, const CountArgs &a, uint32_t nwork, hipStream_t st)
+{
+    switch (k) {
+#define MG_CASE(KK) case KK: return launch_count_one<KK, MODE>(a, nwork, st);
+        MG_CASE(1) MG_CASE(2) MG_CASE(3) MG_CASE(4) MG_CASE(5) MG_CASE(6) MG_CASE(7) MG_CASE(8)
+        MG_CASE(9) MG_CASE(10) MG_CASE(11) MG_CASE(12) MG_CASE(13) MG_CASE(14) MG_CASE(15) MG_CASE(16)
+        MG_CASE(17) MG_CASE(18) MG_CASE(19) MG_CASE(20) MG_CASE(21) MG_CASE(22) MG_CASE(23) MG_CASE(24)
+        MG_CASE(25) MG_CASE(26) MG_CASE(27) MG_CASE(28) MG_CASE(29) MG_CASE(30) MG_CASE(31) MG_CASE(32)
+#undef MG_CASE
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_count_chunks(int k, int mode, const CountArgs &a, uint32_t nwork, hipStream_t stream)
+{
+    if (nwork == 0) return hipSuccess;
+    if (mode == 0) return launch_count_k<0>(k, a, nwork, stream);
+    if (mode == 1) return launch_count_k<1>(k, a, nwork, stream);
+    return launch_count_k<2>(k, a, nwork, stream);
+}
+
+hipError_t launch_count_tstar(const uint32_t *nhash, uint32_t *counts, const unsigned long long *firstpos,
+                              unsigned long long *tstar, uint32_t *need_fix, uint32_t nsketch, uint32_t s,
+                              hipStream_t stream)
+{
+    if (nsketch == 0) return hipSuccess;
+    hipLaunchKernelGGL(count_tstar_kernel, dim3((nsketch + 255) / 256), dim3(256), 0, stream, nhash, counts, firstpos,
+                       tstar, need_fix, nsketch, s);
+    return hipGetLastError();
 }
 
 hipError_t launch_merge_chunks(int nt, const MergeArgs &a, uint32_t nwork, hipStream_t stream)

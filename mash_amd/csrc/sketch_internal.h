@@ -46,6 +46,22 @@ struct MergeArgs {
     uint32_t cap;
 };
 
+struct CountArgs {
+    const uint8_t *bases;
+    const SketchWork *work;
+    const uint8_t *alphabet;
+    const uint64_t *hashes;       // final sketch rows [nsketch * s]
+    const uint32_t *nhash;
+    uint32_t *counts;             // [nsketch * s]
+    unsigned long long *firstpos; // [nsketch * s] first occurrence (byte offset) of every kept hash
+    const unsigned long long *tstar;   // [nsketch] phase 1: only occurrences at positions <= tstar count
+    uint32_t sketch_size;
+    uint32_t seed;
+    uint32_t use64;
+    uint32_t fold_case;
+    uint32_t phase;               // 0: multiplicities + first positions; 1: recount the largest kept hash
+};
+
 // geometry: threads per workgroup and LDS candidate capacity for sketch size s;
 // false if s is too large for the LDS-resident selector.
 bool sketch_geometry(uint64_t s, int *nt_out, uint32_t *cap_out);
@@ -56,5 +72,12 @@ size_t sketch_smem_bytes(uint32_t cap, int nt);
 hipError_t launch_sketch_chunks(int k, int mode, int nt, const SketchArgs &a, uint32_t nwork,
                                 hipStream_t stream);
 hipError_t launch_merge_chunks(int nt, const MergeArgs &a, uint32_t nwork, hipStream_t stream);
+// multiplicities (MinHashHeap counts, incl. the reference's order-dependent count of the
+// largest kept hash): see count_chunks_kernel
+bool count_supported(uint64_t s);
+hipError_t launch_count_chunks(int k, int mode, const CountArgs &a, uint32_t nwork, hipStream_t stream);
+hipError_t launch_count_tstar(const uint32_t *nhash, uint32_t *counts, const unsigned long long *firstpos,
+                              unsigned long long *tstar, uint32_t *need_fix, uint32_t nsketch, uint32_t s,
+                              hipStream_t stream);
 
 }  // namespace mg

@@ -7,7 +7,7 @@
 // sketchParameterSetup.cpp:15-125, Sketch.cpp:105-253).  All hashing / selection /
 // comparison runs on the GPU through libmashgpu; there is no CPU fallback.
 // Not built (the reference's reads-mode noise filters are order dependent):
-// -m >= 2, -b, -c.  Multiplicities (-M, implied by -r) are not stored yet.
+// -m >= 2, -b, -c.
 #include <unistd.h>
 
 #include <algorithm>
@@ -298,15 +298,16 @@ void flush_batch(Gpu &gpu, SketchSet &set, PendingBatch &b)
                    set.p.preserve_case);
     const uint64_t n = b.refs.size(), s = set.p.sketch_size;
     vector<uint64_t> hashes(n * s);
-    vector<uint32_t> nhash(n);
+    vector<uint32_t> nhash(n), counts(set.p.counts ? n * s : 0);
     if (b.bases.empty()) b.bases.push_back((uint8_t)MG_RECORD_SEP);
     if (mg_sketch_host(gpu.ctx, &mp, b.bases.data(), b.bases.size(), b.off.data(), n, hashes.data(), nhash.data(),
-                       nullptr) != MG_OK) {
+                       set.p.counts ? counts.data() : nullptr) != MG_OK) {
         cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl;
         exit(1);
     }
     for (uint64_t i = 0; i < n; i++) {
         b.refs[i].hashes.assign(hashes.begin() + i * s, hashes.begin() + i * s + nhash[i]);
+        if (set.p.counts) b.refs[i].counts.assign(counts.begin() + i * s, counts.begin() + i * s + nhash[i]);
         set.refs.push_back(std::move(b.refs[i]));
     }
     b = PendingBatch();
@@ -417,7 +418,9 @@ void sketch_reads(Gpu &gpu, SketchSet &set, const vector<string> &files)
         est = std::pow(2.0, set.p.use64 ? 64.0 : 32.0) * (double)r.hashes.size() / (double)r.hashes.back();
     r.length = set.p.genome_size ? set.p.genome_size : (uint64_t)est;
     cerr << "Estimated genome size: " << est << endl;
-    cerr << "Estimated coverage:    " << "n/a (multiplicities are not computed on the GPU path)" << endl;
+    double msum = 0;                                       // estimateMultiplicity (MinHashHeap.h:44)
+    for (uint32_t c : r.counts) msum += c;
+    cerr << "Estimated coverage:    " << (r.counts.empty() ? 0.0 : msum / (double)r.counts.size()) << endl;
 }
 
 // the .msh branch of Sketch::initFromFiles (Sketch.cpp:120-172) + loadCapnp
@@ -596,8 +599,6 @@ int cmd_sketch(int argc, const char **argv)
     Params p;
     p.counts = c.o("counts").active;
     if (sketch_parameter_setup(p, c)) return 1;
-    if (p.counts) cerr << "WARNING: k-mer multiplicities (-M / -r) are not stored by the GPU sketching path yet." << endl;
-    p.counts = false;
     vector<string> files;
     for (const string &a : c.args) { if (c.o("list").active) split_file(a, files); else files.push_back(a); }
     if ((c.o("id").active || c.o("comment").active) && files.size() > 1 && !p.reads)

@@ -27,14 +27,19 @@ def eng():
 def _check_sketches(eng, oracle, sketches, **kw):
     p = eng.params(**kw)
     op = oracle.params(**kw)
-    hashes, nhash = eng.sketch_host(sketches, p)
+    hashes, nhash, counts = eng.sketch_host(sketches, p, counts=True)
+    hashes2, nhash2 = eng.sketch_host(sketches, p)                 # the no-counts path gives the same sketch
+    assert np.array_equal(hashes, hashes2) and np.array_equal(nhash, nhash2)
     s = kw.get("s", 1000)
     for i, recs in enumerate(sketches):
-        h, _, _, _, _ = oracle.sketch_records(list(recs), op)
+        h, c, _, _, _ = oracle.sketch_records(list(recs), op)
         assert nhash[i] == len(h), (i, kw, int(nhash[i]), len(h))
         assert np.array_equal(hashes[i, : len(h)], h), (i, kw)
         assert np.all(hashes[i, len(h):] == np.uint64(abi.HASH_PAD))
         assert hashes.shape[1] == s
+        # multiplicities incl. the reference's order-dependent count of the largest kept hash
+        assert np.array_equal(counts[i, : len(h)], c), (i, kw)
+        assert np.all(counts[i, len(h):] == 0)
 
 
 # ---------------------------------------------------------------- sketching
@@ -71,9 +76,10 @@ def test_sketch_reference_run_vectors(eng):
     for cfg, recs, gh, gc in helpers.load_ref_sketch_vectors():
         p = eng.params(k=cfg["k"], s=cfg["s"], alphabet=cfg["alphabet"],
                        noncanonical=cfg["noncanonical"], preserve_case=cfg["preserve_case"])
-        hashes, nhash = eng.sketch_host([recs], p)
+        hashes, nhash, counts = eng.sketch_host([recs], p, counts=True)
         assert nhash[0] == len(gh), cfg
         assert np.array_equal(hashes[0, : len(gh)], gh), cfg
+        assert np.array_equal(counts[0, : len(gc)], gc), cfg       # counts produced by the reference objects
 
 
 def test_sketch_reads_json_golden(eng, golden_dir):
