@@ -159,6 +159,32 @@ double mg_distance(uint32_t numer, uint32_t denom, int kmer_size);
 double mg_p_value(uint64_t x, uint64_t len_ref, uint64_t len_qry, double kmer_space,
                   uint64_t sketch_size);
 
+/* ---- screening (containment of sketches in a mixture) -----------------------------
+ * Replaces, for nucleotide query sketches, the data-parallel part of `mash screen`:
+ * the hashTable / hashCounts build (CommandScreen.cpp:99-114), hashSequence over the
+ * mixture (CommandScreen.cpp:484-599: every valid canonical k-mer is hashed, counted if
+ * it occurs in any query sketch, and offered to the mixture's own bottom-s heap) and the
+ * per-hash observation lookup behind `shared` / median multiplicity (:338-355, :402-455).
+ *
+ * mg_screen_create builds the device table of distinct hashes of `db` (which must outlive
+ * the screen).  mg_screen_add_* consumes one batch of the mixture: records separated by
+ * MG_RECORD_SEP, any case, as kseq delivers them (records shorter than k contribute no
+ * k-mer).  mg_screen_finish_host returns counts_out[db_rows * db_s] = observations of
+ * every sketch hash in the mixture (0 beyond nhash), the mixture's bottom-s sketch
+ * (mix_hashes_out[sketch_size], ascending, padded; its estimateSetSize feeds the p-value,
+ * CommandScreen.cpp:322) and the number of distinct hashes in the table.
+ * 6-frame translation for protein sketches (CommandScreen.cpp:516-531) is not built. */
+typedef struct mg_screen mg_screen;
+int  mg_screen_create(mg_ctx *ctx, const mg_params *p, const mg_table *db, mg_screen **out);
+int  mg_screen_add_host(mg_screen *sc, const uint8_t *bases, uint64_t nbases);
+int  mg_screen_add_dev(mg_screen *sc, const uint8_t *bases_dev, uint64_t nbases);
+int  mg_screen_finish_host(mg_screen *sc, uint32_t *counts_out, uint64_t *mix_hashes_out,
+                           uint32_t *mix_nhash_out, uint64_t *distinct_out);
+void mg_screen_free(mg_screen *sc);
+/* estimateIdentity (CommandScreen.cpp:463-482) and pValueWithin (:601-615), host arithmetic. */
+double mg_identity(uint64_t common, uint64_t denom, int kmer_size);
+double mg_p_value_within(uint64_t x, uint64_t set_size, double kmer_space, uint64_t sketch_size);
+
 /* ---- timing hook for bench.py ----------------------------------------------
  * Average duration (ms) of the last `name` kernel launches recorded with HIP
  * events on the context's stream since mg_prof_reset; name = "compare" or

@@ -22,6 +22,8 @@ EXPORTS = [
     "mg_compare_tri_dev", "mg_compare_tri_host", "mg_compare_rect_dev", "mg_compare_rect_host",
     "mg_finish_tri_host", "mg_finish_rect_host", "mg_distance", "mg_p_value",
     "mg_prof_enable", "mg_prof_reset", "mg_prof_avg_ms",
+    "mg_screen_create", "mg_screen_add_host", "mg_screen_add_dev", "mg_screen_finish_host", "mg_screen_free",
+    "mg_identity", "mg_p_value_within",
 ]
 
 
@@ -100,6 +102,16 @@ def load_library():
     lib.mg_prof_reset.restype = None
     lib.mg_prof_avg_ms.argtypes = [vp, C.c_char_p, C.POINTER(u64)]
     lib.mg_prof_avg_ms.restype = dbl
+    lib.mg_screen_create.argtypes = [vp, C.POINTER(MgParams), vp, C.POINTER(vp)]
+    lib.mg_screen_add_host.argtypes = [vp, vp, u64]
+    lib.mg_screen_add_dev.argtypes = [vp, vp, u64]
+    lib.mg_screen_finish_host.argtypes = [vp, vp, vp, C.POINTER(u32), C.POINTER(u64)]
+    lib.mg_screen_free.argtypes = [vp]
+    lib.mg_screen_free.restype = None
+    lib.mg_identity.argtypes = [u64, u64, i32]
+    lib.mg_identity.restype = dbl
+    lib.mg_p_value_within.argtypes = [u64, u64, dbl, u64]
+    lib.mg_p_value_within.restype = dbl
     return lib
 
 
@@ -258,6 +270,25 @@ class MashGpu:
                                           out.ctypes.data)
         self._check(rc)
         return out
+
+    # ---- screening -------------------------------------------------------------------
+    def screen(self, db, p, batches):
+        """Containment counts of every hash of table `db` in a mixture given as batches of
+        record lists.  Returns (counts u32[n, s], mixture sketch u64[<=s], distinct hashes)."""
+        h = C.c_void_p()
+        self._check(self.lib.mg_screen_create(self.ctx, C.byref(p), db.handle, C.byref(h)))
+        try:
+            for recs in batches:
+                blob = np.frombuffer(join_records(recs), dtype=np.uint8)
+                self._check(self.lib.mg_screen_add_host(h, blob.ctypes.data, len(blob)))
+            n, s = db.rows, db.sketch_size
+            counts = np.zeros((n, s), dtype=np.uint32)
+            mix = np.zeros(int(p.sketch_size), dtype=np.uint64)
+            mn, dist = C.c_uint32(0), C.c_uint64(0)
+            self._check(self.lib.mg_screen_finish_host(h, counts.ctypes.data, mix.ctypes.data, C.byref(mn), C.byref(dist)))
+            return counts, mix[: mn.value].copy(), int(dist.value)
+        finally:
+            self.lib.mg_screen_free(h)
 
     # ---- profiling hook -----------------------------------------------------------
     def prof_enable(self, on=True):

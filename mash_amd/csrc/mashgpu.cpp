@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <iterator>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -13,6 +14,7 @@
 #include "../../include/mashgpu.h"
 #include "compare_internal.h"
 #include "pvalue.h"
+#include "screen_internal.h"
 #include "sketch_internal.h"
 
 namespace {
@@ -690,6 +692,202 @@ int mg_finish_rect_host(const mg_counts *counts, const uint64_t *len_ref, uint64
             finish_one(counts[idx], len_ref[r], len_qry[q], kmer_size, kmer_space, max_distance, max_p_value, out + idx);
         }
     return MG_OK;
+}
+
+/* ------------------------------------------------------------------ screening */
+
+struct mg_screen {
+    mg_ctx *ctx = nullptr;
+    mg_params p;
+    const mg_table *db = nullptr;
+    unsigned long long *keys = nullptr;
+    uint32_t *obs = nullptr;
+    uint64_t slots = 0;
+    uint8_t *d_alpha = nullptr;
+    int mode = 0;
+    std::vector<uint64_t> mix;          // running bottom-s of the mixture (host, ascending, distinct)
+};
+
+int mg_screen_create(mg_ctx *ctx, const mg_params *p, const mg_table *db, mg_screen **out)
+{
+    if (!ctx) return MG_ERR_INVALID;
+    if (!p || !db || !out) return fail(ctx, MG_ERR_INVALID, "mg_screen_create: NULL argument");
+    const bool dna = alphabet_is_dna(p);
+    if (!p->noncanonical && !dna) return fail(ctx, MG_ERR_UNSUPPORTED, "mg_screen: canonical k-mers need the ACGT alphabet");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    mg_screen *sc = new mg_screen;
+    sc->ctx = ctx;
+    sc->p = *p;
+    sc->db = db;
+    sc->mode = dna ? (p->noncanonical ? 1 : 0) : 2;
+    uint64_t slots = 1024;
+    while (slots < 2 * db->n * db->s) slots <<= 1;
+    sc->slots = slots;
+    hipError_t e = hipMalloc(&sc->keys, slots * 8);
+    if (e == hipSuccess) e = hipMalloc(&sc->obs, slots * 4);
+    if (e == hipSuccess) e = hipMalloc(&sc->d_alpha, 256);
+    if (e == hipSuccess) e = hipMemsetAsync(sc->keys, 0xFF, slots * 8, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(sc->obs, 0, slots * 4, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(sc->d_alpha, p->alphabet, 256, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = mg::launch_screen_build(db->hashes, db->nhash, db->n, db->s, sc->keys, slots - 1, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        mg_screen_free(sc);
+        return fail(ctx, MG_ERR_HIP, std::string("mg_screen_create: ") + hipGetErrorString(e));
+    }
+    *out = sc;
+    return MG_OK;
+}
+
+int mg_screen_add_dev(mg_screen *sc, const uint8_t *bases_dev, uint64_t nbases)
+{
+    if (!sc) return MG_ERR_INVALID;
+    mg_ctx *ctx = sc->ctx;
+    const uint64_t k = (uint64_t)sc->p.kmer_size;
+    if (nbases < k) return MG_OK;
+    if (((uintptr_t)bases_dev & 15) != 0) return fail(ctx, MG_ERR_INVALID, "mg_screen_add: bases must be 16-byte aligned");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // 1) the mixture's own bottom-s: one sketch over the whole batch, folded into the running one
+    const uint64_t s = sc->p.sketch_size;
+    uint64_t *d_h = nullptr;
+    uint32_t *d_n = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d_h, s * 8));
+    if (hipMalloc(&d_n, 4) != hipSuccess) { hipFree(d_h); return fail(ctx, MG_ERR_NOMEM, "mg_screen_add: allocation failed"); }
+    const uint64_t off[2] = {0, nbases};
+    int rc = mg_sketch_dev(ctx, &sc->p, bases_dev, nbases, off, 1, d_h, d_n, nullptr);
+    std::vector<uint64_t> bh(s);
+    uint32_t bn = 0;
+    if (rc == MG_OK) {
+        if (hipMemcpyAsync(bh.data(), d_h, s * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(&bn, d_n, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess)
+            rc = fail(ctx, MG_ERR_HIP, "mg_screen_add: D2H copy failed");
+    }
+    hipFree(d_h);
+    hipFree(d_n);
+    if (rc != MG_OK) return rc;
+    std::vector<uint64_t> merged;
+    merged.reserve(sc->mix.size() + bn);
+    std::merge(sc->mix.begin(), sc->mix.end(), bh.begin(), bh.begin() + bn, std::back_inserter(merged));
+    merged.erase(std::unique(merged.begin(), merged.end()), merged.end());
+    if (merged.size() > s) merged.resize(s);
+    sc->mix.swap(merged);
+    // 2) probe: every valid k-mer against the table
+    const uint64_t tile = mg::sketch_tile(256);
+    const uint64_t npos = nbases - k + 1;
+    uint64_t chunk = (npos + 8191) / 8192;
+    if (chunk < 2 * tile) chunk = 2 * tile;
+    chunk = (chunk + tile - 1) / tile * tile;
+    std::vector<mg::SketchWork> work;
+    for (uint64_t b = 0; b < npos; b += chunk) {
+        mg::SketchWork w;
+        w.begin = b;
+        w.end = std::min(npos, b + chunk);
+        w.limit = nbases;
+        w.sketch = 0; w.slot = 0; w.nchunks = 1; w._pad = 0;
+        work.push_back(w);
+    }
+    mg::SketchWork *d_work = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d_work, work.size() * sizeof(mg::SketchWork)));
+    hipError_t e = hipMemcpyAsync(d_work, work.data(), work.size() * sizeof(mg::SketchWork), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        mg::ScreenProbeArgs a;
+        a.bases = bases_dev;
+        a.work = d_work;
+        a.alphabet = sc->d_alpha;
+        a.keys = sc->keys;
+        a.obs = sc->obs;
+        a.mask = sc->slots - 1;
+        a.seed = sc->p.seed;
+        a.use64 = sc->p.use64;
+        a.fold_case = sc->p.preserve_case ? 0 : 1;
+        e = mg::launch_screen_probe(sc->p.kmer_size, sc->mode, a, (uint32_t)work.size(), ctx->stream);
+    }
+    hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    hipFree(d_work);
+    if (e != hipSuccess || e2 != hipSuccess)
+        return fail(ctx, MG_ERR_HIP, std::string("mg_screen_add: ") + hipGetErrorString(e != hipSuccess ? e : e2));
+    return MG_OK;
+}
+
+int mg_screen_add_host(mg_screen *sc, const uint8_t *bases, uint64_t nbases)
+{
+    if (!sc) return MG_ERR_INVALID;
+    mg_ctx *ctx = sc->ctx;
+    if (!bases && nbases) return fail(ctx, MG_ERR_INVALID, "mg_screen_add_host: NULL bases");
+    if (nbases == 0) return MG_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    uint8_t *d = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d, nbases + 64));
+    int rc = MG_OK;
+    if (hipMemcpyAsync(d, bases, nbases, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+        rc = fail(ctx, MG_ERR_HIP, "mg_screen_add_host: H2D copy failed");
+    else
+        rc = mg_screen_add_dev(sc, d, nbases);
+    hipStreamSynchronize(ctx->stream);
+    hipFree(d);
+    return rc;
+}
+
+int mg_screen_finish_host(mg_screen *sc, uint32_t *counts_out, uint64_t *mix_hashes_out, uint32_t *mix_nhash_out,
+                          uint64_t *distinct_out)
+{
+    if (!sc) return MG_ERR_INVALID;
+    mg_ctx *ctx = sc->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint64_t total = sc->db->n * sc->db->s;
+    if (counts_out && total) {
+        uint32_t *d = nullptr;
+        HIP_TRY(ctx, hipMalloc(&d, total * 4));
+        hipError_t e = mg::launch_screen_gather(sc->db->hashes, sc->db->nhash, sc->db->n, sc->db->s, sc->keys, sc->obs,
+                                                sc->slots - 1, d, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(counts_out, d, total * 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        hipFree(d);
+        if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("mg_screen_finish: ") + hipGetErrorString(e));
+    }
+    const uint64_t s = sc->p.sketch_size;
+    if (mix_hashes_out) {
+        for (uint64_t i = 0; i < s; i++) mix_hashes_out[i] = i < sc->mix.size() ? sc->mix[i] : MG_HASH_PAD;
+    }
+    if (mix_nhash_out) *mix_nhash_out = (uint32_t)sc->mix.size();
+    if (distinct_out) {
+        // distinct table entries = occupied slots (keys are unique by construction)
+        std::vector<unsigned long long> hk(std::min<uint64_t>(sc->slots, 1u << 22));
+        uint64_t cnt = 0;
+        for (uint64_t o = 0; o < sc->slots; o += hk.size()) {
+            const uint64_t nn = std::min<uint64_t>(hk.size(), sc->slots - o);
+            if (hipMemcpy(hk.data(), sc->keys + o, nn * 8, hipMemcpyDeviceToHost) != hipSuccess)
+                return fail(ctx, MG_ERR_HIP, "mg_screen_finish: D2H copy failed");
+            for (uint64_t i = 0; i < nn; i++) cnt += hk[i] != 0xFFFFFFFFFFFFFFFFull;
+        }
+        *distinct_out = cnt;
+    }
+    return MG_OK;
+}
+
+double mg_identity(uint64_t common, uint64_t denom, int kmer_size)
+{
+    if (common == denom) return 1.;                       // avoid -0
+    if (common == 0) return 0.;                           // avoid inf
+    return pow((double)common / (double)denom, 1. / kmer_size);
+}
+
+double mg_p_value_within(uint64_t x, uint64_t set_size, double kmer_space, uint64_t sketch_size)
+{
+    if (x == 0) return 1.;
+    const double r = (double)set_size / kmer_space;
+    return mg::binomial_q(x - 1, r, sketch_size);
+}
+
+void mg_screen_free(mg_screen *sc)
+{
+    if (!sc) return;
+    hipSetDevice(sc->ctx->device);
+    if (sc->keys) hipFree(sc->keys);
+    if (sc->obs) hipFree(sc->obs);
+    if (sc->d_alpha) hipFree(sc->d_alpha);
+    delete sc;
 }
 
 /* ------------------------------------------------------------------ profiling */

@@ -27,6 +27,7 @@
 #include <type_traits>
 
 #include "kmer_hash.h"
+#include "kmer_stream.h"
 #include "sketch_internal.h"
 
 namespace mg {
@@ -36,7 +37,6 @@ namespace mg {
 // NT=1024 (s <= 12288, e.g. the s=10000 configuration): the candidate buffer takes
 // 128 KB of LDS, so the tile shrinks to 28 starts per lane (7-dword stride) and the
 // capacity check runs every 4 k-mers.
-__host__ __device__ constexpr int sk_L(int nt) { return nt == 256 ? 60 : 28; }
 __host__ __device__ constexpr int sk_seg_dw(int nt) { return nt == 256 ? 2 : 1; }
 constexpr int SK_E = 16;          // buffer elements per thread during unique-compaction
 constexpr uint64_t HPAD = 0xFFFFFFFFFFFFFFFFULL;
@@ -365,12 +365,9 @@ __global__ __launch_bounds__(256) void count_chunks_kernel(CountArgs a)
 {
     constexpr int NT = 256;
     extern __shared__ __align__(16) unsigned char smem[];
-    constexpr int SK_L = sk_L(NT);
-    constexpr int TILE = NT * SK_L;
-    constexpr int TILE_DW = TILE / 4 + 32;
     uint64_t *hl = reinterpret_cast<uint64_t *>(smem);                              // [s]
     uint32_t *tile = reinterpret_cast<uint32_t *>(smem + (size_t)a.sketch_size * 8);
-    uint8_t *alpha = reinterpret_cast<uint8_t *>(tile + TILE_DW);
+    uint8_t *alpha = reinterpret_cast<uint8_t *>(tile + sk_tile_dw(NT));
 
     const int tid = threadIdx.x;
     const SketchWork w = a.work[blockIdx.x];
@@ -385,79 +382,24 @@ __global__ __launch_bounds__(256) void count_chunks_kernel(CountArgs a)
     const uint64_t tstar = a.phase ? a.tstar[w.sketch] : 0;
     uint32_t *cnt = a.counts + (uint64_t)w.sketch * s;
     unsigned long long *fp = a.firstpos + (uint64_t)w.sketch * s;
-    const uint32_t seed = a.seed;
-    const bool use64 = a.use64 != 0, fold = a.fold_case != 0;
-    constexpr int NBYTES = SK_L + K - 1;
-    constexpr int ND = (NBYTES + 3) / 4;
-
-    for (uint64_t t0 = w.begin; t0 < w.end; t0 += TILE) {
-        const uint64_t a0 = t0 & ~15ULL;
-        const uint32_t shift = (uint32_t)(t0 - a0);
-        for (int q = tid; q < TILE_DW / 4; q += NT) {
-            const uint64_t o = a0 + (uint64_t)q * 16;
-            uint4 x = make_uint4(0, 0, 0, 0);
-            if (o + 16 <= w.limit) {
-                x = *reinterpret_cast<const uint4 *>(a.bases + o);
-            } else if (o < w.limit) {
-                uint32_t d[4] = {0, 0, 0, 0};
-                for (int b = 0; b < 16 && o + b < w.limit; b++)
-                    d[b >> 2] |= (uint32_t)a.bases[o + b] << (8 * (b & 3));
-                x = make_uint4(d[0], d[1], d[2], d[3]);
+    const uint32_t phase = a.phase;
+    stream_chunk<K, MODE, NT>(a.bases, w, tile, alpha, a.fold_case != 0, a.seed, a.use64 != 0,
+                              [&](uint64_t h, uint64_t kpos) {
+        if (h > T) return;
+        if (phase == 0) {
+            uint32_t lo = 0, hi = n;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (hl[mid] < h) lo = mid + 1; else hi = mid;
             }
-            reinterpret_cast<uint4 *>(tile)[q] = x;
-        }
-        __syncthreads();
-        const uint32_t lane_byte0 = shift + (uint32_t)tid * SK_L;
-        const uint32_t *lw = tile + (lane_byte0 >> 2);
-        const uint32_t bsh = lane_byte0 & 3;
-        const uint64_t rem64 = w.end - t0;
-        const uint32_t remaining = rem64 > (uint64_t)TILE ? (uint32_t)TILE : (uint32_t)rem64;
-        const uint32_t lane_first = (uint32_t)tid * SK_L;
-        KmerRoller<K, MODE == 0> r;
-        r.reset();
-        uint32_t cur = lw[0];
-#pragma unroll 1
-        for (int d = 0; d < ND; d++) {
-            const uint32_t nxt = lw[d + 1];
-            const uint32_t word = __builtin_amdgcn_alignbyte(nxt, cur, bsh);
-            cur = nxt;
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const int pos = 4 * d + b;
-                uint32_t c = (word >> (8 * b)) & 0xFFu;
-                if (MODE == 2) {
-                    if (fold) c = fold_upper(c);
-                    r.push(c, alpha[c] != 0);
-                } else {
-                    if (fold) c &= 0xDFu;
-                    uint32_t code, comp;
-                    const bool valid = dna_classify(c, code, comp);
-                    r.push(c, valid, code, comp);
-                }
-                if (pos >= K - 1 && pos < NBYTES) {
-                    const uint32_t start = (uint32_t)(pos - (K - 1));
-                    const uint64_t h = r.hash(seed, use64);
-                    if (r.kmer_valid() && (lane_first + start < remaining) && h <= T) {
-                        const uint64_t kpos = t0 + lane_first + start;
-                        if (a.phase == 0) {
-                            uint32_t lo = 0, hi = n;
-                            while (lo < hi) {
-                                const uint32_t mid = (lo + hi) >> 1;
-                                if (hl[mid] < h) lo = mid + 1; else hi = mid;
-                            }
-                            if (lo < n && hl[lo] == h) {          // always true: every value <= h_max is kept
-                                atomicAdd(&cnt[lo], 1u);
-                                atomicMin(&fp[lo], (unsigned long long)kpos);
-                            }
-                        } else if (h == T && kpos <= tstar) {
-                            atomicAdd(&cnt[n - 1], 1u);
-                        }
-                    }
-                }
+            if (lo < n && hl[lo] == h) {                   // always true: every value <= h_max is kept
+                atomicAdd(&cnt[lo], 1u);
+                atomicMin(&fp[lo], (unsigned long long)kpos);
             }
+        } else if (h == T && kpos <= tstar) {
+            atomicAdd(&cnt[n - 1], 1u);
         }
-        __syncthreads();
-    }
+    });
 }
 
 // one thread per sketch: t* = latest first occurrence among the kept hashes of a FULL sketch;

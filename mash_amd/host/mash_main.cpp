@@ -1,4 +1,4 @@
-// mash_main.cpp — `mash sketch | dist | triangle | info | paste` on the MI355X hot path.
+// mash_main.cpp — `mash sketch | dist | triangle | info | paste | screen` on the MI355X hot path.
 //
 // Host C++ above the C ABI (include/mashgpu.h).  Option letters, defaults, file naming,
 // stdout/stderr text and output order follow the reference commands
@@ -950,6 +950,145 @@ int cmd_paste(int argc, const char **argv)
     return 0;
 }
 
+// mash screen (CommandScreen.cpp:54-461), nucleotide query sketches
+int cmd_screen(int argc, const char **argv)
+{
+    Cmd c;
+    c.name = "screen";
+    c.add("help", Opt::Boolean, "h");
+    c.add("threads", Opt::Integer, "p", "1");
+    c.add("winning!", Opt::Boolean, "w");
+    c.add("identity", Opt::Number, "i", "0", -1., 1.);
+    c.add("pvalue", Opt::Number, "v", "1.0", 0., 1.);
+    if (c.parse(argc, argv)) return 1;
+    if (c.args.size() < 2 || c.o("help").active) {
+        cout << "\nUsage:\n\n  mash screen [options] <queries>.msh <mixture> [<mixture>] ...\n\n"
+                "Output fields: [identity, shared-hashes, median-multiplicity, p-value, query-ID, query-comment].\n"
+                "Options: -w (winner-takes-all) -i <min identity> -v <max p-value>\n\n";
+        return 0;
+    }
+    if (!has_suffix(c.args[0], kSuffix)) { cerr << "ERROR: " << c.args[0] << " does not look like a sketch (.msh)" << endl; exit(1); }
+    const double p_max = c.o("pvalue").num, identity_min = c.o("identity").num;
+    SketchSet set;
+    load_msh_into(set, c.args[0], true);
+    if (set.p.alphabet == normalise_alphabet(kAlphabetProtein, false)) {
+        cerr << "ERROR: 6-frame translation for amino-acid sketches is not supported by the GPU screen path." << endl;
+        return 1;
+    }
+    Gpu gpu;
+    cerr << "Loading " << c.args[0] << "..." << endl;
+    const uint64_t n = set.refs.size(), s = set.p.sketch_size;
+    mg_table *t = upload(gpu, set, s);
+    mg_params mp;
+    mg_params_init(&mp, set.p.kmer, s, set.p.seed, set.p.alphabet.c_str(), set.p.noncanonical, set.p.preserve_case);
+    mg_screen *sc = nullptr;
+    if (mg_screen_create(gpu.ctx, &mp, t, &sc) != MG_OK) { cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl; return 1; }
+    const int nq = (int)c.args.size() - 1;
+    vector<fastx::Reader *> readers;
+    for (int f = 1; f <= nq; f++) {
+        if (c.args[f] == "-" && f > 1) { cerr << "ERROR: '-' for stdin must be first query" << endl; exit(1); }
+        fastx::Reader *r = new fastx::Reader;
+        if (!r->open(c.args[f])) { cerr << "ERROR: could not open " << c.args[f] << endl; exit(1); }
+        readers.push_back(r);
+    }
+    // mixture records, round robin over the inputs (CommandScreen.cpp:197-270); records < k are dropped
+    vector<uint8_t> batch;
+    batch.reserve(256u << 20);
+    auto flush = [&]() {
+        if (batch.empty()) return;
+        if (mg_screen_add_host(sc, batch.data(), batch.size()) != MG_OK) { cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl; exit(1); }
+        batch.clear();
+    };
+    fastx::Record rec;
+    size_t it = 0;
+    long l = -1;
+    uint64_t count = 0;
+    while (!readers.empty()) {
+        l = readers[it]->next(rec);
+        if (l < -1) break;
+        if (l == -1) {
+            delete readers[it];
+            readers.erase(readers.begin() + it);
+            if (it == readers.size()) it = 0;
+            continue;
+        }
+        count++;
+        if (l >= set.p.kmer) {
+            batch.insert(batch.end(), rec.seq.begin(), rec.seq.end());
+            batch.push_back((uint8_t)MG_RECORD_SEP);
+            if (batch.size() > (255u << 20)) flush();
+        }
+        it++;
+        if (it == readers.size()) it = 0;
+    }
+    for (auto *r : readers) delete r;
+    if (l != -1) { cerr << "\nERROR: reading inputs" << endl; exit(1); }
+    flush();
+    vector<uint32_t> counts(std::max<uint64_t>(n * s, 1));
+    vector<uint64_t> mix(s);
+    uint32_t mix_n = 0;
+    uint64_t distinct = 0;
+    if (mg_screen_finish_host(sc, counts.data(), mix.data(), &mix_n, &distinct) != MG_OK) { cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl; return 1; }
+    mg_screen_free(sc);
+    mg_table_free(t);
+    cerr << "   " << distinct << " distinct hashes." << endl;
+    cerr << "Streaming from ";
+    if (nq == 1) cerr << c.args[1]; else cerr << nq << " inputs";
+    cerr << "..." << endl;
+    if (count == 0) { cerr << "\nERROR: Did not find sequence records in inputs" << endl; exit(1); }
+    // estimateSetSize of the mixture's bottom-s (MinHashHeap.h:45, CommandScreen.cpp:322)
+    double est = 0;
+    if (mix_n) est = std::pow(2.0, set.p.use64 ? 64.0 : 32.0) * (double)mix_n / (double)mix[mix_n - 1];
+    const uint64_t set_size = (uint64_t)est;
+    cerr << "   Estimated distinct k-mers in mixture: " << set_size << endl;
+    if (set_size == 0) cerr << "WARNING: no valid k-mers in input." << endl;
+    cerr << "Summing shared..." << endl;
+    vector<uint64_t> shared(n, 0);
+    vector<vector<uint64_t>> depths(n);
+    for (uint64_t i = 0; i < n; i++)
+        for (size_t j = 0; j < set.refs[i].hashes.size() && j < s; j++)
+            if (counts[i * s + j] >= 1) { shared[i]++; depths[i].push_back(counts[i * s + j]); }
+    const double kspace = set.kmer_space();
+    if (c.o("winning!").active) {
+        cerr << "Reallocating to winners..." << endl;
+        vector<double> scores(n);
+        for (uint64_t i = 0; i < n; i++) scores[i] = mg_identity(shared[i], set.refs[i].hashes.size(), set.p.kmer);
+        // each observed hash goes to the best-scoring sketch containing it (ties: larger length, then first seen)
+        std::map<uint64_t, vector<uint32_t>> owners;
+        std::map<uint64_t, uint32_t> obs;
+        for (uint64_t i = 0; i < n; i++)
+            for (size_t j = 0; j < set.refs[i].hashes.size() && j < s; j++)
+                if (counts[i * s + j] >= 1) { owners[set.refs[i].hashes[j]].push_back((uint32_t)i); obs[set.refs[i].hashes[j]] = counts[i * s + j]; }
+        std::fill(shared.begin(), shared.end(), 0);
+        for (auto &d : depths) d.clear();
+        for (const auto &kv : owners) {
+            double max_score = 0;
+            uint64_t max_len = 0, max_idx = kv.second[0];
+            for (uint32_t k : kv.second) {
+                if (scores[k] > max_score) { max_score = scores[k]; max_idx = k; max_len = set.refs[k].length; }
+                else if (scores[k] == max_score && set.refs[k].length > max_len) { max_idx = k; max_len = set.refs[k].length; }
+            }
+            shared[max_idx]++;
+            depths[max_idx].push_back(obs[kv.first]);
+        }
+    }
+    cerr << "Computing coverage medians..." << endl;
+    for (auto &d : depths) std::sort(d.begin(), d.end());
+    cerr << "Writing output..." << endl;
+    for (uint64_t i = 0; i < n; i++) {
+        if (shared[i] != 0 || identity_min < 0.0) {
+            const uint64_t denom = set.refs[i].hashes.size();
+            const double identity = mg_identity(shared[i], denom, set.p.kmer);
+            if (identity < identity_min) continue;
+            const double pv = mg_p_value_within(shared[i], set_size, kspace, denom);
+            if (pv > p_max) continue;
+            cout << identity << '\t' << shared[i] << '/' << denom << '\t' << (shared[i] > 0 ? depths[i].at(shared[i] / 2) : 0)
+                 << '\t' << pv << '\t' << set.refs[i].name << '\t' << set.refs[i].comment << endl;
+        }
+    }
+    return 0;
+}
+
 // test/interchange helper: rebuild a .msh from the JSON `mash info -d` prints (no GPU)
 int cmd_json2msh(int argc, const char **argv)
 {
@@ -1014,7 +1153,8 @@ int main(int argc, const char **argv)
         "\nMash (MI355X hot path), commands:\n\n  sketch    Create sketches (reduced representations for fast operations).\n"
         "  dist      Estimate the distance of query sequences to references.\n"
         "  triangle  Estimate a lower-triangular distance matrix.\n  info      Display information about sketch files.\n"
-        "  paste     Create a single sketch file from multiple sketch files.\n\n";
+        "  paste     Create a single sketch file from multiple sketch files.\n"
+        "  screen    Determine whether query sequences are within a larger mixture of sequences.\n\n";
     if (argc < 2) { cout << usage; return 0; }
     const string cmd = argv[1];
     if (cmd == "sketch") return cmd_sketch(argc - 2, argv + 2);
@@ -1022,6 +1162,7 @@ int main(int argc, const char **argv)
     if (cmd == "triangle") return cmd_triangle(argc - 2, argv + 2);
     if (cmd == "info") return cmd_info(argc - 2, argv + 2);
     if (cmd == "paste") return cmd_paste(argc - 2, argv + 2);
+    if (cmd == "screen") return cmd_screen(argc - 2, argv + 2);
     if (cmd == "json2msh") return cmd_json2msh(argc - 2, argv + 2);
     if (cmd == "--version") { cout << "2.3-mi355x" << endl; return 0; }
     cerr << "ERROR: Unknown command: " << cmd << endl;

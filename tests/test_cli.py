@@ -171,6 +171,24 @@ def test_make_test_recipe_on_gpu(built, tmp_path, oracle):
 
 
 @pytest.mark.gpu
+def test_make_test_screen_recipe_on_gpu(built, tmp_path):
+    """testScreen of the reference's Makefile (Makefile.in:113-115):
+    mash screen genomes.msh reads1.fastq reads2.fastq == test/ref/screen, byte for byte."""
+    for f in ("reads1.fastq", "reads2.fastq"):
+        with gzip.open(os.path.join(GOLD, f + ".gz"), "rb") as fi, open(tmp_path / f, "wb") as fo:
+            shutil.copyfileobj(fi, fo)
+    run("json2msh", os.path.join(GOLD, "genomes.json"), "genomes.msh", cwd=tmp_path)
+    r = run("screen", "genomes.msh", "reads1.fastq", "reads2.fastq", cwd=tmp_path)
+    assert r.stdout == open(os.path.join(GOLD, "screen")).read()
+    assert "Estimated distinct k-mers in mixture: 502359" in r.stderr and "distinct hashes." in r.stderr
+    w = run("screen", "-w", "genomes.msh", "reads1.fastq", "reads2.fastq", cwd=tmp_path).stdout.splitlines()
+    tot = sum(int(l.split("\t")[1].split("/")[0]) for l in w)
+    assert 44 <= tot <= 44 + 36 and len(w) >= 1                      # shared hashes are assigned to one winner each
+    none = run("screen", "-i", "0.95", "genomes.msh", "reads1.fastq", cwd=tmp_path).stdout
+    assert none == ""
+
+
+@pytest.mark.gpu
 def test_sketch_and_triangle_cli_vs_oracle(built, tmp_path, oracle):
     rng = np.random.default_rng(3)
     genomes = [synth._rand_dna(rng, 40000) for _ in range(5)]

@@ -262,3 +262,74 @@ def test_compare_c3_scale_properties(eng, oracle):
     same = (np.arange(i) % 60) == (i % 60)
     assert row["numer"][same].min() > 300 and row["numer"][~same].max() < 50
     t.free()
+
+
+# ---------------------------------------------------------------- screening
+
+def test_screen_golden(eng, golden_dir):
+    """mash screen genomes.msh reads1.fastq reads2.fastq == test/ref/screen, through the ABI:
+    device hash table of the 3 golden sketches, every k-mer of the reads probed on the GPU."""
+    gh, glens, names = helpers.load_golden_genomes()
+    r1 = helpers.read_fastx(os.path.join(golden_dir, "reads1.fastq.gz"))
+    r2 = helpers.read_fastx(os.path.join(golden_dir, "reads2.fastq.gz"))
+    recs = [r[2] for r in helpers.round_robin([r1, r2]) if len(r[2]) >= 21]
+    db = eng.table_upload(gh, np.full(3, 1000, np.uint32), glens)
+    p = eng.params(k=21, s=1000)
+    half = len(recs) // 2
+    counts, mix, distinct = eng.screen(db, p, [recs[:half], recs[half:]])        # two batches
+    rh, rlen, _ = helpers.load_golden_reads()
+    assert np.array_equal(mix, rh)                                     # mixture bottom-s == sketch of all reads
+    set_size = int(2.0 ** 64 * len(mix) / float(mix[-1]))
+    assert set_size == rlen
+    assert distinct == len(np.unique(gh))
+    lines = [ln.rstrip("\n").split("\t") for ln in open(os.path.join(golden_dir, "screen"))]
+    for i in range(3):
+        shared = int((counts[i] > 0).sum())
+        depths = np.sort(counts[i][counts[i] > 0])
+        assert "%d/%d" % (shared, 1000) == lines[i][1]
+        assert "%g" % eng.lib.mg_identity(shared, 1000, 21) == lines[i][0]
+        assert str(int(depths[shared // 2])) == lines[i][2]
+        assert "%g" % eng.lib.mg_p_value_within(shared, set_size, KSPACE21, 1000) == lines[i][3]
+    db.free()
+
+
+def test_screen_counts_vs_oracle(eng, oracle):
+    """Observation counts of every sketch hash vs a direct count over oracle hashes, incl.
+    multi-chunk mixtures, N / lowercase / short records and repeats."""
+    rng = np.random.default_rng(8)
+    genomes = [synth._rand_dna(rng, 30000) for _ in range(4)]
+    p = eng.params(k=21, s=500)
+    op = oracle.params(k=21, s=500)
+    hashes, nhash = eng.sketch_host([[g] for g in genomes], p)
+    db = eng.table_upload(hashes, nhash, np.full(4, 30000, np.uint64))
+    reads = []
+    for _ in range(3000):
+        g = genomes[int(rng.integers(0, 3))]                         # genome 3 is never sampled
+        st = int(rng.integers(0, 30000 - 150))
+        r = bytearray(g[st:st + 150])
+        if rng.random() < 0.3:
+            r[int(rng.integers(0, 150))] = ord("N")
+        if rng.random() < 0.2:
+            r = bytearray(bytes(r).lower())
+        reads.append(bytes(r) if rng.random() < 0.5 else bytes(_revcomp(bytes(r).upper())))
+    reads += [b"ACGT", b"", synth.adversarial_dna_records(rng, 2)[0]]
+    counts, mix, _ = eng.screen(db, p, [reads[:1000], reads[1000:]])
+    # expected: hash every valid canonical k-mer of every read on the CPU
+    want = {}
+    for r in reads:
+        if len(r) < 21:
+            continue
+        h, c, _, _, _ = oracle.sketch_records([r], oracle.params(k=21, s=100000))
+        for hv, cv in zip(h, c):
+            want[int(hv)] = want.get(int(hv), 0) + int(cv)
+    for i in range(4):
+        exp = np.array([want.get(int(x), 0) for x in hashes[i, : nhash[i]]], dtype=np.uint32)
+        assert np.array_equal(counts[i, : nhash[i]], exp), i
+    assert counts[3].sum() <= counts[0].sum()
+    allh = np.array(sorted(want), dtype=np.uint64)[:500]
+    assert np.array_equal(mix, allh)
+    db.free()
+
+
+def _revcomp(b):
+    return bytes({65: 84, 67: 71, 71: 67, 84: 65, 78: 78}[x] for x in reversed(b))
