@@ -2,6 +2,10 @@
 
 The product is the C ABI; this module only loads it.  There is no CPU fallback:
 if the HIP library is missing or no GPU is visible, calls fail loudly.
+
+Note for processes that also use torch on the GPU: call torch.cuda.init() BEFORE creating a
+MashGpu context — torch wheels bundle their own HIP runtime and it must be the one that
+initialises first (bench.py and the tests do this); the library itself never needs torch.
 """
 import ctypes as C
 import os

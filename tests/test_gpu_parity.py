@@ -19,6 +19,10 @@ KSPACE21 = 4.0 ** 21
 
 @pytest.fixture(scope="module")
 def eng():
+    # torch ships its own HIP runtime: when both live in one process torch must initialise first
+    # (the loader then shares one runtime); the library itself never needs torch.
+    import torch
+    torch.cuda.init()
     e = abi.MashGpu(0)
     yield e
     e.close()
@@ -333,3 +337,81 @@ def test_screen_counts_vs_oracle(eng, oracle):
 
 def _revcomp(b):
     return bytes({65: 84, 67: 71, 71: 67, 84: 65, 78: 78}[x] for x in reversed(b))
+
+
+# ---------------------------------------------------------------- BASELINE-size runs (device-resident)
+
+def test_c2_scale_sketch_properties(eng, oracle, monkeypatch):
+    """BASELINE config 2 at 1/10 scale, device resident: 1000 synthetic 1 Mbp genomes (10^9 bases)
+    sketched in one call.  (a) every sketch is full, ascending, distinct; (b) sampled genomes equal
+    the oracle; (c) a different work decomposition (forced multi-chunk + merge kernel) gives the
+    identical table; (d) multiplicities sum to the number of k-mers for a repeat-free genome's keys."""
+    import torch
+    from mash_amd import synth_torch
+    ng, L = 1000, 1_000_000
+    dev = torch.device("cuda", 0)
+    bases = synth_torch.synthetic_genomes(0, ng, L, device=dev)
+    off = np.arange(ng + 1, dtype=np.uint64) * np.uint64(L)
+    p = eng.params(k=21, s=1000)
+    out = torch.empty((ng, 1000), dtype=torch.int64, device=dev)
+    nh = torch.empty(ng, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    eng.sketch_dev(bases.data_ptr(), ng * L, off, p, out.data_ptr(), nh.data_ptr())
+    eng.synchronize()
+    assert int(nh.min()) == 1000 and int(nh.max()) == 1000
+    assert bool((out[:, 1:] > out[:, :-1]).all())                    # values < 2^63 here: signed compare is fine
+    host = out.cpu().numpy().view(np.uint64)
+    op = oracle.params(k=21, s=1000)
+    for g in (0, 1, 499, 999):
+        h, _, _, _, _ = oracle.sketch_records([bytes(synth.synthetic_genome(g, L))], op)
+        assert np.array_equal(host[g], h), g
+    monkeypatch.setenv("MASHGPU_SKETCH_MIN_CHUNK", "61440")
+    monkeypatch.setenv("MASHGPU_SKETCH_ITEMS", "1000000")
+    out2 = torch.empty_like(out)
+    nh2 = torch.empty_like(nh)
+    eng.sketch_dev(bases.data_ptr(), ng * L, off, p, out2.data_ptr(), nh2.data_ptr())
+    eng.synchronize()
+    assert torch.equal(out, out2) and torch.equal(nh, nh2)
+
+
+def test_c3_scale_triangle_properties(eng, oracle):
+    """BASELINE config 3 at N = 40 000 (8.0e8 pairs, 6.4 GB of results resident in HBM):
+    (a) denom == s and numer <= s everywhere; (b) sampled rows equal the oracle;
+    (c) a row block recomputed with the per-row tiled kernel and with the generic kernel is
+    identical; (d) cluster structure of the synthetic table."""
+    import torch
+    from mash_amd import synth_torch
+    n, s = 40000, 1000
+    dev = torch.device("cuda", 0)
+    hashes, nhash, lengths = synth_torch.clustered_sketch_table(n, s, clusters=400, device=dev)
+    table = eng.table_wrap(hashes.data_ptr(), nhash.data_ptr(), lengths.data_ptr(), n, s)
+    out = torch.empty((n * (n - 1) // 2, 2), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    eng.compare_tri_dev(table, 0, n, out.data_ptr())
+    eng.synchronize()
+    assert int(out[:, 1].min()) == s and int(out[:, 1].max()) == s and int(out[:, 0].max()) <= s
+    th = hashes.cpu().numpy().view(np.uint64)
+    tn = nhash.cpu().numpy().astype(np.uint32)
+    tl = lengths.cpu().numpy().astype(np.uint64)
+    for i in (1, 17, 4096, 20001, 39999):
+        numer, denom = _oracle_tri(oracle, th, tn, tl, i, i + 1)
+        row = out[i * (i - 1) // 2: i * (i - 1) // 2 + i].cpu().numpy()
+        assert np.array_equal(row[:, 0], numer) and np.array_equal(row[:, 1], denom), i
+    lo, hi = 30000, 30200
+    base = lo * (lo - 1) // 2
+    npairs = hi * (hi - 1) // 2 - base
+    ref_block = out[base: base + npairs].cpu()
+    for other in ("tiled", "generic"):
+        os.environ["MASHGPU_COMPARE_KERNEL"] = other
+        try:
+            o2 = torch.empty((npairs, 2), dtype=torch.int32, device=dev)
+            eng.compare_tri_dev(table, lo, hi, o2.data_ptr())
+            eng.synchronize()
+        finally:
+            del os.environ["MASHGPU_COMPARE_KERNEL"]
+        assert torch.equal(o2.cpu(), ref_block), other
+    i = 33333
+    row = out[i * (i - 1) // 2: i * (i - 1) // 2 + i, 0].cpu().numpy()
+    same = (np.arange(i) % 400) == (i % 400)
+    assert row[same].min() > 300 and row[~same].max() < 50
+    table.free()
