@@ -141,6 +141,25 @@ int mg_compare_rect_dev(mg_ctx *ctx, const mg_table *ref, const mg_table *qry,
 int mg_compare_rect_host(mg_ctx *ctx, const mg_table *ref, const mg_table *qry,
                          uint64_t q_begin, uint64_t q_end, mg_counts *out_host);
 
+/* Thresholded all-pairs ("edge list": `mash dist -d`, `mash triangle -E -d`).
+ * Same pairs and order as the calls above, but the distance filter of
+ * compareSketches (CommandDistance.cpp:409-412, `distance > maxDistance` rejects)
+ * and the compaction run on the device: only surviving pairs cross PCIe.
+ * The filter is exact: the threshold is converted on the host (same libm as
+ * mg_finish_*) into the smallest passing numer per denom and the device compares
+ * integers.  out_host receives the survivors in reference order (row-major;
+ * row = triangle row i / query index, col = j / reference index); *count_out is
+ * their total number.  If it exceeds `capacity`, MG_ERR_NOMEM is returned, the
+ * content of out_host is unspecified and the caller retries with *count_out
+ * entries.  The p-value filter (:419-422) stays with the caller (mg_p_value). */
+typedef struct mg_edge { uint32_t row, col, numer, denom; } mg_edge;
+int mg_compare_tri_filter_host(mg_ctx *ctx, const mg_table *t, uint64_t row_begin, uint64_t row_end,
+                               int kmer_size, double max_distance, mg_edge *out_host,
+                               uint64_t capacity, uint64_t *count_out);
+int mg_compare_rect_filter_host(mg_ctx *ctx, const mg_table *ref, const mg_table *qry,
+                                uint64_t q_begin, uint64_t q_end, int kmer_size, double max_distance,
+                                mg_edge *out_host, uint64_t capacity, uint64_t *count_out);
+
 /* Distance + p-value + filters for pairs already counted (the tail of
  * compareSketches, CommandDistance.cpp:387-424, and pValue, :427-448).
  * Host arithmetic (glibc log, the same libm the reference links), so distances

@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmashgpu.so")
 
 MG_OK = 0
+MG_ERR_NOMEM = -4
 HASH_PAD = 0xFFFFFFFFFFFFFFFF
 RECORD_SEP = 0x0A
 
@@ -24,6 +25,7 @@ EXPORTS = [
     "mg_ctx_cu_count", "mg_params_init", "mg_sketch_host", "mg_sketch_dev", "mg_table_upload",
     "mg_table_wrap_dev", "mg_table_free", "mg_table_rows", "mg_table_sketch_size",
     "mg_compare_tri_dev", "mg_compare_tri_host", "mg_compare_rect_dev", "mg_compare_rect_host",
+    "mg_compare_tri_filter_host", "mg_compare_rect_filter_host",
     "mg_finish_tri_host", "mg_finish_rect_host", "mg_distance", "mg_p_value",
     "mg_prof_enable", "mg_prof_reset", "mg_prof_avg_ms",
     "mg_screen_create", "mg_screen_add_host", "mg_screen_add_dev", "mg_screen_finish_host", "mg_screen_free",
@@ -59,6 +61,7 @@ class MgPair(C.Structure):
 PAIR_DTYPE = np.dtype([("numer", "<u4"), ("denom", "<u4"), ("distance", "<f8"), ("p_value", "<f8"),
                        ("pass", "u1"), ("_pad", "u1", 7)])
 COUNTS_DTYPE = np.dtype([("numer", "<u4"), ("denom", "<u4")])
+EDGE_DTYPE = np.dtype([("row", "<u4"), ("col", "<u4"), ("numer", "<u4"), ("denom", "<u4")])
 
 
 class MashGpuError(RuntimeError):
@@ -95,6 +98,8 @@ def load_library():
     lib.mg_compare_tri_host.argtypes = [vp, vp, u64, u64, vp]
     lib.mg_compare_rect_dev.argtypes = [vp, vp, vp, u64, u64, vp]
     lib.mg_compare_rect_host.argtypes = [vp, vp, vp, u64, u64, vp]
+    lib.mg_compare_tri_filter_host.argtypes = [vp, vp, u64, u64, C.c_int, C.c_double, vp, u64, vp]
+    lib.mg_compare_rect_filter_host.argtypes = [vp, vp, vp, u64, u64, C.c_int, C.c_double, vp, u64, vp]
     lib.mg_finish_tri_host.argtypes = [vp, vp, u64, u64, i32, dbl, dbl, dbl, vp]
     lib.mg_finish_rect_host.argtypes = [vp, vp, u64, vp, u64, i32, dbl, dbl, dbl, vp]
     lib.mg_distance.argtypes = [u32, u32, i32]
@@ -253,6 +258,30 @@ class MashGpu:
 
     def compare_rect_dev(self, ref, qry, q_begin, q_end, out_ptr):
         self._check(self.lib.mg_compare_rect_dev(self.ctx, ref.handle, qry.handle, q_begin, q_end, out_ptr))
+
+    def _filter(self, call, capacity):
+        """run a *_filter_host call, growing the edge buffer once if the first guess was too small"""
+        n = C.c_uint64(0)
+        for _ in range(2):
+            out = np.zeros(max(int(capacity), 1), dtype=EDGE_DTYPE)
+            rc = call(out.ctypes.data, int(capacity), C.byref(n))
+            if rc == MG_OK:
+                return out[:n.value]
+            if rc != MG_ERR_NOMEM or n.value <= capacity:               # MG_ERR_NOMEM with a count: retry
+                self._check(rc)
+            capacity = n.value
+        self._check(rc)
+
+    def compare_tri_filter(self, table, k, max_d, row_begin=0, row_end=None, capacity=1 << 20):
+        """pairs of rows [row_begin,row_end) x earlier rows with distance <= max_d, reference order"""
+        row_end = table.rows if row_end is None else min(row_end, table.rows)
+        return self._filter(lambda o, c, n: self.lib.mg_compare_tri_filter_host(
+            self.ctx, table.handle, row_begin, row_end, k, max_d, o, c, n), capacity)
+
+    def compare_rect_filter(self, ref, qry, k, max_d, q_begin=0, q_end=None, capacity=1 << 20):
+        q_end = qry.rows if q_end is None else min(q_end, qry.rows)
+        return self._filter(lambda o, c, n: self.lib.mg_compare_rect_filter_host(
+            self.ctx, ref.handle, qry.handle, q_begin, q_end, k, max_d, o, c, n), capacity)
 
     # ---- finishing (host arithmetic) --------------------------------------------
     def finish_tri(self, counts, lengths, row_begin, row_end, k, kmer_space, max_d=-1.0, max_p=-1.0):

@@ -46,4 +46,25 @@ hipError_t launch_make_prefix(const uint64_t *hashes, uint64_t count, uint32_t s
 // Generic kernel (any s): one wave per pair, binary search in global memory.
 hipError_t launch_compare_generic(const CompareArgs &a, hipStream_t stream);
 
+// Distance filter + ordered compaction (see filter_pass_kernel).  `counts` holds
+// `pairs` entries in the layout the compare kernels write, starting at row
+// `first_row` (triangle row / query index).  Survivors with rank in
+// [win_lo, win_lo + win_n) are written to edges[rank - win_lo].
+struct FilterArgs {
+    const uint2 *counts;
+    const uint32_t *min_numer;    // [s+1] smallest numer passing the distance filter, per denom
+    uint32_t *seg_count;          // [filter_segments(pairs)]
+    unsigned long long *seg_off;  // [filter_segments(pairs)] exclusive scan of seg_count
+    uint4 *edges;                 // {row, col, numer, denom}
+    uint64_t pairs;
+    uint64_t first_row;
+    uint64_t ncols;               // rect: number of refs
+    uint64_t win_lo, win_n;
+    uint32_t s;
+    uint32_t triangle;
+};
+uint64_t filter_segments(uint64_t pairs);
+hipError_t launch_filter_count(const FilterArgs &a, unsigned long long *total, hipStream_t stream);
+hipError_t launch_filter_write(const FilterArgs &a, hipStream_t stream);
+
 }  // namespace mg

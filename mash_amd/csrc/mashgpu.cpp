@@ -694,6 +694,137 @@ int mg_finish_rect_host(const mg_counts *counts, const uint64_t *len_ref, uint64
     return MG_OK;
 }
 
+/* ------------------------------------------------- thresholded all-pairs (edge list) */
+
+// smallest numer whose distance passes `max_d`, for every denom in [0, s]: the
+// same host arithmetic finish_one uses, so the device's integer test selects
+// exactly the pairs the reference's `distance > maxDistance` test keeps.
+static void build_min_numer(uint32_t s, int k, double max_d, std::vector<uint32_t> &out)
+{
+    out.assign((size_t)s + 1, 0);
+    for (uint32_t d = 0; d <= s; d++) {
+        if (mg::mash_distance(0, d, k) <= max_d) { out[d] = 0; continue; }
+        if (!(mg::mash_distance(d, d, k) <= max_d)) { out[d] = d + 1; continue; }
+        uint32_t lo = 0, hi = d;                           // lo fails, hi passes
+        while (hi - lo > 1) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if (mg::mash_distance(mid, d, k) <= max_d) hi = mid; else lo = mid;
+        }
+        out[d] = hi;
+    }
+}
+
+static int compare_filter(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, uint64_t rb, uint64_t re,
+                          bool triangle, int kmer_size, double max_distance, mg_edge *out_host, uint64_t capacity,
+                          uint64_t *count_out)
+{
+    *count_out = 0;
+    if (re > rows->n) re = rows->n;
+    if (rb >= re) return MG_OK;
+    if (kmer_size < 1) return fail(ctx, MG_ERR_INVALID, "compare filter: bad k-mer size");
+    const uint64_t s64 = std::min(rows->s, cols->s);
+    if (s64 > 0xFFFFFFFEull) return fail(ctx, MG_ERR_INVALID, "compare: sketch size too large");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::vector<uint32_t> min_numer;
+    build_min_numer((uint32_t)s64, kmer_size, max_distance, min_numer);
+
+    // row blocks of up to 2^30 pairs (8 GiB of counts): large launches keep the
+    // tail of the compare kernel short; survivors leave in windows of 2^26 edges
+    const uint64_t max_pairs = 1ull << 30, window = 1ull << 26;
+    const uint64_t all_pairs = triangle ? tri_pairs(rb, re) : (re - rb) * cols->n;
+    const uint64_t blk_pairs = std::min(all_pairs, max_pairs + (triangle ? re : cols->n));
+    mg_counts *d_counts = nullptr;
+    uint4 *d_edges = nullptr;
+    uint32_t *d_min = nullptr, *d_segc = nullptr;
+    unsigned long long *d_sego = nullptr, *d_n = nullptr;
+    uint64_t total = 0, r = rb;
+    int rc = MG_OK;
+    auto cleanup = [&]() {
+        hipStreamSynchronize(ctx->stream);
+        for (void *p : {(void *)d_counts, (void *)d_edges, (void *)d_min, (void *)d_segc, (void *)d_sego, (void *)d_n})
+            if (p) hipFree(p);
+    };
+    if (all_pairs == 0) return MG_OK;
+    const uint64_t nseg_max = mg::filter_segments(blk_pairs);
+    if (hipMalloc(&d_min, min_numer.size() * 4) != hipSuccess || hipMalloc(&d_n, 8) != hipSuccess ||
+        hipMalloc(&d_counts, blk_pairs * sizeof(mg_counts)) != hipSuccess ||
+        hipMalloc(&d_edges, std::min(blk_pairs, window) * sizeof(uint4)) != hipSuccess ||
+        hipMalloc(&d_segc, nseg_max * 4) != hipSuccess || hipMalloc(&d_sego, nseg_max * 8) != hipSuccess ||
+        hipMemcpyAsync(d_min, min_numer.data(), min_numer.size() * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+        cleanup();
+        return fail(ctx, MG_ERR_NOMEM, "compare filter: device allocation failed");
+    }
+    while (r < re && rc == MG_OK) {
+        uint64_t r2 = r, pairs = 0;
+        while (r2 < re) {
+            const uint64_t add = triangle ? r2 : cols->n;
+            if (pairs && pairs + add > max_pairs) break;
+            pairs += add;
+            r2++;
+        }
+        if (pairs) {
+            rc = run_compare(ctx, rows, cols, r, r2, triangle, d_counts);
+            if (rc != MG_OK) break;
+            mg::FilterArgs f;
+            f.counts = reinterpret_cast<const uint2 *>(d_counts);
+            f.min_numer = d_min;
+            f.seg_count = d_segc;
+            f.seg_off = d_sego;
+            f.edges = d_edges;
+            f.pairs = pairs;
+            f.first_row = r;
+            f.ncols = cols->n;
+            f.win_lo = 0; f.win_n = 0;
+            f.s = (uint32_t)s64;
+            f.triangle = triangle ? 1 : 0;
+            unsigned long long n_blk = 0;
+            if (mg::launch_filter_count(f, d_n, ctx->stream) != hipSuccess ||
+                hipMemcpyAsync(&n_blk, d_n, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess) {
+                rc = fail(ctx, MG_ERR_HIP, "compare filter: kernel failed");
+                break;
+            }
+            // survivors already rank in reference order; skip the copy once `capacity` is exceeded
+            for (uint64_t lo = 0; lo < n_blk && total + n_blk <= capacity; lo += window) {
+                f.win_lo = lo;
+                f.win_n = std::min<uint64_t>(window, n_blk - lo);
+                if (mg::launch_filter_write(f, ctx->stream) != hipSuccess ||
+                    hipMemcpyAsync(out_host + total + lo, d_edges, f.win_n * sizeof(mg_edge), hipMemcpyDeviceToHost,
+                                   ctx->stream) != hipSuccess ||
+                    hipStreamSynchronize(ctx->stream) != hipSuccess) {
+                    rc = fail(ctx, MG_ERR_HIP, "compare filter: compaction failed");
+                    break;
+                }
+            }
+            total += n_blk;
+        }
+        r = r2;
+    }
+    cleanup();
+    if (rc != MG_OK) return rc;
+    *count_out = total;
+    if (total > capacity) return fail(ctx, MG_ERR_NOMEM, "compare filter: more passing pairs than `capacity` (see *count_out)");
+    return MG_OK;
+}
+
+int mg_compare_tri_filter_host(mg_ctx *ctx, const mg_table *t, uint64_t row_begin, uint64_t row_end, int kmer_size,
+                               double max_distance, mg_edge *out_host, uint64_t capacity, uint64_t *count_out)
+{
+    if (!ctx) return MG_ERR_INVALID;
+    if (!t || !count_out || (!out_host && capacity)) return fail(ctx, MG_ERR_INVALID, "mg_compare_tri_filter_host: NULL argument");
+    return compare_filter(ctx, t, t, row_begin, row_end, true, kmer_size, max_distance, out_host, capacity, count_out);
+}
+
+int mg_compare_rect_filter_host(mg_ctx *ctx, const mg_table *ref, const mg_table *qry, uint64_t q_begin, uint64_t q_end,
+                                int kmer_size, double max_distance, mg_edge *out_host, uint64_t capacity,
+                                uint64_t *count_out)
+{
+    if (!ctx) return MG_ERR_INVALID;
+    if (!ref || !qry || !count_out || (!out_host && capacity))
+        return fail(ctx, MG_ERR_INVALID, "mg_compare_rect_filter_host: NULL argument");
+    return compare_filter(ctx, qry, ref, q_begin, q_end, false, kmer_size, max_distance, out_host, capacity, count_out);
+}
+
 /* ------------------------------------------------------------------ screening */
 
 struct mg_screen {

@@ -628,6 +628,36 @@ void print_pair_line(const Ref &ref, const Ref &qry, bool comment, const mg_pair
     cout << '\t' << pr.distance << '\t' << pr.p_value << '\t' << pr.numer << '/' << pr.denom << endl;
 }
 
+// Thresholded runs (-d < 1): the distance filter and compaction run on the device
+// (mg_compare_*_filter_host) so only surviving pairs come back; the p-value filter
+// and the arithmetic of the survivors are the same host code as the full path.
+bool edge_filter_wanted(double d_max) { return d_max < 1.0 && !getenv("MASH_AMD_NO_FILTER"); }
+
+template <class Call>
+bool fetch_edges(Gpu &gpu, vector<mg_edge> &edges, Call call)
+{
+    uint64_t n = 0;
+    if (edges.size() < (1u << 16)) edges.resize(1u << 16);
+    int rc = call(edges.data(), (uint64_t)edges.size(), &n);
+    if (rc == MG_ERR_NOMEM && n > edges.size()) {
+        edges.resize(n);
+        rc = call(edges.data(), (uint64_t)edges.size(), &n);
+    }
+    if (rc != MG_OK) { cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl; return false; }
+    edges.resize(n);
+    return true;
+}
+
+bool finish_edge(const mg_edge &e, uint64_t len_ref, uint64_t len_qry, int k, double kspace, double p_max, mg_pair &pr)
+{
+    pr.numer = e.numer;
+    pr.denom = e.denom;
+    pr.distance = mg_distance(e.numer, e.denom, k);
+    pr.p_value = mg_p_value(e.numer, len_ref, len_qry, kspace, e.denom);
+    pr.pass = pr.p_value <= p_max;                           // CommandDistance.cpp:419-422
+    return pr.pass;
+}
+
 int cmd_dist(int argc, const char **argv)
 {
     Cmd c;
@@ -694,6 +724,24 @@ int cmd_dist(int argc, const char **argv)
     const uint64_t qblock = std::max<uint64_t>(1, (1ull << 24) / nref);
     vector<mg_counts> counts;
     vector<mg_pair> pairs;
+    if (!table && edge_filter_wanted(d_max)) {
+        vector<mg_edge> edges;
+        const uint64_t fblock = std::max<uint64_t>(1, (1ull << 30) / nref);
+        for (uint64_t q0 = 0; q0 < nq; q0 += fblock) {
+            const uint64_t q1 = std::min(nq, q0 + fblock);
+            if (!fetch_edges(gpu, edges, [&](mg_edge *o, uint64_t cap, uint64_t *n) {
+                    return mg_compare_rect_filter_host(gpu.ctx, tr, tq, q0, q1, ref.p.kmer, d_max, o, cap, n); }))
+                return 1;
+            mg_pair pr;
+            for (const mg_edge &e : edges)
+                if (finish_edge(e, len_ref[e.col], len_qry[e.row], ref.p.kmer, kspace, p_max, pr))
+                    print_pair_line(ref.refs[e.col], qry.refs[e.row], comment, pr);
+        }
+        mg_table_free(tr);
+        mg_table_free(tq);
+        if (w.count > 0 && !p.reads) warn_kmer_size(ref, w);
+        return 0;
+    }
     for (uint64_t q0 = 0; q0 < nq; q0 += qblock) {
         const uint64_t q1 = std::min(nq, q0 + qblock);
         counts.resize((q1 - q0) * nref);
@@ -761,6 +809,22 @@ int cmd_triangle(int argc, const char **argv)
     vector<mg_counts> counts;
     vector<mg_pair> pairs;
     uint64_t r0 = 1;
+    if (edge && edge_filter_wanted(d_max)) {
+        vector<mg_edge> edges;
+        while (r0 < n) {
+            uint64_t r1 = r0, npairs = 0;
+            while (r1 < n && (npairs == 0 || npairs + r1 <= (1ull << 31))) { npairs += r1; r1++; }
+            if (!fetch_edges(gpu, edges, [&](mg_edge *o, uint64_t cap, uint64_t *cnt) {
+                    return mg_compare_tri_filter_host(gpu.ctx, t, r0, r1, set.p.kmer, d_max, o, cap, cnt); }))
+                return 1;
+            mg_pair pr;
+            for (const mg_edge &e : edges)
+                if (finish_edge(e, lengths[e.row], lengths[e.col], set.p.kmer, kspace, p_max, pr))
+                    cout << label(set.refs[e.row]) << '\t' << label(set.refs[e.col]) << '\t' << pr.distance << '\t'
+                         << pr.p_value << '\t' << pr.numer << '/' << pr.denom << endl;
+            r0 = r1;
+        }
+    }
     while (r0 < n) {
         uint64_t r1 = r0, npairs = 0;
         while (r1 < n && (npairs == 0 || npairs + r1 <= (1ull << 24))) { npairs += r1; r1++; }

@@ -27,8 +27,9 @@ def built():
     return True
 
 
-def run(*args, check=True, cwd=None):
-    r = subprocess.run([MASH, *args], capture_output=True, text=True, cwd=cwd)
+def run(*args, check=True, cwd=None, env=None):
+    r = subprocess.run([MASH, *args], capture_output=True, text=True, cwd=cwd,
+                       env=dict(os.environ, **env) if env else None)
     if check:
         assert r.returncode == 0, r.stderr
     return r
@@ -239,3 +240,13 @@ def test_sketch_and_triangle_cli_vs_oracle(built, tmp_path, oracle):
     for l in e:
         a, b, *rest = l.split("\t")
         assert dd[(b, a)] == rest
+    # thresholded runs: the device-side filter path and the full path print the same lines
+    nofilter = {"MASH_AMD_NO_FILTER": "1"}
+    for d_max in ("0", "0.05", "0.2", "0.9"):
+        for cmd in (("triangle", "-E", "-d", d_max, "ind.msh"), ("dist", "-d", d_max, "ind.msh", "ind.msh"),
+                    ("dist", "-d", d_max, "-v", "1e-10", "ind.msh", "cat.msh")):
+            a = run(*cmd, cwd=tmp_path).stdout
+            b = run(*cmd, cwd=tmp_path, env=nofilter).stdout
+            assert a == b, cmd
+    e0 = run("triangle", "-d", "0", "ind.msh", cwd=tmp_path).stdout.splitlines()
+    assert len(e0) == 1 and e0[0].split("\t")[:3] == ["seq4", "seq0", "0"]

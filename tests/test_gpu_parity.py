@@ -236,6 +236,62 @@ def test_compare_rect_and_golden_dist(eng, oracle, golden_dir):
     ref.free(); qry.free(); t.free(); tq.free()
 
 
+def _py_distance(numer, denom, k):
+    """CommandDistance.cpp:387-407 with CPython's libm log (the one the reference links)."""
+    import math
+    if numer == denom:
+        return 0.0
+    if numer == 0:
+        return 1.0
+    j = float(numer) / float(denom)
+    return min(1.0, -math.log(2 * j / (1.0 + j)) / k)
+
+
+@pytest.mark.parametrize("s", [7, 400, 1000, 4096])
+def test_compare_filter_edges(eng, oracle, s):
+    """Device-side distance filter + compaction == the reference's `distance > maxDistance`
+    test applied to every pair, in reference order (triangle and rect, ragged rows)."""
+    n, k = 170, 21
+    table, nhash, lengths = synth.clustered_sketches(n, s, clusters=6, seed=100 + s, pool=int(1.5 * s) + 2,
+                                                     private=max(1, int(0.3 * s)))
+    nhash[3] = 0
+    nhash[4] = 0
+    nhash[8] = max(1, s // 2)
+    table[21] = table[20]
+    nhash[21] = nhash[20]
+    t = eng.table_upload(table, nhash, lengths)
+    numer, denom = _oracle_tri(oracle, table, nhash, lengths, 0, n)
+    dist = np.array([_py_distance(int(a), int(b), k) for a, b in zip(numer, denom)])
+    rows = np.concatenate([np.full(i, i, np.uint32) for i in range(n)])
+    cols = np.concatenate([np.arange(i, dtype=np.uint32) for i in range(n)])
+    some = np.unique(dist)
+    for max_d in [0.0, float(some[len(some) // 3]), float(some[len(some) // 2]), 0.05, 0.3, 0.999999, 1.0]:
+        keep = dist <= max_d
+        got = eng.compare_tri_filter(t, k, max_d, capacity=16)      # forces the grow-and-retry path
+        assert len(got) == int(keep.sum()), max_d
+        assert np.array_equal(got["row"], rows[keep]) and np.array_equal(got["col"], cols[keep])
+        assert np.array_equal(got["numer"], numer[keep]) and np.array_equal(got["denom"], denom[keep])
+        # row sub-range
+        lo, hi = 40, 133
+        sub = (rows >= lo) & (rows < hi) & keep
+        got2 = eng.compare_tri_filter(t, k, max_d, lo, hi)
+        assert np.array_equal(got2["row"], rows[sub]) and np.array_equal(got2["col"], cols[sub])
+        assert np.array_equal(got2["numer"], numer[sub])
+    # rect: queries 30..90 against all rows
+    tq = eng.table_upload(table[30:90], nhash[30:90], lengths[30:90])
+    full = eng.compare_rect_host(t, tq)
+    dfull = np.array([[_py_distance(int(c["numer"]), int(c["denom"]), k) for c in row] for row in full])
+    for max_d in [0.0, 0.05, 0.5]:
+        got = eng.compare_rect_filter(t, tq, k, max_d, capacity=8)
+        qq, rr = np.nonzero(dfull <= max_d)
+        assert np.array_equal(got["row"], qq.astype(np.uint32)) and np.array_equal(got["col"], rr.astype(np.uint32))
+        assert np.array_equal(got["numer"], full["numer"][qq, rr]) and np.array_equal(got["denom"], full["denom"][qq, rr])
+        got2 = eng.compare_rect_filter(t, tq, k, max_d, 10, 25)
+        m = (qq >= 10) & (qq < 25)
+        assert np.array_equal(got2["row"], qq[m].astype(np.uint32)) and np.array_equal(got2["col"], rr[m].astype(np.uint32))
+    t.free(); tq.free()
+
+
 def test_compare_c3_scale_properties(eng, oracle):
     """BASELINE config 3 shape at a size the oracle can sample: N = 6000 clustered
     s=1000 sketches (1.8e7 pairs).  Checks (a) sampled rows against the oracle,
