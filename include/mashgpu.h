@@ -199,6 +199,12 @@ int  mg_screen_add_host(mg_screen *sc, const uint8_t *bases, uint64_t nbases);
 int  mg_screen_add_dev(mg_screen *sc, const uint8_t *bases_dev, uint64_t nbases);
 int  mg_screen_finish_host(mg_screen *sc, uint32_t *counts_out, uint64_t *mix_hashes_out,
                            uint32_t *mix_nhash_out, uint64_t *distinct_out);
+/* Device-resident counts_out[db_rows * db_s] (same content as mg_screen_finish_host's):
+ * the operand of the one collective of a read-sharded screen -- every rank screens
+ * its share of the mixture against the same db, the counts are summed across
+ * ranks (RCCL all-reduce, u32 sum) and the per-rank mixture sketches are merged
+ * (bottom-s of their union); see mash_amd/screen_dist.py. */
+int  mg_screen_counts_dev(mg_screen *sc, uint32_t *counts_out_dev);
 void mg_screen_free(mg_screen *sc);
 /* estimateIdentity (CommandScreen.cpp:463-482) and pValueWithin (:601-615), host arithmetic. */
 double mg_identity(uint64_t common, uint64_t denom, int kmer_size);

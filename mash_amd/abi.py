@@ -28,7 +28,7 @@ EXPORTS = [
     "mg_compare_tri_filter_host", "mg_compare_rect_filter_host",
     "mg_finish_tri_host", "mg_finish_rect_host", "mg_distance", "mg_p_value",
     "mg_prof_enable", "mg_prof_reset", "mg_prof_avg_ms",
-    "mg_screen_create", "mg_screen_add_host", "mg_screen_add_dev", "mg_screen_finish_host", "mg_screen_free",
+    "mg_screen_create", "mg_screen_add_host", "mg_screen_add_dev", "mg_screen_finish_host", "mg_screen_counts_dev", "mg_screen_free",
     "mg_identity", "mg_p_value_within",
 ]
 
@@ -62,6 +62,54 @@ PAIR_DTYPE = np.dtype([("numer", "<u4"), ("denom", "<u4"), ("distance", "<f8"), 
                        ("pass", "u1"), ("_pad", "u1", 7)])
 COUNTS_DTYPE = np.dtype([("numer", "<u4"), ("denom", "<u4")])
 EDGE_DTYPE = np.dtype([("row", "<u4"), ("col", "<u4"), ("numer", "<u4"), ("denom", "<u4")])
+
+
+class ScreenSession:
+    """One mg_screen: add batches of the mixture, then read the per-hash observation counts.
+    Use as a context manager or call close()."""
+
+    def __init__(self, eng, db, p):
+        self.eng, self.db, self.p = eng, db, p
+        self.h = C.c_void_p()
+        eng._check(eng.lib.mg_screen_create(eng.ctx, C.byref(p), db.handle, C.byref(self.h)))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def close(self):
+        if self.h:
+            self.eng.lib.mg_screen_free(self.h)
+            self.h = C.c_void_p()
+
+    def add_records(self, recs):
+        blob = np.frombuffer(join_records(recs), dtype=np.uint8)
+        self.add_host(blob)
+
+    def add_host(self, blob):
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        self.eng._check(self.eng.lib.mg_screen_add_host(self.h, blob.ctypes.data, len(blob)))
+
+    def add_dev(self, ptr, nbytes):
+        """records joined with MG_RECORD_SEP, device memory, 16-byte aligned"""
+        self.eng._check(self.eng.lib.mg_screen_add_dev(self.h, ptr, nbytes))
+
+    def counts_dev(self, out_ptr):
+        """u32[db.rows * db.sketch_size] into device memory (operand of the all-reduce)"""
+        self.eng._check(self.eng.lib.mg_screen_counts_dev(self.h, out_ptr))
+
+    def finish(self, want_counts=True, want_distinct=True):
+        """(counts u32[n, s] or None, mixture sketch u64[<=s], distinct table hashes or None)"""
+        n, s = self.db.rows, self.db.sketch_size
+        counts = np.zeros((n, s), dtype=np.uint32) if want_counts else None
+        mix = np.zeros(int(self.p.sketch_size), dtype=np.uint64)
+        mn, dist = C.c_uint32(0), C.c_uint64(0)
+        self.eng._check(self.eng.lib.mg_screen_finish_host(
+            self.h, counts.ctypes.data if want_counts else None, mix.ctypes.data, C.byref(mn),
+            C.byref(dist) if want_distinct else None))
+        return counts, mix[: mn.value].copy(), (int(dist.value) if want_distinct else None)
 
 
 class MashGpuError(RuntimeError):
@@ -115,6 +163,7 @@ def load_library():
     lib.mg_screen_add_host.argtypes = [vp, vp, u64]
     lib.mg_screen_add_dev.argtypes = [vp, vp, u64]
     lib.mg_screen_finish_host.argtypes = [vp, vp, vp, C.POINTER(u32), C.POINTER(u64)]
+    lib.mg_screen_counts_dev.argtypes = [vp, vp]
     lib.mg_screen_free.argtypes = [vp]
     lib.mg_screen_free.restype = None
     lib.mg_identity.argtypes = [u64, u64, i32]
@@ -305,6 +354,10 @@ class MashGpu:
         return out
 
     # ---- screening -------------------------------------------------------------------
+    def screen_open(self, db, p):
+        """incremental screen against table `db` (see ScreenSession)"""
+        return ScreenSession(self, db, p)
+
     def screen(self, db, p, batches):
         """Containment counts of every hash of table `db` in a mixture given as batches of
         record lists.  Returns (counts u32[n, s], mixture sketch u64[<=s], distinct hashes)."""

@@ -164,9 +164,28 @@ static bool alphabet_is_dna(const mg_params *p)
     return p->alphabet['A'] && p->alphabet['C'] && p->alphabet['G'] && p->alphabet['T'];
 }
 
+// table probe fused into the sketch pass (mash screen)
+struct ProbeHook {
+    const unsigned long long *keys;
+    uint32_t *obs;
+    uint64_t mask, key_max;
+};
+
+static int sketch_dev_impl(mg_ctx *ctx, const mg_params *p, const uint8_t *bases_dev, uint64_t nbases,
+                           const uint64_t *sketch_off, uint64_t nsketch, uint64_t *hashes_out_dev,
+                           uint32_t *nhash_out_dev, uint32_t *counts_out_dev, const ProbeHook *probe);
+
 int mg_sketch_dev(mg_ctx *ctx, const mg_params *p, const uint8_t *bases_dev, uint64_t nbases,
                   const uint64_t *sketch_off, uint64_t nsketch, uint64_t *hashes_out_dev,
                   uint32_t *nhash_out_dev, uint32_t *counts_out_dev)
+{
+    return sketch_dev_impl(ctx, p, bases_dev, nbases, sketch_off, nsketch, hashes_out_dev, nhash_out_dev,
+                           counts_out_dev, nullptr);
+}
+
+static int sketch_dev_impl(mg_ctx *ctx, const mg_params *p, const uint8_t *bases_dev, uint64_t nbases,
+                           const uint64_t *sketch_off, uint64_t nsketch, uint64_t *hashes_out_dev,
+                           uint32_t *nhash_out_dev, uint32_t *counts_out_dev, const ProbeHook *probe)
 {
     if (!ctx) return MG_ERR_INVALID;
     if (!p || !sketch_off || !hashes_out_dev || !nhash_out_dev || (!bases_dev && nbases))
@@ -208,7 +227,7 @@ int mg_sketch_dev(mg_ctx *ctx, const mg_params *p, const uint8_t *bases_dev, uin
     chunk = (chunk + tile - 1) / tile * tile;
 
     std::vector<mg::SketchWork> work;
-    std::vector<mg::MergeWork> merges;
+    std::vector<mg::MergeWork> merges, merges1;       // final merges; first level of two-level merges
     uint64_t nslots = 0;
     for (uint64_t i = 0; i < nsketch; i++) {
         const uint64_t b = sketch_off[i], e = sketch_off[i + 1];
@@ -218,8 +237,21 @@ int mg_sketch_dev(mg_ctx *ctx, const mg_params *p, const uint8_t *bases_dev, uin
         const uint64_t nch = (npos + chunk - 1) / chunk;
         if (nch > 0xFFFFFFFFull || nslots + nch > 0xFFFFFFFFull) return fail(ctx, MG_ERR_INVALID, "mg_sketch: too many chunks");
         if (nch > 1) {
-            mg::MergeWork m{(uint32_t)i, (uint32_t)nslots, (uint32_t)nch, 0};
-            merges.push_back(m);
+            // many chunks: groups of MERGE_GROUP slots are merged in parallel into their first
+            // slot, then one workgroup merges the group results
+            const uint64_t G = 32;
+            if (nch > 2 * G) {
+                const uint64_t ngroups = (nch + G - 1) / G;
+                for (uint64_t g = 0; g < ngroups; g++) {
+                    mg::MergeWork m{(uint32_t)i, (uint32_t)(nslots + g * G), (uint32_t)std::min(G, nch - g * G), 1, 1};
+                    merges1.push_back(m);
+                }
+                mg::MergeWork m{(uint32_t)i, (uint32_t)nslots, (uint32_t)ngroups, (uint32_t)G, 0};
+                merges.push_back(m);
+            } else {
+                mg::MergeWork m{(uint32_t)i, (uint32_t)nslots, (uint32_t)nch, 1, 0};
+                merges.push_back(m);
+            }
         }
         for (uint64_t c = 0; c < nch; c++) {
             mg::SketchWork w;
@@ -281,6 +313,7 @@ int mg_sketch_dev(mg_ctx *ctx, const mg_params *p, const uint8_t *bases_dev, uin
         TRY_C(hipMemsetAsync(d_pool_n, 0, nslots * 4, ctx->stream));
         TRY_C(hipMalloc(&d_gT, nsketch * 8));
         TRY_C(hipMemsetAsync(d_gT, 0xFF, nsketch * 8, ctx->stream));
+        merges.insert(merges.end(), merges1.begin(), merges1.end());      // [final ..., first level ...]
         TRY_C(hipMalloc(&d_merge, merges.size() * sizeof(mg::MergeWork)));
         TRY_C(hipMemcpyAsync(d_merge, merges.data(), merges.size() * sizeof(mg::MergeWork), hipMemcpyHostToDevice, ctx->stream));
     }
@@ -298,6 +331,10 @@ int mg_sketch_dev(mg_ctx *ctx, const mg_params *p, const uint8_t *bases_dev, uin
     a.seed = p->seed;
     a.use64 = p->use64;
     a.fold_case = p->preserve_case ? 0 : 1;
+    a.probe_keys = probe ? probe->keys : nullptr;
+    a.probe_obs = probe ? probe->obs : nullptr;
+    a.probe_mask = probe ? probe->mask : 0;
+    a.probe_max = probe ? probe->key_max : 0;
     prof_begin(ctx, ctx->prof_sketch);
     TRY_C(mg::launch_sketch_chunks(p->kmer_size, mode, nt, a, (uint32_t)work.size(), ctx->stream));
     prof_end(ctx, ctx->prof_sketch);
@@ -310,7 +347,13 @@ int mg_sketch_dev(mg_ctx *ctx, const mg_params *p, const uint8_t *bases_dev, uin
         m.nhash_out = nhash_out_dev;
         m.sketch_size = (uint32_t)s;
         m.cap = cap;
-        TRY_C(mg::launch_merge_chunks(nt, m, (uint32_t)merges.size(), ctx->stream));
+        const uint32_t nfinal = (uint32_t)(merges.size() - merges1.size());
+        if (!merges1.empty()) {
+            m.work = d_merge + nfinal;
+            TRY_C(mg::launch_merge_chunks(nt, m, (uint32_t)merges1.size(), ctx->stream));
+            m.work = d_merge;
+        }
+        TRY_C(mg::launch_merge_chunks(nt, m, nfinal, ctx->stream));
     }
     if (counts_out_dev) {
         // multiplicities: re-stream every chunk against the finished sketches (count_chunks_kernel)
@@ -834,6 +877,7 @@ struct mg_screen {
     unsigned long long *keys = nullptr;
     uint32_t *obs = nullptr;
     uint64_t slots = 0;
+    uint64_t key_max = 0;
     uint8_t *d_alpha = nullptr;
     int mode = 0;
     std::vector<uint64_t> mix;          // running bottom-s of the mixture (host, ascending, distinct)
@@ -851,6 +895,10 @@ int mg_screen_create(mg_ctx *ctx, const mg_params *p, const mg_table *db, mg_scr
     sc->p = *p;
     sc->db = db;
     sc->mode = dna ? (p->noncanonical ? 1 : 0) : 2;
+    {
+        const int rc = table_max(ctx, db, &sc->key_max);
+        if (rc != MG_OK) { delete sc; return rc; }
+    }
     uint64_t slots = 1024;
     while (slots < 2 * db->n * db->s) slots <<= 1;
     sc->slots = slots;
@@ -878,14 +926,16 @@ int mg_screen_add_dev(mg_screen *sc, const uint8_t *bases_dev, uint64_t nbases)
     if (nbases < k) return MG_OK;
     if (((uintptr_t)bases_dev & 15) != 0) return fail(ctx, MG_ERR_INVALID, "mg_screen_add: bases must be 16-byte aligned");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    // 1) the mixture's own bottom-s: one sketch over the whole batch, folded into the running one
+    // one pass over the batch: its bottom-s (folded into the mixture's running sketch) and,
+    // fused into the same kernel, the table probe of every k-mer (hashCounts[key]++)
     const uint64_t s = sc->p.sketch_size;
     uint64_t *d_h = nullptr;
     uint32_t *d_n = nullptr;
     HIP_TRY(ctx, hipMalloc(&d_h, s * 8));
     if (hipMalloc(&d_n, 4) != hipSuccess) { hipFree(d_h); return fail(ctx, MG_ERR_NOMEM, "mg_screen_add: allocation failed"); }
     const uint64_t off[2] = {0, nbases};
-    int rc = mg_sketch_dev(ctx, &sc->p, bases_dev, nbases, off, 1, d_h, d_n, nullptr);
+    const ProbeHook hook{sc->keys, sc->obs, sc->slots - 1, sc->key_max};
+    int rc = sketch_dev_impl(ctx, &sc->p, bases_dev, nbases, off, 1, d_h, d_n, nullptr, &hook);
     std::vector<uint64_t> bh(s);
     uint32_t bn = 0;
     if (rc == MG_OK) {
@@ -903,41 +953,6 @@ int mg_screen_add_dev(mg_screen *sc, const uint8_t *bases_dev, uint64_t nbases)
     merged.erase(std::unique(merged.begin(), merged.end()), merged.end());
     if (merged.size() > s) merged.resize(s);
     sc->mix.swap(merged);
-    // 2) probe: every valid k-mer against the table
-    const uint64_t tile = mg::sketch_tile(256);
-    const uint64_t npos = nbases - k + 1;
-    uint64_t chunk = (npos + 8191) / 8192;
-    if (chunk < 2 * tile) chunk = 2 * tile;
-    chunk = (chunk + tile - 1) / tile * tile;
-    std::vector<mg::SketchWork> work;
-    for (uint64_t b = 0; b < npos; b += chunk) {
-        mg::SketchWork w;
-        w.begin = b;
-        w.end = std::min(npos, b + chunk);
-        w.limit = nbases;
-        w.sketch = 0; w.slot = 0; w.nchunks = 1; w._pad = 0;
-        work.push_back(w);
-    }
-    mg::SketchWork *d_work = nullptr;
-    HIP_TRY(ctx, hipMalloc(&d_work, work.size() * sizeof(mg::SketchWork)));
-    hipError_t e = hipMemcpyAsync(d_work, work.data(), work.size() * sizeof(mg::SketchWork), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) {
-        mg::ScreenProbeArgs a;
-        a.bases = bases_dev;
-        a.work = d_work;
-        a.alphabet = sc->d_alpha;
-        a.keys = sc->keys;
-        a.obs = sc->obs;
-        a.mask = sc->slots - 1;
-        a.seed = sc->p.seed;
-        a.use64 = sc->p.use64;
-        a.fold_case = sc->p.preserve_case ? 0 : 1;
-        e = mg::launch_screen_probe(sc->p.kmer_size, sc->mode, a, (uint32_t)work.size(), ctx->stream);
-    }
-    hipError_t e2 = hipStreamSynchronize(ctx->stream);
-    hipFree(d_work);
-    if (e != hipSuccess || e2 != hipSuccess)
-        return fail(ctx, MG_ERR_HIP, std::string("mg_screen_add: ") + hipGetErrorString(e != hipSuccess ? e : e2));
     return MG_OK;
 }
 
@@ -958,6 +973,20 @@ int mg_screen_add_host(mg_screen *sc, const uint8_t *bases, uint64_t nbases)
     hipStreamSynchronize(ctx->stream);
     hipFree(d);
     return rc;
+}
+
+int mg_screen_counts_dev(mg_screen *sc, uint32_t *counts_out_dev)
+{
+    if (!sc) return MG_ERR_INVALID;
+    mg_ctx *ctx = sc->ctx;
+    if (!counts_out_dev) return fail(ctx, MG_ERR_INVALID, "mg_screen_counts_dev: NULL argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (sc->db->n * sc->db->s == 0) return MG_OK;
+    hipError_t e = mg::launch_screen_gather(sc->db->hashes, sc->db->nhash, sc->db->n, sc->db->s, sc->keys, sc->obs,
+                                            sc->slots - 1, counts_out_dev, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("mg_screen_counts_dev: ") + hipGetErrorString(e));
+    return MG_OK;
 }
 
 int mg_screen_finish_host(mg_screen *sc, uint32_t *counts_out, uint64_t *mix_hashes_out, uint32_t *mix_nhash_out,

@@ -7,21 +7,29 @@
 
 namespace mg {
 
-struct ScreenProbeArgs {
-    const uint8_t *bases;
-    const SketchWork *work;
-    const uint8_t *alphabet;
-    const unsigned long long *keys;   // open-addressing table, ~0 = empty
-    uint32_t *obs;                    // observation counter per slot
-    uint64_t mask;                    // slots - 1
-    uint32_t seed;
-    uint32_t use64;
-    uint32_t fold_case;
-};
+// open-addressing table shared by screen.hip (build, gather) and the probe fused into the
+// sketch kernel: u64 keys, linear probing, ~0 = empty, load <= 0.5
+constexpr unsigned long long SCR_EMPTY = 0xFFFFFFFFFFFFFFFFULL;
+
+__device__ __forceinline__ uint64_t scr_slot(uint64_t key, uint64_t mask)
+{
+    uint64_t x = key * 0x9E3779B97F4A7C15ULL;              // keys are murmur outputs: one multiply suffices
+    return (x >> 20) & mask;
+}
+
+__device__ __forceinline__ bool scr_find(const unsigned long long *keys, uint64_t mask, uint64_t key, uint64_t *slot_out)
+{
+    uint64_t slot = scr_slot(key, mask);
+    for (;;) {
+        const unsigned long long k = keys[slot];
+        if (k == key) { *slot_out = slot; return true; }
+        if (k == SCR_EMPTY) return false;
+        slot = (slot + 1) & mask;
+    }
+}
 
 hipError_t launch_screen_build(const uint64_t *hashes, const uint32_t *nhash, uint64_t n, uint64_t s,
                                unsigned long long *keys, uint64_t mask, hipStream_t stream);
-hipError_t launch_screen_probe(int k, int mode, const ScreenProbeArgs &a, uint32_t nwork, hipStream_t stream);
 hipError_t launch_screen_gather(const uint64_t *hashes, const uint32_t *nhash, uint64_t n, uint64_t s,
                                 const unsigned long long *keys, const uint32_t *obs, uint64_t mask,
                                 uint32_t *counts_out, hipStream_t stream);

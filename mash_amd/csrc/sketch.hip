@@ -28,6 +28,7 @@
 
 #include "kmer_hash.h"
 #include "kmer_stream.h"
+#include "screen_internal.h"
 #include "sketch_internal.h"
 
 namespace mg {
@@ -185,6 +186,10 @@ __global__ __launch_bounds__(NT) void sketch_chunks_kernel(SketchArgs a)
     constexpr int ND = (NBYTES + 3) / 4;
     constexpr uint32_t NW = NT / 64;
     uint32_t seg_no = 0;                                   // segments finished (uniform)
+    const unsigned long long *probe_keys = a.probe_keys;
+    uint32_t *probe_obs = a.probe_obs;
+    const uint64_t probe_mask = a.probe_mask, probe_max = a.probe_max;
+    const bool probing = probe_keys != nullptr;
 
     for (uint64_t t0 = w.begin; t0 < w.end; t0 += TILE) {
         // ---- stage the tile: bytes [a0, a0 + TILE_DW*4), a0 = t0 rounded down to 16 ----
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(NT) void sketch_chunks_kernel(SketchArgs a)
         // steady state — the threshold is set, candidates are rare, so the tile runs without
         // a single barrier; appends are bounds-checked and an overflow (pathological repeats)
         // discards the tile's candidates and re-runs it with SEG = true.
-        auto run_tile = [&](auto seg_tag) {
+        auto run_tile = [&](auto seg_tag, const bool probe_now) {
             constexpr bool SEG = decltype(seg_tag)::value;
             KmerRoller<K, MODE == 0> r;
             r.reset();
@@ -249,8 +254,12 @@ __global__ __launch_bounds__(NT) void sketch_chunks_kernel(SketchArgs a)
                     if (pos >= K - 1 && pos < NBYTES) {    // uniform
                         const uint32_t start = (uint32_t)(pos - (K - 1));
                         const uint64_t h = r.hash(seed, use64);
-                        const bool pass = r.kmer_valid() && (lane_first + start < remaining) &&
-                                          (!full || h < T);
+                        const bool mine = r.kmer_valid() && (lane_first + start < remaining);
+                        const bool pass = mine && (!full || h < T);
+                        if (probe_now && mine && h <= probe_max) {   // sketches are bottom-s sets: rare
+                            uint64_t slot;
+                            if (scr_find(probe_keys, probe_mask, h, &slot)) atomicAdd(&probe_obs[slot], 1u);
+                        }
                         const uint64_t m = __ballot(pass);
                         if (m != 0) {
                             const uint32_t off = __builtin_amdgcn_mbcnt_hi(
@@ -286,16 +295,16 @@ __global__ __launch_bounds__(NT) void sketch_chunks_kernel(SketchArgs a)
         const bool steady = st->full != 0 && count0 + (uint32_t)NT <= cap;
         __syncthreads();                                   // everybody has read count0 / full
         if (steady) {
-            run_tile(std::false_type{});
+            run_tile(std::false_type{}, probing);
             __syncthreads();
             if (st->count > cap) {                         // uniform: overflow, redo the tile carefully
                 __syncthreads();
                 if (tid == 0) st->count = count0;
                 compact_buffer<NT>(buf, st, s_wsum, s, g_T);
-                run_tile(std::true_type{});
+                run_tile(std::true_type{}, false);         // its k-mers were already probed
             }
         } else {
-            run_tile(std::true_type{});
+            run_tile(std::true_type{}, probing);
         }
         __syncthreads();      // tile may be overwritten
     }
@@ -328,7 +337,7 @@ __global__ __launch_bounds__(NT) void merge_chunks_kernel(MergeArgs a)
     __syncthreads();
     const uint32_t batch = cap - s;                        // room guaranteed after a compaction
     for (uint32_t c = 0; c < w.nchunks; c++) {
-        const uint32_t slot = w.first_slot + c;
+        const uint32_t slot = w.first_slot + c * w.stride;
         const uint32_t n = a.pool_n[slot];
         const uint64_t *src = a.pool + (uint64_t)slot * s;
         for (uint32_t b0 = 0; b0 < n; b0 += batch) {
@@ -346,6 +355,12 @@ __global__ __launch_bounds__(NT) void merge_chunks_kernel(MergeArgs a)
     }
     compact_buffer<NT>(buf, st, s_wsum, s, nullptr);
     const uint32_t n = st->count;
+    if (w.to_pool) {                                       // all reads of this group's slots are done
+        uint64_t *out = a.pool + (uint64_t)w.first_slot * s;
+        for (uint32_t i = tid; i < n; i += NT) out[i] = buf[i];
+        if (tid == 0) a.pool_n[w.first_slot] = n;
+        return;
+    }
     uint64_t *out = a.hashes_out + (uint64_t)w.sketch * s;
     for (uint32_t i = tid; i < s; i += NT) out[i] = i < n ? buf[i] : HPAD;
     if (tid == 0) a.nhash_out[w.sketch] = n;

@@ -30,16 +30,26 @@ struct SketchArgs {
     uint32_t seed;
     uint32_t use64;
     uint32_t fold_case;
+    // optional fused table probe (mash screen): every valid k-mer hash <= probe_max is looked
+    // up in the open-addressing table and its observation counter incremented
+    const unsigned long long *probe_keys;   // nullptr: plain sketching
+    uint32_t *probe_obs;
+    uint64_t probe_mask;
+    uint64_t probe_max;
 };
 
+// Merge of pool slots first_slot, first_slot+stride, ... (nchunks of them).
+// to_pool = 1: the result replaces slot first_slot (first level of a two-level merge of a
+// sketch with many chunks); 0: it becomes row `sketch` of the output.
 struct MergeWork {
-    uint32_t sketch, first_slot, nchunks, _pad;
+    uint32_t sketch, first_slot, nchunks;
+    uint32_t stride : 31, to_pool : 1;
 };
 
 struct MergeArgs {
     const MergeWork *work;
-    const uint64_t *pool;
-    const uint32_t *pool_n;
+    uint64_t *pool;
+    uint32_t *pool_n;
     uint64_t *hashes_out;
     uint32_t *nhash_out;
     uint32_t sketch_size;

@@ -1,0 +1,82 @@
+"""Read-sharded `mash screen` across ranks (BASELINE config 4).
+
+Every rank holds the same query-sketch table `db` and screens ITS share of the mixture
+(the reference already cuts the mixture into independent ~1 MiB chunks,
+CommandScreen.cpp:192,224-249).  Two things are exchanged at the end, and nothing before:
+
+  * the per-hash observation counts, u32[db_rows * s]: summed over ranks -- the one
+    collective of the data path (RCCL all-reduce over xGMI on GPUs; gloo on CPU tests).
+    It replaces the shared atomic `hashCounts` map of the reference (CommandScreen.h:131);
+  * each rank's bottom-s sketch of its share of the mixture: all-gathered (s u64 per rank)
+    and merged -- bottom-s of the union of bottom-s sets is the bottom-s of the whole
+    mixture, which is what the reference's heap merge computes (CommandScreen.cpp:288-302).
+
+`local_screen` abstracts the device work so the exchange logic can run under gloo without a
+GPU: it returns (counts tensor on `device`, u32 stored as int32/int64; mixture numpy u64).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HASH_PAD = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def shard_batches(n_batches, rank, world):
+    """batch indices of this rank: round-robin, like the reference hands chunks to threads"""
+    return list(range(rank, n_batches, world))
+
+
+def merge_mixtures(mixes, s):
+    """bottom-s distinct of the union of ascending distinct u64 arrays"""
+    if not mixes:
+        return np.zeros(0, dtype=np.uint64)
+    u = np.unique(np.concatenate([np.asarray(m, dtype=np.uint64) for m in mixes]))
+    return u[:s]
+
+
+def exchange(counts, mix, s, group=None):
+    """all-reduce the counts in place (sum) and merge the mixtures of all ranks.
+    counts: integer tensor on the collective's device; mix: numpy u64 (<= s, ascending)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return counts, np.asarray(mix, dtype=np.uint64)[:s]
+    dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+    # fixed-size payload: s hashes (padded) + the count, as int64 bit patterns
+    pay = np.full(s + 1, HASH_PAD, dtype=np.uint64)
+    pay[: len(mix)] = mix
+    pay[s] = len(mix)
+    mine = torch.from_numpy(pay.view(np.int64).copy()).to(counts.device)
+    gathered = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine, group=group)
+    mixes = []
+    for g in gathered:
+        a = g.cpu().numpy().view(np.uint64)
+        mixes.append(a[: int(a[s])])
+    return counts, merge_mixtures(mixes, s)
+
+
+def screen_sharded(local_screen, batches, s, group=None):
+    """local_screen(list of this rank's batches) -> (counts tensor, mixture u64 array).
+    Returns (summed counts tensor, merged mixture) on every rank."""
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    mine = [batches[i] for i in shard_batches(len(batches), rank, world)]
+    counts, mix = local_screen(mine)
+    return exchange(counts, mix, s, group)
+
+
+def gpu_local_screen(eng, db, p):
+    """local_screen over libmashgpu: batches are lists of record bytes (host) or
+    (device_ptr, nbytes, keepalive) tuples; counts stay on the GPU for the collective."""
+    def run(my_batches):
+        with eng.screen_open(db, p) as sc:
+            for b in my_batches:
+                if isinstance(b, tuple):
+                    sc.add_dev(b[0], b[1])
+                else:
+                    sc.add_records(b)
+            counts = torch.empty(db.rows * db.sketch_size, dtype=torch.int32, device="cuda")
+            sc.counts_dev(counts.data_ptr())
+            _, mix, _ = sc.finish(want_counts=False, want_distinct=False)
+        return counts, mix
+    return run

@@ -52,9 +52,16 @@ def clustered_sketch_table(n, s=1000, clusters=1000, seed=0, pool=1500, private=
     return hashes, nhash, lengths
 
 
-def synthetic_genomes(g_begin, g_end, length, device="cuda", block=256):
+def synthetic_genomes(g_begin, g_end, length, device="cuda", block=256, stride=1):
     """ASCII bases uint8[(g_end-g_begin), length] of synthetic genomes g_begin..g_end-1
-    (same definition as mash_amd.synth.synthetic_genome)."""
+    (same definition as mash_amd.synth.synthetic_genome).
+
+    SURVEY.md section 8d seeds genome g with GOLDEN*(g+1), and GOLDEN is also splitmix64's
+    state increment: consecutive genomes are the same stream shifted by one word (32 bases).
+    That is harmless for sketch throughput (the work per k-mer does not depend on the data)
+    but makes every genome contain every other's k-mers; workloads that need unrelated
+    genomes (screen) pass stride > length/32 to take genome ids g*stride, whose streams
+    do not overlap."""
     n = g_end - g_begin
     out = torch.empty((n, length), dtype=torch.uint8, device=device)
     lut = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=device)
@@ -62,7 +69,7 @@ def synthetic_genomes(g_begin, g_end, length, device="cuda", block=256):
     shifts = torch.arange(32, device=device, dtype=torch.int64) * 2
     for b0 in range(0, n, block):
         b1 = min(n, b0 + block)
-        g = torch.arange(g_begin + b0, g_begin + b1, device=device, dtype=torch.int64)
+        g = torch.arange(g_begin + b0, g_begin + b1, device=device, dtype=torch.int64) * stride
         w = splitmix64(_GOLDEN * (g + 1), nw)                                 # [B, nw]
         codes = ((w.unsqueeze(-1) >> shifts) & 3).reshape(b1 - b0, nw * 32)[:, :length]
         out[b0:b1] = lut[codes]

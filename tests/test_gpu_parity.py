@@ -391,6 +391,31 @@ def test_screen_counts_vs_oracle(eng, oracle):
     db.free()
 
 
+def test_screen_sharded_orchestrator_single_rank(eng, oracle):
+    """mash_amd.screen_dist over libmashgpu (world 1): device-resident counts, host and
+    device batches, same numbers as mg_screen_finish_host."""
+    import torch
+    from mash_amd import screen_dist
+    rng = np.random.default_rng(12)
+    genomes = [synth._rand_dna(rng, 20000) for _ in range(3)]
+    p = eng.params(k=21, s=300)
+    hashes, nhash = eng.sketch_host([[g] for g in genomes], p)
+    db = eng.table_upload(hashes, nhash, np.full(3, 20000, np.uint64))
+    reads = [genomes[i % 2][st:st + 120] for i, st in enumerate(rng.integers(0, 20000 - 120, 4000))]
+    batches = [reads[i:i + 500] for i in range(0, 4000, 500)]
+    # one batch handed over as device memory
+    from mash_amd.abi import join_records
+    blob = torch.from_numpy(np.frombuffer(join_records(batches[3]), dtype=np.uint8).copy()).cuda()
+    mixed = list(batches)
+    mixed[3] = (blob.data_ptr(), blob.numel(), blob)
+    counts, mix = screen_dist.screen_sharded(screen_dist.gpu_local_screen(eng, db, p), mixed, 300)
+    want_counts, want_mix, _ = eng.screen(db, p, batches)
+    assert np.array_equal(counts.cpu().numpy().astype(np.uint32).reshape(3, 300), want_counts)
+    assert np.array_equal(mix, want_mix)
+    assert want_counts[2].sum() < want_counts[0].sum()
+    db.free()
+
+
 def _revcomp(b):
     return bytes({65: 84, 67: 71, 71: 67, 84: 65, 78: 78}[x] for x in reversed(b))
 

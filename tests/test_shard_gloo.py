@@ -101,3 +101,84 @@ def test_bench_multirank_plumbing_dry(tmp_path):
     assert d["dry"] is True and d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong"
     assert d["rank_blocks"][0] == 0 and d["rank_blocks"][-1] == 300 and len(d["rank_blocks"]) == 3
     assert d["config"]["parallelism"] == "rowblock2" and d["config"]["table_broadcast_ms"] > 0
+
+
+# ------------------------------------------------------------------ read-sharded screen
+
+def _screen_case():
+    """small mixture + query sketches; expected counts by direct hashing with the oracle"""
+    from mash_amd import synth
+    from oracle import pyoracle
+    orc = pyoracle.Oracle()
+    rng = np.random.default_rng(5)
+    k, s = 21, 60
+    genomes = [synth._rand_dna(rng, 3000) for _ in range(3)]
+    p = orc.params(k=k, s=s)
+    db = [orc.sketch_records([g], p)[0] for g in genomes]
+    reads = []
+    for _ in range(240):
+        g = genomes[int(rng.integers(0, 2))]
+        st = int(rng.integers(0, 3000 - 100))
+        reads.append(g[st:st + 100])
+    batches = [reads[i:i + 30] for i in range(0, len(reads), 30)]         # 8 batches
+    return orc, k, s, db, batches
+
+
+def _oracle_local_screen(orc, k, s, db):
+    """what one rank computes on its share (the GPU does this through mg_screen_*)"""
+    import torch
+
+    def run(my_batches):
+        seen = {}
+        for b in my_batches:
+            for r in b:
+                h, c, _, _, _ = orc.sketch_records([r], orc.params(k=k, s=100000))
+                for hv, cv in zip(h, c):
+                    seen[int(hv)] = seen.get(int(hv), 0) + int(cv)
+        counts = np.array([[seen.get(int(x), 0) for x in row] for row in db], dtype=np.int32)
+        mix = np.array(sorted(seen), dtype=np.uint64)[:s]
+        return torch.from_numpy(counts.reshape(-1)), mix
+    return run
+
+
+def _screen_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from mash_amd import screen_dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    orc, k, s, db, batches = _screen_case()
+    counts, mix = screen_dist.screen_sharded(_oracle_local_screen(orc, k, s, db), batches, s)
+    q.put((rank, counts.numpy().copy(), mix.copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_screen_allreduce_and_mixture_merge(oracle):
+    """counts summed over ranks and the merged mixture equal the single-process result"""
+    import torch.multiprocessing as mp
+    from mash_amd import screen_dist
+    assert screen_dist.shard_batches(5, 1, 2) == [1, 3]
+    a = np.array([1, 5, 9], np.uint64); b = np.array([2, 5, 7, 11], np.uint64)
+    assert list(screen_dist.merge_mixtures([a, b], 4)) == [1, 2, 5, 7]
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_screen_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    orc, k, s, db, batches = _screen_case()
+    want_counts, want_mix = _oracle_local_screen(orc, k, s, db)(batches)
+    for r in res:
+        assert np.array_equal(r[1], want_counts.numpy())
+        assert np.array_equal(r[2], want_mix)
+    assert want_counts.numpy().reshape(3, -1)[2].sum() <= want_counts.numpy().reshape(3, -1)[0].sum()
+
