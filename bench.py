@@ -47,6 +47,8 @@ def parse_args():
     ap.add_argument("--n-genomes", type=int, default=10_000)
     ap.add_argument("--genome-len", type=int, default=1_000_000)
     ap.add_argument("--no-sketch", action="store_true", help="skip the secondary sketch measurement")
+    ap.add_argument("--no-screen", action="store_true", help="skip the tertiary screen measurement (config 4)")
+    ap.add_argument("--n-reads", type=int, default=10_000_000)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--dry-cpu", action="store_true",
@@ -304,6 +306,84 @@ def main():
         if rank == 0 and world == 1 and not args.no_cpu:
             sketch["cpu_baseline"] = cpu_baseline_sketch(min(args.cpu_seconds, 6.0))
         result["sketch"] = sketch
+
+    # ------------------------------------------------------------------ tertiary: screen (config 4)
+    # 10^7 x 150 bp reads (0.5 % errors, both strands) against the first 10^5 - 10^3 rows of the
+    # C3 table + the real sketches of the 10^3 genomes the reads come from.  Reads are sharded
+    # by batch; the one collective is the all-reduce of the observation counters (RCCL) plus
+    # an all-gather of the per-rank mixture sketches (mash_amd/screen_dist.py).  A step is the
+    # whole job: table build, every batch, counters gathered + exchanged.
+    if not args.no_screen and not dry:
+        import gc
+        bases = sk_hashes = sk_nhash = None             # release the sketch workload
+        gc.collect()
+        torch.cuda.empty_cache()
+        from mash_amd import screen_dist
+        scr = {"metric": "screened reads/sec (150 bp, k=21, s=1000, 100k-sketch database)", "unit": "reads/s"}
+        ok = torch.ones(1, dtype=torch.int32, device=dev)
+        try:
+            RL, NSRC, GL = 150, 1000, 1_000_000
+            p = eng.params(k=K, s=S)
+            genomes = synth_torch.synthetic_genomes(0, NSRC, GL, device=dev, stride=40000)
+            gh = torch.empty((NSRC, S), dtype=torch.int64, device=dev)
+            gn = torch.empty(NSRC, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()                 # torch stream -> library stream
+            eng.sketch_dev(genomes.data_ptr(), NSRC * GL, np.arange(NSRC + 1, dtype=np.uint64) * np.uint64(GL), p,
+                           gh.data_ptr(), gn.data_ptr())
+            rest = max(0, min(n, 100_000) - NSRC)
+            db_h = torch.cat([gh, hashes[:rest]], 0).contiguous()
+            db_n = torch.cat([gn, nhash[:rest]], 0).contiguous()
+            db_l = torch.full((NSRC + rest,), GL, dtype=torch.int64, device=dev)
+            torch.cuda.synchronize()
+            db = eng.table_wrap(db_h.data_ptr(), db_n.data_ptr(), db_l.data_ptr(), NSRC + rest, S, keep=(db_h, db_n, db_l))
+            nb = max(4, world)                        # >= one batch per rank; few, large batches
+            per_batch = (args.n_reads + nb - 1) // nb
+            mine = screen_dist.shard_batches(nb, rank, world)
+            batches = [synth_torch.synthetic_reads(genomes, min(per_batch, args.n_reads - b * per_batch), RL, seed=7000 + b)
+                       for b in mine]
+            del genomes
+            torch.cuda.synchronize()
+            local = screen_dist.gpu_local_screen(eng, db, p)
+            handles = [(b.data_ptr(), int(b.numel()), b) for b in batches]
+
+            def scr_step():
+                counts, mix = local(handles)
+                return screen_dist.exchange(counts, mix, S)
+        except Exception as e:                      # keep every rank in step for the collectives below
+            ok.zero_()
+            scr["error"] = repr(e)
+        if world > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            counts, mix = scr_step()
+            barrier()
+            t0 = time.perf_counter()
+            scr_steps = max(2, args.steps)
+            for _ in range(scr_steps):
+                counts, mix = scr_step()
+            barrier()
+            qdt = time.perf_counter() - t0
+            tmax = torch.tensor([qdt], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            qdt = float(tmax.item())
+            shared = (counts.view(NSRC + rest, S)[:NSRC] > 0).sum(1).float().mean().item()
+            assert 500 < shared < 900 and len(mix) == S, f"screen output failed sanity check (shared {shared}, mix {len(mix)})"
+            scr.update({"value": args.n_reads * scr_steps / qdt, "ms_per_step": qdt * 1e3 / scr_steps, "steps": scr_steps,
+                        "bp_per_s": args.n_reads * RL * scr_steps / qdt,
+                        "config": {"workload": f"mash screen: {args.n_reads} synthetic {RL} bp reads (0.5% errors) vs "
+                                               f"{NSRC + rest} sketches ({(NSRC + rest) * S} keys), reads resident in HBM, "
+                                               f"batch-sharded x{world}, counters all-reduced",
+                                   "mean_shared_hashes_of_sampled_genomes": round(shared, 1)},
+                        "roofline": {"bound": "hbm", "achieved": round(args.n_reads * (RL + 1) * scr_steps / qdt / 1e9, 1),
+                                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": round(args.n_reads * (RL + 1) * scr_steps / qdt / 1e9 / HBM_PEAK_GBS, 4),
+                                     "traffic": None, "kernel": "sketch_chunks_kernel<21,0,256> (fused table probe)",
+                                     "note": "1 B/base streamed once; integer-ALU bound like sketching (one murmur per "
+                                             "k-mer), table probes filtered by the largest key; whole-step time, "
+                                             "includes table build, counter gather and the exchange"}})
+            db.free()
+        result["screen"] = scr
 
     if rank == 0:
         print(json.dumps(result))

@@ -74,3 +74,29 @@ def synthetic_genomes(g_begin, g_end, length, device="cuda", block=256, stride=1
         codes = ((w.unsqueeze(-1) >> shifts) & 3).reshape(b1 - b0, nw * 32)[:, :length]
         out[b0:b1] = lut[codes]
     return out
+
+
+def synthetic_reads(genomes, n_reads, read_len=150, seed=0, err=0.005):
+    """uint8[n_reads, read_len + 1] on the GPU: reads sampled uniformly from both strands of
+    `genomes` (uint8[G, L] ASCII ACGT) with substitution errors at rate `err`, each followed
+    by the record separator (0x0A) -- the buffer can be handed to mg_screen_add_dev /
+    mg_sketch_dev as is."""
+    dev = genomes.device
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    ng, length = genomes.shape
+    gi = torch.randint(0, ng, (n_reads,), device=dev, generator=gen)
+    st = torch.randint(0, length - read_len, (n_reads,), device=dev, generator=gen)
+    idx = (gi * length + st).unsqueeze(1) + torch.arange(read_len, device=dev).unsqueeze(0)
+    r = genomes.reshape(-1)[idx]
+    code = ((r >> 1) & 3).to(torch.int64)                 # ASCII bits 1-2: A=0 C=1 T=2 G=3
+    hit = torch.rand((n_reads, read_len), device=dev, generator=gen) < err
+    shift = torch.randint(1, 4, (n_reads, read_len), device=dev, generator=gen)
+    code = torch.where(hit, (code + shift) & 3, code)     # substitute by one of the other three bases
+    rc = torch.rand((n_reads,), device=dev, generator=gen) < 0.5
+    code = torch.where(rc.unsqueeze(1), torch.flip(code ^ 2, dims=[1]), code)   # complement = code ^ 2
+    lut = torch.tensor([65, 67, 84, 71], dtype=torch.uint8, device=dev)
+    out = torch.full((n_reads, read_len + 1), 10, dtype=torch.uint8, device=dev)
+    out[:, :read_len] = lut[code]
+    return out
+

@@ -23,30 +23,6 @@ from mash_amd.abi import MashGpu  # noqa: E402
 K, S, L, RL = 21, 1000, 1_000_000, 150
 
 
-def make_reads(genomes, n_reads, seed, err=0.005):
-    """[n_reads, RL+1] uint8 on the GPU: reads sampled uniformly (both strands) from `genomes`
-    with substitution errors, each followed by the record separator."""
-    g = torch.Generator(device="cuda")
-    g.manual_seed(seed)
-    ng = genomes.shape[0]
-    gi = torch.randint(0, ng, (n_reads,), device="cuda", generator=g)
-    st = torch.randint(0, L - RL, (n_reads,), device="cuda", generator=g)
-    idx = (gi * L + st).unsqueeze(1) + torch.arange(RL, device="cuda").unsqueeze(0)
-    r = genomes.reshape(-1)[idx]                                     # [n, RL] ASCII
-    # substitution errors: replace by one of the three other bases
-    code = ((r >> 1) & 3).to(torch.int64)                             # A=0 C=1 T=2 G=3 (ASCII bits)
-    hit = torch.rand((n_reads, RL), device="cuda", generator=g) < err
-    shift = torch.randint(1, 4, (n_reads, RL), device="cuda", generator=g)
-    code = torch.where(hit, (code + shift) & 3, code)
-    # reverse-complement half of the reads: complement = code ^ 2 in this encoding (A<->T, C<->G)
-    rc = torch.rand((n_reads,), device="cuda", generator=g) < 0.5
-    code = torch.where(rc.unsqueeze(1), torch.flip(code ^ 2, dims=[1]), code)
-    lut = torch.tensor([65, 67, 84, 71], dtype=torch.uint8, device="cuda")
-    out = torch.full((n_reads, RL + 1), 10, dtype=torch.uint8, device="cuda")
-    out[:, :RL] = lut[code]
-    return out
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reads", type=int, default=10_000_000)
@@ -77,7 +53,7 @@ def main():
     batches = []
     for b0 in range(0, a.reads, a.batch):
         n = min(a.batch, a.reads - b0)
-        batches.append(make_reads(genomes, n, seed=1000 + b0))
+        batches.append(synth_torch.synthetic_reads(genomes, n, RL, seed=1000 + b0))
     torch.cuda.synchronize()
     nb = sum(int(b.numel()) for b in batches)
     res = {"reads": a.reads, "read_len": RL, "db_sketches": a.src + rest, "bytes": nb}
