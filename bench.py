@@ -347,7 +347,14 @@ def main():
             handles = [(b.data_ptr(), int(b.numel()), b) for b in batches]
 
             def scr_step():
-                counts, mix = local(handles)
+                # a local failure must not leave the other ranks alone in the collective
+                try:
+                    counts, mix = local(handles)
+                except Exception as e:
+                    scr["error"] = repr(e)
+                    ok.zero_()
+                    counts = torch.zeros((NSRC + rest) * S, dtype=torch.int32, device=dev)
+                    mix = np.zeros(0, dtype=np.uint64)
                 return screen_dist.exchange(counts, mix, S)
         except Exception as e:                      # keep every rank in step for the collectives below
             ok.zero_()
@@ -366,7 +373,9 @@ def main():
             tmax = torch.tensor([qdt], dtype=torch.float64, device=dev)
             if world > 1:
                 dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             qdt = float(tmax.item())
+        if int(ok.item()) == 1:
             shared = (counts.view(NSRC + rest, S)[:NSRC] > 0).sum(1).float().mean().item()
             assert 500 < shared < 900 and len(mix) == S, f"screen output failed sanity check (shared {shared}, mix {len(mix)})"
             scr.update({"value": args.n_reads * scr_steps / qdt, "ms_per_step": qdt * 1e3 / scr_steps, "steps": scr_steps,
@@ -383,6 +392,8 @@ def main():
                                              "k-mer), table probes filtered by the largest key; whole-step time, "
                                              "includes table build, counter gather and the exchange"}})
             db.free()
+        elif "error" not in scr:
+            scr["error"] = "failed on another rank"
         result["screen"] = scr
 
     if rank == 0:
