@@ -53,6 +53,8 @@ typedef struct mg_params {
     uint8_t  use64;            /* use64 = alphabetSize^k > 2^32  (Sketch.cpp:1136) */
     uint8_t  noncanonical;     /* noncanonical (-n, forced by -a / -z)           */
     uint8_t  counts;           /* counts (multiplicities requested)              */
+    uint32_t min_copies;       /* minCov (-m, reads mode; Sketch.cpp:1156): a hash enters the sketch at
+                                * its m-th occurrence.  0 / 1 = every k-mer (mg_params_init sets 1). */
 } mg_params;
 
 /* {numer, denom} of one pair: what the merge loop of compareSketches produces

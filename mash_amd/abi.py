@@ -44,6 +44,7 @@ class MgParams(C.Structure):
         ("use64", C.c_uint8),
         ("noncanonical", C.c_uint8),
         ("counts", C.c_uint8),
+        ("min_copies", C.c_uint32),
     ]
 
 
@@ -178,11 +179,13 @@ def tri_pairs(row_begin, row_end):
     return t(row_end) - t(row_begin)
 
 
-def make_params(lib, k=21, s=1000, seed=42, alphabet="ACGT", noncanonical=False, preserve_case=False):
+def make_params(lib, k=21, s=1000, seed=42, alphabet="ACGT", noncanonical=False, preserve_case=False,
+                min_copies=1):
     p = MgParams()
     rc = lib.mg_params_init(C.byref(p), k, s, seed, alphabet.encode(), int(noncanonical), int(preserve_case))
     if rc != MG_OK:
         raise MashGpuError(f"mg_params_init failed ({rc})")
+    p.min_copies = min_copies
     return p
 
 

@@ -33,7 +33,6 @@ constexpr int MR_EPT = 20;                   // table entries built per thread (
 constexpr int MR_CB = 8;                     // consecutive columns per wave batch (64 B of output per row)
 constexpr int MR_KU = 4;                     // 64-element blocks of a column in flight
 constexpr uint32_t MR_OVF = 0x8000u;         // dir flag: bucket has more than MR_W entries
-constexpr uint64_t HMAX64 = 0xFFFFFFFFFFFFFFFFULL;
 
 struct MergedHdr {
     uint32_t shr;        // (unused: the prefix shift is launch-wide, CompareArgs::pfx_shr)

@@ -146,6 +146,7 @@ int mg_params_init(mg_params *p, int kmer_size, uint64_t sketch_size, uint32_t s
     p->seed = seed;
     p->noncanonical = noncanonical ? 1 : 0;
     p->preserve_case = preserve_case ? 1 : 0;
+    p->min_copies = 1;
     for (const char *c = alphabet; *c; c++) {            // Sketch.cpp:1113-1125
         char u = *c;
         if (!preserve_case && u > 96 && u < 123) u -= 32;
@@ -181,6 +182,121 @@ int mg_sketch_dev(mg_ctx *ctx, const mg_params *p, const uint8_t *bases_dev, uin
 {
     return sketch_dev_impl(ctx, p, bases_dev, nbases, sketch_off, nsketch, hashes_out_dev, nhash_out_dev,
                            counts_out_dev, nullptr);
+}
+
+// minCov >= 2: bottom-s of the hashes seen at least m times (see range_count_kernel).  One
+// sketch at a time; `work` holds the chunks of all sketches, grouped by sketch.
+static int sketch_min_copies(mg_ctx *ctx, const mg_params *p, int mode, const uint8_t *bases_dev,
+                             const std::vector<mg::SketchWork> &work, const mg::SketchWork *d_work,
+                             const uint8_t *d_alpha, uint64_t nsketch, uint64_t *hashes_out_dev,
+                             uint32_t *nhash_out_dev)
+{
+    const uint64_t s = p->sketch_size;
+    const uint64_t hash_max = p->use64 ? 0xFFFFFFFFFFFFFFFEull : 0xFFFFFFFFull;
+    const uint64_t max_expect = 1ull << 24;                 // distinct hashes aimed at per round (table: 4x slots)
+    unsigned long long *d_keys = nullptr, *d_out = nullptr, *d_outn = nullptr;
+    uint32_t *d_cnts = nullptr, *d_ovf = nullptr;
+    uint64_t slots_cap = 0, out_cap = 0;
+    int rc = MG_OK;
+    auto release = [&]() {
+        hipStreamSynchronize(ctx->stream);
+        for (void *q : {(void *)d_keys, (void *)d_out, (void *)d_outn, (void *)d_cnts, (void *)d_ovf})
+            if (q) hipFree(q);
+    };
+    if (hipMalloc(&d_outn, 8) != hipSuccess || hipMalloc(&d_ovf, 4) != hipSuccess) {
+        release();
+        return fail(ctx, MG_ERR_NOMEM, "mg_sketch: allocation failed");
+    }
+    size_t w0 = 0;
+    while (w0 < work.size() && rc == MG_OK) {
+        const uint32_t sk = work[w0].sketch;
+        size_t w1 = w0;
+        uint64_t npos = 0;
+        while (w1 < work.size() && work[w1].sketch == sk) { npos += work[w1].end - work[w1].begin; w1++; }
+        std::vector<uint64_t> kept;                          // ascending across rounds
+        uint64_t lo = 0;
+        uint64_t expect = std::max<uint64_t>(64 * s, 1ull << 16);
+        if (const char *e = getenv("MASHGPU_MINCOPIES_EXPECT")) expect = std::max<uint64_t>(1024, strtoull(e, nullptr, 10));  // test knob
+        bool exhausted = false;
+        while (kept.size() < s && !exhausted && rc == MG_OK) {
+            // range [lo, hi] expected to hold <= `expect` distinct hashes (there are <= npos k-mers)
+            const long double frac = npos <= expect ? 1.0L : (long double)expect / (long double)npos;
+            const long double width = frac * ((long double)hash_max + 1.0L);
+            uint64_t hi = hash_max;
+            if (frac < 1.0L && width < (long double)(hash_max - lo)) hi = lo + (uint64_t)width;
+            const uint64_t want = std::min<uint64_t>(expect, npos);
+            uint64_t slots = 1024;
+            while (slots < 4 * want) slots <<= 1;
+            if (slots > slots_cap) {
+                if (d_keys) hipFree(d_keys);
+                if (d_cnts) hipFree(d_cnts);
+                d_keys = nullptr; d_cnts = nullptr;
+                if (hipMalloc(&d_keys, slots * 8) != hipSuccess || hipMalloc(&d_cnts, slots * 4) != hipSuccess) {
+                    rc = fail(ctx, MG_ERR_NOMEM, "mg_sketch: allocation failed (min_copies table)");
+                    break;
+                }
+                slots_cap = slots;
+            }
+            if (slots / 2 > out_cap) {
+                if (d_out) hipFree(d_out);
+                d_out = nullptr;
+                if (hipMalloc(&d_out, slots / 2 * 8) != hipSuccess) {
+                    rc = fail(ctx, MG_ERR_NOMEM, "mg_sketch: allocation failed (min_copies list)");
+                    break;
+                }
+                out_cap = slots / 2;
+            }
+            mg::RangeCountArgs ra;
+            ra.bases = bases_dev;
+            ra.work = d_work + w0;
+            ra.alphabet = d_alpha;
+            ra.keys = d_keys;
+            ra.cnts = d_cnts;
+            ra.overflow = d_ovf;
+            ra.mask = slots - 1;
+            ra.lo = lo; ra.hi = hi;
+            ra.seed = p->seed;
+            ra.use64 = p->use64;
+            ra.fold_case = p->preserve_case ? 0 : 1;
+            unsigned long long n_out = 0;
+            uint32_t ovf = 0;
+            hipError_t e = hipMemsetAsync(d_keys, 0xFF, slots * 8, ctx->stream);
+            if (e == hipSuccess) e = hipMemsetAsync(d_cnts, 0, slots * 4, ctx->stream);
+            if (e == hipSuccess) e = hipMemsetAsync(d_ovf, 0, 4, ctx->stream);
+            if (e == hipSuccess) e = hipMemsetAsync(d_outn, 0, 8, ctx->stream);
+            if (e == hipSuccess) e = mg::launch_range_count(p->kmer_size, mode, ra, (uint32_t)(w1 - w0), ctx->stream);
+            if (e == hipSuccess) e = mg::launch_range_extract(d_keys, d_cnts, slots, p->min_copies, d_out, d_outn, out_cap, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(&n_out, d_outn, 8, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(&ovf, d_ovf, 4, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) { rc = fail(ctx, MG_ERR_HIP, std::string("mg_sketch (min_copies): ") + hipGetErrorString(e)); break; }
+            if (ovf || n_out > out_cap) {                    // more distinct hashes than planned: narrow the range
+                if (expect <= 1024) { rc = fail(ctx, MG_ERR_HIP, "mg_sketch (min_copies): counting table overflow"); break; }
+                expect /= 4;
+                continue;
+            }
+            std::vector<uint64_t> got(n_out);
+            if (n_out && hipMemcpy(got.data(), d_out, n_out * 8, hipMemcpyDeviceToHost) != hipSuccess) {
+                rc = fail(ctx, MG_ERR_HIP, "mg_sketch (min_copies): D2H copy failed");
+                break;
+            }
+            std::sort(got.begin(), got.end());
+            for (uint64_t v : got) { if (kept.size() < s) kept.push_back(v); }
+            if (hi >= hash_max) exhausted = true;
+            else lo = hi + 1;
+            if (expect < max_expect) expect *= 8;
+        }
+        if (rc != MG_OK) break;
+        const uint32_t n = (uint32_t)kept.size();
+        if (n && hipMemcpy(hashes_out_dev + (uint64_t)sk * s, kept.data(), (size_t)n * 8, hipMemcpyHostToDevice) != hipSuccess)
+            rc = fail(ctx, MG_ERR_HIP, "mg_sketch (min_copies): H2D copy failed");
+        if (rc == MG_OK && hipMemcpy(nhash_out_dev + sk, &n, 4, hipMemcpyHostToDevice) != hipSuccess)
+            rc = fail(ctx, MG_ERR_HIP, "mg_sketch (min_copies): H2D copy failed");
+        w0 = w1;
+    }
+    (void)nsketch;
+    release();
+    return rc;
 }
 
 static int sketch_dev_impl(mg_ctx *ctx, const mg_params *p, const uint8_t *bases_dev, uint64_t nbases,
@@ -278,13 +394,14 @@ static int sketch_dev_impl(mg_ctx *ctx, const mg_params *p, const uint8_t *bases
     uint8_t *d_alpha = nullptr;
     uint64_t *d_pool = nullptr, *d_gT = nullptr;
     uint32_t *d_pool_n = nullptr, *d_fix = nullptr;
-    unsigned long long *d_firstpos = nullptr, *d_tstar = nullptr;
+    unsigned long long *d_firstpos = nullptr, *d_tstar = nullptr, *d_pos2 = nullptr;
     int rc = MG_OK;
     auto cleanup = [&]() {
         hipStreamSynchronize(ctx->stream);
         if (d_work2) hipFree(d_work2);
         if (d_fix) hipFree(d_fix);
         if (d_firstpos) hipFree(d_firstpos);
+        if (d_pos2) hipFree(d_pos2);
         if (d_tstar) hipFree(d_tstar);
         if (d_work) hipFree(d_work);
         if (d_merge) hipFree(d_merge);
@@ -335,10 +452,18 @@ static int sketch_dev_impl(mg_ctx *ctx, const mg_params *p, const uint8_t *bases
     a.probe_obs = probe ? probe->obs : nullptr;
     a.probe_mask = probe ? probe->mask : 0;
     a.probe_max = probe ? probe->key_max : 0;
+    const uint32_t min_copies = p->min_copies > 1 ? p->min_copies : 1;
+    if (min_copies > 1) {
+        // -m: bottom-s of the hashes seen at least m times, by exact range counting (sketch.hip)
+        if (probe) { cleanup(); return fail(ctx, MG_ERR_UNSUPPORTED, "mg_screen: min_copies does not apply"); }
+        rc = sketch_min_copies(ctx, p, mode, bases_dev, work, d_work, d_alpha, nsketch, hashes_out_dev, nhash_out_dev);
+        if (rc != MG_OK) { cleanup(); return rc; }
+    } else {
     prof_begin(ctx, ctx->prof_sketch);
     TRY_C(mg::launch_sketch_chunks(p->kmer_size, mode, nt, a, (uint32_t)work.size(), ctx->stream));
     prof_end(ctx, ctx->prof_sketch);
-    if (!merges.empty()) {
+    }
+    if (min_copies == 1 && !merges.empty()) {
         mg::MergeArgs m;
         m.work = d_merge;
         m.pool = d_pool;
@@ -374,9 +499,27 @@ static int sketch_dev_impl(mg_ctx *ctx, const mg_params *p, const uint8_t *bases
         ca.seed = p->seed;
         ca.use64 = p->use64;
         ca.fold_case = p->preserve_case ? 0 : 1;
+        ca.prevpos = nullptr;
         ca.phase = 0;
         TRY_C(mg::launch_count_chunks(p->kmer_size, mode, ca, (uint32_t)work.size(), ctx->stream));
-        TRY_C(mg::launch_count_tstar(nhash_out_dev, counts_out_dev, d_firstpos, d_tstar, d_fix, (uint32_t)nsketch,
+        // minCov m: a hash is promoted at its m-th occurrence, so t* is the latest m-th occurrence:
+        // walk from the first to the m-th position, one pass per step
+        unsigned long long *pos_m = d_firstpos;
+        if (min_copies > 1) {
+            TRY_C(hipMalloc(&d_pos2, nsketch * s * 8));
+            unsigned long long *cur = d_pos2, *prv = d_firstpos;
+            for (uint32_t j = 2; j <= min_copies; j++) {
+                TRY_C(hipMemsetAsync(cur, 0xFF, nsketch * s * 8, ctx->stream));
+                ca.firstpos = cur;
+                ca.prevpos = prv;
+                ca.phase = 2;
+                TRY_C(mg::launch_count_chunks(p->kmer_size, mode, ca, (uint32_t)work.size(), ctx->stream));
+                std::swap(cur, prv);
+            }
+            pos_m = prv;
+            ca.prevpos = nullptr;
+        }
+        TRY_C(mg::launch_count_tstar(nhash_out_dev, counts_out_dev, pos_m, d_tstar, d_fix, (uint32_t)nsketch,
                                      (uint32_t)s, ctx->stream));
         std::vector<uint32_t> fix(nsketch);
         TRY_C(hipMemcpyAsync(fix.data(), d_fix, nsketch * 4, hipMemcpyDeviceToHost, ctx->stream));

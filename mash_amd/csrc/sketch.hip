@@ -398,16 +398,27 @@ __global__ __launch_bounds__(256) void count_chunks_kernel(CountArgs a)
     uint32_t *cnt = a.counts + (uint64_t)w.sketch * s;
     unsigned long long *fp = a.firstpos + (uint64_t)w.sketch * s;
     const uint32_t phase = a.phase;
+    const unsigned long long *prev = a.prevpos ? a.prevpos + (uint64_t)w.sketch * s : nullptr;
     stream_chunk<K, MODE, NT>(a.bases, w, tile, alpha, a.fold_case != 0, a.seed, a.use64 != 0,
                               [&](uint64_t h, uint64_t kpos) {
         if (h > T) return;
+        if (phase == 2) {                                  // position of the next occurrence after prev[]
+            uint32_t lo = 0, hi = n;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (hl[mid] < h) lo = mid + 1; else hi = mid;
+            }
+            if (lo < n && hl[lo] == h && (unsigned long long)kpos > prev[lo])
+                atomicMin(&fp[lo], (unsigned long long)kpos);
+            return;
+        }
         if (phase == 0) {
             uint32_t lo = 0, hi = n;
             while (lo < hi) {
                 const uint32_t mid = (lo + hi) >> 1;
                 if (hl[mid] < h) lo = mid + 1; else hi = mid;
             }
-            if (lo < n && hl[lo] == h) {                   // always true: every value <= h_max is kept
+            if (lo < n && hl[lo] == h) {                   // minCov 1: always true (every value <= h_max is kept)
                 atomicAdd(&cnt[lo], 1u);
                 atomicMin(&fp[lo], (unsigned long long)kpos);
             }
@@ -437,6 +448,98 @@ __global__ void count_tstar_kernel(const uint32_t *nhash, uint32_t *counts, cons
     }
     tstar[i] = t;
     need_fix[i] = fix;
+}
+
+// ---------------------------------------------------------------------------
+// minCov >= 2 (`mash sketch -m`, MinHashHeap.cpp:96-118): a hash enters the sketch at its m-th
+// occurrence.  The result is order independent -- it is the s smallest hashes of
+// Q = {h : multiplicity(h) >= m} (a member of that set passes the `size < s || hash < top` test
+// at every occurrence before its promotion, is never evicted, and the pending-set clean-up only
+// drops hashes above an evicted top; checked against the reference's objects in
+// tests/golden/ref_sketch_vectors_m.npz).  Q is found by exact counting: all k-mers whose
+// hash lies in [lo, hi] are counted in an open-addressing table in HBM (the range is sized from
+// the k-mer total so that it holds a bounded number of distinct hashes), survivors with count
+// >= m are extracted, and the range moves up until s survivors exist or the hash space ends.
+template <int K, int MODE>
+__global__ __launch_bounds__(256) void range_count_kernel(RangeCountArgs a)
+{
+    constexpr int NT = 256;
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t *tile = reinterpret_cast<uint32_t *>(smem);
+    uint8_t *alpha = reinterpret_cast<uint8_t *>(tile + sk_tile_dw(NT));
+    if (MODE == 2) {
+        for (int i = threadIdx.x; i < 256; i += NT) alpha[i] = a.alphabet[i];
+        __syncthreads();
+    }
+    const SketchWork w = a.work[blockIdx.x];
+    unsigned long long *keys = a.keys;
+    uint32_t *cnts = a.cnts;
+    const uint64_t mask = a.mask, lo = a.lo, hi = a.hi;
+    stream_chunk<K, MODE, NT>(a.bases, w, tile, alpha, a.fold_case != 0, a.seed, a.use64 != 0,
+                              [&](uint64_t h, uint64_t) {
+        if (h < lo || h > hi) return;
+        uint64_t slot = scr_slot(h, mask);
+        for (uint32_t step = 0; step < 4096; step++) {
+            const unsigned long long old = atomicCAS(&keys[slot], SCR_EMPTY, (unsigned long long)h);
+            if (old == SCR_EMPTY || old == h) { atomicAdd(&cnts[slot], 1u); return; }
+            slot = (slot + 1) & mask;
+        }
+        atomicOr(a.overflow, 1u);                          // table too full: the host retries a narrower range
+    });
+}
+
+__global__ void range_extract_kernel(const unsigned long long *keys, const uint32_t *cnts, uint64_t slots,
+                                     uint32_t min_copies, unsigned long long *out, unsigned long long *out_n,
+                                     uint64_t out_cap)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += stride) {
+        if (keys[i] != SCR_EMPTY && cnts[i] >= min_copies) {
+            const unsigned long long at = atomicAdd(out_n, 1ull);
+            if (at < out_cap) out[at] = keys[i];
+        }
+    }
+}
+
+template <int K, int MODE>
+static hipError_t launch_range_one(const RangeCountArgs &a, uint32_t nwork, hipStream_t stream)
+{
+    const size_t smem = (size_t)sk_tile_dw(256) * 4 + 256 + 64;
+    hipLaunchKernelGGL((range_count_kernel<K, MODE>), dim3(nwork), dim3(256), smem, stream, a);
+    return hipGetLastError();
+}
+
+template <int MODE>
+static hipError_t launch_range_k(int k, const RangeCountArgs &a, uint32_t nwork, hipStream_t st)
+{
+    switch (k) {
+#define MG_CASE(KK) case KK: return launch_range_one<KK, MODE>(a, nwork, st);
+        MG_CASE(1) MG_CASE(2) MG_CASE(3) MG_CASE(4) MG_CASE(5) MG_CASE(6) MG_CASE(7) MG_CASE(8)
+        MG_CASE(9) MG_CASE(10) MG_CASE(11) MG_CASE(12) MG_CASE(13) MG_CASE(14) MG_CASE(15) MG_CASE(16)
+        MG_CASE(17) MG_CASE(18) MG_CASE(19) MG_CASE(20) MG_CASE(21) MG_CASE(22) MG_CASE(23) MG_CASE(24)
+        MG_CASE(25) MG_CASE(26) MG_CASE(27) MG_CASE(28) MG_CASE(29) MG_CASE(30) MG_CASE(31) MG_CASE(32)
+#undef MG_CASE
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_range_count(int k, int mode, const RangeCountArgs &a, uint32_t nwork, hipStream_t stream)
+{
+    if (nwork == 0) return hipSuccess;
+    if (mode == 0) return launch_range_k<0>(k, a, nwork, stream);
+    if (mode == 1) return launch_range_k<1>(k, a, nwork, stream);
+    return launch_range_k<2>(k, a, nwork, stream);
+}
+
+hipError_t launch_range_extract(const unsigned long long *keys, const uint32_t *cnts, uint64_t slots,
+                                uint32_t min_copies, unsigned long long *out, unsigned long long *out_n,
+                                uint64_t out_cap, hipStream_t stream)
+{
+    uint64_t blocks = (slots + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(range_extract_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, keys, cnts, slots,
+                       min_copies, out, out_n, out_cap);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------

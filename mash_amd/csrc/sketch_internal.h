@@ -63,14 +63,36 @@ struct CountArgs {
     const uint64_t *hashes;       // final sketch rows [nsketch * s]
     const uint32_t *nhash;
     uint32_t *counts;             // [nsketch * s]
-    unsigned long long *firstpos; // [nsketch * s] first occurrence (byte offset) of every kept hash
+    unsigned long long *firstpos; // [nsketch * s] phase 0: first occurrence (byte offset) of every kept hash;
+                                  // phase 2: first occurrence AFTER prevpos (initialise to ~0)
+    const unsigned long long *prevpos; // [nsketch * s] phase 2 only
     const unsigned long long *tstar;   // [nsketch] phase 1: only occurrences at positions <= tstar count
     uint32_t sketch_size;
     uint32_t seed;
     uint32_t use64;
     uint32_t fold_case;
-    uint32_t phase;               // 0: multiplicities + first positions; 1: recount the largest kept hash
+    uint32_t phase;               // 0: multiplicities + first positions; 1: recount the largest kept hash;
+                                  // 2: next occurrence after prevpos (minCov > 1: position of the m-th occurrence)
 };
+
+// exact multiplicities of every k-mer hash in [lo, hi] (minCov > 1, see range_count_kernel)
+struct RangeCountArgs {
+    const uint8_t *bases;
+    const SketchWork *work;
+    const uint8_t *alphabet;
+    unsigned long long *keys;     // open-addressing table, ~0 = empty
+    uint32_t *cnts;
+    uint32_t *overflow;           // set when an insertion ran out of probes
+    uint64_t mask;                // slots - 1
+    uint64_t lo, hi;              // inclusive hash range
+    uint32_t seed;
+    uint32_t use64;
+    uint32_t fold_case;
+};
+hipError_t launch_range_count(int k, int mode, const RangeCountArgs &a, uint32_t nwork, hipStream_t stream);
+hipError_t launch_range_extract(const unsigned long long *keys, const uint32_t *cnts, uint64_t slots,
+                                uint32_t min_copies, unsigned long long *out, unsigned long long *out_n,
+                                uint64_t out_cap, hipStream_t stream);
 
 // geometry: threads per workgroup and LDS candidate capacity for sketch size s;
 // false if s is too large for the LDS-resident selector.

@@ -161,6 +161,7 @@ struct Params {                               // Sketch::Parameters (Sketch.h:34
     bool concatenated = false, noncanonical = false, preserve_case = false, reads = false, counts = false;
     float warning = 0;
     uint64_t genome_size = 0;
+    uint32_t min_copies = 1;                  // minCov (-m)
     string alphabet;                          // normalised (uppercased unless preserve_case), sorted
     uint32_t alphabet_size = 0;
     bool use64 = false;
@@ -197,12 +198,17 @@ int sketch_parameter_setup(Params &p, const Cmd &c)
     p.preserve_case = c.o("case").active;
     if (c.has("warning")) p.warning = c.o("warning").num;
     if (c.o("memory").active || c.o("minCov").active || c.o("targetCov").active) {
-        if ((c.o("minCov").active && c.o("minCov").num > 1) || c.o("memory").active || c.o("targetCov").active) {
-            cerr << "ERROR: The options -m (>1), -b and -c depend on the order k-mers are seen and are not "
-                    "supported by the GPU sketching path." << endl;
+        if (c.o("memory").active && c.o("minCov").active) {          // sketchParameterSetup.cpp:44-48
+            cerr << "ERROR: The option " << c.o("minCov").id << " cannot be used with " << c.o("memory").id << "." << endl;
+            return 1;
+        }
+        if (c.o("memory").active || c.o("targetCov").active) {
+            cerr << "ERROR: The options -b (Bloom filter) and -c (early stop) depend on the order k-mers are "
+                    "seen and are not supported by the GPU sketching path." << endl;
             return 1;
         }
         p.reads = true;
+        if (c.o("minCov").num >= 1) p.min_copies = (uint32_t)c.o("minCov").num;   // Sketch.cpp:1156 (reads mode only)
     }
     if (c.o("genome").active) { p.reads = true; p.genome_size = (uint64_t)c.o("genome").num; }
     if (p.reads) p.counts = true;
@@ -296,6 +302,7 @@ void flush_batch(Gpu &gpu, SketchSet &set, PendingBatch &b)
     mg_params mp;
     mg_params_init(&mp, set.p.kmer, set.p.sketch_size, set.p.seed, set.p.alphabet.c_str(), set.p.noncanonical,
                    set.p.preserve_case);
+    if (set.p.reads) mp.min_copies = set.p.min_copies;
     const uint64_t n = b.refs.size(), s = set.p.sketch_size;
     vector<uint64_t> hashes(n * s);
     vector<uint32_t> nhash(n), counts(set.p.counts ? n * s : 0);

@@ -95,7 +95,22 @@ struct oracle_heap {
     int       use64;
     uint64_t *v;        /* ascending, distinct, n <= cap+1 */
     uint32_t *c;
+    /* multiplicityMinimum > 1: hashesPending (set with counts) + hashesQueuePending (max-heap
+     * that may hold zombies already erased from the set), MinHashHeap.h:33-34 */
+    uint64_t  mmin;
+    uint64_t *pv; uint32_t *pc; uint64_t pn, pcap;      /* pending set, ascending */
+    uint64_t *pq; uint64_t qn, qcap;                    /* pending queue: multiset, ascending */
 };
+
+static uint64_t lower_bound64(const uint64_t *v, uint64_t n, uint64_t x)
+{
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {
+        uint64_t mid = (lo + hi) >> 1;
+        if (v[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
 
 oracle_heap *oracle_heap_new(uint64_t cardinality_max, int use64)
 {
@@ -107,16 +122,82 @@ oracle_heap *oracle_heap_new(uint64_t cardinality_max, int use64)
     return h;
 }
 
+oracle_heap *oracle_heap_new_m(uint64_t cardinality_max, int use64, uint64_t multiplicity_min)
+{
+    oracle_heap *h = oracle_heap_new(cardinality_max, use64);
+    h->mmin = multiplicity_min;
+    return h;
+}
+
 void oracle_heap_free(oracle_heap *h)
 {
     if (!h) return;
-    free(h->v); free(h->c); free(h);
+    free(h->v); free(h->c); free(h->pv); free(h->pc); free(h->pq); free(h);
+}
+
+static void pending_set_erase(oracle_heap *h, uint64_t x)
+{
+    uint64_t i = lower_bound64(h->pv, h->pn, x);
+    if (i < h->pn && h->pv[i] == x) {
+        memmove(h->pv + i, h->pv + i + 1, (h->pn - i - 1) * sizeof(uint64_t));
+        memmove(h->pc + i, h->pc + i + 1, (h->pn - i - 1) * sizeof(uint32_t));
+        h->pn--;
+    }
+}
+
+/* the multiplicityMinimum > 1 branch of tryInsert (MinHashHeap.cpp:96-118 and :126-144) */
+static void heap_try_insert_m(oracle_heap *h, uint64_t hash)
+{
+    if (!(h->n < h->cap || hash < h->v[h->n - 1])) return;          /* :70-74 */
+    uint64_t lo = lower_bound64(h->v, h->n, hash);
+    if (lo < h->n && h->v[lo] == hash) {                              /* :120-124 */
+        h->c[lo]++;
+        h->msum++;
+    } else {
+        uint64_t pi = lower_bound64(h->pv, h->pn, hash);
+        const int pend = pi < h->pn && h->pv[pi] == hash;
+        const uint64_t pcount = pend ? h->pc[pi] : 0;
+        if (pcount == h->mmin - 1) {                                  /* :96-109 promote */
+            memmove(h->v + lo + 1, h->v + lo, (h->n - lo) * sizeof(uint64_t));
+            memmove(h->c + lo + 1, h->c + lo, (h->n - lo) * sizeof(uint32_t));
+            h->v[lo] = hash; h->c[lo] = (uint32_t)h->mmin;
+            h->n++; h->msum += h->mmin;
+            pending_set_erase(h, hash);                               /* the queue keeps a zombie */
+        } else {                                                      /* :110-118 */
+            if (!pend) {
+                if (h->qn == h->qcap) { h->qcap = h->qcap ? 2 * h->qcap : 1024; h->pq = (uint64_t *)realloc(h->pq, h->qcap * 8); }
+                uint64_t qi = lower_bound64(h->pq, h->qn, hash);      /* hashesQueuePending.push */
+                memmove(h->pq + qi + 1, h->pq + qi, (h->qn - qi) * 8);
+                h->pq[qi] = hash; h->qn++;
+                if (h->pn == h->pcap) {
+                    h->pcap = h->pcap ? 2 * h->pcap : 1024;
+                    h->pv = (uint64_t *)realloc(h->pv, h->pcap * 8);
+                    h->pc = (uint32_t *)realloc(h->pc, h->pcap * 4);
+                }
+                memmove(h->pv + pi + 1, h->pv + pi, (h->pn - pi) * 8);
+                memmove(h->pc + pi + 1, h->pc + pi, (h->pn - pi) * 4);
+                h->pv[pi] = hash; h->pc[pi] = 0; h->pn++;
+            }
+            h->pc[pi]++;                                              /* hashesPending.insert(hash, 1) */
+        }
+    }
+    if (h->n > h->cap) {                                              /* :126-144 */
+        const uint64_t top = h->v[h->n - 1];
+        h->msum -= h->c[h->n - 1];
+        h->n--;
+        /* drop pending hashes above the evicted top (zombies included) */
+        while (h->qn > 0 && top < h->pq[h->qn - 1]) {
+            pending_set_erase(h, h->pq[h->qn - 1]);
+            h->qn--;
+        }
+    }
 }
 
 uint64_t oracle_heap_size(const oracle_heap *h) { return h->n; }
 
 void oracle_heap_try_insert(oracle_heap *h, uint64_t hash)
 {
+    if (h->mmin > 1) { heap_try_insert_m(h, hash); return; }
     /* :70-74  size < max || hash < top */
     if (!(h->n < h->cap || hash < h->v[h->n - 1])) return;
     /* lower bound */
@@ -215,7 +296,8 @@ int oracle_sketch_records(const char *bases, const uint64_t *rec_off, uint64_t n
                           uint64_t *hashes_out, uint32_t *counts_out, uint64_t *n_out,
                           uint64_t *length_out, double *set_size_out)
 {
-    oracle_heap *h = oracle_heap_new(p->sketch_size, p->use64);
+    /* Sketch.cpp:1156: minCov applies in reads mode; callers set min_copies only then */
+    oracle_heap *h = oracle_heap_new_m(p->sketch_size, p->use64, p->min_copies > 1 ? p->min_copies : 1);
     uint64_t length = 0;
     int any = 0;
     for (uint64_t r = 0; r < nrec; r++) {

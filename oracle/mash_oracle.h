@@ -41,6 +41,7 @@ typedef struct {
     int      noncanonical;     /* ::noncanonical                        (Sketch.h:98)  */
     int      preserve_case;    /* ::preserveCase                        (Sketch.h:89)  */
     uint8_t  alphabet[256];    /* ::alphabet                            (Sketch.h:87)  */
+    uint32_t min_copies;       /* ::minCov (reads mode, -m)             (Sketch.h:102); 0 or 1 = off */
 } oracle_params;
 
 /* setAlphabetFromString, Sketch.cpp:1108-1137 (fills alphabet + use64). */
@@ -52,9 +53,12 @@ void oracle_murmur3_x64_128(const void *key, int len, uint32_t seed, uint64_t ou
 /* getHash, hash.cpp:10-38: low 64 bits (use64) or low 32 bits of h1. */
 uint64_t oracle_get_hash(const char *kmer, int k, uint32_t seed, int use64);
 
-/* Opaque MinHashHeap (MinHashHeap.cpp:68-145, minCov==1, no bloom filter). */
+/* Opaque MinHashHeap (MinHashHeap.cpp:68-145, no bloom filter).  oracle_heap_new: minCov 1;
+ * oracle_heap_new_m: multiplicityMinimum >= 1 with the pending set / pending queue (:101-118,
+ * :131-141). */
 typedef struct oracle_heap oracle_heap;
 oracle_heap *oracle_heap_new(uint64_t cardinality_max, int use64);
+oracle_heap *oracle_heap_new_m(uint64_t cardinality_max, int use64, uint64_t multiplicity_min);
 void         oracle_heap_free(oracle_heap *h);
 void         oracle_heap_try_insert(oracle_heap *h, uint64_t hash);
 uint64_t     oracle_heap_size(const oracle_heap *h);

@@ -26,6 +26,7 @@ class OracleParams(C.Structure):
         ("noncanonical", C.c_int),
         ("preserve_case", C.c_int),
         ("alphabet", C.c_uint8 * 256),
+        ("min_copies", C.c_uint32),
     ]
 
 
@@ -97,8 +98,9 @@ class Oracle:
 
     # -- parameters --------------------------------------------------------
     def params(self, k=21, s=1000, seed=42, alphabet="ACGT", noncanonical=False,
-               preserve_case=False):
+               preserve_case=False, min_copies=1):
         p = OracleParams()
+        p.min_copies = min_copies
         p.kmer_size = k
         p.sketch_size = s
         p.seed = seed

@@ -14,6 +14,7 @@ Independent numeric cross-check:
 Reference-run vectors (oracle/_ref = the reference's own objects, run here):
   random/adversarial sequences            -> ref_sketch_vectors.npz
   random sketch pairs                     -> ref_compare_vectors.npz
+  read sets with -m 2..5                  -> ref_sketch_vectors_m.npz
 """
 import gzip
 import json
@@ -128,8 +129,60 @@ def main():
     numer, denom, dist, pval = ref.triangle(table, nhash, lengths, 0, 64, 21, kspace, stats=True)
     np.savez_compressed(f"{HERE}/ref_compare_vectors.npz", table=table, nhash=nhash, lengths=lengths,
                         numer=numer, denom=denom, dist=dist, pval=pval, k=21, kmer_space=kspace)
+    make_mincopies_vectors(ref)
     print("golden fixtures written to", HERE)
 
 
+def make_mincopies_vectors(ref):
+    """`mash sketch -r -m <m>`: read sets sketched by the reference's own MinHashHeap with
+    multiplicityMinimum = m (oracle/_ref) -> ref_sketch_vectors_m.npz."""
+    from mash_amd import synth
+    rng = np.random.default_rng(4242)
+    outs, cfgs = {}, []
+    for idx, (k, s, m, glen, cov) in enumerate([
+        (21, 1000, 2, 20000, 6.0),      # full sketch, typical
+        (21, 200, 3, 6000, 8.0),
+        (16, 100, 2, 5000, 5.0),        # 32-bit hashes
+        (11, 64, 4, 3000, 12.0),
+        (21, 5000, 2, 4000, 3.0),       # fewer than s hashes reach m copies
+        (5, 300, 2, 2000, 4.0),         # k-mer space smaller than s
+        (21, 300, 2, 8000, 0.7),        # low coverage: most k-mers are singletons
+        (31, 500, 5, 3000, 20.0),
+    ]):
+        g = synth._rand_dna(rng, glen)
+        recs = []
+        total = 0
+        while total < cov * glen:
+            l = int(rng.integers(40, 151))
+            st = int(rng.integers(0, glen - l))
+            r = bytearray(g[st:st + l])
+            u = rng.random()
+            if u < 0.15:
+                r[int(rng.integers(0, l))] = ord("ACGT"[int(rng.integers(0, 4))])     # substitution
+            elif u < 0.20:
+                r[int(rng.integers(0, l))] = ord("N")
+            elif u < 0.25:
+                r = bytearray(bytes(r).lower())
+            if rng.random() < 0.5:
+                r = bytearray(bytes(r).upper().translate(bytes.maketrans(b"ACGTN", b"TGCAN"))[::-1])
+            recs.append(bytes(r))
+            total += l
+        recs.append(b"ACGTAC")                                  # shorter than k (k >= 11): skipped
+        p = ref.params(k=k, s=s, min_copies=m)
+        h, c, length, setsz, rc = ref.sketch_records(recs, p)
+        cfgs.append(dict(k=k, s=s, min_copies=m, nrec=len(recs), length=length, rc=rc, set_size=setsz, idx=idx))
+        outs[f"bases_{idx}"] = np.frombuffer(b"".join(recs), dtype=np.uint8)
+        outs[f"reclen_{idx}"] = np.array([len(x) for x in recs], dtype=np.uint64)
+        outs[f"hashes_{idx}"] = h
+        outs[f"counts_{idx}"] = c
+    outs["cfgs"] = np.array(json.dumps(cfgs))
+    np.savez_compressed(f"{HERE}/ref_sketch_vectors_m.npz", **outs)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "mincopies":
+        from oracle import pyoracle
+        pyoracle.build(ref=True)
+        make_mincopies_vectors(pyoracle.Oracle(ref=True))
+    else:
+        main()

@@ -75,8 +75,8 @@ def load_golden_reads():
     return z["hashes"], int(z["length"]), str(z["comment"])
 
 
-def load_ref_sketch_vectors():
-    z = np.load(os.path.join(GOLDEN, "ref_sketch_vectors.npz"))
+def load_ref_sketch_vectors(name="ref_sketch_vectors.npz"):
+    z = np.load(os.path.join(GOLDEN, name))
     cfgs = json.loads(str(z["cfgs"]))
     out = []
     for c in cfgs:

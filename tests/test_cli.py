@@ -158,6 +158,17 @@ def test_make_test_recipe_on_gpu(built, tmp_path, oracle):
                                                helpers.read_fastx(str(tmp_path / "reads2.fastq"))])]
     _, oc, _, _, _ = oracle.sketch_records(recs, oracle.params(k=21, s=1000))
     assert counts == [int(x) for x in oc]
+    # -m 2: a hash enters the sketch at its second occurrence (MinHashHeap.cpp:96-118)
+    r2 = run("sketch", "-r", "-m", "2", "-o", "reads_m2", "reads1.fastq", "reads2.fastq", cwd=tmp_path)
+    dump2 = run("info", "-d", "reads_m2.msh", cwd=tmp_path).stdout       # (the reference's dump with counts is not strict JSON)
+    ha, hb = dump2.index('\t\t\t"hashes" :'), dump2.index('\t\t\t"counts" :')
+    hashes2 = [int(x.strip().rstrip(",")) for x in dump2[ha:hb].splitlines()[2:] if x.strip().rstrip(",").isdigit()]
+    counts2 = [int(x.strip().rstrip(",")) for x in dump2[hb:dump2.index("\t\t}\n\t]")].splitlines()[2:-1]]
+    oh, oc2, _, osz, _ = oracle.sketch_records(recs, oracle.params(k=21, s=1000, min_copies=2))
+    assert hashes2 == [int(x) for x in oh] and counts2 == [int(x) for x in oc2]
+    assert '"length" : %d,' % int(osz) in dump2 and min(counts2) >= 2 and "Estimated coverage:" in r2.stderr
+    bad = run("sketch", "-r", "-m", "2", "-b", "1G", "-o", "x", "reads1.fastq", cwd=tmp_path, check=False)
+    assert bad.returncode == 1 and "cannot be used with" in bad.stderr
     hist = run("info", "-c", "reads.msh", cwd=tmp_path).stdout.splitlines()
     assert hist[0] == "#Sketch\tBin\tFrequency" and sum(int(l.split("\t")[2]) for l in hist[1:]) == 1000
     assert "Estimated coverage:" in r.stderr

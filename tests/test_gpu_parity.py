@@ -86,6 +86,53 @@ def test_sketch_reference_run_vectors(eng):
         assert np.array_equal(counts[0, : len(gc)], gc), cfg       # counts produced by the reference objects
 
 
+def test_sketch_min_copies_reference_run_vectors(eng):
+    """`mash sketch -r -m <m>` on the device == the reference's MinHashHeap with
+    multiplicityMinimum = m (tests/golden/ref_sketch_vectors_m.npz): hashes and counts."""
+    for cfg, recs, gh, gc in helpers.load_ref_sketch_vectors("ref_sketch_vectors_m.npz"):
+        p = eng.params(k=cfg["k"], s=cfg["s"], min_copies=cfg["min_copies"])
+        hashes, nhash, counts = eng.sketch_host([recs], p, counts=True)
+        assert nhash[0] == len(gh), cfg
+        assert np.array_equal(hashes[0, : len(gh)], gh), cfg
+        assert np.array_equal(counts[0, : len(gc)], gc), cfg
+        h2, n2 = eng.sketch_host([recs], p)                          # without the multiplicity pass
+        assert n2[0] == len(gh) and np.array_equal(h2[0, : len(gh)], gh)
+
+
+def test_sketch_min_copies_rounds_and_batches(eng, oracle, monkeypatch):
+    """Several sketches in one call, many counting rounds (tiny ranges forced), table overflow
+    retry, 32-bit hashes, and a read set in which no k-mer repeats."""
+    rng = np.random.default_rng(21)
+
+    def reads_of(g, cov, lo=60, hi=200):
+        out, tot = [], 0
+        while tot < cov * len(g):
+            l = int(rng.integers(lo, hi))
+            st = int(rng.integers(0, len(g) - l))
+            r = g[st:st + l]
+            out.append(r if rng.random() < 0.5 else _revcomp(r))
+            tot += l
+        return out
+
+    sets = [reads_of(synth._rand_dna(rng, 30000), 5.0), reads_of(synth._rand_dna(rng, 8000), 2.0),
+            [synth._rand_dna(rng, 50000)],                            # unique k-mers only: empty sketch
+            reads_of(synth._rand_dna(rng, 12000), 9.0), [b"ACGT"]]
+    for k, s, m in [(21, 400, 2), (15, 250, 3)]:
+        for expect in (None, "2048"):
+            if expect:
+                monkeypatch.setenv("MASHGPU_MINCOPIES_EXPECT", expect)
+            else:
+                monkeypatch.delenv("MASHGPU_MINCOPIES_EXPECT", raising=False)
+            p = eng.params(k=k, s=s, min_copies=m)
+            hashes, nhash, counts = eng.sketch_host(sets, p, counts=True)
+            for i, recs in enumerate(sets):
+                oh, oc, _, _, _ = oracle.sketch_records(recs, oracle.params(k=k, s=s, min_copies=m))
+                assert nhash[i] == len(oh), (k, s, m, i, expect)
+                assert np.array_equal(hashes[i, : len(oh)], oh), (k, s, m, i, expect)
+                assert np.array_equal(counts[i, : len(oh)], oc), (k, s, m, i, expect)
+            assert nhash[2] == 0 and nhash[4] == 0
+
+
 def test_sketch_reads_json_golden(eng, golden_dir):
     """mash sketch -r reads1.fastq reads2.fastq == test/ref/reads.json (hashes)."""
     r1 = helpers.read_fastx(os.path.join(golden_dir, "reads1.fastq.gz"))

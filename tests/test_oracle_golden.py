@@ -112,6 +112,23 @@ def test_oracle_equals_reference_sketch_vectors(oracle):
         assert setsz == cfg["set_size"]
 
 
+def test_oracle_min_copies_equals_reference_vectors(oracle):
+    """`-m`: the restated pending-set logic (MinHashHeap.cpp:96-118, :126-144) reproduces what the
+    reference's MinHashHeap produced, and the result has the order-independent form the GPU path
+    relies on: the s smallest hashes seen >= m times, true multiplicities except the largest."""
+    for cfg, recs, gh, gc in helpers.load_ref_sketch_vectors("ref_sketch_vectors_m.npz"):
+        m = cfg["min_copies"]
+        p = oracle.params(k=cfg["k"], s=cfg["s"], min_copies=m)
+        h, c, length, setsz, rc = oracle.sketch_records(recs, p)
+        assert rc == cfg["rc"] and length == cfg["length"] and setsz == cfg["set_size"]
+        assert np.array_equal(h, gh) and np.array_equal(c, gc), cfg
+        fh, fc, _, _, _ = oracle.sketch_records(recs, oracle.params(k=cfg["k"], s=10 ** 6))
+        keep = fc >= m
+        assert np.array_equal(fh[keep][: cfg["s"]], gh), cfg
+        diff = np.nonzero(fc[keep][: cfg["s"]] != gc)[0]
+        assert len(diff) == 0 or (len(diff) == 1 and diff[0] == len(gh) - 1 and len(gh) == cfg["s"]), cfg
+
+
 def test_oracle_equals_reference_compare_vectors(oracle, golden_dir):
     z = np.load(os.path.join(golden_dir, "ref_compare_vectors.npz"))
     numer, denom, dist, pval = oracle.triangle(z["table"], z["nhash"], z["lengths"], 0, 64,
