@@ -194,9 +194,14 @@ double mg_p_value(uint64_t x, uint64_t len_ref, uint64_t len_qry, double kmer_sp
  * every sketch hash in the mixture (0 beyond nhash), the mixture's bottom-s sketch
  * (mix_hashes_out[sketch_size], ascending, padded; its estimateSetSize feeds the p-value,
  * CommandScreen.cpp:322) and the number of distinct hashes in the table.
- * 6-frame translation for protein sketches (CommandScreen.cpp:516-531) is not built. */
+ */
 typedef struct mg_screen mg_screen;
 int  mg_screen_create(mg_ctx *ctx, const mg_params *p, const mg_table *db, mg_screen **out);
+/* Amino-acid query sketches (`trans`, CommandScreen.cpp:120): the mixture stays nucleotide and
+ * every batch is translated in six frames on the device (:516-531, translate/aaFromCodon
+ * :617-809; codons holding anything but ACGT give '*', which ends k-mers) before the same pass.
+ * `p` must carry the sketches' amino-acid alphabet (noncanonical). */
+int  mg_screen_create_translated(mg_ctx *ctx, const mg_params *p, const mg_table *db, mg_screen **out);
 int  mg_screen_add_host(mg_screen *sc, const uint8_t *bases, uint64_t nbases);
 int  mg_screen_add_dev(mg_screen *sc, const uint8_t *bases_dev, uint64_t nbases);
 int  mg_screen_finish_host(mg_screen *sc, uint32_t *counts_out, uint64_t *mix_hashes_out,

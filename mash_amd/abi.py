@@ -28,7 +28,7 @@ EXPORTS = [
     "mg_compare_tri_filter_host", "mg_compare_rect_filter_host",
     "mg_finish_tri_host", "mg_finish_rect_host", "mg_distance", "mg_p_value",
     "mg_prof_enable", "mg_prof_reset", "mg_prof_avg_ms",
-    "mg_screen_create", "mg_screen_add_host", "mg_screen_add_dev", "mg_screen_finish_host", "mg_screen_counts_dev", "mg_screen_free",
+    "mg_screen_create", "mg_screen_create_translated", "mg_screen_add_host", "mg_screen_add_dev", "mg_screen_finish_host", "mg_screen_counts_dev", "mg_screen_free",
     "mg_identity", "mg_p_value_within",
 ]
 
@@ -69,10 +69,11 @@ class ScreenSession:
     """One mg_screen: add batches of the mixture, then read the per-hash observation counts.
     Use as a context manager or call close()."""
 
-    def __init__(self, eng, db, p):
+    def __init__(self, eng, db, p, translate=False):
         self.eng, self.db, self.p = eng, db, p
         self.h = C.c_void_p()
-        eng._check(eng.lib.mg_screen_create(eng.ctx, C.byref(p), db.handle, C.byref(self.h)))
+        create = eng.lib.mg_screen_create_translated if translate else eng.lib.mg_screen_create
+        eng._check(create(eng.ctx, C.byref(p), db.handle, C.byref(self.h)))
 
     def __enter__(self):
         return self
@@ -161,6 +162,7 @@ def load_library():
     lib.mg_prof_avg_ms.argtypes = [vp, C.c_char_p, C.POINTER(u64)]
     lib.mg_prof_avg_ms.restype = dbl
     lib.mg_screen_create.argtypes = [vp, C.POINTER(MgParams), vp, C.POINTER(vp)]
+    lib.mg_screen_create_translated.argtypes = [vp, C.POINTER(MgParams), vp, C.POINTER(vp)]
     lib.mg_screen_add_host.argtypes = [vp, vp, u64]
     lib.mg_screen_add_dev.argtypes = [vp, vp, u64]
     lib.mg_screen_finish_host.argtypes = [vp, vp, vp, C.POINTER(u32), C.POINTER(u64)]
@@ -357,9 +359,10 @@ class MashGpu:
         return out
 
     # ---- screening -------------------------------------------------------------------
-    def screen_open(self, db, p):
-        """incremental screen against table `db` (see ScreenSession)"""
-        return ScreenSession(self, db, p)
+    def screen_open(self, db, p, translate=False):
+        """incremental screen against table `db` (see ScreenSession); translate=True: amino-acid
+        sketches against a nucleotide mixture, translated in six frames on the device"""
+        return ScreenSession(self, db, p, translate)
 
     def screen(self, db, p, batches):
         """Containment counts of every hash of table `db` in a mixture given as batches of

@@ -1021,8 +1021,7 @@ struct mg_screen {
     uint32_t *obs = nullptr;
     uint64_t slots = 0;
     uint64_t key_max = 0;
-    uint8_t *d_alpha = nullptr;
-    int mode = 0;
+    bool translate = false;             // mixture is nucleotide, queries are amino-acid sketches
     std::vector<uint64_t> mix;          // running bottom-s of the mixture (host, ascending, distinct)
 };
 
@@ -1037,7 +1036,6 @@ int mg_screen_create(mg_ctx *ctx, const mg_params *p, const mg_table *db, mg_scr
     sc->ctx = ctx;
     sc->p = *p;
     sc->db = db;
-    sc->mode = dna ? (p->noncanonical ? 1 : 0) : 2;
     {
         const int rc = table_max(ctx, db, &sc->key_max);
         if (rc != MG_OK) { delete sc; return rc; }
@@ -1047,10 +1045,8 @@ int mg_screen_create(mg_ctx *ctx, const mg_params *p, const mg_table *db, mg_scr
     sc->slots = slots;
     hipError_t e = hipMalloc(&sc->keys, slots * 8);
     if (e == hipSuccess) e = hipMalloc(&sc->obs, slots * 4);
-    if (e == hipSuccess) e = hipMalloc(&sc->d_alpha, 256);
     if (e == hipSuccess) e = hipMemsetAsync(sc->keys, 0xFF, slots * 8, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(sc->obs, 0, slots * 4, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(sc->d_alpha, p->alphabet, 256, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = mg::launch_screen_build(db->hashes, db->nhash, db->n, db->s, sc->keys, slots - 1, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
@@ -1061,10 +1057,24 @@ int mg_screen_create(mg_ctx *ctx, const mg_params *p, const mg_table *db, mg_scr
     return MG_OK;
 }
 
+int mg_screen_create_translated(mg_ctx *ctx, const mg_params *p, const mg_table *db, mg_screen **out)
+{
+    if (!ctx) return MG_ERR_INVALID;
+    if (!p || !out) return fail(ctx, MG_ERR_INVALID, "mg_screen_create_translated: NULL argument");
+    if (!p->noncanonical || alphabet_is_dna(p))
+        return fail(ctx, MG_ERR_INVALID, "mg_screen_create_translated: needs an amino-acid (noncanonical) alphabet");
+    const int rc = mg_screen_create(ctx, p, db, out);
+    if (rc == MG_OK) (*out)->translate = true;
+    return rc;
+}
+
+static int screen_add_translated(mg_screen *sc, const uint8_t *bases_dev, uint64_t nbases);
+
 int mg_screen_add_dev(mg_screen *sc, const uint8_t *bases_dev, uint64_t nbases)
 {
     if (!sc) return MG_ERR_INVALID;
     mg_ctx *ctx = sc->ctx;
+    if (sc->translate) return screen_add_translated(sc, bases_dev, nbases);
     const uint64_t k = (uint64_t)sc->p.kmer_size;
     if (nbases < k) return MG_OK;
     if (((uintptr_t)bases_dev & 15) != 0) return fail(ctx, MG_ERR_INVALID, "mg_screen_add: bases must be 16-byte aligned");
@@ -1097,6 +1107,29 @@ int mg_screen_add_dev(mg_screen *sc, const uint8_t *bases_dev, uint64_t nbases)
     if (merged.size() > s) merged.resize(s);
     sc->mix.swap(merged);
     return MG_OK;
+}
+
+// amino-acid queries: translate the nucleotide batch in six frames on the device, then run the
+// ordinary (table-alphabet, forward-only) pass over the translated bytes
+static int screen_add_translated(mg_screen *sc, const uint8_t *bases_dev, uint64_t nbases)
+{
+    mg_ctx *ctx = sc->ctx;
+    if (nbases < 3) return MG_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint64_t seg = (nbases / 3 + 1 + 15) & ~15ull;        // >= one separator byte after every frame
+    uint8_t *d_aa = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d_aa, 6 * seg + 64));
+    hipError_t e = mg::launch_translate6(bases_dev, nbases, d_aa, seg, !sc->p.preserve_case, ctx->stream);
+    int rc = MG_OK;
+    if (e != hipSuccess) rc = fail(ctx, MG_ERR_HIP, std::string("mg_screen_add (translate): ") + hipGetErrorString(e));
+    if (rc == MG_OK) {
+        sc->translate = false;                                   // the translated bytes take the plain path
+        rc = mg_screen_add_dev(sc, d_aa, 6 * seg);
+        sc->translate = true;
+    }
+    hipStreamSynchronize(ctx->stream);
+    hipFree(d_aa);
+    return rc;
 }
 
 int mg_screen_add_host(mg_screen *sc, const uint8_t *bases, uint64_t nbases)
@@ -1189,7 +1222,6 @@ void mg_screen_free(mg_screen *sc)
     hipSetDevice(sc->ctx->device);
     if (sc->keys) hipFree(sc->keys);
     if (sc->obs) hipFree(sc->obs);
-    if (sc->d_alpha) hipFree(sc->d_alpha);
     delete sc;
 }
 

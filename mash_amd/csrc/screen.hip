@@ -59,6 +59,64 @@ __global__ void screen_gather_kernel(const uint64_t *hashes, const uint32_t *nha
     }
 }
 
+// 6-frame translation of a nucleotide batch (CommandScreen.cpp:516-531 + translate/aaFromCodon,
+// :617-809) for amino-acid query sketches.  The reference translates each `*`-joined chunk of
+// reads as one string in frames 0..2 of the chunk and of its reverse complement; a codon that
+// holds anything but upper-case ACGT (after the optional case fold) becomes '*', which no k-mer
+// may contain -- so codons never bridge records and the set of k-mers does not depend on how
+// reads were chunked.  Output: six segments of `seg` bytes, amino acids then MG_RECORD_SEP
+// padding (not in the protein alphabet), ready for the table-alphabet sketch/probe pass.
+__constant__ char kCodonTable[65] = "KNKNTTTTRSRSIIMIQHQHPPPPRRRRLLLLEDEDAAAAGGGGVVVV*Y*YSSSS*CWCLFLF";
+
+__device__ __forceinline__ int nt_digit(uint32_t c, bool fold)
+{
+    if (fold) c &= 0xDFu;                                  // only a/c/g/t fold onto A/C/G/T
+    switch (c) {
+        case 'A': return 0;
+        case 'C': return 1;
+        case 'G': return 2;
+        case 'T': return 3;
+        default: return -1;
+    }
+}
+
+__global__ void translate6_kernel(const uint8_t *in, uint64_t n, uint8_t *out, uint64_t seg, uint32_t fold)
+{
+    const uint64_t total = 6 * seg;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const uint32_t fr = (uint32_t)(idx / seg);
+        const uint64_t j = idx - (uint64_t)fr * seg;
+        const uint32_t f = fr % 3;
+        const bool rev = fr >= 3;
+        const uint64_t len = n >= f ? (n - f) / 3 : 0;        // lenTrans = (l - frame) / 3
+        uint8_t aa = 0x0A;
+        if (j < len) {
+            int d0, d1, d2;
+            if (!rev) {
+                const uint64_t p = f + 3 * j;
+                d0 = nt_digit(in[p], fold != 0); d1 = nt_digit(in[p + 1], fold != 0); d2 = nt_digit(in[p + 2], fold != 0);
+            } else {                                           // reverse complement read backwards
+                const uint64_t p = n - 1 - f - 3 * j;
+                d0 = nt_digit(in[p], fold != 0); d1 = nt_digit(in[p - 1], fold != 0); d2 = nt_digit(in[p - 2], fold != 0);
+                if (d0 >= 0) d0 = 3 - d0;
+                if (d1 >= 0) d1 = 3 - d1;
+                if (d2 >= 0) d2 = 3 - d2;
+            }
+            aa = (d0 | d1 | d2) < 0 ? (uint8_t)'*' : (uint8_t)kCodonTable[d0 * 16 + d1 * 4 + d2];
+        }
+        out[idx] = aa;
+    }
+}
+
+hipError_t launch_translate6(const uint8_t *in, uint64_t n, uint8_t *out, uint64_t seg, bool fold, hipStream_t stream)
+{
+    uint64_t blocks = (6 * seg + 255) / 256;
+    if (blocks > 65535) blocks = 65535;
+    hipLaunchKernelGGL(translate6_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, in, n, out, seg, fold ? 1u : 0u);
+    return hipGetLastError();
+}
+
 hipError_t launch_screen_build(const uint64_t *hashes, const uint32_t *nhash, uint64_t n, uint64_t s,
                                unsigned long long *keys, uint64_t mask, hipStream_t stream)
 {

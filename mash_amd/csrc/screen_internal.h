@@ -28,6 +28,8 @@ __device__ __forceinline__ bool scr_find(const unsigned long long *keys, uint64_
     }
 }
 
+// six translated segments of `seg` bytes each (seg > n/3), see translate6_kernel
+hipError_t launch_translate6(const uint8_t *in, uint64_t n, uint8_t *out, uint64_t seg, bool fold, hipStream_t stream);
 hipError_t launch_screen_build(const uint64_t *hashes, const uint32_t *nhash, uint64_t n, uint64_t s,
                                unsigned long long *keys, uint64_t mask, hipStream_t stream);
 hipError_t launch_screen_gather(const uint64_t *hashes, const uint32_t *nhash, uint64_t n, uint64_t s,

@@ -1042,10 +1042,7 @@ int cmd_screen(int argc, const char **argv)
     const double p_max = c.o("pvalue").num, identity_min = c.o("identity").num;
     SketchSet set;
     load_msh_into(set, c.args[0], true);
-    if (set.p.alphabet == normalise_alphabet(kAlphabetProtein, false)) {
-        cerr << "ERROR: 6-frame translation for amino-acid sketches is not supported by the GPU screen path." << endl;
-        return 1;
-    }
+    const bool trans = set.p.alphabet == normalise_alphabet(kAlphabetProtein, false);   // CommandScreen.cpp:120
     Gpu gpu;
     cerr << "Loading " << c.args[0] << "..." << endl;
     const uint64_t n = set.refs.size(), s = set.p.sketch_size;
@@ -1053,7 +1050,10 @@ int cmd_screen(int argc, const char **argv)
     mg_params mp;
     mg_params_init(&mp, set.p.kmer, s, set.p.seed, set.p.alphabet.c_str(), set.p.noncanonical, set.p.preserve_case);
     mg_screen *sc = nullptr;
-    if (mg_screen_create(gpu.ctx, &mp, t, &sc) != MG_OK) { cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl; return 1; }
+    if ((trans ? mg_screen_create_translated(gpu.ctx, &mp, t, &sc) : mg_screen_create(gpu.ctx, &mp, t, &sc)) != MG_OK) {
+        cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl;
+        return 1;
+    }
     const int nq = (int)c.args.size() - 1;
     vector<fastx::Reader *> readers;
     for (int f = 1; f <= nq; f++) {
@@ -1103,7 +1103,7 @@ int cmd_screen(int argc, const char **argv)
     mg_screen_free(sc);
     mg_table_free(t);
     cerr << "   " << distinct << " distinct hashes." << endl;
-    cerr << "Streaming from ";
+    cerr << (trans ? "Translating from " : "Streaming from ");
     if (nq == 1) cerr << c.args[1]; else cerr << nq << " inputs";
     cerr << "..." << endl;
     if (count == 0) { cerr << "\nERROR: Did not find sequence records in inputs" << endl; exit(1); }
@@ -1111,7 +1111,7 @@ int cmd_screen(int argc, const char **argv)
     double est = 0;
     if (mix_n) est = std::pow(2.0, set.p.use64 ? 64.0 : 32.0) * (double)mix_n / (double)mix[mix_n - 1];
     const uint64_t set_size = (uint64_t)est;
-    cerr << "   Estimated distinct k-mers in mixture: " << set_size << endl;
+    cerr << "   Estimated distinct" << (trans ? " (translated)" : "") << " k-mers in mixture: " << set_size << endl;
     if (set_size == 0) cerr << "WARNING: no valid k-mers in input." << endl;
     cerr << "Summing shared..." << endl;
     vector<uint64_t> shared(n, 0);

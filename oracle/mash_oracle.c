@@ -320,6 +320,31 @@ int oracle_sketch_records(const char *bases, const uint64_t *rec_off, uint64_t n
 }
 
 /* ------------------------------------------------------------------------- */
+/* translate / aaFromCodon — CommandScreen.cpp:617-809.  The nested switch of the reference
+ * is the standard genetic code; here as a 64-entry table indexed by the codon read as three
+ * base-4 digits with A=0, C=1, G=2, T=3 (pinned by tests/golden/codon_table.json, produced by
+ * the reference's own function).                                                             */
+void oracle_translate(const char *src, char *dst, uint64_t len)
+{
+    static const char code[65] = "KNKNTTTTRSRSIIMIQHQHPPPPRRRRLLLLEDEDAAAAGGGGVVVV*Y*YSSSS*CWCLFLF";
+    for (uint64_t a = 0; a < len; a++) {
+        int idx = 0, ok = 1;
+        for (int j = 0; j < 3; j++) {
+            int d;
+            switch (src[3 * a + j]) {
+                case 'A': d = 0; break;
+                case 'C': d = 1; break;
+                case 'G': d = 2; break;
+                case 'T': d = 3; break;
+                default: d = 0; ok = 0; break;
+            }
+            idx = idx * 4 + d;
+        }
+        dst[a] = ok ? code[idx] : '*';            /* :640 default */
+    }
+}
+
+/* ------------------------------------------------------------------------- */
 /* Binomial upper tail.  Reference: gsl_cdf_binomial_Q(x-1, r, n) or Boost
  * cdf(complement(binomial(n,r), x-1)) — CommandDistance.cpp:443-447; both are
  * P[X > k] = I_p(k+1, n-k) (regularized incomplete beta).                    */

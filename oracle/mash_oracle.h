@@ -86,6 +86,10 @@ int oracle_sketch_records(const char *bases, const uint64_t *rec_off, uint64_t n
                           uint64_t *hashes_out, uint32_t *counts_out, uint64_t *n_out,
                           uint64_t *length_out, double *set_size_out);
 
+/* translate / aaFromCodon, CommandScreen.cpp:617-809: dst[a] = amino acid of the codon
+ * src[3a..3a+2] (standard code, upper-case ACGT only); any other byte in the codon gives '*'. */
+void oracle_translate(const char *src, char *dst, uint64_t len);
+
 typedef struct {
     uint64_t numer;     /* PairOutput::numer    CommandDistance.h:63-70 */
     uint64_t denom;

@@ -91,6 +91,9 @@ class Oracle:
         self._sketch = sk
         self._compare = getattr(L, self.prefix + "compare_sketches")
         self._compare.restype = None
+        self._translate = getattr(L, self.prefix + "translate")
+        self._translate.restype = None
+        self._translate.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64]
         if ref:
             L.ref_table_new.restype = C.c_void_p
             L.ref_table_free.argtypes = [C.c_void_p]
@@ -112,6 +115,23 @@ class Oracle:
     # -- hashing -----------------------------------------------------------
     def get_hash(self, kmer: bytes, seed=42, use64=True):
         return int(self._get_hash(kmer, len(kmer), seed, int(use64)))
+
+    # -- translation (mash screen, amino-acid queries) ---------------------------
+    def translate(self, seq: bytes) -> bytes:
+        """translate(), CommandScreen.cpp:617-623: one amino acid per full codon of `seq`"""
+        n = len(seq) // 3
+        out = C.create_string_buffer(max(n, 1))
+        self._translate(seq, out, n)
+        return out.raw[:n]
+
+    def six_frames(self, seq: bytes, preserve_case=False):
+        """the six translated strings hashSequence walks for one chunk (CommandScreen.cpp:498-531):
+        frames 0..2 of the (upper-cased) chunk, then frames 0..2 of its reverse complement"""
+        if not preserve_case:
+            seq = bytes(b - 32 if 96 < b < 123 else b for b in seq)
+        comp = {65: 84, 67: 71, 71: 67, 84: 65}
+        rc = bytes(comp.get(b, 78) for b in reversed(seq))      # non-ACGT never survives translation
+        return [self.translate(src[f:]) for src in (seq, rc) for f in range(3)]
 
     # -- sketching ---------------------------------------------------------
     def sketch_records(self, records, p):

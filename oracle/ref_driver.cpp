@@ -46,6 +46,11 @@ namespace mash {
 #include "gen/compare_hotpath.inc"
 }
 
+namespace mashscreen {                       /* CommandScreen.cpp:617-809 */
+char aaFromCodon(const char *codon);
+#include "gen/translate.inc"
+}
+
 static void fill_params(Sketch::Parameters &P, const oracle_params *p)
 {
     P.kmerSize = p->kmer_size;
@@ -173,5 +178,8 @@ uint64_t ref_triangle(void *tv, uint64_t row_begin, uint64_t row_end, int kmer_s
         }
     return idx;
 }
+
+/* translate, CommandScreen.cpp:617-623: dst[a] = aaFromCodon(src + 3a), a < len */
+void ref_translate(const char *src, char *dst, uint64_t len) { mashscreen::translate(src, dst, len); }
 
 } /* extern "C" */

@@ -15,6 +15,7 @@ Reference-run vectors (oracle/_ref = the reference's own objects, run here):
   random/adversarial sequences            -> ref_sketch_vectors.npz
   random sketch pairs                     -> ref_compare_vectors.npz
   read sets with -m 2..5                  -> ref_sketch_vectors_m.npz
+  aaFromCodon over all codons             -> codon_table.json
 """
 import gzip
 import json
@@ -130,7 +131,22 @@ def main():
     np.savez_compressed(f"{HERE}/ref_compare_vectors.npz", table=table, nhash=nhash, lengths=lengths,
                         numer=numer, denom=denom, dist=dist, pval=pval, k=21, kmer_space=kspace)
     make_mincopies_vectors(ref)
+    make_codon_table(ref)
     print("golden fixtures written to", HERE)
+
+
+def make_codon_table(ref):
+    """aaFromCodon (CommandScreen.cpp:625-809) run on every ACGT codon and on codons holding
+    other bytes -> codon_table.json"""
+    tab = {}
+    for a in "ACGT":
+        for b in "ACGT":
+            for c in "ACGT":
+                tab[a + b + c] = ref.translate((a + b + c).encode()).decode()
+    for cod in ("ANA", "NNN", "acg", "A*C", "RYK", "AC\n", "\nGT", "TG-"):
+        tab[cod] = ref.translate(cod.encode()).decode()
+    with open(f"{HERE}/codon_table.json", "w") as f:
+        json.dump(tab, f, indent=0, sort_keys=True)
 
 
 def make_mincopies_vectors(ref):
@@ -180,9 +196,9 @@ def make_mincopies_vectors(ref):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "mincopies":
+    if len(sys.argv) > 1 and sys.argv[1] in ("mincopies", "codons"):
         from oracle import pyoracle
         pyoracle.build(ref=True)
-        make_mincopies_vectors(pyoracle.Oracle(ref=True))
+        {"mincopies": make_mincopies_vectors, "codons": make_codon_table}[sys.argv[1]](pyoracle.Oracle(ref=True))
     else:
         main()

@@ -201,6 +201,53 @@ def test_make_test_screen_recipe_on_gpu(built, tmp_path):
 
 
 @pytest.mark.gpu
+def test_screen_protein_queries_translate_the_mixture(built, tmp_path, oracle):
+    """`mash screen` with amino-acid sketches (`mash sketch -a`): the nucleotide mixture is
+    6-frame translated (CommandScreen.cpp:120, 516-531); shared counts vs the oracle."""
+    rng = np.random.default_rng(17)
+    k, s = 9, 200
+    genomes = [synth._rand_dna(rng, 6000) for _ in range(2)]
+    with open(tmp_path / "prot.faa", "wb") as f:
+        for i, g in enumerate(genomes):
+            for j, fr in enumerate(oracle.six_frames(g)):
+                f.write(b">g%d_f%d\n%s\n" % (i, j, fr.replace(b"*", b"X")))    # X is outside the alphabet too
+    # one sketch per genome: six records each
+    for i in range(2):
+        with open(tmp_path / ("p%d.faa" % i), "wb") as f:
+            for j, fr in enumerate(oracle.six_frames(genomes[i])):
+                f.write(b">g%d_f%d\n%s\n" % (i, j, fr.replace(b"*", b"X")))
+    run("sketch", "-a", "-k", str(k), "-s", str(s), "-o", "prot", "p0.faa", "p1.faa", cwd=tmp_path)
+    reads = []
+    with open(tmp_path / "mix.fa", "wb") as f:
+        for n in range(600):
+            l = int(rng.integers(60, 150))
+            st = int(rng.integers(0, 6000 - l))
+            r = genomes[0][st:st + l]                                  # only genome 0 is in the mixture
+            reads.append(r)
+            f.write(b">r%d\n%s\n" % (n, r))
+    only_hits = run("screen", "prot.msh", "mix.fa", cwd=tmp_path).stdout.splitlines()
+    out = run("screen", "-i", "-1", "prot.msh", "mix.fa", cwd=tmp_path)      # -1: also queries sharing nothing
+    assert "Translating from mix.fa..." in out.stderr and "(translated)" in out.stderr
+    prot = "ACDEFGHIKLMNPQRSTVWY"
+    want = set()
+    for r in reads:
+        for fr in oracle.six_frames(r):
+            if len(fr) >= k:
+                want.update(int(x) for x in oracle.sketch_records([fr], oracle.params(k=k, s=10 ** 6, alphabet=prot, noncanonical=True))[0])
+    lines = [l.split("\t") for l in out.stdout.splitlines()]
+    assert [l[4] for l in lines] == ["p0.faa", "p1.faa"]
+    for i, l in enumerate(lines):
+        recs = [fr.replace(b"*", b"X") for fr in oracle.six_frames(genomes[i])]
+        sk = oracle.sketch_records(recs, oracle.params(k=k, s=s, alphabet=prot, noncanonical=True))[0]
+        shared = sum(1 for x in sk if int(x) in want)
+        assert l[1] == "%d/%d" % (shared, s), (i, l)
+        ident = 1.0 if shared == s else (0.0 if shared == 0 else (shared / s) ** (1.0 / k))
+        assert l[0] == helpers.fmt_g(ident)
+    assert int(lines[0][1].split("/")[0]) > 100 > int(lines[1][1].split("/")[0])
+    assert [l.split("\t")[4] for l in only_hits] == [l[4] for l in lines if not l[1].startswith("0/")]
+
+
+@pytest.mark.gpu
 def test_sketch_and_triangle_cli_vs_oracle(built, tmp_path, oracle):
     rng = np.random.default_rng(3)
     genomes = [synth._rand_dna(rng, 40000) for _ in range(5)]

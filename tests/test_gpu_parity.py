@@ -438,6 +438,55 @@ def test_screen_counts_vs_oracle(eng, oracle):
     db.free()
 
 
+def test_screen_translated_vs_oracle(eng, oracle):
+    """Amino-acid query sketches against a nucleotide mixture: the device translates every batch
+    in six frames (CommandScreen.cpp:516-531, 617-809); expected counts come from the oracle's
+    restated translate() + direct hashing of every amino-acid k-mer of every frame of every read."""
+    rng = np.random.default_rng(31)
+    prot = "ACDEFGHIKLMNPQRSTVWY"
+    k, s = 7, 300
+    genomes = [synth._rand_dna(rng, 9000) for _ in range(3)]
+    p = eng.params(k=k, s=s, alphabet=prot, noncanonical=True)
+    op_all = oracle.params(k=k, s=10 ** 6, alphabet=prot, noncanonical=True)
+    # queries: protein sketches of the six-frame translations of each genome
+    hashes, nhash = eng.sketch_host([oracle.six_frames(g) for g in genomes], p)
+    for i, g in enumerate(genomes):
+        oh = oracle.sketch_records(oracle.six_frames(g), oracle.params(k=k, s=s, alphabet=prot, noncanonical=True))[0]
+        assert nhash[i] == len(oh) and np.array_equal(hashes[i, : len(oh)], oh)
+    db = eng.table_upload(hashes, nhash, np.full(3, 9000, np.uint64))
+    reads = []
+    for _ in range(1500):
+        g = genomes[int(rng.integers(0, 2))]                         # genome 2 is never sampled
+        l = int(rng.integers(30, 160))
+        st = int(rng.integers(0, 9000 - l))
+        r = bytearray(g[st:st + l])
+        u = rng.random()
+        if u < 0.2:
+            r[int(rng.integers(0, l))] = ord("N")
+        elif u < 0.35:
+            r = bytearray(bytes(r).lower())
+        reads.append(bytes(r) if rng.random() < 0.5 else _revcomp(bytes(r).upper()))
+    reads += [b"AC", b"ACGTACGTAC", b""]
+    with eng.screen_open(db, p, translate=True) as sc:
+        sc.add_records(reads[:700])
+        sc.add_records(reads[700:])
+        counts, mix, _ = sc.finish()
+    want = {}
+    for r in reads:
+        for fr in oracle.six_frames(r):
+            if len(fr) < k:
+                continue
+            h, c, _, _, _ = oracle.sketch_records([fr], op_all)
+            for hv, cv in zip(h, c):
+                want[int(hv)] = want.get(int(hv), 0) + int(cv)
+    for i in range(3):
+        exp = np.array([want.get(int(x), 0) for x in hashes[i, : nhash[i]]], dtype=np.uint32)
+        assert np.array_equal(counts[i, : nhash[i]], exp), i
+    assert counts[0].sum() > 0 and counts[2].sum() < counts[0].sum()
+    assert np.array_equal(mix, np.array(sorted(want), dtype=np.uint64)[:s])
+    db.free()
+
+
 def test_screen_sharded_orchestrator_single_rank(eng, oracle):
     """mash_amd.screen_dist over libmashgpu (world 1): device-resident counts, host and
     device batches, same numbers as mg_screen_finish_host."""

@@ -129,6 +129,19 @@ def test_oracle_min_copies_equals_reference_vectors(oracle):
         assert len(diff) == 0 or (len(diff) == 1 and diff[0] == len(gh) - 1 and len(gh) == cfg["s"]), cfg
 
 
+def test_oracle_translate_equals_reference_codon_table(oracle, golden_dir):
+    """6-frame translation of `mash screen` (CommandScreen.cpp:617-809): the restated table vs
+    the output of the reference's own aaFromCodon for all 64 codons + invalid ones."""
+    import json
+    tab = json.load(open(os.path.join(golden_dir, "codon_table.json")))
+    assert len(tab) == 64 + 8
+    for cod, aa in tab.items():
+        assert oracle.translate(cod.encode()).decode() == aa, cod
+    assert "".join(tab[a + b + c] for a in "ACGT" for b in "ACGT" for c in "ACGT").count("*") == 3
+    fr = oracle.six_frames(b"atgGCCTAAnACGT")
+    assert fr[0] == b"MA**" and len(fr) == 6 and [len(x) for x in fr] == [4, 4, 4, 4, 4, 4]
+
+
 def test_oracle_equals_reference_compare_vectors(oracle, golden_dir):
     z = np.load(os.path.join(golden_dir, "ref_compare_vectors.npz"))
     numer, denom, dist, pval = oracle.triangle(z["table"], z["nhash"], z["lengths"], 0, 64,
