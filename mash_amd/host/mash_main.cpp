@@ -16,7 +16,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <fstream>
+#include <future>
 #include <iostream>
 #include <map>
 #include <string>
@@ -162,6 +164,7 @@ struct Params {                               // Sketch::Parameters (Sketch.h:34
     float warning = 0;
     uint64_t genome_size = 0;
     uint32_t min_copies = 1;                  // minCov (-m)
+    int threads = 1;                          // -p: files parsed concurrently (the GPU does the sketching)
     string alphabet;                          // normalised (uppercased unless preserve_case), sorted
     uint32_t alphabet_size = 0;
     bool use64 = false;
@@ -196,6 +199,7 @@ int sketch_parameter_setup(Params &p, const Cmd &c)
     p.seed = (uint32_t)c.o("seed").num;
     p.reads = c.o("reads").active;
     p.preserve_case = c.o("case").active;
+    p.threads = std::max(1, (int)c.o("threads").num);
     if (c.has("warning")) p.warning = c.o("warning").num;
     if (c.o("memory").active || c.o("minCov").active || c.o("targetCov").active) {
         if (c.o("memory").active && c.o("minCov").active) {          // sketchParameterSetup.cpp:44-48
@@ -322,35 +326,52 @@ void flush_batch(Gpu &gpu, SketchSet &set, PendingBatch &b)
 
 const uint64_t kBatchBytes = 2ull << 30;
 
-// sketchFile in concatenated mode for ONE file (Sketch.cpp:1147-1336), non-reads
-void queue_file_concatenated(Gpu &gpu, SketchSet &set, PendingBatch &b, const string &file)
-{
-    fastx::Reader rd;
-    if (!rd.open(file)) { cerr << "ERROR: could not open " << file << endl; exit(1); }
+// sketchFile in concatenated mode for ONE file (Sketch.cpp:1147-1336), non-reads: the host half
+// (kseq parse, name/comment/length) -- runs on a worker thread with -p > 1, like the reference's
+// ThreadPool workers, while the k-mer work of earlier files is on the GPU.
+struct ParsedFile {
     Ref ref;
+    vector<uint8_t> bases;                    // records >= k, each followed by MG_RECORD_SEP
+    string error;                             // fatal message (printed by the consumer, in input order)
+    bool warn_only = false;
+};
+
+ParsedFile parse_file_concatenated(const string &file, int kmer)
+{
+    ParsedFile out;
+    fastx::Reader rd;
+    if (!rd.open(file)) { out.error = "ERROR: could not open " + file; return out; }
+    Ref &ref = out.ref;
     if (file != "-") ref.name = file;
     fastx::Record rec;
     long l;
     int count = 0;
     bool skipped = false;
     while ((l = rd.next(rec)) >= 0) {
-        if (l < set.p.kmer) { skipped = true; continue; }
+        if (l < kmer) { skipped = true; continue; }
         if (count == 0) {
             if (file == "-") { ref.name = rec.name; ref.comment = rec.comment; }
             else ref.comment = rec.name + " " + rec.comment;
         }
         count++;
         ref.length += (uint64_t)l;
-        b.add_record(rec.seq);
+        out.bases.insert(out.bases.end(), rec.seq.begin(), rec.seq.end());
+        out.bases.push_back((uint8_t)MG_RECORD_SEP);
     }
     if (count > 1) ref.comment = "[" + std::to_string(count) + " seqs] " + ref.comment + " [...]";
-    if (l != -1) { cerr << "\nERROR: reading input files." << endl; exit(1); }
+    if (l != -1) { out.error = "\nERROR: reading input files."; return out; }
     if (ref.length == 0) {
-        if (skipped) cerr << "\nWARNING: All fasta records in input files were shorter than the k-mer size (" << set.p.kmer << ")." << endl;
-        else cerr << "\nERROR: Did not find fasta records in \"input files\"." << endl;
-        exit(1);
+        if (skipped) out.error = "\nWARNING: All fasta records in input files were shorter than the k-mer size (" + std::to_string(kmer) + ").";
+        else out.error = "\nERROR: Did not find fasta records in \"input files\".";
     }
-    b.end_sketch(std::move(ref));
+    return out;
+}
+
+void queue_parsed_file(Gpu &gpu, SketchSet &set, PendingBatch &b, ParsedFile &&pf)
+{
+    if (!pf.error.empty()) { cerr << pf.error << endl; exit(1); }
+    b.bases.insert(b.bases.end(), pf.bases.begin(), pf.bases.end());
+    b.end_sketch(std::move(pf.ref));
     if (b.bases.size() > kBatchBytes) flush_batch(gpu, set, b);
 }
 
@@ -482,6 +503,21 @@ void init_from_files(Gpu &gpu, SketchSet &set, const vector<string> &files, cons
 {
     set.p = p;
     PendingBatch b;
+    // concatenated mode: up to 2 x threads files are parsed ahead on worker threads; results are
+    // consumed strictly in input order (the reference's pool also delivers in submission order)
+    std::deque<std::pair<size_t, std::future<ParsedFile>>> ahead;
+    size_t next_submit = 0;
+    const size_t lookahead = (size_t)std::max(1, p.threads) * 2;
+    auto parseable = [&](size_t i) { return set.p.concatenated && !has_suffix(files[i], kSuffix) && files[i] != "-"; };
+    auto submit_more = [&](size_t upto) {
+        if (p.threads <= 1) return;
+        for (; next_submit < files.size() && next_submit < upto + lookahead && ahead.size() < lookahead; next_submit++) {
+            if (!parseable(next_submit)) continue;
+            const string f = files[next_submit];
+            const int k = set.p.kmer;
+            ahead.emplace_back(next_submit, std::async(std::launch::async, [f, k]() { return parse_file_concatenated(f, k); }));
+        }
+    };
     for (size_t i = 0; i < files.size(); i++) {
         if (has_suffix(files[i], kSuffix)) {
             flush_batch(gpu, set, b);                      // keep input order
@@ -496,8 +532,19 @@ void init_from_files(Gpu &gpu, SketchSet &set, const vector<string> &files, cons
                 if (!t) { cerr << "ERROR: could not open " << files[i] << " for reading." << endl; exit(1); }
                 fclose(t);
             }
-            if (set.p.concatenated) queue_file_concatenated(gpu, set, b, files[i]);
-            else queue_file_by_sequence(gpu, set, b, files[i]);
+            if (set.p.concatenated) {
+                if (next_submit <= i) next_submit = i;     // .msh inputs may have changed k: submit late
+                submit_more(i);
+                if (!ahead.empty() && ahead.front().first == i) {
+                    ParsedFile pf = ahead.front().second.get();
+                    ahead.pop_front();
+                    queue_parsed_file(gpu, set, b, std::move(pf));
+                } else {
+                    queue_parsed_file(gpu, set, b, parse_file_concatenated(files[i], set.p.kmer));
+                }
+            } else {
+                queue_file_by_sequence(gpu, set, b, files[i]);
+            }
         }
     }
     flush_batch(gpu, set, b);

@@ -308,3 +308,25 @@ def test_sketch_and_triangle_cli_vs_oracle(built, tmp_path, oracle):
             assert a == b, cmd
     e0 = run("triangle", "-d", "0", "ind.msh", cwd=tmp_path).stdout.splitlines()
     assert len(e0) == 1 and e0[0].split("\t")[:3] == ["seq4", "seq0", "0"]
+
+
+@pytest.mark.gpu
+def test_parallel_ingest_keeps_input_order(built, tmp_path):
+    """-p N parses files on worker threads; sketches come out in input order, byte-identical
+    to the single-threaded run (ThreadPool delivers in submission order, ThreadPool.hxx:127-167)."""
+    rng = np.random.default_rng(23)
+    names = []
+    for i in range(9):
+        n = "g%d.fa" % i
+        names.append(n)
+        with open(tmp_path / n, "wb") as f:
+            for r in range(int(rng.integers(1, 4))):
+                f.write(b">c%d_%d some comment\n%s\n" % (i, r, synth._rand_dna(rng, int(rng.integers(2000, 30000)))))
+    run("sketch", "-s", "200", "-o", "seq", *names, cwd=tmp_path)
+    run("sketch", "-p", "4", "-s", "200", "-o", "par", *names, cwd=tmp_path)
+    assert open(tmp_path / "seq.msh", "rb").read() == open(tmp_path / "par.msh", "rb").read()
+    tab = run("info", "-t", "par.msh", cwd=tmp_path).stdout.splitlines()[1:]
+    assert [l.split("\t")[2] for l in tab] == names
+    missing = run("sketch", "-p", "4", "-o", "x", names[0], "nope.fa", names[1], cwd=tmp_path, check=False)
+    assert missing.returncode == 1 and "could not open nope.fa" in missing.stderr
+
