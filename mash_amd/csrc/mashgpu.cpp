@@ -215,7 +215,8 @@ static int sketch_min_copies(mg_ctx *ctx, const mg_params *p, int mode, const ui
         while (w1 < work.size() && work[w1].sketch == sk) { npos += work[w1].end - work[w1].begin; w1++; }
         std::vector<uint64_t> kept;                          // ascending across rounds
         uint64_t lo = 0;
-        uint64_t expect = std::max<uint64_t>(64 * s, 1ull << 16);
+        // m copies: most distinct hashes of a read set are singletons, plan for 64 s; m = 1: 2 s suffice
+        uint64_t expect = std::max<uint64_t>((p->min_copies > 1 ? 64 : 2) * s, 1ull << 16);
         if (const char *e = getenv("MASHGPU_MINCOPIES_EXPECT")) expect = std::max<uint64_t>(1024, strtoull(e, nullptr, 10));  // test knob
         bool exhausted = false;
         while (kept.size() < s && !exhausted && rc == MG_OK) {
@@ -265,7 +266,7 @@ static int sketch_min_copies(mg_ctx *ctx, const mg_params *p, int mode, const ui
             if (e == hipSuccess) e = hipMemsetAsync(d_ovf, 0, 4, ctx->stream);
             if (e == hipSuccess) e = hipMemsetAsync(d_outn, 0, 8, ctx->stream);
             if (e == hipSuccess) e = mg::launch_range_count(p->kmer_size, mode, ra, (uint32_t)(w1 - w0), ctx->stream);
-            if (e == hipSuccess) e = mg::launch_range_extract(d_keys, d_cnts, slots, p->min_copies, d_out, d_outn, out_cap, ctx->stream);
+            if (e == hipSuccess) e = mg::launch_range_extract(d_keys, d_cnts, slots, p->min_copies > 1 ? p->min_copies : 1, d_out, d_outn, out_cap, ctx->stream);
             if (e == hipSuccess) e = hipMemcpyAsync(&n_out, d_outn, 8, hipMemcpyDeviceToHost, ctx->stream);
             if (e == hipSuccess) e = hipMemcpyAsync(&ovf, d_ovf, 4, hipMemcpyDeviceToHost, ctx->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -317,8 +318,14 @@ static int sketch_dev_impl(mg_ctx *ctx, const mg_params *p, const uint8_t *bases
         return fail(ctx, MG_ERR_UNSUPPORTED, "mg_sketch: canonical k-mers need the ACGT alphabet");
     int nt = 0;
     uint32_t cap = 0;
-    if (!mg::sketch_geometry(p->sketch_size, &nt, &cap))
-        return fail(ctx, MG_ERR_UNSUPPORTED, "mg_sketch: sketch size too large for the LDS selector (max 12288)");
+    // sketch sizes beyond the LDS selector (s > 12288) take the exact range-counting path that
+    // also serves min_copies > 1: bottom-s distinct hashes via an open-addressing table in HBM
+    const bool lds_selector = mg::sketch_geometry(p->sketch_size, &nt, &cap);
+    if (!lds_selector) {
+        if (probe) return fail(ctx, MG_ERR_UNSUPPORTED, "mg_screen: sketch size too large (max 12288)");
+        nt = 256;                                          // chunk geometry only
+        cap = 0;
+    }
     const int mode = dna ? (p->noncanonical ? 1 : 0) : 2;
     const uint64_t s = p->sketch_size;
     const uint64_t k = (uint64_t)p->kmer_size;
@@ -424,7 +431,9 @@ static int sketch_dev_impl(mg_ctx *ctx, const mg_params *p, const uint8_t *bases
     TRY_C(hipMemcpyAsync(d_work, work.data(), work.size() * sizeof(mg::SketchWork), hipMemcpyHostToDevice, ctx->stream));
     TRY_C(hipMalloc(&d_alpha, 256));
     TRY_C(hipMemcpyAsync(d_alpha, p->alphabet, 256, hipMemcpyHostToDevice, ctx->stream));
-    if (nslots) {
+    const uint32_t min_copies = p->min_copies > 1 ? p->min_copies : 1;
+    const bool range_path = min_copies > 1 || !lds_selector;
+    if (nslots && !range_path) {
         TRY_C(hipMalloc(&d_pool, nslots * s * 8));
         TRY_C(hipMalloc(&d_pool_n, nslots * 4));
         TRY_C(hipMemsetAsync(d_pool_n, 0, nslots * 4, ctx->stream));
@@ -452,8 +461,7 @@ static int sketch_dev_impl(mg_ctx *ctx, const mg_params *p, const uint8_t *bases
     a.probe_obs = probe ? probe->obs : nullptr;
     a.probe_mask = probe ? probe->mask : 0;
     a.probe_max = probe ? probe->key_max : 0;
-    const uint32_t min_copies = p->min_copies > 1 ? p->min_copies : 1;
-    if (min_copies > 1) {
+    if (range_path) {
         // -m: bottom-s of the hashes seen at least m times, by exact range counting (sketch.hip)
         if (probe) { cleanup(); return fail(ctx, MG_ERR_UNSUPPORTED, "mg_screen: min_copies does not apply"); }
         rc = sketch_min_copies(ctx, p, mode, bases_dev, work, d_work, d_alpha, nsketch, hashes_out_dev, nhash_out_dev);
@@ -463,7 +471,7 @@ static int sketch_dev_impl(mg_ctx *ctx, const mg_params *p, const uint8_t *bases
     TRY_C(mg::launch_sketch_chunks(p->kmer_size, mode, nt, a, (uint32_t)work.size(), ctx->stream));
     prof_end(ctx, ctx->prof_sketch);
     }
-    if (min_copies == 1 && !merges.empty()) {
+    if (!range_path && !merges.empty()) {
         mg::MergeArgs m;
         m.work = d_merge;
         m.pool = d_pool;

@@ -133,6 +133,27 @@ def test_sketch_min_copies_rounds_and_batches(eng, oracle, monkeypatch):
             assert nhash[2] == 0 and nhash[4] == 0
 
 
+@pytest.mark.parametrize("k,s", [(21, 20000), (31, 60000), (14, 13000)])
+def test_sketch_beyond_lds_selector(eng, oracle, k, s):
+    """s > 12288: bottom-s by exact range counting in HBM instead of the LDS selector (same
+    result by definition: the s smallest distinct hashes); full and short sketches, two at once."""
+    rng = np.random.default_rng(s)
+    seqs = [[synth._rand_dna(rng, 150000)], [synth._rand_dna(rng, 9000), b"ACGTNNNN" * 3, synth._rand_dna(rng, 4000)]]
+    p = eng.params(k=k, s=s)
+    hashes, nhash = eng.sketch_host(seqs, p)
+    for i, recs in enumerate(seqs):
+        oh = oracle.sketch_records(recs, oracle.params(k=k, s=s))[0]
+        assert nhash[i] == len(oh), (k, s, i)
+        assert np.array_equal(hashes[i, : len(oh)], oh), (k, s, i)
+    assert nhash[0] == s and nhash[1] < s
+    # the compare path takes such sketches through the generic kernel
+    t = eng.table_upload(hashes, nhash, np.array([150000, 13000], np.uint64))
+    got = eng.compare_tri_host(t)
+    o = oracle.compare(hashes[1, : nhash[1]], hashes[0, : nhash[0]], 13000, 150000, s, k, 4.0 ** k)
+    assert (int(got["numer"][0]), int(got["denom"][0])) == (o.numer, o.denom)
+    t.free()
+
+
 def test_sketch_reads_json_golden(eng, golden_dir):
     """mash sketch -r reads1.fastq reads2.fastq == test/ref/reads.json (hashes)."""
     r1 = helpers.read_fastx(os.path.join(golden_dir, "reads1.fastq.gz"))
