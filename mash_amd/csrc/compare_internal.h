@@ -20,6 +20,7 @@ struct CompareArgs {
     const CompareTile *tiles;
     uint2 *out;                   // {numer, denom}
     uint64_t row_stride, col_stride;
+    uint64_t row_pfx_stride, col_pfx_stride;   // strides of the padded prefix images
     uint64_t row_begin, row_end;  // rows handled by this launch
     uint64_t ncols;               // rect: number of refs
     uint64_t out_base;            // triangle: row_begin*(row_begin-1)/2
@@ -41,8 +42,9 @@ hipError_t launch_compare_merged(const CompareArgs &a, uint32_t ntiles, hipStrea
 // table max (u64 atomicMax over the last valid entry of every row) and prefix image
 hipError_t launch_table_max(const uint64_t *hashes, const uint32_t *nhash, uint64_t n, uint64_t stride,
                             unsigned long long *out_max, hipStream_t stream);
-hipError_t launch_make_prefix(const uint64_t *hashes, uint64_t count, uint32_t shr, uint32_t *out,
-                              hipStream_t stream);
+uint64_t compare_pfx_stride(uint64_t s);          // row stride (u32 entries) of the padded prefix image
+hipError_t launch_make_prefix(const uint64_t *hashes, const uint32_t *nhash, uint64_t n, uint64_t s,
+                              uint64_t pfx_stride, uint32_t shr, uint32_t *out, hipStream_t stream);
 // Generic kernel (any s): one wave per pair, binary search in global memory.
 hipError_t launch_compare_generic(const CompareArgs &a, hipStream_t stream);
 

@@ -31,7 +31,7 @@ constexpr int MR_NW = MR_NT / 64;
 constexpr int MR_W = 4;                      // window: entries read per probe
 constexpr int MR_EPT = 20;                   // table entries built per thread (R*s <= 20480)
 constexpr int MR_CB = 8;                     // consecutive columns per wave batch (64 B of output per row)
-constexpr int MR_KU = 4;                     // 64-element blocks of a column in flight
+constexpr int MR_KU_DEFAULT = 3;             // 64-element blocks of a column between rank tests (template KU)
 constexpr uint32_t MR_OVF = 0x8000u;         // dir flag: bucket has more than MR_W entries
 
 struct MergedHdr {
@@ -87,8 +87,10 @@ __device__ __forceinline__ uint32_t mr_prefix(uint64_t v, uint32_t shr)
     return (t >> 32) != 0 ? 0xFFFFFFFFu : (uint32_t)t;
 }
 
+template <int KU>
 __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
 {
+    constexpr int MR_KU = KU;
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t s = a.s;
     const uint32_t R = a.rows_per_tile;
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
             if (i < a.row_end) {
                 n = a.row_nhash[i];
                 if (n > s) n = s;
-                if (n > 0) mx = a.row_pfx[i * a.row_stride + n - 1];
+                if (n > 0) mx = a.row_pfx[i * a.row_pfx_stride + n - 1];
             }
         }
         hdr->row_n[tid] = n;
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
         hdr->nent = e;
     }
     __syncthreads();
-    const uint32_t scale = hdr->scale, xmax = hdr->xmax, E = hdr->nent;
+    const uint32_t scale = hdr->scale, E = hdr->nent;
 
     // pass 1: bucket histogram; entries are enumerated row-major, thread tid owns
     // e = tid, tid + NT, ... (coalesced loads of the rows' prefix images)
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
         e_pfx[t] = 0;
         e_tag[t] = 0;
         if (r < R && idx < hdr->row_n[r]) {
-            const uint32_t x = a.row_pfx[((uint64_t)tile.row0 + r) * a.row_stride + idx];
+            const uint32_t x = a.row_pfx[((uint64_t)tile.row0 + r) * a.row_pfx_stride + idx];
             const uint32_t bk = __umulhi(x, scale);
             const uint32_t old = atomicAdd(&cnt32[bk >> 1], (bk & 1u) ? 0x10000u : 1u);
             const uint32_t slot = (bk & 1u) ? (old >> 16) : (old & 0xFFFFu);
@@ -205,12 +207,12 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
             tag[pos] = e_tag[t];
         }
     }
-    if (tid < MR_W) { pfx[E + tid] = 0xFFFFFFFFu; tag[E + tid] = 0xFFFFu; }
+    if (tid < MR_W) { pfx[E + tid] = 0xFFFFFFFEu; tag[E + tid] = 0xFFFFu; }   // equals no real prefix, nor the padding
     __syncthreads();
 
     // ------------------------------------------------------------------ stream columns
     const uint32_t my_n = lane < 32 ? hdr->row_n[lane] : 0;                // row `lane`
-    const uint32_t *my_row = a.row_pfx + ((uint64_t)tile.row0 + (((uint64_t)tile.row0 + lane < a.row_end && lane < R) ? lane : 0)) * a.row_stride;
+    const uint32_t *my_row = a.row_pfx + ((uint64_t)tile.row0 + (((uint64_t)tile.row0 + lane < a.row_end && lane < R) ? lane : 0)) * a.row_pfx_stride;
 
     // Column streaming is software-pipelined with UNCONDITIONAL loads (indices clamped into
     // the row, which is padded to s entries) so the compiler can count vmcnt exactly:
@@ -218,12 +220,11 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
     //   and (issued during group 0) the first group + length of the wave's next column.
     // VMEM returns in order, so the small L2-resident rank-test operand is always issued
     // BEFORE the streaming loads that follow it.
-    const uint32_t qclamp = s - 1;
     auto load_group = [&](const uint32_t *src, uint32_t qbase, uint32_t (&dst)[MR_KU]) {
 #pragma unroll
         for (int u = 0; u < MR_KU; u++) {
             const uint32_t q = qbase + u * 64 + lane;
-            dst[u] = src[q < qclamp ? q : qclamp];
+            dst[u] = src[q];                              // rows of the image are padded (0xFFFFFFFF)
         }
     };
     const uint32_t rmax = (a.row_end - tile.row0) < (uint64_t)R ? (uint32_t)(a.row_end - tile.row0) : R;
@@ -269,12 +270,12 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
     uint32_t tcol = 0;
     uint32_t j = col_of(0);
     if (j < tile.col1) {
-        load_group(a.col_pfx + (uint64_t)j * a.col_stride, 0, ncol);
+        load_group(a.col_pfx + (uint64_t)j * a.col_pfx_stride, 0, ncol);
         nB_next = a.col_nhash[j];
     }
     for (; j < tile.col1; tcol++, j = col_of(tcol)) {
         uint32_t nB = nB_next < s ? nB_next : s;
-        const uint32_t *bsrc = a.col_pfx + (uint64_t)j * a.col_stride;
+        const uint32_t *bsrc = a.col_pfx + (uint64_t)j * a.col_pfx_stride;
         const uint64_t *bsrc64 = a.col_hashes + (uint64_t)j * a.col_stride;
         uint32_t cur[MR_KU], nxt[MR_KU];
 #pragma unroll
@@ -290,12 +291,12 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
         const uint32_t ngroups = valid == 0 ? 0 : (nB + 64 * MR_KU - 1) / (64 * MR_KU);
         // prologue: rank-test operand of group 0, data of group 1, then the next column
         int32_t t_chk = (int32_t)s - (int32_t)(64 * MR_KU) + (int32_t)st_call;      // s-1-qlast+c, qlast = 64*KU-1
-        uint32_t a_chk = my_row[t_chk >= 1 ? ((uint32_t)t_chk - 1 < qclamp ? (uint32_t)t_chk - 1 : qclamp) : 0];
+        uint32_t a_chk = my_row[t_chk >= 1 ? (uint32_t)t_chk - 1 : 0];
         load_group(bsrc, 64 * MR_KU, nxt);
         {
             const uint32_t jnx = col_of(tcol + 1);
             const uint32_t jn = jnx < tile.col1 ? jnx : j;
-            load_group(a.col_pfx + (uint64_t)jn * a.col_stride, 0, ncol);
+            load_group(a.col_pfx + (uint64_t)jn * a.col_pfx_stride, 0, ncol);
             nB_next = a.col_nhash[jn];
         }
         for (uint32_t g = 0; g < ngroups && active != 0; g++) {
@@ -305,15 +306,13 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
 
             // ---- one probe per element for ALL rows of the tile ----
             uint32_t x[MR_KU], s0[MR_KU], h[MR_KU][MR_W];
-            uint64_t inbm[MR_KU], tiem[MR_KU];
+            uint64_t tiem[MR_KU];
             uint64_t anytie = 0;
 #pragma unroll
             for (int u = 0; u < MR_KU; u++) {
-                const uint32_t qb = q0 + u * 64;
-                inbm[u] = qb + 64 <= nB ? ~0ULL : (qb >= nB ? 0ULL : ((1ULL << (nB - qb)) - 1ULL));
                 x[u] = cur[u];
                 const uint32_t bk = __umulhi(x[u], scale);
-                s0[u] = dir[x[u] > xmax ? NB : bk];
+                s0[u] = dir[bk < NB ? bk : NB];              // prefixes above the tile's maximum (and padding) -> sentinel
             }
 #pragma unroll
             for (int u = 0; u < MR_KU; u++)
@@ -324,7 +323,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
                 uint64_t t = __ballot((s0[u] & MR_OVF) != 0);            // oversize bucket: inspect it fully
 #pragma unroll
                 for (int w = 0; w < MR_W; w++) t |= __ballot(h[u][w] == x[u]);
-                tiem[u] = t & inbm[u] & __ballot(x[u] <= xmax);
+                tiem[u] = t;
                 anytie |= tiem[u];
             }
 
@@ -414,7 +413,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
             if (!col_end) {
                 if (c_changed) {                                         // uniform; counts moved: re-read operand
                     t_chk = (int32_t)s - 1 - (int32_t)qlast + (int32_t)st_call;
-                    a_chk = my_row[t_chk >= 1 ? ((uint32_t)t_chk - 1 < qclamp ? (uint32_t)t_chk - 1 : qclamp) : 0];
+                    a_chk = my_row[t_chk >= 1 ? (uint32_t)t_chk - 1 : 0];
                 }
                 // prefix compare is conservative: prefix(A) < prefix(B) => A < B (a later exit is harmless)
                 const uint32_t xlast = (uint32_t)__builtin_amdgcn_readlane((int)cur[MR_KU - 1], 63);
@@ -426,7 +425,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
 #pragma unroll
                 for (int u = 0; u < MR_KU; u++) cur[u] = nxt[u];
                 t_chk = (int32_t)s - 1 - (int32_t)(qlast + 64 * MR_KU) + (int32_t)st_call;
-                a_chk = my_row[t_chk >= 1 ? ((uint32_t)t_chk - 1 < qclamp ? (uint32_t)t_chk - 1 : qclamp) : 0];
+                a_chk = my_row[t_chk >= 1 ? (uint32_t)t_chk - 1 : 0];
                 load_group(bsrc, q0 + 2 * 64 * MR_KU, nxt);
             }
         }
@@ -460,11 +459,20 @@ __global__ void table_max_kernel(const uint64_t *hashes, const uint32_t *nhash, 
     if ((threadIdx.x & 63) == 0 && v) atomicMax(out_max, v);
 }
 
-__global__ void make_prefix_kernel(const uint64_t *hashes, uint64_t count, uint32_t shr, uint32_t *out)
+// u32 prefix image with a padded row stride: entries beyond a row's valid hashes (and the
+// padding columns) hold 0xFFFFFFFF, which no real prefix equals (the shift keeps real prefixes
+// <= 0xFFFFFFFD), so the compare kernel needs neither index clamps nor in-range masks.
+__global__ void make_prefix_kernel(const uint64_t *hashes, const uint32_t *nhash, uint64_t n, uint64_t s,
+                                   uint64_t pfx_stride, uint32_t shr, uint32_t *out)
 {
+    const uint64_t total = n * pfx_stride;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride)
-        out[i] = mr_prefix(hashes[i], shr);
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const uint64_t i = e / pfx_stride, j = e - i * pfx_stride;
+        uint32_t k = nhash[i];
+        if (k > s) k = (uint32_t)s;
+        out[e] = j < k ? mr_prefix(hashes[i * s + j], shr) : 0xFFFFFFFFu;
+    }
 }
 
 hipError_t launch_table_max(const uint64_t *hashes, const uint32_t *nhash, uint64_t n, uint64_t stride,
@@ -476,13 +484,32 @@ hipError_t launch_table_max(const uint64_t *hashes, const uint32_t *nhash, uint6
     return hipGetLastError();
 }
 
-hipError_t launch_make_prefix(const uint64_t *hashes, uint64_t count, uint32_t shr, uint32_t *out,
-                              hipStream_t stream)
+uint64_t compare_pfx_stride(uint64_t s)
 {
-    if (count == 0) return hipSuccess;
-    uint64_t blocks = (count + 1023) / 1024;
+    // every group the pipeline may touch lies inside the row: round s up to 64 and add
+    // two groups of the largest KU variant (+1 block)
+    return ((s + 63) / 64) * 64 + 64 * 13;             // covers KU <= 4: 64 (KU - 1) + 128 KU <= 832
+}
+
+hipError_t launch_make_prefix(const uint64_t *hashes, const uint32_t *nhash, uint64_t n, uint64_t s,
+                              uint64_t pfx_stride, uint32_t shr, uint32_t *out, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    uint64_t blocks = (n * pfx_stride + 1023) / 1024;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(make_prefix_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, hashes, count, shr, out);
+    hipLaunchKernelGGL(make_prefix_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, hashes, nhash, n, s,
+                       pfx_stride, shr, out);
+    return hipGetLastError();
+}
+
+template <int KU>
+static hipError_t launch_merged_k(const CompareArgs &a, uint32_t ntiles, size_t smem, hipStream_t stream)
+{
+    auto kern = compare_merged_kernel<KU>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(ntiles), dim3(MR_NT), smem, stream, a);
     return hipGetLastError();
 }
 
@@ -490,12 +517,13 @@ hipError_t launch_compare_merged(const CompareArgs &a, uint32_t ntiles, hipStrea
 {
     if (ntiles == 0) return hipSuccess;
     const size_t smem = merged_lds_bytes(a.rows_per_tile, a.s);
-    auto kern = compare_merged_kernel;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(ntiles), dim3(MR_NT), smem, stream, a);
-    return hipGetLastError();
+    // a.unroll (MASHGPU_COMPARE_VARIANT) selects the group size for tuning runs; 0 = default
+    switch (a.unroll ? (int)a.unroll : MR_KU_DEFAULT) {
+        case 2: return launch_merged_k<2>(a, ntiles, smem, stream);
+        case 3: return launch_merged_k<3>(a, ntiles, smem, stream);
+        case 4: return launch_merged_k<4>(a, ntiles, smem, stream);
+        default: return launch_merged_k<MR_KU_DEFAULT>(a, ntiles, smem, stream);
+    }
 }
 
 }  // namespace mg

@@ -664,8 +664,9 @@ static int table_max(mg_ctx *ctx, const mg_table *t, uint64_t *out)
 static int table_prefix(mg_ctx *ctx, const mg_table *t, int shr)
 {
     if (t->pfx && t->pfx_shr == shr) return MG_OK;
-    if (!t->pfx) HIP_TRY(ctx, hipMalloc(&t->pfx, std::max<uint64_t>(t->n * t->s * 4, 4)));
-    HIP_TRY(ctx, mg::launch_make_prefix(t->hashes, t->n * t->s, (uint32_t)shr, t->pfx, ctx->stream));
+    const uint64_t ps = mg::compare_pfx_stride(t->s);
+    if (!t->pfx) HIP_TRY(ctx, hipMalloc(&t->pfx, std::max<uint64_t>(t->n * ps * 4, 4)));
+    HIP_TRY(ctx, mg::launch_make_prefix(t->hashes, t->nhash, t->n, t->s, ps, (uint32_t)shr, t->pfx, ctx->stream));
     t->pfx_shr = shr;
     return MG_OK;
 }
@@ -703,6 +704,7 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
         return MG_OK;
     }
     a.row_pfx = a.col_pfx = nullptr;
+    a.row_pfx_stride = a.col_pfx_stride = 0;
     a.pfx_shr = 0;
     if (use_merged) {
         // both tables are viewed through one 32-bit prefix: value >> shr, shr from the larger maximum
@@ -712,12 +714,15 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
         if (rc != MG_OK) return rc;
         const uint64_t mx = std::max(m1, m2) | 1ull;
         const int bl = 64 - __builtin_clzll(mx);
-        const int shr = bl > 32 ? bl - 32 : 0;
+        int shr = bl > 32 ? bl - 32 : 0;
+        if ((mx >> shr) >= 0xFFFFFFFEull) shr++;          // 0xFFFFFFFE / 0xFFFFFFFF are reserved (sentinel, padding)
         rc = table_prefix(ctx, rows, shr);
         if (rc == MG_OK && cols != rows) rc = table_prefix(ctx, cols, shr);
         if (rc != MG_OK) return rc;
         a.row_pfx = rows->pfx;
         a.col_pfx = cols->pfx;
+        a.row_pfx_stride = mg::compare_pfx_stride(rows->s);
+        a.col_pfx_stride = mg::compare_pfx_stride(cols->s);
         a.pfx_shr = (uint32_t)shr;
     }
     uint32_t R = use_merged ? mg::compare_merged_rows(a.s) : mg::compare_rows_per_tile(a.s);
