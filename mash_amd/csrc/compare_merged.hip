@@ -51,23 +51,31 @@ __host__ __device__ inline uint32_t merged_idx_bits(uint32_t s)
     return b;
 }
 
-// power-of-two bucket count with about one entry per bucket (load factor <= 1.25)
+constexpr size_t MR_LDS_LIMIT = 160 * 1024 - 512;       // dynamic part; 512 B left for the static arrays
+
+// LDS bytes of a tile table with nb buckets
+__host__ __device__ inline size_t merged_lds_bytes_nb(uint32_t R, uint32_t s, uint32_t nb)
+{
+    const size_t ecap = (size_t)R * s + MR_W;
+    return 512 + ((size_t)nb + 8) * 2 + ((ecap * 4 + 15) & ~(size_t)15) + ((ecap * 2 + 15) & ~(size_t)15) +
+           (size_t)MR_NW * R * MR_CB * 8;                             // + per-wave output staging
+}
+
+// Bucket count: at least 0.8 buckets per entry (power of two), then as many more as LDS holds
+// up to two per entry -- buckets with more than MR_W entries cost an extra scan per probe that
+// lands in them, and their share falls quickly with the load factor.
 __host__ __device__ inline uint32_t merged_buckets(uint32_t R, uint32_t s)
 {
     uint32_t nb = 1024;
     while (nb * 5 < R * s * 4) nb <<= 1;
+    while (nb + 1024 <= 2 * R * s && nb + 1024 <= 65536 - 16 && merged_lds_bytes_nb(R, s, nb + 1024) <= MR_LDS_LIMIT) nb += 1024;
     return nb;
 }
 
 __host__ __device__ inline size_t merged_lds_bytes(uint32_t R, uint32_t s)
 {
-    const size_t ecap = (size_t)R * s + MR_W;
-    const size_t nb = merged_buckets(R, s);
-    return 512 + (nb + 8) * 2 + ((ecap * 4 + 15) & ~(size_t)15) + ((ecap * 2 + 15) & ~(size_t)15) +
-           (size_t)MR_NW * R * MR_CB * 8;                             // + per-wave output staging
+    return merged_lds_bytes_nb(R, s, merged_buckets(R, s));
 }
-
-constexpr size_t MR_LDS_LIMIT = 160 * 1024 - 512;       // dynamic part; 512 B left for the static arrays
 
 bool compare_merged_supported(uint32_t s) { return s >= 1 && s <= 16384 && merged_lds_bytes(1, s) <= MR_LDS_LIMIT; }
 
@@ -94,7 +102,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t s = a.s;
     const uint32_t R = a.rows_per_tile;
-    const uint32_t NB = merged_buckets(R, s);
+    const uint32_t NB = a.nbuckets;
     const uint32_t ecap = R * s + MR_W;
     MergedHdr *hdr = reinterpret_cast<MergedHdr *>(smem);
     uint16_t *dir = reinterpret_cast<uint16_t *>(smem + 512);                       // [NB + 8]
@@ -318,14 +326,32 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
             for (int u = 0; u < MR_KU; u++)
 #pragma unroll
                 for (int w = 0; w < MR_W; w++) h[u][w] = pfx[(s0[u] & 0x7FFFu) + w];
+            uint64_t anyovf = 0;
 #pragma unroll
             for (int u = 0; u < MR_KU; u++) {
-                uint64_t t = __ballot((s0[u] & MR_OVF) != 0);            // oversize bucket: inspect it fully
+                uint64_t t = 0;
 #pragma unroll
                 for (int w = 0; w < MR_W; w++) t |= __ballot(h[u][w] == x[u]);
                 tiem[u] = t;
-                anytie |= tiem[u];
+                anyovf |= __ballot(s0[u] > 0x7FFFu);
             }
+            if (anyovf != 0) {
+                // some element fell into a bucket with more than MR_W entries: compare it with the
+                // rest of that bucket right here (a few LDS reads) instead of sending the whole
+                // block down the exact path
+#pragma unroll
+                for (int u = 0; u < MR_KU; u++) {
+                    bool hit = false;
+                    if (s0[u] > 0x7FFFu) {
+                        const uint32_t bk = __umulhi(x[u], scale);        // < NB: the sentinel bucket is never oversize
+                        const uint32_t e1 = dir[bk + 1] & 0x7FFFu;
+                        for (uint32_t e = (s0[u] & 0x7FFFu) + MR_W; e < e1; e++) hit |= pfx[e] == x[u];
+                    }
+                    tiem[u] |= __ballot(hit);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < MR_KU; u++) anytie |= tiem[u];
 
             bool c_changed = false;
             if (anytie != 0) {
@@ -513,10 +539,12 @@ static hipError_t launch_merged_k(const CompareArgs &a, uint32_t ntiles, size_t 
     return hipGetLastError();
 }
 
-hipError_t launch_compare_merged(const CompareArgs &a, uint32_t ntiles, hipStream_t stream)
+hipError_t launch_compare_merged(const CompareArgs &a_in, uint32_t ntiles, hipStream_t stream)
 {
     if (ntiles == 0) return hipSuccess;
-    const size_t smem = merged_lds_bytes(a.rows_per_tile, a.s);
+    CompareArgs a = a_in;
+    a.nbuckets = merged_buckets(a.rows_per_tile, a.s);
+    const size_t smem = merged_lds_bytes_nb(a.rows_per_tile, a.s, a.nbuckets);
     // a.unroll (MASHGPU_COMPARE_VARIANT) selects the group size for tuning runs; 0 = default
     switch (a.unroll ? (int)a.unroll : MR_KU_DEFAULT) {
         case 2: return launch_merged_k<2>(a, ntiles, smem, stream);
