@@ -30,6 +30,7 @@ struct CompareArgs {
     uint32_t unroll;              // probes in flight per wave (tuning knob; 0 = default)
     uint32_t pfx_shr;             // prefix shift shared by both tables
     uint32_t nbuckets;            // merged kernel: buckets of the tile table (set by its launcher)
+    unsigned long long *dbg;      // tuning hook: per-tile {start, built, end} clocks (nullptr = off)
 };
 
 // LDS-tiled kernel usable when s <= 1024; rows_per_tile chosen by compare_rows_per_tile.

@@ -35,7 +35,7 @@ constexpr int MR_KU_DEFAULT = 3;             // 64-element blocks of a column be
 constexpr uint32_t MR_OVF = 0x8000u;         // dir flag: bucket has more than MR_W entries
 
 struct MergedHdr {
-    uint32_t shr;        // (unused: the prefix shift is launch-wide, CompareArgs::pfx_shr)
+    uint32_t collide;    // set by the build when two DIFFERENT values of the tile share a prefix
     uint32_t scale;      // bucket = mulhi(prefix, scale)
     uint32_t xmax;       // largest prefix present in the tile
     uint32_t nent;       // total entries E
@@ -115,6 +115,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
 
     const CompareTile tile = a.tiles[blockIdx.x];
     const int tid = threadIdx.x;
+    if (a.dbg && tid == 0) a.dbg[3 * (uint64_t)blockIdx.x] = __builtin_readcyclecounter();
     const uint32_t lane = tid & 63;
     const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
 
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
         for (uint32_t r = 0; r < 32; r++) mxall = s_rowmax[r] > mxall ? s_rowmax[r] : mxall;
         const uint32_t xmax = (uint32_t)mxall;                    // largest prefix of the tile's rows
         const uint64_t sc = ((uint64_t)NB << 32) / ((uint64_t)xmax + 1ULL);
-        hdr->shr = a.pfx_shr;
+        hdr->collide = 0;
         hdr->xmax = xmax;
         hdr->scale = sc > 0xFFFFFFFFULL ? 0xFFFFFFFFu : (uint32_t)sc;
         hdr->nent = e;
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
         uint32_t run = woff + inc - sum;
         for (uint32_t b = b0; b < b0 + per && b < NB; b++) {
             const uint32_t c = dir[b];
-            dir[b] = (uint16_t)(run | (c > (uint32_t)MR_W ? MR_OVF : 0u));
+            dir[b] = (uint16_t)run;                        // the oversize flag is set by pass 3
             run += c;
         }
         if (tid == MR_NT - 1) {
@@ -217,7 +218,49 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
     }
     if (tid < MR_W) { pfx[E + tid] = 0xFFFFFFFEu; tag[E + tid] = 0xFFFFu; }   // equals no real prefix, nor the padding
     __syncthreads();
+    // pass 3, per bucket: (a) move one entry of every DISTINCT prefix to the front, so the probe
+    // window (the first MR_W entries) decides "is this prefix in the tile" no matter how many rows
+    // share a value -- related rows in one tile would otherwise turn every bucket of theirs into
+    // an oversize one; a bucket is oversize only if it holds more than MR_W distinct prefixes.
+    // (b) Check that equal prefix means equal value inside the tile: every duplicate compares its
+    // 64-bit value with the front entry of its prefix (loads happen only where rows share
+    // values).  Tiles that pass -- practically all -- let the exact path trust prefix equality
+    // between table entries and verify one representative per column element.
+    {
+        const uint32_t per = (NB + MR_NT - 1) / MR_NT;
+        const uint32_t b0 = tid * per;
+        for (uint32_t b = b0; b < b0 + per && b < NB; b++) {
+            const uint32_t st = dir[b] & 0x7FFFu, en = dir[b + 1] & 0x7FFFu;
+            const uint32_t c = en - st;
+            uint32_t nd = c;
+            if (c >= 2) {
+                nd = 1;
+                for (uint32_t i = 1; i < c; i++) {
+                    const uint32_t pi = pfx[st + i];
+                    const uint16_t ti = tag[st + i];
+                    uint32_t d = 0;
+                    while (d < nd && pfx[st + d] != pi) d++;
+                    if (d == nd) {                                       // new prefix: swap to the front region
+                        if (i != nd) {
+                            pfx[st + i] = pfx[st + nd]; tag[st + i] = tag[st + nd];
+                            pfx[st + nd] = pi; tag[st + nd] = ti;
+                        }
+                        nd++;
+                    } else {
+                        const uint32_t tg0 = tag[st + d], tg1 = ti;
+                        const uint64_t v0 = a.row_hashes[((uint64_t)tile.row0 + (tg0 >> idx_bits)) * a.row_stride + (tg0 & idx_mask)];
+                        const uint64_t v1 = a.row_hashes[((uint64_t)tile.row0 + (tg1 >> idx_bits)) * a.row_stride + (tg1 & idx_mask)];
+                        if (v0 != v1) hdr->collide = 1;
+                    }
+                }
+            }
+            if (nd > (uint32_t)MR_W) dir[b] = (uint16_t)(st | MR_OVF);
+        }
+    }
+    __syncthreads();
+    const bool clean = hdr->collide == 0;
 
+    if (a.dbg && tid == 0) a.dbg[3 * (uint64_t)blockIdx.x + 1] = __builtin_readcyclecounter();
     // ------------------------------------------------------------------ stream columns
     const uint32_t my_n = lane < 32 ? hdr->row_n[lane] : 0;                // row `lane`
     const uint32_t *my_row = a.row_pfx + ((uint64_t)tile.row0 + (((uint64_t)tile.row0 + lane < a.row_end && lane < R) ? lane : 0)) * a.row_pfx_stride;
@@ -362,6 +405,60 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
                     const uint32_t qb = q0 + u * 64;
                     const bool mine = (tiem[u] >> lane) & 1ULL;
                     const uint64_t b = mine ? bsrc64[qb + lane] : 0;   // 64-bit value only for tied lanes
+                    if (clean) {
+                        // every table entry with b's prefix holds the same value (build pass 3): collect
+                        // the rows and b's index in each from LDS, verify ONE representative on 64 bits
+                        uint32_t rowmask = 0, rep = 0xFFFFFFFFu;
+                        uint32_t pk[8];                                  // idx of b in row r: 16 bits each
+#pragma unroll
+                        for (int k = 0; k < 8; k++) pk[k] = 0;
+                        auto take = [&](uint32_t tg) {
+                            const uint32_t r = tg >> idx_bits, idx = tg & idx_mask;
+                            if (rep == 0xFFFFFFFFu) rep = tg;
+                            rowmask |= 1u << r;
+                            const uint32_t val = idx << ((r & 1u) * 16u), wd = r >> 1;
+#pragma unroll
+                            for (int k = 0; k < 8; k++) pk[k] |= (wd == (uint32_t)k) ? val : 0u;
+                        };
+                        if (mine) {
+                            const uint32_t st = s0[u] & 0x7FFFu;
+#pragma unroll
+                            for (int w = 0; w < MR_W; w++)
+                                if (h[u][w] == x[u]) take(tag[st + w]);
+                            {                                            // rows sharing the value sit behind the distinct entries
+                                const uint32_t bk = __umulhi(x[u], scale);
+                                const uint32_t e1 = dir[bk + 1] & 0x7FFFu;
+                                for (uint32_t e = st + MR_W; e < e1; e++)
+                                    if (pfx[e] == x[u]) take(tag[e]);
+                            }
+                            if (rep != 0xFFFFFFFFu) {
+                                const uint64_t v = a.row_hashes[((uint64_t)tile.row0 + (rep >> idx_bits)) * a.row_stride + (rep & idx_mask)];
+                                if (v != b) rowmask = 0;                  // same prefix, different value
+                            }
+                        }
+                        uint32_t any = rowmask;                           // rows involved anywhere in this block
+#pragma unroll
+                        for (int d = 32; d > 0; d >>= 1) any |= __shfl_xor(any, d);
+                        const uint32_t rows_any = (uint32_t)__builtin_amdgcn_readfirstlane((int)any) & active;
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            if (!((rows_any >> r) & 1u)) continue;       // uniform
+                            const bool mt = (rowmask >> r) & 1u;
+                            const uint32_t idx = (pk[r >> 1] >> ((r & 1) * 16)) & 0xFFFFu;
+                            uint32_t c_all = (uint32_t)__builtin_amdgcn_readlane((int)st_call, r);
+                            uint32_t common = (uint32_t)__builtin_amdgcn_readlane((int)st_common, r);
+                            const uint64_t mm = __ballot(mt);
+                            const uint32_t before = c_all + __builtin_amdgcn_mbcnt_hi(
+                                (uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0));
+                            const uint32_t rank = qb + lane + idx - before;
+                            common += (uint32_t)__popcll(__ballot(mt && rank < s));
+                            c_all += (uint32_t)__popcll(mm);
+                            st_call = (lane == (uint32_t)r) ? c_all : st_call;
+                            st_common = (lane == (uint32_t)r) ? common : st_common;
+                            c_changed = true;
+                        }
+                        continue;
+                    }
                     // scan my bucket: rows whose value equals b (verified on 64 bits), remember
                     // the index (= lower bound of b in that row) of up to the first 4 hits in regs
                     uint32_t rowmask = 0;
@@ -380,7 +477,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
                                 if (v == b) { rowmask |= 1u << r; hit_tag[w] = tg; }
                             }
                         }
-                        if (s0[u] & MR_OVF) {
+                        {
                             const uint32_t bk = __umulhi(x[u], scale);
                             extra_lo = st + MR_W;
                             extra_hi = dir[bk + 1] & 0x7FFFu;
@@ -465,6 +562,9 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
         }
         if ((tcol % MR_CB) == MR_CB - 1 || col_of(tcol + 1) >= tile.col1)
             flush_batch(j - (tcol % MR_CB), (tcol % MR_CB) + 1);
+    }
+    if (a.dbg) {
+        if (lane == 0) atomicMax(&a.dbg[3 * (uint64_t)blockIdx.x + 2], (unsigned long long)__builtin_readcyclecounter());
     }
 }
 

@@ -750,6 +750,13 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
     if (tiles.empty()) return MG_OK;
     mg::CompareTile *d_tiles = nullptr;
     HIP_TRY(ctx, hipMalloc(&d_tiles, tiles.size() * sizeof(mg::CompareTile)));
+    a.dbg = nullptr;
+    unsigned long long *d_dbg = nullptr;
+    if (getenv("MASHGPU_COMPARE_DBG") && use_merged) {
+        hipMalloc(&d_dbg, tiles.size() * 24);
+        hipMemsetAsync(d_dbg, 0, tiles.size() * 24, ctx->stream);
+        a.dbg = d_dbg;
+    }
     hipError_t e = hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(mg::CompareTile),
                                   hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
@@ -761,6 +768,20 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
     }
     // the tile list must outlive the launch
     hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    if (d_dbg) {
+        std::vector<unsigned long long> h(tiles.size() * 3);
+        hipMemcpy(h.data(), d_dbg, h.size() * 8, hipMemcpyDeviceToHost);
+        double b = 0, t = 0;
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (size_t i = 0; i < tiles.size(); i++) {
+            b += (double)(h[3 * i + 1] - h[3 * i]);
+            t += (double)(h[3 * i + 2] - h[3 * i]);
+            t0 = std::min(t0, h[3 * i]); t1 = std::max(t1, h[3 * i + 2]);
+        }
+        fprintf(stderr, "compare dbg: %zu tiles, build %.0f clk avg, tile %.0f clk avg, span %llu clk, sum(tile)/span %.1f\n",
+                tiles.size(), b / tiles.size(), t / tiles.size(), t1 - t0, t / (double)(t1 - t0));
+        hipFree(d_dbg);
+    }
     hipFree(d_tiles);
     if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare launch: ") + hipGetErrorString(e));
     if (e2 != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare kernel: ") + hipGetErrorString(e2));

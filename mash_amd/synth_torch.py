@@ -23,7 +23,7 @@ def splitmix64(state0, n):
 
 
 def clustered_sketch_table(n, s=1000, clusters=1000, seed=0, pool=1500, private=400, keep_p=0.8,
-                           length=1_000_000, device="cuda", block=20000):
+                           length=1_000_000, device="cuda", block=20000, contiguous=False):
     """C3 table on `device`: (hashes int64[n, s] = uint64 bits, padded with -1 (=2^64-1);
     nhash int32[n]; lengths int64[n])."""
     gen = torch.Generator(device=device)
@@ -35,7 +35,10 @@ def clustered_sketch_table(n, s=1000, clusters=1000, seed=0, pool=1500, private=
     for b0 in range(0, n, block):
         b1 = min(n, b0 + block)
         m = torch.arange(b0, b1, device=device, dtype=torch.int64)
-        ph = pools[m % clusters]                                              # [B, pool]
+        # SURVEY 8d interleaves the clusters (m % C); contiguous=True lays each cluster out as a
+        # run of consecutive rows, the order taxonomically sorted collections have
+        cl = (m * clusters) // n if contiguous else m % clusters
+        ph = pools[cl]                                                        # [B, pool]
         take = torch.rand((b1 - b0, pool), device=device, generator=gen) < keep_p
         ph = torch.where(take, ph, torch.full_like(ph, _PAD_SORT))
         priv = _lsr(splitmix64(-6882143410218379217 * (m + 1) + seed, private), 10)   # 0xA0761D6478BD642F

@@ -18,7 +18,8 @@ def main():
     dev = torch.device("cuda", 0)
     eng = abi.MashGpu(0)
     n = a.n
-    hashes, nhash, lengths = synth_torch.clustered_sketch_table(n, 1000, clusters=max(1, n // 100), device=dev)
+    hashes, nhash, lengths = synth_torch.clustered_sketch_table(n, 1000, clusters=max(1, n // 100), device=dev,
+                                                                contiguous=(a.mode == "contiguous"))
     if a.mode == "identical":
         hashes[:] = hashes[0]
     table = eng.table_wrap(hashes.data_ptr(), nhash.data_ptr(), lengths.data_ptr(), n, 1000)
