@@ -727,7 +727,9 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
     }
     uint32_t R = use_merged ? mg::compare_merged_rows(a.s) : mg::compare_rows_per_tile(a.s);
     if (const char *e = getenv("MASHGPU_COMPARE_ROWS")) { uint32_t v = (uint32_t)atoi(e); if (v >= 1 && v < R) R = v; }
-    uint64_t CC = use_merged ? 8192 : 1024;
+    // columns per tile: long tiles amortise the table build and the ragged end of a tile
+    // (profiles/r01_compare_sweep2.txt); smaller problems keep more tiles for balance
+    uint64_t CC = use_merged ? (cols->n >= 40000 ? 16384 : 8192) : 1024;
     if (const char *e = getenv("MASHGPU_COMPARE_COLS")) { uint64_t v = strtoull(e, nullptr, 10); if (v >= 16) CC = v; }
     a.rows_per_tile = R;
     // tiles: column chunk outer, row tile inner (concurrent workgroups share a column chunk in L2)
