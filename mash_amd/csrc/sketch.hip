@@ -31,6 +31,17 @@
 #include "screen_internal.h"
 #include "sketch_internal.h"
 
+// This file is compiled four times (-DSK_PART=0..3, see Makefile): every part instantiates the
+// K-templated kernels for eight k-mer sizes, part 0 also holds everything that is not
+// templated on K.  One translation unit with all 32 x 3 x (2 + 1 + 1) kernels takes ~5 min.
+#ifndef SK_PART
+#define SK_PART 0
+#endif
+#define SK_K0 (SK_PART * 8)
+#define SK_CAT2(a, b) a##b
+#define SK_CAT(a, b) SK_CAT2(a, b)
+#define SK_PARTFN(base) SK_CAT(base, SK_PART)
+
 namespace mg {
 
 // Geometry per workgroup size.  NT=256 (s <= 2048): 60 k-mer starts per lane per tile
@@ -322,6 +333,7 @@ __global__ __launch_bounds__(NT) void sketch_chunks_kernel(SketchArgs a)
     }
 }
 
+#if SK_PART == 0
 // One workgroup per multi-chunk sketch: bottom-s distinct of the union of its chunk lists.
 template <int NT>
 __global__ __launch_bounds__(NT) void merge_chunks_kernel(MergeArgs a)
@@ -365,6 +377,8 @@ __global__ __launch_bounds__(NT) void merge_chunks_kernel(MergeArgs a)
     for (uint32_t i = tid; i < s; i += NT) out[i] = i < n ? buf[i] : HPAD;
     if (tid == 0) a.nhash_out[w.sketch] = n;
 }
+
+#endif  // SK_PART == 0
 
 // ---------------------------------------------------------------------------
 // Multiplicities (Sketch::Reference::counts, HashSet.cpp:78-118 / MinHashHeap.cpp:96-124).
@@ -428,6 +442,7 @@ __global__ __launch_bounds__(256) void count_chunks_kernel(CountArgs a)
     });
 }
 
+#if SK_PART == 0
 // one thread per sketch: t* = latest first occurrence among the kept hashes of a FULL sketch;
 // the largest hash needs the positional recount only if it repeats
 __global__ void count_tstar_kernel(const uint32_t *nhash, uint32_t *counts, const unsigned long long *firstpos,
@@ -449,6 +464,8 @@ __global__ void count_tstar_kernel(const uint32_t *nhash, uint32_t *counts, cons
     tstar[i] = t;
     need_fix[i] = fix;
 }
+
+#endif  // SK_PART == 0
 
 // ---------------------------------------------------------------------------
 // minCov >= 2 (`mash sketch -m`, MinHashHeap.cpp:96-118): a hash enters the sketch at its m-th
@@ -488,6 +505,7 @@ __global__ __launch_bounds__(256) void range_count_kernel(RangeCountArgs a)
     });
 }
 
+#if SK_PART == 0
 __global__ void range_extract_kernel(const unsigned long long *keys, const uint32_t *cnts, uint64_t slots,
                                      uint32_t min_copies, unsigned long long *out, unsigned long long *out_n,
                                      uint64_t out_cap)
@@ -500,6 +518,8 @@ __global__ void range_extract_kernel(const unsigned long long *keys, const uint3
         }
     }
 }
+
+#endif  // SK_PART == 0
 
 template <int K, int MODE>
 static hipError_t launch_range_one(const RangeCountArgs &a, uint32_t nwork, hipStream_t stream)
@@ -514,21 +534,35 @@ static hipError_t launch_range_k(int k, const RangeCountArgs &a, uint32_t nwork,
 {
     switch (k) {
 #define MG_CASE(KK) case KK: return launch_range_one<KK, MODE>(a, nwork, st);
-        MG_CASE(1) MG_CASE(2) MG_CASE(3) MG_CASE(4) MG_CASE(5) MG_CASE(6) MG_CASE(7) MG_CASE(8)
-        MG_CASE(9) MG_CASE(10) MG_CASE(11) MG_CASE(12) MG_CASE(13) MG_CASE(14) MG_CASE(15) MG_CASE(16)
-        MG_CASE(17) MG_CASE(18) MG_CASE(19) MG_CASE(20) MG_CASE(21) MG_CASE(22) MG_CASE(23) MG_CASE(24)
-        MG_CASE(25) MG_CASE(26) MG_CASE(27) MG_CASE(28) MG_CASE(29) MG_CASE(30) MG_CASE(31) MG_CASE(32)
+        MG_CASE(SK_K0 + 1) MG_CASE(SK_K0 + 2) MG_CASE(SK_K0 + 3) MG_CASE(SK_K0 + 4)
+        MG_CASE(SK_K0 + 5) MG_CASE(SK_K0 + 6) MG_CASE(SK_K0 + 7) MG_CASE(SK_K0 + 8)
 #undef MG_CASE
     }
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_range_count(int k, int mode, const RangeCountArgs &a, uint32_t nwork, hipStream_t stream)
+hipError_t SK_PARTFN(launch_range_part)(int k, int mode, const RangeCountArgs &a, uint32_t nwork, hipStream_t stream)
 {
-    if (nwork == 0) return hipSuccess;
     if (mode == 0) return launch_range_k<0>(k, a, nwork, stream);
     if (mode == 1) return launch_range_k<1>(k, a, nwork, stream);
     return launch_range_k<2>(k, a, nwork, stream);
+}
+
+#if SK_PART == 0
+hipError_t launch_range_part1(int, int, const RangeCountArgs &, uint32_t, hipStream_t);
+hipError_t launch_range_part2(int, int, const RangeCountArgs &, uint32_t, hipStream_t);
+hipError_t launch_range_part3(int, int, const RangeCountArgs &, uint32_t, hipStream_t);
+
+hipError_t launch_range_count(int k, int mode, const RangeCountArgs &a, uint32_t nwork, hipStream_t stream)
+{
+    if (nwork == 0) return hipSuccess;
+    switch ((k - 1) / 8) {
+        case 0: return launch_range_part0(k, mode, a, nwork, stream);
+        case 1: return launch_range_part1(k, mode, a, nwork, stream);
+        case 2: return launch_range_part2(k, mode, a, nwork, stream);
+        case 3: return launch_range_part3(k, mode, a, nwork, stream);
+    }
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_range_extract(const unsigned long long *keys, const uint32_t *cnts, uint64_t slots,
@@ -541,6 +575,7 @@ hipError_t launch_range_extract(const unsigned long long *keys, const uint32_t *
                        min_copies, out, out_n, out_cap);
     return hipGetLastError();
 }
+#endif  // SK_PART == 0
 
 // ---------------------------------------------------------------------------
 // dispatch tables
@@ -561,20 +596,35 @@ static hipError_t launch_k(int k, const SketchArgs &a, uint32_t nwork, size_t sm
 {
     switch (k) {
 #define MG_CASE(KK) case KK: return launch_one<KK, MODE, NT>(a, nwork, smem, st);
-        MG_CASE(1) MG_CASE(2) MG_CASE(3) MG_CASE(4) MG_CASE(5) MG_CASE(6) MG_CASE(7) MG_CASE(8)
-        MG_CASE(9) MG_CASE(10) MG_CASE(11) MG_CASE(12) MG_CASE(13) MG_CASE(14) MG_CASE(15) MG_CASE(16)
-        MG_CASE(17) MG_CASE(18) MG_CASE(19) MG_CASE(20) MG_CASE(21) MG_CASE(22) MG_CASE(23) MG_CASE(24)
-        MG_CASE(25) MG_CASE(26) MG_CASE(27) MG_CASE(28) MG_CASE(29) MG_CASE(30) MG_CASE(31) MG_CASE(32)
+        MG_CASE(SK_K0 + 1) MG_CASE(SK_K0 + 2) MG_CASE(SK_K0 + 3) MG_CASE(SK_K0 + 4)
+        MG_CASE(SK_K0 + 5) MG_CASE(SK_K0 + 6) MG_CASE(SK_K0 + 7) MG_CASE(SK_K0 + 8)
 #undef MG_CASE
     }
     return hipErrorInvalidValue;
 }
 
-size_t sketch_smem_bytes(uint32_t cap, int nt)
+static size_t sketch_smem_bytes_impl(uint32_t cap, int nt)
 {
     const size_t tile_dw = (size_t)nt * sk_L(nt) / 4 + 32;
     return (size_t)cap * 8 + tile_dw * 4 + 256 + ((size_t)nt / 64 + 2) * 4 + sizeof(SelState) + 16;
 }
+
+hipError_t SK_PARTFN(launch_sketch_part)(int k, int mode, int nt, const SketchArgs &a, uint32_t nwork,
+                                         hipStream_t stream)
+{
+    const size_t smem = sketch_smem_bytes_impl(a.cap, nt);
+    if (nt == 256) {
+        if (mode == 0) return launch_k<0, 256>(k, a, nwork, smem, stream);
+        if (mode == 1) return launch_k<1, 256>(k, a, nwork, smem, stream);
+        return launch_k<2, 256>(k, a, nwork, smem, stream);
+    }
+    if (mode == 0) return launch_k<0, 1024>(k, a, nwork, smem, stream);
+    if (mode == 1) return launch_k<1, 1024>(k, a, nwork, smem, stream);
+    return launch_k<2, 1024>(k, a, nwork, smem, stream);
+}
+
+#if SK_PART == 0
+size_t sketch_smem_bytes(uint32_t cap, int nt) { return sketch_smem_bytes_impl(cap, nt); }
 
 uint32_t sketch_tile(int nt) { return (uint32_t)nt * sk_L(nt); }
 
@@ -593,24 +643,27 @@ bool sketch_geometry(uint64_t s, int *nt_out, uint32_t *cap_out)
     return false;
 }
 
+hipError_t launch_sketch_part1(int, int, int, const SketchArgs &, uint32_t, hipStream_t);
+hipError_t launch_sketch_part2(int, int, int, const SketchArgs &, uint32_t, hipStream_t);
+hipError_t launch_sketch_part3(int, int, int, const SketchArgs &, uint32_t, hipStream_t);
+
 hipError_t launch_sketch_chunks(int k, int mode, int nt, const SketchArgs &a, uint32_t nwork,
                                 hipStream_t stream)
 {
-    const size_t smem = sketch_smem_bytes(a.cap, nt);
-    if (nt == 256) {
-        if (mode == 0) return launch_k<0, 256>(k, a, nwork, smem, stream);
-        if (mode == 1) return launch_k<1, 256>(k, a, nwork, smem, stream);
-        return launch_k<2, 256>(k, a, nwork, smem, stream);
+    switch ((k - 1) / 8) {
+        case 0: return launch_sketch_part0(k, mode, nt, a, nwork, stream);
+        case 1: return launch_sketch_part1(k, mode, nt, a, nwork, stream);
+        case 2: return launch_sketch_part2(k, mode, nt, a, nwork, stream);
+        case 3: return launch_sketch_part3(k, mode, nt, a, nwork, stream);
     }
-    if (mode == 0) return launch_k<0, 1024>(k, a, nwork, smem, stream);
-    if (mode == 1) return launch_k<1, 1024>(k, a, nwork, smem, stream);
-    return launch_k<2, 1024>(k, a, nwork, smem, stream);
+    return hipErrorInvalidValue;
 }
 
 bool count_supported(uint64_t s)
 {
     return s * 8 + ((size_t)256 * sk_L(256) / 4 + 32) * 4 + 256 + 64 <= 160 * 1024;
 }
+#endif  // SK_PART == 0
 
 template <int K, int MODE>
 static hipError_t launch_count_one(const CountArgs &a, uint32_t nwork, hipStream_t stream)
@@ -629,21 +682,35 @@ static hipError_t launch_count_k(int k, const CountArgs &a, uint32_t nwork, hipS
 {
     switch (k) {
 #define MG_CASE(KK) case KK: return launch_count_one<KK, MODE>(a, nwork, st);
-        MG_CASE(1) MG_CASE(2) MG_CASE(3) MG_CASE(4) MG_CASE(5) MG_CASE(6) MG_CASE(7) MG_CASE(8)
-        MG_CASE(9) MG_CASE(10) MG_CASE(11) MG_CASE(12) MG_CASE(13) MG_CASE(14) MG_CASE(15) MG_CASE(16)
-        MG_CASE(17) MG_CASE(18) MG_CASE(19) MG_CASE(20) MG_CASE(21) MG_CASE(22) MG_CASE(23) MG_CASE(24)
-        MG_CASE(25) MG_CASE(26) MG_CASE(27) MG_CASE(28) MG_CASE(29) MG_CASE(30) MG_CASE(31) MG_CASE(32)
+        MG_CASE(SK_K0 + 1) MG_CASE(SK_K0 + 2) MG_CASE(SK_K0 + 3) MG_CASE(SK_K0 + 4)
+        MG_CASE(SK_K0 + 5) MG_CASE(SK_K0 + 6) MG_CASE(SK_K0 + 7) MG_CASE(SK_K0 + 8)
 #undef MG_CASE
     }
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_count_chunks(int k, int mode, const CountArgs &a, uint32_t nwork, hipStream_t stream)
+hipError_t SK_PARTFN(launch_count_part)(int k, int mode, const CountArgs &a, uint32_t nwork, hipStream_t stream)
 {
-    if (nwork == 0) return hipSuccess;
     if (mode == 0) return launch_count_k<0>(k, a, nwork, stream);
     if (mode == 1) return launch_count_k<1>(k, a, nwork, stream);
     return launch_count_k<2>(k, a, nwork, stream);
+}
+
+#if SK_PART == 0
+hipError_t launch_count_part1(int, int, const CountArgs &, uint32_t, hipStream_t);
+hipError_t launch_count_part2(int, int, const CountArgs &, uint32_t, hipStream_t);
+hipError_t launch_count_part3(int, int, const CountArgs &, uint32_t, hipStream_t);
+
+hipError_t launch_count_chunks(int k, int mode, const CountArgs &a, uint32_t nwork, hipStream_t stream)
+{
+    if (nwork == 0) return hipSuccess;
+    switch ((k - 1) / 8) {
+        case 0: return launch_count_part0(k, mode, a, nwork, stream);
+        case 1: return launch_count_part1(k, mode, a, nwork, stream);
+        case 2: return launch_count_part2(k, mode, a, nwork, stream);
+        case 3: return launch_count_part3(k, mode, a, nwork, stream);
+    }
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_count_tstar(const uint32_t *nhash, uint32_t *counts, const unsigned long long *firstpos,
@@ -674,5 +741,7 @@ hipError_t launch_merge_chunks(int nt, const MergeArgs &a, uint32_t nwork, hipSt
     }
     return hipGetLastError();
 }
+
+#endif  // SK_PART == 0
 
 }  // namespace mg
