@@ -159,7 +159,7 @@ __device__ void compact_buffer(uint64_t *buf, SelState *st, uint32_t *s_wsum, ui
 
 // ---------------------------------------------------------------------------
 // MODE 0: DNA canonical, 1: DNA forward-only (-n), 2: table alphabet forward-only
-template <int K, int MODE, int NT>
+template <int K, int MODE, int NT, bool PROBE>
 __global__ __launch_bounds__(NT) void sketch_chunks_kernel(SketchArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(NT) void sketch_chunks_kernel(SketchArgs a)
     const unsigned long long *probe_keys = a.probe_keys;
     uint32_t *probe_obs = a.probe_obs;
     const uint64_t probe_mask = a.probe_mask, probe_max = a.probe_max;
-    const bool probing = probe_keys != nullptr;
+    constexpr bool probing = PROBE;                        // fused table probe (mash screen) compiled in or out
 
     for (uint64_t t0 = w.begin; t0 < w.end; t0 += TILE) {
         // ---- stage the tile: bytes [a0, a0 + TILE_DW*4), a0 = t0 rounded down to 16 ----
@@ -583,7 +583,7 @@ hipError_t launch_range_extract(const unsigned long long *keys, const uint32_t *
 template <int K, int MODE, int NT>
 static hipError_t launch_one(const SketchArgs &a, uint32_t nwork, size_t smem, hipStream_t stream)
 {
-    auto kern = sketch_chunks_kernel<K, MODE, NT>;
+    auto kern = a.probe_keys ? sketch_chunks_kernel<K, MODE, NT, true> : sketch_chunks_kernel<K, MODE, NT, false>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
