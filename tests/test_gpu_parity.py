@@ -613,3 +613,39 @@ def test_c3_scale_triangle_properties(eng, oracle):
     same = (np.arange(i) % 400) == (i % 400)
     assert row[same].min() > 300 and row[~same].max() < 50
     table.free()
+
+
+@pytest.mark.parametrize("contiguous", [False, True])
+def test_c3_scale_filter_and_cluster_layouts(eng, oracle, contiguous):
+    """Thresholded all-pairs at N = 47 000 (1.1e9 pairs: two device row blocks) against the full
+    count matrix thresholded with torch; clusters interleaved or laid out as runs of
+    consecutive rows (every tile then holds 16 related rows: distinct-first buckets, single
+    representative verification), sampled rows against the oracle."""
+    import torch
+    from mash_amd import synth_torch
+    n, s, k = 47000, 1000, 21
+    dev = torch.device("cuda", 0)
+    hashes, nhash, lengths = synth_torch.clustered_sketch_table(n, s, clusters=470, device=dev, contiguous=contiguous)
+    table = eng.table_wrap(hashes.data_ptr(), nhash.data_ptr(), lengths.data_ptr(), n, s)
+    out = torch.empty((n * (n - 1) // 2, 2), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    eng.compare_tri_dev(table, 0, n, out.data_ptr())
+    eng.synchronize()
+    th = hashes.cpu().numpy().view(np.uint64)
+    tn = nhash.cpu().numpy().astype(np.uint32)
+    tl = lengths.cpu().numpy().astype(np.uint64)
+    for i in (3, 1234, 23456, 46999):
+        numer, denom = _oracle_tri(oracle, th, tn, tl, i, i + 1)
+        row = out[i * (i - 1) // 2: i * (i - 1) // 2 + i].cpu().numpy()
+        assert np.array_equal(row[:, 0], numer) and np.array_equal(row[:, 1], denom), i
+    max_d = 0.05
+    t_min = min(x for x in range(s + 1) if _py_distance(x, s, k) <= max_d)
+    assert int(out[:, 1].min()) == s
+    keep = torch.nonzero(out[:, 0] >= t_min).squeeze(1)
+    edges = eng.compare_tri_filter(table, k, max_d, capacity=1 << 24)
+    assert len(edges) == int(keep.numel()) > 100000
+    flat = (edges["row"].astype(np.int64) * (edges["row"].astype(np.int64) - 1)) // 2 + edges["col"].astype(np.int64)
+    assert np.array_equal(flat, keep.cpu().numpy())                       # same pairs, reference order
+    assert np.array_equal(edges["numer"], out[keep, 0].cpu().numpy().astype(np.uint32))
+    table.free()
+
