@@ -11,6 +11,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <charconv>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -673,13 +674,47 @@ int cmd_sketch(int argc, const char **argv)
     return 0;
 }
 
-void print_pair_line(const Ref &ref, const Ref &qry, bool comment, const mg_pair &pr)
+// Bulk result lines: same bytes `cout << double` would print (default precision 6 == "%g" ==
+// to_chars general/6), but buffered and without a flush per line -- at 10^8 lines the
+// reference's `<< endl` formatting is what a run waits for once the kernels take milliseconds.
+struct FastOut {
+    string buf;
+    FastOut() { buf.reserve(1u << 22); }
+    ~FastOut() { flush(); }
+    void flush()
+    {
+        cout.flush();
+        if (!buf.empty()) { fwrite(buf.data(), 1, buf.size(), stdout); fflush(stdout); buf.clear(); }
+    }
+    void room() { if (buf.size() > (1u << 22) - 4096) flush(); }
+    FastOut &operator<<(const string &x) { buf += x; return *this; }
+    FastOut &operator<<(const char *x) { buf += x; return *this; }
+    FastOut &operator<<(char x) { buf += x; return *this; }
+    FastOut &operator<<(double v)
+    {
+        char t[40];
+        auto r = std::to_chars(t, t + sizeof t, v, std::chars_format::general, 6);
+        buf.append(t, r.ptr);
+        return *this;
+    }
+    FastOut &operator<<(uint32_t v)
+    {
+        char t[16];
+        auto r = std::to_chars(t, t + sizeof t, v);
+        buf.append(t, r.ptr);
+        return *this;
+    }
+    void eol() { buf += '\n'; room(); }
+};
+
+void print_pair_line(FastOut &out, const Ref &ref, const Ref &qry, bool comment, const mg_pair &pr)
 {
-    cout << ref.name;
-    if (comment) cout << ':' << ref.comment;
-    cout << '\t' << qry.name;
-    if (comment) cout << ':' << qry.comment;
-    cout << '\t' << pr.distance << '\t' << pr.p_value << '\t' << pr.numer << '/' << pr.denom << endl;
+    out << ref.name;
+    if (comment) out << ':' << ref.comment;
+    out << '\t' << qry.name;
+    if (comment) out << ':' << qry.comment;
+    out << '\t' << pr.distance << '\t' << pr.p_value << '\t' << pr.numer << '/' << pr.denom;
+    out.eol();
 }
 
 // Thresholded runs (-d < 1): the distance filter and compaction run on the device
@@ -778,6 +813,7 @@ int cmd_dist(int argc, const char **argv)
     const uint64_t qblock = std::max<uint64_t>(1, (1ull << 24) / nref);
     vector<mg_counts> counts;
     vector<mg_pair> pairs;
+    FastOut out;
     if (!table && edge_filter_wanted(d_max)) {
         vector<mg_edge> edges;
         const uint64_t fblock = std::max<uint64_t>(1, (1ull << 30) / nref);
@@ -789,7 +825,7 @@ int cmd_dist(int argc, const char **argv)
             mg_pair pr;
             for (const mg_edge &e : edges)
                 if (finish_edge(e, len_ref[e.col], len_qry[e.row], ref.p.kmer, kspace, p_max, pr))
-                    print_pair_line(ref.refs[e.col], qry.refs[e.row], comment, pr);
+                    print_pair_line(out, ref.refs[e.col], qry.refs[e.row], comment, pr);
         }
         mg_table_free(tr);
         mg_table_free(tq);
@@ -803,13 +839,13 @@ int cmd_dist(int argc, const char **argv)
         if (mg_compare_rect_host(gpu.ctx, tr, tq, q0, q1, counts.data()) != MG_OK) { cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl; return 1; }
         mg_finish_rect_host(counts.data(), len_ref.data(), nref, len_qry.data() + q0, q1 - q0, ref.p.kmer, kspace, d_max, p_max, pairs.data());
         for (uint64_t q = q0; q < q1; q++) {                 // writeOutput, CommandDistance.cpp:247-304
-            if (table) cout << qry.refs[q].name;
+            if (table) out << qry.refs[q].name;
             for (uint64_t r = 0; r < nref; r++) {
                 const mg_pair &pr = pairs[(q - q0) * nref + r];
-                if (table) { cout << '\t'; if (pr.pass) cout << pr.distance; }
-                else if (pr.pass) print_pair_line(ref.refs[r], qry.refs[q], comment, pr);
+                if (table) { out << '\t'; if (pr.pass) out << pr.distance; out.room(); }
+                else if (pr.pass) print_pair_line(out, ref.refs[r], qry.refs[q], comment, pr);
             }
-            if (table) cout << endl;
+            if (table) out.eol();
         }
     }
     mg_table_free(tr);
@@ -863,6 +899,7 @@ int cmd_triangle(int argc, const char **argv)
     vector<mg_counts> counts;
     vector<mg_pair> pairs;
     uint64_t r0 = 1;
+    FastOut out;
     if (edge && edge_filter_wanted(d_max)) {
         vector<mg_edge> edges;
         while (r0 < n) {
@@ -873,9 +910,11 @@ int cmd_triangle(int argc, const char **argv)
                 return 1;
             mg_pair pr;
             for (const mg_edge &e : edges)
-                if (finish_edge(e, lengths[e.row], lengths[e.col], set.p.kmer, kspace, p_max, pr))
-                    cout << label(set.refs[e.row]) << '\t' << label(set.refs[e.col]) << '\t' << pr.distance << '\t'
-                         << pr.p_value << '\t' << pr.numer << '/' << pr.denom << endl;
+                if (finish_edge(e, lengths[e.row], lengths[e.col], set.p.kmer, kspace, p_max, pr)) {
+                    out << label(set.refs[e.row]) << '\t' << label(set.refs[e.col]) << '\t' << pr.distance << '\t'
+                        << pr.p_value << '\t' << pr.numer << '/' << pr.denom;
+                    out.eol();
+                }
             r0 = r1;
         }
     }
@@ -889,19 +928,22 @@ int cmd_triangle(int argc, const char **argv)
         uint64_t idx = 0;
         for (uint64_t i = r0; i < r1; i++) {                 // writeOutput, CommandTriangle.cpp:159-198
             const Ref &ref = set.refs[i];
-            if (!edge) cout << label(ref);
+            if (!edge) out << label(ref);
             for (uint64_t j = 0; j < i; j++, idx++) {
                 const mg_pair &pr = pairs[idx];
                 if (edge) {
-                    if (pr.pass)
-                        cout << label(ref) << '\t' << label(set.refs[j]) << '\t' << pr.distance << '\t' << pr.p_value << '\t'
-                             << pr.numer << '/' << pr.denom << endl;
+                    if (pr.pass) {
+                        out << label(ref) << '\t' << label(set.refs[j]) << '\t' << pr.distance << '\t' << pr.p_value << '\t'
+                            << pr.numer << '/' << pr.denom;
+                        out.eol();
+                    }
                 } else {
-                    cout << '\t' << pr.distance;
+                    out << '\t' << pr.distance;
+                    out.room();
                 }
                 if (pr.p_value > p_peak) p_peak = pr.p_value;
             }
-            if (!edge) cout << endl;
+            if (!edge) out.eol();
         }
         r0 = r1;
     }
