@@ -273,6 +273,36 @@ def test_compare_extremes_and_random(eng, oracle):
     t.free()
 
 
+@pytest.mark.parametrize("kernel", ["merged", "tiled"])
+@pytest.mark.parametrize("top", [0xFFFFFFFF, 0xFFFFFFFFFFFFFFFE, 0xFFFFFFFE00000000])
+def test_compare_values_at_the_top_of_the_hash_range(eng, oracle, kernel, top, monkeypatch):
+    """32-bit sketches reaching 0xFFFFFFFF / 64-bit sketches reaching 2^64-2: the prefix image
+    reserves 0xFFFFFFFE (sentinel) and 0xFFFFFFFF (padding), so the shift must keep real
+    prefixes below them; short rows, shared top values and a row holding only the top value."""
+    monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", kernel)
+    rng = np.random.default_rng(top % 1000)
+    n, s = 40, 64
+    table = np.full((n, s), np.uint64(0xFFFFFFFFFFFFFFFF), dtype=np.uint64)
+    nhash = np.zeros(n, dtype=np.uint32)
+    pool = np.unique(np.concatenate([
+        (rng.integers(0, 2 ** 62, 150).astype(np.uint64) % np.uint64(top)),
+        np.array([top, top - 1, top - 2, top - 3, top >> 1, (top >> 1) + 1, 0, 1], dtype=np.uint64)]))
+    for i in range(n):
+        k = int(rng.integers(1, s + 1))
+        row = np.sort(rng.choice(pool, size=min(k, len(pool)), replace=False))
+        if i % 3 == 0:
+            row = np.unique(np.concatenate([row[: s - 2], np.array([top - 1, top], dtype=np.uint64)]))
+        table[i, : len(row)] = row
+        nhash[i] = len(row)
+    table[5, :] = np.uint64(0xFFFFFFFFFFFFFFFF); table[5, 0] = np.uint64(top); nhash[5] = 1
+    lengths = np.full(n, 1000, dtype=np.uint64)
+    t = eng.table_upload(table, nhash, lengths)
+    got = eng.compare_tri_host(t)
+    numer, denom = _oracle_tri(oracle, table, nhash, lengths, 0, n)
+    assert np.array_equal(got["numer"], numer) and np.array_equal(got["denom"], denom)
+    t.free()
+
+
 def test_compare_rect_and_golden_dist(eng, oracle, golden_dir):
     """mash dist genomes.msh reads.msh == test/ref/genomes.dist, via rect compare + finish."""
     gh, glens, names = helpers.load_golden_genomes()
