@@ -212,10 +212,13 @@ def main():
     bytes_per_pair = 2 * S * 8 + 8
     achieved = (my_pairs * bytes_per_pair / (kern_ms * 1e-3)) / 1e9 if kern_ms > 0 else 0.0
     traffic = None
+    units = None
     pmc_path = os.path.join(ROOT, "profiles", "compare_pmc_latest.json")
     if os.path.exists(pmc_path):
         try:
-            traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+            pmc = json.load(open(pmc_path))
+            traffic = pmc.get("hbm_bytes_per_launch")
+            units = pmc.get("units")
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -224,6 +227,7 @@ def main():
                 "algorithmic_bytes_per_pair": bytes_per_pair,
                 "measured_hbm_frac": (round(traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                                       if traffic and kern_ms > 0 and n == 100_000 and world == 1 else None),
+                "units": units,           # PMC pass over this command: VALU / SALU issue, LDS activity
                 "note": "achieved/frac use the mandated no-reuse model of SURVEY.md §8d (2*s*8+8 B per pair); every "
                         "sketch is re-used ~1000x from LDS/L2, so frac exceeds 1. traffic = PMC-measured HBM bytes per "
                         "launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/compare_pmc_latest.json); measured_hbm_frac = "
@@ -286,10 +290,13 @@ def main():
         assert int(sk_nhash.min()) == S, "sketch output failed sanity check"
         sk_bytes = ng * (L + 8 * S)                   # 1 B/base in + 8*s B per sketch out
         sk_traffic = None
+        sk_units = None
         sk_pmc = os.path.join(ROOT, "profiles", "sketch_pmc_latest.json")
         if os.path.exists(sk_pmc) and world == 1 and args.n_genomes == 10_000 and L == 1_000_000:
             try:
-                sk_traffic = json.load(open(sk_pmc)).get("hbm_bytes_per_launch")
+                pmc = json.load(open(sk_pmc))
+                sk_traffic = pmc.get("hbm_bytes_per_launch")
+                sk_units = pmc.get("units")
             except Exception:
                 sk_traffic = None
         sk_ach = sk_bytes / (sk_ms * 1e-3) / 1e9 if sk_ms > 0 else 0.0
@@ -299,10 +306,11 @@ def main():
                                          f"ASCII bases resident in HBM, sharded x{world}"},
                   "roofline": {"bound": "hbm", "achieved": round(sk_ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(sk_ach / HBM_PEAK_GBS, 4), "traffic": sk_traffic,
-                               "kernel": "sketch_chunks_kernel<21,0,256>", "kernel_ms": round(sk_ms, 3),
-                               "launches": sk_launches,
-                               "note": "integer-ALU bound: PMC shows VALU 95% busy at ~176 VALU instructions per k-mer "
-                                       "(10 64-bit multiplies), HBM traffic = algorithmic bytes; see DESIGN.md"}}
+                               "kernel": "sketch_chunks_kernel<21,0,256,false>", "kernel_ms": round(sk_ms, 3),
+                               "launches": sk_launches, "units": sk_units,
+                               "note": "integer-ALU bound: PMC shows the VALU issuing 98% of the time at ~176 VALU "
+                                       "instructions per k-mer (10 64-bit multiplies), HBM traffic = algorithmic "
+                                       "bytes; see DESIGN.md"}}
         if rank == 0 and world == 1 and not args.no_cpu:
             sketch["cpu_baseline"] = cpu_baseline_sketch(min(args.cpu_seconds, 6.0))
         result["sketch"] = sketch
