@@ -295,9 +295,11 @@ class MashGpu:
         return Table(self, h, keep)
 
     # ---- comparing -------------------------------------------------------------
-    def compare_tri_host(self, table, row_begin=0, row_end=None):
+    def compare_tri_host(self, table, row_begin=0, row_end=None, out=None):
         row_end = table.rows if row_end is None else min(row_end, table.rows)
-        out = np.zeros(tri_pairs(row_begin, row_end), dtype=COUNTS_DTYPE)
+        if out is None:
+            out = np.zeros(tri_pairs(row_begin, row_end), dtype=COUNTS_DTYPE)
+        assert out.dtype == COUNTS_DTYPE and len(out) >= tri_pairs(row_begin, row_end) and out.flags.c_contiguous
         self._check(self.lib.mg_compare_tri_host(self.ctx, table.handle, row_begin, row_end, out.ctypes.data))
         return out
 

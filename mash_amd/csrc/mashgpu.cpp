@@ -851,7 +851,6 @@ static int compare_host(mg_ctx *ctx, const mg_table *rows, const mg_table *cols,
         r = r2;
     }
     if (d_out) hipFree(d_out);
-    (void)tri_pairs;
     return rc;
 }
 
