@@ -10,6 +10,15 @@ struct CompareTile {
     uint32_t col0, col1;    // columns [col0, col1)
 };
 
+// Tile of the merged-rows kernel: up to 16 rows given EXPLICITLY (ascending row indices,
+// 0xFFFFFFFF = unused slot) and a column range.  Rows of one tile need not be adjacent: the
+// host groups rows of similar hash density (see run_compare), because one linear
+// value -> bucket map per tile only spreads entries evenly when its rows are equally dense.
+struct MergedTile {
+    uint32_t rows[16];
+    uint32_t col0, col1;
+};
+
 struct CompareArgs {
     const uint64_t *row_hashes;   // table whose rows sit in LDS (triangle: the table; rect: queries)
     const uint32_t *row_nhash;
@@ -18,6 +27,7 @@ struct CompareArgs {
     const uint32_t *row_pfx;      // u32 prefix images (value >> pfx_shr, saturated), same strides
     const uint32_t *col_pfx;
     const CompareTile *tiles;
+    const MergedTile *mtiles;     // merged kernel
     uint2 *out;                   // {numer, denom}
     uint64_t row_stride, col_stride;
     uint64_t row_pfx_stride, col_pfx_stride;   // strides of the padded prefix images
@@ -44,6 +54,9 @@ hipError_t launch_compare_merged(const CompareArgs &a, uint32_t ntiles, hipStrea
 // table max (u64 atomicMax over the last valid entry of every row) and prefix image
 hipError_t launch_table_max(const uint64_t *hashes, const uint32_t *nhash, uint64_t n, uint64_t stride,
                             unsigned long long *out_max, hipStream_t stream);
+// density class of every row: bit length of (largest hash / number of hashes), 0 for empty rows
+hipError_t launch_row_classes(const uint64_t *hashes, const uint32_t *nhash, uint64_t n, uint64_t stride,
+                              uint8_t *out, unsigned long long *last_out, hipStream_t stream);
 uint64_t compare_pfx_stride(uint64_t s);          // row stride (u32 entries) of the padded prefix image
 hipError_t launch_make_prefix(const uint64_t *hashes, const uint32_t *nhash, uint64_t n, uint64_t s,
                               uint64_t pfx_stride, uint32_t shr, uint32_t *out, hipStream_t stream);

@@ -41,6 +41,7 @@ struct MergedHdr {
     uint32_t nent;       // total entries E
     uint32_t row_n[32];
     uint32_t row_base[32];   // first entry id of row r in (row, index) enumeration order
+    uint32_t row_id[32];     // table row index of slot r (0xFFFFFFFF = unused)
 };
 
 // tag = row << idx_bits | index-in-row ; idx_bits = bits needed for an index < s (>= 10)
@@ -89,10 +90,12 @@ uint32_t compare_merged_rows(uint32_t s)
     return r;
 }
 
+// values beyond the image's range saturate to 0xFFFFFFFD (0xFFFFFFFE = table sentinel,
+// 0xFFFFFFFF = padding); the rows a shift was chosen for stay below all three
 __device__ __forceinline__ uint32_t mr_prefix(uint64_t v, uint32_t shr)
 {
     const uint64_t t = v >> shr;
-    return (t >> 32) != 0 ? 0xFFFFFFFFu : (uint32_t)t;
+    return t >= 0xFFFFFFFDull ? 0xFFFFFFFDu : (uint32_t)t;
 }
 
 template <int KU>
@@ -113,7 +116,9 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
     __shared__ uint32_t s_wsum[MR_NW + 2];
     __shared__ uint64_t s_rowmax[32];
 
-    const CompareTile tile = a.tiles[blockIdx.x];
+    // (fields are read individually: indexing a by-value copy of rows[] would put the tile in scratch)
+    const MergedTile *tile_p = a.mtiles + blockIdx.x;
+    struct { uint32_t col0, col1; } tile = {tile_p->col0, tile_p->col1};
     const int tid = threadIdx.x;
     if (a.dbg && tid == 0) a.dbg[3 * (uint64_t)blockIdx.x] = __builtin_readcyclecounter();
     const uint32_t lane = tid & 63;
@@ -123,15 +128,16 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
     if (tid < 32) {
         uint32_t n = 0;
         uint64_t mx = 0;
-        if ((uint32_t)tid < R) {
-            const uint64_t i = (uint64_t)tile.row0 + tid;
-            if (i < a.row_end) {
-                n = a.row_nhash[i];
-                if (n > s) n = s;
-                if (n > 0) mx = a.row_pfx[i * a.row_pfx_stride + n - 1];
-            }
+        uint32_t rid = 0xFFFFFFFFu;
+        if ((uint32_t)tid < R && tid < 16) rid = tile_p->rows[tid];
+        if (rid != 0xFFFFFFFFu) {
+            const uint64_t i = rid;
+            n = a.row_nhash[i];
+            if (n > s) n = s;
+            if (n > 0) mx = a.row_pfx[i * a.row_pfx_stride + n - 1];
         }
         hdr->row_n[tid] = n;
+        hdr->row_id[tid] = rid;
         s_rowmax[tid] = mx;
     }
     for (uint32_t b = tid; b < (NB + 8) / 2; b += MR_NT) cnt32[b] = 0;
@@ -168,7 +174,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
         e_pfx[t] = 0;
         e_tag[t] = 0;
         if (r < R && idx < hdr->row_n[r]) {
-            const uint32_t x = a.row_pfx[((uint64_t)tile.row0 + r) * a.row_pfx_stride + idx];
+            const uint32_t x = a.row_pfx[(uint64_t)hdr->row_id[r] * a.row_pfx_stride + idx];
             const uint32_t bk = __umulhi(x, scale);
             const uint32_t old = atomicAdd(&cnt32[bk >> 1], (bk & 1u) ? 0x10000u : 1u);
             const uint32_t slot = (bk & 1u) ? (old >> 16) : (old & 0xFFFFu);
@@ -248,8 +254,8 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
                         nd++;
                     } else {
                         const uint32_t tg0 = tag[st + d], tg1 = ti;
-                        const uint64_t v0 = a.row_hashes[((uint64_t)tile.row0 + (tg0 >> idx_bits)) * a.row_stride + (tg0 & idx_mask)];
-                        const uint64_t v1 = a.row_hashes[((uint64_t)tile.row0 + (tg1 >> idx_bits)) * a.row_stride + (tg1 & idx_mask)];
+                        const uint64_t v0 = a.row_hashes[(uint64_t)hdr->row_id[tg0 >> idx_bits] * a.row_stride + (tg0 & idx_mask)];
+                        const uint64_t v1 = a.row_hashes[(uint64_t)hdr->row_id[tg1 >> idx_bits] * a.row_stride + (tg1 & idx_mask)];
                         if (v0 != v1) hdr->collide = 1;
                     }
                 }
@@ -263,7 +269,8 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
     if (a.dbg && tid == 0) a.dbg[3 * (uint64_t)blockIdx.x + 1] = __builtin_readcyclecounter();
     // ------------------------------------------------------------------ stream columns
     const uint32_t my_n = lane < 32 ? hdr->row_n[lane] : 0;                // row `lane`
-    const uint32_t *my_row = a.row_pfx + ((uint64_t)tile.row0 + (((uint64_t)tile.row0 + lane < a.row_end && lane < R) ? lane : 0)) * a.row_pfx_stride;
+    const uint32_t my_id = lane < 32 ? hdr->row_id[lane] : 0xFFFFFFFFu;     // table row of slot `lane`
+    const uint32_t *my_row = a.row_pfx + (uint64_t)(my_id != 0xFFFFFFFFu ? my_id : hdr->row_id[0]) * a.row_pfx_stride;
 
     // Column streaming is software-pipelined with UNCONDITIONAL loads (indices clamped into
     // the row, which is padded to s entries) so the compiler can count vmcnt exactly:
@@ -278,8 +285,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
             dst[u] = src[q];                              // rows of the image are padded (0xFFFFFFFF)
         }
     };
-    const uint32_t rmax = (a.row_end - tile.row0) < (uint64_t)R ? (uint32_t)(a.row_end - tile.row0) : R;
-    const uint32_t rows_all = rmax >= 32 ? 0xFFFFFFFFu : ((1u << rmax) - 1u);
+    const uint32_t rows_all = (uint32_t)__ballot(my_id != 0xFFFFFFFFu);       // slots in use
     // Wave w owns batches of MR_CB consecutive columns: batch k -> columns
     // col0 + (k*NW + w)*CB ... +CB-1.  Results of a batch are staged in LDS and written
     // as 64-B row segments (nontemporal), instead of 8-B scattered stores that thrash L2.
@@ -292,8 +298,8 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const uint32_t r = lane >> 2, c0 = (lane & 3u) * 2;
-        const uint64_t i = (uint64_t)tile.row0 + r;
-        if (r < R && i < a.row_end) {
+        const uint64_t i = (uint32_t)__shfl((int)my_id, (int)r);           // table row of slot r
+        if (r < R && i != 0xFFFFFFFFull) {
             const uint4 v = *reinterpret_cast<const uint4 *>(&stage[r * MR_CB + c0]);
             const uint64_t j0 = (uint64_t)jb + c0;
             const bool ok0 = c0 < ncols_done && (!a.triangle || j0 < i);
@@ -333,10 +339,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
         for (int u = 0; u < MR_KU; u++) cur[u] = ncol[u];
         // rows of the tile this column is compared with (triangle: only rows i > j)
         uint32_t valid = rows_all;
-        if (a.triangle && j >= tile.row0) {
-            const uint32_t lo = j - tile.row0 + 1;
-            valid = lo >= 32 ? 0u : (valid & ~((1u << lo) - 1u));
-        }
+        if (a.triangle) valid &= (uint32_t)__ballot(my_id != 0xFFFFFFFFu && my_id > j);
         uint32_t active = valid, brokem = 0;
         uint32_t st_call = 0, st_common = 0;                             // lane r <-> row r
         const uint32_t ngroups = valid == 0 ? 0 : (nB + 64 * MR_KU - 1) / (64 * MR_KU);
@@ -432,7 +435,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
                                     if (pfx[e] == x[u]) take(tag[e]);
                             }
                             if (rep != 0xFFFFFFFFu) {
-                                const uint64_t v = a.row_hashes[((uint64_t)tile.row0 + (rep >> idx_bits)) * a.row_stride + (rep & idx_mask)];
+                                const uint64_t v = a.row_hashes[(uint64_t)hdr->row_id[rep >> idx_bits] * a.row_stride + (rep & idx_mask)];
                                 if (v != b) rowmask = 0;                  // same prefix, different value
                             }
                         }
@@ -473,7 +476,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
                             if (h[u][w] == x[u] && st + w < E) {
                                 const uint32_t tg = tag[st + w];
                                 const uint32_t r = tg >> idx_bits, idx = tg & idx_mask;
-                                const uint64_t v = a.row_hashes[((uint64_t)tile.row0 + r) * a.row_stride + idx];
+                                const uint64_t v = a.row_hashes[(uint64_t)hdr->row_id[r] * a.row_stride + idx];
                                 if (v == b) { rowmask |= 1u << r; hit_tag[w] = tg; }
                             }
                         }
@@ -485,7 +488,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
                                 if (pfx[e] == x[u]) {
                                     const uint32_t tg = tag[e];
                                     const uint32_t r = tg >> idx_bits, idx = tg & idx_mask;
-                                    const uint64_t v = a.row_hashes[((uint64_t)tile.row0 + r) * a.row_stride + idx];
+                                    const uint64_t v = a.row_hashes[(uint64_t)hdr->row_id[r] * a.row_stride + idx];
                                     if (v == b) rowmask |= 1u << r;
                                 }
                             }
@@ -512,7 +515,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
                             for (uint32_t e = extra_lo; e < extra_hi; e++) {
                                 const uint32_t tg = tag[e];
                                 if (pfx[e] == x[u] && (tg >> idx_bits) == r) {
-                                    const uint64_t v = a.row_hashes[((uint64_t)tile.row0 + r) * a.row_stride + (tg & idx_mask)];
+                                    const uint64_t v = a.row_hashes[(uint64_t)hdr->row_id[r] * a.row_stride + (tg & idx_mask)];
                                     if (v == b) idx = tg & idx_mask;
                                 }
                             }
@@ -607,6 +610,33 @@ hipError_t launch_table_max(const uint64_t *hashes, const uint32_t *nhash, uint6
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(table_max_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, hashes, nhash, n,
                        stride, out_max);
+    return hipGetLastError();
+}
+
+__global__ void row_classes_kernel(const uint64_t *hashes, const uint32_t *nhash, uint64_t n, uint64_t stride,
+                                   uint8_t *out, unsigned long long *last_out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t k = nhash[i];
+    if (k > stride) k = stride;
+    uint8_t c = 0;
+    unsigned long long last = 0;
+    if (k > 0) {
+        last = hashes[i * stride + k - 1];
+        const uint64_t gap = last / k;                                   // mean spacing of the row's hashes
+        c = (uint8_t)(64 - __clzll((long long)(gap | 1ull)));
+    }
+    out[i] = c;
+    last_out[i] = last;
+}
+
+hipError_t launch_row_classes(const uint64_t *hashes, const uint32_t *nhash, uint64_t n, uint64_t stride,
+                              uint8_t *out, unsigned long long *last_out, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(row_classes_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, hashes, nhash, n,
+                       stride, out, last_out);
     return hipGetLastError();
 }
 

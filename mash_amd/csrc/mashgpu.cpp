@@ -45,8 +45,9 @@ struct mg_table {
     // lazily built by the compare path (cached across calls; the table is immutable)
     mutable bool have_max = false;
     mutable uint64_t maxval = 0;
-    mutable uint32_t *pfx = nullptr;      // u32 prefix image [n * s]
-    mutable int pfx_shr = -1;
+    mutable std::vector<std::pair<int, uint32_t *>> pfx;   // u32 prefix images, one per shift in use
+    mutable std::vector<uint8_t> cls;     // density class per row (host copy, see table_classes)
+    mutable std::vector<uint64_t> last;   // largest hash per row (host copy)
 };
 
 #define HIP_TRY(ctx, call)                                                           \
@@ -625,7 +626,7 @@ int mg_table_wrap_dev(mg_ctx *ctx, const uint64_t *hashes_dev, const uint32_t *n
 void mg_table_free(mg_table *t)
 {
     if (!t) return;
-    if (t->pfx) { hipSetDevice(t->ctx->device); hipFree(t->pfx); }
+    if (!t->pfx.empty()) { hipSetDevice(t->ctx->device); for (auto &im : t->pfx) hipFree(im.second); }
     if (t->owns) {
         hipSetDevice(t->ctx->device);
         hipFree((void *)t->hashes);
@@ -660,14 +661,46 @@ static int table_max(mg_ctx *ctx, const mg_table *t, uint64_t *out)
     return MG_OK;
 }
 
-// u32 prefix image of a table for shift `shr` (cached)
-static int table_prefix(mg_ctx *ctx, const mg_table *t, int shr)
+// u32 prefix image of a table for shift `shr` (cached; a table mixing very different hash
+// densities is compared class by class, each class through its own shift)
+static int table_prefix(mg_ctx *ctx, const mg_table *t, int shr, const uint32_t **out)
 {
-    if (t->pfx && t->pfx_shr == shr) return MG_OK;
+    for (auto &im : t->pfx)
+        if (im.first == shr) { *out = im.second; return MG_OK; }
+    if (t->pfx.size() >= 24) {                             // keep the cache bounded
+        hipStreamSynchronize(ctx->stream);
+        hipFree(t->pfx.front().second);
+        t->pfx.erase(t->pfx.begin());
+    }
     const uint64_t ps = mg::compare_pfx_stride(t->s);
-    if (!t->pfx) HIP_TRY(ctx, hipMalloc(&t->pfx, std::max<uint64_t>(t->n * ps * 4, 4)));
-    HIP_TRY(ctx, mg::launch_make_prefix(t->hashes, t->nhash, t->n, t->s, ps, (uint32_t)shr, t->pfx, ctx->stream));
-    t->pfx_shr = shr;
+    uint32_t *img = nullptr;
+    HIP_TRY(ctx, hipMalloc(&img, std::max<uint64_t>(t->n * ps * 4, 4)));
+    hipError_t e = mg::launch_make_prefix(t->hashes, t->nhash, t->n, t->s, ps, (uint32_t)shr, img, ctx->stream);
+    if (e != hipSuccess) { hipFree(img); return fail(ctx, MG_ERR_HIP, std::string("compare (prefix image): ") + hipGetErrorString(e)); }
+    t->pfx.emplace_back(shr, img);
+    *out = img;
+    return MG_OK;
+}
+
+// density class of every row (bit length of the mean hash spacing), computed once per table
+static int table_classes(mg_ctx *ctx, const mg_table *t)
+{
+    if (t->cls.size() == t->n) return MG_OK;
+    uint8_t *d = nullptr;
+    unsigned long long *dl = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d, std::max<uint64_t>(t->n, 1)));
+    if (hipMalloc(&dl, std::max<uint64_t>(t->n, 1) * 8) != hipSuccess) { hipFree(d); return fail(ctx, MG_ERR_NOMEM, "compare: allocation failed"); }
+    std::vector<uint8_t> h(t->n);
+    std::vector<uint64_t> hl(t->n);
+    hipError_t e = mg::launch_row_classes(t->hashes, t->nhash, t->n, t->s, d, dl, ctx->stream);
+    if (e == hipSuccess && t->n) e = hipMemcpyAsync(h.data(), d, t->n, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && t->n) e = hipMemcpyAsync(hl.data(), dl, t->n * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipFree(d);
+    hipFree(dl);
+    if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare (row classes): ") + hipGetErrorString(e));
+    t->cls.swap(h);
+    t->last.swap(hl);
     return MG_OK;
 }
 
@@ -684,6 +717,7 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
     a.row_hashes = rows->hashes; a.row_nhash = rows->nhash; a.row_stride = rows->s;
     a.col_hashes = cols->hashes; a.col_nhash = cols->nhash; a.col_stride = cols->s;
     a.tiles = nullptr;
+    a.mtiles = nullptr;
     a.out = reinterpret_cast<uint2 *>(out_dev);
     a.row_begin = row_begin; a.row_end = row_end;
     a.ncols = cols->n;
@@ -706,25 +740,6 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
     a.row_pfx = a.col_pfx = nullptr;
     a.row_pfx_stride = a.col_pfx_stride = 0;
     a.pfx_shr = 0;
-    if (use_merged) {
-        // both tables are viewed through one 32-bit prefix: value >> shr, shr from the larger maximum
-        uint64_t m1 = 0, m2 = 0;
-        int rc = table_max(ctx, rows, &m1);
-        if (rc == MG_OK) rc = table_max(ctx, cols, &m2);
-        if (rc != MG_OK) return rc;
-        const uint64_t mx = std::max(m1, m2) | 1ull;
-        const int bl = 64 - __builtin_clzll(mx);
-        int shr = bl > 32 ? bl - 32 : 0;
-        if ((mx >> shr) >= 0xFFFFFFFEull) shr++;          // 0xFFFFFFFE / 0xFFFFFFFF are reserved (sentinel, padding)
-        rc = table_prefix(ctx, rows, shr);
-        if (rc == MG_OK && cols != rows) rc = table_prefix(ctx, cols, shr);
-        if (rc != MG_OK) return rc;
-        a.row_pfx = rows->pfx;
-        a.col_pfx = cols->pfx;
-        a.row_pfx_stride = mg::compare_pfx_stride(rows->s);
-        a.col_pfx_stride = mg::compare_pfx_stride(cols->s);
-        a.pfx_shr = (uint32_t)shr;
-    }
     uint32_t R = use_merged ? mg::compare_merged_rows(a.s) : mg::compare_rows_per_tile(a.s);
     if (const char *e = getenv("MASHGPU_COMPARE_ROWS")) { uint32_t v = (uint32_t)atoi(e); if (v >= 1 && v < R) R = v; }
     // columns per tile: long tiles amortise the table build and the ragged end of a tile
@@ -733,57 +748,114 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
     if (const char *e = getenv("MASHGPU_COMPARE_COLS")) { uint64_t v = strtoull(e, nullptr, 10); if (v >= 16) CC = v; }
     a.rows_per_tile = R;
     // tiles: column chunk outer, row tile inner (concurrent workgroups share a column chunk in L2)
-    const uint64_t nrt = (row_end - row_begin + R - 1) / R;
     const uint64_t maxcols = triangle ? (row_end - 1) : cols->n;       // columns [0, maxcols)
     std::vector<mg::CompareTile> tiles;
-    for (uint64_t c0 = 0; c0 < maxcols; c0 += CC) {
-        for (uint64_t t = 0; t < nrt; t++) {
-            const uint64_t r0 = row_begin + t * R;
-            const uint64_t rlast = std::min(r0 + R, row_end) - 1;      // largest row index of the tile
-            const uint64_t cend = triangle ? rlast : cols->n;         // columns needed: [0, cend)
-            if (c0 >= cend) continue;
-            mg::CompareTile tl;
-            tl.row0 = (uint32_t)r0;
-            tl.col0 = (uint32_t)c0;
-            tl.col1 = (uint32_t)std::min(c0 + CC, cend);
-            tiles.push_back(tl);
+    if (use_merged) {
+        // Rows are grouped by hash DENSITY before they are cut into tiles of R: one linear
+        // value -> bucket map per tile spreads the entries evenly only if its rows are equally
+        // dense, and collections mix genomes of very different sizes (a virus sketch spans the
+        // whole hash range, a bacterial one its bottom 1/5000).  Within a class rows keep their
+        // order, so a tile's rows stay close together and the triangle's "columns below the
+        // row" rule wastes little: a tile runs to its largest row.  Every class is compared
+        // through its own 32-bit prefix image (value >> shr, shr from the class maximum, larger
+        // values saturate): a prefix must resolve the values of the tile's rows, or equal
+        // prefixes of different values send block after block down the exact path.
+        int rc = table_classes(ctx, rows);
+        if (rc != MG_OK) return rc;
+        std::vector<std::vector<uint32_t>> by_class(65);
+        for (uint64_t i = row_begin; i < row_end; i++) by_class[rows->cls[i] > 64 ? 64 : rows->cls[i]].push_back((uint32_t)i);
+        a.dbg = nullptr;
+        a.row_pfx_stride = mg::compare_pfx_stride(rows->s);
+        a.col_pfx_stride = mg::compare_pfx_stride(cols->s);
+        for (const auto &list : by_class) {
+            if (list.empty()) continue;
+            uint64_t mx = 1;
+            for (uint32_t i : list) mx = std::max(mx, rows->last[i]);
+            const int bl = 64 - __builtin_clzll(mx);
+            int shr = bl > 32 ? bl - 32 : 0;
+            if ((mx >> shr) >= 0xFFFFFFFDull) shr++;      // 0xFFFFFFFD..F: saturated values, sentinel, padding
+            rc = table_prefix(ctx, rows, shr, &a.row_pfx);
+            if (rc == MG_OK) rc = table_prefix(ctx, cols, shr, &a.col_pfx);
+            if (rc != MG_OK) return rc;
+            a.pfx_shr = (uint32_t)shr;
+            std::vector<mg::MergedTile> mtiles;
+            for (uint64_t c0 = 0; c0 < maxcols; c0 += CC) {
+                for (size_t k = 0; k < list.size(); k += R) {
+                    const uint32_t last = list[std::min(list.size(), k + R) - 1];
+                    const uint64_t cend = triangle ? last : cols->n;         // columns needed: [0, cend)
+                    if (c0 >= cend) continue;
+                    mg::MergedTile tl;
+                    for (uint32_t r = 0; r < 16; r++) tl.rows[r] = (r < R && k + r < list.size()) ? list[k + r] : 0xFFFFFFFFu;
+                    tl.col0 = (uint32_t)c0;
+                    tl.col1 = (uint32_t)std::min<uint64_t>(c0 + CC, cend);
+                    mtiles.push_back(tl);
+                }
+            }
+            if (mtiles.empty()) continue;
+            mg::MergedTile *d_mt = nullptr;
+            HIP_TRY(ctx, hipMalloc(&d_mt, mtiles.size() * sizeof(mg::MergedTile)));
+            unsigned long long *d_dbg = nullptr;
+            if (getenv("MASHGPU_COMPARE_DBG")) {
+                hipMalloc(&d_dbg, mtiles.size() * 24);
+                hipMemsetAsync(d_dbg, 0, mtiles.size() * 24, ctx->stream);
+            }
+            a.dbg = d_dbg;
+            hipError_t e = hipMemcpyAsync(d_mt, mtiles.data(), mtiles.size() * sizeof(mg::MergedTile), hipMemcpyHostToDevice,
+                                          ctx->stream);
+            if (e == hipSuccess) {
+                a.mtiles = d_mt;
+                prof_begin(ctx, ctx->prof_compare);
+                e = mg::launch_compare_merged(a, (uint32_t)mtiles.size(), ctx->stream);
+                prof_end(ctx, ctx->prof_compare);
+            }
+            hipError_t e2 = hipStreamSynchronize(ctx->stream);              // the tile list must outlive the launch
+            if (d_dbg) {
+                std::vector<unsigned long long> h(mtiles.size() * 3);
+                hipMemcpy(h.data(), d_dbg, h.size() * 8, hipMemcpyDeviceToHost);
+                double bsum = 0, tsum = 0;
+                for (size_t i = 0; i < mtiles.size(); i++) {
+                    bsum += (double)(h[3 * i + 1] - h[3 * i]);
+                    tsum += (double)(h[3 * i + 2] - h[3 * i]);
+                }
+                fprintf(stderr, "compare dbg: shift %d, %zu rows, %zu tiles, build %.0f clk avg, tile %.0f clk avg\n", shr,
+                        list.size(), mtiles.size(), bsum / mtiles.size(), tsum / mtiles.size());
+                hipFree(d_dbg);
+            }
+            hipFree(d_mt);
+            if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare launch: ") + hipGetErrorString(e));
+            if (e2 != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare kernel: ") + hipGetErrorString(e2));
+        }
+        return MG_OK;
+    } else {
+        const uint64_t nrt = (row_end - row_begin + R - 1) / R;
+        for (uint64_t c0 = 0; c0 < maxcols; c0 += CC) {
+            for (uint64_t t = 0; t < nrt; t++) {
+                const uint64_t r0 = row_begin + t * R;
+                const uint64_t rlast = std::min(r0 + R, row_end) - 1;  // largest row index of the tile
+                const uint64_t cend = triangle ? rlast : cols->n;     // columns needed: [0, cend)
+                if (c0 >= cend) continue;
+                mg::CompareTile tl;
+                tl.row0 = (uint32_t)r0;
+                tl.col0 = (uint32_t)c0;
+                tl.col1 = (uint32_t)std::min(c0 + CC, cend);
+                tiles.push_back(tl);
+            }
         }
     }
     if (tiles.empty()) return MG_OK;
     mg::CompareTile *d_tiles = nullptr;
     HIP_TRY(ctx, hipMalloc(&d_tiles, tiles.size() * sizeof(mg::CompareTile)));
     a.dbg = nullptr;
-    unsigned long long *d_dbg = nullptr;
-    if (getenv("MASHGPU_COMPARE_DBG") && use_merged) {
-        hipMalloc(&d_dbg, tiles.size() * 24);
-        hipMemsetAsync(d_dbg, 0, tiles.size() * 24, ctx->stream);
-        a.dbg = d_dbg;
-    }
-    hipError_t e = hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(mg::CompareTile),
-                                  hipMemcpyHostToDevice, ctx->stream);
+    hipError_t e = hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(mg::CompareTile), hipMemcpyHostToDevice,
+                                  ctx->stream);
     if (e == hipSuccess) {
         a.tiles = d_tiles;
         prof_begin(ctx, ctx->prof_compare);
-        e = use_merged ? mg::launch_compare_merged(a, (uint32_t)tiles.size(), ctx->stream)
-                       : mg::launch_compare_tiled(a, (uint32_t)tiles.size(), ctx->stream);
+        e = mg::launch_compare_tiled(a, (uint32_t)tiles.size(), ctx->stream);
         prof_end(ctx, ctx->prof_compare);
     }
     // the tile list must outlive the launch
     hipError_t e2 = hipStreamSynchronize(ctx->stream);
-    if (d_dbg) {
-        std::vector<unsigned long long> h(tiles.size() * 3);
-        hipMemcpy(h.data(), d_dbg, h.size() * 8, hipMemcpyDeviceToHost);
-        double b = 0, t = 0;
-        unsigned long long t0 = ~0ull, t1 = 0;
-        for (size_t i = 0; i < tiles.size(); i++) {
-            b += (double)(h[3 * i + 1] - h[3 * i]);
-            t += (double)(h[3 * i + 2] - h[3 * i]);
-            t0 = std::min(t0, h[3 * i]); t1 = std::max(t1, h[3 * i + 2]);
-        }
-        fprintf(stderr, "compare dbg: %zu tiles, build %.0f clk avg, tile %.0f clk avg, span %llu clk, sum(tile)/span %.1f\n",
-                tiles.size(), b / tiles.size(), t / tiles.size(), t1 - t0, t / (double)(t1 - t0));
-        hipFree(d_dbg);
-    }
     hipFree(d_tiles);
     if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare launch: ") + hipGetErrorString(e));
     if (e2 != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare kernel: ") + hipGetErrorString(e2));

@@ -22,6 +22,12 @@ def main():
                                                                 contiguous=(a.mode == "contiguous"))
     if a.mode == "identical":
         hashes[:] = hashes[0]
+    if a.mode.startswith("mixed"):
+        # every 10th (mixed) / every 97th (mixed97) row is a "small genome": its sketch spans the
+        # whole 64-bit range instead of the bottom 2^54 (values << 9), like a virus next to bacteria
+        step = 97 if a.mode == "mixed97" else 10
+        sel = torch.arange(0, n, step, device=dev)
+        hashes[sel] = hashes[sel] << 9
     table = eng.table_wrap(hashes.data_ptr(), nhash.data_ptr(), lengths.data_ptr(), n, 1000)
     pairs = n * (n - 1) // 2
     out = torch.empty((pairs, 2), dtype=torch.int32, device=dev)
