@@ -303,6 +303,50 @@ def test_compare_values_at_the_top_of_the_hash_range(eng, oracle, kernel, top, m
     t.free()
 
 
+@pytest.mark.parametrize("kernel", ["merged", "tiled"])
+def test_compare_mixed_hash_densities(eng, oracle, kernel, monkeypatch):
+    """Sketches of very different genome sizes in one table (hash ranges from 2^44 to 2^64):
+    the merged kernel tiles rows by density class and compares every class through its own
+    prefix image; triangle and rect, incl. related sketches across classes and short rows."""
+    monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", kernel)
+    rng = np.random.default_rng(77)
+    n, s = 210, 256
+    table = np.full((n, s), np.uint64(0xFFFFFFFFFFFFFFFF), dtype=np.uint64)
+    nhash = np.zeros(n, dtype=np.uint32)
+    shared = np.sort(rng.integers(1, 2 ** 44, 400).astype(np.uint64))          # small values: in every range
+    for i in range(n):
+        bits = [44, 50, 54, 58, 62, 64][int(rng.integers(0, 6))] if i % 7 else 64
+        k = s if i % 5 else int(rng.integers(1, s))
+        top = (1 << bits) - 2
+        own = rng.integers(1, 2 ** 63, 2 * s).astype(np.uint64) % np.uint64(top)
+        take = np.concatenate([own, rng.choice(shared, size=int(rng.integers(0, 60)), replace=False)])
+        row = np.unique(take)
+        if len(row) > k:
+            row = np.sort(rng.choice(row, size=k, replace=False)) if i % 3 else row[:k]
+        table[i, : len(row)] = row
+        nhash[i] = len(row)
+    table[50] = table[49]; nhash[50] = nhash[49]                               # identical pair
+    lengths = np.full(n, 5000, dtype=np.uint64)
+    t = eng.table_upload(table, nhash, lengths)
+    got = eng.compare_tri_host(t)
+    numer, denom = _oracle_tri(oracle, table, nhash, lengths, 0, n)
+    assert np.array_equal(got["numer"], numer) and np.array_equal(got["denom"], denom)
+    assert numer.max() >= min(nhash[49], s) > 0
+    got2 = eng.compare_tri_host(t, 33, 170)
+    n2, d2 = _oracle_tri(oracle, table, nhash, lengths, 33, 170)
+    assert np.array_equal(got2["numer"], n2) and np.array_equal(got2["denom"], d2)
+    tq = eng.table_upload(table[100:160], nhash[100:160], lengths[100:160])
+    rect = eng.compare_rect_host(t, tq)
+    for q in range(60):
+        for r in range(0, n, 3):
+            i, j = max(q + 100, r), min(q + 100, r)
+            if i == j:
+                continue
+            idx = i * (i - 1) // 2 + j
+            assert (rect["numer"][q, r], rect["denom"][q, r]) == (numer[idx], denom[idx]), (q, r)
+    t.free(); tq.free()
+
+
 def test_compare_rect_and_golden_dist(eng, oracle, golden_dir):
     """mash dist genomes.msh reads.msh == test/ref/genomes.dist, via rect compare + finish."""
     gh, glens, names = helpers.load_golden_genomes()
