@@ -5,7 +5,8 @@ Every rank holds the same query-sketch table `db` and screens ITS share of the m
 CommandScreen.cpp:192,224-249).  Two things are exchanged at the end, and nothing before:
 
   * the per-hash observation counts, u32[db_rows * s]: summed over ranks -- the one
-    collective of the data path (RCCL all-reduce over xGMI on GPUs; gloo on CPU tests).
+    collective of the data path (RCCL over xGMI on GPUs; gloo on CPU tests): an all-gather of
+    the non-zero (index, count) lists while they are sparse, a dense all-reduce otherwise.
     It replaces the shared atomic `hashCounts` map of the reference (CommandScreen.h:131);
   * each rank's bottom-s sketch of its share of the mixture: all-gathered (s u64 per rank)
     and merged -- bottom-s of the union of bottom-s sets is the bottom-s of the whole
@@ -34,13 +35,41 @@ def merge_mixtures(mixes, s):
     return u[:s]
 
 
-def exchange(counts, mix, s, group=None):
-    """all-reduce the counts in place (sum) and merge the mixtures of all ranks.
+def sum_counts(counts, group=None, sparse_below=0.05):
+    """Sum the observation counters over ranks, in place.  A mixture touches few of a large
+    database's hashes (config 4: 7e5 of 1e8 counters per rank are non-zero), so when every
+    rank's non-zero share is below `sparse_below` the ranks all-gather their (index, count)
+    lists -- megabytes -- instead of all-reducing the dense vector (400 MB at config 4);
+    otherwise one dense all-reduce."""
+    world = dist.get_world_size(group)
+    idx = torch.nonzero(counts).squeeze(1)
+    nnz = torch.tensor([idx.numel()], dtype=torch.int64, device=counts.device)
+    dist.all_reduce(nnz, op=dist.ReduceOp.MAX, group=group)
+    m = int(nnz.item())
+    if m > sparse_below * counts.numel():
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+        return counts
+    pay = torch.zeros((2, m + 1), dtype=torch.int64, device=counts.device)       # row 0: indices, row 1: counts
+    pay[0, : idx.numel()] = idx
+    pay[1, : idx.numel()] = counts[idx].to(torch.int64)
+    pay[0, m] = idx.numel()
+    parts = [torch.empty_like(pay) for _ in range(world)]
+    dist.all_gather(parts, pay, group=group)
+    counts.zero_()
+    for p in parts:
+        k = int(p[0, m].item())
+        if k:
+            counts.index_add_(0, p[0, :k], p[1, :k].to(counts.dtype))
+    return counts
+
+
+def exchange(counts, mix, s, group=None, sparse_below=0.05):
+    """sum the counts over ranks in place and merge the mixtures of all ranks.
     counts: integer tensor on the collective's device; mix: numpy u64 (<= s, ascending)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return counts, np.asarray(mix, dtype=np.uint64)[:s]
-    dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+    sum_counts(counts, group, sparse_below)
     # fixed-size payload: s hashes (padded) + the count, as int64 bit patterns
     pay = np.full(s + 1, HASH_PAD, dtype=np.uint64)
     pay[: len(mix)] = mix
@@ -55,14 +84,14 @@ def exchange(counts, mix, s, group=None):
     return counts, merge_mixtures(mixes, s)
 
 
-def screen_sharded(local_screen, batches, s, group=None):
+def screen_sharded(local_screen, batches, s, group=None, sparse_below=0.05):
     """local_screen(list of this rank's batches) -> (counts tensor, mixture u64 array).
     Returns (summed counts tensor, merged mixture) on every rank."""
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     mine = [batches[i] for i in shard_batches(len(batches), rank, world)]
     counts, mix = local_screen(mine)
-    return exchange(counts, mix, s, group)
+    return exchange(counts, mix, s, group, sparse_below)
 
 
 def gpu_local_screen(eng, db, p):

@@ -141,7 +141,7 @@ def _oracle_local_screen(orc, k, s, db):
     return run
 
 
-def _screen_worker(rank, world, port, q):
+def _screen_worker(rank, world, port, q, sparse_below=0.05):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from mash_amd import screen_dist
@@ -149,14 +149,16 @@ def _screen_worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     orc, k, s, db, batches = _screen_case()
-    counts, mix = screen_dist.screen_sharded(_oracle_local_screen(orc, k, s, db), batches, s)
+    counts, mix = screen_dist.screen_sharded(_oracle_local_screen(orc, k, s, db), batches, s, sparse_below=sparse_below)
     q.put((rank, counts.numpy().copy(), mix.copy()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_screen_allreduce_and_mixture_merge(oracle):
-    """counts summed over ranks and the merged mixture equal the single-process result"""
+@pytest.mark.parametrize("sparse_below", [0.0, 1.0])
+def test_two_rank_screen_allreduce_and_mixture_merge(oracle, sparse_below):
+    """counts summed over ranks (dense all-reduce / sparse index-count all-gather) and the merged
+    mixture equal the single-process result"""
     import torch.multiprocessing as mp
     from mash_amd import screen_dist
     assert screen_dist.shard_batches(5, 1, 2) == [1, 3]
@@ -168,7 +170,7 @@ def test_two_rank_screen_allreduce_and_mixture_merge(oracle):
     sk.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_screen_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_screen_worker, args=(r, 2, port, q, sparse_below)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
