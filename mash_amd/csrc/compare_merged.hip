@@ -5,20 +5,24 @@
 // ALL R rows of a tile share ONE bucketed table in LDS, so a column element is probed once
 // for the whole tile instead of once per row.
 //
-//   table : R*s entries {32-bit prefix, 16-bit tag = row<<10 | index-in-row}, grouped by
-//           bucket = mulhi(prefix, scale_tile) (CSR layout, ~1 entry per bucket);
+//   tile  : up to 16 rows listed explicitly (rows of one hash-density class, see
+//           mashgpu.cpp::run_compare) x a range of columns;
+//   table : R*s entries {32-bit prefix, 16-bit tag = row<<idx_bits | index-in-row}, grouped
+//           by bucket = mulhi(prefix, scale_tile) (CSR layout, load ~0.65); inside a bucket
+//           one entry of every DISTINCT prefix comes first;
 //   dir   : u16 per bucket = first entry of the bucket, bit 15 set when the bucket holds
-//           more than W entries.
+//           more than MR_W distinct prefixes.
 //
 // Every value occurring in any row of the tile sits in the bucket its prefix maps to, so
-// "b occurs in some row" <=> one of the bucket's prefixes equals b's prefix (then verified
-// on the 64-bit value in HBM/L2).  Unrelated sketches never tie, so for them a column
-// costs one probe per element for all R rows plus one rank test per row per 128
+// "b occurs in some row" <=> one of the bucket's distinct prefixes equals b's prefix (then
+// verified on the 64-bit value in HBM/L2).  Unrelated sketches never tie, so for them a
+// column costs one probe per element for all R rows plus one rank test per row per 64*KU
 // elements:  rank(B[q] in row r) >= s-1  <=>  A_r[s-1-q+c_r - 1] < B[q]  — a single
 // load per row (tested conservatively on prefixes).  Columns are streamed as 32-bit
-// prefixes (mg_table keeps a u32 image of the table with a table-wide shift), halving
-// the kernel's dominant HBM traffic; 64-bit values are fetched only for tied lanes.  Matches (ties) are ranked exactly with ballot + mbcnt using the
-// index stored in the tag (it IS the lower bound of the matched value in its row).
+// prefixes (mg_table keeps padded u32 images of the table, one per density class's shift),
+// halving the kernel's dominant HBM traffic; 64-bit values are fetched only for tied lanes.
+// Matches (ties) are ranked exactly with ballot + mbcnt using the index stored in the tag
+// (it IS the lower bound of the matched value in its row).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -272,8 +276,8 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
     const uint32_t my_id = lane < 32 ? hdr->row_id[lane] : 0xFFFFFFFFu;     // table row of slot `lane`
     const uint32_t *my_row = a.row_pfx + (uint64_t)(my_id != 0xFFFFFFFFu ? my_id : hdr->row_id[0]) * a.row_pfx_stride;
 
-    // Column streaming is software-pipelined with UNCONDITIONAL loads (indices clamped into
-    // the row, which is padded to s entries) so the compiler can count vmcnt exactly:
+    // Column streaming is software-pipelined with UNCONDITIONAL loads (the image's rows are
+    // padded, no index needs clamping):
     //   in flight while group g is probed:  rank-test operand of g, data of group g+1,
     //   and (issued during group 0) the first group + length of the wave's next column.
     // VMEM returns in order, so the small L2-resident rank-test operand is always issued
