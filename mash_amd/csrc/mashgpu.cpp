@@ -59,6 +59,20 @@ struct mg_table {
         }                                                                            \
     } while (0)
 
+// device allocation released on every exit path (hipFree synchronises with the device, so
+// nothing launched on the buffer is still running when it goes away)
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { if (p) hipFree(p); }
+    hipError_t alloc(uint64_t count) { return hipMalloc(&p, std::max<uint64_t>(count, 1) * sizeof(T)); }
+    T *release() { T *q = p; p = nullptr; return q; }
+    operator T *() const { return p; }
+};
+
 static int fail(mg_ctx *ctx, int code, const std::string &msg)
 {
     if (ctx) ctx->err = msg; else g_create_error = msg;
@@ -559,32 +573,22 @@ int mg_sketch_host(mg_ctx *ctx, const mg_params *p, const uint8_t *bases, uint64
     if (nsketch == 0) return MG_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint64_t s = p->sketch_size;
-    uint8_t *d_bases = nullptr;
-    uint64_t *d_hashes = nullptr;
-    uint32_t *d_nhash = nullptr, *d_counts = nullptr;
-    if (counts_out) HIP_TRY(ctx, hipMalloc(&d_counts, nsketch * s * 4));
-    HIP_TRY(ctx, hipMalloc(&d_bases, nbases + 64));
-    int rc = MG_OK;
-    if (hipMalloc(&d_hashes, nsketch * s * 8) != hipSuccess || hipMalloc(&d_nhash, nsketch * 4) != hipSuccess) {
-        rc = fail(ctx, MG_ERR_NOMEM, "mg_sketch_host: device allocation failed");
-    } else if (hipMemcpyAsync(d_bases, bases, nbases, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
-        rc = fail(ctx, MG_ERR_HIP, "mg_sketch_host: H2D copy failed");
-    } else {
-        rc = mg_sketch_dev(ctx, p, d_bases, nbases, sketch_off, nsketch, d_hashes, d_nhash, d_counts);
-        if (rc == MG_OK) {
-            if ((counts_out && hipMemcpyAsync(counts_out, d_counts, nsketch * s * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) ||
-                hipMemcpyAsync(hashes_out, d_hashes, nsketch * s * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-                hipMemcpyAsync(nhash_out, d_nhash, nsketch * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-                hipStreamSynchronize(ctx->stream) != hipSuccess)
-                rc = fail(ctx, MG_ERR_HIP, "mg_sketch_host: D2H copy failed");
-        }
-    }
-    hipStreamSynchronize(ctx->stream);
-    if (d_bases) hipFree(d_bases);
-    if (d_hashes) hipFree(d_hashes);
-    if (d_nhash) hipFree(d_nhash);
-    if (d_counts) hipFree(d_counts);
-    return rc;
+    DevBuf<uint8_t> d_bases;
+    DevBuf<uint64_t> d_hashes;
+    DevBuf<uint32_t> d_nhash, d_counts;
+    if ((counts_out && d_counts.alloc(nsketch * s) != hipSuccess) || d_bases.alloc(nbases + 64) != hipSuccess ||
+        d_hashes.alloc(nsketch * s) != hipSuccess || d_nhash.alloc(nsketch) != hipSuccess)
+        return fail(ctx, MG_ERR_NOMEM, "mg_sketch_host: device allocation failed");
+    if (hipMemcpyAsync(d_bases, bases, nbases, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+        return fail(ctx, MG_ERR_HIP, "mg_sketch_host: H2D copy failed");
+    const int rc = mg_sketch_dev(ctx, p, d_bases, nbases, sketch_off, nsketch, d_hashes, d_nhash, d_counts);
+    if (rc != MG_OK) return rc;
+    if ((counts_out && hipMemcpyAsync(counts_out, d_counts, nsketch * s * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) ||
+        hipMemcpyAsync(hashes_out, d_hashes, nsketch * s * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(nhash_out, d_nhash, nsketch * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess)
+        return fail(ctx, MG_ERR_HIP, "mg_sketch_host: D2H copy failed");
+    return MG_OK;
 }
 
 /* ------------------------------------------------------------------ tables */
@@ -595,18 +599,17 @@ int mg_table_upload(mg_ctx *ctx, const uint64_t *hashes, const uint32_t *nhash, 
     if (!ctx) return MG_ERR_INVALID;
     if (!hashes || !nhash || !out || s == 0) return fail(ctx, MG_ERR_INVALID, "mg_table_upload: bad argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    uint64_t *dh = nullptr, *dl = nullptr;
-    uint32_t *dn = nullptr;
-    HIP_TRY(ctx, hipMalloc(&dh, std::max<uint64_t>(n * s * 8, 8)));
-    HIP_TRY(ctx, hipMalloc(&dn, std::max<uint64_t>(n * 4, 4)));
-    HIP_TRY(ctx, hipMalloc(&dl, std::max<uint64_t>(n * 8, 8)));
+    DevBuf<uint64_t> dh, dl;
+    DevBuf<uint32_t> dn;
+    if (dh.alloc(n * s) != hipSuccess || dn.alloc(n) != hipSuccess || dl.alloc(n) != hipSuccess)
+        return fail(ctx, MG_ERR_NOMEM, "mg_table_upload: device allocation failed");
     HIP_TRY(ctx, hipMemcpyAsync(dh, hashes, n * s * 8, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(dn, nhash, n * 4, hipMemcpyHostToDevice, ctx->stream));
     if (lengths) HIP_TRY(ctx, hipMemcpyAsync(dl, lengths, n * 8, hipMemcpyHostToDevice, ctx->stream));
     else HIP_TRY(ctx, hipMemsetAsync(dl, 0, n * 8, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     mg_table *t = new mg_table;
-    t->ctx = ctx; t->hashes = dh; t->nhash = dn; t->lengths = dl; t->n = n; t->s = s; t->owns = true;
+    t->ctx = ctx; t->hashes = dh.release(); t->nhash = dn.release(); t->lengths = dl.release(); t->n = n; t->s = s; t->owns = true;
     *out = t;
     return MG_OK;
 }
