@@ -347,6 +347,61 @@ def test_compare_mixed_hash_densities(eng, oracle, kernel, monkeypatch):
     t.free(); tq.free()
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_compare_random_tables_vs_oracle(eng, oracle, seed):
+    """Randomised tables: any sketch size, ragged / empty / identical rows, values shared between
+    rows (several rows of a tile holding the same value), hash ranges from 2^20 to 2^64, random
+    row ranges, triangle and rect -- the merged kernel against the oracle, bit for bit."""
+    rng = np.random.default_rng(1000 + seed)
+    s = int(rng.choice([1, 2, 3, 5, 17, 64, 100, 257, 600, 1000, 1024, 1500]))
+    n = int(rng.integers(2, 70))
+    table = np.full((n, s), np.uint64(0xFFFFFFFFFFFFFFFF), dtype=np.uint64)
+    nhash = np.zeros(n, dtype=np.uint32)
+    pool = rng.integers(1, 2 ** 63, 3 * s + 8).astype(np.uint64)
+    for i in range(n):
+        bits = int(rng.choice([20, 33, 44, 54, 60, 64]))
+        u = rng.random()
+        if u < 0.08:
+            continue                                                  # empty row
+        if u < 0.2 and i > 0:
+            table[i] = table[int(rng.integers(0, i))]                 # identical to an earlier row
+            nhash[i] = nhash[np.where((table[:i] == table[i]).all(axis=1))[0][0]]
+            continue
+        k = int(rng.integers(1, s + 1)) if rng.random() < 0.4 else s
+        top = np.uint64((1 << bits) - 2)
+        own = rng.integers(1, 2 ** 63, 2 * s + 4).astype(np.uint64) % top
+        shared = rng.choice(pool, size=int(rng.integers(0, min(len(pool), s) + 1)), replace=False) % top
+        row = np.unique(np.concatenate([own, shared]))
+        row = row[:k] if rng.random() < 0.5 else np.sort(rng.choice(row, size=min(k, len(row)), replace=False))
+        table[i, : len(row)] = row
+        nhash[i] = len(row)
+    lengths = rng.integers(1000, 10 ** 7, n).astype(np.uint64)
+    t = eng.table_upload(table, nhash, lengths)
+    kmer = 21 if s < 1000 else 31
+    numer, denom = _oracle_tri(oracle, table, nhash, lengths, 0, n, k=kmer, kspace=4.0 ** kmer)
+    got = eng.compare_tri_host(t)
+    assert np.array_equal(got["numer"], numer) and np.array_equal(got["denom"], denom), (seed, s, n)
+    lo = int(rng.integers(0, n)); hi = int(rng.integers(lo, n + 1))
+    g2 = eng.compare_tri_host(t, lo, hi)
+    n2, d2 = _oracle_tri(oracle, table, nhash, lengths, lo, hi, k=kmer, kspace=4.0 ** kmer)
+    assert np.array_equal(g2["numer"], n2) and np.array_equal(g2["denom"], d2), (seed, lo, hi)
+    q0 = int(rng.integers(0, n)); q1 = int(rng.integers(q0, n + 1))
+    if q1 > q0:
+        tq = eng.table_upload(table[q0:q1], nhash[q0:q1], lengths[q0:q1])
+        rect = eng.compare_rect_host(t, tq)
+        for q in range(q1 - q0):
+            for r in range(n):
+                i, j = max(q + q0, r), min(q + q0, r)
+                if i == j:
+                    exp = (nhash[i], nhash[i]) if nhash[i] <= s else (s, s)
+                    assert (rect["numer"][q, r], rect["denom"][q, r]) == (min(nhash[i], s), min(nhash[i], s)), (seed, q, r)
+                else:
+                    idx = i * (i - 1) // 2 + j
+                    assert (rect["numer"][q, r], rect["denom"][q, r]) == (numer[idx], denom[idx]), (seed, q, r)
+        tq.free()
+    t.free()
+
+
 def test_compare_rect_and_golden_dist(eng, oracle, golden_dir):
     """mash dist genomes.msh reads.msh == test/ref/genomes.dist, via rect compare + finish."""
     gh, glens, names = helpers.load_golden_genomes()
