@@ -71,7 +71,19 @@ MG_HD u64x2 mul64c(u64x2 x, uint64_t c)
     return {(uint32_t)p, (uint32_t)(p >> 32) + x.lo * ch + x.hi * cl};
 }
 
-MG_HD u64x2 add64(u64x2 a, u64x2 b) { return make64(to64(a) + to64(b)); }
+// 64-bit add on halves with an explicit carry (v_add_co / v_addc): no register-pair shuffling
+MG_HD u64x2 add64(u64x2 a, u64x2 b)
+{
+    const uint32_t lo = a.lo + b.lo;
+    return {lo, a.hi + b.hi + (uint32_t)(lo < a.lo)};
+}
+
+// h * 5 + c (c < 2^32): one 32x32->64 multiply-add for the low half, shift-add for the high half
+MG_HD u64x2 mul5add(u64x2 h, uint32_t c)
+{
+    const uint64_t p = (uint64_t)h.lo * 5u + c;
+    return {(uint32_t)p, (uint32_t)(p >> 32) + h.hi * 5u};
+}
 MG_HD u64x2 xor64(u64x2 a, u64x2 b) { return {a.lo ^ b.lo, a.hi ^ b.hi}; }
 
 MG_HD u64x2 fmix64h(u64x2 k)
@@ -98,10 +110,10 @@ MG_HD uint64_t murmur3_h1(const uint32_t w[8], uint32_t seed)
         u64x2 k1 = {w[4 * i], w[4 * i + 1]}, k2 = {w[4 * i + 2], w[4 * i + 3]};
         k1 = mul64c(k1, c1); k1 = rotl64h<31>(k1); k1 = mul64c(k1, c2); h1 = xor64(h1, k1);
         h1 = rotl64h<27>(h1); h1 = add64(h1, h2);
-        h1 = make64(to64(h1) * 5 + 0x52dce729);
+        h1 = mul5add(h1, 0x52dce729u);
         k2 = mul64c(k2, c2); k2 = rotl64h<33>(k2); k2 = mul64c(k2, c1); h2 = xor64(h2, k2);
         h2 = rotl64h<31>(h2); h2 = add64(h2, h1);
-        h2 = make64(to64(h2) * 5 + 0x38495ab5);
+        h2 = mul5add(h2, 0x38495ab5u);
     }
     if (REM > 8) {
         u64x2 k2 = {w[(4 * NB + 2) & 7], w[(4 * NB + 3) & 7]};
