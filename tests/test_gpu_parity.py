@@ -75,6 +75,25 @@ def test_sketch_modes_vs_oracle(eng, oracle, kw):
     _check_sketches(eng, oracle, sketches, **kw)
 
 
+@pytest.mark.parametrize("k", range(1, 33))
+def test_sketch_every_kmer_size(eng, oracle, k):
+    """Every k-mer size is its own kernel instantiation (window dwords, tail bytes of the hash,
+    32- vs 64-bit hashes): canonical DNA, forward-only DNA, protein and a min-copies run for each,
+    on adversarial records, sketch sizes around the number of distinct k-mers."""
+    rng = np.random.default_rng(500 + k)
+    dna = [synth.adversarial_dna_records(rng, v) for v in (0, 2, 3)]
+    s = int(rng.choice([16, 64, 300]))
+    _check_sketches(eng, oracle, dna, k=k, s=s)
+    _check_sketches(eng, oracle, dna[:2], k=k, s=s, noncanonical=True, preserve_case=bool(k % 2))
+    prot = [synth.random_protein_records(rng, v) for v in (0, 1)]
+    _check_sketches(eng, oracle, prot, k=k, s=s, alphabet="ACDEFGHIKLMNPQRSTVWY", noncanonical=True)
+    reads = [r for recs in dna for r in recs] * 2                  # every k-mer at least twice
+    p = eng.params(k=k, s=s, min_copies=2)
+    hashes, nhash, counts = eng.sketch_host([reads], p, counts=True)
+    oh, oc, _, _, _ = oracle.sketch_records(reads, oracle.params(k=k, s=s, min_copies=2))
+    assert nhash[0] == len(oh) and np.array_equal(hashes[0, : len(oh)], oh) and np.array_equal(counts[0, : len(oh)], oc)
+
+
 def test_sketch_reference_run_vectors(eng):
     """Device vs outputs of the reference's own objects (tests/golden/ref_sketch_vectors.npz)."""
     for cfg, recs, gh, gc in helpers.load_ref_sketch_vectors():
