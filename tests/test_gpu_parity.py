@@ -607,6 +607,37 @@ def test_screen_counts_vs_oracle(eng, oracle):
     db.free()
 
 
+@pytest.mark.parametrize("k,nonc", [(11, False), (16, True), (27, False), (32, False), (5, True)])
+def test_screen_other_kmer_sizes(eng, oracle, k, nonc):
+    """the fused sketch+probe instantiations at other k-mer sizes / forward-only k-mers"""
+    rng = np.random.default_rng(40 + k)
+    genomes = [synth._rand_dna(rng, 6000) for _ in range(3)]
+    s = 200
+    p = eng.params(k=k, s=s, noncanonical=nonc)
+    hashes, nhash = eng.sketch_host([[g] for g in genomes], p)
+    db = eng.table_upload(hashes, nhash, np.full(3, 6000, np.uint64))
+    reads = []
+    for _ in range(800):
+        g = genomes[int(rng.integers(0, 2))]
+        st = int(rng.integers(0, 6000 - 120))
+        r = g[st:st + int(rng.integers(k, 120))]
+        reads.append(r if (nonc or rng.random() < 0.5) else _revcomp(r))
+    counts, mix, _ = eng.screen(db, p, [reads[:300], reads[300:]])
+    want = {}
+    op_all = oracle.params(k=k, s=10 ** 6, noncanonical=nonc)
+    for r in reads:
+        if len(r) < k:
+            continue
+        h, c, _, _, _ = oracle.sketch_records([r], op_all)
+        for hv, cv in zip(h, c):
+            want[int(hv)] = want.get(int(hv), 0) + int(cv)
+    for i in range(3):
+        exp = np.array([want.get(int(x), 0) for x in hashes[i, : nhash[i]]], dtype=np.uint32)
+        assert np.array_equal(counts[i, : nhash[i]], exp), (k, i)
+    assert np.array_equal(mix, np.array(sorted(want), dtype=np.uint64)[:s])
+    db.free()
+
+
 def test_screen_translated_vs_oracle(eng, oracle):
     """Amino-acid query sketches against a nucleotide mixture: the device translates every batch
     in six frames (CommandScreen.cpp:516-531, 617-809); expected counts come from the oracle's
