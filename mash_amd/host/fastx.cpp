@@ -59,8 +59,37 @@ long Reader::next(Record &rec)
     c = until_(0, rec.name);
     if (c == -1 && rec.name.empty() && begin_ >= end_ && eof_) return -1;
     if (c != '\n' && c != -1) until_(1, rec.comment);
-    while ((c = getc_()) != -1 && c != '>' && c != '+' && c != '@')
-        if (isgraph(c)) rec.seq.push_back((char)c);
+    // sequence bytes: same rule as the byte-by-byte loop of kseq (append isgraph bytes until
+    // '>', '+' or '@'), but scanned a buffer at a time: runs of sequence bytes are appended in
+    // one go -- this loop is what a multi-gigabyte input spends its time in
+    static const struct Classes {
+        unsigned char t[256];                      // 0: sequence byte, 1: skipped, 2: terminator
+        Classes()
+        {
+            for (int i = 0; i < 256; i++) t[i] = isgraph(i) ? 0 : 1;
+            t[(unsigned char)'>'] = t[(unsigned char)'+'] = t[(unsigned char)'@'] = 2;
+        }
+    } cls;
+    c = -1;
+    for (;;) {
+        if (begin_ >= end_) {                      // refill
+            const int first = getc_();
+            if (first < 0) break;
+            begin_--;                              // leave it in the buffer
+        }
+        const unsigned char *b = buf_ + begin_, *e = buf_ + end_, *q = b;
+        bool stop = false;
+        while (q < e) {
+            const unsigned char *run = q;
+            while (q < e && cls.t[*q] == 0) q++;
+            if (q > run) rec.seq.append(reinterpret_cast<const char *>(run), (size_t)(q - run));
+            if (q == e) break;
+            if (cls.t[*q] == 2) { c = *q++; stop = true; break; }
+            q++;                                   // skipped byte (newline, blank, control)
+        }
+        begin_ = (int)(q - buf_);
+        if (stop) break;
+    }
     if (c == '>' || c == '@') last_char_ = c;
     if (c != '+') {
         if (c == -1) last_char_ = 0;
@@ -69,8 +98,20 @@ long Reader::next(Record &rec)
     while ((c = getc_()) != -1 && c != '\n') {}    // rest of the '+' line
     if (c == -1) return -2;
     size_t q = 0;
-    while (q < rec.seq.size() && (c = getc_()) != -1)
-        if (c >= 33 && c <= 127) q++;
+    while (q < rec.seq.size()) {                   // quality bytes, a buffer at a time
+        if (begin_ >= end_) {
+            if ((c = getc_()) == -1) break;
+            begin_--;
+        }
+        const unsigned char *b = buf_ + begin_, *e = buf_ + end_;
+        const size_t need = rec.seq.size() - q;
+        while (b < e && q < rec.seq.size()) {
+            q += (*b >= 33 && *b <= 127) ? 1 : 0;
+            b++;
+        }
+        (void)need;
+        begin_ = (int)(b - buf_);
+    }
     last_char_ = 0;
     if (q != rec.seq.size()) return -2;
     return (long)rec.seq.size();

@@ -50,6 +50,28 @@ int mshio_parse_summary(const uint8_t *data, uint64_t size, uint32_t *kmer, uint
     return 0;
 }
 
+// all records of a file as "name\tcomment\tseq\n" lines in a malloc'ed buffer (differential
+// tests against a byte-by-byte restatement of kseq); returns the last status of Reader::next
+long fastx_dump(const char *path, char **out, unsigned long long *out_len)
+{
+    fastx::Reader rd;
+    *out = nullptr;
+    *out_len = 0;
+    if (!rd.open(path)) return -10;
+    std::string all;
+    fastx::Record rec;
+    long l;
+    while ((l = rd.next(rec)) >= 0) {
+        all += rec.name; all += '\t'; all += rec.comment; all += '\t'; all += rec.seq; all += '\n';
+    }
+    *out = (char *)malloc(all.size() + 1);
+    memcpy(*out, all.data(), all.size());
+    *out_len = all.size();
+    return l;
+}
+
+void fastx_free(char *p) { free(p); }
+
 // count records / total sequence bytes of a fasta/fastq file the way kseq would
 long fastx_count(const char *path, long min_len, unsigned long long *total_bases, unsigned long long *name_bytes)
 {

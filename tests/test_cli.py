@@ -136,6 +136,95 @@ def test_fastx_reader_has_kseq_semantics(built, tmp_path):
     assert lib.fastx_count(str(fq).encode(), C.c_long(0), C.byref(tb), C.byref(nb)) == -2
 
 
+def _kseq_bytewise(data):
+    """kseq_read of the reference's vendored kseq.h (:171-208), one byte at a time.
+    Returns ([(name, comment, seq)], status) with status -1 (EOF) or -2 (short quality)."""
+    pos, n = 0, len(data)
+    recs, last = [], 0
+
+    def getc():
+        nonlocal pos
+        if pos >= n:
+            return -1
+        pos += 1
+        return data[pos - 1]
+
+    isspace = lambda c: c in (9, 10, 11, 12, 13, 32)
+    while True:
+        if last == 0:
+            c = getc()
+            while c != -1 and c not in (62, 64):
+                c = getc()
+            if c == -1:
+                return recs, -1
+            last = c
+        name, comment, seq = bytearray(), bytearray(), bytearray()
+        c = getc()
+        while c != -1 and not isspace(c):
+            name.append(c); c = getc()
+        if c == -1 and not name:
+            return recs, -1
+        if c != 10 and c != -1:
+            c = getc()
+            while c != -1 and c != 10:
+                comment.append(c); c = getc()
+        c = getc()
+        while c != -1 and c not in (62, 43, 64):
+            if 33 <= c <= 126:
+                seq.append(c)
+            c = getc()
+        if c in (62, 64):
+            last = c
+        if c != 43:
+            if c == -1:
+                last = 0
+            recs.append((bytes(name), bytes(comment), bytes(seq)))
+            continue
+        c = getc()
+        while c != -1 and c != 10:
+            c = getc()
+        if c == -1:
+            return recs, -2
+        q = 0
+        while q < len(seq):
+            c = getc()
+            if c == -1:
+                break
+            if 33 <= c <= 127:
+                q += 1
+        last = 0
+        if q != len(seq):
+            return recs, -2
+        recs.append((bytes(name), bytes(comment), bytes(seq)))
+
+
+def test_fastx_reader_matches_bytewise_kseq_on_random_input(built, tmp_path):
+    """The buffered reader against the byte-by-byte state machine on byte soup: headers and
+    '+' anywhere, blank / CR / control / high bytes, records across the 64 KiB refill boundary,
+    truncated quality strings."""
+    lib = C.CDLL(os.path.join(ROOT, "mash_amd", "libmshio.so"))
+    lib.fastx_dump.restype = C.c_long
+    lib.fastx_dump.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_ulonglong)]
+    rng = np.random.default_rng(99)
+    alpha = np.frombuffer(b"ACGTNacgt\n\n\r >@+\t-\x00\xff\x7f!I~", dtype=np.uint8)
+    weights = np.array([30, 30, 30, 30, 3, 2, 2, 2, 2, 8, 8, 1, 2, 0.4, 0.4, 0.4, 0.5, 0.5, 0.2, 0.2, 0.2, 1, 1, 1])
+    weights = weights / weights.sum()
+    for trial in range(40):
+        size = int(rng.choice([50, 2000, 70000, 140000]))
+        body = rng.choice(alpha, size=size, p=weights).tobytes()
+        if trial % 4 == 0:                                   # a well-formed long FASTQ record across the buffer edge
+            seq = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=66000).tobytes()
+            body = b"@r1 c\n" + seq + b"\n+\n" + b"I" * (66000 if trial % 8 else 65990) + b"\n" + body
+        path = tmp_path / ("f%d" % trial)
+        path.write_bytes(body)
+        out, ln = C.c_char_p(), C.c_ulonglong()
+        status = lib.fastx_dump(str(path).encode(), C.byref(out), C.byref(ln))
+        got = C.string_at(out, ln.value)
+        want_recs, want_status = _kseq_bytewise(body)
+        want = b"".join(a + b"\t" + b + b"\t" + c + b"\n" for a, b, c in want_recs)
+        assert status == want_status and got == want, trial
+
+
 # ---------------------------------------------------------------------------------- GPU
 
 @pytest.mark.gpu
