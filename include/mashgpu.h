@@ -116,7 +116,9 @@ int mg_sketch_dev(mg_ctx *ctx, const mg_params *p,
  * hashes[n * s] row-major ascending + nhash[n] + lengths[n] (Reference::length). */
 int  mg_table_upload(mg_ctx *ctx, const uint64_t *hashes, const uint32_t *nhash,
                      const uint64_t *lengths, uint64_t n, uint64_t s, mg_table **out);
-/* Adopt device buffers without copying (they must outlive the table). */
+/* Adopt device buffers without copying.  They must outlive the table and must not change
+ * while it exists: the compare path caches derived data per table (row maxima, density classes,
+ * 32-bit prefix images). */
 int  mg_table_wrap_dev(mg_ctx *ctx, const uint64_t *hashes_dev, const uint32_t *nhash_dev,
                        const uint64_t *lengths_dev, uint64_t n, uint64_t s, mg_table **out);
 void mg_table_free(mg_table *t);
