@@ -421,6 +421,34 @@ def test_compare_random_tables_vs_oracle(eng, oracle, seed):
     t.free()
 
 
+@pytest.mark.parametrize("kernel", ["merged", "tiled"])
+@pytest.mark.parametrize("seed", range(6))
+def test_compare_values_sharing_a_prefix(eng, oracle, kernel, seed, monkeypatch):
+    """Different 64-bit values that share their 32-bit prefix, inside one row, across rows of a
+    tile and between rows and columns: the tile's prefix/value consistency check fails, and
+    matches must come from the fully verified exact path (and near-misses must not count)."""
+    monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", kernel)
+    rng = np.random.default_rng(700 + seed)
+    n, s = 40, 200
+    base = np.unique(rng.integers(2 ** 40, 2 ** 63, 260).astype(np.uint64) & np.uint64(~0xFFFF & (2 ** 64 - 1)))
+    table = np.full((n, s), np.uint64(0xFFFFFFFFFFFFFFFF), dtype=np.uint64)
+    nhash = np.zeros(n, dtype=np.uint32)
+    for i in range(n):
+        pick = rng.choice(base, size=int(rng.integers(60, 150)), replace=False)
+        low = rng.integers(0, 4, len(pick)).astype(np.uint64)          # 4 variants per prefix: v, v+1, v+2, v+3
+        extra = pick[: len(pick) // 3] + ((low[: len(pick) // 3] + np.uint64(1)) % np.uint64(4))
+        row = np.unique(np.concatenate([pick + low, extra]))[:s]
+        table[i, : len(row)] = row
+        nhash[i] = len(row)
+    lengths = np.full(n, 10 ** 6, dtype=np.uint64)
+    t = eng.table_upload(table, nhash, lengths)
+    got = eng.compare_tri_host(t)
+    numer, denom = _oracle_tri(oracle, table, nhash, lengths, 0, n)
+    assert np.array_equal(got["numer"], numer) and np.array_equal(got["denom"], denom)
+    assert 0 < numer.max() < nhash.max()                                # some true matches, never everything
+    t.free()
+
+
 def test_compare_rect_and_golden_dist(eng, oracle, golden_dir):
     """mash dist genomes.msh reads.msh == test/ref/genomes.dist, via rect compare + finish."""
     gh, glens, names = helpers.load_golden_genomes()
