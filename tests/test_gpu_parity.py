@@ -856,3 +856,35 @@ def test_c3_scale_filter_and_cluster_layouts(eng, oracle, contiguous):
     assert np.array_equal(edges["numer"], out[keep, 0].cpu().numpy().astype(np.uint32))
     table.free()
 
+
+def test_c3_full_size_triangle(eng, oracle):
+    """BASELINE config 3 at its full size: 100 000 sketches, 4.99995e9 pairs, 40 GB of counts
+    resident in HBM; sampled rows against the oracle, denom == s everywhere, cluster structure."""
+    import torch
+    from mash_amd import synth_torch
+    n, s = 100000, 1000
+    dev = torch.device("cuda", 0)
+    hashes, nhash, lengths = synth_torch.clustered_sketch_table(n, s, clusters=1000, device=dev)
+    table = eng.table_wrap(hashes.data_ptr(), nhash.data_ptr(), lengths.data_ptr(), n, s)
+    out = torch.empty((n * (n - 1) // 2, 2), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    eng.compare_tri_dev(table, 0, n, out.data_ptr())
+    eng.synchronize()
+    th = hashes.cpu().numpy().view(np.uint64)
+    tn = nhash.cpu().numpy().astype(np.uint32)
+    tl = lengths.cpu().numpy().astype(np.uint64)
+    for i in (1, 16384, 65537, 99999):
+        numer, denom = _oracle_tri(oracle, th, tn, tl, i, i + 1)
+        row = out[i * (i - 1) // 2: i * (i - 1) // 2 + i].cpu().numpy()
+        assert np.array_equal(row[:, 0], numer) and np.array_equal(row[:, 1], denom), i
+    step = 1 << 28
+    for o in range(0, out.shape[0], step):                           # denom == s, numer <= s, in slices
+        part = out[o:o + step]
+        assert int(part[:, 1].min()) == s and int(part[:, 1].max()) == s and int(part[:, 0].max()) <= s
+    i = 77777
+    row = out[i * (i - 1) // 2: i * (i - 1) // 2 + i, 0].cpu().numpy()
+    same = (np.arange(i) % 1000) == (i % 1000)
+    assert row[same].min() > 300 and row[~same].max() < 50
+    del out
+    table.free()
+
