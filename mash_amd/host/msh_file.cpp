@@ -261,7 +261,8 @@ std::string read_msh(const std::string &path, File &out, bool header_only, uint6
 }
 
 // ------------------------------------------------------------------------------------------
-// writer: one segment, objects laid out in the order writeToCapnp creates them
+// writer: one segment (objects laid out in the order writeToCapnp creates them) while the
+// message fits, several segments with far pointers beyond
 
 namespace {
 
@@ -292,20 +293,47 @@ struct Builder {
     }
     void set_text(uint64_t at, const std::string &s)
     {
+        if (multi) { far_list(at, 2, s.size() + 1, s.data(), s.size()); return; }
         const uint64_t n = s.size() + 1;                           // with NUL
         const uint64_t t = alloc((n + 7) / 8);
         memcpy(reinterpret_cast<char *>(&w[t]), s.data(), s.size());
         set_list_ptr(at, t, 2, n);
     }
+
+    // ---- multi-segment mode: segment 0 (`w`) keeps the structs, every out-of-line list goes to
+    // a data segment and is reached through a far pointer whose landing pad sits right in
+    // front of the list (Cap'n Proto encoding: far pointer = {2, pad offset, segment id};
+    // the pad is an ordinary list pointer with offset 0)
+    bool multi = false;
+    uint64_t seg_limit = 0;                                        // words per data segment
+    std::vector<std::vector<uint64_t>> data;
+
+    // list of `count` elements of size code `code` whose payload is `bytes` bytes at `src`
+    void far_list(uint64_t at, uint32_t code, uint64_t count, const void *src, uint64_t bytes)
+    {
+        const uint64_t bits = code == 2 ? 8 : code == 4 ? 32 : 64;
+        const uint64_t words = (count * bits + 63) / 64;
+        if (count >= (1ull << 29) || words + 1 > seg_limit) { overflow = true; return; }
+        if (data.empty() || data.back().size() + words + 1 > seg_limit) data.emplace_back();
+        std::vector<uint64_t> &d = data.back();
+        const uint64_t pad = d.size();
+        d.resize(pad + 1 + words, 0);
+        d[pad] = 1ull | ((uint64_t)code << 32) | (count << 35);    // list pointer, offset 0
+        if (bytes) memcpy(&d[pad + 1], src, bytes);
+        if (pad >= (1ull << 29)) { overflow = true; return; }
+        w[at] = 2ull | (pad << 3) | ((uint64_t)data.size() << 32); // far pointer -> segment id data.size()
+    }
 };
 
 }  // namespace
 
-std::string serialize_msh(const File &in, std::vector<uint64_t> &out)
+static std::string serialize_impl(const File &in, std::vector<uint64_t> &out, bool multi, uint64_t seg_limit)
 {
     const Header &h = in.header;
     const bool use64 = use64_for(h.alphabet, h.preserve_case, h.kmer_size);
     Builder b;
+    b.multi = multi;
+    b.seg_limit = seg_limit;
     b.w.reserve(64 + in.references.size() * 16);
     const uint64_t rootp = b.alloc(1);
     const uint64_t root = b.alloc(3 + 4);
@@ -326,19 +354,32 @@ std::string serialize_msh(const File &in, std::vector<uint64_t> &out)
         b.w[s + 1] = r.length;                                     // length64; legacy length stays 0 (Sketch.cpp:407)
         if (!r.hashes.empty()) {
             if (use64) {
-                const uint64_t t = b.alloc(r.hashes.size());
-                memcpy(&b.w[t], r.hashes.data(), r.hashes.size() * 8);
-                b.set_list_ptr(s + 2 + 5, t, 5, r.hashes.size());
+                if (multi) {
+                    b.far_list(s + 2 + 5, 5, r.hashes.size(), r.hashes.data(), r.hashes.size() * 8);
+                } else {
+                    const uint64_t t = b.alloc(r.hashes.size());
+                    memcpy(&b.w[t], r.hashes.data(), r.hashes.size() * 8);
+                    b.set_list_ptr(s + 2 + 5, t, 5, r.hashes.size());
+                }
             } else {
-                const uint64_t t = b.alloc((r.hashes.size() + 1) / 2);
-                uint32_t *p = reinterpret_cast<uint32_t *>(&b.w[t]);
-                for (size_t k = 0; k < r.hashes.size(); k++) p[k] = (uint32_t)r.hashes[k];
-                b.set_list_ptr(s + 2 + 4, t, 4, r.hashes.size());
+                std::vector<uint32_t> h32(r.hashes.size());
+                for (size_t k = 0; k < r.hashes.size(); k++) h32[k] = (uint32_t)r.hashes[k];
+                if (multi) {
+                    b.far_list(s + 2 + 4, 4, h32.size(), h32.data(), h32.size() * 4);
+                } else {
+                    const uint64_t t = b.alloc((h32.size() + 1) / 2);
+                    memcpy(&b.w[t], h32.data(), h32.size() * 4);
+                    b.set_list_ptr(s + 2 + 4, t, 4, h32.size());
+                }
             }
             if (!r.counts.empty() && h.has_counts) {               // Sketch.cpp:432-444
-                const uint64_t t = b.alloc((r.counts.size() + 1) / 2);
-                memcpy(&b.w[t], r.counts.data(), r.counts.size() * 4);
-                b.set_list_ptr(s + 2 + 6, t, 4, r.counts.size());
+                if (multi) {
+                    b.far_list(s + 2 + 6, 4, r.counts.size(), r.counts.data(), r.counts.size() * 4);
+                } else {
+                    const uint64_t t = b.alloc((r.counts.size() + 1) / 2);
+                    memcpy(&b.w[t], r.counts.data(), r.counts.size() * 4);
+                    b.set_list_ptr(s + 2 + 6, t, 4, r.counts.size());
+                }
                 b.w[s] |= 1ull << 32;                              // counts32Sorted
             }
         }
@@ -357,14 +398,34 @@ std::string serialize_msh(const File &in, std::vector<uint64_t> &out)
                     ((uint64_t)(h.noncanonical ? 1 : 0) << 33) | ((uint64_t)(h.preserve_case ? 1 : 0) << 34);
     b.w[root + 2] = (uint64_t)ebits | ((uint64_t)(h.seed ^ 42u) << 32);
     b.set_text(root + 3 + 2, h.alphabet);
-    if (b.overflow) return "sketch file too large for the single-segment writer (4 GiB)";
-    if (b.w.size() > 0xFFFFFFFFull) return "sketch file too large";
-    // stream framing: u32 (segments - 1), u32 words of segment 0, then the segment
+    if (b.overflow) return multi ? "sketch file too large (a list or the sketch index exceeds a segment)"
+                                 : "needs more than one segment";
+    if (!multi && b.w.size() > seg_limit) return "needs more than one segment";
+    if (b.w.size() >= (1ull << 29)) return "too many sketches for one .msh file";
+    // stream framing: u32 (segments - 1), u32 words of every segment, padded to 8 bytes, then the segments
+    const uint64_t nseg = 1 + b.data.size();
+    std::vector<uint32_t> frame;
+    frame.push_back((uint32_t)(nseg - 1));
+    frame.push_back((uint32_t)b.w.size());
+    for (const auto &d : b.data) frame.push_back((uint32_t)d.size());
+    if (frame.size() & 1) frame.push_back(0);
     out.clear();
-    out.reserve(b.w.size() + 1);
-    out.push_back(((uint64_t)b.w.size() << 32) | 0ull);
+    out.resize(frame.size() / 2);
+    memcpy(out.data(), frame.data(), frame.size() * 4);
     out.insert(out.end(), b.w.begin(), b.w.end());
+    for (const auto &d : b.data) out.insert(out.end(), d.begin(), d.end());
     return "";
+}
+
+// One segment whenever the message fits (objects in the order writeToCapnp creates them);
+// beyond `max_segment_words` (default 2^28 words = 2 GiB, below the 30-bit offset limit of
+// in-segment pointers) the lists move to further segments behind far pointers.
+std::string serialize_msh(const File &in, std::vector<uint64_t> &out, uint64_t max_segment_words)
+{
+    if (max_segment_words == 0) max_segment_words = 1ull << 28;
+    std::string e = serialize_impl(in, out, false, max_segment_words);
+    if (e == "needs more than one segment") e = serialize_impl(in, out, true, max_segment_words);
+    return e;
 }
 
 std::string write_msh(const std::string &path, const File &in)

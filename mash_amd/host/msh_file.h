@@ -5,9 +5,10 @@
 // (Sketch.cpp:384-490, :907-1067, :255-324).  The wire layout (struct sizes, field slots,
 // default XOR for hashSeed) is derived from Cap'n Proto's slot-allocation rule
 // (SURVEY.md Appendix A).  The reader accepts anything libcapnp can emit for this schema:
-// multi-segment messages, far and double-far pointers.  The writer emits one segment
-// (no far pointers), which every Cap'n Proto reader accepts; files are limited to 4 GiB
-// minus change (30-bit word offsets) — ~500k sketches of s=1000.
+// multi-segment messages, far and double-far pointers.  The writer emits one segment (no far
+// pointers) while the message fits in 2 GiB, and otherwise keeps the structs in segment 0 and
+// moves every list to further segments behind far pointers (30-bit in-segment word offsets
+// cannot span more); every Cap'n Proto reader accepts both.
 #pragma once
 #include <cstdint>
 #include <string>
@@ -51,6 +52,7 @@ std::string write_msh(const std::string &path, const File &in);
 
 // in-memory variants (tests, pipes)
 std::string parse_msh(const uint8_t *data, size_t size, File &out, bool header_only, uint64_t max_hashes);
-std::string serialize_msh(const File &in, std::vector<uint64_t> &words_out);   // framing included
+// framing included; max_segment_words = 0 means the default segment limit (2 GiB)
+std::string serialize_msh(const File &in, std::vector<uint64_t> &words_out, uint64_t max_segment_words = 0);
 
 }  // namespace mshio

@@ -1,5 +1,6 @@
 // mshio_c.cpp — tiny C surface over the .msh codec and the fastx reader, for the CPU tests
 // (ctypes).  Host-only; no GPU dependency.
+#include <cstdio>
 #include <cstring>
 #include <string>
 
@@ -27,6 +28,21 @@ int mshio_roundtrip_check(const char *path)
             return 3;
     }
     return 0;
+}
+
+// read `in_path`, write it to `out_path` with the given segment limit (small limits force the
+// multi-segment layout); returns the number of segments written, or < 0
+long mshio_rewrite(const char *in_path, const char *out_path, unsigned long long max_segment_words)
+{
+    mshio::File a;
+    if (!mshio::read_msh(in_path, a).empty()) return -1;
+    std::vector<uint64_t> words;
+    if (!mshio::serialize_msh(a, words, max_segment_words).empty()) return -2;
+    FILE *f = fopen(out_path, "wb");
+    if (!f) return -3;
+    fwrite(words.data(), 8, words.size(), f);
+    fclose(f);
+    return (long)(words[0] & 0xFFFFFFFFull) + 1;
 }
 
 // parse a raw message image (used with hand-built multi-segment / far-pointer messages)

@@ -120,6 +120,35 @@ def test_msh_wire_layout_and_foreign_encodings(built, tmp_path):
     assert summary(b"\x00" * 16)[0] in (0, -1)
 
 
+def test_multi_segment_writer_roundtrips_through_golden_dumps(built, tmp_path):
+    """Files beyond one segment: structs stay in segment 0, lists move behind far pointers.
+    Forced here with a tiny segment limit; `mash info -d` of the rewritten files still equals the
+    reference's golden dumps, and the single-segment default is unchanged."""
+    lib = C.CDLL(os.path.join(ROOT, "mash_amd", "libmshio.so"))
+    lib.mshio_rewrite.restype = C.c_long
+    lib.mshio_rewrite.argtypes = [C.c_char_p, C.c_char_p, C.c_ulonglong]
+    for name in ("genomes", "reads"):
+        one = str(tmp_path / f"{name}.msh")
+        run("json2msh", os.path.join(GOLD, f"{name}.json"), one)
+        gold = open(os.path.join(GOLD, f"{name}.json")).read()
+        for limit, min_segs in ((0, 1), (1100 if name == "genomes" else 1010, 3 if name == "genomes" else 2), (300, None)):
+            out = str(tmp_path / f"{name}_{limit}.msh")
+            nseg = lib.mshio_rewrite(one.encode(), out.encode(), limit)
+            if min_segs is None:                                 # a 1000-hash list does not fit 300 words
+                assert nseg == -2
+                continue
+            assert nseg >= min_segs and (limit != 0 or nseg == 1)
+            assert run("info", "-d", out).stdout == gold
+            assert lib.mshio_roundtrip_check(out.encode()) == 0
+            if limit == 0:
+                assert open(out, "rb").read() == open(one, "rb").read()
+    # paste of multi-segment inputs
+    a, b = str(tmp_path / "genomes_1100.msh"), str(tmp_path / "genomes_0.msh")
+    run("paste", str(tmp_path / "both"), a, b)
+    tab = run("info", "-t", str(tmp_path / "both.msh")).stdout.splitlines()
+    assert len(tab) == 1 + 6
+
+
 def test_fastx_reader_has_kseq_semantics(built, tmp_path):
     lib = C.CDLL(os.path.join(ROOT, "mash_amd", "libmshio.so"))
     lib.fastx_count.restype = C.c_long
