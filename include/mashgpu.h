@@ -55,6 +55,8 @@ typedef struct mg_params {
     uint8_t  counts;           /* counts (multiplicities requested)              */
     uint32_t min_copies;       /* minCov (-m, reads mode; Sketch.cpp:1156): a hash enters the sketch at
                                 * its m-th occurrence.  0 / 1 = every k-mer (mg_params_init sets 1). */
+    double   target_cov;       /* targetCov (-c, reads mode; Sketch.cpp:1258), 0 = off: only
+                                * mg_sketch_reads_host honours it (mg_params_init sets 0). */
 } mg_params;
 
 /* {numer, denom} of one pair: what the merge loop of compareSketches produces
@@ -110,6 +112,19 @@ int mg_sketch_dev(mg_ctx *ctx, const mg_params *p,
                   const uint8_t *bases_dev, uint64_t nbases,
                   const uint64_t *sketch_off_host, uint64_t nsketch,
                   uint64_t *hashes_out_dev, uint32_t *nhash_out_dev, uint32_t *counts_out_dev);
+
+/* Reads mode with the early stop of `mash sketch -r -c <cov>` (Sketch.cpp:1200-1270): ONE sketch
+ * over all records of `bases` (separated by MG_RECORD_SEP, in the order the reference reads
+ * them); after every record the reference stops once the heap's average multiplicity
+ * (estimateMultiplicity, MinHashHeap.h:44) has reached p->target_cov.  That is a property of the
+ * sequential heap; it is reproduced exactly: the device emits every k-mer hash that can still
+ * change the heap (those below its current top), the host replays MinHashHeap::tryInsert
+ * (incl. min_copies) over that thinned stream.  hashes_out[sketch_size], counts_out[sketch_size]
+ * (nullable), *records_used_out = records (>= k long) consumed -- the "Reads used" line
+ * (Sketch.cpp:1324-1327).  With target_cov == 0 this is mg_sketch_host for one sketch. */
+int mg_sketch_reads_host(mg_ctx *ctx, const mg_params *p, const uint8_t *bases, uint64_t nbases,
+                         uint64_t *hashes_out, uint32_t *nhash_out, uint32_t *counts_out,
+                         uint64_t *records_used_out);
 
 /* ---- sketch tables ----------------------------------------------------------
  * Dense replacement for vector<Sketch::Reference> (Sketch.h:131-139):

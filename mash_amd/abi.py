@@ -22,7 +22,7 @@ RECORD_SEP = 0x0A
 
 EXPORTS = [
     "mg_ctx_create", "mg_ctx_destroy", "mg_last_error", "mg_ctx_set_stream", "mg_ctx_synchronize",
-    "mg_ctx_cu_count", "mg_params_init", "mg_sketch_host", "mg_sketch_dev", "mg_table_upload",
+    "mg_ctx_cu_count", "mg_params_init", "mg_sketch_host", "mg_sketch_dev", "mg_sketch_reads_host", "mg_table_upload",
     "mg_table_wrap_dev", "mg_table_free", "mg_table_rows", "mg_table_sketch_size",
     "mg_compare_tri_dev", "mg_compare_tri_host", "mg_compare_rect_dev", "mg_compare_rect_host",
     "mg_compare_tri_filter_host", "mg_compare_rect_filter_host",
@@ -45,6 +45,7 @@ class MgParams(C.Structure):
         ("noncanonical", C.c_uint8),
         ("counts", C.c_uint8),
         ("min_copies", C.c_uint32),
+        ("target_cov", C.c_double),
     ]
 
 
@@ -136,6 +137,7 @@ def load_library():
     lib.mg_params_init.argtypes = [C.POINTER(MgParams), i32, u64, u32, C.c_char_p, i32, i32]
     lib.mg_sketch_host.argtypes = [vp, C.POINTER(MgParams), vp, u64, vp, u64, vp, vp, vp]
     lib.mg_sketch_dev.argtypes = [vp, C.POINTER(MgParams), vp, u64, vp, u64, vp, vp, vp]
+    lib.mg_sketch_reads_host.argtypes = [vp, C.POINTER(MgParams), vp, u64, vp, vp, vp, vp]
     lib.mg_table_upload.argtypes = [vp, vp, vp, vp, u64, u64, C.POINTER(vp)]
     lib.mg_table_wrap_dev.argtypes = [vp, vp, vp, vp, u64, u64, C.POINTER(vp)]
     lib.mg_table_free.argtypes = [vp]
@@ -182,12 +184,13 @@ def tri_pairs(row_begin, row_end):
 
 
 def make_params(lib, k=21, s=1000, seed=42, alphabet="ACGT", noncanonical=False, preserve_case=False,
-                min_copies=1):
+                min_copies=1, target_cov=0.0):
     p = MgParams()
     rc = lib.mg_params_init(C.byref(p), k, s, seed, alphabet.encode(), int(noncanonical), int(preserve_case))
     if rc != MG_OK:
         raise MashGpuError(f"mg_params_init failed ({rc})")
     p.min_copies = min_copies
+    p.target_cov = target_cov
     return p
 
 
@@ -270,6 +273,18 @@ class MashGpu:
                                             off.ctypes.data, n, hashes.ctypes.data, nhash.ctypes.data,
                                             cnt.ctypes.data if counts else None))
         return (hashes, nhash, cnt) if counts else (hashes, nhash)
+
+    def sketch_reads(self, records, p):
+        """reads mode, one sketch over `records` in order, honouring p.target_cov (-c):
+        (hashes u64[n], counts u32[n], records_used)"""
+        blob = np.frombuffer(join_records(records), dtype=np.uint8)
+        s = int(p.sketch_size)
+        hashes = np.full(s, HASH_PAD, dtype=np.uint64)
+        counts = np.zeros(s, dtype=np.uint32)
+        n, used = C.c_uint32(0), C.c_uint64(0)
+        self._check(self.lib.mg_sketch_reads_host(self.ctx, C.byref(p), blob.ctypes.data, len(blob), hashes.ctypes.data,
+                                                  C.byref(n), counts.ctypes.data, C.byref(used)))
+        return hashes[: n.value].copy(), counts[: n.value].copy(), int(used.value)
 
     def sketch_dev(self, bases_ptr, nbases, off, p, hashes_ptr, nhash_ptr):
         off = np.ascontiguousarray(off, dtype=np.uint64)

@@ -5,6 +5,8 @@
 #include <algorithm>
 #include <cmath>
 #include <iterator>
+#include <map>
+#include <queue>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -162,6 +164,7 @@ int mg_params_init(mg_params *p, int kmer_size, uint64_t sketch_size, uint32_t s
     p->noncanonical = noncanonical ? 1 : 0;
     p->preserve_case = preserve_case ? 1 : 0;
     p->min_copies = 1;
+    p->target_cov = 0.0;
     for (const char *c = alphabet; *c; c++) {            // Sketch.cpp:1113-1125
         char u = *c;
         if (!preserve_case && u > 96 && u < 123) u -= 32;
@@ -325,6 +328,7 @@ static int sketch_dev_impl(mg_ctx *ctx, const mg_params *p, const uint8_t *bases
     if (p->kmer_size < 1 || p->kmer_size > 32) return fail(ctx, MG_ERR_INVALID, "mg_sketch: k must be 1..32");
     if (counts_out_dev && !mg::count_supported(p->sketch_size))
         return fail(ctx, MG_ERR_UNSUPPORTED, "mg_sketch: sketch size too large for the multiplicity pass");
+    if (p->target_cov > 0) return fail(ctx, MG_ERR_UNSUPPORTED, "mg_sketch: target_cov needs mg_sketch_reads_host");
     if (nsketch == 0) return MG_OK;
     if (nsketch > 0xFFFFFFFFull) return fail(ctx, MG_ERR_INVALID, "mg_sketch: too many sketches");
     if (((uintptr_t)bases_dev & 15) != 0) return fail(ctx, MG_ERR_INVALID, "mg_sketch: bases must be 16-byte aligned");
@@ -588,6 +592,190 @@ int mg_sketch_host(mg_ctx *ctx, const mg_params *p, const uint8_t *bases, uint64
         hipMemcpyAsync(nhash_out, d_nhash, nsketch * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
         hipStreamSynchronize(ctx->stream) != hipSuccess)
         return fail(ctx, MG_ERR_HIP, "mg_sketch_host: D2H copy failed");
+    return MG_OK;
+}
+
+/* ------------------------------------------------- reads mode with early stop (-c) */
+
+namespace {
+
+// MinHashHeap::tryInsert (MinHashHeap.cpp:68-145, no Bloom filter) over explicit containers:
+// kept hashes with counts, pending hashes (multiplicityMinimum > 1) and the pending max-queue
+// that may hold hashes already erased from the pending set.
+struct ReadsHeap {
+    uint64_t cap, mmin;
+    std::map<uint64_t, uint32_t> kept;
+    std::map<uint64_t, uint32_t> pending;
+    std::priority_queue<uint64_t> pending_q;
+    uint64_t msum = 0;                                       // multiplicitySum
+
+    ReadsHeap(uint64_t s, uint64_t m) : cap(s), mmin(m < 1 ? 1 : m) {}
+    bool full() const { return kept.size() >= cap; }
+    uint64_t top() const { return kept.rbegin()->first; }
+    double multiplicity() const { return kept.empty() ? 0.0 : (double)msum / (double)kept.size(); }   // MinHashHeap.h:44
+
+    void try_insert(uint64_t h)
+    {
+        if (!(kept.size() < cap || h < top())) return;       // :70-74
+        auto it = kept.find(h);
+        if (it != kept.end()) {                              // :120-124
+            it->second++;
+            msum++;
+        } else {
+            auto pit = pending.find(h);
+            const uint64_t pc = pit == pending.end() ? 0 : pit->second;
+            if (mmin == 1 || pc == mmin - 1) {               // :96-109
+                kept.emplace(h, (uint32_t)mmin);
+                msum += mmin;
+                if (mmin > 1 && pit != pending.end()) pending.erase(pit);
+            } else {                                         // :110-118
+                if (pit == pending.end()) { pending_q.push(h); pending.emplace(h, 1u); }
+                else pit->second++;
+            }
+        }
+        if (kept.size() > cap) {                             // :126-144
+            auto last = std::prev(kept.end());
+            const uint64_t tv = last->first;
+            msum -= last->second;
+            kept.erase(last);
+            while (!pending_q.empty() && tv < pending_q.top()) {
+                pending.erase(pending_q.top());
+                pending_q.pop();
+            }
+        }
+    }
+};
+
+}  // namespace
+
+int mg_sketch_reads_host(mg_ctx *ctx, const mg_params *p, const uint8_t *bases, uint64_t nbases, uint64_t *hashes_out,
+                         uint32_t *nhash_out, uint32_t *counts_out, uint64_t *records_used_out)
+{
+    if (!ctx) return MG_ERR_INVALID;
+    if (!p || !hashes_out || !nhash_out || (!bases && nbases)) return fail(ctx, MG_ERR_INVALID, "mg_sketch_reads_host: NULL argument");
+    if (p->kmer_size < 1 || p->kmer_size > 32) return fail(ctx, MG_ERR_INVALID, "mg_sketch: k must be 1..32");
+    const uint64_t s = p->sketch_size, k = (uint64_t)p->kmer_size;
+    // records of the batch (kseq drops nothing inside a record, so separators are record ends)
+    std::vector<uint64_t> rec_begin, rec_end;
+    for (uint64_t b = 0; b < nbases;) {
+        const void *q = memchr(bases + b, MG_RECORD_SEP, nbases - b);
+        const uint64_t e = q ? (uint64_t)((const uint8_t *)q - bases) : nbases;
+        if (e - b >= k) { rec_begin.push_back(b); rec_end.push_back(e); }   // shorter records are skipped (Sketch.cpp:1222-1226)
+        b = e + 1;
+    }
+    if (records_used_out) *records_used_out = rec_begin.size();
+    if (!(p->target_cov > 0)) {
+        mg_params q = *p;
+        q.target_cov = 0;
+        const uint64_t off[2] = {0, nbases};
+        return mg_sketch_host(ctx, &q, bases, nbases, off, 1, hashes_out, nhash_out, counts_out);
+    }
+    const bool dna = alphabet_is_dna(p);
+    if (!p->noncanonical && !dna) return fail(ctx, MG_ERR_UNSUPPORTED, "mg_sketch: canonical k-mers need the ACGT alphabet");
+    const int mode = dna ? (p->noncanonical ? 1 : 0) : 2;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (uint64_t i = 0; i < s; i++) hashes_out[i] = MG_HASH_PAD;
+    if (counts_out) memset(counts_out, 0, s * 4);
+    *nhash_out = 0;
+    if (rec_begin.empty()) { if (records_used_out) *records_used_out = 0; return MG_OK; }
+
+    const uint64_t ev_cap = 1ull << 23;                      // events per pass (128 MiB)
+    DevBuf<uint8_t> d_bases, d_alpha;
+    DevBuf<mg::HashEvent> d_ev;
+    DevBuf<unsigned long long> d_cnt;
+    if (d_bases.alloc(nbases + 64) != hipSuccess || d_alpha.alloc(256) != hipSuccess || d_ev.alloc(ev_cap) != hipSuccess ||
+        d_cnt.alloc(1) != hipSuccess)
+        return fail(ctx, MG_ERR_NOMEM, "mg_sketch_reads_host: device allocation failed");
+    HIP_TRY(ctx, hipMemcpyAsync(d_bases, bases, nbases, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_alpha, p->alphabet, 256, hipMemcpyHostToDevice, ctx->stream));
+
+    ReadsHeap heap(s, p->min_copies);
+    const double hash_space = p->use64 ? 18446744073709551616.0 : 4294967296.0;
+    const uint64_t tile = mg::sketch_tile(256);
+    std::vector<mg::HashEvent> ev;
+    size_t r0 = 0;                                           // next record
+    const uint64_t want_bytes = 2ull << 20;                  // while the heap is not full everything is an event
+    double shrink = 1.0;                                     // after an overflowing pass
+    bool stopped = false;
+    uint64_t used = 0;
+    while (r0 < rec_begin.size() && !stopped) {
+        // records [r0, r1): as many as are expected to stay within the event capacity
+        const uint64_t bound = heap.full() ? heap.top() : 0xFFFFFFFFFFFFFFFFull;
+        const double pass = heap.full() ? std::min(1.0, ((double)bound + 1.0) / hash_space) : 1.0;
+        uint64_t budget = (uint64_t)std::min<double>((double)(1ull << 40), (double)(ev_cap / 2) / std::max(pass, 1e-12));
+        if (budget < want_bytes || !heap.full()) budget = want_bytes;
+        budget = (uint64_t)std::max(1.0, (double)budget * shrink);
+        size_t r1 = r0;
+        uint64_t bytes = 0;
+        while (r1 < rec_begin.size() && (r1 == r0 || bytes + (rec_end[r1] - rec_begin[r1]) <= budget)) {
+            bytes += rec_end[r1] - rec_begin[r1];
+            r1++;
+        }
+        const uint64_t b0 = rec_begin[r0], b1 = rec_end[r1 - 1];
+        // work items: k-mer start positions [b0, b1 - k]
+        std::vector<mg::SketchWork> work;
+        const uint64_t npos = b1 - b0 - k + 1;
+        uint64_t chunk = (npos + 4095) / 4096;
+        if (chunk < 2 * tile) chunk = 2 * tile;
+        chunk = (chunk + tile - 1) / tile * tile;
+        for (uint64_t o = 0; o < npos; o += chunk) {
+            mg::SketchWork w;
+            w.begin = b0 + o; w.end = b0 + std::min(npos, o + chunk); w.limit = b1;
+            w.sketch = 0; w.slot = 0; w.nchunks = 1; w._pad = 0;
+            work.push_back(w);
+        }
+        DevBuf<mg::SketchWork> d_work;
+        if (d_work.alloc(work.size()) != hipSuccess) return fail(ctx, MG_ERR_NOMEM, "mg_sketch_reads_host: device allocation failed");
+        mg::EventArgs ea;
+        ea.bases = d_bases; ea.work = d_work; ea.alphabet = d_alpha; ea.out = d_ev; ea.count = d_cnt;
+        ea.capacity = ev_cap; ea.bound = bound; ea.seed = p->seed; ea.use64 = p->use64;
+        ea.fold_case = p->preserve_case ? 0 : 1;
+        unsigned long long n_ev = 0;
+        hipError_t e = hipMemcpyAsync(d_work, work.data(), work.size() * sizeof(mg::SketchWork), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_cnt, 0, 8, ctx->stream);
+        if (e == hipSuccess) e = mg::launch_hash_events(p->kmer_size, mode, ea, (uint32_t)work.size(), ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&n_ev, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("mg_sketch_reads_host: ") + hipGetErrorString(e));
+        if (n_ev > ev_cap) {                                 // denser than expected: take fewer records
+            if (r1 - r0 == 1) return fail(ctx, MG_ERR_UNSUPPORTED, "mg_sketch_reads_host: a single record exceeds the event buffer");
+            shrink /= 4;
+            continue;
+        }
+        shrink = 1.0;
+        ev.resize(n_ev);
+        if (n_ev && hipMemcpy(ev.data(), d_ev, n_ev * sizeof(mg::HashEvent), hipMemcpyDeviceToHost) != hipSuccess)
+            return fail(ctx, MG_ERR_HIP, "mg_sketch_reads_host: D2H copy failed");
+        std::sort(ev.begin(), ev.end(), [](const mg::HashEvent &x, const mg::HashEvent &y) { return x.pos < y.pos; });
+        // replay, record by record; the stop test follows every record that changed the heap
+        size_t rr = r0;
+        bool touched = false;
+        for (size_t i = 0; i <= ev.size() && !stopped; i++) {
+            const bool end = i == ev.size();
+            while (!end && ev[i].pos >= rec_end[rr]) {       // event belongs to a later record: close record rr
+                if (touched && heap.multiplicity() >= p->target_cov) { stopped = true; used = rr + 1; break; }
+                touched = false;
+                rr++;
+            }
+            if (stopped) break;
+            if (end) {
+                if (touched && heap.multiplicity() >= p->target_cov) { stopped = true; used = rr + 1; }
+                break;
+            }
+            heap.try_insert(ev[i].hash);
+            touched = true;
+        }
+        r0 = r1;
+    }
+    if (!stopped) used = rec_begin.size();
+    if (records_used_out) *records_used_out = used;
+    uint32_t n = 0;
+    for (const auto &kv : heap.kept) {
+        hashes_out[n] = kv.first;
+        if (counts_out) counts_out[n] = kv.second;
+        n++;
+    }
+    *nhash_out = n;
     return MG_OK;
 }
 

@@ -521,6 +521,76 @@ __global__ void range_extract_kernel(const unsigned long long *keys, const uint3
 
 #endif  // SK_PART == 0
 
+// `mash sketch -r -c <cov>` stops reading once the heap's average multiplicity reaches the target
+// (Sketch.cpp:1258) -- a property of the sequential heap.  It is reproduced exactly by replaying
+// that heap on the host over a THINNED stream: only hashes below the heap's current top can ever
+// change it (MinHashHeap.cpp:70-74), so the device emits {hash, position} of exactly those.
+template <int K, int MODE>
+__global__ __launch_bounds__(256) void hash_events_kernel(EventArgs a)
+{
+    constexpr int NT = 256;
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t *tile = reinterpret_cast<uint32_t *>(smem);
+    uint8_t *alpha = reinterpret_cast<uint8_t *>(tile + sk_tile_dw(NT));
+    if (MODE == 2) {
+        for (int i = threadIdx.x; i < 256; i += NT) alpha[i] = a.alphabet[i];
+        __syncthreads();
+    }
+    const SketchWork w = a.work[blockIdx.x];
+    const uint64_t bound = a.bound, cap = a.capacity;
+    stream_chunk<K, MODE, NT>(a.bases, w, tile, alpha, a.fold_case != 0, a.seed, a.use64 != 0,
+                              [&](uint64_t h, uint64_t kpos) {
+        if (h > bound) return;
+        const unsigned long long at = atomicAdd(a.count, 1ull);
+        if (at < cap) a.out[at] = HashEvent{(unsigned long long)h, (unsigned long long)kpos};
+    });
+}
+
+template <int K, int MODE>
+static hipError_t launch_events_one(const EventArgs &a, uint32_t nwork, hipStream_t stream)
+{
+    const size_t smem = (size_t)sk_tile_dw(256) * 4 + 256 + 64;
+    hipLaunchKernelGGL((hash_events_kernel<K, MODE>), dim3(nwork), dim3(256), smem, stream, a);
+    return hipGetLastError();
+}
+
+template <int MODE>
+static hipError_t launch_events_k(int k, const EventArgs &a, uint32_t nwork, hipStream_t st)
+{
+    switch (k) {
+#define MG_CASE(KK) case KK: return launch_events_one<KK, MODE>(a, nwork, st);
+        MG_CASE(SK_K0 + 1) MG_CASE(SK_K0 + 2) MG_CASE(SK_K0 + 3) MG_CASE(SK_K0 + 4)
+        MG_CASE(SK_K0 + 5) MG_CASE(SK_K0 + 6) MG_CASE(SK_K0 + 7) MG_CASE(SK_K0 + 8)
+#undef MG_CASE
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t SK_PARTFN(launch_events_part)(int k, int mode, const EventArgs &a, uint32_t nwork, hipStream_t stream)
+{
+    if (mode == 0) return launch_events_k<0>(k, a, nwork, stream);
+    if (mode == 1) return launch_events_k<1>(k, a, nwork, stream);
+    return launch_events_k<2>(k, a, nwork, stream);
+}
+
+#if SK_PART == 0
+hipError_t launch_events_part1(int, int, const EventArgs &, uint32_t, hipStream_t);
+hipError_t launch_events_part2(int, int, const EventArgs &, uint32_t, hipStream_t);
+hipError_t launch_events_part3(int, int, const EventArgs &, uint32_t, hipStream_t);
+
+hipError_t launch_hash_events(int k, int mode, const EventArgs &a, uint32_t nwork, hipStream_t stream)
+{
+    if (nwork == 0) return hipSuccess;
+    switch ((k - 1) / 8) {
+        case 0: return launch_events_part0(k, mode, a, nwork, stream);
+        case 1: return launch_events_part1(k, mode, a, nwork, stream);
+        case 2: return launch_events_part2(k, mode, a, nwork, stream);
+        case 3: return launch_events_part3(k, mode, a, nwork, stream);
+    }
+    return hipErrorInvalidValue;
+}
+#endif  // SK_PART == 0
+
 template <int K, int MODE>
 static hipError_t launch_range_one(const RangeCountArgs &a, uint32_t nwork, hipStream_t stream)
 {

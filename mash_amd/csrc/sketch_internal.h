@@ -89,6 +89,24 @@ struct RangeCountArgs {
     uint32_t use64;
     uint32_t fold_case;
 };
+// every k-mer hash <= bound with its position, appended in arbitrary order (the sequential
+// heap of `mash sketch -r -c` is replayed on the host over this thinned stream)
+struct HashEvent {
+    unsigned long long hash, pos;
+};
+struct EventArgs {
+    const uint8_t *bases;
+    const SketchWork *work;
+    const uint8_t *alphabet;
+    HashEvent *out;
+    unsigned long long *count;    // events produced (may exceed capacity)
+    uint64_t capacity;
+    uint64_t bound;               // inclusive
+    uint32_t seed;
+    uint32_t use64;
+    uint32_t fold_case;
+};
+hipError_t launch_hash_events(int k, int mode, const EventArgs &a, uint32_t nwork, hipStream_t stream);
 hipError_t launch_range_count(int k, int mode, const RangeCountArgs &a, uint32_t nwork, hipStream_t stream);
 hipError_t launch_range_extract(const unsigned long long *keys, const uint32_t *cnts, uint64_t slots,
                                 uint32_t min_copies, unsigned long long *out, unsigned long long *out_n,

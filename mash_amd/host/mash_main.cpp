@@ -165,6 +165,7 @@ struct Params {                               // Sketch::Parameters (Sketch.h:34
     float warning = 0;
     uint64_t genome_size = 0;
     uint32_t min_copies = 1;                  // minCov (-m)
+    double target_cov = 0;                    // targetCov (-c)
     int threads = 1;                          // -p: files parsed concurrently (the GPU does the sketching)
     string alphabet;                          // normalised (uppercased unless preserve_case), sorted
     uint32_t alphabet_size = 0;
@@ -207,12 +208,12 @@ int sketch_parameter_setup(Params &p, const Cmd &c)
             cerr << "ERROR: The option " << c.o("minCov").id << " cannot be used with " << c.o("memory").id << "." << endl;
             return 1;
         }
-        if (c.o("memory").active || c.o("targetCov").active) {
-            cerr << "ERROR: The options -b (Bloom filter) and -c (early stop) depend on the order k-mers are "
-                    "seen and are not supported by the GPU sketching path." << endl;
+        if (c.o("memory").active) {
+            cerr << "ERROR: The option -b (Bloom filter) is not supported by the GPU sketching path." << endl;
             return 1;
         }
         p.reads = true;
+        if (c.o("targetCov").active) p.target_cov = c.o("targetCov").num;          // sketchParameterSetup.cpp:24
         if (c.o("minCov").num >= 1) p.min_copies = (uint32_t)c.o("minCov").num;   // Sketch.cpp:1156 (reads mode only)
     }
     if (c.o("genome").active) { p.reads = true; p.genome_size = (uint64_t)c.o("genome").num; }
@@ -435,11 +436,36 @@ void sketch_reads(Gpu &gpu, SketchSet &set, const vector<string> &files)
         // records shorter than k are skipped without advancing to the next file (Sketch.cpp:1222-1226)
     }
     for (auto *r : readers) delete r;
-    if (count > 1) ref.comment = "[" + std::to_string(count) + " seqs] " + ref.comment + " [...]";
     if (l != -1) { cerr << "\nERROR: reading input files." << endl; exit(1); }
     if (count == 0) { cerr << "\nERROR: Did not find fasta records in \"input files\"." << endl; exit(1); }
-    b.end_sketch(std::move(ref));
-    flush_batch(gpu, set, b);
+    uint64_t reads_used = (uint64_t)count;
+    auto wrap_comment = [&](uint64_t n) {                   // "[N seqs] first [...]" (Sketch.cpp:1284-1292)
+        if (n > 1) ref.comment = "[" + std::to_string(n) + " seqs] " + ref.comment + " [...]";
+    };
+    if (set.p.target_cov > 0) {
+        // -c: the sequential heap decides where reading stops (Sketch.cpp:1258); replayed exactly
+        mg_params mp;
+        mg_params_init(&mp, set.p.kmer, set.p.sketch_size, set.p.seed, set.p.alphabet.c_str(), set.p.noncanonical,
+                       set.p.preserve_case);
+        mp.min_copies = set.p.min_copies;
+        mp.target_cov = set.p.target_cov;
+        const uint64_t s = set.p.sketch_size;
+        vector<uint64_t> hashes(s);
+        vector<uint32_t> counts(s);
+        uint32_t nh = 0;
+        if (mg_sketch_reads_host(gpu.ctx, &mp, b.bases.data(), b.bases.size(), hashes.data(), &nh, counts.data(), &reads_used) != MG_OK) {
+            cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl;
+            exit(1);
+        }
+        ref.hashes.assign(hashes.begin(), hashes.begin() + nh);
+        ref.counts.assign(counts.begin(), counts.begin() + nh);
+        wrap_comment(reads_used);                              // the reference counts the reads it consumed
+        set.refs.push_back(std::move(ref));
+    } else {
+        wrap_comment(reads_used);
+        b.end_sketch(std::move(ref));
+        flush_batch(gpu, set, b);
+    }
     Ref &r = set.refs.back();
     // estimateSetSize (MinHashHeap.h:45): 2^bits * n / max kept hash
     double est = 0;
@@ -450,6 +476,7 @@ void sketch_reads(Gpu &gpu, SketchSet &set, const vector<string> &files)
     double msum = 0;                                       // estimateMultiplicity (MinHashHeap.h:44)
     for (uint32_t c : r.counts) msum += c;
     cerr << "Estimated coverage:    " << (r.counts.empty() ? 0.0 : msum / (double)r.counts.size()) << endl;
+    if (set.p.target_cov > 0) cerr << "Reads used:            " << reads_used << endl;      // Sketch.cpp:1324-1327
 }
 
 // the .msh branch of Sketch::initFromFiles (Sketch.cpp:120-172) + loadCapnp

@@ -296,9 +296,18 @@ int oracle_sketch_records(const char *bases, const uint64_t *rec_off, uint64_t n
                           uint64_t *hashes_out, uint32_t *counts_out, uint64_t *n_out,
                           uint64_t *length_out, double *set_size_out)
 {
+    return oracle_sketch_reads(bases, rec_off, nrec, p, hashes_out, counts_out, n_out, length_out, set_size_out,
+                               NULL, NULL);
+}
+
+int oracle_sketch_reads(const char *bases, const uint64_t *rec_off, uint64_t nrec,
+                        const oracle_params *p,
+                        uint64_t *hashes_out, uint32_t *counts_out, uint64_t *n_out,
+                        uint64_t *length_out, double *set_size_out, uint64_t *used_out, double *mult_out)
+{
     /* Sketch.cpp:1156: minCov applies in reads mode; callers set min_copies only then */
     oracle_heap *h = oracle_heap_new_m(p->sketch_size, p->use64, p->min_copies > 1 ? p->min_copies : 1);
-    uint64_t length = 0;
+    uint64_t length = 0, used = 0;
     int any = 0;
     for (uint64_t r = 0; r < nrec; r++) {
         uint64_t l = rec_off[r + 1] - rec_off[r];
@@ -310,7 +319,12 @@ int oracle_sketch_records(const char *bases, const uint64_t *rec_off, uint64_t n
         copy[l] = 0;
         oracle_add_min_hashes(h, copy, l, p);
         free(copy);
+        used++;
+        /* :1258 (reads mode): stop as soon as the average multiplicity reaches the target */
+        if (p->target_cov > 0 && oracle_heap_estimate_multiplicity(h) >= p->target_cov) break;
     }
+    if (used_out) *used_out = used;
+    if (mult_out) *mult_out = oracle_heap_estimate_multiplicity(h);
     uint64_t n = oracle_heap_to_list(h, hashes_out, counts_out);
     if (n_out) *n_out = n;
     if (length_out) *length_out = length;

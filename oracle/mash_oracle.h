@@ -42,6 +42,7 @@ typedef struct {
     int      preserve_case;    /* ::preserveCase                        (Sketch.h:89)  */
     uint8_t  alphabet[256];    /* ::alphabet                            (Sketch.h:87)  */
     uint32_t min_copies;       /* ::minCov (reads mode, -m)             (Sketch.h:102); 0 or 1 = off */
+    double   target_cov;       /* ::targetCov (reads mode, -c)          (Sketch.h:103); 0 = off      */
 } oracle_params;
 
 /* setAlphabetFromString, Sketch.cpp:1108-1137 (fills alphabet + use64). */
@@ -89,6 +90,14 @@ int oracle_sketch_records(const char *bases, const uint64_t *rec_off, uint64_t n
 /* translate / aaFromCodon, CommandScreen.cpp:617-809: dst[a] = amino acid of the codon
  * src[3a..3a+2] (standard code, upper-case ACGT only); any other byte in the codon gives '*'. */
 void oracle_translate(const char *src, char *dst, uint64_t len);
+
+/* Same, reads mode with the early stop of -c (Sketch.cpp:1258): after every record the loop
+ * ends once estimateMultiplicity() >= p->target_cov.  *used_out = records (>= k long) consumed,
+ * the "Reads used" line (:1324-1327); *mult_out = estimateMultiplicity at the end. */
+int oracle_sketch_reads(const char *bases, const uint64_t *rec_off, uint64_t nrec,
+                        const oracle_params *p,
+                        uint64_t *hashes_out, uint32_t *counts_out, uint64_t *n_out,
+                        uint64_t *length_out, double *set_size_out, uint64_t *used_out, double *mult_out);
 
 typedef struct {
     uint64_t numer;     /* PairOutput::numer    CommandDistance.h:63-70 */

@@ -27,6 +27,7 @@ class OracleParams(C.Structure):
         ("preserve_case", C.c_int),
         ("alphabet", C.c_uint8 * 256),
         ("min_copies", C.c_uint32),
+        ("target_cov", C.c_double),
     ]
 
 
@@ -101,9 +102,10 @@ class Oracle:
 
     # -- parameters --------------------------------------------------------
     def params(self, k=21, s=1000, seed=42, alphabet="ACGT", noncanonical=False,
-               preserve_case=False, min_copies=1):
+               preserve_case=False, min_copies=1, target_cov=0.0):
         p = OracleParams()
         p.min_copies = min_copies
+        p.target_cov = target_cov
         p.kmer_size = k
         p.sketch_size = s
         p.seed = seed
@@ -148,6 +150,22 @@ class Oracle:
         rc = self._sketch(C.c_char_p(bases), _u64p(off), C.c_uint64(len(records)), C.byref(p),
                           _u64p(hashes), _u32p(counts), C.byref(n), C.byref(length), C.byref(setsz))
         return hashes[: n.value].copy(), counts[: n.value].copy(), int(length.value), float(setsz.value), rc
+
+    def sketch_reads(self, records, p):
+        """reads mode with the -c early stop: (hashes, counts, set_size, records_used, multiplicity)"""
+        bases = b"".join(records)
+        off = np.zeros(len(records) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(r) for r in records], dtype=np.uint64)
+        s = int(p.sketch_size)
+        hashes = np.zeros(s, dtype=np.uint64)
+        counts = np.zeros(s, dtype=np.uint32)
+        n, length, used = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        setsz, mult = C.c_double(0), C.c_double(0)
+        fn = getattr(self.lib, self.prefix + "sketch_reads")
+        fn.restype = C.c_int
+        fn(C.c_char_p(bases), _u64p(off), C.c_uint64(len(records)), C.byref(p), _u64p(hashes), _u32p(counts),
+           C.byref(n), C.byref(length), C.byref(setsz), C.byref(used), C.byref(mult))
+        return hashes[: n.value].copy(), counts[: n.value].copy(), float(setsz.value), int(used.value), float(mult.value)
 
     # -- comparing ---------------------------------------------------------
     def compare(self, a, b, len_a, len_b, s, k, kmer_space, max_d=-1.0, max_p=-1.0, use64=True):

@@ -80,15 +80,29 @@ uint64_t ref_get_hash(const char *kmer, int k, uint32_t seed, int use64)
 }
 
 /* same contract as oracle_sketch_records */
+int ref_sketch_reads(const char *bases, const uint64_t *rec_off, uint64_t nrec,
+                     const oracle_params *p,
+                     uint64_t *hashes_out, uint32_t *counts_out, uint64_t *n_out,
+                     uint64_t *length_out, double *set_size_out, uint64_t *used_out, double *mult_out);
+
 int ref_sketch_records(const char *bases, const uint64_t *rec_off, uint64_t nrec,
                        const oracle_params *p,
                        uint64_t *hashes_out, uint32_t *counts_out, uint64_t *n_out,
                        uint64_t *length_out, double *set_size_out)
 {
+    return ref_sketch_reads(bases, rec_off, nrec, p, hashes_out, counts_out, n_out, length_out, set_size_out, 0, 0);
+}
+
+/* the record loop of sketchFile with the reference's MinHashHeap and its -c early stop (Sketch.cpp:1258) */
+int ref_sketch_reads(const char *bases, const uint64_t *rec_off, uint64_t nrec,
+                     const oracle_params *p,
+                     uint64_t *hashes_out, uint32_t *counts_out, uint64_t *n_out,
+                     uint64_t *length_out, double *set_size_out, uint64_t *used_out, double *mult_out)
+{
     Sketch::Parameters P;
     fill_params(P, p);
     MinHashHeap heap(P.use64, P.minHashesPerWindow, p->min_copies > 1 ? p->min_copies : 1, 0);   // Sketch.cpp:1156
-    uint64_t length = 0;
+    uint64_t length = 0, used = 0;
     bool any = false;
     for (uint64_t r = 0; r < nrec; r++) {
         uint64_t l = rec_off[r + 1] - rec_off[r];
@@ -98,7 +112,11 @@ int ref_sketch_records(const char *bases, const uint64_t *rec_off, uint64_t nrec
         vector<char> copy(bases + rec_off[r], bases + rec_off[r] + l);
         copy.push_back(0);
         addMinHashes(heap, copy.data(), l, P);
+        used++;
+        if (p->target_cov > 0 && heap.estimateMultiplicity() >= p->target_cov) break;
     }
+    if (used_out) *used_out = used;
+    if (mult_out) *mult_out = heap.estimateMultiplicity();
     Sketch::Reference ref;
     ref.hashesSorted.setUse64(P.use64);
     setMinHashesForReference(ref, heap);

@@ -16,6 +16,7 @@ Reference-run vectors (oracle/_ref = the reference's own objects, run here):
   random sketch pairs                     -> ref_compare_vectors.npz
   read sets with -m 2..5                  -> ref_sketch_vectors_m.npz
   aaFromCodon over all codons             -> codon_table.json
+  read sets with -c (and -m)              -> ref_sketch_vectors_c.npz
 """
 import gzip
 import json
@@ -132,7 +133,46 @@ def main():
                         numer=numer, denom=denom, dist=dist, pval=pval, k=21, kmer_space=kspace)
     make_mincopies_vectors(ref)
     make_codon_table(ref)
+    make_cov_vectors(ref)
     print("golden fixtures written to", HERE)
+
+
+def make_cov_vectors(ref):
+    """`mash sketch -r -c <cov>` (and with -m): the record loop of sketchFile with the reference's
+    MinHashHeap and its early stop (Sketch.cpp:1258) -> ref_sketch_vectors_c.npz (hashes, counts,
+    reads used)."""
+    from mash_amd import synth
+    rng = np.random.default_rng(9090)
+    outs, cfgs = {}, []
+    for idx, (k, s, m, cov, glen, nreads) in enumerate([
+        (21, 1000, 1, 2.0, 20000, 4000),
+        (21, 200, 1, 5.0, 5000, 3000),
+        (21, 200, 2, 3.0, 5000, 3000),
+        (16, 100, 1, 1.2, 4000, 1500),     # 32-bit hashes
+        (11, 64, 3, 6.0, 3000, 2500),
+        (21, 500, 1, 50.0, 4000, 800),     # never reached: all reads used
+    ]):
+        g = synth._rand_dna(rng, glen)
+        recs = []
+        for _ in range(nreads):
+            l = int(rng.integers(40, 151))
+            st = int(rng.integers(0, glen - l))
+            r = bytearray(g[st:st + l])
+            if rng.random() < 0.1:
+                r[int(rng.integers(0, l))] = ord("N")
+            if rng.random() < 0.5:
+                r = bytearray(bytes(r).translate(bytes.maketrans(b"ACGTN", b"TGCAN"))[::-1])
+            recs.append(bytes(r))
+        recs.insert(3, b"ACGTAC")
+        p = ref.params(k=k, s=s, min_copies=m, target_cov=cov)
+        h, c, setsz, used, mult = ref.sketch_reads(recs, p)
+        cfgs.append(dict(k=k, s=s, min_copies=m, target_cov=cov, nrec=len(recs), used=used, set_size=setsz, mult=mult, idx=idx))
+        outs[f"bases_{idx}"] = np.frombuffer(b"".join(recs), dtype=np.uint8)
+        outs[f"reclen_{idx}"] = np.array([len(x) for x in recs], dtype=np.uint64)
+        outs[f"hashes_{idx}"] = h
+        outs[f"counts_{idx}"] = c
+    outs["cfgs"] = np.array(json.dumps(cfgs))
+    np.savez_compressed(f"{HERE}/ref_sketch_vectors_c.npz", **outs)
 
 
 def make_codon_table(ref):
@@ -196,9 +236,9 @@ def make_mincopies_vectors(ref):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] in ("mincopies", "codons"):
+    if len(sys.argv) > 1 and sys.argv[1] in ("mincopies", "codons", "cov"):
         from oracle import pyoracle
         pyoracle.build(ref=True)
-        {"mincopies": make_mincopies_vectors, "codons": make_codon_table}[sys.argv[1]](pyoracle.Oracle(ref=True))
+        {"mincopies": make_mincopies_vectors, "codons": make_codon_table, "cov": make_cov_vectors}[sys.argv[1]](pyoracle.Oracle(ref=True))
     else:
         main()

@@ -285,6 +285,15 @@ def test_make_test_recipe_on_gpu(built, tmp_path, oracle):
     oh, oc2, _, osz, _ = oracle.sketch_records(recs, oracle.params(k=21, s=1000, min_copies=2))
     assert hashes2 == [int(x) for x in oh] and counts2 == [int(x) for x in oc2]
     assert '"length" : %d,' % int(osz) in dump2 and min(counts2) >= 2 and "Estimated coverage:" in r2.stderr
+    # -c 3: reading stops once the average multiplicity of the kept hashes reaches 3 (Sketch.cpp:1258)
+    r3 = run("sketch", "-r", "-c", "3", "-o", "reads_c3", "reads1.fastq", "reads2.fastq", cwd=tmp_path)
+    oh3, oc3, osz3, oused3, omult3 = oracle.sketch_reads(recs, oracle.params(k=21, s=1000, target_cov=3.0))
+    dump3 = run("info", "-d", "reads_c3.msh", cwd=tmp_path).stdout
+    ha, hb = dump3.index('\t\t\t"hashes" :'), dump3.index('\t\t\t"counts" :')
+    hashes3 = [int(x.strip().rstrip(",")) for x in dump3[ha:hb].splitlines()[2:] if x.strip().rstrip(",").isdigit()]
+    assert hashes3 == [int(x) for x in oh3]
+    assert "Reads used:            %d" % oused3 in r3.stderr and '"comment" : "[%d seqs] ' % oused3 in dump3
+    assert "Estimated coverage:    %s" % helpers.fmt_g(omult3) in r3.stderr
     bad = run("sketch", "-r", "-m", "2", "-b", "1G", "-o", "x", "reads1.fastq", cwd=tmp_path, check=False)
     assert bad.returncode == 1 and "cannot be used with" in bad.stderr
     hist = run("info", "-c", "reads.msh", cwd=tmp_path).stdout.splitlines()

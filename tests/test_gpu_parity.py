@@ -173,6 +173,46 @@ def test_sketch_beyond_lds_selector(eng, oracle, k, s):
     t.free()
 
 
+def test_sketch_target_coverage_reference_run_vectors(eng):
+    """-c on the device + host replay == the reference's record loop with its own MinHashHeap
+    (tests/golden/ref_sketch_vectors_c.npz): reads used, hashes, counts."""
+    for cfg, recs, gh, gc in helpers.load_ref_sketch_vectors("ref_sketch_vectors_c.npz"):
+        p = eng.params(k=cfg["k"], s=cfg["s"], min_copies=cfg["min_copies"], target_cov=cfg["target_cov"])
+        h, c, used = eng.sketch_reads(recs, p)
+        assert used == cfg["used"], cfg
+        assert np.array_equal(h, gh) and np.array_equal(c, gc), cfg
+
+
+@pytest.mark.parametrize("k,s,m", [(21, 200, 1), (21, 1000, 1), (16, 100, 2), (11, 64, 3), (31, 300, 1)])
+def test_sketch_target_coverage_early_stop(eng, oracle, k, s, m):
+    """`mash sketch -r -c <cov>`: the sequential heap decides after which read the input ends
+    (Sketch.cpp:1258).  Device event stream + host replay against the oracle: same hashes, same
+    counts, same number of reads used; thresholds below, inside and beyond what the input reaches,
+    with and without -m."""
+    rng = np.random.default_rng(k * 100 + s)
+    g = synth._rand_dna(rng, 6000)
+    reads = []
+    for _ in range(3000):
+        l = int(rng.integers(30, 150))
+        st = int(rng.integers(0, 6000 - l))
+        r = g[st:st + l]
+        if rng.random() < 0.1:
+            r = r[: l // 2] + b"N" + r[l // 2 + 1:]
+        reads.append(r if rng.random() < 0.5 else _revcomp(r))
+    reads.insert(5, b"ACGT")                                          # shorter than k: not counted
+    for cov in (1.01, 1.7, 4.0, 11.5, 1000.0):
+        p = eng.params(k=k, s=s, min_copies=m, target_cov=cov)
+        gh, gc, used = eng.sketch_reads(reads, p)
+        oh, oc, _, oused, omult = oracle.sketch_reads(reads, oracle.params(k=k, s=s, min_copies=m, target_cov=cov))
+        assert used == oused, (k, s, m, cov, used, oused)
+        assert np.array_equal(gh, oh) and np.array_equal(gc, oc), (k, s, m, cov)
+    long_enough = sum(1 for r in reads if len(r) >= k)
+    assert used == long_enough                                        # 1000x is never reached: everything is read
+    h0, c0, u0 = eng.sketch_reads(reads, eng.params(k=k, s=s, min_copies=m))       # target_cov 0: plain reads mode
+    ph, pn, pc = eng.sketch_host([reads], eng.params(k=k, s=s, min_copies=m), counts=True)
+    assert u0 == long_enough and np.array_equal(h0, ph[0, : pn[0]]) and np.array_equal(c0, pc[0, : pn[0]])
+
+
 def test_sketch_reads_json_golden(eng, golden_dir):
     """mash sketch -r reads1.fastq reads2.fastq == test/ref/reads.json (hashes)."""
     r1 = helpers.read_fastx(os.path.join(golden_dir, "reads1.fastq.gz"))

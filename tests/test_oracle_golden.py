@@ -129,6 +129,17 @@ def test_oracle_min_copies_equals_reference_vectors(oracle):
         assert len(diff) == 0 or (len(diff) == 1 and diff[0] == len(gh) - 1 and len(gh) == cfg["s"]), cfg
 
 
+def test_oracle_target_coverage_equals_reference_vectors(oracle):
+    """`-c`: the restated record loop stops after the same read as the reference's (reads used),
+    with the same hashes and counts (tests/golden/ref_sketch_vectors_c.npz)."""
+    for cfg, recs, gh, gc in helpers.load_ref_sketch_vectors("ref_sketch_vectors_c.npz"):
+        p = oracle.params(k=cfg["k"], s=cfg["s"], min_copies=cfg["min_copies"], target_cov=cfg["target_cov"])
+        h, c, setsz, used, mult = oracle.sketch_reads(recs, p)
+        assert used == cfg["used"] and setsz == cfg["set_size"] and mult == cfg["mult"], cfg
+        assert np.array_equal(h, gh) and np.array_equal(c, gc), cfg
+    assert any(c["used"] < c["nrec"] - 1 for c, _, _, _ in helpers.load_ref_sketch_vectors("ref_sketch_vectors_c.npz"))
+
+
 def test_oracle_translate_equals_reference_codon_table(oracle, golden_dir):
     """6-frame translation of `mash screen` (CommandScreen.cpp:617-809): the restated table vs
     the output of the reference's own aaFromCodon for all 64 codons + invalid ones."""
