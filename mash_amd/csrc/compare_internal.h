@@ -60,6 +60,10 @@ hipError_t launch_row_classes(const uint64_t *hashes, const uint32_t *nhash, uin
 uint64_t compare_pfx_stride(uint64_t s);          // row stride (u32 entries) of the padded prefix image
 hipError_t launch_make_prefix(const uint64_t *hashes, const uint32_t *nhash, uint64_t n, uint64_t s,
                               uint64_t pfx_stride, uint32_t shr, uint32_t *out, hipStream_t stream);
+// Merge-path kernel (s <= ~4000): one wave per pair, row in LDS; ~500 instructions per pair
+// whatever the pair shares.
+bool compare_pairs_supported(uint32_t s);
+hipError_t launch_compare_pairs(const CompareArgs &a, hipStream_t stream);
 // Generic kernel (any s): one wave per pair, binary search in global memory.
 hipError_t launch_compare_generic(const CompareArgs &a, hipStream_t stream);
 

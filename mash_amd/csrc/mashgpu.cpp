@@ -919,6 +919,13 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
     a.unroll = 0;
     if (const char *e = getenv("MASHGPU_COMPARE_VARIANT")) a.unroll = (uint32_t)atoi(e);
     const char *force = getenv("MASHGPU_COMPARE_KERNEL");
+    if (force && strcmp(force, "pairs") == 0 && mg::compare_pairs_supported(a.s)) {
+        prof_begin(ctx, ctx->prof_compare);
+        HIP_TRY(ctx, mg::launch_compare_pairs(a, ctx->stream));
+        prof_end(ctx, ctx->prof_compare);
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return MG_OK;
+    }
     const bool want_generic = force && strcmp(force, "generic") == 0;
     const bool want_tiled = force && strcmp(force, "tiled") == 0;
     const bool use_merged = !want_tiled && !want_generic && mg::compare_merged_supported(a.s);

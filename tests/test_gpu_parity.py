@@ -262,7 +262,7 @@ def _oracle_tri(oracle, table, nhash, lengths, rb, re, k=21, kspace=KSPACE21):
     return numer, denom
 
 
-@pytest.mark.parametrize("kernel", ["merged", "tiled", "generic"])
+@pytest.mark.parametrize("kernel", ["merged", "tiled", "generic", "pairs"])
 def test_compare_reference_run_vectors(eng, golden_dir, kernel, monkeypatch):
     monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", kernel)
     z = np.load(os.path.join(golden_dir, "ref_compare_vectors.npz"))
@@ -277,7 +277,7 @@ def test_compare_reference_run_vectors(eng, golden_dir, kernel, monkeypatch):
     t.free()
 
 
-@pytest.mark.parametrize("kernel", ["merged", "tiled"])
+@pytest.mark.parametrize("kernel", ["merged", "tiled", "pairs"])
 @pytest.mark.parametrize("s", [1, 7, 64, 65, 100, 400, 1000, 1024])
 def test_compare_tiled_vs_oracle_sizes(eng, oracle, s, kernel, monkeypatch):
     monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", kernel)
@@ -332,7 +332,7 @@ def test_compare_extremes_and_random(eng, oracle):
     t.free()
 
 
-@pytest.mark.parametrize("kernel", ["merged", "tiled"])
+@pytest.mark.parametrize("kernel", ["merged", "tiled", "pairs"])
 @pytest.mark.parametrize("top", [0xFFFFFFFF, 0xFFFFFFFFFFFFFFFE, 0xFFFFFFFE00000000])
 def test_compare_values_at_the_top_of_the_hash_range(eng, oracle, kernel, top, monkeypatch):
     """32-bit sketches reaching 0xFFFFFFFF / 64-bit sketches reaching 2^64-2: the prefix image
@@ -362,7 +362,7 @@ def test_compare_values_at_the_top_of_the_hash_range(eng, oracle, kernel, top, m
     t.free()
 
 
-@pytest.mark.parametrize("kernel", ["merged", "tiled"])
+@pytest.mark.parametrize("kernel", ["merged", "tiled", "pairs"])
 def test_compare_mixed_hash_densities(eng, oracle, kernel, monkeypatch):
     """Sketches of very different genome sizes in one table (hash ranges from 2^44 to 2^64):
     the merged kernel tiles rows by density class and compares every class through its own
@@ -406,11 +406,13 @@ def test_compare_mixed_hash_densities(eng, oracle, kernel, monkeypatch):
     t.free(); tq.free()
 
 
+@pytest.mark.parametrize("kernel", ["merged", "pairs"])
 @pytest.mark.parametrize("seed", range(24))
-def test_compare_random_tables_vs_oracle(eng, oracle, seed):
+def test_compare_random_tables_vs_oracle(eng, oracle, seed, kernel, monkeypatch):
     """Randomised tables: any sketch size, ragged / empty / identical rows, values shared between
     rows (several rows of a tile holding the same value), hash ranges from 2^20 to 2^64, random
     row ranges, triangle and rect -- the merged kernel against the oracle, bit for bit."""
+    monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", kernel)
     rng = np.random.default_rng(1000 + seed)
     s = int(rng.choice([1, 2, 3, 5, 17, 64, 100, 257, 600, 1000, 1024, 1500]))
     n = int(rng.integers(2, 70))
@@ -461,7 +463,7 @@ def test_compare_random_tables_vs_oracle(eng, oracle, seed):
     t.free()
 
 
-@pytest.mark.parametrize("kernel", ["merged", "tiled"])
+@pytest.mark.parametrize("kernel", ["merged", "tiled", "pairs"])
 @pytest.mark.parametrize("seed", range(6))
 def test_compare_values_sharing_a_prefix(eng, oracle, kernel, seed, monkeypatch):
     """Different 64-bit values that share their 32-bit prefix, inside one row, across rows of a

@@ -37,7 +37,7 @@ def main():
     for rd in range(a.rounds + 1):
         for v in a.variants:
             parts = v.split(":")
-            if parts[0] in ("merged", "tiled", "generic"):
+            if parts[0] in ("merged", "tiled", "generic", "pairs"):
                 os.environ["MASHGPU_COMPARE_KERNEL"] = parts[0]
                 os.environ.pop("MASHGPU_COMPARE_VARIANT", None)
             else:
