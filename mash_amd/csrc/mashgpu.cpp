@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mashgpu.h"
@@ -1161,14 +1162,49 @@ static inline void finish_one(const mg_counts &c, uint64_t len_ref, uint64_t len
     o->pass = 1;
 }
 
+// Distance and p-value are ~165 ns of scalar libm work per pair: at 10^7 pairs and more that, not
+// the kernels, is what a caller waits for, so large batches are split over host threads
+// (every pair is independent; the output is identical).
+extern "C++" {
+template <class F>
+static void finish_parallel(uint64_t items, F fn)
+{
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt > 16) nt = 16;
+    if (items < (1ull << 20) || nt < 2) { fn(0, items); return; }
+    std::vector<std::thread> th;
+    const uint64_t per = (items + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; t++) {
+        const uint64_t b = t * per, e = std::min(items, b + per);
+        if (b < e) th.emplace_back([=]() { fn(b, e); });
+    }
+    for (auto &x : th) x.join();
+}
+} // extern "C++"
+
 int mg_finish_tri_host(const mg_counts *counts, const uint64_t *lengths, uint64_t row_begin, uint64_t row_end,
                        int kmer_size, double kmer_space, double max_distance, double max_p_value, mg_pair *out)
 {
     if (!counts || !lengths || !out) return MG_ERR_INVALID;
-    uint64_t idx = 0;
-    for (uint64_t i = row_begin; i < row_end; i++)
-        for (uint64_t j = 0; j < i; j++, idx++)
-            finish_one(counts[idx], lengths[i], lengths[j], kmer_size, kmer_space, max_distance, max_p_value, out + idx);
+    if (row_end <= row_begin) return MG_OK;
+    const uint64_t base = tri_pairs(0, row_begin), total = tri_pairs(row_begin, row_end);
+    // split by pairs, then round each cut up to a row boundary, so threads get equal work
+    auto row_of = [=](uint64_t pair) {
+        uint64_t lo = row_begin, hi = row_end;           // first row whose start is >= pair
+        while (lo < hi) {
+            const uint64_t mid = lo + (hi - lo) / 2;
+            if (tri_pairs(0, mid) - base >= pair) hi = mid; else lo = mid + 1;
+        }
+        return lo;
+    };
+    finish_parallel(total, [=](uint64_t b, uint64_t e) {
+        const uint64_t r0 = row_of(b), r1 = e >= total ? row_end : row_of(e);
+        for (uint64_t i = r0; i < r1; i++) {
+            uint64_t idx = tri_pairs(0, i) - base;
+            for (uint64_t j = 0; j < i; j++, idx++)
+                finish_one(counts[idx], lengths[i], lengths[j], kmer_size, kmer_space, max_distance, max_p_value, out + idx);
+        }
+    });
     return MG_OK;
 }
 
@@ -1177,11 +1213,12 @@ int mg_finish_rect_host(const mg_counts *counts, const uint64_t *len_ref, uint64
                         mg_pair *out)
 {
     if (!counts || !len_ref || !len_qry || !out) return MG_ERR_INVALID;
-    for (uint64_t q = 0; q < nqry; q++)
-        for (uint64_t r = 0; r < nref; r++) {
-            const uint64_t idx = q * nref + r;
+    finish_parallel(nqry * nref, [=](uint64_t b, uint64_t e) {
+        for (uint64_t idx = b; idx < e; idx++) {
+            const uint64_t q = idx / nref, r = idx - q * nref;
             finish_one(counts[idx], len_ref[r], len_qry[q], kmer_size, kmer_space, max_distance, max_p_value, out + idx);
         }
+    });
     return MG_OK;
 }
 

@@ -90,6 +90,40 @@ def test_finish_host_matches_oracle(lib, oracle, golden_dir):
     assert np.array_equal(out2["pass"].astype(bool), exp_pass)
 
 
+def test_finish_host_threaded_matches_serial(lib):
+    """Batches above 2^20 pairs are split over host threads; the bytes must not depend on it.
+    Small calls (one row block each) stay on the calling thread and serve as the reference."""
+    rng = np.random.default_rng(5)
+    n, s = 1600, 1000
+    lengths = rng.integers(10_000, 5_000_000, n).astype(np.uint64)
+    npairs = n * (n - 1) // 2
+    counts = np.zeros(npairs, dtype=abi.COUNTS_DTYPE)
+    counts["numer"] = rng.integers(0, s + 1, npairs)
+    counts["denom"] = s
+    big = np.zeros(npairs, dtype=abi.PAIR_DTYPE)
+    assert lib.mg_finish_tri_host(counts.ctypes.data, lengths.ctypes.data, 0, n, 21, 4.0 ** 21, 0.3, 1e-3,
+                                  big.ctypes.data) == 0
+    small = np.zeros(npairs, dtype=abi.PAIR_DTYPE)
+    for r0 in range(0, n, 400):
+        off = r0 * (r0 - 1) // 2 if r0 else 0
+        assert lib.mg_finish_tri_host(counts[off:].ctypes.data, lengths.ctypes.data, r0, min(n, r0 + 400), 21,
+                                      4.0 ** 21, 0.3, 1e-3, small[off:].ctypes.data) == 0
+    assert big.tobytes() == small.tobytes()
+    # rectangle: 1100 x 1000 in one call vs per-query rows
+    nref, nq = 1100, 1000
+    c2 = counts[: nref * nq]
+    rect = np.zeros(nref * nq, dtype=abi.PAIR_DTYPE)
+    assert lib.mg_finish_rect_host(c2.ctypes.data, lengths[:nref].ctypes.data, nref, lengths[-nq:].ctypes.data, nq,
+                                   21, 4.0 ** 21, -1.0, -1.0, rect.ctypes.data) == 0
+    rows = np.zeros(nref * nq, dtype=abi.PAIR_DTYPE)
+    lq = np.ascontiguousarray(lengths[-nq:])
+    for q in range(0, nq, 250):
+        assert lib.mg_finish_rect_host(c2[q * nref:].ctypes.data, lengths[:nref].ctypes.data, nref,
+                                       lq[q:].ctypes.data, 250, 21, 4.0 ** 21, -1.0, -1.0,
+                                       rows[q * nref:].ctypes.data) == 0
+    assert rect.tobytes() == rows.tobytes()
+
+
 def test_no_gpu_fails_loudly(lib):
     """On a box without a GPU the context cannot be created — no silent fallback."""
     import torch
