@@ -963,6 +963,18 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
         if (rc != MG_OK) return rc;
         std::vector<std::vector<uint32_t>> by_class(65);
         for (uint64_t i = row_begin; i < row_end; i++) by_class[rows->cls[i] > 64 ? 64 : rows->cls[i]].push_back((uint32_t)i);
+        // A launch of few row tiles (a handful of queries against a large database) would leave
+        // most CUs idle with full-length column chunks: cut the columns finer until there are
+        // ~4 tiles per CU (a table build costs about as much as 100 columns, so not below 256).
+        if (!getenv("MASHGPU_COMPARE_COLS")) {
+            uint64_t nrt = 0;
+            for (const auto &list : by_class) nrt += (list.size() + R - 1) / R;
+            if (nrt * ((maxcols + CC - 1) / CC) < 512) {
+                const uint64_t chunks = (1024 + nrt - 1) / nrt;
+                const uint64_t cc = ((maxcols + chunks - 1) / chunks + 63) & ~63ull;
+                CC = std::min<uint64_t>(CC, std::max<uint64_t>(256, cc));
+            }
+        }
         a.dbg = nullptr;
         a.row_pfx_stride = mg::compare_pfx_stride(rows->s);
         a.col_pfx_stride = mg::compare_pfx_stride(cols->s);

@@ -23,6 +23,7 @@
 #include <iostream>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mashgpu.h"
@@ -706,14 +707,15 @@ int cmd_sketch(int argc, const char **argv)
 // reference's `<< endl` formatting is what a run waits for once the kernels take milliseconds.
 struct FastOut {
     string buf;
-    FastOut() { buf.reserve(1u << 22); }
-    ~FastOut() { flush(); }
+    bool sink;                               // false: a worker's piece, appended to the real one in order
+    explicit FastOut(bool to_stdout = true) : sink(to_stdout) { if (sink) buf.reserve(1u << 22); }
+    ~FastOut() { if (sink) flush(); }
     void flush()
     {
         cout.flush();
         if (!buf.empty()) { fwrite(buf.data(), 1, buf.size(), stdout); fflush(stdout); buf.clear(); }
     }
-    void room() { if (buf.size() > (1u << 22) - 4096) flush(); }
+    void room() { if (sink && buf.size() > (1u << 22) - 4096) flush(); }
     FastOut &operator<<(const string &x) { buf += x; return *this; }
     FastOut &operator<<(const char *x) { buf += x; return *this; }
     FastOut &operator<<(char x) { buf += x; return *this; }
@@ -733,6 +735,51 @@ struct FastOut {
     }
     void eol() { buf += '\n'; room(); }
 };
+
+// Text of a block of result rows, formatted on worker threads and written in row order (number
+// formatting, not the GPU, bounds a full matrix: ~50 ns per value on one core).  Rows are cut
+// into chunks of >= 2^17 pairs, a wave of chunks is formatted concurrently, the pieces are
+// appended in order; fn(out, row, slot) must only touch slot-private state besides `out`.
+unsigned emit_threads()
+{
+    static const unsigned nt = []() {
+        if (const char *e = getenv("MASH_AMD_EMIT_THREADS")) return (unsigned)std::min(64, std::max(1, atoi(e)));
+        return std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    }();
+    return nt;
+}
+
+template <class CostFn, class RowFn>
+void emit_rows(FastOut &out, uint64_t r0, uint64_t r1, CostFn cost, RowFn fn)
+{
+    const unsigned nt = emit_threads();
+    vector<uint64_t> cut{r0};
+    uint64_t acc = 0;
+    for (uint64_t r = r0; r < r1; r++) {
+        acc += cost(r);
+        if (acc >= (1u << 17)) { cut.push_back(r + 1); acc = 0; }
+    }
+    if (cut.back() != r1) cut.push_back(r1);
+    const size_t nchunks = cut.size() - 1;
+    if (nt < 2 || nchunks < 2) {
+        for (uint64_t r = r0; r < r1; r++) fn(out, r, 0u);
+        return;
+    }
+    vector<FastOut> part;
+    part.reserve(nt);
+    for (unsigned t = 0; t < nt; t++) part.emplace_back(false);
+    for (size_t c0 = 0; c0 < nchunks; c0 += nt) {
+        const unsigned m = (unsigned)std::min<size_t>(nt, nchunks - c0);
+        vector<std::thread> th;
+        for (unsigned t = 0; t < m; t++)
+            th.emplace_back([&, t]() {
+                part[t].buf.clear();
+                for (uint64_t r = cut[c0 + t]; r < cut[c0 + t + 1]; r++) fn(part[t], r, t);
+            });
+        for (auto &x : th) x.join();
+        for (unsigned t = 0; t < m; t++) { out.buf += part[t].buf; out.room(); }
+    }
+}
 
 void print_pair_line(FastOut &out, const Ref &ref, const Ref &qry, bool comment, const mg_pair &pr)
 {
@@ -865,15 +912,15 @@ int cmd_dist(int argc, const char **argv)
         pairs.resize(counts.size());
         if (mg_compare_rect_host(gpu.ctx, tr, tq, q0, q1, counts.data()) != MG_OK) { cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl; return 1; }
         mg_finish_rect_host(counts.data(), len_ref.data(), nref, len_qry.data() + q0, q1 - q0, ref.p.kmer, kspace, d_max, p_max, pairs.data());
-        for (uint64_t q = q0; q < q1; q++) {                 // writeOutput, CommandDistance.cpp:247-304
-            if (table) out << qry.refs[q].name;
+        emit_rows(out, q0, q1, [&](uint64_t) { return nref; }, [&](FastOut &o, uint64_t q, unsigned) {
+            if (table) o << qry.refs[q].name;                // writeOutput, CommandDistance.cpp:247-304
             for (uint64_t r = 0; r < nref; r++) {
                 const mg_pair &pr = pairs[(q - q0) * nref + r];
-                if (table) { out << '\t'; if (pr.pass) out << pr.distance; out.room(); }
-                else if (pr.pass) print_pair_line(out, ref.refs[r], qry.refs[q], comment, pr);
+                if (table) { o << '\t'; if (pr.pass) o << pr.distance; o.room(); }
+                else if (pr.pass) print_pair_line(o, ref.refs[r], qry.refs[q], comment, pr);
             }
-            if (table) out.eol();
-        }
+            if (table) o.eol();
+        });
     }
     mg_table_free(tr);
     mg_table_free(tq);
@@ -952,26 +999,31 @@ int cmd_triangle(int argc, const char **argv)
         pairs.resize(npairs);
         if (mg_compare_tri_host(gpu.ctx, t, r0, r1, counts.data()) != MG_OK) { cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl; return 1; }
         mg_finish_tri_host(counts.data(), lengths.data(), r0, r1, set.p.kmer, kspace, d_max, p_max, pairs.data());
-        uint64_t idx = 0;
-        for (uint64_t i = r0; i < r1; i++) {                 // writeOutput, CommandTriangle.cpp:159-198
-            const Ref &ref = set.refs[i];
-            if (!edge) out << label(ref);
+        const uint64_t base = r0 * (r0 - 1) / 2;
+        vector<double> peak(emit_threads(), 0.0);
+        emit_rows(out, r0, r1, [](uint64_t i) { return i; }, [&](FastOut &o, uint64_t i, unsigned slot) {
+            const Ref &ref = set.refs[i];                     // writeOutput, CommandTriangle.cpp:159-198
+            uint64_t idx = i * (i - 1) / 2 - base;
+            double pk = peak[slot];
+            if (!edge) o << label(ref);
             for (uint64_t j = 0; j < i; j++, idx++) {
                 const mg_pair &pr = pairs[idx];
                 if (edge) {
                     if (pr.pass) {
-                        out << label(ref) << '\t' << label(set.refs[j]) << '\t' << pr.distance << '\t' << pr.p_value << '\t'
-                            << pr.numer << '/' << pr.denom;
-                        out.eol();
+                        o << label(ref) << '\t' << label(set.refs[j]) << '\t' << pr.distance << '\t' << pr.p_value << '\t'
+                          << pr.numer << '/' << pr.denom;
+                        o.eol();
                     }
                 } else {
-                    out << '\t' << pr.distance;
-                    out.room();
+                    o << '\t' << pr.distance;
+                    o.room();
                 }
-                if (pr.p_value > p_peak) p_peak = pr.p_value;
+                if (pr.p_value > pk) pk = pr.p_value;
             }
-            if (!edge) out.eol();
-        }
+            peak[slot] = pk;
+            if (!edge) o.eol();
+        });
+        for (double v : peak) if (v > p_peak) p_peak = v;
         r0 = r1;
     }
     mg_table_free(t);

@@ -457,3 +457,34 @@ def test_parallel_ingest_keeps_input_order(built, tmp_path):
     missing = run("sketch", "-p", "4", "-o", "x", names[0], "nope.fa", names[1], cwd=tmp_path, check=False)
     assert missing.returncode == 1 and "could not open nope.fa" in missing.stderr
 
+
+
+@pytest.mark.gpu
+def test_large_outputs_do_not_depend_on_formatting_threads(built, tmp_path):
+    """Blocks of result rows are formatted on worker threads (mash_main.cpp::emit_rows) and
+    finished on host threads inside the library; the text must equal the one-thread run."""
+    rng = np.random.default_rng(31)
+    base = np.frombuffer(synth._rand_dna(rng, 3000), dtype=np.uint8)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    with open(tmp_path / "many.fa", "wb") as f:
+        for i in range(1000):
+            seq = base.copy()
+            idx = rng.integers(0, 3000, int(rng.integers(0, 600)))
+            seq[idx] = lut[rng.integers(0, 4, len(idx))]
+            f.write(b">r%d c%d\n%s\n" % (i, i, seq.tobytes()))
+    run("sketch", "-i", "-s", "64", "-k", "15", "-o", "many", "many.fa", cwd=tmp_path)
+    one = {"MASH_AMD_EMIT_THREADS": "1"}
+    many = {"MASH_AMD_EMIT_THREADS": "7"}
+    for cmd in (("triangle", "many.msh"), ("triangle", "-E", "many.msh"), ("triangle", "-C", "-v", "1e-5", "many.msh"),
+                ("dist", "many.msh", "many.msh"), ("dist", "-t", "many.msh", "many.msh"),
+                ("dist", "-v", "1e-8", "-C", "many.msh", "many.msh")):
+        a = run(*cmd, cwd=tmp_path, env=one)
+        b = run(*cmd, cwd=tmp_path, env=many)
+        assert a.stdout == b.stdout and a.stderr == b.stderr, cmd
+        assert len(a.stdout) > 1000
+    tri = run("triangle", "many.msh", cwd=tmp_path, env=many).stdout.splitlines()
+    assert tri[0] == "\t1000" and len(tri) == 1001
+    assert [len(l.split("\t")) for l in tri[1:]] == list(range(1, 1001))
+    d = run("dist", "many.msh", "many.msh", cwd=tmp_path, env=many).stdout.splitlines()
+    assert len(d) == 1000 * 1000
+    assert d[1000 * 7 + 3].split("\t")[:2] == ["r3", "r7"]
