@@ -36,6 +36,14 @@ struct mg_ctx {
     std::string err;
     bool prof = false;
     std::vector<ProfRec> prof_compare, prof_sketch;
+    // tile lists of the compare launches: device buffer + pinned staging, kept across calls
+    // (entry points are synchronous, so a call never finds them in use)
+    void *tile_dev = nullptr, *tile_host = nullptr;
+    size_t tile_cap = 0;
+    // small device blocks handed back by finished calls (ctx_malloc / ctx_free)
+    struct Block { void *p; size_t bytes; };
+    std::vector<Block> blk_free, blk_live;
+    size_t blk_cached = 0;
 };
 
 struct mg_table {
@@ -62,16 +70,72 @@ struct mg_table {
         }                                                                            \
     } while (0)
 
-// device allocation released on every exit path (hipFree synchronises with the device, so
-// nothing launched on the buffer is still running when it goes away)
+// Scratch of the latency-sensitive entry points (one genome sketched, a few queries compared)
+// comes from a per-context cache: hipMalloc + hipFree cost tens of microseconds each and a call
+// makes a dozen of them.  Blocks up to 64 MiB are kept (256 MiB in total) and reused by later
+// calls; everything runs on ctx->stream, so a block handed back while work on it is still
+// queued is only ever touched again by work queued behind it.
+static hipError_t ctx_malloc(mg_ctx *ctx, void **out, size_t bytes)
+{
+    bytes = (std::max<size_t>(bytes, 1) + 255) & ~size_t(255);
+    size_t best = SIZE_MAX;
+    for (size_t i = 0; i < ctx->blk_free.size(); i++) {
+        const size_t b = ctx->blk_free[i].bytes;
+        if (b >= bytes && b <= 2 * bytes + (64u << 10) && (best == SIZE_MAX || b < ctx->blk_free[best].bytes)) best = i;
+    }
+    if (best != SIZE_MAX) {
+        *out = ctx->blk_free[best].p;
+        ctx->blk_live.push_back(ctx->blk_free[best]);
+        ctx->blk_cached -= ctx->blk_free[best].bytes;
+        ctx->blk_free.erase(ctx->blk_free.begin() + (long)best);
+        return hipSuccess;
+    }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipSuccess && !ctx->blk_free.empty()) {          // give the cache back and retry
+        (void)hipGetLastError();
+        for (auto &b : ctx->blk_free) hipFree(b.p);
+        ctx->blk_free.clear();
+        ctx->blk_cached = 0;
+        e = hipMalloc(out, bytes);
+    }
+    if (e == hipSuccess) ctx->blk_live.push_back({*out, bytes});
+    return e;
+}
+
+static void ctx_free(mg_ctx *ctx, void *p)
+{
+    if (!p) return;
+    for (size_t i = 0; i < ctx->blk_live.size(); i++) {
+        if (ctx->blk_live[i].p != p) continue;
+        const mg_ctx::Block b = ctx->blk_live[i];
+        ctx->blk_live.erase(ctx->blk_live.begin() + (long)i);
+        if (b.bytes <= (64u << 20) && ctx->blk_cached + b.bytes <= (256u << 20) && ctx->blk_free.size() < 64) {
+            ctx->blk_free.push_back(b);
+            ctx->blk_cached += b.bytes;
+        } else {
+            hipFree(p);
+        }
+        return;
+    }
+    hipFree(p);                                                // not ours: plain allocation
+}
+
+// device allocation released on every exit path; with a context it comes from the context's
+// block cache, without one hipFree synchronises with the device
 template <class T>
 struct DevBuf {
     T *p = nullptr;
+    mg_ctx *owner = nullptr;
     DevBuf() = default;
+    explicit DevBuf(mg_ctx *ctx) : owner(ctx) {}
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
-    ~DevBuf() { if (p) hipFree(p); }
-    hipError_t alloc(uint64_t count) { return hipMalloc(&p, std::max<uint64_t>(count, 1) * sizeof(T)); }
+    ~DevBuf() { if (p) { if (owner) ctx_free(owner, p); else hipFree(p); } }
+    hipError_t alloc(uint64_t count)
+    {
+        const size_t bytes = std::max<uint64_t>(count, 1) * sizeof(T);
+        return owner ? ctx_malloc(owner, reinterpret_cast<void **>(&p), bytes) : hipMalloc(&p, bytes);
+    }
     T *release() { T *q = p; p = nullptr; return q; }
     operator T *() const { return p; }
 };
@@ -125,6 +189,10 @@ void mg_ctx_destroy(mg_ctx *ctx)
 {
     if (!ctx) return;
     mg_prof_reset(ctx);
+    if (ctx->tile_dev) hipFree(ctx->tile_dev);
+    if (ctx->tile_host) hipHostFree(ctx->tile_host);
+    for (auto &b : ctx->blk_free) hipFree(b.p);
+    for (auto &b : ctx->blk_live) hipFree(b.p);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -425,17 +493,17 @@ static int sketch_dev_impl(mg_ctx *ctx, const mg_params *p, const uint8_t *bases
     int rc = MG_OK;
     auto cleanup = [&]() {
         hipStreamSynchronize(ctx->stream);
-        if (d_work2) hipFree(d_work2);
-        if (d_fix) hipFree(d_fix);
-        if (d_firstpos) hipFree(d_firstpos);
-        if (d_pos2) hipFree(d_pos2);
-        if (d_tstar) hipFree(d_tstar);
-        if (d_work) hipFree(d_work);
-        if (d_merge) hipFree(d_merge);
-        if (d_alpha) hipFree(d_alpha);
-        if (d_pool) hipFree(d_pool);
-        if (d_gT) hipFree(d_gT);
-        if (d_pool_n) hipFree(d_pool_n);
+        if (d_work2) ctx_free(ctx, d_work2);
+        if (d_fix) ctx_free(ctx, d_fix);
+        if (d_firstpos) ctx_free(ctx, d_firstpos);
+        if (d_pos2) ctx_free(ctx, d_pos2);
+        if (d_tstar) ctx_free(ctx, d_tstar);
+        if (d_work) ctx_free(ctx, d_work);
+        if (d_merge) ctx_free(ctx, d_merge);
+        if (d_alpha) ctx_free(ctx, d_alpha);
+        if (d_pool) ctx_free(ctx, d_pool);
+        if (d_gT) ctx_free(ctx, d_gT);
+        if (d_pool_n) ctx_free(ctx, d_pool_n);
     };
 #define TRY_C(call)                                                                   \
     do {                                                                              \
@@ -447,20 +515,20 @@ static int sketch_dev_impl(mg_ctx *ctx, const mg_params *p, const uint8_t *bases
             return rc;                                                                \
         }                                                                             \
     } while (0)
-    TRY_C(hipMalloc(&d_work, work.size() * sizeof(mg::SketchWork)));
+    TRY_C(ctx_malloc(ctx, (void **)&d_work, work.size() * sizeof(mg::SketchWork)));
     TRY_C(hipMemcpyAsync(d_work, work.data(), work.size() * sizeof(mg::SketchWork), hipMemcpyHostToDevice, ctx->stream));
-    TRY_C(hipMalloc(&d_alpha, 256));
+    TRY_C(ctx_malloc(ctx, (void **)&d_alpha, 256));
     TRY_C(hipMemcpyAsync(d_alpha, p->alphabet, 256, hipMemcpyHostToDevice, ctx->stream));
     const uint32_t min_copies = p->min_copies > 1 ? p->min_copies : 1;
     const bool range_path = min_copies > 1 || !lds_selector;
     if (nslots && !range_path) {
-        TRY_C(hipMalloc(&d_pool, nslots * s * 8));
-        TRY_C(hipMalloc(&d_pool_n, nslots * 4));
+        TRY_C(ctx_malloc(ctx, (void **)&d_pool, nslots * s * 8));
+        TRY_C(ctx_malloc(ctx, (void **)&d_pool_n, nslots * 4));
         TRY_C(hipMemsetAsync(d_pool_n, 0, nslots * 4, ctx->stream));
-        TRY_C(hipMalloc(&d_gT, nsketch * 8));
+        TRY_C(ctx_malloc(ctx, (void **)&d_gT, nsketch * 8));
         TRY_C(hipMemsetAsync(d_gT, 0xFF, nsketch * 8, ctx->stream));
         merges.insert(merges.end(), merges1.begin(), merges1.end());      // [final ..., first level ...]
-        TRY_C(hipMalloc(&d_merge, merges.size() * sizeof(mg::MergeWork)));
+        TRY_C(ctx_malloc(ctx, (void **)&d_merge, merges.size() * sizeof(mg::MergeWork)));
         TRY_C(hipMemcpyAsync(d_merge, merges.data(), merges.size() * sizeof(mg::MergeWork), hipMemcpyHostToDevice, ctx->stream));
     }
     mg::SketchArgs a;
@@ -510,10 +578,10 @@ static int sketch_dev_impl(mg_ctx *ctx, const mg_params *p, const uint8_t *bases
     }
     if (counts_out_dev) {
         // multiplicities: re-stream every chunk against the finished sketches (count_chunks_kernel)
-        TRY_C(hipMalloc(&d_firstpos, nsketch * s * 8));
+        TRY_C(ctx_malloc(ctx, (void **)&d_firstpos, nsketch * s * 8));
         TRY_C(hipMemsetAsync(d_firstpos, 0xFF, nsketch * s * 8, ctx->stream));
-        TRY_C(hipMalloc(&d_tstar, nsketch * 8));
-        TRY_C(hipMalloc(&d_fix, nsketch * 4));
+        TRY_C(ctx_malloc(ctx, (void **)&d_tstar, nsketch * 8));
+        TRY_C(ctx_malloc(ctx, (void **)&d_fix, nsketch * 4));
         mg::CountArgs ca;
         ca.bases = bases_dev;
         ca.work = d_work;
@@ -534,7 +602,7 @@ static int sketch_dev_impl(mg_ctx *ctx, const mg_params *p, const uint8_t *bases
         // walk from the first to the m-th position, one pass per step
         unsigned long long *pos_m = d_firstpos;
         if (min_copies > 1) {
-            TRY_C(hipMalloc(&d_pos2, nsketch * s * 8));
+            TRY_C(ctx_malloc(ctx, (void **)&d_pos2, nsketch * s * 8));
             unsigned long long *cur = d_pos2, *prv = d_firstpos;
             for (uint32_t j = 2; j <= min_copies; j++) {
                 TRY_C(hipMemsetAsync(cur, 0xFF, nsketch * s * 8, ctx->stream));
@@ -556,7 +624,7 @@ static int sketch_dev_impl(mg_ctx *ctx, const mg_params *p, const uint8_t *bases
         for (const mg::SketchWork &w : work) if (fix[w.sketch]) work2.push_back(w);
         if (!work2.empty()) {
             // the reference stops counting its largest kept hash once the heap is full with it on top
-            TRY_C(hipMalloc(&d_work2, work2.size() * sizeof(mg::SketchWork)));
+            TRY_C(ctx_malloc(ctx, (void **)&d_work2, work2.size() * sizeof(mg::SketchWork)));
             TRY_C(hipMemcpyAsync(d_work2, work2.data(), work2.size() * sizeof(mg::SketchWork), hipMemcpyHostToDevice, ctx->stream));
             ca.work = d_work2;
             ca.phase = 1;
@@ -578,9 +646,9 @@ int mg_sketch_host(mg_ctx *ctx, const mg_params *p, const uint8_t *bases, uint64
     if (nsketch == 0) return MG_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint64_t s = p->sketch_size;
-    DevBuf<uint8_t> d_bases;
-    DevBuf<uint64_t> d_hashes;
-    DevBuf<uint32_t> d_nhash, d_counts;
+    DevBuf<uint8_t> d_bases(ctx);
+    DevBuf<uint64_t> d_hashes(ctx);
+    DevBuf<uint32_t> d_nhash(ctx), d_counts(ctx);
     if ((counts_out && d_counts.alloc(nsketch * s) != hipSuccess) || d_bases.alloc(nbases + 64) != hipSuccess ||
         d_hashes.alloc(nsketch * s) != hipSuccess || d_nhash.alloc(nsketch) != hipSuccess)
         return fail(ctx, MG_ERR_NOMEM, "mg_sketch_host: device allocation failed");
@@ -896,6 +964,24 @@ static int table_classes(mg_ctx *ctx, const mg_table *t)
     return MG_OK;
 }
 
+// Copies a tile list to the context's device scratch through pinned staging (grown on demand).
+static int stage_tiles(mg_ctx *ctx, const void *tiles, size_t bytes, void **dev_out)
+{
+    if (bytes > ctx->tile_cap) {
+        if (ctx->tile_dev) { hipFree(ctx->tile_dev); ctx->tile_dev = nullptr; }
+        if (ctx->tile_host) { hipHostFree(ctx->tile_host); ctx->tile_host = nullptr; }
+        ctx->tile_cap = 0;
+        const size_t cap = std::max<size_t>(bytes + bytes / 2, 1u << 16);
+        HIP_TRY(ctx, hipMalloc(&ctx->tile_dev, cap));
+        HIP_TRY(ctx, hipHostMalloc(&ctx->tile_host, cap, hipHostMallocDefault));
+        ctx->tile_cap = cap;
+    }
+    memcpy(ctx->tile_host, tiles, bytes);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->tile_dev, ctx->tile_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    *dev_out = ctx->tile_dev;
+    return MG_OK;
+}
+
 static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, uint64_t row_begin,
                        uint64_t row_end, bool triangle, mg_counts *out_dev)
 {
@@ -970,8 +1056,15 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
             uint64_t nrt = 0;
             for (const auto &list : by_class) nrt += (list.size() + R - 1) / R;
             if (nrt * ((maxcols + CC - 1) / CC) < 512) {
-                const uint64_t chunks = (1024 + nrt - 1) / nrt;
-                const uint64_t cc = ((maxcols + chunks - 1) / chunks + 63) & ~63ull;
+                uint64_t chunks = (1024 + nrt - 1) / nrt;
+                const uint64_t most = std::max<uint64_t>(1, maxcols / 256);
+                if (chunks > most) {
+                    // the floor of 256 columns binds: then at least fill whole rounds of the CUs
+                    chunks = most;
+                    const uint64_t cus = ctx->cu_count > 0 ? (uint64_t)ctx->cu_count : 256;
+                    if (nrt * chunks > cus) chunks = std::max<uint64_t>(1, (nrt * chunks / cus) * cus / nrt);
+                }
+                const uint64_t cc = ((maxcols + chunks - 1) / chunks + 7) & ~7ull;
                 CC = std::min<uint64_t>(CC, std::max<uint64_t>(256, cc));
             }
         }
@@ -1003,23 +1096,20 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
                 }
             }
             if (mtiles.empty()) continue;
-            mg::MergedTile *d_mt = nullptr;
-            HIP_TRY(ctx, hipMalloc(&d_mt, mtiles.size() * sizeof(mg::MergedTile)));
+            void *d_mt = nullptr;
+            rc = stage_tiles(ctx, mtiles.data(), mtiles.size() * sizeof(mg::MergedTile), &d_mt);
+            if (rc != MG_OK) return rc;
             unsigned long long *d_dbg = nullptr;
             if (getenv("MASHGPU_COMPARE_DBG")) {
                 hipMalloc(&d_dbg, mtiles.size() * 24);
                 hipMemsetAsync(d_dbg, 0, mtiles.size() * 24, ctx->stream);
             }
             a.dbg = d_dbg;
-            hipError_t e = hipMemcpyAsync(d_mt, mtiles.data(), mtiles.size() * sizeof(mg::MergedTile), hipMemcpyHostToDevice,
-                                          ctx->stream);
-            if (e == hipSuccess) {
-                a.mtiles = d_mt;
-                prof_begin(ctx, ctx->prof_compare);
-                e = mg::launch_compare_merged(a, (uint32_t)mtiles.size(), ctx->stream);
-                prof_end(ctx, ctx->prof_compare);
-            }
-            hipError_t e2 = hipStreamSynchronize(ctx->stream);              // the tile list must outlive the launch
+            a.mtiles = static_cast<const mg::MergedTile *>(d_mt);
+            prof_begin(ctx, ctx->prof_compare);
+            hipError_t e = mg::launch_compare_merged(a, (uint32_t)mtiles.size(), ctx->stream);
+            prof_end(ctx, ctx->prof_compare);
+            hipError_t e2 = hipStreamSynchronize(ctx->stream);              // the tile list is reused by the next launch
             if (d_dbg) {
                 std::vector<unsigned long long> h(mtiles.size() * 3);
                 hipMemcpy(h.data(), d_dbg, h.size() * 8, hipMemcpyDeviceToHost);
@@ -1032,7 +1122,6 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
                         list.size(), mtiles.size(), bsum / mtiles.size(), tsum / mtiles.size());
                 hipFree(d_dbg);
             }
-            hipFree(d_mt);
             if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare launch: ") + hipGetErrorString(e));
             if (e2 != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare kernel: ") + hipGetErrorString(e2));
         }
@@ -1054,20 +1143,17 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
         }
     }
     if (tiles.empty()) return MG_OK;
-    mg::CompareTile *d_tiles = nullptr;
-    HIP_TRY(ctx, hipMalloc(&d_tiles, tiles.size() * sizeof(mg::CompareTile)));
-    a.dbg = nullptr;
-    hipError_t e = hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(mg::CompareTile), hipMemcpyHostToDevice,
-                                  ctx->stream);
-    if (e == hipSuccess) {
-        a.tiles = d_tiles;
-        prof_begin(ctx, ctx->prof_compare);
-        e = mg::launch_compare_tiled(a, (uint32_t)tiles.size(), ctx->stream);
-        prof_end(ctx, ctx->prof_compare);
+    void *d_tiles = nullptr;
+    {
+        const int rc = stage_tiles(ctx, tiles.data(), tiles.size() * sizeof(mg::CompareTile), &d_tiles);
+        if (rc != MG_OK) return rc;
     }
-    // the tile list must outlive the launch
-    hipError_t e2 = hipStreamSynchronize(ctx->stream);
-    hipFree(d_tiles);
+    a.dbg = nullptr;
+    a.tiles = static_cast<const mg::CompareTile *>(d_tiles);
+    prof_begin(ctx, ctx->prof_compare);
+    hipError_t e = mg::launch_compare_tiled(a, (uint32_t)tiles.size(), ctx->stream);
+    prof_end(ctx, ctx->prof_compare);
+    hipError_t e2 = hipStreamSynchronize(ctx->stream);      // the tile list is reused by the next launch
     if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare launch: ") + hipGetErrorString(e));
     if (e2 != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare kernel: ") + hipGetErrorString(e2));
     return MG_OK;
@@ -1116,9 +1202,9 @@ static int compare_host(mg_ctx *ctx, const mg_table *rows, const mg_table *cols,
             r2++;
         }
         if (pairs > cap_pairs) {
-            if (d_out) hipFree(d_out);
+            if (d_out) ctx_free(ctx, d_out);
             d_out = nullptr;
-            if (hipMalloc(&d_out, std::max<uint64_t>(pairs, 1) * sizeof(mg_counts)) != hipSuccess) {
+            if (ctx_malloc(ctx, (void **)&d_out, std::max<uint64_t>(pairs, 1) * sizeof(mg_counts)) != hipSuccess) {
                 rc = fail(ctx, MG_ERR_NOMEM, "compare: device allocation failed");
                 break;
             }
@@ -1133,7 +1219,7 @@ static int compare_host(mg_ctx *ctx, const mg_table *rows, const mg_table *cols,
         done += pairs;
         r = r2;
     }
-    if (d_out) hipFree(d_out);
+    if (d_out) ctx_free(ctx, d_out);
     return rc;
 }
 

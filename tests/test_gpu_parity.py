@@ -522,6 +522,30 @@ def test_compare_rect_and_golden_dist(eng, oracle, golden_dir):
     ref.free(); qry.free(); t.free(); tq.free()
 
 
+@pytest.mark.parametrize("n,s,nq", [(6001, 1000, 1), (6001, 1000, 3), (6001, 1000, 40), (70001, 64, 1), (70001, 64, 5)])
+def test_compare_few_queries_against_many_references(eng, oracle, n, s, nq):
+    """The serving shape (a launch with few row tiles) cuts the columns into finer chunks
+    (mashgpu.cpp::run_compare); chunk boundaries must not show in the result."""
+    table, nhash, lengths = synth.clustered_sketches(n + nq, s, clusters=max(1, n // 50), seed=n + nq,
+                                                     pool=int(1.5 * s), private=int(0.4 * s))
+    ref = eng.table_upload(table[:n], nhash[:n], lengths[:n])
+    # queries: the extra rows (members of the first clusters) and, for nq > 1, a copy of a reference
+    q_tab, q_nh, q_len = table[n:].copy(), nhash[n:].copy(), lengths[n:].copy()
+    if nq > 1:
+        q_tab[1], q_nh[1], q_len[1] = table[n // 2], nhash[n // 2], lengths[n // 2]
+    qry = eng.table_upload(q_tab, q_nh, q_len)
+    got = eng.compare_rect_host(ref, qry)
+    assert got.shape == (nq, n)
+    for q in range(nq):
+        # oracle: the query appended to the references is the last row of a triangle
+        t2 = np.concatenate([table[:n], q_tab[q:q + 1]])
+        numer, denom = _oracle_tri(oracle, t2, np.append(nhash[:n], q_nh[q]), np.append(lengths[:n], q_len[q]), n, n + 1)
+        assert np.array_equal(got["numer"][q], numer) and np.array_equal(got["denom"][q], denom)
+    if nq > 1:
+        assert got["numer"][1, n // 2] == nhash[n // 2]
+    ref.free(); qry.free()
+
+
 def _py_distance(numer, denom, k):
     """CommandDistance.cpp:387-407 with CPython's libm log (the one the reference links)."""
     import math

@@ -44,6 +44,12 @@ def main():
                 torch.cuda.synchronize()
                 ts.append(time.perf_counter() - t)
             case[tag] = round(1e3 * sorted(ts)[len(ts) // 2], 4)
+            if not env:                                          # kernel time inside the call (HIP events)
+                eng.prof_enable(True); eng.prof_reset()
+                eng.compare_rect_dev(ref, qry, 0, nq, out.data_ptr())
+                torch.cuda.synchronize()
+                case["kernel_ms"] = round(eng.prof_avg_ms("compare")[0], 4)
+                eng.prof_enable(False)
             if keep is None:
                 keep = out.clone()
             else:
@@ -55,6 +61,54 @@ def main():
         case["pairs_per_s"] = round(nq * a.refs / (case["adaptive_ms"] * 1e-3))
         res["cases"].append(case)
         qry.free()
+    # the other half of a query: sketching ONE genome handed over in host memory (mg_sketch_host)
+    import numpy as np
+    rng = np.random.default_rng(3)
+    prm = eng.params(k=21, s=a.s)
+    res["sketch_one"] = []
+    for nb in (100_000, 5_000_000, 100_000_000):
+        bases = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, nb)]
+        off = np.array([0, nb], dtype=np.uint64)
+        eng.sketch_host_raw(bases, off, prm)
+        ts = []
+        for _ in range(5):
+            t = time.perf_counter()
+            eng.sketch_host_raw(bases, off, prm)
+            ts.append(time.perf_counter() - t)
+        eng.prof_enable(True); eng.prof_reset()
+        eng.sketch_host_raw(bases, off, prm)
+        kms = eng.prof_avg_ms("sketch")[0]
+        eng.prof_enable(False)
+        dbuf = torch.from_numpy(bases).to(dev)
+        hb = torch.empty((1, a.s), dtype=torch.int64, device=dev); nb_ = torch.empty(1, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        td = []
+        for _ in range(5):
+            t = time.perf_counter()
+            eng.sketch_dev(dbuf.data_ptr(), nb, off, prm, hb.data_ptr(), nb_.data_ptr())
+            torch.cuda.synchronize()
+            td.append(time.perf_counter() - t)
+        res["sketch_one"].append({"bases": nb, "ms": round(1e3 * sorted(ts)[2], 4), "chunk_kernel_ms": round(kms, 4),
+                                  "dev_call_ms": round(1e3 * sorted(td)[2], 4)})
+    # whole query, host to host: sketch one 5 Mbp genome, upload it as a 1-row table, compare it
+    # with the resident database, bring the counts back, distances + p-values on the host
+    bases = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 5_000_000)]
+    off = np.array([0, len(bases)], dtype=np.uint64)
+    ref_len = ln.cpu().numpy().astype(np.uint64)
+    def one_query():
+        qh, qn = eng.sketch_host_raw(bases, off, prm)
+        qt = eng.table_upload(qh, qn, np.array([len(bases)], np.uint64))
+        counts = eng.compare_rect_host(ref, qt)
+        fin = eng.finish_rect(counts, ref_len, np.array([len(bases)], np.uint64), 21, 4.0 ** 21, max_d=0.1)
+        qt.free()
+        return fin
+    one_query()
+    ts = []
+    for _ in range(5):
+        t = time.perf_counter()
+        one_query()
+        ts.append(time.perf_counter() - t)
+    res["query_host_to_host_ms"] = round(1e3 * sorted(ts)[2], 4)
     print(json.dumps(res))
 
 
