@@ -41,6 +41,14 @@ struct CompareArgs {
     uint32_t pfx_shr;             // prefix shift shared by both tables
     uint32_t nbuckets;            // merged kernel: buckets of the tile table (set by its launcher)
     unsigned long long *dbg;      // tuning hook: per-tile {start, built, end} clocks (nullptr = off)
+    // Value-window mode of the merged kernel (large sketches, see compare_merged.hip): one launch
+    // handles the hashes whose prefix lies in [win_lo, win_hi); row_win / col_win give, per row and
+    // window boundary, the index of the first hash at or above the boundary (nwin + 1 per row).
+    const uint32_t *row_win;
+    const uint32_t *col_win;
+    uint32_t win, nwin;           // this launch's window, number of windows (0 = not windowed)
+    uint32_t win_lo, win_hi;      // prefix range of the window (win_hi: exclusive, for the bucket scale)
+    uint32_t win_ecap;            // table entries a windowed tile may hold
 };
 
 // LDS-tiled kernel usable when s <= 1024; rows_per_tile chosen by compare_rows_per_tile.
@@ -51,6 +59,11 @@ hipError_t launch_compare_tiled(const CompareArgs &a, uint32_t ntiles, hipStream
 bool compare_merged_supported(uint32_t s);
 uint32_t compare_merged_rows(uint32_t s);
 hipError_t launch_compare_merged(const CompareArgs &a, uint32_t ntiles, hipStream_t stream);
+// windowed mode: rows per tile, entries per tile, and the per-row window offsets
+uint32_t compare_window_rows();
+uint32_t compare_window_entries();
+hipError_t launch_window_offsets(const uint32_t *pfx, uint64_t pfx_stride, const uint32_t *nhash, uint64_t n, uint32_t s,
+                                 uint32_t nwin, uint32_t delta, uint32_t *out, hipStream_t stream);
 // table max (u64 atomicMax over the last valid entry of every row) and prefix image
 hipError_t launch_table_max(const uint64_t *hashes, const uint32_t *nhash, uint64_t n, uint64_t stride,
                             unsigned long long *out_max, hipStream_t stream);

@@ -58,13 +58,26 @@ __host__ __device__ inline uint32_t merged_idx_bits(uint32_t s)
 
 constexpr size_t MR_LDS_LIMIT = 160 * 1024 - 512;       // dynamic part; 512 B left for the static arrays
 
-// LDS bytes of a tile table with nb buckets
-__host__ __device__ inline size_t merged_lds_bytes_nb(uint32_t R, uint32_t s, uint32_t nb)
+// LDS bytes of a tile table of `entries` entries in nb buckets
+__host__ __device__ constexpr size_t merged_lds_bytes_e(uint32_t R, size_t entries, uint32_t nb)
 {
-    const size_t ecap = (size_t)R * s + MR_W;
+    const size_t ecap = entries + MR_W;
     return 512 + ((size_t)nb + 8) * 2 + ((ecap * 4 + 15) & ~(size_t)15) + ((ecap * 2 + 15) & ~(size_t)15) +
            (size_t)MR_NW * R * MR_CB * 8;                             // + per-wave output staging
 }
+
+__host__ __device__ inline size_t merged_lds_bytes_nb(uint32_t R, uint32_t s, uint32_t nb)
+{
+    return merged_lds_bytes_e(R, (size_t)R * s, nb);
+}
+
+// Window mode (large sketches): a tile holds 16 rows' hashes of ONE value window, at most
+// MR_WIN_ENTRIES of them, in MR_WIN_BUCKETS buckets -- the geometry of an s = 1000 tile.
+constexpr uint32_t MR_WIN_ROWS = 16;
+constexpr uint32_t MR_WIN_ENTRIES = 16000;
+constexpr uint32_t MR_WIN_BUCKETS = 24576;
+constexpr uint32_t MR_WIN_IDX_BITS = 12;               // index of an entry inside its row's window (< 4096)
+static_assert(merged_lds_bytes_e(MR_WIN_ROWS, MR_WIN_ENTRIES, MR_WIN_BUCKETS) <= 160 * 1024 - 512, "window tile exceeds LDS");
 
 // Bucket count: at least 0.8 buckets per entry (power of two), then as many more as LDS holds
 // up to two per entry -- buckets with more than MR_W entries cost an extra scan per probe that
@@ -102,7 +115,7 @@ __device__ __forceinline__ uint32_t mr_prefix(uint64_t v, uint32_t shr)
     return t >= 0xFFFFFFFDull ? 0xFFFFFFFDu : (uint32_t)t;
 }
 
-template <int KU>
+template <int KU, bool WIN>
 __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
 {
     constexpr int MR_KU = KU;
@@ -110,7 +123,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
     const uint32_t s = a.s;
     const uint32_t R = a.rows_per_tile;
     const uint32_t NB = a.nbuckets;
-    const uint32_t ecap = R * s + MR_W;
+    const uint32_t ecap = (WIN ? a.win_ecap : R * s) + MR_W;
     MergedHdr *hdr = reinterpret_cast<MergedHdr *>(smem);
     uint16_t *dir = reinterpret_cast<uint16_t *>(smem + 512);                       // [NB + 8]
     uint32_t *cnt32 = reinterpret_cast<uint32_t *>(dir);                            // build-time view
@@ -119,6 +132,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
     uint2 *stage_all = reinterpret_cast<uint2 *>(reinterpret_cast<unsigned char *>(tag) + (((size_t)ecap * 2 + 15) & ~(size_t)15));
     __shared__ uint32_t s_wsum[MR_NW + 2];
     __shared__ uint64_t s_rowmax[32];
+    __shared__ uint32_t s_rowlo[16], s_rowlen[16];      // WIN: first index of the row's window; full row length
 
     // (fields are read individually: indexing a by-value copy of rows[] would put the tile in scratch)
     const MergedTile *tile_p = a.mtiles + blockIdx.x;
@@ -140,6 +154,16 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
             if (n > s) n = s;
             if (n > 0) mx = a.row_pfx[i * a.row_pfx_stride + n - 1];
         }
+        if (WIN && tid < 16) {
+            uint32_t lo = 0, hi = 0;
+            if (rid != 0xFFFFFFFFu) {
+                lo = a.row_win[(uint64_t)rid * (a.nwin + 1) + a.win];
+                hi = a.row_win[(uint64_t)rid * (a.nwin + 1) + a.win + 1];
+            }
+            s_rowlo[tid] = lo;
+            s_rowlen[tid] = n;
+            n = hi - lo;                                  // entries of this row inside the window
+        }
         hdr->row_n[tid] = n;
         hdr->row_id[tid] = rid;
         s_rowmax[tid] = mx;
@@ -155,7 +179,8 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
         uint64_t mxall = 0;
         for (uint32_t r = 0; r < 32; r++) mxall = s_rowmax[r] > mxall ? s_rowmax[r] : mxall;
         const uint32_t xmax = (uint32_t)mxall;                    // largest prefix of the tile's rows
-        const uint64_t sc = ((uint64_t)NB << 32) / ((uint64_t)xmax + 1ULL);
+        // bucket = mulhi(prefix - origin, scale): the whole value range, or the launch's window
+        const uint64_t sc = ((uint64_t)NB << 32) / (WIN ? (uint64_t)(a.win_hi - a.win_lo) : (uint64_t)xmax + 1ULL);
         hdr->collide = 0;
         hdr->xmax = xmax;
         hdr->scale = sc > 0xFFFFFFFFULL ? 0xFFFFFFFFu : (uint32_t)sc;
@@ -166,20 +191,36 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
 
     // pass 1: bucket histogram; entries are enumerated row-major, thread tid owns
     // e = tid, tid + NT, ... (coalesced loads of the rows' prefix images)
-    const uint32_t idx_bits = merged_idx_bits(s);
+    const uint32_t idx_bits = WIN ? MR_WIN_IDX_BITS : merged_idx_bits(s);
     const uint32_t idx_mask = (1u << idx_bits) - 1u;
+    const uint32_t origin = WIN ? a.win_lo : 0u;
+    // WIN: tags hold the index inside the row's window; lo_of(r) turns it into the index in the row
+    auto lo_of = [&](uint32_t r) -> uint32_t { return WIN ? s_rowlo[r & 15u] : 0u; };
     uint32_t e_pfx[MR_EPT], e_bs[MR_EPT];    // prefix; bucket | slot << 16, kept in registers
     uint16_t e_tag[MR_EPT];
 #pragma unroll
     for (int t = 0; t < MR_EPT; t++) {
         const uint32_t e = (uint32_t)tid + (uint32_t)t * MR_NT;
-        const uint32_t r = e / s, idx = e - r * s;
+        uint32_t r, idx;
+        bool have;
+        if (WIN) {
+            // entries are the concatenated window ranges of the rows: find the row of entry e
+            r = 0;
+            for (uint32_t k = 1; k < 16; k++) r += hdr->row_base[k] <= e ? 1u : 0u;   // row_base is non-decreasing
+            idx = e - hdr->row_base[r];
+            have = e < E;
+        } else {
+            r = e / s;
+            idx = e - r * s;
+            have = r < R && idx < hdr->row_n[r];
+        }
         e_bs[t] = 0xFFFFFFFFu;
         e_pfx[t] = 0;
         e_tag[t] = 0;
-        if (r < R && idx < hdr->row_n[r]) {
-            const uint32_t x = a.row_pfx[(uint64_t)hdr->row_id[r] * a.row_pfx_stride + idx];
-            const uint32_t bk = __umulhi(x, scale);
+        if (have) {
+            const uint32_t x = a.row_pfx[(uint64_t)hdr->row_id[r] * a.row_pfx_stride + lo_of(r) + idx];
+            uint32_t bk = __umulhi(x - origin, scale);
+            if (WIN && bk >= NB) bk = NB - 1;
             const uint32_t old = atomicAdd(&cnt32[bk >> 1], (bk & 1u) ? 0x10000u : 1u);
             const uint32_t slot = (bk & 1u) ? (old >> 16) : (old & 0xFFFFu);
             e_pfx[t] = x;
@@ -258,8 +299,8 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
                         nd++;
                     } else {
                         const uint32_t tg0 = tag[st + d], tg1 = ti;
-                        const uint64_t v0 = a.row_hashes[(uint64_t)hdr->row_id[tg0 >> idx_bits] * a.row_stride + (tg0 & idx_mask)];
-                        const uint64_t v1 = a.row_hashes[(uint64_t)hdr->row_id[tg1 >> idx_bits] * a.row_stride + (tg1 & idx_mask)];
+                        const uint64_t v0 = a.row_hashes[(uint64_t)hdr->row_id[tg0 >> idx_bits] * a.row_stride + lo_of(tg0 >> idx_bits) + (tg0 & idx_mask)];
+                        const uint64_t v1 = a.row_hashes[(uint64_t)hdr->row_id[tg1 >> idx_bits] * a.row_stride + lo_of(tg1 >> idx_bits) + (tg1 & idx_mask)];
                         if (v0 != v1) hdr->collide = 1;
                     }
                 }
@@ -272,7 +313,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
 
     if (a.dbg && tid == 0) a.dbg[3 * (uint64_t)blockIdx.x + 1] = __builtin_readcyclecounter();
     // ------------------------------------------------------------------ stream columns
-    const uint32_t my_n = lane < 32 ? hdr->row_n[lane] : 0;                // row `lane`
+    const uint32_t my_n = WIN ? (lane < 16 ? s_rowlen[lane] : 0) : (lane < 32 ? hdr->row_n[lane] : 0);   // row `lane`
     const uint32_t my_id = lane < 32 ? hdr->row_id[lane] : 0xFFFFFFFFu;     // table row of slot `lane`
     const uint32_t *my_row = a.row_pfx + (uint64_t)(my_id != 0xFFFFFFFFu ? my_id : hdr->row_id[0]) * a.row_pfx_stride;
 
@@ -326,12 +367,37 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
+    // WIN: the column range of this launch's window, [col_win[j][win], col_win[j][win+1]), and
+    // the state a pair carries from window to window, kept in its output slot until it is final:
+    // {common, 0x80000000 | matches so far} while in progress, {common, denom} once decided.
+    auto win_range = [&](uint32_t jj, uint32_t &lo, uint32_t &hi) {
+        const uint32_t *wp = a.col_win + (uint64_t)jj * (a.nwin + 1) + a.win;
+        lo = wp[0];
+        hi = wp[1];
+    };
+    auto load_state = [&](uint32_t jj) -> uint2 {
+        uint2 v = make_uint2(0u, 0u);
+        if (lane < R && my_id != 0xFFFFFFFFu && (!a.triangle || jj < my_id)) {
+            const uint64_t i = my_id;
+            const uint64_t oidx = a.triangle ? i * (i - 1) / 2 + jj - a.out_base : (i - a.row_begin) * a.ncols + jj;
+            v = a.out[oidx];
+        }
+        return v;
+    };
     uint32_t ncol[MR_KU];
     uint32_t nB_next = 0;
+    uint32_t nx_lo = 0, nx_hi = 0, n2_lo = 0, n2_hi = 0;   // WIN: window ranges of the next two columns
+    uint2 st_next = make_uint2(0u, 0u);                    // WIN: carried state of the next column (lane r <-> row r)
     uint32_t tcol = 0;
     uint32_t j = col_of(0);
     if (j < tile.col1) {
-        load_group(a.col_pfx + (uint64_t)j * a.col_pfx_stride, 0, ncol);
+        if (WIN) {
+            win_range(j, nx_lo, nx_hi);
+            const uint32_t j2 = col_of(1);
+            win_range(j2 < tile.col1 ? j2 : j, n2_lo, n2_hi);
+            if (a.win > 0) st_next = load_state(j);
+        }
+        load_group(a.col_pfx + (uint64_t)j * a.col_pfx_stride, nx_lo, ncol);
         nB_next = a.col_nhash[j];
     }
     for (; j < tile.col1; tcol++, j = col_of(tcol)) {
@@ -346,20 +412,38 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
         if (a.triangle) valid &= (uint32_t)__ballot(my_id != 0xFFFFFFFFu && my_id > j);
         uint32_t active = valid, brokem = 0;
         uint32_t st_call = 0, st_common = 0;                             // lane r <-> row r
-        const uint32_t ngroups = valid == 0 ? 0 : (nB + 64 * MR_KU - 1) / (64 * MR_KU);
+        const uint32_t qlo = WIN ? nx_lo : 0u;                           // this launch's part of the column
+        const uint32_t qhi = WIN ? nx_hi : nB;
+        uint32_t fin_denom = 0;
+        if (WIN && a.win > 0) {
+            // pairs decided in an earlier window keep their result; the others resume
+            const bool inprog = (st_next.y & 0x80000000u) != 0;
+            st_common = st_next.x;
+            st_call = inprog ? (st_next.y & 0x7FFFFFFFu) : 0u;
+            fin_denom = st_next.y;
+            active &= (uint32_t)__ballot(lane < R && inprog);
+        }
+        const uint32_t started = active;                                 // rows this launch works on
+        const uint32_t ngroups = active == 0 ? 0 : (qhi - qlo + 64 * MR_KU - 1) / (64 * MR_KU);
         // prologue: rank-test operand of group 0, data of group 1, then the next column
-        int32_t t_chk = (int32_t)s - (int32_t)(64 * MR_KU) + (int32_t)st_call;      // s-1-qlast+c, qlast = 64*KU-1
+        int32_t t_chk = (int32_t)s - (int32_t)(64 * MR_KU) - (int32_t)qlo + (int32_t)st_call;   // s-1-qlast+c, qlast = qlo+64*KU-1
         uint32_t a_chk = my_row[t_chk >= 1 ? (uint32_t)t_chk - 1 : 0];
-        load_group(bsrc, 64 * MR_KU, nxt);
+        load_group(bsrc, qlo + 64 * MR_KU, nxt);
         {
             const uint32_t jnx = col_of(tcol + 1);
             const uint32_t jn = jnx < tile.col1 ? jnx : j;
-            load_group(a.col_pfx + (uint64_t)jn * a.col_pfx_stride, 0, ncol);
+            if (WIN) { nx_lo = n2_lo; nx_hi = n2_hi; }                   // jn's range (clamped duplicates are never used)
+            load_group(a.col_pfx + (uint64_t)jn * a.col_pfx_stride, WIN ? nx_lo : 0u, ncol);
             nB_next = a.col_nhash[jn];
+            if (WIN) {
+                if (a.win > 0) st_next = load_state(jn);
+                const uint32_t j2x = col_of(tcol + 2);
+                win_range(j2x < tile.col1 ? j2x : jn, n2_lo, n2_hi);
+            }
         }
         for (uint32_t g = 0; g < ngroups && active != 0; g++) {
-            const uint32_t q0 = g * 64 * MR_KU;
-            const bool col_end = q0 + 64 * MR_KU >= nB;
+            const uint32_t q0 = qlo + g * 64 * MR_KU;
+            const bool col_end = q0 + 64 * MR_KU >= qhi;                 // WIN: end of the window's part (no rank test there)
             const uint32_t qlast = q0 + 64 * MR_KU - 1;
 
             // ---- one probe per element for ALL rows of the tile ----
@@ -369,7 +453,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
 #pragma unroll
             for (int u = 0; u < MR_KU; u++) {
                 x[u] = cur[u];
-                const uint32_t bk = __umulhi(x[u], scale);
+                const uint32_t bk = __umulhi(x[u] - origin, scale);
                 s0[u] = dir[bk < NB ? bk : NB];              // prefixes above the tile's maximum (and padding) -> sentinel
             }
 #pragma unroll
@@ -393,7 +477,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
                 for (int u = 0; u < MR_KU; u++) {
                     bool hit = false;
                     if (s0[u] > 0x7FFFu) {
-                        const uint32_t bk = __umulhi(x[u], scale);        // < NB: the sentinel bucket is never oversize
+                        const uint32_t bk = __umulhi(x[u] - origin, scale);   // < NB: the sentinel bucket is never oversize
                         const uint32_t e1 = dir[bk + 1] & 0x7FFFu;
                         for (uint32_t e = (s0[u] & 0x7FFFu) + MR_W; e < e1; e++) hit |= pfx[e] == x[u];
                     }
@@ -433,13 +517,13 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
                             for (int w = 0; w < MR_W; w++)
                                 if (h[u][w] == x[u]) take(tag[st + w]);
                             {                                            // rows sharing the value sit behind the distinct entries
-                                const uint32_t bk = __umulhi(x[u], scale);
+                                const uint32_t bk = __umulhi(x[u] - origin, scale);
                                 const uint32_t e1 = dir[bk + 1] & 0x7FFFu;
                                 for (uint32_t e = st + MR_W; e < e1; e++)
                                     if (pfx[e] == x[u]) take(tag[e]);
                             }
                             if (rep != 0xFFFFFFFFu) {
-                                const uint64_t v = a.row_hashes[(uint64_t)hdr->row_id[rep >> idx_bits] * a.row_stride + (rep & idx_mask)];
+                                const uint64_t v = a.row_hashes[(uint64_t)hdr->row_id[rep >> idx_bits] * a.row_stride + lo_of(rep >> idx_bits) + (rep & idx_mask)];
                                 if (v != b) rowmask = 0;                  // same prefix, different value
                             }
                         }
@@ -451,7 +535,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
                         for (int r = 0; r < 16; r++) {
                             if (!((rows_any >> r) & 1u)) continue;       // uniform
                             const bool mt = (rowmask >> r) & 1u;
-                            const uint32_t idx = (pk[r >> 1] >> ((r & 1) * 16)) & 0xFFFFu;
+                            const uint32_t idx = ((pk[r >> 1] >> ((r & 1) * 16)) & 0xFFFFu) + lo_of((uint32_t)r);
                             uint32_t c_all = (uint32_t)__builtin_amdgcn_readlane((int)st_call, r);
                             uint32_t common = (uint32_t)__builtin_amdgcn_readlane((int)st_common, r);
                             const uint64_t mm = __ballot(mt);
@@ -479,19 +563,19 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
                         for (int w = 0; w < MR_W; w++) {
                             if (h[u][w] == x[u] && st + w < E) {
                                 const uint32_t tg = tag[st + w];
-                                const uint32_t r = tg >> idx_bits, idx = tg & idx_mask;
+                                const uint32_t r = tg >> idx_bits, idx = (tg & idx_mask) + lo_of(tg >> idx_bits);
                                 const uint64_t v = a.row_hashes[(uint64_t)hdr->row_id[r] * a.row_stride + idx];
                                 if (v == b) { rowmask |= 1u << r; hit_tag[w] = tg; }
                             }
                         }
                         {
-                            const uint32_t bk = __umulhi(x[u], scale);
+                            const uint32_t bk = __umulhi(x[u] - origin, scale);
                             extra_lo = st + MR_W;
                             extra_hi = dir[bk + 1] & 0x7FFFu;
                             for (uint32_t e = extra_lo; e < extra_hi; e++) {
                                 if (pfx[e] == x[u]) {
                                     const uint32_t tg = tag[e];
-                                    const uint32_t r = tg >> idx_bits, idx = tg & idx_mask;
+                                    const uint32_t r = tg >> idx_bits, idx = (tg & idx_mask) + lo_of(tg >> idx_bits);
                                     const uint64_t v = a.row_hashes[(uint64_t)hdr->row_id[r] * a.row_stride + idx];
                                     if (v == b) rowmask |= 1u << r;
                                 }
@@ -512,15 +596,15 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
                         bool have = false;
 #pragma unroll
                         for (int w = 0; w < MR_W; w++) {
-                            if (hit_tag[w] != 0xFFFFFFFFu && (hit_tag[w] >> idx_bits) == r) { idx = hit_tag[w] & idx_mask; have = true; }
+                            if (hit_tag[w] != 0xFFFFFFFFu && (hit_tag[w] >> idx_bits) == r) { idx = (hit_tag[w] & idx_mask) + lo_of(r); have = true; }
                         }
                         if (mt && !have) {
                             // hit came from beyond the window of an oversize bucket (rare): rescan
                             for (uint32_t e = extra_lo; e < extra_hi; e++) {
                                 const uint32_t tg = tag[e];
                                 if (pfx[e] == x[u] && (tg >> idx_bits) == r) {
-                                    const uint64_t v = a.row_hashes[(uint64_t)hdr->row_id[r] * a.row_stride + (tg & idx_mask)];
-                                    if (v == b) idx = tg & idx_mask;
+                                    const uint64_t v = a.row_hashes[(uint64_t)hdr->row_id[r] * a.row_stride + lo_of(r) + (tg & idx_mask)];
+                                    if (v == b) idx = lo_of(r) + (tg & idx_mask);
                                 }
                             }
                         }
@@ -564,6 +648,12 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
             if (!((brokem >> lane) & 1u)) {
                 const uint32_t uni = my_n + nB - st_call;
                 denom = uni < s ? uni : s;
+                if (WIN) {
+                    // no exit yet: the pair is decided only when the column is exhausted (nothing
+                    // left that could match) or this was the last window
+                    if (!((started >> lane) & 1u)) denom = fin_denom;                      // decided earlier (or not ours)
+                    else if (a.win + 1 < a.nwin && qhi < nB) denom = 0x80000000u | st_call;
+                }
             }
             stage[lane * MR_CB + (tcol % MR_CB)] = make_uint2(st_common, denom);
         }
@@ -662,10 +752,48 @@ hipError_t launch_make_prefix(const uint64_t *hashes, const uint32_t *nhash, uin
     return hipGetLastError();
 }
 
-template <int KU>
+// First index of every row at or above each window boundary (boundary w = w * delta for w < nwin,
+// boundary nwin = end of the row): out[i * (nwin + 1) + w].  One thread per (row, boundary).
+__global__ void window_offsets_kernel(const uint32_t *pfx, uint64_t pfx_stride, const uint32_t *nhash, uint64_t n, uint32_t s,
+                                      uint32_t nwin, uint32_t delta, uint32_t *out)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * (nwin + 1)) return;
+    const uint64_t i = t / (nwin + 1);
+    const uint32_t w = (uint32_t)(t - i * (nwin + 1));
+    uint32_t len = nhash[i];
+    if (len > s) len = s;
+    uint32_t lo = 0, hi = len;
+    if (w < nwin) {
+        const uint64_t bound = (uint64_t)w * delta;
+        const uint32_t *row = pfx + i * pfx_stride;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if ((uint64_t)row[mid] < bound) lo = mid + 1; else hi = mid;
+        }
+    } else {
+        lo = len;
+    }
+    out[t] = lo;
+}
+
+hipError_t launch_window_offsets(const uint32_t *pfx, uint64_t pfx_stride, const uint32_t *nhash, uint64_t n, uint32_t s,
+                                 uint32_t nwin, uint32_t delta, uint32_t *out, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    const uint64_t total = n * (nwin + 1);
+    hipLaunchKernelGGL(window_offsets_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, pfx, pfx_stride,
+                       nhash, n, s, nwin, delta, out);
+    return hipGetLastError();
+}
+
+uint32_t compare_window_rows() { return MR_WIN_ROWS; }
+uint32_t compare_window_entries() { return MR_WIN_ENTRIES; }
+
+template <int KU, bool WIN = false>
 static hipError_t launch_merged_k(const CompareArgs &a, uint32_t ntiles, size_t smem, hipStream_t stream)
 {
-    auto kern = compare_merged_kernel<KU>;
+    auto kern = compare_merged_kernel<KU, WIN>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
@@ -677,6 +805,14 @@ hipError_t launch_compare_merged(const CompareArgs &a_in, uint32_t ntiles, hipSt
 {
     if (ntiles == 0) return hipSuccess;
     CompareArgs a = a_in;
+    if (a.nwin > 0) {
+        // window mode: fixed tile geometry (16 rows, MR_WIN_ENTRIES entries, MR_WIN_BUCKETS buckets)
+        a.rows_per_tile = MR_WIN_ROWS;
+        a.nbuckets = MR_WIN_BUCKETS;
+        a.win_ecap = MR_WIN_ENTRIES;
+        return launch_merged_k<MR_KU_DEFAULT, true>(a, ntiles, merged_lds_bytes_e(MR_WIN_ROWS, MR_WIN_ENTRIES, MR_WIN_BUCKETS),
+                                                    stream);
+    }
     a.nbuckets = merged_buckets(a.rows_per_tile, a.s);
     const size_t smem = merged_lds_bytes_nb(a.rows_per_tile, a.s, a.nbuckets);
     // a.unroll (MASHGPU_COMPARE_VARIANT) selects the group size for tuning runs; 0 = default

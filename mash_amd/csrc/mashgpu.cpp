@@ -59,6 +59,10 @@ struct mg_table {
     mutable std::vector<std::pair<int, uint32_t *>> pfx;   // u32 prefix images, one per shift in use
     mutable std::vector<uint8_t> cls;     // density class per row (host copy, see table_classes)
     mutable std::vector<uint64_t> last;   // largest hash per row (host copy)
+    mutable std::vector<uint32_t> nh;     // hashes per row (host copy)
+    // window offsets of the large-sketch compare path (see table_windows), cached per geometry
+    struct Windows { int shr; uint32_t delta, nwin, s; uint32_t *dev; std::vector<uint32_t> host; };
+    mutable std::vector<Windows> win;
 };
 
 #define HIP_TRY(ctx, call)                                                           \
@@ -887,6 +891,7 @@ void mg_table_free(mg_table *t)
 {
     if (!t) return;
     if (!t->pfx.empty()) { hipSetDevice(t->ctx->device); for (auto &im : t->pfx) hipFree(im.second); }
+    if (!t->win.empty()) { hipSetDevice(t->ctx->device); for (auto &w : t->win) hipFree(w.dev); }
     if (t->owns) {
         hipSetDevice(t->ctx->device);
         hipFree((void *)t->hashes);
@@ -952,7 +957,9 @@ static int table_classes(mg_ctx *ctx, const mg_table *t)
     if (hipMalloc(&dl, std::max<uint64_t>(t->n, 1) * 8) != hipSuccess) { hipFree(d); return fail(ctx, MG_ERR_NOMEM, "compare: allocation failed"); }
     std::vector<uint8_t> h(t->n);
     std::vector<uint64_t> hl(t->n);
+    std::vector<uint32_t> hn(t->n);
     hipError_t e = mg::launch_row_classes(t->hashes, t->nhash, t->n, t->s, d, dl, ctx->stream);
+    if (e == hipSuccess && t->n) e = hipMemcpyAsync(hn.data(), t->nhash, t->n * 4, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess && t->n) e = hipMemcpyAsync(h.data(), d, t->n, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess && t->n) e = hipMemcpyAsync(hl.data(), dl, t->n * 8, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -961,6 +968,38 @@ static int table_classes(mg_ctx *ctx, const mg_table *t)
     if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare (row classes): ") + hipGetErrorString(e));
     t->cls.swap(h);
     t->last.swap(hl);
+    t->nh.swap(hn);
+    return MG_OK;
+}
+
+// Window offsets of a table for the large-sketch compare path: for every row and every boundary
+// w * delta (w < nwin; boundary nwin = end of the row) the index of the first hash whose prefix
+// (shift shr) is at or above it, over the row's first min(nhash, s) hashes.  Device array of
+// (nwin + 1) per row plus a host copy (the host sizes tiles from it); cached per geometry.
+static int table_windows(mg_ctx *ctx, const mg_table *t, int shr, uint32_t delta, uint32_t nwin, uint32_t s,
+                         const mg_table::Windows **out)
+{
+    for (auto &w : t->win)
+        if (w.shr == shr && w.delta == delta && w.nwin == nwin && w.s == s) { *out = &w; return MG_OK; }
+    if (t->win.size() >= 8) {
+        hipStreamSynchronize(ctx->stream);
+        hipFree(t->win.front().dev);
+        t->win.erase(t->win.begin());
+    }
+    const uint32_t *img = nullptr;
+    int rc = table_prefix(ctx, t, shr, &img);
+    if (rc != MG_OK) return rc;
+    mg_table::Windows w;
+    w.shr = shr; w.delta = delta; w.nwin = nwin; w.s = s; w.dev = nullptr;
+    const uint64_t count = t->n * (uint64_t)(nwin + 1);
+    HIP_TRY(ctx, hipMalloc(&w.dev, std::max<uint64_t>(count, 1) * 4));
+    w.host.resize(count);
+    hipError_t e = mg::launch_window_offsets(img, mg::compare_pfx_stride(t->s), t->nhash, t->n, s, nwin, delta, w.dev, ctx->stream);
+    if (e == hipSuccess && count) e = hipMemcpyAsync(w.host.data(), w.dev, count * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { hipFree(w.dev); return fail(ctx, MG_ERR_HIP, std::string("compare (window offsets): ") + hipGetErrorString(e)); }
+    t->win.push_back(std::move(w));
+    *out = &t->win.back();
     return MG_OK;
 }
 
@@ -1004,6 +1043,8 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
     a.triangle = triangle ? 1 : 0;
     a.rows_per_tile = 0;
     a.unroll = 0;
+    a.row_win = a.col_win = nullptr;
+    a.win = a.nwin = a.win_lo = a.win_hi = a.win_ecap = 0;
     if (const char *e = getenv("MASHGPU_COMPARE_VARIANT")) a.unroll = (uint32_t)atoi(e);
     const char *force = getenv("MASHGPU_COMPARE_KERNEL");
     if (force && strcmp(force, "pairs") == 0 && mg::compare_pairs_supported(a.s)) {
@@ -1049,25 +1090,33 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
         if (rc != MG_OK) return rc;
         std::vector<std::vector<uint32_t>> by_class(65);
         for (uint64_t i = row_begin; i < row_end; i++) by_class[rows->cls[i] > 64 ? 64 : rows->cls[i]].push_back((uint32_t)i);
-        // A launch of few row tiles (a handful of queries against a large database) would leave
-        // most CUs idle with full-length column chunks: cut the columns finer until there are
-        // ~4 tiles per CU (a table build costs about as much as 100 columns, so not below 256).
-        if (!getenv("MASHGPU_COMPARE_COLS")) {
-            uint64_t nrt = 0;
-            for (const auto &list : by_class) nrt += (list.size() + R - 1) / R;
-            if (nrt * ((maxcols + CC - 1) / CC) < 512) {
-                uint64_t chunks = (1024 + nrt - 1) / nrt;
-                const uint64_t most = std::max<uint64_t>(1, maxcols / 256);
-                if (chunks > most) {
-                    // the floor of 256 columns binds: then at least fill whole rounds of the CUs
-                    chunks = most;
-                    const uint64_t cus = ctx->cu_count > 0 ? (uint64_t)ctx->cu_count : 256;
-                    if (nrt * chunks > cus) chunks = std::max<uint64_t>(1, (nrt * chunks / cus) * cus / nrt);
-                }
-                const uint64_t cc = ((maxcols + chunks - 1) / chunks + 7) & ~7ull;
-                CC = std::min<uint64_t>(CC, std::max<uint64_t>(256, cc));
+        // Large sketches: R*s <= ~16 000 leaves few rows per tile (2 at s = 10 000), and a probe
+        // serves only that many pairs.  They are compared VALUE WINDOW by value window instead:
+        // a launch handles the hashes of one prefix range, sized so that 16 rows' share of it fills
+        // the tile table; a pair carries its match count from launch to launch in its output slot
+        // and drops out once its union reaches s (see compare_merged.hip, WIN).
+        bool want_win = R <= 6;
+        if (const char *e = getenv("MASHGPU_COMPARE_WINDOWS")) want_win = atoi(e) != 0;
+        const uint32_t Rw = mg::compare_window_rows();
+        const uint32_t R_plain = R;
+        // A launch of few row tiles (a handful of queries against a large database, or a small
+        // density class) would leave most CUs idle with full-length column chunks: cut the columns
+        // finer until there are ~4 tiles per CU (a table build costs about as much as 100 columns,
+        // so not below 256).  Every class is its own launch, so this is decided per class.
+        const bool cc_forced = getenv("MASHGPU_COMPARE_COLS") != nullptr;
+        auto chunk_for = [&](uint64_t nrt) -> uint64_t {
+            if (cc_forced || nrt == 0 || nrt * ((maxcols + CC - 1) / CC) >= 512) return CC;
+            uint64_t chunks = (1024 + nrt - 1) / nrt;
+            const uint64_t most = std::max<uint64_t>(1, maxcols / 256);
+            if (chunks > most) {
+                // the floor of 256 columns binds: then at least fill whole rounds of the CUs
+                chunks = most;
+                const uint64_t cus = ctx->cu_count > 0 ? (uint64_t)ctx->cu_count : 256;
+                if (nrt * chunks > cus) chunks = std::max<uint64_t>(1, (nrt * chunks / cus) * cus / nrt);
             }
-        }
+            const uint64_t cc = ((maxcols + chunks - 1) / chunks + 7) & ~7ull;
+            return std::min<uint64_t>(CC, std::max<uint64_t>(256, cc));
+        };
         a.dbg = nullptr;
         a.row_pfx_stride = mg::compare_pfx_stride(rows->s);
         a.col_pfx_stride = mg::compare_pfx_stride(cols->s);
@@ -1082,16 +1131,64 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
             if (rc == MG_OK) rc = table_prefix(ctx, cols, shr, &a.col_pfx);
             if (rc != MG_OK) return rc;
             a.pfx_shr = (uint32_t)shr;
+            // ---- window plan of this class (large sketches) ----
+            const mg_table::Windows *wr = nullptr, *wc = nullptr;
+            uint32_t delta = 0, nwin = 0;
+            const uint64_t xmax = mx >> shr;
+            if (want_win) {
+                double target = 0.8 * mg::compare_window_entries() / Rw;        // entries of the densest row per window
+                if (const char *e = getenv("MASHGPU_COMPARE_WIN_TARGET")) target = std::max(1.0, atof(e));
+                for (int attempt = 0; attempt < 2 && !wr; attempt++, target *= 0.7) {
+                    double dens = 0;                                             // hashes per unit of prefix, densest row
+                    for (uint32_t i : list) {
+                        const uint64_t ni = std::min<uint64_t>(rows->nh[i], a.s);
+                        if (ni) dens = std::max(dens, (double)ni / ((double)(rows->last[i] >> shr) + 1.0));
+                    }
+                    if (dens <= 0) break;
+                    const double dd = std::floor(target / dens);
+                    if (dd < 1.0 || dd >= (double)xmax + 1.0) break;            // one window: nothing to gain
+                    delta = (uint32_t)dd;
+                    const uint64_t nw = (xmax + delta) / delta;                 // ceil((xmax + 1) / delta)
+                    if (nw < 2 || nw > 255) break;
+                    nwin = (uint32_t)nw;
+                    const mg_table::Windows *cand = nullptr;
+                    rc = table_windows(ctx, rows, shr, delta, nwin, a.s, &cand);
+                    if (rc != MG_OK) return rc;
+                    // every tile's share of every window must fit the tile table
+                    bool fits = true;
+                    for (size_t k = 0; k < list.size() && fits; k += Rw) {
+                        for (uint32_t w = 0; w < nwin && fits; w++) {
+                            uint64_t tot = 0;
+                            for (size_t r = k; r < std::min(list.size(), k + Rw); r++) {
+                                const uint32_t *o = &cand->host[(uint64_t)list[r] * (nwin + 1) + w];
+                                const uint32_t c = o[1] - o[0];
+                                if (c > 4095) fits = false;
+                                tot += c;
+                            }
+                            if (tot > mg::compare_window_entries()) fits = false;
+                        }
+                    }
+                    if (fits) wr = cand;
+                }
+                if (wr) {
+                    rc = table_windows(ctx, cols, shr, delta, nwin, a.s, &wc);
+                    if (rc != MG_OK) return rc;
+                    if (rows == cols) wr = wc;                                   // the cache vector may have moved
+                }
+            }
+            const uint32_t Rc = wr ? Rw : R_plain;                               // rows per tile of this class
+            a.rows_per_tile = Rc;
+            const uint64_t CCc = chunk_for((list.size() + Rc - 1) / Rc);
             std::vector<mg::MergedTile> mtiles;
-            for (uint64_t c0 = 0; c0 < maxcols; c0 += CC) {
-                for (size_t k = 0; k < list.size(); k += R) {
-                    const uint32_t last = list[std::min(list.size(), k + R) - 1];
+            for (uint64_t c0 = 0; c0 < maxcols; c0 += CCc) {
+                for (size_t k = 0; k < list.size(); k += Rc) {
+                    const uint32_t last = list[std::min(list.size(), k + Rc) - 1];
                     const uint64_t cend = triangle ? last : cols->n;         // columns needed: [0, cend)
                     if (c0 >= cend) continue;
                     mg::MergedTile tl;
-                    for (uint32_t r = 0; r < 16; r++) tl.rows[r] = (r < R && k + r < list.size()) ? list[k + r] : 0xFFFFFFFFu;
+                    for (uint32_t r = 0; r < 16; r++) tl.rows[r] = (r < Rc && k + r < list.size()) ? list[k + r] : 0xFFFFFFFFu;
                     tl.col0 = (uint32_t)c0;
-                    tl.col1 = (uint32_t)std::min<uint64_t>(c0 + CC, cend);
+                    tl.col1 = (uint32_t)std::min<uint64_t>(c0 + CCc, cend);
                     mtiles.push_back(tl);
                 }
             }
@@ -1100,26 +1197,55 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
             rc = stage_tiles(ctx, mtiles.data(), mtiles.size() * sizeof(mg::MergedTile), &d_mt);
             if (rc != MG_OK) return rc;
             unsigned long long *d_dbg = nullptr;
+            const size_t dbg_sets = wr ? nwin : 1;                  // one {start, built, end} set per tile and launch
             if (getenv("MASHGPU_COMPARE_DBG")) {
-                hipMalloc(&d_dbg, mtiles.size() * 24);
-                hipMemsetAsync(d_dbg, 0, mtiles.size() * 24, ctx->stream);
+                hipMalloc(&d_dbg, dbg_sets * mtiles.size() * 24);
+                hipMemsetAsync(d_dbg, 0, dbg_sets * mtiles.size() * 24, ctx->stream);
             }
             a.dbg = d_dbg;
             a.mtiles = static_cast<const mg::MergedTile *>(d_mt);
-            prof_begin(ctx, ctx->prof_compare);
-            hipError_t e = mg::launch_compare_merged(a, (uint32_t)mtiles.size(), ctx->stream);
-            prof_end(ctx, ctx->prof_compare);
+            hipError_t e = hipSuccess;
+            if (wr) {
+                a.row_win = wr->dev;
+                a.col_win = wc->dev;
+                a.nwin = nwin;
+                uint32_t wstop = nwin;                                           // tuning hook: stop early, leaving pairs in progress
+                if (const char *ev = getenv("MASHGPU_COMPARE_WIN_STOP")) wstop = std::min<uint32_t>(nwin, (uint32_t)atoi(ev));
+                for (uint32_t w = 0; w < wstop && e == hipSuccess; w++) {        // stream order: window w + 1 resumes window w
+                    a.win = w;
+                    a.win_lo = w * delta;
+                    a.win_hi = (uint32_t)std::min<uint64_t>((uint64_t)(w + 1) * delta, xmax + 1);
+                    a.dbg = d_dbg ? d_dbg + (size_t)w * mtiles.size() * 3 : nullptr;
+                    prof_begin(ctx, ctx->prof_compare);
+                    e = mg::launch_compare_merged(a, (uint32_t)mtiles.size(), ctx->stream);
+                    prof_end(ctx, ctx->prof_compare);
+                }
+                a.row_win = a.col_win = nullptr;
+                a.nwin = a.win = 0;
+            } else {
+                prof_begin(ctx, ctx->prof_compare);
+                e = mg::launch_compare_merged(a, (uint32_t)mtiles.size(), ctx->stream);
+                prof_end(ctx, ctx->prof_compare);
+            }
             hipError_t e2 = hipStreamSynchronize(ctx->stream);              // the tile list is reused by the next launch
             if (d_dbg) {
-                std::vector<unsigned long long> h(mtiles.size() * 3);
+                std::vector<unsigned long long> h(dbg_sets * mtiles.size() * 3);
                 hipMemcpy(h.data(), d_dbg, h.size() * 8, hipMemcpyDeviceToHost);
-                double bsum = 0, tsum = 0;
-                for (size_t i = 0; i < mtiles.size(); i++) {
-                    bsum += (double)(h[3 * i + 1] - h[3 * i]);
-                    tsum += (double)(h[3 * i + 2] - h[3 * i]);
+                for (size_t w = 0; w < dbg_sets; w++) {
+                    double bsum = 0, tsum = 0, tmax = 0;
+                    unsigned long long first = ~0ull, last = 0;
+                    for (size_t i = 0; i < mtiles.size(); i++) {
+                        const unsigned long long *q = &h[(w * mtiles.size() + i) * 3];
+                        bsum += (double)(q[1] - q[0]);
+                        tsum += (double)(q[2] - q[0]);
+                        tmax = std::max(tmax, (double)(q[2] - q[0]));
+                        first = std::min(first, q[0]);
+                        last = std::max(last, q[2]);
+                    }
+                    fprintf(stderr, "compare dbg: shift %d window %zu/%zu, %zu rows, %zu tiles, build %.0f clk avg, tile %.0f clk avg, "
+                            "longest %.0f, launch %.0f\n", shr, w, dbg_sets, list.size(), mtiles.size(), bsum / mtiles.size(),
+                            tsum / mtiles.size(), tmax, (double)(last - first));
                 }
-                fprintf(stderr, "compare dbg: shift %d, %zu rows, %zu tiles, build %.0f clk avg, tile %.0f clk avg\n", shr,
-                        list.size(), mtiles.size(), bsum / mtiles.size(), tsum / mtiles.size());
                 hipFree(d_dbg);
             }
             if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare launch: ") + hipGetErrorString(e));

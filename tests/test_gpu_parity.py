@@ -257,6 +257,19 @@ def test_sketch_c2_genomes_full_size(eng, oracle):
 
 # ---------------------------------------------------------------- comparing
 
+def _set_kernel(monkeypatch, kernel):
+    """Select the compare engine.  "windows": the merged kernel in value-window mode (the
+    large-sketch path) forced on whatever the sketch size, with a small window target so that even
+    short sketches are cut into many windows and pairs are carried from launch to launch."""
+    if kernel.startswith("windows"):
+        monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", "merged")
+        monkeypatch.setenv("MASHGPU_COMPARE_WINDOWS", "1")
+        if kernel != "windows":
+            monkeypatch.setenv("MASHGPU_COMPARE_WIN_TARGET", kernel[len("windows"):])
+    else:
+        monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", kernel)
+
+
 def _oracle_tri(oracle, table, nhash, lengths, rb, re, k=21, kspace=KSPACE21):
     numer, denom, _, _ = oracle.triangle(table, nhash, lengths, rb, re, k, kspace)
     return numer, denom
@@ -264,7 +277,7 @@ def _oracle_tri(oracle, table, nhash, lengths, rb, re, k=21, kspace=KSPACE21):
 
 @pytest.mark.parametrize("kernel", ["merged", "tiled", "generic", "pairs"])
 def test_compare_reference_run_vectors(eng, golden_dir, kernel, monkeypatch):
-    monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", kernel)
+    _set_kernel(monkeypatch, kernel)
     z = np.load(os.path.join(golden_dir, "ref_compare_vectors.npz"))
     t = eng.table_upload(z["table"], z["nhash"], z["lengths"])
     got = eng.compare_tri_host(t)
@@ -277,10 +290,10 @@ def test_compare_reference_run_vectors(eng, golden_dir, kernel, monkeypatch):
     t.free()
 
 
-@pytest.mark.parametrize("kernel", ["merged", "tiled", "pairs"])
+@pytest.mark.parametrize("kernel", ["merged", "tiled", "pairs", "windows29"])
 @pytest.mark.parametrize("s", [1, 7, 64, 65, 100, 400, 1000, 1024])
 def test_compare_tiled_vs_oracle_sizes(eng, oracle, s, kernel, monkeypatch):
-    monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", kernel)
+    _set_kernel(monkeypatch, kernel)
     n = 150
     table, nhash, lengths = synth.clustered_sketches(n, s, clusters=5, seed=s, pool=int(1.5 * s) + 2,
                                                      private=max(1, int(0.4 * s)))
@@ -302,21 +315,41 @@ def test_compare_tiled_vs_oracle_sizes(eng, oracle, s, kernel, monkeypatch):
     t.free()
 
 
-@pytest.mark.parametrize("kernel", ["merged", "generic"])
+@pytest.mark.parametrize("kernel", ["merged", "generic", "windows", "windows150"])
 @pytest.mark.parametrize("s", [1500, 4096, 10000])
 def test_compare_large_sketch(eng, oracle, s, kernel, monkeypatch):
     """Config-5 sized sketches (s = 10000): merged-rows kernel with few rows per tile, and the
     generic binary-search kernel as an independent cross-check."""
-    monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", kernel)
+    _set_kernel(monkeypatch, kernel)
     n = 24
     table, nhash, lengths = synth.clustered_sketches(n, s, clusters=3, seed=3, pool=int(1.5 * s),
                                                      private=int(0.4 * s))
     nhash[4] = s // 3
     t = eng.table_upload(table, nhash, lengths)
+    windows = kernel.startswith("windows")
+    if windows:
+        eng.prof_enable(True)
+        eng.prof_reset()
     got = eng.compare_tri_host(t)
+    if windows:                                   # the window path really ran: one launch per window
+        launches = eng.prof_avg_ms("compare")[1]
+        eng.prof_enable(False)
+        assert launches >= (2 if kernel == "windows" else s // 150 - 2), launches
     numer, denom = _oracle_tri(oracle, table, nhash, lengths, 0, n, k=31, kspace=4.0 ** 31)
     assert np.array_equal(got["numer"], numer) and np.array_equal(got["denom"], denom)
-    t.free()
+    # a few queries against the table (rect), and a row range
+    tq = eng.table_upload(table[5:8], nhash[5:8], lengths[5:8])
+    rect = eng.compare_rect_host(t, tq)
+    for q in range(3):
+        for r in range(n):
+            i, j = max(q + 5, r), min(q + 5, r)
+            if i != j:
+                idx = i * (i - 1) // 2 + j
+                assert (rect["numer"][q, r], rect["denom"][q, r]) == (numer[idx], denom[idx]), (q, r)
+    got2 = eng.compare_tri_host(t, 9, 20)
+    n2, d2 = _oracle_tri(oracle, table, nhash, lengths, 9, 20, k=31, kspace=4.0 ** 31)
+    assert np.array_equal(got2["numer"], n2) and np.array_equal(got2["denom"], d2)
+    t.free(); tq.free()
 
 
 def test_compare_extremes_and_random(eng, oracle):
@@ -332,13 +365,13 @@ def test_compare_extremes_and_random(eng, oracle):
     t.free()
 
 
-@pytest.mark.parametrize("kernel", ["merged", "tiled", "pairs"])
+@pytest.mark.parametrize("kernel", ["merged", "tiled", "pairs", "windows61"])
 @pytest.mark.parametrize("top", [0xFFFFFFFF, 0xFFFFFFFFFFFFFFFE, 0xFFFFFFFE00000000])
 def test_compare_values_at_the_top_of_the_hash_range(eng, oracle, kernel, top, monkeypatch):
     """32-bit sketches reaching 0xFFFFFFFF / 64-bit sketches reaching 2^64-2: the prefix image
     reserves 0xFFFFFFFE (sentinel) and 0xFFFFFFFF (padding), so the shift must keep real
     prefixes below them; short rows, shared top values and a row holding only the top value."""
-    monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", kernel)
+    _set_kernel(monkeypatch, kernel)
     rng = np.random.default_rng(top % 1000)
     n, s = 40, 64
     table = np.full((n, s), np.uint64(0xFFFFFFFFFFFFFFFF), dtype=np.uint64)
@@ -362,12 +395,12 @@ def test_compare_values_at_the_top_of_the_hash_range(eng, oracle, kernel, top, m
     t.free()
 
 
-@pytest.mark.parametrize("kernel", ["merged", "tiled", "pairs"])
+@pytest.mark.parametrize("kernel", ["merged", "tiled", "pairs", "windows90"])
 def test_compare_mixed_hash_densities(eng, oracle, kernel, monkeypatch):
     """Sketches of very different genome sizes in one table (hash ranges from 2^44 to 2^64):
     the merged kernel tiles rows by density class and compares every class through its own
     prefix image; triangle and rect, incl. related sketches across classes and short rows."""
-    monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", kernel)
+    _set_kernel(monkeypatch, kernel)
     rng = np.random.default_rng(77)
     n, s = 210, 256
     table = np.full((n, s), np.uint64(0xFFFFFFFFFFFFFFFF), dtype=np.uint64)
@@ -406,13 +439,13 @@ def test_compare_mixed_hash_densities(eng, oracle, kernel, monkeypatch):
     t.free(); tq.free()
 
 
-@pytest.mark.parametrize("kernel", ["merged", "pairs"])
+@pytest.mark.parametrize("kernel", ["merged", "pairs", "windows13", "windows200"])
 @pytest.mark.parametrize("seed", range(24))
 def test_compare_random_tables_vs_oracle(eng, oracle, seed, kernel, monkeypatch):
     """Randomised tables: any sketch size, ragged / empty / identical rows, values shared between
     rows (several rows of a tile holding the same value), hash ranges from 2^20 to 2^64, random
     row ranges, triangle and rect -- the merged kernel against the oracle, bit for bit."""
-    monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", kernel)
+    _set_kernel(monkeypatch, kernel)
     rng = np.random.default_rng(1000 + seed)
     s = int(rng.choice([1, 2, 3, 5, 17, 64, 100, 257, 600, 1000, 1024, 1500]))
     n = int(rng.integers(2, 70))
@@ -463,13 +496,13 @@ def test_compare_random_tables_vs_oracle(eng, oracle, seed, kernel, monkeypatch)
     t.free()
 
 
-@pytest.mark.parametrize("kernel", ["merged", "tiled", "pairs"])
+@pytest.mark.parametrize("kernel", ["merged", "tiled", "pairs", "windows40"])
 @pytest.mark.parametrize("seed", range(6))
 def test_compare_values_sharing_a_prefix(eng, oracle, kernel, seed, monkeypatch):
     """Different 64-bit values that share their 32-bit prefix, inside one row, across rows of a
     tile and between rows and columns: the tile's prefix/value consistency check fails, and
     matches must come from the fully verified exact path (and near-misses must not count)."""
-    monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", kernel)
+    _set_kernel(monkeypatch, kernel)
     rng = np.random.default_rng(700 + seed)
     n, s = 40, 200
     base = np.unique(rng.integers(2 ** 40, 2 ** 63, 260).astype(np.uint64) & np.uint64(~0xFFFF & (2 ** 64 - 1)))

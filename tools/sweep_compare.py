@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """A/B sweep of compare-kernel variants in ONE process (interleaved rounds).
-usage: tools/sweep_compare.py [--n 30000] [--rounds 3] variant[:ROWS[:COLS]] ..."""
+usage: tools/sweep_compare.py [--n 30000] [--s 1000] [--rounds 3] variant[:ROWS[:COLS]] ...
+variant: 0|2|3|4 (group size), merged|tiled|generic|pairs (engine), win|winNNN|nowin (value windows)"""
 import argparse, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,6 +12,7 @@ def main():
     ap.add_argument("--n", type=int, default=30000)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--mode", default="clustered")
+    ap.add_argument("--s", type=int, default=1000)
     ap.add_argument("variants", nargs="*", default=["0"])
     a = ap.parse_args()
     import torch
@@ -18,7 +20,7 @@ def main():
     dev = torch.device("cuda", 0)
     eng = abi.MashGpu(0)
     n = a.n
-    hashes, nhash, lengths = synth_torch.clustered_sketch_table(n, 1000, clusters=max(1, n // 100), device=dev,
+    hashes, nhash, lengths = synth_torch.clustered_sketch_table(n, a.s, clusters=max(1, n // 100), device=dev, pool=int(1.5 * a.s), private=int(0.4 * a.s),
                                                                 contiguous=(a.mode == "contiguous"))
     if a.mode == "identical":
         hashes[:] = hashes[0]
@@ -28,7 +30,7 @@ def main():
         step = 97 if a.mode == "mixed97" else 10
         sel = torch.arange(0, n, step, device=dev)
         hashes[sel] = hashes[sel] << 9
-    table = eng.table_wrap(hashes.data_ptr(), nhash.data_ptr(), lengths.data_ptr(), n, 1000)
+    table = eng.table_wrap(hashes.data_ptr(), nhash.data_ptr(), lengths.data_ptr(), n, a.s)
     pairs = n * (n - 1) // 2
     out = torch.empty((pairs, 2), dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
@@ -37,7 +39,16 @@ def main():
     for rd in range(a.rounds + 1):
         for v in a.variants:
             parts = v.split(":")
-            if parts[0] in ("merged", "tiled", "generic", "pairs"):
+            for key in ("MASHGPU_COMPARE_WINDOWS", "MASHGPU_COMPARE_WIN_TARGET"):
+                os.environ.pop(key, None)
+            if parts[0].startswith("win") or parts[0] == "nowin":
+                # value-window mode on (optionally winNNN = window target) / off
+                os.environ.pop("MASHGPU_COMPARE_KERNEL", None)
+                os.environ.pop("MASHGPU_COMPARE_VARIANT", None)
+                os.environ["MASHGPU_COMPARE_WINDOWS"] = "0" if parts[0] == "nowin" else "1"
+                if parts[0] not in ("win", "nowin"):
+                    os.environ["MASHGPU_COMPARE_WIN_TARGET"] = parts[0][3:]
+            elif parts[0] in ("merged", "tiled", "generic", "pairs"):
                 os.environ["MASHGPU_COMPARE_KERNEL"] = parts[0]
                 os.environ.pop("MASHGPU_COMPARE_VARIANT", None)
             else:
