@@ -49,6 +49,8 @@ struct CompareArgs {
     uint32_t win, nwin;           // this launch's window, number of windows (0 = not windowed)
     uint32_t win_lo, win_hi;      // prefix range of the window (win_hi: exclusive, for the bucket scale)
     uint32_t win_ecap;            // table entries a windowed tile may hold
+    uint8_t *win_mask;            // [tiles][16 waves][win_kmax]: live columns per batch, carried between launches
+    uint32_t win_kmax;            // batches of 8 columns per wave and tile
 };
 
 // LDS-tiled kernel usable when s <= 1024; rows_per_tile chosen by compare_rows_per_tile.

@@ -23,6 +23,14 @@
 // halving the kernel's dominant HBM traffic; 64-bit values are fetched only for tied lanes.
 // Matches (ties) are ranked exactly with ballot + mbcnt using the index stored in the tag
 // (it IS the lower bound of the matched value in its row).
+//
+// WIN = true (large sketches): the same kernel over ONE VALUE WINDOW of the hash range per launch.
+// R*s <= ~16 000 entries would leave 16000/s rows per tile; instead a tile always has 16 rows and
+// its table holds only their hashes with prefix in [win_lo, win_hi) (tags: index inside the row's
+// window, lo_of(r) restores the index in the row), a column streams only its elements of the
+// window, and a pair keeps {common, 0x80000000 | matches} in its output slot from launch to launch
+// until the rank test, the end of the column or the last window decides it.  All indices in the
+// rank arithmetic stay global, so the decision rule is the one above.  Host side: run_compare.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -338,7 +346,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
     auto col_of = [&](uint32_t t) -> uint32_t {
         return tile.col0 + ((t / MR_CB) * MR_NW + wid) * MR_CB + (t % MR_CB);
     };
-    auto flush_batch = [&](uint32_t jb, uint32_t ncols_done) {
+    auto flush_batch = [&](uint32_t jb, uint32_t ncols_done, uint32_t procmask) {
         // lane -> (row = lane/4, two columns 2*(lane%4), +1) : 16 B per lane, 64 B per row
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -347,8 +355,11 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
         if (r < R && i != 0xFFFFFFFFull) {
             const uint4 v = *reinterpret_cast<const uint4 *>(&stage[r * MR_CB + c0]);
             const uint64_t j0 = (uint64_t)jb + c0;
-            const bool ok0 = c0 < ncols_done && (!a.triangle || j0 < i);
-            const bool ok1 = c0 + 1 < ncols_done && (!a.triangle || j0 + 1 < i);
+            // WIN: only the columns this launch worked on (the others keep their earlier result)
+            const bool in0 = WIN ? ((procmask >> c0) & 1u) != 0 : c0 < ncols_done;
+            const bool in1 = WIN ? ((procmask >> (c0 + 1)) & 1u) != 0 : c0 + 1 < ncols_done;
+            const bool ok0 = in0 && (!a.triangle || j0 < i);
+            const bool ok1 = in1 && (!a.triangle || j0 + 1 < i);
             uint64_t oidx;
             if (a.triangle) oidx = i * (i - 1) / 2 + j0 - a.out_base;
             else oidx = (i - a.row_begin) * a.ncols + j0;
@@ -388,19 +399,49 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
     uint32_t nB_next = 0;
     uint32_t nx_lo = 0, nx_hi = 0, n2_lo = 0, n2_hi = 0;   // WIN: window ranges of the next two columns
     uint2 st_next = make_uint2(0u, 0u);                    // WIN: carried state of the next column (lane r <-> row r)
-    uint32_t tcol = 0;
-    uint32_t j = col_of(0);
+    // WIN: a column whose 16 pairs are all decided is not touched again.  Every wave keeps one
+    // byte per batch of its columns (bit c: column c of the batch still has a pair in progress),
+    // written when the batch is flushed and read by the same wave of the next launch; lane l of
+    // mk_lane holds the byte of batch mk_base + l.
+    uint8_t *wmask = WIN ? a.win_mask + ((uint64_t)blockIdx.x * MR_NW + wid) * a.win_kmax : nullptr;
+    uint32_t mk_lane = 0xFFu, mk_base = 0;
+    auto mk_load = [&](uint32_t kb) {
+        mk_base = kb;
+        const uint32_t k = kb + lane;
+        mk_lane = k < a.win_kmax ? (uint32_t)wmask[k] : 0u;
+    };
+    // first position t' >= t of the wave's column sequence whose column is still live (or beyond the tile)
+    auto next_col = [&](uint32_t t) -> uint32_t {
+        if (!WIN) return t;
+        if (a.win == 0) return t;
+        for (;;) {
+            const uint32_t k = t / MR_CB;
+            if (col_of(k * MR_CB) >= tile.col1) return t;
+            if (k - mk_base >= 64u) mk_load(k & ~63u);
+            const uint32_t rel = (uint32_t)__builtin_amdgcn_readfirstlane((int)(k - mk_base));
+            const uint32_t m = ((uint32_t)__builtin_amdgcn_readlane((int)mk_lane, (int)rel) & 0xFFu) >> (t % MR_CB);
+            if (m != 0) return t + (uint32_t)__builtin_ctz(m);
+            uint64_t nz = __ballot(mk_lane != 0);
+            nz = rel + 1 < 64u ? nz >> (rel + 1) : 0ull;
+            t = nz != 0 ? (k + 1 + (uint32_t)__builtin_ctzll(nz)) * MR_CB : (mk_base + 64u) * MR_CB;
+        }
+    };
+    if (WIN && a.win > 0) mk_load(0);
+    uint32_t procmask = 0, progmask = 0;                   // WIN: columns of the open batch worked on / still in progress
+    uint32_t tcol = next_col(0);
+    uint32_t t1 = next_col(tcol + 1), t2 = next_col(t1 + 1);   // the next two live columns
+    uint32_t j = col_of(tcol);
     if (j < tile.col1) {
         if (WIN) {
             win_range(j, nx_lo, nx_hi);
-            const uint32_t j2 = col_of(1);
+            const uint32_t j2 = col_of(t1);
             win_range(j2 < tile.col1 ? j2 : j, n2_lo, n2_hi);
             if (a.win > 0) st_next = load_state(j);
         }
         load_group(a.col_pfx + (uint64_t)j * a.col_pfx_stride, nx_lo, ncol);
         nB_next = a.col_nhash[j];
     }
-    for (; j < tile.col1; tcol++, j = col_of(tcol)) {
+    while (j < tile.col1) {
         uint32_t nB = nB_next < s ? nB_next : s;
         const uint32_t *bsrc = a.col_pfx + (uint64_t)j * a.col_pfx_stride;
         const uint64_t *bsrc64 = a.col_hashes + (uint64_t)j * a.col_stride;
@@ -430,14 +471,14 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
         uint32_t a_chk = my_row[t_chk >= 1 ? (uint32_t)t_chk - 1 : 0];
         load_group(bsrc, qlo + 64 * MR_KU, nxt);
         {
-            const uint32_t jnx = col_of(tcol + 1);
+            const uint32_t jnx = col_of(t1);
             const uint32_t jn = jnx < tile.col1 ? jnx : j;
             if (WIN) { nx_lo = n2_lo; nx_hi = n2_hi; }                   // jn's range (clamped duplicates are never used)
             load_group(a.col_pfx + (uint64_t)jn * a.col_pfx_stride, WIN ? nx_lo : 0u, ncol);
             nB_next = a.col_nhash[jn];
             if (WIN) {
                 if (a.win > 0) st_next = load_state(jn);
-                const uint32_t j2x = col_of(tcol + 2);
+                const uint32_t j2x = col_of(t2);
                 win_range(j2x < tile.col1 ? j2x : jn, n2_lo, n2_hi);
             }
         }
@@ -643,6 +684,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
                 load_group(bsrc, q0 + 2 * 64 * MR_KU, nxt);
             }
         }
+        bool prog = false;                                                   // WIN: my pair stays in progress
         if (lane < R) {
             uint32_t denom = s;
             if (!((brokem >> lane) & 1u)) {
@@ -652,13 +694,26 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
                     // no exit yet: the pair is decided only when the column is exhausted (nothing
                     // left that could match) or this was the last window
                     if (!((started >> lane) & 1u)) denom = fin_denom;                      // decided earlier (or not ours)
-                    else if (a.win + 1 < a.nwin && qhi < nB) denom = 0x80000000u | st_call;
+                    else if (a.win + 1 < a.nwin && qhi < nB) { denom = 0x80000000u | st_call; prog = true; }
                 }
             }
             stage[lane * MR_CB + (tcol % MR_CB)] = make_uint2(st_common, denom);
         }
-        if ((tcol % MR_CB) == MR_CB - 1 || col_of(tcol + 1) >= tile.col1)
-            flush_batch(j - (tcol % MR_CB), (tcol % MR_CB) + 1);
+        if (WIN) {
+            procmask |= 1u << (tcol % MR_CB);
+            if (__ballot(prog) != 0) progmask |= 1u << (tcol % MR_CB);
+        }
+        if (t1 / MR_CB != tcol / MR_CB || col_of(t1) >= tile.col1) {
+            flush_batch(j - (tcol % MR_CB), (tcol % MR_CB) + 1, procmask);
+            if (WIN) {
+                if (lane == 0) wmask[tcol / MR_CB] = (uint8_t)progmask;
+                procmask = progmask = 0;
+            }
+        }
+        tcol = t1;
+        t1 = t2;
+        t2 = next_col(t2 + 1);
+        j = col_of(tcol);
     }
     if (a.dbg) {
         if (lane == 0) atomicMax(&a.dbg[3 * (uint64_t)blockIdx.x + 2], (unsigned long long)__builtin_readcyclecounter());

@@ -1045,6 +1045,8 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
     a.unroll = 0;
     a.row_win = a.col_win = nullptr;
     a.win = a.nwin = a.win_lo = a.win_hi = a.win_ecap = 0;
+    a.win_mask = nullptr;
+    a.win_kmax = 0;
     if (const char *e = getenv("MASHGPU_COMPARE_VARIANT")) a.unroll = (uint32_t)atoi(e);
     const char *force = getenv("MASHGPU_COMPARE_KERNEL");
     if (force && strcmp(force, "pairs") == 0 && mg::compare_pairs_supported(a.s)) {
@@ -1095,7 +1097,7 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
         // a launch handles the hashes of one prefix range, sized so that 16 rows' share of it fills
         // the tile table; a pair carries its match count from launch to launch in its output slot
         // and drops out once its union reaches s (see compare_merged.hip, WIN).
-        bool want_win = R <= 6;
+        bool want_win = R <= 8;                                 // s >= ~1800: measured gain from 1.2x (s = 2000) to 3.8x (s = 10 000)
         if (const char *e = getenv("MASHGPU_COMPARE_WINDOWS")) want_win = atoi(e) != 0;
         const uint32_t Rw = mg::compare_window_rows();
         const uint32_t R_plain = R;
@@ -1205,7 +1207,16 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
             a.dbg = d_dbg;
             a.mtiles = static_cast<const mg::MergedTile *>(d_mt);
             hipError_t e = hipSuccess;
+            void *d_mask = nullptr;
             if (wr) {
+                // live-column masks: one byte per wave and batch of 8 columns, kept between the launches
+                a.win_kmax = (uint32_t)(((CCc + 7) / 8 + 15) / 16);
+                const size_t mbytes = mtiles.size() * 16 * (size_t)a.win_kmax;
+                if (ctx_malloc(ctx, &d_mask, mbytes) != hipSuccess) return fail(ctx, MG_ERR_NOMEM, "compare: allocation failed (window masks)");
+                e = hipMemsetAsync(d_mask, 0, mbytes, ctx->stream);
+                a.win_mask = static_cast<uint8_t *>(d_mask);
+            }
+            if (wr && e == hipSuccess) {
                 a.row_win = wr->dev;
                 a.col_win = wc->dev;
                 a.nwin = nwin;
@@ -1222,12 +1233,14 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
                 }
                 a.row_win = a.col_win = nullptr;
                 a.nwin = a.win = 0;
-            } else {
+                a.win_mask = nullptr;
+            } else if (!wr) {
                 prof_begin(ctx, ctx->prof_compare);
                 e = mg::launch_compare_merged(a, (uint32_t)mtiles.size(), ctx->stream);
                 prof_end(ctx, ctx->prof_compare);
             }
             hipError_t e2 = hipStreamSynchronize(ctx->stream);              // the tile list is reused by the next launch
+            ctx_free(ctx, d_mask);
             if (d_dbg) {
                 std::vector<unsigned long long> h(dbg_sets * mtiles.size() * 3);
                 hipMemcpy(h.data(), d_dbg, h.size() * 8, hipMemcpyDeviceToHost);
