@@ -1220,9 +1220,7 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
                 a.row_win = wr->dev;
                 a.col_win = wc->dev;
                 a.nwin = nwin;
-                uint32_t wstop = nwin;                                           // tuning hook: stop early, leaving pairs in progress
-                if (const char *ev = getenv("MASHGPU_COMPARE_WIN_STOP")) wstop = std::min<uint32_t>(nwin, (uint32_t)atoi(ev));
-                for (uint32_t w = 0; w < wstop && e == hipSuccess; w++) {        // stream order: window w + 1 resumes window w
+                for (uint32_t w = 0; w < nwin && e == hipSuccess; w++) {         // stream order: window w + 1 resumes window w
                     a.win = w;
                     a.win_lo = w * delta;
                     a.win_hi = (uint32_t)std::min<uint64_t>((uint64_t)(w + 1) * delta, xmax + 1);
