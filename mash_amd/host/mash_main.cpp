@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <charconv>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -740,6 +741,29 @@ struct FastOut {
 // formatting, not the GPU, bounds a full matrix: ~50 ns per value on one core).  Rows are cut
 // into chunks of >= 2^17 pairs, a wave of chunks is formatted concurrently, the pieces are
 // appended in order; fn(out, row, slot) must only touch slot-private state besides `out`.
+// MASH_AMD_TIMING=1: wall time of the stages of a full-matrix run, to stderr at exit
+struct StageClock {
+    const bool on = getenv("MASH_AMD_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    vector<std::pair<string, double>> acc;
+    void lap(const char *name)
+    {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        const double dt = std::chrono::duration<double>(t1 - t0).count();
+        t0 = t1;
+        for (auto &a : acc) if (a.first == name) { a.second += dt; return; }
+        acc.emplace_back(name, dt);
+    }
+    ~StageClock()
+    {
+        if (!on) return;
+        cerr << "timing:";
+        for (auto &a : acc) cerr << ' ' << a.first << ' ' << a.second << " s;";
+        cerr << endl;
+    }
+};
+
 unsigned emit_threads()
 {
     static const unsigned nt = []() {
@@ -896,21 +920,45 @@ int cmd_dist(int argc, const char **argv)
             if (!fetch_edges(gpu, edges, [&](mg_edge *o, uint64_t cap, uint64_t *n) {
                     return mg_compare_rect_filter_host(gpu.ctx, tr, tq, q0, q1, ref.p.kmer, d_max, o, cap, n); }))
                 return 1;
-            mg_pair pr;
-            for (const mg_edge &e : edges)
+            emit_rows(out, 0, edges.size(), [](uint64_t) { return 1; }, [&](FastOut &o, uint64_t x, unsigned) {
+                const mg_edge &e = edges[x];
+                mg_pair pr;
                 if (finish_edge(e, len_ref[e.col], len_qry[e.row], ref.p.kmer, kspace, p_max, pr))
-                    print_pair_line(out, ref.refs[e.col], qry.refs[e.row], comment, pr);
+                    print_pair_line(o, ref.refs[e.col], qry.refs[e.row], comment, pr);
+            });
         }
         mg_table_free(tr);
         mg_table_free(tq);
         if (w.count > 0 && !p.reads) warn_kmer_size(ref, w);
         return 0;
     }
+    // -t without a p-value filter prints distances only: they come from one table per run
+    // (a distance depends on numer / denom alone) and no p-value is evaluated
+    const uint64_t s_tab = std::min(ref.p.sketch_size, qry.p.sketch_size);
+    vector<double> dist_lut;
+    if (table && p_max >= 1.0 && s_tab <= (1u << 20) && !getenv("MASH_AMD_FULL_FINISH")) {
+        dist_lut.resize(s_tab + 1);
+        for (uint64_t x = 0; x <= s_tab; x++) dist_lut[x] = mg_distance((uint32_t)x, (uint32_t)s_tab, ref.p.kmer);
+    }
     for (uint64_t q0 = 0; q0 < nq; q0 += qblock) {
         const uint64_t q1 = std::min(nq, q0 + qblock);
         counts.resize((q1 - q0) * nref);
-        pairs.resize(counts.size());
         if (mg_compare_rect_host(gpu.ctx, tr, tq, q0, q1, counts.data()) != MG_OK) { cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl; return 1; }
+        if (!dist_lut.empty()) {
+            emit_rows(out, q0, q1, [&](uint64_t) { return nref; }, [&](FastOut &o, uint64_t q, unsigned) {
+                o << qry.refs[q].name;                            // writeOutput, CommandDistance.cpp:247-304
+                for (uint64_t r = 0; r < nref; r++) {
+                    const mg_counts &c = counts[(q - q0) * nref + r];
+                    const double d = c.denom == s_tab ? dist_lut[c.numer] : mg_distance(c.numer, c.denom, ref.p.kmer);
+                    o << '\t';
+                    if (!(d > d_max)) o << d;                      // CommandDistance.cpp:409-412
+                    o.room();
+                }
+                o.eol();
+            });
+            continue;
+        }
+        pairs.resize(counts.size());
         mg_finish_rect_host(counts.data(), len_ref.data(), nref, len_qry.data() + q0, q1 - q0, ref.p.kmer, kspace, d_max, p_max, pairs.data());
         emit_rows(out, q0, q1, [&](uint64_t) { return nref; }, [&](FastOut &o, uint64_t q, unsigned) {
             if (table) o << qry.refs[q].name;                // writeOutput, CommandDistance.cpp:247-304
@@ -973,6 +1021,7 @@ int cmd_triangle(int argc, const char **argv)
     vector<mg_counts> counts;
     vector<mg_pair> pairs;
     uint64_t r0 = 1;
+    StageClock clk;
     FastOut out;
     if (edge && edge_filter_wanted(d_max)) {
         vector<mg_edge> edges;
@@ -982,25 +1031,75 @@ int cmd_triangle(int argc, const char **argv)
             if (!fetch_edges(gpu, edges, [&](mg_edge *o, uint64_t cap, uint64_t *cnt) {
                     return mg_compare_tri_filter_host(gpu.ctx, t, r0, r1, set.p.kmer, d_max, o, cap, cnt); }))
                 return 1;
-            mg_pair pr;
-            for (const mg_edge &e : edges)
+            clk.lap("compare+filter+copy");
+            emit_rows(out, 0, edges.size(), [](uint64_t) { return 1; }, [&](FastOut &o, uint64_t x, unsigned) {
+                const mg_edge &e = edges[x];
+                mg_pair pr;
                 if (finish_edge(e, lengths[e.row], lengths[e.col], set.p.kmer, kspace, p_max, pr)) {
-                    out << label(set.refs[e.row]) << '\t' << label(set.refs[e.col]) << '\t' << pr.distance << '\t'
-                        << pr.p_value << '\t' << pr.numer << '/' << pr.denom;
-                    out.eol();
+                    o << label(set.refs[e.row]) << '\t' << label(set.refs[e.col]) << '\t' << pr.distance << '\t'
+                      << pr.p_value << '\t' << pr.numer << '/' << pr.denom;
+                    o.eol();
                 }
+            });
+            clk.lap("finish+format+write");
             r0 = r1;
         }
     }
+    // The Phylip matrix prints distances only, and of the p-values just the largest (to stderr).
+    // A distance depends on (numer, denom) alone -> one table per run; and a p-value can only raise
+    // the peak if even the pair of the two longest genomes sharing that many hashes would: the
+    // p-value grows with both lengths (larger r in CommandDistance.cpp:437-441, the binomial tail
+    // grows with r), so pairs whose bound stays below the running peak skip the incomplete-beta
+    // evaluation.  The bound test has a 1e-9 relative margin for the rounding of that evaluation.
+    const uint64_t s_tab = set.p.sketch_size;
+    vector<double> dist_lut, p_bound;
+    if (!edge && s_tab <= (1u << 20) && !getenv("MASH_AMD_FULL_FINISH")) {          // (env: the plain path, for tests)
+        uint64_t l1 = 0, l2 = 0;                                   // the two largest lengths
+        for (uint64_t v : lengths) { if (v > l1) { l2 = l1; l1 = v; } else if (v > l2) l2 = v; }
+        dist_lut.resize(s_tab + 1);
+        p_bound.resize(s_tab + 1);
+        for (uint64_t x = 0; x <= s_tab; x++) {
+            dist_lut[x] = mg_distance((uint32_t)x, (uint32_t)s_tab, set.p.kmer);
+            p_bound[x] = mg_p_value(x, l1, l2, kspace, s_tab) * (1.0 + 1e-9);
+        }
+    }
+    const bool lean = !dist_lut.empty();
     while (r0 < n) {
         uint64_t r1 = r0, npairs = 0;
         while (r1 < n && (npairs == 0 || npairs + r1 <= (1ull << 24))) { npairs += r1; r1++; }
         counts.resize(npairs);
-        pairs.resize(npairs);
+        if (!lean) pairs.resize(npairs);
+        clk.lap("setup");
         if (mg_compare_tri_host(gpu.ctx, t, r0, r1, counts.data()) != MG_OK) { cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl; return 1; }
-        mg_finish_tri_host(counts.data(), lengths.data(), r0, r1, set.p.kmer, kspace, d_max, p_max, pairs.data());
+        clk.lap("compare+copy");
+        if (!lean) mg_finish_tri_host(counts.data(), lengths.data(), r0, r1, set.p.kmer, kspace, d_max, p_max, pairs.data());
+        clk.lap("finish");
         const uint64_t base = r0 * (r0 - 1) / 2;
         vector<double> peak(emit_threads(), 0.0);
+        if (lean) {
+            for (double &v : peak) v = p_peak;                     // what earlier blocks established
+            emit_rows(out, r0, r1, [](uint64_t i) { return i; }, [&](FastOut &o, uint64_t i, unsigned slot) {
+                uint64_t idx = i * (i - 1) / 2 - base;             // writeOutput, CommandTriangle.cpp:159-198
+                double pk = peak[slot];
+                o << label(set.refs[i]);
+                for (uint64_t j = 0; j < i; j++, idx++) {
+                    const mg_counts &c = counts[idx];
+                    const bool full = c.denom == s_tab;
+                    o << '\t' << (full ? dist_lut[c.numer] : mg_distance(c.numer, c.denom, set.p.kmer));
+                    o.room();
+                    if (!full || p_bound[c.numer] >= pk) {
+                        const double pv = mg_p_value(c.numer, lengths[i], lengths[j], kspace, c.denom);
+                        if (pv > pk) pk = pv;
+                    }
+                }
+                peak[slot] = pk;
+                o.eol();
+            });
+            for (double v : peak) if (v > p_peak) p_peak = v;
+            clk.lap("format+write");
+            r0 = r1;
+            continue;
+        }
         emit_rows(out, r0, r1, [](uint64_t i) { return i; }, [&](FastOut &o, uint64_t i, unsigned slot) {
             const Ref &ref = set.refs[i];                     // writeOutput, CommandTriangle.cpp:159-198
             uint64_t idx = i * (i - 1) / 2 - base;
@@ -1024,6 +1123,7 @@ int cmd_triangle(int argc, const char **argv)
             if (!edge) o.eol();
         });
         for (double v : peak) if (v > p_peak) p_peak = v;
+        clk.lap("format+write");
         r0 = r1;
     }
     mg_table_free(t);

@@ -482,6 +482,15 @@ def test_large_outputs_do_not_depend_on_formatting_threads(built, tmp_path):
         b = run(*cmd, cwd=tmp_path, env=many)
         assert a.stdout == b.stdout and a.stderr == b.stderr, cmd
         assert len(a.stdout) > 1000
+    # the Phylip path takes distances from a table and skips p-values that cannot raise the peak:
+    # same matrix and same "Max p-value" as finishing every pair
+    a = run("triangle", "many.msh", cwd=tmp_path)
+    b = run("triangle", "many.msh", cwd=tmp_path, env={"MASH_AMD_FULL_FINISH": "1"})
+    assert a.stdout == b.stdout and a.stderr == b.stderr and "Max p-value:" in a.stderr
+    for cmd in (("dist", "-t", "many.msh", "many.msh"), ("dist", "-t", "-d", "0.08", "many.msh", "many.msh")):
+        a = run(*cmd, cwd=tmp_path)
+        b = run(*cmd, cwd=tmp_path, env={"MASH_AMD_FULL_FINISH": "1"})
+        assert a.stdout == b.stdout, cmd
     tri = run("triangle", "many.msh", cwd=tmp_path, env=many).stdout.splitlines()
     assert tri[0] == "\t1000" and len(tri) == 1001
     assert [len(l.split("\t")) for l in tri[1:]] == list(range(1, 1001))

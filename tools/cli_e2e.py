@@ -12,8 +12,10 @@ def main():
     ap.add_argument("--genomes", type=int, default=500)
     ap.add_argument("--len", type=int, default=1_000_000)
     ap.add_argument("--threads", type=int, default=16)
+    ap.add_argument("--only-edge", action="store_true", help="time only the thresholded edge-list run")
     a = ap.parse_args()
     d = tempfile.mkdtemp(prefix="mash_e2e_")
+    os.environ["MASH_AMD_TIMING"] = "1"
     rng = np.random.default_rng(1)
     lut = np.frombuffer(b"ACGT", dtype=np.uint8)
     base = lut[rng.integers(0, 4, a.len)]
@@ -39,14 +41,34 @@ def main():
             r = subprocess.run([MASH, *cmd], stdout=fo, stderr=subprocess.PIPE, cwd=d)
         assert r.returncode == 0, r.stderr.decode()[-500:]
         res[tag] = time.perf_counter() - t
+        for ln in r.stderr.decode().splitlines():
+            if ln.startswith("timing:"):
+                res[tag + "_stages"] = ln[len("timing:"):].strip()
 
     run("sketch_p1_s", "sketch", "-l", "-o", "seq", lst)
     run("sketch_pN_s", "sketch", "-p", str(a.threads), "-l", "-o", "par", lst)
     assert open(os.path.join(d, "seq.msh"), "rb").read() == open(os.path.join(d, "par.msh"), "rb").read()
+    if a.only_edge:
+        run("triangle_edge_d0.2_s", "triangle", "-E", "-d", "0.2", "par.msh", out=os.path.join(d, "edge.txt"))
+        os.environ["MASH_AMD_EMIT_THREADS"] = "1"
+        run("triangle_edge_d0.2_1thread_s", "triangle", "-E", "-d", "0.2", "par.msh", out=os.path.join(d, "edge1.txt"))
+        res["edge_lines"] = sum(1 for _ in open(os.path.join(d, "edge.txt")))
+        assert open(os.path.join(d, "edge.txt"), "rb").read() == open(os.path.join(d, "edge1.txt"), "rb").read()
+        print(json.dumps(res))
+        subprocess.run(["rm", "-rf", d])
+        return
     run("triangle_s", "triangle", "par.msh", out=os.path.join(d, "tri.txt"))
     run("triangle_edge_d0.2_s", "triangle", "-E", "-d", "0.2", "par.msh", out=os.path.join(d, "edge.txt"))
-    run("dist_s", "dist", "par.msh", "par.msh", out=os.path.join(d, "dist.txt"))
-    res["dist_lines"] = sum(1 for _ in open(os.path.join(d, "dist.txt")))
+    if a.genomes <= 5000:                                    # n^2 text lines: keep the file bounded
+        run("dist_s", "dist", "par.msh", "par.msh", out=os.path.join(d, "dist.txt"))
+        res["dist_lines"] = sum(1 for _ in open(os.path.join(d, "dist.txt")))
+    else:
+        run("dist_table_s", "dist", "-t", "par.msh", "par.msh", out=os.path.join(d, "dist.txt"))
+    res["triangle_bytes"] = os.path.getsize(os.path.join(d, "tri.txt"))
+    os.environ["MASH_AMD_EMIT_THREADS"] = "1"
+    run("triangle_1thread_format_s", "triangle", "par.msh", out=os.path.join(d, "tri1.txt"))
+    del os.environ["MASH_AMD_EMIT_THREADS"]
+    assert open(os.path.join(d, "tri.txt"), "rb").read() == open(os.path.join(d, "tri1.txt"), "rb").read()
     res["edge_lines"] = sum(1 for _ in open(os.path.join(d, "edge.txt")))
     res["bases_per_s_sketch_pN"] = a.genomes * a.len / res["sketch_pN_s"]
     print(json.dumps(res))
