@@ -43,11 +43,24 @@ MG_PV_HD double beta_cf(double a, double b, double x)
     return h;
 }
 
+// log-gamma: on the host the reentrant form -- plain lgamma() stores the sign in the global
+// `signgam`, and threads finishing pairs side by side would pass that cache line around
+// (measured: 16 threads no faster than 3); same value either way
+MG_PV_HD double ln_gamma(double v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return lgamma(v);
+#else
+    int sign;
+    return lgamma_r(v, &sign);
+#endif
+}
+
 MG_PV_HD double reg_inc_beta(double a, double b, double x)
 {
     if (x <= 0.0) return 0.0;
     if (x >= 1.0) return 1.0;
-    const double ln_pre = lgamma(a + b) - lgamma(a) - lgamma(b) + a * log(x) + b * log1p(-x);
+    const double ln_pre = ln_gamma(a + b) - ln_gamma(a) - ln_gamma(b) + a * log(x) + b * log1p(-x);
     if (x < (a + 1.0) / (a + b + 2.0)) return exp(ln_pre) * beta_cf(a, b, x) / a;
     return 1.0 - exp(ln_pre) * beta_cf(b, a, 1.0 - x) / b;
 }

@@ -4,6 +4,7 @@
  * Plain-C restatement of the Mash 2.3 hot path.  Citations are into
  * /root/reference/src/mash/.
  */
+#define _DEFAULT_SOURCE                 /* lgamma_r under -std=c11 */
 #include "mash_oracle.h"
 
 #include <math.h>
@@ -395,7 +396,10 @@ static double reg_inc_beta(double a, double b, double x)
 {
     if (x <= 0.0) return 0.0;
     if (x >= 1.0) return 1.0;
-    double ln_pre = lgamma(a + b) - lgamma(a) - lgamma(b) + a * log(x) + b * log1p(-x);
+    /* lgamma_r: the plain form stores the sign in the global `signgam`; the baseline's threads
+     * (bench.py cpu_baseline) would pass that cache line around.  Same value. */
+    int sg;
+    double ln_pre = lgamma_r(a + b, &sg) - lgamma_r(a, &sg) - lgamma_r(b, &sg) + a * log(x) + b * log1p(-x);
     if (x < (a + 1.0) / (a + b + 2.0))
         return exp(ln_pre) * beta_cont_frac(a, b, x) / a;
     return 1.0 - exp(ln_pre) * beta_cont_frac(b, a, 1.0 - x) / b;
