@@ -491,13 +491,18 @@ static int sketch_dev_impl(mg_ctx *ctx, const mg_params *p, const uint8_t *bases
     mg::SketchWork *d_work = nullptr, *d_work2 = nullptr;
     mg::MergeWork *d_merge = nullptr;
     uint8_t *d_alpha = nullptr;
-    uint64_t *d_pool = nullptr, *d_gT = nullptr;
+    uint64_t *d_pool = nullptr, *d_gT = nullptr, *d_seed = nullptr;
+    mg::SketchWork *d_workR = nullptr;
+    mg::MergeWork *d_mergeR = nullptr;
     uint32_t *d_pool_n = nullptr, *d_fix = nullptr;
     unsigned long long *d_firstpos = nullptr, *d_tstar = nullptr, *d_pos2 = nullptr;
     int rc = MG_OK;
     auto cleanup = [&]() {
         hipStreamSynchronize(ctx->stream);
         if (d_work2) ctx_free(ctx, d_work2);
+        if (d_seed) ctx_free(ctx, d_seed);
+        if (d_workR) ctx_free(ctx, d_workR);
+        if (d_mergeR) ctx_free(ctx, d_mergeR);
         if (d_fix) ctx_free(ctx, d_fix);
         if (d_firstpos) ctx_free(ctx, d_firstpos);
         if (d_pos2) ctx_free(ctx, d_pos2);
@@ -553,6 +558,31 @@ static int sketch_dev_impl(mg_ctx *ctx, const mg_params *p, const uint8_t *bases
     a.probe_obs = probe ? probe->obs : nullptr;
     a.probe_mask = probe ? probe->mask : 0;
     a.probe_max = probe ? probe->key_max : 0;
+    // Seeded thresholds (sketch.hip, SelState::T0): a sketch of L k-mers is started with the
+    // threshold 3 s/L of the hash range instead of discovering it (the discovery sorts the candidate
+    // buffer about ten times per chunk: 6-9 % of a 1 Mbp genome, most of the latency of a small
+    // call).  Sketches that end with fewer than s hashes below their seed are run again without
+    // one, so the result never depends on it.
+    a.seed_T = nullptr;
+    std::vector<uint64_t> seeds;
+    bool any_seed = false;
+    if (!range_path && !getenv("MASHGPU_SKETCH_NO_SEED")) {
+        seeds.assign(nsketch, ~0ull);
+        for (uint64_t i = 0; i < nsketch; i++) {
+            const uint64_t len = sketch_off[i + 1] - sketch_off[i];
+            if (len < k) continue;
+            const double npos = (double)(len - k + 1);
+            const double frac = 3.0 * (double)s / npos;
+            if (frac >= 0.25) continue;                                 // short input: nothing to gain
+            seeds[i] = (uint64_t)(frac * (p->use64 ? 18446744073709551616.0 : 4294967296.0));
+            any_seed = true;
+        }
+        if (any_seed) {
+            TRY_C(ctx_malloc(ctx, (void **)&d_seed, nsketch * 8));
+            TRY_C(hipMemcpyAsync(d_seed, seeds.data(), nsketch * 8, hipMemcpyHostToDevice, ctx->stream));
+            a.seed_T = d_seed;
+        }
+    }
     if (range_path) {
         // -m: bottom-s of the hashes seen at least m times, by exact range counting (sketch.hip)
         if (probe) { cleanup(); return fail(ctx, MG_ERR_UNSUPPORTED, "mg_screen: min_copies does not apply"); }
@@ -579,6 +609,61 @@ static int sketch_dev_impl(mg_ctx *ctx, const mg_params *p, const uint8_t *bases
             m.work = d_merge;
         }
         TRY_C(mg::launch_merge_chunks(nt, m, nfinal, ctx->stream));
+    }
+    if (any_seed) {
+        // which seeded sketches came out short?  (also those that simply have fewer than s distinct
+        // k-mers: their second run gives the same list)
+        std::vector<uint32_t> nh(nsketch);
+        TRY_C(hipMemcpyAsync(nh.data(), nhash_out_dev, nsketch * 4, hipMemcpyDeviceToHost, ctx->stream));
+        TRY_C(hipStreamSynchronize(ctx->stream));
+        std::vector<uint8_t> again(nsketch, 0);
+        bool any = false;
+        for (uint64_t i = 0; i < nsketch; i++)
+            if (seeds[i] != ~0ull && nh[i] < s) { again[i] = 1; any = true; }
+        if (any) {
+            std::vector<mg::SketchWork> workR;
+            for (const mg::SketchWork &w : work) if (again[w.sketch]) workR.push_back(w);
+            std::vector<mg::MergeWork> fin, lvl1;
+            const size_t nfinal0 = merges.size() - merges1.size();
+            for (size_t q = 0; q < merges.size(); q++)
+                if (again[merges[q].sketch]) (q < nfinal0 ? fin : lvl1).push_back(merges[q]);
+            uint32_t prev = 0xFFFFFFFFu;
+            for (const mg::SketchWork &w : workR) {        // a sketch's chunks are consecutive, slots ascending
+                if (w.nchunks > 1 && w.sketch != prev) {
+                    TRY_C(hipMemsetAsync(d_pool_n + w.slot, 0, (size_t)w.nchunks * 4, ctx->stream));
+                    TRY_C(hipMemsetAsync(d_gT + w.sketch, 0xFF, 8, ctx->stream));
+                }
+                prev = w.sketch;
+            }
+            TRY_C(ctx_malloc(ctx, (void **)&d_workR, workR.size() * sizeof(mg::SketchWork)));
+            TRY_C(hipMemcpyAsync(d_workR, workR.data(), workR.size() * sizeof(mg::SketchWork), hipMemcpyHostToDevice, ctx->stream));
+            mg::SketchArgs r = a;
+            r.work = d_workR;
+            r.seed_T = nullptr;
+            r.probe_keys = nullptr;                        // every k-mer was already looked up by the first run
+            r.probe_obs = nullptr;
+            TRY_C(mg::launch_sketch_chunks(p->kmer_size, mode, nt, r, (uint32_t)workR.size(), ctx->stream));
+            if (!fin.empty()) {
+                std::vector<mg::MergeWork> both = fin;
+                both.insert(both.end(), lvl1.begin(), lvl1.end());
+                TRY_C(ctx_malloc(ctx, (void **)&d_mergeR, both.size() * sizeof(mg::MergeWork)));
+                TRY_C(hipMemcpyAsync(d_mergeR, both.data(), both.size() * sizeof(mg::MergeWork), hipMemcpyHostToDevice, ctx->stream));
+                mg::MergeArgs m;
+                m.pool = d_pool;
+                m.pool_n = d_pool_n;
+                m.hashes_out = hashes_out_dev;
+                m.nhash_out = nhash_out_dev;
+                m.sketch_size = (uint32_t)s;
+                m.cap = cap;
+                if (!lvl1.empty()) {
+                    m.work = d_mergeR + fin.size();
+                    TRY_C(mg::launch_merge_chunks(nt, m, (uint32_t)lvl1.size(), ctx->stream));
+                }
+                m.work = d_mergeR;
+                TRY_C(mg::launch_merge_chunks(nt, m, (uint32_t)fin.size(), ctx->stream));
+            }
+            TRY_C(hipStreamSynchronize(ctx->stream));      // workR / both go out of scope
+        }
     }
     if (counts_out_dev) {
         // multiplicities: re-stream every chunk against the finished sketches (count_chunks_kernel)

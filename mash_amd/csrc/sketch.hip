@@ -86,6 +86,7 @@ struct SelState {            // LDS-resident selection state of one workgroup
     uint32_t full;           // >= s distinct values known (or a shared threshold adopted)
     uint32_t arrive;         // monotone wave-arrival ticket (segment boundaries)
     uint32_t snap;           // `count` as seen by the last wave to finish a segment
+    uint64_t T0;             // seeded threshold (HPAD = none): only hashes below it are collected at all
 };
 
 // Sort + unique + truncate the candidate buffer.  All NT threads call.
@@ -142,9 +143,9 @@ __device__ void compact_buffer(uint64_t *buf, SelState *st, uint32_t *s_wsum, ui
     if (tid == 0) {
         const uint32_t kept = total < s ? total : s;
         st->count = kept;
-        uint64_t T = HPAD;
-        uint32_t full = 0;
-        if (total >= s) { full = 1; T = buf[s - 1]; }
+        uint64_t T = st->T0;                               // a seeded threshold stays in force
+        uint32_t full = T != HPAD ? 1u : 0u;
+        if (total >= s) { full = 1; T = buf[s - 1]; }      // (< T0: every candidate is)
         if (g_T) {
             // exchange with the other chunks of this sketch
             if (full) atomicMin(g_T, (unsigned long long)T);
@@ -179,10 +180,16 @@ __global__ __launch_bounds__(NT) void sketch_chunks_kernel(SketchArgs a)
     unsigned long long *g_T = w.nchunks > 1 ? (unsigned long long *)&a.g_T[w.sketch] : nullptr;
 
     if (tid == 0) {
-        st->count = 0; st->full = 0; st->T = HPAD; st->arrive = 0; st->snap = 0;
+        // Seeded start (SketchArgs::seed_T): with L k-mers in the sketch the s-th smallest hash
+        // sits near s/L of the hash range, so a threshold a few times that spares the warm-up in
+        // which the candidate buffer is sorted again and again while the threshold is still loose.
+        // Exact as long as the sketch ends up with s hashes below the seed; the host re-runs the
+        // few that do not (repeats, mostly invalid input) without a seed.
+        const uint64_t t0 = a.seed_T ? a.seed_T[w.sketch] : HPAD;
+        st->count = 0; st->full = t0 != HPAD ? 1u : 0u; st->T = t0; st->T0 = t0; st->arrive = 0; st->snap = 0;
         if (g_T) {
             const uint64_t gt = __hip_atomic_load(g_T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (gt != HPAD) { st->T = gt; st->full = 1; }
+            if (gt < st->T) { st->T = gt; st->full = 1; }
         }
     }
     if (MODE == 2) for (int i = tid; i < 256; i += NT) alpha[i] = a.alphabet[i];
@@ -345,7 +352,7 @@ __global__ __launch_bounds__(NT) void merge_chunks_kernel(MergeArgs a)
     const int tid = threadIdx.x;
     const MergeWork w = a.work[blockIdx.x];
     const uint32_t s = a.sketch_size, cap = a.cap;
-    if (tid == 0) { st->count = 0; st->full = 0; st->T = HPAD; st->arrive = 0; st->snap = 0; }
+    if (tid == 0) { st->count = 0; st->full = 0; st->T = HPAD; st->T0 = HPAD; st->arrive = 0; st->snap = 0; }
     __syncthreads();
     const uint32_t batch = cap - s;                        // room guaranteed after a compaction
     for (uint32_t c = 0; c < w.nchunks; c++) {

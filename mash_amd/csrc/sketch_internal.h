@@ -36,6 +36,7 @@ struct SketchArgs {
     uint32_t *probe_obs;
     uint64_t probe_mask;
     uint64_t probe_max;
+    const uint64_t *seed_T;       // [nsketch] seeded thresholds (HPAD = none), or nullptr
 };
 
 // Merge of pool slots first_slot, first_slot+stride, ... (nchunks of them).

@@ -240,6 +240,34 @@ def test_sketch_multichunk_and_overflow(eng, oracle, monkeypatch):
     _check_sketches(eng, oracle, sketches[:2], k=16, s=100)
 
 
+@pytest.mark.parametrize("chunks", ["one", "many"])
+def test_sketch_seeded_threshold_is_never_trusted(eng, oracle, chunks, monkeypatch):
+    """Sketches start from a threshold guessed from their length (3 s/L of the hash range,
+    sketch_dev_impl); inputs with far fewer distinct k-mers than positions (tandem repeats, mostly
+    invalid bytes, 32-bit hashes of a small k) end up short below the guess and must be re-run
+    unseeded -- next to ordinary genomes in the same call, single- and multi-chunk, with counts."""
+    if chunks == "many":
+        monkeypatch.setenv("MASHGPU_SKETCH_MIN_CHUNK", "15360")
+        monkeypatch.setenv("MASHGPU_SKETCH_ITEMS", "100000")
+    rng = np.random.default_rng(77)
+    unit_small = synth._rand_dna(rng, 700)           # < s distinct k-mers
+    unit_mid = synth._rand_dna(rng, 2500)            # > s distinct, but almost none below the seed
+    normal = synth._rand_dna(rng, 400_000)
+    mostly_n = (b"N" * 900 + synth._rand_dna(rng, 100)) * 400
+    sketches = [[normal], [unit_small * 400], [unit_mid * 120], [mostly_n], [normal[:200_000], unit_mid * 60],
+                [unit_mid * 120 + normal[:50_000]]]
+    _check_sketches(eng, oracle, sketches, k=21, s=1000)
+    _check_sketches(eng, oracle, sketches, k=16, s=400)
+    _check_sketches(eng, oracle, sketches, k=9, s=1000)          # k <= 16: 32-bit hashes, 4^9 = 262144 possible k-mers
+    # the unseeded run is the same sketch
+    monkeypatch.setenv("MASHGPU_SKETCH_NO_SEED", "1")
+    p = eng.params(k=21, s=1000)
+    plain = eng.sketch_host(sketches, p)
+    monkeypatch.delenv("MASHGPU_SKETCH_NO_SEED")
+    seeded = eng.sketch_host(sketches, p)
+    assert np.array_equal(plain[0], seeded[0]) and np.array_equal(plain[1], seeded[1])
+
+
 def test_sketch_c2_genomes_full_size(eng, oracle):
     """BASELINE config 2 shape: 1 Mbp synthetic genomes, k=21 s=1000 (a batch of 12,
     incl. the robustness variant) vs the oracle; plus concatenation property:
