@@ -308,9 +308,9 @@ def main():
                                "frac": round(sk_ach / HBM_PEAK_GBS, 4), "traffic": sk_traffic,
                                "kernel": "sketch_chunks_kernel<21,0,256,false>", "kernel_ms": round(sk_ms, 3),
                                "launches": sk_launches, "units": sk_units,
-                               "note": "integer-ALU bound: PMC shows the VALU issuing 98% of the time at ~176 VALU "
-                                       "instructions per k-mer (10 64-bit multiplies), HBM traffic = algorithmic "
-                                       "bytes; see DESIGN.md"}}
+                               "note": "integer-ALU bound: PMC (units) shows the VALU issuing practically every "
+                                       "cycle at ~150 VALU instructions per k-mer (10 64-bit multiplies on 32-bit "
+                                       "halves), HBM traffic = algorithmic bytes; see DESIGN.md 4.2"}}
         if rank == 0 and world == 1 and not args.no_cpu:
             sketch["cpu_baseline"] = cpu_baseline_sketch(min(args.cpu_seconds, 6.0))
         result["sketch"] = sketch
