@@ -568,12 +568,14 @@ static int sketch_dev_impl(mg_ctx *ctx, const mg_params *p, const uint8_t *bases
     bool any_seed = false;
     if (!range_path && !getenv("MASHGPU_SKETCH_NO_SEED")) {
         seeds.assign(nsketch, ~0ull);
+        const double kmer_space = std::pow((double)std::max<uint32_t>(p->alphabet_size, 2), (double)k) / (p->noncanonical ? 1.0 : 2.0);
         for (uint64_t i = 0; i < nsketch; i++) {
             const uint64_t len = sketch_off[i + 1] - sketch_off[i];
             if (len < k) continue;
             const double npos = (double)(len - k + 1);
             const double frac = 3.0 * (double)s / npos;
             if (frac >= 0.25) continue;                                 // short input: nothing to gain
+            if (kmer_space < 64.0 * npos) continue;                     // few possible k-mers: distinct << L, the guess would miss
             seeds[i] = (uint64_t)(frac * (p->use64 ? 18446744073709551616.0 : 4294967296.0));
             any_seed = true;
         }
