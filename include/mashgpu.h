@@ -185,7 +185,9 @@ int mg_compare_rect_filter_host(mg_ctx *ctx, const mg_table *ref, const mg_table
  * are bit-identical to the reference build on this box.
  * len_ref/len_qry: Reference::length of the two sketches of each pair are taken
  * from the tables by index: triangle pairs use (i,j) in reference order.
- * max_distance / max_p_value < 0 disable the filters (the CLI passes 1 / 1). */
+ * max_distance / max_p_value < 0 disable the filters (the CLI passes 1 / 1).
+ * Batches of 2^20 pairs and more are split over up to 16 host threads (the reference runs
+ * compare jobs on its -p pool); every pair is independent, the output does not depend on it. */
 int mg_finish_tri_host(const mg_counts *counts, const uint64_t *lengths, uint64_t row_begin,
                        uint64_t row_end, int kmer_size, double kmer_space,
                        double max_distance, double max_p_value, mg_pair *out);
