@@ -1108,6 +1108,218 @@ static int stage_tiles(mg_ctx *ctx, const void *tiles, size_t bytes, void **dev_
     return MG_OK;
 }
 
+// Value windows of one density class (large sketches, see run_compare_merged): the window width
+// delta (prefix domain) is taken from the class's densest row so that 16 rows' share of a window
+// fills the tile table; the plan stands only if, by the actual offsets, every tile's share of every
+// window fits -- else a narrower second try, else no plan (the class uses plain tiles).
+struct WindowPlan {
+    const mg_table::Windows *rows = nullptr, *cols = nullptr;
+    uint32_t delta = 0, nwin = 0;
+};
+
+static int plan_windows(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, const std::vector<uint32_t> &list, int shr,
+                        uint64_t xmax, uint32_t s, WindowPlan *out)
+{
+    const uint32_t Rw = mg::compare_window_rows();
+    double target = 0.8 * mg::compare_window_entries() / Rw;                // entries of the densest row per window
+    if (const char *e = getenv("MASHGPU_COMPARE_WIN_TARGET")) target = std::max(1.0, atof(e));
+    double dens = 0;                                                         // hashes per unit of prefix, densest row
+    for (uint32_t i : list) {
+        const uint64_t ni = std::min<uint64_t>(rows->nh[i], s);
+        if (ni) dens = std::max(dens, (double)ni / ((double)(rows->last[i] >> shr) + 1.0));
+    }
+    if (dens <= 0) return MG_OK;
+    for (int attempt = 0; attempt < 2; attempt++, target *= 0.7) {
+        const double dd = std::floor(target / dens);
+        if (dd < 1.0 || dd >= (double)xmax + 1.0) return MG_OK;              // one window: nothing to gain
+        const uint32_t delta = (uint32_t)dd;
+        const uint64_t nw = (xmax + delta) / delta;                          // ceil((xmax + 1) / delta)
+        if (nw < 2 || nw > 255) return MG_OK;
+        const uint32_t nwin = (uint32_t)nw;
+        const mg_table::Windows *cand = nullptr;
+        int rc = table_windows(ctx, rows, shr, delta, nwin, s, &cand);
+        if (rc != MG_OK) return rc;
+        bool fits = true;
+        for (size_t k = 0; k < list.size() && fits; k += Rw) {
+            for (uint32_t w = 0; w < nwin && fits; w++) {
+                uint64_t tot = 0;
+                for (size_t r = k; r < std::min(list.size(), k + Rw); r++) {
+                    const uint32_t *o = &cand->host[(uint64_t)list[r] * (nwin + 1) + w];
+                    const uint32_t c = o[1] - o[0];
+                    if (c > 4095) fits = false;                              // the tag's index field
+                    tot += c;
+                }
+                if (tot > mg::compare_window_entries()) fits = false;
+            }
+        }
+        if (!fits) continue;
+        const mg_table::Windows *wc = nullptr;
+        rc = table_windows(ctx, cols, shr, delta, nwin, s, &wc);
+        if (rc != MG_OK) return rc;
+        out->rows = rows == cols ? wc : cand;
+        out->cols = wc;
+        out->delta = delta;
+        out->nwin = nwin;
+        return MG_OK;
+    }
+    return MG_OK;
+}
+
+// The merged-rows engine (compare_merged.hip) over rows [row_begin, row_end): density classes,
+// per-class prefix images, optional value windows, tile lists, launches.
+static int run_compare_merged(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, uint64_t row_begin, uint64_t row_end,
+                              bool triangle, mg::CompareArgs &a, uint32_t R, uint64_t CC, uint64_t maxcols)
+{
+    // Rows are grouped by hash DENSITY before they are cut into tiles of R: one linear
+    // value -> bucket map per tile spreads the entries evenly only if its rows are equally
+    // dense, and collections mix genomes of very different sizes (a virus sketch spans the
+    // whole hash range, a bacterial one its bottom 1/5000).  Within a class rows keep their
+    // order, so a tile's rows stay close together and the triangle's "columns below the
+    // row" rule wastes little: a tile runs to its largest row.  Every class is compared
+    // through its own 32-bit prefix image (value >> shr, shr from the class maximum, larger
+    // values saturate): a prefix must resolve the values of the tile's rows, or equal
+    // prefixes of different values send block after block down the exact path.
+    int rc = table_classes(ctx, rows);
+    if (rc != MG_OK) return rc;
+    std::vector<std::vector<uint32_t>> by_class(65);
+    for (uint64_t i = row_begin; i < row_end; i++) by_class[rows->cls[i] > 64 ? 64 : rows->cls[i]].push_back((uint32_t)i);
+    // Large sketches: R*s <= ~16 000 leaves few rows per tile (2 at s = 10 000), and a probe
+    // serves only that many pairs.  They are compared VALUE WINDOW by value window instead:
+    // a launch handles the hashes of one prefix range, sized so that 16 rows' share of it fills
+    // the tile table; a pair carries its match count from launch to launch in its output slot
+    // and drops out once its union reaches s (see compare_merged.hip, WIN).
+    bool want_win = R <= 8;                                 // s >= ~1800: measured gain from 1.2x (s = 2000) to 3.8x (s = 10 000)
+    if (const char *e = getenv("MASHGPU_COMPARE_WINDOWS")) want_win = atoi(e) != 0;
+    const uint32_t Rw = mg::compare_window_rows();
+    const uint32_t R_plain = R;
+    // A launch of few row tiles (a handful of queries against a large database, or a small
+    // density class) would leave most CUs idle with full-length column chunks: cut the columns
+    // finer until there are ~4 tiles per CU (a table build costs about as much as 100 columns,
+    // so not below 256).  Every class is its own launch, so this is decided per class.
+    const bool cc_forced = getenv("MASHGPU_COMPARE_COLS") != nullptr;
+    auto chunk_for = [&](uint64_t nrt) -> uint64_t {
+        if (cc_forced || nrt == 0 || nrt * ((maxcols + CC - 1) / CC) >= 512) return CC;
+        uint64_t chunks = (1024 + nrt - 1) / nrt;
+        const uint64_t most = std::max<uint64_t>(1, maxcols / 256);
+        if (chunks > most) {
+            // the floor of 256 columns binds: then at least fill whole rounds of the CUs
+            chunks = most;
+            const uint64_t cus = ctx->cu_count > 0 ? (uint64_t)ctx->cu_count : 256;
+            if (nrt * chunks > cus) chunks = std::max<uint64_t>(1, (nrt * chunks / cus) * cus / nrt);
+        }
+        const uint64_t cc = ((maxcols + chunks - 1) / chunks + 7) & ~7ull;
+        return std::min<uint64_t>(CC, std::max<uint64_t>(256, cc));
+    };
+    a.dbg = nullptr;
+    a.row_pfx_stride = mg::compare_pfx_stride(rows->s);
+    a.col_pfx_stride = mg::compare_pfx_stride(cols->s);
+    for (const auto &list : by_class) {
+        if (list.empty()) continue;
+        uint64_t mx = 1;
+        for (uint32_t i : list) mx = std::max(mx, rows->last[i]);
+        const int bl = 64 - __builtin_clzll(mx);
+        int shr = bl > 32 ? bl - 32 : 0;
+        if ((mx >> shr) >= 0xFFFFFFFDull) shr++;      // 0xFFFFFFFD..F: saturated values, sentinel, padding
+        rc = table_prefix(ctx, rows, shr, &a.row_pfx);
+        if (rc == MG_OK) rc = table_prefix(ctx, cols, shr, &a.col_pfx);
+        if (rc != MG_OK) return rc;
+        a.pfx_shr = (uint32_t)shr;
+        // ---- window plan of this class (large sketches) ----
+        WindowPlan plan;
+        const uint64_t xmax = mx >> shr;
+        if (want_win) {
+            rc = plan_windows(ctx, rows, cols, list, shr, xmax, a.s, &plan);
+            if (rc != MG_OK) return rc;
+        }
+        const mg_table::Windows *wr = plan.rows, *wc = plan.cols;
+        const uint32_t delta = plan.delta, nwin = plan.nwin;
+        const uint32_t Rc = wr ? Rw : R_plain;                               // rows per tile of this class
+        a.rows_per_tile = Rc;
+        const uint64_t CCc = chunk_for((list.size() + Rc - 1) / Rc);
+        std::vector<mg::MergedTile> mtiles;
+        for (uint64_t c0 = 0; c0 < maxcols; c0 += CCc) {
+            for (size_t k = 0; k < list.size(); k += Rc) {
+                const uint32_t last = list[std::min(list.size(), k + Rc) - 1];
+                const uint64_t cend = triangle ? last : cols->n;         // columns needed: [0, cend)
+                if (c0 >= cend) continue;
+                mg::MergedTile tl;
+                for (uint32_t r = 0; r < 16; r++) tl.rows[r] = (r < Rc && k + r < list.size()) ? list[k + r] : 0xFFFFFFFFu;
+                tl.col0 = (uint32_t)c0;
+                tl.col1 = (uint32_t)std::min<uint64_t>(c0 + CCc, cend);
+                mtiles.push_back(tl);
+            }
+        }
+        if (mtiles.empty()) continue;
+        void *d_mt = nullptr;
+        rc = stage_tiles(ctx, mtiles.data(), mtiles.size() * sizeof(mg::MergedTile), &d_mt);
+        if (rc != MG_OK) return rc;
+        unsigned long long *d_dbg = nullptr;
+        const size_t dbg_sets = wr ? nwin : 1;                  // one {start, built, end} set per tile and launch
+        if (getenv("MASHGPU_COMPARE_DBG")) {
+            hipMalloc(&d_dbg, dbg_sets * mtiles.size() * 24);
+            hipMemsetAsync(d_dbg, 0, dbg_sets * mtiles.size() * 24, ctx->stream);
+        }
+        a.dbg = d_dbg;
+        a.mtiles = static_cast<const mg::MergedTile *>(d_mt);
+        hipError_t e = hipSuccess;
+        void *d_mask = nullptr;
+        if (wr) {
+            // live-column masks: one byte per wave and batch of 8 columns, kept between the launches
+            a.win_kmax = (uint32_t)(((CCc + 7) / 8 + 15) / 16);
+            const size_t mbytes = mtiles.size() * 16 * (size_t)a.win_kmax;
+            if (ctx_malloc(ctx, &d_mask, mbytes) != hipSuccess) return fail(ctx, MG_ERR_NOMEM, "compare: allocation failed (window masks)");
+            e = hipMemsetAsync(d_mask, 0, mbytes, ctx->stream);
+            a.win_mask = static_cast<uint8_t *>(d_mask);
+        }
+        if (wr && e == hipSuccess) {
+            a.row_win = wr->dev;
+            a.col_win = wc->dev;
+            a.nwin = nwin;
+            for (uint32_t w = 0; w < nwin && e == hipSuccess; w++) {         // stream order: window w + 1 resumes window w
+                a.win = w;
+                a.win_lo = w * delta;
+                a.win_hi = (uint32_t)std::min<uint64_t>((uint64_t)(w + 1) * delta, xmax + 1);
+                a.dbg = d_dbg ? d_dbg + (size_t)w * mtiles.size() * 3 : nullptr;
+                prof_begin(ctx, ctx->prof_compare);
+                e = mg::launch_compare_merged(a, (uint32_t)mtiles.size(), ctx->stream);
+                prof_end(ctx, ctx->prof_compare);
+            }
+            a.row_win = a.col_win = nullptr;
+            a.nwin = a.win = 0;
+            a.win_mask = nullptr;
+        } else if (!wr) {
+            prof_begin(ctx, ctx->prof_compare);
+            e = mg::launch_compare_merged(a, (uint32_t)mtiles.size(), ctx->stream);
+            prof_end(ctx, ctx->prof_compare);
+        }
+        hipError_t e2 = hipStreamSynchronize(ctx->stream);              // the tile list is reused by the next launch
+        ctx_free(ctx, d_mask);
+        if (d_dbg) {
+            std::vector<unsigned long long> h(dbg_sets * mtiles.size() * 3);
+            hipMemcpy(h.data(), d_dbg, h.size() * 8, hipMemcpyDeviceToHost);
+            for (size_t w = 0; w < dbg_sets; w++) {
+                double bsum = 0, tsum = 0, tmax = 0;
+                unsigned long long first = ~0ull, last = 0;
+                for (size_t i = 0; i < mtiles.size(); i++) {
+                    const unsigned long long *q = &h[(w * mtiles.size() + i) * 3];
+                    bsum += (double)(q[1] - q[0]);
+                    tsum += (double)(q[2] - q[0]);
+                    tmax = std::max(tmax, (double)(q[2] - q[0]));
+                    first = std::min(first, q[0]);
+                    last = std::max(last, q[2]);
+                }
+                fprintf(stderr, "compare dbg: shift %d window %zu/%zu, %zu rows, %zu tiles, build %.0f clk avg, tile %.0f clk avg, "
+                        "longest %.0f, launch %.0f\n", shr, w, dbg_sets, list.size(), mtiles.size(), bsum / mtiles.size(),
+                        tsum / mtiles.size(), tmax, (double)(last - first));
+            }
+            hipFree(d_dbg);
+        }
+        if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare launch: ") + hipGetErrorString(e));
+        if (e2 != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare kernel: ") + hipGetErrorString(e2));
+    }
+    return MG_OK;
+}
+
 static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, uint64_t row_begin,
                        uint64_t row_end, bool triangle, mg_counts *out_dev)
 {
@@ -1165,192 +1377,8 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
     // tiles: column chunk outer, row tile inner (concurrent workgroups share a column chunk in L2)
     const uint64_t maxcols = triangle ? (row_end - 1) : cols->n;       // columns [0, maxcols)
     std::vector<mg::CompareTile> tiles;
-    if (use_merged) {
-        // Rows are grouped by hash DENSITY before they are cut into tiles of R: one linear
-        // value -> bucket map per tile spreads the entries evenly only if its rows are equally
-        // dense, and collections mix genomes of very different sizes (a virus sketch spans the
-        // whole hash range, a bacterial one its bottom 1/5000).  Within a class rows keep their
-        // order, so a tile's rows stay close together and the triangle's "columns below the
-        // row" rule wastes little: a tile runs to its largest row.  Every class is compared
-        // through its own 32-bit prefix image (value >> shr, shr from the class maximum, larger
-        // values saturate): a prefix must resolve the values of the tile's rows, or equal
-        // prefixes of different values send block after block down the exact path.
-        int rc = table_classes(ctx, rows);
-        if (rc != MG_OK) return rc;
-        std::vector<std::vector<uint32_t>> by_class(65);
-        for (uint64_t i = row_begin; i < row_end; i++) by_class[rows->cls[i] > 64 ? 64 : rows->cls[i]].push_back((uint32_t)i);
-        // Large sketches: R*s <= ~16 000 leaves few rows per tile (2 at s = 10 000), and a probe
-        // serves only that many pairs.  They are compared VALUE WINDOW by value window instead:
-        // a launch handles the hashes of one prefix range, sized so that 16 rows' share of it fills
-        // the tile table; a pair carries its match count from launch to launch in its output slot
-        // and drops out once its union reaches s (see compare_merged.hip, WIN).
-        bool want_win = R <= 8;                                 // s >= ~1800: measured gain from 1.2x (s = 2000) to 3.8x (s = 10 000)
-        if (const char *e = getenv("MASHGPU_COMPARE_WINDOWS")) want_win = atoi(e) != 0;
-        const uint32_t Rw = mg::compare_window_rows();
-        const uint32_t R_plain = R;
-        // A launch of few row tiles (a handful of queries against a large database, or a small
-        // density class) would leave most CUs idle with full-length column chunks: cut the columns
-        // finer until there are ~4 tiles per CU (a table build costs about as much as 100 columns,
-        // so not below 256).  Every class is its own launch, so this is decided per class.
-        const bool cc_forced = getenv("MASHGPU_COMPARE_COLS") != nullptr;
-        auto chunk_for = [&](uint64_t nrt) -> uint64_t {
-            if (cc_forced || nrt == 0 || nrt * ((maxcols + CC - 1) / CC) >= 512) return CC;
-            uint64_t chunks = (1024 + nrt - 1) / nrt;
-            const uint64_t most = std::max<uint64_t>(1, maxcols / 256);
-            if (chunks > most) {
-                // the floor of 256 columns binds: then at least fill whole rounds of the CUs
-                chunks = most;
-                const uint64_t cus = ctx->cu_count > 0 ? (uint64_t)ctx->cu_count : 256;
-                if (nrt * chunks > cus) chunks = std::max<uint64_t>(1, (nrt * chunks / cus) * cus / nrt);
-            }
-            const uint64_t cc = ((maxcols + chunks - 1) / chunks + 7) & ~7ull;
-            return std::min<uint64_t>(CC, std::max<uint64_t>(256, cc));
-        };
-        a.dbg = nullptr;
-        a.row_pfx_stride = mg::compare_pfx_stride(rows->s);
-        a.col_pfx_stride = mg::compare_pfx_stride(cols->s);
-        for (const auto &list : by_class) {
-            if (list.empty()) continue;
-            uint64_t mx = 1;
-            for (uint32_t i : list) mx = std::max(mx, rows->last[i]);
-            const int bl = 64 - __builtin_clzll(mx);
-            int shr = bl > 32 ? bl - 32 : 0;
-            if ((mx >> shr) >= 0xFFFFFFFDull) shr++;      // 0xFFFFFFFD..F: saturated values, sentinel, padding
-            rc = table_prefix(ctx, rows, shr, &a.row_pfx);
-            if (rc == MG_OK) rc = table_prefix(ctx, cols, shr, &a.col_pfx);
-            if (rc != MG_OK) return rc;
-            a.pfx_shr = (uint32_t)shr;
-            // ---- window plan of this class (large sketches) ----
-            const mg_table::Windows *wr = nullptr, *wc = nullptr;
-            uint32_t delta = 0, nwin = 0;
-            const uint64_t xmax = mx >> shr;
-            if (want_win) {
-                double target = 0.8 * mg::compare_window_entries() / Rw;        // entries of the densest row per window
-                if (const char *e = getenv("MASHGPU_COMPARE_WIN_TARGET")) target = std::max(1.0, atof(e));
-                for (int attempt = 0; attempt < 2 && !wr; attempt++, target *= 0.7) {
-                    double dens = 0;                                             // hashes per unit of prefix, densest row
-                    for (uint32_t i : list) {
-                        const uint64_t ni = std::min<uint64_t>(rows->nh[i], a.s);
-                        if (ni) dens = std::max(dens, (double)ni / ((double)(rows->last[i] >> shr) + 1.0));
-                    }
-                    if (dens <= 0) break;
-                    const double dd = std::floor(target / dens);
-                    if (dd < 1.0 || dd >= (double)xmax + 1.0) break;            // one window: nothing to gain
-                    delta = (uint32_t)dd;
-                    const uint64_t nw = (xmax + delta) / delta;                 // ceil((xmax + 1) / delta)
-                    if (nw < 2 || nw > 255) break;
-                    nwin = (uint32_t)nw;
-                    const mg_table::Windows *cand = nullptr;
-                    rc = table_windows(ctx, rows, shr, delta, nwin, a.s, &cand);
-                    if (rc != MG_OK) return rc;
-                    // every tile's share of every window must fit the tile table
-                    bool fits = true;
-                    for (size_t k = 0; k < list.size() && fits; k += Rw) {
-                        for (uint32_t w = 0; w < nwin && fits; w++) {
-                            uint64_t tot = 0;
-                            for (size_t r = k; r < std::min(list.size(), k + Rw); r++) {
-                                const uint32_t *o = &cand->host[(uint64_t)list[r] * (nwin + 1) + w];
-                                const uint32_t c = o[1] - o[0];
-                                if (c > 4095) fits = false;
-                                tot += c;
-                            }
-                            if (tot > mg::compare_window_entries()) fits = false;
-                        }
-                    }
-                    if (fits) wr = cand;
-                }
-                if (wr) {
-                    rc = table_windows(ctx, cols, shr, delta, nwin, a.s, &wc);
-                    if (rc != MG_OK) return rc;
-                    if (rows == cols) wr = wc;                                   // the cache vector may have moved
-                }
-            }
-            const uint32_t Rc = wr ? Rw : R_plain;                               // rows per tile of this class
-            a.rows_per_tile = Rc;
-            const uint64_t CCc = chunk_for((list.size() + Rc - 1) / Rc);
-            std::vector<mg::MergedTile> mtiles;
-            for (uint64_t c0 = 0; c0 < maxcols; c0 += CCc) {
-                for (size_t k = 0; k < list.size(); k += Rc) {
-                    const uint32_t last = list[std::min(list.size(), k + Rc) - 1];
-                    const uint64_t cend = triangle ? last : cols->n;         // columns needed: [0, cend)
-                    if (c0 >= cend) continue;
-                    mg::MergedTile tl;
-                    for (uint32_t r = 0; r < 16; r++) tl.rows[r] = (r < Rc && k + r < list.size()) ? list[k + r] : 0xFFFFFFFFu;
-                    tl.col0 = (uint32_t)c0;
-                    tl.col1 = (uint32_t)std::min<uint64_t>(c0 + CCc, cend);
-                    mtiles.push_back(tl);
-                }
-            }
-            if (mtiles.empty()) continue;
-            void *d_mt = nullptr;
-            rc = stage_tiles(ctx, mtiles.data(), mtiles.size() * sizeof(mg::MergedTile), &d_mt);
-            if (rc != MG_OK) return rc;
-            unsigned long long *d_dbg = nullptr;
-            const size_t dbg_sets = wr ? nwin : 1;                  // one {start, built, end} set per tile and launch
-            if (getenv("MASHGPU_COMPARE_DBG")) {
-                hipMalloc(&d_dbg, dbg_sets * mtiles.size() * 24);
-                hipMemsetAsync(d_dbg, 0, dbg_sets * mtiles.size() * 24, ctx->stream);
-            }
-            a.dbg = d_dbg;
-            a.mtiles = static_cast<const mg::MergedTile *>(d_mt);
-            hipError_t e = hipSuccess;
-            void *d_mask = nullptr;
-            if (wr) {
-                // live-column masks: one byte per wave and batch of 8 columns, kept between the launches
-                a.win_kmax = (uint32_t)(((CCc + 7) / 8 + 15) / 16);
-                const size_t mbytes = mtiles.size() * 16 * (size_t)a.win_kmax;
-                if (ctx_malloc(ctx, &d_mask, mbytes) != hipSuccess) return fail(ctx, MG_ERR_NOMEM, "compare: allocation failed (window masks)");
-                e = hipMemsetAsync(d_mask, 0, mbytes, ctx->stream);
-                a.win_mask = static_cast<uint8_t *>(d_mask);
-            }
-            if (wr && e == hipSuccess) {
-                a.row_win = wr->dev;
-                a.col_win = wc->dev;
-                a.nwin = nwin;
-                for (uint32_t w = 0; w < nwin && e == hipSuccess; w++) {         // stream order: window w + 1 resumes window w
-                    a.win = w;
-                    a.win_lo = w * delta;
-                    a.win_hi = (uint32_t)std::min<uint64_t>((uint64_t)(w + 1) * delta, xmax + 1);
-                    a.dbg = d_dbg ? d_dbg + (size_t)w * mtiles.size() * 3 : nullptr;
-                    prof_begin(ctx, ctx->prof_compare);
-                    e = mg::launch_compare_merged(a, (uint32_t)mtiles.size(), ctx->stream);
-                    prof_end(ctx, ctx->prof_compare);
-                }
-                a.row_win = a.col_win = nullptr;
-                a.nwin = a.win = 0;
-                a.win_mask = nullptr;
-            } else if (!wr) {
-                prof_begin(ctx, ctx->prof_compare);
-                e = mg::launch_compare_merged(a, (uint32_t)mtiles.size(), ctx->stream);
-                prof_end(ctx, ctx->prof_compare);
-            }
-            hipError_t e2 = hipStreamSynchronize(ctx->stream);              // the tile list is reused by the next launch
-            ctx_free(ctx, d_mask);
-            if (d_dbg) {
-                std::vector<unsigned long long> h(dbg_sets * mtiles.size() * 3);
-                hipMemcpy(h.data(), d_dbg, h.size() * 8, hipMemcpyDeviceToHost);
-                for (size_t w = 0; w < dbg_sets; w++) {
-                    double bsum = 0, tsum = 0, tmax = 0;
-                    unsigned long long first = ~0ull, last = 0;
-                    for (size_t i = 0; i < mtiles.size(); i++) {
-                        const unsigned long long *q = &h[(w * mtiles.size() + i) * 3];
-                        bsum += (double)(q[1] - q[0]);
-                        tsum += (double)(q[2] - q[0]);
-                        tmax = std::max(tmax, (double)(q[2] - q[0]));
-                        first = std::min(first, q[0]);
-                        last = std::max(last, q[2]);
-                    }
-                    fprintf(stderr, "compare dbg: shift %d window %zu/%zu, %zu rows, %zu tiles, build %.0f clk avg, tile %.0f clk avg, "
-                            "longest %.0f, launch %.0f\n", shr, w, dbg_sets, list.size(), mtiles.size(), bsum / mtiles.size(),
-                            tsum / mtiles.size(), tmax, (double)(last - first));
-                }
-                hipFree(d_dbg);
-            }
-            if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare launch: ") + hipGetErrorString(e));
-            if (e2 != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare kernel: ") + hipGetErrorString(e2));
-        }
-        return MG_OK;
-    } else {
+    if (use_merged) return run_compare_merged(ctx, rows, cols, row_begin, row_end, triangle, a, R, CC, maxcols);
+    {
         const uint64_t nrt = (row_end - row_begin + R - 1) / R;
         for (uint64_t c0 = 0; c0 < maxcols; c0 += CC) {
             for (uint64_t t = 0; t < nrt; t++) {
