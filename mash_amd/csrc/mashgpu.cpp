@@ -263,6 +263,264 @@ struct ProbeHook {
     uint64_t mask, key_max;
 };
 
+// Work decomposition of one sketching call: chunks of k-mer start positions (one workgroup each)
+// and, for sketches cut into several chunks, the merges that finish them.
+struct SketchPlan {
+    std::vector<mg::SketchWork> work;
+    std::vector<mg::MergeWork> merges;      // [final merges ..., first level of the two-level merges ...]
+    size_t nfinal = 0;                      // merges[0, nfinal) write sketches, the rest write pool slots
+    uint64_t nslots = 0;                    // pool slots (one per chunk of a multi-chunk sketch)
+};
+
+static int plan_sketch_work(mg_ctx *ctx, const mg_params *p, const uint64_t *sketch_off, uint64_t nsketch, uint64_t nbases,
+                            int nt, SketchPlan *plan)
+{
+    const uint64_t k = (uint64_t)p->kmer_size;
+    const uint64_t tile = mg::sketch_tile(nt);
+    uint64_t total_pos = 0;
+    for (uint64_t i = 0; i < nsketch; i++) {
+        if (sketch_off[i + 1] < sketch_off[i] || sketch_off[i + 1] > nbases)
+            return fail(ctx, MG_ERR_INVALID, "mg_sketch: sketch_off not monotone / out of range");
+        const uint64_t len = sketch_off[i + 1] - sketch_off[i];
+        if (len >= k) total_pos += len - k + 1;
+    }
+    uint64_t target_items = 2048;
+    if (const char *e = getenv("MASHGPU_SKETCH_ITEMS")) target_items = strtoull(e, nullptr, 10);
+    if (target_items < 1) target_items = 1;
+    uint64_t chunk = (total_pos + target_items - 1) / target_items;
+    uint64_t min_chunk = 4 * tile;
+    if (const char *e = getenv("MASHGPU_SKETCH_MIN_CHUNK")) min_chunk = strtoull(e, nullptr, 10);
+    if (chunk < min_chunk) chunk = min_chunk;
+    chunk = (chunk + tile - 1) / tile * tile;
+
+    std::vector<mg::MergeWork> level1;
+    uint64_t nslots = 0;
+    for (uint64_t i = 0; i < nsketch; i++) {
+        const uint64_t b = sketch_off[i], e = sketch_off[i + 1];
+        const uint64_t len = e - b;
+        if (len < k) continue;
+        const uint64_t npos = len - k + 1;
+        const uint64_t nch = (npos + chunk - 1) / chunk;
+        if (nch > 0xFFFFFFFFull || nslots + nch > 0xFFFFFFFFull) return fail(ctx, MG_ERR_INVALID, "mg_sketch: too many chunks");
+        if (nch > 1) {
+            // many chunks: groups of G slots are merged in parallel into their first slot, then one
+            // workgroup merges the group results
+            const uint64_t G = 32;
+            if (nch > 2 * G) {
+                const uint64_t ngroups = (nch + G - 1) / G;
+                for (uint64_t g = 0; g < ngroups; g++)
+                    level1.push_back(mg::MergeWork{(uint32_t)i, (uint32_t)(nslots + g * G), (uint32_t)std::min(G, nch - g * G), 1, 1});
+                plan->merges.push_back(mg::MergeWork{(uint32_t)i, (uint32_t)nslots, (uint32_t)ngroups, (uint32_t)G, 0});
+            } else {
+                plan->merges.push_back(mg::MergeWork{(uint32_t)i, (uint32_t)nslots, (uint32_t)nch, 1, 0});
+            }
+        }
+        for (uint64_t c = 0; c < nch; c++) {
+            mg::SketchWork w;
+            w.begin = b + c * chunk;
+            w.end = b + std::min(npos, (c + 1) * chunk);
+            w.limit = e;
+            w.sketch = (uint32_t)i;
+            w.slot = nch > 1 ? (uint32_t)(nslots + c) : 0u;
+            w.nchunks = (uint32_t)nch;
+            w._pad = 0;
+            plan->work.push_back(w);
+        }
+        if (nch > 1) nslots += nch;
+    }
+    plan->nfinal = plan->merges.size();
+    plan->merges.insert(plan->merges.end(), level1.begin(), level1.end());
+    plan->nslots = nslots;
+    return MG_OK;
+}
+
+// What one sketching call holds on the device (released when the call returns) and the launch
+// arguments built over it.
+struct SketchRun {
+    mg_ctx *ctx;
+    const mg_params *p;
+    int mode = 0, nt = 0;
+    uint32_t cap = 0;
+    uint64_t s = 0, nsketch = 0;
+    SketchPlan plan;
+    mg::SketchArgs a;
+    DevBuf<mg::SketchWork> d_work;
+    DevBuf<mg::MergeWork> d_merge;
+    DevBuf<uint8_t> d_alpha;
+    DevBuf<uint64_t> d_pool, d_gT, d_seed;
+    DevBuf<uint32_t> d_pool_n;
+    std::vector<uint64_t> seeds;            // per sketch, ~0 = not seeded (empty: no seeding at all)
+    SketchRun(mg_ctx *c, const mg_params *pp)
+        : ctx(c), p(pp), d_work(c), d_merge(c), d_alpha(c), d_pool(c), d_gT(c), d_seed(c), d_pool_n(c) {}
+};
+
+// merges[0, nfinal) are final, [nfinal, nfinal + nlevel1) first level: the first level runs first
+static int launch_merges(SketchRun &r, const mg::MergeWork *d_list, size_t nfinal, size_t nlevel1, uint64_t *hashes_out_dev,
+                         uint32_t *nhash_out_dev)
+{
+    if (nfinal + nlevel1 == 0) return MG_OK;
+    mg::MergeArgs m;
+    m.pool = r.d_pool;
+    m.pool_n = r.d_pool_n;
+    m.hashes_out = hashes_out_dev;
+    m.nhash_out = nhash_out_dev;
+    m.sketch_size = (uint32_t)r.s;
+    m.cap = r.cap;
+    if (nlevel1) {
+        m.work = d_list + nfinal;
+        HIP_TRY(r.ctx, mg::launch_merge_chunks(r.nt, m, (uint32_t)nlevel1, r.ctx->stream));
+    }
+    m.work = d_list;
+    HIP_TRY(r.ctx, mg::launch_merge_chunks(r.nt, m, (uint32_t)nfinal, r.ctx->stream));
+    return MG_OK;
+}
+
+// Seeded thresholds (sketch.hip, SelState::T0): a sketch of L k-mers is started with the threshold
+// 3 s/L of the hash range instead of discovering it (the discovery sorts the candidate buffer about
+// ten times per chunk: 15 % of a 1 Mbp genome, most of the latency of a small call).  Sketches that
+// end with fewer than s hashes below their seed are run again without one (rerun_short_sketches), so
+// the result never depends on it.
+static int seed_thresholds(SketchRun &r, const uint64_t *sketch_off)
+{
+    r.a.seed_T = nullptr;
+    if (getenv("MASHGPU_SKETCH_NO_SEED")) return MG_OK;
+    const uint64_t k = (uint64_t)r.p->kmer_size;
+    const double kmer_space = std::pow((double)std::max<uint32_t>(r.p->alphabet_size, 2), (double)k) / (r.p->noncanonical ? 1.0 : 2.0);
+    std::vector<uint64_t> seeds(r.nsketch, ~0ull);
+    bool any = false;
+    for (uint64_t i = 0; i < r.nsketch; i++) {
+        const uint64_t len = sketch_off[i + 1] - sketch_off[i];
+        if (len < k) continue;
+        const double npos = (double)(len - k + 1);
+        const double frac = 3.0 * (double)r.s / npos;
+        if (frac >= 0.25) continue;                                 // short input: nothing to gain
+        if (kmer_space < 64.0 * npos) continue;                     // few possible k-mers: distinct << L, the guess would miss
+        seeds[i] = (uint64_t)(frac * (r.p->use64 ? 18446744073709551616.0 : 4294967296.0));
+        any = true;
+    }
+    if (!any) return MG_OK;
+    HIP_TRY(r.ctx, r.d_seed.alloc(r.nsketch));
+    HIP_TRY(r.ctx, hipMemcpyAsync(r.d_seed, seeds.data(), r.nsketch * 8, hipMemcpyHostToDevice, r.ctx->stream));
+    r.a.seed_T = r.d_seed;
+    r.seeds.swap(seeds);
+    return MG_OK;
+}
+
+// Second, unseeded run of the seeded sketches that came out short (also of those that simply have
+// fewer than s distinct k-mers: their second run gives the same list).
+static int rerun_short_sketches(SketchRun &r, uint64_t *hashes_out_dev, uint32_t *nhash_out_dev)
+{
+    if (r.seeds.empty()) return MG_OK;
+    mg_ctx *ctx = r.ctx;
+    std::vector<uint32_t> nh(r.nsketch);
+    HIP_TRY(ctx, hipMemcpyAsync(nh.data(), nhash_out_dev, r.nsketch * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<uint8_t> again(r.nsketch, 0);
+    bool any = false;
+    for (uint64_t i = 0; i < r.nsketch; i++)
+        if (r.seeds[i] != ~0ull && nh[i] < r.s) { again[i] = 1; any = true; }
+    if (!any) return MG_OK;
+    const SketchPlan &plan = r.plan;
+    std::vector<mg::SketchWork> work;
+    for (const mg::SketchWork &w : plan.work) if (again[w.sketch]) work.push_back(w);
+    std::vector<mg::MergeWork> fin, lvl1;
+    for (size_t q = 0; q < plan.merges.size(); q++)
+        if (again[plan.merges[q].sketch]) (q < plan.nfinal ? fin : lvl1).push_back(plan.merges[q]);
+    uint32_t prev = 0xFFFFFFFFu;
+    for (const mg::SketchWork &w : work) {             // a sketch's chunks are consecutive, slots ascending
+        if (w.nchunks > 1 && w.sketch != prev) {
+            HIP_TRY(ctx, hipMemsetAsync(r.d_pool_n + w.slot, 0, (size_t)w.nchunks * 4, ctx->stream));
+            HIP_TRY(ctx, hipMemsetAsync(r.d_gT + w.sketch, 0xFF, 8, ctx->stream));
+        }
+        prev = w.sketch;
+    }
+    DevBuf<mg::SketchWork> d_work(ctx);
+    DevBuf<mg::MergeWork> d_merge(ctx);
+    HIP_TRY(ctx, d_work.alloc(work.size()));
+    HIP_TRY(ctx, hipMemcpyAsync(d_work, work.data(), work.size() * sizeof(mg::SketchWork), hipMemcpyHostToDevice, ctx->stream));
+    mg::SketchArgs a = r.a;
+    a.work = d_work;
+    a.seed_T = nullptr;
+    a.probe_keys = nullptr;                            // every k-mer was already looked up by the first run
+    a.probe_obs = nullptr;
+    HIP_TRY(ctx, mg::launch_sketch_chunks(r.p->kmer_size, r.mode, r.nt, a, (uint32_t)work.size(), ctx->stream));
+    if (!fin.empty()) {
+        std::vector<mg::MergeWork> both = fin;
+        both.insert(both.end(), lvl1.begin(), lvl1.end());
+        HIP_TRY(ctx, d_merge.alloc(both.size()));
+        HIP_TRY(ctx, hipMemcpyAsync(d_merge, both.data(), both.size() * sizeof(mg::MergeWork), hipMemcpyHostToDevice, ctx->stream));
+        const int rc = launch_merges(r, d_merge, fin.size(), lvl1.size(), hashes_out_dev, nhash_out_dev);
+        if (rc != MG_OK) return rc;
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the lists above go out of scope
+    return MG_OK;
+}
+
+// Multiplicities: re-stream every chunk against the finished sketches (count_chunks_kernel).
+static int count_multiplicities(SketchRun &r, const uint8_t *bases_dev, const uint64_t *hashes_dev, const uint32_t *nhash_dev,
+                                uint32_t *counts_out_dev, uint32_t min_copies)
+{
+    mg_ctx *ctx = r.ctx;
+    const uint64_t s = r.s, nsketch = r.nsketch;
+    const std::vector<mg::SketchWork> &work = r.plan.work;
+    DevBuf<unsigned long long> d_firstpos(ctx), d_tstar(ctx), d_pos2(ctx);
+    DevBuf<uint32_t> d_fix(ctx);
+    DevBuf<mg::SketchWork> d_work2(ctx);
+    HIP_TRY(ctx, d_firstpos.alloc(nsketch * s));
+    HIP_TRY(ctx, hipMemsetAsync(d_firstpos, 0xFF, nsketch * s * 8, ctx->stream));
+    HIP_TRY(ctx, d_tstar.alloc(nsketch));
+    HIP_TRY(ctx, d_fix.alloc(nsketch));
+    mg::CountArgs ca;
+    ca.bases = bases_dev;
+    ca.work = r.d_work;
+    ca.alphabet = r.d_alpha;
+    ca.hashes = hashes_dev;
+    ca.nhash = nhash_dev;
+    ca.counts = counts_out_dev;
+    ca.firstpos = d_firstpos;
+    ca.tstar = d_tstar;
+    ca.sketch_size = (uint32_t)s;
+    ca.seed = r.p->seed;
+    ca.use64 = r.p->use64;
+    ca.fold_case = r.p->preserve_case ? 0 : 1;
+    ca.prevpos = nullptr;
+    ca.phase = 0;
+    HIP_TRY(ctx, mg::launch_count_chunks(r.p->kmer_size, r.mode, ca, (uint32_t)work.size(), ctx->stream));
+    // minCov m: a hash is promoted at its m-th occurrence, so t* is the latest m-th occurrence:
+    // walk from the first to the m-th position, one pass per step
+    unsigned long long *pos_m = d_firstpos;
+    if (min_copies > 1) {
+        HIP_TRY(ctx, d_pos2.alloc(nsketch * s));
+        unsigned long long *cur = d_pos2, *prv = d_firstpos;
+        for (uint32_t j = 2; j <= min_copies; j++) {
+            HIP_TRY(ctx, hipMemsetAsync(cur, 0xFF, nsketch * s * 8, ctx->stream));
+            ca.firstpos = cur;
+            ca.prevpos = prv;
+            ca.phase = 2;
+            HIP_TRY(ctx, mg::launch_count_chunks(r.p->kmer_size, r.mode, ca, (uint32_t)work.size(), ctx->stream));
+            std::swap(cur, prv);
+        }
+        pos_m = prv;
+        ca.prevpos = nullptr;
+    }
+    HIP_TRY(ctx, mg::launch_count_tstar(nhash_dev, counts_out_dev, pos_m, d_tstar, d_fix, (uint32_t)nsketch, (uint32_t)s, ctx->stream));
+    std::vector<uint32_t> fix(nsketch);
+    HIP_TRY(ctx, hipMemcpyAsync(fix.data(), d_fix, nsketch * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<mg::SketchWork> work2;
+    for (const mg::SketchWork &w : work) if (fix[w.sketch]) work2.push_back(w);
+    if (!work2.empty()) {
+        // the reference stops counting its largest kept hash once the heap is full with it on top
+        HIP_TRY(ctx, d_work2.alloc(work2.size()));
+        HIP_TRY(ctx, hipMemcpyAsync(d_work2, work2.data(), work2.size() * sizeof(mg::SketchWork), hipMemcpyHostToDevice, ctx->stream));
+        ca.work = d_work2;
+        ca.phase = 1;
+        HIP_TRY(ctx, mg::launch_count_chunks(r.p->kmer_size, r.mode, ca, (uint32_t)work2.size(), ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // work2 goes out of scope
+    }
+    return MG_OK;
+}
+
 static int sketch_dev_impl(mg_ctx *ctx, const mg_params *p, const uint8_t *bases_dev, uint64_t nbases,
                            const uint64_t *sketch_off, uint64_t nsketch, uint64_t *hashes_out_dev,
                            uint32_t *nhash_out_dev, uint32_t *counts_out_dev, const ProbeHook *probe);
@@ -420,135 +678,44 @@ static int sketch_dev_impl(mg_ctx *ctx, const mg_params *p, const uint8_t *bases
     }
     const int mode = dna ? (p->noncanonical ? 1 : 0) : 2;
     const uint64_t s = p->sketch_size;
-    const uint64_t k = (uint64_t)p->kmer_size;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
 
-    // ---- work list: chunks of k-mer start positions ----
-    const uint64_t tile = mg::sketch_tile(nt);
-    uint64_t total_pos = 0;
-    for (uint64_t i = 0; i < nsketch; i++) {
-        if (sketch_off[i + 1] < sketch_off[i] || sketch_off[i + 1] > nbases)
-            return fail(ctx, MG_ERR_INVALID, "mg_sketch: sketch_off not monotone / out of range");
-        const uint64_t len = sketch_off[i + 1] - sketch_off[i];
-        if (len >= k) total_pos += len - k + 1;
-    }
-    uint64_t target_items = 2048;
-    if (const char *e = getenv("MASHGPU_SKETCH_ITEMS")) target_items = strtoull(e, nullptr, 10);
-    if (target_items < 1) target_items = 1;
-    uint64_t chunk = (total_pos + target_items - 1) / target_items;
-    uint64_t min_chunk = 4 * tile;
-    if (const char *e = getenv("MASHGPU_SKETCH_MIN_CHUNK")) min_chunk = strtoull(e, nullptr, 10);
-    if (chunk < min_chunk) chunk = min_chunk;
-    chunk = (chunk + tile - 1) / tile * tile;
-
-    std::vector<mg::SketchWork> work;
-    std::vector<mg::MergeWork> merges, merges1;       // final merges; first level of two-level merges
-    uint64_t nslots = 0;
-    for (uint64_t i = 0; i < nsketch; i++) {
-        const uint64_t b = sketch_off[i], e = sketch_off[i + 1];
-        const uint64_t len = e - b;
-        if (len < k) continue;
-        const uint64_t npos = len - k + 1;
-        const uint64_t nch = (npos + chunk - 1) / chunk;
-        if (nch > 0xFFFFFFFFull || nslots + nch > 0xFFFFFFFFull) return fail(ctx, MG_ERR_INVALID, "mg_sketch: too many chunks");
-        if (nch > 1) {
-            // many chunks: groups of MERGE_GROUP slots are merged in parallel into their first
-            // slot, then one workgroup merges the group results
-            const uint64_t G = 32;
-            if (nch > 2 * G) {
-                const uint64_t ngroups = (nch + G - 1) / G;
-                for (uint64_t g = 0; g < ngroups; g++) {
-                    mg::MergeWork m{(uint32_t)i, (uint32_t)(nslots + g * G), (uint32_t)std::min(G, nch - g * G), 1, 1};
-                    merges1.push_back(m);
-                }
-                mg::MergeWork m{(uint32_t)i, (uint32_t)nslots, (uint32_t)ngroups, (uint32_t)G, 0};
-                merges.push_back(m);
-            } else {
-                mg::MergeWork m{(uint32_t)i, (uint32_t)nslots, (uint32_t)nch, 1, 0};
-                merges.push_back(m);
-            }
-        }
-        for (uint64_t c = 0; c < nch; c++) {
-            mg::SketchWork w;
-            w.begin = b + c * chunk;
-            w.end = b + std::min(npos, (c + 1) * chunk);
-            w.limit = e;
-            w.sketch = (uint32_t)i;
-            w.slot = nch > 1 ? (uint32_t)(nslots + c) : 0u;
-            w.nchunks = (uint32_t)nch;
-            w._pad = 0;
-            work.push_back(w);
-        }
-        if (nch > 1) nslots += nch;
-    }
+    SketchRun run(ctx, p);
+    run.mode = mode; run.nt = nt; run.cap = cap; run.s = s; run.nsketch = nsketch;
+    int rc = plan_sketch_work(ctx, p, sketch_off, nsketch, nbases, nt, &run.plan);
+    if (rc != MG_OK) return rc;
+    const SketchPlan &plan = run.plan;
 
     // outputs default to "empty sketch"
     HIP_TRY(ctx, hipMemsetAsync(hashes_out_dev, 0xFF, nsketch * s * 8, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(nhash_out_dev, 0, nsketch * 4, ctx->stream));
-    if (work.empty()) return MG_OK;
-
+    if (plan.work.empty()) return MG_OK;
     if (counts_out_dev) HIP_TRY(ctx, hipMemsetAsync(counts_out_dev, 0, nsketch * s * 4, ctx->stream));
-    mg::SketchWork *d_work = nullptr, *d_work2 = nullptr;
-    mg::MergeWork *d_merge = nullptr;
-    uint8_t *d_alpha = nullptr;
-    uint64_t *d_pool = nullptr, *d_gT = nullptr, *d_seed = nullptr;
-    mg::SketchWork *d_workR = nullptr;
-    mg::MergeWork *d_mergeR = nullptr;
-    uint32_t *d_pool_n = nullptr, *d_fix = nullptr;
-    unsigned long long *d_firstpos = nullptr, *d_tstar = nullptr, *d_pos2 = nullptr;
-    int rc = MG_OK;
-    auto cleanup = [&]() {
-        hipStreamSynchronize(ctx->stream);
-        if (d_work2) ctx_free(ctx, d_work2);
-        if (d_seed) ctx_free(ctx, d_seed);
-        if (d_workR) ctx_free(ctx, d_workR);
-        if (d_mergeR) ctx_free(ctx, d_mergeR);
-        if (d_fix) ctx_free(ctx, d_fix);
-        if (d_firstpos) ctx_free(ctx, d_firstpos);
-        if (d_pos2) ctx_free(ctx, d_pos2);
-        if (d_tstar) ctx_free(ctx, d_tstar);
-        if (d_work) ctx_free(ctx, d_work);
-        if (d_merge) ctx_free(ctx, d_merge);
-        if (d_alpha) ctx_free(ctx, d_alpha);
-        if (d_pool) ctx_free(ctx, d_pool);
-        if (d_gT) ctx_free(ctx, d_gT);
-        if (d_pool_n) ctx_free(ctx, d_pool_n);
-    };
-#define TRY_C(call)                                                                   \
-    do {                                                                              \
-        hipError_t e__ = (call);                                                      \
-        if (e__ != hipSuccess) {                                                      \
-            ctx->err = std::string(#call) + ": " + hipGetErrorString(e__);           \
-            rc = MG_ERR_HIP;                                                          \
-            cleanup();                                                                \
-            return rc;                                                                \
-        }                                                                             \
-    } while (0)
-    TRY_C(ctx_malloc(ctx, (void **)&d_work, work.size() * sizeof(mg::SketchWork)));
-    TRY_C(hipMemcpyAsync(d_work, work.data(), work.size() * sizeof(mg::SketchWork), hipMemcpyHostToDevice, ctx->stream));
-    TRY_C(ctx_malloc(ctx, (void **)&d_alpha, 256));
-    TRY_C(hipMemcpyAsync(d_alpha, p->alphabet, 256, hipMemcpyHostToDevice, ctx->stream));
+
+    HIP_TRY(ctx, run.d_work.alloc(plan.work.size()));
+    HIP_TRY(ctx, hipMemcpyAsync(run.d_work, plan.work.data(), plan.work.size() * sizeof(mg::SketchWork), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, run.d_alpha.alloc(256));
+    HIP_TRY(ctx, hipMemcpyAsync(run.d_alpha, p->alphabet, 256, hipMemcpyHostToDevice, ctx->stream));
     const uint32_t min_copies = p->min_copies > 1 ? p->min_copies : 1;
     const bool range_path = min_copies > 1 || !lds_selector;
-    if (nslots && !range_path) {
-        TRY_C(ctx_malloc(ctx, (void **)&d_pool, nslots * s * 8));
-        TRY_C(ctx_malloc(ctx, (void **)&d_pool_n, nslots * 4));
-        TRY_C(hipMemsetAsync(d_pool_n, 0, nslots * 4, ctx->stream));
-        TRY_C(ctx_malloc(ctx, (void **)&d_gT, nsketch * 8));
-        TRY_C(hipMemsetAsync(d_gT, 0xFF, nsketch * 8, ctx->stream));
-        merges.insert(merges.end(), merges1.begin(), merges1.end());      // [final ..., first level ...]
-        TRY_C(ctx_malloc(ctx, (void **)&d_merge, merges.size() * sizeof(mg::MergeWork)));
-        TRY_C(hipMemcpyAsync(d_merge, merges.data(), merges.size() * sizeof(mg::MergeWork), hipMemcpyHostToDevice, ctx->stream));
+    if (plan.nslots && !range_path) {
+        HIP_TRY(ctx, run.d_pool.alloc(plan.nslots * s));
+        HIP_TRY(ctx, run.d_pool_n.alloc(plan.nslots));
+        HIP_TRY(ctx, hipMemsetAsync(run.d_pool_n, 0, plan.nslots * 4, ctx->stream));
+        HIP_TRY(ctx, run.d_gT.alloc(nsketch));
+        HIP_TRY(ctx, hipMemsetAsync(run.d_gT, 0xFF, nsketch * 8, ctx->stream));
+        HIP_TRY(ctx, run.d_merge.alloc(plan.merges.size()));
+        HIP_TRY(ctx, hipMemcpyAsync(run.d_merge, plan.merges.data(), plan.merges.size() * sizeof(mg::MergeWork), hipMemcpyHostToDevice, ctx->stream));
     }
-    mg::SketchArgs a;
+    mg::SketchArgs &a = run.a;
     a.bases = bases_dev;
-    a.work = d_work;
-    a.alphabet = d_alpha;
+    a.work = run.d_work;
+    a.alphabet = run.d_alpha;
     a.hashes_out = hashes_out_dev;
     a.nhash_out = nhash_out_dev;
-    a.pool = d_pool;
-    a.pool_n = d_pool_n;
-    a.g_T = d_gT;
+    a.pool = run.d_pool;
+    a.pool_n = run.d_pool_n;
+    a.g_T = run.d_gT;
     a.sketch_size = (uint32_t)s;
     a.cap = cap;
     a.seed = p->seed;
@@ -558,174 +725,29 @@ static int sketch_dev_impl(mg_ctx *ctx, const mg_params *p, const uint8_t *bases
     a.probe_obs = probe ? probe->obs : nullptr;
     a.probe_mask = probe ? probe->mask : 0;
     a.probe_max = probe ? probe->key_max : 0;
-    // Seeded thresholds (sketch.hip, SelState::T0): a sketch of L k-mers is started with the
-    // threshold 3 s/L of the hash range instead of discovering it (the discovery sorts the candidate
-    // buffer about ten times per chunk: 6-9 % of a 1 Mbp genome, most of the latency of a small
-    // call).  Sketches that end with fewer than s hashes below their seed are run again without
-    // one, so the result never depends on it.
     a.seed_T = nullptr;
-    std::vector<uint64_t> seeds;
-    bool any_seed = false;
-    if (!range_path && !getenv("MASHGPU_SKETCH_NO_SEED")) {
-        seeds.assign(nsketch, ~0ull);
-        const double kmer_space = std::pow((double)std::max<uint32_t>(p->alphabet_size, 2), (double)k) / (p->noncanonical ? 1.0 : 2.0);
-        for (uint64_t i = 0; i < nsketch; i++) {
-            const uint64_t len = sketch_off[i + 1] - sketch_off[i];
-            if (len < k) continue;
-            const double npos = (double)(len - k + 1);
-            const double frac = 3.0 * (double)s / npos;
-            if (frac >= 0.25) continue;                                 // short input: nothing to gain
-            if (kmer_space < 64.0 * npos) continue;                     // few possible k-mers: distinct << L, the guess would miss
-            seeds[i] = (uint64_t)(frac * (p->use64 ? 18446744073709551616.0 : 4294967296.0));
-            any_seed = true;
-        }
-        if (any_seed) {
-            TRY_C(ctx_malloc(ctx, (void **)&d_seed, nsketch * 8));
-            TRY_C(hipMemcpyAsync(d_seed, seeds.data(), nsketch * 8, hipMemcpyHostToDevice, ctx->stream));
-            a.seed_T = d_seed;
-        }
-    }
     if (range_path) {
-        // -m: bottom-s of the hashes seen at least m times, by exact range counting (sketch.hip)
-        if (probe) { cleanup(); return fail(ctx, MG_ERR_UNSUPPORTED, "mg_screen: min_copies does not apply"); }
-        rc = sketch_min_copies(ctx, p, mode, bases_dev, work, d_work, d_alpha, nsketch, hashes_out_dev, nhash_out_dev);
-        if (rc != MG_OK) { cleanup(); return rc; }
+        // -m / s beyond the LDS selector: bottom-s of the hashes seen at least m times, by exact range counting
+        if (probe) return fail(ctx, MG_ERR_UNSUPPORTED, "mg_screen: min_copies does not apply");
+        rc = sketch_min_copies(ctx, p, mode, bases_dev, plan.work, run.d_work, run.d_alpha, nsketch, hashes_out_dev, nhash_out_dev);
+        if (rc != MG_OK) return rc;
     } else {
-    prof_begin(ctx, ctx->prof_sketch);
-    TRY_C(mg::launch_sketch_chunks(p->kmer_size, mode, nt, a, (uint32_t)work.size(), ctx->stream));
-    prof_end(ctx, ctx->prof_sketch);
-    }
-    if (!range_path && !merges.empty()) {
-        mg::MergeArgs m;
-        m.work = d_merge;
-        m.pool = d_pool;
-        m.pool_n = d_pool_n;
-        m.hashes_out = hashes_out_dev;
-        m.nhash_out = nhash_out_dev;
-        m.sketch_size = (uint32_t)s;
-        m.cap = cap;
-        const uint32_t nfinal = (uint32_t)(merges.size() - merges1.size());
-        if (!merges1.empty()) {
-            m.work = d_merge + nfinal;
-            TRY_C(mg::launch_merge_chunks(nt, m, (uint32_t)merges1.size(), ctx->stream));
-            m.work = d_merge;
-        }
-        TRY_C(mg::launch_merge_chunks(nt, m, nfinal, ctx->stream));
-    }
-    if (any_seed) {
-        // which seeded sketches came out short?  (also those that simply have fewer than s distinct
-        // k-mers: their second run gives the same list)
-        std::vector<uint32_t> nh(nsketch);
-        TRY_C(hipMemcpyAsync(nh.data(), nhash_out_dev, nsketch * 4, hipMemcpyDeviceToHost, ctx->stream));
-        TRY_C(hipStreamSynchronize(ctx->stream));
-        std::vector<uint8_t> again(nsketch, 0);
-        bool any = false;
-        for (uint64_t i = 0; i < nsketch; i++)
-            if (seeds[i] != ~0ull && nh[i] < s) { again[i] = 1; any = true; }
-        if (any) {
-            std::vector<mg::SketchWork> workR;
-            for (const mg::SketchWork &w : work) if (again[w.sketch]) workR.push_back(w);
-            std::vector<mg::MergeWork> fin, lvl1;
-            const size_t nfinal0 = merges.size() - merges1.size();
-            for (size_t q = 0; q < merges.size(); q++)
-                if (again[merges[q].sketch]) (q < nfinal0 ? fin : lvl1).push_back(merges[q]);
-            uint32_t prev = 0xFFFFFFFFu;
-            for (const mg::SketchWork &w : workR) {        // a sketch's chunks are consecutive, slots ascending
-                if (w.nchunks > 1 && w.sketch != prev) {
-                    TRY_C(hipMemsetAsync(d_pool_n + w.slot, 0, (size_t)w.nchunks * 4, ctx->stream));
-                    TRY_C(hipMemsetAsync(d_gT + w.sketch, 0xFF, 8, ctx->stream));
-                }
-                prev = w.sketch;
-            }
-            TRY_C(ctx_malloc(ctx, (void **)&d_workR, workR.size() * sizeof(mg::SketchWork)));
-            TRY_C(hipMemcpyAsync(d_workR, workR.data(), workR.size() * sizeof(mg::SketchWork), hipMemcpyHostToDevice, ctx->stream));
-            mg::SketchArgs r = a;
-            r.work = d_workR;
-            r.seed_T = nullptr;
-            r.probe_keys = nullptr;                        // every k-mer was already looked up by the first run
-            r.probe_obs = nullptr;
-            TRY_C(mg::launch_sketch_chunks(p->kmer_size, mode, nt, r, (uint32_t)workR.size(), ctx->stream));
-            if (!fin.empty()) {
-                std::vector<mg::MergeWork> both = fin;
-                both.insert(both.end(), lvl1.begin(), lvl1.end());
-                TRY_C(ctx_malloc(ctx, (void **)&d_mergeR, both.size() * sizeof(mg::MergeWork)));
-                TRY_C(hipMemcpyAsync(d_mergeR, both.data(), both.size() * sizeof(mg::MergeWork), hipMemcpyHostToDevice, ctx->stream));
-                mg::MergeArgs m;
-                m.pool = d_pool;
-                m.pool_n = d_pool_n;
-                m.hashes_out = hashes_out_dev;
-                m.nhash_out = nhash_out_dev;
-                m.sketch_size = (uint32_t)s;
-                m.cap = cap;
-                if (!lvl1.empty()) {
-                    m.work = d_mergeR + fin.size();
-                    TRY_C(mg::launch_merge_chunks(nt, m, (uint32_t)lvl1.size(), ctx->stream));
-                }
-                m.work = d_mergeR;
-                TRY_C(mg::launch_merge_chunks(nt, m, (uint32_t)fin.size(), ctx->stream));
-            }
-            TRY_C(hipStreamSynchronize(ctx->stream));      // workR / both go out of scope
-        }
+        rc = seed_thresholds(run, sketch_off);
+        if (rc != MG_OK) return rc;
+        prof_begin(ctx, ctx->prof_sketch);
+        HIP_TRY(ctx, mg::launch_sketch_chunks(p->kmer_size, mode, nt, a, (uint32_t)plan.work.size(), ctx->stream));
+        prof_end(ctx, ctx->prof_sketch);
+        rc = launch_merges(run, run.d_merge, plan.nfinal, plan.merges.size() - plan.nfinal, hashes_out_dev, nhash_out_dev);
+        if (rc == MG_OK) rc = rerun_short_sketches(run, hashes_out_dev, nhash_out_dev);
+        if (rc != MG_OK) return rc;
     }
     if (counts_out_dev) {
-        // multiplicities: re-stream every chunk against the finished sketches (count_chunks_kernel)
-        TRY_C(ctx_malloc(ctx, (void **)&d_firstpos, nsketch * s * 8));
-        TRY_C(hipMemsetAsync(d_firstpos, 0xFF, nsketch * s * 8, ctx->stream));
-        TRY_C(ctx_malloc(ctx, (void **)&d_tstar, nsketch * 8));
-        TRY_C(ctx_malloc(ctx, (void **)&d_fix, nsketch * 4));
-        mg::CountArgs ca;
-        ca.bases = bases_dev;
-        ca.work = d_work;
-        ca.alphabet = d_alpha;
-        ca.hashes = hashes_out_dev;
-        ca.nhash = nhash_out_dev;
-        ca.counts = counts_out_dev;
-        ca.firstpos = d_firstpos;
-        ca.tstar = d_tstar;
-        ca.sketch_size = (uint32_t)s;
-        ca.seed = p->seed;
-        ca.use64 = p->use64;
-        ca.fold_case = p->preserve_case ? 0 : 1;
-        ca.prevpos = nullptr;
-        ca.phase = 0;
-        TRY_C(mg::launch_count_chunks(p->kmer_size, mode, ca, (uint32_t)work.size(), ctx->stream));
-        // minCov m: a hash is promoted at its m-th occurrence, so t* is the latest m-th occurrence:
-        // walk from the first to the m-th position, one pass per step
-        unsigned long long *pos_m = d_firstpos;
-        if (min_copies > 1) {
-            TRY_C(ctx_malloc(ctx, (void **)&d_pos2, nsketch * s * 8));
-            unsigned long long *cur = d_pos2, *prv = d_firstpos;
-            for (uint32_t j = 2; j <= min_copies; j++) {
-                TRY_C(hipMemsetAsync(cur, 0xFF, nsketch * s * 8, ctx->stream));
-                ca.firstpos = cur;
-                ca.prevpos = prv;
-                ca.phase = 2;
-                TRY_C(mg::launch_count_chunks(p->kmer_size, mode, ca, (uint32_t)work.size(), ctx->stream));
-                std::swap(cur, prv);
-            }
-            pos_m = prv;
-            ca.prevpos = nullptr;
-        }
-        TRY_C(mg::launch_count_tstar(nhash_out_dev, counts_out_dev, pos_m, d_tstar, d_fix, (uint32_t)nsketch,
-                                     (uint32_t)s, ctx->stream));
-        std::vector<uint32_t> fix(nsketch);
-        TRY_C(hipMemcpyAsync(fix.data(), d_fix, nsketch * 4, hipMemcpyDeviceToHost, ctx->stream));
-        TRY_C(hipStreamSynchronize(ctx->stream));
-        std::vector<mg::SketchWork> work2;
-        for (const mg::SketchWork &w : work) if (fix[w.sketch]) work2.push_back(w);
-        if (!work2.empty()) {
-            // the reference stops counting its largest kept hash once the heap is full with it on top
-            TRY_C(ctx_malloc(ctx, (void **)&d_work2, work2.size() * sizeof(mg::SketchWork)));
-            TRY_C(hipMemcpyAsync(d_work2, work2.data(), work2.size() * sizeof(mg::SketchWork), hipMemcpyHostToDevice, ctx->stream));
-            ca.work = d_work2;
-            ca.phase = 1;
-            TRY_C(mg::launch_count_chunks(p->kmer_size, mode, ca, (uint32_t)work2.size(), ctx->stream));
-        }
+        rc = count_multiplicities(run, bases_dev, hashes_out_dev, nhash_out_dev, counts_out_dev, min_copies);
+        if (rc != MG_OK) return rc;
     }
-#undef TRY_C
-    // work lists are freed after the stream drains (keeps the call self-contained)
-    cleanup();
-    return rc;
+    // the call is synchronous: results are complete, and the work lists may go
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MG_OK;
 }
 
 int mg_sketch_host(mg_ctx *ctx, const mg_params *p, const uint8_t *bases, uint64_t nbases,
