@@ -388,11 +388,13 @@ static int seed_thresholds(SketchRun &r, const uint64_t *sketch_off)
     const double kmer_space = std::pow((double)std::max<uint32_t>(r.p->alphabet_size, 2), (double)k) / (r.p->noncanonical ? 1.0 : 2.0);
     std::vector<uint64_t> seeds(r.nsketch, ~0ull);
     bool any = false;
+    double factor = 3.0;                                            // expected hashes below the seed, in units of s
+    if (const char *e = getenv("MASHGPU_SKETCH_SEED_FACTOR")) factor = std::max(1.0, atof(e));
     for (uint64_t i = 0; i < r.nsketch; i++) {
         const uint64_t len = sketch_off[i + 1] - sketch_off[i];
         if (len < k) continue;
         const double npos = (double)(len - k + 1);
-        const double frac = 3.0 * (double)r.s / npos;
+        const double frac = factor * (double)r.s / npos;
         if (frac >= 0.25) continue;                                 // short input: nothing to gain
         if (kmer_space < 64.0 * npos) continue;                     // few possible k-mers: distinct << L, the guess would miss
         seeds[i] = (uint64_t)(frac * (r.p->use64 ? 18446744073709551616.0 : 4294967296.0));
