@@ -1141,8 +1141,10 @@ struct WindowPlan {
     uint32_t delta = 0, nwin = 0;
 };
 
+// `must`: the sketches are too large for plain tiles (s > 16 384), so a class that would be served
+// by one window (few hashes, or none) still gets a plan -- of that single window.
 static int plan_windows(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, const std::vector<uint32_t> &list, int shr,
-                        uint64_t xmax, uint32_t s, WindowPlan *out)
+                        uint64_t xmax, uint32_t s, bool must, WindowPlan *out)
 {
     const uint32_t Rw = mg::compare_window_rows();
     double target = 0.8 * mg::compare_window_entries() / Rw;                // entries of the densest row per window
@@ -1152,13 +1154,17 @@ static int plan_windows(mg_ctx *ctx, const mg_table *rows, const mg_table *cols,
         const uint64_t ni = std::min<uint64_t>(rows->nh[i], s);
         if (ni) dens = std::max(dens, (double)ni / ((double)(rows->last[i] >> shr) + 1.0));
     }
-    if (dens <= 0) return MG_OK;
+    if (dens <= 0 && !must) return MG_OK;
     for (int attempt = 0; attempt < 2; attempt++, target *= 0.7) {
-        const double dd = std::floor(target / dens);
-        if (dd < 1.0 || dd >= (double)xmax + 1.0) return MG_OK;              // one window: nothing to gain
+        double dd = dens > 0 ? std::floor(target / dens) : (double)xmax + 1.0;
+        if (dd < 1.0) return MG_OK;
+        if (dd >= (double)xmax + 1.0) {                                      // one window: nothing to gain
+            if (!must) return MG_OK;
+            dd = (double)xmax + 1.0;
+        }
         const uint32_t delta = (uint32_t)dd;
         const uint64_t nw = (xmax + delta) / delta;                          // ceil((xmax + 1) / delta)
-        if (nw < 2 || nw > 255) return MG_OK;
+        if ((nw < 2 && !must) || nw > 255) return MG_OK;
         const uint32_t nwin = (uint32_t)nw;
         const mg_table::Windows *cand = nullptr;
         int rc = table_windows(ctx, rows, shr, delta, nwin, s, &cand);
@@ -1191,8 +1197,12 @@ static int plan_windows(mg_ctx *ctx, const mg_table *rows, const mg_table *cols,
 
 // The merged-rows engine (compare_merged.hip) over rows [row_begin, row_end): density classes,
 // per-class prefix images, optional value windows, tile lists, launches.
+// `windows_only`: s is beyond plain tiles; every class must get a window plan, else nothing is
+// launched and kNoWindowPlan is returned (the caller falls back to the generic kernel).
+static const int kNoWindowPlan = -1000;
+
 static int run_compare_merged(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, uint64_t row_begin, uint64_t row_end,
-                              bool triangle, mg::CompareArgs &a, uint32_t R, uint64_t CC, uint64_t maxcols)
+                              bool triangle, mg::CompareArgs &a, uint32_t R, uint64_t CC, uint64_t maxcols, bool windows_only)
 {
     // Rows are grouped by hash DENSITY before they are cut into tiles of R: one linear
     // value -> bucket map per tile spreads the entries evenly only if its rows are equally
@@ -1214,6 +1224,7 @@ static int run_compare_merged(mg_ctx *ctx, const mg_table *rows, const mg_table 
     // and drops out once its union reaches s (see compare_merged.hip, WIN).
     bool want_win = R <= 8;                                 // s >= ~1800: measured gain from 1.2x (s = 2000) to 3.8x (s = 10 000)
     if (const char *e = getenv("MASHGPU_COMPARE_WINDOWS")) want_win = atoi(e) != 0;
+    if (windows_only) want_win = true;
     const uint32_t Rw = mg::compare_window_rows();
     const uint32_t R_plain = R;
     // A launch of few row tiles (a handful of queries against a large database, or a small
@@ -1237,13 +1248,32 @@ static int run_compare_merged(mg_ctx *ctx, const mg_table *rows, const mg_table 
     a.dbg = nullptr;
     a.row_pfx_stride = mg::compare_pfx_stride(rows->s);
     a.col_pfx_stride = mg::compare_pfx_stride(cols->s);
-    for (const auto &list : by_class) {
-        if (list.empty()) continue;
+    // prefix shift of a class: its largest hash must stay below the three reserved prefixes
+    auto class_shift = [&](const std::vector<uint32_t> &list, uint64_t *mx_out) -> int {
         uint64_t mx = 1;
         for (uint32_t i : list) mx = std::max(mx, rows->last[i]);
         const int bl = 64 - __builtin_clzll(mx);
         int shr = bl > 32 ? bl - 32 : 0;
         if ((mx >> shr) >= 0xFFFFFFFDull) shr++;      // 0xFFFFFFFD..F: saturated values, sentinel, padding
+        *mx_out = mx;
+        return shr;
+    };
+    if (windows_only) {
+        // nothing may be launched unless every class can be windowed
+        for (const auto &list : by_class) {
+            if (list.empty()) continue;
+            uint64_t mx;
+            const int shr = class_shift(list, &mx);
+            WindowPlan plan;
+            rc = plan_windows(ctx, rows, cols, list, shr, mx >> shr, a.s, true, &plan);
+            if (rc != MG_OK) return rc;
+            if (!plan.rows) return kNoWindowPlan;
+        }
+    }
+    for (const auto &list : by_class) {
+        if (list.empty()) continue;
+        uint64_t mx;
+        const int shr = class_shift(list, &mx);
         rc = table_prefix(ctx, rows, shr, &a.row_pfx);
         if (rc == MG_OK) rc = table_prefix(ctx, cols, shr, &a.col_pfx);
         if (rc != MG_OK) return rc;
@@ -1252,8 +1282,9 @@ static int run_compare_merged(mg_ctx *ctx, const mg_table *rows, const mg_table 
         WindowPlan plan;
         const uint64_t xmax = mx >> shr;
         if (want_win) {
-            rc = plan_windows(ctx, rows, cols, list, shr, xmax, a.s, &plan);
+            rc = plan_windows(ctx, rows, cols, list, shr, xmax, a.s, windows_only, &plan);
             if (rc != MG_OK) return rc;
+            if (windows_only && !plan.rows) return fail(ctx, MG_ERR_HIP, "compare: window plan changed between passes");
         }
         const mg_table::Windows *wr = plan.rows, *wc = plan.cols;
         const uint32_t delta = plan.delta, nwin = plan.nwin;
@@ -1382,6 +1413,19 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
     const bool want_generic = force && strcmp(force, "generic") == 0;
     const bool want_tiled = force && strcmp(force, "tiled") == 0;
     const bool use_merged = !want_tiled && !want_generic && mg::compare_merged_supported(a.s);
+    if (!use_merged && !want_tiled && !want_generic && a.s > 16384 && a.s <= (1u << 22) &&
+        !(getenv("MASHGPU_COMPARE_WINDOWS") && atoi(getenv("MASHGPU_COMPARE_WINDOWS")) == 0)) {
+        // Beyond the plain tile kernel's reach (s > 16 384) the value-window mode still applies: its
+        // tiles hold one window's hashes whatever s is.  If some class cannot be windowed, nothing
+        // has been launched and the generic kernel below takes the call.
+        a.row_pfx = a.col_pfx = nullptr;
+        a.row_pfx_stride = a.col_pfx_stride = 0;
+        a.pfx_shr = 0;
+        a.rows_per_tile = 1;
+        const uint64_t maxc = triangle ? (row_end - 1) : cols->n;
+        const int rcw = run_compare_merged(ctx, rows, cols, row_begin, row_end, triangle, a, 1, cols->n >= 40000 ? 16384 : 8192, maxc, true);
+        if (rcw != kNoWindowPlan) return rcw;
+    }
     if ((!use_merged && !mg::compare_tiled_supported(a.s)) || want_generic) {
         prof_begin(ctx, ctx->prof_compare);
         HIP_TRY(ctx, mg::launch_compare_generic(a, ctx->stream));
@@ -1401,7 +1445,7 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
     // tiles: column chunk outer, row tile inner (concurrent workgroups share a column chunk in L2)
     const uint64_t maxcols = triangle ? (row_end - 1) : cols->n;       // columns [0, maxcols)
     std::vector<mg::CompareTile> tiles;
-    if (use_merged) return run_compare_merged(ctx, rows, cols, row_begin, row_end, triangle, a, R, CC, maxcols);
+    if (use_merged) return run_compare_merged(ctx, rows, cols, row_begin, row_end, triangle, a, R, CC, maxcols, false);
     {
         const uint64_t nrt = (row_end - row_begin + R - 1) / R;
         for (uint64_t c0 = 0; c0 < maxcols; c0 += CC) {

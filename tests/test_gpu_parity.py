@@ -380,6 +380,43 @@ def test_compare_large_sketch(eng, oracle, s, kernel, monkeypatch):
     t.free(); tq.free()
 
 
+@pytest.mark.parametrize("s", [20000, 50000])
+def test_compare_sketches_beyond_plain_tiles(eng, oracle, s, monkeypatch):
+    """s > 16 384 does not fit the plain tile kernel at all; the value-window mode still applies
+    (its tiles hold one window's hashes whatever s is), including classes that need a single
+    window (a tiny sketch, an empty one).  Checked against the oracle and the generic kernel."""
+    n = 14
+    table, nhash, lengths = synth.clustered_sketches(n, s, clusters=2, seed=s, pool=int(1.5 * s), private=int(0.4 * s))
+    nhash[3] = s // 3
+    nhash[5] = 50                                   # a class of its own: one window
+    table[5, 50:] = np.uint64(abi.HASH_PAD)
+    nhash[9] = 0                                    # empty sketch
+    table[9, :] = np.uint64(abi.HASH_PAD)
+    table[11] = table[2]; nhash[11] = nhash[2]      # identical pair
+    t = eng.table_upload(table, nhash, lengths)
+    eng.prof_enable(True)
+    eng.prof_reset()
+    got = eng.compare_tri_host(t)
+    launches = eng.prof_avg_ms("compare")[1]
+    eng.prof_enable(False)
+    assert launches >= s // 1000, launches          # one launch per window: the window path ran
+    numer, denom = _oracle_tri(oracle, table, nhash, lengths, 0, n, k=31, kspace=4.0 ** 31)
+    assert np.array_equal(got["numer"], numer) and np.array_equal(got["denom"], denom)
+    monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", "generic")
+    gen = eng.compare_tri_host(t)
+    assert np.array_equal(gen["numer"], numer) and np.array_equal(gen["denom"], denom)
+    monkeypatch.delenv("MASHGPU_COMPARE_KERNEL")
+    tq = eng.table_upload(table[4:7], nhash[4:7], lengths[4:7])
+    rect = eng.compare_rect_host(t, tq)
+    for q in range(3):
+        for r in range(n):
+            i, j = max(q + 4, r), min(q + 4, r)
+            if i != j:
+                idx = i * (i - 1) // 2 + j
+                assert (rect["numer"][q, r], rect["denom"][q, r]) == (numer[idx], denom[idx]), (q, r)
+    t.free(); tq.free()
+
+
 def test_compare_extremes_and_random(eng, oracle):
     """All-random (common ~ 0) and all-identical (common = s) bracket the merge."""
     table, nhash, lengths = synth.random_sketches(200, 1000, seed=9)
