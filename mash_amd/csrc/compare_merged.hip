@@ -865,8 +865,14 @@ hipError_t launch_compare_merged(const CompareArgs &a_in, uint32_t ntiles, hipSt
         a.rows_per_tile = MR_WIN_ROWS;
         a.nbuckets = MR_WIN_BUCKETS;
         a.win_ecap = MR_WIN_ENTRIES;
-        return launch_merged_k<MR_KU_DEFAULT, true>(a, ntiles, merged_lds_bytes_e(MR_WIN_ROWS, MR_WIN_ENTRIES, MR_WIN_BUCKETS),
-                                                    stream);
+        const size_t wsmem = merged_lds_bytes_e(MR_WIN_ROWS, MR_WIN_ENTRIES, MR_WIN_BUCKETS);
+        // groups of 256 elements here: a window's share of a column (~700-800 elements) has no early
+        // exit inside it, so fewer, larger groups win (s = 10 000: 1.03 / 1.08 / 1.11e9 pairs/s for 2 / 3 / 4)
+        switch (a.unroll ? (int)a.unroll : 4) {
+            case 2: return launch_merged_k<2, true>(a, ntiles, wsmem, stream);
+            case 3: return launch_merged_k<3, true>(a, ntiles, wsmem, stream);
+            default: return launch_merged_k<4, true>(a, ntiles, wsmem, stream);
+        }
     }
     a.nbuckets = merged_buckets(a.rows_per_tile, a.s);
     const size_t smem = merged_lds_bytes_nb(a.rows_per_tile, a.s, a.nbuckets);

@@ -47,7 +47,12 @@ def main():
                 os.environ.pop("MASHGPU_COMPARE_VARIANT", None)
                 os.environ["MASHGPU_COMPARE_WINDOWS"] = "0" if parts[0] == "nowin" else "1"
                 if parts[0] not in ("win", "nowin"):
-                    os.environ["MASHGPU_COMPARE_WIN_TARGET"] = parts[0][3:]
+                    tgt = parts[0][3:]
+                    if "k" in tgt:                                  # winNNNkK: window target NNN, group size K
+                        tgt, ku = tgt.split("k")
+                        os.environ["MASHGPU_COMPARE_VARIANT"] = ku
+                    if tgt:
+                        os.environ["MASHGPU_COMPARE_WIN_TARGET"] = tgt
             elif parts[0] in ("merged", "tiled", "generic", "pairs"):
                 os.environ["MASHGPU_COMPARE_KERNEL"] = parts[0]
                 os.environ.pop("MASHGPU_COMPARE_VARIANT", None)
