@@ -51,6 +51,7 @@ struct CompareArgs {
     uint32_t win_ecap;            // table entries a windowed tile may hold
     uint8_t *win_mask;            // [tiles][16 waves][win_kmax]: live columns per batch, carried between launches
     uint32_t win_kmax;            // batches of 8 columns per wave and tile
+    uint32_t xcd_remap;           // 1: XCD x takes the x-th contiguous eighth of the tile list
 };
 
 // LDS-tiled kernel usable when s <= 1024; rows_per_tile chosen by compare_rows_per_tile.

@@ -143,7 +143,20 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
     __shared__ uint32_t s_rowlo[16], s_rowlen[16];      // WIN: first index of the row's window; full row length
 
     // (fields are read individually: indexing a by-value copy of rows[] would put the tile in scratch)
-    const MergedTile *tile_p = a.mtiles + blockIdx.x;
+    // Workgroups are dealt to the 8 XCDs round-robin by index, and each XCD has its own L2.  With
+    // xcd_remap, XCD x works through the x-th contiguous eighth of the tile list (which is ordered
+    // column chunk major), so a column chunk is streamed into one L2 instead of all eight.
+    // Measured on C3: 18.4 -> 15.5e9 pairs/s -- 32 workgroups walking the same columns at the same
+    // time queue up on the same L2 channels, and HBM is not this kernel's limit -- so it is off
+    // (MASHGPU_COMPARE_XCD=1 turns it on for experiments).
+    uint32_t tile_index = blockIdx.x;
+    if (a.xcd_remap) {
+        const uint32_t nt = gridDim.x, x = blockIdx.x & 7u, q = blockIdx.x >> 3;
+        uint32_t start = 0;
+        for (uint32_t y = 0; y < x; y++) start += (nt - 1u - y) / 8u + 1u;      // blocks with index % 8 == y (nt > y)
+        tile_index = start + q;
+    }
+    const MergedTile *tile_p = a.mtiles + tile_index;
     struct { uint32_t col0, col1; } tile = {tile_p->col0, tile_p->col1};
     const int tid = threadIdx.x;
     if (a.dbg && tid == 0) a.dbg[3 * (uint64_t)blockIdx.x] = __builtin_readcyclecounter();

@@ -1401,6 +1401,8 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
     a.win = a.nwin = a.win_lo = a.win_hi = a.win_ecap = 0;
     a.win_mask = nullptr;
     a.win_kmax = 0;
+    a.xcd_remap = 0;
+    if (const char *e = getenv("MASHGPU_COMPARE_XCD")) a.xcd_remap = atoi(e) != 0;
     if (const char *e = getenv("MASHGPU_COMPARE_VARIANT")) a.unroll = (uint32_t)atoi(e);
     const char *force = getenv("MASHGPU_COMPARE_KERNEL");
     if (force && strcmp(force, "pairs") == 0 && mg::compare_pairs_supported(a.s)) {
