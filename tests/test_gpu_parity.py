@@ -644,6 +644,36 @@ def test_compare_few_queries_against_many_references(eng, oracle, n, s, nq):
     ref.free(); qry.free()
 
 
+@pytest.mark.parametrize("s_ref,s_qry", [(1000, 600), (400, 1000), (3000, 2000), (2000, 5000)])
+def test_compare_rect_with_different_sketch_sizes(eng, oracle, s_ref, s_qry):
+    """`mash dist` compares on the smaller of the two sketch sizes (CommandDistance.cpp:313-315);
+    the tables keep their own strides and prefix images, the kernels clamp both sides."""
+    n_ref, n_qry = 40, 9
+    big = max(s_ref, s_qry)
+    table, nhash, lengths = synth.clustered_sketches(n_ref + n_qry, big, clusters=3, seed=s_ref + s_qry,
+                                                     pool=int(1.5 * big), private=int(0.4 * big))
+    rt = np.full((n_ref, s_ref), np.uint64(abi.HASH_PAD), dtype=np.uint64)
+    qt = np.full((n_qry, s_qry), np.uint64(abi.HASH_PAD), dtype=np.uint64)
+    rn = np.minimum(nhash[:n_ref], s_ref).astype(np.uint32)
+    qn = np.minimum(nhash[n_ref:], s_qry).astype(np.uint32)
+    qn[2] = s_qry // 5                                         # a short query
+    for i in range(n_ref):
+        rt[i, : rn[i]] = table[i, : rn[i]]
+    for i in range(n_qry):
+        qt[i, : qn[i]] = table[n_ref + i, : qn[i]]
+    qt[4, : min(s_qry, rn[7])] = rt[7, : min(s_qry, rn[7])]     # a query equal to (a prefix of) a reference
+    qn[4] = min(s_qry, rn[7])
+    ref = eng.table_upload(rt, rn, lengths[:n_ref])
+    qry = eng.table_upload(qt, qn, lengths[n_ref:])
+    got = eng.compare_rect_host(ref, qry)
+    s_cmp = min(s_ref, s_qry)
+    for q in range(n_qry):
+        for r in range(n_ref):
+            o = oracle.compare(rt[r, : rn[r]], qt[q, : qn[q]], int(lengths[r]), int(lengths[n_ref + q]), s_cmp, 21, KSPACE21)
+            assert (got["numer"][q, r], got["denom"][q, r]) == (o.numer, o.denom), (q, r)
+    ref.free(); qry.free()
+
+
 def _py_distance(numer, denom, k):
     """CommandDistance.cpp:387-407 with CPython's libm log (the one the reference links)."""
     import math
