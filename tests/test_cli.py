@@ -497,3 +497,33 @@ def test_large_outputs_do_not_depend_on_formatting_threads(built, tmp_path):
     d = run("dist", "many.msh", "many.msh", cwd=tmp_path, env=many).stdout.splitlines()
     assert len(d) == 1000 * 1000
     assert d[1000 * 7 + 3].split("\t")[:2] == ["r3", "r7"]
+
+
+def test_msh_reader_survives_corrupted_files(built, tmp_path):
+    """Truncated or bit-flipped .msh files (wrong segment table, pointers past the end, absurd
+    list lengths) must end in an error message and exit status 1, never in a crash."""
+    import random
+    msh = str(tmp_path / "g.msh")
+    run("json2msh", os.path.join(GOLD, "genomes.json"), msh)
+    data = open(msh, "rb").read()
+    rnd = random.Random(7)
+    bad = str(tmp_path / "bad.msh")
+    outcomes = set()
+    for it in range(120):
+        b = bytearray(data)
+        mode = rnd.random()
+        if mode < 0.3:
+            b = b[: rnd.randrange(0, len(b))]
+        elif mode < 0.8:
+            for _ in range(rnd.randrange(1, 8)):
+                i = rnd.randrange(0, 4096 if rnd.random() < 0.7 else len(b))
+                b[i] = rnd.randrange(256)
+        else:
+            i = rnd.randrange(0, len(b) - 8)
+            b[i:i + 8] = bytes(rnd.randrange(256) for _ in range(8))
+        open(bad, "wb").write(b)
+        for args in (("info", "-d", bad), ("info", "-t", bad)):
+            r = subprocess.run([MASH, *args], capture_output=True)      # bytes: corrupted names are not UTF-8
+            assert r.returncode in (0, 1), (it, args, r.returncode, r.stderr[-200:])
+            outcomes.add(r.returncode)
+    assert 1 in outcomes
