@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <charconv>
 #include <chrono>
+#include <condition_variable>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -20,9 +21,12 @@
 #include <cstring>
 #include <deque>
 #include <fstream>
+#include <functional>
 #include <future>
 #include <iostream>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -304,6 +308,31 @@ struct PendingBatch {
     }
 };
 
+// MASH_AMD_TIMING=1: wall time of the stages of a run, to stderr at exit
+struct StageClock {
+    const bool on = getenv("MASH_AMD_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    vector<std::pair<string, double>> acc;
+    void lap(const char *name)
+    {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        const double dt = std::chrono::duration<double>(t1 - t0).count();
+        t0 = t1;
+        for (auto &a : acc) if (a.first == name) { a.second += dt; return; }
+        acc.emplace_back(name, dt);
+    }
+    ~StageClock()
+    {
+        if (!on) return;
+        cerr << "timing:";
+        for (auto &a : acc) cerr << ' ' << a.first << ' ' << a.second << " s;";
+        cerr << endl;
+    }
+};
+
+double g_gpu_sketch_seconds = 0;            // time inside mg_sketch_host (MASH_AMD_TIMING)
+
 void flush_batch(Gpu &gpu, SketchSet &set, PendingBatch &b)
 {
     if (b.refs.empty()) return;
@@ -315,8 +344,11 @@ void flush_batch(Gpu &gpu, SketchSet &set, PendingBatch &b)
     vector<uint64_t> hashes(n * s);
     vector<uint32_t> nhash(n), counts(set.p.counts ? n * s : 0);
     if (b.bases.empty()) b.bases.push_back((uint8_t)MG_RECORD_SEP);
-    if (mg_sketch_host(gpu.ctx, &mp, b.bases.data(), b.bases.size(), b.off.data(), n, hashes.data(), nhash.data(),
-                       set.p.counts ? counts.data() : nullptr) != MG_OK) {
+    const auto t_gpu = std::chrono::steady_clock::now();
+    const int sk_rc = mg_sketch_host(gpu.ctx, &mp, b.bases.data(), b.bases.size(), b.off.data(), n, hashes.data(), nhash.data(),
+                                     set.p.counts ? counts.data() : nullptr);
+    g_gpu_sketch_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_gpu).count();
+    if (sk_rc != MG_OK) {
         cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl;
         exit(1);
     }
@@ -528,26 +560,82 @@ bool load_msh_into(SketchSet &set, const string &file, bool first_sets_params, b
 }
 
 // Sketch::initFromFiles (Sketch.cpp:105-253)
+// -p N: N worker threads parse input files ahead of the consumer (decompress + kseq parse, the
+// host half of the reference's ThreadPool workers).  Files are claimed in input order, at most
+// `window` positions ahead of the file the consumer is waiting for, and handed over strictly in
+// input order, so the output does not depend on N.  The workers live as long as the pool: one
+// thread per FILE (std::async) costs more than parsing a small genome.
+class ParsePool {
+public:
+    ParsePool(const vector<string> &files, size_t threads, std::function<bool(size_t)> parseable)
+        : files_(files), parseable_(std::move(parseable)), nthreads_(threads), window_(threads * 2) {}
+    ~ParsePool()
+    {
+        { std::lock_guard<std::mutex> g(m_); stop_ = true; }
+        cv_work_.notify_all();
+        for (auto &t : workers_) t.join();
+    }
+    // result for file i (parsed by a worker, or here if no worker got to it); indices must ascend
+    ParsedFile take(size_t i, int kmer)
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        if (workers_.empty()) {                          // first use: k is final now (a leading .msh may have set it)
+            kmer_ = kmer;
+            next_ = i;
+            for (size_t t = 0; t < nthreads_; t++) workers_.emplace_back([this]() { work(); });
+        }
+        pos_ = i;
+        if (next_ < i) next_ = i;
+        cv_work_.notify_all();
+        if (next_ == i) {                                // nobody has claimed it: parse on this thread
+            next_ = i + 1;
+            lk.unlock();
+            cv_work_.notify_all();
+            return parse_file_concatenated(files_[i], kmer);
+        }
+        cv_done_.wait(lk, [&]() { return done_.count(i) != 0; });
+        ParsedFile pf = std::move(done_[i]);
+        done_.erase(i);
+        return pf;
+    }
+
+private:
+    void work()
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        for (;;) {
+            cv_work_.wait(lk, [&]() { return stop_ || (next_ < files_.size() && next_ <= pos_ + window_); });
+            if (stop_) return;
+            const size_t i = next_++;
+            if (!parseable_(i)) continue;                // .msh / stdin: the consumer handles those itself
+            lk.unlock();
+            ParsedFile pf = parse_file_concatenated(files_[i], kmer_);
+            lk.lock();
+            done_[i] = std::move(pf);
+            cv_done_.notify_all();
+        }
+    }
+    const vector<string> &files_;
+    std::function<bool(size_t)> parseable_;
+    size_t nthreads_, window_;
+    std::mutex m_;
+    std::condition_variable cv_work_, cv_done_;
+    std::map<size_t, ParsedFile> done_;
+    vector<std::thread> workers_;
+    size_t next_ = 0, pos_ = 0;
+    int kmer_ = 0;
+    bool stop_ = false;
+};
+
 void init_from_files(Gpu &gpu, SketchSet &set, const vector<string> &files, const Params &p, int verbosity = 1,
                      bool enforce_parameters = false)
 {
     set.p = p;
     PendingBatch b;
-    // concatenated mode: up to 2 x threads files are parsed ahead on worker threads; results are
-    // consumed strictly in input order (the reference's pool also delivers in submission order)
-    std::deque<std::pair<size_t, std::future<ParsedFile>>> ahead;
-    size_t next_submit = 0;
-    const size_t lookahead = (size_t)std::max(1, p.threads) * 2;
+    // concatenated mode with -p > 1: files are parsed ahead by a pool of workers (ParsePool)
     auto parseable = [&](size_t i) { return set.p.concatenated && !has_suffix(files[i], kSuffix) && files[i] != "-"; };
-    auto submit_more = [&](size_t upto) {
-        if (p.threads <= 1) return;
-        for (; next_submit < files.size() && next_submit < upto + lookahead && ahead.size() < lookahead; next_submit++) {
-            if (!parseable(next_submit)) continue;
-            const string f = files[next_submit];
-            const int k = set.p.kmer;
-            ahead.emplace_back(next_submit, std::async(std::launch::async, [f, k]() { return parse_file_concatenated(f, k); }));
-        }
-    };
+    std::unique_ptr<ParsePool> pool;
+    if (p.threads > 1) pool.reset(new ParsePool(files, (size_t)p.threads, parseable));
     for (size_t i = 0; i < files.size(); i++) {
         if (has_suffix(files[i], kSuffix)) {
             flush_batch(gpu, set, b);                      // keep input order
@@ -563,15 +651,8 @@ void init_from_files(Gpu &gpu, SketchSet &set, const vector<string> &files, cons
                 fclose(t);
             }
             if (set.p.concatenated) {
-                if (next_submit <= i) next_submit = i;     // .msh inputs may have changed k: submit late
-                submit_more(i);
-                if (!ahead.empty() && ahead.front().first == i) {
-                    ParsedFile pf = ahead.front().second.get();
-                    ahead.pop_front();
-                    queue_parsed_file(gpu, set, b, std::move(pf));
-                } else {
-                    queue_parsed_file(gpu, set, b, parse_file_concatenated(files[i], set.p.kmer));
-                }
+                if (pool && parseable(i)) queue_parsed_file(gpu, set, b, pool->take(i, set.p.kmer));
+                else queue_parsed_file(gpu, set, b, parse_file_concatenated(files[i], set.p.kmer));
             } else {
                 queue_file_by_sequence(gpu, set, b, files[i]);
             }
@@ -687,10 +768,14 @@ int cmd_sketch(int argc, const char **argv)
     for (const string &a : c.args) { if (c.o("list").active) split_file(a, files); else files.push_back(a); }
     if ((c.o("id").active || c.o("comment").active) && files.size() > 1 && !p.reads)
         cerr << "WARNING: -I and -C will only apply to first sketch" << endl;
+    StageClock clk;
     Gpu gpu;
+    clk.lap("device");
     SketchSet set;
     if (p.reads) { set.p = p; sketch_reads(gpu, set, files); }
     else init_from_files(gpu, set, files, p, 1);
+    clk.lap("ingest+sketch");
+    if (clk.on) cerr << "timing: of which mg_sketch_host " << g_gpu_sketch_seconds << " s" << endl;
     if (c.o("id").active && !set.refs.empty()) set.refs[0].name = c.o("id").arg;
     if (c.o("comment").active && !set.refs.empty()) set.refs[0].comment = c.o("comment").arg;
     const KmerWarning w = scan_kmer_warning(set);
@@ -698,6 +783,7 @@ int cmd_sketch(int argc, const char **argv)
     if (!has_suffix(prefix, kSuffix)) prefix += kSuffix;
     cerr << "Writing to " << prefix << "..." << endl;
     const string e = write_set(set, prefix);
+    clk.lap("write");
     if (!e.empty()) { cerr << "ERROR: " << e << endl; return 1; }
     if (w.count > 0 && !p.reads) warn_kmer_size(set, w);
     return 0;
@@ -741,29 +827,6 @@ struct FastOut {
 // formatting, not the GPU, bounds a full matrix: ~50 ns per value on one core).  Rows are cut
 // into chunks of >= 2^17 pairs, a wave of chunks is formatted concurrently, the pieces are
 // appended in order; fn(out, row, slot) must only touch slot-private state besides `out`.
-// MASH_AMD_TIMING=1: wall time of the stages of a full-matrix run, to stderr at exit
-struct StageClock {
-    const bool on = getenv("MASH_AMD_TIMING") != nullptr;
-    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-    vector<std::pair<string, double>> acc;
-    void lap(const char *name)
-    {
-        if (!on) return;
-        const auto t1 = std::chrono::steady_clock::now();
-        const double dt = std::chrono::duration<double>(t1 - t0).count();
-        t0 = t1;
-        for (auto &a : acc) if (a.first == name) { a.second += dt; return; }
-        acc.emplace_back(name, dt);
-    }
-    ~StageClock()
-    {
-        if (!on) return;
-        cerr << "timing:";
-        for (auto &a : acc) cerr << ' ' << a.first << ' ' << a.second << " s;";
-        cerr << endl;
-    }
-};
-
 unsigned emit_threads()
 {
     static const unsigned nt = []() {

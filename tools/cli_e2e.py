@@ -13,6 +13,7 @@ def main():
     ap.add_argument("--len", type=int, default=1_000_000)
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--only-edge", action="store_true", help="time only the thresholded edge-list run")
+    ap.add_argument("--only-sketch", action="store_true", help="time only `mash sketch`")
     a = ap.parse_args()
     d = tempfile.mkdtemp(prefix="mash_e2e_")
     os.environ["MASH_AMD_TIMING"] = "1"
@@ -41,13 +42,17 @@ def main():
             r = subprocess.run([MASH, *cmd], stdout=fo, stderr=subprocess.PIPE, cwd=d)
         assert r.returncode == 0, r.stderr.decode()[-500:]
         res[tag] = time.perf_counter() - t
-        for ln in r.stderr.decode().splitlines():
-            if ln.startswith("timing:"):
-                res[tag + "_stages"] = ln[len("timing:"):].strip()
+        stages = [ln[len("timing:"):].strip() for ln in r.stderr.decode().splitlines() if ln.startswith("timing:")]
+        if stages:
+            res[tag + "_stages"] = " | ".join(stages)
 
     run("sketch_p1_s", "sketch", "-l", "-o", "seq", lst)
     run("sketch_pN_s", "sketch", "-p", str(a.threads), "-l", "-o", "par", lst)
     assert open(os.path.join(d, "seq.msh"), "rb").read() == open(os.path.join(d, "par.msh"), "rb").read()
+    if a.only_sketch:
+        print(json.dumps(res))
+        subprocess.run(["rm", "-rf", d])
+        return
     if a.only_edge:
         run("triangle_edge_d0.2_s", "triangle", "-E", "-d", "0.2", "par.msh", out=os.path.join(d, "edge.txt"))
         os.environ["MASH_AMD_EMIT_THREADS"] = "1"
