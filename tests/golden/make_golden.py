@@ -13,7 +13,7 @@ Independent numeric cross-check:
   scipy.stats.binom.sf (Boost-backed)     -> binom_sf.json (p-value fixtures)
 Reference-run vectors (oracle/_ref = the reference's own objects, run here):
   random/adversarial sequences            -> ref_sketch_vectors.npz
-  random sketch pairs                     -> ref_compare_vectors.npz
+  random sketch pairs                     -> ref_compare_vectors.npz, ref_compare_vectors_large.npz (s = 3000)
   read sets with -m 2..5                  -> ref_sketch_vectors_m.npz
   aaFromCodon over all codons             -> codon_table.json
   read sets with -c (and -m)              -> ref_sketch_vectors_c.npz
@@ -131,10 +131,31 @@ def main():
     numer, denom, dist, pval = ref.triangle(table, nhash, lengths, 0, 64, 21, kspace, stats=True)
     np.savez_compressed(f"{HERE}/ref_compare_vectors.npz", table=table, nhash=nhash, lengths=lengths,
                         numer=numer, denom=denom, dist=dist, pval=pval, k=21, kmer_space=kspace)
+    make_large_compare_vectors(ref)
     make_mincopies_vectors(ref)
     make_codon_table(ref)
     make_cov_vectors(ref)
     print("golden fixtures written to", HERE)
+
+
+def make_large_compare_vectors(ref):
+    """Reference-run triangle at a sketch size where the GPU path compares value window by value
+    window (s = 3000, k = 31) -> ref_compare_vectors_large.npz."""
+    from mash_amd import synth
+    s = 3000
+    table, nhash, lengths = synth.clustered_sketches(16, s, clusters=2, seed=31, pool=int(1.5 * s), private=int(0.4 * s))
+    nhash[2] = 0
+    nhash[5] = 37
+    nhash[6] = s - 1
+    nhash[9] = s // 2
+    table[12] = table[4]
+    nhash[12] = nhash[4]
+    for i in range(16):
+        table[i, nhash[i]:] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    kspace = 4.0 ** 31
+    numer, denom, dist, pval = ref.triangle(table, nhash, lengths, 0, 16, 31, kspace, stats=True)
+    np.savez_compressed(f"{HERE}/ref_compare_vectors_large.npz", table=table, nhash=nhash, lengths=lengths,
+                        numer=numer, denom=denom, dist=dist, pval=pval, k=31, kmer_space=kspace)
 
 
 def make_cov_vectors(ref):
@@ -239,6 +260,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] in ("mincopies", "codons", "cov"):
         from oracle import pyoracle
         pyoracle.build(ref=True)
-        {"mincopies": make_mincopies_vectors, "codons": make_codon_table, "cov": make_cov_vectors}[sys.argv[1]](pyoracle.Oracle(ref=True))
+        {"mincopies": make_mincopies_vectors, "codons": make_codon_table, "cov": make_cov_vectors,
+         "largecompare": make_large_compare_vectors}[sys.argv[1]](pyoracle.Oracle(ref=True))
     else:
         main()

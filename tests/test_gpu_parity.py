@@ -318,6 +318,23 @@ def test_compare_reference_run_vectors(eng, golden_dir, kernel, monkeypatch):
     t.free()
 
 
+@pytest.mark.parametrize("kernel", ["merged", "generic", "pairs", "windows", "windows150", "windows7"])
+def test_compare_large_reference_run_vectors(eng, golden_dir, kernel, monkeypatch):
+    """Counts produced by the reference's own objects at s = 3000: the default path there is the
+    value-window mode; forced window sizes, the merge-path and the generic kernel must agree."""
+    _set_kernel(monkeypatch, kernel)
+    z = np.load(os.path.join(golden_dir, "ref_compare_vectors_large.npz"))
+    t = eng.table_upload(z["table"], z["nhash"], z["lengths"])
+    got = eng.compare_tri_host(t)
+    assert np.array_equal(got["numer"], z["numer"])
+    assert np.array_equal(got["denom"], z["denom"])
+    fin = eng.finish_tri(got, z["lengths"], 0, 16, int(z["k"]), float(z["kmer_space"]))
+    assert np.array_equal(fin["distance"], z["dist"])
+    nz = z["pval"] > 1e-290
+    assert np.all(np.abs(fin["p_value"][nz] - z["pval"][nz]) <= 1e-9 * z["pval"][nz])
+    t.free()
+
+
 @pytest.mark.parametrize("kernel", ["merged", "tiled", "pairs", "windows29"])
 @pytest.mark.parametrize("s", [1, 7, 64, 65, 100, 400, 1000, 1024])
 def test_compare_tiled_vs_oracle_sizes(eng, oracle, s, kernel, monkeypatch):

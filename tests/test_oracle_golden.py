@@ -166,6 +166,15 @@ def test_oracle_equals_reference_compare_vectors(oracle, golden_dir):
     assert np.array_equal(n2, z["numer"]) and np.array_equal(d2, z["denom"])
 
 
+def test_oracle_equals_reference_large_compare_vectors(oracle, golden_dir):
+    """s = 3000 reference-run triangle (the size class the GPU compares window by window)."""
+    z = np.load(os.path.join(golden_dir, "ref_compare_vectors_large.npz"))
+    numer, denom, dist, pval = oracle.triangle(z["table"], z["nhash"], z["lengths"], 0, 16,
+                                               int(z["k"]), float(z["kmer_space"]), stats=True)
+    assert np.array_equal(numer, z["numer"]) and np.array_equal(denom, z["denom"])
+    assert np.array_equal(dist, z["dist"]) and np.array_equal(pval, z["pval"])
+
+
 def test_oracle_vs_reference_live(oracle, ref_oracle):
     """Where oracle/_ref exists: random k-mers hash identically; random sketches too."""
     rng = np.random.default_rng(99)
