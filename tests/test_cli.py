@@ -527,3 +527,42 @@ def test_msh_reader_survives_corrupted_files(built, tmp_path):
             assert r.returncode in (0, 1), (it, args, r.returncode, r.stderr[-200:])
             outcomes.add(r.returncode)
     assert 1 in outcomes
+
+
+def test_info_and_paste_behave_like_the_reference_cli(built, tmp_path):
+    """`mash info` / `mash paste` need no GPU, so where the reference CLI has been built
+    (oracle/_ref/mash-ref, make -C oracle refcli) both binaries are run side by side on sketches
+    written by the reference's code: same stdout, same stderr, same exit status -- including the
+    refusals (incompatible options, missing or non-sketch inputs, mismatched k-mer sizes, existing
+    output)."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "mash-ref")
+    cli_in = os.path.join(GOLD, "cli", "in")
+    if not os.path.exists(ref):
+        pytest.skip("reference CLI not built here (make -C oracle refcli)")
+    dirs = {}
+    for tag, exe in (("ref", ref), ("ours", MASH)):
+        d = tmp_path / tag
+        d.mkdir()
+        for f in os.listdir(cli_in):
+            shutil.copy(os.path.join(cli_in, f), d)
+        # the sketches always come from the reference's code (ours would need the GPU)
+        for args in (["sketch", "-s", "300", "-o", "a", "g1.fa", "g2.fa", "g3.fa"], ["sketch", "-M", "-s", "100", "-o", "m", "g1.fa", "g3.fa"],
+                     ["sketch", "-k", "16", "-s", "120", "-i", "-o", "b", "multi.fa"], ["sketch", "-a", "-k", "9", "-s", "150", "-i", "-o", "p", "prot.fa"],
+                     ["sketch", "-s", "300", "-o", "d", "g4.fa"], ["sketch", "-S", "9", "-s", "300", "-o", "s9", "g4.fa"]):
+            subprocess.run([ref, *args], cwd=d, capture_output=True, check=True)
+        open(d / "mshlist.txt", "w").write("a.msh\nd.msh\n")
+        dirs[tag] = (exe, d)
+    cases = [["info", "-t", "a.msh"], ["info", "-H", "a.msh"], ["info", "-d", "b.msh"], ["info", "-d", "m.msh"], ["info", "-c", "m.msh"],
+             ["info", "-c", "a.msh"], ["info", "-t", "p.msh"], ["info", "-H", "p.msh"], ["info", "-d", "p.msh"], ["info", "-H", "m.msh"],
+             ["info", "-H", "s9.msh"], ["info", "-H", "-t", "a.msh"], ["info", "-d", "-c", "a.msh"], ["info", "-t", "-c", "m.msh"],
+             ["info", "nope.msh"], ["info", "-t", "g1.fa"], ["info", "-x", "a.msh"],
+             ["paste", "x", "a.msh", "d.msh"], ["info", "-t", "x.msh"], ["info", "-d", "x.msh"], ["paste", "x", "a.msh", "d.msh"],
+             ["paste", "y", "a.msh", "b.msh"], ["paste", "z", "a.msh", "p.msh"], ["paste", "w", "a.msh", "s9.msh"],
+             ["paste", "-l", "v", "mshlist.txt"], ["info", "-t", "v.msh"], ["paste", "u.msh", "a.msh", "m.msh"], ["info", "-d", "u.msh"],
+             ["paste", "t", "a.msh", "missing.msh"], ["paste", "r", "g1.fa"]]
+    for args in cases:
+        got = {}
+        for tag, (exe, d) in dirs.items():
+            r = subprocess.run([exe, *args], cwd=d, capture_output=True)
+            got[tag] = (r.returncode, r.stdout, r.stderr)
+        assert got["ours"] == got["ref"], (args, got["ours"][0], got["ref"][0], got["ours"][2][-200:], got["ref"][2][-200:])
