@@ -566,3 +566,28 @@ def test_info_and_paste_behave_like_the_reference_cli(built, tmp_path):
             r = subprocess.run([exe, *args], cwd=d, capture_output=True)
             got[tag] = (r.returncode, r.stdout, r.stderr)
         assert got["ours"] == got["ref"], (args, got["ours"][0], got["ref"][0], got["ours"][2][-200:], got["ref"][2][-200:])
+
+
+def test_option_refusals_match_the_reference_cli(built, tmp_path):
+    """Argument errors are decided before any GPU work, so they can be compared with the reference
+    CLI (oracle/_ref/mash-ref) on CPU: same message on stderr, same stdout, same exit status."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "mash-ref")
+    cli_in = os.path.join(GOLD, "cli", "in")
+    if not os.path.exists(ref):
+        pytest.skip("reference CLI not built here (make -C oracle refcli)")
+    for f in os.listdir(cli_in):
+        shutil.copy(os.path.join(cli_in, f), tmp_path)
+    subprocess.run([ref, "sketch", "-s", "300", "-o", "a", "g1.fa", "g2.fa", "g3.fa"], cwd=tmp_path, capture_output=True, check=True)
+    cases = [["sketch", "-k", "33", "g1.fa"], ["sketch", "-k", "0", "g1.fa"], ["sketch", "-r", "-i", "g1.fa"],
+             ["sketch", "-m", "2", "-b", "1G", "reads.fq"], ["sketch", "-q", "g1.fa"], ["sketch", "-k"], ["sketch", "-k", "abc", "g1.fa"],
+             ["sketch", "-w", "2", "g1.fa"], ["sketch", "-S", "-1", "g1.fa"], ["sketch", "-z", "AC", "-k", "40", "g1.fa"],
+             ["sketch", "-s", "1e3", "-k", "2.5", "g1.fa"], ["dist", "-v", "2", "a.msh", "a.msh"], ["dist", "-d", "2", "a.msh", "a.msh"],
+             ["dist", "-k", "16", "a.msh", "g1.fa"], ["triangle", "-v", "3", "a.msh"], ["screen", "-i", "2", "a.msh", "reads.fq"],
+             ["screen", "-v", "-1", "a.msh", "reads.fq"]]
+    for args in cases:
+        got = []
+        for exe in (ref, MASH):
+            r = subprocess.run([exe, *args], cwd=tmp_path, capture_output=True, stdin=subprocess.DEVNULL, timeout=20)
+            got.append((r.returncode, r.stdout, r.stderr))
+        assert got[0][0] != 0, args                              # these are refusals
+        assert got[0] == got[1], (args, got[0][2][-200:], got[1][2][-200:])
