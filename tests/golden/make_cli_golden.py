@@ -114,6 +114,36 @@ CASES = [
 ]
 
 
+# More of the same, written after the round's GPU budget was spent: replayed by the test as
+# non-blocking cases (xfail(strict=False)) until a GPU run has confirmed them.
+EXTRA = [
+    ("x_sketch_k32", [["sketch", "-k", "32", "-s", "200", "-o", "k32", "g1.fa", "g3.fa"]], ["info", "-d", "k32.msh"]),
+    ("x_sketch_k5", [["sketch", "-k", "5", "-s", "1000", "-o", "k5", "g1.fa"]], ["info", "-d", "k5.msh"]),
+    ("x_sketch_s1", [["sketch", "-s", "1", "-o", "s1", "g1.fa", "g2.fa"]], ["info", "-d", "s1.msh"]),
+    ("x_sketch_s5000", [["sketch", "-s", "5000", "-o", "s5k", "g1.fa", "g3.fa"]], ["info", "-t", "s5k.msh"]),
+    ("x_triangle_s5000", [], ["triangle", "-s", "5000", "g1.fa", "g3.fa", "g4.fa", "g2.fa"]),
+    ("x_dist_s5000", [], ["dist", "-s", "5000", "g1.fa", "g3.fa", "g4.fa"]),
+    ("x_sketch_genome_size", [["sketch", "-r", "-g", "30k", "-s", "100", "-o", "gs", "reads.fq"]], ["info", "-t", "gs.msh"]),
+    ("x_sketch_reads_m3", [["sketch", "-m", "3", "-s", "100", "-o", "m3", "reads.fq"]], ["info", "-d", "m3.msh"]),
+    ("x_sketch_protein_concat", [["sketch", "-a", "-s", "200", "-o", "pc", "prot.fa"]], ["info", "-d", "pc.msh"]),
+    ("x_sketch_stdin_name", [["sketch", "-s", "50", "-o", "two", "g1.fa", "g1.fa"]], ["info", "-t", "two.msh"]),
+    ("x_dist_size_mismatch", [["sketch", "-s", "300", "-o", "a", "g1.fa", "g2.fa", "g3.fa"], ["sketch", "-s", "100", "-o", "e", "g4.fa", "g3.fa"]],
+     ["dist", "a.msh", "e.msh"]),
+    ("x_dist_threads", [["sketch", "-s", "300", "-o", "a", "g1.fa", "g2.fa", "g3.fa"]], ["dist", "-p", "4", "a.msh", "a.msh", "g4.fa"]),
+    ("x_dist_table_comment", [["sketch", "-s", "300", "-o", "a", "g1.fa", "g2.fa", "g3.fa"]], ["dist", "-t", "-C", "a.msh", "a.msh"]),
+    ("x_dist_protein", [], ["dist", "-a", "-i", "-s", "150", "prot.fa", "prot.fa"]),
+    ("x_dist_noncanonical", [], ["dist", "-n", "-k", "17", "-s", "200", "g1.fa", "g3.fa"]),
+    ("x_triangle_threads_edge", [], ["triangle", "-p", "3", "-E", "-s", "200", "g1.fa", "g3.fa", "g4.fa", "g2.fa"]),
+    ("x_triangle_maxp", [], ["triangle", "-v", "1e-20", "-s", "200", "g1.fa", "g3.fa", "g4.fa", "g2.fa"]),
+    ("x_triangle_protein", [], ["triangle", "-a", "-s", "150", "prot.fa"]),
+    ("x_screen_threads", [["sketch", "-s", "300", "-o", "a", "g1.fa", "g2.fa", "g3.fa"]], ["screen", "-p", "4", "a.msh", "reads.fq"]),
+    ("x_screen_k16", [["sketch", "-k", "16", "-s", "200", "-o", "a16", "g1.fa", "g2.fa", "g3.fa"]], ["screen", "a16.msh", "reads.fq"]),
+    ("x_screen_genomes", [["sketch", "-s", "300", "-o", "a", "g1.fa", "g2.fa", "g3.fa"]], ["screen", "a.msh", "g3.fa", "g4.fa"]),
+    ("x_paste_three", [["sketch", "-s", "100", "-o", "q1", "g1.fa"], ["sketch", "-s", "100", "-o", "q2", "g2.fa"], ["sketch", "-s", "100", "-o", "q3", "g3.fa"],
+                       ["paste", "q", "q1.msh", "q2.msh", "q3.msh"]], ["dist", "q.msh", "q.msh"]),
+]
+
+
 def main():
     if not os.path.exists(REFCLI):
         sys.exit("build the reference CLI first: make -C oracle refcli")
@@ -121,17 +151,18 @@ def main():
     os.makedirs(f"{OUT}/in")
     make_inputs(f"{OUT}/in")
     manifest = []
-    for name, setup, cmd in CASES:
+    for name, setup, cmd in CASES + EXTRA:
         d = tempfile.mkdtemp(prefix="cligold_")
         for f in os.listdir(f"{OUT}/in"):
             shutil.copy(f"{OUT}/in/{f}", d)
         for s in setup:
-            r = subprocess.run([REFCLI, *s], cwd=d, capture_output=True)
+            r = subprocess.run([REFCLI, *s], cwd=d, capture_output=True, timeout=120)
             assert r.returncode == 0, (name, s, r.stderr[-300:])
-        r = subprocess.run([REFCLI, *cmd], cwd=d, capture_output=True)
+        r = subprocess.run([REFCLI, *cmd], cwd=d, capture_output=True, timeout=120)
         assert r.returncode == 0, (name, cmd, r.stderr[-300:])
         open(f"{OUT}/{name}.out", "wb").write(r.stdout)
-        manifest.append({"name": name, "setup": setup, "cmd": cmd, "stdout_bytes": len(r.stdout)})
+        manifest.append({"name": name, "setup": setup, "cmd": cmd, "stdout_bytes": len(r.stdout),
+                         "confirmed_on_gpu": not name.startswith("x_")})
         shutil.rmtree(d)
         print(f"{name:28s} {len(r.stdout):8d} bytes")
     json.dump(manifest, open(f"{OUT}/cases.json", "w"), indent=1)

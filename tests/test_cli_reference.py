@@ -20,18 +20,31 @@ CASES = json.load(open(os.path.join(CLI, "cases.json")))
 KNOWN_DIFFERENCES = {}
 
 
+def _params():
+    out = []
+    for c in CASES:
+        marks = []
+        if not c.get("confirmed_on_gpu", True):
+            # written when no GPU time was left to replay them: they report (XPASS / xfail) without
+            # deciding the suite until a GPU run has confirmed them and the flag is flipped
+            marks.append(pytest.mark.xfail(strict=False, reason="reference CLI fixture not yet replayed on a GPU"))
+        out.append(pytest.param(c, id=c["name"], marks=marks))
+    return out
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+@pytest.mark.parametrize("case", _params())
 def test_cli_prints_what_the_reference_cli_prints(case, tmp_path):
     if case["name"] in KNOWN_DIFFERENCES:
         pytest.xfail(KNOWN_DIFFERENCES[case["name"]])
     assert os.path.exists(MASH), "mash_amd/bin/mash is not built"
     for f in os.listdir(os.path.join(CLI, "in")):
         shutil.copy(os.path.join(CLI, "in", f), tmp_path)
+    limit = 300 if case.get("confirmed_on_gpu", True) else 45
     for s in case["setup"]:
-        r = subprocess.run([MASH, *s], cwd=tmp_path, capture_output=True)
+        r = subprocess.run([MASH, *s], cwd=tmp_path, capture_output=True, timeout=limit)
         assert r.returncode == 0, (s, r.stderr[-300:])
-    r = subprocess.run([MASH, *case["cmd"]], cwd=tmp_path, capture_output=True)
+    r = subprocess.run([MASH, *case["cmd"]], cwd=tmp_path, capture_output=True, timeout=limit)
     assert r.returncode == 0, (case["cmd"], r.stderr[-300:])
     want = open(os.path.join(CLI, case["name"] + ".out"), "rb").read()
     assert r.stdout == want, case["name"]
