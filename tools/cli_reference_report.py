@@ -6,7 +6,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLI = os.path.join(ROOT, "tests", "golden", "cli")
 MASH = os.path.join(ROOT, "mash_amd", "bin", "mash")
 bad = 0
+only_extra = "--extra" in sys.argv
 for case in json.load(open(os.path.join(CLI, "cases.json"))):
+    if only_extra and case.get("confirmed_on_gpu", True):
+        continue
     d = tempfile.mkdtemp(prefix="clirep_")
     for f in os.listdir(os.path.join(CLI, "in")):
         shutil.copy(os.path.join(CLI, "in", f), d)
@@ -25,7 +28,7 @@ for case in json.load(open(os.path.join(CLI, "cases.json"))):
             a, b = r.stdout.splitlines(), want.splitlines()
             i = next((k for k in range(min(len(a), len(b))) if a[k] != b[k]), min(len(a), len(b)))
             msg = "line %d: got %r want %r (lines %d vs %d)" % (i, a[i][:120] if i < len(a) else None, b[i][:120] if i < len(b) else None, len(a), len(b))
-    print(("DIFF " if msg else "same ") + case["name"] + (": " + msg if msg else ""))
+    print(("DIFF " if msg else "same ") + case["name"] + (": " + msg if msg else ""), flush=True)
     bad += msg is not None
     shutil.rmtree(d)
 print("differing cases:", bad)
