@@ -221,3 +221,43 @@ def test_reference_cli_build_passes_the_reference_make_test(golden_dir, tmp_path
     assert run(ref, "info", "-d", "genomes.msh") == open(os.path.join(golden_dir, "genomes.json"), "rb").read()
     assert run(ref, "dist", "genomes.msh", "reads.msh") == open(os.path.join(golden_dir, "genomes.dist"), "rb").read()
     assert run(ref, "screen", "genomes.msh", "reads1.fastq", "reads2.fastq") == open(os.path.join(golden_dir, "screen"), "rb").read()
+
+
+def test_oracle_equals_reference_cli_on_random_inputs(oracle, tmp_path):
+    """Random FASTA files and parameters (k 1..32, -n, -Z, N runs, lower case, empty and short
+    records): `mash-ref sketch` + `info -d` (the reference's own sketchFile / addMinHashes / heap)
+    against the oracle's sketch_records -- hash list and length."""
+    import json, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref = os.path.join(root, "oracle", "_ref", "mash-ref")
+    if not os.path.exists(ref):
+        pytest.skip("reference CLI not built here (make -C oracle refcli)")
+    rng = np.random.default_rng(4242)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    compared = 0
+    for it in range(40):
+        k = int(rng.integers(1, 33)); s = int(rng.choice([1, 10, 100, 400, 1000]))
+        nonc = bool(rng.random() < 0.3); pc = bool(rng.random() < 0.2)
+        recs = []
+        for r in range(int(rng.integers(1, 5))):
+            n = int(rng.choice([0, 3, 40, 500, 5000, 20000]))
+            seq = lut[rng.integers(0, 4, n)].copy()
+            if n and rng.random() < 0.4:
+                i = int(rng.integers(0, n)); seq[i:i + int(rng.integers(1, 30))] = ord("N")
+            seq = seq.tobytes()
+            if rng.random() < 0.3:
+                seq = seq[: n // 2] + seq[n // 2:].lower()
+            recs.append((b"r%d c%d" % (r, it), seq))
+        with open(tmp_path / "x.fa", "wb") as f:
+            for name, seq in recs:
+                f.write(b">" + name + b"\n" + seq + b"\n")
+        args = ["sketch", "-k", str(k), "-s", str(s), "-o", "x"] + (["-n"] if nonc else []) + (["-Z"] if pc else []) + ["x.fa"]
+        r = subprocess.run([ref, *args], cwd=tmp_path, capture_output=True, timeout=60)
+        if r.returncode != 0:
+            continue                                    # nothing sketchable: the reference refuses
+        j = json.loads(subprocess.run([ref, "info", "-d", "x.msh"], cwd=tmp_path, capture_output=True, timeout=60, check=True).stdout)
+        h, _, length, _, _ = oracle.sketch_records([q for _, q in recs], oracle.params(k=k, s=s, noncanonical=nonc, preserve_case=pc))
+        assert [int(x) for x in h] == j["sketches"][0]["hashes"], (it, args)
+        assert j["sketches"][0]["length"] == length, (it, args)
+        compared += 1
+    assert compared >= 25
