@@ -15,7 +15,7 @@ struct CompareTile {
 // host groups rows of similar hash density (see run_compare), because one linear
 // value -> bucket map per tile only spreads entries evenly when its rows are equally dense.
 struct MergedTile {
-    uint32_t rows[16];
+    uint32_t rows[32];      // plain tiles list up to 16 rows, window tiles up to 32
     uint32_t col0, col1;
 };
 
@@ -52,6 +52,7 @@ struct CompareArgs {
     uint8_t *win_mask;            // [tiles][16 waves][win_kmax]: live columns per batch, carried between launches
     uint32_t win_kmax;            // batches of 8 columns per wave and tile
     uint32_t xcd_remap;           // 1: XCD x takes the x-th contiguous eighth of the tile list
+    uint32_t stage_pack;          // window mode: results staged as u16 pairs (s < 32768; set by the launcher)
 };
 
 // LDS-tiled kernel usable when s <= 1024; rows_per_tile chosen by compare_rows_per_tile.
@@ -63,8 +64,9 @@ bool compare_merged_supported(uint32_t s);
 uint32_t compare_merged_rows(uint32_t s);
 hipError_t launch_compare_merged(const CompareArgs &a, uint32_t ntiles, hipStream_t stream);
 // windowed mode: rows per tile, entries per tile, and the per-row window offsets
-uint32_t compare_window_rows();
-uint32_t compare_window_entries();
+uint32_t compare_window_rows(uint32_t s);     // rows a window tile may list (32, or 16 for s >= 32768)
+uint32_t compare_window_entries();            // entries a window tile may hold
+uint32_t compare_window_row_entries();        // entries of ONE row a window tile may hold (tag index field)
 hipError_t launch_window_offsets(const uint32_t *pfx, uint64_t pfx_stride, const uint32_t *nhash, uint64_t n, uint32_t s,
                                  uint32_t nwin, uint32_t delta, uint32_t *out, hipStream_t stream);
 // table max (u64 atomicMax over the last valid entry of every row) and prefix image

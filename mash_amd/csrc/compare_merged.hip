@@ -81,11 +81,16 @@ __host__ __device__ inline size_t merged_lds_bytes_nb(uint32_t R, uint32_t s, ui
 
 // Window mode (large sketches): a tile holds 16 rows' hashes of ONE value window, at most
 // MR_WIN_ENTRIES of them, in MR_WIN_BUCKETS buckets -- the geometry of an s = 1000 tile.
-constexpr uint32_t MR_WIN_ROWS = 16;
+// Up to 32 rows share a window tile: unrelated pairs are decided by the lower ~54 % of the hash
+// range (the union of two sketches reaches s elements there), so a window holds ~0.54 s entries
+// of a row and 29 rows fit where 16 whole rows did -- every probe then serves 29 pairs.
+constexpr uint32_t MR_WIN_ROWS = 32;
 constexpr uint32_t MR_WIN_ENTRIES = 16000;
 constexpr uint32_t MR_WIN_BUCKETS = 24576;
-constexpr uint32_t MR_WIN_IDX_BITS = 12;               // index of an entry inside its row's window (< 4096)
-static_assert(merged_lds_bytes_e(MR_WIN_ROWS, MR_WIN_ENTRIES, MR_WIN_BUCKETS) <= 160 * 1024 - 512, "window tile exceeds LDS");
+constexpr uint32_t MR_WIN_IDX_BITS = 11;               // index of an entry inside its row's window (< 2048)
+// per-wave output staging of a window tile: 4 B per pair ({common, denom} as two u16) while
+// s < 32768, else 8 B and at most 16 rows
+static_assert(merged_lds_bytes_e(MR_WIN_ROWS / 2, MR_WIN_ENTRIES, MR_WIN_BUCKETS) <= 160 * 1024 - 512, "window tile exceeds LDS");
 
 // Bucket count: at least 0.8 buckets per entry (power of two), then as many more as LDS holds
 // up to two per entry -- buckets with more than MR_W entries cost an extra scan per probe that
@@ -137,10 +142,13 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
     uint32_t *cnt32 = reinterpret_cast<uint32_t *>(dir);                            // build-time view
     uint32_t *pfx = reinterpret_cast<uint32_t *>(smem + 512 + (size_t)(NB + 8) * 2);   // [ecap]
     uint16_t *tag = reinterpret_cast<uint16_t *>(reinterpret_cast<unsigned char *>(pfx) + (((size_t)ecap * 4 + 15) & ~(size_t)15));
-    uint2 *stage_all = reinterpret_cast<uint2 *>(reinterpret_cast<unsigned char *>(tag) + (((size_t)ecap * 2 + 15) & ~(size_t)15));
+    unsigned char *stage_all = reinterpret_cast<unsigned char *>(tag) + (((size_t)ecap * 2 + 15) & ~(size_t)15);
     __shared__ uint32_t s_wsum[MR_NW + 2];
     __shared__ uint64_t s_rowmax[32];
-    __shared__ uint32_t s_rowlo[16], s_rowlen[16];      // WIN: first index of the row's window; full row length
+    __shared__ uint32_t s_rowlo[32], s_rowlen[32];      // WIN: first index of the row's window; full row length
+    constexpr uint32_t MAXR = WIN ? 32u : 16u;          // rows a tile may list
+    // WIN: results are staged as {common, denom} u16 pairs while s < 32768 (bit 15 of denom = in progress)
+    const bool pack = WIN && a.stage_pack != 0;
 
     // (fields are read individually: indexing a by-value copy of rows[] would put the tile in scratch)
     // Workgroups are dealt to the 8 XCDs round-robin by index, and each XCD has its own L2.  With
@@ -163,19 +171,27 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
     const uint32_t lane = tid & 63;
     const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
 
+    if (WIN && a.win > 0) {
+        // later windows: a tile none of whose columns still has a pair in progress has nothing to do
+        const uint8_t *m = a.win_mask + (uint64_t)blockIdx.x * MR_NW * a.win_kmax;
+        const uint32_t nbytes = MR_NW * a.win_kmax;
+        uint32_t any = 0;
+        for (uint32_t b = tid; b < nbytes; b += MR_NT) any |= m[b];
+        if (__syncthreads_or((int)any) == 0) return;
+    }
     // ------------------------------------------------------------------ build the tile table
     if (tid < 32) {
         uint32_t n = 0;
         uint64_t mx = 0;
         uint32_t rid = 0xFFFFFFFFu;
-        if ((uint32_t)tid < R && tid < 16) rid = tile_p->rows[tid];
+        if ((uint32_t)tid < R && (uint32_t)tid < MAXR) rid = tile_p->rows[tid];
         if (rid != 0xFFFFFFFFu) {
             const uint64_t i = rid;
             n = a.row_nhash[i];
             if (n > s) n = s;
             if (n > 0) mx = a.row_pfx[i * a.row_pfx_stride + n - 1];
         }
-        if (WIN && tid < 16) {
+        if (WIN) {
             uint32_t lo = 0, hi = 0;
             if (rid != 0xFFFFFFFFu) {
                 lo = a.row_win[(uint64_t)rid * (a.nwin + 1) + a.win];
@@ -216,7 +232,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
     const uint32_t idx_mask = (1u << idx_bits) - 1u;
     const uint32_t origin = WIN ? a.win_lo : 0u;
     // WIN: tags hold the index inside the row's window; lo_of(r) turns it into the index in the row
-    auto lo_of = [&](uint32_t r) -> uint32_t { return WIN ? s_rowlo[r & 15u] : 0u; };
+    auto lo_of = [&](uint32_t r) -> uint32_t { return WIN ? s_rowlo[r & 31u] : 0u; };
     uint32_t e_pfx[MR_EPT], e_bs[MR_EPT];    // prefix; bucket | slot << 16, kept in registers
     uint16_t e_tag[MR_EPT];
 #pragma unroll
@@ -226,8 +242,9 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
         bool have;
         if (WIN) {
             // entries are the concatenated window ranges of the rows: find the row of entry e
-            r = 0;
-            for (uint32_t k = 1; k < 16; k++) r += hdr->row_base[k] <= e ? 1u : 0u;   // row_base is non-decreasing
+            r = 0;                                      // last row whose base is <= e (row_base is non-decreasing)
+#pragma unroll
+            for (uint32_t step = 16; step >= 1; step >>= 1) r += hdr->row_base[r + step] <= e ? step : 0u;
             idx = e - hdr->row_base[r];
             have = e < E;
         } else {
@@ -334,7 +351,9 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
 
     if (a.dbg && tid == 0) a.dbg[3 * (uint64_t)blockIdx.x + 1] = __builtin_readcyclecounter();
     // ------------------------------------------------------------------ stream columns
-    const uint32_t my_n = WIN ? (lane < 16 ? s_rowlen[lane] : 0) : (lane < 32 ? hdr->row_n[lane] : 0);   // row `lane`
+    const uint32_t my_n = WIN ? (lane < 32 ? s_rowlen[lane] : 0) : (lane < 32 ? hdr->row_n[lane] : 0);   // row `lane`
+    // WIN: index in row `lane` of its first hash at or above the window's end
+    const uint32_t my_pend = WIN && lane < 32 ? s_rowlo[lane] + hdr->row_n[lane] : 0u;
     const uint32_t my_id = lane < 32 ? hdr->row_id[lane] : 0xFFFFFFFFu;     // table row of slot `lane`
     const uint32_t *my_row = a.row_pfx + (uint64_t)(my_id != 0xFFFFFFFFu ? my_id : hdr->row_id[0]) * a.row_pfx_stride;
 
@@ -355,7 +374,9 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
     // Wave w owns batches of MR_CB consecutive columns: batch k -> columns
     // col0 + (k*NW + w)*CB ... +CB-1.  Results of a batch are staged in LDS and written
     // as 64-B row segments (nontemporal), instead of 8-B scattered stores that thrash L2.
-    uint2 *stage = stage_all + (size_t)wid * R * MR_CB;                   // [R rows][CB]
+    unsigned char *stage_b = stage_all + (size_t)wid * R * MR_CB * (pack ? 4u : 8u);   // [R rows][CB]
+    uint2 *stage = reinterpret_cast<uint2 *>(stage_b);
+    uint32_t *stage_p = reinterpret_cast<uint32_t *>(stage_b);            // packed form
     auto col_of = [&](uint32_t t) -> uint32_t {
         return tile.col0 + ((t / MR_CB) * MR_NW + wid) * MR_CB + (t % MR_CB);
     };
@@ -363,10 +384,21 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
         // lane -> (row = lane/4, two columns 2*(lane%4), +1) : 16 B per lane, 64 B per row
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const uint32_t r = lane >> 2, c0 = (lane & 3u) * 2;
-        const uint64_t i = (uint32_t)__shfl((int)my_id, (int)r);           // table row of slot r
+        const uint32_t c0 = (lane & 3u) * 2;
+        for (uint32_t r = lane >> 2; r < ((R + 15u) & ~15u); r += 16) {   // uniform trip count: 16 rows per pass
+        const uint64_t i = (uint32_t)__shfl((int)my_id, (int)(r & 31u));   // table row of slot r
         if (r < R && i != 0xFFFFFFFFull) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(&stage[r * MR_CB + c0]);
+            uint4 v;
+            if (pack) {
+                const uint2 w = *reinterpret_cast<const uint2 *>(&stage_p[r * MR_CB + c0]);
+                const uint32_t d0 = w.x >> 16, d1 = w.y >> 16;
+                v.x = w.x & 0xFFFFu;
+                v.y = (d0 & 0x8000u) ? (0x80000000u | (d0 & 0x7FFFu)) : d0;
+                v.z = w.y & 0xFFFFu;
+                v.w = (d1 & 0x8000u) ? (0x80000000u | (d1 & 0x7FFFu)) : d1;
+            } else {
+                v = *reinterpret_cast<const uint4 *>(&stage[r * MR_CB + c0]);
+            }
             const uint64_t j0 = (uint64_t)jb + c0;
             // WIN: only the columns this launch worked on (the others keep their earlier result)
             const bool in0 = WIN ? ((procmask >> c0) & 1u) != 0 : c0 < ncols_done;
@@ -387,6 +419,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
                 if (ok0) __builtin_nontemporal_store(w0, reinterpret_cast<u32x2 *>(dst));
                 if (ok1) __builtin_nontemporal_store(w1, reinterpret_cast<u32x2 *>(dst + 1));
             }
+        }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -480,8 +513,9 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
         const uint32_t started = active;                                 // rows this launch works on
         const uint32_t ngroups = active == 0 ? 0 : (qhi - qlo + 64 * MR_KU - 1) / (64 * MR_KU);
         // prologue: rank-test operand of group 0, data of group 1, then the next column
+        // (WIN: no rank test between groups -- the pair is decided exactly at the end of the window's part)
         int32_t t_chk = (int32_t)s - (int32_t)(64 * MR_KU) - (int32_t)qlo + (int32_t)st_call;   // s-1-qlast+c, qlast = qlo+64*KU-1
-        uint32_t a_chk = my_row[t_chk >= 1 ? (uint32_t)t_chk - 1 : 0];
+        uint32_t a_chk = WIN ? 0u : my_row[t_chk >= 1 ? (uint32_t)t_chk - 1 : 0];
         load_group(bsrc, qlo + 64 * MR_KU, nxt);
         {
             const uint32_t jnx = col_of(t1);
@@ -493,6 +527,16 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
                 if (a.win > 0) st_next = load_state(jn);
                 const uint32_t j2x = col_of(t2);
                 win_range(j2x < tile.col1 ? j2x : jn, n2_lo, n2_hi);
+            }
+        }
+        // directory entries are fetched one group ahead (s0c: this group's, read while the previous
+        // group was compared), so a group waits for ONE LDS round trip -- its window reads -- not two
+        uint32_t s0c[MR_KU];
+        if (ngroups != 0) {
+#pragma unroll
+            for (int u = 0; u < MR_KU; u++) {
+                const uint32_t bk = __umulhi(cur[u] - origin, scale);
+                s0c[u] = dir[bk < NB ? bk : NB];
             }
         }
         for (uint32_t g = 0; g < ngroups && active != 0; g++) {
@@ -507,13 +551,19 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
 #pragma unroll
             for (int u = 0; u < MR_KU; u++) {
                 x[u] = cur[u];
-                const uint32_t bk = __umulhi(x[u] - origin, scale);
-                s0[u] = dir[bk < NB ? bk : NB];              // prefixes above the tile's maximum (and padding) -> sentinel
+                s0[u] = s0c[u];                              // dir[bucket of x]; prefixes above the tile's maximum (and padding) -> sentinel
             }
 #pragma unroll
             for (int u = 0; u < MR_KU; u++)
 #pragma unroll
                 for (int w = 0; w < MR_W; w++) h[u][w] = pfx[(s0[u] & 0x7FFFu) + w];
+            if (!col_end) {
+#pragma unroll
+                for (int u = 0; u < MR_KU; u++) {            // next group's directory entries, behind this group's window reads
+                    const uint32_t bk = __umulhi(nxt[u] - origin, scale);
+                    s0c[u] = dir[bk < NB ? bk : NB];
+                }
+            }
             uint64_t anyovf = 0;
 #pragma unroll
             for (int u = 0; u < MR_KU; u++) {
@@ -554,16 +604,16 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
                         // every table entry with b's prefix holds the same value (build pass 3): collect
                         // the rows and b's index in each from LDS, verify ONE representative on 64 bits
                         uint32_t rowmask = 0, rep = 0xFFFFFFFFu;
-                        uint32_t pk[8];                                  // idx of b in row r: 16 bits each
+                        uint32_t pk[MAXR / 2];                           // idx of b in row r: 16 bits each
 #pragma unroll
-                        for (int k = 0; k < 8; k++) pk[k] = 0;
+                        for (int k = 0; k < (int)(MAXR / 2); k++) pk[k] = 0;
                         auto take = [&](uint32_t tg) {
                             const uint32_t r = tg >> idx_bits, idx = tg & idx_mask;
                             if (rep == 0xFFFFFFFFu) rep = tg;
                             rowmask |= 1u << r;
                             const uint32_t val = idx << ((r & 1u) * 16u), wd = r >> 1;
 #pragma unroll
-                            for (int k = 0; k < 8; k++) pk[k] |= (wd == (uint32_t)k) ? val : 0u;
+                            for (int k = 0; k < (int)(MAXR / 2); k++) pk[k] |= (wd == (uint32_t)k) ? val : 0u;
                         };
                         if (mine) {
                             const uint32_t st = s0[u] & 0x7FFFu;
@@ -586,7 +636,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
                         for (int d = 32; d > 0; d >>= 1) any |= __shfl_xor(any, d);
                         const uint32_t rows_any = (uint32_t)__builtin_amdgcn_readfirstlane((int)any) & active;
 #pragma unroll
-                        for (int r = 0; r < 16; r++) {
+                        for (int r = 0; r < (int)MAXR; r++) {
                             if (!((rows_any >> r) & 1u)) continue;       // uniform
                             const bool mt = (rowmask >> r) & 1u;
                             const uint32_t idx = ((pk[r >> 1] >> ((r & 1) * 16)) & 0xFFFFu) + lo_of((uint32_t)r);
@@ -679,21 +729,25 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
 
             // ---- rank test per row: has the union reached s elements at the group's last element?
             if (!col_end) {
-                if (c_changed) {                                         // uniform; counts moved: re-read operand
-                    t_chk = (int32_t)s - 1 - (int32_t)qlast + (int32_t)st_call;
-                    a_chk = my_row[t_chk >= 1 ? (uint32_t)t_chk - 1 : 0];
+                if (!WIN) {
+                    if (c_changed) {                                     // uniform; counts moved: re-read operand
+                        t_chk = (int32_t)s - 1 - (int32_t)qlast + (int32_t)st_call;
+                        a_chk = my_row[t_chk >= 1 ? (uint32_t)t_chk - 1 : 0];
+                    }
+                    // prefix compare is conservative: prefix(A) < prefix(B) => A < B (a later exit is harmless)
+                    const uint32_t xlast = (uint32_t)__builtin_amdgcn_readlane((int)cur[MR_KU - 1], 63);
+                    const bool done = lane < R && (t_chk <= 0 || ((uint32_t)t_chk <= my_n && a_chk < xlast));
+                    const uint32_t dm = (uint32_t)__ballot(done) & active;
+                    active &= ~dm;
+                    brokem |= dm;
                 }
-                // prefix compare is conservative: prefix(A) < prefix(B) => A < B (a later exit is harmless)
-                const uint32_t xlast = (uint32_t)__builtin_amdgcn_readlane((int)cur[MR_KU - 1], 63);
-                const bool done = lane < R && (t_chk <= 0 || ((uint32_t)t_chk <= my_n && a_chk < xlast));
-                const uint32_t dm = (uint32_t)__ballot(done) & active;
-                active &= ~dm;
-                brokem |= dm;
                 // advance the pipeline: data of group g+1 becomes current; issue operand of g+1, data of g+2
 #pragma unroll
                 for (int u = 0; u < MR_KU; u++) cur[u] = nxt[u];
-                t_chk = (int32_t)s - 1 - (int32_t)(qlast + 64 * MR_KU) + (int32_t)st_call;
-                a_chk = my_row[t_chk >= 1 ? (uint32_t)t_chk - 1 : 0];
+                if (!WIN) {
+                    t_chk = (int32_t)s - 1 - (int32_t)(qlast + 64 * MR_KU) + (int32_t)st_call;
+                    a_chk = my_row[t_chk >= 1 ? (uint32_t)t_chk - 1 : 0];
+                }
                 load_group(bsrc, q0 + 2 * 64 * MR_KU, nxt);
             }
         }
@@ -704,13 +758,19 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
                 const uint32_t uni = my_n + nB - st_call;
                 denom = uni < s ? uni : s;
                 if (WIN) {
-                    // no exit yet: the pair is decided only when the column is exhausted (nothing
-                    // left that could match) or this was the last window
+                    // Decided exactly at the end of the window's part: all union elements below the
+                    // window's end are known -- my_pend of the row, qhi of the column, st_call shared.
+                    // If they number s or more, the first s union elements (and every match among them,
+                    // counted with its rank) lie behind us: denom = s.  Else the pair goes on to the
+                    // next window unless the row or the column is exhausted (nothing left that could
+                    // match: denom = |union| capped at s) or this was the last window.
                     if (!((started >> lane) & 1u)) denom = fin_denom;                      // decided earlier (or not ours)
-                    else if (a.win + 1 < a.nwin && qhi < nB) { denom = 0x80000000u | st_call; prog = true; }
+                    else if (my_pend + qhi - st_call >= s) denom = s;
+                    else if (a.win + 1 < a.nwin && qhi < nB && my_pend < my_n) { denom = 0x80000000u | st_call; prog = true; }
                 }
             }
-            stage[lane * MR_CB + (tcol % MR_CB)] = make_uint2(st_common, denom);
+            if (pack) stage_p[lane * MR_CB + (tcol % MR_CB)] = (st_common & 0xFFFFu) | (((denom & 0x80000000u) ? (0x8000u | (denom & 0x7FFFu)) : denom) << 16);
+            else stage[lane * MR_CB + (tcol % MR_CB)] = make_uint2(st_common, denom);
         }
         if (WIN) {
             procmask |= 1u << (tcol % MR_CB);
@@ -855,8 +915,10 @@ hipError_t launch_window_offsets(const uint32_t *pfx, uint64_t pfx_stride, const
     return hipGetLastError();
 }
 
-uint32_t compare_window_rows() { return MR_WIN_ROWS; }
+// rows a window tile may list: 32 while results can be staged as u16 pairs, else 16
+uint32_t compare_window_rows(uint32_t s) { return s < 32768u ? MR_WIN_ROWS : MR_WIN_ROWS / 2; }
 uint32_t compare_window_entries() { return MR_WIN_ENTRIES; }
+uint32_t compare_window_row_entries() { return (1u << MR_WIN_IDX_BITS) - 1u; }
 
 template <int KU, bool WIN = false>
 static hipError_t launch_merged_k(const CompareArgs &a, uint32_t ntiles, size_t smem, hipStream_t stream)
@@ -874,14 +936,13 @@ hipError_t launch_compare_merged(const CompareArgs &a_in, uint32_t ntiles, hipSt
     if (ntiles == 0) return hipSuccess;
     CompareArgs a = a_in;
     if (a.nwin > 0) {
-        // window mode: fixed tile geometry (16 rows, MR_WIN_ENTRIES entries, MR_WIN_BUCKETS buckets)
-        a.rows_per_tile = MR_WIN_ROWS;
+        // window mode: fixed tile geometry (up to 32 rows, MR_WIN_ENTRIES entries, MR_WIN_BUCKETS buckets)
+        a.stage_pack = a.s < 32768u ? 1u : 0u;
+        a.rows_per_tile = compare_window_rows(a.s);
         a.nbuckets = MR_WIN_BUCKETS;
         a.win_ecap = MR_WIN_ENTRIES;
-        const size_t wsmem = merged_lds_bytes_e(MR_WIN_ROWS, MR_WIN_ENTRIES, MR_WIN_BUCKETS);
-        // groups of 256 elements here: a window's share of a column (~700-800 elements) has no early
-        // exit inside it, so fewer, larger groups win (s = 10 000: 1.03 / 1.08 / 1.11e9 pairs/s for 2 / 3 / 4)
-        switch (a.unroll ? (int)a.unroll : 4) {
+        const size_t wsmem = merged_lds_bytes_e(MR_WIN_ROWS / 2, MR_WIN_ENTRIES, MR_WIN_BUCKETS);
+        switch (a.unroll ? (int)a.unroll : 3) {
             case 2: return launch_merged_k<2, true>(a, ntiles, wsmem, stream);
             case 3: return launch_merged_k<3, true>(a, ntiles, wsmem, stream);
             default: return launch_merged_k<4, true>(a, ntiles, wsmem, stream);

@@ -1132,27 +1132,65 @@ static int stage_tiles(mg_ctx *ctx, const void *tiles, size_t bytes, void **dev_
     return MG_OK;
 }
 
-// Value windows of one density class (large sketches, see run_compare_merged): the window width
-// delta (prefix domain) is taken from the class's densest row so that 16 rows' share of a window
-// fills the tile table; the plan stands only if, by the actual offsets, every tile's share of every
-// window fits -- else a narrower second try, else no plan (the class uses plain tiles).
+// Value windows of one density class (see run_compare_merged): the window width delta (prefix
+// domain) is taken from the class's densest row so that it has `target` hashes per window, and the
+// rows are then cut into tiles greedily by their ACTUAL window offsets: a tile takes rows (in
+// order) while it has fewer than the kernel's row limit and its share of every window fits the
+// tile table.  The plan stands only if no row has more hashes in a window than a tag can index --
+// else a narrower second try, else no plan (the class uses plain tiles).
 struct WindowPlan {
     const mg_table::Windows *rows = nullptr, *cols = nullptr;
     uint32_t delta = 0, nwin = 0;
+    std::vector<std::pair<uint32_t, uint32_t>> groups;    // tiles: [first, last) positions in the class's row list
 };
+
+// Hashes of the densest row per window.  A pair of unrelated sketches is decided once the union of
+// the two reaches s elements, i.e. after ~0.5 s hashes of either (0.537 s covers the spread of
+// that point over a tile's pairs); cost per pair ~ windows until then x (hashes + fixed cost per
+// window and column) / rows per tile, rows = what fits the tile table.
+static double window_target(uint32_t s, uint32_t rows_max)
+{
+    const double need = 0.537 * (double)s, fixed = 150.0;
+    const double row_cap = (double)mg::compare_window_row_entries() * 0.45, ecap = (double)mg::compare_window_entries();
+    double best = 0, best_cost = 1e300;
+    for (int m = 1; m <= 255; m++) {
+        const double tw = std::ceil(need / m);
+        if (tw > row_cap) continue;
+        const double rows = std::min((double)rows_max, std::floor(0.97 * ecap / tw));
+        if (rows < 1) continue;
+        const double cost = m * (tw + fixed) / rows;
+        if (cost < best_cost) { best_cost = cost; best = tw; }
+        if (tw <= 64) break;
+    }
+    return best > 0 ? best : std::min(row_cap, need);
+}
 
 // `must`: the sketches are too large for plain tiles (s > 16 384), so a class that would be served
 // by one window (few hashes, or none) still gets a plan -- of that single window.
 static int plan_windows(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, const std::vector<uint32_t> &list, int shr,
                         uint64_t xmax, uint32_t s, bool must, WindowPlan *out)
 {
-    const uint32_t Rw = mg::compare_window_rows();
-    double target = 0.8 * mg::compare_window_entries() / Rw;                // entries of the densest row per window
+    const uint32_t Rw = mg::compare_window_rows(s);
+    double target = window_target(s, Rw);                                    // entries of the densest row per window
     if (const char *e = getenv("MASHGPU_COMPARE_WIN_TARGET")) target = std::max(1.0, atof(e));
-    double dens = 0;                                                         // hashes per unit of prefix, densest row
-    for (uint32_t i : list) {
-        const uint64_t ni = std::min<uint64_t>(rows->nh[i], s);
-        if (ni) dens = std::max(dens, (double)ni / ((double)(rows->last[i] >> shr) + 1.0));
+    // Hashes per unit of prefix of a row at the class's 10th percentile: rows at least that dense
+    // (90 % of them) have `target` hashes or more in a window, so their pairs are decided where the
+    // target says.  (Taken from the DENSEST row, typical rows fell a few per cent short of it and one
+    // pair in six stayed open after the first window -- every column then ran twice.)  What a tile
+    // holds is decided below from the actual offsets, whatever the density of its rows.
+    double dens = 0;
+    {
+        std::vector<double> d;
+        d.reserve(list.size());
+        for (uint32_t i : list) {
+            const uint64_t ni = std::min<uint64_t>(rows->nh[i], s);
+            if (ni) d.push_back((double)ni / ((double)(rows->last[i] >> shr) + 1.0));
+        }
+        if (!d.empty()) {
+            const size_t q = d.size() / 10;
+            std::nth_element(d.begin(), d.begin() + (long)q, d.end());
+            dens = d[q];
+        }
     }
     if (dens <= 0 && !must) return MG_OK;
     for (int attempt = 0; attempt < 2; attempt++, target *= 0.7) {
@@ -1170,19 +1208,26 @@ static int plan_windows(mg_ctx *ctx, const mg_table *rows, const mg_table *cols,
         int rc = table_windows(ctx, rows, shr, delta, nwin, s, &cand);
         if (rc != MG_OK) return rc;
         bool fits = true;
-        for (size_t k = 0; k < list.size() && fits; k += Rw) {
-            for (uint32_t w = 0; w < nwin && fits; w++) {
-                uint64_t tot = 0;
-                for (size_t r = k; r < std::min(list.size(), k + Rw); r++) {
-                    const uint32_t *o = &cand->host[(uint64_t)list[r] * (nwin + 1) + w];
-                    const uint32_t c = o[1] - o[0];
-                    if (c > 4095) fits = false;                              // the tag's index field
-                    tot += c;
-                }
-                if (tot > mg::compare_window_entries()) fits = false;
+        std::vector<std::pair<uint32_t, uint32_t>> groups;
+        std::vector<uint32_t> tot(nwin, 0);
+        uint32_t g0 = 0;
+        for (uint32_t k = 0; k < list.size() && fits; k++) {
+            const uint32_t *o = &cand->host[(uint64_t)list[k] * (nwin + 1)];
+            bool room = k - g0 < Rw;
+            for (uint32_t w = 0; w < nwin; w++) {
+                const uint32_t c = o[w + 1] - o[w];
+                if (c > mg::compare_window_row_entries()) fits = false;      // the tag's index field
+                if (tot[w] + c > mg::compare_window_entries()) room = false;
             }
+            if (!room) {                                                     // row k opens the next tile
+                groups.emplace_back(g0, k);
+                g0 = k;
+                std::fill(tot.begin(), tot.end(), 0u);
+            }
+            for (uint32_t w = 0; w < nwin; w++) tot[w] += o[w + 1] - o[w];
         }
         if (!fits) continue;
+        if (g0 < list.size()) groups.emplace_back(g0, (uint32_t)list.size());
         const mg_table::Windows *wc = nullptr;
         rc = table_windows(ctx, cols, shr, delta, nwin, s, &wc);
         if (rc != MG_OK) return rc;
@@ -1190,6 +1235,7 @@ static int plan_windows(mg_ctx *ctx, const mg_table *rows, const mg_table *cols,
         out->cols = wc;
         out->delta = delta;
         out->nwin = nwin;
+        out->groups.swap(groups);
         return MG_OK;
     }
     return MG_OK;
@@ -1222,10 +1268,13 @@ static int run_compare_merged(mg_ctx *ctx, const mg_table *rows, const mg_table 
     // a launch handles the hashes of one prefix range, sized so that 16 rows' share of it fills
     // the tile table; a pair carries its match count from launch to launch in its output slot
     // and drops out once its union reaches s (see compare_merged.hip, WIN).
-    bool want_win = R <= 8;                                 // s >= ~1800: measured gain from 1.2x (s = 2000) to 3.8x (s = 10 000)
+    // Smaller sketches use the same mode with TWO windows or so: unrelated pairs are decided by the
+    // lower half of the hash range (the union of two sketches reaches s elements there), so the
+    // first window holds ~0.54 s hashes of a row and 29 rows share a tile -- and a probe -- instead
+    // of 16; the few pairs still open (related sketches) go on to the next window.
+    bool want_win = a.s >= 200;
     if (const char *e = getenv("MASHGPU_COMPARE_WINDOWS")) want_win = atoi(e) != 0;
     if (windows_only) want_win = true;
-    const uint32_t Rw = mg::compare_window_rows();
     const uint32_t R_plain = R;
     // A launch of few row tiles (a handful of queries against a large database, or a small
     // density class) would leave most CUs idle with full-length column chunks: cut the columns
@@ -1288,17 +1337,21 @@ static int run_compare_merged(mg_ctx *ctx, const mg_table *rows, const mg_table 
         }
         const mg_table::Windows *wr = plan.rows, *wc = plan.cols;
         const uint32_t delta = plan.delta, nwin = plan.nwin;
-        const uint32_t Rc = wr ? Rw : R_plain;                               // rows per tile of this class
-        a.rows_per_tile = Rc;
-        const uint64_t CCc = chunk_for((list.size() + Rc - 1) / Rc);
+        // rows of a tile: positions [first, last) of the class's list -- the window plan's groups, or R at a time
+        std::vector<std::pair<uint32_t, uint32_t>> plain_groups;
+        if (!wr)
+            for (size_t k = 0; k < list.size(); k += R_plain) plain_groups.emplace_back((uint32_t)k, (uint32_t)std::min(list.size(), k + R_plain));
+        const std::vector<std::pair<uint32_t, uint32_t>> &groups = wr ? plan.groups : plain_groups;
+        a.rows_per_tile = wr ? mg::compare_window_rows(a.s) : R_plain;
+        const uint64_t CCc = chunk_for(groups.size());
         std::vector<mg::MergedTile> mtiles;
         for (uint64_t c0 = 0; c0 < maxcols; c0 += CCc) {
-            for (size_t k = 0; k < list.size(); k += Rc) {
-                const uint32_t last = list[std::min(list.size(), k + Rc) - 1];
+            for (const auto &g : groups) {
+                const uint32_t last = list[g.second - 1];
                 const uint64_t cend = triangle ? last : cols->n;         // columns needed: [0, cend)
                 if (c0 >= cend) continue;
                 mg::MergedTile tl;
-                for (uint32_t r = 0; r < 16; r++) tl.rows[r] = (r < Rc && k + r < list.size()) ? list[k + r] : 0xFFFFFFFFu;
+                for (uint32_t r = 0; r < 32; r++) tl.rows[r] = g.first + r < g.second ? list[g.first + r] : 0xFFFFFFFFu;
                 tl.col0 = (uint32_t)c0;
                 tl.col1 = (uint32_t)std::min<uint64_t>(c0 + CCc, cend);
                 mtiles.push_back(tl);

@@ -289,7 +289,10 @@ def _set_kernel(monkeypatch, kernel):
     """Select the compare engine.  "windows": the merged kernel in value-window mode (the
     large-sketch path) forced on whatever the sketch size, with a small window target so that even
     short sketches are cut into many windows and pairs are carried from launch to launch."""
-    if kernel.startswith("windows"):
+    if kernel == "plain":                      # merged kernel, whole rows in the tile table (no value windows)
+        monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", "merged")
+        monkeypatch.setenv("MASHGPU_COMPARE_WINDOWS", "0")
+    elif kernel.startswith("windows"):
         monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", "merged")
         monkeypatch.setenv("MASHGPU_COMPARE_WINDOWS", "1")
         if kernel != "windows":
@@ -303,7 +306,7 @@ def _oracle_tri(oracle, table, nhash, lengths, rb, re, k=21, kspace=KSPACE21):
     return numer, denom
 
 
-@pytest.mark.parametrize("kernel", ["merged", "tiled", "generic", "pairs"])
+@pytest.mark.parametrize("kernel", ["merged", "plain", "tiled", "generic", "pairs"])
 def test_compare_reference_run_vectors(eng, golden_dir, kernel, monkeypatch):
     _set_kernel(monkeypatch, kernel)
     z = np.load(os.path.join(golden_dir, "ref_compare_vectors.npz"))
@@ -318,7 +321,7 @@ def test_compare_reference_run_vectors(eng, golden_dir, kernel, monkeypatch):
     t.free()
 
 
-@pytest.mark.parametrize("kernel", ["merged", "generic", "pairs", "windows", "windows150", "windows7"])
+@pytest.mark.parametrize("kernel", ["merged", "plain", "generic", "pairs", "windows", "windows150", "windows7"])
 def test_compare_large_reference_run_vectors(eng, golden_dir, kernel, monkeypatch):
     """Counts produced by the reference's own objects at s = 3000: the default path there is the
     value-window mode; forced window sizes, the merge-path and the generic kernel must agree."""
@@ -335,7 +338,7 @@ def test_compare_large_reference_run_vectors(eng, golden_dir, kernel, monkeypatc
     t.free()
 
 
-@pytest.mark.parametrize("kernel", ["merged", "tiled", "pairs", "windows29"])
+@pytest.mark.parametrize("kernel", ["merged", "plain", "tiled", "pairs", "windows29"])
 @pytest.mark.parametrize("s", [1, 7, 64, 65, 100, 400, 1000, 1024])
 def test_compare_tiled_vs_oracle_sizes(eng, oracle, s, kernel, monkeypatch):
     _set_kernel(monkeypatch, kernel)
@@ -360,7 +363,7 @@ def test_compare_tiled_vs_oracle_sizes(eng, oracle, s, kernel, monkeypatch):
     t.free()
 
 
-@pytest.mark.parametrize("kernel", ["merged", "generic", "windows", "windows150"])
+@pytest.mark.parametrize("kernel", ["merged", "plain", "generic", "windows", "windows150"])
 @pytest.mark.parametrize("s", [1500, 4096, 10000])
 def test_compare_large_sketch(eng, oracle, s, kernel, monkeypatch):
     """Config-5 sized sketches (s = 10000): merged-rows kernel with few rows per tile, and the
@@ -447,7 +450,7 @@ def test_compare_extremes_and_random(eng, oracle):
     t.free()
 
 
-@pytest.mark.parametrize("kernel", ["merged", "tiled", "pairs", "windows61"])
+@pytest.mark.parametrize("kernel", ["merged", "plain", "tiled", "pairs", "windows61"])
 @pytest.mark.parametrize("top", [0xFFFFFFFF, 0xFFFFFFFFFFFFFFFE, 0xFFFFFFFE00000000])
 def test_compare_values_at_the_top_of_the_hash_range(eng, oracle, kernel, top, monkeypatch):
     """32-bit sketches reaching 0xFFFFFFFF / 64-bit sketches reaching 2^64-2: the prefix image
@@ -477,7 +480,7 @@ def test_compare_values_at_the_top_of_the_hash_range(eng, oracle, kernel, top, m
     t.free()
 
 
-@pytest.mark.parametrize("kernel", ["merged", "tiled", "pairs", "windows90"])
+@pytest.mark.parametrize("kernel", ["merged", "plain", "tiled", "pairs", "windows90"])
 def test_compare_mixed_hash_densities(eng, oracle, kernel, monkeypatch):
     """Sketches of very different genome sizes in one table (hash ranges from 2^44 to 2^64):
     the merged kernel tiles rows by density class and compares every class through its own
@@ -521,7 +524,7 @@ def test_compare_mixed_hash_densities(eng, oracle, kernel, monkeypatch):
     t.free(); tq.free()
 
 
-@pytest.mark.parametrize("kernel", ["merged", "pairs", "windows13", "windows200"])
+@pytest.mark.parametrize("kernel", ["merged", "plain", "pairs", "windows13", "windows200"])
 @pytest.mark.parametrize("seed", range(24))
 def test_compare_random_tables_vs_oracle(eng, oracle, seed, kernel, monkeypatch):
     """Randomised tables: any sketch size, ragged / empty / identical rows, values shared between
@@ -578,7 +581,71 @@ def test_compare_random_tables_vs_oracle(eng, oracle, seed, kernel, monkeypatch)
     t.free()
 
 
-@pytest.mark.parametrize("kernel", ["merged", "tiled", "pairs", "windows40"])
+@pytest.mark.parametrize("kernel", ["merged", "plain", "windows100", "windows333"])
+@pytest.mark.parametrize("s,n,seed", [(1000, 150, 0), (300, 260, 1), (2000, 90, 2), (1000, 40, 3)])
+def test_compare_wide_window_tiles(eng, oracle, s, n, seed, kernel, monkeypatch):
+    """Window tiles list up to 32 rows of ONE density class (the default engine for s >= 200: two
+    windows or so, pairs decided exactly at the end of a window's part).  Rows of equal density,
+    with everything that stresses the carried state: clusters of related rows (consecutive AND
+    interleaved), identical rows, short rows, a value shared by every row, rows that are subsets of
+    others -- triangle and rect against the oracle, bit for bit."""
+    _set_kernel(monkeypatch, kernel)
+    rng = np.random.default_rng(77 + seed)
+    top = np.uint64(1) << np.uint64(54)
+    table = np.full((n, s), np.uint64(0xFFFFFFFFFFFFFFFF), dtype=np.uint64)
+    nhash = np.zeros(n, dtype=np.uint32)
+    nclu = 5
+    pools = [rng.integers(1, 2 ** 63, 2 * s).astype(np.uint64) % top for _ in range(nclu)]
+    everywhere = np.uint64(int(top) // 3)
+    for i in range(n):
+        u = rng.random()
+        c = (i // 12) % nclu if i < n // 2 else i % nclu             # consecutive runs, then interleaved
+        own = rng.integers(1, 2 ** 63, 2 * s).astype(np.uint64) % top
+        if u < 0.05 and i > 0:
+            j = int(rng.integers(0, i))
+            table[i], nhash[i] = table[j], nhash[j]                   # identical to an earlier row
+            continue
+        if u < 0.45:
+            keep = pools[c][rng.random(2 * s) < rng.choice([0.3, 0.7, 0.95])]
+            vals = np.concatenate([keep, own[: s // 2]])
+        else:
+            vals = own
+        vals = np.unique(np.concatenate([vals, [everywhere]]))
+        # equal density: keep the values below a common bound (about s of them), not the s smallest
+        bound = np.uint64(int(top) * min(1.0, s / len(vals)))
+        vals = vals[vals < bound][:s]
+        if u > 0.93:
+            vals = vals[: int(rng.integers(1, len(vals) + 1))]        # short row (a prefix: same density)
+        if 0.88 < u <= 0.93 and i > 0:
+            j = int(rng.integers(0, i))
+            vals = table[j, : nhash[j]][rng.random(int(nhash[j])) < 0.5]   # subset of an earlier row
+        table[i, : len(vals)] = vals
+        nhash[i] = len(vals)
+    lengths = rng.integers(10 ** 5, 10 ** 7, n).astype(np.uint64)
+    t = eng.table_upload(table, nhash, lengths)
+    numer, denom = _oracle_tri(oracle, table, nhash, lengths, 0, n)
+    got = eng.compare_tri_host(t)
+    bad = np.flatnonzero((got["numer"] != numer) | (got["denom"] != denom))
+    assert bad.size == 0, (kernel, s, n, bad[:5], got[bad[:5]], numer[bad[:5]], denom[bad[:5]])
+    lo = n // 3
+    g2 = eng.compare_tri_host(t, lo, n - 5)
+    n2, d2 = _oracle_tri(oracle, table, nhash, lengths, lo, n - 5)
+    assert np.array_equal(g2["numer"], n2) and np.array_equal(g2["denom"], d2)
+    q = np.sort(rng.choice(n, size=min(n, 37), replace=False))
+    tq = eng.table_upload(table[q], nhash[q], lengths[q])
+    rect = eng.compare_rect_host(t, tq)
+    for a_, qi in enumerate(q):
+        for r in range(n):
+            i, j = max(qi, r), min(qi, r)
+            if i == j:
+                continue
+            idx = i * (i - 1) // 2 + j
+            assert (rect["numer"][a_, r], rect["denom"][a_, r]) == (numer[idx], denom[idx]), (kernel, qi, r)
+    tq.free()
+    t.free()
+
+
+@pytest.mark.parametrize("kernel", ["merged", "plain", "tiled", "pairs", "windows40"])
 @pytest.mark.parametrize("seed", range(6))
 def test_compare_values_sharing_a_prefix(eng, oracle, kernel, seed, monkeypatch):
     """Different 64-bit values that share their 32-bit prefix, inside one row, across rows of a
