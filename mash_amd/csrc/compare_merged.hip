@@ -353,7 +353,8 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
     // ------------------------------------------------------------------ stream columns
     const uint32_t my_n = WIN ? (lane < 32 ? s_rowlen[lane] : 0) : (lane < 32 ? hdr->row_n[lane] : 0);   // row `lane`
     // WIN: index in row `lane` of its first hash at or above the window's end
-    const uint32_t my_pend = WIN && lane < 32 ? s_rowlo[lane] + hdr->row_n[lane] : 0u;
+    const uint32_t my_lo = WIN && lane < 32 ? s_rowlo[lane] : 0u;
+    const uint32_t my_pend = WIN && lane < 32 ? my_lo + hdr->row_n[lane] : 0u;
     const uint32_t my_id = lane < 32 ? hdr->row_id[lane] : 0xFFFFFFFFu;     // table row of slot `lane`
     const uint32_t *my_row = a.row_pfx + (uint64_t)(my_id != 0xFFFFFFFFu ? my_id : hdr->row_id[0]) * a.row_pfx_stride;
 
@@ -639,7 +640,10 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
                         for (int r = 0; r < (int)MAXR; r++) {
                             if (!((rows_any >> r) & 1u)) continue;       // uniform
                             const bool mt = (rowmask >> r) & 1u;
-                            const uint32_t idx = ((pk[r >> 1] >> ((r & 1) * 16)) & 0xFFFFu) + lo_of((uint32_t)r);
+                            // (row r's window start comes from lane r's register: indexing s_rowlo with the unrolled r
+                            //  makes the compiler keep all 32 of them in VGPRs across the column loop)
+                            const uint32_t idx = ((pk[r >> 1] >> ((r & 1) * 16)) & 0xFFFFu) +
+                                                 (WIN ? (uint32_t)__builtin_amdgcn_readlane((int)my_lo, r) : 0u);
                             uint32_t c_all = (uint32_t)__builtin_amdgcn_readlane((int)st_call, r);
                             uint32_t common = (uint32_t)__builtin_amdgcn_readlane((int)st_common, r);
                             const uint64_t mm = __ballot(mt);

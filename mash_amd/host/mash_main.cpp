@@ -6,8 +6,9 @@
 // CommandInfo.cpp:40-299, CommandPaste.cpp:30-89, Command.cpp:165-200,311-347,
 // sketchParameterSetup.cpp:15-125, Sketch.cpp:105-253).  All hashing / selection /
 // comparison runs on the GPU through libmashgpu; there is no CPU fallback.
-// Not built (the reference's reads-mode noise filters are order dependent):
-// -m >= 2, -b, -c.
+// Reads mode: -r, -m <copies>, -c <coverage>, -g, -M (exact, see mg_params::min_copies and
+// mg_sketch_reads_host).  Not built: -b (the reference builds its Bloom filter with a false-positive
+// probability of 0, whose geometry is undefined behaviour).
 #include <unistd.h>
 
 #include <algorithm>
@@ -361,6 +362,19 @@ void flush_batch(Gpu &gpu, SketchSet &set, PendingBatch &b)
 }
 
 const uint64_t kBatchBytes = 2ull << 30;
+// ... and once it holds this many hash slots (sketches x sketch size): the hash, count and
+// first-position arrays of a batch are n*s*8 + n*s*4 + n*s*8 bytes on the host and again on the
+// device, so a file of a million short records at -s 10000 must not become one batch (the
+// reference streams such a file in constant memory)
+const uint64_t kBatchHashes = 1ull << 27;
+static bool batch_full(const PendingBatch &b, uint64_t sketch_size)
+{
+    static const uint64_t cap = [] {                       // MASH_AMD_BATCH_HASHES: test knob
+        const char *e = getenv("MASH_AMD_BATCH_HASHES");
+        return e ? std::max<uint64_t>(1, strtoull(e, nullptr, 10)) : kBatchHashes;
+    }();
+    return b.bases.size() > kBatchBytes || (uint64_t)b.refs.size() * sketch_size > cap;
+}
 
 // sketchFile in concatenated mode for ONE file (Sketch.cpp:1147-1336), non-reads: the host half
 // (kseq parse, name/comment/length) -- runs on a worker thread with -p > 1, like the reference's
@@ -408,7 +422,7 @@ void queue_parsed_file(Gpu &gpu, SketchSet &set, PendingBatch &b, ParsedFile &&p
     if (!pf.error.empty()) { cerr << pf.error << endl; exit(1); }
     b.bases.insert(b.bases.end(), pf.bases.begin(), pf.bases.end());
     b.end_sketch(std::move(pf.ref));
-    if (b.bases.size() > kBatchBytes) flush_batch(gpu, set, b);
+    if (batch_full(b, set.p.sketch_size)) flush_batch(gpu, set, b);
 }
 
 // sketchFileBySequence (Sketch.cpp:326-370): one sketch per record
@@ -426,7 +440,7 @@ void queue_file_by_sequence(Gpu &gpu, SketchSet &set, PendingBatch &b, const str
         ref.length = (uint64_t)l;
         b.add_record(rec.seq);
         b.end_sketch(std::move(ref));
-        if (b.bases.size() > kBatchBytes) flush_batch(gpu, set, b);
+        if (batch_full(b, set.p.sketch_size)) flush_batch(gpu, set, b);
     }
     if (l != -1) { cerr << "\nERROR: reading " << file << "." << endl; exit(1); }
 }

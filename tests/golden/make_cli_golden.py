@@ -145,7 +145,17 @@ EXTRA = [
 ]
 
 
-UNCONFIRMED = set()        # names of cases not yet replayed on a GPU
+# Third batch: BASELINE.json config 5 exactly (k = 31, 64-bit hashes, s = 10 000: the NT = 1024 sketch
+# selector and the value-window compare path) through the CLI.
+C5 = [
+    ("c5_sketch_k31_s10000", [["sketch", "-k", "31", "-s", "10000", "-o", "c5", "g1.fa", "g3.fa", "g4.fa", "g2.fa"]], ["info", "-t", "c5.msh"]),
+    ("c5_triangle_k31_s10000", [], ["triangle", "-k", "31", "-s", "10000", "g1.fa", "g3.fa", "g4.fa", "g2.fa"]),
+    ("c5_dist_k31_s10000", [["sketch", "-k", "31", "-s", "10000", "-o", "c5", "g1.fa", "g3.fa", "g4.fa", "g2.fa"]], ["dist", "c5.msh", "c5.msh"]),
+    ("c5_dist_msh_vs_fasta", [["sketch", "-k", "31", "-s", "10000", "-o", "c5", "g1.fa", "g3.fa"]], ["dist", "-t", "c5.msh", "g4.fa", "g2.fa"]),
+]
+
+
+UNCONFIRMED = set()        # names of cases not yet replayed on a GPU (the C5 batch was confirmed in round 2)
 
 
 def main():
@@ -155,7 +165,7 @@ def main():
     os.makedirs(f"{OUT}/in")
     make_inputs(f"{OUT}/in")
     manifest = []
-    for name, setup, cmd in CASES + EXTRA:
+    for name, setup, cmd in CASES + EXTRA + C5:
         d = tempfile.mkdtemp(prefix="cligold_")
         for f in os.listdir(f"{OUT}/in"):
             shutil.copy(f"{OUT}/in/{f}", d)

@@ -438,6 +438,30 @@ def test_sketch_and_triangle_cli_vs_oracle(built, tmp_path, oracle):
 
 
 @pytest.mark.gpu
+def test_many_short_records_are_sketched_in_bounded_batches(built, tmp_path):
+    """`-i` over a file of many short records: batches are flushed by hash slots (sketches x
+    sketch size), not only by bytes, so memory stays bounded -- and the .msh does not depend on
+    where the batches end (MASH_AMD_BATCH_HASHES forces a flush every few sketches)."""
+    rng = np.random.default_rng(5)
+    recs = [b">r%d amplicon\n" % i + np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 600)].tobytes() + b"\n"
+            for i in range(300)]
+    fa = tmp_path / "amp.fa"
+    fa.write_bytes(b"".join(recs))
+    run("sketch", "-i", "-s", "500", "-o", str(tmp_path / "one"), str(fa))
+    run("sketch", "-i", "-s", "500", "-o", str(tmp_path / "many"), str(fa), env={"MASH_AMD_BATCH_HASHES": "3500"})
+    assert (tmp_path / "one.msh").read_bytes() == (tmp_path / "many.msh").read_bytes()
+    # concatenated mode over many small files takes the same cap
+    files = []
+    for i in range(12):
+        f = tmp_path / f"g{i}.fa"
+        f.write_bytes(recs[i])
+        files.append(str(f))
+    run("sketch", "-s", "500", "-o", str(tmp_path / "c1"), *files)
+    run("sketch", "-s", "500", "-o", str(tmp_path / "c2"), *files, env={"MASH_AMD_BATCH_HASHES": "1200"})
+    assert (tmp_path / "c1.msh").read_bytes() == (tmp_path / "c2.msh").read_bytes()
+
+
+@pytest.mark.gpu
 def test_parallel_ingest_keeps_input_order(built, tmp_path):
     """-p N parses files on worker threads; sketches come out in input order, byte-identical
     to the single-threaded run (ThreadPool delivers in submission order, ThreadPool.hxx:127-167)."""

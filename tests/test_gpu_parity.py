@@ -283,6 +283,49 @@ def test_sketch_c2_genomes_full_size(eng, oracle):
     assert np.array_equal(hs[2], union)
 
 
+def test_config5_k31_s10000_sketch_and_triangle(eng, oracle):
+    """BASELINE.json configs[4] exactly: k = 31 (64-bit hashes, 15-byte murmur tail), s = 10 000 --
+    the NT = 1024 selector of sketch_chunks_kernel<31, 0, 1024, *> with its multi-pass bitonic
+    merge, then the value-window compare path at s = 10 000 -- on three adversarial inputs, two
+    synthetic 1 Mbp genomes and three relatives of them (so that pairs share thousands of hashes),
+    against the oracle: hashes, multiplicities, numer/denom, distances bit for bit."""
+    rng = np.random.default_rng(31_10000)
+    g0 = synth.synthetic_genome(0, 1_000_000)
+    g1 = synth.synthetic_genome(1, 1_000_000)
+
+    def mutated(g, rate):
+        a = g.copy()
+        idx = np.flatnonzero(rng.random(len(a)) < rate)
+        a[idx] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, len(idx))]
+        return a
+
+    sketches = [synth.adversarial_dna_records(rng, v) for v in (0, 2, 3)]
+    sketches += [[bytes(g0)], [bytes(g1)], [bytes(mutated(g0, 0.01))], [bytes(mutated(g0, 0.08))],
+                 [bytes(synth.robust_variant(g1, 1))], [bytes(g1[:400_000]), bytes(g0[:300_000])]]
+    kw = dict(k=31, s=10000)
+    p, op = eng.params(**kw), oracle.params(**kw)
+    assert p.use64 == 1
+    hashes, nhash, counts = eng.sketch_host(sketches, p, counts=True)
+    lengths = np.zeros(len(sketches), dtype=np.uint64)
+    for i, recs in enumerate(sketches):
+        h, c, _, _, _ = oracle.sketch_records(list(recs), op)
+        assert nhash[i] == len(h) and np.array_equal(hashes[i, : len(h)], h), i
+        assert np.array_equal(counts[i, : len(h)], c), i
+        lengths[i] = sum(len(r) for r in recs)
+    assert int(nhash[3]) == 10000 and int(nhash[4]) == 10000
+    t = eng.table_upload(hashes, nhash, lengths)
+    got = eng.compare_tri_host(t)
+    n = len(sketches)
+    numer, denom, dist, pval = oracle.triangle(hashes, nhash, lengths, 0, n, 31, 4.0 ** 31, stats=True)
+    assert np.array_equal(got["numer"], numer) and np.array_equal(got["denom"], denom)
+    assert int(got["numer"].max()) > 3000                              # the relatives really share hashes
+    fin = eng.finish_tri(got, lengths, 0, n, 31, 4.0 ** 31)
+    assert np.array_equal(fin["distance"], dist)
+    big = pval > 1e-290
+    assert np.all(np.abs(fin["p_value"][big] - pval[big]) <= 1e-9 * pval[big]) and np.all(fin["p_value"][~big] <= 1e-280)
+    t.free()
+
+
 # ---------------------------------------------------------------- comparing
 
 def _set_kernel(monkeypatch, kernel):
@@ -316,8 +359,11 @@ def test_compare_reference_run_vectors(eng, golden_dir, kernel, monkeypatch):
     assert np.array_equal(got["denom"], z["denom"])
     fin = eng.finish_tri(got, z["lengths"], 0, 64, int(z["k"]), float(z["kmer_space"]))
     assert np.array_equal(fin["distance"], z["dist"])
+    # (vectors made through the oracle's log-space tail: 1e-9 relative is ITS accuracy; the product's
+    # own bar -- 1 ulp of the exact tail, denormals and zeros included -- is tests/test_pvalue_exact.py)
     nz = z["pval"] > 1e-290
     assert np.all(np.abs(fin["p_value"][nz] - z["pval"][nz]) <= 1e-9 * z["pval"][nz])
+    assert np.all(fin["p_value"][~nz] <= 1e-280)
     t.free()
 
 
@@ -333,8 +379,11 @@ def test_compare_large_reference_run_vectors(eng, golden_dir, kernel, monkeypatc
     assert np.array_equal(got["denom"], z["denom"])
     fin = eng.finish_tri(got, z["lengths"], 0, 16, int(z["k"]), float(z["kmer_space"]))
     assert np.array_equal(fin["distance"], z["dist"])
+    # (vectors made through the oracle's log-space tail: 1e-9 relative is ITS accuracy; the product's
+    # own bar -- 1 ulp of the exact tail, denormals and zeros included -- is tests/test_pvalue_exact.py)
     nz = z["pval"] > 1e-290
     assert np.all(np.abs(fin["p_value"][nz] - z["pval"][nz]) <= 1e-9 * z["pval"][nz])
+    assert np.all(fin["p_value"][~nz] <= 1e-280)
     t.free()
 
 
