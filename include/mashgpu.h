@@ -194,10 +194,94 @@ int mg_finish_tri_host(const mg_counts *counts, const uint64_t *lengths, uint64_
 int mg_finish_rect_host(const mg_counts *counts, const uint64_t *len_ref, uint64_t nref,
                         const uint64_t *len_qry, uint64_t nqry, int kmer_size, double kmer_space,
                         double max_distance, double max_p_value, mg_pair *out);
+/* The same tail ON THE DEVICE (finish.hip): distances from a table the host builds with its libm
+ * (one row per denominator that occurs), p-values by the exact double-double binomial tail of
+ * pvalue.h -- both bit-identical to mg_finish_*_host -- and both filters before anything crosses
+ * PCIe.  `t` / `ref`,`qry` supply Reference::length by index (the tables must carry lengths).
+ * max_distance < 0 or >= 1 and max_p_value < 0 or >= 1 disable the respective filter.
+ *   mg_finish_*_dev          counts (device, layout of mg_compare_*_dev) -> mg_pair (device)
+ *   mg_compare_*_pairs_host  compare + finish, every pair, 32 B per pair to the host
+ *   mg_compare_*_results_host compare + both filters + ordered compaction: survivors only, in
+ *                            reference order; capacity / *count_out / MG_ERR_NOMEM as for
+ *                            mg_compare_*_filter_host.  This is what `mash dist -d/-v` and
+ *                            `mash triangle -E` print (CommandDistance.cpp:247-304). */
+typedef struct mg_result { uint32_t row, col, numer, denom; double distance, p_value; } mg_result;
+int mg_finish_tri_dev(mg_ctx *ctx, const mg_table *t, const mg_counts *counts_dev, uint64_t row_begin,
+                      uint64_t row_end, int kmer_size, double kmer_space, double max_distance,
+                      double max_p_value, mg_pair *out_dev);
+int mg_finish_rect_dev(mg_ctx *ctx, const mg_table *ref, const mg_table *qry, const mg_counts *counts_dev,
+                       uint64_t q_begin, uint64_t q_end, int kmer_size, double kmer_space,
+                       double max_distance, double max_p_value, mg_pair *out_dev);
+int mg_compare_tri_pairs_host(mg_ctx *ctx, const mg_table *t, uint64_t row_begin, uint64_t row_end,
+                              int kmer_size, double kmer_space, double max_distance, double max_p_value,
+                              mg_pair *out_host);
+int mg_compare_rect_pairs_host(mg_ctx *ctx, const mg_table *ref, const mg_table *qry, uint64_t q_begin,
+                               uint64_t q_end, int kmer_size, double kmer_space, double max_distance,
+                               double max_p_value, mg_pair *out_host);
+int mg_compare_tri_results_host(mg_ctx *ctx, const mg_table *t, uint64_t row_begin, uint64_t row_end,
+                                int kmer_size, double kmer_space, double max_distance, double max_p_value,
+                                mg_result *out_host, uint64_t capacity, uint64_t *count_out);
+int mg_compare_rect_results_host(mg_ctx *ctx, const mg_table *ref, const mg_table *qry, uint64_t q_begin,
+                                 uint64_t q_end, int kmer_size, double kmer_space, double max_distance,
+                                 double max_p_value, mg_result *out_host, uint64_t capacity,
+                                 uint64_t *count_out);
 /* Scalar helpers (same arithmetic as the bulk calls). */
 double mg_distance(uint32_t numer, uint32_t denom, int kmer_size);
 double mg_p_value(uint64_t x, uint64_t len_ref, uint64_t len_qry, double kmer_space,
                   uint64_t sketch_size);
+
+/* ---- several GPUs ---------------------------------------------------------------------
+ * Replaces the fan-out loops of the reference's compare commands (one ThreadPool job per row,
+ * CommandTriangle.cpp:129-139; per block of pairs, CommandDistance.cpp:195-232): every pair is
+ * independent, so rows (triangle) / queries (dist) are cut into one block per GPU against a
+ * sketch table resident on EVERY GPU.  The one exchange is the broadcast of that table from GPU 0
+ * (RCCL, xGMI); the compare data path has no collective and each GPU writes its own slice of
+ * the reference-ordered output.
+ *
+ * local communicator : one process drives all GPUs (the `mash` CLI) -- a context per device,
+ *                      ncclCommInitAll; mg_dtable = a table replicated on every device;
+ *                      mg_compare_*_sharded_host = the single-GPU call of the same name, rows
+ *                      split into equal-AREA blocks (triangle) or evenly (rect), one host thread
+ *                      per GPU, output byte-identical to the single-GPU call.
+ * rank communicator  : one process per GPU (bench.py under torchrun) -- ncclCommInitRank on
+ *                      128 bytes from mg_comm_unique_id that the caller hands to every rank;
+ *                      mg_table_broadcast, then each rank compares the rows mg_shard_tri_rows
+ *                      gives it with the ordinary mg_compare_*_dev.
+ * A device list that repeats a device (tests on a one-GPU box) exchanges by device copies. */
+typedef struct mg_comm   mg_comm;
+typedef struct mg_dtable mg_dtable;
+int      mg_comm_create_local(const int *devices, int n, mg_comm **out);
+int      mg_comm_unique_id(void *id_out, size_t id_bytes);                 /* >= 128 bytes */
+int      mg_comm_create_rank(mg_ctx *ctx, const void *id, size_t id_bytes, int nranks, int rank, mg_comm **out);
+void     mg_comm_destroy(mg_comm *c);
+int      mg_comm_size(const mg_comm *c);
+int      mg_comm_rank(const mg_comm *c);
+int      mg_comm_uses_rccl(const mg_comm *c);                              /* 0: one device / repeated devices */
+mg_ctx  *mg_comm_ctx(mg_comm *c, int i);                                   /* local: context of device i */
+const char *mg_comm_last_error(mg_comm *c);
+/* rows [row_begin,row_end) of the lower triangle -> block of `rank`: equal numbers of pairs */
+void     mg_shard_tri_rows(uint64_t row_begin, uint64_t row_end, int nranks, int rank, uint64_t *b_out, uint64_t *e_out);
+void     mg_shard_rows(uint64_t row_begin, uint64_t row_end, int nranks, int rank, uint64_t *b_out, uint64_t *e_out);
+int      mg_dtable_upload(mg_comm *c, const uint64_t *hashes, const uint32_t *nhash, const uint64_t *lengths,
+                          uint64_t n, uint64_t s, mg_dtable **out);         /* host -> GPU 0 -> broadcast */
+void     mg_dtable_free(mg_dtable *d);
+mg_table *mg_dtable_local(mg_dtable *d, int i);
+int      mg_table_broadcast(mg_comm *c, const mg_table *src, int root, uint64_t n, uint64_t s, mg_table **out);
+int      mg_comm_allreduce_u32_sum(mg_comm *c, uint32_t *buf_dev, uint64_t count);
+int mg_compare_tri_sharded_host(mg_comm *c, const mg_dtable *t, uint64_t row_begin, uint64_t row_end, mg_counts *out_host);
+int mg_compare_rect_sharded_host(mg_comm *c, const mg_dtable *ref, const mg_dtable *qry, uint64_t q_begin, uint64_t q_end,
+                                 mg_counts *out_host);
+int mg_compare_tri_pairs_sharded_host(mg_comm *c, const mg_dtable *t, uint64_t row_begin, uint64_t row_end, int kmer_size,
+                                      double kmer_space, double max_distance, double max_p_value, mg_pair *out_host);
+int mg_compare_rect_pairs_sharded_host(mg_comm *c, const mg_dtable *ref, const mg_dtable *qry, uint64_t q_begin,
+                                       uint64_t q_end, int kmer_size, double kmer_space, double max_distance,
+                                       double max_p_value, mg_pair *out_host);
+int mg_compare_tri_results_sharded_host(mg_comm *c, const mg_dtable *t, uint64_t row_begin, uint64_t row_end, int kmer_size,
+                                        double kmer_space, double max_distance, double max_p_value, mg_result *out_host,
+                                        uint64_t capacity, uint64_t *count_out);
+int mg_compare_rect_results_sharded_host(mg_comm *c, const mg_dtable *ref, const mg_dtable *qry, uint64_t q_begin,
+                                         uint64_t q_end, int kmer_size, double kmer_space, double max_distance,
+                                         double max_p_value, mg_result *out_host, uint64_t capacity, uint64_t *count_out);
 
 /* ---- screening (containment of sketches in a mixture) -----------------------------
  * Replaces, for nucleotide query sketches, the data-parallel part of `mash screen`:

@@ -27,6 +27,8 @@ EXPORTS = [
     "mg_compare_tri_dev", "mg_compare_tri_host", "mg_compare_rect_dev", "mg_compare_rect_host",
     "mg_compare_tri_filter_host", "mg_compare_rect_filter_host",
     "mg_finish_tri_host", "mg_finish_rect_host", "mg_distance", "mg_p_value",
+    "mg_finish_tri_dev", "mg_finish_rect_dev", "mg_compare_tri_pairs_host", "mg_compare_rect_pairs_host",
+    "mg_compare_tri_results_host", "mg_compare_rect_results_host",
     "mg_prof_enable", "mg_prof_reset", "mg_prof_avg_ms",
     "mg_screen_create", "mg_screen_create_translated", "mg_screen_add_host", "mg_screen_add_dev", "mg_screen_finish_host", "mg_screen_counts_dev", "mg_screen_free",
     "mg_identity", "mg_p_value_within",
@@ -64,6 +66,8 @@ PAIR_DTYPE = np.dtype([("numer", "<u4"), ("denom", "<u4"), ("distance", "<f8"), 
                        ("pass", "u1"), ("_pad", "u1", 7)])
 COUNTS_DTYPE = np.dtype([("numer", "<u4"), ("denom", "<u4")])
 EDGE_DTYPE = np.dtype([("row", "<u4"), ("col", "<u4"), ("numer", "<u4"), ("denom", "<u4")])
+RESULT_DTYPE = np.dtype([("row", "<u4"), ("col", "<u4"), ("numer", "<u4"), ("denom", "<u4"),
+                         ("distance", "<f8"), ("p_value", "<f8")])
 
 
 class ScreenSession:
@@ -154,6 +158,12 @@ def load_library():
     lib.mg_compare_rect_filter_host.argtypes = [vp, vp, vp, u64, u64, C.c_int, C.c_double, vp, u64, vp]
     lib.mg_finish_tri_host.argtypes = [vp, vp, u64, u64, i32, dbl, dbl, dbl, vp]
     lib.mg_finish_rect_host.argtypes = [vp, vp, u64, vp, u64, i32, dbl, dbl, dbl, vp]
+    lib.mg_finish_tri_dev.argtypes = [vp, vp, vp, u64, u64, i32, dbl, dbl, dbl, vp]
+    lib.mg_finish_rect_dev.argtypes = [vp, vp, vp, vp, u64, u64, i32, dbl, dbl, dbl, vp]
+    lib.mg_compare_tri_pairs_host.argtypes = [vp, vp, u64, u64, i32, dbl, dbl, dbl, vp]
+    lib.mg_compare_rect_pairs_host.argtypes = [vp, vp, vp, u64, u64, i32, dbl, dbl, dbl, vp]
+    lib.mg_compare_tri_results_host.argtypes = [vp, vp, u64, u64, i32, dbl, dbl, dbl, vp, u64, vp]
+    lib.mg_compare_rect_results_host.argtypes = [vp, vp, vp, u64, u64, i32, dbl, dbl, dbl, vp, u64, vp]
     lib.mg_distance.argtypes = [u32, u32, i32]
     lib.mg_distance.restype = dbl
     lib.mg_p_value.argtypes = [u64, u64, u64, dbl, u64]
@@ -330,11 +340,11 @@ class MashGpu:
     def compare_rect_dev(self, ref, qry, q_begin, q_end, out_ptr):
         self._check(self.lib.mg_compare_rect_dev(self.ctx, ref.handle, qry.handle, q_begin, q_end, out_ptr))
 
-    def _filter(self, call, capacity):
-        """run a *_filter_host call, growing the edge buffer once if the first guess was too small"""
+    def _filter(self, call, capacity, dtype=EDGE_DTYPE):
+        """run a *_filter_host / *_results_host call, growing the buffer once if the first guess was too small"""
         n = C.c_uint64(0)
         for _ in range(2):
-            out = np.zeros(max(int(capacity), 1), dtype=EDGE_DTYPE)
+            out = np.zeros(max(int(capacity), 1), dtype=dtype)
             rc = call(out.ctypes.data, int(capacity), C.byref(n))
             if rc == MG_OK:
                 return out[:n.value]
@@ -353,6 +363,39 @@ class MashGpu:
         q_end = qry.rows if q_end is None else min(q_end, qry.rows)
         return self._filter(lambda o, c, n: self.lib.mg_compare_rect_filter_host(
             self.ctx, ref.handle, qry.handle, q_begin, q_end, k, max_d, o, c, n), capacity)
+
+    # ---- compare + finish on the device ---------------------------------------------
+    def compare_tri_pairs(self, table, k, kmer_space, max_d=-1.0, max_p=-1.0, row_begin=0, row_end=None):
+        """every pair of rows [row_begin,row_end) x earlier rows as PairOutput records (device finish)"""
+        row_end = table.rows if row_end is None else min(row_end, table.rows)
+        out = np.zeros(tri_pairs(row_begin, row_end), dtype=PAIR_DTYPE)
+        self._check(self.lib.mg_compare_tri_pairs_host(self.ctx, table.handle, row_begin, row_end, k, kmer_space,
+                                                       max_d, max_p, out.ctypes.data))
+        return out
+
+    def compare_rect_pairs(self, ref, qry, k, kmer_space, max_d=-1.0, max_p=-1.0, q_begin=0, q_end=None):
+        q_end = qry.rows if q_end is None else min(q_end, qry.rows)
+        out = np.zeros((q_end - q_begin, ref.rows), dtype=PAIR_DTYPE)
+        self._check(self.lib.mg_compare_rect_pairs_host(self.ctx, ref.handle, qry.handle, q_begin, q_end, k, kmer_space,
+                                                        max_d, max_p, out.ctypes.data))
+        return out
+
+    def compare_tri_results(self, table, k, kmer_space, max_d=-1.0, max_p=-1.0, row_begin=0, row_end=None,
+                            capacity=1 << 20):
+        """survivors of both filters with distance and p-value, reference order (all on the device)"""
+        row_end = table.rows if row_end is None else min(row_end, table.rows)
+        return self._filter(lambda o, c, n: self.lib.mg_compare_tri_results_host(
+            self.ctx, table.handle, row_begin, row_end, k, kmer_space, max_d, max_p, o, c, n), capacity, RESULT_DTYPE)
+
+    def compare_rect_results(self, ref, qry, k, kmer_space, max_d=-1.0, max_p=-1.0, q_begin=0, q_end=None,
+                             capacity=1 << 20):
+        q_end = qry.rows if q_end is None else min(q_end, qry.rows)
+        return self._filter(lambda o, c, n: self.lib.mg_compare_rect_results_host(
+            self.ctx, ref.handle, qry.handle, q_begin, q_end, k, kmer_space, max_d, max_p, o, c, n), capacity, RESULT_DTYPE)
+
+    def finish_tri_dev(self, table, counts_ptr, row_begin, row_end, k, kmer_space, max_d, max_p, out_ptr):
+        self._check(self.lib.mg_finish_tri_dev(self.ctx, table.handle, counts_ptr, row_begin, row_end, k, kmer_space,
+                                               max_d, max_p, out_ptr))
 
     # ---- finishing (host arithmetic) --------------------------------------------
     def finish_tri(self, counts, lengths, row_begin, row_end, k, kmer_space, max_d=-1.0, max_p=-1.0):

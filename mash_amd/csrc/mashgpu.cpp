@@ -1,11 +1,13 @@
 // mashgpu.cpp — the C ABI (include/mashgpu.h) over the gfx950 kernels.
 // Host-side orchestration only: work lists, device buffers, launches, error strings.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <cmath>
 #include <iterator>
 #include <map>
+#include <mutex>
 #include <queue>
 #include <cstdio>
 #include <cstdlib>
@@ -16,6 +18,7 @@
 
 #include "../../include/mashgpu.h"
 #include "compare_internal.h"
+#include "finish_internal.h"
 #include "pvalue.h"
 #include "screen_internal.h"
 #include "sketch_internal.h"
@@ -1824,6 +1827,740 @@ int mg_compare_rect_filter_host(mg_ctx *ctx, const mg_table *ref, const mg_table
     if (!ref || !qry || !count_out || (!out_host && capacity))
         return fail(ctx, MG_ERR_INVALID, "mg_compare_rect_filter_host: NULL argument");
     return compare_filter(ctx, qry, ref, q_begin, q_end, false, kmer_size, max_distance, out_host, capacity, count_out);
+}
+
+/* ------------------------------------------------- device tail of compareSketches */
+
+static_assert(sizeof(mg_pair) == sizeof(mg::FinishPair) && sizeof(mg_result) == sizeof(mg::FinishEdge), "ABI structs");
+
+// What the device finish needs besides the counts: the distance table (host libm, one row per
+// denominator flagged in `seen`, row s always) and the integer form of the distance filter.
+struct FinishTables {
+    DevBuf<uint32_t> d_start, d_min;
+    DevBuf<double> d_lut;
+    bool complete = true;                   // false: some flagged denominator did not fit the budget (device yields NaN)
+    explicit FinishTables(mg_ctx *c) : d_start(c), d_min(c), d_lut(c) {}
+};
+
+static int build_finish_tables(mg_ctx *ctx, uint32_t s, int k, double max_d, const std::vector<uint32_t> &seen, FinishTables &ft)
+{
+    const uint64_t budget = 1ull << 26;                       // doubles (512 MiB): every denominator up to s = 11 583
+    std::vector<uint32_t> start((size_t)s + 1, 0xFFFFFFFFu);
+    std::vector<double> lut;
+    auto add_row = [&](uint32_t d) {
+        if (start[d] != 0xFFFFFFFFu) return;
+        if (lut.size() + (uint64_t)d + 1 > budget || lut.size() + (uint64_t)d + 1 > 0xFFFFFFF0ull) { ft.complete = false; return; }
+        start[d] = (uint32_t)lut.size();
+        for (uint32_t x = 0; x <= d; x++) lut.push_back(mg::mash_distance(x, d, k));
+    };
+    add_row(s);
+    for (uint32_t d = 0; d <= s && d < seen.size(); d++)
+        if (seen[d]) add_row(d);
+    HIP_TRY(ctx, ft.d_start.alloc(start.size()));
+    HIP_TRY(ctx, ft.d_lut.alloc(lut.size()));
+    HIP_TRY(ctx, hipMemcpyAsync(ft.d_start, start.data(), start.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ft.d_lut, lut.data(), lut.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (max_d >= 0 && max_d < 1.0) {
+        std::vector<uint32_t> mn;
+        build_min_numer(s, k, max_d, mn);
+        HIP_TRY(ctx, ft.d_min.alloc(mn.size()));
+        HIP_TRY(ctx, hipMemcpyAsync(ft.d_min, mn.data(), mn.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));          // the host vectors go out of scope
+    return MG_OK;
+}
+
+// counts (device) of `pairs` pairs starting at row `first_row` -> mg_pair (device)
+static int finish_pairs_dev(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, const mg_counts *counts_dev, uint64_t pairs,
+                            uint64_t first_row, bool triangle, int kmer_size, double kmer_space, double max_d, double max_p,
+                            mg_pair *out_dev, bool *complete_out)
+{
+    if (pairs == 0) return MG_OK;
+    if (!rows->lengths || !cols->lengths) return fail(ctx, MG_ERR_INVALID, "finish: the tables carry no lengths");
+    if (kmer_size < 1) return fail(ctx, MG_ERR_INVALID, "finish: bad k-mer size");
+    const uint64_t s64 = std::min(rows->s, cols->s);
+    if (s64 > 0xFFFFFFFEull) return fail(ctx, MG_ERR_INVALID, "finish: sketch size too large");
+    const uint32_t s = (uint32_t)s64;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf<uint32_t> d_seen(ctx);
+    HIP_TRY(ctx, d_seen.alloc((uint64_t)s + 1));
+    HIP_TRY(ctx, hipMemsetAsync(d_seen, 0, ((uint64_t)s + 1) * 4, ctx->stream));
+    HIP_TRY(ctx, mg::launch_denom_flags(reinterpret_cast<const uint2 *>(counts_dev), pairs, s, d_seen, ctx->stream));
+    std::vector<uint32_t> seen((size_t)s + 1);
+    HIP_TRY(ctx, hipMemcpyAsync(seen.data(), d_seen, seen.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    FinishTables ft(ctx);
+    int rc = build_finish_tables(ctx, s, kmer_size, max_d, seen, ft);
+    if (rc != MG_OK) return rc;
+    mg::FinishArgs a{};
+    a.counts = reinterpret_cast<const uint2 *>(counts_dev);
+    a.pairs = pairs;
+    a.first_row = first_row;
+    a.ncols = cols->n;
+    a.len_row = rows->lengths;
+    a.len_col = cols->lengths;
+    a.min_numer = ft.d_min;
+    a.lut_start = ft.d_start;
+    a.lut = ft.d_lut;
+    a.kmer_space = kmer_space;
+    a.max_p = max_p;
+    a.s = s;
+    a.triangle = triangle ? 1 : 0;
+    a.pairs_out = reinterpret_cast<mg::FinishPair *>(out_dev);
+    HIP_TRY(ctx, mg::launch_finish_pairs(a, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));          // the tables are released on return
+    if (complete_out) *complete_out = ft.complete;
+    else if (!ft.complete)
+        return fail(ctx, MG_ERR_UNSUPPORTED, "finish: too many distinct denominators for the device distance table (use mg_finish_*_host)");
+    return MG_OK;
+}
+
+int mg_finish_tri_dev(mg_ctx *ctx, const mg_table *t, const mg_counts *counts_dev, uint64_t row_begin, uint64_t row_end,
+                      int kmer_size, double kmer_space, double max_distance, double max_p_value, mg_pair *out_dev)
+{
+    if (!ctx) return MG_ERR_INVALID;
+    if (!t || !counts_dev || !out_dev) return fail(ctx, MG_ERR_INVALID, "mg_finish_tri_dev: NULL argument");
+    if (row_end > t->n) row_end = t->n;
+    if (row_begin >= row_end) return MG_OK;
+    return finish_pairs_dev(ctx, t, t, counts_dev, tri_pairs(row_begin, row_end), row_begin, true, kmer_size, kmer_space,
+                            max_distance, max_p_value, out_dev, nullptr);
+}
+
+int mg_finish_rect_dev(mg_ctx *ctx, const mg_table *ref, const mg_table *qry, const mg_counts *counts_dev, uint64_t q_begin,
+                       uint64_t q_end, int kmer_size, double kmer_space, double max_distance, double max_p_value,
+                       mg_pair *out_dev)
+{
+    if (!ctx) return MG_ERR_INVALID;
+    if (!ref || !qry || !counts_dev || !out_dev) return fail(ctx, MG_ERR_INVALID, "mg_finish_rect_dev: NULL argument");
+    if (q_end > qry->n) q_end = qry->n;
+    if (q_begin >= q_end) return MG_OK;
+    return finish_pairs_dev(ctx, qry, ref, counts_dev, (q_end - q_begin) * ref->n, q_begin, false, kmer_size, kmer_space,
+                            max_distance, max_p_value, out_dev, nullptr);
+}
+
+// compare + finish on the device, full PairOutput records to the host (32 B per pair), in row blocks
+static int compare_pairs_host(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, uint64_t rb, uint64_t re, bool triangle,
+                              int kmer_size, double kmer_space, double max_d, double max_p, mg_pair *out_host)
+{
+    if (re > rows->n) re = rows->n;
+    if (rb >= re) return MG_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint64_t max_pairs = 1ull << 26;                   // 2 GiB of records, 512 MiB of counts
+    DevBuf<mg_counts> d_counts(ctx);
+    DevBuf<mg_pair> d_pairs(ctx);
+    uint64_t cap = 0, done = 0, r = rb;
+    std::vector<uint64_t> len_rows, len_cols;                // host copies, only if a block must be patched
+    while (r < re) {
+        uint64_t r2 = r, pairs = 0;
+        while (r2 < re) {
+            const uint64_t add = triangle ? r2 : cols->n;
+            if (pairs && pairs + add > max_pairs) break;
+            pairs += add;
+            r2++;
+        }
+        if (pairs > cap) {
+            if (d_counts.p) { ctx_free(ctx, d_counts.release()); }
+            if (d_pairs.p) { ctx_free(ctx, d_pairs.release()); }
+            if (d_counts.alloc(pairs) != hipSuccess || d_pairs.alloc(pairs) != hipSuccess)
+                return fail(ctx, MG_ERR_NOMEM, "compare: device allocation failed");
+            cap = pairs;
+        }
+        int rc = pairs ? run_compare(ctx, rows, cols, r, r2, triangle, d_counts) : MG_OK;
+        if (rc != MG_OK) return rc;
+        bool complete = true;
+        if (pairs) {
+            rc = finish_pairs_dev(ctx, rows, cols, d_counts, pairs, r, triangle, kmer_size, kmer_space, max_d, max_p, d_pairs, &complete);
+            if (rc != MG_OK) return rc;
+            if (hipMemcpyAsync(out_host + done, d_pairs, pairs * sizeof(mg_pair), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess)
+                return fail(ctx, MG_ERR_HIP, "compare: D2H copy failed");
+            if (!complete) {
+                // a denominator beyond the device table's budget left NaN distances: those pairs are finished here
+                if (len_rows.empty()) {
+                    len_rows.resize(rows->n);
+                    len_cols.resize(cols->n);
+                    if (hipMemcpy(len_rows.data(), rows->lengths, rows->n * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+                        hipMemcpy(len_cols.data(), cols->lengths, cols->n * 8, hipMemcpyDeviceToHost) != hipSuccess)
+                        return fail(ctx, MG_ERR_HIP, "compare: D2H copy failed");
+                }
+                uint64_t idx = 0;
+                for (uint64_t i = r; i < r2; i++) {
+                    const uint64_t ncol = triangle ? i : cols->n;
+                    for (uint64_t j = 0; j < ncol; j++, idx++) {
+                        mg_pair &pr = out_host[done + idx];
+                        if (pr.distance == pr.distance) continue;
+                        const mg_counts c{pr.numer, pr.denom};
+                        finish_one(c, len_rows[i], len_cols[j], kmer_size, kmer_space, max_d, max_p, &pr);
+                    }
+                }
+            }
+        }
+        done += pairs;
+        r = r2;
+    }
+    return MG_OK;
+}
+
+int mg_compare_tri_pairs_host(mg_ctx *ctx, const mg_table *t, uint64_t row_begin, uint64_t row_end, int kmer_size,
+                              double kmer_space, double max_distance, double max_p_value, mg_pair *out_host)
+{
+    if (!ctx) return MG_ERR_INVALID;
+    if (!t || !out_host) return fail(ctx, MG_ERR_INVALID, "mg_compare_tri_pairs_host: NULL argument");
+    if (!t->lengths) return fail(ctx, MG_ERR_INVALID, "mg_compare_tri_pairs_host: the table carries no lengths");
+    return compare_pairs_host(ctx, t, t, row_begin, row_end, true, kmer_size, kmer_space, max_distance, max_p_value, out_host);
+}
+
+int mg_compare_rect_pairs_host(mg_ctx *ctx, const mg_table *ref, const mg_table *qry, uint64_t q_begin, uint64_t q_end,
+                               int kmer_size, double kmer_space, double max_distance, double max_p_value, mg_pair *out_host)
+{
+    if (!ctx) return MG_ERR_INVALID;
+    if (!ref || !qry || !out_host) return fail(ctx, MG_ERR_INVALID, "mg_compare_rect_pairs_host: NULL argument");
+    if (!ref->lengths || !qry->lengths) return fail(ctx, MG_ERR_INVALID, "mg_compare_rect_pairs_host: the tables carry no lengths");
+    return compare_pairs_host(ctx, qry, ref, q_begin, q_end, false, kmer_size, kmer_space, max_distance, max_p_value, out_host);
+}
+
+// compare + both filters + compaction on the device: survivors only, as full records, in reference order
+static int compare_results(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, uint64_t rb, uint64_t re, bool triangle,
+                           int kmer_size, double kmer_space, double max_d, double max_p, mg_result *out_host, uint64_t capacity,
+                           uint64_t *count_out)
+{
+    *count_out = 0;
+    if (re > rows->n) re = rows->n;
+    if (rb >= re) return MG_OK;
+    if (kmer_size < 1) return fail(ctx, MG_ERR_INVALID, "compare: bad k-mer size");
+    const uint64_t s64 = std::min(rows->s, cols->s);
+    if (s64 > 0xFFFFFFFEull) return fail(ctx, MG_ERR_INVALID, "compare: sketch size too large");
+    const uint32_t s = (uint32_t)s64;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint64_t max_pairs = 1ull << 30, window = 1ull << 25;
+    const uint64_t all_pairs = triangle ? tri_pairs(rb, re) : (re - rb) * cols->n;
+    if (all_pairs == 0) return MG_OK;
+    const uint64_t blk_pairs = std::min(all_pairs, max_pairs + (triangle ? re : cols->n));
+    DevBuf<mg_counts> d_counts;
+    DevBuf<mg::FinishEdge> d_edges;
+    DevBuf<unsigned long long> d_masks, d_sego, d_n;
+    DevBuf<uint32_t> d_segc, d_seen;
+    if (d_counts.alloc(blk_pairs) != hipSuccess || d_edges.alloc(std::min(blk_pairs, window)) != hipSuccess ||
+        d_masks.alloc(mg::finish_mask_words(blk_pairs)) != hipSuccess || d_segc.alloc(mg::finish_segments(blk_pairs)) != hipSuccess ||
+        d_sego.alloc(mg::finish_segments(blk_pairs)) != hipSuccess || d_n.alloc(1) != hipSuccess || d_seen.alloc((uint64_t)s + 1) != hipSuccess)
+        return fail(ctx, MG_ERR_NOMEM, "compare: device allocation failed");
+    // pass A needs the distance filter but no distances: tables without any extra denominator row
+    std::vector<uint32_t> seen((size_t)s + 1, 0);
+    uint64_t total = 0, r = rb;
+    std::vector<uint64_t> len_rows, len_cols;
+    while (r < re) {
+        uint64_t r2 = r, pairs = 0;
+        while (r2 < re) {
+            const uint64_t add = triangle ? r2 : cols->n;
+            if (pairs && pairs + add > max_pairs) break;
+            pairs += add;
+            r2++;
+        }
+        if (pairs) {
+            int rc = run_compare(ctx, rows, cols, r, r2, triangle, d_counts);
+            if (rc != MG_OK) return rc;
+            FinishTables fa(ctx);
+            std::fill(seen.begin(), seen.end(), 0u);
+            rc = build_finish_tables(ctx, s, kmer_size, max_d, seen, fa);
+            if (rc != MG_OK) return rc;
+            mg::FinishArgs a{};
+            a.counts = reinterpret_cast<const uint2 *>(d_counts.p);
+            a.pairs = pairs;
+            a.first_row = r;
+            a.ncols = cols->n;
+            a.len_row = rows->lengths;
+            a.len_col = cols->lengths;
+            a.min_numer = fa.d_min;
+            a.lut_start = fa.d_start;
+            a.lut = fa.d_lut;
+            a.kmer_space = kmer_space;
+            a.max_p = max_p;
+            a.s = s;
+            a.triangle = triangle ? 1 : 0;
+            a.masks = d_masks;
+            a.seg_count = d_segc;
+            a.seg_off = d_sego;
+            a.denom_seen = d_seen;
+            a.edges = d_edges;
+            unsigned long long n_blk = 0;
+            HIP_TRY(ctx, hipMemsetAsync(d_seen, 0, ((uint64_t)s + 1) * 4, ctx->stream));
+            HIP_TRY(ctx, mg::launch_finish_mark(a, d_n, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(&n_blk, d_n, 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(seen.data(), d_seen, seen.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (n_blk && total + n_blk <= capacity) {
+                FinishTables fb(ctx);                        // now with the rows of the survivors' denominators
+                rc = build_finish_tables(ctx, s, kmer_size, max_d, seen, fb);
+                if (rc != MG_OK) return rc;
+                a.lut_start = fb.d_start;
+                a.lut = fb.d_lut;
+                a.min_numer = fb.d_min;
+                for (uint64_t lo = 0; lo < n_blk; lo += window) {
+                    a.win_lo = lo;
+                    a.win_n = std::min<uint64_t>(window, n_blk - lo);
+                    HIP_TRY(ctx, mg::launch_finish_write(a, ctx->stream));
+                    HIP_TRY(ctx, hipMemcpyAsync(out_host + total + lo, d_edges, a.win_n * sizeof(mg_result), hipMemcpyDeviceToHost, ctx->stream));
+                    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                }
+                if (!fb.complete) {
+                    for (uint64_t i = 0; i < n_blk; i++) {
+                        mg_result &e = out_host[total + i];
+                        if (e.distance != e.distance) e.distance = mg::mash_distance(e.numer, e.denom, kmer_size);
+                    }
+                }
+            }
+            total += n_blk;
+        }
+        r = r2;
+    }
+    *count_out = total;
+    if (total > capacity) return fail(ctx, MG_ERR_NOMEM, "compare: more passing pairs than `capacity` (see *count_out)");
+    return MG_OK;
+}
+
+int mg_compare_tri_results_host(mg_ctx *ctx, const mg_table *t, uint64_t row_begin, uint64_t row_end, int kmer_size,
+                                double kmer_space, double max_distance, double max_p_value, mg_result *out_host,
+                                uint64_t capacity, uint64_t *count_out)
+{
+    if (!ctx) return MG_ERR_INVALID;
+    if (!t || !count_out || (!out_host && capacity)) return fail(ctx, MG_ERR_INVALID, "mg_compare_tri_results_host: NULL argument");
+    if (!t->lengths) return fail(ctx, MG_ERR_INVALID, "mg_compare_tri_results_host: the table carries no lengths");
+    return compare_results(ctx, t, t, row_begin, row_end, true, kmer_size, kmer_space, max_distance, max_p_value, out_host, capacity, count_out);
+}
+
+int mg_compare_rect_results_host(mg_ctx *ctx, const mg_table *ref, const mg_table *qry, uint64_t q_begin, uint64_t q_end,
+                                 int kmer_size, double kmer_space, double max_distance, double max_p_value, mg_result *out_host,
+                                 uint64_t capacity, uint64_t *count_out)
+{
+    if (!ctx) return MG_ERR_INVALID;
+    if (!ref || !qry || !count_out || (!out_host && capacity))
+        return fail(ctx, MG_ERR_INVALID, "mg_compare_rect_results_host: NULL argument");
+    if (!ref->lengths || !qry->lengths) return fail(ctx, MG_ERR_INVALID, "mg_compare_rect_results_host: the tables carry no lengths");
+    return compare_results(ctx, qry, ref, q_begin, q_end, false, kmer_size, kmer_space, max_distance, max_p_value, out_host, capacity, count_out);
+}
+
+/* ------------------------------------------------- several GPUs: communicator, replicated tables, row-block sharding */
+
+// every pair is independent, so the all-pairs matrix is cut into row blocks,
+// one per GPU, against a sketch table that is resident on every GPU.  The one exchange is the
+// BROADCAST of that table from GPU 0 (RCCL over xGMI); the compare data path has no collective.
+// Two shapes of the same thing:
+//   local : one process drives every GPU (the `mash` CLI): a context per device, ncclCommInitAll;
+//   rank  : one process per GPU (bench.py under torchrun): ncclCommInitRank on an id the caller
+//           hands round (128 bytes, any transport).
+struct mg_comm {
+    bool local = false;
+    int nranks = 1, rank = 0;                 // rank mode: this process; local mode: rank is unused
+    std::vector<mg_ctx *> ctxs;               // local: one per device, owned; rank: the caller's context
+    std::vector<ncclComm_t> comms;            // local: one per device; rank: one; empty = no RCCL (see below)
+    std::string err;
+};
+
+struct mg_dtable {
+    mg_comm *comm = nullptr;
+    std::vector<mg_table *> t;                // one replica per context of the communicator
+};
+
+static int comm_fail(mg_comm *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define NCCL_TRY(c, call)                                                             \
+    do {                                                                              \
+        ncclResult_t r__ = (call);                                                    \
+        if (r__ != ncclSuccess) return comm_fail((c), MG_ERR_HIP, std::string(#call) + ": " + ncclGetErrorString(r__)); \
+    } while (0)
+
+int mg_comm_create_local(const int *devices, int n, mg_comm **out)
+{
+    if (!out || !devices || n < 1) return comm_fail(nullptr, MG_ERR_INVALID, "mg_comm_create_local: bad argument");
+    mg_comm *c = new mg_comm;
+    c->local = true;
+    c->nranks = n;
+    bool distinct = true;
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < i; j++) distinct = distinct && devices[i] != devices[j];
+    for (int i = 0; i < n; i++) {
+        mg_ctx *x = nullptr;
+        const int rc = mg_ctx_create(devices[i], &x);
+        if (rc != MG_OK) { mg_comm_destroy(c); return rc; }          // g_create_error holds the text
+        c->ctxs.push_back(x);
+    }
+    // RCCL needs distinct devices; a list that repeats a device (tests on a one-GPU box: two
+    // contexts on one device) exchanges by plain device copies instead.  One device needs nothing,
+    // unless MASHGPU_COMM_FORCE_RCCL asks for the one-rank communicator (tests of the call path).
+    if (distinct && (n > 1 || getenv("MASHGPU_COMM_FORCE_RCCL"))) {
+        c->comms.resize((size_t)n);
+        const ncclResult_t r = ncclCommInitAll(c->comms.data(), n, devices);
+        if (r != ncclSuccess) {
+            c->comms.clear();
+            const std::string msg = std::string("ncclCommInitAll: ") + ncclGetErrorString(r);
+            mg_comm_destroy(c);
+            return comm_fail(nullptr, MG_ERR_HIP, msg);
+        }
+    }
+    *out = c;
+    return MG_OK;
+}
+
+int mg_comm_unique_id(void *id_out, size_t id_bytes)
+{
+    if (!id_out || id_bytes < sizeof(ncclUniqueId)) return comm_fail(nullptr, MG_ERR_INVALID, "mg_comm_unique_id: buffer too small (128 bytes)");
+    ncclUniqueId id;
+    const ncclResult_t r = ncclGetUniqueId(&id);
+    if (r != ncclSuccess) return comm_fail(nullptr, MG_ERR_HIP, std::string("ncclGetUniqueId: ") + ncclGetErrorString(r));
+    memcpy(id_out, &id, sizeof id);
+    return MG_OK;
+}
+
+int mg_comm_create_rank(mg_ctx *ctx, const void *id, size_t id_bytes, int nranks, int rank, mg_comm **out)
+{
+    if (!ctx || !out || !id || id_bytes < sizeof(ncclUniqueId) || nranks < 1 || rank < 0 || rank >= nranks)
+        return comm_fail(nullptr, MG_ERR_INVALID, "mg_comm_create_rank: bad argument");
+    if (hipSetDevice(ctx->device) != hipSuccess) return comm_fail(nullptr, MG_ERR_HIP, "mg_comm_create_rank: hipSetDevice failed");
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof uid);
+    ncclComm_t nc;
+    const ncclResult_t r = ncclCommInitRank(&nc, nranks, uid, rank);
+    if (r != ncclSuccess) return comm_fail(nullptr, MG_ERR_HIP, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+    mg_comm *c = new mg_comm;
+    c->local = false;
+    c->nranks = nranks;
+    c->rank = rank;
+    c->ctxs.push_back(ctx);
+    c->comms.push_back(nc);
+    *out = c;
+    return MG_OK;
+}
+
+void mg_comm_destroy(mg_comm *c)
+{
+    if (!c) return;
+    for (size_t i = 0; i < c->comms.size(); i++) {
+        hipSetDevice(c->ctxs[i]->device);
+        ncclCommDestroy(c->comms[i]);
+    }
+    if (c->local) for (mg_ctx *x : c->ctxs) mg_ctx_destroy(x);
+    delete c;
+}
+
+int mg_comm_size(const mg_comm *c) { return c ? c->nranks : 0; }
+int mg_comm_rank(const mg_comm *c) { return c ? c->rank : -1; }
+int mg_comm_uses_rccl(const mg_comm *c) { return c && !c->comms.empty() ? 1 : 0; }
+mg_ctx *mg_comm_ctx(mg_comm *c, int i) { return c && i >= 0 && (size_t)i < c->ctxs.size() ? c->ctxs[(size_t)i] : nullptr; }
+const char *mg_comm_last_error(mg_comm *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+// Equal-AREA row blocks of the lower triangle (row i holds i pairs): block g of G over rows
+// [row_begin, row_end) starts where g/G of the pairs lie behind -- boundaries go with sqrt(g/G).
+void mg_shard_tri_rows(uint64_t row_begin, uint64_t row_end, int nranks, int rank, uint64_t *b_out, uint64_t *e_out)
+{
+    auto boundary = [&](int g) -> uint64_t {
+        if (g <= 0) return row_begin;
+        if (g >= nranks) return row_end;
+        const long double total = (long double)tri_pairs(row_begin, row_end);
+        const long double want = total * g / nranks + (long double)tri_pairs(0, row_begin);
+        uint64_t r = (uint64_t)((1.0L + sqrtl(1.0L + 8.0L * want)) * 0.5L);
+        if (r < row_begin) r = row_begin;
+        if (r > row_end) r = row_end;
+        while (r > row_begin && (long double)tri_pairs(0, r) > want) r--;
+        while (r < row_end && (long double)tri_pairs(0, r + 1) <= want) r++;
+        return r;
+    };
+    if (b_out) *b_out = boundary(rank);
+    if (e_out) *e_out = boundary(rank + 1);
+}
+
+void mg_shard_rows(uint64_t row_begin, uint64_t row_end, int nranks, int rank, uint64_t *b_out, uint64_t *e_out)
+{
+    const uint64_t n = row_end > row_begin ? row_end - row_begin : 0;
+    if (b_out) *b_out = row_begin + n * (uint64_t)rank / (uint64_t)nranks;
+    if (e_out) *e_out = row_begin + n * (uint64_t)(rank + 1) / (uint64_t)nranks;
+}
+
+// src (root's buffers, device memory of context `root`) -> dst buffers on every context; count bytes
+static int comm_broadcast_bytes(mg_comm *c, int root, const std::vector<void *> &bufs, size_t bytes)
+{
+    if (bytes == 0) return MG_OK;
+    const size_t n = c->ctxs.size();
+    if (!c->comms.empty()) {
+        NCCL_TRY(c, ncclGroupStart());
+        for (size_t i = 0; i < n; i++) {
+            const ncclResult_t r = ncclBroadcast(bufs[(size_t)root], bufs[i], bytes, ncclUint8, root, c->comms[i], c->ctxs[i]->stream);
+            if (r != ncclSuccess) { ncclGroupEnd(); return comm_fail(c, MG_ERR_HIP, std::string("ncclBroadcast: ") + ncclGetErrorString(r)); }
+        }
+        NCCL_TRY(c, ncclGroupEnd());
+    } else {
+        for (size_t i = 0; i < n; i++) {
+            if ((int)i == root || bufs[i] == bufs[(size_t)root]) continue;
+            if (hipMemcpyPeerAsync(bufs[i], c->ctxs[i]->device, bufs[(size_t)root], c->ctxs[(size_t)root]->device, bytes,
+                                   c->ctxs[(size_t)root]->stream) != hipSuccess)
+                return comm_fail(c, MG_ERR_HIP, "table broadcast: device copy failed");
+        }
+    }
+    return MG_OK;
+}
+
+static int comm_sync_all(mg_comm *c)
+{
+    for (mg_ctx *x : c->ctxs) {
+        if (hipSetDevice(x->device) != hipSuccess || hipStreamSynchronize(x->stream) != hipSuccess)
+            return comm_fail(c, MG_ERR_HIP, "communicator: stream synchronisation failed");
+    }
+    return MG_OK;
+}
+
+int mg_dtable_upload(mg_comm *c, const uint64_t *hashes, const uint32_t *nhash, const uint64_t *lengths, uint64_t n,
+                     uint64_t s, mg_dtable **out)
+{
+    if (!c || !c->local || !out) return comm_fail(c, MG_ERR_INVALID, "mg_dtable_upload: needs a local communicator");
+    mg_dtable *d = new mg_dtable;
+    d->comm = c;
+    mg_table *t0 = nullptr;
+    int rc = mg_table_upload(c->ctxs[0], hashes, nhash, lengths, n, s, &t0);   // host -> GPU 0
+    if (rc != MG_OK) { c->err = c->ctxs[0]->err; delete d; return rc; }
+    d->t.push_back(t0);
+    const size_t G = c->ctxs.size();
+    std::vector<void *> bh{(void *)t0->hashes}, bn{(void *)t0->nhash}, bl{(void *)t0->lengths};
+    for (size_t i = 1; i < G; i++) {
+        mg_ctx *x = c->ctxs[i];
+        void *ph = nullptr, *pn = nullptr, *pl = nullptr;
+        if (hipSetDevice(x->device) != hipSuccess || hipMalloc(&ph, std::max<uint64_t>(n * s, 1) * 8) != hipSuccess ||
+            hipMalloc(&pn, std::max<uint64_t>(n, 1) * 4) != hipSuccess || hipMalloc(&pl, std::max<uint64_t>(n, 1) * 8) != hipSuccess) {
+            mg_dtable_free(d);
+            return comm_fail(c, MG_ERR_NOMEM, "mg_dtable_upload: device allocation failed");
+        }
+        mg_table *t = new mg_table;
+        t->ctx = x; t->hashes = (const uint64_t *)ph; t->nhash = (const uint32_t *)pn; t->lengths = (const uint64_t *)pl;
+        t->n = n; t->s = s; t->owns = true;
+        d->t.push_back(t);
+        bh.push_back(ph); bn.push_back(pn); bl.push_back(pl);
+    }
+    // GPU 0 -> every GPU: the one exchange of the all-pairs job
+    rc = comm_broadcast_bytes(c, 0, bh, n * s * 8);
+    if (rc == MG_OK) rc = comm_broadcast_bytes(c, 0, bn, n * 4);
+    if (rc == MG_OK) rc = comm_broadcast_bytes(c, 0, bl, n * 8);
+    if (rc == MG_OK) rc = comm_sync_all(c);
+    if (rc != MG_OK) { mg_dtable_free(d); return rc; }
+    *out = d;
+    return MG_OK;
+}
+
+void mg_dtable_free(mg_dtable *d)
+{
+    if (!d) return;
+    for (mg_table *t : d->t) mg_table_free(t);
+    delete d;
+}
+
+mg_table *mg_dtable_local(mg_dtable *d, int i) { return d && i >= 0 && (size_t)i < d->t.size() ? d->t[(size_t)i] : nullptr; }
+
+// rank mode: the root's table -> a table on every rank (the root gets a non-owning alias of `src`)
+int mg_table_broadcast(mg_comm *c, const mg_table *src, int root, uint64_t n, uint64_t s, mg_table **out)
+{
+    if (!c || c->local || !out || root < 0 || root >= c->nranks) return comm_fail(c, MG_ERR_INVALID, "mg_table_broadcast: needs a rank communicator");
+    mg_ctx *x = c->ctxs[0];
+    if (c->rank == root && (!src || src->n != n || src->s != s || !src->lengths))
+        return comm_fail(c, MG_ERR_INVALID, "mg_table_broadcast: the root must pass the table (with lengths) and its true size");
+    if (hipSetDevice(x->device) != hipSuccess) return comm_fail(c, MG_ERR_HIP, "hipSetDevice failed");
+    mg_table *t = new mg_table;
+    t->ctx = x; t->n = n; t->s = s;
+    if (c->rank == root) {
+        t->hashes = src->hashes; t->nhash = src->nhash; t->lengths = src->lengths; t->owns = false;
+    } else {
+        void *ph = nullptr, *pn = nullptr, *pl = nullptr;
+        if (hipMalloc(&ph, std::max<uint64_t>(n * s, 1) * 8) != hipSuccess || hipMalloc(&pn, std::max<uint64_t>(n, 1) * 4) != hipSuccess ||
+            hipMalloc(&pl, std::max<uint64_t>(n, 1) * 8) != hipSuccess) {
+            delete t;
+            return comm_fail(c, MG_ERR_NOMEM, "mg_table_broadcast: device allocation failed");
+        }
+        t->hashes = (const uint64_t *)ph; t->nhash = (const uint32_t *)pn; t->lengths = (const uint64_t *)pl; t->owns = true;
+    }
+    ncclResult_t r = ncclGroupStart();
+    if (r == ncclSuccess) r = ncclBroadcast(t->hashes, (void *)t->hashes, n * s * 8, ncclUint8, root, c->comms[0], x->stream);
+    if (r == ncclSuccess) r = ncclBroadcast(t->nhash, (void *)t->nhash, n * 4, ncclUint8, root, c->comms[0], x->stream);
+    if (r == ncclSuccess) r = ncclBroadcast(t->lengths, (void *)t->lengths, n * 8, ncclUint8, root, c->comms[0], x->stream);
+    const ncclResult_t r2 = ncclGroupEnd();
+    if (r == ncclSuccess) r = r2;
+    if (r != ncclSuccess || hipStreamSynchronize(x->stream) != hipSuccess) {
+        mg_table_free(t);
+        return comm_fail(c, MG_ERR_HIP, std::string("mg_table_broadcast: ") + (r != ncclSuccess ? ncclGetErrorString(r) : "stream error"));
+    }
+    *out = t;
+    return MG_OK;
+}
+
+// rank mode: element-wise sum of a u32 device buffer over all ranks (the counter exchange of a read-sharded screen)
+int mg_comm_allreduce_u32_sum(mg_comm *c, uint32_t *buf_dev, uint64_t count)
+{
+    if (!c || c->local || (!buf_dev && count)) return comm_fail(c, MG_ERR_INVALID, "mg_comm_allreduce_u32_sum: needs a rank communicator");
+    if (count == 0) return MG_OK;
+    mg_ctx *x = c->ctxs[0];
+    if (hipSetDevice(x->device) != hipSuccess) return comm_fail(c, MG_ERR_HIP, "hipSetDevice failed");
+    NCCL_TRY(c, ncclAllReduce(buf_dev, buf_dev, count, ncclUint32, ncclSum, c->comms[0], x->stream));
+    if (hipStreamSynchronize(x->stream) != hipSuccess) return comm_fail(c, MG_ERR_HIP, "mg_comm_allreduce_u32_sum: stream error");
+    return MG_OK;
+}
+
+// local mode: rows [rb, re) cut into one block per GPU, every GPU driven by its own host thread;
+// `fn(g, ctx, table replica(s), block begin, block end, pairs before the block)` does one block
+extern "C++" {
+template <class F>
+static int sharded_blocks(mg_comm *c, uint64_t rb, uint64_t re, bool triangle, uint64_t ncols, F fn)
+{
+    const int G = (int)c->ctxs.size();
+    std::vector<uint64_t> b((size_t)G + 1);
+    for (int g = 0; g <= G; g++) {
+        uint64_t lo, hi;
+        if (triangle) mg_shard_tri_rows(rb, re, G, std::min(g, G - 1), &lo, &hi);
+        else mg_shard_rows(rb, re, G, std::min(g, G - 1), &lo, &hi);
+        b[(size_t)g] = g < G ? lo : hi;
+    }
+    std::vector<int> rcs((size_t)G, MG_OK);
+    std::vector<std::thread> th;
+    for (int g = 0; g < G; g++) {
+        const uint64_t lo = b[(size_t)g], hi = b[(size_t)g + 1];
+        const uint64_t before = triangle ? tri_pairs(rb, lo) : (lo - rb) * ncols;
+        if (lo >= hi) continue;
+        if (G == 1) rcs[0] = fn(0, lo, hi, before);
+        else th.emplace_back([&, g, lo, hi, before]() { rcs[(size_t)g] = fn(g, lo, hi, before); });
+    }
+    for (auto &t : th) t.join();
+    for (int g = 0; g < G; g++)
+        if (rcs[(size_t)g] != MG_OK) { c->err = c->ctxs[(size_t)g]->err; return rcs[(size_t)g]; }
+    return MG_OK;
+}
+}  // extern "C++"
+
+static int dtable_check(mg_comm *c, const mg_dtable *t, const char *who)
+{
+    if (!c || !c->local || !t || t->comm != c || t->t.size() != c->ctxs.size())
+        return comm_fail(c, MG_ERR_INVALID, std::string(who) + ": needs a local communicator and tables uploaded through it");
+    return MG_OK;
+}
+
+int mg_compare_tri_sharded_host(mg_comm *c, const mg_dtable *t, uint64_t row_begin, uint64_t row_end, mg_counts *out_host)
+{
+    int rc = dtable_check(c, t, "mg_compare_tri_sharded_host");
+    if (rc != MG_OK) return rc;
+    if (row_end > t->t[0]->n) row_end = t->t[0]->n;
+    if (row_begin >= row_end) return MG_OK;
+    return sharded_blocks(c, row_begin, row_end, true, 0, [&](int g, uint64_t lo, uint64_t hi, uint64_t before) {
+        return mg_compare_tri_host(c->ctxs[(size_t)g], t->t[(size_t)g], lo, hi, out_host + before);
+    });
+}
+
+int mg_compare_rect_sharded_host(mg_comm *c, const mg_dtable *ref, const mg_dtable *qry, uint64_t q_begin, uint64_t q_end,
+                                 mg_counts *out_host)
+{
+    int rc = dtable_check(c, ref, "mg_compare_rect_sharded_host");
+    if (rc == MG_OK) rc = dtable_check(c, qry, "mg_compare_rect_sharded_host");
+    if (rc != MG_OK) return rc;
+    if (q_end > qry->t[0]->n) q_end = qry->t[0]->n;
+    if (q_begin >= q_end) return MG_OK;
+    const uint64_t nref = ref->t[0]->n;
+    return sharded_blocks(c, q_begin, q_end, false, nref, [&](int g, uint64_t lo, uint64_t hi, uint64_t before) {
+        return mg_compare_rect_host(c->ctxs[(size_t)g], ref->t[(size_t)g], qry->t[(size_t)g], lo, hi, out_host + before);
+    });
+}
+
+int mg_compare_tri_pairs_sharded_host(mg_comm *c, const mg_dtable *t, uint64_t row_begin, uint64_t row_end, int kmer_size,
+                                      double kmer_space, double max_distance, double max_p_value, mg_pair *out_host)
+{
+    int rc = dtable_check(c, t, "mg_compare_tri_pairs_sharded_host");
+    if (rc != MG_OK) return rc;
+    if (row_end > t->t[0]->n) row_end = t->t[0]->n;
+    if (row_begin >= row_end) return MG_OK;
+    return sharded_blocks(c, row_begin, row_end, true, 0, [&](int g, uint64_t lo, uint64_t hi, uint64_t before) {
+        return mg_compare_tri_pairs_host(c->ctxs[(size_t)g], t->t[(size_t)g], lo, hi, kmer_size, kmer_space, max_distance,
+                                         max_p_value, out_host + before);
+    });
+}
+
+int mg_compare_rect_pairs_sharded_host(mg_comm *c, const mg_dtable *ref, const mg_dtable *qry, uint64_t q_begin, uint64_t q_end,
+                                       int kmer_size, double kmer_space, double max_distance, double max_p_value,
+                                       mg_pair *out_host)
+{
+    int rc = dtable_check(c, ref, "mg_compare_rect_pairs_sharded_host");
+    if (rc == MG_OK) rc = dtable_check(c, qry, "mg_compare_rect_pairs_sharded_host");
+    if (rc != MG_OK) return rc;
+    if (q_end > qry->t[0]->n) q_end = qry->t[0]->n;
+    if (q_begin >= q_end) return MG_OK;
+    const uint64_t nref = ref->t[0]->n;
+    return sharded_blocks(c, q_begin, q_end, false, nref, [&](int g, uint64_t lo, uint64_t hi, uint64_t before) {
+        return mg_compare_rect_pairs_host(c->ctxs[(size_t)g], ref->t[(size_t)g], qry->t[(size_t)g], lo, hi, kmer_size, kmer_space,
+                                          max_distance, max_p_value, out_host + before);
+    });
+}
+
+// survivors of both filters: every GPU collects its block's list, the lists are joined in block (= reference) order
+extern "C++" {
+template <class Call>
+static int sharded_results(mg_comm *c, uint64_t rb, uint64_t re, bool triangle, uint64_t ncols, mg_result *out_host,
+                           uint64_t capacity, uint64_t *count_out, Call call)
+{
+    const size_t G = c->ctxs.size();
+    std::vector<std::vector<mg_result>> part(G);
+    const int rc = sharded_blocks(c, rb, re, triangle, ncols, [&](int g, uint64_t lo, uint64_t hi, uint64_t) {
+        std::vector<mg_result> &v = part[(size_t)g];
+        v.resize(1u << 16);
+        uint64_t n = 0;
+        int r = call(g, lo, hi, v.data(), (uint64_t)v.size(), &n);
+        if (r == MG_ERR_NOMEM && n > v.size()) {
+            v.resize(n);
+            r = call(g, lo, hi, v.data(), (uint64_t)v.size(), &n);
+        }
+        v.resize(r == MG_OK ? n : 0);
+        return r;
+    });
+    if (rc != MG_OK) return rc;
+    uint64_t total = 0;
+    for (auto &v : part) total += v.size();
+    *count_out = total;
+    if (total > capacity) return comm_fail(c, MG_ERR_NOMEM, "compare: more passing pairs than `capacity` (see *count_out)");
+    uint64_t at = 0;
+    for (auto &v : part) {
+        if (!v.empty()) memcpy(out_host + at, v.data(), v.size() * sizeof(mg_result));
+        at += v.size();
+    }
+    return MG_OK;
+}
+}  // extern "C++"
+
+int mg_compare_tri_results_sharded_host(mg_comm *c, const mg_dtable *t, uint64_t row_begin, uint64_t row_end, int kmer_size,
+                                        double kmer_space, double max_distance, double max_p_value, mg_result *out_host,
+                                        uint64_t capacity, uint64_t *count_out)
+{
+    int rc = dtable_check(c, t, "mg_compare_tri_results_sharded_host");
+    if (rc != MG_OK) return rc;
+    if (!count_out || (!out_host && capacity)) return comm_fail(c, MG_ERR_INVALID, "mg_compare_tri_results_sharded_host: NULL argument");
+    *count_out = 0;
+    if (row_end > t->t[0]->n) row_end = t->t[0]->n;
+    if (row_begin >= row_end) return MG_OK;
+    return sharded_results(c, row_begin, row_end, true, 0, out_host, capacity, count_out,
+                           [&](int g, uint64_t lo, uint64_t hi, mg_result *o, uint64_t cap, uint64_t *n) {
+        return mg_compare_tri_results_host(c->ctxs[(size_t)g], t->t[(size_t)g], lo, hi, kmer_size, kmer_space, max_distance,
+                                           max_p_value, o, cap, n);
+    });
+}
+
+int mg_compare_rect_results_sharded_host(mg_comm *c, const mg_dtable *ref, const mg_dtable *qry, uint64_t q_begin,
+                                         uint64_t q_end, int kmer_size, double kmer_space, double max_distance,
+                                         double max_p_value, mg_result *out_host, uint64_t capacity, uint64_t *count_out)
+{
+    int rc = dtable_check(c, ref, "mg_compare_rect_results_sharded_host");
+    if (rc == MG_OK) rc = dtable_check(c, qry, "mg_compare_rect_results_sharded_host");
+    if (rc != MG_OK) return rc;
+    if (!count_out || (!out_host && capacity)) return comm_fail(c, MG_ERR_INVALID, "mg_compare_rect_results_sharded_host: NULL argument");
+    *count_out = 0;
+    if (q_end > qry->t[0]->n) q_end = qry->t[0]->n;
+    if (q_begin >= q_end) return MG_OK;
+    return sharded_results(c, q_begin, q_end, false, ref->t[0]->n, out_host, capacity, count_out,
+                           [&](int g, uint64_t lo, uint64_t hi, mg_result *o, uint64_t cap, uint64_t *n) {
+        return mg_compare_rect_results_host(c->ctxs[(size_t)g], ref->t[(size_t)g], qry->t[(size_t)g], lo, hi, kmer_size, kmer_space,
+                                            max_distance, max_p_value, o, cap, n);
+    });
 }
 
 /* ------------------------------------------------------------------ screening */

@@ -892,10 +892,27 @@ void print_pair_line(FastOut &out, const Ref &ref, const Ref &qry, bool comment,
     out.eol();
 }
 
-// Thresholded runs (-d < 1): the distance filter and compaction run on the device
-// (mg_compare_*_filter_host) so only surviving pairs come back; the p-value filter
-// and the arithmetic of the survivors are the same host code as the full path.
-bool edge_filter_wanted(double d_max) { return d_max < 1.0 && !getenv("MASH_AMD_NO_FILTER"); }
+// Thresholded runs (-d < 1 or -v < 1): both filters of compareSketches, the distances and p-values
+// of the survivors and their compaction run on the device (mg_compare_*_results_host), so only
+// surviving pairs cross PCIe, as finished records; bit-identical to the host arithmetic
+// (MASH_AMD_NO_FILTER=1 takes the full-matrix path instead, MASH_AMD_HOST_FINISH=1 the host tail).
+bool edge_filter_wanted(double d_max, double p_max) { return (d_max < 1.0 || p_max < 1.0) && !getenv("MASH_AMD_NO_FILTER"); }
+bool host_finish_wanted() { return getenv("MASH_AMD_HOST_FINISH") != nullptr; }
+
+template <class Call>
+bool fetch_results(Gpu &gpu, vector<mg_result> &res, Call call)
+{
+    uint64_t n = 0;
+    if (res.size() < (1u << 16)) res.resize(1u << 16);
+    int rc = call(res.data(), (uint64_t)res.size(), &n);
+    if (rc == MG_ERR_NOMEM && n > res.size()) {
+        res.resize(n);
+        rc = call(res.data(), (uint64_t)res.size(), &n);
+    }
+    if (rc != MG_OK) { cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl; return false; }
+    res.resize(n);
+    return true;
+}
 
 template <class Call>
 bool fetch_edges(Gpu &gpu, vector<mg_edge> &edges, Call call)
@@ -989,11 +1006,24 @@ int cmd_dist(int argc, const char **argv)
     vector<mg_counts> counts;
     vector<mg_pair> pairs;
     FastOut out;
-    if (!table && edge_filter_wanted(d_max)) {
+    if (!table && edge_filter_wanted(d_max, p_max)) {
         vector<mg_edge> edges;
+        vector<mg_result> res;
         const uint64_t fblock = std::max<uint64_t>(1, (1ull << 30) / nref);
         for (uint64_t q0 = 0; q0 < nq; q0 += fblock) {
             const uint64_t q1 = std::min(nq, q0 + fblock);
+            if (!host_finish_wanted()) {
+                if (!fetch_results(gpu, res, [&](mg_result *o, uint64_t cap, uint64_t *n) {
+                        return mg_compare_rect_results_host(gpu.ctx, tr, tq, q0, q1, ref.p.kmer, kspace, d_max, p_max, o, cap, n); }))
+                    return 1;
+                emit_rows(out, 0, res.size(), [](uint64_t) { return 1; }, [&](FastOut &o, uint64_t x, unsigned) {
+                    const mg_result &e = res[x];
+                    mg_pair pr;
+                    pr.numer = e.numer; pr.denom = e.denom; pr.distance = e.distance; pr.p_value = e.p_value; pr.pass = 1;
+                    print_pair_line(o, ref.refs[e.col], qry.refs[e.row], comment, pr);
+                });
+                continue;
+            }
             if (!fetch_edges(gpu, edges, [&](mg_edge *o, uint64_t cap, uint64_t *n) {
                     return mg_compare_rect_filter_host(gpu.ctx, tr, tq, q0, q1, ref.p.kmer, d_max, o, cap, n); }))
                 return 1;
@@ -1019,8 +1049,17 @@ int cmd_dist(int argc, const char **argv)
     }
     for (uint64_t q0 = 0; q0 < nq; q0 += qblock) {
         const uint64_t q1 = std::min(nq, q0 + qblock);
-        counts.resize((q1 - q0) * nref);
-        if (mg_compare_rect_host(gpu.ctx, tr, tq, q0, q1, counts.data()) != MG_OK) { cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl; return 1; }
+        if (dist_lut.empty() && !host_finish_wanted()) {
+            // compare + distance + p-value + filters on the device, finished records back
+            pairs.resize((q1 - q0) * nref);
+            if (mg_compare_rect_pairs_host(gpu.ctx, tr, tq, q0, q1, ref.p.kmer, kspace, d_max, p_max, pairs.data()) != MG_OK) {
+                cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl;
+                return 1;
+            }
+        } else {
+            counts.resize((q1 - q0) * nref);
+            if (mg_compare_rect_host(gpu.ctx, tr, tq, q0, q1, counts.data()) != MG_OK) { cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl; return 1; }
+        }
         if (!dist_lut.empty()) {
             emit_rows(out, q0, q1, [&](uint64_t) { return nref; }, [&](FastOut &o, uint64_t q, unsigned) {
                 o << qry.refs[q].name;                            // writeOutput, CommandDistance.cpp:247-304
@@ -1035,8 +1074,10 @@ int cmd_dist(int argc, const char **argv)
             });
             continue;
         }
-        pairs.resize(counts.size());
-        mg_finish_rect_host(counts.data(), len_ref.data(), nref, len_qry.data() + q0, q1 - q0, ref.p.kmer, kspace, d_max, p_max, pairs.data());
+        if (host_finish_wanted()) {
+            pairs.resize(counts.size());
+            mg_finish_rect_host(counts.data(), len_ref.data(), nref, len_qry.data() + q0, q1 - q0, ref.p.kmer, kspace, d_max, p_max, pairs.data());
+        }
         emit_rows(out, q0, q1, [&](uint64_t) { return nref; }, [&](FastOut &o, uint64_t q, unsigned) {
             if (table) o << qry.refs[q].name;                // writeOutput, CommandDistance.cpp:247-304
             for (uint64_t r = 0; r < nref; r++) {
@@ -1100,11 +1141,27 @@ int cmd_triangle(int argc, const char **argv)
     uint64_t r0 = 1;
     StageClock clk;
     FastOut out;
-    if (edge && edge_filter_wanted(d_max)) {
+    if (edge && edge_filter_wanted(d_max, p_max)) {
         vector<mg_edge> edges;
+        vector<mg_result> res;
         while (r0 < n) {
             uint64_t r1 = r0, npairs = 0;
             while (r1 < n && (npairs == 0 || npairs + r1 <= (1ull << 31))) { npairs += r1; r1++; }
+            if (!host_finish_wanted()) {
+                if (!fetch_results(gpu, res, [&](mg_result *o, uint64_t cap, uint64_t *cnt) {
+                        return mg_compare_tri_results_host(gpu.ctx, t, r0, r1, set.p.kmer, kspace, d_max, p_max, o, cap, cnt); }))
+                    return 1;
+                clk.lap("compare+finish+filter+copy");
+                emit_rows(out, 0, res.size(), [](uint64_t) { return 1; }, [&](FastOut &o, uint64_t x, unsigned) {
+                    const mg_result &e = res[x];
+                    o << label(set.refs[e.row]) << '\t' << label(set.refs[e.col]) << '\t' << e.distance << '\t'
+                      << e.p_value << '\t' << e.numer << '/' << e.denom;
+                    o.eol();
+                });
+                clk.lap("format+write");
+                r0 = r1;
+                continue;
+            }
             if (!fetch_edges(gpu, edges, [&](mg_edge *o, uint64_t cap, uint64_t *cnt) {
                     return mg_compare_tri_filter_host(gpu.ctx, t, r0, r1, set.p.kmer, d_max, o, cap, cnt); }))
                 return 1;
@@ -1144,13 +1201,22 @@ int cmd_triangle(int argc, const char **argv)
     while (r0 < n) {
         uint64_t r1 = r0, npairs = 0;
         while (r1 < n && (npairs == 0 || npairs + r1 <= (1ull << 24))) { npairs += r1; r1++; }
-        counts.resize(npairs);
+        const bool dev_finish = !lean && !host_finish_wanted();
+        if (!dev_finish) counts.resize(npairs);
         if (!lean) pairs.resize(npairs);
         clk.lap("setup");
-        if (mg_compare_tri_host(gpu.ctx, t, r0, r1, counts.data()) != MG_OK) { cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl; return 1; }
-        clk.lap("compare+copy");
-        if (!lean) mg_finish_tri_host(counts.data(), lengths.data(), r0, r1, set.p.kmer, kspace, d_max, p_max, pairs.data());
-        clk.lap("finish");
+        if (dev_finish) {
+            if (mg_compare_tri_pairs_host(gpu.ctx, t, r0, r1, set.p.kmer, kspace, d_max, p_max, pairs.data()) != MG_OK) {
+                cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl;
+                return 1;
+            }
+            clk.lap("compare+finish+copy");
+        } else {
+            if (mg_compare_tri_host(gpu.ctx, t, r0, r1, counts.data()) != MG_OK) { cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl; return 1; }
+            clk.lap("compare+copy");
+            if (!lean) mg_finish_tri_host(counts.data(), lengths.data(), r0, r1, set.p.kmer, kspace, d_max, p_max, pairs.data());
+            clk.lap("finish");
+        }
         const uint64_t base = r0 * (r0 - 1) / 2;
         vector<double> peak(emit_threads(), 0.0);
         if (lean) {

@@ -433,6 +433,14 @@ def test_sketch_and_triangle_cli_vs_oracle(built, tmp_path, oracle):
             a = run(*cmd, cwd=tmp_path).stdout
             b = run(*cmd, cwd=tmp_path, env=nofilter).stdout
             assert a == b, cmd
+    # the device tail (distance table + exact p-value + both filters, finish.hip) prints what the host tail prints
+    hostfin = {"MASH_AMD_HOST_FINISH": "1"}
+    for cmd in (("triangle", "-E", "ind.msh"), ("triangle", "-E", "-v", "1e-5", "ind.msh"), ("triangle", "-E", "-d", "0.1", "-v", "1e-20", "ind.msh"),
+                ("dist", "ind.msh", "cat.msh"), ("dist", "-v", "1e-8", "ind.msh", "ind.msh"), ("dist", "-d", "0.3", "-v", "1e-3", "ind.msh", "cat.msh"),
+                ("dist", "-t", "-v", "1e-8", "ind.msh", "ind.msh")):
+        a = run(*cmd, cwd=tmp_path).stdout
+        b = run(*cmd, cwd=tmp_path, env=hostfin).stdout
+        assert a == b and (a or "-v" in cmd), cmd
     e0 = run("triangle", "-d", "0", "ind.msh", cwd=tmp_path).stdout.splitlines()
     assert len(e0) == 1 and e0[0].split("\t")[:3] == ["seq4", "seq0", "0"]
 

@@ -863,6 +863,64 @@ def test_compare_filter_edges(eng, oracle, s):
     t.free(); tq.free()
 
 
+def _same_bits(a, b):
+    return np.array_equal(np.asarray(a).view(np.uint64), np.asarray(b).view(np.uint64))
+
+
+@pytest.mark.parametrize("max_d,max_p", [(-1.0, -1.0), (1.0, 1.0), (0.2, -1.0), (-1.0, 1e-10), (0.08, 1e-30), (0.0, 1.0)])
+def test_device_finish_equals_host_finish(eng, oracle, golden_dir, max_d, max_p):
+    """The tail of compareSketches on the device (finish.hip: distance from a host-libm table,
+    p-value by the exact double-double tail, both filters) == mg_finish_*_host BIT FOR BIT: on the
+    reference-run vectors, on clustered and ragged tables (many distinct denominators), triangle
+    and rect, full records and the compacted survivor list."""
+    z = np.load(os.path.join(golden_dir, "ref_compare_vectors.npz"))
+    cases = [(z["table"], z["nhash"], z["lengths"], int(z["k"]), float(z["kmer_space"]))]
+    table, nh, lengths = synth.clustered_sketches(300, 400, clusters=6, seed=9)
+    rng = np.random.default_rng(3)
+    lengths = rng.integers(10 ** 4, 10 ** 8, len(lengths)).astype(np.uint64)
+    cases.append((table, nh, lengths, 21, KSPACE21))
+    t2, n2, _ = synth.clustered_sketches(120, 300, clusters=3, seed=4)
+    for i in range(0, 120, 3):                                     # ragged rows: denominators below s
+        n2[i] = rng.integers(1, 300)
+        t2[i, n2[i]:] = np.uint64(abi.HASH_PAD)
+    cases.append((t2, n2, rng.integers(500, 10 ** 6, 120).astype(np.uint64), 16, 4.0 ** 16))
+    for table, nh, lengths, k, ks in cases:
+        n = len(nh)
+        t = eng.table_upload(table, nh, lengths)
+        counts = eng.compare_tri_host(t)
+        host = eng.finish_tri(counts, lengths, 0, n, k, ks, max_d, max_p)
+        dev = eng.compare_tri_pairs(t, k, ks, max_d, max_p)
+        assert np.array_equal(dev["numer"], host["numer"]) and np.array_equal(dev["denom"], host["denom"])
+        assert np.array_equal(dev["pass"], host["pass"])
+        assert _same_bits(dev["distance"], host["distance"])
+        ok = host["pass"] == 1 if (0 <= max_d < 1) else np.ones(len(host), bool)   # rejected by -d: only `pass` is meaningful
+        assert _same_bits(dev["p_value"][ok], host["p_value"][ok])
+        # survivors only, compacted on the device, reference order
+        res = eng.compare_tri_results(t, k, ks, max_d, max_p, capacity=64)          # small: exercises the retry
+        keep = np.flatnonzero(host["pass"] == 1)
+        assert len(res) == len(keep)
+        ii = np.repeat(np.arange(n), np.arange(n))
+        jj = np.concatenate([np.arange(i) for i in range(n)]) if n > 1 else np.zeros(0, int)
+        assert np.array_equal(res["row"], ii[keep]) and np.array_equal(res["col"], jj[keep])
+        assert np.array_equal(res["numer"], host["numer"][keep]) and np.array_equal(res["denom"], host["denom"][keep])
+        assert _same_bits(res["distance"], host["distance"][keep]) and _same_bits(res["p_value"], host["p_value"][keep])
+        # rect: a slice of the rows as queries against all
+        q = np.arange(n // 4, n // 2)
+        tq = eng.table_upload(table[q], nh[q], lengths[q])
+        rc = eng.compare_rect_host(t, tq)
+        hr = eng.finish_rect(rc, lengths, lengths[q], k, ks, max_d, max_p)
+        dr = eng.compare_rect_pairs(t, tq, k, ks, max_d, max_p)
+        assert np.array_equal(dr["pass"], hr["pass"]) and _same_bits(dr["distance"], hr["distance"])
+        okr = hr["pass"] == 1 if (0 <= max_d < 1) else np.ones(hr.shape, bool)
+        assert _same_bits(dr["p_value"][okr], hr["p_value"][okr])
+        rr = eng.compare_rect_results(t, tq, k, ks, max_d, max_p)
+        kq, kr = np.nonzero(hr["pass"] == 1)
+        assert np.array_equal(rr["row"], kq) and np.array_equal(rr["col"], kr)
+        assert _same_bits(rr["distance"], hr["distance"][kq, kr]) and _same_bits(rr["p_value"], hr["p_value"][kq, kr])
+        tq.free()
+        t.free()
+
+
 def test_compare_c3_scale_properties(eng, oracle):
     """BASELINE config 3 shape at a size the oracle can sample: N = 6000 clustered
     s=1000 sketches (1.8e7 pairs).  Checks (a) sampled rows against the oracle,
