@@ -2,29 +2,39 @@
 """bench.py — headline benchmark of the Mash hot path on MI355X.
 
 Metric (BASELINE.json): pairwise Mash distances/sec at s=1000, k=21 (64-bit hashes).
-Workload: BASELINE config 3 — `mash triangle`, all-vs-all on N=100 000 pre-built
-clustered synthetic sketches: 4.99995e9 pairs per step.  The table
-(800 MB) is resident in HBM on every rank before the timed region; a step = one full
-pass over the lower triangle, row-block sharded (equal-area blocks) across the ranks,
-each rank writing {numer, denom} for its rows into its own HBM buffer (8 B/pair).
-Total work is fixed as N grows ("scaling": "strong").  The only exchange is one RCCL
-broadcast of the table from rank 0 before the timed region (reported separately).
+Workload: BASELINE config 3 — `mash triangle`, all-vs-all on N=100 000 pre-built clustered
+synthetic sketches: 4.99995e9 pairs per step.  The table (800 MB) is resident
+in HBM on every rank before the timed region; a step = one full pass over the lower triangle,
+row-block sharded (equal-area blocks, mg_shard_tri_rows) across the ranks, each rank writing
+{numer, denom} for its rows into its own HBM buffer (8 B/pair).  Total work is fixed as N grows
+("scaling": "strong").  The only exchange is ONE broadcast of the table from rank 0 before the
+timed region, through the library's own RCCL communicator (mg_comm rank mode: ncclCommInitRank +
+ncclBroadcast inside libmashgpu; the 128-byte id travels through torch.distributed); it is
+reported separately (`config.table_broadcast_ms`, `config.rccl_ranks`).
 
-Secondary (same JSON line, key "sketch"): BASELINE config 2 — sketch 10 000 synthetic
-1 Mbp genomes, k=21 s=1000, reported as sketched bp/sec.
-
-Also reported: `roofline` for the dominant kernel (compare_tiled_kernel), measured live
-with HIP events on the launch stream inside libmashgpu (mg_prof_*), and `cpu_baseline`
-= the reference's own compareSketches (oracle/_ref, kind "reference") or the C port
-(kind "port") timed on this box's host cores on a bounded sample of the same table
-(rank 0, N=1 only).
+Same JSON line, further objects:
+  roofline      dominant kernel (compare_merged_kernel): the mandated algorithmic-bytes model of
+                SURVEY §8d, plus the two bounds that mean something for a tiled kernel: `issue`
+                (wave-instructions issued vs what 1024 SIMDs can issue) and `measured_hbm_frac`
+                (PMC bytes / time / peak).  PMC-derived figures come from profiles/*.json and are
+                dropped when the kernel source they were taken on differs from the one running.
+  cpu_baseline  the reference's own compareSketches (oracle/_ref) on the host cores.
+  host_to_host  SURVEY §8d(i)/(ii): table in HOST memory -> results in HOST memory (PCIe included),
+                on a bounded sample, and the whole C3 triangle through the thresholded path.
+  sketch        BASELINE config 2 (10 000 x 1 Mbp, k=21 s=1000), bp/s, own roofline, cpu baselines
+                at 1 thread, at all cores, and the reference CLI incl. FASTA parsing.
+  screen        BASELINE config 4.
+  c5            BASELINE config 5: triangle at s=10 000 (64-bit hashes, k=31 style), N=100 000.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--n-sketches 100000] [--n-genomes 10000]
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -34,8 +44,14 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+CLOCK_HZ = 2.4e9               # engine clock under load (MI355X_MICROARCH.md)
+SIMDS = 256 * 4
 S = 1000
 K = 21
+# sum of numer / sum of denom over the whole C3 triangle of the default synthetic table (seed 0):
+# taken from a run whose output tests/test_gpu_parity.py::test_c3_full_size_triangle checks against
+# the oracle (and asserts the same sums)
+C3_CHECKSUM = {(100_000, 1000): (2122078313, 4999950000000), (100_000, 10000): (21217550236, 49999500000000)}
 
 
 def parse_args():
@@ -48,12 +64,35 @@ def parse_args():
     ap.add_argument("--genome-len", type=int, default=1_000_000)
     ap.add_argument("--no-sketch", action="store_true", help="skip the secondary sketch measurement")
     ap.add_argument("--no-screen", action="store_true", help="skip the tertiary screen measurement (config 4)")
+    ap.add_argument("--no-c5", action="store_true", help="skip the large-sketch triangle (config 5)")
+    ap.add_argument("--no-h2h", action="store_true", help="skip the host-to-host legs")
     ap.add_argument("--n-reads", type=int, default=10_000_000)
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--dry-cpu", action="store_true",
                     help="plumbing test only (CI without GPUs): gloo + CPU tensors, no kernels, output marked dry")
     return ap.parse_args()
+
+
+def src_sha(*rel):
+    h = hashlib.sha256()
+    for r in rel:
+        h.update(open(os.path.join(ROOT, r), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc(name, *src):
+    """profiles/<name>: PMC figures of one pass, valid only for the kernel source they were taken on."""
+    p = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(p):
+        return None
+    try:
+        d = json.load(open(p))
+    except Exception:
+        return None
+    if d.get("kernel_src_sha") != src_sha(*src):
+        return None                                    # stale: the kernel changed since the counters were read
+    return d
 
 
 def cpu_baseline_compare(table_np, nhash_np, lengths_np, budget_s):
@@ -88,21 +127,67 @@ def cpu_baseline_compare(table_np, nhash_np, lengths_np, budget_s):
                       f"{pairs} pairs, {cores} threads, {dt2:.1f} s"}
 
 
-def cpu_baseline_sketch(budget_s):
+def cpu_baseline_sketch(budget_s, threads):
+    """addMinHashes + MinHashHeap (the reference's objects) on `threads` host threads, 1 Mbp genomes."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import pyoracle
     from mash_amd import synth
     use_ref = pyoracle.ref_available()
     orc = pyoracle.Oracle(ref=use_ref)
     p = orc.params(k=K, s=S)
-    g = bytes(synth.synthetic_genome(0, 1_000_000))
+    genomes = [bytes(synth.synthetic_genome(g, 1_000_000)) for g in range(min(threads, 8))]
     t0 = time.perf_counter()
     n = 0
-    while time.perf_counter() - t0 < budget_s:
-        orc.sketch_records([g], p)
-        n += 1
+
+    def work(i):
+        c = 0
+        while time.perf_counter() - t0 < budget_s:
+            orc.sketch_records([genomes[i % len(genomes)]], p)
+            c += 1
+        return c
+
+    if threads == 1:
+        n = work(0)
+    else:
+        with ThreadPoolExecutor(threads) as ex:
+            n = sum(ex.map(work, range(threads)))
     dt = time.perf_counter() - t0
-    return {"value": n * 1e6 / dt, "unit": "bp/s", "cores": 1, "kind": "reference" if use_ref else "port",
-            "sample": f"{n} x 1 Mbp synthetic genome, addMinHashes+MinHashHeap, 1 thread, {dt:.1f} s"}
+    return {"value": n * 1e6 / dt, "unit": "bp/s", "cores": threads, "kind": "reference" if use_ref else "port",
+            "sample": f"{n} x 1 Mbp synthetic genome, addMinHashes+MinHashHeap, {threads} thread(s), {dt:.1f} s"}
+
+
+def cpu_baseline_sketch_cli(n_genomes, threads):
+    """The reference CLI itself (oracle/_ref/mash-ref: all of the reference's translation units) on
+    FASTA files: kseq parsing + sketching + .msh writing, `mash sketch -p <threads>`."""
+    from mash_amd import synth
+    exe = os.path.join(ROOT, "oracle", "_ref", "mash-ref")
+    if not os.path.exists(exe):
+        return None
+    d = tempfile.mkdtemp(prefix="bench_refcli_")
+    try:
+        files = []
+        for g in range(n_genomes):
+            seq = bytes(synth.synthetic_genome(g, 1_000_000))
+            f = os.path.join(d, f"g{g}.fna")
+            with open(f, "wb") as fh:
+                fh.write(b">g%d\n" % g)
+                for o in range(0, len(seq), 80):
+                    fh.write(seq[o:o + 80] + b"\n")
+            files.append(f)
+        out = {}
+        for p in sorted({1, threads}):
+            nf = n_genomes if p > 1 else max(8, n_genomes // 8)
+            t0 = time.perf_counter()
+            r = subprocess.run([exe, "sketch", "-p", str(p), "-o", os.path.join(d, f"out{p}"), *files[:nf]],
+                               capture_output=True, timeout=300)
+            dt = time.perf_counter() - t0
+            if r.returncode != 0:
+                return None
+            out[p] = {"value": nf * 1e6 / dt, "unit": "bp/s", "cores": p, "kind": "reference",
+                      "sample": f"mash-ref sketch -p {p} on {nf} FASTA files of 1 Mbp (kseq parse + sketch + .msh), {dt:.1f} s"}
+        return out
+    finally:
+        subprocess.run(["rm", "-rf", d])
 
 
 def main():
@@ -136,7 +221,14 @@ def main():
         if not dry:
             torch.cuda.synchronize()
 
+    def max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     class _DryEngine:                      # no kernels: only the control flow around them is exercised
+        lib = None
         def table_wrap(self, *a, **k):
             return self
         def compare_tri_dev(self, table, rb, re, out_ptr):
@@ -154,28 +246,69 @@ def main():
 
     eng = _DryEngine() if dry else abi.MashGpu(local_rank, stream=torch.cuda.current_stream().cuda_stream)
 
-    # ------------------------------------------------------------------ table
+    # ------------------------------------------------------------------ table: rank 0 builds it, the library broadcasts it
     n = args.n_sketches
-    if rank == 0:
+    bcast_ms, rccl_ranks, comm_kind = 0.0, 0, "none"
+    hashes = nhash = lengths = None
+    if rank == 0 or dry:
         hashes, nhash, lengths = synth_torch.clustered_sketch_table(n, S, clusters=max(1, n // 100), device=dev)
-    else:
-        hashes = torch.empty((n, S), dtype=torch.int64, device=dev)
-        nhash = torch.empty(n, dtype=torch.int32, device=dev)
-        lengths = torch.empty(n, dtype=torch.int64, device=dev)
-    bcast_ms = 0.0
-    if world > 1:
+    if dry and world > 1:
         barrier()
         t0 = time.perf_counter()
-        dist.broadcast(hashes, 0)          # the one exchange step: sketch table over xGMI
-        dist.broadcast(nhash, 0)
-        dist.broadcast(lengths, 0)
+        for t in (hashes, nhash, lengths):
+            dist.broadcast(t, 0)
         barrier()
-        bcast_ms = (time.perf_counter() - t0) * 1e3
-    table = eng.table_wrap(hashes.data_ptr(), nhash.data_ptr(), lengths.data_ptr(), n, S,
-                           keep=(hashes, nhash, lengths))
+        bcast_ms, comm_kind = (time.perf_counter() - t0) * 1e3, "torch.distributed/gloo (dry)"
+    table = comm = None
+    if not dry:
+        torch.cuda.synchronize()
+        root_table = eng.table_wrap(hashes.data_ptr(), nhash.data_ptr(), lengths.data_ptr(), n, S,
+                                    keep=(hashes, nhash, lengths)) if rank == 0 else None
+        if world > 1:
+            # the library's own communicator: ncclCommInitRank on an id handed round by torch.distributed
+            def exchange(raw):
+                box = [raw]
+                dist.broadcast_object_list(box, src=0)
+                return box[0]
+            ok = torch.ones(1, dtype=torch.int32, device=dev)
+            try:
+                comm = abi.RankComm(eng, world, rank, exchange)
+            except Exception as e:                       # keep every rank in step: fall back together
+                print(f"[bench] rank {rank}: library communicator unavailable ({e}); falling back to torch.distributed", file=sys.stderr)
+                ok.zero_()
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 1:
+                barrier()
+                t0 = time.perf_counter()
+                table = comm.table_broadcast(root_table, n, S)     # the one exchange step: sketch table over xGMI
+                barrier()
+                bcast_ms = (time.perf_counter() - t0) * 1e3
+                rccl_ranks, comm_kind = world, "libmashgpu/RCCL"
+            else:
+                comm = None
+                if rank != 0:
+                    hashes = torch.empty((n, S), dtype=torch.int64, device=dev)
+                    nhash = torch.empty(n, dtype=torch.int32, device=dev)
+                    lengths = torch.empty(n, dtype=torch.int64, device=dev)
+                barrier()
+                t0 = time.perf_counter()
+                for t in (hashes, nhash, lengths):
+                    dist.broadcast(t, 0)
+                barrier()
+                bcast_ms = (time.perf_counter() - t0) * 1e3
+                comm_kind = "torch.distributed/RCCL"
+                table = eng.table_wrap(hashes.data_ptr(), nhash.data_ptr(), lengths.data_ptr(), n, S, keep=(hashes, nhash, lengths))
+        else:
+            table = root_table
+    else:
+        table = eng.table_wrap(0, 0, 0, n, S)
 
-    blocks = shard.equal_area_row_blocks(n, world)
-    rb, re = blocks[rank], blocks[rank + 1]
+    if dry:
+        blocks = shard.equal_area_row_blocks(n, world)
+        rb, re = blocks[rank], blocks[rank + 1]
+    else:
+        rb, re = abi.shard_tri_rows(eng.lib, 0, n, world, rank)
+        blocks = [abi.shard_tri_rows(eng.lib, 0, n, world, g)[0] for g in range(world)] + [n]
     my_pairs = shard.tri_pairs(rb, re)
     total_pairs = n * (n - 1) // 2
     out = torch.empty((max(my_pairs, 1), 2), dtype=torch.int32, device=dev)
@@ -197,41 +330,52 @@ def main():
     dt = time.perf_counter() - t0
     kern_ms, launches = eng.prof_avg_ms("compare")
     eng.prof_enable(False)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    dt = max_over_ranks(dt)
     value = total_pairs * args.steps / dt
+    launches_per_step = launches / args.steps if args.steps else 0
+    pass_ms = kern_ms * launches_per_step          # summed launch time of one pass over this rank's rows
 
-    # cheap sanity on the produced output (outside the timed region): denom == s, numer <= s
-    chk = out[: min(my_pairs, 1_000_000)]
+    # the produced output (outside the timed region): every pair's denom and numer, as sums
+    checksum = None
     if not dry:
-        assert int(chk[:, 1].min()) == S and int(chk[:, 0].max()) <= S, "compare output failed sanity check"
+        sums = torch.stack([out[:my_pairs, 0].sum(dtype=torch.int64), out[:my_pairs, 1].sum(dtype=torch.int64)])
+        if world > 1:
+            dist.all_reduce(sums)
+        checksum = [int(sums[0].item()), int(sums[1].item())]
+        want = C3_CHECKSUM.get((n, S))
+        assert int(out[:my_pairs, 1].max()) <= S and int(out[:my_pairs, 0].max()) <= S, "compare output failed sanity check"
+        if want is not None:
+            assert checksum == list(want), f"compare output checksum {checksum} != verified {want}"
 
-    # roofline of the dominant kernel on this rank: algorithmic bytes = pairs * (2*s*8 + 8)
+    # roofline of the dominant kernel on this rank
     bytes_per_pair = 2 * S * 8 + 8
-    achieved = (my_pairs * bytes_per_pair / (kern_ms * 1e-3)) / 1e9 if kern_ms > 0 else 0.0
-    traffic = None
-    units = None
-    pmc_path = os.path.join(ROOT, "profiles", "compare_pmc_latest.json")
-    if os.path.exists(pmc_path):
-        try:
-            pmc = json.load(open(pmc_path))
-            traffic = pmc.get("hbm_bytes_per_launch")
-            units = pmc.get("units")
-        except Exception:
-            traffic = None
+    achieved = (my_pairs * bytes_per_pair / (pass_ms * 1e-3)) / 1e9 if pass_ms > 0 else 0.0
+    pmc = load_pmc("compare_pmc_latest.json", "mash_amd/csrc/compare_merged.hip", "mash_amd/csrc/compare_internal.h") \
+        if (n == 100_000 and world == 1) else None
+    traffic = pmc.get("hbm_bytes_per_pass") if pmc else None
+    issue = None
+    if pmc and pass_ms > 0:
+        ipp = pmc["valu_per_pair"] + pmc["salu_per_pair"] + pmc["lds_per_pair"] + pmc.get("vmem_per_pair", 0.0)
+        peak = SIMDS * CLOCK_HZ / 4.0                    # one wave-instruction per SIMD every 4 clocks
+        ach = ipp * my_pairs / (pass_ms * 1e-3)
+        issue = {"achieved": round(ach / 1e9, 2), "peak": round(peak / 1e9, 2), "unit": "G wave-instr/s",
+                 "frac": round(ach / peak, 4), "instr_per_pair": round(ipp, 2),
+                 "valu_per_pair": pmc["valu_per_pair"], "salu_per_pair": pmc["salu_per_pair"],
+                 "lds_per_pair": pmc["lds_per_pair"], "lds_active_frac": pmc.get("lds_active_frac"),
+                 "lds_bank_conflict_share": pmc.get("lds_bank_conflict_share"), "source": pmc.get("source")}
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "kernel": "compare_merged_kernel", "kernel_ms": round(kern_ms, 3), "launches": launches,
+                "launches_per_pass": launches_per_step, "pass_ms": round(pass_ms, 3),
                 "algorithmic_bytes_per_pair": bytes_per_pair,
-                "measured_hbm_frac": (round(traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-                                      if traffic and kern_ms > 0 and n == 100_000 and world == 1 else None),
-                "units": units,           # PMC pass over this command: VALU / SALU issue, LDS activity
-                "note": "achieved/frac use the mandated no-reuse model of SURVEY.md §8d (2*s*8+8 B per pair); every "
-                        "sketch is re-used ~1000x from LDS/L2, so frac exceeds 1. traffic = PMC-measured HBM bytes per "
-                        "launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/compare_pmc_latest.json); measured_hbm_frac = "
-                        "traffic / kernel time / peak"}
+                "measured_hbm_frac": (round(traffic / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and pass_ms > 0 else None),
+                "issue": issue,
+                "note": "achieved/frac: the mandated no-reuse model of SURVEY.md §8d (2*s*8+8 B per pair) over the summed launch "
+                        "time of one pass (a pass = one launch per value window, launches_per_pass of the same kernel); every "
+                        "sketch is re-used ~1000x from LDS/L2, so frac exceeds 1 and bounds nothing.  The bounds that do: "
+                        "`issue` = wave-instructions issued (PMC VALU+SALU+LDS+VMEM per pair x pairs/s) against 1024 SIMDs x "
+                        "clock / 4, and measured_hbm_frac = PMC HBM bytes (FETCH_SIZE x2 + WRITE_SIZE) / time / 8 TB/s.  PMC "
+                        "figures are read from profiles/compare_pmc_latest.json and dropped when the kernel source differs."}
 
     result = {
         "metric": "pairwise Mash distances/sec (s=1000)",
@@ -241,22 +385,70 @@ def main():
         "config": {"workload": f"mash triangle all-vs-all, {n} clustered synthetic sketches, k={K} s={S}, "
                                f"{total_pairs} pairs/step, row-block sharded x{world}",
                    "n_sketches": n, "sketch_size": S, "kmer": K, "hash_bits": 64,
-                   "parallelism": f"rowblock{world}", "table_broadcast_ms": round(bcast_ms, 2)},
+                   "parallelism": f"rowblock{world}", "table_broadcast_ms": round(bcast_ms, 2),
+                   "rccl_ranks": rccl_ranks, "comm": comm_kind, "output_checksum": checksum},
         "roofline": roofline,
     }
     if dry:
         result["dry"] = True               # plumbing test: NOT a measurement
         result["rank_blocks"] = blocks
 
+    single = rank == 0 and world == 1 and not dry
     # ------------------------------------------------------------------ cpu baseline (rank 0, N=1)
-    if rank == 0 and world == 1 and not args.no_cpu:
+    if single and not args.no_cpu:
         m = min(n, 6000)
         result["cpu_baseline"] = cpu_baseline_compare(
             hashes[:m].cpu().numpy().view(np.uint64), nhash[:m].cpu().numpy().astype(np.uint32),
             lengths[:m].cpu().numpy().astype(np.uint64), args.cpu_seconds)
 
-    # ------------------------------------------------------------------ secondary: sketching (config 2)
+    # ------------------------------------------------------------------ host to host, N=1
     del out
+    if single and not args.no_h2h:
+        h2h = {}
+        try:
+            m = min(n, 16384)
+            th, tn, tl = (hashes[:m].cpu().numpy().view(np.uint64), nhash[:m].cpu().numpy().astype(np.uint32),
+                          lengths[:m].cpu().numpy().astype(np.uint64))
+            mp = m * (m - 1) // 2
+            buf_c = np.zeros(mp, dtype=abi.COUNTS_DTYPE)
+            buf_p = np.zeros(mp, dtype=abi.PAIR_DTYPE)
+            buf_c[:] = 0
+            buf_p["pass"] = 0                                        # pages exist before the clock starts
+            for kind in ("counts", "pairs"):
+                best = None
+                for _ in range(2):
+                    t0 = time.perf_counter()
+                    t = eng.table_upload(th, tn, tl)
+                    if kind == "counts":
+                        eng.compare_tri_host(t, out=buf_c)
+                    else:
+                        eng._check(eng.lib.mg_compare_tri_pairs_host(eng.ctx, t.handle, 0, m, K, 4.0 ** K, -1.0, -1.0, buf_p.ctypes.data))
+                    d = time.perf_counter() - t0
+                    t.free()
+                    best = d if best is None else min(best, d)
+                h2h[kind] = {"value": mp / best, "unit": "pairs/s", "ms": round(best * 1e3, 2),
+                             "bytes_per_pair_over_pcie": 8 if kind == "counts" else 32}
+            h2h["sample"] = (f"first {m} sketches of the C3 table: table in host memory -> "
+                             f"{{numer, denom}} (counts) / {{numer, denom, distance, p-value}} (pairs, device finish) in host "
+                             f"memory, {mp} pairs, upload + compare + copy back, pageable memory, best of 2")
+            # the whole C3 triangle host to host through the thresholded path (only survivors cross PCIe)
+            hh, hn, hl = (hashes.cpu().numpy().view(np.uint64), nhash.cpu().numpy().astype(np.uint32),
+                          lengths.cpu().numpy().astype(np.uint64))
+            t0 = time.perf_counter()
+            t = eng.table_upload(hh, hn, hl)
+            res = eng.compare_tri_results(t, K, 4.0 ** K, 0.05, 1.0, capacity=1 << 23)
+            d = time.perf_counter() - t0
+            t.free()
+            h2h["full_c3_thresholded"] = {"value": total_pairs / d, "unit": "pairs/s", "ms": round(d * 1e3, 1),
+                                          "survivors": int(len(res)),
+                                          "what": "C3 table in host memory -> every pair with distance <= 0.05 as "
+                                                  "{row, col, numer, denom, distance, p-value} in host memory"}
+            del hh, res
+        except Exception as e:
+            h2h["error"] = repr(e)
+        result["host_to_host"] = h2h
+
+    # ------------------------------------------------------------------ secondary: sketching (config 2)
     if not args.no_sketch and not dry:
         g_blocks = shard.even_blocks(args.n_genomes, world)
         g0, g1 = g_blocks[rank], g_blocks[rank + 1]
@@ -283,37 +475,58 @@ def main():
         sdt = time.perf_counter() - t0
         sk_ms, sk_launches = eng.prof_avg_ms("sketch")
         eng.prof_enable(False)
-        tmax = torch.tensor([sdt], dtype=torch.float64, device=dev)
-        if world > 1:
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        sdt = float(tmax.item())
+        sdt = max_over_ranks(sdt)
         assert int(sk_nhash.min()) == S, "sketch output failed sanity check"
         sk_bytes = ng * (L + 8 * S)                   # 1 B/base in + 8*s B per sketch out
-        sk_traffic = None
-        sk_units = None
-        sk_pmc = os.path.join(ROOT, "profiles", "sketch_pmc_latest.json")
-        if os.path.exists(sk_pmc) and world == 1 and args.n_genomes == 10_000 and L == 1_000_000:
-            try:
-                pmc = json.load(open(sk_pmc))
-                sk_traffic = pmc.get("hbm_bytes_per_launch")
-                sk_units = pmc.get("units")
-            except Exception:
-                sk_traffic = None
+        sk_pmc = load_pmc("sketch_pmc_latest.json", "mash_amd/csrc/sketch.hip", "mash_amd/csrc/kmer_hash.h") \
+            if (world == 1 and args.n_genomes == 10_000 and L == 1_000_000) else None
         sk_ach = sk_bytes / (sk_ms * 1e-3) / 1e9 if sk_ms > 0 else 0.0
+        sk_issue = None
+        if sk_pmc and sk_ms > 0:
+            ipk = sk_pmc["valu_per_kmer"] + sk_pmc["salu_per_kmer"]
+            ach = ipk * ng * (L - K + 1) / (sk_ms * 1e-3)
+            peak = SIMDS * CLOCK_HZ / 4.0
+            sk_issue = {"achieved": round(ach / 1e9, 2), "peak": round(peak / 1e9, 2), "unit": "G wave-instr/s",
+                        "frac": round(ach / peak, 4), "valu_per_kmer": sk_pmc["valu_per_kmer"],
+                        "salu_per_kmer": sk_pmc["salu_per_kmer"], "source": sk_pmc.get("source")}
         sketch = {"metric": "sketched bp/sec (k=21, s=1000)", "value": args.n_genomes * L * sk_steps / sdt,
                   "unit": "bp/s", "ms_per_step": sdt * 1e3 / sk_steps, "steps": sk_steps,
                   "config": {"workload": f"sketch {args.n_genomes} synthetic {L} bp genomes, k={K} s={S}, "
                                          f"ASCII bases resident in HBM, sharded x{world}"},
                   "roofline": {"bound": "hbm", "achieved": round(sk_ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(sk_ach / HBM_PEAK_GBS, 4), "traffic": sk_traffic,
+                               "frac": round(sk_ach / HBM_PEAK_GBS, 4),
+                               "traffic": sk_pmc.get("hbm_bytes_per_launch") if sk_pmc else None,
                                "kernel": "sketch_chunks_kernel<21,0,256,false>", "kernel_ms": round(sk_ms, 3),
-                               "launches": sk_launches, "units": sk_units,
-                               "note": "integer-ALU bound: PMC (units) shows the VALU issuing practically every "
-                                       "cycle at ~150 VALU instructions per k-mer (10 64-bit multiplies on 32-bit "
-                                       "halves), HBM traffic = algorithmic bytes; see DESIGN.md 4.2"}}
-        if rank == 0 and world == 1 and not args.no_cpu:
-            sketch["cpu_baseline"] = cpu_baseline_sketch(min(args.cpu_seconds, 6.0))
+                               "launches": sk_launches, "issue": sk_issue,
+                               "note": "integer-ALU bound: one MurmurHash3_x64_128 per k-mer (10 64-bit multiplies on 32-bit "
+                                       "halves) keeps the VALU issuing every cycle; HBM traffic = algorithmic bytes (1 B/base "
+                                       "+ 8 s B/sketch), a few per cent of the HBM peak; `issue` is the bound that applies"}}
+        if single and not args.no_cpu:
+            cores = min(os.cpu_count() or 1, 16)
+            sketch["cpu_baseline"] = cpu_baseline_sketch(min(args.cpu_seconds, 6.0), 1)
+            sketch["cpu_baseline_all_cores"] = cpu_baseline_sketch(min(args.cpu_seconds, 6.0), cores)
+            cli = cpu_baseline_sketch_cli(200, cores)
+            if cli:
+                sketch["cpu_baseline_cli"] = cli
+        if single and not args.no_h2h:
+            # FASTA bytes in HOST memory -> hash lists in HOST memory
+            try:
+                mg = min(ng, 2000)
+                hb = bases[:mg].cpu().numpy().reshape(-1)
+                hoff = np.arange(mg + 1, dtype=np.uint64) * np.uint64(L)
+                best = None
+                for _ in range(2):
+                    t0 = time.perf_counter()
+                    eng.sketch_host_raw(hb, hoff, p)
+                    d = time.perf_counter() - t0
+                    best = d if best is None else min(best, d)
+                sketch["host_to_host"] = {"value": mg * L / best, "unit": "bp/s", "ms": round(best * 1e3, 1),
+                                          "sample": f"{mg} genomes x {L} bp in pageable host memory -> hashes in host memory "
+                                                    f"(mg_sketch_host: H2D + kernel + D2H), best of 2"}
+            except Exception as e:
+                sketch["host_to_host"] = {"error": repr(e)}
         result["sketch"] = sketch
+        bases = sk_hashes = sk_nhash = None
 
     # ------------------------------------------------------------------ tertiary: screen (config 4)
     # 10^7 x 150 bp reads (0.5 % errors, both strands) against the first 10^5 - 10^3 rows of the
@@ -323,7 +536,6 @@ def main():
     # whole job: table build, every batch, counters gathered + exchanged.
     if not args.no_screen and not dry:
         import gc
-        bases = sk_hashes = sk_nhash = None             # release the sketch workload
         gc.collect()
         torch.cuda.empty_cache()
         from mash_amd import screen_dist
@@ -339,8 +551,13 @@ def main():
             eng.sketch_dev(genomes.data_ptr(), NSRC * GL, np.arange(NSRC + 1, dtype=np.uint64) * np.uint64(GL), p,
                            gh.data_ptr(), gn.data_ptr())
             rest = max(0, min(n, 100_000) - NSRC)
-            db_h = torch.cat([gh, hashes[:rest]], 0).contiguous()
-            db_n = torch.cat([gn, nhash[:rest]], 0).contiguous()
+            if hashes is None:                           # ranks > 0: the same table again (the generator is deterministic)
+                fh_all, fn_all, _ = synth_torch.clustered_sketch_table(n, S, clusters=max(1, n // 100), device=dev)
+                fh, fn = fh_all[:rest], fn_all[:rest]
+            else:
+                fh, fn = hashes[:rest], nhash[:rest]
+            db_h = torch.cat([gh, fh], 0).contiguous()
+            db_n = torch.cat([gn, fn], 0).contiguous()
             db_l = torch.full((NSRC + rest,), GL, dtype=torch.int64, device=dev)
             torch.cuda.synchronize()
             db = eng.table_wrap(db_h.data_ptr(), db_n.data_ptr(), db_l.data_ptr(), NSRC + rest, S, keep=(db_h, db_n, db_l))
@@ -377,12 +594,9 @@ def main():
             for _ in range(scr_steps):
                 counts, mix = scr_step()
             barrier()
-            qdt = time.perf_counter() - t0
-            tmax = torch.tensor([qdt], dtype=torch.float64, device=dev)
+            qdt = max_over_ranks(time.perf_counter() - t0)
             if world > 1:
-                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            qdt = float(tmax.item())
         if int(ok.item()) == 1:
             shared = (counts.view(NSRC + rest, S)[:NSRC] > 0).sum(1).float().mean().item()
             assert 500 < shared < 900 and len(mix) == S, f"screen output failed sanity check (shared {shared}, mix {len(mix)})"
@@ -400,13 +614,70 @@ def main():
                                              "k-mer), table probes filtered by the largest key; whole-step time, "
                                              "includes table build, counter gather and the exchange"}})
             db.free()
+            del db_h, db_n, counts
         elif "error" not in scr:
             scr["error"] = "failed on another rank"
         result["screen"] = scr
+        batches = handles = None
+
+    # ------------------------------------------------------------------ config 5: triangle at s = 10 000 (N = 1 only)
+    if single and not args.no_c5:
+        import gc
+        c5 = {"metric": "pairwise Mash distances/sec (s=10000, 64-bit hashes)", "unit": "pairs/s"}
+        try:
+            table.free()
+            table = None
+            hashes = nhash = lengths = None
+            gc.collect()
+            torch.cuda.empty_cache()
+            S5 = 10000
+            n5 = n
+            h5, nh5, l5 = synth_torch.clustered_sketch_table(n5, S5, clusters=max(1, n5 // 100), pool=15000, private=4000,
+                                                             device=dev, block=2000)
+            torch.cuda.synchronize()
+            t5 = eng.table_wrap(h5.data_ptr(), nh5.data_ptr(), l5.data_ptr(), n5, S5, keep=(h5, nh5, l5))
+            pairs5 = n5 * (n5 - 1) // 2
+            out5 = torch.empty((pairs5, 2), dtype=torch.int32, device=dev)
+            eng.compare_tri_dev(t5, 0, n5, out5.data_ptr())            # warm-up: prefix image, window offsets
+            eng.prof_enable(True)
+            eng.prof_reset()
+            torch.cuda.synchronize()
+            steps5 = 2
+            t0 = time.perf_counter()
+            for _ in range(steps5):
+                eng.compare_tri_dev(t5, 0, n5, out5.data_ptr())
+            torch.cuda.synchronize()
+            d5 = time.perf_counter() - t0
+            k5, l5n = eng.prof_avg_ms("compare")
+            eng.prof_enable(False)
+            sums5 = [int(out5[:, 0].sum(dtype=torch.int64).item()), int(out5[:, 1].sum(dtype=torch.int64).item())]
+            assert int(out5[:, 1].min()) == S5 and int(out5[:, 0].max()) <= S5, "c5 output failed sanity check"
+            want5 = C3_CHECKSUM.get((n5, S5))
+            if want5 is not None:
+                assert sums5 == list(want5), f"c5 checksum {sums5} != verified {want5}"
+            b5 = 2 * S5 * 8 + 8
+            c5.update({"value": pairs5 * steps5 / d5, "ms_per_step": d5 * 1e3 / steps5, "steps": steps5,
+                       "config": {"workload": f"mash triangle, {n5} clustered synthetic sketches of s={S5} 64-bit hashes "
+                                              f"(k=31 style), {pairs5} pairs/step, 1 GPU", "output_checksum": sums5},
+                       "roofline": {"bound": "hbm", "kernel": "compare_merged_kernel (value windows)",
+                                    "kernel_ms": round(k5, 3), "launches": l5n, "launches_per_pass": l5n / steps5,
+                                    "pass_ms": round(k5 * l5n / steps5, 2),
+                                    "achieved": round(pairs5 * b5 / (k5 * l5n / steps5 * 1e-3) / 1e9, 1) if k5 > 0 else 0.0,
+                                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": round(pairs5 * b5 / (k5 * l5n / steps5 * 1e-3) / 1e9 / HBM_PEAK_GBS, 3) if k5 > 0 else 0.0,
+                                    "algorithmic_bytes_per_pair": b5, "traffic": None}})
+            t5.free()
+            del out5, h5
+        except Exception as e:
+            c5["error"] = repr(e)
+        result["c5"] = c5
 
     if rank == 0:
         print(json.dumps(result))
-    table.free()
+    if table is not None:
+        table.free()
+    if comm is not None:
+        comm.close()
     eng.close()
     if world > 1:
         dist.destroy_process_group()

@@ -74,6 +74,7 @@ typedef struct mg_pair {
 } mg_pair;
 
 /* ---- context -------------------------------------------------------------- */
+int         mg_device_count(void);               /* visible GPUs (0 when there is none) */
 int         mg_ctx_create(int device, mg_ctx **out);
 void        mg_ctx_destroy(mg_ctx *ctx);
 const char *mg_last_error(mg_ctx *ctx);      /* ctx may be NULL: last create error */
@@ -112,6 +113,23 @@ int mg_sketch_dev(mg_ctx *ctx, const mg_params *p,
                   const uint8_t *bases_dev, uint64_t nbases,
                   const uint64_t *sketch_off_host, uint64_t nsketch,
                   uint64_t *hashes_out_dev, uint32_t *nhash_out_dev, uint32_t *counts_out_dev);
+
+/* Streamed ingest (replaces the reader side of sketchFile's overlap of parsing and sketching,
+ * ThreadPool.hxx:127-167 + kseq.h:171-208 feeding addMinHashes): the caller hands over bytes as it
+ * parses them -- no concatenated batch on the host.  mg_sketch_add appends to the CURRENT sketch's
+ * byte range (records separated by MG_RECORD_SEP by the caller); mg_sketch_end_sketch closes it.
+ * The bytes are packed into two pinned staging buffers and copied to the device on a copy stream
+ * while the caller goes on parsing.  mg_sketch_finish sketches everything closed so far: row i of
+ * hashes_out[n * sketch_size] / nhash_out[n] / counts_out (nullable) = the i-th closed sketch,
+ * n = mg_sketch_pending(); the session is then empty and can be filled again.  Results are those of
+ * mg_sketch_host on the concatenation.  One thread at a time per session. */
+typedef struct mg_sketch_session mg_sketch_session;
+int      mg_sketch_begin(mg_ctx *ctx, const mg_params *p, mg_sketch_session **out);
+int      mg_sketch_add(mg_sketch_session *ss, const uint8_t *bytes, uint64_t len);
+int      mg_sketch_end_sketch(mg_sketch_session *ss);
+uint64_t mg_sketch_pending(const mg_sketch_session *ss);
+int      mg_sketch_finish(mg_sketch_session *ss, uint64_t *hashes_out, uint32_t *nhash_out, uint32_t *counts_out);
+void     mg_sketch_session_free(mg_sketch_session *ss);
 
 /* Reads mode with the early stop of `mash sketch -r -c <cov>` (Sketch.cpp:1200-1270): ONE sketch
  * over all records of `bases` (separated by MG_RECORD_SEP, in the order the reference reads

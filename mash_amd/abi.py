@@ -21,8 +21,9 @@ HASH_PAD = 0xFFFFFFFFFFFFFFFF
 RECORD_SEP = 0x0A
 
 EXPORTS = [
-    "mg_ctx_create", "mg_ctx_destroy", "mg_last_error", "mg_ctx_set_stream", "mg_ctx_synchronize",
-    "mg_ctx_cu_count", "mg_params_init", "mg_sketch_host", "mg_sketch_dev", "mg_sketch_reads_host", "mg_table_upload",
+    "mg_device_count", "mg_ctx_create", "mg_ctx_destroy", "mg_last_error", "mg_ctx_set_stream", "mg_ctx_synchronize",
+    "mg_ctx_cu_count", "mg_params_init", "mg_sketch_host", "mg_sketch_dev", "mg_sketch_reads_host", "mg_sketch_begin", "mg_sketch_add",
+    "mg_sketch_end_sketch", "mg_sketch_pending", "mg_sketch_finish", "mg_sketch_session_free", "mg_table_upload",
     "mg_table_wrap_dev", "mg_table_free", "mg_table_rows", "mg_table_sketch_size",
     "mg_compare_tri_dev", "mg_compare_tri_host", "mg_compare_rect_dev", "mg_compare_rect_host",
     "mg_compare_tri_filter_host", "mg_compare_rect_filter_host",
@@ -32,6 +33,11 @@ EXPORTS = [
     "mg_prof_enable", "mg_prof_reset", "mg_prof_avg_ms",
     "mg_screen_create", "mg_screen_create_translated", "mg_screen_add_host", "mg_screen_add_dev", "mg_screen_finish_host", "mg_screen_counts_dev", "mg_screen_free",
     "mg_identity", "mg_p_value_within",
+    "mg_comm_create_local", "mg_comm_unique_id", "mg_comm_create_rank", "mg_comm_destroy", "mg_comm_size", "mg_comm_rank",
+    "mg_comm_uses_rccl", "mg_comm_ctx", "mg_comm_last_error", "mg_shard_tri_rows", "mg_shard_rows", "mg_dtable_upload",
+    "mg_dtable_free", "mg_dtable_local", "mg_table_broadcast", "mg_comm_allreduce_u32_sum",
+    "mg_compare_tri_sharded_host", "mg_compare_rect_sharded_host", "mg_compare_tri_pairs_sharded_host",
+    "mg_compare_rect_pairs_sharded_host", "mg_compare_tri_results_sharded_host", "mg_compare_rect_results_sharded_host",
 ]
 
 
@@ -130,6 +136,7 @@ def load_library():
             "(there is no CPU fallback)")
     lib = C.CDLL(LIB_PATH)
     vp, u64, u32, i32, dbl = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_double
+    lib.mg_device_count.argtypes = []
     lib.mg_ctx_create.argtypes = [i32, C.POINTER(vp)]
     lib.mg_ctx_destroy.argtypes = [vp]
     lib.mg_ctx_destroy.restype = None
@@ -142,6 +149,14 @@ def load_library():
     lib.mg_sketch_host.argtypes = [vp, C.POINTER(MgParams), vp, u64, vp, u64, vp, vp, vp]
     lib.mg_sketch_dev.argtypes = [vp, C.POINTER(MgParams), vp, u64, vp, u64, vp, vp, vp]
     lib.mg_sketch_reads_host.argtypes = [vp, C.POINTER(MgParams), vp, u64, vp, vp, vp, vp]
+    lib.mg_sketch_begin.argtypes = [vp, C.POINTER(MgParams), C.POINTER(vp)]
+    lib.mg_sketch_add.argtypes = [vp, vp, u64]
+    lib.mg_sketch_end_sketch.argtypes = [vp]
+    lib.mg_sketch_pending.argtypes = [vp]
+    lib.mg_sketch_pending.restype = u64
+    lib.mg_sketch_finish.argtypes = [vp, vp, vp, vp]
+    lib.mg_sketch_session_free.argtypes = [vp]
+    lib.mg_sketch_session_free.restype = None
     lib.mg_table_upload.argtypes = [vp, vp, vp, vp, u64, u64, C.POINTER(vp)]
     lib.mg_table_wrap_dev.argtypes = [vp, vp, vp, vp, u64, u64, C.POINTER(vp)]
     lib.mg_table_free.argtypes = [vp]
@@ -164,6 +179,35 @@ def load_library():
     lib.mg_compare_rect_pairs_host.argtypes = [vp, vp, vp, u64, u64, i32, dbl, dbl, dbl, vp]
     lib.mg_compare_tri_results_host.argtypes = [vp, vp, u64, u64, i32, dbl, dbl, dbl, vp, u64, vp]
     lib.mg_compare_rect_results_host.argtypes = [vp, vp, vp, u64, u64, i32, dbl, dbl, dbl, vp, u64, vp]
+    lib.mg_comm_create_local.argtypes = [C.POINTER(C.c_int), i32, C.POINTER(vp)]
+    lib.mg_comm_unique_id.argtypes = [vp, C.c_size_t]
+    lib.mg_comm_create_rank.argtypes = [vp, vp, C.c_size_t, i32, i32, C.POINTER(vp)]
+    lib.mg_comm_destroy.argtypes = [vp]
+    lib.mg_comm_destroy.restype = None
+    lib.mg_comm_size.argtypes = [vp]
+    lib.mg_comm_rank.argtypes = [vp]
+    lib.mg_comm_uses_rccl.argtypes = [vp]
+    lib.mg_comm_ctx.argtypes = [vp, i32]
+    lib.mg_comm_ctx.restype = vp
+    lib.mg_comm_last_error.argtypes = [vp]
+    lib.mg_comm_last_error.restype = C.c_char_p
+    lib.mg_shard_tri_rows.argtypes = [u64, u64, i32, i32, C.POINTER(u64), C.POINTER(u64)]
+    lib.mg_shard_tri_rows.restype = None
+    lib.mg_shard_rows.argtypes = [u64, u64, i32, i32, C.POINTER(u64), C.POINTER(u64)]
+    lib.mg_shard_rows.restype = None
+    lib.mg_dtable_upload.argtypes = [vp, vp, vp, vp, u64, u64, C.POINTER(vp)]
+    lib.mg_dtable_free.argtypes = [vp]
+    lib.mg_dtable_free.restype = None
+    lib.mg_dtable_local.argtypes = [vp, i32]
+    lib.mg_dtable_local.restype = vp
+    lib.mg_table_broadcast.argtypes = [vp, vp, i32, u64, u64, C.POINTER(vp)]
+    lib.mg_comm_allreduce_u32_sum.argtypes = [vp, vp, u64]
+    lib.mg_compare_tri_sharded_host.argtypes = [vp, vp, u64, u64, vp]
+    lib.mg_compare_rect_sharded_host.argtypes = [vp, vp, vp, u64, u64, vp]
+    lib.mg_compare_tri_pairs_sharded_host.argtypes = [vp, vp, u64, u64, i32, dbl, dbl, dbl, vp]
+    lib.mg_compare_rect_pairs_sharded_host.argtypes = [vp, vp, vp, u64, u64, i32, dbl, dbl, dbl, vp]
+    lib.mg_compare_tri_results_sharded_host.argtypes = [vp, vp, u64, u64, i32, dbl, dbl, dbl, vp, u64, vp]
+    lib.mg_compare_rect_results_sharded_host.argtypes = [vp, vp, vp, u64, u64, i32, dbl, dbl, dbl, vp, u64, vp]
     lib.mg_distance.argtypes = [u32, u32, i32]
     lib.mg_distance.restype = dbl
     lib.mg_p_value.argtypes = [u64, u64, u64, dbl, u64]
@@ -233,6 +277,133 @@ class Table:
             pass
 
 
+def shard_tri_rows(lib, row_begin, row_end, nranks, rank):
+    """equal-area row block of `rank` (mg_shard_tri_rows)"""
+    b, e = C.c_uint64(0), C.c_uint64(0)
+    lib.mg_shard_tri_rows(row_begin, row_end, nranks, rank, C.byref(b), C.byref(e))
+    return int(b.value), int(e.value)
+
+
+class LocalComm:
+    """mg_comm in local mode: one process, a context per listed device, tables replicated on all of
+    them (RCCL broadcast from device 0), compares sharded by row blocks."""
+
+    def __init__(self, devices):
+        self.lib = load_library()
+        arr = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        rc = self.lib.mg_comm_create_local(arr, len(devices), C.byref(h))
+        if rc != MG_OK:
+            raise MashGpuError("mg_comm_create_local: " + self.lib.mg_comm_last_error(None).decode())
+        self.h = h
+        self.size = len(devices)
+
+    def _check(self, rc):
+        if rc != MG_OK:
+            raise MashGpuError(f"libmashgpu error {rc}: " + self.lib.mg_comm_last_error(self.h).decode())
+
+    @property
+    def uses_rccl(self):
+        return bool(self.lib.mg_comm_uses_rccl(self.h))
+
+    def close(self):
+        if self.h:
+            self.lib.mg_comm_destroy(self.h)
+            self.h = None
+
+    def upload(self, hashes, nhash, lengths):
+        hashes = np.ascontiguousarray(hashes, dtype=np.uint64)
+        nhash = np.ascontiguousarray(nhash, dtype=np.uint32)
+        lengths = np.ascontiguousarray(lengths, dtype=np.uint64)
+        n, s = hashes.shape
+        d = C.c_void_p()
+        self._check(self.lib.mg_dtable_upload(self.h, hashes.ctypes.data, nhash.ctypes.data, lengths.ctypes.data, n, s, C.byref(d)))
+        return d
+
+    def free(self, d):
+        self.lib.mg_dtable_free(d)
+
+    def tri(self, d, n, row_begin=0, row_end=None):
+        row_end = n if row_end is None else row_end
+        out = np.zeros(tri_pairs(row_begin, row_end), dtype=COUNTS_DTYPE)
+        self._check(self.lib.mg_compare_tri_sharded_host(self.h, d, row_begin, row_end, out.ctypes.data))
+        return out
+
+    def rect(self, dref, dqry, nref, nq, q_begin=0, q_end=None):
+        q_end = nq if q_end is None else q_end
+        out = np.zeros((q_end - q_begin, nref), dtype=COUNTS_DTYPE)
+        self._check(self.lib.mg_compare_rect_sharded_host(self.h, dref, dqry, q_begin, q_end, out.ctypes.data))
+        return out
+
+    def tri_pairs(self, d, n, k, kmer_space, max_d=-1.0, max_p=-1.0):
+        out = np.zeros(tri_pairs(0, n), dtype=PAIR_DTYPE)
+        self._check(self.lib.mg_compare_tri_pairs_sharded_host(self.h, d, 0, n, k, kmer_space, max_d, max_p, out.ctypes.data))
+        return out
+
+    def rect_pairs(self, dref, dqry, nref, nq, k, kmer_space, max_d=-1.0, max_p=-1.0):
+        out = np.zeros((nq, nref), dtype=PAIR_DTYPE)
+        self._check(self.lib.mg_compare_rect_pairs_sharded_host(self.h, dref, dqry, 0, nq, k, kmer_space, max_d, max_p, out.ctypes.data))
+        return out
+
+    def _results(self, call, capacity):
+        n = C.c_uint64(0)
+        for _ in range(2):
+            out = np.zeros(max(int(capacity), 1), dtype=RESULT_DTYPE)
+            rc = call(out.ctypes.data, int(capacity), C.byref(n))
+            if rc == MG_OK:
+                return out[:n.value]
+            if rc != MG_ERR_NOMEM or n.value <= capacity:
+                self._check(rc)
+            capacity = n.value
+        self._check(rc)
+
+    def tri_results(self, d, n, k, kmer_space, max_d=-1.0, max_p=-1.0, capacity=1 << 16):
+        return self._results(lambda o, c, cnt: self.lib.mg_compare_tri_results_sharded_host(
+            self.h, d, 0, n, k, kmer_space, max_d, max_p, o, c, cnt), capacity)
+
+    def rect_results(self, dref, dqry, nq, k, kmer_space, max_d=-1.0, max_p=-1.0, capacity=1 << 16):
+        return self._results(lambda o, c, cnt: self.lib.mg_compare_rect_results_sharded_host(
+            self.h, dref, dqry, 0, nq, k, kmer_space, max_d, max_p, o, c, cnt), capacity)
+
+
+class RankComm:
+    """mg_comm in rank mode: one process per GPU.  `exchange(bytes_or_None) -> bytes` hands rank 0's
+    128-byte id to every rank (torch.distributed, a file, anything)."""
+
+    def __init__(self, eng, nranks, rank, exchange):
+        self.eng, self.lib = eng, eng.lib
+        idbuf = C.create_string_buffer(128)
+        if rank == 0:
+            rc = self.lib.mg_comm_unique_id(idbuf, 128)
+            if rc != MG_OK:
+                raise MashGpuError("mg_comm_unique_id: " + self.lib.mg_comm_last_error(None).decode())
+        raw = exchange(bytes(idbuf.raw) if rank == 0 else None)
+        idbuf = C.create_string_buffer(raw, 128)
+        h = C.c_void_p()
+        rc = self.lib.mg_comm_create_rank(eng.ctx, idbuf, 128, nranks, rank, C.byref(h))
+        if rc != MG_OK:
+            raise MashGpuError("mg_comm_create_rank: " + self.lib.mg_comm_last_error(None).decode())
+        self.h, self.nranks, self.rank = h, nranks, rank
+
+    def _check(self, rc):
+        if rc != MG_OK:
+            raise MashGpuError(f"libmashgpu error {rc}: " + self.lib.mg_comm_last_error(self.h).decode())
+
+    def close(self):
+        if self.h:
+            self.lib.mg_comm_destroy(self.h)
+            self.h = None
+
+    def table_broadcast(self, src_table, n, s, root=0):
+        """table of the root on every rank (ncclBroadcast of hashes, nhash, lengths)"""
+        h = C.c_void_p()
+        self._check(self.lib.mg_table_broadcast(self.h, src_table.handle if src_table is not None else None, root, n, s, C.byref(h)))
+        return Table(self.eng, h, keep=(src_table,))
+
+    def allreduce_u32_sum(self, ptr, count):
+        self._check(self.lib.mg_comm_allreduce_u32_sum(self.h, ptr, count))
+
+
 class MashGpu:
     """One context = one process + one GPU (mg_ctx)."""
 
@@ -283,6 +454,28 @@ class MashGpu:
                                             off.ctypes.data, n, hashes.ctypes.data, nhash.ctypes.data,
                                             cnt.ctypes.data if counts else None))
         return (hashes, nhash, cnt) if counts else (hashes, nhash)
+
+    def sketch_stream(self, sketches, p, counts=False, piece=None):
+        """same result as sketch_host, through a session: bytes handed over piece by piece"""
+        h = C.c_void_p()
+        self._check(self.lib.mg_sketch_begin(self.ctx, C.byref(p), C.byref(h)))
+        try:
+            for recs in sketches:
+                blob = np.frombuffer(join_records(recs), dtype=np.uint8)
+                step = piece or max(1, len(blob))
+                for o in range(0, len(blob), step):
+                    part = np.ascontiguousarray(blob[o:o + step])
+                    self._check(self.lib.mg_sketch_add(h, part.ctypes.data, len(part)))
+                self._check(self.lib.mg_sketch_end_sketch(h))
+            n, s = int(self.lib.mg_sketch_pending(h)), int(p.sketch_size)
+            hashes = np.zeros((n, s), dtype=np.uint64)
+            nhash = np.zeros(n, dtype=np.uint32)
+            cnt = np.zeros((n, s), dtype=np.uint32) if counts else None
+            self._check(self.lib.mg_sketch_finish(h, hashes.ctypes.data, nhash.ctypes.data, cnt.ctypes.data if counts else None))
+            assert int(self.lib.mg_sketch_pending(h)) == 0
+            return (hashes, nhash, cnt) if counts else (hashes, nhash)
+        finally:
+            self.lib.mg_sketch_session_free(h)
 
     def sketch_reads(self, records, p):
         """reads mode, one sketch over `records` in order, honouring p.target_cov (-c):

@@ -66,6 +66,7 @@ __global__ __launch_bounds__(256) void finish_pairs_kernel(FinishArgs a)
         o.distance = lut_distance(a, c.x, c.y);
         o.p_value = 0.0;
         o.pass = 0;
+        for (int b = 0; b < 7; b++) o._pad[b] = 0;                        // records are compared and hashed as bytes
         if (passes_distance(a, c.x, c.y)) {
             uint64_t row, col;
             pair_rc(a, idx, row, col);

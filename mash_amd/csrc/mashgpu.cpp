@@ -171,6 +171,13 @@ static void prof_end(mg_ctx *ctx, std::vector<ProfRec> &v)
 
 extern "C" {
 
+int mg_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
 int mg_ctx_create(int device, mg_ctx **out)
 {
     if (!out) return fail(nullptr, MG_ERR_INVALID, "mg_ctx_create: out is NULL");
@@ -780,6 +787,156 @@ int mg_sketch_host(mg_ctx *ctx, const mg_params *p, const uint8_t *bases, uint64
         hipStreamSynchronize(ctx->stream) != hipSuccess)
         return fail(ctx, MG_ERR_HIP, "mg_sketch_host: D2H copy failed");
     return MG_OK;
+}
+
+/* ------------------------------------------------- streamed ingest: segments in, sketches out */
+
+// mg_sketch_host wants the whole batch as ONE host array: a caller that parses files has to
+// concatenate them first (600 MB of memcpy for 12 000 small genomes) and the pageable H2D copy
+// then runs while nothing else does.  A session instead takes the bytes as they are parsed:
+// they are packed into a ring of two pinned staging buffers and leave for the device on a copy
+// stream while the caller parses on; sketch boundaries are marked as they occur; mg_sketch_finish
+// runs the kernels over what has arrived and hands the sketches back.  (The reference overlaps
+// parsing and sketching the same way through its ThreadPool, ThreadPool.hxx:127-167.)
+struct mg_sketch_session {
+    mg_ctx *ctx = nullptr;
+    mg_params p;
+    uint8_t *d_bases = nullptr;
+    uint64_t d_cap = 0, d_used = 0;
+    uint8_t *stage[2] = {nullptr, nullptr};
+    uint64_t stage_cap = 32ull << 20, fill = 0;
+    int cur = 0;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool ev_pending[2] = {false, false};
+    hipStream_t copy_stream = nullptr;
+    std::vector<uint64_t> off{0};
+};
+
+static int session_submit(mg_sketch_session *ss)
+{
+    mg_ctx *ctx = ss->ctx;
+    if (ss->fill == 0) return MG_OK;
+    if (ss->d_used + ss->fill + 64 > ss->d_cap) {
+        // grow the device arena (copies what has arrived; rare: capacity doubles)
+        uint64_t cap = std::max<uint64_t>(ss->d_cap * 2, 256ull << 20);
+        while (cap < ss->d_used + ss->fill + 64) cap *= 2;
+        uint8_t *nb = nullptr;
+        if (hipMalloc(&nb, cap) != hipSuccess) return fail(ctx, MG_ERR_NOMEM, "mg_sketch_add: device allocation failed");
+        if (ss->d_used)
+            HIP_TRY(ctx, hipMemcpyAsync(nb, ss->d_bases, ss->d_used, hipMemcpyDeviceToDevice, ss->copy_stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ss->copy_stream));
+        if (ss->d_bases) hipFree(ss->d_bases);
+        ss->d_bases = nb;
+        ss->d_cap = cap;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ss->d_bases + ss->d_used, ss->stage[ss->cur], ss->fill, hipMemcpyHostToDevice, ss->copy_stream));
+    HIP_TRY(ctx, hipEventRecord(ss->ev[ss->cur], ss->copy_stream));
+    ss->ev_pending[ss->cur] = true;
+    ss->d_used += ss->fill;
+    ss->fill = 0;
+    ss->cur ^= 1;
+    if (ss->ev_pending[ss->cur]) {                          // the other buffer's copy must have left before it is refilled
+        HIP_TRY(ctx, hipEventSynchronize(ss->ev[ss->cur]));
+        ss->ev_pending[ss->cur] = false;
+    }
+    return MG_OK;
+}
+
+int mg_sketch_begin(mg_ctx *ctx, const mg_params *p, mg_sketch_session **out)
+{
+    if (!ctx) return MG_ERR_INVALID;
+    if (!p || !out) return fail(ctx, MG_ERR_INVALID, "mg_sketch_begin: NULL argument");
+    if (p->target_cov > 0) return fail(ctx, MG_ERR_UNSUPPORTED, "mg_sketch_begin: target_cov needs mg_sketch_reads_host");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    mg_sketch_session *ss = new mg_sketch_session;
+    ss->ctx = ctx;
+    ss->p = *p;
+    if (const char *e = getenv("MASHGPU_STAGE_BYTES")) ss->stage_cap = std::max<uint64_t>(64, strtoull(e, nullptr, 10));   // test knob
+    hipError_t e = hipStreamCreateWithFlags(&ss->copy_stream, hipStreamNonBlocking);
+    for (int i = 0; i < 2 && e == hipSuccess; i++) {
+        e = hipHostMalloc((void **)&ss->stage[i], ss->stage_cap, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ss->ev[i], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) {
+        mg_sketch_session_free(ss);
+        return fail(ctx, MG_ERR_HIP, std::string("mg_sketch_begin: ") + hipGetErrorString(e));
+    }
+    *out = ss;
+    return MG_OK;
+}
+
+int mg_sketch_add(mg_sketch_session *ss, const uint8_t *bytes, uint64_t len)
+{
+    if (!ss) return MG_ERR_INVALID;
+    if (!bytes && len) return fail(ss->ctx, MG_ERR_INVALID, "mg_sketch_add: NULL bytes");
+    while (len) {
+        const uint64_t n = std::min(len, ss->stage_cap - ss->fill);
+        memcpy(ss->stage[ss->cur] + ss->fill, bytes, n);
+        ss->fill += n;
+        bytes += n;
+        len -= n;
+        if (ss->fill == ss->stage_cap) {
+            const int rc = session_submit(ss);
+            if (rc != MG_OK) return rc;
+        }
+    }
+    return MG_OK;
+}
+
+int mg_sketch_end_sketch(mg_sketch_session *ss)
+{
+    if (!ss) return MG_ERR_INVALID;
+    ss->off.push_back(ss->d_used + ss->fill);
+    return MG_OK;
+}
+
+uint64_t mg_sketch_pending(const mg_sketch_session *ss) { return ss ? ss->off.size() - 1 : 0; }
+
+int mg_sketch_finish(mg_sketch_session *ss, uint64_t *hashes_out, uint32_t *nhash_out, uint32_t *counts_out)
+{
+    if (!ss) return MG_ERR_INVALID;
+    mg_ctx *ctx = ss->ctx;
+    const uint64_t nsketch = ss->off.size() - 1;
+    int rc = MG_OK;
+    if (nsketch) {
+        if (!hashes_out || !nhash_out) return fail(ctx, MG_ERR_INVALID, "mg_sketch_finish: NULL argument");
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        if (ss->fill == 0 && ss->d_used == 0) { uint8_t sep = MG_RECORD_SEP; rc = mg_sketch_add(ss, &sep, 1); }   // all sketches empty
+        if (rc == MG_OK) rc = session_submit(ss);
+        if (rc != MG_OK) return rc;
+        HIP_TRY(ctx, hipStreamSynchronize(ss->copy_stream));
+        ss->ev_pending[0] = ss->ev_pending[1] = false;
+        const uint64_t s = ss->p.sketch_size;
+        DevBuf<uint64_t> d_hashes(ctx);
+        DevBuf<uint32_t> d_nhash(ctx), d_counts(ctx);
+        if ((counts_out && d_counts.alloc(nsketch * s) != hipSuccess) || d_hashes.alloc(nsketch * s) != hipSuccess ||
+            d_nhash.alloc(nsketch) != hipSuccess)
+            return fail(ctx, MG_ERR_NOMEM, "mg_sketch_finish: device allocation failed");
+        rc = mg_sketch_dev(ctx, &ss->p, ss->d_bases, ss->d_used, ss->off.data(), nsketch, d_hashes, d_nhash, d_counts);
+        if (rc != MG_OK) return rc;
+        if ((counts_out && hipMemcpyAsync(counts_out, d_counts, nsketch * s * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) ||
+            hipMemcpyAsync(hashes_out, d_hashes, nsketch * s * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(nhash_out, d_nhash, nsketch * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess)
+            return fail(ctx, MG_ERR_HIP, "mg_sketch_finish: D2H copy failed");
+    }
+    ss->d_used = 0;                                       // the arena and the staging ring are kept for the next batch
+    ss->fill = 0;
+    ss->off.assign(1, 0);
+    return MG_OK;
+}
+
+void mg_sketch_session_free(mg_sketch_session *ss)
+{
+    if (!ss) return;
+    hipSetDevice(ss->ctx->device);
+    if (ss->copy_stream) { hipStreamSynchronize(ss->copy_stream); hipStreamDestroy(ss->copy_stream); }
+    for (int i = 0; i < 2; i++) {
+        if (ss->stage[i]) hipHostFree(ss->stage[i]);
+        if (ss->ev[i]) hipEventDestroy(ss->ev[i]);
+    }
+    if (ss->d_bases) hipFree(ss->d_bases);
+    delete ss;
 }
 
 /* ------------------------------------------------- reads mode with early stop (-c) */

@@ -266,18 +266,38 @@ struct SketchSet {                            // the part of class Sketch the co
     double kmer_space() const { return std::pow((double)p.alphabet_size, (double)p.kmer); }   // Sketch.cpp:509
 };
 
+// Every visible GPU by default (MASH_GPU_DEVICES="0,1,..." picks some, MASH_GPU_DEVICE=<n> one):
+// a local communicator -- one context per device, RCCL between them.  `ctx` is the first
+// device's context: sketching and screening run there, `dist` and `triangle` shard their row
+// blocks over all of them (mg_compare_*_sharded_host; the reference fans the same loops out to
+// its -p threads, CommandTriangle.cpp:129-139, CommandDistance.cpp:195-232).
 struct Gpu {
+    mg_comm *comm = nullptr;
     mg_ctx *ctx = nullptr;
     Gpu()
     {
-        int dev = 0;
-        if (const char *e = getenv("MASH_GPU_DEVICE")) dev = atoi(e);
-        if (mg_ctx_create(dev, &ctx) != MG_OK) {
-            cerr << "ERROR: no usable GPU: " << mg_last_error(nullptr) << endl;
+        vector<int> devs;
+        if (const char *e = getenv("MASH_GPU_DEVICE")) devs.push_back(atoi(e));
+        else if (const char *l = getenv("MASH_GPU_DEVICES")) {
+            for (const char *q = l; *q;) {
+                char *end;
+                const long v = strtol(q, &end, 10);
+                if (end == q) break;
+                devs.push_back((int)v);
+                q = *end == ',' ? end + 1 : end;
+            }
+        } else {
+            const int n = mg_device_count();
+            for (int i = 0; i < n; i++) devs.push_back(i);
+        }
+        if (devs.empty()) devs.push_back(0);
+        if (mg_comm_create_local(devs.data(), (int)devs.size(), &comm) != MG_OK) {
+            cerr << "ERROR: no usable GPU: " << mg_comm_last_error(nullptr) << endl;
             exit(1);
         }
+        ctx = mg_comm_ctx(comm, 0);
     }
-    ~Gpu() { mg_ctx_destroy(ctx); }
+    ~Gpu() { mg_comm_destroy(comm); }
 };
 
 void params_from_header(Params &p, const mshio::Header &h)     // initParametersFromCapnp, Sketch.cpp:255-324
@@ -293,19 +313,43 @@ void params_from_header(Params &p, const mshio::Header &h)     // initParameters
 }
 
 // One batch of inputs -> GPU -> hash lists appended to `set`.
+// Two modes: `stream` (files -> sketches): the bytes go to a mg_sketch_session as they are parsed --
+// packed into pinned staging buffers and copied to the device while parsing goes on, no
+// concatenated copy on the host; host mode (reads mode, whose -c replay needs the bytes): `bases`.
 struct PendingBatch {
     vector<uint8_t> bases;
     vector<uint64_t> off{0};
     vector<Ref> refs;
+    bool stream = false;
+    mg_sketch_session *sess = nullptr;        // stream mode, created at the first byte (parameters are final by then)
+    uint64_t nbytes = 0;
+    void append(const uint8_t *p, size_t n)
+    {
+        if (sess) {
+            if (mg_sketch_add(sess, p, n) != MG_OK) { cerr << "ERROR: could not stage input for the GPU" << endl; exit(1); }
+        } else {
+            bases.insert(bases.end(), p, p + n);
+        }
+        nbytes += n;
+    }
     void add_record(const string &seq)
     {
-        bases.insert(bases.end(), seq.begin(), seq.end());
-        bases.push_back((uint8_t)MG_RECORD_SEP);
+        append(reinterpret_cast<const uint8_t *>(seq.data()), seq.size());
+        const uint8_t sep = (uint8_t)MG_RECORD_SEP;
+        append(&sep, 1);
     }
     void end_sketch(Ref &&r)
     {
-        off.push_back(bases.size());
+        if (sess) mg_sketch_end_sketch(sess);
+        off.push_back(nbytes);
         refs.push_back(std::move(r));
+    }
+    void reset()
+    {
+        bases.clear();
+        off.assign(1, 0);
+        refs.clear();
+        nbytes = 0;
     }
 };
 
@@ -334,20 +378,35 @@ struct StageClock {
 
 double g_gpu_sketch_seconds = 0;            // time inside mg_sketch_host (MASH_AMD_TIMING)
 
-void flush_batch(Gpu &gpu, SketchSet &set, PendingBatch &b)
+static mg_params batch_params(const SketchSet &set)
 {
-    if (b.refs.empty()) return;
     mg_params mp;
     mg_params_init(&mp, set.p.kmer, set.p.sketch_size, set.p.seed, set.p.alphabet.c_str(), set.p.noncanonical,
                    set.p.preserve_case);
     if (set.p.reads) mp.min_copies = set.p.min_copies;
+    return mp;
+}
+
+// stream mode: the session is opened when the first sketch of a batch arrives
+void ensure_session(Gpu &gpu, const SketchSet &set, PendingBatch &b)
+{
+    if (!b.stream || b.sess) return;
+    const mg_params mp = batch_params(set);
+    if (mg_sketch_begin(gpu.ctx, &mp, &b.sess) != MG_OK) { cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl; exit(1); }
+}
+
+void flush_batch(Gpu &gpu, SketchSet &set, PendingBatch &b)
+{
+    if (b.refs.empty()) return;
+    const mg_params mp = batch_params(set);
     const uint64_t n = b.refs.size(), s = set.p.sketch_size;
     vector<uint64_t> hashes(n * s);
     vector<uint32_t> nhash(n), counts(set.p.counts ? n * s : 0);
-    if (b.bases.empty()) b.bases.push_back((uint8_t)MG_RECORD_SEP);
+    if (!b.sess && b.bases.empty()) b.bases.push_back((uint8_t)MG_RECORD_SEP);
     const auto t_gpu = std::chrono::steady_clock::now();
-    const int sk_rc = mg_sketch_host(gpu.ctx, &mp, b.bases.data(), b.bases.size(), b.off.data(), n, hashes.data(), nhash.data(),
-                                     set.p.counts ? counts.data() : nullptr);
+    const int sk_rc = b.sess ? mg_sketch_finish(b.sess, hashes.data(), nhash.data(), set.p.counts ? counts.data() : nullptr)
+                             : mg_sketch_host(gpu.ctx, &mp, b.bases.data(), b.bases.size(), b.off.data(), n, hashes.data(), nhash.data(),
+                                              set.p.counts ? counts.data() : nullptr);
     g_gpu_sketch_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_gpu).count();
     if (sk_rc != MG_OK) {
         cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl;
@@ -358,7 +417,7 @@ void flush_batch(Gpu &gpu, SketchSet &set, PendingBatch &b)
         if (set.p.counts) b.refs[i].counts.assign(counts.begin() + i * s, counts.begin() + i * s + nhash[i]);
         set.refs.push_back(std::move(b.refs[i]));
     }
-    b = PendingBatch();
+    b.reset();
 }
 
 const uint64_t kBatchBytes = 2ull << 30;
@@ -373,7 +432,7 @@ static bool batch_full(const PendingBatch &b, uint64_t sketch_size)
         const char *e = getenv("MASH_AMD_BATCH_HASHES");
         return e ? std::max<uint64_t>(1, strtoull(e, nullptr, 10)) : kBatchHashes;
     }();
-    return b.bases.size() > kBatchBytes || (uint64_t)b.refs.size() * sketch_size > cap;
+    return b.nbytes > kBatchBytes || (uint64_t)b.refs.size() * sketch_size > cap;
 }
 
 // sketchFile in concatenated mode for ONE file (Sketch.cpp:1147-1336), non-reads: the host half
@@ -420,7 +479,8 @@ ParsedFile parse_file_concatenated(const string &file, int kmer)
 void queue_parsed_file(Gpu &gpu, SketchSet &set, PendingBatch &b, ParsedFile &&pf)
 {
     if (!pf.error.empty()) { cerr << pf.error << endl; exit(1); }
-    b.bases.insert(b.bases.end(), pf.bases.begin(), pf.bases.end());
+    ensure_session(gpu, set, b);
+    b.append(pf.bases.data(), pf.bases.size());
     b.end_sketch(std::move(pf.ref));
     if (batch_full(b, set.p.sketch_size)) flush_batch(gpu, set, b);
 }
@@ -438,6 +498,7 @@ void queue_file_by_sequence(Gpu &gpu, SketchSet &set, PendingBatch &b, const str
         ref.name = rec.name;
         ref.comment = rec.comment;
         ref.length = (uint64_t)l;
+        ensure_session(gpu, set, b);
         b.add_record(rec.seq);
         b.end_sketch(std::move(ref));
         if (batch_full(b, set.p.sketch_size)) flush_batch(gpu, set, b);
@@ -646,6 +707,7 @@ void init_from_files(Gpu &gpu, SketchSet &set, const vector<string> &files, cons
 {
     set.p = p;
     PendingBatch b;
+    b.stream = !getenv("MASH_AMD_NO_STREAM");             // (env: the concatenate-then-copy path, for tests)
     // concatenated mode with -p > 1: files are parsed ahead by a pool of workers (ParsePool)
     auto parseable = [&](size_t i) { return set.p.concatenated && !has_suffix(files[i], kSuffix) && files[i] != "-"; };
     std::unique_ptr<ParsePool> pool;
@@ -673,6 +735,7 @@ void init_from_files(Gpu &gpu, SketchSet &set, const vector<string> &files, cons
         }
     }
     flush_batch(gpu, set, b);
+    if (b.sess) mg_sketch_session_free(b.sess);
 }
 
 string write_set(const SketchSet &set, const string &path)
@@ -735,6 +798,28 @@ void warn_kmer_size(const SketchSet &set, const KmerWarning &w)
 }
 
 // dense table upload
+// the same table on EVERY device of the communicator (host -> GPU 0 -> RCCL broadcast)
+mg_dtable *upload_all(Gpu &gpu, const SketchSet &set, uint64_t s, vector<uint64_t> *lengths_out = nullptr)
+{
+    const uint64_t n = set.refs.size();
+    vector<uint64_t> h(std::max<uint64_t>(n * s, 1), MG_HASH_PAD), len(std::max<uint64_t>(n, 1));
+    vector<uint32_t> nh(std::max<uint64_t>(n, 1));
+    for (uint64_t i = 0; i < n; i++) {
+        const Ref &r = set.refs[i];
+        const uint64_t k = std::min<uint64_t>(r.hashes.size(), s);
+        nh[i] = (uint32_t)k;
+        len[i] = r.length;
+        std::copy(r.hashes.begin(), r.hashes.begin() + k, h.begin() + i * s);
+    }
+    mg_dtable *d = nullptr;
+    if (mg_dtable_upload(gpu.comm, h.data(), nh.data(), len.data(), n, s, &d) != MG_OK) {
+        cerr << "ERROR: " << mg_comm_last_error(gpu.comm) << endl;
+        exit(1);
+    }
+    if (lengths_out) *lengths_out = len;
+    return d;
+}
+
 mg_table *upload(Gpu &gpu, const SketchSet &set, uint64_t s, vector<uint64_t> *lengths_out = nullptr)
 {
     const uint64_t n = set.refs.size();
@@ -999,8 +1084,9 @@ int cmd_dist(int argc, const char **argv)
     const uint64_t nref = ref.refs.size(), nq = qry.refs.size();
     if (nref == 0 || nq == 0) return 0;
     vector<uint64_t> len_ref, len_qry;
-    mg_table *tr = upload(gpu, ref, ref.p.sketch_size, &len_ref);
-    mg_table *tq = upload(gpu, qry, qry.p.sketch_size, &len_qry);
+    mg_dtable *dr = upload_all(gpu, ref, ref.p.sketch_size, &len_ref);
+    mg_dtable *dq = upload_all(gpu, qry, qry.p.sketch_size, &len_qry);
+    mg_table *tr = mg_dtable_local(dr, 0), *tq = mg_dtable_local(dq, 0);
     const double kspace = ref.kmer_space();
     const uint64_t qblock = std::max<uint64_t>(1, (1ull << 24) / nref);
     vector<mg_counts> counts;
@@ -1014,7 +1100,7 @@ int cmd_dist(int argc, const char **argv)
             const uint64_t q1 = std::min(nq, q0 + fblock);
             if (!host_finish_wanted()) {
                 if (!fetch_results(gpu, res, [&](mg_result *o, uint64_t cap, uint64_t *n) {
-                        return mg_compare_rect_results_host(gpu.ctx, tr, tq, q0, q1, ref.p.kmer, kspace, d_max, p_max, o, cap, n); }))
+                        return mg_compare_rect_results_sharded_host(gpu.comm, dr, dq, q0, q1, ref.p.kmer, kspace, d_max, p_max, o, cap, n); }))
                     return 1;
                 emit_rows(out, 0, res.size(), [](uint64_t) { return 1; }, [&](FastOut &o, uint64_t x, unsigned) {
                     const mg_result &e = res[x];
@@ -1034,8 +1120,8 @@ int cmd_dist(int argc, const char **argv)
                     print_pair_line(o, ref.refs[e.col], qry.refs[e.row], comment, pr);
             });
         }
-        mg_table_free(tr);
-        mg_table_free(tq);
+        mg_dtable_free(dr);
+        mg_dtable_free(dq);
         if (w.count > 0 && !p.reads) warn_kmer_size(ref, w);
         return 0;
     }
@@ -1052,13 +1138,13 @@ int cmd_dist(int argc, const char **argv)
         if (dist_lut.empty() && !host_finish_wanted()) {
             // compare + distance + p-value + filters on the device, finished records back
             pairs.resize((q1 - q0) * nref);
-            if (mg_compare_rect_pairs_host(gpu.ctx, tr, tq, q0, q1, ref.p.kmer, kspace, d_max, p_max, pairs.data()) != MG_OK) {
-                cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl;
+            if (mg_compare_rect_pairs_sharded_host(gpu.comm, dr, dq, q0, q1, ref.p.kmer, kspace, d_max, p_max, pairs.data()) != MG_OK) {
+                cerr << "ERROR: " << mg_comm_last_error(gpu.comm) << endl;
                 return 1;
             }
         } else {
             counts.resize((q1 - q0) * nref);
-            if (mg_compare_rect_host(gpu.ctx, tr, tq, q0, q1, counts.data()) != MG_OK) { cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl; return 1; }
+            if (mg_compare_rect_sharded_host(gpu.comm, dr, dq, q0, q1, counts.data()) != MG_OK) { cerr << "ERROR: " << mg_comm_last_error(gpu.comm) << endl; return 1; }
         }
         if (!dist_lut.empty()) {
             emit_rows(out, q0, q1, [&](uint64_t) { return nref; }, [&](FastOut &o, uint64_t q, unsigned) {
@@ -1088,8 +1174,8 @@ int cmd_dist(int argc, const char **argv)
             if (table) o.eol();
         });
     }
-    mg_table_free(tr);
-    mg_table_free(tq);
+    mg_dtable_free(dr);
+    mg_dtable_free(dq);
     if (w.count > 0 && !p.reads) warn_kmer_size(ref, w);
     return 0;
 }
@@ -1133,7 +1219,8 @@ int cmd_triangle(int argc, const char **argv)
         cout << label(set.refs[0]) << endl;
     }
     vector<uint64_t> lengths;
-    mg_table *t = upload(gpu, set, set.p.sketch_size, &lengths);
+    mg_dtable *dt = upload_all(gpu, set, set.p.sketch_size, &lengths);
+    mg_table *t = mg_dtable_local(dt, 0);
     const double kspace = set.kmer_space();
     double p_peak = 0;
     vector<mg_counts> counts;
@@ -1149,7 +1236,7 @@ int cmd_triangle(int argc, const char **argv)
             while (r1 < n && (npairs == 0 || npairs + r1 <= (1ull << 31))) { npairs += r1; r1++; }
             if (!host_finish_wanted()) {
                 if (!fetch_results(gpu, res, [&](mg_result *o, uint64_t cap, uint64_t *cnt) {
-                        return mg_compare_tri_results_host(gpu.ctx, t, r0, r1, set.p.kmer, kspace, d_max, p_max, o, cap, cnt); }))
+                        return mg_compare_tri_results_sharded_host(gpu.comm, dt, r0, r1, set.p.kmer, kspace, d_max, p_max, o, cap, cnt); }))
                     return 1;
                 clk.lap("compare+finish+filter+copy");
                 emit_rows(out, 0, res.size(), [](uint64_t) { return 1; }, [&](FastOut &o, uint64_t x, unsigned) {
@@ -1206,13 +1293,13 @@ int cmd_triangle(int argc, const char **argv)
         if (!lean) pairs.resize(npairs);
         clk.lap("setup");
         if (dev_finish) {
-            if (mg_compare_tri_pairs_host(gpu.ctx, t, r0, r1, set.p.kmer, kspace, d_max, p_max, pairs.data()) != MG_OK) {
-                cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl;
+            if (mg_compare_tri_pairs_sharded_host(gpu.comm, dt, r0, r1, set.p.kmer, kspace, d_max, p_max, pairs.data()) != MG_OK) {
+                cerr << "ERROR: " << mg_comm_last_error(gpu.comm) << endl;
                 return 1;
             }
             clk.lap("compare+finish+copy");
         } else {
-            if (mg_compare_tri_host(gpu.ctx, t, r0, r1, counts.data()) != MG_OK) { cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl; return 1; }
+            if (mg_compare_tri_sharded_host(gpu.comm, dt, r0, r1, counts.data()) != MG_OK) { cerr << "ERROR: " << mg_comm_last_error(gpu.comm) << endl; return 1; }
             clk.lap("compare+copy");
             if (!lean) mg_finish_tri_host(counts.data(), lengths.data(), r0, r1, set.p.kmer, kspace, d_max, p_max, pairs.data());
             clk.lap("finish");
@@ -1269,7 +1356,7 @@ int cmd_triangle(int argc, const char **argv)
         clk.lap("format+write");
         r0 = r1;
     }
-    mg_table_free(t);
+    mg_dtable_free(dt);
     if (!edge) cerr << "Max p-value: " << p_peak << endl;
     if (w.count > 0 && !p.reads) warn_kmer_size(set, w);
     return 0;

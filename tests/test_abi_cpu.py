@@ -134,3 +134,36 @@ def test_no_gpu_fails_loudly(lib):
     assert lib.mg_last_error(None)
     with pytest.raises(abi.MashGpuError):
         abi.MashGpu(0)
+
+
+def test_shard_rows_partition_the_work_evenly(lib):
+    """mg_shard_tri_rows / mg_shard_rows (the row blocks of the multi-GPU paths): blocks
+    tile the row range without gaps, and every block of the triangle holds the same number of
+    pairs to within one row."""
+    for n, rb in ((100_000, 0), (100_000, 1), (12_345, 777), (9, 0), (2, 1), (5, 5)):
+        for G in (1, 2, 3, 4, 8):
+            prev, areas = rb, []
+            for g in range(G):
+                b, e = abi.shard_tri_rows(lib, rb, n, G, g)
+                assert b == prev and b <= e <= n
+                areas.append(abi.tri_pairs(b, e))
+                prev = e
+            assert prev == n and sum(areas) == abi.tri_pairs(rb, n)
+            if n - rb >= 64 * G:
+                assert max(areas) - min(areas) <= 2 * n, (n, rb, G, areas)
+            prev = rb
+            for g in range(G):
+                b, e = C.c_uint64(), C.c_uint64()
+                lib.mg_shard_rows(rb, n, G, g, C.byref(b), C.byref(e))
+                assert b.value == prev and e.value >= b.value
+                prev = e.value
+            assert prev == max(n, rb)
+
+
+def test_comm_without_gpu_fails_loudly(lib):
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("a GPU is present")
+    h = C.c_void_p()
+    devs = (C.c_int * 2)(0, 1)
+    assert lib.mg_comm_create_local(devs, 2, C.byref(h)) != 0
+    assert b"HIP" in lib.mg_comm_last_error(None) or b"device" in lib.mg_comm_last_error(None)

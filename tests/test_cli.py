@@ -441,6 +441,13 @@ def test_sketch_and_triangle_cli_vs_oracle(built, tmp_path, oracle):
         a = run(*cmd, cwd=tmp_path).stdout
         b = run(*cmd, cwd=tmp_path, env=hostfin).stdout
         assert a == b and (a or "-v" in cmd), cmd
+    # several GPUs (here: two contexts on device 0): rows sharded by mg_compare_*_sharded_host, same bytes
+    two = {"MASH_GPU_DEVICES": "0,0"}
+    for cmd in (("triangle", "ind.msh"), ("triangle", "-E", "ind.msh"), ("triangle", "-E", "-d", "0.2", "ind.msh"),
+                ("dist", "ind.msh", "cat.msh"), ("dist", "-t", "ind.msh", "ind.msh"), ("dist", "-d", "0.3", "-v", "1e-3", "ind.msh", "cat.msh")):
+        a = run(*cmd, cwd=tmp_path)
+        b = run(*cmd, cwd=tmp_path, env=two)
+        assert a.stdout == b.stdout and a.stderr == b.stderr, cmd
     e0 = run("triangle", "-d", "0", "ind.msh", cwd=tmp_path).stdout.splitlines()
     assert len(e0) == 1 and e0[0].split("\t")[:3] == ["seq4", "seq0", "0"]
 
@@ -467,6 +474,12 @@ def test_many_short_records_are_sketched_in_bounded_batches(built, tmp_path):
     run("sketch", "-s", "500", "-o", str(tmp_path / "c1"), *files)
     run("sketch", "-s", "500", "-o", str(tmp_path / "c2"), *files, env={"MASH_AMD_BATCH_HASHES": "1200"})
     assert (tmp_path / "c1.msh").read_bytes() == (tmp_path / "c2.msh").read_bytes()
+    # streamed ingest (segments -> pinned ring -> device while parsing) vs the concatenate-then-copy path
+    for extra in ((), ("-p", "4"), ("-i",), ("-M",)):
+        run("sketch", "-s", "500", *extra, "-o", str(tmp_path / "s1"), *files, str(fa))
+        run("sketch", "-s", "500", *extra, "-o", str(tmp_path / "s2"), *files, str(fa), env={"MASH_AMD_NO_STREAM": "1"})
+        run("sketch", "-s", "500", *extra, "-o", str(tmp_path / "s3"), *files, str(fa), env={"MASHGPU_STAGE_BYTES": "333"})
+        assert (tmp_path / "s1.msh").read_bytes() == (tmp_path / "s2.msh").read_bytes() == (tmp_path / "s3.msh").read_bytes(), extra
 
 
 @pytest.mark.gpu

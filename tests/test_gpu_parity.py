@@ -213,6 +213,28 @@ def test_sketch_target_coverage_early_stop(eng, oracle, k, s, m):
     assert u0 == long_enough and np.array_equal(h0, ph[0, : pn[0]]) and np.array_equal(c0, pc[0, : pn[0]])
 
 
+@pytest.mark.parametrize("stage", [None, "4096", "100"])
+def test_streamed_ingest_equals_one_batch(eng, oracle, stage, monkeypatch):
+    """mg_sketch_begin / add / end_sketch / finish (pinned staging ring, copies on a copy stream) ==
+    mg_sketch_host on the concatenation: pieces of any size, sketches spanning many staging buffers,
+    empty sketches, two batches through one session, multiplicities."""
+    if stage:
+        monkeypatch.setenv("MASHGPU_STAGE_BYTES", stage)
+    rng = np.random.default_rng(12)
+    sketches = [synth.adversarial_dna_records(rng, v) for v in (0, 1, 2, 3, 4)]
+    sketches.insert(2, [b""])
+    sketches.append([b"ACGT"])
+    sketches.append([bytes(synth.synthetic_genome(7, 300_000))])
+    p = eng.params(k=21, s=400)
+    want = eng.sketch_host(sketches, p, counts=True)
+    for piece in (None, 7, 1000):
+        got = eng.sketch_stream(sketches, p, counts=True, piece=piece)
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b), (stage, piece)
+    h, n = eng.sketch_stream([[b""], [b"AC"]], p)                       # nothing but empty sketches
+    assert h.shape == (2, 400) and not n.any() and np.all(h == np.uint64(abi.HASH_PAD))
+
+
 def test_sketch_reads_json_golden(eng, golden_dir):
     """mash sketch -r reads1.fastq reads2.fastq == test/ref/reads.json (hashes)."""
     r1 = helpers.read_fastx(os.path.join(golden_dir, "reads1.fastq.gz"))
@@ -919,6 +941,69 @@ def test_device_finish_equals_host_finish(eng, oracle, golden_dir, max_d, max_p)
         assert _same_bits(rr["distance"], hr["distance"][kq, kr]) and _same_bits(rr["p_value"], hr["p_value"][kq, kr])
         tq.free()
         t.free()
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
+def test_sharded_compare_equals_single_gpu(eng, oracle, devices, monkeypatch):
+    """The multi-GPU entry points (mg_comm local mode, mg_dtable, mg_compare_*_sharded_host): row
+    blocks on several contexts, driven by one host thread each, give byte-identical output to the
+    single-context calls.  One GPU here: a device list that repeats device 0 runs the sharding,
+    the threads and the table replication (device copies); the one-device communicator with
+    MASHGPU_COMM_FORCE_RCCL runs the RCCL calls (ncclCommInitAll, grouped ncclBroadcast)."""
+    if devices == [0]:
+        monkeypatch.setenv("MASHGPU_COMM_FORCE_RCCL", "1")
+    table, nh, lengths = synth.clustered_sketches(500, 1000, clusters=7, seed=21)
+    rng = np.random.default_rng(8)
+    lengths = rng.integers(10 ** 5, 10 ** 7, 500).astype(np.uint64)
+    for i in range(0, 500, 50):
+        nh[i] = rng.integers(1, 1000)
+        table[i, nh[i]:] = np.uint64(abi.HASH_PAD)
+    t = eng.table_upload(table, nh, lengths)
+    want = eng.compare_tri_host(t)
+    comm = abi.LocalComm(devices)
+    assert comm.uses_rccl == (devices == [0])
+    d = comm.upload(table, nh, lengths)
+    got = comm.tri(d, 500)
+    assert np.array_equal(got, want)
+    assert np.array_equal(comm.tri(d, 500, 123, 456), eng.compare_tri_host(t, 123, 456))
+    q = np.arange(40, 170)
+    tq = eng.table_upload(table[q], nh[q], lengths[q])
+    dq = comm.upload(table[q], nh[q], lengths[q])
+    assert np.array_equal(comm.rect(d, dq, 500, len(q)), eng.compare_rect_host(t, tq))
+    k, ks = 21, KSPACE21
+    for max_d, max_p in ((-1.0, -1.0), (0.1, 1e-20)):
+        a, b = comm.tri_pairs(d, 500, k, ks, max_d, max_p), eng.compare_tri_pairs(t, k, ks, max_d, max_p)
+        assert a.tobytes() == b.tobytes()
+        a, b = comm.rect_pairs(d, dq, 500, len(q), k, ks, max_d, max_p), eng.compare_rect_pairs(t, tq, k, ks, max_d, max_p)
+        assert a.tobytes() == b.tobytes()
+        a, b = comm.tri_results(d, 500, k, ks, max_d, max_p, capacity=16), eng.compare_tri_results(t, k, ks, max_d, max_p, capacity=1 << 18)
+        assert a.tobytes() == b.tobytes() and (len(a) > 0)
+        a, b = comm.rect_results(d, dq, len(q), k, ks, max_d, max_p), eng.compare_rect_results(t, tq, k, ks, max_d, max_p, capacity=1 << 18)
+        assert a.tobytes() == b.tobytes()
+    comm.free(dq)
+    comm.free(d)
+    comm.close()
+    tq.free()
+    t.free()
+
+
+def test_rank_communicator_single_rank(eng):
+    """mg_comm rank mode with one rank: unique id, ncclCommInitRank, mg_table_broadcast (the root
+    aliases its own table), all-reduce of a u32 buffer -- the call path bench.py takes under
+    torchrun, where the id travels through torch.distributed."""
+    import torch
+    table, nh, lengths = synth.clustered_sketches(64, 200, clusters=2, seed=5)
+    t = eng.table_upload(table, nh, lengths)
+    comm = abi.RankComm(eng, 1, 0, lambda b: b)
+    tb = comm.table_broadcast(t, 64, 200)
+    assert np.array_equal(eng.compare_tri_host(tb), eng.compare_tri_host(t))
+    buf = torch.arange(1000, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    comm.allreduce_u32_sum(buf.data_ptr(), 1000)
+    assert torch.equal(buf.cpu(), torch.arange(1000, dtype=torch.int32))
+    tb.free()
+    comm.close()
+    t.free()
 
 
 def test_compare_c3_scale_properties(eng, oracle):
