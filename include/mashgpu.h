@@ -73,7 +73,9 @@ typedef struct mg_pair {
     uint8_t  _pad[7];
 } mg_pair;
 
-/* ---- context -------------------------------------------------------------- */
+/* ---- context --------------------------------------------------------------
+ * (Tuning knobs are environment variables read per call -- about a microsecond -- so that tests
+ *  can switch engines on a live context; none is needed in normal use) */
 int         mg_device_count(void);               /* visible GPUs (0 when there is none) */
 int         mg_ctx_create(int device, mg_ctx **out);
 void        mg_ctx_destroy(mg_ctx *ctx);
@@ -81,6 +83,14 @@ const char *mg_last_error(mg_ctx *ctx);      /* ctx may be NULL: last create err
 /* Run on an existing hipStream_t (e.g. torch's current stream). NULL = own stream. */
 int         mg_ctx_set_stream(mg_ctx *ctx, void *hip_stream);
 int         mg_ctx_synchronize(mg_ctx *ctx);
+/* Entry points lock their context: any number of host threads may drive one context (their
+ * calls run one at a time, in lock order, on the context's stream).  With async on, the compare
+ * *_dev entry points return as soon as their work is queued on that stream -- tile lists live in
+ * a ring of pinned slots, scratch goes back to the context in stream order, no call ends in a
+ * stream synchronisation once the table's derived data is cached; mg_ctx_synchronize (or work
+ * queued behind on the same stream) completes them, and an error of a queued kernel is reported
+ * by the next synchronising call.  Default off: *_dev calls return with their output complete. */
+int         mg_ctx_set_async(mg_ctx *ctx, int on);
 /* Number of CUs of the device (for callers sizing work). */
 int         mg_ctx_cu_count(mg_ctx *ctx);
 

@@ -21,7 +21,7 @@ HASH_PAD = 0xFFFFFFFFFFFFFFFF
 RECORD_SEP = 0x0A
 
 EXPORTS = [
-    "mg_device_count", "mg_ctx_create", "mg_ctx_destroy", "mg_last_error", "mg_ctx_set_stream", "mg_ctx_synchronize",
+    "mg_device_count", "mg_ctx_create", "mg_ctx_destroy", "mg_last_error", "mg_ctx_set_stream", "mg_ctx_synchronize", "mg_ctx_set_async",
     "mg_ctx_cu_count", "mg_params_init", "mg_sketch_host", "mg_sketch_dev", "mg_sketch_reads_host", "mg_sketch_begin", "mg_sketch_add",
     "mg_sketch_end_sketch", "mg_sketch_pending", "mg_sketch_finish", "mg_sketch_session_free", "mg_table_upload",
     "mg_table_wrap_dev", "mg_table_free", "mg_table_rows", "mg_table_sketch_size",
@@ -144,6 +144,7 @@ def load_library():
     lib.mg_last_error.restype = C.c_char_p
     lib.mg_ctx_set_stream.argtypes = [vp, vp]
     lib.mg_ctx_synchronize.argtypes = [vp]
+    lib.mg_ctx_set_async.argtypes = [vp, i32]
     lib.mg_ctx_cu_count.argtypes = [vp]
     lib.mg_params_init.argtypes = [C.POINTER(MgParams), i32, u64, u32, C.c_char_p, i32, i32]
     lib.mg_sketch_host.argtypes = [vp, C.POINTER(MgParams), vp, u64, vp, u64, vp, vp, vp]
@@ -431,6 +432,9 @@ class MashGpu:
 
     def synchronize(self):
         self._check(self.lib.mg_ctx_synchronize(self.ctx))
+
+    def set_async(self, on=True):
+        self._check(self.lib.mg_ctx_set_async(self.ctx, int(on)))
 
     # ---- sketching ---------------------------------------------------------
     def sketch_host(self, sketches, p, counts=False):

@@ -128,7 +128,10 @@ __device__ __forceinline__ uint32_t mr_prefix(uint64_t v, uint32_t shr)
     return t >= 0xFFFFFFFDull ? 0xFFFFFFFDu : (uint32_t)t;
 }
 
-template <int KU, bool WIN>
+// W0 (window mode): this launch is the FIRST window -- no pair carries state yet and every column is
+// live, so the state loads, the live-column masks and their bookkeeping are compiled out of the
+// launch that does nine tenths of the work.
+template <int KU, bool WIN, bool W0 = false>
 __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
 {
     constexpr int MR_KU = KU;
@@ -167,11 +170,13 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
     const MergedTile *tile_p = a.mtiles + tile_index;
     struct { uint32_t col0, col1; } tile = {tile_p->col0, tile_p->col1};
     const int tid = threadIdx.x;
+#ifdef MASHGPU_TILE_CLOCKS
     if (a.dbg && tid == 0) a.dbg[3 * (uint64_t)blockIdx.x] = __builtin_readcyclecounter();
+#endif
     const uint32_t lane = tid & 63;
     const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
 
-    if (WIN && a.win > 0) {
+    if (WIN && !W0) {
         // later windows: a tile none of whose columns still has a pair in progress has nothing to do
         const uint8_t *m = a.win_mask + (uint64_t)blockIdx.x * MR_NW * a.win_kmax;
         const uint32_t nbytes = MR_NW * a.win_kmax;
@@ -349,7 +354,9 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
     __syncthreads();
     const bool clean = hdr->collide == 0;
 
+#ifdef MASHGPU_TILE_CLOCKS
     if (a.dbg && tid == 0) a.dbg[3 * (uint64_t)blockIdx.x + 1] = __builtin_readcyclecounter();
+#endif
     // ------------------------------------------------------------------ stream columns
     const uint32_t my_n = WIN ? (lane < 32 ? s_rowlen[lane] : 0) : (lane < 32 ? hdr->row_n[lane] : 0);   // row `lane`
     // WIN: index in row `lane` of its first hash at or above the window's end
@@ -364,14 +371,24 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
     //   and (issued during group 0) the first group + length of the wave's next column.
     // VMEM returns in order, so the small L2-resident rank-test operand is always issued
     // BEFORE the streaming loads that follow it.
+    // (src and qbase are uniform: the group's base goes into scalar registers and every load is
+    //  base + lane * 4 + an immediate, no per-load address arithmetic on the vector unit)
     auto load_group = [&](const uint32_t *src, uint32_t qbase, uint32_t (&dst)[MR_KU]) {
+        const uint32_t *gp = src + (uint32_t)__builtin_amdgcn_readfirstlane((int)qbase);
 #pragma unroll
-        for (int u = 0; u < MR_KU; u++) {
-            const uint32_t q = qbase + u * 64 + lane;
-            dst[u] = src[q];                              // rows of the image are padded (0xFFFFFFFF)
-        }
+        for (int u = 0; u < MR_KU; u++) dst[u] = gp[u * 64 + lane];   // rows of the image are padded (0xFFFFFFFF)
     };
     const uint32_t rows_all = (uint32_t)__ballot(my_id != 0xFFFFFFFFu);       // slots in use
+    // Per row, once per tile: which columns it is compared with (j < my_lim: its own index in the
+    // triangle, every column in a rect; 0 for unused slots) and where its results start in the
+    // output (pair index of column 0) -- the column loop then needs neither the triangle flag nor
+    // row_begin / ncols / out_base, which are scalar registers it does not have.
+    const uint32_t my_lim = my_id == 0xFFFFFFFFu ? 0u : (a.triangle ? my_id : 0xFFFFFFFFu);
+    uint64_t my_obase = 0;
+    if (my_id != 0xFFFFFFFFu) {
+        const uint64_t i = my_id;
+        my_obase = a.triangle ? i * (i - 1) / 2 - a.out_base : (i - a.row_begin) * a.ncols;
+    }
     // Wave w owns batches of MR_CB consecutive columns: batch k -> columns
     // col0 + (k*NW + w)*CB ... +CB-1.  Results of a batch are staged in LDS and written
     // as 64-B row segments (nontemporal), instead of 8-B scattered stores that thrash L2.
@@ -387,8 +404,10 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
         __builtin_amdgcn_wave_barrier();
         const uint32_t c0 = (lane & 3u) * 2;
         for (uint32_t r = lane >> 2; r < ((R + 15u) & ~15u); r += 16) {   // uniform trip count: 16 rows per pass
-        const uint64_t i = (uint32_t)__shfl((int)my_id, (int)(r & 31u));   // table row of slot r
-        if (r < R && i != 0xFFFFFFFFull) {
+        const uint32_t lim = (uint32_t)__shfl((int)my_lim, (int)(r & 31u));                // columns of slot r's row
+        const uint64_t obase = (uint64_t)(uint32_t)__shfl((int)(uint32_t)my_obase, (int)(r & 31u)) |
+                               ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(my_obase >> 32), (int)(r & 31u)) << 32);
+        if (r < R && lim != 0) {
             uint4 v;
             if (pack) {
                 const uint2 w = *reinterpret_cast<const uint2 *>(&stage_p[r * MR_CB + c0]);
@@ -404,12 +423,9 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
             // WIN: only the columns this launch worked on (the others keep their earlier result)
             const bool in0 = WIN ? ((procmask >> c0) & 1u) != 0 : c0 < ncols_done;
             const bool in1 = WIN ? ((procmask >> (c0 + 1)) & 1u) != 0 : c0 + 1 < ncols_done;
-            const bool ok0 = in0 && (!a.triangle || j0 < i);
-            const bool ok1 = in1 && (!a.triangle || j0 + 1 < i);
-            uint64_t oidx;
-            if (a.triangle) oidx = i * (i - 1) / 2 + j0 - a.out_base;
-            else oidx = (i - a.row_begin) * a.ncols + j0;
-            uint2 *dst = a.out + oidx;
+            const bool ok0 = in0 && j0 < lim;
+            const bool ok1 = in1 && j0 + 1 < lim;
+            uint2 *dst = a.out + (obase + j0);
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
             typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
             if (ok0 && ok1 && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
@@ -435,11 +451,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
     };
     auto load_state = [&](uint32_t jj) -> uint2 {
         uint2 v = make_uint2(0u, 0u);
-        if (lane < R && my_id != 0xFFFFFFFFu && (!a.triangle || jj < my_id)) {
-            const uint64_t i = my_id;
-            const uint64_t oidx = a.triangle ? i * (i - 1) / 2 + jj - a.out_base : (i - a.row_begin) * a.ncols + jj;
-            v = a.out[oidx];
-        }
+        if (lane < R && jj < my_lim) v = a.out[my_obase + jj];
         return v;
     };
     uint32_t ncol[MR_KU];
@@ -460,7 +472,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
     // first position t' >= t of the wave's column sequence whose column is still live (or beyond the tile)
     auto next_col = [&](uint32_t t) -> uint32_t {
         if (!WIN) return t;
-        if (a.win == 0) return t;
+        if (W0) return t;
         for (;;) {
             const uint32_t k = t / MR_CB;
             if (col_of(k * MR_CB) >= tile.col1) return t;
@@ -473,7 +485,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
             t = nz != 0 ? (k + 1 + (uint32_t)__builtin_ctzll(nz)) * MR_CB : (mk_base + 64u) * MR_CB;
         }
     };
-    if (WIN && a.win > 0) mk_load(0);
+    if (WIN && !W0) mk_load(0);
     uint32_t procmask = 0, progmask = 0;                   // WIN: columns of the open batch worked on / still in progress
     uint32_t tcol = next_col(0);
     uint32_t t1 = next_col(tcol + 1), t2 = next_col(t1 + 1);   // the next two live columns
@@ -483,7 +495,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
             win_range(j, nx_lo, nx_hi);
             const uint32_t j2 = col_of(t1);
             win_range(j2 < tile.col1 ? j2 : j, n2_lo, n2_hi);
-            if (a.win > 0) st_next = load_state(j);
+            if (!W0) st_next = load_state(j);
         }
         load_group(a.col_pfx + (uint64_t)j * a.col_pfx_stride, nx_lo, ncol);
         nB_next = a.col_nhash[j];
@@ -491,19 +503,17 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
     while (j < tile.col1) {
         uint32_t nB = nB_next < s ? nB_next : s;
         const uint32_t *bsrc = a.col_pfx + (uint64_t)j * a.col_pfx_stride;
-        const uint64_t *bsrc64 = a.col_hashes + (uint64_t)j * a.col_stride;
         uint32_t cur[MR_KU], nxt[MR_KU];
 #pragma unroll
         for (int u = 0; u < MR_KU; u++) cur[u] = ncol[u];
         // rows of the tile this column is compared with (triangle: only rows i > j)
-        uint32_t valid = rows_all;
-        if (a.triangle) valid &= (uint32_t)__ballot(my_id != 0xFFFFFFFFu && my_id > j);
+        const uint32_t valid = (uint32_t)__ballot(j < my_lim);
         uint32_t active = valid, brokem = 0;
         uint32_t st_call = 0, st_common = 0;                             // lane r <-> row r
         const uint32_t qlo = WIN ? nx_lo : 0u;                           // this launch's part of the column
         const uint32_t qhi = WIN ? nx_hi : nB;
         uint32_t fin_denom = 0;
-        if (WIN && a.win > 0) {
+        if (WIN && !W0) {
             // pairs decided in an earlier window keep their result; the others resume
             const bool inprog = (st_next.y & 0x80000000u) != 0;
             st_common = st_next.x;
@@ -525,7 +535,7 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
             load_group(a.col_pfx + (uint64_t)jn * a.col_pfx_stride, WIN ? nx_lo : 0u, ncol);
             nB_next = a.col_nhash[jn];
             if (WIN) {
-                if (a.win > 0) st_next = load_state(jn);
+                if (!W0) st_next = load_state(jn);
                 const uint32_t j2x = col_of(t2);
                 win_range(j2x < tile.col1 ? j2x : jn, n2_lo, n2_hi);
             }
@@ -594,13 +604,20 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
 
             bool c_changed = false;
             if (anytie != 0) {
+                // (the window entries are made opaque here, so the compares below are recomputed rather
+                //  than kept as twelve live 64-bit masks across the fast path -- scalar registers are
+                //  what this kernel runs out of)
+#pragma unroll
+                for (int u = 0; u < MR_KU; u++)
+#pragma unroll
+                    for (int w = 0; w < MR_W; w++) asm volatile("" : "+v"(h[u][w]));
                 // ---- exact path: which rows contain which elements, ranked in column order ----
 #pragma unroll
                 for (int u = 0; u < MR_KU; u++) {
                     if (tiem[u] == 0) continue;                          // uniform
                     const uint32_t qb = q0 + u * 64;
                     const bool mine = (tiem[u] >> lane) & 1ULL;
-                    const uint64_t b = mine ? bsrc64[qb + lane] : 0;   // 64-bit value only for tied lanes
+                    const uint64_t b = mine ? a.col_hashes[(uint64_t)j * a.col_stride + qb + lane] : 0;   // 64-bit value only for tied lanes
                     if (clean) {
                         // every table entry with b's prefix holds the same value (build pass 3): collect
                         // the rows and b's index in each from LDS, verify ONE representative on 64 bits
@@ -792,9 +809,11 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
         t2 = next_col(t2 + 1);
         j = col_of(tcol);
     }
+#ifdef MASHGPU_TILE_CLOCKS
     if (a.dbg) {
         if (lane == 0) atomicMax(&a.dbg[3 * (uint64_t)blockIdx.x + 2], (unsigned long long)__builtin_readcyclecounter());
     }
+#endif
 }
 
 __global__ void table_max_kernel(const uint64_t *hashes, const uint32_t *nhash, uint64_t n, uint64_t stride,
@@ -924,10 +943,10 @@ uint32_t compare_window_rows(uint32_t s) { return s < 32768u ? MR_WIN_ROWS : MR_
 uint32_t compare_window_entries() { return MR_WIN_ENTRIES; }
 uint32_t compare_window_row_entries() { return (1u << MR_WIN_IDX_BITS) - 1u; }
 
-template <int KU, bool WIN = false>
+template <int KU, bool WIN = false, bool W0 = false>
 static hipError_t launch_merged_k(const CompareArgs &a, uint32_t ntiles, size_t smem, hipStream_t stream)
 {
-    auto kern = compare_merged_kernel<KU, WIN>;
+    auto kern = compare_merged_kernel<KU, WIN, W0>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
@@ -946,10 +965,17 @@ hipError_t launch_compare_merged(const CompareArgs &a_in, uint32_t ntiles, hipSt
         a.nbuckets = MR_WIN_BUCKETS;
         a.win_ecap = MR_WIN_ENTRIES;
         const size_t wsmem = merged_lds_bytes_e(MR_WIN_ROWS / 2, MR_WIN_ENTRIES, MR_WIN_BUCKETS);
+        if (a.win == 0) {
+            switch (a.unroll ? (int)a.unroll : 3) {
+                case 2: return launch_merged_k<2, true, true>(a, ntiles, wsmem, stream);
+                case 4: return launch_merged_k<4, true, true>(a, ntiles, wsmem, stream);
+                default: return launch_merged_k<3, true, true>(a, ntiles, wsmem, stream);
+            }
+        }
         switch (a.unroll ? (int)a.unroll : 3) {
             case 2: return launch_merged_k<2, true>(a, ntiles, wsmem, stream);
-            case 3: return launch_merged_k<3, true>(a, ntiles, wsmem, stream);
-            default: return launch_merged_k<4, true>(a, ntiles, wsmem, stream);
+            case 4: return launch_merged_k<4, true>(a, ntiles, wsmem, stream);
+            default: return launch_merged_k<3, true>(a, ntiles, wsmem, stream);
         }
     }
     a.nbuckets = merged_buckets(a.rows_per_tile, a.s);

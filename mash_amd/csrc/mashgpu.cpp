@@ -39,10 +39,17 @@ struct mg_ctx {
     std::string err;
     bool prof = false;
     std::vector<ProfRec> prof_compare, prof_sketch;
-    // tile lists of the compare launches: device buffer + pinned staging, kept across calls
-    // (entry points are synchronous, so a call never finds them in use)
-    void *tile_dev = nullptr, *tile_host = nullptr;
-    size_t tile_cap = 0;
+    // Entry points lock the context: any number of host threads may drive one context, one call at
+    // a time (SURVEY 8b "thread-safe per ctx"); recursive because entry points call each other.
+    std::recursive_mutex mu;
+    // mg_ctx_set_async: compare *_dev calls return once their work is queued on `stream`
+    bool async = false;
+    // tile lists of the compare launches: a ring of {device buffer, pinned staging}; a slot is taken
+    // again only after the launches that read it are done (its event), so calls need not end in a
+    // stream synchronisation for the list's sake
+    struct TileSlot { void *dev = nullptr, *host = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool pending = false; };
+    TileSlot slots[4];
+    unsigned slot_next = 0;
     // small device blocks handed back by finished calls (ctx_malloc / ctx_free)
     struct Block { void *p; size_t bytes; };
     std::vector<Block> blk_free, blk_live;
@@ -203,8 +210,11 @@ void mg_ctx_destroy(mg_ctx *ctx)
 {
     if (!ctx) return;
     mg_prof_reset(ctx);
-    if (ctx->tile_dev) hipFree(ctx->tile_dev);
-    if (ctx->tile_host) hipHostFree(ctx->tile_host);
+    for (auto &sl : ctx->slots) {
+        if (sl.dev) hipFree(sl.dev);
+        if (sl.host) hipHostFree(sl.host);
+        if (sl.done) hipEventDestroy(sl.done);
+    }
     for (auto &b : ctx->blk_free) hipFree(b.p);
     for (auto &b : ctx->blk_live) hipFree(b.p);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
@@ -216,6 +226,7 @@ const char *mg_last_error(mg_ctx *ctx) { return ctx ? ctx->err.c_str() : g_creat
 int mg_ctx_set_stream(mg_ctx *ctx, void *hip_stream)
 {
     if (!ctx) return MG_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (ctx->own_stream && ctx->stream) { hipStreamDestroy(ctx->stream); ctx->own_stream = false; }
     if (hip_stream == nullptr) {
         HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
@@ -226,9 +237,18 @@ int mg_ctx_set_stream(mg_ctx *ctx, void *hip_stream)
     return MG_OK;
 }
 
+int mg_ctx_set_async(mg_ctx *ctx, int on)
+{
+    if (!ctx) return MG_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    ctx->async = on != 0;
+    return MG_OK;
+}
+
 int mg_ctx_synchronize(mg_ctx *ctx)
 {
     if (!ctx) return MG_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return MG_OK;
@@ -666,6 +686,7 @@ static int sketch_dev_impl(mg_ctx *ctx, const mg_params *p, const uint8_t *bases
                            uint32_t *nhash_out_dev, uint32_t *counts_out_dev, const ProbeHook *probe)
 {
     if (!ctx) return MG_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (!p || !sketch_off || !hashes_out_dev || !nhash_out_dev || (!bases_dev && nbases))
         return fail(ctx, MG_ERR_INVALID, "mg_sketch: NULL argument");
     if (p->kmer_size < 1 || p->kmer_size > 32) return fail(ctx, MG_ERR_INVALID, "mg_sketch: k must be 1..32");
@@ -767,6 +788,7 @@ int mg_sketch_host(mg_ctx *ctx, const mg_params *p, const uint8_t *bases, uint64
                    uint32_t *nhash_out, uint32_t *counts_out)
 {
     if (!ctx) return MG_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (!p || !hashes_out || !nhash_out) return fail(ctx, MG_ERR_INVALID, "mg_sketch_host: NULL argument");
     if (nsketch == 0) return MG_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -815,6 +837,7 @@ struct mg_sketch_session {
 static int session_submit(mg_sketch_session *ss)
 {
     mg_ctx *ctx = ss->ctx;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (ss->fill == 0) return MG_OK;
     if (ss->d_used + ss->fill + 64 > ss->d_cap) {
         // grow the device arena (copies what has arrived; rare: capacity doubles)
@@ -845,6 +868,7 @@ static int session_submit(mg_sketch_session *ss)
 int mg_sketch_begin(mg_ctx *ctx, const mg_params *p, mg_sketch_session **out)
 {
     if (!ctx) return MG_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (!p || !out) return fail(ctx, MG_ERR_INVALID, "mg_sketch_begin: NULL argument");
     if (p->target_cov > 0) return fail(ctx, MG_ERR_UNSUPPORTED, "mg_sketch_begin: target_cov needs mg_sketch_reads_host");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -896,6 +920,7 @@ int mg_sketch_finish(mg_sketch_session *ss, uint64_t *hashes_out, uint32_t *nhas
 {
     if (!ss) return MG_ERR_INVALID;
     mg_ctx *ctx = ss->ctx;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     const uint64_t nsketch = ss->off.size() - 1;
     int rc = MG_OK;
     if (nsketch) {
@@ -996,6 +1021,7 @@ int mg_sketch_reads_host(mg_ctx *ctx, const mg_params *p, const uint8_t *bases, 
                          uint32_t *nhash_out, uint32_t *counts_out, uint64_t *records_used_out)
 {
     if (!ctx) return MG_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (!p || !hashes_out || !nhash_out || (!bases && nbases)) return fail(ctx, MG_ERR_INVALID, "mg_sketch_reads_host: NULL argument");
     if (p->kmer_size < 1 || p->kmer_size > 32) return fail(ctx, MG_ERR_INVALID, "mg_sketch: k must be 1..32");
     const uint64_t s = p->sketch_size, k = (uint64_t)p->kmer_size;
@@ -1129,6 +1155,7 @@ int mg_table_upload(mg_ctx *ctx, const uint64_t *hashes, const uint32_t *nhash, 
                     uint64_t n, uint64_t s, mg_table **out)
 {
     if (!ctx) return MG_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (!hashes || !nhash || !out || s == 0) return fail(ctx, MG_ERR_INVALID, "mg_table_upload: bad argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     DevBuf<uint64_t> dh, dl;
@@ -1150,6 +1177,7 @@ int mg_table_wrap_dev(mg_ctx *ctx, const uint64_t *hashes_dev, const uint32_t *n
                       const uint64_t *lengths_dev, uint64_t n, uint64_t s, mg_table **out)
 {
     if (!ctx) return MG_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (!hashes_dev || !nhash_dev || !out || s == 0) return fail(ctx, MG_ERR_INVALID, "mg_table_wrap_dev: bad argument");
     mg_table *t = new mg_table;
     t->ctx = ctx; t->hashes = hashes_dev; t->nhash = nhash_dev; t->lengths = lengths_dev;
@@ -1274,21 +1302,38 @@ static int table_windows(mg_ctx *ctx, const mg_table *t, int shr, uint32_t delta
     return MG_OK;
 }
 
-// Copies a tile list to the context's device scratch through pinned staging (grown on demand).
-static int stage_tiles(mg_ctx *ctx, const void *tiles, size_t bytes, void **dev_out)
+// Copies a tile list to the device through a slot of the context's staging ring (grown on demand);
+// tiles_release marks the slot as in use until the launches queued so far are done.
+static int stage_tiles(mg_ctx *ctx, const void *tiles, size_t bytes, void **dev_out, int *slot_out)
 {
-    if (bytes > ctx->tile_cap) {
-        if (ctx->tile_dev) { hipFree(ctx->tile_dev); ctx->tile_dev = nullptr; }
-        if (ctx->tile_host) { hipHostFree(ctx->tile_host); ctx->tile_host = nullptr; }
-        ctx->tile_cap = 0;
-        const size_t cap = std::max<size_t>(bytes + bytes / 2, 1u << 16);
-        HIP_TRY(ctx, hipMalloc(&ctx->tile_dev, cap));
-        HIP_TRY(ctx, hipHostMalloc(&ctx->tile_host, cap, hipHostMallocDefault));
-        ctx->tile_cap = cap;
+    const int si = (int)(ctx->slot_next++ % 4u);
+    mg_ctx::TileSlot &sl = ctx->slots[si];
+    if (!sl.done) HIP_TRY(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    if (sl.pending) {                                      // four launches behind at most
+        HIP_TRY(ctx, hipEventSynchronize(sl.done));
+        sl.pending = false;
     }
-    memcpy(ctx->tile_host, tiles, bytes);
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->tile_dev, ctx->tile_host, bytes, hipMemcpyHostToDevice, ctx->stream));
-    *dev_out = ctx->tile_dev;
+    if (bytes > sl.cap) {
+        if (sl.dev) { hipFree(sl.dev); sl.dev = nullptr; }
+        if (sl.host) { hipHostFree(sl.host); sl.host = nullptr; }
+        sl.cap = 0;
+        const size_t cap = std::max<size_t>(bytes + bytes / 2, 1u << 16);
+        HIP_TRY(ctx, hipMalloc(&sl.dev, cap));
+        HIP_TRY(ctx, hipHostMalloc(&sl.host, cap, hipHostMallocDefault));
+        sl.cap = cap;
+    }
+    memcpy(sl.host, tiles, bytes);
+    HIP_TRY(ctx, hipMemcpyAsync(sl.dev, sl.host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    *dev_out = sl.dev;
+    *slot_out = si;
+    return MG_OK;
+}
+
+static int tiles_release(mg_ctx *ctx, int slot)
+{
+    mg_ctx::TileSlot &sl = ctx->slots[slot];
+    HIP_TRY(ctx, hipEventRecord(sl.done, ctx->stream));
+    sl.pending = true;
     return MG_OK;
 }
 
@@ -1519,7 +1564,8 @@ static int run_compare_merged(mg_ctx *ctx, const mg_table *rows, const mg_table 
         }
         if (mtiles.empty()) continue;
         void *d_mt = nullptr;
-        rc = stage_tiles(ctx, mtiles.data(), mtiles.size() * sizeof(mg::MergedTile), &d_mt);
+        int slot = 0;
+        rc = stage_tiles(ctx, mtiles.data(), mtiles.size() * sizeof(mg::MergedTile), &d_mt, &slot);
         if (rc != MG_OK) return rc;
         unsigned long long *d_dbg = nullptr;
         const size_t dbg_sets = wr ? nwin : 1;                  // one {start, built, end} set per tile and launch
@@ -1560,9 +1606,12 @@ static int run_compare_merged(mg_ctx *ctx, const mg_table *rows, const mg_table 
             e = mg::launch_compare_merged(a, (uint32_t)mtiles.size(), ctx->stream);
             prof_end(ctx, ctx->prof_compare);
         }
-        hipError_t e2 = hipStreamSynchronize(ctx->stream);              // the tile list is reused by the next launch
+        // (no synchronisation: the tile list sits in its own slot of the ring, the masks go back to
+        //  the block cache in stream order)
+        hipError_t e2 = e == hipSuccess ? (tiles_release(ctx, slot) == MG_OK ? hipSuccess : hipErrorUnknown) : hipSuccess;
         ctx_free(ctx, d_mask);
         if (d_dbg) {
+            hipStreamSynchronize(ctx->stream);
             std::vector<unsigned long long> h(dbg_sets * mtiles.size() * 3);
             hipMemcpy(h.data(), d_dbg, h.size() * 8, hipMemcpyDeviceToHost);
             for (size_t w = 0; w < dbg_sets; w++) {
@@ -1679,8 +1728,9 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
     }
     if (tiles.empty()) return MG_OK;
     void *d_tiles = nullptr;
+    int slot = 0;
     {
-        const int rc = stage_tiles(ctx, tiles.data(), tiles.size() * sizeof(mg::CompareTile), &d_tiles);
+        const int rc = stage_tiles(ctx, tiles.data(), tiles.size() * sizeof(mg::CompareTile), &d_tiles, &slot);
         if (rc != MG_OK) return rc;
     }
     a.dbg = nullptr;
@@ -1688,10 +1738,8 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
     prof_begin(ctx, ctx->prof_compare);
     hipError_t e = mg::launch_compare_tiled(a, (uint32_t)tiles.size(), ctx->stream);
     prof_end(ctx, ctx->prof_compare);
-    hipError_t e2 = hipStreamSynchronize(ctx->stream);      // the tile list is reused by the next launch
     if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare launch: ") + hipGetErrorString(e));
-    if (e2 != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare kernel: ") + hipGetErrorString(e2));
-    return MG_OK;
+    return tiles_release(ctx, slot);
 }
 
 static uint64_t tri_pairs(uint64_t row_begin, uint64_t row_end)
@@ -1705,7 +1753,11 @@ int mg_compare_tri_dev(mg_ctx *ctx, const mg_table *t, uint64_t row_begin, uint6
 {
     if (!ctx) return MG_ERR_INVALID;
     if (!t || !out_dev) return fail(ctx, MG_ERR_INVALID, "mg_compare_tri_dev: NULL argument");
-    return run_compare(ctx, t, t, row_begin, row_end, true, out_dev);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    const int rc = run_compare(ctx, t, t, row_begin, row_end, true, out_dev);
+    if (rc != MG_OK || ctx->async) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MG_OK;
 }
 
 int mg_compare_rect_dev(mg_ctx *ctx, const mg_table *ref, const mg_table *qry, uint64_t q_begin,
@@ -1713,7 +1765,11 @@ int mg_compare_rect_dev(mg_ctx *ctx, const mg_table *ref, const mg_table *qry, u
 {
     if (!ctx) return MG_ERR_INVALID;
     if (!ref || !qry || !out_dev) return fail(ctx, MG_ERR_INVALID, "mg_compare_rect_dev: NULL argument");
-    return run_compare(ctx, qry, ref, q_begin, q_end, false, out_dev);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    const int rc = run_compare(ctx, qry, ref, q_begin, q_end, false, out_dev);
+    if (rc != MG_OK || ctx->async) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MG_OK;
 }
 
 // host-output variants: bounded device staging, processed in row blocks
@@ -1761,6 +1817,7 @@ static int compare_host(mg_ctx *ctx, const mg_table *rows, const mg_table *cols,
 int mg_compare_tri_host(mg_ctx *ctx, const mg_table *t, uint64_t row_begin, uint64_t row_end, mg_counts *out_host)
 {
     if (!ctx) return MG_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (!t || !out_host) return fail(ctx, MG_ERR_INVALID, "mg_compare_tri_host: NULL argument");
     return compare_host(ctx, t, t, row_begin, row_end, true, out_host);
 }
@@ -1769,6 +1826,7 @@ int mg_compare_rect_host(mg_ctx *ctx, const mg_table *ref, const mg_table *qry, 
                          uint64_t q_end, mg_counts *out_host)
 {
     if (!ctx) return MG_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (!ref || !qry || !out_host) return fail(ctx, MG_ERR_INVALID, "mg_compare_rect_host: NULL argument");
     return compare_host(ctx, qry, ref, q_begin, q_end, false, out_host);
 }
@@ -1972,6 +2030,7 @@ int mg_compare_tri_filter_host(mg_ctx *ctx, const mg_table *t, uint64_t row_begi
                                double max_distance, mg_edge *out_host, uint64_t capacity, uint64_t *count_out)
 {
     if (!ctx) return MG_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (!t || !count_out || (!out_host && capacity)) return fail(ctx, MG_ERR_INVALID, "mg_compare_tri_filter_host: NULL argument");
     return compare_filter(ctx, t, t, row_begin, row_end, true, kmer_size, max_distance, out_host, capacity, count_out);
 }
@@ -1981,6 +2040,7 @@ int mg_compare_rect_filter_host(mg_ctx *ctx, const mg_table *ref, const mg_table
                                 uint64_t *count_out)
 {
     if (!ctx) return MG_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (!ref || !qry || !count_out || (!out_host && capacity))
         return fail(ctx, MG_ERR_INVALID, "mg_compare_rect_filter_host: NULL argument");
     return compare_filter(ctx, qry, ref, q_begin, q_end, false, kmer_size, max_distance, out_host, capacity, count_out);
@@ -2076,6 +2136,7 @@ int mg_finish_tri_dev(mg_ctx *ctx, const mg_table *t, const mg_counts *counts_de
                       int kmer_size, double kmer_space, double max_distance, double max_p_value, mg_pair *out_dev)
 {
     if (!ctx) return MG_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (!t || !counts_dev || !out_dev) return fail(ctx, MG_ERR_INVALID, "mg_finish_tri_dev: NULL argument");
     if (row_end > t->n) row_end = t->n;
     if (row_begin >= row_end) return MG_OK;
@@ -2088,6 +2149,7 @@ int mg_finish_rect_dev(mg_ctx *ctx, const mg_table *ref, const mg_table *qry, co
                        mg_pair *out_dev)
 {
     if (!ctx) return MG_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (!ref || !qry || !counts_dev || !out_dev) return fail(ctx, MG_ERR_INVALID, "mg_finish_rect_dev: NULL argument");
     if (q_end > qry->n) q_end = qry->n;
     if (q_begin >= q_end) return MG_OK;
@@ -2162,6 +2224,7 @@ int mg_compare_tri_pairs_host(mg_ctx *ctx, const mg_table *t, uint64_t row_begin
                               double kmer_space, double max_distance, double max_p_value, mg_pair *out_host)
 {
     if (!ctx) return MG_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (!t || !out_host) return fail(ctx, MG_ERR_INVALID, "mg_compare_tri_pairs_host: NULL argument");
     if (!t->lengths) return fail(ctx, MG_ERR_INVALID, "mg_compare_tri_pairs_host: the table carries no lengths");
     return compare_pairs_host(ctx, t, t, row_begin, row_end, true, kmer_size, kmer_space, max_distance, max_p_value, out_host);
@@ -2171,6 +2234,7 @@ int mg_compare_rect_pairs_host(mg_ctx *ctx, const mg_table *ref, const mg_table 
                                int kmer_size, double kmer_space, double max_distance, double max_p_value, mg_pair *out_host)
 {
     if (!ctx) return MG_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (!ref || !qry || !out_host) return fail(ctx, MG_ERR_INVALID, "mg_compare_rect_pairs_host: NULL argument");
     if (!ref->lengths || !qry->lengths) return fail(ctx, MG_ERR_INVALID, "mg_compare_rect_pairs_host: the tables carry no lengths");
     return compare_pairs_host(ctx, qry, ref, q_begin, q_end, false, kmer_size, kmer_space, max_distance, max_p_value, out_host);
@@ -2280,6 +2344,7 @@ int mg_compare_tri_results_host(mg_ctx *ctx, const mg_table *t, uint64_t row_beg
                                 uint64_t capacity, uint64_t *count_out)
 {
     if (!ctx) return MG_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (!t || !count_out || (!out_host && capacity)) return fail(ctx, MG_ERR_INVALID, "mg_compare_tri_results_host: NULL argument");
     if (!t->lengths) return fail(ctx, MG_ERR_INVALID, "mg_compare_tri_results_host: the table carries no lengths");
     return compare_results(ctx, t, t, row_begin, row_end, true, kmer_size, kmer_space, max_distance, max_p_value, out_host, capacity, count_out);
@@ -2290,6 +2355,7 @@ int mg_compare_rect_results_host(mg_ctx *ctx, const mg_table *ref, const mg_tabl
                                  uint64_t capacity, uint64_t *count_out)
 {
     if (!ctx) return MG_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (!ref || !qry || !count_out || (!out_host && capacity))
         return fail(ctx, MG_ERR_INVALID, "mg_compare_rect_results_host: NULL argument");
     if (!ref->lengths || !qry->lengths) return fail(ctx, MG_ERR_INVALID, "mg_compare_rect_results_host: the tables carry no lengths");
@@ -2737,6 +2803,7 @@ struct mg_screen {
 int mg_screen_create(mg_ctx *ctx, const mg_params *p, const mg_table *db, mg_screen **out)
 {
     if (!ctx) return MG_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (!p || !db || !out) return fail(ctx, MG_ERR_INVALID, "mg_screen_create: NULL argument");
     const bool dna = alphabet_is_dna(p);
     if (!p->noncanonical && !dna) return fail(ctx, MG_ERR_UNSUPPORTED, "mg_screen: canonical k-mers need the ACGT alphabet");
@@ -2769,6 +2836,7 @@ int mg_screen_create(mg_ctx *ctx, const mg_params *p, const mg_table *db, mg_scr
 int mg_screen_create_translated(mg_ctx *ctx, const mg_params *p, const mg_table *db, mg_screen **out)
 {
     if (!ctx) return MG_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (!p || !out) return fail(ctx, MG_ERR_INVALID, "mg_screen_create_translated: NULL argument");
     if (!p->noncanonical || alphabet_is_dna(p))
         return fail(ctx, MG_ERR_INVALID, "mg_screen_create_translated: needs an amino-acid (noncanonical) alphabet");
@@ -2783,6 +2851,7 @@ int mg_screen_add_dev(mg_screen *sc, const uint8_t *bases_dev, uint64_t nbases)
 {
     if (!sc) return MG_ERR_INVALID;
     mg_ctx *ctx = sc->ctx;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (sc->translate) return screen_add_translated(sc, bases_dev, nbases);
     const uint64_t k = (uint64_t)sc->p.kmer_size;
     if (nbases < k) return MG_OK;
@@ -2823,6 +2892,7 @@ int mg_screen_add_dev(mg_screen *sc, const uint8_t *bases_dev, uint64_t nbases)
 static int screen_add_translated(mg_screen *sc, const uint8_t *bases_dev, uint64_t nbases)
 {
     mg_ctx *ctx = sc->ctx;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (nbases < 3) return MG_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint64_t seg = (nbases / 3 + 1 + 15) & ~15ull;        // >= one separator byte after every frame
@@ -2845,6 +2915,7 @@ int mg_screen_add_host(mg_screen *sc, const uint8_t *bases, uint64_t nbases)
 {
     if (!sc) return MG_ERR_INVALID;
     mg_ctx *ctx = sc->ctx;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (!bases && nbases) return fail(ctx, MG_ERR_INVALID, "mg_screen_add_host: NULL bases");
     if (nbases == 0) return MG_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -2864,6 +2935,7 @@ int mg_screen_counts_dev(mg_screen *sc, uint32_t *counts_out_dev)
 {
     if (!sc) return MG_ERR_INVALID;
     mg_ctx *ctx = sc->ctx;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (!counts_out_dev) return fail(ctx, MG_ERR_INVALID, "mg_screen_counts_dev: NULL argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (sc->db->n * sc->db->s == 0) return MG_OK;
@@ -2879,6 +2951,7 @@ int mg_screen_finish_host(mg_screen *sc, uint32_t *counts_out, uint64_t *mix_has
 {
     if (!sc) return MG_ERR_INVALID;
     mg_ctx *ctx = sc->ctx;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint64_t total = sc->db->n * sc->db->s;
     if (counts_out && total) {
@@ -2939,6 +3012,7 @@ void mg_screen_free(mg_screen *sc)
 int mg_prof_enable(mg_ctx *ctx, int on)
 {
     if (!ctx) return MG_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     ctx->prof = on != 0;
     return MG_OK;
 }

@@ -1006,6 +1006,69 @@ def test_rank_communicator_single_rank(eng):
     t.free()
 
 
+def test_two_host_threads_drive_one_context(eng):
+    """entry points are thread-safe per context -- two host threads issue sketch and
+    compare calls on ONE mg_ctx at the same time (ctypes releases the GIL); every result equals the
+    single-threaded one."""
+    import threading
+    table, nh, lengths = synth.clustered_sketches(400, 1000, clusters=5, seed=2)
+    t = eng.table_upload(table, nh, lengths)
+    want_c = eng.compare_tri_host(t)
+    rng = np.random.default_rng(4)
+    sketches = [synth.adversarial_dna_records(rng, v) for v in (0, 1, 2, 3)] + [[bytes(synth.synthetic_genome(3, 200_000))]]
+    p = eng.params(k=21, s=500)
+    want_s = eng.sketch_host(sketches, p, counts=True)
+    errors = []
+
+    def compares():
+        try:
+            for _ in range(6):
+                assert np.array_equal(eng.compare_tri_host(t), want_c)
+                assert np.array_equal(eng.compare_tri_host(t, 100, 300), want_c[abi.tri_pairs(0, 100):abi.tri_pairs(0, 300)])
+        except Exception as e:                                     # noqa: BLE001
+            errors.append(e)
+
+    def sketching():
+        try:
+            for _ in range(6):
+                got = eng.sketch_host(sketches, p, counts=True)
+                assert all(np.array_equal(a, b) for a, b in zip(got, want_s))
+        except Exception as e:                                     # noqa: BLE001
+            errors.append(e)
+
+    th = [threading.Thread(target=compares), threading.Thread(target=sketching), threading.Thread(target=compares)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errors, errors
+    t.free()
+
+
+def test_async_compare_calls_are_stream_ordered(eng):
+    """mg_ctx_set_async: compare *_dev calls only queue their work (tile lists in the ring of pinned
+    slots); several calls back to back -- more than the ring has slots -- then ONE synchronisation;
+    every output equals the synchronous one."""
+    import torch
+    table, nh, lengths = synth.clustered_sketches(600, 1000, clusters=6, seed=13)
+    t = eng.table_upload(table, nh, lengths)
+    want = eng.compare_tri_host(t)
+    nq = 9
+    outs = [torch.zeros((abi.tri_pairs(0, 600), 2), dtype=torch.int32, device="cuda") for _ in range(nq)]
+    torch.cuda.synchronize()
+    eng.set_async(True)
+    try:
+        for o in outs:
+            eng.compare_tri_dev(t, 0, 600, o.data_ptr())
+        eng.synchronize()
+    finally:
+        eng.set_async(False)
+    for o in outs:
+        got = o.cpu().numpy().view(np.uint32)
+        assert np.array_equal(got[:, 0], want["numer"]) and np.array_equal(got[:, 1], want["denom"])
+    t.free()
+
+
 def test_compare_c3_scale_properties(eng, oracle):
     """BASELINE config 3 shape at a size the oracle can sample: N = 6000 clustered
     s=1000 sketches (1.8e7 pairs).  Checks (a) sampled rows against the oracle,
