@@ -348,6 +348,18 @@ void mg_screen_free(mg_screen *sc);
 double mg_identity(uint64_t common, uint64_t denom, int kmer_size);
 double mg_p_value_within(uint64_t x, uint64_t set_size, double kmer_space, uint64_t sketch_size);
 
+/* Screening on every GPU of a local communicator: the mixture is sharded by batch (batch b ->
+ * device b mod G, each with its own replica of the query table and its own host thread), the
+ * observation counters are summed at the end (ncclReduce to GPU 0) and the per-device mixture
+ * sketches merged -- SURVEY.md section 8e, the C++ form of mash_amd/screen_dist.py.  Results equal
+ * one mg_screen fed every batch.  mg_dscreen_add_host returns once the batch is copied. */
+typedef struct mg_dscreen mg_dscreen;
+int  mg_dscreen_create(mg_comm *c, const mg_params *p, const mg_dtable *db, int translated, mg_dscreen **out);
+int  mg_dscreen_add_host(mg_dscreen *d, const uint8_t *bases, uint64_t nbases);
+int  mg_dscreen_finish_host(mg_dscreen *d, uint32_t *counts_out, uint64_t *mix_hashes_out, uint32_t *mix_nhash_out,
+                            uint64_t *distinct_out);
+void mg_dscreen_free(mg_dscreen *d);
+
 /* ---- timing hook for bench.py ----------------------------------------------
  * Average duration (ms) of the last `name` kernel launches recorded with HIP
  * events on the context's stream since mg_prof_reset; name = "compare" or

@@ -38,6 +38,7 @@ EXPORTS = [
     "mg_dtable_free", "mg_dtable_local", "mg_table_broadcast", "mg_comm_allreduce_u32_sum",
     "mg_compare_tri_sharded_host", "mg_compare_rect_sharded_host", "mg_compare_tri_pairs_sharded_host",
     "mg_compare_rect_pairs_sharded_host", "mg_compare_tri_results_sharded_host", "mg_compare_rect_results_sharded_host",
+    "mg_dscreen_create", "mg_dscreen_add_host", "mg_dscreen_finish_host", "mg_dscreen_free",
 ]
 
 
@@ -209,6 +210,11 @@ def load_library():
     lib.mg_compare_rect_pairs_sharded_host.argtypes = [vp, vp, vp, u64, u64, i32, dbl, dbl, dbl, vp]
     lib.mg_compare_tri_results_sharded_host.argtypes = [vp, vp, u64, u64, i32, dbl, dbl, dbl, vp, u64, vp]
     lib.mg_compare_rect_results_sharded_host.argtypes = [vp, vp, vp, u64, u64, i32, dbl, dbl, dbl, vp, u64, vp]
+    lib.mg_dscreen_create.argtypes = [vp, C.POINTER(MgParams), vp, i32, C.POINTER(vp)]
+    lib.mg_dscreen_add_host.argtypes = [vp, vp, u64]
+    lib.mg_dscreen_finish_host.argtypes = [vp, vp, vp, C.POINTER(u32), C.POINTER(u64)]
+    lib.mg_dscreen_free.argtypes = [vp]
+    lib.mg_dscreen_free.restype = None
     lib.mg_distance.argtypes = [u32, u32, i32]
     lib.mg_distance.restype = dbl
     lib.mg_p_value.argtypes = [u64, u64, u64, dbl, u64]
@@ -323,6 +329,22 @@ class LocalComm:
 
     def free(self, d):
         self.lib.mg_dtable_free(d)
+
+    def screen(self, d, n, s, p, batches, translate=False):
+        """sharded screen of `batches` (lists of records) against replicated table d"""
+        h = C.c_void_p()
+        self._check(self.lib.mg_dscreen_create(self.h, C.byref(p), d, int(translate), C.byref(h)))
+        try:
+            for recs in batches:
+                blob = np.frombuffer(join_records(recs), dtype=np.uint8)
+                self._check(self.lib.mg_dscreen_add_host(h, blob.ctypes.data, len(blob)))
+            counts = np.zeros((n, s), dtype=np.uint32)
+            mix = np.zeros(int(p.sketch_size), dtype=np.uint64)
+            mn, dist = C.c_uint32(0), C.c_uint64(0)
+            self._check(self.lib.mg_dscreen_finish_host(h, counts.ctypes.data, mix.ctypes.data, C.byref(mn), C.byref(dist)))
+            return counts, mix[: mn.value].copy(), int(dist.value)
+        finally:
+            self.lib.mg_dscreen_free(h)
 
     def tri(self, d, n, row_begin=0, row_end=None):
         row_end = n if row_end is None else row_end

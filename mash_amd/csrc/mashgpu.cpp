@@ -5,6 +5,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
+#include <memory>
 #include <iterator>
 #include <map>
 #include <mutex>
@@ -3005,6 +3007,164 @@ void mg_screen_free(mg_screen *sc)
     if (sc->keys) hipFree(sc->keys);
     if (sc->obs) hipFree(sc->obs);
     delete sc;
+}
+
+/* ------------------------------------------------- screening on several GPUs (local communicator) */
+
+// The mixture is sharded by BATCH: batch b goes to device b mod G, which screens it against its own
+// replica of the query table on its own host thread while the caller parses the next batch; the
+// one exchange is the sum of the per-hash observation counters at the end (ncclReduce to GPU 0
+// over xGMI, or host adds when the communicator has no RCCL) plus the merge of the G mixture
+// sketches (bottom-s of their union).  Same results as one mg_screen fed every batch.
+struct mg_dscreen {
+    mg_comm *comm = nullptr;
+    const mg_dtable *db = nullptr;
+    std::vector<mg_screen *> sc;
+    struct Worker {
+        std::thread th;
+        std::mutex m;
+        std::condition_variable cv;
+        std::vector<uint8_t> buf;
+        bool busy = false, stop = false;
+        int rc = MG_OK;
+    };
+    std::vector<std::unique_ptr<Worker>> w;
+    unsigned next = 0;
+};
+
+int mg_dscreen_create(mg_comm *c, const mg_params *p, const mg_dtable *db, int translated, mg_dscreen **out)
+{
+    int rc = dtable_check(c, db, "mg_dscreen_create");
+    if (rc != MG_OK) return rc;
+    if (!p || !out) return comm_fail(c, MG_ERR_INVALID, "mg_dscreen_create: NULL argument");
+    mg_dscreen *d = new mg_dscreen;
+    d->comm = c;
+    d->db = db;
+    const size_t G = c->ctxs.size();
+    for (size_t g = 0; g < G; g++) {
+        mg_screen *s1 = nullptr;
+        rc = translated ? mg_screen_create_translated(c->ctxs[g], p, db->t[g], &s1) : mg_screen_create(c->ctxs[g], p, db->t[g], &s1);
+        if (rc != MG_OK) { c->err = c->ctxs[g]->err; mg_dscreen_free(d); return rc; }
+        d->sc.push_back(s1);
+    }
+    for (size_t g = 0; g < G; g++) {
+        d->w.emplace_back(new mg_dscreen::Worker);
+        mg_dscreen::Worker *wk = d->w.back().get();
+        mg_screen *s1 = d->sc[g];
+        wk->th = std::thread([wk, s1]() {
+            std::unique_lock<std::mutex> lk(wk->m);
+            for (;;) {
+                wk->cv.wait(lk, [&] { return wk->busy || wk->stop; });
+                if (wk->stop && !wk->busy) return;
+                lk.unlock();
+                const int r = mg_screen_add_host(s1, wk->buf.data(), wk->buf.size());
+                lk.lock();
+                if (r != MG_OK && wk->rc == MG_OK) wk->rc = r;
+                wk->busy = false;
+                wk->cv.notify_all();
+            }
+        });
+    }
+    *out = d;
+    return MG_OK;
+}
+
+// hands one batch (records separated by MG_RECORD_SEP) to the next device; returns once the bytes are
+// copied (the caller's buffer is free again), not when the batch is screened
+int mg_dscreen_add_host(mg_dscreen *d, const uint8_t *bases, uint64_t nbases)
+{
+    if (!d) return MG_ERR_INVALID;
+    if (!bases && nbases) return comm_fail(d->comm, MG_ERR_INVALID, "mg_dscreen_add_host: NULL bases");
+    if (nbases == 0) return MG_OK;
+    mg_dscreen::Worker *wk = d->w[d->next++ % d->w.size()].get();
+    std::unique_lock<std::mutex> lk(wk->m);
+    wk->cv.wait(lk, [&] { return !wk->busy; });
+    if (wk->rc != MG_OK) return wk->rc;
+    wk->buf.assign(bases, bases + nbases);
+    wk->busy = true;
+    wk->cv.notify_all();
+    return MG_OK;
+}
+
+int mg_dscreen_finish_host(mg_dscreen *d, uint32_t *counts_out, uint64_t *mix_hashes_out, uint32_t *mix_nhash_out,
+                           uint64_t *distinct_out)
+{
+    if (!d) return MG_ERR_INVALID;
+    mg_comm *c = d->comm;
+    const size_t G = d->sc.size();
+    for (size_t g = 0; g < G; g++) {                                      // drain the workers
+        mg_dscreen::Worker *wk = d->w[g].get();
+        std::unique_lock<std::mutex> lk(wk->m);
+        wk->cv.wait(lk, [&] { return !wk->busy; });
+        if (wk->rc != MG_OK) { c->err = c->ctxs[g]->err; return wk->rc; }
+    }
+    const uint64_t total = d->db->t[0]->n * d->db->t[0]->s;
+    const uint64_t s = d->sc[0]->p.sketch_size;
+    // device 0 delivers its own counts, the distinct-hash number and (below) receives the others' counts
+    std::vector<uint64_t> mix0(s);
+    uint32_t mn0 = 0;
+    if (G == 1) return mg_screen_finish_host(d->sc[0], counts_out, mix_hashes_out, mix_nhash_out, distinct_out);
+    int rc = mg_screen_finish_host(d->sc[0], nullptr, mix0.data(), &mn0, distinct_out);
+    if (rc != MG_OK) { c->err = c->ctxs[0]->err; return rc; }
+    std::vector<uint64_t> merged(mix0.begin(), mix0.begin() + mn0);
+    for (size_t g = 1; g < G; g++) {                                      // mixture sketch: bottom-s of the union
+        const std::vector<uint64_t> &m = d->sc[g]->mix;
+        std::vector<uint64_t> u;
+        u.reserve(merged.size() + m.size());
+        std::merge(merged.begin(), merged.end(), m.begin(), m.end(), std::back_inserter(u));
+        u.erase(std::unique(u.begin(), u.end()), u.end());
+        if (u.size() > s) u.resize(s);
+        merged.swap(u);
+    }
+    if (mix_hashes_out) for (uint64_t i = 0; i < s; i++) mix_hashes_out[i] = i < merged.size() ? merged[i] : MG_HASH_PAD;
+    if (mix_nhash_out) *mix_nhash_out = (uint32_t)merged.size();
+    if (!counts_out || total == 0) return MG_OK;
+    // observation counters: sum over the devices
+    std::vector<uint32_t *> bufs(G, nullptr);
+    auto release = [&]() { for (size_t g = 0; g < G; g++) if (bufs[g]) { hipSetDevice(c->ctxs[g]->device); hipFree(bufs[g]); } };
+    for (size_t g = 0; g < G; g++) {
+        if (hipSetDevice(c->ctxs[g]->device) != hipSuccess || hipMalloc(&bufs[g], total * 4) != hipSuccess) {
+            release();
+            return comm_fail(c, MG_ERR_NOMEM, "mg_dscreen_finish_host: device allocation failed");
+        }
+        rc = mg_screen_counts_dev(d->sc[g], bufs[g]);
+        if (rc != MG_OK) { c->err = c->ctxs[g]->err; release(); return rc; }
+    }
+    if (!c->comms.empty()) {
+        ncclResult_t r = ncclGroupStart();
+        for (size_t g = 0; g < G && r == ncclSuccess; g++)
+            r = ncclReduce(bufs[g], bufs[g], total, ncclUint32, ncclSum, 0, c->comms[g], c->ctxs[g]->stream);
+        const ncclResult_t r2 = ncclGroupEnd();
+        if (r == ncclSuccess) r = r2;
+        if (r != ncclSuccess) { release(); return comm_fail(c, MG_ERR_HIP, std::string("ncclReduce: ") + ncclGetErrorString(r)); }
+        rc = comm_sync_all(c);
+        if (rc == MG_OK && (hipSetDevice(c->ctxs[0]->device) != hipSuccess ||
+                            hipMemcpy(counts_out, bufs[0], total * 4, hipMemcpyDeviceToHost) != hipSuccess))
+            rc = comm_fail(c, MG_ERR_HIP, "mg_dscreen_finish_host: D2H copy failed");
+    } else {
+        std::vector<uint32_t> part(total);
+        memset(counts_out, 0, total * 4);
+        for (size_t g = 0; g < G && rc == MG_OK; g++) {
+            if (hipSetDevice(c->ctxs[g]->device) != hipSuccess || hipMemcpy(part.data(), bufs[g], total * 4, hipMemcpyDeviceToHost) != hipSuccess)
+                rc = comm_fail(c, MG_ERR_HIP, "mg_dscreen_finish_host: D2H copy failed");
+            else
+                for (uint64_t i = 0; i < total; i++) counts_out[i] += part[i];
+        }
+    }
+    release();
+    return rc;
+}
+
+void mg_dscreen_free(mg_dscreen *d)
+{
+    if (!d) return;
+    for (auto &wk : d->w) {
+        { std::lock_guard<std::mutex> lk(wk->m); wk->stop = true; }
+        wk->cv.notify_all();
+        if (wk->th.joinable()) wk->th.join();
+    }
+    for (mg_screen *s1 : d->sc) mg_screen_free(s1);
+    delete d;
 }
 
 /* ------------------------------------------------------------------ profiling */

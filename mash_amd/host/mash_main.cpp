@@ -519,6 +519,13 @@ void sketch_reads(Gpu &gpu, SketchSet &set, const vector<string> &files)
         readers.push_back(r);
     }
     PendingBatch b;
+    // Without -c the reads leave for the device as they are parsed (pinned staging ring, copies
+    // overlapped with parsing): the host never holds the read set, only the device does (one
+    // sketch over everything at the end, exact as before; 288 GB of HBM bound the input).  -c
+    // replays the heap on the host over a thinned event stream and still takes the bytes from
+    // host memory (mg_sketch_reads_host).
+    b.stream = !(set.p.target_cov > 0) && !getenv("MASH_AMD_NO_STREAM");
+    ensure_session(gpu, set, b);
     fastx::Record rec;
     size_t it = 0;
     long l = -1;
@@ -575,6 +582,7 @@ void sketch_reads(Gpu &gpu, SketchSet &set, const vector<string> &files)
         b.end_sketch(std::move(ref));
         flush_batch(gpu, set, b);
     }
+    if (b.sess) mg_sketch_session_free(b.sess);
     Ref &r = set.refs.back();
     // estimateSetSize (MinHashHeap.h:45): 2^bits * n / max kept hash
     double est = 0;
@@ -818,27 +826,6 @@ mg_dtable *upload_all(Gpu &gpu, const SketchSet &set, uint64_t s, vector<uint64_
     }
     if (lengths_out) *lengths_out = len;
     return d;
-}
-
-mg_table *upload(Gpu &gpu, const SketchSet &set, uint64_t s, vector<uint64_t> *lengths_out = nullptr)
-{
-    const uint64_t n = set.refs.size();
-    vector<uint64_t> h(std::max<uint64_t>(n * s, 1), MG_HASH_PAD), len(std::max<uint64_t>(n, 1));
-    vector<uint32_t> nh(std::max<uint64_t>(n, 1));
-    for (uint64_t i = 0; i < n; i++) {
-        const Ref &r = set.refs[i];
-        const uint64_t k = std::min<uint64_t>(r.hashes.size(), s);
-        nh[i] = (uint32_t)k;
-        len[i] = r.length;
-        std::copy(r.hashes.begin(), r.hashes.begin() + k, h.begin() + i * s);
-    }
-    mg_table *t = nullptr;
-    if (mg_table_upload(gpu.ctx, h.data(), nh.data(), len.data(), n, s, &t) != MG_OK) {
-        cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl;
-        exit(1);
-    }
-    if (lengths_out) *lengths_out = len;
-    return t;
 }
 
 // ------------------------------------------------------------------------------- commands
@@ -1544,12 +1531,13 @@ int cmd_screen(int argc, const char **argv)
     Gpu gpu;
     cerr << "Loading " << c.args[0] << "..." << endl;
     const uint64_t n = set.refs.size(), s = set.p.sketch_size;
-    mg_table *t = upload(gpu, set, s);
+    // the query table on every GPU; the mixture is sharded by batch over them (mg_dscreen)
+    mg_dtable *t = upload_all(gpu, set, s);
     mg_params mp;
     mg_params_init(&mp, set.p.kmer, s, set.p.seed, set.p.alphabet.c_str(), set.p.noncanonical, set.p.preserve_case);
-    mg_screen *sc = nullptr;
-    if ((trans ? mg_screen_create_translated(gpu.ctx, &mp, t, &sc) : mg_screen_create(gpu.ctx, &mp, t, &sc)) != MG_OK) {
-        cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl;
+    mg_dscreen *sc = nullptr;
+    if (mg_dscreen_create(gpu.comm, &mp, t, trans ? 1 : 0, &sc) != MG_OK) {
+        cerr << "ERROR: " << mg_comm_last_error(gpu.comm) << endl;
         return 1;
     }
     const int nq = (int)c.args.size() - 1;
@@ -1563,9 +1551,11 @@ int cmd_screen(int argc, const char **argv)
     // mixture records, round robin over the inputs (CommandScreen.cpp:197-270); records < k are dropped
     vector<uint8_t> batch;
     batch.reserve(256u << 20);
+    size_t screen_batch_bytes = 255u << 20;
+    if (const char *e = getenv("MASH_AMD_SCREEN_BATCH")) screen_batch_bytes = std::max<size_t>(64, strtoull(e, nullptr, 10));   // test knob
     auto flush = [&]() {
         if (batch.empty()) return;
-        if (mg_screen_add_host(sc, batch.data(), batch.size()) != MG_OK) { cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl; exit(1); }
+        if (mg_dscreen_add_host(sc, batch.data(), batch.size()) != MG_OK) { cerr << "ERROR: " << mg_comm_last_error(gpu.comm) << endl; exit(1); }
         batch.clear();
     };
     fastx::Record rec;
@@ -1585,7 +1575,7 @@ int cmd_screen(int argc, const char **argv)
         if (l >= set.p.kmer) {
             batch.insert(batch.end(), rec.seq.begin(), rec.seq.end());
             batch.push_back((uint8_t)MG_RECORD_SEP);
-            if (batch.size() > (255u << 20)) flush();
+            if (batch.size() > screen_batch_bytes) flush();
         }
         it++;
         if (it == readers.size()) it = 0;
@@ -1597,9 +1587,9 @@ int cmd_screen(int argc, const char **argv)
     vector<uint64_t> mix(s);
     uint32_t mix_n = 0;
     uint64_t distinct = 0;
-    if (mg_screen_finish_host(sc, counts.data(), mix.data(), &mix_n, &distinct) != MG_OK) { cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl; return 1; }
-    mg_screen_free(sc);
-    mg_table_free(t);
+    if (mg_dscreen_finish_host(sc, counts.data(), mix.data(), &mix_n, &distinct) != MG_OK) { cerr << "ERROR: " << mg_comm_last_error(gpu.comm) << endl; return 1; }
+    mg_dscreen_free(sc);
+    mg_dtable_free(t);
     cerr << "   " << distinct << " distinct hashes." << endl;
     cerr << (trans ? "Translating from " : "Streaming from ");
     if (nq == 1) cerr << c.args[1]; else cerr << nq << " inputs";

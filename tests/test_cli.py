@@ -325,6 +325,11 @@ def test_make_test_screen_recipe_on_gpu(built, tmp_path):
     assert 44 <= tot <= 44 + 36 and len(w) >= 1                      # shared hashes are assigned to one winner each
     none = run("screen", "-i", "0.95", "genomes.msh", "reads1.fastq", cwd=tmp_path).stdout
     assert none == ""
+    # several GPUs (two contexts on device 0 here) and many small batches: the mixture is sharded by
+    # batch (mg_dscreen), the counters are summed -- same bytes on stdout and stderr
+    multi = run("screen", "genomes.msh", "reads1.fastq", "reads2.fastq", cwd=tmp_path,
+                env={"MASH_GPU_DEVICES": "0,0", "MASH_AMD_SCREEN_BATCH": "40000"})
+    assert multi.stdout == r.stdout and multi.stderr == r.stderr
 
 
 @pytest.mark.gpu
@@ -475,7 +480,7 @@ def test_many_short_records_are_sketched_in_bounded_batches(built, tmp_path):
     run("sketch", "-s", "500", "-o", str(tmp_path / "c2"), *files, env={"MASH_AMD_BATCH_HASHES": "1200"})
     assert (tmp_path / "c1.msh").read_bytes() == (tmp_path / "c2.msh").read_bytes()
     # streamed ingest (segments -> pinned ring -> device while parsing) vs the concatenate-then-copy path
-    for extra in ((), ("-p", "4"), ("-i",), ("-M",)):
+    for extra in ((), ("-p", "4"), ("-i",), ("-M",), ("-r",), ("-r", "-m", "2")):
         run("sketch", "-s", "500", *extra, "-o", str(tmp_path / "s1"), *files, str(fa))
         run("sketch", "-s", "500", *extra, "-o", str(tmp_path / "s2"), *files, str(fa), env={"MASH_AMD_NO_STREAM": "1"})
         run("sketch", "-s", "500", *extra, "-o", str(tmp_path / "s3"), *files, str(fa), env={"MASHGPU_STAGE_BYTES": "333"})

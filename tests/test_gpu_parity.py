@@ -987,6 +987,38 @@ def test_sharded_compare_equals_single_gpu(eng, oracle, devices, monkeypatch):
     t.free()
 
 
+@pytest.mark.parametrize("devices", [[0], [0, 0, 0]])
+def test_sharded_screen_equals_single_gpu(eng, devices, monkeypatch):
+    """mg_dscreen: mixture batches dealt to the devices of a local communicator, counters summed
+    (ncclReduce on the forced one-rank communicator, host adds on the repeated-device list),
+    mixture sketches merged == one mg_screen fed every batch."""
+    if devices == [0]:
+        monkeypatch.setenv("MASHGPU_COMM_FORCE_RCCL", "1")
+    rng = np.random.default_rng(17)
+    genomes = [synth.synthetic_genome(40_000 * g, 60_000) for g in range(6)]
+    p = eng.params(k=21, s=300)
+    hashes, nhash = eng.sketch_host([[bytes(g)] for g in genomes], p)
+    lengths = np.full(6, 60_000, dtype=np.uint64)
+    batches = []
+    for b in range(7):
+        recs = []
+        for _ in range(300):
+            g = genomes[int(rng.integers(0, 4))]
+            o = int(rng.integers(0, len(g) - 150))
+            recs.append(bytes(g[o:o + 150]))
+        batches.append(recs)
+    t = eng.table_upload(hashes, nhash, lengths)
+    want = eng.screen(t, p, batches)
+    comm = abi.LocalComm(devices)
+    d = comm.upload(hashes, nhash, lengths)
+    got = comm.screen(d, 6, 300, p, batches)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and got[2] == want[2]
+    assert want[0][:4].sum() > 0
+    comm.free(d)
+    comm.close()
+    t.free()
+
+
 def test_rank_communicator_single_rank(eng):
     """mg_comm rank mode with one rank: unique id, ncclCommInitRank, mg_table_broadcast (the root
     aliases its own table), all-reduce of a u32 buffer -- the call path bench.py takes under
