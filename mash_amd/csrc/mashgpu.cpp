@@ -1479,7 +1479,12 @@ static int run_compare_merged(mg_ctx *ctx, const mg_table *rows, const mg_table 
     // lower half of the hash range (the union of two sketches reaches s elements there), so the
     // first window holds ~0.54 s hashes of a row and 29 rows share a tile -- and a probe -- instead
     // of 16; the few pairs still open (related sketches) go on to the next window.
-    bool want_win = a.s >= 200;
+    // Measured (profiles/r02_engine_sweep.txt, s = 1000): the window engine wins from ~30 000 sketches
+    // on (40 000: 16.9 vs 15.5e9 pairs/s; 70 000: 22.2 vs 17.2; 100 000: 26.5 vs 17.7) and loses below
+    // (20 000: 10.2 vs 11.9; 10 000: 6.0 vs 7.5) -- more launches, each with its tail, and a table
+    // build per tile and window -- so small jobs keep plain tiles; large sketches (s >= 1800) always
+    // take windows (plain tiles would hold 8 rows or fewer).
+    bool want_win = a.s >= 1800 || (a.s >= 200 && (row_end - row_begin) * maxcols >= 800000000ull);
     if (const char *e = getenv("MASHGPU_COMPARE_WINDOWS")) want_win = atoi(e) != 0;
     if (windows_only) want_win = true;
     const uint32_t R_plain = R;
@@ -1489,8 +1494,12 @@ static int run_compare_merged(mg_ctx *ctx, const mg_table *rows, const mg_table 
     // so not below 256).  Every class is its own launch, so this is decided per class.
     const bool cc_forced = getenv("MASHGPU_COMPARE_COLS") != nullptr;
     auto chunk_for = [&](uint64_t nrt) -> uint64_t {
-        if (cc_forced || nrt == 0 || nrt * ((maxcols + CC - 1) / CC) >= 512) return CC;
-        uint64_t chunks = (1024 + nrt - 1) / nrt;
+        // measured (profiles/r02_engine_sweep.txt): 2048 tiles pay from ~10 000 columns on (n = 10 000:
+        // 4.1 -> 6.0e9 pairs/s windows, 6.3 -> 7.5e9 plain); below that the tiles get too short for their builds
+        uint64_t min_tiles = maxcols >= 8192 ? 2048 : 512;  // (MASHGPU_COMPARE_MIN_TILES: tuning knob)
+        if (const char *e = getenv("MASHGPU_COMPARE_MIN_TILES")) min_tiles = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
+        if (cc_forced || nrt == 0 || nrt * ((maxcols + CC - 1) / CC) >= min_tiles) return CC;
+        uint64_t chunks = (2 * min_tiles + nrt - 1) / nrt;
         const uint64_t most = std::max<uint64_t>(1, maxcols / 256);
         if (chunks > most) {
             // the floor of 256 columns binds: then at least fill whole rounds of the CUs
