@@ -112,6 +112,10 @@ long Reader::next(Record &rec)
         (void)need;
         begin_ = (int)(b - buf_);
     }
+    // kseq's loop reads a byte BEFORE it tests whether the quality string is complete
+    // (`while ((c = ks_getc(ks)) != -1 && qual.l < seq.l)`, kseq.h:201), so one more byte -- the
+    // newline of a well-formed file, a header character if there is none -- is consumed
+    if (q == rec.seq.size()) (void)getc_();
     last_char_ = 0;
     if (q != rec.seq.size()) return -2;
     return (long)rec.seq.size();

@@ -844,7 +844,9 @@ int cmd_sketch(int argc, const char **argv)
     if (c.args.empty() || c.o("help").active) {
         cout << "\nUsage:\n\n  mash sketch [options] <input> [<input>] ...\n\n"
                 "Create a sketch file (.msh) from fasta/fastq inputs (gzipped or not) on the GPU.\n"
-                "Options: -l -o <prefix> -I <id> -C <comment> -k <1-32> -s <size> -S <seed> -i -n -a -z <alphabet> -Z -r -g <size> -w <p>\n\n";
+                "Options: -l -o <prefix> -I <id> -C <comment> -p <threads> -k <1-32> -s <size> -S <seed> -i -n -a -z <alphabet> -Z -w <p>\n"
+                "Reads:   -r  -m <min copies> (0 is taken as 1: the reference's behaviour for 0 is undefined)  -c <target coverage>\n"
+                "         -g <genome size>  -M (store multiplicities)      (-b, the Bloom filter, is not supported)\n\n";
         return 0;
     }
     Params p;

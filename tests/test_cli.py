@@ -215,9 +215,9 @@ def _kseq_bytewise(data):
         if c == -1:
             return recs, -2
         q = 0
-        while q < len(seq):
+        while True:                                  # kseq.h:201 reads a byte, THEN tests qual.l < seq.l
             c = getc()
-            if c == -1:
+            if c == -1 or q >= len(seq):
                 break
             if 33 <= c <= 127:
                 q += 1
@@ -241,6 +241,8 @@ def test_fastx_reader_matches_bytewise_kseq_on_random_input(built, tmp_path):
     for trial in range(40):
         size = int(rng.choice([50, 2000, 70000, 140000]))
         body = rng.choice(alpha, size=size, p=weights).tobytes()
+        if trial % 4 == 1:                                   # quality string followed DIRECTLY by the next header (no newline):
+            body = b"@a\nACGT\n+\nIIII@b\nGGCC\n+\nIIII>c\nTTTT\n" + body      # kseq swallows that header byte (kseq.h:201)
         if trial % 4 == 0:                                   # a well-formed long FASTQ record across the buffer edge
             seq = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=66000).tobytes()
             body = b"@r1 c\n" + seq + b"\n+\n" + b"I" * (66000 if trial % 8 else 65990) + b"\n" + body
