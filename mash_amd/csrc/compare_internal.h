@@ -53,6 +53,11 @@ struct CompareArgs {
     uint32_t win_kmax;            // batches of 8 columns per wave and tile
     uint32_t xcd_remap;           // 1: XCD x takes the x-th contiguous eighth of the tile list
     uint32_t stage_pack;          // window mode: results staged as u16 pairs (s < 32768; set by the launcher)
+    // direct-mapped engine (compare_direct.hip): scratch regions in HBM for the table builds
+    uint32_t *dscr_pfx;           // [regions][16384] prefixes of a tile's entries, bucket by bucket
+    uint16_t *dscr_tag;           // [regions][16384] their tags
+    uint32_t *dscr_lock;          // [regions] 0 = free
+    uint32_t dscr_regions;
 };
 
 // LDS-tiled kernel usable when s <= 1024; rows_per_tile chosen by compare_rows_per_tile.
@@ -78,6 +83,13 @@ hipError_t launch_row_classes(const uint64_t *hashes, const uint32_t *nhash, uin
 uint64_t compare_pfx_stride(uint64_t s);          // row stride (u32 entries) of the padded prefix image
 hipError_t launch_make_prefix(const uint64_t *hashes, const uint32_t *nhash, uint64_t n, uint64_t s,
                               uint64_t pfx_stride, uint32_t shr, uint32_t *out, hipStream_t stream);
+// Direct-mapped engine (compare_direct.hip): window tiles over a fingerprint table read with one
+// ds_read_b128 per column element; same arguments as the merged kernel in window mode plus scratch.
+bool compare_direct_supported(uint32_t s);
+uint32_t compare_direct_rows();
+uint32_t compare_direct_entries();
+uint32_t compare_direct_row_entries();
+hipError_t launch_compare_direct(const CompareArgs &a, uint32_t ntiles, hipStream_t stream);
 // Merge-path kernel (s <= ~4000): one wave per pair, row in LDS; ~500 instructions per pair
 // whatever the pair shares.
 bool compare_pairs_supported(uint32_t s);

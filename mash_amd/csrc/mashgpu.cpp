@@ -52,6 +52,9 @@ struct mg_ctx {
     struct TileSlot { void *dev = nullptr, *host = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool pending = false; };
     TileSlot slots[4];
     unsigned slot_next = 0;
+    // scratch regions of the direct-mapped compare engine's table builds (compare_direct.hip), allocated on first use
+    void *dscr = nullptr;
+    uint32_t dscr_regions = 0;
     // small device blocks handed back by finished calls (ctx_malloc / ctx_free)
     struct Block { void *p; size_t bytes; };
     std::vector<Block> blk_free, blk_live;
@@ -212,6 +215,7 @@ void mg_ctx_destroy(mg_ctx *ctx)
 {
     if (!ctx) return;
     mg_prof_reset(ctx);
+    if (ctx->dscr) hipFree(ctx->dscr);
     for (auto &sl : ctx->slots) {
         if (sl.dev) hipFree(sl.dev);
         if (sl.host) hipHostFree(sl.host);
@@ -1375,8 +1379,9 @@ static double window_target(uint32_t s, uint32_t rows_max)
 // `must`: the sketches are too large for plain tiles (s > 16 384), so a class that would be served
 // by one window (few hashes, or none) still gets a plan -- of that single window.
 static int plan_windows(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, const std::vector<uint32_t> &list, int shr,
-                        uint64_t xmax, uint32_t s, bool must, WindowPlan *out)
+                        uint64_t xmax, uint32_t s, bool must, WindowPlan *out, uint32_t row_cap = 0)
 {
+    if (row_cap == 0) row_cap = mg::compare_window_row_entries();         // entries of one row a tile's tag can index
     const uint32_t Rw = mg::compare_window_rows(s);
     double target = window_target(s, Rw);                                    // entries of the densest row per window
     if (const char *e = getenv("MASHGPU_COMPARE_WIN_TARGET")) target = std::max(1.0, atof(e));
@@ -1423,7 +1428,7 @@ static int plan_windows(mg_ctx *ctx, const mg_table *rows, const mg_table *cols,
             bool room = k - g0 < Rw;
             for (uint32_t w = 0; w < nwin; w++) {
                 const uint32_t c = o[w + 1] - o[w];
-                if (c > mg::compare_window_row_entries()) fits = false;      // the tag's index field
+                if (c > row_cap) fits = false;                               // the tag's index field
                 if (tot[w] + c > mg::compare_window_entries()) room = false;
             }
             if (!room) {                                                     // row k opens the next tile
@@ -1487,6 +1492,12 @@ static int run_compare_merged(mg_ctx *ctx, const mg_table *rows, const mg_table 
     bool want_win = a.s >= 1800 || (a.s >= 200 && (row_end - row_begin) * maxcols >= 800000000ull);
     if (const char *e = getenv("MASHGPU_COMPARE_WINDOWS")) want_win = atoi(e) != 0;
     if (windows_only) want_win = true;
+    // window tiles over the direct-mapped table (compare_direct.hip): MASHGPU_COMPARE_KERNEL=direct forces
+    // it (with windows), MASHGPU_COMPARE_DIRECT=0|1 switches the default
+    bool want_direct = false;
+    if (const char *e = getenv("MASHGPU_COMPARE_DIRECT")) want_direct = atoi(e) != 0;
+    if (const char *e = getenv("MASHGPU_COMPARE_KERNEL")) { if (strcmp(e, "direct") == 0) { want_direct = true; want_win = true; } }
+    if (windows_only) want_direct = false;
     const uint32_t R_plain = R;
     // A launch of few row tiles (a handful of queries against a large database, or a small
     // density class) would leave most CUs idle with full-length column chunks: cut the columns
@@ -1546,10 +1557,33 @@ static int run_compare_merged(mg_ctx *ctx, const mg_table *rows, const mg_table 
         // ---- window plan of this class (large sketches) ----
         WindowPlan plan;
         const uint64_t xmax = mx >> shr;
-        if (want_win) {
+        // The direct-mapped engine (compare_direct.hip) takes the class when its tags can index the
+        // plan's rows (<= 1023 hashes of a row per window); else the merged kernel's window mode.
+        bool direct = false;
+        if (want_win && want_direct && mg::compare_direct_supported(a.s)) {
+            rc = plan_windows(ctx, rows, cols, list, shr, xmax, a.s, false, &plan, mg::compare_direct_row_entries());
+            if (rc != MG_OK) return rc;
+            direct = plan.rows != nullptr;
+            if (!direct) plan = WindowPlan();
+        }
+        if (want_win && !direct) {
             rc = plan_windows(ctx, rows, cols, list, shr, xmax, a.s, windows_only, &plan);
             if (rc != MG_OK) return rc;
             if (windows_only && !plan.rows) return fail(ctx, MG_ERR_HIP, "compare: window plan changed between passes");
+        }
+        if (direct && !ctx->dscr) {
+            const uint32_t regions = 512;                       // > the workgroups resident at any time (one per CU)
+            const size_t per = 16384;
+            HIP_TRY(ctx, hipMalloc(&ctx->dscr, (size_t)regions * per * 6 + (size_t)regions * 4));
+            HIP_TRY(ctx, hipMemsetAsync(ctx->dscr, 0, (size_t)regions * per * 6 + (size_t)regions * 4, ctx->stream));
+            ctx->dscr_regions = regions;
+        }
+        if (direct) {
+            const size_t per = 16384;
+            a.dscr_pfx = static_cast<uint32_t *>(ctx->dscr);
+            a.dscr_tag = reinterpret_cast<uint16_t *>(static_cast<unsigned char *>(ctx->dscr) + (size_t)ctx->dscr_regions * per * 4);
+            a.dscr_lock = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(ctx->dscr) + (size_t)ctx->dscr_regions * per * 6);
+            a.dscr_regions = ctx->dscr_regions;
         }
         const mg_table::Windows *wr = plan.rows, *wc = plan.cols;
         const uint32_t delta = plan.delta, nwin = plan.nwin;
@@ -1606,7 +1640,8 @@ static int run_compare_merged(mg_ctx *ctx, const mg_table *rows, const mg_table 
                 a.win_hi = (uint32_t)std::min<uint64_t>((uint64_t)(w + 1) * delta, xmax + 1);
                 a.dbg = d_dbg ? d_dbg + (size_t)w * mtiles.size() * 3 : nullptr;
                 prof_begin(ctx, ctx->prof_compare);
-                e = mg::launch_compare_merged(a, (uint32_t)mtiles.size(), ctx->stream);
+                e = direct ? mg::launch_compare_direct(a, (uint32_t)mtiles.size(), ctx->stream)
+                           : mg::launch_compare_merged(a, (uint32_t)mtiles.size(), ctx->stream);
                 prof_end(ctx, ctx->prof_compare);
             }
             a.row_win = a.col_win = nullptr;
@@ -1675,6 +1710,8 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
     a.win_mask = nullptr;
     a.win_kmax = 0;
     a.xcd_remap = 0;
+    a.stage_pack = 0;
+    a.dscr_pfx = nullptr; a.dscr_tag = nullptr; a.dscr_lock = nullptr; a.dscr_regions = 0;
     if (const char *e = getenv("MASHGPU_COMPARE_XCD")) a.xcd_remap = atoi(e) != 0;
     if (const char *e = getenv("MASHGPU_COMPARE_VARIANT")) a.unroll = (uint32_t)atoi(e);
     const char *force = getenv("MASHGPU_COMPARE_KERNEL");

@@ -43,6 +43,8 @@ for name, h, nh, ln in tables():
             os.environ.pop(k, None)
         if e == "plain":
             os.environ["MASHGPU_COMPARE_WINDOWS"] = "0"
+        elif e == "windows":
+            os.environ["MASHGPU_COMPARE_WINDOWS"] = "1"
         elif e != "default":
             os.environ["MASHGPU_COMPARE_KERNEL"] = e
         m = n if e != "pairs" else min(n, 6000)            # the one-wave-per-pair engine is slow everywhere
