@@ -154,6 +154,18 @@ int mg_sketch_reads_host(mg_ctx *ctx, const mg_params *p, const uint8_t *bases, 
                          uint64_t *hashes_out, uint32_t *nhash_out, uint32_t *counts_out,
                          uint64_t *records_used_out);
 
+/* The same as a session: chunks of WHOLE records in reading order (any chunk size); the heap lives on
+ * the host between chunks, the device holds one chunk at a time, and *stopped_out turns 1 with the
+ * chunk in which the target coverage is reached -- the caller stops reading its files there, as the
+ * reference's reader loop does (Sketch.cpp:1258).  Results are those of mg_sketch_reads_host on
+ * the concatenation of the chunks. */
+typedef struct mg_reads_session mg_reads_session;
+int  mg_reads_begin(mg_ctx *ctx, const mg_params *p, mg_reads_session **out);          /* p->target_cov > 0 */
+int  mg_reads_add_host(mg_reads_session *rs, const uint8_t *bases, uint64_t nbases, int *stopped_out);
+int  mg_reads_finish(mg_reads_session *rs, uint64_t *hashes_out, uint32_t *nhash_out, uint32_t *counts_out,
+                     uint64_t *records_used_out);
+void mg_reads_free(mg_reads_session *rs);
+
 /* ---- sketch tables ----------------------------------------------------------
  * Dense replacement for vector<Sketch::Reference> (Sketch.h:131-139):
  * hashes[n * s] row-major ascending + nhash[n] + lengths[n] (Reference::length). */

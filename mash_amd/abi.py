@@ -23,7 +23,8 @@ RECORD_SEP = 0x0A
 EXPORTS = [
     "mg_device_count", "mg_ctx_create", "mg_ctx_destroy", "mg_last_error", "mg_ctx_set_stream", "mg_ctx_synchronize", "mg_ctx_set_async",
     "mg_ctx_cu_count", "mg_params_init", "mg_sketch_host", "mg_sketch_dev", "mg_sketch_reads_host", "mg_sketch_begin", "mg_sketch_add",
-    "mg_sketch_end_sketch", "mg_sketch_pending", "mg_sketch_finish", "mg_sketch_session_free", "mg_table_upload",
+    "mg_sketch_end_sketch", "mg_sketch_pending", "mg_sketch_finish", "mg_sketch_session_free",
+    "mg_reads_begin", "mg_reads_add_host", "mg_reads_finish", "mg_reads_free", "mg_table_upload",
     "mg_table_wrap_dev", "mg_table_free", "mg_table_rows", "mg_table_sketch_size",
     "mg_compare_tri_dev", "mg_compare_tri_host", "mg_compare_rect_dev", "mg_compare_rect_host",
     "mg_compare_tri_filter_host", "mg_compare_rect_filter_host",
@@ -159,6 +160,11 @@ def load_library():
     lib.mg_sketch_finish.argtypes = [vp, vp, vp, vp]
     lib.mg_sketch_session_free.argtypes = [vp]
     lib.mg_sketch_session_free.restype = None
+    lib.mg_reads_begin.argtypes = [vp, C.POINTER(MgParams), C.POINTER(vp)]
+    lib.mg_reads_add_host.argtypes = [vp, vp, u64, C.POINTER(C.c_int)]
+    lib.mg_reads_finish.argtypes = [vp, vp, vp, vp, vp]
+    lib.mg_reads_free.argtypes = [vp]
+    lib.mg_reads_free.restype = None
     lib.mg_table_upload.argtypes = [vp, vp, vp, vp, u64, u64, C.POINTER(vp)]
     lib.mg_table_wrap_dev.argtypes = [vp, vp, vp, vp, u64, u64, C.POINTER(vp)]
     lib.mg_table_free.argtypes = [vp]
@@ -514,6 +520,29 @@ class MashGpu:
         self._check(self.lib.mg_sketch_reads_host(self.ctx, C.byref(p), blob.ctypes.data, len(blob), hashes.ctypes.data,
                                                   C.byref(n), counts.ctypes.data, C.byref(used)))
         return hashes[: n.value].copy(), counts[: n.value].copy(), int(used.value)
+
+    def sketch_reads_chunked(self, records, p, per_chunk):
+        """sketch_reads through a session, `per_chunk` records at a time; stops feeding at the stop:
+        (hashes, counts, records_used, chunks_fed)"""
+        h = C.c_void_p()
+        self._check(self.lib.mg_reads_begin(self.ctx, C.byref(p), C.byref(h)))
+        try:
+            fed = 0
+            stopped = C.c_int(0)
+            for o in range(0, len(records), per_chunk):
+                blob = np.frombuffer(join_records(records[o:o + per_chunk]) + bytes([RECORD_SEP]), dtype=np.uint8)
+                self._check(self.lib.mg_reads_add_host(h, blob.ctypes.data, len(blob), C.byref(stopped)))
+                fed += 1
+                if stopped.value:
+                    break
+            s = int(p.sketch_size)
+            hashes = np.full(s, HASH_PAD, dtype=np.uint64)
+            counts = np.zeros(s, dtype=np.uint32)
+            n, used = C.c_uint32(0), C.c_uint64(0)
+            self._check(self.lib.mg_reads_finish(h, hashes.ctypes.data, C.byref(n), counts.ctypes.data, C.byref(used)))
+            return hashes[: n.value].copy(), counts[: n.value].copy(), int(used.value), fed
+        finally:
+            self.lib.mg_reads_free(h)
 
     def sketch_dev(self, bases_ptr, nbases, off, p, hashes_ptr, nhash_ptr):
         off = np.ascontiguousarray(off, dtype=np.uint64)

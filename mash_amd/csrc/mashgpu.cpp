@@ -1023,15 +1023,64 @@ struct ReadsHeap {
 
 }  // namespace
 
-int mg_sketch_reads_host(mg_ctx *ctx, const mg_params *p, const uint8_t *bases, uint64_t nbases, uint64_t *hashes_out,
-                         uint32_t *nhash_out, uint32_t *counts_out, uint64_t *records_used_out)
+// Reads mode with -c as a SESSION: chunks of whole records in reading order; the heap (incl. the -m
+// pending set) lives on the host between chunks, the device sees one chunk at a time, and the
+// caller stops reading its files the moment a chunk reports the target coverage.
+struct mg_reads_session {
+    mg_ctx *ctx = nullptr;
+    mg_params p;
+    int mode = 0;
+    ReadsHeap heap;
+    bool stopped = false;
+    uint64_t used = 0;                  // records consumed when the stop occurred
+    uint64_t records = 0;               // records (>= k) seen so far
+    double shrink = 1.0;
+    uint8_t *d_bases = nullptr;
+    uint64_t d_cap = 0;
+    uint8_t *d_alpha = nullptr;
+    mg::HashEvent *d_ev = nullptr;
+    unsigned long long *d_cnt = nullptr;
+    std::vector<mg::HashEvent> ev;
+    mg_reads_session(uint64_t s, uint64_t m) : heap(s, m) {}
+};
+
+static const uint64_t kReadsEventCap = 1ull << 23;           // events per pass (128 MiB)
+
+int mg_reads_begin(mg_ctx *ctx, const mg_params *p, mg_reads_session **out)
 {
     if (!ctx) return MG_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
-    if (!p || !hashes_out || !nhash_out || (!bases && nbases)) return fail(ctx, MG_ERR_INVALID, "mg_sketch_reads_host: NULL argument");
+    if (!p || !out) return fail(ctx, MG_ERR_INVALID, "mg_reads_begin: NULL argument");
     if (p->kmer_size < 1 || p->kmer_size > 32) return fail(ctx, MG_ERR_INVALID, "mg_sketch: k must be 1..32");
-    const uint64_t s = p->sketch_size, k = (uint64_t)p->kmer_size;
-    // records of the batch (kseq drops nothing inside a record, so separators are record ends)
+    if (!(p->target_cov > 0)) return fail(ctx, MG_ERR_INVALID, "mg_reads_begin: needs target_cov > 0 (plain reads mode is mg_sketch_begin / mg_sketch_host)");
+    const bool dna = alphabet_is_dna(p);
+    if (!p->noncanonical && !dna) return fail(ctx, MG_ERR_UNSUPPORTED, "mg_sketch: canonical k-mers need the ACGT alphabet");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    mg_reads_session *rs = new mg_reads_session(p->sketch_size, p->min_copies);
+    rs->ctx = ctx;
+    rs->p = *p;
+    rs->mode = dna ? (p->noncanonical ? 1 : 0) : 2;
+    if (hipMalloc(&rs->d_alpha, 256) != hipSuccess || hipMalloc(&rs->d_ev, kReadsEventCap * sizeof(mg::HashEvent)) != hipSuccess ||
+        hipMalloc(&rs->d_cnt, 8) != hipSuccess ||
+        hipMemcpyAsync(rs->d_alpha, p->alphabet, 256, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+        mg_reads_free(rs);
+        return fail(ctx, MG_ERR_NOMEM, "mg_reads_begin: device allocation failed");
+    }
+    *out = rs;
+    return MG_OK;
+}
+
+int mg_reads_add_host(mg_reads_session *rs, const uint8_t *bases, uint64_t nbases, int *stopped_out)
+{
+    if (!rs) return MG_ERR_INVALID;
+    mg_ctx *ctx = rs->ctx;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    if (stopped_out) *stopped_out = rs->stopped ? 1 : 0;
+    if (!bases && nbases) return fail(ctx, MG_ERR_INVALID, "mg_reads_add_host: NULL bases");
+    if (rs->stopped || nbases == 0) return MG_OK;
+    const mg_params *p = &rs->p;
+    const uint64_t k = (uint64_t)p->kmer_size;
+    // records of the chunk (kseq drops nothing inside a record, so separators are record ends)
     std::vector<uint64_t> rec_begin, rec_end;
     for (uint64_t b = 0; b < nbases;) {
         const void *q = memchr(bases + b, MG_RECORD_SEP, nbases - b);
@@ -1039,48 +1088,30 @@ int mg_sketch_reads_host(mg_ctx *ctx, const mg_params *p, const uint8_t *bases, 
         if (e - b >= k) { rec_begin.push_back(b); rec_end.push_back(e); }   // shorter records are skipped (Sketch.cpp:1222-1226)
         b = e + 1;
     }
-    if (records_used_out) *records_used_out = rec_begin.size();
-    if (!(p->target_cov > 0)) {
-        mg_params q = *p;
-        q.target_cov = 0;
-        const uint64_t off[2] = {0, nbases};
-        return mg_sketch_host(ctx, &q, bases, nbases, off, 1, hashes_out, nhash_out, counts_out);
-    }
-    const bool dna = alphabet_is_dna(p);
-    if (!p->noncanonical && !dna) return fail(ctx, MG_ERR_UNSUPPORTED, "mg_sketch: canonical k-mers need the ACGT alphabet");
-    const int mode = dna ? (p->noncanonical ? 1 : 0) : 2;
+    if (rec_begin.empty()) return MG_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    for (uint64_t i = 0; i < s; i++) hashes_out[i] = MG_HASH_PAD;
-    if (counts_out) memset(counts_out, 0, s * 4);
-    *nhash_out = 0;
-    if (rec_begin.empty()) { if (records_used_out) *records_used_out = 0; return MG_OK; }
+    if (nbases + 64 > rs->d_cap) {
+        if (rs->d_bases) { hipStreamSynchronize(ctx->stream); hipFree(rs->d_bases); rs->d_bases = nullptr; }
+        rs->d_cap = 0;
+        const uint64_t cap = std::max<uint64_t>(nbases + 64, 1ull << 20);
+        if (hipMalloc(&rs->d_bases, cap) != hipSuccess) return fail(ctx, MG_ERR_NOMEM, "mg_reads_add_host: device allocation failed");
+        rs->d_cap = cap;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(rs->d_bases, bases, nbases, hipMemcpyHostToDevice, ctx->stream));
 
-    const uint64_t ev_cap = 1ull << 23;                      // events per pass (128 MiB)
-    DevBuf<uint8_t> d_bases, d_alpha;
-    DevBuf<mg::HashEvent> d_ev;
-    DevBuf<unsigned long long> d_cnt;
-    if (d_bases.alloc(nbases + 64) != hipSuccess || d_alpha.alloc(256) != hipSuccess || d_ev.alloc(ev_cap) != hipSuccess ||
-        d_cnt.alloc(1) != hipSuccess)
-        return fail(ctx, MG_ERR_NOMEM, "mg_sketch_reads_host: device allocation failed");
-    HIP_TRY(ctx, hipMemcpyAsync(d_bases, bases, nbases, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(d_alpha, p->alphabet, 256, hipMemcpyHostToDevice, ctx->stream));
-
-    ReadsHeap heap(s, p->min_copies);
+    ReadsHeap &heap = rs->heap;
     const double hash_space = p->use64 ? 18446744073709551616.0 : 4294967296.0;
     const uint64_t tile = mg::sketch_tile(256);
-    std::vector<mg::HashEvent> ev;
+    std::vector<mg::HashEvent> &ev = rs->ev;
     size_t r0 = 0;                                           // next record
     const uint64_t want_bytes = 2ull << 20;                  // while the heap is not full everything is an event
-    double shrink = 1.0;                                     // after an overflowing pass
-    bool stopped = false;
-    uint64_t used = 0;
-    while (r0 < rec_begin.size() && !stopped) {
+    while (r0 < rec_begin.size() && !rs->stopped) {
         // records [r0, r1): as many as are expected to stay within the event capacity
         const uint64_t bound = heap.full() ? heap.top() : 0xFFFFFFFFFFFFFFFFull;
         const double pass = heap.full() ? std::min(1.0, ((double)bound + 1.0) / hash_space) : 1.0;
-        uint64_t budget = (uint64_t)std::min<double>((double)(1ull << 40), (double)(ev_cap / 2) / std::max(pass, 1e-12));
+        uint64_t budget = (uint64_t)std::min<double>((double)(1ull << 40), (double)(kReadsEventCap / 2) / std::max(pass, 1e-12));
         if (budget < want_bytes || !heap.full()) budget = want_bytes;
-        budget = (uint64_t)std::max(1.0, (double)budget * shrink);
+        budget = (uint64_t)std::max(1.0, (double)budget * rs->shrink);
         size_t r1 = r0;
         uint64_t bytes = 0;
         while (r1 < rec_begin.size() && (r1 == r0 || bytes + (rec_end[r1] - rec_begin[r1]) <= budget)) {
@@ -1101,41 +1132,41 @@ int mg_sketch_reads_host(mg_ctx *ctx, const mg_params *p, const uint8_t *bases, 
             work.push_back(w);
         }
         DevBuf<mg::SketchWork> d_work;
-        if (d_work.alloc(work.size()) != hipSuccess) return fail(ctx, MG_ERR_NOMEM, "mg_sketch_reads_host: device allocation failed");
+        if (d_work.alloc(work.size()) != hipSuccess) return fail(ctx, MG_ERR_NOMEM, "mg_reads_add_host: device allocation failed");
         mg::EventArgs ea;
-        ea.bases = d_bases; ea.work = d_work; ea.alphabet = d_alpha; ea.out = d_ev; ea.count = d_cnt;
-        ea.capacity = ev_cap; ea.bound = bound; ea.seed = p->seed; ea.use64 = p->use64;
+        ea.bases = rs->d_bases; ea.work = d_work; ea.alphabet = rs->d_alpha; ea.out = rs->d_ev; ea.count = rs->d_cnt;
+        ea.capacity = kReadsEventCap; ea.bound = bound; ea.seed = p->seed; ea.use64 = p->use64;
         ea.fold_case = p->preserve_case ? 0 : 1;
         unsigned long long n_ev = 0;
         hipError_t e = hipMemcpyAsync(d_work, work.data(), work.size() * sizeof(mg::SketchWork), hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipMemsetAsync(d_cnt, 0, 8, ctx->stream);
-        if (e == hipSuccess) e = mg::launch_hash_events(p->kmer_size, mode, ea, (uint32_t)work.size(), ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(&n_ev, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(rs->d_cnt, 0, 8, ctx->stream);
+        if (e == hipSuccess) e = mg::launch_hash_events(p->kmer_size, rs->mode, ea, (uint32_t)work.size(), ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&n_ev, rs->d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("mg_sketch_reads_host: ") + hipGetErrorString(e));
-        if (n_ev > ev_cap) {                                 // denser than expected: take fewer records
-            if (r1 - r0 == 1) return fail(ctx, MG_ERR_UNSUPPORTED, "mg_sketch_reads_host: a single record exceeds the event buffer");
-            shrink /= 4;
+        if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("mg_reads_add_host: ") + hipGetErrorString(e));
+        if (n_ev > kReadsEventCap) {                         // denser than expected: take fewer records
+            if (r1 - r0 == 1) return fail(ctx, MG_ERR_UNSUPPORTED, "mg_reads_add_host: a single record exceeds the event buffer");
+            rs->shrink /= 4;
             continue;
         }
-        shrink = 1.0;
+        rs->shrink = 1.0;
         ev.resize(n_ev);
-        if (n_ev && hipMemcpy(ev.data(), d_ev, n_ev * sizeof(mg::HashEvent), hipMemcpyDeviceToHost) != hipSuccess)
-            return fail(ctx, MG_ERR_HIP, "mg_sketch_reads_host: D2H copy failed");
+        if (n_ev && hipMemcpy(ev.data(), rs->d_ev, n_ev * sizeof(mg::HashEvent), hipMemcpyDeviceToHost) != hipSuccess)
+            return fail(ctx, MG_ERR_HIP, "mg_reads_add_host: D2H copy failed");
         std::sort(ev.begin(), ev.end(), [](const mg::HashEvent &x, const mg::HashEvent &y) { return x.pos < y.pos; });
         // replay, record by record; the stop test follows every record that changed the heap
         size_t rr = r0;
         bool touched = false;
-        for (size_t i = 0; i <= ev.size() && !stopped; i++) {
+        for (size_t i = 0; i <= ev.size() && !rs->stopped; i++) {
             const bool end = i == ev.size();
             while (!end && ev[i].pos >= rec_end[rr]) {       // event belongs to a later record: close record rr
-                if (touched && heap.multiplicity() >= p->target_cov) { stopped = true; used = rr + 1; break; }
+                if (touched && heap.multiplicity() >= p->target_cov) { rs->stopped = true; rs->used = rs->records + rr + 1; break; }
                 touched = false;
                 rr++;
             }
-            if (stopped) break;
+            if (rs->stopped) break;
             if (end) {
-                if (touched && heap.multiplicity() >= p->target_cov) { stopped = true; used = rr + 1; }
+                if (touched && heap.multiplicity() >= p->target_cov) { rs->stopped = true; rs->used = rs->records + rr + 1; }
                 break;
             }
             heap.try_insert(ev[i].hash);
@@ -1143,16 +1174,70 @@ int mg_sketch_reads_host(mg_ctx *ctx, const mg_params *p, const uint8_t *bases, 
         }
         r0 = r1;
     }
-    if (!stopped) used = rec_begin.size();
-    if (records_used_out) *records_used_out = used;
+    rs->records += rec_begin.size();
+    if (stopped_out) *stopped_out = rs->stopped ? 1 : 0;
+    return MG_OK;
+}
+
+int mg_reads_finish(mg_reads_session *rs, uint64_t *hashes_out, uint32_t *nhash_out, uint32_t *counts_out, uint64_t *records_used_out)
+{
+    if (!rs) return MG_ERR_INVALID;
+    if (!hashes_out || !nhash_out) return fail(rs->ctx, MG_ERR_INVALID, "mg_reads_finish: NULL argument");
+    const uint64_t s = rs->p.sketch_size;
+    for (uint64_t i = 0; i < s; i++) hashes_out[i] = MG_HASH_PAD;
+    if (counts_out) memset(counts_out, 0, s * 4);
     uint32_t n = 0;
-    for (const auto &kv : heap.kept) {
+    for (const auto &kv : rs->heap.kept) {
         hashes_out[n] = kv.first;
         if (counts_out) counts_out[n] = kv.second;
         n++;
     }
     *nhash_out = n;
+    if (records_used_out) *records_used_out = rs->stopped ? rs->used : rs->records;
     return MG_OK;
+}
+
+void mg_reads_free(mg_reads_session *rs)
+{
+    if (!rs) return;
+    hipSetDevice(rs->ctx->device);
+    hipStreamSynchronize(rs->ctx->stream);
+    for (void *q : {(void *)rs->d_bases, (void *)rs->d_alpha, (void *)rs->d_ev, (void *)rs->d_cnt})
+        if (q) hipFree(q);
+    delete rs;
+}
+
+int mg_sketch_reads_host(mg_ctx *ctx, const mg_params *p, const uint8_t *bases, uint64_t nbases, uint64_t *hashes_out,
+                         uint32_t *nhash_out, uint32_t *counts_out, uint64_t *records_used_out)
+{
+    if (!ctx) return MG_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    if (!p || !hashes_out || !nhash_out || (!bases && nbases)) return fail(ctx, MG_ERR_INVALID, "mg_sketch_reads_host: NULL argument");
+    if (p->kmer_size < 1 || p->kmer_size > 32) return fail(ctx, MG_ERR_INVALID, "mg_sketch: k must be 1..32");
+    if (!(p->target_cov > 0)) {
+        // records of the batch (shorter ones are skipped, Sketch.cpp:1222-1226): the "reads used" of a run without -c
+        const uint64_t k = (uint64_t)p->kmer_size;
+        uint64_t nrec = 0;
+        for (uint64_t b = 0; b < nbases;) {
+            const void *q = memchr(bases + b, MG_RECORD_SEP, nbases - b);
+            const uint64_t e = q ? (uint64_t)((const uint8_t *)q - bases) : nbases;
+            if (e - b >= k) nrec++;
+            b = e + 1;
+        }
+        if (records_used_out) *records_used_out = nrec;
+        mg_params q = *p;
+        q.target_cov = 0;
+        const uint64_t off[2] = {0, nbases};
+        return mg_sketch_host(ctx, &q, bases, nbases, off, 1, hashes_out, nhash_out, counts_out);
+    }
+    // one chunk through the session
+    mg_reads_session *rs = nullptr;
+    int rc = mg_reads_begin(ctx, p, &rs);
+    if (rc != MG_OK) return rc;
+    rc = mg_reads_add_host(rs, bases, nbases, nullptr);
+    if (rc == MG_OK) rc = mg_reads_finish(rs, hashes_out, nhash_out, counts_out, records_used_out);
+    mg_reads_free(rs);
+    return rc;
 }
 
 /* ------------------------------------------------------------------ tables */

@@ -1,6 +1,10 @@
 // fastx.cpp — see fastx.h (semantics of kseq.h:67-208, re-implemented over zlib).
 #include "fastx.h"
 
+#include <errno.h>
+#include <fcntl.h>
+#include <unistd.h>
+
 #include <cctype>
 #include <cstdio>
 
@@ -9,10 +13,23 @@ namespace fastx {
 bool Reader::open(const std::string &path)
 {
     close();
-    f_ = path == "-" ? gzdopen(fileno(stdin), "r") : gzopen(path.c_str(), "r");
     begin_ = end_ = 0;
     eof_ = false;
     last_char_ = 0;
+    if (path != "-") {
+        // plain (not gzipped) files are read with read(2) straight into the parse buffer: zlib's
+        // pass-through costs a 512 KiB buffer allocation per file and a copy per byte, which is most
+        // of the time of a collection of thousands of small genomes
+        const int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        unsigned char magic[2] = {0, 0};
+        const ssize_t got = ::read(fd, magic, 2);
+        if (!(got == 2 && magic[0] == 0x1f && magic[1] == 0x8b)) {
+            if (::lseek(fd, 0, SEEK_SET) == 0) { fd_ = fd; return true; }
+        }
+        ::close(fd);                                   // gzip (or unseekable): through zlib
+    }
+    f_ = path == "-" ? gzdopen(fileno(stdin), "r") : gzopen(path.c_str(), "r");
     if (f_) gzbuffer(f_, 1 << 18);
     return f_ != nullptr;
 }
@@ -21,6 +38,8 @@ void Reader::close()
 {
     if (f_) gzclose(f_);
     f_ = nullptr;
+    if (fd_ >= 0) ::close(fd_);
+    fd_ = -1;
 }
 
 int Reader::getc_()
@@ -28,8 +47,16 @@ int Reader::getc_()
     if (begin_ >= end_) {
         if (eof_) return -1;
         begin_ = 0;
-        end_ = gzread(f_, buf_, sizeof buf_);
-        if (end_ < (int)sizeof buf_) eof_ = true;
+        if (fd_ >= 0) {
+            // read(2) may return short of a full buffer before the end: only 0 means end of file
+            ssize_t n;
+            do { n = ::read(fd_, buf_, sizeof buf_); } while (n < 0 && errno == EINTR);
+            end_ = n > 0 ? (int)n : 0;
+            if (n <= 0) eof_ = true;
+        } else {
+            end_ = gzread(f_, buf_, sizeof buf_);
+            if (end_ < (int)sizeof buf_) eof_ = true;
+        }
         if (end_ <= 0) { end_ = 0; return -1; }
     }
     return buf_[begin_++];

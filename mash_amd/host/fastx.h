@@ -31,7 +31,8 @@ private:
     int getc_();
     // read until delimiter class: 0 = whitespace, 1 = newline; returns the delimiter or -1
     int until_(int mode, std::string &out);
-    gzFile f_ = nullptr;
+    gzFile f_ = nullptr;                          // gzipped input and stdin
+    int fd_ = -1;                                 // plain files: read(2) into buf_
     unsigned char buf_[1 << 16];
     int begin_ = 0, end_ = 0;
     bool eof_ = false;

@@ -522,10 +522,28 @@ void sketch_reads(Gpu &gpu, SketchSet &set, const vector<string> &files)
     // Without -c the reads leave for the device as they are parsed (pinned staging ring, copies
     // overlapped with parsing): the host never holds the read set, only the device does (one
     // sketch over everything at the end, exact as before; 288 GB of HBM bound the input).  -c
-    // replays the heap on the host over a thinned event stream and still takes the bytes from
-    // host memory (mg_sketch_reads_host).
-    b.stream = !(set.p.target_cov > 0) && !getenv("MASH_AMD_NO_STREAM");
+    // goes through a reads session chunk by chunk (the heap is replayed on the host over a thinned
+    // event stream) and STOPS READING the files with the chunk that reaches the target coverage,
+    // as the reference's reader loop does (Sketch.cpp:1258): neither host nor device ever holds
+    // more than one chunk.
+    const bool cov_mode = set.p.target_cov > 0;
+    b.stream = !cov_mode && !getenv("MASH_AMD_NO_STREAM");
     ensure_session(gpu, set, b);
+    mg_reads_session *rs = nullptr;
+    size_t reads_chunk = 64u << 20;
+    if (const char *e = getenv("MASH_AMD_READS_CHUNK")) reads_chunk = std::max<size_t>(1, strtoull(e, nullptr, 10));   // test knob
+    int cov_stopped = 0;
+    auto feed_chunk = [&]() {
+        if (b.bases.empty()) return;
+        if (mg_reads_add_host(rs, b.bases.data(), b.bases.size(), &cov_stopped) != MG_OK) { cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl; exit(1); }
+        b.bases.clear();
+    };
+    if (cov_mode) {
+        mg_params mp = batch_params(set);
+        mp.min_copies = set.p.min_copies;
+        mp.target_cov = set.p.target_cov;
+        if (mg_reads_begin(gpu.ctx, &mp, &rs) != MG_OK) { cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl; exit(1); }
+    }
     fastx::Record rec;
     size_t it = 0;
     long l = -1;
@@ -548,6 +566,10 @@ void sketch_reads(Gpu &gpu, SketchSet &set, const vector<string> &files)
             b.add_record(rec.seq);
             it++;
             if (it == readers.size()) it = 0;
+            if (cov_mode && b.bases.size() >= reads_chunk) {
+                feed_chunk();
+                if (cov_stopped) { l = -1; break; }            // target coverage reached: the rest is not read
+            }
         }
         // records shorter than k are skipped without advancing to the next file (Sketch.cpp:1222-1226)
     }
@@ -558,21 +580,18 @@ void sketch_reads(Gpu &gpu, SketchSet &set, const vector<string> &files)
     auto wrap_comment = [&](uint64_t n) {                   // "[N seqs] first [...]" (Sketch.cpp:1284-1292)
         if (n > 1) ref.comment = "[" + std::to_string(n) + " seqs] " + ref.comment + " [...]";
     };
-    if (set.p.target_cov > 0) {
+    if (cov_mode) {
         // -c: the sequential heap decides where reading stops (Sketch.cpp:1258); replayed exactly
-        mg_params mp;
-        mg_params_init(&mp, set.p.kmer, set.p.sketch_size, set.p.seed, set.p.alphabet.c_str(), set.p.noncanonical,
-                       set.p.preserve_case);
-        mp.min_copies = set.p.min_copies;
-        mp.target_cov = set.p.target_cov;
+        if (!cov_stopped) feed_chunk();
         const uint64_t s = set.p.sketch_size;
         vector<uint64_t> hashes(s);
         vector<uint32_t> counts(s);
         uint32_t nh = 0;
-        if (mg_sketch_reads_host(gpu.ctx, &mp, b.bases.data(), b.bases.size(), hashes.data(), &nh, counts.data(), &reads_used) != MG_OK) {
+        if (mg_reads_finish(rs, hashes.data(), &nh, counts.data(), &reads_used) != MG_OK) {
             cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl;
             exit(1);
         }
+        mg_reads_free(rs);
         ref.hashes.assign(hashes.begin(), hashes.begin() + nh);
         ref.counts.assign(counts.begin(), counts.begin() + nh);
         wrap_comment(reads_used);                              // the reference counts the reads it consumed
@@ -600,7 +619,9 @@ void sketch_reads(Gpu &gpu, SketchSet &set, const vector<string> &files)
 bool load_msh_into(SketchSet &set, const string &file, bool first_sets_params, bool contain = false)
 {
     mshio::File hdr;
-    string e = mshio::read_msh(file, hdr, true);
+    vector<uint8_t> image;                                       // read once, parsed twice (header, then lists)
+    string e = mshio::load_file(file, image);
+    if (e.empty()) e = mshio::parse_msh(image.data(), image.size(), hdr, true, 0);
     if (!e.empty()) { cerr << "ERROR: " << e << endl; exit(1); }
     if (first_sets_params) params_from_header(set.p, hdr.header);
     Params t;
@@ -628,7 +649,7 @@ bool load_msh_into(SketchSet &set, const string &file, bool first_sets_params, b
     if (t.sketch_size > set.p.sketch_size)
         cerr << "\nWARNING: The sketch file " << file << " has a target sketch size (" << t.sketch_size << ") that is larger than the current sketch size (" << set.p.sketch_size << "). Its sketches will be reduced." << endl << endl;
     mshio::File f;
-    e = mshio::read_msh(file, f, false, set.p.sketch_size);
+    e = mshio::parse_msh(image.data(), image.size(), f, false, set.p.sketch_size);
     if (!e.empty()) { cerr << "ERROR: " << e << endl; exit(1); }
     for (auto &r : f.references) {
         Ref x;

@@ -244,6 +244,21 @@ std::string parse_msh(const uint8_t *data, size_t size, File &out, bool header_o
     return "";
 }
 
+std::string load_file(const std::string &path, std::vector<uint8_t> &buf)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return "could not open \"" + path + "\" for reading.";
+    fseek(f, 0, SEEK_END);
+    const long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    if (sz < 0) { fclose(f); return "could not get file stats for \"" + path + "\"."; }
+    buf.resize((size_t)sz);
+    const size_t got = fread(buf.data(), 1, (size_t)sz, f);
+    fclose(f);
+    if (got != (size_t)sz) return "short read on \"" + path + "\".";
+    return "";
+}
+
 std::string read_msh(const std::string &path, File &out, bool header_only, uint64_t max_hashes)
 {
     FILE *f = fopen(path.c_str(), "rb");

@@ -50,6 +50,9 @@ bool use64_for(const std::string &alphabet, bool preserve_case, uint32_t kmer_si
 std::string read_msh(const std::string &path, File &out, bool header_only = false, uint64_t max_hashes = 0);
 std::string write_msh(const std::string &path, const File &in);
 
+// whole file into memory ("" on success): callers that need the header first and the lists after
+// parse the same image twice instead of reading the file twice
+std::string load_file(const std::string &path, std::vector<uint8_t> &out);
 // in-memory variants (tests, pipes)
 std::string parse_msh(const uint8_t *data, size_t size, File &out, bool header_only, uint64_t max_hashes);
 // framing included; max_segment_words = 0 means the default segment limit (2 GiB)

@@ -487,6 +487,14 @@ def test_many_short_records_are_sketched_in_bounded_batches(built, tmp_path):
         run("sketch", "-s", "500", *extra, "-o", str(tmp_path / "s2"), *files, str(fa), env={"MASH_AMD_NO_STREAM": "1"})
         run("sketch", "-s", "500", *extra, "-o", str(tmp_path / "s3"), *files, str(fa), env={"MASHGPU_STAGE_BYTES": "333"})
         assert (tmp_path / "s1.msh").read_bytes() == (tmp_path / "s2.msh").read_bytes() == (tmp_path / "s3.msh").read_bytes(), extra
+    # -c: the reads session is fed chunk by chunk and reading stops with the chunk that reaches the
+    # coverage; same sketch and same "Reads used" whatever the chunk size
+    reads = tmp_path / "cov.fa"
+    reads.write_bytes(b"".join(recs[i % 40] for i in range(400)))
+    a = run("sketch", "-r", "-c", "3", "-s", "200", "-o", str(tmp_path / "v1"), str(reads))
+    b = run("sketch", "-r", "-c", "3", "-s", "200", "-o", str(tmp_path / "v2"), str(reads), env={"MASH_AMD_READS_CHUNK": "3000"})
+    assert (tmp_path / "v1.msh").read_bytes() == (tmp_path / "v2.msh").read_bytes()
+    assert "Reads used:" in a.stderr and a.stderr == b.stderr
 
 
 @pytest.mark.gpu

@@ -206,6 +206,14 @@ def test_sketch_target_coverage_early_stop(eng, oracle, k, s, m):
         oh, oc, _, oused, omult = oracle.sketch_reads(reads, oracle.params(k=k, s=s, min_copies=m, target_cov=cov))
         assert used == oused, (k, s, m, cov, used, oused)
         assert np.array_equal(gh, oh) and np.array_equal(gc, oc), (k, s, m, cov)
+        # the same through a session, a few records at a time: identical sketch and "reads used", and
+        # the caller is told to stop reading with the chunk in which the coverage is reached
+        for per in (1, 37, 5000):
+            ch, cc, cused, fed = eng.sketch_reads_chunked(reads, p, per)
+            assert cused == used and np.array_equal(ch, gh) and np.array_equal(cc, gc), (k, s, m, cov, per)
+            nchunks = (len(reads) + per - 1) // per
+            if used < sum(1 for r in reads if len(r) >= k) and per == 37:
+                assert fed < nchunks
     long_enough = sum(1 for r in reads if len(r) >= k)
     assert used == long_enough                                        # 1000x is never reached: everything is read
     h0, c0, u0 = eng.sketch_reads(reads, eng.params(k=k, s=s, min_copies=m))       # target_cov 0: plain reads mode
