@@ -599,6 +599,10 @@ def main():
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 1:
             shared = (counts.view(NSRC + rest, S)[:NSRC] > 0).sum(1).float().mean().item()
+            # HBM bytes of the fused sketch + probe kernel per step (PMC, per read x reads; stamped like the others)
+            spmc = load_pmc("screen_pmc_latest.json", "mash_amd/csrc/sketch.hip", "mash_amd/csrc/kmer_hash.h", "mash_amd/csrc/screen.hip") \
+                if (world == 1 and args.n_reads == 10_000_000) else None
+            scr_traffic = spmc["hbm_bytes_per_pass"] / spmc["units_per_pass"] * args.n_reads if spmc else None
             assert 500 < shared < 900 and len(mix) == S, f"screen output failed sanity check (shared {shared}, mix {len(mix)})"
             scr.update({"value": args.n_reads * scr_steps / qdt, "ms_per_step": qdt * 1e3 / scr_steps, "steps": scr_steps,
                         "bp_per_s": args.n_reads * RL * scr_steps / qdt,
@@ -609,7 +613,7 @@ def main():
                         "roofline": {"bound": "hbm", "achieved": round(args.n_reads * (RL + 1) * scr_steps / qdt / 1e9, 1),
                                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                      "frac": round(args.n_reads * (RL + 1) * scr_steps / qdt / 1e9 / HBM_PEAK_GBS, 4),
-                                     "traffic": None, "kernel": "sketch_chunks_kernel<21,0,256> (fused table probe)",
+                                     "traffic": scr_traffic, "kernel": "sketch_chunks_kernel<21,0,256> (fused table probe)",
                                      "note": "1 B/base streamed once; integer-ALU bound like sketching (one murmur per "
                                              "k-mer), table probes filtered by the largest key; whole-step time, "
                                              "includes table build, counter gather and the exchange"}})
