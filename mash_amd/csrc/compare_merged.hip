@@ -348,6 +348,18 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
                     }
                 }
             }
+            // (c) order the duplicates by (prefix, row): the rows sharing a value then form one run,
+            // and the exact path reads row r's entry at run start + popcount(lower rows)
+            for (uint32_t i = st + nd + 1; i < st + c; i++) {
+                const uint32_t pi = pfx[i];
+                const uint16_t ti = tag[i];
+                uint32_t q = i;
+                while (q > st + nd && (pfx[q - 1] > pi || (pfx[q - 1] == pi && tag[q - 1] > ti))) {
+                    pfx[q] = pfx[q - 1]; tag[q] = tag[q - 1];
+                    q--;
+                }
+                pfx[q] = pi; tag[q] = ti;
+            }
             if (nd > (uint32_t)MR_W) dir[b] = (uint16_t)(st | MR_OVF);
         }
     }
@@ -621,45 +633,50 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
                     if (clean) {
                         // every table entry with b's prefix holds the same value (build pass 3): collect
                         // the rows and b's index in each from LDS, verify ONE representative on 64 bits
-                        uint32_t rowmask = 0, rep = 0xFFFFFFFFu;
-                        uint32_t pk[MAXR / 2];                           // idx of b in row r: 16 bits each
-#pragma unroll
-                        for (int k = 0; k < (int)(MAXR / 2); k++) pk[k] = 0;
-                        auto take = [&](uint32_t tg) {
-                            const uint32_t r = tg >> idx_bits, idx = tg & idx_mask;
+                        // (the first entry with b's prefix is its representative; further ones are the
+                        //  duplicates, one run ordered by row -- build pass 3c)
+                        uint32_t rowmask = 0, dupmask = 0, rep = 0xFFFFFFFFu, first_e = 0;
+                        auto take = [&](uint32_t e) {
+                            const uint32_t tg = tag[e];
                             if (rep == 0xFFFFFFFFu) rep = tg;
-                            rowmask |= 1u << r;
-                            const uint32_t val = idx << ((r & 1u) * 16u), wd = r >> 1;
-#pragma unroll
-                            for (int k = 0; k < (int)(MAXR / 2); k++) pk[k] |= (wd == (uint32_t)k) ? val : 0u;
+                            else {
+                                if (dupmask == 0) first_e = e;
+                                dupmask |= 1u << (tg >> idx_bits);
+                            }
                         };
                         if (mine) {
                             const uint32_t st = s0[u] & 0x7FFFu;
 #pragma unroll
                             for (int w = 0; w < MR_W; w++)
-                                if (h[u][w] == x[u]) take(tag[st + w]);
-                            {                                            // rows sharing the value sit behind the distinct entries
+                                if (h[u][w] == x[u]) take(st + w);
+                            {
                                 const uint32_t bk = __umulhi(x[u] - origin, scale);
                                 const uint32_t e1 = dir[bk + 1] & 0x7FFFu;
                                 for (uint32_t e = st + MR_W; e < e1; e++)
-                                    if (pfx[e] == x[u]) take(tag[e]);
+                                    if (pfx[e] == x[u]) take(e);
                             }
                             if (rep != 0xFFFFFFFFu) {
                                 const uint64_t v = a.row_hashes[(uint64_t)hdr->row_id[rep >> idx_bits] * a.row_stride + lo_of(rep >> idx_bits) + (rep & idx_mask)];
-                                if (v != b) rowmask = 0;                  // same prefix, different value
+                                if (v == b) rowmask = dupmask | (1u << (rep >> idx_bits));   // else: same prefix, different value
+                                else dupmask = 0;
                             }
                         }
+                        const bool anydup = __ballot(dupmask != 0) != 0;
                         uint32_t any = rowmask;                           // rows involved anywhere in this block
 #pragma unroll
                         for (int d = 32; d > 0; d >>= 1) any |= __shfl_xor(any, d);
                         const uint32_t rows_any = (uint32_t)__builtin_amdgcn_readfirstlane((int)any) & active;
-#pragma unroll
-                        for (int r = 0; r < (int)MAXR; r++) {
-                            if (!((rows_any >> r) & 1u)) continue;       // uniform
+                        for (uint32_t rest = rows_any; rest != 0; rest &= rest - 1) {
+                            const int r = __builtin_ctz(rest);            // uniform
                             const bool mt = (rowmask >> r) & 1u;
                             // (row r's window start comes from lane r's register: indexing s_rowlo with the unrolled r
                             //  makes the compiler keep all 32 of them in VGPRs across the column loop)
-                            const uint32_t idx = ((pk[r >> 1] >> ((r & 1) * 16)) & 0xFFFFu) +
+                            uint32_t tg = rep;
+                            if (anydup) {                                 // uniform
+                                if (mt && (rep >> idx_bits) != (uint32_t)r)
+                                    tg = tag[first_e + (uint32_t)__popc(dupmask & ((1u << r) - 1u))];
+                            }
+                            const uint32_t idx = (tg & idx_mask) +
                                                  (WIN ? (uint32_t)__builtin_amdgcn_readlane((int)my_lo, r) : 0u);
                             uint32_t c_all = (uint32_t)__builtin_amdgcn_readlane((int)st_call, r);
                             uint32_t common = (uint32_t)__builtin_amdgcn_readlane((int)st_common, r);
