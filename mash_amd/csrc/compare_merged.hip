@@ -624,27 +624,31 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
 #pragma unroll
                     for (int w = 0; w < MR_W; w++) asm volatile("" : "+v"(h[u][w]));
                 // ---- exact path: which rows contain which elements, ranked in column order ----
+                if (clean) {
+                    // every table entry with b's prefix holds the same value (build pass 3).  Phase A,
+                    // for all blocks of the group: collect the rows and where b's index in each is found
+                    // (the first entry with b's prefix is its representative; further ones are the
+                    // duplicates, one run ordered by row -- build pass 3c) and ISSUE the two 64-bit loads
+                    // that verify one representative per element; phase B consumes them, so a group
+                    // waits for one round trip to memory, not one per block.
+                    uint32_t dupm[MR_KU], repv[MR_KU], firste[MR_KU];
+                    uint64_t bv[MR_KU], vv[MR_KU];
 #pragma unroll
-                for (int u = 0; u < MR_KU; u++) {
-                    if (tiem[u] == 0) continue;                          // uniform
-                    const uint32_t qb = q0 + u * 64;
-                    const bool mine = (tiem[u] >> lane) & 1ULL;
-                    const uint64_t b = mine ? a.col_hashes[(uint64_t)j * a.col_stride + qb + lane] : 0;   // 64-bit value only for tied lanes
-                    if (clean) {
-                        // every table entry with b's prefix holds the same value (build pass 3): collect
-                        // the rows and b's index in each from LDS, verify ONE representative on 64 bits
-                        // (the first entry with b's prefix is its representative; further ones are the
-                        //  duplicates, one run ordered by row -- build pass 3c)
-                        uint32_t rowmask = 0, dupmask = 0, rep = 0xFFFFFFFFu, first_e = 0;
-                        auto take = [&](uint32_t e) {
-                            const uint32_t tg = tag[e];
-                            if (rep == 0xFFFFFFFFu) rep = tg;
-                            else {
-                                if (dupmask == 0) first_e = e;
-                                dupmask |= 1u << (tg >> idx_bits);
-                            }
-                        };
+                    for (int u = 0; u < MR_KU; u++) {
+                        dupm[u] = 0; repv[u] = 0xFFFFFFFFu; firste[u] = 0; bv[u] = 0; vv[u] = 0;
+                        if (tiem[u] == 0) continue;                      // uniform
+                        const bool mine = (tiem[u] >> lane) & 1ULL;
                         if (mine) {
+                            bv[u] = a.col_hashes[(uint64_t)j * a.col_stride + q0 + u * 64 + lane];   // 64-bit value only for tied lanes
+                            uint32_t dupmask = 0, rep = 0xFFFFFFFFu, first_e = 0;
+                            auto take = [&](uint32_t e) {
+                                const uint32_t tg = tag[e];
+                                if (rep == 0xFFFFFFFFu) rep = tg;
+                                else {
+                                    if (dupmask == 0) first_e = e;
+                                    dupmask |= 1u << (tg >> idx_bits);
+                                }
+                            };
                             const uint32_t st = s0[u] & 0x7FFFu;
 #pragma unroll
                             for (int w = 0; w < MR_W; w++)
@@ -655,11 +659,20 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
                                 for (uint32_t e = st + MR_W; e < e1; e++)
                                     if (pfx[e] == x[u]) take(e);
                             }
-                            if (rep != 0xFFFFFFFFu) {
-                                const uint64_t v = a.row_hashes[(uint64_t)hdr->row_id[rep >> idx_bits] * a.row_stride + lo_of(rep >> idx_bits) + (rep & idx_mask)];
-                                if (v == b) rowmask = dupmask | (1u << (rep >> idx_bits));   // else: same prefix, different value
-                                else dupmask = 0;
-                            }
+                            if (rep != 0xFFFFFFFFu)
+                                vv[u] = a.row_hashes[(uint64_t)hdr->row_id[rep >> idx_bits] * a.row_stride + lo_of(rep >> idx_bits) + (rep & idx_mask)];
+                            dupm[u] = dupmask; repv[u] = rep; firste[u] = first_e;
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < MR_KU; u++) {
+                        if (tiem[u] == 0) continue;                      // uniform
+                        const uint32_t qb = q0 + u * 64;
+                        const uint32_t rep = repv[u], first_e = firste[u];
+                        uint32_t dupmask = dupm[u], rowmask = 0;
+                        if (rep != 0xFFFFFFFFu) {
+                            if (vv[u] == bv[u]) rowmask = dupmask | (1u << (rep >> idx_bits));   // else: same prefix, different value
+                            else dupmask = 0;
                         }
                         const bool anydup = __ballot(dupmask != 0) != 0;
                         uint32_t any = rowmask;                           // rows involved anywhere in this block
@@ -669,13 +682,12 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
                         for (uint32_t rest = rows_any; rest != 0; rest &= rest - 1) {
                             const int r = __builtin_ctz(rest);            // uniform
                             const bool mt = (rowmask >> r) & 1u;
-                            // (row r's window start comes from lane r's register: indexing s_rowlo with the unrolled r
-                            //  makes the compiler keep all 32 of them in VGPRs across the column loop)
                             uint32_t tg = rep;
                             if (anydup) {                                 // uniform
                                 if (mt && (rep >> idx_bits) != (uint32_t)r)
                                     tg = tag[first_e + (uint32_t)__popc(dupmask & ((1u << r) - 1u))];
                             }
+                            // (row r's window start comes from lane r's register)
                             const uint32_t idx = (tg & idx_mask) +
                                                  (WIN ? (uint32_t)__builtin_amdgcn_readlane((int)my_lo, r) : 0u);
                             uint32_t c_all = (uint32_t)__builtin_amdgcn_readlane((int)st_call, r);
@@ -690,8 +702,14 @@ __global__ __launch_bounds__(MR_NT) void compare_merged_kernel(CompareArgs a)
                             st_common = (lane == (uint32_t)r) ? common : st_common;
                             c_changed = true;
                         }
-                        continue;
                     }
+                } else
+#pragma unroll
+                for (int u = 0; u < MR_KU; u++) {
+                    if (tiem[u] == 0) continue;                          // uniform
+                    const uint32_t qb = q0 + u * 64;
+                    const bool mine = (tiem[u] >> lane) & 1ULL;
+                    const uint64_t b = mine ? a.col_hashes[(uint64_t)j * a.col_stride + qb + lane] : 0;   // 64-bit value only for tied lanes
                     // scan my bucket: rows whose value equals b (verified on 64 bits), remember
                     // the index (= lower bound of b in that row) of up to the first 4 hits in regs
                     uint32_t rowmask = 0;
