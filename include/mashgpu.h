@@ -57,6 +57,13 @@ typedef struct mg_params {
                                 * its m-th occurrence.  0 / 1 = every k-mer (mg_params_init sets 1). */
     double   target_cov;       /* targetCov (-c, reads mode; Sketch.cpp:1258), 0 = off: only
                                 * mg_sketch_reads_host honours it (mg_params_init sets 0). */
+    uint64_t bloom_bytes;      /* memoryBound (-b, reads mode; Sketch.h:101, MinHashHeap.cpp:19-41,78-94),
+                                * 0 = off (mg_params_init): a Bloom filter of this many bytes stands in
+                                * front of the heap -- a hash enters the sketch, with count 2, when its
+                                * bit is found set, else it sets the bit.  Order-dependent by design
+                                * (aliases); reproduced exactly by mg_sketch_reads_host / mg_reads_*,
+                                * refused elsewhere.  Geometry: one hash function over bloom_bytes * 8
+                                * bits, what x86-64 builds of the reference use. */
 } mg_params;
 
 /* {numer, denom} of one pair: what the merge loop of compareSketches produces
@@ -149,7 +156,10 @@ void     mg_sketch_session_free(mg_sketch_session *ss);
  * change the heap (those below its current top), the host replays MinHashHeap::tryInsert
  * (incl. min_copies) over that thinned stream.  hashes_out[sketch_size], counts_out[sketch_size]
  * (nullable), *records_used_out = records (>= k long) consumed -- the "Reads used" line
- * (Sketch.cpp:1324-1327).  With target_cov == 0 this is mg_sketch_host for one sketch. */
+ * (Sketch.cpp:1324-1327).  With target_cov == 0 this is mg_sketch_host for one sketch.
+ * p->bloom_bytes > 0 (`-b`): the replayed heap has the reference's Bloom filter in front
+ * (MinHashHeap.cpp:78-94), with or without target_cov; until the sketch is full every k-mer
+ * hash is such an event, afterwards only those below its top. */
 int mg_sketch_reads_host(mg_ctx *ctx, const mg_params *p, const uint8_t *bases, uint64_t nbases,
                          uint64_t *hashes_out, uint32_t *nhash_out, uint32_t *counts_out,
                          uint64_t *records_used_out);
@@ -160,7 +170,7 @@ int mg_sketch_reads_host(mg_ctx *ctx, const mg_params *p, const uint8_t *bases, 
  * reference's reader loop does (Sketch.cpp:1258).  Results are those of mg_sketch_reads_host on
  * the concatenation of the chunks. */
 typedef struct mg_reads_session mg_reads_session;
-int  mg_reads_begin(mg_ctx *ctx, const mg_params *p, mg_reads_session **out);          /* p->target_cov > 0 */
+int  mg_reads_begin(mg_ctx *ctx, const mg_params *p, mg_reads_session **out);          /* p->target_cov > 0 or p->bloom_bytes > 0 */
 int  mg_reads_add_host(mg_reads_session *rs, const uint8_t *bases, uint64_t nbases, int *stopped_out);
 int  mg_reads_finish(mg_reads_session *rs, uint64_t *hashes_out, uint32_t *nhash_out, uint32_t *counts_out,
                      uint64_t *records_used_out);

@@ -56,6 +56,7 @@ class MgParams(C.Structure):
         ("counts", C.c_uint8),
         ("min_copies", C.c_uint32),
         ("target_cov", C.c_double),
+        ("bloom_bytes", C.c_uint64),
     ]
 
 
@@ -251,13 +252,14 @@ def tri_pairs(row_begin, row_end):
 
 
 def make_params(lib, k=21, s=1000, seed=42, alphabet="ACGT", noncanonical=False, preserve_case=False,
-                min_copies=1, target_cov=0.0):
+                min_copies=1, target_cov=0.0, bloom_bytes=0):
     p = MgParams()
     rc = lib.mg_params_init(C.byref(p), k, s, seed, alphabet.encode(), int(noncanonical), int(preserve_case))
     if rc != MG_OK:
         raise MashGpuError(f"mg_params_init failed ({rc})")
     p.min_copies = min_copies
     p.target_cov = target_cov
+    p.bloom_bytes = bloom_bytes
     return p
 
 
@@ -510,7 +512,8 @@ class MashGpu:
             self.lib.mg_sketch_session_free(h)
 
     def sketch_reads(self, records, p):
-        """reads mode, one sketch over `records` in order, honouring p.target_cov (-c):
+        """reads mode, one sketch over `records` in order, honouring p.target_cov (-c) and
+        p.bloom_bytes (-b):
         (hashes u64[n], counts u32[n], records_used)"""
         blob = np.frombuffer(join_records(records), dtype=np.uint8)
         s = int(p.sketch_size)

@@ -274,6 +274,7 @@ int mg_params_init(mg_params *p, int kmer_size, uint64_t sketch_size, uint32_t s
     p->preserve_case = preserve_case ? 1 : 0;
     p->min_copies = 1;
     p->target_cov = 0.0;
+    p->bloom_bytes = 0;
     for (const char *c = alphabet; *c; c++) {            // Sketch.cpp:1113-1125
         char u = *c;
         if (!preserve_case && u > 96 && u < 123) u -= 32;
@@ -699,6 +700,7 @@ static int sketch_dev_impl(mg_ctx *ctx, const mg_params *p, const uint8_t *bases
     if (counts_out_dev && !mg::count_supported(p->sketch_size))
         return fail(ctx, MG_ERR_UNSUPPORTED, "mg_sketch: sketch size too large for the multiplicity pass");
     if (p->target_cov > 0) return fail(ctx, MG_ERR_UNSUPPORTED, "mg_sketch: target_cov needs mg_sketch_reads_host");
+    if (p->bloom_bytes) return fail(ctx, MG_ERR_UNSUPPORTED, "mg_sketch: bloom_bytes needs mg_sketch_reads_host");
     if (nsketch == 0) return MG_OK;
     if (nsketch > 0xFFFFFFFFull) return fail(ctx, MG_ERR_INVALID, "mg_sketch: too many sketches");
     if (((uintptr_t)bases_dev & 15) != 0) return fail(ctx, MG_ERR_INVALID, "mg_sketch: bases must be 16-byte aligned");
@@ -877,6 +879,7 @@ int mg_sketch_begin(mg_ctx *ctx, const mg_params *p, mg_sketch_session **out)
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (!p || !out) return fail(ctx, MG_ERR_INVALID, "mg_sketch_begin: NULL argument");
     if (p->target_cov > 0) return fail(ctx, MG_ERR_UNSUPPORTED, "mg_sketch_begin: target_cov needs mg_sketch_reads_host");
+    if (p->bloom_bytes) return fail(ctx, MG_ERR_UNSUPPORTED, "mg_sketch_begin: bloom_bytes needs mg_sketch_reads_host");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     mg_sketch_session *ss = new mg_sketch_session;
     ss->ctx = ctx;
@@ -974,15 +977,55 @@ void mg_sketch_session_free(mg_sketch_session *ss)
 
 namespace {
 
-// MinHashHeap::tryInsert (MinHashHeap.cpp:68-145, no Bloom filter) over explicit containers:
-// kept hashes with counts, pending hashes (multiplicityMinimum > 1) and the pending max-queue
-// that may hold hashes already erased from the pending set.
+// MinHashHeap::tryInsert (MinHashHeap.cpp:68-145) over explicit containers: kept hashes with
+// counts, pending hashes (multiplicityMinimum > 1) and the pending max-queue that may hold hashes
+// already erased from the pending set; with -b, the Bloom filter in front of the kept set.
+//
+// The filter (MinHashHeap.cpp:19-41: vendored bloom_filter.hpp with projected_element_count 1e9,
+// false_positive_probability 0, maximum_size = bytes * 8): probability 0 makes
+// compute_optimal_parameters (bloom_filter.hpp:107-155) pick one hash function and cast -inf to
+// the table size, which x86-64 builds turn into 2^63 and the clamp into maximum_size -- ONE hash
+// over bytes * 8 bits.  Salt :449-508 (salt_count 1), hash_ap :526-568 over the hash's 8 or 4
+// bytes, bit = hash % table_size :443-447.
+struct ReadsBloom {
+    std::vector<uint8_t> bits;
+    uint64_t nbits = 0;
+    bool use64 = true;
+    void init(uint64_t bytes, bool u64)
+    {
+        nbits = bytes * 8;
+        use64 = u64;
+        bits.assign((size_t)std::min<uint64_t>(bytes, 1ull << 29), 0);   // a 32-bit hash stays below bit 2^32
+    }
+    uint64_t bit_of(uint64_t hash) const
+    {
+        const uint64_t seed = 0xA5A5A5A55A5A5A5Aull * 0xA5A5A5A5ull + 1ull;     // random_seed_
+        uint32_t h = 0xAAAAAAAAu * 0xAAAAAAAAu + (uint32_t)seed;                // the filter's only salt
+        if (use64) {
+            const uint32_t w0 = (uint32_t)hash, w1 = (uint32_t)(hash >> 32);
+            h ^= (h << 7) ^ (w0 * (h >> 3)) ^ (~((h << 11) + (w1 ^ (h >> 5))));
+        } else {
+            h ^= ~((h << 11) + ((uint32_t)hash ^ (h >> 5)));
+        }
+        return (uint64_t)h % nbits;
+    }
+    bool test_and_set(uint64_t hash)                        // contains ? true : (insert, false)
+    {
+        const uint64_t b = bit_of(hash);
+        const uint8_t m = (uint8_t)(1u << (b & 7));
+        if (bits[b >> 3] & m) return true;
+        bits[b >> 3] |= m;
+        return false;
+    }
+};
+
 struct ReadsHeap {
     uint64_t cap, mmin;
     std::map<uint64_t, uint32_t> kept;
     std::map<uint64_t, uint32_t> pending;
     std::priority_queue<uint64_t> pending_q;
     uint64_t msum = 0;                                       // multiplicitySum
+    ReadsBloom bloom;                                        // nbits == 0: none
 
     ReadsHeap(uint64_t s, uint64_t m) : cap(s), mmin(m < 1 ? 1 : m) {}
     bool full() const { return kept.size() >= cap; }
@@ -996,6 +1039,11 @@ struct ReadsHeap {
         if (it != kept.end()) {                              // :120-124
             it->second++;
             msum++;
+        } else if (bloom.nbits) {                            // :78-94
+            if (bloom.test_and_set(h)) {
+                kept.emplace(h, 2u);
+                msum += 2;
+            }
         } else {
             auto pit = pending.find(h);
             const uint64_t pc = pit == pending.end() ? 0 : pit->second;
@@ -1052,7 +1100,10 @@ int mg_reads_begin(mg_ctx *ctx, const mg_params *p, mg_reads_session **out)
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (!p || !out) return fail(ctx, MG_ERR_INVALID, "mg_reads_begin: NULL argument");
     if (p->kmer_size < 1 || p->kmer_size > 32) return fail(ctx, MG_ERR_INVALID, "mg_sketch: k must be 1..32");
-    if (!(p->target_cov > 0)) return fail(ctx, MG_ERR_INVALID, "mg_reads_begin: needs target_cov > 0 (plain reads mode is mg_sketch_begin / mg_sketch_host)");
+    if (!(p->target_cov > 0) && p->bloom_bytes == 0)
+        return fail(ctx, MG_ERR_INVALID, "mg_reads_begin: needs target_cov > 0 or bloom_bytes > 0 (plain reads mode is mg_sketch_begin / mg_sketch_host)");
+    if (p->bloom_bytes && p->min_copies > 1) return fail(ctx, MG_ERR_INVALID, "mg_reads_begin: min_copies cannot be used with bloom_bytes");   // sketchParameterSetup.cpp:44-48
+    if (p->bloom_bytes > (1ull << 60)) return fail(ctx, MG_ERR_INVALID, "mg_reads_begin: bloom_bytes out of range");
     const bool dna = alphabet_is_dna(p);
     if (!p->noncanonical && !dna) return fail(ctx, MG_ERR_UNSUPPORTED, "mg_sketch: canonical k-mers need the ACGT alphabet");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1060,6 +1111,10 @@ int mg_reads_begin(mg_ctx *ctx, const mg_params *p, mg_reads_session **out)
     rs->ctx = ctx;
     rs->p = *p;
     rs->mode = dna ? (p->noncanonical ? 1 : 0) : 2;
+    if (p->bloom_bytes) {
+        try { rs->heap.bloom.init(p->bloom_bytes, p->use64 != 0); }
+        catch (const std::bad_alloc &) { delete rs; return fail(ctx, MG_ERR_NOMEM, "mg_reads_begin: the Bloom filter does not fit in host memory"); }
+    }
     if (hipMalloc(&rs->d_alpha, 256) != hipSuccess || hipMalloc(&rs->d_ev, kReadsEventCap * sizeof(mg::HashEvent)) != hipSuccess ||
         hipMalloc(&rs->d_cnt, 8) != hipSuccess ||
         hipMemcpyAsync(rs->d_alpha, p->alphabet, 256, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
@@ -1100,6 +1155,7 @@ int mg_reads_add_host(mg_reads_session *rs, const uint8_t *bases, uint64_t nbase
     HIP_TRY(ctx, hipMemcpyAsync(rs->d_bases, bases, nbases, hipMemcpyHostToDevice, ctx->stream));
 
     ReadsHeap &heap = rs->heap;
+    const bool cov = p->target_cov > 0;                     // without -c (a -b session) nothing stops the reading
     const double hash_space = p->use64 ? 18446744073709551616.0 : 4294967296.0;
     const uint64_t tile = mg::sketch_tile(256);
     std::vector<mg::HashEvent> &ev = rs->ev;
@@ -1160,13 +1216,13 @@ int mg_reads_add_host(mg_reads_session *rs, const uint8_t *bases, uint64_t nbase
         for (size_t i = 0; i <= ev.size() && !rs->stopped; i++) {
             const bool end = i == ev.size();
             while (!end && ev[i].pos >= rec_end[rr]) {       // event belongs to a later record: close record rr
-                if (touched && heap.multiplicity() >= p->target_cov) { rs->stopped = true; rs->used = rs->records + rr + 1; break; }
+                if (cov && touched && heap.multiplicity() >= p->target_cov) { rs->stopped = true; rs->used = rs->records + rr + 1; break; }
                 touched = false;
                 rr++;
             }
             if (rs->stopped) break;
             if (end) {
-                if (touched && heap.multiplicity() >= p->target_cov) { rs->stopped = true; rs->used = rs->records + rr + 1; }
+                if (cov && touched && heap.multiplicity() >= p->target_cov) { rs->stopped = true; rs->used = rs->records + rr + 1; }
                 break;
             }
             heap.try_insert(ev[i].hash);
@@ -1214,7 +1270,7 @@ int mg_sketch_reads_host(mg_ctx *ctx, const mg_params *p, const uint8_t *bases, 
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (!p || !hashes_out || !nhash_out || (!bases && nbases)) return fail(ctx, MG_ERR_INVALID, "mg_sketch_reads_host: NULL argument");
     if (p->kmer_size < 1 || p->kmer_size > 32) return fail(ctx, MG_ERR_INVALID, "mg_sketch: k must be 1..32");
-    if (!(p->target_cov > 0)) {
+    if (!(p->target_cov > 0) && p->bloom_bytes == 0) {
         // records of the batch (shorter ones are skipped, Sketch.cpp:1222-1226): the "reads used" of a run without -c
         const uint64_t k = (uint64_t)p->kmer_size;
         uint64_t nrec = 0;

@@ -6,9 +6,9 @@
 // CommandInfo.cpp:40-299, CommandPaste.cpp:30-89, Command.cpp:165-200,311-347,
 // sketchParameterSetup.cpp:15-125, Sketch.cpp:105-253).  All hashing / selection /
 // comparison runs on the GPU through libmashgpu; there is no CPU fallback.
-// Reads mode: -r, -m <copies>, -c <coverage>, -g, -M (exact, see mg_params::min_copies and
-// mg_sketch_reads_host).  Not built: -b (the reference builds its Bloom filter with a false-positive
-// probability of 0, whose geometry is undefined behaviour).
+// Reads mode: -r, -m <copies>, -c <coverage>, -b <bytes>, -g, -M (exact, see mg_params::min_copies,
+// ::bloom_bytes and mg_sketch_reads_host; the Bloom filter of -b has the geometry x86-64 builds of
+// the reference use).
 #include <unistd.h>
 
 #include <algorithm>
@@ -173,6 +173,7 @@ struct Params {                               // Sketch::Parameters (Sketch.h:34
     uint64_t genome_size = 0;
     uint32_t min_copies = 1;                  // minCov (-m)
     double target_cov = 0;                    // targetCov (-c)
+    uint64_t bloom_bytes = 0;                 // memoryBound (-b)
     int threads = 1;                          // -p: files parsed concurrently (the GPU does the sketching)
     string alphabet;                          // normalised (uppercased unless preserve_case), sorted
     uint32_t alphabet_size = 0;
@@ -215,10 +216,7 @@ int sketch_parameter_setup(Params &p, const Cmd &c)
             cerr << "ERROR: The option " << c.o("minCov").id << " cannot be used with " << c.o("memory").id << "." << endl;
             return 1;
         }
-        if (c.o("memory").active) {
-            cerr << "ERROR: The option -b (Bloom filter) is not supported by the GPU sketching path." << endl;
-            return 1;
-        }
+        if (c.o("memory").active) p.bloom_bytes = (uint64_t)c.o("memory").num;      // sketchParameterSetup.cpp:42
         p.reads = true;
         if (c.o("targetCov").active) p.target_cov = c.o("targetCov").num;          // sketchParameterSetup.cpp:24
         if (c.o("minCov").num >= 1) p.min_copies = (uint32_t)c.o("minCov").num;   // Sketch.cpp:1156 (reads mode only)
@@ -526,7 +524,8 @@ void sketch_reads(Gpu &gpu, SketchSet &set, const vector<string> &files)
     // event stream) and STOPS READING the files with the chunk that reaches the target coverage,
     // as the reference's reader loop does (Sketch.cpp:1258): neither host nor device ever holds
     // more than one chunk.
-    const bool cov_mode = set.p.target_cov > 0;
+    // (-b, the Bloom filter in front of the heap, is order-dependent too and takes the same route)
+    const bool cov_mode = set.p.target_cov > 0 || set.p.bloom_bytes > 0;
     b.stream = !cov_mode && !getenv("MASH_AMD_NO_STREAM");
     ensure_session(gpu, set, b);
     mg_reads_session *rs = nullptr;
@@ -542,12 +541,14 @@ void sketch_reads(Gpu &gpu, SketchSet &set, const vector<string> &files)
         mg_params mp = batch_params(set);
         mp.min_copies = set.p.min_copies;
         mp.target_cov = set.p.target_cov;
+        mp.bloom_bytes = set.p.bloom_bytes;
         if (mg_reads_begin(gpu.ctx, &mp, &rs) != MG_OK) { cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl; exit(1); }
     }
     fastx::Record rec;
     size_t it = 0;
     long l = -1;
     int count = 0;
+    bool skipped = false;
     while (!readers.empty()) {
         l = readers[it]->next(rec);
         if (l < -1) break;
@@ -571,11 +572,17 @@ void sketch_reads(Gpu &gpu, SketchSet &set, const vector<string> &files)
                 if (cov_stopped) { l = -1; break; }            // target coverage reached: the rest is not read
             }
         }
-        // records shorter than k are skipped without advancing to the next file (Sketch.cpp:1222-1226)
+        else skipped = true;                                   // skipped without advancing to the next file (Sketch.cpp:1222-1226)
     }
     for (auto *r : readers) delete r;
     if (l != -1) { cerr << "\nERROR: reading input files." << endl; exit(1); }
-    if (count == 0) { cerr << "\nERROR: Did not find fasta records in \"input files\"." << endl; exit(1); }
+    // (an empty result is refused below, once the length is known: Sketch.cpp:1302-1314)
+    auto refuse_empty = [&]() {
+        if (skipped) cerr << "\nWARNING: All fasta records in input files were shorter than the k-mer size (" << set.p.kmer << ")." << endl;
+        else cerr << "\nERROR: Did not find fasta records in \"input files\"." << endl;
+        exit(1);
+    };
+    if (count == 0 && set.p.genome_size == 0) refuse_empty();
     uint64_t reads_used = (uint64_t)count;
     auto wrap_comment = [&](uint64_t n) {                   // "[N seqs] first [...]" (Sketch.cpp:1284-1292)
         if (n > 1) ref.comment = "[" + std::to_string(n) + " seqs] " + ref.comment + " [...]";
@@ -608,6 +615,8 @@ void sketch_reads(Gpu &gpu, SketchSet &set, const vector<string> &files)
     if (!r.hashes.empty())
         est = std::pow(2.0, set.p.use64 ? 64.0 : 32.0) * (double)r.hashes.size() / (double)r.hashes.back();
     r.length = set.p.genome_size ? set.p.genome_size : (uint64_t)est;
+    // nothing kept (e.g. -m 2 on a genome without repeats) and no -g: length 0 is "no records" (Sketch.cpp:1302-1314)
+    if (r.length == 0) refuse_empty();
     cerr << "Estimated genome size: " << est << endl;
     double msum = 0;                                       // estimateMultiplicity (MinHashHeap.h:44)
     for (uint32_t c : r.counts) msum += c;
@@ -738,9 +747,14 @@ void init_from_files(Gpu &gpu, SketchSet &set, const vector<string> &files, cons
     PendingBatch b;
     b.stream = !getenv("MASH_AMD_NO_STREAM");             // (env: the concatenate-then-copy path, for tests)
     // concatenated mode with -p > 1: files are parsed ahead by a pool of workers (ParsePool)
-    auto parseable = [&](size_t i) { return set.p.concatenated && !has_suffix(files[i], kSuffix) && files[i] != "-"; };
+    // Reads options (-r -m -c -b -g) reach sketchFile through here too (`mash dist -r ref.msh reads.fq`,
+    // `mash triangle -r ...`): ONE sketch per file with the reads-mode heap, the estimated (or -g)
+    // genome size as its length and the two "Estimated ..." lines (Sketch.cpp:1156, :1272-1282,
+    // :1320-1330) -- the same code path as `mash sketch -r` over that one file.
+    const bool reads_files = set.p.reads && set.p.concatenated;
+    auto parseable = [&](size_t i) { return set.p.concatenated && !reads_files && !has_suffix(files[i], kSuffix) && files[i] != "-"; };
     std::unique_ptr<ParsePool> pool;
-    if (p.threads > 1) pool.reset(new ParsePool(files, (size_t)p.threads, parseable));
+    if (p.threads > 1 && !reads_files) pool.reset(new ParsePool(files, (size_t)p.threads, parseable));
     for (size_t i = 0; i < files.size(); i++) {
         if (has_suffix(files[i], kSuffix)) {
             flush_batch(gpu, set, b);                      // keep input order
@@ -755,7 +769,10 @@ void init_from_files(Gpu &gpu, SketchSet &set, const vector<string> &files, cons
                 if (!t) { cerr << "ERROR: could not open " << files[i] << " for reading." << endl; exit(1); }
                 fclose(t);
             }
-            if (set.p.concatenated) {
+            if (reads_files) {
+                flush_batch(gpu, set, b);                  // keep input order
+                sketch_reads(gpu, set, {files[i]});
+            } else if (set.p.concatenated) {
                 if (pool && parseable(i)) queue_parsed_file(gpu, set, b, pool->take(i, set.p.kmer));
                 else queue_parsed_file(gpu, set, b, parse_file_concatenated(files[i], set.p.kmer));
             } else {
@@ -867,7 +884,7 @@ int cmd_sketch(int argc, const char **argv)
                 "Create a sketch file (.msh) from fasta/fastq inputs (gzipped or not) on the GPU.\n"
                 "Options: -l -o <prefix> -I <id> -C <comment> -p <threads> -k <1-32> -s <size> -S <seed> -i -n -a -z <alphabet> -Z -w <p>\n"
                 "Reads:   -r  -m <min copies> (0 is taken as 1: the reference's behaviour for 0 is undefined)  -c <target coverage>\n"
-                "         -g <genome size>  -M (store multiplicities)      (-b, the Bloom filter, is not supported)\n\n";
+                "         -b <Bloom filter bytes, K/M/G/T>  -g <genome size>  -M (store multiplicities)\n\n";
         return 0;
     }
     Params p;

@@ -101,6 +101,9 @@ struct oracle_heap {
     uint64_t  mmin;
     uint64_t *pv; uint32_t *pc; uint64_t pn, pcap;      /* pending set, ascending */
     uint64_t *pq; uint64_t qn, qcap;                    /* pending queue: multiset, ascending */
+    /* -b: Bloom filter in front of the kept set (MinHashHeap.cpp:78-94) */
+    uint8_t  *bloom;
+    uint64_t  bloom_bits;
 };
 
 static uint64_t lower_bound64(const uint64_t *v, uint64_t n, uint64_t x)
@@ -130,10 +133,52 @@ oracle_heap *oracle_heap_new_m(uint64_t cardinality_max, int use64, uint64_t mul
     return h;
 }
 
+/* The Bloom filter of `mash sketch -b <bytes>` (MinHashHeap.cpp:19-41) is the vendored "Open Bloom
+ * Filter" (bloom_filter.hpp) set up with projected_element_count 10^9, false_positive_probability 0
+ * and maximum_size = bytes * 8.  With probability 0, compute_optimal_parameters
+ * (bloom_filter.hpp:107-155) evaluates -k * 10^9 / log(1 - 0^(1/k)) = -inf already for k = 1, so
+ * number_of_hashes = 1, and table_size = (unsigned long long)(-inf): undefined behaviour in C++.
+ * x86-64 compilers emit cvttsd2si, whose out-of-range result is 2^63, and the clamp (:149-152)
+ * turns that into maximum_size.  This DE-FACTO geometry -- ONE hash function over bytes * 8 bits --
+ * is what is restated here; it is pinned by sketches that the reference's own MinHashHeap /
+ * bloom_filter.hpp produced in this container (tests/golden/ref_sketch_vectors_b.npz, the `-b`
+ * fixtures of tests/golden/cli).
+ *   salt  (:449-508, salt_count 1): predef_salt[0] = 0xAAAAAAAA, then salt = salt * salt +
+ *         (uint32) random_seed_, random_seed_ = 0xA5A5A5A55A5A5A5A * 0xA5A5A5A5 + 1 (:180)
+ *   hash  hash_ap (:526-568) over the 8 bytes of a 64-bit hash (one round of the two-word mix)
+ *         or the 4 bytes of a 32-bit hash (the single-word branch with loop = 0)
+ *   bit   hash % table_size (:443-447); insert sets it (:281-291), contains tests it (:318-332). */
+uint32_t oracle_bloom_hash(uint64_t hash, int use64)
+{
+    const uint64_t seed = 0xA5A5A5A55A5A5A5AULL * 0xA5A5A5A5ULL + 1ULL;
+    uint32_t h = 0xAAAAAAAAu * 0xAAAAAAAAu + (uint32_t)seed;
+    if (use64) {
+        const uint32_t i1 = (uint32_t)hash, i2 = (uint32_t)(hash >> 32);
+        h ^= (h << 7) ^ (i1 * (h >> 3)) ^ (~((h << 11) + (i2 ^ (h >> 5))));
+    } else {
+        const uint32_t i = (uint32_t)hash;
+        h ^= ~((h << 11) + (i ^ (h >> 5)));
+    }
+    return h;
+}
+
+oracle_heap *oracle_heap_new_b(uint64_t cardinality_max, int use64, uint64_t bloom_bytes)
+{
+    oracle_heap *h = oracle_heap_new(cardinality_max, use64);
+    h->mmin = 1;
+    if (bloom_bytes) {
+        h->bloom_bits = bloom_bytes * 8;
+        /* a 32-bit hash never reaches beyond bit 2^32 - 1 */
+        uint64_t bytes = bloom_bytes < (1ULL << 29) ? bloom_bytes : (1ULL << 29);
+        h->bloom = (uint8_t *)calloc(bytes, 1);
+    }
+    return h;
+}
+
 void oracle_heap_free(oracle_heap *h)
 {
     if (!h) return;
-    free(h->v); free(h->c); free(h->pv); free(h->pc); free(h->pq); free(h);
+    free(h->v); free(h->c); free(h->pv); free(h->pc); free(h->pq); free(h->bloom); free(h);
 }
 
 static void pending_set_erase(oracle_heap *h, uint64_t x)
@@ -210,6 +255,16 @@ void oracle_heap_try_insert(oracle_heap *h, uint64_t hash)
     if (lo < h->n && h->v[lo] == hash) {          /* :120-124 already kept: count++ */
         h->c[lo]++;
         h->msum++;
+    } else if (h->bloom) {                         /* :78-94 Bloom filter first */
+        const uint64_t bit = (uint64_t)oracle_bloom_hash(hash, h->use64) % h->bloom_bits;
+        if (h->bloom[bit >> 3] & (1u << (bit & 7))) {    /* seen (or aliased) before: kept with count 2 */
+            memmove(h->v + lo + 1, h->v + lo, (h->n - lo) * sizeof(uint64_t));
+            memmove(h->c + lo + 1, h->c + lo, (h->n - lo) * sizeof(uint32_t));
+            h->v[lo] = hash; h->c[lo] = 2;
+            h->n++; h->msum += 2;
+        } else {
+            h->bloom[bit >> 3] |= (uint8_t)(1u << (bit & 7));
+        }
     } else {                                       /* :96-100 insert with count 1 */
         memmove(h->v + lo + 1, h->v + lo, (h->n - lo) * sizeof(uint64_t));
         memmove(h->c + lo + 1, h->c + lo, (h->n - lo) * sizeof(uint32_t));
@@ -307,7 +362,8 @@ int oracle_sketch_reads(const char *bases, const uint64_t *rec_off, uint64_t nre
                         uint64_t *length_out, double *set_size_out, uint64_t *used_out, double *mult_out)
 {
     /* Sketch.cpp:1156: minCov applies in reads mode; callers set min_copies only then */
-    oracle_heap *h = oracle_heap_new_m(p->sketch_size, p->use64, p->min_copies > 1 ? p->min_copies : 1);
+    oracle_heap *h = p->bloom_bytes ? oracle_heap_new_b(p->sketch_size, p->use64, p->bloom_bytes)
+                                    : oracle_heap_new_m(p->sketch_size, p->use64, p->min_copies > 1 ? p->min_copies : 1);
     uint64_t length = 0, used = 0;
     int any = 0;
     for (uint64_t r = 0; r < nrec; r++) {

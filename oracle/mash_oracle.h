@@ -43,6 +43,7 @@ typedef struct {
     uint8_t  alphabet[256];    /* ::alphabet                            (Sketch.h:87)  */
     uint32_t min_copies;       /* ::minCov (reads mode, -m)             (Sketch.h:102); 0 or 1 = off */
     double   target_cov;       /* ::targetCov (reads mode, -c)          (Sketch.h:103); 0 = off      */
+    uint64_t bloom_bytes;      /* ::memoryBound (reads mode, -b)        (Sketch.h:101); 0 = off      */
 } oracle_params;
 
 /* setAlphabetFromString, Sketch.cpp:1108-1137 (fills alphabet + use64). */
@@ -54,12 +55,17 @@ void oracle_murmur3_x64_128(const void *key, int len, uint32_t seed, uint64_t ou
 /* getHash, hash.cpp:10-38: low 64 bits (use64) or low 32 bits of h1. */
 uint64_t oracle_get_hash(const char *kmer, int k, uint32_t seed, int use64);
 
-/* Opaque MinHashHeap (MinHashHeap.cpp:68-145, no bloom filter).  oracle_heap_new: minCov 1;
+/* Opaque MinHashHeap (MinHashHeap.cpp:68-145).  oracle_heap_new: minCov 1;
  * oracle_heap_new_m: multiplicityMinimum >= 1 with the pending set / pending queue (:101-118,
- * :131-141). */
+ * :131-141); oracle_heap_new_b: with the Bloom filter of `-b <bytes>` (:19-41, :78-94; geometry
+ * and hash: see mash_oracle.c). */
 typedef struct oracle_heap oracle_heap;
 oracle_heap *oracle_heap_new(uint64_t cardinality_max, int use64);
 oracle_heap *oracle_heap_new_m(uint64_t cardinality_max, int use64, uint64_t multiplicity_min);
+oracle_heap *oracle_heap_new_b(uint64_t cardinality_max, int use64, uint64_t bloom_bytes);
+/* hash_ap of the vendored bloom_filter.hpp (:526-568) over the 8 / 4 bytes of a hash, with the
+ * filter's single salt; the bit a hash maps to is this value modulo bloom_bytes * 8 (:443-447) */
+uint32_t     oracle_bloom_hash(uint64_t hash, int use64);
 void         oracle_heap_free(oracle_heap *h);
 void         oracle_heap_try_insert(oracle_heap *h, uint64_t hash);
 uint64_t     oracle_heap_size(const oracle_heap *h);

@@ -28,6 +28,7 @@ class OracleParams(C.Structure):
         ("alphabet", C.c_uint8 * 256),
         ("min_copies", C.c_uint32),
         ("target_cov", C.c_double),
+        ("bloom_bytes", C.c_uint64),
     ]
 
 
@@ -83,6 +84,8 @@ class Oracle:
         L.oracle_p_value.restype = C.c_double
         L.oracle_p_value.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_double, C.c_uint64]
         L.oracle_triangle.restype = C.c_uint64
+        L.oracle_bloom_hash.restype = C.c_uint32
+        L.oracle_bloom_hash.argtypes = [C.c_uint64, C.c_int]
         gh = getattr(L, self.prefix + "get_hash")
         gh.restype = C.c_uint64
         gh.argtypes = [C.c_char_p, C.c_int, C.c_uint32, C.c_int]
@@ -102,10 +105,11 @@ class Oracle:
 
     # -- parameters --------------------------------------------------------
     def params(self, k=21, s=1000, seed=42, alphabet="ACGT", noncanonical=False,
-               preserve_case=False, min_copies=1, target_cov=0.0):
+               preserve_case=False, min_copies=1, target_cov=0.0, bloom_bytes=0):
         p = OracleParams()
         p.min_copies = min_copies
         p.target_cov = target_cov
+        p.bloom_bytes = bloom_bytes
         p.kmer_size = k
         p.sketch_size = s
         p.seed = seed

@@ -101,7 +101,7 @@ int ref_sketch_reads(const char *bases, const uint64_t *rec_off, uint64_t nrec,
 {
     Sketch::Parameters P;
     fill_params(P, p);
-    MinHashHeap heap(P.use64, P.minHashesPerWindow, p->min_copies > 1 ? p->min_copies : 1, 0);   // Sketch.cpp:1156
+    MinHashHeap heap(P.use64, P.minHashesPerWindow, p->min_copies > 1 ? p->min_copies : 1, p->bloom_bytes);   // Sketch.cpp:1156
     uint64_t length = 0, used = 0;
     bool any = false;
     for (uint64_t r = 0; r < nrec; r++) {

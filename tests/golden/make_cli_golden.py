@@ -155,7 +155,34 @@ C5 = [
 ]
 
 
-UNCONFIRMED = set()        # names of cases not yet replayed on a GPU (the C5 batch was confirmed in round 2)
+# Fourth batch: -b, the Bloom filter in front of the heap (MinHashHeap.cpp:19-41,78-94).  Small filters:
+# aliasing is what makes the outcome depend on the order of the k-mers.
+BLOOM = [
+    ("b_sketch_bloom_1k", [["sketch", "-b", "1K", "-s", "100", "-o", "b1", "reads.fq"]], ["info", "-d", "b1.msh"]),
+    ("b_sketch_bloom_300", [["sketch", "-b", "300", "-s", "200", "-o", "b2", "reads.fq"]], ["info", "-d", "b2.msh"]),
+    ("b_sketch_bloom_cov", [["sketch", "-b", "2K", "-c", "1.5", "-s", "100", "-o", "b3", "reads.fq"]], ["info", "-d", "b3.msh"]),
+    ("b_sketch_bloom_k16", [["sketch", "-k", "16", "-b", "5K", "-s", "150", "-o", "b4", "reads.fq"]], ["info", "-d", "b4.msh"]),
+    ("b_sketch_bloom_two_files", [["sketch", "-b", "1M", "-s", "300", "-o", "b5", "reads.fq", "g4.fa"]], ["info", "-d", "b5.msh"]),
+    ("b_dist_bloom_query", [["sketch", "-s", "300", "-o", "a", "g1.fa", "g2.fa", "g3.fa"]], ["dist", "-b", "4K", "a.msh", "reads.fq"]),
+]
+
+# Fifth batch: reads options outside `mash sketch` -- initFromFiles hands every query FILE to sketchFile
+# with the reads-mode heap (Sketch.cpp:1156) and the estimated / -g genome size as its length (:1272-1282),
+# which the p-values of dist / triangle then use.
+READS_Q = [
+    ("r_dist_reads_query", [["sketch", "-s", "300", "-o", "a", "g1.fa", "g2.fa", "g3.fa"]], ["dist", "-r", "a.msh", "reads.fq"]),
+    ("r_dist_reads_m2", [["sketch", "-s", "300", "-o", "a", "g1.fa", "g2.fa", "g3.fa"]], ["dist", "-m", "2", "a.msh", "reads.fq"]),
+    ("r_dist_reads_cov", [["sketch", "-s", "300", "-o", "a", "g1.fa", "g2.fa", "g3.fa"]], ["dist", "-c", "1.02", "a.msh", "reads.fq"]),
+    ("r_dist_reads_genome_size", [["sketch", "-s", "300", "-o", "a", "g1.fa", "g2.fa", "g3.fa"]], ["dist", "-g", "25k", "a.msh", "reads.fq"]),
+    ("r_dist_reads_both_sides", [], ["dist", "-r", "-s", "200", "reads.fq", "g1.fa", "reads.fq"]),
+    ("r_triangle_reads", [], ["triangle", "-r", "-s", "200", "reads.fq", "g1.fa", "g3.fa"]),
+    ("r_dist_reads_small_sketch", [], ["dist", "-r", "-s", "25", "g1.fa", "reads.fq", "g3.fa"]),            # p-values that show the length
+    ("r_dist_genome_size_small_sketch", [], ["dist", "-g", "25k", "-s", "25", "g1.fa", "reads.fq", "g3.fa"]),
+    ("r_triangle_reads_small_sketch", [], ["triangle", "-r", "-s", "25", "-E", "reads.fq", "g1.fa", "g3.fa"]),
+]
+
+
+UNCONFIRMED = set()        # names of cases not yet replayed on a GPU (BLOOM and READS_Q were confirmed in round 2)
 
 
 def main():
@@ -165,7 +192,7 @@ def main():
     os.makedirs(f"{OUT}/in")
     make_inputs(f"{OUT}/in")
     manifest = []
-    for name, setup, cmd in CASES + EXTRA + C5:
+    for name, setup, cmd in CASES + EXTRA + C5 + BLOOM + READS_Q:
         d = tempfile.mkdtemp(prefix="cligold_")
         for f in os.listdir(f"{OUT}/in"):
             shutil.copy(f"{OUT}/in/{f}", d)

@@ -17,6 +17,7 @@ Reference-run vectors (oracle/_ref = the reference's own objects, run here):
   read sets with -m 2..5                  -> ref_sketch_vectors_m.npz
   aaFromCodon over all codons             -> codon_table.json
   read sets with -c (and -m)              -> ref_sketch_vectors_c.npz
+  read sets with -b (Bloom filter)        -> ref_sketch_vectors_b.npz
 """
 import gzip
 import json
@@ -135,6 +136,7 @@ def main():
     make_mincopies_vectors(ref)
     make_codon_table(ref)
     make_cov_vectors(ref)
+    make_bloom_vectors(ref)
     print("golden fixtures written to", HERE)
 
 
@@ -194,6 +196,46 @@ def make_cov_vectors(ref):
         outs[f"counts_{idx}"] = c
     outs["cfgs"] = np.array(json.dumps(cfgs))
     np.savez_compressed(f"{HERE}/ref_sketch_vectors_c.npz", **outs)
+
+
+def make_bloom_vectors(ref):
+    """`mash sketch -b <bytes>` (optionally with -c): the record loop of sketchFile with the
+    reference's MinHashHeap and ITS Bloom filter (MinHashHeap.cpp:19-41,78-94; the vendored
+    bloom_filter.hpp, compiled from /root/reference) -> ref_sketch_vectors_b.npz.  Small filters
+    on purpose: aliasing (false positives) is what makes the result depend on the order."""
+    from mash_amd import synth
+    rng = np.random.default_rng(4242)
+    outs, cfgs = {}, []
+    for idx, (k, s, bloom, cov, glen, nreads) in enumerate([
+        (21, 1000, 1 << 20, 0.0, 20000, 4000),
+        (21, 200, 4096, 0.0, 5000, 3000),        # 32768 bits for ~3*10^5 k-mers: mostly aliases
+        (21, 200, 100000, 2.5, 5000, 3000),      # with the early stop of -c
+        (16, 100, 50000, 0.0, 4000, 1500),       # 32-bit hashes: the 4-byte branch of hash_ap
+        (11, 64, 1000, 0.0, 3000, 2500),
+        (21, 500, 1 << 16, 0.0, 40000, 300),     # low coverage: the sketch never fills
+        (21, 300, 3, 0.0, 3000, 500),            # 24 bits
+    ]):
+        g = synth._rand_dna(rng, glen)
+        recs = []
+        for _ in range(nreads):
+            l = int(rng.integers(40, 151))
+            st = int(rng.integers(0, glen - l))
+            r = bytearray(g[st:st + l])
+            if rng.random() < 0.1:
+                r[int(rng.integers(0, l))] = ord("N")
+            if rng.random() < 0.5:
+                r = bytearray(bytes(r).translate(bytes.maketrans(b"ACGTN", b"TGCAN"))[::-1])
+            recs.append(bytes(r))
+        recs.insert(3, b"ACGTAC")
+        p = ref.params(k=k, s=s, target_cov=cov, bloom_bytes=bloom)
+        h, c, setsz, used, mult = ref.sketch_reads(recs, p)
+        cfgs.append(dict(k=k, s=s, bloom_bytes=bloom, target_cov=cov, nrec=len(recs), used=used, set_size=setsz, mult=mult, idx=idx))
+        outs[f"bases_{idx}"] = np.frombuffer(b"".join(recs), dtype=np.uint8)
+        outs[f"reclen_{idx}"] = np.array([len(x) for x in recs], dtype=np.uint64)
+        outs[f"hashes_{idx}"] = h
+        outs[f"counts_{idx}"] = c
+    outs["cfgs"] = np.array(json.dumps(cfgs))
+    np.savez_compressed(f"{HERE}/ref_sketch_vectors_b.npz", **outs)
 
 
 def make_codon_table(ref):
@@ -257,10 +299,10 @@ def make_mincopies_vectors(ref):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] in ("mincopies", "codons", "cov"):
+    if len(sys.argv) > 1 and sys.argv[1] in ("mincopies", "codons", "cov", "bloom", "largecompare"):
         from oracle import pyoracle
         pyoracle.build(ref=True)
-        {"mincopies": make_mincopies_vectors, "codons": make_codon_table, "cov": make_cov_vectors,
+        {"mincopies": make_mincopies_vectors, "codons": make_codon_table, "cov": make_cov_vectors, "bloom": make_bloom_vectors,
          "largecompare": make_large_compare_vectors}[sys.argv[1]](pyoracle.Oracle(ref=True))
     else:
         main()

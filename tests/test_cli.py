@@ -298,6 +298,32 @@ def test_make_test_recipe_on_gpu(built, tmp_path, oracle):
     assert "Estimated coverage:    %s" % helpers.fmt_g(omult3) in r3.stderr
     bad = run("sketch", "-r", "-m", "2", "-b", "1G", "-o", "x", "reads1.fastq", cwd=tmp_path, check=False)
     assert bad.returncode == 1 and "cannot be used with" in bad.stderr
+    # -b: Bloom filter in front of the heap (MinHashHeap.cpp:78-94), on the reference's own test reads,
+    # filter sizes from aliasing (3K) to none (8M); -b implies -r; the read chunk size does not matter
+    for bb, nbytes in (("3K", 3000), ("8M", 8000000)):
+        rb = run("sketch", "-b", bb, "-o", "reads_b" + bb, "reads1.fastq", "reads2.fastq", cwd=tmp_path)
+        ohb, ocb, _, oszb, omultb = oracle.sketch_records(recs, oracle.params(k=21, s=1000, bloom_bytes=nbytes))
+        dumpb = run("info", "-d", "reads_b%s.msh" % bb, cwd=tmp_path).stdout
+        ha, hb = dumpb.index('\t\t\t"hashes" :'), dumpb.index('\t\t\t"counts" :')
+        hashesb = [int(x.strip().rstrip(",")) for x in dumpb[ha:hb].splitlines()[2:] if x.strip().rstrip(",").isdigit()]
+        countsb = [int(x.strip().rstrip(",")) for x in dumpb[hb:dumpb.index("\t\t}\n\t]")].splitlines()[2:-1]]
+        assert hashesb == [int(x) for x in ohb] and countsb == [int(x) for x in ocb], bb
+        assert '"length" : %d,' % int(oszb) in dumpb and min(countsb) >= 2
+        env = dict(os.environ, MASH_AMD_READS_CHUNK="20000")
+        run("sketch", "-b", bb, "-o", "reads_bc" + bb, "reads1.fastq", "reads2.fastq", cwd=tmp_path, env=env)
+        assert run("info", "-d", "reads_bc%s.msh" % bb, cwd=tmp_path).stdout == dumpb
+    # reads options reach every query file of dist / triangle (initFromFiles -> sketchFile, Sketch.cpp:1156):
+    # the two estimate lines per file, and a file of which nothing is kept (-m 2 on a sequence without
+    # repeated k-mers) ends the run like an empty file (reference.length == 0, Sketch.cpp:1302-1314)
+    rng = np.random.default_rng(77)
+    with open(tmp_path / "uniq.fa", "wb") as f:
+        f.write(b">u\n" + np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 5000)].tobytes() + b"\n")
+    rq = run("dist", "-r", "reads.msh", "reads1.fastq", "uniq.fa", cwd=tmp_path)
+    assert rq.stderr.count("Estimated genome size:") == 2 and rq.stderr.count("Estimated coverage:") == 2
+    assert len(rq.stdout.splitlines()) == 2
+    empty = run("dist", "-m", "2", "reads.msh", "reads1.fastq", "uniq.fa", cwd=tmp_path, check=False)
+    assert empty.returncode == 1 and 'ERROR: Did not find fasta records in "input files".' in empty.stderr
+    assert empty.stderr.count("Estimated genome size:") == 1                  # reads1.fastq was sketched before the refusal
     hist = run("info", "-c", "reads.msh", cwd=tmp_path).stdout.splitlines()
     assert hist[0] == "#Sketch\tBin\tFrequency" and sum(int(l.split("\t")[2]) for l in hist[1:]) == 1000
     assert "Estimated coverage:" in r.stderr

@@ -221,6 +221,66 @@ def test_sketch_target_coverage_early_stop(eng, oracle, k, s, m):
     assert u0 == long_enough and np.array_equal(h0, ph[0, : pn[0]]) and np.array_equal(c0, pc[0, : pn[0]])
 
 
+def test_sketch_bloom_reference_run_vectors(eng):
+    """-b on the device + host replay == the reference's record loop with its own MinHashHeap and
+    the vendored Bloom filter (tests/golden/ref_sketch_vectors_b.npz): hashes, counts, reads used;
+    in one piece and through a session a few records at a time."""
+    for cfg, recs, gh, gc in helpers.load_ref_sketch_vectors("ref_sketch_vectors_b.npz"):
+        p = eng.params(k=cfg["k"], s=cfg["s"], target_cov=cfg["target_cov"], bloom_bytes=cfg["bloom_bytes"])
+        h, c, used = eng.sketch_reads(recs, p)
+        assert used == cfg["used"], cfg
+        assert np.array_equal(h, gh) and np.array_equal(c, gc), cfg
+        for per in (1, 53, 100000):
+            ch, cc, cused, _ = eng.sketch_reads_chunked(recs, p, per)
+            assert cused == used and np.array_equal(ch, gh) and np.array_equal(cc, gc), (cfg, per)
+
+
+@pytest.mark.parametrize("k,s,bloom", [(21, 200, 64), (21, 1000, 20000), (16, 100, 700), (11, 64, 5), (31, 300, 1 << 22), (21, 50, 1)])
+def test_sketch_bloom_filter(eng, oracle, k, s, bloom):
+    """`mash sketch -b <bytes>` (MinHashHeap.cpp:78-94): a hash is kept, with count 2, when the bit it
+    maps to is already set -- by itself or by an alias -- so the sketch depends on the ORDER of the
+    k-mers.  Device event stream + host replay against the oracle, filters from 8 bits (everything
+    aliases) to 32 Mbit (nothing does), with noisy reads (singletons) so that aliases matter; with
+    and without -c; shuffling the reads changes the result the same way on both sides."""
+    rng = np.random.default_rng(k * 1000 + s + bloom)
+    g = synth._rand_dna(rng, 8000)
+    reads = []
+    for _ in range(2500):
+        l = int(rng.integers(30, 150))
+        st = int(rng.integers(0, 8000 - l))
+        r = bytearray(g[st:st + l])
+        for _ in range(int(rng.integers(0, 3))):                      # substitution errors: k-mers seen once
+            r[int(rng.integers(0, l))] = b"ACGT"[int(rng.integers(0, 4))]
+        r = bytes(r)
+        reads.append(r if rng.random() < 0.5 else _revcomp(r))
+    reads.insert(7, b"ACG")
+    outcomes = []
+    for order in (reads, reads[::-1]):
+        for cov in (0.0, 2.2):
+            p = eng.params(k=k, s=s, target_cov=cov, bloom_bytes=bloom)
+            gh, gc, used = eng.sketch_reads(order, p)
+            oh, oc, _, oused, _ = oracle.sketch_reads(order, oracle.params(k=k, s=s, target_cov=cov, bloom_bytes=bloom))
+            assert used == oused, (k, s, bloom, cov)
+            assert np.array_equal(gh, oh) and np.array_equal(gc, oc), (k, s, bloom, cov)
+            assert len(gc) == 0 or gc.min() >= 2
+            ch, cc, cused, _ = eng.sketch_reads_chunked(order, p, 41)
+            assert cused == used and np.array_equal(ch, gh) and np.array_equal(cc, gc), (k, s, bloom, cov)
+            if cov == 0.0:
+                outcomes.append(gh)
+    if bloom in (64, 700):
+        assert not np.array_equal(outcomes[0], outcomes[1])           # aliases: the order matters
+
+
+def test_sketch_bloom_refusals(eng):
+    """-b is a property of the sequential heap: the batch entry points refuse it, and it excludes
+    -m as in the reference (sketchParameterSetup.cpp:44-48)."""
+    p = eng.params(k=21, s=100, bloom_bytes=1000)
+    with pytest.raises(abi.MashGpuError, match="bloom_bytes needs mg_sketch_reads_host"):
+        eng.sketch_host([[b"ACGT" * 20]], p)
+    with pytest.raises(abi.MashGpuError, match="min_copies cannot be used with bloom_bytes"):
+        eng.sketch_reads([b"ACGT" * 20], eng.params(k=21, s=100, bloom_bytes=1000, min_copies=2))
+
+
 @pytest.mark.parametrize("stage", [None, "4096", "100"])
 def test_streamed_ingest_equals_one_batch(eng, oracle, stage, monkeypatch):
     """mg_sketch_begin / add / end_sketch / finish (pinned staging ring, copies on a copy stream) ==

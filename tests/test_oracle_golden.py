@@ -140,6 +140,41 @@ def test_oracle_target_coverage_equals_reference_vectors(oracle):
     assert any(c["used"] < c["nrec"] - 1 for c, _, _, _ in helpers.load_ref_sketch_vectors("ref_sketch_vectors_c.npz"))
 
 
+def test_oracle_bloom_equals_reference_vectors(oracle):
+    """`-b`: the restated Bloom filter (one hash function over bytes * 8 bits, hash_ap, salt) in
+    front of the restated heap == the reference's MinHashHeap with the vendored bloom_filter.hpp,
+    run here (tests/golden/ref_sketch_vectors_b.npz): hashes, counts, set size, multiplicity, reads
+    used (one case carries -c).  The vectors include filters small enough that aliases decide
+    which hashes are kept: an exact -m 2 filter gives a different sketch there."""
+    differs = 0
+    for cfg, recs, gh, gc in helpers.load_ref_sketch_vectors("ref_sketch_vectors_b.npz"):
+        p = oracle.params(k=cfg["k"], s=cfg["s"], target_cov=cfg["target_cov"], bloom_bytes=cfg["bloom_bytes"])
+        h, c, setsz, used, mult = oracle.sketch_reads(recs, p)
+        assert used == cfg["used"] and setsz == cfg["set_size"] and mult == cfg["mult"], cfg
+        assert np.array_equal(h, gh) and np.array_equal(c, gc), cfg
+        assert c.min() >= 2, cfg                                        # a hash is kept with count 2 (MinHashHeap.cpp:85)
+        h2, _, _, _, _ = oracle.sketch_reads(recs, oracle.params(k=cfg["k"], s=cfg["s"], min_copies=2, target_cov=cfg["target_cov"]))
+        differs += not np.array_equal(h2, gh)
+    assert differs >= 2
+
+
+def test_oracle_bloom_hash_known_values(oracle):
+    """hash_ap of bloom_filter.hpp (:526-568) with the filter's salt, restated independently here in
+    Python integers: 64-bit hashes take the two-word round, 32-bit hashes the one-word branch."""
+    M = 0xFFFFFFFF
+    seed = (0xA5A5A5A55A5A5A5A * 0xA5A5A5A5 + 1) & 0xFFFFFFFFFFFFFFFF
+    salt = (0xAAAAAAAA * 0xAAAAAAAA + (seed & M)) & M
+    rng = np.random.default_rng(5)
+    for v in [0, 1, M, 0xFFFFFFFFFFFFFFFF, 0x0123456789ABCDEF] + [int(x) for x in rng.integers(0, 2 ** 63, 50)]:
+        h = salt
+        i1, i2 = v & M, (v >> 32) & M
+        h ^= ((h << 7) & M) ^ ((i1 * (h >> 3)) & M) ^ (~(((h << 11) & M) + (i2 ^ (h >> 5))) & M)
+        assert oracle.lib.oracle_bloom_hash(v, 1) == h & M, hex(v)
+        h = salt
+        h ^= ~(((h << 11) & M) + ((v & M) ^ (h >> 5))) & M
+        assert oracle.lib.oracle_bloom_hash(v & M, 0) == h & M, hex(v)
+
+
 def test_oracle_translate_equals_reference_codon_table(oracle, golden_dir):
     """6-frame translation of `mash screen` (CommandScreen.cpp:617-809): the restated table vs
     the output of the reference's own aaFromCodon for all 64 codons + invalid ones."""
