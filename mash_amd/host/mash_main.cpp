@@ -1089,6 +1089,10 @@ int cmd_dist(int argc, const char **argv)
     init_from_files(gpu, ref, {file_ref}, p, is_sketch ? 1 : 0);
     KmerWarning w;
     if (is_sketch) {
+        if (c.o("sketchSize").active && p.reads && p.sketch_size != ref.p.sketch_size) {        // CommandDistance.cpp:121-128
+            cerr << "ERROR: The sketch size must match the reference when using a bloom filter (leave this option out to inherit from the reference sketch)." << endl;
+            return 1;
+        }
         p.sketch_size = ref.p.sketch_size;
         p.kmer = ref.p.kmer;
         p.noncanonical = ref.p.noncanonical;

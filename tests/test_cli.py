@@ -324,6 +324,10 @@ def test_make_test_recipe_on_gpu(built, tmp_path, oracle):
     empty = run("dist", "-m", "2", "reads.msh", "reads1.fastq", "uniq.fa", cwd=tmp_path, check=False)
     assert empty.returncode == 1 and 'ERROR: Did not find fasta records in "input files".' in empty.stderr
     assert empty.stderr.count("Estimated genome size:") == 1                  # reads1.fastq was sketched before the refusal
+    # a reference SKETCH fixes the sketch size of a reads-mode query (CommandDistance.cpp:121-128)
+    mism = run("dist", "-s", "300", "-r", "reads.msh", "reads1.fastq", cwd=tmp_path, check=False)
+    assert mism.returncode == 1 and mism.stdout == "" and "ERROR: The sketch size must match the reference when using a bloom filter" in mism.stderr
+    assert run("dist", "-s", "1000", "-r", "reads.msh", "reads1.fastq", cwd=tmp_path).stdout == rq.stdout.splitlines(True)[0]
     hist = run("info", "-c", "reads.msh", cwd=tmp_path).stdout.splitlines()
     assert hist[0] == "#Sketch\tBin\tFrequency" and sum(int(l.split("\t")[2]) for l in hist[1:]) == 1000
     assert "Estimated coverage:" in r.stderr

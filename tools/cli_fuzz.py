@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Differential fuzz of the CLI against the reference CLI (oracle/_ref/mash-ref, built from the
+reference's own sources; it travels to the GPU box with the snapshot).  Random command lines from a
+small grammar over the committed inputs of tests/golden/cli/in -- sketching modes and reads options,
+dist / triangle / screen / paste / info with their option variants -- are run through BOTH binaries
+in separate scratch directories; exit codes and stdout must agree (stderr is shown on a difference).
+
+    python tools/cli_fuzz.py [--n 200] [--seed 1] [--seconds 240]      # on a GPU box
+
+Prints one line per differing case and a summary; exit code 1 if anything differed."""
+import argparse, os, random, shutil, subprocess, sys, tempfile, time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+IN = os.path.join(ROOT, "tests", "golden", "cli", "in")
+OURS = os.path.join(ROOT, "mash_amd", "bin", "mash")
+REF = os.path.join(ROOT, "oracle", "_ref", "mash-ref")
+
+DNA = ["g1.fa", "g2.fa", "g3.fa", "g4.fa", "g5.fa.gz", "multi.fa"]
+READS = ["reads.fq"]
+
+
+def pick(rng, xs, lo=1, hi=None):
+    hi = hi or len(xs)
+    return rng.sample(xs, rng.randint(lo, min(hi, len(xs))))
+
+
+def sketch_opts(rng, allow_reads=True, protein=False):
+    o = []
+    if protein:
+        o += ["-a"] if rng.random() < 0.7 else ["-z", "ACDEFGHIKLMNPQRSTVWY"]
+        if rng.random() < 0.6:
+            o += ["-k", str(rng.choice([3, 5, 7, 9, 12]))]
+    else:
+        if rng.random() < 0.6:
+            o += ["-k", str(rng.choice([4, 7, 11, 15, 16, 17, 21, 27, 31, 32]))]
+        if rng.random() < 0.2:
+            o += ["-n"]
+        if rng.random() < 0.15:
+            o += ["-Z"]
+        if rng.random() < 0.08:
+            o += ["-z", rng.choice(["ACGTN", "ACGTacgt", "AC"])]
+    if rng.random() < 0.7:
+        o += ["-s", str(rng.choice([1, 2, 10, 50, 100, 300, 1000, 2500]))]
+    if rng.random() < 0.2:
+        o += ["-S", str(rng.choice([0, 1, 7, 1000, 4294967295]))]
+    if rng.random() < 0.2:
+        o += ["-p", str(rng.choice([1, 2, 5]))]
+    if rng.random() < 0.1:
+        o += ["-w", rng.choice(["0.5", "0.001", "1"])]
+    if allow_reads and not protein and rng.random() < 0.35:
+        kind = rng.choice(["r", "m", "c", "b", "g", "mc", "bc", "rg"])
+        if "r" in kind:
+            o += ["-r"]
+        if "m" in kind:
+            o += ["-m", str(rng.choice([1, 2, 3]))]
+        if "c" in kind:
+            o += ["-c", rng.choice(["1.05", "1.5", "3", "40"])]
+        if "b" in kind:
+            o += ["-b", rng.choice(["7", "300", "3K", "2M"])]
+        if "g" in kind:
+            o += ["-g", rng.choice(["10k", "123456", "2M"])]
+    return o
+
+
+def gen_case(rng, idx):
+    """-> (setup command lists, final command list)"""
+    kind = rng.choice(["sketch", "sketch", "dist", "dist", "triangle", "screen", "paste", "info"])
+    protein = kind in ("sketch", "dist", "triangle") and rng.random() < 0.12
+    files = ["prot.fa"] if protein else None
+    if kind == "sketch":
+        o = sketch_opts(rng, protein=protein)
+        reads_mode = any(x in o for x in ("-r", "-m", "-c", "-b", "-g"))
+        if rng.random() < 0.25 and not reads_mode:
+            o += ["-i"]
+        if rng.random() < 0.15 and not reads_mode:
+            o += ["-M"]
+        if rng.random() < 0.15:
+            o += ["-I", "my id"]
+        if rng.random() < 0.15:
+            o += ["-C", "a comment"]
+        if files is None:
+            files = pick(rng, READS + DNA[:2], 1, 2) if reads_mode and rng.random() < 0.8 else pick(rng, DNA + READS, 1, 4)
+        if rng.random() < 0.1 and not protein and not reads_mode:
+            o += ["-l"]
+            files = ["list.txt"]
+        setup = [["sketch", *o, "-o", "out", *files]]
+        return setup, ["info", rng.choice(["-d", "-t", "-H", "-c"]), "out.msh"]
+    if kind == "info":
+        o = sketch_opts(rng, allow_reads=False)
+        o = [x for i, x in enumerate(o) if x not in ("-p", "-w") and (i == 0 or o[i - 1] not in ("-p", "-w"))]
+        setup = [["sketch", *o, *(["-M"] if rng.random() < 0.5 else []), "-o", "out", *pick(rng, DNA, 1, 3)]]
+        return setup, ["info", rng.choice(["-d", "-t", "-H", "-c"]), "out.msh"]
+    if kind == "paste":
+        s = str(rng.choice([10, 100, 300]))
+        k = str(rng.choice([16, 21]))
+        setup = [["sketch", "-s", s, "-k", k, "-o", "p%d" % i, *pick(rng, DNA, 1, 2)] for i in range(rng.randint(2, 3))]
+        setup.append(["paste", "joined", *["p%d.msh" % i for i in range(len(setup))]])
+        return setup, rng.choice([["info", "-t", "joined.msh"], ["info", "-d", "joined.msh"], ["dist", "joined.msh", "joined.msh"]])
+    if kind == "screen":
+        k = rng.choice([16, 21])
+        setup = [["sketch", "-s", str(rng.choice([100, 300, 1000])), "-k", str(k), "-o", "db", *pick(rng, DNA[:5], 2, 5)]]
+        o = []
+        if rng.random() < 0.4:
+            o += ["-w"]
+        if rng.random() < 0.3:
+            o += ["-i", rng.choice(["0", "0.5", "0.9", "-1"])]
+        if rng.random() < 0.3:
+            o += ["-v", rng.choice(["1", "0.01", "1e-10"])]
+        if rng.random() < 0.3:
+            o += ["-p", str(rng.choice([1, 3]))]
+        return setup, ["screen", *o, "db.msh", *pick(rng, READS + DNA[:4], 1, 2)]
+    # dist / triangle
+    o = sketch_opts(rng, protein=protein)
+    reads_mode = any(x in o for x in ("-r", "-m", "-c", "-b", "-g"))
+    if rng.random() < 0.2 and not reads_mode:
+        o += ["-i"]
+    if rng.random() < 0.25:
+        o += ["-d", rng.choice(["0.05", "0.2", "1", "0"])]
+    if rng.random() < 0.25:
+        o += ["-v", rng.choice(["1", "1e-5", "1e-100", "0"])]
+    pool = ["prot.fa"] if protein else (DNA + READS if reads_mode or rng.random() < 0.2 else DNA)
+    if kind == "triangle":
+        if rng.random() < 0.4:
+            o += ["-E"]
+        if rng.random() < 0.2:
+            o += ["-C"]
+        return [], ["triangle", *o, *pick(rng, pool, 1 if protein or "-i" in o else 2, 4)]
+    if rng.random() < 0.3:
+        o += ["-t"]
+    if rng.random() < 0.15:
+        o += ["-C"]
+    if rng.random() < 0.4 and not protein:
+        # reference given as a sketch: k, s, alphabet are inherited; -k / -n / -a / -z are then refused
+        so = [x for x in sketch_opts(rng, allow_reads=False) if True]
+        setup = [["sketch", *so, "-o", "refdb", *pick(rng, DNA, 1, 3)]]
+        o = [x for i, x in enumerate(o) if x not in ("-k", "-n", "-z", "-Z", "-S") and (i == 0 or o[i - 1] not in ("-k", "-z", "-S"))]
+        return setup, ["dist", *o, "refdb.msh", *pick(rng, pool, 1, 3)]
+    return [], ["dist", *o, *pick(rng, pool, 1, 1), *pick(rng, pool, 1, 3)]
+
+
+def run_seq(binary, setup, cmd, d):
+    for s in setup:
+        r = subprocess.run([binary, *s], cwd=d, capture_output=True, timeout=300)
+        if r.returncode != 0:
+            return ("setup", s, r.returncode, b"", r.stderr)
+    r = subprocess.run([binary, *cmd], cwd=d, capture_output=True, timeout=300)
+    return ("cmd", cmd, r.returncode, r.stdout, r.stderr)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=200)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--seconds", type=float, default=240)
+    a = ap.parse_args()
+    for b in (OURS, REF):
+        if not os.path.exists(b):
+            sys.exit("missing " + b)
+    rng = random.Random(a.seed)
+    t0 = time.time()
+    bad = same = refused = 0
+    for idx in range(a.n):
+        if time.time() - t0 > a.seconds:
+            break
+        setup, cmd = gen_case(rng, idx)
+        res = []
+        for binary in (REF, OURS):
+            d = tempfile.mkdtemp(prefix="clifuzz_")
+            for f in os.listdir(IN):
+                shutil.copy(os.path.join(IN, f), d)
+            try:
+                res.append(run_seq(binary, setup, cmd, d))
+            except subprocess.TimeoutExpired:
+                res.append(("timeout", cmd, -999, b"", b""))
+            shutil.rmtree(d)
+        (ws, wc, wrc, wout, werr), (gs, gc, grc, gout, gerr) = res
+        ok = ws == gs and wrc == grc and wout == gout
+        if ok:
+            same += 1
+            refused += wrc != 0
+            continue
+        bad += 1
+        print("DIFF #%d setup=%s cmd=%s" % (idx, setup, cmd))
+        print("   ref : stage %s rc %d stdout %d B; stderr tail %r" % (ws, wrc, len(wout), werr[-200:]))
+        print("   ours: stage %s rc %d stdout %d B; stderr tail %r" % (gs, grc, len(gout), gerr[-200:]))
+        if wrc == grc == 0:
+            x, y = wout.splitlines(), gout.splitlines()
+            i = next((k for k in range(min(len(x), len(y))) if x[k] != y[k]), min(len(x), len(y)))
+            print("   first differing line %d: ref %r ours %r" % (i, x[i][:140] if i < len(x) else None, y[i][:140] if i < len(y) else None))
+        sys.stdout.flush()
+    print("cases run: %d  identical: %d (of which refused by both: %d)  differing: %d  [seed %d, %.0f s]"
+          % (same + bad, same, refused, bad, a.seed, time.time() - t0))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
