@@ -87,7 +87,9 @@ int         mg_device_count(void);               /* visible GPUs (0 when there i
 int         mg_ctx_create(int device, mg_ctx **out);
 void        mg_ctx_destroy(mg_ctx *ctx);
 const char *mg_last_error(mg_ctx *ctx);      /* ctx may be NULL: last create error */
-/* Run on an existing hipStream_t (e.g. torch's current stream). NULL = own stream. */
+/* Run on an existing hipStream_t (e.g. torch's current stream).  NULL (which is also what the legacy
+ * default stream's handle is) = the context's own stream: a blocking stream, i.e. implicitly ordered
+ * with work on the legacy default stream, as every hipStreamDefault stream is. */
 int         mg_ctx_set_stream(mg_ctx *ctx, void *hip_stream);
 int         mg_ctx_synchronize(mg_ctx *ctx);
 /* Entry points lock their context: any number of host threads may drive one context (their

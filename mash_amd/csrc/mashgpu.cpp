@@ -202,7 +202,9 @@ int mg_ctx_create(int device, mg_ctx **out)
     if (e != hipSuccess) return fail(nullptr, MG_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
     mg_ctx *c = new mg_ctx;
     c->device = device;
-    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    // a BLOCKING stream: implicitly ordered with the legacy default stream, so a caller that prepares
+    // inputs or clears outputs on stream 0 (torch's default) needs no event between that and our work
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamDefault);
     if (e != hipSuccess) { delete c; return fail(nullptr, MG_ERR_HIP, "hipStreamCreate failed"); }
     c->own_stream = true;
     hipDeviceProp_t prop;
@@ -235,7 +237,7 @@ int mg_ctx_set_stream(mg_ctx *ctx, void *hip_stream)
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (ctx->own_stream && ctx->stream) { hipStreamDestroy(ctx->stream); ctx->own_stream = false; }
     if (hip_stream == nullptr) {
-        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamDefault));   // blocking, see mg_ctx_create
         ctx->own_stream = true;
     } else {
         ctx->stream = (hipStream_t)hip_stream;

@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python tools/cli_fuzz.py --n 700 --seed 2 --seconds 400 > gpurun_out/z_fuzz2.txt 2>&1; echo rc=$?
-tail -40 gpurun_out/z_fuzz2.txt | cut -c1-600
-timeout 900 python -m pytest tests/test_cli.py -x -q -m gpu > gpurun_out/z_tests.log 2>&1; echo "tests rc=$?"; tail -5 gpurun_out/z_tests.log
+timeout 600 python tools/compare_fuzz.py --n 3000 --seed 3 --seconds 150 > gpurun_out/z_cfuzz3.txt 2>&1; echo rc=$?
+tail -12 gpurun_out/z_cfuzz3.txt | cut -c1-400
+timeout 300 python tools/compare_fuzz.py --n 2047 --seed 3 --only 2046 --seconds 1000 > gpurun_out/z_cfuzz3b.txt 2>&1; echo rc=$?
+tail -12 gpurun_out/z_cfuzz3b.txt | cut -c1-400
