@@ -309,9 +309,17 @@ __global__ __launch_bounds__(NT) void sketch_chunks_kernel(SketchArgs a)
                 }
             }
         };
-        const uint32_t count0 = st->count;
+        uint32_t count0 = st->count;
         const bool steady = st->full != 0 && count0 + (uint32_t)NT <= cap;
         __syncthreads();                                   // everybody has read count0 / full
+        if (!steady && count0 + (uint32_t)NT * 4 * SK_SEG_DW > cap) {
+            // A segmented pass checks the capacity AFTER each segment, so it must start with room for
+            // one (steady tiles may leave the buffer fuller than that: they have no check at their end).
+            // Without this, input whose k-mers keep passing the threshold -- a handful of distinct k-mers,
+            // low-complexity runs -- wrote its first segment past the buffer into the staged tile.
+            compact_buffer<NT>(buf, st, s_wsum, s, g_T);
+            count0 = st->count;
+        }
         if (steady) {
             run_tile(std::false_type{}, probing);
             __syncthreads();

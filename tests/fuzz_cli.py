@@ -5,9 +5,10 @@ small grammar over the committed inputs of tests/golden/cli/in -- sketching mode
 dist / triangle / screen / paste / info with their option variants -- are run through BOTH binaries
 in separate scratch directories; exit codes and stdout must agree (stderr is shown on a difference).
 
-    python tools/cli_fuzz.py [--n 200] [--seed 1] [--seconds 240]      # on a GPU box
+    python tests/fuzz_cli.py [--n 200] [--seed 1] [--seconds 240]      # on a GPU box
 
-Prints one line per differing case and a summary; exit code 1 if anything differed."""
+Prints one line per differing case and a summary; exit code 1 if anything differed.
+(Test infrastructure: it lives under tests/ because it executes oracle/_ref.)"""
 import argparse, os, random, shutil, subprocess, sys, tempfile, time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

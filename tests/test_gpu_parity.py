@@ -221,6 +221,56 @@ def test_sketch_target_coverage_early_stop(eng, oracle, k, s, m):
     assert u0 == long_enough and np.array_equal(h0, ph[0, : pn[0]]) and np.array_equal(c0, pc[0, : pn[0]])
 
 
+def test_sketch_fuzz_regressions(eng, oracle):
+    """Inputs on which tests/fuzz_sketch.py found the engine wrong (tests/golden/sketch_fuzz_regressions.npz):
+    long records over a handful of distinct k-mers (protein k = 3, k = 1 over an 8-letter alphabet).
+    Nearly every k-mer keeps passing the threshold there; a segmented tile that started with a
+    nearly full candidate buffer wrote its first segment past the buffer, into the staged bases."""
+    import json
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "sketch_fuzz_regressions.npz"))
+    for cfg in json.loads(str(z["cfgs"])):
+        i = cfg["idx"]
+        bases, lens = z[f"bases_{i}"].tobytes(), z[f"lens_{i}"]
+        recs, o = [], 0
+        for l in lens:
+            recs.append(bases[o:o + int(l)])
+            o += int(l)
+        kw = dict(k=cfg["k"], s=cfg["s"], seed=cfg["seed"], alphabet=cfg["alphabet"], noncanonical=bool(cfg["noncanonical"]),
+                  preserve_case=bool(cfg["preserve_case"]))
+        h, n, c = eng.sketch_host([recs, recs], eng.params(**kw), counts=True)
+        oh, oc, _, _, _ = oracle.sketch_records(recs, oracle.params(**kw))
+        assert np.array_equal(oh, z[f"oracle_{i}"]), cfg["tag"]
+        for r in (0, 1):
+            assert np.array_equal(h[r, : n[r]], oh) and np.array_equal(c[r, : n[r]], oc), cfg["tag"]
+
+
+@pytest.mark.parametrize("alphabet,k,s,length", [("ACDEFGHIKLMNPQRSTVWY", 3, 400, 37000), ("ACDEFGHIKLMNPQRSTVWY", 2, 300, 61000),
+                                                 ("ACGTacgt", 1, 2, 39000), ("AC", 7, 100, 45000), ("ACGT", 3, 40, 70000),
+                                                 ("ACGT", 21, 1000, 50000)])
+def test_sketch_few_distinct_kmers(eng, oracle, alphabet, k, s, length):
+    """Long inputs with few distinct k-mers (tiny k-mer spaces; for k = 21 a short unit repeated):
+    duplicates of kept hashes pass the threshold all the time, the candidate buffer fills within a
+    fraction of a tile, every tile goes through overflow handling.  Several sketches per batch,
+    forward and canonical, against the oracle, with multiplicities."""
+    rng = np.random.default_rng(k * 1000 + s)
+    letters = np.frombuffer(alphabet.upper().encode(), dtype=np.uint8)
+    sketches = []
+    for v in range(4):
+        if k == 21:
+            unit = letters[rng.integers(0, len(letters), int(rng.integers(25, 400)))].tobytes()
+            seq = (unit * (length // len(unit) + 1))[:length]
+        else:
+            seq = letters[rng.integers(0, len(letters), length + 1000 * v)].tobytes()
+        sketches.append([seq])
+    for noncanon in ([True] if alphabet != "ACGT" else [False, True]):
+        kw = dict(k=k, s=s, alphabet=alphabet, noncanonical=noncanon)
+        h, n, c = eng.sketch_host(sketches, eng.params(**kw), counts=True)
+        for i, recs in enumerate(sketches):
+            oh, oc, _, _, _ = oracle.sketch_records(recs, oracle.params(**kw))
+            assert np.array_equal(h[i, : n[i]], oh), (alphabet, k, s, noncanon, i)
+            assert np.array_equal(c[i, : n[i]], oc), (alphabet, k, s, noncanon, i)
+
+
 def test_sketch_bloom_reference_run_vectors(eng):
     """-b on the device + host replay == the reference's record loop with its own MinHashHeap and
     the vendored Bloom filter (tests/golden/ref_sketch_vectors_b.npz): hashes, counts, reads used;

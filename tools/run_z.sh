@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python tools/compare_fuzz.py --n 3000 --seed 3 --seconds 150 > gpurun_out/z_cfuzz3.txt 2>&1; echo rc=$?
-tail -12 gpurun_out/z_cfuzz3.txt | cut -c1-400
-timeout 300 python tools/compare_fuzz.py --n 2047 --seed 3 --only 2046 --seconds 1000 > gpurun_out/z_cfuzz3b.txt 2>&1; echo rc=$?
-tail -12 gpurun_out/z_cfuzz3b.txt | cut -c1-400
+for seed in 2 3 4; do
+timeout 600 python tests/fuzz_sketch.py --n 6000 --seed $seed --seconds 100 --dump gpurun_out/sfuzz > gpurun_out/z_sfuzz$seed.txt 2>&1; echo rc=$?
+tail -8 gpurun_out/z_sfuzz$seed.txt | cut -c1-600
+done
