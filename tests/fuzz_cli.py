@@ -100,6 +100,8 @@ def gen_case(rng, idx):
     if kind == "screen":
         k = rng.choice([16, 21])
         setup = [["sketch", "-s", str(rng.choice([100, 300, 1000])), "-k", str(k), "-o", "db", *pick(rng, DNA[:5], 2, 5)]]
+        if rng.random() < 0.25:                              # amino-acid database: the mixture is translated in six frames
+            setup = [["sketch", "-a", "-i", "-k", str(rng.choice([5, 7, 9])), "-s", str(rng.choice([50, 200, 1000])), "-o", "db", "prot.fa"]]
         o = []
         if rng.random() < 0.4:
             o += ["-w"]
@@ -139,12 +141,12 @@ def gen_case(rng, idx):
     return [], ["dist", *o, *pick(rng, pool, 1, 1), *pick(rng, pool, 1, 3)]
 
 
-def run_seq(binary, setup, cmd, d):
+def run_seq(binary, setup, cmd, d, env=None):
     for s in setup:
-        r = subprocess.run([binary, *s], cwd=d, capture_output=True, timeout=300)
+        r = subprocess.run([binary, *s], cwd=d, capture_output=True, timeout=300, env=env)
         if r.returncode != 0:
             return ("setup", s, r.returncode, b"", r.stderr)
-    r = subprocess.run([binary, *cmd], cwd=d, capture_output=True, timeout=300)
+    r = subprocess.run([binary, *cmd], cwd=d, capture_output=True, timeout=300, env=env)
     return ("cmd", cmd, r.returncode, r.stdout, r.stderr)
 
 
@@ -153,7 +155,9 @@ def main():
     ap.add_argument("--n", type=int, default=200)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--seconds", type=float, default=240)
+    ap.add_argument("--env", action="append", default=[], help="KEY=VALUE for our binary only, e.g. MASH_GPU_DEVICES=0,0 (the sharded paths)")
     a = ap.parse_args()
+    ours_env = dict(os.environ, **dict(kv.split("=", 1) for kv in a.env)) if a.env else None
     for b in (OURS, REF):
         if not os.path.exists(b):
             sys.exit("missing " + b)
@@ -170,7 +174,7 @@ def main():
             for f in os.listdir(IN):
                 shutil.copy(os.path.join(IN, f), d)
             try:
-                res.append(run_seq(binary, setup, cmd, d))
+                res.append(run_seq(binary, setup, cmd, d, ours_env if binary == OURS else None))
             except subprocess.TimeoutExpired:
                 res.append(("timeout", cmd, -999, b"", b""))
             shutil.rmtree(d)
