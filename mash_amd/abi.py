@@ -404,11 +404,14 @@ class RankComm:
     def __init__(self, eng, nranks, rank, exchange):
         self.eng, self.lib = eng, eng.lib
         idbuf = C.create_string_buffer(128)
-        if rank == 0:
-            rc = self.lib.mg_comm_unique_id(idbuf, 128)
-            if rc != MG_OK:
-                raise MashGpuError("mg_comm_unique_id: " + self.lib.mg_comm_last_error(None).decode())
-        raw = exchange(bytes(idbuf.raw) if rank == 0 else None)
+        err = None
+        if rank == 0 and self.lib.mg_comm_unique_id(idbuf, 128) != MG_OK:
+            err = "mg_comm_unique_id: " + self.lib.mg_comm_last_error(None).decode()
+        # (a failure on rank 0 still goes through the exchange, as an empty id: the other ranks are
+        #  waiting in it and must fail with rank 0, not hang)
+        raw = exchange((bytes(idbuf.raw) if err is None else b"") if rank == 0 else None)
+        if not raw or len(raw) != 128:
+            raise MashGpuError(err or "rank 0 could not create a communicator id")
         idbuf = C.create_string_buffer(raw, 128)
         h = C.c_void_p()
         rc = self.lib.mg_comm_create_rank(eng.ctx, idbuf, 128, nranks, rank, C.byref(h))
