@@ -25,6 +25,13 @@ def pick(rng, xs, lo=1, hi=None):
     return rng.sample(xs, rng.randint(lo, min(hi, len(xs))))
 
 
+def split_stdin(args):
+    """a trailing "<file" argument means: run with that file on stdin"""
+    if args and args[-1].startswith("<"):
+        return args[:-1], args[-1][1:]
+    return args, None
+
+
 def sketch_opts(rng, allow_reads=True, protein=False):
     o = []
     if protein:
@@ -84,6 +91,13 @@ def gen_case(rng, idx):
         if rng.random() < 0.1 and not protein and not reads_mode:
             o += ["-l"]
             files = ["list.txt"]
+        r = rng.random()
+        if r < 0.12 and files[0] not in ("list.txt",):
+            # no -o: the output is named after the first input (CommandSketch.cpp:137-150)
+            return [["sketch", *o, *files]], ["info", rng.choice(["-d", "-t"]), files[0] + ".msh"]
+        if r < 0.2 and "-l" not in o:
+            # first input from stdin
+            return [["sketch", *o, "-o", "out", "-", *files[1:], "<" + files[0]]], ["info", rng.choice(["-d", "-t"]), "out.msh"]
         setup = [["sketch", *o, "-o", "out", *files]]
         return setup, ["info", rng.choice(["-d", "-t", "-H", "-c"]), "out.msh"]
     if kind == "info":
@@ -127,6 +141,8 @@ def gen_case(rng, idx):
             o += ["-E"]
         if rng.random() < 0.2:
             o += ["-C"]
+        if rng.random() < 0.15 and not protein:
+            return [], ["triangle", *o, "-l", "list.txt", *pick(rng, ["list.txt"], 0, 1)]
         return [], ["triangle", *o, *pick(rng, pool, 1 if protein or "-i" in o else 2, 4)]
     if rng.random() < 0.3:
         o += ["-t"]
@@ -138,15 +154,27 @@ def gen_case(rng, idx):
         setup = [["sketch", *so, "-o", "refdb", *pick(rng, DNA, 1, 3)]]
         o = [x for i, x in enumerate(o) if x not in ("-k", "-n", "-z", "-Z", "-S") and (i == 0 or o[i - 1] not in ("-k", "-z", "-S"))]
         return setup, ["dist", *o, "refdb.msh", *pick(rng, pool, 1, 3)]
+    if rng.random() < 0.15 and not protein:
+        return [], ["dist", *o, "-l", *pick(rng, pool, 1, 1), "list.txt"]
+    if rng.random() < 0.1 and not protein:
+        return [], ["dist", *o, *pick(rng, pool, 1, 1), "-", "<" + rng.choice(pool)]       # query from stdin
     return [], ["dist", *o, *pick(rng, pool, 1, 1), *pick(rng, pool, 1, 3)]
+
+
+def run_one(binary, args, d, env):
+    args, stdin_file = split_stdin(args)
+    if stdin_file is None:
+        return subprocess.run([binary, *args], cwd=d, capture_output=True, timeout=300, env=env, stdin=subprocess.DEVNULL)
+    with open(os.path.join(d, stdin_file), "rb") as f:
+        return subprocess.run([binary, *args], cwd=d, capture_output=True, timeout=300, env=env, stdin=f)
 
 
 def run_seq(binary, setup, cmd, d, env=None):
     for s in setup:
-        r = subprocess.run([binary, *s], cwd=d, capture_output=True, timeout=300, env=env)
+        r = run_one(binary, s, d, env)
         if r.returncode != 0:
             return ("setup", s, r.returncode, b"", r.stderr)
-    r = subprocess.run([binary, *cmd], cwd=d, capture_output=True, timeout=300, env=env)
+    r = run_one(binary, cmd, d, env)
     return ("cmd", cmd, r.returncode, r.stdout, r.stderr)
 
 
