@@ -1631,8 +1631,12 @@ static int run_compare_merged(mg_ctx *ctx, const mg_table *rows, const mg_table 
     // on (40 000: 16.9 vs 15.5e9 pairs/s; 70 000: 22.2 vs 17.2; 100 000: 26.5 vs 17.7) and loses below
     // (20 000: 10.2 vs 11.9; 10 000: 6.0 vs 7.5) -- more launches, each with its tail, and a table
     // build per tile and window -- so small jobs keep plain tiles; large sketches (s >= 1800) always
-    // take windows (plain tiles would hold 8 rows or fewer).
-    bool want_win = a.s >= 1800 || (a.s >= 200 && (row_end - row_begin) * maxcols >= 800000000ull);
+    // take windows (plain tiles would hold 8 rows or fewer).  With the round-2 kernel
+    // (tools/small_n_profile.py) the crossover sits at ~23 000 sketches for s = 1000 (28 000: 16.4 vs
+    // 14.8; 20 000: 12.1 vs 12.9) and at ~11 000 for s = 400 (20 000: 27.3 vs 21.7; 10 000: 16.2 vs
+    // 16.6): rows x columns >= 1.4e8 up to s = 400, rising linearly to 5.5e8 at s = 1000.
+    const double win_cross = a.s <= 400 ? 1.4e8 : a.s >= 1000 ? 5.5e8 : 1.4e8 + (a.s - 400.0) * (4.1e8 / 600.0);
+    bool want_win = a.s >= 1800 || (a.s >= 200 && (double)(row_end - row_begin) * (double)maxcols >= win_cross);
     if (const char *e = getenv("MASHGPU_COMPARE_WINDOWS")) want_win = atoi(e) != 0;
     if (windows_only) want_win = true;
     // window tiles over the direct-mapped table (compare_direct.hip): MASHGPU_COMPARE_KERNEL=direct forces
@@ -1738,8 +1742,14 @@ static int run_compare_merged(mg_ctx *ctx, const mg_table *rows, const mg_table 
         a.rows_per_tile = wr ? mg::compare_window_rows(a.s) : R_plain;
         const uint64_t CCc = chunk_for(groups.size());
         std::vector<mg::MergedTile> mtiles;
+        // Longest tiles first: in a triangle a row group needs the columns below its last row, so within
+        // a column chunk the tiles grow with the row index (from a handful of columns to the whole chunk).
+        // Handing the workgroups out in that order left the largest tiles for the end -- at 20 000 sketches
+        // a tail of one full tile, a fifth of the launch; later chunks hold ever fewer and shorter tiles,
+        // so chunk-major order with the groups reversed is longest-first overall.
         for (uint64_t c0 = 0; c0 < maxcols; c0 += CCc) {
-            for (const auto &g : groups) {
+            for (auto git = groups.rbegin(); git != groups.rend(); ++git) {
+                const auto &g = *git;
                 const uint32_t last = list[g.second - 1];
                 const uint64_t cend = triangle ? last : cols->n;         // columns needed: [0, cend)
                 if (c0 >= cend) continue;
