@@ -18,6 +18,30 @@ REF = os.path.join(ROOT, "oracle", "_ref", "mash-ref")
 
 DNA = ["g1.fa", "g2.fa", "g3.fa", "g4.fa", "g5.fa.gz", "multi.fa"]
 READS = ["reads.fq"]
+EDGE = ["lowc.fa", "tiny.fa", "empty.fa", "allN.fa", "mixed.fq"]       # written by edge_inputs() into every scratch directory
+
+
+def edge_inputs(d):
+    """inputs for the corners: low-complexity sequence (tandem repeats, homopolymers: the same few k-mers
+    over and over), records shorter than any k, an empty file, a record of N only, a FASTQ whose
+    records are partly too short"""
+    r = random.Random(99)
+    unit = "".join(r.choice("ACGT") for _ in range(23))
+    lowc = unit * 900 + "A" * 3000 + "AC" * 2500 + "".join(r.choice("ACGT") for _ in range(400)) + unit[:11] * 700
+    with open(os.path.join(d, "lowc.fa"), "w") as f:
+        f.write(">lowc tandem repeats\n")
+        for i in range(0, len(lowc), 80):
+            f.write(lowc[i:i + 80] + "\n")
+    with open(os.path.join(d, "tiny.fa"), "w") as f:
+        f.write(">t1\nACG\n>t2\nACGTAC\n>t3\n\n")
+    open(os.path.join(d, "empty.fa"), "w").close()
+    with open(os.path.join(d, "allN.fa"), "w") as f:
+        f.write(">n only\n" + "N" * 500 + "\n")
+    with open(os.path.join(d, "mixed.fq"), "w") as f:
+        for i in range(60):
+            l = 10 if i % 4 == 0 else 90
+            seq = "".join(r.choice("ACGT") for _ in range(l))
+            f.write("@m%d\n%s\n+\n%s\n" % (i, seq, "I" * l))
 
 
 def pick(rng, xs, lo=1, hi=None):
@@ -88,6 +112,9 @@ def gen_case(rng, idx):
             o += ["-C", "a comment"]
         if files is None:
             files = pick(rng, READS + DNA[:2], 1, 2) if reads_mode and rng.random() < 0.8 else pick(rng, DNA + READS, 1, 4)
+            if rng.random() < 0.25:                          # corner inputs, alone or among the others
+                files = pick(rng, EDGE, 1, 2) + (files[:1] if rng.random() < 0.5 else [])
+                rng.shuffle(files)
         if rng.random() < 0.1 and not protein and not reads_mode:
             o += ["-l"]
             files = ["list.txt"]
@@ -125,7 +152,7 @@ def gen_case(rng, idx):
             o += ["-v", rng.choice(["1", "0.01", "1e-10"])]
         if rng.random() < 0.3:
             o += ["-p", str(rng.choice([1, 3]))]
-        return setup, ["screen", *o, "db.msh", *pick(rng, READS + DNA[:4], 1, 2)]
+        return setup, ["screen", *o, "db.msh", *pick(rng, READS + DNA[:4] + (EDGE if rng.random() < 0.3 else []), 1, 2)]
     # dist / triangle
     o = sketch_opts(rng, protein=protein)
     reads_mode = any(x in o for x in ("-r", "-m", "-c", "-b", "-g"))
@@ -136,6 +163,8 @@ def gen_case(rng, idx):
     if rng.random() < 0.25:
         o += ["-v", rng.choice(["1", "1e-5", "1e-100", "0"])]
     pool = ["prot.fa"] if protein else (DNA + READS if reads_mode or rng.random() < 0.2 else DNA)
+    if not protein and rng.random() < 0.2:
+        pool = pool + EDGE
     if kind == "triangle":
         if rng.random() < 0.4:
             o += ["-E"]
@@ -191,7 +220,7 @@ def main():
             sys.exit("missing " + b)
     rng = random.Random(a.seed)
     t0 = time.time()
-    bad = same = refused = 0
+    bad = same = refused = crashed = 0
     for idx in range(a.n):
         if time.time() - t0 > a.seconds:
             break
@@ -201,6 +230,7 @@ def main():
             d = tempfile.mkdtemp(prefix="clifuzz_")
             for f in os.listdir(IN):
                 shutil.copy(os.path.join(IN, f), d)
+            edge_inputs(d)
             try:
                 res.append(run_seq(binary, setup, cmd, d, ours_env if binary == OURS else None))
             except subprocess.TimeoutExpired:
@@ -208,6 +238,12 @@ def main():
             shutil.rmtree(d)
         (ws, wc, wrc, wout, werr), (gs, gc, grc, gout, gerr) = res
         ok = ws == gs and wrc == grc and wout == gout
+        if wrc < 0 and wrc != -999:
+            # the reference died from a signal (e.g. SIGFPE in `dist` when the reference side holds no
+            # sketch: pairCount % 0, CommandDistance.cpp:196-214): nothing to be identical to
+            crashed += 1
+            print("REF-CRASH #%d signal %d cmd=%s (ours: rc %d)" % (idx, -wrc, cmd, grc))
+            continue
         if ok:
             same += 1
             refused += wrc != 0
@@ -221,8 +257,8 @@ def main():
             i = next((k for k in range(min(len(x), len(y))) if x[k] != y[k]), min(len(x), len(y)))
             print("   first differing line %d: ref %r ours %r" % (i, x[i][:140] if i < len(x) else None, y[i][:140] if i < len(y) else None))
         sys.stdout.flush()
-    print("cases run: %d  identical: %d (of which refused by both: %d)  differing: %d  [seed %d, %.0f s]"
-          % (same + bad, same, refused, bad, a.seed, time.time() - t0))
+    print("cases run: %d  identical: %d (of which refused by both: %d)  differing: %d  reference crashed: %d  [seed %d, %.0f s]"
+          % (same + bad + crashed, same, refused, bad, crashed, a.seed, time.time() - t0))
     sys.exit(1 if bad else 0)
 
 
