@@ -1160,9 +1160,17 @@ int cmd_dist(int argc, const char **argv)
     // (a distance depends on numer / denom alone) and no p-value is evaluated
     const uint64_t s_tab = std::min(ref.p.sketch_size, qry.p.sketch_size);
     vector<double> dist_lut;
+    vector<string> dist_txt;
     if (table && p_max >= 1.0 && s_tab <= (1u << 20) && !getenv("MASH_AMD_FULL_FINISH")) {
         dist_lut.resize(s_tab + 1);
         for (uint64_t x = 0; x <= s_tab; x++) dist_lut[x] = mg_distance((uint32_t)x, (uint32_t)s_tab, ref.p.kmer);
+        dist_txt.resize(s_tab + 1);                                // the cell of the table, formatted once
+        for (uint64_t x = 0; x <= s_tab; x++) {
+            FastOut t(false);
+            t << '\t';
+            if (!(dist_lut[x] > d_max)) t << dist_lut[x];          // CommandDistance.cpp:409-412
+            dist_txt[x] = t.buf;
+        }
     }
     for (uint64_t q0 = 0; q0 < nq; q0 += qblock) {
         const uint64_t q1 = std::min(nq, q0 + qblock);
@@ -1182,9 +1190,12 @@ int cmd_dist(int argc, const char **argv)
                 o << qry.refs[q].name;                            // writeOutput, CommandDistance.cpp:247-304
                 for (uint64_t r = 0; r < nref; r++) {
                     const mg_counts &c = counts[(q - q0) * nref + r];
-                    const double d = c.denom == s_tab ? dist_lut[c.numer] : mg_distance(c.numer, c.denom, ref.p.kmer);
-                    o << '\t';
-                    if (!(d > d_max)) o << d;                      // CommandDistance.cpp:409-412
+                    if (c.denom == s_tab) o << dist_txt[c.numer];
+                    else {
+                        const double d = mg_distance(c.numer, c.denom, ref.p.kmer);
+                        o << '\t';
+                        if (!(d > d_max)) o << d;                  // CommandDistance.cpp:409-412
+                    }
                     o.room();
                 }
                 o.eol();
@@ -1305,6 +1316,7 @@ int cmd_triangle(int argc, const char **argv)
     // evaluation.  The bound test has a 1e-9 relative margin for the rounding of that evaluation.
     const uint64_t s_tab = set.p.sketch_size;
     vector<double> dist_lut, p_bound;
+    vector<string> dist_txt;                                       // "\t" + the text of dist_lut[x]: formatted once, not per pair
     if (!edge && s_tab <= (1u << 20) && !getenv("MASH_AMD_FULL_FINISH")) {          // (env: the plain path, for tests)
         uint64_t l1 = 0, l2 = 0;                                   // the two largest lengths
         for (uint64_t v : lengths) { if (v > l1) { l2 = l1; l1 = v; } else if (v > l2) l2 = v; }
@@ -1313,6 +1325,12 @@ int cmd_triangle(int argc, const char **argv)
         for (uint64_t x = 0; x <= s_tab; x++) {
             dist_lut[x] = mg_distance((uint32_t)x, (uint32_t)s_tab, set.p.kmer);
             p_bound[x] = mg_p_value(x, l1, l2, kspace, s_tab) * (1.0 + 1e-9);
+        }
+        dist_txt.resize(s_tab + 1);
+        for (uint64_t x = 0; x <= s_tab; x++) {
+            FastOut t(false);
+            t << '\t' << dist_lut[x];
+            dist_txt[x] = t.buf;
         }
     }
     const bool lean = !dist_lut.empty();
@@ -1346,7 +1364,8 @@ int cmd_triangle(int argc, const char **argv)
                 for (uint64_t j = 0; j < i; j++, idx++) {
                     const mg_counts &c = counts[idx];
                     const bool full = c.denom == s_tab;
-                    o << '\t' << (full ? dist_lut[c.numer] : mg_distance(c.numer, c.denom, set.p.kmer));
+                    if (full) o << dist_txt[c.numer];
+                    else o << '\t' << mg_distance(c.numer, c.denom, set.p.kmer);
                     o.room();
                     if (!full || p_bound[c.numer] >= pk) {
                         const double pv = mg_p_value(c.numer, lengths[i], lengths[j], kspace, c.denom);
