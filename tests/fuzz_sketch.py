@@ -66,9 +66,20 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--seconds", type=float, default=200)
     ap.add_argument("--dump", default="", help="directory for the inputs of differing cases")
+    ap.add_argument("--against", default="gpu", choices=["gpu", "ref"],
+                    help="gpu: the engine against the oracle (GPU box); ref: the oracle against the reference's own objects "
+                         "(oracle/_ref/libmash_ref.so, CPU, only where /root/reference was available to build it)")
     a = ap.parse_args()
-    eng = abi.MashGpu(0)
+    sys.exit(run(a.n, a.seed, a.seconds, a.dump, a.against))
+
+
+def run(n_cases, seed, seconds, dump="", against="gpu", quiet=False):
+    import types
+    a = types.SimpleNamespace(n=n_cases, seed=seed, seconds=seconds, dump=dump)
     orc = pyoracle.Oracle()
+    if against == "ref":
+        return run_ref(a, orc, quiet)
+    eng = abi.MashGpu(0)
     rng = np.random.default_rng(a.seed)
     t0 = time.time()
     bad = ran = 0
@@ -149,7 +160,74 @@ def main():
             bad += 1
         ran += 1
     print("cases: %d  differing: %d  [seed %d, %.0f s]" % (ran, bad, a.seed, time.time() - t0))
-    sys.exit(1 if bad else 0)
+    return 1 if bad else 0
+
+
+def gen_case(rng):
+    """the parameter / input generator shared by both modes (same draws in the same order as run())"""
+    protein = rng.random() < 0.2
+    if protein:
+        alphabet = "ACDEFGHIKLMNPQRSTVWY" if rng.random() < 0.7 else "ACDEFGHIKLMNPQRSTVWYXBZ"
+        k = int(rng.choice([1, 2, 3, 5, 7, 8, 9, 12, 20, 32]))
+        noncanon = True
+    else:
+        alphabet = str(rng.choice(["ACGT", "ACGT", "ACGT", "ACGTN", "AC", "ACGTacgt"]))
+        k = int(rng.choice([1, 2, 3, 4, 7, 11, 15, 16, 17, 21, 27, 31, 32]))
+        noncanon = bool(alphabet != "ACGT" or rng.random() < 0.25)
+    s = int(rng.choice([1, 2, 10, 64, 100, 400, 1000, 3000, 10000, 14000]))
+    seed = int(rng.choice([0, 1, 42, 42, 4294967295, int(rng.integers(0, 2 ** 32))]))
+    preserve = bool(rng.random() < 0.2)
+    mode = rng.choice(["plain", "plain", "counts", "mincopies", "cov", "bloom"])
+    if mode in ("cov", "bloom") and s > 3000:
+        s = 1000
+    sketches = gen_sketches(rng, protein, k)
+    return protein, alphabet, k, noncanon, s, seed, preserve, mode, sketches
+
+
+def run_ref(a, orc, quiet=False):
+    """the oracle (C restatement) against the reference's own MinHashHeap / addMinHashes / bloom_filter on
+    the fuzzer's cases; bytes >= 0x80 are replaced first (the reference indexes alphabet[] with a negative
+    char there, Sketch.cpp:550 -- undefined behaviour, nothing to compare with)"""
+    refo = pyoracle.Oracle(ref=True)
+    rng = np.random.default_rng(a.seed)
+    t0 = time.time()
+    bad = ran = 0
+    clean = bytes(range(128)) + b"N" * 128
+    for case in range(a.n):
+        if time.time() - t0 > a.seconds:
+            break
+        protein, alphabet, k, noncanon, s, seed, preserve, mode, sketches = gen_case(rng)
+        sketches = [[r.translate(clean) for r in sk] for sk in sketches]
+        kw = dict(k=k, s=s, seed=seed, alphabet=alphabet, noncanonical=noncanon, preserve_case=preserve)
+        tag = "case %d %s k=%d s=%d seed=%d alphabet=%s noncanonical=%d preserve=%d nsk=%d" % (case, mode, k, s, seed, alphabet, noncanon, preserve, len(sketches))
+        if mode in ("plain", "counts", "mincopies"):
+            m = int(rng.choice([2, 3])) if mode == "mincopies" else 1
+            if mode != "plain" and s > 10000:
+                kw["s"] = 10000
+            rng.choice([1 << 30, 4096, 977])                          # (the draw run() spends on the piece size)
+            for i, recs in enumerate(sketches):
+                x = orc.sketch_records(recs, orc.params(min_copies=m, **kw))
+                y = refo.sketch_records(recs, refo.params(min_copies=m, **kw))
+                if not (np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and x[2:] == y[2:]):
+                    print("DIFF", tag, "sketch", i)
+                    bad += 1
+                    break
+        else:
+            recs = [r for sk in sketches for r in sk] or [b""]
+            if mode == "cov":
+                extra = dict(target_cov=float(rng.choice([1.05, 1.5, 3.0, 100.0])), min_copies=int(rng.choice([1, 1, 2])))
+            else:
+                extra = dict(bloom_bytes=int(rng.choice([1, 9, 300, 5000, 1 << 20])), target_cov=float(rng.choice([0.0, 0.0, 2.0])))
+            rng.choice([1, 3, 50])                                    # (the draw run() spends on the chunk size)
+            x = orc.sketch_reads(recs, orc.params(**kw, **extra))
+            y = refo.sketch_reads(recs, refo.params(**kw, **extra))
+            if not (np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and x[2:] == y[2:]):
+                print("DIFF", tag, extra)
+                bad += 1
+        ran += 1
+    if not quiet or bad:
+        print("oracle vs reference objects: cases %d  differing %d  [seed %d, %.0f s]" % (ran, bad, a.seed, time.time() - t0))
+    return 1 if bad else 0
 
 
 if __name__ == "__main__":

@@ -158,6 +158,21 @@ def test_oracle_bloom_equals_reference_vectors(oracle):
     assert differs >= 2
 
 
+def test_oracle_equals_reference_objects_on_fuzz_cases():
+    """The oracle against the reference's own addMinHashes / MinHashHeap / bloom_filter (oracle/_ref,
+    built here from /root/reference) on the cases tests/fuzz_sketch.py generates: random k, sketch
+    sizes, seeds, alphabets, dirty and low-complexity records, multiplicities, -m, -c, -b.  Skipped
+    where the reference objects are not built (they are not on the GPU box's CPU-only path either)."""
+    from oracle import pyoracle
+    if not pyoracle.ref_available():
+        pytest.skip("oracle/_ref/libmash_ref.so not built here")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_sketch", os.path.join(os.path.dirname(__file__), "fuzz_sketch.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    assert fz.run(250, 11, 60, against="ref", quiet=True) == 0
+
+
 def test_oracle_bloom_hash_known_values(oracle):
     """hash_ap of bloom_filter.hpp (:526-568) with the filter's salt, restated independently here in
     Python integers: 64-bit hashes take the two-word round, 32-bit hashes the one-word branch."""
