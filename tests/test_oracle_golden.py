@@ -173,6 +173,56 @@ def test_oracle_equals_reference_objects_on_fuzz_cases():
     assert fz.run(250, 11, 60, against="ref", quiet=True) == 0
 
 
+def test_oracle_compare_equals_reference_objects_on_random_pairs():
+    """compareSketches: the restated merge + distance + filters against the reference's own function
+    (CommandDistance.cpp:336-425 compiled into oracle/_ref) on random pairs built for the corners: shared
+    pools (every Jaccard value), one side empty or shorter than s, sketch sizes 1..5000, 32-bit hashes,
+    identical lists, disjoint ranges, both filters on and off.  (The p-value goes through the same
+    restated binomial tail on both sides -- GSL is absent -- so it is not an independent check here.)"""
+    from oracle import pyoracle
+    if not pyoracle.ref_available():
+        pytest.skip("oracle/_ref/libmash_ref.so not built here")
+    orc, ref = pyoracle.Oracle(), pyoracle.Oracle(ref=True)
+    rng = np.random.default_rng(2026)
+    checked = passed = 0
+    for case in range(3000):
+        s = int(rng.choice([1, 2, 5, 50, 400, 1000, 5000]))
+        use64 = bool(rng.random() < 0.7)
+        k = int(rng.choice([21, 31, 32])) if use64 else int(rng.choice([5, 11, 16]))
+        top = 2 ** 64 - 2 if use64 else 2 ** 32 - 2
+        style = rng.choice(["pool", "disjoint", "identical", "ragged", "empty"])
+        pool = np.unique(rng.integers(0, top, int(s * rng.uniform(1.0, 3.0)) + 2, dtype=np.uint64))
+        def draw(frac):
+            v = pool[rng.random(len(pool)) < frac]
+            return np.sort(v)[:s]
+        if style == "pool":
+            a, b = draw(rng.uniform(0.3, 1.0)), draw(rng.uniform(0.3, 1.0))
+        elif style == "disjoint":
+            a, b = pool[: len(pool) // 2][:s], pool[len(pool) // 2:][:s]
+        elif style == "identical":
+            a = draw(0.9)
+            b = a.copy()
+        elif style == "ragged":
+            a, b = draw(0.8)[: int(rng.integers(0, s + 1))], draw(0.8)
+        else:
+            a, b = np.zeros(0, dtype=np.uint64), draw(0.7)
+        if rng.random() < 0.5:
+            a, b = b, a
+        la, lb = int(rng.integers(1, 10 ** 7)), int(rng.integers(1, 10 ** 7))
+        kspace = float(4 ** k)
+        max_d = float(rng.choice([-1.0, 0.02, 0.2, 1.0]))
+        max_p = float(rng.choice([-1.0, 1e-30, 1e-3, 1.0]))
+        x = orc.compare(a, b, la, lb, s, k, kspace, max_d, max_p, use64)
+        y = ref.compare(a, b, la, lb, s, k, kspace, max_d, max_p, use64)
+        assert x.pass_ == y.pass_, (case, style, s, k, max_d, max_p)
+        if x.pass_:                                              # a rejected pair carries no more than `pass` (CommandDistance.cpp:409-422)
+            assert (x.numer, x.denom) == (y.numer, y.denom), (case, style, s, k)
+            assert x.distance == y.distance and x.p_value == y.p_value, (case, style, s, k, x.distance, y.distance)
+            passed += 1
+        checked += 1
+    assert checked == 3000 and passed > 1000
+
+
 def test_oracle_bloom_hash_known_values(oracle):
     """hash_ap of bloom_filter.hpp (:526-568) with the filter's salt, restated independently here in
     Python integers: 64-bit hashes take the two-word round, 32-bit hashes the one-word branch."""
