@@ -761,8 +761,9 @@ void init_from_files(Gpu &gpu, SketchSet &set, const vector<string> &files, cons
             load_msh_into(set, files[i], i == 0 && !enforce_parameters);
         } else {
             if (verbosity > 0) {
+                // (one string, one write(2): stderr is unbuffered, no need for four system calls per file)
                 if (files[i] == "-") cerr << "Sketching from stdin..." << endl;
-                else cerr << "Sketching " << files[i] << "..." << endl;
+                else cerr << ("Sketching " + files[i] + "...\n") << std::flush;
             }
             if (files[i] != "-") {
                 FILE *t = fopen(files[i].c_str(), "r");
