@@ -97,6 +97,45 @@ hipError_t launch_compare_pairs(const CompareArgs &a, hipStream_t stream);
 // Generic kernel (any s): one wave per pair, binary search in global memory.
 hipError_t launch_compare_generic(const CompareArgs &a, hipStream_t stream);
 
+// Inverted-index ("sparse") engine (compare_sparse.hip): fill + discover + merge over an index of
+// the column table built once per table (mashgpu.cpp::table_sparse_index).
+struct SparseArgs {
+    const uint32_t *sorted_rows;   // column table: row of the entry at every sorted position (value major, rows ascending)
+    const uint2 *lohi;             // per entry of the ROW side: [lo, hi) = run of partner rows in sorted_rows
+    const uint32_t *off;           // row side: compact entry offsets (triangle: the table's; rect: the queries' from q_begin)
+    const uint32_t *row_img;       // row side code image (triangle: rank image; rect: query codes)
+    const uint32_t *col_img;       // column side rank image (codes 2 * rank)
+    const uint32_t *col_cnt_off;   // column side compact offsets (hash counts = differences)
+    uint32_t rs_row, rs_col;       // row strides of the two images (multiples of 4, padded)
+    uint32_t row_begin, row_end;   // rows handled (rect: 0 .. number of queries, relative to q_begin)
+    uint32_t ncols;                // rect: rows of the reference table
+    uint32_t triangle;
+    uint32_t s;
+    uint64_t out_base;             // triangle: row_begin (row_begin - 1) / 2
+    uint2 *cand;                   // candidate pairs {row, col}
+    uint64_t cand_cap;
+    unsigned long long *counters;  // [0] candidates, [1] shared hashes of the rows handled, [2] candidate list overflowed
+    uint2 *out;
+};
+size_t sparse_sort_temp_bytes(uint32_t E, uint32_t end_bit);
+uint32_t sparse_img_stride(uint32_t s);          // row stride of a code image
+hipError_t sparse_build_index(const uint64_t *hashes, uint64_t stride, const uint32_t *off, uint32_t n, uint32_t E,
+                              uint32_t rs, uint32_t end_bit, void *temp, size_t temp_bytes, uint64_t *keys_a,
+                              uint32_t *eid_a, uint64_t *keys_sorted, uint32_t *eid_sorted, uint32_t *head, uint32_t *grp,
+                              uint32_t *gstart, uint32_t *sorted_rows, uint2 *lohi, uint32_t *rank_img,
+                              unsigned long long *incidences, uint32_t *max_group, uint32_t *bad, hipStream_t stream);
+hipError_t launch_sparse_locate(const uint64_t *qhashes, uint64_t qstride, const uint32_t *qoff, uint32_t q_begin, uint32_t nq,
+                                const uint64_t *keys_sorted, const uint32_t *grp, const uint32_t *gstart, uint32_t E, uint32_t G,
+                                uint32_t rs, uint2 *qlohi, uint32_t *qcode_img, hipStream_t stream);
+bool sparse_discover_supported(uint32_t ncols_max);
+hipError_t launch_sparse_discover(const SparseArgs &a, bool count_only, hipStream_t stream);
+hipError_t launch_sparse_merge(const SparseArgs &a, uint64_t expect, uint32_t cus, hipStream_t stream);
+hipError_t launch_sparse_fill(uint2 *out, uint64_t pairs, uint32_t denom, uint32_t cus, hipStream_t stream);
+hipError_t launch_sparse_fill_short(uint2 *out, const uint32_t *short_rows, const uint32_t *short_rcnt, uint32_t nshort_rows,
+                                    const uint32_t *short_cols, const uint32_t *short_ccnt, uint32_t nshort_cols,
+                                    uint32_t row_begin, uint32_t ncols, uint32_t triangle, uint64_t out_base, uint32_t s,
+                                    hipStream_t stream);
+
 // Distance filter + ordered compaction (see filter_pass_kernel).  `counts` holds
 // `pairs` entries in the layout the compare kernels write, starting at row
 // `first_row` (triangle row / query index).  Survivors with rank in

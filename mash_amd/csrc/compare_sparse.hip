@@ -1,0 +1,487 @@
+// compare_sparse.hip — gfx950 pairwise comparison through an INVERTED INDEX of the sketch table.
+//
+// Same contract as the tile kernels (the merge loop of compareSketches, CommandDistance.cpp:347-385:
+// {common, denom} per pair, reference output order), different cost: the tile engine
+// (compare_merged.hip) pays for every pair, although two sketches that share no hash always give
+// {0, min(s, |A| + |B|)} -- and in a collection of n sketches almost every pair is such a pair.
+// Here the work is
+//
+//   fill      every output slot gets {0, min(s, |A| + |B|)}: one streaming write of 8 B per pair,
+//             the compulsory HBM traffic of the whole job;
+//   discover  the pairs that share at least one hash, from an index built once per table: all
+//             (value, row) entries sorted by value (rows ascending inside a value), so the rows
+//             sharing a value are one contiguous run; a workgroup per row ORs the runs of the
+//             row's values into a bitmap of columns in LDS and appends the set bits to a
+//             candidate list;
+//   merge     one lane per candidate pair walks the reference's merge loop literally -- on
+//             32-bit RANKS instead of 64-bit values: every entry of the table is replaced by
+//             the dense rank of its value among the table's distinct values (a by-product of the
+//             sort), which preserves order and equality inside the table, so the loop takes the
+//             same branches and the counts are the reference's.
+//
+// Cost: 8 B written per pair + O(shared hashes) instead of O(n^2 * s / rows per tile).
+// Rect (mash dist): the queries are located in the reference table's index by binary search; a
+// query value between two table values gets the odd code between their even codes (2 * rank),
+// which again preserves every comparison the merge makes.
+//
+// The sort of the index is rocPRIM's stable radix sort (value keys, entry ids as payload); every
+// other step is a kernel below.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "compare_internal.h"
+
+namespace mg {
+
+// ------------------------------------------------------------------------------------------------
+// index build
+
+// compact entry ids: row r owns [off[r], off[r + 1]) -- its first min(nhash, s) hashes
+__global__ __launch_bounds__(256) void sp_fill_entries_kernel(const uint64_t *hashes, uint64_t stride, const uint32_t *off,
+                                                              uint64_t *keys, uint32_t *eid)
+{
+    const uint32_t row = blockIdx.x;
+    const uint32_t b = off[row], cnt = off[row + 1] - b;
+    const uint64_t *src = hashes + (uint64_t)row * stride;
+    for (uint32_t p = threadIdx.x; p < cnt; p += 256) {
+        keys[b + p] = src[p];
+        eid[b + p] = b + p;
+    }
+}
+
+// head[pos] = 1 where a new value starts; inside a value the entry ids must ascend (the sort is
+// stable and ids ascend with the row), else *bad is set and the index is not used
+__global__ __launch_bounds__(256) void sp_heads_kernel(const uint64_t *keys, const uint32_t *eid, uint32_t E, uint32_t *head,
+                                                       uint32_t *bad)
+{
+    const uint32_t pos = blockIdx.x * 256u + threadIdx.x;
+    if (pos >= E) return;
+    uint32_t h = 1;
+    if (pos > 0 && keys[pos] == keys[pos - 1]) {
+        h = 0;
+        if (eid[pos] <= eid[pos - 1]) *bad = 1;
+    }
+    head[pos] = h;
+}
+
+// grp[pos] = inclusive scan of head = (group id + 1); gstart[g] = first sorted position of group g
+__global__ __launch_bounds__(256) void sp_gstart_kernel(const uint32_t *grp, uint32_t E, uint32_t *gstart)
+{
+    const uint32_t pos = blockIdx.x * 256u + threadIdx.x;
+    if (pos >= E) return;
+    const uint32_t g = grp[pos];
+    if (pos == 0 || grp[pos - 1] != g) gstart[g - 1] = pos;
+    if (pos == E - 1) gstart[g] = E;                      // end marker
+}
+
+// per sorted position: scatter {group start, own position} and the rank back to the entry, resolve the row
+__global__ __launch_bounds__(256) void sp_scatter_kernel(const uint32_t *eid, const uint32_t *grp, const uint32_t *gstart,
+                                                         const uint32_t *off, uint32_t n, uint32_t E, uint32_t rs,
+                                                         uint32_t *sorted_rows, uint2 *lohi, uint32_t *rank_img,
+                                                         unsigned long long *incidences, uint32_t *max_group)
+{
+    const uint32_t pos = blockIdx.x * 256u + threadIdx.x;
+    unsigned long long inc = 0;
+    uint32_t glen = 0;
+    if (pos < E) {
+        const uint32_t e = eid[pos];
+        const uint32_t g = grp[pos] - 1;
+        const uint32_t gs = gstart[g];
+        // row of entry e: last r with off[r] <= e
+        uint32_t lo = 0, hi = n;                          // invariant: off[lo] <= e < off[hi]
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (off[mid] <= e) lo = mid; else hi = mid;
+        }
+        sorted_rows[pos] = lo;
+        lohi[e] = make_uint2(gs, pos);
+        rank_img[(uint64_t)lo * rs + (e - off[lo])] = g << 1;
+        inc = pos - gs;
+        glen = gstart[g + 1] - gs;
+    }
+    // block sums (one atomic per workgroup)
+    for (int d = 32; d > 0; d >>= 1) {
+        inc += __shfl_xor(inc, d);
+        const uint32_t o = __shfl_xor(glen, d);
+        glen = o > glen ? o : glen;
+    }
+    __shared__ unsigned long long s_inc[4];
+    __shared__ uint32_t s_len[4];
+    if ((threadIdx.x & 63) == 0) { s_inc[threadIdx.x >> 6] = inc; s_len[threadIdx.x >> 6] = glen; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long t = s_inc[0] + s_inc[1] + s_inc[2] + s_inc[3];
+        uint32_t m = s_len[0];
+        for (int w = 1; w < 4; w++) m = s_len[w] > m ? s_len[w] : m;
+        if (t) atomicAdd(incidences, t);
+        if (m > 1) atomicMax(max_group, m);
+    }
+}
+
+__global__ __launch_bounds__(256) void sp_fill_u32_kernel(uint32_t *p, uint64_t count, uint32_t v)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < count; i += stride) p[i] = v;
+}
+
+// row stride of a code image: s rounded up to a chunk of four, plus one chunk the loop may load behind the row
+uint32_t sparse_img_stride(uint32_t s) { return ((s + 3u) & ~3u) + 4u; }
+
+size_t sparse_sort_temp_bytes(uint32_t E, uint32_t end_bit)
+{
+    size_t bytes = 0;
+    rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr, (const uint32_t *)nullptr,
+                              (uint32_t *)nullptr, (size_t)E, 0u, end_bit, (hipStream_t) nullptr);
+    size_t b2 = 0;
+    rocprim::inclusive_scan(nullptr, b2, (const uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)E, rocprim::plus<uint32_t>(),
+                            (hipStream_t) nullptr);
+    return bytes > b2 ? bytes : b2;
+}
+
+// All device buffers are the caller's.  keys_a / eid_a: scratch of E entries each (input of the sort),
+// keys_sorted / eid_sorted: its output; head: scratch of E u32.  On return (stream order) the index
+// arrays are complete; *bad != 0 means the order inside a value was not by row (never seen: the sort
+// is stable) and the index must not be used.
+hipError_t sparse_build_index(const uint64_t *hashes, uint64_t stride, const uint32_t *off, uint32_t n, uint32_t E,
+                              uint32_t rs, uint32_t end_bit, void *temp, size_t temp_bytes, uint64_t *keys_a,
+                              uint32_t *eid_a, uint64_t *keys_sorted, uint32_t *eid_sorted, uint32_t *head, uint32_t *grp,
+                              uint32_t *gstart, uint32_t *sorted_rows, uint2 *lohi, uint32_t *rank_img,
+                              unsigned long long *incidences, uint32_t *max_group, uint32_t *bad, hipStream_t stream)
+{
+    if (n == 0 || E == 0) return hipSuccess;
+    hipLaunchKernelGGL(sp_fill_entries_kernel, dim3(n), dim3(256), 0, stream, hashes, stride, off, keys_a, eid_a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    e = rocprim::radix_sort_pairs(temp, temp_bytes, (const uint64_t *)keys_a, keys_sorted, (const uint32_t *)eid_a, eid_sorted,
+                                  (size_t)E, 0u, end_bit, stream);
+    if (e != hipSuccess) return e;
+    const uint32_t blocks = (E + 255u) / 256u;
+    hipLaunchKernelGGL(sp_heads_kernel, dim3(blocks), dim3(256), 0, stream, keys_sorted, eid_sorted, E, head, bad);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    e = rocprim::inclusive_scan(temp, temp_bytes, (const uint32_t *)head, grp, (size_t)E, rocprim::plus<uint32_t>(), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sp_gstart_kernel, dim3(blocks), dim3(256), 0, stream, grp, E, gstart);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    // padding of the rank image: larger than every code, so chunked loads past a row's end are harmless
+    {
+        const uint64_t total = (uint64_t)n * rs;
+        uint64_t fb = (total + 1023) / 1024;
+        if (fb > 8192) fb = 8192;
+        hipLaunchKernelGGL(sp_fill_u32_kernel, dim3((uint32_t)fb), dim3(256), 0, stream, rank_img, total, 0xFFFFFFFFu);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(sp_scatter_kernel, dim3(blocks), dim3(256), 0, stream, eid_sorted, grp, gstart, off, n, E, rs, sorted_rows,
+                       lohi, rank_img, incidences, max_group);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// rect: locate the queries' values in the reference table's index
+
+// One thread per query entry (compact id over the query rows [q_begin, q_end)): code in the
+// reference table's rank space (2 * rank if the value occurs there, else the odd code between its
+// neighbours) and the run of rows holding the value.
+__global__ __launch_bounds__(256) void sp_locate_kernel(const uint64_t *qhashes, uint64_t qstride, const uint32_t *qoff,
+                                                        uint32_t q_begin, uint32_t nq, const uint64_t *keys_sorted,
+                                                        const uint32_t *grp, const uint32_t *gstart, uint32_t E, uint32_t G,
+                                                        uint32_t rs, uint2 *qlohi, uint32_t *qcode_img)
+{
+    const uint32_t q = blockIdx.x;                       // query index relative to q_begin
+    if (q >= nq) return;
+    const uint32_t b = qoff[q], cnt = qoff[q + 1] - b;
+    const uint64_t *src = qhashes + (uint64_t)(q_begin + q) * qstride;
+    for (uint32_t p = threadIdx.x; p < cnt; p += 256) {
+        const uint64_t v = src[p];
+        uint32_t lo = 0, hi = E;                          // lower bound: first position with key >= v
+        while (lo < hi) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if (keys_sorted[mid] < v) lo = mid + 1; else hi = mid;
+        }
+        // Codes of the query image: table codes are 2 * rank, and the merge adds one to every table
+        // code it loads in rect mode (an unsigned code cannot sit below rank 0 otherwise): a value
+        // found in group g gets 2g + 1 -- equal to the table's -- and a value between groups g - 1
+        // and g gets 2g (g = G: above every key), which is above 2(g - 1) + 1 and below 2g + 1.
+        const uint32_t g = lo < E ? grp[lo] - 1u : G;     // group of the first key >= v
+        const bool found = lo < E && keys_sorted[lo] == v;
+        const uint32_t code = found ? (g << 1) + 1u : (g << 1);
+        uint2 lh = make_uint2(0u, 0u);
+        if (found) lh = make_uint2(gstart[g], gstart[g + 1]);
+        qlohi[b + p] = lh;
+        qcode_img[(uint64_t)q * rs + p] = code;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// discovery
+
+template <bool COUNT_ONLY>
+__global__ __launch_bounds__(256) void sp_discover_kernel(SparseArgs a)
+{
+    extern __shared__ uint32_t bm[];
+    __shared__ uint32_t s_w[4];
+    __shared__ unsigned long long s_base;
+    __shared__ unsigned long long s_inc[4];
+    // largest rows first (triangle: they have the most columns)
+    const uint32_t row = a.row_end - 1u - blockIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+    const uint32_t ncols = a.triangle ? row : a.ncols;
+    const uint32_t W = (ncols + 31u) >> 5;
+    const uint32_t b = a.off[row], cnt = a.off[row + 1] - b;
+    if (cnt == 0 || ncols == 0) return;                  // uniform
+    for (uint32_t w = tid; w < W; w += 256) bm[w] = 0;
+    __syncthreads();
+    unsigned long long inc = 0;
+    constexpr uint32_t SHORT = 6;
+    for (uint32_t base = wid * 64u; base < cnt; base += 256u) {
+        const uint32_t p = base + lane;
+        uint2 lh = make_uint2(0u, 0u);
+        if (p < cnt) lh = a.lohi[b + p];
+        const uint32_t len = lh.y - lh.x;
+        inc += len;
+        if (len != 0 && len <= SHORT) {
+            for (uint32_t t = 0; t < len; t++) {
+                const uint32_t r = a.sorted_rows[lh.x + t];
+                atomicOr(&bm[r >> 5], 1u << (r & 31u));
+            }
+        }
+        uint64_t longm = __ballot(len > SHORT);
+        while (longm != 0) {
+            const int l = __builtin_ctzll(longm);
+            longm &= longm - 1;
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)lh.x, l);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)lh.y, l);
+            for (uint32_t q = lo + lane; q < hi; q += 64u) {
+                const uint32_t r = a.sorted_rows[q];
+                atomicOr(&bm[r >> 5], 1u << (r & 31u));
+            }
+        }
+    }
+    __syncthreads();
+    // set bits of the bitmap -> candidates, in column order; thread t owns a contiguous run of words
+    const uint32_t per = (W + 255u) / 256u;
+    const uint32_t w0 = tid * per, w1 = w0 + per < W ? w0 + per : W;
+    uint32_t mine = 0;
+    for (uint32_t w = w0; w < w1; w++) mine += (uint32_t)__popc(bm[w]);
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(incl, d);
+        if (lane >= (uint32_t)d) incl += t;
+    }
+    for (int d = 32; d > 0; d >>= 1) inc += __shfl_xor(inc, d);
+    if (lane == 63) s_w[wid] = incl;
+    if (lane == 0) s_inc[wid] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (uint32_t w = 0; w < wid; w++) woff += s_w[w];
+    const uint32_t total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    if (tid == 0) {
+        s_base = atomicAdd(&a.counters[0], (unsigned long long)total);
+        atomicAdd(&a.counters[1], s_inc[0] + s_inc[1] + s_inc[2] + s_inc[3]);
+    }
+    if (COUNT_ONLY) return;
+    __syncthreads();
+    const unsigned long long gbase = s_base;
+    if (gbase + total > a.cand_cap) {                    // uniform; the host grows the list and repeats
+        if (tid == 0) a.counters[2] = 1;
+        return;
+    }
+    unsigned long long o = gbase + woff + incl - mine;
+    for (uint32_t w = w0; w < w1; w++) {
+        uint32_t bits = bm[w];
+        while (bits != 0) {
+            const uint32_t c = (w << 5) + (uint32_t)__builtin_ctz(bits);
+            bits &= bits - 1;
+            a.cand[o++] = make_uint2(row, c);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// merge: one lane per candidate pair, the reference's loop on 32-bit codes
+
+__device__ __forceinline__ uint32_t sp_pick(const uint4 &c, uint32_t k)
+{
+    const uint32_t lo = (k & 1u) ? c.y : c.x;
+    const uint32_t hi = (k & 1u) ? c.w : c.z;
+    return (k & 2u) ? hi : lo;
+}
+
+// RECT: column codes are the table's 2 * rank, the query image is in the shifted space (see
+// sp_locate_kernel), so the column side adds one to whatever it loads (the padding 0xFFFFFFFF is
+// never compared: the loop ends at the row's length).
+template <bool RECT>
+__global__ __launch_bounds__(256) void sp_merge_kernel(SparseArgs a)
+{
+    unsigned long long K = a.counters[0];
+    if (K > a.cand_cap) K = a.cand_cap;
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    const uint32_t s = a.s;
+    for (uint64_t c = (uint64_t)blockIdx.x * 256u + threadIdx.x; c < K; c += stride) {
+        const uint2 pr = a.cand[c];
+        const uint32_t i = pr.x, j = pr.y;
+        const uint32_t nA = a.off[i + 1] - a.off[i];
+        const uint32_t nB = a.col_cnt_off[j + 1] - a.col_cnt_off[j];
+        const uint4 *A4 = reinterpret_cast<const uint4 *>(a.row_img + (uint64_t)i * a.rs_row);
+        const uint4 *B4 = reinterpret_cast<const uint4 *>(a.col_img + (uint64_t)j * a.rs_col);
+        uint4 ca = A4[0], cb = B4[0];
+        uint32_t av = ca.x, bv = RECT ? cb.x + 1u : cb.x;
+        uint32_t ia = 0, ib = 0, common = 0, denom = 0;
+        while (denom < s && ia < nA && ib < nB) {          // CommandDistance.cpp:347-365
+            const bool adva = av <= bv, advb = bv <= av;
+            common += (adva && advb) ? 1u : 0u;
+            denom++;
+            if (adva) {
+                ia++;
+                if ((ia & 3u) == 0) ca = A4[ia >> 2];
+                av = sp_pick(ca, ia & 3u);
+            }
+            if (advb) {
+                ib++;
+                if ((ib & 3u) == 0) cb = B4[ib >> 2];
+                bv = sp_pick(cb, ib & 3u);
+                if (RECT) bv += 1u;
+            }
+        }
+        if (denom < s) {                                   // :367-385
+            denom += (nA - ia) + (nB - ib);
+            if (denom > s) denom = s;
+        }
+        uint64_t oidx;
+        if (RECT) oidx = (uint64_t)(i - a.row_begin) * a.ncols + j;
+        else oidx = (uint64_t)i * (i - 1u) / 2u + j - a.out_base;
+        a.out[oidx] = make_uint2(common, denom);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fill: {0, denom} for every pair
+
+typedef uint32_t sp_u32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void sp_fill_const_kernel(uint2 *out, uint64_t pairs, uint32_t denom)
+{
+    // 16-byte stores over the aligned body, 8-byte stores for an unaligned first / odd last pair
+    const uint64_t head = ((reinterpret_cast<uintptr_t>(out) & 8u) != 0 && pairs > 0) ? 1u : 0u;
+    const uint64_t nvec = (pairs - head) >> 1;
+    sp_u32x4 *body = reinterpret_cast<sp_u32x4 *>(out + head);
+    const sp_u32x4 v = {0u, denom, 0u, denom};
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    for (; i + 3 * stride < nvec; i += 4 * stride) {
+        __builtin_nontemporal_store(v, body + i);
+        __builtin_nontemporal_store(v, body + i + stride);
+        __builtin_nontemporal_store(v, body + i + 2 * stride);
+        __builtin_nontemporal_store(v, body + i + 3 * stride);
+    }
+    for (; i < nvec; i += stride) __builtin_nontemporal_store(v, body + i);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (head) out[0] = make_uint2(0u, denom);
+        if (((pairs - head) & 1u) != 0) out[pairs - 1] = make_uint2(0u, denom);
+    }
+}
+
+// pairs of two SHORT sketches (|A| + |B| < s): denom = |A| + |B|.  One workgroup per short row of
+// the row side, threads over the short rows of the column side (both lists ascending).
+__global__ __launch_bounds__(256) void sp_fill_short_kernel(uint2 *out, const uint32_t *short_rows, const uint32_t *short_rcnt,
+                                                            uint32_t nshort_rows, const uint32_t *short_cols,
+                                                            const uint32_t *short_ccnt, uint32_t nshort_cols, uint32_t row_begin,
+                                                            uint32_t ncols, uint32_t triangle, uint64_t out_base, uint32_t s)
+{
+    const uint32_t k = blockIdx.x;
+    if (k >= nshort_rows) return;
+    const uint32_t i = short_rows[k], ni = short_rcnt[k];
+    for (uint32_t t = threadIdx.x; t < nshort_cols; t += 256) {
+        const uint32_t j = short_cols[t];
+        if (triangle && j >= i) break;                      // ascending
+        const uint32_t d = ni + short_ccnt[t];
+        if (d < s) {
+            const uint64_t oidx = triangle ? (uint64_t)i * (i - 1u) / 2u + j - out_base : (uint64_t)(i - row_begin) * ncols + j;
+            out[oidx] = make_uint2(0u, d);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+
+hipError_t launch_sparse_locate(const uint64_t *qhashes, uint64_t qstride, const uint32_t *qoff, uint32_t q_begin, uint32_t nq,
+                                const uint64_t *keys_sorted, const uint32_t *grp, const uint32_t *gstart, uint32_t E, uint32_t G,
+                                uint32_t rs, uint2 *qlohi, uint32_t *qcode_img, hipStream_t stream)
+{
+    if (nq == 0) return hipSuccess;
+    {
+        const uint64_t total = (uint64_t)nq * rs;
+        uint64_t fb = (total + 1023) / 1024;
+        if (fb > 8192) fb = 8192;
+        hipLaunchKernelGGL(sp_fill_u32_kernel, dim3((uint32_t)fb), dim3(256), 0, stream, qcode_img, total, 0xFFFFFFFFu);
+    }
+    hipLaunchKernelGGL(sp_locate_kernel, dim3(nq), dim3(256), 0, stream, qhashes, qstride, qoff, q_begin, nq, keys_sorted, grp,
+                       gstart, E, G, rs, qlohi, qcode_img);
+    return hipGetLastError();
+}
+
+size_t sparse_discover_lds(uint32_t ncols_max) { return (((size_t)ncols_max + 31) / 32) * 4 + 16; }
+bool sparse_discover_supported(uint32_t ncols_max) { return sparse_discover_lds(ncols_max) <= 160 * 1024 - 256; }
+
+hipError_t launch_sparse_discover(const SparseArgs &a, bool count_only, hipStream_t stream)
+{
+    const uint32_t nrows = a.row_end - a.row_begin;
+    if (nrows == 0) return hipSuccess;
+    const size_t smem = sparse_discover_lds(a.triangle ? a.row_end : a.ncols);
+    hipError_t e;
+    if (count_only) {
+        auto kern = sp_discover_kernel<true>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(nrows), dim3(256), smem, stream, a);
+    } else {
+        auto kern = sp_discover_kernel<false>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(nrows), dim3(256), smem, stream, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_sparse_merge(const SparseArgs &a, uint64_t expect, uint32_t cus, hipStream_t stream)
+{
+    if (expect == 0) return hipSuccess;
+    uint64_t blocks = (expect + 255) / 256;
+    const uint64_t most = (uint64_t)(cus ? cus : 256) * 32;      // grid-stride beyond ~8 workgroups per CU x 4 rounds
+    if (blocks > most) blocks = most;
+    if (a.triangle) hipLaunchKernelGGL(sp_merge_kernel<false>, dim3((uint32_t)blocks), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(sp_merge_kernel<true>, dim3((uint32_t)blocks), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_sparse_fill(uint2 *out, uint64_t pairs, uint32_t denom, uint32_t cus, hipStream_t stream)
+{
+    if (pairs == 0) return hipSuccess;
+    uint64_t blocks = (pairs / 2 + 1023) / 1024;                 // >= 4 stores per thread
+    const uint64_t most = (uint64_t)(cus ? cus : 256) * 16;
+    if (blocks > most) blocks = most;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(sp_fill_const_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, out, pairs, denom);
+    return hipGetLastError();
+}
+
+hipError_t launch_sparse_fill_short(uint2 *out, const uint32_t *short_rows, const uint32_t *short_rcnt, uint32_t nshort_rows,
+                                    const uint32_t *short_cols, const uint32_t *short_ccnt, uint32_t nshort_cols,
+                                    uint32_t row_begin, uint32_t ncols, uint32_t triangle, uint64_t out_base, uint32_t s,
+                                    hipStream_t stream)
+{
+    if (nshort_rows == 0 || nshort_cols == 0) return hipSuccess;
+    hipLaunchKernelGGL(sp_fill_short_kernel, dim3(nshort_rows), dim3(256), 0, stream, out, short_rows, short_rcnt, nshort_rows,
+                       short_cols, short_ccnt, nshort_cols, row_begin, ncols, triangle, out_base, s);
+    return hipGetLastError();
+}
+
+}  // namespace mg

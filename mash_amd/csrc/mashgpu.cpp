@@ -41,6 +41,8 @@ struct mg_ctx {
     std::string err;
     bool prof = false;
     std::vector<ProfRec> prof_compare, prof_sketch;
+    // phases of the inverted-index compare engine (compare_sparse.hip), each its own kernel
+    std::vector<ProfRec> prof_fill, prof_discover, prof_merge, prof_index;
     // Entry points lock the context: any number of host threads may drive one context, one call at
     // a time (SURVEY 8b "thread-safe per ctx"); recursive because entry points call each other.
     std::recursive_mutex mu;
@@ -78,6 +80,33 @@ struct mg_table {
     // window offsets of the large-sketch compare path (see table_windows), cached per geometry
     struct Windows { int shr; uint32_t delta, nwin, s; uint32_t *dev; std::vector<uint32_t> host; };
     mutable std::vector<Windows> win;
+    // inverted index of the compare path's sparse engine (see table_sparse_index), one per sketch size in use
+    struct Sparse {
+        uint32_t s = 0;                    // sketch size the index covers (the first min(nhash, s) hashes of a row)
+        bool usable = false;               // false: outside the engine's reach (reason in `why`), the tile engine is used
+        std::string why;
+        uint32_t E = 0, G = 0, rs = 0;     // entries, distinct values, row stride of the rank image
+        uint64_t shared = 0;               // sum over values of (copies choose 2): pairs x shared hashes
+        uint32_t max_group = 0;            // copies of the most frequent value
+        double build_ms = 0;
+        uint32_t *off = nullptr;           // [n + 1] compact entry offsets (device)
+        std::vector<uint32_t> off_host;
+        uint64_t *keys_sorted = nullptr;   // [E]
+        uint32_t *grp = nullptr;           // [E] group id + 1 per sorted position
+        uint32_t *gstart = nullptr;        // [G + 1]
+        uint32_t *sorted_rows = nullptr;   // [E]
+        uint2 *lohi = nullptr;             // [E]
+        uint32_t *rank_img = nullptr;      // [n * rs]
+        uint32_t *short_rows = nullptr, *short_cnt = nullptr;    // rows with fewer than s hashes (ascending) and their counts
+        std::vector<uint32_t> short_rows_host;
+        // what a (rows, range) job costs, learned by a counting pass the first time it is seen
+        struct Plan { const void *rows; uint64_t rb, re; bool triangle; uint64_t cand, shared; bool use; };
+        std::vector<Plan> plans;
+        uint2 *cand = nullptr;             // candidate list, grown on demand
+        uint64_t cand_cap = 0;
+        unsigned long long *counters = nullptr;   // [4] device
+    };
+    mutable std::vector<Sparse *> sparse;
 };
 
 #define HIP_TRY(ctx, call)                                                           \
@@ -1340,6 +1369,16 @@ void mg_table_free(mg_table *t)
     if (!t) return;
     if (!t->pfx.empty()) { hipSetDevice(t->ctx->device); for (auto &im : t->pfx) hipFree(im.second); }
     if (!t->win.empty()) { hipSetDevice(t->ctx->device); for (auto &w : t->win) hipFree(w.dev); }
+    if (!t->sparse.empty()) {
+        hipSetDevice(t->ctx->device);
+        for (mg_table::Sparse *sp : t->sparse) {
+            for (void *q : {(void *)sp->off, (void *)sp->keys_sorted, (void *)sp->grp, (void *)sp->gstart, (void *)sp->sorted_rows,
+                            (void *)sp->lohi, (void *)sp->rank_img, (void *)sp->short_rows, (void *)sp->short_cnt, (void *)sp->cand,
+                            (void *)sp->counters})
+                if (q) hipFree(q);
+            delete sp;
+        }
+    }
     if (t->owns) {
         hipSetDevice(t->ctx->device);
         hipFree((void *)t->hashes);
@@ -1836,6 +1875,298 @@ static int run_compare_merged(mg_ctx *ctx, const mg_table *rows, const mg_table 
     return MG_OK;
 }
 
+// ---- inverted-index engine (compare_sparse.hip) ----------------------------------------------
+//
+// Index of a table for sketch size s: every (value, row) entry of the rows' first min(nhash, s)
+// hashes sorted by value, rows ascending inside a value (stable sort over row-major entry ids).
+// Built once per table and sketch size, cached in the mg_table like the prefix images.  Retained:
+// the sorted values (rect queries are located in them), the group id per sorted position and the
+// group starts, the row per sorted position, per entry the run [group start, own position) of
+// rows BELOW its row holding the same value, and the rank image (2 * dense rank of every entry's
+// value, padded row stride).  A table the engine cannot take (2^31 entries and more, a real hash
+// equal to the padding value, no memory) is marked unusable and keeps the tile engine.
+static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, mg_table::Sparse **out)
+{
+    for (mg_table::Sparse *sp : t->sparse)
+        if (sp->s == s) { *out = sp; return MG_OK; }
+    int rc = table_classes(ctx, t);                        // host copies of nhash and the rows' largest hashes
+    if (rc != MG_OK) return rc;
+    mg_table::Sparse *sp = new mg_table::Sparse;
+    sp->s = s;
+    t->sparse.push_back(sp);
+    *out = sp;
+    auto unusable = [&](const char *why) { sp->usable = false; sp->why = why; return MG_OK; };
+    const uint64_t n = t->n;
+    if (n == 0) return unusable("empty table");
+    if (n >= (1ull << 31)) return unusable("too many rows");
+    uint64_t E64 = 0, maxv = 0;
+    sp->off_host.resize(n + 1);
+    for (uint64_t i = 0; i < n; i++) {
+        sp->off_host[i] = (uint32_t)E64;
+        const uint64_t c = std::min<uint64_t>(std::min<uint64_t>(t->nh[i], t->s), s);
+        E64 += c;
+        if (E64 >= (1ull << 31)) return unusable("2^31 entries or more");
+        if (c) {
+            // a real hash equal to the padding value would sort among the padding: keep the tile engine
+            if (t->last[i] == MG_HASH_PAD) return unusable("a hash equals the padding value");
+            maxv = std::max(maxv, t->last[i]);
+            if (c < s) sp->short_rows_host.push_back((uint32_t)i);
+        } else {
+            sp->short_rows_host.push_back((uint32_t)i);
+        }
+    }
+    sp->off_host[n] = (uint32_t)E64;
+    if (E64 == 0) return unusable("no hashes");
+    const uint32_t E = (uint32_t)E64;
+    sp->E = E;
+    sp->rs = mg::sparse_img_stride(s);
+    const uint32_t end_bit = (uint32_t)(64 - __builtin_clzll(maxv | 1ull));
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEventCreate(&ev0);
+    hipEventCreate(&ev1);
+    hipEventRecord(ev0, ctx->stream);
+    // transient buffers
+    const size_t temp_bytes = mg::sparse_sort_temp_bytes(E, end_bit);
+    void *temp = nullptr;
+    uint64_t *keys_a = nullptr;
+    uint32_t *eid_a = nullptr, *eid_sorted = nullptr;
+    struct Stat { unsigned long long shared; uint32_t max_group, bad, last_grp, pad; } *d_stat = nullptr, h_stat = {0, 0, 0, 0, 0};
+    bool ok = hipMalloc(&temp, std::max<size_t>(temp_bytes, 16)) == hipSuccess &&
+              hipMalloc(&keys_a, (size_t)E * 8) == hipSuccess && hipMalloc(&eid_a, (size_t)E * 4) == hipSuccess &&
+              hipMalloc(&eid_sorted, (size_t)E * 4) == hipSuccess && hipMalloc(&d_stat, sizeof(Stat)) == hipSuccess;
+    // retained buffers
+    ok = ok && hipMalloc(&sp->off, (n + 1) * 4) == hipSuccess && hipMalloc(&sp->keys_sorted, (size_t)E * 8) == hipSuccess &&
+         hipMalloc(&sp->grp, (size_t)E * 4) == hipSuccess && hipMalloc(&sp->gstart, ((size_t)E + 1) * 4) == hipSuccess &&
+         hipMalloc(&sp->sorted_rows, (size_t)E * 4) == hipSuccess && hipMalloc(&sp->lohi, (size_t)E * 8) == hipSuccess &&
+         hipMalloc(&sp->rank_img, (size_t)n * sp->rs * 4) == hipSuccess && hipMalloc(&sp->counters, 4 * 8) == hipSuccess;
+    const size_t nshort = sp->short_rows_host.size();
+    std::vector<uint32_t> short_cnt(nshort);
+    for (size_t k = 0; k < nshort; k++) {
+        const uint32_t i = sp->short_rows_host[k];
+        short_cnt[k] = sp->off_host[i + 1] - sp->off_host[i];
+    }
+    if (ok && nshort)
+        ok = hipMalloc(&sp->short_rows, nshort * 4) == hipSuccess && hipMalloc(&sp->short_cnt, nshort * 4) == hipSuccess;
+    hipError_t e = hipSuccess;
+    if (ok) {
+        e = hipMemcpyAsync(sp->off, sp->off_host.data(), (n + 1) * 4, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess && nshort) e = hipMemcpyAsync(sp->short_rows, sp->short_rows_host.data(), nshort * 4, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess && nshort) e = hipMemcpyAsync(sp->short_cnt, short_cnt.data(), nshort * 4, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_stat, 0, sizeof(Stat), ctx->stream);
+        if (e == hipSuccess)
+            e = mg::sparse_build_index(t->hashes, t->s, sp->off, (uint32_t)n, E, sp->rs, end_bit, temp, temp_bytes, keys_a, eid_a,
+                                       sp->keys_sorted, eid_sorted, /*head=*/eid_a, sp->grp, sp->gstart, sp->sorted_rows, sp->lohi,
+                                       sp->rank_img, &d_stat->shared, &d_stat->max_group, &d_stat->bad, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&h_stat.last_grp, sp->grp + (E - 1), 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&h_stat, d_stat, offsetof(Stat, last_grp), hipMemcpyDeviceToHost, ctx->stream);
+        hipEventRecord(ev1, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    }
+    float ms = 0.f;
+    if (ok && e == hipSuccess) hipEventElapsedTime(&ms, ev0, ev1);
+    hipEventDestroy(ev0);
+    hipEventDestroy(ev1);
+    for (void *q : {(void *)temp, (void *)keys_a, (void *)eid_a, (void *)eid_sorted, (void *)d_stat})
+        if (q) hipFree(q);
+    auto drop = [&]() {
+        for (void **q : {(void **)&sp->off, (void **)&sp->keys_sorted, (void **)&sp->grp, (void **)&sp->gstart, (void **)&sp->sorted_rows,
+                         (void **)&sp->lohi, (void **)&sp->rank_img, (void **)&sp->short_rows, (void **)&sp->short_cnt, (void **)&sp->counters})
+            if (*q) { hipFree(*q); *q = nullptr; }
+    };
+    if (!ok) { (void)hipGetLastError(); drop(); return unusable("no device memory for the index"); }
+    if (e != hipSuccess) { drop(); return fail(ctx, MG_ERR_HIP, std::string("compare (index build): ") + hipGetErrorString(e)); }
+    if (h_stat.bad) { drop(); return unusable("sort order inside a value not by row"); }
+    sp->G = h_stat.last_grp;
+    sp->shared = h_stat.shared;
+    sp->max_group = h_stat.max_group;
+    sp->build_ms = ms;
+    sp->usable = true;
+    if (getenv("MASHGPU_COMPARE_DBG"))
+        fprintf(stderr, "compare sparse: index of %llu rows, s %u: %u entries, %u distinct, shared %llu, largest run %u, %.2f ms\n",
+                (unsigned long long)n, s, E, sp->G, (unsigned long long)sp->shared, sp->max_group, ms);
+    return MG_OK;
+}
+
+// Pairs of the job and the engine choice.  `force`: MASHGPU_COMPARE_KERNEL=sparse.  *handled = false:
+// the caller goes on to the tile engine (table outside the index's reach, or the job is one the
+// tile engine does faster: nearly every pair shares a few hashes -- a candidate costs a merge of
+// ~2 s steps here, an unrelated pair there costs 1/30 of that).
+static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, uint64_t row_begin, uint64_t row_end,
+                              bool triangle, uint32_t s, mg_counts *out_dev, bool force, bool *handled)
+{
+    *handled = false;
+    const uint64_t nrows = row_end - row_begin;
+    const uint64_t pairs = triangle ? (row_end * (row_end - 1) / 2 - (row_begin ? row_begin * (row_begin - 1) / 2 : 0)) : nrows * cols->n;
+    if (pairs == 0) return MG_OK;
+    if (!force && pairs < 4000000ull) return MG_OK;        // small jobs: one tile launch beats an index
+    if (nrows >= (1ull << 31) || cols->n >= (1ull << 31)) return MG_OK;
+    if (!mg::sparse_discover_supported((uint32_t)(triangle ? row_end : cols->n))) return MG_OK;
+    mg_table::Sparse *ix = nullptr;
+    int rc = table_sparse_index(ctx, cols, s, &ix);
+    if (rc != MG_OK) return rc;
+    if (!ix->usable) return MG_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+    // ---- row side ----
+    mg::SparseArgs a;
+    a.sorted_rows = ix->sorted_rows;
+    a.col_img = ix->rank_img;
+    a.col_cnt_off = ix->off;
+    a.rs_col = ix->rs;
+    a.ncols = (uint32_t)cols->n;
+    a.triangle = triangle ? 1u : 0u;
+    a.s = s;
+    a.out = reinterpret_cast<uint2 *>(out_dev);
+    a.counters = ix->counters;
+    DevBuf<uint32_t> q_off, q_img, q_short, q_short_cnt;
+    DevBuf<uint2> q_lohi;
+    std::vector<uint32_t> qshort_h, qshort_cnt_h;
+    const uint32_t *short_rows_dev = nullptr, *short_rcnt_dev = nullptr;
+    uint32_t nshort_rows = 0;
+    if (triangle) {
+        a.lohi = ix->lohi;
+        a.off = ix->off;
+        a.row_img = ix->rank_img;
+        a.rs_row = ix->rs;
+        a.row_begin = (uint32_t)row_begin;
+        a.row_end = (uint32_t)row_end;
+        a.out_base = row_begin ? row_begin * (row_begin - 1) / 2 : 0;
+        // short rows inside [row_begin, row_end): a slice of the table's ascending list
+        const auto &sr = ix->short_rows_host;
+        const size_t k0 = std::lower_bound(sr.begin(), sr.end(), (uint32_t)row_begin) - sr.begin();
+        const size_t k1 = std::lower_bound(sr.begin(), sr.end(), (uint32_t)row_end) - sr.begin();
+        nshort_rows = (uint32_t)(k1 - k0);
+        short_rows_dev = ix->short_rows ? ix->short_rows + k0 : nullptr;
+        short_rcnt_dev = ix->short_cnt ? ix->short_cnt + k0 : nullptr;
+    } else {
+        // queries [row_begin, row_end) of `rows`, located in the reference table's index
+        rc = table_classes(ctx, rows);
+        if (rc != MG_OK) return rc;
+        std::vector<uint32_t> qoff(nrows + 1);
+        uint64_t Eq = 0;
+        for (uint64_t q = 0; q < nrows; q++) {
+            qoff[q] = (uint32_t)Eq;
+            const uint64_t c = std::min<uint64_t>(std::min<uint64_t>(rows->nh[row_begin + q], rows->s), s);
+            Eq += c;
+            if (Eq >= (1ull << 31)) return MG_OK;
+            if (c < s) { qshort_h.push_back((uint32_t)q); qshort_cnt_h.push_back((uint32_t)c); }
+            if (c && rows->last[row_begin + q] == MG_HASH_PAD) return MG_OK;
+        }
+        qoff[nrows] = (uint32_t)Eq;
+        q_off.owner = q_img.owner = q_short.owner = q_short_cnt.owner = ctx;
+        q_lohi.owner = ctx;
+        const uint32_t rsq = ix->rs;
+        if (q_off.alloc(nrows + 1) != hipSuccess || q_img.alloc(nrows * rsq) != hipSuccess || q_lohi.alloc(std::max<uint64_t>(Eq, 1)) != hipSuccess ||
+            q_short.alloc(std::max<size_t>(qshort_h.size(), 1)) != hipSuccess || q_short_cnt.alloc(std::max<size_t>(qshort_h.size(), 1)) != hipSuccess) {
+            (void)hipGetLastError();
+            return MG_OK;                                   // no memory for the query side: tile engine
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(q_off, qoff.data(), (nrows + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+        if (!qshort_h.empty()) {
+            HIP_TRY(ctx, hipMemcpyAsync(q_short, qshort_h.data(), qshort_h.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(q_short_cnt, qshort_cnt_h.data(), qshort_h.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        }
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));    // the host vectors go out of scope below
+        HIP_TRY(ctx, mg::launch_sparse_locate(rows->hashes, rows->s, q_off, (uint32_t)row_begin, (uint32_t)nrows, ix->keys_sorted, ix->grp,
+                                              ix->gstart, ix->E, ix->G, rsq, q_lohi, q_img, ctx->stream));
+        a.lohi = q_lohi;
+        a.off = q_off;
+        a.row_img = q_img;
+        a.rs_row = rsq;
+        a.row_begin = 0;
+        a.row_end = (uint32_t)nrows;
+        a.out_base = 0;
+        nshort_rows = (uint32_t)qshort_h.size();
+        short_rows_dev = q_short;
+        short_rcnt_dev = q_short_cnt;
+    }
+
+    // ---- what the job holds: candidates and shared hashes (counted the first time the job is seen) ----
+    mg_table::Sparse::Plan *plan = nullptr;
+    if (triangle)                                           // rect: the query table may change between calls, count every time
+        for (auto &pl : ix->plans)
+            if (pl.rows == (const void *)rows && pl.rb == row_begin && pl.re == row_end && pl.triangle == triangle) plan = &pl;
+    mg_table::Sparse::Plan fresh;
+    if (!plan) {
+        a.cand = nullptr;
+        a.cand_cap = 0;
+        HIP_TRY(ctx, hipMemsetAsync(ix->counters, 0, 4 * 8, ctx->stream));
+        prof_begin(ctx, ctx->prof_index);
+        hipError_t e = mg::launch_sparse_discover(a, true, ctx->stream);
+        prof_end(ctx, ctx->prof_index);
+        if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare (candidate count): ") + hipGetErrorString(e));
+        unsigned long long h[2] = {0, 0};
+        HIP_TRY(ctx, hipMemcpyAsync(h, ix->counters, 16, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        fresh.rows = rows; fresh.rb = row_begin; fresh.re = row_end; fresh.triangle = triangle;
+        fresh.cand = h[0];
+        fresh.shared = h[1];
+        // seconds, one MI355X (measured: profiles/r03_sparse_phases.txt)
+        const double np = (double)pairs;
+        const double t_sparse = np * 8.0 / 4.5e12 + (double)fresh.shared * 2.0e-12 + (double)nrows * s * 4.0e-11 + (double)fresh.cand * 1.0e-9 + 2.0e-5;
+        const double dense_rate = np < 3.0e8 ? 8.0e9 : np < 2.0e9 ? 1.5e10 : 3.0e10;
+        const double t_dense = np / dense_rate + (double)fresh.shared * 2.2e-12;
+        fresh.use = t_sparse < t_dense;
+        if (getenv("MASHGPU_COMPARE_DBG"))
+            fprintf(stderr, "compare sparse: rows [%llu, %llu) %s: %llu pairs, %llu candidates, %llu shared hashes; model sparse %.3f ms, tiles %.3f ms\n",
+                    (unsigned long long)row_begin, (unsigned long long)row_end, triangle ? "triangle" : "rect", (unsigned long long)pairs,
+                    (unsigned long long)fresh.cand, (unsigned long long)fresh.shared, t_sparse * 1e3, t_dense * 1e3);
+        if (triangle) {
+            if (ix->plans.size() >= 64) ix->plans.erase(ix->plans.begin());
+            ix->plans.push_back(fresh);
+            plan = &ix->plans.back();
+        } else {
+            plan = &fresh;
+        }
+    }
+    if (!force && !plan->use) return MG_OK;
+    if (const char *e = getenv("MASHGPU_COMPARE_SPARSE")) { if (atoi(e) == 0 && !force) return MG_OK; }
+
+    // ---- fill ----
+    {
+        prof_begin(ctx, ctx->prof_fill);
+        hipError_t e = mg::launch_sparse_fill(a.out, pairs, s, (uint32_t)ctx->cu_count, ctx->stream);
+        if (e == hipSuccess && nshort_rows && !ix->short_rows_host.empty())
+            e = mg::launch_sparse_fill_short(a.out, short_rows_dev, short_rcnt_dev, nshort_rows, ix->short_rows, ix->short_cnt,
+                                             (uint32_t)ix->short_rows_host.size(), a.row_begin, a.ncols, a.triangle, a.out_base, s, ctx->stream);
+        prof_end(ctx, ctx->prof_fill);
+        if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare (fill): ") + hipGetErrorString(e));
+    }
+    *handled = true;
+    if (plan->cand == 0) return MG_OK;
+    // ---- discover + merge ----
+    if (plan->cand > ix->cand_cap) {
+        if (ix->cand) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); hipFree(ix->cand); ix->cand = nullptr; ix->cand_cap = 0; }
+        const uint64_t cap = plan->cand + plan->cand / 8 + 1024;
+        if (hipMalloc(&ix->cand, cap * sizeof(uint2)) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(ctx, MG_ERR_NOMEM, "compare: no device memory for the candidate list");
+        }
+        ix->cand_cap = cap;
+    }
+    a.cand = ix->cand;
+    a.cand_cap = ix->cand_cap;
+    HIP_TRY(ctx, hipMemsetAsync(ix->counters, 0, 4 * 8, ctx->stream));
+    prof_begin(ctx, ctx->prof_discover);
+    hipError_t e = mg::launch_sparse_discover(a, false, ctx->stream);
+    prof_end(ctx, ctx->prof_discover);
+    if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare (discover): ") + hipGetErrorString(e));
+    prof_begin(ctx, ctx->prof_merge);
+    e = mg::launch_sparse_merge(a, plan->cand, (uint32_t)ctx->cu_count, ctx->stream);
+    prof_end(ctx, ctx->prof_merge);
+    if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare (merge): ") + hipGetErrorString(e));
+    if (!ctx->async || !triangle) {
+        // the candidate list was sized from the counting pass of the same rows: an overflow means the
+        // tables changed under the cache (mg_table_wrap_dev's contract forbids it)
+        unsigned long long h[3] = {0, 0, 0};
+        HIP_TRY(ctx, hipMemcpyAsync(h, ix->counters, 24, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (h[2] != 0 || h[0] != plan->cand) return fail(ctx, MG_ERR_INVALID, "compare: the table changed since its index was built");
+    }
+    return MG_OK;
+}
+
 static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, uint64_t row_begin,
                        uint64_t row_end, bool triangle, mg_counts *out_dev)
 {
@@ -1868,6 +2199,13 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
     if (const char *e = getenv("MASHGPU_COMPARE_XCD")) a.xcd_remap = atoi(e) != 0;
     if (const char *e = getenv("MASHGPU_COMPARE_VARIANT")) a.unroll = (uint32_t)atoi(e);
     const char *force = getenv("MASHGPU_COMPARE_KERNEL");
+    // Inverted-index engine first: it takes the job when the counting pass says so (or when forced)
+    if (!force || strcmp(force, "sparse") == 0) {
+        bool handled = false;
+        const int rcs = run_compare_sparse(ctx, rows, cols, row_begin, row_end, triangle, a.s, out_dev, force != nullptr, &handled);
+        if (rcs != MG_OK || handled) return rcs;
+        if (force) return fail(ctx, MG_ERR_UNSUPPORTED, "compare: the sparse engine cannot take this table");
+    }
     if (force && strcmp(force, "pairs") == 0 && mg::compare_pairs_supported(a.s)) {
         prof_begin(ctx, ctx->prof_compare);
         HIP_TRY(ctx, mg::launch_compare_pairs(a, ctx->stream));
@@ -3379,7 +3717,7 @@ int mg_prof_enable(mg_ctx *ctx, int on)
 void mg_prof_reset(mg_ctx *ctx)
 {
     if (!ctx) return;
-    for (auto *v : {&ctx->prof_compare, &ctx->prof_sketch}) {
+    for (auto *v : {&ctx->prof_compare, &ctx->prof_sketch, &ctx->prof_fill, &ctx->prof_discover, &ctx->prof_merge, &ctx->prof_index}) {
         for (auto &r : *v) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
         v->clear();
     }
@@ -3392,6 +3730,10 @@ double mg_prof_avg_ms(mg_ctx *ctx, const char *name, uint64_t *launches_out)
     std::vector<ProfRec> *v = nullptr;
     if (strcmp(name, "compare") == 0) v = &ctx->prof_compare;
     else if (strcmp(name, "sketch") == 0) v = &ctx->prof_sketch;
+    else if (strcmp(name, "compare_fill") == 0) v = &ctx->prof_fill;
+    else if (strcmp(name, "compare_discover") == 0) v = &ctx->prof_discover;
+    else if (strcmp(name, "compare_merge") == 0) v = &ctx->prof_merge;
+    else if (strcmp(name, "compare_index") == 0) v = &ctx->prof_index;
     if (!v || v->empty()) return 0.0;
     hipStreamSynchronize(ctx->stream);
     double tot = 0.0;

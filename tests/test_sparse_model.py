@@ -1,0 +1,167 @@
+"""CPU model of the inverted-index compare engine (mash_amd/csrc/compare_sparse.hip), step for
+step in numpy, against the oracle's merge loop (compareSketches, CommandDistance.cpp:347-385).
+
+It pins the three claims the engine rests on, on tables with every edge the domain has (empty,
+short and identical rows, values shared by many rows, values at the top of the hash range):
+  1. a pair that shares no hash gives {0, min(s, |A| + |B|)} -- the fill;
+  2. the pairs sharing a hash are exactly what the runs of the sorted (value, row) index yield
+     -- the discovery;
+  3. the reference's loop run on codes (2 * dense rank in the table; for rect queries the code
+     scheme of sp_locate_kernel) takes the same branches as on the 64-bit values -- the merge.
+The GPU tests then only have to show that the kernels do what this model does."""
+import numpy as np
+import pytest
+
+from mash_amd import synth
+
+PAD = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def build_index(table, nhash, s):
+    n = table.shape[0]
+    cnt = np.minimum(np.minimum(nhash, table.shape[1]), s).astype(np.int64)
+    off = np.concatenate([[0], np.cumsum(cnt)])
+    keys = np.concatenate([table[i, : cnt[i]] for i in range(n)]) if off[-1] else np.zeros(0, np.uint64)
+    row_of = np.repeat(np.arange(n), cnt)
+    order = np.argsort(keys, kind="stable")               # stable: rows ascend inside a value
+    ks = keys[order]
+    head = np.ones(len(ks), dtype=bool)
+    head[1:] = ks[1:] != ks[:-1]
+    grp = np.cumsum(head) - 1                              # group id per sorted position
+    gstart = np.flatnonzero(head)
+    gstart = np.concatenate([gstart, [len(ks)]])
+    sorted_rows = row_of[order]
+    pos_of = np.empty(len(ks), dtype=np.int64)
+    pos_of[order] = np.arange(len(ks))                     # entry -> sorted position
+    rank_of = grp[pos_of]                                  # entry -> dense rank of its value
+    lo_of = gstart[rank_of]
+    return dict(cnt=cnt, off=off, ks=ks, grp=grp, gstart=gstart, sorted_rows=sorted_rows, pos_of=pos_of,
+                rank_of=rank_of, lo_of=lo_of)
+
+
+def merge_codes(a, b, s):
+    i = j = common = denom = 0
+    na, nb = len(a), len(b)
+    while denom < s and i < na and j < nb:
+        if a[i] < b[j]:
+            i += 1
+        elif b[j] < a[i]:
+            j += 1
+        else:
+            i += 1; j += 1; common += 1
+        denom += 1
+    if denom < s:
+        denom = min(s, denom + (na - i) + (nb - j))
+    return common, denom
+
+
+def model_triangle(table, nhash, s, rb, re):
+    ix = build_index(table, nhash, s)
+    cnt, off = ix["cnt"], ix["off"]
+    numer, denom = [], []
+    ncand = 0
+    for i in range(rb, re):
+        # fill
+        row_n = np.zeros(i, dtype=np.int64)
+        row_d = np.minimum(s, cnt[i] + cnt[:i])
+        # discover: runs [group start, own position) of the row's entries
+        cand = set()
+        for p in range(cnt[i]):
+            e = off[i] + p
+            cand.update(ix["sorted_rows"][ix["lo_of"][e]: ix["pos_of"][e]].tolist())
+        assert all(j < i for j in cand)
+        ncand += len(cand)
+        # merge on codes
+        ai = 2 * ix["rank_of"][off[i]: off[i + 1]]
+        for j in sorted(cand):
+            bj = 2 * ix["rank_of"][off[j]: off[j + 1]]
+            row_n[j], row_d[j] = merge_codes(ai, bj, s)
+        numer.append(row_n); denom.append(row_d)
+    return np.concatenate(numer) if numer else np.zeros(0), np.concatenate(denom) if denom else np.zeros(0), ncand
+
+
+def model_rect(ref, ref_nh, qry, qry_nh, s):
+    ix = build_index(ref, ref_nh, s)
+    G = len(ix["gstart"]) - 1
+    nq, nr = qry.shape[0], ref.shape[0]
+    numer = np.zeros((nq, nr), dtype=np.int64)
+    denom = np.zeros((nq, nr), dtype=np.int64)
+    qcnt = np.minimum(np.minimum(qry_nh, qry.shape[1]), s).astype(np.int64)
+    for q in range(nq):
+        denom[q] = np.minimum(s, qcnt[q] + ix["cnt"])
+        vals = qry[q, : qcnt[q]]
+        lb = np.searchsorted(ix["ks"], vals, side="left")
+        codes = np.zeros(len(vals), dtype=np.int64)
+        cand = set()
+        for t, v in enumerate(vals):
+            g = ix["grp"][lb[t]] if lb[t] < len(ix["ks"]) else G
+            found = lb[t] < len(ix["ks"]) and ix["ks"][lb[t]] == v
+            codes[t] = 2 * g + 1 if found else 2 * g
+            if found:
+                cand.update(ix["sorted_rows"][ix["gstart"][g]: ix["gstart"][g + 1]].tolist())
+        # query values between the same two table values share a code: they are only ever compared with
+        # table codes, so ascending (not strictly) is all the merge needs
+        assert np.all(np.diff(codes) >= 0)
+        for r in cand:
+            bc = 2 * ix["rank_of"][ix["off"][r]: ix["off"][r + 1]] + 1      # the merge adds one to every table code
+            numer[q, r], denom[q, r] = merge_codes(codes, bc, s)
+    return numer, denom
+
+
+def _edge_table(n, s, seed):
+    table, nhash, lengths = synth.clustered_sketches(n, s, clusters=4, seed=seed, pool=int(1.5 * s) + 2,
+                                                     private=max(1, int(0.4 * s)))
+    nhash[2] = 0
+    table[2, :] = PAD
+    nhash[5] = min(1, s)
+    table[5, nhash[5]:] = PAD
+    nhash[9] = max(0, s - 1)
+    table[9, nhash[9]:] = PAD
+    if s >= 3:
+        nhash[11] = s // 3
+        table[11, nhash[11]:] = PAD
+        nhash[12] = s // 3
+        table[12] = table[11]
+    table[17] = table[16]
+    nhash[17] = nhash[16]
+    # a value at the very top of the range (not the padding value) shared by two rows
+    if s >= 2:
+        for r in (20, 21):
+            k = int(nhash[r])
+            table[r, k - 1] = np.uint64(0xFFFFFFFFFFFFFFFE)
+    return table, nhash, lengths
+
+
+@pytest.mark.parametrize("s", [1, 2, 7, 64, 100])
+def test_model_triangle_equals_oracle(oracle, s):
+    n = 40
+    table, nhash, lengths = _edge_table(n, s, seed=s)
+    numer, denom, _, _ = oracle.triangle(table, nhash, lengths, 0, n, 21, 4.0 ** 21)
+    got_n, got_d, ncand = model_triangle(table, nhash, s, 0, n)
+    assert np.array_equal(got_n, numer) and np.array_equal(got_d, denom)
+    # the candidates are exactly the pairs sharing a hash: every other pair has numer 0
+    assert ncand >= int(np.count_nonzero(numer))
+    # a row range
+    n2, d2, _, _ = oracle.triangle(table, nhash, lengths, 13, 29, 21, 4.0 ** 21)
+    g2n, g2d, _ = model_triangle(table, nhash, s, 13, 29)
+    assert np.array_equal(g2n, n2) and np.array_equal(g2d, d2)
+
+
+@pytest.mark.parametrize("s", [1, 5, 64])
+def test_model_rect_equals_oracle(oracle, s):
+    """Queries against a reference table, including query values below, between and above the
+    table's values, found and not found, and a smaller sketch size than the tables'."""
+    n = 30
+    table, nhash, lengths = _edge_table(n, s, seed=100 + s)
+    rng = np.random.default_rng(s)
+    qtab, qnh, _ = synth.clustered_sketches(6, s, clusters=4, seed=100 + s, pool=int(1.5 * s) + 2, private=max(1, int(0.4 * s)))
+    # query rows: one copy of a table row, one all-new row with extreme values, an empty one
+    qtab[1] = table[3]; qnh[1] = nhash[3]
+    new = np.unique(np.concatenate([rng.integers(0, 1 << 54, s).astype(np.uint64), np.array([0, 2 ** 64 - 2], dtype=np.uint64)]))[:s]
+    qtab[2, :] = PAD; qtab[2, : len(new)] = np.sort(new); qnh[2] = len(new)
+    qnh[4] = 0; qtab[4, :] = PAD
+    got_n, got_d = model_rect(table, nhash, qtab, qnh, s)
+    for q in range(6):
+        for r in range(n):
+            c, d = merge_codes(qtab[q, : qnh[q]].tolist(), table[r, : nhash[r]].tolist(), s)
+            assert (got_n[q, r], got_d[q, r]) == (c, d), (q, r)
