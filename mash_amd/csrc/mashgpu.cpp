@@ -1982,7 +1982,7 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, mg_tab
     sp->max_group = h_stat.max_group;
     sp->build_ms = ms;
     sp->usable = true;
-    if (getenv("MASHGPU_COMPARE_DBG"))
+    if (getenv("MASHGPU_SPARSE_DBG"))
         fprintf(stderr, "compare sparse: index of %llu rows, s %u: %u entries, %u distinct, shared %llu, largest run %u, %.2f ms\n",
                 (unsigned long long)n, s, E, sp->G, (unsigned long long)sp->shared, sp->max_group, ms);
     return MG_OK;
@@ -2000,6 +2000,7 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
     const uint64_t pairs = triangle ? (row_end * (row_end - 1) / 2 - (row_begin ? row_begin * (row_begin - 1) / 2 : 0)) : nrows * cols->n;
     if (pairs == 0) return MG_OK;
     if (!force && pairs < 4000000ull) return MG_OK;        // small jobs: one tile launch beats an index
+    if (const char *e = getenv("MASHGPU_COMPARE_SPARSE")) { if (atoi(e) == 0 && !force) return MG_OK; }
     if (nrows >= (1ull << 31) || cols->n >= (1ull << 31)) return MG_OK;
     if (!mg::sparse_discover_supported((uint32_t)(triangle ? row_end : cols->n))) return MG_OK;
     mg_table::Sparse *ix = nullptr;
@@ -2108,7 +2109,7 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
         const double dense_rate = np < 3.0e8 ? 8.0e9 : np < 2.0e9 ? 1.5e10 : 3.0e10;
         const double t_dense = np / dense_rate + (double)fresh.shared * 2.2e-12;
         fresh.use = t_sparse < t_dense;
-        if (getenv("MASHGPU_COMPARE_DBG"))
+        if (getenv("MASHGPU_SPARSE_DBG"))
             fprintf(stderr, "compare sparse: rows [%llu, %llu) %s: %llu pairs, %llu candidates, %llu shared hashes; model sparse %.3f ms, tiles %.3f ms\n",
                     (unsigned long long)row_begin, (unsigned long long)row_end, triangle ? "triangle" : "rect", (unsigned long long)pairs,
                     (unsigned long long)fresh.cand, (unsigned long long)fresh.shared, t_sparse * 1e3, t_dense * 1e3);
@@ -2121,7 +2122,6 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
         }
     }
     if (!force && !plan->use) return MG_OK;
-    if (const char *e = getenv("MASHGPU_COMPARE_SPARSE")) { if (atoi(e) == 0 && !force) return MG_OK; }
 
     // ---- fill ----
     {

@@ -12,7 +12,7 @@ from mash_amd import abi, synth_torch
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=20000)
-ap.add_argument("--engines", default="default,plain,pairs")
+ap.add_argument("--engines", default="default,sparse,merged,plain")
 args = ap.parse_args()
 torch.cuda.init()
 dev = torch.device("cuda", 0)
