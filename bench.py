@@ -48,10 +48,7 @@ CLOCK_HZ = 2.4e9               # engine clock under load (MI355X_MICROARCH.md)
 SIMDS = 256 * 4
 S = 1000
 K = 21
-# sum of numer / sum of denom over the whole C3 triangle of the default synthetic table (seed 0):
-# taken from a run whose output tests/test_gpu_parity.py::test_c3_full_size_triangle checks against
-# the oracle (and asserts the same sums)
-C3_CHECKSUM = {(100_000, 1000): (2122078313, 4999950000000), (100_000, 10000): (21217550236, 49999500000000)}
+from workloads.checksums import C3_CHECKSUM    # established by tests/test_gpu_parity.py::test_c3_full_size_triangle
 
 
 def parse_args():
@@ -131,7 +128,7 @@ def cpu_baseline_sketch(budget_s, threads):
     """addMinHashes + MinHashHeap (the reference's objects) on `threads` host threads, 1 Mbp genomes."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import pyoracle
-    from mash_amd import synth
+    from workloads import synth
     use_ref = pyoracle.ref_available()
     orc = pyoracle.Oracle(ref=use_ref)
     p = orc.params(k=K, s=S)
@@ -159,7 +156,7 @@ def cpu_baseline_sketch(budget_s, threads):
 def cpu_baseline_sketch_cli(n_genomes, threads):
     """The reference CLI itself (oracle/_ref/mash-ref: all of the reference's translation units) on
     FASTA files: kseq parsing + sketching + .msh writing, `mash sketch -p <threads>`."""
-    from mash_amd import synth
+    from workloads import synth
     exe = os.path.join(ROOT, "oracle", "_ref", "mash-ref")
     if not os.path.exists(exe):
         return None
@@ -194,7 +191,8 @@ def main():
     args = parse_args()
     import torch
     import torch.distributed as dist
-    from mash_amd import abi, shard, synth_torch
+    from mash_amd import abi, shard
+    from workloads import synth_torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

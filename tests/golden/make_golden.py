@@ -83,7 +83,7 @@ def main():
     from oracle import pyoracle
     pyoracle.build(ref=True)
     ref = pyoracle.Oracle(ref=True)
-    from mash_amd import synth
+    from workloads import synth
 
     seqs, outs = [], {}
     cfgs = []
@@ -143,7 +143,7 @@ def main():
 def make_large_compare_vectors(ref):
     """Reference-run triangle at a sketch size where the GPU path compares value window by value
     window (s = 3000, k = 31) -> ref_compare_vectors_large.npz."""
-    from mash_amd import synth
+    from workloads import synth
     s = 3000
     table, nhash, lengths = synth.clustered_sketches(16, s, clusters=2, seed=31, pool=int(1.5 * s), private=int(0.4 * s))
     nhash[2] = 0
@@ -164,7 +164,7 @@ def make_cov_vectors(ref):
     """`mash sketch -r -c <cov>` (and with -m): the record loop of sketchFile with the reference's
     MinHashHeap and its early stop (Sketch.cpp:1258) -> ref_sketch_vectors_c.npz (hashes, counts,
     reads used)."""
-    from mash_amd import synth
+    from workloads import synth
     rng = np.random.default_rng(9090)
     outs, cfgs = {}, []
     for idx, (k, s, m, cov, glen, nreads) in enumerate([
@@ -203,7 +203,7 @@ def make_bloom_vectors(ref):
     reference's MinHashHeap and ITS Bloom filter (MinHashHeap.cpp:19-41,78-94; the vendored
     bloom_filter.hpp, compiled from /root/reference) -> ref_sketch_vectors_b.npz.  Small filters
     on purpose: aliasing (false positives) is what makes the result depend on the order."""
-    from mash_amd import synth
+    from workloads import synth
     rng = np.random.default_rng(4242)
     outs, cfgs = {}, []
     for idx, (k, s, bloom, cov, glen, nreads) in enumerate([
@@ -255,7 +255,7 @@ def make_codon_table(ref):
 def make_mincopies_vectors(ref):
     """`mash sketch -r -m <m>`: read sets sketched by the reference's own MinHashHeap with
     multiplicityMinimum = m (oracle/_ref) -> ref_sketch_vectors_m.npz."""
-    from mash_amd import synth
+    from workloads import synth
     rng = np.random.default_rng(4242)
     outs, cfgs = {}, []
     for idx, (k, s, m, glen, cov) in enumerate([

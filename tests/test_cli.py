@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from mash_amd import synth
+from workloads import synth
 from tests import helpers
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -9,7 +9,9 @@ import os
 import numpy as np
 import pytest
 
-from mash_amd import abi, synth
+from mash_amd import abi
+
+from workloads import synth
 from tests import helpers
 
 pytestmark = pytest.mark.gpu
@@ -1439,7 +1441,7 @@ def test_c2_scale_sketch_properties(eng, oracle, monkeypatch):
     the oracle; (c) a different work decomposition (forced multi-chunk + merge kernel) gives the
     identical table; (d) multiplicities sum to the number of k-mers for a repeat-free genome's keys."""
     import torch
-    from mash_amd import synth_torch
+    from workloads import synth_torch
     ng, L = 1000, 1_000_000
     dev = torch.device("cuda", 0)
     bases = synth_torch.synthetic_genomes(0, ng, L, device=dev)
@@ -1472,7 +1474,7 @@ def test_c3_scale_triangle_properties(eng, oracle):
     (c) a row block recomputed with the per-row tiled kernel and with the generic kernel is
     identical; (d) cluster structure of the synthetic table."""
     import torch
-    from mash_amd import synth_torch
+    from workloads import synth_torch
     n, s = 40000, 1000
     dev = torch.device("cuda", 0)
     hashes, nhash, lengths = synth_torch.clustered_sketch_table(n, s, clusters=400, device=dev)
@@ -1516,7 +1518,7 @@ def test_c3_scale_filter_and_cluster_layouts(eng, oracle, contiguous):
     consecutive rows (every tile then holds 16 related rows: distinct-first buckets, single
     representative verification), sampled rows against the oracle."""
     import torch
-    from mash_amd import synth_torch
+    from workloads import synth_torch
     n, s, k = 47000, 1000, 21
     dev = torch.device("cuda", 0)
     hashes, nhash, lengths = synth_torch.clustered_sketch_table(n, s, clusters=470, device=dev, contiguous=contiguous)
@@ -1544,11 +1546,53 @@ def test_c3_scale_filter_and_cluster_layouts(eng, oracle, contiguous):
     table.free()
 
 
-def test_c3_full_size_triangle(eng, oracle):
-    """BASELINE config 3 at its full size: 100 000 sketches, 4.99995e9 pairs, 40 GB of counts
-    resident in HBM; sampled rows against the oracle, denom == s everywhere, cluster structure."""
+def _check_full_triangle_against_reference(out, th, tn, tl, n, k, clusters, nclu_checked, ncross_rows):
+    """`out`: device tensor [pairs, 2] of a full triangle over the table (th, tn, tl).  Every pair
+    inside `nclu_checked` of the interleaved clusters (the pairs that share hashes) and every pair
+    among `ncross_rows` random rows (cross-cluster pairs, for all practical purposes) against the
+    REFERENCE's own compareSketches where oracle/_ref travelled with the snapshot (else the C
+    restatement), on all host threads."""
     import torch
-    from mash_amd import synth_torch
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import pyoracle
+    orc = pyoracle.Oracle(ref=pyoracle.ref_available())
+    kspace = 4.0 ** k
+    rng = np.random.default_rng(12345)
+    groups = [np.arange(c, n, clusters) for c in rng.choice(clusters, size=nclu_checked, replace=False)]
+    groups.append(np.sort(rng.choice(n, size=ncross_rows, replace=False)))
+
+    def check(rows):
+        sub = (np.ascontiguousarray(th[rows]), np.ascontiguousarray(tn[rows]), np.ascontiguousarray(tl[rows]))
+        numer, denom, _, _ = orc.triangle(sub[0], sub[1], sub[2], 0, len(rows), k, kspace)
+        x, y = np.tril_indices(len(rows), -1)                          # x > y, row-major: the triangle's order
+        gi, gj = rows[x].astype(np.int64), rows[y].astype(np.int64)
+        return gi * (gi - 1) // 2 + gj, numer, denom
+
+    with ThreadPoolExecutor(min(16, os.cpu_count() or 1)) as ex:        # ctypes releases the GIL
+        parts = list(ex.map(check, groups))
+    idx = np.concatenate([p[0] for p in parts])
+    numer = np.concatenate([p[1] for p in parts])
+    denom = np.concatenate([p[2] for p in parts])
+    got = out[torch.from_numpy(idx).to(out.device)].cpu().numpy()
+    assert np.array_equal(got[:, 0].astype(np.uint32), numer) and np.array_equal(got[:, 1].astype(np.uint32), denom)
+    return len(idx), int(np.count_nonzero(numer))
+
+
+def _sums(out):
+    import torch
+    return (int(out[:, 0].sum(dtype=torch.int64).item()), int(out[:, 1].sum(dtype=torch.int64).item()))
+
+
+def test_c3_full_size_triangle(eng, oracle, monkeypatch):
+    """BASELINE config 3 at its full size: 100 000 sketches, 4.99995e9 pairs, 40 GB of counts resident
+    in HBM.  This is the run bench.py's checksum constant comes from (workloads/checksums.py): ALL
+    4.95e6 within-cluster pairs and 1.1e6 cross-cluster pairs of the output against the reference's
+    compareSketches (CommandDistance.cpp:336-425), sampled whole rows against the oracle, denom == s
+    everywhere, the sums of the default engine, of the inverted-index engine and of the tile engine
+    equal to each other and to the constant, the generic kernel's sums on the first 20 000 rows."""
+    import torch
+    from workloads import synth_torch
+    from workloads.checksums import C3_CHECKSUM
     n, s = 100000, 1000
     dev = torch.device("cuda", 0)
     hashes, nhash, lengths = synth_torch.clustered_sketch_table(n, s, clusters=1000, device=dev)
@@ -1572,6 +1616,82 @@ def test_c3_full_size_triangle(eng, oracle):
     row = out[i * (i - 1) // 2: i * (i - 1) // 2 + i, 0].cpu().numpy()
     same = (np.arange(i) % 1000) == (i % 1000)
     assert row[same].min() > 300 and row[~same].max() < 50
+    checked, shared = _check_full_triangle_against_reference(out, th, tn, tl, n, 21, 1000, 1000, 1500)
+    assert checked >= 4950000 + 1100000 and shared >= 4900000
+    want = C3_CHECKSUM[(n, s)]
+    assert _sums(out) == want
+    for kernel in ("sparse", "merged"):                                # the two engines, each forced
+        monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", kernel)
+        out.zero_()
+        eng.compare_tri_dev(table, 0, n, out.data_ptr())
+        eng.synchronize()
+        assert _sums(out) == want, kernel
+    m = 20000
+    mp = m * (m - 1) // 2
+    ref_sums = _sums(out[:mp])
+    monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", "generic")            # one wave per pair, binary search: shares no code with either
+    out[:mp].zero_()
+    eng.compare_tri_dev(table, 0, m, out.data_ptr())
+    eng.synchronize()
+    assert _sums(out[:mp]) == ref_sums
+    monkeypatch.delenv("MASHGPU_COMPARE_KERNEL")
+    del out
+    table.free()
+
+
+def test_c5_full_size_triangle(eng, oracle, monkeypatch):
+    """BASELINE config 5 at config-3 scale (100 000 sketches of s = 10 000, 8 GB table): 100 whole
+    clusters (4.95e5 pairs sharing thousands of hashes) and 2e5 cross-cluster pairs against the
+    reference's compareSketches, both engines' sums equal to the constant bench.py asserts."""
+    import torch
+    from workloads import synth_torch
+    from workloads.checksums import C3_CHECKSUM
+    n, s = 100000, 10000
+    dev = torch.device("cuda", 0)
+    hashes, nhash, lengths = synth_torch.clustered_sketch_table(n, s, clusters=1000, pool=15000, private=4000, device=dev, block=2000)
+    table = eng.table_wrap(hashes.data_ptr(), nhash.data_ptr(), lengths.data_ptr(), n, s)
+    out = torch.empty((n * (n - 1) // 2, 2), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    eng.compare_tri_dev(table, 0, n, out.data_ptr())
+    eng.synchronize()
+    want = C3_CHECKSUM[(n, s)]
+    assert _sums(out) == want
+    rows = np.concatenate([np.arange(c, n, 1000) for c in range(0, 1000, 10)] + [np.arange(0, n, 157)])
+    rows = np.unique(rows)
+    # only the rows used travel to the host (the table is 8 GB)
+    sub_h = hashes[torch.from_numpy(rows).to(dev)].cpu().numpy().view(np.uint64)
+    sub_n = nhash[torch.from_numpy(rows).to(dev)].cpu().numpy().astype(np.uint32)
+    sub_l = lengths[torch.from_numpy(rows).to(dev)].cpu().numpy().astype(np.uint64)
+    # a compact table of the rows used, addressed by their rank; the helper maps back through `rows`
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import pyoracle
+    orc = pyoracle.Oracle(ref=pyoracle.ref_available())
+    pos = {int(r): k for k, r in enumerate(rows)}
+    groups = [np.arange(c, n, 1000) for c in range(0, 1000, 10)] + [np.arange(0, n, 157)]
+
+    def check(g):
+        sel = np.array([pos[int(r)] for r in g])
+        numer, denom, _, _ = orc.triangle(np.ascontiguousarray(sub_h[sel]), np.ascontiguousarray(sub_n[sel]),
+                                          np.ascontiguousarray(sub_l[sel]), 0, len(g), 31, 4.0 ** 31)
+        x, y = np.tril_indices(len(g), -1)
+        gi, gj = g[x].astype(np.int64), g[y].astype(np.int64)
+        return gi * (gi - 1) // 2 + gj, numer, denom
+
+    with ThreadPoolExecutor(min(16, os.cpu_count() or 1)) as ex:
+        parts = list(ex.map(check, groups))
+    idx = np.concatenate([p[0] for p in parts])
+    numer = np.concatenate([p[1] for p in parts])
+    denom = np.concatenate([p[2] for p in parts])
+    got = out[torch.from_numpy(idx).to(dev)].cpu().numpy()
+    assert np.array_equal(got[:, 0].astype(np.uint32), numer) and np.array_equal(got[:, 1].astype(np.uint32), denom)
+    assert len(idx) >= 495000 + 200000 and int(numer.max()) > 3000
+    for kernel in ("sparse", "merged"):
+        monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", kernel)
+        out.zero_()
+        eng.compare_tri_dev(table, 0, n, out.data_ptr())
+        eng.synchronize()
+        assert _sums(out) == want, kernel
+    monkeypatch.delenv("MASHGPU_COMPARE_KERNEL")
     del out
     table.free()
 

@@ -284,7 +284,7 @@ def test_oracle_vs_reference_live(oracle, ref_oracle):
             for use64 in (True, False):
                 assert oracle.get_hash(kmer, 42, use64) == ref_oracle.get_hash(kmer, 42, use64)
             assert oracle.get_hash(kmer, 7, True) == ref_oracle.get_hash(kmer, 7, True)
-    from mash_amd import synth
+    from workloads import synth
     for variant in range(4):
         recs = synth.adversarial_dna_records(rng, variant)
         for (k, s) in ((21, 1000), (15, 100), (32, 77)):

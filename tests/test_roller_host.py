@@ -8,7 +8,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from mash_amd import synth
+from workloads import synth
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 

@@ -30,7 +30,7 @@ def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
-    from mash_amd import synth
+    from workloads import synth
     from oracle import pyoracle
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -57,7 +57,7 @@ def _worker(rank, world, port, q):
 
 def test_two_rank_triangle_reassembles(oracle):
     import torch.multiprocessing as mp
-    from mash_amd import synth
+    from workloads import synth
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -107,7 +107,7 @@ def test_bench_multirank_plumbing_dry(tmp_path):
 
 def _screen_case():
     """small mixture + query sketches; expected counts by direct hashing with the oracle"""
-    from mash_amd import synth
+    from workloads import synth
     from oracle import pyoracle
     orc = pyoracle.Oracle()
     rng = np.random.default_rng(5)

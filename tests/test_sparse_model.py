@@ -12,7 +12,7 @@ The GPU tests then only have to show that the kernels do what this model does.""
 import numpy as np
 import pytest
 
-from mash_amd import synth
+from workloads import synth
 
 PAD = np.uint64(0xFFFFFFFFFFFFFFFF)
 

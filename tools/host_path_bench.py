@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-from mash_amd import synth_torch  # noqa: E402
+from workloads import synth_torch  # noqa: E402
 from mash_amd.abi import MashGpu  # noqa: E402
 from mash_amd.shard import tri_pairs  # noqa: E402
 

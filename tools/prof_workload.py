@@ -21,7 +21,8 @@ def main():
     ap.add_argument("--reps", type=int, default=2)
     a = ap.parse_args()
     import torch
-    from mash_amd import abi, synth_torch
+    from mash_amd import abi
+    from workloads import synth_torch
     dev = torch.device("cuda", 0)
     eng = abi.MashGpu(0)
     hashes, nhash, lengths = synth_torch.clustered_sketch_table(a.n, 1000, clusters=max(1, a.n // 100), device=dev)

@@ -8,7 +8,8 @@ resident in/out, synchronous call) and the same with full-length column chunks
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from mash_amd import abi, synth_torch
+from mash_amd import abi
+from workloads import synth_torch
 
 
 def main():

@@ -8,7 +8,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch
-from mash_amd import abi, synth_torch
+from mash_amd import abi
+from workloads import synth_torch
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=20000)

@@ -6,7 +6,8 @@ import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-from mash_amd import abi, synth_torch
+from mash_amd import abi
+from workloads import synth_torch
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--s", type=int, default=1000)

@@ -16,7 +16,8 @@ def main():
     ap.add_argument("variants", nargs="*", default=["0"])
     a = ap.parse_args()
     import torch
-    from mash_amd import abi, synth_torch
+    from mash_amd import abi
+    from workloads import synth_torch
     dev = torch.device("cuda", 0)
     eng = abi.MashGpu(0)
     n = a.n

@@ -5,7 +5,8 @@ import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-from mash_amd import abi, synth_torch
+from mash_amd import abi
+from workloads import synth_torch
 torch.cuda.init()
 dev = torch.device("cuda", 0)
 eng = abi.MashGpu(0, stream=torch.cuda.current_stream().cuda_stream)

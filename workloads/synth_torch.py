@@ -57,7 +57,7 @@ def clustered_sketch_table(n, s=1000, clusters=1000, seed=0, pool=1500, private=
 
 def synthetic_genomes(g_begin, g_end, length, device="cuda", block=256, stride=1):
     """ASCII bases uint8[(g_end-g_begin), length] of synthetic genomes g_begin..g_end-1
-    (same definition as mash_amd.synth.synthetic_genome).
+    (same definition as workloads.synth.synthetic_genome).
 
     SURVEY.md section 8d seeds genome g with GOLDEN*(g+1), and GOLDEN is also splitmix64's
     state increment: consecutive genomes are the same stream shifted by one word (32 bases).
