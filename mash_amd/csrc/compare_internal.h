@@ -116,6 +116,10 @@ struct SparseArgs {
     uint64_t cand_cap;
     unsigned long long *counters;  // [0] candidates, [1] shared hashes of the rows handled, [2] candidate list overflowed
     uint2 *out;
+    uint2 *res;                    // {common, denom} per candidate, in list order (scattered to `out` after the fill)
+    unsigned long long *seg_base;  // per discover slot (slot = row_end - 1 - row): the row's segment of the list
+    uint32_t *seg_cnt;
+    uint32_t *chunk_inc;           // inclusive scan of the rows' merge work items
 };
 size_t sparse_sort_temp_bytes(uint32_t E, uint32_t end_bit);
 uint32_t sparse_img_stride(uint32_t s);          // row stride of a code image
@@ -130,7 +134,12 @@ hipError_t launch_sparse_locate(const uint64_t *qhashes, uint64_t qstride, const
 bool sparse_discover_supported(uint32_t ncols_max);
 hipError_t launch_sparse_discover(const SparseArgs &a, bool count_only, hipStream_t stream);
 hipError_t launch_sparse_merge(const SparseArgs &a, uint64_t expect, uint32_t cus, hipStream_t stream);
-hipError_t launch_sparse_fill(uint2 *out, uint64_t pairs, uint32_t denom, uint32_t cus, hipStream_t stream);
+bool sparse_merge_rows_supported(uint32_t rs_row);
+size_t sparse_scan_temp_bytes(uint32_t nrows);
+hipError_t launch_sparse_merge_rows(const SparseArgs &a, uint64_t expect, uint32_t *chunks, void *temp, size_t temp_bytes,
+                                    hipStream_t stream);
+hipError_t launch_sparse_scatter(const SparseArgs &a, uint64_t expect, uint32_t cus, hipStream_t stream);
+hipError_t launch_sparse_fill(uint2 *out, uint64_t pairs, uint32_t denom, uint32_t blocks_per_cu, uint32_t cus, hipStream_t stream);
 hipError_t launch_sparse_fill_short(uint2 *out, const uint32_t *short_rows, const uint32_t *short_rcnt, uint32_t nshort_rows,
                                     const uint32_t *short_cols, const uint32_t *short_ccnt, uint32_t nshort_cols,
                                     uint32_t row_begin, uint32_t ncols, uint32_t triangle, uint64_t out_base, uint32_t s,

@@ -293,6 +293,10 @@ __global__ __launch_bounds__(256) void sp_discover_kernel(SparseArgs a)
         if (tid == 0) a.counters[2] = 1;
         return;
     }
+    if (tid == 0) {                                      // the row's segment of the list (slot = blockIdx.x)
+        a.seg_base[blockIdx.x] = gbase;
+        a.seg_cnt[blockIdx.x] = total;
+    }
     unsigned long long o = gbase + woff + incl - mine;
     for (uint32_t w = w0; w < w1; w++) {
         uint32_t bits = bm[w];
@@ -354,10 +358,124 @@ __global__ __launch_bounds__(256) void sp_merge_kernel(SparseArgs a)
             denom += (nA - ia) + (nB - ib);
             if (denom > s) denom = s;
         }
+        a.res[c] = make_uint2(common, denom);
+    }
+}
+
+// Work items of the row-blocked merge: SPM_NT candidates of one row.  chunks[slot] = items of the
+// row in discover slot `slot`; an inclusive scan turns it into the item -> row map.
+constexpr uint32_t SPM_NT = 128;
+constexpr uint32_t SPM_RING = 32;                         // column codes a lane keeps in LDS
+
+__global__ __launch_bounds__(256) void sp_chunks_kernel(const uint32_t *seg_cnt, uint32_t nrows, uint32_t *chunks)
+{
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r < nrows) chunks[r] = (seg_cnt[r] + SPM_NT - 1u) / SPM_NT;
+}
+
+// Row-blocked merge: a workgroup = one row and up to SPM_NT of its candidates, one lane per
+// candidate.  The row's codes sit in LDS for everyone; every lane streams its column's codes through
+// a private ring of SPM_RING codes in LDS (code e of lane l at word (e mod 32) * 64 + l: reads are
+// conflict free), refilled eight codes at a
+// time on a fixed cadence -- every 8 merge steps a lane lands the chunk it requested a round ago
+// and requests the next if its ring has room -- so the loop body has no divergent loads and a
+// request has a whole round to arrive.  A lane advances at most 8 codes per round and holds at
+// least 16 after landing, so it never runs dry; a chunk is only requested when the 8 codes it
+// overwrites are consumed.  The loop itself is the reference's (CommandDistance.cpp:347-385).
+template <bool RECT>
+__global__ __launch_bounds__(SPM_NT) void sp_merge_rows_kernel(SparseArgs a)
+{
+    extern __shared__ __align__(16) uint32_t lds[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t nrows = a.row_end - a.row_begin;
+    const uint32_t item = blockIdx.x;
+    if (item >= a.chunk_inc[nrows - 1]) return;
+    uint32_t lo = 0, hi = nrows - 1;                     // first slot whose inclusive count exceeds item
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a.chunk_inc[mid] > item) hi = mid; else lo = mid + 1;
+    }
+    const uint32_t slot = lo;
+    const uint32_t chunk = item - (slot ? a.chunk_inc[slot - 1] : 0u);
+    const uint32_t row = a.row_end - 1u - slot;          // as sp_discover_kernel maps its workgroups
+    const uint32_t cnt = a.seg_cnt[slot];
+    const uint64_t base = a.seg_base[slot] + (uint64_t)chunk * SPM_NT;
+    const uint32_t left = cnt - chunk * SPM_NT;
+    const bool have = tid < left;
+    const uint32_t s = a.s;
+    const uint32_t nA = a.off[row + 1] - a.off[row];
+    // the row's codes (and one chunk of its padding: A[nA] is read by a lane that has just finished)
+    uint32_t *A = lds;
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.row_img + (uint64_t)row * a.rs_row);
+        const uint32_t nvec = (nA >> 2) + 1u;
+        for (uint32_t v = tid; v < nvec; v += SPM_NT) reinterpret_cast<uint4 *>(A)[v] = src[v];
+    }
+    uint32_t *myring = lds + a.rs_row + (tid >> 6) * (SPM_RING * 64u) + lane;   // code e of this lane: myring[(e & 31) * 64]
+    const uint32_t j = have ? a.cand[base + tid].y : 0u;
+    const uint32_t nB = have ? a.col_cnt_off[j + 1] - a.col_cnt_off[j] : 0u;
+    const uint4 *B4 = reinterpret_cast<const uint4 *>(a.col_img + (uint64_t)j * a.rs_col);
+    auto land = [&](uint32_t e, const uint4 &v) {         // codes e .. e + 3 (e a multiple of 4)
+        uint32_t *q = myring + (e & (SPM_RING - 1u)) * 64u;
+        q[0] = v.x; q[64] = v.y; q[128] = v.z; q[192] = v.w;
+    };
+    // codes [0, 16) land now, [16, 24) are the first pending chunk
+    {
+        const uint4 x0 = B4[0], x1 = B4[1], x2 = B4[2], x3 = B4[3];
+        land(0, x0); land(4, x1); land(8, x2); land(12, x3);
+    }
+    uint4 p0 = B4[4], p1 = B4[5];
+    uint32_t loaded = 16;
+    bool pend = true;
+    __syncthreads();                                     // A staged
+    uint32_t ia = 0, ib = 0, common = 0, denom = 0;
+    bool active = have && s > 0 && nA > 0 && nB > 0;
+    while (__ballot(active) != 0) {
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            const uint32_t av = A[ia];
+            uint32_t bv = myring[(ib & (SPM_RING - 1u)) * 64u];
+            if (RECT) bv += 1u;
+            const bool adva = active && av <= bv, advb = active && bv <= av;
+            common += (adva && advb) ? 1u : 0u;
+            denom += active ? 1u : 0u;
+            ia += adva ? 1u : 0u;
+            ib += advb ? 1u : 0u;
+            active = active && denom < s && ia < nA && ib < nB;
+        }
+        if (pend) {
+            land(loaded, p0);
+            land(loaded + 4u, p1);
+            loaded += 8;
+        }
+        pend = active && loaded + 8u - ib <= SPM_RING;
+        if (pend) {
+            p0 = B4[loaded >> 2];
+            p1 = B4[(loaded >> 2) + 1u];
+        }
+    }
+    if (have) {
+        if (denom < s) {                                   // :367-385
+            denom += (nA - ia) + (nB - ib);
+            if (denom > s) denom = s;
+        }
+        a.res[base + tid] = make_uint2(common, denom);
+    }
+}
+
+// results of the candidates -> their output slots (after the fill)
+__global__ __launch_bounds__(256) void sp_scatter_kernel(SparseArgs a)
+{
+    unsigned long long K = a.counters[0];
+    if (K > a.cand_cap) K = a.cand_cap;
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    for (uint64_t c = (uint64_t)blockIdx.x * 256u + threadIdx.x; c < K; c += stride) {
+        const uint2 pr = a.cand[c];
+        const uint32_t i = pr.x, j = pr.y;
         uint64_t oidx;
-        if (RECT) oidx = (uint64_t)(i - a.row_begin) * a.ncols + j;
-        else oidx = (uint64_t)i * (i - 1u) / 2u + j - a.out_base;
-        a.out[oidx] = make_uint2(common, denom);
+        if (a.triangle) oidx = (uint64_t)i * (i - 1u) / 2u + j - a.out_base;
+        else oidx = (uint64_t)(i - a.row_begin) * a.ncols + j;
+        a.out[oidx] = a.res[c];
     }
 }
 
@@ -462,11 +580,60 @@ hipError_t launch_sparse_merge(const SparseArgs &a, uint64_t expect, uint32_t cu
     return hipGetLastError();
 }
 
-hipError_t launch_sparse_fill(uint2 *out, uint64_t pairs, uint32_t denom, uint32_t cus, hipStream_t stream)
+size_t sparse_merge_rows_lds(uint32_t rs_row) { return ((size_t)rs_row + (SPM_NT / 64u) * SPM_RING * 64u) * 4; }
+bool sparse_merge_rows_supported(uint32_t rs_row) { return sparse_merge_rows_lds(rs_row) <= 160 * 1024 - 256; }
+size_t sparse_scan_temp_bytes(uint32_t nrows)
+{
+    size_t b = 0;
+    rocprim::inclusive_scan(nullptr, b, (const uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)nrows, rocprim::plus<uint32_t>(),
+                            (hipStream_t) nullptr);
+    return b;
+}
+
+// Row-blocked merge of the candidates the discover launch listed: work items from the rows' segment
+// sizes (scan), then one workgroup per item.  `expect`: the candidate count of the counting pass.
+hipError_t launch_sparse_merge_rows(const SparseArgs &a, uint64_t expect, uint32_t *chunks, void *temp, size_t temp_bytes,
+                                    hipStream_t stream)
+{
+    const uint32_t nrows = a.row_end - a.row_begin;
+    if (expect == 0 || nrows == 0) return hipSuccess;
+    hipLaunchKernelGGL(sp_chunks_kernel, dim3((nrows + 255u) / 256u), dim3(256), 0, stream, a.seg_cnt, nrows, chunks);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    e = rocprim::inclusive_scan(temp, temp_bytes, (const uint32_t *)chunks, a.chunk_inc, (size_t)nrows, rocprim::plus<uint32_t>(), stream);
+    if (e != hipSuccess) return e;
+    const uint64_t items = expect / SPM_NT + nrows;              // upper bound: one partial item per row
+    if (items >= (1ull << 31)) return hipErrorInvalidValue;
+    const size_t smem = sparse_merge_rows_lds(a.rs_row);
+    if (a.triangle) {
+        auto kern = sp_merge_rows_kernel<false>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3((uint32_t)items), dim3(SPM_NT), smem, stream, a);
+    } else {
+        auto kern = sp_merge_rows_kernel<true>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3((uint32_t)items), dim3(SPM_NT), smem, stream, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_sparse_scatter(const SparseArgs &a, uint64_t expect, uint32_t cus, hipStream_t stream)
+{
+    if (expect == 0) return hipSuccess;
+    uint64_t blocks = (expect + 255) / 256;
+    const uint64_t most = (uint64_t)(cus ? cus : 256) * 16;
+    if (blocks > most) blocks = most;
+    hipLaunchKernelGGL(sp_scatter_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_sparse_fill(uint2 *out, uint64_t pairs, uint32_t denom, uint32_t blocks_per_cu, uint32_t cus, hipStream_t stream)
 {
     if (pairs == 0) return hipSuccess;
     uint64_t blocks = (pairs / 2 + 1023) / 1024;                 // >= 4 stores per thread
-    const uint64_t most = (uint64_t)(cus ? cus : 256) * 16;
+    const uint64_t most = (uint64_t)(cus ? cus : 256) * (blocks_per_cu ? blocks_per_cu : 16);
     if (blocks > most) blocks = most;
     if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL(sp_fill_const_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, out, pairs, denom);

@@ -43,6 +43,9 @@ struct mg_ctx {
     std::vector<ProfRec> prof_compare, prof_sketch;
     // phases of the inverted-index compare engine (compare_sparse.hip), each its own kernel
     std::vector<ProfRec> prof_fill, prof_discover, prof_merge, prof_index;
+    // its fill runs on a stream of its own beside discover + merge (HBM-write bound vs latency bound)
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // Entry points lock the context: any number of host threads may drive one context, one call at
     // a time (SURVEY 8b "thread-safe per ctx"); recursive because entry points call each other.
     std::recursive_mutex mu;
@@ -102,9 +105,15 @@ struct mg_table {
         // what a (rows, range) job costs, learned by a counting pass the first time it is seen
         struct Plan { const void *rows; uint64_t rb, re; bool triangle; uint64_t cand, shared; bool use; };
         std::vector<Plan> plans;
-        uint2 *cand = nullptr;             // candidate list, grown on demand
+        uint2 *cand = nullptr, *res = nullptr;    // candidate list and the candidates' results, grown on demand
         uint64_t cand_cap = 0;
         unsigned long long *counters = nullptr;   // [4] device
+        // per row of a launch: its segment of the candidate list, its merge work items (+ scan scratch)
+        unsigned long long *seg_base = nullptr;
+        uint32_t *seg_cnt = nullptr, *chunks = nullptr, *chunk_inc = nullptr;
+        void *scan_temp = nullptr;
+        size_t scan_temp_bytes = 0;
+        uint64_t seg_rows = 0;
     };
     mutable std::vector<Sparse *> sparse;
 };
@@ -194,20 +203,20 @@ static int fail(mg_ctx *ctx, int code, const std::string &msg)
     return code;
 }
 
-static void prof_begin(mg_ctx *ctx, std::vector<ProfRec> &v)
+static void prof_begin(mg_ctx *ctx, std::vector<ProfRec> &v, hipStream_t stream = nullptr)
 {
     if (!ctx->prof) return;
     ProfRec r;
     hipEventCreate(&r.a);
     hipEventCreate(&r.b);
-    hipEventRecord(r.a, ctx->stream);
+    hipEventRecord(r.a, stream ? stream : ctx->stream);
     v.push_back(r);
 }
 
-static void prof_end(mg_ctx *ctx, std::vector<ProfRec> &v)
+static void prof_end(mg_ctx *ctx, std::vector<ProfRec> &v, hipStream_t stream = nullptr)
 {
     if (!ctx->prof || v.empty()) return;
-    hipEventRecord(v.back().b, ctx->stream);
+    hipEventRecord(v.back().b, stream ? stream : ctx->stream);
 }
 
 extern "C" {
@@ -254,6 +263,9 @@ void mg_ctx_destroy(mg_ctx *ctx)
     }
     for (auto &b : ctx->blk_free) hipFree(b.p);
     for (auto &b : ctx->blk_live) hipFree(b.p);
+    if (ctx->aux) hipStreamDestroy(ctx->aux);
+    if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -1374,7 +1386,8 @@ void mg_table_free(mg_table *t)
         for (mg_table::Sparse *sp : t->sparse) {
             for (void *q : {(void *)sp->off, (void *)sp->keys_sorted, (void *)sp->grp, (void *)sp->gstart, (void *)sp->sorted_rows,
                             (void *)sp->lohi, (void *)sp->rank_img, (void *)sp->short_rows, (void *)sp->short_cnt, (void *)sp->cand,
-                            (void *)sp->counters})
+                            (void *)sp->res, (void *)sp->seg_base, (void *)sp->seg_cnt, (void *)sp->chunks, (void *)sp->chunk_inc,
+                            sp->scan_temp, (void *)sp->counters})
                 if (q) hipFree(q);
             delete sp;
         }
@@ -1939,7 +1952,7 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, mg_tab
     ok = ok && hipMalloc(&sp->off, (n + 1) * 4) == hipSuccess && hipMalloc(&sp->keys_sorted, (size_t)E * 8) == hipSuccess &&
          hipMalloc(&sp->grp, (size_t)E * 4) == hipSuccess && hipMalloc(&sp->gstart, ((size_t)E + 1) * 4) == hipSuccess &&
          hipMalloc(&sp->sorted_rows, (size_t)E * 4) == hipSuccess && hipMalloc(&sp->lohi, (size_t)E * 8) == hipSuccess &&
-         hipMalloc(&sp->rank_img, (size_t)n * sp->rs * 4) == hipSuccess && hipMalloc(&sp->counters, 4 * 8) == hipSuccess;
+         hipMalloc(&sp->rank_img, ((size_t)n * sp->rs + 64) * 4) == hipSuccess && hipMalloc(&sp->counters, 4 * 8) == hipSuccess;
     const size_t nshort = sp->short_rows_host.size();
     std::vector<uint32_t> short_cnt(nshort);
     for (size_t k = 0; k < nshort; k++) {
@@ -2123,39 +2136,86 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
     }
     if (!force && !plan->use) return MG_OK;
 
-    // ---- fill ----
+    // ---- fill, on its own stream beside discover + merge: one is bound by HBM writes, the others by
+    // latency and instruction issue.  The candidates' results are kept in list order and scattered
+    // into the output once both sides are done.
+    bool overlap = plan->cand != 0;
+    if (const char *e = getenv("MASHGPU_SPARSE_OVERLAP")) overlap = overlap && atoi(e) != 0;
+    uint32_t fill_bpc = overlap ? 4u : 16u;               // workgroups per CU: leave room for the other kernels
+    if (const char *e = getenv("MASHGPU_SPARSE_FILL_BPC")) fill_bpc = (uint32_t)std::max(1, atoi(e));
+    hipStream_t fs = ctx->stream;
+    if (overlap) {
+        if (!ctx->aux) {
+            HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+        }
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));      // the output buffer is ours from here on
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
+        fs = ctx->aux;
+    }
     {
-        prof_begin(ctx, ctx->prof_fill);
-        hipError_t e = mg::launch_sparse_fill(a.out, pairs, s, (uint32_t)ctx->cu_count, ctx->stream);
+        prof_begin(ctx, ctx->prof_fill, fs);
+        hipError_t e = mg::launch_sparse_fill(a.out, pairs, s, fill_bpc, (uint32_t)ctx->cu_count, fs);
         if (e == hipSuccess && nshort_rows && !ix->short_rows_host.empty())
             e = mg::launch_sparse_fill_short(a.out, short_rows_dev, short_rcnt_dev, nshort_rows, ix->short_rows, ix->short_cnt,
-                                             (uint32_t)ix->short_rows_host.size(), a.row_begin, a.ncols, a.triangle, a.out_base, s, ctx->stream);
-        prof_end(ctx, ctx->prof_fill);
+                                             (uint32_t)ix->short_rows_host.size(), a.row_begin, a.ncols, a.triangle, a.out_base, s, fs);
+        prof_end(ctx, ctx->prof_fill, fs);
         if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare (fill): ") + hipGetErrorString(e));
+        if (overlap) HIP_TRY(ctx, hipEventRecord(ctx->ev_join, fs));
     }
     *handled = true;
     if (plan->cand == 0) return MG_OK;
     // ---- discover + merge ----
     if (plan->cand > ix->cand_cap) {
-        if (ix->cand) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); hipFree(ix->cand); ix->cand = nullptr; ix->cand_cap = 0; }
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (void **q : {(void **)&ix->cand, (void **)&ix->res})
+            if (*q) { hipFree(*q); *q = nullptr; }
+        ix->cand_cap = 0;
         const uint64_t cap = plan->cand + plan->cand / 8 + 1024;
-        if (hipMalloc(&ix->cand, cap * sizeof(uint2)) != hipSuccess) {
+        if (hipMalloc(&ix->cand, cap * sizeof(uint2)) != hipSuccess || hipMalloc(&ix->res, cap * sizeof(uint2)) != hipSuccess) {
             (void)hipGetLastError();
             return fail(ctx, MG_ERR_NOMEM, "compare: no device memory for the candidate list");
         }
         ix->cand_cap = cap;
     }
+    if (nrows > ix->seg_rows) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (void **q : {(void **)&ix->seg_base, (void **)&ix->seg_cnt, (void **)&ix->chunks, (void **)&ix->chunk_inc, &ix->scan_temp})
+            if (*q) { hipFree(*q); *q = nullptr; }
+        ix->seg_rows = 0;
+        const uint64_t cap = nrows + nrows / 8 + 256;
+        ix->scan_temp_bytes = mg::sparse_scan_temp_bytes((uint32_t)cap);
+        if (hipMalloc(&ix->seg_base, cap * 8) != hipSuccess || hipMalloc(&ix->seg_cnt, cap * 4) != hipSuccess ||
+            hipMalloc(&ix->chunks, cap * 4) != hipSuccess || hipMalloc(&ix->chunk_inc, cap * 4) != hipSuccess ||
+            hipMalloc(&ix->scan_temp, std::max<size_t>(ix->scan_temp_bytes, 16)) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(ctx, MG_ERR_NOMEM, "compare: no device memory for the merge work list");
+        }
+        ix->seg_rows = cap;
+    }
     a.cand = ix->cand;
+    a.res = ix->res;
     a.cand_cap = ix->cand_cap;
+    a.seg_base = ix->seg_base;
+    a.seg_cnt = ix->seg_cnt;
+    a.chunk_inc = ix->chunk_inc;
     HIP_TRY(ctx, hipMemsetAsync(ix->counters, 0, 4 * 8, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ix->seg_cnt, 0, nrows * 4, ctx->stream));
     prof_begin(ctx, ctx->prof_discover);
     hipError_t e = mg::launch_sparse_discover(a, false, ctx->stream);
     prof_end(ctx, ctx->prof_discover);
     if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare (discover): ") + hipGetErrorString(e));
+    bool by_rows = mg::sparse_merge_rows_supported(a.rs_row);
+    if (const char *ev = getenv("MASHGPU_SPARSE_MERGE")) by_rows = by_rows && strcmp(ev, "lanes") != 0;
     prof_begin(ctx, ctx->prof_merge);
-    e = mg::launch_sparse_merge(a, plan->cand, (uint32_t)ctx->cu_count, ctx->stream);
+    e = by_rows ? mg::launch_sparse_merge_rows(a, plan->cand, ix->chunks, ix->scan_temp, ix->scan_temp_bytes, ctx->stream)
+                : mg::launch_sparse_merge(a, plan->cand, (uint32_t)ctx->cu_count, ctx->stream);
     prof_end(ctx, ctx->prof_merge);
     if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare (merge): ") + hipGetErrorString(e));
+    if (overlap) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));      // the fill is done
+    e = mg::launch_sparse_scatter(a, plan->cand, (uint32_t)ctx->cu_count, ctx->stream);
+    if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare (scatter): ") + hipGetErrorString(e));
     if (!ctx->async || !triangle) {
         // the candidate list was sized from the counting pass of the same rows: an overflow means the
         // tables changed under the cache (mg_table_wrap_dev's contract forbids it)

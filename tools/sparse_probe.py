@@ -14,6 +14,7 @@ ap.add_argument("--n", type=int, default=100000)
 ap.add_argument("--s", type=int, default=1000)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--no-dense", action="store_true")
+ap.add_argument("--variants", default="", help="extra sparse runs: name:ENV=V,ENV=V;name2:...")
 args = ap.parse_args()
 torch.cuda.init()
 dev = torch.device("cuda", 0)
@@ -32,8 +33,14 @@ def sums():
     return [int(out[:, 0].sum(dtype=torch.int64).item()), int(out[:, 1].sum(dtype=torch.int64).item())]
 
 
-for engine in (["sparse"] if args.no_dense else ["sparse", "merged"]):
+runs = [("sparse", "sparse", {})] + ([] if args.no_dense else [("merged", "merged", {})])
+for v in filter(None, args.variants.split(";")):
+    name, _, envs = v.partition(":")
+    runs.append((name, "sparse", dict(kv.split("=") for kv in envs.split(",") if kv)))
+for name, engine, extra in runs:
     os.environ["MASHGPU_COMPARE_KERNEL"] = engine
+    for k_, v_ in extra.items():
+        os.environ[k_] = v_
     out.zero_()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -57,7 +64,9 @@ for engine in (["sparse"] if args.no_dense else ["sparse", "merged"]):
             row[name] = {"avg_ms": ms, "launches": k}
     eng.prof_enable(False)
     row["checksum_after_steps"] = sums()
-    res[engine] = row
+    res[name] = row
+    for k_ in extra:
+        os.environ.pop(k_, None)
 os.environ.pop("MASHGPU_COMPARE_KERNEL", None)
 # what the default dispatch picks
 eng.prof_enable(True)
