@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void sp_discover_kernel(SparseArgs a)
         if (len != 0 && len <= SHORT) {
             for (uint32_t t = 0; t < len; t++) {
                 const uint32_t r = a.sorted_rows[lh.x + t];
-                atomicOr(&bm[r >> 5], 1u << (r & 31u));
+                if (!((bm[r >> 5] >> (r & 31u)) & 1u)) atomicOr(&bm[r >> 5], 1u << (r & 31u));
             }
         }
         uint64_t longm = __ballot(len > SHORT);
@@ -257,9 +257,11 @@ __global__ __launch_bounds__(256) void sp_discover_kernel(SparseArgs a)
             longm &= longm - 1;
             const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)lh.x, l);
             const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)lh.y, l);
+            // (test before set: the rows of a clade name each other in every one of their runs, and
+            //  consecutive rows share a word -- reads of one word broadcast, atomics on it queue up)
             for (uint32_t q = lo + lane; q < hi; q += 64u) {
                 const uint32_t r = a.sorted_rows[q];
-                atomicOr(&bm[r >> 5], 1u << (r & 31u));
+                if (!((bm[r >> 5] >> (r & 31u)) & 1u)) atomicOr(&bm[r >> 5], 1u << (r & 31u));
             }
         }
     }

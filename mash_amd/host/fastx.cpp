@@ -3,6 +3,7 @@
 
 #include <errno.h>
 #include <fcntl.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <cctype>
@@ -22,14 +23,21 @@ bool Reader::open(const std::string &path)
         // of the time of a collection of thousands of small genomes
         const int fd = ::open(path.c_str(), O_RDONLY);
         if (fd < 0) return false;
-        unsigned char magic[2] = {0, 0};
-        const ssize_t got = ::read(fd, magic, 2);
-        if (!(got == 2 && magic[0] == 0x1f && magic[1] == 0x8b)) {
-            if (::lseek(fd, 0, SEEK_SET) == 0) { fd_ = fd; return true; }
+        // Only a REGULAR file can be probed and rewound.  A FIFO, a process substitution or
+        // /dev/stdin would lose the probed bytes, so the untouched descriptor goes to zlib, which
+        // handles both plain and gzipped streams (as the reference's gzopen does).
+        struct stat st;
+        if (::fstat(fd, &st) == 0 && S_ISREG(st.st_mode)) {
+            unsigned char magic[2] = {0, 0};
+            const ssize_t got = ::pread(fd, magic, 2, 0);          // does not move the file offset
+            if (!(got == 2 && magic[0] == 0x1f && magic[1] == 0x8b)) { fd_ = fd; return true; }
         }
-        ::close(fd);                                   // gzip (or unseekable): through zlib
+        f_ = gzdopen(fd, "r");                                    // owns fd from here on
+        if (!f_) { ::close(fd); return false; }
+        gzbuffer(f_, 1 << 18);
+        return true;
     }
-    f_ = path == "-" ? gzdopen(fileno(stdin), "r") : gzopen(path.c_str(), "r");
+    f_ = gzdopen(fileno(stdin), "r");
     if (f_) gzbuffer(f_, 1 << 18);
     return f_ != nullptr;
 }

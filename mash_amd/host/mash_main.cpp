@@ -172,6 +172,7 @@ struct Params {                               // Sketch::Parameters (Sketch.h:34
     float warning = 0;
     uint64_t genome_size = 0;
     uint32_t min_copies = 1;                  // minCov (-m)
+    bool never_admit = false;                 // -m 0: the reference's heap admits no hash at all (an empty sketch)
     double target_cov = 0;                    // targetCov (-c)
     uint64_t bloom_bytes = 0;                 // memoryBound (-b)
     int threads = 1;                          // -p: files parsed concurrently (the GPU does the sketching)
@@ -220,6 +221,9 @@ int sketch_parameter_setup(Params &p, const Cmd &c)
         p.reads = true;
         if (c.o("targetCov").active) p.target_cov = c.o("targetCov").num;          // sketchParameterSetup.cpp:24
         if (c.o("minCov").num >= 1) p.min_copies = (uint32_t)c.o("minCov").num;   // Sketch.cpp:1156 (reads mode only)
+        // -m 0: multiplicityMinimum - 1 wraps (uint64_t), no pending count ever equals it, so the
+        // reference's heap admits nothing (MinHashHeap.cpp:96-118): an empty sketch
+        else if (c.o("minCov").active) p.never_admit = true;
     }
     if (c.o("genome").active) { p.reads = true; p.genome_size = (uint64_t)c.o("genome").num; }
     if (p.reads) p.counts = true;
@@ -264,8 +268,9 @@ struct SketchSet {                            // the part of class Sketch the co
     double kmer_space() const { return std::pow((double)p.alphabet_size, (double)p.kmer); }   // Sketch.cpp:509
 };
 
-// Every visible GPU by default (MASH_GPU_DEVICES="0,1,..." picks some, MASH_GPU_DEVICE=<n> one):
-// a local communicator -- one context per device, RCCL between them.  `ctx` is the first
+// One device by default; more on request (MASH_GPU_DEVICES=all or "0,1,...", MASH_GPU_DEVICE=<n> picks the one):
+// a local communicator -- one context per device, RCCL between them (MASH_GPU_DEVICES=all or a list;
+// one device, device 0 or MASH_GPU_DEVICE, without it).  `ctx` is the first
 // device's context: sketching and screening run there, `dist` and `triangle` shard their row
 // blocks over all of them (mg_compare_*_sharded_host; the reference fans the same loops out to
 // its -p threads, CommandTriangle.cpp:129-139, CommandDistance.cpp:195-232).
@@ -277,6 +282,14 @@ struct Gpu {
         vector<int> devs;
         if (const char *e = getenv("MASH_GPU_DEVICE")) devs.push_back(atoi(e));
         else if (const char *l = getenv("MASH_GPU_DEVICES")) {
+            // "all": every visible GPU; else a comma separated list.  Without the variable ONE device is
+            // used: more GPUs mean a communicator (RCCL start-up: seconds) that small jobs never earn
+            // back, so the caller asks for them.
+            if (strcmp(l, "all") == 0) {
+                const int n = mg_device_count();
+                for (int i = 0; i < n; i++) devs.push_back(i);
+                l = "";
+            }
             for (const char *q = l; *q;) {
                 char *end;
                 const long v = strtol(q, &end, 10);
@@ -284,9 +297,6 @@ struct Gpu {
                 devs.push_back((int)v);
                 q = *end == ',' ? end + 1 : end;
             }
-        } else {
-            const int n = mg_device_count();
-            for (int i = 0; i < n; i++) devs.push_back(i);
         }
         if (devs.empty()) devs.push_back(0);
         if (mg_comm_create_local(devs.data(), (int)devs.size(), &comm) != MG_OK) {
@@ -525,8 +535,9 @@ void sketch_reads(Gpu &gpu, SketchSet &set, const vector<string> &files)
     // as the reference's reader loop does (Sketch.cpp:1258): neither host nor device ever holds
     // more than one chunk.
     // (-b, the Bloom filter in front of the heap, is order-dependent too and takes the same route)
-    const bool cov_mode = set.p.target_cov > 0 || set.p.bloom_bytes > 0;
-    b.stream = !cov_mode && !getenv("MASH_AMD_NO_STREAM");
+    const bool none = set.p.never_admit;          // -m 0: every record is read and counted, no hash is kept
+    const bool cov_mode = !none && (set.p.target_cov > 0 || set.p.bloom_bytes > 0);
+    b.stream = !none && !cov_mode && !getenv("MASH_AMD_NO_STREAM");
     ensure_session(gpu, set, b);
     mg_reads_session *rs = nullptr;
     size_t reads_chunk = 64u << 20;
@@ -564,7 +575,7 @@ void sketch_reads(Gpu &gpu, SketchSet &set, const vector<string> &files)
                 else ref.comment = rec.name + " " + rec.comment;
             }
             count++;
-            b.add_record(rec.seq);
+            if (!none) b.add_record(rec.seq);
             it++;
             if (it == readers.size()) it = 0;
             if (cov_mode && b.bases.size() >= reads_chunk) {
@@ -602,6 +613,9 @@ void sketch_reads(Gpu &gpu, SketchSet &set, const vector<string> &files)
         ref.hashes.assign(hashes.begin(), hashes.begin() + nh);
         ref.counts.assign(counts.begin(), counts.begin() + nh);
         wrap_comment(reads_used);                              // the reference counts the reads it consumed
+        set.refs.push_back(std::move(ref));
+    } else if (none) {
+        wrap_comment(reads_used);
         set.refs.push_back(std::move(ref));
     } else {
         wrap_comment(reads_used);
@@ -884,7 +898,7 @@ int cmd_sketch(int argc, const char **argv)
         cout << "\nUsage:\n\n  mash sketch [options] <input> [<input>] ...\n\n"
                 "Create a sketch file (.msh) from fasta/fastq inputs (gzipped or not) on the GPU.\n"
                 "Options: -l -o <prefix> -I <id> -C <comment> -p <threads> -k <1-32> -s <size> -S <seed> -i -n -a -z <alphabet> -Z -w <p>\n"
-                "Reads:   -r  -m <min copies> (0 is taken as 1: the reference's behaviour for 0 is undefined)  -c <target coverage>\n"
+                "Reads:   -r  -m <min copies> (0 keeps no hash, as in the reference: refused unless -g gives a length)  -c <target coverage>\n"
                 "         -b <Bloom filter bytes, K/M/G/T>  -g <genome size>  -M (store multiplicities)\n\n";
         return 0;
     }
@@ -1022,7 +1036,12 @@ bool fetch_results(Gpu &gpu, vector<mg_result> &res, Call call)
         res.resize(n);
         rc = call(res.data(), (uint64_t)res.size(), &n);
     }
-    if (rc != MG_OK) { cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl; return false; }
+    if (rc != MG_OK) {
+        // the sharded calls record their error in the communicator (or a shard's context)
+        const char *m = mg_comm_last_error(gpu.comm);
+        cerr << "ERROR: " << ((m && *m) ? m : mg_last_error(gpu.ctx)) << endl;
+        return false;
+    }
     res.resize(n);
     return true;
 }

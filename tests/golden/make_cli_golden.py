@@ -182,7 +182,16 @@ READS_Q = [
 ]
 
 
-UNCONFIRMED = set()        # names of cases not yet replayed on a GPU (BLOOM and READS_Q were confirmed in round 2)
+# Sixth batch: -m 0.  multiplicityMinimum - 1 wraps (uint64_t), no pending count ever equals it, the heap
+# admits nothing (MinHashHeap.cpp:96-118): an empty sketch, refused unless -g supplies a length
+# (Sketch.cpp:1272-1314; the refusal itself is compared on the CPU in tests/test_cli.py).
+M0 = [
+    ("m0_sketch_genome_size", [["sketch", "-m", "0", "-g", "30k", "-s", "100", "-o", "m0", "reads.fq"]], ["info", "-d", "m0.msh"]),
+    ("m0_sketch_cov", [["sketch", "-m", "0", "-c", "2", "-g", "1000", "-s", "50", "-o", "m0c", "reads.fq"]], ["info", "-t", "m0c.msh"]),
+    ("m0_dist_genome_size", [["sketch", "-s", "300", "-o", "a", "g1.fa", "g2.fa", "g3.fa"]], ["dist", "-m", "0", "-g", "500", "a.msh", "reads.fq"]),
+]
+
+UNCONFIRMED = {"m0_sketch_genome_size", "m0_sketch_cov", "m0_dist_genome_size"}        # not yet replayed on a GPU
 
 
 def main():
@@ -192,7 +201,7 @@ def main():
     os.makedirs(f"{OUT}/in")
     make_inputs(f"{OUT}/in")
     manifest = []
-    for name, setup, cmd in CASES + EXTRA + C5 + BLOOM + READS_Q:
+    for name, setup, cmd in CASES + EXTRA + C5 + BLOOM + READS_Q + M0:
         d = tempfile.mkdtemp(prefix="cligold_")
         for f in os.listdir(f"{OUT}/in"):
             shutil.copy(f"{OUT}/in/{f}", d)

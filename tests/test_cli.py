@@ -256,6 +256,40 @@ def test_fastx_reader_matches_bytewise_kseq_on_random_input(built, tmp_path):
         assert status == want_status and got == want, trial
 
 
+def test_fastx_reader_on_pipes(built, tmp_path):
+    """Unseekable inputs -- a FIFO, as `<(zcat x.gz)` or /dev/stdin give -- carry plain or gzipped
+    data and must yield the same records as the regular file: nothing may be read from the
+    descriptor before zlib gets it (the first record used to be lost)."""
+    import gzip
+    import threading
+    lib = C.CDLL(os.path.join(ROOT, "mash_amd", "libmshio.so"))
+    lib.fastx_dump.restype = C.c_long
+    lib.fastx_dump.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_ulonglong)]
+    body = b">a first\nACGTACGTAA\nCCGG\n>b\nTTTTGGGG\n@c q\nACGT\n+\nIIII\n"
+
+    def dump(path):
+        out, ln = C.c_char_p(), C.c_ulonglong()
+        status = lib.fastx_dump(str(path).encode(), C.byref(out), C.byref(ln))
+        return status, C.string_at(out, ln.value)
+
+    plain = tmp_path / "x.fa"
+    plain.write_bytes(body)
+    want = dump(plain)
+    assert want[1].count(b"\n") == 3
+    gz = tmp_path / "x.fa.gz"
+    gz.write_bytes(gzip.compress(body))
+    assert dump(gz) == want
+    for payload in (body, gzip.compress(body)):
+        fifo = tmp_path / "pipe"
+        os.mkfifo(fifo)
+        t = threading.Thread(target=lambda: open(fifo, "wb").write(payload))
+        t.start()
+        got = dump(fifo)
+        t.join()
+        os.unlink(fifo)
+        assert got == want
+
+
 # ---------------------------------------------------------------------------------- GPU
 
 @pytest.mark.gpu
@@ -339,6 +373,29 @@ def test_make_test_recipe_on_gpu(built, tmp_path, oracle):
     assert out_t[0] == "#query\tgenome1.fna\tgenome2.fna\tgenome3.fna" and out_t[1] == "reads\t0.12101\t0.12827\t0.12101"
     out_d = run("dist", "-d", "0.125", "genomes.msh", "reads.msh", cwd=tmp_path).stdout.splitlines()
     assert len(out_d) == 2 and all("0.12101" in l for l in out_d)
+
+
+@pytest.mark.gpu
+def test_min_copies_zero_keeps_nothing_like_the_reference(built, tmp_path):
+    """-m 0: `multiplicityMinimum - 1` wraps in the reference's heap (MinHashHeap.cpp:96-118, uint64_t),
+    no pending count ever equals it and nothing is admitted: the sketch is empty, which sketchFile
+    refuses (Sketch.cpp:1302-1314) unless -g supplies a length.  Same text, same exit status; with -g
+    the three m0_* fixtures of the reference CLI compare the written sketch."""
+    import gzip, shutil
+    with gzip.open(os.path.join(GOLD, "reads1.fastq.gz"), "rb") as fi, open(tmp_path / "r.fq", "wb") as fo:
+        shutil.copyfileobj(fi, fo)
+    ours = subprocess.run([MASH, "sketch", "-m", "0", "-o", "x", "r.fq"], cwd=tmp_path, capture_output=True)
+    assert ours.returncode == 1 and not (tmp_path / "x.msh").exists()
+    assert ours.stderr.decode().strip().splitlines()[-1] == 'ERROR: Did not find fasta records in "input files".'
+    ref = os.path.join(ROOT, "oracle", "_ref", "mash-ref")
+    if os.path.exists(ref):
+        theirs = subprocess.run([ref, "sketch", "-m", "0", "-o", "y", "r.fq"], cwd=tmp_path, capture_output=True)
+        assert (theirs.returncode, theirs.stderr) == (ours.returncode, ours.stderr)
+        for extra in (["-g", "12345"], ["-g", "777", "-c", "3"]):
+            a = subprocess.run([MASH, "sketch", "-m", "0", *extra, "-o", "x", "r.fq"], cwd=tmp_path, capture_output=True)
+            b = subprocess.run([ref, "sketch", "-m", "0", *extra, "-o", "y", "r.fq"], cwd=tmp_path, capture_output=True)
+            assert (a.returncode, a.stderr.replace(b"x.msh", b"y.msh")) == (b.returncode, b.stderr)
+            assert (tmp_path / "x.msh").read_bytes() == (tmp_path / "y.msh").read_bytes()
 
 
 @pytest.mark.gpu

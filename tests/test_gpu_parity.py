@@ -1067,6 +1067,67 @@ def test_device_finish_equals_host_finish(eng, oracle, golden_dir, max_d, max_p)
         t.free()
 
 
+def test_device_finish_on_exact_p_values(eng, golden_dir):
+    """The 4812 exact p-values of tests/golden/binom_exact_pairs.json through the DEVICE tail
+    (mg_finish_tri_dev, finish.hip): the counts of a pair are set to a case's {x, n} and the two rows
+    carry its genome lengths, so the device computes r from the lengths and the tail exactly as for a
+    real pair.  Device == host bit for bit and within 1 ulp of the exact value, down through the
+    denormals to 0 (tests/test_pvalue_exact.py holds the host side of the same cases)."""
+    import json
+    import struct
+    import torch
+    cases = json.load(open(os.path.join(golden_dir, "binom_exact_pairs.json")))
+    lens = sorted({c["len_ref"] for c in cases} | {c["len_qry"] for c in cases})
+    pos = {l: k for k, l in enumerate(lens)}
+    n = 2 * len(lens)                                              # every length twice: (len, len) pairs exist too
+    lengths = np.repeat(np.array(lens, dtype=np.uint64), 2)
+    smax = max(c["n"] for c in cases)                              # the table's sketch size bounds the denominators
+    table = np.full((n, smax), np.uint64(abi.HASH_PAD), dtype=np.uint64)
+    t = eng.table_upload(table, np.zeros(n, np.uint32), lengths)
+    npairs = n * (n - 1) // 2
+    by_space = {}
+    for c in cases:
+        a, b = pos[c["len_ref"]], pos[c["len_qry"]]
+        i, j = (2 * a, 2 * b) if a != b else (2 * a + 1, 2 * a)
+        if i < j:
+            i, j = j, i
+        by_space.setdefault(c["kmer_space"], {}).setdefault(i * (i - 1) // 2 + j, []).append(c)
+    dev = torch.device("cuda", 0)
+    checked = zeros = 0
+
+    def ordint(x):
+        v = struct.unpack("<q", struct.pack("<d", x))[0]
+        return v if v >= 0 else -(v & 0x7FFFFFFFFFFFFFFF)
+
+    for ks_hex, slots in by_space.items():
+        ks = float.fromhex(ks_hex)
+        rounds = max(len(v) for v in slots.values())
+        for rnd in range(rounds):
+            counts = np.zeros(npairs, dtype=abi.COUNTS_DTYPE)
+            counts["denom"] = 1
+            want = {}
+            for idx, lst in slots.items():
+                if rnd < len(lst):
+                    counts[idx] = (lst[rnd]["x"], lst[rnd]["n"])
+                    want[idx] = lst[rnd]
+            d_counts = torch.from_numpy(counts.view(np.uint8)).to(dev)
+            d_out = torch.zeros(npairs * abi.PAIR_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            eng.finish_tri_dev(t, d_counts.data_ptr(), 0, n, 21, ks, -1.0, -1.0, d_out.data_ptr())
+            eng.synchronize()
+            got = d_out.cpu().numpy().view(abi.PAIR_DTYPE)
+            host = eng.finish_tri(counts, lengths, 0, n, 21, ks)
+            assert _same_bits(got["p_value"], host["p_value"]) and _same_bits(got["distance"], host["distance"])
+            for idx, c in want.items():
+                exact = float.fromhex(c["exact"])
+                pv = float(got["p_value"][idx])
+                assert abs(ordint(pv) - ordint(exact)) <= 1, (c, pv)
+                checked += 1
+                zeros += exact == 0.0
+    assert checked == len(cases) and zeros >= 100
+    t.free()
+
+
 @pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
 def test_sharded_compare_equals_single_gpu(eng, oracle, devices, monkeypatch):
     """The multi-GPU entry points (mg_comm local mode, mg_dtable, mg_compare_*_sharded_host): row

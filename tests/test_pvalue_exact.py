@@ -125,3 +125,33 @@ def test_oracle_binomial_is_an_independent_algorithm(oracle, cases):
         else:
             assert got < 1e-280
     print("\noracle (Lentz) worst relative error vs exact: %.2e" % worst)
+
+
+@pytest.fixture(scope="module")
+def pair_cases(golden_dir):
+    out = []
+    for c in json.load(open(os.path.join(golden_dir, "binom_exact_pairs.json"))):
+        out.append(dict(x=c["x"], n=c["n"], len_ref=c["len_ref"], len_qry=c["len_qry"], kmer_space=float.fromhex(c["kmer_space"]),
+                        r=float.fromhex(c["r"]), exact=float.fromhex(c["exact"])))
+    return out
+
+
+def test_pair_p_value_within_one_ulp_of_exact(lib, pair_cases):
+    """pValue(x, lenRef, lenQry, kmerSpace, sketchSize) as compareSketches calls it (CommandDistance.cpp:427-448):
+    r from the two genome lengths, then the tail -- 4812 cases against exact values
+    (tests/golden/make_binom_exact_pairs.py), the form in which the tail also runs on the device
+    (tests/test_gpu_parity.py::test_device_finish_on_exact_p_values feeds the same cases to finish.hip)."""
+    lib.mg_p_value.restype = C.c_double
+    lib.mg_p_value.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_double, C.c_uint64]
+    worst = 0
+    for c in pair_cases:
+        pX = 1.0 / (1.0 + c["kmer_space"] / float(c["len_ref"]))
+        pY = 1.0 / (1.0 + c["kmer_space"] / float(c["len_qry"]))
+        assert pX * pY / (pX + pY - pX * pY) == c["r"]                 # the fixture's r is this machine's r
+        got = lib.mg_p_value(c["x"], c["len_ref"], c["len_qry"], c["kmer_space"], c["n"])
+        u = ulps(got, c["exact"])
+        worst = max(worst, u)
+        assert u <= 1, (c, got)
+        assert "%g" % got == "%g" % c["exact"], (c, got)
+    assert sum(1 for c in pair_cases if c["exact"] == 0.0) >= 100 and sum(1 for c in pair_cases if 0.0 < c["exact"] < 2.3e-308) >= 5
+    print("\npair p-values: %d cases, worst %d ulp" % (len(pair_cases), worst))

@@ -52,11 +52,18 @@ for name, h, nh, ln in tables():
         mp = m * (m - 1) // 2
         eng.compare_tri_dev(t, 0, m, out.data_ptr())
         torch.cuda.synchronize()
+        eng.prof_enable(True)
+        eng.prof_reset()
         t0 = time.perf_counter()
         eng.compare_tri_dev(t, 0, m, out.data_ptr())
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         row[e] = {"pairs_per_s": mp / dt, "ms": dt * 1e3, "rows": m}
+        for phase in ("compare", "compare_fill", "compare_discover", "compare_merge"):
+            ms, k = eng.prof_avg_ms(phase)
+            if k:
+                row[e][phase + "_ms"] = round(ms * k, 3)
+        eng.prof_enable(False)
         sums[e] = (int(out[:mp, 0].sum(dtype=torch.int64).item()), int(out[:mp, 1].sum(dtype=torch.int64).item())) if m == n else None
     full = [v for v in sums.values() if v is not None]
     row["engines_agree"] = all(v == full[0] for v in full)

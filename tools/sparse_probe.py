@@ -58,10 +58,10 @@ for name, engine, extra in runs:
     dt = (time.perf_counter() - t0) / args.steps
     row["ms_per_step"] = dt * 1e3
     row["pairs_per_s"] = pairs / dt
-    for name in ("compare", "compare_fill", "compare_discover", "compare_merge", "compare_index"):
-        ms, k = eng.prof_avg_ms(name)
+    for phase in ("compare", "compare_fill", "compare_discover", "compare_merge", "compare_index"):
+        ms, k = eng.prof_avg_ms(phase)
         if k:
-            row[name] = {"avg_ms": ms, "launches": k}
+            row[phase] = {"avg_ms": ms, "launches": k}
     eng.prof_enable(False)
     row["checksum_after_steps"] = sums()
     res[name] = row
