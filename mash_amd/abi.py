@@ -343,8 +343,8 @@ class LocalComm:
         h = C.c_void_p()
         self._check(self.lib.mg_dscreen_create(self.h, C.byref(p), d, int(translate), C.byref(h)))
         try:
-            for recs in batches:
-                blob = np.frombuffer(join_records(recs), dtype=np.uint8)
+            for recs in batches:                      # a list of records, or the bytes already joined (uint8 array)
+                blob = np.ascontiguousarray(recs) if isinstance(recs, np.ndarray) else np.frombuffer(join_records(recs), dtype=np.uint8)
                 self._check(self.lib.mg_dscreen_add_host(h, blob.ctypes.data, len(blob)))
             counts = np.zeros((n, s), dtype=np.uint32)
             mix = np.zeros(int(p.sketch_size), dtype=np.uint64)
@@ -684,8 +684,8 @@ class MashGpu:
         h = C.c_void_p()
         self._check(self.lib.mg_screen_create(self.ctx, C.byref(p), db.handle, C.byref(h)))
         try:
-            for recs in batches:
-                blob = np.frombuffer(join_records(recs), dtype=np.uint8)
+            for recs in batches:                      # a list of records, or the bytes already joined (uint8 array)
+                blob = np.ascontiguousarray(recs) if isinstance(recs, np.ndarray) else np.frombuffer(join_records(recs), dtype=np.uint8)
                 self._check(self.lib.mg_screen_add_host(h, blob.ctypes.data, len(blob)))
             n, s = db.rows, db.sketch_size
             counts = np.zeros((n, s), dtype=np.uint32)

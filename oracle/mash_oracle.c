@@ -303,9 +303,12 @@ static const char complement_tab[26] = {
     'N','N','N','N','Y','S','A','A','B','W','N','R','N'
 };
 
-/* addMinHashes — Sketch.cpp:512-583 */
-void oracle_add_min_hashes(oracle_heap *h, char *seq, uint64_t length, const oracle_params *p)
+/* addMinHashes — Sketch.cpp:512-583.  With h == NULL the hashes go to out[] in k-mer order instead
+ * of a heap (the loop mash screen's hashSequence runs over every record, CommandScreen.cpp:533-575,
+ * is this one with a table lookup in place of the heap); returns their number. */
+static uint64_t scan_kmers(oracle_heap *h, uint64_t *out, char *seq, uint64_t length, const oracle_params *p)
 {
+    uint64_t emitted = 0;
     const int k = p->kmer_size;
     if (!p->preserve_case)                          /* :524-530 */
         for (uint64_t i = 0; i < length; i++)
@@ -340,10 +343,33 @@ void oracle_add_min_hashes(oracle_heap *h, char *seq, uint64_t length, const ora
                 const char *rv = rev + length - i - k;
                 if (memcmp(fwd, rv, (size_t)k) > 0) kmer = rv;   /* :569-571 */
             }
-            oracle_heap_try_insert(h, oracle_get_hash(kmer, k, p->seed, p->use64));
+            const uint64_t hv = oracle_get_hash(kmer, k, p->seed, p->use64);
+            if (h) oracle_heap_try_insert(h, hv);
+            else out[emitted] = hv;
+            emitted++;
         }
     }
     free(rev);
+    return emitted;
+}
+
+void oracle_add_min_hashes(oracle_heap *h, char *seq, uint64_t length, const oracle_params *p)
+{
+    (void)scan_kmers(h, NULL, seq, length, p);
+}
+
+/* Every valid k-mer hash of every record (records of at least k bytes), in order: what hashSequence
+ * looks up in the screen's table.  out must hold sum(max(0, len - k + 1)) entries; seq bytes are
+ * uppercased in place as the reference does. */
+uint64_t oracle_kmer_hashes(char *bases, const uint64_t *rec_off, uint64_t nrec, const oracle_params *p, uint64_t *out)
+{
+    uint64_t n = 0;
+    for (uint64_t r = 0; r < nrec; r++) {
+        const uint64_t l = rec_off[r + 1] - rec_off[r];
+        if (l < (uint64_t)p->kmer_size) continue;
+        n += scan_kmers(NULL, out + n, bases + rec_off[r], l, p);
+    }
+    return n;
 }
 
 /* sketchFile (concatenated) — Sketch.cpp:1147-1336; sketchSequence — :1338-1365 */

@@ -78,6 +78,9 @@ uint64_t     oracle_heap_to_list(const oracle_heap *h, uint64_t *hashes, uint32_
 /* addMinHashes, Sketch.cpp:512-583.  `seq` is modified in place (uppercased)
  * exactly as the reference does. */
 void oracle_add_min_hashes(oracle_heap *h, char *seq, uint64_t length, const oracle_params *p);
+/* the same loop without a heap: every valid k-mer hash of every record, in order (what mash screen's
+ * hashSequence looks up, CommandScreen.cpp:533-575); returns their number */
+uint64_t oracle_kmer_hashes(char *bases, const uint64_t *rec_off, uint64_t nrec, const oracle_params *p, uint64_t *out);
 
 /*
  * One sketch from a list of records, following sketchFile (Sketch.cpp:1147-1336,

@@ -171,6 +171,21 @@ class Oracle:
            C.byref(n), C.byref(length), C.byref(setsz), C.byref(used), C.byref(mult))
         return hashes[: n.value].copy(), counts[: n.value].copy(), float(setsz.value), int(used.value), float(mult.value)
 
+    def kmer_hashes(self, bases, rec_off, p):
+        """Hash of every valid k-mer of every record (C restatement only): bases = writable uint8 array
+        (uppercased in place), rec_off = uint64[nrec + 1]."""
+        from ctypes import CDLL
+        lib = self.lib if not self.is_ref else CDLL(os.path.join(_HERE, "libmash_oracle.so"))
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        rec_off = np.ascontiguousarray(rec_off, dtype=np.uint64)
+        lens = np.diff(rec_off).astype(np.int64)
+        k = int(p.kmer_size)
+        cap = int(np.maximum(lens - k + 1, 0).sum())
+        out = np.zeros(max(cap, 1), dtype=np.uint64)
+        lib.oracle_kmer_hashes.restype = C.c_uint64
+        n = lib.oracle_kmer_hashes(bases.ctypes.data_as(C.c_char_p), _u64p(rec_off), C.c_uint64(len(rec_off) - 1), C.byref(p), _u64p(out))
+        return out[: int(n)]
+
     # -- comparing ---------------------------------------------------------
     def compare(self, a, b, len_a, len_b, s, k, kmer_space, max_d=-1.0, max_p=-1.0, use64=True):
         a = np.ascontiguousarray(a, dtype=np.uint64)

@@ -1385,6 +1385,79 @@ def test_screen_counts_vs_oracle(eng, oracle):
     db.free()
 
 
+def test_screen_config4_scale_vs_oracle(eng, oracle):
+    """BASELINE config 4 at its DATABASE scale: 100 000 sketches (10^8 keys in the open-addressing
+    table: probe chains, load factor, u32 counters at the size bench.py runs) against 10^6 reads
+    sampled as bench.py samples them.  The oracle hashes every k-mer of every read on the host
+    (oracle_kmer_hashes: the reference's loop, Sketch.cpp:512-583 / CommandScreen.cpp:533-575); the
+    observation counts of 240 database rows (rows the reads come from and rows they do not), the
+    mixture's own bottom-s sketch and the number of distinct keys must agree exactly -- through one
+    mg_screen and through mg_dscreen on three contexts."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from workloads import synth_torch
+    dev = torch.device("cuda", 0)
+    S, K, RL, NSRC, GL, NREADS, NDB = 1000, 21, 150, 1000, 1_000_000, 1_000_000, 100_000
+    p = eng.params(k=K, s=S)
+    op = oracle.params(k=K, s=S)
+    genomes = synth_torch.synthetic_genomes(0, NSRC, GL, device=dev, stride=40000)
+    gh = torch.empty((NSRC, S), dtype=torch.int64, device=dev)
+    gn = torch.empty(NSRC, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    eng.sketch_dev(genomes.data_ptr(), NSRC * GL, np.arange(NSRC + 1, dtype=np.uint64) * np.uint64(GL), p, gh.data_ptr(), gn.data_ptr())
+    fh, fn, _ = synth_torch.clustered_sketch_table(NDB - NSRC, S, clusters=(NDB - NSRC) // 100, device=dev)
+    db_h = torch.cat([gh, fh], 0).contiguous()
+    db_n = torch.cat([gn, fn], 0).contiguous()
+    reads = synth_torch.synthetic_reads(genomes, NREADS, RL, seed=7001)          # [NREADS, RL + 1], separator included
+    torch.cuda.synchronize()
+    distinct_want = int(torch.unique(db_h.flatten()).numel())                    # every row is full: no padding among them
+    assert int(db_n.min()) == S
+    del genomes, gh, fh
+    th = db_h.cpu().numpy().view(np.uint64)
+    tn = db_n.cpu().numpy().astype(np.uint32)
+    tl = np.full(NDB, GL, dtype=np.uint64)
+    host_reads = reads.cpu().numpy()
+    del reads, db_h, db_n
+    torch.cuda.empty_cache()
+    blobs = [np.ascontiguousarray(b).reshape(-1) for b in np.array_split(host_reads, 4)]
+    db = eng.table_upload(th, tn, tl)
+    counts, mix, distinct = eng.screen(db, p, blobs)
+    # ---- the oracle's side
+    rng = np.random.default_rng(4)
+    rows = np.unique(np.concatenate([rng.choice(NSRC, 120, replace=False), NSRC + rng.choice(NDB - NSRC, 117, replace=False),
+                                     [0, NSRC - 1, NDB - 1]]))
+    keys = np.unique(th[rows].reshape(-1))
+
+    def chunk(part):
+        bases = np.ascontiguousarray(part).reshape(-1).copy()
+        off = np.arange(len(part) + 1, dtype=np.uint64) * np.uint64(RL + 1)      # the separator ends no k-mer: not in the alphabet
+        H = oracle.kmer_hashes(bases, off, op)
+        idx = np.searchsorted(keys, H)
+        idx[idx == len(keys)] = 0
+        hit = keys[idx] == H
+        return np.bincount(idx[hit], minlength=len(keys)), np.unique(H)[:S], len(H)
+
+    with ThreadPoolExecutor(min(16, os.cpu_count() or 1)) as ex:
+        parts = list(ex.map(chunk, np.array_split(host_reads, 40)))
+    cnt = np.sum([q[0] for q in parts], axis=0)
+    assert sum(q[2] for q in parts) >= NREADS * (RL - K + 1) * 0.99              # every read gave its k-mers
+    want_mix = np.unique(np.concatenate([q[1] for q in parts]))[:S]
+    for i in rows:
+        exp = cnt[np.searchsorted(keys, th[i])].astype(np.uint32)
+        assert np.array_equal(counts[i], exp), i
+    assert counts[rows[rows < NSRC]].sum() > 100 * counts[rows[rows >= NSRC]].sum()   # the reads' genomes are seen, the others are not
+    assert np.array_equal(mix, want_mix)
+    assert distinct == distinct_want
+    # ---- the same through mg_dscreen on three contexts of this device
+    comm = abi.LocalComm([0, 0, 0])
+    d = comm.upload(th, tn, tl)
+    got = comm.screen(d, NDB, S, p, blobs)
+    assert np.array_equal(got[0], counts) and np.array_equal(got[1], mix) and got[2] == distinct
+    comm.free(d)
+    comm.close()
+    db.free()
+
+
 @pytest.mark.parametrize("k,nonc", [(11, False), (16, True), (27, False), (32, False), (5, True)])
 def test_screen_other_kmer_sizes(eng, oracle, k, nonc):
     """the fused sketch+probe instantiations at other k-mer sizes / forward-only k-mers"""
