@@ -13,11 +13,17 @@ ncclBroadcast inside libmashgpu; the 128-byte id travels through torch.distribut
 reported separately (`config.table_broadcast_ms`, `config.rccl_ranks`).
 
 Same JSON line, further objects:
-  roofline      dominant kernel (compare_merged_kernel): the mandated algorithmic-bytes model of
-                SURVEY §8d, plus the two bounds that mean something for a tiled kernel: `issue`
-                (wave-instructions issued vs what 1024 SIMDs can issue) and `measured_hbm_frac`
-                (PMC bytes / time / peak).  PMC-derived figures come from profiles/*.json and are
-                dropped when the kernel source they were taken on differs from the one running.
+  roofline      the kernels of one pass.  Default engine (compare_sparse.hip): fill (HBM-write bound,
+                the dominant kernel), discover, merge -- each timed with HIP events on the stream it
+                runs on.  `achieved`/`frac`: the mandated algorithmic-bytes model of SURVEY §8d over the
+                summed kernel time of a pass (a no-reuse model; it bounds nothing here); the bounds that
+                do: `write_roofline` (8 B per pair over the fill kernel's time against the HBM peak),
+                `compulsory_bytes` vs PMC `traffic`, and per kernel the share of every issue port
+                (`ports`, from profiles/compare_<leg>_pmc.json -- dropped when the kernel sources
+                differ from the ones the counters were read on).
+  brackets      SURVEY §8d's extremes at the same size: all-random, all-identical, clades of 1000
+                near-identical sketches; each verified against the tile engine (a second, independent
+                implementation) or a closed form, each with the reference's compareSketches on a sample.
   cpu_baseline  the reference's own compareSketches (oracle/_ref) on the host cores.
   host_to_host  SURVEY §8d(i)/(ii): table in HOST memory -> results in HOST memory (PCIe included),
                 on a bounded sample, and the whole C3 triangle through the thresholded path.
@@ -63,6 +69,7 @@ def parse_args():
     ap.add_argument("--no-screen", action="store_true", help="skip the tertiary screen measurement (config 4)")
     ap.add_argument("--no-c5", action="store_true", help="skip the large-sketch triangle (config 5)")
     ap.add_argument("--no-h2h", action="store_true", help="skip the host-to-host legs")
+    ap.add_argument("--no-brackets", action="store_true", help="skip SURVEY 8d's extremes (all-random / all-identical / clades)")
     ap.add_argument("--n-reads", type=int, default=10_000_000)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -90,6 +97,46 @@ def load_pmc(name, *src):
     if d.get("kernel_src_sha") != src_sha(*src):
         return None                                    # stale: the kernel changed since the counters were read
     return d
+
+
+def compare_roofline(eng, pairs, n, s, steps, pmc, engine_hint=None):
+    """Roofline object of one triangle pass from the library's HIP-event records (mg_prof_*): which
+    engine ran, its kernels' times, the mandated algorithmic model, and what actually bounds it."""
+    phases = {}
+    for name in ("compare", "compare_fill", "compare_discover", "compare_merge"):
+        ms, k = eng.prof_avg_ms(name)
+        if k:
+            phases[name] = {"avg_launch_ms": round(ms, 4), "launches_per_pass": k / steps, "ms_per_pass": round(ms * k / steps, 4)}
+    sparse = "compare_fill" in phases
+    pass_ms = sum(v["ms_per_pass"] for v in phases.values())
+    bytes_per_pair = 2 * s * 8 + 8
+    achieved = pairs * bytes_per_pair / (pass_ms * 1e-3) / 1e9 if pass_ms > 0 else 0.0
+    compulsory = pairs * 8 + n * s * 8 + n * 12           # every pair written once, the table read once
+    traffic = pmc.get("hbm_bytes_per_pass") if pmc else None
+    r = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+         "engine": "inverted index (compare_sparse.hip)" if sparse else "tiles (compare_merged.hip)",
+         "kernel": "mg::sp_fill_const_kernel" if sparse else "mg::compare_merged_kernel",
+         "kernel_ms": phases["compare_fill"]["avg_launch_ms"] if sparse else (phases.get("compare", {}).get("avg_launch_ms")),
+         "pass_ms": round(pass_ms, 3), "phases": phases, "algorithmic_bytes_per_pair": bytes_per_pair,
+         "compulsory_bytes": compulsory,
+         "traffic_over_compulsory": round(traffic / compulsory, 3) if traffic else None,
+         "measured_hbm_frac": round(traffic / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and pass_ms > 0 else None}
+    if sparse:
+        f = phases["compare_fill"]["ms_per_pass"]
+        r["write_roofline"] = {"bytes": pairs * 8, "ms": f, "achieved": round(pairs * 8 / (f * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": round(pairs * 8 / (f * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                               "what": "the fill kernel: 8 B written per pair, nothing read -- the compulsory traffic of the job"}
+    if pmc:
+        r["ports"] = {k: dict(v.get("ports", {}), ms_per_pass=v.get("ms_per_pass"), effective_clock_ghz=v.get("effective_clock_ghz"),
+                              hbm_bytes_per_pass=(v.get("hbm_read_bytes_per_pass", 0) + v.get("hbm_write_bytes_per_pass", 0)))
+                      for k, v in pmc.get("kernels", {}).items() if not v.get("cold_only")}
+        r["pmc_source"] = pmc.get("source")
+    r["note"] = ("achieved/frac: the mandated no-reuse model of SURVEY.md §8d (2*s*8+8 B per pair) over the summed kernel time of one "
+                 "pass; a pair that shares no hash costs this engine 8 written bytes, so the model exceeds the HBM peak by orders of "
+                 "magnitude and bounds nothing.  What bounds the pass: write_roofline (fill), and for discover / merge the issue ports "
+                 "listed under `ports` (each port on its own, never summed; PMC figures from profiles/, dropped when stale).")
+    return r
 
 
 def cpu_baseline_compare(table_np, nhash_np, lengths_np, budget_s):
@@ -316,8 +363,13 @@ def main():
 
     if not dry:
         torch.cuda.synchronize()       # table generation (torch stream) -> library stream
-    for _ in range(args.warmup):
+    cold_ms = None
+    for w in range(args.warmup):
+        tw = time.perf_counter()
         step()
+        if w == 0 and not dry:
+            torch.cuda.synchronize()
+            cold_ms = (time.perf_counter() - tw) * 1e3    # first call on the table: index build + counting pass + one pass
     eng.prof_enable(True)
     eng.prof_reset()
     barrier()
@@ -326,12 +378,12 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
-    kern_ms, launches = eng.prof_avg_ms("compare")
+    pmc = load_pmc("compare_c3_pmc.json", "mash_amd/csrc/compare_sparse.hip", "mash_amd/csrc/compare_merged.hip", "mash_amd/csrc/compare_internal.h") \
+        if (n == 100_000 and world == 1 and not dry) else None
+    roofline = compare_roofline(eng, my_pairs, n, S, args.steps, pmc) if not dry else {"bound": "hbm", "dry": True}
     eng.prof_enable(False)
     dt = max_over_ranks(dt)
     value = total_pairs * args.steps / dt
-    launches_per_step = launches / args.steps if args.steps else 0
-    pass_ms = kern_ms * launches_per_step          # summed launch time of one pass over this rank's rows
 
     # the produced output (outside the timed region): every pair's denom and numer, as sums
     checksum = None
@@ -345,36 +397,6 @@ def main():
         if want is not None:
             assert checksum == list(want), f"compare output checksum {checksum} != verified {want}"
 
-    # roofline of the dominant kernel on this rank
-    bytes_per_pair = 2 * S * 8 + 8
-    achieved = (my_pairs * bytes_per_pair / (pass_ms * 1e-3)) / 1e9 if pass_ms > 0 else 0.0
-    pmc = load_pmc("compare_pmc_latest.json", "mash_amd/csrc/compare_merged.hip", "mash_amd/csrc/compare_internal.h") \
-        if (n == 100_000 and world == 1) else None
-    traffic = pmc.get("hbm_bytes_per_pass") if pmc else None
-    issue = None
-    if pmc and pass_ms > 0:
-        ipp = pmc["valu_per_pair"] + pmc["salu_per_pair"] + pmc["lds_per_pair"] + pmc.get("vmem_per_pair", 0.0)
-        peak = SIMDS * CLOCK_HZ / 4.0                    # one wave-instruction per SIMD every 4 clocks
-        ach = ipp * my_pairs / (pass_ms * 1e-3)
-        issue = {"achieved": round(ach / 1e9, 2), "peak": round(peak / 1e9, 2), "unit": "G wave-instr/s",
-                 "frac": round(ach / peak, 4), "instr_per_pair": round(ipp, 2),
-                 "valu_per_pair": pmc["valu_per_pair"], "salu_per_pair": pmc["salu_per_pair"],
-                 "lds_per_pair": pmc["lds_per_pair"], "lds_active_frac": pmc.get("lds_active_frac"),
-                 "lds_bank_conflict_share": pmc.get("lds_bank_conflict_share"), "source": pmc.get("source")}
-    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": "compare_merged_kernel", "kernel_ms": round(kern_ms, 3), "launches": launches,
-                "launches_per_pass": launches_per_step, "pass_ms": round(pass_ms, 3),
-                "algorithmic_bytes_per_pair": bytes_per_pair,
-                "measured_hbm_frac": (round(traffic / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and pass_ms > 0 else None),
-                "issue": issue,
-                "note": "achieved/frac: the mandated no-reuse model of SURVEY.md §8d (2*s*8+8 B per pair) over the summed launch "
-                        "time of one pass (a pass = one launch per value window, launches_per_pass of the same kernel); every "
-                        "sketch is re-used ~1000x from LDS/L2, so frac exceeds 1 and bounds nothing.  The bounds that do: "
-                        "`issue` = wave-instructions issued (PMC VALU+SALU+LDS+VMEM per pair x pairs/s) against 1024 SIMDs x "
-                        "clock / 4, and measured_hbm_frac = PMC HBM bytes (FETCH_SIZE x2 + WRITE_SIZE) / time / 8 TB/s.  PMC "
-                        "figures are read from profiles/compare_pmc_latest.json and dropped when the kernel source differs."}
-
     result = {
         "metric": "pairwise Mash distances/sec (s=1000)",
         "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -384,7 +406,10 @@ def main():
                                f"{total_pairs} pairs/step, row-block sharded x{world}",
                    "n_sketches": n, "sketch_size": S, "kmer": K, "hash_bits": 64,
                    "parallelism": f"rowblock{world}", "table_broadcast_ms": round(bcast_ms, 2),
-                   "rccl_ranks": rccl_ranks, "comm": comm_kind, "output_checksum": checksum},
+                   "rccl_ranks": rccl_ranks, "comm": comm_kind, "output_checksum": checksum,
+                   "first_call_ms": round(cold_ms, 2) if cold_ms is not None else None,
+                   "first_call_note": "the first (untimed, warm-up) call on a table builds what later calls reuse: the inverted "
+                                      "index of the table (sort of all its hashes) and the job's candidate count"},
         "roofline": roofline,
     }
     if dry:
@@ -398,6 +423,61 @@ def main():
         result["cpu_baseline"] = cpu_baseline_compare(
             hashes[:m].cpu().numpy().view(np.uint64), nhash[:m].cpu().numpy().astype(np.uint32),
             lengths[:m].cpu().numpy().astype(np.uint64), args.cpu_seconds)
+
+    # ------------------------------------------------------------------ SURVEY 8d brackets (N=1): the extremes of the merge
+    if single and not args.no_brackets:
+        br = {}
+        gens = [("all_random", "random", lambda: synth_torch.random_sketch_table(n, S, device=dev)),
+                ("all_identical", "identical", lambda: synth_torch.identical_sketch_table(n, S, device=dev)),
+                ("clades_of_1000", "clades", lambda: synth_torch.clade_sketch_table(n, S, device=dev))]
+        bsteps = max(2, args.steps)
+        for name, leg, gen in gens:
+            try:
+                bh, bn, bl = gen()
+                torch.cuda.synchronize()
+                bt = eng.table_wrap(bh.data_ptr(), bn.data_ptr(), bl.data_ptr(), n, S, keep=(bh, bn, bl))
+                eng.compare_tri_dev(bt, 0, n, out.data_ptr())                       # warm-up: index, counting pass
+                eng.prof_enable(True)
+                eng.prof_reset()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(bsteps):
+                    eng.compare_tri_dev(bt, 0, n, out.data_ptr())
+                torch.cuda.synchronize()
+                bd = time.perf_counter() - t0
+                bpmc = load_pmc(f"compare_{leg}_pmc.json", "mash_amd/csrc/compare_sparse.hip", "mash_amd/csrc/compare_merged.hip",
+                                "mash_amd/csrc/compare_internal.h") if n == 100_000 else None
+                rf = compare_roofline(eng, total_pairs, n, S, bsteps, bpmc)
+                eng.prof_enable(False)
+                sums = [int(out[:, 0].sum(dtype=torch.int64).item()), int(out[:, 1].sum(dtype=torch.int64).item())]
+                if name == "all_identical":
+                    assert sums == [total_pairs * S, total_pairs * S], f"{name}: {sums}"
+                    how = "closed form: every pair s/s"
+                else:
+                    os.environ["MASHGPU_COMPARE_KERNEL"] = "merged"                 # the tile engine: independent code
+                    try:
+                        out.zero_()
+                        eng.compare_tri_dev(bt, 0, n, out.data_ptr())
+                        torch.cuda.synchronize()
+                    finally:
+                        os.environ.pop("MASHGPU_COMPARE_KERNEL", None)
+                    sums2 = [int(out[:, 0].sum(dtype=torch.int64).item()), int(out[:, 1].sum(dtype=torch.int64).item())]
+                    assert sums == sums2 and sums[1] == total_pairs * S, f"{name}: {sums} vs tile engine {sums2}"
+                    how = "sums over the full output equal the tile engine's (compare_merged.hip)"
+                br[name] = {"value": total_pairs * bsteps / bd, "unit": "pairs/s", "ms_per_step": bd * 1e3 / bsteps, "steps": bsteps,
+                            "mean_shared_hashes": round(sums[0] / total_pairs, 3), "output_checksum": sums, "verified": how,
+                            "roofline": rf}
+                if not args.no_cpu:
+                    m = min(n, 3000)
+                    br[name]["cpu_baseline"] = cpu_baseline_compare(bh[:m].cpu().numpy().view(np.uint64), bn[:m].cpu().numpy().astype(np.uint32),
+                                                                    bl[:m].cpu().numpy().astype(np.uint64), min(args.cpu_seconds, 4.0))
+                bt.free()
+                del bh, bn, bl
+            except Exception as e:
+                br[name] = {"error": repr(e)}
+        br["workload"] = (f"mash triangle on {n} sketches of s={S}: all-random (every sketch its own values), all-identical (n copies "
+                          f"of one sketch), clades of 1000 near-identical sketches (consecutive rows); {total_pairs} pairs per step")
+        result["brackets"] = br
 
     # ------------------------------------------------------------------ host to host, N=1
     del out
@@ -640,7 +720,11 @@ def main():
             t5 = eng.table_wrap(h5.data_ptr(), nh5.data_ptr(), l5.data_ptr(), n5, S5, keep=(h5, nh5, l5))
             pairs5 = n5 * (n5 - 1) // 2
             out5 = torch.empty((pairs5, 2), dtype=torch.int32, device=dev)
-            eng.compare_tri_dev(t5, 0, n5, out5.data_ptr())            # warm-up: prefix image, window offsets
+            torch.cuda.synchronize()
+            tc = time.perf_counter()
+            eng.compare_tri_dev(t5, 0, n5, out5.data_ptr())            # warm-up: inverted index (10^9 entries), counting pass
+            torch.cuda.synchronize()
+            cold5 = (time.perf_counter() - tc) * 1e3
             eng.prof_enable(True)
             eng.prof_reset()
             torch.cuda.synchronize()
@@ -650,24 +734,20 @@ def main():
                 eng.compare_tri_dev(t5, 0, n5, out5.data_ptr())
             torch.cuda.synchronize()
             d5 = time.perf_counter() - t0
-            k5, l5n = eng.prof_avg_ms("compare")
+            pmc5 = load_pmc("compare_c5_pmc.json", "mash_amd/csrc/compare_sparse.hip", "mash_amd/csrc/compare_merged.hip",
+                            "mash_amd/csrc/compare_internal.h") if n5 == 100_000 else None
+            rf5 = compare_roofline(eng, pairs5, n5, S5, steps5, pmc5)
             eng.prof_enable(False)
             sums5 = [int(out5[:, 0].sum(dtype=torch.int64).item()), int(out5[:, 1].sum(dtype=torch.int64).item())]
             assert int(out5[:, 1].min()) == S5 and int(out5[:, 0].max()) <= S5, "c5 output failed sanity check"
             want5 = C3_CHECKSUM.get((n5, S5))
             if want5 is not None:
                 assert sums5 == list(want5), f"c5 checksum {sums5} != verified {want5}"
-            b5 = 2 * S5 * 8 + 8
             c5.update({"value": pairs5 * steps5 / d5, "ms_per_step": d5 * 1e3 / steps5, "steps": steps5,
                        "config": {"workload": f"mash triangle, {n5} clustered synthetic sketches of s={S5} 64-bit hashes "
-                                              f"(k=31 style), {pairs5} pairs/step, 1 GPU", "output_checksum": sums5},
-                       "roofline": {"bound": "hbm", "kernel": "compare_merged_kernel (value windows)",
-                                    "kernel_ms": round(k5, 3), "launches": l5n, "launches_per_pass": l5n / steps5,
-                                    "pass_ms": round(k5 * l5n / steps5, 2),
-                                    "achieved": round(pairs5 * b5 / (k5 * l5n / steps5 * 1e-3) / 1e9, 1) if k5 > 0 else 0.0,
-                                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "frac": round(pairs5 * b5 / (k5 * l5n / steps5 * 1e-3) / 1e9 / HBM_PEAK_GBS, 3) if k5 > 0 else 0.0,
-                                    "algorithmic_bytes_per_pair": b5, "traffic": None}})
+                                              f"(k=31 style), {pairs5} pairs/step, 1 GPU", "output_checksum": sums5,
+                                  "first_call_ms": round(cold5, 1)},
+                       "roofline": rf5})
             t5.free()
             del out5, h5
         except Exception as e:

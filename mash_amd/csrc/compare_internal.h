@@ -120,7 +120,18 @@ struct SparseArgs {
     unsigned long long *seg_base;  // per discover slot (slot = row_end - 1 - row): the row's segment of the list
     uint32_t *seg_cnt;
     uint32_t *chunk_inc;           // inclusive scan of the rows' merge work items
+    // identical rows of the column table (nullptr: none): rep[row] = first row of its class; classes of two
+    // rows and more: cls_of[representative] = class id (else 0xFFFFFFFF), rows cls_rows[cls_off[id] .. cls_off[id + 1]) ascending
+    const uint32_t *rep;
+    const uint32_t *cls_of;
+    const uint32_t *cls_off;
+    const uint32_t *cls_rows;
+    const uint32_t *gstart;        // first sorted position of every value (a copy walks the whole run of a value)
 };
+hipError_t launch_sparse_row_digest(const uint64_t *hashes, uint64_t stride, const uint32_t *cnt, uint32_t n,
+                                    unsigned long long *digest, hipStream_t stream);
+hipError_t launch_sparse_row_equal(const uint64_t *hashes, uint64_t stride, const uint32_t *cnt, const uint2 *pairs, uint32_t npairs,
+                                   uint32_t *equal, hipStream_t stream);
 size_t sparse_sort_temp_bytes(uint32_t E, uint32_t end_bit);
 uint32_t sparse_img_stride(uint32_t s);          // row stride of a code image
 hipError_t sparse_build_index(const uint64_t *hashes, uint64_t stride, const uint32_t *off, uint32_t n, uint32_t E,

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void sp_gstart_kernel(const uint32_t *grp, uin
 }
 
 // per sorted position: scatter {group start, own position} and the rank back to the entry, resolve the row
-__global__ __launch_bounds__(256) void sp_scatter_kernel(const uint32_t *eid, const uint32_t *grp, const uint32_t *gstart,
+__global__ __launch_bounds__(256) void sp_index_scatter_kernel(const uint32_t *eid, const uint32_t *grp, const uint32_t *gstart,
                                                          const uint32_t *off, uint32_t n, uint32_t E, uint32_t rs,
                                                          uint32_t *sorted_rows, uint2 *lohi, uint32_t *rank_img,
                                                          unsigned long long *incidences, uint32_t *max_group)
@@ -126,6 +126,63 @@ __global__ __launch_bounds__(256) void sp_fill_u32_kernel(uint32_t *p, uint64_t 
 {
     const uint64_t stride = (uint64_t)gridDim.x * 256u;
     for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < count; i += stride) p[i] = v;
+}
+
+// ---- identical rows: collections hold many copies of one sketch (isolates of an outbreak, re-submitted
+// genomes).  Copies form a CLASS represented by its first row: only representatives enter the index,
+// discovery marks classes and expands them to rows when it lists candidates, and a pair inside a
+// class is {n, n} without a merge.
+
+// order-independent 64-bit digest of a row's first cnt values (sum of mixed (value, position) words)
+__global__ __launch_bounds__(256) void sp_row_digest_kernel(const uint64_t *hashes, uint64_t stride, const uint32_t *cnt,
+                                                            unsigned long long *digest)
+{
+    const uint32_t row = blockIdx.x;
+    const uint32_t n = cnt[row];
+    const uint64_t *src = hashes + (uint64_t)row * stride;
+    unsigned long long h = 0;
+    for (uint32_t p = threadIdx.x; p < n; p += 256) {
+        unsigned long long z = src[p] + 0x9E3779B97F4A7C15ull * (unsigned long long)(p + 1);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        h += z ^ (z >> 31);
+    }
+    for (int d = 32; d > 0; d >>= 1) h += __shfl_xor(h, d);
+    __shared__ unsigned long long s_h[4];
+    if ((threadIdx.x & 63) == 0) s_h[threadIdx.x >> 6] = h;
+    __syncthreads();
+    if (threadIdx.x == 0) digest[row] = s_h[0] + s_h[1] + s_h[2] + s_h[3];
+}
+
+// pairs[k] = {row, candidate representative}: equal[k] = 1 iff the two rows hold the same cnt values
+__global__ __launch_bounds__(256) void sp_row_equal_kernel(const uint64_t *hashes, uint64_t stride, const uint32_t *cnt,
+                                                           const uint2 *pairs, uint32_t npairs, uint32_t *equal)
+{
+    const uint32_t k = blockIdx.x;
+    if (k >= npairs) return;
+    const uint2 pr = pairs[k];
+    const uint32_t n = cnt[pr.x];
+    int diff = cnt[pr.y] != n;
+    const uint64_t *x = hashes + (uint64_t)pr.x * stride, *y = hashes + (uint64_t)pr.y * stride;
+    for (uint32_t p = threadIdx.x; p < n && !diff; p += 256) diff |= x[p] != y[p];
+    diff = __syncthreads_or(diff);
+    if (threadIdx.x == 0) equal[k] = diff ? 0u : 1u;
+}
+
+hipError_t launch_sparse_row_digest(const uint64_t *hashes, uint64_t stride, const uint32_t *cnt, uint32_t n,
+                                    unsigned long long *digest, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(sp_row_digest_kernel, dim3(n), dim3(256), 0, stream, hashes, stride, cnt, digest);
+    return hipGetLastError();
+}
+
+hipError_t launch_sparse_row_equal(const uint64_t *hashes, uint64_t stride, const uint32_t *cnt, const uint2 *pairs, uint32_t npairs,
+                                   uint32_t *equal, hipStream_t stream)
+{
+    if (npairs == 0) return hipSuccess;
+    hipLaunchKernelGGL(sp_row_equal_kernel, dim3(npairs), dim3(256), 0, stream, hashes, stride, cnt, pairs, npairs, equal);
+    return hipGetLastError();
 }
 
 // row stride of a code image: s rounded up to a chunk of four, plus one chunk the loop may load behind the row
@@ -177,7 +234,7 @@ hipError_t sparse_build_index(const uint64_t *hashes, uint64_t stride, const uin
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(sp_scatter_kernel, dim3(blocks), dim3(256), 0, stream, eid_sorted, grp, gstart, off, n, E, rs, sorted_rows,
+    hipLaunchKernelGGL(sp_index_scatter_kernel, dim3(blocks), dim3(256), 0, stream, eid_sorted, grp, gstart, off, n, E, rs, sorted_rows,
                        lohi, rank_img, incidences, max_group);
     return hipGetLastError();
 }
@@ -221,7 +278,28 @@ __global__ __launch_bounds__(256) void sp_locate_kernel(const uint64_t *qhashes,
 // ------------------------------------------------------------------------------------------------
 // discovery
 
-template <bool COUNT_ONLY>
+// rows of the class of representative c that count as partners of `row`: all of them (rect), those
+// below `row` (triangle); a representative without copies is its own single row
+__device__ __forceinline__ uint32_t sp_class_span(const SparseArgs &a, uint32_t c, uint32_t row, uint32_t &first)
+{
+    const uint32_t k = a.cls_of[c];
+    if (k == 0xFFFFFFFFu) { first = 0xFFFFFFFFu; return 1u; }
+    const uint32_t lo = a.cls_off[k], hi = a.cls_off[k + 1];
+    first = lo;
+    if (!a.triangle) return hi - lo;
+    uint32_t l = lo, h = hi;                               // class rows ascend: how many lie below `row`
+    while (l < h) {
+        const uint32_t mid = (l + h) >> 1;
+        if (a.cls_rows[mid] < row) l = mid + 1; else h = mid;
+    }
+    return l - lo;
+}
+
+// DEDUP: the column table holds copies (a.rep / a.cls_* are set).  Bits of the bitmap then stand for
+// CLASSES (bit = the representative's row); a copy takes its representative's index entries -- and,
+// being a later row, every class of their values whose representative lies below it, its own class
+// included -- and classes are expanded to rows when the candidates are listed.
+template <bool COUNT_ONLY, bool DEDUP>
 __global__ __launch_bounds__(256) void sp_discover_kernel(SparseArgs a)
 {
     extern __shared__ uint32_t bm[];
@@ -233,7 +311,9 @@ __global__ __launch_bounds__(256) void sp_discover_kernel(SparseArgs a)
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
     const uint32_t ncols = a.triangle ? row : a.ncols;
     const uint32_t W = (ncols + 31u) >> 5;
-    const uint32_t b = a.off[row], cnt = a.off[row + 1] - b;
+    const uint32_t er = (DEDUP && a.triangle) ? a.rep[row] : row;      // the row whose index entries speak for this one
+    const bool copy = DEDUP && a.triangle && er != row;
+    const uint32_t b = a.off[er], cnt = a.off[er + 1] - b;
     if (cnt == 0 || ncols == 0) return;                  // uniform
     for (uint32_t w = tid; w < W; w += 256) bm[w] = 0;
     __syncthreads();
@@ -242,12 +322,17 @@ __global__ __launch_bounds__(256) void sp_discover_kernel(SparseArgs a)
     for (uint32_t base = wid * 64u; base < cnt; base += 256u) {
         const uint32_t p = base + lane;
         uint2 lh = make_uint2(0u, 0u);
-        if (p < cnt) lh = a.lohi[b + p];
+        if (p < cnt) {
+            lh = a.lohi[b + p];
+            // a copy: the whole run of the value (its classes ascend; those at or above `row` are skipped below)
+            if (copy) lh.y = a.gstart[(a.row_img[(uint64_t)er * a.rs_row + p] >> 1) + 1u];
+        }
         const uint32_t len = lh.y - lh.x;
         inc += len;
         if (len != 0 && len <= SHORT) {
             for (uint32_t t = 0; t < len; t++) {
                 const uint32_t r = a.sorted_rows[lh.x + t];
+                if (copy && r >= row) break;
                 if (!((bm[r >> 5] >> (r & 31u)) & 1u)) atomicOr(&bm[r >> 5], 1u << (r & 31u));
             }
         }
@@ -261,6 +346,7 @@ __global__ __launch_bounds__(256) void sp_discover_kernel(SparseArgs a)
             //  consecutive rows share a word -- reads of one word broadcast, atomics on it queue up)
             for (uint32_t q = lo + lane; q < hi; q += 64u) {
                 const uint32_t r = a.sorted_rows[q];
+                if (copy && r >= row) continue;
                 if (!((bm[r >> 5] >> (r & 31u)) & 1u)) atomicOr(&bm[r >> 5], 1u << (r & 31u));
             }
         }
@@ -270,7 +356,19 @@ __global__ __launch_bounds__(256) void sp_discover_kernel(SparseArgs a)
     const uint32_t per = (W + 255u) / 256u;
     const uint32_t w0 = tid * per, w1 = w0 + per < W ? w0 + per : W;
     uint32_t mine = 0;
-    for (uint32_t w = w0; w < w1; w++) mine += (uint32_t)__popc(bm[w]);
+    for (uint32_t w = w0; w < w1; w++) {
+        if (!DEDUP) {
+            mine += (uint32_t)__popc(bm[w]);
+        } else {
+            uint32_t bits = bm[w];
+            while (bits != 0) {
+                const uint32_t c = (w << 5) + (uint32_t)__builtin_ctz(bits);
+                bits &= bits - 1;
+                uint32_t first;
+                mine += sp_class_span(a, c, row, first);
+            }
+        }
+    }
     uint32_t incl = mine;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -305,7 +403,14 @@ __global__ __launch_bounds__(256) void sp_discover_kernel(SparseArgs a)
         while (bits != 0) {
             const uint32_t c = (w << 5) + (uint32_t)__builtin_ctz(bits);
             bits &= bits - 1;
-            a.cand[o++] = make_uint2(row, c);
+            if (!DEDUP) {
+                a.cand[o++] = make_uint2(row, c);
+            } else {
+                uint32_t first;
+                const uint32_t k = sp_class_span(a, c, row, first);
+                if (first == 0xFFFFFFFFu) a.cand[o++] = make_uint2(row, c);
+                else for (uint32_t t = 0; t < k; t++) a.cand[o++] = make_uint2(row, a.cls_rows[first + t]);
+            }
         }
     }
 }
@@ -332,8 +437,10 @@ __global__ __launch_bounds__(256) void sp_merge_kernel(SparseArgs a)
     const uint32_t s = a.s;
     for (uint64_t c = (uint64_t)blockIdx.x * 256u + threadIdx.x; c < K; c += stride) {
         const uint2 pr = a.cand[c];
-        const uint32_t i = pr.x, j = pr.y;
+        // copies are compared through their representatives; two rows of one class are {n, n}
+        const uint32_t i = (a.rep && !RECT) ? a.rep[pr.x] : pr.x, j = a.rep ? a.rep[pr.y] : pr.y;
         const uint32_t nA = a.off[i + 1] - a.off[i];
+        if (!RECT && i == j) { a.res[c] = make_uint2(nA, nA); continue; }
         const uint32_t nB = a.col_cnt_off[j + 1] - a.col_cnt_off[j];
         const uint4 *A4 = reinterpret_cast<const uint4 *>(a.row_img + (uint64_t)i * a.rs_row);
         const uint4 *B4 = reinterpret_cast<const uint4 *>(a.col_img + (uint64_t)j * a.rs_col);
@@ -405,16 +512,20 @@ __global__ __launch_bounds__(SPM_NT) void sp_merge_rows_kernel(SparseArgs a)
     const uint32_t left = cnt - chunk * SPM_NT;
     const bool have = tid < left;
     const uint32_t s = a.s;
-    const uint32_t nA = a.off[row + 1] - a.off[row];
+    // copies are compared through their representatives; two rows of one class are {n, n}
+    const uint32_t arow = (a.rep && !RECT) ? a.rep[row] : row;
+    const uint32_t nA = a.off[arow + 1] - a.off[arow];
     // the row's codes (and one chunk of its padding: A[nA] is read by a lane that has just finished)
     uint32_t *A = lds;
     {
-        const uint4 *src = reinterpret_cast<const uint4 *>(a.row_img + (uint64_t)row * a.rs_row);
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.row_img + (uint64_t)arow * a.rs_row);
         const uint32_t nvec = (nA >> 2) + 1u;
         for (uint32_t v = tid; v < nvec; v += SPM_NT) reinterpret_cast<uint4 *>(A)[v] = src[v];
     }
     uint32_t *myring = lds + a.rs_row + (tid >> 6) * (SPM_RING * 64u) + lane;   // code e of this lane: myring[(e & 31) * 64]
-    const uint32_t j = have ? a.cand[base + tid].y : 0u;
+    uint32_t j = have ? a.cand[base + tid].y : 0u;
+    if (a.rep) j = a.rep[j];
+    const bool same = !RECT && a.rep != nullptr && j == arow;
     const uint32_t nB = have ? a.col_cnt_off[j + 1] - a.col_cnt_off[j] : 0u;
     const uint4 *B4 = reinterpret_cast<const uint4 *>(a.col_img + (uint64_t)j * a.rs_col);
     auto land = [&](uint32_t e, const uint4 &v) {         // codes e .. e + 3 (e a multiple of 4)
@@ -431,7 +542,7 @@ __global__ __launch_bounds__(SPM_NT) void sp_merge_rows_kernel(SparseArgs a)
     bool pend = true;
     __syncthreads();                                     // A staged
     uint32_t ia = 0, ib = 0, common = 0, denom = 0;
-    bool active = have && s > 0 && nA > 0 && nB > 0;
+    bool active = have && !same && s > 0 && nA > 0 && nB > 0;
     while (__ballot(active) != 0) {
 #pragma unroll
         for (int t = 0; t < 8; t++) {
@@ -457,7 +568,9 @@ __global__ __launch_bounds__(SPM_NT) void sp_merge_rows_kernel(SparseArgs a)
         }
     }
     if (have) {
-        if (denom < s) {                                   // :367-385
+        if (same) {
+            common = denom = nA;
+        } else if (denom < s) {                            // :367-385
             denom += (nA - ia) + (nB - ib);
             if (denom > s) denom = s;
         }
@@ -556,19 +669,15 @@ hipError_t launch_sparse_discover(const SparseArgs &a, bool count_only, hipStrea
     const uint32_t nrows = a.row_end - a.row_begin;
     if (nrows == 0) return hipSuccess;
     const size_t smem = sparse_discover_lds(a.triangle ? a.row_end : a.ncols);
-    hipError_t e;
-    if (count_only) {
-        auto kern = sp_discover_kernel<true>;
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    auto go = [&](auto kern) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(nrows), dim3(256), smem, stream, a);
-    } else {
-        auto kern = sp_discover_kernel<false>;
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(nrows), dim3(256), smem, stream, a);
-    }
-    return hipGetLastError();
+        return hipGetLastError();
+    };
+    const bool dedup = a.rep != nullptr;
+    if (count_only) return dedup ? go(sp_discover_kernel<true, true>) : go(sp_discover_kernel<true, false>);
+    return dedup ? go(sp_discover_kernel<false, true>) : go(sp_discover_kernel<false, false>);
 }
 
 hipError_t launch_sparse_merge(const SparseArgs &a, uint64_t expect, uint32_t cus, hipStream_t stream)

@@ -100,6 +100,9 @@ struct mg_table {
         uint32_t *sorted_rows = nullptr;   // [E]
         uint2 *lohi = nullptr;             // [E]
         uint32_t *rank_img = nullptr;      // [n * rs]
+        // identical rows: rep[row] = first row of its class (nullptr: the table has no copies), classes of >= 2 rows
+        uint32_t *rep = nullptr, *cls_of = nullptr, *cls_off = nullptr, *cls_rows = nullptr;
+        uint64_t copies = 0;               // rows that are a copy of an earlier row
         uint32_t *short_rows = nullptr, *short_cnt = nullptr;    // rows with fewer than s hashes (ascending) and their counts
         std::vector<uint32_t> short_rows_host;
         // what a (rows, range) job costs, learned by a counting pass the first time it is seen
@@ -1387,7 +1390,8 @@ void mg_table_free(mg_table *t)
             for (void *q : {(void *)sp->off, (void *)sp->keys_sorted, (void *)sp->grp, (void *)sp->gstart, (void *)sp->sorted_rows,
                             (void *)sp->lohi, (void *)sp->rank_img, (void *)sp->short_rows, (void *)sp->short_cnt, (void *)sp->cand,
                             (void *)sp->res, (void *)sp->seg_base, (void *)sp->seg_cnt, (void *)sp->chunks, (void *)sp->chunk_inc,
-                            sp->scan_temp, (void *)sp->counters})
+                            sp->scan_temp, (void *)sp->counters, (void *)sp->rep, (void *)sp->cls_of, (void *)sp->cls_off,
+                            (void *)sp->cls_rows})
                 if (q) hipFree(q);
             delete sp;
         }
@@ -1912,12 +1916,73 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, mg_tab
     const uint64_t n = t->n;
     if (n == 0) return unusable("empty table");
     if (n >= (1ull << 31)) return unusable("too many rows");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // ---- identical rows (see compare_sparse.hip): digest every row, group equal digests on the host,
+    // verify the groups value by value on the device; copies then stay out of the index
+    std::vector<uint32_t> cnt_true(n), rep(n);
+    for (uint64_t i = 0; i < n; i++) {
+        cnt_true[i] = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(t->nh[i], t->s), s);
+        rep[i] = (uint32_t)i;
+    }
+    DevBuf<uint32_t> d_cnt;
+    if (d_cnt.alloc(n) != hipSuccess) { (void)hipGetLastError(); return unusable("no device memory for the index"); }
+    HIP_TRY(ctx, hipMemcpyAsync(d_cnt, cnt_true.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (!getenv("MASHGPU_SPARSE_NO_DEDUP")) {
+        DevBuf<unsigned long long> d_dig;
+        if (d_dig.alloc(n) != hipSuccess) { (void)hipGetLastError(); return unusable("no device memory for the index"); }
+        std::vector<unsigned long long> dig(n);
+        HIP_TRY(ctx, mg::launch_sparse_row_digest(t->hashes, t->s, d_cnt, (uint32_t)n, d_dig, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(dig.data(), d_dig, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        std::vector<uint32_t> order;
+        order.reserve(n);
+        for (uint64_t i = 0; i < n; i++)
+            if (cnt_true[i]) order.push_back((uint32_t)i);
+        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+            if (dig[x] != dig[y]) return dig[x] < dig[y];
+            if (cnt_true[x] != cnt_true[y]) return cnt_true[x] < cnt_true[y];
+            return x < y;
+        });
+        std::vector<uint2> pairs;                          // {row, first row with the same digest and length}
+        for (size_t k = 1, g0 = 0; k < order.size(); k++) {
+            if (dig[order[k]] == dig[order[g0]] && cnt_true[order[k]] == cnt_true[order[g0]]) pairs.push_back(make_uint2(order[k], order[g0]));
+            else g0 = k;
+        }
+        if (!pairs.empty()) {
+            DevBuf<uint2> d_pairs;
+            DevBuf<uint32_t> d_eq;
+            if (d_pairs.alloc(pairs.size()) != hipSuccess || d_eq.alloc(pairs.size()) != hipSuccess) { (void)hipGetLastError(); return unusable("no device memory for the index"); }
+            std::vector<uint32_t> eq(pairs.size());
+            HIP_TRY(ctx, hipMemcpyAsync(d_pairs, pairs.data(), pairs.size() * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(ctx, mg::launch_sparse_row_equal(t->hashes, t->s, d_cnt, d_pairs, (uint32_t)pairs.size(), d_eq, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(eq.data(), d_eq, pairs.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            for (size_t k = 0; k < pairs.size(); k++)
+                if (eq[k]) { rep[pairs[k].x] = pairs[k].y; sp->copies++; }
+        }
+    }
+    std::vector<uint32_t> cls_of, cls_off, cls_rows;
+    if (sp->copies) {
+        cls_of.assign(n, 0xFFFFFFFFu);
+        std::vector<uint32_t> size(n, 0);
+        for (uint64_t i = 0; i < n; i++) size[rep[i]]++;
+        uint32_t ncls = 0, tot = 0;
+        for (uint64_t i = 0; i < n; i++)
+            if (size[i] >= 2) { cls_of[i] = ncls++; cls_off.push_back(tot); tot += size[i]; }
+        cls_off.push_back(tot);
+        cls_rows.resize(tot);
+        std::vector<uint32_t> fillp(cls_off.begin(), cls_off.end() - 1);
+        for (uint64_t i = 0; i < n; i++) {                 // ascending rows inside a class
+            const uint32_t k = cls_of[rep[i]];
+            if (k != 0xFFFFFFFFu) cls_rows[fillp[k]++] = (uint32_t)i;
+        }
+    }
     uint64_t E64 = 0, maxv = 0;
     sp->off_host.resize(n + 1);
     for (uint64_t i = 0; i < n; i++) {
         sp->off_host[i] = (uint32_t)E64;
-        const uint64_t c = std::min<uint64_t>(std::min<uint64_t>(t->nh[i], t->s), s);
-        E64 += c;
+        const uint64_t c = cnt_true[i];
+        if (rep[i] == i) E64 += c;                          // copies stay out of the index
         if (E64 >= (1ull << 31)) return unusable("2^31 entries or more");
         if (c) {
             // a real hash equal to the padding value would sort among the padding: keep the tile engine
@@ -1955,14 +2020,20 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, mg_tab
          hipMalloc(&sp->rank_img, ((size_t)n * sp->rs + 64) * 4) == hipSuccess && hipMalloc(&sp->counters, 4 * 8) == hipSuccess;
     const size_t nshort = sp->short_rows_host.size();
     std::vector<uint32_t> short_cnt(nshort);
-    for (size_t k = 0; k < nshort; k++) {
-        const uint32_t i = sp->short_rows_host[k];
-        short_cnt[k] = sp->off_host[i + 1] - sp->off_host[i];
-    }
+    for (size_t k = 0; k < nshort; k++) short_cnt[k] = cnt_true[sp->short_rows_host[k]];
     if (ok && nshort)
         ok = hipMalloc(&sp->short_rows, nshort * 4) == hipSuccess && hipMalloc(&sp->short_cnt, nshort * 4) == hipSuccess;
+    if (ok && sp->copies)
+        ok = hipMalloc(&sp->rep, n * 4) == hipSuccess && hipMalloc(&sp->cls_of, n * 4) == hipSuccess &&
+             hipMalloc(&sp->cls_off, cls_off.size() * 4) == hipSuccess && hipMalloc(&sp->cls_rows, std::max<size_t>(cls_rows.size(), 1) * 4) == hipSuccess;
     hipError_t e = hipSuccess;
-    if (ok) {
+    if (ok && sp->copies) {
+        e = hipMemcpyAsync(sp->rep, rep.data(), n * 4, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(sp->cls_of, cls_of.data(), n * 4, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(sp->cls_off, cls_off.data(), cls_off.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(sp->cls_rows, cls_rows.data(), cls_rows.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+    }
+    if (ok && e == hipSuccess) {
         e = hipMemcpyAsync(sp->off, sp->off_host.data(), (n + 1) * 4, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess && nshort) e = hipMemcpyAsync(sp->short_rows, sp->short_rows_host.data(), nshort * 4, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess && nshort) e = hipMemcpyAsync(sp->short_cnt, short_cnt.data(), nshort * 4, hipMemcpyHostToDevice, ctx->stream);
@@ -1984,7 +2055,8 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, mg_tab
         if (q) hipFree(q);
     auto drop = [&]() {
         for (void **q : {(void **)&sp->off, (void **)&sp->keys_sorted, (void **)&sp->grp, (void **)&sp->gstart, (void **)&sp->sorted_rows,
-                         (void **)&sp->lohi, (void **)&sp->rank_img, (void **)&sp->short_rows, (void **)&sp->short_cnt, (void **)&sp->counters})
+                         (void **)&sp->lohi, (void **)&sp->rank_img, (void **)&sp->short_rows, (void **)&sp->short_cnt, (void **)&sp->counters,
+                         (void **)&sp->rep, (void **)&sp->cls_of, (void **)&sp->cls_off, (void **)&sp->cls_rows})
             if (*q) { hipFree(*q); *q = nullptr; }
     };
     if (!ok) { (void)hipGetLastError(); drop(); return unusable("no device memory for the index"); }
@@ -1996,8 +2068,8 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, mg_tab
     sp->build_ms = ms;
     sp->usable = true;
     if (getenv("MASHGPU_SPARSE_DBG"))
-        fprintf(stderr, "compare sparse: index of %llu rows, s %u: %u entries, %u distinct, shared %llu, largest run %u, %.2f ms\n",
-                (unsigned long long)n, s, E, sp->G, (unsigned long long)sp->shared, sp->max_group, ms);
+        fprintf(stderr, "compare sparse: index of %llu rows (%llu copies of earlier rows), s %u: %u entries, %u distinct, shared %llu, largest run %u, %.2f ms\n",
+                (unsigned long long)n, (unsigned long long)sp->copies, s, E, sp->G, (unsigned long long)sp->shared, sp->max_group, ms);
     return MG_OK;
 }
 
@@ -2033,6 +2105,15 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
     a.s = s;
     a.out = reinterpret_cast<uint2 *>(out_dev);
     a.counters = ix->counters;
+    a.rep = ix->rep;
+    a.cls_of = ix->cls_of;
+    a.cls_off = ix->cls_off;
+    a.cls_rows = ix->cls_rows;
+    a.gstart = ix->gstart;
+    a.res = nullptr;
+    a.seg_base = nullptr;
+    a.seg_cnt = nullptr;
+    a.chunk_inc = nullptr;
     DevBuf<uint32_t> q_off, q_img, q_short, q_short_cnt;
     DevBuf<uint2> q_lohi;
     std::vector<uint32_t> qshort_h, qshort_cnt_h;

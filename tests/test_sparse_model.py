@@ -55,27 +55,59 @@ def merge_codes(a, b, s):
     return common, denom
 
 
-def model_triangle(table, nhash, s, rb, re):
-    ix = build_index(table, nhash, s)
-    cnt, off = ix["cnt"], ix["off"]
+def classes_of(table, nhash, s):
+    """Identical rows: rep[row] = first row holding the same values (empty rows stay on their own)."""
+    n = table.shape[0]
+    cnt = np.minimum(np.minimum(nhash, table.shape[1]), s).astype(np.int64)
+    rep = np.arange(n)
+    first = {}
+    for i in range(n):
+        if cnt[i] == 0:
+            continue
+        key = table[i, : cnt[i]].tobytes()
+        rep[i] = first.setdefault(key, i)
+    members = {}
+    for i in range(n):
+        members.setdefault(int(rep[i]), []).append(i)
+    return cnt, rep, members
+
+
+def model_triangle(table, nhash, s, rb, re, dedup=True):
+    """dedup: copies of an earlier row stay out of the index; discovery marks CLASSES (a copy walks the
+    whole run of each of its representative's values, up to its own row) and expands them to rows; a
+    pair inside a class is {n, n} without a merge -- as compare_sparse.hip does it."""
+    cnt, rep, members = classes_of(table, nhash, s)
+    if not dedup:
+        rep = np.arange(table.shape[0])
+        members = {i: [i] for i in range(table.shape[0])}
+    idx_nhash = np.where(rep == np.arange(len(rep)), cnt, 0).astype(nhash.dtype)     # copies: no entries
+    ix = build_index(table, idx_nhash, s)
+    off = ix["off"]
     numer, denom = [], []
     ncand = 0
     for i in range(rb, re):
-        # fill
+        # fill (true counts)
         row_n = np.zeros(i, dtype=np.int64)
         row_d = np.minimum(s, cnt[i] + cnt[:i])
-        # discover: runs [group start, own position) of the row's entries
-        cand = set()
-        for p in range(cnt[i]):
-            e = off[i] + p
-            cand.update(ix["sorted_rows"][ix["lo_of"][e]: ix["pos_of"][e]].tolist())
-        assert all(j < i for j in cand)
+        # discover: classes named by the runs of the entries of the row's representative
+        er = int(rep[i])
+        marked = set()
+        for p in range(ix["cnt"][er]):
+            e = off[er] + p
+            lo = ix["lo_of"][e]
+            hi = ix["pos_of"][e] if er == i else ix["gstart"][ix["rank_of"][e] + 1]
+            marked.update(int(r) for r in ix["sorted_rows"][lo:hi] if r < i)
+        assert all(rep[c] == c for c in marked)
+        cand = sorted(b for c in marked for b in members[c] if b < i)
         ncand += len(cand)
-        # merge on codes
-        ai = 2 * ix["rank_of"][off[i]: off[i + 1]]
-        for j in sorted(cand):
-            bj = 2 * ix["rank_of"][off[j]: off[j + 1]]
-            row_n[j], row_d[j] = merge_codes(ai, bj, s)
+        # merge on codes, through the representatives
+        ai = 2 * ix["rank_of"][off[er]: off[er + 1]]
+        for j in cand:
+            rj = int(rep[j])
+            if rj == er:
+                row_n[j] = row_d[j] = cnt[i]
+            else:
+                row_n[j], row_d[j] = merge_codes(ai, 2 * ix["rank_of"][off[rj]: off[rj + 1]], s)
         numer.append(row_n); denom.append(row_d)
     return np.concatenate(numer) if numer else np.zeros(0), np.concatenate(denom) if denom else np.zeros(0), ncand
 
@@ -132,18 +164,23 @@ def _edge_table(n, s, seed):
     return table, nhash, lengths
 
 
+@pytest.mark.parametrize("dedup", [True, False])
 @pytest.mark.parametrize("s", [1, 2, 7, 64, 100])
-def test_model_triangle_equals_oracle(oracle, s):
+def test_model_triangle_equals_oracle(oracle, s, dedup):
     n = 40
     table, nhash, lengths = _edge_table(n, s, seed=s)
+    # more copies: a class of four spread over the table, a copy of a copy, a copy of a short row
+    for dst, src in ((30, 3), (35, 3), (39, 30), (33, 9), (25, 24)):
+        table[dst] = table[src]
+        nhash[dst] = nhash[src]
     numer, denom, _, _ = oracle.triangle(table, nhash, lengths, 0, n, 21, 4.0 ** 21)
-    got_n, got_d, ncand = model_triangle(table, nhash, s, 0, n)
+    got_n, got_d, ncand = model_triangle(table, nhash, s, 0, n, dedup)
     assert np.array_equal(got_n, numer) and np.array_equal(got_d, denom)
     # the candidates are exactly the pairs sharing a hash: every other pair has numer 0
     assert ncand >= int(np.count_nonzero(numer))
     # a row range
-    n2, d2, _, _ = oracle.triangle(table, nhash, lengths, 13, 29, 21, 4.0 ** 21)
-    g2n, g2d, _ = model_triangle(table, nhash, s, 13, 29)
+    n2, d2, _, _ = oracle.triangle(table, nhash, lengths, 13, 38, 21, 4.0 ** 21)
+    g2n, g2d, _ = model_triangle(table, nhash, s, 13, 38, dedup)
     assert np.array_equal(g2n, n2) and np.array_equal(g2d, d2)
 
 

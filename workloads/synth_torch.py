@@ -55,6 +55,38 @@ def clustered_sketch_table(n, s=1000, clusters=1000, seed=0, pool=1500, private=
     return hashes, nhash, lengths
 
 
+def random_sketch_table(n, s=1000, seed=0, bits=54, length=1_000_000, device="cuda", block=20000):
+    """SURVEY 8d bracket "all-random": every sketch its own s ascending distinct values below 2^bits
+    (common ~ 0 for every pair)."""
+    hashes = torch.empty((n, s), dtype=torch.int64, device=device)
+    for b0 in range(0, n, block):
+        b1 = min(n, b0 + block)
+        m = torch.arange(b0, b1, device=device, dtype=torch.int64)
+        x = _lsr(splitmix64(-6882143410218379217 * (m + 1) + seed, s + 8), 64 - bits)
+        x, _ = torch.sort(x, dim=1)
+        dup = torch.zeros_like(x, dtype=torch.bool)
+        dup[:, 1:] = x[:, 1:] == x[:, :-1]
+        x = torch.where(dup, torch.full_like(x, _PAD_SORT), x)
+        x, _ = torch.sort(x, dim=1)
+        assert int((x[:, :s] == _PAD_SORT).sum()) == 0
+        hashes[b0:b1] = x[:, :s]
+    return hashes, torch.full((n,), s, dtype=torch.int32, device=device), torch.full((n,), length, dtype=torch.int64, device=device)
+
+
+def identical_sketch_table(n, s=1000, seed=0, length=1_000_000, device="cuda"):
+    """SURVEY 8d bracket "all-identical": n copies of one sketch (common = s for every pair)."""
+    h, nh, ln = random_sketch_table(1, s, seed=seed, length=length, device=device)
+    return h.repeat(n, 1).contiguous(), nh.repeat(n).contiguous(), ln.repeat(n).contiguous()
+
+
+def clade_sketch_table(n, s=1000, clade=1000, seed=0, device="cuda", contiguous=True):
+    """Clades of `clade` near-identical sketches (97 % of a clade's pool of 1.06 s values kept, 2 % private):
+    what collections of thousands of isolates of one species look like.  Rows of a clade are consecutive
+    (taxonomic order) unless contiguous=False."""
+    return clustered_sketch_table(n, s, clusters=max(1, n // clade), seed=seed, pool=int(1.06 * s), private=max(1, s // 50),
+                                  keep_p=0.97, device=device, contiguous=contiguous)
+
+
 def synthetic_genomes(g_begin, g_end, length, device="cuda", block=256, stride=1):
     """ASCII bases uint8[(g_end-g_begin), length] of synthetic genomes g_begin..g_end-1
     (same definition as workloads.synth.synthetic_genome).
