@@ -316,10 +316,24 @@ void     mg_shard_tri_rows(uint64_t row_begin, uint64_t row_end, int nranks, int
 void     mg_shard_rows(uint64_t row_begin, uint64_t row_end, int nranks, int rank, uint64_t *b_out, uint64_t *e_out);
 int      mg_dtable_upload(mg_comm *c, const uint64_t *hashes, const uint32_t *nhash, const uint64_t *lengths,
                           uint64_t n, uint64_t s, mg_dtable **out);         /* host -> GPU 0 -> broadcast */
+/* The larger side of a rect job need not be replicated: device g gets a block of consecutive rows (host ->
+ * each GPU its own rows, no exchange).  Such a table can only be the REFERENCE side of
+ * mg_compare_rect_*_sharded_host, which then cuts the job by reference rows and puts the blocks back into
+ * the reference's query-major order (SURVEY.md 8e "broadcast the smaller side, shard the larger side by
+ * rows"; the reference cuts the same grid into jobs of 0x1000 pairs, CommandDistance.cpp:195-232).  With
+ * replicated tables the rect calls cut whichever side is larger (one query against a million references
+ * uses every GPU). */
+int      mg_dtable_upload_rows(mg_comm *c, const uint64_t *hashes, const uint32_t *nhash, const uint64_t *lengths,
+                               uint64_t n, uint64_t s, mg_dtable **out);
 void     mg_dtable_free(mg_dtable *d);
 mg_table *mg_dtable_local(mg_dtable *d, int i);
 int      mg_table_broadcast(mg_comm *c, const mg_table *src, int root, uint64_t n, uint64_t s, mg_table **out);
 int      mg_comm_allreduce_u32_sum(mg_comm *c, uint32_t *buf_dev, uint64_t count);
+/* mg_sketch_host on every GPU: blocks of consecutive sketches balanced by bytes, one host thread per device,
+ * no collective; rows of the outputs in input order (replaces the fan-out of sketchFile / sketchSequence over
+ * the -p threads, Sketch.cpp:211,354, whose results ThreadPool.hxx:127-167 hands back in submission order). */
+int mg_sketch_sharded_host(mg_comm *c, const mg_params *p, const uint8_t *bases, uint64_t nbases, const uint64_t *sketch_off,
+                           uint64_t nsketch, uint64_t *hashes_out, uint32_t *nhash_out, uint32_t *counts_out);
 int mg_compare_tri_sharded_host(mg_comm *c, const mg_dtable *t, uint64_t row_begin, uint64_t row_end, mg_counts *out_host);
 int mg_compare_rect_sharded_host(mg_comm *c, const mg_dtable *ref, const mg_dtable *qry, uint64_t q_begin, uint64_t q_end,
                                  mg_counts *out_host);

@@ -36,7 +36,7 @@ EXPORTS = [
     "mg_identity", "mg_p_value_within",
     "mg_comm_create_local", "mg_comm_unique_id", "mg_comm_create_rank", "mg_comm_destroy", "mg_comm_size", "mg_comm_rank",
     "mg_comm_uses_rccl", "mg_comm_ctx", "mg_comm_last_error", "mg_shard_tri_rows", "mg_shard_rows", "mg_dtable_upload",
-    "mg_dtable_free", "mg_dtable_local", "mg_table_broadcast", "mg_comm_allreduce_u32_sum",
+    "mg_dtable_free", "mg_dtable_local", "mg_table_broadcast", "mg_comm_allreduce_u32_sum", "mg_dtable_upload_rows", "mg_sketch_sharded_host",
     "mg_compare_tri_sharded_host", "mg_compare_rect_sharded_host", "mg_compare_tri_pairs_sharded_host",
     "mg_compare_rect_pairs_sharded_host", "mg_compare_tri_results_sharded_host", "mg_compare_rect_results_sharded_host",
     "mg_dscreen_create", "mg_dscreen_add_host", "mg_dscreen_finish_host", "mg_dscreen_free",
@@ -205,6 +205,8 @@ def load_library():
     lib.mg_shard_rows.argtypes = [u64, u64, i32, i32, C.POINTER(u64), C.POINTER(u64)]
     lib.mg_shard_rows.restype = None
     lib.mg_dtable_upload.argtypes = [vp, vp, vp, vp, u64, u64, C.POINTER(vp)]
+    lib.mg_dtable_upload_rows.argtypes = [vp, vp, vp, vp, u64, u64, C.POINTER(vp)]
+    lib.mg_sketch_sharded_host.argtypes = [vp, C.POINTER(MgParams), vp, u64, vp, u64, vp, vp, vp]
     lib.mg_dtable_free.argtypes = [vp]
     lib.mg_dtable_free.restype = None
     lib.mg_dtable_local.argtypes = [vp, i32]
@@ -359,6 +361,30 @@ class LocalComm:
         out = np.zeros(tri_pairs(row_begin, row_end), dtype=COUNTS_DTYPE)
         self._check(self.lib.mg_compare_tri_sharded_host(self.h, d, row_begin, row_end, out.ctypes.data))
         return out
+
+    def upload_rows(self, hashes, nhash, lengths):
+        """row-sharded table (one block of consecutive rows per device): the reference side of rect jobs"""
+        hashes = np.ascontiguousarray(hashes, dtype=np.uint64)
+        nhash = np.ascontiguousarray(nhash, dtype=np.uint32)
+        lengths = np.ascontiguousarray(lengths, dtype=np.uint64)
+        n, s = hashes.shape
+        d = C.c_void_p()
+        self._check(self.lib.mg_dtable_upload_rows(self.h, hashes.ctypes.data, nhash.ctypes.data, lengths.ctypes.data, n, s, C.byref(d)))
+        return d
+
+    def sketch(self, sketches, p, counts=False):
+        """mg_sketch_sharded_host: lists of records per sketch, on every device of the communicator"""
+        blobs = [join_records(recs) for recs in sketches]
+        bases = np.frombuffer(b"".join(blobs), dtype=np.uint8)
+        off = np.zeros(len(blobs) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(b) for b in blobs], dtype=np.uint64)
+        s = int(p.sketch_size)
+        hashes = np.zeros((len(blobs), s), dtype=np.uint64)
+        nhash = np.zeros(len(blobs), dtype=np.uint32)
+        cnt = np.zeros((len(blobs), s), dtype=np.uint32) if counts else None
+        self._check(self.lib.mg_sketch_sharded_host(self.h, C.byref(p), bases.ctypes.data if len(bases) else None, len(bases), off.ctypes.data,
+                                                    len(blobs), hashes.ctypes.data, nhash.ctypes.data, cnt.ctypes.data if counts else None))
+        return (hashes, nhash, cnt) if counts else (hashes, nhash)
 
     def rect(self, dref, dqry, nref, nq, q_begin=0, q_end=None):
         q_end = nq if q_end is None else q_end

@@ -128,6 +128,9 @@ struct SparseArgs {
     const uint32_t *cls_rows;
     const uint32_t *gstart;        // first sorted position of every value (a copy walks the whole run of a value)
 };
+hipError_t launch_sparse_class_pairs(uint2 *out, const uint32_t *cls_rows, const uint32_t *cls_first, const uint32_t *off,
+                                     const uint32_t *rep, uint32_t members, uint32_t row_begin, uint32_t row_end, uint64_t out_base,
+                                     hipStream_t stream);
 hipError_t launch_sparse_row_digest(const uint64_t *hashes, uint64_t stride, const uint32_t *cnt, uint32_t n,
                                     unsigned long long *digest, hipStream_t stream);
 hipError_t launch_sparse_row_equal(const uint64_t *hashes, uint64_t stride, const uint32_t *cnt, const uint2 *pairs, uint32_t npairs,

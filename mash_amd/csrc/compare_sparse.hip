@@ -297,8 +297,9 @@ __device__ __forceinline__ uint32_t sp_class_span(const SparseArgs &a, uint32_t 
 
 // DEDUP: the column table holds copies (a.rep / a.cls_* are set).  Bits of the bitmap then stand for
 // CLASSES (bit = the representative's row); a copy takes its representative's index entries -- and,
-// being a later row, every class of their values whose representative lies below it, its own class
-// included -- and classes are expanded to rows when the candidates are listed.
+// being a later row, every class of their values whose representative lies below it -- and classes
+// are expanded to rows when the candidates are listed.  Pairs INSIDE a class never become
+// candidates: they are {n, n}, written by sp_class_pairs_kernel.
 template <bool COUNT_ONLY, bool DEDUP>
 __global__ __launch_bounds__(256) void sp_discover_kernel(SparseArgs a)
 {
@@ -333,6 +334,7 @@ __global__ __launch_bounds__(256) void sp_discover_kernel(SparseArgs a)
             for (uint32_t t = 0; t < len; t++) {
                 const uint32_t r = a.sorted_rows[lh.x + t];
                 if (copy && r >= row) break;
+                if (copy && r == er) continue;           // its own class: sp_class_pairs_kernel
                 if (!((bm[r >> 5] >> (r & 31u)) & 1u)) atomicOr(&bm[r >> 5], 1u << (r & 31u));
             }
         }
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(256) void sp_discover_kernel(SparseArgs a)
             //  consecutive rows share a word -- reads of one word broadcast, atomics on it queue up)
             for (uint32_t q = lo + lane; q < hi; q += 64u) {
                 const uint32_t r = a.sorted_rows[q];
-                if (copy && r >= row) continue;
+                if (copy && (r >= row || r == er)) continue;         // (its own class: sp_class_pairs_kernel)
                 if (!((bm[r >> 5] >> (r & 31u)) & 1u)) atomicOr(&bm[r >> 5], 1u << (r & 31u));
             }
         }
@@ -592,6 +594,33 @@ __global__ __launch_bounds__(256) void sp_scatter_kernel(SparseArgs a)
         else oidx = (uint64_t)(i - a.row_begin) * a.ncols + j;
         a.out[oidx] = a.res[c];
     }
+}
+
+// pairs of two copies of one sketch (triangle): {n, n}, n = the sketch's hash count.  One workgroup per
+// member of a class of two rows and more: member i of cls_rows writes its pairs with the members of
+// its class below it (first[i] = where its class starts in cls_rows).
+__global__ __launch_bounds__(256) void sp_class_pairs_kernel(uint2 *out, const uint32_t *cls_rows, const uint32_t *cls_first,
+                                                             const uint32_t *off, const uint32_t *rep, uint32_t members,
+                                                             uint32_t row_begin, uint32_t row_end, uint64_t out_base)
+{
+    const uint32_t i = blockIdx.x;
+    if (i >= members) return;
+    const uint32_t row = cls_rows[i];
+    if (row < row_begin || row >= row_end) return;       // uniform
+    const uint32_t r = rep[row], n = off[r + 1] - off[r];
+    const uint64_t base = (uint64_t)row * (row - 1u) / 2u - out_base;
+    const uint2 v = make_uint2(n, n);
+    for (uint32_t u = cls_first[i] + threadIdx.x; u < i; u += 256) out[base + cls_rows[u]] = v;
+}
+
+hipError_t launch_sparse_class_pairs(uint2 *out, const uint32_t *cls_rows, const uint32_t *cls_first, const uint32_t *off,
+                                     const uint32_t *rep, uint32_t members, uint32_t row_begin, uint32_t row_end, uint64_t out_base,
+                                     hipStream_t stream)
+{
+    if (members == 0) return hipSuccess;
+    hipLaunchKernelGGL(sp_class_pairs_kernel, dim3(members), dim3(256), 0, stream, out, cls_rows, cls_first, off, rep, members, row_begin,
+                       row_end, out_base);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -101,7 +101,9 @@ struct mg_table {
         uint2 *lohi = nullptr;             // [E]
         uint32_t *rank_img = nullptr;      // [n * rs]
         // identical rows: rep[row] = first row of its class (nullptr: the table has no copies), classes of >= 2 rows
-        uint32_t *rep = nullptr, *cls_of = nullptr, *cls_off = nullptr, *cls_rows = nullptr;
+        uint32_t *rep = nullptr, *cls_of = nullptr, *cls_off = nullptr, *cls_rows = nullptr, *cls_first = nullptr;
+        uint32_t cls_members = 0;          // rows in classes of two and more
+        uint64_t cls_pairs = 0;            // pairs inside those classes (full triangle)
         uint64_t copies = 0;               // rows that are a copy of an earlier row
         uint32_t *short_rows = nullptr, *short_cnt = nullptr;    // rows with fewer than s hashes (ascending) and their counts
         std::vector<uint32_t> short_rows_host;
@@ -1391,7 +1393,7 @@ void mg_table_free(mg_table *t)
                             (void *)sp->lohi, (void *)sp->rank_img, (void *)sp->short_rows, (void *)sp->short_cnt, (void *)sp->cand,
                             (void *)sp->res, (void *)sp->seg_base, (void *)sp->seg_cnt, (void *)sp->chunks, (void *)sp->chunk_inc,
                             sp->scan_temp, (void *)sp->counters, (void *)sp->rep, (void *)sp->cls_of, (void *)sp->cls_off,
-                            (void *)sp->cls_rows})
+                            (void *)sp->cls_rows, (void *)sp->cls_first})
                 if (q) hipFree(q);
             delete sp;
         }
@@ -1961,7 +1963,7 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, mg_tab
                 if (eq[k]) { rep[pairs[k].x] = pairs[k].y; sp->copies++; }
         }
     }
-    std::vector<uint32_t> cls_of, cls_off, cls_rows;
+    std::vector<uint32_t> cls_of, cls_off, cls_rows, cls_first;
     if (sp->copies) {
         cls_of.assign(n, 0xFFFFFFFFu);
         std::vector<uint32_t> size(n, 0);
@@ -1976,6 +1978,13 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, mg_tab
             const uint32_t k = cls_of[rep[i]];
             if (k != 0xFFFFFFFFu) cls_rows[fillp[k]++] = (uint32_t)i;
         }
+        cls_first.resize(tot);
+        for (uint32_t k = 0; k < ncls; k++) {
+            const uint64_t m = cls_off[k + 1] - cls_off[k];
+            sp->cls_pairs += m * (m - 1) / 2;
+            for (uint32_t u = cls_off[k]; u < cls_off[k + 1]; u++) cls_first[u] = cls_off[k];
+        }
+        sp->cls_members = tot;
     }
     uint64_t E64 = 0, maxv = 0;
     sp->off_host.resize(n + 1);
@@ -2025,13 +2034,15 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, mg_tab
         ok = hipMalloc(&sp->short_rows, nshort * 4) == hipSuccess && hipMalloc(&sp->short_cnt, nshort * 4) == hipSuccess;
     if (ok && sp->copies)
         ok = hipMalloc(&sp->rep, n * 4) == hipSuccess && hipMalloc(&sp->cls_of, n * 4) == hipSuccess &&
-             hipMalloc(&sp->cls_off, cls_off.size() * 4) == hipSuccess && hipMalloc(&sp->cls_rows, std::max<size_t>(cls_rows.size(), 1) * 4) == hipSuccess;
+             hipMalloc(&sp->cls_off, cls_off.size() * 4) == hipSuccess && hipMalloc(&sp->cls_rows, std::max<size_t>(cls_rows.size(), 1) * 4) == hipSuccess &&
+             hipMalloc(&sp->cls_first, std::max<size_t>(cls_first.size(), 1) * 4) == hipSuccess;
     hipError_t e = hipSuccess;
     if (ok && sp->copies) {
         e = hipMemcpyAsync(sp->rep, rep.data(), n * 4, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(sp->cls_of, cls_of.data(), n * 4, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(sp->cls_off, cls_off.data(), cls_off.size() * 4, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(sp->cls_rows, cls_rows.data(), cls_rows.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(sp->cls_first, cls_first.data(), cls_first.size() * 4, hipMemcpyHostToDevice, ctx->stream);
     }
     if (ok && e == hipSuccess) {
         e = hipMemcpyAsync(sp->off, sp->off_host.data(), (n + 1) * 4, hipMemcpyHostToDevice, ctx->stream);
@@ -2056,7 +2067,7 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, mg_tab
     auto drop = [&]() {
         for (void **q : {(void **)&sp->off, (void **)&sp->keys_sorted, (void **)&sp->grp, (void **)&sp->gstart, (void **)&sp->sorted_rows,
                          (void **)&sp->lohi, (void **)&sp->rank_img, (void **)&sp->short_rows, (void **)&sp->short_cnt, (void **)&sp->counters,
-                         (void **)&sp->rep, (void **)&sp->cls_of, (void **)&sp->cls_off, (void **)&sp->cls_rows})
+                         (void **)&sp->rep, (void **)&sp->cls_of, (void **)&sp->cls_off, (void **)&sp->cls_rows, (void **)&sp->cls_first})
             if (*q) { hipFree(*q); *q = nullptr; }
     };
     if (!ok) { (void)hipGetLastError(); drop(); return unusable("no device memory for the index"); }
@@ -2199,7 +2210,8 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
         fresh.shared = h[1];
         // seconds, one MI355X (measured: profiles/r03_sparse_phases.txt)
         const double np = (double)pairs;
-        const double t_sparse = np * 8.0 / 4.5e12 + (double)fresh.shared * 2.0e-12 + (double)nrows * s * 4.0e-11 + (double)fresh.cand * 1.0e-9 + 2.0e-5;
+        const double t_sparse = np * 8.0 / 4.5e12 + (double)fresh.shared * 2.0e-12 + (double)nrows * s * 4.0e-11 + (double)fresh.cand * 1.0e-9 + 2.0e-5 +
+                                (triangle ? (double)ix->cls_pairs * 8.0 / 2.0e12 : 0.0);
         const double dense_rate = np < 3.0e8 ? 8.0e9 : np < 2.0e9 ? 1.5e10 : 3.0e10;
         const double t_dense = np / dense_rate + (double)fresh.shared * 2.2e-12;
         fresh.use = t_sparse < t_dense;
@@ -2219,11 +2231,45 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
 
     // ---- fill, on its own stream beside discover + merge: one is bound by HBM writes, the others by
     // latency and instruction issue.  The candidates' results are kept in list order and scattered
-    // into the output once both sides are done.
+    // into the output once both sides are done.  Everything small that discover needs is queued
+    // BEFORE the fill starts: a kernel that ends while the fill is running waits for the L2's
+    // write-back at its end, behind 40 GB of dirty lines -- measured: a 32-byte memset took 4.4 ms
+    // (profiles/r03_overlap_trace.txt) -- so the only kernel boundary under the fill is discover's own.
     bool overlap = plan->cand != 0;
     if (const char *e = getenv("MASHGPU_SPARSE_OVERLAP")) overlap = overlap && atoi(e) != 0;
     uint32_t fill_bpc = overlap ? 4u : 16u;               // workgroups per CU: leave room for the other kernels
     if (const char *e = getenv("MASHGPU_SPARSE_FILL_BPC")) fill_bpc = (uint32_t)std::max(1, atoi(e));
+    if (plan->cand != 0) {
+        if (plan->cand > ix->cand_cap) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            for (void **q : {(void **)&ix->cand, (void **)&ix->res})
+                if (*q) { hipFree(*q); *q = nullptr; }
+            ix->cand_cap = 0;
+            const uint64_t cap = plan->cand + plan->cand / 8 + 1024;
+            if (hipMalloc(&ix->cand, cap * sizeof(uint2)) != hipSuccess || hipMalloc(&ix->res, cap * sizeof(uint2)) != hipSuccess) {
+                (void)hipGetLastError();
+                return fail(ctx, MG_ERR_NOMEM, "compare: no device memory for the candidate list");
+            }
+            ix->cand_cap = cap;
+        }
+        if (nrows > ix->seg_rows) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            for (void **q : {(void **)&ix->seg_base, (void **)&ix->seg_cnt, (void **)&ix->chunks, (void **)&ix->chunk_inc, &ix->scan_temp})
+                if (*q) { hipFree(*q); *q = nullptr; }
+            ix->seg_rows = 0;
+            const uint64_t cap = nrows + nrows / 8 + 256;
+            ix->scan_temp_bytes = mg::sparse_scan_temp_bytes((uint32_t)cap);
+            if (hipMalloc(&ix->seg_base, cap * 8) != hipSuccess || hipMalloc(&ix->seg_cnt, cap * 4) != hipSuccess ||
+                hipMalloc(&ix->chunks, cap * 4) != hipSuccess || hipMalloc(&ix->chunk_inc, cap * 4) != hipSuccess ||
+                hipMalloc(&ix->scan_temp, std::max<size_t>(ix->scan_temp_bytes, 16)) != hipSuccess) {
+                (void)hipGetLastError();
+                return fail(ctx, MG_ERR_NOMEM, "compare: no device memory for the merge work list");
+            }
+            ix->seg_rows = cap;
+        }
+        HIP_TRY(ctx, hipMemsetAsync(ix->counters, 0, 4 * 8, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ix->seg_cnt, 0, nrows * 4, ctx->stream));
+    }
     hipStream_t fs = ctx->stream;
     if (overlap) {
         if (!ctx->aux) {
@@ -2241,6 +2287,10 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
         if (e == hipSuccess && nshort_rows && !ix->short_rows_host.empty())
             e = mg::launch_sparse_fill_short(a.out, short_rows_dev, short_rcnt_dev, nshort_rows, ix->short_rows, ix->short_cnt,
                                              (uint32_t)ix->short_rows_host.size(), a.row_begin, a.ncols, a.triangle, a.out_base, s, fs);
+        // pairs of two copies of one sketch: {n, n} (after the fill, on its stream)
+        if (e == hipSuccess && triangle && ix->cls_members)
+            e = mg::launch_sparse_class_pairs(a.out, ix->cls_rows, ix->cls_first, ix->off, ix->rep, ix->cls_members, a.row_begin, a.row_end,
+                                              a.out_base, fs);
         prof_end(ctx, ctx->prof_fill, fs);
         if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare (fill): ") + hipGetErrorString(e));
         if (overlap) HIP_TRY(ctx, hipEventRecord(ctx->ev_join, fs));
@@ -2248,41 +2298,12 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
     *handled = true;
     if (plan->cand == 0) return MG_OK;
     // ---- discover + merge ----
-    if (plan->cand > ix->cand_cap) {
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        for (void **q : {(void **)&ix->cand, (void **)&ix->res})
-            if (*q) { hipFree(*q); *q = nullptr; }
-        ix->cand_cap = 0;
-        const uint64_t cap = plan->cand + plan->cand / 8 + 1024;
-        if (hipMalloc(&ix->cand, cap * sizeof(uint2)) != hipSuccess || hipMalloc(&ix->res, cap * sizeof(uint2)) != hipSuccess) {
-            (void)hipGetLastError();
-            return fail(ctx, MG_ERR_NOMEM, "compare: no device memory for the candidate list");
-        }
-        ix->cand_cap = cap;
-    }
-    if (nrows > ix->seg_rows) {
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        for (void **q : {(void **)&ix->seg_base, (void **)&ix->seg_cnt, (void **)&ix->chunks, (void **)&ix->chunk_inc, &ix->scan_temp})
-            if (*q) { hipFree(*q); *q = nullptr; }
-        ix->seg_rows = 0;
-        const uint64_t cap = nrows + nrows / 8 + 256;
-        ix->scan_temp_bytes = mg::sparse_scan_temp_bytes((uint32_t)cap);
-        if (hipMalloc(&ix->seg_base, cap * 8) != hipSuccess || hipMalloc(&ix->seg_cnt, cap * 4) != hipSuccess ||
-            hipMalloc(&ix->chunks, cap * 4) != hipSuccess || hipMalloc(&ix->chunk_inc, cap * 4) != hipSuccess ||
-            hipMalloc(&ix->scan_temp, std::max<size_t>(ix->scan_temp_bytes, 16)) != hipSuccess) {
-            (void)hipGetLastError();
-            return fail(ctx, MG_ERR_NOMEM, "compare: no device memory for the merge work list");
-        }
-        ix->seg_rows = cap;
-    }
     a.cand = ix->cand;
     a.res = ix->res;
     a.cand_cap = ix->cand_cap;
     a.seg_base = ix->seg_base;
     a.seg_cnt = ix->seg_cnt;
     a.chunk_inc = ix->chunk_inc;
-    HIP_TRY(ctx, hipMemsetAsync(ix->counters, 0, 4 * 8, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(ix->seg_cnt, 0, nrows * 4, ctx->stream));
     prof_begin(ctx, ctx->prof_discover);
     hipError_t e = mg::launch_sparse_discover(a, false, ctx->stream);
     prof_end(ctx, ctx->prof_discover);
@@ -3061,7 +3082,15 @@ struct mg_comm {
 
 struct mg_dtable {
     mg_comm *comm = nullptr;
-    std::vector<mg_table *> t;                // one replica per context of the communicator
+    std::vector<mg_table *> t;                // one replica per context of the communicator -- or, row-sharded
+                                              // (mg_dtable_upload_rows), context g's rows [row0[g], row0[g + 1])
+    bool by_rows = false;
+    std::vector<uint64_t> row0;               // row-sharded: G + 1 boundaries
+    uint64_t n = 0, s = 0;
+    // replicated tables compared by reference rows: views of a replica's row slice, kept for their caches
+    struct View { size_t g; uint64_t lo, hi; mg_table *t; };
+    mutable std::vector<View> views;
+    mutable std::mutex views_mu;
 };
 
 static int comm_fail(mg_comm *c, int code, const std::string &msg)
@@ -3220,6 +3249,8 @@ int mg_dtable_upload(mg_comm *c, const uint64_t *hashes, const uint32_t *nhash, 
     if (!c || !c->local || !out) return comm_fail(c, MG_ERR_INVALID, "mg_dtable_upload: needs a local communicator");
     mg_dtable *d = new mg_dtable;
     d->comm = c;
+    d->n = n;
+    d->s = s;
     mg_table *t0 = nullptr;
     int rc = mg_table_upload(c->ctxs[0], hashes, nhash, lengths, n, s, &t0);   // host -> GPU 0
     if (rc != MG_OK) { c->err = c->ctxs[0]->err; delete d; return rc; }
@@ -3253,8 +3284,49 @@ int mg_dtable_upload(mg_comm *c, const uint64_t *hashes, const uint32_t *nhash, 
 void mg_dtable_free(mg_dtable *d)
 {
     if (!d) return;
+    for (auto &v : d->views) mg_table_free(v.t);
     for (mg_table *t : d->t) mg_table_free(t);
     delete d;
+}
+
+// The LARGER side of a rect job need not be replicated: every device gets a block of consecutive rows
+// (host -> each GPU its own rows, no exchange).  Such a table is the reference side of
+// mg_compare_rect_*_sharded_host, which then splits the job by reference rows ("broadcast
+// the smaller side, shard the larger side by rows").
+int mg_dtable_upload_rows(mg_comm *c, const uint64_t *hashes, const uint32_t *nhash, const uint64_t *lengths, uint64_t n,
+                          uint64_t s, mg_dtable **out)
+{
+    if (!c || !c->local || !out) return comm_fail(c, MG_ERR_INVALID, "mg_dtable_upload_rows: needs a local communicator");
+    if (!hashes || !nhash || s == 0) return comm_fail(c, MG_ERR_INVALID, "mg_dtable_upload_rows: bad argument");
+    mg_dtable *d = new mg_dtable;
+    d->comm = c;
+    d->by_rows = true;
+    d->n = n;
+    d->s = s;
+    const int G = (int)c->ctxs.size();
+    d->row0.resize((size_t)G + 1);
+    for (int g = 0; g < G; g++) {
+        uint64_t lo, hi;
+        mg_shard_rows(0, n, G, g, &lo, &hi);
+        d->row0[(size_t)g] = lo;
+        d->row0[(size_t)g + 1] = hi;
+    }
+    d->t.assign((size_t)G, nullptr);
+    std::vector<int> rcs((size_t)G, MG_OK);
+    std::vector<std::thread> th;
+    auto up = [&](int g) {
+        const uint64_t lo = d->row0[(size_t)g], hi = d->row0[(size_t)g + 1];
+        // (an empty block still gets a table: one padding row, zero rows visible)
+        rcs[(size_t)g] = mg_table_upload(c->ctxs[(size_t)g], hashes + lo * s, nhash + lo, lengths ? lengths + lo : nullptr, hi - lo, s, &d->t[(size_t)g]);
+    };
+    for (int g = 0; g < G; g++) {
+        if (G == 1) up(g); else th.emplace_back(up, g);
+    }
+    for (auto &t : th) t.join();
+    for (int g = 0; g < G; g++)
+        if (rcs[(size_t)g] != MG_OK) { c->err = c->ctxs[(size_t)g]->err; const int rc = rcs[(size_t)g]; mg_dtable_free(d); return rc; }
+    *out = d;
+    return MG_OK;
 }
 
 mg_table *mg_dtable_local(mg_dtable *d, int i) { return d && i >= 0 && (size_t)i < d->t.size() ? d->t[(size_t)i] : nullptr; }
@@ -3336,11 +3408,87 @@ static int sharded_blocks(mg_comm *c, uint64_t rb, uint64_t re, bool triangle, u
 }
 }  // extern "C++"
 
-static int dtable_check(mg_comm *c, const mg_dtable *t, const char *who)
+static int dtable_check(mg_comm *c, const mg_dtable *t, const char *who, bool rows_ok = false)
 {
     if (!c || !c->local || !t || t->comm != c || t->t.size() != c->ctxs.size())
         return comm_fail(c, MG_ERR_INVALID, std::string(who) + ": needs a local communicator and tables uploaded through it");
+    if (t->by_rows && !rows_ok)
+        return comm_fail(c, MG_ERR_INVALID, std::string(who) + ": a row-sharded table (mg_dtable_upload_rows) can only be the reference side of a rect job");
     return MG_OK;
+}
+
+// ---- rect jobs split by REFERENCE rows: device g compares every query with its block of
+// reference rows -- its own rows of a row-sharded table, or a view of its replica's rows [lo, hi) -- and
+// the blocks are put back into the reference's query-major order on the host.
+static int ref_block(mg_comm *c, const mg_dtable *ref, size_t g, const mg_table **tab, uint64_t *lo_out, uint64_t *hi_out)
+{
+    const size_t G = c->ctxs.size();
+    if (ref->by_rows) {
+        *tab = ref->t[g];
+        *lo_out = ref->row0[g];
+        *hi_out = ref->row0[g + 1];
+        return MG_OK;
+    }
+    uint64_t lo, hi;
+    mg_shard_rows(0, ref->t[0]->n, (int)G, (int)g, &lo, &hi);
+    *lo_out = lo;
+    *hi_out = hi;
+    std::lock_guard<std::mutex> lk(ref->views_mu);
+    for (auto &v : ref->views)
+        if (v.g == g && v.lo == lo && v.hi == hi) { *tab = v.t; return MG_OK; }
+    const mg_table *full = ref->t[g];
+    mg_table *view = nullptr;
+    const int rc = mg_table_wrap_dev(c->ctxs[g], full->hashes + lo * full->s, full->nhash + lo, full->lengths ? full->lengths + lo : nullptr,
+                                     hi - lo, full->s, &view);
+    if (rc != MG_OK) return rc;
+    ref->views.push_back({g, lo, hi, view});
+    *tab = view;
+    return MG_OK;
+}
+
+extern "C++" {
+// dense outputs (mg_counts / mg_pair): call(g, ref block, query replica, q0, q1, out) fills (q1 - q0) x block rows
+template <class T, class Call>
+static int rect_by_ref_rows(mg_comm *c, const mg_dtable *ref, const mg_dtable *qry, uint64_t q_begin, uint64_t q_end, T *out_host, Call call)
+{
+    const size_t G = c->ctxs.size();
+    const uint64_t nref = ref->by_rows ? ref->n : ref->t[0]->n;
+    std::vector<int> rcs(G, MG_OK);
+    std::vector<std::thread> th;
+    auto work = [&](size_t g) {
+        const mg_table *blk = nullptr;
+        uint64_t lo = 0, hi = 0;
+        int rc = ref_block(c, ref, g, &blk, &lo, &hi);
+        if (rc != MG_OK || lo >= hi) { rcs[g] = rc; return; }
+        const uint64_t w = hi - lo;
+        // queries in blocks that bound the staging buffer (256 MiB)
+        const uint64_t qstep = std::max<uint64_t>(1, (256ull << 20) / (w * sizeof(T)));
+        std::vector<T> tmp;
+        for (uint64_t q0 = q_begin; q0 < q_end && rc == MG_OK; q0 += qstep) {
+            const uint64_t q1 = std::min(q_end, q0 + qstep);
+            tmp.resize((q1 - q0) * w);
+            rc = call(g, blk, qry->t[g], q0, q1, tmp.data());
+            for (uint64_t q = q0; q < q1 && rc == MG_OK; q++)
+                memcpy(out_host + (q - q_begin) * nref + lo, tmp.data() + (q - q0) * w, w * sizeof(T));
+        }
+        rcs[g] = rc;
+    };
+    for (size_t g = 0; g < G; g++) {
+        if (G == 1) work(g); else th.emplace_back(work, g);
+    }
+    for (auto &t : th) t.join();
+    for (size_t g = 0; g < G; g++)
+        if (rcs[g] != MG_OK) { c->err = c->ctxs[g]->err; return rcs[g]; }
+    return MG_OK;
+}
+}  // extern "C++"
+
+// which side of a rect job is cut: the reference rows when that table is row-sharded or the larger side
+static bool rect_split_refs(const mg_dtable *ref, uint64_t nq)
+{
+    if (ref->by_rows) return true;
+    if (getenv("MASHGPU_RECT_SPLIT")) return strcmp(getenv("MASHGPU_RECT_SPLIT"), "refs") == 0;
+    return ref->t.size() > 1 && ref->t[0]->n > nq;
 }
 
 int mg_compare_tri_sharded_host(mg_comm *c, const mg_dtable *t, uint64_t row_begin, uint64_t row_end, mg_counts *out_host)
@@ -3357,11 +3505,16 @@ int mg_compare_tri_sharded_host(mg_comm *c, const mg_dtable *t, uint64_t row_beg
 int mg_compare_rect_sharded_host(mg_comm *c, const mg_dtable *ref, const mg_dtable *qry, uint64_t q_begin, uint64_t q_end,
                                  mg_counts *out_host)
 {
-    int rc = dtable_check(c, ref, "mg_compare_rect_sharded_host");
+    int rc = dtable_check(c, ref, "mg_compare_rect_sharded_host", true);
     if (rc == MG_OK) rc = dtable_check(c, qry, "mg_compare_rect_sharded_host");
     if (rc != MG_OK) return rc;
     if (q_end > qry->t[0]->n) q_end = qry->t[0]->n;
     if (q_begin >= q_end) return MG_OK;
+    if (rect_split_refs(ref, q_end - q_begin))
+        return rect_by_ref_rows<mg_counts>(c, ref, qry, q_begin, q_end, out_host,
+                                           [&](size_t g, const mg_table *blk, const mg_table *q, uint64_t q0, uint64_t q1, mg_counts *o) {
+            return mg_compare_rect_host(c->ctxs[g], blk, q, q0, q1, o);
+        });
     const uint64_t nref = ref->t[0]->n;
     return sharded_blocks(c, q_begin, q_end, false, nref, [&](int g, uint64_t lo, uint64_t hi, uint64_t before) {
         return mg_compare_rect_host(c->ctxs[(size_t)g], ref->t[(size_t)g], qry->t[(size_t)g], lo, hi, out_host + before);
@@ -3385,11 +3538,16 @@ int mg_compare_rect_pairs_sharded_host(mg_comm *c, const mg_dtable *ref, const m
                                        int kmer_size, double kmer_space, double max_distance, double max_p_value,
                                        mg_pair *out_host)
 {
-    int rc = dtable_check(c, ref, "mg_compare_rect_pairs_sharded_host");
+    int rc = dtable_check(c, ref, "mg_compare_rect_pairs_sharded_host", true);
     if (rc == MG_OK) rc = dtable_check(c, qry, "mg_compare_rect_pairs_sharded_host");
     if (rc != MG_OK) return rc;
     if (q_end > qry->t[0]->n) q_end = qry->t[0]->n;
     if (q_begin >= q_end) return MG_OK;
+    if (rect_split_refs(ref, q_end - q_begin))
+        return rect_by_ref_rows<mg_pair>(c, ref, qry, q_begin, q_end, out_host,
+                                         [&](size_t g, const mg_table *blk, const mg_table *q, uint64_t q0, uint64_t q1, mg_pair *o) {
+            return mg_compare_rect_pairs_host(c->ctxs[g], blk, q, q0, q1, kmer_size, kmer_space, max_distance, max_p_value, o);
+        });
     const uint64_t nref = ref->t[0]->n;
     return sharded_blocks(c, q_begin, q_end, false, nref, [&](int g, uint64_t lo, uint64_t hi, uint64_t before) {
         return mg_compare_rect_pairs_host(c->ctxs[(size_t)g], ref->t[(size_t)g], qry->t[(size_t)g], lo, hi, kmer_size, kmer_space,
@@ -3452,18 +3610,110 @@ int mg_compare_rect_results_sharded_host(mg_comm *c, const mg_dtable *ref, const
                                          uint64_t q_end, int kmer_size, double kmer_space, double max_distance,
                                          double max_p_value, mg_result *out_host, uint64_t capacity, uint64_t *count_out)
 {
-    int rc = dtable_check(c, ref, "mg_compare_rect_results_sharded_host");
+    int rc = dtable_check(c, ref, "mg_compare_rect_results_sharded_host", true);
     if (rc == MG_OK) rc = dtable_check(c, qry, "mg_compare_rect_results_sharded_host");
     if (rc != MG_OK) return rc;
     if (!count_out || (!out_host && capacity)) return comm_fail(c, MG_ERR_INVALID, "mg_compare_rect_results_sharded_host: NULL argument");
     *count_out = 0;
     if (q_end > qry->t[0]->n) q_end = qry->t[0]->n;
     if (q_begin >= q_end) return MG_OK;
+    if (rect_split_refs(ref, q_end - q_begin)) {
+        // every device lists the survivors of its reference block (query major, columns relative to the block);
+        // the reference order is query major over ALL references: per query, the blocks' runs in block order
+        const size_t G = c->ctxs.size();
+        std::vector<std::vector<mg_result>> part(G);
+        std::vector<uint64_t> lo_of(G, 0);
+        std::vector<int> rcs(G, MG_OK);
+        std::vector<std::thread> th;
+        auto work = [&](size_t g) {
+            const mg_table *blk = nullptr;
+            uint64_t lo = 0, hi = 0;
+            int r = ref_block(c, ref, g, &blk, &lo, &hi);
+            lo_of[g] = lo;
+            if (r != MG_OK || lo >= hi) { rcs[g] = r; return; }
+            std::vector<mg_result> &v = part[g];
+            v.resize(1u << 16);
+            uint64_t n = 0;
+            r = mg_compare_rect_results_host(c->ctxs[g], blk, qry->t[g], q_begin, q_end, kmer_size, kmer_space, max_distance, max_p_value,
+                                             v.data(), (uint64_t)v.size(), &n);
+            if (r == MG_ERR_NOMEM && n > v.size()) {
+                v.resize(n);
+                r = mg_compare_rect_results_host(c->ctxs[g], blk, qry->t[g], q_begin, q_end, kmer_size, kmer_space, max_distance, max_p_value,
+                                                 v.data(), (uint64_t)v.size(), &n);
+            }
+            v.resize(r == MG_OK ? n : 0);
+            rcs[g] = r;
+        };
+        for (size_t g = 0; g < G; g++) {
+            if (G == 1) work(g); else th.emplace_back(work, g);
+        }
+        for (auto &t : th) t.join();
+        for (size_t g = 0; g < G; g++)
+            if (rcs[g] != MG_OK) { c->err = c->ctxs[g]->err; return rcs[g]; }
+        uint64_t total = 0;
+        for (auto &v : part) total += v.size();
+        *count_out = total;
+        if (total > capacity) return comm_fail(c, MG_ERR_NOMEM, "compare: more passing pairs than `capacity` (see *count_out)");
+        std::vector<size_t> cur(G, 0);
+        uint64_t at = 0;
+        for (uint64_t q = q_begin; q < q_end; q++)                 // (rows of the results are query indices)
+            for (size_t g = 0; g < G; g++) {
+                std::vector<mg_result> &v = part[g];
+                while (cur[g] < v.size() && v[cur[g]].row == q) {
+                    mg_result r = v[cur[g]++];
+                    r.col += (uint32_t)lo_of[g];
+                    out_host[at++] = r;
+                }
+            }
+        return MG_OK;
+    }
     return sharded_results(c, q_begin, q_end, false, ref->t[0]->n, out_host, capacity, count_out,
                            [&](int g, uint64_t lo, uint64_t hi, mg_result *o, uint64_t cap, uint64_t *n) {
         return mg_compare_rect_results_host(c->ctxs[(size_t)g], ref->t[(size_t)g], qry->t[(size_t)g], lo, hi, kmer_size, kmer_space,
                                             max_distance, max_p_value, o, cap, n);
     });
+}
+
+/* Sketching on every GPU of a local communicator (independent units, no collective; the
+ * reference fans its files / records out to its -p threads, Sketch.cpp:211,354, and consumes the
+ * results in submission order, ThreadPool.hxx:127-167): the sketches are cut into one block of
+ * consecutive sketches per device, balanced by BYTES, one host thread per device runs mg_sketch_host on
+ * its block, and every block writes its own rows of the outputs -- input order by construction. */
+int mg_sketch_sharded_host(mg_comm *c, const mg_params *p, const uint8_t *bases, uint64_t nbases, const uint64_t *sketch_off,
+                           uint64_t nsketch, uint64_t *hashes_out, uint32_t *nhash_out, uint32_t *counts_out)
+{
+    if (!c || !c->local) return comm_fail(c, MG_ERR_INVALID, "mg_sketch_sharded_host: needs a local communicator");
+    if (!p || !sketch_off || !hashes_out || !nhash_out || (!bases && nbases)) return comm_fail(c, MG_ERR_INVALID, "mg_sketch_sharded_host: NULL argument");
+    if (nsketch == 0) return MG_OK;
+    const size_t G = c->ctxs.size();
+    const uint64_t s = p->sketch_size;
+    // block boundaries: sketch k goes to the device whose share of the bytes its first byte falls in
+    std::vector<uint64_t> b(G + 1, nsketch);
+    b[0] = 0;
+    const uint64_t total = sketch_off[nsketch] - sketch_off[0];
+    for (size_t g = 1; g < G; g++) {
+        const uint64_t want = sketch_off[0] + (uint64_t)((unsigned __int128)total * g / G);
+        b[g] = (uint64_t)(std::lower_bound(sketch_off, sketch_off + nsketch, want) - sketch_off);
+        if (b[g] < b[g - 1]) b[g] = b[g - 1];
+    }
+    std::vector<int> rcs(G, MG_OK);
+    std::vector<std::thread> th;
+    auto work = [&](size_t g) {
+        const uint64_t k0 = b[g], k1 = b[g + 1];
+        if (k0 >= k1) return;
+        const uint64_t base = sketch_off[k0];
+        std::vector<uint64_t> off(k1 - k0 + 1);
+        for (uint64_t k = k0; k <= k1; k++) off[k - k0] = sketch_off[k] - base;
+        rcs[g] = mg_sketch_host(c->ctxs[g], p, bases + base, off.back(), off.data(), k1 - k0, hashes_out + k0 * s, nhash_out + k0,
+                                counts_out ? counts_out + k0 * s : nullptr);
+    };
+    for (size_t g = 0; g < G; g++) {
+        if (G == 1) work(g); else th.emplace_back(work, g);
+    }
+    for (auto &t : th) t.join();
+    for (size_t g = 0; g < G; g++)
+        if (rcs[g] != MG_OK) { c->err = c->ctxs[g]->err; return rcs[g]; }
+    return MG_OK;
 }
 
 /* ------------------------------------------------------------------ screening */

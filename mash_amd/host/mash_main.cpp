@@ -412,12 +412,17 @@ void flush_batch(Gpu &gpu, SketchSet &set, PendingBatch &b)
     vector<uint32_t> nhash(n), counts(set.p.counts ? n * s : 0);
     if (!b.sess && b.bases.empty()) b.bases.push_back((uint8_t)MG_RECORD_SEP);
     const auto t_gpu = std::chrono::steady_clock::now();
+    // (several GPUs, MASH_GPU_DEVICES: the batch is cut into byte-balanced blocks of sketches, one per device)
     const int sk_rc = b.sess ? mg_sketch_finish(b.sess, hashes.data(), nhash.data(), set.p.counts ? counts.data() : nullptr)
-                             : mg_sketch_host(gpu.ctx, &mp, b.bases.data(), b.bases.size(), b.off.data(), n, hashes.data(), nhash.data(),
-                                              set.p.counts ? counts.data() : nullptr);
+                      : mg_comm_size(gpu.comm) > 1 && mp.min_copies <= 1
+                          ? mg_sketch_sharded_host(gpu.comm, &mp, b.bases.data(), b.bases.size(), b.off.data(), n, hashes.data(), nhash.data(),
+                                                   set.p.counts ? counts.data() : nullptr)
+                          : mg_sketch_host(gpu.ctx, &mp, b.bases.data(), b.bases.size(), b.off.data(), n, hashes.data(), nhash.data(),
+                                           set.p.counts ? counts.data() : nullptr);
     g_gpu_sketch_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_gpu).count();
     if (sk_rc != MG_OK) {
-        cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl;
+        const char *m = mg_comm_last_error(gpu.comm);
+        cerr << "ERROR: " << ((m && *m) ? m : mg_last_error(gpu.ctx)) << endl;
         exit(1);
     }
     for (uint64_t i = 0; i < n; i++) {
@@ -759,7 +764,8 @@ void init_from_files(Gpu &gpu, SketchSet &set, const vector<string> &files, cons
 {
     set.p = p;
     PendingBatch b;
-    b.stream = !getenv("MASH_AMD_NO_STREAM");             // (env: the concatenate-then-copy path, for tests)
+    // (env: the concatenate-then-copy path, for tests; several GPUs: whole batches, cut over the devices)
+    b.stream = !getenv("MASH_AMD_NO_STREAM") && mg_comm_size(gpu.comm) <= 1;
     // concatenated mode with -p > 1: files are parsed ahead by a pool of workers (ParsePool)
     // Reads options (-r -m -c -b -g) reach sketchFile through here too (`mash dist -r ref.msh reads.fq`,
     // `mash triangle -r ...`): ONE sketch per file with the reads-mode heap, the estimated (or -g)
@@ -860,7 +866,7 @@ void warn_kmer_size(const SketchSet &set, const KmerWarning &w)
 
 // dense table upload
 // the same table on EVERY device of the communicator (host -> GPU 0 -> RCCL broadcast)
-mg_dtable *upload_all(Gpu &gpu, const SketchSet &set, uint64_t s, vector<uint64_t> *lengths_out = nullptr)
+mg_dtable *upload_all(Gpu &gpu, const SketchSet &set, uint64_t s, vector<uint64_t> *lengths_out = nullptr, bool by_rows = false)
 {
     const uint64_t n = set.refs.size();
     vector<uint64_t> h(std::max<uint64_t>(n * s, 1), MG_HASH_PAD), len(std::max<uint64_t>(n, 1));
@@ -873,7 +879,9 @@ mg_dtable *upload_all(Gpu &gpu, const SketchSet &set, uint64_t s, vector<uint64_
         std::copy(r.hashes.begin(), r.hashes.begin() + k, h.begin() + i * s);
     }
     mg_dtable *d = nullptr;
-    if (mg_dtable_upload(gpu.comm, h.data(), nh.data(), len.data(), n, s, &d) != MG_OK) {
+    // by_rows: the larger side of a rect job -- every GPU gets a block of its rows instead of a replica
+    if ((by_rows ? mg_dtable_upload_rows(gpu.comm, h.data(), nh.data(), len.data(), n, s, &d)
+                 : mg_dtable_upload(gpu.comm, h.data(), nh.data(), len.data(), n, s, &d)) != MG_OK) {
         cerr << "ERROR: " << mg_comm_last_error(gpu.comm) << endl;
         exit(1);
     }
@@ -1135,7 +1143,10 @@ int cmd_dist(int argc, const char **argv)
     const uint64_t nref = ref.refs.size(), nq = qry.refs.size();
     if (nref == 0 || nq == 0) return 0;
     vector<uint64_t> len_ref, len_qry;
-    mg_dtable *dr = upload_all(gpu, ref, ref.p.sketch_size, &len_ref);
+    // several GPUs: the larger side is cut into row blocks; references larger than the queries
+    // are then not even replicated (the host-tail test paths address device 0's table as a whole)
+    const bool ref_by_rows = mg_comm_size(gpu.comm) > 1 && nref > nq && !host_finish_wanted() && !getenv("MASH_AMD_NO_FILTER");
+    mg_dtable *dr = upload_all(gpu, ref, ref.p.sketch_size, &len_ref, ref_by_rows);
     mg_dtable *dq = upload_all(gpu, qry, qry.p.sketch_size, &len_qry);
     mg_table *tr = mg_dtable_local(dr, 0), *tq = mg_dtable_local(dq, 0);
     const double kspace = ref.kmer_space();

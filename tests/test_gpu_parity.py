@@ -1204,6 +1204,71 @@ def test_sharded_screen_equals_single_gpu(eng, devices, monkeypatch):
     t.free()
 
 
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0, 0, 0]])
+def test_sharded_sketch_equals_single_gpu(eng, oracle, devices):
+    """mg_sketch_sharded_host: blocks of consecutive sketches balanced by bytes, one host thread per
+    context, rows in input order == mg_sketch_host on one context -- sketches of very different sizes
+    (one of them most of the bytes), empty ones, more devices than sketches, counts."""
+    rng = np.random.default_rng(len(devices))
+    sizes = [3000, 120000, 10, 0, 700, 45000, 45000, 21, 9000]
+    sketches = [[synth._rand_dna(rng, n)] if n else [b""] for n in sizes]
+    sketches[5] = [synth._rand_dna(rng, 20000), b"ACGT", synth._rand_dna(rng, 25000)]        # several records
+    p = eng.params(k=21, s=300)
+    want = eng.sketch_host(sketches, p, counts=True)
+    comm = abi.LocalComm(devices)
+    got = comm.sketch(sketches, p, counts=True)
+    for a_, b_ in zip(got, want):
+        assert np.array_equal(a_, b_)
+    two = comm.sketch(sketches[:2], p)                                   # fewer sketches than devices
+    assert np.array_equal(two[0], want[0][:2]) and np.array_equal(two[1], want[1][:2])
+    h, _, _, _, _ = oracle.sketch_records(sketches[1], oracle.params(k=21, s=300))
+    assert np.array_equal(got[0][1, : len(h)], h)
+    comm.close()
+
+
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0]])
+def test_rect_split_by_reference_rows(eng, oracle, devices, monkeypatch):
+    """SURVEY 8e for `mash dist`: the larger side is cut.  Few queries against many references: every
+    context compares all queries with ITS block of reference rows (a view of its replica, or its own rows
+    of a row-sharded table) and the blocks go back into the reference's query-major order -- counts,
+    finished records and the survivor list equal the single-context calls byte for byte."""
+    table, nh, lengths = synth.clustered_sketches(331, 200, clusters=5, seed=21)
+    nh[7] = 50; table[7, 50:] = np.uint64(abi.HASH_PAD)
+    lengths = np.random.default_rng(2).integers(10 ** 4, 10 ** 7, 331).astype(np.uint64)
+    q = np.array([3, 120, 7, 330])
+    t = eng.table_upload(table, nh, lengths)
+    tq = eng.table_upload(table[q], nh[q], lengths[q])
+    want_c = eng.compare_rect_host(t, tq)
+    want_p = eng.compare_rect_pairs(t, tq, 21, KSPACE21, 0.3, 1e-3)
+    want_r = eng.compare_rect_results(t, tq, 21, KSPACE21, 0.3, 1e-3)
+    assert 0 < len(want_r) < want_c.size
+    comm = abi.LocalComm(devices)
+    dq = comm.upload(table[q], nh[q], lengths[q])
+    for mode in ("replicated", "rows"):
+        dr = comm.upload(table, nh, lengths) if mode == "replicated" else comm.upload_rows(table, nh, lengths)
+        got_c = comm.rect(dr, dq, 331, 4)                                # 331 references > 4 queries: cut by reference rows
+        assert np.array_equal(got_c, want_c), mode
+        got_p = comm.rect_pairs(dr, dq, 331, 4, 21, KSPACE21, 0.3, 1e-3)
+        assert np.array_equal(got_p["pass"], want_p["pass"]) and _same_bits(got_p["distance"], want_p["distance"])
+        ok = want_p["pass"] == 1
+        assert _same_bits(got_p["p_value"][ok], want_p["p_value"][ok])
+        got_r = comm.rect_results(dr, dq, 4, 21, KSPACE21, 0.3, 1e-3, capacity=8)      # small: exercises the retry
+        assert got_r.tobytes() == want_r.tobytes(), mode
+        comm.free(dr)
+    # the query side cut instead (as before) gives the same
+    monkeypatch.setenv("MASHGPU_RECT_SPLIT", "queries")
+    dr = comm.upload(table, nh, lengths)
+    assert np.array_equal(comm.rect(dr, dq, 331, 4), want_c)
+    monkeypatch.delenv("MASHGPU_RECT_SPLIT")
+    # a row-sharded table cannot be a triangle's table
+    drows = comm.upload_rows(table, nh, lengths)
+    with pytest.raises(abi.MashGpuError):
+        comm.tri(drows, 331)
+    comm.free(drows); comm.free(dr); comm.free(dq)
+    comm.close()
+    t.free(); tq.free()
+
+
 def test_rank_communicator_single_rank(eng):
     """mg_comm rank mode with one rank: unique id, ncclCommInitRank, mg_table_broadcast (the root
     aliases its own table), all-reduce of a u32 buffer -- the call path bench.py takes under

@@ -96,7 +96,7 @@ def model_triangle(table, nhash, s, rb, re, dedup=True):
             e = off[er] + p
             lo = ix["lo_of"][e]
             hi = ix["pos_of"][e] if er == i else ix["gstart"][ix["rank_of"][e] + 1]
-            marked.update(int(r) for r in ix["sorted_rows"][lo:hi] if r < i)
+            marked.update(int(r) for r in ix["sorted_rows"][lo:hi] if r < i and r != er)
         assert all(rep[c] == c for c in marked)
         cand = sorted(b for c in marked for b in members[c] if b < i)
         ncand += len(cand)
@@ -104,10 +104,12 @@ def model_triangle(table, nhash, s, rb, re, dedup=True):
         ai = 2 * ix["rank_of"][off[er]: off[er + 1]]
         for j in cand:
             rj = int(rep[j])
-            if rj == er:
+            assert rj != er
+            row_n[j], row_d[j] = merge_codes(ai, 2 * ix["rank_of"][off[rj]: off[rj + 1]], s)
+        # pairs inside the row's class: {n, n} (sp_class_pairs_kernel)
+        for j in members[er]:
+            if j < i:
                 row_n[j] = row_d[j] = cnt[i]
-            else:
-                row_n[j], row_d[j] = merge_codes(ai, 2 * ix["rank_of"][off[rj]: off[rj + 1]], s)
         numer.append(row_n); denom.append(row_d)
     return np.concatenate(numer) if numer else np.zeros(0), np.concatenate(denom) if denom else np.zeros(0), ncand
 
@@ -177,7 +179,7 @@ def test_model_triangle_equals_oracle(oracle, s, dedup):
     got_n, got_d, ncand = model_triangle(table, nhash, s, 0, n, dedup)
     assert np.array_equal(got_n, numer) and np.array_equal(got_d, denom)
     # the candidates are exactly the pairs sharing a hash: every other pair has numer 0
-    assert ncand >= int(np.count_nonzero(numer))
+    assert ncand + sum(len(v) * (len(v) - 1) // 2 for v in classes_of(table, nhash, s)[2].values()) >= int(np.count_nonzero(numer))
     # a row range
     n2, d2, _, _ = oracle.triangle(table, nhash, lengths, 13, 38, 21, 4.0 ** 21)
     g2n, g2d, _ = model_triangle(table, nhash, s, 13, 38, dedup)
