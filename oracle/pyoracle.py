@@ -42,11 +42,16 @@ class OraclePair(C.Structure):
     ]
 
 
-def build(ref=False):
-    """Compile the oracle (and, where /root/reference exists, oracle/_ref)."""
+def build(ref=False, cli=False):
+    """Compile the oracle (and, where /root/reference exists, oracle/_ref; cli: also the reference CLI,
+    plain and bound to libmashgpu.so -- the latter needs mash_amd/libmashgpu.so to be built)."""
     subprocess.run(["make", "-C", _HERE, "-s"], check=True)
     if ref and os.path.isdir("/root/reference/src/mash"):
         subprocess.run(["make", "-C", _HERE, "-s", "ref"], check=True)
+        if cli:
+            subprocess.run(["make", "-C", _HERE, "-s", "refcli"], check=True)
+            if os.path.exists(os.path.join(os.path.dirname(_HERE), "mash_amd", "libmashgpu.so")):
+                subprocess.run(["make", "-C", _HERE, "-s", "refcli-gpu"], check=True)
 
 
 def ref_available():
