@@ -127,7 +127,10 @@ struct SparseArgs {
     const uint32_t *cls_off;
     const uint32_t *cls_rows;
     const uint32_t *gstart;        // first sorted position of every value (a copy walks the whole run of a value)
+    const uint32_t *order;         // rows of the launch in visiting order (nullptr: row_end - 1 - slot)
 };
+hipError_t launch_sparse_row_keys(const uint32_t *off, const uint32_t *rank_img, const uint32_t *gstart, uint32_t n, uint32_t rs,
+                                  uint32_t *key, hipStream_t stream);
 hipError_t launch_sparse_class_pairs(uint2 *out, const uint32_t *cls_rows, const uint32_t *cls_first, const uint32_t *off,
                                      const uint32_t *rep, uint32_t members, uint32_t row_begin, uint32_t row_end, uint64_t out_base,
                                      hipStream_t stream);

@@ -185,6 +185,32 @@ hipError_t launch_sparse_row_equal(const uint64_t *hashes, uint64_t stride, cons
     return hipGetLastError();
 }
 
+// key of a row for the order in which discovery visits the rows: the start of the run of its first value that
+// another row holds too (rows of one clade then sit next to each other and read the same runs), 0xFFFFFFFF
+// for a row that shares nothing
+__global__ __launch_bounds__(256) void sp_row_key_kernel(const uint32_t *off, const uint32_t *rank_img, const uint32_t *gstart, uint32_t n,
+                                                         uint32_t rs, uint32_t *key)
+{
+    const uint32_t row = blockIdx.x * 256u + threadIdx.x;
+    if (row >= n) return;
+    const uint32_t cnt = off[row + 1] - off[row];
+    uint32_t k = 0xFFFFFFFFu;
+    for (uint32_t p = 0; p < cnt; p++) {
+        const uint32_t g = rank_img[(uint64_t)row * rs + p] >> 1;
+        const uint32_t gs = gstart[g];
+        if (gstart[g + 1] - gs >= 2u) { k = gs; break; }
+    }
+    key[row] = k;
+}
+
+hipError_t launch_sparse_row_keys(const uint32_t *off, const uint32_t *rank_img, const uint32_t *gstart, uint32_t n, uint32_t rs,
+                                  uint32_t *key, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(sp_row_key_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, off, rank_img, gstart, n, rs, key);
+    return hipGetLastError();
+}
+
 // row stride of a code image: s rounded up to a chunk of four, plus one chunk the loop may load behind the row
 uint32_t sparse_img_stride(uint32_t s) { return ((s + 3u) & ~3u) + 4u; }
 
@@ -307,8 +333,9 @@ __global__ __launch_bounds__(256) void sp_discover_kernel(SparseArgs a)
     __shared__ uint32_t s_w[4];
     __shared__ unsigned long long s_base;
     __shared__ unsigned long long s_inc[4];
-    // largest rows first (triangle: they have the most columns)
-    const uint32_t row = a.row_end - 1u - blockIdx.x;
+    // rows in the order of a.order (rows that share runs of the index next to each other: the runs then stay
+    // in L2), else largest rows first
+    const uint32_t row = a.order ? a.order[blockIdx.x] : a.row_end - 1u - blockIdx.x;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
     const uint32_t ncols = a.triangle ? row : a.ncols;
     const uint32_t W = (ncols + 31u) >> 5;
@@ -508,7 +535,7 @@ __global__ __launch_bounds__(SPM_NT) void sp_merge_rows_kernel(SparseArgs a)
     }
     const uint32_t slot = lo;
     const uint32_t chunk = item - (slot ? a.chunk_inc[slot - 1] : 0u);
-    const uint32_t row = a.row_end - 1u - slot;          // as sp_discover_kernel maps its workgroups
+    const uint32_t row = a.order ? a.order[slot] : a.row_end - 1u - slot;      // as sp_discover_kernel maps its workgroups
     const uint32_t cnt = a.seg_cnt[slot];
     const uint64_t base = a.seg_base[slot] + (uint64_t)chunk * SPM_NT;
     const uint32_t left = cnt - chunk * SPM_NT;
@@ -543,20 +570,43 @@ __global__ __launch_bounds__(SPM_NT) void sp_merge_rows_kernel(SparseArgs a)
     uint32_t loaded = 16;
     bool pend = true;
     __syncthreads();                                     // A staged
-    uint32_t ia = 0, ib = 0, common = 0, denom = 0;
+    uint32_t ia = 0, ib = 0, denom = 0;                  // (common = ia + ib - denom: a match advances both sides for one union element)
     bool active = have && !same && s > 0 && nA > 0 && nB > 0;
     while (__ballot(active) != 0) {
+        // A lane with at least 8 codes left on both sides and 8 union elements to go cannot reach any of
+        // the loop's three bounds within 8 steps: when that holds for every lane still merging, the round
+        // runs without the per-step tests (two compares, two advances, two LDS reads per step).
+        uint32_t room = 0;
+        if (active) {
+            const uint32_t ra = nA - ia, rb = nB - ib, rd = s - denom;
+            room = ra < rb ? ra : rb;
+            room = room < rd ? room : rd;
+        }
+        if (__ballot(active && room < 8u) == 0) {
+            if (active) {
 #pragma unroll
-        for (int t = 0; t < 8; t++) {
-            const uint32_t av = A[ia];
-            uint32_t bv = myring[(ib & (SPM_RING - 1u)) * 64u];
-            if (RECT) bv += 1u;
-            const bool adva = active && av <= bv, advb = active && bv <= av;
-            common += (adva && advb) ? 1u : 0u;
-            denom += active ? 1u : 0u;
-            ia += adva ? 1u : 0u;
-            ib += advb ? 1u : 0u;
-            active = active && denom < s && ia < nA && ib < nB;
+                for (int t = 0; t < 8; t++) {
+                    const uint32_t av = A[ia];
+                    uint32_t bv = myring[(ib & (SPM_RING - 1u)) * 64u];
+                    if (RECT) bv += 1u;
+                    ia += av <= bv ? 1u : 0u;
+                    ib += bv <= av ? 1u : 0u;
+                }
+                denom += 8;
+                active = denom < s && ia < nA && ib < nB;
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const uint32_t av = A[ia];
+                uint32_t bv = myring[(ib & (SPM_RING - 1u)) * 64u];
+                if (RECT) bv += 1u;
+                const bool adva = active && av <= bv, advb = active && bv <= av;
+                denom += active ? 1u : 0u;
+                ia += adva ? 1u : 0u;
+                ib += advb ? 1u : 0u;
+                active = active && denom < s && ia < nA && ib < nB;
+            }
         }
         if (pend) {
             land(loaded, p0);
@@ -570,6 +620,7 @@ __global__ __launch_bounds__(SPM_NT) void sp_merge_rows_kernel(SparseArgs a)
         }
     }
     if (have) {
+        uint32_t common = ia + ib - denom;
         if (same) {
             common = denom = nA;
         } else if (denom < s) {                            // :367-385

@@ -108,7 +108,8 @@ struct mg_table {
         uint32_t *short_rows = nullptr, *short_cnt = nullptr;    // rows with fewer than s hashes (ascending) and their counts
         std::vector<uint32_t> short_rows_host;
         // what a (rows, range) job costs, learned by a counting pass the first time it is seen
-        struct Plan { const void *rows; uint64_t rb, re; bool triangle; uint64_t cand, shared; bool use; };
+        struct Plan { const void *rows; uint64_t rb, re; bool triangle; uint64_t cand, shared; bool use; uint32_t *order; };
+        std::vector<uint32_t> order_host;  // all rows by locality key (see sp_row_key_kernel)
         std::vector<Plan> plans;
         uint2 *cand = nullptr, *res = nullptr;    // candidate list and the candidates' results, grown on demand
         uint64_t cand_cap = 0;
@@ -1389,6 +1390,8 @@ void mg_table_free(mg_table *t)
     if (!t->sparse.empty()) {
         hipSetDevice(t->ctx->device);
         for (mg_table::Sparse *sp : t->sparse) {
+            for (auto &pl : sp->plans)
+                if (pl.order) hipFree(pl.order);
             for (void *q : {(void *)sp->off, (void *)sp->keys_sorted, (void *)sp->grp, (void *)sp->gstart, (void *)sp->sorted_rows,
                             (void *)sp->lohi, (void *)sp->rank_img, (void *)sp->short_rows, (void *)sp->short_cnt, (void *)sp->cand,
                             (void *)sp->res, (void *)sp->seg_base, (void *)sp->seg_cnt, (void *)sp->chunks, (void *)sp->chunk_inc,
@@ -2078,6 +2081,24 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, mg_tab
     sp->max_group = h_stat.max_group;
     sp->build_ms = ms;
     sp->usable = true;
+    // visiting order of the rows: by the run of their first shared value, larger rows first inside a run
+    if (!getenv("MASHGPU_SPARSE_NO_ORDER")) {
+        DevBuf<uint32_t> d_key;
+        std::vector<uint32_t> key(n);
+        if (d_key.alloc(n) == hipSuccess &&
+            mg::launch_sparse_row_keys(sp->off, sp->rank_img, sp->gstart, (uint32_t)n, sp->rs, d_key, ctx->stream) == hipSuccess &&
+            hipMemcpyAsync(key.data(), d_key, n * 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+            hipStreamSynchronize(ctx->stream) == hipSuccess) {
+            sp->order_host.resize(n);
+            for (uint64_t i = 0; i < n; i++) sp->order_host[i] = (uint32_t)i;
+            std::sort(sp->order_host.begin(), sp->order_host.end(), [&](uint32_t x, uint32_t y) {
+                const uint32_t kx = key[rep[x]], ky = key[rep[y]];          // a copy reads what its representative reads
+                return kx != ky ? kx < ky : x > y;
+            });
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     if (getenv("MASHGPU_SPARSE_DBG"))
         fprintf(stderr, "compare sparse: index of %llu rows (%llu copies of earlier rows), s %u: %u entries, %u distinct, shared %llu, largest run %u, %.2f ms\n",
                 (unsigned long long)n, (unsigned long long)sp->copies, s, E, sp->G, (unsigned long long)sp->shared, sp->max_group, ms);
@@ -2194,7 +2215,22 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
         for (auto &pl : ix->plans)
             if (pl.rows == (const void *)rows && pl.rb == row_begin && pl.re == row_end && pl.triangle == triangle) plan = &pl;
     mg_table::Sparse::Plan fresh;
+    fresh.order = nullptr;
+    a.order = plan ? plan->order : nullptr;
     if (!plan) {
+        if (triangle && !ix->order_host.empty()) {         // the rows of this job in visiting order
+            std::vector<uint32_t> ord;
+            ord.reserve(nrows);
+            for (uint32_t r : ix->order_host)
+                if (r >= row_begin && r < row_end) ord.push_back(r);
+            if (ord.size() == nrows && hipMalloc(&fresh.order, nrows * 4) == hipSuccess) {
+                if (hipMemcpyAsync(fresh.order, ord.data(), nrows * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+                    hipStreamSynchronize(ctx->stream) != hipSuccess) { hipFree(fresh.order); fresh.order = nullptr; }
+            } else {
+                (void)hipGetLastError();
+            }
+            a.order = fresh.order;
+        }
         a.cand = nullptr;
         a.cand_cap = 0;
         HIP_TRY(ctx, hipMemsetAsync(ix->counters, 0, 4 * 8, ctx->stream));
@@ -2220,7 +2256,11 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
                     (unsigned long long)row_begin, (unsigned long long)row_end, triangle ? "triangle" : "rect", (unsigned long long)pairs,
                     (unsigned long long)fresh.cand, (unsigned long long)fresh.shared, t_sparse * 1e3, t_dense * 1e3);
         if (triangle) {
-            if (ix->plans.size() >= 64) ix->plans.erase(ix->plans.begin());
+            if (ix->plans.size() >= 64) {
+                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                if (ix->plans.front().order) hipFree(ix->plans.front().order);
+                ix->plans.erase(ix->plans.begin());
+            }
             ix->plans.push_back(fresh);
             plan = &ix->plans.back();
         } else {
@@ -2229,14 +2269,16 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
     }
     if (!force && !plan->use) return MG_OK;
 
-    // ---- fill, on its own stream beside discover + merge: one is bound by HBM writes, the others by
-    // latency and instruction issue.  The candidates' results are kept in list order and scattered
-    // into the output once both sides are done.  Everything small that discover needs is queued
-    // BEFORE the fill starts: a kernel that ends while the fill is running waits for the L2's
-    // write-back at its end, behind 40 GB of dirty lines -- measured: a 32-byte memset took 4.4 ms
-    // (profiles/r03_overlap_trace.txt) -- so the only kernel boundary under the fill is discover's own.
-    bool overlap = plan->cand != 0;
-    if (const char *e = getenv("MASHGPU_SPARSE_OVERLAP")) overlap = overlap && atoi(e) != 0;
+    // ---- fill.  The candidates' results are kept in list order and scattered into the output after it.
+    // (Optionally on its own stream beside discover + merge.  Everything small that discover needs is
+    // queued BEFORE the fill starts: a kernel that ends while the fill is running waits for the L2's
+    // write-back at its end, behind 40 GB of dirty lines -- measured: a 32-byte memset took 4.4 ms,
+    // profiles/r03_overlap_trace.txt.)
+    // MEASURED (profiles/r03_sparse_phases.json): side by side with the fill, discover takes 13.2 ms instead
+    // of 6.2 -- its loads queue behind 40 GB of writes -- and the pass 19.4 ms instead of 19.3: nothing is
+    // gained, so the phases run one after the other unless MASHGPU_SPARSE_OVERLAP=1 asks for the experiment.
+    bool overlap = false;
+    if (const char *e = getenv("MASHGPU_SPARSE_OVERLAP")) overlap = plan->cand != 0 && atoi(e) != 0;
     uint32_t fill_bpc = overlap ? 4u : 16u;               // workgroups per CU: leave room for the other kernels
     if (const char *e = getenv("MASHGPU_SPARSE_FILL_BPC")) fill_bpc = (uint32_t)std::max(1, atoi(e));
     if (plan->cand != 0) {

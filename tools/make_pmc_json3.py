@@ -43,6 +43,8 @@ for tag in ("fetch", "write", "sqa", "sqb"):
             k = short(r["Kernel_Name"])
             if k is None:
                 continue
+            if tag == "sqb" and r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                continue                                   # every SQ pass carries its own cycles: sqb's are used below, with its LDS counters
             d = ctr.setdefault(k, {})
             d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
             if r["Counter_Name"] in ("FETCH_SIZE", "GRBM_GUI_ACTIVE"):
