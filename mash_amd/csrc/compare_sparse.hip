@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -365,18 +366,33 @@ __global__ __launch_bounds__(256) void sp_discover_kernel(SparseArgs a)
                 if (!((bm[r >> 5] >> (r & 31u)) & 1u)) atomicOr(&bm[r >> 5], 1u << (r & 31u));
             }
         }
+        // Long runs, four at a time: the first 64 rows of each are requested before any is consumed (a run is
+        // a dependent global load away; one run at a time left the wave waiting on each), the rest of a run
+        // longer than 64 follows in strides.
+        // (test before set: the rows of a clade name each other in every one of their runs, and consecutive
+        //  rows share a word -- reads of one word broadcast, atomics on it queue up)
+        auto mark = [&](uint32_t r) {
+            if (copy && (r >= row || r == er)) return;               // (its own class: sp_class_pairs_kernel)
+            if (!((bm[r >> 5] >> (r & 31u)) & 1u)) atomicOr(&bm[r >> 5], 1u << (r & 31u));
+        };
         uint64_t longm = __ballot(len > SHORT);
         while (longm != 0) {
-            const int l = __builtin_ctzll(longm);
-            longm &= longm - 1;
-            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)lh.x, l);
-            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)lh.y, l);
-            // (test before set: the rows of a clade name each other in every one of their runs, and
-            //  consecutive rows share a word -- reads of one word broadcast, atomics on it queue up)
-            for (uint32_t q = lo + lane; q < hi; q += 64u) {
-                const uint32_t r = a.sorted_rows[q];
-                if (copy && (r >= row || r == er)) continue;         // (its own class: sp_class_pairs_kernel)
-                if (!((bm[r >> 5] >> (r & 31u)) & 1u)) atomicOr(&bm[r >> 5], 1u << (r & 31u));
+            uint32_t lo4[4], hi4[4], r4[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                lo4[k] = hi4[k] = 0;
+                if (longm != 0) {                                    // uniform
+                    const int l = __builtin_ctzll(longm);
+                    longm &= longm - 1;
+                    lo4[k] = (uint32_t)__builtin_amdgcn_readlane((int)lh.x, l);
+                    hi4[k] = (uint32_t)__builtin_amdgcn_readlane((int)lh.y, l);
+                }
+                r4[k] = lo4[k] + lane < hi4[k] ? a.sorted_rows[lo4[k] + lane] : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (r4[k] != 0xFFFFFFFFu) mark(r4[k]);
+                for (uint32_t q = lo4[k] + 64u + lane; q < hi4[k]; q += 64u) mark(a.sorted_rows[q]);
             }
         }
     }
@@ -820,6 +836,29 @@ hipError_t launch_sparse_scatter(const SparseArgs &a, uint64_t expect, uint32_t 
     return hipGetLastError();
 }
 
+// variant: every wave writes 4 KB of consecutive addresses per round (four stores 1 KB apart) instead of four
+// streams a grid apart (MASHGPU_SPARSE_FILL_MODE=1; measured against the default in profiles/)
+__global__ __launch_bounds__(256) void sp_fill_const_wave_kernel(uint2 *out, uint64_t pairs, uint32_t denom)
+{
+    const uint64_t head = ((reinterpret_cast<uintptr_t>(out) & 8u) != 0 && pairs > 0) ? 1u : 0u;
+    const uint64_t nvec = (pairs - head) >> 1;
+    sp_u32x4 *body = reinterpret_cast<sp_u32x4 *>(out + head);
+    const sp_u32x4 v = {0u, denom, 0u, denom};
+    const uint64_t lane = threadIdx.x & 63u;
+    const uint64_t gw = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6), tw = (uint64_t)gridDim.x * 4u;
+    for (uint64_t base = gw * 256u; base < nvec; base += tw * 256u) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint64_t i = base + (uint64_t)u * 64u + lane;
+            if (i < nvec) __builtin_nontemporal_store(v, body + i);
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (head) out[0] = make_uint2(0u, denom);
+        if (((pairs - head) & 1u) != 0) out[pairs - 1] = make_uint2(0u, denom);
+    }
+}
+
 hipError_t launch_sparse_fill(uint2 *out, uint64_t pairs, uint32_t denom, uint32_t blocks_per_cu, uint32_t cus, hipStream_t stream)
 {
     if (pairs == 0) return hipSuccess;
@@ -827,7 +866,9 @@ hipError_t launch_sparse_fill(uint2 *out, uint64_t pairs, uint32_t denom, uint32
     const uint64_t most = (uint64_t)(cus ? cus : 256) * (blocks_per_cu ? blocks_per_cu : 16);
     if (blocks > most) blocks = most;
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(sp_fill_const_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, out, pairs, denom);
+    const int mode = getenv("MASHGPU_SPARSE_FILL_MODE") ? atoi(getenv("MASHGPU_SPARSE_FILL_MODE")) : 0;
+    if (mode == 1) hipLaunchKernelGGL(sp_fill_const_wave_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, out, pairs, denom);
+    else hipLaunchKernelGGL(sp_fill_const_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, out, pairs, denom);
     return hipGetLastError();
 }
 
