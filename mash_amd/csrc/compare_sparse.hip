@@ -647,6 +647,52 @@ __global__ __launch_bounds__(SPM_NT) void sp_merge_rows_kernel(SparseArgs a)
     }
 }
 
+// candidates in REFERENCE order (rows ascending; a row's segment is already in column order): the rows'
+// counts (by row), then, after an exclusive scan, every segment copied to its row's place
+__global__ __launch_bounds__(256) void sp_row_counts_kernel(SparseArgs a, uint32_t *cnt_by_row)
+{
+    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t nrows = a.row_end - a.row_begin;
+    if (slot >= nrows) return;
+    const uint32_t row = a.order ? a.order[slot] : a.row_end - 1u - slot;
+    cnt_by_row[row - a.row_begin] = a.seg_cnt[slot];
+}
+
+__global__ __launch_bounds__(256) void sp_gather_rows_kernel(SparseArgs a, const uint32_t *row_base, uint32_t row_add, uint2 *rc_out, uint2 *counts_out)
+{
+    const uint32_t slot = blockIdx.x;
+    const uint32_t row = a.order ? a.order[slot] : a.row_end - 1u - slot;
+    const uint32_t cnt = a.seg_cnt[slot];
+    const unsigned long long src = a.seg_base[slot];
+    const uint32_t dst = row_base[row - a.row_begin];
+    for (uint32_t t = threadIdx.x; t < cnt; t += 256) {
+        const uint2 pr = a.cand[src + t];
+        rc_out[dst + t] = make_uint2(pr.x + row_add, pr.y);
+        counts_out[dst + t] = a.res[src + t];
+    }
+}
+
+hipError_t launch_sparse_gather_rows(const SparseArgs &a, uint32_t *cnt_by_row, uint32_t *row_base, void *temp, size_t temp_bytes, uint32_t row_add,
+                                     uint2 *rc_out, uint2 *counts_out, hipStream_t stream)
+{
+    const uint32_t nrows = a.row_end - a.row_begin;
+    if (nrows == 0) return hipSuccess;
+    hipLaunchKernelGGL(sp_row_counts_kernel, dim3((nrows + 255u) / 256u), dim3(256), 0, stream, a, cnt_by_row);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    e = rocprim::exclusive_scan(temp, temp_bytes, (const uint32_t *)cnt_by_row, row_base, 0u, (size_t)nrows, rocprim::plus<uint32_t>(), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sp_gather_rows_kernel, dim3(nrows), dim3(256), 0, stream, a, (const uint32_t *)row_base, row_add, rc_out, counts_out);
+    return hipGetLastError();
+}
+
+size_t sparse_gather_temp_bytes(uint32_t nrows)
+{
+    size_t b = 0;
+    rocprim::exclusive_scan(nullptr, b, (const uint32_t *)nullptr, (uint32_t *)nullptr, 0u, (size_t)nrows, rocprim::plus<uint32_t>(), (hipStream_t) nullptr);
+    return b;
+}
+
 // results of the candidates -> their output slots (after the fill)
 __global__ __launch_bounds__(256) void sp_scatter_kernel(SparseArgs a)
 {
@@ -836,8 +882,7 @@ hipError_t launch_sparse_scatter(const SparseArgs &a, uint64_t expect, uint32_t 
     return hipGetLastError();
 }
 
-// variant: every wave writes 4 KB of consecutive addresses per round (four stores 1 KB apart) instead of four
-// streams a grid apart (MASHGPU_SPARSE_FILL_MODE=1; measured against the default in profiles/)
+// every wave writes 4 KB of consecutive addresses per round (four stores 1 KB apart): the default
 __global__ __launch_bounds__(256) void sp_fill_const_wave_kernel(uint2 *out, uint64_t pairs, uint32_t denom)
 {
     const uint64_t head = ((reinterpret_cast<uintptr_t>(out) & 8u) != 0 && pairs > 0) ? 1u : 0u;
@@ -866,7 +911,9 @@ hipError_t launch_sparse_fill(uint2 *out, uint64_t pairs, uint32_t denom, uint32
     const uint64_t most = (uint64_t)(cus ? cus : 256) * (blocks_per_cu ? blocks_per_cu : 16);
     if (blocks > most) blocks = most;
     if (blocks == 0) blocks = 1;
-    const int mode = getenv("MASHGPU_SPARSE_FILL_MODE") ? atoi(getenv("MASHGPU_SPARSE_FILL_MODE")) : 0;
+    // default: every wave writes 4 KB of consecutive addresses per round (6.7 ms for the 40 GB of C3 against
+    // 7.1 ms with four streams a grid apart, MASHGPU_SPARSE_FILL_MODE=0; profiles/r03_sparse_tuning.json)
+    const int mode = getenv("MASHGPU_SPARSE_FILL_MODE") ? atoi(getenv("MASHGPU_SPARSE_FILL_MODE")) : 1;
     if (mode == 1) hipLaunchKernelGGL(sp_fill_const_wave_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, out, pairs, denom);
     else hipLaunchKernelGGL(sp_fill_const_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, out, pairs, denom);
     return hipGetLastError();

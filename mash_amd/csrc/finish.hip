@@ -26,6 +26,12 @@ constexpr int FN_SEG = FN_NT * FN_PER;       // pairs per workgroup of the mark 
 
 __device__ __forceinline__ void pair_rc(const FinishArgs &a, uint64_t idx, uint64_t &row, uint64_t &col)
 {
+    if (a.list_rc) {                                       // a list of pairs (the sparse engine's candidates), not a block of the matrix
+        const uint2 rc = a.list_rc[idx];
+        row = rc.x;
+        col = rc.y;
+        return;
+    }
     if (a.triangle) {
         const uint64_t f = a.first_row;
         const uint64_t g = (f ? f * (f - 1) / 2 : 0) + idx;               // index in the whole triangle

@@ -38,6 +38,7 @@ struct FinishArgs {
     uint32_t *denom_seen;          // [s + 1] denominators carried by survivors (pass A)
     FinishEdge *edges;             // pass B: survivors with rank in [win_lo, win_lo + win_n)
     uint64_t win_lo, win_n;
+    const uint2 *list_rc;          // list mode: counts[idx] belongs to pair {row, col} = list_rc[idx] (reference order); nullptr: flat order
 };
 
 uint64_t finish_segments(uint64_t pairs);

@@ -105,6 +105,7 @@ struct mg_table {
         uint32_t cls_members = 0;          // rows in classes of two and more
         uint64_t cls_pairs = 0;            // pairs inside those classes (full triangle)
         uint64_t copies = 0;               // rows that are a copy of an earlier row
+        bool has_empty = false;            // some row has no hash at all
         uint32_t *short_rows = nullptr, *short_cnt = nullptr;    // rows with fewer than s hashes (ascending) and their counts
         std::vector<uint32_t> short_rows_host;
         // what a (rows, range) job costs, learned by a counting pass the first time it is seen
@@ -2003,6 +2004,7 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, mg_tab
             if (c < s) sp->short_rows_host.push_back((uint32_t)i);
         } else {
             sp->short_rows_host.push_back((uint32_t)i);
+            sp->has_empty = true;
         }
     }
     sp->off_host[n] = (uint32_t)E64;
@@ -2109,8 +2111,14 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, mg_tab
 // the caller goes on to the tile engine (table outside the index's reach, or the job is one the
 // tile engine does faster: nearly every pair shares a few hashes -- a candidate costs a merge of
 // ~2 s steps here, an unrelated pair there costs 1/30 of that).
+// `job` != nullptr: only the candidates are wanted (thresholded calls: a pair that shares no hash has
+// distance 1 and p-value 1, no filter lets it through) -- discover + merge run, the output is neither
+// filled nor touched, and the job describes the candidate list {row, col} / {common, denom} left in
+// the index's buffers.  Refused (handled = false) where pairs outside the list could survive.
+struct SparseJob { mg::SparseArgs args; uint64_t cand = 0; mg_table::Sparse *ix = nullptr; };
+
 static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, uint64_t row_begin, uint64_t row_end,
-                              bool triangle, uint32_t s, mg_counts *out_dev, bool force, bool *handled)
+                              bool triangle, uint32_t s, mg_counts *out_dev, bool force, bool *handled, SparseJob *job = nullptr)
 {
     *handled = false;
     const uint64_t nrows = row_end - row_begin;
@@ -2124,6 +2132,9 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
     int rc = table_sparse_index(ctx, cols, s, &ix);
     if (rc != MG_OK) return rc;
     if (!ix->usable) return MG_OK;
+    // (list mode: two copies of one sketch are a pair at distance 0 that is no candidate, two EMPTY sketches
+    //  likewise -- such tables take the matrix path)
+    if (job && (ix->copies || ix->has_empty)) return MG_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
 
     // ---- row side ----
@@ -2178,6 +2189,7 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
             Eq += c;
             if (Eq >= (1ull << 31)) return MG_OK;
             if (c < s) { qshort_h.push_back((uint32_t)q); qshort_cnt_h.push_back((uint32_t)c); }
+            if (c == 0 && job) return MG_OK;
             if (c && rows->last[row_begin + q] == MG_HASH_PAD) return MG_OK;
         }
         qoff[nrows] = (uint32_t)Eq;
@@ -2313,6 +2325,7 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
         HIP_TRY(ctx, hipMemsetAsync(ix->seg_cnt, 0, nrows * 4, ctx->stream));
     }
     hipStream_t fs = ctx->stream;
+    if (job) overlap = false;
     if (overlap) {
         if (!ctx->aux) {
             HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
@@ -2323,7 +2336,7 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
         fs = ctx->aux;
     }
-    {
+    if (!job) {
         prof_begin(ctx, ctx->prof_fill, fs);
         hipError_t e = mg::launch_sparse_fill(a.out, pairs, s, fill_bpc, (uint32_t)ctx->cu_count, fs);
         if (e == hipSuccess && nshort_rows && !ix->short_rows_host.empty())
@@ -2338,6 +2351,7 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
         if (overlap) HIP_TRY(ctx, hipEventRecord(ctx->ev_join, fs));
     }
     *handled = true;
+    if (job) { job->ix = ix; job->cand = plan->cand; job->args = a; }
     if (plan->cand == 0) return MG_OK;
     // ---- discover + merge ----
     a.cand = ix->cand;
@@ -2357,10 +2371,13 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
                 : mg::launch_sparse_merge(a, plan->cand, (uint32_t)ctx->cu_count, ctx->stream);
     prof_end(ctx, ctx->prof_merge);
     if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare (merge): ") + hipGetErrorString(e));
+    if (job) job->args = a;
     if (overlap) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));      // the fill is done
-    e = mg::launch_sparse_scatter(a, plan->cand, (uint32_t)ctx->cu_count, ctx->stream);
-    if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare (scatter): ") + hipGetErrorString(e));
-    if (!ctx->async || !triangle) {
+    if (!job) {
+        e = mg::launch_sparse_scatter(a, plan->cand, (uint32_t)ctx->cu_count, ctx->stream);
+        if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare (scatter): ") + hipGetErrorString(e));
+    }
+    if (!ctx->async || !triangle || job) {
         // the candidate list was sized from the counting pass of the same rows: an overflow means the
         // tables changed under the cache (mg_table_wrap_dev's contract forbids it)
         unsigned long long h[3] = {0, 0, 0};
@@ -2999,6 +3016,90 @@ static int compare_results(mg_ctx *ctx, const mg_table *rows, const mg_table *co
     const uint64_t max_pairs = 1ull << 30, window = 1ull << 25;
     const uint64_t all_pairs = triangle ? tri_pairs(rb, re) : (re - rb) * cols->n;
     if (all_pairs == 0) return MG_OK;
+    // ---- a filter is on: only pairs that share a hash can pass (numer = 0 means distance 1 and p-value 1), and
+    // those are the inverted-index engine's candidates -- no matrix is filled, no 8 B per pair read back by
+    // the filter pass: discover + merge, the candidates put into reference order, the same two finish passes
+    // over that list.
+    const char *force_kernel = getenv("MASHGPU_COMPARE_KERNEL");
+    if (((max_d >= 0.0 && max_d < 1.0) || (max_p >= 0.0 && max_p < 1.0)) && (!force_kernel || strcmp(force_kernel, "sparse") == 0) &&
+        !getenv("MASHGPU_RESULTS_MATRIX")) {
+        SparseJob job;
+        bool handled = false;
+        int rc = run_compare_sparse(ctx, rows, cols, rb, re, triangle, s, nullptr, force_kernel != nullptr, &handled, &job);
+        if (rc != MG_OK) return rc;
+        if (handled) {
+            const uint64_t K = job.cand;
+            if (K == 0) return MG_OK;
+            if (K >= (1ull << 32)) return fail(ctx, MG_ERR_UNSUPPORTED, "compare: too many candidate pairs for the list path");
+            const uint32_t nrows = (uint32_t)(re - rb);
+            DevBuf<uint2> d_rc, d_cnt;
+            DevBuf<uint32_t> d_byrow, d_base, d_segc2, d_seen2;
+            DevBuf<unsigned long long> d_masks2, d_sego2, d_n2;
+            DevBuf<mg::FinishEdge> d_edges2;
+            DevBuf<unsigned char> d_temp;
+            const size_t tb = mg::sparse_gather_temp_bytes(nrows);
+            if (d_rc.alloc(K) != hipSuccess || d_cnt.alloc(K) != hipSuccess || d_byrow.alloc(nrows) != hipSuccess || d_base.alloc(nrows) != hipSuccess ||
+                d_temp.alloc(std::max<size_t>(tb, 16)) != hipSuccess || d_masks2.alloc(mg::finish_mask_words(K)) != hipSuccess ||
+                d_segc2.alloc(mg::finish_segments(K)) != hipSuccess || d_sego2.alloc(mg::finish_segments(K)) != hipSuccess || d_n2.alloc(1) != hipSuccess ||
+                d_seen2.alloc((uint64_t)s + 1) != hipSuccess || d_edges2.alloc(std::min(K, window)) != hipSuccess)
+                return fail(ctx, MG_ERR_NOMEM, "compare: device allocation failed");
+            HIP_TRY(ctx, hipMemsetAsync(d_byrow, 0, (size_t)nrows * 4, ctx->stream));
+            HIP_TRY(ctx, mg::launch_sparse_gather_rows(job.args, d_byrow, d_base, d_temp, tb, triangle ? 0u : (uint32_t)rb, d_rc, d_cnt, ctx->stream));
+            std::vector<uint32_t> seen2((size_t)s + 1, 0);
+            FinishTables fa(ctx);
+            rc = build_finish_tables(ctx, s, kmer_size, max_d, seen2, fa);
+            if (rc != MG_OK) return rc;
+            mg::FinishArgs f{};
+            f.counts = d_cnt;
+            f.list_rc = d_rc;
+            f.pairs = K;
+            f.first_row = rb;
+            f.ncols = cols->n;
+            f.len_row = rows->lengths;
+            f.len_col = cols->lengths;
+            f.min_numer = fa.d_min;
+            f.lut_start = fa.d_start;
+            f.lut = fa.d_lut;
+            f.kmer_space = kmer_space;
+            f.max_p = max_p;
+            f.s = s;
+            f.triangle = triangle ? 1 : 0;
+            f.masks = d_masks2;
+            f.seg_count = d_segc2;
+            f.seg_off = d_sego2;
+            f.denom_seen = d_seen2;
+            f.edges = d_edges2;
+            unsigned long long n_all = 0;
+            HIP_TRY(ctx, hipMemsetAsync(d_seen2, 0, ((uint64_t)s + 1) * 4, ctx->stream));
+            HIP_TRY(ctx, mg::launch_finish_mark(f, d_n2, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(&n_all, d_n2, 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(seen2.data(), d_seen2, seen2.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            *count_out = n_all;
+            if (n_all > capacity) return fail(ctx, MG_ERR_NOMEM, "compare: more passing pairs than `capacity` (see *count_out)");
+            if (n_all) {
+                FinishTables fb(ctx);
+                rc = build_finish_tables(ctx, s, kmer_size, max_d, seen2, fb);
+                if (rc != MG_OK) return rc;
+                f.lut_start = fb.d_start;
+                f.lut = fb.d_lut;
+                f.min_numer = fb.d_min;
+                for (uint64_t lo = 0; lo < n_all; lo += window) {
+                    f.win_lo = lo;
+                    f.win_n = std::min<uint64_t>(window, n_all - lo);
+                    HIP_TRY(ctx, mg::launch_finish_write(f, ctx->stream));
+                    HIP_TRY(ctx, hipMemcpyAsync(out_host + lo, d_edges2, f.win_n * sizeof(mg_result), hipMemcpyDeviceToHost, ctx->stream));
+                    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                }
+                if (!fb.complete)
+                    for (uint64_t i = 0; i < n_all; i++) {
+                        mg_result &e = out_host[i];
+                        if (e.distance != e.distance) e.distance = mg::mash_distance(e.numer, e.denom, kmer_size);
+                    }
+            }
+            return MG_OK;
+        }
+    }
     const uint64_t blk_pairs = std::min(all_pairs, max_pairs + (triangle ? re : cols->n));
     DevBuf<mg_counts> d_counts;
     DevBuf<mg::FinishEdge> d_edges;

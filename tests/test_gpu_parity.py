@@ -1013,12 +1013,15 @@ def _same_bits(a, b):
     return np.array_equal(np.asarray(a).view(np.uint64), np.asarray(b).view(np.uint64))
 
 
+@pytest.mark.parametrize("engine", ["default", "sparse"])
 @pytest.mark.parametrize("max_d,max_p", [(-1.0, -1.0), (1.0, 1.0), (0.2, -1.0), (-1.0, 1e-10), (0.08, 1e-30), (0.0, 1.0)])
-def test_device_finish_equals_host_finish(eng, oracle, golden_dir, max_d, max_p):
+def test_device_finish_equals_host_finish(eng, oracle, golden_dir, max_d, max_p, engine, monkeypatch):
     """The tail of compareSketches on the device (finish.hip: distance from a host-libm table,
     p-value by the exact double-double tail, both filters) == mg_finish_*_host BIT FOR BIT: on the
     reference-run vectors, on clustered and ragged tables (many distinct denominators), triangle
     and rect, full records and the compacted survivor list."""
+    if engine == "sparse":        # with a filter on, the survivor lists then come straight from the candidate list (no matrix)
+        monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", "sparse")
     z = np.load(os.path.join(golden_dir, "ref_compare_vectors.npz"))
     cases = [(z["table"], z["nhash"], z["lengths"], int(z["k"]), float(z["kmer_space"]))]
     table, nh, lengths = synth.clustered_sketches(300, 400, clusters=6, seed=9)
@@ -1126,6 +1129,34 @@ def test_device_finish_on_exact_p_values(eng, golden_dir):
                 zeros += exact == 0.0
     assert checked == len(cases) and zeros >= 100
     t.free()
+
+
+def test_survivor_lists_from_candidates_equal_the_matrix_path(eng, monkeypatch):
+    """`mash triangle -E -d`, `mash dist -d / -v` at a size where the default dispatch takes the inverted
+    index: with a filter on, the survivors are computed from the candidate list alone (nothing is filled,
+    no 8 B per pair read back) -- same records, same order as the matrix path, triangle (also a row
+    range) and rect, three filter settings."""
+    table, nh, lengths = synth.clustered_sketches(3100, 256, clusters=31, seed=77, pool=400, private=100)
+    lengths = np.random.default_rng(5).integers(10 ** 5, 10 ** 7, 3100).astype(np.uint64)
+    t = eng.table_upload(table, nh, lengths)
+    q = np.arange(100, 1500)
+    tq = eng.table_upload(table[q], nh[q], lengths[q])
+    for max_d, max_p in ((0.1, -1.0), (-1.0, 1e-20), (0.3, 1e-5)):
+        monkeypatch.setenv("MASHGPU_RESULTS_MATRIX", "1")
+        want_t = eng.compare_tri_results(t, 21, KSPACE21, max_d, max_p, capacity=1 << 10)
+        want_s = eng.compare_tri_results(t, 21, KSPACE21, max_d, max_p, row_begin=700, row_end=3000)
+        want_r = eng.compare_rect_results(t, tq, 21, KSPACE21, max_d, max_p)
+        monkeypatch.delenv("MASHGPU_RESULTS_MATRIX")
+        eng.prof_enable(True)
+        eng.prof_reset()
+        got_t = eng.compare_tri_results(t, 21, KSPACE21, max_d, max_p, capacity=1 << 10)
+        assert eng.prof_avg_ms("compare_merge")[1] >= 1 and eng.prof_avg_ms("compare_fill")[1] == 0      # the list path ran
+        eng.prof_enable(False)
+        got_s = eng.compare_tri_results(t, 21, KSPACE21, max_d, max_p, row_begin=700, row_end=3000)
+        got_r = eng.compare_rect_results(t, tq, 21, KSPACE21, max_d, max_p)
+        assert len(want_t) > 1000 and got_t.tobytes() == want_t.tobytes(), (max_d, max_p)
+        assert got_s.tobytes() == want_s.tobytes() and got_r.tobytes() == want_r.tobytes(), (max_d, max_p)
+    t.free(); tq.free()
 
 
 @pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
