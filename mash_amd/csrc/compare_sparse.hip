@@ -520,6 +520,7 @@ __global__ __launch_bounds__(256) void sp_merge_kernel(SparseArgs a)
 // row in discover slot `slot`; an inclusive scan turns it into the item -> row map.
 constexpr uint32_t SPM_NT = 128;
 constexpr uint32_t SPM_RING = 32;                         // column codes a lane keeps in LDS
+constexpr uint32_t SPM_AWIN = 2048;                       // codes of the row staged in LDS at a time
 
 __global__ __launch_bounds__(256) void sp_chunks_kernel(const uint32_t *seg_cnt, uint32_t nrows, uint32_t *chunks)
 {
@@ -560,14 +561,12 @@ __global__ __launch_bounds__(SPM_NT) void sp_merge_rows_kernel(SparseArgs a)
     // copies are compared through their representatives; two rows of one class are {n, n}
     const uint32_t arow = (a.rep && !RECT) ? a.rep[row] : row;
     const uint32_t nA = a.off[arow + 1] - a.off[arow];
-    // the row's codes (and one chunk of its padding: A[nA] is read by a lane that has just finished)
+    // The row's codes sit in LDS a WINDOW of SPM_AWIN at a time (a whole row of s <= 2048; a row of
+    // s = 10 000 in five windows: 40 KB of LDS per workgroup would leave four waves per CU).  A lane that
+    // reaches the window's end waits there; the next window is staged when none is left running.
     uint32_t *A = lds;
-    {
-        const uint4 *src = reinterpret_cast<const uint4 *>(a.row_img + (uint64_t)arow * a.rs_row);
-        const uint32_t nvec = (nA >> 2) + 1u;
-        for (uint32_t v = tid; v < nvec; v += SPM_NT) reinterpret_cast<uint4 *>(A)[v] = src[v];
-    }
-    uint32_t *myring = lds + a.rs_row + (tid >> 6) * (SPM_RING * 64u) + lane;   // code e of this lane: myring[(e & 31) * 64]
+    const uint32_t awords = a.rs_row < SPM_AWIN + 8u ? a.rs_row : SPM_AWIN + 8u;
+    uint32_t *myring = lds + awords + (tid >> 6) * (SPM_RING * 64u) + lane;      // code e of this lane: myring[(e & 31) * 64]
     uint32_t j = have ? a.cand[base + tid].y : 0u;
     if (a.rep) j = a.rep[j];
     const bool same = !RECT && a.rep != nullptr && j == arow;
@@ -585,55 +584,68 @@ __global__ __launch_bounds__(SPM_NT) void sp_merge_rows_kernel(SparseArgs a)
     uint4 p0 = B4[4], p1 = B4[5];
     uint32_t loaded = 16;
     bool pend = true;
-    __syncthreads();                                     // A staged
     uint32_t ia = 0, ib = 0, denom = 0;                  // (common = ia + ib - denom: a match advances both sides for one union element)
     bool active = have && !same && s > 0 && nA > 0 && nB > 0;
-    while (__ballot(active) != 0) {
-        // A lane with at least 8 codes left on both sides and 8 union elements to go cannot reach any of
-        // the loop's three bounds within 8 steps: when that holds for every lane still merging, the round
-        // runs without the per-step tests (two compares, two advances, two LDS reads per step).
-        uint32_t room = 0;
-        if (active) {
-            const uint32_t ra = nA - ia, rb = nB - ib, rd = s - denom;
-            room = ra < rb ? ra : rb;
-            room = room < rd ? room : rd;
+    const uint4 *Asrc = reinterpret_cast<const uint4 *>(a.row_img + (uint64_t)arow * a.rs_row);
+    for (uint32_t a0 = 0;; a0 += SPM_AWIN) {
+        const uint32_t aend = a0 + SPM_AWIN < nA ? a0 + SPM_AWIN : nA;       // this window: codes [a0, aend) (+ one chunk: A[aend] is read, not used)
+        {
+            const uint32_t nvec = ((aend - a0) >> 2) + 1u;
+            for (uint32_t v = tid; v < nvec; v += SPM_NT) reinterpret_cast<uint4 *>(A)[v] = Asrc[(a0 >> 2) + v];
         }
-        if (__ballot(active && room < 8u) == 0) {
-            if (active) {
+        __syncthreads();
+        bool running = active && ia < aend;
+        while (__ballot(running) != 0) {
+            // A lane with at least 8 codes left on both sides (of the window, of its column) and 8 union
+            // elements to go cannot reach any bound within 8 steps: when that holds for every lane still
+            // running, the round runs without the per-step tests (two compares, two advances, two LDS reads).
+            uint32_t room = 0;
+            if (running) {
+                const uint32_t ra = aend - ia, rb = nB - ib, rd = s - denom;
+                room = ra < rb ? ra : rb;
+                room = room < rd ? room : rd;
+            }
+            if (__ballot(running && room < 8u) == 0) {
+                if (running) {
+#pragma unroll
+                    for (int t = 0; t < 8; t++) {
+                        const uint32_t av = A[ia - a0];
+                        uint32_t bv = myring[(ib & (SPM_RING - 1u)) * 64u];
+                        if (RECT) bv += 1u;
+                        ia += av <= bv ? 1u : 0u;
+                        ib += bv <= av ? 1u : 0u;
+                    }
+                    denom += 8;
+                }
+            } else {
+                bool go = running;
 #pragma unroll
                 for (int t = 0; t < 8; t++) {
-                    const uint32_t av = A[ia];
+                    const uint32_t av = A[go ? ia - a0 : 0u];
                     uint32_t bv = myring[(ib & (SPM_RING - 1u)) * 64u];
                     if (RECT) bv += 1u;
-                    ia += av <= bv ? 1u : 0u;
-                    ib += bv <= av ? 1u : 0u;
+                    const bool adva = go && av <= bv, advb = go && bv <= av;
+                    denom += go ? 1u : 0u;
+                    ia += adva ? 1u : 0u;
+                    ib += advb ? 1u : 0u;
+                    go = go && denom < s && ia < aend && ib < nB;
                 }
-                denom += 8;
-                active = denom < s && ia < nA && ib < nB;
             }
-        } else {
-#pragma unroll
-            for (int t = 0; t < 8; t++) {
-                const uint32_t av = A[ia];
-                uint32_t bv = myring[(ib & (SPM_RING - 1u)) * 64u];
-                if (RECT) bv += 1u;
-                const bool adva = active && av <= bv, advb = active && bv <= av;
-                denom += active ? 1u : 0u;
-                ia += adva ? 1u : 0u;
-                ib += advb ? 1u : 0u;
-                active = active && denom < s && ia < nA && ib < nB;
+            if (running) active = denom < s && ia < nA && ib < nB;
+            running = active && ia < aend;
+            if (pend) {
+                land(loaded, p0);
+                land(loaded + 4u, p1);
+                loaded += 8;
+            }
+            pend = active && loaded + 8u - ib <= SPM_RING;
+            if (pend) {
+                p0 = B4[loaded >> 2];
+                p1 = B4[(loaded >> 2) + 1u];
             }
         }
-        if (pend) {
-            land(loaded, p0);
-            land(loaded + 4u, p1);
-            loaded += 8;
-        }
-        pend = active && loaded + 8u - ib <= SPM_RING;
-        if (pend) {
-            p0 = B4[loaded >> 2];
-            p1 = B4[(loaded >> 2) + 1u];
-        }
+        if (aend >= nA) break;                             // uniform: the row is through
+        if (__syncthreads_or(active ? 1 : 0) == 0) break;  // nobody waits for the next window (also: this window's reads are done)
     }
     if (have) {
         uint32_t common = ia + ib - denom;
@@ -833,7 +845,11 @@ hipError_t launch_sparse_merge(const SparseArgs &a, uint64_t expect, uint32_t cu
     return hipGetLastError();
 }
 
-size_t sparse_merge_rows_lds(uint32_t rs_row) { return ((size_t)rs_row + (SPM_NT / 64u) * SPM_RING * 64u) * 4; }
+size_t sparse_merge_rows_lds(uint32_t rs_row)
+{
+    const size_t awords = rs_row < SPM_AWIN + 8u ? rs_row : SPM_AWIN + 8u;
+    return (awords + (SPM_NT / 64u) * SPM_RING * 64u) * 4;
+}
 bool sparse_merge_rows_supported(uint32_t rs_row) { return sparse_merge_rows_lds(rs_row) <= 160 * 1024 - 256; }
 size_t sparse_scan_temp_bytes(uint32_t nrows)
 {

@@ -134,7 +134,7 @@ MG_PV_HD SD binom_pmf_sd(uint64_t j, uint64_t n, double p, DD q)
     SD c{DD{1.0, 0.0}, 0};
     for (uint64_t i = 1; i <= m; i++) {
         c.m = dd_div_d(dd_mul_d(c.m, (double)(n - m + i)), (double)i);
-        if ((i & 31) == 0) c = sd_norm(c);
+        if (c.m.h > 0x1p400) c = sd_norm(c);         // by magnitude: a factor is below 2^64, whatever n is
     }
     c = sd_norm(c);
     return sd_mul(sd_mul(c, sd_pow(DD{p, 0.0}, j)), sd_pow(q, n - j));

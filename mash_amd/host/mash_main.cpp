@@ -1347,16 +1347,34 @@ int cmd_triangle(int argc, const char **argv)
     // evaluation.  The bound test has a 1e-9 relative margin for the rounding of that evaluation.
     const uint64_t s_tab = set.p.sketch_size;
     vector<double> dist_lut, p_bound;
+    uint64_t bound_l1 = 0, bound_l2 = 0;
+    // p-value of the two longest genomes sharing x hashes, with a 1e-9 margin; memoised (workers may both
+    // evaluate an entry: they store the same bits)
+    auto bound_of = [&](uint32_t x) -> double {
+        uint64_t bits = __atomic_load_n(reinterpret_cast<const uint64_t *>(&p_bound[x]), __ATOMIC_RELAXED);
+        double v;
+        memcpy(&v, &bits, 8);
+        if (v != v) {                                              // not evaluated yet
+            v = mg_p_value(x, bound_l1, bound_l2, kspace, s_tab) * (1.0 + 1e-9);
+            memcpy(&bits, &v, 8);
+            __atomic_store_n(reinterpret_cast<uint64_t *>(&p_bound[x]), bits, __ATOMIC_RELAXED);
+        }
+        return v;
+    };
     vector<string> dist_txt;                                       // "\t" + the text of dist_lut[x]: formatted once, not per pair
     if (!edge && s_tab <= (1u << 20) && !getenv("MASH_AMD_FULL_FINISH")) {          // (env: the plain path, for tests)
         uint64_t l1 = 0, l2 = 0;                                   // the two largest lengths
         for (uint64_t v : lengths) { if (v > l1) { l2 = l1; l1 = v; } else if (v > l2) l2 = v; }
         dist_lut.resize(s_tab + 1);
         p_bound.resize(s_tab + 1);
+        // (the bounds are evaluated on first use: a run meets a few hundred distinct numerators, and an
+        //  exact tail costs O(x) -- all s of them up front were minutes at s = 10^5 and a large r)
         for (uint64_t x = 0; x <= s_tab; x++) {
             dist_lut[x] = mg_distance((uint32_t)x, (uint32_t)s_tab, set.p.kmer);
-            p_bound[x] = mg_p_value(x, l1, l2, kspace, s_tab) * (1.0 + 1e-9);
+            p_bound[x] = std::nan("");
         }
+        bound_l1 = l1;
+        bound_l2 = l2;
         dist_txt.resize(s_tab + 1);
         for (uint64_t x = 0; x <= s_tab; x++) {
             FastOut t(false);
@@ -1398,7 +1416,7 @@ int cmd_triangle(int argc, const char **argv)
                     if (full) o << dist_txt[c.numer];
                     else o << '\t' << mg_distance(c.numer, c.denom, set.p.kmer);
                     o.room();
-                    if (!full || p_bound[c.numer] >= pk) {
+                    if (!full || bound_of(c.numer) >= pk) {
                         const double pv = mg_p_value(c.numer, lengths[i], lengths[j], kspace, c.denom);
                         if (pv > pk) pk = pv;
                     }
