@@ -520,7 +520,9 @@ void queue_file_by_sequence(Gpu &gpu, SketchSet &set, PendingBatch &b, const str
 }
 
 // Sketch::initFromReads -> sketchFile over all files, round robin (Sketch.cpp:96-103, :1147-1336)
-void sketch_reads(Gpu &gpu, SketchSet &set, const vector<string> &files)
+// `shared`: a streamed-ingest session kept by the caller across calls (one reads-mode query file after the
+// other in `mash dist -r`): its pinned staging buffers are allocated once, not per file
+void sketch_reads(Gpu &gpu, SketchSet &set, const vector<string> &files, mg_sketch_session **shared = nullptr)
 {
     vector<fastx::Reader *> readers;
     Ref ref;
@@ -543,6 +545,7 @@ void sketch_reads(Gpu &gpu, SketchSet &set, const vector<string> &files)
     const bool none = set.p.never_admit;          // -m 0: every record is read and counted, no hash is kept
     const bool cov_mode = !none && (set.p.target_cov > 0 || set.p.bloom_bytes > 0);
     b.stream = !none && !cov_mode && !getenv("MASH_AMD_NO_STREAM");
+    if (b.stream && shared) b.sess = *shared;
     ensure_session(gpu, set, b);
     mg_reads_session *rs = nullptr;
     size_t reads_chunk = 64u << 20;
@@ -627,7 +630,8 @@ void sketch_reads(Gpu &gpu, SketchSet &set, const vector<string> &files)
         b.end_sketch(std::move(ref));
         flush_batch(gpu, set, b);
     }
-    if (b.sess) mg_sketch_session_free(b.sess);
+    if (b.sess && shared) *shared = b.sess;               // empty again after its finish: the next file fills it
+    else if (b.sess) mg_sketch_session_free(b.sess);
     Ref &r = set.refs.back();
     // estimateSetSize (MinHashHeap.h:45): 2^bits * n / max kept hash
     double est = 0;
@@ -764,6 +768,7 @@ void init_from_files(Gpu &gpu, SketchSet &set, const vector<string> &files, cons
 {
     set.p = p;
     PendingBatch b;
+    mg_sketch_session *reads_sess = nullptr;               // shared by the reads-mode query files
     // (env: the concatenate-then-copy path, for tests; several GPUs: whole batches, cut over the devices)
     b.stream = !getenv("MASH_AMD_NO_STREAM") && mg_comm_size(gpu.comm) <= 1;
     // concatenated mode with -p > 1: files are parsed ahead by a pool of workers (ParsePool)
@@ -792,7 +797,7 @@ void init_from_files(Gpu &gpu, SketchSet &set, const vector<string> &files, cons
             }
             if (reads_files) {
                 flush_batch(gpu, set, b);                  // keep input order
-                sketch_reads(gpu, set, {files[i]});
+                sketch_reads(gpu, set, {files[i]}, &reads_sess);
             } else if (set.p.concatenated) {
                 if (pool && parseable(i)) queue_parsed_file(gpu, set, b, pool->take(i, set.p.kmer));
                 else queue_parsed_file(gpu, set, b, parse_file_concatenated(files[i], set.p.kmer));
@@ -803,6 +808,7 @@ void init_from_files(Gpu &gpu, SketchSet &set, const vector<string> &files, cons
     }
     flush_batch(gpu, set, b);
     if (b.sess) mg_sketch_session_free(b.sess);
+    if (reads_sess) mg_sketch_session_free(reads_sess);
 }
 
 string write_set(const SketchSet &set, const string &path)
