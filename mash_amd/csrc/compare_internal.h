@@ -1,14 +1,10 @@
-// compare_internal.h — launch interface between mashgpu.cpp and compare.hip.
+// compare_internal.h — launch interface between mashgpu.cpp and the compare kernels (compare_sparse.hip,
+// compare_merged.hip, compare.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace mg {
-
-struct CompareTile {
-    uint32_t row0;          // first row of the tile (rows [row0, row0+R) clipped to row_end)
-    uint32_t col0, col1;    // columns [col0, col1)
-};
 
 // Tile of the merged-rows kernel: up to 16 rows given EXPLICITLY (ascending row indices,
 // 0xFFFFFFFF = unused slot) and a column range.  Rows of one tile need not be adjacent: the
@@ -26,7 +22,6 @@ struct CompareArgs {
     const uint32_t *col_nhash;
     const uint32_t *row_pfx;      // u32 prefix images (value >> pfx_shr, saturated), same strides
     const uint32_t *col_pfx;
-    const CompareTile *tiles;
     const MergedTile *mtiles;     // merged kernel
     uint2 *out;                   // {numer, denom}
     uint64_t row_stride, col_stride;
@@ -53,18 +48,9 @@ struct CompareArgs {
     uint32_t win_kmax;            // batches of 8 columns per wave and tile
     uint32_t xcd_remap;           // 1: XCD x takes the x-th contiguous eighth of the tile list
     uint32_t stage_pack;          // window mode: results staged as u16 pairs (s < 32768; set by the launcher)
-    // direct-mapped engine (compare_direct.hip): scratch regions in HBM for the table builds
-    uint32_t *dscr_pfx;           // [regions][16384] prefixes of a tile's entries, bucket by bucket
-    uint16_t *dscr_tag;           // [regions][16384] their tags
-    uint32_t *dscr_lock;          // [regions] 0 = free
-    uint32_t dscr_regions;
 };
 
-// LDS-tiled kernel usable when s <= 1024; rows_per_tile chosen by compare_rows_per_tile.
-bool compare_tiled_supported(uint32_t s);
-uint32_t compare_rows_per_tile(uint32_t s);
-hipError_t launch_compare_tiled(const CompareArgs &a, uint32_t ntiles, hipStream_t stream);
-// Merged-rows kernel (s <= 1024): one bucketed table for all rows of a tile.
+// Tile engine ("merged rows", compare_merged.hip): one bucketed table for all rows of a tile.
 bool compare_merged_supported(uint32_t s);
 uint32_t compare_merged_rows(uint32_t s);
 hipError_t launch_compare_merged(const CompareArgs &a, uint32_t ntiles, hipStream_t stream);
@@ -83,17 +69,6 @@ hipError_t launch_row_classes(const uint64_t *hashes, const uint32_t *nhash, uin
 uint64_t compare_pfx_stride(uint64_t s);          // row stride (u32 entries) of the padded prefix image
 hipError_t launch_make_prefix(const uint64_t *hashes, const uint32_t *nhash, uint64_t n, uint64_t s,
                               uint64_t pfx_stride, uint32_t shr, uint32_t *out, hipStream_t stream);
-// Direct-mapped engine (compare_direct.hip): window tiles over a fingerprint table read with one
-// ds_read_b128 per column element; same arguments as the merged kernel in window mode plus scratch.
-bool compare_direct_supported(uint32_t s);
-uint32_t compare_direct_rows();
-uint32_t compare_direct_entries();
-uint32_t compare_direct_row_entries();
-hipError_t launch_compare_direct(const CompareArgs &a, uint32_t ntiles, hipStream_t stream);
-// Merge-path kernel (s <= ~4000): one wave per pair, row in LDS; ~500 instructions per pair
-// whatever the pair shares.
-bool compare_pairs_supported(uint32_t s);
-hipError_t launch_compare_pairs(const CompareArgs &a, hipStream_t stream);
 // Generic kernel (any s): one wave per pair, binary search in global memory.
 hipError_t launch_compare_generic(const CompareArgs &a, hipStream_t stream);
 

@@ -57,9 +57,6 @@ struct mg_ctx {
     struct TileSlot { void *dev = nullptr, *host = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool pending = false; };
     TileSlot slots[4];
     unsigned slot_next = 0;
-    // scratch regions of the direct-mapped compare engine's table builds (compare_direct.hip), allocated on first use
-    void *dscr = nullptr;
-    uint32_t dscr_regions = 0;
     // small device blocks handed back by finished calls (ctx_malloc / ctx_free)
     struct Block { void *p; size_t bytes; };
     std::vector<Block> blk_free, blk_live;
@@ -262,7 +259,6 @@ void mg_ctx_destroy(mg_ctx *ctx)
 {
     if (!ctx) return;
     mg_prof_reset(ctx);
-    if (ctx->dscr) hipFree(ctx->dscr);
     for (auto &sl : ctx->slots) {
         if (sl.dev) hipFree(sl.dev);
         if (sl.host) hipHostFree(sl.host);
@@ -1701,12 +1697,6 @@ static int run_compare_merged(mg_ctx *ctx, const mg_table *rows, const mg_table 
     bool want_win = a.s >= 1800 || (a.s >= 200 && (double)(row_end - row_begin) * (double)maxcols >= win_cross);
     if (const char *e = getenv("MASHGPU_COMPARE_WINDOWS")) want_win = atoi(e) != 0;
     if (windows_only) want_win = true;
-    // window tiles over the direct-mapped table (compare_direct.hip): MASHGPU_COMPARE_KERNEL=direct forces
-    // it (with windows), MASHGPU_COMPARE_DIRECT=0|1 switches the default
-    bool want_direct = false;
-    if (const char *e = getenv("MASHGPU_COMPARE_DIRECT")) want_direct = atoi(e) != 0;
-    if (const char *e = getenv("MASHGPU_COMPARE_KERNEL")) { if (strcmp(e, "direct") == 0) { want_direct = true; want_win = true; } }
-    if (windows_only) want_direct = false;
     const uint32_t R_plain = R;
     // A launch of few row tiles (a handful of queries against a large database, or a small
     // density class) would leave most CUs idle with full-length column chunks: cut the columns
@@ -1766,33 +1756,10 @@ static int run_compare_merged(mg_ctx *ctx, const mg_table *rows, const mg_table 
         // ---- window plan of this class (large sketches) ----
         WindowPlan plan;
         const uint64_t xmax = mx >> shr;
-        // The direct-mapped engine (compare_direct.hip) takes the class when its tags can index the
-        // plan's rows (<= 1023 hashes of a row per window); else the merged kernel's window mode.
-        bool direct = false;
-        if (want_win && want_direct && mg::compare_direct_supported(a.s)) {
-            rc = plan_windows(ctx, rows, cols, list, shr, xmax, a.s, false, &plan, mg::compare_direct_row_entries());
-            if (rc != MG_OK) return rc;
-            direct = plan.rows != nullptr;
-            if (!direct) plan = WindowPlan();
-        }
-        if (want_win && !direct) {
+        if (want_win) {
             rc = plan_windows(ctx, rows, cols, list, shr, xmax, a.s, windows_only, &plan);
             if (rc != MG_OK) return rc;
             if (windows_only && !plan.rows) return fail(ctx, MG_ERR_HIP, "compare: window plan changed between passes");
-        }
-        if (direct && !ctx->dscr) {
-            const uint32_t regions = 512;                       // > the workgroups resident at any time (one per CU)
-            const size_t per = 16384;
-            HIP_TRY(ctx, hipMalloc(&ctx->dscr, (size_t)regions * per * 6 + (size_t)regions * 4));
-            HIP_TRY(ctx, hipMemsetAsync(ctx->dscr, 0, (size_t)regions * per * 6 + (size_t)regions * 4, ctx->stream));
-            ctx->dscr_regions = regions;
-        }
-        if (direct) {
-            const size_t per = 16384;
-            a.dscr_pfx = static_cast<uint32_t *>(ctx->dscr);
-            a.dscr_tag = reinterpret_cast<uint16_t *>(static_cast<unsigned char *>(ctx->dscr) + (size_t)ctx->dscr_regions * per * 4);
-            a.dscr_lock = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(ctx->dscr) + (size_t)ctx->dscr_regions * per * 6);
-            a.dscr_regions = ctx->dscr_regions;
         }
         const mg_table::Windows *wr = plan.rows, *wc = plan.cols;
         const uint32_t delta = plan.delta, nwin = plan.nwin;
@@ -1855,8 +1822,7 @@ static int run_compare_merged(mg_ctx *ctx, const mg_table *rows, const mg_table 
                 a.win_hi = (uint32_t)std::min<uint64_t>((uint64_t)(w + 1) * delta, xmax + 1);
                 a.dbg = d_dbg ? d_dbg + (size_t)w * mtiles.size() * 3 : nullptr;
                 prof_begin(ctx, ctx->prof_compare);
-                e = direct ? mg::launch_compare_direct(a, (uint32_t)mtiles.size(), ctx->stream)
-                           : mg::launch_compare_merged(a, (uint32_t)mtiles.size(), ctx->stream);
+                e = mg::launch_compare_merged(a, (uint32_t)mtiles.size(), ctx->stream);
                 prof_end(ctx, ctx->prof_compare);
             }
             a.row_win = a.col_win = nullptr;
@@ -2388,6 +2354,12 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
     return MG_OK;
 }
 
+// Engine choice (MASHGPU_COMPARE_KERNEL forces one: sparse | merged | generic):
+//   1. the inverted-index engine (compare_sparse.hip) when its counting pass says the job is sparse
+//      enough -- nearly always for a collection;
+//   2. the tile engine (compare_merged.hip): jobs below 4e6 pairs, jobs where nearly every pair shares a
+//      few hashes, tables the index cannot take;
+//   3. the generic kernel: sketch sizes the tile engine cannot window, and as the independent cross-check.
 static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, uint64_t row_begin,
                        uint64_t row_end, bool triangle, mg_counts *out_dev)
 {
@@ -2400,7 +2372,6 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
     mg::CompareArgs a;
     a.row_hashes = rows->hashes; a.row_nhash = rows->nhash; a.row_stride = rows->s;
     a.col_hashes = cols->hashes; a.col_nhash = cols->nhash; a.col_stride = cols->s;
-    a.tiles = nullptr;
     a.mtiles = nullptr;
     a.out = reinterpret_cast<uint2 *>(out_dev);
     a.row_begin = row_begin; a.row_end = row_end;
@@ -2416,7 +2387,7 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
     a.win_kmax = 0;
     a.xcd_remap = 0;
     a.stage_pack = 0;
-    a.dscr_pfx = nullptr; a.dscr_tag = nullptr; a.dscr_lock = nullptr; a.dscr_regions = 0;
+    a.dbg = nullptr;
     if (const char *e = getenv("MASHGPU_COMPARE_XCD")) a.xcd_remap = atoi(e) != 0;
     if (const char *e = getenv("MASHGPU_COMPARE_VARIANT")) a.unroll = (uint32_t)atoi(e);
     const char *force = getenv("MASHGPU_COMPARE_KERNEL");
@@ -2427,79 +2398,36 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
         if (rcs != MG_OK || handled) return rcs;
         if (force) return fail(ctx, MG_ERR_UNSUPPORTED, "compare: the sparse engine cannot take this table");
     }
-    if (force && strcmp(force, "pairs") == 0 && mg::compare_pairs_supported(a.s)) {
-        prof_begin(ctx, ctx->prof_compare);
-        HIP_TRY(ctx, mg::launch_compare_pairs(a, ctx->stream));
-        prof_end(ctx, ctx->prof_compare);
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        return MG_OK;
-    }
     const bool want_generic = force && strcmp(force, "generic") == 0;
-    const bool want_tiled = force && strcmp(force, "tiled") == 0;
-    const bool use_merged = !want_tiled && !want_generic && mg::compare_merged_supported(a.s);
-    if (!use_merged && !want_tiled && !want_generic && a.s > 16384 && a.s <= (1u << 22) &&
+    const bool use_merged = !want_generic && mg::compare_merged_supported(a.s);
+    a.row_pfx = a.col_pfx = nullptr;
+    a.row_pfx_stride = a.col_pfx_stride = 0;
+    a.pfx_shr = 0;
+    if (!use_merged && !want_generic && a.s > 16384 && a.s <= (1u << 22) &&
         !(getenv("MASHGPU_COMPARE_WINDOWS") && atoi(getenv("MASHGPU_COMPARE_WINDOWS")) == 0)) {
         // Beyond the plain tile kernel's reach (s > 16 384) the value-window mode still applies: its
         // tiles hold one window's hashes whatever s is.  If some class cannot be windowed, nothing
         // has been launched and the generic kernel below takes the call.
-        a.row_pfx = a.col_pfx = nullptr;
-        a.row_pfx_stride = a.col_pfx_stride = 0;
-        a.pfx_shr = 0;
         a.rows_per_tile = 1;
         const uint64_t maxc = triangle ? (row_end - 1) : cols->n;
         const int rcw = run_compare_merged(ctx, rows, cols, row_begin, row_end, triangle, a, 1, cols->n >= 40000 ? 16384 : 8192, maxc, true);
         if (rcw != kNoWindowPlan) return rcw;
     }
-    if ((!use_merged && !mg::compare_tiled_supported(a.s)) || want_generic) {
+    if (!use_merged) {
         prof_begin(ctx, ctx->prof_compare);
         HIP_TRY(ctx, mg::launch_compare_generic(a, ctx->stream));
         prof_end(ctx, ctx->prof_compare);
         return MG_OK;
     }
-    a.row_pfx = a.col_pfx = nullptr;
-    a.row_pfx_stride = a.col_pfx_stride = 0;
-    a.pfx_shr = 0;
-    uint32_t R = use_merged ? mg::compare_merged_rows(a.s) : mg::compare_rows_per_tile(a.s);
+    uint32_t R = mg::compare_merged_rows(a.s);
     if (const char *e = getenv("MASHGPU_COMPARE_ROWS")) { uint32_t v = (uint32_t)atoi(e); if (v >= 1 && v < R) R = v; }
     // columns per tile: long tiles amortise the table build and the ragged end of a tile
     // (profiles/r01_compare_sweep2.txt); smaller problems keep more tiles for balance
-    uint64_t CC = use_merged ? (cols->n >= 40000 ? 16384 : 8192) : 1024;
+    uint64_t CC = cols->n >= 40000 ? 16384 : 8192;
     if (const char *e = getenv("MASHGPU_COMPARE_COLS")) { uint64_t v = strtoull(e, nullptr, 10); if (v >= 16) CC = v; }
     a.rows_per_tile = R;
-    // tiles: column chunk outer, row tile inner (concurrent workgroups share a column chunk in L2)
     const uint64_t maxcols = triangle ? (row_end - 1) : cols->n;       // columns [0, maxcols)
-    std::vector<mg::CompareTile> tiles;
-    if (use_merged) return run_compare_merged(ctx, rows, cols, row_begin, row_end, triangle, a, R, CC, maxcols, false);
-    {
-        const uint64_t nrt = (row_end - row_begin + R - 1) / R;
-        for (uint64_t c0 = 0; c0 < maxcols; c0 += CC) {
-            for (uint64_t t = 0; t < nrt; t++) {
-                const uint64_t r0 = row_begin + t * R;
-                const uint64_t rlast = std::min(r0 + R, row_end) - 1;  // largest row index of the tile
-                const uint64_t cend = triangle ? rlast : cols->n;     // columns needed: [0, cend)
-                if (c0 >= cend) continue;
-                mg::CompareTile tl;
-                tl.row0 = (uint32_t)r0;
-                tl.col0 = (uint32_t)c0;
-                tl.col1 = (uint32_t)std::min(c0 + CC, cend);
-                tiles.push_back(tl);
-            }
-        }
-    }
-    if (tiles.empty()) return MG_OK;
-    void *d_tiles = nullptr;
-    int slot = 0;
-    {
-        const int rc = stage_tiles(ctx, tiles.data(), tiles.size() * sizeof(mg::CompareTile), &d_tiles, &slot);
-        if (rc != MG_OK) return rc;
-    }
-    a.dbg = nullptr;
-    a.tiles = static_cast<const mg::CompareTile *>(d_tiles);
-    prof_begin(ctx, ctx->prof_compare);
-    hipError_t e = mg::launch_compare_tiled(a, (uint32_t)tiles.size(), ctx->stream);
-    prof_end(ctx, ctx->prof_compare);
-    if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare launch: ") + hipGetErrorString(e));
-    return tiles_release(ctx, slot);
+    return run_compare_merged(ctx, rows, cols, row_begin, row_end, triangle, a, R, CC, maxcols, false);
 }
 
 static uint64_t tri_pairs(uint64_t row_begin, uint64_t row_end)

@@ -477,10 +477,6 @@ def _set_kernel(monkeypatch, kernel):
     if kernel == "plain":                      # merged kernel, whole rows in the tile table (no value windows)
         monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", "merged")
         monkeypatch.setenv("MASHGPU_COMPARE_WINDOWS", "0")
-    elif kernel.startswith("direct"):          # window tiles over the direct-mapped key table (compare_direct.hip)
-        monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", "direct")
-        if kernel != "direct":
-            monkeypatch.setenv("MASHGPU_COMPARE_WIN_TARGET", kernel[len("direct"):])
     elif kernel.startswith("windows"):
         monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", "merged")
         monkeypatch.setenv("MASHGPU_COMPARE_WINDOWS", "1")
@@ -495,7 +491,7 @@ def _oracle_tri(oracle, table, nhash, lengths, rb, re, k=21, kspace=KSPACE21):
     return numer, denom
 
 
-@pytest.mark.parametrize("kernel", ["merged", "sparse", "plain", "tiled", "generic", "pairs", "windows150", "direct150"])
+@pytest.mark.parametrize("kernel", ["merged", "sparse", "plain", "generic", "windows150"])
 def test_compare_reference_run_vectors(eng, golden_dir, kernel, monkeypatch):
     _set_kernel(monkeypatch, kernel)
     z = np.load(os.path.join(golden_dir, "ref_compare_vectors.npz"))
@@ -513,7 +509,7 @@ def test_compare_reference_run_vectors(eng, golden_dir, kernel, monkeypatch):
     t.free()
 
 
-@pytest.mark.parametrize("kernel", ["merged", "sparse", "plain", "generic", "pairs", "windows", "windows150", "windows7", "direct", "direct150", "direct7"])
+@pytest.mark.parametrize("kernel", ["merged", "sparse", "plain", "generic", "windows", "windows150", "windows7"])
 def test_compare_large_reference_run_vectors(eng, golden_dir, kernel, monkeypatch):
     """Counts produced by the reference's own objects at s = 3000: the default path there is the
     value-window mode; forced window sizes, the merge-path and the generic kernel must agree."""
@@ -533,7 +529,7 @@ def test_compare_large_reference_run_vectors(eng, golden_dir, kernel, monkeypatc
     t.free()
 
 
-@pytest.mark.parametrize("kernel", ["merged", "sparse", "plain", "tiled", "pairs", "windows29", "direct29"])
+@pytest.mark.parametrize("kernel", ["merged", "sparse", "plain", "windows29"])
 @pytest.mark.parametrize("s", [1, 7, 64, 65, 100, 400, 1000, 1024])
 def test_compare_tiled_vs_oracle_sizes(eng, oracle, s, kernel, monkeypatch):
     _set_kernel(monkeypatch, kernel)
@@ -558,7 +554,7 @@ def test_compare_tiled_vs_oracle_sizes(eng, oracle, s, kernel, monkeypatch):
     t.free()
 
 
-@pytest.mark.parametrize("kernel", ["merged", "sparse", "plain", "generic", "windows", "windows150", "direct", "direct150"])
+@pytest.mark.parametrize("kernel", ["merged", "sparse", "plain", "generic", "windows", "windows150"])
 @pytest.mark.parametrize("s", [1500, 4096, 10000])
 def test_compare_large_sketch(eng, oracle, s, kernel, monkeypatch):
     """Config-5 sized sketches (s = 10000): merged-rows kernel with few rows per tile, and the
@@ -645,7 +641,7 @@ def test_compare_extremes_and_random(eng, oracle):
     t.free()
 
 
-@pytest.mark.parametrize("kernel", ["merged", "sparse", "plain", "tiled", "pairs", "windows61", "direct61"])
+@pytest.mark.parametrize("kernel", ["merged", "sparse", "plain", "windows61"])
 @pytest.mark.parametrize("top", [0xFFFFFFFF, 0xFFFFFFFFFFFFFFFE, 0xFFFFFFFE00000000])
 def test_compare_values_at_the_top_of_the_hash_range(eng, oracle, kernel, top, monkeypatch):
     """32-bit sketches reaching 0xFFFFFFFF / 64-bit sketches reaching 2^64-2: the prefix image
@@ -675,7 +671,7 @@ def test_compare_values_at_the_top_of_the_hash_range(eng, oracle, kernel, top, m
     t.free()
 
 
-@pytest.mark.parametrize("kernel", ["merged", "sparse", "plain", "tiled", "pairs", "windows90", "direct90"])
+@pytest.mark.parametrize("kernel", ["merged", "sparse", "plain", "windows90"])
 def test_compare_mixed_hash_densities(eng, oracle, kernel, monkeypatch):
     """Sketches of very different genome sizes in one table (hash ranges from 2^44 to 2^64):
     the merged kernel tiles rows by density class and compares every class through its own
@@ -719,7 +715,7 @@ def test_compare_mixed_hash_densities(eng, oracle, kernel, monkeypatch):
     t.free(); tq.free()
 
 
-@pytest.mark.parametrize("kernel", ["merged", "sparse", "plain", "pairs", "windows13", "windows200", "direct13", "direct200"])
+@pytest.mark.parametrize("kernel", ["merged", "sparse", "plain", "windows13", "windows200"])
 @pytest.mark.parametrize("seed", range(24))
 def test_compare_random_tables_vs_oracle(eng, oracle, seed, kernel, monkeypatch):
     """Randomised tables: any sketch size, ragged / empty / identical rows, values shared between
@@ -776,7 +772,7 @@ def test_compare_random_tables_vs_oracle(eng, oracle, seed, kernel, monkeypatch)
     t.free()
 
 
-@pytest.mark.parametrize("kernel", ["merged", "sparse", "plain", "windows100", "windows333", "direct100", "direct333"])
+@pytest.mark.parametrize("kernel", ["merged", "sparse", "plain", "windows100", "windows333"])
 @pytest.mark.parametrize("s,n,seed", [(1000, 150, 0), (300, 260, 1), (2000, 90, 2), (1000, 40, 3)])
 def test_compare_wide_window_tiles(eng, oracle, s, n, seed, kernel, monkeypatch):
     """Window tiles list up to 32 rows of ONE density class (the default engine for s >= 200: two
@@ -840,7 +836,7 @@ def test_compare_wide_window_tiles(eng, oracle, s, n, seed, kernel, monkeypatch)
     t.free()
 
 
-@pytest.mark.parametrize("kernel", ["merged", "sparse", "plain", "tiled", "pairs", "windows40", "direct40"])
+@pytest.mark.parametrize("kernel", ["merged", "sparse", "plain", "windows40"])
 @pytest.mark.parametrize("seed", range(6))
 def test_compare_values_sharing_a_prefix(eng, oracle, kernel, seed, monkeypatch):
     """Different 64-bit values that share their 32-bit prefix, inside one row, across rows of a
@@ -1399,7 +1395,7 @@ def test_compare_c3_scale_properties(eng, oracle):
         row = got[i * (i - 1) // 2: i * (i - 1) // 2 + i]
         assert np.array_equal(row["numer"], numer) and np.array_equal(row["denom"], denom), i
     lo = 5000 * 4999 // 2
-    for other in ("generic", "tiled"):
+    for other in ("generic", "merged", "sparse"):
         os.environ["MASHGPU_COMPARE_KERNEL"] = other
         try:
             got_g = eng.compare_tri_host(t, 5000, 5400)
@@ -1725,7 +1721,7 @@ def test_c3_scale_triangle_properties(eng, oracle):
     base = lo * (lo - 1) // 2
     npairs = hi * (hi - 1) // 2 - base
     ref_block = out[base: base + npairs].cpu()
-    for other in ("tiled", "generic"):
+    for other in ("merged", "sparse", "generic"):
         os.environ["MASHGPU_COMPARE_KERNEL"] = other
         try:
             o2 = torch.empty((npairs, 2), dtype=torch.int32, device=dev)

@@ -5,7 +5,7 @@ four distinct prefixes (oversize), 64-bit values that agree in the probe prefix 
 (the verifying loads and the non-clean tile path), ragged and empty sketches, tiny and wide value
 ranges (density classes), triangle and rectangle.  The generic kernel (one wave per pair, binary
 search in global memory, compare.hip) is the independent side; plain tiles, value windows, the
-direct-mapped engine and the merge-path kernel must give the same {numer, denom} for every pair.
+inverted-index engine must give the same {numer, denom} for every pair.
 
     python tools/compare_fuzz.py [--n 120] [--seed 1] [--seconds 200]"""
 import argparse, os, sys, time
@@ -65,9 +65,8 @@ def main():
     dev = torch.device("cuda", 0)
     eng = abi.MashGpu(0, stream=torch.cuda.current_stream().cuda_stream)
     rng = np.random.default_rng(a.seed)
-    engines = [("generic", {"MASHGPU_COMPARE_KERNEL": "generic"}), ("plain", {"MASHGPU_COMPARE_WINDOWS": "0"}),
-               ("windows", {"MASHGPU_COMPARE_WINDOWS": "1"}), ("default", {}), ("direct", {"MASHGPU_COMPARE_KERNEL": "direct"}),
-               ("pairs", {"MASHGPU_COMPARE_KERNEL": "pairs"})]
+    engines = [("generic", {"MASHGPU_COMPARE_KERNEL": "generic"}), ("plain", {"MASHGPU_COMPARE_KERNEL": "merged", "MASHGPU_COMPARE_WINDOWS": "0"}),
+               ("windows", {"MASHGPU_COMPARE_KERNEL": "merged", "MASHGPU_COMPARE_WINDOWS": "1"}), ("default", {}), ("sparse", {"MASHGPU_COMPARE_KERNEL": "sparse"})]
     t0 = time.time()
     bad = ran = 0
     for case in range(a.n):
@@ -106,7 +105,7 @@ def main():
                     eng.compare_tri_dev(t, 0, n, out.data_ptr())
                 eng.synchronize()
             except abi.MashGpuError as e:
-                if name in ("direct", "windows") and "unsupported" in str(e).lower():
+                if name in ("windows",) and "unsupported" in str(e).lower():
                     continue
                 print("ERROR case %d %s n=%d s=%d %s: %s" % (case, style, n, s, name, e))
                 bad += 1

@@ -48,7 +48,7 @@ for name, h, nh, ln in tables():
             os.environ["MASHGPU_COMPARE_WINDOWS"] = "1"
         elif e != "default":
             os.environ["MASHGPU_COMPARE_KERNEL"] = e
-        m = n if e != "pairs" else min(n, 6000)            # the one-wave-per-pair engine is slow everywhere
+        m = n
         mp = m * (m - 1) // 2
         eng.compare_tri_dev(t, 0, m, out.data_ptr())
         torch.cuda.synchronize()

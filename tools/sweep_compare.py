@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B sweep of compare-kernel variants in ONE process (interleaved rounds).
 usage: tools/sweep_compare.py [--n 30000] [--s 1000] [--rounds 3] variant[:ROWS[:COLS]] ...
-variant: 0|2|3|4 (group size), merged|tiled|generic|pairs (engine), win|winNNN|nowin (value windows)"""
+variant: 0|2|3|4 (group size), merged|sparse|generic (engine), win|winNNN|nowin (value windows)"""
 import argparse, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -54,7 +54,7 @@ def main():
                         os.environ["MASHGPU_COMPARE_VARIANT"] = ku
                     if tgt:
                         os.environ["MASHGPU_COMPARE_WIN_TARGET"] = tgt
-            elif parts[0] in ("merged", "tiled", "generic", "pairs"):
+            elif parts[0] in ("merged", "sparse", "generic"):
                 os.environ["MASHGPU_COMPARE_KERNEL"] = parts[0]
                 os.environ.pop("MASHGPU_COMPARE_VARIANT", None)
             else:
