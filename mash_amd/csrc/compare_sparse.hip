@@ -537,8 +537,122 @@ __global__ __launch_bounds__(256) void sp_chunks_kernel(const uint32_t *seg_cnt,
 // request has a whole round to arrive.  A lane advances at most 8 codes per round and holds at
 // least 16 after landing, so it never runs dry; a chunk is only requested when the 8 codes it
 // overwrites are consumed.  The loop itself is the reference's (CommandDistance.cpp:347-385).
+// (two instantiations of the same loop: this one keeps the WHOLE row in LDS -- rows of up to SPM_AWIN codes, every
+//  sketch size in common use -- and has no window logic in its rounds; sp_merge_rows_win_kernel below stages the
+//  row a window at a time.  Measured at s = 1000: 4.3 ms against 6.9 ms for the windowed form of the same pass.)
 template <bool RECT>
 __global__ __launch_bounds__(SPM_NT) void sp_merge_rows_kernel(SparseArgs a)
+{
+    extern __shared__ __align__(16) uint32_t lds[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t nrows = a.row_end - a.row_begin;
+    const uint32_t item = blockIdx.x;
+    if (item >= a.chunk_inc[nrows - 1]) return;
+    uint32_t lo = 0, hi = nrows - 1;                     // first slot whose inclusive count exceeds item
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a.chunk_inc[mid] > item) hi = mid; else lo = mid + 1;
+    }
+    const uint32_t slot = lo;
+    const uint32_t chunk = item - (slot ? a.chunk_inc[slot - 1] : 0u);
+    const uint32_t row = a.order ? a.order[slot] : a.row_end - 1u - slot;      // as sp_discover_kernel maps its workgroups
+    const uint32_t cnt = a.seg_cnt[slot];
+    const uint64_t base = a.seg_base[slot] + (uint64_t)chunk * SPM_NT;
+    const uint32_t left = cnt - chunk * SPM_NT;
+    const bool have = tid < left;
+    const uint32_t s = a.s;
+    // copies are compared through their representatives; two rows of one class are {n, n}
+    const uint32_t arow = (a.rep && !RECT) ? a.rep[row] : row;
+    const uint32_t nA = a.off[arow + 1] - a.off[arow];
+    // the row's codes (and one chunk of its padding: A[nA] is read by a lane that has just finished)
+    uint32_t *A = lds;
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.row_img + (uint64_t)arow * a.rs_row);
+        const uint32_t nvec = (nA >> 2) + 1u;
+        for (uint32_t v = tid; v < nvec; v += SPM_NT) reinterpret_cast<uint4 *>(A)[v] = src[v];
+    }
+    uint32_t *myring = lds + a.rs_row + (tid >> 6) * (SPM_RING * 64u) + lane;   // code e of this lane: myring[(e & 31) * 64]
+    uint32_t j = have ? a.cand[base + tid].y : 0u;
+    if (a.rep) j = a.rep[j];
+    const bool same = !RECT && a.rep != nullptr && j == arow;
+    const uint32_t nB = have ? a.col_cnt_off[j + 1] - a.col_cnt_off[j] : 0u;
+    const uint4 *B4 = reinterpret_cast<const uint4 *>(a.col_img + (uint64_t)j * a.rs_col);
+    auto land = [&](uint32_t e, const uint4 &v) {         // codes e .. e + 3 (e a multiple of 4)
+        uint32_t *q = myring + (e & (SPM_RING - 1u)) * 64u;
+        q[0] = v.x; q[64] = v.y; q[128] = v.z; q[192] = v.w;
+    };
+    // codes [0, 16) land now, [16, 24) are the first pending chunk
+    {
+        const uint4 x0 = B4[0], x1 = B4[1], x2 = B4[2], x3 = B4[3];
+        land(0, x0); land(4, x1); land(8, x2); land(12, x3);
+    }
+    uint4 p0 = B4[4], p1 = B4[5];
+    uint32_t loaded = 16;
+    bool pend = true;
+    __syncthreads();                                     // A staged
+    uint32_t ia = 0, ib = 0, denom = 0;                  // (common = ia + ib - denom: a match advances both sides for one union element)
+    bool active = have && !same && s > 0 && nA > 0 && nB > 0;
+    while (__ballot(active) != 0) {
+        // A lane with at least 8 codes left on both sides and 8 union elements to go cannot reach any of
+        // the loop's three bounds within 8 steps: when that holds for every lane still merging, the round
+        // runs without the per-step tests (two compares, two advances, two LDS reads per step).
+        uint32_t room = 0;
+        if (active) {
+            const uint32_t ra = nA - ia, rb = nB - ib, rd = s - denom;
+            room = ra < rb ? ra : rb;
+            room = room < rd ? room : rd;
+        }
+        if (__ballot(active && room < 8u) == 0) {
+            if (active) {
+#pragma unroll
+                for (int t = 0; t < 8; t++) {
+                    const uint32_t av = A[ia];
+                    uint32_t bv = myring[(ib & (SPM_RING - 1u)) * 64u];
+                    if (RECT) bv += 1u;
+                    ia += av <= bv ? 1u : 0u;
+                    ib += bv <= av ? 1u : 0u;
+                }
+                denom += 8;
+                active = denom < s && ia < nA && ib < nB;
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const uint32_t av = A[ia];
+                uint32_t bv = myring[(ib & (SPM_RING - 1u)) * 64u];
+                if (RECT) bv += 1u;
+                const bool adva = active && av <= bv, advb = active && bv <= av;
+                denom += active ? 1u : 0u;
+                ia += adva ? 1u : 0u;
+                ib += advb ? 1u : 0u;
+                active = active && denom < s && ia < nA && ib < nB;
+            }
+        }
+        if (pend) {
+            land(loaded, p0);
+            land(loaded + 4u, p1);
+            loaded += 8;
+        }
+        pend = active && loaded + 8u - ib <= SPM_RING;
+        if (pend) {
+            p0 = B4[loaded >> 2];
+            p1 = B4[(loaded >> 2) + 1u];
+        }
+    }
+    if (have) {
+        uint32_t common = ia + ib - denom;
+        if (same) {
+            common = denom = nA;
+        } else if (denom < s) {                            // :367-385
+            denom += (nA - ia) + (nB - ib);
+            if (denom > s) denom = s;
+        }
+        a.res[base + tid] = make_uint2(common, denom);
+    }
+}
+
+template <bool RECT>
+__global__ __launch_bounds__(SPM_NT) void sp_merge_rows_win_kernel(SparseArgs a)
 {
     extern __shared__ __align__(16) uint32_t lds[];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -874,18 +988,16 @@ hipError_t launch_sparse_merge_rows(const SparseArgs &a, uint64_t expect, uint32
     const uint64_t items = expect / SPM_NT + nrows;              // upper bound: one partial item per row
     if (items >= (1ull << 31)) return hipErrorInvalidValue;
     const size_t smem = sparse_merge_rows_lds(a.rs_row);
-    if (a.triangle) {
-        auto kern = sp_merge_rows_kernel<false>;
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return e;
+    auto go = [&](auto kern) -> hipError_t {
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e2 != hipSuccess) return e2;
         hipLaunchKernelGGL(kern, dim3((uint32_t)items), dim3(SPM_NT), smem, stream, a);
-    } else {
-        auto kern = sp_merge_rows_kernel<true>;
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3((uint32_t)items), dim3(SPM_NT), smem, stream, a);
-    }
-    return hipGetLastError();
+        return hipGetLastError();
+    };
+    // rows that fit the LDS window whole take the kernel without window logic
+    const bool whole = a.rs_row <= SPM_AWIN + 8u && !getenv("MASHGPU_SPARSE_MERGE_WINDOWS");
+    if (a.triangle) return whole ? go(sp_merge_rows_kernel<false>) : go(sp_merge_rows_win_kernel<false>);
+    return whole ? go(sp_merge_rows_kernel<true>) : go(sp_merge_rows_win_kernel<true>);
 }
 
 hipError_t launch_sparse_scatter(const SparseArgs &a, uint64_t expect, uint32_t cus, hipStream_t stream)
