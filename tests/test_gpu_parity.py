@@ -1155,7 +1155,18 @@ def test_survivor_lists_from_candidates_equal_the_matrix_path(eng, monkeypatch):
     t.free(); tq.free()
 
 
-@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
+def _device_lists(*lists):
+    """Device lists of the sharded tests.  One GPU per box here, so the lists repeat device 0; on a box
+    with several GPUs tools/scale_check.sh sets MASHGPU_TEST_DEVICES=0,1,...: the same tests then also run
+    on DISTINCT devices (real peer copies, real RCCL rings)."""
+    out = [list(l) for l in lists]
+    extra = os.environ.get("MASHGPU_TEST_DEVICES")
+    if extra:
+        out.append([int(x) for x in extra.split(",")])
+    return out
+
+
+@pytest.mark.parametrize("devices", _device_lists([0], [0, 0], [0, 0, 0]))
 def test_sharded_compare_equals_single_gpu(eng, oracle, devices, monkeypatch):
     """The multi-GPU entry points (mg_comm local mode, mg_dtable, mg_compare_*_sharded_host): row
     blocks on several contexts, driven by one host thread each, give byte-identical output to the
@@ -1199,7 +1210,7 @@ def test_sharded_compare_equals_single_gpu(eng, oracle, devices, monkeypatch):
     t.free()
 
 
-@pytest.mark.parametrize("devices", [[0], [0, 0, 0]])
+@pytest.mark.parametrize("devices", _device_lists([0], [0, 0, 0]))
 def test_sharded_screen_equals_single_gpu(eng, devices, monkeypatch):
     """mg_dscreen: mixture batches dealt to the devices of a local communicator, counters summed
     (ncclReduce on the forced one-rank communicator, host adds on the repeated-device list),
@@ -1231,7 +1242,7 @@ def test_sharded_screen_equals_single_gpu(eng, devices, monkeypatch):
     t.free()
 
 
-@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0, 0, 0]])
+@pytest.mark.parametrize("devices", _device_lists([0], [0, 0], [0, 0, 0, 0, 0]))
 def test_sharded_sketch_equals_single_gpu(eng, oracle, devices):
     """mg_sketch_sharded_host: blocks of consecutive sketches balanced by bytes, one host thread per
     context, rows in input order == mg_sketch_host on one context -- sketches of very different sizes
@@ -1253,7 +1264,7 @@ def test_sharded_sketch_equals_single_gpu(eng, oracle, devices):
     comm.close()
 
 
-@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0]])
+@pytest.mark.parametrize("devices", _device_lists([0, 0], [0, 0, 0]))
 def test_rect_split_by_reference_rows(eng, oracle, devices, monkeypatch):
     """SURVEY 8e for `mash dist`: the larger side is cut.  Few queries against many references: every
     context compares all queries with ITS block of reference rows (a view of its replica, or its own rows
