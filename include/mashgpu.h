@@ -141,10 +141,21 @@ int mg_sketch_dev(mg_ctx *ctx, const mg_params *p,
  * while the caller goes on parsing.  mg_sketch_finish sketches everything closed so far: row i of
  * hashes_out[n * sketch_size] / nhash_out[n] / counts_out (nullable) = the i-th closed sketch,
  * n = mg_sketch_pending(); the session is then empty and can be filled again.  Results are those of
- * mg_sketch_host on the concatenation.  One thread at a time per session. */
+ * mg_sketch_host on the concatenation.  One thread at a time per session.
+ *
+ * Zero-copy form of mg_sketch_add for callers that parse on several threads (the reference's -p workers,
+ * Sketch.cpp:211,354): mg_sketch_stage lends a window of `len` contiguous bytes of the pinned staging
+ * buffer at the stream's current end (len <= mg_sketch_stage_capacity(); the buffer in use is sent first if
+ * the window does not fit behind its contents); the caller fills it -- from as many threads as it likes --
+ * and mg_sketch_commit(n <= len) appends its first n bytes to the stream (several commits may consume one
+ * window piece by piece, with mg_sketch_end_sketch between them).  No other session call between stage
+ * and the last commit of its window. */
 typedef struct mg_sketch_session mg_sketch_session;
 int      mg_sketch_begin(mg_ctx *ctx, const mg_params *p, mg_sketch_session **out);
 int      mg_sketch_add(mg_sketch_session *ss, const uint8_t *bytes, uint64_t len);
+uint64_t mg_sketch_stage_capacity(const mg_sketch_session *ss);
+int      mg_sketch_stage(mg_sketch_session *ss, uint64_t len, uint8_t **window);
+int      mg_sketch_commit(mg_sketch_session *ss, uint64_t len);
 int      mg_sketch_end_sketch(mg_sketch_session *ss);
 uint64_t mg_sketch_pending(const mg_sketch_session *ss);
 int      mg_sketch_finish(mg_sketch_session *ss, uint64_t *hashes_out, uint32_t *nhash_out, uint32_t *counts_out);

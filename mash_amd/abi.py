@@ -23,7 +23,7 @@ RECORD_SEP = 0x0A
 EXPORTS = [
     "mg_device_count", "mg_ctx_create", "mg_ctx_destroy", "mg_last_error", "mg_ctx_set_stream", "mg_ctx_synchronize", "mg_ctx_set_async",
     "mg_ctx_cu_count", "mg_params_init", "mg_sketch_host", "mg_sketch_dev", "mg_sketch_reads_host", "mg_sketch_begin", "mg_sketch_add",
-    "mg_sketch_end_sketch", "mg_sketch_pending", "mg_sketch_finish", "mg_sketch_session_free",
+    "mg_sketch_stage_capacity", "mg_sketch_stage", "mg_sketch_commit", "mg_sketch_end_sketch", "mg_sketch_pending", "mg_sketch_finish", "mg_sketch_session_free",
     "mg_reads_begin", "mg_reads_add_host", "mg_reads_finish", "mg_reads_free", "mg_table_upload",
     "mg_table_wrap_dev", "mg_table_free", "mg_table_rows", "mg_table_sketch_size",
     "mg_compare_tri_dev", "mg_compare_tri_host", "mg_compare_rect_dev", "mg_compare_rect_host",
@@ -156,6 +156,10 @@ def load_library():
     lib.mg_sketch_begin.argtypes = [vp, C.POINTER(MgParams), C.POINTER(vp)]
     lib.mg_sketch_add.argtypes = [vp, vp, u64]
     lib.mg_sketch_end_sketch.argtypes = [vp]
+    lib.mg_sketch_stage_capacity.argtypes = [vp]
+    lib.mg_sketch_stage_capacity.restype = u64
+    lib.mg_sketch_stage.argtypes = [vp, u64, C.POINTER(vp)]
+    lib.mg_sketch_commit.argtypes = [vp, u64]
     lib.mg_sketch_pending.argtypes = [vp]
     lib.mg_sketch_pending.restype = u64
     lib.mg_sketch_finish.argtypes = [vp, vp, vp, vp]
@@ -518,18 +522,41 @@ class MashGpu:
                                             cnt.ctypes.data if counts else None))
         return (hashes, nhash, cnt) if counts else (hashes, nhash)
 
-    def sketch_stream(self, sketches, p, counts=False, piece=None):
-        """same result as sketch_host, through a session: bytes handed over piece by piece"""
+    def sketch_stream(self, sketches, p, counts=False, piece=None, windows=False):
+        """same result as sketch_host, through a session: bytes handed over piece by piece -- copied by
+        mg_sketch_add, or (windows) written by the caller into windows lent by mg_sketch_stage: as many
+        whole sketches per window as fit, committed one by one; larger sketches go through mg_sketch_add"""
         h = C.c_void_p()
         self._check(self.lib.mg_sketch_begin(self.ctx, C.byref(p), C.byref(h)))
         try:
-            for recs in sketches:
-                blob = np.frombuffer(join_records(recs), dtype=np.uint8)
+            blobs = [np.frombuffer(join_records(recs), dtype=np.uint8) for recs in sketches]
+            cap = int(self.lib.mg_sketch_stage_capacity(h))
+            i = 0
+            while i < len(blobs):
+                if windows and len(blobs[i]) <= cap:
+                    j, total = i, 0
+                    while j < len(blobs) and total + len(blobs[j]) <= cap:
+                        total += len(blobs[j])
+                        j += 1
+                    win = C.c_void_p()
+                    self._check(self.lib.mg_sketch_stage(h, min(cap, total + (piece or 0) % 3), C.byref(win)))     # (a window may be lent larger than used)
+                    at = 0
+                    for b in blobs[i:j]:
+                        if len(b):
+                            C.memmove(win.value + at, b.ctypes.data, len(b))
+                        at += len(b)
+                    for b in blobs[i:j]:
+                        self._check(self.lib.mg_sketch_commit(h, len(b)))
+                        self._check(self.lib.mg_sketch_end_sketch(h))
+                    i = j
+                    continue
+                blob = blobs[i]
                 step = piece or max(1, len(blob))
                 for o in range(0, len(blob), step):
                     part = np.ascontiguousarray(blob[o:o + step])
                     self._check(self.lib.mg_sketch_add(h, part.ctypes.data, len(part)))
                 self._check(self.lib.mg_sketch_end_sketch(h))
+                i += 1
             n, s = int(self.lib.mg_sketch_pending(h)), int(p.sketch_size)
             hashes = np.zeros((n, s), dtype=np.uint64)
             nhash = np.zeros(n, dtype=np.uint32)

@@ -885,6 +885,7 @@ struct mg_sketch_session {
     hipEvent_t ev[2] = {nullptr, nullptr};
     bool ev_pending[2] = {false, false};
     hipStream_t copy_stream = nullptr;
+    uint64_t window = 0;                      // bytes lent by mg_sketch_stage and not yet committed
     std::vector<uint64_t> off{0};
 };
 
@@ -960,6 +961,30 @@ int mg_sketch_add(mg_sketch_session *ss, const uint8_t *bytes, uint64_t len)
         }
     }
     return MG_OK;
+}
+
+uint64_t mg_sketch_stage_capacity(const mg_sketch_session *ss) { return ss ? ss->stage_cap : 0; }
+
+int mg_sketch_stage(mg_sketch_session *ss, uint64_t len, uint8_t **window)
+{
+    if (!ss || !window) return MG_ERR_INVALID;
+    if (len > ss->stage_cap) return fail(ss->ctx, MG_ERR_INVALID, "mg_sketch_stage: window larger than the staging buffer (use mg_sketch_add)");
+    if (ss->fill + len > ss->stage_cap) {
+        const int rc = session_submit(ss);
+        if (rc != MG_OK) return rc;
+    }
+    ss->window = len;
+    *window = ss->stage[ss->cur] + ss->fill;
+    return MG_OK;
+}
+
+int mg_sketch_commit(mg_sketch_session *ss, uint64_t len)
+{
+    if (!ss) return MG_ERR_INVALID;
+    if (len > ss->window) return fail(ss->ctx, MG_ERR_INVALID, "mg_sketch_commit: more bytes than the window that was lent");
+    ss->window -= len;
+    ss->fill += len;
+    return ss->fill == ss->stage_cap ? session_submit(ss) : MG_OK;
 }
 
 int mg_sketch_end_sketch(mg_sketch_session *ss)

@@ -12,6 +12,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <charconv>
 #include <chrono>
 #include <condition_variable>
@@ -320,6 +321,24 @@ void params_from_header(Params &p, const mshio::Header &h)     // initParameters
     set_alphabet(p, h.has_alphabet ? h.alphabet : string(kAlphabetNucleotide));
 }
 
+// "Sketching <file>..." lines: one write(2) per file is what the consumer of 12 000 small genomes would
+// spend a tenth of its time in.  Lines are gathered and written when 4 KiB have accumulated, before the
+// consumer sleeps, and before anything else goes to stderr.
+struct ProgressLog {
+    string buf;
+    void line(const string &l)
+    {
+        buf += l;
+        if (buf.size() >= 4096) flush();
+    }
+    void flush()
+    {
+        if (buf.empty()) return;
+        cerr << buf << std::flush;
+        buf.clear();
+    }
+} g_progress;
+
 // One batch of inputs -> GPU -> hash lists appended to `set`.
 // Two modes: `stream` (files -> sketches): the bytes go to a mg_sketch_session as they are parsed --
 // packed into pinned staging buffers and copied to the device while parsing goes on, no
@@ -378,6 +397,7 @@ struct StageClock {
     ~StageClock()
     {
         if (!on) return;
+        lap("teardown");                             // (declared before the Gpu: its destruction is in here)
         cerr << "timing:";
         for (auto &a : acc) cerr << ' ' << a.first << ' ' << a.second << " s;";
         cerr << endl;
@@ -421,6 +441,7 @@ void flush_batch(Gpu &gpu, SketchSet &set, PendingBatch &b)
                                            set.p.counts ? counts.data() : nullptr);
     g_gpu_sketch_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_gpu).count();
     if (sk_rc != MG_OK) {
+        g_progress.flush();
         const char *m = mg_comm_last_error(gpu.comm);
         cerr << "ERROR: " << ((m && *m) ? m : mg_last_error(gpu.ctx)) << endl;
         exit(1);
@@ -462,7 +483,7 @@ ParsedFile parse_file_concatenated(const string &file, int kmer)
 {
     ParsedFile out;
     fastx::Reader rd;
-    if (!rd.open(file)) { out.error = "ERROR: could not open " + file; return out; }
+    if (!rd.open(file)) { out.error = "ERROR: could not open " + file + " for reading."; return out; }
     Ref &ref = out.ref;
     if (file != "-") ref.name = file;
     fastx::Record rec;
@@ -491,7 +512,7 @@ ParsedFile parse_file_concatenated(const string &file, int kmer)
 
 void queue_parsed_file(Gpu &gpu, SketchSet &set, PendingBatch &b, ParsedFile &&pf)
 {
-    if (!pf.error.empty()) { cerr << pf.error << endl; exit(1); }
+    if (!pf.error.empty()) { g_progress.flush(); cerr << pf.error << endl; exit(1); }
     ensure_session(gpu, set, b);
     b.append(pf.bases.data(), pf.bases.size());
     b.end_sketch(std::move(pf.ref));
@@ -703,68 +724,194 @@ bool load_msh_into(SketchSet &set, const string &file, bool first_sets_params, b
 // thread per FILE (std::async) costs more than parsing a small genome.
 class ParsePool {
 public:
+    struct Copy { uint8_t *dst; const uint8_t *src; size_t n; };
+
     ParsePool(const vector<string> &files, size_t threads, std::function<bool(size_t)> parseable)
-        : files_(files), parseable_(std::move(parseable)), nthreads_(threads), window_(threads * 2) {}
+        : files_(files), parseable_(std::move(parseable)), nthreads_(threads),
+          window_(std::max<size_t>(64, std::min<size_t>(files.size(), 1 << 14))), ring_(window_)
+    {
+        if (const char *e = getenv("MASH_AMD_PARSE_AHEAD")) ahead_limit_ = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
+    }
     ~ParsePool()
     {
         { std::lock_guard<std::mutex> g(m_); stop_ = true; }
         cv_work_.notify_all();
         for (auto &t : workers_) t.join();
     }
+    // Start the workers on files[first..] (k must be final).  `mash sketch` calls this BEFORE the device
+    // context exists: its creation (0.15-0.25 s) is then spent parsing, up to ahead_limit_ bytes.
+    void start(size_t first, int kmer)
+    {
+        std::lock_guard<std::mutex> g(m_);
+        if (!workers_.empty()) return;
+        kmer_ = kmer;
+        next_ = first;
+        pos_.store(first);
+        for (size_t t = 0; t < nthreads_; t++) workers_.emplace_back([this]() { work(); });
+    }
+    // file i, which the consumer handles itself (.msh, stdin), is behind us
+    void skip(size_t i) { advance(i + 1); }
+    // bytes of file i if a worker has finished it, else -1 (never blocks)
+    long long ready_bytes(size_t i)
+    {
+        Slot &sl = ring_[i % window_];
+        if (sl.state.load(std::memory_order_acquire) != 1 || sl.index != i) return -1;
+        return (long long)sl.pf.bases.size();
+    }
     // result for file i (parsed by a worker, or here if no worker got to it); indices must ascend
     ParsedFile take(size_t i, int kmer)
     {
-        std::unique_lock<std::mutex> lk(m_);
-        if (workers_.empty()) {                          // first use: k is final now (a leading .msh may have set it)
-            kmer_ = kmer;
-            next_ = i;
-            for (size_t t = 0; t < nthreads_; t++) workers_.emplace_back([this]() { work(); });
+        if (workers_.empty()) start(i, kmer);
+        if (pos_.load() < i) advance(i);
+        Slot &sl = ring_[i % window_];
+        bool mine = false;
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            if (next_ < i) next_ = i;
+            if (next_ == i) { next_ = i + 1; mine = true; }      // nobody has claimed it: parse on this thread
         }
-        pos_ = i;
-        if (next_ < i) next_ = i;
-        cv_work_.notify_all();
-        if (next_ == i) {                                // nobody has claimed it: parse on this thread
-            next_ = i + 1;
-            lk.unlock();
-            cv_work_.notify_all();
-            return parse_file_concatenated(files_[i], kmer);
+        ParsedFile pf;
+        if (mine) {
+            pf = parse_file_concatenated(files_[i], kmer);
+        } else {
+            for (int spin = 0; !(sl.state.load(std::memory_order_acquire) == 1 && sl.index == i); spin++) {
+                if (spin < 2000) { std::this_thread::yield(); continue; }
+                std::unique_lock<std::mutex> lk(m_);             // a slow file (gzip, a large genome): sleep
+                consumer_waits_.store(true);
+                cv_done_.wait_for(lk, std::chrono::milliseconds(2),
+                                  [&]() { return sl.state.load(std::memory_order_acquire) == 1 && sl.index == i; });
+                consumer_waits_.store(false);
+            }
+            pf = std::move(sl.pf);
+            sl.pf = ParsedFile();
+            held_.fetch_sub(pf.bases.size());
+            sl.state.store(0, std::memory_order_release);
         }
-        cv_done_.wait(lk, [&]() { return done_.count(i) != 0; });
-        ParsedFile pf = std::move(done_[i]);
-        done_.erase(i);
+        advance(i + 1);
         return pf;
+    }
+    // memcpy jobs spread over the workers and the caller; returns when all have been carried out
+    void copy_all(const vector<Copy> &jobs)
+    {
+        if (jobs.empty()) return;
+        std::unique_lock<std::mutex> lk(m_);
+        if (workers_.empty() || jobs.size() == 1) {
+            lk.unlock();
+            for (const Copy &c : jobs) memcpy(c.dst, c.src, c.n);
+            return;
+        }
+        copies_ = &jobs;
+        copy_next_ = 0;
+        copy_left_ = jobs.size();
+        cv_work_.notify_all();
+        while (copy_next_ < jobs.size()) {
+            const Copy c = jobs[copy_next_++];
+            lk.unlock();
+            memcpy(c.dst, c.src, c.n);
+            lk.lock();
+            copy_left_--;
+        }
+        cv_copy_.wait(lk, [&]() { return copy_left_ == 0; });
+        copies_ = nullptr;
     }
 
 private:
+    struct Slot {
+        std::atomic<int> state{0};                       // 0: free, 1: pf holds file `index`
+        size_t index = 0;
+        ParsedFile pf;
+    };
+    void advance(size_t pos)
+    {
+        pos_.store(pos);
+        if (waiting_.load() > 0) {                       // (a worker raises waiting_ under m_ BEFORE it tests pos_)
+            std::lock_guard<std::mutex> g(m_);
+            cv_work_.notify_all();
+        }
+    }
+    bool can_claim() const { return next_ < files_.size() && next_ < pos_.load() + window_ && held_.load() < ahead_limit_; }
     void work()
     {
         std::unique_lock<std::mutex> lk(m_);
         for (;;) {
-            cv_work_.wait(lk, [&]() { return stop_ || (next_ < files_.size() && next_ <= pos_ + window_); });
+            waiting_.fetch_add(1);
+            cv_work_.wait(lk, [&]() { return stop_ || (copies_ && copy_next_ < copies_->size()) || can_claim(); });
+            waiting_.fetch_sub(1);
             if (stop_) return;
+            if (copies_ && copy_next_ < copies_->size()) {
+                const Copy c = (*copies_)[copy_next_++];
+                lk.unlock();
+                memcpy(c.dst, c.src, c.n);
+                lk.lock();
+                if (--copy_left_ == 0) cv_copy_.notify_all();
+                continue;
+            }
             const size_t i = next_++;
             if (!parseable_(i)) continue;                // .msh / stdin: the consumer handles those itself
             lk.unlock();
             ParsedFile pf = parse_file_concatenated(files_[i], kmer_);
+            Slot &sl = ring_[i % window_];
+            held_.fetch_add(pf.bases.size());
+            sl.pf = std::move(pf);
+            sl.index = i;
+            sl.state.store(1, std::memory_order_release);
             lk.lock();
-            done_[i] = std::move(pf);
-            cv_done_.notify_all();
+            if (consumer_waits_.load()) cv_done_.notify_all();
         }
     }
     const vector<string> &files_;
     std::function<bool(size_t)> parseable_;
     size_t nthreads_, window_;
+    vector<Slot> ring_;
     std::mutex m_;
-    std::condition_variable cv_work_, cv_done_;
-    std::map<size_t, ParsedFile> done_;
+    std::condition_variable cv_work_, cv_done_, cv_copy_;
     vector<std::thread> workers_;
-    size_t next_ = 0, pos_ = 0;
+    size_t next_ = 0;                                    // next file to claim (under m_)
+    std::atomic<size_t> pos_{0};                         // files below have been taken by the consumer
+    std::atomic<uint64_t> held_{0};                      // bytes parsed and not yet taken
+    uint64_t ahead_limit_ = 1ull << 30;
+    std::atomic<int> waiting_{0};
+    std::atomic<bool> consumer_waits_{false};
+    const vector<Copy> *copies_ = nullptr;
+    size_t copy_next_ = 0, copy_left_ = 0;
     int kmer_ = 0;
     bool stop_ = false;
 };
 
+bool parseable_by_pool(const vector<string> &files, size_t i, const Params &p)
+{
+    return p.concatenated && !(p.reads && p.concatenated) && !has_suffix(files[i], kSuffix) && files[i] != "-";
+}
+
+// A run of parsed files goes to the device as ONE window of the session's pinned staging buffer
+// (mg_sketch_stage): the copies into it are dealt to the parse workers, the consumer only keeps the books.
+void queue_parsed_group(Gpu &gpu, SketchSet &set, PendingBatch &b, vector<ParsedFile> &group, ParsePool &pool)
+{
+    ensure_session(gpu, set, b);
+    uint64_t total = 0;
+    for (const ParsedFile &pf : group) total += pf.bases.size();
+    uint8_t *win = nullptr;
+    if (mg_sketch_stage(b.sess, total, &win) != MG_OK) { g_progress.flush(); cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl; exit(1); }
+    vector<ParsePool::Copy> jobs;
+    uint64_t at = 0;
+    for (const ParsedFile &pf : group) {
+        // (pieces of <= 1 MiB, so that one large genome is copied by several workers too)
+        for (uint64_t o = 0; o < pf.bases.size(); o += 1 << 20)
+            jobs.push_back({win + at + o, pf.bases.data() + o, (size_t)std::min<uint64_t>(1 << 20, pf.bases.size() - o)});
+        at += pf.bases.size();
+    }
+    pool.copy_all(jobs);
+    for (ParsedFile &pf : group) {
+        if (mg_sketch_commit(b.sess, pf.bases.size()) != MG_OK) { g_progress.flush(); cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl; exit(1); }
+        b.nbytes += pf.bases.size();
+        b.end_sketch(std::move(pf.ref));
+    }
+    group.clear();
+    if (batch_full(b, set.p.sketch_size)) flush_batch(gpu, set, b);
+}
+
 void init_from_files(Gpu &gpu, SketchSet &set, const vector<string> &files, const Params &p, int verbosity = 1,
-                     bool enforce_parameters = false)
+                     bool enforce_parameters = false, ParsePool *early = nullptr)
 {
     set.p = p;
     PendingBatch b;
@@ -777,41 +924,77 @@ void init_from_files(Gpu &gpu, SketchSet &set, const vector<string> &files, cons
     // genome size as its length and the two "Estimated ..." lines (Sketch.cpp:1156, :1272-1282,
     // :1320-1330) -- the same code path as `mash sketch -r` over that one file.
     const bool reads_files = set.p.reads && set.p.concatenated;
-    auto parseable = [&](size_t i) { return set.p.concatenated && !reads_files && !has_suffix(files[i], kSuffix) && files[i] != "-"; };
-    std::unique_ptr<ParsePool> pool;
-    if (p.threads > 1 && !reads_files) pool.reset(new ParsePool(files, (size_t)p.threads, parseable));
+    auto parseable = [&](size_t i) { return parseable_by_pool(files, i, set.p); };
+    std::unique_ptr<ParsePool> own;
+    ParsePool *pool = early;
+    if (!pool && p.threads > 1 && !reads_files) { own.reset(new ParsePool(files, (size_t)p.threads, parseable)); pool = own.get(); }
+    const bool grouped = pool && b.stream && !getenv("MASH_AMD_NO_GROUPS");
+    vector<ParsedFile> group;
+    auto announce = [&](size_t i) {
+        if (verbosity <= 0) return;
+        if (files[i] == "-") g_progress.line("Sketching from stdin...\n");
+        else g_progress.line("Sketching " + files[i] + "...\n");
+    };
     for (size_t i = 0; i < files.size(); i++) {
         if (has_suffix(files[i], kSuffix)) {
+            g_progress.flush();
             flush_batch(gpu, set, b);                      // keep input order
             load_msh_into(set, files[i], i == 0 && !enforce_parameters);
+            if (pool) pool->skip(i);
+            continue;
+        }
+        announce(i);
+        if (pool && parseable(i)) {
+            // (a worker opens the file; a failure comes back in input order as the file's error)
+            if (pool->ready_bytes(i) < 0) g_progress.flush();          // about to wait: show where we are
+            ParsedFile pf = pool->take(i, set.p.kmer);
+            if (grouped) ensure_session(gpu, set, b);
+            const uint64_t cap = grouped ? mg_sketch_stage_capacity(b.sess) : 0;
+            if (!grouped || !pf.error.empty() || pf.bases.size() > cap) {
+                queue_parsed_file(gpu, set, b, std::move(pf));
+                continue;
+            }
+            // this file and those behind it that are parsed already, while they fit one staging window
+            uint64_t bytes = pf.bases.size();
+            group.push_back(std::move(pf));
+            while (i + 1 < files.size() && group.size() < 4096 && parseable(i + 1)) {
+                const long long nb = pool->ready_bytes(i + 1);
+                if (nb < 0 || bytes + (uint64_t)nb > cap) break;
+                ParsedFile nx = pool->take(i + 1, set.p.kmer);
+                announce(++i);
+                if (!nx.error.empty()) {                   // everything before it first, then its message (and exit)
+                    queue_parsed_group(gpu, set, b, group, *pool);
+                    queue_parsed_file(gpu, set, b, std::move(nx));
+                }
+                bytes += (uint64_t)nb;
+                group.push_back(std::move(nx));
+            }
+            queue_parsed_group(gpu, set, b, group, *pool);
+            continue;
+        }
+        g_progress.flush();
+        if (files[i] != "-") {
+            FILE *t = fopen(files[i].c_str(), "r");
+            if (!t) { cerr << "ERROR: could not open " << files[i] << " for reading." << endl; exit(1); }
+            fclose(t);
+        }
+        if (pool) pool->skip(i);
+        if (reads_files) {
+            flush_batch(gpu, set, b);                      // keep input order
+            sketch_reads(gpu, set, {files[i]}, &reads_sess);
+        } else if (set.p.concatenated) {
+            queue_parsed_file(gpu, set, b, parse_file_concatenated(files[i], set.p.kmer));
         } else {
-            if (verbosity > 0) {
-                // (one string, one write(2): stderr is unbuffered, no need for four system calls per file)
-                if (files[i] == "-") cerr << "Sketching from stdin..." << endl;
-                else cerr << ("Sketching " + files[i] + "...\n") << std::flush;
-            }
-            if (files[i] != "-") {
-                FILE *t = fopen(files[i].c_str(), "r");
-                if (!t) { cerr << "ERROR: could not open " << files[i] << " for reading." << endl; exit(1); }
-                fclose(t);
-            }
-            if (reads_files) {
-                flush_batch(gpu, set, b);                  // keep input order
-                sketch_reads(gpu, set, {files[i]}, &reads_sess);
-            } else if (set.p.concatenated) {
-                if (pool && parseable(i)) queue_parsed_file(gpu, set, b, pool->take(i, set.p.kmer));
-                else queue_parsed_file(gpu, set, b, parse_file_concatenated(files[i], set.p.kmer));
-            } else {
-                queue_file_by_sequence(gpu, set, b, files[i]);
-            }
+            queue_file_by_sequence(gpu, set, b, files[i]);
         }
     }
+    g_progress.flush();
     flush_batch(gpu, set, b);
     if (b.sess) mg_sketch_session_free(b.sess);
     if (reads_sess) mg_sketch_session_free(reads_sess);
 }
 
-string write_set(const SketchSet &set, const string &path)
+string write_set(SketchSet &set, const string &path, bool consume = false)
 {
     mshio::File f;
     f.header.kmer_size = (uint32_t)set.p.kmer;
@@ -823,9 +1006,12 @@ string write_set(const SketchSet &set, const string &path)
     f.header.has_alphabet = true;
     f.header.alphabet = set.p.alphabet;
     f.header.has_counts = set.p.counts;
-    for (const Ref &r : set.refs) {
+    f.references.reserve(set.refs.size());
+    for (Ref &r : set.refs) {
         mshio::Reference x;
-        x.name = r.name; x.comment = r.comment; x.length = r.length; x.hashes = r.hashes; x.counts = r.counts;
+        x.name = r.name; x.comment = r.comment; x.length = r.length;
+        if (consume) { x.hashes = std::move(r.hashes); x.counts = std::move(r.counts); }     // (the caller is done with the set)
+        else { x.hashes = r.hashes; x.counts = r.counts; }
         f.references.push_back(std::move(x));
     }
     return mshio::write_msh(path, f);
@@ -924,11 +1110,20 @@ int cmd_sketch(int argc, const char **argv)
     if ((c.o("id").active || c.o("comment").active) && files.size() > 1 && !p.reads)
         cerr << "WARNING: -I and -C will only apply to first sketch" << endl;
     StageClock clk;
+    // -p N: the parse workers start BEFORE the device context exists -- creating it takes 0.15-0.25 s, in
+    // which 16 workers parse a gigabyte (bounded: MASH_AMD_PARSE_AHEAD bytes, default 1 GiB).  Not when a
+    // leading .msh may still change k (Sketch.cpp:140-160).
+    std::unique_ptr<ParsePool> early;
+    if (!p.reads && p.concatenated && p.threads > 1 && !files.empty() && !has_suffix(files[0], kSuffix) && !getenv("MASH_AMD_NO_EARLY_PARSE")) {
+        early.reset(new ParsePool(files, (size_t)p.threads, [&files, &p](size_t i) { return parseable_by_pool(files, i, p); }));
+        early->start(0, p.kmer);
+    }
     Gpu gpu;
     clk.lap("device");
     SketchSet set;
     if (p.reads) { set.p = p; sketch_reads(gpu, set, files); }
-    else init_from_files(gpu, set, files, p, 1);
+    else init_from_files(gpu, set, files, p, 1, false, early.get());
+    early.reset();
     clk.lap("ingest+sketch");
     if (clk.on) cerr << "timing: of which mg_sketch_host " << g_gpu_sketch_seconds << " s" << endl;
     if (c.o("id").active && !set.refs.empty()) set.refs[0].name = c.o("id").arg;
@@ -937,7 +1132,7 @@ int cmd_sketch(int argc, const char **argv)
     string prefix = !c.o("prefix").arg.empty() ? c.o("prefix").arg : (c.args[0] == "-" ? string("stdin") : c.args[0]);
     if (!has_suffix(prefix, kSuffix)) prefix += kSuffix;
     cerr << "Writing to " << prefix << "..." << endl;
-    const string e = write_set(set, prefix);
+    const string e = write_set(set, prefix, true);
     clk.lap("write");
     if (!e.empty()) { cerr << "ERROR: " << e << endl; return 1; }
     if (w.count > 0 && !p.reads) warn_kmer_size(set, w);
@@ -1834,15 +2029,36 @@ int main(int argc, const char **argv)
         "  screen    Determine whether query sequences are within a larger mixture of sequences.\n\n";
     if (argc < 2) { cout << usage; return 0; }
     const string cmd = argv[1];
-    if (cmd == "sketch") return cmd_sketch(argc - 2, argv + 2);
-    if (cmd == "dist") return cmd_dist(argc - 2, argv + 2);
-    if (cmd == "triangle") return cmd_triangle(argc - 2, argv + 2);
-    if (cmd == "info") return cmd_info(argc - 2, argv + 2);
-    if (cmd == "paste") return cmd_paste(argc - 2, argv + 2);
-    if (cmd == "screen") return cmd_screen(argc - 2, argv + 2);
-    if (cmd == "json2msh") return cmd_json2msh(argc - 2, argv + 2);
-    if (cmd == "--version") { cout << "2.3-mi355x" << endl; return 0; }
-    cerr << "ERROR: Unknown command: " << cmd << endl;
-    cout << usage;
-    return 1;
+    const bool timing = getenv("MASH_AMD_TIMING") != nullptr;
+    auto stamp = [&](const char *what) {             // CLOCK_MONOTONIC, comparable with the caller's clock (tools/cli_e2e.py)
+        if (timing) cerr << "timing: " << what << ' ' << std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() << endl;
+    };
+    cerr.precision(12);
+    stamp("main_begin");
+    cerr.precision(6);
+    int rc;
+    if (cmd == "sketch") rc = cmd_sketch(argc - 2, argv + 2);
+    else if (cmd == "dist") rc = cmd_dist(argc - 2, argv + 2);
+    else if (cmd == "triangle") rc = cmd_triangle(argc - 2, argv + 2);
+    else if (cmd == "info") rc = cmd_info(argc - 2, argv + 2);
+    else if (cmd == "paste") rc = cmd_paste(argc - 2, argv + 2);
+    else if (cmd == "screen") rc = cmd_screen(argc - 2, argv + 2);
+    else if (cmd == "json2msh") rc = cmd_json2msh(argc - 2, argv + 2);
+    else if (cmd == "--version") { cout << "2.3-mi355x" << endl; rc = 0; }
+    else {
+        cerr << "ERROR: Unknown command: " << cmd << endl;
+        cout << usage;
+        rc = 1;
+    }
+    cerr.precision(12);
+    stamp("main_end");
+    // Everything this process owns is released by the kernel; unloading the HIP runtime and its code
+    // objects politely takes tens of milliseconds that a caller of a 0.4 s command waits for.
+    if (!getenv("MASH_AMD_SLOW_EXIT")) {
+        cout.flush();
+        cerr.flush();
+        fflush(nullptr);
+        _exit(rc);
+    }
+    return rc;
 }

@@ -349,7 +349,14 @@ static std::string serialize_impl(const File &in, std::vector<uint64_t> &out, bo
     Builder b;
     b.multi = multi;
     b.seg_limit = seg_limit;
-    b.w.reserve(64 + in.references.size() * 16);
+    // One allocation for the whole segment (growing by doubling re-copies a 100 MB message twice); in
+    // single-segment mode word 0 is the stream frame, so the segment IS the output (pointer offsets are
+    // relative: a prefix moves nothing).
+    uint64_t est = 64 + in.references.size() * 10;
+    for (const Reference &r : in.references)
+        est += (r.name.size() + 8) / 8 + (r.comment.size() + 8) / 8 + (multi ? 0 : r.hashes.size() + (r.counts.size() + 1) / 2);
+    b.w.reserve(est);
+    const uint64_t prefix = multi ? 0 : b.alloc(1);
     const uint64_t rootp = b.alloc(1);
     const uint64_t root = b.alloc(3 + 4);
     b.set_struct_ptr(rootp, root, 3, 4);
@@ -372,8 +379,8 @@ static std::string serialize_impl(const File &in, std::vector<uint64_t> &out, bo
                 if (multi) {
                     b.far_list(s + 2 + 5, 5, r.hashes.size(), r.hashes.data(), r.hashes.size() * 8);
                 } else {
-                    const uint64_t t = b.alloc(r.hashes.size());
-                    memcpy(&b.w[t], r.hashes.data(), r.hashes.size() * 8);
+                    const uint64_t t = b.w.size();
+                    b.w.insert(b.w.end(), r.hashes.begin(), r.hashes.end());      // (no zero fill first)
                     b.set_list_ptr(s + 2 + 5, t, 5, r.hashes.size());
                 }
             } else {
@@ -415,8 +422,13 @@ static std::string serialize_impl(const File &in, std::vector<uint64_t> &out, bo
     b.set_text(root + 3 + 2, h.alphabet);
     if (b.overflow) return multi ? "sketch file too large (a list or the sketch index exceeds a segment)"
                                  : "needs more than one segment";
-    if (!multi && b.w.size() > seg_limit) return "needs more than one segment";
+    if (!multi && b.w.size() - prefix > seg_limit) return "needs more than one segment";
     if (b.w.size() >= (1ull << 29)) return "too many sketches for one .msh file";
+    if (!multi) {                                                  // frame: 0 further segments, then this one's size
+        b.w[0] = (uint64_t)(b.w.size() - 1) << 32;
+        out = std::move(b.w);
+        return "";
+    }
     // stream framing: u32 (segments - 1), u32 words of every segment, padded to 8 bytes, then the segments
     const uint64_t nseg = 1 + b.data.size();
     std::vector<uint32_t> frame;

@@ -348,9 +348,17 @@ def test_streamed_ingest_equals_one_batch(eng, oracle, stage, monkeypatch):
     p = eng.params(k=21, s=400)
     want = eng.sketch_host(sketches, p, counts=True)
     for piece in (None, 7, 1000):
-        got = eng.sketch_stream(sketches, p, counts=True, piece=piece)
-        for a, b in zip(got, want):
-            assert np.array_equal(a, b), (stage, piece)
+        for windows in (False, True):       # mg_sketch_add copies / the caller fills windows lent by mg_sketch_stage
+            got = eng.sketch_stream(sketches, p, counts=True, piece=piece, windows=windows)
+            for a, b in zip(got, want):
+                assert np.array_equal(a, b), (stage, piece, windows)
+    with pytest.raises(abi.MashGpuError, match="larger than the staging buffer"):
+        win, ss = abi.C.c_void_p(), abi.C.c_void_p()
+        eng._check(eng.lib.mg_sketch_begin(eng.ctx, abi.C.byref(p), abi.C.byref(ss)))
+        try:
+            eng._check(eng.lib.mg_sketch_stage(ss, eng.lib.mg_sketch_stage_capacity(ss) + 1, abi.C.byref(win)))
+        finally:
+            eng.lib.mg_sketch_session_free(ss)
     h, n = eng.sketch_stream([[b""], [b"AC"]], p)                       # nothing but empty sketches
     assert h.shape == (2, 400) and not n.any() and np.all(h == np.uint64(abi.HASH_PAD))
 
