@@ -15,12 +15,14 @@ reported separately (`config.table_broadcast_ms`, `config.rccl_ranks`).
 Same JSON line, further objects:
   roofline      the kernels of one pass.  Default engine (compare_sparse.hip): fill (HBM-write bound,
                 the dominant kernel), discover, merge -- each timed with HIP events on the stream it
-                runs on.  `achieved`/`frac`: the mandated algorithmic-bytes model of SURVEY §8d over the
-                summed kernel time of a pass (a no-reuse model; it bounds nothing here); the bounds that
-                do: `write_roofline` (8 B per pair over the fill kernel's time against the HBM peak),
-                `compulsory_bytes` vs PMC `traffic`, and per kernel the share of every issue port
-                (`ports`, from profiles/compare_<leg>_pmc.json -- dropped when the kernel sources
-                differ from the ones the counters were read on).
+                runs on.  `achieved`/`frac`: the fill kernel -- the 8 B of every pair (SURVEY 8d's
+                compulsory traffic, the output-write bound) over its launch time against the HBM peak;
+                `traffic`: its PMC bytes per launch.  `pass`: the whole pass against the same bound,
+                PMC bytes of the pass vs the compulsory ones.  `survey_8d_no_reuse_model`: the mandated
+                2*s*8+8 B per pair over the pass (bounds nothing here: a pair that shares no hash costs
+                8 written bytes).  `ports`: per kernel the share of every issue port (from
+                profiles/compare_<leg>_pmc.json -- dropped when the kernel sources differ from the ones
+                the counters were read on).
   brackets      SURVEY §8d's extremes at the same size: all-random, all-identical, clades of 1000
                 near-identical sketches; each verified against the tile engine (a second, independent
                 implementation) or a closed form, each with the reference's compareSketches on a sample.
@@ -30,6 +32,8 @@ Same JSON line, further objects:
   sketch        BASELINE config 2 (10 000 x 1 Mbp, k=21 s=1000), bp/s, own roofline, cpu baselines
                 at 1 thread, at all cores, and the reference CLI incl. FASTA parsing.
   screen        BASELINE config 4.
+  cli_e2e       `mash sketch -p 16` of 12 000 FASTA files, ours and the reference CLI on the same files in
+                this run (tools/sketch_e2e.py): wall time of the whole process, stages, bp/s.
   c5            BASELINE config 5: triangle at s=10 000 (64-bit hashes, k=31 style), N=100 000.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--n-sketches 100000] [--n-genomes 10000]
@@ -69,6 +73,7 @@ def parse_args():
     ap.add_argument("--no-screen", action="store_true", help="skip the tertiary screen measurement (config 4)")
     ap.add_argument("--no-c5", action="store_true", help="skip the large-sketch triangle (config 5)")
     ap.add_argument("--no-h2h", action="store_true", help="skip the host-to-host legs")
+    ap.add_argument("--no-cli", action="store_true", help="skip the CLI end-to-end leg (mash sketch, ours vs the reference CLI)")
     ap.add_argument("--no-brackets", action="store_true", help="skip SURVEY 8d's extremes (all-random / all-identical / clades)")
     ap.add_argument("--n-reads", type=int, default=10_000_000)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
@@ -110,32 +115,49 @@ def compare_roofline(eng, pairs, n, s, steps, pmc, engine_hint=None):
     sparse = "compare_fill" in phases
     pass_ms = sum(v["ms_per_pass"] for v in phases.values())
     bytes_per_pair = 2 * s * 8 + 8
-    achieved = pairs * bytes_per_pair / (pass_ms * 1e-3) / 1e9 if pass_ms > 0 else 0.0
+    model = pairs * bytes_per_pair / (pass_ms * 1e-3) / 1e9 if pass_ms > 0 else 0.0
     compulsory = pairs * 8 + n * s * 8 + n * 12           # every pair written once, the table read once
     traffic = pmc.get("hbm_bytes_per_pass") if pmc else None
-    r = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-         "engine": "inverted index (compare_sparse.hip)" if sparse else "tiles (compare_merged.hip)",
-         "kernel": "mg::sp_fill_const_kernel" if sparse else "mg::compare_merged_kernel",
-         "kernel_ms": phases["compare_fill"]["avg_launch_ms"] if sparse else (phases.get("compare", {}).get("avg_launch_ms")),
-         "pass_ms": round(pass_ms, 3), "phases": phases, "algorithmic_bytes_per_pair": bytes_per_pair,
-         "compulsory_bytes": compulsory,
-         "traffic_over_compulsory": round(traffic / compulsory, 3) if traffic else None,
-         "measured_hbm_frac": round(traffic / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and pass_ms > 0 else None}
-    if sparse:
+    no_reuse = {"bytes_per_pair": bytes_per_pair, "achieved": round(model, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(model / HBM_PEAK_GBS, 4),
+                "what": "SURVEY.md 8d's no-reuse streaming model (2*s*8+8 B per pair) over the summed kernel time of one pass"}
+    whole = {"ms": round(pass_ms, 3), "traffic": traffic, "compulsory_bytes": compulsory,
+             "traffic_over_compulsory": round(traffic / compulsory, 3) if traffic else None,
+             "measured_hbm_frac": round(traffic / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and pass_ms > 0 else None,
+             "output_write_bound_frac": round(pairs * 8 / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if pass_ms > 0 else None}
+    if not sparse:
+        # the tile engine: one kernel per window, priced with the mandated model
+        r = {"bound": "hbm", "achieved": round(model, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(model / HBM_PEAK_GBS, 4),
+             "traffic": traffic, "engine": "tiles (compare_merged.hip)", "kernel": "mg::compare_merged_kernel",
+             "kernel_ms": phases.get("compare", {}).get("avg_launch_ms"), "pass_ms": round(pass_ms, 3), "phases": phases,
+             "algorithmic_bytes_per_pair": bytes_per_pair, "pass": whole,
+             "note": "achieved/frac: SURVEY.md 8d's no-reuse model; every sketch is re-used from LDS/L2, so it bounds nothing (DESIGN 4.1b)"}
+    else:
+        # The inverted-index engine.  Its dominant kernel is the fill: it writes the 8 B of every pair -- SURVEY 8d's
+        # "compulsory traffic ... 8 B/pair written", the output-write bound of 1e12 pairs/s -- and reads nothing.
         f = phases["compare_fill"]["ms_per_pass"]
-        r["write_roofline"] = {"bytes": pairs * 8, "ms": f, "achieved": round(pairs * 8 / (f * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": round(pairs * 8 / (f * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                               "what": "the fill kernel: 8 B written per pair, nothing read -- the compulsory traffic of the job"}
+        fill = pairs * 8 / (f * 1e-3) / 1e9
+        kname = "mg::sp_fill_const_wave_kernel"
+        kp = (pmc or {}).get("kernels", {}).get(kname)
+        r = {"bound": "hbm", "achieved": round(fill, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fill / HBM_PEAK_GBS, 4),
+             "traffic": (kp["hbm_read_bytes_per_pass"] + kp["hbm_write_bytes_per_pass"]) if kp else None,
+             "engine": "inverted index (compare_sparse.hip)", "kernel": kname, "kernel_ms": phases["compare_fill"]["avg_launch_ms"],
+             "algorithmic_bytes_per_launch": pairs * 8, "algorithmic_bytes_per_pair": 8,
+             "pass_ms": round(pass_ms, 3), "phases": phases, "pass": whole, "survey_8d_no_reuse_model": no_reuse,
+             "note": ("achieved/frac: the dominant kernel of the pass, the fill -- algorithmic bytes = the 8 B {numer, denom} of every pair "
+                      "(SURVEY.md 8d: the compulsory traffic of the job, output-write bound) over its HIP-event time; `traffic`: its PMC "
+                      "bytes per launch.  `pass`: all kernels of one pass against the same bound and the PMC bytes of the whole pass "
+                      "against the compulsory ones.  `survey_8d_no_reuse_model`: the mandated 2*s*8+8 B per pair; a pair that shares no "
+                      "hash costs this engine 8 written bytes, so that model exceeds the HBM peak by orders of magnitude and bounds "
+                      "nothing.  discover / merge are bound by their issue ports (`ports`: each port on its own, never summed; PMC "
+                      "figures from profiles/, dropped when the kernel sources changed since).")}
+        if "compare_discover" not in phases and "compare_merge" not in phases:
+            r["note"] += "  (This table: every pair is inside a class of identical sketches; the fill phase is the plain fill plus sp_class_pairs_kernel.)"
     if pmc:
         r["ports"] = {k: dict(v.get("ports", {}), ms_per_pass=v.get("ms_per_pass"), effective_clock_ghz=v.get("effective_clock_ghz"),
                               hbm_bytes_per_pass=(v.get("hbm_read_bytes_per_pass", 0) + v.get("hbm_write_bytes_per_pass", 0)))
                       for k, v in pmc.get("kernels", {}).items() if not v.get("cold_only")}
         r["pmc_source"] = pmc.get("source")
-    r["note"] = ("achieved/frac: the mandated no-reuse model of SURVEY.md §8d (2*s*8+8 B per pair) over the summed kernel time of one "
-                 "pass; a pair that shares no hash costs this engine 8 written bytes, so the model exceeds the HBM peak by orders of "
-                 "magnitude and bounds nothing.  What bounds the pass: write_roofline (fill), and for discover / merge the issue ports "
-                 "listed under `ports` (each port on its own, never summed; PMC figures from profiles/, dropped when stale).")
     return r
 
 
@@ -753,6 +775,17 @@ def main():
         except Exception as e:
             c5["error"] = repr(e)
         result["c5"] = c5
+
+    # --- the CLI end to end: `mash sketch -p 16`, ours and the reference CLI on the same files
+    if single and not args.no_cli and not dry:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import sketch_e2e
+            torch.cuda.synchronize()
+            result["cli_e2e"] = sketch_e2e.run(genomes=12000, length=50000, threads=16, reps=3)
+            result["cli_e2e"]["host_cores"] = os.cpu_count()
+        except Exception as e:
+            result["cli_e2e"] = {"error": repr(e)}
 
     if rank == 0:
         print(json.dumps(result))

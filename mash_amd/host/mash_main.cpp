@@ -350,6 +350,16 @@ struct PendingBatch {
     bool stream = false;
     mg_sketch_session *sess = nullptr;        // stream mode, created at the first byte (parameters are final by then)
     uint64_t nbytes = 0;
+    // flush threshold in bytes: with parse workers the batches are SMALL, so that sketching, copying back and
+    // handing out the hashes of one batch run while the workers parse the next (init_from_files)
+    uint64_t max_bytes = 2ull << 30;
+    // result buffers of mg_sketch_*: kept over the batches of a run (a fresh 100 MB vector is 25 000 page faults)
+    std::unique_ptr<uint64_t[]> out_hashes;
+    std::unique_ptr<uint32_t[]> out_nhash, out_counts;
+    uint64_t out_cap = 0, out_cap_n = 0;
+    // fn(0..n-1), possibly on several threads (the parse workers, when there are any)
+    std::function<void(size_t, const std::function<void(size_t)> &)> parallel_for =
+        [](size_t n, const std::function<void(size_t)> &fn) { for (size_t i = 0; i < n; i++) fn(i); };
     void append(const uint8_t *p, size_t n)
     {
         if (sess) {
@@ -428,17 +438,22 @@ void flush_batch(Gpu &gpu, SketchSet &set, PendingBatch &b)
     if (b.refs.empty()) return;
     const mg_params mp = batch_params(set);
     const uint64_t n = b.refs.size(), s = set.p.sketch_size;
-    vector<uint64_t> hashes(n * s);
-    vector<uint32_t> nhash(n), counts(set.p.counts ? n * s : 0);
+    if (n * s > b.out_cap || n > b.out_cap_n) {
+        b.out_cap = std::max<uint64_t>(n * s, b.out_cap);
+        b.out_cap_n = std::max<uint64_t>(n, b.out_cap_n);
+        b.out_hashes.reset(new uint64_t[b.out_cap]);
+        b.out_nhash.reset(new uint32_t[b.out_cap_n]);
+        if (set.p.counts) b.out_counts.reset(new uint32_t[b.out_cap]);
+    }
+    uint64_t *hashes = b.out_hashes.get();
+    uint32_t *nhash = b.out_nhash.get(), *counts = set.p.counts ? b.out_counts.get() : nullptr;
     if (!b.sess && b.bases.empty()) b.bases.push_back((uint8_t)MG_RECORD_SEP);
     const auto t_gpu = std::chrono::steady_clock::now();
     // (several GPUs, MASH_GPU_DEVICES: the batch is cut into byte-balanced blocks of sketches, one per device)
-    const int sk_rc = b.sess ? mg_sketch_finish(b.sess, hashes.data(), nhash.data(), set.p.counts ? counts.data() : nullptr)
+    const int sk_rc = b.sess ? mg_sketch_finish(b.sess, hashes, nhash, counts)
                       : mg_comm_size(gpu.comm) > 1 && mp.min_copies <= 1
-                          ? mg_sketch_sharded_host(gpu.comm, &mp, b.bases.data(), b.bases.size(), b.off.data(), n, hashes.data(), nhash.data(),
-                                                   set.p.counts ? counts.data() : nullptr)
-                          : mg_sketch_host(gpu.ctx, &mp, b.bases.data(), b.bases.size(), b.off.data(), n, hashes.data(), nhash.data(),
-                                           set.p.counts ? counts.data() : nullptr);
+                          ? mg_sketch_sharded_host(gpu.comm, &mp, b.bases.data(), b.bases.size(), b.off.data(), n, hashes, nhash, counts)
+                          : mg_sketch_host(gpu.ctx, &mp, b.bases.data(), b.bases.size(), b.off.data(), n, hashes, nhash, counts);
     g_gpu_sketch_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_gpu).count();
     if (sk_rc != MG_OK) {
         g_progress.flush();
@@ -446,11 +461,14 @@ void flush_batch(Gpu &gpu, SketchSet &set, PendingBatch &b)
         cerr << "ERROR: " << ((m && *m) ? m : mg_last_error(gpu.ctx)) << endl;
         exit(1);
     }
-    for (uint64_t i = 0; i < n; i++) {
-        b.refs[i].hashes.assign(hashes.begin() + i * s, hashes.begin() + i * s + nhash[i]);
-        if (set.p.counts) b.refs[i].counts.assign(counts.begin() + i * s, counts.begin() + i * s + nhash[i]);
-        set.refs.push_back(std::move(b.refs[i]));
-    }
+    const size_t piece = 64;                                 // sketches per job
+    b.parallel_for((n + piece - 1) / piece, [&](size_t j) {
+        for (uint64_t i = j * piece; i < std::min<uint64_t>(n, (j + 1) * piece); i++) {
+            b.refs[i].hashes.assign(hashes + i * s, hashes + i * s + nhash[i]);
+            if (counts) b.refs[i].counts.assign(counts + i * s, counts + i * s + nhash[i]);
+        }
+    });
+    for (uint64_t i = 0; i < n; i++) set.refs.push_back(std::move(b.refs[i]));
     b.reset();
 }
 
@@ -466,7 +484,7 @@ static bool batch_full(const PendingBatch &b, uint64_t sketch_size)
         const char *e = getenv("MASH_AMD_BATCH_HASHES");
         return e ? std::max<uint64_t>(1, strtoull(e, nullptr, 10)) : kBatchHashes;
     }();
-    return b.nbytes > kBatchBytes || (uint64_t)b.refs.size() * sketch_size > cap;
+    return b.nbytes > std::min(kBatchBytes, b.max_bytes) || (uint64_t)b.refs.size() * sketch_size > cap;
 }
 
 // sketchFile in concatenated mode for ONE file (Sketch.cpp:1147-1336), non-reads: the host half
@@ -745,7 +763,7 @@ public:
         std::lock_guard<std::mutex> g(m_);
         if (!workers_.empty()) return;
         kmer_ = kmer;
-        next_ = first;
+        next_.store(first);
         pos_.store(first);
         for (size_t t = 0; t < nthreads_; t++) workers_.emplace_back([this]() { work(); });
     }
@@ -767,8 +785,8 @@ public:
         bool mine = false;
         {
             std::lock_guard<std::mutex> lk(m_);
-            if (next_ < i) next_ = i;
-            if (next_ == i) { next_ = i + 1; mine = true; }      // nobody has claimed it: parse on this thread
+            if (next_.load() < i) next_.store(i);
+            if (next_.load() == i) { next_.store(i + 1); mine = true; }      // nobody has claimed it: parse on this thread
         }
         ParsedFile pf;
         if (mine) {
@@ -790,29 +808,35 @@ public:
         advance(i + 1);
         return pf;
     }
-    // memcpy jobs spread over the workers and the caller; returns when all have been carried out
-    void copy_all(const vector<Copy> &jobs)
+    // fn(0) ... fn(n - 1) spread over the workers and the caller; returns when all have been carried out
+    // (workers in the middle of a file join when they are through with it)
+    void run_jobs(size_t n, const std::function<void(size_t)> &fn)
     {
-        if (jobs.empty()) return;
+        if (n == 0) return;
         std::unique_lock<std::mutex> lk(m_);
-        if (workers_.empty() || jobs.size() == 1) {
+        if (workers_.empty() || n == 1) {
             lk.unlock();
-            for (const Copy &c : jobs) memcpy(c.dst, c.src, c.n);
+            for (size_t j = 0; j < n; j++) fn(j);
             return;
         }
-        copies_ = &jobs;
-        copy_next_ = 0;
-        copy_left_ = jobs.size();
+        job_fn_ = &fn;
+        job_count_ = n;
+        job_next_ = 0;
+        job_left_ = n;
         cv_work_.notify_all();
-        while (copy_next_ < jobs.size()) {
-            const Copy c = jobs[copy_next_++];
+        while (job_next_ < n) {
+            const size_t j = job_next_++;
             lk.unlock();
-            memcpy(c.dst, c.src, c.n);
+            fn(j);
             lk.lock();
-            copy_left_--;
+            job_left_--;
         }
-        cv_copy_.wait(lk, [&]() { return copy_left_ == 0; });
-        copies_ = nullptr;
+        cv_copy_.wait(lk, [&]() { return job_left_ == 0; });
+        job_fn_ = nullptr;
+    }
+    void copy_all(const vector<Copy> &jobs)
+    {
+        run_jobs(jobs.size(), [&jobs](size_t j) { memcpy(jobs[j].dst, jobs[j].src, jobs[j].n); });
     }
 
 private:
@@ -824,29 +848,34 @@ private:
     void advance(size_t pos)
     {
         pos_.store(pos);
-        if (waiting_.load() > 0) {                       // (a worker raises waiting_ under m_ BEFORE it tests pos_)
+        // Only workers held back by the look-ahead limits can use this news (a worker raises limit_waiters_
+        // under m_ BEFORE it tests pos_).  Workers that are idle because every file has been claimed must
+        // NOT be woken here: 16 of them, 12 000 times, is what the consumer then spends its time on.
+        if (limit_waiters_.load() > 0 && next_.load() < files_.size()) {
             std::lock_guard<std::mutex> g(m_);
             cv_work_.notify_all();
         }
     }
-    bool can_claim() const { return next_ < files_.size() && next_ < pos_.load() + window_ && held_.load() < ahead_limit_; }
+    bool can_claim() const { return next_.load() < files_.size() && next_.load() < pos_.load() + window_ && held_.load() < ahead_limit_; }
     void work()
     {
         std::unique_lock<std::mutex> lk(m_);
         for (;;) {
-            waiting_.fetch_add(1);
-            cv_work_.wait(lk, [&]() { return stop_ || (copies_ && copy_next_ < copies_->size()) || can_claim(); });
-            waiting_.fetch_sub(1);
+            const bool limited = next_.load() < files_.size();          // if it has to wait, then for the consumer to move on
+            if (limited) limit_waiters_.fetch_add(1);
+            cv_work_.wait(lk, [&]() { return stop_ || (job_fn_ && job_next_ < job_count_) || can_claim(); });
+            if (limited) limit_waiters_.fetch_sub(1);
             if (stop_) return;
-            if (copies_ && copy_next_ < copies_->size()) {
-                const Copy c = (*copies_)[copy_next_++];
+            if (job_fn_ && job_next_ < job_count_) {
+                const size_t j = job_next_++;
+                const std::function<void(size_t)> &fn = *job_fn_;
                 lk.unlock();
-                memcpy(c.dst, c.src, c.n);
+                fn(j);
                 lk.lock();
-                if (--copy_left_ == 0) cv_copy_.notify_all();
+                if (--job_left_ == 0) cv_copy_.notify_all();
                 continue;
             }
-            const size_t i = next_++;
+            const size_t i = next_.fetch_add(1);
             if (!parseable_(i)) continue;                // .msh / stdin: the consumer handles those itself
             lk.unlock();
             ParsedFile pf = parse_file_concatenated(files_[i], kmer_);
@@ -866,14 +895,14 @@ private:
     std::mutex m_;
     std::condition_variable cv_work_, cv_done_, cv_copy_;
     vector<std::thread> workers_;
-    size_t next_ = 0;                                    // next file to claim (under m_)
+    std::atomic<size_t> next_{0};                        // next file to claim (written under m_)
     std::atomic<size_t> pos_{0};                         // files below have been taken by the consumer
     std::atomic<uint64_t> held_{0};                      // bytes parsed and not yet taken
     uint64_t ahead_limit_ = 1ull << 30;
-    std::atomic<int> waiting_{0};
+    std::atomic<int> limit_waiters_{0};
     std::atomic<bool> consumer_waits_{false};
-    const vector<Copy> *copies_ = nullptr;
-    size_t copy_next_ = 0, copy_left_ = 0;
+    const std::function<void(size_t)> *job_fn_ = nullptr;
+    size_t job_count_ = 0, job_next_ = 0, job_left_ = 0;
     int kmer_ = 0;
     bool stop_ = false;
 };
@@ -929,6 +958,13 @@ void init_from_files(Gpu &gpu, SketchSet &set, const vector<string> &files, cons
     ParsePool *pool = early;
     if (!pool && p.threads > 1 && !reads_files) { own.reset(new ParsePool(files, (size_t)p.threads, parseable)); pool = own.get(); }
     const bool grouped = pool && b.stream && !getenv("MASH_AMD_NO_GROUPS");
+    if (pool) {
+        b.parallel_for = [pool](size_t n, const std::function<void(size_t)> &fn) { pool->run_jobs(n, fn); };
+        if (b.stream) {
+            const char *e = getenv("MASH_AMD_BATCH_BYTES");
+            b.max_bytes = e ? std::max<uint64_t>(1, strtoull(e, nullptr, 10)) : 64ull << 20;
+        }
+    }
     vector<ParsedFile> group;
     auto announce = [&](size_t i) {
         if (verbosity <= 0) return;

@@ -8,7 +8,7 @@ set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
 LEGS=${@:-c3 c5 random identical clades sketch screen}
-STEPS=2
+STEPS=6
 cd /tmp && export TMPDIR=/tmp
 run() { local leg=$1 name=$2; shift 2; timeout 900 rocprofv3 "$@" --output-format csv -d "$OUT/r03_${leg}_${name}" -o p -- python $ROOT/tools/prof_leg.py --leg $leg --steps $STEPS > "$OUT/r03_${leg}_${name}.log" 2>&1; echo "$leg $name rc=$? $(grep -o '"ms_per_step": [0-9.]*' $OUT/r03_${leg}_${name}.log | head -1)"; }
 for leg in $LEGS; do

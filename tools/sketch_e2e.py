@@ -81,8 +81,9 @@ def run(genomes=12000, length=50000, threads=16, reps=3, variants=False, ref_thr
         if variants:
             for tag, extra in (("p1", None), ("no_early_parse", {"MASH_AMD_NO_EARLY_PARSE": "1"}), ("no_groups", {"MASH_AMD_NO_GROUPS": "1"}),
                                ("neither", {"MASH_AMD_NO_EARLY_PARSE": "1", "MASH_AMD_NO_GROUPS": "1"}), ("slow_exit", {"MASH_AMD_SLOW_EXIT": "1"}),
-                               ("p64", None)):
-                th = "1" if tag == "p1" else "64" if tag == "p64" else str(threads)
+                               ("one_batch", {"MASH_AMD_BATCH_BYTES": str(2 << 30)}), ("batch_16M", {"MASH_AMD_BATCH_BYTES": str(16 << 20)}),
+                               ("batch_256M", {"MASH_AMD_BATCH_BYTES": str(256 << 20)}), ("p4", None), ("p8", None), ("p32", None), ("p64", None)):
+                th = tag[1:] if tag[0] == "p" and tag[1:].isdigit() else str(threads)
                 s, st = timed([MASH, "sketch", "-p", th, "-l", "-o", "v_" + tag, lst], d, dict(env, **(extra or {})), reps)
                 res["ours_" + tag + "_s"], res["ours_" + tag + "_stages"] = s, st
                 assert open(os.path.join(d, "v_" + tag + ".msh"), "rb").read() == open(os.path.join(d, "ours.msh"), "rb").read(), tag
