@@ -1146,11 +1146,14 @@ int cmd_sketch(int argc, const char **argv)
     if ((c.o("id").active || c.o("comment").active) && files.size() > 1 && !p.reads)
         cerr << "WARNING: -I and -C will only apply to first sketch" << endl;
     StageClock clk;
-    // -p N: the parse workers start BEFORE the device context exists -- creating it takes 0.15-0.25 s, in
-    // which 16 workers parse a gigabyte (bounded: MASH_AMD_PARSE_AHEAD bytes, default 1 GiB).  Not when a
-    // leading .msh may still change k (Sketch.cpp:140-160).
+    // MASH_AMD_EARLY_PARSE=1: the parse workers start BEFORE the device context exists, so that its creation
+    // (0.07-0.2 s) is spent parsing (bounded: MASH_AMD_PARSE_AHEAD bytes, default 1 GiB).  Off by default:
+    // measured (tools/sketch_e2e.py, 12 000 x 50 kbp at -p 16: 0.26 s with, 0.21 s without) -- once the
+    // consumer's chain (staging copies, device tail, hand-out) is what bounds the run, parsing earlier buys
+    // nothing and a gigabyte of parse buffers allocated up front slows context creation and the writer.
+    // Not when a leading .msh may still change k (Sketch.cpp:140-160).
     std::unique_ptr<ParsePool> early;
-    if (!p.reads && p.concatenated && p.threads > 1 && !files.empty() && !has_suffix(files[0], kSuffix) && !getenv("MASH_AMD_NO_EARLY_PARSE")) {
+    if (!p.reads && p.concatenated && p.threads > 1 && !files.empty() && !has_suffix(files[0], kSuffix) && getenv("MASH_AMD_EARLY_PARSE")) {
         early.reset(new ParsePool(files, (size_t)p.threads, [&files, &p](size_t i) { return parseable_by_pool(files, i, p); }));
         early->start(0, p.kmer);
     }

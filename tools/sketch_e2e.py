@@ -79,8 +79,8 @@ def run(genomes=12000, length=50000, threads=16, reps=3, variants=False, ref_thr
         res["ours_s"], res["ours_stages"] = s, st
         res["ours_bp_per_s"] = res["bp"] / s
         if variants:
-            for tag, extra in (("p1", None), ("no_early_parse", {"MASH_AMD_NO_EARLY_PARSE": "1"}), ("no_groups", {"MASH_AMD_NO_GROUPS": "1"}),
-                               ("neither", {"MASH_AMD_NO_EARLY_PARSE": "1", "MASH_AMD_NO_GROUPS": "1"}), ("slow_exit", {"MASH_AMD_SLOW_EXIT": "1"}),
+            for tag, extra in (("p1", None), ("early_parse", {"MASH_AMD_EARLY_PARSE": "1"}), ("no_groups", {"MASH_AMD_NO_GROUPS": "1"}),
+                               ("early_no_groups", {"MASH_AMD_EARLY_PARSE": "1", "MASH_AMD_NO_GROUPS": "1"}), ("slow_exit", {"MASH_AMD_SLOW_EXIT": "1"}),
                                ("one_batch", {"MASH_AMD_BATCH_BYTES": str(2 << 30)}), ("batch_16M", {"MASH_AMD_BATCH_BYTES": str(16 << 20)}),
                                ("batch_256M", {"MASH_AMD_BATCH_BYTES": str(256 << 20)}), ("p4", None), ("p8", None), ("p32", None), ("p64", None)):
                 th = tag[1:] if tag[0] == "p" and tag[1:].isdigit() else str(threads)
