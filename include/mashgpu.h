@@ -181,9 +181,13 @@ int mg_sketch_reads_host(mg_ctx *ctx, const mg_params *p, const uint8_t *bases, 
  * the host between chunks, the device holds one chunk at a time, and *stopped_out turns 1 with the
  * chunk in which the target coverage is reached -- the caller stops reading its files there, as the
  * reference's reader loop does (Sketch.cpp:1258).  Results are those of mg_sketch_reads_host on
- * the concatenation of the chunks. */
+ * the concatenation of the chunks.  Every reads option goes through it -- also plain -r / -m (neither
+ * target_cov nor bloom_bytes): host and device memory are then bounded by one chunk, as the reference's
+ * are by its heap (Sketch.cpp:1196-1270), where mg_sketch_host over the whole read set needs it in HBM;
+ * the result, incl. the order-dependent multiplicity of the largest kept hash under min_copies > 1
+ * (MinHashHeap.cpp:96-144), is the same. */
 typedef struct mg_reads_session mg_reads_session;
-int  mg_reads_begin(mg_ctx *ctx, const mg_params *p, mg_reads_session **out);          /* p->target_cov > 0 or p->bloom_bytes > 0 */
+int  mg_reads_begin(mg_ctx *ctx, const mg_params *p, mg_reads_session **out);
 int  mg_reads_add_host(mg_reads_session *rs, const uint8_t *bases, uint64_t nbases, int *stopped_out);
 int  mg_reads_finish(mg_reads_session *rs, uint64_t *hashes_out, uint32_t *nhash_out, uint32_t *counts_out,
                      uint64_t *records_used_out);
@@ -392,6 +396,23 @@ int  mg_screen_finish_host(mg_screen *sc, uint32_t *counts_out, uint64_t *mix_ha
  * ranks (RCCL all-reduce, u32 sum) and the per-rank mixture sketches are merged
  * (bottom-s of their union); see mash_amd/screen_dist.py. */
 int  mg_screen_counts_dev(mg_screen *sc, uint32_t *counts_out_dev);
+/* A database that stays resident (the reference rebuilds hashTable / hashCounts for every run,
+ * CommandScreen.cpp:93-116; a service screens mixture after mixture against one database):
+ * mg_screen_reset makes the screen ready for the NEXT mixture -- counters of the hashes the last one
+ * touched back to 0, mixture sketch emptied; the key table, its two-tier bound and the rows-by-hash
+ * index stay.  mg_screen_finish_sparse_host returns what a mixture touched instead of a dense matrix:
+ * one hit per (row, hash) whose hash was observed -- {row, count = observations, hash} -- i.e. the
+ * non-zero cells of mg_screen_finish_host's counts_out (`shared` of a row = its hits, its median
+ * multiplicity = the median of their counts; CommandScreen.cpp:338-355), ordered by row, then hash.
+ * *nhits_out = their number; the first min(capacity, *nhits_out) are written (call with capacity 0 to
+ * size the buffer).  Cost proportional to what was touched, not to the database.
+ * mg_screen_tier_note: how the key bound was laid out for this database (one tier / two tiers, see
+ * DESIGN.md section 7), for logs. */
+typedef struct mg_screen_hit { uint32_t row, count; uint64_t hash; } mg_screen_hit;
+int  mg_screen_reset(mg_screen *sc);
+int  mg_screen_finish_sparse_host(mg_screen *sc, mg_screen_hit *hits_out, uint64_t capacity, uint64_t *nhits_out,
+                                  uint64_t *mix_hashes_out, uint32_t *mix_nhash_out, uint64_t *distinct_out);
+const char *mg_screen_tier_note(const mg_screen *sc);
 void mg_screen_free(mg_screen *sc);
 /* estimateIdentity (CommandScreen.cpp:463-482) and pValueWithin (:601-615), host arithmetic. */
 double mg_identity(uint64_t common, uint64_t denom, int kmer_size);
@@ -407,6 +428,12 @@ int  mg_dscreen_create(mg_comm *c, const mg_params *p, const mg_dtable *db, int 
 int  mg_dscreen_add_host(mg_dscreen *d, const uint8_t *bases, uint64_t nbases);
 int  mg_dscreen_finish_host(mg_dscreen *d, uint32_t *counts_out, uint64_t *mix_hashes_out, uint32_t *mix_nhash_out,
                             uint64_t *distinct_out);
+/* The sparse form over all devices: every device's hits (mg_screen_finish_sparse_host) are merged on the
+ * host -- counts of the same (row, hash) summed -- so the exchange is megabytes over PCIe, no collective;
+ * mg_dscreen_reset readies every device for the next mixture. */
+int  mg_dscreen_finish_sparse_host(mg_dscreen *d, mg_screen_hit *hits_out, uint64_t capacity, uint64_t *nhits_out,
+                                   uint64_t *mix_hashes_out, uint32_t *mix_nhash_out, uint64_t *distinct_out);
+int  mg_dscreen_reset(mg_dscreen *d);
 void mg_dscreen_free(mg_dscreen *d);
 
 /* ---- timing hook for bench.py ----------------------------------------------

@@ -33,6 +33,7 @@ EXPORTS = [
     "mg_compare_tri_results_host", "mg_compare_rect_results_host",
     "mg_prof_enable", "mg_prof_reset", "mg_prof_avg_ms",
     "mg_screen_create", "mg_screen_create_translated", "mg_screen_add_host", "mg_screen_add_dev", "mg_screen_finish_host", "mg_screen_counts_dev", "mg_screen_free",
+    "mg_screen_reset", "mg_screen_finish_sparse_host", "mg_screen_tier_note", "mg_dscreen_finish_sparse_host", "mg_dscreen_reset",
     "mg_identity", "mg_p_value_within",
     "mg_comm_create_local", "mg_comm_unique_id", "mg_comm_create_rank", "mg_comm_destroy", "mg_comm_size", "mg_comm_rank",
     "mg_comm_uses_rccl", "mg_comm_ctx", "mg_comm_last_error", "mg_shard_tri_rows", "mg_shard_rows", "mg_dtable_upload",
@@ -126,6 +127,37 @@ class ScreenSession:
             self.h, counts.ctypes.data if want_counts else None, mix.ctypes.data, C.byref(mn),
             C.byref(dist) if want_distinct else None))
         return counts, mix[: mn.value].copy(), (int(dist.value) if want_distinct else None)
+
+    def finish_sparse(self):
+        """(hits HIT_DTYPE[nhits] ordered by row then hash, mixture sketch, distinct table hashes): the non-zero
+        cells of finish()'s counts"""
+        return _finish_sparse(self.eng, self.eng.lib.mg_screen_finish_sparse_host, self.h, int(self.p.sketch_size))
+
+    def reset(self):
+        """ready for the next mixture against the same (resident) database"""
+        self.eng._check(self.eng.lib.mg_screen_reset(self.h))
+
+    def tier_note(self):
+        return self.eng.lib.mg_screen_tier_note(self.h).decode()
+
+
+HIT_DTYPE = np.dtype([("row", np.uint32), ("count", np.uint32), ("hash", np.uint64)])
+
+
+def _finish_sparse(owner, fn, h, s):
+    n = C.c_uint64(0)
+    owner._check(fn(h, None, 0, C.byref(n), None, None, None))
+    hits = np.zeros(n.value, dtype=HIT_DTYPE)
+    mix = np.zeros(s, dtype=np.uint64)
+    mn, dist = C.c_uint32(0), C.c_uint64(0)
+    owner._check(fn(h, hits.ctypes.data if n.value else None, n.value, C.byref(n), mix.ctypes.data, C.byref(mn), C.byref(dist)))
+    return hits, mix[: mn.value].copy(), int(dist.value)
+
+
+def hits_of_counts(counts):
+    """the sparse form of a dense counts matrix (row-major order = by row; hashes not known here)"""
+    r, c = np.nonzero(counts)
+    return r.astype(np.uint32), counts[r, c]
 
 
 class MashGpuError(RuntimeError):
@@ -245,6 +277,12 @@ def load_library():
     lib.mg_screen_counts_dev.argtypes = [vp, vp]
     lib.mg_screen_free.argtypes = [vp]
     lib.mg_screen_free.restype = None
+    lib.mg_screen_reset.argtypes = [vp]
+    lib.mg_screen_finish_sparse_host.argtypes = [vp, vp, u64, C.POINTER(u64), vp, C.POINTER(u32), C.POINTER(u64)]
+    lib.mg_screen_tier_note.argtypes = [vp]
+    lib.mg_screen_tier_note.restype = C.c_char_p
+    lib.mg_dscreen_finish_sparse_host.argtypes = [vp, vp, u64, C.POINTER(u64), vp, C.POINTER(u32), C.POINTER(u64)]
+    lib.mg_dscreen_reset.argtypes = [vp]
     lib.mg_identity.argtypes = [u64, u64, i32]
     lib.mg_identity.restype = dbl
     lib.mg_p_value_within.argtypes = [u64, u64, dbl, u64]
@@ -344,14 +382,21 @@ class LocalComm:
     def free(self, d):
         self.lib.mg_dtable_free(d)
 
-    def screen(self, d, n, s, p, batches, translate=False):
-        """sharded screen of `batches` (lists of records) against replicated table d"""
+    def screen(self, d, n, s, p, batches, translate=False, sparse=False, again=None):
+        """sharded screen of `batches` (lists of records) against replicated table d; sparse: hits instead of
+        the dense matrix; again: a second list of batches screened after a reset of the same (resident)
+        database -- its result is returned instead"""
         h = C.c_void_p()
         self._check(self.lib.mg_dscreen_create(self.h, C.byref(p), d, int(translate), C.byref(h)))
         try:
-            for recs in batches:                      # a list of records, or the bytes already joined (uint8 array)
-                blob = np.ascontiguousarray(recs) if isinstance(recs, np.ndarray) else np.frombuffer(join_records(recs), dtype=np.uint8)
-                self._check(self.lib.mg_dscreen_add_host(h, blob.ctypes.data, len(blob)))
+            for rnd in ([batches] if again is None else [batches, again]):
+                if rnd is again:
+                    self._check(self.lib.mg_dscreen_reset(h))
+                for recs in rnd:                      # a list of records, or the bytes already joined (uint8 array)
+                    blob = np.ascontiguousarray(recs) if isinstance(recs, np.ndarray) else np.frombuffer(join_records(recs), dtype=np.uint8)
+                    self._check(self.lib.mg_dscreen_add_host(h, blob.ctypes.data, len(blob)))
+            if sparse:
+                return _finish_sparse(self, self.lib.mg_dscreen_finish_sparse_host, h, int(p.sketch_size))
             counts = np.zeros((n, s), dtype=np.uint32)
             mix = np.zeros(int(p.sketch_size), dtype=np.uint64)
             mn, dist = C.c_uint32(0), C.c_uint64(0)

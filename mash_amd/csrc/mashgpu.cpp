@@ -344,6 +344,12 @@ struct ProbeHook {
     const unsigned long long *keys;
     uint32_t *obs;
     uint64_t mask, key_max;
+    uint32_t *touched;                   // see SketchArgs::probe_touched
+    unsigned long long *ntouched;
+    uint64_t touched_cap;
+    uint64_t tier;                       // == key_max: one tier
+    const uint32_t *bits;
+    uint64_t bits_scale;
 };
 
 // Work decomposition of one sketching call: chunks of k-mer start positions (one workgroup each)
@@ -812,6 +818,12 @@ static int sketch_dev_impl(mg_ctx *ctx, const mg_params *p, const uint8_t *bases
     a.probe_obs = probe ? probe->obs : nullptr;
     a.probe_mask = probe ? probe->mask : 0;
     a.probe_max = probe ? probe->key_max : 0;
+    a.probe_touched = probe ? probe->touched : nullptr;
+    a.probe_ntouched = probe ? probe->ntouched : nullptr;
+    a.probe_touched_cap = probe ? probe->touched_cap : 0;
+    a.probe_tier = probe ? probe->tier : 0;
+    a.probe_bits = probe ? probe->bits : nullptr;
+    a.probe_bits_scale = probe ? probe->bits_scale : 0;
     a.seed_T = nullptr;
     if (range_path) {
         // -m / s beyond the LDS selector: bottom-s of the hashes seen at least m times, by exact range counting
@@ -1142,9 +1154,11 @@ struct ReadsHeap {
 
 }  // namespace
 
-// Reads mode with -c as a SESSION: chunks of whole records in reading order; the heap (incl. the -m
-// pending set) lives on the host between chunks, the device sees one chunk at a time, and the
-// caller stops reading its files the moment a chunk reports the target coverage.
+// Reads mode as a SESSION: chunks of whole records in reading order; the heap (incl. the -m pending
+// set) lives on the host between chunks, the device sees one chunk at a time, and with -c the caller
+// stops reading its files the moment a chunk reports the target coverage.  Host and device memory are
+// bounded by one chunk for EVERY reads option (-r, -m, -c, -b): what the reference's reader loop does
+// (Sketch.cpp:1196-1270), where mg_sketch_host / mg_sketch_begin keep the whole read set in HBM.
 struct mg_reads_session {
     mg_ctx *ctx = nullptr;
     mg_params p;
@@ -1171,8 +1185,7 @@ int mg_reads_begin(mg_ctx *ctx, const mg_params *p, mg_reads_session **out)
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (!p || !out) return fail(ctx, MG_ERR_INVALID, "mg_reads_begin: NULL argument");
     if (p->kmer_size < 1 || p->kmer_size > 32) return fail(ctx, MG_ERR_INVALID, "mg_sketch: k must be 1..32");
-    if (!(p->target_cov > 0) && p->bloom_bytes == 0)
-        return fail(ctx, MG_ERR_INVALID, "mg_reads_begin: needs target_cov > 0 or bloom_bytes > 0 (plain reads mode is mg_sketch_begin / mg_sketch_host)");
+    // (neither -c nor -b: plain reads mode, any min_copies, in constant memory -- nothing stops the reading)
     if (p->bloom_bytes && p->min_copies > 1) return fail(ctx, MG_ERR_INVALID, "mg_reads_begin: min_copies cannot be used with bloom_bytes");   // sketchParameterSetup.cpp:44-48
     if (p->bloom_bytes > (1ull << 60)) return fail(ctx, MG_ERR_INVALID, "mg_reads_begin: bloom_bytes out of range");
     const bool dna = alphabet_is_dna(p);
@@ -3824,7 +3837,73 @@ struct mg_screen {
     uint64_t key_max = 0;
     bool translate = false;             // mixture is nucleotide, queries are amino-acid sketches
     std::vector<uint64_t> mix;          // running bottom-s of the mixture (host, ascending, distinct)
+    uint64_t distinct = 0;              // distinct hashes of the database (counted while the table is built)
+    // what a job touched: slots whose counter left 0 (device list), so that results and reset are O(touched)
+    uint32_t *touched = nullptr;
+    unsigned long long *ntouched = nullptr;      // device; [1] = cursor of the hit list
+    uint64_t touched_cap = 0;
+    // rows by slot (built at the first sparse finish): slot_end[slot] = end of its run in ent
+    uint32_t *slot_end = nullptr, *ent = nullptr;
+    // second tier of the key bound (SketchArgs::probe_tier): keys above `tier` are announced by a bitmap
+    uint64_t tier = 0, bits_scale = 0;
+    uint32_t *bits = nullptr;
+    std::string tier_note;
 };
+
+// Two-tier key bound.  A k-mer hash above the table's largest key cannot be a key; that bound is only as
+// good as the database's SMALLEST genome (bottom-s hashes of a 30 kbp virus reach 1/30 of the hash range, those
+// of a 5 Mbp bacterium 1/5000).  So the range is cut at `tier`: below it a hash goes to the table as before,
+// above it only if its bit in a bitmap over (tier, key_max] is set.  tier = the candidate (key_max / 2^j)
+// with the least expected cost per k-mer, a table probe counting 1 and a bitmap read 0.15.
+static int screen_plan_tiers(mg_ctx *ctx, mg_screen *sc)
+{
+    sc->tier = sc->key_max;
+    if (sc->distinct == 0 || sc->key_max < (1ull << 40)) return MG_OK;
+    if (const char *e = getenv("MASHGPU_SCREEN_TIERS")) { if (atoi(e) == 0) { sc->tier_note = "off (MASHGPU_SCREEN_TIERS=0)"; return MG_OK; } }
+    uint32_t log_bits = 27;
+    if (const char *e = getenv("MASHGPU_SCREEN_BITS")) log_bits = (uint32_t)std::min(34, std::max(10, atoi(e)));
+    const uint64_t B = 1ull << log_bits;
+    const uint32_t NB = 24;
+    std::vector<uint64_t> bounds(NB);
+    for (uint32_t j = 0; j < NB; j++) bounds[j] = sc->key_max >> (j + 1);
+    DevBuf<uint64_t> d_bounds(ctx);
+    DevBuf<unsigned long long> d_below(ctx);
+    std::vector<unsigned long long> below(NB, 0);
+    if (d_bounds.alloc(NB) != hipSuccess || d_below.alloc(NB) != hipSuccess) return fail(ctx, MG_ERR_NOMEM, "mg_screen_create: device allocation failed");
+    hipError_t e = hipMemcpyAsync(d_bounds, bounds.data(), NB * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_below, 0, NB * 8, ctx->stream);
+    if (e == hipSuccess) e = mg::launch_screen_count_below(sc->keys, sc->slots, d_bounds, NB, d_below, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(below.data(), d_below, NB * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("mg_screen_create (tiers): ") + hipGetErrorString(e));
+    const double R = 18446744073709551616.0, one = (double)sc->key_max / R;
+    double best = one;
+    int best_j = -1;
+    for (uint32_t j = 0; j < NB; j++) {
+        const double t = (double)bounds[j] / R, above = (double)(sc->distinct - below[j]);
+        const double cost = t + (one - t) * (0.15 + std::min(1.0, above / (double)B));
+        if (cost < best) { best = cost; best_j = (int)j; }
+    }
+    char note[200];
+    if (best_j < 0 || best > 0.8 * one) {
+        snprintf(note, sizeof note, "one tier (key bound %.3g of the hash range, best two-tier cost %.3g)", one, best);
+        sc->tier_note = note;
+        return MG_OK;
+    }
+    const uint64_t tier = bounds[best_j], range = sc->key_max - tier;
+    if (range < 2 * B) return MG_OK;
+    sc->bits_scale = (uint64_t)(((unsigned __int128)B << 64) / range);
+    if (hipMalloc(&sc->bits, B / 8) != hipSuccess) return fail(ctx, MG_ERR_NOMEM, "mg_screen_create: device allocation failed");
+    e = hipMemsetAsync(sc->bits, 0, B / 8, ctx->stream);
+    if (e == hipSuccess) e = mg::launch_screen_bits(sc->keys, sc->slots, tier, sc->bits_scale, sc->bits, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("mg_screen_create (tiers): ") + hipGetErrorString(e));
+    sc->tier = tier;
+    snprintf(note, sizeof note, "two tiers: table below %.3g of the hash range, %llu keys behind a %u-bit bitmap up to %.3g (cost %.3g -> %.3g)",
+             (double)tier / R, (unsigned long long)(sc->distinct - below[best_j]), log_bits, one, one, best);
+    sc->tier_note = note;
+    return MG_OK;
+}
 
 int mg_screen_create(mg_ctx *ctx, const mg_params *p, const mg_table *db, mg_screen **out)
 {
@@ -3845,15 +3924,27 @@ int mg_screen_create(mg_ctx *ctx, const mg_params *p, const mg_table *db, mg_scr
     uint64_t slots = 1024;
     while (slots < 2 * db->n * db->s) slots <<= 1;
     sc->slots = slots;
+    if (db->n * db->s >= (1ull << 32)) { delete sc; return fail(ctx, MG_ERR_UNSUPPORTED, "mg_screen_create: more than 2^32 database hashes"); }
+    sc->touched_cap = std::max<uint64_t>(db->n * db->s, 1);
     hipError_t e = hipMalloc(&sc->keys, slots * 8);
     if (e == hipSuccess) e = hipMalloc(&sc->obs, slots * 4);
+    if (e == hipSuccess) e = hipMalloc(&sc->touched, sc->touched_cap * 4);
+    if (e == hipSuccess) e = hipMalloc(&sc->ntouched, 16);
     if (e == hipSuccess) e = hipMemsetAsync(sc->keys, 0xFF, slots * 8, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(sc->obs, 0, slots * 4, ctx->stream);
-    if (e == hipSuccess) e = mg::launch_screen_build(db->hashes, db->nhash, db->n, db->s, sc->keys, slots - 1, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(sc->ntouched, 0, 16, ctx->stream);
+    if (e == hipSuccess) e = mg::launch_screen_build(db->hashes, db->nhash, db->n, db->s, sc->keys, slots - 1, sc->ntouched + 1, ctx->stream);
+    unsigned long long distinct = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&distinct, sc->ntouched + 1, 8, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
         mg_screen_free(sc);
         return fail(ctx, MG_ERR_HIP, std::string("mg_screen_create: ") + hipGetErrorString(e));
+    }
+    sc->distinct = distinct;
+    {
+        const int rc = screen_plan_tiers(ctx, sc);
+        if (rc != MG_OK) { mg_screen_free(sc); return rc; }
     }
     *out = sc;
     return MG_OK;
@@ -3891,7 +3982,7 @@ int mg_screen_add_dev(mg_screen *sc, const uint8_t *bases_dev, uint64_t nbases)
     HIP_TRY(ctx, hipMalloc(&d_h, s * 8));
     if (hipMalloc(&d_n, 4) != hipSuccess) { hipFree(d_h); return fail(ctx, MG_ERR_NOMEM, "mg_screen_add: allocation failed"); }
     const uint64_t off[2] = {0, nbases};
-    const ProbeHook hook{sc->keys, sc->obs, sc->slots - 1, sc->key_max};
+    const ProbeHook hook{sc->keys, sc->obs, sc->slots - 1, sc->key_max, sc->touched, sc->ntouched, sc->touched_cap, sc->tier, sc->bits, sc->bits_scale};
     int rc = sketch_dev_impl(ctx, &sc->p, bases_dev, nbases, off, 1, d_h, d_n, nullptr, &hook);
     std::vector<uint64_t> bh(s);
     uint32_t bn = 0;
@@ -3995,18 +4086,108 @@ int mg_screen_finish_host(mg_screen *sc, uint32_t *counts_out, uint64_t *mix_has
         for (uint64_t i = 0; i < s; i++) mix_hashes_out[i] = i < sc->mix.size() ? sc->mix[i] : MG_HASH_PAD;
     }
     if (mix_nhash_out) *mix_nhash_out = (uint32_t)sc->mix.size();
-    if (distinct_out) {
-        // distinct table entries = occupied slots (keys are unique by construction)
-        std::vector<unsigned long long> hk(std::min<uint64_t>(sc->slots, 1u << 22));
-        uint64_t cnt = 0;
-        for (uint64_t o = 0; o < sc->slots; o += hk.size()) {
-            const uint64_t nn = std::min<uint64_t>(hk.size(), sc->slots - o);
-            if (hipMemcpy(hk.data(), sc->keys + o, nn * 8, hipMemcpyDeviceToHost) != hipSuccess)
-                return fail(ctx, MG_ERR_HIP, "mg_screen_finish: D2H copy failed");
-            for (uint64_t i = 0; i < nn; i++) cnt += hk[i] != 0xFFFFFFFFFFFFFFFFull;
-        }
-        *distinct_out = cnt;
+    if (distinct_out) *distinct_out = sc->distinct;         // counted while the table was built
+    return MG_OK;
+}
+
+static int screen_touched(mg_screen *sc, uint64_t *nt)
+{
+    unsigned long long v = 0;
+    if (hipMemcpyAsync(&v, sc->ntouched, 8, hipMemcpyDeviceToHost, sc->ctx->stream) != hipSuccess || hipStreamSynchronize(sc->ctx->stream) != hipSuccess)
+        return fail(sc->ctx, MG_ERR_HIP, "mg_screen: D2H copy failed");
+    *nt = std::min<uint64_t>(v, sc->touched_cap);
+    return MG_OK;
+}
+
+int mg_screen_reset(mg_screen *sc)
+{
+    if (!sc) return MG_ERR_INVALID;
+    mg_ctx *ctx = sc->ctx;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    uint64_t nt = 0;
+    const int rc = screen_touched(sc, &nt);
+    if (rc != MG_OK) return rc;
+    hipError_t e = mg::launch_screen_reset(sc->touched, nt, sc->obs, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(sc->ntouched, 0, 8, ctx->stream);
+    if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("mg_screen_reset: ") + hipGetErrorString(e));
+    sc->mix.clear();
+    return MG_OK;
+}
+
+const char *mg_screen_tier_note(const mg_screen *sc) { return sc ? sc->tier_note.c_str() : ""; }
+
+// rows by slot, once per database
+static int screen_ensure_index(mg_screen *sc)
+{
+    if (sc->slot_end) return MG_OK;
+    mg_ctx *ctx = sc->ctx;
+    const mg_table *db = sc->db;
+    const size_t tb = mg::screen_index_temp_bytes(sc->slots);
+    DevBuf<uint8_t> temp(ctx);
+    hipError_t e = hipMalloc(&sc->slot_end, sc->slots * 4);
+    if (e == hipSuccess) e = hipMalloc(&sc->ent, std::max<uint64_t>(db->n * db->s, 1) * 4);
+    if (e == hipSuccess) e = temp.alloc(std::max<size_t>(tb, 1));
+    if (e == hipSuccess) e = hipMemsetAsync(sc->slot_end, 0, sc->slots * 4, ctx->stream);
+    if (e == hipSuccess) e = mg::launch_screen_index(db->hashes, db->nhash, db->n, db->s, sc->keys, sc->slots - 1, sc->slot_end, sc->ent, temp, tb, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        if (sc->slot_end) hipFree(sc->slot_end);
+        if (sc->ent) hipFree(sc->ent);
+        sc->slot_end = sc->ent = nullptr;
+        return fail(ctx, MG_ERR_HIP, std::string("mg_screen (index): ") + hipGetErrorString(e));
     }
+    return MG_OK;
+}
+
+int mg_screen_finish_sparse_host(mg_screen *sc, mg_screen_hit *hits_out, uint64_t capacity, uint64_t *nhits_out,
+                                 uint64_t *mix_hashes_out, uint32_t *mix_nhash_out, uint64_t *distinct_out)
+{
+    if (!sc) return MG_ERR_INVALID;
+    mg_ctx *ctx = sc->ctx;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    if (!nhits_out || (!hits_out && capacity)) return fail(ctx, MG_ERR_INVALID, "mg_screen_finish_sparse_host: NULL argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = screen_ensure_index(sc);
+    uint64_t nt = 0;
+    if (rc == MG_OK) rc = screen_touched(sc, &nt);
+    if (rc != MG_OK) return rc;
+    unsigned long long total = 0;
+    if (nt) {
+        hipError_t e = hipMemsetAsync(sc->ntouched + 1, 0, 8, ctx->stream);
+        if (e == hipSuccess) e = mg::launch_screen_hits(sc->touched, nt, sc->keys, sc->obs, sc->slot_end, sc->ent, nullptr, sc->ntouched + 1, 0, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&total, sc->ntouched + 1, 8, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("mg_screen_finish_sparse: ") + hipGetErrorString(e));
+    }
+    *nhits_out = total;
+    const uint64_t take = std::min<uint64_t>(total, capacity);
+    if (take) {
+        DevBuf<mg::ScreenHit> d_hits(ctx);
+        if (d_hits.alloc(total) != hipSuccess) return fail(ctx, MG_ERR_NOMEM, "mg_screen_finish_sparse: device allocation failed");
+        hipError_t e = hipMemsetAsync(sc->ntouched + 1, 0, 8, ctx->stream);
+        if (e == hipSuccess) e = mg::launch_screen_hits(sc->touched, nt, sc->keys, sc->obs, sc->slot_end, sc->ent, d_hits, sc->ntouched + 1, total, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("mg_screen_finish_sparse: ") + hipGetErrorString(e));
+        // in a defined order: by row, then hash (the kernel emits them in the order the slots were touched)
+        DevBuf<mg::ScreenHit> d_sorted(ctx);
+        DevBuf<unsigned long long> k64a(ctx), k64b(ctx);
+        DevBuf<uint32_t> u32a(ctx), u32b(ctx), u32c(ctx), u32d(ctx);
+        DevBuf<uint8_t> temp(ctx);
+        const size_t tb = mg::screen_sort_temp_bytes(total);
+        if (d_sorted.alloc(total) != hipSuccess || k64a.alloc(total) != hipSuccess || k64b.alloc(total) != hipSuccess || u32a.alloc(total) != hipSuccess ||
+            u32b.alloc(total) != hipSuccess || u32c.alloc(total) != hipSuccess || u32d.alloc(total) != hipSuccess || temp.alloc(std::max<size_t>(tb, 1)) != hipSuccess)
+            return fail(ctx, MG_ERR_NOMEM, "mg_screen_finish_sparse: device allocation failed");
+        e = mg::launch_screen_sort_hits(d_hits, total, d_sorted, k64a, k64b, u32a, u32b, u32c, u32d, temp, tb, ctx->stream);
+        static_assert(sizeof(mg_screen_hit) == sizeof(mg::ScreenHit), "mg_screen_hit layout");
+        if (e == hipSuccess) e = hipMemcpyAsync(hits_out, d_sorted, take * sizeof(mg_screen_hit), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("mg_screen_finish_sparse: ") + hipGetErrorString(e));
+    }
+    const uint64_t s = sc->p.sketch_size;
+    if (mix_hashes_out) for (uint64_t i = 0; i < s; i++) mix_hashes_out[i] = i < sc->mix.size() ? sc->mix[i] : MG_HASH_PAD;
+    if (mix_nhash_out) *mix_nhash_out = (uint32_t)sc->mix.size();
+    if (distinct_out) *distinct_out = sc->distinct;
     return MG_OK;
 }
 
@@ -4028,8 +4209,8 @@ void mg_screen_free(mg_screen *sc)
 {
     if (!sc) return;
     hipSetDevice(sc->ctx->device);
-    if (sc->keys) hipFree(sc->keys);
-    if (sc->obs) hipFree(sc->obs);
+    for (void *q : {(void *)sc->keys, (void *)sc->obs, (void *)sc->touched, (void *)sc->ntouched, (void *)sc->slot_end, (void *)sc->ent, (void *)sc->bits})
+        if (q) hipFree(q);
     delete sc;
 }
 
@@ -4176,6 +4357,75 @@ int mg_dscreen_finish_host(mg_dscreen *d, uint32_t *counts_out, uint64_t *mix_ha
         }
     }
     release();
+    return rc;
+}
+
+static int dscreen_drain(mg_dscreen *d)
+{
+    for (size_t g = 0; g < d->sc.size(); g++) {
+        mg_dscreen::Worker *wk = d->w[g].get();
+        std::unique_lock<std::mutex> lk(wk->m);
+        wk->cv.wait(lk, [&] { return !wk->busy; });
+        if (wk->rc != MG_OK) { d->comm->err = d->comm->ctxs[g]->err; return wk->rc; }
+    }
+    return MG_OK;
+}
+
+int mg_dscreen_finish_sparse_host(mg_dscreen *d, mg_screen_hit *hits_out, uint64_t capacity, uint64_t *nhits_out,
+                                  uint64_t *mix_hashes_out, uint32_t *mix_nhash_out, uint64_t *distinct_out)
+{
+    if (!d) return MG_ERR_INVALID;
+    mg_comm *c = d->comm;
+    if (!nhits_out || (!hits_out && capacity)) return comm_fail(c, MG_ERR_INVALID, "mg_dscreen_finish_sparse_host: NULL argument");
+    int rc = dscreen_drain(d);
+    if (rc != MG_OK) return rc;
+    const size_t G = d->sc.size();
+    if (G == 1) {
+        rc = mg_screen_finish_sparse_host(d->sc[0], hits_out, capacity, nhits_out, mix_hashes_out, mix_nhash_out, distinct_out);
+        if (rc != MG_OK) c->err = c->ctxs[0]->err;
+        return rc;
+    }
+    const uint64_t s = d->sc[0]->p.sketch_size;
+    std::vector<mg_screen_hit> all, part, next;
+    std::vector<uint64_t> merged;
+    auto before = [](const mg_screen_hit &a, const mg_screen_hit &b) { return a.row != b.row ? a.row < b.row : a.hash < b.hash; };
+    for (size_t g = 0; g < G; g++) {
+        uint64_t n = 0;
+        rc = mg_screen_finish_sparse_host(d->sc[g], nullptr, 0, &n, nullptr, nullptr, g == 0 ? distinct_out : nullptr);
+        part.resize(n);
+        if (rc == MG_OK && n) rc = mg_screen_finish_sparse_host(d->sc[g], part.data(), n, &n, nullptr, nullptr, nullptr);
+        if (rc != MG_OK) { c->err = c->ctxs[g]->err; return rc; }
+        next.resize(all.size() + part.size());                             // every device's list is ordered: a linear merge
+        std::merge(all.begin(), all.end(), part.begin(), part.end(), next.begin(), before);
+        all.swap(next);
+        const std::vector<uint64_t> &m = d->sc[g]->mix;                 // mixture sketch: bottom-s of the union
+        std::vector<uint64_t> u;
+        u.reserve(merged.size() + m.size());
+        std::merge(merged.begin(), merged.end(), m.begin(), m.end(), std::back_inserter(u));
+        u.erase(std::unique(u.begin(), u.end()), u.end());
+        if (u.size() > s) u.resize(s);
+        merged.swap(u);
+    }
+    size_t w = 0;
+    for (size_t i = 0; i < all.size(); i++) {
+        if (w && all[w - 1].row == all[i].row && all[w - 1].hash == all[i].hash) all[w - 1].count += all[i].count;
+        else all[w++] = all[i];
+    }
+    *nhits_out = w;
+    if (capacity) memcpy(hits_out, all.data(), std::min<uint64_t>(w, capacity) * sizeof(mg_screen_hit));
+    if (mix_hashes_out) for (uint64_t i = 0; i < s; i++) mix_hashes_out[i] = i < merged.size() ? merged[i] : MG_HASH_PAD;
+    if (mix_nhash_out) *mix_nhash_out = (uint32_t)merged.size();
+    return MG_OK;
+}
+
+int mg_dscreen_reset(mg_dscreen *d)
+{
+    if (!d) return MG_ERR_INVALID;
+    int rc = dscreen_drain(d);
+    for (size_t g = 0; g < d->sc.size() && rc == MG_OK; g++) {
+        rc = mg_screen_reset(d->sc[g]);
+        if (rc != MG_OK) d->comm->err = d->comm->ctxs[g]->err;
+    }
     return rc;
 }
 

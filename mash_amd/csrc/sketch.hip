@@ -206,7 +206,7 @@ __global__ __launch_bounds__(NT) void sketch_chunks_kernel(SketchArgs a)
     uint32_t seg_no = 0;                                   // segments finished (uniform)
     const unsigned long long *probe_keys = a.probe_keys;
     uint32_t *probe_obs = a.probe_obs;
-    const uint64_t probe_mask = a.probe_mask, probe_max = a.probe_max;
+    const uint64_t probe_mask = a.probe_mask, probe_max = a.probe_max, probe_tier = a.probe_tier;
     constexpr bool probing = PROBE;                        // fused table probe (mash screen) compiled in or out
 
     for (uint64_t t0 = w.begin; t0 < w.end; t0 += TILE) {
@@ -275,8 +275,18 @@ __global__ __launch_bounds__(NT) void sketch_chunks_kernel(SketchArgs a)
                         const bool mine = r.kmer_valid() && (lane_first + start < remaining);
                         const bool pass = mine && (!full || h < T);
                         if (probe_now && mine && h <= probe_max) {   // sketches are bottom-s sets: rare
+                            bool look = true;
+                            if (h > probe_tier) {                // second tier: the keys of the database's small genomes
+                                const uint64_t b = __umul64hi(h - probe_tier - 1, a.probe_bits_scale);
+                                look = (a.probe_bits[b >> 5] >> (b & 31)) & 1u;
+                            }
                             uint64_t slot;
-                            if (scr_find(probe_keys, probe_mask, h, &slot)) atomicAdd(&probe_obs[slot], 1u);
+                            if (look && scr_find(probe_keys, probe_mask, h, &slot)) {
+                                if (atomicAdd(&probe_obs[slot], 1u) == 0 && a.probe_touched) {
+                                    const unsigned long long i = atomicAdd(a.probe_ntouched, 1ULL);
+                                    if (i < a.probe_touched_cap) a.probe_touched[i] = (uint32_t)slot;
+                                }
+                            }
                         }
                         const uint64_t m = __ballot(pass);
                         if (m != 0) {

@@ -36,6 +36,17 @@ struct SketchArgs {
     uint32_t *probe_obs;
     uint64_t probe_mask;
     uint64_t probe_max;
+    // slots whose counter went 0 -> 1 are appended here (any order): what a job touched, so that its results
+    // and the reset for the next job cost O(touched) instead of O(table) (resident database, mg_screen_reset)
+    uint32_t *probe_touched;                 // nullptr: no list
+    unsigned long long *probe_ntouched;
+    uint64_t probe_touched_cap;
+    // two-tier key bound (databases mixing small and large genomes): a hash in (probe_tier, probe_max] is
+    // looked up only if its bit in probe_bits is set -- bit = mulhi(hash - probe_tier - 1, probe_bits_scale);
+    // the bitmap is a filter, a set bit without a key costs one futile probe.  probe_tier == probe_max: one tier.
+    uint64_t probe_tier;
+    const uint32_t *probe_bits;
+    uint64_t probe_bits_scale;
     const uint64_t *seed_T;       // [nsketch] seeded thresholds (HPAD = none), or nullptr
 };
 

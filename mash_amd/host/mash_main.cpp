@@ -573,16 +573,17 @@ void sketch_reads(Gpu &gpu, SketchSet &set, const vector<string> &files, mg_sket
         readers.push_back(r);
     }
     PendingBatch b;
-    // Without -c the reads leave for the device as they are parsed (pinned staging ring, copies
-    // overlapped with parsing): the host never holds the read set, only the device does (one
-    // sketch over everything at the end, exact as before; 288 GB of HBM bound the input).  -c
-    // goes through a reads session chunk by chunk (the heap is replayed on the host over a thinned
-    // event stream) and STOPS READING the files with the chunk that reaches the target coverage,
-    // as the reference's reader loop does (Sketch.cpp:1258): neither host nor device ever holds
-    // more than one chunk.
-    // (-b, the Bloom filter in front of the heap, is order-dependent too and takes the same route)
+    // Every reads option goes through a reads session, chunk by chunk: the device hashes a chunk and hands
+    // back the k-mers that can still change the heap, the host replays MinHashHeap::tryInsert over that
+    // thinned stream (-m pending set, -b Bloom filter, -c stop test included) -- neither host nor device ever
+    // holds more than a chunk or two, as the reference's reader loop holds one record and its heap
+    // (Sketch.cpp:1196-1270).  With -c the reading STOPS with the chunk that reaches the target coverage
+    // (Sketch.cpp:1258).  A chunk is on the device while the next one is being parsed.
+    // MASH_AMD_READS_RESIDENT=1 (tests; plain -r / -m only): the round-2 route -- the reads leave for the device as
+    // they are parsed and ONE sketch call runs over the whole read set in HBM at the end; same bytes out.
     const bool none = set.p.never_admit;          // -m 0: every record is read and counted, no hash is kept
-    const bool cov_mode = !none && (set.p.target_cov > 0 || set.p.bloom_bytes > 0);
+    const bool must_replay = set.p.target_cov > 0 || set.p.bloom_bytes > 0;      // order-dependent by definition
+    const bool cov_mode = !none && (must_replay || !getenv("MASH_AMD_READS_RESIDENT"));
     b.stream = !none && !cov_mode && !getenv("MASH_AMD_NO_STREAM");
     if (b.stream && shared) b.sess = *shared;
     ensure_session(gpu, set, b);
@@ -590,10 +591,18 @@ void sketch_reads(Gpu &gpu, SketchSet &set, const vector<string> &files, mg_sket
     size_t reads_chunk = 64u << 20;
     if (const char *e = getenv("MASH_AMD_READS_CHUNK")) reads_chunk = std::max<size_t>(1, strtoull(e, nullptr, 10));   // test knob
     int cov_stopped = 0;
+    vector<uint8_t> in_flight;                    // the chunk the device is working on
+    std::future<int> pending;
+    auto wait_chunk = [&]() {
+        if (!pending.valid()) return;
+        if (pending.get() != MG_OK) { cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl; exit(1); }
+    };
     auto feed_chunk = [&]() {
-        if (b.bases.empty()) return;
-        if (mg_reads_add_host(rs, b.bases.data(), b.bases.size(), &cov_stopped) != MG_OK) { cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl; exit(1); }
+        wait_chunk();                             // (cov_stopped now tells about the chunk before this one)
+        if (b.bases.empty() || cov_stopped) { b.bases.clear(); return; }
+        in_flight.swap(b.bases);
         b.bases.clear();
+        pending = std::async(std::launch::async, [&]() { return mg_reads_add_host(rs, in_flight.data(), in_flight.size(), &cov_stopped); });
     };
     if (cov_mode) {
         mg_params mp = batch_params(set);
@@ -601,6 +610,7 @@ void sketch_reads(Gpu &gpu, SketchSet &set, const vector<string> &files, mg_sket
         mp.target_cov = set.p.target_cov;
         mp.bloom_bytes = set.p.bloom_bytes;
         if (mg_reads_begin(gpu.ctx, &mp, &rs) != MG_OK) { cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl; exit(1); }
+        b.bases.reserve(std::min<size_t>(reads_chunk, 64u << 20) + (1u << 16));
     }
     fastx::Record rec;
     size_t it = 0;
@@ -646,8 +656,9 @@ void sketch_reads(Gpu &gpu, SketchSet &set, const vector<string> &files, mg_sket
         if (n > 1) ref.comment = "[" + std::to_string(n) + " seqs] " + ref.comment + " [...]";
     };
     if (cov_mode) {
-        // -c: the sequential heap decides where reading stops (Sketch.cpp:1258); replayed exactly
-        if (!cov_stopped) feed_chunk();
+        // the sequential heap, replayed exactly; with -c it also decided where reading stopped (Sketch.cpp:1258)
+        feed_chunk();
+        wait_chunk();
         const uint64_t s = set.p.sketch_size;
         vector<uint64_t> hashes(s);
         vector<uint32_t> counts(s);
@@ -1935,11 +1946,14 @@ int cmd_screen(int argc, const char **argv)
     for (auto *r : readers) delete r;
     if (l != -1) { cerr << "\nERROR: reading inputs" << endl; exit(1); }
     flush();
-    vector<uint32_t> counts(std::max<uint64_t>(n * s, 1));
+    // what the mixture touched: one hit per (sketch, hash) that was observed -- not the n x s matrix of
+    // counters, of which a mixture leaves all but a fraction of a per cent at zero
     vector<uint64_t> mix(s);
     uint32_t mix_n = 0;
-    uint64_t distinct = 0;
-    if (mg_dscreen_finish_host(sc, counts.data(), mix.data(), &mix_n, &distinct) != MG_OK) { cerr << "ERROR: " << mg_comm_last_error(gpu.comm) << endl; return 1; }
+    uint64_t distinct = 0, nhits = 0;
+    if (mg_dscreen_finish_sparse_host(sc, nullptr, 0, &nhits, mix.data(), &mix_n, &distinct) != MG_OK) { cerr << "ERROR: " << mg_comm_last_error(gpu.comm) << endl; return 1; }
+    vector<mg_screen_hit> hits(nhits);
+    if (nhits && mg_dscreen_finish_sparse_host(sc, hits.data(), nhits, &nhits, nullptr, nullptr, nullptr) != MG_OK) { cerr << "ERROR: " << mg_comm_last_error(gpu.comm) << endl; return 1; }
     mg_dscreen_free(sc);
     mg_dtable_free(t);
     cerr << "   " << distinct << " distinct hashes." << endl;
@@ -1956,9 +1970,7 @@ int cmd_screen(int argc, const char **argv)
     cerr << "Summing shared..." << endl;
     vector<uint64_t> shared(n, 0);
     vector<vector<uint64_t>> depths(n);
-    for (uint64_t i = 0; i < n; i++)
-        for (size_t j = 0; j < set.refs[i].hashes.size() && j < s; j++)
-            if (counts[i * s + j] >= 1) { shared[i]++; depths[i].push_back(counts[i * s + j]); }
+    for (const mg_screen_hit &h : hits) { shared[h.row]++; depths[h.row].push_back(h.count); }       // (ordered by sketch, then hash)
     const double kspace = set.kmer_space();
     if (c.o("winning!").active) {
         cerr << "Reallocating to winners..." << endl;
@@ -1967,9 +1979,7 @@ int cmd_screen(int argc, const char **argv)
         // each observed hash goes to the best-scoring sketch containing it (ties: larger length, then first seen)
         std::map<uint64_t, vector<uint32_t>> owners;
         std::map<uint64_t, uint32_t> obs;
-        for (uint64_t i = 0; i < n; i++)
-            for (size_t j = 0; j < set.refs[i].hashes.size() && j < s; j++)
-                if (counts[i * s + j] >= 1) { owners[set.refs[i].hashes[j]].push_back((uint32_t)i); obs[set.refs[i].hashes[j]] = counts[i * s + j]; }
+        for (const mg_screen_hit &h : hits) { owners[h.hash].push_back(h.row); obs[h.hash] = h.count; }
         std::fill(shared.begin(), shared.end(), 0);
         for (auto &d : depths) d.clear();
         for (const auto &kv : owners) {

@@ -94,11 +94,23 @@ def screen_sharded(local_screen, batches, s, group=None, sparse_below=0.05):
     return exchange(counts, mix, s, group, sparse_below)
 
 
-def gpu_local_screen(eng, db, p):
+def gpu_local_screen(eng, db, p, resident=False):
     """local_screen over libmashgpu: batches are lists of record bytes (host) or
-    (device_ptr, nbytes, keepalive) tuples; counts stay on the GPU for the collective."""
+    (device_ptr, nbytes, keepalive) tuples; counts stay on the GPU for the collective.
+    resident: ONE mg_screen for all calls (the database's key table is built once, every call starts with
+    mg_screen_reset); run.close() frees it."""
+    state = {"sc": None}
+
     def run(my_batches):
-        with eng.screen_open(db, p) as sc:
+        if resident:
+            if state["sc"] is None:
+                state["sc"] = eng.screen_open(db, p)
+            else:
+                state["sc"].reset()
+            sc = state["sc"]
+        else:
+            sc = eng.screen_open(db, p)
+        try:
             for b in my_batches:
                 if isinstance(b, tuple):
                     sc.add_dev(b[0], b[1])
@@ -107,5 +119,14 @@ def gpu_local_screen(eng, db, p):
             counts = torch.empty(db.rows * db.sketch_size, dtype=torch.int32, device="cuda")
             sc.counts_dev(counts.data_ptr())
             _, mix, _ = sc.finish(want_counts=False, want_distinct=False)
+        finally:
+            if not resident:
+                sc.close()
         return counts, mix
+
+    def close():
+        if state["sc"] is not None:
+            state["sc"].close()
+            state["sc"] = None
+    run.close = close
     return run

@@ -140,7 +140,8 @@ def run(n_cases, seed, seconds, dump="", against="gpu", quiet=False):
             else:
                 recs = [r for sk in sketches for r in sk]
                 if mode == "cov":
-                    extra = dict(target_cov=float(rng.choice([1.05, 1.5, 3.0, 100.0])), min_copies=int(rng.choice([1, 1, 2])))
+                    # (target_cov 0: plain -r / -m -- the one-shot call keeps the read set in HBM, the session does not)
+                    extra = dict(target_cov=float(rng.choice([0.0, 0.0, 1.05, 1.5, 3.0, 100.0])), min_copies=int(rng.choice([1, 1, 2, 3])))
                 else:
                     extra = dict(bloom_bytes=int(rng.choice([1, 9, 300, 5000, 1 << 20])), target_cov=float(rng.choice([0.0, 0.0, 2.0])))
                 if not recs:

@@ -584,6 +584,14 @@ def test_many_short_records_are_sketched_in_bounded_batches(built, tmp_path):
     used = [l for l in a.stderr.splitlines() if l.startswith("Reads used:")]
     assert used and used == [l for l in b.stderr.splitlines() if l.startswith("Reads used:")]
     assert int(used[0].split()[-1]) < 400                                    # stopped before the end of the input
+    # plain -r / -m in constant memory (the default since round 3: a reads session, chunk by chunk) against the
+    # route that keeps the whole read set in HBM for one sketch call: same .msh whatever the chunk size -- incl.
+    # the multiplicities (-M is implied by -r) and with them the order-dependent count of the largest kept hash
+    for extra in (("-r",), ("-r", "-m", "2"), ("-r", "-m", "3", "-k", "15")):
+        run("sketch", *extra, "-s", "200", "-o", str(tmp_path / "m1"), str(reads))
+        run("sketch", *extra, "-s", "200", "-o", str(tmp_path / "m2"), str(reads), env={"MASH_AMD_READS_CHUNK": "3000"})
+        run("sketch", *extra, "-s", "200", "-o", str(tmp_path / "m3"), str(reads), env={"MASH_AMD_READS_RESIDENT": "1"})
+        assert (tmp_path / "m1.msh").read_bytes() == (tmp_path / "m2.msh").read_bytes() == (tmp_path / "m3.msh").read_bytes(), extra
 
 
 @pytest.mark.gpu

@@ -221,6 +221,15 @@ def test_sketch_target_coverage_early_stop(eng, oracle, k, s, m):
     h0, c0, u0 = eng.sketch_reads(reads, eng.params(k=k, s=s, min_copies=m))       # target_cov 0: plain reads mode
     ph, pn, pc = eng.sketch_host([reads], eng.params(k=k, s=s, min_copies=m), counts=True)
     assert u0 == long_enough and np.array_equal(h0, ph[0, : pn[0]]) and np.array_equal(c0, pc[0, : pn[0]])
+    # plain reads mode in CONSTANT memory (Sketch.cpp:1196-1270): the read set cut into 7 chunks
+    # (and into many) through a reads session gives the one-shot call's hashes AND counts -- incl. the
+    # order-dependent multiplicity of the largest kept hash under -m (MinHashHeap.cpp:96-144) -- and the oracle's
+    oh, oc, _, _, _ = oracle.sketch_reads(reads, oracle.params(k=k, s=s, min_copies=m))
+    assert np.array_equal(h0, oh) and np.array_equal(c0, oc)
+    for per in ((len(reads) + 6) // 7, 211):
+        ch, cc, cu, fed = eng.sketch_reads_chunked(reads, eng.params(k=k, s=s, min_copies=m), per)
+        assert fed == (len(reads) + per - 1) // per and cu == long_enough, (k, s, m, per)
+        assert np.array_equal(ch, h0) and np.array_equal(cc, c0), (k, s, m, per)
 
 
 def test_sketch_fuzz_regressions(eng, oracle):
@@ -1496,6 +1505,96 @@ def test_screen_counts_vs_oracle(eng, oracle):
     db.free()
 
 
+def _hits_equal_counts(hits, counts, table, nhash):
+    """hits == the non-zero cells of the dense counts matrix, hash values included, ordered by row then hash"""
+    r, c = np.nonzero(counts)
+    assert len(hits) == len(r)
+    want = np.zeros(len(r), dtype=abi.HIT_DTYPE)
+    want["row"], want["count"], want["hash"] = r, counts[r, c], table[r, c]
+    want = want[np.lexsort((want["hash"], want["row"]))]
+    assert np.array_equal(hits, want)
+
+
+@pytest.mark.parametrize("bits", [None, "12"])
+def test_screen_resident_database_sparse_hits_two_tiers(eng, oracle, bits, monkeypatch):
+    """A database that stays resident (the reference rebuilds hashTable for every run,
+    CommandScreen.cpp:93-116): mixture after mixture against ONE mg_screen with mg_screen_reset between
+    them gives what a fresh screen gives; mg_screen_finish_sparse_host returns exactly the non-zero cells
+    of the dense matrix (rows that share a hash -- copies of a genome -- each get their hit).  The database
+    mixes 2 kbp and 200 kbp genomes, so the key bound takes two tiers (a bitmap in front of the table for
+    the hashes only small genomes reach; with 2^12 bits it is crowded and mostly says yes): same counts as
+    with MASHGPU_SCREEN_TIERS=0, and as the oracle's direct count."""
+    if bits:
+        monkeypatch.setenv("MASHGPU_SCREEN_BITS", bits)
+    rng = np.random.default_rng(31)
+    small = [synth._rand_dna(rng, 2000) for _ in range(12)]
+    large = [synth._rand_dna(rng, 200000) for _ in range(5)]
+    genomes = large[:3] + small + large[3:] + [small[4], large[1]]           # two copies: rows that share every hash
+    p = eng.params(k=21, s=200)
+    hashes, nhash = eng.sketch_host([[g] for g in genomes], p)
+    db = eng.table_upload(hashes, nhash, np.array([len(g) for g in genomes], dtype=np.uint64))
+
+    def mixture(seed, sources):
+        r = np.random.default_rng(seed)
+        out = []
+        for _ in range(4000):
+            g = genomes[int(r.choice(sources))]
+            st = int(r.integers(0, len(g) - 120))
+            x = g[st:st + 120]
+            out.append(x if r.random() < 0.5 else _revcomp(x))
+        return [out[:1500], out[1500:]]
+
+    mix_a, mix_b = mixture(1, [0, 3, 7, 5, 16]), mixture(2, [1, 7, 9, 18])
+    want = {}
+    for name, m in (("a", mix_a), ("b", mix_b)):
+        cnt = {}
+        for r in (x for part in m for x in part):
+            h, c, _, _, _ = oracle.sketch_records([r], oracle.params(k=21, s=100000))
+            for hv, cv in zip(h, c):
+                cnt[int(hv)] = cnt.get(int(hv), 0) + int(cv)
+        want[name] = np.array([[cnt.get(int(x), 0) if j < nhash[i] else 0 for j, x in enumerate(hashes[i])] for i in range(len(genomes))], dtype=np.uint32)
+    with eng.screen_open(db, p) as sc:
+        assert "two tiers" in sc.tier_note(), sc.tier_note()
+        for part in mix_a:
+            sc.add_records(part)
+        counts_a, sk_a, distinct = sc.finish()
+        hits_a, sk_a2, distinct2 = sc.finish_sparse()
+        assert np.array_equal(counts_a, want["a"]) and distinct == distinct2 == len(np.unique(hashes[hashes != np.uint64(abi.HASH_PAD)]))
+        assert np.array_equal(sk_a, sk_a2)
+        _hits_equal_counts(hits_a, counts_a, hashes, nhash)
+        assert np.array_equal(counts_a[7], counts_a[17]) and counts_a[7].sum() > 0      # the copy gets the same hits
+        sc.reset()
+        for part in mix_b:
+            sc.add_records(part)
+        counts_b, sk_b, _ = sc.finish()
+        hits_b, _, _ = sc.finish_sparse()
+        assert np.array_equal(counts_b, want["b"])
+        _hits_equal_counts(hits_b, counts_b, hashes, nhash)
+        sc.reset()
+        none, sk0, _ = sc.finish_sparse()                                      # nothing screened: no hit, empty mixture sketch
+        assert len(none) == 0 and len(sk0) == 0
+    fresh_b, fresh_sk, _ = eng.screen(db, p, mix_b)
+    assert np.array_equal(fresh_b, counts_b) and np.array_equal(fresh_sk, sk_b)
+    monkeypatch.setenv("MASHGPU_SCREEN_TIERS", "0")
+    with eng.screen_open(db, p) as sc:
+        assert "off" in sc.tier_note()
+        for part in mix_a:
+            sc.add_records(part)
+        one_tier, _, _ = sc.finish()
+    assert np.array_equal(one_tier, counts_a)
+    monkeypatch.delenv("MASHGPU_SCREEN_TIERS")
+    # the same over three contexts: hits of every device merged on the host, and a second mixture after a reset
+    comm = abi.LocalComm([0, 0, 0])
+    d = comm.upload(hashes, nhash, np.array([len(g) for g in genomes], dtype=np.uint64))
+    sh, ssk, sd = comm.screen(d, len(genomes), 200, p, mix_a, sparse=True)
+    assert np.array_equal(sh, hits_a) and np.array_equal(ssk, sk_a) and sd == distinct
+    sh2, _, _ = comm.screen(d, len(genomes), 200, p, mix_a, sparse=True, again=mix_b)
+    assert np.array_equal(sh2, hits_b)
+    comm.free(d)
+    comm.close()
+    db.free()
+
+
 def test_screen_config4_scale_vs_oracle(eng, oracle):
     """BASELINE config 4 at its DATABASE scale: 100 000 sketches (10^8 keys in the open-addressing
     table: probe chains, load factor, u32 counters at the size bench.py runs) against 10^6 reads
@@ -1564,6 +1663,12 @@ def test_screen_config4_scale_vs_oracle(eng, oracle):
     d = comm.upload(th, tn, tl)
     got = comm.screen(d, NDB, S, p, blobs)
     assert np.array_equal(got[0], counts) and np.array_equal(got[1], mix) and got[2] == distinct
+    # ---- and in the sparse form (what the CLI reads): the non-zero cells, nothing else; a second mixture after a reset
+    hits, hmix, hdist = comm.screen(d, NDB, S, p, blobs, sparse=True)
+    _hits_equal_counts(hits, counts, th, tn)
+    assert np.array_equal(hmix, mix) and hdist == distinct and len(hits) < 0.02 * NDB * S
+    hits2, _, _ = comm.screen(d, NDB, S, p, blobs[:1], sparse=True, again=blobs)
+    assert np.array_equal(hits2, hits)
     comm.free(d)
     comm.close()
     db.free()
