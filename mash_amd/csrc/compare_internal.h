@@ -134,7 +134,8 @@ hipError_t launch_sparse_scatter(const SparseArgs &a, uint64_t expect, uint32_t 
 size_t sparse_gather_temp_bytes(uint32_t nrows);
 hipError_t launch_sparse_gather_rows(const SparseArgs &a, uint32_t *cnt_by_row, uint32_t *row_base, void *temp, size_t temp_bytes, uint32_t row_add,
                                      uint2 *rc_out, uint2 *counts_out, hipStream_t stream);
-hipError_t launch_sparse_fill(uint2 *out, uint64_t pairs, uint32_t denom, uint32_t blocks_per_cu, uint32_t cus, hipStream_t stream);
+// every slot = {numer, denom}: {0, s} for the pairs that share nothing; {c, c} when the whole table is c-hash copies of one sketch
+hipError_t launch_sparse_fill(uint2 *out, uint64_t pairs, uint32_t numer, uint32_t denom, uint32_t blocks_per_cu, uint32_t cus, hipStream_t stream);
 hipError_t launch_sparse_fill_short(uint2 *out, const uint32_t *short_rows, const uint32_t *short_rcnt, uint32_t nshort_rows,
                                     const uint32_t *short_cols, const uint32_t *short_ccnt, uint32_t nshort_cols,
                                     uint32_t row_begin, uint32_t ncols, uint32_t triangle, uint64_t out_base, uint32_t s,

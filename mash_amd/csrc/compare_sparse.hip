@@ -867,13 +867,13 @@ hipError_t launch_sparse_class_pairs(uint2 *out, const uint32_t *cls_rows, const
 
 typedef uint32_t sp_u32x4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void sp_fill_const_kernel(uint2 *out, uint64_t pairs, uint32_t denom)
+__global__ __launch_bounds__(256) void sp_fill_const_kernel(uint2 *out, uint64_t pairs, uint32_t numer, uint32_t denom)
 {
     // 16-byte stores over the aligned body, 8-byte stores for an unaligned first / odd last pair
     const uint64_t head = ((reinterpret_cast<uintptr_t>(out) & 8u) != 0 && pairs > 0) ? 1u : 0u;
     const uint64_t nvec = (pairs - head) >> 1;
     sp_u32x4 *body = reinterpret_cast<sp_u32x4 *>(out + head);
-    const sp_u32x4 v = {0u, denom, 0u, denom};
+    const sp_u32x4 v = {numer, denom, numer, denom};
     const uint64_t stride = (uint64_t)gridDim.x * 256u;
     uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     for (; i + 3 * stride < nvec; i += 4 * stride) {
@@ -884,8 +884,8 @@ __global__ __launch_bounds__(256) void sp_fill_const_kernel(uint2 *out, uint64_t
     }
     for (; i < nvec; i += stride) __builtin_nontemporal_store(v, body + i);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (head) out[0] = make_uint2(0u, denom);
-        if (((pairs - head) & 1u) != 0) out[pairs - 1] = make_uint2(0u, denom);
+        if (head) out[0] = make_uint2(numer, denom);
+        if (((pairs - head) & 1u) != 0) out[pairs - 1] = make_uint2(numer, denom);
     }
 }
 
@@ -1011,12 +1011,12 @@ hipError_t launch_sparse_scatter(const SparseArgs &a, uint64_t expect, uint32_t 
 }
 
 // every wave writes 4 KB of consecutive addresses per round (four stores 1 KB apart): the default
-__global__ __launch_bounds__(256) void sp_fill_const_wave_kernel(uint2 *out, uint64_t pairs, uint32_t denom)
+__global__ __launch_bounds__(256) void sp_fill_const_wave_kernel(uint2 *out, uint64_t pairs, uint32_t numer, uint32_t denom)
 {
     const uint64_t head = ((reinterpret_cast<uintptr_t>(out) & 8u) != 0 && pairs > 0) ? 1u : 0u;
     const uint64_t nvec = (pairs - head) >> 1;
     sp_u32x4 *body = reinterpret_cast<sp_u32x4 *>(out + head);
-    const sp_u32x4 v = {0u, denom, 0u, denom};
+    const sp_u32x4 v = {numer, denom, numer, denom};
     const uint64_t lane = threadIdx.x & 63u;
     const uint64_t gw = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6), tw = (uint64_t)gridDim.x * 4u;
     for (uint64_t base = gw * 256u; base < nvec; base += tw * 256u) {
@@ -1027,12 +1027,12 @@ __global__ __launch_bounds__(256) void sp_fill_const_wave_kernel(uint2 *out, uin
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (head) out[0] = make_uint2(0u, denom);
-        if (((pairs - head) & 1u) != 0) out[pairs - 1] = make_uint2(0u, denom);
+        if (head) out[0] = make_uint2(numer, denom);
+        if (((pairs - head) & 1u) != 0) out[pairs - 1] = make_uint2(numer, denom);
     }
 }
 
-hipError_t launch_sparse_fill(uint2 *out, uint64_t pairs, uint32_t denom, uint32_t blocks_per_cu, uint32_t cus, hipStream_t stream)
+hipError_t launch_sparse_fill(uint2 *out, uint64_t pairs, uint32_t numer, uint32_t denom, uint32_t blocks_per_cu, uint32_t cus, hipStream_t stream)
 {
     if (pairs == 0) return hipSuccess;
     uint64_t blocks = (pairs / 2 + 1023) / 1024;                 // >= 4 stores per thread
@@ -1042,8 +1042,8 @@ hipError_t launch_sparse_fill(uint2 *out, uint64_t pairs, uint32_t denom, uint32
     // default: every wave writes 4 KB of consecutive addresses per round (6.7 ms for the 40 GB of C3 against
     // 7.1 ms with four streams a grid apart, MASHGPU_SPARSE_FILL_MODE=0; profiles/r03_sparse_tuning.json)
     const int mode = getenv("MASHGPU_SPARSE_FILL_MODE") ? atoi(getenv("MASHGPU_SPARSE_FILL_MODE")) : 1;
-    if (mode == 1) hipLaunchKernelGGL(sp_fill_const_wave_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, out, pairs, denom);
-    else hipLaunchKernelGGL(sp_fill_const_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, out, pairs, denom);
+    if (mode == 1) hipLaunchKernelGGL(sp_fill_const_wave_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, out, pairs, numer, denom);
+    else hipLaunchKernelGGL(sp_fill_const_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, out, pairs, numer, denom);
     return hipGetLastError();
 }
 

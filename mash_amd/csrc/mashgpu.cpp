@@ -102,6 +102,7 @@ struct mg_table {
         uint32_t cls_members = 0;          // rows in classes of two and more
         uint64_t cls_pairs = 0;            // pairs inside those classes (full triangle)
         uint64_t copies = 0;               // rows that are a copy of an earlier row
+        uint32_t one_class = 0;            // != 0: EVERY row is a copy of row 0, which has this many hashes (every pair is {c, c})
         bool has_empty = false;            // some row has no hash at all
         uint32_t *short_rows = nullptr, *short_cnt = nullptr;    // rows with fewer than s hashes (ascending) and their counts
         std::vector<uint32_t> short_rows_host;
@@ -249,8 +250,8 @@ int mg_ctx_create(int device, mg_ctx **out)
     e = hipStreamCreateWithFlags(&c->stream, hipStreamDefault);
     if (e != hipSuccess) { delete c; return fail(nullptr, MG_ERR_HIP, "hipStreamCreate failed"); }
     c->own_stream = true;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->cu_count = prop.multiProcessorCount;
+    int cus = 0;                        // (one attribute, not hipGetDeviceProperties: that call fills a page of fields)
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess) c->cu_count = cus;
     *out = c;
     return MG_OK;
 }
@@ -1993,6 +1994,7 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, mg_tab
             for (uint32_t u = cls_off[k]; u < cls_off[k + 1]; u++) cls_first[u] = cls_off[k];
         }
         sp->cls_members = tot;
+        if (ncls == 1 && tot == n && cnt_true[0] > 0) sp->one_class = (uint32_t)cnt_true[0];
     }
     uint64_t E64 = 0, maxv = 0;
     sp->off_host.resize(n + 1);
@@ -2342,12 +2344,15 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
     }
     if (!job) {
         prof_begin(ctx, ctx->prof_fill, fs);
-        hipError_t e = mg::launch_sparse_fill(a.out, pairs, s, fill_bpc, (uint32_t)ctx->cu_count, fs);
+        // (a table of n copies of one sketch: the fill IS the answer, {c, c} in every slot, written once)
+        const bool all_copies = triangle && ix->one_class != 0;
+        hipError_t e = all_copies ? mg::launch_sparse_fill(a.out, pairs, ix->one_class, ix->one_class, fill_bpc, (uint32_t)ctx->cu_count, fs)
+                                  : mg::launch_sparse_fill(a.out, pairs, 0, s, fill_bpc, (uint32_t)ctx->cu_count, fs);
         if (e == hipSuccess && nshort_rows && !ix->short_rows_host.empty())
             e = mg::launch_sparse_fill_short(a.out, short_rows_dev, short_rcnt_dev, nshort_rows, ix->short_rows, ix->short_cnt,
                                              (uint32_t)ix->short_rows_host.size(), a.row_begin, a.ncols, a.triangle, a.out_base, s, fs);
         // pairs of two copies of one sketch: {n, n} (after the fill, on its stream)
-        if (e == hipSuccess && triangle && ix->cls_members)
+        if (e == hipSuccess && triangle && ix->cls_members && !all_copies)
             e = mg::launch_sparse_class_pairs(a.out, ix->cls_rows, ix->cls_first, ix->off, ix->rep, ix->cls_members, a.row_begin, a.row_end,
                                               a.out_base, fs);
         prof_end(ctx, ctx->prof_fill, fs);
@@ -3859,6 +3864,12 @@ static int screen_plan_tiers(mg_ctx *ctx, mg_screen *sc)
 {
     sc->tier = sc->key_max;
     if (sc->distinct == 0 || sc->key_max < (1ull << 40)) return MG_OK;
+    // (a bound that already spares all but a few k-mers in a thousand needs no second tier: C4's database of
+    //  like-sized genomes sends 0.1 % of the mixture's k-mers to the table)
+    if ((double)sc->key_max / 18446744073709551616.0 < 0.004 && !getenv("MASHGPU_SCREEN_TIERS")) {
+        sc->tier_note = "one tier (the largest key already spares all but a few k-mers in a thousand)";
+        return MG_OK;
+    }
     if (const char *e = getenv("MASHGPU_SCREEN_TIERS")) { if (atoi(e) == 0) { sc->tier_note = "off (MASHGPU_SCREEN_TIERS=0)"; return MG_OK; } }
     uint32_t log_bits = 27;
     if (const char *e = getenv("MASHGPU_SCREEN_BITS")) log_bits = (uint32_t)std::min(34, std::max(10, atoi(e)));

@@ -143,15 +143,21 @@ __global__ void screen_bits_kernel(const unsigned long long *keys, uint64_t slot
 __global__ void screen_count_below_kernel(const unsigned long long *keys, uint64_t slots, const uint64_t *bounds, uint32_t nb,
                                           unsigned long long *below)
 {
+    // nb <= 32 bounds, descending (bounds[q] = largest key >> (q + 1)): a key's count goes to every bound at or above
+    // it; each lane keeps one bound's tally (lane q for bound q) and adds it once at the end
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    unsigned long long mine = 0;
     for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x; i0 < slots; i0 += stride) {
         const uint64_t i = i0 + threadIdx.x;
         const unsigned long long k = i < slots ? keys[i] : SCR_EMPTY;
         for (uint32_t q = 0; q < nb; q++) {
             const uint32_t c = (uint32_t)__popcll(__ballot(k != SCR_EMPTY && k <= bounds[q]));
-            if ((threadIdx.x & 63) == 0 && c) atomicAdd(&below[q], (unsigned long long)c);
+            if (lane == q) mine += c;
+            if (c == 0) break;                             // (bounds descend: nothing below this one, nothing below the next)
         }
     }
+    if (lane < nb && mine) atomicAdd(&below[lane], mine);
 }
 
 __global__ void screen_gather_kernel(const uint64_t *hashes, const uint32_t *nhash, uint64_t n, uint64_t s,

@@ -92,16 +92,36 @@ elif args.leg == "screen":
     per = (args.n_reads + nb - 1) // nb
     batches = [synth_torch.synthetic_reads(genomes, min(per, args.n_reads - b * per), RL, seed=7000 + b) for b in range(nb)]
     handles = [(b.data_ptr(), int(b.numel()), b) for b in batches]
-    local = screen_dist.gpu_local_screen(eng, db, p)
+    t_create = time.perf_counter()
+    sc = eng.screen_open(db, p)
     torch.cuda.synchronize()
-    local(handles)
-    torch.cuda.synchronize()
+    res["create_ms"] = (time.perf_counter() - t_create) * 1e3
+    res["key_bound"] = sc.tier_note()
+    phase = {"reset": 0.0, "add": 0.0, "finish_sparse": 0.0}
+
+    def step(timed):
+        t = time.perf_counter()
+        sc.reset()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for h in handles:
+            sc.add_dev(h[0], h[1])
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        hits, mix, _ = sc.finish_sparse()
+        t3 = time.perf_counter()
+        if timed:
+            phase["reset"] += t1 - t; phase["add"] += t2 - t1; phase["finish_sparse"] += t3 - t2
+        return hits
+
+    step(False)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        counts, mix = local(handles)
-    torch.cuda.synchronize()
+        hits = step(True)
     dt = (time.perf_counter() - t0) / args.steps
-    res.update({"reads": args.n_reads, "ms_per_step": dt * 1e3, "reads_per_s": args.n_reads / dt})
+    res.update({"reads": args.n_reads, "ms_per_step": dt * 1e3, "reads_per_s": args.n_reads / dt, "hits": int(len(hits)),
+                "phase_ms": {k: v * 1e3 / args.steps for k, v in phase.items()}})
+    sc.close()
 else:
     raise SystemExit("unknown leg")
 print(json.dumps(res))
