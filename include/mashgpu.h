@@ -191,6 +191,9 @@ int  mg_reads_begin(mg_ctx *ctx, const mg_params *p, mg_reads_session **out);
 int  mg_reads_add_host(mg_reads_session *rs, const uint8_t *bases, uint64_t nbases, int *stopped_out);
 int  mg_reads_finish(mg_reads_session *rs, uint64_t *hashes_out, uint32_t *nhash_out, uint32_t *counts_out,
                      uint64_t *records_used_out);
+/* an empty heap again (same parameters): the next read set through the same session -- its device buffers
+ * (128 MiB of event space) are allocated once, not per input file (`mash dist -r ref.msh a.fq b.fq ...`) */
+int  mg_reads_reset(mg_reads_session *rs);
 void mg_reads_free(mg_reads_session *rs);
 
 /* ---- sketch tables ----------------------------------------------------------

@@ -24,7 +24,7 @@ EXPORTS = [
     "mg_device_count", "mg_ctx_create", "mg_ctx_destroy", "mg_last_error", "mg_ctx_set_stream", "mg_ctx_synchronize", "mg_ctx_set_async",
     "mg_ctx_cu_count", "mg_params_init", "mg_sketch_host", "mg_sketch_dev", "mg_sketch_reads_host", "mg_sketch_begin", "mg_sketch_add",
     "mg_sketch_stage_capacity", "mg_sketch_stage", "mg_sketch_commit", "mg_sketch_end_sketch", "mg_sketch_pending", "mg_sketch_finish", "mg_sketch_session_free",
-    "mg_reads_begin", "mg_reads_add_host", "mg_reads_finish", "mg_reads_free", "mg_table_upload",
+    "mg_reads_begin", "mg_reads_add_host", "mg_reads_finish", "mg_reads_reset", "mg_reads_free", "mg_table_upload",
     "mg_table_wrap_dev", "mg_table_free", "mg_table_rows", "mg_table_sketch_size",
     "mg_compare_tri_dev", "mg_compare_tri_host", "mg_compare_rect_dev", "mg_compare_rect_host",
     "mg_compare_tri_filter_host", "mg_compare_rect_filter_host",
@@ -200,6 +200,7 @@ def load_library():
     lib.mg_reads_begin.argtypes = [vp, C.POINTER(MgParams), C.POINTER(vp)]
     lib.mg_reads_add_host.argtypes = [vp, vp, u64, C.POINTER(C.c_int)]
     lib.mg_reads_finish.argtypes = [vp, vp, vp, vp, vp]
+    lib.mg_reads_reset.argtypes = [vp]
     lib.mg_reads_free.argtypes = [vp]
     lib.mg_reads_free.restype = None
     lib.mg_table_upload.argtypes = [vp, vp, vp, vp, u64, u64, C.POINTER(vp)]
@@ -625,12 +626,17 @@ class MashGpu:
                                                   C.byref(n), counts.ctypes.data, C.byref(used)))
         return hashes[: n.value].copy(), counts[: n.value].copy(), int(used.value)
 
-    def sketch_reads_chunked(self, records, p, per_chunk):
+    def sketch_reads_chunked(self, records, p, per_chunk, first=None):
         """sketch_reads through a session, `per_chunk` records at a time; stops feeding at the stop:
-        (hashes, counts, records_used, chunks_fed)"""
+        (hashes, counts, records_used, chunks_fed).  first: another read set pushed through the session
+        before (and discarded by mg_reads_reset) -- the result must not depend on it"""
         h = C.c_void_p()
         self._check(self.lib.mg_reads_begin(self.ctx, C.byref(p), C.byref(h)))
         try:
+            if first is not None:
+                blob = np.frombuffer(join_records(first) + bytes([RECORD_SEP]), dtype=np.uint8)
+                self._check(self.lib.mg_reads_add_host(h, blob.ctypes.data, len(blob), None))
+                self._check(self.lib.mg_reads_reset(h))
             fed = 0
             stopped = C.c_int(0)
             for o in range(0, len(records), per_chunk):

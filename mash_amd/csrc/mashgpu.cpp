@@ -1338,6 +1338,21 @@ int mg_reads_finish(mg_reads_session *rs, uint64_t *hashes_out, uint32_t *nhash_
     return MG_OK;
 }
 
+int mg_reads_reset(mg_reads_session *rs)
+{
+    if (!rs) return MG_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(rs->ctx->mu);
+    ReadsBloom bloom;
+    std::swap(bloom, rs->heap.bloom);                       // keep the filter's memory, clear its bits
+    std::fill(bloom.bits.begin(), bloom.bits.end(), 0);
+    rs->heap = ReadsHeap(rs->p.sketch_size, rs->p.min_copies);
+    std::swap(bloom, rs->heap.bloom);
+    rs->stopped = false;
+    rs->used = rs->records = 0;
+    rs->shrink = 1.0;
+    return MG_OK;
+}
+
 void mg_reads_free(mg_reads_session *rs)
 {
     if (!rs) return;

@@ -561,7 +561,8 @@ void queue_file_by_sequence(Gpu &gpu, SketchSet &set, PendingBatch &b, const str
 // Sketch::initFromReads -> sketchFile over all files, round robin (Sketch.cpp:96-103, :1147-1336)
 // `shared`: a streamed-ingest session kept by the caller across calls (one reads-mode query file after the
 // other in `mash dist -r`): its pinned staging buffers are allocated once, not per file
-void sketch_reads(Gpu &gpu, SketchSet &set, const vector<string> &files, mg_sketch_session **shared = nullptr)
+void sketch_reads(Gpu &gpu, SketchSet &set, const vector<string> &files, mg_sketch_session **shared = nullptr,
+                  mg_reads_session **shared_reads = nullptr)
 {
     vector<fastx::Reader *> readers;
     Ref ref;
@@ -609,7 +610,9 @@ void sketch_reads(Gpu &gpu, SketchSet &set, const vector<string> &files, mg_sket
         mp.min_copies = set.p.min_copies;
         mp.target_cov = set.p.target_cov;
         mp.bloom_bytes = set.p.bloom_bytes;
-        if (mg_reads_begin(gpu.ctx, &mp, &rs) != MG_OK) { cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl; exit(1); }
+        // (one session for all reads-mode files of a run: its device buffers are allocated once)
+        if (shared_reads && *shared_reads) rs = *shared_reads;
+        else if (mg_reads_begin(gpu.ctx, &mp, &rs) != MG_OK) { cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl; exit(1); }
         b.bases.reserve(std::min<size_t>(reads_chunk, 64u << 20) + (1u << 16));
     }
     fastx::Record rec;
@@ -667,7 +670,8 @@ void sketch_reads(Gpu &gpu, SketchSet &set, const vector<string> &files, mg_sket
             cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl;
             exit(1);
         }
-        mg_reads_free(rs);
+        if (shared_reads) { mg_reads_reset(rs); *shared_reads = rs; }
+        else mg_reads_free(rs);
         ref.hashes.assign(hashes.begin(), hashes.begin() + nh);
         ref.counts.assign(counts.begin(), counts.begin() + nh);
         wrap_comment(reads_used);                              // the reference counts the reads it consumed
@@ -956,6 +960,7 @@ void init_from_files(Gpu &gpu, SketchSet &set, const vector<string> &files, cons
     set.p = p;
     PendingBatch b;
     mg_sketch_session *reads_sess = nullptr;               // shared by the reads-mode query files
+    mg_reads_session *reads_rs = nullptr;
     // (env: the concatenate-then-copy path, for tests; several GPUs: whole batches, cut over the devices)
     b.stream = !getenv("MASH_AMD_NO_STREAM") && mg_comm_size(gpu.comm) <= 1;
     // concatenated mode with -p > 1: files are parsed ahead by a pool of workers (ParsePool)
@@ -1028,7 +1033,7 @@ void init_from_files(Gpu &gpu, SketchSet &set, const vector<string> &files, cons
         if (pool) pool->skip(i);
         if (reads_files) {
             flush_batch(gpu, set, b);                      // keep input order
-            sketch_reads(gpu, set, {files[i]}, &reads_sess);
+            sketch_reads(gpu, set, {files[i]}, &reads_sess, &reads_rs);
         } else if (set.p.concatenated) {
             queue_parsed_file(gpu, set, b, parse_file_concatenated(files[i], set.p.kmer));
         } else {
@@ -1039,6 +1044,7 @@ void init_from_files(Gpu &gpu, SketchSet &set, const vector<string> &files, cons
     flush_batch(gpu, set, b);
     if (b.sess) mg_sketch_session_free(b.sess);
     if (reads_sess) mg_sketch_session_free(reads_sess);
+    if (reads_rs) mg_reads_free(reads_rs);
 }
 
 string write_set(SketchSet &set, const string &path, bool consume = false)
