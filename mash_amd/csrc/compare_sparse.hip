@@ -651,6 +651,155 @@ __global__ __launch_bounds__(SPM_NT) void sp_merge_rows_kernel(SparseArgs a)
     }
 }
 
+// The same merge with SEVERAL rows per work item.  A collection's rows have tens of candidates each (C3: 0 ... 99,
+// 50 on average), so an item of one row fills half its lanes.  Here the candidates of all rows form one line of
+// UNITS in visiting order -- a row with candidates takes max(candidates, SPM_PACK_MIN) units, so that at most
+// SPM_PACK_ROWS rows meet in the 128 units of an item -- and item t takes units [128 t, 128 t + 128): every lane
+// finds its row among the item's (at most one row boundary lies between two units 32 apart, so the rows of the
+// units 0, 32, 64, 96 and 127 are all there are), all of them are staged in LDS, and the loop is the one above
+// with a per-lane row base.  Lanes on a row's padding units idle (C3: 9 % against 43 %).
+constexpr uint32_t SPM_PACK_MIN = 32;
+constexpr uint32_t SPM_PACK_ROWS = 5;
+
+__global__ __launch_bounds__(256) void sp_pack_costs_kernel(const uint32_t *seg_cnt, uint32_t nrows, uint32_t *chunks)
+{
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r < nrows) {
+        const uint32_t c = seg_cnt[r];
+        chunks[r] = c ? (c < SPM_PACK_MIN ? SPM_PACK_MIN : c) : 0u;
+    }
+}
+
+template <bool RECT>
+__global__ __launch_bounds__(SPM_NT) void sp_merge_pack_kernel(SparseArgs a)
+{
+    extern __shared__ __align__(16) uint32_t lds[];
+    __shared__ uint32_t pslot[SPM_PACK_ROWS];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t nrows = a.row_end - a.row_begin;
+    const uint32_t total = a.chunk_inc[nrows - 1];         // units in all (inclusive scan of the rows' costs)
+    const uint32_t u0 = blockIdx.x * SPM_NT;
+    if (u0 >= total) return;
+    if (tid < SPM_PACK_ROWS) {                             // the rows of units 0, 32, 64, 96, 127 of this item
+        uint32_t u = u0 + (tid == SPM_PACK_ROWS - 1u ? SPM_NT - 1u : tid * SPM_PACK_MIN);
+        if (u >= total) u = total - 1u;
+        uint32_t lo = 0, hi = nrows - 1;                   // first slot whose inclusive cost exceeds u
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (a.chunk_inc[mid] > u) hi = mid; else lo = mid + 1;
+        }
+        pslot[tid] = lo;
+    }
+    __syncthreads();
+    const uint32_t s = a.s;
+    // stage the item's rows (copies are compared through their representatives)
+    {
+        uint32_t nd = 0;
+        for (uint32_t j = 0; j < SPM_PACK_ROWS; j++) {
+            if (j && pslot[j] == pslot[j - 1]) continue;
+            const uint32_t sl = pslot[j];
+            const uint32_t row = a.order ? a.order[sl] : a.row_end - 1u - sl;
+            const uint32_t ar = (a.rep && !RECT) ? a.rep[row] : row;
+            const uint32_t n = a.off[ar + 1] - a.off[ar];
+            const uint4 *src = reinterpret_cast<const uint4 *>(a.row_img + (uint64_t)ar * a.rs_row);
+            uint4 *dst = reinterpret_cast<uint4 *>(lds + nd * a.rs_row);
+            const uint32_t nvec = (n >> 2) + 1u;           // (and one chunk of the padding: A[nA] is read by a lane that has just finished)
+            for (uint32_t v = tid; v < nvec; v += SPM_NT) dst[v] = src[v];
+            nd++;
+        }
+    }
+    // this lane's unit -> row, candidate
+    const uint32_t u = u0 + tid;
+    const uint32_t sA = pslot[tid >> 5], sB = pslot[(tid >> 5) + 1u];
+    uint32_t slot = sA;
+    if (sB != sA && u >= a.chunk_inc[sB - 1u]) slot = sB;  // (sB > sA: the units before sB's first end with the slot before it)
+    const uint32_t q = u - (slot ? a.chunk_inc[slot - 1u] : 0u);
+    const uint32_t cnt = a.seg_cnt[slot];
+    const bool have = u < total && q < cnt;
+    uint32_t ridx = 0;
+#pragma unroll
+    for (uint32_t j = 1; j < SPM_PACK_ROWS; j++) ridx += (pslot[j] != pslot[j - 1] && pslot[j] <= slot) ? 1u : 0u;
+    const uint32_t row = a.order ? a.order[slot] : a.row_end - 1u - slot;
+    const uint32_t arow = (a.rep && !RECT) ? a.rep[row] : row;
+    const uint32_t nA = a.off[arow + 1] - a.off[arow];
+    const uint32_t *A = lds + ridx * a.rs_row;
+    const uint64_t at = a.seg_base[slot] + q;              // this lane's candidate (and result slot)
+    uint32_t *myring = lds + SPM_PACK_ROWS * a.rs_row + (tid >> 6) * (SPM_RING * 64u) + lane;   // code e of this lane: myring[(e & 31) * 64]
+    uint32_t j = have ? a.cand[at].y : 0u;
+    if (a.rep) j = a.rep[j];
+    const bool same = !RECT && a.rep != nullptr && j == arow;
+    const uint32_t nB = have ? a.col_cnt_off[j + 1] - a.col_cnt_off[j] : 0u;
+    const uint4 *B4 = reinterpret_cast<const uint4 *>(a.col_img + (uint64_t)j * a.rs_col);
+    auto land = [&](uint32_t e, const uint4 &v) {         // codes e .. e + 3 (e a multiple of 4)
+        uint32_t *p = myring + (e & (SPM_RING - 1u)) * 64u;
+        p[0] = v.x; p[64] = v.y; p[128] = v.z; p[192] = v.w;
+    };
+    {
+        const uint4 x0 = B4[0], x1 = B4[1], x2 = B4[2], x3 = B4[3];
+        land(0, x0); land(4, x1); land(8, x2); land(12, x3);
+    }
+    uint4 p0 = B4[4], p1 = B4[5];
+    uint32_t loaded = 16;
+    bool pend = true;
+    __syncthreads();                                     // rows staged
+    uint32_t ia = 0, ib = 0, denom = 0;                  // (common = ia + ib - denom)
+    bool active = have && !same && s > 0 && nA > 0 && nB > 0;
+    while (__ballot(active) != 0) {
+        uint32_t room = 0;
+        if (active) {
+            const uint32_t ra = nA - ia, rb = nB - ib, rd = s - denom;
+            room = ra < rb ? ra : rb;
+            room = room < rd ? room : rd;
+        }
+        if (__ballot(active && room < 8u) == 0) {
+            if (active) {
+#pragma unroll
+                for (int t = 0; t < 8; t++) {
+                    const uint32_t av = A[ia];
+                    uint32_t bv = myring[(ib & (SPM_RING - 1u)) * 64u];
+                    if (RECT) bv += 1u;
+                    ia += av <= bv ? 1u : 0u;
+                    ib += bv <= av ? 1u : 0u;
+                }
+                denom += 8;
+                active = denom < s && ia < nA && ib < nB;
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const uint32_t av = A[ia];
+                uint32_t bv = myring[(ib & (SPM_RING - 1u)) * 64u];
+                if (RECT) bv += 1u;
+                const bool adva = active && av <= bv, advb = active && bv <= av;
+                denom += active ? 1u : 0u;
+                ia += adva ? 1u : 0u;
+                ib += advb ? 1u : 0u;
+                active = active && denom < s && ia < nA && ib < nB;
+            }
+        }
+        if (pend) {
+            land(loaded, p0);
+            land(loaded + 4u, p1);
+            loaded += 8;
+        }
+        pend = active && loaded + 8u - ib <= SPM_RING;
+        if (pend) {
+            p0 = B4[loaded >> 2];
+            p1 = B4[(loaded >> 2) + 1u];
+        }
+    }
+    if (have) {
+        uint32_t common = ia + ib - denom;
+        if (same) {
+            common = denom = nA;
+        } else if (denom < s) {                            // :367-385
+            denom += (nA - ia) + (nB - ib);
+            if (denom > s) denom = s;
+        }
+        a.res[at] = make_uint2(common, denom);
+    }
+}
+
 template <bool RECT>
 __global__ __launch_bounds__(SPM_NT) void sp_merge_rows_win_kernel(SparseArgs a)
 {
@@ -980,22 +1129,29 @@ hipError_t launch_sparse_merge_rows(const SparseArgs &a, uint64_t expect, uint32
 {
     const uint32_t nrows = a.row_end - a.row_begin;
     if (expect == 0 || nrows == 0) return hipSuccess;
-    hipLaunchKernelGGL(sp_chunks_kernel, dim3((nrows + 255u) / 256u), dim3(256), 0, stream, a.seg_cnt, nrows, chunks);
+    // rows that fit the LDS window whole take the kernels without window logic; of those, jobs whose rows have few
+    // candidates each (fewer than 96 on average) pack several rows into an item (MASHGPU_SPARSE_MERGE_PACK=0|1 forces)
+    const bool whole = a.rs_row <= SPM_AWIN + 8u && !getenv("MASHGPU_SPARSE_MERGE_WINDOWS");
+    const size_t pack_smem = ((size_t)SPM_PACK_ROWS * a.rs_row + (SPM_NT / 64u) * SPM_RING * 64u) * 4;
+    bool pack = whole && pack_smem <= 64 * 1024 && expect < 96ull * nrows;
+    if (const char *ev = getenv("MASHGPU_SPARSE_MERGE_PACK")) pack = whole && pack_smem <= 160 * 1024 - 256 && atoi(ev) != 0;
+    if (pack) hipLaunchKernelGGL(sp_pack_costs_kernel, dim3((nrows + 255u) / 256u), dim3(256), 0, stream, a.seg_cnt, nrows, chunks);
+    else hipLaunchKernelGGL(sp_chunks_kernel, dim3((nrows + 255u) / 256u), dim3(256), 0, stream, a.seg_cnt, nrows, chunks);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     e = rocprim::inclusive_scan(temp, temp_bytes, (const uint32_t *)chunks, a.chunk_inc, (size_t)nrows, rocprim::plus<uint32_t>(), stream);
     if (e != hipSuccess) return e;
-    const uint64_t items = expect / SPM_NT + nrows;              // upper bound: one partial item per row
-    if (items >= (1ull << 31)) return hipErrorInvalidValue;
-    const size_t smem = sparse_merge_rows_lds(a.rs_row);
+    // upper bounds: one partial item per row / every row with candidates padded to SPM_PACK_MIN units
+    const uint64_t items = pack ? (expect + (uint64_t)SPM_PACK_MIN * nrows) / SPM_NT + 1 : expect / SPM_NT + nrows;
+    if (items >= (1ull << 31) || (pack && expect + (uint64_t)SPM_PACK_MIN * nrows >= (1ull << 32))) return hipErrorInvalidValue;
+    const size_t smem = pack ? pack_smem : sparse_merge_rows_lds(a.rs_row);
     auto go = [&](auto kern) -> hipError_t {
         hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e2 != hipSuccess) return e2;
         hipLaunchKernelGGL(kern, dim3((uint32_t)items), dim3(SPM_NT), smem, stream, a);
         return hipGetLastError();
     };
-    // rows that fit the LDS window whole take the kernel without window logic
-    const bool whole = a.rs_row <= SPM_AWIN + 8u && !getenv("MASHGPU_SPARSE_MERGE_WINDOWS");
+    if (pack) return a.triangle ? go(sp_merge_pack_kernel<false>) : go(sp_merge_pack_kernel<true>);
     if (a.triangle) return whole ? go(sp_merge_rows_kernel<false>) : go(sp_merge_rows_win_kernel<false>);
     return whole ? go(sp_merge_rows_kernel<true>) : go(sp_merge_rows_win_kernel<true>);
 }
