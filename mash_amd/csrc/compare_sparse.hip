@@ -658,21 +658,21 @@ __global__ __launch_bounds__(SPM_NT) void sp_merge_rows_kernel(SparseArgs a)
 // finds its row among the item's (at most one row boundary lies between two units 32 apart, so the rows of the
 // units 0, 32, 64, 96 and 127 are all there are), all of them are staged in LDS, and the loop is the one above
 // with a per-lane row base.  Lanes on a row's padding units idle (C3: 9 % against 43 %).
-constexpr uint32_t SPM_PACK_MIN = 32;
-constexpr uint32_t SPM_PACK_ROWS = 5;
-
-__global__ __launch_bounds__(256) void sp_pack_costs_kernel(const uint32_t *seg_cnt, uint32_t nrows, uint32_t *chunks)
+__global__ __launch_bounds__(256) void sp_pack_costs_kernel(const uint32_t *seg_cnt, uint32_t nrows, uint32_t pack_min, uint32_t *chunks)
 {
     const uint32_t r = blockIdx.x * 256u + threadIdx.x;
     if (r < nrows) {
         const uint32_t c = seg_cnt[r];
-        chunks[r] = c ? (c < SPM_PACK_MIN ? SPM_PACK_MIN : c) : 0u;
+        chunks[r] = c ? (c < pack_min ? pack_min : c) : 0u;
     }
 }
 
-template <bool RECT>
+// SPM_PACK_MIN: units a row with candidates takes at least (32: up to 5 rows per item, 43: 4, 64: 3 -- fewer rows staged
+// = more workgroups per CU, more padding units = more idle lanes)
+template <bool RECT, uint32_t SPM_PACK_MIN>
 __global__ __launch_bounds__(SPM_NT) void sp_merge_pack_kernel(SparseArgs a)
 {
+    constexpr uint32_t SPM_PACK_ROWS = (SPM_NT + SPM_PACK_MIN - 1u) / SPM_PACK_MIN + 1u;
     extern __shared__ __align__(16) uint32_t lds[];
     __shared__ uint32_t pslot[SPM_PACK_ROWS];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -710,7 +710,7 @@ __global__ __launch_bounds__(SPM_NT) void sp_merge_pack_kernel(SparseArgs a)
     }
     // this lane's unit -> row, candidate
     const uint32_t u = u0 + tid;
-    const uint32_t sA = pslot[tid >> 5], sB = pslot[(tid >> 5) + 1u];
+    const uint32_t sA = pslot[tid / SPM_PACK_MIN], sB = pslot[tid / SPM_PACK_MIN + 1u];
     uint32_t slot = sA;
     if (sB != sA && u >= a.chunk_inc[sB - 1u]) slot = sB;  // (sB > sA: the units before sB's first end with the slot before it)
     const uint32_t q = u - (slot ? a.chunk_inc[slot - 1u] : 0u);
@@ -1132,18 +1132,21 @@ hipError_t launch_sparse_merge_rows(const SparseArgs &a, uint64_t expect, uint32
     // rows that fit the LDS window whole take the kernels without window logic; of those, jobs whose rows have few
     // candidates each (fewer than 96 on average) pack several rows into an item (MASHGPU_SPARSE_MERGE_PACK=0|1 forces)
     const bool whole = a.rs_row <= SPM_AWIN + 8u && !getenv("MASHGPU_SPARSE_MERGE_WINDOWS");
-    const size_t pack_smem = ((size_t)SPM_PACK_ROWS * a.rs_row + (SPM_NT / 64u) * SPM_RING * 64u) * 4;
+    uint32_t pack_min = 32;
+    if (const char *ev = getenv("MASHGPU_SPARSE_PACK_MIN")) pack_min = atoi(ev) >= 64 ? 64u : atoi(ev) >= 43 ? 43u : 32u;
+    const uint32_t pack_rows = (SPM_NT + pack_min - 1u) / pack_min + 1u;
+    const size_t pack_smem = ((size_t)pack_rows * a.rs_row + (SPM_NT / 64u) * SPM_RING * 64u) * 4;
     bool pack = whole && pack_smem <= 64 * 1024 && expect < 96ull * nrows;
     if (const char *ev = getenv("MASHGPU_SPARSE_MERGE_PACK")) pack = whole && pack_smem <= 160 * 1024 - 256 && atoi(ev) != 0;
-    if (pack) hipLaunchKernelGGL(sp_pack_costs_kernel, dim3((nrows + 255u) / 256u), dim3(256), 0, stream, a.seg_cnt, nrows, chunks);
+    if (pack) hipLaunchKernelGGL(sp_pack_costs_kernel, dim3((nrows + 255u) / 256u), dim3(256), 0, stream, a.seg_cnt, nrows, pack_min, chunks);
     else hipLaunchKernelGGL(sp_chunks_kernel, dim3((nrows + 255u) / 256u), dim3(256), 0, stream, a.seg_cnt, nrows, chunks);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     e = rocprim::inclusive_scan(temp, temp_bytes, (const uint32_t *)chunks, a.chunk_inc, (size_t)nrows, rocprim::plus<uint32_t>(), stream);
     if (e != hipSuccess) return e;
     // upper bounds: one partial item per row / every row with candidates padded to SPM_PACK_MIN units
-    const uint64_t items = pack ? (expect + (uint64_t)SPM_PACK_MIN * nrows) / SPM_NT + 1 : expect / SPM_NT + nrows;
-    if (items >= (1ull << 31) || (pack && expect + (uint64_t)SPM_PACK_MIN * nrows >= (1ull << 32))) return hipErrorInvalidValue;
+    const uint64_t items = pack ? (expect + (uint64_t)pack_min * nrows) / SPM_NT + 1 : expect / SPM_NT + nrows;
+    if (items >= (1ull << 31) || (pack && expect + (uint64_t)pack_min * nrows >= (1ull << 32))) return hipErrorInvalidValue;
     const size_t smem = pack ? pack_smem : sparse_merge_rows_lds(a.rs_row);
     auto go = [&](auto kern) -> hipError_t {
         hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -1151,7 +1154,9 @@ hipError_t launch_sparse_merge_rows(const SparseArgs &a, uint64_t expect, uint32
         hipLaunchKernelGGL(kern, dim3((uint32_t)items), dim3(SPM_NT), smem, stream, a);
         return hipGetLastError();
     };
-    if (pack) return a.triangle ? go(sp_merge_pack_kernel<false>) : go(sp_merge_pack_kernel<true>);
+    if (pack && pack_min == 32) return a.triangle ? go(sp_merge_pack_kernel<false, 32>) : go(sp_merge_pack_kernel<true, 32>);
+    if (pack && pack_min == 43) return a.triangle ? go(sp_merge_pack_kernel<false, 43>) : go(sp_merge_pack_kernel<true, 43>);
+    if (pack) return a.triangle ? go(sp_merge_pack_kernel<false, 64>) : go(sp_merge_pack_kernel<true, 64>);
     if (a.triangle) return whole ? go(sp_merge_rows_kernel<false>) : go(sp_merge_rows_win_kernel<false>);
     return whole ? go(sp_merge_rows_kernel<true>) : go(sp_merge_rows_win_kernel<true>);
 }

@@ -2363,7 +2363,7 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
         const bool all_copies = triangle && ix->one_class != 0;
         hipError_t e = all_copies ? mg::launch_sparse_fill(a.out, pairs, ix->one_class, ix->one_class, fill_bpc, (uint32_t)ctx->cu_count, fs)
                                   : mg::launch_sparse_fill(a.out, pairs, 0, s, fill_bpc, (uint32_t)ctx->cu_count, fs);
-        if (e == hipSuccess && nshort_rows && !ix->short_rows_host.empty())
+        if (e == hipSuccess && nshort_rows && !ix->short_rows_host.empty() && !all_copies)      // (copies of a SHORT sketch are {c, c} too, not {0, 2c})
             e = mg::launch_sparse_fill_short(a.out, short_rows_dev, short_rcnt_dev, nshort_rows, ix->short_rows, ix->short_cnt,
                                              (uint32_t)ix->short_rows_host.size(), a.row_begin, a.ncols, a.triangle, a.out_base, s, fs);
         // pairs of two copies of one sketch: {n, n} (after the fill, on its stream)

@@ -659,6 +659,30 @@ def test_compare_extremes_and_random(eng, oracle):
     t.free()
 
 
+@pytest.mark.parametrize("kernel", ["merged", "sparse"])
+@pytest.mark.parametrize("count", [1, 24, 1000])
+def test_compare_table_of_copies(eng, oracle, kernel, count, monkeypatch):
+    """Nothing but copies of ONE sketch -- full, short (24 of s = 1000 hashes: two short sketches that share
+    nothing would be {0, 48}, copies are {24, 24}) and of a single hash: every pair {c, c}; whole triangle and a row
+    range.  (The inverted-index engine answers such a table with its fill alone; tools/compare_fuzz.py found
+    the short-pairs pass overwriting it.)"""
+    _set_kernel(monkeypatch, kernel)
+    one, _, _ = synth.random_sketches(1, 1000, seed=4)
+    n = 300
+    table = np.full((n, 1000), np.uint64(abi.HASH_PAD), dtype=np.uint64)
+    table[:, :count] = one[0, :count]
+    nhash = np.full(n, count, dtype=np.uint32)
+    lengths = np.full(n, 10 ** 6, dtype=np.uint64)
+    t = eng.table_upload(table, nhash, lengths)
+    got = eng.compare_tri_host(t)
+    assert np.all(got["numer"] == count) and np.all(got["denom"] == count)
+    part = eng.compare_tri_host(t, 100, 250)
+    assert len(part) == abi.tri_pairs(100, 250) and np.all(part["numer"] == count) and np.all(part["denom"] == count)
+    numer, denom = _oracle_tri(oracle, table[:40], nhash[:40], lengths[:40], 0, 40)
+    assert np.all(numer == count) and np.all(denom == count)
+    t.free()
+
+
 @pytest.mark.parametrize("kernel", ["merged", "sparse", "plain", "windows61"])
 @pytest.mark.parametrize("top", [0xFFFFFFFF, 0xFFFFFFFFFFFFFFFE, 0xFFFFFFFE00000000])
 def test_compare_values_at_the_top_of_the_hash_range(eng, oracle, kernel, top, monkeypatch):

@@ -13,7 +13,6 @@ eng = abi.MashGpu(0, stream=torch.cuda.current_stream().cuda_stream)
 res = {}
 for name, make in (("c3", lambda: synth_torch.clustered_sketch_table(100000, 1000, clusters=1000, device=dev)),
                    ("c3_n20000", lambda: synth_torch.clustered_sketch_table(20000, 1000, clusters=200, device=dev)),
-                   ("clades", lambda: synth_torch.clade_sketch_table(100000, 1000, device=dev)),
                    ("s400", lambda: synth_torch.clustered_sketch_table(100000, 400, clusters=1000, pool=600, private=160, device=dev))):
     h, nh, ln = make()
     n, s = h.shape
@@ -24,8 +23,9 @@ for name, make in (("c3", lambda: synth_torch.clustered_sketch_table(100000, 100
     eng.compare_tri_dev(t, 0, n, out.data_ptr())
     r = {}
     for rep in range(2):
-        for pack in ("0", "1"):
+        for pack, pmin in (("0", "32"), ("1", "32"), ("1", "43"), ("1", "64")):
             os.environ["MASHGPU_SPARSE_MERGE_PACK"] = pack
+            os.environ["MASHGPU_SPARSE_PACK_MIN"] = pmin
             out.zero_()
             torch.cuda.synchronize()
             eng.prof_enable(True); eng.prof_reset()
@@ -37,9 +37,9 @@ for name, make in (("c3", lambda: synth_torch.clustered_sketch_table(100000, 100
             ph = {k: round(eng.prof_avg_ms(k)[0], 3) for k in ("compare_fill", "compare_discover", "compare_merge")}
             eng.prof_enable(False)
             cs = [int(out[:, 0].sum(dtype=torch.int64)), int(out[:, 1].sum(dtype=torch.int64))]
-            r.setdefault("pack" + pack, []).append({"ms": round(dt * 1e3, 3), **ph, "checksum": cs})
-    assert r["pack0"][0]["checksum"] == r["pack1"][0]["checksum"] == r["pack1"][1]["checksum"], (name, r)
-    del os.environ["MASHGPU_SPARSE_MERGE_PACK"]
+            r.setdefault("pack" + pack + ("_min" + pmin if pack == "1" else ""), []).append({"ms": round(dt * 1e3, 3), **ph, "checksum": cs})
+    assert len({tuple(x["checksum"]) for v in r.values() for x in v}) == 1, (name, r)
+    del os.environ["MASHGPU_SPARSE_MERGE_PACK"], os.environ["MASHGPU_SPARSE_PACK_MIN"]
     res[name] = r
     t.free(); del out, h
     torch.cuda.empty_cache()
