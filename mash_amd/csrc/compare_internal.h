@@ -115,6 +115,10 @@ hipError_t launch_sparse_row_equal(const uint64_t *hashes, uint64_t stride, cons
                                    uint32_t *equal, hipStream_t stream);
 size_t sparse_sort_temp_bytes(uint32_t E, uint32_t end_bit);
 uint32_t sparse_img_stride(uint32_t s);          // row stride of a code image
+// runs of the index that name the same rows: per row all but one of them are emptied in lohi (compare_sparse.hip)
+hipError_t launch_sparse_run_dedupe(const uint32_t *gstart, const uint32_t *sorted_rows, uint32_t G, const uint32_t *off,
+                                    const uint32_t *rank_img, uint32_t rs, uint2 *lohi, uint32_t n, uint32_t max_cnt,
+                                    unsigned long long *dig, unsigned long long *removed, hipStream_t stream);
 hipError_t sparse_build_index(const uint64_t *hashes, uint64_t stride, const uint32_t *off, uint32_t n, uint32_t E,
                               uint32_t rs, uint32_t end_bit, void *temp, size_t temp_bytes, uint64_t *keys_a,
                               uint32_t *eid_a, uint64_t *keys_sorted, uint32_t *eid_sorted, uint32_t *head, uint32_t *grp,

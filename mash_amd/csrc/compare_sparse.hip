@@ -212,6 +212,120 @@ hipError_t launch_sparse_row_keys(const uint32_t *off, const uint32_t *rank_img,
     return hipGetLastError();
 }
 
+// ---- runs that name the same rows -----------------------------------------------------------------------------
+// In a clade of near-identical sketches most values are held by the same set of rows: their runs are copies of each
+// other, and a row that ORs one of them into its bitmap learns nothing from the next.  Once per index: a 128-bit
+// digest of every run (which rows, in which order), then per row the entries whose run equals the run of another entry
+// of the row -- same digest, same number of rows below this one, same first row -- lose their share of the work:
+// their {lo, hi} becomes empty, discovery skips them like values nobody else holds.  Candidates are the rows named by
+// ANY entry of a row, so dropping a copy of a run changes nothing (and two different runs are taken for copies only
+// if 128 bits of digest, the length and the first row agree).
+__device__ __forceinline__ uint64_t sp_mix64(uint64_t x)
+{
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ULL;
+    x ^= x >> 27; x *= 0x94D049BB133111EBULL;
+    return x ^ (x >> 31);
+}
+
+__global__ __launch_bounds__(256) void sp_run_digest_kernel(const uint32_t *gstart, const uint32_t *sorted_rows, uint32_t G,
+                                                            unsigned long long *dig)
+{
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t lo = 0, hi = 0;
+    if (g < G) { lo = gstart[g]; hi = gstart[g + 1]; }
+    const uint32_t len = hi - lo;
+    uint64_t d1 = 0, d2 = 0;
+    if (len >= 2u && len <= 32u) {                       // (a run of one row is that row alone: never a candidate)
+        for (uint32_t q = lo; q < hi; q++) {
+            const uint64_t x = (uint64_t)sorted_rows[q] | ((uint64_t)(q - lo) << 32);
+            d1 += sp_mix64(x);
+            d2 += sp_mix64(x * 0x9E3779B97F4A7C15ULL + 0xD1B54A32D192ED03ULL);
+        }
+    }
+    uint64_t m = __ballot(len > 32u);                    // long runs: the wave together
+    while (m != 0) {
+        const int l = __builtin_ctzll(m);
+        m &= m - 1;
+        const uint32_t LO = (uint32_t)__builtin_amdgcn_readlane((int)lo, l), HI = (uint32_t)__builtin_amdgcn_readlane((int)hi, l);
+        uint64_t p1 = 0, p2 = 0;
+        for (uint32_t q = LO + lane; q < HI; q += 64u) {
+            const uint64_t x = (uint64_t)sorted_rows[q] | ((uint64_t)(q - LO) << 32);
+            p1 += sp_mix64(x);
+            p2 += sp_mix64(x * 0x9E3779B97F4A7C15ULL + 0xD1B54A32D192ED03ULL);
+        }
+        for (int d = 32; d > 0; d >>= 1) { p1 += __shfl_xor(p1, d); p2 += __shfl_xor(p2, d); }
+        if ((int)lane == l) { d1 = p1; d2 = p2; }
+    }
+    if (g < G) {
+        dig[2ull * g] = d1 + (uint64_t)len * 0xC2B2AE3D27D4EB4FULL;
+        dig[2ull * g + 1] = d2 ^ ((uint64_t)len << 40);
+    }
+}
+
+// one workgroup per row; LDS: an open-addressing table of `tsize` {key, check} pairs (tsize a power of two >= 2 x the row's entries)
+__global__ __launch_bounds__(256) void sp_run_dedupe_kernel(const uint32_t *off, const uint32_t *rank_img, uint32_t rs,
+                                                            const unsigned long long *dig, const uint32_t *sorted_rows, uint2 *lohi,
+                                                            uint32_t tsize, unsigned long long *removed)
+{
+    extern __shared__ unsigned long long tab[];          // [tsize] keys, [tsize] checks
+    const uint32_t row = blockIdx.x, tid = threadIdx.x;
+    const uint32_t b = off[row], cnt = off[row + 1] - b;
+    if (cnt == 0 || 2u * cnt > tsize) return;            // (uniform; rows too long for the table keep all their runs)
+    unsigned long long *keys = tab, *chk = tab + tsize;
+    for (uint32_t i = tid; i < 2u * tsize; i += 256u) tab[i] = 0;
+    __syncthreads();
+    uint32_t dropped = 0;
+    for (uint32_t p = tid; p < cnt; p += 256u) {
+        const uint2 lh = lohi[b + p];
+        const uint32_t len = lh.y - lh.x;
+        if (len == 0) continue;
+        const uint32_t g = rank_img[(uint64_t)row * rs + p] >> 1;
+        // (equal runs put this row at the same place: equal prefix length, equal first row)
+        const uint64_t salt = sp_mix64(((uint64_t)len << 32) | sorted_rows[lh.x]);
+        uint64_t key = dig[2ull * g] ^ salt, check = dig[2ull * g + 1] + salt;
+        if (key == 0) key = 1;
+        if (check == 0) check = 1;
+        uint32_t slot = (uint32_t)(key >> 17) & (tsize - 1u);
+        bool done = false;
+        while (!done) {
+            const unsigned long long old = atomicCAS(&keys[slot], 0ULL, (unsigned long long)key);
+            // The owner of a slot publishes its check word BEFORE anyone of its own wave looks for one (lanes of a wave
+            // cannot wait for each other inside a divergent loop); a lane that finds another wave's key waits for that
+            // wave, which runs on its own.
+            if (old == 0) {                                          // first of its kind: stays
+                __hip_atomic_store(&chk[slot], (unsigned long long)check, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                done = true;
+            }
+            if (!done && old == key) {
+                unsigned long long c;
+                while ((c = __hip_atomic_load(&chk[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0) {}
+                if (c == check) { lohi[b + p] = make_uint2(lh.x, lh.x); dropped++; done = true; }
+            }
+            if (!done) slot = (slot + 1u) & (tsize - 1u);
+        }
+    }
+    if (removed && dropped) atomicAdd(removed, (unsigned long long)dropped);
+}
+
+// dig: scratch of 2 G u64.  max_cnt: the most entries a row has.  *removed += entries whose run was a copy.
+hipError_t launch_sparse_run_dedupe(const uint32_t *gstart, const uint32_t *sorted_rows, uint32_t G, const uint32_t *off,
+                                    const uint32_t *rank_img, uint32_t rs, uint2 *lohi, uint32_t n, uint32_t max_cnt,
+                                    unsigned long long *dig, unsigned long long *removed, hipStream_t stream)
+{
+    if (n == 0 || G == 0) return hipSuccess;
+    uint32_t tsize = 256;
+    while (tsize < 2u * max_cnt && tsize < 8192u) tsize <<= 1;
+    hipLaunchKernelGGL(sp_run_digest_kernel, dim3((G + 255u) / 256u), dim3(256), 0, stream, gstart, sorted_rows, G, dig);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const size_t smem = (size_t)tsize * 16;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(sp_run_dedupe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sp_run_dedupe_kernel, dim3(n), dim3(256), smem, stream, off, rank_img, rs, dig, sorted_rows, lohi, tsize, removed);
+    return hipGetLastError();
+}
+
 // row stride of a code image: s rounded up to a chunk of four, plus one chunk the loop may load behind the row
 uint32_t sparse_img_stride(uint32_t s) { return ((s + 3u) & ~3u) + 4u; }
 

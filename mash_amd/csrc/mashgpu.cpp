@@ -4,6 +4,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <memory>
@@ -102,6 +103,7 @@ struct mg_table {
         uint32_t cls_members = 0;          // rows in classes of two and more
         uint64_t cls_pairs = 0;            // pairs inside those classes (full triangle)
         uint64_t copies = 0;               // rows that are a copy of an earlier row
+        uint64_t runs_dropped = 0;         // entries whose run was a copy of another run of the same row (sp_run_dedupe_kernel)
         uint32_t one_class = 0;            // != 0: EVERY row is a copy of row 0, which has this many hashes (every pair is {c, c})
         bool has_empty = false;            // some row has no hash at all
         uint32_t *short_rows = nullptr, *short_cnt = nullptr;    // rows with fewer than s hashes (ascending) and their counts
@@ -2104,6 +2106,28 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, mg_tab
     sp->max_group = h_stat.max_group;
     sp->build_ms = ms;
     sp->usable = true;
+    // runs that name the same rows (clades): per row all but one are emptied -- discovery then reads one of them
+    if (!getenv("MASHGPU_SPARSE_NO_RUN_DEDUP") && sp->G && sp->max_group >= 2) {
+        const auto t0 = std::chrono::steady_clock::now();
+        uint32_t max_cnt = 0;
+        for (uint64_t i = 0; i < n; i++) if (rep[i] == i) max_cnt = std::max(max_cnt, cnt_true[i]);
+        unsigned long long *dig = nullptr;
+        unsigned long long dropped = 0;
+        if (hipMalloc(&dig, ((size_t)sp->G * 2 + 1) * 8) == hipSuccess) {
+            hipError_t e2 = hipMemsetAsync(dig + (size_t)sp->G * 2, 0, 8, ctx->stream);
+            if (e2 == hipSuccess)
+                e2 = mg::launch_sparse_run_dedupe(sp->gstart, sp->sorted_rows, sp->G, sp->off, sp->rank_img, sp->rs, sp->lohi, (uint32_t)n, max_cnt,
+                                                  dig, dig + (size_t)sp->G * 2, ctx->stream);
+            if (e2 == hipSuccess) e2 = hipMemcpyAsync(&dropped, dig + (size_t)sp->G * 2, 8, hipMemcpyDeviceToHost, ctx->stream);
+            if (e2 == hipSuccess) e2 = hipStreamSynchronize(ctx->stream);
+            hipFree(dig);
+            if (e2 != hipSuccess) { drop(); sp->usable = false; return fail(ctx, MG_ERR_HIP, std::string("compare (index build, runs): ") + hipGetErrorString(e2)); }
+            sp->runs_dropped = dropped;
+            sp->build_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        } else {
+            (void)hipGetLastError();                     // (no memory for the digests: every run stays)
+        }
+    }
     // visiting order of the rows: by the run of their first shared value, larger rows first inside a run
     if (!getenv("MASHGPU_SPARSE_NO_ORDER")) {
         DevBuf<uint32_t> d_key;
@@ -2123,8 +2147,9 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, mg_tab
         }
     }
     if (getenv("MASHGPU_SPARSE_DBG"))
-        fprintf(stderr, "compare sparse: index of %llu rows (%llu copies of earlier rows), s %u: %u entries, %u distinct, shared %llu, largest run %u, %.2f ms\n",
-                (unsigned long long)n, (unsigned long long)sp->copies, s, E, sp->G, (unsigned long long)sp->shared, sp->max_group, ms);
+        fprintf(stderr, "compare sparse: index of %llu rows (%llu copies of earlier rows), s %u: %u entries, %u distinct, shared %llu, largest run %u, %llu entries with a copied run, %.2f ms\n",
+                (unsigned long long)n, (unsigned long long)sp->copies, s, E, sp->G, (unsigned long long)sp->shared, sp->max_group,
+                (unsigned long long)sp->runs_dropped, sp->build_ms);
     return MG_OK;
 }
 

@@ -659,6 +659,50 @@ def test_compare_extremes_and_random(eng, oracle):
     t.free()
 
 
+def test_compare_runs_that_name_the_same_rows(eng, oracle, monkeypatch):
+    """The index empties, per row, all but one of the runs that name the same rows (clades: hundreds of values
+    held by exactly the same sketches).  What must survive: every pair that is linked by ANY value -- here rows of two
+    clades with a common core each (copied runs), values held by all rows but one (runs that differ from the core's
+    in a single row), and bridge values between the clades that are the ONLY link of their pairs.  Inverted-index
+    engine == oracle == the same engine with the run dedupe switched off."""
+    rng = np.random.default_rng(77)
+    n, s = 90, 96
+    vals = np.sort(rng.choice(np.arange(1, 10 ** 6, dtype=np.uint64), 4000, replace=False))
+    core = [vals[:40], vals[40:80]]
+    table = np.full((n, s), np.uint64(abi.HASH_PAD), dtype=np.uint64)
+    nhash = np.zeros(n, dtype=np.uint32)
+    rows = []
+    nxt = 80
+    for i in range(n):
+        c = i % 2
+        own = set(int(x) for x in core[c])
+        if i % 7 == 0:                                   # a member that lacks one core value: that value's run differs in one row
+            own.discard(int(core[c][i % 40]))
+        for _ in range(int(rng.integers(5, 30))):        # private values
+            own.add(int(vals[nxt])); nxt += 1
+        rows.append(own)
+    for b in range(25):                                  # bridges: one value, two rows of different clades (or any two rows)
+        x, y = int(rng.integers(0, n)), int(rng.integers(0, n))
+        v = int(vals[nxt]); nxt += 1
+        rows[x].add(v); rows[y].add(v)
+    for i, own in enumerate(rows):
+        r = np.array(sorted(own), dtype=np.uint64)[:s]
+        table[i, : len(r)] = r
+        nhash[i] = len(r)
+    lengths = np.full(n, 10 ** 6, dtype=np.uint64)
+    numer, denom = _oracle_tri(oracle, table, nhash, lengths, 0, n)
+    monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", "sparse")
+    t = eng.table_upload(table, nhash, lengths)
+    got = eng.compare_tri_host(t)
+    assert np.array_equal(got["numer"], numer) and np.array_equal(got["denom"], denom)
+    t.free()
+    monkeypatch.setenv("MASHGPU_SPARSE_NO_RUN_DEDUP", "1")
+    t = eng.table_upload(table, nhash, lengths)
+    plain = eng.compare_tri_host(t)
+    assert plain.tobytes() == got.tobytes()
+    t.free()
+
+
 @pytest.mark.parametrize("kernel", ["merged", "sparse"])
 @pytest.mark.parametrize("count", [1, 24, 1000])
 def test_compare_table_of_copies(eng, oracle, kernel, count, monkeypatch):
