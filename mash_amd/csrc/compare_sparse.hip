@@ -263,7 +263,10 @@ __global__ __launch_bounds__(256) void sp_run_digest_kernel(const uint32_t *gsta
     }
 }
 
-// one workgroup per row; LDS: an open-addressing table of `tsize` {key, check} pairs (tsize a power of two >= 2 x the row's entries)
+// one workgroup per row; LDS: an open-addressing table of `tsize` {key, check} pairs (tsize a power of two >= 2 x the row's
+// entries, so a thread handles at most 16 entries).  Two phases with a barrier between them and NO waiting inside a
+// wave (lanes of a wave cannot wait for each other): (1) every entry claims the slot of its key or finds it claimed;
+// claimers publish their check word; (2) the others compare theirs with the published one.
 __global__ __launch_bounds__(256) void sp_run_dedupe_kernel(const uint32_t *off, const uint32_t *rank_img, uint32_t rs,
                                                             const unsigned long long *dig, const uint32_t *sorted_rows, uint2 *lohi,
                                                             uint32_t tsize, unsigned long long *removed)
@@ -271,12 +274,18 @@ __global__ __launch_bounds__(256) void sp_run_dedupe_kernel(const uint32_t *off,
     extern __shared__ unsigned long long tab[];          // [tsize] keys, [tsize] checks
     const uint32_t row = blockIdx.x, tid = threadIdx.x;
     const uint32_t b = off[row], cnt = off[row + 1] - b;
-    if (cnt == 0 || 2u * cnt > tsize) return;            // (uniform; rows too long for the table keep all their runs)
+    if (cnt == 0 || 2u * cnt > tsize || cnt > 16u * 256u) return;      // (uniform; rows too long for the table keep all their runs)
     unsigned long long *keys = tab, *chk = tab + tsize;
     for (uint32_t i = tid; i < 2u * tsize; i += 256u) tab[i] = 0;
     __syncthreads();
-    uint32_t dropped = 0;
-    for (uint32_t p = tid; p < cnt; p += 256u) {
+    uint32_t found[16];                                  // slot + 1 where an entry found its key claimed by another; 0: it stays
+    unsigned long long mycheck[16];
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+        found[it] = 0;
+        mycheck[it] = 0;
+        const uint32_t p = tid + (uint32_t)it * 256u;
+        if (p >= cnt) continue;
         const uint2 lh = lohi[b + p];
         const uint32_t len = lh.y - lh.x;
         if (len == 0) continue;
@@ -287,23 +296,23 @@ __global__ __launch_bounds__(256) void sp_run_dedupe_kernel(const uint32_t *off,
         if (key == 0) key = 1;
         if (check == 0) check = 1;
         uint32_t slot = (uint32_t)(key >> 17) & (tsize - 1u);
-        bool done = false;
-        while (!done) {
+        for (uint32_t tries = 0; tries < tsize; tries++) {
             const unsigned long long old = atomicCAS(&keys[slot], 0ULL, (unsigned long long)key);
-            // The owner of a slot publishes its check word BEFORE anyone of its own wave looks for one (lanes of a wave
-            // cannot wait for each other inside a divergent loop); a lane that finds another wave's key waits for that
-            // wave, which runs on its own.
-            if (old == 0) {                                          // first of its kind: stays
-                __hip_atomic_store(&chk[slot], (unsigned long long)check, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                done = true;
-            }
-            if (!done && old == key) {
-                unsigned long long c;
-                while ((c = __hip_atomic_load(&chk[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0) {}
-                if (c == check) { lohi[b + p] = make_uint2(lh.x, lh.x); dropped++; done = true; }
-            }
-            if (!done) slot = (slot + 1u) & (tsize - 1u);
+            if (old == 0) { chk[slot] = check; break; }                          // first of its kind: stays
+            if (old == key) { found[it] = slot + 1u; mycheck[it] = check; break; }
+            slot = (slot + 1u) & (tsize - 1u);
         }
+    }
+    __syncthreads();                                     // every claimed slot has its check word
+    uint32_t dropped = 0;
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+        if (found[it] == 0) continue;
+        if (chk[found[it] - 1u] != mycheck[it]) continue;                        // (same key, another run: both stay)
+        const uint32_t p = tid + (uint32_t)it * 256u;
+        const uint2 lh = lohi[b + p];
+        lohi[b + p] = make_uint2(lh.x, lh.x);
+        dropped++;
     }
     if (removed && dropped) atomicAdd(removed, (unsigned long long)dropped);
 }

@@ -2107,7 +2107,8 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, mg_tab
     sp->build_ms = ms;
     sp->usable = true;
     // runs that name the same rows (clades): per row all but one are emptied -- discovery then reads one of them
-    if (!getenv("MASHGPU_SPARSE_NO_RUN_DEDUP") && sp->G && sp->max_group >= 2) {
+    // (OPT-IN, MASHGPU_SPARSE_RUN_DEDUP=1: written at the very end of round 3, its GPU validation did not finish)
+    if (getenv("MASHGPU_SPARSE_RUN_DEDUP") && !getenv("MASHGPU_SPARSE_NO_RUN_DEDUP") && sp->G && sp->max_group >= 2) {
         const auto t0 = std::chrono::steady_clock::now();
         uint32_t max_cnt = 0;
         for (uint64_t i = 0; i < n; i++) if (rep[i] == i) max_cnt = std::max(max_cnt, cnt_true[i]);

@@ -660,11 +660,12 @@ def test_compare_extremes_and_random(eng, oracle):
 
 
 def test_compare_runs_that_name_the_same_rows(eng, oracle, monkeypatch):
-    """The index empties, per row, all but one of the runs that name the same rows (clades: hundreds of values
-    held by exactly the same sketches).  What must survive: every pair that is linked by ANY value -- here rows of two
-    clades with a common core each (copied runs), values held by all rows but one (runs that differ from the core's
-    in a single row), and bridge values between the clades that are the ONLY link of their pairs.  Inverted-index
-    engine == oracle == the same engine with the run dedupe switched off."""
+    """Clades: hundreds of values held by exactly the same sketches, i.e. runs of the index that are copies of each
+    other.  Every pair that is linked by ANY value must be found -- here rows of two clades with a common core each
+    (copied runs), values held by all rows but one (runs that differ from the core's in a single row), and bridge
+    values between the clades that are the ONLY link of their pairs.  Inverted-index engine == oracle.  With
+    MASHGPU_TEST_RUN_DEDUP=1 also with the index's run dedupe switched on (opt-in: MASHGPU_SPARSE_RUN_DEDUP, written at
+    the end of round 3, not yet validated on the GPU -- hence not part of the default suite)."""
     rng = np.random.default_rng(77)
     n, s = 90, 96
     vals = np.sort(rng.choice(np.arange(1, 10 ** 6, dtype=np.uint64), 4000, replace=False))
@@ -696,11 +697,12 @@ def test_compare_runs_that_name_the_same_rows(eng, oracle, monkeypatch):
     got = eng.compare_tri_host(t)
     assert np.array_equal(got["numer"], numer) and np.array_equal(got["denom"], denom)
     t.free()
-    monkeypatch.setenv("MASHGPU_SPARSE_NO_RUN_DEDUP", "1")
-    t = eng.table_upload(table, nhash, lengths)
-    plain = eng.compare_tri_host(t)
-    assert plain.tobytes() == got.tobytes()
-    t.free()
+    if os.environ.get("MASHGPU_TEST_RUN_DEDUP"):
+        monkeypatch.setenv("MASHGPU_SPARSE_RUN_DEDUP", "1")
+        t = eng.table_upload(table, nhash, lengths)
+        dedup = eng.compare_tri_host(t)
+        assert dedup.tobytes() == got.tobytes()
+        t.free()
 
 
 @pytest.mark.parametrize("kernel", ["merged", "sparse"])
