@@ -610,7 +610,8 @@ void sketch_reads(Gpu &gpu, SketchSet &set, const vector<string> &files, mg_sket
         mp.min_copies = set.p.min_copies;
         mp.target_cov = set.p.target_cov;
         mp.bloom_bytes = set.p.bloom_bytes;
-        // (one session for all reads-mode files of a run: its device buffers are allocated once)
+        // (MASH_AMD_SHARED_READS=1: one session for all reads-mode files of a run, emptied by mg_reads_reset between
+        //  them -- its device buffers are then allocated once; opt-in until it has run on the GPU)
         if (shared_reads && *shared_reads) rs = *shared_reads;
         else if (mg_reads_begin(gpu.ctx, &mp, &rs) != MG_OK) { cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl; exit(1); }
         b.bases.reserve(std::min<size_t>(reads_chunk, 64u << 20) + (1u << 16));
@@ -670,7 +671,7 @@ void sketch_reads(Gpu &gpu, SketchSet &set, const vector<string> &files, mg_sket
             cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl;
             exit(1);
         }
-        if (shared_reads) { mg_reads_reset(rs); *shared_reads = rs; }
+        if (shared_reads && getenv("MASH_AMD_SHARED_READS")) { mg_reads_reset(rs); *shared_reads = rs; }
         else mg_reads_free(rs);
         ref.hashes.assign(hashes.begin(), hashes.begin() + nh);
         ref.counts.assign(counts.begin(), counts.begin() + nh);
