@@ -115,10 +115,6 @@ hipError_t launch_sparse_row_equal(const uint64_t *hashes, uint64_t stride, cons
                                    uint32_t *equal, hipStream_t stream);
 size_t sparse_sort_temp_bytes(uint32_t E, uint32_t end_bit);
 uint32_t sparse_img_stride(uint32_t s);          // row stride of a code image
-// runs of the index that name the same rows: per row all but one of them are emptied in lohi (compare_sparse.hip)
-hipError_t launch_sparse_run_dedupe(const uint32_t *gstart, const uint32_t *sorted_rows, uint32_t G, const uint32_t *off,
-                                    const uint32_t *rank_img, uint32_t rs, uint2 *lohi, uint32_t n, uint32_t max_cnt,
-                                    unsigned long long *dig, unsigned long long *removed, hipStream_t stream);
 hipError_t sparse_build_index(const uint64_t *hashes, uint64_t stride, const uint32_t *off, uint32_t n, uint32_t E,
                               uint32_t rs, uint32_t end_bit, void *temp, size_t temp_bytes, uint64_t *keys_a,
                               uint32_t *eid_a, uint64_t *keys_sorted, uint32_t *eid_sorted, uint32_t *head, uint32_t *grp,
@@ -138,8 +134,7 @@ hipError_t launch_sparse_scatter(const SparseArgs &a, uint64_t expect, uint32_t 
 size_t sparse_gather_temp_bytes(uint32_t nrows);
 hipError_t launch_sparse_gather_rows(const SparseArgs &a, uint32_t *cnt_by_row, uint32_t *row_base, void *temp, size_t temp_bytes, uint32_t row_add,
                                      uint2 *rc_out, uint2 *counts_out, hipStream_t stream);
-// every slot = {numer, denom}: {0, s} for the pairs that share nothing; {c, c} when the whole table is c-hash copies of one sketch
-hipError_t launch_sparse_fill(uint2 *out, uint64_t pairs, uint32_t numer, uint32_t denom, uint32_t blocks_per_cu, uint32_t cus, hipStream_t stream);
+hipError_t launch_sparse_fill(uint2 *out, uint64_t pairs, uint32_t denom, uint32_t blocks_per_cu, uint32_t cus, hipStream_t stream);
 hipError_t launch_sparse_fill_short(uint2 *out, const uint32_t *short_rows, const uint32_t *short_rcnt, uint32_t nshort_rows,
                                     const uint32_t *short_cols, const uint32_t *short_ccnt, uint32_t nshort_cols,
                                     uint32_t row_begin, uint32_t ncols, uint32_t triangle, uint64_t out_base, uint32_t s,

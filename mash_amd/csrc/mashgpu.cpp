@@ -21,6 +21,7 @@
 
 #include "../../include/mashgpu.h"
 #include "compare_internal.h"
+#include "compare_sparse_x.h"
 #include "finish_internal.h"
 #include "pvalue.h"
 #include "screen_internal.h"
@@ -2385,10 +2386,11 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
     }
     if (!job) {
         prof_begin(ctx, ctx->prof_fill, fs);
-        // (a table of n copies of one sketch: the fill IS the answer, {c, c} in every slot, written once)
-        const bool all_copies = triangle && ix->one_class != 0;
-        hipError_t e = all_copies ? mg::launch_sparse_fill(a.out, pairs, ix->one_class, ix->one_class, fill_bpc, (uint32_t)ctx->cu_count, fs)
-                                  : mg::launch_sparse_fill(a.out, pairs, 0, s, fill_bpc, (uint32_t)ctx->cu_count, fs);
+        // (MASHGPU_SPARSE_ONE_CLASS=1 -- opt-in, compare_sparse_x.hip: a table of n copies of one sketch: the fill IS the
+        //  answer, {c, c} in every slot, written once)
+        const bool all_copies = triangle && ix->one_class != 0 && getenv("MASHGPU_SPARSE_ONE_CLASS") != nullptr;
+        hipError_t e = all_copies ? mg::launch_sparse_fill_value(a.out, pairs, ix->one_class, ix->one_class, fill_bpc, (uint32_t)ctx->cu_count, fs)
+                                  : mg::launch_sparse_fill(a.out, pairs, s, fill_bpc, (uint32_t)ctx->cu_count, fs);
         if (e == hipSuccess && nshort_rows && !ix->short_rows_host.empty() && !all_copies)      // (copies of a SHORT sketch are {c, c} too, not {0, 2c})
             e = mg::launch_sparse_fill_short(a.out, short_rows_dev, short_rcnt_dev, nshort_rows, ix->short_rows, ix->short_cnt,
                                              (uint32_t)ix->short_rows_host.size(), a.row_begin, a.ncols, a.triangle, a.out_base, s, fs);
@@ -2417,8 +2419,12 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
     bool by_rows = mg::sparse_merge_rows_supported(a.rs_row);
     if (const char *ev = getenv("MASHGPU_SPARSE_MERGE")) by_rows = by_rows && strcmp(ev, "lanes") != 0;
     prof_begin(ctx, ctx->prof_merge);
-    e = by_rows ? mg::launch_sparse_merge_rows(a, plan->cand, ix->chunks, ix->scan_temp, ix->scan_temp_bytes, ctx->stream)
-                : mg::launch_sparse_merge(a, plan->cand, (uint32_t)ctx->cu_count, ctx->stream);
+    bool packed = false;                                  // (MASHGPU_SPARSE_MERGE_PACK=1 -- opt-in, compare_sparse_x.hip: several rows per work item)
+    if (by_rows && getenv("MASHGPU_SPARSE_MERGE_PACK") && atoi(getenv("MASHGPU_SPARSE_MERGE_PACK")) != 0)
+        e = mg::launch_sparse_merge_pack(a, plan->cand, ix->chunks, ix->scan_temp, ix->scan_temp_bytes, &packed, ctx->stream);
+    if (!packed && e == hipSuccess)
+        e = by_rows ? mg::launch_sparse_merge_rows(a, plan->cand, ix->chunks, ix->scan_temp, ix->scan_temp_bytes, ctx->stream)
+                    : mg::launch_sparse_merge(a, plan->cand, (uint32_t)ctx->cu_count, ctx->stream);
     prof_end(ctx, ctx->prof_merge);
     if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare (merge): ") + hipGetErrorString(e));
     if (job) job->args = a;
