@@ -204,3 +204,97 @@ def test_model_rect_equals_oracle(oracle, s):
         for r in range(n):
             c, d = merge_codes(qtab[q, : qnh[q]].tolist(), table[r, : nhash[r]].tolist(), s)
             assert (got_n[q, r], got_d[q, r]) == (c, d), (q, r)
+
+
+@pytest.mark.parametrize("pack_min", [32, 43, 64])
+def test_pack_mapping_of_candidates_to_lanes(pack_min):
+    """The work distribution of sp_merge_pack_kernel (compare_sparse_x.hip) in numpy: candidates of all rows as one line
+    of units (a row with candidates takes max(candidates, pack_min) units), item t = units [128 t, 128 t + 128).  Every
+    lane finds its row from the rows of the item's probe units (0, pack_min, 2 pack_min, ..., 127) alone -- at most
+    one row boundary lies between two probes -- and every candidate of every row is some lane's, exactly once."""
+    rng = np.random.default_rng(pack_min)
+    for trial in range(30):
+        nrows = int(rng.integers(1, 400))
+        cnt = rng.integers(0, 200, nrows)
+        cnt[rng.random(nrows) < 0.4] = 0                                   # rows without candidates
+        if trial % 5 == 0:
+            cnt[:] = rng.integers(0, 3, nrows)                             # nearly all rows tiny
+        if cnt.sum() == 0:
+            cnt[0] = 1
+        cost = np.where(cnt > 0, np.maximum(cnt, pack_min), 0)
+        inc = np.cumsum(cost)                                              # chunk_inc
+        total = int(inc[-1])
+        nprobe = (128 + pack_min - 1) // pack_min + 1
+        seen = [np.zeros(c, dtype=np.int32) for c in cnt]
+        for item in range((total + 127) // 128):
+            u0 = item * 128
+            probes = [min(u0 + (127 if k == nprobe - 1 else k * pack_min), total - 1) for k in range(nprobe)]
+            pslot = [int(np.searchsorted(inc, u, side="right")) for u in probes]   # first slot whose inclusive cost exceeds u
+            assert len(set(pslot)) <= nprobe
+            for tid in range(128):
+                u = u0 + tid
+                k = tid // pack_min
+                sa, sb = pslot[k], pslot[k + 1]
+                slot = sb if (sb != sa and u >= inc[sb - 1]) else sa
+                start = inc[slot - 1] if slot else 0
+                if u < total:
+                    assert slot == int(np.searchsorted(inc, u, side="right")), (trial, item, tid)
+                    q = u - start
+                    assert q >= 0
+                    if q < cnt[slot]:
+                        seen[slot][q] += 1
+                        # the row's index among the item's staged rows exists
+                        distinct = [pslot[0]] + [pslot[j] for j in range(1, nprobe) if pslot[j] != pslot[j - 1]]
+                        assert slot in distinct
+        for r in range(nrows):
+            assert np.all(seen[r] == 1), (trial, r)
+
+
+def test_runs_that_name_the_same_rows_can_be_read_once():
+    """The claim behind sp_run_dedupe_kernel (compare_sparse_x.hip, opt-in): of the entries of a row whose runs hold
+    the same rows in the same order, all but one can lose their {lo, hi} -- the candidates of the row (the rows below it
+    named by ANY of its entries) stay the same.  Table: clades with a common core, members lacking one core value
+    (runs that differ in a single row), private values, bridges that are the only link of their pairs."""
+    rng = np.random.default_rng(5)
+    n, s = 120, 64
+    vals = np.sort(rng.choice(np.arange(1, 10 ** 6, dtype=np.uint64), 6000, replace=False))
+    core = [vals[:30], vals[30:60], vals[60:90]]
+    nxt = 90
+    rows = []
+    for i in range(n):
+        own = set(int(x) for x in core[i % 3])
+        if i % 5 == 0:
+            own.discard(int(core[i % 3][i % 30]))
+        for _ in range(int(rng.integers(0, 20))):
+            own.add(int(vals[nxt])); nxt += 1
+        rows.append(own)
+    for _ in range(40):
+        x, y = int(rng.integers(0, n)), int(rng.integers(0, n))
+        v = int(vals[nxt]); nxt += 1
+        rows[x].add(v); rows[y].add(v)
+    table = np.full((n, s), PAD, dtype=np.uint64)
+    nhash = np.zeros(n, dtype=np.uint32)
+    for i, own in enumerate(rows):
+        r = np.array(sorted(own), dtype=np.uint64)[:s]
+        table[i, : len(r)] = r
+        nhash[i] = len(r)
+    ix = build_index(table, nhash, s)
+    dropped_total = 0
+    for row in range(n):
+        full, kept = set(), set()
+        seen_runs = set()
+        for e in range(ix["off"][row], ix["off"][row + 1]):
+            g = ix["rank_of"][e]
+            lo, hi = ix["gstart"][g], ix["gstart"][g + 1]
+            run = tuple(ix["sorted_rows"][lo:hi])
+            below = [r for r in run if r < row]
+            full.update(below)
+            if len(below) == 0:
+                continue
+            if run in seen_runs:                                          # a copy of a run this row has read: skipped
+                dropped_total += 1
+                continue
+            seen_runs.add(run)
+            kept.update(below)
+        assert kept == full, row
+    assert dropped_total > 1000                                           # the cores: ~29 of 30 runs per row are copies
