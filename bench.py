@@ -101,6 +101,7 @@ def load_pmc(name, *src):
         return None
     if d.get("kernel_src_sha") != src_sha(*src):
         return None                                    # stale: the kernel changed since the counters were read
+    d.setdefault("source", "profiles/" + name)
     return d
 
 
