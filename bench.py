@@ -386,6 +386,42 @@ def main():
 
     if not dry:
         torch.cuda.synchronize()       # table generation (torch stream) -> library stream
+    # Several ranks: equal AREAS balance the fill (8 B per pair), not discovery and merge, which cost per ROW -- on C3 a
+    # row costs what 60 000 pairs cost, and the block of the short rows (a third of all rows at 8 ranks) would take twice
+    # its share.  One measured step with the equal-area split tells what a row costs on THIS table; the blocks are then
+    # cut so that pairs + row_weight x rows is the same for every rank (mg_shard_tri_rows_weighted).  Untimed.
+    row_weight = 0.0
+    if world > 1:
+        if dry:                        # (figures of C3's order, so that the exchange and the re-cut run under gloo)
+            fill_ms, dm_ms = my_pairs * 1.34e-9, (re - rb) * 8e-5
+        else:
+            eng.prof_enable(True)
+            eng.prof_reset()
+            step()
+            torch.cuda.synchronize()
+            fill_ms = dm_ms = 0.0
+            for name in ("compare_fill", "compare_discover", "compare_merge"):
+                ms, k = eng.prof_avg_ms(name)
+                if name == "compare_fill":
+                    fill_ms += ms * k
+                else:
+                    dm_ms += ms * k
+            eng.prof_enable(False)
+        cost = torch.tensor([fill_ms, dm_ms, float(my_pairs), float(re - rb)], dtype=torch.float64, device=dev)
+        dist.all_reduce(cost)
+        if float(cost[0]) > 0 and float(cost[2]) > 0 and float(cost[3]) > 0:
+            row_weight = (float(cost[1]) / float(cost[3])) / (float(cost[0]) / float(cost[2]))
+        if row_weight > 0:
+            if dry:
+                blocks = shard.weighted_row_blocks(n, world, row_weight)
+            else:
+                blocks = [abi.shard_tri_rows_weighted(eng.lib, 0, n, world, g, row_weight)[0] for g in range(world)] + [n]
+            rb, re = blocks[rank], blocks[rank + 1]
+            my_pairs = shard.tri_pairs(rb, re)
+            del out
+            out = torch.empty((max(my_pairs, 1), 2), dtype=torch.int32, device=dev)
+            if not dry:
+                torch.cuda.synchronize()
     cold_ms = None
     for w in range(args.warmup):
         tw = time.perf_counter()
@@ -428,7 +464,8 @@ def main():
         "config": {"workload": f"mash triangle all-vs-all, {n} clustered synthetic sketches, k={K} s={S}, "
                                f"{total_pairs} pairs/step, row-block sharded x{world}",
                    "n_sketches": n, "sketch_size": S, "kmer": K, "hash_bits": 64,
-                   "parallelism": f"rowblock{world}", "table_broadcast_ms": round(bcast_ms, 2),
+                   "parallelism": f"rowblock{world}", "rank_row_blocks": blocks, "row_weight_pairs": round(row_weight, 1),
+                   "table_broadcast_ms": round(bcast_ms, 2),
                    "rccl_ranks": rccl_ranks, "comm": comm_kind, "output_checksum": checksum,
                    "first_call_ms": round(cold_ms, 2) if cold_ms is not None else None,
                    "first_call_note": "the first (untimed, warm-up) call on a table builds what later calls reuse: the inverted "

@@ -331,6 +331,12 @@ mg_ctx  *mg_comm_ctx(mg_comm *c, int i);                                   /* lo
 const char *mg_comm_last_error(mg_comm *c);
 /* rows [row_begin,row_end) of the lower triangle -> block of `rank`: equal numbers of pairs */
 void     mg_shard_tri_rows(uint64_t row_begin, uint64_t row_end, int nranks, int rank, uint64_t *b_out, uint64_t *e_out);
+/* The same with a cost per row on top of the cost per pair (row i costs i + row_weight pair-units): the inverted-index
+ * engine writes 8 bytes per pair but discovers and merges per row, so equal areas overload the block of the short rows.
+ * bench.py measures row_weight on the table in its warm-up (time per row of discover + merge over time per pair of the
+ * fill, summed over the ranks).  row_weight <= 0: mg_shard_tri_rows. */
+void     mg_shard_tri_rows_weighted(uint64_t row_begin, uint64_t row_end, int nranks, int rank, double row_weight,
+                                    uint64_t *b_out, uint64_t *e_out);
 void     mg_shard_rows(uint64_t row_begin, uint64_t row_end, int nranks, int rank, uint64_t *b_out, uint64_t *e_out);
 int      mg_dtable_upload(mg_comm *c, const uint64_t *hashes, const uint32_t *nhash, const uint64_t *lengths,
                           uint64_t n, uint64_t s, mg_dtable **out);         /* host -> GPU 0 -> broadcast */

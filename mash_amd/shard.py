@@ -24,6 +24,27 @@ def equal_area_row_blocks(n, world):
     return b
 
 
+def weighted_row_blocks(n, world, row_weight):
+    """Boundaries when row i costs i + row_weight pair-units (mg_shard_tri_rows_weighted): the inverted-index engine
+    fills per pair but discovers and merges per row.  row_weight 0 = equal_area_row_blocks."""
+    if not row_weight > 0:
+        return equal_area_row_blocks(n, world)
+    cost = lambda r: r * (r - 1) // 2 + row_weight * r
+    total = cost(n)
+    b = [0]
+    for g in range(1, world):
+        want = total * g / world
+        h = row_weight - 0.5
+        r = int(max(0.0, min(float(n), -h + math.sqrt(h * h + 2.0 * want))))
+        while r > 0 and cost(r) > want:
+            r -= 1
+        while r < n and cost(r + 1) <= want:
+            r += 1
+        b.append(min(max(r, b[-1]), n))
+    b.append(n)
+    return b
+
+
 def tri_pairs(row_begin, row_end):
     t = lambda x: x * (x - 1) // 2 if x else 0
     return t(row_end) - t(row_begin)

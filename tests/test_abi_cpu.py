@@ -167,3 +167,28 @@ def test_comm_without_gpu_fails_loudly(lib):
     devs = (C.c_int * 2)(0, 1)
     assert lib.mg_comm_create_local(devs, 2, C.byref(h)) != 0
     assert b"HIP" in lib.mg_comm_last_error(None) or b"device" in lib.mg_comm_last_error(None)
+
+
+def test_weighted_shard_balances_pairs_plus_rows(lib):
+    """mg_shard_tri_rows_weighted: row i costs i + w pair-units (the inverted-index engine fills per pair and discovers
+    and merges per row).  Blocks tile the range, every block's cost is the same to within a row's cost, weight 0 is the
+    equal-area split, and the Python mirror bench.py's dry path uses gives the same boundaries."""
+    from mash_amd import shard
+    for n, rb in ((100_000, 0), (100_000, 1), (12_345, 777), (9, 0), (2, 1), (5, 5), (1, 0)):
+        for G in (1, 2, 3, 8):
+            for w in (0.0, 1.0, 750.5, 6e4, 1e7):
+                prev, costs = rb, []
+                for g in range(G):
+                    b, e = abi.shard_tri_rows_weighted(lib, rb, n, G, g, w)
+                    assert b == prev and b <= e <= max(n, rb), (n, rb, G, g, w, b, e)
+                    costs.append(abi.tri_pairs(b, e) + w * (e - b))
+                    prev = e
+                assert prev == max(n, rb)
+                if n - rb >= 64 * G:
+                    assert max(costs) - min(costs) <= 2 * (n + w), (n, rb, G, w, costs)
+                if w == 0.0:
+                    assert [abi.shard_tri_rows_weighted(lib, rb, n, G, g, w) for g in range(G)] == [abi.shard_tri_rows(lib, rb, n, G, g) for g in range(G)]
+                elif rb == 0:
+                    assert [abi.shard_tri_rows_weighted(lib, 0, n, G, g, w)[0] for g in range(G)] + [n] == shard.weighted_row_blocks(n, G, w)
+    # C3 at 8 ranks with a row worth 60 000 pairs: the first block shrinks from 35 355 rows to under 20 000
+    assert abi.shard_tri_rows(lib, 0, 100_000, 8, 0)[1] == 35_355 and abi.shard_tri_rows_weighted(lib, 0, 100_000, 8, 0, 6e4)[1] < 20_000

@@ -101,6 +101,11 @@ def test_bench_multirank_plumbing_dry(tmp_path):
     assert d["dry"] is True and d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong"
     assert d["rank_blocks"][0] == 0 and d["rank_blocks"][-1] == 300 and len(d["rank_blocks"]) == 3
     assert d["config"]["parallelism"] == "rowblock2" and d["config"]["table_broadcast_ms"] > 0
+    # the blocks were re-cut after the measured step: a row's cost in pairs came out of the all-reduce, and with it the
+    # first block is smaller than its equal-area size
+    from mash_amd import shard
+    assert d["config"]["row_weight_pairs"] > 0 and d["config"]["rank_row_blocks"] == d["rank_blocks"]
+    assert d["rank_blocks"][1] < shard.equal_area_row_blocks(300, 2)[1]
 
 
 # ------------------------------------------------------------------ read-sharded screen
