@@ -1,5 +1,5 @@
-// mshio_c.cpp — tiny C surface over the .msh codec and the fastx reader, for the CPU tests
-// (ctypes).  Host-only; no GPU dependency.
+// tests/mshio_c.cpp — tiny C surface over the .msh codec and the fastx reader of mash_amd/host/, for the CPU tests
+// (ctypes).  Test support: built as tests/libmshio.so by mash_amd/host/Makefile.  Host-only; no GPU dependency.
 #include <cstdio>
 #include <cstring>
 #include <string>

@@ -22,7 +22,7 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 @pytest.fixture(scope="module")
 def built():
     import __graft_entry__ as g
-    if not os.path.exists(MASH) or not os.path.exists(os.path.join(ROOT, "mash_amd", "libmshio.so")):
+    if not os.path.exists(MASH) or not os.path.exists(os.path.join(ROOT, "tests", "libmshio.so")):
         g.build()
     return True
 
@@ -70,7 +70,7 @@ def test_info_header_tabular_and_paste(built, tmp_path):
 def test_msh_wire_layout_and_foreign_encodings(built, tmp_path):
     """Wire-level checks of the hand-written codec: slot layout, seed
     default XOR, and reading what libcapnp may emit (multi-segment, far / double-far pointers)."""
-    lib = C.CDLL(os.path.join(ROOT, "mash_amd", "libmshio.so"))
+    lib = C.CDLL(os.path.join(ROOT, "tests", "libmshio.so"))
     g = str(tmp_path / "genomes.msh")
     run("json2msh", os.path.join(GOLD, "genomes.json"), g)
     assert lib.mshio_roundtrip_check(g.encode()) == 0
@@ -124,7 +124,7 @@ def test_multi_segment_writer_roundtrips_through_golden_dumps(built, tmp_path):
     """Files beyond one segment: structs stay in segment 0, lists move behind far pointers.
     Forced here with a tiny segment limit; `mash info -d` of the rewritten files still equals the
     reference's golden dumps, and the single-segment default is unchanged."""
-    lib = C.CDLL(os.path.join(ROOT, "mash_amd", "libmshio.so"))
+    lib = C.CDLL(os.path.join(ROOT, "tests", "libmshio.so"))
     lib.mshio_rewrite.restype = C.c_long
     lib.mshio_rewrite.argtypes = [C.c_char_p, C.c_char_p, C.c_ulonglong]
     for name in ("genomes", "reads"):
@@ -150,7 +150,7 @@ def test_multi_segment_writer_roundtrips_through_golden_dumps(built, tmp_path):
 
 
 def test_fastx_reader_has_kseq_semantics(built, tmp_path):
-    lib = C.CDLL(os.path.join(ROOT, "mash_amd", "libmshio.so"))
+    lib = C.CDLL(os.path.join(ROOT, "tests", "libmshio.so"))
     lib.fastx_count.restype = C.c_long
     tb, nb = C.c_ulonglong(), C.c_ulonglong()
     n = lib.fastx_count(os.path.join(GOLD, "reads1.fastq.gz").encode(), C.c_long(0), C.byref(tb), C.byref(nb))
@@ -231,7 +231,7 @@ def test_fastx_reader_matches_bytewise_kseq_on_random_input(built, tmp_path):
     """The buffered reader against the byte-by-byte state machine on byte soup: headers and
     '+' anywhere, blank / CR / control / high bytes, records across the 64 KiB refill boundary,
     truncated quality strings."""
-    lib = C.CDLL(os.path.join(ROOT, "mash_amd", "libmshio.so"))
+    lib = C.CDLL(os.path.join(ROOT, "tests", "libmshio.so"))
     lib.fastx_dump.restype = C.c_long
     lib.fastx_dump.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_ulonglong)]
     rng = np.random.default_rng(99)
@@ -262,7 +262,7 @@ def test_fastx_reader_on_pipes(built, tmp_path):
     descriptor before zlib gets it (the first record used to be lost)."""
     import gzip
     import threading
-    lib = C.CDLL(os.path.join(ROOT, "mash_amd", "libmshio.so"))
+    lib = C.CDLL(os.path.join(ROOT, "tests", "libmshio.so"))
     lib.fastx_dump.restype = C.c_long
     lib.fastx_dump.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_ulonglong)]
     body = b">a first\nACGTACGTAA\nCCGG\n>b\nTTTTGGGG\n@c q\nACGT\n+\nIIII\n"
