@@ -712,8 +712,9 @@ def test_compare_runs_that_name_the_same_rows(eng, oracle, monkeypatch):
 def test_compare_table_of_copies(eng, oracle, kernel, count, monkeypatch):
     """Nothing but copies of ONE sketch -- full, short (24 of s = 1000 hashes: two short sketches that share
     nothing would be {0, 48}, copies are {24, 24}) and of a single hash: every pair {c, c}; whole triangle and a row
-    range.  (The inverted-index engine answers such a table with its fill alone; tools/compare_fuzz.py found
-    the short-pairs pass overwriting it.)"""
+    range.  (With MASHGPU_SPARSE_ONE_CLASS=1 the inverted-index engine answers such a table with its fill alone;
+    tools/compare_fuzz.py found the short-pairs pass overwriting that fill before it shipped -- by default the pairs
+    inside a class of copies are written by their own kernel after the fill.)"""
     _set_kernel(monkeypatch, kernel)
     one, _, _ = synth.random_sketches(1, 1000, seed=4)
     n = 300
