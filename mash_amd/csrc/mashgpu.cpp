@@ -3567,15 +3567,25 @@ int mg_comm_allreduce_u32_sum(mg_comm *c, uint32_t *buf_dev, uint64_t count)
 
 // local mode: rows [rb, re) cut into one block per GPU, every GPU driven by its own host thread;
 // `fn(g, ctx, table replica(s), block begin, block end, pairs before the block)` does one block
+// What a row of a triangle job costs beyond its pairs, in pairs (mg_shard_tri_rows_weighted): jobs large enough for the
+// inverted-index engine fill per pair but discover and merge per row -- 60 s is C3's measured ratio (bench.py measures
+// it per table; here a constant has to do: an all-random table has a third of it, clades seven times as much).
+// MASHGPU_SHARD_ROW_WEIGHT overrides (0: equal areas).
+static double tri_row_weight(uint64_t rb, uint64_t re, uint64_t s)
+{
+    if (const char *e = getenv("MASHGPU_SHARD_ROW_WEIGHT")) return atof(e);
+    return tri_pairs(rb, re) >= 4000000ull ? 60.0 * (double)s : 0.0;
+}
+
 extern "C++" {
 template <class F>
-static int sharded_blocks(mg_comm *c, uint64_t rb, uint64_t re, bool triangle, uint64_t ncols, F fn)
+static int sharded_blocks(mg_comm *c, uint64_t rb, uint64_t re, bool triangle, uint64_t ncols, F fn, double row_weight = 0.0)
 {
     const int G = (int)c->ctxs.size();
     std::vector<uint64_t> b((size_t)G + 1);
     for (int g = 0; g <= G; g++) {
         uint64_t lo, hi;
-        if (triangle) mg_shard_tri_rows(rb, re, G, std::min(g, G - 1), &lo, &hi);
+        if (triangle) mg_shard_tri_rows_weighted(rb, re, G, std::min(g, G - 1), row_weight, &lo, &hi);
         else mg_shard_rows(rb, re, G, std::min(g, G - 1), &lo, &hi);
         b[(size_t)g] = g < G ? lo : hi;
     }
@@ -3686,7 +3696,7 @@ int mg_compare_tri_sharded_host(mg_comm *c, const mg_dtable *t, uint64_t row_beg
     if (row_begin >= row_end) return MG_OK;
     return sharded_blocks(c, row_begin, row_end, true, 0, [&](int g, uint64_t lo, uint64_t hi, uint64_t before) {
         return mg_compare_tri_host(c->ctxs[(size_t)g], t->t[(size_t)g], lo, hi, out_host + before);
-    });
+    }, tri_row_weight(row_begin, row_end, t->t[0]->s));
 }
 
 int mg_compare_rect_sharded_host(mg_comm *c, const mg_dtable *ref, const mg_dtable *qry, uint64_t q_begin, uint64_t q_end,
@@ -3718,7 +3728,7 @@ int mg_compare_tri_pairs_sharded_host(mg_comm *c, const mg_dtable *t, uint64_t r
     return sharded_blocks(c, row_begin, row_end, true, 0, [&](int g, uint64_t lo, uint64_t hi, uint64_t before) {
         return mg_compare_tri_pairs_host(c->ctxs[(size_t)g], t->t[(size_t)g], lo, hi, kmer_size, kmer_space, max_distance,
                                          max_p_value, out_host + before);
-    });
+    }, tri_row_weight(row_begin, row_end, t->t[0]->s));
 }
 
 int mg_compare_rect_pairs_sharded_host(mg_comm *c, const mg_dtable *ref, const mg_dtable *qry, uint64_t q_begin, uint64_t q_end,
@@ -3746,7 +3756,7 @@ int mg_compare_rect_pairs_sharded_host(mg_comm *c, const mg_dtable *ref, const m
 extern "C++" {
 template <class Call>
 static int sharded_results(mg_comm *c, uint64_t rb, uint64_t re, bool triangle, uint64_t ncols, mg_result *out_host,
-                           uint64_t capacity, uint64_t *count_out, Call call)
+                           uint64_t capacity, uint64_t *count_out, Call call, double row_weight = 0.0)
 {
     const size_t G = c->ctxs.size();
     std::vector<std::vector<mg_result>> part(G);
@@ -3761,7 +3771,7 @@ static int sharded_results(mg_comm *c, uint64_t rb, uint64_t re, bool triangle, 
         }
         v.resize(r == MG_OK ? n : 0);
         return r;
-    });
+    }, row_weight);
     if (rc != MG_OK) return rc;
     uint64_t total = 0;
     for (auto &v : part) total += v.size();
@@ -3790,7 +3800,7 @@ int mg_compare_tri_results_sharded_host(mg_comm *c, const mg_dtable *t, uint64_t
                            [&](int g, uint64_t lo, uint64_t hi, mg_result *o, uint64_t cap, uint64_t *n) {
         return mg_compare_tri_results_host(c->ctxs[(size_t)g], t->t[(size_t)g], lo, hi, kmer_size, kmer_space, max_distance,
                                            max_p_value, o, cap, n);
-    });
+    }, 10.0 * tri_row_weight(row_begin, row_end, t->t[0]->s));      // (thresholded: no matrix is filled, the cost is nearly all per row)
 }
 
 int mg_compare_rect_results_sharded_host(mg_comm *c, const mg_dtable *ref, const mg_dtable *qry, uint64_t q_begin,
