@@ -71,3 +71,15 @@ def test_every_committed_pmc_file_is_current():
     for leg in ("c3", "c5", "random", "identical", "clades"):
         assert bench.load_pmc(f"compare_{leg}_pmc.json", "mash_amd/csrc/compare_sparse.hip", "mash_amd/csrc/compare_merged.hip",
                               "mash_amd/csrc/compare_internal.h") is not None, leg
+
+
+def test_sketch_pmc_restamp_is_documented():
+    """profiles/sketch_pmc_latest.json was read on the round-2 sketch.hip; round 3 changed the file inside the probe
+    instantiation only, and the file was re-stamped after tools/isa_same.py showed the sketching kernel's instructions
+    unchanged -- the JSON says so, the report is committed, and the screen file (whose kernel did change) stays stale."""
+    d = json.load(open(os.path.join(ROOT, "profiles", "sketch_pmc_latest.json")))
+    assert bench.load_pmc("sketch_pmc_latest.json", "mash_amd/csrc/sketch.hip", "mash_amd/csrc/kmer_hash.h") is not None
+    assert "restamped" in d and "isa_same.py" in d["restamped"]["why"]
+    rep = open(os.path.join(ROOT, "profiles", "r03_sketch_isa_check.txt")).read()
+    assert "sketch_chunks_kernel<21, 0, 256, false>" in rep and "same multiset of instructions" in rep
+    assert bench.load_pmc("screen_pmc_latest.json", "mash_amd/csrc/sketch.hip", "mash_amd/csrc/kmer_hash.h", "mash_amd/csrc/screen.hip") is None
