@@ -4018,7 +4018,8 @@ int mg_screen_create(mg_ctx *ctx, const mg_params *p, const mg_table *db, mg_scr
     uint64_t slots = 1024;
     while (slots < 2 * db->n * db->s) slots <<= 1;
     sc->slots = slots;
-    if (db->n * db->s >= (1ull << 32)) { delete sc; return fail(ctx, MG_ERR_UNSUPPORTED, "mg_screen_create: more than 2^32 database hashes"); }
+    // (slots are addressed with 32 bits in the touched list and the rows-by-slot index: at most 2^32 slots = 2^31 hashes)
+    if (db->n * db->s > (1ull << 31)) { delete sc; return fail(ctx, MG_ERR_UNSUPPORTED, "mg_screen_create: more than 2^31 database hashes"); }
     sc->touched_cap = std::max<uint64_t>(db->n * db->s, 1);
     hipError_t e = hipMalloc(&sc->keys, slots * 8);
     if (e == hipSuccess) e = hipMalloc(&sc->obs, slots * 4);
