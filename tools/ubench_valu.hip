@@ -113,7 +113,8 @@ int main()
     hipMalloc(&d, 4096 * 16);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int waves : {4}) {
+    for (int waves : {1, 2, 4, 8}) {
+        // 1/2/4 waves per SIMD: one block per CU of 256/512/1024 threads; 8: two 1024-thread blocks per CU
         const int bt = waves >= 4 ? 1024 : 256 * waves;
         const int grid = waves == 8 ? 512 : 256;
         printf("--- %d wave(s) per SIMD (block %d threads, grid %d): wall-clock throughput ---\n", waves, bt, grid);
