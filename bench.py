@@ -2,39 +2,20 @@
 """bench.py — headline benchmark of the Mash hot path on MI355X.
 
 Metric (BASELINE.json): pairwise Mash distances/sec at s=1000, k=21 (64-bit hashes).
-Workload: BASELINE config 3 — `mash triangle`, all-vs-all on N=100 000 pre-built clustered
-synthetic sketches: 4.99995e9 pairs per step.  The table (800 MB) is resident
-in HBM on every rank before the timed region; a step = one full pass over the lower triangle,
-row-block sharded (equal-area blocks, mg_shard_tri_rows) across the ranks, each rank writing
-{numer, denom} for its rows into its own HBM buffer (8 B/pair).  Total work is fixed as N grows
-("scaling": "strong").  The only exchange is ONE broadcast of the table from rank 0 before the
-timed region, through the library's own RCCL communicator (mg_comm rank mode: ncclCommInitRank +
-ncclBroadcast inside libmashgpu; the 128-byte id travels through torch.distributed); it is
-reported separately (`config.table_broadcast_ms`, `config.rccl_ranks`).
+Workload: BASELINE config 3 — `mash triangle`, all-vs-all on N=100 000 pre-built clustered synthetic
+sketches: 4.99995e9 pairs per step.  The table (800 MB) is resident in HBM on every rank
+before the timed region.  A STEP IS THE PER-TABLE JOB, as `mash triangle` pays it once per table
+(CommandTriangle.cpp:129-139): every step starts from a table the library has not seen
+(mg_table_invalidate) -- inverted index built, candidates discovered, 8 B written for every pair, candidates
+merged -- row-block sharded across the ranks (mg_shard_tri_rows), each rank writing {numer, denom} for its
+rows into its own HBM buffer.  `warm_value` is the rate of further passes over a table whose index exists.
+Total work is fixed as N grows ("scaling": "strong").  The one exchange is the broadcast of the table from
+rank 0 before the timed region (mg_comm rank mode: ncclBroadcast inside libmashgpu; `config.rccl_ranks`).
 
-Same JSON line, further objects:
-  roofline      the kernels of one pass.  Default engine (compare_sparse.hip): fill (HBM-write bound,
-                the dominant kernel), discover, merge -- each timed with HIP events on the stream it
-                runs on.  `achieved`/`frac`: the fill kernel -- the 8 B of every pair (SURVEY 8d's
-                compulsory traffic, the output-write bound) over its launch time against the HBM peak;
-                `traffic`: its PMC bytes per launch.  `pass`: the whole pass against the same bound,
-                PMC bytes of the pass vs the compulsory ones.  `survey_8d_no_reuse_model`: the mandated
-                2*s*8+8 B per pair over the pass (bounds nothing here: a pair that shares no hash costs
-                8 written bytes).  `ports`: per kernel the share of every issue port (from
-                profiles/compare_<leg>_pmc.json -- dropped when the kernel sources differ from the ones
-                the counters were read on).
-  brackets      SURVEY §8d's extremes at the same size: all-random, all-identical, clades of 1000
-                near-identical sketches; each verified against the tile engine (a second, independent
-                implementation) or a closed form, each with the reference's compareSketches on a sample.
-  cpu_baseline  the reference's own compareSketches (oracle/_ref) on the host cores.
-  host_to_host  SURVEY §8d(i)/(ii): table in HOST memory -> results in HOST memory (PCIe included),
-                on a bounded sample, and the whole C3 triangle through the thresholded path.
-  sketch        BASELINE config 2 (10 000 x 1 Mbp, k=21 s=1000), bp/s, own roofline, cpu baselines
-                at 1 thread, at all cores, and the reference CLI incl. FASTA parsing.
-  screen        BASELINE config 4.
-  cli_e2e       `mash sketch -p 16` of 12 000 FASTA files, ours and the reference CLI on the same files in
-                this run (tools/sketch_e2e.py): wall time of the whole process, stages, bp/s.
-  c5            BASELINE config 5: triangle at s=10 000 (64-bit hashes, k=31 style), N=100 000.
+Output: the LAST stdout line is the headline, one compact JSON object (< 3 KB: metric, value, roofline,
+cpu_baseline, one scalar per secondary leg); a few short per-leg lines precede it; every detail (phases,
+ports, notes, samples) goes to bench_detail.json next to this file (and to gpurun_out/ when that exists).
+What the fields mean is written once, in DESIGN.md section 5.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--n-sketches 100000] [--n-genomes 10000]
 """
@@ -78,6 +59,7 @@ def parse_args():
     ap.add_argument("--n-reads", type=int, default=10_000_000)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--detail", default=None, help="where the full result goes (default: bench_detail.json next to this file, and gpurun_out/)")
     ap.add_argument("--dry-cpu", action="store_true",
                     help="plumbing test only (CI without GPUs): gloo + CPU tensors, no kernels, output marked dry")
     return ap.parse_args()
@@ -105,61 +87,56 @@ def load_pmc(name, *src):
     return d
 
 
-def compare_roofline(eng, pairs, n, s, steps, pmc, engine_hint=None):
-    """Roofline object of one triangle pass from the library's HIP-event records (mg_prof_*): which
-    engine ran, its kernels' times, the mandated algorithmic model, and what actually bounds it."""
+def compare_roofline(eng, pairs, n, s, steps, pmc):
+    """Roofline object of one triangle pass from the library's HIP-event records (mg_prof_*): which engine ran, its
+    phases' times (index = the per-table build, present in cold steps only), and the dominant kernel against the
+    bound that applies.  Meaning of every field: DESIGN.md section 5."""
     phases = {}
-    for name in ("compare", "compare_fill", "compare_discover", "compare_merge"):
+    for name in ("compare", "compare_index", "compare_discover", "compare_fill", "compare_merge"):
         ms, k = eng.prof_avg_ms(name)
         if k:
-            phases[name] = {"avg_launch_ms": round(ms, 4), "launches_per_pass": k / steps, "ms_per_pass": round(ms * k / steps, 4)}
-    sparse = "compare_fill" in phases
+            phases[name.replace("compare_", "")] = {"avg_ms": round(ms, 4), "per_pass": k / steps, "ms_per_pass": round(ms * k / steps, 4)}
+    sparse = "fill" in phases
     pass_ms = sum(v["ms_per_pass"] for v in phases.values())
-    bytes_per_pair = 2 * s * 8 + 8
-    model = pairs * bytes_per_pair / (pass_ms * 1e-3) / 1e9 if pass_ms > 0 else 0.0
     compulsory = pairs * 8 + n * s * 8 + n * 12           # every pair written once, the table read once
     traffic = pmc.get("hbm_bytes_per_pass") if pmc else None
-    no_reuse = {"bytes_per_pair": bytes_per_pair, "achieved": round(model, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(model / HBM_PEAK_GBS, 4),
-                "what": "SURVEY.md 8d's no-reuse streaming model (2*s*8+8 B per pair) over the summed kernel time of one pass"}
     whole = {"ms": round(pass_ms, 3), "traffic": traffic, "compulsory_bytes": compulsory,
              "traffic_over_compulsory": round(traffic / compulsory, 3) if traffic else None,
-             "measured_hbm_frac": round(traffic / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and pass_ms > 0 else None,
              "output_write_bound_frac": round(pairs * 8 / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if pass_ms > 0 else None}
+    model = pairs * (2 * s * 8 + 8) / (pass_ms * 1e-3) / 1e9 if pass_ms > 0 else 0.0
     if not sparse:
-        # the tile engine: one kernel per window, priced with the mandated model
+        # the tile engine: one kernel per window, priced with SURVEY 8d's no-reuse model (bounds nothing: DESIGN 4.1b)
         r = {"bound": "hbm", "achieved": round(model, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(model / HBM_PEAK_GBS, 4),
-             "traffic": traffic, "engine": "tiles (compare_merged.hip)", "kernel": "mg::compare_merged_kernel",
-             "kernel_ms": phases.get("compare", {}).get("avg_launch_ms"), "pass_ms": round(pass_ms, 3), "phases": phases,
-             "algorithmic_bytes_per_pair": bytes_per_pair, "pass": whole,
-             "note": "achieved/frac: SURVEY.md 8d's no-reuse model; every sketch is re-used from LDS/L2, so it bounds nothing (DESIGN 4.1b)"}
+             "traffic": traffic, "engine": "tiles", "kernel": "mg::compare_merged_kernel",
+             "kernel_ms": phases.get("compare", {}).get("avg_ms"), "phases": phases, "pass": whole}
     else:
-        # The inverted-index engine.  Its dominant kernel is the fill: it writes the 8 B of every pair -- SURVEY 8d's
-        # "compulsory traffic ... 8 B/pair written", the output-write bound of 1e12 pairs/s -- and reads nothing.
-        f = phases["compare_fill"]["ms_per_pass"]
+        # the inverted-index engine: the dominant kernel is the fill -- 8 B written per pair (SURVEY 8d's compulsory traffic)
+        f = phases["fill"]["ms_per_pass"]
         fill = pairs * 8 / (f * 1e-3) / 1e9
-        kname = "mg::sp_fill_const_wave_kernel"
+        kname = "mg::sp_fill_value_kernel"
         kp = (pmc or {}).get("kernels", {}).get(kname)
         r = {"bound": "hbm", "achieved": round(fill, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fill / HBM_PEAK_GBS, 4),
              "traffic": (kp["hbm_read_bytes_per_pass"] + kp["hbm_write_bytes_per_pass"]) if kp else None,
-             "engine": "inverted index (compare_sparse.hip)", "kernel": kname, "kernel_ms": phases["compare_fill"]["avg_launch_ms"],
-             "algorithmic_bytes_per_launch": pairs * 8, "algorithmic_bytes_per_pair": 8,
-             "pass_ms": round(pass_ms, 3), "phases": phases, "pass": whole, "survey_8d_no_reuse_model": no_reuse,
-             "note": ("achieved/frac: the dominant kernel of the pass, the fill -- algorithmic bytes = the 8 B {numer, denom} of every pair "
-                      "(SURVEY.md 8d: the compulsory traffic of the job, output-write bound) over its HIP-event time; `traffic`: its PMC "
-                      "bytes per launch.  `pass`: all kernels of one pass against the same bound and the PMC bytes of the whole pass "
-                      "against the compulsory ones.  `survey_8d_no_reuse_model`: the mandated 2*s*8+8 B per pair; a pair that shares no "
-                      "hash costs this engine 8 written bytes, so that model exceeds the HBM peak by orders of magnitude and bounds "
-                      "nothing.  discover / merge are bound by their issue ports (`ports`: each port on its own, never summed; PMC "
-                      "figures from profiles/, dropped when the kernel sources changed since).")}
-        if "compare_discover" not in phases and "compare_merge" not in phases:
-            r["note"] += "  (This table: every pair is inside a class of identical sketches; the fill phase is the plain fill plus sp_class_pairs_kernel.)"
+             "engine": "inverted index", "kernel": kname, "kernel_ms": phases["fill"]["avg_ms"],
+             "algorithmic_bytes_per_launch": pairs * 8, "phases": phases, "pass": whole,
+             "survey_8d_no_reuse_model_gbs": round(model, 1)}
     if pmc:
         r["ports"] = {k: dict(v.get("ports", {}), ms_per_pass=v.get("ms_per_pass"), effective_clock_ghz=v.get("effective_clock_ghz"),
                               hbm_bytes_per_pass=(v.get("hbm_read_bytes_per_pass", 0) + v.get("hbm_write_bytes_per_pass", 0)))
-                      for k, v in pmc.get("kernels", {}).items() if not v.get("cold_only")}
+                      for k, v in pmc.get("kernels", {}).items()}
         r["pmc_source"] = pmc.get("source")
     return r
+
+
+def compact_roofline(r):
+    """The few roofline fields of the headline line (everything else stays in bench_detail.json)."""
+    if not r or "phases" not in r:
+        return r
+    return {"bound": r["bound"], "kernel": r["kernel"], "kernel_ms": r["kernel_ms"], "achieved": r["achieved"], "peak": r["peak"],
+            "unit": r["unit"], "frac": r["frac"], "traffic": r["traffic"],
+            "pass": {"ms": r["pass"]["ms"], "phases_ms": {k: round(v["ms_per_pass"], 3) for k, v in r["phases"].items()},
+                     "traffic_over_compulsory": r["pass"]["traffic_over_compulsory"],
+                     "output_write_bound_frac": r["pass"]["output_write_bound_frac"]}}
 
 
 def cpu_baseline_compare(table_np, nhash_np, lengths_np, budget_s):
@@ -257,6 +234,83 @@ def cpu_baseline_sketch_cli(n_genomes, threads):
         subprocess.run(["rm", "-rf", d])
 
 
+def _num(x, digits=4):
+    """Short float for the headline line."""
+    if x is None or isinstance(x, (str, bool, int)):
+        return x
+    return float(f"{x:.{digits}g}")
+
+
+def headline_of(result):
+    """The compact object of the LAST stdout line (< 3 KB; DESIGN.md section 5 says what each field is)."""
+    cfg = result.get("config", {})
+    h = {k: result.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                    "scaling", "vs_baseline", "dtype", "data")}
+    h["value"], h["ms_per_step"] = _num(h["value"], 6), _num(h["ms_per_step"], 5)
+    h["config"] = {"workload": cfg.get("workload"), "parallelism": cfg.get("parallelism"), "output_checksum": cfg.get("output_checksum"),
+                   "first_call_ms": cfg.get("first_call_ms"), "rccl_ranks": cfg.get("rccl_ranks"),
+                   "table_broadcast_ms": cfg.get("table_broadcast_ms")}
+    h["warm_value"], h["warm_ms_per_step"] = _num(result.get("warm_value"), 6), _num(result.get("warm_ms_per_step"), 5)
+    if result.get("dry"):
+        h["dry"] = True
+        h["rank_blocks"] = result.get("rank_blocks")
+    h["roofline"] = compact_roofline(result.get("roofline"))
+    cb = result.get("cpu_baseline")
+    if cb:
+        h["cpu_baseline"] = {"value": _num(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                             "sample": cb["sample"][:160]}
+    sk, c5, scr, cli, br, hh = (result.get(k) or {} for k in ("sketch", "c5", "screen", "cli_e2e", "brackets", "host_to_host"))
+    if "value" in sk:
+        h["sketch_bp_s"] = _num(sk["value"])
+        h["sketch_h2h_bp_s"] = _num((sk.get("host_to_host") or {}).get("value"))
+        h["sketch_roofline_frac"] = (sk.get("roofline") or {}).get("frac")
+    if "value" in c5:
+        h["c5_pairs_s"], h["c5_warm_pairs_s"] = _num(c5["value"]), _num(c5.get("warm_value"))
+    if "value" in scr:
+        h["screen_reads_s"] = _num(scr["value"])
+    if cli:
+        h["cli_e2e_speedup"] = {k: _num(v.get("speedup_vs_reference")) for k, v in cli.items() if isinstance(v, dict) and "speedup_vs_reference" in v}
+    if br:
+        h["brackets_pairs_s"] = {k: [_num(v.get("value")), _num(v.get("warm_value"))] for k, v in br.items() if isinstance(v, dict) and "value" in v}
+    if "full_c3_thresholded" in hh:
+        h["h2h_thresholded_pairs_s"] = _num(hh["full_c3_thresholded"].get("value"))
+    errs = [k for k in ("sketch", "c5", "screen", "cli_e2e", "brackets", "host_to_host") if "error" in (result.get(k) or {})]
+    errs += [f"brackets.{k}" for k, v in br.items() if isinstance(v, dict) and "error" in v]
+    if errs:
+        h["leg_errors"] = errs
+    h["detail"] = "bench_detail.json"
+    return h
+
+
+def emit(result, detail_path=None):
+    """bench_detail.json (everything), a short line per secondary leg, and LAST the headline line."""
+    detail = json.dumps(result)
+    paths = [detail_path] if detail_path else [os.path.join(ROOT, "bench_detail.json"), os.path.join(ROOT, "gpurun_out", "bench_detail.json")]
+    for f in paths:
+        if os.path.isdir(os.path.dirname(os.path.abspath(f))):
+            try:
+                with open(f, "w") as fh:
+                    fh.write(detail + "\n")
+            except OSError:
+                pass
+    for leg in ("sketch", "screen", "c5", "host_to_host", "cli_e2e"):
+        v = result.get(leg)
+        if isinstance(v, dict):
+            short = {"leg": leg}
+            for k in ("value", "unit", "ms_per_step", "warm_value", "warm_ms_per_step", "error"):
+                if k in v:
+                    short[k] = _num(v[k], 5)
+            rf = v.get("roofline")
+            if isinstance(rf, dict):
+                short["roofline"] = compact_roofline(rf) if "phases" in rf else {k: rf.get(k) for k in ("bound", "kernel", "kernel_ms", "achieved", "peak", "unit", "frac", "traffic")}
+            line = json.dumps(short)
+            if len(line) < 1200:
+                print(line)
+    line = json.dumps(headline_of(result), separators=(",", ":"))
+    assert len(line) < 4000, f"headline line too long ({len(line)} bytes)"
+    print(line, flush=True)
+
+
 def main():
     args = parse_args()
     import torch
@@ -308,6 +362,10 @@ def main():
         def prof_avg_ms(self, name):
             return 0.0, 0
         def free(self):
+            pass
+        def invalidate(self):
+            pass
+        def trim(self):
             pass
         def close(self):
             pass
@@ -422,27 +480,44 @@ def main():
             out = torch.empty((max(my_pairs, 1), 2), dtype=torch.int32, device=dev)
             if not dry:
                 torch.cuda.synchronize()
-    cold_ms = None
+    # ---- the timed region: the PER-TABLE job.  Every step starts from a table the library has not seen
+    # (mg_table_invalidate drops the index and every plan; its blocks go back to the context's pool), as one
+    # `mash triangle` pays it (CommandTriangle.cpp:129-139): index build + discover + fill + merge.
+    def cold_step():
+        table.invalidate()
+        step()
+
+    first_call_ms = None
     for w in range(args.warmup):
         tw = time.perf_counter()
-        step()
+        cold_step()
         if w == 0 and not dry:
             torch.cuda.synchronize()
-            cold_ms = (time.perf_counter() - tw) * 1e3    # first call on the table: index build + counting pass + one pass
+            first_call_ms = (time.perf_counter() - tw) * 1e3    # the very first call of the process: also pays the hipMallocs
     eng.prof_enable(True)
+    eng.prof_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        cold_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    srcs = ("mash_amd/csrc/compare_sparse.hip", "mash_amd/csrc/compare_merged.hip", "mash_amd/csrc/compare_internal.h")
+    pmc = load_pmc("compare_c3_cold_pmc.json", *srcs) if (n == 100_000 and world == 1 and not dry) else None
+    roofline = compare_roofline(eng, my_pairs, n, S, args.steps, pmc) if not dry else {"bound": "hbm", "dry": True}
+    dt = max_over_ranks(dt)
+    value = total_pairs * args.steps / dt
+    # further passes over the same table (index and plan exist): the warm rate
     eng.prof_reset()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
-    dt = time.perf_counter() - t0
-    pmc = load_pmc("compare_c3_pmc.json", "mash_amd/csrc/compare_sparse.hip", "mash_amd/csrc/compare_merged.hip", "mash_amd/csrc/compare_internal.h") \
-        if (n == 100_000 and world == 1 and not dry) else None
-    roofline = compare_roofline(eng, my_pairs, n, S, args.steps, pmc) if not dry else {"bound": "hbm", "dry": True}
+    wdt = max_over_ranks(time.perf_counter() - t0)
+    pmc_w = load_pmc("compare_c3_pmc.json", *srcs) if (n == 100_000 and world == 1 and not dry) else None
+    roofline_warm = compare_roofline(eng, my_pairs, n, S, args.steps, pmc_w) if not dry else None
     eng.prof_enable(False)
-    dt = max_over_ranks(dt)
-    value = total_pairs * args.steps / dt
 
     # the produced output (outside the timed region): every pair's denom and numer, as sums
     checksum = None
@@ -461,16 +536,15 @@ def main():
         "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": f"mash triangle all-vs-all, {n} clustered synthetic sketches, k={K} s={S}, "
-                               f"{total_pairs} pairs/step, row-block sharded x{world}",
+        "config": {"workload": f"mash triangle all-vs-all, {n} clustered synthetic sketches, k={K} s={S}, {total_pairs} pairs/step, "
+                               f"per-table job (index build + discover + fill + merge each step), row-block sharded x{world}",
                    "n_sketches": n, "sketch_size": S, "kmer": K, "hash_bits": 64,
                    "parallelism": f"rowblock{world}", "rank_row_blocks": blocks, "row_weight_pairs": round(row_weight, 1),
                    "table_broadcast_ms": round(bcast_ms, 2),
                    "rccl_ranks": rccl_ranks, "comm": comm_kind, "output_checksum": checksum,
-                   "first_call_ms": round(cold_ms, 2) if cold_ms is not None else None,
-                   "first_call_note": "the first (untimed, warm-up) call on a table builds what later calls reuse: the inverted "
-                                      "index of the table (sort of all its hashes) and the job's candidate count"},
-        "roofline": roofline,
+                   "first_call_ms": round(first_call_ms, 2) if first_call_ms is not None else None},
+        "warm_value": total_pairs * args.steps / wdt, "warm_ms_per_step": wdt * 1e3 / args.steps,
+        "roofline": roofline, "roofline_warm": roofline_warm,
     }
     if dry:
         result["dry"] = True               # plumbing test: NOT a measurement
@@ -485,50 +559,71 @@ def main():
             lengths[:m].cpu().numpy().astype(np.uint64), args.cpu_seconds)
 
     # ------------------------------------------------------------------ SURVEY 8d brackets (N=1): the extremes of the merge
+    # value = the per-table job (every step from an invalidated table), warm_value = further passes
     if single and not args.no_brackets:
         br = {}
-        gens = [("all_random", "random", lambda: synth_torch.random_sketch_table(n, S, device=dev)),
-                ("all_identical", "identical", lambda: synth_torch.identical_sketch_table(n, S, device=dev)),
-                ("clades_of_1000", "clades", lambda: synth_torch.clade_sketch_table(n, S, device=dev))]
-        bsteps = max(2, args.steps)
-        for name, leg, gen in gens:
+        n1 = min(n, 32768)
+        gens = [("all_random", "random", n, lambda: synth_torch.random_sketch_table(n, S, device=dev)),
+                ("all_identical", "identical", n, lambda: synth_torch.identical_sketch_table(n, S, device=dev)),
+                ("clades_of_1000", "clades", n, lambda: synth_torch.clade_sketch_table(n, S, device=dev)),
+                # the worst case of an engine that pays per candidate: ONE clade -- every pair shares ~900 of 1000 hashes
+                ("one_clade", "one_clade", n1, lambda: synth_torch.clade_sketch_table(n1, S, clade=n1, device=dev))]
+        bsteps = max(2, min(args.steps, 5))
+        for name, leg, bn_rows, gen in gens:
             try:
                 bh, bn, bl = gen()
+                bpairs = bn_rows * (bn_rows - 1) // 2
                 torch.cuda.synchronize()
-                bt = eng.table_wrap(bh.data_ptr(), bn.data_ptr(), bl.data_ptr(), n, S, keep=(bh, bn, bl))
-                eng.compare_tri_dev(bt, 0, n, out.data_ptr())                       # warm-up: index, counting pass
+                bt = eng.table_wrap(bh.data_ptr(), bn.data_ptr(), bl.data_ptr(), bn_rows, S, keep=(bh, bn, bl))
+                eng.compare_tri_dev(bt, 0, bn_rows, out.data_ptr())                 # warm-up (pool, plan)
                 eng.prof_enable(True)
                 eng.prof_reset()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for _ in range(bsteps):
-                    eng.compare_tri_dev(bt, 0, n, out.data_ptr())
+                    bt.invalidate()
+                    eng.compare_tri_dev(bt, 0, bn_rows, out.data_ptr())
                 torch.cuda.synchronize()
                 bd = time.perf_counter() - t0
+                rf_cold = compare_roofline(eng, bpairs, bn_rows, S, bsteps, None)
+                eng.prof_reset()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(bsteps):
+                    eng.compare_tri_dev(bt, 0, bn_rows, out.data_ptr())
+                torch.cuda.synchronize()
+                bw = time.perf_counter() - t0
                 bpmc = load_pmc(f"compare_{leg}_pmc.json", "mash_amd/csrc/compare_sparse.hip", "mash_amd/csrc/compare_merged.hip",
                                 "mash_amd/csrc/compare_internal.h") if n == 100_000 else None
-                rf = compare_roofline(eng, total_pairs, n, S, bsteps, bpmc)
+                rf = compare_roofline(eng, bpairs, bn_rows, S, bsteps, bpmc)
                 eng.prof_enable(False)
-                sums = [int(out[:, 0].sum(dtype=torch.int64).item()), int(out[:, 1].sum(dtype=torch.int64).item())]
+                o = out[:bpairs]
+                sums = [int(o[:, 0].sum(dtype=torch.int64).item()), int(o[:, 1].sum(dtype=torch.int64).item())]
                 if name == "all_identical":
-                    assert sums == [total_pairs * S, total_pairs * S], f"{name}: {sums}"
+                    assert sums == [bpairs * S, bpairs * S], f"{name}: {sums}"
                     how = "closed form: every pair s/s"
                 else:
-                    os.environ["MASHGPU_COMPARE_KERNEL"] = "merged"                 # the tile engine: independent code
+                    # an independent implementation on the same table: the tile engine (every pair), or -- where that one is
+                    # the engine under test -- the generic kernel on the last rows
+                    os.environ["MASHGPU_COMPARE_KERNEL"] = "merged" if rf.get("engine") != "tiles" else "generic"
                     try:
-                        out.zero_()
-                        eng.compare_tri_dev(bt, 0, n, out.data_ptr())
+                        rb2 = 0 if rf.get("engine") != "tiles" else bn_rows - 64
+                        keep = o[rb2 * (rb2 - 1) // 2 if rb2 else 0:].clone()
+                        o.zero_()
+                        eng.compare_tri_dev(bt, rb2, bn_rows, out.data_ptr())
                         torch.cuda.synchronize()
                     finally:
                         os.environ.pop("MASHGPU_COMPARE_KERNEL", None)
-                    sums2 = [int(out[:, 0].sum(dtype=torch.int64).item()), int(out[:, 1].sum(dtype=torch.int64).item())]
-                    assert sums == sums2 and sums[1] == total_pairs * S, f"{name}: {sums} vs tile engine {sums2}"
-                    how = "sums over the full output equal the tile engine's (compare_merged.hip)"
-                br[name] = {"value": total_pairs * bsteps / bd, "unit": "pairs/s", "ms_per_step": bd * 1e3 / bsteps, "steps": bsteps,
-                            "mean_shared_hashes": round(sums[0] / total_pairs, 3), "output_checksum": sums, "verified": how,
-                            "roofline": rf}
+                    assert torch.equal(keep, out[:keep.shape[0]]), f"{name}: engines disagree"
+                    assert sums[1] == bpairs * S, f"{name}: {sums}"
+                    how = ("every pair equal to the tile engine's (compare_merged.hip)" if rb2 == 0 else
+                           "the last 64 rows equal to the generic kernel's (compare.hip)")
+                br[name] = {"value": bpairs * bsteps / bd, "unit": "pairs/s", "ms_per_step": bd * 1e3 / bsteps, "steps": bsteps,
+                            "warm_value": bpairs * bsteps / bw, "warm_ms_per_step": bw * 1e3 / bsteps, "n_sketches": bn_rows,
+                            "mean_shared_hashes": round(sums[0] / bpairs, 3), "output_checksum": sums, "verified": how,
+                            "roofline": rf_cold, "roofline_warm": rf}
                 if not args.no_cpu:
-                    m = min(n, 3000)
+                    m = min(bn_rows, 3000)
                     br[name]["cpu_baseline"] = cpu_baseline_compare(bh[:m].cpu().numpy().view(np.uint64), bn[:m].cpu().numpy().astype(np.uint32),
                                                                     bl[:m].cpu().numpy().astype(np.uint64), min(args.cpu_seconds, 4.0))
                 bt.free()
@@ -536,7 +631,7 @@ def main():
             except Exception as e:
                 br[name] = {"error": repr(e)}
         br["workload"] = (f"mash triangle on {n} sketches of s={S}: all-random (every sketch its own values), all-identical (n copies "
-                          f"of one sketch), clades of 1000 near-identical sketches (consecutive rows); {total_pairs} pairs per step")
+                          f"of one sketch), clades of 1000 near-identical sketches (consecutive rows); one clade of {n1} distinct near-copies")
         result["brackets"] = br
 
     # ------------------------------------------------------------------ host to host, N=1
@@ -619,14 +714,17 @@ def main():
         sk_pmc = load_pmc("sketch_pmc_latest.json", "mash_amd/csrc/sketch.hip", "mash_amd/csrc/kmer_hash.h") \
             if (world == 1 and args.n_genomes == 10_000 and L == 1_000_000) else None
         sk_ach = sk_bytes / (sk_ms * 1e-3) / 1e9 if sk_ms > 0 else 0.0
-        sk_issue = None
+        sk_valu = None
         if sk_pmc and sk_ms > 0:
-            ipk = sk_pmc["valu_per_kmer"] + sk_pmc["salu_per_kmer"]
-            ach = ipk * ng * (L - K + 1) / (sk_ms * 1e-3)
-            peak = SIMDS * CLOCK_HZ / 4.0
-            sk_issue = {"achieved": round(ach / 1e9, 2), "peak": round(peak / 1e9, 2), "unit": "G wave-instr/s",
-                        "frac": round(ach / peak, 4), "valu_per_kmer": sk_pmc["valu_per_kmer"],
-                        "salu_per_kmer": sk_pmc["salu_per_kmer"], "source": sk_pmc.get("source")}
+            # the VALU port on its own (never summed with the scalar port: they issue side by side).  Issue cost measured
+            # with tools/ubench_valu.hip at 2-8 waves per SIMD (profiles/r04_ubench_valu.txt): ~2.7 cycles per wave64
+            # two-operand instruction, ~4.3 per three-operand one (v_alignbit, v_mad_u64_u32, v_add3, v_perm, v_mul_lo)
+            # (valu_per_kmer: wave-instructions per k-mer = instructions a lane executes per k-mer / 64)
+            ach = sk_pmc["valu_per_kmer"] * ng * (L - K + 1) / (sk_ms * 1e-3)              # wave-instructions / s
+            sk_valu = {"valu_lane_instr_per_kmer": round(sk_pmc["valu_per_kmer"] * 64, 1), "achieved": round(ach / 1e9, 2), "unit": "G wave-instr/s",
+                       "cycles_per_wave_instr": round(SIMDS * CLOCK_HZ / ach, 3),
+                       "peak_2_cycle": round(SIMDS * CLOCK_HZ / 2.0 / 1e9, 1), "peak_4_cycle": round(SIMDS * CLOCK_HZ / 4.0 / 1e9, 1),
+                       "frac_of_2_cycle_peak": round(ach / (SIMDS * CLOCK_HZ / 2.0), 4), "source": sk_pmc.get("source")}
         sketch = {"metric": "sketched bp/sec (k=21, s=1000)", "value": args.n_genomes * L * sk_steps / sdt,
                   "unit": "bp/s", "ms_per_step": sdt * 1e3 / sk_steps, "steps": sk_steps,
                   "config": {"workload": f"sketch {args.n_genomes} synthetic {L} bp genomes, k={K} s={S}, "
@@ -635,10 +733,7 @@ def main():
                                "frac": round(sk_ach / HBM_PEAK_GBS, 4),
                                "traffic": sk_pmc.get("hbm_bytes_per_launch") if sk_pmc else None,
                                "kernel": "sketch_chunks_kernel<21,0,256,false>", "kernel_ms": round(sk_ms, 3),
-                               "launches": sk_launches, "issue": sk_issue,
-                               "note": "integer-ALU bound: one MurmurHash3_x64_128 per k-mer (10 64-bit multiplies on 32-bit "
-                                       "halves) keeps the VALU issuing every cycle; HBM traffic = algorithmic bytes (1 B/base "
-                                       "+ 8 s B/sketch), a few per cent of the HBM peak; `issue` is the bound that applies"}}
+                               "launches": sk_launches, "valu": sk_valu}}
         if single and not args.no_cpu:
             cores = min(os.cpu_count() or 1, 16)
             sketch["cpu_baseline"] = cpu_baseline_sketch(min(args.cpu_seconds, 6.0), 1)
@@ -839,6 +934,7 @@ def main():
             hashes = nhash = lengths = None
             gc.collect()
             torch.cuda.empty_cache()
+            eng.trim()                                   # the s = 1000 index blocks are of no use to this shape
             S5 = 10000
             n5 = n
             h5, nh5, l5 = synth_torch.clustered_sketch_table(n5, S5, clusters=max(1, n5 // 100), pool=15000, private=4000,
@@ -849,18 +945,27 @@ def main():
             out5 = torch.empty((pairs5, 2), dtype=torch.int32, device=dev)
             torch.cuda.synchronize()
             tc = time.perf_counter()
-            eng.compare_tri_dev(t5, 0, n5, out5.data_ptr())            # warm-up: inverted index (10^9 entries), counting pass
+            eng.compare_tri_dev(t5, 0, n5, out5.data_ptr())            # the first call of this shape: also pays the hipMallocs (32 GB of index)
             torch.cuda.synchronize()
-            cold5 = (time.perf_counter() - tc) * 1e3
+            first5 = (time.perf_counter() - tc) * 1e3
             eng.prof_enable(True)
             eng.prof_reset()
             torch.cuda.synchronize()
             steps5 = 2
             t0 = time.perf_counter()
-            for _ in range(steps5):
+            for _ in range(steps5):                                    # the per-table job
+                t5.invalidate()
                 eng.compare_tri_dev(t5, 0, n5, out5.data_ptr())
             torch.cuda.synchronize()
             d5 = time.perf_counter() - t0
+            rf5_cold = compare_roofline(eng, pairs5, n5, S5, steps5, None)
+            eng.prof_reset()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps5):                                    # further passes
+                eng.compare_tri_dev(t5, 0, n5, out5.data_ptr())
+            torch.cuda.synchronize()
+            w5 = time.perf_counter() - t0
             pmc5 = load_pmc("compare_c5_pmc.json", "mash_amd/csrc/compare_sparse.hip", "mash_amd/csrc/compare_merged.hip",
                             "mash_amd/csrc/compare_internal.h") if n5 == 100_000 else None
             rf5 = compare_roofline(eng, pairs5, n5, S5, steps5, pmc5)
@@ -871,10 +976,11 @@ def main():
             if want5 is not None:
                 assert sums5 == list(want5), f"c5 checksum {sums5} != verified {want5}"
             c5.update({"value": pairs5 * steps5 / d5, "ms_per_step": d5 * 1e3 / steps5, "steps": steps5,
+                       "warm_value": pairs5 * steps5 / w5, "warm_ms_per_step": w5 * 1e3 / steps5,
                        "config": {"workload": f"mash triangle, {n5} clustered synthetic sketches of s={S5} 64-bit hashes "
-                                              f"(k=31 style), {pairs5} pairs/step, 1 GPU", "output_checksum": sums5,
-                                  "first_call_ms": round(cold5, 1)},
-                       "roofline": rf5})
+                                              f"(k=31 style), {pairs5} pairs/step, per-table job, 1 GPU", "output_checksum": sums5,
+                                  "first_call_ms": round(first5, 1)},
+                       "roofline": rf5_cold, "roofline_warm": rf5})
             t5.free()
             del out5, h5
         except Exception as e:
@@ -887,13 +993,14 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import sketch_e2e
             torch.cuda.synchronize()
-            result["cli_e2e"] = sketch_e2e.run(genomes=12000, length=50000, threads=16, reps=3)
-            result["cli_e2e"]["host_cores"] = os.cpu_count()
+            sk_cli = sketch_e2e.run(genomes=12000, length=50000, threads=16, reps=3)
+            sk_cli["speedup_vs_reference"] = sk_cli.get("speedup_vs_ref_same_threads")
+            result["cli_e2e"] = {"sketch": sk_cli, "host_cores": os.cpu_count()}
         except Exception as e:
             result["cli_e2e"] = {"error": repr(e)}
 
     if rank == 0:
-        print(json.dumps(result))
+        emit(result, args.detail)
     if table is not None:
         table.free()
     if comm is not None:

@@ -100,6 +100,11 @@ int         mg_ctx_synchronize(mg_ctx *ctx);
  * queued behind on the same stream) completes them, and an error of a queued kernel is reported
  * by the next synchronising call.  Default off: *_dev calls return with their output complete. */
 int         mg_ctx_set_async(mg_ctx *ctx, int on);
+/* Device blocks that finished calls and freed / invalidated tables handed back are kept by the context for the
+ * next call (small scratch: 256 MiB; large blocks -- the inverted index of a table, candidate lists -- up to
+ * 48 GiB, so that the next table of the same shape pays no hipMalloc).  mg_ctx_trim waits for the context's
+ * stream and returns all of them to the driver; they are also dropped whenever an allocation fails. */
+int         mg_ctx_trim(mg_ctx *ctx);
 /* Number of CUs of the device (for callers sizing work). */
 int         mg_ctx_cu_count(mg_ctx *ctx);
 
@@ -207,6 +212,13 @@ int  mg_table_upload(mg_ctx *ctx, const uint64_t *hashes, const uint32_t *nhash,
 int  mg_table_wrap_dev(mg_ctx *ctx, const uint64_t *hashes_dev, const uint32_t *nhash_dev,
                        const uint64_t *lengths_dev, uint64_t n, uint64_t s, mg_table **out);
 void mg_table_free(mg_table *t);
+/* The contents of the table's buffers changed (a wrapped buffer was refilled, an uploaded one written to): drop
+ * everything derived from them -- row maxima, density classes, prefix images, window offsets, the inverted index
+ * and its plans.  The next compare call rebuilds what it needs, as the first call on a fresh table does (the
+ * reference pays that per command: it re-reads and re-walks its sketches for every `mash triangle`,
+ * CommandTriangle.cpp:101-139).  Without it a table whose buffers changed is answered from a stale index; the
+ * candidate-count check of a pass catches most such cases ("the table changed since its index was built"), not all. */
+int  mg_table_invalidate(mg_table *t);
 uint64_t mg_table_rows(const mg_table *t);
 uint64_t mg_table_sketch_size(const mg_table *t);
 

@@ -21,11 +21,11 @@ HASH_PAD = 0xFFFFFFFFFFFFFFFF
 RECORD_SEP = 0x0A
 
 EXPORTS = [
-    "mg_device_count", "mg_ctx_create", "mg_ctx_destroy", "mg_last_error", "mg_ctx_set_stream", "mg_ctx_synchronize", "mg_ctx_set_async",
+    "mg_device_count", "mg_ctx_create", "mg_ctx_destroy", "mg_last_error", "mg_ctx_set_stream", "mg_ctx_synchronize", "mg_ctx_set_async", "mg_ctx_trim",
     "mg_ctx_cu_count", "mg_params_init", "mg_sketch_host", "mg_sketch_dev", "mg_sketch_reads_host", "mg_sketch_begin", "mg_sketch_add",
     "mg_sketch_stage_capacity", "mg_sketch_stage", "mg_sketch_commit", "mg_sketch_end_sketch", "mg_sketch_pending", "mg_sketch_finish", "mg_sketch_session_free",
     "mg_reads_begin", "mg_reads_add_host", "mg_reads_finish", "mg_reads_reset", "mg_reads_free", "mg_table_upload",
-    "mg_table_wrap_dev", "mg_table_free", "mg_table_rows", "mg_table_sketch_size",
+    "mg_table_wrap_dev", "mg_table_free", "mg_table_invalidate", "mg_table_rows", "mg_table_sketch_size",
     "mg_compare_tri_dev", "mg_compare_tri_host", "mg_compare_rect_dev", "mg_compare_rect_host",
     "mg_compare_tri_filter_host", "mg_compare_rect_filter_host",
     "mg_finish_tri_host", "mg_finish_rect_host", "mg_distance", "mg_p_value",
@@ -207,6 +207,8 @@ def load_library():
     lib.mg_table_wrap_dev.argtypes = [vp, vp, vp, vp, u64, u64, C.POINTER(vp)]
     lib.mg_table_free.argtypes = [vp]
     lib.mg_table_free.restype = None
+    lib.mg_table_invalidate.argtypes = [vp]
+    lib.mg_ctx_trim.argtypes = [vp]
     lib.mg_table_rows.argtypes = [vp]
     lib.mg_table_rows.restype = u64
     lib.mg_table_sketch_size.argtypes = [vp]
@@ -331,6 +333,10 @@ class Table:
         if self.handle:
             self.eng.lib.mg_table_free(self.handle)
             self.handle = None
+
+    def invalidate(self):
+        """The buffers' contents changed: drop everything derived from them (mg_table_invalidate)."""
+        self.eng._check(self.eng.lib.mg_table_invalidate(self.handle))
 
     def __del__(self):
         try:
@@ -550,6 +556,10 @@ class MashGpu:
 
     def synchronize(self):
         self._check(self.lib.mg_ctx_synchronize(self.ctx))
+
+    def trim(self):
+        """Return the context's cached device blocks to the driver (mg_ctx_trim)."""
+        self._check(self.lib.mg_ctx_trim(self.ctx))
 
     def set_async(self, on=True):
         self._check(self.lib.mg_ctx_set_async(self.ctx, int(on)))

@@ -76,10 +76,15 @@ hipError_t launch_compare_generic(const CompareArgs &a, hipStream_t stream);
 // the column table built once per table (mashgpu.cpp::table_sparse_index).
 struct SparseArgs {
     const uint32_t *sorted_rows;   // column table: row of the entry at every sorted position (value major, rows ascending)
-    const uint2 *lohi;             // per entry of the ROW side: [lo, hi) = run of partner rows in sorted_rows
+    // per entry of the ROW side (image layout, stride rs_row): [lo_img >> lo_shift, hi_img) = run of partner rows in
+    // sorted_rows.  Triangle: lo_img = the code image (2 x group start, lo_shift 1), hi_img = the position image (the
+    // entry's own sorted position: the rows BELOW it).  Rect: the located run of every query value (lo_shift 0).
+    const uint32_t *lo_img;
+    const uint32_t *hi_img;
+    uint32_t lo_shift;
     const uint32_t *off;           // row side: compact entry offsets (triangle: the table's; rect: the queries' from q_begin)
-    const uint32_t *row_img;       // row side code image (triangle: rank image; rect: query codes)
-    const uint32_t *col_img;       // column side rank image (codes 2 * rank)
+    const uint32_t *row_img;       // row side code image (triangle: the table's; rect: query codes)
+    const uint32_t *col_img;       // column side code image (codes 2 * start position of the value's group in the sorted index)
     const uint32_t *col_cnt_off;   // column side compact offsets (hash counts = differences)
     uint32_t rs_row, rs_col;       // row strides of the two images (multiples of 4, padded)
     uint32_t row_begin, row_end;   // rows handled (rect: 0 .. number of queries, relative to q_begin)
@@ -101,11 +106,20 @@ struct SparseArgs {
     const uint32_t *cls_of;
     const uint32_t *cls_off;
     const uint32_t *cls_rows;
-    const uint32_t *gstart;        // first sorted position of every value (a copy walks the whole run of a value)
+    const uint32_t *gend;          // at a group's start position: one past its last (a copy walks the whole run of a value)
     const uint32_t *order;         // rows of the launch in visiting order (nullptr: row_end - 1 - slot)
 };
-hipError_t launch_sparse_row_keys(const uint32_t *off, const uint32_t *rank_img, const uint32_t *gstart, uint32_t n, uint32_t rs,
-                                  uint32_t *key, hipStream_t stream);
+size_t sparse_dup_temp_bytes(uint32_t n);
+hipError_t launch_sparse_dup_suspects(const unsigned long long *dig, const uint32_t *cnt, uint32_t n, void *temp, size_t temp_bytes,
+                                      unsigned long long *dig_sorted, uint32_t *rows_sorted, uint32_t *flags, uint32_t *nflag,
+                                      hipStream_t stream);
+size_t sparse_order_temp_bytes(uint32_t n);
+hipError_t launch_sparse_row_order(const uint32_t *off, const uint32_t *code_img, const uint32_t *gend, const uint32_t *rep, uint32_t n,
+                                   uint32_t rs, void *temp, size_t temp_bytes, unsigned long long *key_a, unsigned long long *key_b,
+                                   uint32_t *order, hipStream_t stream);
+size_t sparse_order_slice_temp_bytes(uint32_t n);
+hipError_t launch_sparse_order_slice(const uint32_t *order, uint32_t n, uint32_t rb, uint32_t re, void *temp, size_t temp_bytes,
+                                     uint32_t *out, uint32_t *count_out, hipStream_t stream);
 hipError_t launch_sparse_class_pairs(uint2 *out, const uint32_t *cls_rows, const uint32_t *cls_first, const uint32_t *off,
                                      const uint32_t *rep, uint32_t members, uint32_t row_begin, uint32_t row_end, uint64_t out_base,
                                      hipStream_t stream);
@@ -117,12 +131,12 @@ size_t sparse_sort_temp_bytes(uint32_t E, uint32_t end_bit);
 uint32_t sparse_img_stride(uint32_t s);          // row stride of a code image
 hipError_t sparse_build_index(const uint64_t *hashes, uint64_t stride, const uint32_t *off, uint32_t n, uint32_t E,
                               uint32_t rs, uint32_t end_bit, void *temp, size_t temp_bytes, uint64_t *keys_a,
-                              uint32_t *eid_a, uint64_t *keys_sorted, uint32_t *eid_sorted, uint32_t *head, uint32_t *grp,
-                              uint32_t *gstart, uint32_t *sorted_rows, uint2 *lohi, uint32_t *rank_img,
-                              unsigned long long *incidences, uint32_t *max_group, uint32_t *bad, hipStream_t stream);
+                              uint32_t *idx_a, uint64_t *keys_sorted, uint32_t *idx_sorted, uint32_t *head, uint32_t *gs_of,
+                              uint32_t *sorted_rows, uint32_t *gend, uint32_t *code_img, uint32_t *pos_img,
+                              unsigned long long *incidences, uint32_t *max_group, uint32_t *groups, uint32_t *bad, hipStream_t stream);
 hipError_t launch_sparse_locate(const uint64_t *qhashes, uint64_t qstride, const uint32_t *qoff, uint32_t q_begin, uint32_t nq,
-                                const uint64_t *keys_sorted, const uint32_t *grp, const uint32_t *gstart, uint32_t E, uint32_t G,
-                                uint32_t rs, uint2 *qlohi, uint32_t *qcode_img, hipStream_t stream);
+                                const uint64_t *keys_sorted, const uint32_t *gend, uint32_t E, uint32_t rs, uint32_t *qlo_img,
+                                uint32_t *qhi_img, uint32_t *qcode_img, hipStream_t stream);
 bool sparse_discover_supported(uint32_t ncols_max);
 hipError_t launch_sparse_discover(const SparseArgs &a, bool count_only, hipStream_t stream);
 hipError_t launch_sparse_merge(const SparseArgs &a, uint64_t expect, uint32_t cus, hipStream_t stream);
@@ -134,7 +148,10 @@ hipError_t launch_sparse_scatter(const SparseArgs &a, uint64_t expect, uint32_t 
 size_t sparse_gather_temp_bytes(uint32_t nrows);
 hipError_t launch_sparse_gather_rows(const SparseArgs &a, uint32_t *cnt_by_row, uint32_t *row_base, void *temp, size_t temp_bytes, uint32_t row_add,
                                      uint2 *rc_out, uint2 *counts_out, hipStream_t stream);
-hipError_t launch_sparse_fill(uint2 *out, uint64_t pairs, uint32_t denom, uint32_t blocks_per_cu, uint32_t cus, hipStream_t stream);
+hipError_t launch_sparse_fill_value(uint2 *out, uint64_t pairs, uint32_t numer, uint32_t denom, uint32_t blocks_per_cu, uint32_t cus,
+                                    hipStream_t stream);
+hipError_t launch_sparse_merge_pack(const SparseArgs &a, uint64_t expect, uint32_t *chunks, void *temp, size_t temp_bytes, bool *used,
+                                    hipStream_t stream);
 hipError_t launch_sparse_fill_short(uint2 *out, const uint32_t *short_rows, const uint32_t *short_rcnt, uint32_t nshort_rows,
                                     const uint32_t *short_cols, const uint32_t *short_ccnt, uint32_t nshort_cols,
                                     uint32_t row_begin, uint32_t ncols, uint32_t triangle, uint64_t out_base, uint32_t s,

@@ -33,6 +33,8 @@
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 
 #include "compare_internal.h"
 
@@ -40,79 +42,78 @@ namespace mg {
 
 // ------------------------------------------------------------------------------------------------
 // index build
+//
+// Layout (round 4).  The code of an entry is 2 x the sorted position at which the GROUP of its value starts (the
+// start position orders and identifies the values exactly as their dense rank does, and it needs no second scan,
+// no gather).  Per table: keys_sorted[E], sorted_rows[E], gend[E] (defined at group starts: one past the group's
+// last position), the code image (n x rs, padded with 0xFFFFFFFF) and the position image (n x rs: the entry's OWN
+// sorted position, so [code / 2, own position) is the run of rows below it holding the same value).
+// The sort's payload is the entry's index in the images (row * rs + position in the row): the pass that writes
+// the images back needs neither a search for the row nor the compact entry ids.
 
-// compact entry ids: row r owns [off[r], off[r + 1]) -- its first min(nhash, s) hashes
+// keys[e] = value, idx[e] = image index; row r owns the compact range [off[r], off[r + 1]) -- its first min(nhash, s) hashes
 __global__ __launch_bounds__(256) void sp_fill_entries_kernel(const uint64_t *hashes, uint64_t stride, const uint32_t *off,
-                                                              uint64_t *keys, uint32_t *eid)
+                                                              uint32_t rs, uint64_t *keys, uint32_t *idx)
 {
     const uint32_t row = blockIdx.x;
     const uint32_t b = off[row], cnt = off[row + 1] - b;
     const uint64_t *src = hashes + (uint64_t)row * stride;
+    const uint32_t ib = row * rs;
     for (uint32_t p = threadIdx.x; p < cnt; p += 256) {
         keys[b + p] = src[p];
-        eid[b + p] = b + p;
+        idx[b + p] = ib + p;
     }
 }
 
-// head[pos] = 1 where a new value starts; inside a value the entry ids must ascend (the sort is
-// stable and ids ascend with the row), else *bad is set and the index is not used
-__global__ __launch_bounds__(256) void sp_heads_kernel(const uint64_t *keys, const uint32_t *eid, uint32_t E, uint32_t *head,
+// head[pos] = pos where a new value starts, else 0 (an inclusive max-scan then gives every position the start of
+// its group); inside a value the image indices must ascend (the sort is stable and they ascend with the row),
+// else *bad is set and the index is not used
+__global__ __launch_bounds__(256) void sp_heads_kernel(const uint64_t *keys, const uint32_t *idx, uint32_t E, uint32_t *head,
                                                        uint32_t *bad)
 {
     const uint32_t pos = blockIdx.x * 256u + threadIdx.x;
     if (pos >= E) return;
-    uint32_t h = 1;
+    uint32_t h = pos;
     if (pos > 0 && keys[pos] == keys[pos - 1]) {
         h = 0;
-        if (eid[pos] <= eid[pos - 1]) *bad = 1;
+        if (idx[pos] <= idx[pos - 1]) *bad = 1;
     }
     head[pos] = h;
 }
 
-// grp[pos] = inclusive scan of head = (group id + 1); gstart[g] = first sorted position of group g
-__global__ __launch_bounds__(256) void sp_gstart_kernel(const uint32_t *grp, uint32_t E, uint32_t *gstart)
-{
-    const uint32_t pos = blockIdx.x * 256u + threadIdx.x;
-    if (pos >= E) return;
-    const uint32_t g = grp[pos];
-    if (pos == 0 || grp[pos - 1] != g) gstart[g - 1] = pos;
-    if (pos == E - 1) gstart[g] = E;                      // end marker
-}
-
-// per sorted position: scatter {group start, own position} and the rank back to the entry, resolve the row
-__global__ __launch_bounds__(256) void sp_index_scatter_kernel(const uint32_t *eid, const uint32_t *grp, const uint32_t *gstart,
-                                                         const uint32_t *off, uint32_t n, uint32_t E, uint32_t rs,
-                                                         uint32_t *sorted_rows, uint2 *lohi, uint32_t *rank_img,
-                                                         unsigned long long *incidences, uint32_t *max_group)
+// per sorted position: the row, and the entry's code and own position back into the images; the last position of a
+// group leaves the group's end at the group's start
+__global__ __launch_bounds__(256) void sp_index_scatter_kernel(const uint64_t *keys, const uint32_t *idx, const uint32_t *gs_of, uint32_t E,
+                                                               uint32_t rs, uint32_t *sorted_rows, uint32_t *gend, uint32_t *code_img,
+                                                               uint32_t *pos_img, unsigned long long *incidences, uint32_t *max_group,
+                                                               uint32_t *groups)
 {
     const uint32_t pos = blockIdx.x * 256u + threadIdx.x;
     unsigned long long inc = 0;
-    uint32_t glen = 0;
+    uint32_t glen = 0, heads = 0;
     if (pos < E) {
-        const uint32_t e = eid[pos];
-        const uint32_t g = grp[pos] - 1;
-        const uint32_t gs = gstart[g];
-        // row of entry e: last r with off[r] <= e
-        uint32_t lo = 0, hi = n;                          // invariant: off[lo] <= e < off[hi]
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (off[mid] <= e) lo = mid; else hi = mid;
-        }
-        sorted_rows[pos] = lo;
-        lohi[e] = make_uint2(gs, pos);
-        rank_img[(uint64_t)lo * rs + (e - off[lo])] = g << 1;
+        const uint32_t i = idx[pos];
+        const uint32_t gs = gs_of[pos];
+        sorted_rows[pos] = i / rs;
+        code_img[i] = gs << 1;
+        pos_img[i] = pos;
         inc = pos - gs;
-        glen = gstart[g + 1] - gs;
+        heads = gs == pos ? 1u : 0u;
+        if (pos + 1u == E || keys[pos + 1u] != keys[pos]) {
+            gend[gs] = pos + 1u;
+            glen = pos + 1u - gs;
+        }
     }
     // block sums (one atomic per workgroup)
     for (int d = 32; d > 0; d >>= 1) {
         inc += __shfl_xor(inc, d);
+        heads += __shfl_xor(heads, d);
         const uint32_t o = __shfl_xor(glen, d);
         glen = o > glen ? o : glen;
     }
     __shared__ unsigned long long s_inc[4];
-    __shared__ uint32_t s_len[4];
-    if ((threadIdx.x & 63) == 0) { s_inc[threadIdx.x >> 6] = inc; s_len[threadIdx.x >> 6] = glen; }
+    __shared__ uint32_t s_len[4], s_heads[4];
+    if ((threadIdx.x & 63) == 0) { s_inc[threadIdx.x >> 6] = inc; s_len[threadIdx.x >> 6] = glen; s_heads[threadIdx.x >> 6] = heads; }
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned long long t = s_inc[0] + s_inc[1] + s_inc[2] + s_inc[3];
@@ -120,6 +121,7 @@ __global__ __launch_bounds__(256) void sp_index_scatter_kernel(const uint32_t *e
         for (int w = 1; w < 4; w++) m = s_len[w] > m ? s_len[w] : m;
         if (t) atomicAdd(incidences, t);
         if (m > 1) atomicMax(max_group, m);
+        atomicAdd(groups, s_heads[0] + s_heads[1] + s_heads[2] + s_heads[3]);
     }
 }
 
@@ -186,34 +188,131 @@ hipError_t launch_sparse_row_equal(const uint64_t *hashes, uint64_t stride, cons
     return hipGetLastError();
 }
 
-// key of a row for the order in which discovery visits the rows: the start of the run of its first value that
-// another row holds too (rows of one clade then sit next to each other and read the same runs), 0xFFFFFFFF
-// for a row that shares nothing
-__global__ __launch_bounds__(256) void sp_row_key_kernel(const uint32_t *off, const uint32_t *rank_img, const uint32_t *gstart, uint32_t n,
-                                                         uint32_t rs, uint32_t *key)
+// ---- copies, found on the device: rows sorted by digest (stable, so equal digests keep ascending rows); a row
+// whose digest and length equal its predecessor's is a suspect -- the host only looks at the sorted lists when
+// there are suspects at all
+__global__ __launch_bounds__(256) void sp_dup_flags_kernel(const unsigned long long *dig_sorted, const uint32_t *rows_sorted,
+                                                           const uint32_t *cnt, uint32_t n, uint32_t *flags, uint32_t *nflag)
 {
-    const uint32_t row = blockIdx.x * 256u + threadIdx.x;
-    if (row >= n) return;
-    const uint32_t cnt = off[row + 1] - off[row];
-    uint32_t k = 0xFFFFFFFFu;
-    for (uint32_t p = 0; p < cnt; p++) {
-        const uint32_t g = rank_img[(uint64_t)row * rs + p] >> 1;
-        const uint32_t gs = gstart[g];
-        if (gstart[g + 1] - gs >= 2u) { k = gs; break; }
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= n) return;
+    uint32_t f = 0;
+    if (k > 0 && dig_sorted[k] == dig_sorted[k - 1]) {
+        const uint32_t c = cnt[rows_sorted[k]];
+        f = (c != 0 && c == cnt[rows_sorted[k - 1]]) ? 1u : 0u;
     }
-    key[row] = k;
+    flags[k] = f;
+    if (f) atomicAdd(nflag, 1u);
 }
 
-hipError_t launch_sparse_row_keys(const uint32_t *off, const uint32_t *rank_img, const uint32_t *gstart, uint32_t n, uint32_t rs,
-                                  uint32_t *key, hipStream_t stream)
+size_t sparse_dup_temp_bytes(uint32_t n)
+{
+    size_t b = 0;
+    rocprim::radix_sort_pairs(nullptr, b, (const unsigned long long *)nullptr, (unsigned long long *)nullptr,
+                              rocprim::counting_iterator<uint32_t>(0u), (uint32_t *)nullptr, (size_t)n, 0u, 64u, (hipStream_t) nullptr);
+    return b;
+}
+
+// dig[n] -> dig_sorted[n], rows_sorted[n], flags[n], *nflag (zeroed here)
+hipError_t launch_sparse_dup_suspects(const unsigned long long *dig, const uint32_t *cnt, uint32_t n, void *temp, size_t temp_bytes,
+                                      unsigned long long *dig_sorted, uint32_t *rows_sorted, uint32_t *flags, uint32_t *nflag,
+                                      hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(sp_row_key_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, off, rank_img, gstart, n, rs, key);
+    hipError_t e = hipMemsetAsync(nflag, 0, 4, stream);
+    if (e != hipSuccess) return e;
+    e = rocprim::radix_sort_pairs(temp, temp_bytes, dig, dig_sorted, rocprim::counting_iterator<uint32_t>(0u), rows_sorted, (size_t)n, 0u, 64u,
+                                  stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sp_dup_flags_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, dig_sorted, rows_sorted, cnt, n, flags, nflag);
     return hipGetLastError();
+}
+
+// ---- visiting order of the rows.  Key of a row: the start of the run of its first value that another row holds too
+// (rows of one clade then sit next to each other and read the same runs), 0xFFFFFFFF for a row that shares nothing;
+// a copy reads what its representative reads; inside a key larger rows first.  The 64-bit sort key is
+// {key, ~row}; sorted ascending, the low words give the order.
+__global__ __launch_bounds__(256) void sp_row_key_kernel(const uint32_t *off, const uint32_t *code_img, const uint32_t *gend,
+                                                         const uint32_t *rep, uint32_t n, uint32_t rs, unsigned long long *key64)
+{
+    // one wave per row: 64 entries at a time, the first lane whose value another row holds too decides
+    const uint32_t row = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (row >= n) return;
+    const uint32_t er = rep ? rep[row] : row;
+    const uint32_t cnt = off[er + 1] - off[er];
+    uint32_t k = 0xFFFFFFFFu;
+    for (uint32_t base = 0; base < cnt; base += 64u) {
+        const uint32_t p = base + lane;
+        uint32_t gs = 0;
+        bool hit = false;
+        if (p < cnt) {
+            gs = code_img[(uint64_t)er * rs + p] >> 1;
+            hit = gend[gs] - gs >= 2u;
+        }
+        const uint64_t m = __ballot(hit);
+        if (m != 0) {
+            k = (uint32_t)__builtin_amdgcn_readlane((int)gs, __builtin_ctzll(m));
+            break;
+        }
+    }
+    if (lane == 0) key64[row] = ((unsigned long long)k << 32) | (unsigned long long)(0xFFFFFFFFu - row);
+}
+
+__global__ __launch_bounds__(256) void sp_order_from_keys_kernel(const unsigned long long *key64_sorted, uint32_t n, uint32_t *order)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) order[i] = 0xFFFFFFFFu - (uint32_t)(key64_sorted[i] & 0xFFFFFFFFull);
+}
+
+size_t sparse_order_temp_bytes(uint32_t n)
+{
+    size_t b = 0;
+    rocprim::radix_sort_keys(nullptr, b, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, (size_t)n, 0u, 64u,
+                             (hipStream_t) nullptr);
+    return b;
+}
+
+// key_a / key_b: scratch of n u64 each; order[n] out
+hipError_t launch_sparse_row_order(const uint32_t *off, const uint32_t *code_img, const uint32_t *gend, const uint32_t *rep, uint32_t n,
+                                   uint32_t rs, void *temp, size_t temp_bytes, unsigned long long *key_a, unsigned long long *key_b,
+                                   uint32_t *order, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(sp_row_key_kernel, dim3((n + 3u) / 4u), dim3(256), 0, stream, off, code_img, gend, rep, n, rs, key_a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    e = rocprim::radix_sort_keys(temp, temp_bytes, (const unsigned long long *)key_a, key_b, (size_t)n, 0u, 64u, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sp_order_from_keys_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, (const unsigned long long *)key_b, n, order);
+    return hipGetLastError();
+}
+
+// the rows of [rb, re) in the table's visiting order (order-preserving selection)
+struct sp_in_range {
+    uint32_t rb, re;
+    __device__ bool operator()(const uint32_t &r) const { return r >= rb && r < re; }
+};
+
+size_t sparse_order_slice_temp_bytes(uint32_t n)
+{
+    size_t b = 0;
+    rocprim::select(nullptr, b, (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)n, sp_in_range{0u, 0u},
+                    (hipStream_t) nullptr);
+    return b;
+}
+
+hipError_t launch_sparse_order_slice(const uint32_t *order, uint32_t n, uint32_t rb, uint32_t re, void *temp, size_t temp_bytes,
+                                     uint32_t *out, uint32_t *count_out, hipStream_t stream)
+{
+    return rocprim::select(temp, temp_bytes, order, out, count_out, (size_t)n, sp_in_range{rb, re}, stream);
 }
 
 // row stride of a code image: s rounded up to a chunk of four, plus one chunk the loop may load behind the row
 uint32_t sparse_img_stride(uint32_t s) { return ((s + 3u) & ~3u) + 4u; }
+
+struct sp_max_u32 {
+    __device__ uint32_t operator()(const uint32_t &a, const uint32_t &b) const { return a > b ? a : b; }
+};
 
 size_t sparse_sort_temp_bytes(uint32_t E, uint32_t end_bit)
 {
@@ -221,65 +320,59 @@ size_t sparse_sort_temp_bytes(uint32_t E, uint32_t end_bit)
     rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr, (const uint32_t *)nullptr,
                               (uint32_t *)nullptr, (size_t)E, 0u, end_bit, (hipStream_t) nullptr);
     size_t b2 = 0;
-    rocprim::inclusive_scan(nullptr, b2, (const uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)E, rocprim::plus<uint32_t>(),
-                            (hipStream_t) nullptr);
+    rocprim::inclusive_scan(nullptr, b2, (const uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)E, sp_max_u32(), (hipStream_t) nullptr);
     return bytes > b2 ? bytes : b2;
 }
 
-// All device buffers are the caller's.  keys_a / eid_a: scratch of E entries each (input of the sort),
-// keys_sorted / eid_sorted: its output; head: scratch of E u32.  On return (stream order) the index
-// arrays are complete; *bad != 0 means the order inside a value was not by row (never seen: the sort
-// is stable) and the index must not be used.
+// All device buffers are the caller's.  keys_a / idx_a: scratch of E entries each (input of the sort),
+// keys_sorted / idx_sorted: its output; head: scratch of E u32 (may be idx_a), gs_of: scratch of E u32.  On return
+// (stream order) the index arrays are complete; *bad != 0 means the order inside a value was not by row (never
+// seen: the sort is stable) and the index must not be used.  *incidences, *max_group, *groups, *bad: zeroed by the caller.
 hipError_t sparse_build_index(const uint64_t *hashes, uint64_t stride, const uint32_t *off, uint32_t n, uint32_t E,
                               uint32_t rs, uint32_t end_bit, void *temp, size_t temp_bytes, uint64_t *keys_a,
-                              uint32_t *eid_a, uint64_t *keys_sorted, uint32_t *eid_sorted, uint32_t *head, uint32_t *grp,
-                              uint32_t *gstart, uint32_t *sorted_rows, uint2 *lohi, uint32_t *rank_img,
-                              unsigned long long *incidences, uint32_t *max_group, uint32_t *bad, hipStream_t stream)
+                              uint32_t *idx_a, uint64_t *keys_sorted, uint32_t *idx_sorted, uint32_t *head, uint32_t *gs_of,
+                              uint32_t *sorted_rows, uint32_t *gend, uint32_t *code_img, uint32_t *pos_img,
+                              unsigned long long *incidences, uint32_t *max_group, uint32_t *groups, uint32_t *bad, hipStream_t stream)
 {
     if (n == 0 || E == 0) return hipSuccess;
-    hipLaunchKernelGGL(sp_fill_entries_kernel, dim3(n), dim3(256), 0, stream, hashes, stride, off, keys_a, eid_a);
+    hipLaunchKernelGGL(sp_fill_entries_kernel, dim3(n), dim3(256), 0, stream, hashes, stride, off, rs, keys_a, idx_a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    e = rocprim::radix_sort_pairs(temp, temp_bytes, (const uint64_t *)keys_a, keys_sorted, (const uint32_t *)eid_a, eid_sorted,
+    e = rocprim::radix_sort_pairs(temp, temp_bytes, (const uint64_t *)keys_a, keys_sorted, (const uint32_t *)idx_a, idx_sorted,
                                   (size_t)E, 0u, end_bit, stream);
     if (e != hipSuccess) return e;
     const uint32_t blocks = (E + 255u) / 256u;
-    hipLaunchKernelGGL(sp_heads_kernel, dim3(blocks), dim3(256), 0, stream, keys_sorted, eid_sorted, E, head, bad);
+    hipLaunchKernelGGL(sp_heads_kernel, dim3(blocks), dim3(256), 0, stream, keys_sorted, idx_sorted, E, head, bad);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    e = rocprim::inclusive_scan(temp, temp_bytes, (const uint32_t *)head, grp, (size_t)E, rocprim::plus<uint32_t>(), stream);
+    e = rocprim::inclusive_scan(temp, temp_bytes, (const uint32_t *)head, gs_of, (size_t)E, sp_max_u32(), stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(sp_gstart_kernel, dim3(blocks), dim3(256), 0, stream, grp, E, gstart);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    // padding of the rank image: larger than every code, so chunked loads past a row's end are harmless
+    // padding of the code image: larger than every code, so chunked loads past a row's end are harmless
     {
         const uint64_t total = (uint64_t)n * rs;
         uint64_t fb = (total + 1023) / 1024;
         if (fb > 8192) fb = 8192;
-        hipLaunchKernelGGL(sp_fill_u32_kernel, dim3((uint32_t)fb), dim3(256), 0, stream, rank_img, total, 0xFFFFFFFFu);
+        hipLaunchKernelGGL(sp_fill_u32_kernel, dim3((uint32_t)fb), dim3(256), 0, stream, code_img, total, 0xFFFFFFFFu);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(sp_index_scatter_kernel, dim3(blocks), dim3(256), 0, stream, eid_sorted, grp, gstart, off, n, E, rs, sorted_rows,
-                       lohi, rank_img, incidences, max_group);
+    hipLaunchKernelGGL(sp_index_scatter_kernel, dim3(blocks), dim3(256), 0, stream, (const uint64_t *)keys_sorted, (const uint32_t *)idx_sorted,
+                       (const uint32_t *)gs_of, E, rs, sorted_rows, gend, code_img, pos_img, incidences, max_group, groups);
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------
 // rect: locate the queries' values in the reference table's index
 
-// One thread per query entry (compact id over the query rows [q_begin, q_end)): code in the
-// reference table's rank space (2 * rank if the value occurs there, else the odd code between its
-// neighbours) and the run of rows holding the value.
+// One thread per query entry: code in the reference table's code space and the run of rows holding the value.
 __global__ __launch_bounds__(256) void sp_locate_kernel(const uint64_t *qhashes, uint64_t qstride, const uint32_t *qoff,
                                                         uint32_t q_begin, uint32_t nq, const uint64_t *keys_sorted,
-                                                        const uint32_t *grp, const uint32_t *gstart, uint32_t E, uint32_t G,
-                                                        uint32_t rs, uint2 *qlohi, uint32_t *qcode_img)
+                                                        const uint32_t *gend, uint32_t E, uint32_t rs, uint32_t *qlo_img,
+                                                        uint32_t *qhi_img, uint32_t *qcode_img)
 {
     const uint32_t q = blockIdx.x;                       // query index relative to q_begin
     if (q >= nq) return;
-    const uint32_t b = qoff[q], cnt = qoff[q + 1] - b;
+    const uint32_t cnt = qoff[q + 1] - qoff[q];
     const uint64_t *src = qhashes + (uint64_t)(q_begin + q) * qstride;
     for (uint32_t p = threadIdx.x; p < cnt; p += 256) {
         const uint64_t v = src[p];
@@ -288,17 +381,16 @@ __global__ __launch_bounds__(256) void sp_locate_kernel(const uint64_t *qhashes,
             const uint32_t mid = lo + ((hi - lo) >> 1);
             if (keys_sorted[mid] < v) lo = mid + 1; else hi = mid;
         }
-        // Codes of the query image: table codes are 2 * rank, and the merge adds one to every table
-        // code it loads in rect mode (an unsigned code cannot sit below rank 0 otherwise): a value
-        // found in group g gets 2g + 1 -- equal to the table's -- and a value between groups g - 1
-        // and g gets 2g (g = G: above every key), which is above 2(g - 1) + 1 and below 2g + 1.
-        const uint32_t g = lo < E ? grp[lo] - 1u : G;     // group of the first key >= v
+        // Codes of the query image: table codes are 2 * (start position of the value's group), and the merge adds
+        // one to every table code it loads in rect mode (an unsigned code cannot sit below the first group
+        // otherwise): a value found -- its lower bound IS its group's start -- gets 2 lo + 1, equal to the
+        // table's; a value between two groups gets 2 lo (lo = E: above every key), which is above the previous
+        // group's 2 gs + 1 (gs < lo) and below the next group's 2 lo + 1.
         const bool found = lo < E && keys_sorted[lo] == v;
-        const uint32_t code = found ? (g << 1) + 1u : (g << 1);
-        uint2 lh = make_uint2(0u, 0u);
-        if (found) lh = make_uint2(gstart[g], gstart[g + 1]);
-        qlohi[b + p] = lh;
-        qcode_img[(uint64_t)q * rs + p] = code;
+        const uint64_t at = (uint64_t)q * rs + p;
+        qcode_img[at] = found ? (lo << 1) + 1u : (lo << 1);
+        qlo_img[at] = lo;
+        qhi_img[at] = found ? gend[lo] : lo;
     }
 }
 
@@ -342,8 +434,18 @@ __global__ __launch_bounds__(256) void sp_discover_kernel(SparseArgs a)
     const uint32_t W = (ncols + 31u) >> 5;
     const uint32_t er = (DEDUP && a.triangle) ? a.rep[row] : row;      // the row whose index entries speak for this one
     const bool copy = DEDUP && a.triangle && er != row;
-    const uint32_t b = a.off[er], cnt = a.off[er + 1] - b;
+    const uint32_t cnt = a.off[er + 1] - a.off[er];
     if (cnt == 0 || ncols == 0) return;                  // uniform
+    if (!copy) {
+        // a row none of whose values is held by a row below it (most rows of a collection of unrelated genomes) has
+        // nothing to mark: neither the bitmap (n / 8 bytes of LDS to clear and to scan) nor the rest is needed
+        int any = 0;
+        for (uint32_t p = tid; p < cnt; p += 256u) {
+            const uint64_t at = (uint64_t)er * a.rs_row + p;
+            any |= (a.lo_img[at] >> a.lo_shift) != a.hi_img[at];
+        }
+        if (__syncthreads_or(any) == 0) return;          // uniform
+    }
     for (uint32_t w = tid; w < W; w += 256) bm[w] = 0;
     __syncthreads();
     unsigned long long inc = 0;
@@ -352,9 +454,10 @@ __global__ __launch_bounds__(256) void sp_discover_kernel(SparseArgs a)
         const uint32_t p = base + lane;
         uint2 lh = make_uint2(0u, 0u);
         if (p < cnt) {
-            lh = a.lohi[b + p];
+            const uint64_t at = (uint64_t)er * a.rs_row + p;
+            lh = make_uint2(a.lo_img[at] >> a.lo_shift, a.hi_img[at]);
             // a copy: the whole run of the value (its classes ascend; those at or above `row` are skipped below)
-            if (copy) lh.y = a.gstart[(a.row_img[(uint64_t)er * a.rs_row + p] >> 1) + 1u];
+            if (copy) lh.y = a.gend[lh.x];
         }
         const uint32_t len = lh.y - lh.x;
         inc += len;
@@ -773,6 +876,188 @@ __global__ __launch_bounds__(SPM_NT) void sp_merge_rows_win_kernel(SparseArgs a)
     }
 }
 
+// The same merge with SEVERAL rows per work item.  A collection's rows have tens of candidates each (C3: 0 ... 99,
+// 50 on average), so an item of one row fills half its lanes.  Here the candidates of all rows form one line of
+// UNITS in visiting order -- a row with candidates takes max(candidates, SPM_PACK_MIN) units, so that at most
+// SPM_PACK_ROWS rows meet in the 128 units of an item -- and item t takes units [128 t, 128 t + 128): every lane
+// finds its row among the item's (at most one row boundary lies between two units 32 apart, so the rows of the
+// units 0, 32, 64, 96 and 127 are all there are), all of them are staged in LDS, and the loop is the one above
+// with a per-lane row base.  Lanes on a row's padding units idle (C3: 9 % against 43 %).
+__global__ __launch_bounds__(256) void sp_pack_costs_kernel(const uint32_t *seg_cnt, uint32_t nrows, uint32_t pack_min, uint32_t *chunks)
+{
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r < nrows) {
+        const uint32_t c = seg_cnt[r];
+        chunks[r] = c ? (c < pack_min ? pack_min : c) : 0u;
+    }
+}
+
+// SPM_PACK_MIN: units a row with candidates takes at least (32: up to 5 rows per item, 43: 4, 64: 3 -- fewer rows staged
+// = more workgroups per CU, more padding units = more idle lanes)
+template <bool RECT, uint32_t SPM_PACK_MIN>
+__global__ __launch_bounds__(SPM_NT) void sp_merge_pack_kernel(SparseArgs a)
+{
+    constexpr uint32_t SPM_PACK_ROWS = (SPM_NT + SPM_PACK_MIN - 1u) / SPM_PACK_MIN + 1u;
+    extern __shared__ __align__(16) uint32_t lds[];
+    __shared__ uint32_t pslot[SPM_PACK_ROWS];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t nrows = a.row_end - a.row_begin;
+    const uint32_t total = a.chunk_inc[nrows - 1];         // units in all (inclusive scan of the rows' costs)
+    const uint32_t u0 = blockIdx.x * SPM_NT;
+    if (u0 >= total) return;
+    if (tid < SPM_PACK_ROWS) {                             // the rows of units 0, 32, 64, 96, 127 of this item
+        uint32_t u = u0 + (tid == SPM_PACK_ROWS - 1u ? SPM_NT - 1u : tid * SPM_PACK_MIN);
+        if (u >= total) u = total - 1u;
+        uint32_t lo = 0, hi = nrows - 1;                   // first slot whose inclusive cost exceeds u
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (a.chunk_inc[mid] > u) hi = mid; else lo = mid + 1;
+        }
+        pslot[tid] = lo;
+    }
+    __syncthreads();
+    const uint32_t s = a.s;
+    // stage the item's rows (copies are compared through their representatives)
+    {
+        uint32_t nd = 0;
+        for (uint32_t j = 0; j < SPM_PACK_ROWS; j++) {
+            if (j && pslot[j] == pslot[j - 1]) continue;
+            const uint32_t sl = pslot[j];
+            const uint32_t row = a.order ? a.order[sl] : a.row_end - 1u - sl;
+            const uint32_t ar = (a.rep && !RECT) ? a.rep[row] : row;
+            const uint32_t n = a.off[ar + 1] - a.off[ar];
+            const uint4 *src = reinterpret_cast<const uint4 *>(a.row_img + (uint64_t)ar * a.rs_row);
+            uint4 *dst = reinterpret_cast<uint4 *>(lds + nd * a.rs_row);
+            const uint32_t nvec = (n >> 2) + 1u;           // (and one chunk of the padding: A[nA] is read by a lane that has just finished)
+            for (uint32_t v = tid; v < nvec; v += SPM_NT) dst[v] = src[v];
+            nd++;
+        }
+    }
+    // this lane's unit -> row, candidate
+    const uint32_t u = u0 + tid;
+    const uint32_t sA = pslot[tid / SPM_PACK_MIN], sB = pslot[tid / SPM_PACK_MIN + 1u];
+    uint32_t slot = sA;
+    if (sB != sA && u >= a.chunk_inc[sB - 1u]) slot = sB;  // (sB > sA: the units before sB's first end with the slot before it)
+    const uint32_t q = u - (slot ? a.chunk_inc[slot - 1u] : 0u);
+    const uint32_t cnt = a.seg_cnt[slot];
+    const bool have = u < total && q < cnt;
+    uint32_t ridx = 0;
+#pragma unroll
+    for (uint32_t j = 1; j < SPM_PACK_ROWS; j++) ridx += (pslot[j] != pslot[j - 1] && pslot[j] <= slot) ? 1u : 0u;
+    const uint32_t row = a.order ? a.order[slot] : a.row_end - 1u - slot;
+    const uint32_t arow = (a.rep && !RECT) ? a.rep[row] : row;
+    const uint32_t nA = a.off[arow + 1] - a.off[arow];
+    const uint32_t *A = lds + ridx * a.rs_row;
+    const uint64_t at = a.seg_base[slot] + q;              // this lane's candidate (and result slot)
+    uint32_t *myring = lds + SPM_PACK_ROWS * a.rs_row + (tid >> 6) * (SPM_RING * 64u) + lane;   // code e of this lane: myring[(e & 31) * 64]
+    uint32_t j = have ? a.cand[at].y : 0u;
+    if (a.rep) j = a.rep[j];
+    const bool same = !RECT && a.rep != nullptr && j == arow;
+    const uint32_t nB = have ? a.col_cnt_off[j + 1] - a.col_cnt_off[j] : 0u;
+    const uint4 *B4 = reinterpret_cast<const uint4 *>(a.col_img + (uint64_t)j * a.rs_col);
+    auto land = [&](uint32_t e, const uint4 &v) {         // codes e .. e + 3 (e a multiple of 4)
+        uint32_t *p = myring + (e & (SPM_RING - 1u)) * 64u;
+        p[0] = v.x; p[64] = v.y; p[128] = v.z; p[192] = v.w;
+    };
+    {
+        const uint4 x0 = B4[0], x1 = B4[1], x2 = B4[2], x3 = B4[3];
+        land(0, x0); land(4, x1); land(8, x2); land(12, x3);
+    }
+    uint4 p0 = B4[4], p1 = B4[5];
+    uint32_t loaded = 16;
+    bool pend = true;
+    __syncthreads();                                     // rows staged
+    uint32_t ia = 0, ib = 0, denom = 0;                  // (common = ia + ib - denom)
+    bool active = have && !same && s > 0 && nA > 0 && nB > 0;
+    while (__ballot(active) != 0) {
+        uint32_t room = 0;
+        if (active) {
+            const uint32_t ra = nA - ia, rb = nB - ib, rd = s - denom;
+            room = ra < rb ? ra : rb;
+            room = room < rd ? room : rd;
+        }
+        if (__ballot(active && room < 8u) == 0) {
+            if (active) {
+#pragma unroll
+                for (int t = 0; t < 8; t++) {
+                    const uint32_t av = A[ia];
+                    uint32_t bv = myring[(ib & (SPM_RING - 1u)) * 64u];
+                    if (RECT) bv += 1u;
+                    ia += av <= bv ? 1u : 0u;
+                    ib += bv <= av ? 1u : 0u;
+                }
+                denom += 8;
+                active = denom < s && ia < nA && ib < nB;
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const uint32_t av = A[ia];
+                uint32_t bv = myring[(ib & (SPM_RING - 1u)) * 64u];
+                if (RECT) bv += 1u;
+                const bool adva = active && av <= bv, advb = active && bv <= av;
+                denom += active ? 1u : 0u;
+                ia += adva ? 1u : 0u;
+                ib += advb ? 1u : 0u;
+                active = active && denom < s && ia < nA && ib < nB;
+            }
+        }
+        if (pend) {
+            land(loaded, p0);
+            land(loaded + 4u, p1);
+            loaded += 8;
+        }
+        pend = active && loaded + 8u - ib <= SPM_RING;
+        if (pend) {
+            p0 = B4[loaded >> 2];
+            p1 = B4[(loaded >> 2) + 1u];
+        }
+    }
+    if (have) {
+        uint32_t common = ia + ib - denom;
+        if (same) {
+            common = denom = nA;
+        } else if (denom < s) {                            // :367-385
+            denom += (nA - ia) + (nB - ib);
+            if (denom > s) denom = s;
+        }
+        a.res[at] = make_uint2(common, denom);
+    }
+}
+
+// chunks / chunk_inc / temp as for launch_sparse_merge_rows; false in *used: the job is not one for this kernel (rows
+// longer than the LDS window, too much LDS) and the caller takes launch_sparse_merge_rows
+hipError_t launch_sparse_merge_pack(const SparseArgs &a, uint64_t expect, uint32_t *chunks, void *temp, size_t temp_bytes, bool *used,
+                                    hipStream_t stream)
+{
+    *used = false;
+    const uint32_t nrows = a.row_end - a.row_begin;
+    if (expect == 0 || nrows == 0) return hipSuccess;
+    uint32_t pack_min = 32;
+    if (const char *ev = getenv("MASHGPU_SPARSE_PACK_MIN")) pack_min = atoi(ev) >= 64 ? 64u : atoi(ev) >= 43 ? 43u : 32u;
+    const uint32_t pack_rows = (SPM_NT + pack_min - 1u) / pack_min + 1u;
+    const size_t smem = ((size_t)pack_rows * a.rs_row + (SPM_NT / 64u) * SPM_RING * 64u) * 4;
+    if (a.rs_row > SPM_AWIN + 8u || smem > 160 * 1024 - 256) return hipSuccess;
+    const uint64_t items = (expect + (uint64_t)pack_min * nrows) / SPM_NT + 1;
+    if (items >= (1ull << 31) || expect + (uint64_t)pack_min * nrows >= (1ull << 32)) return hipSuccess;
+    hipLaunchKernelGGL(sp_pack_costs_kernel, dim3((nrows + 255u) / 256u), dim3(256), 0, stream, a.seg_cnt, nrows, pack_min, chunks);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    e = rocprim::inclusive_scan(temp, temp_bytes, (const uint32_t *)chunks, a.chunk_inc, (size_t)nrows, rocprim::plus<uint32_t>(), stream);
+    if (e != hipSuccess) return e;
+    auto go = [&](auto kern) -> hipError_t {
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e2 != hipSuccess) return e2;
+        hipLaunchKernelGGL(kern, dim3((uint32_t)items), dim3(SPM_NT), smem, stream, a);
+        return hipGetLastError();
+    };
+    *used = true;
+    if (pack_min == 32) return a.triangle ? go(sp_merge_pack_kernel<false, 32>) : go(sp_merge_pack_kernel<true, 32>);
+    if (pack_min == 43) return a.triangle ? go(sp_merge_pack_kernel<false, 43>) : go(sp_merge_pack_kernel<true, 43>);
+    return a.triangle ? go(sp_merge_pack_kernel<false, 64>) : go(sp_merge_pack_kernel<true, 64>);
+}
+
+
 // candidates in REFERENCE order (rows ascending; a row's segment is already in column order): the rows'
 // counts (by row), then, after an exclusive scan, every segment copied to its row's place
 __global__ __launch_bounds__(256) void sp_row_counts_kernel(SparseArgs a, uint32_t *cnt_by_row)
@@ -867,26 +1152,40 @@ hipError_t launch_sparse_class_pairs(uint2 *out, const uint32_t *cls_rows, const
 
 typedef uint32_t sp_u32x4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void sp_fill_const_kernel(uint2 *out, uint64_t pairs, uint32_t denom)
+// every wave writes 4 KB of consecutive addresses per round (four 16-byte nontemporal stores 1 KB apart; 6.7 ms for the 40 GB of
+// C3 against 7.1 ms with four streams a grid apart, profiles/r03_sparse_tuning.json); {0, s} for a collection, {c, c} for a
+// table that is nothing but copies of one sketch
+__global__ __launch_bounds__(256) void sp_fill_value_kernel(uint2 *out, uint64_t pairs, uint32_t numer, uint32_t denom)
 {
-    // 16-byte stores over the aligned body, 8-byte stores for an unaligned first / odd last pair
     const uint64_t head = ((reinterpret_cast<uintptr_t>(out) & 8u) != 0 && pairs > 0) ? 1u : 0u;
     const uint64_t nvec = (pairs - head) >> 1;
     sp_u32x4 *body = reinterpret_cast<sp_u32x4 *>(out + head);
-    const sp_u32x4 v = {0u, denom, 0u, denom};
-    const uint64_t stride = (uint64_t)gridDim.x * 256u;
-    uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    for (; i + 3 * stride < nvec; i += 4 * stride) {
-        __builtin_nontemporal_store(v, body + i);
-        __builtin_nontemporal_store(v, body + i + stride);
-        __builtin_nontemporal_store(v, body + i + 2 * stride);
-        __builtin_nontemporal_store(v, body + i + 3 * stride);
+    const sp_u32x4 v = {numer, denom, numer, denom};
+    const uint64_t lane = threadIdx.x & 63u;
+    const uint64_t gw = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6), tw = (uint64_t)gridDim.x * 4u;
+    for (uint64_t base = gw * 256u; base < nvec; base += tw * 256u) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint64_t i = base + (uint64_t)u * 64u + lane;
+            if (i < nvec) __builtin_nontemporal_store(v, body + i);
+        }
     }
-    for (; i < nvec; i += stride) __builtin_nontemporal_store(v, body + i);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (head) out[0] = make_uint2(0u, denom);
-        if (((pairs - head) & 1u) != 0) out[pairs - 1] = make_uint2(0u, denom);
+        if (head) out[0] = make_uint2(numer, denom);
+        if (((pairs - head) & 1u) != 0) out[pairs - 1] = make_uint2(numer, denom);
     }
+}
+
+hipError_t launch_sparse_fill_value(uint2 *out, uint64_t pairs, uint32_t numer, uint32_t denom, uint32_t blocks_per_cu, uint32_t cus,
+                                    hipStream_t stream)
+{
+    if (pairs == 0) return hipSuccess;
+    uint64_t blocks = (pairs / 2 + 1023) / 1024;
+    const uint64_t most = (uint64_t)(cus ? cus : 256) * (blocks_per_cu ? blocks_per_cu : 16);
+    if (blocks > most) blocks = most;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(sp_fill_value_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, out, pairs, numer, denom);
+    return hipGetLastError();
 }
 
 // pairs of two SHORT sketches (|A| + |B| < s): denom = |A| + |B|.  One workgroup per short row of
@@ -914,8 +1213,8 @@ __global__ __launch_bounds__(256) void sp_fill_short_kernel(uint2 *out, const ui
 // launchers
 
 hipError_t launch_sparse_locate(const uint64_t *qhashes, uint64_t qstride, const uint32_t *qoff, uint32_t q_begin, uint32_t nq,
-                                const uint64_t *keys_sorted, const uint32_t *grp, const uint32_t *gstart, uint32_t E, uint32_t G,
-                                uint32_t rs, uint2 *qlohi, uint32_t *qcode_img, hipStream_t stream)
+                                const uint64_t *keys_sorted, const uint32_t *gend, uint32_t E, uint32_t rs, uint32_t *qlo_img,
+                                uint32_t *qhi_img, uint32_t *qcode_img, hipStream_t stream)
 {
     if (nq == 0) return hipSuccess;
     {
@@ -924,8 +1223,8 @@ hipError_t launch_sparse_locate(const uint64_t *qhashes, uint64_t qstride, const
         if (fb > 8192) fb = 8192;
         hipLaunchKernelGGL(sp_fill_u32_kernel, dim3((uint32_t)fb), dim3(256), 0, stream, qcode_img, total, 0xFFFFFFFFu);
     }
-    hipLaunchKernelGGL(sp_locate_kernel, dim3(nq), dim3(256), 0, stream, qhashes, qstride, qoff, q_begin, nq, keys_sorted, grp,
-                       gstart, E, G, rs, qlohi, qcode_img);
+    hipLaunchKernelGGL(sp_locate_kernel, dim3(nq), dim3(256), 0, stream, qhashes, qstride, qoff, q_begin, nq, keys_sorted, gend, E, rs,
+                       qlo_img, qhi_img, qcode_img);
     return hipGetLastError();
 }
 
@@ -1007,43 +1306,6 @@ hipError_t launch_sparse_scatter(const SparseArgs &a, uint64_t expect, uint32_t 
     const uint64_t most = (uint64_t)(cus ? cus : 256) * 16;
     if (blocks > most) blocks = most;
     hipLaunchKernelGGL(sp_scatter_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, a);
-    return hipGetLastError();
-}
-
-// every wave writes 4 KB of consecutive addresses per round (four stores 1 KB apart): the default
-__global__ __launch_bounds__(256) void sp_fill_const_wave_kernel(uint2 *out, uint64_t pairs, uint32_t denom)
-{
-    const uint64_t head = ((reinterpret_cast<uintptr_t>(out) & 8u) != 0 && pairs > 0) ? 1u : 0u;
-    const uint64_t nvec = (pairs - head) >> 1;
-    sp_u32x4 *body = reinterpret_cast<sp_u32x4 *>(out + head);
-    const sp_u32x4 v = {0u, denom, 0u, denom};
-    const uint64_t lane = threadIdx.x & 63u;
-    const uint64_t gw = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6), tw = (uint64_t)gridDim.x * 4u;
-    for (uint64_t base = gw * 256u; base < nvec; base += tw * 256u) {
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint64_t i = base + (uint64_t)u * 64u + lane;
-            if (i < nvec) __builtin_nontemporal_store(v, body + i);
-        }
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (head) out[0] = make_uint2(0u, denom);
-        if (((pairs - head) & 1u) != 0) out[pairs - 1] = make_uint2(0u, denom);
-    }
-}
-
-hipError_t launch_sparse_fill(uint2 *out, uint64_t pairs, uint32_t denom, uint32_t blocks_per_cu, uint32_t cus, hipStream_t stream)
-{
-    if (pairs == 0) return hipSuccess;
-    uint64_t blocks = (pairs / 2 + 1023) / 1024;                 // >= 4 stores per thread
-    const uint64_t most = (uint64_t)(cus ? cus : 256) * (blocks_per_cu ? blocks_per_cu : 16);
-    if (blocks > most) blocks = most;
-    if (blocks == 0) blocks = 1;
-    // default: every wave writes 4 KB of consecutive addresses per round (6.7 ms for the 40 GB of C3 against
-    // 7.1 ms with four streams a grid apart, MASHGPU_SPARSE_FILL_MODE=0; profiles/r03_sparse_tuning.json)
-    const int mode = getenv("MASHGPU_SPARSE_FILL_MODE") ? atoi(getenv("MASHGPU_SPARSE_FILL_MODE")) : 1;
-    if (mode == 1) hipLaunchKernelGGL(sp_fill_const_wave_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, out, pairs, denom);
-    else hipLaunchKernelGGL(sp_fill_const_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, out, pairs, denom);
     return hipGetLastError();
 }
 

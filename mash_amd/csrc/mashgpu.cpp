@@ -17,11 +17,11 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/mashgpu.h"
 #include "compare_internal.h"
-#include "compare_sparse_x.h"
 #include "finish_internal.h"
 #include "pvalue.h"
 #include "screen_internal.h"
@@ -63,6 +63,11 @@ struct mg_ctx {
     struct Block { void *p; size_t bytes; };
     std::vector<Block> blk_free, blk_live;
     size_t blk_cached = 0;
+    // large blocks (the inverted index of a table, candidate lists: hundreds of MB each) handed back by
+    // mg_table_free / mg_table_invalidate: a hipMalloc of 3 GB costs milliseconds, the next table of the same
+    // shape takes the very same blocks.  Bounded by big_limit; dropped when any allocation fails; mg_ctx_trim.
+    std::vector<Block> big_free;
+    size_t big_cached = 0, big_limit = (size_t)48 << 30;
 };
 
 struct mg_table {
@@ -87,18 +92,19 @@ struct mg_table {
         uint32_t s = 0;                    // sketch size the index covers (the first min(nhash, s) hashes of a row)
         bool usable = false;               // false: outside the engine's reach (reason in `why`), the tile engine is used
         std::string why;
-        uint32_t E = 0, G = 0, rs = 0;     // entries, distinct values, row stride of the rank image
+        uint32_t E = 0, G = 0, rs = 0;     // entries, distinct values, row stride of the images
         uint64_t shared = 0;               // sum over values of (copies choose 2): pairs x shared hashes
         uint32_t max_group = 0;            // copies of the most frequent value
         double build_ms = 0;
         uint32_t *off = nullptr;           // [n + 1] compact entry offsets (device)
         std::vector<uint32_t> off_host;
-        uint64_t *keys_sorted = nullptr;   // [E]
-        uint32_t *grp = nullptr;           // [E] group id + 1 per sorted position
-        uint32_t *gstart = nullptr;        // [G + 1]
-        uint32_t *sorted_rows = nullptr;   // [E]
-        uint2 *lohi = nullptr;             // [E]
-        uint32_t *rank_img = nullptr;      // [n * rs]
+        uint64_t *keys_sorted = nullptr;   // [E] the values in sorted order (rect queries are located in them)
+        uint32_t *gend = nullptr;          // [E] at the first sorted position of a value: one past its last
+        uint32_t *sorted_rows = nullptr;   // [E] row of every sorted position
+        uint32_t *code_img = nullptr;      // [n * rs + 64] 2 x (first sorted position of the entry's value), padding 0xFFFFFFFF
+        uint32_t *pos_img = nullptr;       // [n * rs] the entry's own sorted position
+        uint32_t *order = nullptr;         // [n] rows in visiting order (see sp_row_key_kernel); nullptr: table order
+        uint32_t *row_inc = nullptr;       // (unused)
         // identical rows: rep[row] = first row of its class (nullptr: the table has no copies), classes of >= 2 rows
         uint32_t *rep = nullptr, *cls_of = nullptr, *cls_off = nullptr, *cls_rows = nullptr, *cls_first = nullptr;
         uint32_t cls_members = 0;          // rows in classes of two and more
@@ -111,7 +117,6 @@ struct mg_table {
         std::vector<uint32_t> short_rows_host;
         // what a (rows, range) job costs, learned by a counting pass the first time it is seen
         struct Plan { const void *rows; uint64_t rb, re; bool triangle; uint64_t cand, shared; bool use; uint32_t *order; };
-        std::vector<uint32_t> order_host;  // all rows by locality key (see sp_row_key_kernel)
         std::vector<Plan> plans;
         uint2 *cand = nullptr, *res = nullptr;    // candidate list and the candidates' results, grown on demand
         uint64_t cand_cap = 0;
@@ -140,9 +145,45 @@ struct mg_table {
 // makes a dozen of them.  Blocks up to 64 MiB are kept (256 MiB in total) and reused by later
 // calls; everything runs on ctx->stream, so a block handed back while work on it is still
 // queued is only ever touched again by work queued behind it.
+static void ctx_trim(mg_ctx *ctx)
+{
+    for (auto &b : ctx->blk_free) hipFree(b.p);
+    ctx->blk_free.clear();
+    ctx->blk_cached = 0;
+    for (auto &b : ctx->big_free) hipFree(b.p);
+    ctx->big_free.clear();
+    ctx->big_cached = 0;
+}
+
+constexpr size_t CTX_SMALL_BLOCK = (size_t)64 << 20;
+
 static hipError_t ctx_malloc(mg_ctx *ctx, void **out, size_t bytes)
 {
     bytes = (std::max<size_t>(bytes, 1) + 255) & ~size_t(255);
+    if (bytes > CTX_SMALL_BLOCK) {
+        // large block: best fit among the blocks handed back, at most a quarter larger than asked for
+        size_t pick = SIZE_MAX;
+        for (size_t i = 0; i < ctx->big_free.size(); i++) {
+            const size_t b = ctx->big_free[i].bytes;
+            if (b >= bytes && b <= bytes + bytes / 4 && (pick == SIZE_MAX || b < ctx->big_free[pick].bytes)) pick = i;
+        }
+        if (pick != SIZE_MAX) {
+            *out = ctx->big_free[pick].p;
+            ctx->blk_live.push_back(ctx->big_free[pick]);
+            ctx->big_cached -= ctx->big_free[pick].bytes;
+            ctx->big_free.erase(ctx->big_free.begin() + (long)pick);
+            return hipSuccess;
+        }
+        hipError_t e = hipMalloc(out, bytes);
+        if (e != hipSuccess && (!ctx->big_free.empty() || !ctx->blk_free.empty())) {
+            (void)hipGetLastError();
+            hipStreamSynchronize(ctx->stream);
+            ctx_trim(ctx);
+            e = hipMalloc(out, bytes);
+        }
+        if (e == hipSuccess) ctx->blk_live.push_back({*out, bytes});
+        return e;
+    }
     size_t best = SIZE_MAX;
     for (size_t i = 0; i < ctx->blk_free.size(); i++) {
         const size_t b = ctx->blk_free[i].bytes;
@@ -156,11 +197,10 @@ static hipError_t ctx_malloc(mg_ctx *ctx, void **out, size_t bytes)
         return hipSuccess;
     }
     hipError_t e = hipMalloc(out, bytes);
-    if (e != hipSuccess && !ctx->blk_free.empty()) {          // give the cache back and retry
+    if (e != hipSuccess && (!ctx->blk_free.empty() || !ctx->big_free.empty())) {          // give the caches back and retry
         (void)hipGetLastError();
-        for (auto &b : ctx->blk_free) hipFree(b.p);
-        ctx->blk_free.clear();
-        ctx->blk_cached = 0;
+        hipStreamSynchronize(ctx->stream);
+        ctx_trim(ctx);
         e = hipMalloc(out, bytes);
     }
     if (e == hipSuccess) ctx->blk_live.push_back({*out, bytes});
@@ -174,9 +214,12 @@ static void ctx_free(mg_ctx *ctx, void *p)
         if (ctx->blk_live[i].p != p) continue;
         const mg_ctx::Block b = ctx->blk_live[i];
         ctx->blk_live.erase(ctx->blk_live.begin() + (long)i);
-        if (b.bytes <= (64u << 20) && ctx->blk_cached + b.bytes <= (256u << 20) && ctx->blk_free.size() < 64) {
+        if (b.bytes <= CTX_SMALL_BLOCK && ctx->blk_cached + b.bytes <= (256u << 20) && ctx->blk_free.size() < 64) {
             ctx->blk_free.push_back(b);
             ctx->blk_cached += b.bytes;
+        } else if (b.bytes > CTX_SMALL_BLOCK && ctx->big_cached + b.bytes <= ctx->big_limit && ctx->big_free.size() < 64) {
+            ctx->big_free.push_back(b);
+            ctx->big_cached += b.bytes;
         } else {
             hipFree(p);
         }
@@ -268,7 +311,7 @@ void mg_ctx_destroy(mg_ctx *ctx)
         if (sl.host) hipHostFree(sl.host);
         if (sl.done) hipEventDestroy(sl.done);
     }
-    for (auto &b : ctx->blk_free) hipFree(b.p);
+    ctx_trim(ctx);
     for (auto &b : ctx->blk_live) hipFree(b.p);
     if (ctx->aux) hipStreamDestroy(ctx->aux);
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
@@ -278,6 +321,16 @@ void mg_ctx_destroy(mg_ctx *ctx)
 }
 
 const char *mg_last_error(mg_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int mg_ctx_trim(mg_ctx *ctx)
+{
+    if (!ctx) return MG_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx_trim(ctx);
+    return MG_OK;
+}
 
 int mg_ctx_set_stream(mg_ctx *ctx, void *hip_stream)
 {
@@ -1247,10 +1300,23 @@ int mg_reads_add_host(mg_reads_session *rs, const uint8_t *bases, uint64_t nbase
     const double hash_space = p->use64 ? 18446744073709551616.0 : 4294967296.0;
     const uint64_t tile = mg::sketch_tile(256);
     std::vector<mg::HashEvent> &ev = rs->ev;
-    size_t r0 = 0;                                           // next record
+    // The unit of a launch is a PIECE: a range of k-mer start positions inside one record.  A record of any length (a
+    // chromosome under -r, Sketch.cpp:1196-1270 has no limit) is cut into pieces of at most kPiece positions -- every
+    // position yields at most one event, so a piece always fits the event buffer -- and the stop test of -c still
+    // follows whole records only (Sketch.cpp:1258).
+    constexpr uint64_t kPiece = kReadsEventCap / 4;
+    struct Piece { uint64_t pb, pe; uint32_t rec; bool last; };
+    std::vector<Piece> pieces;
+    for (size_t r = 0; r < rec_begin.size(); r++) {
+        const uint64_t p0 = rec_begin[r], p1 = rec_end[r] - k + 1;       // k-mer starts [p0, p1)
+        for (uint64_t o = p0; o < p1; o += kPiece) pieces.push_back({o, std::min(p1, o + kPiece), (uint32_t)r, o + kPiece >= p1});
+    }
+    size_t r0 = 0;                                           // next piece
+    size_t rr = 0;                                           // record the replay is in
+    bool touched = false;                                    // ... and whether it changed the heap
     const uint64_t want_bytes = 2ull << 20;                  // while the heap is not full everything is an event
-    while (r0 < rec_begin.size() && !rs->stopped) {
-        // records [r0, r1): as many as are expected to stay within the event capacity
+    while (r0 < pieces.size() && !rs->stopped) {
+        // pieces [r0, r1): as many as are expected to stay within the event capacity
         const uint64_t bound = heap.full() ? heap.top() : 0xFFFFFFFFFFFFFFFFull;
         const double pass = heap.full() ? std::min(1.0, ((double)bound + 1.0) / hash_space) : 1.0;
         uint64_t budget = (uint64_t)std::min<double>((double)(1ull << 40), (double)(kReadsEventCap / 2) / std::max(pass, 1e-12));
@@ -1258,14 +1324,14 @@ int mg_reads_add_host(mg_reads_session *rs, const uint8_t *bases, uint64_t nbase
         budget = (uint64_t)std::max(1.0, (double)budget * rs->shrink);
         size_t r1 = r0;
         uint64_t bytes = 0;
-        while (r1 < rec_begin.size() && (r1 == r0 || bytes + (rec_end[r1] - rec_begin[r1]) <= budget)) {
-            bytes += rec_end[r1] - rec_begin[r1];
+        while (r1 < pieces.size() && (r1 == r0 || bytes + (pieces[r1].pe - pieces[r1].pb) <= budget)) {
+            bytes += pieces[r1].pe - pieces[r1].pb;
             r1++;
         }
-        const uint64_t b0 = rec_begin[r0], b1 = rec_end[r1 - 1];
-        // work items: k-mer start positions [b0, b1 - k]
+        // work items: k-mer start positions [b0, b0 + npos), none reading past the last piece's record
+        const uint64_t b0 = pieces[r0].pb, b1 = rec_end[pieces[r1 - 1].rec];
         std::vector<mg::SketchWork> work;
-        const uint64_t npos = b1 - b0 - k + 1;
+        const uint64_t npos = pieces[r1 - 1].pe - b0;
         uint64_t chunk = (npos + 4095) / 4096;
         if (chunk < 2 * tile) chunk = 2 * tile;
         chunk = (chunk + tile - 1) / tile * tile;
@@ -1275,7 +1341,7 @@ int mg_reads_add_host(mg_reads_session *rs, const uint8_t *bases, uint64_t nbase
             w.sketch = 0; w.slot = 0; w.nchunks = 1; w._pad = 0;
             work.push_back(w);
         }
-        DevBuf<mg::SketchWork> d_work;
+        DevBuf<mg::SketchWork> d_work(ctx);
         if (d_work.alloc(work.size()) != hipSuccess) return fail(ctx, MG_ERR_NOMEM, "mg_reads_add_host: device allocation failed");
         mg::EventArgs ea;
         ea.bases = rs->d_bases; ea.work = d_work; ea.alphabet = rs->d_alpha; ea.out = rs->d_ev; ea.count = rs->d_cnt;
@@ -1288,8 +1354,8 @@ int mg_reads_add_host(mg_reads_session *rs, const uint8_t *bases, uint64_t nbase
         if (e == hipSuccess) e = hipMemcpyAsync(&n_ev, rs->d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("mg_reads_add_host: ") + hipGetErrorString(e));
-        if (n_ev > kReadsEventCap) {                         // denser than expected: take fewer records
-            if (r1 - r0 == 1) return fail(ctx, MG_ERR_UNSUPPORTED, "mg_reads_add_host: a single record exceeds the event buffer");
+        if (n_ev > kReadsEventCap) {                         // denser than expected: take fewer pieces
+            if (r1 - r0 == 1) return fail(ctx, MG_ERR_HIP, "mg_reads_add_host: more events than k-mer positions in a piece");
             rs->shrink /= 4;
             continue;
         }
@@ -1299,23 +1365,22 @@ int mg_reads_add_host(mg_reads_session *rs, const uint8_t *bases, uint64_t nbase
             return fail(ctx, MG_ERR_HIP, "mg_reads_add_host: D2H copy failed");
         std::sort(ev.begin(), ev.end(), [](const mg::HashEvent &x, const mg::HashEvent &y) { return x.pos < y.pos; });
         // replay, record by record; the stop test follows every record that changed the heap
-        size_t rr = r0;
-        bool touched = false;
-        for (size_t i = 0; i <= ev.size() && !rs->stopped; i++) {
-            const bool end = i == ev.size();
-            while (!end && ev[i].pos >= rec_end[rr]) {       // event belongs to a later record: close record rr
-                if (cov && touched && heap.multiplicity() >= p->target_cov) { rs->stopped = true; rs->used = rs->records + rr + 1; break; }
-                touched = false;
-                rr++;
-            }
-            if (rs->stopped) break;
-            if (end) {
+        auto close_records = [&](size_t upto) {               // records [rr, upto) are complete
+            if (rr < upto) {
                 if (cov && touched && heap.multiplicity() >= p->target_cov) { rs->stopped = true; rs->used = rs->records + rr + 1; }
-                break;
+                touched = false;
+                rr = upto;
             }
+        };
+        for (size_t i = 0; i < ev.size() && !rs->stopped; i++) {
+            size_t at = rr;
+            while (ev[i].pos >= rec_end[at]) at++;           // the event's record
+            close_records(at);
+            if (rs->stopped) break;
             heap.try_insert(ev[i].hash);
             touched = true;
         }
+        if (!rs->stopped) close_records(pieces[r1 - 1].last ? (size_t)pieces[r1 - 1].rec + 1 : (size_t)pieces[r1 - 1].rec);
         r0 = r1;
     }
     rs->records += rec_begin.size();
@@ -1408,8 +1473,8 @@ int mg_table_upload(mg_ctx *ctx, const uint64_t *hashes, const uint32_t *nhash, 
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (!hashes || !nhash || !out || s == 0) return fail(ctx, MG_ERR_INVALID, "mg_table_upload: bad argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    DevBuf<uint64_t> dh, dl;
-    DevBuf<uint32_t> dn;
+    DevBuf<uint64_t> dh(ctx), dl(ctx);                     // (from the context's pool: the next table of this shape takes the same blocks)
+    DevBuf<uint32_t> dn(ctx);
     if (dh.alloc(n * s) != hipSuccess || dn.alloc(n) != hipSuccess || dl.alloc(n) != hipSuccess)
         return fail(ctx, MG_ERR_NOMEM, "mg_table_upload: device allocation failed");
     HIP_TRY(ctx, hipMemcpyAsync(dh, hashes, n * s * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -1436,32 +1501,56 @@ int mg_table_wrap_dev(mg_ctx *ctx, const uint64_t *hashes_dev, const uint32_t *n
     return MG_OK;
 }
 
+// everything the compare path derived from the table's contents goes back to the context (large blocks to its
+// pool, in stream order: whatever is still queued on them runs before anything queued later reuses them)
+static void table_drop_derived(mg_table *t)
+{
+    mg_ctx *ctx = t->ctx;
+    if (!t->pfx.empty() || !t->win.empty() || !t->sparse.empty()) hipSetDevice(ctx->device);
+    for (auto &im : t->pfx) ctx_free(ctx, im.second);
+    t->pfx.clear();
+    for (auto &w : t->win) ctx_free(ctx, w.dev);
+    t->win.clear();
+    for (mg_table::Sparse *sp : t->sparse) {
+        for (auto &pl : sp->plans)
+            if (pl.order) ctx_free(ctx, pl.order);
+        for (void *q : {(void *)sp->off, (void *)sp->keys_sorted, (void *)sp->gend, (void *)sp->sorted_rows,
+                        (void *)sp->pos_img, (void *)sp->code_img, (void *)sp->short_rows, (void *)sp->short_cnt, (void *)sp->cand,
+                        (void *)sp->res, (void *)sp->seg_base, (void *)sp->seg_cnt, (void *)sp->chunks, (void *)sp->chunk_inc,
+                        sp->scan_temp, (void *)sp->counters, (void *)sp->rep, (void *)sp->cls_of, (void *)sp->cls_off,
+                        (void *)sp->cls_rows, (void *)sp->cls_first, (void *)sp->order, (void *)sp->row_inc})
+            if (q) ctx_free(ctx, q);
+        delete sp;
+    }
+    t->sparse.clear();
+    t->cls.clear();
+    t->last.clear();
+    t->nh.clear();
+    t->have_max = false;
+}
+
 void mg_table_free(mg_table *t)
 {
     if (!t) return;
-    if (!t->pfx.empty()) { hipSetDevice(t->ctx->device); for (auto &im : t->pfx) hipFree(im.second); }
-    if (!t->win.empty()) { hipSetDevice(t->ctx->device); for (auto &w : t->win) hipFree(w.dev); }
-    if (!t->sparse.empty()) {
-        hipSetDevice(t->ctx->device);
-        for (mg_table::Sparse *sp : t->sparse) {
-            for (auto &pl : sp->plans)
-                if (pl.order) hipFree(pl.order);
-            for (void *q : {(void *)sp->off, (void *)sp->keys_sorted, (void *)sp->grp, (void *)sp->gstart, (void *)sp->sorted_rows,
-                            (void *)sp->lohi, (void *)sp->rank_img, (void *)sp->short_rows, (void *)sp->short_cnt, (void *)sp->cand,
-                            (void *)sp->res, (void *)sp->seg_base, (void *)sp->seg_cnt, (void *)sp->chunks, (void *)sp->chunk_inc,
-                            sp->scan_temp, (void *)sp->counters, (void *)sp->rep, (void *)sp->cls_of, (void *)sp->cls_off,
-                            (void *)sp->cls_rows, (void *)sp->cls_first})
-                if (q) hipFree(q);
-            delete sp;
+    {
+        std::lock_guard<std::recursive_mutex> lk(t->ctx->mu);
+        table_drop_derived(t);
+        if (t->owns) {
+            hipSetDevice(t->ctx->device);
+            ctx_free(t->ctx, (void *)t->hashes);
+            ctx_free(t->ctx, (void *)t->nhash);
+            ctx_free(t->ctx, (void *)t->lengths);
         }
     }
-    if (t->owns) {
-        hipSetDevice(t->ctx->device);
-        hipFree((void *)t->hashes);
-        hipFree((void *)t->nhash);
-        hipFree((void *)t->lengths);
-    }
     delete t;
+}
+
+int mg_table_invalidate(mg_table *t)
+{
+    if (!t) return MG_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(t->ctx->mu);
+    table_drop_derived(t);
+    return MG_OK;
 }
 
 uint64_t mg_table_rows(const mg_table *t) { return t ? t->n : 0; }
@@ -1924,13 +2013,18 @@ static int run_compare_merged(mg_ctx *ctx, const mg_table *rows, const mg_table 
 // ---- inverted-index engine (compare_sparse.hip) ----------------------------------------------
 //
 // Index of a table for sketch size s: every (value, row) entry of the rows' first min(nhash, s)
-// hashes sorted by value, rows ascending inside a value (stable sort over row-major entry ids).
-// Built once per table and sketch size, cached in the mg_table like the prefix images.  Retained:
-// the sorted values (rect queries are located in them), the group id per sorted position and the
-// group starts, the row per sorted position, per entry the run [group start, own position) of
-// rows BELOW its row holding the same value, and the rank image (2 * dense rank of every entry's
-// value, padded row stride).  A table the engine cannot take (2^31 entries and more, a real hash
-// equal to the padding value, no memory) is marked unusable and keeps the tile engine.
+// hashes sorted by value, rows ascending inside a value (stable sort over row-major image indices).
+// Built once per table and sketch size, cached in the mg_table like the prefix images (dropped by
+// mg_table_invalidate; its blocks then go back to the context's pool and the next table of the same shape
+// takes them).  Retained: the sorted values (rect queries are located in them), the row per sorted
+// position, the end of every group of equal values (kept at the group's first position), and two images in
+// the table's own layout (row stride rs): the CODE image (2 x first sorted position of the entry's value --
+// ordered and equal exactly as the values are) and the POSITION image (the entry's own sorted position: the
+// rows below it that hold the same value are sorted_rows[code / 2 .. position)).  A table the engine cannot
+// take (2^31 entries and more, a real hash equal to the padding value, no memory) is marked unusable and
+// keeps the tile engine.
+// Host work per build is O(n) loops and three synchronisations (row classes, copy suspects, build
+// statistics); sorting of digests and of the visiting order happens on the device.
 static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, mg_table::Sparse **out)
 {
     for (mg_table::Sparse *sp : t->sparse)
@@ -1945,41 +2039,51 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, mg_tab
     const uint64_t n = t->n;
     if (n == 0) return unusable("empty table");
     if (n >= (1ull << 31)) return unusable("too many rows");
+    sp->rs = mg::sparse_img_stride(s);
+    if (n * sp->rs >= (1ull << 32)) return unusable("image index beyond 32 bits");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    // ---- identical rows (see compare_sparse.hip): digest every row, group equal digests on the host,
-    // verify the groups value by value on the device; copies then stay out of the index
-    std::vector<uint32_t> cnt_true(n), rep(n);
+    const auto t_begin = std::chrono::steady_clock::now();
+    // ---- identical rows (see compare_sparse.hip): digest every row, sort the digests on the device; rows whose
+    // digest and length equal their predecessor's are suspects, verified value by value; copies then stay out
+    // of the index
+    std::vector<uint32_t> cnt_true(n);
+    uint32_t max_cnt = 0;
     for (uint64_t i = 0; i < n; i++) {
         cnt_true[i] = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(t->nh[i], t->s), s);
-        rep[i] = (uint32_t)i;
+        max_cnt = std::max(max_cnt, cnt_true[i]);
     }
-    DevBuf<uint32_t> d_cnt;
+    std::vector<uint32_t> rep;                              // empty: no copies
+    DevBuf<uint32_t> d_cnt(ctx);
     if (d_cnt.alloc(n) != hipSuccess) { (void)hipGetLastError(); return unusable("no device memory for the index"); }
     HIP_TRY(ctx, hipMemcpyAsync(d_cnt, cnt_true.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
     if (!getenv("MASHGPU_SPARSE_NO_DEDUP")) {
-        DevBuf<unsigned long long> d_dig;
-        if (d_dig.alloc(n) != hipSuccess) { (void)hipGetLastError(); return unusable("no device memory for the index"); }
-        std::vector<unsigned long long> dig(n);
-        HIP_TRY(ctx, mg::launch_sparse_row_digest(t->hashes, t->s, d_cnt, (uint32_t)n, d_dig, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(dig.data(), d_dig, n * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        std::vector<uint32_t> order;
-        order.reserve(n);
-        for (uint64_t i = 0; i < n; i++)
-            if (cnt_true[i]) order.push_back((uint32_t)i);
-        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
-            if (dig[x] != dig[y]) return dig[x] < dig[y];
-            if (cnt_true[x] != cnt_true[y]) return cnt_true[x] < cnt_true[y];
-            return x < y;
-        });
-        std::vector<uint2> pairs;                          // {row, first row with the same digest and length}
-        for (size_t k = 1, g0 = 0; k < order.size(); k++) {
-            if (dig[order[k]] == dig[order[g0]] && cnt_true[order[k]] == cnt_true[order[g0]]) pairs.push_back(make_uint2(order[k], order[g0]));
-            else g0 = k;
+        DevBuf<unsigned long long> d_dig(ctx), d_dig_sorted(ctx);
+        DevBuf<uint32_t> d_rows_sorted(ctx), d_flags(ctx), d_nflag(ctx);
+        DevBuf<unsigned char> d_tmp(ctx);
+        const size_t tb = mg::sparse_dup_temp_bytes((uint32_t)n);
+        if (d_dig.alloc(n) != hipSuccess || d_dig_sorted.alloc(n) != hipSuccess || d_rows_sorted.alloc(n) != hipSuccess ||
+            d_flags.alloc(n) != hipSuccess || d_nflag.alloc(1) != hipSuccess || d_tmp.alloc(std::max<size_t>(tb, 16)) != hipSuccess) {
+            (void)hipGetLastError();
+            return unusable("no device memory for the index");
         }
-        if (!pairs.empty()) {
-            DevBuf<uint2> d_pairs;
-            DevBuf<uint32_t> d_eq;
+        uint32_t nflag = 0;
+        HIP_TRY(ctx, mg::launch_sparse_row_digest(t->hashes, t->s, d_cnt, (uint32_t)n, d_dig, ctx->stream));
+        HIP_TRY(ctx, mg::launch_sparse_dup_suspects(d_dig, d_cnt, (uint32_t)n, d_tmp, tb, d_dig_sorted, d_rows_sorted, d_flags, d_nflag, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(&nflag, d_nflag, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (nflag) {
+            std::vector<uint32_t> rows_sorted(n), flags(n);
+            HIP_TRY(ctx, hipMemcpyAsync(rows_sorted.data(), d_rows_sorted, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(flags.data(), d_flags, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            std::vector<uint2> pairs;                      // {row, first row of its run of equal digests and lengths}
+            pairs.reserve(nflag);
+            for (uint64_t k = 1, g0 = 0; k < n; k++) {
+                if (flags[k]) pairs.push_back(make_uint2(rows_sorted[k], rows_sorted[g0]));
+                else g0 = k;
+            }
+            DevBuf<uint2> d_pairs(ctx);
+            DevBuf<uint32_t> d_eq(ctx);
             if (d_pairs.alloc(pairs.size()) != hipSuccess || d_eq.alloc(pairs.size()) != hipSuccess) { (void)hipGetLastError(); return unusable("no device memory for the index"); }
             std::vector<uint32_t> eq(pairs.size());
             HIP_TRY(ctx, hipMemcpyAsync(d_pairs, pairs.data(), pairs.size() * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
@@ -1987,7 +2091,11 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, mg_tab
             HIP_TRY(ctx, hipMemcpyAsync(eq.data(), d_eq, pairs.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             for (size_t k = 0; k < pairs.size(); k++)
-                if (eq[k]) { rep[pairs[k].x] = pairs[k].y; sp->copies++; }
+                if (eq[k]) {
+                    if (rep.empty()) { rep.resize(n); for (uint64_t i = 0; i < n; i++) rep[i] = (uint32_t)i; }
+                    rep[pairs[k].x] = pairs[k].y;
+                    sp->copies++;
+                }
         }
     }
     std::vector<uint32_t> cls_of, cls_off, cls_rows, cls_first;
@@ -2019,7 +2127,7 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, mg_tab
     for (uint64_t i = 0; i < n; i++) {
         sp->off_host[i] = (uint32_t)E64;
         const uint64_t c = cnt_true[i];
-        if (rep[i] == i) E64 += c;                          // copies stay out of the index
+        if (rep.empty() || rep[i] == i) E64 += c;           // copies stay out of the index
         if (E64 >= (1ull << 31)) return unusable("2^31 entries or more");
         if (c) {
             // a real hash equal to the padding value would sort among the padding: keep the tile engine
@@ -2035,36 +2143,37 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, mg_tab
     if (E64 == 0) return unusable("no hashes");
     const uint32_t E = (uint32_t)E64;
     sp->E = E;
-    sp->rs = mg::sparse_img_stride(s);
     const uint32_t end_bit = (uint32_t)(64 - __builtin_clzll(maxv | 1ull));
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    hipEventCreate(&ev0);
-    hipEventCreate(&ev1);
-    hipEventRecord(ev0, ctx->stream);
-    // transient buffers
-    const size_t temp_bytes = mg::sparse_sort_temp_bytes(E, end_bit);
-    void *temp = nullptr;
-    uint64_t *keys_a = nullptr;
-    uint32_t *eid_a = nullptr, *eid_sorted = nullptr;
-    struct Stat { unsigned long long shared; uint32_t max_group, bad, last_grp, pad; } *d_stat = nullptr, h_stat = {0, 0, 0, 0, 0};
-    bool ok = hipMalloc(&temp, std::max<size_t>(temp_bytes, 16)) == hipSuccess &&
-              hipMalloc(&keys_a, (size_t)E * 8) == hipSuccess && hipMalloc(&eid_a, (size_t)E * 4) == hipSuccess &&
-              hipMalloc(&eid_sorted, (size_t)E * 4) == hipSuccess && hipMalloc(&d_stat, sizeof(Stat)) == hipSuccess;
+    // transient buffers (back to the pool at the end of this function, in stream order)
+    const size_t temp_bytes = std::max(mg::sparse_sort_temp_bytes(E, end_bit),
+                                       std::max(mg::sparse_order_temp_bytes((uint32_t)n), mg::sparse_order_slice_temp_bytes((uint32_t)n)));
+    DevBuf<unsigned char> temp(ctx);
+    DevBuf<uint64_t> keys_a(ctx);
+    DevBuf<uint32_t> idx_a(ctx), idx_sorted(ctx), gs_of(ctx);
+    DevBuf<unsigned long long> key64_a(ctx), key64_b(ctx);
+    struct Stat { unsigned long long shared; uint32_t max_group, groups, bad, pad; } h_stat = {0, 0, 0, 0, 0};
+    DevBuf<Stat> d_stat(ctx);
+    const bool want_order = !getenv("MASHGPU_SPARSE_NO_ORDER");
+    bool ok = temp.alloc(std::max<size_t>(temp_bytes, 16)) == hipSuccess && keys_a.alloc(E) == hipSuccess && idx_a.alloc(E) == hipSuccess &&
+              idx_sorted.alloc(E) == hipSuccess && gs_of.alloc(E) == hipSuccess && d_stat.alloc(1) == hipSuccess &&
+              (!want_order || (key64_a.alloc(n) == hipSuccess && key64_b.alloc(n) == hipSuccess));
     // retained buffers
-    ok = ok && hipMalloc(&sp->off, (n + 1) * 4) == hipSuccess && hipMalloc(&sp->keys_sorted, (size_t)E * 8) == hipSuccess &&
-         hipMalloc(&sp->grp, (size_t)E * 4) == hipSuccess && hipMalloc(&sp->gstart, ((size_t)E + 1) * 4) == hipSuccess &&
-         hipMalloc(&sp->sorted_rows, (size_t)E * 4) == hipSuccess && hipMalloc(&sp->lohi, (size_t)E * 8) == hipSuccess &&
-         hipMalloc(&sp->rank_img, ((size_t)n * sp->rs + 64) * 4) == hipSuccess && hipMalloc(&sp->counters, 4 * 8) == hipSuccess;
+    auto take = [&](auto **p, size_t count) {
+        void *q = nullptr;
+        if (ctx_malloc(ctx, &q, std::max<size_t>(count, 1) * sizeof(**p)) != hipSuccess) return false;
+        *p = static_cast<std::remove_reference_t<decltype(*p)>>(q);
+        return true;
+    };
+    ok = ok && take(&sp->off, n + 1) && take(&sp->keys_sorted, E) && take(&sp->gend, E) && take(&sp->sorted_rows, E) &&
+         take(&sp->code_img, (size_t)n * sp->rs + 64) && take(&sp->pos_img, (size_t)n * sp->rs) && take(&sp->counters, 4) &&
+         (!want_order || take(&sp->order, n));
     const size_t nshort = sp->short_rows_host.size();
     std::vector<uint32_t> short_cnt(nshort);
     for (size_t k = 0; k < nshort; k++) short_cnt[k] = cnt_true[sp->short_rows_host[k]];
-    if (ok && nshort)
-        ok = hipMalloc(&sp->short_rows, nshort * 4) == hipSuccess && hipMalloc(&sp->short_cnt, nshort * 4) == hipSuccess;
+    if (ok && nshort) ok = take(&sp->short_rows, nshort) && take(&sp->short_cnt, nshort);
     if (ok && sp->copies)
-        ok = hipMalloc(&sp->rep, n * 4) == hipSuccess && hipMalloc(&sp->cls_of, n * 4) == hipSuccess &&
-             hipMalloc(&sp->cls_off, cls_off.size() * 4) == hipSuccess && hipMalloc(&sp->cls_rows, std::max<size_t>(cls_rows.size(), 1) * 4) == hipSuccess &&
-             hipMalloc(&sp->cls_first, std::max<size_t>(cls_first.size(), 1) * 4) == hipSuccess;
+        ok = take(&sp->rep, n) && take(&sp->cls_of, n) && take(&sp->cls_off, cls_off.size()) && take(&sp->cls_rows, cls_rows.size()) &&
+             take(&sp->cls_first, cls_first.size());
     hipError_t e = hipSuccess;
     if (ok && sp->copies) {
         e = hipMemcpyAsync(sp->rep, rep.data(), n * 4, hipMemcpyHostToDevice, ctx->stream);
@@ -2078,80 +2187,36 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, mg_tab
         if (e == hipSuccess && nshort) e = hipMemcpyAsync(sp->short_rows, sp->short_rows_host.data(), nshort * 4, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess && nshort) e = hipMemcpyAsync(sp->short_cnt, short_cnt.data(), nshort * 4, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipMemsetAsync(d_stat, 0, sizeof(Stat), ctx->stream);
+        prof_begin(ctx, ctx->prof_index);
         if (e == hipSuccess)
-            e = mg::sparse_build_index(t->hashes, t->s, sp->off, (uint32_t)n, E, sp->rs, end_bit, temp, temp_bytes, keys_a, eid_a,
-                                       sp->keys_sorted, eid_sorted, /*head=*/eid_a, sp->grp, sp->gstart, sp->sorted_rows, sp->lohi,
-                                       sp->rank_img, &d_stat->shared, &d_stat->max_group, &d_stat->bad, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(&h_stat.last_grp, sp->grp + (E - 1), 4, hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(&h_stat, d_stat, offsetof(Stat, last_grp), hipMemcpyDeviceToHost, ctx->stream);
-        hipEventRecord(ev1, ctx->stream);
+            e = mg::sparse_build_index(t->hashes, t->s, sp->off, (uint32_t)n, E, sp->rs, end_bit, temp, temp_bytes, keys_a, idx_a,
+                                       sp->keys_sorted, idx_sorted, /*head=*/idx_a, gs_of, sp->sorted_rows, sp->gend, sp->code_img, sp->pos_img,
+                                       &d_stat.p->shared, &d_stat.p->max_group, &d_stat.p->groups, &d_stat.p->bad, ctx->stream);
+        // visiting order of the rows: by the run of their first shared value, larger rows first inside a run
+        if (e == hipSuccess && want_order)
+            e = mg::launch_sparse_row_order(sp->off, sp->code_img, sp->gend, sp->rep, (uint32_t)n, sp->rs, temp, temp_bytes, key64_a, key64_b,
+                                            sp->order, ctx->stream);
+        prof_end(ctx, ctx->prof_index);
+        if (e == hipSuccess) e = hipMemcpyAsync(&h_stat, d_stat, sizeof(Stat), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     }
-    float ms = 0.f;
-    if (ok && e == hipSuccess) hipEventElapsedTime(&ms, ev0, ev1);
-    hipEventDestroy(ev0);
-    hipEventDestroy(ev1);
-    for (void *q : {(void *)temp, (void *)keys_a, (void *)eid_a, (void *)eid_sorted, (void *)d_stat})
-        if (q) hipFree(q);
     auto drop = [&]() {
-        for (void **q : {(void **)&sp->off, (void **)&sp->keys_sorted, (void **)&sp->grp, (void **)&sp->gstart, (void **)&sp->sorted_rows,
-                         (void **)&sp->lohi, (void **)&sp->rank_img, (void **)&sp->short_rows, (void **)&sp->short_cnt, (void **)&sp->counters,
+        for (void **q : {(void **)&sp->off, (void **)&sp->keys_sorted, (void **)&sp->gend, (void **)&sp->sorted_rows, (void **)&sp->code_img,
+                         (void **)&sp->pos_img, (void **)&sp->short_rows, (void **)&sp->short_cnt, (void **)&sp->counters, (void **)&sp->order,
                          (void **)&sp->rep, (void **)&sp->cls_of, (void **)&sp->cls_off, (void **)&sp->cls_rows, (void **)&sp->cls_first})
-            if (*q) { hipFree(*q); *q = nullptr; }
+            if (*q) { ctx_free(ctx, *q); *q = nullptr; }
     };
     if (!ok) { (void)hipGetLastError(); drop(); return unusable("no device memory for the index"); }
     if (e != hipSuccess) { drop(); return fail(ctx, MG_ERR_HIP, std::string("compare (index build): ") + hipGetErrorString(e)); }
     if (h_stat.bad) { drop(); return unusable("sort order inside a value not by row"); }
-    sp->G = h_stat.last_grp;
+    sp->G = h_stat.groups;
     sp->shared = h_stat.shared;
     sp->max_group = h_stat.max_group;
-    sp->build_ms = ms;
+    sp->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     sp->usable = true;
-    // runs that name the same rows (clades): per row all but one are emptied -- discovery then reads one of them
-    // (OPT-IN, MASHGPU_SPARSE_RUN_DEDUP=1: written at the very end of round 3, its GPU validation did not finish)
-    if (getenv("MASHGPU_SPARSE_RUN_DEDUP") && !getenv("MASHGPU_SPARSE_NO_RUN_DEDUP") && sp->G && sp->max_group >= 2) {
-        const auto t0 = std::chrono::steady_clock::now();
-        uint32_t max_cnt = 0;
-        for (uint64_t i = 0; i < n; i++) if (rep[i] == i) max_cnt = std::max(max_cnt, cnt_true[i]);
-        unsigned long long *dig = nullptr;
-        unsigned long long dropped = 0;
-        if (hipMalloc(&dig, ((size_t)sp->G * 2 + 1) * 8) == hipSuccess) {
-            hipError_t e2 = hipMemsetAsync(dig + (size_t)sp->G * 2, 0, 8, ctx->stream);
-            if (e2 == hipSuccess)
-                e2 = mg::launch_sparse_run_dedupe(sp->gstart, sp->sorted_rows, sp->G, sp->off, sp->rank_img, sp->rs, sp->lohi, (uint32_t)n, max_cnt,
-                                                  dig, dig + (size_t)sp->G * 2, ctx->stream);
-            if (e2 == hipSuccess) e2 = hipMemcpyAsync(&dropped, dig + (size_t)sp->G * 2, 8, hipMemcpyDeviceToHost, ctx->stream);
-            if (e2 == hipSuccess) e2 = hipStreamSynchronize(ctx->stream);
-            hipFree(dig);
-            if (e2 != hipSuccess) { drop(); sp->usable = false; return fail(ctx, MG_ERR_HIP, std::string("compare (index build, runs): ") + hipGetErrorString(e2)); }
-            sp->runs_dropped = dropped;
-            sp->build_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        } else {
-            (void)hipGetLastError();                     // (no memory for the digests: every run stays)
-        }
-    }
-    // visiting order of the rows: by the run of their first shared value, larger rows first inside a run
-    if (!getenv("MASHGPU_SPARSE_NO_ORDER")) {
-        DevBuf<uint32_t> d_key;
-        std::vector<uint32_t> key(n);
-        if (d_key.alloc(n) == hipSuccess &&
-            mg::launch_sparse_row_keys(sp->off, sp->rank_img, sp->gstart, (uint32_t)n, sp->rs, d_key, ctx->stream) == hipSuccess &&
-            hipMemcpyAsync(key.data(), d_key, n * 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
-            hipStreamSynchronize(ctx->stream) == hipSuccess) {
-            sp->order_host.resize(n);
-            for (uint64_t i = 0; i < n; i++) sp->order_host[i] = (uint32_t)i;
-            std::sort(sp->order_host.begin(), sp->order_host.end(), [&](uint32_t x, uint32_t y) {
-                const uint32_t kx = key[rep[x]], ky = key[rep[y]];          // a copy reads what its representative reads
-                return kx != ky ? kx < ky : x > y;
-            });
-        } else {
-            (void)hipGetLastError();
-        }
-    }
     if (getenv("MASHGPU_SPARSE_DBG"))
-        fprintf(stderr, "compare sparse: index of %llu rows (%llu copies of earlier rows), s %u: %u entries, %u distinct, shared %llu, largest run %u, %llu entries with a copied run, %.2f ms\n",
-                (unsigned long long)n, (unsigned long long)sp->copies, s, E, sp->G, (unsigned long long)sp->shared, sp->max_group,
-                (unsigned long long)sp->runs_dropped, sp->build_ms);
+        fprintf(stderr, "compare sparse: index of %llu rows (%llu copies of earlier rows), s %u: %u entries, %u distinct, shared %llu, largest run %u, %.2f ms\n",
+                (unsigned long long)n, (unsigned long long)sp->copies, s, E, sp->G, (unsigned long long)sp->shared, sp->max_group, sp->build_ms);
     return MG_OK;
 }
 
@@ -2163,6 +2228,9 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, mg_tab
 // distance 1 and p-value 1, no filter lets it through) -- discover + merge run, the output is neither
 // filled nor touched, and the job describes the candidate list {row, col} / {common, denom} left in
 // the index's buffers.  Refused (handled = false) where pairs outside the list could survive.
+// Order of a pass: DISCOVER first (it also counts: the candidates K and the shared hashes I of the job,
+// which decide the engine the first time a job is seen -- there is no separate counting pass), then fill,
+// merge, scatter.
 struct SparseJob { mg::SparseArgs args; uint64_t cand = 0; mg_table::Sparse *ix = nullptr; };
 
 static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, uint64_t row_begin, uint64_t row_end,
@@ -2188,7 +2256,7 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
     // ---- row side ----
     mg::SparseArgs a;
     a.sorted_rows = ix->sorted_rows;
-    a.col_img = ix->rank_img;
+    a.col_img = ix->code_img;
     a.col_cnt_off = ix->off;
     a.rs_col = ix->rs;
     a.ncols = (uint32_t)cols->n;
@@ -2200,20 +2268,21 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
     a.cls_of = ix->cls_of;
     a.cls_off = ix->cls_off;
     a.cls_rows = ix->cls_rows;
-    a.gstart = ix->gstart;
+    a.gend = ix->gend;
     a.res = nullptr;
     a.seg_base = nullptr;
     a.seg_cnt = nullptr;
     a.chunk_inc = nullptr;
-    DevBuf<uint32_t> q_off, q_img, q_short, q_short_cnt;
-    DevBuf<uint2> q_lohi;
+    DevBuf<uint32_t> q_off(ctx), q_img(ctx), q_lo(ctx), q_hi(ctx), q_short(ctx), q_short_cnt(ctx);
     std::vector<uint32_t> qshort_h, qshort_cnt_h;
     const uint32_t *short_rows_dev = nullptr, *short_rcnt_dev = nullptr;
     uint32_t nshort_rows = 0;
     if (triangle) {
-        a.lohi = ix->lohi;
+        a.lo_img = ix->code_img;
+        a.hi_img = ix->pos_img;
+        a.lo_shift = 1;
         a.off = ix->off;
-        a.row_img = ix->rank_img;
+        a.row_img = ix->code_img;
         a.rs_row = ix->rs;
         a.row_begin = (uint32_t)row_begin;
         a.row_end = (uint32_t)row_end;
@@ -2241,11 +2310,11 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
             if (c && rows->last[row_begin + q] == MG_HASH_PAD) return MG_OK;
         }
         qoff[nrows] = (uint32_t)Eq;
-        q_off.owner = q_img.owner = q_short.owner = q_short_cnt.owner = ctx;
-        q_lohi.owner = ctx;
         const uint32_t rsq = ix->rs;
-        if (q_off.alloc(nrows + 1) != hipSuccess || q_img.alloc(nrows * rsq) != hipSuccess || q_lohi.alloc(std::max<uint64_t>(Eq, 1)) != hipSuccess ||
-            q_short.alloc(std::max<size_t>(qshort_h.size(), 1)) != hipSuccess || q_short_cnt.alloc(std::max<size_t>(qshort_h.size(), 1)) != hipSuccess) {
+        if (nrows * rsq >= (1ull << 32)) return MG_OK;
+        if (q_off.alloc(nrows + 1) != hipSuccess || q_img.alloc(nrows * rsq) != hipSuccess || q_lo.alloc(nrows * rsq) != hipSuccess ||
+            q_hi.alloc(nrows * rsq) != hipSuccess || q_short.alloc(std::max<size_t>(qshort_h.size(), 1)) != hipSuccess ||
+            q_short_cnt.alloc(std::max<size_t>(qshort_h.size(), 1)) != hipSuccess) {
             (void)hipGetLastError();
             return MG_OK;                                   // no memory for the query side: tile engine
         }
@@ -2255,9 +2324,11 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
             HIP_TRY(ctx, hipMemcpyAsync(q_short_cnt, qshort_cnt_h.data(), qshort_h.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         }
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));    // the host vectors go out of scope below
-        HIP_TRY(ctx, mg::launch_sparse_locate(rows->hashes, rows->s, q_off, (uint32_t)row_begin, (uint32_t)nrows, ix->keys_sorted, ix->grp,
-                                              ix->gstart, ix->E, ix->G, rsq, q_lohi, q_img, ctx->stream));
-        a.lohi = q_lohi;
+        HIP_TRY(ctx, mg::launch_sparse_locate(rows->hashes, rows->s, q_off, (uint32_t)row_begin, (uint32_t)nrows, ix->keys_sorted, ix->gend,
+                                              ix->E, rsq, q_lo, q_hi, q_img, ctx->stream));
+        a.lo_img = q_lo;
+        a.hi_img = q_hi;
+        a.lo_shift = 0;
         a.off = q_off;
         a.row_img = q_img;
         a.rs_row = rsq;
@@ -2269,39 +2340,113 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
         short_rcnt_dev = q_short_cnt;
     }
 
-    // ---- what the job holds: candidates and shared hashes (counted the first time the job is seen) ----
+    // ---- the plan of a (rows, range) job: its slice of the visiting order; candidates, shared hashes and the engine
+    // choice are learned from the first discover launch (rect: the query table may change between calls, so every
+    // call is a first call)
     mg_table::Sparse::Plan *plan = nullptr;
-    if (triangle)                                           // rect: the query table may change between calls, count every time
+    if (triangle)
         for (auto &pl : ix->plans)
             if (pl.rows == (const void *)rows && pl.rb == row_begin && pl.re == row_end && pl.triangle == triangle) plan = &pl;
     mg_table::Sparse::Plan fresh;
-    fresh.order = nullptr;
-    a.order = plan ? plan->order : nullptr;
-    if (!plan) {
-        if (triangle && !ix->order_host.empty()) {         // the rows of this job in visiting order
-            std::vector<uint32_t> ord;
-            ord.reserve(nrows);
-            for (uint32_t r : ix->order_host)
-                if (r >= row_begin && r < row_end) ord.push_back(r);
-            if (ord.size() == nrows && hipMalloc(&fresh.order, nrows * 4) == hipSuccess) {
-                if (hipMemcpyAsync(fresh.order, ord.data(), nrows * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-                    hipStreamSynchronize(ctx->stream) != hipSuccess) { hipFree(fresh.order); fresh.order = nullptr; }
-            } else {
-                (void)hipGetLastError();
-            }
-            a.order = fresh.order;
-        }
-        a.cand = nullptr;
-        a.cand_cap = 0;
-        HIP_TRY(ctx, hipMemsetAsync(ix->counters, 0, 4 * 8, ctx->stream));
-        prof_begin(ctx, ctx->prof_index);
-        hipError_t e = mg::launch_sparse_discover(a, true, ctx->stream);
-        prof_end(ctx, ctx->prof_index);
-        if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare (candidate count): ") + hipGetErrorString(e));
-        unsigned long long h[2] = {0, 0};
-        HIP_TRY(ctx, hipMemcpyAsync(h, ix->counters, 16, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const bool first = plan == nullptr;
+    if (first) {
         fresh.rows = rows; fresh.rb = row_begin; fresh.re = row_end; fresh.triangle = triangle;
+        fresh.cand = 0; fresh.shared = 0; fresh.use = true; fresh.order = nullptr;
+        if (triangle && ix->order) {
+            if (row_begin == 0 && row_end == cols->n) {
+                fresh.order = nullptr;                      // the whole table: the index's own list
+            } else {                                        // the rows of this job in visiting order
+                void *q = nullptr, *tmp = nullptr, *cnt = nullptr;
+                const size_t tb = mg::sparse_order_slice_temp_bytes((uint32_t)cols->n);
+                if (ctx_malloc(ctx, &q, nrows * 4) == hipSuccess && ctx_malloc(ctx, &tmp, std::max<size_t>(tb, 16)) == hipSuccess &&
+                    ctx_malloc(ctx, &cnt, 8) == hipSuccess &&
+                    mg::launch_sparse_order_slice(ix->order, (uint32_t)cols->n, (uint32_t)row_begin, (uint32_t)row_end, tmp, tb,
+                                                  static_cast<uint32_t *>(q), static_cast<uint32_t *>(cnt), ctx->stream) == hipSuccess) {
+                    fresh.order = static_cast<uint32_t *>(q);
+                    q = nullptr;
+                } else {
+                    (void)hipGetLastError();
+                }
+                ctx_free(ctx, q);
+                ctx_free(ctx, tmp);
+                ctx_free(ctx, cnt);
+            }
+        }
+        plan = &fresh;
+    }
+    a.order = triangle && ix->order ? (plan->order ? plan->order : (row_begin == 0 && row_end == cols->n ? ix->order : nullptr)) : nullptr;
+
+    // ---- lists of the job (grown on demand, kept with the index) ----
+    auto ensure_lists = [&](uint64_t want_cand) -> int {
+        if (want_cand > ix->cand_cap) {
+            for (void **q : {(void **)&ix->cand, (void **)&ix->res})
+                if (*q) { ctx_free(ctx, *q); *q = nullptr; }
+            ix->cand_cap = 0;
+            const uint64_t cap = want_cand + want_cand / 8 + 1024;
+            void *c1 = nullptr, *c2 = nullptr;
+            if (ctx_malloc(ctx, &c1, cap * sizeof(uint2)) != hipSuccess || ctx_malloc(ctx, &c2, cap * sizeof(uint2)) != hipSuccess) {
+                (void)hipGetLastError();
+                ctx_free(ctx, c1);
+                return fail(ctx, MG_ERR_NOMEM, "compare: no device memory for the candidate list");
+            }
+            ix->cand = static_cast<uint2 *>(c1);
+            ix->res = static_cast<uint2 *>(c2);
+            ix->cand_cap = cap;
+        }
+        if (nrows > ix->seg_rows) {
+            for (void **q : {(void **)&ix->seg_base, (void **)&ix->seg_cnt, (void **)&ix->chunks, (void **)&ix->chunk_inc, &ix->scan_temp})
+                if (*q) { ctx_free(ctx, *q); *q = nullptr; }
+            ix->seg_rows = 0;
+            const uint64_t cap = nrows + nrows / 8 + 256;
+            ix->scan_temp_bytes = mg::sparse_scan_temp_bytes((uint32_t)cap);
+            void *p1 = nullptr, *p2 = nullptr, *p3 = nullptr, *p4 = nullptr, *p5 = nullptr;
+            if (ctx_malloc(ctx, &p1, cap * 8) != hipSuccess || ctx_malloc(ctx, &p2, cap * 4) != hipSuccess ||
+                ctx_malloc(ctx, &p3, cap * 4) != hipSuccess || ctx_malloc(ctx, &p4, cap * 4) != hipSuccess ||
+                ctx_malloc(ctx, &p5, std::max<size_t>(ix->scan_temp_bytes, 16)) != hipSuccess) {
+                (void)hipGetLastError();
+                for (void *q : {p1, p2, p3, p4, p5}) ctx_free(ctx, q);
+                return fail(ctx, MG_ERR_NOMEM, "compare: no device memory for the merge work list");
+            }
+            ix->seg_base = static_cast<unsigned long long *>(p1);
+            ix->seg_cnt = static_cast<uint32_t *>(p2);
+            ix->chunks = static_cast<uint32_t *>(p3);
+            ix->chunk_inc = static_cast<uint32_t *>(p4);
+            ix->scan_temp = p5;
+            ix->seg_rows = cap;
+        }
+        return MG_OK;
+    };
+    if (!first && !force && !plan->use) return MG_OK;      // a job the tile engine was found to do faster
+    // first sight of a job: room for one candidate per two index entries, at most 2^27 (2 GB of lists from the pool; C3
+    // has one per twenty, the clade table one per two); a job that holds more is discovered twice, the second time
+    // with the count the first one left
+    uint64_t want = first ? std::max<uint64_t>(ix->cand_cap, std::min<uint64_t>(pairs, std::min<uint64_t>(std::max<uint64_t>((uint64_t)ix->E / 2, 1u << 16), 1ull << 27)))
+                          : plan->cand;
+    unsigned long long h[3] = {0, 0, 0};
+    const bool nothing_to_find = triangle && ix->one_class != 0;      // nothing but copies of one sketch: every pair is inside the class
+    for (int attempt = 0; !nothing_to_find; attempt++) {
+        rc = ensure_lists(want);
+        if (rc != MG_OK) { if (first && fresh.order) ctx_free(ctx, fresh.order); return rc; }
+        a.cand = ix->cand;
+        a.res = ix->res;
+        a.cand_cap = ix->cand_cap;
+        a.seg_base = ix->seg_base;
+        a.seg_cnt = ix->seg_cnt;
+        a.chunk_inc = ix->chunk_inc;
+        HIP_TRY(ctx, hipMemsetAsync(ix->counters, 0, 4 * 8, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ix->seg_cnt, 0, nrows * 4, ctx->stream));
+        prof_begin(ctx, ctx->prof_discover);
+        hipError_t e = mg::launch_sparse_discover(a, false, ctx->stream);
+        prof_end(ctx, ctx->prof_discover);
+        if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare (discover): ") + hipGetErrorString(e));
+        if (!first) break;                                  // a job seen before: its list has the size it needed then (checked at the end)
+        HIP_TRY(ctx, hipMemcpyAsync(h, ix->counters, 24, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (h[2] == 0) break;
+        if (attempt >= 1) { if (fresh.order) ctx_free(ctx, fresh.order); return fail(ctx, MG_ERR_INVALID, "compare: the table changed while it was compared"); }
+        want = h[0];
+    }
+    if (first) {
         fresh.cand = h[0];
         fresh.shared = h[1];
         // seconds, one MI355X (measured: profiles/r03_sparse_phases.txt)
@@ -2317,129 +2462,67 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
                     (unsigned long long)fresh.cand, (unsigned long long)fresh.shared, t_sparse * 1e3, t_dense * 1e3);
         if (triangle) {
             if (ix->plans.size() >= 64) {
-                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-                if (ix->plans.front().order) hipFree(ix->plans.front().order);
+                if (ix->plans.front().order) ctx_free(ctx, ix->plans.front().order);
                 ix->plans.erase(ix->plans.begin());
             }
             ix->plans.push_back(fresh);
             plan = &ix->plans.back();
-        } else {
-            plan = &fresh;
         }
     }
     if (!force && !plan->use) return MG_OK;
 
     // ---- fill.  The candidates' results are kept in list order and scattered into the output after it.
-    // (Optionally on its own stream beside discover + merge.  Everything small that discover needs is
-    // queued BEFORE the fill starts: a kernel that ends while the fill is running waits for the L2's
-    // write-back at its end, behind 40 GB of dirty lines -- measured: a 32-byte memset took 4.4 ms,
-    // profiles/r03_overlap_trace.txt.)
-    // MEASURED (profiles/r03_sparse_phases.json): side by side with the fill, discover takes 13.2 ms instead
-    // of 6.2 -- its loads queue behind 40 GB of writes -- and the pass 19.4 ms instead of 19.3: nothing is
-    // gained, so the phases run one after the other unless MASHGPU_SPARSE_OVERLAP=1 asks for the experiment.
-    bool overlap = false;
-    if (const char *e = getenv("MASHGPU_SPARSE_OVERLAP")) overlap = plan->cand != 0 && atoi(e) != 0;
-    uint32_t fill_bpc = overlap ? 4u : 16u;               // workgroups per CU: leave room for the other kernels
-    if (const char *e = getenv("MASHGPU_SPARSE_FILL_BPC")) fill_bpc = (uint32_t)std::max(1, atoi(e));
-    if (plan->cand != 0) {
-        if (plan->cand > ix->cand_cap) {
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            for (void **q : {(void **)&ix->cand, (void **)&ix->res})
-                if (*q) { hipFree(*q); *q = nullptr; }
-            ix->cand_cap = 0;
-            const uint64_t cap = plan->cand + plan->cand / 8 + 1024;
-            if (hipMalloc(&ix->cand, cap * sizeof(uint2)) != hipSuccess || hipMalloc(&ix->res, cap * sizeof(uint2)) != hipSuccess) {
-                (void)hipGetLastError();
-                return fail(ctx, MG_ERR_NOMEM, "compare: no device memory for the candidate list");
-            }
-            ix->cand_cap = cap;
-        }
-        if (nrows > ix->seg_rows) {
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            for (void **q : {(void **)&ix->seg_base, (void **)&ix->seg_cnt, (void **)&ix->chunks, (void **)&ix->chunk_inc, &ix->scan_temp})
-                if (*q) { hipFree(*q); *q = nullptr; }
-            ix->seg_rows = 0;
-            const uint64_t cap = nrows + nrows / 8 + 256;
-            ix->scan_temp_bytes = mg::sparse_scan_temp_bytes((uint32_t)cap);
-            if (hipMalloc(&ix->seg_base, cap * 8) != hipSuccess || hipMalloc(&ix->seg_cnt, cap * 4) != hipSuccess ||
-                hipMalloc(&ix->chunks, cap * 4) != hipSuccess || hipMalloc(&ix->chunk_inc, cap * 4) != hipSuccess ||
-                hipMalloc(&ix->scan_temp, std::max<size_t>(ix->scan_temp_bytes, 16)) != hipSuccess) {
-                (void)hipGetLastError();
-                return fail(ctx, MG_ERR_NOMEM, "compare: no device memory for the merge work list");
-            }
-            ix->seg_rows = cap;
-        }
-        HIP_TRY(ctx, hipMemsetAsync(ix->counters, 0, 4 * 8, ctx->stream));
-        HIP_TRY(ctx, hipMemsetAsync(ix->seg_cnt, 0, nrows * 4, ctx->stream));
-    }
-    hipStream_t fs = ctx->stream;
-    if (job) overlap = false;
-    if (overlap) {
-        if (!ctx->aux) {
-            HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
-            HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-            HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-        }
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));      // the output buffer is ours from here on
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
-        fs = ctx->aux;
-    }
+    // (Side by side with discover + merge on a second stream the fill was MEASURED to gain nothing -- discover's
+    // loads queue behind 40 GB of writes, and a kernel that merely ends under the fill waits milliseconds for the
+    // L2's write-back, profiles/r03_sparse_phases.json, r03_overlap_trace.txt -- so the phases run one after the other.)
     if (!job) {
-        prof_begin(ctx, ctx->prof_fill, fs);
-        // (MASHGPU_SPARSE_ONE_CLASS=1 -- opt-in, compare_sparse_x.hip: a table of n copies of one sketch: the fill IS the
-        //  answer, {c, c} in every slot, written once)
-        const bool all_copies = triangle && ix->one_class != 0 && getenv("MASHGPU_SPARSE_ONE_CLASS") != nullptr;
-        hipError_t e = all_copies ? mg::launch_sparse_fill_value(a.out, pairs, ix->one_class, ix->one_class, fill_bpc, (uint32_t)ctx->cu_count, fs)
-                                  : mg::launch_sparse_fill(a.out, pairs, s, fill_bpc, (uint32_t)ctx->cu_count, fs);
+        prof_begin(ctx, ctx->prof_fill);
+        // a table of n copies of one sketch: the fill IS the answer, {c, c} in every slot, written once
+        const bool all_copies = triangle && ix->one_class != 0;
+        hipError_t e = all_copies ? mg::launch_sparse_fill_value(a.out, pairs, ix->one_class, ix->one_class, 16u, (uint32_t)ctx->cu_count, ctx->stream)
+                                  : mg::launch_sparse_fill_value(a.out, pairs, 0u, s, 16u, (uint32_t)ctx->cu_count, ctx->stream);
         if (e == hipSuccess && nshort_rows && !ix->short_rows_host.empty() && !all_copies)      // (copies of a SHORT sketch are {c, c} too, not {0, 2c})
             e = mg::launch_sparse_fill_short(a.out, short_rows_dev, short_rcnt_dev, nshort_rows, ix->short_rows, ix->short_cnt,
-                                             (uint32_t)ix->short_rows_host.size(), a.row_begin, a.ncols, a.triangle, a.out_base, s, fs);
-        // pairs of two copies of one sketch: {n, n} (after the fill, on its stream)
+                                             (uint32_t)ix->short_rows_host.size(), a.row_begin, a.ncols, a.triangle, a.out_base, s, ctx->stream);
+        // pairs of two copies of one sketch: {n, n} (after the fill)
         if (e == hipSuccess && triangle && ix->cls_members && !all_copies)
             e = mg::launch_sparse_class_pairs(a.out, ix->cls_rows, ix->cls_first, ix->off, ix->rep, ix->cls_members, a.row_begin, a.row_end,
-                                              a.out_base, fs);
-        prof_end(ctx, ctx->prof_fill, fs);
+                                              a.out_base, ctx->stream);
+        prof_end(ctx, ctx->prof_fill);
         if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare (fill): ") + hipGetErrorString(e));
-        if (overlap) HIP_TRY(ctx, hipEventRecord(ctx->ev_join, fs));
     }
     *handled = true;
     if (job) { job->ix = ix; job->cand = plan->cand; job->args = a; }
     if (plan->cand == 0) return MG_OK;
-    // ---- discover + merge ----
-    a.cand = ix->cand;
-    a.res = ix->res;
-    a.cand_cap = ix->cand_cap;
-    a.seg_base = ix->seg_base;
-    a.seg_cnt = ix->seg_cnt;
-    a.chunk_inc = ix->chunk_inc;
-    prof_begin(ctx, ctx->prof_discover);
-    hipError_t e = mg::launch_sparse_discover(a, false, ctx->stream);
-    prof_end(ctx, ctx->prof_discover);
-    if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare (discover): ") + hipGetErrorString(e));
+    // ---- merge ----
     bool by_rows = mg::sparse_merge_rows_supported(a.rs_row);
     if (const char *ev = getenv("MASHGPU_SPARSE_MERGE")) by_rows = by_rows && strcmp(ev, "lanes") != 0;
     prof_begin(ctx, ctx->prof_merge);
-    bool packed = false;                                  // (MASHGPU_SPARSE_MERGE_PACK=1 -- opt-in, compare_sparse_x.hip: several rows per work item)
-    if (by_rows && getenv("MASHGPU_SPARSE_MERGE_PACK") && atoi(getenv("MASHGPU_SPARSE_MERGE_PACK")) != 0)
-        e = mg::launch_sparse_merge_pack(a, plan->cand, ix->chunks, ix->scan_temp, ix->scan_temp_bytes, &packed, ctx->stream);
+    hipError_t e = hipSuccess;
+    bool packed = false;
+    // rows with few candidates each (a collection: C3 has 50 per row) share a work item; rows with hundreds (clades)
+    // fill their own items and gain nothing from staging their neighbours (measured: 27.8 -> 33.4 ms on the clade table)
+    bool pack = by_rows && plan->cand < 64ull * nrows;
+    if (const char *ev = getenv("MASHGPU_SPARSE_MERGE_PACK")) pack = by_rows && atoi(ev) != 0;
+    if (pack) e = mg::launch_sparse_merge_pack(a, plan->cand, ix->chunks, ix->scan_temp, ix->scan_temp_bytes, &packed, ctx->stream);
     if (!packed && e == hipSuccess)
         e = by_rows ? mg::launch_sparse_merge_rows(a, plan->cand, ix->chunks, ix->scan_temp, ix->scan_temp_bytes, ctx->stream)
                     : mg::launch_sparse_merge(a, plan->cand, (uint32_t)ctx->cu_count, ctx->stream);
     prof_end(ctx, ctx->prof_merge);
     if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare (merge): ") + hipGetErrorString(e));
     if (job) job->args = a;
-    if (overlap) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));      // the fill is done
     if (!job) {
         e = mg::launch_sparse_scatter(a, plan->cand, (uint32_t)ctx->cu_count, ctx->stream);
         if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare (scatter): ") + hipGetErrorString(e));
     }
-    if (!ctx->async || !triangle || job) {
-        // the candidate list was sized from the counting pass of the same rows: an overflow means the
-        // tables changed under the cache (mg_table_wrap_dev's contract forbids it)
-        unsigned long long h[3] = {0, 0, 0};
+    if (!first && !nothing_to_find && (!ctx->async || !triangle || job)) {
+        // the candidate list was sized by the first pass over the same rows: an overflow or another count means the
+        // tables changed under the cache (mg_table_wrap_dev's contract forbids it; mg_table_invalidate is the remedy)
         HIP_TRY(ctx, hipMemcpyAsync(h, ix->counters, 24, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        if (h[2] != 0 || h[0] != plan->cand) return fail(ctx, MG_ERR_INVALID, "compare: the table changed since its index was built");
+        if (h[2] != 0 || h[0] != plan->cand) return fail(ctx, MG_ERR_INVALID, "compare: the table changed since its index was built (mg_table_invalidate)");
+    } else if (!ctx->async || job) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
     return MG_OK;
 }

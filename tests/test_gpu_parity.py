@@ -235,6 +235,27 @@ def test_sketch_target_coverage_early_stop(eng, oracle, k, s, m):
         assert np.array_equal(ch, h0) and np.array_equal(cc, c0), (k, s, m, per)
 
 
+def test_reads_session_record_longer_than_the_event_buffer(eng, oracle):
+    """`mash sketch -r` on a chromosome-level record.  While the heap is not full every k-mer is an
+    event, so a record of more than 2^23 k-mers overflowed the event buffer and the call failed; records are now cut into
+    pieces of k-mer positions, the stop test of -c still follows whole records.  One 9.5 Mbp record between short reads,
+    with -m 2 (the kept set stays below s for long: every k-mer an event), plain -r and -c; the oracle has no limit."""
+    from workloads import synth
+    rng = np.random.default_rng(12)
+    k, s = 21, 1000
+    big = bytes(synth.synthetic_genome(3, 9_500_000))
+    small = [bytes(synth.synthetic_genome(4, 30_000))[i * 150:(i + 1) * 150] for i in range(150)]
+    reads = small[:50] + [big] + small[50:] + [big[4_000_000:4_600_000]]
+    for kw in (dict(min_copies=1), dict(min_copies=2), dict(min_copies=1, target_cov=1.5)):
+        p = eng.params(k=k, s=s, **kw)
+        oh, oc, _, oused, _ = oracle.sketch_reads(reads, oracle.params(k=k, s=s, **kw))
+        for per in (7, 1000):
+            ch, cc, cused, _ = eng.sketch_reads_chunked(reads, p, per)
+            assert np.array_equal(ch, oh) and np.array_equal(cc, oc), (kw, per)
+            if "target_cov" in kw:
+                assert cused == oused, (kw, per, cused, oused)
+
+
 def test_sketch_fuzz_regressions(eng, oracle):
     """Inputs on which tests/fuzz_sketch.py found the engine wrong (tests/golden/sketch_fuzz_regressions.npz):
     long records over a handful of distinct k-mers (protein k = 3, k = 1 over an 8-letter alphabet).
@@ -665,9 +686,7 @@ def test_compare_runs_that_name_the_same_rows(eng, oracle, monkeypatch):
     """Clades: hundreds of values held by exactly the same sketches, i.e. runs of the index that are copies of each
     other.  Every pair that is linked by ANY value must be found -- here rows of two clades with a common core each
     (copied runs), values held by all rows but one (runs that differ from the core's in a single row), and bridge
-    values between the clades that are the ONLY link of their pairs.  Inverted-index engine == oracle.  With
-    MASHGPU_TEST_RUN_DEDUP=1 also with the index's run dedupe switched on (opt-in: MASHGPU_SPARSE_RUN_DEDUP, written at
-    the end of round 3, not yet validated on the GPU -- hence not part of the default suite)."""
+    values between the clades that are the ONLY link of their pairs.  Inverted-index engine == oracle."""
     rng = np.random.default_rng(77)
     n, s = 90, 96
     vals = np.sort(rng.choice(np.arange(1, 10 ** 6, dtype=np.uint64), 4000, replace=False))
@@ -699,12 +718,63 @@ def test_compare_runs_that_name_the_same_rows(eng, oracle, monkeypatch):
     got = eng.compare_tri_host(t)
     assert np.array_equal(got["numer"], numer) and np.array_equal(got["denom"], denom)
     t.free()
-    if os.environ.get("MASHGPU_TEST_RUN_DEDUP"):
-        monkeypatch.setenv("MASHGPU_SPARSE_RUN_DEDUP", "1")
-        t = eng.table_upload(table, nhash, lengths)
-        dedup = eng.compare_tri_host(t)
-        assert dedup.tobytes() == got.tobytes()
-        t.free()
+
+
+def test_table_invalidate_after_the_buffers_changed(eng, oracle, monkeypatch):
+    """mg_table_invalidate: a wrapped table whose buffers were refilled is answered from the NEW contents -- index, plans,
+    classes of copies, short rows all rebuilt (first table: clusters; second: other values, some rows short, some
+    copies) -- and the blocks of the dropped index are reused (the context's pool), also by a table of another shape."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(91)
+    n, s = 400, 120
+    def make(seed, short=False, copies=False):
+        r = np.random.default_rng(seed)
+        pool = np.sort(r.choice(np.arange(1, 10 ** 7, dtype=np.uint64), 40 * 200, replace=False)).reshape(40, 200)
+        table = np.full((n, s), np.uint64(abi.HASH_PAD), dtype=np.uint64)
+        nhash = np.zeros(n, dtype=np.uint32)
+        for i in range(n):
+            c = pool[i % 40]
+            k = int(r.integers(20, s)) if short and i % 5 == 0 else s
+            row = np.sort(r.choice(c, k, replace=False))
+            table[i, :k] = row
+            nhash[i] = k
+        if copies:
+            for i in range(10, n, 37):
+                table[i] = table[i - 7]; nhash[i] = nhash[i - 7]
+        return table, nhash
+    lengths = np.full(n, 10 ** 6, dtype=np.uint64)
+    t1, n1 = make(1)
+    t2, n2 = make(2, short=True, copies=True)
+    monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", "sparse")
+    dh = torch.from_numpy(t1.view(np.int64)).to(dev)
+    dn = torch.from_numpy(n1.view(np.int32)).to(dev)
+    dl = torch.from_numpy(lengths.view(np.int64)).to(dev)
+    out = torch.zeros((n * (n - 1) // 2, 2), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    t = eng.table_wrap(dh.data_ptr(), dn.data_ptr(), dl.data_ptr(), n, s, keep=(dh, dn, dl))
+    for table, nhash in ((t1, n1), (t2, n2), (t1, n1)):
+        dh.copy_(torch.from_numpy(table.view(np.int64)))
+        dn.copy_(torch.from_numpy(nhash.view(np.int32)))
+        torch.cuda.synchronize()
+        t.invalidate()
+        for _ in range(2):                                  # the first pass on the new contents and a pass over its cached plan
+            out.zero_()
+            eng.compare_tri_dev(t, 0, n, out.data_ptr())
+            torch.cuda.synchronize()
+            got = out.cpu().numpy()
+            numer, denom = _oracle_tri(oracle, table, nhash, lengths, 0, n)
+            assert np.array_equal(got[:, 0], numer) and np.array_equal(got[:, 1], denom)
+    # a row range (its own plan and slice of the visiting order), after another invalidate
+    t.invalidate()
+    rb, re = 150, 390
+    eng.compare_tri_dev(t, rb, re, out.data_ptr())
+    torch.cuda.synchronize()
+    numer, denom = _oracle_tri(oracle, t1, n1, lengths, rb, re)
+    got = out.cpu().numpy()[: len(numer)]
+    assert np.array_equal(got[:, 0], numer) and np.array_equal(got[:, 1], denom)
+    t.free()
+    eng.trim()
 
 
 @pytest.mark.parametrize("kernel", ["merged", "sparse"])
@@ -712,7 +782,7 @@ def test_compare_runs_that_name_the_same_rows(eng, oracle, monkeypatch):
 def test_compare_table_of_copies(eng, oracle, kernel, count, monkeypatch):
     """Nothing but copies of ONE sketch -- full, short (24 of s = 1000 hashes: two short sketches that share
     nothing would be {0, 48}, copies are {24, 24}) and of a single hash: every pair {c, c}; whole triangle and a row
-    range.  (With MASHGPU_SPARSE_ONE_CLASS=1 the inverted-index engine answers such a table with its fill alone;
+    range.  (The inverted-index engine answers a table of nothing but copies with its fill alone;
     tools/compare_fuzz.py found the short-pairs pass overwriting that fill before it shipped -- by default the pairs
     inside a class of copies are written by their own kernel after the fill.)"""
     _set_kernel(monkeypatch, kernel)

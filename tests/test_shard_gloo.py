@@ -92,15 +92,18 @@ def test_bench_multirank_plumbing_dry(tmp_path):
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-           "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-cpu", "--n-sketches", "300", "--no-cpu"]
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-cpu", "--n-sketches", "300", "--no-cpu",
+           "--detail", str(tmp_path / "detail.json")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1                                # only rank 0 prints
-    d = json.loads(lines[0])
-    assert d["dry"] is True and d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong"
-    assert d["rank_blocks"][0] == 0 and d["rank_blocks"][-1] == 300 and len(d["rank_blocks"]) == 3
-    assert d["config"]["parallelism"] == "rowblock2" and d["config"]["table_broadcast_ms"] > 0
+    assert len(lines) == 1                                # only rank 0 prints; the headline is the LAST line
+    assert r.stdout.rstrip().splitlines()[-1] == lines[0] and len(lines[0]) < 4096
+    h = json.loads(lines[0])
+    assert h["dry"] is True and h["n_gpus"] == 2 and h["steps"] == 2 and h["scaling"] == "strong"
+    assert h["rank_blocks"][0] == 0 and h["rank_blocks"][-1] == 300 and len(h["rank_blocks"]) == 3
+    assert h["config"]["parallelism"] == "rowblock2" and h["config"]["table_broadcast_ms"] > 0
+    d = json.loads(open(tmp_path / "detail.json").read())      # everything else: the detail file
     # the blocks were re-cut after the measured step: a row's cost in pairs came out of the all-reduce, and with it the
     # first block is smaller than its equal-area size
     from mash_amd import shard

@@ -6,8 +6,9 @@ short and identical rows, values shared by many rows, values at the top of the h
   1. a pair that shares no hash gives {0, min(s, |A| + |B|)} -- the fill;
   2. the pairs sharing a hash are exactly what the runs of the sorted (value, row) index yield
      -- the discovery;
-  3. the reference's loop run on codes (2 * dense rank in the table; for rect queries the code
-     scheme of sp_locate_kernel) takes the same branches as on the 64-bit values -- the merge.
+  3. the reference's loop run on codes (2 * the first sorted position of the value's group in the
+     table's index -- ordered and equal exactly as the values are; for rect queries the code scheme
+     of sp_locate_kernel) takes the same branches as on the 64-bit values -- the merge.
 The GPU tests then only have to show that the kernels do what this model does."""
 import numpy as np
 import pytest
@@ -34,9 +35,11 @@ def build_index(table, nhash, s):
     pos_of = np.empty(len(ks), dtype=np.int64)
     pos_of[order] = np.arange(len(ks))                     # entry -> sorted position
     rank_of = grp[pos_of]                                  # entry -> dense rank of its value
-    lo_of = gstart[rank_of]
+    lo_of = gstart[rank_of]                                # entry -> first sorted position of its value (code / 2)
+    gend = np.zeros(len(ks) + 1, dtype=np.int64)           # defined at group starts: one past the group's last position
+    gend[gstart[:-1]] = gstart[1:]
     return dict(cnt=cnt, off=off, ks=ks, grp=grp, gstart=gstart, sorted_rows=sorted_rows, pos_of=pos_of,
-                rank_of=rank_of, lo_of=lo_of)
+                rank_of=rank_of, lo_of=lo_of, gend=gend)
 
 
 def merge_codes(a, b, s):
@@ -95,17 +98,17 @@ def model_triangle(table, nhash, s, rb, re, dedup=True):
         for p in range(ix["cnt"][er]):
             e = off[er] + p
             lo = ix["lo_of"][e]
-            hi = ix["pos_of"][e] if er == i else ix["gstart"][ix["rank_of"][e] + 1]
+            hi = ix["pos_of"][e] if er == i else ix["gend"][lo]
             marked.update(int(r) for r in ix["sorted_rows"][lo:hi] if r < i and r != er)
         assert all(rep[c] == c for c in marked)
         cand = sorted(b for c in marked for b in members[c] if b < i)
         ncand += len(cand)
         # merge on codes, through the representatives
-        ai = 2 * ix["rank_of"][off[er]: off[er + 1]]
+        ai = 2 * ix["lo_of"][off[er]: off[er + 1]]
         for j in cand:
             rj = int(rep[j])
             assert rj != er
-            row_n[j], row_d[j] = merge_codes(ai, 2 * ix["rank_of"][off[rj]: off[rj + 1]], s)
+            row_n[j], row_d[j] = merge_codes(ai, 2 * ix["lo_of"][off[rj]: off[rj + 1]], s)
         # pairs inside the row's class: {n, n} (sp_class_pairs_kernel)
         for j in members[er]:
             if j < i:
@@ -116,7 +119,6 @@ def model_triangle(table, nhash, s, rb, re, dedup=True):
 
 def model_rect(ref, ref_nh, qry, qry_nh, s):
     ix = build_index(ref, ref_nh, s)
-    G = len(ix["gstart"]) - 1
     nq, nr = qry.shape[0], ref.shape[0]
     numer = np.zeros((nq, nr), dtype=np.int64)
     denom = np.zeros((nq, nr), dtype=np.int64)
@@ -128,16 +130,16 @@ def model_rect(ref, ref_nh, qry, qry_nh, s):
         codes = np.zeros(len(vals), dtype=np.int64)
         cand = set()
         for t, v in enumerate(vals):
-            g = ix["grp"][lb[t]] if lb[t] < len(ix["ks"]) else G
+            # (the lower bound of a value that occurs IS its group's first position)
             found = lb[t] < len(ix["ks"]) and ix["ks"][lb[t]] == v
-            codes[t] = 2 * g + 1 if found else 2 * g
+            codes[t] = 2 * lb[t] + 1 if found else 2 * lb[t]
             if found:
-                cand.update(ix["sorted_rows"][ix["gstart"][g]: ix["gstart"][g + 1]].tolist())
+                cand.update(ix["sorted_rows"][lb[t]: ix["gend"][lb[t]]].tolist())
         # query values between the same two table values share a code: they are only ever compared with
         # table codes, so ascending (not strictly) is all the merge needs
         assert np.all(np.diff(codes) >= 0)
         for r in cand:
-            bc = 2 * ix["rank_of"][ix["off"][r]: ix["off"][r + 1]] + 1      # the merge adds one to every table code
+            bc = 2 * ix["lo_of"][ix["off"][r]: ix["off"][r + 1]] + 1        # the merge adds one to every table code
             numer[q, r], denom[q, r] = merge_codes(codes, bc, s)
     return numer, denom
 
@@ -248,53 +250,3 @@ def test_pack_mapping_of_candidates_to_lanes(pack_min):
                         assert slot in distinct
         for r in range(nrows):
             assert np.all(seen[r] == 1), (trial, r)
-
-
-def test_runs_that_name_the_same_rows_can_be_read_once():
-    """The claim behind sp_run_dedupe_kernel (compare_sparse_x.hip, opt-in): of the entries of a row whose runs hold
-    the same rows in the same order, all but one can lose their {lo, hi} -- the candidates of the row (the rows below it
-    named by ANY of its entries) stay the same.  Table: clades with a common core, members lacking one core value
-    (runs that differ in a single row), private values, bridges that are the only link of their pairs."""
-    rng = np.random.default_rng(5)
-    n, s = 120, 64
-    vals = np.sort(rng.choice(np.arange(1, 10 ** 6, dtype=np.uint64), 6000, replace=False))
-    core = [vals[:30], vals[30:60], vals[60:90]]
-    nxt = 90
-    rows = []
-    for i in range(n):
-        own = set(int(x) for x in core[i % 3])
-        if i % 5 == 0:
-            own.discard(int(core[i % 3][i % 30]))
-        for _ in range(int(rng.integers(0, 20))):
-            own.add(int(vals[nxt])); nxt += 1
-        rows.append(own)
-    for _ in range(40):
-        x, y = int(rng.integers(0, n)), int(rng.integers(0, n))
-        v = int(vals[nxt]); nxt += 1
-        rows[x].add(v); rows[y].add(v)
-    table = np.full((n, s), PAD, dtype=np.uint64)
-    nhash = np.zeros(n, dtype=np.uint32)
-    for i, own in enumerate(rows):
-        r = np.array(sorted(own), dtype=np.uint64)[:s]
-        table[i, : len(r)] = r
-        nhash[i] = len(r)
-    ix = build_index(table, nhash, s)
-    dropped_total = 0
-    for row in range(n):
-        full, kept = set(), set()
-        seen_runs = set()
-        for e in range(ix["off"][row], ix["off"][row + 1]):
-            g = ix["rank_of"][e]
-            lo, hi = ix["gstart"][g], ix["gstart"][g + 1]
-            run = tuple(ix["sorted_rows"][lo:hi])
-            below = [r for r in run if r < row]
-            full.update(below)
-            if len(below) == 0:
-                continue
-            if run in seen_runs:                                          # a copy of a run this row has read: skipped
-                dropped_total += 1
-                continue
-            seen_runs.add(run)
-            kept.update(below)
-        assert kept == full, row
-    assert dropped_total > 1000                                           # the cores: ~29 of 30 runs per row are copies

@@ -21,6 +21,7 @@ ap.add_argument("--steps", type=int, default=2)
 ap.add_argument("--n", type=int, default=100000)
 ap.add_argument("--n-genomes", type=int, default=10000)
 ap.add_argument("--n-reads", type=int, default=10_000_000)
+ap.add_argument("--cold", action="store_true", help="compare legs: every step from an invalidated table (the per-table job)")
 args = ap.parse_args()
 torch.cuda.init()
 dev = torch.device("cuda", 0)
@@ -38,10 +39,12 @@ def triangle(h, nh, ln, n, s):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        if args.cold:
+            t.invalidate()
         eng.compare_tri_dev(t, 0, n, out.data_ptr())
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
-    res.update({"pairs": pairs, "ms_per_step": dt * 1e3, "pairs_per_s": pairs / dt,
+    res.update({"pairs": pairs, "cold": args.cold, "ms_per_step": dt * 1e3, "pairs_per_s": pairs / dt,
                 "checksum": [int(out[:, 0].sum(dtype=torch.int64).item()), int(out[:, 1].sum(dtype=torch.int64).item())]})
     t.free()
 
@@ -57,6 +60,9 @@ elif args.leg == "identical":
     triangle(*synth_torch.identical_sketch_table(n, S, device=dev), n, S)
 elif args.leg == "clades":
     triangle(*synth_torch.clade_sketch_table(n, S, device=dev), n, S)
+elif args.leg == "one_clade":
+    n = min(n, 32768)
+    triangle(*synth_torch.clade_sketch_table(n, S, clade=n, device=dev), n, S)
 elif args.leg == "sketch":
     ng, L = args.n_genomes, 1_000_000
     bases = synth_torch.synthetic_genomes(0, ng, L, device=dev)
