@@ -92,7 +92,7 @@ def compare_roofline(eng, pairs, n, s, steps, pmc):
     phases' times (index = the per-table build, present in cold steps only), and the dominant kernel against the
     bound that applies.  Meaning of every field: DESIGN.md section 5."""
     phases = {}
-    for name in ("compare", "compare_index", "compare_discover", "compare_fill", "compare_merge"):
+    for name in ("compare", "compare_index", "compare_discover", "compare_fill", "compare_dense", "compare_merge"):
         ms, k = eng.prof_avg_ms(name)
         if k:
             phases[name.replace("compare_", "")] = {"avg_ms": round(ms, 4), "per_pass": k / steps, "ms_per_pass": round(ms * k / steps, 4)}
@@ -502,7 +502,7 @@ def main():
         cold_step()
     barrier()
     dt = time.perf_counter() - t0
-    srcs = ("mash_amd/csrc/compare_sparse.hip", "mash_amd/csrc/compare_merged.hip", "mash_amd/csrc/compare_internal.h")
+    srcs = ("mash_amd/csrc/compare_sparse.hip", "mash_amd/csrc/compare_dense.hip", "mash_amd/csrc/compare_merged.hip", "mash_amd/csrc/compare_internal.h")
     pmc = load_pmc("compare_c3_cold_pmc.json", *srcs) if (n == 100_000 and world == 1 and not dry) else None
     roofline = compare_roofline(eng, my_pairs, n, S, args.steps, pmc) if not dry else {"bound": "hbm", "dry": True}
     dt = max_over_ranks(dt)
@@ -593,7 +593,7 @@ def main():
                     eng.compare_tri_dev(bt, 0, bn_rows, out.data_ptr())
                 torch.cuda.synchronize()
                 bw = time.perf_counter() - t0
-                bpmc = load_pmc(f"compare_{leg}_pmc.json", "mash_amd/csrc/compare_sparse.hip", "mash_amd/csrc/compare_merged.hip",
+                bpmc = load_pmc(f"compare_{leg}_pmc.json", "mash_amd/csrc/compare_sparse.hip", "mash_amd/csrc/compare_dense.hip", "mash_amd/csrc/compare_merged.hip",
                                 "mash_amd/csrc/compare_internal.h") if n == 100_000 else None
                 rf = compare_roofline(eng, bpairs, bn_rows, S, bsteps, bpmc)
                 eng.prof_enable(False)
@@ -966,7 +966,7 @@ def main():
                 eng.compare_tri_dev(t5, 0, n5, out5.data_ptr())
             torch.cuda.synchronize()
             w5 = time.perf_counter() - t0
-            pmc5 = load_pmc("compare_c5_pmc.json", "mash_amd/csrc/compare_sparse.hip", "mash_amd/csrc/compare_merged.hip",
+            pmc5 = load_pmc("compare_c5_pmc.json", "mash_amd/csrc/compare_sparse.hip", "mash_amd/csrc/compare_dense.hip", "mash_amd/csrc/compare_merged.hip",
                             "mash_amd/csrc/compare_internal.h") if n5 == 100_000 else None
             rf5 = compare_roofline(eng, pairs5, n5, S5, steps5, pmc5)
             eng.prof_enable(False)
@@ -998,6 +998,15 @@ def main():
             result["cli_e2e"] = {"sketch": sk_cli, "host_cores": os.cpu_count()}
         except Exception as e:
             result["cli_e2e"] = {"error": repr(e)}
+        # ... and the compare commands: `mash triangle`, `triangle -E -d`, `dist -d` (tools/compare_e2e.py)
+        try:
+            import compare_e2e
+            ct = synth_torch.clustered_sketch_table(n, S, clusters=max(1, n // 100), device=dev)
+            tab = (ct[0].cpu().numpy().view(np.uint64), ct[1].cpu().numpy().astype(np.uint32), ct[2].cpu().numpy().astype(np.uint64))
+            del ct
+            result["cli_e2e"].update(compare_e2e.run(n_big=min(n, 20000), n_filter=n, n_small=min(n, 3000), threads=16, table=tab))
+        except Exception as e:
+            result["cli_e2e"]["compare_error"] = repr(e)
 
     if rank == 0:
         emit(result, args.detail)

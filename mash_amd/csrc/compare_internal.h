@@ -132,8 +132,9 @@ uint32_t sparse_img_stride(uint32_t s);          // row stride of a code image
 hipError_t sparse_build_index(const uint64_t *hashes, uint64_t stride, const uint32_t *off, uint32_t n, uint32_t E,
                               uint32_t rs, uint32_t end_bit, void *temp, size_t temp_bytes, uint64_t *keys_a,
                               uint32_t *idx_a, uint64_t *keys_sorted, uint32_t *idx_sorted, uint32_t *head, uint32_t *gs_of,
-                              uint32_t *sorted_rows, uint32_t *gend, uint32_t *code_img, uint32_t *pos_img,
+                              uint32_t *sorted_rows, uint32_t *gend, uint32_t *code_img, uint32_t *pos_img, void *stat_scratch,
                               unsigned long long *incidences, uint32_t *max_group, uint32_t *groups, uint32_t *bad, hipStream_t stream);
+size_t sparse_stat_scratch_bytes();
 hipError_t launch_sparse_locate(const uint64_t *qhashes, uint64_t qstride, const uint32_t *qoff, uint32_t q_begin, uint32_t nq,
                                 const uint64_t *keys_sorted, const uint32_t *gend, uint32_t E, uint32_t rs, uint32_t *qlo_img,
                                 uint32_t *qhi_img, uint32_t *qcode_img, hipStream_t stream);
@@ -156,6 +157,36 @@ hipError_t launch_sparse_fill_short(uint2 *out, const uint32_t *short_rows, cons
                                     const uint32_t *short_cols, const uint32_t *short_ccnt, uint32_t nshort_cols,
                                     uint32_t row_begin, uint32_t ncols, uint32_t triangle, uint64_t out_base, uint32_t s,
                                     hipStream_t stream);
+
+// Dense group engine (compare_dense.hip): the pairs inside a group of near-identical consecutive rows as bit-mask
+// arithmetic over the group's universe (the values at least two of its rows hold).
+struct DenseGroup {
+    uint32_t g0, g1;               // rows [g0, g1)
+    uint32_t ustart, u;            // the group's universe: ulist[ustart .. ustart + u), ascending sorted positions (= codes / 2)
+    uint32_t W;                    // (u >> 6) + 1 mask words per row
+    uint32_t xrow0;                // index of row g0 among the grouped rows (extras of row r: ext + (xrow0 + r - g0) * xs)
+    uint64_t data_off;             // first block of the group in gdata (u64 words); a block = 128 rows: W x 128 u64 + (W + 1) x 128 u16
+};
+struct DenseTile { uint32_t group, row0, cblk; };
+hipError_t launch_dense_neighbors(const uint64_t *hashes, uint64_t stride, const uint32_t *cnt, uint32_t n, uint8_t *link,
+                                  hipStream_t stream);
+size_t dense_universe_temp_bytes(uint32_t E);
+hipError_t dense_select_leaders(const uint32_t *sorted_rows, const uint32_t *gs_of, const uint32_t *gend, const uint32_t *grp_of,
+                                const DenseGroup *groups, uint32_t E, void *temp, size_t temp_bytes, uint8_t *flag, uint32_t *lead_pos,
+                                uint32_t *nlead, hipStream_t stream);
+hipError_t dense_sort_universes(const uint32_t *lead_pos, const uint32_t *nlead, uint32_t m, const uint32_t *sorted_rows, const uint32_t *gs_of,
+                                const uint32_t *grp_of, void *temp, size_t temp_bytes, uint32_t *key, uint32_t *key_sorted, uint32_t *val,
+                                uint32_t *ulist, uint32_t *ustart, uint32_t *uend, uint32_t group_bits, hipStream_t stream);
+hipError_t launch_dense_encode(const uint32_t *off, const uint32_t *code_img, uint32_t rs, const uint32_t *grp_of, const DenseGroup *groups,
+                               const uint32_t *ulist, unsigned long long *gdata, uint16_t *ext, uint32_t xs, uint32_t n, uint32_t wmax,
+                               hipStream_t stream);
+hipError_t launch_dense_clip(const uint32_t *off, const uint32_t *code_img, uint32_t *pos_img, uint32_t rs, const uint32_t *grp_of,
+                             const DenseGroup *groups, const uint32_t *sorted_rows, uint32_t n, hipStream_t stream);
+size_t dense_pairs_lds(uint32_t W);
+uint32_t dense_rows_per_tile();
+hipError_t launch_dense_pairs(const DenseTile *tiles, uint32_t ntiles, const DenseGroup *groups, const unsigned long long *gdata,
+                              const uint16_t *ext, uint32_t xs, uint32_t s, uint32_t wmax, uint32_t row_begin, uint32_t row_end,
+                              uint64_t out_base, uint2 *out, hipStream_t stream);
 
 // Distance filter + ordered compaction (see filter_pass_kernel).  `counts` holds
 // `pairs` entries in the layout the compare kernels write, starting at row

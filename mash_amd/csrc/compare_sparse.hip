@@ -82,11 +82,16 @@ __global__ __launch_bounds__(256) void sp_heads_kernel(const uint64_t *keys, con
 }
 
 // per sorted position: the row, and the entry's code and own position back into the images; the last position of a
-// group leaves the group's end at the group's start
-__global__ __launch_bounds__(256) void sp_index_scatter_kernel(const uint64_t *keys, const uint32_t *idx, const uint32_t *gs_of, uint32_t E,
+// group leaves the group's end at the group's start.  Code = 2 x group start + (1 if another row holds the value too):
+// the low bit travels with the value (every holder of a shared value carries it), so codes still compare as values do.
+// Statistics go to one of SP_STAT_SLOTS slots per workgroup -- 390 000 workgroups adding to ONE address made this
+// kernel 13.6 ms on C3 (5 ms on a table without repeated values, whose workgroups skipped two of the three atomics).
+constexpr uint32_t SP_STAT_SLOTS = 1024;
+struct SpStatSlot { unsigned long long inc; uint32_t max_group, groups; };
+
+__global__ __launch_bounds__(256) void sp_index_scatter_kernel(const uint32_t *idx, const uint32_t *gs_of, uint32_t E,
                                                                uint32_t rs, uint32_t *sorted_rows, uint32_t *gend, uint32_t *code_img,
-                                                               uint32_t *pos_img, unsigned long long *incidences, uint32_t *max_group,
-                                                               uint32_t *groups)
+                                                               uint32_t *pos_img, SpStatSlot *stat)
 {
     const uint32_t pos = blockIdx.x * 256u + threadIdx.x;
     unsigned long long inc = 0;
@@ -94,17 +99,19 @@ __global__ __launch_bounds__(256) void sp_index_scatter_kernel(const uint64_t *k
     if (pos < E) {
         const uint32_t i = idx[pos];
         const uint32_t gs = gs_of[pos];
+        const bool last = pos + 1u == E || gs_of[pos + 1u] != gs;
+        const bool shared = !(last && gs == pos);
         sorted_rows[pos] = i / rs;
-        code_img[i] = gs << 1;
+        code_img[i] = (gs << 1) | (shared ? 1u : 0u);
         pos_img[i] = pos;
         inc = pos - gs;
         heads = gs == pos ? 1u : 0u;
-        if (pos + 1u == E || keys[pos + 1u] != keys[pos]) {
+        if (last) {
             gend[gs] = pos + 1u;
             glen = pos + 1u - gs;
         }
     }
-    // block sums (one atomic per workgroup)
+    // block sums (one atomic per workgroup and statistic, spread over the slots)
     for (int d = 32; d > 0; d >>= 1) {
         inc += __shfl_xor(inc, d);
         heads += __shfl_xor(heads, d);
@@ -116,14 +123,32 @@ __global__ __launch_bounds__(256) void sp_index_scatter_kernel(const uint64_t *k
     if ((threadIdx.x & 63) == 0) { s_inc[threadIdx.x >> 6] = inc; s_len[threadIdx.x >> 6] = glen; s_heads[threadIdx.x >> 6] = heads; }
     __syncthreads();
     if (threadIdx.x == 0) {
+        SpStatSlot *sl = stat + (blockIdx.x & (SP_STAT_SLOTS - 1u));
         const unsigned long long t = s_inc[0] + s_inc[1] + s_inc[2] + s_inc[3];
         uint32_t m = s_len[0];
         for (int w = 1; w < 4; w++) m = s_len[w] > m ? s_len[w] : m;
-        if (t) atomicAdd(incidences, t);
-        if (m > 1) atomicMax(max_group, m);
-        atomicAdd(groups, s_heads[0] + s_heads[1] + s_heads[2] + s_heads[3]);
+        if (t) atomicAdd(&sl->inc, t);
+        if (m > 1) atomicMax(&sl->max_group, m);
+        atomicAdd(&sl->groups, s_heads[0] + s_heads[1] + s_heads[2] + s_heads[3]);
     }
 }
+
+__global__ __launch_bounds__(256) void sp_stat_reduce_kernel(const SpStatSlot *stat, unsigned long long *incidences, uint32_t *max_group,
+                                                             uint32_t *groups)
+{
+    unsigned long long inc = 0;
+    uint32_t m = 0, g = 0;
+    for (uint32_t i = threadIdx.x; i < SP_STAT_SLOTS; i += 256u) {
+        inc += stat[i].inc;
+        m = stat[i].max_group > m ? stat[i].max_group : m;
+        g += stat[i].groups;
+    }
+    if (inc) atomicAdd(incidences, inc);
+    if (m) atomicMax(max_group, m);
+    if (g) atomicAdd(groups, g);
+}
+
+size_t sparse_stat_scratch_bytes() { return sizeof(SpStatSlot) * SP_STAT_SLOTS; }
 
 __global__ __launch_bounds__(256) void sp_fill_u32_kernel(uint32_t *p, uint64_t count, uint32_t v)
 {
@@ -243,15 +268,10 @@ __global__ __launch_bounds__(256) void sp_row_key_kernel(const uint32_t *off, co
     uint32_t k = 0xFFFFFFFFu;
     for (uint32_t base = 0; base < cnt; base += 64u) {
         const uint32_t p = base + lane;
-        uint32_t gs = 0;
-        bool hit = false;
-        if (p < cnt) {
-            gs = code_img[(uint64_t)er * rs + p] >> 1;
-            hit = gend[gs] - gs >= 2u;
-        }
-        const uint64_t m = __ballot(hit);
+        const uint32_t code = p < cnt ? code_img[(uint64_t)er * rs + p] : 0u;     // (low bit: another row holds the value too)
+        const uint64_t m = __ballot((code & 1u) != 0);
         if (m != 0) {
-            k = (uint32_t)__builtin_amdgcn_readlane((int)gs, __builtin_ctzll(m));
+            k = (uint32_t)__builtin_amdgcn_readlane((int)code, __builtin_ctzll(m)) >> 1;
             break;
         }
     }
@@ -331,7 +351,7 @@ size_t sparse_sort_temp_bytes(uint32_t E, uint32_t end_bit)
 hipError_t sparse_build_index(const uint64_t *hashes, uint64_t stride, const uint32_t *off, uint32_t n, uint32_t E,
                               uint32_t rs, uint32_t end_bit, void *temp, size_t temp_bytes, uint64_t *keys_a,
                               uint32_t *idx_a, uint64_t *keys_sorted, uint32_t *idx_sorted, uint32_t *head, uint32_t *gs_of,
-                              uint32_t *sorted_rows, uint32_t *gend, uint32_t *code_img, uint32_t *pos_img,
+                              uint32_t *sorted_rows, uint32_t *gend, uint32_t *code_img, uint32_t *pos_img, void *stat_scratch,
                               unsigned long long *incidences, uint32_t *max_group, uint32_t *groups, uint32_t *bad, hipStream_t stream)
 {
     if (n == 0 || E == 0) return hipSuccess;
@@ -356,8 +376,14 @@ hipError_t sparse_build_index(const uint64_t *hashes, uint64_t stride, const uin
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(sp_index_scatter_kernel, dim3(blocks), dim3(256), 0, stream, (const uint64_t *)keys_sorted, (const uint32_t *)idx_sorted,
-                       (const uint32_t *)gs_of, E, rs, sorted_rows, gend, code_img, pos_img, incidences, max_group, groups);
+    e = hipMemsetAsync(stat_scratch, 0, sparse_stat_scratch_bytes(), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sp_index_scatter_kernel, dim3(blocks), dim3(256), 0, stream, (const uint32_t *)idx_sorted, (const uint32_t *)gs_of, E, rs,
+                       sorted_rows, gend, code_img, pos_img, static_cast<SpStatSlot *>(stat_scratch));
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sp_stat_reduce_kernel, dim3(1), dim3(256), 0, stream, static_cast<const SpStatSlot *>(stat_scratch), incidences, max_group,
+                       groups);
     return hipGetLastError();
 }
 
@@ -381,11 +407,11 @@ __global__ __launch_bounds__(256) void sp_locate_kernel(const uint64_t *qhashes,
             const uint32_t mid = lo + ((hi - lo) >> 1);
             if (keys_sorted[mid] < v) lo = mid + 1; else hi = mid;
         }
-        // Codes of the query image: table codes are 2 * (start position of the value's group), and the merge adds
-        // one to every table code it loads in rect mode (an unsigned code cannot sit below the first group
-        // otherwise): a value found -- its lower bound IS its group's start -- gets 2 lo + 1, equal to the
-        // table's; a value between two groups gets 2 lo (lo = E: above every key), which is above the previous
-        // group's 2 gs + 1 (gs < lo) and below the next group's 2 lo + 1.
+        // Codes of the query image: table codes are 2 * (start position of the value's group) (+ 1 for values several
+        // rows hold), and the merge sets the low bit of every table code it loads in rect mode (an unsigned code
+        // cannot sit below the first group otherwise): a value found -- its lower bound IS its group's start -- gets
+        // 2 lo + 1, equal to the table's; a value between two groups gets 2 lo (lo = E: above every key), which is
+        // above the previous group's 2 gs + 1 (gs < lo) and below the next group's 2 lo + 1.
         const bool found = lo < E && keys_sorted[lo] == v;
         const uint64_t at = (uint64_t)q * rs + p;
         qcode_img[at] = found ? (lo << 1) + 1u : (lo << 1);
@@ -593,7 +619,7 @@ __global__ __launch_bounds__(256) void sp_merge_kernel(SparseArgs a)
         const uint4 *A4 = reinterpret_cast<const uint4 *>(a.row_img + (uint64_t)i * a.rs_row);
         const uint4 *B4 = reinterpret_cast<const uint4 *>(a.col_img + (uint64_t)j * a.rs_col);
         uint4 ca = A4[0], cb = B4[0];
-        uint32_t av = ca.x, bv = RECT ? cb.x + 1u : cb.x;
+        uint32_t av = ca.x, bv = RECT ? (cb.x | 1u) : cb.x;
         uint32_t ia = 0, ib = 0, common = 0, denom = 0;
         while (denom < s && ia < nA && ib < nB) {          // CommandDistance.cpp:347-365
             const bool adva = av <= bv, advb = bv <= av;
@@ -608,7 +634,7 @@ __global__ __launch_bounds__(256) void sp_merge_kernel(SparseArgs a)
                 ib++;
                 if ((ib & 3u) == 0) cb = B4[ib >> 2];
                 bv = sp_pick(cb, ib & 3u);
-                if (RECT) bv += 1u;
+                if (RECT) bv |= 1u;
             }
         }
         if (denom < s) {                                   // :367-385
@@ -711,7 +737,7 @@ __global__ __launch_bounds__(SPM_NT) void sp_merge_rows_kernel(SparseArgs a)
                 for (int t = 0; t < 8; t++) {
                     const uint32_t av = A[ia];
                     uint32_t bv = myring[(ib & (SPM_RING - 1u)) * 64u];
-                    if (RECT) bv += 1u;
+                    if (RECT) bv |= 1u;
                     ia += av <= bv ? 1u : 0u;
                     ib += bv <= av ? 1u : 0u;
                 }
@@ -723,7 +749,7 @@ __global__ __launch_bounds__(SPM_NT) void sp_merge_rows_kernel(SparseArgs a)
             for (int t = 0; t < 8; t++) {
                 const uint32_t av = A[ia];
                 uint32_t bv = myring[(ib & (SPM_RING - 1u)) * 64u];
-                if (RECT) bv += 1u;
+                if (RECT) bv |= 1u;
                 const bool adva = active && av <= bv, advb = active && bv <= av;
                 denom += active ? 1u : 0u;
                 ia += adva ? 1u : 0u;
@@ -828,7 +854,7 @@ __global__ __launch_bounds__(SPM_NT) void sp_merge_rows_win_kernel(SparseArgs a)
                     for (int t = 0; t < 8; t++) {
                         const uint32_t av = A[ia - a0];
                         uint32_t bv = myring[(ib & (SPM_RING - 1u)) * 64u];
-                        if (RECT) bv += 1u;
+                        if (RECT) bv |= 1u;
                         ia += av <= bv ? 1u : 0u;
                         ib += bv <= av ? 1u : 0u;
                     }
@@ -840,7 +866,7 @@ __global__ __launch_bounds__(SPM_NT) void sp_merge_rows_win_kernel(SparseArgs a)
                 for (int t = 0; t < 8; t++) {
                     const uint32_t av = A[go ? ia - a0 : 0u];
                     uint32_t bv = myring[(ib & (SPM_RING - 1u)) * 64u];
-                    if (RECT) bv += 1u;
+                    if (RECT) bv |= 1u;
                     const bool adva = go && av <= bv, advb = go && bv <= av;
                     denom += go ? 1u : 0u;
                     ia += adva ? 1u : 0u;
@@ -982,7 +1008,7 @@ __global__ __launch_bounds__(SPM_NT) void sp_merge_pack_kernel(SparseArgs a)
                 for (int t = 0; t < 8; t++) {
                     const uint32_t av = A[ia];
                     uint32_t bv = myring[(ib & (SPM_RING - 1u)) * 64u];
-                    if (RECT) bv += 1u;
+                    if (RECT) bv |= 1u;
                     ia += av <= bv ? 1u : 0u;
                     ib += bv <= av ? 1u : 0u;
                 }
@@ -994,7 +1020,7 @@ __global__ __launch_bounds__(SPM_NT) void sp_merge_pack_kernel(SparseArgs a)
             for (int t = 0; t < 8; t++) {
                 const uint32_t av = A[ia];
                 uint32_t bv = myring[(ib & (SPM_RING - 1u)) * 64u];
-                if (RECT) bv += 1u;
+                if (RECT) bv |= 1u;
                 const bool adva = active && av <= bv, advb = active && bv <= av;
                 denom += active ? 1u : 0u;
                 ia += adva ? 1u : 0u;

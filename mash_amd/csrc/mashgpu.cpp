@@ -31,6 +31,15 @@ namespace {
 
 thread_local std::string g_create_error;
 
+// contexts that exist: a table freed after its context (interpreter teardown after a failed test) must not touch it
+std::mutex g_live_mu;
+std::vector<const void *> g_live_ctx;
+bool ctx_is_live(const void *c)
+{
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    return std::find(g_live_ctx.begin(), g_live_ctx.end(), c) != g_live_ctx.end();
+}
+
 struct ProfRec { hipEvent_t a, b; };
 
 }  // namespace
@@ -44,7 +53,7 @@ struct mg_ctx {
     bool prof = false;
     std::vector<ProfRec> prof_compare, prof_sketch;
     // phases of the inverted-index compare engine (compare_sparse.hip), each its own kernel
-    std::vector<ProfRec> prof_fill, prof_discover, prof_merge, prof_index;
+    std::vector<ProfRec> prof_fill, prof_discover, prof_merge, prof_index, prof_dense;
     // its fill runs on a stream of its own beside discover + merge (HBM-write bound vs latency bound)
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -104,7 +113,15 @@ struct mg_table {
         uint32_t *code_img = nullptr;      // [n * rs + 64] 2 x (first sorted position of the entry's value), padding 0xFFFFFFFF
         uint32_t *pos_img = nullptr;       // [n * rs] the entry's own sorted position
         uint32_t *order = nullptr;         // [n] rows in visiting order (see sp_row_key_kernel); nullptr: table order
-        uint32_t *row_inc = nullptr;       // (unused)
+        // dense groups (compare_dense.hip): runs of consecutive near-identical rows whose inner pairs are bit-mask arithmetic;
+        // the index's runs are clipped for their rows, so discovery only sees partners outside a row's group
+        std::vector<mg::DenseGroup> dgroups_host;
+        mg::DenseGroup *dgroups = nullptr;
+        uint32_t *grp_of = nullptr;        // [n] group of a row, 0xFFFFFFFF: none
+        uint32_t *ulist = nullptr;         // the groups' universes
+        unsigned long long *gdata = nullptr;
+        uint16_t *ext = nullptr;
+        uint32_t dn_wmax = 0, dn_xs = 0;
         // identical rows: rep[row] = first row of its class (nullptr: the table has no copies), classes of >= 2 rows
         uint32_t *rep = nullptr, *cls_of = nullptr, *cls_off = nullptr, *cls_rows = nullptr, *cls_first = nullptr;
         uint32_t cls_members = 0;          // rows in classes of two and more
@@ -116,7 +133,8 @@ struct mg_table {
         uint32_t *short_rows = nullptr, *short_cnt = nullptr;    // rows with fewer than s hashes (ascending) and their counts
         std::vector<uint32_t> short_rows_host;
         // what a (rows, range) job costs, learned by a counting pass the first time it is seen
-        struct Plan { const void *rows; uint64_t rb, re; bool triangle; uint64_t cand, shared; bool use; uint32_t *order; };
+        struct Plan { const void *rows; uint64_t rb, re; bool triangle; uint64_t cand, shared; bool use; uint32_t *order;
+                      mg::DenseTile *dtiles; uint32_t ndtiles; uint64_t dense_pairs; };
         std::vector<Plan> plans;
         uint2 *cand = nullptr, *res = nullptr;    // candidate list and the candidates' results, grown on demand
         uint64_t cand_cap = 0;
@@ -298,6 +316,7 @@ int mg_ctx_create(int device, mg_ctx **out)
     c->own_stream = true;
     int cus = 0;                        // (one attribute, not hipGetDeviceProperties: that call fills a page of fields)
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess) c->cu_count = cus;
+    { std::lock_guard<std::mutex> lk(g_live_mu); g_live_ctx.push_back(c); }
     *out = c;
     return MG_OK;
 }
@@ -305,6 +324,7 @@ int mg_ctx_create(int device, mg_ctx **out)
 void mg_ctx_destroy(mg_ctx *ctx)
 {
     if (!ctx) return;
+    { std::lock_guard<std::mutex> lk(g_live_mu); g_live_ctx.erase(std::remove(g_live_ctx.begin(), g_live_ctx.end(), (const void *)ctx), g_live_ctx.end()); }
     mg_prof_reset(ctx);
     for (auto &sl : ctx->slots) {
         if (sl.dev) hipFree(sl.dev);
@@ -1512,13 +1532,16 @@ static void table_drop_derived(mg_table *t)
     for (auto &w : t->win) ctx_free(ctx, w.dev);
     t->win.clear();
     for (mg_table::Sparse *sp : t->sparse) {
-        for (auto &pl : sp->plans)
+        for (auto &pl : sp->plans) {
             if (pl.order) ctx_free(ctx, pl.order);
+            if (pl.dtiles) ctx_free(ctx, pl.dtiles);
+        }
         for (void *q : {(void *)sp->off, (void *)sp->keys_sorted, (void *)sp->gend, (void *)sp->sorted_rows,
                         (void *)sp->pos_img, (void *)sp->code_img, (void *)sp->short_rows, (void *)sp->short_cnt, (void *)sp->cand,
                         (void *)sp->res, (void *)sp->seg_base, (void *)sp->seg_cnt, (void *)sp->chunks, (void *)sp->chunk_inc,
                         sp->scan_temp, (void *)sp->counters, (void *)sp->rep, (void *)sp->cls_of, (void *)sp->cls_off,
-                        (void *)sp->cls_rows, (void *)sp->cls_first, (void *)sp->order, (void *)sp->row_inc})
+                        (void *)sp->cls_rows, (void *)sp->cls_first, (void *)sp->order, (void *)sp->dgroups, (void *)sp->grp_of,
+                        (void *)sp->ulist, (void *)sp->gdata, (void *)sp->ext})
             if (q) ctx_free(ctx, q);
         delete sp;
     }
@@ -1532,6 +1555,7 @@ static void table_drop_derived(mg_table *t)
 void mg_table_free(mg_table *t)
 {
     if (!t) return;
+    if (!ctx_is_live(t->ctx)) { delete t; return; }        // the context is gone (and its device memory with it): only the handle is left
     {
         std::lock_guard<std::recursive_mutex> lk(t->ctx->mu);
         table_drop_derived(t);
@@ -1547,7 +1571,7 @@ void mg_table_free(mg_table *t)
 
 int mg_table_invalidate(mg_table *t)
 {
-    if (!t) return MG_ERR_INVALID;
+    if (!t || !ctx_is_live(t->ctx)) return MG_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lk(t->ctx->mu);
     table_drop_derived(t);
     return MG_OK;
@@ -2056,6 +2080,20 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, mg_tab
     DevBuf<uint32_t> d_cnt(ctx);
     if (d_cnt.alloc(n) != hipSuccess) { (void)hipGetLastError(); return unusable("no device memory for the index"); }
     HIP_TRY(ctx, hipMemcpyAsync(d_cnt, cnt_true.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+    // which neighbouring rows are near-copies of each other (dense groups, compare_dense.hip): a sample test per row,
+    // read back with the copy suspects below
+    std::vector<uint8_t> link;
+    bool want_dense = true;
+    if (const char *e = getenv("MASHGPU_COMPARE_DENSE")) want_dense = atoi(e) != 0;
+    DevBuf<uint8_t> d_link(ctx);
+    if (want_dense && n >= 8 && s <= 32768 && d_link.alloc(n) == hipSuccess) {      // (u16 counters of the extras)
+        link.resize(n);
+        HIP_TRY(ctx, mg::launch_dense_neighbors(t->hashes, t->s, d_cnt, (uint32_t)n, d_link, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(link.data(), d_link, n, hipMemcpyDeviceToHost, ctx->stream));
+        if (getenv("MASHGPU_SPARSE_NO_DEDUP")) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    } else {
+        (void)hipGetLastError();
+    }
     if (!getenv("MASHGPU_SPARSE_NO_DEDUP")) {
         DevBuf<unsigned long long> d_dig(ctx), d_dig_sorted(ctx);
         DevBuf<uint32_t> d_rows_sorted(ctx), d_flags(ctx), d_nflag(ctx);
@@ -2153,9 +2191,11 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, mg_tab
     DevBuf<unsigned long long> key64_a(ctx), key64_b(ctx);
     struct Stat { unsigned long long shared; uint32_t max_group, groups, bad, pad; } h_stat = {0, 0, 0, 0, 0};
     DevBuf<Stat> d_stat(ctx);
+    DevBuf<unsigned char> d_slots(ctx);
     const bool want_order = !getenv("MASHGPU_SPARSE_NO_ORDER");
     bool ok = temp.alloc(std::max<size_t>(temp_bytes, 16)) == hipSuccess && keys_a.alloc(E) == hipSuccess && idx_a.alloc(E) == hipSuccess &&
               idx_sorted.alloc(E) == hipSuccess && gs_of.alloc(E) == hipSuccess && d_stat.alloc(1) == hipSuccess &&
+              d_slots.alloc(mg::sparse_stat_scratch_bytes()) == hipSuccess &&
               (!want_order || (key64_a.alloc(n) == hipSuccess && key64_b.alloc(n) == hipSuccess));
     // retained buffers
     auto take = [&](auto **p, size_t count) {
@@ -2191,7 +2231,7 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, mg_tab
         if (e == hipSuccess)
             e = mg::sparse_build_index(t->hashes, t->s, sp->off, (uint32_t)n, E, sp->rs, end_bit, temp, temp_bytes, keys_a, idx_a,
                                        sp->keys_sorted, idx_sorted, /*head=*/idx_a, gs_of, sp->sorted_rows, sp->gend, sp->code_img, sp->pos_img,
-                                       &d_stat.p->shared, &d_stat.p->max_group, &d_stat.p->groups, &d_stat.p->bad, ctx->stream);
+                                       d_slots, &d_stat.p->shared, &d_stat.p->max_group, &d_stat.p->groups, &d_stat.p->bad, ctx->stream);
         // visiting order of the rows: by the run of their first shared value, larger rows first inside a run
         if (e == hipSuccess && want_order)
             e = mg::launch_sparse_row_order(sp->off, sp->code_img, sp->gend, sp->rep, (uint32_t)n, sp->rs, temp, temp_bytes, key64_a, key64_b,
@@ -2214,6 +2254,122 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, mg_tab
     sp->max_group = h_stat.max_group;
     sp->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     sp->usable = true;
+    // ---- dense groups: runs of at least 8 consecutive rows linked to their predecessors.  Their universes come from the
+    // index just built (gs_of is still alive), groups without one (or with one too large for a tile's LDS) are dropped,
+    // the rest are encoded and the index's runs clipped for their rows.  Any failure here leaves the index as it is.
+    if (!link.empty() && sp->copies == 0) {
+        std::vector<mg::DenseGroup> cand_groups;
+        for (uint64_t i = 1; i < n;) {
+            if (!link[i]) { i++; continue; }
+            uint64_t j = i;
+            while (j < n && link[j]) j++;                    // rows [i - 1, j) form a chain
+            if (j - (i - 1) >= 8) {
+                mg::DenseGroup g{};
+                g.g0 = (uint32_t)(i - 1); g.g1 = (uint32_t)j;
+                cand_groups.push_back(g);
+            }
+            i = j + 1;
+        }
+        auto t_dense = std::chrono::steady_clock::now();
+        while (!cand_groups.empty()) {                       // (a block to leave with `break`)
+            const uint32_t ng = (uint32_t)cand_groups.size();
+            std::vector<uint32_t> grp_of(n, 0xFFFFFFFFu);
+            for (uint32_t g = 0; g < ng; g++)
+                for (uint32_t r = cand_groups[g].g0; r < cand_groups[g].g1; r++) grp_of[r] = g;
+            DevBuf<mg::DenseGroup> d_groups(ctx);
+            DevBuf<uint32_t> d_grp_of(ctx), d_lead(ctx), d_nlead(ctx), d_us(ctx), d_ue(ctx), d_key(ctx), d_key2(ctx), d_val(ctx);
+            DevBuf<uint8_t> d_flag(ctx);
+            DevBuf<unsigned char> d_tmp(ctx);
+            const size_t tb = mg::dense_universe_temp_bytes(E);
+            if (d_groups.alloc(ng) != hipSuccess || d_grp_of.alloc(n) != hipSuccess || d_lead.alloc(E) != hipSuccess || d_nlead.alloc(1) != hipSuccess ||
+                d_us.alloc(ng) != hipSuccess || d_ue.alloc(ng) != hipSuccess || d_flag.alloc(E) != hipSuccess ||
+                d_tmp.alloc(std::max<size_t>(tb, 16)) != hipSuccess) { (void)hipGetLastError(); break; }
+            uint32_t nlead = 0;
+            hipError_t e2 = hipMemcpyAsync(d_groups, cand_groups.data(), ng * sizeof(mg::DenseGroup), hipMemcpyHostToDevice, ctx->stream);
+            if (e2 == hipSuccess) e2 = hipMemcpyAsync(d_grp_of, grp_of.data(), n * 4, hipMemcpyHostToDevice, ctx->stream);
+            if (e2 == hipSuccess)
+                e2 = mg::dense_select_leaders(sp->sorted_rows, gs_of, sp->gend, d_grp_of, d_groups, E, d_tmp, tb, d_flag, d_lead, d_nlead, ctx->stream);
+            if (e2 == hipSuccess) e2 = hipMemcpyAsync(&nlead, d_nlead, 4, hipMemcpyDeviceToHost, ctx->stream);
+            if (e2 == hipSuccess) e2 = hipStreamSynchronize(ctx->stream);
+            if (e2 != hipSuccess || nlead == 0) { (void)hipGetLastError(); break; }
+            uint32_t gbits = 1;
+            while ((1u << gbits) < ng) gbits++;
+            std::vector<uint32_t> us(ng, 0), ue(ng, 0);
+            void *ul = nullptr;
+            if (d_key.alloc(nlead) != hipSuccess || d_key2.alloc(nlead) != hipSuccess || d_val.alloc(nlead) != hipSuccess || ctx_malloc(ctx, &ul, (size_t)nlead * 4) != hipSuccess) { (void)hipGetLastError(); break; }
+            sp->ulist = static_cast<uint32_t *>(ul);
+            e2 = hipMemsetAsync(d_us, 0, ng * 4, ctx->stream);
+            if (e2 == hipSuccess) e2 = hipMemsetAsync(d_ue, 0, ng * 4, ctx->stream);
+            if (e2 == hipSuccess)
+                e2 = mg::dense_sort_universes(d_lead, d_nlead, nlead, sp->sorted_rows, gs_of, d_grp_of, d_tmp, tb, d_key, d_key2, d_val, sp->ulist, d_us, d_ue, gbits, ctx->stream);
+            if (e2 == hipSuccess) e2 = hipMemcpyAsync(us.data(), d_us, ng * 4, hipMemcpyDeviceToHost, ctx->stream);
+            if (e2 == hipSuccess) e2 = hipMemcpyAsync(ue.data(), d_ue, ng * 4, hipMemcpyDeviceToHost, ctx->stream);
+            if (e2 == hipSuccess) e2 = hipStreamSynchronize(ctx->stream);
+            if (e2 != hipSuccess) { (void)hipGetLastError(); break; }
+            // the groups that stay: a universe of at least 32 values (else the rows are not near-copies and the pairs are
+            // cheap elsewhere) and at most 48 words (a tile's LDS)
+            constexpr uint32_t kMaxWords = 48;
+            std::fill(grp_of.begin(), grp_of.end(), 0xFFFFFFFFu);
+            uint32_t xrows = 0, wmax = 0;
+            uint64_t words = 0;
+            for (uint32_t g = 0; g < ng; g++) {
+                mg::DenseGroup G = cand_groups[g];
+                G.u = ue[g] > us[g] ? ue[g] - us[g] : 0u;
+                G.ustart = us[g];
+                G.W = (G.u >> 6) + 1u;
+                if (G.u < 32u || G.W > kMaxWords) continue;
+                G.xrow0 = xrows;
+                G.data_off = words;
+                const uint64_t m = G.g1 - G.g0;
+                xrows += (uint32_t)m;
+                words += ((m + 127) / 128) * (128ull * G.W + 32ull * (G.W + 1u));
+                wmax = std::max(wmax, G.W);
+                for (uint32_t r = G.g0; r < G.g1; r++) grp_of[r] = (uint32_t)sp->dgroups_host.size();
+                sp->dgroups_host.push_back(G);
+            }
+            if (sp->dgroups_host.empty()) break;
+            sp->dn_wmax = wmax;
+            sp->dn_xs = ((s + 7u) & ~7u) + 8u;
+            void *p1 = nullptr, *p2 = nullptr, *p3 = nullptr, *p4 = nullptr;
+            if (ctx_malloc(ctx, &p1, sp->dgroups_host.size() * sizeof(mg::DenseGroup)) != hipSuccess || ctx_malloc(ctx, &p2, n * 4) != hipSuccess ||
+                ctx_malloc(ctx, &p3, words * 8) != hipSuccess || ctx_malloc(ctx, &p4, (size_t)xrows * sp->dn_xs * 2) != hipSuccess) {
+                (void)hipGetLastError();
+                for (void *q : {p1, p2, p3, p4}) ctx_free(ctx, q);
+                sp->dgroups_host.clear();
+                break;
+            }
+            sp->dgroups = static_cast<mg::DenseGroup *>(p1);
+            sp->grp_of = static_cast<uint32_t *>(p2);
+            sp->gdata = static_cast<unsigned long long *>(p3);
+            sp->ext = static_cast<uint16_t *>(p4);
+            e2 = hipMemcpyAsync(sp->dgroups, sp->dgroups_host.data(), sp->dgroups_host.size() * sizeof(mg::DenseGroup), hipMemcpyHostToDevice, ctx->stream);
+            if (e2 == hipSuccess) e2 = hipMemcpyAsync(sp->grp_of, grp_of.data(), n * 4, hipMemcpyHostToDevice, ctx->stream);
+            if (e2 == hipSuccess)
+                e2 = mg::launch_dense_encode(sp->off, sp->code_img, sp->rs, sp->grp_of, sp->dgroups, sp->ulist, sp->gdata, sp->ext, sp->dn_xs, (uint32_t)n,
+                                             wmax, ctx->stream);
+            if (e2 == hipSuccess)
+                e2 = mg::launch_dense_clip(sp->off, sp->code_img, sp->pos_img, sp->rs, sp->grp_of, sp->dgroups, sp->sorted_rows, (uint32_t)n, ctx->stream);
+            if (e2 == hipSuccess) e2 = hipStreamSynchronize(ctx->stream);   // (grp_of, the host vector, is read by the copy above)
+            if (e2 != hipSuccess) {
+                // the runs may be half clipped: this index is not to be used
+                drop();
+                for (void **q : {(void **)&sp->dgroups, (void **)&sp->grp_of, (void **)&sp->gdata, (void **)&sp->ext, (void **)&sp->ulist})
+                    if (*q) { ctx_free(ctx, *q); *q = nullptr; }
+                sp->dgroups_host.clear();
+                sp->usable = false;
+                return fail(ctx, MG_ERR_HIP, std::string("compare (index build, dense groups): ") + hipGetErrorString(e2));
+            }
+            break;
+        }
+        if (sp->dgroups_host.empty() && sp->ulist) { ctx_free(ctx, sp->ulist); sp->ulist = nullptr; }
+        sp->build_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dense).count();
+        if (getenv("MASHGPU_SPARSE_DBG")) {
+            uint64_t rows_in = 0;
+            for (auto &G : sp->dgroups_host) rows_in += G.g1 - G.g0;
+            fprintf(stderr, "compare dense: %zu chains of related rows, %zu groups kept (%llu rows, widest universe %u words)\n", cand_groups.size(),
+                    sp->dgroups_host.size(), (unsigned long long)rows_in, sp->dn_wmax);
+        }
+    }
     if (getenv("MASHGPU_SPARSE_DBG"))
         fprintf(stderr, "compare sparse: index of %llu rows (%llu copies of earlier rows), s %u: %u entries, %u distinct, shared %llu, largest run %u, %.2f ms\n",
                 (unsigned long long)n, (unsigned long long)sp->copies, s, E, sp->G, (unsigned long long)sp->shared, sp->max_group, sp->build_ms);
@@ -2249,8 +2405,8 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
     if (rc != MG_OK) return rc;
     if (!ix->usable) return MG_OK;
     // (list mode: two copies of one sketch are a pair at distance 0 that is no candidate, two EMPTY sketches
-    //  likewise -- such tables take the matrix path)
-    if (job && (ix->copies || ix->has_empty)) return MG_OK;
+    //  likewise -- such tables take the matrix path; so do tables with dense groups, whose inner pairs are in no list)
+    if (job && (ix->copies || ix->has_empty || !ix->dgroups_host.empty())) return MG_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
 
     // ---- row side ----
@@ -2352,6 +2508,32 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
     if (first) {
         fresh.rows = rows; fresh.rb = row_begin; fresh.re = row_end; fresh.triangle = triangle;
         fresh.cand = 0; fresh.shared = 0; fresh.use = true; fresh.order = nullptr;
+        fresh.dtiles = nullptr; fresh.ndtiles = 0; fresh.dense_pairs = 0;
+        if (triangle && !ix->dgroups_host.empty()) {
+            // tiles of the dense groups' inner pairs: 32 rows (aligned to the group's first row) x a block of 128 columns
+            const uint32_t R = mg::dense_rows_per_tile();
+            std::vector<mg::DenseTile> tiles;
+            for (uint32_t g = 0; g < ix->dgroups_host.size(); g++) {
+                const mg::DenseGroup &G = ix->dgroups_host[g];
+                if (G.g1 <= row_begin || G.g0 >= row_end) continue;
+                for (uint32_t row0 = G.g0; row0 < G.g1; row0 += R) {
+                    const uint64_t a_lo = std::max<uint64_t>(std::max<uint64_t>(row0, row_begin), (uint64_t)G.g0 + 1), a_hi = std::min<uint64_t>(std::min<uint64_t>(row0 + R, G.g1), row_end);
+                    if (a_lo >= a_hi) continue;
+                    for (uint64_t a = a_lo; a < a_hi; a++) fresh.dense_pairs += a - G.g0;
+                    const uint32_t cb_last = (uint32_t)((a_hi - 2 - G.g0) >> 7);         // the largest column is a_hi - 2
+                    for (uint32_t cb = 0; cb <= cb_last; cb++) tiles.push_back({g, row0, cb});
+                }
+            }
+            if (!tiles.empty()) {
+                void *q = nullptr;
+                if (ctx_malloc(ctx, &q, tiles.size() * sizeof(mg::DenseTile)) != hipSuccess) { (void)hipGetLastError(); return fail(ctx, MG_ERR_NOMEM, "compare: no device memory for the dense tiles"); }
+                hipError_t e = hipMemcpyAsync(q, tiles.data(), tiles.size() * sizeof(mg::DenseTile), hipMemcpyHostToDevice, ctx->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+                if (e != hipSuccess) { ctx_free(ctx, q); return fail(ctx, MG_ERR_HIP, std::string("compare (dense tiles): ") + hipGetErrorString(e)); }
+                fresh.dtiles = static_cast<mg::DenseTile *>(q);
+                fresh.ndtiles = (uint32_t)tiles.size();
+            }
+        }
         if (triangle && ix->order) {
             if (row_begin == 0 && row_end == cols->n) {
                 fresh.order = nullptr;                      // the whole table: the index's own list
@@ -2452,7 +2634,7 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
         // seconds, one MI355X (measured: profiles/r03_sparse_phases.txt)
         const double np = (double)pairs;
         const double t_sparse = np * 8.0 / 4.5e12 + (double)fresh.shared * 2.0e-12 + (double)nrows * s * 4.0e-11 + (double)fresh.cand * 1.0e-9 + 2.0e-5 +
-                                (triangle ? (double)ix->cls_pairs * 8.0 / 2.0e12 : 0.0);
+                                (triangle ? (double)ix->cls_pairs * 8.0 / 2.0e12 : 0.0) + (double)fresh.dense_pairs * 3.0e-11;
         const double dense_rate = np < 3.0e8 ? 8.0e9 : np < 2.0e9 ? 1.5e10 : 3.0e10;
         const double t_dense = np / dense_rate + (double)fresh.shared * 2.2e-12;
         fresh.use = t_sparse < t_dense;
@@ -2463,6 +2645,7 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
         if (triangle) {
             if (ix->plans.size() >= 64) {
                 if (ix->plans.front().order) ctx_free(ctx, ix->plans.front().order);
+                if (ix->plans.front().dtiles) ctx_free(ctx, ix->plans.front().dtiles);
                 ix->plans.erase(ix->plans.begin());
             }
             ix->plans.push_back(fresh);
@@ -2490,6 +2673,14 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
                                               a.out_base, ctx->stream);
         prof_end(ctx, ctx->prof_fill);
         if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare (fill): ") + hipGetErrorString(e));
+        // the pairs inside the dense groups (over the fill; candidates never lie inside a group)
+        if (plan->ndtiles) {
+            prof_begin(ctx, ctx->prof_dense);
+            e = mg::launch_dense_pairs(plan->dtiles, plan->ndtiles, ix->dgroups, ix->gdata, ix->ext, ix->dn_xs, s, ix->dn_wmax, a.row_begin, a.row_end,
+                                       a.out_base, a.out, ctx->stream);
+            prof_end(ctx, ctx->prof_dense);
+            if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare (dense groups): ") + hipGetErrorString(e));
+        }
     }
     *handled = true;
     if (job) { job->ix = ix; job->cand = plan->cand; job->args = a; }
@@ -4632,7 +4823,7 @@ int mg_prof_enable(mg_ctx *ctx, int on)
 void mg_prof_reset(mg_ctx *ctx)
 {
     if (!ctx) return;
-    for (auto *v : {&ctx->prof_compare, &ctx->prof_sketch, &ctx->prof_fill, &ctx->prof_discover, &ctx->prof_merge, &ctx->prof_index}) {
+    for (auto *v : {&ctx->prof_compare, &ctx->prof_sketch, &ctx->prof_fill, &ctx->prof_discover, &ctx->prof_merge, &ctx->prof_index, &ctx->prof_dense}) {
         for (auto &r : *v) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
         v->clear();
     }
@@ -4649,6 +4840,7 @@ double mg_prof_avg_ms(mg_ctx *ctx, const char *name, uint64_t *launches_out)
     else if (strcmp(name, "compare_discover") == 0) v = &ctx->prof_discover;
     else if (strcmp(name, "compare_merge") == 0) v = &ctx->prof_merge;
     else if (strcmp(name, "compare_index") == 0) v = &ctx->prof_index;
+    else if (strcmp(name, "compare_dense") == 0) v = &ctx->prof_dense;
     if (!v || v->empty()) return 0.0;
     hipStreamSynchronize(ctx->stream);
     double tot = 0.0;

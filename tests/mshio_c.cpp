@@ -66,6 +66,28 @@ int mshio_parse_summary(const uint8_t *data, uint64_t size, uint32_t *kmer, uint
     return 0;
 }
 
+// a dense sketch table (hashes[n * s] ascending rows, nhash[n], lengths[n]) as a .msh file with names <prefix><row>
+// (tools/compare_e2e.py: inputs for the compare commands of both CLIs without going through text)
+int mshio_write_table(const char *path, const uint64_t *hashes, const uint32_t *nhash, const uint64_t *lengths, uint64_t n, uint64_t s,
+                      uint32_t kmer, uint32_t seed, const char *prefix)
+{
+    mshio::File f;
+    f.header.kmer_size = kmer;
+    f.header.sketch_size = (uint32_t)s;
+    f.header.seed = seed;
+    f.header.alphabet = "ACGT";
+    f.header.has_alphabet = true;
+    f.header.concatenated = true;
+    f.references.resize(n);
+    for (uint64_t i = 0; i < n; i++) {
+        mshio::Reference &r = f.references[i];
+        r.name = std::string(prefix) + std::to_string(i);
+        r.length = lengths[i];
+        r.hashes.assign(hashes + i * s, hashes + i * s + nhash[i]);
+    }
+    return mshio::write_msh(path, f).empty() ? 0 : -1;
+}
+
 // all records of a file as "name\tcomment\tseq\n" lines in a malloc'ed buffer (differential
 // tests against a byte-by-byte restatement of kseq); returns the last status of Reader::next
 long fastx_dump(const char *path, char **out, unsigned long long *out_len)

@@ -24,7 +24,7 @@ class FakeEngine:
 
 N, S = 100_000, 1000
 PAIRS = N * (N - 1) // 2
-SRCS = ("mash_amd/csrc/compare_sparse.hip", "mash_amd/csrc/compare_merged.hip", "mash_amd/csrc/compare_internal.h")
+SRCS = ("mash_amd/csrc/compare_sparse.hip", "mash_amd/csrc/compare_dense.hip", "mash_amd/csrc/compare_merged.hip", "mash_amd/csrc/compare_internal.h")
 
 
 def _pmc():

@@ -720,6 +720,68 @@ def test_compare_runs_that_name_the_same_rows(eng, oracle, monkeypatch):
     t.free()
 
 
+def _clade_table(rng, sizes, s, keep=0.96, private=0.03, clump=False, short_every=0, gap_rows=3):
+    """consecutive clades of the given sizes (near-copies of a pool of 1.06 s values), separated by `gap_rows` unrelated
+    rows; optionally rows with many private values clumped between two pool values, and short rows"""
+    rows = []
+    for ci, m in enumerate(sizes):
+        pool = np.unique(rng.integers(1, 1 << 60, size=int(1.06 * s) + 8).astype(np.uint64))
+        for i in range(m):
+            own = pool[rng.random(len(pool)) < keep]
+            npriv = max(1, int(private * s))
+            if clump and i % 4 == 0:
+                lo, hi = int(pool[len(pool) // 3]), int(pool[len(pool) // 3 + 1])
+                priv = rng.integers(lo + 1, max(lo + 2, hi), size=5 * npriv).astype(np.uint64)
+            else:
+                priv = rng.integers(1, 1 << 60, size=npriv).astype(np.uint64)
+            r = np.unique(np.concatenate([own, priv]))
+            k = s if not (short_every and i % short_every == 1) else int(rng.integers(s // 3, s))
+            rows.append(r[:k])
+        for _ in range(gap_rows):
+            rows.append(np.unique(rng.integers(1, 1 << 60, size=s + 8).astype(np.uint64))[:s])
+    n = len(rows)
+    table = np.full((n, s), np.uint64(abi.HASH_PAD), dtype=np.uint64)
+    nhash = np.zeros(n, dtype=np.uint32)
+    for i, r in enumerate(rows):
+        table[i, : len(r)] = r
+        nhash[i] = len(r)
+    return table, nhash
+
+
+@pytest.mark.parametrize("s,sizes,kw", [
+    (1000, (40, 9, 130), dict()),                                   # what the engine is for: clades of near-copies
+    (1000, (300,), dict(keep=1.0, private=0.0)),                    # exact pool copies next to each other (the copy classes take them: no groups)
+    (128, (70, 70), dict(keep=0.95, private=0.0)),                  # universe about two words, no extras
+    (64, (200,), dict(keep=0.9, private=0.1, short_every=3)),       # one word, short rows
+    (100, (33, 150, 8), dict(clump=True, short_every=5)),           # many extras inside one gap of the universe
+    (1000, (260,), dict(keep=0.6, private=0.2)),                    # loosely related: a universe larger than s
+    (3000, (140,), dict()),                                         # a universe of 50 words: beyond a tile's LDS, the group is dropped
+])
+def test_compare_dense_groups(eng, oracle, s, sizes, kw, monkeypatch):
+    """Runs of consecutive near-identical rows (compare_dense.hip): their inner pairs as bit-mask arithmetic, everything
+    else through the inverted index with clipped runs == oracle, whole triangle and row ranges that cut through a
+    group; the same bytes with the dense groups switched off."""
+    rng = np.random.default_rng(s + sum(sizes))
+    table, nhash = _clade_table(rng, sizes, s, **kw)
+    n = len(nhash)
+    lengths = np.full(n, 10 ** 6, dtype=np.uint64)
+    numer, denom = _oracle_tri(oracle, table, nhash, lengths, 0, n)
+    monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", "sparse")
+    t = eng.table_upload(table, nhash, lengths)
+    got = eng.compare_tri_host(t)
+    assert np.array_equal(got["numer"], numer) and np.array_equal(got["denom"], denom)
+    for rb, re in ((n // 3, n - 5), (1, 2), (sizes[0] // 2, sizes[0] // 2 + 40)):
+        part = eng.compare_tri_host(t, rb, re)
+        lo, hi = rb * (rb - 1) // 2, re * (re - 1) // 2
+        assert np.array_equal(part["numer"], numer[lo:hi]) and np.array_equal(part["denom"], denom[lo:hi]), (rb, re)
+    t.free()
+    monkeypatch.setenv("MASHGPU_COMPARE_DENSE", "0")
+    t = eng.table_upload(table, nhash, lengths)
+    plain = eng.compare_tri_host(t)
+    assert plain.tobytes() == got.tobytes()
+    t.free()
+
+
 def test_table_invalidate_after_the_buffers_changed(eng, oracle, monkeypatch):
     """mg_table_invalidate: a wrapped table whose buffers were refilled is answered from the NEW contents -- index, plans,
     classes of copies, short rows all rebuilt (first table: clusters; second: other values, some rows short, some

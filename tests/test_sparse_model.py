@@ -38,8 +38,10 @@ def build_index(table, nhash, s):
     lo_of = gstart[rank_of]                                # entry -> first sorted position of its value (code / 2)
     gend = np.zeros(len(ks) + 1, dtype=np.int64)           # defined at group starts: one past the group's last position
     gend[gstart[:-1]] = gstart[1:]
+    # the code of an entry: 2 x group start, + 1 if another row holds the value too (the low bit travels with the value)
+    code_of = 2 * lo_of + (gend[lo_of] - lo_of >= 2)
     return dict(cnt=cnt, off=off, ks=ks, grp=grp, gstart=gstart, sorted_rows=sorted_rows, pos_of=pos_of,
-                rank_of=rank_of, lo_of=lo_of, gend=gend)
+                rank_of=rank_of, lo_of=lo_of, gend=gend, code_of=code_of)
 
 
 def merge_codes(a, b, s):
@@ -104,11 +106,11 @@ def model_triangle(table, nhash, s, rb, re, dedup=True):
         cand = sorted(b for c in marked for b in members[c] if b < i)
         ncand += len(cand)
         # merge on codes, through the representatives
-        ai = 2 * ix["lo_of"][off[er]: off[er + 1]]
+        ai = ix["code_of"][off[er]: off[er + 1]]
         for j in cand:
             rj = int(rep[j])
             assert rj != er
-            row_n[j], row_d[j] = merge_codes(ai, 2 * ix["lo_of"][off[rj]: off[rj + 1]], s)
+            row_n[j], row_d[j] = merge_codes(ai, ix["code_of"][off[rj]: off[rj + 1]], s)
         # pairs inside the row's class: {n, n} (sp_class_pairs_kernel)
         for j in members[er]:
             if j < i:
@@ -139,7 +141,7 @@ def model_rect(ref, ref_nh, qry, qry_nh, s):
         # table codes, so ascending (not strictly) is all the merge needs
         assert np.all(np.diff(codes) >= 0)
         for r in cand:
-            bc = 2 * ix["lo_of"][ix["off"][r]: ix["off"][r + 1]] + 1        # the merge adds one to every table code
+            bc = ix["code_of"][ix["off"][r]: ix["off"][r + 1]] | 1          # the merge sets the low bit of every table code
             numer[q, r], denom[q, r] = merge_codes(codes, bc, s)
     return numer, denom
 
