@@ -393,7 +393,8 @@ int mg_compare_rect_results_sharded_host(mg_comm *c, const mg_dtable *ref, const
  * per-hash observation lookup behind `shared` / median multiplicity (:338-355, :402-455).
  *
  * mg_screen_create builds the device table of distinct hashes of `db` (which must outlive
- * the screen; at most 2^31 hashes, i.e. two million sketches of s = 1000).  mg_screen_add_* consumes one batch of the mixture: records separated by
+ * the screen; beyond 2^31 hashes -- two million sketches of s = 1000 -- only the dense results, mg_screen_finish_host /
+ * mg_screen_counts_dev, are available: mg_screen_reset and mg_screen_finish_sparse_host return MG_ERR_UNSUPPORTED).  mg_screen_add_* consumes one batch of the mixture: records separated by
  * MG_RECORD_SEP, any case, as kseq delivers them (records shorter than k contribute no
  * k-mer).  mg_screen_finish_host returns counts_out[db_rows * db_s] = observations of
  * every sketch hash in the mixture (0 beyond nhash), the mixture's bottom-s sketch

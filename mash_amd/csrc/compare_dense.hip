@@ -281,21 +281,38 @@ hipError_t launch_dense_clip(const uint32_t *off, const uint32_t *code_img, uint
 // memory (word w of lane l at w * 128 + l: conflict free), the rows' words beside them (read by all lanes at once).
 constexpr uint32_t DN_ROWS = 32;
 
+// where a pair of index rows lands in the output: the index may have been built on a PERMUTED table (rows that belong
+// together next to each other, see dense_cluster_rows); inv maps an index row back to the table's row
+__device__ __forceinline__ uint64_t dn_out_index(uint32_t a, uint32_t b, const uint32_t *inv, uint64_t out_base)
+{
+    uint32_t i = a, j = b;
+    if (inv) {
+        i = inv[a];
+        j = inv[b];
+        if (i < j) { const uint32_t t = i; i = j; j = t; }
+    }
+    return (uint64_t)i * (i - 1u) / 2u - out_base + j;
+}
+
+// STREAM: the column block's words are read from global memory (L2) word by word instead of being staged -- universes of
+// hundreds of words (s = 10 000) do not fit the LDS; the rows' words still sit in LDS
+template <bool STREAM>
 __global__ __launch_bounds__(128) void dn_pairs_kernel(const DenseTile *tiles, const DenseGroup *groups, const unsigned long long *gdata,
                                                        const uint16_t *ext, uint32_t xs, uint32_t s, uint32_t row_begin, uint32_t row_end,
-                                                       uint64_t out_base, uint2 *out)
+                                                       uint64_t out_base, const uint32_t *inv, uint2 *out)
 {
     extern __shared__ __align__(16) unsigned long long dl[];
     const DenseTile T = tiles[blockIdx.x];
     const DenseGroup G = groups[T.group];
     const uint32_t W = G.W, tid = threadIdx.x;
     const uint64_t bw = 128ull * W + 32ull * (W + 1u);
-    unsigned long long *Bm = dl;                                          // [W][128]
-    uint16_t *Bcx = reinterpret_cast<uint16_t *>(dl + 128ull * W);        // [W + 1][128]
-    unsigned long long *Am = dl + bw;                                     // [W][DN_ROWS]
-    uint16_t *Acx = reinterpret_cast<uint16_t *>(Am + (uint64_t)DN_ROWS * W);       // [W + 1][DN_ROWS]
     const unsigned long long *bsrc = gdata + G.data_off + (uint64_t)T.cblk * bw;
-    for (uint32_t i = tid; i < (uint32_t)bw; i += 128u) Bm[i] = bsrc[i];
+    const unsigned long long *Bm = STREAM ? bsrc : dl;                                   // [W][128]
+    const uint16_t *Bcx = reinterpret_cast<const uint16_t *>(Bm + 128ull * W);             // [W + 1][128]
+    unsigned long long *Am = dl + (STREAM ? 0ull : bw);                                   // [W][DN_ROWS]
+    uint16_t *Acx = reinterpret_cast<uint16_t *>(Am + (uint64_t)DN_ROWS * W);             // [W + 1][DN_ROWS]
+    if (!STREAM)
+        for (uint32_t i = tid; i < (uint32_t)bw; i += 128u) dl[i] = bsrc[i];
     const uint32_t ra = T.row0 - G.g0;                                    // (a multiple of DN_ROWS: the tile's rows share a block)
     const unsigned long long *asrc = gdata + G.data_off + (uint64_t)(ra >> 7) * bw;
     const uint32_t la0 = ra & 127u;
@@ -353,14 +370,19 @@ __global__ __launch_bounds__(128) void dn_pairs_kernel(const DenseTile *tiles, c
                 const uint32_t total = pu + Acx[W * DN_ROWS + ai] + Bcx[W * 128u + tid];
                 denom = total < s ? total : s;
             }
-            out[(uint64_t)a * (a - 1u) / 2u - out_base + b] = make_uint2(common, denom);
+            out[dn_out_index(a, b, inv, out_base)] = make_uint2(common, denom);
         }
     }
 }
 
+// LDS of a tile: staged column block + rows (W up to dense_max_words_staged()), or the rows alone (streamed column block)
+constexpr uint32_t DN_STAGE_WORDS = 48;
+uint32_t dense_max_words_staged() { return DN_STAGE_WORDS; }
+uint32_t dense_max_words() { return 400; }                 // rows of a tile in LDS: 32 x (8 W + 2 W + 2) bytes
+
 size_t dense_pairs_lds(uint32_t W)
 {
-    const size_t bw = 128ull * W + 32ull * (W + 1u);
+    const size_t bw = W <= DN_STAGE_WORDS ? 128ull * W + 32ull * (W + 1u) : 0;
     return (bw + (size_t)DN_ROWS * W) * 8 + (size_t)(W + 1u) * DN_ROWS * 2 + 16;
 }
 
@@ -368,13 +390,124 @@ uint32_t dense_rows_per_tile() { return DN_ROWS; }
 
 hipError_t launch_dense_pairs(const DenseTile *tiles, uint32_t ntiles, const DenseGroup *groups, const unsigned long long *gdata,
                               const uint16_t *ext, uint32_t xs, uint32_t s, uint32_t wmax, uint32_t row_begin, uint32_t row_end,
-                              uint64_t out_base, uint2 *out, hipStream_t stream)
+                              uint64_t out_base, const uint32_t *inv, uint2 *out, hipStream_t stream)
 {
     if (ntiles == 0) return hipSuccess;
     const size_t smem = dense_pairs_lds(wmax);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(dn_pairs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    auto go = [&](auto kern) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(ntiles), dim3(128), smem, stream, tiles, groups, gdata, ext, xs, s, row_begin, row_end, out_base, inv, out);
+        return hipGetLastError();
+    };
+    return wmax <= DN_STAGE_WORDS ? go(dn_pairs_kernel<false>) : go(dn_pairs_kernel<true>);
+}
+
+// ------------------------------------------------------------------------------------------------
+// which rows belong together, whatever their order in the table (collections are not always listed by species): the
+// LABEL of a row is the smallest row that holds one of its first four hashes -- rows of a clade agree on it with high
+// probability (a member lacks all four of the clade's smallest values only rarely), two jumps label -> label of the
+// label close the chains -- and the rows sorted by (label, row) are the order in which the index is built.  Any
+// order would be correct; this one puts near-copies next to each other so that they form dense groups.
+constexpr uint32_t CL_FIRST = 4;
+
+__global__ __launch_bounds__(256) void cl_emit_kernel(const uint64_t *hashes, uint64_t stride, const uint32_t *cnt, uint32_t n,
+                                                      unsigned long long *key, uint32_t *row_out, uint32_t *label)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n * CL_FIRST) return;
+    const uint32_t row = i / CL_FIRST, f = i % CL_FIRST;
+    key[i] = f < cnt[row] ? (unsigned long long)hashes[(uint64_t)row * stride + f] : ~0ull;
+    row_out[i] = row;
+    if (f == 0) label[row] = row;
+}
+
+__global__ __launch_bounds__(256) void cl_minrow_kernel(const unsigned long long *key_sorted, const uint32_t *row_sorted, uint32_t m,
+                                                        uint32_t *label)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= m) return;
+    const unsigned long long k = key_sorted[i];
+    if (k == ~0ull) return;
+    uint32_t lo = 0, hi = i;                               // first position holding k (the sort is stable: its row is the smallest)
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (key_sorted[mid] < k) lo = mid + 1; else hi = mid;
+    }
+    atomicMin(&label[row_sorted[i]], row_sorted[lo]);
+}
+
+__global__ __launch_bounds__(256) void cl_jump_kernel(const uint32_t *in, uint32_t *out, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) out[i] = in[in[i]];
+}
+
+__global__ __launch_bounds__(256) void cl_order_keys_kernel(const uint32_t *label, uint32_t n, unsigned long long *key)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) key[i] = ((unsigned long long)label[i] << 32) | i;
+}
+
+__global__ __launch_bounds__(256) void cl_split_keys_kernel(const unsigned long long *key_sorted, uint32_t n, uint32_t *inv, uint32_t *label_sorted)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) {
+        inv[i] = (uint32_t)(key_sorted[i] & 0xFFFFFFFFull);
+        label_sorted[i] = (uint32_t)(key_sorted[i] >> 32);
+    }
+}
+
+size_t dense_cluster_temp_bytes(uint32_t n)
+{
+    size_t a = 0, b = 0;
+    rocprim::radix_sort_pairs(nullptr, a, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, (const uint32_t *)nullptr,
+                              (uint32_t *)nullptr, (size_t)n * CL_FIRST, 0u, 64u, (hipStream_t) nullptr);
+    rocprim::radix_sort_keys(nullptr, b, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, (size_t)n, 0u, 64u,
+                             (hipStream_t) nullptr);
+    return a > b ? a : b;
+}
+
+// scratch: key_a / key_b [4 n] u64, row_a / row_b [4 n] u32, lab_a / lab_b [n] u32.  Out: inv[n] (index row -> table row),
+// label_sorted[n] (the label of every index row: equal labels = one cluster).
+hipError_t dense_cluster_rows(const uint64_t *hashes, uint64_t stride, const uint32_t *cnt, uint32_t n, void *temp, size_t temp_bytes,
+                              unsigned long long *key_a, unsigned long long *key_b, uint32_t *row_a, uint32_t *row_b, uint32_t *lab_a,
+                              uint32_t *lab_b, uint32_t *inv, uint32_t *label_sorted, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    const uint32_t m = n * CL_FIRST;
+    hipLaunchKernelGGL(cl_emit_kernel, dim3((m + 255u) / 256u), dim3(256), 0, stream, hashes, stride, cnt, n, key_a, row_a, lab_a);
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(dn_pairs_kernel, dim3(ntiles), dim3(128), smem, stream, tiles, groups, gdata, ext, xs, s, row_begin, row_end, out_base, out);
+    e = rocprim::radix_sort_pairs(temp, temp_bytes, (const unsigned long long *)key_a, key_b, (const uint32_t *)row_a, row_b, (size_t)m, 0u, 64u,
+                                  stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(cl_minrow_kernel, dim3((m + 255u) / 256u), dim3(256), 0, stream, (const unsigned long long *)key_b, (const uint32_t *)row_b, m,
+                       lab_a);
+    hipLaunchKernelGGL(cl_jump_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, (const uint32_t *)lab_a, lab_b, n);
+    hipLaunchKernelGGL(cl_jump_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, (const uint32_t *)lab_b, lab_a, n);
+    hipLaunchKernelGGL(cl_order_keys_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, (const uint32_t *)lab_a, n, key_a);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    e = rocprim::radix_sort_keys(temp, temp_bytes, (const unsigned long long *)key_a, key_b, (size_t)n, 0u, 64u, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(cl_split_keys_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, (const unsigned long long *)key_b, n, inv, label_sorted);
+    return hipGetLastError();
+}
+
+// the table in index order: out[a] = row inv[a] (whole rows, padding included)
+__global__ __launch_bounds__(256) void cl_gather_rows_kernel(const uint64_t *hashes, uint64_t stride, const uint32_t *inv, uint64_t *out)
+{
+    const uint32_t a = blockIdx.x;
+    const uint64_t *src = hashes + (uint64_t)inv[a] * stride;
+    uint64_t *dst = out + (uint64_t)a * stride;
+    for (uint64_t p = threadIdx.x; p < stride; p += 256u) dst[p] = src[p];
+}
+
+hipError_t launch_dense_gather_rows(const uint64_t *hashes, uint64_t stride, const uint32_t *inv, uint32_t n, uint64_t *out, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(cl_gather_rows_kernel, dim3(n), dim3(256), 0, stream, hashes, stride, inv, out);
     return hipGetLastError();
 }
 

@@ -108,6 +108,7 @@ struct SparseArgs {
     const uint32_t *cls_rows;
     const uint32_t *gend;          // at a group's start position: one past its last (a copy walks the whole run of a value)
     const uint32_t *order;         // rows of the launch in visiting order (nullptr: row_end - 1 - slot)
+    const uint32_t *inv;           // index built on a permuted table: index row -> table row (nullptr: the same)
 };
 size_t sparse_dup_temp_bytes(uint32_t n);
 hipError_t launch_sparse_dup_suspects(const unsigned long long *dig, const uint32_t *cnt, uint32_t n, void *temp, size_t temp_bytes,
@@ -122,7 +123,7 @@ hipError_t launch_sparse_order_slice(const uint32_t *order, uint32_t n, uint32_t
                                      uint32_t *out, uint32_t *count_out, hipStream_t stream);
 hipError_t launch_sparse_class_pairs(uint2 *out, const uint32_t *cls_rows, const uint32_t *cls_first, const uint32_t *off,
                                      const uint32_t *rep, uint32_t members, uint32_t row_begin, uint32_t row_end, uint64_t out_base,
-                                     hipStream_t stream);
+                                     const uint32_t *inv, hipStream_t stream);
 hipError_t launch_sparse_row_digest(const uint64_t *hashes, uint64_t stride, const uint32_t *cnt, uint32_t n,
                                     unsigned long long *digest, hipStream_t stream);
 hipError_t launch_sparse_row_equal(const uint64_t *hashes, uint64_t stride, const uint32_t *cnt, const uint2 *pairs, uint32_t npairs,
@@ -156,7 +157,7 @@ hipError_t launch_sparse_merge_pack(const SparseArgs &a, uint64_t expect, uint32
 hipError_t launch_sparse_fill_short(uint2 *out, const uint32_t *short_rows, const uint32_t *short_rcnt, uint32_t nshort_rows,
                                     const uint32_t *short_cols, const uint32_t *short_ccnt, uint32_t nshort_cols,
                                     uint32_t row_begin, uint32_t ncols, uint32_t triangle, uint64_t out_base, uint32_t s,
-                                    hipStream_t stream);
+                                    const uint32_t *inv, hipStream_t stream);
 
 // Dense group engine (compare_dense.hip): the pairs inside a group of near-identical consecutive rows as bit-mask
 // arithmetic over the group's universe (the values at least two of its rows hold).
@@ -184,9 +185,16 @@ hipError_t launch_dense_clip(const uint32_t *off, const uint32_t *code_img, uint
                              const DenseGroup *groups, const uint32_t *sorted_rows, uint32_t n, hipStream_t stream);
 size_t dense_pairs_lds(uint32_t W);
 uint32_t dense_rows_per_tile();
+uint32_t dense_max_words_staged();
+uint32_t dense_max_words();
 hipError_t launch_dense_pairs(const DenseTile *tiles, uint32_t ntiles, const DenseGroup *groups, const unsigned long long *gdata,
                               const uint16_t *ext, uint32_t xs, uint32_t s, uint32_t wmax, uint32_t row_begin, uint32_t row_end,
-                              uint64_t out_base, uint2 *out, hipStream_t stream);
+                              uint64_t out_base, const uint32_t *inv, uint2 *out, hipStream_t stream);
+size_t dense_cluster_temp_bytes(uint32_t n);
+hipError_t dense_cluster_rows(const uint64_t *hashes, uint64_t stride, const uint32_t *cnt, uint32_t n, void *temp, size_t temp_bytes,
+                              unsigned long long *key_a, unsigned long long *key_b, uint32_t *row_a, uint32_t *row_b, uint32_t *lab_a,
+                              uint32_t *lab_b, uint32_t *inv, uint32_t *label_sorted, hipStream_t stream);
+hipError_t launch_dense_gather_rows(const uint64_t *hashes, uint64_t stride, const uint32_t *inv, uint32_t n, uint64_t *out, hipStream_t stream);
 
 // Distance filter + ordered compaction (see filter_pass_kernel).  `counts` holds
 // `pairs` entries in the layout the compare kernels write, starting at row

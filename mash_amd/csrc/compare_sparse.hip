@@ -1138,7 +1138,12 @@ __global__ __launch_bounds__(256) void sp_scatter_kernel(SparseArgs a)
     const uint64_t stride = (uint64_t)gridDim.x * 256u;
     for (uint64_t c = (uint64_t)blockIdx.x * 256u + threadIdx.x; c < K; c += stride) {
         const uint2 pr = a.cand[c];
-        const uint32_t i = pr.x, j = pr.y;
+        uint32_t i = pr.x, j = pr.y;
+        if (a.inv) {                                       // (triangle on a permuted index: back to the table's rows)
+            i = a.inv[pr.x];
+            j = a.inv[pr.y];
+            if (i < j) { const uint32_t t = i; i = j; j = t; }
+        }
         uint64_t oidx;
         if (a.triangle) oidx = (uint64_t)i * (i - 1u) / 2u + j - a.out_base;
         else oidx = (uint64_t)(i - a.row_begin) * a.ncols + j;
@@ -1151,25 +1156,34 @@ __global__ __launch_bounds__(256) void sp_scatter_kernel(SparseArgs a)
 // its class below it (first[i] = where its class starts in cls_rows).
 __global__ __launch_bounds__(256) void sp_class_pairs_kernel(uint2 *out, const uint32_t *cls_rows, const uint32_t *cls_first,
                                                              const uint32_t *off, const uint32_t *rep, uint32_t members,
-                                                             uint32_t row_begin, uint32_t row_end, uint64_t out_base)
+                                                             uint32_t row_begin, uint32_t row_end, uint64_t out_base, const uint32_t *inv)
 {
     const uint32_t i = blockIdx.x;
     if (i >= members) return;
     const uint32_t row = cls_rows[i];
     if (row < row_begin || row >= row_end) return;       // uniform
     const uint32_t r = rep[row], n = off[r + 1] - off[r];
-    const uint64_t base = (uint64_t)row * (row - 1u) / 2u - out_base;
     const uint2 v = make_uint2(n, n);
-    for (uint32_t u = cls_first[i] + threadIdx.x; u < i; u += 256) out[base + cls_rows[u]] = v;
+    if (!inv) {
+        const uint64_t base = (uint64_t)row * (row - 1u) / 2u - out_base;
+        for (uint32_t u = cls_first[i] + threadIdx.x; u < i; u += 256) out[base + cls_rows[u]] = v;
+    } else {                                               // (permuted index: back to the table's rows)
+        const uint32_t oi = inv[row];
+        for (uint32_t u = cls_first[i] + threadIdx.x; u < i; u += 256) {
+            const uint32_t oj = inv[cls_rows[u]];
+            const uint32_t hi = oi > oj ? oi : oj, lo = oi > oj ? oj : oi;
+            out[(uint64_t)hi * (hi - 1u) / 2u - out_base + lo] = v;
+        }
+    }
 }
 
 hipError_t launch_sparse_class_pairs(uint2 *out, const uint32_t *cls_rows, const uint32_t *cls_first, const uint32_t *off,
                                      const uint32_t *rep, uint32_t members, uint32_t row_begin, uint32_t row_end, uint64_t out_base,
-                                     hipStream_t stream)
+                                     const uint32_t *inv, hipStream_t stream)
 {
     if (members == 0) return hipSuccess;
     hipLaunchKernelGGL(sp_class_pairs_kernel, dim3(members), dim3(256), 0, stream, out, cls_rows, cls_first, off, rep, members, row_begin,
-                       row_end, out_base);
+                       row_end, out_base, inv);
     return hipGetLastError();
 }
 
@@ -1219,7 +1233,8 @@ hipError_t launch_sparse_fill_value(uint2 *out, uint64_t pairs, uint32_t numer, 
 __global__ __launch_bounds__(256) void sp_fill_short_kernel(uint2 *out, const uint32_t *short_rows, const uint32_t *short_rcnt,
                                                             uint32_t nshort_rows, const uint32_t *short_cols,
                                                             const uint32_t *short_ccnt, uint32_t nshort_cols, uint32_t row_begin,
-                                                            uint32_t ncols, uint32_t triangle, uint64_t out_base, uint32_t s)
+                                                            uint32_t ncols, uint32_t triangle, uint64_t out_base, uint32_t s,
+                                                            const uint32_t *inv)
 {
     const uint32_t k = blockIdx.x;
     if (k >= nshort_rows) return;
@@ -1229,7 +1244,13 @@ __global__ __launch_bounds__(256) void sp_fill_short_kernel(uint2 *out, const ui
         if (triangle && j >= i) break;                      // ascending
         const uint32_t d = ni + short_ccnt[t];
         if (d < s) {
-            const uint64_t oidx = triangle ? (uint64_t)i * (i - 1u) / 2u + j - out_base : (uint64_t)(i - row_begin) * ncols + j;
+            uint32_t oi = i, oj = j;
+            if (inv) {                                      // (triangle on a permuted index: back to the table's rows)
+                oi = inv[i];
+                oj = inv[j];
+                if (oi < oj) { const uint32_t x = oi; oi = oj; oj = x; }
+            }
+            const uint64_t oidx = triangle ? (uint64_t)oi * (oi - 1u) / 2u + oj - out_base : (uint64_t)(oi - row_begin) * ncols + oj;
             out[oidx] = make_uint2(0u, d);
         }
     }
@@ -1338,11 +1359,11 @@ hipError_t launch_sparse_scatter(const SparseArgs &a, uint64_t expect, uint32_t 
 hipError_t launch_sparse_fill_short(uint2 *out, const uint32_t *short_rows, const uint32_t *short_rcnt, uint32_t nshort_rows,
                                     const uint32_t *short_cols, const uint32_t *short_ccnt, uint32_t nshort_cols,
                                     uint32_t row_begin, uint32_t ncols, uint32_t triangle, uint64_t out_base, uint32_t s,
-                                    hipStream_t stream)
+                                    const uint32_t *inv, hipStream_t stream)
 {
     if (nshort_rows == 0 || nshort_cols == 0) return hipSuccess;
     hipLaunchKernelGGL(sp_fill_short_kernel, dim3(nshort_rows), dim3(256), 0, stream, out, short_rows, short_rcnt, nshort_rows,
-                       short_cols, short_ccnt, nshort_cols, row_begin, ncols, triangle, out_base, s);
+                       short_cols, short_ccnt, nshort_cols, row_begin, ncols, triangle, out_base, s, inv);
     return hipGetLastError();
 }
 

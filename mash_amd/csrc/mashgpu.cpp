@@ -122,6 +122,14 @@ struct mg_table {
         unsigned long long *gdata = nullptr;
         uint16_t *ext = nullptr;
         uint32_t dn_wmax = 0, dn_xs = 0;
+        // The index may be built on the table in ANOTHER ROW ORDER (rows that belong together next to each other, so that
+        // they form dense groups whatever the order of the collection; compare_dense.hip: dense_cluster_rows): `clustered`
+        // says this variant was asked for, inv != nullptr that the order differs -- index row a is table row inv[a], the
+        // index reads the reordered copy `phashes`, and every kernel that writes results maps rows back.  Only the plain
+        // full-triangle job uses it (row ranges, rect and list jobs address table rows and take the other variant).
+        bool clustered = false;
+        uint32_t *inv = nullptr;
+        uint64_t *phashes = nullptr;
         // identical rows: rep[row] = first row of its class (nullptr: the table has no copies), classes of >= 2 rows
         uint32_t *rep = nullptr, *cls_of = nullptr, *cls_off = nullptr, *cls_rows = nullptr, *cls_first = nullptr;
         uint32_t cls_members = 0;          // rows in classes of two and more
@@ -1541,7 +1549,7 @@ static void table_drop_derived(mg_table *t)
                         (void *)sp->res, (void *)sp->seg_base, (void *)sp->seg_cnt, (void *)sp->chunks, (void *)sp->chunk_inc,
                         sp->scan_temp, (void *)sp->counters, (void *)sp->rep, (void *)sp->cls_of, (void *)sp->cls_off,
                         (void *)sp->cls_rows, (void *)sp->cls_first, (void *)sp->order, (void *)sp->dgroups, (void *)sp->grp_of,
-                        (void *)sp->ulist, (void *)sp->gdata, (void *)sp->ext})
+                        (void *)sp->ulist, (void *)sp->gdata, (void *)sp->ext, (void *)sp->inv, (void *)sp->phashes})
             if (q) ctx_free(ctx, q);
         delete sp;
     }
@@ -2049,14 +2057,15 @@ static int run_compare_merged(mg_ctx *ctx, const mg_table *rows, const mg_table 
 // keeps the tile engine.
 // Host work per build is O(n) loops and three synchronisations (row classes, copy suspects, build
 // statistics); sorting of digests and of the visiting order happens on the device.
-static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, mg_table::Sparse **out)
+static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool clustered, mg_table::Sparse **out)
 {
     for (mg_table::Sparse *sp : t->sparse)
-        if (sp->s == s) { *out = sp; return MG_OK; }
+        if (sp->s == s && sp->clustered == clustered) { *out = sp; return MG_OK; }
     int rc = table_classes(ctx, t);                        // host copies of nhash and the rows' largest hashes
     if (rc != MG_OK) return rc;
     mg_table::Sparse *sp = new mg_table::Sparse;
     sp->s = s;
+    sp->clustered = clustered;
     t->sparse.push_back(sp);
     *out = sp;
     auto unusable = [&](const char *why) { sp->usable = false; sp->why = why; return MG_OK; };
@@ -2080,15 +2089,65 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, mg_tab
     DevBuf<uint32_t> d_cnt(ctx);
     if (d_cnt.alloc(n) != hipSuccess) { (void)hipGetLastError(); return unusable("no device memory for the index"); }
     HIP_TRY(ctx, hipMemcpyAsync(d_cnt, cnt_true.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+    // ---- the clustered variant: rows that share one of their smallest hashes next to each other (labels on the device,
+    // two small sorts), the table copied in that order; everything below then works on the copy as if it were the table
+    const uint64_t *H = t->hashes;                          // what the index is built from
+    std::vector<uint64_t> last_p;                           // the rows' largest hashes in index order (empty: t->last)
+    std::vector<uint32_t> lab_sorted;                       // label of every index row (clustered variant)
+    if (clustered && n >= 16 && !getenv("MASHGPU_COMPARE_NO_CLUSTER")) {
+        DevBuf<unsigned long long> k_a(ctx), k_b(ctx);
+        DevBuf<uint32_t> r_a(ctx), r_b(ctx), l_a(ctx), l_b(ctx), d_inv(ctx), d_lab(ctx);
+        DevBuf<unsigned char> d_tmp(ctx);
+        const size_t tb = mg::dense_cluster_temp_bytes((uint32_t)n);
+        std::vector<uint32_t> inv(n);
+        lab_sorted.resize(n);
+        if (k_a.alloc(4 * n) == hipSuccess && k_b.alloc(4 * n) == hipSuccess && r_a.alloc(4 * n) == hipSuccess && r_b.alloc(4 * n) == hipSuccess &&
+            l_a.alloc(n) == hipSuccess && l_b.alloc(n) == hipSuccess && d_inv.alloc(n) == hipSuccess && d_lab.alloc(n) == hipSuccess &&
+            d_tmp.alloc(std::max<size_t>(tb, 16)) == hipSuccess) {
+            HIP_TRY(ctx, mg::dense_cluster_rows(t->hashes, t->s, d_cnt, (uint32_t)n, d_tmp, tb, k_a, k_b, r_a, r_b, l_a, l_b, d_inv, d_lab, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(inv.data(), d_inv, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(lab_sorted.data(), d_lab, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            bool identity = true;
+            for (uint64_t a = 0; a < n && identity; a++) identity = inv[a] == a;
+            if (!identity) {
+                void *pi = nullptr, *ph = nullptr;
+                if (ctx_malloc(ctx, &pi, n * 4) != hipSuccess || ctx_malloc(ctx, &ph, std::max<uint64_t>(n * t->s, 1) * 8) != hipSuccess) {
+                    (void)hipGetLastError();
+                    ctx_free(ctx, pi);
+                    lab_sorted.clear();                     // no memory for the copy: the table's own order
+                } else {
+                    sp->inv = static_cast<uint32_t *>(pi);
+                    sp->phashes = static_cast<uint64_t *>(ph);
+                    HIP_TRY(ctx, hipMemcpyAsync(sp->inv, d_inv, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+                    HIP_TRY(ctx, mg::launch_dense_gather_rows(t->hashes, t->s, sp->inv, (uint32_t)n, sp->phashes, ctx->stream));
+                    H = sp->phashes;
+                    std::vector<uint32_t> c2(n);
+                    last_p.resize(n);
+                    for (uint64_t a = 0; a < n; a++) { c2[a] = cnt_true[inv[a]]; last_p[a] = t->last[inv[a]]; }
+                    cnt_true.swap(c2);
+                    HIP_TRY(ctx, hipMemcpyAsync(d_cnt, cnt_true.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+                    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // (c2, the old counts, leaves scope; the buffers of this block go back to the pool)
+                }
+            }
+        } else {
+            (void)hipGetLastError();
+            lab_sorted.clear();
+        }
+    }
+    const std::vector<uint64_t> &lastv = last_p.empty() ? t->last : last_p;
     // which neighbouring rows are near-copies of each other (dense groups, compare_dense.hip): a sample test per row,
     // read back with the copy suspects below
     std::vector<uint8_t> link;
     bool want_dense = true;
     if (const char *e = getenv("MASHGPU_COMPARE_DENSE")) want_dense = atoi(e) != 0;
     DevBuf<uint8_t> d_link(ctx);
-    if (want_dense && n >= 8 && s <= 32768 && d_link.alloc(n) == hipSuccess) {      // (u16 counters of the extras)
+    if (want_dense && n >= 8 && s <= 32768 && !lab_sorted.empty()) {
+        link.assign(n, 0);                                  // clustered variant: neighbours with the same label
+        for (uint64_t a = 1; a < n; a++) link[a] = (lab_sorted[a] == lab_sorted[a - 1] && cnt_true[a] && cnt_true[a - 1]) ? 1 : 0;
+    } else if (want_dense && n >= 8 && s <= 32768 && d_link.alloc(n) == hipSuccess) {      // (u16 counters of the extras)
         link.resize(n);
-        HIP_TRY(ctx, mg::launch_dense_neighbors(t->hashes, t->s, d_cnt, (uint32_t)n, d_link, ctx->stream));
+        HIP_TRY(ctx, mg::launch_dense_neighbors(H, t->s, d_cnt, (uint32_t)n, d_link, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(link.data(), d_link, n, hipMemcpyDeviceToHost, ctx->stream));
         if (getenv("MASHGPU_SPARSE_NO_DEDUP")) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     } else {
@@ -2105,7 +2164,7 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, mg_tab
             return unusable("no device memory for the index");
         }
         uint32_t nflag = 0;
-        HIP_TRY(ctx, mg::launch_sparse_row_digest(t->hashes, t->s, d_cnt, (uint32_t)n, d_dig, ctx->stream));
+        HIP_TRY(ctx, mg::launch_sparse_row_digest(H, t->s, d_cnt, (uint32_t)n, d_dig, ctx->stream));
         HIP_TRY(ctx, mg::launch_sparse_dup_suspects(d_dig, d_cnt, (uint32_t)n, d_tmp, tb, d_dig_sorted, d_rows_sorted, d_flags, d_nflag, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(&nflag, d_nflag, 4, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -2125,7 +2184,7 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, mg_tab
             if (d_pairs.alloc(pairs.size()) != hipSuccess || d_eq.alloc(pairs.size()) != hipSuccess) { (void)hipGetLastError(); return unusable("no device memory for the index"); }
             std::vector<uint32_t> eq(pairs.size());
             HIP_TRY(ctx, hipMemcpyAsync(d_pairs, pairs.data(), pairs.size() * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
-            HIP_TRY(ctx, mg::launch_sparse_row_equal(t->hashes, t->s, d_cnt, d_pairs, (uint32_t)pairs.size(), d_eq, ctx->stream));
+            HIP_TRY(ctx, mg::launch_sparse_row_equal(H, t->s, d_cnt, d_pairs, (uint32_t)pairs.size(), d_eq, ctx->stream));
             HIP_TRY(ctx, hipMemcpyAsync(eq.data(), d_eq, pairs.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             for (size_t k = 0; k < pairs.size(); k++)
@@ -2169,8 +2228,8 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, mg_tab
         if (E64 >= (1ull << 31)) return unusable("2^31 entries or more");
         if (c) {
             // a real hash equal to the padding value would sort among the padding: keep the tile engine
-            if (t->last[i] == MG_HASH_PAD) return unusable("a hash equals the padding value");
-            maxv = std::max(maxv, t->last[i]);
+            if (lastv[i] == MG_HASH_PAD) return unusable("a hash equals the padding value");
+            maxv = std::max(maxv, lastv[i]);
             if (c < s) sp->short_rows_host.push_back((uint32_t)i);
         } else {
             sp->short_rows_host.push_back((uint32_t)i);
@@ -2229,7 +2288,7 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, mg_tab
         if (e == hipSuccess) e = hipMemsetAsync(d_stat, 0, sizeof(Stat), ctx->stream);
         prof_begin(ctx, ctx->prof_index);
         if (e == hipSuccess)
-            e = mg::sparse_build_index(t->hashes, t->s, sp->off, (uint32_t)n, E, sp->rs, end_bit, temp, temp_bytes, keys_a, idx_a,
+            e = mg::sparse_build_index(H, t->s, sp->off, (uint32_t)n, E, sp->rs, end_bit, temp, temp_bytes, keys_a, idx_a,
                                        sp->keys_sorted, idx_sorted, /*head=*/idx_a, gs_of, sp->sorted_rows, sp->gend, sp->code_img, sp->pos_img,
                                        d_slots, &d_stat.p->shared, &d_stat.p->max_group, &d_stat.p->groups, &d_stat.p->bad, ctx->stream);
         // visiting order of the rows: by the run of their first shared value, larger rows first inside a run
@@ -2307,8 +2366,8 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, mg_tab
             if (e2 == hipSuccess) e2 = hipStreamSynchronize(ctx->stream);
             if (e2 != hipSuccess) { (void)hipGetLastError(); break; }
             // the groups that stay: a universe of at least 32 values (else the rows are not near-copies and the pairs are
-            // cheap elsewhere) and at most 48 words (a tile's LDS)
-            constexpr uint32_t kMaxWords = 48;
+            // cheap elsewhere) and at most as many words as a tile's rows fit the LDS with
+            const uint32_t kMaxWords = mg::dense_max_words();
             std::fill(grp_of.begin(), grp_of.end(), 0xFFFFFFFFu);
             uint32_t xrows = 0, wmax = 0;
             uint64_t words = 0;
@@ -2401,8 +2460,17 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
     if (nrows >= (1ull << 31) || cols->n >= (1ull << 31)) return MG_OK;
     if (!mg::sparse_discover_supported((uint32_t)(triangle ? row_end : cols->n))) return MG_OK;
     mg_table::Sparse *ix = nullptr;
-    int rc = table_sparse_index(ctx, cols, s, &ix);
+    // the plain full triangle takes the CLUSTERED variant of the index (built on the table with related rows next to each
+    // other: dense groups whatever the order of the collection); row ranges, rect and list jobs address table rows
+    bool clustered = triangle && !job && row_begin == 0 && row_end == cols->n;
+    if (const char *e = getenv("MASHGPU_COMPARE_CLUSTER")) clustered = clustered && atoi(e) != 0;
+    int rc = table_sparse_index(ctx, cols, s, clustered, &ix);
     if (rc != MG_OK) return rc;
+    if (!ix->usable && clustered) {                         // (whatever stopped it may not stop the plain variant)
+        clustered = false;
+        rc = table_sparse_index(ctx, cols, s, false, &ix);
+        if (rc != MG_OK) return rc;
+    }
     if (!ix->usable) return MG_OK;
     // (list mode: two copies of one sketch are a pair at distance 0 that is no candidate, two EMPTY sketches
     //  likewise -- such tables take the matrix path; so do tables with dense groups, whose inner pairs are in no list)
@@ -2425,6 +2493,7 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
     a.cls_off = ix->cls_off;
     a.cls_rows = ix->cls_rows;
     a.gend = ix->gend;
+    a.inv = ix->inv;
     a.res = nullptr;
     a.seg_base = nullptr;
     a.seg_cnt = nullptr;
@@ -2666,18 +2735,18 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
                                   : mg::launch_sparse_fill_value(a.out, pairs, 0u, s, 16u, (uint32_t)ctx->cu_count, ctx->stream);
         if (e == hipSuccess && nshort_rows && !ix->short_rows_host.empty() && !all_copies)      // (copies of a SHORT sketch are {c, c} too, not {0, 2c})
             e = mg::launch_sparse_fill_short(a.out, short_rows_dev, short_rcnt_dev, nshort_rows, ix->short_rows, ix->short_cnt,
-                                             (uint32_t)ix->short_rows_host.size(), a.row_begin, a.ncols, a.triangle, a.out_base, s, ctx->stream);
+                                             (uint32_t)ix->short_rows_host.size(), a.row_begin, a.ncols, a.triangle, a.out_base, s, a.inv, ctx->stream);
         // pairs of two copies of one sketch: {n, n} (after the fill)
         if (e == hipSuccess && triangle && ix->cls_members && !all_copies)
             e = mg::launch_sparse_class_pairs(a.out, ix->cls_rows, ix->cls_first, ix->off, ix->rep, ix->cls_members, a.row_begin, a.row_end,
-                                              a.out_base, ctx->stream);
+                                              a.out_base, a.inv, ctx->stream);
         prof_end(ctx, ctx->prof_fill);
         if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare (fill): ") + hipGetErrorString(e));
         // the pairs inside the dense groups (over the fill; candidates never lie inside a group)
         if (plan->ndtiles) {
             prof_begin(ctx, ctx->prof_dense);
             e = mg::launch_dense_pairs(plan->dtiles, plan->ndtiles, ix->dgroups, ix->gdata, ix->ext, ix->dn_xs, s, ix->dn_wmax, a.row_begin, a.row_end,
-                                       a.out_base, a.out, ctx->stream);
+                                       a.out_base, a.inv, a.out, ctx->stream);
             prof_end(ctx, ctx->prof_dense);
             if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare (dense groups): ") + hipGetErrorString(e));
         }
@@ -3319,22 +3388,26 @@ static int compare_results(mg_ctx *ctx, const mg_table *rows, const mg_table *co
         bool handled = false;
         int rc = run_compare_sparse(ctx, rows, cols, rb, re, triangle, s, nullptr, force_kernel != nullptr, &handled, &job);
         if (rc != MG_OK) return rc;
-        if (handled) {
-            const uint64_t K = job.cand;
-            if (K == 0) return MG_OK;
-            if (K >= (1ull << 32)) return fail(ctx, MG_ERR_UNSUPPORTED, "compare: too many candidate pairs for the list path");
-            const uint32_t nrows = (uint32_t)(re - rb);
-            DevBuf<uint2> d_rc, d_cnt;
-            DevBuf<uint32_t> d_byrow, d_base, d_segc2, d_seen2;
-            DevBuf<unsigned long long> d_masks2, d_sego2, d_n2;
-            DevBuf<mg::FinishEdge> d_edges2;
-            DevBuf<unsigned char> d_temp;
-            const size_t tb = mg::sparse_gather_temp_bytes(nrows);
-            if (d_rc.alloc(K) != hipSuccess || d_cnt.alloc(K) != hipSuccess || d_byrow.alloc(nrows) != hipSuccess || d_base.alloc(nrows) != hipSuccess ||
-                d_temp.alloc(std::max<size_t>(tb, 16)) != hipSuccess || d_masks2.alloc(mg::finish_mask_words(K)) != hipSuccess ||
-                d_segc2.alloc(mg::finish_segments(K)) != hipSuccess || d_sego2.alloc(mg::finish_segments(K)) != hipSuccess || d_n2.alloc(1) != hipSuccess ||
-                d_seen2.alloc((uint64_t)s + 1) != hipSuccess || d_edges2.alloc(std::min(K, window)) != hipSuccess)
-                return fail(ctx, MG_ERR_NOMEM, "compare: device allocation failed");
+        // (a list of 2^32 candidates and more, or one whose scratch does not fit, is no error: the blocked matrix path
+        //  below does the job in 2^30-pair blocks -- ADVICE r3)
+        const uint64_t K = handled ? job.cand : 0;
+        if (handled && K == 0) return MG_OK;
+        const uint32_t nrows = (uint32_t)(re - rb);
+        DevBuf<uint2> d_rc(ctx), d_cnt(ctx);
+        DevBuf<uint32_t> d_byrow(ctx), d_base(ctx), d_segc2(ctx), d_seen2(ctx);
+        DevBuf<unsigned long long> d_masks2(ctx), d_sego2(ctx), d_n2(ctx);
+        DevBuf<mg::FinishEdge> d_edges2(ctx);
+        DevBuf<unsigned char> d_temp(ctx);
+        const size_t tb = mg::sparse_gather_temp_bytes(nrows);
+        bool list_ok = handled && K < (1ull << 32);
+        if (list_ok && (d_rc.alloc(K) != hipSuccess || d_cnt.alloc(K) != hipSuccess || d_byrow.alloc(nrows) != hipSuccess || d_base.alloc(nrows) != hipSuccess ||
+                        d_temp.alloc(std::max<size_t>(tb, 16)) != hipSuccess || d_masks2.alloc(mg::finish_mask_words(K)) != hipSuccess ||
+                        d_segc2.alloc(mg::finish_segments(K)) != hipSuccess || d_sego2.alloc(mg::finish_segments(K)) != hipSuccess || d_n2.alloc(1) != hipSuccess ||
+                        d_seen2.alloc((uint64_t)s + 1) != hipSuccess || d_edges2.alloc(std::min(K, window)) != hipSuccess)) {
+            (void)hipGetLastError();
+            list_ok = false;
+        }
+        if (list_ok) {
             HIP_TRY(ctx, hipMemsetAsync(d_byrow, 0, (size_t)nrows * 4, ctx->stream));
             HIP_TRY(ctx, mg::launch_sparse_gather_rows(job.args, d_byrow, d_base, d_temp, tb, triangle ? 0u : (uint32_t)rb, d_rc, d_cnt, ctx->stream));
             std::vector<uint32_t> seen2((size_t)s + 1, 0);
@@ -3848,7 +3921,14 @@ int mg_comm_allreduce_u32_sum(mg_comm *c, uint32_t *buf_dev, uint64_t count)
 static double tri_row_weight(uint64_t rb, uint64_t re, uint64_t s)
 {
     if (const char *e = getenv("MASHGPU_SHARD_ROW_WEIGHT")) return atof(e);
-    return tri_pairs(rb, re) >= 4000000ull ? 60.0 * (double)s : 0.0;
+    // only where the inverted-index engine takes the blocks (the tile engine costs per pair -- with a row weight
+    // a few thousand rows were cut almost evenly by rows and the last device got ten times the first one's pairs) ...
+    if (tri_pairs(rb, re) < 4000000ull) return 0.0;
+    if (const char *e = getenv("MASHGPU_COMPARE_SPARSE")) { if (atoi(e) == 0) return 0.0; }
+    if (const char *e = getenv("MASHGPU_COMPARE_KERNEL")) { if (strcmp(e, "sparse") != 0) return 0.0; }
+    // ... and never more than a mean row's pairs: a row cannot cost more than it holds
+    const double mean_row = (double)tri_pairs(rb, re) / (double)std::max<uint64_t>(re - rb, 1);
+    return std::min(60.0 * (double)s, mean_row);
 }
 
 extern "C++" {
@@ -4292,12 +4372,14 @@ int mg_screen_create(mg_ctx *ctx, const mg_params *p, const mg_table *db, mg_scr
     uint64_t slots = 1024;
     while (slots < 2 * db->n * db->s) slots <<= 1;
     sc->slots = slots;
-    // (slots are addressed with 32 bits in the touched list and the rows-by-slot index: at most 2^32 slots = 2^31 hashes)
-    if (db->n * db->s > (1ull << 31)) { delete sc; return fail(ctx, MG_ERR_UNSUPPORTED, "mg_screen_create: more than 2^31 database hashes"); }
-    sc->touched_cap = std::max<uint64_t>(db->n * db->s, 1);
+    // (slots are addressed with 32 bits in the touched list and the rows-by-slot index: at most 2^32 slots = 2^31 hashes.
+    //  A larger database keeps the dense results -- mg_screen_counts_dev / mg_screen_finish_host, which need neither --
+    //  and has no touched list: the sparse results and the O(touched) reset are refused for it)
+    const bool listed = db->n * db->s <= (1ull << 31);
+    sc->touched_cap = listed ? std::max<uint64_t>(db->n * db->s, 1) : 0;
     hipError_t e = hipMalloc(&sc->keys, slots * 8);
     if (e == hipSuccess) e = hipMalloc(&sc->obs, slots * 4);
-    if (e == hipSuccess) e = hipMalloc(&sc->touched, sc->touched_cap * 4);
+    if (e == hipSuccess && listed) e = hipMalloc(&sc->touched, sc->touched_cap * 4);
     if (e == hipSuccess) e = hipMalloc(&sc->ntouched, 16);
     if (e == hipSuccess) e = hipMemsetAsync(sc->keys, 0xFF, slots * 8, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(sc->obs, 0, slots * 4, ctx->stream);
@@ -4474,6 +4556,7 @@ int mg_screen_reset(mg_screen *sc)
     mg_ctx *ctx = sc->ctx;
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!sc->touched) return fail(ctx, MG_ERR_UNSUPPORTED, "mg_screen_reset: databases of more than 2^31 hashes keep no touched list (create a new screen)");
     uint64_t nt = 0;
     const int rc = screen_touched(sc, &nt);
     if (rc != MG_OK) return rc;
@@ -4516,6 +4599,7 @@ int mg_screen_finish_sparse_host(mg_screen *sc, mg_screen_hit *hits_out, uint64_
     mg_ctx *ctx = sc->ctx;
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (!nhits_out || (!hits_out && capacity)) return fail(ctx, MG_ERR_INVALID, "mg_screen_finish_sparse_host: NULL argument");
+    if (!sc->touched) return fail(ctx, MG_ERR_UNSUPPORTED, "mg_screen_finish_sparse_host: databases of more than 2^31 hashes have dense results only (mg_screen_finish_host)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc = screen_ensure_index(sc);
     uint64_t nt = 0;

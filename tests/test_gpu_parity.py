@@ -755,14 +755,23 @@ def _clade_table(rng, sizes, s, keep=0.96, private=0.03, clump=False, short_ever
     (64, (200,), dict(keep=0.9, private=0.1, short_every=3)),       # one word, short rows
     (100, (33, 150, 8), dict(clump=True, short_every=5)),           # many extras inside one gap of the universe
     (1000, (260,), dict(keep=0.6, private=0.2)),                    # loosely related: a universe larger than s
-    (3000, (140,), dict()),                                         # a universe of 50 words: beyond a tile's LDS, the group is dropped
+    (3000, (140,), dict()),                                         # a universe of 50 words: the column block is streamed, not staged
+    (1000, (60, 45, 90, 30), dict(shuffle=True)),                   # the same clades in RANDOM row order: the index is built on a clustered copy
+    (100, (33, 150, 8), dict(clump=True, short_every=5, shuffle=True)),
+    (4000, (70, 40), dict(shuffle=True, keep=0.8, private=0.2)),    # interleaved AND a universe of ~80 words
 ])
 def test_compare_dense_groups(eng, oracle, s, sizes, kw, monkeypatch):
-    """Runs of consecutive near-identical rows (compare_dense.hip): their inner pairs as bit-mask arithmetic, everything
-    else through the inverted index with clipped runs == oracle, whole triangle and row ranges that cut through a
-    group; the same bytes with the dense groups switched off."""
+    """Near-identical rows (compare_dense.hip): their inner pairs as bit-mask arithmetic, everything else through the
+    inverted index with clipped runs == oracle, whole triangle (the index then works on a copy of the table with related
+    rows next to each other, whatever their order) and row ranges that cut through a group (consecutive rows only); the
+    same bytes with the dense groups switched off."""
     rng = np.random.default_rng(s + sum(sizes))
+    kw = dict(kw)
+    shuffle = kw.pop("shuffle", False)
     table, nhash = _clade_table(rng, sizes, s, **kw)
+    if shuffle:
+        perm = rng.permutation(len(nhash))
+        table, nhash = table[perm].copy(), nhash[perm].copy()
     n = len(nhash)
     lengths = np.full(n, 10 ** 6, dtype=np.uint64)
     numer, denom = _oracle_tri(oracle, table, nhash, lengths, 0, n)

@@ -5,7 +5,8 @@ against the route that keeps the read set in HBM (MASH_AMD_READS_RESIDENT=1) and
     python tools/reads_e2e.py [--reads 4000000] [--len 150] [--genome 5000000]
 
 One FASTA file of `reads` reads sampled from a random genome (both strands, 0.5 % substitutions).  Wall
-times of the whole process, peak RSS of ours (ru_maxrss of the child), same sketches (info -d) everywhere."""
+times of the whole process, peak RSS of EACH child on its own (os.wait4: the rusage of that one process -- RUSAGE_CHILDREN
+is a maximum over all children so far and made every run report the largest), same sketches (info -d) everywhere."""
 import argparse, json, os, resource, shutil, subprocess, sys, tempfile, time
 import numpy as np
 
@@ -45,12 +46,17 @@ def main():
 
         def run(tag, exe, args, env=None):
             t = time.perf_counter()
-            before = resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss
-            r = subprocess.run([exe, "sketch", *args, "-o", os.path.join(d, tag), fn], capture_output=True, env=dict(os.environ, **(env or {})))
-            assert r.returncode == 0, r.stderr.decode()[-400:]
+            errf = os.path.join(d, tag + ".stderr")
+            with open(errf, "wb") as fe:
+                p = subprocess.Popen([exe, "sketch", *args, "-o", os.path.join(d, tag), fn], stdout=subprocess.DEVNULL, stderr=fe,
+                                     env=dict(os.environ, **(env or {})))
+                _, status, ru = os.wait4(p.pid, 0)                   # the rusage of THIS child alone
+                p.returncode = os.waitstatus_to_exitcode(status)
+            err = open(errf, "rb").read().decode()
+            assert p.returncode == 0, err[-400:]
             res[tag + "_s"] = round(time.perf_counter() - t, 3)
-            res[tag + "_maxrss_mb"] = round(max(before, resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss) / 1024)   # (monotone over children)
-            res[tag + "_stderr"] = [l for l in r.stderr.decode().splitlines() if l.startswith("Estimated")]
+            res[tag + "_maxrss_mb"] = round(ru.ru_maxrss / 1024)
+            res[tag + "_stderr"] = [l for l in err.splitlines() if l.startswith("Estimated")]
 
         dump = lambda tag: subprocess.run([MASH, "info", "-d", os.path.join(d, tag + ".msh")], capture_output=True, check=True).stdout
         for opts, name in ((["-r"], "r"), (["-r", "-m", "2"], "m2")):
