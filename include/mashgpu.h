@@ -102,7 +102,7 @@ int         mg_ctx_synchronize(mg_ctx *ctx);
 int         mg_ctx_set_async(mg_ctx *ctx, int on);
 /* Device blocks that finished calls and freed / invalidated tables handed back are kept by the context for the
  * next call (small scratch: 256 MiB; large blocks -- the inverted index of a table, candidate lists -- up to
- * 48 GiB, so that the next table of the same shape pays no hipMalloc).  mg_ctx_trim waits for the context's
+ * 40 % of the device's memory, so that the next table of the same shape pays no hipMalloc).  mg_ctx_trim waits for the context's
  * stream and returns all of them to the driver; they are also dropped whenever an allocation fails. */
 int         mg_ctx_trim(mg_ctx *ctx);
 /* Number of CUs of the device (for callers sizing work). */

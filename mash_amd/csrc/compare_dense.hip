@@ -26,6 +26,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
+
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_select.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
@@ -75,112 +77,173 @@ hipError_t launch_dense_neighbors(const uint64_t *hashes, uint64_t stride, const
 // ------------------------------------------------------------------------------------------------
 // universe of every group: the values held by at least two of its rows.  In the sorted index the rows of a value
 // ascend, a group is a row interval, so a group's holders of a value sit side by side: the first of them is the
-// value's LEADER if a second one follows.  Leaders, in sorted (= value) order, are selected and then sorted by group
-// (stable): every group's universe, ascending, as the sorted positions gs that are the values' codes.
-__global__ __launch_bounds__(256) void dn_leader_flags_kernel(const uint32_t *sorted_rows, const uint32_t *gs_of, const uint32_t *gend,
-                                                              const uint32_t *grp_of, const DenseGroup *groups, uint32_t E,
-                                                              uint8_t *flag)
+// value's LEADER if a second one follows.  Every leader leaves {group, value, its own sorted position} in a list
+// (one atomic per wave for the slots); sorted by (group, value) that list is every group's universe, ascending --
+// values as the starts of their runs in the sorted index, which is what a row's code says -- and beside every
+// universe value the position of its leader: the first holder INSIDE the group, i.e. the end of the run of partners
+// OUTSIDE the group for every other holder in the group (the clipped run, see dn_encode_kernel).
+// (the leaders are appended to one of DN_SUBLISTS lists, by workgroup: a million waves adding to ONE counter took 8 ms on
+//  C3, where nearly every wave holds a leader; dn_sublists_scan / dn_sublists_copy then make the lists one)
+constexpr uint32_t DN_SUBLISTS = 1024;
+
+__global__ __launch_bounds__(256) void dn_leaders_kernel(const uint32_t *sorted_rows, const uint32_t *gs_of, const uint32_t *gend,
+                                                         const uint32_t *grp_of, const DenseGroup *groups, uint32_t E,
+                                                         unsigned long long *key, uint32_t *val, uint32_t cap_sub, uint32_t *cnt)
 {
     const uint32_t pos = blockIdx.x * 256u + threadIdx.x;
-    if (pos >= E) return;
-    const uint32_t row = sorted_rows[pos];
-    const uint32_t g = grp_of[row];
-    uint8_t f = 0;
-    if (g != 0xFFFFFFFFu) {
-        const uint32_t g0 = groups[g].g0, g1 = groups[g].g1;
-        const uint32_t gs = gs_of[pos];
-        const bool first = pos == gs || sorted_rows[pos - 1] < g0;
-        const bool more = pos + 1u < gend[gs] && sorted_rows[pos + 1] < g1;
-        f = (first && more) ? 1 : 0;
+    bool lead = false;
+    uint32_t g = 0xFFFFFFFFu, gs = 0;
+    if (pos < E) {
+        g = grp_of[sorted_rows[pos]];
+        if (g != 0xFFFFFFFFu) {
+            const uint32_t g0 = groups[g].g0, g1 = groups[g].g1;
+            gs = gs_of[pos];
+            const bool first = pos == gs || sorted_rows[pos - 1] < g0;
+            const bool more = pos + 1u < gend[gs] && sorted_rows[pos + 1] < g1;
+            lead = first && more;
+        }
     }
-    flag[pos] = f;
+    const uint64_t bal = __ballot(lead);
+    if (bal == 0) return;
+    const uint32_t lane = threadIdx.x & 63u, sub = blockIdx.x & (DN_SUBLISTS - 1u);
+    uint32_t base = 0;
+    if (lane == (uint32_t)__builtin_ctzll(bal)) base = atomicAdd(&cnt[sub], (uint32_t)__popcll(bal));
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(bal));
+    if (lead) {
+        const uint32_t k = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        if (k < cap_sub) {
+            const uint64_t slot = (uint64_t)sub * cap_sub + k;
+            key[slot] = ((unsigned long long)g << 32) | gs;
+            val[slot] = pos;
+        }
+    }
 }
 
-struct dn_is_set {
-    const uint8_t *flag;
-    __device__ bool operator()(const uint32_t &pos) const { return flag[pos] != 0; }
-};
+// one workgroup: where every list goes in the joined list; total[0] = leaders kept, total[1] = the longest list asked for
+__global__ __launch_bounds__(DN_SUBLISTS) void dn_sublists_scan_kernel(const uint32_t *cnt, uint32_t cap_sub, uint32_t *off, uint32_t *total)
+{
+    __shared__ uint32_t s_w[DN_SUBLISTS / 64];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wid = t >> 6;
+    const uint32_t want = cnt[t], c = want < cap_sub ? want : cap_sub;
+    uint32_t incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t x = __shfl_up(incl, d);
+        if (lane >= (uint32_t)d) incl += x;
+    }
+    if (lane == 63u) s_w[wid] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t k = 0; k < wid; k++) base += s_w[k];
+    off[t] = base + incl - c;
+    if (t == DN_SUBLISTS - 1u) total[0] = base + incl;
+    atomicMax(&total[1], want);
+}
 
-// per leader: its group (the sort key) and the VALUE it stands for -- as the start of the value's run in the sorted index,
-// which is what a row's code says (the leader itself is the first holder inside the group, not the first of the run)
-__global__ __launch_bounds__(256) void dn_leader_keys_kernel(const uint32_t *lead_pos, const uint32_t *nlead, const uint32_t *sorted_rows,
-                                                             const uint32_t *gs_of, const uint32_t *grp_of, uint32_t *key, uint32_t *val)
+__global__ __launch_bounds__(256) void dn_sublists_copy_kernel(const unsigned long long *key, const uint32_t *val, const uint32_t *cnt,
+                                                               const uint32_t *off, uint32_t cap_sub, unsigned long long *key_out,
+                                                               uint32_t *val_out)
+{
+    const uint32_t sub = blockIdx.x;
+    const uint32_t c = cnt[sub] < cap_sub ? cnt[sub] : cap_sub, o = off[sub];
+    for (uint32_t k = threadIdx.x; k < c; k += 256u) {
+        key_out[o + k] = key[(uint64_t)sub * cap_sub + k];
+        val_out[o + k] = val[(uint64_t)sub * cap_sub + k];
+    }
+}
+
+// after the sort by (group, value): the universes' values and leader positions side by side, and where every group's
+// universe starts and ends
+__global__ __launch_bounds__(256) void dn_universe_split_kernel(const unsigned long long *key_sorted, uint32_t m, uint32_t *ulist,
+                                                                uint32_t *ustart, uint32_t *uend)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < *nlead) {
-        const uint32_t pos = lead_pos[i];
-        key[i] = grp_of[sorted_rows[pos]];
-        val[i] = gs_of[pos];
-    }
-}
-
-// after the stable sort by group: where every group's universe starts and how long it is
-__global__ __launch_bounds__(256) void dn_universe_bounds_kernel(const uint32_t *key_sorted, const uint32_t *nlead, uint32_t *ustart, uint32_t *ucount)
-{
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x, m = *nlead;
     if (i >= m) return;
-    const uint32_t g = key_sorted[i];
-    if (i == 0 || key_sorted[i - 1] != g) ustart[g] = i;
-    if (i + 1u == m || key_sorted[i + 1] != g) ucount[g] = i + 1u;      // (one past the last: the host subtracts ustart)
+    const unsigned long long k = key_sorted[i];
+    const uint32_t g = (uint32_t)(k >> 32);
+    ulist[i] = (uint32_t)k;
+    if (i == 0 || (uint32_t)(key_sorted[i - 1] >> 32) != g) ustart[g] = i;
+    if (i + 1u == m || (uint32_t)(key_sorted[i + 1] >> 32) != g) uend[g] = i + 1u;
 }
 
-size_t dense_universe_temp_bytes(uint32_t E)
+size_t dense_universe_temp_bytes(uint32_t cap)
 {
-    size_t a = 0, b = 0;
-    rocprim::select(nullptr, a, rocprim::counting_iterator<uint32_t>(0u), (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)E,
-                    dn_is_set{nullptr}, (hipStream_t) nullptr);
-    rocprim::radix_sort_pairs(nullptr, b, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr,
-                              (size_t)E, 0u, 32u, (hipStream_t) nullptr);
-    return a > b ? a : b;
+    size_t b = 0;
+    rocprim::radix_sort_pairs(nullptr, b, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, (const uint32_t *)nullptr,
+                              (uint32_t *)nullptr, (size_t)cap, 0u, 64u, (hipStream_t) nullptr);
+    return b;
 }
 
-// step 1: flag: scratch of E bytes; lead_pos: out, the leaders' sorted positions in value order; *nlead (device) their number
-hipError_t dense_select_leaders(const uint32_t *sorted_rows, const uint32_t *gs_of, const uint32_t *gend, const uint32_t *grp_of,
-                                const DenseGroup *groups, uint32_t E, void *temp, size_t temp_bytes, uint8_t *flag, uint32_t *lead_pos,
-                                uint32_t *nlead, hipStream_t stream)
+uint32_t dense_sublists() { return DN_SUBLISTS; }
+
+// step 1: key / val: scratch of DN_SUBLISTS * cap_sub entries; key_out / val_out: the leaders joined (room for as many);
+// cnt / off: scratch of DN_SUBLISTS u32; total (device, 2 u32): [0] leaders kept, [1] the longest list ASKED for -- beyond
+// cap_sub leaders were dropped and the caller repeats with more room
+hipError_t dense_find_leaders(const uint32_t *sorted_rows, const uint32_t *gs_of, const uint32_t *gend, const uint32_t *grp_of,
+                              const DenseGroup *groups, uint32_t E, unsigned long long *key, uint32_t *val, uint32_t cap_sub,
+                              unsigned long long *key_out, uint32_t *val_out, uint32_t *cnt, uint32_t *off, uint32_t *total,
+                              hipStream_t stream)
 {
     if (E == 0) return hipSuccess;
-    hipLaunchKernelGGL(dn_leader_flags_kernel, dim3((E + 255u) / 256u), dim3(256), 0, stream, sorted_rows, gs_of, gend, grp_of, groups, E, flag);
-    hipError_t e = hipGetLastError();
+    hipError_t e = hipMemsetAsync(cnt, 0, DN_SUBLISTS * 4, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(total, 0, 8, stream);
     if (e != hipSuccess) return e;
-    return rocprim::select(temp, temp_bytes, rocprim::counting_iterator<uint32_t>(0u), lead_pos, nlead, (size_t)E, dn_is_set{flag}, stream);
+    hipLaunchKernelGGL(dn_leaders_kernel, dim3((E + 255u) / 256u), dim3(256), 0, stream, sorted_rows, gs_of, gend, grp_of, groups, E, key, val, cap_sub,
+                       cnt);
+    hipLaunchKernelGGL(dn_sublists_scan_kernel, dim3(1), dim3(DN_SUBLISTS), 0, stream, (const uint32_t *)cnt, cap_sub, off, total);
+    hipLaunchKernelGGL(dn_sublists_copy_kernel, dim3(DN_SUBLISTS), dim3(256), 0, stream, (const unsigned long long *)key, (const uint32_t *)val,
+                       (const uint32_t *)cnt, (const uint32_t *)off, cap_sub, key_out, val_out);
+    return hipGetLastError();
 }
 
-// step 2 (the host knows m = *nlead): key / key_sorted / val: scratch of m u32; ulist: out, the universes' values (run starts) grouped
-// by group, ascending inside a group; ustart / uend [ngroups]: zeroed by the caller
-hipError_t dense_sort_universes(const uint32_t *lead_pos, const uint32_t *nlead, uint32_t m, const uint32_t *sorted_rows, const uint32_t *gs_of,
-                                const uint32_t *grp_of, void *temp, size_t temp_bytes, uint32_t *key, uint32_t *key_sorted, uint32_t *val,
-                                uint32_t *ulist, uint32_t *ustart, uint32_t *uend, uint32_t group_bits, hipStream_t stream)
+// step 2 (the host knows m = *nlead <= cap): key_sorted: scratch of m u64; ulist / upos: out, the universes' values (run starts)
+// and leader positions grouped by group, ascending inside a group; ustart / uend [ngroups]: zeroed by the caller
+hipError_t dense_sort_universes(const unsigned long long *key, const uint32_t *val, uint32_t m, void *temp, size_t temp_bytes,
+                                unsigned long long *key_sorted, uint32_t *ulist, uint32_t *upos, uint32_t *ustart, uint32_t *uend,
+                                uint32_t group_bits, hipStream_t stream)
 {
     if (m == 0) return hipSuccess;
-    const uint32_t blocks = (m + 255u) / 256u;
-    hipLaunchKernelGGL(dn_leader_keys_kernel, dim3(blocks), dim3(256), 0, stream, lead_pos, nlead, sorted_rows, gs_of, grp_of, key, val);
-    hipError_t e = hipGetLastError();
+    hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, key, key_sorted, val, upos, (size_t)m, 0u, 32u + group_bits, stream);
     if (e != hipSuccess) return e;
-    e = rocprim::radix_sort_pairs(temp, temp_bytes, (const uint32_t *)key, key_sorted, (const uint32_t *)val, ulist, (size_t)m, 0u, group_bits, stream);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(dn_universe_bounds_kernel, dim3(blocks), dim3(256), 0, stream, (const uint32_t *)key_sorted, nlead, ustart, uend);
+    hipLaunchKernelGGL(dn_universe_split_kernel, dim3((m + 255u) / 256u), dim3(256), 0, stream, (const unsigned long long *)key_sorted, m, ulist,
+                       ustart, uend);
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------
-// a grouped row -> its mask words, cumulative extra counts and extras.  One workgroup per row.
-__global__ __launch_bounds__(256) void dn_encode_kernel(const uint32_t *off, const uint32_t *code_img, uint32_t rs, const uint32_t *grp_of,
-                                                        const DenseGroup *groups, const uint32_t *ulist, unsigned long long *gdata,
-                                                        uint16_t *ext, uint32_t xs, uint32_t n)
+// a grouped row -> its mask words, cumulative extra counts, extras -- and its CLIPPED runs.  One workgroup per row, the
+// group's universe staged in LDS, 256 entries at a time, each located in the universe by bisection.
+//  * a value of the universe sets its bit; the end of its run of partners becomes the position of the value's leader --
+//    the first holder inside the group: of the rows below this one that hold the value, discovery is to see those
+//    OUTSIDE the group only (the pairs inside are this file's), and rows ascend inside a run;
+//  * any other value is held by no other row of the group (its run is untouched: whoever holds it lies outside) and is
+//    an EXTRA, recorded by its gap -- the number of universe values below it: in order in `ext`, counted per word in
+//    cx, and per word as three bit masks over the gap's offset in the word (xm: bit o of mask j set = at least j + 1
+//    extras at offset o), which is what the resolve step of dn_pairs_kernel counts with; a word with a fourth extra in
+//    one gap is flagged (bit 15 of the word's cx entry) and resolved from the list instead.
+constexpr uint32_t DN_CX_MASK = 0x7FFFu, DN_CX_FLAG = 0x8000u;           // cx: a count (<= s <= 16384) | flag
+
+__global__ __launch_bounds__(256) void dn_encode_kernel(const uint32_t *off, const uint32_t *code_img, uint32_t *pos_img, uint32_t rs,
+                                                        const uint32_t *grp_of, const DenseGroup *groups, const uint32_t *ulist,
+                                                        const uint32_t *upos, unsigned long long *gdata, unsigned long long *xm,
+                                                        uint32_t wstride, uint16_t *ext, uint32_t xs, uint32_t n, uint32_t ul_in_lds)
 {
-    extern __shared__ uint32_t lds[];                    // [2 * W] mask halves, [W + 1] extras per word, [8] scan scratch
+    extern __shared__ uint32_t lds[];      // [2 W] mask halves, [W + 1] extras per word, [6 W] xm halves, [W] overflow flags, [8] scratch, [u] the universe
     const uint32_t row = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
     if (row >= n) return;
     const uint32_t g = grp_of[row];
     if (g == 0xFFFFFFFFu) return;                        // uniform
     const DenseGroup G = groups[g];
     const uint32_t W = G.W, u = G.u;
-    uint32_t *mask32 = lds, *hist = lds + 2u * W, *scr = hist + W + 1u;
-    for (uint32_t i = tid; i < 3u * W + 1u; i += 256u) lds[i] = 0;
+    uint32_t *mask32 = lds, *hist = lds + 2u * W, *xm32 = hist + W + 1u, *ovf = xm32 + 6u * W, *scr = ovf + W;
+    uint32_t *ull = lds + 10u * wstride + 9u;
+    for (uint32_t i = tid; i < 10u * W + 1u; i += 256u) lds[i] = 0;
+    const uint32_t *ulg = ulist + G.ustart, *up = upos + G.ustart;
+    if (ul_in_lds)
+        for (uint32_t i = tid; i < u; i += 256u) ull[i] = ulg[i];
+    const uint32_t *ul = ul_in_lds ? ull : ulg;
     __syncthreads();
     const uint32_t cnt = off[row + 1] - off[row];
-    const uint32_t *ul = ulist + G.ustart;
     uint16_t *xrow = ext + (uint64_t)(G.xrow0 + (row - G.g0)) * xs;
     uint32_t nx = 0;                                     // extras written so far (uniform)
     for (uint32_t base = 0; base < cnt; base += 256u) {
@@ -188,15 +251,20 @@ __global__ __launch_bounds__(256) void dn_encode_kernel(const uint32_t *off, con
         uint32_t idx = 0;
         bool extra = false;
         if (p < cnt) {
-            const uint32_t gs = code_img[(uint64_t)row * rs + p] >> 1;
+            const uint64_t img = (uint64_t)row * rs + p;
+            const uint32_t gs = code_img[img] >> 1;
             uint32_t lo = 0, hi = u;                      // lower bound of gs in the universe
             while (lo < hi) {
                 const uint32_t mid = (lo + hi) >> 1;
                 if (ul[mid] < gs) lo = mid + 1; else hi = mid;
             }
             idx = lo;
-            if (lo < u && ul[lo] == gs) atomicOr(&mask32[idx >> 5], 1u << (idx & 31u));
-            else extra = true;
+            if (lo < u && ul[lo] == gs) {
+                atomicOr(&mask32[idx >> 5], 1u << (idx & 31u));
+                pos_img[img] = up[idx];                  // (the leader itself: its own position again)
+            } else {
+                extra = true;
+            }
         }
         // extras keep their order (entries ascend, so gaps ascend): block-wide exclusive scan of the flags
         const uint64_t bal = __ballot(extra);
@@ -209,69 +277,50 @@ __global__ __launch_bounds__(256) void dn_encode_kernel(const uint32_t *off, con
         if (extra) {
             xrow[nx + woff + before] = (uint16_t)idx;
             atomicAdd(&hist[idx >> 6], 1u);
+            // the extra's offset in its word, into the first of the word's three masks that does not hold it yet
+            const uint32_t w = idx >> 6, o = idx & 63u, half = o >> 5, bit = 1u << (o & 31u);
+            uint32_t *m3 = xm32 + 6u * w + half;         // masks 0, 1, 2 of word w: halves at +0/+1, +2/+3, +4/+5
+            if (atomicOr(&m3[0], bit) & bit)
+                if (atomicOr(&m3[2], bit) & bit)
+                    if (atomicOr(&m3[4], bit) & bit) ovf[w] = 1u;
         }
         nx += total;
         __syncthreads();                                 // scr is reused
     }
     __syncthreads();
-    // cumulative counts: cx[w] = extras with gap < 64 w (w = 0 .. W), by one wave (W + 1 <= a few dozen)
-    const uint32_t j = (row - G.g0) >> 7, bl = (row - G.g0) & 127u;
+    const uint32_t jb = (row - G.g0) >> 7, bl = (row - G.g0) & 127u;
     const uint64_t bw = 128ull * W + 32ull * (W + 1u);
-    unsigned long long *blk = gdata + G.data_off + (uint64_t)j * bw;
+    unsigned long long *blk = gdata + G.data_off + (uint64_t)jb * bw;
     uint16_t *cxp = reinterpret_cast<uint16_t *>(blk + 128ull * W);
-    if (tid == 0) {
-        uint32_t run = 0;
+    if (tid == 0) {                                       // cumulative counts: cx[w] = extras with gap < 64 w (w = 0 .. W);
+        uint32_t run = 0;                                 // entry w + 1 carries the flag of word w
         for (uint32_t w = 0; w <= W; w++) {
-            cxp[w * 128u + bl] = (uint16_t)run;
+            cxp[w * 128u + bl] = (uint16_t)(run | ((w > 0 && ovf[w - 1u]) ? DN_CX_FLAG : 0u));
             if (w < W) run += hist[w];
         }
     }
-    for (uint32_t w = tid; w < W; w += 256u)
+    unsigned long long *xrow3 = xm + ((uint64_t)(G.xrow0 + (row - G.g0)) * wstride) * 3ull;      // (every row has room for the widest universe)
+    for (uint32_t w = tid; w < W; w += 256u) {
         blk[w * 128u + bl] = (unsigned long long)mask32[2u * w] | ((unsigned long long)mask32[2u * w + 1u] << 32);
-}
-
-hipError_t launch_dense_encode(const uint32_t *off, const uint32_t *code_img, uint32_t rs, const uint32_t *grp_of, const DenseGroup *groups,
-                               const uint32_t *ulist, unsigned long long *gdata, uint16_t *ext, uint32_t xs, uint32_t n, uint32_t wmax,
-                               hipStream_t stream)
-{
-    if (n == 0) return hipSuccess;
-    const size_t smem = ((size_t)3 * wmax + 1 + 8) * 4;
-    hipLaunchKernelGGL(dn_encode_kernel, dim3(n), dim3(256), smem, stream, off, code_img, rs, grp_of, groups, ulist, gdata, ext, xs, n);
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------------
-// the inverted index's runs, clipped for the rows of a group: of the rows below a row that hold one of its values,
-// discovery is to see those OUTSIDE the group only (the pairs inside are this file's).  Rows ascend inside a run and
-// the group is a row interval, so the partners inside are the run's tail: the new end is the first position whose
-// row is not below the group's first row.
-__global__ __launch_bounds__(256) void dn_clip_kernel(const uint32_t *off, const uint32_t *code_img, uint32_t *pos_img, uint32_t rs,
-                                                      const uint32_t *grp_of, const DenseGroup *groups, const uint32_t *sorted_rows,
-                                                      uint32_t n)
-{
-    const uint32_t row = blockIdx.x;
-    if (row >= n) return;
-    const uint32_t g = grp_of[row];
-    if (g == 0xFFFFFFFFu) return;                        // uniform
-    const uint32_t g0 = groups[g].g0;
-    const uint32_t cnt = off[row + 1] - off[row];
-    for (uint32_t p = threadIdx.x; p < cnt; p += 256u) {
-        const uint64_t at = (uint64_t)row * rs + p;
-        uint32_t lo = code_img[at] >> 1, hi = pos_img[at];
-        if (lo == hi) continue;
-        while (lo < hi) {                                  // first position in [lo, hi) with row >= g0
-            const uint32_t mid = (lo + hi) >> 1;
-            if (sorted_rows[mid] < g0) lo = mid + 1; else hi = mid;
-        }
-        pos_img[at] = lo;
+#pragma unroll
+        for (uint32_t k = 0; k < 3u; k++)
+            xrow3[3ull * w + k] = (unsigned long long)xm32[6u * w + 2u * k] | ((unsigned long long)xm32[6u * w + 2u * k + 1u] << 32);
     }
 }
 
-hipError_t launch_dense_clip(const uint32_t *off, const uint32_t *code_img, uint32_t *pos_img, uint32_t rs, const uint32_t *grp_of,
-                             const DenseGroup *groups, const uint32_t *sorted_rows, uint32_t n, hipStream_t stream)
+hipError_t launch_dense_encode(const uint32_t *off, const uint32_t *code_img, uint32_t *pos_img, uint32_t rs, const uint32_t *grp_of,
+                               const DenseGroup *groups, const uint32_t *ulist, const uint32_t *upos, unsigned long long *gdata,
+                               unsigned long long *xm, uint16_t *ext, uint32_t xs, uint32_t n, uint32_t wmax, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(dn_clip_kernel, dim3(n), dim3(256), 0, stream, off, code_img, pos_img, rs, grp_of, groups, sorted_rows, n);
+    // the universe in LDS while it fits beside the masks (64 values per word: always, for the widths dense_max_words allows)
+    const size_t fixed = ((size_t)10 * wmax + 9) * 4, with_ul = fixed + (size_t)wmax * 64 * 4;
+    const bool ul_in_lds = with_ul <= 150 * 1024;
+    const size_t smem = ul_in_lds ? with_ul : fixed;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(dn_encode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(dn_encode_kernel, dim3(n), dim3(256), smem, stream, off, code_img, pos_img, rs, grp_of, groups, ulist, upos, gdata, xm, wmax,
+                       ext, xs, n, ul_in_lds ? 1u : 0u);
     return hipGetLastError();
 }
 
@@ -279,7 +328,6 @@ hipError_t launch_dense_clip(const uint32_t *off, const uint32_t *code_img, uint
 // the pairs of a tile: DN_ROWS rows x the 128 columns of one block of the group, lane = column (so that a row's
 // results leave as one contiguous store per wave).  The column block's words are staged in LDS as they lie in
 // memory (word w of lane l at w * 128 + l: conflict free), the rows' words beside them (read by all lanes at once).
-constexpr uint32_t DN_ROWS = 32;
 
 // where a pair of index rows lands in the output: the index may have been built on a PERMUTED table (rows that belong
 // together next to each other, see dense_cluster_rows); inv maps an index row back to the table's row
@@ -294,10 +342,13 @@ __device__ __forceinline__ uint64_t dn_out_index(uint32_t a, uint32_t b, const u
     return (uint64_t)i * (i - 1u) / 2u - out_base + j;
 }
 
-// STREAM: the column block's words are read from global memory (L2) word by word instead of being staged -- universes of
-// hundreds of words (s = 10 000) do not fit the LDS; the rows' words still sit in LDS
-template <bool STREAM>
+// The column block's words are read from global memory (L2) word by word, the next word requested before the current one
+// is worked on; only the rows' words sit in LDS.  (Staging the block in LDS was measured slower for every width: 26 KB per
+// two waves leave a CU a handful of waves, and the loop lives on having many -- C3 1.47 against 1.10 ms, one clade of
+// 32 768 rows 17.8 against 12.6 ms; universes of hundreds of words, s = 10 000, would not fit anyway.)
+template <uint32_t DN_ROWS>
 __global__ __launch_bounds__(128) void dn_pairs_kernel(const DenseTile *tiles, const DenseGroup *groups, const unsigned long long *gdata,
+                                                       const unsigned long long *xm, uint32_t wstride, uint32_t use_lists,
                                                        const uint16_t *ext, uint32_t xs, uint32_t s, uint32_t row_begin, uint32_t row_end,
                                                        uint64_t out_base, const uint32_t *inv, uint2 *out)
 {
@@ -306,13 +357,10 @@ __global__ __launch_bounds__(128) void dn_pairs_kernel(const DenseTile *tiles, c
     const DenseGroup G = groups[T.group];
     const uint32_t W = G.W, tid = threadIdx.x;
     const uint64_t bw = 128ull * W + 32ull * (W + 1u);
-    const unsigned long long *bsrc = gdata + G.data_off + (uint64_t)T.cblk * bw;
-    const unsigned long long *Bm = STREAM ? bsrc : dl;                                   // [W][128]
+    const unsigned long long *Bm = gdata + G.data_off + (uint64_t)T.cblk * bw;            // [W][128]
     const uint16_t *Bcx = reinterpret_cast<const uint16_t *>(Bm + 128ull * W);             // [W + 1][128]
-    unsigned long long *Am = dl + (STREAM ? 0ull : bw);                                   // [W][DN_ROWS]
+    unsigned long long *Am = dl;                                                          // [W][DN_ROWS]
     uint16_t *Acx = reinterpret_cast<uint16_t *>(Am + (uint64_t)DN_ROWS * W);             // [W + 1][DN_ROWS]
-    if (!STREAM)
-        for (uint32_t i = tid; i < (uint32_t)bw; i += 128u) dl[i] = bsrc[i];
     const uint32_t ra = T.row0 - G.g0;                                    // (a multiple of DN_ROWS: the tile's rows share a block)
     const unsigned long long *asrc = gdata + G.data_off + (uint64_t)(ra >> 7) * bw;
     const uint32_t la0 = ra & 127u;
@@ -324,6 +372,7 @@ __global__ __launch_bounds__(128) void dn_pairs_kernel(const DenseTile *tiles, c
     __syncthreads();
     const uint32_t b = G.g0 + T.cblk * 128u + tid;                         // this lane's column
     const uint16_t *xb = ext + (uint64_t)(G.xrow0 + (b < G.g1 ? b - G.g0 : 0u)) * xs;
+    const unsigned long long *xmb = xm + (uint64_t)(G.xrow0 + (b < G.g1 ? b - G.g0 : 0u)) * wstride * 3ull;
     for (uint32_t ai = 0; ai < DN_ROWS; ai++) {
         const uint32_t a = T.row0 + ai;
         if (a >= G.g1 || a >= row_end) break;                             // uniform
@@ -331,14 +380,23 @@ __global__ __launch_bounds__(128) void dn_pairs_kernel(const DenseTile *tiles, c
         if (G.g0 + T.cblk * 128u >= a) continue;                          // uniform: for this row the whole block is at or above the diagonal
         const bool valid = b < a;
         const uint16_t *xa = ext + (uint64_t)(G.xrow0 + (a - G.g0)) * xs;
+        const unsigned long long *xma = xm + (uint64_t)(G.xrow0 + (a - G.g0)) * wstride * 3ull;
         uint32_t pu = 0, common = 0, denom = 0;
         bool done = !valid;
+        unsigned long long mb_next = Bm[tid];
+        uint32_t cb_next = Bcx[128u + tid], cb0r = Bcx[tid];
         for (uint32_t w = 0; w < W; w++) {
             if (__ballot(!done) == 0) break;                              // uniform
-            const unsigned long long ma = Am[w * DN_ROWS + ai], mb = Bm[w * 128u + tid];
+            const unsigned long long ma = Am[w * DN_ROWS + ai], mb = mb_next;
+            const uint32_t cb1r = cb_next;                                // (bit 15: the word's flag)
+            if (w + 1u < W) {                                             // the next word is on its way while this one is worked on
+                mb_next = Bm[(w + 1u) * 128u + tid];
+                cb_next = Bcx[(w + 2u) * 128u + tid];
+            }
             const unsigned long long un = ma | mb, an = ma & mb;
             const uint32_t pun = (uint32_t)__popcll(un);
-            const uint32_t ca1 = Acx[(w + 1u) * DN_ROWS + ai], cb1 = Bcx[(w + 1u) * 128u + tid];
+            const uint32_t ca1r = Acx[(w + 1u) * DN_ROWS + ai];
+            const uint32_t ca1 = ca1r & DN_CX_MASK, cb1 = cb1r & DN_CX_MASK;
             const uint32_t F = pu + pun + ca1 + cb1;
             if (!done) {
                 if (F <= s) {                                             // the whole word lies before the s-th union element
@@ -348,26 +406,42 @@ __global__ __launch_bounds__(128) void dn_pairs_kernel(const DenseTile *tiles, c
                 } else {
                     // s is reached inside this word: the smallest bit position t with f(t) >= s, f(t) = what lies before the
                     // word + union bits below t + extras of either row with offset <= t; bits below it are counted
-                    const uint32_t ca0 = Acx[w * DN_ROWS + ai], cb0 = Bcx[w * 128u + tid];
+                    const uint32_t ca0 = Acx[w * DN_ROWS + ai] & DN_CX_MASK, cb0 = cb0r & DN_CX_MASK;
                     const uint32_t Fprev = pu + ca0 + cb0;
-                    const uint32_t na = ca1 - ca0, nb = cb1 - cb0, wbase = w << 6;
                     uint32_t lo = 0, hi = 63;
-                    while (lo < hi) {
-                        const uint32_t mid = (lo + hi) >> 1;
-                        uint32_t c = Fprev + (uint32_t)__popcll(un & ((1ull << mid) - 1ull));
-                        for (uint32_t k = 0; k < na; k++) c += ((uint32_t)xa[ca0 + k] - wbase <= mid) ? 1u : 0u;
-                        for (uint32_t k = 0; k < nb; k++) c += ((uint32_t)xb[cb0 + k] - wbase <= mid) ? 1u : 0u;
-                        if (c >= s) hi = mid; else lo = mid + 1u;
+                    if (!use_lists && ((ca1r | cb1r) & DN_CX_FLAG) == 0) {
+                        // the extras of the word as three masks per row (bit o of mask j: at least j + 1 extras at offset o)
+                        const unsigned long long a0 = xma[3u * w], a1 = xma[3u * w + 1u], a2 = xma[3u * w + 2u];
+                        const unsigned long long b0 = xmb[3u * w], b1 = xmb[3u * w + 1u], b2 = xmb[3u * w + 2u];
+                        while (lo < hi) {
+                            const uint32_t mid = (lo + hi) >> 1;                  // <= 62
+                            const unsigned long long below = (1ull << mid) - 1ull, upto = (2ull << mid) - 1ull;
+                            const uint32_t c = Fprev + (uint32_t)__popcll(un & below) + (uint32_t)__popcll(a0 & upto) + (uint32_t)__popcll(a1 & upto) +
+                                               (uint32_t)__popcll(a2 & upto) + (uint32_t)__popcll(b0 & upto) + (uint32_t)__popcll(b1 & upto) +
+                                               (uint32_t)__popcll(b2 & upto);
+                            if (c >= s) hi = mid; else lo = mid + 1u;
+                        }
+                    } else {
+                        // (a gap of this word holds four extras and more in one of the two rows: counted from the lists)
+                        const uint32_t na = ca1 - ca0, nb = cb1 - cb0, wbase = w << 6;
+                        while (lo < hi) {
+                            const uint32_t mid = (lo + hi) >> 1;
+                            uint32_t c = Fprev + (uint32_t)__popcll(un & ((1ull << mid) - 1ull));
+                            for (uint32_t k = 0; k < na; k++) c += ((uint32_t)xa[ca0 + k] - wbase <= mid) ? 1u : 0u;
+                            for (uint32_t k = 0; k < nb; k++) c += ((uint32_t)xb[cb0 + k] - wbase <= mid) ? 1u : 0u;
+                            if (c >= s) hi = mid; else lo = mid + 1u;
+                        }
                     }
                     common += (uint32_t)__popcll(an & ((1ull << lo) - 1ull));
                     done = true;
                     denom = s;
                 }
             }
+            cb0r = cb1r;
         }
         if (valid) {
             if (!done) {                                                  // the union ends before s (short sketches)
-                const uint32_t total = pu + Acx[W * DN_ROWS + ai] + Bcx[W * 128u + tid];
+                const uint32_t total = pu + (Acx[W * DN_ROWS + ai] & DN_CX_MASK) + (Bcx[W * 128u + tid] & DN_CX_MASK);
                 denom = total < s ? total : s;
             }
             out[dn_out_index(a, b, inv, out_base)] = make_uint2(common, denom);
@@ -375,32 +449,30 @@ __global__ __launch_bounds__(128) void dn_pairs_kernel(const DenseTile *tiles, c
     }
 }
 
-// LDS of a tile: staged column block + rows (W up to dense_max_words_staged()), or the rows alone (streamed column block)
-constexpr uint32_t DN_STAGE_WORDS = 48;
-uint32_t dense_max_words_staged() { return DN_STAGE_WORDS; }
-uint32_t dense_max_words() { return 400; }                 // rows of a tile in LDS: 32 x (8 W + 2 W + 2) bytes
+// LDS of a tile: its rows' words and counts
+uint32_t dense_max_words() { return 400; }                 // 32 rows x (8 W + 2 W + 2) bytes
 
-size_t dense_pairs_lds(uint32_t W)
-{
-    const size_t bw = W <= DN_STAGE_WORDS ? 128ull * W + 32ull * (W + 1u) : 0;
-    return (bw + (size_t)DN_ROWS * W) * 8 + (size_t)(W + 1u) * DN_ROWS * 2 + 16;
-}
+size_t dense_pairs_lds(uint32_t W, uint32_t rows) { return (size_t)rows * W * 8 + (size_t)(W + 1u) * rows * 2 + 16; }
 
-uint32_t dense_rows_per_tile() { return DN_ROWS; }
+// rows of a tile: 32 when that still leaves enough tiles to fill the device (a tile is two waves; the rows of a tile are taken
+// one after the other), else 8 -- a collection of small clusters has few column blocks per row block
+uint32_t dense_rows_per_tile(uint64_t wave_rows) { return wave_rows / 32u >= 16384u ? 32u : 8u; }
 
-hipError_t launch_dense_pairs(const DenseTile *tiles, uint32_t ntiles, const DenseGroup *groups, const unsigned long long *gdata,
-                              const uint16_t *ext, uint32_t xs, uint32_t s, uint32_t wmax, uint32_t row_begin, uint32_t row_end,
-                              uint64_t out_base, const uint32_t *inv, uint2 *out, hipStream_t stream)
+hipError_t launch_dense_pairs(const DenseTile *tiles, uint32_t ntiles, uint32_t rows_per_tile, const DenseGroup *groups,
+                              const unsigned long long *gdata, const unsigned long long *xm, bool use_lists, const uint16_t *ext, uint32_t xs,
+                              uint32_t s, uint32_t wmax, uint32_t row_begin, uint32_t row_end, uint64_t out_base, const uint32_t *inv, uint2 *out,
+                              hipStream_t stream)
 {
     if (ntiles == 0) return hipSuccess;
-    const size_t smem = dense_pairs_lds(wmax);
+    const size_t smem = dense_pairs_lds(wmax, rows_per_tile);
     auto go = [&](auto kern) -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(ntiles), dim3(128), smem, stream, tiles, groups, gdata, ext, xs, s, row_begin, row_end, out_base, inv, out);
+        hipLaunchKernelGGL(kern, dim3(ntiles), dim3(128), smem, stream, tiles, groups, gdata, xm, wmax, use_lists ? 1u : 0u, ext, xs, s, row_begin, row_end,
+                           out_base, inv, out);
         return hipGetLastError();
     };
-    return wmax <= DN_STAGE_WORDS ? go(dn_pairs_kernel<false>) : go(dn_pairs_kernel<true>);
+    return rows_per_tile == 32u ? go(dn_pairs_kernel<32>) : go(dn_pairs_kernel<8>);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -171,25 +171,25 @@ struct DenseGroup {
 struct DenseTile { uint32_t group, row0, cblk; };
 hipError_t launch_dense_neighbors(const uint64_t *hashes, uint64_t stride, const uint32_t *cnt, uint32_t n, uint8_t *link,
                                   hipStream_t stream);
-size_t dense_universe_temp_bytes(uint32_t E);
-hipError_t dense_select_leaders(const uint32_t *sorted_rows, const uint32_t *gs_of, const uint32_t *gend, const uint32_t *grp_of,
-                                const DenseGroup *groups, uint32_t E, void *temp, size_t temp_bytes, uint8_t *flag, uint32_t *lead_pos,
-                                uint32_t *nlead, hipStream_t stream);
-hipError_t dense_sort_universes(const uint32_t *lead_pos, const uint32_t *nlead, uint32_t m, const uint32_t *sorted_rows, const uint32_t *gs_of,
-                                const uint32_t *grp_of, void *temp, size_t temp_bytes, uint32_t *key, uint32_t *key_sorted, uint32_t *val,
-                                uint32_t *ulist, uint32_t *ustart, uint32_t *uend, uint32_t group_bits, hipStream_t stream);
-hipError_t launch_dense_encode(const uint32_t *off, const uint32_t *code_img, uint32_t rs, const uint32_t *grp_of, const DenseGroup *groups,
-                               const uint32_t *ulist, unsigned long long *gdata, uint16_t *ext, uint32_t xs, uint32_t n, uint32_t wmax,
-                               hipStream_t stream);
-hipError_t launch_dense_clip(const uint32_t *off, const uint32_t *code_img, uint32_t *pos_img, uint32_t rs, const uint32_t *grp_of,
-                             const DenseGroup *groups, const uint32_t *sorted_rows, uint32_t n, hipStream_t stream);
-size_t dense_pairs_lds(uint32_t W);
-uint32_t dense_rows_per_tile();
-uint32_t dense_max_words_staged();
+size_t dense_universe_temp_bytes(uint32_t cap);
+uint32_t dense_sublists();
+hipError_t dense_find_leaders(const uint32_t *sorted_rows, const uint32_t *gs_of, const uint32_t *gend, const uint32_t *grp_of,
+                              const DenseGroup *groups, uint32_t E, unsigned long long *key, uint32_t *val, uint32_t cap_sub,
+                              unsigned long long *key_out, uint32_t *val_out, uint32_t *cnt, uint32_t *off, uint32_t *total,
+                              hipStream_t stream);
+hipError_t dense_sort_universes(const unsigned long long *key, const uint32_t *val, uint32_t m, void *temp, size_t temp_bytes,
+                                unsigned long long *key_sorted, uint32_t *ulist, uint32_t *upos, uint32_t *ustart, uint32_t *uend,
+                                uint32_t group_bits, hipStream_t stream);
+hipError_t launch_dense_encode(const uint32_t *off, const uint32_t *code_img, uint32_t *pos_img, uint32_t rs, const uint32_t *grp_of,
+                               const DenseGroup *groups, const uint32_t *ulist, const uint32_t *upos, unsigned long long *gdata,
+                               unsigned long long *xm, uint16_t *ext, uint32_t xs, uint32_t n, uint32_t wmax, hipStream_t stream);
+size_t dense_pairs_lds(uint32_t W, uint32_t rows);
+uint32_t dense_rows_per_tile(uint64_t wave_rows);
 uint32_t dense_max_words();
-hipError_t launch_dense_pairs(const DenseTile *tiles, uint32_t ntiles, const DenseGroup *groups, const unsigned long long *gdata,
-                              const uint16_t *ext, uint32_t xs, uint32_t s, uint32_t wmax, uint32_t row_begin, uint32_t row_end,
-                              uint64_t out_base, const uint32_t *inv, uint2 *out, hipStream_t stream);
+hipError_t launch_dense_pairs(const DenseTile *tiles, uint32_t ntiles, uint32_t rows_per_tile, const DenseGroup *groups,
+                              const unsigned long long *gdata, const unsigned long long *xm, bool use_lists, const uint16_t *ext, uint32_t xs,
+                              uint32_t s, uint32_t wmax, uint32_t row_begin, uint32_t row_end, uint64_t out_base, const uint32_t *inv, uint2 *out,
+                              hipStream_t stream);
 size_t dense_cluster_temp_bytes(uint32_t n);
 hipError_t dense_cluster_rows(const uint64_t *hashes, uint64_t stride, const uint32_t *cnt, uint32_t n, void *temp, size_t temp_bytes,
                               unsigned long long *key_a, unsigned long long *key_b, uint32_t *row_a, uint32_t *row_b, uint32_t *lab_a,

@@ -118,10 +118,11 @@ struct mg_table {
         std::vector<mg::DenseGroup> dgroups_host;
         mg::DenseGroup *dgroups = nullptr;
         uint32_t *grp_of = nullptr;        // [n] group of a row, 0xFFFFFFFF: none
-        uint32_t *ulist = nullptr;         // the groups' universes
-        unsigned long long *gdata = nullptr;
+        uint32_t *ulist = nullptr, *upos = nullptr;        // the groups' universes: values and the positions of their leaders
+        unsigned long long *gdata = nullptr, *xm = nullptr; // mask blocks; per row and word three masks of the extras' offsets
         uint16_t *ext = nullptr;
         uint32_t dn_wmax = 0, dn_xs = 0;
+        bool dn_lists = false;             // (test knob) every word resolved from the extras' lists instead of their masks
         // The index may be built on the table in ANOTHER ROW ORDER (rows that belong together next to each other, so that
         // they form dense groups whatever the order of the collection; compare_dense.hip: dense_cluster_rows): `clustered`
         // says this variant was asked for, inv != nullptr that the order differs -- index row a is table row inv[a], the
@@ -142,7 +143,7 @@ struct mg_table {
         std::vector<uint32_t> short_rows_host;
         // what a (rows, range) job costs, learned by a counting pass the first time it is seen
         struct Plan { const void *rows; uint64_t rb, re; bool triangle; uint64_t cand, shared; bool use; uint32_t *order;
-                      mg::DenseTile *dtiles; uint32_t ndtiles; uint64_t dense_pairs; };
+                      mg::DenseTile *dtiles; uint32_t ndtiles, dtile_rows; uint64_t dense_pairs; };
         std::vector<Plan> plans;
         uint2 *cand = nullptr, *res = nullptr;    // candidate list and the candidates' results, grown on demand
         uint64_t cand_cap = 0;
@@ -324,6 +325,13 @@ int mg_ctx_create(int device, mg_ctx **out)
     c->own_stream = true;
     int cus = 0;                        // (one attribute, not hipGetDeviceProperties: that call fills a page of fields)
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess) c->cu_count = cus;
+    {
+        // the pool of large blocks may hold up to 40 % of the device's memory (the index of an s = 10 000 table of 10^5 rows is
+        // 40 GB with its scratch: a pool smaller than a table's blocks frees and allocates them again for every table)
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) c->big_limit = std::max<size_t>(c->big_limit, total_b / 10 * 4);
+        else (void)hipGetLastError();
+    }
     { std::lock_guard<std::mutex> lk(g_live_mu); g_live_ctx.push_back(c); }
     *out = c;
     return MG_OK;
@@ -1549,7 +1557,7 @@ static void table_drop_derived(mg_table *t)
                         (void *)sp->res, (void *)sp->seg_base, (void *)sp->seg_cnt, (void *)sp->chunks, (void *)sp->chunk_inc,
                         sp->scan_temp, (void *)sp->counters, (void *)sp->rep, (void *)sp->cls_of, (void *)sp->cls_off,
                         (void *)sp->cls_rows, (void *)sp->cls_first, (void *)sp->order, (void *)sp->dgroups, (void *)sp->grp_of,
-                        (void *)sp->ulist, (void *)sp->gdata, (void *)sp->ext, (void *)sp->inv, (void *)sp->phashes})
+                        (void *)sp->ulist, (void *)sp->upos, (void *)sp->gdata, (void *)sp->xm, (void *)sp->ext, (void *)sp->inv, (void *)sp->phashes})
             if (q) ctx_free(ctx, q);
         delete sp;
     }
@@ -2142,10 +2150,10 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
     bool want_dense = true;
     if (const char *e = getenv("MASHGPU_COMPARE_DENSE")) want_dense = atoi(e) != 0;
     DevBuf<uint8_t> d_link(ctx);
-    if (want_dense && n >= 8 && s <= 32768 && !lab_sorted.empty()) {
+    if (want_dense && n >= 8 && s <= 16384 && !lab_sorted.empty()) {
         link.assign(n, 0);                                  // clustered variant: neighbours with the same label
         for (uint64_t a = 1; a < n; a++) link[a] = (lab_sorted[a] == lab_sorted[a - 1] && cnt_true[a] && cnt_true[a - 1]) ? 1 : 0;
-    } else if (want_dense && n >= 8 && s <= 32768 && d_link.alloc(n) == hipSuccess) {      // (u16 counters of the extras)
+    } else if (want_dense && n >= 8 && s <= 16384 && d_link.alloc(n) == hipSuccess) {      // (u16 counters of the extras, one bit a flag)
         link.resize(n);
         HIP_TRY(ctx, mg::launch_dense_neighbors(H, t->s, d_cnt, (uint32_t)n, d_link, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(link.data(), d_link, n, hipMemcpyDeviceToHost, ctx->stream));
@@ -2336,31 +2344,55 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
             for (uint32_t g = 0; g < ng; g++)
                 for (uint32_t r = cand_groups[g].g0; r < cand_groups[g].g1; r++) grp_of[r] = g;
             DevBuf<mg::DenseGroup> d_groups(ctx);
-            DevBuf<uint32_t> d_grp_of(ctx), d_lead(ctx), d_nlead(ctx), d_us(ctx), d_ue(ctx), d_key(ctx), d_key2(ctx), d_val(ctx);
-            DevBuf<uint8_t> d_flag(ctx);
+            DevBuf<uint32_t> d_grp_of(ctx), d_val(ctx), d_nlead(ctx), d_us(ctx), d_ue(ctx);
+            DevBuf<unsigned long long> d_key(ctx), d_key2(ctx);
             DevBuf<unsigned char> d_tmp(ctx);
-            const size_t tb = mg::dense_universe_temp_bytes(E);
-            if (d_groups.alloc(ng) != hipSuccess || d_grp_of.alloc(n) != hipSuccess || d_lead.alloc(E) != hipSuccess || d_nlead.alloc(1) != hipSuccess ||
-                d_us.alloc(ng) != hipSuccess || d_ue.alloc(ng) != hipSuccess || d_flag.alloc(E) != hipSuccess ||
-                d_tmp.alloc(std::max<size_t>(tb, 16)) != hipSuccess) { (void)hipGetLastError(); break; }
-            uint32_t nlead = 0;
+            if (d_groups.alloc(ng) != hipSuccess || d_grp_of.alloc(n) != hipSuccess || d_nlead.alloc(2) != hipSuccess || d_us.alloc(ng) != hipSuccess ||
+                d_ue.alloc(ng) != hipSuccess) { (void)hipGetLastError(); break; }
+            // leaders: one list entry each, appended to one of a thousand lists (room for a quarter of the entries in all, evenly;
+            // a table with more, or with lists that fill unevenly, is searched a second time with the room the first pass asked for)
+            const uint32_t L = mg::dense_sublists();
+            DevBuf<unsigned long long> d_keyj(ctx);
+            DevBuf<uint32_t> d_valj(ctx), d_cnt_sub(ctx), d_off_sub(ctx);
+            uint32_t tot[2] = {0, 0}, cap_sub = std::max<uint32_t>(E / 4u / L + 64u, 256u);
             hipError_t e2 = hipMemcpyAsync(d_groups, cand_groups.data(), ng * sizeof(mg::DenseGroup), hipMemcpyHostToDevice, ctx->stream);
             if (e2 == hipSuccess) e2 = hipMemcpyAsync(d_grp_of, grp_of.data(), n * 4, hipMemcpyHostToDevice, ctx->stream);
-            if (e2 == hipSuccess)
-                e2 = mg::dense_select_leaders(sp->sorted_rows, gs_of, sp->gend, d_grp_of, d_groups, E, d_tmp, tb, d_flag, d_lead, d_nlead, ctx->stream);
-            if (e2 == hipSuccess) e2 = hipMemcpyAsync(&nlead, d_nlead, 4, hipMemcpyDeviceToHost, ctx->stream);
-            if (e2 == hipSuccess) e2 = hipStreamSynchronize(ctx->stream);
-            if (e2 != hipSuccess || nlead == 0) { (void)hipGetLastError(); break; }
+            if (e2 == hipSuccess && (d_cnt_sub.alloc(L) != hipSuccess || d_off_sub.alloc(L) != hipSuccess)) { (void)hipGetLastError(); e2 = hipErrorOutOfMemory; }
+            for (int attempt = 0; e2 == hipSuccess; attempt++) {
+                for (void **q : {(void **)&d_key.p, (void **)&d_val.p, (void **)&d_keyj.p, (void **)&d_valj.p})
+                    if (*q) { ctx_free(ctx, *q); *q = nullptr; }
+                const uint64_t room = (uint64_t)L * cap_sub;
+                if (d_key.alloc(room) != hipSuccess || d_val.alloc(room) != hipSuccess || d_keyj.alloc(room) != hipSuccess || d_valj.alloc(room) != hipSuccess) {
+                    (void)hipGetLastError();
+                    e2 = hipErrorOutOfMemory;
+                    break;
+                }
+                e2 = mg::dense_find_leaders(sp->sorted_rows, gs_of, sp->gend, d_grp_of, d_groups, E, d_key, d_val, cap_sub, d_keyj, d_valj, d_cnt_sub, d_off_sub,
+                                            d_nlead, ctx->stream);
+                if (e2 == hipSuccess) e2 = hipMemcpyAsync(tot, d_nlead, 8, hipMemcpyDeviceToHost, ctx->stream);
+                if (e2 == hipSuccess) e2 = hipStreamSynchronize(ctx->stream);
+                if (e2 != hipSuccess || tot[1] <= cap_sub || attempt >= 1) break;
+                cap_sub = tot[1];
+            }
+            const uint32_t nlead = tot[0];
+            if (e2 != hipSuccess || nlead == 0 || tot[1] > cap_sub) { (void)hipGetLastError(); break; }
             uint32_t gbits = 1;
             while ((1u << gbits) < ng) gbits++;
             std::vector<uint32_t> us(ng, 0), ue(ng, 0);
-            void *ul = nullptr;
-            if (d_key.alloc(nlead) != hipSuccess || d_key2.alloc(nlead) != hipSuccess || d_val.alloc(nlead) != hipSuccess || ctx_malloc(ctx, &ul, (size_t)nlead * 4) != hipSuccess) { (void)hipGetLastError(); break; }
+            void *ul = nullptr, *up = nullptr;
+            const size_t tb = mg::dense_universe_temp_bytes(nlead);
+            if (d_key2.alloc(nlead) != hipSuccess || d_tmp.alloc(std::max<size_t>(tb, 16)) != hipSuccess ||
+                ctx_malloc(ctx, &ul, (size_t)nlead * 4) != hipSuccess || ctx_malloc(ctx, &up, (size_t)nlead * 4) != hipSuccess) {
+                (void)hipGetLastError();
+                ctx_free(ctx, ul);
+                break;
+            }
             sp->ulist = static_cast<uint32_t *>(ul);
+            sp->upos = static_cast<uint32_t *>(up);
             e2 = hipMemsetAsync(d_us, 0, ng * 4, ctx->stream);
             if (e2 == hipSuccess) e2 = hipMemsetAsync(d_ue, 0, ng * 4, ctx->stream);
             if (e2 == hipSuccess)
-                e2 = mg::dense_sort_universes(d_lead, d_nlead, nlead, sp->sorted_rows, gs_of, d_grp_of, d_tmp, tb, d_key, d_key2, d_val, sp->ulist, d_us, d_ue, gbits, ctx->stream);
+                e2 = mg::dense_sort_universes(d_keyj, d_valj, nlead, d_tmp, tb, d_key2, sp->ulist, sp->upos, d_us, d_ue, gbits, ctx->stream);
             if (e2 == hipSuccess) e2 = hipMemcpyAsync(us.data(), d_us, ng * 4, hipMemcpyDeviceToHost, ctx->stream);
             if (e2 == hipSuccess) e2 = hipMemcpyAsync(ue.data(), d_ue, ng * 4, hipMemcpyDeviceToHost, ctx->stream);
             if (e2 == hipSuccess) e2 = hipStreamSynchronize(ctx->stream);
@@ -2389,11 +2421,12 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
             if (sp->dgroups_host.empty()) break;
             sp->dn_wmax = wmax;
             sp->dn_xs = ((s + 7u) & ~7u) + 8u;
-            void *p1 = nullptr, *p2 = nullptr, *p3 = nullptr, *p4 = nullptr;
+            void *p1 = nullptr, *p2 = nullptr, *p3 = nullptr, *p4 = nullptr, *p5 = nullptr;
             if (ctx_malloc(ctx, &p1, sp->dgroups_host.size() * sizeof(mg::DenseGroup)) != hipSuccess || ctx_malloc(ctx, &p2, n * 4) != hipSuccess ||
-                ctx_malloc(ctx, &p3, words * 8) != hipSuccess || ctx_malloc(ctx, &p4, (size_t)xrows * sp->dn_xs * 2) != hipSuccess) {
+                ctx_malloc(ctx, &p3, words * 8) != hipSuccess || ctx_malloc(ctx, &p4, (size_t)xrows * sp->dn_xs * 2) != hipSuccess ||
+                ctx_malloc(ctx, &p5, (size_t)xrows * wmax * 24) != hipSuccess) {
                 (void)hipGetLastError();
-                for (void *q : {p1, p2, p3, p4}) ctx_free(ctx, q);
+                for (void *q : {p1, p2, p3, p4, p5}) ctx_free(ctx, q);
                 sp->dgroups_host.clear();
                 break;
             }
@@ -2401,26 +2434,28 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
             sp->grp_of = static_cast<uint32_t *>(p2);
             sp->gdata = static_cast<unsigned long long *>(p3);
             sp->ext = static_cast<uint16_t *>(p4);
+            sp->xm = static_cast<unsigned long long *>(p5);
             e2 = hipMemcpyAsync(sp->dgroups, sp->dgroups_host.data(), sp->dgroups_host.size() * sizeof(mg::DenseGroup), hipMemcpyHostToDevice, ctx->stream);
             if (e2 == hipSuccess) e2 = hipMemcpyAsync(sp->grp_of, grp_of.data(), n * 4, hipMemcpyHostToDevice, ctx->stream);
+            // masks, extras, and the index's runs clipped for the rows of the groups: discovery sees the partners outside only
             if (e2 == hipSuccess)
-                e2 = mg::launch_dense_encode(sp->off, sp->code_img, sp->rs, sp->grp_of, sp->dgroups, sp->ulist, sp->gdata, sp->ext, sp->dn_xs, (uint32_t)n,
-                                             wmax, ctx->stream);
-            if (e2 == hipSuccess)
-                e2 = mg::launch_dense_clip(sp->off, sp->code_img, sp->pos_img, sp->rs, sp->grp_of, sp->dgroups, sp->sorted_rows, (uint32_t)n, ctx->stream);
+                e2 = mg::launch_dense_encode(sp->off, sp->code_img, sp->pos_img, sp->rs, sp->grp_of, sp->dgroups, sp->ulist, sp->upos, sp->gdata, sp->xm,
+                                             sp->ext, sp->dn_xs, (uint32_t)n, wmax, ctx->stream);
             if (e2 == hipSuccess) e2 = hipStreamSynchronize(ctx->stream);   // (grp_of, the host vector, is read by the copy above)
             if (e2 != hipSuccess) {
                 // the runs may be half clipped: this index is not to be used
                 drop();
-                for (void **q : {(void **)&sp->dgroups, (void **)&sp->grp_of, (void **)&sp->gdata, (void **)&sp->ext, (void **)&sp->ulist})
+                for (void **q : {(void **)&sp->dgroups, (void **)&sp->grp_of, (void **)&sp->gdata, (void **)&sp->ext, (void **)&sp->xm, (void **)&sp->ulist,
+                                 (void **)&sp->upos})
                     if (*q) { ctx_free(ctx, *q); *q = nullptr; }
                 sp->dgroups_host.clear();
                 sp->usable = false;
                 return fail(ctx, MG_ERR_HIP, std::string("compare (index build, dense groups): ") + hipGetErrorString(e2));
             }
+            sp->dn_lists = getenv("MASHGPU_DENSE_LISTS") != nullptr;          // (test knob: every word resolved from the lists)
             break;
         }
-        if (sp->dgroups_host.empty() && sp->ulist) { ctx_free(ctx, sp->ulist); sp->ulist = nullptr; }
+        if (sp->dgroups_host.empty() && sp->ulist) { ctx_free(ctx, sp->ulist); ctx_free(ctx, sp->upos); sp->ulist = sp->upos = nullptr; }
         sp->build_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dense).count();
         if (getenv("MASHGPU_SPARSE_DBG")) {
             uint64_t rows_in = 0;
@@ -2577,10 +2612,16 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
     if (first) {
         fresh.rows = rows; fresh.rb = row_begin; fresh.re = row_end; fresh.triangle = triangle;
         fresh.cand = 0; fresh.shared = 0; fresh.use = true; fresh.order = nullptr;
-        fresh.dtiles = nullptr; fresh.ndtiles = 0; fresh.dense_pairs = 0;
+        fresh.dtiles = nullptr; fresh.ndtiles = 0; fresh.dtile_rows = 32; fresh.dense_pairs = 0;
         if (triangle && !ix->dgroups_host.empty()) {
-            // tiles of the dense groups' inner pairs: 32 rows (aligned to the group's first row) x a block of 128 columns
-            const uint32_t R = mg::dense_rows_per_tile();
+            // tiles of the dense groups' inner pairs: 32 or 8 rows (aligned to the group's first row) x a block of 128 columns
+            uint64_t wave_rows = 0;                          // rows x column blocks x two waves: the work there is to hand out
+            for (const mg::DenseGroup &G : ix->dgroups_host) {
+                const uint64_t m = G.g1 - G.g0;
+                wave_rows += m * ((m + 127) / 128);          // (about half of it below the diagonal)
+            }
+            const uint32_t R = mg::dense_rows_per_tile(wave_rows);
+            fresh.dtile_rows = R;
             std::vector<mg::DenseTile> tiles;
             for (uint32_t g = 0; g < ix->dgroups_host.size(); g++) {
                 const mg::DenseGroup &G = ix->dgroups_host[g];
@@ -2745,8 +2786,8 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
         // the pairs inside the dense groups (over the fill; candidates never lie inside a group)
         if (plan->ndtiles) {
             prof_begin(ctx, ctx->prof_dense);
-            e = mg::launch_dense_pairs(plan->dtiles, plan->ndtiles, ix->dgroups, ix->gdata, ix->ext, ix->dn_xs, s, ix->dn_wmax, a.row_begin, a.row_end,
-                                       a.out_base, a.inv, a.out, ctx->stream);
+            e = mg::launch_dense_pairs(plan->dtiles, plan->ndtiles, plan->dtile_rows, ix->dgroups, ix->gdata, ix->xm, ix->dn_lists, ix->ext, ix->dn_xs, s, ix->dn_wmax,
+                                       a.row_begin, a.row_end, a.out_base, a.inv, a.out, ctx->stream);
             prof_end(ctx, ctx->prof_dense);
             if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare (dense groups): ") + hipGetErrorString(e));
         }
