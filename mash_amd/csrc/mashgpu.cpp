@@ -2084,6 +2084,10 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
     if (n * sp->rs >= (1ull << 32)) return unusable("image index beyond 32 bits");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const auto t_begin = std::chrono::steady_clock::now();
+    // (the "index" phase of the library's HIP-event records: everything this function queues -- clustering, digests, sort,
+    //  images, dense groups -- incl. the waits between its steps)
+    prof_begin(ctx, ctx->prof_index);
+    struct ProfEnd { mg_ctx *c; ~ProfEnd() { prof_end(c, c->prof_index); } } prof_end_guard{ctx};
     // ---- identical rows (see compare_sparse.hip): digest every row, sort the digests on the device; rows whose
     // digest and length equal their predecessor's are suspects, verified value by value; copies then stay out
     // of the index
@@ -2102,7 +2106,7 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
     const uint64_t *H = t->hashes;                          // what the index is built from
     std::vector<uint64_t> last_p;                           // the rows' largest hashes in index order (empty: t->last)
     std::vector<uint32_t> lab_sorted;                       // label of every index row (clustered variant)
-    if (clustered && n >= 16 && !getenv("MASHGPU_COMPARE_NO_CLUSTER")) {
+    if (clustered && n >= 16) {
         DevBuf<unsigned long long> k_a(ctx), k_b(ctx);
         DevBuf<uint32_t> r_a(ctx), r_b(ctx), l_a(ctx), l_b(ctx), d_inv(ctx), d_lab(ctx);
         DevBuf<unsigned char> d_tmp(ctx);
@@ -2294,7 +2298,6 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
         if (e == hipSuccess && nshort) e = hipMemcpyAsync(sp->short_rows, sp->short_rows_host.data(), nshort * 4, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess && nshort) e = hipMemcpyAsync(sp->short_cnt, short_cnt.data(), nshort * 4, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipMemsetAsync(d_stat, 0, sizeof(Stat), ctx->stream);
-        prof_begin(ctx, ctx->prof_index);
         if (e == hipSuccess)
             e = mg::sparse_build_index(H, t->s, sp->off, (uint32_t)n, E, sp->rs, end_bit, temp, temp_bytes, keys_a, idx_a,
                                        sp->keys_sorted, idx_sorted, /*head=*/idx_a, gs_of, sp->sorted_rows, sp->gend, sp->code_img, sp->pos_img,
@@ -2303,7 +2306,6 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
         if (e == hipSuccess && want_order)
             e = mg::launch_sparse_row_order(sp->off, sp->code_img, sp->gend, sp->rep, (uint32_t)n, sp->rs, temp, temp_bytes, key64_a, key64_b,
                                             sp->order, ctx->stream);
-        prof_end(ctx, ctx->prof_index);
         if (e == hipSuccess) e = hipMemcpyAsync(&h_stat, d_stat, sizeof(Stat), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     }
