@@ -342,6 +342,41 @@ __device__ __forceinline__ uint64_t dn_out_index(uint32_t a, uint32_t b, const u
     return (uint64_t)i * (i - 1u) / 2u - out_base + j;
 }
 
+constexpr uint32_t DN_IL = 4;                             // rows a wave works on side by side
+
+// The word in which the union reaches its s-th element: the smallest bit position t with f(t) >= s, where f(t) = what lies
+// before the word (fprev) + union bits below t + extras of either row with offset <= t; the bits below t are the ones counted.
+// The extras of the word as three masks per row (bit o of mask j: at least j + 1 extras at offset o), or -- a gap of the word
+// holds four and more in one of the rows -- from the rows' lists.
+__device__ __forceinline__ uint32_t dn_resolve(unsigned long long un, uint32_t fprev, uint32_t s, uint32_t w, bool lists,
+                                               const unsigned long long *xma, const unsigned long long *xmb, const uint16_t *xa,
+                                               const uint16_t *xb, uint32_t ca0, uint32_t na, uint32_t cb0, uint32_t nb)
+{
+    uint32_t lo = 0, hi = 63;
+    if (!lists) {
+        const unsigned long long a0 = xma[3u * w], a1 = xma[3u * w + 1u], a2 = xma[3u * w + 2u];
+        const unsigned long long b0 = xmb[3u * w], b1 = xmb[3u * w + 1u], b2 = xmb[3u * w + 2u];
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;                          // <= 62
+            const unsigned long long below = (1ull << mid) - 1ull, upto = (2ull << mid) - 1ull;
+            const uint32_t c = fprev + (uint32_t)__popcll(un & below) + (uint32_t)__popcll(a0 & upto) + (uint32_t)__popcll(a1 & upto) +
+                               (uint32_t)__popcll(a2 & upto) + (uint32_t)__popcll(b0 & upto) + (uint32_t)__popcll(b1 & upto) +
+                               (uint32_t)__popcll(b2 & upto);
+            if (c >= s) hi = mid; else lo = mid + 1u;
+        }
+    } else {
+        const uint32_t wbase = w << 6;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            uint32_t c = fprev + (uint32_t)__popcll(un & ((1ull << mid) - 1ull));
+            for (uint32_t k = 0; k < na; k++) c += ((uint32_t)xa[ca0 + k] - wbase <= mid) ? 1u : 0u;
+            for (uint32_t k = 0; k < nb; k++) c += ((uint32_t)xb[cb0 + k] - wbase <= mid) ? 1u : 0u;
+            if (c >= s) hi = mid; else lo = mid + 1u;
+        }
+    }
+    return lo;
+}
+
 // The column block's words are read from global memory (L2) word by word, the next word requested before the current one
 // is worked on; only the rows' words sit in LDS.  (Staging the block in LDS was measured slower for every width: 26 KB per
 // two waves leave a CU a handful of waves, and the loop lives on having many -- C3 1.47 against 1.10 ms, one clade of
@@ -373,78 +408,72 @@ __global__ __launch_bounds__(128) void dn_pairs_kernel(const DenseTile *tiles, c
     const uint32_t b = G.g0 + T.cblk * 128u + tid;                         // this lane's column
     const uint16_t *xb = ext + (uint64_t)(G.xrow0 + (b < G.g1 ? b - G.g0 : 0u)) * xs;
     const unsigned long long *xmb = xm + (uint64_t)(G.xrow0 + (b < G.g1 ? b - G.g0 : 0u)) * wstride * 3ull;
-    for (uint32_t ai = 0; ai < DN_ROWS; ai++) {
-        const uint32_t a = T.row0 + ai;
-        if (a >= G.g1 || a >= row_end) break;                             // uniform
-        if (a < row_begin) continue;                                      // uniform
-        if (G.g0 + T.cblk * 128u >= a) continue;                          // uniform: for this row the whole block is at or above the diagonal
-        const bool valid = b < a;
-        const uint16_t *xa = ext + (uint64_t)(G.xrow0 + (a - G.g0)) * xs;
-        const unsigned long long *xma = xm + (uint64_t)(G.xrow0 + (a - G.g0)) * wstride * 3ull;
-        uint32_t pu = 0, common = 0, denom = 0;
-        bool done = !valid;
+    // DN_IL rows at a time: the column block's word is loaded once and serves all of them (their words are broadcast reads
+    // from LDS), and a wave has four independent pairs per lane in flight instead of one
+    for (uint32_t ai = 0; ai < DN_ROWS; ai += DN_IL) {
+        if (T.row0 + ai >= G.g1 || T.row0 + ai >= row_end) break;         // uniform
+        uint32_t pu[DN_IL], common[DN_IL], denom[DN_IL];
+        bool done[DN_IL], valid[DN_IL];
+#pragma unroll
+        for (uint32_t k = 0; k < DN_IL; k++) {
+            const uint32_t a = T.row0 + ai + k;
+            // (uniform: the row exists, belongs to the job, and the column block starts below it)
+            const bool present = a < G.g1 && a < row_end && a >= row_begin && G.g0 + T.cblk * 128u < a;
+            valid[k] = present && b < a;
+            done[k] = !valid[k];
+            pu[k] = common[k] = denom[k] = 0;
+        }
         unsigned long long mb_next = Bm[tid];
         uint32_t cb_next = Bcx[128u + tid], cb0r = Bcx[tid];
         for (uint32_t w = 0; w < W; w++) {
-            if (__ballot(!done) == 0) break;                              // uniform
-            const unsigned long long ma = Am[w * DN_ROWS + ai], mb = mb_next;
+            bool any = false;
+#pragma unroll
+            for (uint32_t k = 0; k < DN_IL; k++) any = any || !done[k];
+            if (__ballot(any) == 0) break;                                // uniform
+            const unsigned long long mb = mb_next;
             const uint32_t cb1r = cb_next;                                // (bit 15: the word's flag)
             if (w + 1u < W) {                                             // the next word is on its way while this one is worked on
                 mb_next = Bm[(w + 1u) * 128u + tid];
                 cb_next = Bcx[(w + 2u) * 128u + tid];
             }
-            const unsigned long long un = ma | mb, an = ma & mb;
-            const uint32_t pun = (uint32_t)__popcll(un);
-            const uint32_t ca1r = Acx[(w + 1u) * DN_ROWS + ai];
-            const uint32_t ca1 = ca1r & DN_CX_MASK, cb1 = cb1r & DN_CX_MASK;
-            const uint32_t F = pu + pun + ca1 + cb1;
-            if (!done) {
-                if (F <= s) {                                             // the whole word lies before the s-th union element
-                    common += (uint32_t)__popcll(an);
-                    pu += pun;
-                    if (F == s) { done = true; denom = s; }
-                } else {
-                    // s is reached inside this word: the smallest bit position t with f(t) >= s, f(t) = what lies before the
-                    // word + union bits below t + extras of either row with offset <= t; bits below it are counted
-                    const uint32_t ca0 = Acx[w * DN_ROWS + ai] & DN_CX_MASK, cb0 = cb0r & DN_CX_MASK;
-                    const uint32_t Fprev = pu + ca0 + cb0;
-                    uint32_t lo = 0, hi = 63;
-                    if (!use_lists && ((ca1r | cb1r) & DN_CX_FLAG) == 0) {
-                        // the extras of the word as three masks per row (bit o of mask j: at least j + 1 extras at offset o)
-                        const unsigned long long a0 = xma[3u * w], a1 = xma[3u * w + 1u], a2 = xma[3u * w + 2u];
-                        const unsigned long long b0 = xmb[3u * w], b1 = xmb[3u * w + 1u], b2 = xmb[3u * w + 2u];
-                        while (lo < hi) {
-                            const uint32_t mid = (lo + hi) >> 1;                  // <= 62
-                            const unsigned long long below = (1ull << mid) - 1ull, upto = (2ull << mid) - 1ull;
-                            const uint32_t c = Fprev + (uint32_t)__popcll(un & below) + (uint32_t)__popcll(a0 & upto) + (uint32_t)__popcll(a1 & upto) +
-                                               (uint32_t)__popcll(a2 & upto) + (uint32_t)__popcll(b0 & upto) + (uint32_t)__popcll(b1 & upto) +
-                                               (uint32_t)__popcll(b2 & upto);
-                            if (c >= s) hi = mid; else lo = mid + 1u;
-                        }
+            const uint32_t cb1 = cb1r & DN_CX_MASK;
+#pragma unroll
+            for (uint32_t k = 0; k < DN_IL; k++) {
+                const unsigned long long ma = Am[w * DN_ROWS + ai + k];
+                const unsigned long long un = ma | mb, an = ma & mb;
+                const uint32_t pun = (uint32_t)__popcll(un);
+                const uint32_t ca1r = Acx[(w + 1u) * DN_ROWS + ai + k];
+                const uint32_t F = pu[k] + pun + (ca1r & DN_CX_MASK) + cb1;
+                if (!done[k]) {
+                    if (F <= s) {                                         // the whole word lies before the s-th union element
+                        common[k] += (uint32_t)__popcll(an);
+                        pu[k] += pun;
+                        if (F == s) { done[k] = true; denom[k] = s; }
                     } else {
-                        // (a gap of this word holds four extras and more in one of the two rows: counted from the lists)
-                        const uint32_t na = ca1 - ca0, nb = cb1 - cb0, wbase = w << 6;
-                        while (lo < hi) {
-                            const uint32_t mid = (lo + hi) >> 1;
-                            uint32_t c = Fprev + (uint32_t)__popcll(un & ((1ull << mid) - 1ull));
-                            for (uint32_t k = 0; k < na; k++) c += ((uint32_t)xa[ca0 + k] - wbase <= mid) ? 1u : 0u;
-                            for (uint32_t k = 0; k < nb; k++) c += ((uint32_t)xb[cb0 + k] - wbase <= mid) ? 1u : 0u;
-                            if (c >= s) hi = mid; else lo = mid + 1u;
-                        }
+                        // s is reached inside this word
+                        const uint32_t a = T.row0 + ai + k;
+                        const uint32_t ca0 = Acx[w * DN_ROWS + ai + k] & DN_CX_MASK, cb0 = cb0r & DN_CX_MASK;
+                        const uint32_t T0 = dn_resolve(un, pu[k] + ca0 + cb0, s, w, use_lists || ((ca1r | cb1r) & DN_CX_FLAG) != 0,
+                                                       xm + (uint64_t)(G.xrow0 + (a - G.g0)) * wstride * 3ull, xmb,
+                                                       ext + (uint64_t)(G.xrow0 + (a - G.g0)) * xs, xb, ca0, (ca1r & DN_CX_MASK) - ca0, cb0, cb1 - cb0);
+                        common[k] += (uint32_t)__popcll(an & ((1ull << T0) - 1ull));
+                        done[k] = true;
+                        denom[k] = s;
                     }
-                    common += (uint32_t)__popcll(an & ((1ull << lo) - 1ull));
-                    done = true;
-                    denom = s;
                 }
             }
             cb0r = cb1r;
         }
-        if (valid) {
-            if (!done) {                                                  // the union ends before s (short sketches)
-                const uint32_t total = pu + (Acx[W * DN_ROWS + ai] & DN_CX_MASK) + (Bcx[W * 128u + tid] & DN_CX_MASK);
-                denom = total < s ? total : s;
+#pragma unroll
+        for (uint32_t k = 0; k < DN_IL; k++) {
+            if (valid[k]) {
+                const uint32_t a = T.row0 + ai + k;
+                if (!done[k]) {                                           // the union ends before s (short sketches)
+                    const uint32_t total = pu[k] + (Acx[W * DN_ROWS + ai + k] & DN_CX_MASK) + (Bcx[W * 128u + tid] & DN_CX_MASK);
+                    denom[k] = total < s ? total : s;
+                }
+                out[dn_out_index(a, b, inv, out_base)] = make_uint2(common[k], denom[k]);
             }
-            out[dn_out_index(a, b, inv, out_base)] = make_uint2(common, denom);
         }
     }
 }
