@@ -134,8 +134,11 @@ hipError_t sparse_build_index(const uint64_t *hashes, uint64_t stride, const uin
                               uint32_t rs, uint32_t end_bit, void *temp, size_t temp_bytes, uint64_t *keys_a,
                               uint32_t *idx_a, uint64_t *keys_sorted, uint32_t *idx_sorted, uint32_t *head, uint32_t *gs_of,
                               uint32_t *sorted_rows, uint32_t *gend, uint32_t *code_img, uint32_t *pos_img, void *stat_scratch,
-                              unsigned long long *incidences, uint32_t *max_group, uint32_t *groups, uint32_t *bad, hipStream_t stream);
+                              uint32_t begin_bit, void *tie_scratch, unsigned long long *incidences, uint32_t *max_group, uint32_t *groups,
+                              uint32_t *bad, uint32_t *tie_overflow, hipStream_t stream);
 size_t sparse_stat_scratch_bytes();
+uint32_t sparse_sort_begin_bit(uint32_t E, uint32_t end_bit);
+size_t sparse_tie_scratch_bytes();
 hipError_t launch_sparse_locate(const uint64_t *qhashes, uint64_t qstride, const uint32_t *qoff, uint32_t q_begin, uint32_t nq,
                                 const uint64_t *keys_sorted, const uint32_t *gend, uint32_t E, uint32_t rs, uint32_t *qlo_img,
                                 uint32_t *qhi_img, uint32_t *qcode_img, hipStream_t stream);

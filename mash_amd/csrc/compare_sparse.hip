@@ -67,16 +67,21 @@ __global__ __launch_bounds__(256) void sp_fill_entries_kernel(const uint64_t *ha
 
 // head[pos] = pos where a new value starts, else 0 (an inclusive max-scan then gives every position the start of
 // its group); inside a value the image indices must ascend (the sort is stable and they ascend with the row),
-// else *bad is set and the index is not used
+// and the values themselves must ascend, else *bad is set and the index is not used
 __global__ __launch_bounds__(256) void sp_heads_kernel(const uint64_t *keys, const uint32_t *idx, uint32_t E, uint32_t *head,
                                                        uint32_t *bad)
 {
     const uint32_t pos = blockIdx.x * 256u + threadIdx.x;
     if (pos >= E) return;
     uint32_t h = pos;
-    if (pos > 0 && keys[pos] == keys[pos - 1]) {
-        h = 0;
-        if (idx[pos] <= idx[pos - 1]) *bad = 1;
+    if (pos > 0) {
+        const uint64_t k = keys[pos], kp = keys[pos - 1];
+        if (k == kp) {
+            h = 0;
+            if (idx[pos] <= idx[pos - 1]) *bad = 1;
+        } else if (k < kp) {
+            *bad = 1;                                        // (not in order: a sort on leading bits whose ties were not all repaired)
+        }
     }
     head[pos] = h;
 }
@@ -334,15 +339,159 @@ struct sp_max_u32 {
     __device__ uint32_t operator()(const uint32_t &a, const uint32_t &b) const { return a > b ? a : b; }
 };
 
+uint32_t sparse_sort_begin_bit(uint32_t E, uint32_t end_bit);
+
 size_t sparse_sort_temp_bytes(uint32_t E, uint32_t end_bit)
 {
     size_t bytes = 0;
     rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr, (const uint32_t *)nullptr,
                               (uint32_t *)nullptr, (size_t)E, 0u, end_bit, (hipStream_t) nullptr);
+    size_t b1 = 0;                                           // (the sort on the leading bits only)
+    rocprim::radix_sort_pairs(nullptr, b1, (const uint64_t *)nullptr, (uint64_t *)nullptr, (const uint32_t *)nullptr,
+                              (uint32_t *)nullptr, (size_t)E, sparse_sort_begin_bit(E, end_bit), end_bit, (hipStream_t) nullptr);
+    bytes = bytes > b1 ? bytes : b1;
     size_t b2 = 0;
     rocprim::inclusive_scan(nullptr, b2, (const uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)E, sp_max_u32(), (hipStream_t) nullptr);
     return bytes > b2 ? bytes : b2;
 }
+
+// ---- fewer sort passes.  The values are hashes: 10^8 of them in a range of 2^54 need their top ~40 bits to be told apart,
+// so the radix sort runs over the bits [begin_bit, end_bit) only (5 passes of 8 bits instead of 7) and the few segments in
+// which two DIFFERENT values share all of those bits (expected: E^2 / 2^(bits + 1), a few thousand) are put in order
+// afterwards: sp_tie_find_kernel lists the breaks between two such values, sp_tie_segments_kernel (a wave per break; the
+// one at a segment's first break does the work) finds the segments' ends, sp_tie_repair_kernel (a wave per segment) rewrites
+// each by its full values, smallest value first, entries of one value in the order the sort left them (stable: rows ascend).  A table that defeats the assumption
+// (too many breaks, a segment too long to walk, more than 64 values in one) raises a flag and the caller builds the index
+// again with every bit sorted.
+constexpr uint32_t SP_TIE_WALK = 1024, SP_TIE_CAP = 1u << 16, SP_TIE_VALUES = 64;      // (walk: chunks of 64 entries)
+
+__global__ __launch_bounds__(256) void sp_tie_find_kernel(const uint64_t *keys, uint32_t E, uint32_t bb, uint32_t *breaks, uint32_t *nbreak,
+                                                          uint32_t *overflow)
+{
+    const uint32_t pos = blockIdx.x * 256u + threadIdx.x;
+    if (pos == 0 || pos >= E) return;
+    const uint64_t k = keys[pos], kp = keys[pos - 1];
+    if ((kp >> bb) != (k >> bb) || k == kp) return;        // not a break between two values of one prefix
+    const uint32_t slot = atomicAdd(nbreak, 1u);
+    if (slot >= SP_TIE_CAP) { *overflow = 1; return; }
+    breaks[slot] = pos;
+}
+
+// one wave per break: the wave at a segment's FIRST break finds the segment's ends and lists it (nothing is rewritten
+// while other waves still walk)
+__global__ __launch_bounds__(64) void sp_tie_segments_kernel(const uint64_t *keys, uint32_t E, uint32_t bb, const uint32_t *breaks,
+                                                             const uint32_t *nbreak, uint2 *segs, uint32_t *nseg, uint32_t *overflow)
+{
+    const uint32_t m = *nbreak < SP_TIE_CAP ? *nbreak : SP_TIE_CAP;
+    if (blockIdx.x >= m) return;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t pos = breaks[blockIdx.x];
+    const uint64_t kp = keys[pos - 1];
+    const uint64_t prefix = kp >> bb;
+    // left: over the entries that hold kp, to the segment's start; another value on the way = an earlier break, whose wave does the work
+    uint32_t s0 = 0;
+    {
+        uint32_t hi = pos - 1;                              // entries [.., hi) are still to look at
+        uint32_t chunks = 0;
+        for (;;) {
+            if (hi == 0) { s0 = 0; break; }
+            const bool in = lane < hi;
+            const uint64_t k = in ? keys[hi - 1u - lane] : 0;
+            const bool other_prefix = in && (k >> bb) != prefix;
+            const bool other_value = in && !other_prefix && k != kp;
+            const uint64_t stop = __ballot(other_prefix || other_value);
+            if (stop) {
+                const uint32_t first = (uint32_t)__builtin_ctzll(stop);
+                if ((__ballot(other_value) >> first) & 1ull) return;
+                s0 = hi - first;
+                break;
+            }
+            if (hi <= 64u) { s0 = 0; break; }
+            hi -= 64u;
+            if (++chunks > SP_TIE_WALK) { if (lane == 0) *overflow = 1; return; }
+        }
+    }
+    uint32_t s1 = E;
+    {
+        uint32_t lo = pos;
+        uint32_t chunks = 0;
+        for (;;) {
+            if (lo >= E) { s1 = E; break; }
+            const uint32_t q = lo + lane;
+            const bool out = q < E && (keys[q] >> bb) != prefix;
+            const uint64_t stop = __ballot(out);
+            if (stop) { s1 = lo + (uint32_t)__builtin_ctzll(stop); break; }
+            lo += 64u;
+            if (++chunks > SP_TIE_WALK) { if (lane == 0) *overflow = 1; return; }
+        }
+    }
+    if (lane == 0) segs[atomicAdd(nseg, 1u)] = make_uint2(s0, s1);      // (at most one per break)
+}
+
+// one wave per segment: rewritten by its full values
+__global__ __launch_bounds__(64) void sp_tie_repair_kernel(uint64_t *keys, uint32_t *idx, const uint2 *segs, const uint32_t *nseg, uint64_t *tk,
+                                                           uint32_t *ti, uint32_t *overflow)
+{
+    if (blockIdx.x >= *nseg) return;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t s0 = segs[blockIdx.x].x, s1 = segs[blockIdx.x].y;
+    // selection by value: smallest first, the entries of one value in the order the sort left them (stable)
+    uint32_t out = s0, rounds = 0;
+    bool have = false;
+    uint64_t last = 0;
+    while (out < s1) {
+        uint64_t best = ~0ull;
+        for (uint32_t q = s0 + lane; q < s1; q += 64u) {
+            const uint64_t k = keys[q];
+            if ((!have || k > last) && k < best) best = k;
+        }
+        for (uint32_t d = 32; d; d >>= 1) {
+            const uint64_t o = __shfl_xor(best, d, 64);
+            best = o < best ? o : best;
+        }
+        if (++rounds > SP_TIE_VALUES) { if (lane == 0) *overflow = 1; return; }      // (nothing written back: the caller sorts every bit)
+        for (uint32_t base = s0; base < s1; base += 64u) {
+            const uint32_t q = base + lane;
+            const bool hit = q < s1 && keys[q] == best;
+            const uint64_t bal = __ballot(hit);
+            if (hit) {
+                const uint32_t w = out + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                tk[w] = best;
+                ti[w] = idx[q];
+            }
+            out += (uint32_t)__popcll(bal);
+        }
+        last = best;
+        have = true;
+    }
+    __threadfence();
+    for (uint32_t q = s0 + lane; q < s1; q += 64u) {
+        keys[q] = __hip_atomic_load(&tk[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        idx[q] = __hip_atomic_load(&ti[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// bits the sort looks at: enough that two different values rarely agree in all of them
+uint32_t sparse_sort_begin_bit(uint32_t E, uint32_t end_bit)
+{
+    // (end_bit 64: rocprim's path for small inputs builds its bit mask with a shift by 64 and returns garbage -- seen on
+    // 1155 entries, bits [48, 64); values that reach the top bit are rare and the gain is one pass, so every bit is sorted)
+    if (getenv("MASHGPU_SPARSE_SORT_ALL_BITS") || end_bit >= 64u) return 0;
+    const char *forced = getenv("MASHGPU_SPARSE_SORT_BITS");        // (test knob: few bits, many ties)
+    if (!forced && E < (1u << 22)) return 0;                         // (small tables: nothing to gain)
+    uint32_t lg = 0;
+    while ((1ull << lg) < (uint64_t)E) lg++;
+    const uint32_t want = 2u * lg > 29u ? 2u * lg - 13u : 16u;      // expected ties E^2 / 2^(bits + 1) = 2^12
+    uint32_t passes = (want + 7u) / 8u;                              // whole passes of 8 bits; one less if that costs two bits at most
+    if (passes > 1u && want - (passes - 1u) * 8u <= 2u) passes--;
+    uint32_t bits = passes * 8u;
+    if (forced) bits = (uint32_t)atoi(forced);
+    if (bits < 8u) bits = 8u;
+    if (bits + 8u > end_bit) return 0;                               // (less than a pass to gain)
+    return end_bit - bits;
+}
+
+size_t sparse_tie_scratch_bytes() { return (size_t)SP_TIE_CAP * (sizeof(uint32_t) + sizeof(uint2)) + 16; }
 
 // All device buffers are the caller's.  keys_a / idx_a: scratch of E entries each (input of the sort),
 // keys_sorted / idx_sorted: its output; head: scratch of E u32 (may be idx_a), gs_of: scratch of E u32.  On return
@@ -352,16 +501,32 @@ hipError_t sparse_build_index(const uint64_t *hashes, uint64_t stride, const uin
                               uint32_t rs, uint32_t end_bit, void *temp, size_t temp_bytes, uint64_t *keys_a,
                               uint32_t *idx_a, uint64_t *keys_sorted, uint32_t *idx_sorted, uint32_t *head, uint32_t *gs_of,
                               uint32_t *sorted_rows, uint32_t *gend, uint32_t *code_img, uint32_t *pos_img, void *stat_scratch,
-                              unsigned long long *incidences, uint32_t *max_group, uint32_t *groups, uint32_t *bad, hipStream_t stream)
+                              uint32_t begin_bit, void *tie_scratch, unsigned long long *incidences, uint32_t *max_group, uint32_t *groups,
+                              uint32_t *bad, uint32_t *tie_overflow, hipStream_t stream)
 {
     if (n == 0 || E == 0) return hipSuccess;
     hipLaunchKernelGGL(sp_fill_entries_kernel, dim3(n), dim3(256), 0, stream, hashes, stride, off, rs, keys_a, idx_a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     e = rocprim::radix_sort_pairs(temp, temp_bytes, (const uint64_t *)keys_a, keys_sorted, (const uint32_t *)idx_a, idx_sorted,
-                                  (size_t)E, 0u, end_bit, stream);
+                                  (size_t)E, begin_bit, end_bit, stream);
     if (e != hipSuccess) return e;
     const uint32_t blocks = (E + 255u) / 256u;
+    if (begin_bit > 0) {
+        // values that agree in every sorted bit: found, and put in order by their full values (keys_a / idx_a, the sort's input, are scratch now)
+        uint2 *segs = static_cast<uint2 *>(tie_scratch);
+        uint32_t *breaks = reinterpret_cast<uint32_t *>(segs + SP_TIE_CAP);
+        uint32_t *nbreak = breaks + SP_TIE_CAP, *nseg = nbreak + 1;
+        e = hipMemsetAsync(nbreak, 0, 8, stream);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(sp_tie_find_kernel, dim3(blocks), dim3(256), 0, stream, (const uint64_t *)keys_sorted, E, begin_bit, breaks, nbreak, tie_overflow);
+        hipLaunchKernelGGL(sp_tie_segments_kernel, dim3(SP_TIE_CAP), dim3(64), 0, stream, (const uint64_t *)keys_sorted, E, begin_bit,
+                           (const uint32_t *)breaks, (const uint32_t *)nbreak, segs, nseg, tie_overflow);
+        hipLaunchKernelGGL(sp_tie_repair_kernel, dim3(SP_TIE_CAP), dim3(64), 0, stream, keys_sorted, idx_sorted, (const uint2 *)segs,
+                           (const uint32_t *)nseg, keys_a, idx_a, tie_overflow);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(sp_heads_kernel, dim3(blocks), dim3(256), 0, stream, keys_sorted, idx_sorted, E, head, bad);
     e = hipGetLastError();
     if (e != hipSuccess) return e;

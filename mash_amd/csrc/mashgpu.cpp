@@ -2260,13 +2260,13 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
     DevBuf<uint64_t> keys_a(ctx);
     DevBuf<uint32_t> idx_a(ctx), idx_sorted(ctx), gs_of(ctx);
     DevBuf<unsigned long long> key64_a(ctx), key64_b(ctx);
-    struct Stat { unsigned long long shared; uint32_t max_group, groups, bad, pad; } h_stat = {0, 0, 0, 0, 0};
+    struct Stat { unsigned long long shared; uint32_t max_group, groups, bad, tie_overflow; } h_stat = {0, 0, 0, 0, 0};
     DevBuf<Stat> d_stat(ctx);
-    DevBuf<unsigned char> d_slots(ctx);
+    DevBuf<unsigned char> d_slots(ctx), d_ties(ctx);
     const bool want_order = !getenv("MASHGPU_SPARSE_NO_ORDER");
     bool ok = temp.alloc(std::max<size_t>(temp_bytes, 16)) == hipSuccess && keys_a.alloc(E) == hipSuccess && idx_a.alloc(E) == hipSuccess &&
               idx_sorted.alloc(E) == hipSuccess && gs_of.alloc(E) == hipSuccess && d_stat.alloc(1) == hipSuccess &&
-              d_slots.alloc(mg::sparse_stat_scratch_bytes()) == hipSuccess &&
+              d_slots.alloc(mg::sparse_stat_scratch_bytes()) == hipSuccess && d_ties.alloc(mg::sparse_tie_scratch_bytes()) == hipSuccess &&
               (!want_order || (key64_a.alloc(n) == hipSuccess && key64_b.alloc(n) == hipSuccess));
     // retained buffers
     auto take = [&](auto **p, size_t count) {
@@ -2297,17 +2297,22 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
         e = hipMemcpyAsync(sp->off, sp->off_host.data(), (n + 1) * 4, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess && nshort) e = hipMemcpyAsync(sp->short_rows, sp->short_rows_host.data(), nshort * 4, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess && nshort) e = hipMemcpyAsync(sp->short_cnt, short_cnt.data(), nshort * 4, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipMemsetAsync(d_stat, 0, sizeof(Stat), ctx->stream);
-        if (e == hipSuccess)
-            e = mg::sparse_build_index(H, t->s, sp->off, (uint32_t)n, E, sp->rs, end_bit, temp, temp_bytes, keys_a, idx_a,
-                                       sp->keys_sorted, idx_sorted, /*head=*/idx_a, gs_of, sp->sorted_rows, sp->gend, sp->code_img, sp->pos_img,
-                                       d_slots, &d_stat.p->shared, &d_stat.p->max_group, &d_stat.p->groups, &d_stat.p->bad, ctx->stream);
-        // visiting order of the rows: by the run of their first shared value, larger rows first inside a run
-        if (e == hipSuccess && want_order)
-            e = mg::launch_sparse_row_order(sp->off, sp->code_img, sp->gend, sp->rep, (uint32_t)n, sp->rs, temp, temp_bytes, key64_a, key64_b,
-                                            sp->order, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(&h_stat, d_stat, sizeof(Stat), hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        // (the sort looks at the values' leading bits only and repairs the few ties; a table that defeats that is sorted again, on every bit)
+        for (uint32_t begin_bit = mg::sparse_sort_begin_bit(E, end_bit);; begin_bit = 0) {
+            if (e == hipSuccess) e = hipMemsetAsync(d_stat, 0, sizeof(Stat), ctx->stream);
+            if (e == hipSuccess)
+                e = mg::sparse_build_index(H, t->s, sp->off, (uint32_t)n, E, sp->rs, end_bit, temp, temp_bytes, keys_a, idx_a,
+                                           sp->keys_sorted, idx_sorted, /*head=*/idx_a, gs_of, sp->sorted_rows, sp->gend, sp->code_img, sp->pos_img,
+                                           d_slots, begin_bit, d_ties, &d_stat.p->shared, &d_stat.p->max_group, &d_stat.p->groups, &d_stat.p->bad,
+                                           &d_stat.p->tie_overflow, ctx->stream);
+            // visiting order of the rows: by the run of their first shared value, larger rows first inside a run
+            if (e == hipSuccess && want_order)
+                e = mg::launch_sparse_row_order(sp->off, sp->code_img, sp->gend, sp->rep, (uint32_t)n, sp->rs, temp, temp_bytes, key64_a, key64_b,
+                                                sp->order, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(&h_stat, d_stat, sizeof(Stat), hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess || !h_stat.tie_overflow || begin_bit == 0) break;
+        }
     }
     auto drop = [&]() {
         for (void **q : {(void **)&sp->off, (void **)&sp->keys_sorted, (void **)&sp->gend, (void **)&sp->sorted_rows, (void **)&sp->code_img,

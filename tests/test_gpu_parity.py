@@ -791,6 +791,44 @@ def test_compare_dense_groups(eng, oracle, s, sizes, kw, monkeypatch):
     t.free()
 
 
+@pytest.mark.parametrize("bits", [9, 20, 26, 34])
+@pytest.mark.parametrize("s,sizes,kw", [
+    (1000, (40, 9, 130), dict()),
+    (100, (33, 150, 8), dict(clump=True, short_every=5)),           # values packed into one gap: long segments of one prefix
+    (200, (60, 45), dict(shuffle=True, gap_rows=400)),              # mostly unrelated rows
+])
+def test_compare_sparse_index_sorted_on_leading_bits(eng, oracle, bits, s, sizes, kw, monkeypatch):
+    """The index sorts the values on their leading bits only and repairs the segments in which different values agree
+    in all of them (sp_tie_find_kernel / sp_tie_repair_kernel).  Forced down to a few bits: many ties, long segments,
+    segments of more than 64 values (the build is then repeated on every bit) -- the same bytes as the oracle and as the
+    index sorted on every bit."""
+    rng = np.random.default_rng(bits * 1000 + s)
+    kw = dict(kw)
+    shuffle = kw.pop("shuffle", False)
+    table, nhash = _clade_table(rng, sizes, s, **kw)
+    if shuffle:
+        perm = rng.permutation(len(nhash))
+        table, nhash = table[perm].copy(), nhash[perm].copy()
+    n = len(nhash)
+    lengths = np.full(n, 10 ** 6, dtype=np.uint64)
+    numer, denom = _oracle_tri(oracle, table, nhash, lengths, 0, n)
+    monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", "sparse")
+    monkeypatch.setenv("MASHGPU_SPARSE_SORT_BITS", str(bits))
+    t = eng.table_upload(table, nhash, lengths)
+    got = eng.compare_tri_host(t)
+    assert np.array_equal(got["numer"], numer) and np.array_equal(got["denom"], denom)
+    rb, re = n // 4, n - 3
+    part = eng.compare_tri_host(t, rb, re)
+    lo, hi = rb * (rb - 1) // 2, re * (re - 1) // 2
+    assert np.array_equal(part["numer"], numer[lo:hi]) and np.array_equal(part["denom"], denom[lo:hi])
+    t.free()
+    monkeypatch.delenv("MASHGPU_SPARSE_SORT_BITS")
+    monkeypatch.setenv("MASHGPU_SPARSE_SORT_ALL_BITS", "1")
+    t = eng.table_upload(table, nhash, lengths)
+    assert eng.compare_tri_host(t).tobytes() == got.tobytes()
+    t.free()
+
+
 def test_table_invalidate_after_the_buffers_changed(eng, oracle, monkeypatch):
     """mg_table_invalidate: a wrapped table whose buffers were refilled is answered from the NEW contents -- index, plans,
     classes of copies, short rows all rebuilt (first table: clusters; second: other values, some rows short, some
