@@ -138,6 +138,37 @@ int mg_sketch_dev(mg_ctx *ctx, const mg_params *p,
                   const uint64_t *sketch_off_host, uint64_t nsketch,
                   uint64_t *hashes_out_dev, uint32_t *nhash_out_dev, uint32_t *counts_out_dev);
 
+/* Packed nucleotide input (BASELINE.json north_star: "packed bases"): the same call as mg_sketch_host / mg_sketch_dev
+ * for the ACGT alphabet, with the bases handed over at 3 bits each instead of 8.
+ *
+ *   packed[(nbases + 3) / 4]        two bits per base, base i in bits 2 (i % 4) .. of byte i / 4,
+ *                                   code = (ASCII >> 1) & 3:  A 0, C 1, T 2, G 3 (either case)
+ *   invalid_mask[(nbases + 7) / 8]  bit i % 8 of byte i / 8 set: base i is none of ACGT (N, IUPAC codes,
+ *                                   MG_RECORD_SEP between two records, lower case under preserve_case); its code
+ *                                   bits mean nothing.  NULL: no such base in the whole input.
+ *
+ * That is all addMinHashes reads of a nucleotide sequence (Sketch.cpp:512-583: upper-cased unless preserveCase, a
+ * k-mer over a character outside the alphabet is skipped, the hash runs over the k-mer's characters), so the
+ * results are those of mg_sketch_host on the unpacked bytes -- same hashes, same counts.  sketch_off[] counts
+ * BASES, as there, and need not be multiples of four.  MG_ERR_UNSUPPORTED for other alphabets.
+ *
+ * mg_pack_bases is the host side (what a parse thread runs over the bytes kseq hands it, kseq.h:171-208): no
+ * context, no device, thread-safe; disjoint ranges whose starts are multiples of 8 bases can be packed by
+ * different threads into the same arrays.  *ninvalid_out (nullable) = bits set in the mask.
+ * mg_sketch_host_packed copies the input to the device in pieces of whole sketches while the previous piece is
+ * being sketched; mg_sketch_dev_packed takes packed input that already is in device memory (16-byte aligned,
+ * readable 8 bytes past the end of both arrays). */
+uint64_t mg_packed_bytes(uint64_t nbases);
+uint64_t mg_packed_mask_bytes(uint64_t nbases);
+int mg_pack_bases(const uint8_t *ascii, uint64_t nbases, int preserve_case, uint8_t *packed, uint8_t *invalid_mask,
+                  uint64_t *ninvalid_out);
+int mg_sketch_host_packed(mg_ctx *ctx, const mg_params *p, const uint8_t *packed, const uint8_t *invalid_mask,
+                          uint64_t nbases, const uint64_t *sketch_off, uint64_t nsketch,
+                          uint64_t *hashes_out, uint32_t *nhash_out, uint32_t *counts_out);
+int mg_sketch_dev_packed(mg_ctx *ctx, const mg_params *p, const uint8_t *packed_dev, const uint8_t *invalid_mask_dev,
+                         uint64_t nbases, const uint64_t *sketch_off_host, uint64_t nsketch,
+                         uint64_t *hashes_out_dev, uint32_t *nhash_out_dev, uint32_t *counts_out_dev);
+
 /* Streamed ingest (replaces the reader side of sketchFile's overlap of parsing and sketching,
  * ThreadPool.hxx:127-167 + kseq.h:171-208 feeding addMinHashes): the caller hands over bytes as it
  * parses them -- no concatenated batch on the host.  mg_sketch_add appends to the CURRENT sketch's

@@ -22,7 +22,8 @@ RECORD_SEP = 0x0A
 
 EXPORTS = [
     "mg_device_count", "mg_ctx_create", "mg_ctx_destroy", "mg_last_error", "mg_ctx_set_stream", "mg_ctx_synchronize", "mg_ctx_set_async", "mg_ctx_trim",
-    "mg_ctx_cu_count", "mg_params_init", "mg_sketch_host", "mg_sketch_dev", "mg_sketch_reads_host", "mg_sketch_begin", "mg_sketch_add",
+    "mg_ctx_cu_count", "mg_params_init", "mg_sketch_host", "mg_sketch_dev", "mg_packed_bytes", "mg_packed_mask_bytes", "mg_pack_bases",
+    "mg_sketch_host_packed", "mg_sketch_dev_packed", "mg_sketch_reads_host", "mg_sketch_begin", "mg_sketch_add",
     "mg_sketch_stage_capacity", "mg_sketch_stage", "mg_sketch_commit", "mg_sketch_end_sketch", "mg_sketch_pending", "mg_sketch_finish", "mg_sketch_session_free",
     "mg_reads_begin", "mg_reads_add_host", "mg_reads_finish", "mg_reads_reset", "mg_reads_free", "mg_table_upload",
     "mg_table_wrap_dev", "mg_table_free", "mg_table_invalidate", "mg_table_rows", "mg_table_sketch_size",
@@ -184,6 +185,13 @@ def load_library():
     lib.mg_params_init.argtypes = [C.POINTER(MgParams), i32, u64, u32, C.c_char_p, i32, i32]
     lib.mg_sketch_host.argtypes = [vp, C.POINTER(MgParams), vp, u64, vp, u64, vp, vp, vp]
     lib.mg_sketch_dev.argtypes = [vp, C.POINTER(MgParams), vp, u64, vp, u64, vp, vp, vp]
+    lib.mg_packed_bytes.argtypes = [u64]
+    lib.mg_packed_bytes.restype = u64
+    lib.mg_packed_mask_bytes.argtypes = [u64]
+    lib.mg_packed_mask_bytes.restype = u64
+    lib.mg_pack_bases.argtypes = [vp, u64, i32, vp, vp, C.POINTER(u64)]
+    lib.mg_sketch_host_packed.argtypes = [vp, C.POINTER(MgParams), vp, vp, u64, vp, u64, vp, vp, vp]
+    lib.mg_sketch_dev_packed.argtypes = [vp, C.POINTER(MgParams), vp, vp, u64, vp, u64, vp, vp, vp]
     lib.mg_sketch_reads_host.argtypes = [vp, C.POINTER(MgParams), vp, u64, vp, vp, vp, vp]
     lib.mg_sketch_begin.argtypes = [vp, C.POINTER(MgParams), C.POINTER(vp)]
     lib.mg_sketch_add.argtypes = [vp, vp, u64]
@@ -529,6 +537,34 @@ class RankComm:
         self._check(self.lib.mg_comm_allreduce_u32_sum(self.h, ptr, count))
 
 
+def pack_bases(bases, preserve_case=False, lib=None, threads=1):
+    """mg_pack_bases (host only: no context, no GPU): bases u8[n] -> (packed u8[(n + 3) / 4], invalid_mask u8[(n + 7) / 8],
+    number of invalid bases).  threads > 1: disjoint ranges (starts multiples of 8) packed side by side."""
+    lib = lib or load_library()
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    n = len(bases)
+    packed = np.zeros(int(lib.mg_packed_bytes(n)) + 16, dtype=np.uint8)[: int(lib.mg_packed_bytes(n))]
+    mask = np.zeros(int(lib.mg_packed_mask_bytes(n)) + 16, dtype=np.uint8)[: int(lib.mg_packed_mask_bytes(n))]
+    if threads <= 1 or n < (1 << 20):
+        ninv = C.c_uint64(0)
+        rc = lib.mg_pack_bases(bases.ctypes.data, n, 1 if preserve_case else 0, packed.ctypes.data, mask.ctypes.data, C.byref(ninv))
+        if rc != MG_OK:
+            raise MashGpuError(f"mg_pack_bases: {rc}")
+        return packed, mask, int(ninv.value)
+    from concurrent.futures import ThreadPoolExecutor
+    step = ((n + threads - 1) // threads + 7) & ~7
+    def one(b0):
+        b1 = min(n, b0 + step)
+        c = C.c_uint64(0)
+        rc = lib.mg_pack_bases(bases.ctypes.data + b0, b1 - b0, 1 if preserve_case else 0, packed.ctypes.data + b0 // 4, mask.ctypes.data + b0 // 8, C.byref(c))
+        if rc != MG_OK:
+            raise MashGpuError(f"mg_pack_bases: {rc}")
+        return int(c.value)
+    with ThreadPoolExecutor(threads) as ex:
+        ninv = sum(ex.map(one, range(0, n, step)))
+    return packed, mask, ninv
+
+
 class MashGpu:
     """One context = one process + one GPU (mg_ctx)."""
 
@@ -586,6 +622,26 @@ class MashGpu:
                                             off.ctypes.data, n, hashes.ctypes.data, nhash.ctypes.data,
                                             cnt.ctypes.data if counts else None))
         return (hashes, nhash, cnt) if counts else (hashes, nhash)
+
+    def sketch_host_packed_raw(self, packed, mask, nbases, off, p, counts=False):
+        """mg_sketch_host_packed: packed u8[(nbases + 3) / 4], mask u8[(nbases + 7) / 8] or None, off u64[n + 1] in bases"""
+        n = len(off) - 1
+        s = int(p.sketch_size)
+        packed = np.ascontiguousarray(packed, dtype=np.uint8)
+        mask = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        hashes = np.zeros((n, s), dtype=np.uint64)
+        nhash = np.zeros(n, dtype=np.uint32)
+        cnt = np.zeros((n, s), dtype=np.uint32) if counts else None
+        self._check(self.lib.mg_sketch_host_packed(self.ctx, C.byref(p), packed.ctypes.data, None if mask is None else mask.ctypes.data,
+                                                   nbases, off.ctypes.data, n, hashes.ctypes.data, nhash.ctypes.data,
+                                                   cnt.ctypes.data if counts else None))
+        return (hashes, nhash, cnt) if counts else (hashes, nhash)
+
+    def sketch_dev_packed(self, packed_ptr, mask_ptr, nbases, off, p, hashes_ptr, nhash_ptr):
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        self._check(self.lib.mg_sketch_dev_packed(self.ctx, C.byref(p), packed_ptr, mask_ptr, nbases, off.ctypes.data,
+                                                  len(off) - 1, hashes_ptr, nhash_ptr, None))
 
     def sketch_stream(self, sketches, p, counts=False, piece=None, windows=False):
         """same result as sketch_host, through a session: bytes handed over piece by piece -- copied by

@@ -875,8 +875,11 @@ static int sketch_dev_impl(mg_ctx *ctx, const mg_params *p, const uint8_t *bases
     // outputs default to "empty sketch"
     HIP_TRY(ctx, hipMemsetAsync(hashes_out_dev, 0xFF, nsketch * s * 8, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(nhash_out_dev, 0, nsketch * 4, ctx->stream));
-    if (plan.work.empty()) return MG_OK;
     if (counts_out_dev) HIP_TRY(ctx, hipMemsetAsync(counts_out_dev, 0, nsketch * s * 4, ctx->stream));
+    if (plan.work.empty()) {                               // (nothing long enough to hold a k-mer: empty sketches, complete on return)
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return MG_OK;
+    }
 
     HIP_TRY(ctx, run.d_work.alloc(plan.work.size()));
     HIP_TRY(ctx, hipMemcpyAsync(run.d_work, plan.work.data(), plan.work.size() * sizeof(mg::SketchWork), hipMemcpyHostToDevice, ctx->stream));
@@ -967,6 +970,132 @@ int mg_sketch_host(mg_ctx *ctx, const mg_params *p, const uint8_t *bases, uint64
         hipMemcpyAsync(nhash_out, d_nhash, nsketch * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
         hipStreamSynchronize(ctx->stream) != hipSuccess)
         return fail(ctx, MG_ERR_HIP, "mg_sketch_host: D2H copy failed");
+    return MG_OK;
+}
+
+/* ------------------------------------------------- packed nucleotide input (ingest.hip, pack_bases.cpp) */
+
+// One implementation behind mg_sketch_host_packed / mg_sketch_dev_packed: the sketches are taken in pieces of whole
+// sketches (about 2^28 bases each); a piece's packed range is turned back into the bytes of the ASCII path
+// (launch_unpack_bases) and handed to the ordinary sketch path.  Host input: the NEXT piece crosses PCIe on a
+// stream of its own (a helper thread issues and awaits the copy) while this one is sketched.
+static int sketch_packed_impl(mg_ctx *ctx, const mg_params *p, const uint8_t *packed, const uint8_t *mask, bool host_input,
+                              uint64_t nbases, const uint64_t *sketch_off, uint64_t nsketch, uint64_t *d_hashes, uint32_t *d_nhash,
+                              uint32_t *d_counts)
+{
+    const uint64_t s = p->sketch_size;
+    uint64_t cap = 1ull << 28;
+    if (const char *e = getenv("MASHGPU_PACKED_PIECE")) cap = std::max<uint64_t>(strtoull(e, nullptr, 10), 1);      // (test knob)
+    for (uint64_t i = 0; i < nsketch; i++)
+        if (sketch_off[i] > sketch_off[i + 1] || sketch_off[i + 1] > nbases) return fail(ctx, MG_ERR_INVALID, "mg_sketch_packed: sketch_off must ascend and end within nbases");
+    struct Piece { uint64_t i0, i1, b0, b1; };
+    std::vector<Piece> pieces;
+    uint64_t longest = 0;
+    for (uint64_t i0 = 0; i0 < nsketch;) {
+        uint64_t i1 = i0 + 1;
+        while (i1 < nsketch && sketch_off[i1 + 1] - sketch_off[i0] <= cap && i1 - i0 < (1ull << 24)) i1++;
+        pieces.push_back({i0, i1, sketch_off[i0], sketch_off[i1]});
+        longest = std::max(longest, sketch_off[i1] - sketch_off[i0]);
+        i0 = i1;
+    }
+    DevBuf<uint8_t> d_ascii(ctx), d_pk[2] = {DevBuf<uint8_t>(ctx), DevBuf<uint8_t>(ctx)}, d_mk[2] = {DevBuf<uint8_t>(ctx), DevBuf<uint8_t>(ctx)};
+    if (d_ascii.alloc(((longest + 15u) & ~15ull) + 64u) != hipSuccess) return fail(ctx, MG_ERR_NOMEM, "mg_sketch_packed: device allocation failed");
+    hipStream_t copy_stream = nullptr;
+    struct StreamGuard { hipStream_t *s; ~StreamGuard() { if (*s) hipStreamDestroy(*s); } } stream_guard{&copy_stream};
+    if (host_input) {
+        for (int k = 0; k < 2; k++)
+            if (d_pk[k].alloc(longest / 4u + 32u) != hipSuccess || (mask && d_mk[k].alloc(longest / 8u + 32u) != hipSuccess))
+                return fail(ctx, MG_ERR_NOMEM, "mg_sketch_packed: device allocation failed");
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+    }
+    // the piece's ranges in the two arrays, cut at 4-byte boundaries (the kernel's loads are dwords)
+    auto pk_byte0 = [](const Piece &q) { return (q.b0 / 4u) & ~3ull; };
+    auto mk_byte0 = [](const Piece &q) { return (q.b0 / 8u) & ~3ull; };
+    const int device = ctx->device;
+    auto copy_piece = [&, device](const Piece &q, int slot, hipError_t *err) {
+        *err = hipSetDevice(device);
+        const uint64_t pb0 = pk_byte0(q), pb1 = (q.b1 + 3u) / 4u, mb0 = mk_byte0(q), mb1 = (q.b1 + 7u) / 8u;
+        if (*err == hipSuccess && pb1 > pb0) *err = hipMemcpyAsync(d_pk[slot], packed + pb0, pb1 - pb0, hipMemcpyHostToDevice, copy_stream);
+        if (*err == hipSuccess && mask && mb1 > mb0) *err = hipMemcpyAsync(d_mk[slot], mask + mb0, mb1 - mb0, hipMemcpyHostToDevice, copy_stream);
+        if (*err == hipSuccess) *err = hipStreamSynchronize(copy_stream);
+    };
+    hipError_t copy_err = hipSuccess;
+    if (host_input && !pieces.empty()) copy_piece(pieces[0], 0, &copy_err);
+    std::vector<uint64_t> off;
+    for (size_t c = 0; c < pieces.size(); c++) {
+        const Piece &q = pieces[c];
+        if (copy_err != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("mg_sketch_packed: H2D copy failed: ") + hipGetErrorString(copy_err));
+        std::thread next;
+        hipError_t next_err = hipSuccess;
+        if (host_input && c + 1 < pieces.size()) next = std::thread(copy_piece, std::cref(pieces[c + 1]), (int)((c + 1) & 1), &next_err);
+        struct Join { std::thread &t; ~Join() { if (t.joinable()) t.join(); } } join{next};
+        const uint64_t len = q.b1 - q.b0;
+        const uint8_t *src_pk, *src_mk;
+        uint32_t skip, mskip;
+        if (host_input) {
+            src_pk = d_pk[c & 1];
+            src_mk = mask ? d_mk[c & 1].p : nullptr;
+            skip = (uint32_t)(q.b0 - pk_byte0(q) * 4u);
+            mskip = (uint32_t)(q.b0 - mk_byte0(q) * 8u);
+        } else {
+            src_pk = packed + pk_byte0(q);
+            src_mk = mask ? mask + mk_byte0(q) : nullptr;
+            skip = (uint32_t)(q.b0 - pk_byte0(q) * 4u);
+            mskip = (uint32_t)(q.b0 - mk_byte0(q) * 8u);
+        }
+        HIP_TRY(ctx, mg::launch_unpack_bases(src_pk, src_mk, skip, mskip, len, d_ascii, ctx->stream));
+        off.resize(q.i1 - q.i0 + 1);
+        for (uint64_t i = q.i0; i <= q.i1; i++) off[i - q.i0] = sketch_off[i] - q.b0;
+        const int rc = sketch_dev_impl(ctx, p, d_ascii, len, off.data(), q.i1 - q.i0, d_hashes + q.i0 * s, d_nhash + q.i0,
+                                       d_counts ? d_counts + q.i0 * s : nullptr, nullptr);
+        if (rc != MG_OK) return rc;
+        if (next.joinable()) next.join();
+        copy_err = next_err;
+    }
+    return MG_OK;
+}
+
+static int sketch_packed_check(mg_ctx *ctx, const mg_params *p, const void *packed, uint64_t nbases, const uint64_t *sketch_off,
+                               const void *hashes_out, const void *nhash_out)
+{
+    if (!p || !sketch_off || !hashes_out || !nhash_out || (!packed && nbases)) return fail(ctx, MG_ERR_INVALID, "mg_sketch_packed: NULL argument");
+    if (!alphabet_is_dna(p)) return fail(ctx, MG_ERR_UNSUPPORTED, "mg_sketch_packed: packed input is defined for the ACGT alphabet only");
+    return MG_OK;
+}
+
+int mg_sketch_dev_packed(mg_ctx *ctx, const mg_params *p, const uint8_t *packed_dev, const uint8_t *invalid_mask_dev, uint64_t nbases,
+                         const uint64_t *sketch_off_host, uint64_t nsketch, uint64_t *hashes_out_dev, uint32_t *nhash_out_dev,
+                         uint32_t *counts_out_dev)
+{
+    if (!ctx) return MG_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    int rc = sketch_packed_check(ctx, p, packed_dev, nbases, sketch_off_host, hashes_out_dev, nhash_out_dev);
+    if (rc != MG_OK || nsketch == 0) return rc;
+    if (((uintptr_t)packed_dev & 15u) || ((uintptr_t)invalid_mask_dev & 15u)) return fail(ctx, MG_ERR_INVALID, "mg_sketch_dev_packed: arrays must be 16-byte aligned");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return sketch_packed_impl(ctx, p, packed_dev, invalid_mask_dev, false, nbases, sketch_off_host, nsketch, hashes_out_dev, nhash_out_dev, counts_out_dev);
+}
+
+int mg_sketch_host_packed(mg_ctx *ctx, const mg_params *p, const uint8_t *packed, const uint8_t *invalid_mask, uint64_t nbases,
+                          const uint64_t *sketch_off, uint64_t nsketch, uint64_t *hashes_out, uint32_t *nhash_out, uint32_t *counts_out)
+{
+    if (!ctx) return MG_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    int rc = sketch_packed_check(ctx, p, packed, nbases, sketch_off, hashes_out, nhash_out);
+    if (rc != MG_OK || nsketch == 0) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint64_t s = p->sketch_size;
+    DevBuf<uint64_t> d_hashes(ctx);
+    DevBuf<uint32_t> d_nhash(ctx), d_counts(ctx);
+    if ((counts_out && d_counts.alloc(nsketch * s) != hipSuccess) || d_hashes.alloc(nsketch * s) != hipSuccess || d_nhash.alloc(nsketch) != hipSuccess)
+        return fail(ctx, MG_ERR_NOMEM, "mg_sketch_host_packed: device allocation failed");
+    rc = sketch_packed_impl(ctx, p, packed, invalid_mask, true, nbases, sketch_off, nsketch, d_hashes, d_nhash, d_counts);
+    if (rc != MG_OK) return rc;
+    if ((counts_out && hipMemcpyAsync(counts_out, d_counts, nsketch * s * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) ||
+        hipMemcpyAsync(hashes_out, d_hashes, nsketch * s * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(nhash_out, d_nhash, nsketch * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess)
+        return fail(ctx, MG_ERR_HIP, "mg_sketch_host_packed: D2H copy failed");
     return MG_OK;
 }
 

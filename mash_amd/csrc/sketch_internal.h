@@ -142,4 +142,11 @@ hipError_t launch_count_tstar(const uint32_t *nhash, uint32_t *counts, const uns
                               unsigned long long *tstar, uint32_t *need_fix, uint32_t nsketch, uint32_t s,
                               hipStream_t stream);
 
+// ingest.hip: a range of the packed transport format (two bits per base + one invalid bit per base) back to the bytes the
+// ASCII path is handed: out[j], j < n = base skip + j of `packed` (skip < 16), invalid bit mskip + j of `mask` (mskip < 32;
+// nullptr: none set).  packed / mask 4-byte aligned and readable 8 bytes past their last used byte; out 16-byte aligned,
+// (n + 15) / 16 * 16 bytes.
+hipError_t launch_unpack_bases(const uint8_t *packed, const uint8_t *mask, uint32_t skip, uint32_t mskip, uint64_t n, uint8_t *out,
+                               hipStream_t stream);
+
 }  // namespace mg

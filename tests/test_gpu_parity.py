@@ -256,6 +256,99 @@ def test_reads_session_record_longer_than_the_event_buffer(eng, oracle):
                 assert cused == oused, (kw, per, cused, oused)
 
 
+def _packed_batch(sketches, preserve_case=False):
+    """records of every sketch joined as mg_sketch_host takes them, then packed (mg_pack_bases)"""
+    blobs = [abi.join_records(r) for r in sketches]
+    bases = np.frombuffer(b"".join(blobs), dtype=np.uint8)
+    off = np.zeros(len(blobs) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(b) for b in blobs], dtype=np.uint64)
+    packed, mask, ninv = abi.pack_bases(bases, preserve_case)
+    return bases, off, packed, mask, ninv
+
+
+@pytest.mark.parametrize("kw", [
+    dict(k=21, s=1000),
+    dict(k=21, s=200, noncanonical=True),
+    dict(k=21, s=200, preserve_case=True),
+    dict(k=16, s=300),                      # 32-bit hashes
+    dict(k=32, s=64, seed=11),
+    dict(k=5, s=50),
+])
+def test_sketch_packed_input_matches_the_ascii_path(eng, oracle, kw, monkeypatch):
+    """mg_sketch_host_packed (two bits per base + one invalid bit, ingest.hip) == mg_sketch_host on the same bytes == the
+    oracle, hashes and multiplicities: adversarial records (N runs, IUPAC codes, lower case, records shorter than k, empty
+    sketches), several records per sketch, sketch boundaries that are no multiples of four bases, the batch taken as
+    one piece and in pieces of a few thousand bases (each piece crosses PCIe while the previous one is sketched)."""
+    rng = np.random.default_rng(77 + kw["k"])
+    sketches = [synth.adversarial_dna_records(rng, v) for v in range(5)] + [[b""], [b"ACGTN"]]
+    sketches += [[bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=int(rng.integers(3000, 9000))))] for _ in range(6)]
+    bases, off, packed, mask, ninv = _packed_batch(sketches, kw.get("preserve_case", False))
+    assert ninv > 0 and len(set(int(o) % 4 for o in off)) > 1
+    p = eng.params(**kw)
+    want_h, want_n, want_c = eng.sketch_host_raw(bases, off, p, counts=True)
+    for piece in (None, "4000", "1"):
+        if piece:
+            monkeypatch.setenv("MASHGPU_PACKED_PIECE", piece)
+        h, n, c = eng.sketch_host_packed_raw(packed, mask, len(bases), off, p, counts=True)
+        assert np.array_equal(n, want_n), (kw, piece, n, want_n)
+        assert np.array_equal(h, want_h), (kw, piece, np.argwhere(h != want_h)[:5])
+        assert np.array_equal(c, want_c), (kw, piece, np.argwhere(c != want_c)[:5], c[c != want_c][:5], want_c[c != want_c][:5])
+    monkeypatch.delenv("MASHGPU_PACKED_PIECE")
+    for i in (0, 3, len(sketches) - 1):
+        oh, oc, _, _, _ = oracle.sketch_records(sketches[i], oracle.params(**kw))
+        assert want_n[i] == len(oh) and np.array_equal(h[i, : len(oh)], oh) and np.array_equal(c[i, : len(oh)], oc), (kw, i)
+
+
+def test_sketch_batch_of_nothing_but_empty_sketches(eng):
+    """No sketch of the batch holds a k-mer: hashes padded, counts ZERO (they used to be left as the pool handed them out --
+    found by the packed path, which sketches piece by piece)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    p = eng.params(k=21, s=64)
+    junk = torch.full((1 << 16,), 0x5A5A5A5A, dtype=torch.int32, device=dev)      # (what a recycled block may hold)
+    del junk
+    h, n, c = eng.sketch_host([[b""], [b"ACGT"], [b"NNNNNNNNNNNNNNNNNNNNNNNNNNNNNN"]], p, counts=True)
+    assert not n.any() and not c.any() and np.all(h == np.uint64(abi.HASH_PAD))
+
+
+def test_sketch_packed_input_without_a_mask_and_from_device_memory(eng):
+    """A clean input (nothing but ACGT, one record per sketch) needs no mask: NULL.  mg_sketch_dev_packed takes the packed
+    arrays from device memory (whole batch, offsets anywhere) and leaves the sketches there."""
+    import torch
+    rng = np.random.default_rng(3)
+    lens = [int(x) for x in rng.integers(2000, 30000, size=9)]
+    bases = rng.choice(np.frombuffer(b"ACGTacgt", dtype=np.uint8), size=sum(lens)).astype(np.uint8)
+    off = np.zeros(len(lens) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(lens, dtype=np.uint64)
+    p = eng.params(k=21, s=400)
+    want_h, want_n = eng.sketch_host_raw(bases, off, p)
+    packed, mask, ninv = abi.pack_bases(bases)
+    assert ninv == 0 and not mask.any()
+    h, n = eng.sketch_host_packed_raw(packed, None, len(bases), off, p)
+    assert np.array_equal(n, want_n) and np.array_equal(h, want_h)
+    dev = torch.device("cuda", 0)
+    pad = np.zeros(16, dtype=np.uint8)
+    d_pk = torch.from_numpy(np.concatenate([packed, pad])).to(dev)
+    dirty = bases.copy()
+    dirty[::977] = ord("N")                               # now with a mask
+    want_h2, want_n2 = eng.sketch_host_raw(dirty, off, p)
+    packed2, mask2, ninv2 = abi.pack_bases(dirty)
+    assert ninv2 == len(dirty[::977])
+    d_pk2 = torch.from_numpy(np.concatenate([packed2, pad])).to(dev)
+    d_mk2 = torch.from_numpy(np.concatenate([mask2, pad])).to(dev)
+    d_h = torch.zeros((len(lens), 400), dtype=torch.int64, device=dev)
+    d_n = torch.zeros(len(lens), dtype=torch.int32, device=dev)
+    eng.sketch_dev_packed(d_pk.data_ptr(), None, len(bases), off, p, d_h.data_ptr(), d_n.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(d_n.cpu().numpy().astype(np.uint32), want_n) and np.array_equal(d_h.cpu().numpy().view(np.uint64), want_h)
+    eng.sketch_dev_packed(d_pk2.data_ptr(), d_mk2.data_ptr(), len(bases), off, p, d_h.data_ptr(), d_n.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(d_n.cpu().numpy().astype(np.uint32), want_n2) and np.array_equal(d_h.cpu().numpy().view(np.uint64), want_h2)
+    # other alphabets have no packed form
+    with pytest.raises(abi.MashGpuError, match="ACGT"):
+        eng.sketch_host_packed_raw(packed, None, len(bases), off, eng.params(k=9, s=100, alphabet="ACDEFGHIKLMNPQRSTVWY", noncanonical=True))
+
+
 def test_sketch_fuzz_regressions(eng, oracle):
     """Inputs on which tests/fuzz_sketch.py found the engine wrong (tests/golden/sketch_fuzz_regressions.npz):
     long records over a handful of distinct k-mers (protein k = 3, k = 1 over an 8-letter alphabet).
