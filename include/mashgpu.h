@@ -100,6 +100,13 @@ int         mg_ctx_synchronize(mg_ctx *ctx);
  * queued behind on the same stream) completes them, and an error of a queued kernel is reported
  * by the next synchronising call.  Default off: *_dev calls return with their output complete. */
 int         mg_ctx_set_async(mg_ctx *ctx, int on);
+/* Tuning and test knobs of ONE context (round 3 review: the library read some thirty MASHGPU_* environment
+ * variables).  name = the knob's name ("MASHGPU_COMPARE_KERNEL", "MASHGPU_COMPARE_DENSE", ... -- DESIGN.md section 7
+ * lists them), value = what the environment variable would hold; NULL removes the setting.  A knob that is not set
+ * on the context is looked up in the environment under the same name, so existing scripts keep working.  Two
+ * knobs inside kernel launchers (MASHGPU_SPARSE_PACK_MIN, MASHGPU_SPARSE_MERGE_WINDOWS) and MASHGPU_COMM_FORCE_RCCL
+ * remain process-wide. */
+int         mg_ctx_set_option(mg_ctx *ctx, const char *name, const char *value);
 /* Device blocks that finished calls and freed / invalidated tables handed back are kept by the context for the
  * next call (small scratch: 256 MiB; large blocks -- the inverted index of a table, candidate lists -- up to
  * 40 % of the device's memory, so that the next table of the same shape pays no hipMalloc).  mg_ctx_trim waits for the context's

@@ -21,7 +21,7 @@ HASH_PAD = 0xFFFFFFFFFFFFFFFF
 RECORD_SEP = 0x0A
 
 EXPORTS = [
-    "mg_device_count", "mg_ctx_create", "mg_ctx_destroy", "mg_last_error", "mg_ctx_set_stream", "mg_ctx_synchronize", "mg_ctx_set_async", "mg_ctx_trim",
+    "mg_device_count", "mg_ctx_create", "mg_ctx_destroy", "mg_last_error", "mg_ctx_set_stream", "mg_ctx_synchronize", "mg_ctx_set_async", "mg_ctx_set_option", "mg_ctx_trim",
     "mg_ctx_cu_count", "mg_params_init", "mg_sketch_host", "mg_sketch_dev", "mg_packed_bytes", "mg_packed_mask_bytes", "mg_pack_bases",
     "mg_sketch_host_packed", "mg_sketch_dev_packed", "mg_sketch_reads_host", "mg_sketch_begin", "mg_sketch_add",
     "mg_sketch_stage_capacity", "mg_sketch_stage", "mg_sketch_commit", "mg_sketch_end_sketch", "mg_sketch_pending", "mg_sketch_finish", "mg_sketch_session_free",
@@ -96,6 +96,10 @@ class ScreenSession:
 
     def __exit__(self, *exc):
         self.close()
+
+    def set_option(self, name, value):
+        """mg_ctx_set_option: a knob of this context (value None: back to the environment's setting)"""
+        self._check(self.lib.mg_ctx_set_option(self.ctx, name.encode(), None if value is None else str(value).encode()))
 
     def close(self):
         if self.h:
@@ -181,6 +185,7 @@ def load_library():
     lib.mg_ctx_set_stream.argtypes = [vp, vp]
     lib.mg_ctx_synchronize.argtypes = [vp]
     lib.mg_ctx_set_async.argtypes = [vp, i32]
+    lib.mg_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
     lib.mg_ctx_cu_count.argtypes = [vp]
     lib.mg_params_init.argtypes = [C.POINTER(MgParams), i32, u64, u32, C.c_char_p, i32, i32]
     lib.mg_sketch_host.argtypes = [vp, C.POINTER(MgParams), vp, u64, vp, u64, vp, vp, vp]

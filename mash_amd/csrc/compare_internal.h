@@ -128,7 +128,7 @@ hipError_t launch_sparse_row_digest(const uint64_t *hashes, uint64_t stride, con
                                     unsigned long long *digest, hipStream_t stream);
 hipError_t launch_sparse_row_equal(const uint64_t *hashes, uint64_t stride, const uint32_t *cnt, const uint2 *pairs, uint32_t npairs,
                                    uint32_t *equal, hipStream_t stream);
-size_t sparse_sort_temp_bytes(uint32_t E, uint32_t end_bit);
+size_t sparse_sort_temp_bytes(uint32_t E, uint32_t end_bit, uint32_t begin_bit);
 uint32_t sparse_img_stride(uint32_t s);          // row stride of a code image
 hipError_t sparse_build_index(const uint64_t *hashes, uint64_t stride, const uint32_t *off, uint32_t n, uint32_t E,
                               uint32_t rs, uint32_t end_bit, void *temp, size_t temp_bytes, uint64_t *keys_a,
@@ -137,7 +137,7 @@ hipError_t sparse_build_index(const uint64_t *hashes, uint64_t stride, const uin
                               uint32_t begin_bit, void *tie_scratch, unsigned long long *incidences, uint32_t *max_group, uint32_t *groups,
                               uint32_t *bad, uint32_t *tie_overflow, hipStream_t stream);
 size_t sparse_stat_scratch_bytes();
-uint32_t sparse_sort_begin_bit(uint32_t E, uint32_t end_bit);
+uint32_t sparse_sort_begin_bit(uint32_t E, uint32_t end_bit, const char *forced_bits, bool all_bits);
 size_t sparse_tie_scratch_bytes();
 hipError_t launch_sparse_locate(const uint64_t *qhashes, uint64_t qstride, const uint32_t *qoff, uint32_t q_begin, uint32_t nq,
                                 const uint64_t *keys_sorted, const uint32_t *gend, uint32_t E, uint32_t rs, uint32_t *qlo_img,

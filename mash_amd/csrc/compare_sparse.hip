@@ -339,16 +339,14 @@ struct sp_max_u32 {
     __device__ uint32_t operator()(const uint32_t &a, const uint32_t &b) const { return a > b ? a : b; }
 };
 
-uint32_t sparse_sort_begin_bit(uint32_t E, uint32_t end_bit);
-
-size_t sparse_sort_temp_bytes(uint32_t E, uint32_t end_bit)
+size_t sparse_sort_temp_bytes(uint32_t E, uint32_t end_bit, uint32_t begin_bit)
 {
     size_t bytes = 0;
     rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr, (const uint32_t *)nullptr,
                               (uint32_t *)nullptr, (size_t)E, 0u, end_bit, (hipStream_t) nullptr);
     size_t b1 = 0;                                           // (the sort on the leading bits only)
     rocprim::radix_sort_pairs(nullptr, b1, (const uint64_t *)nullptr, (uint64_t *)nullptr, (const uint32_t *)nullptr,
-                              (uint32_t *)nullptr, (size_t)E, sparse_sort_begin_bit(E, end_bit), end_bit, (hipStream_t) nullptr);
+                              (uint32_t *)nullptr, (size_t)E, begin_bit, end_bit, (hipStream_t) nullptr);
     bytes = bytes > b1 ? bytes : b1;
     size_t b2 = 0;
     rocprim::inclusive_scan(nullptr, b2, (const uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)E, sp_max_u32(), (hipStream_t) nullptr);
@@ -471,13 +469,14 @@ __global__ __launch_bounds__(64) void sp_tie_repair_kernel(uint64_t *keys, uint3
     }
 }
 
-// bits the sort looks at: enough that two different values rarely agree in all of them
-uint32_t sparse_sort_begin_bit(uint32_t E, uint32_t end_bit)
+// bits the sort looks at: enough that two different values rarely agree in all of them.  forced_bits (nullable, a test
+// knob): that many bits whatever the table's size -- few bits, many ties; all_bits: every bit
+uint32_t sparse_sort_begin_bit(uint32_t E, uint32_t end_bit, const char *forced_bits, bool all_bits)
 {
-    // (end_bit 64: rocprim's path for small inputs builds its bit mask with a shift by 64 and returns garbage -- seen on
-    // 1155 entries, bits [48, 64); values that reach the top bit are rare and the gain is one pass, so every bit is sorted)
-    if (getenv("MASHGPU_SPARSE_SORT_ALL_BITS") || end_bit >= 64u) return 0;
-    const char *forced = getenv("MASHGPU_SPARSE_SORT_BITS");        // (test knob: few bits, many ties)
+    // (end_bit 64: on 1155 entries and bits [48, 64) rocprim's path for small inputs returned a sequence that was not in
+    // order -- seen, not pursued; values that reach the top bit are rare and the gain is one pass, so every bit is sorted)
+    if (all_bits || end_bit >= 64u) return 0;
+    const char *forced = forced_bits;
     if (!forced && E < (1u << 22)) return 0;                         // (small tables: nothing to gain)
     uint32_t lg = 0;
     while ((1ull << lg) < (uint64_t)E) lg++;

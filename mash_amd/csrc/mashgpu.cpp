@@ -77,6 +77,9 @@ struct mg_ctx {
     // shape takes the very same blocks.  Bounded by big_limit; dropped when any allocation fails; mg_ctx_trim.
     std::vector<Block> big_free;
     size_t big_cached = 0, big_limit = (size_t)48 << 30;
+    // mg_ctx_set_option: tuning and test knobs of this context (name -> value); a knob that is not set here is looked
+    // up in the environment under the same name
+    std::map<std::string, std::string> options;
 };
 
 struct mg_table {
@@ -281,6 +284,16 @@ static int fail(mg_ctx *ctx, int code, const std::string &msg)
     return code;
 }
 
+// a knob: the context's own setting, else the environment's (nullptr: not set)
+static const char *ctx_opt(const mg_ctx *ctx, const char *name)
+{
+    if (ctx) {
+        const auto it = ctx->options.find(name);
+        if (it != ctx->options.end()) return it->second.c_str();
+    }
+    return getenv(name);
+}
+
 static void prof_begin(mg_ctx *ctx, std::vector<ProfRec> &v, hipStream_t stream = nullptr)
 {
     if (!ctx->prof) return;
@@ -382,6 +395,15 @@ int mg_ctx_set_stream(mg_ctx *ctx, void *hip_stream)
     return MG_OK;
 }
 
+int mg_ctx_set_option(mg_ctx *ctx, const char *name, const char *value)
+{
+    if (!ctx) return MG_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    if (!name || strncmp(name, "MASHGPU_", 8) != 0) return fail(ctx, MG_ERR_INVALID, "mg_ctx_set_option: knob names start with MASHGPU_");
+    if (value) ctx->options[name] = value; else ctx->options.erase(name);
+    return MG_OK;
+}
+
 int mg_ctx_set_async(mg_ctx *ctx, int on)
 {
     if (!ctx) return MG_ERR_INVALID;
@@ -467,11 +489,11 @@ static int plan_sketch_work(mg_ctx *ctx, const mg_params *p, const uint64_t *ske
         if (len >= k) total_pos += len - k + 1;
     }
     uint64_t target_items = 2048;
-    if (const char *e = getenv("MASHGPU_SKETCH_ITEMS")) target_items = strtoull(e, nullptr, 10);
+    if (const char *e = ctx_opt(ctx, "MASHGPU_SKETCH_ITEMS")) target_items = strtoull(e, nullptr, 10);
     if (target_items < 1) target_items = 1;
     uint64_t chunk = (total_pos + target_items - 1) / target_items;
     uint64_t min_chunk = 4 * tile;
-    if (const char *e = getenv("MASHGPU_SKETCH_MIN_CHUNK")) min_chunk = strtoull(e, nullptr, 10);
+    if (const char *e = ctx_opt(ctx, "MASHGPU_SKETCH_MIN_CHUNK")) min_chunk = strtoull(e, nullptr, 10);
     if (chunk < min_chunk) chunk = min_chunk;
     chunk = (chunk + tile - 1) / tile * tile;
 
@@ -565,13 +587,13 @@ static int launch_merges(SketchRun &r, const mg::MergeWork *d_list, size_t nfina
 static int seed_thresholds(SketchRun &r, const uint64_t *sketch_off)
 {
     r.a.seed_T = nullptr;
-    if (getenv("MASHGPU_SKETCH_NO_SEED")) return MG_OK;
+    if (ctx_opt(r.ctx, "MASHGPU_SKETCH_NO_SEED")) return MG_OK;
     const uint64_t k = (uint64_t)r.p->kmer_size;
     const double kmer_space = std::pow((double)std::max<uint32_t>(r.p->alphabet_size, 2), (double)k) / (r.p->noncanonical ? 1.0 : 2.0);
     std::vector<uint64_t> seeds(r.nsketch, ~0ull);
     bool any = false;
     double factor = 3.0;                                            // expected hashes below the seed, in units of s
-    if (const char *e = getenv("MASHGPU_SKETCH_SEED_FACTOR")) factor = std::max(1.0, atof(e));
+    if (const char *e = ctx_opt(r.ctx, "MASHGPU_SKETCH_SEED_FACTOR")) factor = std::max(1.0, atof(e));
     for (uint64_t i = 0; i < r.nsketch; i++) {
         const uint64_t len = sketch_off[i + 1] - sketch_off[i];
         if (len < k) continue;
@@ -750,7 +772,7 @@ static int sketch_min_copies(mg_ctx *ctx, const mg_params *p, int mode, const ui
         uint64_t lo = 0;
         // m copies: most distinct hashes of a read set are singletons, plan for 64 s; m = 1: 2 s suffice
         uint64_t expect = std::max<uint64_t>((p->min_copies > 1 ? 64 : 2) * s, 1ull << 16);
-        if (const char *e = getenv("MASHGPU_MINCOPIES_EXPECT")) expect = std::max<uint64_t>(1024, strtoull(e, nullptr, 10));  // test knob
+        if (const char *e = ctx_opt(ctx, "MASHGPU_MINCOPIES_EXPECT")) expect = std::max<uint64_t>(1024, strtoull(e, nullptr, 10));  // test knob
         bool exhausted = false;
         while (kept.size() < s && !exhausted && rc == MG_OK) {
             // range [lo, hi] expected to hold <= `expect` distinct hashes (there are <= npos k-mers)
@@ -985,7 +1007,7 @@ static int sketch_packed_impl(mg_ctx *ctx, const mg_params *p, const uint8_t *pa
 {
     const uint64_t s = p->sketch_size;
     uint64_t cap = 1ull << 28;
-    if (const char *e = getenv("MASHGPU_PACKED_PIECE")) cap = std::max<uint64_t>(strtoull(e, nullptr, 10), 1);      // (test knob)
+    if (const char *e = ctx_opt(ctx, "MASHGPU_PACKED_PIECE")) cap = std::max<uint64_t>(strtoull(e, nullptr, 10), 1);      // (test knob)
     for (uint64_t i = 0; i < nsketch; i++)
         if (sketch_off[i] > sketch_off[i + 1] || sketch_off[i + 1] > nbases) return fail(ctx, MG_ERR_INVALID, "mg_sketch_packed: sketch_off must ascend and end within nbases");
     struct Piece { uint64_t i0, i1, b0, b1; };
@@ -1165,7 +1187,7 @@ int mg_sketch_begin(mg_ctx *ctx, const mg_params *p, mg_sketch_session **out)
     mg_sketch_session *ss = new mg_sketch_session;
     ss->ctx = ctx;
     ss->p = *p;
-    if (const char *e = getenv("MASHGPU_STAGE_BYTES")) ss->stage_cap = std::max<uint64_t>(64, strtoull(e, nullptr, 10));   // test knob
+    if (const char *e = ctx_opt(ctx, "MASHGPU_STAGE_BYTES")) ss->stage_cap = std::max<uint64_t>(64, strtoull(e, nullptr, 10));   // test knob
     hipError_t e = hipStreamCreateWithFlags(&ss->copy_stream, hipStreamNonBlocking);
     for (int i = 0; i < 2 && e == hipSuccess; i++) {
         e = hipHostMalloc((void **)&ss->stage[i], ss->stage_cap, hipHostMallocDefault);
@@ -1900,7 +1922,7 @@ static int plan_windows(mg_ctx *ctx, const mg_table *rows, const mg_table *cols,
     if (row_cap == 0) row_cap = mg::compare_window_row_entries();         // entries of one row a tile's tag can index
     const uint32_t Rw = mg::compare_window_rows(s);
     double target = window_target(s, Rw);                                    // entries of the densest row per window
-    if (const char *e = getenv("MASHGPU_COMPARE_WIN_TARGET")) target = std::max(1.0, atof(e));
+    if (const char *e = ctx_opt(ctx, "MASHGPU_COMPARE_WIN_TARGET")) target = std::max(1.0, atof(e));
     // Hashes per unit of prefix of a row at the class's 10th percentile: rows at least that dense
     // (90 % of them) have `target` hashes or more in a window, so their pairs are decided where the
     // target says.  (Taken from the DENSEST row, typical rows fell a few per cent short of it and one
@@ -2010,19 +2032,19 @@ static int run_compare_merged(mg_ctx *ctx, const mg_table *rows, const mg_table 
     // 16.6): rows x columns >= 1.4e8 up to s = 400, rising linearly to 5.5e8 at s = 1000.
     const double win_cross = a.s <= 400 ? 1.4e8 : a.s >= 1000 ? 5.5e8 : 1.4e8 + (a.s - 400.0) * (4.1e8 / 600.0);
     bool want_win = a.s >= 1800 || (a.s >= 200 && (double)(row_end - row_begin) * (double)maxcols >= win_cross);
-    if (const char *e = getenv("MASHGPU_COMPARE_WINDOWS")) want_win = atoi(e) != 0;
+    if (const char *e = ctx_opt(ctx, "MASHGPU_COMPARE_WINDOWS")) want_win = atoi(e) != 0;
     if (windows_only) want_win = true;
     const uint32_t R_plain = R;
     // A launch of few row tiles (a handful of queries against a large database, or a small
     // density class) would leave most CUs idle with full-length column chunks: cut the columns
     // finer until there are ~4 tiles per CU (a table build costs about as much as 100 columns,
     // so not below 256).  Every class is its own launch, so this is decided per class.
-    const bool cc_forced = getenv("MASHGPU_COMPARE_COLS") != nullptr;
+    const bool cc_forced = ctx_opt(ctx, "MASHGPU_COMPARE_COLS") != nullptr;
     auto chunk_for = [&](uint64_t nrt) -> uint64_t {
         // measured (profiles/r02_engine_sweep.txt): 2048 tiles pay from ~10 000 columns on (n = 10 000:
         // 4.1 -> 6.0e9 pairs/s windows, 6.3 -> 7.5e9 plain); below that the tiles get too short for their builds
         uint64_t min_tiles = maxcols >= 8192 ? 2048 : 512;  // (MASHGPU_COMPARE_MIN_TILES: tuning knob)
-        if (const char *e = getenv("MASHGPU_COMPARE_MIN_TILES")) min_tiles = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
+        if (const char *e = ctx_opt(ctx, "MASHGPU_COMPARE_MIN_TILES")) min_tiles = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
         if (cc_forced || nrt == 0 || nrt * ((maxcols + CC - 1) / CC) >= min_tiles) return CC;
         uint64_t chunks = (2 * min_tiles + nrt - 1) / nrt;
         const uint64_t most = std::max<uint64_t>(1, maxcols / 256);
@@ -2111,7 +2133,7 @@ static int run_compare_merged(mg_ctx *ctx, const mg_table *rows, const mg_table 
         if (rc != MG_OK) return rc;
         unsigned long long *d_dbg = nullptr;
         const size_t dbg_sets = wr ? nwin : 1;                  // one {start, built, end} set per tile and launch
-        if (getenv("MASHGPU_COMPARE_DBG")) {
+        if (ctx_opt(ctx, "MASHGPU_COMPARE_DBG")) {
             hipMalloc(&d_dbg, dbg_sets * mtiles.size() * 24);
             hipMemsetAsync(d_dbg, 0, dbg_sets * mtiles.size() * 24, ctx->stream);
         }
@@ -2281,7 +2303,7 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
     // read back with the copy suspects below
     std::vector<uint8_t> link;
     bool want_dense = true;
-    if (const char *e = getenv("MASHGPU_COMPARE_DENSE")) want_dense = atoi(e) != 0;
+    if (const char *e = ctx_opt(ctx, "MASHGPU_COMPARE_DENSE")) want_dense = atoi(e) != 0;
     DevBuf<uint8_t> d_link(ctx);
     if (want_dense && n >= 8 && s <= 16384 && !lab_sorted.empty()) {
         link.assign(n, 0);                                  // clustered variant: neighbours with the same label
@@ -2290,11 +2312,11 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
         link.resize(n);
         HIP_TRY(ctx, mg::launch_dense_neighbors(H, t->s, d_cnt, (uint32_t)n, d_link, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(link.data(), d_link, n, hipMemcpyDeviceToHost, ctx->stream));
-        if (getenv("MASHGPU_SPARSE_NO_DEDUP")) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx_opt(ctx, "MASHGPU_SPARSE_NO_DEDUP")) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     } else {
         (void)hipGetLastError();
     }
-    if (!getenv("MASHGPU_SPARSE_NO_DEDUP")) {
+    if (!ctx_opt(ctx, "MASHGPU_SPARSE_NO_DEDUP")) {
         DevBuf<unsigned long long> d_dig(ctx), d_dig_sorted(ctx);
         DevBuf<uint32_t> d_rows_sorted(ctx), d_flags(ctx), d_nflag(ctx);
         DevBuf<unsigned char> d_tmp(ctx);
@@ -2383,7 +2405,8 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
     sp->E = E;
     const uint32_t end_bit = (uint32_t)(64 - __builtin_clzll(maxv | 1ull));
     // transient buffers (back to the pool at the end of this function, in stream order)
-    const size_t temp_bytes = std::max(mg::sparse_sort_temp_bytes(E, end_bit),
+    const uint32_t sort_begin_bit = mg::sparse_sort_begin_bit(E, end_bit, ctx_opt(ctx, "MASHGPU_SPARSE_SORT_BITS"), ctx_opt(ctx, "MASHGPU_SPARSE_SORT_ALL_BITS") != nullptr);
+    const size_t temp_bytes = std::max(mg::sparse_sort_temp_bytes(E, end_bit, sort_begin_bit),
                                        std::max(mg::sparse_order_temp_bytes((uint32_t)n), mg::sparse_order_slice_temp_bytes((uint32_t)n)));
     DevBuf<unsigned char> temp(ctx);
     DevBuf<uint64_t> keys_a(ctx);
@@ -2392,7 +2415,7 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
     struct Stat { unsigned long long shared; uint32_t max_group, groups, bad, tie_overflow; } h_stat = {0, 0, 0, 0, 0};
     DevBuf<Stat> d_stat(ctx);
     DevBuf<unsigned char> d_slots(ctx), d_ties(ctx);
-    const bool want_order = !getenv("MASHGPU_SPARSE_NO_ORDER");
+    const bool want_order = !ctx_opt(ctx, "MASHGPU_SPARSE_NO_ORDER");
     bool ok = temp.alloc(std::max<size_t>(temp_bytes, 16)) == hipSuccess && keys_a.alloc(E) == hipSuccess && idx_a.alloc(E) == hipSuccess &&
               idx_sorted.alloc(E) == hipSuccess && gs_of.alloc(E) == hipSuccess && d_stat.alloc(1) == hipSuccess &&
               d_slots.alloc(mg::sparse_stat_scratch_bytes()) == hipSuccess && d_ties.alloc(mg::sparse_tie_scratch_bytes()) == hipSuccess &&
@@ -2427,7 +2450,7 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
         if (e == hipSuccess && nshort) e = hipMemcpyAsync(sp->short_rows, sp->short_rows_host.data(), nshort * 4, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess && nshort) e = hipMemcpyAsync(sp->short_cnt, short_cnt.data(), nshort * 4, hipMemcpyHostToDevice, ctx->stream);
         // (the sort looks at the values' leading bits only and repairs the few ties; a table that defeats that is sorted again, on every bit)
-        for (uint32_t begin_bit = mg::sparse_sort_begin_bit(E, end_bit);; begin_bit = 0) {
+        for (uint32_t begin_bit = sort_begin_bit;; begin_bit = 0) {
             if (e == hipSuccess) e = hipMemsetAsync(d_stat, 0, sizeof(Stat), ctx->stream);
             if (e == hipSuccess)
                 e = mg::sparse_build_index(H, t->s, sp->off, (uint32_t)n, E, sp->rs, end_bit, temp, temp_bytes, keys_a, idx_a,
@@ -2588,19 +2611,19 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
                 sp->usable = false;
                 return fail(ctx, MG_ERR_HIP, std::string("compare (index build, dense groups): ") + hipGetErrorString(e2));
             }
-            sp->dn_lists = getenv("MASHGPU_DENSE_LISTS") != nullptr;          // (test knob: every word resolved from the lists)
+            sp->dn_lists = ctx_opt(ctx, "MASHGPU_DENSE_LISTS") != nullptr;          // (test knob: every word resolved from the lists)
             break;
         }
         if (sp->dgroups_host.empty() && sp->ulist) { ctx_free(ctx, sp->ulist); ctx_free(ctx, sp->upos); sp->ulist = sp->upos = nullptr; }
         sp->build_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dense).count();
-        if (getenv("MASHGPU_SPARSE_DBG")) {
+        if (ctx_opt(ctx, "MASHGPU_SPARSE_DBG")) {
             uint64_t rows_in = 0;
             for (auto &G : sp->dgroups_host) rows_in += G.g1 - G.g0;
             fprintf(stderr, "compare dense: %zu chains of related rows, %zu groups kept (%llu rows, widest universe %u words)\n", cand_groups.size(),
                     sp->dgroups_host.size(), (unsigned long long)rows_in, sp->dn_wmax);
         }
     }
-    if (getenv("MASHGPU_SPARSE_DBG"))
+    if (ctx_opt(ctx, "MASHGPU_SPARSE_DBG"))
         fprintf(stderr, "compare sparse: index of %llu rows (%llu copies of earlier rows), s %u: %u entries, %u distinct, shared %llu, largest run %u, %.2f ms\n",
                 (unsigned long long)n, (unsigned long long)sp->copies, s, E, sp->G, (unsigned long long)sp->shared, sp->max_group, sp->build_ms);
     return MG_OK;
@@ -2627,14 +2650,14 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
     const uint64_t pairs = triangle ? (row_end * (row_end - 1) / 2 - (row_begin ? row_begin * (row_begin - 1) / 2 : 0)) : nrows * cols->n;
     if (pairs == 0) return MG_OK;
     if (!force && pairs < 4000000ull) return MG_OK;        // small jobs: one tile launch beats an index
-    if (const char *e = getenv("MASHGPU_COMPARE_SPARSE")) { if (atoi(e) == 0 && !force) return MG_OK; }
+    if (const char *e = ctx_opt(ctx, "MASHGPU_COMPARE_SPARSE")) { if (atoi(e) == 0 && !force) return MG_OK; }
     if (nrows >= (1ull << 31) || cols->n >= (1ull << 31)) return MG_OK;
     if (!mg::sparse_discover_supported((uint32_t)(triangle ? row_end : cols->n))) return MG_OK;
     mg_table::Sparse *ix = nullptr;
     // the plain full triangle takes the CLUSTERED variant of the index (built on the table with related rows next to each
     // other: dense groups whatever the order of the collection); row ranges, rect and list jobs address table rows
     bool clustered = triangle && !job && row_begin == 0 && row_end == cols->n;
-    if (const char *e = getenv("MASHGPU_COMPARE_CLUSTER")) clustered = clustered && atoi(e) != 0;
+    if (const char *e = ctx_opt(ctx, "MASHGPU_COMPARE_CLUSTER")) clustered = clustered && atoi(e) != 0;
     int rc = table_sparse_index(ctx, cols, s, clustered, &ix);
     if (rc != MG_OK) return rc;
     if (!ix->usable && clustered) {                         // (whatever stopped it may not stop the plain variant)
@@ -2884,7 +2907,7 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
         const double dense_rate = np < 3.0e8 ? 8.0e9 : np < 2.0e9 ? 1.5e10 : 3.0e10;
         const double t_dense = np / dense_rate + (double)fresh.shared * 2.2e-12;
         fresh.use = t_sparse < t_dense;
-        if (getenv("MASHGPU_SPARSE_DBG"))
+        if (ctx_opt(ctx, "MASHGPU_SPARSE_DBG"))
             fprintf(stderr, "compare sparse: rows [%llu, %llu) %s: %llu pairs, %llu candidates, %llu shared hashes; model sparse %.3f ms, tiles %.3f ms\n",
                     (unsigned long long)row_begin, (unsigned long long)row_end, triangle ? "triangle" : "rect", (unsigned long long)pairs,
                     (unsigned long long)fresh.cand, (unsigned long long)fresh.shared, t_sparse * 1e3, t_dense * 1e3);
@@ -2933,14 +2956,14 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
     if (plan->cand == 0) return MG_OK;
     // ---- merge ----
     bool by_rows = mg::sparse_merge_rows_supported(a.rs_row);
-    if (const char *ev = getenv("MASHGPU_SPARSE_MERGE")) by_rows = by_rows && strcmp(ev, "lanes") != 0;
+    if (const char *ev = ctx_opt(ctx, "MASHGPU_SPARSE_MERGE")) by_rows = by_rows && strcmp(ev, "lanes") != 0;
     prof_begin(ctx, ctx->prof_merge);
     hipError_t e = hipSuccess;
     bool packed = false;
     // rows with few candidates each (a collection: C3 has 50 per row) share a work item; rows with hundreds (clades)
     // fill their own items and gain nothing from staging their neighbours (measured: 27.8 -> 33.4 ms on the clade table)
     bool pack = by_rows && plan->cand < 64ull * nrows;
-    if (const char *ev = getenv("MASHGPU_SPARSE_MERGE_PACK")) pack = by_rows && atoi(ev) != 0;
+    if (const char *ev = ctx_opt(ctx, "MASHGPU_SPARSE_MERGE_PACK")) pack = by_rows && atoi(ev) != 0;
     if (pack) e = mg::launch_sparse_merge_pack(a, plan->cand, ix->chunks, ix->scan_temp, ix->scan_temp_bytes, &packed, ctx->stream);
     if (!packed && e == hipSuccess)
         e = by_rows ? mg::launch_sparse_merge_rows(a, plan->cand, ix->chunks, ix->scan_temp, ix->scan_temp_bytes, ctx->stream)
@@ -2998,9 +3021,9 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
     a.xcd_remap = 0;
     a.stage_pack = 0;
     a.dbg = nullptr;
-    if (const char *e = getenv("MASHGPU_COMPARE_XCD")) a.xcd_remap = atoi(e) != 0;
-    if (const char *e = getenv("MASHGPU_COMPARE_VARIANT")) a.unroll = (uint32_t)atoi(e);
-    const char *force = getenv("MASHGPU_COMPARE_KERNEL");
+    if (const char *e = ctx_opt(ctx, "MASHGPU_COMPARE_XCD")) a.xcd_remap = atoi(e) != 0;
+    if (const char *e = ctx_opt(ctx, "MASHGPU_COMPARE_VARIANT")) a.unroll = (uint32_t)atoi(e);
+    const char *force = ctx_opt(ctx, "MASHGPU_COMPARE_KERNEL");
     // Inverted-index engine first: it takes the job when the counting pass says so (or when forced)
     if (!force || strcmp(force, "sparse") == 0) {
         bool handled = false;
@@ -3014,7 +3037,7 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
     a.row_pfx_stride = a.col_pfx_stride = 0;
     a.pfx_shr = 0;
     if (!use_merged && !want_generic && a.s > 16384 && a.s <= (1u << 22) &&
-        !(getenv("MASHGPU_COMPARE_WINDOWS") && atoi(getenv("MASHGPU_COMPARE_WINDOWS")) == 0)) {
+        !(ctx_opt(ctx, "MASHGPU_COMPARE_WINDOWS") && atoi(ctx_opt(ctx, "MASHGPU_COMPARE_WINDOWS")) == 0)) {
         // Beyond the plain tile kernel's reach (s > 16 384) the value-window mode still applies: its
         // tiles hold one window's hashes whatever s is.  If some class cannot be windowed, nothing
         // has been launched and the generic kernel below takes the call.
@@ -3030,11 +3053,11 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
         return MG_OK;
     }
     uint32_t R = mg::compare_merged_rows(a.s);
-    if (const char *e = getenv("MASHGPU_COMPARE_ROWS")) { uint32_t v = (uint32_t)atoi(e); if (v >= 1 && v < R) R = v; }
+    if (const char *e = ctx_opt(ctx, "MASHGPU_COMPARE_ROWS")) { uint32_t v = (uint32_t)atoi(e); if (v >= 1 && v < R) R = v; }
     // columns per tile: long tiles amortise the table build and the ragged end of a tile
     // (profiles/r01_compare_sweep2.txt); smaller problems keep more tiles for balance
     uint64_t CC = cols->n >= 40000 ? 16384 : 8192;
-    if (const char *e = getenv("MASHGPU_COMPARE_COLS")) { uint64_t v = strtoull(e, nullptr, 10); if (v >= 16) CC = v; }
+    if (const char *e = ctx_opt(ctx, "MASHGPU_COMPARE_COLS")) { uint64_t v = strtoull(e, nullptr, 10); if (v >= 16) CC = v; }
     a.rows_per_tile = R;
     const uint64_t maxcols = triangle ? (row_end - 1) : cols->n;       // columns [0, maxcols)
     return run_compare_merged(ctx, rows, cols, row_begin, row_end, triangle, a, R, CC, maxcols, false);
@@ -3558,9 +3581,9 @@ static int compare_results(mg_ctx *ctx, const mg_table *rows, const mg_table *co
     // those are the inverted-index engine's candidates -- no matrix is filled, no 8 B per pair read back by
     // the filter pass: discover + merge, the candidates put into reference order, the same two finish passes
     // over that list.
-    const char *force_kernel = getenv("MASHGPU_COMPARE_KERNEL");
+    const char *force_kernel = ctx_opt(ctx, "MASHGPU_COMPARE_KERNEL");
     if (((max_d >= 0.0 && max_d < 1.0) || (max_p >= 0.0 && max_p < 1.0)) && (!force_kernel || strcmp(force_kernel, "sparse") == 0) &&
-        !getenv("MASHGPU_RESULTS_MATRIX")) {
+        !ctx_opt(ctx, "MASHGPU_RESULTS_MATRIX")) {
         SparseJob job;
         bool handled = false;
         int rc = run_compare_sparse(ctx, rows, cols, rb, re, triangle, s, nullptr, force_kernel != nullptr, &handled, &job);
@@ -3808,7 +3831,7 @@ int mg_comm_create_local(const int *devices, int n, mg_comm **out)
     // RCCL needs distinct devices; a list that repeats a device (tests on a one-GPU box: two
     // contexts on one device) exchanges by plain device copies instead.  One device needs nothing,
     // unless MASHGPU_COMM_FORCE_RCCL asks for the one-rank communicator (tests of the call path).
-    if (distinct && (n > 1 || getenv("MASHGPU_COMM_FORCE_RCCL"))) {
+    if (distinct && (n > 1 || getenv("MASHGPU_COMM_FORCE_RCCL"))) {        // (a process-wide test knob: the communicator creates its contexts itself)
         c->comms.resize((size_t)n);
         const ncclResult_t r = ncclCommInitAll(c->comms.data(), n, devices);
         if (r != ncclSuccess) {
@@ -4095,14 +4118,14 @@ int mg_comm_allreduce_u32_sum(mg_comm *c, uint32_t *buf_dev, uint64_t count)
 // inverted-index engine fill per pair but discover and merge per row -- 60 s is C3's measured ratio (bench.py measures
 // it per table; here a constant has to do: an all-random table has a third of it, clades seven times as much).
 // MASHGPU_SHARD_ROW_WEIGHT overrides (0: equal areas).
-static double tri_row_weight(uint64_t rb, uint64_t re, uint64_t s)
+static double tri_row_weight(const mg_ctx *ctx, uint64_t rb, uint64_t re, uint64_t s)
 {
-    if (const char *e = getenv("MASHGPU_SHARD_ROW_WEIGHT")) return atof(e);
+    if (const char *e = ctx_opt(ctx, "MASHGPU_SHARD_ROW_WEIGHT")) return atof(e);
     // only where the inverted-index engine takes the blocks (the tile engine costs per pair -- with a row weight
     // a few thousand rows were cut almost evenly by rows and the last device got ten times the first one's pairs) ...
     if (tri_pairs(rb, re) < 4000000ull) return 0.0;
-    if (const char *e = getenv("MASHGPU_COMPARE_SPARSE")) { if (atoi(e) == 0) return 0.0; }
-    if (const char *e = getenv("MASHGPU_COMPARE_KERNEL")) { if (strcmp(e, "sparse") != 0) return 0.0; }
+    if (const char *e = ctx_opt(ctx, "MASHGPU_COMPARE_SPARSE")) { if (atoi(e) == 0) return 0.0; }
+    if (const char *e = ctx_opt(ctx, "MASHGPU_COMPARE_KERNEL")) { if (strcmp(e, "sparse") != 0) return 0.0; }
     // ... and never more than a mean row's pairs: a row cannot cost more than it holds
     const double mean_row = (double)tri_pairs(rb, re) / (double)std::max<uint64_t>(re - rb, 1);
     return std::min(60.0 * (double)s, mean_row);
@@ -4212,10 +4235,10 @@ static int rect_by_ref_rows(mg_comm *c, const mg_dtable *ref, const mg_dtable *q
 }  // extern "C++"
 
 // which side of a rect job is cut: the reference rows when that table is row-sharded or the larger side
-static bool rect_split_refs(const mg_dtable *ref, uint64_t nq)
+static bool rect_split_refs(const mg_ctx *ctx, const mg_dtable *ref, uint64_t nq)
 {
     if (ref->by_rows) return true;
-    if (getenv("MASHGPU_RECT_SPLIT")) return strcmp(getenv("MASHGPU_RECT_SPLIT"), "refs") == 0;
+    if (ctx_opt(ctx, "MASHGPU_RECT_SPLIT")) return strcmp(ctx_opt(ctx, "MASHGPU_RECT_SPLIT"), "refs") == 0;
     return ref->t.size() > 1 && ref->t[0]->n > nq;
 }
 
@@ -4227,7 +4250,7 @@ int mg_compare_tri_sharded_host(mg_comm *c, const mg_dtable *t, uint64_t row_beg
     if (row_begin >= row_end) return MG_OK;
     return sharded_blocks(c, row_begin, row_end, true, 0, [&](int g, uint64_t lo, uint64_t hi, uint64_t before) {
         return mg_compare_tri_host(c->ctxs[(size_t)g], t->t[(size_t)g], lo, hi, out_host + before);
-    }, tri_row_weight(row_begin, row_end, t->t[0]->s));
+    }, tri_row_weight(c->ctxs[0], row_begin, row_end, t->t[0]->s));
 }
 
 int mg_compare_rect_sharded_host(mg_comm *c, const mg_dtable *ref, const mg_dtable *qry, uint64_t q_begin, uint64_t q_end,
@@ -4238,7 +4261,7 @@ int mg_compare_rect_sharded_host(mg_comm *c, const mg_dtable *ref, const mg_dtab
     if (rc != MG_OK) return rc;
     if (q_end > qry->t[0]->n) q_end = qry->t[0]->n;
     if (q_begin >= q_end) return MG_OK;
-    if (rect_split_refs(ref, q_end - q_begin))
+    if (rect_split_refs(c->ctxs[0], ref, q_end - q_begin))
         return rect_by_ref_rows<mg_counts>(c, ref, qry, q_begin, q_end, out_host,
                                            [&](size_t g, const mg_table *blk, const mg_table *q, uint64_t q0, uint64_t q1, mg_counts *o) {
             return mg_compare_rect_host(c->ctxs[g], blk, q, q0, q1, o);
@@ -4259,7 +4282,7 @@ int mg_compare_tri_pairs_sharded_host(mg_comm *c, const mg_dtable *t, uint64_t r
     return sharded_blocks(c, row_begin, row_end, true, 0, [&](int g, uint64_t lo, uint64_t hi, uint64_t before) {
         return mg_compare_tri_pairs_host(c->ctxs[(size_t)g], t->t[(size_t)g], lo, hi, kmer_size, kmer_space, max_distance,
                                          max_p_value, out_host + before);
-    }, tri_row_weight(row_begin, row_end, t->t[0]->s));
+    }, tri_row_weight(c->ctxs[0], row_begin, row_end, t->t[0]->s));
 }
 
 int mg_compare_rect_pairs_sharded_host(mg_comm *c, const mg_dtable *ref, const mg_dtable *qry, uint64_t q_begin, uint64_t q_end,
@@ -4271,7 +4294,7 @@ int mg_compare_rect_pairs_sharded_host(mg_comm *c, const mg_dtable *ref, const m
     if (rc != MG_OK) return rc;
     if (q_end > qry->t[0]->n) q_end = qry->t[0]->n;
     if (q_begin >= q_end) return MG_OK;
-    if (rect_split_refs(ref, q_end - q_begin))
+    if (rect_split_refs(c->ctxs[0], ref, q_end - q_begin))
         return rect_by_ref_rows<mg_pair>(c, ref, qry, q_begin, q_end, out_host,
                                          [&](size_t g, const mg_table *blk, const mg_table *q, uint64_t q0, uint64_t q1, mg_pair *o) {
             return mg_compare_rect_pairs_host(c->ctxs[g], blk, q, q0, q1, kmer_size, kmer_space, max_distance, max_p_value, o);
@@ -4331,7 +4354,7 @@ int mg_compare_tri_results_sharded_host(mg_comm *c, const mg_dtable *t, uint64_t
                            [&](int g, uint64_t lo, uint64_t hi, mg_result *o, uint64_t cap, uint64_t *n) {
         return mg_compare_tri_results_host(c->ctxs[(size_t)g], t->t[(size_t)g], lo, hi, kmer_size, kmer_space, max_distance,
                                            max_p_value, o, cap, n);
-    }, 10.0 * tri_row_weight(row_begin, row_end, t->t[0]->s));      // (thresholded: no matrix is filled, the cost is nearly all per row)
+    }, 10.0 * tri_row_weight(c->ctxs[0], row_begin, row_end, t->t[0]->s));      // (thresholded: no matrix is filled, the cost is nearly all per row)
 }
 
 int mg_compare_rect_results_sharded_host(mg_comm *c, const mg_dtable *ref, const mg_dtable *qry, uint64_t q_begin,
@@ -4345,7 +4368,7 @@ int mg_compare_rect_results_sharded_host(mg_comm *c, const mg_dtable *ref, const
     *count_out = 0;
     if (q_end > qry->t[0]->n) q_end = qry->t[0]->n;
     if (q_begin >= q_end) return MG_OK;
-    if (rect_split_refs(ref, q_end - q_begin)) {
+    if (rect_split_refs(c->ctxs[0], ref, q_end - q_begin)) {
         // every device lists the survivors of its reference block (query major, columns relative to the block);
         // the reference order is query major over ALL references: per query, the blocks' runs in block order
         const size_t G = c->ctxs.size();
@@ -4480,13 +4503,13 @@ static int screen_plan_tiers(mg_ctx *ctx, mg_screen *sc)
     if (sc->distinct == 0 || sc->key_max < (1ull << 40)) return MG_OK;
     // (a bound that already spares all but a few k-mers in a thousand needs no second tier: C4's database of
     //  like-sized genomes sends 0.1 % of the mixture's k-mers to the table)
-    if ((double)sc->key_max / 18446744073709551616.0 < 0.004 && !getenv("MASHGPU_SCREEN_TIERS")) {
+    if ((double)sc->key_max / 18446744073709551616.0 < 0.004 && !ctx_opt(ctx, "MASHGPU_SCREEN_TIERS")) {
         sc->tier_note = "one tier (the largest key already spares all but a few k-mers in a thousand)";
         return MG_OK;
     }
-    if (const char *e = getenv("MASHGPU_SCREEN_TIERS")) { if (atoi(e) == 0) { sc->tier_note = "off (MASHGPU_SCREEN_TIERS=0)"; return MG_OK; } }
+    if (const char *e = ctx_opt(ctx, "MASHGPU_SCREEN_TIERS")) { if (atoi(e) == 0) { sc->tier_note = "off (MASHGPU_SCREEN_TIERS=0)"; return MG_OK; } }
     uint32_t log_bits = 27;
-    if (const char *e = getenv("MASHGPU_SCREEN_BITS")) log_bits = (uint32_t)std::min(34, std::max(10, atoi(e)));
+    if (const char *e = ctx_opt(ctx, "MASHGPU_SCREEN_BITS")) log_bits = (uint32_t)std::min(34, std::max(10, atoi(e)));
     const uint64_t B = 1ull << log_bits;
     const uint32_t NB = 24;
     std::vector<uint64_t> bounds(NB);

@@ -922,6 +922,38 @@ def test_compare_sparse_index_sorted_on_leading_bits(eng, oracle, bits, s, sizes
     t.free()
 
 
+def test_ctx_options_override_the_environment(eng, oracle, monkeypatch):
+    """mg_ctx_set_option: a knob set on the context wins over the environment, NULL hands it back; names outside
+    MASHGPU_* are refused.  Shown on MASHGPU_COMPARE_KERNEL: "sparse" makes the index engine take a job it would leave to
+    the tile engine (too few pairs) -- and fail loudly on a table it cannot take (a hash equal to the padding value)."""
+    rng = np.random.default_rng(4)
+    n, s = 60, 32
+    table = np.sort(rng.integers(1, 1 << 40, size=(n, s)).astype(np.uint64), axis=1)
+    nhash = np.full(n, s, dtype=np.uint32)
+    lengths = np.full(n, 10 ** 6, dtype=np.uint64)
+    numer, denom = _oracle_tri(oracle, table, nhash, lengths, 0, n)
+    bad = table.copy()
+    bad[7, s - 1] = np.uint64(abi.HASH_PAD)                       # a real hash with the padding's value: outside the index engine
+    monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", "generic")
+    try:
+        eng.set_option("MASHGPU_COMPARE_KERNEL", "sparse")        # the context's setting wins
+        t = eng.table_upload(table, nhash, lengths)
+        got = eng.compare_tri_host(t)
+        assert np.array_equal(got["numer"], numer) and np.array_equal(got["denom"], denom)
+        t.free()
+        tb = eng.table_upload(bad, nhash, lengths)
+        with pytest.raises(abi.MashGpuError, match="sparse engine cannot take"):
+            eng.compare_tri_host(tb)
+        eng.set_option("MASHGPU_COMPARE_KERNEL", None)            # back to the environment: the generic kernel takes it
+        got = eng.compare_tri_host(tb)
+        assert len(got) == n * (n - 1) // 2
+        tb.free()
+        with pytest.raises(abi.MashGpuError, match="MASHGPU_"):
+            eng.set_option("PATH", "x")
+    finally:
+        eng.set_option("MASHGPU_COMPARE_KERNEL", None)
+
+
 def test_table_invalidate_after_the_buffers_changed(eng, oracle, monkeypatch):
     """mg_table_invalidate: a wrapped table whose buffers were refilled is answered from the NEW contents -- index, plans,
     classes of copies, short rows all rebuilt (first table: clusters; second: other values, some rows short, some
