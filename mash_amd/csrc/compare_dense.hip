@@ -21,7 +21,7 @@
 // set of rows would be correct, so the relatedness test is a sample.  Layout per group, in blocks of 128 rows:
 // mask word w of the block's rows side by side (w * 128 + lane, u64), then the cumulative extra counts
 // cx[w] = extras with gap < 64 w (w = 0 .. W, u16, the same way); extras as u16 gaps per row.
-// mashgpu.cpp::table_sparse_index builds this next to the inverted index, whose runs it then clips so that discovery
+// host_compare.cpp::table_sparse_index builds this next to the inverted index, whose runs it then clips so that discovery
 // sees only the partners OUTSIDE a row's group; run_compare_sparse launches dn_pairs_kernel after the fill.
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -1,4 +1,4 @@
-// compare_internal.h — launch interface between mashgpu.cpp and the compare kernels (compare_sparse.hip,
+// compare_internal.h — launch interface between host_compare.cpp and the compare kernels (compare_sparse.hip,
 // compare_merged.hip, compare.hip).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -73,7 +73,7 @@ hipError_t launch_make_prefix(const uint64_t *hashes, const uint32_t *nhash, uin
 hipError_t launch_compare_generic(const CompareArgs &a, hipStream_t stream);
 
 // Inverted-index ("sparse") engine (compare_sparse.hip): fill + discover + merge over an index of
-// the column table built once per table (mashgpu.cpp::table_sparse_index).
+// the column table built once per table (host_compare.cpp::table_sparse_index).
 struct SparseArgs {
     const uint32_t *sorted_rows;   // column table: row of the entry at every sorted position (value major, rows ascending)
     // per entry of the ROW side (image layout, stride rs_row): [lo_img >> lo_shift, hi_img) = run of partner rows in

@@ -6,7 +6,7 @@
 // for the whole tile instead of once per row.
 //
 //   tile  : up to 16 rows listed explicitly (rows of one hash-density class, see
-//           mashgpu.cpp::run_compare) x a range of columns;
+//           host_compare.cpp::run_compare) x a range of columns;
 //   table : R*s entries {32-bit prefix, 16-bit tag = row<<idx_bits | index-in-row}, grouped
 //           by bucket = mulhi(prefix, scale_tile) (CSR layout, load ~0.65); inside a bucket
 //           one entry of every DISTINCT prefix comes first;

@@ -1,4 +1,4 @@
-// finish_internal.h — launch interface between mashgpu.cpp and finish.hip.
+// finish_internal.h — launch interface between host_compare.cpp and finish.hip.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

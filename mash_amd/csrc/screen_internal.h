@@ -1,4 +1,4 @@
-// screen_internal.h — launch interface between mashgpu.cpp and screen.hip.
+// screen_internal.h — launch interface between host_screen.cpp and screen.hip.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

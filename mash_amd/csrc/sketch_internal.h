@@ -1,4 +1,4 @@
-// sketch_internal.h — launch interface between the C-ABI layer (mashgpu.cpp) and
+// sketch_internal.h — launch interface between the C-ABI layer (host_sketch.cpp) and
 // the sketch kernels (sketch.hip).
 #pragma once
 #include <hip/hip_runtime.h>

@@ -1293,7 +1293,7 @@ def test_compare_rect_and_golden_dist(eng, oracle, golden_dir):
 @pytest.mark.parametrize("n,s,nq", [(6001, 1000, 1), (6001, 1000, 3), (6001, 1000, 40), (70001, 64, 1), (70001, 64, 5)])
 def test_compare_few_queries_against_many_references(eng, oracle, n, s, nq):
     """The serving shape (a launch with few row tiles) cuts the columns into finer chunks
-    (mashgpu.cpp::run_compare); chunk boundaries must not show in the result."""
+    (host_compare.cpp::run_compare); chunk boundaries must not show in the result."""
     table, nhash, lengths = synth.clustered_sketches(n + nq, s, clusters=max(1, n // 50), seed=n + nq,
                                                      pool=int(1.5 * s), private=int(0.4 * s))
     ref = eng.table_upload(table[:n], nhash[:n], lengths[:n])
