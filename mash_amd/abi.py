@@ -97,10 +97,6 @@ class ScreenSession:
     def __exit__(self, *exc):
         self.close()
 
-    def set_option(self, name, value):
-        """mg_ctx_set_option: a knob of this context (value None: back to the environment's setting)"""
-        self._check(self.lib.mg_ctx_set_option(self.ctx, name.encode(), None if value is None else str(value).encode()))
-
     def close(self):
         if self.h:
             self.eng.lib.mg_screen_free(self.h)
@@ -582,6 +578,10 @@ class MashGpu:
         self.ctx = h
         if stream is not None:
             self._check(self.lib.mg_ctx_set_stream(self.ctx, C.c_void_p(stream)))
+
+    def set_option(self, name, value):
+        """mg_ctx_set_option: a knob of this context (value None: back to the environment's setting)"""
+        self._check(self.lib.mg_ctx_set_option(self.ctx, name.encode(), None if value is None else str(value).encode()))
 
     def close(self):
         if self.ctx:
