@@ -588,7 +588,14 @@ static int sketch_packed_impl(mg_ctx *ctx, const mg_params *p, const uint8_t *pa
         if (copy_err != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("mg_sketch_packed: H2D copy failed: ") + hipGetErrorString(copy_err));
         std::thread next;
         hipError_t next_err = hipSuccess;
-        if (host_input && c + 1 < pieces.size()) next = std::thread(copy_piece, std::cref(pieces[c + 1]), (int)((c + 1) & 1), &next_err);
+        bool next_copied_here = false;
+        if (host_input && c + 1 < pieces.size()) {
+            try {
+                next = std::thread(copy_piece, std::cref(pieces[c + 1]), (int)((c + 1) & 1), &next_err);
+            } catch (const std::system_error &) {
+                next_copied_here = true;                     // no thread to be had: the copy follows this piece, unoverlapped
+            }
+        }
         struct Join { std::thread &t; ~Join() { if (t.joinable()) t.join(); } } join{next};
         const uint64_t len = q.b1 - q.b0;
         const uint8_t *src_pk, *src_mk;
@@ -611,6 +618,7 @@ static int sketch_packed_impl(mg_ctx *ctx, const mg_params *p, const uint8_t *pa
                                        d_counts ? d_counts + q.i0 * s : nullptr, nullptr);
         if (rc != MG_OK) return rc;
         if (next.joinable()) next.join();
+        if (next_copied_here) copy_piece(pieces[c + 1], (int)((c + 1) & 1), &next_err);
         copy_err = next_err;
     }
     return MG_OK;
