@@ -252,3 +252,84 @@ def test_pack_mapping_of_candidates_to_lanes(pack_min):
                         assert slot in distinct
         for r in range(nrows):
             assert np.all(seen[r] == 1), (trial, r)
+
+
+# ---- the index's sort on the values' leading bits (sp_tie_find / sp_tie_segments / sp_tie_repair_kernel) ----
+
+def sort_on_leading_bits(keys, idx, begin_bit, walk=1 << 16, max_breaks=1 << 16, max_values=64):
+    """What sparse_build_index does when begin_bit > 0, step for step: a STABLE sort that looks at bits >= begin_bit only,
+    the breaks between two different values of one prefix, the segment of every FIRST break (walked to both ends), and
+    each segment rewritten by full value -- smallest first, entries of one value in the order the sort left them.
+    Returns (keys, idx, overflow): overflow = the caller sorts again on every bit."""
+    order = np.argsort(keys >> np.uint64(begin_bit), kind="stable")
+    k, ix = keys[order].copy(), idx[order].copy()
+    E = len(k)
+    pre = k >> np.uint64(begin_bit)
+    breaks = [p for p in range(1, E) if pre[p] == pre[p - 1] and k[p] != k[p - 1]]
+    if len(breaks) > max_breaks:
+        return k, ix, True
+    segs = []
+    for p in breaks:
+        kp = k[p - 1]
+        q, first = p - 1, True
+        while q > 0 and pre[q - 1] == pre[p]:
+            if k[q - 1] != kp:
+                first = False                               # an earlier break of the same segment does the work
+                break
+            q -= 1
+            if p - q > walk:
+                return k, ix, True
+        if not first:
+            continue
+        e = p
+        while e < E and pre[e] == pre[p]:
+            e += 1
+            if e - p > walk:
+                return k, ix, True
+        segs.append((q, e))
+    out_k, out_i = k.copy(), ix.copy()
+    for s0, s1 in segs:
+        vals = np.unique(k[s0:s1])
+        if len(vals) > max_values:
+            return k, ix, True
+        w = s0
+        for v in vals:                                      # ascending; entries of one value in their present order
+            hit = np.flatnonzero(k[s0:s1] == v) + s0
+            out_k[w:w + len(hit)] = v
+            out_i[w:w + len(hit)] = ix[hit]
+            w += len(hit)
+        assert w == s1
+    return out_k, out_i, False
+
+
+@pytest.mark.parametrize("bits_kept", [4, 8, 12, 20, 40])
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_sort_on_leading_bits_with_tie_repair_is_the_stable_full_sort(seed, bits_kept):
+    """rows of ascending values, many values shared (runs of equal keys beside ties), some packed into one prefix"""
+    rng = np.random.default_rng(seed)
+    end_bit = 44
+    pool = rng.integers(1, 1 << end_bit, size=300).astype(np.uint64)
+    pool[:40] = (pool[0] & ~np.uint64(0xFFF)) + np.arange(40, dtype=np.uint64) * np.uint64(3)        # forty values, one prefix at >= 12 bits
+    rows = [np.unique(rng.choice(pool, size=int(rng.integers(5, 60)))) for _ in range(50)]
+    keys = np.concatenate(rows)
+    idx = np.concatenate([np.arange(len(r), dtype=np.int64) + 64 * i for i, r in enumerate(rows)])   # row * stride + position: ascends
+    full = np.argsort(keys, kind="stable")
+    begin_bit = end_bit - bits_kept
+    k, ix, overflow = sort_on_leading_bits(keys, idx, begin_bit)
+    if overflow:
+        assert bits_kept <= 8                               # too few bits for this table: every bit is sorted instead
+        return
+    assert np.array_equal(k, keys[full]) and np.array_equal(ix, idx[full])
+    # (rows ascend inside a value: what discovery's "rows below mine" relies on)
+    same = k[1:] == k[:-1]
+    assert np.all(ix[1:][same] > ix[:-1][same])
+
+
+def test_sort_on_leading_bits_gives_up_on_long_or_crowded_segments():
+    keys = np.arange(1, 200, dtype=np.uint64)               # 199 values, one prefix at begin_bit 8: more than 64 in a segment
+    idx = np.arange(len(keys), dtype=np.int64)
+    assert sort_on_leading_bits(keys[::-1].copy(), idx, 8)[2] is True
+    two = np.array([5] * 50 + [4] * 50, dtype=np.uint64)    # two values, the walk cut short
+    assert sort_on_leading_bits(two, np.arange(100, dtype=np.int64), 8, walk=16)[2] is True
+    k, ix, ov = sort_on_leading_bits(two, np.arange(100, dtype=np.int64), 8)
+    assert not ov and np.array_equal(k, np.sort(two)) and np.array_equal(ix, np.concatenate([np.arange(50, 100), np.arange(50)]))
