@@ -1,8 +1,10 @@
 // pack_bases.cpp -- host side of the packed nucleotide transport (include/mashgpu.h: mg_pack_bases; the device side is
 // ingest.hip).  Plain C++, no device code: what a parse thread runs over the bytes kseq hands it (kseq.h:171-208) before
 // they cross PCIe.  Eight bases per step as one 64-bit word: case fold, four byte-wise comparisons, the 2-bit codes
-// gathered by shifts.
+// gathered by shifts; 32 bases per step where the host has AVX2 + BMI2 (MASHGPU_PACK_PORTABLE=1 in the environment of the
+// process keeps the portable steps: the tests run both).
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/mashgpu.h"
@@ -34,6 +36,35 @@ inline Packed8 pack8(uint64_t x, bool fold)
     return {(uint16_t)t, inv};
 }
 
+#if defined(__x86_64__)
+#include <immintrin.h>
+// 32 bases per step on hosts with AVX2 + BMI2 (chosen at run time; the 64-bit steps above remain the portable form and
+// do the tail): byte-wise compares for the four letters, movemask for the invalid bits, pext for the code bits
+__attribute__((target("avx2,bmi2"))) uint64_t pack_avx2(const uint8_t *ascii, uint64_t groups32, bool fold, uint8_t *packed,
+                                                         uint8_t *invalid_mask)
+{
+    const __m256i fold_mask = _mm256_set1_epi8(fold ? (char)0xDF : (char)0xFF);
+    const __m256i cA = _mm256_set1_epi8('A'), cC = _mm256_set1_epi8('C'), cG = _mm256_set1_epi8('G'), cT = _mm256_set1_epi8('T');
+    uint64_t ninv = 0;
+    for (uint64_t g = 0; g < groups32; g++) {
+        const __m256i x = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(ascii + 32u * g));
+        const __m256i u = _mm256_and_si256(x, fold_mask);
+        const __m256i ok = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(u, cA), _mm256_cmpeq_epi8(u, cC)),
+                                           _mm256_or_si256(_mm256_cmpeq_epi8(u, cG), _mm256_cmpeq_epi8(u, cT)));
+        const uint32_t inv = ~(uint32_t)_mm256_movemask_epi8(ok);
+        memcpy(invalid_mask + 4u * g, &inv, 4);
+        ninv += (uint64_t)__builtin_popcount(inv);
+        alignas(32) uint64_t w[4];
+        _mm256_store_si256(reinterpret_cast<__m256i *>(w), u);
+        for (int q = 0; q < 4; q++) {                       // bits 1..2 of every byte: the code
+            const uint16_t c = (uint16_t)_pext_u64(w[q], 0x0606060606060606ull);
+            memcpy(packed + 8u * g + 2u * q, &c, 2);
+        }
+    }
+    return ninv;
+}
+#endif
+
 }  // namespace
 
 extern "C" {
@@ -48,7 +79,15 @@ int mg_pack_bases(const uint8_t *ascii, uint64_t nbases, int preserve_case, uint
     const bool fold = !preserve_case;
     uint64_t ninv = 0;
     const uint64_t full = nbases / 8u;
-    for (uint64_t g = 0; g < full; g++) {
+    uint64_t g0 = 0;
+#if defined(__x86_64__)
+    static const bool wide = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2") && !getenv("MASHGPU_PACK_PORTABLE");
+    if (wide) {
+        ninv += pack_avx2(ascii, nbases / 32u, fold, packed, invalid_mask);
+        g0 = (nbases / 32u) * 4u;
+    }
+#endif
+    for (uint64_t g = g0; g < full; g++) {
         uint64_t x;
         memcpy(&x, ascii + 8u * g, 8);                      // (little-endian hosts: byte i of the input is byte i of the word)
         const Packed8 r = pack8(x, fold);

@@ -54,3 +54,23 @@ def test_pack_bases_ranges_side_by_side():
     one = abi.pack_bases(bases, False)
     many = abi.pack_bases(bases, False, threads=5)
     assert np.array_equal(one[0], many[0]) and np.array_equal(one[1], many[1]) and one[2] == many[2]
+
+
+def test_pack_bases_portable_and_wide_steps_agree():
+    """hosts with AVX2 + BMI2 pack 32 bases per step; MASHGPU_PACK_PORTABLE=1 (read once per process) keeps the 64-bit
+    steps: both processes must produce the same bytes"""
+    import hashlib, os, subprocess, sys
+    code = ("import numpy as np, hashlib, sys; sys.path.insert(0, %r); from mash_amd import abi;"
+            "rng = np.random.default_rng(5); a = np.frombuffer(%r, dtype=np.uint8);"
+            "b = rng.choice(a, size=100003).astype(np.uint8);"
+            "h = hashlib.sha256();"
+            "[h.update(x.tobytes()) for pc in (False, True) for x in abi.pack_bases(b, pc)[:2]];"
+            "print(h.hexdigest(), abi.pack_bases(b)[2])") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ALPHA.tobytes())
+    outs = []
+    for portable in ("", "1"):
+        env = dict(os.environ)
+        env.pop("MASHGPU_PACK_PORTABLE", None)
+        if portable:
+            env["MASHGPU_PACK_PORTABLE"] = "1"
+        outs.append(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.strip())
+    assert outs[0] == outs[1] and len(outs[0].split()) == 2
