@@ -638,10 +638,14 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
     }
     uint64_t E64 = 0, maxv = 0;
     sp->off_host.resize(n + 1);
+    double dens[65] = {0};                                  // by bit length of a row's largest hash: values per unit of the hash range
     for (uint64_t i = 0; i < n; i++) {
         sp->off_host[i] = (uint32_t)E64;
         const uint64_t c = cnt_true[i];
-        if (rep.empty() || rep[i] == i) E64 += c;           // copies stay out of the index
+        if (rep.empty() || rep[i] == i) {                   // copies stay out of the index
+            E64 += c;
+            if (c) dens[64 - __builtin_clzll(lastv[i] | 1ull)] += (double)c / ((double)lastv[i] + 1.0);
+        }
         if (E64 >= (1ull << 31)) return unusable("2^31 entries or more");
         if (c) {
             // a real hash equal to the padding value would sort among the padding: keep the tile engine
@@ -659,7 +663,29 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
     sp->E = E;
     const uint32_t end_bit = (uint32_t)(64 - __builtin_clzll(maxv | 1ull));
     // transient buffers (back to the pool at the end of this function, in stream order)
-    const uint32_t sort_begin_bit = mg::sparse_sort_begin_bit(E, end_bit, ctx_opt(ctx, "MASHGPU_SPARSE_SORT_BITS"), ctx_opt(ctx, "MASHGPU_SPARSE_SORT_ALL_BITS") != nullptr);
+    // The sort looks at the values' leading bits only (compare_sparse.hip: sparse_sort_begin_bit sizes that for values spread
+    // evenly below the largest one).  A collection of genomes of many sizes is not spread evenly: a row's s smallest hashes
+    // fill [0, its largest hash], so the low end of the range holds the values of every row and the high end those of the
+    // small genomes only.  Where the values are dense they need more bits to be told apart: the expected number of pairs
+    // of different values in one bucket of 2^b is 2^b / 2 x the integral of the squared density, taken here from the rows'
+    // largest hashes (by bit length); b is chosen for 2^13 of them at most, and never above the even-spread rule.
+    uint32_t sort_begin_bit = mg::sparse_sort_begin_bit(E, end_bit, ctx_opt(ctx, "MASHGPU_SPARSE_SORT_BITS"), ctx_opt(ctx, "MASHGPU_SPARSE_SORT_ALL_BITS") != nullptr);
+    if (sort_begin_bit > 0 && !ctx_opt(ctx, "MASHGPU_SPARSE_SORT_BITS")) {
+        double above = 0.0, integral = 0.0;                 // density of the rows reaching bit length b and beyond; sum of width x density^2
+        for (int b = 64; b >= 1; b--) {
+            above += dens[b];
+            integral += std::ldexp(1.0, b - 1) * above * above;
+        }
+        uint32_t b_est = 0;
+        if (integral > 0.0 && std::isfinite(integral)) {
+            const double lg = std::log2(16384.0 / integral);      // 2^b / 2 x integral <= 2^13
+            b_est = lg <= 0.0 ? 0u : lg >= 63.0 ? 63u : (uint32_t)lg;
+        }
+        if (b_est < sort_begin_bit) {
+            const uint32_t passes = (end_bit - b_est + 7u) / 8u;   // whole passes of 8 bits: every bit of a pass that is paid for is used
+            sort_begin_bit = (passes >= (end_bit + 7u) / 8u || passes * 8u >= end_bit) ? 0u : end_bit - passes * 8u;      // (0: no pass saved)
+        }
+    }
     const size_t temp_bytes = std::max(mg::sparse_sort_temp_bytes(E, end_bit, sort_begin_bit),
                                        std::max(mg::sparse_order_temp_bytes((uint32_t)n), mg::sparse_order_slice_temp_bytes((uint32_t)n)));
     DevBuf<unsigned char> temp(ctx);

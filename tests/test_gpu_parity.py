@@ -954,6 +954,46 @@ def test_ctx_options_override_the_environment(eng, oracle, monkeypatch):
         eng.set_option("MASHGPU_COMPARE_KERNEL", None)
 
 
+def test_compare_sparse_index_of_a_collection_of_many_genome_sizes(eng, monkeypatch):
+    """A table large enough for the index's sort on leading bits (>= 2^22 entries) whose values are NOT spread evenly:
+    nine rows in ten keep their hashes below 2^44 (large genomes), the tenth reaches 2^58 -- the low end of the range is
+    a thousand times denser than the even-spread rule assumes; the number of bits comes from the rows' largest hashes
+    (host_compare.cpp).  The index engine == the generic kernel on every pair, with the default choice, with far too few
+    bits (thousands of ties, then the fallback) and with every bit sorted."""
+    rng = np.random.default_rng(12)
+    n, s = 4400, 1000
+    pools = [np.sort(rng.choice(np.arange(1, 1 << 22, dtype=np.uint64), 1500, replace=False)) << np.uint64(22) for _ in range(40)]
+    table = np.zeros((n, s), dtype=np.uint64)
+    for i in range(n):
+        if i % 10 == 9:
+            row = np.unique(rng.integers(1, 1 << 58, size=s + 16).astype(np.uint64))[:s]
+        else:
+            own = rng.choice(pools[i % 40], size=800, replace=False)
+            priv = rng.integers(1, 1 << 44, size=260).astype(np.uint64)
+            row = np.unique(np.concatenate([own, priv]))[:s]
+        assert len(row) == s
+        table[i] = row
+    nhash = np.full(n, s, dtype=np.uint32)
+    lengths = np.full(n, 10 ** 6, dtype=np.uint64)
+    monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", "generic")
+    t = eng.table_upload(table, nhash, lengths)
+    want = eng.compare_tri_host(t)
+    t.free()
+    assert int(want["numer"].max()) > 100                   # (rows of one pool share hundreds of values)
+    monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", "sparse")
+    for knob, value in ((None, None), ("MASHGPU_SPARSE_SORT_BITS", "24"), ("MASHGPU_SPARSE_SORT_ALL_BITS", "1")):
+        if knob:
+            eng.set_option(knob, value)
+        try:
+            t = eng.table_upload(table, nhash, lengths)
+            got = eng.compare_tri_host(t)
+            t.free()
+        finally:
+            if knob:
+                eng.set_option(knob, None)
+        assert got.tobytes() == want.tobytes(), knob
+
+
 def test_table_invalidate_after_the_buffers_changed(eng, oracle, monkeypatch):
     """mg_table_invalidate: a wrapped table whose buffers were refilled is answered from the NEW contents -- index, plans,
     classes of copies, short rows all rebuilt (first table: clusters; second: other values, some rows short, some
