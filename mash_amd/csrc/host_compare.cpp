@@ -1,5 +1,6 @@
 // host_compare.cpp -- the compare entry points: tile engine, inverted-index engine, finishing, thresholded and list outputs
 #include "host_internal.h"
+#include "sort_bits.h"
 
 /* ------------------------------------------------------------------ comparing */
 
@@ -667,25 +668,10 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
     // evenly below the largest one).  A collection of genomes of many sizes is not spread evenly: a row's s smallest hashes
     // fill [0, its largest hash], so the low end of the range holds the values of every row and the high end those of the
     // small genomes only.  Where the values are dense they need more bits to be told apart: the expected number of pairs
-    // of different values in one bucket of 2^b is 2^b / 2 x the integral of the squared density, taken here from the rows'
-    // largest hashes (by bit length); b is chosen for 2^13 of them at most, and never above the even-spread rule.
+    // of different values in one bucket of 2^b is 2^b / 2 x the integral of the squared density, taken from the rows'
+    // largest hashes (by bit length); b is chosen for 2^13 of them at most, and never above the even-spread rule (sort_bits.h).
     uint32_t sort_begin_bit = mg::sparse_sort_begin_bit(E, end_bit, ctx_opt(ctx, "MASHGPU_SPARSE_SORT_BITS"), ctx_opt(ctx, "MASHGPU_SPARSE_SORT_ALL_BITS") != nullptr);
-    if (sort_begin_bit > 0 && !ctx_opt(ctx, "MASHGPU_SPARSE_SORT_BITS")) {
-        double above = 0.0, integral = 0.0;                 // density of the rows reaching bit length b and beyond; sum of width x density^2
-        for (int b = 64; b >= 1; b--) {
-            above += dens[b];
-            integral += std::ldexp(1.0, b - 1) * above * above;
-        }
-        uint32_t b_est = 0;
-        if (integral > 0.0 && std::isfinite(integral)) {
-            const double lg = std::log2(16384.0 / integral);      // 2^b / 2 x integral <= 2^13
-            b_est = lg <= 0.0 ? 0u : lg >= 63.0 ? 63u : (uint32_t)lg;
-        }
-        if (b_est < sort_begin_bit) {
-            const uint32_t passes = (end_bit - b_est + 7u) / 8u;   // whole passes of 8 bits: every bit of a pass that is paid for is used
-            sort_begin_bit = (passes >= (end_bit + 7u) / 8u || passes * 8u >= end_bit) ? 0u : end_bit - passes * 8u;      // (0: no pass saved)
-        }
-    }
+    if (sort_begin_bit > 0 && !ctx_opt(ctx, "MASHGPU_SPARSE_SORT_BITS")) sort_begin_bit = mg::sort_begin_bit_from_density(dens, end_bit, sort_begin_bit);
     const size_t temp_bytes = std::max(mg::sparse_sort_temp_bytes(E, end_bit, sort_begin_bit),
                                        std::max(mg::sparse_order_temp_bytes((uint32_t)n), mg::sparse_order_slice_temp_bytes((uint32_t)n)));
     DevBuf<unsigned char> temp(ctx);
