@@ -134,17 +134,20 @@ def compact_roofline(r):
         return r
     return {"bound": r["bound"], "kernel": r["kernel"], "kernel_ms": r["kernel_ms"], "achieved": r["achieved"], "peak": r["peak"],
             "unit": r["unit"], "frac": r["frac"], "traffic": r["traffic"],
+            # the WHOLE step against the same roof: compulsory bytes (every pair written once + the table read
+            # once) / the timed step / the HBM peak; and what the per-table index costs of it
+            "step_frac": r.get("step_frac"), "index_ms": r.get("index_ms"),
             "pass": {"ms": r["pass"]["ms"], "phases_ms": {k: round(v["ms_per_pass"], 3) for k, v in r["phases"].items()},
                      "traffic_over_compulsory": r["pass"]["traffic_over_compulsory"],
                      "output_write_bound_frac": r["pass"]["output_write_bound_frac"]}}
 
 
-def cpu_baseline_compare(table_np, nhash_np, lengths_np, budget_s):
+def cpu_baseline_compare(table_np, nhash_np, lengths_np, budget_s, cores=None):
     """Reference compareSketches (incl. p-value) on the host cores, bounded sample:
     triangle rows of the first M sketches of the SAME table, M sized for ~budget_s."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import pyoracle
-    cores = min(os.cpu_count() or 1, 16)
+    cores = cores or min(os.cpu_count() or 1, 16)
     use_ref = pyoracle.ref_available()
     orc = pyoracle.Oracle(ref=use_ref)
     kspace = 4.0 ** K
@@ -259,6 +262,8 @@ def headline_of(result):
     if cb:
         h["cpu_baseline"] = {"value": _num(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
                              "sample": cb["sample"][:160]}
+        if result.get("cpu_baseline_by_cores"):
+            h["cpu_baseline"]["by_cores"] = {c: _num(v["value"]) for c, v in result["cpu_baseline_by_cores"].items()}
     sk, c5, scr, cli, br, hh = (result.get(k) or {} for k in ("sketch", "c5", "screen", "cli_e2e", "brackets", "host_to_host"))
     if "value" in sk:
         h["sketch_bp_s"] = _num(sk["value"])
@@ -503,11 +508,15 @@ def main():
         cold_step()
     barrier()
     dt = time.perf_counter() - t0
-    srcs = ("mash_amd/csrc/compare_sparse.hip", "mash_amd/csrc/compare_dense.hip", "mash_amd/csrc/compare_merged.hip", "mash_amd/csrc/compare_internal.h")
+    srcs = ("mash_amd/csrc/compare_sparse.hip", "mash_amd/csrc/compare_dense.hip", "mash_amd/csrc/compare_merged.hip", "mash_amd/csrc/compare_internal.h",
+            "mash_amd/csrc/index_build.hip")
     pmc = load_pmc("compare_c3_cold_pmc.json", *srcs) if (n == 100_000 and world == 1 and not dry) else None
     roofline = compare_roofline(eng, my_pairs, n, S, args.steps, pmc) if not dry else {"bound": "hbm", "dry": True}
     dt = max_over_ranks(dt)
     value = total_pairs * args.steps / dt
+    if not dry and "pass" in roofline:
+        roofline["step_frac"] = round(roofline["pass"]["compulsory_bytes"] / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)
+        roofline["index_ms"] = roofline["phases"].get("index", {}).get("ms_per_pass")
     # further passes over the same table (index and plan exist): the warm rate
     eng.prof_reset()
     barrier()
@@ -555,9 +564,14 @@ def main():
     # ------------------------------------------------------------------ cpu baseline (rank 0, N=1)
     if single and not args.no_cpu:
         m = min(n, 6000)
-        result["cpu_baseline"] = cpu_baseline_compare(
-            hashes[:m].cpu().numpy().view(np.uint64), nhash[:m].cpu().numpy().astype(np.uint32),
-            lengths[:m].cpu().numpy().astype(np.uint64), args.cpu_seconds)
+        # P = nproc (the box's CPU rate: `cpu_baseline`), P = 16 and P = 1 beside it
+        sub = (hashes[:m].cpu().numpy().view(np.uint64), nhash[:m].cpu().numpy().astype(np.uint32), lengths[:m].cpu().numpy().astype(np.uint64))
+        nproc = os.cpu_count() or 1
+        by = {}
+        for c in sorted({1, min(16, nproc), nproc}):
+            by[c] = cpu_baseline_compare(*sub, args.cpu_seconds / 3.0, cores=c)
+        result["cpu_baseline"] = by[nproc]
+        result["cpu_baseline_by_cores"] = {str(c): v for c, v in by.items()}
 
     # ------------------------------------------------------------------ SURVEY 8d brackets (N=1): the extremes of the merge
     # value = the per-table job (every step from an invalidated table), warm_value = further passes

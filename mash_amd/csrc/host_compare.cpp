@@ -1,5 +1,6 @@
 // host_compare.cpp -- the compare entry points: tile engine, inverted-index engine, finishing, thresholded and list outputs
 #include "host_internal.h"
+#include "index_build.h"
 #include "sort_bits.h"
 
 /* ------------------------------------------------------------------ comparing */
@@ -640,12 +641,16 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
     uint64_t E64 = 0, maxv = 0;
     sp->off_host.resize(n + 1);
     double dens[65] = {0};                                  // by bit length of a row's largest hash: values per unit of the hash range
+    double dens0 = 0;                                       // ... and all of them: the density where the table is densest (below every row's largest hash)
     for (uint64_t i = 0; i < n; i++) {
         sp->off_host[i] = (uint32_t)E64;
         const uint64_t c = cnt_true[i];
         if (rep.empty() || rep[i] == i) {                   // copies stay out of the index
             E64 += c;
-            if (c) dens[64 - __builtin_clzll(lastv[i] | 1ull)] += (double)c / ((double)lastv[i] + 1.0);
+            if (c) {
+                dens[64 - __builtin_clzll(lastv[i] | 1ull)] += (double)c / ((double)lastv[i] + 1.0);
+                dens0 += (double)c / ((double)lastv[i] + 1.0);
+            }
         }
         if (E64 >= (1ull << 31)) return unusable("2^31 entries or more");
         if (c) {
@@ -672,19 +677,27 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
     // largest hashes (by bit length); b is chosen for 2^13 of them at most, and never above the even-spread rule (sort_bits.h).
     uint32_t sort_begin_bit = mg::sparse_sort_begin_bit(E, end_bit, ctx_opt(ctx, "MASHGPU_SPARSE_SORT_BITS"), ctx_opt(ctx, "MASHGPU_SPARSE_SORT_ALL_BITS") != nullptr);
     if (sort_begin_bit > 0 && !ctx_opt(ctx, "MASHGPU_SPARSE_SORT_BITS")) sort_begin_bit = mg::sort_begin_bit_from_density(dens, end_bit, sort_begin_bit);
-    const size_t temp_bytes = std::max(mg::sparse_sort_temp_bytes(E, end_bit, sort_begin_bit),
-                                       std::max(mg::sparse_order_temp_bytes((uint32_t)n), mg::sparse_order_slice_temp_bytes((uint32_t)n)));
+    // How the index is built (MASHGPU_SPARSE_INDEX): "tiles" (default) -- index_build.hip: one partition pass over tiles of
+    // (512 rows x a window of buckets), an LDS sort per bucket, the images written back row segment by row segment; "sort" --
+    // rounds 3-4: rocPRIM's radix sort on the leading bits + tie repair + head scan + scattered write-back, also what a
+    // table takes that the tiles refuse (a bucket beyond the LDS: a value held by thousands of rows, values far from
+    // evenly spread); "verify" -- both, compared word by word on the device (tests).
+    const char *ix_mode = ctx_opt(ctx, "MASHGPU_SPARSE_INDEX");
+    const bool ix_verify = ix_mode && strcmp(ix_mode, "verify") == 0;
+    const bool ix_tiles = !ix_mode || strcmp(ix_mode, "sort") != 0;
+    const bool want_gs = !link.empty() && sp->copies == 0;   // (the dense groups' leader search reads every position's group start)
+    mg::IxPlan plan;
+    if (ix_tiles) plan = mg::index_plan((uint32_t)n, E, s, sp->rs, t->s, maxv, dens0, want_gs || ix_verify);
+    const size_t temp_bytes = std::max(mg::sparse_order_temp_bytes((uint32_t)n), mg::sparse_order_slice_temp_bytes((uint32_t)n));
     DevBuf<unsigned char> temp(ctx);
-    DevBuf<uint64_t> keys_a(ctx);
-    DevBuf<uint32_t> idx_a(ctx), idx_sorted(ctx), gs_of(ctx);
+    DevBuf<uint32_t> gs_of(ctx);
     DevBuf<unsigned long long> key64_a(ctx), key64_b(ctx);
-    struct Stat { unsigned long long shared; uint32_t max_group, groups, bad, tie_overflow; } h_stat = {0, 0, 0, 0, 0};
+    struct Stat { unsigned long long shared; uint32_t max_group, groups, bad, tie_overflow; uint32_t ixf[4]; } h_stat = {0, 0, 0, 0, 0, {0, 0, 0, 0}};
     DevBuf<Stat> d_stat(ctx);
-    DevBuf<unsigned char> d_slots(ctx), d_ties(ctx);
+    DevBuf<unsigned char> d_slots(ctx);
     const bool want_order = !ctx_opt(ctx, "MASHGPU_SPARSE_NO_ORDER");
-    bool ok = temp.alloc(std::max<size_t>(temp_bytes, 16)) == hipSuccess && keys_a.alloc(E) == hipSuccess && idx_a.alloc(E) == hipSuccess &&
-              idx_sorted.alloc(E) == hipSuccess && gs_of.alloc(E) == hipSuccess && d_stat.alloc(1) == hipSuccess &&
-              d_slots.alloc(mg::sparse_stat_scratch_bytes()) == hipSuccess && d_ties.alloc(mg::sparse_tie_scratch_bytes()) == hipSuccess &&
+    bool ok = temp.alloc(std::max<size_t>(temp_bytes, 16)) == hipSuccess && gs_of.alloc(E) == hipSuccess && d_stat.alloc(1) == hipSuccess &&
+              d_slots.alloc(std::max(mg::sparse_stat_scratch_bytes(), mg::index_stat_scratch_bytes())) == hipSuccess &&
               (!want_order || (key64_a.alloc(n) == hipSuccess && key64_b.alloc(n) == hipSuccess));
     // retained buffers
     auto take = [&](auto **p, size_t count) {
@@ -715,21 +728,105 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
         e = hipMemcpyAsync(sp->off, sp->off_host.data(), (n + 1) * 4, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess && nshort) e = hipMemcpyAsync(sp->short_rows, sp->short_rows_host.data(), nshort * 4, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess && nshort) e = hipMemcpyAsync(sp->short_cnt, short_cnt.data(), nshort * 4, hipMemcpyHostToDevice, ctx->stream);
-        // (the sort looks at the values' leading bits only and repairs the few ties; a table that defeats that is sorted again, on every bit)
-        for (uint32_t begin_bit = sort_begin_bit;; begin_bit = 0) {
-            if (e == hipSuccess) e = hipMemsetAsync(d_stat, 0, sizeof(Stat), ctx->stream);
+    }
+    // visiting order of the rows (by the run of their first shared value, larger rows first inside a run), the statistics, one wait
+    auto finish_build = [&]() {
+        if (e == hipSuccess && want_order)
+            e = mg::launch_sparse_row_order(sp->off, sp->code_img, sp->gend, sp->rep, (uint32_t)n, sp->rs, temp, temp_bytes, key64_a, key64_b,
+                                            sp->order, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&h_stat, d_stat, sizeof(Stat), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    };
+    bool built = false;
+    if (ok && e == hipSuccess && plan.ok) {
+        DevBuf<unsigned char> d_lb(ctx), d_cnt(ctx), d_start(ctx), d_pk(ctx), d_tc(ctx);
+        if (d_lb.alloc(plan.lb_bytes) == hipSuccess && d_cnt.alloc(plan.cnt_bytes) == hipSuccess && d_start.alloc(plan.start_bytes) == hipSuccess &&
+            d_pk.alloc(plan.pk_bytes) == hipSuccess && d_tc.alloc(plan.tc_bytes) == hipSuccess) {
+            e = hipMemsetAsync(d_stat, 0, sizeof(Stat), ctx->stream);
             if (e == hipSuccess)
-                e = mg::sparse_build_index(H, t->s, sp->off, (uint32_t)n, E, sp->rs, end_bit, temp, temp_bytes, keys_a, idx_a,
-                                           sp->keys_sorted, idx_sorted, /*head=*/idx_a, gs_of, sp->sorted_rows, sp->gend, sp->code_img, sp->pos_img,
-                                           d_slots, begin_bit, d_ties, &d_stat.p->shared, &d_stat.p->max_group, &d_stat.p->groups, &d_stat.p->bad,
-                                           &d_stat.p->tie_overflow, ctx->stream);
-            // visiting order of the rows: by the run of their first shared value, larger rows first inside a run
-            if (e == hipSuccess && want_order)
-                e = mg::launch_sparse_row_order(sp->off, sp->code_img, sp->gend, sp->rep, (uint32_t)n, sp->rs, temp, temp_bytes, key64_a, key64_b,
-                                                sp->order, ctx->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(&h_stat, d_stat, sizeof(Stat), hipMemcpyDeviceToHost, ctx->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-            if (e != hipSuccess || !h_stat.tie_overflow || begin_bit == 0) break;
+                e = mg::index_build(plan, H, sp->off, d_lb, d_cnt, d_start, d_pk, d_tc, sp->keys_sorted, sp->sorted_rows, sp->gend, gs_of, sp->code_img,
+                                    sp->pos_img, d_slots, &d_stat.p->shared, &d_stat.p->max_group, &d_stat.p->groups, d_stat.p->ixf, ctx->stream);
+            finish_build();
+            built = e == hipSuccess && !h_stat.ixf[mg::IXF_OVERSIZE] && !h_stat.ixf[mg::IXF_DEGENERATE];
+            if (ctx_opt(ctx, "MASHGPU_SPARSE_DBG"))
+                fprintf(stderr, "compare sparse: index by tiles: shift %u, %u buckets (%u per window, %u windows), fullest %u%s%s\n", plan.g.shift, plan.g.Bp,
+                        plan.g.BW, plan.g.NW, h_stat.ixf[mg::IXF_MAXBUCKET], h_stat.ixf[mg::IXF_OVERSIZE] ? " -- a bucket beyond the LDS: sorted instead" : "",
+                        h_stat.ixf[mg::IXF_DEGENERATE] ? " -- a bucket of clumped values: sorted instead" : "");
+        } else {
+            (void)hipGetLastError();
+        }
+    } else if (ix_tiles && ctx_opt(ctx, "MASHGPU_SPARSE_DBG")) {
+        fprintf(stderr, "compare sparse: index by tiles refused: %s\n", plan.why);
+    }
+    sp->by_tiles = built;
+    if (ix_verify && !built && ok && e == hipSuccess && !ctx_opt(ctx, "MASHGPU_SPARSE_INDEX_MAY_REFUSE"))
+        return fail(ctx, MG_ERR_INVALID, std::string("index verify: the tile build refused this table (") + (plan.ok ? "bucket flags" : plan.why) + ")");
+    if (ok && e == hipSuccess && (!built || ix_verify)) {
+        // ---- the general way: every entry through a radix sort on the values' leading bits (compare_sparse.hip)
+        const size_t sort_bytes = mg::sparse_sort_temp_bytes(E, end_bit, sort_begin_bit);
+        DevBuf<unsigned char> temp_sort(ctx), d_ties(ctx);
+        DevBuf<uint64_t> keys_a(ctx), v_keys(ctx);
+        DevBuf<uint32_t> idx_a(ctx), idx_sorted(ctx), v_rows(ctx), v_gend(ctx), v_gs(ctx), v_code(ctx), v_pos(ctx);
+        DevBuf<unsigned long long> d_diff(ctx);
+        bool ok2 = temp_sort.alloc(std::max<size_t>(sort_bytes, 16)) == hipSuccess && keys_a.alloc(E) == hipSuccess && idx_a.alloc(E) == hipSuccess &&
+                   idx_sorted.alloc(E) == hipSuccess && d_ties.alloc(mg::sparse_tie_scratch_bytes()) == hipSuccess;
+        if (ok2 && built)                                   // (verify: the second build goes into arrays of its own)
+            ok2 = v_keys.alloc(E) == hipSuccess && v_rows.alloc(E) == hipSuccess && v_gend.alloc(E) == hipSuccess && v_gs.alloc(E) == hipSuccess &&
+                  v_code.alloc((size_t)n * sp->rs + 64) == hipSuccess && v_pos.alloc((size_t)n * sp->rs) == hipSuccess && d_diff.alloc(16) == hipSuccess;
+        if (!ok2) {
+            (void)hipGetLastError();
+            ok = false;
+        } else {
+            const Stat tiles_stat = h_stat;
+            uint64_t *o_keys = built ? v_keys.p : sp->keys_sorted;
+            uint32_t *o_rows = built ? v_rows.p : sp->sorted_rows, *o_gend = built ? v_gend.p : sp->gend, *o_gs = built ? v_gs.p : gs_of.p,
+                     *o_code = built ? v_code.p : sp->code_img, *o_pos = built ? v_pos.p : sp->pos_img;
+            // (the sort looks at the values' leading bits only and repairs the few ties; a table that defeats that is sorted again, on every bit)
+            for (uint32_t begin_bit = sort_begin_bit;; begin_bit = 0) {
+                if (e == hipSuccess) e = hipMemsetAsync(d_stat, 0, sizeof(Stat), ctx->stream);
+                if (e == hipSuccess)
+                    e = mg::sparse_build_index(H, t->s, sp->off, (uint32_t)n, E, sp->rs, end_bit, temp_sort, sort_bytes, keys_a, idx_a, o_keys, idx_sorted,
+                                               /*head=*/idx_a, o_gs, o_rows, o_gend, o_code, o_pos, d_slots, begin_bit, d_ties, &d_stat.p->shared,
+                                               &d_stat.p->max_group, &d_stat.p->groups, &d_stat.p->bad, &d_stat.p->tie_overflow, ctx->stream);
+                if (built) {
+                    if (e == hipSuccess) e = hipMemcpyAsync(&h_stat, d_stat, sizeof(Stat), hipMemcpyDeviceToHost, ctx->stream);
+                    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+                } else {
+                    finish_build();
+                }
+                if (e != hipSuccess || !h_stat.tie_overflow || begin_bit == 0) break;
+            }
+            if (built && e == hipSuccess) {
+                // every array of the two builds, word by word
+                unsigned long long diff[16];
+                for (int k = 0; k < 8; k++) { diff[2 * k] = 0; diff[2 * k + 1] = ~0ull; }
+                e = hipMemcpyAsync(d_diff, diff, sizeof diff, hipMemcpyHostToDevice, ctx->stream);
+                const uint64_t img = (uint64_t)n * sp->rs;
+                if (e == hipSuccess) e = mg::index_verify_words((const uint32_t *)sp->keys_sorted, (const uint32_t *)v_keys.p, nullptr, 0, 2ull * E, d_diff.p + 0, ctx->stream);
+                if (e == hipSuccess) e = mg::index_verify_words(sp->sorted_rows, v_rows, nullptr, 0, E, d_diff.p + 2, ctx->stream);
+                if (e == hipSuccess) e = mg::index_verify_words(gs_of, v_gs, nullptr, 0, E, d_diff.p + 4, ctx->stream);
+                if (e == hipSuccess) e = mg::index_verify_words(sp->gend, v_gend, v_gs, 1, E, d_diff.p + 6, ctx->stream);
+                if (e == hipSuccess) e = mg::index_verify_words(sp->code_img, v_code, nullptr, 0, img, d_diff.p + 8, ctx->stream);
+                if (e == hipSuccess) e = mg::index_verify_words(sp->pos_img, v_pos, v_code, 2, img, d_diff.p + 10, ctx->stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(diff, d_diff, sizeof diff, hipMemcpyDeviceToHost, ctx->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+                if (e == hipSuccess) {
+                    static const char *names[6] = {"values (32-bit words)", "rows", "group starts", "group ends", "code image", "position image"};
+                    std::string msg;
+                    for (int k = 0; k < 6; k++)
+                        if (diff[2 * k]) msg += std::string(msg.empty() ? "" : "; ") + names[k] + ": " + std::to_string(diff[2 * k]) + " differ, first at " + std::to_string(diff[2 * k + 1]);
+                    if (h_stat.shared != tiles_stat.shared || h_stat.max_group != tiles_stat.max_group || h_stat.groups != tiles_stat.groups)
+                        msg += std::string(msg.empty() ? "" : "; ") + "statistics: shared " + std::to_string(tiles_stat.shared) + " / " + std::to_string(h_stat.shared) +
+                               ", largest group " + std::to_string(tiles_stat.max_group) + " / " + std::to_string(h_stat.max_group) + ", groups " +
+                               std::to_string(tiles_stat.groups) + " / " + std::to_string(h_stat.groups);
+                    if (!msg.empty()) {
+                        char geom[160];
+                        snprintf(geom, sizeof geom, " [n %llu, E %u, shift %u, %u buckets, %u per window, %u windows]", (unsigned long long)n, E, plan.g.shift, plan.g.Bp, plan.g.BW, plan.g.NW);
+                        sp->usable = false;
+                        return fail(ctx, MG_ERR_INVALID, "index verify: tiles / sort -- " + msg + geom);
+                    }
+                }
+            }
         }
     }
     auto drop = [&]() {

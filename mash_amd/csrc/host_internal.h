@@ -125,6 +125,7 @@ struct mg_table {
         // index reads the reordered copy `phashes`, and every kernel that writes results maps rows back.  Only the plain
         // full-triangle job uses it (row ranges, rect and list jobs address table rows and take the other variant).
         bool clustered = false;
+        bool by_tiles = false;             // built by index_build.hip (tiles + bucket sorts), not by the general sort
         uint32_t *inv = nullptr;
         uint64_t *phashes = nullptr;
         // identical rows: rep[row] = first row of its class (nullptr: the table has no copies), classes of >= 2 rows

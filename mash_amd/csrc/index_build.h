@@ -1,0 +1,70 @@
+// index_build.h -- the inverted index of a sketch table, built by kernels that use what the table already is:
+// n ascending rows of (near-)uniformly spread hashes.  Interface between host_compare.cpp and index_build.hip.
+//
+// What the index is (unchanged since round 4, compare_sparse.hip): every (value, row) entry of the rows' first
+// min(nhash, s) hashes sorted by value, rows ascending inside a value; per sorted position the value and the row, at a
+// group's first position the group's end, and two images in the table's layout -- the code (2 x group start + shared
+// bit) and the entry's own sorted position.
+//
+// How it is built here (round 5; rounds 3-4: rocPRIM's radix sort in 5-7 passes + 4-byte scattered write-back):
+//   buckets   bucket(v) = v >> shift, about 2 500 - 5 000 entries each; a WINDOW is 2^k consecutive buckets;
+//   K0        per row the position at which every window starts (rows ascend: a row's entries of one window are contiguous);
+//   K1 + K2   entries per (block of 512 rows, bucket) -> where every bucket and every block's share of it starts;
+//   K3        a tile = (block of rows, window): the rows' segments are read, sorted by bucket in LDS (stable: by row, then
+//             position) and written as ONE contiguous piece per bucket -- a single pass replaces the radix passes, because a
+//             tile's entries fall into a few hundred buckets only.  An entry travels as one 64-bit word: its value's bits
+//             below the bucket | its row;
+//   K4        a workgroup per bucket sorts its entries by (value, row) in LDS (counting sort on the next 13 bits, then
+//             rank among the few entries that agree in them), finds the groups of equal values there -- no head flags, no
+//             scan, no tie repair over the whole index -- and writes values, rows, group ends and, in the order the
+//             entries ARRIVED in, {code, position};
+//   K5        the tiles again: the same stable sort tells every entry where K3 put it; {code, position} are read back
+//             from there and written into the images row segment by row segment (no 4-byte scattered stores).
+// A table that does not fit the assumptions (a bucket beyond the LDS capacity: a value held by thousands of rows, values
+// clumped far from uniform; too many buckets) raises a flag and the caller builds the index the old way.
+#pragma once
+#include <stdint.h>
+
+namespace mg {
+
+struct IxGeom {
+    uint32_t n, nblk, E;
+    uint32_t shift;       // bucket = value >> shift
+    uint32_t bw_log, BW;  // buckets per window (a power of two, at most IX_BW_MAX)
+    uint32_t NW, Bp;      // windows; buckets incl. the last window's padding (NW * BW)
+    uint32_t rb;          // bits of a row index in the packed word: word = (value's low `shift` bits) << rb | row
+    uint32_t npass;       // 4-bit passes of the tile's stable sort by bucket
+    uint32_t wgrp;        // tile order: groups of this many windows, inside a group block-major
+    uint32_t nseq;        // length of the tile sequence (incl. the windows past NW of the last group)
+    uint32_t rs;          // row stride of the images
+    uint32_t want_gs;     // 1: also write the group start of every sorted position (dense groups' leader search)
+    uint64_t stride;      // row stride of the table (entries)
+};
+
+struct IxPlan {
+    IxGeom g;
+    bool ok = false;
+    const char *why = "";
+    size_t lb_bytes = 0, cnt_bytes = 0, start_bytes = 0, pk_bytes = 0, tc_bytes = 0;     // scratch
+};
+
+// flags[] (device, 4 u32, zeroed by the caller): what stopped the build
+enum { IXF_OVERSIZE = 0, IXF_DEGENERATE = 1, IXF_MAXBUCKET = 2, IXF_RESERVED = 3 };
+
+// dens0: entries per unit of the hash range where the table is densest (sum over rows of count / (largest hash + 1))
+IxPlan index_plan(uint32_t n, uint32_t E, uint32_t s, uint32_t rs, uint64_t stride, uint64_t maxv, double dens0, bool want_gs);
+size_t index_stat_scratch_bytes();
+// All buffers are the caller's.  lb / cnt / start / pk / tc: scratch of the plan's sizes; the rest as sparse_build_index
+// (compare_internal.h) -- on return (stream order) the index arrays are complete unless flags say otherwise.
+// *incidences, *max_group, *groups, flags[4]: zeroed by the caller.
+hipError_t index_build(const IxPlan &plan, const uint64_t *hashes, const uint32_t *off, void *lb, void *cnt, void *start, void *pk, void *tc,
+                       uint64_t *keys_sorted, uint32_t *sorted_rows, uint32_t *gend, uint32_t *gs_of, uint32_t *code_img, uint32_t *pos_img,
+                       void *stat_scratch, unsigned long long *incidences, uint32_t *max_group, uint32_t *groups, uint32_t *flags,
+                       hipStream_t stream);
+
+// MASHGPU_SPARSE_INDEX=verify: out2[0] += words of a and b that differ, out2[1] = min(out2[1], the first such word);
+// mode 0: all words, 1: where cond[i] == i, 2: where cond[i] != 0xFFFFFFFF
+hipError_t index_verify_words(const uint32_t *a, const uint32_t *b, const uint32_t *cond, uint32_t mode, uint64_t count, unsigned long long *out2,
+                              hipStream_t stream);
+
+}  // namespace mg

@@ -1,0 +1,708 @@
+// index_build.hip -- gfx950: the inverted index of a sketch table without a general-purpose sort (see index_build.h for
+// the plan: window offsets, counts, one partition pass over tiles of (512 rows x a window of buckets), an LDS sort per
+// bucket that also finds the groups of equal values, and the tiles again to write the images back row segment by row segment).
+//
+// The kernels are written so that tools/hipemu/hipemu.h can run them on host threads (MG_HIP_EMU; tests/test_index_emu.py:
+// every array against a std::stable_sort statement of the index, also under ThreadSanitizer): a workgroup leaves a kernel as a
+// whole or not at all, wave operations sit in uniform control flow, and no step relies on the lock step of a wave.
+#ifdef MG_HIP_EMU
+#include "hipemu.h"
+#else
+#include <hip/hip_runtime.h>
+#define MG_DYN_SHARED(T, name)                                   \
+    extern __shared__ __align__(16) unsigned char name##_raw[]; \
+    T *name = reinterpret_cast<T *>(name##_raw)
+#endif
+#include <stdint.h>
+
+#include "index_build.h"
+
+namespace mg {
+
+constexpr uint32_t IX_RB = 512;                 // rows of a block of rows
+constexpr uint32_t IX_NT = 512;                 // work-items of the tile kernels (one per row of the block)
+constexpr uint32_t IX_M = 7;                    // entries a work-item owns in the tile's sort (odd: its strided LDS reads spread over the banks)
+constexpr uint32_t IX_PCAP = IX_NT * IX_M;      // entries of a tile sorted at a time (a larger tile is taken in pieces)
+constexpr uint32_t IX_LPR = 8;                  // lanes that read one row's segment
+constexpr uint32_t IX_BW_MAX = 512;             // buckets per window, at most
+constexpr uint32_t IX_CAP = 6144;               // entries of a bucket the LDS sort takes
+constexpr uint32_t IX_NT4 = 512;
+constexpr uint32_t IX_PER = IX_CAP / IX_NT4;    // 12 entries per work-item
+constexpr uint32_t IX_SUBBITS = 13;             // the counting sort's key: the next 13 bits below the bucket
+constexpr uint32_t IX_NSUB = 1u << IX_SUBBITS;
+constexpr uint32_t IX_MAXM = 48;                // entries that may agree in those bits before the bucket counts as degenerate
+constexpr double IX_TMAX = 5120.0;              // expected entries of the fullest bucket
+constexpr double IX_TILE_TARGET = 3072.0;       // expected entries of a tile
+constexpr uint32_t IX_STAT_SLOTS = 1024;
+
+struct IxStatSlot { unsigned long long inc; uint32_t max_group, groups; };
+
+// ------------------------------------------------------------------------------------------------
+// helpers
+
+// exclusive prefix sum over the workgroup (any whole number of waves up to 16); `part`: 16 u32 of LDS; two barriers inside
+__device__ __forceinline__ uint32_t ix_block_scan_sum(uint32_t x, uint32_t *part, uint32_t &total)
+{
+    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    uint32_t incl = x;
+#pragma unroll
+    for (uint32_t d = 1; d < 64u; d <<= 1) {
+        const uint32_t y = __shfl_up(incl, d);
+        if (lane >= d) incl += y;
+    }
+    if (lane == 63u) part[wid] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+    for (uint32_t k = 0; k < nw; k++) {
+        const uint32_t p = part[k];
+        if (k < wid) base += p;
+        tot += p;
+    }
+    __syncthreads();
+    total = tot;
+    return base + incl - x;
+}
+
+// exclusive prefix maximum over the workgroup (0 for the first work-item)
+__device__ __forceinline__ uint32_t ix_block_scan_max(uint32_t x, uint32_t *part)
+{
+    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    uint32_t incl = x;
+#pragma unroll
+    for (uint32_t d = 1; d < 64u; d <<= 1) {
+        const uint32_t y = __shfl_up(incl, d);
+        if (lane >= d && y > incl) incl = y;
+    }
+    if (lane == 63u) part[wid] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t k = 0; k < wid; k++) base = part[k] > base ? part[k] : base;
+    __syncthreads();
+    const uint32_t before = __shfl_up(incl, 1u);        // the inclusive maximum of the lane before
+    uint32_t ex = lane > 0 ? before : 0u;
+    return ex > base ? ex : base;
+}
+
+// The tiles in the order they are worked on: groups of `wgrp` windows, inside a group block-major, window-minor -- the
+// tiles that follow each other read neighbouring pieces of the same rows (K3) / write them (K5), and the tiles of
+// neighbouring blocks, whose pieces of a bucket are neighbours in memory, are a few tiles apart.  The hardware deals
+// workgroups to the eight XCDs round-robin: XCD x takes the x-th contiguous eighth of the sequence, so that what follows
+// each other meets in ONE L2.
+__device__ __forceinline__ bool ix_tile_id(const IxGeom &g, uint32_t &blk, uint32_t &w)
+{
+    const uint32_t per = gridDim.x >> 3;                  // (the launch has 8 x per workgroups)
+    const uint32_t q = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    if (q >= g.nseq) return false;
+    const uint32_t gsz = g.nblk * g.wgrp;
+    const uint32_t wg = q / gsz, rem = q - wg * gsz;
+    blk = rem / g.wgrp;
+    w = wg * g.wgrp + (rem - blk * g.wgrp);
+    return w < g.NW;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K0: lb[row][w] = the first position of the row whose value lies in window w or above (w = 0 .. NW; lb[row][NW] = count).
+// One wave per row.
+__global__ __launch_bounds__(256) void ix_window_offsets_kernel(IxGeom g, const uint64_t *H, const uint32_t *off, uint16_t *lb)
+{
+    const uint32_t row = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (row < g.n) {
+        const uint32_t cnt = off[row + 1] - off[row];
+        const uint64_t *src = H + (uint64_t)row * g.stride;
+        uint16_t *out = lb + (uint64_t)row * (g.NW + 1u);
+        const uint32_t wsh = g.shift + g.bw_log;
+        for (uint32_t p = lane; p < cnt; p += 64u) {
+            const int w = (int)(uint32_t)(src[p] >> wsh);
+            const int wp = p > 0 ? (int)(uint32_t)(src[p - 1] >> wsh) : -1;
+            for (int x = wp + 1; x <= w; x++) out[x] = (uint16_t)p;
+        }
+        const int wl = cnt > 0 ? (int)(uint32_t)(src[cnt - 1] >> wsh) : -1;
+        for (uint32_t x = (uint32_t)(wl + 1) + lane; x <= g.NW; x += 64u) out[x] = (uint16_t)cnt;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: cnt[blk][bucket] = entries of the block's rows in the bucket, for the buckets of the tile's window
+__global__ __launch_bounds__(IX_NT) void ix_tile_count_kernel(IxGeom g, const uint64_t *H, const uint16_t *lb, uint32_t *cnt)
+{
+    __shared__ uint32_t s_hist[IX_BW_MAX];
+    uint32_t blk = 0, w = 0;
+    if (!ix_tile_id(g, blk, w)) return;                  // uniform
+    const uint32_t tid = threadIdx.x;
+    const uint32_t row0 = blk * IX_RB, nrows = g.n - row0 < IX_RB ? g.n - row0 : IX_RB;
+    if (tid < g.BW) s_hist[tid] = 0;
+    __syncthreads();
+    for (uint32_t r = tid / IX_LPR; r < nrows; r += IX_NT / IX_LPR) {
+        const uint16_t *p = lb + (uint64_t)(row0 + r) * (g.NW + 1u) + w;
+        const uint32_t lo = p[0], hi = p[1];
+        const uint64_t *src = H + (uint64_t)(row0 + r) * g.stride;
+        for (uint32_t k = lo + tid % IX_LPR; k < hi; k += IX_LPR) atomicAdd(&s_hist[(uint32_t)(src[k] >> g.shift) & (g.BW - 1u)], 1u);
+    }
+    __syncthreads();
+    if (tid < g.BW) cnt[(uint64_t)blk * g.Bp + (uint64_t)w * g.BW + tid] = s_hist[tid];
+}
+
+// K2a: per bucket the blocks' counts become exclusive prefixes over the blocks; tot[bucket] = the bucket's entries
+__global__ __launch_bounds__(256) void ix_col_scan_kernel(IxGeom g, uint32_t *cnt, uint32_t *tot)
+{
+    const uint32_t b = blockIdx.x * 256u + threadIdx.x;
+    if (b < g.Bp) {
+        uint32_t run = 0;
+        for (uint32_t blk = 0; blk < g.nblk; blk++) {
+            uint32_t *p = cnt + (uint64_t)blk * g.Bp + b;
+            const uint32_t c = *p;
+            *p = run;
+            run += c;
+        }
+        tot[b] = run;
+    }
+}
+
+// K2b (one workgroup): start[b] = exclusive prefix of the buckets' entries (in place), start[Bp] = E; the fullest bucket
+__global__ __launch_bounds__(1024) void ix_bucket_scan_kernel(IxGeom g, uint32_t *start, uint32_t *flags)
+{
+    __shared__ uint32_t s_part[16], s_max[16];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (g.Bp + 1023u) / 1024u;
+    const uint32_t b0 = tid * per, b1 = b0 + per < g.Bp ? b0 + per : g.Bp;
+    uint32_t sum = 0, mx = 0;
+    for (uint32_t b = b0; b < b1; b++) {
+        const uint32_t c = start[b];
+        sum += c;
+        mx = c > mx ? c : mx;
+    }
+    uint32_t total = 0;
+    uint32_t run = ix_block_scan_sum(sum, s_part, total);
+    for (uint32_t b = b0; b < b1; b++) {
+        const uint32_t c = start[b];
+        start[b] = run;
+        run += c;
+    }
+    if (tid == 0) start[g.Bp] = total;
+#pragma unroll
+    for (uint32_t d = 32; d > 0; d >>= 1) {
+        const uint32_t o = __shfl_xor(mx, d);
+        mx = o > mx ? o : mx;
+    }
+    if ((tid & 63u) == 0) s_max[tid >> 6] = mx;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t m = 0;
+        for (uint32_t k = 0; k < 16u; k++) m = s_max[k] > m ? s_max[k] : m;
+        flags[IXF_MAXBUCKET] = m;
+        if (m > IX_CAP) flags[IXF_OVERSIZE] = 1u;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The tile's stable sort by bucket: src[0 .. np) holds (local bucket << 12 | index in the piece) in the order the entries were
+// read (row by row, positions ascending); LSD passes of 4 bits.  A work-item owns the entries [M t, M t + M) of the current
+// order and sixteen private counters, so the order inside a digit is kept without any ranking among lanes.
+// cnt: 16 x IX_NT u16 of LDS.  Returns the array that holds the result.  The caller has a barrier in front.
+__device__ __forceinline__ uint32_t *ix_tile_sort(uint32_t *src, uint32_t *dst, uint16_t *cnt, uint32_t *part, uint32_t np, uint32_t npass)
+{
+    const uint32_t tid = threadIdx.x, i0 = tid * IX_M;
+    for (uint32_t pass = 0; pass < npass; pass++) {
+        const uint32_t sh = 12u + 4u * pass;
+#pragma unroll
+        for (uint32_t d = 0; d < 16u; d++) cnt[d * IX_NT + tid] = 0;
+        uint32_t e[IX_M];
+#pragma unroll
+        for (uint32_t k = 0; k < IX_M; k++) {
+            e[k] = i0 + k < np ? src[i0 + k] : 0xFFFFFFFFu;
+            if (i0 + k < np) cnt[((e[k] >> sh) & 15u) * IX_NT + tid]++;
+        }
+        __syncthreads();
+        // exclusive prefix over the 16 x NT counters, digit-major: work-item t owns the counters [16 t, 16 t + 16)
+        uint32_t c16[16], sum = 0;
+#pragma unroll
+        for (uint32_t x = 0; x < 16u; x++) {
+            c16[x] = cnt[16u * tid + x];
+            sum += c16[x];
+        }
+        uint32_t total = 0;
+        uint32_t run = ix_block_scan_sum(sum, part, total);
+#pragma unroll
+        for (uint32_t x = 0; x < 16u; x++) {
+            cnt[16u * tid + x] = (uint16_t)run;
+            run += c16[x];
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < IX_M; k++)
+            if (i0 + k < np) {
+                uint16_t *c = &cnt[((e[k] >> sh) & 15u) * IX_NT + tid];
+                dst[*c] = e[k];
+                *c = (uint16_t)(*c + 1u);
+            }
+        __syncthreads();
+        uint32_t *t = src;
+        src = dst;
+        dst = t;
+    }
+    return src;
+}
+
+// LDS of the tile kernels (bytes): entries as packed words, two arrays of sort items, the sort's counters, the rows'
+// segment starts, the buckets' counts and where they go
+constexpr uint32_t IXL_PACK = 0, IXL_PA = IXL_PACK + IX_PCAP * 8u, IXL_PB = IXL_PA + IX_PCAP * 4u, IXL_CNT = IXL_PB + IX_PCAP * 4u,
+                   IXL_ROWPRE = IXL_CNT + 16u * IX_NT * 2u, IXL_LO = IXL_ROWPRE + (IX_RB + 2u) * 4u, IXL_HIST = IXL_LO + IX_RB * 2u,
+                   IXL_GBASE = IXL_HIST + (IX_BW_MAX + 2u) * 4u, IXL_PART = IXL_GBASE + IX_BW_MAX * 4u, IXL_BYTES = IXL_PART + 64u;
+
+// K3 (MODE 1): the tile's entries, sorted by bucket, go to pk as one piece per bucket (stable: the block's rows in order,
+// positions ascending).  K5 (MODE 2): the same sort says where each entry went; {code, position} come back from there
+// (tc, written by K4 in that order) and go into the images.
+template <int MODE>
+__global__ __launch_bounds__(IX_NT) void ix_tile_kernel(IxGeom g, const uint64_t *H, const uint16_t *lb, const uint32_t *colpre, const uint32_t *start,
+                                                        const uint32_t *flags, uint64_t *pk, const uint2 *tc, uint32_t *code_img, uint32_t *pos_img)
+{
+    MG_DYN_SHARED(unsigned char, lds);
+    uint64_t *s_pack = reinterpret_cast<uint64_t *>(lds + IXL_PACK);
+    uint32_t *s_slot = reinterpret_cast<uint32_t *>(lds + IXL_PACK);       // (MODE 2: where every entry of the piece went)
+    uint32_t *s_pa = reinterpret_cast<uint32_t *>(lds + IXL_PA), *s_pb = reinterpret_cast<uint32_t *>(lds + IXL_PB);
+    uint16_t *s_cnt = reinterpret_cast<uint16_t *>(lds + IXL_CNT);
+    uint32_t *s_rowpre = reinterpret_cast<uint32_t *>(lds + IXL_ROWPRE);
+    uint16_t *s_lo = reinterpret_cast<uint16_t *>(lds + IXL_LO);
+    uint32_t *s_hist = reinterpret_cast<uint32_t *>(lds + IXL_HIST);
+    uint32_t *s_gbase = reinterpret_cast<uint32_t *>(lds + IXL_GBASE);
+    uint32_t *s_part = reinterpret_cast<uint32_t *>(lds + IXL_PART);
+    uint32_t blk = 0, w = 0;
+    if (!ix_tile_id(g, blk, w)) return;                  // uniform
+    if (flags[IXF_OVERSIZE]) return;                     // uniform (raised by the scan kernel: the caller builds the index another way)
+    const uint32_t tid = threadIdx.x;
+    const uint32_t row0 = blk * IX_RB, nrows = g.n - row0 < IX_RB ? g.n - row0 : IX_RB;
+    uint32_t len = 0;
+    if (tid < nrows) {
+        const uint16_t *p = lb + (uint64_t)(row0 + tid) * (g.NW + 1u) + w;
+        const uint32_t lo = p[0];
+        len = (uint32_t)p[1] - lo;
+        s_lo[tid] = (uint16_t)lo;
+    }
+    uint32_t total = 0;
+    const uint32_t pre = ix_block_scan_sum(len, s_part, total);
+    if (total == 0) return;                              // uniform
+    s_rowpre[tid] = pre;
+    if (tid == IX_NT - 1u) s_rowpre[IX_NT] = total;
+    if (tid < g.BW) {
+        const uint32_t bg = w * g.BW + tid;
+        s_gbase[tid] = start[bg] + colpre[(uint64_t)blk * g.Bp + bg];
+        s_hist[tid] = 0;
+    }
+    __syncthreads();
+    const uint64_t lowmask = (1ull << g.shift) - 1ull;    // (shift <= 63)
+    for (uint32_t i0 = 0; i0 < total; i0 += IX_PCAP) {
+        const uint32_t np = total - i0 < IX_PCAP ? total - i0 : IX_PCAP;
+        // the rows' segments, IX_LPR lanes per row: entry `pre + k` of the tile is entry k of the row's segment
+        for (uint32_t r = tid / IX_LPR; r < nrows; r += IX_NT / IX_LPR) {
+            const uint32_t rp = s_rowpre[r], ln = s_rowpre[r + 1] - rp;
+            if (rp + ln <= i0 || rp >= i0 + np) continue;
+            const uint64_t *src = H + (uint64_t)(row0 + r) * g.stride + s_lo[r];
+            for (uint32_t k = tid % IX_LPR; k < ln; k += IX_LPR) {
+                const uint32_t i = rp + k;
+                if (i < i0 || i >= i0 + np) continue;
+                const uint64_t v = src[k];
+                const uint32_t bl = (uint32_t)(v >> g.shift) & (g.BW - 1u);
+                atomicAdd(&s_hist[bl], 1u);
+                if (MODE == 1) s_pack[i - i0] = ((v & lowmask) << g.rb) | (uint64_t)(row0 + r);
+                s_pa[i - i0] = (bl << 12) | (i - i0);
+            }
+        }
+        __syncthreads();
+        const uint32_t *srt = ix_tile_sort(s_pa, s_pb, s_cnt, s_part, np, g.npass);
+        {   // where every bucket starts in the sorted piece (in place; entry BW = the piece's size)
+            const uint32_t c = tid < g.BW ? s_hist[tid] : 0u;
+            uint32_t tot = 0;
+            const uint32_t ex = ix_block_scan_sum(c, s_part, tot);
+            if (tid < g.BW) s_hist[tid] = ex;
+            if (tid == 0) s_hist[g.BW] = np;
+        }
+        __syncthreads();
+        if (MODE == 1) {
+            for (uint32_t j = tid; j < np; j += IX_NT) {
+                const uint32_t e = srt[j], b = e >> 12, idx = e & 4095u;
+                pk[s_gbase[b] + (j - s_hist[b])] = s_pack[idx];
+            }
+        } else {
+            for (uint32_t j = tid; j < np; j += IX_NT) {
+                const uint32_t e = srt[j], b = e >> 12, idx = e & 4095u;
+                s_slot[idx] = s_gbase[b] + (j - s_hist[b]);
+            }
+            __syncthreads();
+            for (uint32_t r = tid / IX_LPR; r < nrows; r += IX_NT / IX_LPR) {
+                const uint32_t rp = s_rowpre[r], ln = s_rowpre[r + 1] - rp;
+                if (rp + ln <= i0 || rp >= i0 + np) continue;
+                const uint64_t at0 = (uint64_t)(row0 + r) * g.rs + s_lo[r];
+                for (uint32_t k = tid % IX_LPR; k < ln; k += IX_LPR) {
+                    const uint32_t i = rp + k;
+                    if (i < i0 || i >= i0 + np) continue;
+                    const uint2 cp = tc[s_slot[i - i0]];
+                    code_img[at0 + k] = cp.x;
+                    pos_img[at0 + k] = cp.y;
+                }
+            }
+        }
+        __syncthreads();
+        // the next piece of the tile goes behind this one in every bucket
+        uint32_t add = 0;
+        if (tid < g.BW) add = s_hist[tid + 1] - s_hist[tid];
+        __syncthreads();
+        if (tid < g.BW) {
+            s_gbase[tid] += add;
+            s_hist[tid] = 0;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: one workgroup per bucket.  Its entries (packed words, in the order K3 wrote them) are sorted by (value, row) -- the
+// word's own order: a counting sort on the 13 bits below the bucket (LDS atomics: the order inside a sub-bucket is
+// arbitrary), then every entry ranks itself among the few that share its sub-bucket.  The groups of equal values are
+// found in LDS; out go the values, the rows, the groups' ends, optionally every position's group start, and
+// tc[start + j] = {code, position} of the entry that ARRIVED as the bucket's j-th (K5 reads them from there).
+constexpr uint32_t IX4_PK = 0, IX4_JX = IX4_PK + IX_CAP * 8u, IX4_H = IX4_JX + IX_CAP * 2u, IX4_PART = IX4_H + IX_NSUB * 2u,
+                   IX4_BYTES = IX4_PART + 64u;
+
+__global__ __launch_bounds__(IX_NT4, 4) void ix_bucket_sort_kernel(IxGeom g, const uint64_t *pk, const uint32_t *start, uint64_t *keys_sorted,
+                                                                uint32_t *sorted_rows, uint32_t *gend, uint32_t *gs_of, uint2 *tc,
+                                                                IxStatSlot *stat, uint32_t *flags)
+{
+    MG_DYN_SHARED(unsigned char, lds);
+    uint64_t *s_pk = reinterpret_cast<uint64_t *>(lds + IX4_PK);
+    uint16_t *s_jx = reinterpret_cast<uint16_t *>(lds + IX4_JX);
+    uint32_t *s_h = reinterpret_cast<uint32_t *>(lds + IX4_H);
+    uint32_t *s_part = reinterpret_cast<uint32_t *>(lds + IX4_PART);
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    if (flags[IXF_OVERSIZE]) return;                     // uniform
+    const uint32_t G0 = start[b], N = start[b + 1] - G0;
+    if (N == 0) return;                                  // uniform  (N <= IX_CAP: the scan kernel raised IXF_OVERSIZE otherwise)
+    const uint32_t subshift = g.shift >= IX_SUBBITS ? g.shift + g.rb - IX_SUBBITS : g.rb;
+    for (uint32_t x = tid; x < IX_NSUB / 2u; x += IX_NT4) s_h[x] = 0;
+    __syncthreads();
+    // ---- counting sort on the sub-bucket (two u16 counters per word)
+    // (the per-entry registers are assigned unconditionally: a conditional element write makes the compiler carry the whole
+    //  array through every branch -- 256 VGPRs and spills)
+    uint64_t v[IX_PER];
+    uint32_t sa[IX_PER];
+#pragma unroll
+    for (uint32_t k = 0; k < IX_PER; k++) {
+        const uint32_t j = tid + k * IX_NT4;
+        const bool in = j < N;
+        const uint64_t x = pk[G0 + (in ? j : 0u)];
+        const uint32_t sub = (uint32_t)(x >> subshift) & (IX_NSUB - 1u);
+        const uint32_t h16 = (sub & 1u) * 16u;
+        uint32_t old = 0;
+        if (in) old = atomicAdd(&s_h[sub >> 1], 1u << h16);
+        v[k] = x;
+        sa[k] = sub | (((old >> h16) & 0xFFFFu) << 16);
+    }
+    __syncthreads();
+    {   // exclusive prefix over the 8192 counters, in place; work-item t owns the words [8 t, 8 t + 8)
+        uint32_t wv[8], sum = 0;
+#pragma unroll
+        for (uint32_t x = 0; x < 8u; x++) {
+            wv[x] = s_h[8u * tid + x];
+            sum += (wv[x] & 0xFFFFu) + (wv[x] >> 16);
+        }
+        uint32_t total = 0;
+        uint32_t run = ix_block_scan_sum(sum, s_part, total);
+#pragma unroll
+        for (uint32_t x = 0; x < 8u; x++) {
+            const uint32_t lo = wv[x] & 0xFFFFu, hi = wv[x] >> 16;
+            s_h[8u * tid + x] = run | ((run + lo) << 16);
+            run += lo + hi;
+        }
+    }
+    __syncthreads();
+    const uint16_t *cs = reinterpret_cast<const uint16_t *>(s_h);      // cs[sub]: the sub-bucket's first sorted position
+#pragma unroll
+    for (uint32_t k = 0; k < IX_PER; k++) {
+        const uint32_t j = tid + k * IX_NT4;
+        if (j < N) {
+            const uint32_t q = (uint32_t)cs[sa[k] & 0xFFFFu] + (sa[k] >> 16);
+            s_pk[q] = v[k];
+            s_jx[q] = (uint16_t)j;
+        }
+    }
+    __syncthreads();
+    // ---- inside a sub-bucket: an entry's place is the number of entries below it (words are distinct: value | row)
+    int degen = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < IX_PER; k++) {
+        const uint32_t q = tid + k * IX_NT4;
+        const bool in = q < N;
+        const uint32_t qc = in ? q : 0u;
+        const uint64_t me = s_pk[qc];
+        const uint32_t jv = s_jx[qc];
+        const uint32_t sub = (uint32_t)(me >> subshift) & (IX_NSUB - 1u);
+        const uint32_t a = cs[sub], e = sub + 1u < IX_NSUB ? (uint32_t)cs[sub + 1u] : N;
+        uint32_t r = qc - a;                              // (alone in its sub-bucket: it stays)
+        if (in && e - a > 1u) {
+            if (e - a > IX_MAXM) {
+                degen = 1;
+            } else {
+                r = 0;
+                for (uint32_t x = a; x < e; x++) r += s_pk[x] < me ? 1u : 0u;
+            }
+        }
+        v[k] = me;
+        sa[k] = (a + r) | (jv << 16);
+    }
+    degen = __syncthreads_or(degen);
+    if (degen) {                                         // uniform: a value held by many rows, or values far from uniform
+        if (tid == 0) flags[IXF_DEGENERATE] = 1u;
+        return;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < IX_PER; k++) {
+        const uint32_t q = tid + k * IX_NT4;
+        if (q < N) {
+            s_pk[sa[k] & 0xFFFFu] = v[k];
+            s_jx[sa[k] & 0xFFFFu] = (uint16_t)(sa[k] >> 16);
+        }
+    }
+    __syncthreads();
+    // ---- where the bucket's j-th arrival stands now (the counters are dead: their space holds the inverse)
+    uint16_t *inv = reinterpret_cast<uint16_t *>(s_h);
+#pragma unroll
+    for (uint32_t k = 0; k < IX_PER; k++) {
+        const uint32_t q = tid + k * IX_NT4;
+        if (q < N) inv[s_jx[q]] = (uint16_t)q;
+    }
+    __syncthreads();
+    // ---- groups of equal values: work-item t owns the positions [PER t, PER t + PER); s_jx becomes the group's start
+    const uint32_t c0 = tid * IX_PER;
+    uint32_t lasthead = 0;                               // (position + 1) of the last group start in my positions, 0: none
+    {
+        uint64_t prev = (c0 > 0 && c0 <= N) ? s_pk[c0 - 1u] >> g.rb : 0ull;
+        for (uint32_t x = 0; x < IX_PER; x++) {
+            const uint32_t q = c0 + x;
+            if (q < N) {
+                const uint64_t low = s_pk[q] >> g.rb;
+                if (q == 0 || low != prev) lasthead = q + 1u;
+                prev = low;
+            }
+        }
+    }
+    const uint32_t carry = ix_block_scan_max(lasthead, s_part);
+    unsigned long long inc = 0;
+    uint32_t heads = 0, glen = 0;
+    {
+        uint32_t cur = carry > 0 ? carry - 1u : 0u;
+        uint64_t prev = (c0 > 0 && c0 <= N) ? s_pk[c0 - 1u] >> g.rb : 0ull;
+        for (uint32_t x = 0; x < IX_PER; x++) {
+            const uint32_t q = c0 + x;
+            if (q < N) {
+                const uint64_t low = s_pk[q] >> g.rb;
+                if (q == 0 || low != prev) {
+                    cur = q;
+                    heads++;
+                }
+                prev = low;
+                s_jx[q] = (uint16_t)cur;
+                inc += q - cur;
+                const bool last = q + 1u == N || (s_pk[q + 1u] >> g.rb) != low;
+                if (last && q + 1u - cur > glen) glen = q + 1u - cur;
+            }
+        }
+    }
+    // statistics of the index: one atomic per workgroup and number, spread over the slots
+#pragma unroll
+    for (uint32_t d = 32; d > 0; d >>= 1) {
+        inc += __shfl_xor(inc, d);
+        heads += __shfl_xor(heads, d);
+        const uint32_t o = __shfl_xor(glen, d);
+        glen = o > glen ? o : glen;
+    }
+    __shared__ unsigned long long s_inc[IX_NT4 / 64];
+    __shared__ uint32_t s_len[IX_NT4 / 64], s_heads[IX_NT4 / 64];
+    if ((tid & 63u) == 0) {
+        s_inc[tid >> 6] = inc;
+        s_len[tid >> 6] = glen;
+        s_heads[tid >> 6] = heads;
+    }
+    __syncthreads();                                     // (also: every s_jx[q] holds its group's start from here on)
+    if (tid == 0) {
+        unsigned long long t = 0;
+        uint32_t m = 0, h = 0;
+        for (uint32_t k = 0; k < IX_NT4 / 64u; k++) {
+            t += s_inc[k];
+            m = s_len[k] > m ? s_len[k] : m;
+            h += s_heads[k];
+        }
+        IxStatSlot *sl = stat + (b & (IX_STAT_SLOTS - 1u));
+        if (t) atomicAdd(&sl->inc, t);
+        if (m > 1u) atomicMax(&sl->max_group, m);
+        atomicAdd(&sl->groups, h);
+    }
+    // ---- out, by sorted position
+    const uint64_t rowmask = (1ull << g.rb) - 1ull;
+    const uint64_t vbase = (uint64_t)b << g.shift;
+#pragma unroll
+    for (uint32_t k = 0; k < IX_PER; k++) {
+        const uint32_t q = tid + k * IX_NT4;
+        if (q < N) {
+            const uint64_t w = s_pk[q], low = w >> g.rb;
+            const uint32_t gs = s_jx[q];
+            keys_sorted[G0 + q] = vbase | low;
+            sorted_rows[G0 + q] = (uint32_t)(w & rowmask);
+            if (gs_of) gs_of[G0 + q] = G0 + gs;
+            if (q + 1u == N || (s_pk[q + 1u] >> g.rb) != low) gend[G0 + gs] = G0 + q + 1u;
+        }
+    }
+    // ---- and by arrival: what K5 carries into the images
+#pragma unroll
+    for (uint32_t k = 0; k < IX_PER; k++) {
+        const uint32_t j = tid + k * IX_NT4;
+        if (j < N) {
+            const uint32_t q = inv[j], gs = s_jx[q];
+            const bool last = q + 1u == N || (s_pk[q + 1u] >> g.rb) != (s_pk[q] >> g.rb);
+            const uint32_t shared = (gs == q && last) ? 0u : 1u;
+            tc[G0 + j] = make_uint2(((G0 + gs) << 1) | shared, G0 + q);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ix_stat_reduce_kernel(const IxStatSlot *stat, unsigned long long *incidences, uint32_t *max_group, uint32_t *groups)
+{
+    unsigned long long inc = 0;
+    uint32_t m = 0, gr = 0;
+    for (uint32_t i = threadIdx.x; i < IX_STAT_SLOTS; i += 256u) {
+        inc += stat[i].inc;
+        m = stat[i].max_group > m ? stat[i].max_group : m;
+        gr += stat[i].groups;
+    }
+    if (inc) atomicAdd(incidences, inc);
+    if (m) atomicMax(max_group, m);
+    if (gr) atomicAdd(groups, gr);
+}
+
+__global__ __launch_bounds__(256) void ix_fill_u32_kernel(uint32_t *p, uint64_t count, uint32_t v)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < count; i += stride) p[i] = v;
+}
+
+// Verification (MASHGPU_SPARSE_INDEX=verify): two builds of one index, word by word.  mode 0: every word; 1: where cond[i] == i
+// (group starts: the groups' ends are defined there only); 2: where cond[i] != 0xFFFFFFFF (entries, not the images' padding).
+// out[0] = words that differ, out[1] = the first of them.
+__global__ __launch_bounds__(256) void ix_verify_kernel(const uint32_t *a, const uint32_t *b, const uint32_t *cond, uint32_t mode, uint64_t count,
+                                                        unsigned long long *out)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < count; i += stride) {
+        if (mode == 1u && cond[i] != (uint32_t)i) continue;
+        if (mode == 2u && cond[i] == 0xFFFFFFFFu) continue;
+        if (a[i] != b[i]) {
+            atomicAdd(&out[0], 1ull);
+            atomicMin(&out[1], (unsigned long long)i);
+        }
+    }
+}
+
+hipError_t index_verify_words(const uint32_t *a, const uint32_t *b, const uint32_t *cond, uint32_t mode, uint64_t count, unsigned long long *out2,
+                              hipStream_t stream)
+{
+    if (count == 0) return hipSuccess;
+    uint64_t blocks = (count + 1023u) / 1024u;
+    if (blocks > 8192u) blocks = 8192u;
+    hipLaunchKernelGGL(ix_verify_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, a, b, cond, mode, count, out2);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+
+size_t index_stat_scratch_bytes() { return sizeof(IxStatSlot) * IX_STAT_SLOTS; }
+
+IxPlan index_plan(uint32_t n, uint32_t E, uint32_t s, uint32_t rs, uint64_t stride, uint64_t maxv, double dens0, bool want_gs)
+{
+    IxPlan p;
+    IxGeom &g = p.g;
+    g = IxGeom{};
+    if (n == 0 || E == 0) { p.why = "empty"; return p; }
+    if (s > 65535u) { p.why = "sketch size beyond 16-bit positions"; return p; }
+    g.n = n;
+    g.E = E;
+    g.rs = rs;
+    g.stride = stride;
+    g.want_gs = want_gs ? 1u : 0u;
+    g.nblk = (n + IX_RB - 1u) / IX_RB;
+    g.rb = 1;
+    while (g.rb < 32u && (1ull << g.rb) < (uint64_t)n) g.rb++;
+    // the widest bucket whose expected fill stays below IX_TMAX where the table is densest
+    if (!(dens0 > 0.0)) { p.why = "no density"; return p; }
+    uint32_t shift = 0;
+    while (shift < 63u && dens0 * (double)(1ull << (shift + 1u)) <= IX_TMAX) shift++;
+    if (shift > 64u - g.rb) shift = 64u - g.rb;           // value bits below the bucket | row: one 64-bit word
+    if (shift > 63u) shift = 63u;
+    g.shift = shift;
+    const uint64_t B = (maxv >> shift) + 1ull;
+    if (B > (1ull << 22)) { p.why = "too many buckets (values far from evenly spread)"; return p; }
+    // buckets per window: the largest power of two that keeps a tile near IX_TILE_TARGET entries
+    uint32_t bw_log = 0;
+    while (bw_log < 9u && (1ull << (bw_log + 1u)) <= IX_BW_MAX && shift + bw_log + 1u <= 63u && (1ull << bw_log) < B &&
+           (double)E * (double)(2u << bw_log) / ((double)g.nblk * (double)B) <= IX_TILE_TARGET)
+        bw_log++;
+    g.bw_log = bw_log;
+    g.BW = 1u << bw_log;
+    g.NW = (uint32_t)((B + g.BW - 1u) / g.BW);
+    g.Bp = g.NW * g.BW;
+    g.npass = (bw_log + 3u) / 4u;
+    g.wgrp = 8;
+    const uint64_t nseq = (uint64_t)((g.NW + g.wgrp - 1u) / g.wgrp) * g.wgrp * g.nblk;
+    if (nseq >= (1ull << 30)) { p.why = "too many tiles"; return p; }
+    g.nseq = (uint32_t)nseq;
+    p.lb_bytes = (size_t)n * (g.NW + 1u) * 2u;
+    p.cnt_bytes = (size_t)g.nblk * g.Bp * 4u;
+    p.start_bytes = ((size_t)g.Bp + 1u) * 4u;
+    p.pk_bytes = (size_t)E * 8u;
+    p.tc_bytes = (size_t)E * 8u;
+    if (p.lb_bytes > ((size_t)2 << 30) || p.cnt_bytes > ((size_t)2 << 30)) { p.why = "scratch of the tiles too large"; return p; }
+    p.ok = true;
+    return p;
+}
+
+hipError_t index_build(const IxPlan &plan, const uint64_t *hashes, const uint32_t *off, void *lb_v, void *cnt_v, void *start_v, void *pk_v, void *tc_v,
+                       uint64_t *keys_sorted, uint32_t *sorted_rows, uint32_t *gend, uint32_t *gs_of, uint32_t *code_img, uint32_t *pos_img,
+                       void *stat_scratch, unsigned long long *incidences, uint32_t *max_group, uint32_t *groups, uint32_t *flags,
+                       hipStream_t stream)
+{
+    if (!plan.ok) return hipErrorInvalidValue;
+    const IxGeom g = plan.g;
+    uint16_t *lb = static_cast<uint16_t *>(lb_v);
+    uint32_t *cnt = static_cast<uint32_t *>(cnt_v), *start = static_cast<uint32_t *>(start_v);
+    uint64_t *pk = static_cast<uint64_t *>(pk_v);
+    uint2 *tc = static_cast<uint2 *>(tc_v);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ix_tile_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)IXL_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(ix_tile_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)IXL_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(ix_bucket_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)IX4_BYTES);
+    if (e != hipSuccess) return e;
+    const uint32_t tiles = 8u * ((g.nseq + 7u) / 8u);
+    hipLaunchKernelGGL(ix_window_offsets_kernel, dim3((g.n + 3u) / 4u), dim3(256), 0, stream, g, hashes, off, lb);
+    hipLaunchKernelGGL(ix_tile_count_kernel, dim3(tiles), dim3(IX_NT), 0, stream, g, hashes, (const uint16_t *)lb, cnt);
+    hipLaunchKernelGGL(ix_col_scan_kernel, dim3((g.Bp + 255u) / 256u), dim3(256), 0, stream, g, cnt, start);
+    hipLaunchKernelGGL(ix_bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, g, start, flags);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    {   // padding of the code image: larger than every code, so chunked loads past a row's end are harmless
+        const uint64_t total = (uint64_t)g.n * g.rs;
+        uint64_t fb = (total + 1023u) / 1024u;
+        if (fb > 8192u) fb = 8192u;
+        hipLaunchKernelGGL(ix_fill_u32_kernel, dim3((uint32_t)fb), dim3(256), 0, stream, code_img, total, 0xFFFFFFFFu);
+    }
+    hipLaunchKernelGGL(ix_tile_kernel<1>, dim3(tiles), dim3(IX_NT), IXL_BYTES, stream, g, hashes, (const uint16_t *)lb, (const uint32_t *)cnt,
+                       (const uint32_t *)start, (const uint32_t *)flags, pk, (const uint2 *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(stat_scratch, 0, index_stat_scratch_bytes(), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(ix_bucket_sort_kernel, dim3(g.Bp), dim3(IX_NT4), IX4_BYTES, stream, g, (const uint64_t *)pk, (const uint32_t *)start, keys_sorted,
+                       sorted_rows, gend, g.want_gs ? gs_of : (uint32_t *)nullptr, tc, static_cast<IxStatSlot *>(stat_scratch), flags);
+    hipLaunchKernelGGL(ix_stat_reduce_kernel, dim3(1), dim3(256), 0, stream, static_cast<const IxStatSlot *>(stat_scratch), incidences, max_group, groups);
+    hipLaunchKernelGGL(ix_tile_kernel<2>, dim3(tiles), dim3(IX_NT), IXL_BYTES, stream, g, hashes, (const uint16_t *)lb, (const uint32_t *)cnt,
+                       (const uint32_t *)start, (const uint32_t *)flags, (uint64_t *)nullptr, (const uint2 *)tc, code_img, pos_img);
+    return hipGetLastError();
+}
+
+}  // namespace mg

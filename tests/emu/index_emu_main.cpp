@@ -1,0 +1,199 @@
+// index_emu_main.cpp -- runs the index-build kernels of mash_amd/csrc/index_build.hip on host threads (tools/hipemu) and
+// compares every array they produce with a plain statement of the index: all (value, row) entries in a std::stable_sort by
+// value (rows ascend inside a value because the entries are generated row-major).  TEST INFRASTRUCTURE (tests/test_index_emu.py);
+// built with g++, optionally with -fsanitize=thread: a missing barrier in a kernel is then a reported data race.
+//
+//   index_emu <case> ...      cases: see main(); exit status 0 = every case agrees
+#include "../../tools/hipemu/hipemu.h"
+
+#include <algorithm>
+#include <random>
+#include <string>
+
+#include "../../mash_amd/csrc/index_build.hip"
+
+using namespace mg;
+
+struct Table {
+    uint32_t n = 0, s = 0;
+    uint64_t stride = 0;
+    std::vector<uint64_t> H;          // n x stride, ascending rows, padding ~0
+    std::vector<uint32_t> cnt;        // entries of every row that enter the index
+};
+
+static Table make_table(uint32_t n, uint32_t s, uint64_t seed, const std::string &kind)
+{
+    Table t;
+    t.n = n;
+    t.s = s;
+    t.stride = s;
+    t.H.assign((size_t)n * s, ~0ull);
+    t.cnt.assign(n, 0);
+    std::mt19937_64 rng(seed);
+    std::vector<uint64_t> pool;
+    for (uint32_t r = 0; r < n; r++) {
+        uint32_t c = s;
+        uint64_t top = 1ull << 54;                       // hashes of a 1 Mbp genome at s = 1000 reach about here
+        if (kind == "ragged") {
+            c = (uint32_t)(rng() % (s + 1u));            // short and empty rows
+            if (r % 7 == 3) c = 0;
+        } else if (kind == "sizes") {
+            top = 1ull << (50 + rng() % 10);             // genomes of many sizes: rows of very different density
+        } else if (kind == "top") {
+            top = ~0ull;                                 // values up to the top bit
+        }
+        std::vector<uint64_t> v;
+        if (kind == "clusters" || kind == "clade") {
+            // rows of a cluster draw most of their values from a shared pool: values held by several rows
+            const uint32_t per = kind == "clade" ? n : 8;
+            if (r % per == 0) {
+                pool.clear();
+                for (uint32_t k = 0; k < s + s / 4; k++) pool.push_back(rng() % top);
+            }
+            std::vector<uint64_t> p2 = pool;
+            std::shuffle(p2.begin(), p2.end(), rng);
+            for (uint32_t k = 0; k < c; k++) v.push_back(k % 10 == 9 ? rng() % top : p2[k]);
+        } else {
+            for (uint32_t k = 0; k < c; k++) v.push_back(rng() % top);
+        }
+        std::sort(v.begin(), v.end());
+        v.erase(std::unique(v.begin(), v.end()), v.end());
+        t.cnt[r] = (uint32_t)v.size();
+        std::copy(v.begin(), v.end(), t.H.begin() + (size_t)r * s);
+    }
+    if (kind == "copies")                                 // (a copy of an earlier row stays out of the index: count 0)
+        for (uint32_t r = 1; r < n; r += 3) t.cnt[r] = 0;
+    return t;
+}
+
+struct Ref {
+    std::vector<uint64_t> keys;
+    std::vector<uint32_t> rows, gend, gs, code, pos;
+    unsigned long long inc = 0;
+    uint32_t max_group = 0, groups = 0;
+};
+
+static Ref reference(const Table &t, const std::vector<uint32_t> &off, uint32_t rs)
+{
+    Ref R;
+    const uint32_t E = off[t.n];
+    std::vector<std::pair<uint64_t, uint32_t>> e;          // {value, image index}
+    e.reserve(E);
+    for (uint32_t r = 0; r < t.n; r++)
+        for (uint32_t p = 0; p < off[r + 1] - off[r]; p++) e.push_back({t.H[(size_t)r * t.stride + p], r * rs + p});
+    std::stable_sort(e.begin(), e.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+    R.keys.resize(E);
+    R.rows.resize(E);
+    R.gend.assign(E, 0);
+    R.gs.resize(E);
+    R.code.assign((size_t)t.n * rs, 0xFFFFFFFFu);
+    R.pos.assign((size_t)t.n * rs, 0);
+    for (uint32_t q = 0; q < E;) {
+        uint32_t z = q;
+        while (z < E && e[z].first == e[q].first) z++;
+        R.gend[q] = z;
+        R.groups++;
+        R.max_group = std::max(R.max_group, z - q);
+        for (uint32_t x = q; x < z; x++) {
+            R.keys[x] = e[x].first;
+            R.rows[x] = e[x].second / rs;
+            R.gs[x] = q;
+            R.code[e[x].second] = (q << 1) | (z - q > 1 ? 1u : 0u);
+            R.pos[e[x].second] = x;
+            R.inc += x - q;
+        }
+        q = z;
+    }
+    if (R.max_group < 2) R.max_group = 0;                 // (as the round-4 kernels report it: the largest group of a SHARED value)
+    return R;
+}
+
+static int run_case(const std::string &name, uint32_t n, uint32_t s, uint64_t seed, const std::string &kind, bool expect_fallback = false,
+                    double dens_scale = 1.0)
+{
+    const Table t = make_table(n, s, seed, kind);
+    std::vector<uint32_t> off(n + 1, 0);
+    uint64_t maxv = 0;
+    double dens0 = 0;
+    for (uint32_t r = 0; r < n; r++) {
+        off[r + 1] = off[r] + t.cnt[r];
+        if (t.cnt[r]) {
+            const uint64_t last = t.H[(size_t)r * t.stride + t.cnt[r] - 1];
+            maxv = std::max(maxv, last);
+            dens0 += (double)t.cnt[r] / ((double)last + 1.0);
+        }
+    }
+    const uint32_t E = off[n];
+    const uint32_t rs = ((s + 3u) & ~3u) + 4u;
+    if (E == 0) { printf("%-28s skipped (no entries)\n", name.c_str()); return 0; }
+    const IxPlan plan = index_plan(n, E, s, rs, t.stride, maxv, dens0 * dens_scale, true);
+    if (!plan.ok) {
+        printf("%-28s plan refused: %s%s\n", name.c_str(), plan.why, expect_fallback ? " (expected)" : "");
+        return expect_fallback ? 0 : 1;
+    }
+    const IxGeom &g = plan.g;
+    std::vector<unsigned char> lb(plan.lb_bytes + 16, 0xAB), cnt(plan.cnt_bytes + 16, 0xAB), start(plan.start_bytes + 16, 0xAB), pk(plan.pk_bytes + 16, 0xAB),
+        tc(plan.tc_bytes + 16, 0xAB), stat(index_stat_scratch_bytes());
+    std::vector<uint64_t> keys(E, 0xDEADull);
+    std::vector<uint32_t> rows(E, 0xDEADu), gend(E, 0xDEADu), gs(E, 0xDEADu), code((size_t)n * rs + 64, 0xDEADu), pos((size_t)n * rs, 0xDEADu);
+    unsigned long long inc = 0;
+    uint32_t max_group = 0, groups = 0, flags[4] = {0, 0, 0, 0};
+    const hipError_t e = index_build(plan, t.H.data(), off.data(), lb.data(), cnt.data(), start.data(), pk.data(), tc.data(), keys.data(), rows.data(),
+                                     gend.data(), gs.data(), code.data(), pos.data(), stat.data(), &inc, &max_group, &groups, flags, nullptr);
+    if (e != hipSuccess) { printf("%-28s index_build failed\n", name.c_str()); return 1; }
+    char geom[200];
+    snprintf(geom, sizeof geom, "n %u s %u E %u shift %u B %u BW %u NW %u passes %u fullest %u", n, s, E, g.shift, g.Bp, g.BW, g.NW, g.npass, flags[IXF_MAXBUCKET]);
+    if (flags[IXF_OVERSIZE] || flags[IXF_DEGENERATE]) {
+        printf("%-28s %s: flags oversize %u degenerate %u%s\n", name.c_str(), geom, flags[0], flags[1], expect_fallback ? " (expected)" : " UNEXPECTED");
+        return expect_fallback ? 0 : 1;
+    }
+    if (expect_fallback) { printf("%-28s %s: expected a flag, none raised\n", name.c_str(), geom); return 1; }
+    const Ref R = reference(t, off, rs);
+    int bad = 0;
+    auto report = [&](const char *what, size_t i, unsigned long long got, unsigned long long want) {
+        if (bad++ < 8) printf("  %s[%zu] = %llu, expected %llu\n", what, i, got, want);
+    };
+    for (uint32_t q = 0; q < E; q++) {
+        if (keys[q] != R.keys[q]) report("keys_sorted", q, keys[q], R.keys[q]);
+        if (rows[q] != R.rows[q]) report("sorted_rows", q, rows[q], R.rows[q]);
+        if (gs[q] != R.gs[q]) report("gs_of", q, gs[q], R.gs[q]);
+        if (R.gs[q] == q && gend[q] != R.gend[q]) report("gend", q, gend[q], R.gend[q]);
+    }
+    for (size_t i = 0; i < (size_t)n * rs; i++) {
+        if (code[i] != R.code[i]) report("code_img", i, code[i], R.code[i]);
+        if (R.code[i] != 0xFFFFFFFFu && pos[i] != R.pos[i]) report("pos_img", i, pos[i], R.pos[i]);
+    }
+    if (inc != R.inc) report("incidences", 0, inc, R.inc);
+    if (max_group != R.max_group) report("max_group", 0, max_group, R.max_group);
+    if (groups != R.groups) report("groups", 0, groups, R.groups);
+    printf("%-28s %s: %s\n", name.c_str(), geom, bad ? "MISMATCH" : "ok");
+    return bad ? 1 : 0;
+}
+
+int main(int argc, char **argv)
+{
+    const std::string which = argc > 1 ? argv[1] : "all";
+    int rc = 0;
+    struct Case { const char *name; uint32_t n, s; uint64_t seed; const char *kind; bool fallback; double dens_scale; };
+    const Case cases[] = {
+        {"random_small", 40, 64, 1, "random", false, 1.0},
+        {"random_two_blocks", 700, 48, 2, "random", false, 1.0},
+        {"clusters", 600, 96, 3, "clusters", false, 1.0},
+        {"clusters_windows", 600, 96, 13, "clusters", false, 12.0},   // the same with a dozen times the buckets: windows of several buckets
+        {"ragged", 530, 80, 4, "ragged", false, 1.0},
+        {"ragged_windows", 1030, 80, 14, "ragged", false, 25.0},
+        {"copies_out", 300, 64, 5, "copies", false, 1.0},
+        {"sizes", 520, 64, 6, "sizes", false, 1.0},
+        {"top_bit", 200, 64, 7, "top", false, 1.0},
+        {"one_row", 1, 1000, 8, "random", false, 1.0},
+        {"pieces", 512, 40, 9, "random", false, 0.5},             // full buckets, one block of rows: tiles beyond one piece
+        {"many_buckets", 513, 128, 10, "random", false, 60.0},    // sparse buckets, two sort passes
+        {"three_passes", 100, 128, 15, "random", false, 2000.0},  // windows of 512 buckets
+        {"clade_degenerate", 600, 64, 11, "clade", true, 1.0},    // every value held by hundreds of rows: the flag, not a wrong index
+        {"oversize", 2000, 32, 12, "random", true, 0.0005},       // a bucket beyond the LDS capacity: the flag
+    };
+    for (const Case &c : cases)
+        if (which == "all" || which == c.name) rc |= run_case(c.name, c.n, c.s, c.seed, c.kind, c.fallback, c.dens_scale);
+    printf(rc ? "FAILED\n" : "all cases agree\n");
+    return rc;
+}

@@ -906,6 +906,7 @@ def test_compare_sparse_index_sorted_on_leading_bits(eng, oracle, bits, s, sizes
     lengths = np.full(n, 10 ** 6, dtype=np.uint64)
     numer, denom = _oracle_tri(oracle, table, nhash, lengths, 0, n)
     monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", "sparse")
+    monkeypatch.setenv("MASHGPU_SPARSE_INDEX", "sort")            # (round 5 builds the index by tiles: this test is about the sort)
     monkeypatch.setenv("MASHGPU_SPARSE_SORT_BITS", str(bits))
     t = eng.table_upload(table, nhash, lengths)
     got = eng.compare_tri_host(t)
@@ -954,12 +955,13 @@ def test_ctx_options_override_the_environment(eng, oracle, monkeypatch):
         eng.set_option("MASHGPU_COMPARE_KERNEL", None)
 
 
-def test_compare_sparse_index_of_a_collection_of_many_genome_sizes(eng, monkeypatch):
+def test_compare_sparse_index_of_a_collection_of_many_genome_sizes(eng, oracle, monkeypatch):
     """A table large enough for the index's sort on leading bits (>= 2^22 entries) whose values are NOT spread evenly:
     nine rows in ten keep their hashes below 2^44 (large genomes), the tenth reaches 2^58 -- the low end of the range is
     a thousand times denser than the even-spread rule assumes; the number of bits comes from the rows' largest hashes
-    (host_compare.cpp).  The index engine == the generic kernel on every pair, with the default choice, with far too few
-    bits (thousands of ties, then the fallback) and with every bit sorted."""
+    (host_compare.cpp).  Every pair against the ORACLE (9.7e6 pairs), through the index built by tiles
+    (the default: its buckets are sized from the same density), by the sort with the default bits, with far too few bits
+    (thousands of ties, then the fallback) and with every bit sorted."""
     rng = np.random.default_rng(12)
     n, s = 4400, 1000
     pools = [np.sort(rng.choice(np.arange(1, 1 << 22, dtype=np.uint64), 1500, replace=False)) << np.uint64(22) for _ in range(40)]
@@ -975,23 +977,101 @@ def test_compare_sparse_index_of_a_collection_of_many_genome_sizes(eng, monkeypa
         table[i] = row
     nhash = np.full(n, s, dtype=np.uint32)
     lengths = np.full(n, 10 ** 6, dtype=np.uint64)
-    monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", "generic")
-    t = eng.table_upload(table, nhash, lengths)
-    want = eng.compare_tri_host(t)
-    t.free()
-    assert int(want["numer"].max()) > 100                   # (rows of one pool share hundreds of values)
+    numer, denom = _oracle_tri(oracle, table, nhash, lengths, 0, n)
+    assert int(numer.max()) > 100                           # (rows of one pool share hundreds of values)
     monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", "sparse")
-    for knob, value in ((None, None), ("MASHGPU_SPARSE_SORT_BITS", "24"), ("MASHGPU_SPARSE_SORT_ALL_BITS", "1")):
-        if knob:
+    for knobs in ((), (("MASHGPU_SPARSE_INDEX", "sort"),), (("MASHGPU_SPARSE_INDEX", "sort"), ("MASHGPU_SPARSE_SORT_BITS", "24")),
+                  (("MASHGPU_SPARSE_INDEX", "sort"), ("MASHGPU_SPARSE_SORT_ALL_BITS", "1"))):
+        for knob, value in knobs:
             eng.set_option(knob, value)
         try:
             t = eng.table_upload(table, nhash, lengths)
             got = eng.compare_tri_host(t)
             t.free()
         finally:
-            if knob:
+            for knob, _ in knobs:
                 eng.set_option(knob, None)
-        assert got.tobytes() == want.tobytes(), knob
+        assert np.array_equal(got["numer"], numer) and np.array_equal(got["denom"], denom), knobs
+
+
+def _index_tables(kind, rng):
+    """tables for the tile-built index: (table, nhash, may_refuse)"""
+    if kind == "clusters":                                  # C3 in small: clusters interleaved over the rows
+        table, nhash, _ = synth.clustered_sketches(3000, 1000, clusters=30, seed=5)
+        return table, nhash, False
+    if kind == "random":                                    # nothing shared: every group is one entry
+        table, nhash, _ = synth.random_sketches(2500, 1000, seed=6)
+        return table, nhash, False
+    if kind == "ragged":                                    # short and empty rows, copies of rows (they stay out of the index)
+        table, nhash, _ = synth.clustered_sketches(1800, 600, clusters=12, seed=7)
+        for i in range(0, 1800, 7):
+            nhash[i] = int(rng.integers(0, 600))
+            table[i, nhash[i]:] = np.uint64(abi.HASH_PAD)
+        for i in range(5, 1800, 90):
+            table[i] = table[i - 3]
+            nhash[i] = nhash[i - 3]
+        return table, nhash, False
+    if kind == "large_sketches":                            # config 5's sketch size: tiles of many windows per row
+        table, nhash, _ = synth.clustered_sketches(260, 10000, clusters=4, seed=8, pool=14000, private=2500)
+        return table, nhash, False
+    if kind == "sizes":                                     # genomes of many sizes: dense low end, sparse high end
+        n, s = 2600, 500
+        table = np.zeros((n, s), dtype=np.uint64)
+        for i in range(n):
+            top = 1 << int(rng.integers(46, 60))
+            table[i] = np.unique(rng.integers(1, top, size=s + 40).astype(np.uint64))[:s]
+        return table, np.full(n, s, dtype=np.uint32), True  # (may be refused for too many buckets: then the sort builds it)
+    if kind == "top_bit":                                   # values up to 2^64 - 2
+        n, s = 2200, 400
+        t = rng.integers(0, (1 << 64) - 1, size=(n, s + 8), dtype=np.uint64)
+        t.sort(axis=1)
+        table = np.zeros((n, s), dtype=np.uint64)
+        for i in range(n):
+            table[i] = np.unique(t[i])[:s]
+        return table, np.full(n, s, dtype=np.uint32), False
+    if kind == "clade":                                     # every value of a pool held by hundreds of rows: buckets beyond the LDS sort
+        table, nhash = _clade_table(rng, (700, 500), 400)
+        return table, nhash, True
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind", ["clusters", "random", "ragged", "large_sketches", "sizes", "top_bit", "clade"])
+def test_index_built_by_tiles_equals_the_sorted_index(eng, oracle, kind, monkeypatch):
+    """Round 5 builds the inverted index without a general sort (index_build.hip: one partition pass over tiles of
+    512 rows x a window of buckets, an LDS sort per bucket that finds the groups, the images written back row segment by
+    row segment).  MASHGPU_SPARSE_INDEX=verify builds it BOTH ways and compares every array on the device word by word
+    (values, rows, group starts and ends, code and position images, the statistics); the triangle it serves is compared
+    with the oracle (sampled rows) and with the sort-built index (every byte), for the whole table (the clustered copy)
+    and for a row range (the index in table order).  Tables the tiles refuse (a value held by hundreds of rows: a bucket
+    beyond the LDS) must say so and come out right through the sort."""
+    rng = np.random.default_rng(77)
+    table, nhash, may_refuse = _index_tables(kind, rng)
+    n, s = table.shape
+    lengths = np.full(n, 10 ** 6, dtype=np.uint64)
+    monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", "sparse")
+    monkeypatch.setenv("MASHGPU_SPARSE_INDEX", "sort")
+    t = eng.table_upload(table, nhash, lengths)
+    want = eng.compare_tri_host(t)
+    rb, re = n // 3, n - 5
+    want_part = eng.compare_tri_host(t, rb, re)
+    t.free()
+    rows = sorted(set([1, 2, n // 2, n - 1] + [int(x) for x in rng.integers(1, n, size=6)]))
+    for i in rows:                                          # whole rows against the oracle
+        numer, denom = _oracle_tri(oracle, table, nhash, lengths, i, i + 1)
+        lo = i * (i - 1) // 2
+        assert np.array_equal(want["numer"][lo:lo + i], numer) and np.array_equal(want["denom"][lo:lo + i], denom), i
+    monkeypatch.setenv("MASHGPU_SPARSE_INDEX", "verify")
+    if may_refuse:
+        monkeypatch.setenv("MASHGPU_SPARSE_INDEX_MAY_REFUSE", "1")
+    t = eng.table_upload(table, nhash, lengths)
+    got = eng.compare_tri_host(t)                           # (raises if any array of the two builds differs)
+    assert got.tobytes() == want.tobytes()
+    assert eng.compare_tri_host(t, rb, re).tobytes() == want_part.tobytes()
+    t.free()
+    monkeypatch.setenv("MASHGPU_SPARSE_INDEX", "tiles")
+    t = eng.table_upload(table, nhash, lengths)
+    assert eng.compare_tri_host(t).tobytes() == want.tobytes()
+    t.free()
 
 
 def test_table_invalidate_after_the_buffers_changed(eng, oracle, monkeypatch):

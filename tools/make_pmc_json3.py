@@ -54,7 +54,12 @@ for p in glob.glob(os.path.join(prefix + "stats", "**", "*kernel_stats.csv"), re
     for r in csv.DictReader(open(p)):
         k = short(r["Name"])
         if k is not None:
-            times[k] = {"calls": int(r["Calls"]), "total_ms": float(r["TotalDurationNs"]) / 1e6, "avg_ms": float(r["AverageNs"]) / 1e6}
+            # (several kernels can share a short name -- rocPRIM's templates differ only behind the first 90 characters: their
+            #  launches are summed, not overwritten; round 4's file booked the sort at one launch's average)
+            t = times.setdefault(k, {"calls": 0, "total_ms": 0.0, "avg_ms": 0.0})
+            t["calls"] += int(r["Calls"])
+            t["total_ms"] += float(r["TotalDurationNs"]) / 1e6
+            t["avg_ms"] = t["total_ms"] / max(t["calls"], 1)
 h = hashlib.sha256()
 for s in srcs:
     h.update(open(os.path.join(ROOT, s), "rb").read())

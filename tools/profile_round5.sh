@@ -1,0 +1,44 @@
+#!/bin/bash
+# Round-5 profile passes, one leg at a time (tools/prof_leg.py), through gpurun:
+#   kernel trace + stats per leg  -> gpurun_out/r05_<leg>_stats/  -> gpurun_out/r05_kernel_stats_<leg>.csv
+#   PMC passes (each its own run, never combined with tracing domains): FETCH_SIZE, WRITE_SIZE for every leg;
+#   SQ instruction / LDS counters for the headline leg (c3_cold).
+# A leg named <x>_cold runs every step from an invalidated table (the per-table job: index build included).
+# usage: tools/profile_round5.sh [legs...]      default: c3_cold c3 c5_cold c5
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out
+LEGS=${@:-c3_cold c3 c5_cold c5}
+STEPS=${STEPS:-4}
+cd /tmp && export TMPDIR=/tmp
+run() {
+    local tag=$1 name=$2; shift 2
+    local leg=${tag%_cold} cold=""; [ "$leg" != "$tag" ] && cold="--cold"
+    timeout 600 rocprofv3 "$@" --output-format csv -d "$OUT/r05_${tag}_${name}" -o p -- python $ROOT/tools/prof_leg.py --leg $leg --steps $STEPS $cold > "$OUT/r05_${tag}_${name}.log" 2>&1
+    echo "$tag $name rc=$? $(grep -o '"ms_per_step": [0-9.]*' $OUT/r05_${tag}_${name}.log | head -1)"
+}
+for tag in $LEGS; do
+    run $tag stats --kernel-trace --stats
+    find $OUT/r05_${tag}_stats -name "*kernel_stats.csv" -exec cp {} $OUT/r05_kernel_stats_${tag}.csv \;
+    [ "${STATS_ONLY:-0}" = 1 ] && continue
+    run $tag fetch --pmc FETCH_SIZE
+    run $tag write --pmc WRITE_SIZE
+    if [ $tag = c3_cold ] && [ "${NO_SQ:-0}" != 1 ]; then
+        run $tag sqa --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
+        run $tag sqb --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE
+    fi
+    rm -rf $OUT/r05_${tag}_stats/*/*.db 2>/dev/null
+done
+[ "${STATS_ONLY:-0}" = 1 ] && exit 0
+cd $ROOT
+SRC="mash_amd/csrc/compare_sparse.hip mash_amd/csrc/compare_dense.hip mash_amd/csrc/compare_merged.hip mash_amd/csrc/compare_internal.h mash_amd/csrc/index_build.hip"
+PASS="sp_fill_value,sp_fill_short,sp_class_pairs,sp_discover_kernel,sp_chunks,sp_pack_costs,sp_merge_pack,sp_merge_rows,sp_merge_kernel,sp_scatter_kernel,dn_pairs,compare_merged"
+BUILD="ix_,sp_fill_entries,sp_tie_,sp_heads,sp_index_scatter,sp_stat_reduce,sp_fill_u32,sp_row_digest,sp_dup_flags,sp_row_equal,sp_row_key,sp_order_from_keys,row_classes,cl_emit,cl_minrow,cl_jump,cl_order_keys,cl_split_keys,cl_gather_rows,dn_neighbor,dn_leader,dn_sublists,dn_universe,dn_encode,rocprim"
+for tag in $LEGS; do
+    leg=${tag%_cold}
+    case $leg in one_clade) PAIRS=536854528 ;; *) PAIRS=4999950000 ;; esac
+    # a cold leg builds the index in every pass: its kernels belong to the pass; a warm leg builds it once (reported per run, outside the totals)
+    if [ "$leg" != "$tag" ]; then P="$PASS,$BUILD"; C=""; else P="$PASS"; C="$BUILD"; fi
+    python tools/make_pmc_json3.py gpurun_out/r05_${tag}_ $((STEPS + 1)) $PAIRS pair gpurun_out/compare_${tag}_pmc.json "$P" "$C" $SRC > gpurun_out/r05_${tag}_pmc.txt 2>&1
+    tail -1 gpurun_out/r05_${tag}_pmc.txt
+done
