@@ -7,7 +7,7 @@
 // bit) and the entry's own sorted position.
 //
 // How it is built here (round 5; rounds 3-4: rocPRIM's radix sort in 5-7 passes + 4-byte scattered write-back):
-//   buckets   bucket(v) = v >> shift, about 2 500 - 5 000 entries each; a WINDOW is 2^k consecutive buckets;
+//   buckets   bucket(v) = v >> shift, about 1 300 - 2 500 entries each (room for 6 144: shared values make the fill uneven); a WINDOW is 2^k consecutive buckets;
 //   K0        per row the position at which every window starts (rows ascend: a row's entries of one window are contiguous);
 //   K1 + K2   entries per (block of 512 rows, bucket) -> where every bucket and every block's share of it starts;
 //   K3        a tile = (block of rows, window): the rows' segments are read, sorted by bucket in LDS (stable: by row, then
@@ -18,8 +18,9 @@
 //             rank among the few entries that agree in them), finds the groups of equal values there -- no head flags, no
 //             scan, no tie repair over the whole index -- and writes values, rows, group ends and, in the order the
 //             entries ARRIVED in, {code, position};
-//   K5        the tiles again: the same stable sort tells every entry where K3 put it; {code, position} are read back
-//             from there and written into the images row segment by row segment (no 4-byte scattered stores).
+//             K3 also leaves, in the position image, WHERE it put every entry;
+//   K5        the tiles again (their order keeps the gathered lines in the L2): {code, position} are read back from there
+//             and written into the images row segment by row segment (no 4-byte scattered stores).
 // A table that does not fit the assumptions (a bucket beyond the LDS capacity: a value held by thousands of rows, values
 // clumped far from uniform; too many buckets) raises a flag and the caller builds the index the old way.
 #pragma once

@@ -30,8 +30,11 @@ constexpr uint32_t IX_NT4 = 512;
 constexpr uint32_t IX_PER = IX_CAP / IX_NT4;    // 12 entries per work-item
 constexpr uint32_t IX_SUBBITS = 13;             // the counting sort's key: the next 13 bits below the bucket
 constexpr uint32_t IX_NSUB = 1u << IX_SUBBITS;
-constexpr uint32_t IX_MAXM = 48;                // entries that may agree in those bits before the bucket counts as degenerate
-constexpr double IX_TMAX = 5120.0;              // expected entries of the fullest bucket
+constexpr uint32_t IX_MAXM = 256;               // entries that may agree in those bits (a value held by that many rows) before the bucket counts as degenerate
+// expected entries of the fullest bucket IF values were held by one row each.  Collections are not like that: a value
+// of a cluster is held by ~80 rows at once, so a bucket's fill varies like sqrt(values) x 80, not sqrt(entries) -- C3 at an
+// expected 4 464 had a bucket of 7 046.  Half the capacity is headroom.
+constexpr double IX_TMAX = 2560.0;
 constexpr double IX_TILE_TARGET = 3072.0;       // expected entries of a tile
 constexpr uint32_t IX_STAT_SLOTS = 1024;
 
@@ -122,21 +125,44 @@ __global__ __launch_bounds__(256) void ix_window_offsets_kernel(IxGeom g, const 
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1: cnt[blk][bucket] = entries of the block's rows in the bucket, for the buckets of the tile's window
-__global__ __launch_bounds__(IX_NT) void ix_tile_count_kernel(IxGeom g, const uint64_t *H, const uint16_t *lb, uint32_t *cnt)
+// K1: cnt[blk][bucket] = entries of the block's rows in the bucket, for the buckets of the tile's window.
+// The loads of the eight rounds of rows are issued before any is used (a round at a time cost a memory latency each).
+constexpr uint32_t IX_ROUNDS = IX_RB / (IX_NT / IX_LPR);       // 8 rounds of 64 rows
+
+__global__ __launch_bounds__(IX_NT) void ix_tile_count_kernel(IxGeom g, const uint64_t *__restrict__ H, const uint16_t *__restrict__ lb,
+                                                              uint32_t *__restrict__ cnt)
 {
     __shared__ uint32_t s_hist[IX_BW_MAX];
     uint32_t blk = 0, w = 0;
     if (!ix_tile_id(g, blk, w)) return;                  // uniform
-    const uint32_t tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x, sub = tid % IX_LPR;
     const uint32_t row0 = blk * IX_RB, nrows = g.n - row0 < IX_RB ? g.n - row0 : IX_RB;
     if (tid < g.BW) s_hist[tid] = 0;
+    uint32_t lo[IX_ROUNDS], hi[IX_ROUNDS];
+#pragma unroll
+    for (uint32_t it = 0; it < IX_ROUNDS; it++) {
+        const uint32_t r = it * (IX_NT / IX_LPR) + tid / IX_LPR;
+        const uint16_t *p = lb + (uint64_t)(row0 + (r < nrows ? r : 0u)) * (g.NW + 1u) + w;
+        const uint32_t a = p[0], b = p[1];
+        lo[it] = a;
+        hi[it] = r < nrows ? b : a;
+    }
+    uint64_t v[IX_ROUNDS];
+#pragma unroll
+    for (uint32_t it = 0; it < IX_ROUNDS; it++) {
+        const uint32_t r = it * (IX_NT / IX_LPR) + tid / IX_LPR;
+        const bool in = lo[it] + sub < hi[it];
+        v[it] = H[in ? (uint64_t)(row0 + r) * g.stride + lo[it] + sub : (uint64_t)row0 * g.stride];
+    }
     __syncthreads();
-    for (uint32_t r = tid / IX_LPR; r < nrows; r += IX_NT / IX_LPR) {
-        const uint16_t *p = lb + (uint64_t)(row0 + r) * (g.NW + 1u) + w;
-        const uint32_t lo = p[0], hi = p[1];
-        const uint64_t *src = H + (uint64_t)(row0 + r) * g.stride;
-        for (uint32_t k = lo + tid % IX_LPR; k < hi; k += IX_LPR) atomicAdd(&s_hist[(uint32_t)(src[k] >> g.shift) & (g.BW - 1u)], 1u);
+#pragma unroll
+    for (uint32_t it = 0; it < IX_ROUNDS; it++) {
+        const uint32_t r = it * (IX_NT / IX_LPR) + tid / IX_LPR;
+        if (lo[it] + sub < hi[it]) {
+            atomicAdd(&s_hist[(uint32_t)(v[it] >> g.shift) & (g.BW - 1u)], 1u);
+            const uint64_t *src = H + (uint64_t)(row0 + r) * g.stride;         // (a row with more than IX_LPR entries in the window)
+            for (uint32_t k = lo[it] + sub + IX_LPR; k < hi[it]; k += IX_LPR) atomicAdd(&s_hist[(uint32_t)(src[k] >> g.shift) & (g.BW - 1u)], 1u);
+        }
     }
     __syncthreads();
     if (tid < g.BW) cnt[(uint64_t)blk * g.Bp + (uint64_t)w * g.BW + tid] = s_hist[tid];
@@ -249,16 +275,15 @@ constexpr uint32_t IXL_PACK = 0, IXL_PA = IXL_PACK + IX_PCAP * 8u, IXL_PB = IXL_
                    IXL_ROWPRE = IXL_CNT + 16u * IX_NT * 2u, IXL_LO = IXL_ROWPRE + (IX_RB + 2u) * 4u, IXL_HIST = IXL_LO + IX_RB * 2u,
                    IXL_GBASE = IXL_HIST + (IX_BW_MAX + 2u) * 4u, IXL_PART = IXL_GBASE + IX_BW_MAX * 4u, IXL_BYTES = IXL_PART + 64u;
 
-// K3 (MODE 1): the tile's entries, sorted by bucket, go to pk as one piece per bucket (stable: the block's rows in order,
-// positions ascending).  K5 (MODE 2): the same sort says where each entry went; {code, position} come back from there
-// (tc, written by K4 in that order) and go into the images.
-template <int MODE>
-__global__ __launch_bounds__(IX_NT) void ix_tile_kernel(IxGeom g, const uint64_t *H, const uint16_t *lb, const uint32_t *colpre, const uint32_t *start,
-                                                        const uint32_t *flags, uint64_t *pk, const uint2 *tc, uint32_t *code_img, uint32_t *pos_img)
+// K3: the tile's entries, sorted by bucket, go to pk as one piece per bucket (stable: the block's rows in order, positions
+// ascending); where each entry went is left in the position image (K5 reads {code, position} back from there).
+__global__ __launch_bounds__(IX_NT, 4) void ix_tile_partition_kernel(IxGeom g, const uint64_t *__restrict__ H, const uint16_t *__restrict__ lb,
+                                                                  const uint32_t *__restrict__ colpre, const uint32_t *__restrict__ start,
+                                                                  const uint32_t *__restrict__ flags, uint64_t *__restrict__ pk,
+                                                                  uint32_t *__restrict__ slot_img)
 {
     MG_DYN_SHARED(unsigned char, lds);
     uint64_t *s_pack = reinterpret_cast<uint64_t *>(lds + IXL_PACK);
-    uint32_t *s_slot = reinterpret_cast<uint32_t *>(lds + IXL_PACK);       // (MODE 2: where every entry of the piece went)
     uint32_t *s_pa = reinterpret_cast<uint32_t *>(lds + IXL_PA), *s_pb = reinterpret_cast<uint32_t *>(lds + IXL_PB);
     uint16_t *s_cnt = reinterpret_cast<uint16_t *>(lds + IXL_CNT);
     uint32_t *s_rowpre = reinterpret_cast<uint32_t *>(lds + IXL_ROWPRE);
@@ -269,7 +294,7 @@ __global__ __launch_bounds__(IX_NT) void ix_tile_kernel(IxGeom g, const uint64_t
     uint32_t blk = 0, w = 0;
     if (!ix_tile_id(g, blk, w)) return;                  // uniform
     if (flags[IXF_OVERSIZE]) return;                     // uniform (raised by the scan kernel: the caller builds the index another way)
-    const uint32_t tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x, sub = tid % IX_LPR;
     const uint32_t row0 = blk * IX_RB, nrows = g.n - row0 < IX_RB ? g.n - row0 : IX_RB;
     uint32_t len = 0;
     if (tid < nrows) {
@@ -292,23 +317,48 @@ __global__ __launch_bounds__(IX_NT) void ix_tile_kernel(IxGeom g, const uint64_t
     const uint64_t lowmask = (1ull << g.shift) - 1ull;    // (shift <= 63)
     for (uint32_t i0 = 0; i0 < total; i0 += IX_PCAP) {
         const uint32_t np = total - i0 < IX_PCAP ? total - i0 : IX_PCAP;
-        // the rows' segments, IX_LPR lanes per row: entry `pre + k` of the tile is entry k of the row's segment
+        // the rows' segments, IX_LPR lanes per row: entry `rp + k` of the tile is entry k of the row's segment.  The first
+        // entry of every lane in all eight rounds of rows is requested before any is used.
+        uint32_t at[IX_ROUNDS];                           // index in the piece of the lane's first entry of the round, ~0: none
+        uint64_t v[IX_ROUNDS];
+#pragma unroll
+        for (uint32_t it = 0; it < IX_ROUNDS; it++) {
+            const uint32_t r = it * (IX_NT / IX_LPR) + tid / IX_LPR, rc = r < nrows ? r : 0u;
+            const uint32_t rp = s_rowpre[rc], ln = r < nrows ? s_rowpre[rc + 1u] - rp : 0u;
+            const uint32_t i = rp + sub;
+            const bool in = sub < ln && i >= i0 && i < i0 + np;
+            at[it] = in ? i - i0 : 0xFFFFFFFFu;
+            v[it] = H[in ? (uint64_t)(row0 + r) * g.stride + s_lo[rc] + sub : (uint64_t)row0 * g.stride];
+        }
+#pragma unroll
+        for (uint32_t it = 0; it < IX_ROUNDS; it++) {
+            const uint32_t r = it * (IX_NT / IX_LPR) + tid / IX_LPR;
+            if (at[it] != 0xFFFFFFFFu) {
+                const uint32_t bl = (uint32_t)(v[it] >> g.shift) & (g.BW - 1u);
+                atomicAdd(&s_hist[bl], 1u);
+                s_pack[at[it]] = ((v[it] & lowmask) << g.rb) | (uint64_t)(row0 + r);
+                s_pa[at[it]] = (bl << 12) | at[it];
+            }
+        }
+        // (what a row holds beyond IX_LPR entries in this window: rare, a plain loop)
+#pragma unroll 1
         for (uint32_t r = tid / IX_LPR; r < nrows; r += IX_NT / IX_LPR) {
-            const uint32_t rp = s_rowpre[r], ln = s_rowpre[r + 1] - rp;
-            if (rp + ln <= i0 || rp >= i0 + np) continue;
+            const uint32_t rp = s_rowpre[r], ln = s_rowpre[r + 1u] - rp;
+            if (ln <= IX_LPR || rp + ln <= i0 || rp >= i0 + np) continue;
             const uint64_t *src = H + (uint64_t)(row0 + r) * g.stride + s_lo[r];
-            for (uint32_t k = tid % IX_LPR; k < ln; k += IX_LPR) {
+            for (uint32_t k = sub + IX_LPR; k < ln; k += IX_LPR) {
                 const uint32_t i = rp + k;
                 if (i < i0 || i >= i0 + np) continue;
-                const uint64_t v = src[k];
-                const uint32_t bl = (uint32_t)(v >> g.shift) & (g.BW - 1u);
+                const uint64_t x = src[k];
+                const uint32_t bl = (uint32_t)(x >> g.shift) & (g.BW - 1u);
                 atomicAdd(&s_hist[bl], 1u);
-                if (MODE == 1) s_pack[i - i0] = ((v & lowmask) << g.rb) | (uint64_t)(row0 + r);
+                s_pack[i - i0] = ((x & lowmask) << g.rb) | (uint64_t)(row0 + r);
                 s_pa[i - i0] = (bl << 12) | (i - i0);
             }
         }
         __syncthreads();
-        const uint32_t *srt = ix_tile_sort(s_pa, s_pb, s_cnt, s_part, np, g.npass);
+        uint32_t *srt = ix_tile_sort(s_pa, s_pb, s_cnt, s_part, np, g.npass);
+        uint32_t *s_slot = srt == s_pa ? s_pb : s_pa;     // (the sort's other array: where every entry of the piece goes)
         {   // where every bucket starts in the sorted piece (in place; entry BW = the piece's size)
             const uint32_t c = tid < g.BW ? s_hist[tid] : 0u;
             uint32_t tot = 0;
@@ -317,31 +367,23 @@ __global__ __launch_bounds__(IX_NT) void ix_tile_kernel(IxGeom g, const uint64_t
             if (tid == 0) s_hist[g.BW] = np;
         }
         __syncthreads();
-        if (MODE == 1) {
-            for (uint32_t j = tid; j < np; j += IX_NT) {
-                const uint32_t e = srt[j], b = e >> 12, idx = e & 4095u;
-                pk[s_gbase[b] + (j - s_hist[b])] = s_pack[idx];
-            }
-        } else {
-            for (uint32_t j = tid; j < np; j += IX_NT) {
-                const uint32_t e = srt[j], b = e >> 12, idx = e & 4095u;
-                s_slot[idx] = s_gbase[b] + (j - s_hist[b]);
-            }
-            __syncthreads();
-            for (uint32_t r = tid / IX_LPR; r < nrows; r += IX_NT / IX_LPR) {
-                const uint32_t rp = s_rowpre[r], ln = s_rowpre[r + 1] - rp;
-                if (rp + ln <= i0 || rp >= i0 + np) continue;
-                const uint64_t at0 = (uint64_t)(row0 + r) * g.rs + s_lo[r];
-                for (uint32_t k = tid % IX_LPR; k < ln; k += IX_LPR) {
-                    const uint32_t i = rp + k;
-                    if (i < i0 || i >= i0 + np) continue;
-                    const uint2 cp = tc[s_slot[i - i0]];
-                    code_img[at0 + k] = cp.x;
-                    pos_img[at0 + k] = cp.y;
-                }
-            }
+        for (uint32_t j = tid; j < np; j += IX_NT) {
+            const uint32_t e = srt[j], b = e >> 12, idx = e & 4095u;
+            const uint32_t slot = s_gbase[b] + (j - s_hist[b]);
+            pk[slot] = s_pack[idx];
+            s_slot[idx] = slot;
         }
         __syncthreads();
+#pragma unroll 1
+        for (uint32_t r = tid / IX_LPR; r < nrows; r += IX_NT / IX_LPR) {
+            const uint32_t rp = s_rowpre[r], ln = s_rowpre[r + 1u] - rp;
+            if (rp + ln <= i0 || rp >= i0 + np) continue;
+            const uint64_t at0 = (uint64_t)(row0 + r) * g.rs + s_lo[r];
+            for (uint32_t k = sub; k < ln; k += IX_LPR) {
+                const uint32_t i = rp + k;
+                if (i >= i0 && i < i0 + np) slot_img[at0 + k] = s_slot[i - i0];
+            }
+        }
         // the next piece of the tile goes behind this one in every bucket
         uint32_t add = 0;
         if (tid < g.BW) add = s_hist[tid + 1] - s_hist[tid];
@@ -351,6 +393,54 @@ __global__ __launch_bounds__(IX_NT) void ix_tile_kernel(IxGeom g, const uint64_t
             s_hist[tid] = 0;
         }
         __syncthreads();
+    }
+}
+
+// K5: the tiles again (their order keeps what is gathered in the L2): {code, position} of every entry are read from where K3
+// put the entry -- its slot stands in the position image -- and written into the images, a row segment at a time
+__global__ __launch_bounds__(IX_NT) void ix_tile_images_kernel(IxGeom g, const uint16_t *__restrict__ lb, const uint32_t *__restrict__ flags,
+                                                               const uint2 *__restrict__ tc, uint32_t *__restrict__ code_img, uint32_t *pos_img)
+{
+    uint32_t blk = 0, w = 0;
+    if (!ix_tile_id(g, blk, w)) return;                  // uniform
+    if (flags[IXF_OVERSIZE]) return;
+    const uint32_t tid = threadIdx.x, sub = tid % IX_LPR;
+    const uint32_t row0 = blk * IX_RB, nrows = g.n - row0 < IX_RB ? g.n - row0 : IX_RB;
+    uint32_t lo[IX_ROUNDS], hi[IX_ROUNDS];
+#pragma unroll
+    for (uint32_t it = 0; it < IX_ROUNDS; it++) {
+        const uint32_t r = it * (IX_NT / IX_LPR) + tid / IX_LPR;
+        const uint16_t *p = lb + (uint64_t)(row0 + (r < nrows ? r : 0u)) * (g.NW + 1u) + w;
+        const uint32_t a = p[0], b = p[1];
+        lo[it] = a;
+        hi[it] = r < nrows ? b : a;
+    }
+    uint32_t slot[IX_ROUNDS];
+#pragma unroll
+    for (uint32_t it = 0; it < IX_ROUNDS; it++) {
+        const uint32_t r = it * (IX_NT / IX_LPR) + tid / IX_LPR;
+        const bool in = lo[it] + sub < hi[it];
+        slot[it] = pos_img[in ? (uint64_t)(row0 + r) * g.rs + lo[it] + sub : (uint64_t)row0 * g.rs];
+    }
+    uint2 cp[IX_ROUNDS];
+#pragma unroll
+    for (uint32_t it = 0; it < IX_ROUNDS; it++) {
+        const bool in = lo[it] + sub < hi[it];
+        cp[it] = tc[in ? slot[it] : 0u];
+    }
+#pragma unroll
+    for (uint32_t it = 0; it < IX_ROUNDS; it++) {
+        const uint32_t r = it * (IX_NT / IX_LPR) + tid / IX_LPR;
+        if (lo[it] + sub < hi[it]) {
+            const uint64_t at0 = (uint64_t)(row0 + r) * g.rs;
+            code_img[at0 + lo[it] + sub] = cp[it].x;
+            pos_img[at0 + lo[it] + sub] = cp[it].y;
+            for (uint32_t k = lo[it] + sub + IX_LPR; k < hi[it]; k += IX_LPR) {
+                const uint2 c2 = tc[pos_img[at0 + k]];
+                code_img[at0 + k] = c2.x;
+                pos_img[at0 + k] = c2.y;
+            }
+        }
     }
 }
 
@@ -674,8 +764,7 @@ hipError_t index_build(const IxPlan &plan, const uint64_t *hashes, const uint32_
     uint32_t *cnt = static_cast<uint32_t *>(cnt_v), *start = static_cast<uint32_t *>(start_v);
     uint64_t *pk = static_cast<uint64_t *>(pk_v);
     uint2 *tc = static_cast<uint2 *>(tc_v);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ix_tile_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)IXL_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(ix_tile_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)IXL_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ix_tile_partition_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)IXL_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(ix_bucket_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)IX4_BYTES);
     if (e != hipSuccess) return e;
     const uint32_t tiles = 8u * ((g.nseq + 7u) / 8u);
@@ -691,8 +780,8 @@ hipError_t index_build(const IxPlan &plan, const uint64_t *hashes, const uint32_
         if (fb > 8192u) fb = 8192u;
         hipLaunchKernelGGL(ix_fill_u32_kernel, dim3((uint32_t)fb), dim3(256), 0, stream, code_img, total, 0xFFFFFFFFu);
     }
-    hipLaunchKernelGGL(ix_tile_kernel<1>, dim3(tiles), dim3(IX_NT), IXL_BYTES, stream, g, hashes, (const uint16_t *)lb, (const uint32_t *)cnt,
-                       (const uint32_t *)start, (const uint32_t *)flags, pk, (const uint2 *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
+    hipLaunchKernelGGL(ix_tile_partition_kernel, dim3(tiles), dim3(IX_NT), IXL_BYTES, stream, g, hashes, (const uint16_t *)lb, (const uint32_t *)cnt,
+                       (const uint32_t *)start, (const uint32_t *)flags, pk, pos_img);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(stat_scratch, 0, index_stat_scratch_bytes(), stream);
@@ -700,8 +789,8 @@ hipError_t index_build(const IxPlan &plan, const uint64_t *hashes, const uint32_
     hipLaunchKernelGGL(ix_bucket_sort_kernel, dim3(g.Bp), dim3(IX_NT4), IX4_BYTES, stream, g, (const uint64_t *)pk, (const uint32_t *)start, keys_sorted,
                        sorted_rows, gend, g.want_gs ? gs_of : (uint32_t *)nullptr, tc, static_cast<IxStatSlot *>(stat_scratch), flags);
     hipLaunchKernelGGL(ix_stat_reduce_kernel, dim3(1), dim3(256), 0, stream, static_cast<const IxStatSlot *>(stat_scratch), incidences, max_group, groups);
-    hipLaunchKernelGGL(ix_tile_kernel<2>, dim3(tiles), dim3(IX_NT), IXL_BYTES, stream, g, hashes, (const uint16_t *)lb, (const uint32_t *)cnt,
-                       (const uint32_t *)start, (const uint32_t *)flags, (uint64_t *)nullptr, (const uint2 *)tc, code_img, pos_img);
+    hipLaunchKernelGGL(ix_tile_images_kernel, dim3(tiles), dim3(IX_NT), 0, stream, g, (const uint16_t *)lb, (const uint32_t *)flags, (const uint2 *)tc,
+                       code_img, pos_img);
     return hipGetLastError();
 }
 

@@ -186,7 +186,7 @@ int main(int argc, char **argv)
         {"sizes", 520, 64, 6, "sizes", false, 1.0},
         {"top_bit", 200, 64, 7, "top", false, 1.0},
         {"one_row", 1, 1000, 8, "random", false, 1.0},
-        {"pieces", 512, 40, 9, "random", false, 0.5},             // full buckets, one block of rows: tiles beyond one piece
+        {"pieces", 512, 40, 9, "random", false, 0.25},            // full buckets, one block of rows: tiles beyond one piece
         {"many_buckets", 513, 128, 10, "random", false, 60.0},    // sparse buckets, two sort passes
         {"three_passes", 100, 128, 15, "random", false, 2000.0},  // windows of 512 buckets
         {"clade_degenerate", 600, 64, 11, "clade", true, 1.0},    // every value held by hundreds of rows: the flag, not a wrong index
