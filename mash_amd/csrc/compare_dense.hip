@@ -190,9 +190,18 @@ hipError_t dense_find_leaders(const uint32_t *sorted_rows, const uint32_t *gs_of
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(dn_leaders_kernel, dim3((E + 255u) / 256u), dim3(256), 0, stream, sorted_rows, gs_of, gend, grp_of, groups, E, key, val, cap_sub,
                        cnt);
-    hipLaunchKernelGGL(dn_sublists_scan_kernel, dim3(1), dim3(DN_SUBLISTS), 0, stream, (const uint32_t *)cnt, cap_sub, off, total);
-    hipLaunchKernelGGL(dn_sublists_copy_kernel, dim3(DN_SUBLISTS), dim3(256), 0, stream, (const unsigned long long *)key, (const uint32_t *)val,
-                       (const uint32_t *)cnt, (const uint32_t *)off, cap_sub, key_out, val_out);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return dense_join_leaders(key, val, cap_sub, key_out, val_out, cnt, off, total, stream);
+}
+
+// the lists of leaders made one (also behind the index build by tiles, whose bucket sorts find the leaders themselves:
+// index_build.h, IxLeaders); total (device, 2 u32, zeroed by the caller): [0] leaders kept, [1] the longest list asked for
+hipError_t dense_join_leaders(const unsigned long long *key, const uint32_t *val, uint32_t cap_sub, unsigned long long *key_out, uint32_t *val_out,
+                              const uint32_t *cnt, uint32_t *off, uint32_t *total, hipStream_t stream)
+{
+    hipLaunchKernelGGL(dn_sublists_scan_kernel, dim3(1), dim3(DN_SUBLISTS), 0, stream, cnt, cap_sub, off, total);
+    hipLaunchKernelGGL(dn_sublists_copy_kernel, dim3(DN_SUBLISTS), dim3(256), 0, stream, key, val, cnt, (const uint32_t *)off, cap_sub, key_out, val_out);
     return hipGetLastError();
 }
 

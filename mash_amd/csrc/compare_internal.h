@@ -180,6 +180,8 @@ hipError_t dense_find_leaders(const uint32_t *sorted_rows, const uint32_t *gs_of
                               const DenseGroup *groups, uint32_t E, unsigned long long *key, uint32_t *val, uint32_t cap_sub,
                               unsigned long long *key_out, uint32_t *val_out, uint32_t *cnt, uint32_t *off, uint32_t *total,
                               hipStream_t stream);
+hipError_t dense_join_leaders(const unsigned long long *key, const uint32_t *val, uint32_t cap_sub, unsigned long long *key_out, uint32_t *val_out,
+                              const uint32_t *cnt, uint32_t *off, uint32_t *total, hipStream_t stream);
 hipError_t dense_sort_universes(const unsigned long long *key, const uint32_t *val, uint32_t m, void *temp, size_t temp_bytes,
                                 unsigned long long *key_sorted, uint32_t *ulist, uint32_t *upos, uint32_t *ustart, uint32_t *uend,
                                 uint32_t group_bits, hipStream_t stream);

@@ -685,9 +685,52 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
     const char *ix_mode = ctx_opt(ctx, "MASHGPU_SPARSE_INDEX");
     const bool ix_verify = ix_mode && strcmp(ix_mode, "verify") == 0;
     const bool ix_tiles = !ix_mode || strcmp(ix_mode, "sort") != 0;
-    const bool want_gs = !link.empty() && sp->copies == 0;   // (the dense groups' leader search reads every position's group start)
+    // ---- candidates for dense groups (compare_dense.hip): runs of at least 8 consecutive rows linked to their predecessors.
+    // Known before the index exists, so the build by tiles looks for their leaders while it has every group of equal values in
+    // LDS (index_build.h, IxLeaders); the build by the sort searches the finished index for them (dense_find_leaders).
+    std::vector<mg::DenseGroup> cand_groups;
+    std::vector<uint32_t> grp_of_h;
+    DevBuf<mg::DenseGroup> d_groups(ctx);
+    DevBuf<uint32_t> d_grp_of(ctx), d_val(ctx), d_valj(ctx), d_cnt_sub(ctx), d_off_sub(ctx), d_nlead(ctx);
+    DevBuf<unsigned long long> d_key(ctx), d_keyj(ctx);
+    const uint32_t lead_lists = mg::dense_sublists();
+    uint32_t lead_tot[2] = {0, 0}, lead_cap = std::max<uint32_t>(E / 4u / lead_lists + 64u, 256u);
+    bool lead_ready = false, lead_done = false;
+    static_assert(sizeof(mg::DenseGroup) == 32, "IxLeaders reads a group as 8 words");
+    if (!link.empty() && sp->copies == 0) {
+        for (uint64_t i = 1; i < n;) {
+            if (!link[i]) { i++; continue; }
+            uint64_t j = i;
+            while (j < n && link[j]) j++;                    // rows [i - 1, j) form a chain
+            if (j - (i - 1) >= 8) {
+                mg::DenseGroup g{};
+                g.g0 = (uint32_t)(i - 1); g.g1 = (uint32_t)j;
+                cand_groups.push_back(g);
+            }
+            i = j + 1;
+        }
+        if (!cand_groups.empty()) {
+            const uint32_t ng = (uint32_t)cand_groups.size();
+            grp_of_h.assign(n, 0xFFFFFFFFu);
+            for (uint32_t g = 0; g < ng; g++)
+                for (uint32_t r = cand_groups[g].g0; r < cand_groups[g].g1; r++) grp_of_h[r] = g;
+            const uint64_t room = (uint64_t)lead_lists * lead_cap;
+            if (d_groups.alloc(ng) == hipSuccess && d_grp_of.alloc(n) == hipSuccess && d_nlead.alloc(2) == hipSuccess && d_cnt_sub.alloc(lead_lists) == hipSuccess &&
+                d_off_sub.alloc(lead_lists) == hipSuccess && d_key.alloc(room) == hipSuccess && d_val.alloc(room) == hipSuccess && d_keyj.alloc(room) == hipSuccess &&
+                d_valj.alloc(room) == hipSuccess &&
+                hipMemcpyAsync(d_groups, cand_groups.data(), ng * sizeof(mg::DenseGroup), hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+                hipMemcpyAsync(d_grp_of, grp_of_h.data(), n * 4, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+                hipMemsetAsync(d_cnt_sub, 0, lead_lists * 4, ctx->stream) == hipSuccess && hipMemsetAsync(d_nlead, 0, 8, ctx->stream) == hipSuccess) {
+                lead_ready = true;
+            } else {
+                (void)hipGetLastError();
+                cand_groups.clear();                        // no room: no dense groups
+            }
+        }
+    }
+    const bool want_gs = !cand_groups.empty() && !lead_ready;   // (only the search behind the sort reads every position's group start)
     mg::IxPlan plan;
-    if (ix_tiles) plan = mg::index_plan((uint32_t)n, E, s, sp->rs, t->s, maxv, dens0, want_gs || ix_verify);
+    if (ix_tiles) plan = mg::index_plan((uint32_t)n, E, s, sp->rs, t->s, maxv, dens0, ix_verify);
     const size_t temp_bytes = std::max(mg::sparse_order_temp_bytes((uint32_t)n), mg::sparse_order_slice_temp_bytes((uint32_t)n));
     DevBuf<unsigned char> temp(ctx);
     DevBuf<uint32_t> gs_of(ctx);
@@ -743,11 +786,27 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
         if (d_lb.alloc(plan.lb_bytes) == hipSuccess && d_cnt.alloc(plan.cnt_bytes) == hipSuccess && d_start.alloc(plan.start_bytes) == hipSuccess &&
             d_pk.alloc(plan.pk_bytes) == hipSuccess && d_tc.alloc(plan.tc_bytes) == hipSuccess) {
             e = hipMemsetAsync(d_stat, 0, sizeof(Stat), ctx->stream);
+            mg::IxLeaders lead;
+            if (lead_ready) {
+                lead.grp_of = d_grp_of;
+                lead.groups32 = reinterpret_cast<const uint32_t *>(d_groups.p);
+                lead.key = d_key;
+                lead.val = d_val;
+                lead.cnt = d_cnt_sub;
+                lead.cap_sub = lead_cap;
+                lead.nsub = lead_lists;
+            }
             if (e == hipSuccess)
                 e = mg::index_build(plan, H, sp->off, d_lb, d_cnt, d_start, d_pk, d_tc, sp->keys_sorted, sp->sorted_rows, sp->gend, gs_of, sp->code_img,
-                                    sp->pos_img, d_slots, &d_stat.p->shared, &d_stat.p->max_group, &d_stat.p->groups, d_stat.p->ixf, ctx->stream);
+                                    sp->pos_img, d_slots, &d_stat.p->shared, &d_stat.p->max_group, &d_stat.p->groups, d_stat.p->ixf,
+                                    lead_ready ? &lead : nullptr, ctx->stream);
+            if (e == hipSuccess && lead_ready) {             // the leaders' lists made one; their count comes back with the statistics
+                e = mg::dense_join_leaders(d_key, d_val, lead_cap, d_keyj, d_valj, d_cnt_sub, d_off_sub, d_nlead, ctx->stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(lead_tot, d_nlead, 8, hipMemcpyDeviceToHost, ctx->stream);
+            }
             finish_build();
             built = e == hipSuccess && !h_stat.ixf[mg::IXF_OVERSIZE] && !h_stat.ixf[mg::IXF_DEGENERATE];
+            lead_done = built && lead_ready;
             if (ctx_opt(ctx, "MASHGPU_SPARSE_DBG"))
                 fprintf(stderr, "compare sparse: index by tiles: shift %u, %u buckets (%u per window, %u windows), fullest %u%s%s\n", plan.g.shift, plan.g.Bp,
                         plan.g.BW, plan.g.NW, h_stat.ixf[mg::IXF_MAXBUCKET], h_stat.ixf[mg::IXF_OVERSIZE] ? " -- a bucket beyond the LDS: sorted instead" : "",
@@ -846,55 +905,43 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
     // ---- dense groups: runs of at least 8 consecutive rows linked to their predecessors.  Their universes come from the
     // index just built (gs_of is still alive), groups without one (or with one too large for a tile's LDS) are dropped,
     // the rest are encoded and the index's runs clipped for their rows.  Any failure here leaves the index as it is.
-    if (!link.empty() && sp->copies == 0) {
-        std::vector<mg::DenseGroup> cand_groups;
-        for (uint64_t i = 1; i < n;) {
-            if (!link[i]) { i++; continue; }
-            uint64_t j = i;
-            while (j < n && link[j]) j++;                    // rows [i - 1, j) form a chain
-            if (j - (i - 1) >= 8) {
-                mg::DenseGroup g{};
-                g.g0 = (uint32_t)(i - 1); g.g1 = (uint32_t)j;
-                cand_groups.push_back(g);
-            }
-            i = j + 1;
-        }
+    if (!cand_groups.empty()) {
         auto t_dense = std::chrono::steady_clock::now();
         while (!cand_groups.empty()) {                       // (a block to leave with `break`)
             const uint32_t ng = (uint32_t)cand_groups.size();
-            std::vector<uint32_t> grp_of(n, 0xFFFFFFFFu);
-            for (uint32_t g = 0; g < ng; g++)
-                for (uint32_t r = cand_groups[g].g0; r < cand_groups[g].g1; r++) grp_of[r] = g;
-            DevBuf<mg::DenseGroup> d_groups(ctx);
-            DevBuf<uint32_t> d_grp_of(ctx), d_val(ctx), d_nlead(ctx), d_us(ctx), d_ue(ctx);
-            DevBuf<unsigned long long> d_key(ctx), d_key2(ctx);
+            std::vector<uint32_t> &grp_of = grp_of_h;
+            DevBuf<uint32_t> d_us(ctx), d_ue(ctx);
+            DevBuf<unsigned long long> d_key2(ctx);
             DevBuf<unsigned char> d_tmp(ctx);
-            if (d_groups.alloc(ng) != hipSuccess || d_grp_of.alloc(n) != hipSuccess || d_nlead.alloc(2) != hipSuccess || d_us.alloc(ng) != hipSuccess ||
-                d_ue.alloc(ng) != hipSuccess) { (void)hipGetLastError(); break; }
-            // leaders: one list entry each, appended to one of a thousand lists (room for a quarter of the entries in all, evenly;
-            // a table with more, or with lists that fill unevenly, is searched a second time with the room the first pass asked for)
-            const uint32_t L = mg::dense_sublists();
-            DevBuf<unsigned long long> d_keyj(ctx);
-            DevBuf<uint32_t> d_valj(ctx), d_cnt_sub(ctx), d_off_sub(ctx);
-            uint32_t tot[2] = {0, 0}, cap_sub = std::max<uint32_t>(E / 4u / L + 64u, 256u);
-            hipError_t e2 = hipMemcpyAsync(d_groups, cand_groups.data(), ng * sizeof(mg::DenseGroup), hipMemcpyHostToDevice, ctx->stream);
-            if (e2 == hipSuccess) e2 = hipMemcpyAsync(d_grp_of, grp_of.data(), n * 4, hipMemcpyHostToDevice, ctx->stream);
-            if (e2 == hipSuccess && (d_cnt_sub.alloc(L) != hipSuccess || d_off_sub.alloc(L) != hipSuccess)) { (void)hipGetLastError(); e2 = hipErrorOutOfMemory; }
-            for (int attempt = 0; e2 == hipSuccess; attempt++) {
-                for (void **q : {(void **)&d_key.p, (void **)&d_val.p, (void **)&d_keyj.p, (void **)&d_valj.p})
-                    if (*q) { ctx_free(ctx, *q); *q = nullptr; }
-                const uint64_t room = (uint64_t)L * cap_sub;
-                if (d_key.alloc(room) != hipSuccess || d_val.alloc(room) != hipSuccess || d_keyj.alloc(room) != hipSuccess || d_valj.alloc(room) != hipSuccess) {
-                    (void)hipGetLastError();
-                    e2 = hipErrorOutOfMemory;
-                    break;
+            if (d_us.alloc(ng) != hipSuccess || d_ue.alloc(ng) != hipSuccess) { (void)hipGetLastError(); break; }
+            // leaders: one list entry each, appended to one of a thousand lists (room for a quarter of the entries in all, evenly).
+            // The build by tiles has found them already; behind the sort the finished index is searched, a second time with
+            // the room the first pass asked for if the lists filled unevenly.
+            const uint32_t L = lead_lists;
+            uint32_t *tot = lead_tot, cap_sub = lead_cap;
+            hipError_t e2 = hipSuccess;
+            if (!lead_done) {
+                if (built || !lead_ready) break;             // (searching needs every position's group start: the sort wrote it)
+                for (int attempt = 0; e2 == hipSuccess; attempt++) {
+                    if (attempt > 0) {
+                        for (void **q : {(void **)&d_key.p, (void **)&d_val.p, (void **)&d_keyj.p, (void **)&d_valj.p})
+                            if (*q) { ctx_free(ctx, *q); *q = nullptr; }
+                        const uint64_t room = (uint64_t)L * cap_sub;
+                        if (d_key.alloc(room) != hipSuccess || d_val.alloc(room) != hipSuccess || d_keyj.alloc(room) != hipSuccess || d_valj.alloc(room) != hipSuccess) {
+                            (void)hipGetLastError();
+                            e2 = hipErrorOutOfMemory;
+                            break;
+                        }
+                    }
+                    e2 = mg::dense_find_leaders(sp->sorted_rows, gs_of, sp->gend, d_grp_of, d_groups, E, d_key, d_val, cap_sub, d_keyj, d_valj, d_cnt_sub, d_off_sub,
+                                                d_nlead, ctx->stream);
+                    if (e2 == hipSuccess) e2 = hipMemcpyAsync(tot, d_nlead, 8, hipMemcpyDeviceToHost, ctx->stream);
+                    if (e2 == hipSuccess) e2 = hipStreamSynchronize(ctx->stream);
+                    if (e2 != hipSuccess || tot[1] <= cap_sub || attempt >= 1) break;
+                    cap_sub = tot[1];
                 }
-                e2 = mg::dense_find_leaders(sp->sorted_rows, gs_of, sp->gend, d_grp_of, d_groups, E, d_key, d_val, cap_sub, d_keyj, d_valj, d_cnt_sub, d_off_sub,
-                                            d_nlead, ctx->stream);
-                if (e2 == hipSuccess) e2 = hipMemcpyAsync(tot, d_nlead, 8, hipMemcpyDeviceToHost, ctx->stream);
-                if (e2 == hipSuccess) e2 = hipStreamSynchronize(ctx->stream);
-                if (e2 != hipSuccess || tot[1] <= cap_sub || attempt >= 1) break;
-                cap_sub = tot[1];
+            } else if (tot[1] > cap_sub && ctx_opt(ctx, "MASHGPU_SPARSE_DBG")) {
+                fprintf(stderr, "compare dense: a list of leaders asked for %u entries, room for %u: no dense groups for this table\n", tot[1], cap_sub);
             }
             const uint32_t nlead = tot[0];
             if (e2 != hipSuccess || nlead == 0 || tot[1] > cap_sub) { (void)hipGetLastError(); break; }

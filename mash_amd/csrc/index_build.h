@@ -42,6 +42,18 @@ struct IxGeom {
     uint64_t stride;      // row stride of the table (entries)
 };
 
+// The dense groups' leader search (compare_dense.hip), done where every group of equal values stands in LDS anyway: a value's
+// first holder inside a group of rows is its LEADER if a second holder follows; {group, value's first position, own position}
+// goes to one of `nsub` lists (by bucket).  cnt[nsub] counts what was ASKED for (beyond cap_sub nothing is written).
+struct IxLeaders {
+    const uint32_t *grp_of = nullptr;     // [n] group of a row, 0xFFFFFFFF: none (nullptr: no leader search)
+    const uint32_t *groups32 = nullptr;   // the groups as 8 words each: word 0 = first row, word 1 = one past the last
+    unsigned long long *key = nullptr;    // [nsub * cap_sub] (group << 32) | first sorted position of the value
+    uint32_t *val = nullptr;              // [nsub * cap_sub] the leader's own sorted position
+    uint32_t *cnt = nullptr;              // [nsub], zeroed by the caller
+    uint32_t cap_sub = 0, nsub = 0;       // nsub: a power of two
+};
+
 struct IxPlan {
     IxGeom g;
     bool ok = false;
@@ -61,7 +73,7 @@ size_t index_stat_scratch_bytes();
 hipError_t index_build(const IxPlan &plan, const uint64_t *hashes, const uint32_t *off, void *lb, void *cnt, void *start, void *pk, void *tc,
                        uint64_t *keys_sorted, uint32_t *sorted_rows, uint32_t *gend, uint32_t *gs_of, uint32_t *code_img, uint32_t *pos_img,
                        void *stat_scratch, unsigned long long *incidences, uint32_t *max_group, uint32_t *groups, uint32_t *flags,
-                       hipStream_t stream);
+                       const IxLeaders *leaders, hipStream_t stream);
 
 // MASHGPU_SPARSE_INDEX=verify: out2[0] += words of a and b that differ, out2[1] = min(out2[1], the first such word);
 // mode 0: all words, 1: where cond[i] == i, 2: where cond[i] != 0xFFFFFFFF

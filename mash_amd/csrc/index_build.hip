@@ -15,7 +15,22 @@
 #endif
 #include <stdint.h>
 
+#include <cstdlib>
+
 #include "index_build.h"
+
+// One LDS atomic instruction whose lanes may hit the same counter: the hardware serves them in lane order (that is relied
+// on for SPEED only, see ix_bucket_sort_body); the emulator's lanes are independent fibers, so there the statement is
+// executed lane by lane.
+#ifdef MG_HIP_EMU
+#define IX_IN_LANE_ORDER(stmt)                                   \
+    for (uint32_t l_ = 0; l_ < 64u; l_++) {                     \
+        if ((threadIdx.x & 63u) == l_) { stmt; }                \
+        hipemu::wave_sync();                                     \
+    }
+#else
+#define IX_IN_LANE_ORDER(stmt) { stmt; }
+#endif
 
 namespace mg {
 
@@ -27,10 +42,9 @@ constexpr uint32_t IX_LPR = 8;                  // lanes that read one row's seg
 constexpr uint32_t IX_BW_MAX = 512;             // buckets per window, at most
 constexpr uint32_t IX_CAP = 6144;               // entries of a bucket the LDS sort takes
 constexpr uint32_t IX_NT4 = 512;
-constexpr uint32_t IX_PER = IX_CAP / IX_NT4;    // 12 entries per work-item
 constexpr uint32_t IX_SUBBITS = 13;             // the counting sort's key: the next 13 bits below the bucket
 constexpr uint32_t IX_NSUB = 1u << IX_SUBBITS;
-constexpr uint32_t IX_MAXM = 256;               // entries that may agree in those bits (a value held by that many rows) before the bucket counts as degenerate
+constexpr uint32_t IX_MAXM = 1024;              // entries of a sub-bucket that holds two different values before the bucket counts as degenerate
 // expected entries of the fullest bucket IF values were held by one row each.  Collections are not like that: a value
 // of a cluster is held by ~80 rows at once, so a bucket's fill varies like sqrt(values) x 80, not sqrt(entries) -- C3 at an
 // expected 4 464 had a bucket of 7 046.  Half the capacity is headroom.
@@ -446,45 +460,60 @@ __global__ __launch_bounds__(IX_NT) void ix_tile_images_kernel(IxGeom g, const u
 
 // ------------------------------------------------------------------------------------------------
 // K4: one workgroup per bucket.  Its entries (packed words, in the order K3 wrote them) are sorted by (value, row) -- the
-// word's own order: a counting sort on the 13 bits below the bucket (LDS atomics: the order inside a sub-bucket is
-// arbitrary), then every entry ranks itself among the few that share its sub-bucket.  The groups of equal values are
-// found in LDS; out go the values, the rows, the groups' ends, optionally every position's group start, and
-// tc[start + j] = {code, position} of the entry that ARRIVED as the bucket's j-th (K5 reads them from there).
-constexpr uint32_t IX4_PK = 0, IX4_JX = IX4_PK + IX_CAP * 8u, IX4_H = IX4_JX + IX_CAP * 2u, IX4_PART = IX4_H + IX_NSUB * 2u,
-                   IX4_BYTES = IX4_PART + 64u;
+// word's own order: a STABLE counting sort on the 13 bits below the bucket (see ix_bucket_sort_body), then the sub-buckets
+// that hold two different values are put in order by comparison.  The groups of equal values are found in LDS; out go the
+// values, the rows, the groups' ends, optionally every position's group start, and tc[start + j] = {code, position} of
+// the entry that ARRIVED as the bucket's j-th (K5 reads them from there).
+constexpr uint32_t IX4_PK = 0, IX4_JX = IX4_PK + IX_CAP * 8u, IX4_H = IX4_JX + IX_CAP * 2u, IX4_MIX = IX4_H + IX_NSUB * 2u,
+                   IX4_PART = IX4_MIX + IX_NSUB / 8u, IX4_BYTES = IX4_PART + 64u;
 
-__global__ __launch_bounds__(IX_NT4, 4) void ix_bucket_sort_kernel(IxGeom g, const uint64_t *pk, const uint32_t *start, uint64_t *keys_sorted,
-                                                                uint32_t *sorted_rows, uint32_t *gend, uint32_t *gs_of, uint2 *tc,
-                                                                IxStatSlot *stat, uint32_t *flags)
+// the body for buckets of up to PER x IX_NT4 entries (a bucket of 2 000 entries does not run twelve rounds)
+//
+// Equal values are the rule, not the exception (a value of a cluster is held by ~80 of its rows), and they must come out
+// in row order.  They ARRIVE in row order (K3's partition is stable), so the counting sort is made stable instead of
+// ranking equal entries against each other afterwards (80 x 80 comparisons per value: 60 % of this kernel's time in its
+// first version): the entries are laid down in LDS in arrival order, wave w owns the sub-buckets whose top three bits are w
+// and sweeps ALL entries 64 at a time, taking a ticket for those that are its own -- one wave per counter, its sweeps in
+// program order, and lanes that hit one counter in the same instruction served in lane order.  That last point is how
+// the LDS behaves, not what the ISA promises: the finished order is therefore CHECKED (strictly ascending words) and a
+// bucket that fails it flags the table for the general sort.  What is left to rank by comparison are the sub-buckets that
+// hold two different values.
+template <uint32_t PER>
+__device__ __forceinline__ void ix_bucket_sort_body(const IxGeom &g, const uint64_t *__restrict__ pk, uint64_t *__restrict__ keys_sorted,
+                                                    uint32_t *__restrict__ sorted_rows, uint32_t *__restrict__ gend, uint32_t *__restrict__ gs_of,
+                                                    uint2 *__restrict__ tc, IxStatSlot *stat, uint32_t *flags, const IxLeaders &lead, uint64_t *s_pk,
+                                                    uint16_t *s_jx, uint32_t *s_h, uint32_t *s_mixed, uint32_t *s_part, uint32_t b, uint32_t G0, uint32_t N)
 {
-    MG_DYN_SHARED(unsigned char, lds);
-    uint64_t *s_pk = reinterpret_cast<uint64_t *>(lds + IX4_PK);
-    uint16_t *s_jx = reinterpret_cast<uint16_t *>(lds + IX4_JX);
-    uint32_t *s_h = reinterpret_cast<uint32_t *>(lds + IX4_H);
-    uint32_t *s_part = reinterpret_cast<uint32_t *>(lds + IX4_PART);
-    const uint32_t b = blockIdx.x, tid = threadIdx.x;
-    if (flags[IXF_OVERSIZE]) return;                     // uniform
-    const uint32_t G0 = start[b], N = start[b + 1] - G0;
-    if (N == 0) return;                                  // uniform  (N <= IX_CAP: the scan kernel raised IXF_OVERSIZE otherwise)
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t subshift = g.shift >= IX_SUBBITS ? g.shift + g.rb - IX_SUBBITS : g.rb;
     for (uint32_t x = tid; x < IX_NSUB / 2u; x += IX_NT4) s_h[x] = 0;
-    __syncthreads();
-    // ---- counting sort on the sub-bucket (two u16 counters per word)
+    if (tid < IX_NSUB / 32u) s_mixed[tid] = 0;
+    // ---- the entries in arrival order (registers and LDS)
     // (the per-entry registers are assigned unconditionally: a conditional element write makes the compiler carry the whole
     //  array through every branch -- 256 VGPRs and spills)
-    uint64_t v[IX_PER];
-    uint32_t sa[IX_PER];
+    uint64_t v[PER];
+    uint32_t sa[PER];
 #pragma unroll
-    for (uint32_t k = 0; k < IX_PER; k++) {
+    for (uint32_t k = 0; k < PER; k++) {
         const uint32_t j = tid + k * IX_NT4;
         const bool in = j < N;
         const uint64_t x = pk[G0 + (in ? j : 0u)];
+        v[k] = x;
+        if (in) s_pk[j] = x;
+    }
+    __syncthreads();
+    // ---- tickets, in arrival order (two u16 counters per word; the tickets go where the arrival indices will stand)
+    uint16_t *s_tk = s_jx;
+    for (uint32_t j0 = 0; j0 < N; j0 += 64u) {            // uniform
+        const uint32_t j = j0 + lane;
+        const bool in = j < N;
+        const uint64_t x = s_pk[in ? j : 0u];
         const uint32_t sub = (uint32_t)(x >> subshift) & (IX_NSUB - 1u);
+        const bool mine = in && (sub >> (IX_SUBBITS - 3u)) == wave;
         const uint32_t h16 = (sub & 1u) * 16u;
         uint32_t old = 0;
-        if (in) old = atomicAdd(&s_h[sub >> 1], 1u << h16);
-        v[k] = x;
-        sa[k] = sub | (((old >> h16) & 0xFFFFu) << 16);
+        IX_IN_LANE_ORDER(if (mine) old = atomicAdd(&s_h[sub >> 1], 1u << h16));
+        if (mine) s_tk[j] = (uint16_t)((old >> h16) & 0xFFFFu);
     }
     __syncthreads();
     {   // exclusive prefix over the 8192 counters, in place; work-item t owns the words [8 t, 8 t + 8)
@@ -503,48 +532,70 @@ __global__ __launch_bounds__(IX_NT4, 4) void ix_bucket_sort_kernel(IxGeom g, con
             run += lo + hi;
         }
     }
-    __syncthreads();
     const uint16_t *cs = reinterpret_cast<const uint16_t *>(s_h);      // cs[sub]: the sub-bucket's first sorted position
 #pragma unroll
-    for (uint32_t k = 0; k < IX_PER; k++) {
+    for (uint32_t k = 0; k < PER; k++) {
+        const uint32_t j = tid + k * IX_NT4;
+        sa[k] = s_tk[j < N ? j : 0u];
+    }
+    __syncthreads();                                     // (the counters are prefixes, every ticket is in a register: the arrival copy may go)
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) {
         const uint32_t j = tid + k * IX_NT4;
         if (j < N) {
-            const uint32_t q = (uint32_t)cs[sa[k] & 0xFFFFu] + (sa[k] >> 16);
+            const uint32_t sub = (uint32_t)(v[k] >> subshift) & (IX_NSUB - 1u);
+            const uint32_t q = (uint32_t)cs[sub] + sa[k];
             s_pk[q] = v[k];
             s_jx[q] = (uint16_t)j;
         }
     }
     __syncthreads();
-    // ---- inside a sub-bucket: an entry's place is the number of entries below it (words are distinct: value | row)
+    // ---- sub-buckets that hold more than one value: marked ...
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) {
+        const uint32_t q = tid + k * IX_NT4;
+        if (q < N) {
+            const uint64_t me = s_pk[q];
+            const uint32_t sub = (uint32_t)(me >> subshift) & (IX_NSUB - 1u);
+            if ((s_pk[cs[sub]] >> g.rb) != (me >> g.rb)) atomicOr(&s_mixed[sub >> 5], 1u << (sub & 31u));
+        }
+    }
+    __syncthreads();
+    // ... and put in order: values ascending, the entries of one value as they stand (stable)
     int degen = 0;
 #pragma unroll
-    for (uint32_t k = 0; k < IX_PER; k++) {
+    for (uint32_t k = 0; k < PER; k++) {
         const uint32_t q = tid + k * IX_NT4;
         const bool in = q < N;
         const uint32_t qc = in ? q : 0u;
         const uint64_t me = s_pk[qc];
         const uint32_t jv = s_jx[qc];
         const uint32_t sub = (uint32_t)(me >> subshift) & (IX_NSUB - 1u);
-        const uint32_t a = cs[sub], e = sub + 1u < IX_NSUB ? (uint32_t)cs[sub + 1u] : N;
-        uint32_t r = qc - a;                              // (alone in its sub-bucket: it stays)
-        if (in && e - a > 1u) {
+        uint32_t nq = qc;
+        if (in && ((s_mixed[sub >> 5] >> (sub & 31u)) & 1u)) {
+            const uint32_t a = cs[sub], e = sub + 1u < IX_NSUB ? (uint32_t)cs[sub + 1u] : N;
             if (e - a > IX_MAXM) {
                 degen = 1;
             } else {
-                r = 0;
-                for (uint32_t x = a; x < e; x++) r += s_pk[x] < me ? 1u : 0u;
+                const uint64_t low = me >> g.rb;
+                uint32_t r = 0;
+                for (uint32_t x = a; x < e; x++) {
+                    const uint64_t lx = s_pk[x] >> g.rb;
+                    r += (lx < low || (lx == low && x < qc)) ? 1u : 0u;
+                }
+                nq = a + r;
             }
         }
         v[k] = me;
-        sa[k] = (a + r) | (jv << 16);
+        sa[k] = nq | (jv << 16);
     }
     degen = __syncthreads_or(degen);
-    if (degen) {                                         // uniform: a value held by many rows, or values far from uniform
+    if (degen) {                                         // uniform: values clumped far from uniform
         if (tid == 0) flags[IXF_DEGENERATE] = 1u;
         return;
     }
 #pragma unroll
-    for (uint32_t k = 0; k < IX_PER; k++) {
+    for (uint32_t k = 0; k < PER; k++) {
         const uint32_t q = tid + k * IX_NT4;
         if (q < N) {
             s_pk[sa[k] & 0xFFFFu] = v[k];
@@ -555,24 +606,31 @@ __global__ __launch_bounds__(IX_NT4, 4) void ix_bucket_sort_kernel(IxGeom g, con
     // ---- where the bucket's j-th arrival stands now (the counters are dead: their space holds the inverse)
     uint16_t *inv = reinterpret_cast<uint16_t *>(s_h);
 #pragma unroll
-    for (uint32_t k = 0; k < IX_PER; k++) {
+    for (uint32_t k = 0; k < PER; k++) {
         const uint32_t q = tid + k * IX_NT4;
         if (q < N) inv[s_jx[q]] = (uint16_t)q;
     }
     __syncthreads();
     // ---- groups of equal values: work-item t owns the positions [PER t, PER t + PER); s_jx becomes the group's start
-    const uint32_t c0 = tid * IX_PER;
+    const uint32_t c0 = tid * PER;
     uint32_t lasthead = 0;                               // (position + 1) of the last group start in my positions, 0: none
+    int unordered = 0;                                   // the check of the stable counting sort: words strictly ascending
     {
-        uint64_t prev = (c0 > 0 && c0 <= N) ? s_pk[c0 - 1u] >> g.rb : 0ull;
-        for (uint32_t x = 0; x < IX_PER; x++) {
+        uint64_t prevw = (c0 > 0 && c0 <= N) ? s_pk[c0 - 1u] : 0ull;
+        for (uint32_t x = 0; x < PER; x++) {
             const uint32_t q = c0 + x;
             if (q < N) {
-                const uint64_t low = s_pk[q] >> g.rb;
-                if (q == 0 || low != prev) lasthead = q + 1u;
-                prev = low;
+                const uint64_t w = s_pk[q];
+                if (q > 0 && w <= prevw) unordered = 1;
+                if (q == 0 || (w >> g.rb) != (prevw >> g.rb)) lasthead = q + 1u;
+                prevw = w;
             }
         }
+    }
+    unordered = __syncthreads_or(unordered);
+    if (unordered) {                                     // uniform
+        if (tid == 0) flags[IXF_DEGENERATE] = 1u;
+        return;
     }
     const uint32_t carry = ix_block_scan_max(lasthead, s_part);
     unsigned long long inc = 0;
@@ -580,7 +638,7 @@ __global__ __launch_bounds__(IX_NT4, 4) void ix_bucket_sort_kernel(IxGeom g, con
     {
         uint32_t cur = carry > 0 ? carry - 1u : 0u;
         uint64_t prev = (c0 > 0 && c0 <= N) ? s_pk[c0 - 1u] >> g.rb : 0ull;
-        for (uint32_t x = 0; x < IX_PER; x++) {
+        for (uint32_t x = 0; x < PER; x++) {
             const uint32_t q = c0 + x;
             if (q < N) {
                 const uint64_t low = s_pk[q] >> g.rb;
@@ -625,11 +683,51 @@ __global__ __launch_bounds__(IX_NT4, 4) void ix_bucket_sort_kernel(IxGeom g, con
         if (m > 1u) atomicMax(&sl->max_group, m);
         atomicAdd(&sl->groups, h);
     }
-    // ---- out, by sorted position
     const uint64_t rowmask = (1ull << g.rb) - 1ull;
+    // ---- the dense groups' leaders (see IxLeaders): s_jx[q] is the start of q's group of equal values
+    if (lead.grp_of) {                                   // uniform
+        uint32_t lmask = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) {
+            const uint32_t q = tid + k * IX_NT4;
+            if (q < N) {
+                const uint64_t w = s_pk[q];
+                const uint32_t grp = lead.grp_of[(uint32_t)(w & rowmask)];
+                if (grp != 0xFFFFFFFFu) {
+                    const uint32_t g0 = lead.groups32[8u * grp], g1 = lead.groups32[8u * grp + 1u];
+                    const uint32_t gs = s_jx[q];
+                    const bool first = q == gs || (uint32_t)(s_pk[q - 1u] & rowmask) < g0;
+                    const bool more = q + 1u < N && (s_pk[q + 1u] >> g.rb) == (w >> g.rb) && (uint32_t)(s_pk[q + 1u] & rowmask) < g1;
+                    if (first && more) lmask |= 1u << k;
+                }
+            }
+        }
+        uint32_t ltotal = 0;
+        const uint32_t lbase = ix_block_scan_sum((uint32_t)__popc(lmask), s_part, ltotal);
+        if (ltotal) {                                    // uniform
+            const uint32_t sub = b & (lead.nsub - 1u);
+            if (tid == 0) s_part[15] = atomicAdd(&lead.cnt[sub], ltotal);
+            __syncthreads();
+            uint32_t at = s_part[15] + lbase;
+#pragma unroll
+            for (uint32_t k = 0; k < PER; k++) {
+                if ((lmask >> k) & 1u) {
+                    const uint32_t q = tid + k * IX_NT4;
+                    if (at < lead.cap_sub) {
+                        const uint64_t slot = (uint64_t)sub * lead.cap_sub + at;
+                        lead.key[slot] = ((unsigned long long)lead.grp_of[(uint32_t)(s_pk[q] & rowmask)] << 32) | (unsigned long long)(G0 + s_jx[q]);
+                        lead.val[slot] = G0 + q;
+                    }
+                    at++;
+                }
+            }
+            __syncthreads();                             // (s_part is used again)
+        }
+    }
+    // ---- out, by sorted position
     const uint64_t vbase = (uint64_t)b << g.shift;
 #pragma unroll
-    for (uint32_t k = 0; k < IX_PER; k++) {
+    for (uint32_t k = 0; k < PER; k++) {
         const uint32_t q = tid + k * IX_NT4;
         if (q < N) {
             const uint64_t w = s_pk[q], low = w >> g.rb;
@@ -642,7 +740,7 @@ __global__ __launch_bounds__(IX_NT4, 4) void ix_bucket_sort_kernel(IxGeom g, con
     }
     // ---- and by arrival: what K5 carries into the images
 #pragma unroll
-    for (uint32_t k = 0; k < IX_PER; k++) {
+    for (uint32_t k = 0; k < PER; k++) {
         const uint32_t j = tid + k * IX_NT4;
         if (j < N) {
             const uint32_t q = inv[j], gs = s_jx[q];
@@ -651,6 +749,31 @@ __global__ __launch_bounds__(IX_NT4, 4) void ix_bucket_sort_kernel(IxGeom g, con
             tc[G0 + j] = make_uint2(((G0 + gs) << 1) | shared, G0 + q);
         }
     }
+}
+
+__global__ __launch_bounds__(IX_NT4, 4) void ix_bucket_sort_kernel(IxGeom g, const uint64_t *pk, const uint32_t *start, uint64_t *keys_sorted,
+                                                                uint32_t *sorted_rows, uint32_t *gend, uint32_t *gs_of, uint2 *tc,
+                                                                IxStatSlot *stat, uint32_t *flags, IxLeaders lead)
+{
+    MG_DYN_SHARED(unsigned char, lds);
+    uint64_t *s_pk = reinterpret_cast<uint64_t *>(lds + IX4_PK);
+    uint16_t *s_jx = reinterpret_cast<uint16_t *>(lds + IX4_JX);
+    uint32_t *s_h = reinterpret_cast<uint32_t *>(lds + IX4_H);
+    uint32_t *s_mixed = reinterpret_cast<uint32_t *>(lds + IX4_MIX);
+    uint32_t *s_part = reinterpret_cast<uint32_t *>(lds + IX4_PART);
+    const uint32_t b = blockIdx.x;
+    if (flags[IXF_OVERSIZE]) return;                     // uniform
+    const uint32_t G0 = start[b], N = start[b + 1] - G0;
+    if (N == 0) return;                                  // uniform  (N <= IX_CAP: the scan kernel raised IXF_OVERSIZE otherwise)
+    const uint32_t per = (N + IX_NT4 - 1u) / IX_NT4;      // uniform
+#define IX_BODY(P) ix_bucket_sort_body<P>(g, pk, keys_sorted, sorted_rows, gend, gs_of, tc, stat, flags, lead, s_pk, s_jx, s_h, s_mixed, s_part, b, G0, N)
+    if (per <= 3u) IX_BODY(3);
+    else if (per <= 4u) IX_BODY(4);
+    else if (per <= 5u) IX_BODY(5);
+    else if (per <= 6u) IX_BODY(6);
+    else if (per <= 8u) IX_BODY(8);
+    else IX_BODY(12);
+#undef IX_BODY
 }
 
 __global__ __launch_bounds__(256) void ix_stat_reduce_kernel(const IxStatSlot *stat, unsigned long long *incidences, uint32_t *max_group, uint32_t *groups)
@@ -740,6 +863,10 @@ IxPlan index_plan(uint32_t n, uint32_t E, uint32_t s, uint32_t rs, uint64_t stri
     g.Bp = g.NW * g.BW;
     g.npass = (bw_log + 3u) / 4u;
     g.wgrp = 8;
+    if (const char *e = getenv("MASHGPU_IX_WGRP")) {       // (tuning knob: windows per group of the tile order)
+        const int v = atoi(e);
+        if (v >= 1 && v <= 4096) g.wgrp = (uint32_t)v;
+    }
     const uint64_t nseq = (uint64_t)((g.NW + g.wgrp - 1u) / g.wgrp) * g.wgrp * g.nblk;
     if (nseq >= (1ull << 30)) { p.why = "too many tiles"; return p; }
     g.nseq = (uint32_t)nseq;
@@ -756,7 +883,7 @@ IxPlan index_plan(uint32_t n, uint32_t E, uint32_t s, uint32_t rs, uint64_t stri
 hipError_t index_build(const IxPlan &plan, const uint64_t *hashes, const uint32_t *off, void *lb_v, void *cnt_v, void *start_v, void *pk_v, void *tc_v,
                        uint64_t *keys_sorted, uint32_t *sorted_rows, uint32_t *gend, uint32_t *gs_of, uint32_t *code_img, uint32_t *pos_img,
                        void *stat_scratch, unsigned long long *incidences, uint32_t *max_group, uint32_t *groups, uint32_t *flags,
-                       hipStream_t stream)
+                       const IxLeaders *leaders, hipStream_t stream)
 {
     if (!plan.ok) return hipErrorInvalidValue;
     const IxGeom g = plan.g;
@@ -787,7 +914,8 @@ hipError_t index_build(const IxPlan &plan, const uint64_t *hashes, const uint32_
     e = hipMemsetAsync(stat_scratch, 0, index_stat_scratch_bytes(), stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(ix_bucket_sort_kernel, dim3(g.Bp), dim3(IX_NT4), IX4_BYTES, stream, g, (const uint64_t *)pk, (const uint32_t *)start, keys_sorted,
-                       sorted_rows, gend, g.want_gs ? gs_of : (uint32_t *)nullptr, tc, static_cast<IxStatSlot *>(stat_scratch), flags);
+                       sorted_rows, gend, g.want_gs ? gs_of : (uint32_t *)nullptr, tc, static_cast<IxStatSlot *>(stat_scratch), flags,
+                       leaders ? *leaders : IxLeaders());
     hipLaunchKernelGGL(ix_stat_reduce_kernel, dim3(1), dim3(256), 0, stream, static_cast<const IxStatSlot *>(stat_scratch), incidences, max_group, groups);
     hipLaunchKernelGGL(ix_tile_images_kernel, dim3(tiles), dim3(IX_NT), 0, stream, g, (const uint16_t *)lb, (const uint32_t *)flags, (const uint2 *)tc,
                        code_img, pos_img);

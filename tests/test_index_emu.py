@@ -16,7 +16,7 @@ SRC = os.path.join(ROOT, "tests", "emu", "index_emu_main.cpp")
 INC = ["-I" + os.path.join(ROOT, "tools", "hipemu"), "-I" + os.path.join(ROOT, "mash_amd", "csrc")]
 
 FAST = ["random_small", "random_two_blocks", "clusters", "clusters_windows", "ragged", "ragged_windows", "copies_out", "top_bit", "one_row",
-        "pieces", "clade_degenerate", "oversize"]
+        "pieces", "clade", "oversize"]
 
 
 @pytest.fixture(scope="module")
