@@ -128,6 +128,7 @@ hipError_t launch_sparse_row_digest(const uint64_t *hashes, uint64_t stride, con
                                     unsigned long long *digest, hipStream_t stream);
 hipError_t launch_sparse_row_equal(const uint64_t *hashes, uint64_t stride, const uint32_t *cnt, const uint2 *pairs, uint32_t npairs,
                                    uint32_t *equal, hipStream_t stream);
+hipError_t launch_sparse_row_counts(const uint32_t *nhash, uint32_t n, uint32_t cap, uint32_t *cnt, hipStream_t stream);
 size_t sparse_sort_temp_bytes(uint32_t E, uint32_t end_bit, uint32_t begin_bit);
 uint32_t sparse_img_stride(uint32_t s);          // row stride of a code image
 hipError_t sparse_build_index(const uint64_t *hashes, uint64_t stride, const uint32_t *off, uint32_t n, uint32_t E,

@@ -155,6 +155,20 @@ __global__ __launch_bounds__(256) void sp_stat_reduce_kernel(const SpStatSlot *s
 
 size_t sparse_stat_scratch_bytes() { return sizeof(SpStatSlot) * SP_STAT_SLOTS; }
 
+// the entries of every row that enter the index: its first min(nhash, cap) hashes
+__global__ __launch_bounds__(256) void sp_row_counts_kernel(const uint32_t *nhash, uint32_t n, uint32_t cap, uint32_t *cnt)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) cnt[i] = nhash[i] < cap ? nhash[i] : cap;
+}
+
+hipError_t launch_sparse_row_counts(const uint32_t *nhash, uint32_t n, uint32_t cap, uint32_t *cnt, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(sp_row_counts_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, nhash, n, cap, cnt);
+    return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void sp_fill_u32_kernel(uint32_t *p, uint64_t count, uint32_t v)
 {
     const uint64_t stride = (uint64_t)gridDim.x * 256u;

@@ -476,8 +476,6 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
 {
     for (mg_table::Sparse *sp : t->sparse)
         if (sp->s == s && sp->clustered == clustered) { *out = sp; return MG_OK; }
-    int rc = table_classes(ctx, t);                        // host copies of nhash and the rows' largest hashes
-    if (rc != MG_OK) return rc;
     mg_table::Sparse *sp = new mg_table::Sparse;
     sp->s = s;
     sp->clustered = clustered;
@@ -491,100 +489,148 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
     if (n * sp->rs >= (1ull << 32)) return unusable("image index beyond 32 bits");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const auto t_begin = std::chrono::steady_clock::now();
-    // (the "index" phase of the library's HIP-event records: everything this function queues -- clustering, digests, sort,
-    //  images, dense groups -- incl. the waits between its steps)
+    // (the "index" phase of the library's HIP-event records: everything this function queues -- clustering, digests, the
+    //  index, dense groups -- incl. the waits between its steps)
     prof_begin(ctx, ctx->prof_index);
     struct ProfEnd { mg_ctx *c; ~ProfEnd() { prof_end(c, c->prof_index); } } prof_end_guard{ctx};
-    // ---- identical rows (see compare_sparse.hip): digest every row, sort the digests on the device; rows whose
-    // digest and length equal their predecessor's are suspects, verified value by value; copies then stay out
-    // of the index
-    std::vector<uint32_t> cnt_true(n);
+    // ---- ONE wait for everything the host must know before it can lay the index out (round 4 waited four times here):
+    //  * the rows' hash counts and largest hashes, if the table is new to the library (table_classes' kernel);
+    //  * whether any two rows may be copies of each other: every row's digest, sorted on the device; rows whose digest
+    //    and length equal their predecessor's are suspects.  Taken in the TABLE's order -- whether copies exist is a
+    //    property of the set of rows; only a table that has suspects digests its rows again in the index's order, has
+    //    them verified value by value and keeps the copies out of the index (see compare_sparse.hip);
+    //  * the clustered variant: rows that share one of their smallest hashes next to each other (labels on the device,
+    //    two small sorts); the plain variant: which neighbouring rows are near-copies of each other (dense groups).
+    const bool need_classes = t->cls.size() != n;
+    const bool dedup = !ctx_opt(ctx, "MASHGPU_SPARSE_NO_DEDUP");
+    bool want_dense = true;
+    if (const char *e = ctx_opt(ctx, "MASHGPU_COMPARE_DENSE")) want_dense = atoi(e) != 0;
+    const bool try_cluster = clustered && n >= 16;
+    const bool try_links = !try_cluster && want_dense && n >= 8 && s <= 16384;      // (u16 counters of the extras, one bit a flag)
+    DevBuf<uint8_t> dc_cls(ctx), d_link(ctx);
+    DevBuf<unsigned long long> dc_last(ctx), d_dig(ctx), d_dig_sorted(ctx), k_a(ctx), k_b(ctx);
+    DevBuf<uint32_t> d_cnt(ctx), d_rows_sorted(ctx), d_flags(ctx), d_nflag(ctx), r_a(ctx), r_b(ctx), l_a(ctx), l_b(ctx), d_inv(ctx), d_lab(ctx);
+    DevBuf<unsigned char> d_tmp_dup(ctx), d_tmp_cl(ctx);
+    std::vector<uint8_t> hc_cls, link;
+    std::vector<uint64_t> hc_last;
+    std::vector<uint32_t> hc_nh, inv, lab_sorted;
+    uint32_t nflag = 0;
+    const size_t tb_dup = mg::sparse_dup_temp_bytes((uint32_t)n), tb_cl = mg::dense_cluster_temp_bytes((uint32_t)n);
+    if (d_cnt.alloc(n) != hipSuccess || (need_classes && (dc_cls.alloc(n) != hipSuccess || dc_last.alloc(n) != hipSuccess)) ||
+        (dedup && (d_dig.alloc(n) != hipSuccess || d_dig_sorted.alloc(n) != hipSuccess || d_rows_sorted.alloc(n) != hipSuccess ||
+                   d_flags.alloc(n) != hipSuccess || d_nflag.alloc(1) != hipSuccess || d_tmp_dup.alloc(std::max<size_t>(tb_dup, 16)) != hipSuccess))) {
+        (void)hipGetLastError();
+        return unusable("no device memory for the index");
+    }
+    bool cluster_q = false, links_q = false;
+    {
+        hipError_t e = hipSuccess;
+        if (need_classes) {
+            hc_cls.resize(n);
+            hc_last.resize(n);
+            hc_nh.resize(n);
+            e = mg::launch_row_classes(t->hashes, t->nhash, n, t->s, dc_cls, dc_last, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(hc_nh.data(), t->nhash, n * 4, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(hc_cls.data(), dc_cls, n, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(hc_last.data(), dc_last, n * 8, hipMemcpyDeviceToHost, ctx->stream);
+        }
+        // the rows' entry counts min(nhash, s) straight from the table's counts
+        if (e == hipSuccess) e = mg::launch_sparse_row_counts(t->nhash, (uint32_t)n, (uint32_t)std::min<uint64_t>(t->s, s), d_cnt, ctx->stream);
+        if (e == hipSuccess && dedup) {
+            e = mg::launch_sparse_row_digest(t->hashes, t->s, d_cnt, (uint32_t)n, d_dig, ctx->stream);
+            if (e == hipSuccess)
+                e = mg::launch_sparse_dup_suspects(d_dig, d_cnt, (uint32_t)n, d_tmp_dup, tb_dup, d_dig_sorted, d_rows_sorted, d_flags, d_nflag, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(&nflag, d_nflag, 4, hipMemcpyDeviceToHost, ctx->stream);
+        }
+        if (e == hipSuccess && try_cluster) {
+            if (k_a.alloc(4 * n) == hipSuccess && k_b.alloc(4 * n) == hipSuccess && r_a.alloc(4 * n) == hipSuccess && r_b.alloc(4 * n) == hipSuccess &&
+                l_a.alloc(n) == hipSuccess && l_b.alloc(n) == hipSuccess && d_inv.alloc(n) == hipSuccess && d_lab.alloc(n) == hipSuccess &&
+                d_tmp_cl.alloc(std::max<size_t>(tb_cl, 16)) == hipSuccess) {
+                inv.resize(n);
+                lab_sorted.resize(n);
+                e = mg::dense_cluster_rows(t->hashes, t->s, d_cnt, (uint32_t)n, d_tmp_cl, tb_cl, k_a, k_b, r_a, r_b, l_a, l_b, d_inv, d_lab, ctx->stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(inv.data(), d_inv, n * 4, hipMemcpyDeviceToHost, ctx->stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(lab_sorted.data(), d_lab, n * 4, hipMemcpyDeviceToHost, ctx->stream);
+                cluster_q = true;
+            } else {
+                (void)hipGetLastError();                    // no memory for the clustering: the table's own order
+            }
+        }
+        if (e == hipSuccess && try_links) {
+            if (d_link.alloc(n) == hipSuccess) {
+                link.resize(n);
+                e = mg::launch_dense_neighbors(t->hashes, t->s, d_cnt, (uint32_t)n, d_link, ctx->stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(link.data(), d_link, n, hipMemcpyDeviceToHost, ctx->stream);
+                links_q = true;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+        const hipError_t es = hipStreamSynchronize(ctx->stream);      // (also when something failed: host vectors are targets of copies)
+        if (e == hipSuccess) e = es;
+        if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare (index: rows, copies, order): ") + hipGetErrorString(e));
+    }
+    if (need_classes) {
+        t->cls.swap(hc_cls);
+        t->last.swap(hc_last);
+        t->nh.swap(hc_nh);
+    }
+    if (!links_q) link.clear();
+    std::vector<uint32_t> cnt_true(n), cnt_perm;
     uint32_t max_cnt = 0;
     for (uint64_t i = 0; i < n; i++) {
         cnt_true[i] = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(t->nh[i], t->s), s);
         max_cnt = std::max(max_cnt, cnt_true[i]);
     }
     std::vector<uint32_t> rep;                              // empty: no copies
-    DevBuf<uint32_t> d_cnt(ctx);
-    if (d_cnt.alloc(n) != hipSuccess) { (void)hipGetLastError(); return unusable("no device memory for the index"); }
-    HIP_TRY(ctx, hipMemcpyAsync(d_cnt, cnt_true.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
-    // ---- the clustered variant: rows that share one of their smallest hashes next to each other (labels on the device,
-    // two small sorts), the table copied in that order; everything below then works on the copy as if it were the table
+    // ---- the clustered variant: the table copied in the clustered order; everything below then works on the copy as if
+    // it were the table
     const uint64_t *H = t->hashes;                          // what the index is built from
     std::vector<uint64_t> last_p;                           // the rows' largest hashes in index order (empty: t->last)
-    std::vector<uint32_t> lab_sorted;                       // label of every index row (clustered variant)
-    if (clustered && n >= 16) {
-        DevBuf<unsigned long long> k_a(ctx), k_b(ctx);
-        DevBuf<uint32_t> r_a(ctx), r_b(ctx), l_a(ctx), l_b(ctx), d_inv(ctx), d_lab(ctx);
-        DevBuf<unsigned char> d_tmp(ctx);
-        const size_t tb = mg::dense_cluster_temp_bytes((uint32_t)n);
-        std::vector<uint32_t> inv(n);
-        lab_sorted.resize(n);
-        if (k_a.alloc(4 * n) == hipSuccess && k_b.alloc(4 * n) == hipSuccess && r_a.alloc(4 * n) == hipSuccess && r_b.alloc(4 * n) == hipSuccess &&
-            l_a.alloc(n) == hipSuccess && l_b.alloc(n) == hipSuccess && d_inv.alloc(n) == hipSuccess && d_lab.alloc(n) == hipSuccess &&
-            d_tmp.alloc(std::max<size_t>(tb, 16)) == hipSuccess) {
-            HIP_TRY(ctx, mg::dense_cluster_rows(t->hashes, t->s, d_cnt, (uint32_t)n, d_tmp, tb, k_a, k_b, r_a, r_b, l_a, l_b, d_inv, d_lab, ctx->stream));
-            HIP_TRY(ctx, hipMemcpyAsync(inv.data(), d_inv, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(ctx, hipMemcpyAsync(lab_sorted.data(), d_lab, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            bool identity = true;
-            for (uint64_t a = 0; a < n && identity; a++) identity = inv[a] == a;
-            if (!identity) {
-                void *pi = nullptr, *ph = nullptr;
-                if (ctx_malloc(ctx, &pi, n * 4) != hipSuccess || ctx_malloc(ctx, &ph, std::max<uint64_t>(n * t->s, 1) * 8) != hipSuccess) {
-                    (void)hipGetLastError();
-                    ctx_free(ctx, pi);
-                    lab_sorted.clear();                     // no memory for the copy: the table's own order
-                } else {
-                    sp->inv = static_cast<uint32_t *>(pi);
-                    sp->phashes = static_cast<uint64_t *>(ph);
-                    HIP_TRY(ctx, hipMemcpyAsync(sp->inv, d_inv, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
-                    HIP_TRY(ctx, mg::launch_dense_gather_rows(t->hashes, t->s, sp->inv, (uint32_t)n, sp->phashes, ctx->stream));
-                    H = sp->phashes;
-                    std::vector<uint32_t> c2(n);
-                    last_p.resize(n);
-                    for (uint64_t a = 0; a < n; a++) { c2[a] = cnt_true[inv[a]]; last_p[a] = t->last[inv[a]]; }
-                    cnt_true.swap(c2);
-                    HIP_TRY(ctx, hipMemcpyAsync(d_cnt, cnt_true.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
-                    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // (c2, the old counts, leaves scope; the buffers of this block go back to the pool)
-                }
+    if (cluster_q) {
+        bool identity = true;
+        for (uint64_t a = 0; a < n && identity; a++) identity = inv[a] == a;
+        if (!identity) {
+            void *pi = nullptr, *ph = nullptr;
+            if (ctx_malloc(ctx, &pi, n * 4) != hipSuccess || ctx_malloc(ctx, &ph, std::max<uint64_t>(n * t->s, 1) * 8) != hipSuccess) {
+                (void)hipGetLastError();
+                ctx_free(ctx, pi);
+                lab_sorted.clear();                         // no memory for the copy: the table's own order
+            } else {
+                sp->inv = static_cast<uint32_t *>(pi);
+                sp->phashes = static_cast<uint64_t *>(ph);
+                HIP_TRY(ctx, hipMemcpyAsync(sp->inv, d_inv, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+                HIP_TRY(ctx, mg::launch_dense_gather_rows(t->hashes, t->s, sp->inv, (uint32_t)n, sp->phashes, ctx->stream));
+                H = sp->phashes;
+                cnt_perm.resize(n);
+                last_p.resize(n);
+                for (uint64_t a = 0; a < n; a++) { cnt_perm[a] = cnt_true[inv[a]]; last_p[a] = t->last[inv[a]]; }
+                cnt_true.swap(cnt_perm);                    // (cnt_perm, the table-order counts, lives to the end of the function: no wait for the copy)
+                HIP_TRY(ctx, hipMemcpyAsync(d_cnt, cnt_true.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
             }
-        } else {
-            (void)hipGetLastError();
-            lab_sorted.clear();
         }
+    } else {
+        lab_sorted.clear();
     }
     const std::vector<uint64_t> &lastv = last_p.empty() ? t->last : last_p;
-    // which neighbouring rows are near-copies of each other (dense groups, compare_dense.hip): a sample test per row,
-    // read back with the copy suspects below
-    std::vector<uint8_t> link;
-    bool want_dense = true;
-    if (const char *e = ctx_opt(ctx, "MASHGPU_COMPARE_DENSE")) want_dense = atoi(e) != 0;
-    DevBuf<uint8_t> d_link(ctx);
+    // which neighbouring rows are near-copies of each other (dense groups, compare_dense.hip)
     if (want_dense && n >= 8 && s <= 16384 && !lab_sorted.empty()) {
         link.assign(n, 0);                                  // clustered variant: neighbours with the same label
         for (uint64_t a = 1; a < n; a++) link[a] = (lab_sorted[a] == lab_sorted[a - 1] && cnt_true[a] && cnt_true[a - 1]) ? 1 : 0;
-    } else if (want_dense && n >= 8 && s <= 16384 && d_link.alloc(n) == hipSuccess) {      // (u16 counters of the extras, one bit a flag)
+    } else if (cluster_q && want_dense && n >= 8 && s <= 16384 && d_link.alloc(n) == hipSuccess) {
+        // (the clustering was asked for and came to nothing: the neighbours of the table's own order after all)
         link.resize(n);
         HIP_TRY(ctx, mg::launch_dense_neighbors(H, t->s, d_cnt, (uint32_t)n, d_link, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(link.data(), d_link, n, hipMemcpyDeviceToHost, ctx->stream));
-        if (ctx_opt(ctx, "MASHGPU_SPARSE_NO_DEDUP")) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    } else {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    } else if (!links_q) {
         (void)hipGetLastError();
+        link.clear();
     }
-    if (!ctx_opt(ctx, "MASHGPU_SPARSE_NO_DEDUP")) {
-        DevBuf<unsigned long long> d_dig(ctx), d_dig_sorted(ctx);
-        DevBuf<uint32_t> d_rows_sorted(ctx), d_flags(ctx), d_nflag(ctx);
-        DevBuf<unsigned char> d_tmp(ctx);
-        const size_t tb = mg::sparse_dup_temp_bytes((uint32_t)n);
-        if (d_dig.alloc(n) != hipSuccess || d_dig_sorted.alloc(n) != hipSuccess || d_rows_sorted.alloc(n) != hipSuccess ||
-            d_flags.alloc(n) != hipSuccess || d_nflag.alloc(1) != hipSuccess || d_tmp.alloc(std::max<size_t>(tb, 16)) != hipSuccess) {
-            (void)hipGetLastError();
-            return unusable("no device memory for the index");
-        }
-        uint32_t nflag = 0;
+    if (dedup && nflag) {
+        // suspects: the digests again, of the rows the index will be built from and in its order
         HIP_TRY(ctx, mg::launch_sparse_row_digest(H, t->s, d_cnt, (uint32_t)n, d_dig, ctx->stream));
-        HIP_TRY(ctx, mg::launch_sparse_dup_suspects(d_dig, d_cnt, (uint32_t)n, d_tmp, tb, d_dig_sorted, d_rows_sorted, d_flags, d_nflag, ctx->stream));
+        HIP_TRY(ctx, mg::launch_sparse_dup_suspects(d_dig, d_cnt, (uint32_t)n, d_tmp_dup, tb_dup, d_dig_sorted, d_rows_sorted, d_flags, d_nflag, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(&nflag, d_nflag, 4, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (nflag) {
@@ -728,7 +774,6 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
             }
         }
     }
-    const bool want_gs = !cand_groups.empty() && !lead_ready;   // (only the search behind the sort reads every position's group start)
     mg::IxPlan plan;
     if (ix_tiles) plan = mg::index_plan((uint32_t)n, E, s, sp->rs, t->s, maxv, dens0, ix_verify);
     const size_t temp_bytes = std::max(mg::sparse_order_temp_bytes((uint32_t)n), mg::sparse_order_slice_temp_bytes((uint32_t)n));

@@ -44,6 +44,8 @@ constexpr uint32_t IX_CAP = 6144;               // entries of a bucket the LDS s
 constexpr uint32_t IX_NT4 = 512;
 constexpr uint32_t IX_SUBBITS = 13;             // the counting sort's key: the next 13 bits below the bucket
 constexpr uint32_t IX_NSUB = 1u << IX_SUBBITS;
+constexpr uint32_t IX_SUBLOW = IX_SUBBITS - 3u;      // a sub-bucket's bits below the three that name the wave owning it (IX_NT4 / 64 = 8 waves)
+static_assert(IX_SUBBITS == 13 && IX_NT4 == 512, "the ticket slots hold 3 + 13 bits");
 constexpr uint32_t IX_MAXM = 1024;              // entries of a sub-bucket that holds two different values before the bucket counts as degenerate
 // expected entries of the fullest bucket IF values were held by one row each.  Collections are not like that: a value
 // of a cluster is held by ~80 rows at once, so a bucket's fill varies like sqrt(values) x 80, not sqrt(entries) -- C3 at an
@@ -499,21 +501,37 @@ __device__ __forceinline__ void ix_bucket_sort_body(const IxGeom &g, const uint6
         const bool in = j < N;
         const uint64_t x = pk[G0 + (in ? j : 0u)];
         v[k] = x;
-        if (in) s_pk[j] = x;
+        const uint32_t sub0 = (uint32_t)(x >> subshift) & (IX_NSUB - 1u);
+        if (in) s_jx[j] = (uint16_t)(((sub0 >> IX_SUBLOW) << 13) | (sub0 & ((1u << IX_SUBLOW) - 1u)));
     }
     __syncthreads();
-    // ---- tickets, in arrival order (two u16 counters per word; the tickets go where the arrival indices will stand)
+    // ---- tickets, in arrival order (two u16 counters per word).  Slot j: bits 15..13 the wave that owns the entry's
+    // sub-bucket (its top three bits), below them the sub-bucket's other ten bits until that wave has served the entry, then
+    // the ticket (13 bits).  A wave that does not own the entry looks at the top three bits only, whenever it comes by.
     uint16_t *s_tk = s_jx;
-    for (uint32_t j0 = 0; j0 < N; j0 += 64u) {            // uniform
-        const uint32_t j = j0 + lane;
-        const bool in = j < N;
-        const uint64_t x = s_pk[in ? j : 0u];
-        const uint32_t sub = (uint32_t)(x >> subshift) & (IX_NSUB - 1u);
-        const bool mine = in && (sub >> (IX_SUBBITS - 3u)) == wave;
-        const uint32_t h16 = (sub & 1u) * 16u;
-        uint32_t old = 0;
-        IX_IN_LANE_ORDER(if (mine) old = atomicAdd(&s_h[sub >> 1], 1u << h16));
-        if (mine) s_tk[j] = (uint16_t)((old >> h16) & 0xFFFFu);
+    for (uint32_t j0 = 0; j0 < N; j0 += 256u) {           // uniform; four sweeps of 64 in flight (the LDS serves a wave's requests in order)
+        uint32_t tag[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; u++) {
+            const uint32_t j = j0 + 64u * u + lane;
+            tag[u] = j < N ? (uint32_t)s_tk[j] : 0xFFFFu;    // (beyond the bucket: nobody's -- wave 7 checks j as well)
+        }
+        uint32_t old[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; u++) {
+            const uint32_t j = j0 + 64u * u + lane;
+            const bool mine = (tag[u] >> 13) == wave && j < N;
+            const uint32_t sub = (wave << IX_SUBLOW) | (tag[u] & ((1u << IX_SUBLOW) - 1u));
+            const uint32_t h16 = (sub & 1u) * 16u;
+            uint32_t o = 0;
+            IX_IN_LANE_ORDER(if (mine) o = atomicAdd(&s_h[sub >> 1], 1u << h16));
+            old[u] = (o >> h16) & 0xFFFFu;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; u++) {
+            const uint32_t j = j0 + 64u * u + lane;
+            if ((tag[u] >> 13) == wave && j < N) s_tk[j] = (uint16_t)((wave << 13) | old[u]);
+        }
     }
     __syncthreads();
     {   // exclusive prefix over the 8192 counters, in place; work-item t owns the words [8 t, 8 t + 8)
@@ -536,7 +554,7 @@ __device__ __forceinline__ void ix_bucket_sort_body(const IxGeom &g, const uint6
 #pragma unroll
     for (uint32_t k = 0; k < PER; k++) {
         const uint32_t j = tid + k * IX_NT4;
-        sa[k] = s_tk[j < N ? j : 0u];
+        sa[k] = (uint32_t)s_tk[j < N ? j : 0u] & 0x1FFFu;               // (the ticket: 13 bits below the owner's three)
     }
     __syncthreads();                                     // (the counters are prefixes, every ticket is in a register: the arrival copy may go)
 #pragma unroll
@@ -603,54 +621,69 @@ __device__ __forceinline__ void ix_bucket_sort_body(const IxGeom &g, const uint6
         }
     }
     __syncthreads();
-    // ---- where the bucket's j-th arrival stands now (the counters are dead: their space holds the inverse)
+    // ---- where the bucket's j-th arrival stands now (the counters are dead: their space holds the inverse), and where the
+    // groups of equal values start: one bit per position (a wave's 64 consecutive positions = one ballot = one word).  The
+    // same pass checks the stable counting sort: words strictly ascending.
     uint16_t *inv = reinterpret_cast<uint16_t *>(s_h);
+    unsigned long long *s_hb = reinterpret_cast<unsigned long long *>(s_mixed);      // (the marks are dead too; N / 64 words <= 1 KB)
+    int unordered = 0;
 #pragma unroll
     for (uint32_t k = 0; k < PER; k++) {
         const uint32_t q = tid + k * IX_NT4;
-        if (q < N) inv[s_jx[q]] = (uint16_t)q;
-    }
-    __syncthreads();
-    // ---- groups of equal values: work-item t owns the positions [PER t, PER t + PER); s_jx becomes the group's start
-    const uint32_t c0 = tid * PER;
-    uint32_t lasthead = 0;                               // (position + 1) of the last group start in my positions, 0: none
-    int unordered = 0;                                   // the check of the stable counting sort: words strictly ascending
-    {
-        uint64_t prevw = (c0 > 0 && c0 <= N) ? s_pk[c0 - 1u] : 0ull;
-        for (uint32_t x = 0; x < PER; x++) {
-            const uint32_t q = c0 + x;
-            if (q < N) {
-                const uint64_t w = s_pk[q];
-                if (q > 0 && w <= prevw) unordered = 1;
-                if (q == 0 || (w >> g.rb) != (prevw >> g.rb)) lasthead = q + 1u;
-                prevw = w;
-            }
-        }
+        const bool in = q < N;
+        const uint32_t qc = in ? q : 0u;
+        const uint64_t w = s_pk[qc], prev = s_pk[qc > 0 ? qc - 1u : 0u];
+        const bool head = in && (q == 0 || (w >> g.rb) != (prev >> g.rb));
+        if (in && q > 0 && w <= prev) unordered = 1;
+        if (in) inv[s_jx[q]] = (uint16_t)q;
+        const unsigned long long bal = __ballot(head);
+        if (lane == 0 && q < N) s_hb[q >> 6] = bal;
     }
     unordered = __syncthreads_or(unordered);
     if (unordered) {                                     // uniform
         if (tid == 0) flags[IXF_DEGENERATE] = 1u;
         return;
     }
-    const uint32_t carry = ix_block_scan_max(lasthead, s_part);
+    // the start of q's group: the highest head bit at or below q
+    auto group_start = [&](uint32_t q) -> uint32_t {
+        uint32_t w = q >> 6;
+        unsigned long long m = s_hb[w] & (~0ull >> (63u - (q & 63u)));
+        while (m == 0) m = s_hb[--w];                      // (position 0 is a head)
+        return (w << 6) + 63u - (uint32_t)__builtin_clzll(m);
+    };
+    auto is_head = [&](uint32_t q) -> bool { return (s_hb[q >> 6] >> (q & 63u)) & 1ull; };      // q < N
+    const uint64_t rowmask = (1ull << g.rb) - 1ull;
+    const uint64_t vbase = (uint64_t)b << g.shift;
+    // ---- out, by sorted position; the statistics; the dense groups' leaders (see IxLeaders)
     unsigned long long inc = 0;
-    uint32_t heads = 0, glen = 0;
-    {
-        uint32_t cur = carry > 0 ? carry - 1u : 0u;
-        uint64_t prev = (c0 > 0 && c0 <= N) ? s_pk[c0 - 1u] >> g.rb : 0ull;
-        for (uint32_t x = 0; x < PER; x++) {
-            const uint32_t q = c0 + x;
-            if (q < N) {
-                const uint64_t low = s_pk[q] >> g.rb;
-                if (q == 0 || low != prev) {
-                    cur = q;
-                    heads++;
+    uint32_t heads = 0, glen = 0, lmask = 0;
+    uint32_t gsr[PER];
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) {
+        const uint32_t q = tid + k * IX_NT4;
+        const bool in = q < N;
+        const uint32_t qc = in ? q : 0u;
+        const uint64_t w = s_pk[qc];
+        const uint32_t gs = group_start(qc);
+        gsr[k] = gs;
+        if (in) {
+            const uint32_t row = (uint32_t)(w & rowmask);
+            const bool last = q + 1u == N || is_head(q + 1u);
+            keys_sorted[G0 + q] = vbase | (w >> g.rb);
+            sorted_rows[G0 + q] = row;
+            if (gs_of) gs_of[G0 + q] = G0 + gs;
+            if (last) gend[G0 + gs] = G0 + q + 1u;
+            inc += q - gs;
+            heads += q == gs ? 1u : 0u;
+            if (last && q + 1u - gs > glen) glen = q + 1u - gs;
+            if (lead.grp_of && !(last && q == gs)) {     // (a value held by one row has no leader)
+                const uint32_t grp = lead.grp_of[row];
+                if (grp != 0xFFFFFFFFu) {
+                    const uint32_t g0 = lead.groups32[8u * grp], g1 = lead.groups32[8u * grp + 1u];
+                    const bool first = q == gs || (uint32_t)(s_pk[q - 1u] & rowmask) < g0;
+                    const bool more = !last && (uint32_t)(s_pk[q + 1u] & rowmask) < g1;
+                    if (first && more) lmask |= 1u << k;
                 }
-                prev = low;
-                s_jx[q] = (uint16_t)cur;
-                inc += q - cur;
-                const bool last = q + 1u == N || (s_pk[q + 1u] >> g.rb) != low;
-                if (last && q + 1u - cur > glen) glen = q + 1u - cur;
             }
         }
     }
@@ -664,12 +697,14 @@ __device__ __forceinline__ void ix_bucket_sort_body(const IxGeom &g, const uint6
     }
     __shared__ unsigned long long s_inc[IX_NT4 / 64];
     __shared__ uint32_t s_len[IX_NT4 / 64], s_heads[IX_NT4 / 64];
-    if ((tid & 63u) == 0) {
-        s_inc[tid >> 6] = inc;
-        s_len[tid >> 6] = glen;
-        s_heads[tid >> 6] = heads;
+    if (lane == 0) {
+        s_inc[wave] = inc;
+        s_len[wave] = glen;
+        s_heads[wave] = heads;
     }
-    __syncthreads();                                     // (also: every s_jx[q] holds its group's start from here on)
+    uint32_t ltotal = 0, lbase = 0;
+    if (lead.grp_of) lbase = ix_block_scan_sum((uint32_t)__popc(lmask), s_part, ltotal);       // uniform (barriers inside)
+    else __syncthreads();
     if (tid == 0) {
         unsigned long long t = 0;
         uint32_t m = 0, h = 0;
@@ -682,60 +717,23 @@ __device__ __forceinline__ void ix_bucket_sort_body(const IxGeom &g, const uint6
         if (t) atomicAdd(&sl->inc, t);
         if (m > 1u) atomicMax(&sl->max_group, m);
         atomicAdd(&sl->groups, h);
+        if (ltotal) s_part[15] = atomicAdd(&lead.cnt[b & (lead.nsub - 1u)], ltotal);
     }
-    const uint64_t rowmask = (1ull << g.rb) - 1ull;
-    // ---- the dense groups' leaders (see IxLeaders): s_jx[q] is the start of q's group of equal values
-    if (lead.grp_of) {                                   // uniform
-        uint32_t lmask = 0;
+    if (ltotal) {                                        // uniform
+        __syncthreads();
+        const uint32_t sub = b & (lead.nsub - 1u);
+        uint32_t at = s_part[15] + lbase;
 #pragma unroll
         for (uint32_t k = 0; k < PER; k++) {
-            const uint32_t q = tid + k * IX_NT4;
-            if (q < N) {
-                const uint64_t w = s_pk[q];
-                const uint32_t grp = lead.grp_of[(uint32_t)(w & rowmask)];
-                if (grp != 0xFFFFFFFFu) {
-                    const uint32_t g0 = lead.groups32[8u * grp], g1 = lead.groups32[8u * grp + 1u];
-                    const uint32_t gs = s_jx[q];
-                    const bool first = q == gs || (uint32_t)(s_pk[q - 1u] & rowmask) < g0;
-                    const bool more = q + 1u < N && (s_pk[q + 1u] >> g.rb) == (w >> g.rb) && (uint32_t)(s_pk[q + 1u] & rowmask) < g1;
-                    if (first && more) lmask |= 1u << k;
+            if ((lmask >> k) & 1u) {
+                const uint32_t q = tid + k * IX_NT4;
+                if (at < lead.cap_sub) {
+                    const uint64_t slot = (uint64_t)sub * lead.cap_sub + at;
+                    lead.key[slot] = ((unsigned long long)lead.grp_of[(uint32_t)(s_pk[q] & rowmask)] << 32) | (unsigned long long)(G0 + gsr[k]);
+                    lead.val[slot] = G0 + q;
                 }
+                at++;
             }
-        }
-        uint32_t ltotal = 0;
-        const uint32_t lbase = ix_block_scan_sum((uint32_t)__popc(lmask), s_part, ltotal);
-        if (ltotal) {                                    // uniform
-            const uint32_t sub = b & (lead.nsub - 1u);
-            if (tid == 0) s_part[15] = atomicAdd(&lead.cnt[sub], ltotal);
-            __syncthreads();
-            uint32_t at = s_part[15] + lbase;
-#pragma unroll
-            for (uint32_t k = 0; k < PER; k++) {
-                if ((lmask >> k) & 1u) {
-                    const uint32_t q = tid + k * IX_NT4;
-                    if (at < lead.cap_sub) {
-                        const uint64_t slot = (uint64_t)sub * lead.cap_sub + at;
-                        lead.key[slot] = ((unsigned long long)lead.grp_of[(uint32_t)(s_pk[q] & rowmask)] << 32) | (unsigned long long)(G0 + s_jx[q]);
-                        lead.val[slot] = G0 + q;
-                    }
-                    at++;
-                }
-            }
-            __syncthreads();                             // (s_part is used again)
-        }
-    }
-    // ---- out, by sorted position
-    const uint64_t vbase = (uint64_t)b << g.shift;
-#pragma unroll
-    for (uint32_t k = 0; k < PER; k++) {
-        const uint32_t q = tid + k * IX_NT4;
-        if (q < N) {
-            const uint64_t w = s_pk[q], low = w >> g.rb;
-            const uint32_t gs = s_jx[q];
-            keys_sorted[G0 + q] = vbase | low;
-            sorted_rows[G0 + q] = (uint32_t)(w & rowmask);
-            if (gs_of) gs_of[G0 + q] = G0 + gs;
-            if (q + 1u == N || (s_pk[q + 1u] >> g.rb) != low) gend[G0 + gs] = G0 + q + 1u;
         }
     }
     // ---- and by arrival: what K5 carries into the images
@@ -743,8 +741,8 @@ __device__ __forceinline__ void ix_bucket_sort_body(const IxGeom &g, const uint6
     for (uint32_t k = 0; k < PER; k++) {
         const uint32_t j = tid + k * IX_NT4;
         if (j < N) {
-            const uint32_t q = inv[j], gs = s_jx[q];
-            const bool last = q + 1u == N || (s_pk[q + 1u] >> g.rb) != (s_pk[q] >> g.rb);
+            const uint32_t q = inv[j], gs = group_start(q);
+            const bool last = q + 1u == N || is_head(q + 1u);
             const uint32_t shared = (gs == q && last) ? 0u : 1u;
             tc[G0 + j] = make_uint2(((G0 + gs) << 1) | shared, G0 + q);
         }
