@@ -1,6 +1,9 @@
 // host_compare.cpp -- the compare entry points: tile engine, inverted-index engine, finishing, thresholded and list outputs
 #include "host_internal.h"
 #include "index_build.h"
+#ifdef IX_PHASE_CLOCKS
+namespace mg { void index_dump_clocks(); }
+#endif
 #include "sort_bits.h"
 
 /* ------------------------------------------------------------------ comparing */
@@ -735,14 +738,13 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
     // Known before the index exists, so the build by tiles looks for their leaders while it has every group of equal values in
     // LDS (index_build.h, IxLeaders); the build by the sort searches the finished index for them (dense_find_leaders).
     std::vector<mg::DenseGroup> cand_groups;
-    std::vector<uint32_t> grp_of_h;
+    std::vector<uint32_t> grp_of_h, lead_rows_h;
     DevBuf<mg::DenseGroup> d_groups(ctx);
-    DevBuf<uint32_t> d_grp_of(ctx), d_val(ctx), d_valj(ctx), d_cnt_sub(ctx), d_off_sub(ctx), d_nlead(ctx);
+    DevBuf<uint32_t> d_grp_of(ctx), d_lead_rows(ctx), d_val(ctx), d_valj(ctx), d_cnt_sub(ctx), d_off_sub(ctx), d_nlead(ctx);
     DevBuf<unsigned long long> d_key(ctx), d_keyj(ctx);
     const uint32_t lead_lists = mg::dense_sublists();
     uint32_t lead_tot[2] = {0, 0}, lead_cap = std::max<uint32_t>(E / 4u / lead_lists + 64u, 256u);
     bool lead_ready = false, lead_done = false;
-    static_assert(sizeof(mg::DenseGroup) == 32, "IxLeaders reads a group as 8 words");
     if (!link.empty() && sp->copies == 0) {
         for (uint64_t i = 1; i < n;) {
             if (!link[i]) { i++; continue; }
@@ -758,14 +760,22 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
         if (!cand_groups.empty()) {
             const uint32_t ng = (uint32_t)cand_groups.size();
             grp_of_h.assign(n, 0xFFFFFFFFu);
+            lead_rows_h.assign(4 * n, 0u);                  // per row {group, its first row, one past its last, 0}: what K4 gathers
+            for (uint64_t r = 0; r < n; r++) lead_rows_h[4 * r] = 0xFFFFFFFFu;
             for (uint32_t g = 0; g < ng; g++)
-                for (uint32_t r = cand_groups[g].g0; r < cand_groups[g].g1; r++) grp_of_h[r] = g;
+                for (uint32_t r = cand_groups[g].g0; r < cand_groups[g].g1; r++) {
+                    grp_of_h[r] = g;
+                    lead_rows_h[4ull * r] = g;
+                    lead_rows_h[4ull * r + 1] = cand_groups[g].g0;
+                    lead_rows_h[4ull * r + 2] = cand_groups[g].g1;
+                }
             const uint64_t room = (uint64_t)lead_lists * lead_cap;
-            if (d_groups.alloc(ng) == hipSuccess && d_grp_of.alloc(n) == hipSuccess && d_nlead.alloc(2) == hipSuccess && d_cnt_sub.alloc(lead_lists) == hipSuccess &&
+            if (d_groups.alloc(ng) == hipSuccess && d_grp_of.alloc(n) == hipSuccess && d_lead_rows.alloc(4 * n) == hipSuccess && d_nlead.alloc(2) == hipSuccess && d_cnt_sub.alloc(lead_lists) == hipSuccess &&
                 d_off_sub.alloc(lead_lists) == hipSuccess && d_key.alloc(room) == hipSuccess && d_val.alloc(room) == hipSuccess && d_keyj.alloc(room) == hipSuccess &&
                 d_valj.alloc(room) == hipSuccess &&
                 hipMemcpyAsync(d_groups, cand_groups.data(), ng * sizeof(mg::DenseGroup), hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
                 hipMemcpyAsync(d_grp_of, grp_of_h.data(), n * 4, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+                hipMemcpyAsync(d_lead_rows, lead_rows_h.data(), n * 16, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
                 hipMemsetAsync(d_cnt_sub, 0, lead_lists * 4, ctx->stream) == hipSuccess && hipMemsetAsync(d_nlead, 0, 8, ctx->stream) == hipSuccess) {
                 lead_ready = true;
             } else {
@@ -833,8 +843,7 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
             e = hipMemsetAsync(d_stat, 0, sizeof(Stat), ctx->stream);
             mg::IxLeaders lead;
             if (lead_ready) {
-                lead.grp_of = d_grp_of;
-                lead.groups32 = reinterpret_cast<const uint32_t *>(d_groups.p);
+                lead.grp_of = d_lead_rows;
                 lead.key = d_key;
                 lead.val = d_val;
                 lead.cnt = d_cnt_sub;
@@ -863,6 +872,9 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
         fprintf(stderr, "compare sparse: index by tiles refused: %s\n", plan.why);
     }
     sp->by_tiles = built;
+#ifdef IX_PHASE_CLOCKS
+    if (built && ctx_opt(ctx, "MASHGPU_IX_CLOCKS")) mg::index_dump_clocks();
+#endif
     if (ix_verify && !built && ok && e == hipSuccess && !ctx_opt(ctx, "MASHGPU_SPARSE_INDEX_MAY_REFUSE"))
         return fail(ctx, MG_ERR_INVALID, std::string("index verify: the tile build refused this table (") + (plan.ok ? "bucket flags" : plan.why) + ")");
     if (ok && e == hipSuccess && (!built || ix_verify)) {
@@ -1379,6 +1391,9 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
     if (!force && !plan->use) return MG_OK;
 
     // ---- fill.  The candidates' results are kept in list order and scattered into the output after it.
+    // (Round 5 measured the fill beside the index build by tiles -- kernels that wait for round trips far more than they move
+    // bytes -- on a stream of its own, 2 to 16 of its workgroups per CU: the step took 15.8 - 16.6 ms against 16.0 one after
+    // the other; while 40 GB of writes are queued the build's loads simply wait behind them.  The code is gone.)
     // (Side by side with discover + merge on a second stream the fill was MEASURED to gain nothing -- discover's
     // loads queue behind 40 GB of writes, and a kernel that merely ends under the fill waits milliseconds for the
     // L2's write-back, profiles/r03_sparse_phases.json, r03_overlap_trace.txt -- so the phases run one after the other.)

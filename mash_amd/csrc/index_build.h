@@ -46,8 +46,8 @@ struct IxGeom {
 // first holder inside a group of rows is its LEADER if a second holder follows; {group, value's first position, own position}
 // goes to one of `nsub` lists (by bucket).  cnt[nsub] counts what was ASKED for (beyond cap_sub nothing is written).
 struct IxLeaders {
-    const uint32_t *grp_of = nullptr;     // [n] group of a row, 0xFFFFFFFF: none (nullptr: no leader search)
-    const uint32_t *groups32 = nullptr;   // the groups as 8 words each: word 0 = first row, word 1 = one past the last
+    const uint32_t *grp_of = nullptr;     // [4 n] per row {its group (0xFFFFFFFF: none), the group's first row, one past its last, 0} --
+                                          // one 16-byte gather per entry instead of two dependent ones (nullptr: no leader search)
     unsigned long long *key = nullptr;    // [nsub * cap_sub] (group << 32) | first sorted position of the value
     uint32_t *val = nullptr;              // [nsub * cap_sub] the leader's own sorted position
     uint32_t *cnt = nullptr;              // [nsub], zeroed by the caller

@@ -15,7 +15,9 @@
 #endif
 #include <stdint.h>
 
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include "index_build.h"
 
@@ -33,6 +35,22 @@
 #endif
 
 namespace mg {
+
+// -DIX_PHASE_CLOCKS: work-item 0 of every workgroup adds the cycles between two marks of a kernel to a table (a tuning build:
+// tools/r5_clocks.sh prints it; the marks compile to nothing otherwise)
+#if defined(IX_PHASE_CLOCKS) && !defined(MG_HIP_EMU)
+__device__ unsigned long long ix_clk[64];
+#define IX_CLK_BEGIN() unsigned long long clk_prev_ = threadIdx.x == 0 ? clock64() : 0ull
+#define IX_CLK(i)                                                          \
+    if (threadIdx.x == 0) {                                               \
+        const unsigned long long t_ = clock64();                          \
+        atomicAdd(&ix_clk[i], t_ - clk_prev_);                            \
+        clk_prev_ = t_;                                                   \
+    }
+#else
+#define IX_CLK_BEGIN() ((void)0)
+#define IX_CLK(i) ((void)0)
+#endif
 
 constexpr uint32_t IX_RB = 512;                 // rows of a block of rows
 constexpr uint32_t IX_NT = 512;                 // work-items of the tile kernels (one per row of the block)
@@ -311,8 +329,13 @@ __global__ __launch_bounds__(IX_NT, 4) void ix_tile_partition_kernel(IxGeom g, c
     if (!ix_tile_id(g, blk, w)) return;                  // uniform
     if (flags[IXF_OVERSIZE]) return;                     // uniform (raised by the scan kernel: the caller builds the index another way)
     const uint32_t tid = threadIdx.x, sub = tid % IX_LPR;
+    IX_CLK_BEGIN();
     const uint32_t row0 = blk * IX_RB, nrows = g.n - row0 < IX_RB ? g.n - row0 : IX_RB;
-    uint32_t len = 0;
+    uint32_t len = 0, gb = 0;
+    if (tid < g.BW) {                                    // (asked for before the scan waits for the segments' bounds)
+        const uint32_t bg = w * g.BW + tid;
+        gb = start[bg] + colpre[(uint64_t)blk * g.Bp + bg];
+    }
     if (tid < nrows) {
         const uint16_t *p = lb + (uint64_t)(row0 + tid) * (g.NW + 1u) + w;
         const uint32_t lo = p[0];
@@ -325,11 +348,11 @@ __global__ __launch_bounds__(IX_NT, 4) void ix_tile_partition_kernel(IxGeom g, c
     s_rowpre[tid] = pre;
     if (tid == IX_NT - 1u) s_rowpre[IX_NT] = total;
     if (tid < g.BW) {
-        const uint32_t bg = w * g.BW + tid;
-        s_gbase[tid] = start[bg] + colpre[(uint64_t)blk * g.Bp + bg];
+        s_gbase[tid] = gb;
         s_hist[tid] = 0;
     }
     __syncthreads();
+    IX_CLK(0);
     const uint64_t lowmask = (1ull << g.shift) - 1ull;    // (shift <= 63)
     for (uint32_t i0 = 0; i0 < total; i0 += IX_PCAP) {
         const uint32_t np = total - i0 < IX_PCAP ? total - i0 : IX_PCAP;
@@ -373,7 +396,9 @@ __global__ __launch_bounds__(IX_NT, 4) void ix_tile_partition_kernel(IxGeom g, c
             }
         }
         __syncthreads();
+        IX_CLK(1);
         uint32_t *srt = ix_tile_sort(s_pa, s_pb, s_cnt, s_part, np, g.npass);
+        IX_CLK(2);
         uint32_t *s_slot = srt == s_pa ? s_pb : s_pa;     // (the sort's other array: where every entry of the piece goes)
         {   // where every bucket starts in the sorted piece (in place; entry BW = the piece's size)
             const uint32_t c = tid < g.BW ? s_hist[tid] : 0u;
@@ -383,6 +408,7 @@ __global__ __launch_bounds__(IX_NT, 4) void ix_tile_partition_kernel(IxGeom g, c
             if (tid == 0) s_hist[g.BW] = np;
         }
         __syncthreads();
+        IX_CLK(3);
         for (uint32_t j = tid; j < np; j += IX_NT) {
             const uint32_t e = srt[j], b = e >> 12, idx = e & 4095u;
             const uint32_t slot = s_gbase[b] + (j - s_hist[b]);
@@ -390,16 +416,33 @@ __global__ __launch_bounds__(IX_NT, 4) void ix_tile_partition_kernel(IxGeom g, c
             s_slot[idx] = slot;
         }
         __syncthreads();
+        IX_CLK(4);
+        {   // where every entry went, into the position image: the lanes' first entries of the eight rounds together ...
+            uint32_t sl[IX_ROUNDS], lo8[IX_ROUNDS];
+#pragma unroll
+            for (uint32_t it = 0; it < IX_ROUNDS; it++) {
+                const uint32_t r = it * (IX_NT / IX_LPR) + tid / IX_LPR;
+                sl[it] = s_slot[at[it] != 0xFFFFFFFFu ? at[it] : 0u];
+                lo8[it] = s_lo[r < nrows ? r : 0u];
+            }
+#pragma unroll
+            for (uint32_t it = 0; it < IX_ROUNDS; it++) {
+                const uint32_t r = it * (IX_NT / IX_LPR) + tid / IX_LPR;
+                if (at[it] != 0xFFFFFFFFu) slot_img[(uint64_t)(row0 + r) * g.rs + lo8[it] + sub] = sl[it];
+            }
+        }
+        // ... and what a row holds beyond IX_LPR entries in this window
 #pragma unroll 1
         for (uint32_t r = tid / IX_LPR; r < nrows; r += IX_NT / IX_LPR) {
             const uint32_t rp = s_rowpre[r], ln = s_rowpre[r + 1u] - rp;
-            if (rp + ln <= i0 || rp >= i0 + np) continue;
+            if (ln <= IX_LPR || rp + ln <= i0 || rp >= i0 + np) continue;
             const uint64_t at0 = (uint64_t)(row0 + r) * g.rs + s_lo[r];
-            for (uint32_t k = sub; k < ln; k += IX_LPR) {
+            for (uint32_t k = sub + IX_LPR; k < ln; k += IX_LPR) {
                 const uint32_t i = rp + k;
                 if (i >= i0 && i < i0 + np) slot_img[at0 + k] = s_slot[i - i0];
             }
         }
+        IX_CLK(5);
         // the next piece of the tile goes behind this one in every bucket
         uint32_t add = 0;
         if (tid < g.BW) add = s_hist[tid + 1] - s_hist[tid];
@@ -412,49 +455,59 @@ __global__ __launch_bounds__(IX_NT, 4) void ix_tile_partition_kernel(IxGeom g, c
     }
 }
 
-// K5: the tiles again (their order keeps what is gathered in the L2): {code, position} of every entry are read from where K3
-// put the entry -- its slot stands in the position image -- and written into the images, a row segment at a time
-__global__ __launch_bounds__(IX_NT) void ix_tile_images_kernel(IxGeom g, const uint16_t *__restrict__ lb, const uint32_t *__restrict__ flags,
-                                                               const uint2 *__restrict__ tc, uint32_t *__restrict__ code_img, uint32_t *pos_img)
+// K5: {code, position} of every entry, read from where K3 put the entry (its slot stands in the position image) and written
+// into the images.  A plain pass over the images, four consecutive positions per work-item (16-byte loads of the slots,
+// 16-byte stores of whole lines: the first version wrote a tile's row segments, 23 bytes each, and moved 2 x its payload),
+// in pieces of (a block of 512 rows x 32 positions): the reads of tc are gathers, but the rows of a block hold, at the same
+// positions, neighbouring values -- neighbouring buckets, whose pieces of this block K3 wrote side by side, and the pieces
+// of the next block right behind them.  Pieces follow each other block by block, positions ascending, an XCD taking a
+// contiguous eighth of them.
+constexpr uint32_t IX5_CH = 32;                           // positions of a piece
+constexpr uint32_t IX5_UNR = 4;                           // rows a work-item has in flight
+
+__global__ __launch_bounds__(256) void ix_images_kernel(IxGeom g, const uint32_t *__restrict__ off, const uint32_t *__restrict__ flags,
+                                                        const uint2 *__restrict__ tc, uint32_t *__restrict__ code_img, uint32_t *pos_img, uint32_t nchunk)
 {
-    uint32_t blk = 0, w = 0;
-    if (!ix_tile_id(g, blk, w)) return;                  // uniform
-    if (flags[IXF_OVERSIZE]) return;
-    const uint32_t tid = threadIdx.x, sub = tid % IX_LPR;
+    if (flags[IXF_OVERSIZE]) return;                     // uniform
+    const uint32_t per = gridDim.x >> 3;
+    const uint32_t q = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    if (q >= g.nblk * nchunk) return;                    // uniform
+    const uint32_t blk = q / nchunk, ch = q - blk * nchunk;
+    const uint32_t tid = threadIdx.x, quad = tid & 7u, rsub = tid >> 3;
+    const uint32_t p0 = ch * IX5_CH + quad * 4u;
     const uint32_t row0 = blk * IX_RB, nrows = g.n - row0 < IX_RB ? g.n - row0 : IX_RB;
-    uint32_t lo[IX_ROUNDS], hi[IX_ROUNDS];
+    for (uint32_t rb = rsub; rb < nrows; rb += 32u * IX5_UNR) {          // (32 rows per sweep of the workgroup)
+        uint32_t cnt[IX5_UNR];
+        uint32_t sl[IX5_UNR][4];
 #pragma unroll
-    for (uint32_t it = 0; it < IX_ROUNDS; it++) {
-        const uint32_t r = it * (IX_NT / IX_LPR) + tid / IX_LPR;
-        const uint16_t *p = lb + (uint64_t)(row0 + (r < nrows ? r : 0u)) * (g.NW + 1u) + w;
-        const uint32_t a = p[0], b = p[1];
-        lo[it] = a;
-        hi[it] = r < nrows ? b : a;
-    }
-    uint32_t slot[IX_ROUNDS];
+        for (uint32_t u = 0; u < IX5_UNR; u++) {
+            const uint32_t r = rb + 32u * u;
+            const uint32_t row = row0 + (r < nrows ? r : 0u);
+            const uint32_t c = r < nrows ? off[row + 1u] - off[row] : 0u;
+            cnt[u] = c;
+            const uint32_t *src = pos_img + (uint64_t)row * g.rs + (p0 < c ? p0 : 0u);      // (rs and p0 are multiples of four: 16-byte aligned)
+            sl[u][0] = src[0];
+            sl[u][1] = src[1];
+            sl[u][2] = src[2];
+            sl[u][3] = src[3];
+        }
+        uint2 cp[IX5_UNR][4];
 #pragma unroll
-    for (uint32_t it = 0; it < IX_ROUNDS; it++) {
-        const uint32_t r = it * (IX_NT / IX_LPR) + tid / IX_LPR;
-        const bool in = lo[it] + sub < hi[it];
-        slot[it] = pos_img[in ? (uint64_t)(row0 + r) * g.rs + lo[it] + sub : (uint64_t)row0 * g.rs];
-    }
-    uint2 cp[IX_ROUNDS];
+        for (uint32_t u = 0; u < IX5_UNR; u++)
 #pragma unroll
-    for (uint32_t it = 0; it < IX_ROUNDS; it++) {
-        const bool in = lo[it] + sub < hi[it];
-        cp[it] = tc[in ? slot[it] : 0u];
-    }
+            for (uint32_t e = 0; e < 4u; e++) cp[u][e] = tc[p0 + e < cnt[u] ? sl[u][e] : 0u];
 #pragma unroll
-    for (uint32_t it = 0; it < IX_ROUNDS; it++) {
-        const uint32_t r = it * (IX_NT / IX_LPR) + tid / IX_LPR;
-        if (lo[it] + sub < hi[it]) {
-            const uint64_t at0 = (uint64_t)(row0 + r) * g.rs;
-            code_img[at0 + lo[it] + sub] = cp[it].x;
-            pos_img[at0 + lo[it] + sub] = cp[it].y;
-            for (uint32_t k = lo[it] + sub + IX_LPR; k < hi[it]; k += IX_LPR) {
-                const uint2 c2 = tc[pos_img[at0 + k]];
-                code_img[at0 + k] = c2.x;
-                pos_img[at0 + k] = c2.y;
+        for (uint32_t u = 0; u < IX5_UNR; u++) {
+            const uint32_t r = rb + 32u * u;
+            if (r < nrows && p0 < g.rs) {
+                const uint64_t at = (uint64_t)(row0 + r) * g.rs + p0;
+#pragma unroll
+                for (uint32_t e = 0; e < 4u; e++) {
+                    // (behind the row's last entry: the code image's padding -- larger than every code, so chunked loads past a
+                    //  row's end are harmless --, the position image stays whatever it was)
+                    code_img[at + e] = p0 + e < cnt[u] ? cp[u][e].x : 0xFFFFFFFFu;
+                    if (p0 + e < cnt[u]) pos_img[at + e] = cp[u][e].y;
+                }
             }
         }
     }
@@ -487,6 +540,7 @@ __device__ __forceinline__ void ix_bucket_sort_body(const IxGeom &g, const uint6
                                                     uint16_t *s_jx, uint32_t *s_h, uint32_t *s_mixed, uint32_t *s_part, uint32_t b, uint32_t G0, uint32_t N)
 {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    IX_CLK_BEGIN();
     const uint32_t subshift = g.shift >= IX_SUBBITS ? g.shift + g.rb - IX_SUBBITS : g.rb;
     for (uint32_t x = tid; x < IX_NSUB / 2u; x += IX_NT4) s_h[x] = 0;
     if (tid < IX_NSUB / 32u) s_mixed[tid] = 0;
@@ -505,6 +559,7 @@ __device__ __forceinline__ void ix_bucket_sort_body(const IxGeom &g, const uint6
         if (in) s_jx[j] = (uint16_t)(((sub0 >> IX_SUBLOW) << 13) | (sub0 & ((1u << IX_SUBLOW) - 1u)));
     }
     __syncthreads();
+    IX_CLK(32);
     // ---- tickets, in arrival order (two u16 counters per word).  Slot j: bits 15..13 the wave that owns the entry's
     // sub-bucket (its top three bits), below them the sub-bucket's other ten bits until that wave has served the entry, then
     // the ticket (13 bits).  A wave that does not own the entry looks at the top three bits only, whenever it comes by.
@@ -534,6 +589,7 @@ __device__ __forceinline__ void ix_bucket_sort_body(const IxGeom &g, const uint6
         }
     }
     __syncthreads();
+    IX_CLK(33);
     {   // exclusive prefix over the 8192 counters, in place; work-item t owns the words [8 t, 8 t + 8)
         uint32_t wv[8], sum = 0;
 #pragma unroll
@@ -557,6 +613,7 @@ __device__ __forceinline__ void ix_bucket_sort_body(const IxGeom &g, const uint6
         sa[k] = (uint32_t)s_tk[j < N ? j : 0u] & 0x1FFFu;               // (the ticket: 13 bits below the owner's three)
     }
     __syncthreads();                                     // (the counters are prefixes, every ticket is in a register: the arrival copy may go)
+    IX_CLK(34);
 #pragma unroll
     for (uint32_t k = 0; k < PER; k++) {
         const uint32_t j = tid + k * IX_NT4;
@@ -568,14 +625,24 @@ __device__ __forceinline__ void ix_bucket_sort_body(const IxGeom &g, const uint6
         }
     }
     __syncthreads();
-    // ---- sub-buckets that hold more than one value: marked ...
+    IX_CLK(35);
+    // ---- sub-buckets that hold more than one value: marked ...  (all LDS reads first: an atomic between them would order them)
+    {
+        uint32_t diff = 0;
 #pragma unroll
-    for (uint32_t k = 0; k < PER; k++) {
-        const uint32_t q = tid + k * IX_NT4;
-        if (q < N) {
-            const uint64_t me = s_pk[q];
+        for (uint32_t k = 0; k < PER; k++) {
+            const uint32_t q = tid + k * IX_NT4;
+            const uint64_t me = s_pk[q < N ? q : 0u];
             const uint32_t sub = (uint32_t)(me >> subshift) & (IX_NSUB - 1u);
-            if ((s_pk[cs[sub]] >> g.rb) != (me >> g.rb)) atomicOr(&s_mixed[sub >> 5], 1u << (sub & 31u));
+            if (q < N && (s_pk[cs[sub]] >> g.rb) != (me >> g.rb)) diff |= 1u << k;
+        }
+        if (diff) {
+#pragma unroll
+            for (uint32_t k = 0; k < PER; k++)
+                if ((diff >> k) & 1u) {
+                    const uint32_t sub = (uint32_t)(s_pk[tid + k * IX_NT4] >> subshift) & (IX_NSUB - 1u);
+                    atomicOr(&s_mixed[sub >> 5], 1u << (sub & 31u));
+                }
         }
     }
     __syncthreads();
@@ -595,11 +662,20 @@ __device__ __forceinline__ void ix_bucket_sort_body(const IxGeom &g, const uint6
             if (e - a > IX_MAXM) {
                 degen = 1;
             } else {
-                const uint64_t low = me >> g.rb;
+                // (the entries of a sub-bucket agree in everything above `subshift`: what is compared are the value's bits below)
                 uint32_t r = 0;
-                for (uint32_t x = a; x < e; x++) {
-                    const uint64_t lx = s_pk[x] >> g.rb;
-                    r += (lx < low || (lx == low && x < qc)) ? 1u : 0u;
+                if (subshift - g.rb <= 32u) {
+                    const uint32_t low = (uint32_t)(me >> g.rb);
+                    for (uint32_t x = a; x < e; x++) {
+                        const uint32_t lx = (uint32_t)(s_pk[x] >> g.rb);
+                        r += (lx < low || (lx == low && x < qc)) ? 1u : 0u;
+                    }
+                } else {
+                    const uint64_t low = me >> g.rb;
+                    for (uint32_t x = a; x < e; x++) {
+                        const uint64_t lx = s_pk[x] >> g.rb;
+                        r += (lx < low || (lx == low && x < qc)) ? 1u : 0u;
+                    }
                 }
                 nq = a + r;
             }
@@ -621,6 +697,7 @@ __device__ __forceinline__ void ix_bucket_sort_body(const IxGeom &g, const uint6
         }
     }
     __syncthreads();
+    IX_CLK(36);
     // ---- where the bucket's j-th arrival stands now (the counters are dead: their space holds the inverse), and where the
     // groups of equal values start: one bit per position (a wave's 64 consecutive positions = one ballot = one word).  The
     // same pass checks the stable counting sort: words strictly ascending.
@@ -644,6 +721,7 @@ __device__ __forceinline__ void ix_bucket_sort_body(const IxGeom &g, const uint6
         if (tid == 0) flags[IXF_DEGENERATE] = 1u;
         return;
     }
+    IX_CLK(37);
     // the start of q's group: the highest head bit at or below q
     auto group_start = [&](uint32_t q) -> uint32_t {
         uint32_t w = q >> 6;
@@ -654,39 +732,50 @@ __device__ __forceinline__ void ix_bucket_sort_body(const IxGeom &g, const uint6
     auto is_head = [&](uint32_t q) -> bool { return (s_hb[q >> 6] >> (q & 63u)) & 1ull; };      // q < N
     const uint64_t rowmask = (1ull << g.rb) - 1ull;
     const uint64_t vbase = (uint64_t)b << g.shift;
-    // ---- out, by sorted position; the statistics; the dense groups' leaders (see IxLeaders)
+    // ---- the statistics; the dense groups' leaders (see IxLeaders); out, by sorted position.  First everything that is
+    // READ (LDS, and the rows' groups from global memory: all requests in flight together), then what is written -- a
+    // gather between two stores waits for its own round trip, PER times in a row (27 % of the kernel before).
     unsigned long long inc = 0;
     uint32_t heads = 0, glen = 0, lmask = 0;
-    uint32_t gsr[PER];
+    uint32_t gsr[PER], grpr[PER], g0r[PER], g1r[PER];
 #pragma unroll
     for (uint32_t k = 0; k < PER; k++) {
         const uint32_t q = tid + k * IX_NT4;
         const bool in = q < N;
         const uint32_t qc = in ? q : 0u;
-        const uint64_t w = s_pk[qc];
         const uint32_t gs = group_start(qc);
+        const bool last = qc + 1u == N || is_head(qc + 1u);
         gsr[k] = gs;
-        if (in) {
-            const uint32_t row = (uint32_t)(w & rowmask);
+        // (a value held by one row has no leader: its row's group is not looked up)
+        const bool look = lead.grp_of != nullptr && in && !(last && qc == gs);
+        const uint32_t *gp = lead.grp_of + 4ull * (uint32_t)(s_pk[qc] & rowmask);
+        grpr[k] = look ? gp[0] : 0xFFFFFFFFu;
+        g0r[k] = look ? gp[1] : 0u;
+        g1r[k] = look ? gp[2] : 0u;
+        inc += in ? q - gs : 0u;
+        heads += (in && q == gs) ? 1u : 0u;
+        const uint32_t len = (in && last) ? q + 1u - gs : 0u;
+        glen = len > glen ? len : glen;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) {
+        const uint32_t q = tid + k * IX_NT4;
+        if (q < N) {
+            const uint64_t w = s_pk[q];
+            const uint32_t gs = gsr[k];
             const bool last = q + 1u == N || is_head(q + 1u);
             keys_sorted[G0 + q] = vbase | (w >> g.rb);
-            sorted_rows[G0 + q] = row;
+            sorted_rows[G0 + q] = (uint32_t)(w & rowmask);
             if (gs_of) gs_of[G0 + q] = G0 + gs;
             if (last) gend[G0 + gs] = G0 + q + 1u;
-            inc += q - gs;
-            heads += q == gs ? 1u : 0u;
-            if (last && q + 1u - gs > glen) glen = q + 1u - gs;
-            if (lead.grp_of && !(last && q == gs)) {     // (a value held by one row has no leader)
-                const uint32_t grp = lead.grp_of[row];
-                if (grp != 0xFFFFFFFFu) {
-                    const uint32_t g0 = lead.groups32[8u * grp], g1 = lead.groups32[8u * grp + 1u];
-                    const bool first = q == gs || (uint32_t)(s_pk[q - 1u] & rowmask) < g0;
-                    const bool more = !last && (uint32_t)(s_pk[q + 1u] & rowmask) < g1;
-                    if (first && more) lmask |= 1u << k;
-                }
+            if (grpr[k] != 0xFFFFFFFFu) {
+                const bool first = q == gs || (uint32_t)(s_pk[q - 1u] & rowmask) < g0r[k];
+                const bool more = !last && (uint32_t)(s_pk[q + 1u] & rowmask) < g1r[k];
+                if (first && more) lmask |= 1u << k;
             }
         }
     }
+    IX_CLK(38);
     // statistics of the index: one atomic per workgroup and number, spread over the slots
 #pragma unroll
     for (uint32_t d = 32; d > 0; d >>= 1) {
@@ -706,6 +795,9 @@ __device__ __forceinline__ void ix_bucket_sort_body(const IxGeom &g, const uint6
     if (lead.grp_of) lbase = ix_block_scan_sum((uint32_t)__popc(lmask), s_part, ltotal);       // uniform (barriers inside)
     else __syncthreads();
     if (tid == 0) {
+        // (the leaders' place in their list first: its round trip to the L2 runs while everybody writes tc below --
+        //  the whole workgroup waiting for it was 19 % of the kernel)
+        if (ltotal) s_part[15] = atomicAdd(&lead.cnt[b & (lead.nsub - 1u)], ltotal);
         unsigned long long t = 0;
         uint32_t m = 0, h = 0;
         for (uint32_t k = 0; k < IX_NT4 / 64u; k++) {
@@ -717,26 +809,9 @@ __device__ __forceinline__ void ix_bucket_sort_body(const IxGeom &g, const uint6
         if (t) atomicAdd(&sl->inc, t);
         if (m > 1u) atomicMax(&sl->max_group, m);
         atomicAdd(&sl->groups, h);
-        if (ltotal) s_part[15] = atomicAdd(&lead.cnt[b & (lead.nsub - 1u)], ltotal);
     }
-    if (ltotal) {                                        // uniform
-        __syncthreads();
-        const uint32_t sub = b & (lead.nsub - 1u);
-        uint32_t at = s_part[15] + lbase;
-#pragma unroll
-        for (uint32_t k = 0; k < PER; k++) {
-            if ((lmask >> k) & 1u) {
-                const uint32_t q = tid + k * IX_NT4;
-                if (at < lead.cap_sub) {
-                    const uint64_t slot = (uint64_t)sub * lead.cap_sub + at;
-                    lead.key[slot] = ((unsigned long long)lead.grp_of[(uint32_t)(s_pk[q] & rowmask)] << 32) | (unsigned long long)(G0 + gsr[k]);
-                    lead.val[slot] = G0 + q;
-                }
-                at++;
-            }
-        }
-    }
-    // ---- and by arrival: what K5 carries into the images
+    IX_CLK(39);
+    // ---- by arrival: what K5 carries into the images
 #pragma unroll
     for (uint32_t k = 0; k < PER; k++) {
         const uint32_t j = tid + k * IX_NT4;
@@ -747,6 +822,25 @@ __device__ __forceinline__ void ix_bucket_sort_body(const IxGeom &g, const uint6
             tc[G0 + j] = make_uint2(((G0 + gs) << 1) | shared, G0 + q);
         }
     }
+    IX_CLK(40);
+    if (ltotal) {                                        // uniform
+        __syncthreads();
+        const uint32_t sub = b & (lead.nsub - 1u);
+        uint32_t at = s_part[15] + lbase;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) {
+            if ((lmask >> k) & 1u) {
+                const uint32_t q = tid + k * IX_NT4;
+                if (at < lead.cap_sub) {
+                    const uint64_t slot = (uint64_t)sub * lead.cap_sub + at;
+                    lead.key[slot] = ((unsigned long long)grpr[k] << 32) | (unsigned long long)(G0 + gsr[k]);
+                    lead.val[slot] = G0 + q;
+                }
+                at++;
+            }
+        }
+    }
+    IX_CLK(41);
 }
 
 __global__ __launch_bounds__(IX_NT4, 4) void ix_bucket_sort_kernel(IxGeom g, const uint64_t *pk, const uint32_t *start, uint64_t *keys_sorted,
@@ -826,6 +920,23 @@ hipError_t index_verify_words(const uint32_t *a, const uint32_t *b, const uint32
 
 size_t index_stat_scratch_bytes() { return sizeof(IxStatSlot) * IX_STAT_SLOTS; }
 
+#if defined(IX_PHASE_CLOCKS) && !defined(MG_HIP_EMU)
+void index_dump_clocks()
+{
+    unsigned long long h[64];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(ix_clk), sizeof h) != hipSuccess) return;
+    static const char *k3[] = {"prologue (lb, scan, gbase)", "loads + pack", "tile sort", "bucket scan", "pk + slots to LDS", "slot image"};
+    static const char *k4[] = {"zero + load", "tickets", "counter scan + ticket read", "scatter", "mixed mark + fix-up + write back", "heads + inverse", "out by position + leaders", "statistics + leaders' scan", "tc by arrival", "leaders out"};
+    unsigned long long t3 = 0, t4 = 0;
+    for (int i = 0; i < 6; i++) t3 += h[i];
+    for (int i = 0; i < 10; i++) t4 += h[32 + i];
+    for (int i = 0; i < 6; i++) fprintf(stderr, "ix clocks K3 %-34s %6.2f %%\n", k3[i], 100.0 * h[i] / (t3 ? t3 : 1));
+    for (int i = 0; i < 10; i++) fprintf(stderr, "ix clocks K4 %-34s %6.2f %%\n", k4[i], 100.0 * h[32 + i] / (t4 ? t4 : 1));
+    memset(h, 0, sizeof h);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(ix_clk), h, sizeof h);
+}
+#endif
+
 IxPlan index_plan(uint32_t n, uint32_t E, uint32_t s, uint32_t rs, uint64_t stride, uint64_t maxv, double dens0, bool want_gs)
 {
     IxPlan p;
@@ -899,12 +1010,6 @@ hipError_t index_build(const IxPlan &plan, const uint64_t *hashes, const uint32_
     hipLaunchKernelGGL(ix_bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, g, start, flags);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    {   // padding of the code image: larger than every code, so chunked loads past a row's end are harmless
-        const uint64_t total = (uint64_t)g.n * g.rs;
-        uint64_t fb = (total + 1023u) / 1024u;
-        if (fb > 8192u) fb = 8192u;
-        hipLaunchKernelGGL(ix_fill_u32_kernel, dim3((uint32_t)fb), dim3(256), 0, stream, code_img, total, 0xFFFFFFFFu);
-    }
     hipLaunchKernelGGL(ix_tile_partition_kernel, dim3(tiles), dim3(IX_NT), IXL_BYTES, stream, g, hashes, (const uint16_t *)lb, (const uint32_t *)cnt,
                        (const uint32_t *)start, (const uint32_t *)flags, pk, pos_img);
     e = hipGetLastError();
@@ -915,8 +1020,11 @@ hipError_t index_build(const IxPlan &plan, const uint64_t *hashes, const uint32_
                        sorted_rows, gend, g.want_gs ? gs_of : (uint32_t *)nullptr, tc, static_cast<IxStatSlot *>(stat_scratch), flags,
                        leaders ? *leaders : IxLeaders());
     hipLaunchKernelGGL(ix_stat_reduce_kernel, dim3(1), dim3(256), 0, stream, static_cast<const IxStatSlot *>(stat_scratch), incidences, max_group, groups);
-    hipLaunchKernelGGL(ix_tile_images_kernel, dim3(tiles), dim3(IX_NT), 0, stream, g, (const uint16_t *)lb, (const uint32_t *)flags, (const uint2 *)tc,
-                       code_img, pos_img);
+    {
+        const uint32_t nchunk = (g.rs + IX5_CH - 1u) / IX5_CH;
+        const uint32_t pieces = 8u * ((g.nblk * nchunk + 7u) / 8u);
+        hipLaunchKernelGGL(ix_images_kernel, dim3(pieces), dim3(256), 0, stream, g, off, (const uint32_t *)flags, (const uint2 *)tc, code_img, pos_img, nchunk);
+    }
     return hipGetLastError();
 }
 

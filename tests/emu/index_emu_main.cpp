@@ -150,8 +150,12 @@ static int run_case(const std::string &name, uint32_t n, uint32_t s, uint64_t se
     const uint32_t nsub = 1024, cap_sub = E / 2 + 64;
     std::vector<unsigned long long> lkey((size_t)nsub * cap_sub, ~0ull);
     std::vector<uint32_t> lval((size_t)nsub * cap_sub, ~0u), lcnt(nsub, 0);
-    lead.grp_of = grp_of.data();
-    lead.groups32 = groups32.data();
+    std::vector<uint32_t> lead_rows(4 * (size_t)n, 0);
+    for (uint32_t r = 0; r < n; r++) {
+        lead_rows[4 * r] = grp_of[r];
+        if (grp_of[r] != 0xFFFFFFFFu) { lead_rows[4 * r + 1] = groups32[8 * grp_of[r]]; lead_rows[4 * r + 2] = groups32[8 * grp_of[r] + 1]; }
+    }
+    lead.grp_of = lead_rows.data();
     lead.key = lkey.data();
     lead.val = lval.data();
     lead.cnt = lcnt.data();
