@@ -299,6 +299,24 @@ int mg_compare_rect_filter_host(mg_ctx *ctx, const mg_table *ref, const mg_table
                                 uint64_t q_begin, uint64_t q_end, int kmer_size, double max_distance,
                                 mg_edge *out_host, uint64_t capacity, uint64_t *count_out);
 
+/* The WHOLE matrix without moving it: a pair that shares no hash among its first s union elements is
+ * {0, min(s, |A| + |B|)} (|X| = min(nhash, s): the merge of compareSketches, CommandDistance.cpp:347-385,
+ * never takes its equal branch) -- and in a collection nearly every pair is such a pair; `mash triangle`
+ * prints mostly that constant (CommandTriangle.cpp:159-198).  These calls return the EXCEPTIONS: every
+ * pair with numer >= 1 as {row, col, numer, denom}, in reference order; together with the rule and the
+ * tables' nhash the caller has every {numer, denom} of the job -- 80 MB instead of 40 GB for 100 000
+ * sketches (mg_expand_tri_sparse writes the dense form out of it).  capacity / *count_out / MG_ERR_NOMEM
+ * as for the filter calls above. */
+int mg_compare_tri_sparse_host(mg_ctx *ctx, const mg_table *t, uint64_t row_begin, uint64_t row_end,
+                               mg_edge *out_host, uint64_t capacity, uint64_t *count_out);
+int mg_compare_rect_sparse_host(mg_ctx *ctx, const mg_table *ref, const mg_table *qry,
+                                uint64_t q_begin, uint64_t q_end, mg_edge *out_host, uint64_t capacity,
+                                uint64_t *count_out);
+/* Host helper (no device): the dense triangle mg_compare_tri_host would have returned, from the rule and
+ * the exceptions.  nhash: the table's hash counts (host), s: its sketch size. */
+int mg_expand_tri_sparse(const mg_edge *edges, uint64_t count, const uint32_t *nhash, uint64_t sketch_size,
+                         uint64_t row_begin, uint64_t row_end, mg_counts *out_host);
+
 /* Distance + p-value + filters for pairs already counted (the tail of
  * compareSketches, CommandDistance.cpp:387-424, and pValue, :427-448).
  * Host arithmetic (glibc log, the same libm the reference links), so distances

@@ -28,7 +28,7 @@ EXPORTS = [
     "mg_reads_begin", "mg_reads_add_host", "mg_reads_finish", "mg_reads_reset", "mg_reads_free", "mg_table_upload",
     "mg_table_wrap_dev", "mg_table_free", "mg_table_invalidate", "mg_table_rows", "mg_table_sketch_size",
     "mg_compare_tri_dev", "mg_compare_tri_host", "mg_compare_rect_dev", "mg_compare_rect_host",
-    "mg_compare_tri_filter_host", "mg_compare_rect_filter_host",
+    "mg_compare_tri_filter_host", "mg_compare_rect_filter_host", "mg_compare_tri_sparse_host", "mg_compare_rect_sparse_host", "mg_expand_tri_sparse",
     "mg_finish_tri_host", "mg_finish_rect_host", "mg_distance", "mg_p_value",
     "mg_finish_tri_dev", "mg_finish_rect_dev", "mg_compare_tri_pairs_host", "mg_compare_rect_pairs_host",
     "mg_compare_tri_results_host", "mg_compare_rect_results_host",
@@ -228,6 +228,9 @@ def load_library():
     lib.mg_compare_rect_host.argtypes = [vp, vp, vp, u64, u64, vp]
     lib.mg_compare_tri_filter_host.argtypes = [vp, vp, u64, u64, C.c_int, C.c_double, vp, u64, vp]
     lib.mg_compare_rect_filter_host.argtypes = [vp, vp, vp, u64, u64, C.c_int, C.c_double, vp, u64, vp]
+    lib.mg_compare_tri_sparse_host.argtypes = [vp, vp, u64, u64, vp, u64, vp]
+    lib.mg_compare_rect_sparse_host.argtypes = [vp, vp, vp, u64, u64, vp, u64, vp]
+    lib.mg_expand_tri_sparse.argtypes = [vp, u64, vp, u64, u64, u64, vp]
     lib.mg_finish_tri_host.argtypes = [vp, vp, u64, u64, i32, dbl, dbl, dbl, vp]
     lib.mg_finish_rect_host.argtypes = [vp, vp, u64, vp, u64, i32, dbl, dbl, dbl, vp]
     lib.mg_finish_tri_dev.argtypes = [vp, vp, vp, u64, u64, i32, dbl, dbl, dbl, vp]
@@ -801,6 +804,26 @@ class MashGpu:
         q_end = qry.rows if q_end is None else min(q_end, qry.rows)
         return self._filter(lambda o, c, n: self.lib.mg_compare_rect_filter_host(
             self.ctx, ref.handle, qry.handle, q_begin, q_end, k, max_d, o, c, n), capacity)
+
+    def compare_tri_sparse(self, table, row_begin=0, row_end=None, capacity=1 << 20):
+        """the triangle's EXCEPTIONS: every pair with numer >= 1 as {row, col, numer, denom}, reference order; every other
+        pair is {0, min(s, |A| + |B|)} (mg_compare_tri_sparse_host)"""
+        row_end = table.rows if row_end is None else min(row_end, table.rows)
+        return self._filter(lambda o, c, n: self.lib.mg_compare_tri_sparse_host(self.ctx, table.handle, row_begin, row_end, o, c, n), capacity)
+
+    def compare_rect_sparse(self, ref, qry, q_begin=0, q_end=None, capacity=1 << 20):
+        q_end = qry.rows if q_end is None else min(q_end, qry.rows)
+        return self._filter(lambda o, c, n: self.lib.mg_compare_rect_sparse_host(self.ctx, ref.handle, qry.handle, q_begin, q_end, o, c, n), capacity)
+
+    def expand_tri_sparse(self, edges, nhash, s, row_begin, row_end):
+        """the dense triangle out of the rule and the exceptions (host arithmetic)"""
+        out = np.zeros(tri_pairs(row_begin, row_end), dtype=COUNTS_DTYPE)
+        edges = np.ascontiguousarray(edges)
+        nhash = np.ascontiguousarray(nhash, dtype=np.uint32)
+        rc = self.lib.mg_expand_tri_sparse(edges.ctypes.data, len(edges), nhash.ctypes.data, int(s), int(row_begin), int(row_end), out.ctypes.data)
+        if rc != MG_OK:
+            raise MashGpuError(f"mg_expand_tri_sparse: {rc}")
+        return out
 
     # ---- compare + finish on the device ---------------------------------------------
     def compare_tri_pairs(self, table, k, kmer_space, max_d=-1.0, max_p=-1.0, row_begin=0, row_end=None):

@@ -394,7 +394,7 @@ template <uint32_t DN_ROWS>
 __global__ __launch_bounds__(128) void dn_pairs_kernel(const DenseTile *tiles, const DenseGroup *groups, const unsigned long long *gdata,
                                                        const unsigned long long *xm, uint32_t wstride, uint32_t use_lists,
                                                        const uint16_t *ext, uint32_t xs, uint32_t s, uint32_t row_begin, uint32_t row_end,
-                                                       uint64_t out_base, const uint32_t *inv, uint2 *out)
+                                                       uint64_t out_base, const uint32_t *inv, uint2 *out, DenseList list)
 {
     extern __shared__ __align__(16) unsigned long long dl[];
     const DenseTile T = tiles[blockIdx.x];
@@ -481,7 +481,14 @@ __global__ __launch_bounds__(128) void dn_pairs_kernel(const DenseTile *tiles, c
                     const uint32_t total = pu[k] + (Acx[W * DN_ROWS + ai + k] & DN_CX_MASK) + (Bcx[W * 128u + tid] & DN_CX_MASK);
                     denom[k] = total < s ? total : s;
                 }
-                out[dn_out_index(a, b, inv, out_base)] = make_uint2(common[k], denom[k]);
+                if (list.rc) {                                            // (uniform) a list job: the tail of row a's list
+                    const uint32_t ra = a - list.row_first;
+                    const uint32_t at = list.row_base[ra] + list.row_cnt[ra] - (a - b);
+                    list.rc[at] = make_uint2(a, b);
+                    list.counts[at] = make_uint2(common[k], denom[k]);
+                } else {
+                    out[dn_out_index(a, b, inv, out_base)] = make_uint2(common[k], denom[k]);
+                }
             }
         }
     }
@@ -499,7 +506,7 @@ uint32_t dense_rows_per_tile(uint64_t wave_rows) { return wave_rows / 32u >= 163
 hipError_t launch_dense_pairs(const DenseTile *tiles, uint32_t ntiles, uint32_t rows_per_tile, const DenseGroup *groups,
                               const unsigned long long *gdata, const unsigned long long *xm, bool use_lists, const uint16_t *ext, uint32_t xs,
                               uint32_t s, uint32_t wmax, uint32_t row_begin, uint32_t row_end, uint64_t out_base, const uint32_t *inv, uint2 *out,
-                              hipStream_t stream)
+                              hipStream_t stream, const DenseList *list)
 {
     if (ntiles == 0) return hipSuccess;
     const size_t smem = dense_pairs_lds(wmax, rows_per_tile);
@@ -507,7 +514,7 @@ hipError_t launch_dense_pairs(const DenseTile *tiles, uint32_t ntiles, uint32_t 
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(ntiles), dim3(128), smem, stream, tiles, groups, gdata, xm, wmax, use_lists ? 1u : 0u, ext, xs, s, row_begin, row_end,
-                           out_base, inv, out);
+                           out_base, inv, out, list ? *list : DenseList());
         return hipGetLastError();
     };
     return rows_per_tile == 32u ? go(dn_pairs_kernel<32>) : go(dn_pairs_kernel<8>);

@@ -72,6 +72,7 @@ hipError_t launch_make_prefix(const uint64_t *hashes, const uint32_t *nhash, uin
 // Generic kernel (any s): one wave per pair, binary search in global memory.
 hipError_t launch_compare_generic(const CompareArgs &a, hipStream_t stream);
 
+struct DenseGroup;
 // Inverted-index ("sparse") engine (compare_sparse.hip): fill + discover + merge over an index of
 // the column table built once per table (host_compare.cpp::table_sparse_index).
 struct SparseArgs {
@@ -109,6 +110,9 @@ struct SparseArgs {
     const uint32_t *gend;          // at a group's start position: one past its last (a copy walks the whole run of a value)
     const uint32_t *order;         // rows of the launch in visiting order (nullptr: row_end - 1 - slot)
     const uint32_t *inv;           // index built on a permuted table: index row -> table row (nullptr: the same)
+    // list jobs on a table with dense groups (compare_dense.hip): a grouped row's list ends with its pairs inside the group
+    const uint32_t *dn_grp_of;     // [n] group of a row, 0xFFFFFFFF: none (nullptr: no groups)
+    const DenseGroup *dn_groups;
 };
 size_t sparse_dup_temp_bytes(uint32_t n);
 hipError_t launch_sparse_dup_suspects(const unsigned long long *dig, const uint32_t *cnt, uint32_t n, void *temp, size_t temp_bytes,
@@ -154,6 +158,10 @@ hipError_t launch_sparse_scatter(const SparseArgs &a, uint64_t expect, uint32_t 
 size_t sparse_gather_temp_bytes(uint32_t nrows);
 hipError_t launch_sparse_gather_rows(const SparseArgs &a, uint32_t *cnt_by_row, uint32_t *row_base, void *temp, size_t temp_bytes, uint32_t row_add,
                                      uint2 *rc_out, uint2 *counts_out, hipStream_t stream);
+size_t sparse_edges_temp_bytes(uint64_t K);
+uint64_t sparse_edges_blocks(uint64_t K);
+hipError_t launch_sparse_list_edges(const uint2 *rc, const uint2 *counts, uint64_t K, uint32_t *blk_cnt, uint32_t *blk_off, void *temp, size_t temp_bytes,
+                                    uint4 *edges, unsigned long long *total, hipStream_t stream);
 hipError_t launch_sparse_fill_value(uint2 *out, uint64_t pairs, uint32_t numer, uint32_t denom, uint32_t blocks_per_cu, uint32_t cus,
                                     hipStream_t stream);
 hipError_t launch_sparse_merge_pack(const SparseArgs &a, uint64_t expect, uint32_t *chunks, void *temp, size_t temp_bytes, bool *used,
@@ -173,6 +181,13 @@ struct DenseGroup {
     uint64_t data_off;             // first block of the group in gdata (u64 words); a block = 128 rows: W x 128 u64 + (W + 1) x 128 u16
 };
 struct DenseTile { uint32_t group, row0, cblk; };
+// where a list job wants the pairs inside the groups: the list of row a (reference order: rows ascending, a row's pairs by
+// column) ends with its partners inside its group, so pair (a, b) stands at row_base[a - row_first] + row_cnt[a - row_first] - (a - b)
+struct DenseList {
+    const uint32_t *row_base = nullptr, *row_cnt = nullptr;
+    uint2 *rc = nullptr, *counts = nullptr;               // {row, col} and {common, denom} per list entry (rc == nullptr: the matrix)
+    uint32_t row_first = 0;
+};
 hipError_t launch_dense_neighbors(const uint64_t *hashes, uint64_t stride, const uint32_t *cnt, uint32_t n, uint8_t *link,
                                   hipStream_t stream);
 size_t dense_universe_temp_bytes(uint32_t cap);
@@ -195,7 +210,7 @@ uint32_t dense_max_words();
 hipError_t launch_dense_pairs(const DenseTile *tiles, uint32_t ntiles, uint32_t rows_per_tile, const DenseGroup *groups,
                               const unsigned long long *gdata, const unsigned long long *xm, bool use_lists, const uint16_t *ext, uint32_t xs,
                               uint32_t s, uint32_t wmax, uint32_t row_begin, uint32_t row_end, uint64_t out_base, const uint32_t *inv, uint2 *out,
-                              hipStream_t stream);
+                              hipStream_t stream, const DenseList *list = nullptr);
 size_t dense_cluster_temp_bytes(uint32_t n);
 hipError_t dense_cluster_rows(const uint64_t *hashes, uint64_t stride, const uint32_t *cnt, uint32_t n, void *temp, size_t temp_bytes,
                               unsigned long long *key_a, unsigned long long *key_b, uint32_t *row_a, uint32_t *row_b, uint32_t *lab_a,

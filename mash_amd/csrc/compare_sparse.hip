@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void sp_stat_reduce_kernel(const SpStatSlot *s
 size_t sparse_stat_scratch_bytes() { return sizeof(SpStatSlot) * SP_STAT_SLOTS; }
 
 // the entries of every row that enter the index: its first min(nhash, cap) hashes
-__global__ __launch_bounds__(256) void sp_row_counts_kernel(const uint32_t *nhash, uint32_t n, uint32_t cap, uint32_t *cnt)
+__global__ __launch_bounds__(256) void sp_entry_counts_kernel(const uint32_t *nhash, uint32_t n, uint32_t cap, uint32_t *cnt)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i < n) cnt[i] = nhash[i] < cap ? nhash[i] : cap;
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void sp_row_counts_kernel(const uint32_t *nhas
 hipError_t launch_sparse_row_counts(const uint32_t *nhash, uint32_t n, uint32_t cap, uint32_t *cnt, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(sp_row_counts_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, nhash, n, cap, cnt);
+    hipLaunchKernelGGL(sp_entry_counts_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, nhash, n, cap, cnt);
     return hipGetLastError();
 }
 
@@ -1270,7 +1270,12 @@ __global__ __launch_bounds__(256) void sp_row_counts_kernel(SparseArgs a, uint32
     const uint32_t nrows = a.row_end - a.row_begin;
     if (slot >= nrows) return;
     const uint32_t row = a.order ? a.order[slot] : a.row_end - 1u - slot;
-    cnt_by_row[row - a.row_begin] = a.seg_cnt[slot];
+    uint32_t c = a.seg_cnt[slot];
+    if (a.dn_grp_of) {                                     // (triangle) a grouped row: its partners inside the group follow its candidates
+        const uint32_t g = a.dn_grp_of[row];
+        if (g != 0xFFFFFFFFu) c += row - a.dn_groups[g].g0;
+    }
+    cnt_by_row[row - a.row_begin] = c;
 }
 
 __global__ __launch_bounds__(256) void sp_gather_rows_kernel(SparseArgs a, const uint32_t *row_base, uint32_t row_add, uint2 *rc_out, uint2 *counts_out)
@@ -1298,6 +1303,76 @@ hipError_t launch_sparse_gather_rows(const SparseArgs &a, uint32_t *cnt_by_row, 
     e = rocprim::exclusive_scan(temp, temp_bytes, (const uint32_t *)cnt_by_row, row_base, 0u, (size_t)nrows, rocprim::plus<uint32_t>(), stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(sp_gather_rows_kernel, dim3(nrows), dim3(256), 0, stream, a, (const uint32_t *)row_base, row_add, rc_out, counts_out);
+    return hipGetLastError();
+}
+
+// ---- a list of pairs -> the entries that are worth a record: {row, col, numer, denom} of every pair with numer >= 1, order kept.
+// Blocks of 1024 entries: counted, the counts scanned (rocPRIM), written at their ranks.
+constexpr uint32_t SP_EDGE_BLOCK = 1024;
+
+__global__ __launch_bounds__(256) void sp_edges_count_kernel(const uint2 *counts, uint64_t K, uint32_t *blk_cnt)
+{
+    const uint64_t base = (uint64_t)blockIdx.x * SP_EDGE_BLOCK;
+    uint32_t c = 0;
+    for (uint32_t k = threadIdx.x; k < SP_EDGE_BLOCK; k += 256u)
+        if (base + k < K && counts[base + k].x != 0) c++;
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
+    __shared__ uint32_t s_c[4];
+    if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) blk_cnt[blockIdx.x] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+}
+
+__global__ __launch_bounds__(256) void sp_edges_write_kernel(const uint2 *rc, const uint2 *counts, uint64_t K, const uint32_t *blk_off, uint32_t nblk,
+                                                             uint4 *edges, unsigned long long *total)
+{
+    const uint64_t base = (uint64_t)blockIdx.x * SP_EDGE_BLOCK;
+    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    __shared__ uint32_t s_w[4];
+    uint32_t run = blk_off[blockIdx.x];
+    for (uint32_t k0 = 0; k0 < SP_EDGE_BLOCK; k0 += 256u) {               // (entry order = k0 + thread: kept)
+        const uint64_t i = base + k0 + threadIdx.x;
+        uint2 c = make_uint2(0u, 0u);
+        if (i < K) c = counts[i];
+        const bool keep = i < K && c.x != 0;
+        const uint64_t bal = __ballot(keep);
+        if (lane == 0) s_w[wid] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t before = 0;
+        for (uint32_t w = 0; w < wid; w++) before += s_w[w];
+        const uint32_t all = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        if (keep) {
+            const uint2 p = rc[i];
+            edges[run + before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = make_uint4(p.x, p.y, c.x, c.y);
+        }
+        run += all;
+        __syncthreads();
+    }
+    if (blockIdx.x == nblk - 1u && threadIdx.x == 0) *total = run;
+}
+
+size_t sparse_edges_temp_bytes(uint64_t K)
+{
+    size_t b = 0;
+    rocprim::exclusive_scan(nullptr, b, (const uint32_t *)nullptr, (uint32_t *)nullptr, 0u, (size_t)((K + SP_EDGE_BLOCK - 1) / SP_EDGE_BLOCK), rocprim::plus<uint32_t>(),
+                            (hipStream_t) nullptr);
+    return b;
+}
+
+uint64_t sparse_edges_blocks(uint64_t K) { return (K + SP_EDGE_BLOCK - 1) / SP_EDGE_BLOCK; }
+
+// rc / counts: K list entries; blk_cnt / blk_off: scratch of sparse_edges_blocks(K) u32; edges: room for K; *total (device): how many were written
+hipError_t launch_sparse_list_edges(const uint2 *rc, const uint2 *counts, uint64_t K, uint32_t *blk_cnt, uint32_t *blk_off, void *temp, size_t temp_bytes,
+                                    uint4 *edges, unsigned long long *total, hipStream_t stream)
+{
+    if (K == 0) return hipMemsetAsync(total, 0, 8, stream);
+    const uint32_t nblk = (uint32_t)sparse_edges_blocks(K);
+    hipLaunchKernelGGL(sp_edges_count_kernel, dim3(nblk), dim3(256), 0, stream, counts, K, blk_cnt);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    e = rocprim::exclusive_scan(temp, temp_bytes, (const uint32_t *)blk_cnt, blk_off, 0u, (size_t)nblk, rocprim::plus<uint32_t>(), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sp_edges_write_kernel, dim3(nblk), dim3(256), 0, stream, rc, counts, K, (const uint32_t *)blk_off, nblk, edges, total);
     return hipGetLastError();
 }
 

@@ -910,7 +910,12 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
                 } else {
                     finish_build();
                 }
-                if (e != hipSuccess || !h_stat.tie_overflow || begin_bit == 0) break;
+                // (also when the order came out wrong behind a sort on the leading bits -- never seen since the repair kernels
+                //  exist, but the remedy is the same and silent downgrades to the tile engine are worse)
+                if (e != hipSuccess || (!h_stat.tie_overflow && !h_stat.bad) || begin_bit == 0) break;
+                if (ctx_opt(ctx, "MASHGPU_SPARSE_DBG"))
+                    fprintf(stderr, "compare sparse: sort on bits [%u, %u) %s: every bit again\n", begin_bit, end_bit,
+                            h_stat.bad ? "left values out of order" : "left ties the repair could not take");
             }
             if (built && e == hipSuccess) {
                 // every array of the two builds, word by word
@@ -1107,7 +1112,15 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
 // Order of a pass: DISCOVER first (it also counts: the candidates K and the shared hashes I of the job,
 // which decide the engine the first time a job is seen -- there is no separate counting pass), then fill,
 // merge, scatter.
-struct SparseJob { mg::SparseArgs args; uint64_t cand = 0; mg_table::Sparse *ix = nullptr; };
+struct SparseJob {
+    mg::SparseArgs args;
+    uint64_t cand = 0;                                      // candidates: pairs that share a hash and lie in no dense group
+    mg_table::Sparse *ix = nullptr;
+    // the pairs inside the dense groups of the job's rows (a list job gets them appended to their rows' lists: job_lists)
+    const mg::DenseTile *dtiles = nullptr;
+    uint32_t ndtiles = 0, dtile_rows = 0;
+    uint64_t dense_pairs = 0;
+};
 
 static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, uint64_t row_begin, uint64_t row_end,
                               bool triangle, uint32_t s, mg_counts *out_dev, bool force, bool *handled, SparseJob *job = nullptr)
@@ -1134,8 +1147,10 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
     }
     if (!ix->usable) return MG_OK;
     // (list mode: two copies of one sketch are a pair at distance 0 that is no candidate, two EMPTY sketches
-    //  likewise -- such tables take the matrix path; so do tables with dense groups, whose inner pairs are in no list)
-    if (job && (ix->copies || ix->has_empty || !ix->dgroups_host.empty())) return MG_OK;
+    //  likewise -- such tables take the matrix path.  The pairs inside dense groups are no candidates either: they are
+    //  appended to their rows' lists by the dense kernel itself, see job_lists)
+    if (job && (ix->copies || ix->has_empty)) return MG_OK;
+    if (job && !triangle && !ix->dgroups_host.empty()) return MG_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
 
     // ---- row side ----
@@ -1155,6 +1170,8 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
     a.cls_rows = ix->cls_rows;
     a.gend = ix->gend;
     a.inv = ix->inv;
+    a.dn_grp_of = (job && triangle && !ix->dgroups_host.empty()) ? ix->grp_of : nullptr;
+    a.dn_groups = a.dn_grp_of ? ix->dgroups : nullptr;
     a.res = nullptr;
     a.seg_base = nullptr;
     a.seg_cnt = nullptr;
@@ -1234,6 +1251,13 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
         for (auto &pl : ix->plans)
             if (pl.rows == (const void *)rows && pl.rb == row_begin && pl.re == row_end && pl.triangle == triangle) plan = &pl;
     mg_table::Sparse::Plan fresh;
+    fresh.order = nullptr;
+    fresh.dtiles = nullptr;
+    bool fresh_kept = false;                                // (its buffers belong to the index once it is in ix->plans)
+    struct FreshGuard {                                     // ... and to nobody on every other way out (the dense tiles leaked)
+        mg_ctx *c; mg_table::Sparse::Plan *p; bool *kept;
+        ~FreshGuard() { if (!*kept) { if (p->order) ctx_free(c, p->order); if (p->dtiles) ctx_free(c, p->dtiles); } }
+    } fresh_guard{ctx, &fresh, &fresh_kept};
     const bool first = plan == nullptr;
     if (first) {
         fresh.rows = rows; fresh.rb = row_begin; fresh.re = row_end; fresh.triangle = triangle;
@@ -1344,7 +1368,7 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
     const bool nothing_to_find = triangle && ix->one_class != 0;      // nothing but copies of one sketch: every pair is inside the class
     for (int attempt = 0; !nothing_to_find; attempt++) {
         rc = ensure_lists(want);
-        if (rc != MG_OK) { if (first && fresh.order) ctx_free(ctx, fresh.order); return rc; }
+        if (rc != MG_OK) return rc;
         a.cand = ix->cand;
         a.res = ix->res;
         a.cand_cap = ix->cand_cap;
@@ -1361,7 +1385,7 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
         HIP_TRY(ctx, hipMemcpyAsync(h, ix->counters, 24, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (h[2] == 0) break;
-        if (attempt >= 1) { if (fresh.order) ctx_free(ctx, fresh.order); return fail(ctx, MG_ERR_INVALID, "compare: the table changed while it was compared"); }
+        if (attempt >= 1) return fail(ctx, MG_ERR_INVALID, "compare: the table changed while it was compared");
         want = h[0];
     }
     if (first) {
@@ -1385,6 +1409,7 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
                 ix->plans.erase(ix->plans.begin());
             }
             ix->plans.push_back(fresh);
+            fresh_kept = true;
             plan = &ix->plans.back();
         }
     }
@@ -1422,7 +1447,15 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
         }
     }
     *handled = true;
-    if (job) { job->ix = ix; job->cand = plan->cand; job->args = a; }
+    if (job) {
+        job->ix = ix;
+        job->cand = plan->cand;
+        job->args = a;
+        job->dtiles = plan->dtiles;
+        job->ndtiles = plan->ndtiles;
+        job->dtile_rows = plan->dtile_rows;
+        job->dense_pairs = plan->ndtiles ? plan->dense_pairs : 0;
+    }
     if (plan->cand == 0) return MG_OK;
     // ---- merge ----
     bool by_rows = mg::sparse_merge_rows_supported(a.rs_row);
@@ -1722,6 +1755,7 @@ static void build_min_numer(uint32_t s, int k, double max_d, std::vector<uint32_
     }
 }
 
+// kmer_size == 0: no distance filter -- every pair that shares a hash inside its first s union elements (numer >= 1) passes
 static int compare_filter(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, uint64_t rb, uint64_t re,
                           bool triangle, int kmer_size, double max_distance, mg_edge *out_host, uint64_t capacity,
                           uint64_t *count_out)
@@ -1729,12 +1763,13 @@ static int compare_filter(mg_ctx *ctx, const mg_table *rows, const mg_table *col
     *count_out = 0;
     if (re > rows->n) re = rows->n;
     if (rb >= re) return MG_OK;
-    if (kmer_size < 1) return fail(ctx, MG_ERR_INVALID, "compare filter: bad k-mer size");
+    if (kmer_size < 0) return fail(ctx, MG_ERR_INVALID, "compare filter: bad k-mer size");
     const uint64_t s64 = std::min(rows->s, cols->s);
     if (s64 > 0xFFFFFFFEull) return fail(ctx, MG_ERR_INVALID, "compare: sketch size too large");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     std::vector<uint32_t> min_numer;
-    build_min_numer((uint32_t)s64, kmer_size, max_distance, min_numer);
+    if (kmer_size == 0) min_numer.assign((size_t)s64 + 1, 1u);
+    else build_min_numer((uint32_t)s64, kmer_size, max_distance, min_numer);
 
     // row blocks of up to 2^30 pairs (8 GiB of counts): large launches keep the
     // tail of the compare kernel short; survivors leave in windows of 2^26 edges
@@ -1821,6 +1856,7 @@ int mg_compare_tri_filter_host(mg_ctx *ctx, const mg_table *t, uint64_t row_begi
     if (!ctx) return MG_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (!t || !count_out || (!out_host && capacity)) return fail(ctx, MG_ERR_INVALID, "mg_compare_tri_filter_host: NULL argument");
+    if (kmer_size < 1) return fail(ctx, MG_ERR_INVALID, "compare filter: bad k-mer size");
     return compare_filter(ctx, t, t, row_begin, row_end, true, kmer_size, max_distance, out_host, capacity, count_out);
 }
 
@@ -1832,6 +1868,7 @@ int mg_compare_rect_filter_host(mg_ctx *ctx, const mg_table *ref, const mg_table
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (!ref || !qry || !count_out || (!out_host && capacity))
         return fail(ctx, MG_ERR_INVALID, "mg_compare_rect_filter_host: NULL argument");
+    if (kmer_size < 1) return fail(ctx, MG_ERR_INVALID, "compare filter: bad k-mer size");
     return compare_filter(ctx, qry, ref, q_begin, q_end, false, kmer_size, max_distance, out_host, capacity, count_out);
 }
 
@@ -2030,6 +2067,28 @@ int mg_compare_rect_pairs_host(mg_ctx *ctx, const mg_table *ref, const mg_table 
 }
 
 // compare + both filters + compaction on the device: survivors only, as full records, in reference order
+// The lists of a finished list job in REFERENCE order (rows ascending, a row's pairs by column): the candidates' {row, col}
+// and {common, denom} gathered row by row, and behind a grouped row's candidates -- they all lie below its group -- its pairs
+// inside the group, computed into their places by the dense kernel.  K = job.cand + job.dense_pairs entries.
+static int job_lists(mg_ctx *ctx, const SparseJob &job, uint32_t nrows, uint32_t row_add, uint32_t s, uint32_t *d_byrow, uint32_t *d_base, void *d_temp,
+                     size_t tb, uint2 *d_rc, uint2 *d_cnt)
+{
+    HIP_TRY(ctx, hipMemsetAsync(d_byrow, 0, (size_t)nrows * 4, ctx->stream));
+    HIP_TRY(ctx, mg::launch_sparse_gather_rows(job.args, d_byrow, d_base, d_temp, tb, row_add, d_rc, d_cnt, ctx->stream));
+    if (job.ndtiles) {
+        mg_table::Sparse *ix = job.ix;
+        mg::DenseList L;
+        L.row_base = d_base;
+        L.row_cnt = d_byrow;
+        L.rc = d_rc;
+        L.counts = d_cnt;
+        L.row_first = job.args.row_begin;
+        HIP_TRY(ctx, mg::launch_dense_pairs(job.dtiles, job.ndtiles, job.dtile_rows, ix->dgroups, ix->gdata, ix->xm, ix->dn_lists, ix->ext, ix->dn_xs, s, ix->dn_wmax,
+                                            job.args.row_begin, job.args.row_end, job.args.out_base, nullptr, nullptr, ctx->stream, &L));
+    }
+    return MG_OK;
+}
+
 static int compare_results(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, uint64_t rb, uint64_t re, bool triangle,
                            int kmer_size, double kmer_space, double max_d, double max_p, mg_result *out_host, uint64_t capacity,
                            uint64_t *count_out)
@@ -2058,7 +2117,7 @@ static int compare_results(mg_ctx *ctx, const mg_table *rows, const mg_table *co
         if (rc != MG_OK) return rc;
         // (a list of 2^32 candidates and more, or one whose scratch does not fit, is no error: the blocked matrix path
         //  below does the job in 2^30-pair blocks -- ADVICE r3)
-        const uint64_t K = handled ? job.cand : 0;
+        const uint64_t K = handled ? job.cand + job.dense_pairs : 0;
         if (handled && K == 0) return MG_OK;
         const uint32_t nrows = (uint32_t)(re - rb);
         DevBuf<uint2> d_rc(ctx), d_cnt(ctx);
@@ -2076,8 +2135,8 @@ static int compare_results(mg_ctx *ctx, const mg_table *rows, const mg_table *co
             list_ok = false;
         }
         if (list_ok) {
-            HIP_TRY(ctx, hipMemsetAsync(d_byrow, 0, (size_t)nrows * 4, ctx->stream));
-            HIP_TRY(ctx, mg::launch_sparse_gather_rows(job.args, d_byrow, d_base, d_temp, tb, triangle ? 0u : (uint32_t)rb, d_rc, d_cnt, ctx->stream));
+            rc = job_lists(ctx, job, nrows, triangle ? 0u : (uint32_t)rb, s, d_byrow, d_base, d_temp, tb, d_rc, d_cnt);
+            if (rc != MG_OK) return rc;
             std::vector<uint32_t> seen2((size_t)s + 1, 0);
             FinishTables fa(ctx);
             rc = build_finish_tables(ctx, s, kmer_size, max_d, seen2, fa);
@@ -2213,6 +2272,102 @@ static int compare_results(mg_ctx *ctx, const mg_table *rows, const mg_table *co
     }
     *count_out = total;
     if (total > capacity) return fail(ctx, MG_ERR_NOMEM, "compare: more passing pairs than `capacity` (see *count_out)");
+    return MG_OK;
+}
+
+// ---- the whole matrix as the pairs that are NOT {0, min(s, |A| + |B|)} (include/mashgpu.h: mg_compare_tri_sparse_host)
+static int compare_sparse_matrix(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, uint64_t rb, uint64_t re, bool triangle, mg_edge *out_host,
+                                 uint64_t capacity, uint64_t *count_out)
+{
+    *count_out = 0;
+    if (re > rows->n) re = rows->n;
+    if (rb >= re) return MG_OK;
+    const uint64_t s64 = std::min(rows->s, cols->s);
+    if (s64 > 0xFFFFFFFEull) return fail(ctx, MG_ERR_INVALID, "compare: sketch size too large");
+    const uint32_t s = (uint32_t)s64;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint64_t all_pairs = triangle ? tri_pairs(rb, re) : (re - rb) * cols->n;
+    if (all_pairs == 0) return MG_OK;
+    const char *force_kernel = ctx_opt(ctx, "MASHGPU_COMPARE_KERNEL");
+    if ((!force_kernel || strcmp(force_kernel, "sparse") == 0) && !ctx_opt(ctx, "MASHGPU_RESULTS_MATRIX")) {
+        // the index engine's lists ARE the answer: its candidates (pairs that share a hash) and the pairs inside its dense
+        // groups, in reference order, minus the few that share a hash only behind their first s union elements
+        SparseJob job;
+        bool handled = false;
+        int rc = run_compare_sparse(ctx, rows, cols, rb, re, triangle, s, nullptr, force_kernel != nullptr, &handled, &job);
+        if (rc != MG_OK) return rc;
+        const uint64_t K = handled ? job.cand + job.dense_pairs : 0;
+        if (handled && K == 0) return MG_OK;
+        const uint32_t nrows = (uint32_t)(re - rb);
+        DevBuf<uint2> d_rc(ctx), d_cnt(ctx);
+        DevBuf<uint32_t> d_byrow(ctx), d_base(ctx), d_bc(ctx), d_bo(ctx);
+        DevBuf<uint4> d_edges(ctx);
+        DevBuf<unsigned long long> d_total(ctx);
+        DevBuf<unsigned char> d_temp(ctx);
+        const size_t tb = std::max(mg::sparse_gather_temp_bytes(nrows), mg::sparse_edges_temp_bytes(K));
+        if (handled && K < (1ull << 32) && d_rc.alloc(K) == hipSuccess && d_cnt.alloc(K) == hipSuccess && d_byrow.alloc(nrows) == hipSuccess &&
+            d_base.alloc(nrows) == hipSuccess && d_temp.alloc(std::max<size_t>(tb, 16)) == hipSuccess && d_bc.alloc(mg::sparse_edges_blocks(K)) == hipSuccess &&
+            d_bo.alloc(mg::sparse_edges_blocks(K)) == hipSuccess && d_edges.alloc(K) == hipSuccess && d_total.alloc(1) == hipSuccess) {
+            rc = job_lists(ctx, job, nrows, triangle ? 0u : (uint32_t)rb, s, d_byrow, d_base, d_temp, tb, d_rc, d_cnt);
+            if (rc != MG_OK) return rc;
+            unsigned long long total = 0;
+            HIP_TRY(ctx, mg::launch_sparse_list_edges(d_rc, d_cnt, K, d_bc, d_bo, d_temp, tb, d_edges, d_total, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            *count_out = total;
+            if (total > capacity) return fail(ctx, MG_ERR_NOMEM, "compare: more pairs that share a hash than `capacity` (see *count_out)");
+            if (total) {
+                HIP_TRY(ctx, hipMemcpyAsync(out_host, d_edges, total * sizeof(mg_edge), hipMemcpyDeviceToHost, ctx->stream));
+                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            }
+            return MG_OK;
+        }
+        (void)hipGetLastError();
+    }
+    // tables the list engine leaves alone (copies of rows, empty rows, nearly every pair related): the matrix in blocks, filtered on the device
+    return compare_filter(ctx, rows, cols, rb, re, triangle, 0, 0.0, out_host, capacity, count_out);
+}
+
+int mg_compare_tri_sparse_host(mg_ctx *ctx, const mg_table *t, uint64_t row_begin, uint64_t row_end, mg_edge *out_host, uint64_t capacity,
+                               uint64_t *count_out)
+{
+    if (!ctx) return MG_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    if (!t || !count_out || (!out_host && capacity)) return fail(ctx, MG_ERR_INVALID, "mg_compare_tri_sparse_host: null argument");
+    return compare_sparse_matrix(ctx, t, t, row_begin, row_end, true, out_host, capacity, count_out);
+}
+
+int mg_compare_rect_sparse_host(mg_ctx *ctx, const mg_table *ref, const mg_table *qry, uint64_t q_begin, uint64_t q_end, mg_edge *out_host,
+                                uint64_t capacity, uint64_t *count_out)
+{
+    if (!ctx) return MG_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    if (!ref || !qry || !count_out || (!out_host && capacity)) return fail(ctx, MG_ERR_INVALID, "mg_compare_rect_sparse_host: null argument");
+    return compare_sparse_matrix(ctx, qry, ref, q_begin, q_end, false, out_host, capacity, count_out);
+}
+
+int mg_expand_tri_sparse(const mg_edge *edges, uint64_t count, const uint32_t *nhash, uint64_t sketch_size, uint64_t row_begin, uint64_t row_end,
+                         mg_counts *out_host)
+{
+    if ((!edges && count) || !nhash || !out_host || row_begin > row_end) return MG_ERR_INVALID;
+    const uint64_t base = tri_pairs(0, row_begin);
+    finish_parallel(row_end - row_begin, [=](uint64_t kb, uint64_t ke) {
+        for (uint64_t i = row_begin + kb; i < row_begin + ke; i++) {
+            const uint64_t ni = std::min<uint64_t>(nhash[i], sketch_size);
+            mg_counts *row = out_host + ((i ? i * (i - 1) / 2 : 0) - base);
+            for (uint64_t j = 0; j < i; j++) {
+                row[j].numer = 0;
+                row[j].denom = (uint32_t)std::min<uint64_t>(sketch_size, ni + std::min<uint64_t>(nhash[j], sketch_size));
+            }
+        }
+    });
+    for (uint64_t e = 0; e < count; e++) {
+        const mg_edge &x = edges[e];
+        if (x.row < row_begin || x.row >= row_end || x.col >= x.row) return MG_ERR_INVALID;
+        mg_counts &c = out_host[(uint64_t)x.row * (x.row - 1) / 2 - base + x.col];
+        c.numer = x.numer;
+        c.denom = x.denom;
+    }
     return MG_OK;
 }
 

@@ -568,6 +568,16 @@ static int sketch_packed_impl(mg_ctx *ctx, const mg_params *p, const uint8_t *pa
             if (d_pk[k].alloc(longest / 4u + 32u) != hipSuccess || (mask && d_mk[k].alloc(longest / 8u + 32u) != hipSuccess))
                 return fail(ctx, MG_ERR_NOMEM, "mg_sketch_packed: device allocation failed");
         HIP_TRY(ctx, hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+        // The staging buffers come from the context's pool, whose rule is stream order: a block handed back while work on it
+        // is still queued on the context's stream (mg_ctx_set_async: a compare call may have returned with kernels pending on
+        // its scratch) is only safe for work queued BEHIND that work.  The copy stream is another stream, so it is put behind
+        // everything the context's stream holds right now.
+        hipEvent_t ev = nullptr;
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        hipError_t e = hipEventRecord(ev, ctx->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(copy_stream, ev, 0);
+        (void)hipEventDestroy(ev);                          // (released once the wait has been served)
+        if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("mg_sketch_packed: ") + hipGetErrorString(e));
     }
     // the piece's ranges in the two arrays, cut at 4-byte boundaries (the kernel's loads are dwords)
     auto pk_byte0 = [](const Piece &q) { return (q.b0 / 4u) & ~3ull; };

@@ -6,6 +6,9 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#if defined(__x86_64__)
+#include <immintrin.h>                                      // (outside every namespace: the header's own declarations belong to the global one)
+#endif
 
 #include "../../include/mashgpu.h"
 
@@ -37,7 +40,6 @@ inline Packed8 pack8(uint64_t x, bool fold)
 }
 
 #if defined(__x86_64__)
-#include <immintrin.h>
 // 32 bases per step on hosts with AVX2 + BMI2 (chosen at run time; the 64-bit steps above remain the portable form and
 // do the tail): byte-wise compares for the four letters, movemask for the invalid bits, pext for the code bits
 __attribute__((target("avx2,bmi2"))) uint64_t pack_avx2(const uint8_t *ascii, uint64_t groups32, bool fold, uint8_t *packed,

@@ -994,6 +994,52 @@ def test_compare_sparse_index_of_a_collection_of_many_genome_sizes(eng, oracle, 
         assert np.array_equal(got["numer"], numer) and np.array_equal(got["denom"], denom), knobs
 
 
+@pytest.mark.parametrize("kind", ["clusters", "clades_in_order", "ragged", "random"])
+def test_sparse_matrix_is_the_whole_matrix(eng, oracle, kind, monkeypatch):
+    """mg_compare_tri_sparse_host: the triangle as its exceptions -- every pair with numer >= 1 -- from which the rule
+    {0, min(s, |A| + |B|)} and the tables' hash counts give back EVERY {numer, denom} (mg_expand_tri_sparse), byte for byte
+    what mg_compare_tri_host returns (CommandTriangle.cpp:159-198 prints mostly the constant).  Tables with clusters
+    (candidates), clades listed in order (the index in table order has dense groups: their inner pairs are appended to the
+    rows' lists by the dense kernel -- round 4 sent such list jobs to the blocked matrix path), short / empty / copied rows
+    (the matrix path behind the same call) and unrelated rows (no exception at all); also a row range, and the same
+    through the thresholded results call."""
+    rng = np.random.default_rng(5)
+    if kind == "clusters":
+        table, nhash, _ = synth.clustered_sketches(2200, 1000, clusters=22, seed=9)
+    elif kind == "clades_in_order":
+        table, nhash = _clade_table(rng, (120, 35, 260, 9), 1000, short_every=0)
+    elif kind == "ragged":
+        table, nhash, _ = _index_tables("ragged", rng)
+    else:
+        table, nhash, _ = synth.random_sketches(1500, 1000, seed=3)
+    n, s = table.shape
+    lengths = np.full(n, 10 ** 6, dtype=np.uint64)
+    t = eng.table_upload(table, nhash, lengths)
+    full = eng.compare_tri_host(t)
+    for i in sorted(set([1, n // 2, n - 1])):
+        numer, denom = _oracle_tri(oracle, table, nhash, lengths, i, i + 1)
+        lo = i * (i - 1) // 2
+        assert np.array_equal(full["numer"][lo:lo + i], numer) and np.array_equal(full["denom"][lo:lo + i], denom), i
+    monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", "sparse")
+    monkeypatch.setenv("MASHGPU_SPARSE_DBG", "1")
+    edges = eng.compare_tri_sparse(t)
+    assert len(edges) == int(np.count_nonzero(full["numer"]))
+    assert np.all(edges["numer"] >= 1)
+    key = edges["row"].astype(np.uint64) << np.uint64(32) | edges["col"].astype(np.uint64)
+    assert np.all(key[1:] > key[:-1])                       # reference order
+    assert eng.expand_tri_sparse(edges, nhash, s, 0, n).tobytes() == full.tobytes()
+    rb, re = n // 3, n - 7
+    part = eng.compare_tri_sparse(t, rb, re)
+    lo, hi = rb * (rb - 1) // 2, re * (re - 1) // 2
+    assert eng.expand_tri_sparse(part, nhash, s, rb, re).tobytes() == full[lo:hi].tobytes()
+    # the thresholded results of the same table: the list engine with the groups' pairs in it == the matrix path
+    res = eng.compare_tri_results(t, 21, KSPACE21, max_d=0.2)
+    monkeypatch.setenv("MASHGPU_RESULTS_MATRIX", "1")
+    res_m = eng.compare_tri_results(t, 21, KSPACE21, max_d=0.2)
+    assert res.tobytes() == res_m.tobytes()
+    t.free()
+
+
 def _index_tables(kind, rng):
     """tables for the tile-built index: (table, nhash, may_refuse)"""
     if kind == "clusters":                                  # C3 in small: clusters interleaved over the rows
