@@ -1396,7 +1396,11 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
         const double t_sparse = np * 8.0 / 4.5e12 + (double)fresh.shared * 2.0e-12 + (double)nrows * s * 4.0e-11 + (double)fresh.cand * 1.0e-9 + 2.0e-5 +
                                 (triangle ? (double)ix->cls_pairs * 8.0 / 2.0e12 : 0.0) + (double)fresh.dense_pairs * 3.0e-11;
         const double dense_rate = np < 3.0e8 ? 8.0e9 : np < 2.0e9 ? 1.5e10 : 3.0e10;
-        const double t_dense = np / dense_rate + (double)fresh.shared * 2.2e-12;
+        // (what a shared hash costs the tile engine: 2.2e-12 s between copies of one sketch, 5.5e-12 inside clades -- and
+        //  1.2e-11 in a collection of one species, where every pair shares a few hundred values and no two rows the same
+        //  ones (round 5's one_species bracket: 1.58 s for 5.4e8 pairs where the model said 0.33); priced at the upper
+        //  middle, the copies and clades having engines of their own by now)
+        const double t_dense = np / dense_rate + (double)fresh.shared * 8.0e-12;
         fresh.use = t_sparse < t_dense;
         if (ctx_opt(ctx, "MASHGPU_SPARSE_DBG"))
             fprintf(stderr, "compare sparse: rows [%llu, %llu) %s: %llu pairs, %llu candidates, %llu shared hashes; model sparse %.3f ms, tiles %.3f ms\n",

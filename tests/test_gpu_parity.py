@@ -1040,6 +1040,24 @@ def test_sparse_matrix_is_the_whole_matrix(eng, oracle, kind, monkeypatch):
     t.free()
 
 
+@pytest.mark.parametrize("kernel", ["default", "sparse", "merged"])
+def test_one_species_collection(eng, oracle, kernel, monkeypatch):
+    """The middle of the similarity range: one species as a tree of descent (workloads/synth.species_sketches)
+    -- every pair shares 10 - 50 % of its hashes, no near-copies, no small pool the rows draw from, rows in random order: nothing
+    for the dense groups, everything a candidate.  Every pair against the oracle (compareSketches, CommandDistance.cpp:347-385),
+    through the engine the dispatch picks, the index engine and the tile engine."""
+    n, s = 900, 300
+    table, nhash, lengths = synth.species_sketches(n, s, seed=4)
+    numer, denom = _oracle_tri(oracle, table, nhash, lengths, 0, n)
+    assert 0.08 * s < np.percentile(numer, 1) and np.percentile(numer, 99) < 0.6 * s       # the regime the bracket is about
+    if kernel != "default":
+        monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", kernel)
+    t = eng.table_upload(table, nhash, lengths)
+    got = eng.compare_tri_host(t)
+    assert np.array_equal(got["numer"], numer) and np.array_equal(got["denom"], denom)
+    t.free()
+
+
 def _index_tables(kind, rng):
     """tables for the tile-built index: (table, nhash, may_refuse)"""
     if kind == "clusters":                                  # C3 in small: clusters interleaved over the rows

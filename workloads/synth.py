@@ -83,6 +83,44 @@ def clustered_sketches(n, s=1000, clusters=None, seed=0, pool=1500, private=400,
     return table, nhash, lengths
 
 
+# --------------------------------------------------------------------------
+# one species: a tree of descent (the middle of the similarity range)
+
+_SP_C1, _SP_C2, _SP_C3 = np.uint64(0x9E3779B97F4A7C15), np.uint64(0xC2B2AE3D27D4EB4F), np.uint64(0x165667B19E3779F9)
+
+
+def _sp_mix(z):
+    with np.errstate(over="ignore"):
+        z = (z ^ (z >> np.uint64(30))) * _M1
+        z = (z ^ (z >> np.uint64(27))) * _M2
+        return z ^ (z >> np.uint64(31))
+
+
+def species_sketches(n, s=1000, seed=0, q_inner=0.04, q_leaf=0.18, length=1_000_000):
+    """A single-species collection at Mash distances of roughly 0.02 - 0.1: n leaves of a binary tree of descent; on every
+    edge a share of the sketch's values is replaced by new ones (q_inner on inner edges, q_leaf on the last), so two rows
+    share what neither lineage replaced since their common ancestor: ~50 % for siblings down to ~10 % across the root -- no
+    near-copies, no small common pool (the values held by two rows and more number in the hundreds of thousands).  Slot k
+    of a sketch holds a value of the k-th stratum of the hash range, so rows are ascending by construction.  Rows in a
+    fixed pseudo-random order.  Same bits as workloads/synth_torch.species_sketch_table."""
+    L = max(1, int(np.ceil(np.log2(max(n, 2)))))
+    with np.errstate(over="ignore"):
+        i = np.arange(n, dtype=np.uint64)[:, None]
+        k = np.arange(s, dtype=np.uint64)[None, :]
+        origin = np.zeros((n, s), dtype=np.uint64)
+        sd = np.uint64(seed) * GOLDEN
+        for lev in range(1, L + 1):
+            a = i >> np.uint64(L - lev)
+            u = _sp_mix((k * _SP_C1) ^ (np.uint64(lev) * _SP_C2) ^ (a * _SP_C3) ^ sd)
+            thr = np.uint64(int((q_leaf if lev == L else q_inner) * 4294967296.0))
+            rep = (u >> np.uint64(32)) < thr
+            origin = np.where(rep, (np.uint64(lev) << np.uint64(40)) | a, origin)
+        val = (k << np.uint64(44)) + (_sp_mix((k * _SP_C2) ^ (origin * _SP_C1) ^ sd) & np.uint64((1 << 44) - 1))
+        order = np.argsort(_sp_mix(np.arange(n, dtype=np.uint64) * _SP_C3 ^ sd), kind="stable")
+    table = np.ascontiguousarray(val[order])
+    return table, np.full(n, s, dtype=np.uint32), np.full(n, length, dtype=np.uint64)
+
+
 def random_sketches(n, s=1000, seed=0, bits=54):
     """All-random table (common ~ 0): the cheap extreme of the merge."""
     rng = np.random.default_rng(seed)

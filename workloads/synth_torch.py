@@ -87,6 +87,40 @@ def clade_sketch_table(n, s=1000, clade=1000, seed=0, device="cuda", contiguous=
                                   keep_p=0.97, device=device, contiguous=contiguous)
 
 
+def _sp_mix(z):
+    z = (z ^ _lsr(z, 30)) * _M1
+    z = (z ^ _lsr(z, 27)) * _M2
+    return z ^ _lsr(z, 31)
+
+
+def species_sketch_table(n, s=1000, seed=0, q_inner=0.04, q_leaf=0.18, length=1_000_000, device="cuda", block=4096):
+    """One species as a tree of descent (see workloads/synth.species_sketches: the same bits): pairs share 10 - 50 % of their
+    values, no near-copies, no small common pool; rows in a fixed pseudo-random order."""
+    import math
+    L = max(1, math.ceil(math.log2(max(n, 2))))
+    C1, C2, C3 = _GOLDEN, -4417276706812531889, 1609587929392839161           # 0x9E37.., 0xC2B2AE3D27D4EB4F, 0x165667B19E3779F9
+    sd = (seed * _GOLDEN) & ((1 << 64) - 1)
+    sd = sd - (1 << 64) if sd >= (1 << 63) else sd
+    ids = torch.arange(n, device=device, dtype=torch.int64)
+    order = torch.argsort(_sp_mix(ids * C3 ^ sd).to(torch.float64) + (_sp_mix(ids * C3 ^ sd) < 0) * 18446744073709551616.0, stable=True)
+    hashes = torch.empty((n, s), dtype=torch.int64, device=device)
+    k = torch.arange(s, device=device, dtype=torch.int64)[None, :]
+    for b0 in range(0, n, block):
+        b1 = min(n, b0 + block)
+        i = order[b0:b1][:, None]                                               # the leaves that land in these rows
+        origin = torch.zeros((b1 - b0, s), dtype=torch.int64, device=device)
+        for lev in range(1, L + 1):
+            a = i >> (L - lev)
+            lc = (lev * C2) & ((1 << 64) - 1)
+            lc = lc - (1 << 64) if lc >= (1 << 63) else lc                      # (wrapped to int64 like the tensors' products)
+            u = _sp_mix((k * C1) ^ lc ^ (a * C3) ^ sd)
+            thr = int((q_leaf if lev == L else q_inner) * 4294967296.0)
+            rep = _lsr(u, 32) < thr
+            origin = torch.where(rep, (lev << 40) | a, origin)
+        hashes[b0:b1] = (k << 44) + (_sp_mix((k * C2) ^ (origin * C1) ^ sd) & ((1 << 44) - 1))
+    return hashes, torch.full((n,), s, dtype=torch.int32, device=device), torch.full((n,), length, dtype=torch.int64, device=device)
+
+
 def synthetic_genomes(g_begin, g_end, length, device="cuda", block=256, stride=1):
     """ASCII bases uint8[(g_end-g_begin), length] of synthetic genomes g_begin..g_end-1
     (same definition as workloads.synth.synthetic_genome).
