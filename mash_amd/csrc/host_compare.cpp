@@ -850,15 +850,35 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
                 lead.cap_sub = lead_cap;
                 lead.nsub = lead_lists;
             }
+            // values, rows, groups, statistics, leaders: final behind the bucket sorts.  What the host wants of them is copied
+            // back and marked with an event; the images (K5) and the rows' visiting order are queued behind, and the host waits
+            // for the EVENT -- it lays out the dense groups while the images are still being written.
             if (e == hipSuccess)
                 e = mg::index_build(plan, H, sp->off, d_lb, d_cnt, d_start, d_pk, d_tc, sp->keys_sorted, sp->sorted_rows, sp->gend, gs_of, sp->code_img,
                                     sp->pos_img, d_slots, &d_stat.p->shared, &d_stat.p->max_group, &d_stat.p->groups, d_stat.p->ixf,
-                                    lead_ready ? &lead : nullptr, ctx->stream);
+                                    lead_ready ? &lead : nullptr, ctx->stream, 1);
             if (e == hipSuccess && lead_ready) {             // the leaders' lists made one; their count comes back with the statistics
                 e = mg::dense_join_leaders(d_key, d_val, lead_cap, d_keyj, d_valj, d_cnt_sub, d_off_sub, d_nlead, ctx->stream);
                 if (e == hipSuccess) e = hipMemcpyAsync(lead_tot, d_nlead, 8, hipMemcpyDeviceToHost, ctx->stream);
             }
-            finish_build();
+            hipEvent_t ev_stats = nullptr;
+            if (e == hipSuccess) e = hipMemcpyAsync(&h_stat, d_stat, sizeof(Stat), hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_stats, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventRecord(ev_stats, ctx->stream);
+            if (e == hipSuccess)
+                e = mg::index_build(plan, H, sp->off, d_lb, d_cnt, d_start, d_pk, d_tc, sp->keys_sorted, sp->sorted_rows, sp->gend, gs_of, sp->code_img,
+                                    sp->pos_img, d_slots, &d_stat.p->shared, &d_stat.p->max_group, &d_stat.p->groups, d_stat.p->ixf,
+                                    lead_ready ? &lead : nullptr, ctx->stream, 2);
+            if (e == hipSuccess && want_order)
+                e = mg::launch_sparse_row_order(sp->off, sp->code_img, sp->gend, sp->rep, (uint32_t)n, sp->rs, temp, temp_bytes, key64_a, key64_b,
+                                                sp->order, ctx->stream);
+            if (ev_stats) {
+                const hipError_t ew = e == hipSuccess ? hipEventSynchronize(ev_stats) : hipStreamSynchronize(ctx->stream);
+                if (e == hipSuccess) e = ew;
+                (void)hipEventDestroy(ev_stats);
+            } else {
+                (void)hipStreamSynchronize(ctx->stream);    // (host memory is the target of copies that may be queued)
+            }
             built = e == hipSuccess && !h_stat.ixf[mg::IXF_OVERSIZE] && !h_stat.ixf[mg::IXF_DEGENERATE];
             lead_done = built && lead_ready;
             if (ctx_opt(ctx, "MASHGPU_SPARSE_DBG"))
@@ -1072,7 +1092,9 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
             if (e2 == hipSuccess)
                 e2 = mg::launch_dense_encode(sp->off, sp->code_img, sp->pos_img, sp->rs, sp->grp_of, sp->dgroups, sp->ulist, sp->upos, sp->gdata, sp->xm,
                                              sp->ext, sp->dn_xs, (uint32_t)n, wmax, ctx->stream);
-            if (e2 == hipSuccess) e2 = hipStreamSynchronize(ctx->stream);   // (grp_of, the host vector, is read by the copy above)
+            // (no wait here: what the copies above read -- dgroups_host and the rows' group map -- lives in the index, what
+            //  comes next is queued on the same stream, and a fault shows at its wait)
+            sp->grp_of_host.swap(grp_of);
             if (e2 != hipSuccess) {
                 // the runs may be half clipped: this index is not to be used
                 drop();

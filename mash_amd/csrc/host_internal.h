@@ -113,6 +113,7 @@ struct mg_table {
         // the index's runs are clipped for their rows, so discovery only sees partners outside a row's group
         std::vector<mg::DenseGroup> dgroups_host;
         mg::DenseGroup *dgroups = nullptr;
+        std::vector<uint32_t> grp_of_host; // (the source of grp_of's upload: alive as long as the copy may be pending)
         uint32_t *grp_of = nullptr;        // [n] group of a row, 0xFFFFFFFF: none
         uint32_t *ulist = nullptr, *upos = nullptr;        // the groups' universes: values and the positions of their leaders
         unsigned long long *gdata = nullptr, *xm = nullptr; // mask blocks; per row and word three masks of the extras' offsets

@@ -992,7 +992,7 @@ IxPlan index_plan(uint32_t n, uint32_t E, uint32_t s, uint32_t rs, uint64_t stri
 hipError_t index_build(const IxPlan &plan, const uint64_t *hashes, const uint32_t *off, void *lb_v, void *cnt_v, void *start_v, void *pk_v, void *tc_v,
                        uint64_t *keys_sorted, uint32_t *sorted_rows, uint32_t *gend, uint32_t *gs_of, uint32_t *code_img, uint32_t *pos_img,
                        void *stat_scratch, unsigned long long *incidences, uint32_t *max_group, uint32_t *groups, uint32_t *flags,
-                       const IxLeaders *leaders, hipStream_t stream)
+                       const IxLeaders *leaders, hipStream_t stream, int stages)
 {
     if (!plan.ok) return hipErrorInvalidValue;
     const IxGeom g = plan.g;
@@ -1000,26 +1000,30 @@ hipError_t index_build(const IxPlan &plan, const uint64_t *hashes, const uint32_
     uint32_t *cnt = static_cast<uint32_t *>(cnt_v), *start = static_cast<uint32_t *>(start_v);
     uint64_t *pk = static_cast<uint64_t *>(pk_v);
     uint2 *tc = static_cast<uint2 *>(tc_v);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ix_tile_partition_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)IXL_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(ix_bucket_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)IX4_BYTES);
-    if (e != hipSuccess) return e;
-    const uint32_t tiles = 8u * ((g.nseq + 7u) / 8u);
-    hipLaunchKernelGGL(ix_window_offsets_kernel, dim3((g.n + 3u) / 4u), dim3(256), 0, stream, g, hashes, off, lb);
-    hipLaunchKernelGGL(ix_tile_count_kernel, dim3(tiles), dim3(IX_NT), 0, stream, g, hashes, (const uint16_t *)lb, cnt);
-    hipLaunchKernelGGL(ix_col_scan_kernel, dim3((g.Bp + 255u) / 256u), dim3(256), 0, stream, g, cnt, start);
-    hipLaunchKernelGGL(ix_bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, g, start, flags);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(ix_tile_partition_kernel, dim3(tiles), dim3(IX_NT), IXL_BYTES, stream, g, hashes, (const uint16_t *)lb, (const uint32_t *)cnt,
-                       (const uint32_t *)start, (const uint32_t *)flags, pk, pos_img);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(stat_scratch, 0, index_stat_scratch_bytes(), stream);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(ix_bucket_sort_kernel, dim3(g.Bp), dim3(IX_NT4), IX4_BYTES, stream, g, (const uint64_t *)pk, (const uint32_t *)start, keys_sorted,
-                       sorted_rows, gend, g.want_gs ? gs_of : (uint32_t *)nullptr, tc, static_cast<IxStatSlot *>(stat_scratch), flags,
-                       leaders ? *leaders : IxLeaders());
-    hipLaunchKernelGGL(ix_stat_reduce_kernel, dim3(1), dim3(256), 0, stream, static_cast<const IxStatSlot *>(stat_scratch), incidences, max_group, groups);
+    hipError_t e = hipSuccess;
+    if (stages & 1) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(ix_tile_partition_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)IXL_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(ix_bucket_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)IX4_BYTES);
+        if (e != hipSuccess) return e;
+        const uint32_t tiles = 8u * ((g.nseq + 7u) / 8u);
+        hipLaunchKernelGGL(ix_window_offsets_kernel, dim3((g.n + 3u) / 4u), dim3(256), 0, stream, g, hashes, off, lb);
+        hipLaunchKernelGGL(ix_tile_count_kernel, dim3(tiles), dim3(IX_NT), 0, stream, g, hashes, (const uint16_t *)lb, cnt);
+        hipLaunchKernelGGL(ix_col_scan_kernel, dim3((g.Bp + 255u) / 256u), dim3(256), 0, stream, g, cnt, start);
+        hipLaunchKernelGGL(ix_bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, g, start, flags);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(ix_tile_partition_kernel, dim3(tiles), dim3(IX_NT), IXL_BYTES, stream, g, hashes, (const uint16_t *)lb, (const uint32_t *)cnt,
+                           (const uint32_t *)start, (const uint32_t *)flags, pk, pos_img);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        e = hipMemsetAsync(stat_scratch, 0, index_stat_scratch_bytes(), stream);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(ix_bucket_sort_kernel, dim3(g.Bp), dim3(IX_NT4), IX4_BYTES, stream, g, (const uint64_t *)pk, (const uint32_t *)start, keys_sorted,
+                           sorted_rows, gend, g.want_gs ? gs_of : (uint32_t *)nullptr, tc, static_cast<IxStatSlot *>(stat_scratch), flags,
+                           leaders ? *leaders : IxLeaders());
+        hipLaunchKernelGGL(ix_stat_reduce_kernel, dim3(1), dim3(256), 0, stream, static_cast<const IxStatSlot *>(stat_scratch), incidences, max_group, groups);
+    }
+    if (!(stages & 2)) return hipGetLastError();
     {
         const uint32_t nchunk = (g.rs + IX5_CH - 1u) / IX5_CH;
         const uint32_t pieces = 8u * ((g.nblk * nchunk + 7u) / 8u);
