@@ -785,7 +785,21 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
         }
     }
     mg::IxPlan plan;
-    if (ix_tiles) plan = mg::index_plan((uint32_t)n, E, s, sp->rs, t->s, maxv, dens0, ix_verify);
+    // (a collection of large clades is not for the tiles: a value of a clade of m rows puts m entries into ONE bucket, and
+    //  with a handful of such values per bucket the fullest one holds m x (T/m + 4.5 sqrt(T/m)) entries -- beyond the LDS
+    //  sort's 6 144 from m of a few hundred on.  The clustered order tells: rows of one label stand next to each other.
+    //  Trying anyway costs the first three kernels and a wait before the sort takes over: 1 ms on the clade brackets.)
+    bool tiles_hopeless = false;
+    if (ix_tiles && !ix_verify && !lab_sorted.empty() && !ctx_opt(ctx, "MASHGPU_SPARSE_INDEX")) {
+        uint64_t run = 1, longest = 1;
+        for (uint64_t a = 1; a < n; a++) {
+            run = lab_sorted[a] == lab_sorted[a - 1] ? run + 1 : 1;
+            longest = std::max(longest, run);
+        }
+        tiles_hopeless = longest > 400;
+    }
+    if (ix_tiles && !tiles_hopeless) plan = mg::index_plan((uint32_t)n, E, s, sp->rs, t->s, maxv, dens0, ix_verify);
+    else if (tiles_hopeless) plan.why = "clades of hundreds of rows";
     const size_t temp_bytes = std::max(mg::sparse_order_temp_bytes((uint32_t)n), mg::sparse_order_slice_temp_bytes((uint32_t)n));
     DevBuf<unsigned char> temp(ctx);
     DevBuf<uint32_t> gs_of(ctx);
