@@ -215,10 +215,13 @@ struct ProbeHook {
     uint64_t bits_scale;
 };
 
-// the worker behind mg_sketch_dev / mg_sketch_host / the packed and screening paths (probe: nullable)
+// packed bases the sketch kernel reads itself (SketchArgs::packed): base skip + o / mask bit mskip + o = byte o of the batch
+struct PackedSrc { const uint32_t *packed, *mask; uint32_t skip, mskip; };
+// the worker behind mg_sketch_dev / mg_sketch_host / the packed and screening paths (probe, packed: nullable; with `packed`
+// bases_dev is unused -- plain sketches only: no multiplicities, no min_copies, sketch sizes of the LDS selector)
 int sketch_dev_impl(mg_ctx *ctx, const mg_params *p, const uint8_t *bases_dev, uint64_t nbases, const uint64_t *sketch_off,
                     uint64_t nsketch, uint64_t *hashes_out_dev, uint32_t *nhash_out_dev, uint32_t *counts_out_dev,
-                    const ProbeHook *probe);
+                    const ProbeHook *probe, const PackedSrc *packed = nullptr);
 
 // ---- host_compare.cpp
 int table_max(mg_ctx *ctx, const mg_table *t, uint64_t *out);          // largest hash of a table (device reduction, cached)

@@ -89,7 +89,7 @@ struct SketchRun {
     uint32_t cap = 0;
     uint64_t s = 0, nsketch = 0;
     SketchPlan plan;
-    mg::SketchArgs a;
+    mg::SketchArgs a{};
     DevBuf<mg::SketchWork> d_work;
     DevBuf<mg::MergeWork> d_merge;
     DevBuf<uint8_t> d_alpha;
@@ -396,12 +396,14 @@ static int sketch_min_copies(mg_ctx *ctx, const mg_params *p, int mode, const ui
 
 int sketch_dev_impl(mg_ctx *ctx, const mg_params *p, const uint8_t *bases_dev, uint64_t nbases,
                            const uint64_t *sketch_off, uint64_t nsketch, uint64_t *hashes_out_dev,
-                           uint32_t *nhash_out_dev, uint32_t *counts_out_dev, const ProbeHook *probe)
+                           uint32_t *nhash_out_dev, uint32_t *counts_out_dev, const ProbeHook *probe, const PackedSrc *pk)
 {
     if (!ctx) return MG_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
-    if (!p || !sketch_off || !hashes_out_dev || !nhash_out_dev || (!bases_dev && nbases))
+    if (!p || !sketch_off || !hashes_out_dev || !nhash_out_dev || (!bases_dev && nbases && !pk))
         return fail(ctx, MG_ERR_INVALID, "mg_sketch: NULL argument");
+    if (pk && (counts_out_dev || probe || p->min_copies > 1 || !alphabet_is_dna(p)))
+        return fail(ctx, MG_ERR_UNSUPPORTED, "mg_sketch: packed bases in the kernel serve plain nucleotide sketches only");
     if (p->kmer_size < 1 || p->kmer_size > 32) return fail(ctx, MG_ERR_INVALID, "mg_sketch: k must be 1..32");
     if (counts_out_dev && !mg::count_supported(p->sketch_size))
         return fail(ctx, MG_ERR_UNSUPPORTED, "mg_sketch: sketch size too large for the multiplicity pass");
@@ -482,6 +484,11 @@ int sketch_dev_impl(mg_ctx *ctx, const mg_params *p, const uint8_t *bases_dev, u
     a.probe_bits = probe ? probe->bits : nullptr;
     a.probe_bits_scale = probe ? probe->bits_scale : 0;
     a.seed_T = nullptr;
+    a.packed = pk ? pk->packed : nullptr;
+    a.pmask = pk ? pk->mask : nullptr;
+    a.pskip = pk ? pk->skip : 0;
+    a.pmskip = pk ? pk->mskip : 0;
+    if (pk && range_path) return fail(ctx, MG_ERR_UNSUPPORTED, "mg_sketch: packed bases in the kernel need the LDS selector's sketch sizes");
     if (range_path) {
         // -m / s beyond the LDS selector: bottom-s of the hashes seen at least m times, by exact range counting
         if (probe) return fail(ctx, MG_ERR_UNSUPPORTED, "mg_screen: min_copies does not apply");
@@ -559,8 +566,14 @@ static int sketch_packed_impl(mg_ctx *ctx, const mg_params *p, const uint8_t *pa
         longest = std::max(longest, sketch_off[i1] - sketch_off[i0]);
         i0 = i1;
     }
+    // plain sketches: the kernel reads the packed arrays itself; multiplicities, min_copies and sketch sizes beyond the LDS
+    // selector go through an ASCII copy (unpack_bases_kernel) and the ordinary path.  MASHGPU_PACKED_UNPACK=1: always the copy.
+    int nt_unused = 0;
+    uint32_t cap_unused = 0;
+    const bool direct = !d_counts && p->min_copies <= 1 && alphabet_is_dna(p) && mg::sketch_geometry(p->sketch_size, &nt_unused, &cap_unused) &&
+                        !ctx_opt(ctx, "MASHGPU_PACKED_UNPACK");
     DevBuf<uint8_t> d_ascii(ctx), d_pk[2] = {DevBuf<uint8_t>(ctx), DevBuf<uint8_t>(ctx)}, d_mk[2] = {DevBuf<uint8_t>(ctx), DevBuf<uint8_t>(ctx)};
-    if (d_ascii.alloc(((longest + 15u) & ~15ull) + 64u) != hipSuccess) return fail(ctx, MG_ERR_NOMEM, "mg_sketch_packed: device allocation failed");
+    if (!direct && d_ascii.alloc(((longest + 15u) & ~15ull) + 64u) != hipSuccess) return fail(ctx, MG_ERR_NOMEM, "mg_sketch_packed: device allocation failed");
     hipStream_t copy_stream = nullptr;
     struct StreamGuard { hipStream_t *s; ~StreamGuard() { if (*s) hipStreamDestroy(*s); } } stream_guard{&copy_stream};
     if (host_input) {
@@ -621,11 +634,18 @@ static int sketch_packed_impl(mg_ctx *ctx, const mg_params *p, const uint8_t *pa
             skip = (uint32_t)(q.b0 - pk_byte0(q) * 4u);
             mskip = (uint32_t)(q.b0 - mk_byte0(q) * 8u);
         }
-        HIP_TRY(ctx, mg::launch_unpack_bases(src_pk, src_mk, skip, mskip, len, d_ascii, ctx->stream));
         off.resize(q.i1 - q.i0 + 1);
         for (uint64_t i = q.i0; i <= q.i1; i++) off[i - q.i0] = sketch_off[i] - q.b0;
-        const int rc = sketch_dev_impl(ctx, p, d_ascii, len, off.data(), q.i1 - q.i0, d_hashes + q.i0 * s, d_nhash + q.i0,
-                                       d_counts ? d_counts + q.i0 * s : nullptr, nullptr);
+        int rc;
+        if (direct) {
+            // the sketch kernel expands the codes itself while it stages its tiles (round 5): no ASCII copy in HBM
+            const PackedSrc pks{reinterpret_cast<const uint32_t *>(src_pk), reinterpret_cast<const uint32_t *>(src_mk), skip, mskip};
+            rc = sketch_dev_impl(ctx, p, nullptr, len, off.data(), q.i1 - q.i0, d_hashes + q.i0 * s, d_nhash + q.i0, nullptr, nullptr, &pks);
+        } else {
+            HIP_TRY(ctx, mg::launch_unpack_bases(src_pk, src_mk, skip, mskip, len, d_ascii, ctx->stream));
+            rc = sketch_dev_impl(ctx, p, d_ascii, len, off.data(), q.i1 - q.i0, d_hashes + q.i0 * s, d_nhash + q.i0,
+                                 d_counts ? d_counts + q.i0 * s : nullptr, nullptr);
+        }
         if (rc != MG_OK) return rc;
         if (next.joinable()) next.join();
         if (next_copied_here) copy_piece(pieces[c + 1], (int)((c + 1) & 1), &next_err);

@@ -213,6 +213,45 @@ __global__ __launch_bounds__(NT) void sketch_chunks_kernel(SketchArgs a)
         // ---- stage the tile: bytes [a0, a0 + TILE_DW*4), a0 = t0 rounded down to 16 ----
         const uint64_t a0 = t0 & ~15ULL;
         const uint32_t shift = (uint32_t)(t0 - a0);
+        if (a.packed) {
+            // packed input: 16 bases per lane = one dword of codes (two when the batch does not start at a dword), their
+            // bits of the mask; written into the tile as the characters the ASCII path would have found there
+            for (int q = tid; q < TILE_DW / 4; q += NT) {
+                const uint64_t o = a0 + (uint64_t)q * 16;
+                uint4 x = make_uint4(0, 0, 0, 0);
+                if (o < w.limit) {
+                    const uint64_t t = o >> 4;
+                    uint64_t cw = a.packed[t];
+                    if (a.pskip) cw |= (uint64_t)a.packed[t + 1] << 32;
+                    const uint32_t bits = (uint32_t)(cw >> (2u * a.pskip));
+                    uint32_t inv = 0;
+                    if (a.pmask) {
+                        const uint64_t gm = a.pmskip + o;
+                        const uint32_t sh = (uint32_t)(gm & 31u);
+                        uint64_t m = a.pmask[gm >> 5];
+                        if (sh > 16u) m |= (uint64_t)a.pmask[(gm >> 5) + 1u] << 32;
+                        inv = (uint32_t)(m >> sh) & 0xFFFFu;
+                    }
+                    const uint64_t left = w.limit - o;
+                    uint32_t d[4];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        uint32_t word = 0;
+#pragma unroll
+                        for (int b = 0; b < 4; b++) {
+                            const int i = c * 4 + b;
+                            uint32_t ch = (0x47544341u >> (8u * ((bits >> (2 * i)) & 3u))) & 0xFFu;      // "ACTG"[code]
+                            if ((inv >> i) & 1u) ch = 'N';
+                            if ((uint64_t)i >= left) ch = 0;                                              // (behind the sketch's bytes: as the ASCII path)
+                            word |= ch << (8 * b);
+                        }
+                        d[c] = word;
+                    }
+                    x = make_uint4(d[0], d[1], d[2], d[3]);
+                }
+                reinterpret_cast<uint4 *>(tile)[q] = x;
+            }
+        } else {
         for (int q = tid; q < TILE_DW / 4; q += NT) {
             const uint64_t o = a0 + (uint64_t)q * 16;
             uint4 x = make_uint4(0, 0, 0, 0);
@@ -225,6 +264,7 @@ __global__ __launch_bounds__(NT) void sketch_chunks_kernel(SketchArgs a)
                 x = make_uint4(d[0], d[1], d[2], d[3]);
             }
             reinterpret_cast<uint4 *>(tile)[q] = x;
+        }
         }
         __syncthreads();
 

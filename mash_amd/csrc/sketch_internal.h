@@ -48,6 +48,12 @@ struct SketchArgs {
     const uint32_t *probe_bits;
     uint64_t probe_bits_scale;
     const uint64_t *seed_T;       // [nsketch] seeded thresholds (HPAD = none), or nullptr
+    // packed input read by the kernel itself (round 5; include/mashgpu.h: two bits per base + one invalid bit): base number
+    // pskip + o of `packed` / bit pmskip + o of `pmask` stand for the byte at offset o of the batch; `bases` is unused then.
+    // The tile in LDS is ASCII either way: the hash runs over the k-mer's characters (ingest.hip says why).
+    const uint32_t *packed;       // nullptr: ASCII in `bases`
+    const uint32_t *pmask;        // nullptr: every base valid
+    uint32_t pskip, pmskip;       // < 16, < 32
 };
 
 // Merge of pool slots first_slot, first_slot+stride, ... (nchunks of them).

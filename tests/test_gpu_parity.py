@@ -311,10 +311,15 @@ def test_sketch_batch_of_nothing_but_empty_sketches(eng):
     assert not n.any() and not c.any() and np.all(h == np.uint64(abi.HASH_PAD))
 
 
-def test_sketch_packed_input_without_a_mask_and_from_device_memory(eng):
+@pytest.mark.parametrize("unpack", [False, True])
+def test_sketch_packed_input_without_a_mask_and_from_device_memory(eng, unpack, monkeypatch):
     """A clean input (nothing but ACGT, one record per sketch) needs no mask: NULL.  mg_sketch_dev_packed takes the packed
-    arrays from device memory (whole batch, offsets anywhere) and leaves the sketches there."""
+    arrays from device memory (whole batch, offsets anywhere) and leaves the sketches there.  Both forms of the packed path:
+    the sketch kernel expanding the codes itself while it stages its tiles (round 5, the default for plain sketches) and
+    round 4's unpack_bases_kernel in front of the ASCII kernel (MASHGPU_PACKED_UNPACK=1; what multiplicities still take)."""
     import torch
+    if unpack:
+        monkeypatch.setenv("MASHGPU_PACKED_UNPACK", "1")
     rng = np.random.default_rng(3)
     lens = [int(x) for x in rng.integers(2000, 30000, size=9)]
     bases = rng.choice(np.frombuffer(b"ACGTacgt", dtype=np.uint8), size=sum(lens)).astype(np.uint8)
