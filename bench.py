@@ -272,6 +272,9 @@ def headline_of(result):
         h["sketch_roofline_frac"] = (sk.get("roofline") or {}).get("frac")
     if "value" in c5:
         h["c5_pairs_s"], h["c5_warm_pairs_s"] = _num(c5["value"]), _num(c5.get("warm_value"))
+        r5 = c5.get("roofline") or {}
+        h["c5_roofline"] = {"step_frac": r5.get("step_frac"), "index_ms": _num(r5.get("index_ms")),
+                            "traffic_over_compulsory": (r5.get("pass") or {}).get("traffic_over_compulsory")}
     if "value" in scr:
         h["screen_reads_s"] = _num(scr["value"])
     if cli:
@@ -613,8 +616,7 @@ def main():
                     eng.compare_tri_dev(bt, 0, bn_rows, out.data_ptr())
                 torch.cuda.synchronize()
                 bw = time.perf_counter() - t0
-                bpmc = load_pmc(f"compare_{leg}_pmc.json", "mash_amd/csrc/compare_sparse.hip", "mash_amd/csrc/compare_dense.hip", "mash_amd/csrc/compare_merged.hip",
-                                "mash_amd/csrc/compare_internal.h") if n == 100_000 else None
+                bpmc = load_pmc(f"compare_{leg}_pmc.json", *srcs) if n == 100_000 else None
                 rf = compare_roofline(eng, bpairs, bn_rows, S, bsteps, bpmc)
                 eng.prof_enable(False)
                 o = out[:bpairs]
@@ -1023,7 +1025,12 @@ def main():
                 eng.compare_tri_dev(t5, 0, n5, out5.data_ptr())
             torch.cuda.synchronize()
             d5 = time.perf_counter() - t0
-            rf5_cold = compare_roofline(eng, pairs5, n5, S5, steps5, None)
+            srcs5 = ("mash_amd/csrc/compare_sparse.hip", "mash_amd/csrc/compare_dense.hip", "mash_amd/csrc/compare_merged.hip", "mash_amd/csrc/compare_internal.h",
+                     "mash_amd/csrc/index_build.hip")
+            rf5_cold = compare_roofline(eng, pairs5, n5, S5, steps5, load_pmc("compare_c5_cold_pmc.json", *srcs5) if n5 == 100_000 else None)
+            if "pass" in rf5_cold:
+                rf5_cold["step_frac"] = round(rf5_cold["pass"]["compulsory_bytes"] / (d5 / steps5) / 1e9 / HBM_PEAK_GBS, 4)
+                rf5_cold["index_ms"] = rf5_cold["phases"].get("index", {}).get("ms_per_pass")
             eng.prof_reset()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -1031,8 +1038,7 @@ def main():
                 eng.compare_tri_dev(t5, 0, n5, out5.data_ptr())
             torch.cuda.synchronize()
             w5 = time.perf_counter() - t0
-            pmc5 = load_pmc("compare_c5_pmc.json", "mash_amd/csrc/compare_sparse.hip", "mash_amd/csrc/compare_dense.hip", "mash_amd/csrc/compare_merged.hip",
-                            "mash_amd/csrc/compare_internal.h") if n5 == 100_000 else None
+            pmc5 = load_pmc("compare_c5_pmc.json", *srcs5) if n5 == 100_000 else None
             rf5 = compare_roofline(eng, pairs5, n5, S5, steps5, pmc5)
             eng.prof_enable(False)
             sums5 = [int(out5[:, 0].sum(dtype=torch.int64).item()), int(out5[:, 1].sum(dtype=torch.int64).item())]

@@ -15,6 +15,7 @@ def _fat_result():
     rf = {"bound": "hbm", "achieved": 5952.1, "peak": 8000.0, "unit": "GB/s", "frac": 0.744, "traffic": 40040000000, "engine": "inverted index",
           "kernel": "mg::sp_fill_value_kernel", "kernel_ms": 6.72, "algorithmic_bytes_per_launch": 39999600000, "phases": phases,
           "pass": {"ms": 25.1, "traffic": 9.9e10, "compulsory_bytes": 4.08e10, "traffic_over_compulsory": 2.4, "output_write_bound_frac": 0.2},
+          "step_frac": 0.2031, "index_ms": 7.9,
           "ports": {f"kernel{i}": {"valu": 0.6, "note": note} for i in range(12)}, "note": note}
     leg = {"value": 1.2345678e11, "unit": "pairs/s", "ms_per_step": 12.3, "warm_value": 2.2e11, "warm_ms_per_step": 5.0, "roofline": rf,
            "roofline_warm": rf, "cpu_baseline": {"value": 1.9e6, "unit": "pairs/s", "cores": 16, "kind": "reference", "sample": note},
@@ -26,9 +27,10 @@ def _fat_result():
                        "parallelism": "rowblock1", "rank_row_blocks": list(range(9)), "output_checksum": [2122078313, 4999950000000],
                        "first_call_ms": 63.6, "rccl_ranks": 0, "table_broadcast_ms": 0.0, "note": note},
             "warm_value": 3.4e11, "warm_ms_per_step": 14.7, "roofline": rf, "roofline_warm": rf,
-            "cpu_baseline": {"value": 1.86e6, "unit": "pairs/s", "cores": 16, "kind": "reference", "sample": note},
-            "brackets": {k: dict(leg) for k in ("all_random", "all_identical", "clades_of_1000", "one_clade")} | {"workload": note},
-            "host_to_host": {"counts": leg, "pairs": leg, "full_c3_thresholded": leg, "sample": note},
+            "cpu_baseline": {"value": 1.86e6, "unit": "pairs/s", "cores": 256, "kind": "reference", "sample": note},
+            "cpu_baseline_by_cores": {c: {"value": 1.0e5 * int(c), "unit": "pairs/s", "cores": int(c), "kind": "reference", "sample": note} for c in ("1", "16", "256")},
+            "brackets": {k: dict(leg) for k in ("all_random", "all_identical", "clades_of_1000", "one_clade", "one_species")} | {"workload": note},
+            "host_to_host": {"counts": leg, "pairs": leg, "full_c3_thresholded": leg, "full_c3_sparse": leg, "sample": note},
             "sketch": dict(leg, host_to_host=leg), "screen": dict(leg, mixed_database={"note": note}), "c5": leg,
             "cli_e2e": {"sketch": {"speedup_vs_reference": 3.2, "stages": {str(i): note for i in range(5)}},
                         "triangle": {"speedup_vs_reference": 12.0}, "host_cores": 16}}
@@ -52,8 +54,12 @@ def test_headline_line_is_small_and_complete(capsys, tmp_path):
     for k in ("bound", "kernel", "kernel_ms", "achieved", "peak", "unit", "frac", "traffic", "pass"):
         assert k in rf, k
     assert 0 < rf["frac"] <= 1 and rf["pass"]["phases_ms"]["index"] > 0
+    # the WHOLE step against the same roof and what the per-table index costs of it: where the driver keeps them
+    assert 0 < rf["step_frac"] < rf["frac"] and rf["index_ms"] > 0
+    assert set(h["cpu_baseline"]["by_cores"]) == {"1", "16", "256"}                              # P = 1, 16, nproc
+    assert h["h2h_full_pairs_s"] and h["h2h_thresholded_pairs_s"] and "step_frac" in h["c5_roofline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in h["cpu_baseline"], k
     assert h["sketch_bp_s"] and h["c5_pairs_s"] and h["screen_reads_s"] and h["cli_e2e_speedup"]["sketch"] == 3.2
-    assert set(h["brackets_pairs_s"]) == {"all_random", "all_identical", "clades_of_1000", "one_clade"}
+    assert set(h["brackets_pairs_s"]) == {"all_random", "all_identical", "clades_of_1000", "one_clade", "one_species"}
     assert json.loads(open(tmp_path / "detail.json").read())["brackets"]["one_clade"]["note"]     # the detail kept everything
