@@ -51,7 +51,7 @@ def test_inverted_index_engine_cold_pass_with_pmc():
     for k, v in r["ports"].items():               # each port on its own, none above 1
         assert all(0 <= v[p] <= 1.0 for p in ("valu", "salu", "vmem", "lds_inst", "lds_active")), (k, v)
     c = bench.compact_roofline(r)
-    assert set(c) == {"bound", "kernel", "kernel_ms", "achieved", "peak", "unit", "frac", "traffic", "pass"}
+    assert set(c) == {"bound", "kernel", "kernel_ms", "achieved", "peak", "unit", "frac", "traffic", "pass", "step_frac", "index_ms"}
     assert c["pass"]["phases_ms"] == {"index": 9.5, "discover": 3.56, "fill": 6.72, "merge": 3.93} and c["frac"] <= 1
     assert len(json.dumps(c)) < 600
 
