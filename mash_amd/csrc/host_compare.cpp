@@ -785,10 +785,10 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
         }
     }
     mg::IxPlan plan;
-    // (a collection of large clades is not for the tiles: a value of a clade of m rows puts m entries into ONE bucket, and
-    //  with a handful of such values per bucket the fullest one holds m x (T/m + 4.5 sqrt(T/m)) entries -- beyond the LDS
-    //  sort's 6 144 from m of a few hundred on.  The clustered order tells: rows of one label stand next to each other.
-    //  Trying anyway costs the first three kernels and a wait before the sort takes over: 1 ms on the clade brackets.)
+    // (One clade of many thousands of rows: every value of its pool has more holders than a bucket's LDS sort takes, so the
+    //  whole index goes through the two-level sort of the big buckets -- correct, but measured 0.5 ms behind the general
+    //  sort on the one-clade bracket (32 768 rows: 15.2 vs 14.7 ms per table).  Clades of a thousand rows are the tiles'
+    //  (16.9 vs 19.1 ms on the 100 x 1 000 bracket).  The clustered order tells: rows of one label stand next to each other.)
     bool tiles_hopeless = false;
     if (ix_tiles && !ix_verify && !lab_sorted.empty() && !ctx_opt(ctx, "MASHGPU_SPARSE_INDEX")) {
         uint64_t run = 1, longest = 1;
@@ -796,10 +796,10 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
             run = lab_sorted[a] == lab_sorted[a - 1] ? run + 1 : 1;
             longest = std::max(longest, run);
         }
-        tiles_hopeless = longest > 400;
+        tiles_hopeless = longest > 6144;
     }
     if (ix_tiles && !tiles_hopeless) plan = mg::index_plan((uint32_t)n, E, s, sp->rs, t->s, maxv, dens0, ix_verify);
-    else if (tiles_hopeless) plan.why = "clades of hundreds of rows";
+    else if (tiles_hopeless) plan.why = "a clade of more rows than a bucket's sort takes";
     const size_t temp_bytes = std::max(mg::sparse_order_temp_bytes((uint32_t)n), mg::sparse_order_slice_temp_bytes((uint32_t)n));
     DevBuf<unsigned char> temp(ctx);
     DevBuf<uint32_t> gs_of(ctx);
@@ -851,9 +851,9 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
     };
     bool built = false;
     if (ok && e == hipSuccess && plan.ok) {
-        DevBuf<unsigned char> d_lb(ctx), d_cnt(ctx), d_start(ctx), d_pk(ctx), d_tc(ctx);
+        DevBuf<unsigned char> d_lb(ctx), d_cnt(ctx), d_start(ctx), d_big(ctx), d_pk(ctx), d_tc(ctx);
         if (d_lb.alloc(plan.lb_bytes) == hipSuccess && d_cnt.alloc(plan.cnt_bytes) == hipSuccess && d_start.alloc(plan.start_bytes) == hipSuccess &&
-            d_pk.alloc(plan.pk_bytes) == hipSuccess && d_tc.alloc(plan.tc_bytes) == hipSuccess) {
+            d_big.alloc(plan.big_bytes) == hipSuccess && d_pk.alloc(plan.pk_bytes) == hipSuccess && d_tc.alloc(plan.tc_bytes) == hipSuccess) {
             e = hipMemsetAsync(d_stat, 0, sizeof(Stat), ctx->stream);
             mg::IxLeaders lead;
             if (lead_ready) {
@@ -868,7 +868,7 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
             // back and marked with an event; the images (K5) and the rows' visiting order are queued behind, and the host waits
             // for the EVENT -- it lays out the dense groups while the images are still being written.
             if (e == hipSuccess)
-                e = mg::index_build(plan, H, sp->off, d_lb, d_cnt, d_start, d_pk, d_tc, sp->keys_sorted, sp->sorted_rows, sp->gend, gs_of, sp->code_img,
+                e = mg::index_build(plan, H, sp->off, d_lb, d_cnt, d_start, d_big, d_pk, d_tc, sp->keys_sorted, sp->sorted_rows, sp->gend, gs_of, sp->code_img,
                                     sp->pos_img, d_slots, &d_stat.p->shared, &d_stat.p->max_group, &d_stat.p->groups, d_stat.p->ixf,
                                     lead_ready ? &lead : nullptr, ctx->stream, 1);
             if (e == hipSuccess && lead_ready) {             // the leaders' lists made one; their count comes back with the statistics
@@ -880,7 +880,7 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
             if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_stats, hipEventDisableTiming);
             if (e == hipSuccess) e = hipEventRecord(ev_stats, ctx->stream);
             if (e == hipSuccess)
-                e = mg::index_build(plan, H, sp->off, d_lb, d_cnt, d_start, d_pk, d_tc, sp->keys_sorted, sp->sorted_rows, sp->gend, gs_of, sp->code_img,
+                e = mg::index_build(plan, H, sp->off, d_lb, d_cnt, d_start, d_big, d_pk, d_tc, sp->keys_sorted, sp->sorted_rows, sp->gend, gs_of, sp->code_img,
                                     sp->pos_img, d_slots, &d_stat.p->shared, &d_stat.p->max_group, &d_stat.p->groups, d_stat.p->ixf,
                                     lead_ready ? &lead : nullptr, ctx->stream, 2);
             if (e == hipSuccess && want_order)
@@ -893,12 +893,12 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
             } else {
                 (void)hipStreamSynchronize(ctx->stream);    // (host memory is the target of copies that may be queued)
             }
-            built = e == hipSuccess && !h_stat.ixf[mg::IXF_OVERSIZE] && !h_stat.ixf[mg::IXF_DEGENERATE];
+            built = e == hipSuccess && !h_stat.ixf[mg::IXF_DEGENERATE];
             lead_done = built && lead_ready;
             if (ctx_opt(ctx, "MASHGPU_SPARSE_DBG"))
-                fprintf(stderr, "compare sparse: index by tiles: shift %u, %u buckets (%u per window, %u windows), fullest %u%s%s\n", plan.g.shift, plan.g.Bp,
-                        plan.g.BW, plan.g.NW, h_stat.ixf[mg::IXF_MAXBUCKET], h_stat.ixf[mg::IXF_OVERSIZE] ? " -- a bucket beyond the LDS: sorted instead" : "",
-                        h_stat.ixf[mg::IXF_DEGENERATE] ? " -- a bucket of clumped values: sorted instead" : "");
+                fprintf(stderr, "compare sparse: index by tiles: shift %u, %u buckets (%u per window, %u windows), fullest %u, %u beyond the LDS (%u values streamed)%s\n",
+                        plan.g.shift, plan.g.Bp, plan.g.BW, plan.g.NW, h_stat.ixf[mg::IXF_MAXBUCKET], h_stat.ixf[mg::IXF_NBIG], h_stat.ixf[mg::IXF_NSTREAMED],
+                        h_stat.ixf[mg::IXF_DEGENERATE] ? " -- clumped values: sorted instead" : "");
         } else {
             (void)hipGetLastError();
         }

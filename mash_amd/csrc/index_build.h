@@ -21,8 +21,11 @@
 //             K3 also leaves, in the position image, WHERE it put every entry;
 //   K5        the tiles again (their order keeps the gathered lines in the L2): {code, position} are read back from there
 //             and written into the images row segment by row segment (no 4-byte scattered stores).
-// A table that does not fit the assumptions (a bucket beyond the LDS capacity: a value held by thousands of rows, values
-// clumped far from uniform; too many buckets) raises a flag and the caller builds the index the old way.
+//   K4b       a bucket beyond the LDS capacity (a value held by thousands of rows -- sketches of one species) is sorted in two
+//             levels, the first through global memory; a value with more holders than the LDS takes is already in row order
+//             and streamed out;
+// A table that does not fit the assumptions (values clumped far from uniform: thousands of entries that agree in the 13
+// bits below their bucket without being equal; too many buckets) raises a flag and the caller builds the index the old way.
 #pragma once
 #include <stdint.h>
 
@@ -58,19 +61,21 @@ struct IxPlan {
     IxGeom g;
     bool ok = false;
     const char *why = "";
-    size_t lb_bytes = 0, cnt_bytes = 0, start_bytes = 0, pk_bytes = 0, tc_bytes = 0;     // scratch
+    size_t lb_bytes = 0, cnt_bytes = 0, start_bytes = 0, big_bytes = 0, pk_bytes = 0, tc_bytes = 0;     // scratch
 };
 
-// flags[] (device, 4 u32, zeroed by the caller): what stopped the build
-enum { IXF_OVERSIZE = 0, IXF_DEGENERATE = 1, IXF_MAXBUCKET = 2, IXF_RESERVED = 3 };
+// flags[] (device, 4 u32, zeroed by the caller): IXF_DEGENERATE != 0: the build stopped, the arrays are not an index;
+// the fullest bucket; the buckets that went through the two-level sort (ix_big_bucket_kernel) and the values with more
+// holders than the LDS takes that were streamed out there
+enum { IXF_NSTREAMED = 0, IXF_DEGENERATE = 1, IXF_MAXBUCKET = 2, IXF_NBIG = 3 };
 
 // dens0: entries per unit of the hash range where the table is densest (sum over rows of count / (largest hash + 1))
 IxPlan index_plan(uint32_t n, uint32_t E, uint32_t s, uint32_t rs, uint64_t stride, uint64_t maxv, double dens0, bool want_gs);
 size_t index_stat_scratch_bytes();
-// All buffers are the caller's.  lb / cnt / start / pk / tc: scratch of the plan's sizes; the rest as sparse_build_index
+// All buffers are the caller's.  lb / cnt / start / big / pk / tc: scratch of the plan's sizes; the rest as sparse_build_index
 // (compare_internal.h) -- on return (stream order) the index arrays are complete unless flags say otherwise.
 // *incidences, *max_group, *groups, flags[4]: zeroed by the caller.
-hipError_t index_build(const IxPlan &plan, const uint64_t *hashes, const uint32_t *off, void *lb, void *cnt, void *start, void *pk, void *tc,
+hipError_t index_build(const IxPlan &plan, const uint64_t *hashes, const uint32_t *off, void *lb, void *cnt, void *start, void *big, void *pk, void *tc,
                        uint64_t *keys_sorted, uint32_t *sorted_rows, uint32_t *gend, uint32_t *gs_of, uint32_t *code_img, uint32_t *pos_img,
                        void *stat_scratch, unsigned long long *incidences, uint32_t *max_group, uint32_t *groups, uint32_t *flags,
                        const IxLeaders *leaders, hipStream_t stream, int stages = 3);

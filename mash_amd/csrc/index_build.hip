@@ -64,7 +64,6 @@ constexpr uint32_t IX_SUBBITS = 13;             // the counting sort's key: the 
 constexpr uint32_t IX_NSUB = 1u << IX_SUBBITS;
 constexpr uint32_t IX_SUBLOW = IX_SUBBITS - 3u;      // a sub-bucket's bits below the three that name the wave owning it (IX_NT4 / 64 = 8 waves)
 static_assert(IX_SUBBITS == 13 && IX_NT4 == 512, "the ticket slots hold 3 + 13 bits");
-constexpr uint32_t IX_MAXM = 1024;              // entries of a sub-bucket that holds two different values before the bucket counts as degenerate
 // expected entries of the fullest bucket IF values were held by one row each.  Collections are not like that: a value
 // of a cluster is held by ~80 rows at once, so a bucket's fill varies like sqrt(values) x 80, not sqrt(entries) -- C3 at an
 // expected 4 464 had a bucket of 7 046.  Half the capacity is headroom.
@@ -218,8 +217,9 @@ __global__ __launch_bounds__(256) void ix_col_scan_kernel(IxGeom g, uint32_t *cn
     }
 }
 
-// K2b (one workgroup): start[b] = exclusive prefix of the buckets' entries (in place), start[Bp] = E; the fullest bucket
-__global__ __launch_bounds__(1024) void ix_bucket_scan_kernel(IxGeom g, uint32_t *start, uint32_t *flags)
+// K2b (one workgroup): start[b] = exclusive prefix of the buckets' entries (in place), start[Bp] = E; the fullest bucket;
+// the buckets that the LDS sort does not take (flags[IXF_NBIG] of them, in no particular order)
+__global__ __launch_bounds__(1024) void ix_bucket_scan_kernel(IxGeom g, uint32_t *start, uint32_t *flags, uint32_t *biglist)
 {
     __shared__ uint32_t s_part[16], s_max[16];
     const uint32_t tid = threadIdx.x;
@@ -230,6 +230,9 @@ __global__ __launch_bounds__(1024) void ix_bucket_scan_kernel(IxGeom g, uint32_t
         const uint32_t c = start[b];
         sum += c;
         mx = c > mx ? c : mx;
+        // (a bucket beyond the LDS sort's capacity -- a value held by thousands of rows stands in it: ix_big_bucket_kernel's;
+        //  the list has room for E / IX_CAP + 1 of them, more cannot exist)
+        if (c > IX_CAP) biglist[atomicAdd(&flags[IXF_NBIG], 1u)] = b;
     }
     uint32_t total = 0;
     uint32_t run = ix_block_scan_sum(sum, s_part, total);
@@ -250,7 +253,6 @@ __global__ __launch_bounds__(1024) void ix_bucket_scan_kernel(IxGeom g, uint32_t
         uint32_t m = 0;
         for (uint32_t k = 0; k < 16u; k++) m = s_max[k] > m ? s_max[k] : m;
         flags[IXF_MAXBUCKET] = m;
-        if (m > IX_CAP) flags[IXF_OVERSIZE] = 1u;
     }
 }
 
@@ -327,7 +329,6 @@ __global__ __launch_bounds__(IX_NT, 4) void ix_tile_partition_kernel(IxGeom g, c
     uint32_t *s_part = reinterpret_cast<uint32_t *>(lds + IXL_PART);
     uint32_t blk = 0, w = 0;
     if (!ix_tile_id(g, blk, w)) return;                  // uniform
-    if (flags[IXF_OVERSIZE]) return;                     // uniform (raised by the scan kernel: the caller builds the index another way)
     const uint32_t tid = threadIdx.x, sub = tid % IX_LPR;
     IX_CLK_BEGIN();
     const uint32_t row0 = blk * IX_RB, nrows = g.n - row0 < IX_RB ? g.n - row0 : IX_RB;
@@ -468,7 +469,6 @@ constexpr uint32_t IX5_UNR = 4;                           // rows a work-item ha
 __global__ __launch_bounds__(256) void ix_images_kernel(IxGeom g, const uint32_t *__restrict__ off, const uint32_t *__restrict__ flags,
                                                         const uint2 *__restrict__ tc, uint32_t *__restrict__ code_img, uint32_t *pos_img, uint32_t nchunk)
 {
-    if (flags[IXF_OVERSIZE]) return;                     // uniform
     const uint32_t per = gridDim.x >> 3;
     const uint32_t q = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
     if (q >= g.nblk * nchunk) return;                    // uniform
@@ -519,6 +519,9 @@ __global__ __launch_bounds__(256) void ix_images_kernel(IxGeom g, const uint32_t
 // that hold two different values are put in order by comparison.  The groups of equal values are found in LDS; out go the
 // values, the rows, the groups' ends, optionally every position's group start, and tc[start + j] = {code, position} of
 // the entry that ARRIVED as the bucket's j-th (K5 reads them from there).
+// the counting sort's key: the IX_SUBBITS bits of a packed word right below the bucket (all there are if the bucket is narrower)
+__device__ __forceinline__ uint32_t ix_subshift(const IxGeom &g) { return g.shift >= IX_SUBBITS ? g.shift + g.rb - IX_SUBBITS : g.rb; }
+
 constexpr uint32_t IX4_PK = 0, IX4_JX = IX4_PK + IX_CAP * 8u, IX4_H = IX4_JX + IX_CAP * 2u, IX4_MIX = IX4_H + IX_NSUB * 2u,
                    IX4_PART = IX4_MIX + IX_NSUB / 8u, IX4_BYTES = IX4_PART + 64u;
 
@@ -533,15 +536,19 @@ constexpr uint32_t IX4_PK = 0, IX4_JX = IX4_PK + IX_CAP * 8u, IX4_H = IX4_JX + I
 // the LDS behaves, not what the ISA promises: the finished order is therefore CHECKED (strictly ascending words) and a
 // bucket that fails it flags the table for the general sort.  What is left to rank by comparison are the sub-buckets that
 // hold two different values.
-template <uint32_t PER>
-__device__ __forceinline__ void ix_bucket_sort_body(const IxGeom &g, const uint64_t *__restrict__ pk, uint64_t *__restrict__ keys_sorted,
-                                                    uint32_t *__restrict__ sorted_rows, uint32_t *__restrict__ gend, uint32_t *__restrict__ gs_of,
-                                                    uint2 *__restrict__ tc, IxStatSlot *stat, uint32_t *flags, const IxLeaders &lead, uint64_t *s_pk,
-                                                    uint16_t *s_jx, uint32_t *s_h, uint32_t *s_mixed, uint32_t *s_part, uint32_t b, uint32_t G0, uint32_t N)
+//
+// PART: the entries are a PART of a big bucket (ix_big_bucket_kernel): src[j] is the part's j-th word, arr[j] its place in
+// the order the BUCKET's entries arrived in (tc is indexed by that, from tcbase), and src / arr are the output arrays'
+// own memory (read completely before anything is written).  false: the table was flagged, leave.
+template <uint32_t PER, bool PART>
+__device__ __forceinline__ bool ix_bucket_sort_body(const IxGeom &g, const uint64_t *src, const uint32_t *arr, uint32_t tcbase, uint32_t subshift,
+                                                    uint64_t *keys_sorted, uint32_t *sorted_rows, uint32_t *__restrict__ gend,
+                                                    uint32_t *__restrict__ gs_of, uint2 *__restrict__ tc, IxStatSlot *stat, uint32_t *flags,
+                                                    const IxLeaders &lead, uint64_t *s_pk, uint16_t *s_jx, uint32_t *s_h, uint32_t *s_mixed,
+                                                    uint32_t *s_part, uint32_t b, uint32_t G0, uint32_t N)
 {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     IX_CLK_BEGIN();
-    const uint32_t subshift = g.shift >= IX_SUBBITS ? g.shift + g.rb - IX_SUBBITS : g.rb;
     for (uint32_t x = tid; x < IX_NSUB / 2u; x += IX_NT4) s_h[x] = 0;
     if (tid < IX_NSUB / 32u) s_mixed[tid] = 0;
     // ---- the entries in arrival order (registers and LDS)
@@ -549,12 +556,14 @@ __device__ __forceinline__ void ix_bucket_sort_body(const IxGeom &g, const uint6
     //  array through every branch -- 256 VGPRs and spills)
     uint64_t v[PER];
     uint32_t sa[PER];
+    uint32_t am[PART ? PER : 1u];
 #pragma unroll
     for (uint32_t k = 0; k < PER; k++) {
         const uint32_t j = tid + k * IX_NT4;
         const bool in = j < N;
-        const uint64_t x = pk[G0 + (in ? j : 0u)];
+        const uint64_t x = src[in ? j : 0u];
         v[k] = x;
+        if constexpr (PART) am[k] = arr[in ? j : 0u];
         const uint32_t sub0 = (uint32_t)(x >> subshift) & (IX_NSUB - 1u);
         if (in) s_jx[j] = (uint16_t)(((sub0 >> IX_SUBLOW) << 13) | (sub0 & ((1u << IX_SUBLOW) - 1u)));
     }
@@ -647,7 +656,6 @@ __device__ __forceinline__ void ix_bucket_sort_body(const IxGeom &g, const uint6
     }
     __syncthreads();
     // ... and put in order: values ascending, the entries of one value as they stand (stable)
-    int degen = 0;
 #pragma unroll
     for (uint32_t k = 0; k < PER; k++) {
         const uint32_t q = tid + k * IX_NT4;
@@ -659,10 +667,10 @@ __device__ __forceinline__ void ix_bucket_sort_body(const IxGeom &g, const uint6
         uint32_t nq = qc;
         if (in && ((s_mixed[sub >> 5] >> (sub & 31u)) & 1u)) {
             const uint32_t a = cs[sub], e = sub + 1u < IX_NSUB ? (uint32_t)cs[sub + 1u] : N;
-            if (e - a > IX_MAXM) {
-                degen = 1;
-            } else {
-                // (the entries of a sub-bucket agree in everything above `subshift`: what is compared are the value's bits below)
+            {
+                // (the entries of a sub-bucket agree in everything above `subshift`: what is compared are the value's bits below.
+                //  No limit on e - a: two values of one clade in a sub-bucket are 2 x 1 000 entries -- a few of a collection's
+                //  buckets -- and even a bucket that is ONE sub-bucket costs 6 144 steps per entry, a fraction of a millisecond.)
                 uint32_t r = 0;
                 if (subshift - g.rb <= 32u) {
                     const uint32_t low = (uint32_t)(me >> g.rb);
@@ -683,11 +691,7 @@ __device__ __forceinline__ void ix_bucket_sort_body(const IxGeom &g, const uint6
         v[k] = me;
         sa[k] = nq | (jv << 16);
     }
-    degen = __syncthreads_or(degen);
-    if (degen) {                                         // uniform: values clumped far from uniform
-        if (tid == 0) flags[IXF_DEGENERATE] = 1u;
-        return;
-    }
+    __syncthreads();
 #pragma unroll
     for (uint32_t k = 0; k < PER; k++) {
         const uint32_t q = tid + k * IX_NT4;
@@ -719,7 +723,7 @@ __device__ __forceinline__ void ix_bucket_sort_body(const IxGeom &g, const uint6
     unordered = __syncthreads_or(unordered);
     if (unordered) {                                     // uniform
         if (tid == 0) flags[IXF_DEGENERATE] = 1u;
-        return;
+        return false;
     }
     IX_CLK(37);
     // the start of q's group: the highest head bit at or below q
@@ -819,7 +823,9 @@ __device__ __forceinline__ void ix_bucket_sort_body(const IxGeom &g, const uint6
             const uint32_t q = inv[j], gs = group_start(q);
             const bool last = q + 1u == N || is_head(q + 1u);
             const uint32_t shared = (gs == q && last) ? 0u : 1u;
-            tc[G0 + j] = make_uint2(((G0 + gs) << 1) | shared, G0 + q);
+            uint32_t at = j;
+            if constexpr (PART) at = am[k];
+            tc[tcbase + at] = make_uint2(((G0 + gs) << 1) | shared, G0 + q);
         }
     }
     IX_CLK(40);
@@ -841,6 +847,7 @@ __device__ __forceinline__ void ix_bucket_sort_body(const IxGeom &g, const uint6
         }
     }
     IX_CLK(41);
+    return true;
 }
 
 __global__ __launch_bounds__(IX_NT4, 4) void ix_bucket_sort_kernel(IxGeom g, const uint64_t *pk, const uint32_t *start, uint64_t *keys_sorted,
@@ -854,11 +861,13 @@ __global__ __launch_bounds__(IX_NT4, 4) void ix_bucket_sort_kernel(IxGeom g, con
     uint32_t *s_mixed = reinterpret_cast<uint32_t *>(lds + IX4_MIX);
     uint32_t *s_part = reinterpret_cast<uint32_t *>(lds + IX4_PART);
     const uint32_t b = blockIdx.x;
-    if (flags[IXF_OVERSIZE]) return;                     // uniform
     const uint32_t G0 = start[b], N = start[b + 1] - G0;
-    if (N == 0) return;                                  // uniform  (N <= IX_CAP: the scan kernel raised IXF_OVERSIZE otherwise)
+    if (N == 0 || N > IX_CAP) return;                    // uniform  (beyond the capacity: ix_big_bucket_kernel's)
     const uint32_t per = (N + IX_NT4 - 1u) / IX_NT4;      // uniform
-#define IX_BODY(P) ix_bucket_sort_body<P>(g, pk, keys_sorted, sorted_rows, gend, gs_of, tc, stat, flags, lead, s_pk, s_jx, s_h, s_mixed, s_part, b, G0, N)
+    const uint32_t subshift = ix_subshift(g);
+#define IX_BODY(P)                                                                                                                          \
+    (void)ix_bucket_sort_body<P, false>(g, pk + G0, nullptr, G0, subshift, keys_sorted, sorted_rows, gend, gs_of, tc, stat, flags, lead, s_pk, s_jx, \
+                                        s_h, s_mixed, s_part, b, G0, N)
     if (per <= 3u) IX_BODY(3);
     else if (per <= 4u) IX_BODY(4);
     else if (per <= 5u) IX_BODY(5);
@@ -866,6 +875,247 @@ __global__ __launch_bounds__(IX_NT4, 4) void ix_bucket_sort_kernel(IxGeom g, con
     else if (per <= 8u) IX_BODY(8);
     else IX_BODY(12);
 #undef IX_BODY
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4b: the buckets beyond the LDS sort's capacity.  Sketches of one species share most of their values: a value held by
+// 16 000 rows makes a bucket of 16 000 + the usual entries.  One workgroup takes such a bucket:
+//   1. the same STABLE counting sort on the 13 bits below the bucket, but through global memory (ix_big_split: a histogram,
+//      its prefix, then the entries in arrival order -- one wave per counter range as in the body, the counter's old value
+//      IS the entry's place) into the bucket's own range of the OUTPUT arrays: keys_sorted / sorted_rows hold {word, arrival
+//      index} until their final content is written over it, part by part;
+//   2. the sorted sub-buckets are walked (ix_big_walk): a run of them that fits the LDS goes through ix_bucket_sort_body (a
+//      sub-bucket alone: on the NEXT 13 bits).  A sub-bucket that does not fit holds a value with thousands of holders and,
+//      one time in four, a few strangers: it is split once more on the next 13 bits (into the bucket's range of pk / gend,
+//      which nobody needs any more) and walked; what does not fit THEN is one value, already in row order, written out as it
+//      stands (ix_big_value) -- or two values that 26 bits do not tell apart: flagged, the general sort's.
+constexpr uint32_t IXB_CS1 = IX4_BYTES, IXB_CS2 = IXB_CS1 + IX_NSUB * 4u, IXB_BYTES = IXB_CS2 + IX_NSUB * 4u;
+constexpr uint32_t IXB_CH = 4096;               // entries staged per round of the ordered pass: words, arrival indices, tags
+constexpr uint32_t IXB_W = 0, IXB_ARR = IXB_W + IXB_CH * 8u, IXB_TAG = IXB_ARR + IXB_CH * 4u;
+static_assert(IXB_TAG + IXB_CH * 2u <= IX4_H, "the staging area lies in the body's entry arrays");
+
+struct IxOut {
+    uint64_t *keys_sorted;
+    uint32_t *sorted_rows, *gend, *gs_of;
+    uint2 *tc;
+    IxStatSlot *stat;
+    uint32_t *flags;
+};
+
+// the counters after ix_big_split: cs[k] = one past sub-bucket k's last place
+__device__ __forceinline__ uint32_t ix_big_first(const uint32_t *cs, uint32_t k) { return k ? cs[k - 1u] : 0u; }
+
+// Stable counting sort of `count` words by the IX_SUBBITS bits at `sshift`: src_w[j] (and src_arr[j], or j itself) goes to
+// dst_w / dst_arr [its place].  cs: IX_NSUB counters of LDS; lds: the staging area.
+__device__ __forceinline__ void ix_big_split(const uint64_t *src_w, const uint32_t *src_arr, uint64_t *dst_w, uint32_t *dst_arr, uint32_t count,
+                                             uint32_t sshift, uint32_t *cs, unsigned char *lds, uint32_t *s_part)
+{
+    uint64_t *s_w = reinterpret_cast<uint64_t *>(lds + IXB_W);
+    uint32_t *s_arr = reinterpret_cast<uint32_t *>(lds + IXB_ARR);
+    uint16_t *s_tag = reinterpret_cast<uint16_t *>(lds + IXB_TAG);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    for (uint32_t x = tid; x < IX_NSUB; x += IX_NT4) cs[x] = 0;
+    __syncthreads();
+    for (uint32_t j = tid; j < count; j += IX_NT4) atomicAdd(&cs[(uint32_t)(src_w[j] >> sshift) & (IX_NSUB - 1u)], 1u);
+    __syncthreads();
+    {
+        constexpr uint32_t W = IX_NSUB / IX_NT4;
+        uint32_t c[W], sum = 0;
+#pragma unroll
+        for (uint32_t x = 0; x < W; x++) {
+            c[x] = cs[W * tid + x];
+            sum += c[x];
+        }
+        uint32_t total = 0;
+        uint32_t run = ix_block_scan_sum(sum, s_part, total);
+#pragma unroll
+        for (uint32_t x = 0; x < W; x++) {
+            cs[W * tid + x] = run;
+            run += c[x];
+        }
+    }
+    for (uint32_t j0 = 0; j0 < count; j0 += IXB_CH) {    // uniform
+        __syncthreads();
+        for (uint32_t x = tid; x < IXB_CH; x += IX_NT4) {
+            const uint32_t j = j0 + x, jc = j < count ? j : 0u;
+            const uint64_t w = src_w[jc];
+            const uint32_t sub0 = (uint32_t)(w >> sshift) & (IX_NSUB - 1u);
+            s_w[x] = w;
+            s_arr[x] = src_arr ? src_arr[jc] : j;
+            s_tag[x] = (uint16_t)(((sub0 >> IX_SUBLOW) << 13) | (sub0 & ((1u << IX_SUBLOW) - 1u)));
+        }
+        __syncthreads();
+        const uint32_t xe = count - j0 < IXB_CH ? count - j0 : IXB_CH;
+        for (uint32_t x0 = 0; x0 < xe; x0 += 256u) {      // uniform
+            uint32_t tag[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; u++) tag[u] = s_tag[x0 + 64u * u + lane];
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; u++) {
+                const uint32_t x = x0 + 64u * u + lane;
+                const bool mine = (tag[u] >> 13) == wave && x < xe;
+                const uint32_t sub = (wave << IX_SUBLOW) | (tag[u] & ((1u << IX_SUBLOW) - 1u));
+                uint32_t at = 0;
+                IX_IN_LANE_ORDER(if (mine) at = atomicAdd(&cs[sub], 1u));
+                if (mine) {
+                    dst_w[at] = s_w[x];
+                    dst_arr[at] = s_arr[x];
+                }
+            }
+        }
+    }
+    __threadfence();
+    __syncthreads();
+}
+
+// do the words src_w[0 .. m) hold ONE value?  (uniform)
+__device__ __forceinline__ bool ix_big_one_value(const IxGeom &g, const uint64_t *src_w, uint32_t m)
+{
+    const uint64_t low0 = src_w[0] >> g.rb;
+    int bad = 0;
+    for (uint32_t q = threadIdx.x; q < m; q += IX_NT4) bad |= (src_w[q] >> g.rb) != low0 ? 1 : 0;
+    return __syncthreads_or(bad) == 0;
+}
+
+// One value (ix_big_one_value), m > IX_CAP holders: its words src_w[0 .. m) in row order, src_arr their arrival indices; gs:
+// its first sorted position.  (src may be the output arrays' own memory: a round reads all its entries before it writes any.)
+__device__ __forceinline__ bool ix_big_value(const IxGeom &g, const uint64_t *src_w, const uint32_t *src_arr, const IxOut &o, const IxLeaders &lead,
+                                             uint32_t *s_row, uint32_t *s_part, uint32_t b, uint32_t tcbase, uint32_t gs, uint32_t m)
+{
+    const uint32_t tid = threadIdx.x;
+    const uint64_t rowmask = (1ull << g.rb) - 1ull;
+    const uint64_t vbase = (uint64_t)b << g.shift;
+    int bad = 0;
+    for (uint32_t q0 = 0; q0 < m; q0 += IX_NT4) {         // uniform
+        const uint32_t q = q0 + tid;
+        const bool in = q < m, more_after = q + 1u < m;
+        const uint64_t w = src_w[in ? q : 0u];
+        const uint32_t ar = src_arr[in ? q : 0u];
+        const uint32_t next_row = (uint32_t)(src_w[more_after ? q + 1u : 0u] & rowmask);
+        const uint32_t row = (uint32_t)(w & rowmask);
+        s_row[tid + 1u] = row;
+        __syncthreads();                                 // (everything of this round is read: its places may be written)
+        const uint32_t prev_row = s_row[tid];            // (work-item 0: the round before's last row)
+        if (in && q > 0 && prev_row >= row) bad = 1;      // the stable order that the splits are trusted to give: checked
+        bool isl = false;
+        uint32_t grp = 0xFFFFFFFFu;
+        if (lead.grp_of != nullptr && in) {
+            const uint32_t *gp = lead.grp_of + 4ull * row;
+            grp = gp[0];
+            const bool first = q == 0 || prev_row < gp[1];
+            isl = grp != 0xFFFFFFFFu && first && more_after && next_row < gp[2];
+        }
+        __syncthreads();
+        if (tid == IX_NT4 - 1u) s_row[0] = row;
+        if (in) {
+            o.keys_sorted[gs + q] = vbase | (w >> g.rb);
+            o.sorted_rows[gs + q] = row;
+            if (o.gs_of) o.gs_of[gs + q] = gs;
+            o.tc[tcbase + ar] = make_uint2((gs << 1) | 1u, gs + q);
+        }
+        if (lead.grp_of != nullptr) {                    // uniform
+            uint32_t ltotal = 0;
+            const uint32_t lbase = ix_block_scan_sum(isl ? 1u : 0u, s_part, ltotal);
+            if (ltotal) {                                // uniform
+                const uint32_t sub = b & (lead.nsub - 1u);
+                if (tid == 0) s_part[15] = atomicAdd(&lead.cnt[sub], ltotal);
+                __syncthreads();
+                const uint32_t at = s_part[15] + lbase;
+                if (isl && at < lead.cap_sub) {
+                    const uint64_t slot = (uint64_t)sub * lead.cap_sub + at;
+                    lead.key[slot] = ((unsigned long long)grp << 32) | (unsigned long long)gs;
+                    lead.val[slot] = gs + q;
+                }
+                __syncthreads();
+            }
+        }
+    }
+    bad = __syncthreads_or(bad);
+    if (bad) {                                           // uniform
+        if (tid == 0) o.flags[IXF_DEGENERATE] = 1u;
+        return false;
+    }
+    if (tid == 0) {
+        o.gend[gs] = gs + m;
+        atomicAdd(&o.flags[IXF_NSTREAMED], 1u);
+        IxStatSlot *sl = o.stat + (b & (IX_STAT_SLOTS - 1u));
+        atomicAdd(&sl->inc, (unsigned long long)m * (unsigned long long)(m - 1u) / 2ull);
+        atomicMax(&sl->max_group, m);
+        atomicAdd(&sl->groups, 1u);
+    }
+    return true;
+}
+
+// The sub-buckets of a split (cs, made on the bits at sshift) in order: src_w / src_arr [0 .. count) are the split's result,
+// gpos the sorted position of its first entry; alt_w / alt_arr: free memory of the same extent for one more split (LEVEL 1).
+template <int LEVEL>
+__device__ bool ix_big_walk(const IxGeom &g, const uint64_t *src_w, const uint32_t *src_arr, uint64_t *alt_w, uint32_t *alt_arr, uint32_t gpos,
+                            uint32_t count, uint32_t sshift, const uint32_t *cs, uint32_t *cs_next, const IxOut &o, const IxLeaders &lead,
+                            unsigned char *lds, uint32_t b, uint32_t tcbase)
+{
+    uint64_t *s_pk = reinterpret_cast<uint64_t *>(lds + IX4_PK);
+    uint16_t *s_jx = reinterpret_cast<uint16_t *>(lds + IX4_JX);
+    uint32_t *s_h = reinterpret_cast<uint32_t *>(lds + IX4_H);
+    uint32_t *s_mixed = reinterpret_cast<uint32_t *>(lds + IX4_MIX);
+    uint32_t *s_part = reinterpret_cast<uint32_t *>(lds + IX4_PART);
+    const uint32_t sshift_next = sshift - g.rb >= IX_SUBBITS ? sshift - IX_SUBBITS : g.rb;
+    uint32_t sub = 0;
+    while (sub < IX_NSUB) {                              // uniform
+        const uint32_t a = ix_big_first(cs, sub);
+        if (a == count) break;
+        uint32_t lo = sub, hi = IX_NSUB;                 // first(lo) - a <= IX_CAP < first(hi) - a, unless everything left fits
+        if (count - a <= IX_CAP) lo = hi;
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (ix_big_first(cs, mid) - a <= IX_CAP) lo = mid;
+            else hi = mid;
+        }
+        bool ok = true;
+        if (lo == sub) {
+            const uint32_t m = cs[sub] - a;
+            if (ix_big_one_value(g, src_w + a, m)) {     // uniform
+                ok = ix_big_value(g, src_w + a, src_arr + a, o, lead, reinterpret_cast<uint32_t *>(lds + IX4_PK), s_part, b, tcbase, gpos + a, m);
+            } else if (LEVEL == 1 && sshift > g.rb) {    // uniform: strangers beside the value -- the next 13 bits part them
+                if constexpr (LEVEL == 1) {
+                    ix_big_split(src_w + a, src_arr + a, alt_w + a, alt_arr + a, m, sshift_next, cs_next, lds, s_part);
+                    ok = ix_big_walk<2>(g, alt_w + a, alt_arr + a, nullptr, nullptr, gpos + a, m, sshift_next, cs_next, nullptr, o, lead, lds, b, tcbase);
+                }
+            } else {                                     // two values that 26 bits below the bucket do not tell apart
+                if (threadIdx.x == 0) o.flags[IXF_DEGENERATE] = 1u;
+                ok = false;
+            }
+            sub++;
+        } else {
+            const uint32_t cnt = ix_big_first(cs, lo) - a;
+            if (cnt)
+                ok = ix_bucket_sort_body<IX_CAP / IX_NT4, true>(g, src_w + a, src_arr + a, tcbase, lo == sub + 1u ? sshift_next : sshift, o.keys_sorted,
+                                                                o.sorted_rows, o.gend, o.gs_of, o.tc, o.stat, o.flags, lead, s_pk, s_jx, s_h, s_mixed, s_part,
+                                                                b, gpos + a, cnt);
+            sub = lo;
+        }
+        if (!ok) return false;                           // uniform (the table is flagged)
+        __syncthreads();
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(IX_NT4, 2) void ix_big_bucket_kernel(IxGeom g, uint64_t *pk, const uint32_t *start, const uint32_t *biglist,
+                                                               uint64_t *keys_sorted, uint32_t *sorted_rows, uint32_t *gend, uint32_t *gs_of, uint2 *tc,
+                                                               IxStatSlot *stat, uint32_t *flags, IxLeaders lead)
+{
+    MG_DYN_SHARED(unsigned char, lds);
+    uint32_t *s_part = reinterpret_cast<uint32_t *>(lds + IX4_PART);
+    uint32_t *cs1 = reinterpret_cast<uint32_t *>(lds + IXB_CS1), *cs2 = reinterpret_cast<uint32_t *>(lds + IXB_CS2);
+    const IxOut o{keys_sorted, sorted_rows, gend, gs_of, tc, stat, flags};
+    const uint32_t nbig = flags[IXF_NBIG];
+    const uint32_t sshift = ix_subshift(g);
+    for (uint32_t i = blockIdx.x; i < nbig; i += gridDim.x) {            // uniform
+        const uint32_t b = biglist[i];
+        const uint32_t G0 = start[b], N = start[b + 1] - G0;
+        ix_big_split(pk + G0, nullptr, keys_sorted + G0, sorted_rows + G0, N, sshift, cs1, lds, s_part);
+        if (!ix_big_walk<1>(g, keys_sorted + G0, sorted_rows + G0, pk + G0, gend + G0, G0, N, sshift, cs1, cs2, o, lead, lds, b, G0)) return;
+        __syncthreads();
+    }
 }
 
 __global__ __launch_bounds__(256) void ix_stat_reduce_kernel(const IxStatSlot *stat, unsigned long long *incidences, uint32_t *max_group, uint32_t *groups)
@@ -984,12 +1234,13 @@ IxPlan index_plan(uint32_t n, uint32_t E, uint32_t s, uint32_t rs, uint64_t stri
     p.start_bytes = ((size_t)g.Bp + 1u) * 4u;
     p.pk_bytes = (size_t)E * 8u;
     p.tc_bytes = (size_t)E * 8u;
+    p.big_bytes = ((size_t)E / IX_CAP + 2u) * 4u;
     if (p.lb_bytes > ((size_t)2 << 30) || p.cnt_bytes > ((size_t)2 << 30)) { p.why = "scratch of the tiles too large"; return p; }
     p.ok = true;
     return p;
 }
 
-hipError_t index_build(const IxPlan &plan, const uint64_t *hashes, const uint32_t *off, void *lb_v, void *cnt_v, void *start_v, void *pk_v, void *tc_v,
+hipError_t index_build(const IxPlan &plan, const uint64_t *hashes, const uint32_t *off, void *lb_v, void *cnt_v, void *start_v, void *big_v, void *pk_v, void *tc_v,
                        uint64_t *keys_sorted, uint32_t *sorted_rows, uint32_t *gend, uint32_t *gs_of, uint32_t *code_img, uint32_t *pos_img,
                        void *stat_scratch, unsigned long long *incidences, uint32_t *max_group, uint32_t *groups, uint32_t *flags,
                        const IxLeaders *leaders, hipStream_t stream, int stages)
@@ -1004,12 +1255,13 @@ hipError_t index_build(const IxPlan &plan, const uint64_t *hashes, const uint32_
     if (stages & 1) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(ix_tile_partition_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)IXL_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(ix_bucket_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)IX4_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(ix_big_bucket_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)IXB_BYTES);
         if (e != hipSuccess) return e;
         const uint32_t tiles = 8u * ((g.nseq + 7u) / 8u);
         hipLaunchKernelGGL(ix_window_offsets_kernel, dim3((g.n + 3u) / 4u), dim3(256), 0, stream, g, hashes, off, lb);
         hipLaunchKernelGGL(ix_tile_count_kernel, dim3(tiles), dim3(IX_NT), 0, stream, g, hashes, (const uint16_t *)lb, cnt);
         hipLaunchKernelGGL(ix_col_scan_kernel, dim3((g.Bp + 255u) / 256u), dim3(256), 0, stream, g, cnt, start);
-        hipLaunchKernelGGL(ix_bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, g, start, flags);
+        hipLaunchKernelGGL(ix_bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, g, start, flags, static_cast<uint32_t *>(big_v));
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(ix_tile_partition_kernel, dim3(tiles), dim3(IX_NT), IXL_BYTES, stream, g, hashes, (const uint16_t *)lb, (const uint32_t *)cnt,
@@ -1021,6 +1273,10 @@ hipError_t index_build(const IxPlan &plan, const uint64_t *hashes, const uint32_
         hipLaunchKernelGGL(ix_bucket_sort_kernel, dim3(g.Bp), dim3(IX_NT4), IX4_BYTES, stream, g, (const uint64_t *)pk, (const uint32_t *)start, keys_sorted,
                            sorted_rows, gend, g.want_gs ? gs_of : (uint32_t *)nullptr, tc, static_cast<IxStatSlot *>(stat_scratch), flags,
                            leaders ? *leaders : IxLeaders());
+        // (a workgroup per CU at most; with no big bucket -- the usual case -- they leave at once)
+        hipLaunchKernelGGL(ix_big_bucket_kernel, dim3(256), dim3(IX_NT4), IXB_BYTES, stream, g, pk, (const uint32_t *)start,
+                           (const uint32_t *)big_v, keys_sorted, sorted_rows, gend, g.want_gs ? gs_of : (uint32_t *)nullptr, tc,
+                           static_cast<IxStatSlot *>(stat_scratch), flags, leaders ? *leaders : IxLeaders());
         hipLaunchKernelGGL(ix_stat_reduce_kernel, dim3(1), dim3(256), 0, stream, static_cast<const IxStatSlot *>(stat_scratch), incidences, max_group, groups);
     }
     if (!(stages & 2)) return hipGetLastError();

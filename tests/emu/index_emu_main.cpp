@@ -43,12 +43,14 @@ static Table make_table(uint32_t n, uint32_t s, uint64_t seed, const std::string
             top = ~0ull;                                 // values up to the top bit
         }
         std::vector<uint64_t> v;
-        if (kind == "clusters" || kind == "clade") {
+        if (kind == "clusters" || kind == "clade" || kind == "twins") {
             // rows of a cluster draw most of their values from a shared pool: values held by several rows
-            const uint32_t per = kind == "clade" ? n : 8;
+            const uint32_t per = kind == "clusters" ? 8 : n;
             if (r % per == 0) {
                 pool.clear();
                 for (uint32_t k = 0; k < s + s / 4; k++) pool.push_back(rng() % top);
+                if (kind == "twins")                         // pairs of neighbouring values: no number of leading bits tells them apart
+                    for (uint32_t k = 1; k < pool.size(); k += 2) pool[k] = pool[k - 1] + 1;
             }
             std::vector<uint64_t> p2 = pool;
             std::shuffle(p2.begin(), p2.end(), rng);
@@ -133,7 +135,7 @@ static int run_case(const std::string &name, uint32_t n, uint32_t s, uint64_t se
     }
     const IxGeom &g = plan.g;
     std::vector<unsigned char> lb(plan.lb_bytes + 16, 0xAB), cnt(plan.cnt_bytes + 16, 0xAB), start(plan.start_bytes + 16, 0xAB), pk(plan.pk_bytes + 16, 0xAB),
-        tc(plan.tc_bytes + 16, 0xAB), stat(index_stat_scratch_bytes());
+        tc(plan.tc_bytes + 16, 0xAB), big(plan.big_bytes + 16, 0xAB), stat(index_stat_scratch_bytes());
     std::vector<uint64_t> keys(E, 0xDEADull);
     std::vector<uint32_t> rows(E, 0xDEADu), gend(E, 0xDEADu), gs(E, 0xDEADu), code((size_t)n * rs + 64, 0xDEADu), pos((size_t)n * rs, 0xDEADu);
     unsigned long long inc = 0;
@@ -161,13 +163,14 @@ static int run_case(const std::string &name, uint32_t n, uint32_t s, uint64_t se
     lead.cnt = lcnt.data();
     lead.cap_sub = cap_sub;
     lead.nsub = nsub;
-    const hipError_t e = index_build(plan, t.H.data(), off.data(), lb.data(), cnt.data(), start.data(), pk.data(), tc.data(), keys.data(), rows.data(),
+    const hipError_t e = index_build(plan, t.H.data(), off.data(), lb.data(), cnt.data(), start.data(), big.data(), pk.data(), tc.data(), keys.data(), rows.data(),
                                      gend.data(), gs.data(), code.data(), pos.data(), stat.data(), &inc, &max_group, &groups, flags, &lead, nullptr);
     if (e != hipSuccess) { printf("%-28s index_build failed\n", name.c_str()); return 1; }
     char geom[200];
-    snprintf(geom, sizeof geom, "n %u s %u E %u shift %u B %u BW %u NW %u passes %u fullest %u", n, s, E, g.shift, g.Bp, g.BW, g.NW, g.npass, flags[IXF_MAXBUCKET]);
-    if (flags[IXF_OVERSIZE] || flags[IXF_DEGENERATE]) {
-        printf("%-28s %s: flags oversize %u degenerate %u%s\n", name.c_str(), geom, flags[0], flags[1], expect_fallback ? " (expected)" : " UNEXPECTED");
+    snprintf(geom, sizeof geom, "n %u s %u E %u shift %u B %u BW %u NW %u passes %u fullest %u big %u streamed %u", n, s, E, g.shift, g.Bp, g.BW, g.NW,
+             g.npass, flags[IXF_MAXBUCKET], flags[IXF_NBIG], flags[IXF_NSTREAMED]);
+    if (flags[IXF_DEGENERATE]) {
+        printf("%-28s %s: flagged degenerate%s\n", name.c_str(), geom, expect_fallback ? " (expected)" : " UNEXPECTED");
         return expect_fallback ? 0 : 1;
     }
     if (expect_fallback) { printf("%-28s %s: expected a flag, none raised\n", name.c_str(), geom); return 1; }
@@ -233,7 +236,11 @@ int main(int argc, char **argv)
         {"many_buckets", 513, 128, 10, "random", false, 60.0},    // sparse buckets, two sort passes
         {"three_passes", 100, 128, 15, "random", false, 2000.0},  // windows of 512 buckets
         {"clade", 600, 64, 11, "clade", false, 1.0},              // every value held by hundreds of rows: the stable counting sort takes them as they arrive
-        {"oversize", 2000, 32, 12, "random", true, 0.0005},       // a bucket beyond the LDS capacity: the flag
+        {"big_random", 2000, 32, 12, "random", false, 0.0005},    // buckets beyond the LDS capacity: the two-level sort, parts of many sub-buckets
+        {"big_clade", 10000, 16, 13, "clade", false, 1.0},        // values held by 7 000 rows: more than the LDS takes, streamed out in row order
+        {"big_clade_fit", 7000, 16, 14, "clade", false, 1.0},     // values held by 5 000 rows in buckets beyond the capacity: a part of one sub-bucket
+        {"twins", 2500, 16, 16, "twins", false, 1.0},             // neighbouring values with 1 800 holders each: ranked by comparison in LDS
+        {"big_twins", 10000, 16, 15, "twins", true, 1.0},         // two values, thousands of holders each, that differ in the last bit: the flag
     };
     for (const Case &c : cases)
         if (which == "all" || which == c.name) rc |= run_case(c.name, c.n, c.s, c.seed, c.kind, c.fallback, c.dens_scale);

@@ -1098,21 +1098,36 @@ def _index_tables(kind, rng):
         for i in range(n):
             table[i] = np.unique(t[i])[:s]
         return table, np.full(n, s, dtype=np.uint32), False
-    if kind == "clade":                                     # every value of a pool held by hundreds of rows: buckets beyond the LDS sort
-        table, nhash = _clade_table(rng, (700, 500), 400)
+    if kind == "clade":                                     # every value of a pool held by hundreds of rows: buckets beyond the LDS sort,
+        table, nhash = _clade_table(rng, (700, 500), 400)    # split once more through global memory (ix_big_bucket_kernel)
+        return table, nhash, False
+    if kind == "big_clade":                                 # values held by 6 700 rows: more than the LDS takes, streamed out in row order
+        table, nhash = _clade_table(rng, (7000, 900), 64)
+        return table, nhash, False
+    if kind == "twins":                                     # pairs of NEIGHBOURING values with 6 700 holders each: no leading bits tell
+        n, s = 7000, 32                                      # them apart -- the tiles must refuse and the sort build the index
+        pool = np.unique(rng.integers(1, 1 << 60, size=40).astype(np.uint64))[:34]
+        pool[1::2] = pool[0::2] + np.uint64(1)
+        table = np.full((n, s), np.uint64(abi.HASH_PAD), dtype=np.uint64)
+        nhash = np.zeros(n, dtype=np.uint32)
+        for i in range(n):
+            r = np.unique(np.concatenate([pool[rng.random(len(pool)) < 0.96], rng.integers(1, 1 << 60, size=2).astype(np.uint64)]))[:s]
+            table[i, :len(r)] = r
+            nhash[i] = len(r)
         return table, nhash, True
     raise ValueError(kind)
 
 
-@pytest.mark.parametrize("kind", ["clusters", "random", "ragged", "large_sketches", "sizes", "top_bit", "clade"])
+@pytest.mark.parametrize("kind", ["clusters", "random", "ragged", "large_sketches", "sizes", "top_bit", "clade", "big_clade", "twins"])
 def test_index_built_by_tiles_equals_the_sorted_index(eng, oracle, kind, monkeypatch):
     """Round 5 builds the inverted index without a general sort (index_build.hip: one partition pass over tiles of
     512 rows x a window of buckets, an LDS sort per bucket that finds the groups, the images written back row segment by
     row segment).  MASHGPU_SPARSE_INDEX=verify builds it BOTH ways and compares every array on the device word by word
     (values, rows, group starts and ends, code and position images, the statistics); the triangle it serves is compared
     with the oracle (sampled rows) and with the sort-built index (every byte), for the whole table (the clustered copy)
-    and for a row range (the index in table order).  Tables the tiles refuse (a value held by hundreds of rows: a bucket
-    beyond the LDS) must say so and come out right through the sort."""
+    and for a row range (the index in table order).  A value held by hundreds or thousands of rows makes a bucket beyond the
+    LDS: split once more through global memory, and streamed out if one value alone is beyond it.  Tables the tiles refuse
+    (two neighbouring values with thousands of holders each; too many buckets) must say so and come out right through the sort."""
     rng = np.random.default_rng(77)
     table, nhash, may_refuse = _index_tables(kind, rng)
     n, s = table.shape

@@ -2,8 +2,9 @@
 barriers and wave operations as context switches) and every array they produce is compared with a std::stable_sort statement
 of the inverted index: values, rows, group starts and ends, code and position images, the statistics -- on tables with one
 window and many, one sort pass to three, tiles of several pieces, ragged and empty rows, rows kept out of the index, genomes
-of many sizes, values up to the top bit; a table whose values are held by hundreds of rows and one with a bucket beyond the
-LDS capacity must raise their flags (the caller then builds the index by the general sort).
+of many sizes, values up to the top bit, values held by hundreds of rows, buckets beyond the LDS capacity (the two-level
+sort: random values, and values held by 5 000 and 7 000 rows); a table in which two neighbouring values have thousands of
+holders each must raise the flag (the caller then builds the index by the general sort).
 The kernels' index arithmetic is thereby pinned without a GPU; under ThreadSanitizer (MASH_EMU_TSAN=1, minutes: work-items as
 OS threads) a missing barrier is a reported data race."""
 import os
@@ -16,7 +17,7 @@ SRC = os.path.join(ROOT, "tests", "emu", "index_emu_main.cpp")
 INC = ["-I" + os.path.join(ROOT, "tools", "hipemu"), "-I" + os.path.join(ROOT, "mash_amd", "csrc")]
 
 FAST = ["random_small", "random_two_blocks", "clusters", "clusters_windows", "ragged", "ragged_windows", "copies_out", "top_bit", "one_row",
-        "pieces", "clade", "oversize"]
+        "pieces", "clade", "big_random", "big_clade", "big_clade_fit", "twins", "big_twins"]
 
 
 @pytest.fixture(scope="module")
