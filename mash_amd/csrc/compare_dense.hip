@@ -298,14 +298,18 @@ __global__ __launch_bounds__(256) void dn_encode_kernel(const uint32_t *off, con
     }
     __syncthreads();
     const uint32_t jb = (row - G.g0) >> 7, bl = (row - G.g0) & 127u;
-    const uint64_t bw = 128ull * W + 32ull * (W + 1u);
+    const uint64_t bw = dense_block_words(W);
     unsigned long long *blk = gdata + G.data_off + (uint64_t)jb * bw;
-    uint16_t *cxp = reinterpret_cast<uint16_t *>(blk + 128ull * W);
-    if (tid == 0) {                                       // cumulative counts: cx[w] = extras with gap < 64 w (w = 0 .. W);
-        uint32_t run = 0;                                 // entry w + 1 carries the flag of word w
-        for (uint32_t w = 0; w <= W; w++) {
+    uint16_t *cxp = reinterpret_cast<uint16_t *>(blk + 128ull * W), *totp = cxp + (W + 1u) * 128u;
+    if (tid == 0) {                                       // cumulative counts: cx[w] = extras with gap < 64 w (w = 0 .. W),
+        uint32_t run = 0, all = 0;                        // entry w + 1 carries the flag of word w; tot[w] = ALL the row's values
+        for (uint32_t w = 0; w <= W; w++) {               // before that boundary (universe values held + extras)
             cxp[w * 128u + bl] = (uint16_t)(run | ((w > 0 && ovf[w - 1u]) ? DN_CX_FLAG : 0u));
-            if (w < W) run += hist[w];
+            totp[w * 128u + bl] = (uint16_t)all;
+            if (w < W) {
+                run += hist[w];
+                all += hist[w] + (uint32_t)__popc(mask32[2u * w]) + (uint32_t)__popc(mask32[2u * w + 1u]);
+            }
         }
     }
     unsigned long long *xrow3 = xm + ((uint64_t)(G.xrow0 + (row - G.g0)) * wstride) * 3ull;      // (every row has room for the widest universe)
@@ -351,7 +355,6 @@ __device__ __forceinline__ uint64_t dn_out_index(uint32_t a, uint32_t b, const u
     return (uint64_t)i * (i - 1u) / 2u - out_base + j;
 }
 
-constexpr uint32_t DN_IL = 4;                             // rows a wave works on side by side
 
 // The word in which the union reaches its s-th element: the smallest bit position t with f(t) >= s, where f(t) = what lies
 // before the word (fprev) + union bits below t + extras of either row with offset <= t; the bits below t are the ones counted.
@@ -365,6 +368,18 @@ __device__ __forceinline__ uint32_t dn_resolve(unsigned long long un, uint32_t f
     if (!lists) {
         const unsigned long long a0 = xma[3u * w], a1 = xma[3u * w + 1u], a2 = xma[3u * w + 2u];
         const unsigned long long b0 = xmb[3u * w], b1 = xmb[3u * w + 1u], b2 = xmb[3u * w + 2u];
+        // (two extras in one gap are rare -- a row's extras are a few dozen over a thousand gaps: with none in the whole
+        //  wave a step is three counts instead of seven)
+        if (__ballot((a1 | b1) != 0ull) == 0) {              // uniform  (a third extra implies a second)
+#pragma unroll
+            for (uint32_t step = 0; step < 6u; step++) {      // lo = 0, hi = 63: six halvings
+                const uint32_t mid = (lo + hi) >> 1;
+                const unsigned long long below = (1ull << mid) - 1ull, upto = (2ull << mid) - 1ull;
+                const uint32_t c = fprev + (uint32_t)__popcll(un & below) + (uint32_t)__popcll(a0 & upto) + (uint32_t)__popcll(b0 & upto);
+                if (c >= s) hi = mid; else lo = mid + 1u;
+            }
+            return lo;
+        }
         while (lo < hi) {
             const uint32_t mid = (lo + hi) >> 1;                          // <= 62
             const unsigned long long below = (1ull << mid) - 1ull, upto = (2ull << mid) - 1ull;
@@ -390,7 +405,7 @@ __device__ __forceinline__ uint32_t dn_resolve(unsigned long long un, uint32_t f
 // is worked on; only the rows' words sit in LDS.  (Staging the block in LDS was measured slower for every width: 26 KB per
 // two waves leave a CU a handful of waves, and the loop lives on having many -- C3 1.47 against 1.10 ms, one clade of
 // 32 768 rows 17.8 against 12.6 ms; universes of hundreds of words, s = 10 000, would not fit anyway.)
-template <uint32_t DN_ROWS>
+template <uint32_t DN_ROWS, uint32_t DN_IL>                // DN_IL: rows a wave works on side by side
 __global__ __launch_bounds__(128) void dn_pairs_kernel(const DenseTile *tiles, const DenseGroup *groups, const unsigned long long *gdata,
                                                        const unsigned long long *xm, uint32_t wstride, uint32_t use_lists,
                                                        const uint16_t *ext, uint32_t xs, uint32_t s, uint32_t row_begin, uint32_t row_end,
@@ -400,104 +415,99 @@ __global__ __launch_bounds__(128) void dn_pairs_kernel(const DenseTile *tiles, c
     const DenseTile T = tiles[blockIdx.x];
     const DenseGroup G = groups[T.group];
     const uint32_t W = G.W, tid = threadIdx.x;
-    const uint64_t bw = 128ull * W + 32ull * (W + 1u);
+    const uint64_t bw = dense_block_words(W);
     const unsigned long long *Bm = gdata + G.data_off + (uint64_t)T.cblk * bw;            // [W][128]
     const uint16_t *Bcx = reinterpret_cast<const uint16_t *>(Bm + 128ull * W);             // [W + 1][128]
+    const uint16_t *Btot = Bcx + (W + 1u) * 128u;                                         // [W + 1][128]
     unsigned long long *Am = dl;                                                          // [W][DN_ROWS]
     uint16_t *Acx = reinterpret_cast<uint16_t *>(Am + (uint64_t)DN_ROWS * W);             // [W + 1][DN_ROWS]
+    uint16_t *Atot = Acx + (W + 1u) * DN_ROWS;                                            // [W + 1][DN_ROWS]
     const uint32_t ra = T.row0 - G.g0;                                    // (a multiple of DN_ROWS: the tile's rows share a block)
     const unsigned long long *asrc = gdata + G.data_off + (uint64_t)(ra >> 7) * bw;
     const uint32_t la0 = ra & 127u;
     for (uint32_t i = tid; i < W * DN_ROWS; i += 128u) Am[i] = asrc[(i / DN_ROWS) * 128u + la0 + (i % DN_ROWS)];
     {
+        // (cx and tot lie behind each other in the block and in LDS: one loop over 2 (W + 1) lines)
         const uint16_t *acs = reinterpret_cast<const uint16_t *>(asrc + 128ull * W);
-        for (uint32_t i = tid; i < (W + 1u) * DN_ROWS; i += 128u) Acx[i] = acs[(i / DN_ROWS) * 128u + la0 + (i % DN_ROWS)];
+        for (uint32_t i = tid; i < 2u * (W + 1u) * DN_ROWS; i += 128u) Acx[i] = acs[(i / DN_ROWS) * 128u + la0 + (i % DN_ROWS)];
     }
     __syncthreads();
     const uint32_t b = G.g0 + T.cblk * 128u + tid;                         // this lane's column
     const uint16_t *xb = ext + (uint64_t)(G.xrow0 + (b < G.g1 ? b - G.g0 : 0u)) * xs;
     const unsigned long long *xmb = xm + (uint64_t)(G.xrow0 + (b < G.g1 ? b - G.g0 : 0u)) * wstride * 3ull;
     // DN_IL rows at a time: the column block's word is loaded once and serves all of them (their words are broadcast reads
-    // from LDS), and a wave has four independent pairs per lane in flight instead of one
+    // from LDS), and a wave has several independent pairs per lane in flight instead of one.
+    // Per pair and word: the intersection's bits are counted (common), and what the union holds up to the word's end follows
+    // from the two rows' running totals -- |A u B| = |A| + |B| - |A n B| -- instead of from a second population count:
+    // F = totA + totB - common.  F never falls from word to word, so the loop needs no state but two counters per pair:
+    // while F <= s the word lies before the s-th union element and its common bits count; the number of such words IS the
+    // word in which F passes s.  That word is resolved bit by bit behind the loop (dn_resolve), once per pair and with all
+    // lanes of the wave at it together.  (A pair whose F equals s at a word's end meets the resolve with nothing left to
+    // count, and one that is not a pair of the job -- a column not below the row -- is computed like the others and not stored.)
     for (uint32_t ai = 0; ai < DN_ROWS; ai += DN_IL) {
         if (T.row0 + ai >= G.g1 || T.row0 + ai >= row_end) break;         // uniform
-        uint32_t pu[DN_IL], common[DN_IL], denom[DN_IL];
-        bool done[DN_IL], valid[DN_IL];
+        uint32_t common[DN_IL], nle[DN_IL];
+#pragma unroll
+        for (uint32_t k = 0; k < DN_IL; k++) common[k] = nle[k] = 0;
+        unsigned long long mb_next = Bm[tid];
+        uint32_t tb_next = Btot[128u + tid];
+        for (uint32_t w = 0; w < W; w++) {
+            const unsigned long long mb = mb_next;
+            const uint32_t tb1 = tb_next;
+            if (w + 1u < W) {                                             // the next word is on its way while this one is worked on
+                mb_next = Bm[(w + 1u) * 128u + tid];
+                tb_next = Btot[(w + 2u) * 128u + tid];
+            }
+            bool any = false;
+#pragma unroll
+            for (uint32_t k = 0; k < DN_IL; k++) {
+                const unsigned long long an = Am[w * DN_ROWS + ai + k] & mb;
+                const uint32_t cnew = common[k] + (uint32_t)__popcll(an);
+                const bool before = (uint32_t)Atot[(w + 1u) * DN_ROWS + ai + k] + tb1 - cnew <= s;
+                common[k] = before ? cnew : common[k];
+                nle[k] += before ? 1u : 0u;
+                any = any || before;
+            }
+            if (__ballot(any) == 0) break;                                // uniform: every pair is past its s-th element
+        }
 #pragma unroll
         for (uint32_t k = 0; k < DN_IL; k++) {
             const uint32_t a = T.row0 + ai + k;
             // (uniform: the row exists, belongs to the job, and the column block starts below it)
             const bool present = a < G.g1 && a < row_end && a >= row_begin && G.g0 + T.cblk * 128u < a;
-            valid[k] = present && b < a;
-            done[k] = !valid[k];
-            pu[k] = common[k] = denom[k] = 0;
-        }
-        unsigned long long mb_next = Bm[tid];
-        uint32_t cb_next = Bcx[128u + tid], cb0r = Bcx[tid];
-        for (uint32_t w = 0; w < W; w++) {
-            bool any = false;
-#pragma unroll
-            for (uint32_t k = 0; k < DN_IL; k++) any = any || !done[k];
-            if (__ballot(any) == 0) break;                                // uniform
-            const unsigned long long mb = mb_next;
-            const uint32_t cb1r = cb_next;                                // (bit 15: the word's flag)
-            if (w + 1u < W) {                                             // the next word is on its way while this one is worked on
-                mb_next = Bm[(w + 1u) * 128u + tid];
-                cb_next = Bcx[(w + 2u) * 128u + tid];
+            if (!(present && b < a)) continue;
+            uint32_t denom = s;
+            const uint32_t w = nle[k];
+            if (w < W) {                                                  // s is reached inside word w
+                const unsigned long long ma = Am[w * DN_ROWS + ai + k], mb = Bm[w * 128u + tid];
+                const uint32_t ca0 = Acx[w * DN_ROWS + ai + k] & DN_CX_MASK, ca1r = Acx[(w + 1u) * DN_ROWS + ai + k];
+                const uint32_t cb0 = Bcx[w * 128u + tid] & DN_CX_MASK, cb1r = Bcx[(w + 1u) * 128u + tid];
+                const uint32_t fprev = (uint32_t)Atot[w * DN_ROWS + ai + k] + (uint32_t)Btot[w * 128u + tid] - common[k];
+                const uint32_t T0 = dn_resolve(ma | mb, fprev, s, w, use_lists || ((ca1r | cb1r) & DN_CX_FLAG) != 0,
+                                               xm + (uint64_t)(G.xrow0 + (a - G.g0)) * wstride * 3ull, xmb,
+                                               ext + (uint64_t)(G.xrow0 + (a - G.g0)) * xs, xb, ca0, (ca1r & DN_CX_MASK) - ca0, cb0,
+                                               (cb1r & DN_CX_MASK) - cb0);
+                common[k] += (uint32_t)__popcll(ma & mb & ((1ull << T0) - 1ull));
+            } else {                                                      // the union ends before s (short sketches)
+                const uint32_t total = (uint32_t)Atot[W * DN_ROWS + ai + k] + (uint32_t)Btot[W * 128u + tid] - common[k];
+                denom = total < s ? total : s;
             }
-            const uint32_t cb1 = cb1r & DN_CX_MASK;
-#pragma unroll
-            for (uint32_t k = 0; k < DN_IL; k++) {
-                const unsigned long long ma = Am[w * DN_ROWS + ai + k];
-                const unsigned long long un = ma | mb, an = ma & mb;
-                const uint32_t pun = (uint32_t)__popcll(un);
-                const uint32_t ca1r = Acx[(w + 1u) * DN_ROWS + ai + k];
-                const uint32_t F = pu[k] + pun + (ca1r & DN_CX_MASK) + cb1;
-                if (!done[k]) {
-                    if (F <= s) {                                         // the whole word lies before the s-th union element
-                        common[k] += (uint32_t)__popcll(an);
-                        pu[k] += pun;
-                        if (F == s) { done[k] = true; denom[k] = s; }
-                    } else {
-                        // s is reached inside this word
-                        const uint32_t a = T.row0 + ai + k;
-                        const uint32_t ca0 = Acx[w * DN_ROWS + ai + k] & DN_CX_MASK, cb0 = cb0r & DN_CX_MASK;
-                        const uint32_t T0 = dn_resolve(un, pu[k] + ca0 + cb0, s, w, use_lists || ((ca1r | cb1r) & DN_CX_FLAG) != 0,
-                                                       xm + (uint64_t)(G.xrow0 + (a - G.g0)) * wstride * 3ull, xmb,
-                                                       ext + (uint64_t)(G.xrow0 + (a - G.g0)) * xs, xb, ca0, (ca1r & DN_CX_MASK) - ca0, cb0, cb1 - cb0);
-                        common[k] += (uint32_t)__popcll(an & ((1ull << T0) - 1ull));
-                        done[k] = true;
-                        denom[k] = s;
-                    }
-                }
-            }
-            cb0r = cb1r;
-        }
-#pragma unroll
-        for (uint32_t k = 0; k < DN_IL; k++) {
-            if (valid[k]) {
-                const uint32_t a = T.row0 + ai + k;
-                if (!done[k]) {                                           // the union ends before s (short sketches)
-                    const uint32_t total = pu[k] + (Acx[W * DN_ROWS + ai + k] & DN_CX_MASK) + (Bcx[W * 128u + tid] & DN_CX_MASK);
-                    denom[k] = total < s ? total : s;
-                }
-                if (list.rc) {                                            // (uniform) a list job: the tail of row a's list
-                    const uint32_t ra = a - list.row_first;
-                    const uint32_t at = list.row_base[ra] + list.row_cnt[ra] - (a - b);
-                    list.rc[at] = make_uint2(a, b);
-                    list.counts[at] = make_uint2(common[k], denom[k]);
-                } else {
-                    out[dn_out_index(a, b, inv, out_base)] = make_uint2(common[k], denom[k]);
-                }
+            if (list.rc) {                                                // (uniform) a list job: the tail of row a's list
+                const uint32_t ra = a - list.row_first;
+                const uint32_t at = list.row_base[ra] + list.row_cnt[ra] - (a - b);
+                list.rc[at] = make_uint2(a, b);
+                list.counts[at] = make_uint2(common[k], denom);
+            } else {
+                out[dn_out_index(a, b, inv, out_base)] = make_uint2(common[k], denom);
             }
         }
     }
 }
 
 // LDS of a tile: its rows' words and counts
-uint32_t dense_max_words() { return 400; }                 // 32 rows x (8 W + 2 W + 2) bytes
+uint32_t dense_max_words() { return 400; }                 // 32 rows x (8 W + 4 W + 4) bytes
 
-size_t dense_pairs_lds(uint32_t W, uint32_t rows) { return (size_t)rows * W * 8 + (size_t)(W + 1u) * rows * 2 + 16; }
+size_t dense_pairs_lds(uint32_t W, uint32_t rows) { return (size_t)rows * W * 8 + (size_t)(W + 1u) * rows * 4 + 16; }
 
 // rows of a tile: 32 when that still leaves enough tiles to fill the device (a tile is two waves; the rows of a tile are taken
 // one after the other), else 8 -- a collection of small clusters has few column blocks per row block
@@ -517,7 +527,10 @@ hipError_t launch_dense_pairs(const DenseTile *tiles, uint32_t ntiles, uint32_t 
                            out_base, inv, out, list ? *list : DenseList());
         return hipGetLastError();
     };
-    return rows_per_tile == 32u ? go(dn_pairs_kernel<32>) : go(dn_pairs_kernel<8>);
+    uint32_t il = 8;                                       // (measured on one clade of 32 768 rows, warm: 7.8 / 7.3 / 7.2 ms at 4 / 8 / 16)
+    if (const char *e = getenv("MASHGPU_DENSE_IL")) il = (uint32_t)atoi(e);      // (tuning knob)
+    if (rows_per_tile == 32u) return il >= 16u ? go(dn_pairs_kernel<32, 16>) : il >= 8u ? go(dn_pairs_kernel<32, 8>) : go(dn_pairs_kernel<32, 4>);
+    return il >= 8u ? go(dn_pairs_kernel<8, 8>) : go(dn_pairs_kernel<8, 4>);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -625,6 +638,36 @@ hipError_t launch_dense_gather_rows(const uint64_t *hashes, uint64_t stride, con
 {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(cl_gather_rows_kernel, dim3(n), dim3(256), 0, stream, hashes, stride, inv, out);
+    return hipGetLastError();
+}
+
+// Per row of the table the candidate group it stands in: grp_of[r] (0xFFFFFFFF: none) and lead_rows[r] = {group, its first
+// row, one past its last, 0} -- what the index build's leader search gathers per entry (IxLeaders).  groups: disjoint,
+// ascending.  (Made here from the few groups: 20 bytes per row that the host neither fills nor copies.)
+__global__ __launch_bounds__(256) void dn_group_rows_kernel(const DenseGroup *groups, uint32_t ng, uint32_t n, uint32_t *grp_of, uint4 *lead_rows)
+{
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= n) return;
+    uint32_t lo = 0, hi = ng;                            // the groups below lo start at or before r, those from hi on behind it
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (groups[mid].g0 <= r) lo = mid + 1u;
+        else hi = mid;
+    }
+    uint32_t g = 0xFFFFFFFFu, g0 = 0, g1 = 0;
+    if (lo > 0 && r < groups[lo - 1u].g1) {
+        g = lo - 1u;
+        g0 = groups[g].g0;
+        g1 = groups[g].g1;
+    }
+    grp_of[r] = g;
+    lead_rows[r] = make_uint4(g, g0, g1, 0u);
+}
+
+hipError_t launch_dense_group_rows(const DenseGroup *groups, uint32_t ng, uint32_t n, uint32_t *grp_of, uint32_t *lead_rows, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(dn_group_rows_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, groups, ng, n, grp_of, reinterpret_cast<uint4 *>(lead_rows));
     return hipGetLastError();
 }
 

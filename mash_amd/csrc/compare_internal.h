@@ -133,6 +133,9 @@ hipError_t launch_sparse_row_digest(const uint64_t *hashes, uint64_t stride, con
 hipError_t launch_sparse_row_equal(const uint64_t *hashes, uint64_t stride, const uint32_t *cnt, const uint2 *pairs, uint32_t npairs,
                                    uint32_t *equal, hipStream_t stream);
 hipError_t launch_sparse_row_counts(const uint32_t *nhash, uint32_t n, uint32_t cap, uint32_t *cnt, hipStream_t stream);
+// off[0 .. n]: exclusive prefix of cnt[inv[a]] (inv == nullptr: cnt[a]) -- no row kept out of the index
+size_t sparse_offsets_temp_bytes(uint32_t n);
+hipError_t launch_sparse_offsets(const uint32_t *cnt, const uint32_t *inv, uint32_t n, void *temp, uint32_t *off, hipStream_t stream);
 size_t sparse_sort_temp_bytes(uint32_t E, uint32_t end_bit, uint32_t begin_bit);
 uint32_t sparse_img_stride(uint32_t s);          // row stride of a code image
 hipError_t sparse_build_index(const uint64_t *hashes, uint64_t stride, const uint32_t *off, uint32_t n, uint32_t E,
@@ -181,6 +184,12 @@ struct DenseGroup {
     uint64_t data_off;             // first block of the group in gdata (u64 words); a block = 128 rows: W x 128 u64 + (W + 1) x 128 u16
 };
 struct DenseTile { uint32_t group, row0, cblk; };
+// u64 words of a block of 128 rows of a group with W mask words per row: the masks [W][128], then two tables of u16
+// [W + 1][128] -- cx (extras before every word boundary | flag) and tot (ALL the row's values before it: mask bits + extras)
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+static inline uint64_t dense_block_words(uint32_t W) { return 128ull * W + 64ull * (W + 1u); }
 // where a list job wants the pairs inside the groups: the list of row a (reference order: rows ascending, a row's pairs by
 // column) ends with its partners inside its group, so pair (a, b) stands at row_base[a - row_first] + row_cnt[a - row_first] - (a - b)
 struct DenseList {
@@ -216,6 +225,8 @@ hipError_t dense_cluster_rows(const uint64_t *hashes, uint64_t stride, const uin
                               unsigned long long *key_a, unsigned long long *key_b, uint32_t *row_a, uint32_t *row_b, uint32_t *lab_a,
                               uint32_t *lab_b, uint32_t *inv, uint32_t *label_sorted, hipStream_t stream);
 hipError_t launch_dense_gather_rows(const uint64_t *hashes, uint64_t stride, const uint32_t *inv, uint32_t n, uint64_t *out, hipStream_t stream);
+// grp_of[n], lead_rows[4 n] (16-byte aligned) from the candidate groups (disjoint, ascending)
+hipError_t launch_dense_group_rows(const DenseGroup *groups, uint32_t ng, uint32_t n, uint32_t *grp_of, uint32_t *lead_rows, hipStream_t stream);
 
 // Distance filter + ordered compaction (see filter_pass_kernel).  `counts` holds
 // `pairs` entries in the layout the compare kernels write, starting at row

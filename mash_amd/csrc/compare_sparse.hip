@@ -169,6 +169,62 @@ hipError_t launch_sparse_row_counts(const uint32_t *nhash, uint32_t n, uint32_t 
     return hipGetLastError();
 }
 
+// off[a] = entries of the rows in front of row a of the INDEX's order (row a there = table row inv[a]; inv == nullptr: the
+// table's own order), off[n] = all of them.  The host knows these numbers, but an upload from pageable memory holds it
+// until the stream has caught up -- with the offsets made here the build's kernels are queued behind the clustered copy
+// while that is still running.  Two kernels: sums of blocks of 1024 rows; every block then adds up the sums in front of it
+// (n / 1024 numbers) and scans its own rows.
+__global__ __launch_bounds__(1024) void sp_offsets_sums_kernel(const uint32_t *cnt, const uint32_t *inv, uint32_t n, uint32_t *part)
+{
+    __shared__ uint32_t s_part[16];
+    const uint32_t tid = threadIdx.x, a = blockIdx.x * 1024u + tid;
+    uint32_t c = a < n ? cnt[inv ? inv[a] : a] : 0u;
+#pragma unroll
+    for (uint32_t d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
+    if ((tid & 63u) == 0) s_part[tid >> 6] = c;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t t = 0;
+        for (uint32_t k = 0; k < 16u; k++) t += s_part[k];
+        part[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(1024) void sp_offsets_scan_kernel(const uint32_t *cnt, const uint32_t *inv, uint32_t n, const uint32_t *part, uint32_t *off)
+{
+    __shared__ uint32_t s_part[16], s_base[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6, a = blockIdx.x * 1024u + tid;
+    uint32_t before = 0;
+    for (uint32_t k = tid; k < blockIdx.x; k += 1024u) before += part[k];
+#pragma unroll
+    for (uint32_t d = 32; d > 0; d >>= 1) before += __shfl_xor(before, d);
+    if (lane == 0) s_base[wid] = before;
+    const uint32_t c = a < n ? cnt[inv ? inv[a] : a] : 0u;
+    uint32_t incl = c;
+#pragma unroll
+    for (uint32_t d = 1; d < 64u; d <<= 1) {
+        const uint32_t y = __shfl_up(incl, d);
+        if (lane >= d) incl += y;
+    }
+    if (lane == 63u) s_part[wid] = incl;
+    __syncthreads();
+    uint32_t run = incl - c;
+    for (uint32_t k = 0; k < 16u; k++) run += s_base[k] + (k < wid ? s_part[k] : 0u);
+    if (a < n) off[a] = run;
+    if (a + 1u == n) off[n] = run + c;
+}
+
+size_t sparse_offsets_temp_bytes(uint32_t n) { return ((size_t)n / 1024u + 1u) * 4u; }
+
+hipError_t launch_sparse_offsets(const uint32_t *cnt, const uint32_t *inv, uint32_t n, void *temp, uint32_t *off, hipStream_t stream)
+{
+    if (n == 0) return hipMemsetAsync(off, 0, 4, stream);
+    const uint32_t nb = (n + 1023u) / 1024u;
+    hipLaunchKernelGGL(sp_offsets_sums_kernel, dim3(nb), dim3(1024), 0, stream, cnt, inv, n, static_cast<uint32_t *>(temp));
+    hipLaunchKernelGGL(sp_offsets_scan_kernel, dim3(nb), dim3(1024), 0, stream, cnt, inv, n, static_cast<const uint32_t *>(temp), off);
+    return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void sp_fill_u32_kernel(uint32_t *p, uint64_t count, uint32_t v)
 {
     const uint64_t stride = (uint64_t)gridDim.x * 256u;

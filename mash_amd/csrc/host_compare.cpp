@@ -527,15 +527,15 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
     }
     bool cluster_q = false, links_q = false;
     {
+        // Everything is LAUNCHED first and read back behind: a copy into pageable memory holds the host until the stream has
+        // reached it.  (Measured and dropped: the copy suspects -- one large kernel, a small sort -- on a second stream beside
+        // the clustering's two dozen small kernels end 0.18 ms earlier, and the six read-backs at 40 us each give it back.)
         hipError_t e = hipSuccess;
         if (need_classes) {
             hc_cls.resize(n);
             hc_last.resize(n);
             hc_nh.resize(n);
             e = mg::launch_row_classes(t->hashes, t->nhash, n, t->s, dc_cls, dc_last, ctx->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(hc_nh.data(), t->nhash, n * 4, hipMemcpyDeviceToHost, ctx->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(hc_cls.data(), dc_cls, n, hipMemcpyDeviceToHost, ctx->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(hc_last.data(), dc_last, n * 8, hipMemcpyDeviceToHost, ctx->stream);
         }
         // the rows' entry counts min(nhash, s) straight from the table's counts
         if (e == hipSuccess) e = mg::launch_sparse_row_counts(t->nhash, (uint32_t)n, (uint32_t)std::min<uint64_t>(t->s, s), d_cnt, ctx->stream);
@@ -543,7 +543,6 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
             e = mg::launch_sparse_row_digest(t->hashes, t->s, d_cnt, (uint32_t)n, d_dig, ctx->stream);
             if (e == hipSuccess)
                 e = mg::launch_sparse_dup_suspects(d_dig, d_cnt, (uint32_t)n, d_tmp_dup, tb_dup, d_dig_sorted, d_rows_sorted, d_flags, d_nflag, ctx->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(&nflag, d_nflag, 4, hipMemcpyDeviceToHost, ctx->stream);
         }
         if (e == hipSuccess && try_cluster) {
             if (k_a.alloc(4 * n) == hipSuccess && k_b.alloc(4 * n) == hipSuccess && r_a.alloc(4 * n) == hipSuccess && r_b.alloc(4 * n) == hipSuccess &&
@@ -552,8 +551,6 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
                 inv.resize(n);
                 lab_sorted.resize(n);
                 e = mg::dense_cluster_rows(t->hashes, t->s, d_cnt, (uint32_t)n, d_tmp_cl, tb_cl, k_a, k_b, r_a, r_b, l_a, l_b, d_inv, d_lab, ctx->stream);
-                if (e == hipSuccess) e = hipMemcpyAsync(inv.data(), d_inv, n * 4, hipMemcpyDeviceToHost, ctx->stream);
-                if (e == hipSuccess) e = hipMemcpyAsync(lab_sorted.data(), d_lab, n * 4, hipMemcpyDeviceToHost, ctx->stream);
                 cluster_q = true;
             } else {
                 (void)hipGetLastError();                    // no memory for the clustering: the table's own order
@@ -563,12 +560,22 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
             if (d_link.alloc(n) == hipSuccess) {
                 link.resize(n);
                 e = mg::launch_dense_neighbors(t->hashes, t->s, d_cnt, (uint32_t)n, d_link, ctx->stream);
-                if (e == hipSuccess) e = hipMemcpyAsync(link.data(), d_link, n, hipMemcpyDeviceToHost, ctx->stream);
                 links_q = true;
             } else {
                 (void)hipGetLastError();
             }
         }
+        if (e == hipSuccess && need_classes) {
+            e = hipMemcpyAsync(hc_nh.data(), t->nhash, n * 4, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(hc_cls.data(), dc_cls, n, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(hc_last.data(), dc_last, n * 8, hipMemcpyDeviceToHost, ctx->stream);
+        }
+        if (e == hipSuccess && dedup) e = hipMemcpyAsync(&nflag, d_nflag, 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && cluster_q) {
+            e = hipMemcpyAsync(inv.data(), d_inv, n * 4, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(lab_sorted.data(), d_lab, n * 4, hipMemcpyDeviceToHost, ctx->stream);
+        }
+        if (e == hipSuccess && links_q) e = hipMemcpyAsync(link.data(), d_link, n, hipMemcpyDeviceToHost, ctx->stream);
         const hipError_t es = hipStreamSynchronize(ctx->stream);      // (also when something failed: host vectors are targets of copies)
         if (e == hipSuccess) e = es;
         if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare (index: rows, copies, order): ") + hipGetErrorString(e));
@@ -590,10 +597,13 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
     // it were the table
     const uint64_t *H = t->hashes;                          // what the index is built from
     std::vector<uint64_t> last_p;                           // the rows' largest hashes in index order (empty: t->last)
+    bool cnt_stale = false;                                 // d_cnt still holds the counts in the table's order
     if (cluster_q) {
         bool identity = true;
         for (uint64_t a = 0; a < n && identity; a++) identity = inv[a] == a;
         if (!identity) {
+            // (Measured and dropped: this copy queued BEFORE the read-backs above.  They are copies into pageable memory and
+            //  wait for whatever the stream holds in front of them -- the copy kernel included; the build started 0.4 ms later.)
             void *pi = nullptr, *ph = nullptr;
             if (ctx_malloc(ctx, &pi, n * 4) != hipSuccess || ctx_malloc(ctx, &ph, std::max<uint64_t>(n * t->s, 1) * 8) != hipSuccess) {
                 (void)hipGetLastError();
@@ -608,14 +618,21 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
                 cnt_perm.resize(n);
                 last_p.resize(n);
                 for (uint64_t a = 0; a < n; a++) { cnt_perm[a] = cnt_true[inv[a]]; last_p[a] = t->last[inv[a]]; }
-                cnt_true.swap(cnt_perm);                    // (cnt_perm, the table-order counts, lives to the end of the function: no wait for the copy)
-                HIP_TRY(ctx, hipMemcpyAsync(d_cnt, cnt_true.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+                cnt_true.swap(cnt_perm);
+                // (the device's counts follow only if somebody asks -- copy suspects, no clustering to be had: a copy from
+                //  pageable memory waits for the gather in front of it, and the host has the index to plan meanwhile)
+                cnt_stale = true;
             }
         }
     } else {
         lab_sorted.clear();
     }
     const std::vector<uint64_t> &lastv = last_p.empty() ? t->last : last_p;
+    auto counts_to_device = [&]() -> hipError_t {
+        if (!cnt_stale) return hipSuccess;
+        cnt_stale = false;
+        return hipMemcpyAsync(d_cnt, cnt_true.data(), n * 4, hipMemcpyHostToDevice, ctx->stream);
+    };
     // which neighbouring rows are near-copies of each other (dense groups, compare_dense.hip)
     if (want_dense && n >= 8 && s <= 16384 && !lab_sorted.empty()) {
         link.assign(n, 0);                                  // clustered variant: neighbours with the same label
@@ -623,6 +640,7 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
     } else if (cluster_q && want_dense && n >= 8 && s <= 16384 && d_link.alloc(n) == hipSuccess) {
         // (the clustering was asked for and came to nothing: the neighbours of the table's own order after all)
         link.resize(n);
+        HIP_TRY(ctx, counts_to_device());
         HIP_TRY(ctx, mg::launch_dense_neighbors(H, t->s, d_cnt, (uint32_t)n, d_link, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(link.data(), d_link, n, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -632,6 +650,7 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
     }
     if (dedup && nflag) {
         // suspects: the digests again, of the rows the index will be built from and in its order
+        HIP_TRY(ctx, counts_to_device());
         HIP_TRY(ctx, mg::launch_sparse_row_digest(H, t->s, d_cnt, (uint32_t)n, d_dig, ctx->stream));
         HIP_TRY(ctx, mg::launch_sparse_dup_suspects(d_dig, d_cnt, (uint32_t)n, d_tmp_dup, tb_dup, d_dig_sorted, d_rows_sorted, d_flags, d_nflag, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(&nflag, d_nflag, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -738,14 +757,18 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
     // Known before the index exists, so the build by tiles looks for their leaders while it has every group of equal values in
     // LDS (index_build.h, IxLeaders); the build by the sort searches the finished index for them (dense_find_leaders).
     std::vector<mg::DenseGroup> cand_groups;
-    std::vector<uint32_t> grp_of_h, lead_rows_h;
+    std::vector<uint32_t> grp_of_h;
     DevBuf<mg::DenseGroup> d_groups(ctx);
     DevBuf<uint32_t> d_grp_of(ctx), d_lead_rows(ctx), d_val(ctx), d_valj(ctx), d_cnt_sub(ctx), d_off_sub(ctx), d_nlead(ctx);
     DevBuf<unsigned long long> d_key(ctx), d_keyj(ctx);
     const uint32_t lead_lists = mg::dense_sublists();
     uint32_t lead_tot[2] = {0, 0}, lead_cap = std::max<uint32_t>(E / 4u / lead_lists + 64u, 256u);
     bool lead_ready = false, lead_done = false;
-    if (!link.empty() && sp->copies == 0) {
+    bool cand_prepared = false;
+    auto prepare_candidates = [&]() {
+        if (cand_prepared) return;
+        cand_prepared = true;
+        if (link.empty() || sp->copies != 0) return;
         for (uint64_t i = 1; i < n;) {
             if (!link[i]) { i++; continue; }
             uint64_t j = i;
@@ -757,33 +780,26 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
             }
             i = j + 1;
         }
-        if (!cand_groups.empty()) {
-            const uint32_t ng = (uint32_t)cand_groups.size();
-            grp_of_h.assign(n, 0xFFFFFFFFu);
-            lead_rows_h.assign(4 * n, 0u);                  // per row {group, its first row, one past its last, 0}: what K4 gathers
-            for (uint64_t r = 0; r < n; r++) lead_rows_h[4 * r] = 0xFFFFFFFFu;
-            for (uint32_t g = 0; g < ng; g++)
-                for (uint32_t r = cand_groups[g].g0; r < cand_groups[g].g1; r++) {
-                    grp_of_h[r] = g;
-                    lead_rows_h[4ull * r] = g;
-                    lead_rows_h[4ull * r + 1] = cand_groups[g].g0;
-                    lead_rows_h[4ull * r + 2] = cand_groups[g].g1;
-                }
-            const uint64_t room = (uint64_t)lead_lists * lead_cap;
-            if (d_groups.alloc(ng) == hipSuccess && d_grp_of.alloc(n) == hipSuccess && d_lead_rows.alloc(4 * n) == hipSuccess && d_nlead.alloc(2) == hipSuccess && d_cnt_sub.alloc(lead_lists) == hipSuccess &&
-                d_off_sub.alloc(lead_lists) == hipSuccess && d_key.alloc(room) == hipSuccess && d_val.alloc(room) == hipSuccess && d_keyj.alloc(room) == hipSuccess &&
-                d_valj.alloc(room) == hipSuccess &&
-                hipMemcpyAsync(d_groups, cand_groups.data(), ng * sizeof(mg::DenseGroup), hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
-                hipMemcpyAsync(d_grp_of, grp_of_h.data(), n * 4, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
-                hipMemcpyAsync(d_lead_rows, lead_rows_h.data(), n * 16, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
-                hipMemsetAsync(d_cnt_sub, 0, lead_lists * 4, ctx->stream) == hipSuccess && hipMemsetAsync(d_nlead, 0, 8, ctx->stream) == hipSuccess) {
-                lead_ready = true;
-            } else {
-                (void)hipGetLastError();
-                cand_groups.clear();                        // no room: no dense groups
-            }
+        if (cand_groups.empty()) return;
+        const uint32_t ng = (uint32_t)cand_groups.size();
+        grp_of_h.assign(n, 0xFFFFFFFFu);
+        for (uint32_t g = 0; g < ng; g++)
+            for (uint32_t r = cand_groups[g].g0; r < cand_groups[g].g1; r++) grp_of_h[r] = g;
+        // the device's copies -- every row's group, and per row {group, its first row, one past its last, 0}: what K4
+        // gathers -- are made there from the groups (dn_group_rows_kernel)
+        const uint64_t room = (uint64_t)lead_lists * lead_cap;
+        if (d_groups.alloc(ng) == hipSuccess && d_grp_of.alloc(n) == hipSuccess && d_lead_rows.alloc(4 * n) == hipSuccess && d_nlead.alloc(2) == hipSuccess && d_cnt_sub.alloc(lead_lists) == hipSuccess &&
+            d_off_sub.alloc(lead_lists) == hipSuccess && d_key.alloc(room) == hipSuccess && d_val.alloc(room) == hipSuccess && d_keyj.alloc(room) == hipSuccess &&
+            d_valj.alloc(room) == hipSuccess &&
+            hipMemcpyAsync(d_groups, cand_groups.data(), ng * sizeof(mg::DenseGroup), hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+            mg::launch_dense_group_rows(d_groups, ng, (uint32_t)n, d_grp_of, d_lead_rows, ctx->stream) == hipSuccess &&
+            hipMemsetAsync(d_cnt_sub, 0, lead_lists * 4, ctx->stream) == hipSuccess && hipMemsetAsync(d_nlead, 0, 8, ctx->stream) == hipSuccess) {
+            lead_ready = true;
+        } else {
+            (void)hipGetLastError();
+            cand_groups.clear();                            // no room: no dense groups
         }
-    }
+    };
     mg::IxPlan plan;
     // (One clade of many thousands of rows: every value of its pool has more holders than a bucket's LDS sort takes, so the
     //  whole index goes through the two-level sort of the big buckets -- correct, but measured 0.5 ms behind the general
@@ -800,7 +816,8 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
     }
     if (ix_tiles && !tiles_hopeless) plan = mg::index_plan((uint32_t)n, E, s, sp->rs, t->s, maxv, dens0, ix_verify);
     else if (tiles_hopeless) plan.why = "a clade of more rows than a bucket's sort takes";
-    const size_t temp_bytes = std::max(mg::sparse_order_temp_bytes((uint32_t)n), mg::sparse_order_slice_temp_bytes((uint32_t)n));
+    const size_t temp_bytes = std::max(std::max(mg::sparse_order_temp_bytes((uint32_t)n), mg::sparse_order_slice_temp_bytes((uint32_t)n)),
+                                       mg::sparse_offsets_temp_bytes((uint32_t)n));
     DevBuf<unsigned char> temp(ctx);
     DevBuf<uint32_t> gs_of(ctx);
     DevBuf<unsigned long long> key64_a(ctx), key64_b(ctx);
@@ -837,7 +854,10 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
         if (e == hipSuccess) e = hipMemcpyAsync(sp->cls_first, cls_first.data(), cls_first.size() * 4, hipMemcpyHostToDevice, ctx->stream);
     }
     if (ok && e == hipSuccess) {
-        e = hipMemcpyAsync(sp->off, sp->off_host.data(), (n + 1) * 4, hipMemcpyHostToDevice, ctx->stream);
+        // the rows' offsets: made on the device from its counts (sp_offsets_kernel) unless copies stay out of the index
+        // (its temporary: the ordering's, not in use before the index stands)
+        if (rep.empty()) e = mg::launch_sparse_offsets(d_cnt, cnt_stale ? sp->inv : nullptr, (uint32_t)n, temp, sp->off, ctx->stream);
+        else e = hipMemcpyAsync(sp->off, sp->off_host.data(), (n + 1) * 4, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess && nshort) e = hipMemcpyAsync(sp->short_rows, sp->short_rows_host.data(), nshort * 4, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess && nshort) e = hipMemcpyAsync(sp->short_cnt, short_cnt.data(), nshort * 4, hipMemcpyHostToDevice, ctx->stream);
     }
@@ -851,10 +871,15 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
     };
     bool built = false;
     if (ok && e == hipSuccess && plan.ok) {
-        DevBuf<unsigned char> d_lb(ctx), d_cnt(ctx), d_start(ctx), d_big(ctx), d_pk(ctx), d_tc(ctx);
-        if (d_lb.alloc(plan.lb_bytes) == hipSuccess && d_cnt.alloc(plan.cnt_bytes) == hipSuccess && d_start.alloc(plan.start_bytes) == hipSuccess &&
+        DevBuf<unsigned char> d_lb(ctx), d_tcnt(ctx), d_start(ctx), d_big(ctx), d_pk(ctx), d_tc(ctx);
+        if (d_lb.alloc(plan.lb_bytes) == hipSuccess && d_tcnt.alloc(plan.cnt_bytes) == hipSuccess && d_start.alloc(plan.start_bytes) == hipSuccess &&
             d_big.alloc(plan.big_bytes) == hipSuccess && d_pk.alloc(plan.pk_bytes) == hipSuccess && d_tc.alloc(plan.tc_bytes) == hipSuccess) {
             e = hipMemsetAsync(d_stat, 0, sizeof(Stat), ctx->stream);
+            // the partition (K0 - K3) goes first: the host lays out the candidates for dense groups while it runs
+            if (e == hipSuccess)
+                e = mg::index_build(plan, H, sp->off, d_lb, d_tcnt, d_start, d_big, d_pk, d_tc, sp->keys_sorted, sp->sorted_rows, sp->gend, gs_of, sp->code_img,
+                                    sp->pos_img, d_slots, &d_stat.p->shared, &d_stat.p->max_group, &d_stat.p->groups, d_stat.p->ixf, nullptr, ctx->stream, 1);
+            prepare_candidates();
             mg::IxLeaders lead;
             if (lead_ready) {
                 lead.grp_of = d_lead_rows;
@@ -868,9 +893,9 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
             // back and marked with an event; the images (K5) and the rows' visiting order are queued behind, and the host waits
             // for the EVENT -- it lays out the dense groups while the images are still being written.
             if (e == hipSuccess)
-                e = mg::index_build(plan, H, sp->off, d_lb, d_cnt, d_start, d_big, d_pk, d_tc, sp->keys_sorted, sp->sorted_rows, sp->gend, gs_of, sp->code_img,
+                e = mg::index_build(plan, H, sp->off, d_lb, d_tcnt, d_start, d_big, d_pk, d_tc, sp->keys_sorted, sp->sorted_rows, sp->gend, gs_of, sp->code_img,
                                     sp->pos_img, d_slots, &d_stat.p->shared, &d_stat.p->max_group, &d_stat.p->groups, d_stat.p->ixf,
-                                    lead_ready ? &lead : nullptr, ctx->stream, 1);
+                                    lead_ready ? &lead : nullptr, ctx->stream, 2);
             if (e == hipSuccess && lead_ready) {             // the leaders' lists made one; their count comes back with the statistics
                 e = mg::dense_join_leaders(d_key, d_val, lead_cap, d_keyj, d_valj, d_cnt_sub, d_off_sub, d_nlead, ctx->stream);
                 if (e == hipSuccess) e = hipMemcpyAsync(lead_tot, d_nlead, 8, hipMemcpyDeviceToHost, ctx->stream);
@@ -880,9 +905,9 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
             if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_stats, hipEventDisableTiming);
             if (e == hipSuccess) e = hipEventRecord(ev_stats, ctx->stream);
             if (e == hipSuccess)
-                e = mg::index_build(plan, H, sp->off, d_lb, d_cnt, d_start, d_big, d_pk, d_tc, sp->keys_sorted, sp->sorted_rows, sp->gend, gs_of, sp->code_img,
+                e = mg::index_build(plan, H, sp->off, d_lb, d_tcnt, d_start, d_big, d_pk, d_tc, sp->keys_sorted, sp->sorted_rows, sp->gend, gs_of, sp->code_img,
                                     sp->pos_img, d_slots, &d_stat.p->shared, &d_stat.p->max_group, &d_stat.p->groups, d_stat.p->ixf,
-                                    lead_ready ? &lead : nullptr, ctx->stream, 2);
+                                    lead_ready ? &lead : nullptr, ctx->stream, 4);
             if (e == hipSuccess && want_order)
                 e = mg::launch_sparse_row_order(sp->off, sp->code_img, sp->gend, sp->rep, (uint32_t)n, sp->rs, temp, temp_bytes, key64_a, key64_b,
                                                 sp->order, ctx->stream);
@@ -906,6 +931,7 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
         fprintf(stderr, "compare sparse: index by tiles refused: %s\n", plan.why);
     }
     sp->by_tiles = built;
+    prepare_candidates();                                   // (no tiles: the candidates are still to be laid out)
 #ifdef IX_PHASE_CLOCKS
     if (built && ctx_opt(ctx, "MASHGPU_IX_CLOCKS")) mg::index_dump_clocks();
 #endif
@@ -1054,6 +1080,9 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
             }
             sp->ulist = static_cast<uint32_t *>(ul);
             sp->upos = static_cast<uint32_t *>(up);
+            // (Measured and dropped: this sort -- two dozen small kernels that need the leaders only -- on a second stream beside
+            //  the images' kernel.  The large kernel holds every CU: a 4 us memset took 170 us there, and the sort ended when it
+            //  would have ended behind the images.)
             e2 = hipMemsetAsync(d_us, 0, ng * 4, ctx->stream);
             if (e2 == hipSuccess) e2 = hipMemsetAsync(d_ue, 0, ng * 4, ctx->stream);
             if (e2 == hipSuccess)
@@ -1078,7 +1107,7 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
                 G.data_off = words;
                 const uint64_t m = G.g1 - G.g0;
                 xrows += (uint32_t)m;
-                words += ((m + 127) / 128) * (128ull * G.W + 32ull * (G.W + 1u));
+                words += ((m + 127) / 128) * mg::dense_block_words(G.W);
                 wmax = std::max(wmax, G.W);
                 for (uint32_t r = G.g0; r < G.g1; r++) grp_of[r] = (uint32_t)sp->dgroups_host.size();
                 sp->dgroups_host.push_back(G);

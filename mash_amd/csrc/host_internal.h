@@ -47,9 +47,6 @@ struct mg_ctx {
     std::vector<ProfRec> prof_compare, prof_sketch;
     // phases of the inverted-index compare engine (compare_sparse.hip), each its own kernel
     std::vector<ProfRec> prof_fill, prof_discover, prof_merge, prof_index, prof_dense;
-    // its fill runs on a stream of its own beside discover + merge (HBM-write bound vs latency bound)
-    hipStream_t aux = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // Entry points lock the context: any number of host threads may drive one context, one call at
     // a time (SURVEY 8b "thread-safe per ctx"); recursive because entry points call each other.
     std::recursive_mutex mu;

@@ -78,9 +78,10 @@ size_t index_stat_scratch_bytes();
 hipError_t index_build(const IxPlan &plan, const uint64_t *hashes, const uint32_t *off, void *lb, void *cnt, void *start, void *big, void *pk, void *tc,
                        uint64_t *keys_sorted, uint32_t *sorted_rows, uint32_t *gend, uint32_t *gs_of, uint32_t *code_img, uint32_t *pos_img,
                        void *stat_scratch, unsigned long long *incidences, uint32_t *max_group, uint32_t *groups, uint32_t *flags,
-                       const IxLeaders *leaders, hipStream_t stream, int stages = 3);
-// stages: 1 = everything up to the bucket sorts (values, rows, groups, statistics, leaders are final behind it), 2 = the images
-// (K5); a caller that wants the statistics while the images are still being written queues its copy between the two
+                       const IxLeaders *leaders, hipStream_t stream, int stages = 7);
+// stages (bits): 1 = the partition (K0 - K3; needs neither the statistics' memory nor the leaders'), 2 = the bucket sorts (K4, K4b:
+// values, rows, groups, statistics, leaders are final behind them), 4 = the images (K5).  A caller prepares the leader search
+// while stage 1 runs, and queues its copy of the statistics between stages 2 and 4.
 
 // MASHGPU_SPARSE_INDEX=verify: out2[0] += words of a and b that differ, out2[1] = min(out2[1], the first such word);
 // mode 0: all words, 1: where cond[i] == i, 2: where cond[i] != 0xFFFFFFFF

@@ -540,9 +540,13 @@ constexpr uint32_t IX4_PK = 0, IX4_JX = IX4_PK + IX_CAP * 8u, IX4_H = IX4_JX + I
 // PART: the entries are a PART of a big bucket (ix_big_bucket_kernel): src[j] is the part's j-th word, arr[j] its place in
 // the order the BUCKET's entries arrived in (tc is indexed by that, from tcbase), and src / arr are the output arrays'
 // own memory (read completely before anything is written).  false: the table was flagged, leave.
+// (a whole bucket's entries come from pk and nothing written here is read again: the compiler may know)
+template <bool PART> struct IxBodyPtr { using In = const uint64_t *__restrict__; using Keys = uint64_t *__restrict__; using Rows = uint32_t *__restrict__; };
+template <> struct IxBodyPtr<true> { using In = const uint64_t *; using Keys = uint64_t *; using Rows = uint32_t *; };
+
 template <uint32_t PER, bool PART>
-__device__ __forceinline__ bool ix_bucket_sort_body(const IxGeom &g, const uint64_t *src, const uint32_t *arr, uint32_t tcbase, uint32_t subshift,
-                                                    uint64_t *keys_sorted, uint32_t *sorted_rows, uint32_t *__restrict__ gend,
+__device__ __forceinline__ bool ix_bucket_sort_body(const IxGeom &g, typename IxBodyPtr<PART>::In src, const uint32_t *arr, uint32_t tcbase, uint32_t subshift,
+                                                    typename IxBodyPtr<PART>::Keys keys_sorted, typename IxBodyPtr<PART>::Rows sorted_rows, uint32_t *__restrict__ gend,
                                                     uint32_t *__restrict__ gs_of, uint2 *__restrict__ tc, IxStatSlot *stat, uint32_t *flags,
                                                     const IxLeaders &lead, uint64_t *s_pk, uint16_t *s_jx, uint32_t *s_h, uint32_t *s_mixed,
                                                     uint32_t *s_part, uint32_t b, uint32_t G0, uint32_t N)
@@ -1245,6 +1249,7 @@ hipError_t index_build(const IxPlan &plan, const uint64_t *hashes, const uint32_
                        void *stat_scratch, unsigned long long *incidences, uint32_t *max_group, uint32_t *groups, uint32_t *flags,
                        const IxLeaders *leaders, hipStream_t stream, int stages)
 {
+    // (leaders: looked at by stage 2 only)
     if (!plan.ok) return hipErrorInvalidValue;
     const IxGeom g = plan.g;
     uint16_t *lb = static_cast<uint16_t *>(lb_v);
@@ -1254,8 +1259,6 @@ hipError_t index_build(const IxPlan &plan, const uint64_t *hashes, const uint32_
     hipError_t e = hipSuccess;
     if (stages & 1) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(ix_tile_partition_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)IXL_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(ix_bucket_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)IX4_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(ix_big_bucket_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)IXB_BYTES);
         if (e != hipSuccess) return e;
         const uint32_t tiles = 8u * ((g.nseq + 7u) / 8u);
         hipLaunchKernelGGL(ix_window_offsets_kernel, dim3((g.n + 3u) / 4u), dim3(256), 0, stream, g, hashes, off, lb);
@@ -1268,6 +1271,11 @@ hipError_t index_build(const IxPlan &plan, const uint64_t *hashes, const uint32_
                            (const uint32_t *)start, (const uint32_t *)flags, pk, pos_img);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
+    }
+    if (stages & 2) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(ix_bucket_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)IX4_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(ix_big_bucket_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)IXB_BYTES);
+        if (e != hipSuccess) return e;
         e = hipMemsetAsync(stat_scratch, 0, index_stat_scratch_bytes(), stream);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(ix_bucket_sort_kernel, dim3(g.Bp), dim3(IX_NT4), IX4_BYTES, stream, g, (const uint64_t *)pk, (const uint32_t *)start, keys_sorted,
@@ -1279,7 +1287,7 @@ hipError_t index_build(const IxPlan &plan, const uint64_t *hashes, const uint32_
                            static_cast<IxStatSlot *>(stat_scratch), flags, leaders ? *leaders : IxLeaders());
         hipLaunchKernelGGL(ix_stat_reduce_kernel, dim3(1), dim3(256), 0, stream, static_cast<const IxStatSlot *>(stat_scratch), incidences, max_group, groups);
     }
-    if (!(stages & 2)) return hipGetLastError();
+    if (!(stages & 4)) return hipGetLastError();
     {
         const uint32_t nchunk = (g.rs + IX5_CH - 1u) / IX5_CH;
         const uint32_t pieces = 8u * ((g.nblk * nchunk + 7u) / 8u);

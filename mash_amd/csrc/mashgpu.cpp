@@ -189,9 +189,6 @@ void mg_ctx_destroy(mg_ctx *ctx)
     }
     ctx_trim(ctx);
     for (auto &b : ctx->blk_live) hipFree(b.p);
-    if (ctx->aux) hipStreamDestroy(ctx->aux);
-    if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
-    if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }

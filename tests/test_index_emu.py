@@ -28,9 +28,19 @@ def emu(tmp_path_factory):
     return exe
 
 
+@pytest.fixture(scope="module")
+def fast_runs(emu):
+    """every fast case as a process of its own, a few at a time (a case is one thread of context switches: seconds to half a minute)"""
+    from concurrent.futures import ThreadPoolExecutor
+    def run(case):
+        return subprocess.run([emu, case], capture_output=True, text=True, timeout=900)
+    with ThreadPoolExecutor(max_workers=max(1, min(8, (os.cpu_count() or 2) // 2))) as ex:
+        return dict(zip(FAST, ex.map(run, FAST)))
+
+
 @pytest.mark.parametrize("case", FAST)
-def test_index_kernels_on_the_cpu(emu, case):
-    r = subprocess.run([emu, case], capture_output=True, text=True, timeout=600)
+def test_index_kernels_on_the_cpu(fast_runs, case):
+    r = fast_runs[case]
     assert r.returncode == 0 and "all cases agree" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
