@@ -227,9 +227,11 @@ hipError_t dense_sort_universes(const unsigned long long *key, const uint32_t *v
 //    OUTSIDE the group only (the pairs inside are this file's), and rows ascend inside a run;
 //  * any other value is held by no other row of the group (its run is untouched: whoever holds it lies outside) and is
 //    an EXTRA, recorded by its gap -- the number of universe values below it: in order in `ext`, counted per word in
-//    cx, and per word as three bit masks over the gap's offset in the word (xm: bit o of mask j set = at least j + 1
-//    extras at offset o), which is what the resolve step of dn_pairs_kernel counts with; a word with a fourth extra in
-//    one gap is flagged (bit 15 of the word's cx entry) and resolved from the list instead.
+//    cx, and per word as four bit PLANES over the gap's offset in the word (xm: bit o of plane j = bit j of the number
+//    of extras at offset o), which is what the resolve step of dn_pairs_kernel counts with; a word with sixteen extras
+//    in one gap is flagged (bit 15 of the word's cx entry) and resolved from the list instead.  (Rounds 4-5a kept three
+//    unary masks -- up to three extras per gap.  Loosely related clusters have dozens of extras per word: every word of
+//    C3 was flagged, and the list walk was 3 000 instructions per pair.)
 constexpr uint32_t DN_CX_MASK = 0x7FFFu, DN_CX_FLAG = 0x8000u;           // cx: a count (<= s <= 16384) | flag
 
 __global__ __launch_bounds__(256) void dn_encode_kernel(const uint32_t *off, const uint32_t *code_img, uint32_t *pos_img, uint32_t rs,
@@ -237,16 +239,16 @@ __global__ __launch_bounds__(256) void dn_encode_kernel(const uint32_t *off, con
                                                         const uint32_t *upos, unsigned long long *gdata, unsigned long long *xm,
                                                         uint32_t wstride, uint16_t *ext, uint32_t xs, uint32_t n, uint32_t ul_in_lds)
 {
-    extern __shared__ uint32_t lds[];      // [2 W] mask halves, [W + 1] extras per word, [6 W] xm halves, [W] overflow flags, [8] scratch, [u] the universe
+    extern __shared__ uint32_t lds[];      // [2 W] mask halves, [W + 1] extras per word, [16 W] extras per gap (bytes), [W] overflow flags, [8 W] plane halves, [8] scratch, [u] the universe
     const uint32_t row = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
     if (row >= n) return;
     const uint32_t g = grp_of[row];
     if (g == 0xFFFFFFFFu) return;                        // uniform
     const DenseGroup G = groups[g];
     const uint32_t W = G.W, u = G.u;
-    uint32_t *mask32 = lds, *hist = lds + 2u * W, *xm32 = hist + W + 1u, *ovf = xm32 + 6u * W, *scr = ovf + W;
-    uint32_t *ull = lds + 10u * wstride + 9u;
-    for (uint32_t i = tid; i < 10u * W + 1u; i += 256u) lds[i] = 0;
+    uint32_t *mask32 = lds, *hist = lds + 2u * W, *gap8 = hist + W + 1u, *ovf = gap8 + 16u * W, *pl32 = ovf + W, *scr = pl32 + 8u * W;
+    uint32_t *ull = lds + 28u * wstride + 9u;
+    for (uint32_t i = tid; i < 28u * W + 1u; i += 256u) lds[i] = 0;
     const uint32_t *ulg = ulist + G.ustart, *up = upos + G.ustart;
     if (ul_in_lds)
         for (uint32_t i = tid; i < u; i += 256u) ull[i] = ulg[i];
@@ -286,16 +288,31 @@ __global__ __launch_bounds__(256) void dn_encode_kernel(const uint32_t *off, con
         if (extra) {
             xrow[nx + woff + before] = (uint16_t)idx;
             atomicAdd(&hist[idx >> 6], 1u);
-            // the extra's offset in its word, into the first of the word's three masks that does not hold it yet
-            const uint32_t w = idx >> 6, o = idx & 63u, half = o >> 5, bit = 1u << (o & 31u);
-            uint32_t *m3 = xm32 + 6u * w + half;         // masks 0, 1, 2 of word w: halves at +0/+1, +2/+3, +4/+5
-            if (atomicOr(&m3[0], bit) & bit)
-                if (atomicOr(&m3[2], bit) & bit)
-                    if (atomicOr(&m3[4], bit) & bit) ovf[w] = 1u;
+            // ... and per gap: a byte each (a word with 256 extras and more is flagged whatever its bytes say, see below)
+            atomicAdd(&gap8[idx >> 2], 1u << (8u * (idx & 3u)));
         }
         nx += total;
         __syncthreads();                                 // scr is reused
     }
+    __syncthreads();
+    unsigned long long *xrow4 = xm + ((uint64_t)(G.xrow0 + (row - G.g0)) * wstride) * 4ull;      // (every row has room for the widest universe)
+    for (uint32_t i = tid; i < 16u * W; i += 256u) {      // the gaps' counts as four bit planes: a work-item takes four gaps
+        const uint32_t four = gap8[i], w = i >> 4, q = i & 15u;
+        uint32_t bits[4] = {0u, 0u, 0u, 0u}, over = 0;
+#pragma unroll
+        for (uint32_t e = 0; e < 4u; e++) {
+            const uint32_t c = (four >> (8u * e)) & 255u;
+            over |= c >= 16u ? 1u : 0u;
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; j++) bits[j] |= ((c >> j) & 1u) << ((4u * q + e) & 31u);
+        }
+        if (over || (q == 0 && hist[w] >= 256u)) ovf[w] = 1u;
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; j++)
+            if (bits[j]) atomicOr(&pl32[2u * (4u * w + j) + (q >> 3)], bits[j]);
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < 4u * W; i += 256u) xrow4[i] = (unsigned long long)pl32[2u * i] | ((unsigned long long)pl32[2u * i + 1u] << 32);
     __syncthreads();
     const uint32_t jb = (row - G.g0) >> 7, bl = (row - G.g0) & 127u;
     const uint64_t bw = dense_block_words(W);
@@ -312,13 +329,8 @@ __global__ __launch_bounds__(256) void dn_encode_kernel(const uint32_t *off, con
             }
         }
     }
-    unsigned long long *xrow3 = xm + ((uint64_t)(G.xrow0 + (row - G.g0)) * wstride) * 3ull;      // (every row has room for the widest universe)
-    for (uint32_t w = tid; w < W; w += 256u) {
+    for (uint32_t w = tid; w < W; w += 256u)
         blk[w * 128u + bl] = (unsigned long long)mask32[2u * w] | ((unsigned long long)mask32[2u * w + 1u] << 32);
-#pragma unroll
-        for (uint32_t k = 0; k < 3u; k++)
-            xrow3[3ull * w + k] = (unsigned long long)xm32[6u * w + 2u * k] | ((unsigned long long)xm32[6u * w + 2u * k + 1u] << 32);
-    }
 }
 
 hipError_t launch_dense_encode(const uint32_t *off, const uint32_t *code_img, uint32_t *pos_img, uint32_t rs, const uint32_t *grp_of,
@@ -327,7 +339,7 @@ hipError_t launch_dense_encode(const uint32_t *off, const uint32_t *code_img, ui
 {
     if (n == 0) return hipSuccess;
     // the universe in LDS while it fits beside the masks (64 values per word: always, for the widths dense_max_words allows)
-    const size_t fixed = ((size_t)10 * wmax + 9) * 4, with_ul = fixed + (size_t)wmax * 64 * 4;
+    const size_t fixed = ((size_t)28 * wmax + 9) * 4, with_ul = fixed + (size_t)wmax * 64 * 4;
     const bool ul_in_lds = with_ul <= 150 * 1024;
     const size_t smem = ul_in_lds ? with_ul : fixed;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(dn_encode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -358,21 +370,21 @@ __device__ __forceinline__ uint64_t dn_out_index(uint32_t a, uint32_t b, const u
 
 // The word in which the union reaches its s-th element: the smallest bit position t with f(t) >= s, where f(t) = what lies
 // before the word (fprev) + union bits below t + extras of either row with offset <= t; the bits below t are the ones counted.
-// The extras of the word as three masks per row (bit o of mask j: at least j + 1 extras at offset o), or -- a gap of the word
-// holds four and more in one of the rows -- from the rows' lists.
+// The extras of the word as four bit planes per row (bit o of plane j: bit j of the number of extras at offset o), or -- a gap
+// of the word holds sixteen and more in one of the rows -- from the rows' lists.
 __device__ __forceinline__ uint32_t dn_resolve(unsigned long long un, uint32_t fprev, uint32_t s, uint32_t w, bool lists,
                                                const unsigned long long *xma, const unsigned long long *xmb, const uint16_t *xa,
                                                const uint16_t *xb, uint32_t ca0, uint32_t na, uint32_t cb0, uint32_t nb)
 {
     uint32_t lo = 0, hi = 63;
-    if (!lists) {
-        const unsigned long long a0 = xma[3u * w], a1 = xma[3u * w + 1u], a2 = xma[3u * w + 2u];
-        const unsigned long long b0 = xmb[3u * w], b1 = xmb[3u * w + 1u], b2 = xmb[3u * w + 2u];
-        // (two extras in one gap are rare -- a row's extras are a few dozen over a thousand gaps: with none in the whole
-        //  wave a step is three counts instead of seven)
-        if (__ballot((a1 | b1) != 0ull) == 0) {              // uniform  (a third extra implies a second)
+    if (__ballot(lists) == 0) {                              // uniform
+        const unsigned long long a0 = xma[4u * w], a1 = xma[4u * w + 1u], a2 = xma[4u * w + 2u], a3 = xma[4u * w + 3u];
+        const unsigned long long b0 = xmb[4u * w], b1 = xmb[4u * w + 1u], b2 = xmb[4u * w + 2u], b3 = xmb[4u * w + 3u];
+        // (lo = 0, hi = 63: six halvings.  Near-copies have a few dozen extras over a thousand gaps -- with no gap of the
+        //  whole wave holding two, a step is three counts instead of nine)
+        if (__ballot((a1 | a2 | a3 | b1 | b2 | b3) != 0ull) == 0) {      // uniform
 #pragma unroll
-            for (uint32_t step = 0; step < 6u; step++) {      // lo = 0, hi = 63: six halvings
+            for (uint32_t step = 0; step < 6u; step++) {
                 const uint32_t mid = (lo + hi) >> 1;
                 const unsigned long long below = (1ull << mid) - 1ull, upto = (2ull << mid) - 1ull;
                 const uint32_t c = fprev + (uint32_t)__popcll(un & below) + (uint32_t)__popcll(a0 & upto) + (uint32_t)__popcll(b0 & upto);
@@ -380,23 +392,26 @@ __device__ __forceinline__ uint32_t dn_resolve(unsigned long long un, uint32_t f
             }
             return lo;
         }
-        while (lo < hi) {
+#pragma unroll
+        for (uint32_t step = 0; step < 6u; step++) {
             const uint32_t mid = (lo + hi) >> 1;                          // <= 62
             const unsigned long long below = (1ull << mid) - 1ull, upto = (2ull << mid) - 1ull;
-            const uint32_t c = fprev + (uint32_t)__popcll(un & below) + (uint32_t)__popcll(a0 & upto) + (uint32_t)__popcll(a1 & upto) +
-                               (uint32_t)__popcll(a2 & upto) + (uint32_t)__popcll(b0 & upto) + (uint32_t)__popcll(b1 & upto) +
-                               (uint32_t)__popcll(b2 & upto);
+            const uint32_t c = fprev + (uint32_t)__popcll(un & below) + (uint32_t)__popcll(a0 & upto) + (uint32_t)__popcll(b0 & upto) +
+                               2u * ((uint32_t)__popcll(a1 & upto) + (uint32_t)__popcll(b1 & upto)) +
+                               4u * ((uint32_t)__popcll(a2 & upto) + (uint32_t)__popcll(b2 & upto)) +
+                               8u * ((uint32_t)__popcll(a3 & upto) + (uint32_t)__popcll(b3 & upto));
             if (c >= s) hi = mid; else lo = mid + 1u;
         }
-    } else {
-        const uint32_t wbase = w << 6;
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            uint32_t c = fprev + (uint32_t)__popcll(un & ((1ull << mid) - 1ull));
-            for (uint32_t k = 0; k < na; k++) c += ((uint32_t)xa[ca0 + k] - wbase <= mid) ? 1u : 0u;
-            for (uint32_t k = 0; k < nb; k++) c += ((uint32_t)xb[cb0 + k] - wbase <= mid) ? 1u : 0u;
-            if (c >= s) hi = mid; else lo = mid + 1u;
-        }
+        return lo;
+    }
+    // (some lane's word is flagged: every lane takes its rows' lists, which are exact for all)
+    const uint32_t wbase = w << 6;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        uint32_t c = fprev + (uint32_t)__popcll(un & ((1ull << mid) - 1ull));
+        for (uint32_t k = 0; k < na; k++) c += ((uint32_t)xa[ca0 + k] - wbase <= mid) ? 1u : 0u;
+        for (uint32_t k = 0; k < nb; k++) c += ((uint32_t)xb[cb0 + k] - wbase <= mid) ? 1u : 0u;
+        if (c >= s) hi = mid; else lo = mid + 1u;
     }
     return lo;
 }
@@ -434,7 +449,7 @@ __global__ __launch_bounds__(128) void dn_pairs_kernel(const DenseTile *tiles, c
     __syncthreads();
     const uint32_t b = G.g0 + T.cblk * 128u + tid;                         // this lane's column
     const uint16_t *xb = ext + (uint64_t)(G.xrow0 + (b < G.g1 ? b - G.g0 : 0u)) * xs;
-    const unsigned long long *xmb = xm + (uint64_t)(G.xrow0 + (b < G.g1 ? b - G.g0 : 0u)) * wstride * 3ull;
+    const unsigned long long *xmb = xm + (uint64_t)(G.xrow0 + (b < G.g1 ? b - G.g0 : 0u)) * wstride * 4ull;
     // DN_IL rows at a time: the column block's word is loaded once and serves all of them (their words are broadcast reads
     // from LDS), and a wave has several independent pairs per lane in flight instead of one.
     // Per pair and word: the intersection's bits are counted (common), and what the union holds up to the word's end follows
@@ -484,7 +499,7 @@ __global__ __launch_bounds__(128) void dn_pairs_kernel(const DenseTile *tiles, c
                 const uint32_t cb0 = Bcx[w * 128u + tid] & DN_CX_MASK, cb1r = Bcx[(w + 1u) * 128u + tid];
                 const uint32_t fprev = (uint32_t)Atot[w * DN_ROWS + ai + k] + (uint32_t)Btot[w * 128u + tid] - common[k];
                 const uint32_t T0 = dn_resolve(ma | mb, fprev, s, w, use_lists || ((ca1r | cb1r) & DN_CX_FLAG) != 0,
-                                               xm + (uint64_t)(G.xrow0 + (a - G.g0)) * wstride * 3ull, xmb,
+                                               xm + (uint64_t)(G.xrow0 + (a - G.g0)) * wstride * 4ull, xmb,
                                                ext + (uint64_t)(G.xrow0 + (a - G.g0)) * xs, xb, ca0, (ca1r & DN_CX_MASK) - ca0, cb0,
                                                (cb1r & DN_CX_MASK) - cb0);
                 common[k] += (uint32_t)__popcll(ma & mb & ((1ull << T0) - 1ull));

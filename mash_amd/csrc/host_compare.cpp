@@ -1118,7 +1118,7 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
             void *p1 = nullptr, *p2 = nullptr, *p3 = nullptr, *p4 = nullptr, *p5 = nullptr;
             if (ctx_malloc(ctx, &p1, sp->dgroups_host.size() * sizeof(mg::DenseGroup)) != hipSuccess || ctx_malloc(ctx, &p2, n * 4) != hipSuccess ||
                 ctx_malloc(ctx, &p3, words * 8) != hipSuccess || ctx_malloc(ctx, &p4, (size_t)xrows * sp->dn_xs * 2) != hipSuccess ||
-                ctx_malloc(ctx, &p5, (size_t)xrows * wmax * 24) != hipSuccess) {
+                ctx_malloc(ctx, &p5, (size_t)xrows * wmax * 32) != hipSuccess) {
                 (void)hipGetLastError();
                 for (void *q : {p1, p2, p3, p4, p5}) ctx_free(ctx, q);
                 sp->dgroups_host.clear();
