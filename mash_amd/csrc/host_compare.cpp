@@ -516,7 +516,8 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
     DevBuf<unsigned char> d_tmp_dup(ctx), d_tmp_cl(ctx);
     std::vector<uint8_t> hc_cls, link;
     std::vector<uint64_t> hc_last;
-    std::vector<uint32_t> hc_nh, inv, lab_sorted;
+    std::vector<uint32_t> hc_nh, inv_v, lab_v;
+    const uint32_t *inv = nullptr, *lab_sorted = nullptr;   // the clustering's read-backs (pinned memory or the vectors); lab_sorted == nullptr: no labels
     uint32_t nflag = 0;
     const size_t tb_dup = mg::sparse_dup_temp_bytes((uint32_t)n), tb_cl = mg::dense_cluster_temp_bytes((uint32_t)n);
     if (d_cnt.alloc(n) != hipSuccess || (need_classes && (dc_cls.alloc(n) != hipSuccess || dc_last.alloc(n) != hipSuccess)) ||
@@ -548,8 +549,6 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
             if (k_a.alloc(4 * n) == hipSuccess && k_b.alloc(4 * n) == hipSuccess && r_a.alloc(4 * n) == hipSuccess && r_b.alloc(4 * n) == hipSuccess &&
                 l_a.alloc(n) == hipSuccess && l_b.alloc(n) == hipSuccess && d_inv.alloc(n) == hipSuccess && d_lab.alloc(n) == hipSuccess &&
                 d_tmp_cl.alloc(std::max<size_t>(tb_cl, 16)) == hipSuccess) {
-                inv.resize(n);
-                lab_sorted.resize(n);
                 e = mg::dense_cluster_rows(t->hashes, t->s, d_cnt, (uint32_t)n, d_tmp_cl, tb_cl, k_a, k_b, r_a, r_b, l_a, l_b, d_inv, d_lab, ctx->stream);
                 cluster_q = true;
             } else {
@@ -565,19 +564,41 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
                 (void)hipGetLastError();
             }
         }
+        // the read-backs: into one pinned block if there is one -- queued all at once, one wait, then handed to the vectors
+        // that outlive this call -- else straight into the vectors, one blocking copy after the other
+        const size_t pin_bytes = 8 * n + 4 * n + 4 * n + 4 * n + 8 + n + n + 64;
+        unsigned char *pin = static_cast<unsigned char *>(ctx_pinned(ctx, pin_bytes));
+        unsigned long long *p_last = pin ? reinterpret_cast<unsigned long long *>(pin) : nullptr;
+        uint32_t *p_nh = pin ? reinterpret_cast<uint32_t *>(pin + 8 * n) : nullptr, *p_inv = pin ? p_nh + n : nullptr, *p_lab = pin ? p_inv + n : nullptr;
+        uint32_t *p_nflag = pin ? p_lab + n : &nflag;
+        uint8_t *p_cls = pin ? pin + 20 * n + 8 : nullptr, *p_link = pin ? p_cls + n : nullptr;
+        if (!pin) {
+            if (cluster_q) { inv_v.resize(n); lab_v.resize(n); p_inv = inv_v.data(); p_lab = lab_v.data(); }
+            p_nh = hc_nh.data(); p_cls = hc_cls.data(); p_last = reinterpret_cast<unsigned long long *>(hc_last.data()); p_link = link.data();
+        }
         if (e == hipSuccess && need_classes) {
-            e = hipMemcpyAsync(hc_nh.data(), t->nhash, n * 4, hipMemcpyDeviceToHost, ctx->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(hc_cls.data(), dc_cls, n, hipMemcpyDeviceToHost, ctx->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(hc_last.data(), dc_last, n * 8, hipMemcpyDeviceToHost, ctx->stream);
+            e = hipMemcpyAsync(p_nh, t->nhash, n * 4, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(p_cls, dc_cls, n, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(p_last, dc_last, n * 8, hipMemcpyDeviceToHost, ctx->stream);
         }
-        if (e == hipSuccess && dedup) e = hipMemcpyAsync(&nflag, d_nflag, 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && dedup) e = hipMemcpyAsync(p_nflag, d_nflag, 4, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess && cluster_q) {
-            e = hipMemcpyAsync(inv.data(), d_inv, n * 4, hipMemcpyDeviceToHost, ctx->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(lab_sorted.data(), d_lab, n * 4, hipMemcpyDeviceToHost, ctx->stream);
+            e = hipMemcpyAsync(p_inv, d_inv, n * 4, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(p_lab, d_lab, n * 4, hipMemcpyDeviceToHost, ctx->stream);
         }
-        if (e == hipSuccess && links_q) e = hipMemcpyAsync(link.data(), d_link, n, hipMemcpyDeviceToHost, ctx->stream);
-        const hipError_t es = hipStreamSynchronize(ctx->stream);      // (also when something failed: host vectors are targets of copies)
+        if (e == hipSuccess && links_q) e = hipMemcpyAsync(p_link, d_link, n, hipMemcpyDeviceToHost, ctx->stream);
+        const hipError_t es = hipStreamSynchronize(ctx->stream);      // (also when something failed: host memory is the target of copies)
         if (e == hipSuccess) e = es;
+        if (e == hipSuccess && pin) {
+            if (need_classes) {
+                memcpy(hc_nh.data(), p_nh, n * 4);
+                memcpy(hc_cls.data(), p_cls, n);
+                memcpy(hc_last.data(), p_last, n * 8);
+            }
+            if (dedup) nflag = *p_nflag;
+            if (links_q) memcpy(link.data(), p_link, n);
+        }
+        if (cluster_q) { inv = p_inv; lab_sorted = p_lab; }
         if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare (index: rows, copies, order): ") + hipGetErrorString(e));
     }
     if (need_classes) {
@@ -588,15 +609,29 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
     if (!links_q) link.clear();
     std::vector<uint32_t> cnt_true(n), cnt_perm;
     uint32_t max_cnt = 0;
+    uint64_t maxv = 0;
+    double dens[65] = {0};                                  // by bit length of a row's largest hash: values per unit of the hash range
+    double dens0 = 0;                                       // ... and all of them: the density where the table is densest (below every row's largest hash)
+    // (what does not depend on the rows' order is taken here, in the table's: the pass in the index's order below has the
+    //  offsets left.  Copies of earlier rows, if there are any, count towards the densities: a bucket width is all they decide.)
     for (uint64_t i = 0; i < n; i++) {
-        cnt_true[i] = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(t->nh[i], t->s), s);
-        max_cnt = std::max(max_cnt, cnt_true[i]);
+        const uint32_t c = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(t->nh[i], t->s), s);
+        cnt_true[i] = c;
+        max_cnt = std::max(max_cnt, c);
+        if (c) {
+            const uint64_t last = t->last[i];
+            // a real hash equal to the padding value would sort among the padding: keep the tile engine
+            if (last == MG_HASH_PAD) return unusable("a hash equals the padding value");
+            maxv = std::max(maxv, last);
+            const double d = (double)c / ((double)last + 1.0);
+            dens[64 - __builtin_clzll(last | 1ull)] += d;
+            dens0 += d;
+        }
     }
     std::vector<uint32_t> rep;                              // empty: no copies
     // ---- the clustered variant: the table copied in the clustered order; everything below then works on the copy as if
     // it were the table
     const uint64_t *H = t->hashes;                          // what the index is built from
-    std::vector<uint64_t> last_p;                           // the rows' largest hashes in index order (empty: t->last)
     bool cnt_stale = false;                                 // d_cnt still holds the counts in the table's order
     if (cluster_q) {
         bool identity = true;
@@ -608,7 +643,7 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
             if (ctx_malloc(ctx, &pi, n * 4) != hipSuccess || ctx_malloc(ctx, &ph, std::max<uint64_t>(n * t->s, 1) * 8) != hipSuccess) {
                 (void)hipGetLastError();
                 ctx_free(ctx, pi);
-                lab_sorted.clear();                         // no memory for the copy: the table's own order
+                lab_sorted = nullptr;                       // no memory for the copy: the table's own order
             } else {
                 sp->inv = static_cast<uint32_t *>(pi);
                 sp->phashes = static_cast<uint64_t *>(ph);
@@ -616,8 +651,7 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
                 HIP_TRY(ctx, mg::launch_dense_gather_rows(t->hashes, t->s, sp->inv, (uint32_t)n, sp->phashes, ctx->stream));
                 H = sp->phashes;
                 cnt_perm.resize(n);
-                last_p.resize(n);
-                for (uint64_t a = 0; a < n; a++) { cnt_perm[a] = cnt_true[inv[a]]; last_p[a] = t->last[inv[a]]; }
+                for (uint64_t a = 0; a < n; a++) cnt_perm[a] = cnt_true[inv[a]];
                 cnt_true.swap(cnt_perm);
                 // (the device's counts follow only if somebody asks -- copy suspects, no clustering to be had: a copy from
                 //  pageable memory waits for the gather in front of it, and the host has the index to plan meanwhile)
@@ -625,16 +659,15 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
             }
         }
     } else {
-        lab_sorted.clear();
+        lab_sorted = nullptr;
     }
-    const std::vector<uint64_t> &lastv = last_p.empty() ? t->last : last_p;
     auto counts_to_device = [&]() -> hipError_t {
         if (!cnt_stale) return hipSuccess;
         cnt_stale = false;
         return hipMemcpyAsync(d_cnt, cnt_true.data(), n * 4, hipMemcpyHostToDevice, ctx->stream);
     };
     // which neighbouring rows are near-copies of each other (dense groups, compare_dense.hip)
-    if (want_dense && n >= 8 && s <= 16384 && !lab_sorted.empty()) {
+    if (want_dense && n >= 8 && s <= 16384 && lab_sorted) {
         link.assign(n, 0);                                  // clustered variant: neighbours with the same label
         for (uint64_t a = 1; a < n; a++) link[a] = (lab_sorted[a] == lab_sorted[a - 1] && cnt_true[a] && cnt_true[a - 1]) ? 1 : 0;
     } else if (cluster_q && want_dense && n >= 8 && s <= 16384 && d_link.alloc(n) == hipSuccess) {
@@ -706,30 +739,15 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
         sp->cls_members = tot;
         if (ncls == 1 && tot == n && cnt_true[0] > 0) sp->one_class = (uint32_t)cnt_true[0];
     }
-    uint64_t E64 = 0, maxv = 0;
+    uint64_t E64 = 0;
     sp->off_host.resize(n + 1);
-    double dens[65] = {0};                                  // by bit length of a row's largest hash: values per unit of the hash range
-    double dens0 = 0;                                       // ... and all of them: the density where the table is densest (below every row's largest hash)
     for (uint64_t i = 0; i < n; i++) {
         sp->off_host[i] = (uint32_t)E64;
         const uint64_t c = cnt_true[i];
-        if (rep.empty() || rep[i] == i) {                   // copies stay out of the index
-            E64 += c;
-            if (c) {
-                dens[64 - __builtin_clzll(lastv[i] | 1ull)] += (double)c / ((double)lastv[i] + 1.0);
-                dens0 += (double)c / ((double)lastv[i] + 1.0);
-            }
-        }
+        if (rep.empty() || rep[i] == i) E64 += c;           // copies stay out of the index
         if (E64 >= (1ull << 31)) return unusable("2^31 entries or more");
-        if (c) {
-            // a real hash equal to the padding value would sort among the padding: keep the tile engine
-            if (lastv[i] == MG_HASH_PAD) return unusable("a hash equals the padding value");
-            maxv = std::max(maxv, lastv[i]);
-            if (c < s) sp->short_rows_host.push_back((uint32_t)i);
-        } else {
-            sp->short_rows_host.push_back((uint32_t)i);
-            sp->has_empty = true;
-        }
+        if (c < s) sp->short_rows_host.push_back((uint32_t)i);
+        if (c == 0) sp->has_empty = true;
     }
     sp->off_host[n] = (uint32_t)E64;
     if (E64 == 0) return unusable("no hashes");
@@ -806,7 +824,7 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
     //  sort on the one-clade bracket (32 768 rows: 15.2 vs 14.7 ms per table).  Clades of a thousand rows are the tiles'
     //  (16.9 vs 19.1 ms on the 100 x 1 000 bracket).  The clustered order tells: rows of one label stand next to each other.)
     bool tiles_hopeless = false;
-    if (ix_tiles && !ix_verify && !lab_sorted.empty() && !ctx_opt(ctx, "MASHGPU_SPARSE_INDEX")) {
+    if (ix_tiles && !ix_verify && lab_sorted && !ctx_opt(ctx, "MASHGPU_SPARSE_INDEX")) {
         uint64_t run = 1, longest = 1;
         for (uint64_t a = 1; a < n; a++) {
             run = lab_sorted[a] == lab_sorted[a - 1] ? run + 1 : 1;

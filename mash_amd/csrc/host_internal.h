@@ -47,6 +47,8 @@ struct mg_ctx {
     std::vector<ProfRec> prof_compare, prof_sketch;
     // phases of the inverted-index compare engine (compare_sparse.hip), each its own kernel
     std::vector<ProfRec> prof_fill, prof_discover, prof_merge, prof_index, prof_dense;
+    void *pin = nullptr;                                    // ctx_pinned
+    size_t pin_cap = 0;
     // Entry points lock the context: any number of host threads may drive one context, one call at
     // a time (SURVEY 8b "thread-safe per ctx"); recursive because entry points call each other.
     std::recursive_mutex mu;
@@ -193,6 +195,10 @@ struct DevBuf {
 int fail(mg_ctx *ctx, int code, const std::string &msg);
 // a knob: the context's own setting, else the environment's (nullptr: not set)
 const char *ctx_opt(const mg_ctx *ctx, const char *name);
+// The context's block of pinned host memory (grown on demand, at least `bytes`; nullptr: none to be had -- copy into pageable
+// memory instead).  For read-backs that the host wants QUEUED, not waited for one by one: a copy into pageable memory
+// returns when it is done, 40 us each behind an idle stream.  One user at a time (a call holds the context's lock).
+void *ctx_pinned(mg_ctx *ctx, size_t bytes);
 void prof_begin(mg_ctx *ctx, std::vector<ProfRec> &v, hipStream_t stream = nullptr);
 void prof_end(mg_ctx *ctx, std::vector<ProfRec> &v, hipStream_t stream = nullptr);
 

@@ -113,6 +113,22 @@ int fail(mg_ctx *ctx, int code, const std::string &msg)
 }
 
 // a knob: the context's own setting, else the environment's (nullptr: not set)
+void *ctx_pinned(mg_ctx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->pin_cap) return ctx->pin;
+    if (ctx->pin) (void)hipHostFree(ctx->pin);
+    ctx->pin = nullptr;
+    ctx->pin_cap = 0;
+    const size_t cap = bytes + bytes / 4 + 4096;
+    if (hipHostMalloc(&ctx->pin, cap, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->pin = nullptr;
+        return nullptr;
+    }
+    ctx->pin_cap = cap;
+    return ctx->pin;
+}
+
 const char *ctx_opt(const mg_ctx *ctx, const char *name)
 {
     if (ctx) {
@@ -189,6 +205,7 @@ void mg_ctx_destroy(mg_ctx *ctx)
     }
     ctx_trim(ctx);
     for (auto &b : ctx->blk_live) hipFree(b.p);
+    if (ctx->pin) hipHostFree(ctx->pin);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
