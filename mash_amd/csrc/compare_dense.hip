@@ -23,19 +23,31 @@
 // cx[w] = extras with gap < 64 w (w = 0 .. W, u16, the same way); extras as u16 gaps per row.
 // host_compare.cpp::table_sparse_index builds this next to the inverted index, whose runs it then clips so that discovery
 // sees only the partners OUTSIDE a row's group; run_compare_sparse launches dn_pairs_kernel after the fill.
+// (The encode and pairs kernels also compile for tools/hipemu -- MG_HIP_EMU: work-items as fibers on the CPU,
+//  tests/test_dense_emu.py; what needs rocPRIM or wave intrinsics of the hardware is left out of that build.)
+#ifdef MG_HIP_EMU
+#include "hipemu.h"
+#else
 #include <hip/hip_runtime.h>
+#define MG_DYN_SHARED(T, name)                                   \
+    extern __shared__ __align__(16) unsigned char name##_raw[]; \
+    T *name = reinterpret_cast<T *>(name##_raw)
+#endif
 #include <stdint.h>
 
 #include <cstdlib>
 
+#ifndef MG_HIP_EMU
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_select.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
+#endif
 
 #include "compare_internal.h"
 
 namespace mg {
 
+#ifndef MG_HIP_EMU
 // ------------------------------------------------------------------------------------------------
 // which neighbours are related: link[i] = 1 if at least half of the first 64 values of row i occur among the first
 // 256 of row i - 1 (the smallest hashes of a sketch are as good a sample as any)
@@ -219,6 +231,8 @@ hipError_t dense_sort_universes(const unsigned long long *key, const uint32_t *v
     return hipGetLastError();
 }
 
+#endif  // !MG_HIP_EMU
+
 // ------------------------------------------------------------------------------------------------
 // a grouped row -> its mask words, cumulative extra counts, extras -- and its CLIPPED runs.  One workgroup per row, the
 // group's universe staged in LDS, 256 entries at a time, each located in the universe by bisection.
@@ -240,7 +254,7 @@ __global__ __launch_bounds__(256) void dn_encode_kernel(const uint32_t *off, con
                                                         const uint32_t *upos, unsigned long long *gdata, unsigned long long *xm,
                                                         uint32_t wstride, uint16_t *ext, uint32_t xs, uint32_t n, uint32_t ul_in_lds)
 {
-    extern __shared__ uint32_t lds[];      // [2 W] mask halves, [W + 1] extras per word, [16 W] extras per gap (bytes), [W] overflow flags, [8 W] plane halves, [8] scratch, [u] the universe
+    MG_DYN_SHARED(uint32_t, lds);          // [2 W] mask halves, [W + 1] extras per word, [16 W] extras per gap (bytes), [W] overflow flags, [8 W] plane halves, [8] scratch, [u] the universe
     const uint32_t row = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
     if (row >= n) return;
     const uint32_t g = grp_of[row];
@@ -470,6 +484,8 @@ __device__ __forceinline__ uint64_t dn_out_index(uint32_t a, uint32_t b, const u
 // before the word (fprev) + union bits below t + extras of either row with offset <= t; the bits below t are the ones counted.
 // The extras of the word as four bit planes per row (bit o of plane j: bit j of the number of extras at offset o), or -- a gap
 // of the word holds sixteen and more in one of the rows -- from the rows' lists.
+// Called by every lane of the wave (uniform control flow: the ballots below are taken over all of them); a lane with nothing
+// to resolve passes lists = false, na = nb = 0 and a word that exists, and ignores what comes back.
 __device__ __forceinline__ uint32_t dn_resolve(unsigned long long un, uint32_t fprev, uint32_t s, uint32_t w, bool lists,
                                                const unsigned long long *xma, const unsigned long long *xmb, const uint16_t *xa,
                                                const uint16_t *xb, uint32_t ca0, uint32_t na, uint32_t cb0, uint32_t nb)
@@ -524,7 +540,7 @@ __global__ __launch_bounds__(128) void dn_pairs_kernel(const DenseTile *tiles, c
                                                        const uint16_t *ext, uint32_t xs, uint32_t s, uint32_t row_begin, uint32_t row_end,
                                                        uint64_t out_base, const uint32_t *inv, uint2 *out, DenseList list)
 {
-    extern __shared__ __align__(16) unsigned long long dl[];
+    MG_DYN_SHARED(unsigned long long, dl);
     const DenseTile T = tiles[blockIdx.x];
     const DenseGroup G = groups[T.group];
     const uint32_t W = G.W, tid = threadIdx.x;
@@ -588,20 +604,25 @@ __global__ __launch_bounds__(128) void dn_pairs_kernel(const DenseTile *tiles, c
             const uint32_t a = T.row0 + ai + k;
             // (uniform: the row exists, belongs to the job, and the column block starts below it)
             const bool present = a < G.g1 && a < row_end && a >= row_begin && G.g0 + T.cblk * 128u < a;
-            if (!(present && b < a)) continue;
+            if (!present) continue;                                       // uniform
+            const bool valid = b < a;
             uint32_t denom = s;
             const uint32_t w = nle[k];
-            if (w < W) {                                                  // s is reached inside word w
-                const unsigned long long ma = Am[w * DN_ROWS + ai + k], mb = Bm[w * 128u + tid];
-                const uint32_t ca0 = Acx[w * DN_ROWS + ai + k] & DN_CX_MASK, ca1r = Acx[(w + 1u) * DN_ROWS + ai + k];
-                const uint32_t cb0 = Bcx[w * 128u + tid] & DN_CX_MASK, cb1r = Bcx[(w + 1u) * 128u + tid];
-                const uint32_t fprev = (uint32_t)Atot[w * DN_ROWS + ai + k] + (uint32_t)Btot[w * 128u + tid] - common[k];
-                const uint32_t T0 = dn_resolve(ma | mb, fprev, s, w, use_lists || ((ca1r | cb1r) & DN_CX_FLAG) != 0,
-                                               xm + (uint64_t)(G.xrow0 + (a - G.g0)) * wstride * 4ull, xmb,
-                                               ext + (uint64_t)(G.xrow0 + (a - G.g0)) * xs, xb, ca0, (ca1r & DN_CX_MASK) - ca0, cb0,
-                                               (cb1r & DN_CX_MASK) - cb0);
-                common[k] += (uint32_t)__popcll(ma & mb & ((1ull << T0) - 1ull));
-            } else {                                                      // the union ends before s (short sketches)
+            const bool need = valid && w < W;                             // s is reached inside word w
+            if (__ballot(need) != 0) {                                    // uniform: the resolve is entered by the whole wave
+                const uint32_t wc = need ? w : 0u;
+                const unsigned long long ma = Am[wc * DN_ROWS + ai + k], mb = Bm[wc * 128u + tid];
+                const uint32_t ca0 = Acx[wc * DN_ROWS + ai + k] & DN_CX_MASK, ca1r = Acx[(wc + 1u) * DN_ROWS + ai + k];
+                const uint32_t cb0 = Bcx[wc * 128u + tid] & DN_CX_MASK, cb1r = Bcx[(wc + 1u) * 128u + tid];
+                const uint32_t fprev = (uint32_t)Atot[wc * DN_ROWS + ai + k] + (uint32_t)Btot[wc * 128u + tid] - common[k];
+                const bool lists = need && (use_lists || ((ca1r | cb1r) & DN_CX_FLAG) != 0);
+                const uint32_t T0 = dn_resolve(ma | mb, fprev, s, wc, lists, xm + (uint64_t)(G.xrow0 + (a - G.g0)) * wstride * 4ull, xmb,
+                                               ext + (uint64_t)(G.xrow0 + (a - G.g0)) * xs, xb, ca0, need ? (ca1r & DN_CX_MASK) - ca0 : 0u, cb0,
+                                               need ? (cb1r & DN_CX_MASK) - cb0 : 0u);
+                if (need) common[k] += (uint32_t)__popcll(ma & mb & ((1ull << T0) - 1ull));
+            }
+            if (!valid) continue;
+            if (w >= W) {                                                 // the union ends before s (short sketches)
                 const uint32_t total = (uint32_t)Atot[W * DN_ROWS + ai + k] + (uint32_t)Btot[W * 128u + tid] - common[k];
                 denom = total < s ? total : s;
             }
@@ -646,6 +667,7 @@ hipError_t launch_dense_pairs(const DenseTile *tiles, uint32_t ntiles, uint32_t 
     return il >= 8u ? go(dn_pairs_kernel<8, 8>) : go(dn_pairs_kernel<8, 4>);
 }
 
+#ifndef MG_HIP_EMU
 // ------------------------------------------------------------------------------------------------
 // which rows belong together, whatever their order in the table (collections are not always listed by species): the
 // LABEL of a row is the smallest row that holds one of its first four hashes -- rows of a clade agree on it with high
@@ -753,6 +775,8 @@ hipError_t launch_dense_gather_rows(const uint64_t *hashes, uint64_t stride, con
     hipLaunchKernelGGL(cl_gather_rows_kernel, dim3(n), dim3(256), 0, stream, hashes, stride, inv, out);
     return hipGetLastError();
 }
+
+#endif  // !MG_HIP_EMU
 
 // Per row of the table the candidate group it stands in: grp_of[r] (0xFFFFFFFF: none) and lead_rows[r] = {group, its first
 // row, one past its last, 0} -- what the index build's leader search gathers per entry (IxLeaders).  groups: disjoint,

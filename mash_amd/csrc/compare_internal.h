@@ -1,7 +1,11 @@
 // compare_internal.h — launch interface between host_compare.cpp and the compare kernels (compare_sparse.hip,
 // compare_merged.hip, compare.hip).
 #pragma once
+#ifdef MG_HIP_EMU                    // tools/hipemu: the kernels on host threads (tests/test_dense_emu.py)
+#include "hipemu.h"
+#else
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 
 namespace mg {
