@@ -475,6 +475,22 @@ static int run_compare_merged(mg_ctx *ctx, const mg_table *rows, const mg_table 
 // keeps the tile engine.
 // Host work per build is O(n) loops and three synchronisations (row classes, copy suspects, build
 // statistics); sorting of digests and of the visiting order happens on the device.
+// One clade of many thousands of rows: every value of its pool has more holders than a bucket's LDS sort takes, so the whole
+// index would go through the two-level sort of the big buckets -- correct, but measured 0.5 ms behind the general sort on the
+// one-clade bracket (32 768 rows: 15.2 against 14.7 ms per table; clades of a thousand rows are the tiles': 16.9 against
+// 19.1 on the 100 x 1 000 bracket).  The clustered order tells: rows of one label stand next to each other.
+static const uint64_t kTilesLongestRun = 6144;
+static uint64_t longest_label_run(const uint32_t *lab_sorted, uint64_t n)
+{
+    if (!lab_sorted || n == 0) return 0;
+    uint64_t run = 1, longest = 1;
+    for (uint64_t a = 1; a < n; a++) {
+        run = lab_sorted[a] == lab_sorted[a - 1] ? run + 1 : 1;
+        longest = std::max(longest, run);
+    }
+    return longest;
+}
+
 static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool clustered, mg_table::Sparse **out)
 {
     for (mg_table::Sparse *sp : t->sparse)
@@ -607,9 +623,14 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
         t->nh.swap(hc_nh);
     }
     if (!links_q) link.clear();
+    // How the index is built (MASHGPU_SPARSE_INDEX): "tiles" (default) -- index_build.hip; "sort" -- rounds 3-4, also what a
+    // table takes that the tiles refuse; "verify" -- both, compared word by word on the device (tests).
+    const char *ix_mode = ctx_opt(ctx, "MASHGPU_SPARSE_INDEX");
+    const bool ix_verify = ix_mode && strcmp(ix_mode, "verify") == 0;
+    const bool ix_tiles = !ix_mode || strcmp(ix_mode, "sort") != 0;
     std::vector<uint32_t> cnt_true(n), cnt_perm;
     uint32_t max_cnt = 0;
-    uint64_t maxv = 0;
+    uint64_t maxv = 0, E_all = 0;
     double dens[65] = {0};                                  // by bit length of a row's largest hash: values per unit of the hash range
     double dens0 = 0;                                       // ... and all of them: the density where the table is densest (below every row's largest hash)
     // (what does not depend on the rows' order is taken here, in the table's: the pass in the index's order below has the
@@ -617,6 +638,7 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
     for (uint64_t i = 0; i < n; i++) {
         const uint32_t c = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(t->nh[i], t->s), s);
         cnt_true[i] = c;
+        E_all += c;
         max_cnt = std::max(max_cnt, c);
         if (c) {
             const uint64_t last = t->last[i];
@@ -632,6 +654,9 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
     // ---- the clustered variant: the table copied in the clustered order; everything below then works on the copy as if
     // it were the table
     const uint64_t *H = t->hashes;                          // what the index is built from
+    mg::IxPlan early_plan;                                  // the tiles' plan, if it could be made before the clustered copy ...
+    DevBuf<unsigned char> d_lb(ctx);                        // ... whose kernel then left the rows' window offsets here
+    bool lb_made = false;
     bool cnt_stale = false;                                 // d_cnt still holds the counts in the table's order
     if (cluster_q) {
         bool identity = true;
@@ -648,7 +673,19 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
                 sp->inv = static_cast<uint32_t *>(pi);
                 sp->phashes = static_cast<uint64_t *>(ph);
                 HIP_TRY(ctx, hipMemcpyAsync(sp->inv, d_inv, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
-                HIP_TRY(ctx, mg::launch_dense_gather_rows(t->hashes, t->s, sp->inv, (uint32_t)n, sp->phashes, ctx->stream));
+                // With no copy suspects every row enters the index, so its plan is known NOW (it depends on sums over the rows,
+                // not on their order): the copy kernel then leaves the rows' window offsets (K0 of index_build.hip) on its way
+                // -- one pass over the table less.
+                if (ix_tiles && !(dedup && nflag) && E_all > 0 && E_all < (1ull << 31) && longest_label_run(lab_sorted, n) <= kTilesLongestRun) {
+                    early_plan = mg::index_plan((uint32_t)n, (uint32_t)E_all, s, sp->rs, t->s, maxv, dens0, ix_verify);
+                    if (early_plan.ok && d_lb.alloc(early_plan.lb_bytes) == hipSuccess) {
+                        HIP_TRY(ctx, mg::index_gather_rows(early_plan, t->hashes, sp->inv, d_cnt, sp->phashes, d_lb, ctx->stream));
+                        lb_made = true;
+                    } else {
+                        (void)hipGetLastError();
+                    }
+                }
+                if (!lb_made) HIP_TRY(ctx, mg::launch_dense_gather_rows(t->hashes, t->s, sp->inv, (uint32_t)n, sp->phashes, ctx->stream));
                 H = sp->phashes;
                 cnt_perm.resize(n);
                 for (uint64_t a = 0; a < n; a++) cnt_perm[a] = cnt_true[inv[a]];
@@ -768,9 +805,6 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
     // rounds 3-4: rocPRIM's radix sort on the leading bits + tie repair + head scan + scattered write-back, also what a
     // table takes that the tiles refuse (a bucket beyond the LDS: a value held by thousands of rows, values far from
     // evenly spread); "verify" -- both, compared word by word on the device (tests).
-    const char *ix_mode = ctx_opt(ctx, "MASHGPU_SPARSE_INDEX");
-    const bool ix_verify = ix_mode && strcmp(ix_mode, "verify") == 0;
-    const bool ix_tiles = !ix_mode || strcmp(ix_mode, "sort") != 0;
     // ---- candidates for dense groups (compare_dense.hip): runs of at least 8 consecutive rows linked to their predecessors.
     // Known before the index exists, so the build by tiles looks for their leaders while it has every group of equal values in
     // LDS (index_build.h, IxLeaders); the build by the sort searches the finished index for them (dense_find_leaders).
@@ -819,21 +853,12 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
         }
     };
     mg::IxPlan plan;
-    // (One clade of many thousands of rows: every value of its pool has more holders than a bucket's LDS sort takes, so the
-    //  whole index goes through the two-level sort of the big buckets -- correct, but measured 0.5 ms behind the general
-    //  sort on the one-clade bracket (32 768 rows: 15.2 vs 14.7 ms per table).  Clades of a thousand rows are the tiles'
-    //  (16.9 vs 19.1 ms on the 100 x 1 000 bracket).  The clustered order tells: rows of one label stand next to each other.)
-    bool tiles_hopeless = false;
-    if (ix_tiles && !ix_verify && lab_sorted && !ctx_opt(ctx, "MASHGPU_SPARSE_INDEX")) {
-        uint64_t run = 1, longest = 1;
-        for (uint64_t a = 1; a < n; a++) {
-            run = lab_sorted[a] == lab_sorted[a - 1] ? run + 1 : 1;
-            longest = std::max(longest, run);
-        }
-        tiles_hopeless = longest > 6144;
-    }
+    const bool tiles_hopeless = ix_tiles && !ix_verify && lab_sorted && !ctx_opt(ctx, "MASHGPU_SPARSE_INDEX") &&
+                                longest_label_run(lab_sorted, n) > kTilesLongestRun;
     if (ix_tiles && !tiles_hopeless) plan = mg::index_plan((uint32_t)n, E, s, sp->rs, t->s, maxv, dens0, ix_verify);
     else if (tiles_hopeless) plan.why = "a clade of more rows than a bucket's sort takes";
+    // (the window offsets the clustered copy left are those of this plan, or K0 makes them again)
+    if (lb_made && !(plan.ok && memcmp(&plan.g, &early_plan.g, sizeof plan.g) == 0)) lb_made = false;
     const size_t temp_bytes = std::max(std::max(mg::sparse_order_temp_bytes((uint32_t)n), mg::sparse_order_slice_temp_bytes((uint32_t)n)),
                                        mg::sparse_offsets_temp_bytes((uint32_t)n));
     DevBuf<unsigned char> temp(ctx);
@@ -889,14 +914,15 @@ static int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool c
     };
     bool built = false;
     if (ok && e == hipSuccess && plan.ok) {
-        DevBuf<unsigned char> d_lb(ctx), d_tcnt(ctx), d_start(ctx), d_big(ctx), d_pk(ctx), d_tc(ctx);
-        if (d_lb.alloc(plan.lb_bytes) == hipSuccess && d_tcnt.alloc(plan.cnt_bytes) == hipSuccess && d_start.alloc(plan.start_bytes) == hipSuccess &&
+        DevBuf<unsigned char> d_tcnt(ctx), d_start(ctx), d_big(ctx), d_pk(ctx), d_tc(ctx);
+        if ((lb_made || d_lb.alloc(plan.lb_bytes) == hipSuccess) && d_tcnt.alloc(plan.cnt_bytes) == hipSuccess && d_start.alloc(plan.start_bytes) == hipSuccess &&
             d_big.alloc(plan.big_bytes) == hipSuccess && d_pk.alloc(plan.pk_bytes) == hipSuccess && d_tc.alloc(plan.tc_bytes) == hipSuccess) {
             e = hipMemsetAsync(d_stat, 0, sizeof(Stat), ctx->stream);
             // the partition (K0 - K3) goes first: the host lays out the candidates for dense groups while it runs
             if (e == hipSuccess)
                 e = mg::index_build(plan, H, sp->off, d_lb, d_tcnt, d_start, d_big, d_pk, d_tc, sp->keys_sorted, sp->sorted_rows, sp->gend, gs_of, sp->code_img,
-                                    sp->pos_img, d_slots, &d_stat.p->shared, &d_stat.p->max_group, &d_stat.p->groups, d_stat.p->ixf, nullptr, ctx->stream, 1);
+                                    sp->pos_img, d_slots, &d_stat.p->shared, &d_stat.p->max_group, &d_stat.p->groups, d_stat.p->ixf, nullptr, ctx->stream,
+                                    lb_made ? 1 | 8 : 1);
             prepare_candidates();
             mg::IxLeaders lead;
             if (lead_ready) {

@@ -79,7 +79,12 @@ hipError_t index_build(const IxPlan &plan, const uint64_t *hashes, const uint32_
                        uint64_t *keys_sorted, uint32_t *sorted_rows, uint32_t *gend, uint32_t *gs_of, uint32_t *code_img, uint32_t *pos_img,
                        void *stat_scratch, unsigned long long *incidences, uint32_t *max_group, uint32_t *groups, uint32_t *flags,
                        const IxLeaders *leaders, hipStream_t stream, int stages = 7);
-// stages (bits): 1 = the partition (K0 - K3; needs neither the statistics' memory nor the leaders'), 2 = the bucket sorts (K4, K4b:
+// The copy of the table in another order of its rows (out[a] = row inv[a], whole rows) that also leaves the window offsets of
+// the copy's rows in lb (K0 inside the copy); cnt_table: entry counts in the table's order.  index_build on `out` then
+// takes stage bit 8.
+hipError_t index_gather_rows(const IxPlan &plan, const uint64_t *hashes, const uint32_t *inv, const uint32_t *cnt_table, uint64_t *out, void *lb,
+                             hipStream_t stream);
+// stages (bits): 8 = lb is made already (index_gather_rows), 1 = the partition (K0 - K3; needs neither the statistics' memory nor the leaders'), 2 = the bucket sorts (K4, K4b:
 // values, rows, groups, statistics, leaders are final behind them), 4 = the images (K5).  A caller prepares the leader search
 // while stage 1 runs, and queues its copy of the statistics between stages 2 and 4.
 

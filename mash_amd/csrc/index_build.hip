@@ -139,6 +139,32 @@ __device__ __forceinline__ bool ix_tile_id(const IxGeom &g, uint32_t &blk, uint3
 // ------------------------------------------------------------------------------------------------
 // K0: lb[row][w] = the first position of the row whose value lies in window w or above (w = 0 .. NW; lb[row][NW] = count).
 // One wave per row.
+// K0 inside the copy of the table in clustered order (host_compare.cpp: the index is then built on the copy): out[a] = table
+// row inv[a], whole rows with their padding, and the window offsets of row a from the same read -- one pass over the table
+// less.  cnt: the rows' entry counts in the TABLE's order.  One workgroup per row.
+__global__ __launch_bounds__(256) void ix_gather_offsets_kernel(IxGeom g, const uint64_t *H, const uint32_t *inv, const uint32_t *cnt_table,
+                                                                uint64_t *out, uint16_t *lb)
+{
+    const uint32_t a = blockIdx.x, tid = threadIdx.x;
+    const uint32_t r = inv[a];
+    const uint32_t cnt = cnt_table[r];
+    const uint64_t *src = H + (uint64_t)r * g.stride;
+    uint64_t *dst = out + (uint64_t)a * g.stride;
+    uint16_t *o = lb + (uint64_t)a * (g.NW + 1u);
+    const uint32_t wsh = g.shift + g.bw_log;
+    for (uint64_t p = tid; p < g.stride; p += 256u) {
+        const uint64_t v = src[p];
+        dst[p] = v;
+        if (p < cnt) {
+            const int w = (int)(uint32_t)(v >> wsh);
+            const int wp = p > 0 ? (int)(uint32_t)(src[p - 1] >> wsh) : -1;
+            for (int x = wp + 1; x <= w; x++) o[x] = (uint16_t)p;
+        }
+    }
+    const int wl = cnt > 0 ? (int)(uint32_t)(src[cnt - 1] >> wsh) : -1;
+    for (uint32_t x = (uint32_t)(wl + 1) + tid; x <= g.NW; x += 256u) o[x] = (uint16_t)cnt;
+}
+
 __global__ __launch_bounds__(256) void ix_window_offsets_kernel(IxGeom g, const uint64_t *H, const uint32_t *off, uint16_t *lb)
 {
     const uint32_t row = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
@@ -1244,6 +1270,14 @@ IxPlan index_plan(uint32_t n, uint32_t E, uint32_t s, uint32_t rs, uint64_t stri
     return p;
 }
 
+hipError_t index_gather_rows(const IxPlan &plan, const uint64_t *hashes, const uint32_t *inv, const uint32_t *cnt_table, uint64_t *out, void *lb_v,
+                             hipStream_t stream)
+{
+    if (!plan.ok) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ix_gather_offsets_kernel, dim3(plan.g.n), dim3(256), 0, stream, plan.g, hashes, inv, cnt_table, out, static_cast<uint16_t *>(lb_v));
+    return hipGetLastError();
+}
+
 hipError_t index_build(const IxPlan &plan, const uint64_t *hashes, const uint32_t *off, void *lb_v, void *cnt_v, void *start_v, void *big_v, void *pk_v, void *tc_v,
                        uint64_t *keys_sorted, uint32_t *sorted_rows, uint32_t *gend, uint32_t *gs_of, uint32_t *code_img, uint32_t *pos_img,
                        void *stat_scratch, unsigned long long *incidences, uint32_t *max_group, uint32_t *groups, uint32_t *flags,
@@ -1261,7 +1295,7 @@ hipError_t index_build(const IxPlan &plan, const uint64_t *hashes, const uint32_
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(ix_tile_partition_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)IXL_BYTES);
         if (e != hipSuccess) return e;
         const uint32_t tiles = 8u * ((g.nseq + 7u) / 8u);
-        hipLaunchKernelGGL(ix_window_offsets_kernel, dim3((g.n + 3u) / 4u), dim3(256), 0, stream, g, hashes, off, lb);
+        if (!(stages & 8)) hipLaunchKernelGGL(ix_window_offsets_kernel, dim3((g.n + 3u) / 4u), dim3(256), 0, stream, g, hashes, off, lb);
         hipLaunchKernelGGL(ix_tile_count_kernel, dim3(tiles), dim3(IX_NT), 0, stream, g, hashes, (const uint16_t *)lb, cnt);
         hipLaunchKernelGGL(ix_col_scan_kernel, dim3((g.Bp + 255u) / 256u), dim3(256), 0, stream, g, cnt, start);
         hipLaunchKernelGGL(ix_bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, g, start, flags, static_cast<uint32_t *>(big_v));

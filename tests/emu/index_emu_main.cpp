@@ -212,6 +212,20 @@ static int run_case(const std::string &name, uint32_t n, uint32_t s, uint64_t se
     if (inc != R.inc) report("incidences", 0, inc, R.inc);
     if (max_group != R.max_group) report("max_group", 0, max_group, R.max_group);
     if (groups != R.groups) report("groups", 0, groups, R.groups);
+    {   // K0 inside the copy of the table (index_gather_rows): a table whose rows stand in REVERSE order is copied back into
+        // this one's order; the copy must be the table and the window offsets those K0 made above
+        std::vector<uint64_t> Hrev((size_t)n * t.stride), Hcopy((size_t)n * t.stride, 0x1111ull);
+        std::vector<uint32_t> inv(n), cnt_rev(n);
+        for (uint32_t r = 0; r < n; r++) {
+            inv[r] = n - 1 - r;
+            cnt_rev[n - 1 - r] = off[r + 1] - off[r];
+            std::copy(t.H.begin() + (size_t)r * t.stride, t.H.begin() + (size_t)(r + 1) * t.stride, Hrev.begin() + (size_t)(n - 1 - r) * t.stride);
+        }
+        std::vector<unsigned char> lb2(plan.lb_bytes + 16, 0xCD);
+        if (index_gather_rows(plan, Hrev.data(), inv.data(), cnt_rev.data(), Hcopy.data(), lb2.data(), nullptr) != hipSuccess) report("index_gather_rows", 0, 1, 0);
+        if (Hcopy != t.H) report("the copy of the table", 0, 1, 0);
+        if (memcmp(lb2.data(), lb.data(), plan.lb_bytes) != 0) report("window offsets made by the copy", 0, 1, 0);
+    }
     printf("%-28s %s: %s\n", name.c_str(), geom, bad ? "MISMATCH" : "ok");
     return bad ? 1 : 0;
 }
