@@ -195,6 +195,9 @@ struct DevBuf {
 int fail(mg_ctx *ctx, int code, const std::string &msg);
 // a knob: the context's own setting, else the environment's (nullptr: not set)
 const char *ctx_opt(const mg_ctx *ctx, const char *name);
+// host_index.cpp: the inverted index of table t for sketch size s (cached in the table; (*out)->usable says whether the engine
+// can take it), in the table's own order or -- clustered -- on a copy with related rows next to each other
+int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool clustered, mg_table::Sparse **out);
 // The context's block of pinned host memory (grown on demand, at least `bytes`; nullptr: none to be had -- copy into pageable
 // memory instead).  For read-backs that the host wants QUEUED, not waited for one by one: a copy into pageable memory
 // returns when it is done, 40 us each behind an idle stream.  One user at a time (a call holds the context's lock).

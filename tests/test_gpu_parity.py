@@ -964,7 +964,7 @@ def test_compare_sparse_index_of_a_collection_of_many_genome_sizes(eng, oracle, 
     """A table large enough for the index's sort on leading bits (>= 2^22 entries) whose values are NOT spread evenly:
     nine rows in ten keep their hashes below 2^44 (large genomes), the tenth reaches 2^58 -- the low end of the range is
     a thousand times denser than the even-spread rule assumes; the number of bits comes from the rows' largest hashes
-    (host_compare.cpp).  Every pair against the ORACLE (9.7e6 pairs), through the index built by tiles
+    (host_index.cpp).  Every pair against the ORACLE (9.7e6 pairs), through the index built by tiles
     (the default: its buckets are sized from the same density), by the sort with the default bits, with far too few bits
     (thousands of ties, then the fallback) and with every bit sorted."""
     rng = np.random.default_rng(12)

@@ -1,5 +1,5 @@
 """How many leading bits the inverted index's radix sort looks at (mash_amd/csrc/sort_bits.h, used by
-host_compare.cpp::table_sparse_index): the rule is plain C++, compiled here on its own with g++ and checked on tables whose
+host_index.cpp::SparseIndexBuild::lay_out): the rule is plain C++, compiled here on its own with g++ and checked on tables whose
 answer can be worked out by hand and against a simulation of the thing it estimates -- the number of pairs of DIFFERENT
 values that share a bucket of 2^bb."""
 import ctypes
