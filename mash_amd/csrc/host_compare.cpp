@@ -485,39 +485,122 @@ struct SparseJob {
     uint64_t dense_pairs = 0;
 };
 
-static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, uint64_t row_begin, uint64_t row_end,
-                              bool triangle, uint32_t s, mg_counts *out_dev, bool force, bool *handled, SparseJob *job = nullptr)
+// What the dispatch believes things cost: seconds on one MI355X, each a measured number (profiles/r03_sparse_phases.txt; the
+// dense pairs and the tile engine's price of a shared hash from rounds 4 and 5), written down in ONE place.  They are
+// constants, not calibrated per context: the decision they feed is between engines whose costs differ by factors, and it is
+// cached per (table, rows).
+struct SparseCosts {
+    double fill_bytes_s = 4.5e12;            // the fill writes 8 B per pair
+    double discover_per_shared = 2.0e-12;    // a run entry read by discovery
+    double discover_per_entry = 4.0e-11;     // a row's entry looked at (n x s of them)
+    double merge_per_candidate = 1.0e-9;     // a merge of ~2 s steps
+    double launches = 2.0e-5;
+    double class_bytes_s = 2.0e12;           // pairs inside classes of identical rows
+    double dense_per_pair = 3.0e-11;         // a pair inside a dense group
+    // the tile engine: pairs per second by job size, and what a shared hash costs it -- 2.2e-12 s between copies of one
+    // sketch, 5.5e-12 inside clades, 1.2e-11 in a collection of one species, where every pair shares a few hundred values and
+    // no two rows the same ones (round 5's one_species bracket: 1.58 s for 5.4e8 pairs where the model said 0.33); priced at
+    // the upper middle, the copies and clades having engines of their own by now
+    double tiles_rate_small = 8.0e9, tiles_rate_mid = 1.5e10, tiles_rate_large = 3.0e10;
+    double tiles_per_shared = 8.0e-12;
+};
+static const SparseCosts kSparseCosts;
+
+// One job of the inverted-index engine, phase by phase (run()): the index of the column table, the row side (triangle: the
+// table itself; rect: the queries located in the index), the job's plan (dense tiles, visiting order; cached per table and
+// rows), discovery -- which also counts, so the engine choice needs no pass of its own --, then fill + dense groups, merge
+// and scatter.  A phase that finds the job is not this engine's leaves with *handled as it stands (leave()).
+struct SparseJobRun {
+    mg_ctx *ctx;
+    const mg_table *rows, *cols;
+    const uint64_t row_begin, row_end;
+    const bool triangle;
+    const uint32_t s;
+    mg_counts *out_dev;
+    const bool force;
+    bool *handled;
+    SparseJob *job;
+    const uint64_t nrows, pairs;
+    bool stop = false;
+
+    mg_table::Sparse *ix = nullptr;
+    bool clustered = false;
+    int rc = MG_OK;
+    mg::SparseArgs a;
+    DevBuf<uint32_t> q_off, q_img, q_lo, q_hi, q_short, q_short_cnt;
+    std::vector<uint32_t> qshort_h, qshort_cnt_h;
+    const uint32_t *short_rows_dev = nullptr, *short_rcnt_dev = nullptr;
+    uint32_t nshort_rows = 0;
+    mg_table::Sparse::Plan *plan = nullptr;
+    mg_table::Sparse::Plan fresh;
+    bool fresh_kept = false;                                // (its buffers belong to the index once it is in ix->plans)
+    bool first = false;
+    uint64_t want = 0;
+    unsigned long long h[3] = {0, 0, 0};
+    bool nothing_to_find = false;
+
+    SparseJobRun(mg_ctx *c, const mg_table *r, const mg_table *cl, uint64_t rb, uint64_t re, bool tri, uint32_t sketch_size, mg_counts *out, bool forced,
+                 bool *handled_out, SparseJob *list_job)
+        : ctx(c), rows(r), cols(cl), row_begin(rb), row_end(re), triangle(tri), s(sketch_size), out_dev(out), force(forced), handled(handled_out),
+          job(list_job), nrows(re - rb), pairs(tri ? (re * (re - 1) / 2 - (rb ? rb * (rb - 1) / 2 : 0)) : (re - rb) * cl->n), q_off(c), q_img(c), q_lo(c),
+          q_hi(c), q_short(c), q_short_cnt(c)
+    {
+        fresh.order = nullptr;
+        fresh.dtiles = nullptr;
+    }
+    // a fresh plan's buffers belong to the index once it is in ix->plans -- and to nobody on every other way out
+    ~SparseJobRun()
+    {
+        if (!fresh_kept) {
+            if (fresh.order) ctx_free(ctx, fresh.order);
+            if (fresh.dtiles) ctx_free(ctx, fresh.dtiles);
+        }
+    }
+    int leave() { stop = true; return MG_OK; }              // not (or no longer) this engine's job
+
+    int open_index();
+    int row_side();
+    int find_plan();
+    int ensure_lists(uint64_t want_cand);
+    int discover();
+    int choose_engine();
+    int fill_and_dense();
+    int merge_and_scatter();
+    int run();
+};
+
+int SparseJobRun::open_index()
 {
     *handled = false;
-    const uint64_t nrows = row_end - row_begin;
-    const uint64_t pairs = triangle ? (row_end * (row_end - 1) / 2 - (row_begin ? row_begin * (row_begin - 1) / 2 : 0)) : nrows * cols->n;
-    if (pairs == 0) return MG_OK;
-    if (!force && pairs < 4000000ull) return MG_OK;        // small jobs: one tile launch beats an index
-    if (const char *e = ctx_opt(ctx, "MASHGPU_COMPARE_SPARSE")) { if (atoi(e) == 0 && !force) return MG_OK; }
-    if (nrows >= (1ull << 31) || cols->n >= (1ull << 31)) return MG_OK;
-    if (!mg::sparse_discover_supported((uint32_t)(triangle ? row_end : cols->n))) return MG_OK;
-    mg_table::Sparse *ix = nullptr;
+    if (pairs == 0) return leave();
+    if (!force && pairs < 4000000ull) return leave();        // small jobs: one tile launch beats an index
+    if (const char *e = ctx_opt(ctx, "MASHGPU_COMPARE_SPARSE")) { if (atoi(e) == 0 && !force) return leave(); }
+    if (nrows >= (1ull << 31) || cols->n >= (1ull << 31)) return leave();
+    if (!mg::sparse_discover_supported((uint32_t)(triangle ? row_end : cols->n))) return leave();
     // the plain full triangle takes the CLUSTERED variant of the index (built on the table with related rows next to each
     // other: dense groups whatever the order of the collection); row ranges, rect and list jobs address table rows
-    bool clustered = triangle && !job && row_begin == 0 && row_end == cols->n;
+    clustered = triangle && !job && row_begin == 0 && row_end == cols->n;
     if (const char *e = ctx_opt(ctx, "MASHGPU_COMPARE_CLUSTER")) clustered = clustered && atoi(e) != 0;
-    int rc = table_sparse_index(ctx, cols, s, clustered, &ix);
+    rc = table_sparse_index(ctx, cols, s, clustered, &ix);
     if (rc != MG_OK) return rc;
     if (!ix->usable && clustered) {                         // (whatever stopped it may not stop the plain variant)
         clustered = false;
         rc = table_sparse_index(ctx, cols, s, false, &ix);
         if (rc != MG_OK) return rc;
     }
-    if (!ix->usable) return MG_OK;
+    if (!ix->usable) return leave();
     // (list mode: two copies of one sketch are a pair at distance 0 that is no candidate, two EMPTY sketches
     //  likewise -- such tables take the matrix path.  The pairs inside dense groups are no candidates either: they are
     //  appended to their rows' lists by the dense kernel itself, see job_lists)
-    if (job && (ix->copies || ix->has_empty)) return MG_OK;
-    if (job && !triangle && !ix->dgroups_host.empty()) return MG_OK;
+    if (job && (ix->copies || ix->has_empty)) return leave();
+    if (job && !triangle && !ix->dgroups_host.empty()) return leave();
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return MG_OK;
+}
 
+int SparseJobRun::row_side()
+{
     // ---- row side ----
-    mg::SparseArgs a;
     a.sorted_rows = ix->sorted_rows;
     a.col_img = ix->code_img;
     a.col_cnt_off = ix->off;
@@ -539,10 +622,6 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
     a.seg_base = nullptr;
     a.seg_cnt = nullptr;
     a.chunk_inc = nullptr;
-    DevBuf<uint32_t> q_off(ctx), q_img(ctx), q_lo(ctx), q_hi(ctx), q_short(ctx), q_short_cnt(ctx);
-    std::vector<uint32_t> qshort_h, qshort_cnt_h;
-    const uint32_t *short_rows_dev = nullptr, *short_rcnt_dev = nullptr;
-    uint32_t nshort_rows = 0;
     if (triangle) {
         a.lo_img = ix->code_img;
         a.hi_img = ix->pos_img;
@@ -570,19 +649,19 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
             qoff[q] = (uint32_t)Eq;
             const uint64_t c = std::min<uint64_t>(std::min<uint64_t>(rows->nh[row_begin + q], rows->s), s);
             Eq += c;
-            if (Eq >= (1ull << 31)) return MG_OK;
+            if (Eq >= (1ull << 31)) return leave();
             if (c < s) { qshort_h.push_back((uint32_t)q); qshort_cnt_h.push_back((uint32_t)c); }
-            if (c == 0 && job) return MG_OK;
-            if (c && rows->last[row_begin + q] == MG_HASH_PAD) return MG_OK;
+            if (c == 0 && job) return leave();
+            if (c && rows->last[row_begin + q] == MG_HASH_PAD) return leave();
         }
         qoff[nrows] = (uint32_t)Eq;
         const uint32_t rsq = ix->rs;
-        if (nrows * rsq >= (1ull << 32)) return MG_OK;
+        if (nrows * rsq >= (1ull << 32)) return leave();
         if (q_off.alloc(nrows + 1) != hipSuccess || q_img.alloc(nrows * rsq) != hipSuccess || q_lo.alloc(nrows * rsq) != hipSuccess ||
             q_hi.alloc(nrows * rsq) != hipSuccess || q_short.alloc(std::max<size_t>(qshort_h.size(), 1)) != hipSuccess ||
             q_short_cnt.alloc(std::max<size_t>(qshort_h.size(), 1)) != hipSuccess) {
             (void)hipGetLastError();
-            return MG_OK;                                   // no memory for the query side: tile engine
+            return leave();                                   // no memory for the query side: tile engine
         }
         HIP_TRY(ctx, hipMemcpyAsync(q_off, qoff.data(), (nrows + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
         if (!qshort_h.empty()) {
@@ -605,23 +684,20 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
         short_rows_dev = q_short;
         short_rcnt_dev = q_short_cnt;
     }
+    return MG_OK;
+}
 
+int SparseJobRun::find_plan()
+{
     // ---- the plan of a (rows, range) job: its slice of the visiting order; candidates, shared hashes and the engine
     // choice are learned from the first discover launch (rect: the query table may change between calls, so every
     // call is a first call)
-    mg_table::Sparse::Plan *plan = nullptr;
     if (triangle)
         for (auto &pl : ix->plans)
             if (pl.rows == (const void *)rows && pl.rb == row_begin && pl.re == row_end && pl.triangle == triangle) plan = &pl;
-    mg_table::Sparse::Plan fresh;
     fresh.order = nullptr;
     fresh.dtiles = nullptr;
-    bool fresh_kept = false;                                // (its buffers belong to the index once it is in ix->plans)
-    struct FreshGuard {                                     // ... and to nobody on every other way out (the dense tiles leaked)
-        mg_ctx *c; mg_table::Sparse::Plan *p; bool *kept;
-        ~FreshGuard() { if (!*kept) { if (p->order) ctx_free(c, p->order); if (p->dtiles) ctx_free(c, p->dtiles); } }
-    } fresh_guard{ctx, &fresh, &fresh_kept};
-    const bool first = plan == nullptr;
+    first = plan == nullptr;
     if (first) {
         fresh.rows = rows; fresh.rb = row_begin; fresh.re = row_end; fresh.triangle = triangle;
         fresh.cand = 0; fresh.shared = 0; fresh.use = true; fresh.order = nullptr;
@@ -642,7 +718,7 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
                 for (uint32_t row0 = G.g0; row0 < G.g1; row0 += R) {
                     const uint64_t a_lo = std::max<uint64_t>(std::max<uint64_t>(row0, row_begin), (uint64_t)G.g0 + 1), a_hi = std::min<uint64_t>(std::min<uint64_t>(row0 + R, G.g1), row_end);
                     if (a_lo >= a_hi) continue;
-                    for (uint64_t a = a_lo; a < a_hi; a++) fresh.dense_pairs += a - G.g0;
+                    for (uint64_t ra = a_lo; ra < a_hi; ra++) fresh.dense_pairs += ra - G.g0;
                     const uint32_t cb_last = (uint32_t)((a_hi - 2 - G.g0) >> 7);         // the largest column is a_hi - 2
                     for (uint32_t cb = 0; cb <= cb_last; cb++) tiles.push_back({g, row0, cb});
                 }
@@ -680,55 +756,60 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
         plan = &fresh;
     }
     a.order = triangle && ix->order ? (plan->order ? plan->order : (row_begin == 0 && row_end == cols->n ? ix->order : nullptr)) : nullptr;
+    return MG_OK;
+}
 
-    // ---- lists of the job (grown on demand, kept with the index) ----
-    auto ensure_lists = [&](uint64_t want_cand) -> int {
-        if (want_cand > ix->cand_cap) {
-            for (void **q : {(void **)&ix->cand, (void **)&ix->res})
-                if (*q) { ctx_free(ctx, *q); *q = nullptr; }
-            ix->cand_cap = 0;
-            const uint64_t cap = want_cand + want_cand / 8 + 1024;
-            void *c1 = nullptr, *c2 = nullptr;
-            if (ctx_malloc(ctx, &c1, cap * sizeof(uint2)) != hipSuccess || ctx_malloc(ctx, &c2, cap * sizeof(uint2)) != hipSuccess) {
-                (void)hipGetLastError();
-                ctx_free(ctx, c1);
-                return fail(ctx, MG_ERR_NOMEM, "compare: no device memory for the candidate list");
-            }
-            ix->cand = static_cast<uint2 *>(c1);
-            ix->res = static_cast<uint2 *>(c2);
-            ix->cand_cap = cap;
+// lists of the job (grown on demand, kept with the index)
+int SparseJobRun::ensure_lists(uint64_t want_cand)
+{
+    if (want_cand > ix->cand_cap) {
+        for (void **q : {(void **)&ix->cand, (void **)&ix->res})
+            if (*q) { ctx_free(ctx, *q); *q = nullptr; }
+        ix->cand_cap = 0;
+        const uint64_t cap = want_cand + want_cand / 8 + 1024;
+        void *c1 = nullptr, *c2 = nullptr;
+        if (ctx_malloc(ctx, &c1, cap * sizeof(uint2)) != hipSuccess || ctx_malloc(ctx, &c2, cap * sizeof(uint2)) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx_free(ctx, c1);
+            return fail(ctx, MG_ERR_NOMEM, "compare: no device memory for the candidate list");
         }
-        if (nrows > ix->seg_rows) {
-            for (void **q : {(void **)&ix->seg_base, (void **)&ix->seg_cnt, (void **)&ix->chunks, (void **)&ix->chunk_inc, &ix->scan_temp})
-                if (*q) { ctx_free(ctx, *q); *q = nullptr; }
-            ix->seg_rows = 0;
-            const uint64_t cap = nrows + nrows / 8 + 256;
-            ix->scan_temp_bytes = mg::sparse_scan_temp_bytes((uint32_t)cap);
-            void *p1 = nullptr, *p2 = nullptr, *p3 = nullptr, *p4 = nullptr, *p5 = nullptr;
-            if (ctx_malloc(ctx, &p1, cap * 8) != hipSuccess || ctx_malloc(ctx, &p2, cap * 4) != hipSuccess ||
-                ctx_malloc(ctx, &p3, cap * 4) != hipSuccess || ctx_malloc(ctx, &p4, cap * 4) != hipSuccess ||
-                ctx_malloc(ctx, &p5, std::max<size_t>(ix->scan_temp_bytes, 16)) != hipSuccess) {
-                (void)hipGetLastError();
-                for (void *q : {p1, p2, p3, p4, p5}) ctx_free(ctx, q);
-                return fail(ctx, MG_ERR_NOMEM, "compare: no device memory for the merge work list");
-            }
-            ix->seg_base = static_cast<unsigned long long *>(p1);
-            ix->seg_cnt = static_cast<uint32_t *>(p2);
-            ix->chunks = static_cast<uint32_t *>(p3);
-            ix->chunk_inc = static_cast<uint32_t *>(p4);
-            ix->scan_temp = p5;
-            ix->seg_rows = cap;
+        ix->cand = static_cast<uint2 *>(c1);
+        ix->res = static_cast<uint2 *>(c2);
+        ix->cand_cap = cap;
+    }
+    if (nrows > ix->seg_rows) {
+        for (void **q : {(void **)&ix->seg_base, (void **)&ix->seg_cnt, (void **)&ix->chunks, (void **)&ix->chunk_inc, &ix->scan_temp})
+            if (*q) { ctx_free(ctx, *q); *q = nullptr; }
+        ix->seg_rows = 0;
+        const uint64_t cap = nrows + nrows / 8 + 256;
+        ix->scan_temp_bytes = mg::sparse_scan_temp_bytes((uint32_t)cap);
+        void *p1 = nullptr, *p2 = nullptr, *p3 = nullptr, *p4 = nullptr, *p5 = nullptr;
+        if (ctx_malloc(ctx, &p1, cap * 8) != hipSuccess || ctx_malloc(ctx, &p2, cap * 4) != hipSuccess ||
+            ctx_malloc(ctx, &p3, cap * 4) != hipSuccess || ctx_malloc(ctx, &p4, cap * 4) != hipSuccess ||
+            ctx_malloc(ctx, &p5, std::max<size_t>(ix->scan_temp_bytes, 16)) != hipSuccess) {
+            (void)hipGetLastError();
+            for (void *q : {p1, p2, p3, p4, p5}) ctx_free(ctx, q);
+            return fail(ctx, MG_ERR_NOMEM, "compare: no device memory for the merge work list");
         }
-        return MG_OK;
-    };
-    if (!first && !force && !plan->use) return MG_OK;      // a job the tile engine was found to do faster
+        ix->seg_base = static_cast<unsigned long long *>(p1);
+        ix->seg_cnt = static_cast<uint32_t *>(p2);
+        ix->chunks = static_cast<uint32_t *>(p3);
+        ix->chunk_inc = static_cast<uint32_t *>(p4);
+        ix->scan_temp = p5;
+        ix->seg_rows = cap;
+    }
+    return MG_OK;
+}
+
+int SparseJobRun::discover()
+{
+    if (!first && !force && !plan->use) return leave();      // a job the tile engine was found to do faster
     // first sight of a job: room for one candidate per two index entries, at most 2^27 (2 GB of lists from the pool; C3
     // has one per twenty, the clade table one per two); a job that holds more is discovered twice, the second time
     // with the count the first one left
-    uint64_t want = first ? std::max<uint64_t>(ix->cand_cap, std::min<uint64_t>(pairs, std::min<uint64_t>(std::max<uint64_t>((uint64_t)ix->E / 2, 1u << 16), 1ull << 27)))
+    want = first ? std::max<uint64_t>(ix->cand_cap, std::min<uint64_t>(pairs, std::min<uint64_t>(std::max<uint64_t>((uint64_t)ix->E / 2, 1u << 16), 1ull << 27)))
                           : plan->cand;
-    unsigned long long h[3] = {0, 0, 0};
-    const bool nothing_to_find = triangle && ix->one_class != 0;      // nothing but copies of one sketch: every pair is inside the class
+    nothing_to_find = triangle && ix->one_class != 0;      // nothing but copies of one sketch: every pair is inside the class
     for (int attempt = 0; !nothing_to_find; attempt++) {
         rc = ensure_lists(want);
         if (rc != MG_OK) return rc;
@@ -751,19 +832,26 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
         if (attempt >= 1) return fail(ctx, MG_ERR_INVALID, "compare: the table changed while it was compared");
         want = h[0];
     }
+    return MG_OK;
+}
+
+int SparseJobRun::choose_engine()
+{
     if (first) {
         fresh.cand = h[0];
         fresh.shared = h[1];
         // seconds, one MI355X (measured: profiles/r03_sparse_phases.txt)
         const double np = (double)pairs;
-        const double t_sparse = np * 8.0 / 4.5e12 + (double)fresh.shared * 2.0e-12 + (double)nrows * s * 4.0e-11 + (double)fresh.cand * 1.0e-9 + 2.0e-5 +
-                                (triangle ? (double)ix->cls_pairs * 8.0 / 2.0e12 : 0.0) + (double)fresh.dense_pairs * 3.0e-11;
-        const double dense_rate = np < 3.0e8 ? 8.0e9 : np < 2.0e9 ? 1.5e10 : 3.0e10;
+        const SparseCosts &K = kSparseCosts;
+        const double t_sparse = np * 8.0 / K.fill_bytes_s + (double)fresh.shared * K.discover_per_shared + (double)nrows * s * K.discover_per_entry +
+                                (double)fresh.cand * K.merge_per_candidate + K.launches + (triangle ? (double)ix->cls_pairs * 8.0 / K.class_bytes_s : 0.0) +
+                                (double)fresh.dense_pairs * K.dense_per_pair;
+        const double dense_rate = np < 3.0e8 ? K.tiles_rate_small : np < 2.0e9 ? K.tiles_rate_mid : K.tiles_rate_large;
         // (what a shared hash costs the tile engine: 2.2e-12 s between copies of one sketch, 5.5e-12 inside clades -- and
         //  1.2e-11 in a collection of one species, where every pair shares a few hundred values and no two rows the same
         //  ones (round 5's one_species bracket: 1.58 s for 5.4e8 pairs where the model said 0.33); priced at the upper
         //  middle, the copies and clades having engines of their own by now)
-        const double t_dense = np / dense_rate + (double)fresh.shared * 8.0e-12;
+        const double t_dense = np / dense_rate + (double)fresh.shared * K.tiles_per_shared;
         fresh.use = t_sparse < t_dense;
         if (ctx_opt(ctx, "MASHGPU_SPARSE_DBG"))
             fprintf(stderr, "compare sparse: rows [%llu, %llu) %s: %llu pairs, %llu candidates, %llu shared hashes; model sparse %.3f ms, tiles %.3f ms\n",
@@ -780,8 +868,12 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
             plan = &ix->plans.back();
         }
     }
-    if (!force && !plan->use) return MG_OK;
+    if (!force && !plan->use) return leave();
+    return MG_OK;
+}
 
+int SparseJobRun::fill_and_dense()
+{
     // ---- fill.  The candidates' results are kept in list order and scattered into the output after it.
     // (Round 5 measured the fill beside the index build by tiles -- kernels that wait for round trips far more than they move
     // bytes -- on a stream of its own, 2 to 16 of its workgroups per CU: the step took 15.8 - 16.6 ms against 16.0 one after
@@ -823,7 +915,12 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
         job->dtile_rows = plan->dtile_rows;
         job->dense_pairs = plan->ndtiles ? plan->dense_pairs : 0;
     }
-    if (plan->cand == 0) return MG_OK;
+    if (plan->cand == 0) return leave();
+    return MG_OK;
+}
+
+int SparseJobRun::merge_and_scatter()
+{
     // ---- merge ----
     bool by_rows = mg::sparse_merge_rows_supported(a.rs_row);
     if (const char *ev = ctx_opt(ctx, "MASHGPU_SPARSE_MERGE")) by_rows = by_rows && strcmp(ev, "lanes") != 0;
@@ -856,6 +953,26 @@ static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table 
     }
     return MG_OK;
 }
+
+int SparseJobRun::run()
+{
+    if ((rc = open_index()) != MG_OK || stop) return rc;
+    if ((rc = row_side()) != MG_OK || stop) return rc;
+    if ((rc = find_plan()) != MG_OK || stop) return rc;
+    if ((rc = discover()) != MG_OK || stop) return rc;
+    if ((rc = choose_engine()) != MG_OK || stop) return rc;
+    if ((rc = fill_and_dense()) != MG_OK || stop) return rc;
+    return merge_and_scatter();
+}
+
+static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, uint64_t row_begin, uint64_t row_end,
+                              bool triangle, uint32_t s, mg_counts *out_dev, bool force, bool *handled, SparseJob *job = nullptr)
+{
+    *handled = false;
+    SparseJobRun run(ctx, rows, cols, row_begin, row_end, triangle, s, out_dev, force, handled, job);
+    return run.run();
+}
+
 
 // Engine choice (MASHGPU_COMPARE_KERNEL forces one: sparse | merged | generic):
 //   1. the inverted-index engine (compare_sparse.hip) when its counting pass says the job is sparse
