@@ -439,8 +439,7 @@ int SparseIndexBuild::lay_out()
     E = (uint32_t)E64;
     sp->E = E;
     end_bit = (uint32_t)(64 - __builtin_clzll(maxv | 1ull));
-    // transient buffers (back to the pool at the end of this function, in stream order)
-    // The sort looks at the values' leading bits only (compare_sparse.hip: sparse_sort_begin_bit sizes that for values spread
+    // The fallback sort looks at the values' leading bits only (compare_sparse.hip: sparse_sort_begin_bit sizes that for values spread
     // evenly below the largest one).  A collection of genomes of many sizes is not spread evenly: a row's s smallest hashes
     // fill [0, its largest hash], so the low end of the range holds the values of every row and the high end those of the
     // small genomes only.  Where the values are dense they need more bits to be told apart: the expected number of pairs
@@ -448,24 +447,19 @@ int SparseIndexBuild::lay_out()
     // largest hashes (by bit length); b is chosen for 2^13 of them at most, and never above the even-spread rule (sort_bits.h).
     sort_begin_bit = mg::sparse_sort_begin_bit(E, end_bit, ctx_opt(ctx, "MASHGPU_SPARSE_SORT_BITS"), ctx_opt(ctx, "MASHGPU_SPARSE_SORT_ALL_BITS") != nullptr);
     if (sort_begin_bit > 0 && !ctx_opt(ctx, "MASHGPU_SPARSE_SORT_BITS")) sort_begin_bit = mg::sort_begin_bit_from_density(dens, end_bit, sort_begin_bit);
-    // How the index is built (MASHGPU_SPARSE_INDEX): "tiles" (default) -- index_build.hip: one partition pass over tiles of
-    // (512 rows x a window of buckets), an LDS sort per bucket, the images written back row segment by row segment; "sort" --
-    // rounds 3-4: rocPRIM's radix sort on the leading bits + tie repair + head scan + scattered write-back, also what a
-    // table takes that the tiles refuse (a bucket beyond the LDS: a value held by thousands of rows, values far from
-    // evenly spread); "verify" -- both, compared word by word on the device (tests).
-    // ---- candidates for dense groups (compare_dense.hip): runs of at least 8 consecutive rows linked to their predecessors.
-    // Known before the index exists, so the build by tiles looks for their leaders while it has every group of equal values in
-    // LDS (index_build.h, IxLeaders); the build by the sort searches the finished index for them (dense_find_leaders).
+    // room for the dense groups' leaders (prepare_candidates): one list entry each, a quarter of the entries in all
     lead_lists = mg::dense_sublists();
     lead_cap = std::max<uint32_t>(E / 4u / lead_lists + 64u, 256u);
     const bool tiles_hopeless = ix_tiles && !ix_verify && lab_sorted && !ctx_opt(ctx, "MASHGPU_SPARSE_INDEX") &&
                                 longest_label_run(lab_sorted, n) > kTilesLongestRun;
     if (ix_tiles && !tiles_hopeless) plan = mg::index_plan((uint32_t)n, E, s, sp->rs, t->s, maxv, dens0, ix_verify);
     else if (tiles_hopeless) plan.why = "a clade of more rows than a bucket's sort takes";
-    // (the window offsets the clustered copy left are those of this plan, or K0 makes them again)
+    // the tiles' plan (index_build.hip; MASHGPU_SPARSE_INDEX=sort: none).  The window offsets the clustered copy left are
+    // those of this plan, or K0 makes them again.
     if (lb_made && !(plan.ok && memcmp(&plan.g, &early_plan.g, sizeof plan.g) == 0)) lb_made = false;
+    // transient buffers (members: back to the pool when the build object goes, in stream order) and the retained ones
     temp_bytes = std::max(std::max(mg::sparse_order_temp_bytes((uint32_t)n), mg::sparse_order_slice_temp_bytes((uint32_t)n)),
-                                       mg::sparse_offsets_temp_bytes((uint32_t)n));
+                          mg::sparse_offsets_temp_bytes((uint32_t)n));
     want_order = !ctx_opt(ctx, "MASHGPU_SPARSE_NO_ORDER");
     ok = temp.alloc(std::max<size_t>(temp_bytes, 16)) == hipSuccess && gs_of.alloc(E) == hipSuccess && d_stat.alloc(1) == hipSuccess &&
               d_slots.alloc(std::max(mg::sparse_stat_scratch_bytes(), mg::index_stat_scratch_bytes())) == hipSuccess &&
