@@ -89,6 +89,15 @@ static Table make_table(uint32_t s, uint64_t seed, const std::string &kind)
     } else if (kind == "short") {
         group(16, 1.06, 0.95, 0.03, 0, true);
         group(10, 1.3, 0.70, 0.30, 0, true);
+    } else if (kind == "fuzz") {
+        const uint32_t ng = 1 + (uint32_t)(rng() % 3);
+        for (uint32_t g = 0; g < ng; g++) {
+            const uint32_t m = 2 + (uint32_t)(rng() % (rng() % 4 == 0 ? 150 : 40));
+            const double pool_factor = 1.0 + (double)(rng() % 250) / 100.0, keep = 0.3 + (double)(rng() % 69) / 100.0, priv = (double)(rng() % 40) / 100.0;
+            const uint32_t clump = rng() % 3 == 0 ? (uint32_t)(rng() % 26) : 0u;
+            group(m, pool_factor, keep, priv, clump, rng() % 3 == 0);
+            if (rng() % 2) single();
+        }
     } else if (kind == "wide") {
         group(140, 3.0, 0.33, 0.02, 0, false);       // more rows than a block of 128: two blocks, several column blocks
     }
@@ -283,6 +292,18 @@ int main(int argc, char **argv)
         {"one_word", 40, 6, "near"},       // universes of one word
     };
     int rc = 0, ran = 0;
+    if (argc > 1 && std::string(argv[1]) == "fuzz") {      // dense_emu fuzz <seed> <cases>: groups of random shape
+        std::mt19937_64 rng(argc > 2 ? strtoull(argv[2], nullptr, 10) : 1);
+        const int count = argc > 3 ? atoi(argv[3]) : 30;
+        for (int i = 0; i < count; i++) {
+            const uint32_t s2 = 8 + (uint32_t)(rng() % (rng() % 3 == 0 ? 250 : 90));
+            char name[48];
+            snprintf(name, sizeof name, "fuzz %d", i);
+            rc |= run_case(name, s2, rng(), "fuzz");
+        }
+        printf(rc ? "FAILED\n" : "all cases agree\n");
+        return rc;
+    }
     for (const Case &c : cases) {
         bool want = argc < 2;
         for (int i = 1; i < argc; i++) want = want || std::string(argv[i]) == c.name || std::string(argv[i]) == "all";

@@ -256,6 +256,27 @@ int main(int argc, char **argv)
         {"twins", 2500, 16, 16, "twins", false, 1.0},             // neighbouring values with 1 800 holders each: ranked by comparison in LDS
         {"big_twins", 10000, 16, 15, "twins", true, 1.0},         // two values, thousands of holders each, that differ in the last bit: the flag
     };
+    if (which == "fuzz") {
+        // index_emu fuzz <seed> <cases>: tables of random shape and kind, bucket widths from a twentieth to twenty times the plan's
+        // (full buckets, several pieces per tile, buckets beyond the LDS on one side; windows of hundreds of buckets on the other)
+        std::mt19937_64 rng(argc > 2 ? strtoull(argv[2], nullptr, 10) : 1);
+        const int count = argc > 3 ? atoi(argv[3]) : 50;
+        const char *kinds[] = {"random", "ragged", "clusters", "copies", "sizes", "top", "clade"};
+        const double scales[] = {1.0, 1.0, 0.25, 0.05, 4.0, 20.0, 300.0};
+        for (int i = 0; i < count; i++) {
+            const char *kind = kinds[rng() % 7];
+            const uint32_t n = 1 + (uint32_t)(rng() % (rng() % 4 == 0 ? 1600 : 400)), s2 = 1 + (uint32_t)(rng() % (rng() % 3 == 0 ? 220 : 60));
+            double scale = scales[rng() % 7];
+            const uint64_t seed = rng();
+            // (a workgroup per bucket: keep their number where the emulator finishes in seconds)
+            while (scale > 1.0 && (double)n * s2 * scale / 2560.0 > 3000.0) scale /= 2.0;
+            char name[96];
+            snprintf(name, sizeof name, "fuzz %d: %s x%g seed %llu", i, kind, scale, (unsigned long long)seed);
+            rc |= run_case(name, n, s2, seed, kind, false, scale);
+        }
+        printf(rc ? "FAILED\n" : "all cases agree\n");
+        return rc;
+    }
     for (const Case &c : cases)
         if (which == "all" || which == c.name) rc |= run_case(c.name, c.n, c.s, c.seed, c.kind, c.fallback, c.dens_scale);
     printf(rc ? "FAILED\n" : "all cases agree\n");

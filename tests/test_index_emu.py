@@ -51,6 +51,14 @@ def test_index_kernels_on_the_cpu_slow(emu, case):
     assert r.returncode == 0 and "all cases agree" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+@pytest.mark.skipif(not os.environ.get("MASH_EMU_SLOW"), reason="a quarter of an hour of context switches: MASH_EMU_SLOW=1")
+def test_index_kernels_on_the_cpu_random_tables(emu):
+    """`index_emu fuzz <seed> <cases>`: tables of random shape and kind with bucket widths from a twentieth to twenty times the
+    plan's (full buckets, tiles in pieces, buckets beyond the LDS; windows of hundreds of buckets)"""
+    r = subprocess.run([emu, "fuzz", "20250926", "45"], capture_output=True, text=True, timeout=3000)
+    assert r.returncode == 0 and "all cases agree" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 @pytest.mark.skipif(not os.environ.get("MASH_EMU_TSAN"), reason="ThreadSanitizer over 512 OS threads per workgroup: MASH_EMU_TSAN=1")
 def test_index_kernels_under_thread_sanitizer(tmp_path):
     exe = str(tmp_path / "index_emu_tsan")
