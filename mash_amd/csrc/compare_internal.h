@@ -232,6 +232,43 @@ hipError_t launch_dense_gather_rows(const uint64_t *hashes, uint64_t stride, con
 // grp_of[n], lead_rows[4 n] (16-byte aligned) from the candidate groups (disjoint, ascending)
 hipError_t launch_dense_group_rows(const DenseGroup *groups, uint32_t ng, uint32_t n, uint32_t *grp_of, uint32_t *lead_rows, hipStream_t stream);
 
+// Join engine (compare_join.hip): collections in the middle of the similarity range -- every pair shares a tenth to a half
+// of its values, none is a near-copy.  Rows in blocks of 64; per block the list of its entries in value order, as groups of
+// equal values; a tile (block of rows, block of columns) intersects two lists and counts, per pair and in ascending order,
+// the common values whose rank in the pair's union is below s.  It writes every pair of its tiles: no fill, no discovery.
+struct JoinSide {
+    const uint2 *grp = nullptr;        // per group {value id (code >> 1), first entry}; one record more at the end
+    const uint32_t *ent = nullptr;     // per entry (position in its row << 8) | row in its block; rows ascend inside a group
+    const uint32_t *goff = nullptr;    // [blocks + 1] first group of a block
+    const uint32_t *gend = nullptr;    // [blocks] one past the block's last group that takes part (behind it: the entries left out)
+    const uint32_t *thr = nullptr;     // [blocks * 16] largest value id at position k s / 16 over the block's rows (nullptr: no early stop)
+};
+struct JoinArgs {
+    JoinSide rows, cols;               // triangle: the same lists
+    const uint32_t *row_cnt_off, *col_cnt_off;   // compact entry offsets: hash counts are differences
+    const uint32_t *rep;               // triangle on a table with copies: the row whose entries speak for a row (nullptr: itself)
+    const uint32_t *inv;               // index built on a permuted table: index row -> table row (nullptr: the same)
+    uint2 *out;
+    uint64_t out_base;                 // triangle: row_begin (row_begin - 1) / 2
+    uint64_t ntiles;
+    uint32_t ncols;                    // columns (triangle: rows of the table)
+    uint32_t row_begin, row_end;       // rows of the job
+    uint32_t bi0;                      // first block of rows of the job
+    uint32_t ncb;                      // rect: blocks of columns
+    uint32_t triangle, s;
+};
+uint32_t join_block_rows();
+uint32_t join_levels();
+size_t join_build_temp_bytes(uint64_t slots);
+hipError_t join_build_lists(const uint32_t *img, uint32_t rs, const uint32_t *cnt_off, const uint32_t *rep, uint32_t nrows, uint32_t s, uint32_t E,
+                            bool only_shared, void *temp, size_t temp_bytes, unsigned long long *key_a, unsigned long long *key_b, uint32_t *val_a,
+                            uint32_t *val_b, uint2 *grp, uint32_t *goff, uint32_t *gend, uint32_t *thr, const uint32_t **ent_out, hipStream_t stream);
+hipError_t launch_join_levels(const uint32_t *img, uint32_t rs, const uint32_t *cnt_off, const uint32_t *rep, uint32_t nrows, uint32_t s,
+                              uint32_t *thr, hipStream_t stream);
+hipError_t launch_join_shared(const uint32_t *lo_img, const uint32_t *hi_img, uint32_t lo_shift, uint32_t rs, const uint32_t *cnt_off,
+                              uint32_t row_begin, uint32_t row_end, unsigned long long *sum, hipStream_t stream);
+hipError_t launch_join_tiles(const JoinArgs &a, hipStream_t stream);
+
 // Distance filter + ordered compaction (see filter_pass_kernel).  `counts` holds
 // `pairs` entries in the layout the compare kernels write, starting at row
 // `first_row` (triangle row / query index).  Survivors with rank in

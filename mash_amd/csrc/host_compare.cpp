@@ -503,6 +503,12 @@ struct SparseCosts {
     // the upper middle, the copies and clades having engines of their own by now
     double tiles_rate_small = 8.0e9, tiles_rate_mid = 1.5e10, tiles_rate_large = 3.0e10;
     double tiles_per_shared = 8.0e-12;
+    // the join engine (compare_join.hip): a counter update per (pair, shared value); an intersection step of 64 x 64 group ids
+    // per tile (the lists' groups are bounded by their entries before the lists exist); the lists' sort per slot
+    double join_per_shared = 3.5e-13;
+    double join_per_step = 8.0e-11;
+    double join_per_slot = 8.0e-11;
+    double join_min_shared_per_pair = 4.0;   // below this many shared hashes per pair of the TABLE the engine is not even priced
 };
 static const SparseCosts kSparseCosts;
 
@@ -518,6 +524,7 @@ struct SparseJobRun {
     const uint32_t s;
     mg_counts *out_dev;
     const bool force;
+    const bool force_join;                                  // MASHGPU_COMPARE_KERNEL=join
     bool *handled;
     SparseJob *job;
     const uint64_t nrows, pairs;
@@ -540,8 +547,8 @@ struct SparseJobRun {
     bool nothing_to_find = false;
 
     SparseJobRun(mg_ctx *c, const mg_table *r, const mg_table *cl, uint64_t rb, uint64_t re, bool tri, uint32_t sketch_size, mg_counts *out, bool forced,
-                 bool *handled_out, SparseJob *list_job)
-        : ctx(c), rows(r), cols(cl), row_begin(rb), row_end(re), triangle(tri), s(sketch_size), out_dev(out), force(forced), handled(handled_out),
+                 bool forced_join, bool *handled_out, SparseJob *list_job)
+        : ctx(c), rows(r), cols(cl), row_begin(rb), row_end(re), triangle(tri), s(sketch_size), out_dev(out), force(forced), force_join(forced_join), handled(handled_out),
           job(list_job), nrows(re - rb), pairs(tri ? (re * (re - 1) / 2 - (rb ? rb * (rb - 1) / 2 : 0)) : (re - rb) * cl->n), q_off(c), q_img(c), q_lo(c),
           q_hi(c), q_short(c), q_short_cnt(c)
     {
@@ -561,6 +568,8 @@ struct SparseJobRun {
     int open_index();
     int row_side();
     int find_plan();
+    int keep_plan();
+    int join();
     int ensure_lists(uint64_t want_cand);
     int discover();
     int choose_engine();
@@ -700,7 +709,7 @@ int SparseJobRun::find_plan()
     first = plan == nullptr;
     if (first) {
         fresh.rows = rows; fresh.rb = row_begin; fresh.re = row_end; fresh.triangle = triangle;
-        fresh.cand = 0; fresh.shared = 0; fresh.use = true; fresh.order = nullptr;
+        fresh.cand = 0; fresh.shared = 0; fresh.use = true; fresh.join = false; fresh.order = nullptr;
         fresh.dtiles = nullptr; fresh.ndtiles = 0; fresh.dtile_rows = 32; fresh.dense_pairs = 0;
         if (triangle && !ix->dgroups_host.empty()) {
             // tiles of the dense groups' inner pairs: 32 or 8 rows (aligned to the group's first row) x a block of 128 columns
@@ -857,19 +866,158 @@ int SparseJobRun::choose_engine()
             fprintf(stderr, "compare sparse: rows [%llu, %llu) %s: %llu pairs, %llu candidates, %llu shared hashes; model sparse %.3f ms, tiles %.3f ms\n",
                     (unsigned long long)row_begin, (unsigned long long)row_end, triangle ? "triangle" : "rect", (unsigned long long)pairs,
                     (unsigned long long)fresh.cand, (unsigned long long)fresh.shared, t_sparse * 1e3, t_dense * 1e3);
-        if (triangle) {
-            if (ix->plans.size() >= 64) {
-                if (ix->plans.front().order) ctx_free(ctx, ix->plans.front().order);
-                if (ix->plans.front().dtiles) ctx_free(ctx, ix->plans.front().dtiles);
-                ix->plans.erase(ix->plans.begin());
-            }
-            ix->plans.push_back(fresh);
-            fresh_kept = true;
-            plan = &ix->plans.back();
-        }
+        keep_plan();
     }
     if (!force && !plan->use) return leave();
     return MG_OK;
+}
+
+// a fresh plan of a triangle job joins the index's list (rect: the query table may change between calls)
+int SparseJobRun::keep_plan()
+{
+    if (!triangle || fresh_kept) return MG_OK;
+    if (ix->plans.size() >= 64) {
+        if (ix->plans.front().order) ctx_free(ctx, ix->plans.front().order);
+        if (ix->plans.front().dtiles) ctx_free(ctx, ix->plans.front().dtiles);
+        ix->plans.erase(ix->plans.begin());
+    }
+    ix->plans.push_back(fresh);
+    fresh_kept = true;
+    plan = &ix->plans.back();
+    return MG_OK;
+}
+
+// ---- the join engine (compare_join.hip): a job in the middle of the similarity range -- so many shared hashes per pair that
+// reading them all to FIND the candidates (discovery) already costs more than counting them in rank order does.  Decided
+// before anything is discovered: the shared hashes of the job are the sum of the run lengths in the images (one small
+// kernel, exact), the cost of the join follows from them and the table's shape.  Taken: the lists of the table's blocks are
+// built once per table (rect: the queries' per call), the tiles write EVERY pair of the job, nothing else runs.
+struct JoinListBufs {
+    mg_ctx *ctx;
+    void *bufs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    mg::JoinSide side;
+    explicit JoinListBufs(mg_ctx *c) : ctx(c) {}
+    ~JoinListBufs() { for (void *q : bufs) if (q) ctx_free(ctx, q); }
+    void release_to(void **out) { for (int i = 0; i < 6; i++) { out[i] = bufs[i]; bufs[i] = nullptr; } }
+};
+
+static int join_make_lists(mg_ctx *ctx, const uint32_t *img, uint32_t rs, const uint32_t *cnt_off, const uint32_t *rep, uint32_t nrows, uint32_t s,
+                           uint32_t E, bool only_shared, JoinListBufs &L)
+{
+    const uint64_t slots = (uint64_t)nrows * s;
+    const uint32_t nblocks = (nrows + mg::join_block_rows() - 1u) / mg::join_block_rows();
+    const size_t tb = mg::join_build_temp_bytes(slots);
+    DevBuf<unsigned long long> key_a(ctx), key_b(ctx);
+    DevBuf<unsigned char> temp(ctx);
+    bool ok = key_a.alloc(slots) == hipSuccess && key_b.alloc(slots) == hipSuccess && temp.alloc(std::max<size_t>(tb, 16)) == hipSuccess;
+    const size_t want[6] = {(size_t)(slots + 1) * sizeof(uint2), (size_t)slots * 4, (size_t)slots * 4, (size_t)(nblocks + 1) * 4, (size_t)(nblocks + 1) * 4,
+                            (size_t)nblocks * mg::join_levels() * 4};
+    for (int i = 0; ok && i < 6; i++) ok = ctx_malloc(ctx, &L.bufs[i], want[i]) == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); return MG_ERR_NOMEM; }
+    const uint32_t *ent = nullptr;
+    hipError_t e = mg::join_build_lists(img, rs, cnt_off, rep, nrows, s, E, only_shared, temp, tb, key_a, key_b, static_cast<uint32_t *>(L.bufs[1]),
+                                        static_cast<uint32_t *>(L.bufs[2]), static_cast<uint2 *>(L.bufs[0]), static_cast<uint32_t *>(L.bufs[3]),
+                                        static_cast<uint32_t *>(L.bufs[4]), static_cast<uint32_t *>(L.bufs[5]), &ent, ctx->stream);
+    if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare (join lists): ") + hipGetErrorString(e));
+    L.side.grp = static_cast<const uint2 *>(L.bufs[0]);
+    L.side.ent = ent;
+    L.side.goff = static_cast<const uint32_t *>(L.bufs[3]);
+    L.side.gend = static_cast<const uint32_t *>(L.bufs[4]);
+    L.side.thr = static_cast<const uint32_t *>(L.bufs[5]);
+    return MG_OK;
+}
+
+int SparseJobRun::join()
+{
+    if (job) return MG_OK;                                  // list jobs want candidates, not a matrix
+    if (const char *e = ctx_opt(ctx, "MASHGPU_COMPARE_JOIN")) { if (atoi(e) == 0 && !force_join) return MG_OK; }
+    const uint32_t B = mg::join_block_rows();
+    const uint64_t nside = triangle ? cols->n : nrows;     // rows of the row side's index space
+    const bool can = s >= 1 && s <= 65535u && nside * s < (1ull << 32) && cols->n * (uint64_t)s < (1ull << 32) && ix->E >= 1;
+    if (!can) return force_join ? fail(ctx, MG_ERR_UNSUPPORTED, "compare: the join engine cannot take this job") : MG_OK;
+    bool take = force_join || (plan && !first && plan->join);
+    if (!take && first && !force) {
+        const SparseCosts &K = kSparseCosts;
+        const double table_pairs = triangle ? (double)cols->n * (double)(cols->n - 1) / 2.0 : (double)pairs;
+        // (the index's own statistic -- every value's holders choose 2, before any clipping -- rules most tables out for free;
+        //  rect: the queries are not part of it, the count below decides)
+        if (triangle && (double)ix->shared < K.join_min_shared_per_pair * table_pairs) return MG_OK;
+        DevBuf<unsigned long long> d_sum(ctx);
+        if (d_sum.alloc(1) != hipSuccess) { (void)hipGetLastError(); return MG_OK; }
+        unsigned long long shared_job = 0;
+        HIP_TRY(ctx, mg::launch_join_shared(a.lo_img, a.hi_img, a.lo_shift, a.rs_row, a.off, a.row_begin, a.row_end, d_sum, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(&shared_job, d_sum, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        const double np = (double)pairs, I = (double)shared_job;
+        const double nbr = (double)((nrows + B - 1) / B), nbc = (double)((cols->n + B - 1) / B);
+        const double tiles = triangle ? nbr * (double)((row_begin + row_end) / 2 / B + 1) : nbr * nbc;
+        const double per_block = (double)ix->E / nbc;                                     // entries of a block bound its groups
+        const double build = ix->jn.built ? 0.0 : (double)cols->n * s * K.join_per_slot;
+        const double t_join = np * 8.0 / K.fill_bytes_s + I * K.join_per_shared + tiles * 2.0 * per_block / 64.0 * K.join_per_step + build + K.launches;
+        // what the inverted index pays at the very least: the fill, and discovery reading every shared hash
+        const double t_sparse = np * 8.0 / K.fill_bytes_s + I * K.discover_per_shared + (double)nrows * s * K.discover_per_entry + K.launches;
+        take = t_join < 0.8 * t_sparse;
+        if (ctx_opt(ctx, "MASHGPU_SPARSE_DBG"))
+            fprintf(stderr, "compare join: rows [%llu, %llu) %s: %llu pairs, %llu shared hashes; model join %.3f ms, inverted index at least %.3f ms -> %s\n",
+                    (unsigned long long)row_begin, (unsigned long long)row_end, triangle ? "triangle" : "rect", (unsigned long long)pairs,
+                    (unsigned long long)shared_job, t_join * 1e3, t_sparse * 1e3, take ? "join" : "no");
+        fresh.shared = shared_job;
+    }
+    if (!take) return MG_OK;
+    // ---- the lists
+    const bool only_shared = triangle && ix->copies == 0;   // (a value of ONE row of the index and that row's copies has no shared bit)
+    if (ix->jn.built && ix->jn.only_shared != only_shared) {
+        for (void *&q : ix->jn.bufs) { if (q) ctx_free(ctx, q); q = nullptr; }
+        ix->jn.built = false;
+    }
+    if (!ix->jn.built) {
+        prof_begin(ctx, ctx->prof_index);
+        JoinListBufs L(ctx);
+        rc = join_make_lists(ctx, ix->code_img, ix->rs, ix->off, ix->rep, (uint32_t)cols->n, s, ix->E, only_shared, L);
+        prof_end(ctx, ctx->prof_index);
+        if (rc == MG_ERR_NOMEM) { if (force_join) return fail(ctx, rc, "compare: no device memory for the join lists"); return MG_OK; }
+        if (rc != MG_OK) return rc;
+        ix->jn.side = L.side;
+        L.release_to(ix->jn.bufs);
+        ix->jn.only_shared = only_shared;
+        ix->jn.built = true;
+    }
+    JoinListBufs Q(ctx);
+    mg::JoinArgs j;
+    j.cols = ix->jn.side;
+    if (triangle) {
+        j.rows = ix->jn.side;
+    } else {
+        // the queries' lists: their codes are 2 x (position in the table's sorted values) + 1 where the table holds the value
+        rc = join_make_lists(ctx, a.row_img, a.rs_row, a.off, nullptr, (uint32_t)nrows, s, ix->E, true, Q);
+        if (rc == MG_ERR_NOMEM) { if (force_join) return fail(ctx, rc, "compare: no device memory for the join lists"); return MG_OK; }
+        if (rc != MG_OK) return rc;
+        j.rows = Q.side;
+    }
+    if (ctx_opt(ctx, "MASHGPU_JOIN_NO_EARLY_STOP")) j.rows.thr = j.cols.thr = nullptr;
+    j.row_cnt_off = a.off;
+    j.col_cnt_off = ix->off;
+    j.rep = triangle ? ix->rep : nullptr;
+    j.inv = triangle ? ix->inv : nullptr;
+    j.out = reinterpret_cast<uint2 *>(out_dev);
+    j.out_base = a.out_base;
+    j.ncols = (uint32_t)cols->n;
+    j.row_begin = a.row_begin;
+    j.row_end = a.row_end;
+    j.bi0 = a.row_begin / B;
+    const uint64_t bi1 = ((uint64_t)a.row_end + B - 1) / B;
+    j.ncb = (uint32_t)((cols->n + B - 1) / B);
+    j.triangle = triangle ? 1u : 0u;
+    j.s = s;
+    j.ntiles = triangle ? bi1 * (bi1 + 1) / 2 - (uint64_t)j.bi0 * (j.bi0 + 1) / 2 : (bi1 - j.bi0) * (uint64_t)j.ncb;
+    prof_begin(ctx, ctx->prof_join);
+    hipError_t e = mg::launch_join_tiles(j, ctx->stream);
+    prof_end(ctx, ctx->prof_join);
+    if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare (join): ") + hipGetErrorString(e));
+    if (first) { fresh.join = true; fresh.use = true; keep_plan(); }
+    *handled = true;
+    if (!ctx->async || !triangle) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));     // (rect: the queries' lists go back to the pool)
+    return leave();
 }
 
 int SparseJobRun::fill_and_dense()
@@ -959,6 +1107,8 @@ int SparseJobRun::run()
     if ((rc = open_index()) != MG_OK || stop) return rc;
     if ((rc = row_side()) != MG_OK || stop) return rc;
     if ((rc = find_plan()) != MG_OK || stop) return rc;
+    if ((rc = join()) != MG_OK || stop) return rc;
+    if (force_join) return fail(ctx, MG_ERR_UNSUPPORTED, "compare: the join engine cannot take this job");
     if ((rc = discover()) != MG_OK || stop) return rc;
     if ((rc = choose_engine()) != MG_OK || stop) return rc;
     if ((rc = fill_and_dense()) != MG_OK || stop) return rc;
@@ -966,10 +1116,10 @@ int SparseJobRun::run()
 }
 
 static int run_compare_sparse(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, uint64_t row_begin, uint64_t row_end,
-                              bool triangle, uint32_t s, mg_counts *out_dev, bool force, bool *handled, SparseJob *job = nullptr)
+                              bool triangle, uint32_t s, mg_counts *out_dev, bool force, bool *handled, SparseJob *job = nullptr, bool force_join = false)
 {
     *handled = false;
-    SparseJobRun run(ctx, rows, cols, row_begin, row_end, triangle, s, out_dev, force, handled, job);
+    SparseJobRun run(ctx, rows, cols, row_begin, row_end, triangle, s, out_dev, force, force_join, handled, job);
     return run.run();
 }
 
@@ -1012,9 +1162,10 @@ static int run_compare(mg_ctx *ctx, const mg_table *rows, const mg_table *cols, 
     if (const char *e = ctx_opt(ctx, "MASHGPU_COMPARE_VARIANT")) a.unroll = (uint32_t)atoi(e);
     const char *force = ctx_opt(ctx, "MASHGPU_COMPARE_KERNEL");
     // Inverted-index engine first: it takes the job when the counting pass says so (or when forced)
-    if (!force || strcmp(force, "sparse") == 0) {
+    if (!force || strcmp(force, "sparse") == 0 || strcmp(force, "join") == 0) {
         bool handled = false;
-        const int rcs = run_compare_sparse(ctx, rows, cols, row_begin, row_end, triangle, a.s, out_dev, force != nullptr, &handled);
+        const int rcs = run_compare_sparse(ctx, rows, cols, row_begin, row_end, triangle, a.s, out_dev, force != nullptr, &handled, nullptr,
+                                           force && strcmp(force, "join") == 0);
         if (rcs != MG_OK || handled) return rcs;
         if (force) return fail(ctx, MG_ERR_UNSUPPORTED, "compare: the sparse engine cannot take this table");
     }

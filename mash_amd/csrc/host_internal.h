@@ -46,7 +46,7 @@ struct mg_ctx {
     bool prof = false;
     std::vector<ProfRec> prof_compare, prof_sketch;
     // phases of the inverted-index compare engine (compare_sparse.hip), each its own kernel
-    std::vector<ProfRec> prof_fill, prof_discover, prof_merge, prof_index, prof_dense;
+    std::vector<ProfRec> prof_fill, prof_discover, prof_merge, prof_index, prof_dense, prof_join;
     void *pin = nullptr;                                    // ctx_pinned
     size_t pin_cap = 0;
     // Entry points lock the context: any number of host threads may drive one context, one call at
@@ -138,8 +138,16 @@ struct mg_table {
         bool has_empty = false;            // some row has no hash at all
         uint32_t *short_rows = nullptr, *short_cnt = nullptr;    // rows with fewer than s hashes (ascending) and their counts
         std::vector<uint32_t> short_rows_host;
+        // join engine (compare_join.hip): the block lists of the table's rows, built the first time a job takes that engine
+        // (only_shared: values held by one row left out -- the triangle's variant; a rect job needs every entry)
+        struct Join {
+            bool built = false, only_shared = false;
+            mg::JoinSide side;
+            void *bufs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+            double build_ms = 0;
+        } jn;
         // what a (rows, range) job costs, learned by a counting pass the first time it is seen
-        struct Plan { const void *rows; uint64_t rb, re; bool triangle; uint64_t cand, shared; bool use; uint32_t *order;
+        struct Plan { const void *rows; uint64_t rb, re; bool triangle; uint64_t cand, shared; bool use; bool join; uint32_t *order;
                       mg::DenseTile *dtiles; uint32_t ndtiles, dtile_rows; uint64_t dense_pairs; };
         std::vector<Plan> plans;
         uint2 *cand = nullptr, *res = nullptr;    // candidate list and the candidates' results, grown on demand

@@ -346,6 +346,8 @@ static void table_drop_derived(mg_table *t)
                         (void *)sp->cls_rows, (void *)sp->cls_first, (void *)sp->order, (void *)sp->dgroups, (void *)sp->grp_of,
                         (void *)sp->ulist, (void *)sp->upos, (void *)sp->gdata, (void *)sp->xm, (void *)sp->ext, (void *)sp->inv, (void *)sp->phashes})
             if (q) ctx_free(ctx, q);
+        for (void *q : sp->jn.bufs)
+            if (q) ctx_free(ctx, q);
         delete sp;
     }
     t->sparse.clear();
@@ -396,7 +398,7 @@ int mg_prof_enable(mg_ctx *ctx, int on)
 void mg_prof_reset(mg_ctx *ctx)
 {
     if (!ctx) return;
-    for (auto *v : {&ctx->prof_compare, &ctx->prof_sketch, &ctx->prof_fill, &ctx->prof_discover, &ctx->prof_merge, &ctx->prof_index, &ctx->prof_dense}) {
+    for (auto *v : {&ctx->prof_compare, &ctx->prof_sketch, &ctx->prof_fill, &ctx->prof_discover, &ctx->prof_merge, &ctx->prof_index, &ctx->prof_dense, &ctx->prof_join}) {
         for (auto &r : *v) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
         v->clear();
     }
@@ -414,6 +416,7 @@ double mg_prof_avg_ms(mg_ctx *ctx, const char *name, uint64_t *launches_out)
     else if (strcmp(name, "compare_merge") == 0) v = &ctx->prof_merge;
     else if (strcmp(name, "compare_index") == 0) v = &ctx->prof_index;
     else if (strcmp(name, "compare_dense") == 0) v = &ctx->prof_dense;
+    else if (strcmp(name, "compare_join") == 0) v = &ctx->prof_join;
     if (!v || v->empty()) return 0.0;
     hipStreamSynchronize(ctx->stream);
     double tot = 0.0;

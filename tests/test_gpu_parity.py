@@ -630,7 +630,7 @@ def _oracle_tri(oracle, table, nhash, lengths, rb, re, k=21, kspace=KSPACE21):
     return numer, denom
 
 
-@pytest.mark.parametrize("kernel", ["merged", "sparse", "plain", "generic", "windows150"])
+@pytest.mark.parametrize("kernel", ["merged", "sparse", "join", "plain", "generic", "windows150"])
 def test_compare_reference_run_vectors(eng, golden_dir, kernel, monkeypatch):
     _set_kernel(monkeypatch, kernel)
     z = np.load(os.path.join(golden_dir, "ref_compare_vectors.npz"))
@@ -648,7 +648,7 @@ def test_compare_reference_run_vectors(eng, golden_dir, kernel, monkeypatch):
     t.free()
 
 
-@pytest.mark.parametrize("kernel", ["merged", "sparse", "plain", "generic", "windows", "windows150", "windows7"])
+@pytest.mark.parametrize("kernel", ["merged", "sparse", "join", "plain", "generic", "windows", "windows150", "windows7"])
 def test_compare_large_reference_run_vectors(eng, golden_dir, kernel, monkeypatch):
     """Counts produced by the reference's own objects at s = 3000: the default path there is the
     value-window mode; forced window sizes, the merge-path and the generic kernel must agree."""
@@ -668,7 +668,7 @@ def test_compare_large_reference_run_vectors(eng, golden_dir, kernel, monkeypatc
     t.free()
 
 
-@pytest.mark.parametrize("kernel", ["merged", "sparse", "plain", "windows29"])
+@pytest.mark.parametrize("kernel", ["merged", "sparse", "join", "plain", "windows29"])
 @pytest.mark.parametrize("s", [1, 7, 64, 65, 100, 400, 1000, 1024])
 def test_compare_tiled_vs_oracle_sizes(eng, oracle, s, kernel, monkeypatch):
     _set_kernel(monkeypatch, kernel)
@@ -693,7 +693,7 @@ def test_compare_tiled_vs_oracle_sizes(eng, oracle, s, kernel, monkeypatch):
     t.free()
 
 
-@pytest.mark.parametrize("kernel", ["merged", "sparse", "plain", "generic", "windows", "windows150"])
+@pytest.mark.parametrize("kernel", ["merged", "sparse", "join", "plain", "generic", "windows", "windows150"])
 @pytest.mark.parametrize("s", [1500, 4096, 10000])
 def test_compare_large_sketch(eng, oracle, s, kernel, monkeypatch):
     """Config-5 sized sketches (s = 10000): merged-rows kernel with few rows per tile, and the
@@ -1045,7 +1045,7 @@ def test_sparse_matrix_is_the_whole_matrix(eng, oracle, kind, monkeypatch):
     t.free()
 
 
-@pytest.mark.parametrize("kernel", ["default", "sparse", "merged"])
+@pytest.mark.parametrize("kernel", ["default", "sparse", "merged", "join"])
 def test_one_species_collection(eng, oracle, kernel, monkeypatch):
     """The middle of the similarity range: one species as a tree of descent (workloads/synth.species_sketches)
     -- every pair shares 10 - 50 % of its hashes, no near-copies, no small pool the rows draw from, rows in random order: nothing
@@ -1060,6 +1060,67 @@ def test_one_species_collection(eng, oracle, kernel, monkeypatch):
     t = eng.table_upload(table, nhash, lengths)
     got = eng.compare_tri_host(t)
     assert np.array_equal(got["numer"], numer) and np.array_equal(got["denom"], denom)
+    t.free()
+
+
+def test_one_species_takes_the_join_engine(eng, oracle, monkeypatch):
+    """A collection of one species large enough for the dispatch to look at (4.5e6 pairs): the shared hashes counted from the
+    images say the join engine (compare_join.hip) -- it must be the one that runs (its launches are recorded), on the first
+    call and on a cached plan, for the whole triangle (the index built on the clustered copy: results mapped back through
+    inv) and for a row range that cuts through blocks (the plain index); every pair against the oracle (compareSketches,
+    CommandDistance.cpp:347-385).  Then the same bytes with the engine switched off, and a rect job of the table's own rows
+    and strangers against it."""
+    n, s = 3000, 256
+    table, nhash, lengths = synth.species_sketches(n, s, seed=9)
+    nhash = nhash.copy()
+    nhash[17] = 0                                           # an empty row, short rows, a copy
+    nhash[1200] = 90
+    nhash[2999] = 201
+    table = table.copy()
+    table[777] = table[76]
+    numer, denom = _oracle_tri(oracle, table, nhash, lengths, 0, n)
+    t = eng.table_upload(table, nhash, lengths)
+    eng.prof_enable(True)
+    for rnd in range(2):                                    # (the second call: the plan cached with the table)
+        eng.prof_reset()
+        got = eng.compare_tri_host(t)
+        assert eng.prof_avg_ms("compare_join")[1] == 1 and eng.prof_avg_ms("compare_fill")[1] == 0, rnd
+        assert np.array_equal(got["numer"], numer) and np.array_equal(got["denom"], denom), rnd
+    rb, re = 1501, 2990
+    eng.prof_reset()
+    monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", "join")   # (3.3e6 pairs: below what the dispatch sends to an index at all)
+    got2 = eng.compare_tri_host(t, rb, re)
+    monkeypatch.delenv("MASHGPU_COMPARE_KERNEL")
+    assert eng.prof_avg_ms("compare_join")[1] == 1
+    base = rb * (rb - 1) // 2
+    cnt = re * (re - 1) // 2 - base
+    assert np.array_equal(got2["numer"], numer[base: base + cnt]) and np.array_equal(got2["denom"], denom[base: base + cnt])
+    # the other engines on the same table: the same bytes
+    monkeypatch.setenv("MASHGPU_COMPARE_JOIN", "0")
+    t.invalidate()
+    eng.prof_reset()
+    got3 = eng.compare_tri_host(t)
+    assert eng.prof_avg_ms("compare_join")[1] == 0
+    assert got3.tobytes() == got.tobytes()
+    monkeypatch.delenv("MASHGPU_COMPARE_JOIN")
+    eng.prof_enable(False)
+    # rect: 300 rows of the table and 40 strangers as queries
+    monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", "join")
+    other, onh, olen = synth.species_sketches(40, s, seed=10)
+    q = np.concatenate([table[1000:1300], other])
+    qn = np.concatenate([nhash[1000:1300], onh])
+    ql = np.concatenate([lengths[1000:1300], olen])
+    tq = eng.table_upload(q, qn, ql)
+    rect = eng.compare_rect_host(t, tq)
+    monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", "merged")
+    rect_m = eng.compare_rect_host(t, tq)
+    assert rect.tobytes() == rect_m.tobytes()
+    for qi in (0, 150, 299, 300, 339):
+        a_n = int(qn[qi])
+        for r in (0, 17, 76, 777, 1000 + min(qi, 299), 2999):
+            o = oracle.compare(q[qi, :a_n], table[r, : int(nhash[r])], 1000, 1000, s, 21, KSPACE21)
+            assert (int(rect[qi, r]["numer"]), int(rect[qi, r]["denom"])) == (o.numer, o.denom), (qi, r)
+    tq.free()
     t.free()
 
 
