@@ -246,8 +246,9 @@ struct JoinSide {
 struct JoinArgs {
     JoinSide rows, cols;               // triangle: the same lists
     const uint32_t *row_cnt_off, *col_cnt_off;   // compact entry offsets: hash counts are differences
-    const uint32_t *rep;               // triangle on a table with copies: the row whose entries speak for a row (nullptr: itself)
-    const uint32_t *inv;               // index built on a permuted table: index row -> table row (nullptr: the same)
+    const uint32_t *rep, *col_rep;     // the index row whose entries speak for a row / a column of the lists (nullptr: itself) -- a
+                                       // copy's representative, and the lists may stand on the rows in an order of their own
+    const uint32_t *inv;               // triangle: row of the lists -> row of the TABLE (nullptr: the same)
     uint2 *out;
     uint64_t out_base;                 // triangle: row_begin (row_begin - 1) / 2
     uint64_t ntiles;
@@ -257,6 +258,10 @@ struct JoinArgs {
     uint32_t ncb;                      // rect: blocks of columns
     uint32_t triangle, s;
 };
+size_t join_order_temp_bytes(uint32_t nrows);
+hipError_t join_order_rows(const uint32_t *img, uint32_t rs, const uint32_t *cnt_off, const uint32_t *rep, const uint32_t *inv, const uint32_t *gend,
+                           const uint32_t *sorted_rows, uint32_t nrows, void *temp, size_t temp_bytes, uint32_t *lab, unsigned long long *key_a,
+                           unsigned long long *key_b, uint32_t *val_a, uint32_t *perm, uint32_t *src, uint32_t *map, hipStream_t stream);
 uint32_t join_block_rows();
 uint32_t join_levels();
 size_t join_build_temp_bytes(uint64_t slots);

@@ -156,6 +156,76 @@ __global__ __launch_bounds__(256) void jn_shared_kernel(const uint32_t *lo_img, 
     if (threadIdx.x == 0) atomicAdd(sum, s_part[0] + s_part[1] + s_part[2] + s_part[3]);
 }
 
+// ------------------------------------------------------------------------------------------------ the rows' order
+// Which rows share a block decides what a tile costs: 64 relatives hold the same values (few groups per block, long holder
+// lists: the lanes of an update are busy), 64 strangers hold 64 different ones.  Any order is correct, so the lists are built
+// on the rows in an order of their own: a row's LABEL at radius R is the smallest row that holds one of its values whose run
+// has at most R holders (such a value marks a family of at most R rows; three jumps label -> label of the label close the
+// chains), and the rows are sorted by (label at 4096, label at 512, label at 64, row) -- families inside families, as a tree
+// of descent lists them.  One wave per row.
+constexpr uint32_t JN_RADIUS0 = 64, JN_RADIUS1 = 512, JN_RADIUS2 = 4096;
+
+__global__ __launch_bounds__(256) void jn_labels_kernel(const uint32_t *img, uint32_t rs, const uint32_t *cnt_off, const uint32_t *rep,
+                                                        const uint32_t *gend, const uint32_t *sorted_rows, uint32_t nrows, uint32_t *lab0,
+                                                        uint32_t *lab1, uint32_t *lab2)
+{
+    const uint32_t row = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (row >= nrows) return;                              // (whole waves)
+    const uint32_t src = rep ? rep[row] : row;             // (a copy takes its representative's family)
+    const uint32_t cnt = cnt_off[src + 1] - cnt_off[src];
+    uint32_t l0 = src, l1 = src, l2 = src;
+    for (uint32_t p = lane; p < cnt; p += 64u) {
+        const uint32_t code = img[(uint64_t)src * rs + p];
+        if (code & 1u) {
+            const uint32_t gs = code >> 1, len = gend[gs] - gs, f = sorted_rows[gs];
+            if (len <= JN_RADIUS0) l0 = f < l0 ? f : l0;
+            if (len <= JN_RADIUS1) l1 = f < l1 ? f : l1;
+            if (len <= JN_RADIUS2) l2 = f < l2 ? f : l2;
+        }
+    }
+    for (uint32_t d = 32; d; d >>= 1) {
+        const uint32_t o0 = __shfl_xor(l0, d), o1 = __shfl_xor(l1, d), o2 = __shfl_xor(l2, d);
+        l0 = o0 < l0 ? o0 : l0;
+        l1 = o1 < l1 ? o1 : l1;
+        l2 = o2 < l2 ? o2 : l2;
+    }
+    if (lane == 0) { lab0[row] = l0; lab1[row] = l1; lab2[row] = l2; }
+}
+
+__global__ __launch_bounds__(256) void jn_jump_kernel(const uint32_t *in0, const uint32_t *in1, const uint32_t *in2, uint32_t nrows, uint32_t *out0,
+                                                      uint32_t *out1, uint32_t *out2)
+{
+    const uint32_t row = blockIdx.x * 256u + threadIdx.x;
+    if (row >= nrows) return;
+    out0[row] = in0[in0[row]];
+    out1[row] = in1[in1[row]];
+    out2[row] = in2[in2[row]];
+}
+
+__global__ __launch_bounds__(256) void jn_order_keys_kernel(const uint32_t *lab0, const uint32_t *lab1, const uint32_t *lab2, uint32_t nrows, uint32_t bits,
+                                                            unsigned long long *key, uint32_t *val)
+{
+    const uint32_t row = blockIdx.x * 256u + threadIdx.x;
+    if (row >= nrows) return;
+    unsigned long long k = lab0[row];
+    k |= (unsigned long long)lab1[row] << bits;
+    if (3u * bits <= 64u) k |= (unsigned long long)lab2[row] << (2u * bits);
+    key[row] = k;
+    val[row] = row;
+}
+
+// perm[a] = the index row that is row a of the lists; src[a] = the index row whose entries speak for it (a copy: its
+// representative), map[a] = its row in the TABLE (inv: the index itself may stand on a permuted table)
+__global__ __launch_bounds__(256) void jn_order_maps_kernel(const uint32_t *perm, const uint32_t *rep, const uint32_t *inv, uint32_t nrows, uint32_t *src,
+                                                            uint32_t *map)
+{
+    const uint32_t a = blockIdx.x * 256u + threadIdx.x;
+    if (a >= nrows) return;
+    const uint32_t r = perm[a];
+    src[a] = rep ? rep[r] : r;
+    map[a] = inv ? inv[r] : r;
+}
+
 // ------------------------------------------------------------------------------------------------ the tiles
 // the holders of one matched value: `lanes` entries stand in the lanes (l < nl), `loop` entries are walked (n of them, held
 // by the lanes of `loopv`).  lanes_are_rows: the lanes' holders are rows of I (the loop's: columns of J), else the reverse.
@@ -329,7 +399,7 @@ __global__ __launch_bounds__(256) void jn_tile_kernel(JoinArgs a)
     const uint32_t j = bj * JN_B + lane;
     uint32_t nj = 0, tj = j;
     if (j < a.ncols) {
-        const uint32_t sj = a.rep ? a.rep[j] : j;
+        const uint32_t sj = a.col_rep ? a.col_rep[j] : j;
         nj = a.col_cnt_off[sj + 1] - a.col_cnt_off[sj];
         if (a.inv) tj = a.inv[j];
     }
@@ -406,6 +476,56 @@ size_t join_build_temp_bytes(uint64_t slots)
     return a > b ? a : b;
 }
 #endif
+
+size_t join_order_temp_bytes(uint32_t nrows)
+{
+#ifdef MG_HIP_EMU
+    (void)nrows;
+    return 16;
+#else
+    size_t a = 0;
+    rocprim::radix_sort_pairs(nullptr, a, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+                              (size_t)nrows, 0u, 64u, (hipStream_t) nullptr);
+    return a;
+#endif
+}
+
+// The rows' order for the lists (see jn_labels_kernel).  lab [6 nrows] u32 and key_a / key_b [nrows] u64, val_a [nrows] u32: scratch;
+// perm / src / map [nrows]: out.
+hipError_t join_order_rows(const uint32_t *img, uint32_t rs, const uint32_t *cnt_off, const uint32_t *rep, const uint32_t *inv, const uint32_t *gend,
+                           const uint32_t *sorted_rows, uint32_t nrows, void *temp, size_t temp_bytes, uint32_t *lab, unsigned long long *key_a,
+                           unsigned long long *key_b, uint32_t *val_a, uint32_t *perm, uint32_t *src, uint32_t *map, hipStream_t stream)
+{
+    if (nrows == 0) return hipSuccess;
+    uint32_t *a0 = lab, *a1 = lab + nrows, *a2 = lab + 2ull * nrows, *b0 = lab + 3ull * nrows, *b1 = lab + 4ull * nrows, *b2 = lab + 5ull * nrows;
+    const uint32_t g = (nrows + 255u) / 256u;
+    hipLaunchKernelGGL(jn_labels_kernel, dim3((nrows + 3u) / 4u), dim3(256), 0, stream, img, rs, cnt_off, rep, gend, sorted_rows, nrows, a0, a1, a2);
+    hipLaunchKernelGGL(jn_jump_kernel, dim3(g), dim3(256), 0, stream, (const uint32_t *)a0, (const uint32_t *)a1, (const uint32_t *)a2, nrows, b0, b1, b2);
+    hipLaunchKernelGGL(jn_jump_kernel, dim3(g), dim3(256), 0, stream, (const uint32_t *)b0, (const uint32_t *)b1, (const uint32_t *)b2, nrows, a0, a1, a2);
+    hipLaunchKernelGGL(jn_jump_kernel, dim3(g), dim3(256), 0, stream, (const uint32_t *)a0, (const uint32_t *)a1, (const uint32_t *)a2, nrows, b0, b1, b2);
+    uint32_t bits = 1;
+    while ((1ull << bits) < nrows) bits++;
+    hipLaunchKernelGGL(jn_order_keys_kernel, dim3(g), dim3(256), 0, stream, (const uint32_t *)b0, (const uint32_t *)b1, (const uint32_t *)b2, nrows, bits, key_a,
+                       val_a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const uint32_t key_bits = 3u * bits <= 64u ? 3u * bits : 2u * bits;
+#ifdef MG_HIP_EMU
+    {
+        std::vector<uint32_t> p(nrows);
+        std::iota(p.begin(), p.end(), 0u);
+        std::stable_sort(p.begin(), p.end(), [&](uint32_t x, uint32_t y) { return key_a[x] < key_a[y]; });
+        for (uint32_t a = 0; a < nrows; a++) perm[a] = val_a[p[a]];
+    }
+    (void)key_b; (void)temp; (void)temp_bytes; (void)key_bits;
+#else
+    e = rocprim::radix_sort_pairs(temp, temp_bytes, (const unsigned long long *)key_a, key_b, (const uint32_t *)val_a, perm, (size_t)nrows, 0u, key_bits,
+                                  stream);
+    if (e != hipSuccess) return e;
+#endif
+    hipLaunchKernelGGL(jn_order_maps_kernel, dim3(g), dim3(256), 0, stream, (const uint32_t *)perm, rep, inv, nrows, src, map);
+    return hipGetLastError();
+}
 
 // The lists of one side.  key_a / key_b [slots] u64 and val_a / val_b [slots] u32: the sort's buffers -- the entries end up
 // in *ent_out (one of val_a / val_b), the keys' buffers are scratch afterwards (heads and their scan live in key_a or

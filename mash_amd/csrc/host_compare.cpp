@@ -966,20 +966,47 @@ int SparseJobRun::join()
     if (!take) return MG_OK;
     // ---- the lists
     const bool only_shared = triangle && ix->copies == 0;   // (a value of ONE row of the index and that row's copies has no shared bit)
-    if (ix->jn.built && ix->jn.only_shared != only_shared) {
+    // the whole triangle: the lists on the rows in an order of their own, relatives side by side (compare_join.hip: jn_labels_kernel);
+    // a range of rows is a range of the lists' blocks only in the index's order
+    bool ordered = triangle && row_begin == 0 && row_end == cols->n;
+    if (const char *e = ctx_opt(ctx, "MASHGPU_JOIN_ORDER")) ordered = ordered && atoi(e) != 0;
+    if (ix->jn.built && (ix->jn.only_shared != only_shared || ix->jn.ordered != ordered)) {
         for (void *&q : ix->jn.bufs) { if (q) ctx_free(ctx, q); q = nullptr; }
         ix->jn.built = false;
     }
     if (!ix->jn.built) {
         prof_begin(ctx, ctx->prof_index);
+        const uint32_t n32 = (uint32_t)cols->n;
+        void *order_bufs[3] = {nullptr, nullptr, nullptr};                            // perm, src, map
+        struct OrderGuard { mg_ctx *c; void **b; ~OrderGuard() { for (int i = 0; i < 3; i++) if (b[i]) ctx_free(c, b[i]); } } og{ctx, order_bufs};
+        const uint32_t *src = ix->rep;
+        if (ordered) {
+            const size_t tb = mg::join_order_temp_bytes(n32);
+            DevBuf<unsigned char> temp(ctx);
+            DevBuf<uint32_t> lab(ctx), val_a(ctx);
+            DevBuf<unsigned long long> key_a(ctx), key_b(ctx);
+            bool ok = temp.alloc(std::max<size_t>(tb, 16)) == hipSuccess && lab.alloc(6ull * n32) == hipSuccess && val_a.alloc(n32) == hipSuccess &&
+                      key_a.alloc(n32) == hipSuccess && key_b.alloc(n32) == hipSuccess;
+            for (int i = 0; ok && i < 3; i++) ok = ctx_malloc(ctx, &order_bufs[i], (size_t)n32 * 4) == hipSuccess;
+            if (!ok) { (void)hipGetLastError(); if (force_join) return fail(ctx, MG_ERR_NOMEM, "compare: no device memory for the join order"); return MG_OK; }
+            hipError_t e = mg::join_order_rows(ix->code_img, ix->rs, ix->off, ix->rep, ix->inv, ix->gend, ix->sorted_rows, n32, temp, tb, lab, key_a, key_b, val_a,
+                                               static_cast<uint32_t *>(order_bufs[0]), static_cast<uint32_t *>(order_bufs[1]),
+                                               static_cast<uint32_t *>(order_bufs[2]), ctx->stream);
+            if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare (join order): ") + hipGetErrorString(e));
+            src = static_cast<const uint32_t *>(order_bufs[1]);
+        }
         JoinListBufs L(ctx);
-        rc = join_make_lists(ctx, ix->code_img, ix->rs, ix->off, ix->rep, (uint32_t)cols->n, s, ix->E, only_shared, L);
+        rc = join_make_lists(ctx, ix->code_img, ix->rs, ix->off, src, n32, s, ix->E, only_shared, L);
         prof_end(ctx, ctx->prof_index);
         if (rc == MG_ERR_NOMEM) { if (force_join) return fail(ctx, rc, "compare: no device memory for the join lists"); return MG_OK; }
         if (rc != MG_OK) return rc;
         ix->jn.side = L.side;
         L.release_to(ix->jn.bufs);
+        for (int i = 0; i < 3; i++) { ix->jn.bufs[6 + i] = order_bufs[i]; order_bufs[i] = nullptr; }
+        ix->jn.src = ordered ? static_cast<const uint32_t *>(ix->jn.bufs[7]) : nullptr;
+        ix->jn.map = ordered ? static_cast<const uint32_t *>(ix->jn.bufs[8]) : nullptr;
         ix->jn.only_shared = only_shared;
+        ix->jn.ordered = ordered;
         ix->jn.built = true;
     }
     JoinListBufs Q(ctx);
@@ -997,8 +1024,9 @@ int SparseJobRun::join()
     if (ctx_opt(ctx, "MASHGPU_JOIN_NO_EARLY_STOP")) j.rows.thr = j.cols.thr = nullptr;
     j.row_cnt_off = a.off;
     j.col_cnt_off = ix->off;
-    j.rep = triangle ? ix->rep : nullptr;
-    j.inv = triangle ? ix->inv : nullptr;
+    j.col_rep = ix->jn.ordered ? ix->jn.src : ix->rep;
+    j.rep = triangle ? j.col_rep : nullptr;
+    j.inv = triangle ? (ix->jn.ordered ? ix->jn.map : ix->inv) : nullptr;
     j.out = reinterpret_cast<uint2 *>(out_dev);
     j.out_base = a.out_base;
     j.ncols = (uint32_t)cols->n;

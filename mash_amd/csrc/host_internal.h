@@ -142,8 +142,10 @@ struct mg_table {
         // (only_shared: values held by one row left out -- the triangle's variant; a rect job needs every entry)
         struct Join {
             bool built = false, only_shared = false;
+            bool ordered = false;          // the lists stand on the rows in an order of their own (src / map; the whole triangle only)
             mg::JoinSide side;
-            void *bufs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+            const uint32_t *src = nullptr, *map = nullptr;
+            void *bufs[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
             double build_ms = 0;
         } jn;
         // what a (rows, range) job costs, learned by a counting pass the first time it is seen

@@ -95,7 +95,7 @@ static Rows pool_rows(uint32_t n, uint32_t s, std::mt19937_64 &rng, double pool_
 // 2 x (first sorted position of the value's group) + (another row of the index holds it too)
 struct Index {
     uint32_t n = 0, rs = 0, E = 0;
-    std::vector<uint32_t> off, code, rep;
+    std::vector<uint32_t> off, code, rep, gend, sorted_rows;
     std::vector<uint64_t> keys_sorted;
     bool copies = false;
 };
@@ -126,12 +126,16 @@ static Index build_index(const Rows &rows, uint32_t s, bool dedup)
     std::stable_sort(ent.begin(), ent.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
     ix.code.assign((size_t)ix.n * ix.rs + 64, 0xFFFFFFFFu);
     ix.keys_sorted.resize(ix.E);
+    ix.gend.assign(ix.E, 0xFFFFFFFFu);                      // (defined at the first position of a value's group only)
+    ix.sorted_rows.resize(ix.E);
     for (uint32_t e = 0; e < ix.E;) {
         uint32_t f = e;
         while (f < ix.E && ent[f].first == ent[e].first) f++;
+        ix.gend[e] = f;
         for (uint32_t g = e; g < f; g++) {
             ix.code[ent[g].second] = 2u * e + (f - e >= 2 ? 1u : 0u);
             ix.keys_sorted[g] = ent[g].first;
+            ix.sorted_rows[g] = ent[g].second / ix.rs;
         }
         e = f;
     }
@@ -162,7 +166,8 @@ static void make_lists(const uint32_t *img, uint32_t rs, const uint32_t *off, co
 static uint64_t g_pairs = 0, g_shared = 0;
 
 // triangle over rows [rb, re) of the table; perm: the index is built on the table in another order (index row a = table row inv[a])
-static int run_triangle(const Rows &table, uint32_t s, uint32_t rb, uint32_t re, bool permute, bool early, std::mt19937_64 &rng, const char *what)
+static int run_triangle(const Rows &table, uint32_t s, uint32_t rb, uint32_t re, bool permute, bool early, std::mt19937_64 &rng, const char *what,
+                        bool order = false)
 {
     const uint32_t n = (uint32_t)table.size();
     std::vector<uint32_t> inv(n);
@@ -173,13 +178,29 @@ static int run_triangle(const Rows &table, uint32_t s, uint32_t rb, uint32_t re,
     Index ix = build_index(rows, s, true);
     if (ix.E == 0) return 0;
     Lists L;
-    make_lists(ix.code.data(), ix.rs, ix.off.data(), ix.copies ? ix.rep.data() : nullptr, n, s, ix.E, !ix.copies, L);
+    const uint32_t *src = ix.copies ? ix.rep.data() : nullptr, *map = permute ? inv.data() : nullptr;
+    std::vector<uint32_t> o_perm(n), o_src(n), o_map(n);
+    if (order) {                                            // the lists on the rows in the order of their families (whole triangle only)
+        std::vector<uint32_t> lab(6ull * n), val_a(n);
+        std::vector<unsigned long long> key_a(n), key_b(n);
+        unsigned char temp[16];
+        if (join_order_rows(ix.code.data(), ix.rs, ix.off.data(), src, map, ix.gend.data(), ix.sorted_rows.data(), n, temp, 16, lab.data(), key_a.data(),
+                            key_b.data(), val_a.data(), o_perm.data(), o_src.data(), o_map.data(), nullptr) != hipSuccess) { fprintf(stderr, "join_order_rows failed\n"); return 1; }
+        std::vector<uint32_t> seen(n, 0);
+        for (uint32_t x : o_perm) seen[x]++;
+        for (uint32_t x : seen) if (x != 1) { fprintf(stderr, "%s: the order is no permutation\n", what); return 1; }
+        src = o_src.data();
+        map = o_map.data();
+        rb = 0; re = n;
+    }
+    make_lists(ix.code.data(), ix.rs, ix.off.data(), src, n, s, ix.E, !ix.copies, L);
     JoinArgs a;
     a.rows = a.cols = L.side;
     if (!early) a.rows.thr = a.cols.thr = nullptr;
     a.row_cnt_off = a.col_cnt_off = ix.off.data();
-    a.rep = ix.copies ? ix.rep.data() : nullptr;
-    a.inv = permute ? inv.data() : nullptr;
+    a.rep = a.col_rep = src;
+    a.inv = map;
+    permute = permute || order;
     const uint64_t out_base = rb ? (uint64_t)rb * (rb - 1) / 2 : 0, npairs = (uint64_t)re * (re - 1) / 2 - out_base;
     std::vector<uint2> out(npairs + 1, make_uint2(0xDEADBEEFu, 0xDEADBEEFu));
     a.out = out.data();
@@ -213,7 +234,7 @@ static int run_triangle(const Rows &table, uint32_t s, uint32_t rb, uint32_t re,
 // rect: queries located in the reference table's sorted values (sp_locate_kernel's scheme: 2 lo + 1 where found, else 2 lo)
 static int run_rect(const Rows &ref, const Rows &qry, uint32_t s, bool early, const char *what)
 {
-    Index ix = build_index(ref, s, false);
+    Index ix = build_index(ref, s, true);                 // (copies among the reference rows stay out of the index)
     if (ix.E == 0) return 0;
     const uint32_t nq = (uint32_t)qry.size(), nr = (uint32_t)ref.size();
     std::vector<uint32_t> qoff(nq + 1, 0), qimg((size_t)nq * ix.rs + 64, 0xFFFFFFFFu);
@@ -226,7 +247,7 @@ static int run_rect(const Rows &ref, const Rows &qry, uint32_t s, bool early, co
         }
     }
     Lists LC, LQ;
-    make_lists(ix.code.data(), ix.rs, ix.off.data(), nullptr, nr, s, ix.E, false, LC);
+    make_lists(ix.code.data(), ix.rs, ix.off.data(), ix.copies ? ix.rep.data() : nullptr, nr, s, ix.E, false, LC);
     make_lists(qimg.data(), ix.rs, qoff.data(), nullptr, nq, s, ix.E, true, LQ);
     JoinArgs a;
     a.rows = LQ.side;
@@ -235,6 +256,7 @@ static int run_rect(const Rows &ref, const Rows &qry, uint32_t s, bool early, co
     a.row_cnt_off = qoff.data();
     a.col_cnt_off = ix.off.data();
     a.rep = nullptr;
+    a.col_rep = ix.copies ? ix.rep.data() : nullptr;
     a.inv = nullptr;
     std::vector<uint2> out((size_t)nq * nr + 1, make_uint2(0xDEADBEEFu, 0xDEADBEEFu));
     a.out = out.data();
@@ -301,6 +323,8 @@ int main(int argc, char **argv)
         Rows t = species(150, 96, rng, 0.06, 0.2, false);
         bad += run_triangle(t, 96, 0, 150, false, true, rng, "species");
         bad += run_triangle(t, 96, 0, 150, false, false, rng, "species, no early stop");
+        bad += run_triangle(t, 96, 0, 150, false, true, rng, "species, rows by family", true);
+        bad += run_triangle(t, 96, 0, 150, true, true, rng, "species, rows by family over a permuted index", true);
         bad += check_shared(t, 96);
     } else if (which == "ranges") {
         // row ranges that start and end inside blocks; the permuted index
@@ -322,6 +346,7 @@ int main(int argc, char **argv)
         t[70] = t[3]; t[71] = t[3]; t[5] = t[3];
         bad += run_triangle(t, 40, 0, 80, false, true, rng, "copies");
         bad += run_triangle(t, 40, 0, 80, true, true, rng, "copies, permuted");
+        bad += run_triangle(t, 40, 0, 80, false, true, rng, "copies, rows by family", true);
     } else if (which == "near") {
         // near-copies: every value held by nearly every row (holder lists of 64 on both sides), s reached long before the lists end
         Rows t = pool_rows(130, 64, rng, 1.05, 0.95, false);
@@ -338,6 +363,7 @@ int main(int argc, char **argv)
         if (g_shared != 0) { fprintf(stderr, "random rows share values?\n"); bad++; }
     } else if (which == "rect") {
         Rows ref = species(140, 64, rng, 0.05, 0.2, false);
+        ref[100] = ref[30]; ref[101] = ref[30]; ref[7] = ref[139];      // copies among the reference rows
         Rows qry(ref.begin() + 20, ref.begin() + 95);       // 75 queries: some rows of the table itself
         Rows more = pool_rows(10, 64, rng, 1.5, 0.6, true); // and strangers of every length
         qry.insert(qry.end(), more.begin(), more.end());
@@ -355,7 +381,7 @@ int main(int argc, char **argv)
             if (rng() % 2) { rb = (uint32_t)(rng() % n); re = rb + 1 + (uint32_t)(rng() % (n - rb)); }
             char what[96];
             snprintf(what, sizeof what, "fuzz %d (n %u, s %u, kind %d, rows [%u, %u))", c, n, s, kind, rb, re);
-            bad += run_triangle(t, s, rb, re, rb == 0 && re == n && rng() % 2, rng() % 4 != 0, rng, what);
+            bad += run_triangle(t, s, rb, re, rb == 0 && re == n && rng() % 2, rng() % 4 != 0, rng, what, rb == 0 && re == n && rng() % 2);
             if (bad) break;
         }
     } else {
