@@ -43,6 +43,12 @@ constexpr uint32_t JN_B = 64;            // rows per block
 constexpr uint32_t JN_STRIDE = 66;       // u16 counters per row of a tile (33 dwords: rows fall into distinct banks)
 constexpr uint32_t JN_LEVELS = 16;       // positions k s / 16 at which a block's progress is known (k = 1 .. 15)
 
+// pointers into the tile's counters keep their address space (kept in arrays they would decay to flat pointers: flat stores)
+#ifdef MG_HIP_EMU
+#define JN_LDS
+#else
+#define JN_LDS __attribute__((address_space(3)))
+#endif
 #ifdef MG_HIP_EMU
 static inline uint32_t jn_readlane(uint32_t v, uint32_t l) { return __shfl(v, l); }
 static inline uint32_t jn_ctz64(uint64_t m) { return (uint32_t)__builtin_ctzll(m); }
@@ -227,12 +233,22 @@ __global__ __launch_bounds__(256) void jn_order_maps_kernel(const uint32_t *perm
 }
 
 // ------------------------------------------------------------------------------------------------ the tiles
+#ifndef MG_HIP_EMU
+// c + (c > lim): a compare into the carry and an add with carry
+__device__ __forceinline__ uint32_t jn_bump(uint32_t c, int lim)
+{
+    uint32_t r;
+    asm volatile("v_cmp_lt_i32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, 0, %1, vcc" : "=v"(r) : "v"(c), "v"(lim) : "vcc");
+    return r;
+}
+#endif
+
 // the holders of one matched value: `lanes` entries stand in the lanes (l < nl), `loop` entries are walked (n of them, held
 // by the lanes of `loopv`).  lanes_are_rows: the lanes' holders are rows of I (the loop's: columns of J), else the reverse.
 // Every lane of the wave touches a counter of its own (distinct rows, or distinct columns), and the counters of two loop
 // entries differ too: four of them are read before any is written back -- the reads' round trips overlap.
 template <bool DIAG>
-__device__ __forceinline__ void jn_update(uint16_t *cnt, uint32_t lane, uint32_t lanev, uint32_t nl, uint32_t loopv, uint32_t n,
+__device__ __forceinline__ void jn_update(JN_LDS uint16_t *cnt, uint32_t lane, uint32_t lanev, uint32_t nl, uint32_t loopv, uint32_t n,
                                           bool lanes_are_rows, int s)
 {
     const uint32_t lr = lanev & 0xFFu;
@@ -242,7 +258,7 @@ __device__ __forceinline__ void jn_update(uint16_t *cnt, uint32_t lane, uint32_t
     // one entry of the loop side: its counter, and whether this lane's pair with it is one of the tile (the tile on the
     // diagonal joins a block with itself: a pair is (row, column below it))
 #define JN_ENTRY(o, at, lim, ok)                                                  \
-    uint16_t *at = cnt + base + ((o) & 0xFFu) * step;                             \
+    JN_LDS uint16_t *at = cnt + base + ((o) & 0xFFu) * step;                      \
     const int lim = q + (int)((o) >> 8);                                          \
     const bool ok = !DIAG || (lanes_are_rows ? ((o) & 0xFFu) < lr : lr < ((o) & 0xFFu));
 #ifdef MG_HIP_EMU
@@ -258,6 +274,31 @@ __device__ __forceinline__ void jn_update(uint16_t *cnt, uint32_t lane, uint32_t
     n = (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
     if (lane < nl) {
         uint32_t t = 0;
+        if (!DIAG && n >= 8u) {
+            // eight entries in flight: the counter of entry t + 8 is requested as soon as the one of entry t is written back (the
+            // entries of one value are distinct holders: distinct counters), so a round trip to the LDS is hidden behind seven
+            // others instead of being waited for
+            uint32_t o[8], c[8];
+            JN_LDS uint16_t *at[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                o[u] = jn_readlane(loopv, (uint32_t)u);
+                at[u] = cnt + base + (o[u] & 0xFFu) * step;
+                c[u] = *at[u];
+            }
+            for (; t + 16u <= n; t += 8u) {
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    *at[u] = (uint16_t)jn_bump(c[u], q + (int)(o[u] >> 8));
+                    o[u] = jn_readlane(loopv, t + 8u + (uint32_t)u);
+                    at[u] = cnt + base + (o[u] & 0xFFu) * step;
+                    c[u] = *at[u];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) *at[u] = (uint16_t)jn_bump(c[u], q + (int)(o[u] >> 8));
+            t += 8u;
+        }
         for (; t + 4u <= n; t += 4u) {
             const uint32_t o0 = jn_readlane(loopv, t), o1 = jn_readlane(loopv, t + 1u), o2 = jn_readlane(loopv, t + 2u), o3 = jn_readlane(loopv, t + 3u);
             JN_ENTRY(o0, at0, lim0, ok0)
@@ -281,8 +322,12 @@ __device__ __forceinline__ void jn_update(uint16_t *cnt, uint32_t lane, uint32_t
 #undef JN_ENTRY
 }
 
+// One tile.  Three things are a round trip to memory away -- the next 64 group records of either list, the holders of a
+// step's first matched value, the holders of the value after the one being worked on -- and each is requested one stage
+// before it is needed: the windows of step k + 1 when those of step k have arrived (the two lists' largest ids decide which
+// list moves on), the first holders of step k while the matches of step k - 1 are worked on, every further match one ahead.
 template <bool DIAG>
-__device__ __forceinline__ void jn_tile(const JoinArgs &a, uint16_t *cnt, uint32_t lane, uint32_t bi, uint32_t bj)
+__device__ __forceinline__ void jn_tile(const JoinArgs &a, JN_LDS uint16_t *cnt, uint32_t lane, uint32_t bi, uint32_t bj)
 {
     const JoinSide &RI = a.rows, &CJ = a.cols;
     uint32_t ga = RI.goff[bi], gb = CJ.goff[bj];
@@ -293,44 +338,56 @@ __device__ __forceinline__ void jn_tile(const JoinArgs &a, uint16_t *cnt, uint32
     uint32_t kI = 0, kJ = 0;
     uint32_t nextI = thrI ? thrI[1] : 0xFFFFFFFFu, nextJ = thrJ ? thrJ[1] : 0xFFFFFFFFu;
     bool done = false;
-    while (ga < ga_end && gb < gb_end && !done) {           // uniform
-        const uint32_t na = ga_end - ga < 64u ? ga_end - ga : 64u, nb = gb_end - gb < 64u ? gb_end - gb : 64u;
-        uint2 ra = make_uint2(0xFFFFFFFFu, 0u), rb = make_uint2(0xFFFFFFFFu, 0u);
-        uint32_t ea1 = 0, eb1 = 0;                          // where the NEXT group's entries start = one past this group's
-        if (lane < na) { ra = RI.grp[ga + lane]; ea1 = RI.grp[ga + lane + 1u].y; }
-        if (lane < nb) { rb = CJ.grp[gb + lane]; eb1 = CJ.grp[gb + lane + 1u].y; }
-        const uint32_t amax = jn_readlane(ra.x, na - 1u), bmax = jn_readlane(rb.x, nb - 1u);
+
+    // a window: 64 group records of either list (value id, first entry, one past the last entry)
+    struct Win { uint32_t ax, ay, ae, bx, by, be, na, nb; };
+    auto load_win = [&](uint32_t pa, uint32_t pb) {
+        Win w;
+        w.na = ga_end - pa < 64u ? ga_end - pa : 64u;
+        w.nb = gb_end - pb < 64u ? gb_end - pb : 64u;
+        w.ax = w.bx = 0xFFFFFFFFu;
+        w.ay = w.ae = w.by = w.be = 0;
+        if (lane < w.na) { const uint2 r = RI.grp[pa + lane]; w.ax = r.x; w.ay = r.y; w.ae = RI.grp[pa + lane + 1u].y; }
+        if (lane < w.nb) { const uint2 r = CJ.grp[pb + lane]; w.bx = r.x; w.by = r.y; w.be = CJ.grp[pb + lane + 1u].y; }
+        return w;
+    };
+    // the matches of a step: per lane of list I its group's entries and those of the group of list J that holds the same
+    // value; m: the lanes that found one; cur*: the holders of the first of them, requested when the step was prepared
+    struct Step { uint32_t id, a0, a1, b0, b1; uint64_t m; uint32_t curA, curB, cna, cnb, cid; };
+    auto fetch = [&](const Step &S, uint32_t l, uint32_t &va, uint32_t &vb, uint32_t &na, uint32_t &nb, uint32_t &id) {
+        const uint32_t a0 = jn_readlane(S.a0, l), b0 = jn_readlane(S.b0, l);
+        na = jn_readlane(S.a1, l) - a0;
+        nb = jn_readlane(S.b1, l) - b0;
+        id = jn_readlane(S.id, l);
+        va = vb = 0;
+        if (lane < na) va = RI.ent[a0 + lane];
+        if (lane < nb) vb = CJ.ent[b0 + lane];
+    };
+    auto prepare = [&](const Win &w) {
         // every lane looks its value id up among the 64 of the other list: lower bound by bisection through the lanes
         uint32_t pos = 0;
         for (uint32_t st = 32; st; st >>= 1) {
-            const uint32_t v = __shfl(rb.x, pos + st - 1u);
-            if (v < ra.x) pos += st;
+            const uint32_t v = __shfl(w.bx, pos + st - 1u);
+            if (v < w.ax) pos += st;
         }
-        const uint32_t hitv = __shfl(rb.x, pos), hb0 = __shfl(rb.y, pos), hb1 = __shfl(eb1, pos);
-        uint64_t m = __ballot(hitv == ra.x && ra.x != 0xFFFFFFFFu);
+        Step S;
+        S.id = w.ax; S.a0 = w.ay; S.a1 = w.ae;
+        const uint32_t hitv = __shfl(w.bx, pos);
+        S.b0 = __shfl(w.by, pos);
+        S.b1 = __shfl(w.be, pos);
+        S.m = __ballot(hitv == w.ax && w.ax != 0xFFFFFFFFu);
+        S.curA = S.curB = S.cna = S.cnb = S.cid = 0;
+        if (S.m) fetch(S, jn_ctz64(S.m), S.curA, S.curB, S.cna, S.cnb, S.cid);
+        return S;
+    };
+    auto process = [&](Step &S) {
         // the matched values, ascending; the holders of the next one are requested before this one's are worked on
-        uint32_t curA = 0, curB = 0, cna = 0, cnb = 0, cid = 0;
-        if (m) {
-            const uint32_t l = jn_ctz64(m);
-            const uint32_t a0 = jn_readlane(ra.y, l), b0 = jn_readlane(hb0, l);
-            cna = jn_readlane(ea1, l) - a0;
-            cnb = jn_readlane(hb1, l) - b0;
-            cid = jn_readlane(ra.x, l);
-            if (lane < cna) curA = RI.ent[a0 + lane];
-            if (lane < cnb) curB = CJ.ent[b0 + lane];
-        }
+        uint64_t m = S.m;
+        uint32_t curA = S.curA, curB = S.curB, cna = S.cna, cnb = S.cnb, cid = S.cid;
         while (m) {                                         // uniform
             m &= m - 1;
             uint32_t nxtA = 0, nxtB = 0, nna = 0, nnb = 0, nid = 0;
-            if (m) {
-                const uint32_t l = jn_ctz64(m);
-                const uint32_t a0 = jn_readlane(ra.y, l), b0 = jn_readlane(hb0, l);
-                nna = jn_readlane(ea1, l) - a0;
-                nnb = jn_readlane(hb1, l) - b0;
-                nid = jn_readlane(ra.x, l);
-                if (lane < nna) nxtA = RI.ent[a0 + lane];
-                if (lane < nnb) nxtB = CJ.ent[b0 + lane];
-            }
+            if (m) fetch(S, jn_ctz64(m), nxtA, nxtB, nna, nnb, nid);
             // early stop: what the blocks' levels say about the positions of this and every later value
             if (cid > nextI || cid > nextJ) {
                 while (kI + 1u < JN_LEVELS && cid > nextI) { kI++; nextI = kI + 1u < JN_LEVELS ? thrI[kI + 1u] : 0xFFFFFFFFu; }
@@ -341,7 +398,7 @@ __device__ __forceinline__ void jn_tile(const JoinArgs &a, uint16_t *cnt, uint32
                 if (floor_rank >= a.s) {
                     jn_lanes_in_step();
                     uint32_t cm = 0;
-                    const uint32_t *c32 = reinterpret_cast<const uint32_t *>(cnt);
+                    const JN_LDS uint32_t *c32 = (const JN_LDS uint32_t *)cnt;
                     for (uint32_t u = lane; u < JN_B * JN_STRIDE / 2u; u += 64u) {
                         const uint32_t x = c32[u], lo = x & 0xFFFFu, hi = x >> 16;
                         cm = lo > cm ? lo : cm;
@@ -358,9 +415,28 @@ __device__ __forceinline__ void jn_tile(const JoinArgs &a, uint16_t *cnt, uint32
             else jn_update<DIAG>(cnt, lane, curB, cnb, curA, cna, false, s);
             curA = nxtA; curB = nxtB; cna = nna; cnb = nnb; cid = nid;
         }
-        if (amax <= bmax) ga += na;
-        if (bmax <= amax) gb += nb;
+    };
+
+    if (!(ga < ga_end && gb < gb_end)) return;             // uniform
+    Win w = load_win(ga, gb);
+    Step prev;
+    prev.m = 0;
+    prev.id = prev.a0 = prev.a1 = prev.b0 = prev.b1 = prev.curA = prev.curB = prev.cna = prev.cnb = prev.cid = 0;
+    bool have = true;
+    while (have && !done) {                                 // uniform
+        // which list moves on: the one whose 64 ids end lower (both if they end alike)
+        const uint32_t amax = jn_readlane(w.ax, w.na - 1u), bmax = jn_readlane(w.bx, w.nb - 1u);
+        if (amax <= bmax) ga += w.na;
+        if (bmax <= amax) gb += w.nb;
+        have = ga < ga_end && gb < gb_end;
+        Win wn = w;
+        if (have) wn = load_win(ga, gb);
+        Step cur = prepare(w);
+        process(prev);
+        prev = cur;
+        w = wn;
     }
+    if (!done) process(prev);
 }
 
 __global__ __launch_bounds__(256) void jn_tile_kernel(JoinArgs a)
@@ -389,7 +465,7 @@ __global__ __launch_bounds__(256) void jn_tile_kernel(JoinArgs a)
         bi = a.bi0 + (uint32_t)(tile / a.ncb);
         bj = (uint32_t)(tile % a.ncb);
     }
-    uint16_t *cnt = reinterpret_cast<uint16_t *>(s_cnt[w]);
+    JN_LDS uint16_t *cnt = (JN_LDS uint16_t *)&s_cnt[w][0];
     for (uint32_t u = lane; u < JN_B * JN_STRIDE / 2u; u += 64u) s_cnt[w][u] = 0;
     const bool diag = a.triangle && bi == bj;
     if (diag) jn_tile<true>(a, cnt, lane, bi, bj);

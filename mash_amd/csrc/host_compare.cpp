@@ -505,8 +505,9 @@ struct SparseCosts {
     double tiles_per_shared = 8.0e-12;
     // the join engine (compare_join.hip): a counter update per (pair, shared value); an intersection step of 64 x 64 group ids
     // per tile (the lists' groups are bounded by their entries before the lists exist); the lists' sort per slot
-    double join_per_shared = 3.5e-13;
-    double join_per_step = 8.0e-11;
+    // (round 6, one species of 32 768 rows: 1.25e11 shared hashes in 37.5 ms all in, lists in family order)
+    double join_per_shared = 2.2e-13;
+    double join_per_step = 4.0e-11;
     double join_per_slot = 8.0e-11;
     double join_min_shared_per_pair = 4.0;   // below this many shared hashes per pair of the TABLE the engine is not even priced
 };

@@ -63,6 +63,9 @@ elif args.leg == "clades":
 elif args.leg == "one_clade":
     n = min(n, 32768)
     triangle(*synth_torch.clade_sketch_table(n, S, clade=n, device=dev), n, S)
+elif args.leg == "one_species":
+    n = min(n, 32768)
+    triangle(*synth_torch.species_sketch_table(n, S, device=dev), n, S)
 elif args.leg == "sketch":
     ng, L = args.n_genomes, 1_000_000
     bases = synth_torch.synthetic_genomes(0, ng, L, device=dev)
