@@ -23,6 +23,7 @@ import argparse
 import hashlib
 import json
 import os
+import shutil
 import subprocess
 import sys
 import tempfile
@@ -92,7 +93,7 @@ def compare_roofline(eng, pairs, n, s, steps, pmc):
     phases' times (index = the per-table build, present in cold steps only), and the dominant kernel against the
     bound that applies.  Meaning of every field: DESIGN.md section 5."""
     phases = {}
-    for name in ("compare", "compare_index", "compare_discover", "compare_fill", "compare_dense", "compare_merge"):
+    for name in ("compare", "compare_index", "compare_discover", "compare_fill", "compare_dense", "compare_merge", "compare_join"):
         ms, k = eng.prof_avg_ms(name)
         if k:
             phases[name.replace("compare_", "")] = {"avg_ms": round(ms, 4), "per_pass": k / steps, "ms_per_pass": round(ms * k / steps, 4)}
@@ -104,7 +105,17 @@ def compare_roofline(eng, pairs, n, s, steps, pmc):
              "traffic_over_compulsory": round(traffic / compulsory, 3) if traffic else None,
              "output_write_bound_frac": round(pairs * 8 / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if pass_ms > 0 else None}
     model = pairs * (2 * s * 8 + 8) / (pass_ms * 1e-3) / 1e9 if pass_ms > 0 else 0.0
-    if not sparse:
+    if "join" in phases:
+        # the join engine (compare_join.hip): one kernel writes every pair; what bounds it is instruction issue and the LDS
+        # (a counter update per pair and shared hash), not HBM -- its 8 B per pair against the HBM peak is reported because the
+        # contract asks for one roof, the update rate beside it
+        j = phases["join"]["ms_per_pass"]
+        wr = pairs * 8 / (j * 1e-3) / 1e9
+        r = {"bound": "hbm", "achieved": round(wr, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(wr / HBM_PEAK_GBS, 4), "traffic": traffic,
+             "engine": "join", "kernel": "mg::jn_tile_kernel", "kernel_ms": phases["join"]["avg_ms"], "algorithmic_bytes_per_launch": pairs * 8,
+             "phases": phases, "pass": whole, "survey_8d_no_reuse_model_gbs": round(model, 1),
+             "note": "issue- and LDS-bound (one counter update per pair and shared hash); HBM sees the lists and 8 B per pair"}
+    elif not sparse:
         # the tile engine: one kernel per window, priced with SURVEY 8d's no-reuse model (bounds nothing: DESIGN 4.1b)
         r = {"bound": "hbm", "achieved": round(model, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(model / HBM_PEAK_GBS, 4),
              "traffic": traffic, "engine": "tiles", "kernel": "mg::compare_merged_kernel",
@@ -142,36 +153,64 @@ def compact_roofline(r):
                      "output_write_bound_frac": r["pass"]["output_write_bound_frac"]}}
 
 
-def cpu_baseline_compare(table_np, nhash_np, lengths_np, budget_s, cores=None):
-    """Reference compareSketches (incl. p-value) on the host cores, bounded sample:
-    triangle rows of the first M sketches of the SAME table, M sized for ~budget_s."""
+def cpu_baseline_compare(table_np, nhash_np, lengths_np, budget_s, cores=None, cli=False):
+    """Reference compareSketches (incl. distance and p-value) on the host cores, bounded sample: triangle rows of the first M
+    sketches of the SAME table, M sized for ~budget_s.  The reference's table (vector<Sketch::Reference>) is built ONCE and
+    shared read-only by every thread (round 5 built it per worker: at 256 threads the copies were the measurement); the rows go
+    to the threads as many more blocks of equal area than there are threads, taken as they come (ThreadPool.hxx hands out jobs
+    the same way).  cli: `mash-ref triangle -p <cores>` on the same sample as a second figure (the reference's whole command:
+    .msh read, compare, Phylip text)."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import pyoracle
     cores = cores or min(os.cpu_count() or 1, 16)
     use_ref = pyoracle.ref_available()
     orc = pyoracle.Oracle(ref=use_ref)
     kspace = 4.0 ** K
+    from mash_amd import shard
 
     def run(m):
-        from mash_amd import shard
-        b = shard.equal_area_row_blocks(m, cores)
-        sub = (table_np[:m], nhash_np[:m], lengths_np[:m])
-        t0 = time.perf_counter()
-        with ThreadPoolExecutor(cores) as ex:      # ctypes releases the GIL: real parallelism
-            list(ex.map(lambda g: orc.triangle(sub[0], sub[1], sub[2], b[g], b[g + 1], K, kspace, stats=True),
-                        range(cores)))
-        return time.perf_counter() - t0
+        t = orc.table_open(table_np[:m], nhash_np[:m], lengths_np[:m])          # (outside the timed region, as the reference reads its .msh first)
+        try:
+            b = shard.equal_area_row_blocks(m, min(max(cores * 16, 64), m))
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(cores) as ex:      # ctypes releases the GIL: real parallelism
+                list(ex.map(lambda g: orc.triangle_run(t, b[g], b[g + 1], K, kspace), range(len(b) - 1)))
+            return time.perf_counter() - t0
+        finally:
+            orc.table_close(t)
 
-    m = 400
+    # calibrate on growing samples until one takes a measurable time (a sample too small for the thread count measures thread start-up)
+    m = min(len(table_np), max(400, int(400 * cores ** 0.5)))
     dt = run(m)
+    while dt < 0.3 and m < len(table_np):
+        m = min(len(table_np), m * 2)
+        dt = run(m)
     rate = (m * (m - 1) / 2) / dt
     m2 = int(min(len(table_np), max(m, (2 * rate * budget_s) ** 0.5)))
-    dt2 = run(m2)
+    dt2 = run(m2) if m2 > m else dt
     pairs = m2 * (m2 - 1) // 2
-    return {"value": pairs / dt2, "unit": "pairs/s", "cores": cores,
-            "kind": "reference" if use_ref else "port",
-            "sample": f"triangle (compareSketches incl. p-value) on the first {m2} of the same sketches, "
-                      f"{pairs} pairs, {cores} threads, {dt2:.1f} s"}
+    r = {"value": pairs / dt2, "unit": "pairs/s", "cores": cores,
+         "kind": "reference" if use_ref else "port",
+         "sample": f"triangle (compareSketches incl. p-value) on the first {m2} of the same sketches, "
+                   f"{pairs} pairs, {cores} threads on one shared table, {dt2:.1f} s"}
+    if cli:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import compare_e2e
+            if os.path.exists(compare_e2e.REF):
+                d = tempfile.mkdtemp(prefix="bench_refcli_")
+                try:
+                    mc = int(min(len(table_np), max(1000, (2 * r["value"] * min(budget_s, 6.0)) ** 0.5)))
+                    f = os.path.join(d, "sample.msh")
+                    compare_e2e.write_msh(f, table_np[:mc], nhash_np[:mc], lengths_np[:mc])
+                    dtc = compare_e2e.timed([compare_e2e.REF, "triangle", "-p", str(cores), f], "/dev/null")
+                    r["mash_ref_cli"] = {"value": mc * (mc - 1) / 2 / dtc, "unit": "pairs/s", "threads": cores,
+                                         "sample": f"mash-ref triangle -p {cores} on the first {mc} of the same sketches (.msh read + compare + Phylip text), {dtc:.1f} s"}
+                finally:
+                    shutil.rmtree(d, ignore_errors=True)
+        except Exception as e:
+            r["mash_ref_cli"] = {"error": repr(e)}
+    return r
 
 
 def cpu_baseline_sketch(budget_s, threads):
@@ -253,6 +292,8 @@ def headline_of(result):
     h["config"] = {"workload": cfg.get("workload"), "parallelism": cfg.get("parallelism"), "output_checksum": cfg.get("output_checksum"),
                    "first_call_ms": cfg.get("first_call_ms"), "rccl_ranks": cfg.get("rccl_ranks"),
                    "table_broadcast_ms": cfg.get("table_broadcast_ms")}
+    if cfg.get("index_ms_by_rank"):
+        h["config"]["index_ms_by_rank"] = cfg["index_ms_by_rank"]
     h["warm_value"], h["warm_ms_per_step"] = _num(result.get("warm_value"), 6), _num(result.get("warm_ms_per_step"), 5)
     if result.get("dry"):
         h["dry"] = True
@@ -285,6 +326,9 @@ def headline_of(result):
         h["h2h_thresholded_pairs_s"] = _num(hh["full_c3_thresholded"].get("value"))
     if "full_c3_sparse" in hh:
         h["h2h_full_pairs_s"] = _num(hh["full_c3_sparse"].get("value"))
+        # SURVEY 8d(i) defines the metric host -> host; `value` is the device-resident job (table and results stay in HBM)
+        h["config"]["host_to_host_pairs_s"] = h["h2h_full_pairs_s"]
+        h["config"]["value_is"] = "device-resident (table in, 8 B per pair out, both in HBM); host_to_host_pairs_s = table up, sparse result back"
     errs = [k for k in ("sketch", "c5", "screen", "cli_e2e", "brackets", "host_to_host") if "error" in (result.get(k) or {})]
     errs += [f"brackets.{k}" for k, v in br.items() if isinstance(v, dict) and "error" in v]
     if errs:
@@ -519,6 +563,13 @@ def main():
     roofline = compare_roofline(eng, my_pairs, n, S, args.steps, pmc) if not dry else {"bound": "hbm", "dry": True}
     dt = max_over_ranks(dt)
     value = total_pairs * args.steps / dt
+    # what every rank's index cost (a rank's index covers the rows below its block's end only: host_compare.cpp tri_view)
+    index_ms_by_rank = None
+    if world > 1:
+        mine = 0.0 if dry else float((roofline.get("phases") or {}).get("index", {}).get("ms_per_pass") or 0.0)
+        tens = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(tens, torch.tensor([mine], dtype=torch.float64, device=dev))
+        index_ms_by_rank = [round(float(x.item()), 3) for x in tens]
     if not dry and "pass" in roofline:
         roofline["step_frac"] = round(roofline["pass"]["compulsory_bytes"] / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)
         roofline["index_ms"] = roofline["phases"].get("index", {}).get("ms_per_pass")
@@ -555,7 +606,7 @@ def main():
                                f"per-table job (index build + discover + fill + merge each step), row-block sharded x{world}",
                    "n_sketches": n, "sketch_size": S, "kmer": K, "hash_bits": 64,
                    "parallelism": f"rowblock{world}", "rank_row_blocks": blocks, "row_weight_pairs": round(row_weight, 1),
-                   "table_broadcast_ms": round(bcast_ms, 2),
+                   "table_broadcast_ms": round(bcast_ms, 2), "index_ms_by_rank": index_ms_by_rank,
                    "rccl_ranks": rccl_ranks, "comm": comm_kind, "output_checksum": checksum,
                    "first_call_ms": round(first_call_ms, 2) if first_call_ms is not None else None},
         "warm_value": total_pairs * args.steps / wdt, "warm_ms_per_step": wdt * 1e3 / args.steps,
@@ -568,13 +619,14 @@ def main():
     single = rank == 0 and world == 1 and not dry
     # ------------------------------------------------------------------ cpu baseline (rank 0, N=1)
     if single and not args.no_cpu:
-        m = min(n, 6000)
-        # P = nproc (the box's CPU rate: `cpu_baseline`), P = 16 and P = 1 beside it
+        m = min(n, 40000)
+        # P = nproc (the box's CPU rate: `cpu_baseline`), P = 64, 16 and 1 beside it; the reference CLI
+        # itself (`mash-ref triangle -p nproc`) as a second figure of the same box
         sub = (hashes[:m].cpu().numpy().view(np.uint64), nhash[:m].cpu().numpy().astype(np.uint32), lengths[:m].cpu().numpy().astype(np.uint64))
         nproc = os.cpu_count() or 1
         by = {}
-        for c in sorted({1, min(16, nproc), nproc}):
-            by[c] = cpu_baseline_compare(*sub, args.cpu_seconds / 3.0, cores=c)
+        for c in sorted({1, min(16, nproc), min(64, nproc), nproc}):
+            by[c] = cpu_baseline_compare(*sub, args.cpu_seconds / (4.0 if c != nproc else 2.0), cores=c, cli=(c == nproc))
         result["cpu_baseline"] = by[nproc]
         result["cpu_baseline_by_cores"] = {str(c): v for c, v in by.items()}
 

@@ -661,8 +661,7 @@ hipError_t launch_dense_pairs(const DenseTile *tiles, uint32_t ntiles, uint32_t 
                            out_base, inv, out, list ? *list : DenseList());
         return hipGetLastError();
     };
-    uint32_t il = 8;                                       // (measured on one clade of 32 768 rows, warm: 7.8 / 7.3 / 7.2 ms at 4 / 8 / 16)
-    if (const char *e = getenv("MASHGPU_DENSE_IL")) il = (uint32_t)atoi(e);      // (tuning knob)
+    const uint32_t il = 8;                                 // (measured on one clade of 32 768 rows, warm: 7.8 / 7.3 / 7.2 ms at 4 / 8 / 16)
     if (rows_per_tile == 32u) return il >= 16u ? go(dn_pairs_kernel<32, 16>) : il >= 8u ? go(dn_pairs_kernel<32, 8>) : go(dn_pairs_kernel<32, 4>);
     return il >= 8u ? go(dn_pairs_kernel<8, 8>) : go(dn_pairs_kernel<8, 4>);
 }

@@ -460,6 +460,8 @@ static int run_compare_merged(mg_ctx *ctx, const mg_table *rows, const mg_table 
     return MG_OK;
 }
 
+static const mg_table *tri_view(mg_ctx *ctx, const mg_table *t, uint64_t rb, uint64_t re);
+
 // ---- inverted-index engine (compare_sparse.hip) ----------------------------------------------
 //
 // The index of a table is built by host_index.cpp (table_sparse_index: one object, one function per phase).
@@ -710,7 +712,7 @@ int SparseJobRun::find_plan()
     first = plan == nullptr;
     if (first) {
         fresh.rows = rows; fresh.rb = row_begin; fresh.re = row_end; fresh.triangle = triangle;
-        fresh.cand = 0; fresh.shared = 0; fresh.use = true; fresh.join = false; fresh.order = nullptr;
+        fresh.cand = 0; fresh.shared = 0; fresh.use = true; fresh.use_list = true; fresh.join = false; fresh.order = nullptr;
         fresh.dtiles = nullptr; fresh.ndtiles = 0; fresh.dtile_rows = 32; fresh.dense_pairs = 0;
         if (triangle && !ix->dgroups_host.empty()) {
             // tiles of the dense groups' inner pairs: 32 or 8 rows (aligned to the group's first row) x a block of 128 columns
@@ -813,7 +815,7 @@ int SparseJobRun::ensure_lists(uint64_t want_cand)
 
 int SparseJobRun::discover()
 {
-    if (!first && !force && !plan->use) return leave();      // a job the tile engine was found to do faster
+    if (!first && !force && !(job ? plan->use_list : plan->use)) return leave();      // a job the tile engine was found to do faster
     // first sight of a job: room for one candidate per two index entries, at most 2^27 (2 GB of lists from the pool; C3
     // has one per twenty, the clade table one per two); a job that holds more is discovered twice, the second time
     // with the count the first one left
@@ -863,13 +865,16 @@ int SparseJobRun::choose_engine()
         //  middle, the copies and clades having engines of their own by now)
         const double t_dense = np / dense_rate + (double)fresh.shared * K.tiles_per_shared;
         fresh.use = t_sparse < t_dense;
+        // a list job fills nothing (and its pairs inside dense groups are appended, not written into a matrix): priced
+        // without the 8 B per pair -- its alternative is the blocked matrix path, which pays them all
+        fresh.use_list = t_sparse - np * 8.0 / K.fill_bytes_s - (triangle ? (double)ix->cls_pairs * 8.0 / K.class_bytes_s : 0.0) < t_dense;
         if (ctx_opt(ctx, "MASHGPU_SPARSE_DBG"))
             fprintf(stderr, "compare sparse: rows [%llu, %llu) %s: %llu pairs, %llu candidates, %llu shared hashes; model sparse %.3f ms, tiles %.3f ms\n",
                     (unsigned long long)row_begin, (unsigned long long)row_end, triangle ? "triangle" : "rect", (unsigned long long)pairs,
                     (unsigned long long)fresh.cand, (unsigned long long)fresh.shared, t_sparse * 1e3, t_dense * 1e3);
         keep_plan();
     }
-    if (!force && !plan->use) return leave();
+    if (!force && !(job ? plan->use_list : plan->use)) return leave();
     return MG_OK;
 }
 
@@ -1237,11 +1242,26 @@ uint64_t tri_pairs(uint64_t row_begin, uint64_t row_end)
     return tri(row_end) - tri(row_begin);
 }
 
+// A triangle call over rows [rb, re) looks at rows below re only (CommandTriangle.cpp:200-214: row i against the rows j < i): what
+// the engines derive from the table -- the inverted index above all, 8 of C3's 15 ms -- is derived from the first re rows.  One of
+// G ranks with equal-area blocks thereby builds an index of sqrt((g + 1) / G) of the table instead of all of it (rank 0 of 8:
+// 35 %; the mean: 70 %), and rank 0's job is the WHOLE triangle of its view: the clustered index, dense groups whatever the
+// collection's order, the join engine's ordered lists.  Per CALL, not per internal block of a call: the blocks of one call
+// share one view.  (MASHGPU_TRI_PREFIX=0: off.  A view that saves less than a tenth of the rows is not worth a second index.)
+static const mg_table *tri_view(mg_ctx *ctx, const mg_table *t, uint64_t rb, uint64_t re)
+{
+    if (re > t->n) re = t->n;
+    if (rb >= re || re == t->n || re * 10 > t->n * 9 || tri_pairs(rb, re) < 4000000ull) return t;
+    if (const char *e = ctx_opt(ctx, "MASHGPU_TRI_PREFIX")) { if (atoi(e) == 0) return t; }
+    return table_prefix_view(t, re);
+}
+
 int mg_compare_tri_dev(mg_ctx *ctx, const mg_table *t, uint64_t row_begin, uint64_t row_end, mg_counts *out_dev)
 {
     if (!ctx) return MG_ERR_INVALID;
     if (!t || !out_dev) return fail(ctx, MG_ERR_INVALID, "mg_compare_tri_dev: NULL argument");
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    t = tri_view(ctx, t, row_begin, row_end);
     const int rc = run_compare(ctx, t, t, row_begin, row_end, true, out_dev);
     if (rc != MG_OK || ctx->async) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1266,6 +1286,7 @@ static int compare_host(mg_ctx *ctx, const mg_table *rows, const mg_table *cols,
 {
     if (re > rows->n) re = rows->n;
     if (rb >= re) return MG_OK;
+    if (triangle && rows == cols) rows = cols = tri_view(ctx, cols, rb, re);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint64_t max_pairs = 1ull << 27;                 // 1 GiB of {numer,denom}
     mg_counts *d_out = nullptr;
@@ -1426,6 +1447,7 @@ static int compare_filter(mg_ctx *ctx, const mg_table *rows, const mg_table *col
 {
     *count_out = 0;
     if (re > rows->n) re = rows->n;
+    if (triangle && rows == cols) rows = cols = tri_view(ctx, cols, rb, re);     // (the first re rows are all this call looks at)
     if (rb >= re) return MG_OK;
     if (kmer_size < 0) return fail(ctx, MG_ERR_INVALID, "compare filter: bad k-mer size");
     const uint64_t s64 = std::min(rows->s, cols->s);
@@ -1652,6 +1674,7 @@ static int compare_pairs_host(mg_ctx *ctx, const mg_table *rows, const mg_table 
                               int kmer_size, double kmer_space, double max_d, double max_p, mg_pair *out_host)
 {
     if (re > rows->n) re = rows->n;
+    if (triangle && rows == cols) rows = cols = tri_view(ctx, cols, rb, re);     // (the first re rows are all this call looks at)
     if (rb >= re) return MG_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint64_t max_pairs = 1ull << 26;                   // 2 GiB of records, 512 MiB of counts
@@ -1759,6 +1782,7 @@ static int compare_results(mg_ctx *ctx, const mg_table *rows, const mg_table *co
 {
     *count_out = 0;
     if (re > rows->n) re = rows->n;
+    if (triangle && rows == cols) rows = cols = tri_view(ctx, cols, rb, re);     // (the first re rows are all this call looks at)
     if (rb >= re) return MG_OK;
     if (kmer_size < 1) return fail(ctx, MG_ERR_INVALID, "compare: bad k-mer size");
     const uint64_t s64 = std::min(rows->s, cols->s);
@@ -1945,6 +1969,7 @@ static int compare_sparse_matrix(mg_ctx *ctx, const mg_table *rows, const mg_tab
 {
     *count_out = 0;
     if (re > rows->n) re = rows->n;
+    if (triangle && rows == cols) rows = cols = tri_view(ctx, cols, rb, re);     // (the first re rows are all this call looks at)
     if (rb >= re) return MG_OK;
     const uint64_t s64 = std::min(rows->s, cols->s);
     if (s64 > 0xFFFFFFFEull) return fail(ctx, MG_ERR_INVALID, "compare: sketch size too large");

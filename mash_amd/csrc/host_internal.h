@@ -149,7 +149,7 @@ struct mg_table {
             double build_ms = 0;
         } jn;
         // what a (rows, range) job costs, learned by a counting pass the first time it is seen
-        struct Plan { const void *rows; uint64_t rb, re; bool triangle; uint64_t cand, shared; bool use; bool join; uint32_t *order;
+        struct Plan { const void *rows; uint64_t rb, re; bool triangle; uint64_t cand, shared; bool use; bool use_list; bool join; uint32_t *order;
                       mg::DenseTile *dtiles; uint32_t ndtiles, dtile_rows; uint64_t dense_pairs; };
         std::vector<Plan> plans;
         uint2 *cand = nullptr, *res = nullptr;    // candidate list and the candidates' results, grown on demand
@@ -163,6 +163,10 @@ struct mg_table {
         uint64_t seg_rows = 0;
     };
     mutable std::vector<Sparse *> sparse;
+    // views of the table's first rows (table_prefix_view): a triangle job over rows [rb, re) only ever looks at rows below re,
+    // so everything derived for it -- the inverted index above all -- is derived from the first re rows; owned by this table,
+    // dropped with its derived data
+    mutable std::vector<mg_table *> prefix_views;
 };
 
 #define HIP_TRY(ctx, call)                                                           \
@@ -180,6 +184,8 @@ bool ctx_is_live(const void *c);
 // Scratch of the entry points comes from a per-context cache of device blocks (see mashgpu.cpp)
 void ctx_trim(mg_ctx *ctx);
 hipError_t ctx_malloc(mg_ctx *ctx, void **out, size_t bytes);
+// the first n rows of t as a table of their own (n < t->n; cached with t: at most four views, the oldest goes first)
+const mg_table *table_prefix_view(const mg_table *t, uint64_t n);
 void ctx_free(mg_ctx *ctx, void *p);
 
 // device allocation released on every exit path; with a context it comes from the context's
@@ -195,6 +201,7 @@ struct DevBuf {
     ~DevBuf() { if (p) { if (owner) ctx_free(owner, p); else hipFree(p); } }
     hipError_t alloc(uint64_t count)
     {
+        if (p) { if (owner) ctx_free(owner, p); else hipFree(p); p = nullptr; }     // (a second alloc: the first block goes back)
         const size_t bytes = std::max<uint64_t>(count, 1) * sizeof(T);
         return owner ? ctx_malloc(owner, reinterpret_cast<void **>(&p), bytes) : hipMalloc(&p, bytes);
     }

@@ -1252,10 +1252,6 @@ IxPlan index_plan(uint32_t n, uint32_t E, uint32_t s, uint32_t rs, uint64_t stri
     g.Bp = g.NW * g.BW;
     g.npass = (bw_log + 3u) / 4u;
     g.wgrp = 8;
-    if (const char *e = getenv("MASHGPU_IX_WGRP")) {       // (tuning knob: windows per group of the tile order)
-        const int v = atoi(e);
-        if (v >= 1 && v <= 4096) g.wgrp = (uint32_t)v;
-    }
     const uint64_t nseq = (uint64_t)((g.NW + g.wgrp - 1u) / g.wgrp) * g.wgrp * g.nblk;
     if (nseq >= (1ull << 30)) { p.why = "too many tiles"; return p; }
     g.nseq = (uint32_t)nseq;

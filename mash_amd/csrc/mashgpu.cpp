@@ -329,6 +329,8 @@ int mg_table_wrap_dev(mg_ctx *ctx, const uint64_t *hashes_dev, const uint32_t *n
 static void table_drop_derived(mg_table *t)
 {
     mg_ctx *ctx = t->ctx;
+    for (mg_table *v : t->prefix_views) { table_drop_derived(v); delete v; }
+    t->prefix_views.clear();
     if (!t->pfx.empty() || !t->win.empty() || !t->sparse.empty()) hipSetDevice(ctx->device);
     for (auto &im : t->pfx) ctx_free(ctx, im.second);
     t->pfx.clear();
@@ -355,6 +357,28 @@ static void table_drop_derived(mg_table *t)
     t->last.clear();
     t->nh.clear();
     t->have_max = false;
+}
+
+const mg_table *table_prefix_view(const mg_table *t, uint64_t n)
+{
+    if (n >= t->n) return t;
+    for (mg_table *v : t->prefix_views)
+        if (v->n == n) return v;
+    if (t->prefix_views.size() >= 4) {
+        table_drop_derived(t->prefix_views.front());
+        delete t->prefix_views.front();
+        t->prefix_views.erase(t->prefix_views.begin());
+    }
+    mg_table *v = new mg_table;
+    v->ctx = t->ctx;
+    v->hashes = t->hashes;
+    v->nhash = t->nhash;
+    v->lengths = t->lengths;
+    v->n = n;
+    v->s = t->s;
+    v->owns = false;
+    t->prefix_views.push_back(v);
+    return v;
 }
 
 void mg_table_free(mg_table *t)

@@ -210,6 +210,33 @@ class Oracle:
     def binomial_q(self, k, p, n):
         return float(self.lib.oracle_binomial_q(k, p, n))
 
+    # -- one table shared by many callers (bench.py's cpu_baseline: the table is materialised ONCE and only read) ----------
+    def table_open(self, table, nhash, lengths):
+        """The reference's vector<Sketch::Reference> of a dense table (ref) or the arrays themselves (port), for triangle_run."""
+        table = np.ascontiguousarray(table, dtype=np.uint64)
+        nhash = np.ascontiguousarray(nhash, dtype=np.uint32)
+        lengths = np.ascontiguousarray(lengths, dtype=np.uint64)
+        n, s = table.shape
+        h = None
+        if self.is_ref:
+            h = self.lib.ref_table_new(_u64p(table), _u32p(nhash), _u64p(lengths), C.c_uint64(n), C.c_uint64(s))
+        return {"h": h, "table": table, "nhash": nhash, "lengths": lengths, "n": n, "s": s}
+
+    def table_close(self, t):
+        if self.is_ref and t["h"]:
+            self.lib.ref_table_free(C.c_void_p(t["h"]))
+            t["h"] = None
+
+    def triangle_run(self, t, row_begin, row_end, k, kmer_space):
+        """compareSketches incl. distance and p-value for rows [row_begin, row_end) of an open table, results computed and
+        dropped (nothing is allocated or copied per call: any number of threads may run on one table).  Returns the pairs."""
+        if self.is_ref:
+            return int(self.lib.ref_triangle(C.c_void_p(t["h"]), C.c_uint64(row_begin), C.c_uint64(row_end), C.c_int(k), C.c_double(kmer_space),
+                                             None, None, None, None))
+        return int(self.lib.oracle_triangle(_u64p(t["table"]), _u32p(t["nhash"]), _u64p(t["lengths"]), C.c_uint64(t["n"]), C.c_uint64(t["s"]),
+                                            C.c_uint64(row_begin), C.c_uint64(row_end), C.c_int(k), C.c_double(kmer_space), C.c_int(1),
+                                            None, None, None, None))
+
     def triangle(self, table, nhash, lengths, row_begin, row_end, k, kmer_space, stats=False):
         """Rows [row_begin,row_end) of the lower triangle, reference order.
         Returns (numer u32[], denom u32[], dist f64[]|None, pval f64[]|None)."""

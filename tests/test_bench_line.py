@@ -63,3 +63,33 @@ def test_headline_line_is_small_and_complete(capsys, tmp_path):
     assert h["sketch_bp_s"] and h["c5_pairs_s"] and h["screen_reads_s"] and h["cli_e2e_speedup"]["sketch"] == 3.2
     assert set(h["brackets_pairs_s"]) == {"all_random", "all_identical", "clades_of_1000", "one_clade", "one_species"}
     assert json.loads(open(tmp_path / "detail.json").read())["brackets"]["one_clade"]["note"]     # the detail kept everything
+
+
+def test_cpu_baseline_shares_one_table_between_its_threads():
+    """bench.py's cpu_baseline: the reference's table is built once per run and only read by the worker
+    threads (round 5 rebuilt it in every worker: 256 threads measured their copies), the rows go out as many more blocks than
+    threads, and the sample says so.  Rates cannot be asserted on a shared CI box; that two threads do the same pairs as one,
+    through pyoracle.table_open / triangle_run, can."""
+    import importlib.util
+    import numpy as np
+    from oracle import pyoracle
+    from workloads import synth
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        spec.loader.exec_module(b)
+    finally:
+        sys.argv = argv
+    table, nh, ln = synth.clustered_sketches(700, 200, clusters=7, seed=2, pool=300, private=80)
+    r1 = b.cpu_baseline_compare(table, nh, ln, 0.3, cores=1)
+    r2 = b.cpu_baseline_compare(table, nh, ln, 0.3, cores=2)
+    for r, c in ((r1, 1), (r2, 2)):
+        assert r["cores"] == c and r["unit"] == "pairs/s" and r["value"] > 0 and "one shared table" in r["sample"]
+    orc = pyoracle.Oracle(ref=pyoracle.ref_available())
+    t = orc.table_open(table[:50], nh[:50], ln[:50])
+    try:
+        assert orc.triangle_run(t, 0, 50, 21, 4.0 ** 21) == 50 * 49 // 2
+        assert orc.triangle_run(t, 10, 20, 21, 4.0 ** 21) == sum(range(10, 20))
+    finally:
+        orc.table_close(t)

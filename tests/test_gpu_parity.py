@@ -1124,6 +1124,39 @@ def test_one_species_takes_the_join_engine(eng, oracle, monkeypatch):
     t.free()
 
 
+def test_triangle_rows_are_served_from_a_view_of_the_first_rows(eng, oracle, monkeypatch):
+    """A triangle call over rows [rb, re) looks at rows below re only (CommandTriangle.cpp:200-214), so the library derives
+    what it needs -- the inverted index -- from a VIEW of the table's first re rows (host_compare.cpp: tri_view; what one rank
+    of several does).  Same bytes as with the view switched off, for a range inside the table and for a range that starts at
+    row 0 (then the job is the view's WHOLE triangle: clustered index, dense groups); rows against the oracle; the view goes
+    with the table's derived data (mg_table_invalidate) and the table stays usable."""
+    n, s = 7000, 200
+    table, nhash, lengths = synth.clustered_sketches(n, s, clusters=70, seed=21, pool=300, private=80)
+    nhash = nhash.copy()
+    nhash[100] = 0
+    nhash[2500] = 50
+    t = eng.table_upload(table, nhash, lengths)
+    monkeypatch.setenv("MASHGPU_SPARSE_DBG", "1")
+    for rb, re in ((1500, 4500), (0, 3200)):
+        got = eng.compare_tri_host(t, rb, re)
+        monkeypatch.setenv("MASHGPU_TRI_PREFIX", "0")
+        t.invalidate()
+        ref = eng.compare_tri_host(t, rb, re)
+        monkeypatch.delenv("MASHGPU_TRI_PREFIX")
+        assert got.tobytes() == ref.tobytes(), (rb, re)
+        for i in (rb, rb + 777, re - 1):
+            nn, dd = _oracle_tri(oracle, table, nhash, lengths, i, i + 1)
+            base = i * (i - 1) // 2 - (rb * (rb - 1) // 2 if rb else 0)
+            assert np.array_equal(got["numer"][base: base + i], nn) and np.array_equal(got["denom"][base: base + i], dd), (rb, re, i)
+    # thresholded results of a range: the list engine on the view
+    res = eng.compare_tri_results(t, 21, KSPACE21, max_d=0.2, row_begin=1500, row_end=4500)
+    monkeypatch.setenv("MASHGPU_TRI_PREFIX", "0")
+    t.invalidate()
+    res0 = eng.compare_tri_results(t, 21, KSPACE21, max_d=0.2, row_begin=1500, row_end=4500)
+    assert res.tobytes() == res0.tobytes() and len(res) > 1000
+    t.free()
+
+
 def _index_tables(kind, rng):
     """tables for the tile-built index: (table, nhash, may_refuse)"""
     if kind == "clusters":                                  # C3 in small: clusters interleaved over the rows
