@@ -1253,6 +1253,15 @@ static const mg_table *tri_view(mg_ctx *ctx, const mg_table *t, uint64_t rb, uin
     if (re > t->n) re = t->n;
     if (rb >= re || re == t->n || re * 10 > t->n * 9 || tri_pairs(rb, re) < 4000000ull) return t;
     if (const char *e = ctx_opt(ctx, "MASHGPU_TRI_PREFIX")) { if (atoi(e) == 0) return t; }
+    // One view per table: a rank's calls come with the same range every time, but a caller that walks the table in blocks
+    // of rows (the CLI: 2^24 pairs a call) would pay an index per block -- its first block makes a (small) view, the second
+    // finds no view that covers it and takes the whole table, whose index then serves every later block.
+    if (!t->sparse.empty()) return t;                       // (the whole table's index exists already)
+    const mg_table *best = nullptr;
+    for (const mg_table *v : t->prefix_views)
+        if (v->n >= re && (!best || v->n < best->n)) best = v;
+    if (best) return best;
+    if (!t->prefix_views.empty()) return t;
     return table_prefix_view(t, re);
 }
 

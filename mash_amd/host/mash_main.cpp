@@ -1428,6 +1428,67 @@ int cmd_triangle(int argc, const char **argv)
         }
     }
     const bool lean = !dist_lut.empty();
+    // The Phylip matrix from the SPARSE result (mg_compare_tri_sparse_host): a pair that shares no hash is {0, min(s, |A| + |B|)}
+    // -- distance 1, p-value 1 -- and in a collection nearly every pair is such a pair: what crosses PCIe and is looked at are
+    // the exceptions, a row's text is runs of "\t1" between them (CommandTriangle.cpp:159-198 writes the same cells).  One
+    // device; a block whose exceptions outnumber an eighth of its pairs (one species: every pair shares hashes) sends the
+    // rest of the run down the dense path below, which has the engines for that.  (MASH_AMD_DENSE_MATRIX=1: dense from the start.)
+    bool sparse_rows = lean && mg_comm_size(gpu.comm) == 1 && !getenv("MASH_AMD_DENSE_MATRIX");
+    vector<mg_edge> exc;
+    vector<uint64_t> exc_at;
+    string ones;
+    if (sparse_rows) for (int k = 0; k < 4096; k++) ones += "\t1";
+    while (r0 < n && sparse_rows) {
+        uint64_t r1 = r0, npairs = 0;
+        while (r1 < n && (npairs == 0 || npairs + r1 <= (1ull << 26))) { npairs += r1; r1++; }
+        clk.lap("setup");
+        const uint64_t cap = npairs / 8 + 4096;
+        if (exc.size() < cap) exc.resize(cap);
+        uint64_t cnt = 0;
+        const int rc = mg_compare_tri_sparse_host(gpu.ctx, t, r0, r1, exc.data(), cap, &cnt);
+        if (rc == MG_ERR_NOMEM) { sparse_rows = false; break; }
+        if (rc != MG_OK) { cerr << "ERROR: " << mg_last_error(gpu.ctx) << endl; return 1; }
+        clk.lap("compare+sparse result+copy");
+        exc_at.assign(r1 - r0 + 1, cnt);                      // exceptions of row i: exc[exc_at[i - r0] .. exc_at[i - r0 + 1])
+        for (uint64_t x = cnt; x-- > 0;) exc_at[exc[x].row - r0] = x;
+        for (uint64_t i = r1 - r0; i-- > 0;) if (exc_at[i] > exc_at[i + 1]) exc_at[i] = exc_at[i + 1];
+        vector<double> peak(emit_threads(), p_peak);
+        emit_rows(out, r0, r1, [](uint64_t i) { return i / 16 + 64; }, [&](FastOut &o, uint64_t i, unsigned slot) {
+            double pk = peak[slot];
+            o << label(set.refs[i]);
+            const bool empty_row = set.refs[i].hashes.empty();
+            auto defaults = [&](uint64_t c0, uint64_t c1) {       // columns [c0, c1) share nothing with row i
+                if (c0 >= c1) return;
+                if (pk < 1.0) pk = 1.0;                          // pValue(0, ...) = 1 (CommandDistance.cpp:431-434)
+                if (!empty_row) {
+                    for (uint64_t m = c1 - c0; m;) { const uint64_t k = std::min<uint64_t>(m, 4096); o.buf.append(ones, 0, 2 * k); m -= k; }
+                } else {
+                    // (two empty sketches: 0 / 0 union elements, common == denom: distance 0, CommandDistance.cpp:390-393)
+                    for (uint64_t j = c0; j < c1; j++) o << (set.refs[j].hashes.empty() ? "\t0" : "\t1");
+                }
+                o.room();
+            };
+            uint64_t c = 0;
+            for (uint64_t x = exc_at[i - r0]; x < exc_at[i - r0 + 1]; x++) {
+                const mg_edge &e = exc[x];
+                defaults(c, e.col);
+                const bool full = e.denom == s_tab;
+                if (full) o << dist_txt[e.numer];
+                else o << '\t' << mg_distance(e.numer, e.denom, set.p.kmer);
+                if (!full || bound_of(e.numer) >= pk) {
+                    const double pv = mg_p_value(e.numer, lengths[i], lengths[e.col], kspace, e.denom);
+                    if (pv > pk) pk = pv;
+                }
+                c = (uint64_t)e.col + 1;
+            }
+            defaults(c, i);
+            peak[slot] = pk;
+            o.eol();
+        });
+        for (double v : peak) if (v > p_peak) p_peak = v;
+        clk.lap("format+write");
+        r0 = r1;
+    }
     while (r0 < n) {
         uint64_t r1 = r0, npairs = 0;
         while (r1 < n && (npairs == 0 || npairs + r1 <= (1ull << 24))) { npairs += r1; r1++; }

@@ -748,3 +748,44 @@ def test_option_refusals_match_the_reference_cli(built, tmp_path):
             got.append((r.returncode, r.stdout, r.stderr))
         assert got[0][0] != 0, args                              # these are refusals
         assert got[0] == got[1], (args, got[0][2][-200:], got[1][2][-200:])
+
+
+@pytest.mark.gpu
+def test_phylip_matrix_from_the_sparse_result(built, tmp_path):
+    """`mash triangle` writes its matrix from the pairs that SHARE a hash (mg_compare_tri_sparse_host) and fills the rest of a
+    row with the text of {0, min(s, |A| + |B|)} -- distance 1 -- as CommandTriangle.cpp:159-198 would print it; same bytes and
+    the same "Max p-value" as the dense path (MASH_AMD_DENSE_MATRIX=1) and as the reference CLI, on tables with empty
+    sketches (two of them: distance 0), short ones, copies, and rows that share nothing with anybody; on a collection of one
+    species (every pair an exception) the run falls back to the dense path by itself."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import compare_e2e
+    ref_cli = compare_e2e.REF if os.path.exists(compare_e2e.REF) else None
+    for name, n, s, maker in (("small", 1500, 100, "clusters"), ("large", 4200, 128, "clusters"), ("species", 700, 64, "species")):
+        if maker == "clusters":
+            table, nhash, lengths = synth.clustered_sketches(n, s, clusters=max(3, n // 60), seed=n, pool=int(1.5 * s), private=int(0.4 * s))
+            rnd, rn, _ = synth.random_sketches(40, s, seed=5)
+            table[100:140] = rnd
+            nhash = nhash.copy()
+            nhash[100:140] = rn
+            nhash[7] = 0
+            nhash[900] = 0
+            nhash[33] = s // 3
+            table[1200] = table[77]
+            nhash[1200] = nhash[77]
+        else:
+            table, nhash, lengths = synth.species_sketches(n, s, seed=3)
+        f = str(tmp_path / f"{name}.msh")
+        compare_e2e.write_msh(f, table, nhash, lengths)
+        a = run("triangle", f, cwd=tmp_path)
+        b = run("triangle", f, cwd=tmp_path, env={"MASH_AMD_DENSE_MATRIX": "1"})
+        assert a.stdout == b.stdout and a.stderr == b.stderr, name
+        lines = a.stdout.splitlines()
+        assert lines[0] == f"\t{n}" and len(lines) == n + 1
+        if maker == "clusters":
+            assert lines[1 + 900].split("\t")[1 + 7] == "0"            # two empty sketches
+            assert lines[1 + 1200].split("\t")[1 + 77] == "0"          # a copy
+            assert lines[1 + 139].split("\t")[1:] == ["1"] * 139       # a stranger
+        if ref_cli:
+            r = subprocess.run([ref_cli, "triangle", f], capture_output=True, text=True, cwd=tmp_path)
+            assert r.returncode == 0 and r.stdout == a.stdout and r.stderr == a.stderr, name
