@@ -738,6 +738,32 @@ def main():
                 del bh, bn, bl
             except Exception as e:
                 br[name] = {"error": repr(e)}
+        # what it costs when the index's bucket sorts REFUSE a table: their order check fires -- here forced by
+        # the test knob that swaps two entries of one value behind the partition -- the tile build is thrown away and the general
+        # sort builds the index (round 4's build); the headline's table, per-table job, same checksum
+        try:
+            os.environ["MASHGPU_IX_DEBUG_SWAP"] = "1"
+            eng.prof_enable(True)
+            eng.prof_reset()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(bsteps):
+                table.invalidate()
+                eng.compare_tri_dev(table, rb, re, out.data_ptr())
+            torch.cuda.synchronize()
+            bd = time.perf_counter() - t0
+            ims, ik = eng.prof_avg_ms("compare_index")
+            eng.prof_enable(False)
+            sums = [int(out[:my_pairs, 0].sum(dtype=torch.int64).item()), int(out[:my_pairs, 1].sum(dtype=torch.int64).item())]
+            assert checksum is None or sums == checksum, f"refused index: {sums}"
+            br["c3_index_refused"] = {"value": total_pairs * bsteps / bd, "unit": "pairs/s", "ms_per_step": bd * 1e3 / bsteps, "steps": bsteps,
+                                      "index_ms": round(ims * ik / bsteps, 3), "output_checksum": sums,
+                                      "verified": "the headline's checksum; the bucket sorts' order check fired in every step"}
+        except Exception as e:
+            br["c3_index_refused"] = {"error": repr(e)}
+        finally:
+            os.environ.pop("MASHGPU_IX_DEBUG_SWAP", None)
+            table.invalidate()
         br["workload"] = (f"mash triangle on {n} sketches of s={S}: all-random (every sketch its own values), all-identical (n copies "
                           f"of one sketch), clades of 1000 near-identical sketches (consecutive rows); one clade of {n1} distinct near-copies; "
                           f"one species of {n1} sketches as a tree of descent (pairs share 100 - 500 of 1000 hashes, random row order)")

@@ -450,6 +450,7 @@ int SparseIndexBuild::lay_out()
     // room for the dense groups' leaders (prepare_candidates): one list entry each, a quarter of the entries in all
     lead_lists = mg::dense_sublists();
     lead_cap = std::max<uint32_t>(E / 4u / lead_lists + 64u, 256u);
+    if (const char *ev = ctx_opt(ctx, "MASHGPU_DENSE_LEAD_CAP")) lead_cap = std::max<uint32_t>((uint32_t)atoi(ev), 1u);      // (test knob: lists that overflow)
     const bool tiles_hopeless = ix_tiles && !ix_verify && lab_sorted && !ctx_opt(ctx, "MASHGPU_SPARSE_INDEX") &&
                                 longest_label_run(lab_sorted, n) > kTilesLongestRun;
     if (ix_tiles && !tiles_hopeless) plan = mg::index_plan((uint32_t)n, E, s, sp->rs, t->s, maxv, dens0, ix_verify);
@@ -556,6 +557,12 @@ int SparseIndexBuild::build_by_tiles()
                 e = mg::index_build(plan, H, sp->off, d_lb, d_tcnt, d_start, d_big, d_pk, d_tc, sp->keys_sorted, sp->sorted_rows, sp->gend, gs_of, sp->code_img,
                                     sp->pos_img, d_slots, &d_stat.p->shared, &d_stat.p->max_group, &d_stat.p->groups, d_stat.p->ixf, nullptr, ctx->stream,
                                     lb_made ? 1 | 8 : 1);
+            // (test knob: what a ticket served out of lane order would leave behind -- the sorts' order check has to refuse the table)
+            DevBuf<uint32_t> d_swapped(ctx);
+            if (e == hipSuccess && ctx_opt(ctx, "MASHGPU_IX_DEBUG_SWAP") && d_swapped.alloc(1) == hipSuccess) {
+                e = hipMemsetAsync(d_swapped, 0, 4, ctx->stream);
+                if (e == hipSuccess) e = mg::index_debug_swap(plan, d_pk, d_start, d_swapped, ctx->stream);
+            }
             prepare_candidates();
             mg::IxLeaders lead;
             if (lead_ready) {
@@ -596,6 +603,41 @@ int SparseIndexBuild::build_by_tiles()
                 (void)hipStreamSynchronize(ctx->stream);    // (host memory is the target of copies that may be queued)
             }
             built = e == hipSuccess && !h_stat.ixf[mg::IXF_DEGENERATE];
+            // (not with buckets beyond the LDS: their second split reuses the partition's array, which the sorts would read again)
+            if (built && lead_ready && lead_tot[1] > lead_cap && h_stat.ixf[mg::IXF_NBIG] == 0) {
+                // A list of leaders filled beyond its room (the lists are filled by bucket: a table whose near-copies crowd a few
+                // buckets).  The leaders are found a second time with the room the fullest list asked for: the bucket sorts
+                // again -- the same index into the same arrays, the statistics counted anew (the table used to
+                // lose its dense groups here).
+                e = hipStreamSynchronize(ctx->stream);
+                const uint32_t want_cap = lead_tot[1];
+                for (void **q : {(void **)&d_key.p, (void **)&d_val.p, (void **)&d_keyj.p, (void **)&d_valj.p})
+                    if (*q) { ctx_free(ctx, *q); *q = nullptr; }
+                const uint64_t room = (uint64_t)lead_lists * want_cap;
+                if (e == hipSuccess && d_key.alloc(room) == hipSuccess && d_val.alloc(room) == hipSuccess && d_keyj.alloc(room) == hipSuccess &&
+                    d_valj.alloc(room) == hipSuccess) {
+                    lead_cap = want_cap;
+                    lead.key = d_key;
+                    lead.val = d_val;
+                    lead.cap_sub = lead_cap;
+                    e = hipMemsetAsync(d_cnt_sub, 0, lead_lists * 4, ctx->stream);
+                    if (e == hipSuccess) e = hipMemsetAsync(d_nlead, 0, 8, ctx->stream);
+                    if (e == hipSuccess) e = hipMemsetAsync(d_stat.p, 0, offsetof(Stat, bad), ctx->stream);      // shared, max_group, groups
+                    if (e == hipSuccess)
+                        e = mg::index_build(plan, H, sp->off, d_lb, d_tcnt, d_start, d_big, d_pk, d_tc, sp->keys_sorted, sp->sorted_rows, sp->gend, gs_of,
+                                            sp->code_img, sp->pos_img, d_slots, &d_stat.p->shared, &d_stat.p->max_group, &d_stat.p->groups, d_stat.p->ixf, &lead,
+                                            ctx->stream, 2);
+                    if (e == hipSuccess) e = mg::dense_join_leaders(d_key, d_val, lead_cap, d_keyj, d_valj, d_cnt_sub, d_off_sub, d_nlead, ctx->stream);
+                    if (e == hipSuccess) e = hipMemcpyAsync(lead_tot, d_nlead, 8, hipMemcpyDeviceToHost, ctx->stream);
+                    if (e == hipSuccess) e = hipMemcpyAsync(&h_stat, d_stat, sizeof(Stat), hipMemcpyDeviceToHost, ctx->stream);
+                    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+                    built = e == hipSuccess && !h_stat.ixf[mg::IXF_DEGENERATE];
+                    if (ctx_opt(ctx, "MASHGPU_SPARSE_DBG"))
+                        fprintf(stderr, "compare dense: a list of leaders asked for %u entries: found again with that room (%u leaders)\n", want_cap, lead_tot[0]);
+                } else {
+                    (void)hipGetLastError();                // (no room: the table goes without dense groups, as before)
+                }
+            }
             lead_done = built && lead_ready;
             if (ctx_opt(ctx, "MASHGPU_SPARSE_DBG"))
                 fprintf(stderr, "compare sparse: index by tiles: shift %u, %u buckets (%u per window, %u windows), fullest %u, %u beyond the LDS (%u values streamed)%s\n",

@@ -75,6 +75,8 @@ size_t index_stat_scratch_bytes();
 // All buffers are the caller's.  lb / cnt / start / big / pk / tc: scratch of the plan's sizes; the rest as sparse_build_index
 // (compare_internal.h) -- on return (stream order) the index arrays are complete unless flags say otherwise.
 // *incidences, *max_group, *groups, flags[4]: zeroed by the caller.
+// test knob: two entries of one value swapped behind the partition (the bucket sorts' order check must fire); done: 1 u32, device
+hipError_t index_debug_swap(const IxPlan &plan, void *pk, const void *start, uint32_t *done, hipStream_t stream);
 hipError_t index_build(const IxPlan &plan, const uint64_t *hashes, const uint32_t *off, void *lb, void *cnt, void *start, void *big, void *pk, void *tc,
                        uint64_t *keys_sorted, uint32_t *sorted_rows, uint32_t *gend, uint32_t *gs_of, uint32_t *code_img, uint32_t *pos_img,
                        void *stat_scratch, unsigned long long *incidences, uint32_t *max_group, uint32_t *groups, uint32_t *flags,

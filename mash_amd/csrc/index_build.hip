@@ -1274,6 +1274,35 @@ hipError_t index_gather_rows(const IxPlan &plan, const uint64_t *hashes, const u
     return hipGetLastError();
 }
 
+// TEST KNOB (MASHGPU_IX_DEBUG_SWAP, host_index.cpp): between the partition and the bucket sorts, swap the first two
+// neighbouring entries of one bucket that hold the SAME value -- the stable counting sort then leaves that value's rows in
+// descending order, exactly what a ticket served out of lane order would do, and the order check of ix_bucket_sort_body has to
+// catch it (flags[IXF_DEGENERATE]; the host builds the index by the general sort).  One wave; done[0] = 1 if a pair was found.
+__global__ __launch_bounds__(64) void ix_debug_swap_kernel(IxGeom g, uint64_t *pk, const uint32_t *start, uint32_t *done)
+{
+    if (threadIdx.x != 0) return;
+    for (uint32_t b = 0; b < g.Bp; b++) {
+        const uint32_t a = start[b], e = start[b + 1];
+        if (e - a < 2u || e - a > IX_CAP) continue;
+        for (uint32_t j = a; j + 1u < e; j++) {
+            if ((pk[j] >> g.rb) == (pk[j + 1] >> g.rb)) {
+                const uint64_t t = pk[j];
+                pk[j] = pk[j + 1];
+                pk[j + 1] = t;
+                done[0] = 1u;
+                return;
+            }
+        }
+    }
+}
+
+hipError_t index_debug_swap(const IxPlan &plan, void *pk_v, const void *start_v, uint32_t *done, hipStream_t stream)
+{
+    if (!plan.ok) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ix_debug_swap_kernel, dim3(1), dim3(64), 0, stream, plan.g, static_cast<uint64_t *>(pk_v), static_cast<const uint32_t *>(start_v), done);
+    return hipGetLastError();
+}
+
 hipError_t index_build(const IxPlan &plan, const uint64_t *hashes, const uint32_t *off, void *lb_v, void *cnt_v, void *start_v, void *big_v, void *pk_v, void *tc_v,
                        uint64_t *keys_sorted, uint32_t *sorted_rows, uint32_t *gend, uint32_t *gs_of, uint32_t *code_img, uint32_t *pos_img,
                        void *stat_scratch, unsigned long long *incidences, uint32_t *max_group, uint32_t *groups, uint32_t *flags,

@@ -1254,6 +1254,61 @@ def test_index_built_by_tiles_equals_the_sorted_index(eng, oracle, kind, monkeyp
     t.free()
 
 
+def test_bucket_sorts_refuse_an_order_they_did_not_make(eng, oracle, monkeypatch, capfd):
+    """The bucket sorts of index_build.hip (K4) rely on the LDS serving the lanes of one atomic instruction in lane order for
+    the ORDER of equal values -- checked in the kernel, not promised by the ISA (DESIGN 4.1d).  MASHGPU_IX_DEBUG_SWAP swaps
+    two entries of one value behind the partition, which leaves exactly what a ticket out of order would leave: the check
+    must fire (the build says so), the table must be indexed by the general sort instead, and the results must be the same
+    bytes as without the knob and equal to the oracle's rows (VERDICT r5 #8)."""
+    table, nhash, lengths = synth.clustered_sketches(3200, 400, clusters=32, seed=41, pool=600, private=160)
+    n = table.shape[0]
+    monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", "sparse")
+    t = eng.table_upload(table, nhash, lengths)
+    want = eng.compare_tri_host(t)
+    monkeypatch.setenv("MASHGPU_IX_DEBUG_SWAP", "1")
+    monkeypatch.setenv("MASHGPU_SPARSE_DBG", "1")
+    t.invalidate()
+    capfd.readouterr()
+    got = eng.compare_tri_host(t)
+    err = capfd.readouterr().err
+    assert "clumped values: sorted instead" in err, err[-2000:]
+    assert got.tobytes() == want.tobytes()
+    for i in (5, n // 2, n - 1):
+        numer, denom = _oracle_tri(oracle, table, nhash, lengths, i, i + 1)
+        lo = i * (i - 1) // 2
+        assert np.array_equal(got["numer"][lo:lo + i], numer) and np.array_equal(got["denom"][lo:lo + i], denom), i
+    t.free()
+
+
+def test_dense_groups_survive_leader_lists_that_overflow(eng, oracle, monkeypatch, capfd):
+    """The build by tiles appends the dense groups' leaders to a thousand lists of fixed room, by bucket; a list that overflows
+    used to cost the table its dense groups (ADVICE r5).  With the room forced to 8 entries (MASHGPU_DENSE_LEAD_CAP) the
+    leaders must be found a second time with the room they asked for: the dense pairs kernel still runs, and the bytes are
+    those of the run with room to spare."""
+    table, nhash, lengths = synth.clustered_sketches(4000, 400, clusters=40, seed=43, pool=440, private=20, keep_p=0.95)
+    monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", "sparse")
+    t = eng.table_upload(table, nhash, lengths)
+    eng.prof_enable(True)
+    eng.prof_reset()
+    want = eng.compare_tri_host(t)
+    assert eng.prof_avg_ms("compare_dense")[1] >= 1
+    monkeypatch.setenv("MASHGPU_DENSE_LEAD_CAP", "8")
+    monkeypatch.setenv("MASHGPU_SPARSE_DBG", "1")
+    t.invalidate()
+    eng.prof_reset()
+    capfd.readouterr()
+    got = eng.compare_tri_host(t)
+    err = capfd.readouterr().err
+    assert "found again with that room" in err, err[-2000:]
+    assert eng.prof_avg_ms("compare_dense")[1] >= 1
+    eng.prof_enable(False)
+    assert got.tobytes() == want.tobytes()
+    numer, denom = _oracle_tri(oracle, table, nhash, lengths, 3999, 4000)
+    lo = 3999 * 3998 // 2
+    assert np.array_equal(got["numer"][lo:], numer) and np.array_equal(got["denom"][lo:], denom)
+    t.free()
+
+
 def test_table_invalidate_after_the_buffers_changed(eng, oracle, monkeypatch):
     """mg_table_invalidate: a wrapped table whose buffers were refilled is answered from the NEW contents -- index, plans,
     classes of copies, short rows all rebuilt (first table: clusters; second: other values, some rows short, some
