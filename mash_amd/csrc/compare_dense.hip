@@ -707,10 +707,12 @@ __global__ __launch_bounds__(256) void cl_jump_kernel(const uint32_t *in, uint32
     if (i < n) out[i] = in[in[i]];
 }
 
-__global__ __launch_bounds__(256) void cl_order_keys_kernel(const uint32_t *label, uint32_t n, unsigned long long *key)
+// (split: the rows from `split` on form a segment of their own behind the others -- a triangle job over the rows [split, n) then
+//  finds its rows side by side in the index's order, and the rows of a cluster side by side inside each segment)
+__global__ __launch_bounds__(256) void cl_order_keys_kernel(const uint32_t *label, uint32_t n, uint32_t split, unsigned long long *key)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < n) key[i] = ((unsigned long long)label[i] << 32) | i;
+    if (i < n) key[i] = ((unsigned long long)(i >= split ? 1u : 0u) << 63) | ((unsigned long long)label[i] << 32) | i;
 }
 
 __global__ __launch_bounds__(256) void cl_split_keys_kernel(const unsigned long long *key_sorted, uint32_t n, uint32_t *inv, uint32_t *label_sorted)
@@ -718,7 +720,7 @@ __global__ __launch_bounds__(256) void cl_split_keys_kernel(const unsigned long 
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i < n) {
         inv[i] = (uint32_t)(key_sorted[i] & 0xFFFFFFFFull);
-        label_sorted[i] = (uint32_t)(key_sorted[i] >> 32);
+        label_sorted[i] = (uint32_t)(key_sorted[i] >> 32) & 0x7FFFFFFFu;
     }
 }
 
@@ -736,7 +738,7 @@ size_t dense_cluster_temp_bytes(uint32_t n)
 // label_sorted[n] (the label of every index row: equal labels = one cluster).
 hipError_t dense_cluster_rows(const uint64_t *hashes, uint64_t stride, const uint32_t *cnt, uint32_t n, void *temp, size_t temp_bytes,
                               unsigned long long *key_a, unsigned long long *key_b, uint32_t *row_a, uint32_t *row_b, uint32_t *lab_a,
-                              uint32_t *lab_b, uint32_t *inv, uint32_t *label_sorted, hipStream_t stream)
+                              uint32_t *lab_b, uint32_t *inv, uint32_t *label_sorted, hipStream_t stream, uint32_t split)
 {
     if (n == 0) return hipSuccess;
     const uint32_t m = n * CL_FIRST;
@@ -750,7 +752,7 @@ hipError_t dense_cluster_rows(const uint64_t *hashes, uint64_t stride, const uin
                        lab_a);
     hipLaunchKernelGGL(cl_jump_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, (const uint32_t *)lab_a, lab_b, n);
     hipLaunchKernelGGL(cl_jump_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, (const uint32_t *)lab_b, lab_a, n);
-    hipLaunchKernelGGL(cl_order_keys_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, (const uint32_t *)lab_a, n, key_a);
+    hipLaunchKernelGGL(cl_order_keys_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, (const uint32_t *)lab_a, n, split, key_a);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     e = rocprim::radix_sort_keys(temp, temp_bytes, (const unsigned long long *)key_a, key_b, (size_t)n, 0u, 64u, stream);

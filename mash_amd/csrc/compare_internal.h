@@ -227,7 +227,7 @@ hipError_t launch_dense_pairs(const DenseTile *tiles, uint32_t ntiles, uint32_t 
 size_t dense_cluster_temp_bytes(uint32_t n);
 hipError_t dense_cluster_rows(const uint64_t *hashes, uint64_t stride, const uint32_t *cnt, uint32_t n, void *temp, size_t temp_bytes,
                               unsigned long long *key_a, unsigned long long *key_b, uint32_t *row_a, uint32_t *row_b, uint32_t *lab_a,
-                              uint32_t *lab_b, uint32_t *inv, uint32_t *label_sorted, hipStream_t stream);
+                              uint32_t *lab_b, uint32_t *inv, uint32_t *label_sorted, hipStream_t stream, uint32_t split = 0);
 hipError_t launch_dense_gather_rows(const uint64_t *hashes, uint64_t stride, const uint32_t *inv, uint32_t n, uint64_t *out, hipStream_t stream);
 // grp_of[n], lead_rows[4 n] (16-byte aligned) from the candidate groups (disjoint, ascending)
 hipError_t launch_dense_group_rows(const DenseGroup *groups, uint32_t ng, uint32_t n, uint32_t *grp_of, uint32_t *lead_rows, hipStream_t stream);

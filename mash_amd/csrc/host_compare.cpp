@@ -591,9 +591,16 @@ int SparseJobRun::open_index()
     if (!mg::sparse_discover_supported((uint32_t)(triangle ? row_end : cols->n))) return leave();
     // the plain full triangle takes the CLUSTERED variant of the index (built on the table with related rows next to each
     // other: dense groups whatever the order of the collection); row ranges, rect and list jobs address table rows
-    clustered = triangle && !job && row_begin == 0 && row_end == cols->n;
+    // ... and so does a job over the table's LAST rows [rb, n) -- what a rank of several is given, its table being the view of the
+    // rows below its block's end (tri_view): the clustered order then keeps the rows from rb on in a segment of their own, so the
+    // job's rows are a range of the index's rows as well.  Not when the table's plain index exists already (a
+    // caller walking the table in blocks: its last block ends at n too).
+    clustered = triangle && !job && row_end == cols->n;
+    if (clustered && row_begin != 0)
+        for (const mg_table::Sparse *have : cols->sparse)
+            if (have->s == s && !have->clustered) clustered = false;
     if (const char *e = ctx_opt(ctx, "MASHGPU_COMPARE_CLUSTER")) clustered = clustered && atoi(e) != 0;
-    rc = table_sparse_index(ctx, cols, s, clustered, &ix);
+    rc = table_sparse_index(ctx, cols, s, clustered, &ix, clustered ? (uint32_t)row_begin : 0u);
     if (rc != MG_OK) return rc;
     if (!ix->usable && clustered) {                         // (whatever stopped it may not stop the plain variant)
         clustered = false;

@@ -52,6 +52,7 @@ struct SparseIndexBuild {
     const mg_table *t;
     const uint32_t s;
     const bool clustered;
+    const uint32_t split;                                   // clustered: rows [split, n) in a segment of their own behind the others
     mg_table::Sparse *sp;
     const uint64_t n;
     const std::chrono::steady_clock::time_point t_begin = std::chrono::steady_clock::now();
@@ -114,8 +115,8 @@ struct SparseIndexBuild {
     // ---- build
     bool built = false;
 
-    SparseIndexBuild(mg_ctx *c, const mg_table *tab, uint32_t sketch_size, bool clustered_variant, mg_table::Sparse *index)
-        : ctx(c), t(tab), s(sketch_size), clustered(clustered_variant), sp(index), n(tab->n), dc_cls(c), d_link(c), dc_last(c), d_dig(c),
+    SparseIndexBuild(mg_ctx *c, const mg_table *tab, uint32_t sketch_size, bool clustered_variant, mg_table::Sparse *index, uint32_t split_row)
+        : ctx(c), t(tab), s(sketch_size), clustered(clustered_variant), split(split_row), sp(index), n(tab->n), dc_cls(c), d_link(c), dc_last(c), d_dig(c),
           d_dig_sorted(c), k_a(c), k_b(c), d_cnt(c), d_rows_sorted(c), d_flags(c), d_nflag(c), r_a(c), r_b(c), l_a(c), l_b(c), d_inv(c),
           d_lab(c), d_tmp_dup(c), d_tmp_cl(c), d_lb(c), d_groups(c), d_grp_of(c), d_lead_rows(c), d_val(c), d_valj(c), d_cnt_sub(c),
           d_off_sub(c), d_nlead(c), d_key(c), d_keyj(c), temp(c), gs_of(c), key64_a(c), key64_b(c), d_stat(c), d_slots(c)
@@ -213,7 +214,7 @@ int SparseIndexBuild::scan_rows()
             if (k_a.alloc(4 * n) == hipSuccess && k_b.alloc(4 * n) == hipSuccess && r_a.alloc(4 * n) == hipSuccess && r_b.alloc(4 * n) == hipSuccess &&
                 l_a.alloc(n) == hipSuccess && l_b.alloc(n) == hipSuccess && d_inv.alloc(n) == hipSuccess && d_lab.alloc(n) == hipSuccess &&
                 d_tmp_cl.alloc(std::max<size_t>(tb_cl, 16)) == hipSuccess) {
-                e = mg::dense_cluster_rows(t->hashes, t->s, d_cnt, (uint32_t)n, d_tmp_cl, tb_cl, k_a, k_b, r_a, r_b, l_a, l_b, d_inv, d_lab, ctx->stream);
+                e = mg::dense_cluster_rows(t->hashes, t->s, d_cnt, (uint32_t)n, d_tmp_cl, tb_cl, k_a, k_b, r_a, r_b, l_a, l_b, d_inv, d_lab, ctx->stream, split);
                 cluster_q = true;
             } else {
                 (void)hipGetLastError();                    // no memory for the clustering: the table's own order
@@ -345,7 +346,8 @@ int SparseIndexBuild::order_rows()
     // which neighbouring rows are near-copies of each other (dense groups, compare_dense.hip)
     if (want_dense && n >= 8 && s <= 16384 && lab_sorted) {
         link.assign(n, 0);                                  // clustered variant: neighbours with the same label
-        for (uint64_t a = 1; a < n; a++) link[a] = (lab_sorted[a] == lab_sorted[a - 1] && cnt_true[a] && cnt_true[a - 1]) ? 1 : 0;
+        // (never across the two segments of a split order: index row `split` is the first row of the job's own segment)
+        for (uint64_t a = 1; a < n; a++) link[a] = (a != split && lab_sorted[a] == lab_sorted[a - 1] && cnt_true[a] && cnt_true[a - 1]) ? 1 : 0;
     } else if (cluster_q && want_dense && n >= 8 && s <= 16384 && d_link.alloc(n) == hipSuccess) {
         // (the clustering was asked for and came to nothing: the neighbours of the table's own order after all)
         link.resize(n);
@@ -909,13 +911,15 @@ int SparseIndexBuild::run()
 
 }  // namespace
 
-int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool clustered, mg_table::Sparse **out)
+int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool clustered, mg_table::Sparse **out, uint32_t split)
 {
+    if (!clustered) split = 0;
     for (mg_table::Sparse *sp : t->sparse)
-        if (sp->s == s && sp->clustered == clustered) { *out = sp; return MG_OK; }
+        if (sp->s == s && sp->clustered == clustered && sp->split == split) { *out = sp; return MG_OK; }
     mg_table::Sparse *sp = new mg_table::Sparse;
     sp->s = s;
     sp->clustered = clustered;
+    sp->split = split;
     t->sparse.push_back(sp);
     *out = sp;
     auto unusable = [&](const char *why) { sp->usable = false; sp->why = why; return MG_OK; };
@@ -925,7 +929,7 @@ int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool clustere
     sp->rs = mg::sparse_img_stride(s);
     if (n * sp->rs >= (1ull << 32)) return unusable("image index beyond 32 bits");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    SparseIndexBuild build(ctx, t, s, clustered, sp);
+    SparseIndexBuild build(ctx, t, s, clustered, sp, split);
     // (the "index" phase of the library's HIP-event records: everything the build queues -- clustering, digests, the
     //  index, dense groups -- incl. the waits between its steps)
     prof_begin(ctx, ctx->prof_index);

@@ -125,6 +125,7 @@ struct mg_table {
         // index reads the reordered copy `phashes`, and every kernel that writes results maps rows back.  Only the plain
         // full-triangle job uses it (row ranges, rect and list jobs address table rows and take the other variant).
         bool clustered = false;
+        uint32_t split = 0;                // clustered: the rows from `split` on form a segment of their own (a triangle job over [split, n))
         bool by_tiles = false;             // built by index_build.hip (tiles + bucket sorts), not by the general sort
         uint32_t *inv = nullptr;
         uint64_t *phashes = nullptr;
@@ -214,7 +215,7 @@ int fail(mg_ctx *ctx, int code, const std::string &msg);
 const char *ctx_opt(const mg_ctx *ctx, const char *name);
 // host_index.cpp: the inverted index of table t for sketch size s (cached in the table; (*out)->usable says whether the engine
 // can take it), in the table's own order or -- clustered -- on a copy with related rows next to each other
-int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool clustered, mg_table::Sparse **out);
+int table_sparse_index(mg_ctx *ctx, const mg_table *t, uint32_t s, bool clustered, mg_table::Sparse **out, uint32_t split = 0);
 // The context's block of pinned host memory (grown on demand, at least `bytes`; nullptr: none to be had -- copy into pageable
 // memory instead).  For read-backs that the host wants QUEUED, not waited for one by one: a copy into pageable memory
 // returns when it is done, 40 us each behind an idle stream.  One user at a time (a call holds the context's lock).

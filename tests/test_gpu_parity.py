@@ -1280,6 +1280,41 @@ def test_bucket_sorts_refuse_an_order_they_did_not_make(eng, oracle, monkeypatch
     t.free()
 
 
+def test_row_ranges_keep_the_clustered_index_and_its_dense_groups(eng, oracle, monkeypatch):
+    """a triangle job over a RANGE of rows -- what one rank of several is given -- used to fall back to the index
+    in table order, where the near-copies of an interleaved collection are not neighbours: no dense groups, every pair inside a
+    cluster a merge.  Now the job's table is the view of the rows below the range's end (tri_view) and its index keeps the
+    rows from the range's start on in a segment of their own (clustered order with a split): the job's rows are a range of
+    index rows, the rows of a cluster are neighbours inside each segment, and the dense pairs kernel runs.  Same bytes as the
+    slices of the whole triangle; rows against the oracle."""
+    n, s = 6000, 256
+    table, nhash, lengths = synth.clustered_sketches(n, s, clusters=30, seed=51, pool=280, private=12, keep_p=0.95)
+    nhash = nhash.copy()
+    nhash[4100] = 0
+    nhash[2222] = 100
+    t = eng.table_upload(table, nhash, lengths)
+    whole = eng.compare_tri_host(t)
+    eng.prof_enable(True)
+    for rb, re in ((3000, 6000), (2000, 4500), (4242, 6000)):
+        t.invalidate()
+        eng.prof_reset()
+        got = eng.compare_tri_host(t, rb, re)
+        assert eng.prof_avg_ms("compare_dense")[1] >= 1, (rb, re)       # the groups' pairs went through dn_pairs_kernel
+        lo, hi = rb * (rb - 1) // 2, re * (re - 1) // 2
+        assert got.tobytes() == whole[lo:hi].tobytes(), (rb, re)
+    eng.prof_enable(False)
+    for i in (3000, 4100, 5999):
+        numer, denom = _oracle_tri(oracle, table, nhash, lengths, i, i + 1)
+        lo = i * (i - 1) // 2
+        assert np.array_equal(whole["numer"][lo:lo + i], numer) and np.array_equal(whole["denom"][lo:lo + i], denom), i
+    # the same ranges with the clustering switched off: the same bytes (the plain index)
+    monkeypatch.setenv("MASHGPU_COMPARE_CLUSTER", "0")
+    t.invalidate()
+    got = eng.compare_tri_host(t, 3000, 6000)
+    assert got.tobytes() == whole[3000 * 2999 // 2:].tobytes()
+    t.free()
+
+
 def test_dense_groups_survive_leader_lists_that_overflow(eng, oracle, monkeypatch, capfd):
     """The build by tiles appends the dense groups' leaders to a thousand lists of fixed room, by bucket; a list that overflows
     used to cost the table its dense groups.  With the room forced to 8 entries (MASHGPU_DENSE_LEAD_CAP) the
