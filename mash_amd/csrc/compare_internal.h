@@ -261,7 +261,7 @@ struct JoinArgs {
 size_t join_order_temp_bytes(uint32_t nrows);
 hipError_t join_order_rows(const uint32_t *img, uint32_t rs, const uint32_t *cnt_off, const uint32_t *rep, const uint32_t *inv, const uint32_t *gend,
                            const uint32_t *sorted_rows, uint32_t nrows, void *temp, size_t temp_bytes, uint32_t *lab, unsigned long long *key_a,
-                           unsigned long long *key_b, uint32_t *val_a, uint32_t *perm, uint32_t *src, uint32_t *map, hipStream_t stream);
+                           unsigned long long *key_b, uint32_t *val_a, uint32_t *perm, uint32_t *src, uint32_t *map, hipStream_t stream, uint32_t split = 0);
 uint32_t join_block_rows();
 uint32_t join_levels();
 size_t join_build_temp_bytes(uint64_t slots);

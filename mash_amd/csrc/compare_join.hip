@@ -208,14 +208,18 @@ __global__ __launch_bounds__(256) void jn_jump_kernel(const uint32_t *in0, const
     out2[row] = in2[in2[row]];
 }
 
+// (split: the rows from `split` on in a segment of their own behind the others -- a job over the rows [split, n) is then a range
+//  of the lists' rows, and every pair of it is a (row, earlier row) of the lists)
 __global__ __launch_bounds__(256) void jn_order_keys_kernel(const uint32_t *lab0, const uint32_t *lab1, const uint32_t *lab2, uint32_t nrows, uint32_t bits,
-                                                            unsigned long long *key, uint32_t *val)
+                                                            uint32_t split, unsigned long long *key, uint32_t *val)
 {
     const uint32_t row = blockIdx.x * 256u + threadIdx.x;
     if (row >= nrows) return;
     unsigned long long k = lab0[row];
     k |= (unsigned long long)lab1[row] << bits;
-    if (3u * bits <= 64u) k |= (unsigned long long)lab2[row] << (2u * bits);
+    const bool three = 3u * bits + 1u <= 64u;
+    if (three) k |= (unsigned long long)lab2[row] << (2u * bits);
+    k |= (unsigned long long)(row >= split ? 1u : 0u) << (three ? 3u * bits : 2u * bits);
     key[row] = k;
     val[row] = row;
 }
@@ -570,7 +574,7 @@ size_t join_order_temp_bytes(uint32_t nrows)
 // perm / src / map [nrows]: out.
 hipError_t join_order_rows(const uint32_t *img, uint32_t rs, const uint32_t *cnt_off, const uint32_t *rep, const uint32_t *inv, const uint32_t *gend,
                            const uint32_t *sorted_rows, uint32_t nrows, void *temp, size_t temp_bytes, uint32_t *lab, unsigned long long *key_a,
-                           unsigned long long *key_b, uint32_t *val_a, uint32_t *perm, uint32_t *src, uint32_t *map, hipStream_t stream)
+                           unsigned long long *key_b, uint32_t *val_a, uint32_t *perm, uint32_t *src, uint32_t *map, hipStream_t stream, uint32_t split)
 {
     if (nrows == 0) return hipSuccess;
     uint32_t *a0 = lab, *a1 = lab + nrows, *a2 = lab + 2ull * nrows, *b0 = lab + 3ull * nrows, *b1 = lab + 4ull * nrows, *b2 = lab + 5ull * nrows;
@@ -581,11 +585,11 @@ hipError_t join_order_rows(const uint32_t *img, uint32_t rs, const uint32_t *cnt
     hipLaunchKernelGGL(jn_jump_kernel, dim3(g), dim3(256), 0, stream, (const uint32_t *)a0, (const uint32_t *)a1, (const uint32_t *)a2, nrows, b0, b1, b2);
     uint32_t bits = 1;
     while ((1ull << bits) < nrows) bits++;
-    hipLaunchKernelGGL(jn_order_keys_kernel, dim3(g), dim3(256), 0, stream, (const uint32_t *)b0, (const uint32_t *)b1, (const uint32_t *)b2, nrows, bits, key_a,
-                       val_a);
+    hipLaunchKernelGGL(jn_order_keys_kernel, dim3(g), dim3(256), 0, stream, (const uint32_t *)b0, (const uint32_t *)b1, (const uint32_t *)b2, nrows, bits, split,
+                       key_a, val_a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    const uint32_t key_bits = 3u * bits <= 64u ? 3u * bits : 2u * bits;
+    const uint32_t key_bits = (3u * bits + 1u <= 64u ? 3u * bits : 2u * bits) + 1u;
 #ifdef MG_HIP_EMU
     {
         std::vector<uint32_t> p(nrows);

@@ -981,9 +981,12 @@ int SparseJobRun::join()
     const bool only_shared = triangle && ix->copies == 0;   // (a value of ONE row of the index and that row's copies has no shared bit)
     // the whole triangle: the lists on the rows in an order of their own, relatives side by side (compare_join.hip: jn_labels_kernel);
     // a range of rows is a range of the lists' blocks only in the index's order
-    bool ordered = triangle && row_begin == 0 && row_end == cols->n;
+    // (a job over the table's last rows [rb, n) -- a rank's, on the view of the rows below its block's end -- likewise: those rows
+    //  form a segment of their own behind the others, so the job is a range of the lists' rows)
+    bool ordered = triangle && row_end == cols->n;
     if (const char *e = ctx_opt(ctx, "MASHGPU_JOIN_ORDER")) ordered = ordered && atoi(e) != 0;
-    if (ix->jn.built && (ix->jn.only_shared != only_shared || ix->jn.ordered != ordered)) {
+    const uint32_t jsplit = ordered ? a.row_begin : 0u;
+    if (ix->jn.built && (ix->jn.only_shared != only_shared || ix->jn.ordered != ordered || ix->jn.split != jsplit)) {
         for (void *&q : ix->jn.bufs) { if (q) ctx_free(ctx, q); q = nullptr; }
         ix->jn.built = false;
     }
@@ -1004,7 +1007,7 @@ int SparseJobRun::join()
             if (!ok) { (void)hipGetLastError(); if (force_join) return fail(ctx, MG_ERR_NOMEM, "compare: no device memory for the join order"); return MG_OK; }
             hipError_t e = mg::join_order_rows(ix->code_img, ix->rs, ix->off, ix->rep, ix->inv, ix->gend, ix->sorted_rows, n32, temp, tb, lab, key_a, key_b, val_a,
                                                static_cast<uint32_t *>(order_bufs[0]), static_cast<uint32_t *>(order_bufs[1]),
-                                               static_cast<uint32_t *>(order_bufs[2]), ctx->stream);
+                                               static_cast<uint32_t *>(order_bufs[2]), ctx->stream, jsplit);
             if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare (join order): ") + hipGetErrorString(e));
             src = static_cast<const uint32_t *>(order_bufs[1]);
         }
@@ -1020,6 +1023,7 @@ int SparseJobRun::join()
         ix->jn.map = ordered ? static_cast<const uint32_t *>(ix->jn.bufs[8]) : nullptr;
         ix->jn.only_shared = only_shared;
         ix->jn.ordered = ordered;
+        ix->jn.split = jsplit;
         ix->jn.built = true;
     }
     JoinListBufs Q(ctx);

@@ -143,7 +143,8 @@ struct mg_table {
         // (only_shared: values held by one row left out -- the triangle's variant; a rect job needs every entry)
         struct Join {
             bool built = false, only_shared = false;
-            bool ordered = false;          // the lists stand on the rows in an order of their own (src / map; the whole triangle only)
+            bool ordered = false;          // the lists stand on the rows in an order of their own (src / map): a triangle job over the
+            uint32_t split = 0;            // table's last rows [split, n), those rows in a segment of their own behind the others
             mg::JoinSide side;
             const uint32_t *src = nullptr, *map = nullptr;
             void *bufs[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

@@ -172,7 +172,7 @@ static int run_triangle(const Rows &table, uint32_t s, uint32_t rb, uint32_t re,
     const uint32_t n = (uint32_t)table.size();
     std::vector<uint32_t> inv(n);
     for (uint32_t i = 0; i < n; i++) inv[i] = i;
-    if (permute) std::shuffle(inv.begin(), inv.end(), rng);
+    if (permute) { std::shuffle(inv.begin(), inv.end(), rng); rb = 0; re = n; }
     Rows rows(n);
     for (uint32_t a = 0; a < n; a++) rows[a] = table[inv[a]];
     Index ix = build_index(rows, s, true);
@@ -180,18 +180,23 @@ static int run_triangle(const Rows &table, uint32_t s, uint32_t rb, uint32_t re,
     Lists L;
     const uint32_t *src = ix.copies ? ix.rep.data() : nullptr, *map = permute ? inv.data() : nullptr;
     std::vector<uint32_t> o_perm(n), o_src(n), o_map(n);
-    if (order) {                                            // the lists on the rows in the order of their families (whole triangle only)
+    // the lists on the rows in the order of their families: the whole triangle, or a job over the table's LAST rows [rb, n), which
+    // then form a segment of their own behind the others (not together with a permuted index: the range is one of index rows)
+    uint32_t split = 0;
+    if (order) {
+        if (!permute && re == n) split = rb; else { rb = 0; re = n; }
         std::vector<uint32_t> lab(6ull * n), val_a(n);
         std::vector<unsigned long long> key_a(n), key_b(n);
         unsigned char temp[16];
         if (join_order_rows(ix.code.data(), ix.rs, ix.off.data(), src, map, ix.gend.data(), ix.sorted_rows.data(), n, temp, 16, lab.data(), key_a.data(),
-                            key_b.data(), val_a.data(), o_perm.data(), o_src.data(), o_map.data(), nullptr) != hipSuccess) { fprintf(stderr, "join_order_rows failed\n"); return 1; }
+                            key_b.data(), val_a.data(), o_perm.data(), o_src.data(), o_map.data(), nullptr, split) != hipSuccess) { fprintf(stderr, "join_order_rows failed\n"); return 1; }
         std::vector<uint32_t> seen(n, 0);
         for (uint32_t x : o_perm) seen[x]++;
         for (uint32_t x : seen) if (x != 1) { fprintf(stderr, "%s: the order is no permutation\n", what); return 1; }
+        for (uint32_t a2 = 0; a2 < n; a2++)
+            if ((o_perm[a2] >= split) != (a2 >= split)) { fprintf(stderr, "%s: the rows from %u on are not the order's last\n", what, split); return 1; }
         src = o_src.data();
         map = o_map.data();
-        rb = 0; re = n;
     }
     make_lists(ix.code.data(), ix.rs, ix.off.data(), src, n, s, ix.E, !ix.copies, L);
     JoinArgs a;
@@ -206,8 +211,8 @@ static int run_triangle(const Rows &table, uint32_t s, uint32_t rb, uint32_t re,
     a.out = out.data();
     a.out_base = out_base;
     a.ncols = n;
-    a.row_begin = permute ? 0 : rb;                        // (a permuted index serves the whole triangle only)
-    a.row_end = permute ? n : re;
+    a.row_begin = rb;                                       // (a permuted index serves the whole triangle only: rb = 0, re = n there)
+    a.row_end = re;
     a.bi0 = a.row_begin / 64u;
     const uint64_t bi1 = ((uint64_t)a.row_end + 63u) / 64u;
     a.ncb = (n + 63u) / 64u;
@@ -216,7 +221,7 @@ static int run_triangle(const Rows &table, uint32_t s, uint32_t rb, uint32_t re,
     a.ntiles = bi1 * (bi1 + 1) / 2 - (uint64_t)a.bi0 * (a.bi0 + 1) / 2;
     if (launch_join_tiles(a, nullptr) != hipSuccess) { fprintf(stderr, "launch failed\n"); return 1; }
     int bad = 0;
-    for (uint32_t i = (permute ? 0 : rb); i < (permute ? n : re); i++)
+    for (uint32_t i = rb; i < re; i++)
         for (uint32_t j = 0; j < i; j++) {
             uint32_t c, d;
             reference_pair(table[i], table[j], s, c, d);
@@ -333,6 +338,8 @@ int main(int argc, char **argv)
         bad += run_triangle(t, 64, 128, 200, false, true, rng, "rows [128, 200)");
         bad += run_triangle(t, 64, 0, 65, false, true, rng, "rows [0, 65)");
         bad += run_triangle(t, 64, 0, 200, true, true, rng, "permuted index");
+        bad += run_triangle(t, 64, 70, 200, false, true, rng, "rows [70, 200), rows by family in two segments", true);
+        bad += run_triangle(t, 64, 128, 200, false, true, rng, "rows [128, 200), rows by family in two segments", true);
     } else if (which == "ragged") {
         // rows of every length (empty ones too) over one pool and over a tree: positions differ between the rows of a pair
         Rows t = pool_rows(90, 50, rng, 2.5, 0.4, true);
@@ -381,7 +388,8 @@ int main(int argc, char **argv)
             if (rng() % 2) { rb = (uint32_t)(rng() % n); re = rb + 1 + (uint32_t)(rng() % (n - rb)); }
             char what[96];
             snprintf(what, sizeof what, "fuzz %d (n %u, s %u, kind %d, rows [%u, %u))", c, n, s, kind, rb, re);
-            bad += run_triangle(t, s, rb, re, rb == 0 && re == n && rng() % 2, rng() % 4 != 0, rng, what, rb == 0 && re == n && rng() % 2);
+            if (rng() % 3 == 0) re = n;
+            bad += run_triangle(t, s, rb, re, rb == 0 && re == n && rng() % 2, rng() % 4 != 0, rng, what, re == n && rng() % 2);
             if (bad) break;
         }
     } else {

@@ -1089,9 +1089,14 @@ def test_one_species_takes_the_join_engine(eng, oracle, monkeypatch):
     rb, re = 1501, 2990
     eng.prof_reset()
     monkeypatch.setenv("MASHGPU_COMPARE_KERNEL", "join")   # (3.3e6 pairs: below what the dispatch sends to an index at all)
+    t.invalidate()
     got2 = eng.compare_tri_host(t, rb, re)
-    monkeypatch.delenv("MASHGPU_COMPARE_KERNEL")
+    # ... and the table's LAST rows (a rank's job on its view): the lists in family order, those rows in a segment of their own
+    eng.prof_reset()
+    got4 = eng.compare_tri_host(t, 1200, n)
     assert eng.prof_avg_ms("compare_join")[1] == 1
+    assert np.array_equal(got4["numer"], numer[1200 * 1199 // 2:]) and np.array_equal(got4["denom"], denom[1200 * 1199 // 2:])
+    monkeypatch.delenv("MASHGPU_COMPARE_KERNEL")
     base = rb * (rb - 1) // 2
     cnt = re * (re - 1) // 2 - base
     assert np.array_equal(got2["numer"], numer[base: base + cnt]) and np.array_equal(got2["denom"], denom[base: base + cnt])
