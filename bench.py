@@ -535,30 +535,39 @@ def main():
     # cut so that pairs + row_weight x rows is the same for every rank (mg_shard_tri_rows_weighted).  Untimed.
     row_weight = 0.0
     if world > 1:
+        # A rank's index covers the rows below its block's end only (host_compare.cpp: tri_view), so a block also costs per row
+        # of that prefix: prefix_weight = index time per row of the view over fill time per pair (mg_shard_tri_rows_costed).
         if dry:                        # (figures of C3's order, so that the exchange and the re-cut run under gloo)
-            fill_ms, dm_ms = my_pairs * 1.34e-9, (re - rb) * 8e-5
+            fill_ms, dm_ms, ix_ms = my_pairs * 1.34e-9, (re - rb) * 8e-5, re * 7.9e-5
         else:
             eng.prof_enable(True)
             eng.prof_reset()
+            table.invalidate()
             step()
             torch.cuda.synchronize()
-            fill_ms = dm_ms = 0.0
-            for name in ("compare_fill", "compare_discover", "compare_merge"):
+            fill_ms = dm_ms = ix_ms = 0.0
+            for name in ("compare_fill", "compare_discover", "compare_merge", "compare_index", "compare_join"):
                 ms, k = eng.prof_avg_ms(name)
-                if name == "compare_fill":
-                    fill_ms += ms * k
+                if name == "compare_index":
+                    ix_ms += ms * k
+                elif name in ("compare_fill", "compare_join"):
+                    fill_ms += ms * k                    # (what is paid per pair)
                 else:
                     dm_ms += ms * k
             eng.prof_enable(False)
-        cost = torch.tensor([fill_ms, dm_ms, float(my_pairs), float(re - rb)], dtype=torch.float64, device=dev)
+        cost = torch.tensor([fill_ms, dm_ms, float(my_pairs), float(re - rb), ix_ms, float(re)], dtype=torch.float64, device=dev)
         dist.all_reduce(cost)
+        prefix_weight = 0.0
         if float(cost[0]) > 0 and float(cost[2]) > 0 and float(cost[3]) > 0:
-            row_weight = (float(cost[1]) / float(cost[3])) / (float(cost[0]) / float(cost[2]))
-        if row_weight > 0:
+            per_pair = float(cost[0]) / float(cost[2])
+            row_weight = (float(cost[1]) / float(cost[3])) / per_pair
+            if float(cost[5]) > 0 and os.environ.get("MASHGPU_TRI_PREFIX") != "0":
+                prefix_weight = (float(cost[4]) / float(cost[5])) / per_pair
+        if row_weight > 0 or prefix_weight > 0:
             if dry:
-                blocks = shard.weighted_row_blocks(n, world, row_weight)
+                blocks = shard.costed_row_blocks(n, world, row_weight, prefix_weight)
             else:
-                blocks = [abi.shard_tri_rows_weighted(eng.lib, 0, n, world, g, row_weight)[0] for g in range(world)] + [n]
+                blocks = [abi.shard_tri_rows_costed(eng.lib, 0, n, world, g, row_weight, prefix_weight)[0] for g in range(world)] + [n]
             rb, re = blocks[rank], blocks[rank + 1]
             my_pairs = shard.tri_pairs(rb, re)
             del out
@@ -636,6 +645,7 @@ def main():
                                f"per-table job (index build + discover + fill + merge each step), row-block sharded x{world}",
                    "n_sketches": n, "sketch_size": S, "kmer": K, "hash_bits": 64,
                    "parallelism": f"rowblock{world}", "rank_row_blocks": blocks, "row_weight_pairs": round(row_weight, 1),
+                   "prefix_weight_pairs": round(prefix_weight, 1) if world > 1 else 0.0,
                    "table_broadcast_ms": round(bcast_ms, 2), "index_ms_by_rank": index_ms_by_rank,
                    "rccl_ranks": rccl_ranks, "comm": comm_kind, "output_checksum": checksum,
                    "first_call_ms": round(first_call_ms, 2) if first_call_ms is not None else None},

@@ -405,6 +405,12 @@ void     mg_shard_tri_rows(uint64_t row_begin, uint64_t row_end, int nranks, int
  * fill, summed over the ranks).  row_weight <= 0: mg_shard_tri_rows. */
 void     mg_shard_tri_rows_weighted(uint64_t row_begin, uint64_t row_end, int nranks, int rank, double row_weight,
                                     uint64_t *b_out, uint64_t *e_out);
+/* ... and with a cost per row of the table BELOW a block's end (prefix_weight hi pair-units for the block [lo, hi)): a rank
+ * builds its inverted index over the rows below its block's end only (a triangle job over rows [lo, hi) looks at no row from hi
+ * on, CommandTriangle.cpp:200-214), so late blocks pay for more of the table and get fewer pairs.  bench.py measures
+ * prefix_weight in its warm-up (index time per row of the view over fill time per pair).  prefix_weight <= 0: the call above. */
+void     mg_shard_tri_rows_costed(uint64_t row_begin, uint64_t row_end, int nranks, int rank, double row_weight, double prefix_weight,
+                                  uint64_t *b_out, uint64_t *e_out);
 void     mg_shard_rows(uint64_t row_begin, uint64_t row_end, int nranks, int rank, uint64_t *b_out, uint64_t *e_out);
 int      mg_dtable_upload(mg_comm *c, const uint64_t *hashes, const uint32_t *nhash, const uint64_t *lengths,
                           uint64_t n, uint64_t s, mg_dtable **out);         /* host -> GPU 0 -> broadcast */

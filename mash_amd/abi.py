@@ -37,7 +37,7 @@ EXPORTS = [
     "mg_screen_reset", "mg_screen_finish_sparse_host", "mg_screen_tier_note", "mg_dscreen_finish_sparse_host", "mg_dscreen_reset",
     "mg_identity", "mg_p_value_within",
     "mg_comm_create_local", "mg_comm_unique_id", "mg_comm_create_rank", "mg_comm_destroy", "mg_comm_size", "mg_comm_rank",
-    "mg_comm_uses_rccl", "mg_comm_ctx", "mg_comm_last_error", "mg_shard_tri_rows", "mg_shard_tri_rows_weighted", "mg_shard_rows", "mg_dtable_upload",
+    "mg_comm_uses_rccl", "mg_comm_ctx", "mg_comm_last_error", "mg_shard_tri_rows", "mg_shard_tri_rows_weighted", "mg_shard_tri_rows_costed", "mg_shard_rows", "mg_dtable_upload",
     "mg_dtable_free", "mg_dtable_local", "mg_table_broadcast", "mg_comm_allreduce_u32_sum", "mg_dtable_upload_rows", "mg_sketch_sharded_host",
     "mg_compare_tri_sharded_host", "mg_compare_rect_sharded_host", "mg_compare_tri_pairs_sharded_host",
     "mg_compare_rect_pairs_sharded_host", "mg_compare_tri_results_sharded_host", "mg_compare_rect_results_sharded_host",
@@ -255,6 +255,8 @@ def load_library():
     lib.mg_shard_tri_rows.restype = None
     lib.mg_shard_tri_rows_weighted.argtypes = [u64, u64, i32, i32, C.c_double, C.POINTER(u64), C.POINTER(u64)]
     lib.mg_shard_tri_rows_weighted.restype = None
+    lib.mg_shard_tri_rows_costed.argtypes = [u64, u64, i32, i32, C.c_double, C.c_double, C.POINTER(u64), C.POINTER(u64)]
+    lib.mg_shard_tri_rows_costed.restype = None
     lib.mg_shard_rows.argtypes = [u64, u64, i32, i32, C.POINTER(u64), C.POINTER(u64)]
     lib.mg_shard_rows.restype = None
     lib.mg_dtable_upload.argtypes = [vp, vp, vp, vp, u64, u64, C.POINTER(vp)]
@@ -362,6 +364,13 @@ def shard_tri_rows_weighted(lib, row_begin, row_end, nranks, rank, row_weight):
     b, e = C.c_uint64(0), C.c_uint64(0)
     lib.mg_shard_tri_rows_weighted(row_begin, row_end, nranks, rank, float(row_weight), C.byref(b), C.byref(e))
     return int(b.value), int(e.value)
+
+
+def shard_tri_rows_costed(lib, row_begin, row_end, nranks, rank, row_weight, prefix_weight):
+    """row block of `rank` when the block [lo, hi) costs pairs + row_weight (hi - lo) + prefix_weight hi (mg_shard_tri_rows_costed)"""
+    b, e = C.c_uint64(0), C.c_uint64(0)
+    lib.mg_shard_tri_rows_costed(row_begin, row_end, nranks, rank, float(row_weight), float(prefix_weight), C.byref(b), C.byref(e))
+    return b.value, e.value
 
 
 def shard_tri_rows(lib, row_begin, row_end, nranks, rank):

@@ -147,6 +147,47 @@ void mg_shard_tri_rows_weighted(uint64_t row_begin, uint64_t row_end, int nranks
     if (e_out) *e_out = boundary(rank + 1);
 }
 
+// ... and with a cost per row of the table BELOW a block's end: a rank derives what it needs -- the inverted index above all --
+// from the view of the rows below its block's end (host_compare.cpp: tri_view), so its block [lo, hi) costs
+//     pairs(lo, hi) + row_weight (hi - lo) + prefix_weight hi
+// pair-units.  The blocks of equal cost are found by bisection on that cost: for a cost T the blocks are laid one after the other
+// (each as long as T allows); the smallest T whose G blocks reach row_end is the answer.  Every rank computes all boundaries.
+void mg_shard_tri_rows_costed(uint64_t row_begin, uint64_t row_end, int nranks, int rank, double row_weight, double prefix_weight,
+                              uint64_t *b_out, uint64_t *e_out)
+{
+    if (!(prefix_weight > 0)) { mg_shard_tri_rows_weighted(row_begin, row_end, nranks, rank, row_weight, b_out, e_out); return; }
+    if (nranks < 1) nranks = 1;
+    const long double w = row_weight > 0 ? (long double)row_weight : 0.0L, v = (long double)prefix_weight;
+    auto cost = [&](uint64_t lo, uint64_t hi) -> long double {
+        return (long double)tri_pairs(lo, hi) + w * (long double)(hi - lo) + v * (long double)hi;
+    };
+    std::vector<uint64_t> b((size_t)nranks + 1, row_end);
+    auto lay = [&](long double T) -> bool {                // blocks of cost <= T, one after the other; true: they reach row_end
+        uint64_t lo = row_begin;
+        b[0] = row_begin;
+        for (int g = 0; g < nranks; g++) {
+            uint64_t a = lo, e = row_end;                    // the largest hi in [lo, row_end] with cost(lo, hi) <= T (hi = lo: an empty block)
+            if (cost(lo, e) <= T) a = e;
+            else while (e - a > 1) { const uint64_t m = a + (e - a) / 2; if (cost(lo, m) <= T) a = m; else e = m; }
+            if (a > lo && cost(lo, a) > T) a = lo;
+            b[(size_t)g + 1] = a;
+            lo = a;
+        }
+        return lo >= row_end;
+    };
+    long double t_lo = 0.0L, t_hi = cost(row_begin, row_end);
+    for (int it = 0; it < 200 && t_hi - t_lo > 0.5L; it++) {
+        const long double mid = (t_lo + t_hi) * 0.5L;
+        if (lay(mid)) t_hi = mid; else t_lo = mid;
+    }
+    (void)lay(t_hi);
+    b[(size_t)nranks] = row_end;
+    if (rank < 0) rank = 0;
+    if (rank >= nranks) rank = nranks - 1;
+    if (b_out) *b_out = b[(size_t)rank];
+    if (e_out) *e_out = b[(size_t)rank + 1];
+}
+
 void mg_shard_rows(uint64_t row_begin, uint64_t row_end, int nranks, int rank, uint64_t *b_out, uint64_t *e_out)
 {
     const uint64_t n = row_end > row_begin ? row_end - row_begin : 0;

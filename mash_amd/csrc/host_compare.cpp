@@ -1258,11 +1258,11 @@ uint64_t tri_pairs(uint64_t row_begin, uint64_t row_end)
 // G ranks with equal-area blocks thereby builds an index of sqrt((g + 1) / G) of the table instead of all of it (rank 0 of 8:
 // 35 %; the mean: 70 %), and rank 0's job is the WHOLE triangle of its view: the clustered index, dense groups whatever the
 // collection's order, the join engine's ordered lists.  Per CALL, not per internal block of a call: the blocks of one call
-// share one view.  (MASHGPU_TRI_PREFIX=0: off.  A view that saves less than a tenth of the rows is not worth a second index.)
+// share one view.  (MASHGPU_TRI_PREFIX=0: off.)
 static const mg_table *tri_view(mg_ctx *ctx, const mg_table *t, uint64_t rb, uint64_t re)
 {
     if (re > t->n) re = t->n;
-    if (rb >= re || re == t->n || re * 10 > t->n * 9 || tri_pairs(rb, re) < 4000000ull) return t;
+    if (rb >= re || re == t->n || tri_pairs(rb, re) < 4000000ull) return t;
     if (const char *e = ctx_opt(ctx, "MASHGPU_TRI_PREFIX")) { if (atoi(e) == 0) return t; }
     // One view per table: a rank's calls come with the same range every time, but a caller that walks the table in blocks
     // of rows (the CLI: 2^24 pairs a call) would pay an index per block -- its first block makes a (small) view, the second

@@ -45,6 +45,48 @@ def weighted_row_blocks(n, world, row_weight):
     return b
 
 
+def costed_row_blocks(n, world, row_weight, prefix_weight):
+    """Boundaries when the block [lo, hi) costs pairs + row_weight (hi - lo) + prefix_weight hi pair-units
+    (mg_shard_tri_rows_costed): a rank indexes the rows below its block's end only.  prefix_weight 0 = weighted_row_blocks."""
+    if not prefix_weight > 0:
+        return weighted_row_blocks(n, world, row_weight)
+    w = max(float(row_weight), 0.0)
+    v = float(prefix_weight)
+    cost = lambda lo, hi: tri_pairs(lo, hi) + w * (hi - lo) + v * hi
+
+    def lay(T):
+        b, lo = [0], 0
+        for _ in range(world):
+            a, e = lo, n
+            if cost(lo, e) <= T:
+                a = e
+            else:
+                while e - a > 1:
+                    m = a + (e - a) // 2
+                    if cost(lo, m) <= T:
+                        a = m
+                    else:
+                        e = m
+            if a > lo and cost(lo, a) > T:
+                a = lo
+            b.append(a)
+            lo = a
+        return b, lo >= n
+
+    t_lo, t_hi = 0.0, float(cost(0, n))
+    for _ in range(200):
+        if t_hi - t_lo <= 0.5:
+            break
+        mid = (t_lo + t_hi) * 0.5
+        if lay(mid)[1]:
+            t_hi = mid
+        else:
+            t_lo = mid
+    b = lay(t_hi)[0]
+    b[-1] = n
+    return b
+
+
 def tri_pairs(row_begin, row_end):
     t = lambda x: x * (x - 1) // 2 if x else 0
     return t(row_end) - t(row_begin)

@@ -192,3 +192,28 @@ def test_weighted_shard_balances_pairs_plus_rows(lib):
                     assert [abi.shard_tri_rows_weighted(lib, 0, n, G, g, w)[0] for g in range(G)] + [n] == shard.weighted_row_blocks(n, G, w)
     # C3 at 8 ranks with a row worth 60 000 pairs: the first block shrinks from 35 355 rows to under 20 000
     assert abi.shard_tri_rows(lib, 0, 100_000, 8, 0)[1] == 35_355 and abi.shard_tri_rows_weighted(lib, 0, 100_000, 8, 0, 6e4)[1] < 20_000
+
+
+def test_costed_shard_balances_pairs_rows_and_the_prefix_below_a_block(lib):
+    """mg_shard_tri_rows_costed: the block [lo, hi) costs pairs + w (hi - lo) + v hi pair-units -- a rank indexes the rows
+    below its block's end only (host_compare.cpp: tri_view), so late blocks pay for more of the table.  The blocks cover the
+    rows without gaps, the costs of all blocks but the last agree to within one row's cost (the last takes what is left and is
+    no dearer), v = 0 is the weighted cut, and mash_amd/shard.py (what bench.py's gloo dry run uses) cuts the same rows."""
+    from mash_amd import shard
+    for n in (1, 7, 1000, 100_000):
+        for G in (1, 2, 3, 8):
+            for w, v in ((0.0, 5.9e4), (6e4, 5.9e4), (3e3, 1.0), (0.0, 1e7)):
+                b = [abi.shard_tri_rows_costed(lib, 0, n, G, g, w, v) for g in range(G)]
+                assert b[0][0] == 0 and b[-1][1] == n and all(b[g][1] == b[g + 1][0] for g in range(G - 1)), (n, G, w, v, b)
+                cost = lambda lo, hi: shard.tri_pairs(lo, hi) + w * (hi - lo) + v * hi
+                one_row = n + w + v + 1
+                full = [cost(lo, hi) for lo, hi in b if lo < hi < n]
+                last = [cost(lo, hi) for lo, hi in b if lo < hi == n]
+                if full:
+                    assert max(full) - min(full) <= one_row, (n, G, w, v, b)
+                    assert last and last[0] <= max(full) + one_row, (n, G, w, v, b)
+                assert [x[0] for x in b] + [n] == shard.costed_row_blocks(n, G, w, v), (n, G, w, v)
+            assert [abi.shard_tri_rows_costed(lib, 0, n, G, g, 6e4, 0.0) for g in range(G)] == [abi.shard_tri_rows_weighted(lib, 0, n, G, g, 6e4) for g in range(G)]
+    # C3 on 8 ranks with the measured weight: the last rank, whose view is the whole table, gets a sliver of the pairs
+    b = shard.costed_row_blocks(100_000, 8, 0.0, 5.9e4)
+    assert shard.tri_pairs(b[7], b[8]) < shard.tri_pairs(b[0], b[1]) / 3

@@ -29,27 +29,46 @@ t = eng.table_wrap(h.data_ptr(), nh.data_ptr(), ln.data_ptr(), n, S, keep=(h, nh
 blocks = shard.equal_area_row_blocks(n, G)
 out = torch.empty((max(shard.tri_pairs(blocks[g], blocks[g + 1]) for g in range(G)), 2), dtype=torch.int32, device=dev)
 eng.compare_tri_dev(t, 0, n, torch.empty((n * (n - 1) // 2, 2), dtype=torch.int32, device=dev).data_ptr())     # warm the pool
-res = []
-for g in range(G):
-    rb, re = blocks[g], blocks[g + 1]
-    best = None
-    for rep in range(3):
-        t.invalidate()
-        eng.prof_enable(True)
-        eng.prof_reset()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        eng.compare_tri_dev(t, rb, re, out.data_ptr())
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) * 1e3
-        ph = {p: round(eng.prof_avg_ms("compare_" + p)[0] * eng.prof_avg_ms("compare_" + p)[1], 3) for p in ("index", "discover", "fill", "dense", "merge", "join")}
-        eng.prof_enable(False)
-        if best is None or ms < best[0]:
-            best = (ms, ph)
-    pairs = shard.tri_pairs(rb, re)
-    sums = [int(out[:pairs, 0].sum(dtype=torch.int64).item()), int(out[:pairs, 1].sum(dtype=torch.int64).item())]
-    res.append({"rank": g, "rows": [rb, re], "pairs": pairs, "ms": round(best[0], 3), "phases_ms": best[1], "sums": sums})
-    print(json.dumps(res[-1]), flush=True)
+def run_blocks(blocks):
+  res = []
+  for g in range(G):
+      rb, re = blocks[g], blocks[g + 1]
+      best = None
+      for rep in range(3):
+          t.invalidate()
+          eng.prof_enable(True)
+          eng.prof_reset()
+          torch.cuda.synchronize()
+          t0 = time.perf_counter()
+          eng.compare_tri_dev(t, rb, re, out.data_ptr())
+          torch.cuda.synchronize()
+          ms = (time.perf_counter() - t0) * 1e3
+          ph = {p: round(eng.prof_avg_ms("compare_" + p)[0] * eng.prof_avg_ms("compare_" + p)[1], 3) for p in ("index", "discover", "fill", "dense", "merge", "join")}
+          eng.prof_enable(False)
+          if best is None or ms < best[0]:
+              best = (ms, ph)
+      pairs = shard.tri_pairs(rb, re)
+      sums = [int(out[:pairs, 0].sum(dtype=torch.int64).item()), int(out[:pairs, 1].sum(dtype=torch.int64).item())]
+      res.append({"rank": g, "rows": [rb, re], "pairs": pairs, "ms": round(best[0], 3), "phases_ms": best[1], "sums": sums})
+      print(json.dumps(res[-1]), flush=True)
+  return res
+
+
+res = run_blocks(blocks)
 tot = n * (n - 1) // 2
-print(json.dumps({"workload": which, "ranks": G, "prefix_views": os.environ.get("PREFIX") != "0", "max_ms": max(r["ms"] for r in res),
+print(json.dumps({"workload": which, "ranks": G, "cut": "equal areas", "prefix_views": os.environ.get("PREFIX") != "0", "max_ms": max(r["ms"] for r in res),
                   "pairs_s_if_sharded": tot / (max(r["ms"] for r in res) * 1e-3), "checksum": [sum(r["sums"][0] for r in res), sum(r["sums"][1] for r in res)]}))
+# the cut bench.py makes from one measured step (mg_shard_tri_rows_costed): per pair what fill / join cost, per row discover + merge,
+# per row of the view the index
+fill = sum(r["phases_ms"]["fill"] + r["phases_ms"]["join"] for r in res)
+dm = sum(r["phases_ms"]["discover"] + r["phases_ms"]["merge"] for r in res)
+ix = sum(r["phases_ms"]["index"] for r in res)
+per_pair = fill / tot
+w = (dm / n) / per_pair
+v = (ix / sum(r["rows"][1] for r in res)) / per_pair if os.environ.get("PREFIX") != "0" else 0.0
+blocks2 = [abi.shard_tri_rows_costed(eng.lib, 0, n, G, g, w, v)[0] for g in range(G)] + [n]
+out = torch.empty((max(shard.tri_pairs(blocks2[g], blocks2[g + 1]) for g in range(G)), 2), dtype=torch.int32, device=dev)
+res2 = run_blocks(blocks2)
+print(json.dumps({"workload": which, "ranks": G, "cut": "costed", "row_weight": round(w, 1), "prefix_weight": round(v, 1), "blocks": blocks2,
+                  "max_ms": max(r["ms"] for r in res2), "pairs_s_if_sharded": tot / (max(r["ms"] for r in res2) * 1e-3),
+                  "checksum": [sum(r["sums"][0] for r in res2), sum(r["sums"][1] for r in res2)]}))
