@@ -244,30 +244,37 @@ __global__ __launch_bounds__(256) void ix_col_scan_kernel(IxGeom g, uint32_t *cn
 }
 
 // K2b (one workgroup): start[b] = exclusive prefix of the buckets' entries (in place), start[Bp] = E; the fullest bucket;
-// the buckets that the LDS sort does not take (flags[IXF_NBIG] of them, in no particular order)
+// the buckets that the LDS sort does not take (flags[IXF_NBIG] of them, in no particular order).
+// Rounds of 4 096 buckets, four consecutive ones per work-item: the workgroup reads and writes whole lines (round 5 gave every
+// work-item a contiguous slice of the buckets -- 380 loads a lane, each lane in a line of its own: 1.24 ms on C5's 390 000
+// buckets for 6 MB of traffic).
 __global__ __launch_bounds__(1024) void ix_bucket_scan_kernel(IxGeom g, uint32_t *start, uint32_t *flags, uint32_t *biglist)
 {
     __shared__ uint32_t s_part[16], s_max[16];
     const uint32_t tid = threadIdx.x;
-    const uint32_t per = (g.Bp + 1023u) / 1024u;
-    const uint32_t b0 = tid * per, b1 = b0 + per < g.Bp ? b0 + per : g.Bp;
-    uint32_t sum = 0, mx = 0;
-    for (uint32_t b = b0; b < b1; b++) {
-        const uint32_t c = start[b];
-        sum += c;
-        mx = c > mx ? c : mx;
-        // (a bucket beyond the LDS sort's capacity -- a value held by thousands of rows stands in it: ix_big_bucket_kernel's;
-        //  the list has room for E / IX_CAP + 1 of them, more cannot exist)
-        if (c > IX_CAP) biglist[atomicAdd(&flags[IXF_NBIG], 1u)] = b;
+    uint32_t carry = 0, mx = 0;
+    for (uint32_t base = 0; base < g.Bp; base += 4096u) {   // uniform
+        const uint32_t b = base + 4u * tid;
+        uint32_t c[4], sum = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; k++) {
+            c[k] = b + k < g.Bp ? start[b + k] : 0u;
+            sum += c[k];
+            mx = c[k] > mx ? c[k] : mx;
+            // (a bucket beyond the LDS sort's capacity -- a value held by thousands of rows stands in it: ix_big_bucket_kernel's;
+            //  the list has room for E / IX_CAP + 1 of them, more cannot exist)
+            if (c[k] > IX_CAP) biglist[atomicAdd(&flags[IXF_NBIG], 1u)] = b + k;
+        }
+        uint32_t total = 0;
+        uint32_t run = carry + ix_block_scan_sum(sum, s_part, total);       // (two barriers inside)
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; k++) {
+            if (b + k < g.Bp) start[b + k] = run;
+            run += c[k];
+        }
+        carry += total;
     }
-    uint32_t total = 0;
-    uint32_t run = ix_block_scan_sum(sum, s_part, total);
-    for (uint32_t b = b0; b < b1; b++) {
-        const uint32_t c = start[b];
-        start[b] = run;
-        run += c;
-    }
-    if (tid == 0) start[g.Bp] = total;
+    if (tid == 0) start[g.Bp] = carry;
 #pragma unroll
     for (uint32_t d = 32; d > 0; d >>= 1) {
         const uint32_t o = __shfl_xor(mx, d);

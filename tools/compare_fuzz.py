@@ -66,7 +66,8 @@ def main():
     eng = abi.MashGpu(0, stream=torch.cuda.current_stream().cuda_stream)
     rng = np.random.default_rng(a.seed)
     engines = [("generic", {"MASHGPU_COMPARE_KERNEL": "generic"}), ("plain", {"MASHGPU_COMPARE_KERNEL": "merged", "MASHGPU_COMPARE_WINDOWS": "0"}),
-               ("windows", {"MASHGPU_COMPARE_KERNEL": "merged", "MASHGPU_COMPARE_WINDOWS": "1"}), ("default", {}), ("sparse", {"MASHGPU_COMPARE_KERNEL": "sparse"})]
+               ("windows", {"MASHGPU_COMPARE_KERNEL": "merged", "MASHGPU_COMPARE_WINDOWS": "1"}), ("default", {}), ("sparse", {"MASHGPU_COMPARE_KERNEL": "sparse"}),
+               ("join", {"MASHGPU_COMPARE_KERNEL": "join"})]
     t0 = time.time()
     bad = ran = 0
     for case in range(a.n):
@@ -105,7 +106,7 @@ def main():
                     eng.compare_tri_dev(t, 0, n, out.data_ptr())
                 eng.synchronize()
             except abi.MashGpuError as e:
-                if name in ("windows",) and "unsupported" in str(e).lower():
+                if name in ("windows", "join") and ("unsupported" in str(e).lower() or "cannot take" in str(e).lower()):
                     continue
                 print("ERROR case %d %s n=%d s=%d %s: %s" % (case, style, n, s, name, e))
                 bad += 1
