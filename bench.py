@@ -597,7 +597,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     srcs = ("mash_amd/csrc/compare_sparse.hip", "mash_amd/csrc/compare_dense.hip", "mash_amd/csrc/compare_merged.hip", "mash_amd/csrc/compare_internal.h",
-            "mash_amd/csrc/index_build.hip")
+            "mash_amd/csrc/index_build.hip", "mash_amd/csrc/compare_join.hip")
     pmc = load_pmc("compare_c3_cold_pmc.json", *srcs) if (n == 100_000 and world == 1 and not dry) else None
     roofline = compare_roofline(eng, my_pairs, n, S, args.steps, pmc) if not dry else {"bound": "hbm", "dry": True}
     dt = max_over_ranks(dt)
@@ -1147,8 +1147,7 @@ def main():
                 eng.compare_tri_dev(t5, 0, n5, out5.data_ptr())
             torch.cuda.synchronize()
             d5 = time.perf_counter() - t0
-            srcs5 = ("mash_amd/csrc/compare_sparse.hip", "mash_amd/csrc/compare_dense.hip", "mash_amd/csrc/compare_merged.hip", "mash_amd/csrc/compare_internal.h",
-                     "mash_amd/csrc/index_build.hip")
+            srcs5 = srcs
             rf5_cold = compare_roofline(eng, pairs5, n5, S5, steps5, load_pmc("compare_c5_cold_pmc.json", *srcs5) if n5 == 100_000 else None)
             if "pass" in rf5_cold:
                 rf5_cold["step_frac"] = round(rf5_cold["pass"]["compulsory_bytes"] / (d5 / steps5) / 1e9 / HBM_PEAK_GBS, 4)

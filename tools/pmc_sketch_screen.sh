@@ -1,6 +1,6 @@
 #!/bin/bash
-# HBM and issue counters of the sketch kernel and the screen kernel again (sketch.hip changed this round: the packed staging
-# branch): PMC passes, each its own run, over bench.py's sketch leg / screen leg -> gpurun_out/{sketch,screen}_pmc_latest.json
+# HBM and issue counters of the sketch kernel and the screen kernel (to be run again whenever sketch.hip, kmer_hash.h or screen.hip
+# change: bench.py drops the files when the sources' hash differs): PMC passes, each its own run, over bench.py's sketch leg / screen leg -> gpurun_out/{sketch,screen}_pmc_latest.json
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out

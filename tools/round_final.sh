@@ -1,0 +1,19 @@
+#!/bin/bash
+# A round's closing run on one box (TAG=r06): every GPU test, the smoke entry, the profile legs (kernel statistics + HBM
+# counters; SQ counters for the headline's leg and the join engine's kernel), the fuzzers, then the bench line with the PMC
+# files of THIS tree.  To be repeated whenever the hot path changes afterwards.
+#   gpurun --timeout 5400 -- 'TAG=r06 bash tools/round_final.sh'
+TAG=${TAG:-r06}
+export TAG
+cd ${GRAFT_REPO_ROOT:-.}
+mkdir -p gpurun_out
+timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/${TAG}_gpu_tests.log 2>&1
+echo "gpu tests rc=$? $(grep -E 'passed|failed' gpurun_out/${TAG}_gpu_tests.log | tail -1)"
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+timeout 2400 bash tools/profile_round.sh ${LEGS:-c3_cold c3 c5_cold c5 clades one_clade random identical one_species_cold one_species} 2>&1 | tail -40
+cp gpurun_out/compare_*_pmc.json profiles/ 2>/dev/null
+LEG=one_species timeout 600 bash tools/pmc_join.sh > gpurun_out/${TAG}_one_species_sq.txt 2>&1; tail -4 gpurun_out/${TAG}_one_species_sq.txt
+timeout 400 python tools/compare_fuzz.py --seed 606 --seconds 150 --n 100000 > gpurun_out/${TAG}_compare_fuzz.txt 2>&1; tail -1 gpurun_out/${TAG}_compare_fuzz.txt
+for w in c3 one_species; do timeout 300 python tools/ranks_on_one_gpu.py $w 8 > gpurun_out/${TAG}_ranks_$w.txt 2>/dev/null; grep '"cut"' gpurun_out/${TAG}_ranks_$w.txt; done
+timeout 1500 python bench.py --detail gpurun_out/${TAG}_bench_detail.json > gpurun_out/${TAG}_bench_line.json 2> gpurun_out/${TAG}_bench_stderr.log
+echo "bench rc=$?"; tail -1 gpurun_out/${TAG}_bench_line.json | cut -c1-3500
