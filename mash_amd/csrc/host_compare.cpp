@@ -942,7 +942,11 @@ static int join_make_lists(mg_ctx *ctx, const uint32_t *img, uint32_t rs, const 
 
 int SparseJobRun::join()
 {
-    if (job) return MG_OK;                                  // list jobs want candidates, not a matrix
+    // (a LIST job -- thresholded results, the sparse matrix -- wants candidates, not a matrix: the engine does not make lists.  But
+    //  where it would take the matrix of the same rows, the list engine is the wrong one too -- every pair a candidate, a merge
+    //  each --, so the job is handed back and its caller takes the matrix path in blocks, which reaches this engine per block
+    //  and filters on the device)
+    if (job && force_join) return MG_OK;
     if (const char *e = ctx_opt(ctx, "MASHGPU_COMPARE_JOIN")) { if (atoi(e) == 0 && !force_join) return MG_OK; }
     const uint32_t B = mg::join_block_rows();
     const uint64_t nside = triangle ? cols->n : nrows;     // rows of the row side's index space
@@ -977,6 +981,10 @@ int SparseJobRun::join()
         fresh.shared = shared_job;
     }
     if (!take) return MG_OK;
+    if (job) {
+        if (first) { fresh.join = true; keep_plan(); }
+        return leave();
+    }
     // ---- the lists
     const bool only_shared = triangle && ix->copies == 0;   // (a value of ONE row of the index and that row's copies has no shared bit)
     // the whole triangle: the lists on the rows in an order of their own, relatives side by side (compare_join.hip: jn_labels_kernel);

@@ -1100,6 +1100,28 @@ def test_one_species_takes_the_join_engine(eng, oracle, monkeypatch):
     base = rb * (rb - 1) // 2
     cnt = re * (re - 1) // 2 - base
     assert np.array_equal(got2["numer"], numer[base: base + cnt]) and np.array_equal(got2["denom"], denom[base: base + cnt])
+    # a LIST job on such a table (thresholded results): the list engine would merge every pair, so the job goes down the matrix
+    # path in blocks -- through this engine -- and is filtered on the device; same records as with the engine switched off
+    t.invalidate()
+    eng.prof_reset()
+    res = eng.compare_tri_results(t, 21, KSPACE21, max_d=0.25, capacity=1 << 22)
+    assert eng.prof_avg_ms("compare_join")[1] >= 1 and len(res) > 10000
+    monkeypatch.setenv("MASHGPU_COMPARE_JOIN", "0")
+    t.invalidate()
+    res0 = eng.compare_tri_results(t, 21, KSPACE21, max_d=0.25, capacity=1 << 22)
+    assert res.tobytes() == res0.tobytes()
+    monkeypatch.delenv("MASHGPU_COMPARE_JOIN")
+    # (the table above has an empty row and a copy, which the list engine declines by itself; a clean one takes the hand-over)
+    clean, cn, cl = synth.species_sketches(n, s, seed=12)
+    tc = eng.table_upload(clean, cn, cl)
+    eng.prof_reset()
+    res = eng.compare_tri_results(tc, 21, KSPACE21, max_d=0.25, capacity=1 << 22)
+    assert eng.prof_avg_ms("compare_join")[1] >= 1 and eng.prof_avg_ms("compare_merge")[1] == 0 and len(res) > 10000
+    monkeypatch.setenv("MASHGPU_COMPARE_JOIN", "0")
+    tc.invalidate()
+    assert eng.compare_tri_results(tc, 21, KSPACE21, max_d=0.25, capacity=1 << 22).tobytes() == res.tobytes()
+    monkeypatch.delenv("MASHGPU_COMPARE_JOIN")
+    tc.free()
     # the other engines on the same table: the same bytes
     monkeypatch.setenv("MASHGPU_COMPARE_JOIN", "0")
     t.invalidate()
