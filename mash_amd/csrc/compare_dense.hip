@@ -443,12 +443,15 @@ __global__ __launch_bounds__(256) void dn_encode_kernel(const uint32_t *off, con
 
 hipError_t launch_dense_encode(const uint32_t *off, const uint32_t *code_img, uint32_t *pos_img, uint32_t rs, const uint32_t *grp_of,
                                const DenseGroup *groups, const uint32_t *ulist, const uint32_t *upos, unsigned long long *gdata,
-                               unsigned long long *xm, uint16_t *ext, uint32_t xs, uint32_t n, uint32_t wmax, hipStream_t stream)
+                               unsigned long long *xm, uint16_t *ext, uint32_t xs, uint32_t n, uint32_t wmax, hipStream_t stream, int ul_mode)
 {
     if (n == 0) return hipSuccess;
-    // the universe in LDS while it fits beside the masks (64 values per word: always, for the widths dense_max_words allows)
+    // The universe in LDS while that leaves a CU several workgroups: a universe of 15 000 values (C5: 86 KB with the masks) made it
+    // ONE workgroup of four waves per CU, each staging 60 KB for one row -- read from the L2 instead (the row ascends, so do its
+    // probes) the kernel keeps five workgroups per CU: C5 per table 92.3 -> 88.1 ms; C3's 1 500 values stay staged (15.0 against
+    // 14.8 ms unstaged).  ul_mode 0 / 1 (MASHGPU_DENSE_UL_LDS): never / whenever it fits at all.
     const size_t fixed = ((size_t)28 * wmax + 9) * 4, with_ul = fixed + (size_t)wmax * 64 * 4;
-    const bool ul_in_lds = with_ul <= 150 * 1024;
+    const bool ul_in_lds = ul_mode == 0 ? false : ul_mode == 1 ? with_ul <= 150 * 1024 : with_ul <= 40 * 1024;
     const size_t smem = ul_in_lds ? with_ul : fixed;
     // (measured: eight entries per work-item 13.6 -> 11.4 ms at s = 10 000, 0.72 -> 0.86 ms at s = 1 000)
     auto go = [&](auto kern) -> hipError_t {

@@ -216,7 +216,7 @@ hipError_t dense_sort_universes(const unsigned long long *key, const uint32_t *v
                                 uint32_t group_bits, hipStream_t stream);
 hipError_t launch_dense_encode(const uint32_t *off, const uint32_t *code_img, uint32_t *pos_img, uint32_t rs, const uint32_t *grp_of,
                                const DenseGroup *groups, const uint32_t *ulist, const uint32_t *upos, unsigned long long *gdata,
-                               unsigned long long *xm, uint16_t *ext, uint32_t xs, uint32_t n, uint32_t wmax, hipStream_t stream);
+                               unsigned long long *xm, uint16_t *ext, uint32_t xs, uint32_t n, uint32_t wmax, hipStream_t stream, int ul_mode = -1);
 size_t dense_pairs_lds(uint32_t W, uint32_t rows);
 uint32_t dense_rows_per_tile(uint64_t wave_rows);
 uint32_t dense_max_words();

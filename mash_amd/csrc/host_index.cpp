@@ -864,7 +864,8 @@ int SparseIndexBuild::dense_groups()
             // masks, extras, and the index's runs clipped for the rows of the groups: discovery sees the partners outside only
             if (e2 == hipSuccess)
                 e2 = mg::launch_dense_encode(sp->off, sp->code_img, sp->pos_img, sp->rs, sp->grp_of, sp->dgroups, sp->ulist, sp->upos, sp->gdata, sp->xm,
-                                             sp->ext, sp->dn_xs, (uint32_t)n, wmax, ctx->stream);
+                                             sp->ext, sp->dn_xs, (uint32_t)n, wmax, ctx->stream,
+                                             ctx_opt(ctx, "MASHGPU_DENSE_UL_LDS") ? atoi(ctx_opt(ctx, "MASHGPU_DENSE_UL_LDS")) : -1);
             // (no wait here: what the copies above read -- dgroups_host and the rows' group map -- lives in the index, what
             //  comes next is queued on the same stream, and a fault shows at its wait)
             sp->grp_of_host.swap(grp_of);
