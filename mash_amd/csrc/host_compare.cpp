@@ -487,33 +487,11 @@ struct SparseJob {
     uint64_t dense_pairs = 0;
 };
 
-// What the dispatch believes things cost: seconds on one MI355X, each a measured number (profiles/r03_sparse_phases.txt; the
-// dense pairs and the tile engine's price of a shared hash from rounds 4 and 5), written down in ONE place.  They are
-// constants, not calibrated per context: the decision they feed is between engines whose costs differ by factors, and it is
-// cached per (table, rows).
-struct SparseCosts {
-    double fill_bytes_s = 4.5e12;            // the fill writes 8 B per pair
-    double discover_per_shared = 2.0e-12;    // a run entry read by discovery
-    double discover_per_entry = 4.0e-11;     // a row's entry looked at (n x s of them)
-    double merge_per_candidate = 1.0e-9;     // a merge of ~2 s steps
-    double launches = 2.0e-5;
-    double class_bytes_s = 2.0e12;           // pairs inside classes of identical rows
-    double dense_per_pair = 3.0e-11;         // a pair inside a dense group
-    // the tile engine: pairs per second by job size, and what a shared hash costs it -- 2.2e-12 s between copies of one
-    // sketch, 5.5e-12 inside clades, 1.2e-11 in a collection of one species, where every pair shares a few hundred values and
-    // no two rows the same ones (round 5's one_species bracket: 1.58 s for 5.4e8 pairs where the model said 0.33); priced at
-    // the upper middle, the copies and clades having engines of their own by now
-    double tiles_rate_small = 8.0e9, tiles_rate_mid = 1.5e10, tiles_rate_large = 3.0e10;
-    double tiles_per_shared = 8.0e-12;
-    // the join engine (compare_join.hip): a counter update per (pair, shared value); an intersection step of 64 x 64 group ids
-    // per tile (the lists' groups are bounded by their entries before the lists exist); the lists' sort per slot
-    // (round 6, one species of 32 768 rows: 1.25e11 shared hashes in 37.5 ms all in, lists in family order)
-    double join_per_shared = 2.2e-13;
-    double join_per_step = 4.0e-11;
-    double join_per_slot = 8.0e-11;
-    double join_min_shared_per_pair = 4.0;   // below this many shared hashes per pair of the TABLE the engine is not even priced
-};
-static const SparseCosts kSparseCosts;
+// What the dispatch believes things cost: SparseCosts (host_internal.h) -- a context starts from numbers measured on one MI355X
+// and corrects them from its OWN launches: the phases of every job seen for the first time are timed (events on the context's
+// stream, read when the job has ended) and the per-unit prices move half way towards what was measured, within a factor of
+// four of the defaults (SparseJobRun::learn).  MASHGPU_COSTS_FIXED: the defaults, always.
+
 
 // One job of the inverted-index engine, phase by phase (run()): the index of the column table, the row side (triangle: the
 // table itself; rect: the queries located in the index), the job's plan (dense tiles, visiting order; cached per table and
@@ -573,6 +551,14 @@ struct SparseJobRun {
     int find_plan();
     int keep_plan();
     int join();
+    // the context's cost table learns from the phases of a job seen for the first time
+    enum { CK_FILL, CK_DISCOVER, CK_MERGE, CK_DENSE, CK_JOIN, CK_N };
+    bool clk_used[CK_N] = {false, false, false, false, false};
+    double join_steps = 0.0;
+    bool learning() const { return first && !ctx->async && !ctx_opt(ctx, "MASHGPU_COSTS_FIXED"); }
+    void clk_begin(int k);
+    void clk_end(int k);
+    void learn();
     int ensure_lists(uint64_t want_cand);
     int discover();
     int choose_engine();
@@ -841,7 +827,9 @@ int SparseJobRun::discover()
         HIP_TRY(ctx, hipMemsetAsync(ix->counters, 0, 4 * 8, ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(ix->seg_cnt, 0, nrows * 4, ctx->stream));
         prof_begin(ctx, ctx->prof_discover);
+        if (attempt == 0) clk_begin(CK_DISCOVER);
         hipError_t e = mg::launch_sparse_discover(a, false, ctx->stream);
+        if (attempt == 0) clk_end(CK_DISCOVER);
         prof_end(ctx, ctx->prof_discover);
         if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare (discover): ") + hipGetErrorString(e));
         if (!first) break;                                  // a job seen before: its list has the size it needed then (checked at the end)
@@ -861,7 +849,7 @@ int SparseJobRun::choose_engine()
         fresh.shared = h[1];
         // seconds, one MI355X (measured: profiles/r03_sparse_phases.txt)
         const double np = (double)pairs;
-        const SparseCosts &K = kSparseCosts;
+        const SparseCosts &K = ctx->costs;
         const double t_sparse = np * 8.0 / K.fill_bytes_s + (double)fresh.shared * K.discover_per_shared + (double)nrows * s * K.discover_per_entry +
                                 (double)fresh.cand * K.merge_per_candidate + K.launches + (triangle ? (double)ix->cls_pairs * 8.0 / K.class_bytes_s : 0.0) +
                                 (double)fresh.dense_pairs * K.dense_per_pair;
@@ -954,7 +942,7 @@ int SparseJobRun::join()
     if (!can) return force_join ? fail(ctx, MG_ERR_UNSUPPORTED, "compare: the join engine cannot take this job") : MG_OK;
     bool take = force_join || (plan && !first && plan->join);
     if (!take && first && !force) {
-        const SparseCosts &K = kSparseCosts;
+        const SparseCosts &K = ctx->costs;
         const double table_pairs = triangle ? (double)cols->n * (double)(cols->n - 1) / 2.0 : (double)pairs;
         // (the index's own statistic -- every value's holders choose 2, before any clipping -- rules most tables out for free;
         //  rect: the queries are not part of it, the count below decides)
@@ -1064,8 +1052,11 @@ int SparseJobRun::join()
     j.s = s;
     j.ntiles = triangle ? bi1 * (bi1 + 1) / 2 - (uint64_t)j.bi0 * (j.bi0 + 1) / 2 : (bi1 - j.bi0) * (uint64_t)j.ncb;
     prof_begin(ctx, ctx->prof_join);
+    clk_begin(CK_JOIN);
     hipError_t e = mg::launch_join_tiles(j, ctx->stream);
+    clk_end(CK_JOIN);
     prof_end(ctx, ctx->prof_join);
+    join_steps = (double)j.ntiles * 2.0 * ((double)ix->E / (double)std::max<uint32_t>(j.ncb, 1u)) / 64.0;
     if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare (join): ") + hipGetErrorString(e));
     if (first) { fresh.join = true; fresh.use = true; keep_plan(); }
     *handled = true;
@@ -1086,8 +1077,10 @@ int SparseJobRun::fill_and_dense()
         prof_begin(ctx, ctx->prof_fill);
         // a table of n copies of one sketch: the fill IS the answer, {c, c} in every slot, written once
         const bool all_copies = triangle && ix->one_class != 0;
+        clk_begin(CK_FILL);
         hipError_t e = all_copies ? mg::launch_sparse_fill_value(a.out, pairs, ix->one_class, ix->one_class, 16u, (uint32_t)ctx->cu_count, ctx->stream)
                                   : mg::launch_sparse_fill_value(a.out, pairs, 0u, s, 16u, (uint32_t)ctx->cu_count, ctx->stream);
+        clk_end(CK_FILL);
         if (e == hipSuccess && nshort_rows && !ix->short_rows_host.empty() && !all_copies)      // (copies of a SHORT sketch are {c, c} too, not {0, 2c})
             e = mg::launch_sparse_fill_short(a.out, short_rows_dev, short_rcnt_dev, nshort_rows, ix->short_rows, ix->short_cnt,
                                              (uint32_t)ix->short_rows_host.size(), a.row_begin, a.ncols, a.triangle, a.out_base, s, a.inv, ctx->stream);
@@ -1100,8 +1093,10 @@ int SparseJobRun::fill_and_dense()
         // the pairs inside the dense groups (over the fill; candidates never lie inside a group)
         if (plan->ndtiles) {
             prof_begin(ctx, ctx->prof_dense);
+            clk_begin(CK_DENSE);
             e = mg::launch_dense_pairs(plan->dtiles, plan->ndtiles, plan->dtile_rows, ix->dgroups, ix->gdata, ix->xm, ix->dn_lists, ix->ext, ix->dn_xs, s, ix->dn_wmax,
                                        a.row_begin, a.row_end, a.out_base, a.inv, a.out, ctx->stream);
+            clk_end(CK_DENSE);
             prof_end(ctx, ctx->prof_dense);
             if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare (dense groups): ") + hipGetErrorString(e));
         }
@@ -1126,6 +1121,7 @@ int SparseJobRun::merge_and_scatter()
     bool by_rows = mg::sparse_merge_rows_supported(a.rs_row);
     if (const char *ev = ctx_opt(ctx, "MASHGPU_SPARSE_MERGE")) by_rows = by_rows && strcmp(ev, "lanes") != 0;
     prof_begin(ctx, ctx->prof_merge);
+    clk_begin(CK_MERGE);
     hipError_t e = hipSuccess;
     bool packed = false;
     // rows with few candidates each (a collection: C3 has 50 per row) share a work item; rows with hundreds (clades)
@@ -1136,6 +1132,7 @@ int SparseJobRun::merge_and_scatter()
     if (!packed && e == hipSuccess)
         e = by_rows ? mg::launch_sparse_merge_rows(a, plan->cand, ix->chunks, ix->scan_temp, ix->scan_temp_bytes, ctx->stream)
                     : mg::launch_sparse_merge(a, plan->cand, (uint32_t)ctx->cu_count, ctx->stream);
+    clk_end(CK_MERGE);
     prof_end(ctx, ctx->prof_merge);
     if (e != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare (merge): ") + hipGetErrorString(e));
     if (job) job->args = a;
@@ -1155,8 +1152,61 @@ int SparseJobRun::merge_and_scatter()
     return MG_OK;
 }
 
+void SparseJobRun::clk_begin(int k)
+{
+    if (!learning()) return;
+    mg_ctx::CostClock &c = ctx->cost_clk[k];
+    if (!c.a && (hipEventCreate(&c.a) != hipSuccess || hipEventCreate(&c.b) != hipSuccess)) { (void)hipGetLastError(); c.a = c.b = nullptr; return; }
+    if (hipEventRecord(c.a, ctx->stream) == hipSuccess) clk_used[k] = true;
+}
+
+void SparseJobRun::clk_end(int k)
+{
+    if (clk_used[k] && hipEventRecord(ctx->cost_clk[k].b, ctx->stream) != hipSuccess) clk_used[k] = false;
+}
+
+// prices per unit from the phases just timed: half way from what the context believed to what it measured, never further than
+// a factor of four from the defaults (one odd table must not turn the dispatch over); phases too short to say anything are skipped
+void SparseJobRun::learn()
+{
+    bool any = false;
+    for (bool u : clk_used) any = any || u;
+    if (!any || !plan) return;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) { (void)hipGetLastError(); return; }
+    const SparseCosts D;                                    // the defaults
+    SparseCosts &K = ctx->costs;
+    auto secs = [&](int k) -> double {
+        float ms = 0.f;
+        if (!clk_used[k] || hipEventElapsedTime(&ms, ctx->cost_clk[k].a, ctx->cost_clk[k].b) != hipSuccess) { (void)hipGetLastError(); return 0.0; }
+        return (double)ms * 1e-3;
+    };
+    auto move = [](double &c, double measured, double def) {
+        const double v = 0.5 * c + 0.5 * measured;
+        c = std::min(std::max(v, def / 4.0), def * 4.0);
+    };
+    const double floor_s = 1.0e-4;                          // (below 0.1 ms a phase is its launch)
+    double t;
+    if ((t = secs(CK_FILL)) > floor_s) { double bps = K.fill_bytes_s; move(bps, (double)pairs * 8.0 / t, D.fill_bytes_s); K.fill_bytes_s = bps; }
+    if ((t = secs(CK_DISCOVER)) > floor_s) {
+        const double model = (double)plan->shared * K.discover_per_shared + (double)nrows * s * K.discover_per_entry;
+        if (model > 0) { const double r = t / model; move(K.discover_per_shared, K.discover_per_shared * r, D.discover_per_shared); move(K.discover_per_entry, K.discover_per_entry * r, D.discover_per_entry); }
+    }
+    if ((t = secs(CK_MERGE)) > floor_s && plan->cand >= 10000) move(K.merge_per_candidate, t / (double)plan->cand, D.merge_per_candidate);
+    if ((t = secs(CK_DENSE)) > floor_s && plan->dense_pairs >= 100000) move(K.dense_per_pair, t / (double)plan->dense_pairs, D.dense_per_pair);
+    if ((t = secs(CK_JOIN)) > floor_s) {
+        const double model = (double)plan->shared * K.join_per_shared + join_steps * K.join_per_step;
+        if (model > 0) { const double r = t / model; move(K.join_per_shared, K.join_per_shared * r, D.join_per_shared); move(K.join_per_step, K.join_per_step * r, D.join_per_step); }
+    }
+    ctx->cost_updates++;
+    if (ctx_opt(ctx, "MASHGPU_SPARSE_DBG"))
+        fprintf(stderr, "compare costs (context, after %llu jobs): fill %.3g B/s, discover %.3g s per shared hash + %.3g per entry, merge %.3g per candidate, dense %.3g per pair, join %.3g per shared hash + %.3g per step\n",
+                (unsigned long long)ctx->cost_updates, K.fill_bytes_s, K.discover_per_shared, K.discover_per_entry, K.merge_per_candidate, K.dense_per_pair,
+                K.join_per_shared, K.join_per_step);
+}
+
 int SparseJobRun::run()
 {
+    struct Learn { SparseJobRun *r; ~Learn() { r->learn(); } } learn_at_exit{this};
     if ((rc = open_index()) != MG_OK || stop) return rc;
     if ((rc = row_side()) != MG_OK || stop) return rc;
     if ((rc = find_plan()) != MG_OK || stop) return rc;

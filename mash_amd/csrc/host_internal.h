@@ -37,6 +37,34 @@
 
 struct ProfRec { hipEvent_t a, b; };
 
+// What the compare dispatch believes things cost (host_compare.cpp: SparseJobRun::join / choose_engine): seconds on one MI355X,
+// each a measured number (profiles/r03_sparse_phases.txt; the dense pairs and the tile engine's price of a shared hash from
+// rounds 4 and 5; the join engine's from round 6), written down in ONE place.  These are the DEFAULTS: every context keeps a
+// copy and corrects it from the phases of its own jobs (SparseJobRun::learn).
+struct SparseCosts {
+    double fill_bytes_s = 4.5e12;            // the fill writes 8 B per pair
+    double discover_per_shared = 2.0e-12;    // a run entry read by discovery
+    double discover_per_entry = 4.0e-11;     // a row's entry looked at (n x s of them)
+    double merge_per_candidate = 1.0e-9;     // a merge of ~2 s steps
+    double launches = 2.0e-5;
+    double class_bytes_s = 2.0e12;           // pairs inside classes of identical rows
+    double dense_per_pair = 3.0e-11;         // a pair inside a dense group
+    // the tile engine: pairs per second by job size, and what a shared hash costs it -- 2.2e-12 s between copies of one
+    // sketch, 5.5e-12 inside clades, 1.2e-11 in a collection of one species, where every pair shares a few hundred values and
+    // no two rows the same ones (round 5's one_species bracket: 1.58 s for 5.4e8 pairs where the model said 0.33); priced at
+    // the upper middle, the copies and clades having engines of their own by now
+    double tiles_rate_small = 8.0e9, tiles_rate_mid = 1.5e10, tiles_rate_large = 3.0e10;
+    double tiles_per_shared = 8.0e-12;
+    // the join engine (compare_join.hip): a counter update per (pair, shared value); an intersection step of 64 x 64 group ids
+    // per tile (the lists' groups are bounded by their entries before the lists exist); the lists' sort per slot
+    // (round 6, one species of 32 768 rows: 1.25e11 shared hashes in 37.5 ms all in, lists in family order)
+    double join_per_shared = 2.2e-13;
+    double join_per_step = 4.0e-11;
+    double join_per_slot = 8.0e-11;
+    double join_min_shared_per_pair = 4.0;   // below this many shared hashes per pair of the TABLE the engine is not even priced
+};
+
+
 struct mg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -72,6 +100,11 @@ struct mg_ctx {
     // mg_ctx_set_option: tuning and test knobs of this context (name -> value); a knob that is not set here is looked
     // up in the environment under the same name
     std::map<std::string, std::string> options;
+    // the compare dispatch's prices, corrected from this context's own launches; the event pairs that time a phase
+    SparseCosts costs;
+    struct CostClock { hipEvent_t a = nullptr, b = nullptr; };
+    CostClock cost_clk[5];
+    uint64_t cost_updates = 0;
 };
 
 struct mg_table {

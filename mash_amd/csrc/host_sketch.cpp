@@ -405,7 +405,7 @@ int sketch_dev_impl(mg_ctx *ctx, const mg_params *p, const uint8_t *bases_dev, u
     if (pk && (counts_out_dev || probe || p->min_copies > 1 || !alphabet_is_dna(p)))
         return fail(ctx, MG_ERR_UNSUPPORTED, "mg_sketch: packed bases in the kernel serve plain nucleotide sketches only");
     // (what the unpack kernel's launcher checked before the sketch kernel read packed bases itself: ADVICE r5)
-    if (pk && (!pk->packed || !pk->mask || pk->skip >= 16u || pk->mskip >= 32u || ((uintptr_t)pk->packed & 3) != 0 || ((uintptr_t)pk->mask & 3) != 0))
+    if (pk && (!pk->packed || pk->skip >= 16u || pk->mskip >= 32u || ((uintptr_t)pk->packed & 3) != 0 || ((uintptr_t)pk->mask & 3) != 0))      // (mask: nullable)
         return fail(ctx, MG_ERR_INVALID, "mg_sketch: packed bases must be 4-byte aligned words, base skip < 16, mask skip < 32");
     if (p->kmer_size < 1 || p->kmer_size > 32) return fail(ctx, MG_ERR_INVALID, "mg_sketch: k must be 1..32");
     if (counts_out_dev && !mg::count_supported(p->sketch_size))

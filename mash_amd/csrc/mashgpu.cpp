@@ -198,6 +198,7 @@ void mg_ctx_destroy(mg_ctx *ctx)
     if (!ctx) return;
     { std::lock_guard<std::mutex> lk(g_live_mu); g_live_ctx.erase(std::remove(g_live_ctx.begin(), g_live_ctx.end(), (const void *)ctx), g_live_ctx.end()); }
     mg_prof_reset(ctx);
+    for (auto &c : ctx->cost_clk) { if (c.a) hipEventDestroy(c.a); if (c.b) hipEventDestroy(c.b); }
     for (auto &sl : ctx->slots) {
         if (sl.dev) hipFree(sl.dev);
         if (sl.host) hipHostFree(sl.host);

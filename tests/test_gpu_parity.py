@@ -1342,6 +1342,44 @@ def test_row_ranges_keep_the_clustered_index_and_its_dense_groups(eng, oracle, m
     t.free()
 
 
+def test_dispatch_costs_are_learned_per_context(eng, monkeypatch, capfd):
+    """the cost table of the compare dispatch (SparseCosts) is a per-context copy of the defaults that
+    moves half way towards what the context's own launches measure -- the phases of every job seen for the first time are
+    timed -- and never further than a factor of four from the defaults.  Shown on two tables (an index job, a join job): the
+    context reports its prices after each, they lie inside the clamp, MASHGPU_COSTS_FIXED keeps the defaults, and the results
+    do not depend on any of it."""
+    import re
+    defaults = {"fill": 4.5e12, "discover": 2.0e-12, "merge": 1.0e-9, "dense": 3.0e-11, "join": 2.2e-13}
+    table, nhash, lengths = synth.clustered_sketches(4000, 300, clusters=40, seed=61, pool=450, private=120)
+    sp, spn, spl = synth.species_sketches(3000, 256, seed=13)
+    monkeypatch.setenv("MASHGPU_SPARSE_DBG", "1")
+    outs = {}
+    for fixed in (False, True):
+        if fixed:
+            monkeypatch.setenv("MASHGPU_COSTS_FIXED", "1")
+        t1 = eng.table_upload(table, nhash, lengths)
+        t2 = eng.table_upload(sp, spn, spl)
+        capfd.readouterr()
+        a = eng.compare_tri_host(t1)
+        b = eng.compare_tri_host(t2)
+        err = capfd.readouterr().err
+        lines = [l for l in err.splitlines() if l.startswith("compare costs (context")]
+        if fixed:
+            assert not lines
+        else:
+            assert len(lines) >= 2, err[-1500:]
+            m = re.search(r"fill ([0-9.e+-]+) B/s, discover ([0-9.e+-]+) s per shared hash \+ ([0-9.e+-]+) per entry, merge ([0-9.e+-]+) per candidate, "
+                          r"dense ([0-9.e+-]+) per pair, join ([0-9.e+-]+) per shared hash", lines[-1])
+            assert m, lines[-1]
+            got = dict(zip(("fill", "discover", "entry", "merge", "dense", "join"), map(float, m.groups())))
+            for k, d in defaults.items():
+                assert d / 4.0001 <= got[k] <= d * 4.0001, (k, got[k], d)
+        outs[fixed] = (a.tobytes(), b.tobytes())
+        t1.free()
+        t2.free()
+    assert outs[False] == outs[True]
+
+
 def test_dense_groups_survive_leader_lists_that_overflow(eng, oracle, monkeypatch, capfd):
     """The build by tiles appends the dense groups' leaders to a thousand lists of fixed room, by bucket; a list that overflows
     used to cost the table its dense groups.  With the room forced to 8 entries (MASHGPU_DENSE_LEAD_CAP) the

@@ -13,6 +13,7 @@ run() {
 run stats --kernel-trace --stats
 find $OUT/${TAG:-r06}_sq_${LEG}_stats -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG:-r06}_sq_kernel_stats_${LEG}.csv \;
 rm -rf $OUT/${TAG:-r06}_sq_${LEG}_stats/*/*.db 2>/dev/null
+find $OUT/${TAG:-r06}_sq_${LEG}_stats -name "*kernel_trace.csv" -delete 2>/dev/null
 run sqa --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
 run sqb --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE
 run sqc --pmc SQ_WAVES SQ_INSTS_SMEM SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE

@@ -31,6 +31,8 @@ for tag in $LEGS; do
     fi
     rm -rf $OUT/${TAG}_${tag}_stats/*/*.db 2>/dev/null
 done
+# (gpurun brings back 64 MiB at most: the kernel traces -- a row per launch -- stay on the box, the per-kernel statistics travel)
+find $OUT -name "*kernel_trace.csv" -path "*${TAG}_*" -delete 2>/dev/null
 [ "${STATS_ONLY:-0}" = 1 ] && exit 0
 cd $ROOT
 SRC="mash_amd/csrc/compare_sparse.hip mash_amd/csrc/compare_dense.hip mash_amd/csrc/compare_merged.hip mash_amd/csrc/compare_internal.h mash_amd/csrc/index_build.hip mash_amd/csrc/compare_join.hip"

@@ -17,3 +17,7 @@ timeout 400 python tools/compare_fuzz.py --seed 606 --seconds 150 --n 100000 > g
 for w in c3 one_species; do timeout 300 python tools/ranks_on_one_gpu.py $w 8 > gpurun_out/${TAG}_ranks_$w.txt 2>/dev/null; grep '"cut"' gpurun_out/${TAG}_ranks_$w.txt; done
 timeout 1500 python bench.py --detail gpurun_out/${TAG}_bench_detail.json > gpurun_out/${TAG}_bench_line.json 2> gpurun_out/${TAG}_bench_stderr.log
 echo "bench rc=$?"; tail -1 gpurun_out/${TAG}_bench_line.json | cut -c1-3500
+# what travels back: summaries only (64 MiB at most)
+find gpurun_out -name "*kernel_trace.csv" -delete 2>/dev/null
+for d in gpurun_out/${TAG}_*_fetch gpurun_out/${TAG}_*_write gpurun_out/${TAG}_*_sqa gpurun_out/${TAG}_*_sqb gpurun_out/${TAG}_*_sqc; do [ -d "$d" ] && rm -rf "$d"; done
+du -sh gpurun_out | cut -f1
