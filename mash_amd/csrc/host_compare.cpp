@@ -1184,7 +1184,10 @@ void SparseJobRun::learn()
         const double v = 0.5 * c + 0.5 * measured;
         c = std::min(std::max(v, def / 4.0), def * 4.0);
     };
-    const double floor_s = 1.0e-4;                          // (below 0.1 ms a phase is its launch)
+    // (a phase below a millisecond is its launch, its first wave's round trips and a tail: on a table of a few thousand rows
+    //  every price came out three to four times too high, and the list engine lost a job it does in half the time --
+    //  test_survivor_lists_from_candidates_equal_the_matrix_path; the phases that decide anything are the long ones)
+    const double floor_s = 1.0e-3;
     double t;
     if ((t = secs(CK_FILL)) > floor_s) { double bps = K.fill_bytes_s; move(bps, (double)pairs * 8.0 / t, D.fill_bytes_s); K.fill_bytes_s = bps; }
     if ((t = secs(CK_DISCOVER)) > floor_s) {

@@ -1345,39 +1345,48 @@ def test_row_ranges_keep_the_clustered_index_and_its_dense_groups(eng, oracle, m
 def test_dispatch_costs_are_learned_per_context(eng, monkeypatch, capfd):
     """the cost table of the compare dispatch (SparseCosts) is a per-context copy of the defaults that
     moves half way towards what the context's own launches measure -- the phases of every job seen for the first time are
-    timed -- and never further than a factor of four from the defaults.  Shown on two tables (an index job, a join job): the
-    context reports its prices after each, they lie inside the clamp, MASHGPU_COSTS_FIXED keeps the defaults, and the results
-    do not depend on any of it."""
+    timed, those of a millisecond and more count -- and never further than a factor of four from the defaults.  Shown on a job
+    whose fill runs for milliseconds (6.5e8 pairs): the context reports a fill rate that is no longer the default's and lies
+    inside the clamp; a small job teaches nothing (its phases are their launches); MASHGPU_COSTS_FIXED keeps the defaults;
+    the results do not depend on any of it."""
     import re
-    defaults = {"fill": 4.5e12, "discover": 2.0e-12, "merge": 1.0e-9, "dense": 3.0e-11, "join": 2.2e-13}
-    table, nhash, lengths = synth.clustered_sketches(4000, 300, clusters=40, seed=61, pool=450, private=120)
-    sp, spn, spl = synth.species_sketches(3000, 256, seed=13)
-    monkeypatch.setenv("MASHGPU_SPARSE_DBG", "1")
-    outs = {}
-    for fixed in (False, True):
-        if fixed:
-            monkeypatch.setenv("MASHGPU_COSTS_FIXED", "1")
-        t1 = eng.table_upload(table, nhash, lengths)
-        t2 = eng.table_upload(sp, spn, spl)
-        capfd.readouterr()
-        a = eng.compare_tri_host(t1)
-        b = eng.compare_tri_host(t2)
-        err = capfd.readouterr().err
+    import torch
+    from workloads import synth_torch
+    dev = torch.device("cuda", 0)
+    default_fill = 4.5e12
+
+    def fill_rate(err):
         lines = [l for l in err.splitlines() if l.startswith("compare costs (context")]
-        if fixed:
-            assert not lines
-        else:
-            assert len(lines) >= 2, err[-1500:]
-            m = re.search(r"fill ([0-9.e+-]+) B/s, discover ([0-9.e+-]+) s per shared hash \+ ([0-9.e+-]+) per entry, merge ([0-9.e+-]+) per candidate, "
-                          r"dense ([0-9.e+-]+) per pair, join ([0-9.e+-]+) per shared hash", lines[-1])
-            assert m, lines[-1]
-            got = dict(zip(("fill", "discover", "entry", "merge", "dense", "join"), map(float, m.groups())))
-            for k, d in defaults.items():
-                assert d / 4.0001 <= got[k] <= d * 4.0001, (k, got[k], d)
-        outs[fixed] = (a.tobytes(), b.tobytes())
-        t1.free()
-        t2.free()
-    assert outs[False] == outs[True]
+        return [float(re.search(r"fill ([0-9.e+-]+) B/s", l).group(1)) for l in lines]
+
+    n, s = 36000, 32
+    h, nh, ln = synth_torch.random_sketch_table(n, s, device=dev)
+    out = torch.empty((n * (n - 1) // 2, 2), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    t = eng.table_wrap(h.data_ptr(), nh.data_ptr(), ln.data_ptr(), n, s, keep=(h, nh, ln))
+    small, snh, sln = synth.clustered_sketches(4000, 300, clusters=40, seed=61, pool=450, private=120)
+    ts = eng.table_upload(small, snh, sln)
+    monkeypatch.setenv("MASHGPU_SPARSE_DBG", "1")
+    capfd.readouterr()
+    a = eng.compare_tri_host(ts)                           # phases of microseconds: nothing learned
+    rates = fill_rate(capfd.readouterr().err)
+    assert rates and all(r == default_fill for r in rates), rates
+    eng.compare_tri_dev(t, 0, n, out.data_ptr())           # a fill of milliseconds
+    torch.cuda.synchronize()
+    rates = fill_rate(capfd.readouterr().err)
+    assert rates and rates[-1] != default_fill and default_fill / 4.0001 <= rates[-1] <= default_fill * 4.0001, rates
+    sums = [int(out[:, 0].sum(dtype=torch.int64).item()), int(out[:, 1].sum(dtype=torch.int64).item())]
+    monkeypatch.setenv("MASHGPU_COSTS_FIXED", "1")
+    t.invalidate()
+    ts.invalidate()
+    capfd.readouterr()
+    eng.compare_tri_dev(t, 0, n, out.data_ptr())
+    torch.cuda.synchronize()
+    b = eng.compare_tri_host(ts)
+    assert not fill_rate(capfd.readouterr().err)
+    assert sums == [int(out[:, 0].sum(dtype=torch.int64).item()), int(out[:, 1].sum(dtype=torch.int64).item())] and a.tobytes() == b.tobytes()
+    t.free()
+    ts.free()
 
 
 def test_dense_groups_survive_leader_lists_that_overflow(eng, oracle, monkeypatch, capfd):
