@@ -555,7 +555,11 @@ struct SparseJobRun {
     enum { CK_FILL, CK_DISCOVER, CK_MERGE, CK_DENSE, CK_JOIN, CK_N };
     bool clk_used[CK_N] = {false, false, false, false, false};
     double join_steps = 0.0;
-    bool learning() const { return first && !ctx->async && !ctx_opt(ctx, "MASHGPU_COSTS_FIXED"); }
+    // MASHGPU_COSTS_FIXED=1: the defaults decide and nothing is learned (the test suite: one context serves hundreds of tests, and
+    // which engine takes a job of borderline size must not depend on what ran before)
+    bool costs_fixed() const { const char *e = ctx_opt(ctx, "MASHGPU_COSTS_FIXED"); return e && atoi(e) != 0; }
+    const SparseCosts &costs() const { static const SparseCosts defaults; return costs_fixed() ? defaults : ctx->costs; }
+    bool learning() const { return first && !ctx->async && !costs_fixed(); }
     void clk_begin(int k);
     void clk_end(int k);
     void learn();
@@ -849,7 +853,7 @@ int SparseJobRun::choose_engine()
         fresh.shared = h[1];
         // seconds, one MI355X (measured: profiles/r03_sparse_phases.txt)
         const double np = (double)pairs;
-        const SparseCosts &K = ctx->costs;
+        const SparseCosts &K = costs();
         const double t_sparse = np * 8.0 / K.fill_bytes_s + (double)fresh.shared * K.discover_per_shared + (double)nrows * s * K.discover_per_entry +
                                 (double)fresh.cand * K.merge_per_candidate + K.launches + (triangle ? (double)ix->cls_pairs * 8.0 / K.class_bytes_s : 0.0) +
                                 (double)fresh.dense_pairs * K.dense_per_pair;
@@ -942,7 +946,7 @@ int SparseJobRun::join()
     if (!can) return force_join ? fail(ctx, MG_ERR_UNSUPPORTED, "compare: the join engine cannot take this job") : MG_OK;
     bool take = force_join || (plan && !first && plan->join);
     if (!take && first && !force) {
-        const SparseCosts &K = ctx->costs;
+        const SparseCosts &K = costs();
         const double table_pairs = triangle ? (double)cols->n * (double)(cols->n - 1) / 2.0 : (double)pairs;
         // (the index's own statistic -- every value's holders choose 2, before any clipping -- rules most tables out for free;
         //  rect: the queries are not part of it, the count below decides)

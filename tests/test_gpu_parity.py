@@ -26,6 +26,10 @@ def eng():
     import torch
     torch.cuda.init()
     e = abi.MashGpu(0)
+    # the dispatch's prices stay at their defaults: this one context serves every test of the module, and which engine takes a
+    # job of borderline size must not depend on the tests that ran before (test_dispatch_costs_are_learned_per_context
+    # switches the learning on for itself)
+    e.set_option("MASHGPU_COSTS_FIXED", "1")
     yield e
     e.close()
 
@@ -1367,6 +1371,7 @@ def test_dispatch_costs_are_learned_per_context(eng, monkeypatch, capfd):
     small, snh, sln = synth.clustered_sketches(4000, 300, clusters=40, seed=61, pool=450, private=120)
     ts = eng.table_upload(small, snh, sln)
     monkeypatch.setenv("MASHGPU_SPARSE_DBG", "1")
+    eng.set_option("MASHGPU_COSTS_FIXED", "0")             # (the module's context keeps the defaults otherwise)
     capfd.readouterr()
     a = eng.compare_tri_host(ts)                           # phases of microseconds: nothing learned
     rates = fill_rate(capfd.readouterr().err)
@@ -1376,7 +1381,7 @@ def test_dispatch_costs_are_learned_per_context(eng, monkeypatch, capfd):
     rates = fill_rate(capfd.readouterr().err)
     assert rates and rates[-1] != default_fill and default_fill / 4.0001 <= rates[-1] <= default_fill * 4.0001, rates
     sums = [int(out[:, 0].sum(dtype=torch.int64).item()), int(out[:, 1].sum(dtype=torch.int64).item())]
-    monkeypatch.setenv("MASHGPU_COSTS_FIXED", "1")
+    eng.set_option("MASHGPU_COSTS_FIXED", "1")
     t.invalidate()
     ts.invalidate()
     capfd.readouterr()
