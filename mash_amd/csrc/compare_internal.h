@@ -257,6 +257,7 @@ struct JoinArgs {
     uint32_t bi0;                      // first block of rows of the job
     uint32_t ncb;                      // rect: blocks of columns
     uint32_t triangle, s;
+    uint32_t tiles_per_wg = 1;         // 1 or 4 waves per workgroup (a wave takes a tile)
 };
 size_t join_order_temp_bytes(uint32_t nrows);
 hipError_t join_order_rows(const uint32_t *img, uint32_t rs, const uint32_t *cnt_off, const uint32_t *rep, const uint32_t *inv, const uint32_t *gend,

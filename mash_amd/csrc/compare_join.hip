@@ -443,9 +443,13 @@ __device__ __forceinline__ void jn_tile(const JoinArgs &a, JN_LDS uint16_t *cnt,
     if (!done) process(prev);
 }
 
-__global__ __launch_bounds__(256) void jn_tile_kernel(JoinArgs a)
+// TPW tiles (waves) per workgroup.  Nothing is shared between the waves of a workgroup but its life: with four tiles a
+// workgroup's wave slots and LDS stay taken until its slowest tile is done -- tiles differ in what they hold -- and a CU
+// averaged 12 of its 16 waves; with one tile per workgroup every slot is refilled by itself.
+template <uint32_t TPW>
+__global__ __launch_bounds__(64 * TPW) void jn_tile_kernel(JoinArgs a)
 {
-    __shared__ uint32_t s_cnt[4][JN_B * JN_STRIDE / 2u];
+    __shared__ uint32_t s_cnt[TPW][JN_B * JN_STRIDE / 2u];
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     // workgroups are dealt round-robin to the eight XCDs: XCD x takes the x-th contiguous eighth of the tile sequence, so
     // the tiles that share a block's list run in one L2
@@ -454,7 +458,7 @@ __global__ __launch_bounds__(256) void jn_tile_kernel(JoinArgs a)
         const uint32_t nwg = gridDim.x, q = nwg >> 3, r = nwg & 7u, x = blockIdx.x & 7u, k = blockIdx.x >> 3;
         wg = (uint64_t)x * q + (x < r ? x : r) + k;
     }
-    const uint64_t tile = wg * 4u + w;
+    const uint64_t tile = wg * TPW + w;
     if (tile >= a.ntiles) return;                           // (the whole wave; no workgroup barrier below)
     uint32_t bi, bj;
     if (a.triangle) {
@@ -511,9 +515,11 @@ __global__ __launch_bounds__(256) void jn_tile_kernel(JoinArgs a)
 hipError_t launch_join_tiles(const JoinArgs &a, hipStream_t stream)
 {
     if (a.ntiles == 0) return hipSuccess;
-    const uint64_t nwg = (a.ntiles + 3u) / 4u;
+    const uint32_t tpw = a.tiles_per_wg == 4u ? 4u : 1u;
+    const uint64_t nwg = (a.ntiles + tpw - 1u) / tpw;
     if (nwg > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(jn_tile_kernel, dim3((uint32_t)nwg), dim3(256), 0, stream, a);
+    if (tpw == 4u) hipLaunchKernelGGL(jn_tile_kernel<4>, dim3((uint32_t)nwg), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(jn_tile_kernel<1>, dim3((uint32_t)nwg), dim3(64), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -1054,6 +1054,7 @@ int SparseJobRun::join()
     j.ncb = (uint32_t)((cols->n + B - 1) / B);
     j.triangle = triangle ? 1u : 0u;
     j.s = s;
+    if (const char *e = ctx_opt(ctx, "MASHGPU_JOIN_TILES_PER_WG")) j.tiles_per_wg = atoi(e) == 4 ? 4u : 1u;      // (A/B)
     j.ntiles = triangle ? bi1 * (bi1 + 1) / 2 - (uint64_t)j.bi0 * (j.bi0 + 1) / 2 : (bi1 - j.bi0) * (uint64_t)j.ncb;
     prof_begin(ctx, ctx->prof_join);
     clk_begin(CK_JOIN);
