@@ -1031,7 +1031,7 @@ def main():
             counts, mix = scr_step()
             barrier()
             t0 = time.perf_counter()
-            scr_steps = max(2, args.steps)
+            scr_steps = max(5, args.steps)                      # (12 ms each: one stalled step of two halved the rate once)
             for _ in range(scr_steps):
                 counts, mix = scr_step()
             barrier()
