@@ -318,8 +318,9 @@ def headline_of(result):
     h["config"] = {"workload": cfg.get("workload"), "parallelism": cfg.get("parallelism"), "output_checksum": cfg.get("output_checksum"),
                    "first_call_ms": cfg.get("first_call_ms"), "rccl_ranks": cfg.get("rccl_ranks"),
                    "table_broadcast_ms": cfg.get("table_broadcast_ms")}
-    if cfg.get("index_ms_by_rank"):
-        h["config"]["index_ms_by_rank"] = cfg["index_ms_by_rank"]
+    if (result.get("n_gpus") or 1) > 1:                     # several ranks: who talked to whom, who got which rows, what each index cost
+        for k in ("comm", "rank_row_blocks", "row_weight_pairs", "prefix_weight_pairs", "index_ms_by_rank"):
+            h["config"][k] = cfg.get(k)
     h["warm_value"], h["warm_ms_per_step"] = _num(result.get("warm_value"), 6), _num(result.get("warm_ms_per_step"), 5)
     if result.get("dry"):
         h["dry"] = True

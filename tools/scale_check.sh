@@ -1,6 +1,7 @@
 #!/bin/bash
 # tools/scale_check.sh -- everything there is to run the minute a box with several MI355X shows up
-# (no such box was available to rounds 1-3, so NO multi-GPU number in this repository is measured).
+# (no such box was available to rounds 1-6, so NO multi-GPU number in this repository is measured; what each rank
+#  would pay for its block is measured on ONE GPU by tools/ranks_on_one_gpu.py).
 #
 #   bash tools/scale_check.sh [BENCH_JSON]      (from the repository root, extension built: python -c 'import __graft_entry__ as g; g.build()')
 #
@@ -95,7 +96,8 @@ for l in lines:
     line_ok &= c.get("output_checksum") == base["config"].get("output_checksum")
     ok &= line_ok
     print(f"N={l['n_gpus']}: {l['value']:.4g} {l['unit']}  x{l['value'] / base['value']:.2f} over N=1  ms/step {l['ms_per_step']:.2f}  "
-          f"broadcast {c.get('table_broadcast_ms')} ms  ranks {c.get('rccl_ranks')} ({c.get('comm')})  checksum {c.get('output_checksum')}  "
+          f"broadcast {c.get('table_broadcast_ms')} ms  ranks {c.get('rccl_ranks')} ({c.get('comm')})  blocks {c.get('rank_row_blocks')}  "
+          f"index ms by rank {c.get('index_ms_by_rank')}  checksum {c.get('output_checksum')}  "
           f"{'ok' if line_ok else 'FAILED'}")
 sys.exit(0 if ok else 1)
 EOF
