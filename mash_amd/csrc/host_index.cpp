@@ -35,6 +35,8 @@ namespace {
 // one-clade bracket (32 768 rows: 15.2 against 14.7 ms per table; clades of a thousand rows are the tiles': 16.9 against
 // 19.1 on the 100 x 1 000 bracket).  The clustered order tells: rows of one label stand next to each other.
 const uint64_t kTilesLongestRun = 6144;
+static const uint64_t kSplitMinRun = 128;       // rows of the longest family in a segment from which a range job's index is reordered
+
 uint64_t longest_label_run(const uint32_t *lab_sorted, uint64_t n)
 {
     if (!lab_sorted || n == 0) return 0;
@@ -303,10 +305,20 @@ int SparseIndexBuild::order_rows()
     // ---- the clustered variant: the table copied in the clustered order; everything below then works on the copy as if
     // it were the table
     H = t->hashes;
+    // A job over a RANGE of rows (split != 0) pays for the permuted copy and the clustering's order only where the collection
+    // has large families: the split order keeps the pairs INSIDE each segment of a family dense, the pairs across the cut are
+    // merged one by one either way.  With families of a hundred rows (C3) that is 1.9 against 2.6 ms of merges per pass for
+    // 1.4 ms more per table (tools/range_check.py); with a clade of thousands it is the difference between a dense kernel and
+    // a merge for every pair.  Below kSplitMinRun rows in the longest family of a segment the table keeps its own order.
+    bool keep_table_order = false;
+    if (cluster_q && split != 0 && lab_sorted && !ctx_opt(ctx, "MASHGPU_SPLIT_ALWAYS") && longest_label_run(lab_sorted, n) < kSplitMinRun) {
+        keep_table_order = true;
+        lab_sorted = nullptr;
+    }
     if (cluster_q) {
         bool identity = true;
         for (uint64_t a = 0; a < n && identity; a++) identity = inv[a] == a;
-        if (!identity) {
+        if (!identity && !keep_table_order) {
             // (Measured and dropped: this copy queued BEFORE the read-backs above.  They are copies into pageable memory and
             //  wait for whatever the stream holds in front of them -- the copy kernel included; the build started 0.4 ms later.)
             void *pi = nullptr, *ph = nullptr;

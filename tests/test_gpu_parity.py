@@ -1319,12 +1319,15 @@ def test_row_ranges_keep_the_clustered_index_and_its_dense_groups(eng, oracle, m
     index rows, the rows of a cluster are neighbours inside each segment, and the dense pairs kernel runs.  Same bytes as the
     slices of the whole triangle; rows against the oracle."""
     n, s = 6000, 256
-    table, nhash, lengths = synth.clustered_sketches(n, s, clusters=30, seed=51, pool=280, private=12, keep_p=0.95)
+    table, nhash, lengths = synth.clustered_sketches(n, s, clusters=10, seed=51, pool=280, private=12, keep_p=0.95)      # families of 600 rows
     nhash = nhash.copy()
     nhash[4100] = 0
     nhash[2222] = 100
     t = eng.table_upload(table, nhash, lengths)
     whole = eng.compare_tri_host(t)
+    # (the pairs ACROSS the cut share hundreds of hashes each: left to itself the dispatch hands such a range to the join
+    #  engine -- the same bytes, asserted at the end; this test is about the index engine's groups)
+    monkeypatch.setenv("MASHGPU_COMPARE_JOIN", "0")
     eng.prof_enable(True)
     for rb, re in ((3000, 6000), (2000, 4500), (4242, 6000)):
         t.invalidate()
@@ -1338,12 +1341,28 @@ def test_row_ranges_keep_the_clustered_index_and_its_dense_groups(eng, oracle, m
         numer, denom = _oracle_tri(oracle, table, nhash, lengths, i, i + 1)
         lo = i * (i - 1) // 2
         assert np.array_equal(whole["numer"][lo:lo + i], numer) and np.array_equal(whole["denom"][lo:lo + i], denom), i
+    monkeypatch.delenv("MASHGPU_COMPARE_JOIN")
+    t.invalidate()
+    assert eng.compare_tri_host(t, 3000, 6000).tobytes() == whole[3000 * 2999 // 2:].tobytes()       # (whatever engine the dispatch picks)
     # the same ranges with the clustering switched off: the same bytes (the plain index)
     monkeypatch.setenv("MASHGPU_COMPARE_CLUSTER", "0")
     t.invalidate()
     got = eng.compare_tri_host(t, 3000, 6000)
     assert got.tobytes() == whole[3000 * 2999 // 2:].tobytes()
+    monkeypatch.delenv("MASHGPU_COMPARE_CLUSTER")
     t.free()
+    # families of a hundred rows: a range job keeps the table's own order (the split order would cost more than it saves) --
+    # and gives the same bytes when it is forced
+    small, snh, sln = synth.clustered_sketches(5000, 256, clusters=50, seed=52, pool=280, private=12, keep_p=0.95)
+    ts = eng.table_upload(small, snh, sln)
+    a = eng.compare_tri_host(ts, 2000, 5000)
+    monkeypatch.setenv("MASHGPU_SPLIT_ALWAYS", "1")
+    ts.invalidate()
+    b = eng.compare_tri_host(ts, 2000, 5000)
+    assert a.tobytes() == b.tobytes()
+    numer, denom = _oracle_tri(oracle, small, snh, sln, 4999, 5000)
+    assert np.array_equal(a["numer"][-4999:], numer) and np.array_equal(a["denom"][-4999:], denom)
+    ts.free()
 
 
 def test_dispatch_costs_are_learned_per_context(eng, monkeypatch, capfd):
