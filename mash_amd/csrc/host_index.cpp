@@ -309,9 +309,11 @@ int SparseIndexBuild::order_rows()
     // has large families: the split order keeps the pairs INSIDE each segment of a family dense, the pairs across the cut are
     // merged one by one either way.  With families of a hundred rows (C3) that is 1.9 against 2.6 ms of merges per pass for
     // 1.4 ms more per table (tools/range_check.py); with a clade of thousands it is the difference between a dense kernel and
-    // a merge for every pair.  Below kSplitMinRun rows in the longest family of a segment the table keeps its own order.
+    // a merge for every pair.  Below kSplitMinRun rows (at s = 1000) in the longest family of a segment the table keeps its own order.
     bool keep_table_order = false;
-    if (cluster_q && split != 0 && lab_sorted && !ctx_opt(ctx, "MASHGPU_SPLIT_ALWAYS") && longest_label_run(lab_sorted, n) < kSplitMinRun) {
+    // (a merge costs what the sketches are long: the rule is on rows x sketch size, 128 rows at s = 1000 -- C5's families of
+    //  50 + 50 rows at s = 10 000 take the split order: 7 x against 10 x their share of a whole pass)
+    if (cluster_q && split != 0 && lab_sorted && !ctx_opt(ctx, "MASHGPU_SPLIT_ALWAYS") && longest_label_run(lab_sorted, n) * (uint64_t)s < kSplitMinRun * 1000ull) {
         keep_table_order = true;
         lab_sorted = nullptr;
     }

@@ -1319,7 +1319,7 @@ def test_row_ranges_keep_the_clustered_index_and_its_dense_groups(eng, oracle, m
     index rows, the rows of a cluster are neighbours inside each segment, and the dense pairs kernel runs.  Same bytes as the
     slices of the whole triangle; rows against the oracle."""
     n, s = 6000, 256
-    table, nhash, lengths = synth.clustered_sketches(n, s, clusters=10, seed=51, pool=280, private=12, keep_p=0.95)      # families of 600 rows
+    table, nhash, lengths = synth.clustered_sketches(n, s, clusters=5, seed=51, pool=280, private=12, keep_p=0.95)       # families of 1 200 rows
     nhash = nhash.copy()
     nhash[4100] = 0
     nhash[2222] = 100
