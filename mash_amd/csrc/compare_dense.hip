@@ -483,6 +483,18 @@ __device__ __forceinline__ uint64_t dn_out_index(uint32_t a, uint32_t b, const u
 }
 
 
+// popcount(x) + acc as ONE instruction (the compiler adds three terms with v_add3 behind two counts into zero)
+__device__ __forceinline__ uint32_t dn_count_add(uint32_t x, uint32_t acc)
+{
+#ifdef MG_HIP_EMU
+    return (uint32_t)__popc(x) + acc;
+#else
+    uint32_t d;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(acc));
+    return d;
+#endif
+}
+
 // The word in which the union reaches its s-th element: the smallest bit position t with f(t) >= s, where f(t) = what lies
 // before the word (fprev) + union bits below t + extras of either row with offset <= t; the bits below t are the ones counted.
 // The extras of the word as four bit planes per row (bit o of plane j: bit j of the number of extras at offset o), or -- a gap
@@ -493,34 +505,51 @@ __device__ __forceinline__ uint32_t dn_resolve(unsigned long long un, uint32_t f
                                                const unsigned long long *xma, const unsigned long long *xmb, const uint16_t *xa,
                                                const uint16_t *xb, uint32_t ca0, uint32_t na, uint32_t cb0, uint32_t nb)
 {
-    uint32_t lo = 0, hi = 63;
     if (__ballot(lists) == 0) {                              // uniform
         const unsigned long long a0 = xma[4u * w], a1 = xma[4u * w + 1u], a2 = xma[4u * w + 2u], a3 = xma[4u * w + 3u];
         const unsigned long long b0 = xmb[4u * w], b1 = xmb[4u * w + 1u], b2 = xmb[4u * w + 2u], b3 = xmb[4u * w + 3u];
-        // (lo = 0, hi = 63: six halvings.  Near-copies have a few dozen extras over a thousand gaps -- with no gap of the
-        //  whole wave holding two, a step is three counts instead of nine)
-        if (__ballot((a1 | a2 | a3 | b1 | b2 | b3) != 0ull) == 0) {      // uniform
+        // (near-copies have a few dozen extras over a thousand gaps: with no gap of the whole wave holding two, a count is
+        //  three population counts instead of nine)
+        const bool planes = __ballot((a1 | a2 | a3 | b1 | b2 | b3) != 0ull) != 0;      // uniform
+        // Which half of the word: f(31) = fprev + the union's bits 0 .. 30 + the extras at offsets 0 .. 31; from there on every
+        // count is over 32-bit halves (a 64-bit mask and count is two shifts with carries and two counts per operand).
+        const uint32_t ulo = (uint32_t)un, uhi = (uint32_t)(un >> 32);
+        uint32_t c31 = dn_count_add((uint32_t)b0, dn_count_add((uint32_t)a0, dn_count_add(ulo & 0x7FFFFFFFu, fprev)));
+        if (planes)
+            c31 += 2u * (uint32_t)(__popc((uint32_t)a1) + __popc((uint32_t)b1)) + 4u * (uint32_t)(__popc((uint32_t)a2) + __popc((uint32_t)b2)) +
+                   8u * (uint32_t)(__popc((uint32_t)a3) + __popc((uint32_t)b3));
+        const bool upper = c31 < s;                          // s is reached at offset 32 or above: the lower half lies before
+        const uint32_t base = upper ? c31 + (ulo >> 31) : fprev;
+        const uint32_t u = upper ? uhi : ulo;
+        const uint32_t A0 = upper ? (uint32_t)(a0 >> 32) : (uint32_t)a0, B0 = upper ? (uint32_t)(b0 >> 32) : (uint32_t)b0;
+        // pos = the number of offsets x in 0 .. 30 of the half with f(x) < s, bit by bit from the top (f never falls): the
+        // smallest offset at which s is reached, or 31
+        uint32_t pos = 0;
+        if (!planes) {
 #pragma unroll
-            for (uint32_t step = 0; step < 6u; step++) {
-                const uint32_t mid = (lo + hi) >> 1;
-                const unsigned long long below = (1ull << mid) - 1ull, upto = (2ull << mid) - 1ull;
-                const uint32_t c = fprev + (uint32_t)__popcll(un & below) + (uint32_t)__popcll(a0 & upto) + (uint32_t)__popcll(b0 & upto);
-                if (c >= s) hi = mid; else lo = mid + 1u;
+            for (uint32_t bit = 16u; bit != 0u; bit >>= 1) {
+                const uint32_t x = pos + bit - 1u;                            // <= 30
+                const uint32_t below = (1u << x) - 1u, upto = (below << 1) | 1u;
+                const uint32_t c = dn_count_add(B0 & upto, dn_count_add(A0 & upto, dn_count_add(u & below, base)));
+                pos += c < s ? bit : 0u;
             }
-            return lo;
-        }
+        } else {
+            const uint32_t A1 = upper ? (uint32_t)(a1 >> 32) : (uint32_t)a1, B1 = upper ? (uint32_t)(b1 >> 32) : (uint32_t)b1;
+            const uint32_t A2 = upper ? (uint32_t)(a2 >> 32) : (uint32_t)a2, B2 = upper ? (uint32_t)(b2 >> 32) : (uint32_t)b2;
+            const uint32_t A3 = upper ? (uint32_t)(a3 >> 32) : (uint32_t)a3, B3 = upper ? (uint32_t)(b3 >> 32) : (uint32_t)b3;
 #pragma unroll
-        for (uint32_t step = 0; step < 6u; step++) {
-            const uint32_t mid = (lo + hi) >> 1;                          // <= 62
-            const unsigned long long below = (1ull << mid) - 1ull, upto = (2ull << mid) - 1ull;
-            const uint32_t c = fprev + (uint32_t)__popcll(un & below) + (uint32_t)__popcll(a0 & upto) + (uint32_t)__popcll(b0 & upto) +
-                               2u * ((uint32_t)__popcll(a1 & upto) + (uint32_t)__popcll(b1 & upto)) +
-                               4u * ((uint32_t)__popcll(a2 & upto) + (uint32_t)__popcll(b2 & upto)) +
-                               8u * ((uint32_t)__popcll(a3 & upto) + (uint32_t)__popcll(b3 & upto));
-            if (c >= s) hi = mid; else lo = mid + 1u;
+            for (uint32_t bit = 16u; bit != 0u; bit >>= 1) {
+                const uint32_t x = pos + bit - 1u;
+                const uint32_t below = (1u << x) - 1u, upto = (below << 1) | 1u;
+                const uint32_t c = dn_count_add(B0 & upto, dn_count_add(A0 & upto, dn_count_add(u & below, base))) +
+                                   2u * (uint32_t)(__popc(B1 & upto) + __popc(A1 & upto)) + 4u * (uint32_t)(__popc(B2 & upto) + __popc(A2 & upto)) +
+                                   8u * (uint32_t)(__popc(B3 & upto) + __popc(A3 & upto));
+                pos += c < s ? bit : 0u;
+            }
         }
-        return lo;
+        return (upper ? 32u : 0u) + pos;
     }
+    uint32_t lo = 0, hi = 63;
     // (some lane's word is flagged: every lane takes its rows' lists, which are exact for all)
     const uint32_t wbase = w << 6;
     while (lo < hi) {
@@ -564,7 +593,24 @@ __global__ __launch_bounds__(128) void dn_pairs_kernel(const DenseTile *tiles, c
         for (uint32_t i = tid; i < 2u * (W + 1u) * DN_ROWS; i += 128u) Acx[i] = acs[(i / DN_ROWS) * 128u + la0 + (i % DN_ROWS)];
     }
     __syncthreads();
+    // the largest total of every batch of DN_IL rows before every word boundary: while that and the column's total stay
+    // within s, no pair of the batch has reached its s-th union element whatever its rows have in common
+    constexpr uint32_t DN_NB = DN_ROWS / DN_IL;
+    uint16_t *Amax = Atot + (W + 1u) * DN_ROWS;                                           // [DN_NB][W + 1]
+    for (uint32_t i = tid; i < DN_NB * (W + 1u); i += 128u) {
+        const uint32_t bt = i / (W + 1u), w = i - bt * (W + 1u);
+        uint32_t m = 0;
+        for (uint32_t k = 0; k < DN_IL; k++)
+            if (T.row0 + bt * DN_IL + k < G.g1) {                          // (rows behind the group's end are not written)
+                const uint32_t v = Atot[w * DN_ROWS + bt * DN_IL + k];
+                m = v > m ? v : m;
+            }
+        Amax[i] = (uint16_t)m;
+    }
+    __syncthreads();
     const uint32_t b = G.g0 + T.cblk * 128u + tid;                         // this lane's column
+    // (a lane behind the group's end works on the group's last row: what it reads is written, what it computes is not stored)
+    const uint32_t lb = b < G.g1 ? tid : G.g1 - 1u - (G.g0 + T.cblk * 128u);
     const uint16_t *xb = ext + (uint64_t)(G.xrow0 + (b < G.g1 ? b - G.g0 : 0u)) * xs;
     const unsigned long long *xmb = xm + (uint64_t)(G.xrow0 + (b < G.g1 ? b - G.g0 : 0u)) * wstride * 4ull;
     // DN_IL rows at a time: the column block's word is loaded once and serves all of them (their words are broadcast reads
@@ -576,26 +622,47 @@ __global__ __launch_bounds__(128) void dn_pairs_kernel(const DenseTile *tiles, c
     // word in which F passes s.  That word is resolved bit by bit behind the loop (dn_resolve), once per pair and with all
     // lanes of the wave at it together.  (A pair whose F equals s at a word's end meets the resolve with nothing left to
     // count, and one that is not a pair of the job -- a column not below the row -- is computed like the others and not stored.)
+    // The first words -- about half of them for near-copies: totA + totB reaches s where either row holds s / 2 -- need no
+    // comparison at all (Amax): two ANDs and two counts per pair and word, ten instructions afterwards.
     for (uint32_t ai = 0; ai < DN_ROWS; ai += DN_IL) {
         if (T.row0 + ai >= G.g1 || T.row0 + ai >= row_end) break;         // uniform
+        const uint16_t *amax = Amax + (ai / DN_IL) * (W + 1u);
         uint32_t common[DN_IL], nle[DN_IL];
 #pragma unroll
         for (uint32_t k = 0; k < DN_IL; k++) common[k] = nle[k] = 0;
-        unsigned long long mb_next = Bm[tid];
-        uint32_t tb_next = Btot[128u + tid];
-        for (uint32_t w = 0; w < W; w++) {
+        unsigned long long mb_next = Bm[lb];
+        uint32_t tb_next = Btot[128u + lb];
+        uint32_t wi = 0;
+        // the words no pair of the batch can end in (tb_next: the column's total at the end of word wi)
+        for (; wi < W; wi++) {
+            if (__ballot((uint32_t)amax[wi + 1u] + tb_next > s) != 0) break;          // uniform
             const unsigned long long mb = mb_next;
-            const uint32_t tb1 = tb_next;
-            if (w + 1u < W) {                                             // the next word is on its way while this one is worked on
-                mb_next = Bm[(w + 1u) * 128u + tid];
-                tb_next = Btot[(w + 2u) * 128u + tid];
+            if (wi + 1u < W) {                                             // the next word is on its way while this one is worked on
+                mb_next = Bm[(wi + 1u) * 128u + lb];
+                tb_next = Btot[(wi + 2u) * 128u + lb];
             }
+            const uint32_t mlo = (uint32_t)mb, mhi = (uint32_t)(mb >> 32);
+#pragma unroll
+            for (uint32_t k = 0; k < DN_IL; k++) {
+                const unsigned long long am = Am[wi * DN_ROWS + ai + k];
+                common[k] = dn_count_add((uint32_t)am & mlo, dn_count_add((uint32_t)(am >> 32) & mhi, common[k]));
+            }
+        }
+        const uint32_t nfast = wi;
+        for (; wi < W; wi++) {
+            const unsigned long long mb = mb_next;
+            const int32_t tbs = (int32_t)tb_next - (int32_t)s;            // F <= s  <=>  totA + (totB - s) <= common
+            if (wi + 1u < W) {
+                mb_next = Bm[(wi + 1u) * 128u + lb];
+                tb_next = Btot[(wi + 2u) * 128u + lb];
+            }
+            const uint32_t mlo = (uint32_t)mb, mhi = (uint32_t)(mb >> 32);
             bool any = false;
 #pragma unroll
             for (uint32_t k = 0; k < DN_IL; k++) {
-                const unsigned long long an = Am[w * DN_ROWS + ai + k] & mb;
-                const uint32_t cnew = common[k] + (uint32_t)__popcll(an);
-                const bool before = (uint32_t)Atot[(w + 1u) * DN_ROWS + ai + k] + tb1 - cnew <= s;
+                const unsigned long long am = Am[wi * DN_ROWS + ai + k];
+                const uint32_t cnew = dn_count_add((uint32_t)am & mlo, dn_count_add((uint32_t)(am >> 32) & mhi, common[k]));
+                const bool before = (int32_t)Atot[(wi + 1u) * DN_ROWS + ai + k] + tbs <= (int32_t)cnew;
                 common[k] = before ? cnew : common[k];
                 nle[k] += before ? 1u : 0u;
                 any = any || before;
@@ -610,14 +677,14 @@ __global__ __launch_bounds__(128) void dn_pairs_kernel(const DenseTile *tiles, c
             if (!present) continue;                                       // uniform
             const bool valid = b < a;
             uint32_t denom = s;
-            const uint32_t w = nle[k];
+            const uint32_t w = nfast + nle[k];
             const bool need = valid && w < W;                             // s is reached inside word w
             if (__ballot(need) != 0) {                                    // uniform: the resolve is entered by the whole wave
                 const uint32_t wc = need ? w : 0u;
-                const unsigned long long ma = Am[wc * DN_ROWS + ai + k], mb = Bm[wc * 128u + tid];
+                const unsigned long long ma = Am[wc * DN_ROWS + ai + k], mb = Bm[wc * 128u + lb];
                 const uint32_t ca0 = Acx[wc * DN_ROWS + ai + k] & DN_CX_MASK, ca1r = Acx[(wc + 1u) * DN_ROWS + ai + k];
-                const uint32_t cb0 = Bcx[wc * 128u + tid] & DN_CX_MASK, cb1r = Bcx[(wc + 1u) * 128u + tid];
-                const uint32_t fprev = (uint32_t)Atot[wc * DN_ROWS + ai + k] + (uint32_t)Btot[wc * 128u + tid] - common[k];
+                const uint32_t cb0 = Bcx[wc * 128u + lb] & DN_CX_MASK, cb1r = Bcx[(wc + 1u) * 128u + lb];
+                const uint32_t fprev = (uint32_t)Atot[wc * DN_ROWS + ai + k] + (uint32_t)Btot[wc * 128u + lb] - common[k];
                 const bool lists = need && (use_lists || ((ca1r | cb1r) & DN_CX_FLAG) != 0);
                 const uint32_t T0 = dn_resolve(ma | mb, fprev, s, wc, lists, xm + (uint64_t)(G.xrow0 + (a - G.g0)) * wstride * 4ull, xmb,
                                                ext + (uint64_t)(G.xrow0 + (a - G.g0)) * xs, xb, ca0, need ? (ca1r & DN_CX_MASK) - ca0 : 0u, cb0,
@@ -626,7 +693,7 @@ __global__ __launch_bounds__(128) void dn_pairs_kernel(const DenseTile *tiles, c
             }
             if (!valid) continue;
             if (w >= W) {                                                 // the union ends before s (short sketches)
-                const uint32_t total = (uint32_t)Atot[W * DN_ROWS + ai + k] + (uint32_t)Btot[W * 128u + tid] - common[k];
+                const uint32_t total = (uint32_t)Atot[W * DN_ROWS + ai + k] + (uint32_t)Btot[W * 128u + lb] - common[k];
                 denom = total < s ? total : s;
             }
             if (list.rc) {                                                // (uniform) a list job: the tail of row a's list
@@ -644,7 +711,7 @@ __global__ __launch_bounds__(128) void dn_pairs_kernel(const DenseTile *tiles, c
 // LDS of a tile: its rows' words and counts
 uint32_t dense_max_words() { return 400; }                 // 32 rows x (8 W + 4 W + 4) bytes
 
-size_t dense_pairs_lds(uint32_t W, uint32_t rows) { return (size_t)rows * W * 8 + (size_t)(W + 1u) * rows * 4 + 16; }
+size_t dense_pairs_lds(uint32_t W, uint32_t rows) { return (size_t)rows * W * 8 + (size_t)(W + 1u) * rows * 4 + (size_t)(W + 1u) * 8 * 2 + 16; }
 
 // rows of a tile: 32 when that still leaves enough tiles to fill the device (a tile is two waves; the rows of a tile are taken
 // one after the other), else 8 -- a collection of small clusters has few column blocks per row block
