@@ -241,7 +241,7 @@ hipError_t dense_sort_universes(const unsigned long long *key, const uint32_t *v
 //    OUTSIDE the group only (the pairs inside are this file's), and rows ascend inside a run;
 //  * any other value is held by no other row of the group (its run is untouched: whoever holds it lies outside) and is
 //    an EXTRA, recorded by its gap -- the number of universe values below it: in order in `ext`, counted per word in
-//    cx, and per word as four bit PLANES over the gap's offset in the word (xm: bit o of plane j = bit j of the number
+//    cx, and per word as four bit PLANES over the gap's offset in the word (in the block: bit o of plane j = bit j of the number
 //    of extras at offset o), which is what the resolve step of dn_pairs_kernel counts with; a word with sixteen extras
 //    in one gap is flagged (bit 15 of the word's cx entry) and resolved from the list instead.  (Rounds 4-5a kept three
 //    unary masks -- up to three extras per gap.  Loosely related clusters have dozens of extras per word: every word of
@@ -251,11 +251,16 @@ constexpr uint32_t DN_CX_MASK = 0x7FFFu, DN_CX_FLAG = 0x8000u;           // cx: 
 template <uint32_t DN_EK>                                  // entries a work-item takes at a time
 __global__ __launch_bounds__(256) void dn_encode_kernel(const uint32_t *off, const uint32_t *code_img, uint32_t *pos_img, uint32_t rs,
                                                         const uint32_t *grp_of, const DenseGroup *groups, const uint32_t *ulist,
-                                                        const uint32_t *upos, unsigned long long *gdata, unsigned long long *xm,
-                                                        uint32_t wstride, uint16_t *ext, uint32_t xs, uint32_t n, uint32_t ul_in_lds)
+                                                        const uint32_t *upos, unsigned long long *gdata, uint32_t wstride, uint16_t *ext,
+                                                        uint32_t xs, uint32_t n, uint32_t ul_in_lds)
 {
     MG_DYN_SHARED(uint32_t, lds);          // [2 W] mask halves, [W + 1] extras per word, [16 W] extras per gap (bytes), [W] overflow flags, [8 W] plane halves, [8] scratch, [u] the universe
-    const uint32_t row = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+    // (the hardware deals workgroups to the eight XCDs round-robin; a row's words go to one lane of its block's lines, eight
+    //  bytes a kilobyte apart: of 64 workgroups that follow each other every XCD takes eight CONSECUTIVE rows, so that its L2
+    //  holds 64 contiguous bytes of every line instead of every eighth lane)
+    const uint32_t bid = blockIdx.x;
+    const uint32_t row = (bid & ~63u) | ((bid & 7u) << 3) | ((bid >> 3) & 7u);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
     if (row >= n) return;
     const uint32_t g = grp_of[row];
     if (g == 0xFFFFFFFFu) return;                        // uniform
@@ -403,7 +408,11 @@ __global__ __launch_bounds__(256) void dn_encode_kernel(const uint32_t *off, con
         }
     }
     __syncthreads();
-    unsigned long long *xrow4 = xm + ((uint64_t)(G.xrow0 + (row - G.g0)) * wstride) * 4ull;      // (every row has room for the widest universe)
+    const uint32_t jb = (row - G.g0) >> 7, bl = (row - G.g0) & 127u;
+    const uint64_t bw = dense_block_words(W);
+    unsigned long long *blk = gdata + G.data_off + (uint64_t)jb * bw;
+    uint16_t *cxp = reinterpret_cast<uint16_t *>(blk + 128ull * W), *totp = cxp + (W + 1u) * 128u;
+    unsigned long long *xpl = blk + dense_block_planes(W);                                // [W][4][128]
     for (uint32_t i = tid; i < 16u * W; i += 256u) {      // the gaps' counts as four bit planes: a work-item takes four gaps
         const uint32_t four = gap8[i], w = i >> 4, q = i & 15u;
         uint32_t bits[4] = {0u, 0u, 0u, 0u}, over = 0;
@@ -420,12 +429,7 @@ __global__ __launch_bounds__(256) void dn_encode_kernel(const uint32_t *off, con
             if (bits[j]) atomicOr(&pl32[2u * (4u * w + j) + (q >> 3)], bits[j]);
     }
     __syncthreads();
-    for (uint32_t i = tid; i < 4u * W; i += 256u) xrow4[i] = (unsigned long long)pl32[2u * i] | ((unsigned long long)pl32[2u * i + 1u] << 32);
-    __syncthreads();
-    const uint32_t jb = (row - G.g0) >> 7, bl = (row - G.g0) & 127u;
-    const uint64_t bw = dense_block_words(W);
-    unsigned long long *blk = gdata + G.data_off + (uint64_t)jb * bw;
-    uint16_t *cxp = reinterpret_cast<uint16_t *>(blk + 128ull * W), *totp = cxp + (W + 1u) * 128u;
+    for (uint32_t i = tid; i < 4u * W; i += 256u) xpl[i * 128u + bl] = (unsigned long long)pl32[2u * i] | ((unsigned long long)pl32[2u * i + 1u] << 32);
     if (tid == 0) {                                       // cumulative counts: cx[w] = extras with gap < 64 w (w = 0 .. W),
         uint32_t run = 0, all = 0;                        // entry w + 1 carries the flag of word w; tot[w] = ALL the row's values
         for (uint32_t w = 0; w <= W; w++) {               // before that boundary (universe values held + extras)
@@ -443,7 +447,7 @@ __global__ __launch_bounds__(256) void dn_encode_kernel(const uint32_t *off, con
 
 hipError_t launch_dense_encode(const uint32_t *off, const uint32_t *code_img, uint32_t *pos_img, uint32_t rs, const uint32_t *grp_of,
                                const DenseGroup *groups, const uint32_t *ulist, const uint32_t *upos, unsigned long long *gdata,
-                               unsigned long long *xm, uint16_t *ext, uint32_t xs, uint32_t n, uint32_t wmax, hipStream_t stream, int ul_mode)
+                               uint16_t *ext, uint32_t xs, uint32_t n, uint32_t wmax, hipStream_t stream, int ul_mode)
 {
     if (n == 0) return hipSuccess;
     // The universe in LDS while that leaves a CU several workgroups: a universe of 15 000 values (C5: 86 KB with the masks) made it
@@ -457,8 +461,8 @@ hipError_t launch_dense_encode(const uint32_t *off, const uint32_t *code_img, ui
     auto go = [&](auto kern) -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(n), dim3(256), smem, stream, off, code_img, pos_img, rs, grp_of, groups, ulist, upos, gdata, xm, wmax, ext, xs, n,
-                           ul_in_lds ? 1u : 0u);
+        hipLaunchKernelGGL(kern, dim3((n + 63u) & ~63u), dim3(256), smem, stream, off, code_img, pos_img, rs, grp_of, groups, ulist, upos, gdata, wmax, ext, xs,
+                           n, ul_in_lds ? 1u : 0u);
         return hipGetLastError();
     };
     return rs >= 4096u ? go(dn_encode_kernel<8>) : go(dn_encode_kernel<1>);
@@ -469,19 +473,9 @@ hipError_t launch_dense_encode(const uint32_t *off, const uint32_t *code_img, ui
 // results leave as one contiguous store per wave).  The column block's words are staged in LDS as they lie in
 // memory (word w of lane l at w * 128 + l: conflict free), the rows' words beside them (read by all lanes at once).
 
-// where a pair of index rows lands in the output: the index may have been built on a PERMUTED table (rows that belong
-// together next to each other, see dense_cluster_rows); inv maps an index row back to the table's row
-__device__ __forceinline__ uint64_t dn_out_index(uint32_t a, uint32_t b, const uint32_t *inv, uint64_t out_base)
-{
-    uint32_t i = a, j = b;
-    if (inv) {
-        i = inv[a];
-        j = inv[b];
-        if (i < j) { const uint32_t t = i; i = j; j = t; }
-    }
-    return (uint64_t)i * (i - 1u) / 2u - out_base + j;
-}
-
+// Where a pair of index rows lands in the output: the index may have been built on a PERMUTED table (rows that belong
+// together next to each other, see dense_cluster_rows); inv maps an index row back to the table's row, and the pair of table
+// rows i > j stands at i (i - 1) / 2 - out_base + j.
 
 // popcount(x) + acc as ONE instruction (the compiler adds three terms with v_add3 behind two counts into zero)
 __device__ __forceinline__ uint32_t dn_count_add(uint32_t x, uint32_t acc)
@@ -495,59 +489,83 @@ __device__ __forceinline__ uint32_t dn_count_add(uint32_t x, uint32_t acc)
 #endif
 }
 
+// the low y bits of x (y = 0 .. 31)
+__device__ __forceinline__ uint32_t dn_low_bits(uint32_t x, uint32_t y)
+{
+#ifdef MG_HIP_EMU
+    return x & ((1u << y) - 1u);
+#else
+    return __builtin_amdgcn_ubfe(x, 0u, y);
+#endif
+}
+
+// One half (32 offsets) of the word in which the union reaches its s-th element: the number of offsets x in 0 .. 30 with
+// f(x) < s, bit by bit from the top (f never falls) -- the smallest offset at which s is reached, or 31.
+// f(x) = base + the union's bits below x + the extras of either row at offsets <= x; u1 is the union's half shifted up by
+// one, so that both are "the low x + 1 bits".  NP: the planes above the first that hold anything (0, 1 or 3).
+template <uint32_t NP>
+__device__ __forceinline__ uint32_t dn_descend(uint32_t base, uint32_t s, uint32_t u1, uint32_t A0, uint32_t B0, uint32_t A1, uint32_t B1,
+                                               uint32_t A2, uint32_t B2, uint32_t A3, uint32_t B3)
+{
+    uint32_t pos = 0;
+#pragma unroll
+    for (uint32_t bit = 16u; bit != 0u; bit >>= 1) {
+        const uint32_t y = pos + bit;                                     // offset y - 1 is tested
+        uint32_t c = dn_count_add(dn_low_bits(B0, y), dn_count_add(dn_low_bits(A0, y), dn_count_add(dn_low_bits(u1, y), base)));
+        if (NP >= 1u) c += 2u * dn_count_add(dn_low_bits(B1, y), (uint32_t)__popc(dn_low_bits(A1, y)));
+        if (NP >= 3u)
+            c += 4u * dn_count_add(dn_low_bits(B2, y), (uint32_t)__popc(dn_low_bits(A2, y))) +
+                 8u * dn_count_add(dn_low_bits(B3, y), (uint32_t)__popc(dn_low_bits(A3, y)));
+        pos = c < s ? y : pos;
+    }
+    return pos;
+}
+
 // The word in which the union reaches its s-th element: the smallest bit position t with f(t) >= s, where f(t) = what lies
-// before the word (fprev) + union bits below t + extras of either row with offset <= t; the bits below t are the ones counted.
+// before the word (fprev) + union bits below t + extras of either row with offset <= t; the COMMON bits below t are what comes
+// back (mab: the two rows' masks ANDed).
 // The extras of the word as four bit planes per row (bit o of plane j: bit j of the number of extras at offset o), or -- a gap
 // of the word holds sixteen and more in one of the rows -- from the rows' lists.
 // Called by every lane of the wave (uniform control flow: the ballots below are taken over all of them); a lane with nothing
 // to resolve passes lists = false, na = nb = 0 and a word that exists, and ignores what comes back.
-__device__ __forceinline__ uint32_t dn_resolve(unsigned long long un, uint32_t fprev, uint32_t s, uint32_t w, bool lists,
-                                               const unsigned long long *xma, const unsigned long long *xmb, const uint16_t *xa,
+__device__ __forceinline__ uint32_t dn_resolve(unsigned long long un, unsigned long long mab, uint32_t fprev, uint32_t s, uint32_t w, bool lists,
+                                               const unsigned long long *xpa, const unsigned long long *xpb, const uint16_t *xa,
                                                const uint16_t *xb, uint32_t ca0, uint32_t na, uint32_t cb0, uint32_t nb)
 {
     if (__ballot(lists) == 0) {                              // uniform
-        const unsigned long long a0 = xma[4u * w], a1 = xma[4u * w + 1u], a2 = xma[4u * w + 2u], a3 = xma[4u * w + 3u];
-        const unsigned long long b0 = xmb[4u * w], b1 = xmb[4u * w + 1u], b2 = xmb[4u * w + 2u], b3 = xmb[4u * w + 3u];
-        // (near-copies have a few dozen extras over a thousand gaps: with no gap of the whole wave holding two, a count is
-        //  three population counts instead of nine)
-        const bool planes = __ballot((a1 | a2 | a3 | b1 | b2 | b3) != 0ull) != 0;      // uniform
+        // (xpa / xpb: the row's and the column's lane in the planes of their blocks, [W][4][128]: lanes that resolve the same
+        //  word -- near-copies nearly all do -- read a line per plane between them)
+        const unsigned long long a0 = xpa[512u * w], a1 = xpa[512u * w + 128u], a2 = xpa[512u * w + 256u], a3 = xpa[512u * w + 384u];
+        const unsigned long long b0 = xpb[512u * w], b1 = xpb[512u * w + 128u], b2 = xpb[512u * w + 256u], b3 = xpb[512u * w + 384u];
         // Which half of the word: f(31) = fprev + the union's bits 0 .. 30 + the extras at offsets 0 .. 31; from there on every
         // count is over 32-bit halves (a 64-bit mask and count is two shifts with carries and two counts per operand).
+        // (near-copies have a few dozen extras over a thousand gaps: where no gap of the whole wave holds two, a count is three
+        //  population counts, five where none holds four, else nine)
+        const bool p1 = __ballot((a1 | b1) != 0ull) != 0, p23 = __ballot((a2 | a3 | b2 | b3) != 0ull) != 0;      // uniform
         const uint32_t ulo = (uint32_t)un, uhi = (uint32_t)(un >> 32);
         uint32_t c31 = dn_count_add((uint32_t)b0, dn_count_add((uint32_t)a0, dn_count_add(ulo & 0x7FFFFFFFu, fprev)));
-        if (planes)
-            c31 += 2u * (uint32_t)(__popc((uint32_t)a1) + __popc((uint32_t)b1)) + 4u * (uint32_t)(__popc((uint32_t)a2) + __popc((uint32_t)b2)) +
-                   8u * (uint32_t)(__popc((uint32_t)a3) + __popc((uint32_t)b3));
+        if (p1 || p23) c31 += 2u * dn_count_add((uint32_t)b1, (uint32_t)__popc((uint32_t)a1));
+        if (p23)
+            c31 += 4u * dn_count_add((uint32_t)b2, (uint32_t)__popc((uint32_t)a2)) + 8u * dn_count_add((uint32_t)b3, (uint32_t)__popc((uint32_t)a3));
         const bool upper = c31 < s;                          // s is reached at offset 32 or above: the lower half lies before
         const uint32_t base = upper ? c31 + (ulo >> 31) : fprev;
-        const uint32_t u = upper ? uhi : ulo;
+        const uint32_t u1 = (upper ? uhi : ulo) << 1;
         const uint32_t A0 = upper ? (uint32_t)(a0 >> 32) : (uint32_t)a0, B0 = upper ? (uint32_t)(b0 >> 32) : (uint32_t)b0;
-        // pos = the number of offsets x in 0 .. 30 of the half with f(x) < s, bit by bit from the top (f never falls): the
-        // smallest offset at which s is reached, or 31
-        uint32_t pos = 0;
-        if (!planes) {
-#pragma unroll
-            for (uint32_t bit = 16u; bit != 0u; bit >>= 1) {
-                const uint32_t x = pos + bit - 1u;                            // <= 30
-                const uint32_t below = (1u << x) - 1u, upto = (below << 1) | 1u;
-                const uint32_t c = dn_count_add(B0 & upto, dn_count_add(A0 & upto, dn_count_add(u & below, base)));
-                pos += c < s ? bit : 0u;
-            }
+        uint32_t pos;
+        if (!p1 && !p23) {
+            pos = dn_descend<0>(base, s, u1, A0, B0, 0, 0, 0, 0, 0, 0);
         } else {
             const uint32_t A1 = upper ? (uint32_t)(a1 >> 32) : (uint32_t)a1, B1 = upper ? (uint32_t)(b1 >> 32) : (uint32_t)b1;
-            const uint32_t A2 = upper ? (uint32_t)(a2 >> 32) : (uint32_t)a2, B2 = upper ? (uint32_t)(b2 >> 32) : (uint32_t)b2;
-            const uint32_t A3 = upper ? (uint32_t)(a3 >> 32) : (uint32_t)a3, B3 = upper ? (uint32_t)(b3 >> 32) : (uint32_t)b3;
-#pragma unroll
-            for (uint32_t bit = 16u; bit != 0u; bit >>= 1) {
-                const uint32_t x = pos + bit - 1u;
-                const uint32_t below = (1u << x) - 1u, upto = (below << 1) | 1u;
-                const uint32_t c = dn_count_add(B0 & upto, dn_count_add(A0 & upto, dn_count_add(u & below, base))) +
-                                   2u * (uint32_t)(__popc(B1 & upto) + __popc(A1 & upto)) + 4u * (uint32_t)(__popc(B2 & upto) + __popc(A2 & upto)) +
-                                   8u * (uint32_t)(__popc(B3 & upto) + __popc(A3 & upto));
-                pos += c < s ? bit : 0u;
+            if (!p23) {
+                pos = dn_descend<1>(base, s, u1, A0, B0, A1, B1, 0, 0, 0, 0);
+            } else {
+                const uint32_t A2 = upper ? (uint32_t)(a2 >> 32) : (uint32_t)a2, B2 = upper ? (uint32_t)(b2 >> 32) : (uint32_t)b2;
+                const uint32_t A3 = upper ? (uint32_t)(a3 >> 32) : (uint32_t)a3, B3 = upper ? (uint32_t)(b3 >> 32) : (uint32_t)b3;
+                pos = dn_descend<3>(base, s, u1, A0, B0, A1, B1, A2, B2, A3, B3);
             }
         }
-        return (upper ? 32u : 0u) + pos;
+        const uint32_t mlo = (uint32_t)mab, mhi = (uint32_t)(mab >> 32);
+        return upper ? dn_count_add(dn_low_bits(mhi, pos), (uint32_t)__popc(mlo)) : (uint32_t)__popc(dn_low_bits(mlo, pos));
     }
     uint32_t lo = 0, hi = 63;
     // (some lane's word is flagged: every lane takes its rows' lists, which are exact for all)
@@ -559,7 +577,7 @@ __device__ __forceinline__ uint32_t dn_resolve(unsigned long long un, uint32_t f
         for (uint32_t k = 0; k < nb; k++) c += ((uint32_t)xb[cb0 + k] - wbase <= mid) ? 1u : 0u;
         if (c >= s) hi = mid; else lo = mid + 1u;
     }
-    return lo;
+    return (uint32_t)__popcll(mab & ((1ull << lo) - 1ull));
 }
 
 // The column block's words are read from global memory (L2) word by word, the next word requested before the current one
@@ -568,7 +586,7 @@ __device__ __forceinline__ uint32_t dn_resolve(unsigned long long un, uint32_t f
 // 32 768 rows 17.8 against 12.6 ms; universes of hundreds of words, s = 10 000, would not fit anyway.)
 template <uint32_t DN_ROWS, uint32_t DN_IL>                // DN_IL: rows a wave works on side by side
 __global__ __launch_bounds__(128) void dn_pairs_kernel(const DenseTile *tiles, const DenseGroup *groups, const unsigned long long *gdata,
-                                                       const unsigned long long *xm, uint32_t wstride, uint32_t use_lists,
+                                                       uint32_t use_lists,
                                                        const uint16_t *ext, uint32_t xs, uint32_t s, uint32_t row_begin, uint32_t row_end,
                                                        uint64_t out_base, const uint32_t *inv, uint2 *out, DenseList list)
 {
@@ -612,7 +630,11 @@ __global__ __launch_bounds__(128) void dn_pairs_kernel(const DenseTile *tiles, c
     // (a lane behind the group's end works on the group's last row: what it reads is written, what it computes is not stored)
     const uint32_t lb = b < G.g1 ? tid : G.g1 - 1u - (G.g0 + T.cblk * 128u);
     const uint16_t *xb = ext + (uint64_t)(G.xrow0 + (b < G.g1 ? b - G.g0 : 0u)) * xs;
-    const unsigned long long *xmb = xm + (uint64_t)(G.xrow0 + (b < G.g1 ? b - G.g0 : 0u)) * wstride * 4ull;
+    const unsigned long long *xpb = Bm + dense_block_planes(W) + lb;
+    // where this lane's pairs land: the column's table row and its triangle base once per tile -- per pair a
+    // comparison and an addition are left, the row's share is uniform
+    const uint32_t colrow = inv ? inv[G.g0 + T.cblk * 128u + lb] : G.g0 + T.cblk * 128u + lb;
+    const uint64_t tri_col = (colrow ? (uint64_t)colrow * (colrow - 1u) / 2u : 0ull) - out_base;
     // DN_IL rows at a time: the column block's word is loaded once and serves all of them (their words are broadcast reads
     // from LDS), and a wave has several independent pairs per lane in flight instead of one.
     // Per pair and word: the intersection's bits are counted (common), and what the union holds up to the word's end follows
@@ -686,10 +708,10 @@ __global__ __launch_bounds__(128) void dn_pairs_kernel(const DenseTile *tiles, c
                 const uint32_t cb0 = Bcx[wc * 128u + lb] & DN_CX_MASK, cb1r = Bcx[(wc + 1u) * 128u + lb];
                 const uint32_t fprev = (uint32_t)Atot[wc * DN_ROWS + ai + k] + (uint32_t)Btot[wc * 128u + lb] - common[k];
                 const bool lists = need && (use_lists || ((ca1r | cb1r) & DN_CX_FLAG) != 0);
-                const uint32_t T0 = dn_resolve(ma | mb, fprev, s, wc, lists, xm + (uint64_t)(G.xrow0 + (a - G.g0)) * wstride * 4ull, xmb,
+                const uint32_t add = dn_resolve(ma | mb, ma & mb, fprev, s, wc, lists, asrc + dense_block_planes(W) + la0 + ai + k, xpb,
                                                ext + (uint64_t)(G.xrow0 + (a - G.g0)) * xs, xb, ca0, need ? (ca1r & DN_CX_MASK) - ca0 : 0u, cb0,
                                                need ? (cb1r & DN_CX_MASK) - cb0 : 0u);
-                if (need) common[k] += (uint32_t)__popcll(ma & mb & ((1ull << T0) - 1ull));
+                if (need) common[k] += add;
             }
             if (!valid) continue;
             if (w >= W) {                                                 // the union ends before s (short sketches)
@@ -702,7 +724,9 @@ __global__ __launch_bounds__(128) void dn_pairs_kernel(const DenseTile *tiles, c
                 list.rc[at] = make_uint2(a, b);
                 list.counts[at] = make_uint2(common[k], denom);
             } else {
-                out[dn_out_index(a, b, inv, out_base)] = make_uint2(common[k], denom);
+                const uint32_t arow = inv ? inv[a] : a;                   // (uniform)
+                const uint64_t tri_a = (uint64_t)arow * (arow - 1u) / 2u - out_base;
+                out[arow > colrow ? tri_a + colrow : tri_col + arow] = make_uint2(common[k], denom);
             }
         }
     }
@@ -718,7 +742,7 @@ size_t dense_pairs_lds(uint32_t W, uint32_t rows) { return (size_t)rows * W * 8 
 uint32_t dense_rows_per_tile(uint64_t wave_rows) { return wave_rows / 32u >= 16384u ? 32u : 8u; }
 
 hipError_t launch_dense_pairs(const DenseTile *tiles, uint32_t ntiles, uint32_t rows_per_tile, const DenseGroup *groups,
-                              const unsigned long long *gdata, const unsigned long long *xm, bool use_lists, const uint16_t *ext, uint32_t xs,
+                              const unsigned long long *gdata, bool use_lists, const uint16_t *ext, uint32_t xs,
                               uint32_t s, uint32_t wmax, uint32_t row_begin, uint32_t row_end, uint64_t out_base, const uint32_t *inv, uint2 *out,
                               hipStream_t stream, const DenseList *list)
 {
@@ -727,7 +751,7 @@ hipError_t launch_dense_pairs(const DenseTile *tiles, uint32_t ntiles, uint32_t 
     auto go = [&](auto kern) -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(ntiles), dim3(128), smem, stream, tiles, groups, gdata, xm, wmax, use_lists ? 1u : 0u, ext, xs, s, row_begin, row_end,
+        hipLaunchKernelGGL(kern, dim3(ntiles), dim3(128), smem, stream, tiles, groups, gdata, use_lists ? 1u : 0u, ext, xs, s, row_begin, row_end,
                            out_base, inv, out, list ? *list : DenseList());
         return hipGetLastError();
     };

@@ -185,15 +185,21 @@ struct DenseGroup {
     uint32_t ustart, u;            // the group's universe: ulist[ustart .. ustart + u), ascending sorted positions (= codes / 2)
     uint32_t W;                    // (u >> 6) + 1 mask words per row
     uint32_t xrow0;                // index of row g0 among the grouped rows (extras of row r: ext + (xrow0 + r - g0) * xs)
-    uint64_t data_off;             // first block of the group in gdata (u64 words); a block = 128 rows: W x 128 u64 + (W + 1) x 128 u16
+    uint64_t data_off;             // first block of the group in gdata (u64 words), see dense_block_words
 };
 struct DenseTile { uint32_t group, row0, cblk; };
 // u64 words of a block of 128 rows of a group with W mask words per row: the masks [W][128], then two tables of u16
 // [W + 1][128] -- cx (extras before every word boundary | flag) and tot (ALL the row's values before it: mask bits + extras)
+// -- then the extras' bit planes [W][4][128] (bit o of plane j of word w: bit j of the number of extras at offset o of the
+// word), lane = row of the block everywhere: the 128 columns of a tile read whole lines
 #ifdef __HIPCC__
 __host__ __device__
 #endif
-static inline uint64_t dense_block_words(uint32_t W) { return 128ull * W + 64ull * (W + 1u); }
+static inline uint64_t dense_block_planes(uint32_t W) { return 128ull * W + 64ull * (W + 1u); }      // where the planes start
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+static inline uint64_t dense_block_words(uint32_t W) { return dense_block_planes(W) + 512ull * W; }
 // where a list job wants the pairs inside the groups: the list of row a (reference order: rows ascending, a row's pairs by
 // column) ends with its partners inside its group, so pair (a, b) stands at row_base[a - row_first] + row_cnt[a - row_first] - (a - b)
 struct DenseList {
@@ -216,12 +222,12 @@ hipError_t dense_sort_universes(const unsigned long long *key, const uint32_t *v
                                 uint32_t group_bits, hipStream_t stream);
 hipError_t launch_dense_encode(const uint32_t *off, const uint32_t *code_img, uint32_t *pos_img, uint32_t rs, const uint32_t *grp_of,
                                const DenseGroup *groups, const uint32_t *ulist, const uint32_t *upos, unsigned long long *gdata,
-                               unsigned long long *xm, uint16_t *ext, uint32_t xs, uint32_t n, uint32_t wmax, hipStream_t stream, int ul_mode = -1);
+                               uint16_t *ext, uint32_t xs, uint32_t n, uint32_t wmax, hipStream_t stream, int ul_mode = -1);
 size_t dense_pairs_lds(uint32_t W, uint32_t rows);
 uint32_t dense_rows_per_tile(uint64_t wave_rows);
 uint32_t dense_max_words();
 hipError_t launch_dense_pairs(const DenseTile *tiles, uint32_t ntiles, uint32_t rows_per_tile, const DenseGroup *groups,
-                              const unsigned long long *gdata, const unsigned long long *xm, bool use_lists, const uint16_t *ext, uint32_t xs,
+                              const unsigned long long *gdata, bool use_lists, const uint16_t *ext, uint32_t xs,
                               uint32_t s, uint32_t wmax, uint32_t row_begin, uint32_t row_end, uint64_t out_base, const uint32_t *inv, uint2 *out,
                               hipStream_t stream, const DenseList *list = nullptr);
 size_t dense_cluster_temp_bytes(uint32_t n);

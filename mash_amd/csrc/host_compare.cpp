@@ -1099,7 +1099,7 @@ int SparseJobRun::fill_and_dense()
         if (plan->ndtiles) {
             prof_begin(ctx, ctx->prof_dense);
             clk_begin(CK_DENSE);
-            e = mg::launch_dense_pairs(plan->dtiles, plan->ndtiles, plan->dtile_rows, ix->dgroups, ix->gdata, ix->xm, ix->dn_lists, ix->ext, ix->dn_xs, s, ix->dn_wmax,
+            e = mg::launch_dense_pairs(plan->dtiles, plan->ndtiles, plan->dtile_rows, ix->dgroups, ix->gdata, ix->dn_lists, ix->ext, ix->dn_xs, s, ix->dn_wmax,
                                        a.row_begin, a.row_end, a.out_base, a.inv, a.out, ctx->stream);
             clk_end(CK_DENSE);
             prof_end(ctx, ctx->prof_dense);
@@ -1856,7 +1856,7 @@ static int job_lists(mg_ctx *ctx, const SparseJob &job, uint32_t nrows, uint32_t
         L.rc = d_rc;
         L.counts = d_cnt;
         L.row_first = job.args.row_begin;
-        HIP_TRY(ctx, mg::launch_dense_pairs(job.dtiles, job.ndtiles, job.dtile_rows, ix->dgroups, ix->gdata, ix->xm, ix->dn_lists, ix->ext, ix->dn_xs, s, ix->dn_wmax,
+        HIP_TRY(ctx, mg::launch_dense_pairs(job.dtiles, job.ndtiles, job.dtile_rows, ix->dgroups, ix->gdata, ix->dn_lists, ix->ext, ix->dn_xs, s, ix->dn_wmax,
                                             job.args.row_begin, job.args.row_end, job.args.out_base, nullptr, nullptr, ctx->stream, &L));
     }
     return MG_OK;

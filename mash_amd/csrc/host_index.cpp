@@ -859,12 +859,11 @@ int SparseIndexBuild::dense_groups()
             if (sp->dgroups_host.empty()) break;
             sp->dn_wmax = wmax;
             sp->dn_xs = ((s + 7u) & ~7u) + 8u;
-            void *p1 = nullptr, *p2 = nullptr, *p3 = nullptr, *p4 = nullptr, *p5 = nullptr;
+            void *p1 = nullptr, *p2 = nullptr, *p3 = nullptr, *p4 = nullptr;
             if (ctx_malloc(ctx, &p1, sp->dgroups_host.size() * sizeof(mg::DenseGroup)) != hipSuccess || ctx_malloc(ctx, &p2, n * 4) != hipSuccess ||
-                ctx_malloc(ctx, &p3, words * 8) != hipSuccess || ctx_malloc(ctx, &p4, (size_t)xrows * sp->dn_xs * 2) != hipSuccess ||
-                ctx_malloc(ctx, &p5, (size_t)xrows * wmax * 32) != hipSuccess) {
+                ctx_malloc(ctx, &p3, words * 8) != hipSuccess || ctx_malloc(ctx, &p4, (size_t)xrows * sp->dn_xs * 2) != hipSuccess) {
                 (void)hipGetLastError();
-                for (void *q : {p1, p2, p3, p4, p5}) ctx_free(ctx, q);
+                for (void *q : {p1, p2, p3, p4}) ctx_free(ctx, q);
                 sp->dgroups_host.clear();
                 break;
             }
@@ -872,12 +871,11 @@ int SparseIndexBuild::dense_groups()
             sp->grp_of = static_cast<uint32_t *>(p2);
             sp->gdata = static_cast<unsigned long long *>(p3);
             sp->ext = static_cast<uint16_t *>(p4);
-            sp->xm = static_cast<unsigned long long *>(p5);
             e2 = hipMemcpyAsync(sp->dgroups, sp->dgroups_host.data(), sp->dgroups_host.size() * sizeof(mg::DenseGroup), hipMemcpyHostToDevice, ctx->stream);
             if (e2 == hipSuccess) e2 = hipMemcpyAsync(sp->grp_of, grp_of.data(), n * 4, hipMemcpyHostToDevice, ctx->stream);
             // masks, extras, and the index's runs clipped for the rows of the groups: discovery sees the partners outside only
             if (e2 == hipSuccess)
-                e2 = mg::launch_dense_encode(sp->off, sp->code_img, sp->pos_img, sp->rs, sp->grp_of, sp->dgroups, sp->ulist, sp->upos, sp->gdata, sp->xm,
+                e2 = mg::launch_dense_encode(sp->off, sp->code_img, sp->pos_img, sp->rs, sp->grp_of, sp->dgroups, sp->ulist, sp->upos, sp->gdata,
                                              sp->ext, sp->dn_xs, (uint32_t)n, wmax, ctx->stream,
                                              ctx_opt(ctx, "MASHGPU_DENSE_UL_LDS") ? atoi(ctx_opt(ctx, "MASHGPU_DENSE_UL_LDS")) : -1);
             // (no wait here: what the copies above read -- dgroups_host and the rows' group map -- lives in the index, what
@@ -886,7 +884,7 @@ int SparseIndexBuild::dense_groups()
             if (e2 != hipSuccess) {
                 // the runs may be half clipped: this index is not to be used
                 drop();
-                for (void **q : {(void **)&sp->dgroups, (void **)&sp->grp_of, (void **)&sp->gdata, (void **)&sp->ext, (void **)&sp->xm, (void **)&sp->ulist,
+                for (void **q : {(void **)&sp->dgroups, (void **)&sp->grp_of, (void **)&sp->gdata, (void **)&sp->ext, (void **)&sp->ulist,
                                  (void **)&sp->upos})
                     if (*q) { ctx_free(ctx, *q); *q = nullptr; }
                 sp->dgroups_host.clear();

@@ -148,7 +148,7 @@ struct mg_table {
         std::vector<uint32_t> grp_of_host; // (the source of grp_of's upload: alive as long as the copy may be pending)
         uint32_t *grp_of = nullptr;        // [n] group of a row, 0xFFFFFFFF: none
         uint32_t *ulist = nullptr, *upos = nullptr;        // the groups' universes: values and the positions of their leaders
-        unsigned long long *gdata = nullptr, *xm = nullptr; // mask blocks; per row and word three masks of the extras' offsets
+        unsigned long long *gdata = nullptr;                // the groups' blocks: masks, counts, the extras' bit planes (compare_internal.h)
         uint16_t *ext = nullptr;
         uint32_t dn_wmax = 0, dn_xs = 0;
         bool dn_lists = false;             // (test knob) every word resolved from the extras' lists instead of their masks

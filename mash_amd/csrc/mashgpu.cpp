@@ -347,7 +347,7 @@ static void table_drop_derived(mg_table *t)
                         (void *)sp->res, (void *)sp->seg_base, (void *)sp->seg_cnt, (void *)sp->chunks, (void *)sp->chunk_inc,
                         sp->scan_temp, (void *)sp->counters, (void *)sp->rep, (void *)sp->cls_of, (void *)sp->cls_off,
                         (void *)sp->cls_rows, (void *)sp->cls_first, (void *)sp->order, (void *)sp->dgroups, (void *)sp->grp_of,
-                        (void *)sp->ulist, (void *)sp->upos, (void *)sp->gdata, (void *)sp->xm, (void *)sp->ext, (void *)sp->inv, (void *)sp->phashes})
+                        (void *)sp->ulist, (void *)sp->upos, (void *)sp->gdata, (void *)sp->ext, (void *)sp->inv, (void *)sp->phashes})
             if (q) ctx_free(ctx, q);
         for (void *q : sp->jn.bufs)
             if (q) ctx_free(ctx, q);

@@ -128,17 +128,17 @@ static void reference_pair(const std::vector<uint64_t> &A, const std::vector<uin
 
 template <uint32_t EK> static void run_encode(uint32_t n, size_t smem, const uint32_t *off, const uint32_t *code, uint32_t *pos, uint32_t rs,
                                               const uint32_t *grp_of, const DenseGroup *groups, const uint32_t *ulist, const uint32_t *upos,
-                                              unsigned long long *gdata, unsigned long long *xm, uint32_t wmax, uint16_t *ext, uint32_t xs)
+                                              unsigned long long *gdata, uint32_t wmax, uint16_t *ext, uint32_t xs)
 {
-    hipLaunchKernelGGL(dn_encode_kernel<EK>, dim3(n), dim3(256), smem, nullptr, off, code, pos, rs, grp_of, groups, ulist, upos, gdata, xm, wmax, ext,
+    hipLaunchKernelGGL(dn_encode_kernel<EK>, dim3((n + 63u) & ~63u), dim3(256), smem, nullptr, off, code, pos, rs, grp_of, groups, ulist, upos, gdata, wmax, ext,
                        xs, n, 1u);
 }
 
 template <uint32_t R, uint32_t IL> static void run_pairs(const std::vector<DenseTile> &tiles, size_t smem, const DenseGroup *groups,
-                                                         const unsigned long long *gdata, const unsigned long long *xm, uint32_t wmax,
+                                                         const unsigned long long *gdata, uint32_t wmax,
                                                          uint32_t use_lists, const uint16_t *ext, uint32_t xs, uint32_t s, uint32_t n, uint2 *out)
 {
-    hipLaunchKernelGGL((dn_pairs_kernel<R, IL>), dim3((uint32_t)tiles.size()), dim3(128), smem, nullptr, tiles.data(), groups, gdata, xm, wmax,
+    hipLaunchKernelGGL((dn_pairs_kernel<R, IL>), dim3((uint32_t)tiles.size()), dim3(128), smem, nullptr, tiles.data(), groups, gdata,
                        use_lists, ext, xs, s, 0u, n, (uint64_t)0, (const uint32_t *)nullptr, out, DenseList());
 }
 
@@ -211,11 +211,11 @@ static int run_case(const std::string &name, uint32_t s, uint64_t seed, const st
     const uint64_t npairs = (uint64_t)n * (n - 1) / 2;
     std::vector<unsigned long long> gdata_first;
     for (int variant = 0; variant < 2; variant++) {        // an entry per work-item; eight entries per work-item
-        std::vector<unsigned long long> gdata(words + 1, 0xABABABABABABABABull), xm((size_t)xrows * wmax * 4 + 1, 0xCDCDCDCDCDCDCDCDull);
+        std::vector<unsigned long long> gdata(words + 1, 0xABABABABABABABABull);
         std::vector<uint16_t> ext((size_t)xrows * xs + 1, 0xEEEE);
         pos = pos0;
-        if (variant == 0) run_encode<1>(n, smem_enc, off.data(), code.data(), pos.data(), rs, grp_of.data(), groups.data(), ulist.data(), upos.data(), gdata.data(), xm.data(), wmax, ext.data(), xs);
-        else run_encode<8>(n, smem_enc, off.data(), code.data(), pos.data(), rs, grp_of.data(), groups.data(), ulist.data(), upos.data(), gdata.data(), xm.data(), wmax, ext.data(), xs);
+        if (variant == 0) run_encode<1>(n, smem_enc, off.data(), code.data(), pos.data(), rs, grp_of.data(), groups.data(), ulist.data(), upos.data(), gdata.data(), wmax, ext.data(), xs);
+        else run_encode<8>(n, smem_enc, off.data(), code.data(), pos.data(), rs, grp_of.data(), groups.data(), ulist.data(), upos.data(), gdata.data(), wmax, ext.data(), xs);
         // the clipped runs: an entry whose value is in its group's universe ends at the leader's position
         for (uint32_t r = 0; r < n; r++) {
             const uint32_t g = grp_of[r];
@@ -251,11 +251,11 @@ static int run_case(const std::string &name, uint32_t s, uint64_t seed, const st
                 if (variant == 1 && il != 8) continue;     // (the second encode's data through one shape of the pairs kernel)
                 for (uint32_t lists = 0; lists < 2; lists++) {
                     std::vector<uint2> out(npairs + 1, make_uint2(0xDEADu, 0xDEADu));
-                    if (R == 8 && il == 4) run_pairs<8, 4>(tiles, smem, groups.data(), gdata.data(), xm.data(), wmax, lists, ext.data(), xs, s, n, out.data());
-                    else if (R == 8) run_pairs<8, 8>(tiles, smem, groups.data(), gdata.data(), xm.data(), wmax, lists, ext.data(), xs, s, n, out.data());
-                    else if (il == 4) run_pairs<32, 4>(tiles, smem, groups.data(), gdata.data(), xm.data(), wmax, lists, ext.data(), xs, s, n, out.data());
-                    else if (il == 8) run_pairs<32, 8>(tiles, smem, groups.data(), gdata.data(), xm.data(), wmax, lists, ext.data(), xs, s, n, out.data());
-                    else run_pairs<32, 16>(tiles, smem, groups.data(), gdata.data(), xm.data(), wmax, lists, ext.data(), xs, s, n, out.data());
+                    if (R == 8 && il == 4) run_pairs<8, 4>(tiles, smem, groups.data(), gdata.data(), wmax, lists, ext.data(), xs, s, n, out.data());
+                    else if (R == 8) run_pairs<8, 8>(tiles, smem, groups.data(), gdata.data(), wmax, lists, ext.data(), xs, s, n, out.data());
+                    else if (il == 4) run_pairs<32, 4>(tiles, smem, groups.data(), gdata.data(), wmax, lists, ext.data(), xs, s, n, out.data());
+                    else if (il == 8) run_pairs<32, 8>(tiles, smem, groups.data(), gdata.data(), wmax, lists, ext.data(), xs, s, n, out.data());
+                    else run_pairs<32, 16>(tiles, smem, groups.data(), gdata.data(), wmax, lists, ext.data(), xs, s, n, out.data());
                     char what[96];
                     snprintf(what, sizeof what, "pair (tile %u rows, %u side by side, %s)", R, il, lists ? "lists" : "planes");
                     for (uint32_t a = 1; a < n; a++)
