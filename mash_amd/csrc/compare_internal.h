@@ -169,6 +169,11 @@ size_t sparse_edges_temp_bytes(uint64_t K);
 uint64_t sparse_edges_blocks(uint64_t K);
 hipError_t launch_sparse_list_edges(const uint2 *rc, const uint2 *counts, uint64_t K, uint32_t *blk_cnt, uint32_t *blk_off, void *temp, size_t temp_bytes,
                                     uint4 *edges, unsigned long long *total, hipStream_t stream);
+// the fill in chunks handed out by a counter: any number of launches (a slow one beside other work, a fast one to end it) share one job
+uint64_t sparse_fill_chunks(uint64_t pairs);
+constexpr uint32_t kFillStop = 0x80000000u;                 // the counter's value that ends every launch at its next chunk
+hipError_t launch_sparse_fill_chunks(uint2 *out, uint64_t pairs, uint32_t numer, uint32_t denom, uint32_t blocks, uint32_t naps, uint32_t *ctr,
+                                     hipStream_t stream, uint32_t threads = 256);
 hipError_t launch_sparse_fill_value(uint2 *out, uint64_t pairs, uint32_t numer, uint32_t denom, uint32_t blocks_per_cu, uint32_t cus,
                                     hipStream_t stream);
 hipError_t launch_sparse_merge_pack(const SparseArgs &a, uint64_t expect, uint32_t *chunks, void *temp, size_t temp_bytes, bool *used,

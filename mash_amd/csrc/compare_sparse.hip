@@ -1525,6 +1525,52 @@ __global__ __launch_bounds__(256) void sp_fill_value_kernel(uint2 *out, uint64_t
     }
 }
 
+// The same fill in CHUNKS of 64 KB that a wave takes from a counter, with `naps` pauses of 64 cycles behind every 4 KB it
+// writes: launched with few workgroups and some naps it runs beside kernels that live on round trips to memory (the index
+// build: a fill at full speed keeps the memory's queues full of writes and the build's loads wait behind them), and a second
+// launch -- whole device, no naps -- takes what is left from the same counter when the other work has ended.
+constexpr uint32_t SP_FILL_CHUNK = 4096;                   // 16-byte vectors per chunk
+
+__global__ __launch_bounds__(256) void sp_fill_chunks_kernel(uint2 *out, uint64_t pairs, uint32_t numer, uint32_t denom, uint32_t naps, uint32_t *ctr,
+                                                             uint32_t nchunks)
+{
+    const uint64_t head = ((reinterpret_cast<uintptr_t>(out) & 8u) != 0 && pairs > 0) ? 1u : 0u;
+    const uint64_t nvec = (pairs - head) >> 1;
+    sp_u32x4 *body = reinterpret_cast<sp_u32x4 *>(out + head);
+    const sp_u32x4 v = {numer, denom, numer, denom};
+    const uint32_t lane = threadIdx.x & 63u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (head) out[0] = make_uint2(numer, denom);
+        if (((pairs - head) & 1u) != 0) out[pairs - 1] = make_uint2(numer, denom);
+    }
+    for (;;) {
+        uint32_t c = 0;
+        if (lane == 0) c = atomicAdd(ctr, 1u);
+        c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+        if (c >= nchunks) break;
+        const uint64_t first = (uint64_t)c * SP_FILL_CHUNK;
+        for (uint32_t r = 0; r < SP_FILL_CHUNK; r += 256u) {
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; u++) {
+                const uint64_t i = first + r + u * 64u + lane;
+                if (i < nvec) __builtin_nontemporal_store(v, body + i);
+            }
+            for (uint32_t z = 0; z < naps; z++) __builtin_amdgcn_s_sleep(1);
+        }
+    }
+}
+
+uint64_t sparse_fill_chunks(uint64_t pairs) { return (pairs / 2 + SP_FILL_CHUNK - 1) / SP_FILL_CHUNK; }
+
+hipError_t launch_sparse_fill_chunks(uint2 *out, uint64_t pairs, uint32_t numer, uint32_t denom, uint32_t blocks, uint32_t naps, uint32_t *ctr,
+                                     hipStream_t stream, uint32_t threads)
+{
+    if (pairs == 0) return hipSuccess;
+    hipLaunchKernelGGL(sp_fill_chunks_kernel, dim3(blocks ? blocks : 256u), dim3(threads), 0, stream, out, pairs, numer, denom, naps, ctr,
+                       (uint32_t)sparse_fill_chunks(pairs));
+    return hipGetLastError();
+}
+
 hipError_t launch_sparse_fill_value(uint2 *out, uint64_t pairs, uint32_t numer, uint32_t denom, uint32_t blocks_per_cu, uint32_t cus,
                                     hipStream_t stream)
 {

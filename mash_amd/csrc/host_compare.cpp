@@ -526,6 +526,7 @@ struct SparseJobRun {
     uint64_t want = 0;
     unsigned long long h[3] = {0, 0, 0};
     bool nothing_to_find = false;
+    bool prefilled = false;                                 // {0, s} is in every slot of the output already (prefill)
 
     SparseJobRun(mg_ctx *c, const mg_table *r, const mg_table *cl, uint64_t rb, uint64_t re, bool tri, uint32_t sketch_size, mg_counts *out, bool forced,
                  bool forced_join, bool *handled_out, SparseJob *list_job)
@@ -547,6 +548,8 @@ struct SparseJobRun {
     int leave() { stop = true; return MG_OK; }              // not (or no longer) this engine's job
 
     int open_index();
+    int prefill();
+    int end_prefill(bool finish);
     int row_side();
     int find_plan();
     int keep_plan();
@@ -590,6 +593,11 @@ int SparseJobRun::open_index()
         for (const mg_table::Sparse *have : cols->sparse)
             if (have->s == s && !have->clustered) clustered = false;
     if (const char *e = ctx_opt(ctx, "MASHGPU_COMPARE_CLUSTER")) clustered = clustered && atoi(e) != 0;
+    bool cold = true;                                       // no index of this sketch size yet: it is built now
+    for (const mg_table::Sparse *have : cols->sparse) cold = cold && have->s != s;
+    uint64_t aside_min = 100000000ull;                       // (below: the fill is a fraction of a millisecond)
+    if (const char *e = ctx_opt(ctx, "MASHGPU_FILL_ASIDE_MIN_PAIRS")) aside_min = strtoull(e, nullptr, 10);
+    if (cold && !job && out_dev && pairs >= aside_min && mg::sparse_fill_chunks(pairs) < mg::kFillStop / 2u && (rc = prefill()) != MG_OK) return rc;
     rc = table_sparse_index(ctx, cols, s, clustered, &ix, clustered ? (uint32_t)row_begin : 0u);
     if (rc != MG_OK) return rc;
     if (!ix->usable && clustered) {                         // (whatever stopped it may not stop the plain variant)
@@ -604,6 +612,56 @@ int SparseJobRun::open_index()
     if (job && (ix->copies || ix->has_empty)) return leave();
     if (job && !triangle && !ix->dgroups_host.empty()) return leave();
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return MG_OK;
+}
+
+// The constant of a matrix job -- {0, s} for every pair that shares no hash -- depends on nothing the index says: while the
+// index is built it is written on a stream of its own, 64 KB chunks taken from a counter by a few workgroups -- a quarter of
+// the CUs have one: a fill at full speed keeps the memory's queues full of writes and the build's loads, kernels that live
+// on round trips, wait behind them (round 5 measured exactly that with 2 - 16 workgroups per CU and dropped it; 64
+// workgroups write ~4 TB/s and the build takes 10 ms instead of 8, with the fill's 6.7 ms gone).  What is left when the build
+// has ended is taken from the same counter at full speed on the context's stream (end_prefill), so a pace that is too slow
+// costs little.  C3 per table: 15.4 -> 11.8 ms (tools/aside_sweep.sh).
+// MASHGPU_FILL_ASIDE = "<workgroups>[,<naps of 64 cycles per 4 KB>[,<work-items>]]"; 0: off.
+int SparseJobRun::prefill()
+{
+    uint32_t wgs = std::max(16u, (uint32_t)ctx->cu_count / 4u), naps = 1, threads = 256;
+    if (const char *e = ctx_opt(ctx, "MASHGPU_FILL_ASIDE")) {
+        if (atoi(e) == 0) return MG_OK;
+        if (sscanf(e, "%u,%u,%u", &wgs, &naps, &threads) < 1 || wgs == 0 || (threads != 64 && threads != 128 && threads != 256)) return MG_OK;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->aux) {
+        if (hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->aux_go, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->aux_done, hipEventDisableTiming) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&ctx->aux_ctr), 256) != hipSuccess) {
+            (void)hipGetLastError();
+            if (ctx->aux) hipStreamDestroy(ctx->aux);
+            ctx->aux = nullptr;
+            return MG_OK;
+        }
+    }
+    HIP_TRY(ctx, hipMemsetAsync(ctx->aux_ctr, 0, 4, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->aux_go, ctx->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ctx->aux_go, 0));
+    prof_begin(ctx, ctx->prof_fill_aside, ctx->aux);
+    HIP_TRY(ctx, mg::launch_sparse_fill_chunks(reinterpret_cast<uint2 *>(out_dev), pairs, 0u, s, wgs, naps, ctx->aux_ctr, ctx->aux, threads));
+    prof_end(ctx, ctx->prof_fill_aside, ctx->aux);
+    HIP_TRY(ctx, hipEventRecord(ctx->aux_done, ctx->aux));
+    prefilled = true;
+    return MG_OK;
+}
+
+// The end of the fill beside the build: what is left of it at full speed on the context's stream (finish), or nothing more --
+// somebody else writes the whole output, or the constant was the wrong one -- and the stream waits for the chunks in flight.
+int SparseJobRun::end_prefill(bool finish)
+{
+    if (!prefilled) return MG_OK;
+    prefilled = false;
+    hipError_t e;
+    if (finish) e = mg::launch_sparse_fill_chunks(reinterpret_cast<uint2 *>(out_dev), pairs, 0u, s, (uint32_t)ctx->cu_count * 16u, 0u, ctx->aux_ctr, ctx->stream);
+    else e = hipMemsetAsync(ctx->aux_ctr, 0x80, 4, ctx->stream);             // (0x80808080 >= kFillStop)
+    const hipError_t e2 = hipStreamWaitEvent(ctx->stream, ctx->aux_done, 0);
+    if (e != hipSuccess || e2 != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare (fill beside the build): ") + hipGetErrorString(e != hipSuccess ? e : e2));
     return MG_OK;
 }
 
@@ -973,6 +1031,7 @@ int SparseJobRun::join()
         fresh.shared = shared_job;
     }
     if (!take) return MG_OK;
+    if ((rc = end_prefill(false)) != MG_OK) return rc;       // (the join engine writes every pair itself)
     if (job) {
         if (first) { fresh.join = true; keep_plan(); }
         return leave();
@@ -1072,9 +1131,7 @@ int SparseJobRun::join()
 int SparseJobRun::fill_and_dense()
 {
     // ---- fill.  The candidates' results are kept in list order and scattered into the output after it.
-    // (Round 5 measured the fill beside the index build by tiles -- kernels that wait for round trips far more than they move
-    // bytes -- on a stream of its own, 2 to 16 of its workgroups per CU: the step took 15.8 - 16.6 ms against 16.0 one after
-    // the other; while 40 GB of writes are queued the build's loads simply wait behind them.  The code is gone.)
+    // (Beside the index build the fill runs on a stream of its own, see prefill: then what is left of it ends here.)
     // (Side by side with discover + merge on a second stream the fill was MEASURED to gain nothing -- discover's
     // loads queue behind 40 GB of writes, and a kernel that merely ends under the fill waits milliseconds for the
     // L2's write-back, profiles/r03_sparse_phases.json, r03_overlap_trace.txt -- so the phases run one after the other.)
@@ -1082,10 +1139,15 @@ int SparseJobRun::fill_and_dense()
         prof_begin(ctx, ctx->prof_fill);
         // a table of n copies of one sketch: the fill IS the answer, {c, c} in every slot, written once
         const bool all_copies = triangle && ix->one_class != 0;
-        clk_begin(CK_FILL);
-        hipError_t e = all_copies ? mg::launch_sparse_fill_value(a.out, pairs, ix->one_class, ix->one_class, 16u, (uint32_t)ctx->cu_count, ctx->stream)
-                                  : mg::launch_sparse_fill_value(a.out, pairs, 0u, s, 16u, (uint32_t)ctx->cu_count, ctx->stream);
-        clk_end(CK_FILL);
+        hipError_t e = hipSuccess;
+        const bool beside = prefilled;
+        if ((rc = end_prefill(!all_copies)) != MG_OK) return rc;
+        if (all_copies || !beside) {
+            clk_begin(CK_FILL);
+            e = all_copies ? mg::launch_sparse_fill_value(a.out, pairs, ix->one_class, ix->one_class, 16u, (uint32_t)ctx->cu_count, ctx->stream)
+                           : mg::launch_sparse_fill_value(a.out, pairs, 0u, s, 16u, (uint32_t)ctx->cu_count, ctx->stream);
+            clk_end(CK_FILL);
+        }
         if (e == hipSuccess && nshort_rows && !ix->short_rows_host.empty() && !all_copies)      // (copies of a SHORT sketch are {c, c} too, not {0, 2c})
             e = mg::launch_sparse_fill_short(a.out, short_rows_dev, short_rcnt_dev, nshort_rows, ix->short_rows, ix->short_cnt,
                                              (uint32_t)ix->short_rows_host.size(), a.row_begin, a.ncols, a.triangle, a.out_base, s, a.inv, ctx->stream);
@@ -1215,6 +1277,8 @@ void SparseJobRun::learn()
 int SparseJobRun::run()
 {
     struct Learn { SparseJobRun *r; ~Learn() { r->learn(); } } learn_at_exit{this};
+    // (whoever takes the job from here -- another engine, an error -- finds no write to the output in flight)
+    struct Aside { SparseJobRun *r; ~Aside() { (void)r->end_prefill(false); } } aside_at_exit{this};
     if ((rc = open_index()) != MG_OK || stop) return rc;
     if ((rc = row_side()) != MG_OK || stop) return rc;
     if ((rc = find_plan()) != MG_OK || stop) return rc;

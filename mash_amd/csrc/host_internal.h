@@ -75,6 +75,7 @@ struct mg_ctx {
     std::vector<ProfRec> prof_compare, prof_sketch;
     // phases of the inverted-index compare engine (compare_sparse.hip), each its own kernel
     std::vector<ProfRec> prof_fill, prof_discover, prof_merge, prof_index, prof_dense, prof_join;
+    std::vector<ProfRec> prof_fill_aside;                  // the fill beside the index build, on `aux` (SparseJobRun::prefill)
     void *pin = nullptr;                                    // ctx_pinned
     size_t pin_cap = 0;
     // Entry points lock the context: any number of host threads may drive one context, one call at
@@ -105,6 +106,10 @@ struct mg_ctx {
     struct CostClock { hipEvent_t a = nullptr, b = nullptr; };
     CostClock cost_clk[5];
     uint64_t cost_updates = 0;
+    // the constant fill of a matrix job beside the index build (host_compare.cpp: SparseJobRun::prefill)
+    hipStream_t aux = nullptr;
+    hipEvent_t aux_go = nullptr, aux_done = nullptr;
+    uint32_t *aux_ctr = nullptr;                            // the next chunk of the output nobody has taken yet
 };
 
 struct mg_table {

@@ -207,6 +207,7 @@ void mg_ctx_destroy(mg_ctx *ctx)
     ctx_trim(ctx);
     for (auto &b : ctx->blk_live) hipFree(b.p);
     if (ctx->pin) hipHostFree(ctx->pin);
+    if (ctx->aux) { hipStreamDestroy(ctx->aux); hipEventDestroy(ctx->aux_go); hipEventDestroy(ctx->aux_done); hipFree(ctx->aux_ctr); ctx->aux = nullptr; }
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -423,7 +424,7 @@ int mg_prof_enable(mg_ctx *ctx, int on)
 void mg_prof_reset(mg_ctx *ctx)
 {
     if (!ctx) return;
-    for (auto *v : {&ctx->prof_compare, &ctx->prof_sketch, &ctx->prof_fill, &ctx->prof_discover, &ctx->prof_merge, &ctx->prof_index, &ctx->prof_dense, &ctx->prof_join}) {
+    for (auto *v : {&ctx->prof_compare, &ctx->prof_sketch, &ctx->prof_fill, &ctx->prof_discover, &ctx->prof_merge, &ctx->prof_index, &ctx->prof_dense, &ctx->prof_join, &ctx->prof_fill_aside}) {
         for (auto &r : *v) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
         v->clear();
     }
@@ -437,6 +438,7 @@ double mg_prof_avg_ms(mg_ctx *ctx, const char *name, uint64_t *launches_out)
     if (strcmp(name, "compare") == 0) v = &ctx->prof_compare;
     else if (strcmp(name, "sketch") == 0) v = &ctx->prof_sketch;
     else if (strcmp(name, "compare_fill") == 0) v = &ctx->prof_fill;
+    else if (strcmp(name, "compare_fill_aside") == 0) v = &ctx->prof_fill_aside;
     else if (strcmp(name, "compare_discover") == 0) v = &ctx->prof_discover;
     else if (strcmp(name, "compare_merge") == 0) v = &ctx->prof_merge;
     else if (strcmp(name, "compare_index") == 0) v = &ctx->prof_index;

@@ -56,6 +56,23 @@ def test_inverted_index_engine_cold_pass_with_pmc():
     assert len(json.dumps(c)) < 600
 
 
+def test_per_table_step_with_the_fill_beside_the_index_build():
+    """A per-table step writes its constant on a stream of its own while the index is built (compare_fill_aside) and ends what
+    is left behind the build (compare_fill): the aside launch lies INSIDE the index phase -- the pass is the sum of the others --
+    and the dominant kernel's 8 B per pair are priced over both launches' durations."""
+    eng = FakeEngine({"compare_index": (10.1, 2), "compare_fill_aside": (9.8, 2), "compare_fill": (0.45, 2), "compare_discover": (0.36, 2),
+                      "compare_dense": (0.24, 2), "compare_merge": (0.14, 2)})
+    pm = _pmc()
+    pm["kernels"]["mg::sp_fill_chunks_kernel"] = {"hbm_read_bytes_per_pass": 2e6, "hbm_write_bytes_per_pass": PAIRS * 8 + 1e7, "ports": {}, "ms_per_pass": 10.25}
+    r = bench.compare_roofline(eng, PAIRS, N, S, 2, pm)
+    assert r["kernel"] == "mg::sp_fill_chunks_kernel" and r["kernel_ms"] == pytest.approx(10.25) and "index build" in r["beside"]
+    assert r["achieved"] == pytest.approx(PAIRS * 8 / 10.25e-3 / 1e9, rel=1e-3) and r["frac"] == pytest.approx(r["achieved"] / 8000.0, abs=1e-4)
+    assert r["pass"]["ms"] == pytest.approx(10.1 + 0.45 + 0.36 + 0.24 + 0.14, abs=1e-3)
+    assert r["traffic"] == pytest.approx(PAIRS * 8, rel=0.01)
+    c = bench.compact_roofline(r)
+    assert c["beside"] == r["beside"] and c["pass"]["phases_ms"]["fill_aside"] == 9.8 and len(json.dumps(c)) < 800
+
+
 def test_without_pmc_and_table_of_copies_and_tile_engine():
     r = bench.compare_roofline(FakeEngine({"compare_fill": (7.0, 3), "compare_discover": (2.4, 3), "compare_merge": (0.09, 3)}), PAIRS, N, S, 3, None)
     assert r["traffic"] is None and r["pass"]["traffic"] is None and r["pass"]["traffic_over_compulsory"] is None and "ports" not in r

@@ -1499,6 +1499,77 @@ def test_table_invalidate_after_the_buffers_changed(eng, oracle, monkeypatch):
     eng.trim()
 
 
+@pytest.mark.parametrize("pace", [None, "2,0", "48,300", "4096,0,64"])
+def test_the_fill_beside_the_index_build_changes_nothing(eng, oracle, pace, monkeypatch):
+    """A matrix job on a table without an index writes its constant -- {0, s} for every pair -- on a stream of its own WHILE
+    the index is built (SparseJobRun::prefill: chunks of the output taken from a counter, what is left ended at full speed on
+    the context's stream).  Switched on for small tables here (by default jobs of 1e8 pairs and more), at the default pace, with
+    two workgroups, with a pace so slow that the build ends first, and at full speed: a collection (the inverted index), one
+    species (the join engine takes the job from under the fill), a table of nothing but copies (the constant is another one),
+    a table the index refuses (a hash equal to the padding value: the tile engine), a range of the last rows (the view), a
+    rect job, and an output that starts 8 bytes off a 16-byte boundary -- every pair against the oracle (compareSketches,
+    CommandDistance.cpp:347-385); a warm pass launches nothing aside."""
+    import torch
+    monkeypatch.setenv("MASHGPU_FILL_ASIDE_MIN_PAIRS", "1")
+    if pace:
+        monkeypatch.setenv("MASHGPU_FILL_ASIDE", pace)
+    eng.prof_enable(True)
+    n, s = 3000, 256
+    tables = {"collection": synth.clustered_sketches(n, s, clusters=60, seed=21, pool=400, private=100),
+              "species": synth.species_sketches(n, s, seed=22)}
+    one, _, _ = synth.random_sketches(1, s, seed=4)
+    tables["copies"] = (np.repeat(one[:1], n, axis=0), np.full(n, s, dtype=np.uint32), np.full(n, 10 ** 6, dtype=np.uint64))
+    ref, rn, rl = (x.copy() for x in tables["collection"])
+    ref[5, int(rn[5]) - 1] = np.uint64(abi.HASH_PAD)         # (the largest value of a row: the padding value itself)
+    tables["refused"] = (ref, rn, rl)
+    for name, (table, nhash, lengths) in tables.items():
+        numer, denom = _oracle_tri(oracle, table, nhash, lengths, 0, n)
+        t = eng.table_upload(table, nhash, lengths)
+        eng.prof_reset()
+        got = eng.compare_tri_host(t)
+        assert eng.prof_avg_ms("compare_fill_aside")[1] == 1, name
+        assert np.array_equal(got["numer"], numer) and np.array_equal(got["denom"], denom), name
+        if name == "species":
+            assert eng.prof_avg_ms("compare_join")[1] == 1
+        eng.prof_reset()
+        got = eng.compare_tri_host(t)                       # warm: the index (or its refusal) is there
+        assert eng.prof_avg_ms("compare_fill_aside")[1] == 0, name
+        assert np.array_equal(got["numer"], numer) and np.array_equal(got["denom"], denom), name
+        if name == "collection":
+            # the last rows on a fresh table: the index of the view, the fill beside it
+            t.invalidate()
+            rb = 900                                        # (4.09e6 pairs: still the index's)
+            eng.prof_reset()
+            part = eng.compare_tri_host(t, rb, n)
+            base = rb * (rb - 1) // 2
+            assert eng.prof_avg_ms("compare_fill_aside")[1] == 1
+            assert np.array_equal(part["numer"], numer[base:]) and np.array_equal(part["denom"], denom[base:])
+            # ... and into device memory 8 bytes off a 16-byte boundary
+            t.invalidate()
+            pairs = n * (n - 1) // 2
+            buf = torch.zeros((pairs + 3, 2), dtype=torch.int32, device="cuda")
+            eng.compare_tri_dev(t, 0, n, buf.data_ptr() + 8)
+            torch.cuda.synchronize()
+            dev = buf.cpu().numpy()
+            assert np.array_equal(dev[1:pairs + 1, 0].astype(np.uint32), numer) and np.array_equal(dev[1:pairs + 1, 1].astype(np.uint32), denom)
+            assert not dev[0].any() and not dev[pairs + 1:].any()
+            # rect: a table of queries against the collection, the collection's index not built yet
+            t.invalidate()
+            q = eng.table_upload(table[100:1700], nhash[100:1700], lengths[100:1700])
+            eng.prof_reset()
+            rect = eng.compare_rect_host(t, q)
+            assert eng.prof_avg_ms("compare_fill_aside")[1] == 1
+            for qi in (0, 7, 800, 1599):                    # (pairs of the triangle, read across)
+                a = qi + 100
+                for b in (0, 99, 101, 1500, 2999):
+                    hi, lo = max(a, b), min(a, b)
+                    k = hi * (hi - 1) // 2 + lo
+                    assert (int(rect["numer"][qi, b]), int(rect["denom"][qi, b])) == (int(numer[k]), int(denom[k])), (qi, b)
+            q.free()
+        t.free()
+    eng.prof_enable(False)
+
+
 @pytest.mark.parametrize("kernel", ["merged", "sparse"])
 @pytest.mark.parametrize("count", [1, 24, 1000])
 def test_compare_table_of_copies(eng, oracle, kernel, count, monkeypatch):

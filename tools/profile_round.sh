@@ -36,7 +36,7 @@ find $OUT -name "*kernel_trace.csv" -path "*${TAG}_*" -delete 2>/dev/null
 [ "${STATS_ONLY:-0}" = 1 ] && exit 0
 cd $ROOT
 SRC="mash_amd/csrc/compare_sparse.hip mash_amd/csrc/compare_dense.hip mash_amd/csrc/compare_merged.hip mash_amd/csrc/compare_internal.h mash_amd/csrc/index_build.hip mash_amd/csrc/compare_join.hip"
-PASS="jn_tile_kernel,sp_fill_value,sp_fill_short,sp_class_pairs,sp_discover_kernel,sp_chunks,sp_pack_costs,sp_merge_pack,sp_merge_rows,sp_merge_kernel,sp_scatter_kernel,dn_pairs,compare_merged"
+PASS="jn_tile_kernel,sp_fill_value,sp_fill_chunks,sp_fill_short,sp_class_pairs,sp_discover_kernel,sp_chunks,sp_pack_costs,sp_merge_pack,sp_merge_rows,sp_merge_kernel,sp_scatter_kernel,dn_pairs,compare_merged"
 BUILD="mg::ix_,jn_emit,jn_heads,jn_groups,jn_gend,jn_levels,jn_labels,jn_jump,jn_order,jn_shared,sp_fill_entries,sp_tie_,sp_heads,sp_index_scatter,sp_stat_reduce,sp_fill_u32,sp_row_digest,sp_dup_flags,sp_row_equal,sp_row_key,sp_order_from_keys,sp_entry_counts,sp_offsets,dn_group_rows,row_classes,cl_emit,cl_minrow,cl_jump,cl_order_keys,cl_split_keys,cl_gather_rows,dn_neighbor,dn_leader,dn_sublists,dn_universe,dn_encode,ROCPRIM_400200"
 for tag in $LEGS; do
     leg=${tag%_cold}

@@ -33,7 +33,7 @@ for name, a, b in (("whole", 0, n), ("range", rb, re)):
     eng.compare_tri_dev(t, a, b, out.data_ptr())
     torch.cuda.synchronize()
     cold = (time.perf_counter() - t0) * 1e3
-    ph = {p: round(eng.prof_avg_ms("compare_" + p)[0] * eng.prof_avg_ms("compare_" + p)[1], 3) for p in ("index", "discover", "fill", "dense", "merge", "join")}
+    ph = {p: round(eng.prof_avg_ms("compare_" + p)[0] * eng.prof_avg_ms("compare_" + p)[1], 3) for p in ("index", "discover", "fill", "fill_aside", "dense", "merge", "join")}
     eng.prof_reset()
     t0 = time.perf_counter()
     for _ in range(3):
