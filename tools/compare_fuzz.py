@@ -67,7 +67,11 @@ def main():
     rng = np.random.default_rng(a.seed)
     engines = [("generic", {"MASHGPU_COMPARE_KERNEL": "generic"}), ("plain", {"MASHGPU_COMPARE_KERNEL": "merged", "MASHGPU_COMPARE_WINDOWS": "0"}),
                ("windows", {"MASHGPU_COMPARE_KERNEL": "merged", "MASHGPU_COMPARE_WINDOWS": "1"}), ("default", {}), ("sparse", {"MASHGPU_COMPARE_KERNEL": "sparse"}),
-               ("join", {"MASHGPU_COMPARE_KERNEL": "join"})]
+               ("join", {"MASHGPU_COMPARE_KERNEL": "join"}),
+               # the per-table job of a large table: the table's derived data dropped, the fill beside the index build at some pace
+               ("sparse, fill beside the build", {"MASHGPU_COMPARE_KERNEL": "sparse", "MASHGPU_FILL_ASIDE_MIN_PAIRS": "1", "MASHGPU_FILL_ASIDE": None}),
+               ("default, fill beside the build", {"MASHGPU_FILL_ASIDE_MIN_PAIRS": "1", "MASHGPU_FILL_ASIDE": None})]
+    knobs = ("MASHGPU_COMPARE_KERNEL", "MASHGPU_COMPARE_WINDOWS", "MASHGPU_FILL_ASIDE_MIN_PAIRS", "MASHGPU_FILL_ASIDE")
     t0 = time.time()
     bad = ran = 0
     for case in range(a.n):
@@ -93,9 +97,14 @@ def main():
         else:
             pairs = n * (n - 1) // 2
         ref = None
+        paces = [str(rng.choice(["1,0", "2,3", "7,0,64", "64,1", "64,40", "300,0,128", "4096,0"])) for _ in range(2)]
         for name, env in engines:
-            for k in ("MASHGPU_COMPARE_KERNEL", "MASHGPU_COMPARE_WINDOWS"):
+            for k in knobs:
                 os.environ.pop(k, None)
+            env = dict(env)
+            if "MASHGPU_FILL_ASIDE" in env:
+                env["MASHGPU_FILL_ASIDE"] = paces.pop()
+                t.invalidate()
             os.environ.update(env)
             out = torch.full((max(pairs, 1), 2), -1, dtype=torch.int32, device=dev)
             torch.cuda.synchronize()                             # the fill ran on torch's stream
@@ -133,7 +142,7 @@ def main():
         t.free()
         if rect:
             tq.free()
-    for k in ("MASHGPU_COMPARE_KERNEL", "MASHGPU_COMPARE_WINDOWS"):
+    for k in knobs:
         os.environ.pop(k, None)
     print("tables: %d  engine disagreements: %d  [seed %d, %.0f s]" % (ran, bad, a.seed, time.time() - t0))
     sys.exit(1 if bad else 0)
