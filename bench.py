@@ -139,6 +139,9 @@ def compare_roofline(eng, pairs, n, s, steps, pmc):
             # queue behind the writes), one at full speed for what is left -- their durations added; the kernel alone, a
             # further pass over the indexed table (roofline_warm), writes at 0.75 of the peak
             r["beside"] = "the index build, on a stream of its own (%.3f ms), then what is left (%.3f ms)" % (aside["ms_per_pass"], phases["fill"]["ms_per_pass"])
+            # (rocprofv3 --stats averages over the launches: two per pass)
+            r["kernel_launches_per_pass"] = 2
+            r["kernel_avg_launch_ms"] = round(f / 2.0, 4)
     if pmc:
         r["ports"] = {k: dict(v.get("ports", {}), ms_per_pass=v.get("ms_per_pass"), effective_clock_ghz=v.get("effective_clock_ghz"),
                               hbm_bytes_per_pass=(v.get("hbm_read_bytes_per_pass", 0) + v.get("hbm_write_bytes_per_pass", 0)))
@@ -155,7 +158,7 @@ def compact_roofline(r):
             "unit": r["unit"], "frac": r["frac"], "traffic": r["traffic"],
             # the WHOLE step against the same roof: compulsory bytes (every pair written once + the table read
             # once) / the timed step / the HBM peak; and what the per-table index costs of it
-            "step_frac": r.get("step_frac"), "index_ms": r.get("index_ms"), **({"beside": r["beside"]} if r.get("beside") else {}),
+            "step_frac": r.get("step_frac"), "index_ms": r.get("index_ms"), **({"beside": r["beside"], "kernel_launches_per_pass": r["kernel_launches_per_pass"], "kernel_avg_launch_ms": r["kernel_avg_launch_ms"]} if r.get("beside") else {}),
             "pass": {"ms": r["pass"]["ms"], "phases_ms": {k: round(v["ms_per_pass"], 3) for k, v in r["phases"].items()},
                      "traffic_over_compulsory": r["pass"]["traffic_over_compulsory"],
                      "output_write_bound_frac": r["pass"]["output_write_bound_frac"]}}

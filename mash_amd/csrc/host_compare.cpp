@@ -526,7 +526,9 @@ struct SparseJobRun {
     uint64_t want = 0;
     unsigned long long h[3] = {0, 0, 0};
     bool nothing_to_find = false;
-    bool prefilled = false;                                 // {0, s} is in every slot of the output already (prefill)
+    bool prefilled = false;                                 // the fill runs beside the index build (prefill): its constant, its counter
+    uint32_t aside_numer = 0, aside_denom = 0, aside_wgs = 0, aside_naps = 0, aside_threads = 256;
+    uint32_t *aside_ctr = nullptr;
 
     SparseJobRun(mg_ctx *c, const mg_table *r, const mg_table *cl, uint64_t rb, uint64_t re, bool tri, uint32_t sketch_size, mg_counts *out, bool forced,
                  bool forced_join, bool *handled_out, SparseJob *list_job)
@@ -549,6 +551,8 @@ struct SparseJobRun {
 
     int open_index();
     int prefill();
+    int aside_launch(uint32_t numer, uint32_t denom, uint32_t *ctr);
+    void aside_other_constant(uint32_t c);
     int end_prefill(bool finish);
     int row_side();
     int find_plan();
@@ -640,26 +644,45 @@ int SparseJobRun::prefill()
             return MG_OK;
         }
     }
-    HIP_TRY(ctx, hipMemsetAsync(ctx->aux_ctr, 0, 4, ctx->stream));
+    aside_wgs = wgs; aside_naps = naps; aside_threads = threads;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->aux_ctr, 0, 128, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->aux_go, ctx->stream));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ctx->aux_go, 0));
+    if ((rc = aside_launch(0u, s, ctx->aux_ctr)) != MG_OK) return rc;
+    ctx->aside_all_copies = [this](uint32_t c) { aside_other_constant(c); };
+    return MG_OK;
+}
+
+int SparseJobRun::aside_launch(uint32_t numer, uint32_t denom, uint32_t *ctr)
+{
     prof_begin(ctx, ctx->prof_fill_aside, ctx->aux);
-    HIP_TRY(ctx, mg::launch_sparse_fill_chunks(reinterpret_cast<uint2 *>(out_dev), pairs, 0u, s, wgs, naps, ctx->aux_ctr, ctx->aux, threads));
+    HIP_TRY(ctx, mg::launch_sparse_fill_chunks(reinterpret_cast<uint2 *>(out_dev), pairs, numer, denom, aside_wgs, aside_naps, ctr, ctx->aux, aside_threads));
     prof_end(ctx, ctx->prof_fill_aside, ctx->aux);
     HIP_TRY(ctx, hipEventRecord(ctx->aux_done, ctx->aux));
+    aside_numer = numer; aside_denom = denom; aside_ctr = ctr;
     prefilled = true;
     return MG_OK;
+}
+
+// The build has found the table to be nothing but copies of one sketch of c hashes (host_index.cpp: find_copies): every pair is
+// {c, c}.  The launch beside the build ends at its next chunk and another one starts behind it, with that constant and a
+// counter of its own.  (A triangle job's matter: a rect job's queries are not the table's rows.)
+void SparseJobRun::aside_other_constant(uint32_t c)
+{
+    if (!prefilled || !triangle) return;
+    if (hipMemsetAsync(aside_ctr, 0x80, 4, ctx->stream) != hipSuccess || aside_launch(c, c, ctx->aux_ctr + 16) != MG_OK) (void)hipGetLastError();
 }
 
 // The end of the fill beside the build: what is left of it at full speed on the context's stream (finish), or nothing more --
 // somebody else writes the whole output, or the constant was the wrong one -- and the stream waits for the chunks in flight.
 int SparseJobRun::end_prefill(bool finish)
 {
+    ctx->aside_all_copies = nullptr;
     if (!prefilled) return MG_OK;
     prefilled = false;
     hipError_t e;
-    if (finish) e = mg::launch_sparse_fill_chunks(reinterpret_cast<uint2 *>(out_dev), pairs, 0u, s, (uint32_t)ctx->cu_count * 16u, 0u, ctx->aux_ctr, ctx->stream);
-    else e = hipMemsetAsync(ctx->aux_ctr, 0x80, 4, ctx->stream);             // (0x80808080 >= kFillStop)
+    if (finish) e = mg::launch_sparse_fill_chunks(reinterpret_cast<uint2 *>(out_dev), pairs, aside_numer, aside_denom, (uint32_t)ctx->cu_count * 16u, 0u, aside_ctr, ctx->stream);
+    else e = hipMemsetAsync(aside_ctr, 0x80, 4, ctx->stream);                // (0x80808080 >= kFillStop)
     const hipError_t e2 = hipStreamWaitEvent(ctx->stream, ctx->aux_done, 0);
     if (e != hipSuccess || e2 != hipSuccess) return fail(ctx, MG_ERR_HIP, std::string("compare (fill beside the build): ") + hipGetErrorString(e != hipSuccess ? e : e2));
     return MG_OK;
@@ -1140,9 +1163,10 @@ int SparseJobRun::fill_and_dense()
         // a table of n copies of one sketch: the fill IS the answer, {c, c} in every slot, written once
         const bool all_copies = triangle && ix->one_class != 0;
         hipError_t e = hipSuccess;
-        const bool beside = prefilled;
-        if ((rc = end_prefill(!all_copies)) != MG_OK) return rc;
-        if (all_copies || !beside) {
+        // (beside the index build the fill has run already, with the right constant unless the job's rows are not the table's)
+        const bool beside = prefilled && (all_copies ? aside_numer == ix->one_class && aside_denom == ix->one_class : aside_numer == 0u);
+        if ((rc = end_prefill(beside)) != MG_OK) return rc;
+        if (!beside) {
             clk_begin(CK_FILL);
             e = all_copies ? mg::launch_sparse_fill_value(a.out, pairs, ix->one_class, ix->one_class, 16u, (uint32_t)ctx->cu_count, ctx->stream)
                            : mg::launch_sparse_fill_value(a.out, pairs, 0u, s, 16u, (uint32_t)ctx->cu_count, ctx->stream);

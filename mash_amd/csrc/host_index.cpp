@@ -434,6 +434,7 @@ int SparseIndexBuild::find_copies()
         }
         sp->cls_members = tot;
         if (ncls == 1 && tot == n && cnt_true[0] > 0) sp->one_class = (uint32_t)cnt_true[0];
+        if (sp->one_class && ctx->aside_all_copies) ctx->aside_all_copies(sp->one_class);     // (a fill beside this build has the wrong constant)
     }
     return MG_OK;
 }

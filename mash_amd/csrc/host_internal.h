@@ -16,6 +16,7 @@
 #include <condition_variable>
 #include <memory>
 #include <iterator>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <queue>
@@ -109,7 +110,10 @@ struct mg_ctx {
     // the constant fill of a matrix job beside the index build (host_compare.cpp: SparseJobRun::prefill)
     hipStream_t aux = nullptr;
     hipEvent_t aux_go = nullptr, aux_done = nullptr;
-    uint32_t *aux_ctr = nullptr;                            // the next chunk of the output nobody has taken yet
+    uint32_t *aux_ctr = nullptr;                            // the next chunk of the output nobody has taken yet (two counters, 64 B apart)
+    // set while a job's fill runs beside its index build: the build calls it when the table turns out to be nothing but
+    // copies of one sketch of c hashes -- the fill's constant is {c, c} then, not {0, s}
+    std::function<void(uint32_t)> aside_all_copies;
 };
 
 struct mg_table {

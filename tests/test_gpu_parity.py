@@ -1369,7 +1369,7 @@ def test_dispatch_costs_are_learned_per_context(eng, monkeypatch, capfd):
     """the cost table of the compare dispatch (SparseCosts) is a per-context copy of the defaults that
     moves half way towards what the context's own launches measure -- the phases of every job seen for the first time are
     timed, those of a millisecond and more count -- and never further than a factor of four from the defaults.  Shown on a job
-    whose fill runs for milliseconds (6.5e8 pairs, on a table that has its index: beside an index build the fill is not timed):
+    whose fill runs for more than a millisecond (1.15e9 pairs, on a table that has its index: beside an index build the fill is not timed):
     the context reports a fill rate that is no longer the default's and lies
     inside the clamp; a small job teaches nothing (its phases are their launches); MASHGPU_COSTS_FIXED keeps the defaults;
     the results do not depend on any of it."""
@@ -1383,7 +1383,7 @@ def test_dispatch_costs_are_learned_per_context(eng, monkeypatch, capfd):
         lines = [l for l in err.splitlines() if l.startswith("compare costs (context")]
         return [float(re.search(r"fill ([0-9.e+-]+) B/s", l).group(1)) for l in lines]
 
-    n, s = 36000, 32
+    n, s = 48000, 32                                        # (9.2 GB of fill: 1.4 ms and more, the floor is 1 ms)
     h, nh, ln = synth_torch.random_sketch_table(n, s, device=dev)
     out = torch.empty((n * (n - 1) // 2, 2), dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
@@ -1530,7 +1530,9 @@ def test_the_fill_beside_the_index_build_changes_nothing(eng, oracle, pace, monk
         t = eng.table_upload(table, nhash, lengths)
         eng.prof_reset()
         got = eng.compare_tri_host(t)
-        assert eng.prof_avg_ms("compare_fill_aside")[1] == 1, name
+        # (nothing but copies: the build says so, the launch ends at its next chunk and another one writes {c, c})
+        assert eng.prof_avg_ms("compare_fill_aside")[1] == (2 if name == "copies" else 1), name
+        assert eng.prof_avg_ms("compare_fill")[1] == (0 if name in ("species", "refused") else 1), name
         assert np.array_equal(got["numer"], numer) and np.array_equal(got["denom"], denom), name
         if name == "species":
             assert eng.prof_avg_ms("compare_join")[1] == 1
