@@ -523,7 +523,12 @@ void mg_dscreen_free(mg_dscreen *d);
 /* ---- timing hook for bench.py ----------------------------------------------
  * Average duration (ms) of the last `name` kernel launches recorded with HIP
  * events on the context's stream since mg_prof_reset; name = "compare" or
- * "sketch".  launches_out receives the number of launches averaged. */
+ * "sketch", or a phase of the inverted-index compare engine: "compare_index",
+ * "compare_discover", "compare_fill", "compare_dense", "compare_merge",
+ * "compare_join", and "compare_fill_aside" -- the fill's launch beside the
+ * index build of a per-table job, on a stream of the library's own (ordered
+ * with the context's stream by events: the caller sees one stream).
+ * launches_out receives the number of launches averaged. */
 int    mg_prof_enable(mg_ctx *ctx, int on);
 void   mg_prof_reset(mg_ctx *ctx);
 double mg_prof_avg_ms(mg_ctx *ctx, const char *name, uint64_t *launches_out);

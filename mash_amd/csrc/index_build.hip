@@ -230,14 +230,21 @@ __global__ __launch_bounds__(IX_NT) void ix_tile_count_kernel(IxGeom g, const ui
 // K2a: per bucket the blocks' counts become exclusive prefixes over the blocks; tot[bucket] = the bucket's entries
 __global__ __launch_bounds__(256) void ix_col_scan_kernel(IxGeom g, uint32_t *cnt, uint32_t *tot)
 {
+    // (sixteen blocks' counts are read before the first prefix is written: a load behind every store -- the two may alias, the
+    //  compiler keeps their order -- was a round trip per block, 82 us for C3's 196 blocks and 260 beside the fill)
     const uint32_t b = blockIdx.x * 256u + threadIdx.x;
     if (b < g.Bp) {
         uint32_t run = 0;
-        for (uint32_t blk = 0; blk < g.nblk; blk++) {
-            uint32_t *p = cnt + (uint64_t)blk * g.Bp + b;
-            const uint32_t c = *p;
-            *p = run;
-            run += c;
+        for (uint32_t blk0 = 0; blk0 < g.nblk; blk0 += 16u) {
+            uint32_t c[16];
+#pragma unroll
+            for (uint32_t k = 0; k < 16u; k++) c[k] = blk0 + k < g.nblk ? cnt[(uint64_t)(blk0 + k) * g.Bp + b] : 0u;
+#pragma unroll
+            for (uint32_t k = 0; k < 16u; k++)
+                if (blk0 + k < g.nblk) {
+                    cnt[(uint64_t)(blk0 + k) * g.Bp + b] = run;
+                    run += c[k];
+                }
         }
         tot[b] = run;
     }
