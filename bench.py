@@ -159,6 +159,7 @@ def compact_roofline(r):
             # the WHOLE step against the same roof: compulsory bytes (every pair written once + the table read
             # once) / the timed step / the HBM peak; and what the per-table index costs of it
             "step_frac": r.get("step_frac"), "index_ms": r.get("index_ms"), **({"beside": r["beside"], "kernel_launches_per_pass": r["kernel_launches_per_pass"], "kernel_avg_launch_ms": r["kernel_avg_launch_ms"]} if r.get("beside") else {}),
+            **({"alone": r["alone"]} if r.get("alone") else {}),
             "pass": {"ms": r["pass"]["ms"], "phases_ms": {k: round(v["ms_per_pass"], 3) for k, v in r["phases"].items()},
                      "traffic_over_compulsory": r["pass"]["traffic_over_compulsory"],
                      "output_write_bound_frac": r["pass"]["output_write_bound_frac"]}}
@@ -635,6 +636,11 @@ def main():
     pmc_w = load_pmc("compare_c3_pmc.json", *srcs) if (n == 100_000 and world == 1 and not dry) else None
     roofline_warm = compare_roofline(eng, my_pairs, n, S, args.steps, pmc_w) if not dry else None
     eng.prof_enable(False)
+    # the dominant kernel BY ITSELF (a further pass over the indexed table launches it once, nothing beside it): what the
+    # per-table step's paced launches are to be read against
+    if roofline_warm and roofline.get("beside") and roofline_warm.get("kernel") == "mg::sp_fill_value_kernel":
+        roofline["alone"] = {"kernel": roofline_warm["kernel"], "kernel_ms": roofline_warm["kernel_ms"], "achieved": roofline_warm["achieved"],
+                             "frac": roofline_warm["frac"]}
 
     # the produced output (outside the timed region): every pair's denom and numer, as sums
     checksum = None

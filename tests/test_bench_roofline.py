@@ -72,6 +72,9 @@ def test_per_table_step_with_the_fill_beside_the_index_build():
     c = bench.compact_roofline(r)
     assert c["beside"] == r["beside"] and c["pass"]["phases_ms"]["fill_aside"] == 9.8 and len(json.dumps(c)) < 900
     assert c["kernel_launches_per_pass"] == 2 and c["kernel_avg_launch_ms"] == pytest.approx(10.25 / 2)      # (what rocprofv3 --stats averages)
+    # the same kernel by itself (bench.py takes it from the further passes it times next): it travels in the headline
+    r["alone"] = {"kernel": "mg::sp_fill_value_kernel", "kernel_ms": 6.65, "achieved": 6015.0, "frac": 0.7519}
+    assert bench.compact_roofline(r)["alone"]["frac"] == 0.7519 and len(json.dumps(bench.compact_roofline(r))) < 1100
 
 
 def test_without_pmc_and_table_of_copies_and_tile_engine():
