@@ -2348,6 +2348,74 @@ def test_async_compare_calls_are_stream_ordered(eng):
     t.free()
 
 
+def test_fill_beside_the_build_queued_and_from_two_contexts(eng, monkeypatch):
+    """The fill beside the index build in the two settings where its second stream could be forgotten: a context in async
+    mode -- per-table jobs of several tables queued back to back, ONE synchronisation of the context's stream at the end --
+    and two contexts on one device driven from two threads at once.  Every output equals the one computed with the fill
+    switched off."""
+    import threading
+    import torch
+    monkeypatch.setenv("MASHGPU_FILL_ASIDE_MIN_PAIRS", "1")
+    n = 3000
+    tabs = [synth.clustered_sketches(n, 200, clusters=30, seed=70 + i, pool=300, private=80) for i in range(3)]
+    pairs = abi.tri_pairs(0, n)
+    monkeypatch.setenv("MASHGPU_FILL_ASIDE", "0")
+    want = []
+    for table, nh, lengths in tabs:
+        t = eng.table_upload(table, nh, lengths)
+        want.append(eng.compare_tri_host(t))
+        t.free()
+    monkeypatch.delenv("MASHGPU_FILL_ASIDE")
+
+    def same(o, w):
+        got = o.cpu().numpy().view(np.uint32)
+        return np.array_equal(got[:, 0], w["numer"]) and np.array_equal(got[:, 1], w["denom"])
+
+    # queued: three tables, each job cold (its fill beside its build), one wait
+    ts = [eng.table_upload(*x) for x in tabs]
+    outs = [torch.full((pairs, 2), -1, dtype=torch.int32, device="cuda") for _ in tabs]
+    torch.cuda.synchronize()
+    eng.prof_enable(True)
+    eng.prof_reset()
+    eng.set_async(True)
+    try:
+        for t, o in zip(ts, outs):
+            eng.compare_tri_dev(t, 0, n, o.data_ptr())
+        eng.synchronize()
+    finally:
+        eng.set_async(False)
+    assert eng.prof_avg_ms("compare_fill_aside")[1] == 3
+    eng.prof_enable(False)
+    for o, w in zip(outs, want):
+        assert same(o, w)
+    for t in ts:
+        t.free()
+    # two contexts, two threads
+    errors = []
+
+    def worker(k):
+        try:
+            e2 = abi.MashGpu(0)
+            e2.set_option("MASHGPU_COSTS_FIXED", "1")
+            for rnd in range(3):
+                i = (k + rnd) % 3
+                t2 = e2.table_upload(*tabs[i])
+                got = e2.compare_tri_host(t2)
+                if not (np.array_equal(got["numer"], want[i]["numer"]) and np.array_equal(got["denom"], want[i]["denom"])):
+                    errors.append((k, rnd))
+                t2.free()
+            e2.close()
+        except Exception as ex:                            # noqa: BLE001
+            errors.append((k, repr(ex)))
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errors, errors
+
+
 def test_compare_c3_scale_properties(eng, oracle):
     """BASELINE config 3 shape at a size the oracle can sample: N = 6000 clustered
     s=1000 sketches (1.8e7 pairs).  Checks (a) sampled rows against the oracle,
