@@ -638,9 +638,14 @@ int SparseJobRun::prefill()
     if (!ctx->aux) {
         if (hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->aux_go, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ctx->aux_done, hipEventDisableTiming) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&ctx->aux_ctr), 256) != hipSuccess) {
-            (void)hipGetLastError();
+            (void)hipGetLastError();                        // (no second stream: the fill runs behind the build as it always did)
             if (ctx->aux) hipStreamDestroy(ctx->aux);
+            if (ctx->aux_go) hipEventDestroy(ctx->aux_go);
+            if (ctx->aux_done) hipEventDestroy(ctx->aux_done);
+            if (ctx->aux_ctr) hipFree(ctx->aux_ctr);
             ctx->aux = nullptr;
+            ctx->aux_go = ctx->aux_done = nullptr;
+            ctx->aux_ctr = nullptr;
             return MG_OK;
         }
     }
