@@ -529,6 +529,7 @@ struct SparseJobRun {
     bool prefilled = false;                                 // the fill runs beside the index build (prefill): its constant, its counter
     uint32_t aside_numer = 0, aside_denom = 0, aside_wgs = 0, aside_naps = 0, aside_threads = 256;
     uint32_t *aside_ctr = nullptr;
+    uint32_t aside_copies = 0;                              // the table is nothing but copies of a sketch of this many hashes
 
     SparseJobRun(mg_ctx *c, const mg_table *r, const mg_table *cl, uint64_t rb, uint64_t re, bool tri, uint32_t sketch_size, mg_counts *out, bool forced,
                  bool forced_join, bool *handled_out, SparseJob *list_job)
@@ -551,6 +552,7 @@ struct SparseJobRun {
 
     int open_index();
     int prefill();
+    int aside_start();
     int aside_launch(uint32_t numer, uint32_t denom, uint32_t *ctr);
     void aside_other_constant(uint32_t c);
     int end_prefill(bool finish);
@@ -650,12 +652,28 @@ int SparseJobRun::prefill()
         }
     }
     aside_wgs = wgs; aside_naps = naps; aside_threads = threads;
+    ctx->aside_all_copies = [this](uint32_t c) { aside_other_constant(c); };
+    // Where the build is long (C5: 10^9 entries, 79 ms) the fill waits for the bucket sorts: the build's first kernels -- the
+    // clustered copy, K1, K3 -- are the ones that move bytes, K4 works in LDS for a third of the build.  (MASHGPU_FILL_ASIDE_AT_SORT:
+    // entries from which on; tables the tiles refuse never get there and fill behind their build.)
+    uint64_t late_from = 300000000ull;
+    if (const char *e = ctx_opt(ctx, "MASHGPU_FILL_ASIDE_AT_SORT")) late_from = strtoull(e, nullptr, 10);
+    if (cols->n * std::min<uint64_t>(cols->s, s) >= late_from) {
+        ctx->aside_at_sort = [this]() { (void)aside_start(); };
+        return MG_OK;
+    }
+    return aside_start();
+}
+
+int SparseJobRun::aside_start()
+{
+    ctx->aside_at_sort = nullptr;
+    if (prefilled) return MG_OK;
     HIP_TRY(ctx, hipMemsetAsync(ctx->aux_ctr, 0, 128, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->aux_go, ctx->stream));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ctx->aux_go, 0));
-    if ((rc = aside_launch(0u, s, ctx->aux_ctr)) != MG_OK) return rc;
-    ctx->aside_all_copies = [this](uint32_t c) { aside_other_constant(c); };
-    return MG_OK;
+    const bool copies = triangle && aside_copies != 0;
+    return aside_launch(copies ? aside_copies : 0u, copies ? aside_copies : s, ctx->aux_ctr);
 }
 
 int SparseJobRun::aside_launch(uint32_t numer, uint32_t denom, uint32_t *ctr)
@@ -674,6 +692,7 @@ int SparseJobRun::aside_launch(uint32_t numer, uint32_t denom, uint32_t *ctr)
 // counter of its own.  (A triangle job's matter: a rect job's queries are not the table's rows.)
 void SparseJobRun::aside_other_constant(uint32_t c)
 {
+    aside_copies = c;                                       // (a fill that has not started yet starts with it)
     if (!prefilled || !triangle) return;
     if (hipMemsetAsync(aside_ctr, 0x80, 4, ctx->stream) != hipSuccess || aside_launch(c, c, ctx->aux_ctr + 16) != MG_OK) (void)hipGetLastError();
 }
@@ -683,6 +702,7 @@ void SparseJobRun::aside_other_constant(uint32_t c)
 int SparseJobRun::end_prefill(bool finish)
 {
     ctx->aside_all_copies = nullptr;
+    ctx->aside_at_sort = nullptr;
     if (!prefilled) return MG_OK;
     prefilled = false;
     hipError_t e;

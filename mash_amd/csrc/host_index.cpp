@@ -593,6 +593,7 @@ int SparseIndexBuild::build_by_tiles()
             // values, rows, groups, statistics, leaders: final behind the bucket sorts.  What the host wants of them is copied
             // back and marked with an event; the images (K5) and the rows' visiting order are queued behind, and the host waits
             // for the EVENT -- it lays out the dense groups while the images are still being written.
+            if (e == hipSuccess && ctx->aside_at_sort) ctx->aside_at_sort();      // (a job's fill that waits for the sorts: host_compare.cpp, prefill)
             if (e == hipSuccess)
                 e = mg::index_build(plan, H, sp->off, d_lb, d_tcnt, d_start, d_big, d_pk, d_tc, sp->keys_sorted, sp->sorted_rows, sp->gend, gs_of, sp->code_img,
                                     sp->pos_img, d_slots, &d_stat.p->shared, &d_stat.p->max_group, &d_stat.p->groups, d_stat.p->ixf,

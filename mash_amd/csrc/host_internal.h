@@ -114,6 +114,8 @@ struct mg_ctx {
     // set while a job's fill runs beside its index build: the build calls it when the table turns out to be nothing but
     // copies of one sketch of c hashes -- the fill's constant is {c, c} then, not {0, s}
     std::function<void(uint32_t)> aside_all_copies;
+    // ... and this one when the bucket sorts (K4) are about to be queued: where the build is long, the fill starts there
+    std::function<void()> aside_at_sort;
 };
 
 struct mg_table {

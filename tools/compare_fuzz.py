@@ -71,7 +71,7 @@ def main():
                # the per-table job of a large table: the table's derived data dropped, the fill beside the index build at some pace
                ("sparse, fill beside the build", {"MASHGPU_COMPARE_KERNEL": "sparse", "MASHGPU_FILL_ASIDE_MIN_PAIRS": "1", "MASHGPU_FILL_ASIDE": None}),
                ("default, fill beside the build", {"MASHGPU_FILL_ASIDE_MIN_PAIRS": "1", "MASHGPU_FILL_ASIDE": None})]
-    knobs = ("MASHGPU_COMPARE_KERNEL", "MASHGPU_COMPARE_WINDOWS", "MASHGPU_FILL_ASIDE_MIN_PAIRS", "MASHGPU_FILL_ASIDE")
+    knobs = ("MASHGPU_COMPARE_KERNEL", "MASHGPU_COMPARE_WINDOWS", "MASHGPU_FILL_ASIDE_MIN_PAIRS", "MASHGPU_FILL_ASIDE", "MASHGPU_FILL_ASIDE_AT_SORT")
     t0 = time.time()
     bad = ran = 0
     for case in range(a.n):
@@ -98,12 +98,15 @@ def main():
             pairs = n * (n - 1) // 2
         ref = None
         paces = [str(rng.choice(["1,0", "2,3", "7,0,64", "64,1", "64,40", "300,0,128", "4096,0"])) for _ in range(2)]
+        late = [bool(rng.random() < 0.4) for _ in range(2)]
         for name, env in engines:
             for k in knobs:
                 os.environ.pop(k, None)
             env = dict(env)
             if "MASHGPU_FILL_ASIDE" in env:
                 env["MASHGPU_FILL_ASIDE"] = paces.pop()
+                if late.pop():                             # (the fill waits for the bucket sorts, as behind a long build)
+                    env["MASHGPU_FILL_ASIDE_AT_SORT"] = "1"
                 t.invalidate()
             os.environ.update(env)
             out = torch.full((max(pairs, 1), 2), -1, dtype=torch.int32, device=dev)
